@@ -1,0 +1,1003 @@
+/*
+ * oracle/ecc_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the reference's algorithm for the hot path
+ *   nn_mul_redc1 -> fp_{add,sub,mul_monty,inv} -> prj_pt_add -> prj_pt_mul
+ * and its three protocol callers (ECDSA sign/verify, ECC-CDH).  Every function cites the
+ * reference file:line it follows (paths relative to /root/reference/src).
+ *
+ * PINNED: checked (tests/test_oracle.py) against
+ *   - the reference's own known-answer vectors extracted to tests/golden/*.json
+ *     (ECC-CDH NIST KATs, RFC 6979 / fixed-k ECDSA vectors), and
+ *   - the unmodified reference itself built into oracle/_ref/libecc_ref.so
+ *     (random batches + the edge list of SURVEY.md section 3.1).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ * The product (libecc_amd/) never links, loads or falls back to it.
+ *
+ * Deliberate restatement choices (they cannot change any observable byte):
+ *   - no randomisation: the reference blinds (X,Y,Z) by a random lambda and masks the
+ *     ladder's register indices with a random r (curves/prj_pt.c:1266-1291,1631); only
+ *     the affine result is deterministic and that is what we
+ *     return.  lambda = 1, r = 0 here.
+ *   - values whose result is unique mod the modulus (plain fp_mul, nn_mod, modular
+ *     inverse) are computed by simpler algorithms than the reference's constant-time
+ *     reciprocal division / binary xgcd; the unique reduced result is identical.
+ */
+#include <string.h>
+#include "ecc_oracle.h"
+
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+typedef uint8_t u8;
+
+/* ------------------------------------------------------------------------------------
+ * nn layer: little-endian arrays of 64-bit words (nn/nn.h:42-45,67-71), fixed length n.
+ * ---------------------------------------------------------------------------------- */
+static void nn_zero(u64 *a, int n) { memset(a, 0, (size_t)n * 8); }
+static void nn_copy(u64 *d, const u64 *s, int n) { memcpy(d, s, (size_t)n * 8); }
+
+/* nn_cmp (nn/nn.c:360) */
+static int nn_cmp(const u64 *a, const u64 *b, int n)
+{
+	int i;
+	for (i = n - 1; i >= 0; i--) {
+		if (a[i] != b[i]) {
+			return (a[i] < b[i]) ? -1 : 1;
+		}
+	}
+	return 0;
+}
+
+static int nn_iszero(const u64 *a, int n)
+{
+	int i;
+	u64 acc = 0;
+	for (i = 0; i < n; i++) {
+		acc |= a[i];
+	}
+	return acc == 0;
+}
+
+/* _nn_cnd_add (nn/nn_add.c:60): returns carry */
+static u64 nn_add(u64 *out, const u64 *a, const u64 *b, int n)
+{
+	u64 carry = 0;
+	int i;
+	for (i = 0; i < n; i++) {
+		u128 t = (u128)a[i] + b[i] + carry;
+		out[i] = (u64)t;
+		carry = (u64)(t >> 64);
+	}
+	return carry;
+}
+
+/* nn_cnd_sub (nn/nn_add.c:250): returns borrow */
+static u64 nn_sub(u64 *out, const u64 *a, const u64 *b, int n)
+{
+	u64 borrow = 0;
+	int i;
+	for (i = 0; i < n; i++) {
+		u128 t = (u128)a[i] - b[i] - borrow;
+		out[i] = (u64)t;
+		borrow = (u64)(t >> 64) & 1;
+	}
+	return borrow;
+}
+
+/* nn_bitlen (nn/nn_logical.c:514) */
+static int nn_bitlen(const u64 *a, int n)
+{
+	int i, b;
+	for (i = n - 1; i >= 0; i--) {
+		if (a[i]) {
+			for (b = 63; b >= 0; b--) {
+				if ((a[i] >> b) & 1) {
+					return i * 64 + b + 1;
+				}
+			}
+		}
+	}
+	return 0;
+}
+
+/* nn_getbit (nn/nn_logical.c:541) */
+static int nn_getbit(const u64 *a, int bit) { return (int)((a[bit / 64] >> (bit % 64)) & 1); }
+
+/* nn_mul schoolbook (nn/nn_mul.c:43-102): out has na+nb words */
+static void nn_mul(u64 *out, const u64 *a, int na, const u64 *b, int nb)
+{
+	int i, j;
+	nn_zero(out, na + nb);
+	for (i = 0; i < na; i++) {
+		u64 carry = 0;
+		for (j = 0; j < nb; j++) {
+			u128 t = (u128)a[i] * b[j] + out[i + j] + carry;
+			out[i + j] = (u64)t;
+			carry = (u64)(t >> 64);
+		}
+		out[i + nb] = carry;
+	}
+}
+
+/* nn_init_from_buf (nn/nn.c:479): big-endian octets, right aligned, into n words.
+ * Returns -1 if the value does not fit (non-zero bytes beyond n words). */
+static int nn_from_be(u64 *out, int n, const u8 *buf, int len)
+{
+	int i;
+	nn_zero(out, n);
+	for (i = 0; i < len; i++) {
+		int pos = len - 1 - i; /* byte significance */
+		if (pos / 8 >= n) {
+			if (buf[i]) {
+				return -1;
+			}
+			continue;
+		}
+		out[pos / 8] |= (u64)buf[i] << (8 * (pos % 8));
+	}
+	return 0;
+}
+
+/* nn_export_to_buf (nn/nn.c:511): truncates MSBs / zero-pads on the left */
+static void nn_to_be(u8 *buf, int len, const u64 *a, int n)
+{
+	int i;
+	for (i = 0; i < len; i++) {
+		int pos = len - 1 - i;
+		buf[i] = (pos / 8 < n) ? (u8)(a[pos / 8] >> (8 * (pos % 8))) : 0;
+	}
+}
+
+/* a mod m for 'na'-word a, result in n words (n = words of m).  The reference does this
+ * with a normalised reciprocal division (nn/nn_div.c:193-279,536,1005); the remainder is
+ * unique, so a bitwise shift-subtract reduction restates it. */
+static void nn_mod(u64 *out, const u64 *a, int na, const u64 *m, int n)
+{
+	u64 r[ORC_MAXW + 1], t[ORC_MAXW + 1], mm[ORC_MAXW + 1];
+	int bit, i;
+	nn_zero(r, n + 1);
+	nn_zero(mm, n + 1);
+	nn_copy(mm, m, n);
+	for (bit = na * 64 - 1; bit >= 0; bit--) {
+		/* r = 2r + bit */
+		for (i = n; i > 0; i--) {
+			r[i] = (r[i] << 1) | (r[i - 1] >> 63);
+		}
+		r[0] = (r[0] << 1) | (u64)nn_getbit(a, bit);
+		if (nn_cmp(r, mm, n + 1) >= 0) {
+			nn_sub(t, r, mm, n + 1);
+			nn_copy(r, t, n + 1);
+		}
+	}
+	nn_copy(out, r, n);
+}
+
+/* ------------------------------------------------------------------------------------
+ * Montgomery context (fp/fp.h:31-57; constants as derived in scripts/expand_libecc.py:62-71)
+ * ---------------------------------------------------------------------------------- */
+/* -p^-1 mod 2^64 (nn_compute_redc1_coefs, nn/nn_mul_redc1.c:40-106 via nn_modinv_2exp) */
+static u64 compute_mpinv(u64 p0)
+{
+	u64 x = 1;
+	int i;
+	for (i = 0; i < 6; i++) {
+		x *= 2 - p0 * x; /* Newton: doubles the number of correct bits */
+	}
+	return (u64)0 - x;
+}
+
+static int fp_ctx_init(orc_fp_ctx *c, const u64 *p, int n)
+{
+	u64 t[2 * ORC_MAXW + 2];
+	if (n < 1 || 2 * n + 1 > ORC_MAXW || !(p[0] & 1)) {
+		return -1;
+	}
+	memset(c, 0, sizeof(*c));
+	c->n = n;
+	nn_copy(c->p, p, n);
+	c->pbits = nn_bitlen(p, n);
+	c->mpinv = compute_mpinv(p[0]);
+	/* r = 2^(64n) mod p, r2 = 2^(128n) mod p */
+	nn_zero(t, 2 * n + 1);
+	t[n] = 1;
+	nn_mod(c->r, t, n + 1, p, n);
+	nn_zero(t, 2 * n + 1);
+	t[2 * n] = 1;
+	nn_mod(c->r2, t, 2 * n + 1, p, n);
+	return 0;
+}
+
+/*
+ * _nn_mul_redc1 (nn/nn_mul_redc1.c:124-218): CIOS Montgomery multiplication
+ * out = a*b*2^(-64n) mod p, inputs < p, one final conditional subtraction (:210-211).
+ * Loop structure follows the reference: multiply row (:175-187), m = out[0]*mpinv (:189),
+ * reduction row with the one-word shift (:190-204).
+ */
+static void mul_redc1(u64 *out, const u64 *a, const u64 *b, const orc_fp_ctx *c)
+{
+	const int n = c->n;
+	u64 t[ORC_MAXW + 2], s[ORC_MAXW + 2];
+	int i, j;
+	nn_zero(t, n + 2);
+	for (i = 0; i < n; i++) {
+		u64 carry = 0, m, acc;
+		u128 x;
+		for (j = 0; j < n; j++) {
+			x = (u128)a[i] * b[j] + t[j] + carry;
+			t[j] = (u64)x;
+			carry = (u64)(x >> 64);
+		}
+		x = (u128)t[n] + carry;
+		t[n] = (u64)x;
+		acc = (u64)(x >> 64);
+		m = t[0] * c->mpinv;
+		x = (u128)m * c->p[0] + t[0];
+		carry = (u64)(x >> 64);
+		for (j = 1; j < n; j++) {
+			x = (u128)m * c->p[j] + t[j] + carry;
+			t[j - 1] = (u64)x;
+			carry = (u64)(x >> 64);
+		}
+		x = (u128)t[n] + carry;
+		t[n - 1] = (u64)x;
+		t[n] = acc + (u64)(x >> 64);
+	}
+	/* msw is 0 or 1 here; subtract p if out >= p */
+	nn_zero(s, n + 1);
+	nn_copy(s, c->p, n);
+	if (nn_cmp(t, s, n + 1) >= 0) {
+		u64 d[ORC_MAXW + 2];
+		nn_sub(d, t, s, n + 1);
+		nn_copy(out, d, n);
+	} else {
+		nn_copy(out, t, n);
+	}
+}
+
+/* nn_mod_add (nn/nn_add.c:337) / fp_add (fp/fp_add.c:23) */
+static void fp_add(u64 *out, const u64 *a, const u64 *b, const orc_fp_ctx *c)
+{
+	u64 t[ORC_MAXW + 1], pp[ORC_MAXW + 1], d[ORC_MAXW + 1];
+	const int n = c->n;
+	nn_zero(pp, n + 1);
+	nn_copy(pp, c->p, n);
+	t[n] = nn_add(t, a, b, n);
+	if (nn_cmp(t, pp, n + 1) >= 0) {
+		nn_sub(d, t, pp, n + 1);
+		nn_copy(out, d, n);
+	} else {
+		nn_copy(out, t, n);
+	}
+}
+
+/* nn_mod_sub (nn/nn_add.c:398) / fp_sub (fp/fp_add.c:69) */
+static void fp_sub(u64 *out, const u64 *a, const u64 *b, const orc_fp_ctx *c)
+{
+	u64 t[ORC_MAXW];
+	const int n = c->n;
+	if (nn_sub(t, a, b, n)) {
+		nn_add(t, t, c->p, n);
+	}
+	nn_copy(out, t, n);
+}
+
+/* fp_redcify / fp_unredcify (fp/fp_mul_redc1.c:62,79) */
+static void fp_redcify(u64 *out, const u64 *a, const orc_fp_ctx *c) { mul_redc1(out, a, c->r2, c); }
+static void fp_unredcify(u64 *out, const u64 *a, const orc_fp_ctx *c)
+{
+	u64 one[ORC_MAXW];
+	nn_zero(one, c->n);
+	one[0] = 1;
+	mul_redc1(out, a, one, c);
+}
+
+/* plain fp_mul (fp/fp_mul.c:23-37: nn_mul + nn_mod_unshifted); restated as
+ * redc(redc(a,b), r^2) = a*b mod p -- the unique reduced product. */
+static void fp_mul(u64 *out, const u64 *a, const u64 *b, const orc_fp_ctx *c)
+{
+	u64 t[ORC_MAXW];
+	mul_redc1(t, a, b, c);
+	mul_redc1(out, t, c->r2, c);
+}
+
+/*
+ * fp_inv (fp/fp_mul.c:51-68) = nn_modinv_fermat_redc (nn/nn_modinv.c:538) = x^(p-2) by the
+ * left-to-right Montgomery-ladder modexp _nn_exp_monty_ladder_ltr (nn/nn_mod_pow.c:39-155):
+ * redcify (:83), per exponent bit one square + one multiply on the (T0,T1) pair (:114,:121),
+ * unredcify (:135).  The random Itoh mask (:56) is dropped.  Plain in -> plain out.
+ */
+static void fp_pow_pm2(u64 *out, const u64 *x, const orc_fp_ctx *c)
+{
+	u64 e[ORC_MAXW], two[ORC_MAXW], T0[ORC_MAXW], T1[ORC_MAXW], xm[ORC_MAXW];
+	int n = c->n, bits, i;
+	nn_zero(two, n);
+	two[0] = 2;
+	nn_sub(e, c->p, two, n);
+	bits = nn_bitlen(e, n);
+	fp_redcify(xm, x, c);
+	nn_copy(T0, c->r, n); /* 1 in Montgomery form */
+	nn_copy(T1, xm, n);
+	for (i = bits - 1; i >= 0; i--) {
+		if (nn_getbit(e, i)) {
+			mul_redc1(T0, T0, T1, c);
+			mul_redc1(T1, T1, T1, c);
+		} else {
+			mul_redc1(T1, T0, T1, c);
+			mul_redc1(T0, T0, T0, c);
+		}
+	}
+	fp_unredcify(out, T0, c);
+}
+
+/* fp_import_from_buf (fp/fp.c:435-450): rejects values >= p */
+static int fp_from_be(u64 *out, const u8 *buf, int len, const orc_fp_ctx *c)
+{
+	if (nn_from_be(out, c->n, buf, len)) {
+		return -1;
+	}
+	return (nn_cmp(out, c->p, c->n) < 0) ? 0 : -1;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Projective points (curves/prj_pt.h:26-32): homogeneous (X:Y:Z), infinity = (0:1:0)
+ * ---------------------------------------------------------------------------------- */
+typedef struct { u64 X[ORC_MAXW], Y[ORC_MAXW], Z[ORC_MAXW]; } pt;
+
+static void pt_zero(pt *P, const orc_curve *c) /* prj_pt_zero (curves/prj_pt.c:124-136) */
+{
+	nn_zero(P->X, c->fp.n);
+	nn_zero(P->Y, c->fp.n);
+	P->Y[0] = 1;
+	nn_zero(P->Z, c->fp.n);
+}
+
+/* prj_pt_is_on_curve (curves/prj_pt.c:144-190): Y^2 Z = X^3 + a X Z^2 + b Z^3, plain fp ops
+ * in the same order as :166-177. */
+static int pt_is_on_curve(const pt *P, const orc_curve *c)
+{
+	const orc_fp_ctx *f = &c->fp;
+	u64 X[ORC_MAXW], Y[ORC_MAXW], Z[ORC_MAXW];
+	fp_mul(X, P->X, P->X, f);
+	fp_mul(X, X, P->X, f);
+	fp_mul(Z, P->X, c->a, f);
+	fp_mul(Y, c->b, P->Z, f);
+	fp_add(Z, Z, Y, f);
+	fp_mul(Z, Z, P->Z, f);
+	fp_mul(Z, Z, P->Z, f);
+	fp_add(X, X, Z, f);
+	fp_mul(Y, P->Y, P->Y, f);
+	fp_mul(Y, Y, P->Z, f);
+	return nn_cmp(X, Y, f->n) == 0;
+}
+
+/*
+ * __prj_pt_add_monty_cf (curves/prj_pt.c:971-1071): Renes-Costello-Batina Algorithm 1,
+ * generic a, 17 Montgomery multiplications + 23 add/sub, same operation order as :990-1035.
+ * Returns -1 for the Y3 = Z3 = 0 "exceptional pair" test (:1058-1060).  'out' may alias.
+ */
+static int pt_add(pt *out, const pt *in1, const pt *in2, const orc_curve *c)
+{
+	const orc_fp_ctx *f = &c->fp;
+	u64 t0[ORC_MAXW], t1[ORC_MAXW], t2[ORC_MAXW], t3[ORC_MAXW], t4[ORC_MAXW], t5[ORC_MAXW];
+	u64 X3[ORC_MAXW], Y3[ORC_MAXW], Z3[ORC_MAXW];
+#define MM(o, x, y) mul_redc1(o, x, y, f)
+#define AD(o, x, y) fp_add(o, x, y, f)
+#define SB(o, x, y) fp_sub(o, x, y, f)
+	MM(t0, in1->X, in2->X);
+	MM(t1, in1->Y, in2->Y);
+	MM(t2, in1->Z, in2->Z);
+	AD(t3, in1->X, in1->Y);
+	AD(t4, in2->X, in2->Y);
+
+	MM(t3, t3, t4);
+	AD(t4, t0, t1);
+	SB(t3, t3, t4);
+	AD(t4, in1->X, in1->Z);
+	AD(t5, in2->X, in2->Z);
+
+	MM(t4, t4, t5);
+	AD(t5, t0, t2);
+	SB(t4, t4, t5);
+	AD(t5, in1->Y, in1->Z);
+	AD(X3, in2->Y, in2->Z);
+
+	MM(t5, t5, X3);
+	AD(X3, t1, t2);
+	SB(t5, t5, X3);
+	MM(Z3, c->a_m, t4);
+	MM(X3, c->b3_m, t2);
+
+	AD(Z3, X3, Z3);
+	SB(X3, t1, Z3);
+	AD(Z3, t1, Z3);
+	MM(Y3, X3, Z3);
+	AD(t1, t0, t0);
+
+	AD(t1, t1, t0);
+	MM(t2, c->a_m, t2);
+	MM(t4, c->b3_m, t4);
+	AD(t1, t1, t2);
+	SB(t2, t0, t2);
+
+	MM(t2, c->a_m, t2);
+	AD(t4, t4, t2);
+	MM(t0, t1, t4);
+	AD(Y3, Y3, t0);
+	MM(t0, t5, t4);
+
+	MM(X3, t3, X3);
+	SB(X3, X3, t0);
+	MM(t0, t3, t1);
+	MM(Z3, t5, Z3);
+	AD(Z3, Z3, t0);
+#undef MM
+#undef AD
+#undef SB
+	nn_copy(out->X, X3, f->n);
+	nn_copy(out->Y, Y3, f->n);
+	nn_copy(out->Z, Z3, f->n);
+	return (nn_iszero(Z3, f->n) && nn_iszero(Y3, f->n)) ? -1 : 0;
+}
+
+/*
+ * __prj_pt_dbl_monty_cf (curves/prj_pt.c:892-950): RCB Algorithm 3, 16 mults + 15 add/sub.
+ * (Not used by the default ladder, only by prj_pt_dbl / _prj_pt_unprotected_mult.)
+ */
+static int pt_dbl(pt *out, const pt *in, const orc_curve *c)
+{
+	const orc_fp_ctx *f = &c->fp;
+	u64 t0[ORC_MAXW], t1[ORC_MAXW], t2[ORC_MAXW], t3[ORC_MAXW];
+	u64 X3[ORC_MAXW], Y3[ORC_MAXW], Z3[ORC_MAXW];
+#define MM(o, x, y) mul_redc1(o, x, y, f)
+#define AD(o, x, y) fp_add(o, x, y, f)
+#define SB(o, x, y) fp_sub(o, x, y, f)
+	MM(t0, in->X, in->X);
+	MM(t1, in->Y, in->Y);
+	MM(t2, in->Z, in->Z);
+	MM(t3, in->X, in->Y);
+	AD(t3, t3, t3);
+
+	MM(Z3, in->X, in->Z);
+	AD(Z3, Z3, Z3);
+	MM(X3, c->a_m, Z3);
+	MM(Y3, c->b3_m, t2);
+	AD(Y3, X3, Y3);
+
+	SB(X3, t1, Y3);
+	AD(Y3, t1, Y3);
+	MM(Y3, X3, Y3);
+	MM(X3, t3, X3);
+	MM(Z3, c->b3_m, Z3);
+
+	MM(t2, c->a_m, t2);
+	SB(t3, t0, t2);
+	MM(t3, c->a_m, t3);
+	AD(t3, t3, Z3);
+	AD(Z3, t0, t0);
+
+	AD(t0, Z3, t0);
+	AD(t0, t0, t2);
+	MM(t0, t0, t3);
+	AD(Y3, Y3, t0);
+	MM(t2, in->Y, in->Z);
+
+	AD(t2, t2, t2);
+	MM(t0, t2, t3);
+	SB(X3, X3, t0);
+	MM(Z3, t2, t1);
+	AD(Z3, Z3, Z3);
+
+	AD(Z3, Z3, Z3);
+#undef MM
+#undef AD
+#undef SB
+	nn_copy(out->X, X3, f->n);
+	nn_copy(out->Y, Y3, f->n);
+	nn_copy(out->Z, Z3, f->n);
+	return 0;
+}
+
+/*
+ * _prj_pt_mul_ltr_monty_ladder (curves/prj_pt.c:1569-1720), default build.
+ *   m' (:1588-1617): m < q : m + q, plus q again if bitlen(m+q) == bitlen(q);
+ *                    q <= m < q^2 : same with q^2;   m >= q^2 : m.
+ *   (q is the CURVE order, in->crv->order.)  mlen = bitlen(m') - 1 (:1621-1623).
+ *   T[rbit] = in (blinding dropped), T[1-rbit] = add(T[rbit],T[rbit]) (:1645-1654)
+ *   loop (:1660-1702): T[2] = add(T[b^r],T[b^r]); T[1] = add(T[0],T[1]);
+ *                      T[0] = T[2-(b^r')]; T[1] = T[1+(b^r')].
+ * With r = 0: rbit = rbit_next = 0.  Add failures are OR-ed (ret_ops).
+ * 'm' has mn words (mn <= ORC_MAXW-1).
+ */
+static int pt_mul_ladder(pt *out, const u64 *m, int mn, const pt *in, const orc_curve *c)
+{
+	u64 q2[ORC_MAXW], mf[ORC_MAXW + 1], mm[ORC_MAXW + 1], qq[ORC_MAXW + 1];
+	const int W = ORC_MAXW;
+	pt T[3];
+	int mlen, ret_ops = 0, mbit;
+	int qn = c->order_n;
+
+	nn_zero(mm, W + 1);
+	nn_copy(mm, m, mn);
+	nn_zero(qq, W + 1);
+	nn_copy(qq, c->order, qn);
+	nn_zero(q2, W);
+	nn_mul(q2, c->order, qn, c->order, qn);
+
+	if (nn_cmp(mm, qq, W) < 0) {
+		nn_add(mf, mm, qq, W);
+		if (nn_bitlen(mf, W) == nn_bitlen(qq, W)) {
+			nn_add(mf, mf, qq, W);
+		}
+	} else if (nn_cmp(mm, q2, W) < 0) {
+		nn_add(mf, mm, q2, W);
+		if (nn_bitlen(mf, W) == nn_bitlen(q2, W)) {
+			nn_add(mf, mf, q2, W);
+		}
+	} else {
+		nn_copy(mf, mm, W);
+	}
+	mlen = nn_bitlen(mf, W);
+	if (mlen == 0) {
+		return -1; /* MUST_HAVE((mlen != 0)) :1622 */
+	}
+	mlen--;
+
+	T[0] = *in;
+	ret_ops |= pt_add(&T[1], &T[0], &T[0], c);
+	while (mlen > 0) {
+		--mlen;
+		mbit = nn_getbit(mf, mlen);
+		ret_ops |= pt_add(&T[2], &T[mbit], &T[mbit], c);
+		ret_ops |= pt_add(&T[1], &T[0], &T[1], c);
+		T[0] = T[2 - mbit];
+		T[1] = T[1 + mbit];
+	}
+	*out = T[0];
+	return ret_ops ? -1 : 0;
+}
+
+/* prj_pt_mul (curves/prj_pt.c:1759-1780): on-curve check in, ladder, on-curve check out */
+static int pt_mul(pt *out, const u64 *m, int mn, const pt *in, const orc_curve *c)
+{
+	pt R;
+	if (!pt_is_on_curve(in, c)) {
+		return -1;
+	}
+	if (pt_mul_ladder(&R, m, mn, in, c)) {
+		return -1;
+	}
+	if (!pt_is_on_curve(&R, c)) {
+		return -1;
+	}
+	*out = R;
+	return 0;
+}
+
+/* prj_pt_unique (curves/prj_pt.c:241-273): -1 on infinity; x = X/Z, y = Y/Z via fp_inv + 2 fp_mul */
+static int pt_unique(pt *P, const orc_curve *c)
+{
+	const orc_fp_ctx *f = &c->fp;
+	u64 zi[ORC_MAXW];
+	if (nn_iszero(P->Z, f->n)) {
+		return -1;
+	}
+	fp_pow_pm2(zi, P->Z, f);
+	fp_mul(P->Y, P->Y, zi, f);
+	fp_mul(P->X, P->X, zi, f);
+	nn_zero(P->Z, f->n);
+	P->Z[0] = 1;
+	return 0;
+}
+
+/* prj_pt_import_from_aff_buf (curves/prj_pt.c:511-552): X||Y, each clen bytes BE, Z = 1,
+ * coordinates >= p rejected (fp.c:441-442), off-curve rejected (:541-545) */
+static int pt_import_aff(pt *P, const u8 *buf, const orc_curve *c)
+{
+	if (fp_from_be(P->X, buf, c->clen, &c->fp) || fp_from_be(P->Y, buf + c->clen, c->clen, &c->fp)) {
+		return -1;
+	}
+	nn_zero(P->Z, c->fp.n);
+	P->Z[0] = 1;
+	return pt_is_on_curve(P, c) ? 0 : -1;
+}
+
+/* prj_pt_export_to_aff_buf (curves/prj_pt.c:600-624) after prj_pt_unique */
+static void pt_export_aff(u8 *buf, const pt *P, const orc_curve *c)
+{
+	nn_to_be(buf, c->clen, P->X, c->fp.n);
+	nn_to_be(buf + c->clen, c->clen, P->Y, c->fp.n);
+}
+
+/* ------------------------------------------------------------------------------------
+ * Public (ctypes) surface
+ * ---------------------------------------------------------------------------------- */
+static int words_for(int bytes) { return (bytes + 7) / 8; }
+
+int orc_sizeof_curve(void) { return (int)sizeof(orc_curve); }
+
+/* import_params (curves/ec_params.c:24-194) + ec_shortw_crv_init (curves/ec_shortw.c:41-97):
+ * a_monty = a*R, b3 = 3b, b3_monty (ec_shortw.c:75,86-87). All inputs big-endian. */
+int orc_curve_init(orc_curve *c, const uint8_t *p, int plen, const uint8_t *a, int alen,
+		   const uint8_t *b, int blen, const uint8_t *order, int olen,
+		   const uint8_t *gx, int gxlen, const uint8_t *gy, int gylen,
+		   const uint8_t *q, int qlen)
+{
+	u64 pw[ORC_MAXW], b3[ORC_MAXW], tmp[ORC_MAXW];
+	int n, nq, k;
+	memset(c, 0, sizeof(*c));
+	/* strip to the number of significant words of p */
+	if (nn_from_be(pw, ORC_MAXW, p, plen)) {
+		return -1;
+	}
+	n = (nn_bitlen(pw, ORC_MAXW) + 63) / 64;
+	if (fp_ctx_init(&c->fp, pw, n)) {
+		return -1;
+	}
+	if (fp_from_be(c->a, a, alen, &c->fp) || fp_from_be(c->b, b, blen, &c->fp) ||
+	    fp_from_be(c->gx, gx, gxlen, &c->fp) || fp_from_be(c->gy, gy, gylen, &c->fp)) {
+		return -1;
+	}
+	fp_redcify(c->a_m, c->a, &c->fp);
+	fp_add(b3, c->b, c->b, &c->fp);
+	fp_add(b3, b3, c->b, &c->fp);
+	fp_redcify(c->b3_m, b3, &c->fp);
+	if (nn_from_be(tmp, ORC_MAXW, order, olen)) {
+		return -1;
+	}
+	c->order_n = (nn_bitlen(tmp, ORC_MAXW) + 63) / 64;
+	nn_copy(c->order, tmp, ORC_MAXW);
+	if (nn_from_be(tmp, ORC_MAXW, q, qlen)) {
+		return -1;
+	}
+	c->qbits = nn_bitlen(tmp, ORC_MAXW);
+	nq = (c->qbits + 63) / 64;
+	c->q_n = nq;
+	nn_copy(c->q, tmp, ORC_MAXW);
+	if (fp_ctx_init(&c->fq, tmp, nq)) {
+		return -1;
+	}
+	c->clen = (c->fp.pbits + 7) / 8;
+	c->qlen = (c->qbits + 7) / 8;
+	(void)k;
+	(void)words_for;
+	return 0;
+}
+
+int orc_fp_op_batch(const orc_curve *c, int op, uint32_t n, const uint64_t *a, const uint64_t *b,
+		    uint64_t *out)
+{
+	const orc_fp_ctx *f = &c->fp;
+	uint32_t i;
+	for (i = 0; i < n; i++) {
+		const u64 *x = a + (size_t)i * f->n, *y = b + (size_t)i * f->n;
+		u64 z[ORC_MAXW];
+		if (nn_cmp(x, f->p, f->n) >= 0 || nn_cmp(y, f->p, f->n) >= 0) {
+			return -1;
+		}
+		switch (op) {
+		case 0: mul_redc1(z, x, y, f); break;
+		case 1: fp_add(z, x, y, f); break;
+		case 2: fp_sub(z, x, y, f); break;
+		case 3: fp_mul(z, x, y, f); break;
+		case 4: fp_pow_pm2(z, x, f); break;
+		default: return -1;
+		}
+		nn_copy(out + (size_t)i * f->n, z, f->n);
+	}
+	return 0;
+}
+
+/* status: 0 ok, 1 error (-1 in the reference), 2 result is the point at infinity */
+int orc_scalar_mult_batch(const orc_curve *c, uint32_t n, const uint8_t *scalars, uint32_t slen,
+			  const uint8_t *points, uint8_t *out, uint8_t *status)
+{
+	uint32_t i;
+	const int plen = 2 * c->clen;
+	for (i = 0; i < n; i++) {
+		pt P, Q;
+		u64 m[ORC_MAXW];
+		int mn = ((int)slen + 7) / 8;
+		status[i] = 1;
+		memset(out + (size_t)i * plen, 0, (size_t)plen);
+		if (mn > ORC_MAXW - 1 || nn_from_be(m, mn, scalars + (size_t)i * slen, (int)slen)) {
+			continue;
+		}
+		if (points) {
+			if (pt_import_aff(&P, points + (size_t)i * plen, c)) {
+				continue;
+			}
+		} else {
+			nn_copy(P.X, c->gx, c->fp.n);
+			nn_copy(P.Y, c->gy, c->fp.n);
+			nn_zero(P.Z, c->fp.n);
+			P.Z[0] = 1;
+		}
+		if (pt_mul(&Q, m, mn, &P, c)) {
+			continue;
+		}
+		if (nn_iszero(Q.Z, c->fp.n)) {
+			status[i] = 2;
+			continue;
+		}
+		if (pt_unique(&Q, c)) {
+			continue;
+		}
+		pt_export_aff(out + (size_t)i * plen, &Q, c);
+		status[i] = 0;
+	}
+	return 0;
+}
+
+/* prj_pt_add (curves/prj_pt.c:1204) / prj_pt_dbl (:1132) on affine-encoded inputs */
+int orc_pt_add_batch(const orc_curve *c, uint32_t n, const uint8_t *p1, const uint8_t *p2,
+		     uint8_t *out, uint8_t *status, int dbl)
+{
+	uint32_t i;
+	const int plen = 2 * c->clen;
+	for (i = 0; i < n; i++) {
+		pt A, B, C;
+		int ret;
+		status[i] = 1;
+		memset(out + (size_t)i * plen, 0, (size_t)plen);
+		if (pt_import_aff(&A, p1 + (size_t)i * plen, c)) {
+			continue;
+		}
+		if (dbl) {
+			ret = pt_dbl(&C, &A, c);
+		} else {
+			if (pt_import_aff(&B, p2 + (size_t)i * plen, c)) {
+				continue;
+			}
+			ret = pt_add(&C, &A, &B, c);
+		}
+		if (ret) {
+			continue;
+		}
+		if (nn_iszero(C.Z, c->fp.n)) {
+			status[i] = 2;
+			continue;
+		}
+		pt_unique(&C, c);
+		pt_export_aff(out + (size_t)i * plen, &C, c);
+		status[i] = 0;
+	}
+	return 0;
+}
+
+/* ---- mod-q helpers for the protocol layer (q = generator order, prime) ---- */
+/* nn_mod_mul (nn/nn_mul_redc1.c:286-342): in1*in2 mod q */
+static void q_mul(u64 *out, const u64 *a, const u64 *b, const orc_curve *c) { fp_mul(out, a, b, &c->fq); }
+/* s^-1 mod q: nn_modinv (nn/nn_modinv.c:220, binary xgcd) in verify and nn_modinv_fermat (:504)
+ * in sign; q is prime so both equal s^(q-2) mod q. */
+static void q_inv(u64 *out, const u64 *a, const orc_curve *c) { fp_pow_pm2(out, a, &c->fq); }
+
+/* e = (OS2I(h) >> max(0, 8*hsize - qbits)) mod q  (sig/ecdsa_common.c:398-413, 760-778) */
+static int digest_to_e(u64 *e, const u8 *h, uint32_t hsize, const orc_curve *c)
+{
+	u64 t[ORC_MAXW];
+	int hn = ((int)hsize + 7) / 8, rshift = 0, i;
+	if (hn > ORC_MAXW - 1) {
+		return -1;
+	}
+	nn_from_be(t, ORC_MAXW, h, (int)hsize);
+	if ((int)hsize * 8 > c->qbits) {
+		rshift = (int)hsize * 8 - c->qbits;
+	}
+	while (rshift >= 64) {
+		for (i = 0; i < ORC_MAXW - 1; i++) {
+			t[i] = t[i + 1];
+		}
+		t[ORC_MAXW - 1] = 0;
+		rshift -= 64;
+	}
+	if (rshift) {
+		for (i = 0; i < ORC_MAXW - 1; i++) {
+			t[i] = (t[i] >> rshift) | (t[i + 1] << (64 - rshift));
+		}
+		t[ORC_MAXW - 1] >>= rshift;
+	}
+	nn_mod(e, t, ORC_MAXW, c->q, c->q_n);
+	return 0;
+}
+
+static void load_gen(pt *G, const orc_curve *c)
+{
+	nn_copy(G->X, c->gx, c->fp.n);
+	nn_copy(G->Y, c->gy, c->fp.n);
+	nn_zero(G->Z, c->fp.n);
+	G->Z[0] = 1;
+}
+
+/* r, s in [1, q-1] (sig/ecdsa_common.c:648-658) */
+static int import_rs(u64 *r, u64 *s, const u8 *sig, const orc_curve *c)
+{
+	if (nn_from_be(r, c->q_n, sig, c->qlen) || nn_from_be(s, c->q_n, sig + c->qlen, c->qlen)) {
+		return -1;
+	}
+	if (nn_iszero(r, c->q_n) || nn_iszero(s, c->q_n) || nn_cmp(r, c->q, c->q_n) >= 0 ||
+	    nn_cmp(s, c->q, c->q_n) >= 0) {
+		return -1;
+	}
+	return 0;
+}
+
+/* check_prj_pt_order (curves/prj_pt.c:1909): [q]P == infinity, plain double-and-add
+ * (_prj_pt_unprotected_mult :1835-1880, MSB first with prj_pt_dbl / prj_pt_add). */
+static int pt_unprotected_mult(pt *out, const u64 *m, int mn, const pt *in, const orc_curve *c)
+{
+	pt R;
+	int bits = nn_bitlen(m, mn), i, ret = 0;
+	pt_zero(&R, c);
+	for (i = bits - 1; i >= 0; i--) {
+		ret |= pt_dbl(&R, &R, c);
+		if (nn_getbit(m, i)) {
+			ret |= pt_add(&R, &R, in, c);
+		}
+	}
+	*out = R;
+	return ret ? -1 : 0;
+}
+
+/* ec_pub_key_import_from_aff_buf (sig/ec_key.c:181-214): subgroup check iff cofactor != 1 */
+static int pub_import(pt *Y, const u8 *buf, const orc_curve *c)
+{
+	if (pt_import_aff(Y, buf, c)) {
+		return -1;
+	}
+	if (nn_cmp(c->order, c->q, ORC_MAXW) != 0) { /* cofactor != 1 */
+		pt T;
+		if (pt_unprotected_mult(&T, c->q, c->q_n, Y, c)) {
+			return -1;
+		}
+		if (!nn_iszero(T.Z, c->fp.n)) {
+			return -1;
+		}
+	}
+	return 0;
+}
+
+/*
+ * __ecdsa_verify_init + __ecdsa_verify_finalize (sig/ecdsa_common.c:619-675, 702-840) with the
+ * digest h = H(m) supplied by the caller.  result: 0 accept, 1 reject.
+ */
+int orc_ecdsa_verify_batch(const orc_curve *c, uint32_t n, const uint8_t *pubs_aff,
+			   const uint8_t *sigs, const uint8_t *digests, uint32_t hsize,
+			   uint8_t *result)
+{
+	uint32_t i;
+	for (i = 0; i < n; i++) {
+		pt Y, G, uG, vY, W;
+		u64 r[ORC_MAXW], s[ORC_MAXW], e[ORC_MAXW], sinv[ORC_MAXW], u[ORC_MAXW], v[ORC_MAXW];
+		u64 rp[ORC_MAXW];
+		result[i] = 1;
+		if (pub_import(&Y, pubs_aff + (size_t)i * 2 * c->clen, c)) {
+			continue;
+		}
+		if (import_rs(r, s, sigs + (size_t)i * 2 * c->qlen, c)) {
+			continue;
+		}
+		if (digest_to_e(e, digests + (size_t)i * hsize, hsize, c)) {
+			continue;
+		}
+		q_inv(sinv, s, c);
+		q_mul(u, e, sinv, c);
+		q_mul(v, r, sinv, c);
+		load_gen(&G, c);
+		if (pt_mul(&uG, u, c->q_n, &G, c) || pt_mul(&vY, v, c->q_n, &Y, c)) {
+			continue;
+		}
+		if (pt_add(&W, &uG, &vY, c)) {
+			continue;
+		}
+		if (nn_iszero(W.Z, c->fp.n)) {
+			continue;
+		}
+		pt_unique(&W, c);
+		nn_mod(rp, W.X, c->fp.n, c->q, c->q_n);
+		result[i] = (nn_cmp(rp, r, c->q_n) == 0) ? 0 : 1;
+	}
+	return 0;
+}
+
+/*
+ * __ecdsa_sign_finalize (sig/ecdsa_common.c:318-586) with the nonce k and digest supplied:
+ * kG = prj_pt_mul(k, G) (:479), r = kG.x mod q (:487), s = k^-1 (x r + e) mod q (:511-542).
+ * The reference restarts on r = 0 / e == x r / s = 0 (:492,516,548); with a fixed nonce
+ * that cannot progress, so those cases are reported as status 1 here.
+ */
+int orc_ecdsa_sign_batch(const orc_curve *c, uint32_t n, const uint8_t *privs,
+			 const uint8_t *nonces, const uint8_t *digests, uint32_t hsize,
+			 uint8_t *sigs, uint8_t *status)
+{
+	uint32_t i;
+	for (i = 0; i < n; i++) {
+		pt G, kG;
+		u64 x[ORC_MAXW], k[ORC_MAXW], e[ORC_MAXW], r[ORC_MAXW], s[ORC_MAXW], t[ORC_MAXW];
+		u64 kinv[ORC_MAXW];
+		status[i] = 1;
+		memset(sigs + (size_t)i * 2 * c->qlen, 0, (size_t)(2 * c->qlen));
+		if (nn_from_be(x, c->q_n, privs + (size_t)i * c->qlen, c->qlen) ||
+		    nn_from_be(k, c->q_n, nonces + (size_t)i * c->qlen, c->qlen)) {
+			continue;
+		}
+		if (nn_iszero(k, c->q_n) || nn_cmp(k, c->q, c->q_n) >= 0) {
+			continue;
+		}
+		if (digest_to_e(e, digests + (size_t)i * hsize, hsize, c)) {
+			continue;
+		}
+		load_gen(&G, c);
+		if (pt_mul(&kG, k, c->q_n, &G, c) || pt_unique(&kG, c)) {
+			continue;
+		}
+		nn_mod(r, kG.X, c->fp.n, c->q, c->q_n);
+		if (nn_iszero(r, c->q_n)) {
+			continue;
+		}
+		nn_mod(t, x, c->q_n, c->q, c->q_n);
+		q_mul(t, t, r, c);
+		if (nn_cmp(e, t, c->q_n) == 0) {
+			continue;
+		}
+		fp_add(t, t, e, &c->fq);
+		q_inv(kinv, k, c);
+		q_mul(s, t, kinv, c);
+		if (nn_iszero(s, c->q_n)) {
+			continue;
+		}
+		nn_to_be(sigs + (size_t)i * 2 * c->qlen, c->qlen, r, c->q_n);
+		nn_to_be(sigs + (size_t)i * 2 * c->qlen + c->qlen, c->qlen, s, c->q_n);
+		status[i] = 0;
+	}
+	return 0;
+}
+
+/* ecccdh_derive_secret (ecdh/ecccdh.c:167-233): import peer (on-curve + subgroup check),
+ * cofactor multiplication if h != 1, reject infinity, d*Q, reject infinity, x coordinate. */
+int orc_ecccdh_batch(const orc_curve *c, uint32_t n, const uint8_t *privs, const uint8_t *peers_aff,
+		     uint8_t *secrets, uint8_t *status)
+{
+	uint32_t i;
+	for (i = 0; i < n; i++) {
+		pt Q;
+		u64 d[ORC_MAXW];
+		status[i] = 1;
+		memset(secrets + (size_t)i * c->clen, 0, (size_t)c->clen);
+		if (nn_from_be(d, c->q_n, privs + (size_t)i * c->qlen, c->qlen)) {
+			continue;
+		}
+		if (pub_import(&Q, peers_aff + (size_t)i * 2 * c->clen, c)) {
+			continue;
+		}
+		if (nn_cmp(c->order, c->q, ORC_MAXW) != 0) {
+			/* cofactor h = order / q; the only built-in values are 4 and 8 */
+			u64 h[ORC_MAXW], t[2 * ORC_MAXW];
+			int hv, found = 0;
+			for (hv = 2; hv <= 16 && !found; hv++) {
+				nn_zero(h, ORC_MAXW);
+				h[0] = (u64)hv;
+				nn_mul(t, c->q, c->q_n, h, 1);
+				if (nn_cmp(t, c->order, c->q_n + 1) == 0) {
+					found = 1;
+				}
+			}
+			if (!found || pt_unprotected_mult(&Q, h, 1, &Q, c)) {
+				continue;
+			}
+		}
+		if (nn_iszero(Q.Z, c->fp.n)) {
+			continue;
+		}
+		if (pt_mul(&Q, d, c->q_n, &Q, c)) {
+			continue;
+		}
+		if (nn_iszero(Q.Z, c->fp.n)) {
+			continue;
+		}
+		pt_unique(&Q, c);
+		nn_to_be(secrets + (size_t)i * c->clen, c->clen, Q.X, c->fp.n);
+		status[i] = 0;
+	}
+	return 0;
+}

@@ -1,0 +1,455 @@
+/*
+ * oracle/ref_driver.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A thin batch driver over the UNMODIFIED reference library (compiled from
+ * /root/reference/src by oracle/Makefile into oracle/_ref/libecc_ref.so).  It is the
+ * ground truth the plain-C restatement (ecc_oracle.c) and the HIP path are pinned
+ * against, and the "reference" CPU baseline timed by bench.py.  Nothing under
+ * libecc_amd/ may link or load this file.
+ *
+ * It supplies the three symbols the reference library leaves undefined
+ * (get_random / get_unsafe_random: external_deps/rand.c:76,128 -- here a seeded,
+ * thread-local splitmix64 so runs are reproducible; ext_printf comes from the
+ * reference's external_deps/print.c) and exposes plain C-ABI loops over the
+ * reference API:
+ *   prj_pt_import_from_aff_buf (curves/prj_pt.c:511) -> prj_pt_mul (:1759)
+ *   -> prj_pt_unique (:241) -> prj_pt_export_to_aff_buf (:600)
+ *   ec_verify (sig/sig_algs.c:655), _ec_sign (:473), ecccdh_derive_secret (ecdh/ecccdh.c:167)
+ *   nn_mul_redc1 (nn/nn_mul_redc1.c:246), prj_pt_add (:1204), prj_pt_dbl (:1132)
+ */
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
+#include <time.h>
+#include <pthread.h>
+#include "libsig.h"
+
+/* ---- randomness hooks the reference imports (seeded, thread-local) ---- */
+static __thread uint64_t tl_seed = 0x9E3779B97F4A7C15ULL;
+static uint64_t splitmix64(void)
+{
+	uint64_t z = (tl_seed += 0x9E3779B97F4A7C15ULL);
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	return z ^ (z >> 31);
+}
+int get_random(unsigned char *buf, u16 len)
+{
+	u16 i;
+	for (i = 0; i < len; i++) {
+		buf[i] = (unsigned char)(splitmix64() >> 24);
+	}
+	return 0;
+}
+int get_unsafe_random(unsigned char *buf, u16 len) { return get_random(buf, len); }
+void refdrv_seed(uint64_t s) { tl_seed = s; }
+
+/* ---- helpers ---- */
+static int load_params(const char *curve, ec_params *params)
+{
+	const ec_str_params *sp = NULL;
+	int ret;
+	ret = ec_get_curve_params_by_name((const u8 *)curve, (u8)(strlen(curve) + 1), &sp);
+	if (ret || sp == NULL) {
+		return -1;
+	}
+	return import_params(params, sp);
+}
+
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int refdrv_coord_len(const char *curve)
+{
+	ec_params params;
+	if (load_params(curve, &params)) {
+		return -1;
+	}
+	return (int)BYTECEIL(params.ec_fp.p_bitlen);
+}
+
+int refdrv_order_len(const char *curve)
+{
+	ec_params params;
+	if (load_params(curve, &params)) {
+		return -1;
+	}
+	return (int)BYTECEIL(params.ec_gen_order_bitlen);
+}
+
+/* ---- batched scalar multiplication through the public API ---- */
+typedef struct {
+	const ec_params *params;
+	uint32_t lo, hi, slen, clen;
+	const uint8_t *scalars, *points;
+	uint8_t *out, *status;
+	double t_mul; /* seconds spent inside prj_pt_mul + prj_pt_unique only */
+} smul_job;
+
+static void *smul_worker(void *arg)
+{
+	smul_job *j = (smul_job *)arg;
+	uint32_t i;
+	const uint32_t plen = 2 * j->clen;
+	double acc = 0.0;
+	refdrv_seed(0x5EC9256ULL + j->lo);
+	for (i = j->lo; i < j->hi; i++) {
+		prj_pt P, Q;
+		nn m;
+		int ret, iszero = 0;
+		double t0;
+		P.magic = Q.magic = WORD(0);
+		m.magic = WORD(0);
+		j->status[i] = 1;
+		memset(j->out + (size_t)i * plen, 0, plen);
+		ret = nn_init_from_buf(&m, j->scalars + (size_t)i * j->slen, (u16)j->slen);
+		if (ret) {
+			continue;
+		}
+		if (j->points) {
+			ret = prj_pt_import_from_aff_buf(&P, j->points + (size_t)i * plen, (u16)plen,
+							 &j->params->ec_curve);
+		} else {
+			ret = prj_pt_copy(&P, &j->params->ec_gen);
+		}
+		if (ret) {
+			continue;
+		}
+		t0 = now_s();
+		ret = prj_pt_mul(&Q, &m, &P);
+		if (!ret) {
+			ret = prj_pt_iszero(&Q, &iszero);
+		}
+		if (!ret && !iszero) {
+			ret = prj_pt_unique(&Q, &Q);
+		}
+		acc += now_s() - t0;
+		if (ret) {
+			continue;
+		}
+		if (iszero) {
+			j->status[i] = 2;
+			continue;
+		}
+		ret = prj_pt_export_to_aff_buf(&Q, j->out + (size_t)i * plen, plen);
+		j->status[i] = ret ? 1 : 0;
+	}
+	j->t_mul = acc;
+	return NULL;
+}
+
+/*
+ * status[i]: 0 = ok (out = affine X||Y big-endian), 1 = error (the reference returned -1:
+ * coordinate >= p, off-curve, ...), 2 = result is the point at infinity (prj_pt_mul
+ * returned 0 with Z = 0; prj_pt_unique would return -1).
+ * *elapsed = wall seconds of the whole loop; *mul_seconds = max over threads of the time
+ * spent inside prj_pt_mul + prj_pt_unique.
+ */
+int refdrv_scalar_mult_batch(const char *curve, uint32_t n, const uint8_t *scalars, uint32_t slen,
+			     const uint8_t *points, uint8_t *out, uint8_t *status, int nthreads,
+			     double *elapsed, double *mul_seconds)
+{
+	ec_params params;
+	pthread_t th[256];
+	smul_job jobs[256];
+	int t;
+	double t0, mx = 0.0;
+	if (load_params(curve, &params)) {
+		return -1;
+	}
+	if (nthreads < 1) {
+		nthreads = 1;
+	}
+	if (nthreads > 256) {
+		nthreads = 256;
+	}
+	t0 = now_s();
+	for (t = 0; t < nthreads; t++) {
+		jobs[t].params = &params;
+		jobs[t].lo = (uint32_t)(((uint64_t)n * (uint64_t)t) / (uint64_t)nthreads);
+		jobs[t].hi = (uint32_t)(((uint64_t)n * (uint64_t)(t + 1)) / (uint64_t)nthreads);
+		jobs[t].slen = slen;
+		jobs[t].clen = (uint32_t)BYTECEIL(params.ec_fp.p_bitlen);
+		jobs[t].scalars = scalars;
+		jobs[t].points = points;
+		jobs[t].out = out;
+		jobs[t].status = status;
+		jobs[t].t_mul = 0.0;
+		if (nthreads == 1) {
+			smul_worker(&jobs[t]);
+		} else if (pthread_create(&th[t], NULL, smul_worker, &jobs[t])) {
+			return -1;
+		}
+	}
+	for (t = 0; t < nthreads; t++) {
+		if (nthreads > 1) {
+			pthread_join(th[t], NULL);
+		}
+		if (jobs[t].t_mul > mx) {
+			mx = jobs[t].t_mul;
+		}
+	}
+	if (elapsed) {
+		*elapsed = now_s() - t0;
+	}
+	if (mul_seconds) {
+		*mul_seconds = mx;
+	}
+	return 0;
+}
+
+/* ---- point addition / doubling (affine in, affine out) ---- */
+int refdrv_pt_add_batch(const char *curve, uint32_t n, const uint8_t *p1, const uint8_t *p2,
+			uint8_t *out, uint8_t *status, int dbl)
+{
+	ec_params params;
+	uint32_t i, clen, plen;
+	if (load_params(curve, &params)) {
+		return -1;
+	}
+	clen = (uint32_t)BYTECEIL(params.ec_fp.p_bitlen);
+	plen = 2 * clen;
+	for (i = 0; i < n; i++) {
+		prj_pt A, B, C;
+		int ret, iszero = 0;
+		A.magic = B.magic = C.magic = WORD(0);
+		status[i] = 1;
+		memset(out + (size_t)i * plen, 0, plen);
+		ret = prj_pt_import_from_aff_buf(&A, p1 + (size_t)i * plen, (u16)plen, &params.ec_curve);
+		if (ret) {
+			continue;
+		}
+		if (dbl) {
+			ret = prj_pt_dbl(&C, &A);
+		} else {
+			ret = prj_pt_import_from_aff_buf(&B, p2 + (size_t)i * plen, (u16)plen,
+							 &params.ec_curve);
+			if (ret) {
+				continue;
+			}
+			ret = prj_pt_add(&C, &A, &B);
+		}
+		if (ret) {
+			continue;
+		}
+		ret = prj_pt_iszero(&C, &iszero);
+		if (ret) {
+			continue;
+		}
+		if (iszero) {
+			status[i] = 2;
+			continue;
+		}
+		ret = prj_pt_unique(&C, &C);
+		if (ret) {
+			continue;
+		}
+		ret = prj_pt_export_to_aff_buf(&C, out + (size_t)i * plen, plen);
+		status[i] = ret ? 1 : 0;
+	}
+	return 0;
+}
+
+/* ---- field level: nn_mul_redc1 / plain fp ops on little-endian u64 limbs ---- */
+/* op: 0 = fp_mul_monty (nn_mul_redc1), 1 = fp_add, 2 = fp_sub, 3 = fp_mul (plain), 4 = fp_inv (b ignored) */
+int refdrv_fp_op_batch(const char *curve, int op, uint32_t n, uint32_t nlimbs, const uint64_t *a,
+		       const uint64_t *b, uint64_t *out)
+{
+	ec_params params;
+	uint32_t i, k;
+	if (load_params(curve, &params)) {
+		return -1;
+	}
+	for (i = 0; i < n; i++) {
+		fp x, y, z;
+		nn t;
+		int ret;
+		x.magic = y.magic = z.magic = WORD(0);
+		t.magic = WORD(0);
+		ret = fp_init(&x, &params.ec_fp);
+		ret |= fp_init(&y, &params.ec_fp);
+		ret |= fp_init(&z, &params.ec_fp);
+		ret |= nn_init(&t, (u16)(nlimbs * 8));
+		if (ret) {
+			return -1;
+		}
+		for (k = 0; k < nlimbs; k++) {
+			t.val[k] = a[(size_t)i * nlimbs + k];
+		}
+		ret = fp_set_nn(&x, &t);
+		for (k = 0; k < nlimbs; k++) {
+			t.val[k] = b[(size_t)i * nlimbs + k];
+		}
+		ret |= fp_set_nn(&y, &t);
+		if (ret) {
+			return -1;
+		}
+		switch (op) {
+		case 0: ret = fp_mul_monty(&z, &x, &y); break;
+		case 1: ret = fp_add(&z, &x, &y); break;
+		case 2: ret = fp_sub(&z, &x, &y); break;
+		case 3: ret = fp_mul(&z, &x, &y); break;
+		case 4: ret = fp_inv(&z, &x); break;
+		default: ret = -1;
+		}
+		if (ret) {
+			return -1;
+		}
+		for (k = 0; k < nlimbs; k++) {
+			out[(size_t)i * nlimbs + k] = (k < z.fp_val.wlen) ? z.fp_val.val[k] : 0;
+		}
+	}
+	return 0;
+}
+
+/* ---- ECDSA verify / sign and ECC-CDH through the protocol API ---- */
+/* result[i] = 0 accept, 1 reject (ec_verify returned -1, incl. import failure) */
+int refdrv_ecdsa_verify_batch(const char *curve, int hash_type, uint32_t n, const uint8_t *pubs_aff,
+			      const uint8_t *sigs, const uint8_t *msgs, uint32_t msg_len,
+			      uint8_t *result)
+{
+	ec_params params;
+	uint32_t i, clen, qlen;
+	if (load_params(curve, &params)) {
+		return -1;
+	}
+	clen = (uint32_t)BYTECEIL(params.ec_fp.p_bitlen);
+	qlen = (uint32_t)BYTECEIL(params.ec_gen_order_bitlen);
+	for (i = 0; i < n; i++) {
+		ec_pub_key pub;
+		int ret;
+		result[i] = 1;
+		ret = ec_pub_key_import_from_aff_buf(&pub, &params, pubs_aff + (size_t)i * 2 * clen,
+						     (u8)(2 * clen), ECDSA);
+		if (ret) {
+			continue;
+		}
+		ret = ec_verify(sigs + (size_t)i * 2 * qlen, (u8)(2 * qlen), &pub,
+				msgs + (size_t)i * msg_len, msg_len, ECDSA, (hash_alg_type)hash_type,
+				NULL, 0);
+		result[i] = ret ? 1 : 0;
+	}
+	return 0;
+}
+
+static __thread const uint8_t *tl_nonce;
+static __thread uint32_t tl_nonce_len;
+static int fixed_nonce(nn_t out, nn_src_t q)
+{
+	int ret, cmp;
+	ret = nn_init_from_buf(out, tl_nonce, (u16)tl_nonce_len);
+	if (ret) {
+		return ret;
+	}
+	ret = nn_cmp(out, q, &cmp);
+	if (ret) {
+		return ret;
+	}
+	return (cmp >= 0) ? -1 : 0;
+}
+
+/* Sign with a caller-supplied nonce k (as the reference's KAT harness does through the
+ * same callback pointer, tests/ec_self_tests_core.c:731-1012). status 0 ok / 1 error. */
+int refdrv_ecdsa_sign_batch(const char *curve, int hash_type, uint32_t n, const uint8_t *privs,
+			    const uint8_t *nonces, const uint8_t *msgs, uint32_t msg_len,
+			    uint8_t *sigs, uint8_t *pubs_aff, uint8_t *status)
+{
+	ec_params params;
+	uint32_t i, clen, qlen;
+	if (load_params(curve, &params)) {
+		return -1;
+	}
+	clen = (uint32_t)BYTECEIL(params.ec_fp.p_bitlen);
+	qlen = (uint32_t)BYTECEIL(params.ec_gen_order_bitlen);
+	for (i = 0; i < n; i++) {
+		ec_key_pair kp;
+		int ret;
+		status[i] = 1;
+		ret = ec_key_pair_import_from_priv_key_buf(&kp, &params, privs + (size_t)i * qlen,
+							   (u8)qlen, ECDSA);
+		if (ret) {
+			continue;
+		}
+		if (pubs_aff) {
+			ret = ec_pub_key_export_to_aff_buf(&kp.pub_key, pubs_aff + (size_t)i * 2 * clen,
+							   (u8)(2 * clen));
+			if (ret) {
+				continue;
+			}
+		}
+		tl_nonce = nonces + (size_t)i * qlen;
+		tl_nonce_len = qlen;
+		ret = _ec_sign(sigs + (size_t)i * 2 * qlen, (u8)(2 * qlen), &kp,
+			       msgs + (size_t)i * msg_len, msg_len, fixed_nonce, ECDSA,
+			       (hash_alg_type)hash_type, NULL, 0);
+		status[i] = ret ? 1 : 0;
+	}
+	return 0;
+}
+
+/* ECC-CDH: shared secret = x(d * Q_peer); status 0 ok / 1 error (-1 from the reference) */
+int refdrv_ecccdh_batch(const char *curve, uint32_t n, const uint8_t *privs, const uint8_t *peers_aff,
+			uint8_t *secrets, uint8_t *status)
+{
+	ec_params params;
+	uint32_t i, clen, qlen;
+	if (load_params(curve, &params)) {
+		return -1;
+	}
+	clen = (uint32_t)BYTECEIL(params.ec_fp.p_bitlen);
+	qlen = (uint32_t)BYTECEIL(params.ec_gen_order_bitlen);
+	for (i = 0; i < n; i++) {
+		ec_priv_key priv;
+		int ret;
+		status[i] = 1;
+		memset(secrets + (size_t)i * clen, 0, clen);
+		ret = ec_priv_key_import_from_buf(&priv, &params, privs + (size_t)i * qlen, (u8)qlen,
+						  ECCCDH);
+		if (ret) {
+			continue;
+		}
+		ret = ecccdh_derive_secret(&priv, peers_aff + (size_t)i * 2 * clen, (u8)(2 * clen),
+					   secrets + (size_t)i * clen, (u8)clen);
+		status[i] = ret ? 1 : 0;
+	}
+	return 0;
+}
+
+/* ---- domain-parameter export (used once by tools/gen_curve_table.py) ---- */
+static int put_str_param(const ec_str_param *sp, uint8_t *dst, uint32_t cap)
+{
+	if (sp == NULL || sp->buflen > cap) {
+		return -1;
+	}
+	memcpy(dst, sp->buf, sp->buflen);
+	return (int)sp->buflen;
+}
+
+/*
+ * Dump the big-endian byte strings of curve number 'type' (ec_curve_type, 1..EC_CURVES_NUM).
+ * fields, each written to out + k*256 with its length in lens[k]:
+ *   0 name, 1 p, 2 a, 3 b, 4 curve_order, 5 gx, 6 gy, 7 gen_order, 8 cofactor
+ * returns 0, or -1 if the type is not built in.
+ */
+int refdrv_curve_params(int type, uint8_t *out, int32_t *lens)
+{
+	const ec_str_params *sp = NULL;
+	const ec_str_param *f[9];
+	int k;
+	if (ec_get_curve_params_by_type((ec_curve_type)type, &sp) || sp == NULL) {
+		return -1;
+	}
+	f[0] = sp->name; f[1] = sp->p; f[2] = sp->a; f[3] = sp->b; f[4] = sp->curve_order;
+	f[5] = sp->gx; f[6] = sp->gy; f[7] = sp->gen_order; f[8] = sp->cofactor;
+	for (k = 0; k < 9; k++) {
+		lens[k] = put_str_param(f[k], out + k * 256, 256);
+		if (lens[k] < 0) {
+			return -1;
+		}
+	}
+	return 0;
+}

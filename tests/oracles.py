@@ -1,0 +1,265 @@
+"""ctypes front-ends for the two CPU checkers (TEST INFRASTRUCTURE):
+
+  Oracle  -- oracle/liboracle.so, our plain-C restatement (oracle/ecc_oracle.c)
+  RefLib  -- oracle/_ref/libecc_ref.so, the unmodified reference + oracle/ref_driver.c
+             (present when it was built in the authoring container; it travels to the GPU box)
+
+Nothing under libecc_amd/ imports this module.
+"""
+import ctypes as C
+import hashlib
+import hmac
+import json
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+u8p = C.c_char_p
+
+
+def curves():
+    with open(os.path.join(GOLDEN, "curves.json")) as f:
+        out = {}
+        for c in json.load(f):
+            out[c["name"]] = {k: (int(v, 16) if k not in ("name", "type") else v) for k, v in c.items()}
+        return out
+
+
+CURVES = curves()
+
+
+def clen(curve):
+    return (CURVES[curve]["p"].bit_length() + 7) // 8
+
+
+def qlen(curve):
+    return (CURVES[curve]["q"].bit_length() + 7) // 8
+
+
+def _be(x, n=None):
+    n = n or max(1, (x.bit_length() + 7) // 8)
+    return x.to_bytes(n, "big")
+
+
+def build_oracle():
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    src = os.path.join(ROOT, "oracle", "ecc_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+class Oracle:
+    """Restatement oracle bound to one curve."""
+
+    def __init__(self, curve):
+        self.L = C.CDLL(build_oracle())
+        self.curve = curve
+        c = CURVES[curve]
+        self.clen, self.qlen = clen(curve), qlen(curve)
+        self.nl = (c["p"].bit_length() + 63) // 64
+        self.ctx = C.create_string_buffer(self.L.orc_sizeof_curve())
+        args = []
+        for k in ("p", "a", "b", "order", "gx", "gy", "q"):
+            b = _be(c[k])
+            args += [b, len(b)]
+        assert self.L.orc_curve_init(self.ctx, *args) == 0
+
+    def scalar_mult(self, scalars, points=None, slen=None):
+        slen = slen or self.qlen
+        n = len(scalars) // slen
+        out = C.create_string_buffer(2 * self.clen * n)
+        st = C.create_string_buffer(n)
+        assert self.L.orc_scalar_mult_batch(self.ctx, n, scalars, slen, points, out, st) == 0
+        return out.raw, st.raw
+
+    def pt_add(self, p1, p2=None):
+        n = len(p1) // (2 * self.clen)
+        out = C.create_string_buffer(2 * self.clen * n)
+        st = C.create_string_buffer(n)
+        assert self.L.orc_pt_add_batch(self.ctx, n, p1, p2, out, st, 1 if p2 is None else 0) == 0
+        return out.raw, st.raw
+
+    def fp_op(self, op, a, b):
+        """a, b: lists of ints < p; returns list of ints."""
+        n = len(a)
+        A = (C.c_uint64 * (n * self.nl))(*[(x >> (64 * k)) & (2**64 - 1) for x in a for k in range(self.nl)])
+        B = (C.c_uint64 * (n * self.nl))(*[(x >> (64 * k)) & (2**64 - 1) for x in b for k in range(self.nl)])
+        O = (C.c_uint64 * (n * self.nl))()
+        assert self.L.orc_fp_op_batch(self.ctx, op, n, A, B, O) == 0
+        return [sum(O[i * self.nl + k] << (64 * k) for k in range(self.nl)) for i in range(n)]
+
+    def ecdsa_verify(self, pubs, sigs, digests, hsize):
+        n = len(pubs) // (2 * self.clen)
+        res = C.create_string_buffer(n)
+        assert self.L.orc_ecdsa_verify_batch(self.ctx, n, pubs, sigs, digests, hsize, res) == 0
+        return res.raw
+
+    def ecdsa_sign(self, privs, nonces, digests, hsize):
+        n = len(privs) // self.qlen
+        sigs = C.create_string_buffer(2 * self.qlen * n)
+        st = C.create_string_buffer(n)
+        assert self.L.orc_ecdsa_sign_batch(self.ctx, n, privs, nonces, digests, hsize, sigs, st) == 0
+        return sigs.raw, st.raw
+
+    def ecccdh(self, privs, peers):
+        n = len(privs) // self.qlen
+        sec = C.create_string_buffer(self.clen * n)
+        st = C.create_string_buffer(n)
+        assert self.L.orc_ecccdh_batch(self.ctx, n, privs, peers, sec, st) == 0
+        return sec.raw, st.raw
+
+
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libecc_ref.so")
+HASH_IDS = {"SHA224": 1, "SHA256": 2, "SHA384": 3, "SHA512": 4, "SHA3_224": 5, "SHA3_256": 6,
+            "SHA3_384": 7, "SHA3_512": 8}
+HASHLIB = {"SHA224": "sha224", "SHA256": "sha256", "SHA384": "sha384", "SHA512": "sha512",
+           "SHA3_224": "sha3_224", "SHA3_256": "sha3_256", "SHA3_384": "sha3_384",
+           "SHA3_512": "sha3_512"}
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+class RefLib:
+    """The unmodified reference, through oracle/ref_driver.c."""
+
+    def __init__(self, curve):
+        self.L = C.CDLL(REF_SO)
+        self.curve = curve
+        self.name = curve.encode()
+        self.clen, self.qlen = clen(curve), qlen(curve)
+        self.nl = (CURVES[curve]["p"].bit_length() + 63) // 64
+        assert self.L.refdrv_coord_len(self.name) == self.clen
+
+    def scalar_mult(self, scalars, points=None, slen=None, nthreads=1, timing=False):
+        slen = slen or self.qlen
+        n = len(scalars) // slen
+        out = C.create_string_buffer(2 * self.clen * n)
+        st = C.create_string_buffer(n)
+        el, ms = C.c_double(), C.c_double()
+        r = self.L.refdrv_scalar_mult_batch(self.name, C.c_uint32(n), scalars, C.c_uint32(slen), points,
+                                            out, st, nthreads, C.byref(el), C.byref(ms))
+        assert r == 0
+        if timing:
+            return out.raw, st.raw, el.value, ms.value
+        return out.raw, st.raw
+
+    def pt_add(self, p1, p2=None):
+        n = len(p1) // (2 * self.clen)
+        out = C.create_string_buffer(2 * self.clen * n)
+        st = C.create_string_buffer(n)
+        assert self.L.refdrv_pt_add_batch(self.name, n, p1, p2, out, st, 1 if p2 is None else 0) == 0
+        return out.raw, st.raw
+
+    def fp_op(self, op, a, b):
+        n = len(a)
+        A = (C.c_uint64 * (n * self.nl))(*[(x >> (64 * k)) & (2**64 - 1) for x in a for k in range(self.nl)])
+        B = (C.c_uint64 * (n * self.nl))(*[(x >> (64 * k)) & (2**64 - 1) for x in b for k in range(self.nl)])
+        O = (C.c_uint64 * (n * self.nl))()
+        assert self.L.refdrv_fp_op_batch(self.name, op, n, self.nl, A, B, O) == 0
+        return [sum(O[i * self.nl + k] << (64 * k) for k in range(self.nl)) for i in range(n)]
+
+    def ecdsa_verify(self, hash_name, pubs, sigs, msgs, msg_len):
+        n = len(pubs) // (2 * self.clen)
+        res = C.create_string_buffer(n)
+        assert self.L.refdrv_ecdsa_verify_batch(self.name, HASH_IDS[hash_name], n, pubs, sigs, msgs,
+                                                msg_len, res) == 0
+        return res.raw
+
+    def ecdsa_sign(self, hash_name, privs, nonces, msgs, msg_len):
+        n = len(privs) // self.qlen
+        sigs = C.create_string_buffer(2 * self.qlen * n)
+        pubs = C.create_string_buffer(2 * self.clen * n)
+        st = C.create_string_buffer(n)
+        assert self.L.refdrv_ecdsa_sign_batch(self.name, HASH_IDS[hash_name], n, privs, nonces, msgs,
+                                              msg_len, sigs, pubs, st) == 0
+        return sigs.raw, pubs.raw, st.raw
+
+    def ecccdh(self, privs, peers):
+        n = len(privs) // self.qlen
+        sec = C.create_string_buffer(self.clen * n)
+        st = C.create_string_buffer(n)
+        assert self.L.refdrv_ecccdh_batch(self.name, n, privs, peers, sec, st) == 0
+        return sec.raw, st.raw
+
+
+def digest(hash_name, msg):
+    return hashlib.new(HASHLIB[hash_name], msg).digest()
+
+
+def rfc6979_nonce(curve, hash_name, priv, msg):
+    """RFC 6979 section 3.2 (the reference's __ecdsa_rfc6979_nonce, sig/ecdsa_common.c:48-169)."""
+    q = CURVES[curve]["q"]
+    qbits, rlen = q.bit_length(), (q.bit_length() + 7) // 8
+    hname = HASHLIB[hash_name]
+    h1 = hashlib.new(hname, msg).digest()
+    hl = len(h1)
+
+    def bits2int(b):
+        x = int.from_bytes(b, "big")
+        return x >> (len(b) * 8 - qbits) if len(b) * 8 > qbits else x
+
+    x = int.from_bytes(priv, "big")
+    bx = x.to_bytes(rlen, "big") + (bits2int(h1) % q).to_bytes(rlen, "big")
+    V, K = b"\x01" * hl, b"\x00" * hl
+    K = hmac.new(K, V + b"\x00" + bx, hname).digest()
+    V = hmac.new(K, V, hname).digest()
+    K = hmac.new(K, V + b"\x01" + bx, hname).digest()
+    V = hmac.new(K, V, hname).digest()
+    while True:
+        T = b""
+        while len(T) < rlen:
+            V = hmac.new(K, V, hname).digest()
+            T += V
+        k = bits2int(T[:rlen])
+        if 1 <= k < q:
+            return k
+        K = hmac.new(K, V + b"\x00", hname).digest()
+        V = hmac.new(K, V, hname).digest()
+
+
+# ---- independent Python affine arithmetic (third opinion, tiny cases only) ----
+def py_add(P, Q, a, p):
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    if P[0] == Q[0]:
+        if (P[1] + Q[1]) % p == 0:
+            return None
+        lam = (3 * P[0] * P[0] + a) * pow(2 * P[1], p - 2, p) % p
+    else:
+        lam = (Q[1] - P[1]) * pow(Q[0] - P[0], p - 2, p) % p
+    x = (lam * lam - P[0] - Q[0]) % p
+    return (x, (lam * (P[0] - x) - P[1]) % p)
+
+
+def py_mul(k, P, a, p):
+    R = None
+    while k:
+        if k & 1:
+            R = py_add(R, P, a, p)
+        P = py_add(P, P, a, p)
+        k >>= 1
+    return R
+
+
+def py_smul_bytes(curve, k, P=None):
+    c = CURVES[curve]
+    P = P or (c["gx"], c["gy"])
+    R = py_mul(k % c["order"], P, c["a"], c["p"])
+    n = clen(curve)
+    return None if R is None else R[0].to_bytes(n, "big") + R[1].to_bytes(n, "big")
+
+
+def rand_points(curve, rng, n):
+    """n affine points [t]G (bytes) via Python ints -- slow, keep n small -- or via Oracle."""
+    o = Oracle(curve)
+    sc = b"".join(int(rng.integers(1, 2**62)).to_bytes(o.qlen, "big") for _ in range(n))
+    pts, st = o.scalar_mult(sc)
+    assert set(st) == {0}
+    return pts
