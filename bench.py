@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""bench.py -- scalar-mults/sec of the batched prj_pt_mul hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run with one rank per GPU (RCCL).  A "step" is one pass of the hot path over
+one batch: B = 2^20 secp256r1 variable-base scalar multiplications per GPU (BASELINE.json
+configs[1]), scalars uniform in [1, q-1], base points P_i = [t_i]G, affine X||Y in / out --
+inputs resident in HBM before the timed region.  For N > 1 the batch is sharded by rank (weak
+scaling: every rank owns 2^20 items) and the step ends with one RCCL all-gather of the
+output points, as north_star specifies.
+
+Rank 0 prints ONE JSON line with the driver's fields plus
+  roofline     executed 32x32 multiply-accumulates per second against the v_mad_u64_u32 issue
+               peak MEASURED on this device by libecc_amd/lib/ubench, and
+               the HBM view (algorithmic bytes / s against 8 TB/s) beside it;
+  cpu_baseline the reference's own prj_pt_mul + prj_pt_unique (oracle/_ref, "reference") or the
+               C restatement ("port") timed on this box's host cores on a bounded sample.
+Before anything is timed a random subset of the GPU output is compared byte-for-byte with the
+CPU oracle; a mismatch aborts the run.
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import libecc_amd  # noqa: E402
+
+CURVE = "SECP256R1"
+SEED = 0x5EC9256
+
+
+def popcount(x):
+    return bin(x).count("1")
+
+
+def work_model(curve_params, nw, slen):
+    """Montgomery multiplications and 32x32 MADs the k_smul kernel executes per item
+    (libecc_amd/csrc/ecamd_kernels.hip): derived from the kernel's own parameters."""
+    p = curve_params["p"]
+    pbits = p.bit_length()
+    nwin = 2 * slen
+    mm_add, mm_dbl = 17, 16                     # RCB Alg. 1 / Alg. 3, generic a
+    mm = 0
+    mm += 2 + 3                                 # to Montgomery (x, y) + on-curve check
+    mm += 14 * mm_add                           # table [2..15]P
+    mm += (nwin - 1) * (4 * mm_dbl + mm_add)    # windows
+    mm += pbits + popcount(p - 2)               # Fermat inversion (square-and-multiply)
+    mm += 2 + 2                                 # X/Z, Y/Z, from Montgomery
+    mads_per_mm = 2 * nw * nw + nw              # FIPS Montgomery multiplication, 32-bit words
+    return mm, mm * mads_per_mm
+
+
+def ref_equiv_mads():
+    """the reference algorithm's work per P-256 scalar mult (W_ref)"""
+    return 8724 * 136
+
+
+def measured_mad_peak():
+    exe = os.path.join(ROOT, "libecc_amd", "lib", "ubench")
+    try:
+        out = subprocess.run([exe, "2000"], capture_output=True, text=True, timeout=120).stdout
+        j = json.loads(out)
+        return j["v_mad_u64_u32"]["lane_ops_per_s"], j
+    except Exception:
+        return None, None
+
+
+def cpu_baseline(curve, scalars, points, slen):
+    from oracles import Oracle, RefLib, have_ref
+    cores = os.cpu_count() or 1
+    if have_ref():
+        r = RefLib(curve)
+        probe = 64
+        t0 = time.time()
+        r.scalar_mult(scalars[:probe * slen], points[:probe * 64], slen)
+        rate1 = probe / (time.time() - t0)
+        n = int(min(len(scalars) // slen, max(256, rate1 * cores * 10.0)))   # ~10 s of wall time
+        _, st, el, _ = r.scalar_mult(scalars[:n * slen], points[:n * 64], slen, nthreads=cores, timing=True)
+        return {"value": n / el, "unit": "scalar-mults/s", "cores": cores, "kind": "reference",
+                "sample": f"first {n} items of the same batch, prj_pt_mul+prj_pt_unique via oracle/_ref "
+                          f"({cores} pthreads, {el:.1f} s wall); 1-core probe {rate1:.0f}/s"}
+    o = Oracle(curve)
+    n = 2048
+    t0 = time.time()
+    o.scalar_mult(scalars[:n * slen], points[:n * 64], slen)
+    el = time.time() - t0
+    return {"value": n / el, "unit": "scalar-mults/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} items of the same batch through oracle/ecc_oracle.c, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-log2", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from oracles import CURVES, Oracle
+    cp = CURVES[CURVE]
+    q = cp["q"]
+    B = 1 << args.batch_log2
+    slen, clen = 32, 32
+
+    ctx = libecc_amd.Context(local_rank)
+    cv = ctx.curve(CURVE)
+
+    # ---- synthetic inputs (seeded; rank-dependent shard) ----
+    rng = np.random.default_rng(SEED + rank)
+
+    def rand_scalars(n):
+        raw = rng.integers(0, 256, size=(n, 40), dtype=np.uint8)
+        vals = [(int.from_bytes(raw[i].tobytes(), "big") % (q - 1)) + 1 for i in range(n)]
+        return b"".join(v.to_bytes(32, "big") for v in vals)
+
+    # uniform in [1, q-1]: rejection-free by reducing 320 random bits (bias 2^-64)
+    t_setup = time.time()
+    raw = rng.integers(0, 256, size=(2, B, 40), dtype=np.uint8)
+    qm1 = q - 1
+
+    def reduce_rows(rows):
+        out = bytearray(B * 32)
+        for i in range(B):
+            v = (int.from_bytes(rows[i].tobytes(), "big") % qm1) + 1
+            out[32 * i:32 * i + 32] = v.to_bytes(32, "big")
+        return bytes(out)
+
+    scalars_h = reduce_rows(raw[0])
+    t_h = reduce_rows(raw[1])
+    stream = torch.cuda.current_stream()
+    d_scalars = torch.frombuffer(bytearray(scalars_h), dtype=torch.uint8).to(dev)
+    d_t = torch.frombuffer(bytearray(t_h), dtype=torch.uint8).to(dev)
+    d_points = torch.empty(B * 64, dtype=torch.uint8, device=dev)
+    d_out = torch.empty(B * 64, dtype=torch.uint8, device=dev)
+    d_status = torch.empty(B, dtype=torch.uint8, device=dev)
+    # base points P_i = [t_i]G, produced on the GPU by the same engine (fixed base), untimed
+    cv.scalar_mult_dev(B, d_t.data_ptr(), slen, None, d_points.data_ptr(), d_status.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    assert int(d_status.max().item()) == 0, "base-point generation produced an error status"
+    gathered = None
+    if world > 1:
+        gathered = torch.empty(world * B * 64, dtype=torch.uint8, device=dev)
+
+    def step():
+        cv.scalar_mult_dev(B, d_scalars.data_ptr(), slen, d_points.data_ptr(), d_out.data_ptr(),
+                           d_status.data_ptr(), stream.cuda_stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, d_out)
+
+    # ---- parity gate: random subset vs the CPU oracle, byte for byte ----
+    step()
+    torch.cuda.synchronize()
+    out_h = d_out.cpu().numpy().tobytes()
+    pts_h = d_points.cpu().numpy().tobytes()
+    st_h = d_status.cpu().numpy().tobytes()
+    assert set(st_h) == {0}, "unexpected status in the synthetic batch"
+    idx = np.random.default_rng(1).choice(B, size=min(B, 128), replace=False)
+    o = Oracle(CURVE)
+    sub_s = b"".join(scalars_h[32 * i:32 * i + 32] for i in idx)
+    sub_p = b"".join(pts_h[64 * i:64 * i + 64] for i in idx)
+    exp, est = o.scalar_mult(sub_s, sub_p)
+    got = b"".join(out_h[64 * i:64 * i + 64] for i in idx)
+    if got != exp or set(est) != {0}:
+        raise SystemExit("PARITY FAILURE: GPU output differs from the CPU oracle")
+    setup_s = time.time() - t_setup
+
+    # ---- warmup, then exactly K timed steps ----
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record(stream)
+    for k in range(args.steps):
+        step()
+        ev[k + 1].record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        total_items = B * world * args.steps
+        value = total_items / elapsed
+        mm, mads = work_model(cp, cv.words, slen)
+        launch_ms = float(np.mean(kern_ms))           # HIP-event time of one step on the launch stream
+        mad_rate = B * mads / (launch_ms * 1e-3)       # executed lane-MADs per second, one GPU
+        peak, ub = (None, None)
+        if world == 1:
+            peak, ub = measured_mad_peak()
+        nominal_quarter = 256 * 4 * 16 * 2.4e9 / 4.0   # SURVEY.md 8d planning figure (quarter rate)
+        alg_bytes = 160.0                              # 32 B scalar + 64 B point in + 64 B out
+        hbm_rate = B * alg_bytes / (launch_ms * 1e-3)
+        line = {
+            "metric": "scalar-mults/sec (secp256r1, batch=2^20, variable base, affine out, bit-exact vs CPU)",
+            "value": value, "unit": "scalar-mults/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (v_mad_u64_u32 integer MAD)",
+            "data": "synthetic (seeded): scalars uniform in [1,q-1], base points P_i=[t_i]G",
+            "config": {"workload": f"{CURVE} prj_pt_mul+prj_pt_unique, batch 2^{args.batch_log2} per GPU "
+                                   "(BASELINE.json configs[1])",
+                       "batch_per_gpu": B, "scalar_len": slen, "window": 4,
+                       "sharding": "contiguous per-rank shards" + (", RCCL all_gather of outputs per step" if world > 1 else ""),
+                       "parity_gate": "128 random items byte-identical to the CPU oracle"},
+            "roofline": {
+                "bound": "valu-int-mad (v_mad_u64_u32 issue; not hbm, not mfma -- SURVEY.md 8d)",
+                "achieved": mad_rate / 1e9, "peak": (peak or nominal_quarter) / 1e9, "unit": "GMAD/s",
+                "frac": mad_rate / (peak or nominal_quarter),
+                "peak_source": "measured live by libecc_amd/lib/ubench" if peak else "nominal quarter-rate estimate",
+                "kernel": f"k_smul<{cv.words}>", "kernel_ms": launch_ms,
+                "mont_mults_per_item": mm, "mads_per_item": mads,
+                "ref_equivalent_mads_per_item": ref_equiv_mads(),
+                "traffic": None,
+                "hbm": {"achieved": hbm_rate / 1e9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": hbm_rate / 8e12, "algorithmic_bytes_per_item": alg_bytes},
+            },
+            "setup_s": setup_s,
+        }
+        if ub:
+            line["ubench"] = {k: (v["cycles_per_wave_instr_per_simd"] if isinstance(v, dict) else v)
+                              for k, v in ub.items() if k.startswith("v_")}
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(CURVE, scalars_h, pts_h, slen)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    cv.free()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

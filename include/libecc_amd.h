@@ -1,0 +1,113 @@
+/*
+ * include/libecc_amd.h -- C ABI of the MI355X batched short-Weierstrass scalar-multiplication
+ * engine.  This is the drop-in boundary for libecc's hot path: plain C, plain pointers and
+ * sizes, libecc's wire formats (big-endian octet strings) and libecc's 0 / -1 return
+ * convention (utils/utils.h:80,137-143).  File:line references are relative to
+ * /root/reference/src.
+ *
+ * libecc performs ONE scalar multiplication per call (curves/prj_pt.h:61); a GPU only pays off
+ * on batches, so each entry point below is the batch form of the libecc call chain it
+ * replaces, with a per-item status byte mirroring the scalar API's 0 / -1:
+ *
+ *   ECAMD_OK  (0)  the libecc chain would have returned 0 and produced these bytes
+ *   ECAMD_ERR (1)  some call of the chain would have returned -1 (coordinate >= p, point not
+ *                  on the curve, r/s out of range, ...); the output bytes are zero
+ *   ECAMD_INF (2)  only for point results: the result is the point at infinity (prj_pt_mul
+ *                  returns 0 with Z = 0; prj_pt_unique / prj_pt_to_aff then return -1,
+ *                  curves/prj_pt.c:246-247); the output bytes are zero
+ *
+ * Every function returns 0 on success and -1 on failure of the call itself (bad argument, no
+ * device, HIP error); ecamd_last_error() then describes it.  There is NO CPU fallback: without
+ * a gfx950 device ecamd_ctx_create() fails.
+ */
+#ifndef LIBECC_AMD_H
+#define LIBECC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ECAMD_OK 0
+#define ECAMD_ERR 1
+#define ECAMD_INF 2
+
+typedef struct ecamd_ctx ecamd_ctx;     /* one GPU: device id, stream, scratch buffers */
+typedef struct ecamd_curve ecamd_curve; /* ec_params equivalent (curves/ec_params.h:51-87) */
+
+/* ---- context ---- */
+int ecamd_device_count(void);
+int ecamd_ctx_create(ecamd_ctx **ctx, int device);
+void ecamd_ctx_destroy(ecamd_ctx *ctx);
+const char *ecamd_last_error(void);
+/* Upper bound on the items processed per kernel launch (bounds the per-lane window-table
+ * scratch: 16 * 3 * 4*ceil(|p|/32) bytes per item).  Default 2^20. */
+int ecamd_ctx_set_max_chunk(ecamd_ctx *ctx, uint32_t max_items);
+
+/* ---- curves: ec_get_curve_params_by_name (curves/curves.h:21) + import_params
+ *      (curves/ec_params.h:89).  Same 44 names as libecc's ec_maps[] ("SECP256R1", ...). ---- */
+int ecamd_curve_by_name(ecamd_ctx *ctx, const char *name, ecamd_curve **curve);
+/* User-defined curve from big-endian domain parameters (the ec_str_params fields,
+ * curves/known/ec_params_external.h:42-102; Montgomery constants are derived here). */
+int ecamd_curve_from_params(ecamd_ctx *ctx, const uint8_t *p, uint32_t p_len, const uint8_t *a,
+			    uint32_t a_len, const uint8_t *b, uint32_t b_len,
+			    const uint8_t *curve_order, uint32_t curve_order_len, const uint8_t *gx,
+			    uint32_t gx_len, const uint8_t *gy, uint32_t gy_len,
+			    const uint8_t *gen_order, uint32_t gen_order_len, ecamd_curve **curve);
+void ecamd_curve_free(ecamd_curve *curve);
+int ecamd_curve_coord_len(const ecamd_curve *curve); /* BYTECEIL(p_bitlen): 32 / 48 / 66 ... */
+int ecamd_curve_order_len(const ecamd_curve *curve); /* BYTECEIL(bitlen(generator order)) */
+int ecamd_curve_words(const ecamd_curve *curve);     /* 32-bit words per field element */
+
+/*
+ * ---- the hot path: batched prj_pt_mul ----
+ * Replaces, per item i:
+ *   nn_init_from_buf(m, scalars + i*scalar_len, scalar_len)            nn/nn.c:479
+ *   prj_pt_import_from_aff_buf(P, points + i*2*clen, 2*clen, crv)      curves/prj_pt.c:511
+ *     (points == NULL: P = the generator, params->ec_gen)
+ *   prj_pt_mul(Q, m, P)                                                curves/prj_pt.c:1759
+ *   prj_pt_unique(Q, Q)                                                curves/prj_pt.c:241
+ *   prj_pt_export_to_aff_buf(Q, out + i*2*clen, 2*clen)                curves/prj_pt.c:600
+ * scalars: n x scalar_len big-endian, ANY value (m >= q is fine, as in libecc).
+ * points / out: n x 2*clen, affine X || Y, big-endian.   status: n bytes (ECAMD_*).
+ * Host-pointer form: synchronous (H2D, kernel, D2H).
+ */
+int ec_prj_pt_mul_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n,
+			const uint8_t *scalars, uint32_t scalar_len, const uint8_t *points_aff,
+			uint8_t *out_aff, uint8_t *status);
+/* Device-pointer form: all four buffers already live in HBM; the kernel is enqueued on
+ * hip_stream (a hipStream_t, NULL = the context's stream) and the call returns without
+ * synchronising. */
+int ec_prj_pt_mul_batch_dev(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n,
+			    const void *d_scalars, uint32_t scalar_len, const void *d_points_aff,
+			    void *d_out_aff, void *d_status, void *hip_stream);
+int ecamd_ctx_synchronize(ecamd_ctx *ctx);
+
+/* ---- group law: batched prj_pt_add (curves/prj_pt.c:1204) / prj_pt_dbl (:1132) on affine
+ *      encoded inputs, affine encoded output (host pointers) ---- */
+int ec_prj_pt_add_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *p1_aff,
+			const uint8_t *p2_aff, uint8_t *out_aff, uint8_t *status);
+int ec_prj_pt_dbl_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *p_aff,
+			uint8_t *out_aff, uint8_t *status);
+
+/* ---- field level: batched fp ops on libecc's limb layout: n x nlimbs little-endian 64-bit
+ *      words per operand, nlimbs = ceil(|p|/64) (nn/nn.h:42-45).  Inputs must be < p.
+ *   ECAMD_FP_MUL_MONTY  fp_mul_monty = nn_mul_redc1: a*b*2^(-64*nlimbs) mod p
+ *                       (fp/fp_montgomery.c:44, nn/nn_mul_redc1.c:246)
+ *   ECAMD_FP_ADD / SUB  fp_add / fp_sub (fp/fp_add.c:23,69)
+ *   ECAMD_FP_MUL        plain fp_mul (fp/fp_mul.c:23)
+ *   ECAMD_FP_INV        fp_inv (fp/fp_mul.c:51), b ignored; inv(0) = 0 ---- */
+#define ECAMD_FP_MUL_MONTY 0
+#define ECAMD_FP_ADD 1
+#define ECAMD_FP_SUB 2
+#define ECAMD_FP_MUL 3
+#define ECAMD_FP_INV 4
+int ec_fp_op_batch(ecamd_ctx *ctx, const ecamd_curve *curve, int op, uint32_t n, const uint64_t *a,
+		   const uint64_t *b, uint64_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIBECC_AMD_H */

@@ -1,0 +1,152 @@
+"""ctypes binding of include/libecc_amd.h (one Python method per C entry point)."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ECAMD_OK, ECAMD_ERR, ECAMD_INF = 0, 1, 2
+FP_MUL_MONTY, FP_ADD, FP_SUB, FP_MUL, FP_INV = 0, 1, 2, 3, 4
+
+# every symbol include/libecc_amd.h declares (tests check the .so exports exactly these)
+EXPORTED_SYMBOLS = [
+    "ecamd_device_count", "ecamd_ctx_create", "ecamd_ctx_destroy", "ecamd_last_error",
+    "ecamd_ctx_set_max_chunk", "ecamd_curve_by_name", "ecamd_curve_from_params", "ecamd_curve_free",
+    "ecamd_curve_coord_len", "ecamd_curve_order_len", "ecamd_curve_words", "ec_prj_pt_mul_batch",
+    "ec_prj_pt_mul_batch_dev", "ecamd_ctx_synchronize", "ec_prj_pt_add_batch", "ec_prj_pt_dbl_batch",
+    "ec_fp_op_batch",
+]
+
+
+class EcamdError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(HERE, "lib", "libecc_amd.so")
+
+
+_LIB = None
+
+
+def load_library():
+    """Load the HIP shared library; raises (never falls back) if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise EcamdError(f"{path} is missing: run `python libecc_amd/build.py` "
+                             "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(path)
+        vp, u8p, u32 = C.c_void_p, C.c_char_p, C.c_uint32
+        L.ecamd_last_error.restype = C.c_char_p
+        L.ecamd_ctx_create.argtypes = [C.POINTER(vp), C.c_int]
+        L.ecamd_ctx_destroy.argtypes = [vp]
+        L.ecamd_ctx_destroy.restype = None
+        L.ecamd_ctx_set_max_chunk.argtypes = [vp, u32]
+        L.ecamd_ctx_synchronize.argtypes = [vp]
+        L.ecamd_curve_by_name.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+        L.ecamd_curve_from_params.argtypes = [vp] + [u8p, u32] * 7 + [C.POINTER(vp)]
+        L.ecamd_curve_free.argtypes = [vp]
+        L.ecamd_curve_free.restype = None
+        for f in ("ecamd_curve_coord_len", "ecamd_curve_order_len", "ecamd_curve_words"):
+            getattr(L, f).argtypes = [vp]
+        L.ec_prj_pt_mul_batch.argtypes = [vp, vp, u32, u8p, u32, u8p, u8p, u8p]
+        L.ec_prj_pt_mul_batch_dev.argtypes = [vp, vp, u32, vp, u32, vp, vp, vp, vp]
+        L.ec_prj_pt_add_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
+        L.ec_prj_pt_dbl_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p]
+        L.ec_fp_op_batch.argtypes = [vp, vp, C.c_int, u32, vp, vp, vp]
+        _LIB = L
+    return _LIB
+
+
+def _chk(L, ret, what):
+    if ret != 0:
+        raise EcamdError(f"{what}: {L.ecamd_last_error().decode()}")
+
+
+class Context:
+    """ecamd_ctx: one GPU."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        _chk(self.L, self.L.ecamd_ctx_create(C.byref(self.h), device), "ecamd_ctx_create")
+
+    def close(self):
+        if self.h:
+            self.L.ecamd_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def set_max_chunk(self, n):
+        _chk(self.L, self.L.ecamd_ctx_set_max_chunk(self.h, n), "ecamd_ctx_set_max_chunk")
+
+    def synchronize(self):
+        _chk(self.L, self.L.ecamd_ctx_synchronize(self.h), "ecamd_ctx_synchronize")
+
+    def curve(self, name):
+        return Curve(self, name)
+
+
+class Curve:
+    """ecamd_curve: the ec_params equivalent, bound to a context."""
+
+    def __init__(self, ctx, name=None, params=None):
+        self.ctx, self.L = ctx, ctx.L
+        self.h = C.c_void_p()
+        if params is None:
+            _chk(self.L, self.L.ecamd_curve_by_name(ctx.h, name.encode(), C.byref(self.h)),
+                 "ecamd_curve_by_name")
+        else:
+            args = []
+            for k in ("p", "a", "b", "order", "gx", "gy", "q"):
+                v = params[k]
+                b = v.to_bytes(max(1, (v.bit_length() + 7) // 8), "big")
+                args += [b, len(b)]
+            _chk(self.L, self.L.ecamd_curve_from_params(ctx.h, *args, C.byref(self.h)),
+                 "ecamd_curve_from_params")
+        self.name = name
+        self.clen = self.L.ecamd_curve_coord_len(self.h)
+        self.qlen = self.L.ecamd_curve_order_len(self.h)
+        self.words = self.L.ecamd_curve_words(self.h)
+
+    def free(self):
+        if self.h:
+            self.L.ecamd_curve_free(self.h)
+            self.h = C.c_void_p()
+
+    # -- batched prj_pt_mul, host buffers (bytes in, bytes out) --
+    def scalar_mult(self, scalars, points=None, slen=None):
+        slen = slen or self.qlen
+        n = len(scalars) // slen
+        out = C.create_string_buffer(max(1, 2 * self.clen * n))
+        st = C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_prj_pt_mul_batch(self.ctx.h, self.h, n, scalars, slen, points, out, st),
+             "ec_prj_pt_mul_batch")
+        return out.raw[:2 * self.clen * n], st.raw[:n]
+
+    # -- batched prj_pt_mul, device pointers (e.g. torch tensors' data_ptr()), asynchronous --
+    def scalar_mult_dev(self, n, d_scalars, slen, d_points, d_out, d_status, stream=None):
+        _chk(self.L, self.L.ec_prj_pt_mul_batch_dev(self.ctx.h, self.h, n, d_scalars, slen, d_points,
+                                                     d_out, d_status, stream),
+             "ec_prj_pt_mul_batch_dev")
+
+    def pt_add(self, p1, p2=None):
+        n = len(p1) // (2 * self.clen)
+        out = C.create_string_buffer(max(1, 2 * self.clen * n))
+        st = C.create_string_buffer(max(1, n))
+        if p2 is None:
+            _chk(self.L, self.L.ec_prj_pt_dbl_batch(self.ctx.h, self.h, n, p1, out, st), "ec_prj_pt_dbl_batch")
+        else:
+            _chk(self.L, self.L.ec_prj_pt_add_batch(self.ctx.h, self.h, n, p1, p2, out, st),
+                 "ec_prj_pt_add_batch")
+        return out.raw[:2 * self.clen * n], st.raw[:n]
+
+    def fp_op(self, op, a, b):
+        """a, b: lists of Python ints < p; returns a list of ints (libecc 64-bit limb layout inside)."""
+        n = len(a)
+        nl = (self.clen * 8 + 63) // 64
+        mask = 2**64 - 1
+        A = (C.c_uint64 * (n * nl))(*[(x >> (64 * k)) & mask for x in a for k in range(nl)])
+        B = (C.c_uint64 * (n * nl))(*[(x >> (64 * k)) & mask for x in b for k in range(nl)])
+        O = (C.c_uint64 * (n * nl))()
+        _chk(self.L, self.L.ec_fp_op_batch(self.ctx.h, self.h, op, n, A, B, O), "ec_fp_op_batch")
+        return [sum(O[i * nl + k] << (64 * k) for k in range(nl)) for i in range(n)]

@@ -1,0 +1,685 @@
+// libecc_amd/csrc/ecamd_host.cpp -- host side of the C ABI declared in include/libecc_amd.h.
+//
+// What lives here (and mirrors in the reference, paths relative to /root/reference/src):
+//   * the built-in curve table and import_params (curves/ec_params.c:24-194): domain parameters
+//     -> Montgomery constants R, R^2, -p^-1, a*R, b*R, 3b*R, p-2 (derivations as in
+//     scripts/expand_libecc.py:62-71, but for our radix 2^(32*NW)), uploaded to __constant__;
+//   * batch plumbing: staging buffers, per-lane window-table scratch, chunking, streams.
+// No arithmetic of the hot path runs on the host and there is no CPU fallback: every entry
+// point needs a live HIP device.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <strings.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string>
+#include <vector>
+#include <mutex>
+
+#include "../../include/libecc_amd.h"
+#include "ecamd_internal.h"
+
+// ------------------------------------------------------------------------------------------
+// error reporting
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(const std::string &m)
+{
+	g_err = m;
+	return -1;
+}
+#define HIPCHK(expr) \
+	do { \
+		hipError_t e_ = (expr); \
+		if (e_ != hipSuccess) { \
+			return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+		} \
+	} while (0)
+
+extern "C" const char *ecamd_last_error(void) { return g_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------
+// small host big integers (little-endian 32-bit words); only used to derive constants
+// ------------------------------------------------------------------------------------------
+typedef std::vector<uint32_t> Big;
+
+static void big_trim(Big &a)
+{
+	while (a.size() > 1 && a.back() == 0) {
+		a.pop_back();
+	}
+	if (a.empty()) {
+		a.push_back(0);
+	}
+}
+static Big big_from_be(const uint8_t *b, size_t len)
+{
+	Big r((len + 3) / 4 + 1, 0);
+	for (size_t i = 0; i < len; i++) {
+		size_t pos = len - 1 - i;
+		r[pos / 4] |= (uint32_t)b[i] << (8 * (pos % 4));
+	}
+	big_trim(r);
+	return r;
+}
+static Big big_from_hex(const char *h)
+{
+	size_t n = strlen(h);
+	Big r(n / 8 + 2, 0);
+	for (size_t i = 0; i < n; i++) {
+		char c = h[n - 1 - i];
+		uint32_t v = (c >= '0' && c <= '9') ? (uint32_t)(c - '0')
+			     : (c >= 'a' && c <= 'f') ? (uint32_t)(c - 'a' + 10) : (uint32_t)(c - 'A' + 10);
+		r[i / 8] |= v << (4 * (i % 8));
+	}
+	big_trim(r);
+	return r;
+}
+static int big_cmp(const Big &a, const Big &b)
+{
+	size_t n = a.size() > b.size() ? a.size() : b.size();
+	for (size_t i = n; i-- > 0;) {
+		uint32_t x = i < a.size() ? a[i] : 0, y = i < b.size() ? b[i] : 0;
+		if (x != y) {
+			return x < y ? -1 : 1;
+		}
+	}
+	return 0;
+}
+static int big_bitlen(const Big &a)
+{
+	for (size_t i = a.size(); i-- > 0;) {
+		if (a[i]) {
+			int b = 31;
+			while (!((a[i] >> b) & 1)) {
+				b--;
+			}
+			return (int)i * 32 + b + 1;
+		}
+	}
+	return 0;
+}
+static Big big_add(const Big &a, const Big &b)
+{
+	size_t n = (a.size() > b.size() ? a.size() : b.size()) + 1;
+	Big r(n, 0);
+	uint64_t c = 0;
+	for (size_t i = 0; i < n; i++) {
+		c += (uint64_t)(i < a.size() ? a[i] : 0) + (i < b.size() ? b[i] : 0);
+		r[i] = (uint32_t)c;
+		c >>= 32;
+	}
+	big_trim(r);
+	return r;
+}
+static Big big_sub(const Big &a, const Big &b)  // a >= b
+{
+	Big r(a.size(), 0);
+	int64_t c = 0;
+	for (size_t i = 0; i < a.size(); i++) {
+		int64_t x = (int64_t)a[i] - (i < b.size() ? b[i] : 0) + c;
+		r[i] = (uint32_t)x;
+		c = x >> 32;
+	}
+	big_trim(r);
+	return r;
+}
+static Big big_mul(const Big &a, const Big &b)
+{
+	Big r(a.size() + b.size() + 1, 0);
+	for (size_t i = 0; i < a.size(); i++) {
+		uint64_t c = 0;
+		for (size_t j = 0; j < b.size(); j++) {
+			c += (uint64_t)a[i] * b[j] + r[i + j];
+			r[i + j] = (uint32_t)c;
+			c >>= 32;
+		}
+		r[i + b.size()] += (uint32_t)c;
+	}
+	big_trim(r);
+	return r;
+}
+static Big big_mod(const Big &a, const Big &m)  // bitwise shift-subtract; sizes are tiny
+{
+	Big r(1, 0);
+	for (int bit = big_bitlen(a) - 1; bit >= 0; bit--) {
+		// r = 2r + bit
+		Big t(r.size() + 1, 0);
+		for (size_t i = 0; i < r.size(); i++) {
+			t[i] |= r[i] << 1;
+			t[i + 1] |= r[i] >> 31;
+		}
+		t[0] |= (a[(size_t)bit / 32] >> (bit % 32)) & 1u;
+		big_trim(t);
+		r = (big_cmp(t, m) >= 0) ? big_sub(t, m) : t;
+	}
+	return r;
+}
+static Big big_pow2(int e)
+{
+	Big r((size_t)e / 32 + 1, 0);
+	r[(size_t)e / 32] = 1u << (e % 32);
+	return r;
+}
+static Big big_mulmod(const Big &a, const Big &b, const Big &m) { return big_mod(big_mul(a, b), m); }
+static Big big_powmod(const Big &a, const Big &e, const Big &m)
+{
+	Big r(1, 1), base = big_mod(a, m);
+	for (int i = big_bitlen(e) - 1; i >= 0; i--) {
+		r = big_mulmod(r, r, m);
+		if ((e[(size_t)i / 32] >> (i % 32)) & 1u) {
+			r = big_mulmod(r, base, m);
+		}
+	}
+	return r;
+}
+static void big_store(uint32_t *dst, int nw, const Big &a)
+{
+	for (int i = 0; i < nw; i++) {
+		dst[i] = (size_t)i < a.size() ? a[(size_t)i] : 0;
+	}
+}
+static void big_to_be(uint8_t *dst, int len, const Big &a)
+{
+	for (int i = 0; i < len; i++) {
+		int pos = len - 1 - i;
+		dst[i] = ((size_t)pos / 4 < a.size()) ? (uint8_t)(a[(size_t)pos / 4] >> (8 * (pos % 4))) : 0;
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// curve table (domain parameters only; generated by tools/gen_curve_table.py)
+// ------------------------------------------------------------------------------------------
+struct CurveRow {
+	const char *name;
+	int type;
+	const char *p, *a, *b, *order, *gx, *gy, *q, *h;
+};
+static const CurveRow g_curve_rows[] = {
+#include "ecamd_curve_table.inc"
+};
+
+// ------------------------------------------------------------------------------------------
+// objects behind the opaque handles
+// ------------------------------------------------------------------------------------------
+struct ecamd_ctx {
+	int device;
+	hipStream_t stream;
+	uint32_t max_chunk;
+	// grow-only scratch
+	uint32_t *tbl;
+	size_t tbl_bytes;
+	uint8_t *stage[4];
+	size_t stage_bytes[4];
+	bool slot_used[ECAMD_MAX_SLOTS_HOST];
+	std::mutex mu;
+};
+
+struct ecamd_curve {
+	ecamd_ctx *ctx;
+	int nw;     // 32-bit words per element
+	int slot;   // __constant__ slot
+	int clen;   // BYTECEIL(pbits)
+	int qlen;   // BYTECEIL(qbits)
+	int pbits, qbits;
+	Big p, a, b, order, gx, gy, q;
+	uint8_t *d_gen;  // generator, affine X||Y big-endian, in HBM
+};
+
+static const int k_widths[] = {6, 7, 8, 10, 12, 14, 16, 17};
+
+static int pick_nw(int pbits)
+{
+	for (int w : k_widths) {
+		if (32 * w >= pbits) {
+			return w;
+		}
+	}
+	return 0;
+}
+
+extern "C" int ecamd_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) {
+		return 0;
+	}
+	return n;
+}
+
+extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
+{
+	if (!out) {
+		return fail("ecamd_ctx_create: NULL out pointer");
+	}
+	*out = nullptr;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) {
+		return fail("ecamd_ctx_create: no HIP device available (this library has no CPU fallback)");
+	}
+	if (device < 0 || device >= n) {
+		return fail("ecamd_ctx_create: device index out of range");
+	}
+	HIPCHK(hipSetDevice(device));
+	ecamd_ctx *c = new ecamd_ctx();
+	c->device = device;
+	c->max_chunk = 1u << 20;
+	c->tbl = nullptr;
+	c->tbl_bytes = 0;
+	for (int i = 0; i < 4; i++) {
+		c->stage[i] = nullptr;
+		c->stage_bytes[i] = 0;
+	}
+	for (int i = 0; i < ECAMD_MAX_SLOTS_HOST; i++) {
+		c->slot_used[i] = false;
+	}
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+		delete c;
+		return fail("ecamd_ctx_create: hipStreamCreate failed");
+	}
+	*out = c;
+	return 0;
+}
+
+extern "C" void ecamd_ctx_destroy(ecamd_ctx *c)
+{
+	if (!c) {
+		return;
+	}
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	if (c->tbl) {
+		(void)hipFree(c->tbl);
+	}
+	for (int i = 0; i < 4; i++) {
+		if (c->stage[i]) {
+			(void)hipFree(c->stage[i]);
+		}
+	}
+	(void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+extern "C" int ecamd_ctx_set_max_chunk(ecamd_ctx *c, uint32_t max_items)
+{
+	if (!c || max_items == 0) {
+		return fail("ecamd_ctx_set_max_chunk: bad argument");
+	}
+	c->max_chunk = max_items;
+	return 0;
+}
+
+extern "C" int ecamd_ctx_synchronize(ecamd_ctx *c)
+{
+	if (!c) {
+		return fail("ecamd_ctx_synchronize: NULL context");
+	}
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return 0;
+}
+
+static int ensure(uint8_t **buf, size_t *have, size_t need)
+{
+	if (*have >= need) {
+		return 0;
+	}
+	if (*buf) {
+		HIPCHK(hipFree(*buf));
+		*buf = nullptr;
+		*have = 0;
+	}
+	HIPCHK(hipMalloc((void **)buf, need));
+	*have = need;
+	return 0;
+}
+
+// CurveK<NW> as a flat word image: p r2 one pm2 a b b3 fix64 (NW words each), then
+// mpinv pbits a_is_m3 fix_is_id -- must match ecamd_field.cuh.
+static int build_and_upload(ecamd_curve *cv)
+{
+	const int nw = cv->nw;
+	const Big &p = cv->p;
+	const Big R = big_mod(big_pow2(32 * nw), p);
+	const Big R2 = big_mulmod(R, R, p);
+	Big two(1, 2), three(1, 3);
+	const Big pm2 = big_sub(p, two);
+	const Big aR = big_mulmod(cv->a, R, p);
+	const Big bR = big_mulmod(cv->b, R, p);
+	const Big b3R = big_mulmod(big_mulmod(cv->b, three, p), R, p);
+	// fix64 = R^2 * 2^(-64*ceil(nw/2)) mod p
+	const int n64 = (nw + 1) / 2;
+	const Big R64 = big_mod(big_pow2(64 * n64), p);
+	const Big R64inv = big_powmod(R64, pm2, p);
+	const Big fix = big_mulmod(R2, R64inv, p);
+	// -p^-1 mod 2^32 by Newton iteration
+	uint32_t p0 = p[0], x = 1;
+	for (int i = 0; i < 5; i++) {
+		x *= 2u - p0 * x;
+	}
+	const uint32_t mpinv = 0u - x;
+	std::vector<uint32_t> img((size_t)8 * nw + 4, 0);
+	big_store(&img[0 * nw], nw, p);
+	big_store(&img[1 * nw], nw, R2);
+	big_store(&img[2 * nw], nw, R);
+	big_store(&img[3 * nw], nw, pm2);
+	big_store(&img[4 * nw], nw, aR);
+	big_store(&img[5 * nw], nw, bR);
+	big_store(&img[6 * nw], nw, b3R);
+	big_store(&img[7 * nw], nw, fix);
+	img[8 * nw + 0] = mpinv;
+	img[8 * nw + 1] = (uint32_t)cv->pbits;
+	img[8 * nw + 2] = (big_cmp(big_add(cv->a, three), p) == 0) ? 1u : 0u;
+	img[8 * nw + 3] = (big_cmp(fix, R) == 0) ? 1u : 0u;
+	if (img.size() * 4 != ecamd_curvek_bytes(nw)) {
+		return fail("internal: CurveK image size mismatch");
+	}
+	HIPCHK(ecamd_upload_curve(nw, cv->slot, img.data(), img.size() * 4));
+	return 0;
+}
+
+static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
+{
+	if (!(cv->p[0] & 1) || big_bitlen(cv->p) < 160) {
+		delete cv;
+		return fail("curve: p must be odd and at least 160 bits");
+	}
+	cv->pbits = big_bitlen(cv->p);
+	cv->qbits = big_bitlen(cv->q);
+	cv->nw = pick_nw(cv->pbits);
+	if (!cv->nw || !ecamd_nw_supported(cv->nw)) {
+		delete cv;
+		return fail("curve: field size not supported (max 544 bits)");
+	}
+	if (big_cmp(cv->a, cv->p) >= 0 || big_cmp(cv->b, cv->p) >= 0 || big_cmp(cv->gx, cv->p) >= 0 ||
+	    big_cmp(cv->gy, cv->p) >= 0) {
+		delete cv;
+		return fail("curve: a, b, gx, gy must be < p");
+	}
+	cv->clen = (cv->pbits + 7) / 8;
+	cv->qlen = (cv->qbits + 7) / 8;
+	cv->ctx = ctx;
+	cv->d_gen = nullptr;
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	int slot = -1;
+	for (int i = 0; i < ECAMD_MAX_SLOTS_HOST; i++) {
+		if (!ctx->slot_used[i]) {
+			slot = i;
+			break;
+		}
+	}
+	if (slot < 0) {
+		delete cv;
+		return fail("curve: all constant-memory curve slots are in use (free a curve first)");
+	}
+	cv->slot = slot;
+	if (build_and_upload(cv)) {
+		delete cv;
+		return -1;
+	}
+	std::vector<uint8_t> g((size_t)2 * cv->clen);
+	big_to_be(g.data(), cv->clen, cv->gx);
+	big_to_be(g.data() + cv->clen, cv->clen, cv->gy);
+	if (hipMalloc((void **)&cv->d_gen, g.size()) != hipSuccess ||
+	    hipMemcpy(cv->d_gen, g.data(), g.size(), hipMemcpyHostToDevice) != hipSuccess) {
+		delete cv;
+		return fail("curve: generator upload failed");
+	}
+	ctx->slot_used[slot] = true;
+	*out = cv;
+	return 0;
+}
+
+extern "C" int ecamd_curve_by_name(ecamd_ctx *ctx, const char *name, ecamd_curve **out)
+{
+	if (!ctx || !name || !out) {
+		return fail("ecamd_curve_by_name: NULL argument");
+	}
+	*out = nullptr;
+	for (const CurveRow &r : g_curve_rows) {
+		if (strcasecmp(r.name, name) == 0) {
+			ecamd_curve *cv = new ecamd_curve();
+			cv->p = big_from_hex(r.p);
+			cv->a = big_from_hex(r.a);
+			cv->b = big_from_hex(r.b);
+			cv->order = big_from_hex(r.order);
+			cv->gx = big_from_hex(r.gx);
+			cv->gy = big_from_hex(r.gy);
+			cv->q = big_from_hex(r.q);
+			return curve_finish(ctx, cv, out);
+		}
+	}
+	return fail(std::string("ecamd_curve_by_name: unknown curve ") + name);
+}
+
+extern "C" int ecamd_curve_from_params(ecamd_ctx *ctx, const uint8_t *p, uint32_t p_len, const uint8_t *a,
+				       uint32_t a_len, const uint8_t *b, uint32_t b_len,
+				       const uint8_t *curve_order, uint32_t curve_order_len,
+				       const uint8_t *gx, uint32_t gx_len, const uint8_t *gy, uint32_t gy_len,
+				       const uint8_t *gen_order, uint32_t gen_order_len, ecamd_curve **out)
+{
+	if (!ctx || !p || !a || !b || !curve_order || !gx || !gy || !gen_order || !out) {
+		return fail("ecamd_curve_from_params: NULL argument");
+	}
+	*out = nullptr;
+	ecamd_curve *cv = new ecamd_curve();
+	cv->p = big_from_be(p, p_len);
+	cv->a = big_from_be(a, a_len);
+	cv->b = big_from_be(b, b_len);
+	cv->order = big_from_be(curve_order, curve_order_len);
+	cv->gx = big_from_be(gx, gx_len);
+	cv->gy = big_from_be(gy, gy_len);
+	cv->q = big_from_be(gen_order, gen_order_len);
+	return curve_finish(ctx, cv, out);
+}
+
+extern "C" void ecamd_curve_free(ecamd_curve *cv)
+{
+	if (!cv) {
+		return;
+	}
+	{
+		std::lock_guard<std::mutex> lk(cv->ctx->mu);
+		(void)hipSetDevice(cv->ctx->device);
+		if (cv->d_gen) {
+			(void)hipFree(cv->d_gen);
+		}
+		cv->ctx->slot_used[cv->slot] = false;
+	}
+	delete cv;
+}
+
+extern "C" int ecamd_curve_coord_len(const ecamd_curve *cv) { return cv ? cv->clen : -1; }
+extern "C" int ecamd_curve_order_len(const ecamd_curve *cv) { return cv ? cv->qlen : -1; }
+extern "C" int ecamd_curve_words(const ecamd_curve *cv) { return cv ? cv->nw : -1; }
+
+// ------------------------------------------------------------------------------------------
+// batched prj_pt_mul
+// ------------------------------------------------------------------------------------------
+static size_t tbl_bytes_for(const ecamd_curve *cv, uint32_t stride)
+{
+	return (size_t)ECAMD_TBL_ENTRIES * 3 * (size_t)cv->nw * 4 * (size_t)stride;
+}
+
+static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_scalars,
+			   uint32_t slen, const uint8_t *d_points, uint8_t *d_out, uint8_t *d_status,
+			   hipStream_t s)
+{
+	const uint32_t chunk = n < ctx->max_chunk ? n : ctx->max_chunk;
+	const uint32_t stride = (chunk + 63u) & ~63u;
+	{
+		uint8_t *t = (uint8_t *)ctx->tbl;
+		if (ensure(&t, &ctx->tbl_bytes, tbl_bytes_for(cv, stride))) {
+			ctx->tbl = (uint32_t *)t;
+			return -1;
+		}
+		ctx->tbl = (uint32_t *)t;
+	}
+	for (uint32_t off = 0; off < n; off += chunk) {
+		const uint32_t m = (n - off) < chunk ? (n - off) : chunk;
+		EcamdSmulArgs A;
+		A.scalars = d_scalars + (size_t)off * slen;
+		A.pstride = d_points ? 2u * (uint32_t)cv->clen : 0u;
+		A.points = d_points ? d_points + (size_t)off * 2 * cv->clen : cv->d_gen;
+		A.out = d_out + (size_t)off * 2 * cv->clen;
+		A.status = d_status + off;
+		A.tbl = ctx->tbl;
+		A.n = m;
+		A.slen = slen;
+		A.clen = (uint32_t)cv->clen;
+		A.stride = stride;
+		A.slot = cv->slot;
+		HIPCHK(ecamd_launch_smul(cv->nw, A, s));
+	}
+	return 0;
+}
+
+extern "C" int ec_prj_pt_mul_batch_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n,
+				       const void *d_scalars, uint32_t slen, const void *d_points,
+				       void *d_out, void *d_status, void *hip_stream)
+{
+	if (!ctx || !cv || cv->ctx != ctx || (n && (!d_scalars || !d_out || !d_status))) {
+		return fail("ec_prj_pt_mul_batch_dev: bad argument");
+	}
+	if (slen == 0 || slen > 1024) {
+		return fail("ec_prj_pt_mul_batch_dev: scalar_len must be in 1..1024");
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+	return smul_dev_locked(ctx, cv, n, (const uint8_t *)d_scalars, slen, (const uint8_t *)d_points,
+			       (uint8_t *)d_out, (uint8_t *)d_status, s);
+}
+
+extern "C" int ec_prj_pt_mul_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *scalars,
+				   uint32_t slen, const uint8_t *points, uint8_t *out, uint8_t *status)
+{
+	if (!ctx || !cv || cv->ctx != ctx || (n && (!scalars || !out || !status))) {
+		return fail("ec_prj_pt_mul_batch: bad argument");
+	}
+	if (slen == 0 || slen > 1024) {
+		return fail("ec_prj_pt_mul_batch: scalar_len must be in 1..1024");
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t plen = (size_t)2 * cv->clen;
+	if (ensure(&ctx->stage[0], &ctx->stage_bytes[0], (size_t)n * slen) ||
+	    ensure(&ctx->stage[1], &ctx->stage_bytes[1], (size_t)n * plen) ||
+	    ensure(&ctx->stage[2], &ctx->stage_bytes[2], (size_t)n * plen) ||
+	    ensure(&ctx->stage[3], &ctx->stage_bytes[3], (size_t)n)) {
+		return -1;
+	}
+	hipStream_t s = ctx->stream;
+	HIPCHK(hipMemcpyAsync(ctx->stage[0], scalars, (size_t)n * slen, hipMemcpyHostToDevice, s));
+	if (points) {
+		HIPCHK(hipMemcpyAsync(ctx->stage[1], points, (size_t)n * plen, hipMemcpyHostToDevice, s));
+	}
+	if (smul_dev_locked(ctx, cv, n, ctx->stage[0], slen, points ? ctx->stage[1] : nullptr, ctx->stage[2],
+			    ctx->stage[3], s)) {
+		return -1;
+	}
+	HIPCHK(hipMemcpyAsync(out, ctx->stage[2], (size_t)n * plen, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipMemcpyAsync(status, ctx->stage[3], (size_t)n, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// batched prj_pt_add / prj_pt_dbl
+// ------------------------------------------------------------------------------------------
+static int pt_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *p1, const uint8_t *p2,
+		    uint8_t *out, uint8_t *status, int dbl)
+{
+	if (!ctx || !cv || cv->ctx != ctx || (n && (!p1 || (!dbl && !p2) || !out || !status))) {
+		return fail("ec_prj_pt_add/dbl_batch: bad argument");
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t plen = (size_t)2 * cv->clen;
+	if (ensure(&ctx->stage[0], &ctx->stage_bytes[0], (size_t)n * plen) ||
+	    ensure(&ctx->stage[1], &ctx->stage_bytes[1], (size_t)n * plen) ||
+	    ensure(&ctx->stage[2], &ctx->stage_bytes[2], (size_t)n * plen) ||
+	    ensure(&ctx->stage[3], &ctx->stage_bytes[3], (size_t)n)) {
+		return -1;
+	}
+	hipStream_t s = ctx->stream;
+	HIPCHK(hipMemcpyAsync(ctx->stage[0], p1, (size_t)n * plen, hipMemcpyHostToDevice, s));
+	if (!dbl) {
+		HIPCHK(hipMemcpyAsync(ctx->stage[1], p2, (size_t)n * plen, hipMemcpyHostToDevice, s));
+	}
+	EcamdPtArgs A;
+	A.p1 = ctx->stage[0];
+	A.p2 = ctx->stage[1];
+	A.out = ctx->stage[2];
+	A.status = ctx->stage[3];
+	A.n = n;
+	A.clen = (uint32_t)cv->clen;
+	A.dbl = dbl;
+	A.slot = cv->slot;
+	HIPCHK(ecamd_launch_pt(cv->nw, A, s));
+	HIPCHK(hipMemcpyAsync(out, ctx->stage[2], (size_t)n * plen, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipMemcpyAsync(status, ctx->stage[3], (size_t)n, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	return 0;
+}
+
+extern "C" int ec_prj_pt_add_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *p1,
+				   const uint8_t *p2, uint8_t *out, uint8_t *status)
+{
+	return pt_batch(ctx, cv, n, p1, p2, out, status, 0);
+}
+
+extern "C" int ec_prj_pt_dbl_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *p,
+				   uint8_t *out, uint8_t *status)
+{
+	return pt_batch(ctx, cv, n, p, nullptr, out, status, 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// batched field ops on libecc's 64-bit limb layout
+// ------------------------------------------------------------------------------------------
+extern "C" int ec_fp_op_batch(ecamd_ctx *ctx, const ecamd_curve *cv, int op, uint32_t n, const uint64_t *a,
+			      const uint64_t *b, uint64_t *out)
+{
+	if (!ctx || !cv || cv->ctx != ctx || op < 0 || op > 4 || (n && (!a || !b || !out))) {
+		return fail("ec_fp_op_batch: bad argument");
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	const uint32_t nl = (uint32_t)(cv->pbits + 63) / 64;
+	const size_t bytes = (size_t)n * nl * 8;
+	if (ensure(&ctx->stage[0], &ctx->stage_bytes[0], bytes) || ensure(&ctx->stage[1], &ctx->stage_bytes[1], bytes) ||
+	    ensure(&ctx->stage[2], &ctx->stage_bytes[2], bytes)) {
+		return -1;
+	}
+	hipStream_t s = ctx->stream;
+	HIPCHK(hipMemcpyAsync(ctx->stage[0], a, bytes, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(ctx->stage[1], b, bytes, hipMemcpyHostToDevice, s));
+	EcamdFpArgs A;
+	A.a = (const uint32_t *)ctx->stage[0];
+	A.b = (const uint32_t *)ctx->stage[1];
+	A.out = (uint32_t *)ctx->stage[2];
+	A.n = n;
+	A.wstride = 2 * nl;
+	A.op = op;
+	A.slot = cv->slot;
+	HIPCHK(ecamd_launch_fp(cv->nw, A, s));
+	HIPCHK(hipMemcpyAsync(out, ctx->stage[2], bytes, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	return 0;
+}

@@ -1,0 +1,42 @@
+// libecc_amd/csrc/ecamd_internal.h -- launch interface between the host side (ecamd_host.cpp)
+// and the kernels (ecamd_kernels.hip).  Not part of the public C ABI (include/libecc_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ECAMD_WINDOW 4
+#define ECAMD_TBL_ENTRIES (1 << ECAMD_WINDOW)
+#define ECAMD_MAX_SLOTS_HOST 8  /* == ECAMD_MAX_SLOTS in ecamd_field.cuh */
+
+struct EcamdSmulArgs {
+	const uint8_t *scalars;  // n x slen, big-endian
+	const uint8_t *points;   // n x 2*clen affine X||Y big-endian (pstride = 0: one shared point)
+	uint8_t *out;            // n x 2*clen affine X||Y big-endian
+	uint8_t *status;         // n : 0 ok, 1 error, 2 infinity
+	uint32_t *tbl;           // scratch: ECAMD_TBL_ENTRIES x 3 x NW words x stride
+	uint32_t n, slen, clen, pstride, stride;
+	int slot;
+};
+
+struct EcamdFpArgs {
+	const uint32_t *a, *b;   // n x NW little-endian 32-bit words
+	uint32_t *out;
+	uint32_t n, wstride;     // wstride: 32-bit words per element in memory (>= NW)
+	int op;                  // 0 mul_monty (reference radix 2^(64 nlimbs)), 1 add, 2 sub, 3 mul plain, 4 inv plain
+	int slot;
+};
+
+struct EcamdPtArgs {
+	const uint8_t *p1, *p2;  // affine inputs, n x 2*clen
+	uint8_t *out, *status;
+	uint32_t n, clen;
+	int dbl, slot;
+};
+
+// nw: 32-bit words per field element; must be one of ecamd_supported_nw()
+int ecamd_nw_supported(int nw);
+hipError_t ecamd_upload_curve(int nw, int slot, const void *curvek, size_t bytes);
+hipError_t ecamd_launch_smul(int nw, const EcamdSmulArgs &a, hipStream_t s);
+hipError_t ecamd_launch_fp(int nw, const EcamdFpArgs &a, hipStream_t s);
+hipError_t ecamd_launch_pt(int nw, const EcamdPtArgs &a, hipStream_t s);
+size_t ecamd_curvek_bytes(int nw);

@@ -1,0 +1,303 @@
+// libecc_amd/csrc/ecamd_kernels.hip -- gfx950 kernels for the batched scalar-multiplication path.
+//
+//   k_smul<NW>   one scalar multiplication per lane: replaces prj_pt_import_from_aff_buf ->
+//                prj_pt_mul -> prj_pt_unique -> prj_pt_export_to_aff_buf
+//                (curves/prj_pt.c:511,1759,241,600 in /root/reference/src)
+//   k_fp<NW>     batched field ops (row a6/a7/a13/a14 of SURVEY.md section 8a)
+//   k_pt<NW>     batched prj_pt_add / prj_pt_dbl (rows a17/a18)
+//
+// Algorithm of k_smul (differs from the reference's Montgomery ladder, observable output is
+// identical -- SURVEY.md section 8a "what a GPU implementation may change"):
+//   fixed 4-bit window, left to right over ALL 8*slen bits of the scalar (no reduction mod the
+//   order is needed: the complete formulas have no exceptional cases, so any m is handled the
+//   way the reference's m + q / m + q^2 padding handles it -- [m]P is [m mod #E]P either way);
+//   per-lane table [0..15]P in a global scratch buffer laid out word-major / lane-minor so
+//   that table writes are fully coalesced and a lookup touches at most 16 x 256 B rows;
+//   complete RCB addition/doubling; one Fermat inversion to affine.
+// Per item: 4 on-curve mults, 14 table additions, 8*slen doublings, 2*slen additions,
+// ~1.5*|p| mults for the inversion.
+#include "ecamd_point.cuh"
+#include "ecamd_internal.h"
+
+#define ECAMD_DEF_CONST(NW) __constant__ CurveSlots<NW> g_curves_##NW;
+ECAMD_DEF_CONST(6)
+ECAMD_DEF_CONST(7)
+ECAMD_DEF_CONST(8)
+ECAMD_DEF_CONST(10)
+ECAMD_DEF_CONST(12)
+ECAMD_DEF_CONST(14)
+ECAMD_DEF_CONST(16)
+ECAMD_DEF_CONST(17)
+
+template <int NW> static __device__ __forceinline__ void tbl_store(u32 *tbl, u32 stride, u32 lane, int e, const Pt<NW> &P)
+{
+	u32 *base = tbl + (size_t)e * 3 * NW * stride + lane;
+#pragma unroll
+	for (int w = 0; w < NW; w++) {
+		base[(size_t)(0 * NW + w) * stride] = P.X.v[w];
+		base[(size_t)(1 * NW + w) * stride] = P.Y.v[w];
+		base[(size_t)(2 * NW + w) * stride] = P.Z.v[w];
+	}
+}
+
+template <int NW> static __device__ __forceinline__ Pt<NW> tbl_load(const u32 *tbl, u32 stride, u32 lane, u32 e)
+{
+	const u32 *base = tbl + (size_t)e * 3 * NW * stride + lane;
+	Pt<NW> P;
+#pragma unroll
+	for (int w = 0; w < NW; w++) {
+		P.X.v[w] = base[(size_t)(0 * NW + w) * stride];
+		P.Y.v[w] = base[(size_t)(1 * NW + w) * stride];
+		P.Z.v[w] = base[(size_t)(2 * NW + w) * stride];
+	}
+	return P;
+}
+
+template <int NW> __global__ __launch_bounds__(64) void k_smul(EcamdSmulArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int slot = A.slot;
+	const int clen = (int)A.clen;
+	u8 *out = A.out + (size_t)i * 2 * clen;
+
+	// ---- import: X||Y big-endian, coordinates < p, on curve (prj_pt.c:511-552) ----
+	const u8 *pin = A.points + (size_t)i * A.pstride;
+	Fe<NW> x = fe_load_be<NW>(pin, clen);
+	Fe<NW> y = fe_load_be<NW>(pin + clen, clen);
+	bool ok = fe_lt_p<NW>(x, slot) & fe_lt_p<NW>(y, slot);
+	x = fe_to_mont<NW>(x, slot);
+	y = fe_to_mont<NW>(y, slot);
+	ok = ok & aff_on_curve<NW>(x, y, slot);
+	if (!ok) {
+		A.status[i] = 1;
+		for (int b = 0; b < 2 * clen; b++) {
+			out[b] = 0;
+		}
+		return;
+	}
+
+	// ---- table [0..15]P ----
+	Pt<NW> P;
+	P.X = x;
+	P.Y = y;
+	P.Z = fe_const<NW>(ConstTab<NW>::get(slot).one);
+	Pt<NW> acc = pt_infinity<NW>(slot);
+	tbl_store<NW>(A.tbl, A.stride, i, 0, acc);
+	acc = P;
+	tbl_store<NW>(A.tbl, A.stride, i, 1, acc);
+#pragma unroll 1
+	for (int e = 2; e < ECAMD_TBL_ENTRIES; e++) {
+		acc = pt_add<NW>(acc, P, slot);
+		tbl_store<NW>(A.tbl, A.stride, i, e, acc);
+	}
+
+	// ---- fixed-window left-to-right ----
+	const u8 *sc = A.scalars + (size_t)i * A.slen;
+	const int nwin = 2 * (int)A.slen;
+	acc = tbl_load<NW>(A.tbl, A.stride, i, (u32)(sc[0] >> 4));
+#pragma unroll 1
+	for (int t = 1; t < nwin; t++) {
+#pragma unroll 1
+		for (int d = 0; d < ECAMD_WINDOW; d++) {
+			acc = pt_dbl<NW>(acc, slot);
+		}
+		const u32 byte = sc[t >> 1];
+		const u32 dig = (t & 1) ? (byte & 15u) : (byte >> 4);
+		const Pt<NW> T = tbl_load<NW>(A.tbl, A.stride, i, dig);
+		acc = pt_add<NW>(acc, T, slot);
+	}
+
+	// ---- to affine (prj_pt_unique, prj_pt.c:241-273) and export (:600-624) ----
+	if (fe_is_zero<NW>(acc.Z)) {
+		A.status[i] = 2;
+		for (int b = 0; b < 2 * clen; b++) {
+			out[b] = 0;
+		}
+		return;
+	}
+	const Fe<NW> zi = fe_inv<NW>(acc.Z, slot);
+	Fe<NW> ax = fe_mul<NW>(acc.X, zi, slot);
+	Fe<NW> ay = fe_mul<NW>(acc.Y, zi, slot);
+	ax = fe_from_mont<NW>(ax, slot);
+	ay = fe_from_mont<NW>(ay, slot);
+	fe_store_be<NW>(out, clen, ax);
+	fe_store_be<NW>(out + clen, clen, ay);
+	A.status[i] = 0;
+}
+
+template <int NW> __global__ __launch_bounds__(64) void k_fp(EcamdFpArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int slot = A.slot;
+	Fe<NW> a, b, r;
+#pragma unroll
+	for (int w = 0; w < NW; w++) {
+		a.v[w] = A.a[(size_t)i * A.wstride + w];
+		b.v[w] = A.b[(size_t)i * A.wstride + w];
+	}
+	switch (A.op) {
+	case 0:
+		// nn_mul_redc1 semantics: a*b*2^(-64*nlimbs).  Ours is a*b*2^(-32*NW); when NW is odd
+		// one more Montgomery multiplication by fix64 moves the result to the reference radix.
+		r = fe_mul<NW>(a, b, slot);
+		if (!ConstTab<NW>::get(slot).fix_is_id) {
+			r = fe_mul<NW>(r, fe_const<NW>(ConstTab<NW>::get(slot).fix64), slot);
+		}
+		break;
+	case 1: r = fe_add<NW>(a, b, slot); break;
+	case 2: r = fe_sub<NW>(a, b, slot); break;
+	case 3:
+		r = fe_mul<NW>(fe_to_mont<NW>(a, slot), b, slot);  // a R * b / R = a b
+		break;
+	default:
+		r = fe_from_mont<NW>(fe_inv<NW>(fe_to_mont<NW>(a, slot), slot), slot);
+		break;
+	}
+#pragma unroll
+	for (int w = 0; w < NW; w++) {
+		A.out[(size_t)i * A.wstride + w] = r.v[w];
+	}
+	for (u32 w = NW; w < A.wstride; w++) {
+		A.out[(size_t)i * A.wstride + w] = 0;
+	}
+}
+
+template <int NW> __global__ __launch_bounds__(64) void k_pt(EcamdPtArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int slot = A.slot;
+	const int clen = (int)A.clen;
+	u8 *out = A.out + (size_t)i * 2 * clen;
+	Pt<NW> P, Q;
+	bool ok = true;
+	{
+		const u8 *pin = A.p1 + (size_t)i * 2 * clen;
+		Fe<NW> x = fe_load_be<NW>(pin, clen), y = fe_load_be<NW>(pin + clen, clen);
+		ok = ok & fe_lt_p<NW>(x, slot) & fe_lt_p<NW>(y, slot);
+		P.X = fe_to_mont<NW>(x, slot);
+		P.Y = fe_to_mont<NW>(y, slot);
+		P.Z = fe_const<NW>(ConstTab<NW>::get(slot).one);
+		ok = ok & aff_on_curve<NW>(P.X, P.Y, slot);
+	}
+	if (!A.dbl) {
+		const u8 *pin = A.p2 + (size_t)i * 2 * clen;
+		Fe<NW> x = fe_load_be<NW>(pin, clen), y = fe_load_be<NW>(pin + clen, clen);
+		ok = ok & fe_lt_p<NW>(x, slot) & fe_lt_p<NW>(y, slot);
+		Q.X = fe_to_mont<NW>(x, slot);
+		Q.Y = fe_to_mont<NW>(y, slot);
+		Q.Z = P.Z;
+		ok = ok & aff_on_curve<NW>(Q.X, Q.Y, slot);
+	}
+	if (!ok) {
+		A.status[i] = 1;
+		for (int b = 0; b < 2 * clen; b++) {
+			out[b] = 0;
+		}
+		return;
+	}
+	Pt<NW> R = A.dbl ? pt_dbl<NW>(P, slot) : pt_add<NW>(P, Q, slot);
+	if (fe_is_zero<NW>(R.Z)) {
+		A.status[i] = 2;
+		for (int b = 0; b < 2 * clen; b++) {
+			out[b] = 0;
+		}
+		return;
+	}
+	const Fe<NW> zi = fe_inv<NW>(R.Z, slot);
+	Fe<NW> ax = fe_from_mont<NW>(fe_mul<NW>(R.X, zi, slot), slot);
+	Fe<NW> ay = fe_from_mont<NW>(fe_mul<NW>(R.Y, zi, slot), slot);
+	fe_store_be<NW>(out, clen, ax);
+	fe_store_be<NW>(out + clen, clen, ay);
+	A.status[i] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side dispatch on the word count
+// ------------------------------------------------------------------------------------------
+#define ECAMD_FOR_NW(X) X(6) X(7) X(8) X(10) X(12) X(14) X(16) X(17)
+
+int ecamd_nw_supported(int nw)
+{
+	switch (nw) {
+#define X(N) case N: return 1;
+		ECAMD_FOR_NW(X)
+#undef X
+	default: return 0;
+	}
+}
+
+size_t ecamd_curvek_bytes(int nw)
+{
+	switch (nw) {
+#define X(N) case N: return sizeof(CurveK<N>);
+		ECAMD_FOR_NW(X)
+#undef X
+	default: return 0;
+	}
+}
+
+hipError_t ecamd_upload_curve(int nw, int slot, const void *curvek, size_t bytes)
+{
+	switch (nw) {
+#define X(N) case N: \
+		if (bytes != sizeof(CurveK<N>)) return hipErrorInvalidValue; \
+		return hipMemcpyToSymbol(HIP_SYMBOL(g_curves_##N), curvek, bytes, (size_t)slot * sizeof(CurveK<N>), hipMemcpyHostToDevice);
+		ECAMD_FOR_NW(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+}
+
+hipError_t ecamd_launch_smul(int nw, const EcamdSmulArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	const dim3 grid((a.n + 63) / 64), block(64);
+	switch (nw) {
+#define X(N) case N: hipLaunchKernelGGL(k_smul<N>, grid, block, 0, s, a); break;
+		ECAMD_FOR_NW(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_fp(int nw, const EcamdFpArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	const dim3 grid((a.n + 63) / 64), block(64);
+	switch (nw) {
+#define X(N) case N: hipLaunchKernelGGL(k_fp<N>, grid, block, 0, s, a); break;
+		ECAMD_FOR_NW(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_pt(int nw, const EcamdPtArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	const dim3 grid((a.n + 63) / 64), block(64);
+	switch (nw) {
+#define X(N) case N: hipLaunchKernelGGL(k_pt<N>, grid, block, 0, s, a); break;
+		ECAMD_FOR_NW(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}

@@ -1,0 +1,235 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, the committed
+golden vectors and size-independent algebraic properties.  Bit-exact (integer/byte work)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracles import (CURVES, GOLDEN, Oracle, RefLib, clen, have_ref, py_smul_bytes, qlen)
+
+pytestmark = pytest.mark.gpu
+
+MAIN = ["SECP256R1", "SECP384R1", "SECP521R1", "WEI25519"]
+WIDTHS = ["SECP192R1", "SECP224R1", "BRAINPOOLP320R1", "WEI448", "BRAINPOOLP512R1", "SECP256K1"]
+
+
+def rand_bytes(rng, n):
+    return rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+
+
+def edge_scalars(curve, slen):
+    q, order = CURVES[curve]["q"], CURVES[curve]["order"]
+    top = (1 << (8 * slen)) - 1
+    vals = [0, 1, 2, 3, 15, 16, 17, q - 1, q, q + 1, order - 1, order, order + 1, 2 * q, top, top - 1,
+            1 << (8 * slen - 1)]
+    return b"".join((v & top).to_bytes(slen, "big") for v in vals)
+
+
+@pytest.mark.parametrize("curve", MAIN + WIDTHS)
+def test_fp_ops_vs_oracle(gpu_ctx, curve):
+    """rows a6/a7/a13/a14: nn_mul_redc1 (limb-for-limb, reference radix), fp_add, fp_sub, fp_mul, fp_inv"""
+    rng = np.random.default_rng(1)
+    p = CURVES[curve]["p"]
+    cv = gpu_ctx.curve(curve)
+    o = Oracle(curve)
+    try:
+        n = 512
+        a = [int.from_bytes(rand_bytes(rng, o.clen + 8), "big") % p for _ in range(n)]
+        b = [int.from_bytes(rand_bytes(rng, o.clen + 8), "big") % p for _ in range(n)]
+        edge = [0, 1, 2, p - 1, p - 2, (1 << (64 * o.nl)) % p, pow(2, 32 * cv.words, p)]
+        a[:len(edge)] = edge
+        b[:len(edge)] = list(reversed(edge))
+        for op in range(5):
+            if op == 4:
+                aa = [x if x else 1 for x in a]
+                assert cv.fp_op(op, aa, b) == o.fp_op(op, aa, b), f"op {op}"
+            else:
+                assert cv.fp_op(op, a, b) == o.fp_op(op, a, b), f"op {op}"
+        # independent check against Python ints
+        nl = o.nl
+        rinv = pow(pow(2, 64 * nl, p), p - 2, p)
+        assert cv.fp_op(0, a[:64], b[:64]) == [x * y * rinv % p for x, y in zip(a[:64], b[:64])]
+    finally:
+        cv.free()
+
+
+@pytest.mark.parametrize("curve", MAIN + WIDTHS)
+def test_scalar_mult_vs_oracle(gpu_ctx, curve):
+    """row a19: fixed base and variable base, random + edge scalars, vs the restatement oracle"""
+    rng = np.random.default_rng(2)
+    cv = gpu_ctx.curve(curve)
+    o = Oracle(curve)
+    try:
+        slen = o.qlen
+        sc = edge_scalars(curve, slen) + rand_bytes(rng, slen * 47)
+        got = cv.scalar_mult(sc)
+        exp = o.scalar_mult(sc)
+        assert got[1] == exp[1]
+        assert got[0] == exp[0]
+        assert set(exp[1]) >= {0, 2}
+        # variable base: use the valid outputs above as base points
+        pts = b"".join(exp[0][i * 2 * o.clen:(i + 1) * 2 * o.clen] for i in range(len(exp[1])) if exp[1][i] == 0)
+        npts = len(pts) // (2 * o.clen)
+        sc2 = (edge_scalars(curve, slen) + rand_bytes(rng, slen * npts))[:slen * npts]
+        got = cv.scalar_mult(sc2, pts)
+        exp = o.scalar_mult(sc2, pts)
+        assert got == exp
+    finally:
+        cv.free()
+
+
+@pytest.mark.parametrize("curve", ["SECP256R1", "SECP521R1", "WEI25519"])
+def test_scalar_mult_rejections(gpu_ctx, curve):
+    """off-curve points and coordinates >= p must be rejected exactly like prj_pt_import_from_aff_buf"""
+    rng = np.random.default_rng(3)
+    cv = gpu_ctx.curve(curve)
+    o = Oracle(curve)
+    try:
+        c = CURVES[curve]
+        p, n = c["p"], o.clen
+        g = c["gx"].to_bytes(n, "big") + c["gy"].to_bytes(n, "big")
+        bad = [
+            c["gx"].to_bytes(n, "big") + ((c["gy"] + 1) % p).to_bytes(n, "big"),  # off curve
+            ((c["gx"] + 1) % p).to_bytes(n, "big") + c["gy"].to_bytes(n, "big"),
+            bytes(n) + bytes(n),                                                  # (0,0)
+            g,
+        ]
+        if (c["gx"] + p) < (1 << (8 * n)):
+            bad.append((c["gx"] + p).to_bytes(n, "big") + c["gy"].to_bytes(n, "big"))  # x >= p, same residue
+        if (c["gy"] + p) < (1 << (8 * n)):
+            bad.append(c["gx"].to_bytes(n, "big") + (c["gy"] + p).to_bytes(n, "big"))
+        bad.append(p.to_bytes(n, "big") + c["gy"].to_bytes(n, "big"))
+        bad.append(b"\xff" * (2 * n))
+        bad += [rand_bytes(rng, 2 * n) for _ in range(8)]
+        pts = b"".join(bad)
+        sc = rand_bytes(rng, o.qlen * len(bad))
+        got = cv.scalar_mult(sc, pts)
+        exp = o.scalar_mult(sc, pts)
+        assert got == exp
+        assert 1 in exp[1] and 0 in exp[1]
+    finally:
+        cv.free()
+
+
+@pytest.mark.parametrize("curve", ["SECP256R1", "SECP384R1", "SECP521R1", "SECP192R1", "SECP224R1"])
+def test_ecccdh_golden(gpu_ctx, curve):
+    """the reference's own NIST ECC-CDH KATs: d*G == exp_our_pub_key, x(d*Q) == exp_shared_secret"""
+    kats = [k for k in json.load(open(os.path.join(GOLDEN, "ecccdh_kats.json"))) if k["curve"] == curve]
+    assert len(kats) == 25
+    cv = gpu_ctx.curve(curve)
+    try:
+        n = cv.clen
+        d = b"".join(bytes.fromhex(k["our_priv_key"]) for k in kats)
+        slen = len(d) // len(kats)
+        pub, st = cv.scalar_mult(d, None, slen)
+        assert set(st) == {0}
+        assert pub == b"".join(bytes.fromhex(k["exp_our_pub_key"]) for k in kats)
+        peers = b"".join(bytes.fromhex(k["peer_pub_key"]) for k in kats)
+        sh, st = cv.scalar_mult(d, peers, slen)
+        assert set(st) == {0}
+        xs = b"".join(sh[i * 2 * n:i * 2 * n + n] for i in range(len(kats)))
+        assert xs == b"".join(bytes.fromhex(k["exp_shared_secret"]) for k in kats)
+    finally:
+        cv.free()
+
+
+@pytest.mark.parametrize("curve", MAIN + ["BRAINPOOLP320R1"])
+def test_point_add_dbl_vs_oracle(gpu_ctx, curve):
+    """rows a17/a18: prj_pt_add / prj_pt_dbl incl. P+P, P+(-P)"""
+    rng = np.random.default_rng(4)
+    cv = gpu_ctx.curve(curve)
+    o = Oracle(curve)
+    try:
+        c = CURVES[curve]
+        sc = rand_bytes(rng, o.qlen * 32)
+        pts, st = o.scalar_mult(sc)
+        n = o.clen
+        P = [pts[i * 2 * n:(i + 1) * 2 * n] for i in range(32) if st[i] == 0]
+        neg = [x[:n] + ((c["p"] - int.from_bytes(x[n:], "big")) % c["p"]).to_bytes(n, "big") for x in P]
+        p1 = b"".join(P + P[:4] + P[:4])
+        p2 = b"".join(P[1:] + P[:1] + P[:4] + neg[:4])
+        assert cv.pt_add(p1, p2) == o.pt_add(p1, p2)
+        assert cv.pt_add(p1) == o.pt_add(p1)
+    finally:
+        cv.free()
+
+
+def test_linearity_large_batch(gpu_ctx):
+    """size-independent property at a large batch: [a]P + [b]P == [a+b]P and [a]([b]G) == [ab mod q]G,
+    plus a spot check of a random subset against the oracle and chunking across launches."""
+    curve = "SECP256R1"
+    rng = np.random.default_rng(5)
+    cv = gpu_ctx.curve(curve)
+    o = Oracle(curve)
+    try:
+        q = CURVES[curve]["q"]
+        n = 1 << 15
+        gpu_ctx.set_max_chunk(5000)  # force several chunks with a ragged tail
+        a = [int.from_bytes(rand_bytes(rng, 40), "big") % q for _ in range(n)]
+        b = [int.from_bytes(rand_bytes(rng, 40), "big") % q for _ in range(n)]
+        A = b"".join(x.to_bytes(32, "big") for x in a)
+        B = b"".join(x.to_bytes(32, "big") for x in b)
+        bG, st = cv.scalar_mult(B)
+        assert set(st) == {0}
+        abG, st = cv.scalar_mult(A, bG)
+        assert set(st) == {0}
+        AB = b"".join((x * y % q).to_bytes(32, "big") for x, y in zip(a, b))
+        abG2, st = cv.scalar_mult(AB)
+        assert abG == abG2
+        aG, _ = cv.scalar_mult(A)
+        S = b"".join(((x + y) % q).to_bytes(32, "big") for x, y in zip(a, b))
+        sG, st2 = cv.scalar_mult(S)
+        sumG, st3 = cv.pt_add(aG, bG)
+        assert st2 == st3 and sG == sumG
+        idx = rng.choice(n, size=64, replace=False)
+        sub = b"".join(A[i * 32:(i + 1) * 32] for i in idx)
+        subp = b"".join(bG[i * 64:(i + 1) * 64] for i in idx)
+        exp, _ = o.scalar_mult(sub, subp)
+        assert exp == b"".join(abG[i * 64:(i + 1) * 64] for i in idx)
+    finally:
+        gpu_ctx.set_max_chunk(1 << 20)
+        cv.free()
+
+
+def test_long_and_short_scalars(gpu_ctx):
+    """scalar_len other than |q|: 1 byte, 8 bytes, 2|q|+8 bytes (blinded-size scalars, m >= q^2 branch)"""
+    curve = "SECP256R1"
+    rng = np.random.default_rng(6)
+    cv = gpu_ctx.curve(curve)
+    o = Oracle(curve)
+    try:
+        for slen in (1, 8, 33, 72):
+            sc = rand_bytes(rng, slen * 16)
+            assert cv.scalar_mult(sc, None, slen) == o.scalar_mult(sc, None, slen), slen
+    finally:
+        cv.free()
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref/libecc_ref.so not built")
+@pytest.mark.parametrize("curve", ["SECP256R1", "SECP384R1"])
+def test_scalar_mult_vs_reference_binary(gpu_ctx, curve):
+    """directly against the unmodified reference (prj_pt_mul + prj_pt_unique)"""
+    rng = np.random.default_rng(7)
+    cv = gpu_ctx.curve(curve)
+    r = RefLib(curve)
+    try:
+        sc = edge_scalars(curve, r.qlen) + rand_bytes(rng, r.qlen * 15)
+        assert cv.scalar_mult(sc) == r.scalar_mult(sc)
+    finally:
+        cv.free()
+
+
+def test_user_curve_from_params(gpu_ctx):
+    """ecamd_curve_from_params == built-in curve"""
+    import libecc_amd
+    c = CURVES["BRAINPOOLP256R1"]
+    cv = libecc_amd.Curve(gpu_ctx, params=c)
+    cv2 = gpu_ctx.curve("BRAINPOOLP256R1")
+    try:
+        sc = bytes(range(32)) * 4
+        assert cv.scalar_mult(sc) == cv2.scalar_mult(sc)
+        assert cv.scalar_mult(sc)[0][:64] == py_smul_bytes("BRAINPOOLP256R1", int.from_bytes(sc[:32], "big"))
+    finally:
+        cv.free()
+        cv2.free()
