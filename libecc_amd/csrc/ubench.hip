@@ -20,6 +20,13 @@ template <int KIND> __global__ __launch_bounds__(256) void k_rate(u32 *out, u32 
 	u32 a = seed ^ threadIdx.x, b = seed * 2654435761u + blockIdx.x;
 	u64 acc[8];
 	u32 w[8];
+	u64 mask = 0x5555aaaa5555aaaaull ^ seed;
+	mask = ((u64)__builtin_amdgcn_readfirstlane((u32)(mask >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)mask);
+	u64 cs[4] = {mask, ~mask, mask >> 1, mask << 1};
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		cs[i] = ((u64)__builtin_amdgcn_readfirstlane((u32)(cs[i] >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)cs[i]);
+	}
 #pragma unroll
 	for (int i = 0; i < 8; i++) {
 		acc[i] = (u64)(a + i) << 20;
@@ -50,6 +57,16 @@ template <int KIND> __global__ __launch_bounds__(256) void k_rate(u32 *out, u32 
 					asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(w[(i + 3) & 7]) : "vcc");
 				} else if (KIND == 9) {  // v_alignbit_b32
 					asm volatile("v_alignbit_b32 %0, %0, %1, 28" : "+v"(w[i]) : "v"(a));
+				} else if (KIND == 10) {  // v_cndmask_b32 with an SGPR-pair condition that nobody rewrites
+					asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(w[i]) : "v"(a), "s"(mask));
+				} else if (KIND == 11) {  // v_add_co_u32 (writes vcc), independent registers
+					asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(w[i]) : "v"(a) : "vcc");
+				} else if (KIND == 12) {  // v_addc_co_u32 e64 with distinct SGPR carry pairs (no vcc chain)
+					asm volatile("v_addc_co_u32 %0, %1, 0, %0, %1" : "+v"(w[i]), "+s"(cs[i & 3]));
+				} else if (KIND == 13) {  // v_xor_b32 VOP2 e32
+					asm volatile("v_xor_b32 %0, %1, %0" : "+v"(w[i]) : "v"(a));
+				} else if (KIND == 14) {  // v_add3_u32 (VOP3, 8-byte encoding)
+					asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(w[i]) : "v"(a), "v"(b));
 				}
 			}
 		}
@@ -106,9 +123,11 @@ int main(int argc, char **argv)
 	const int iters = (argc > 1) ? atoi(argv[1]) : 4000;
 	u32 *d_out;
 	hipMalloc(&d_out, (size_t)blocks * 256 * 4);
-	const char *names[10] = {"v_mad_u64_u32", "v_add_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_lshl_add_u64",
-				 "v_mad_u32_u24", "v_addc_co_u32", "v_cndmask_b32", "v_mad_u64_u32_b", "v_alignbit_b32"};
-	double r[10];
+	const int NK = 15;
+	const char *names[NK] = {"v_mad_u64_u32", "v_add_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_lshl_add_u64",
+				 "v_mad_u32_u24", "v_addc_co_u32_vccchain", "v_cndmask_b32_vcc", "v_mad_u64_u32_b", "v_alignbit_b32",
+				 "v_cndmask_b32_sgpr", "v_add_co_u32", "v_addc_co_u32_sgprpairs", "v_xor_b32", "v_add3_u32"};
+	double r[NK];
 	r[0] = run_rate<0>(d_out, blocks, iters);
 	r[1] = run_rate<1>(d_out, blocks, iters);
 	r[2] = run_rate<2>(d_out, blocks, iters);
@@ -119,6 +138,11 @@ int main(int argc, char **argv)
 	r[7] = run_rate<7>(d_out, blocks, iters);
 	r[8] = run_rate<8>(d_out, blocks, iters);
 	r[9] = run_rate<9>(d_out, blocks, iters);
+	r[10] = run_rate<10>(d_out, blocks, iters);
+	r[11] = run_rate<11>(d_out, blocks, iters);
+	r[12] = run_rate<12>(d_out, blocks, iters);
+	r[13] = run_rate<13>(d_out, blocks, iters);
+	r[14] = run_rate<14>(d_out, blocks, iters);
 	// dependent chain, one wave per SIMD
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0);
@@ -135,7 +159,7 @@ int main(int argc, char **argv)
 	const double dep_cycles = (ms * 1e-3) * clk_hz / ((double)iters * 32.0);
 	printf("{\"device\": \"%s\", \"gcn_arch\": \"%s\", \"cus\": %d, \"clock_mhz\": %.0f, \"iters\": %d,\n", prop.name,
 	       prop.gcnArchName, cus, clk_hz / 1e6, iters);
-	for (int i = 0; i < 10; i++) {
+	for (int i = 0; i < NK; i++) {
 		// cycles per wave64 instruction per SIMD at the nominal clock
 		const double per_simd = r[i] / ((double)cus * 4.0);          // lane-ops/s per SIMD
 		const double cyc = 64.0 * clk_hz / per_simd;

@@ -1,0 +1,150 @@
+"""CPU tests (no GPU): pin the C restatement oracle against (1) the reference's own known-answer
+vectors, (2) independent Python integer arithmetic, (3) the unmodified reference binary."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracles import (CURVES, GOLDEN, Oracle, RefLib, digest, have_ref, py_smul_bytes, rfc6979_nonce)
+
+KAT_CDH = json.load(open(os.path.join(GOLDEN, "ecccdh_kats.json")))
+KAT_DSA = json.load(open(os.path.join(GOLDEN, "ecdsa_kats.json")))
+
+
+def rb(rng, n):
+    return rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+
+
+@pytest.mark.parametrize("curve", sorted({k["curve"] for k in KAT_CDH}))
+def test_ecccdh_kats(curve):
+    kats = [k for k in KAT_CDH if k["curve"] == curve]
+    assert len(kats) == 25
+    o = Oracle(curve)
+    d = b"".join(bytes.fromhex(k["our_priv_key"]) for k in kats)
+    slen = len(d) // 25
+    pub, st = o.scalar_mult(d, None, slen)
+    assert set(st) == {0}
+    assert pub == b"".join(bytes.fromhex(k["exp_our_pub_key"]) for k in kats)
+    if slen == o.qlen:
+        sec, st = o.ecccdh(d, b"".join(bytes.fromhex(k["peer_pub_key"]) for k in kats))
+        assert set(st) == {0}
+        assert sec == b"".join(bytes.fromhex(k["exp_shared_secret"]) for k in kats)
+
+
+@pytest.mark.parametrize("kat", KAT_DSA, ids=[k["name"].replace(" ", "_") for k in KAT_DSA])
+def test_ecdsa_kats(kat):
+    curve, h = kat["curve"], kat["hash"]
+    o = Oracle(curve)
+    priv, msg, exp = bytes.fromhex(kat["priv_key"]), bytes.fromhex(kat["msg"]), bytes.fromhex(kat["exp_sig"])
+    assert len(exp) == 2 * o.qlen
+    if kat["k"] is not None:
+        k = int(kat["k"], 16)
+    else:
+        k = rfc6979_nonce(curve, h, priv, msg)
+    dg = digest(h, msg)
+    privp = priv.rjust(o.qlen, b"\0")[-o.qlen:]
+    sig, st = o.ecdsa_sign(privp, k.to_bytes(o.qlen, "big"), dg, len(dg))
+    assert st == b"\0" and sig == exp
+    pub, st = o.scalar_mult(privp)
+    assert o.ecdsa_verify(pub, exp, dg, len(dg)) == b"\0"
+    bad = bytearray(exp)
+    bad[-1] ^= 1
+    assert o.ecdsa_verify(pub, bytes(bad), dg, len(dg)) == b"\1"
+
+
+@pytest.mark.parametrize("curve", ["SECP256R1", "SECP384R1", "SECP521R1", "WEI25519", "SECP224R1", "BRAINPOOLP320R1"])
+def test_fp_ops_vs_python(curve):
+    rng = np.random.default_rng(11)
+    p = CURVES[curve]["p"]
+    o = Oracle(curve)
+    a = [int.from_bytes(rb(rng, o.clen + 8), "big") % p for _ in range(64)] + [0, 1, p - 1]
+    b = [int.from_bytes(rb(rng, o.clen + 8), "big") % p for _ in range(64)] + [p - 1, p - 1, p - 1]
+    rinv = pow(pow(2, 64 * o.nl, p), p - 2, p)
+    assert o.fp_op(0, a, b) == [x * y * rinv % p for x, y in zip(a, b)]
+    assert o.fp_op(1, a, b) == [(x + y) % p for x, y in zip(a, b)]
+    assert o.fp_op(2, a, b) == [(x - y) % p for x, y in zip(a, b)]
+    assert o.fp_op(3, a, b) == [x * y % p for x, y in zip(a, b)]
+    assert o.fp_op(4, b, b) == [pow(y, p - 2, p) for y in b]
+
+
+@pytest.mark.parametrize("curve", ["SECP256R1", "SECP521R1", "WEI25519", "SECP256K1"])
+def test_scalar_mult_vs_python(curve):
+    rng = np.random.default_rng(12)
+    o = Oracle(curve)
+    ks = [1, 2, 3, CURVES[curve]["q"] - 1] + [int.from_bytes(rb(rng, o.qlen), "big") for _ in range(4)]
+    sc = b"".join(k.to_bytes(o.qlen, "big") for k in ks)
+    out, st = o.scalar_mult(sc)
+    for i, k in enumerate(ks):
+        exp = py_smul_bytes(curve, k)
+        assert st[i] == (2 if exp is None else 0)
+        if exp:
+            assert out[i * 2 * o.clen:(i + 1) * 2 * o.clen] == exp
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref/libecc_ref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("curve", ["SECP256R1", "SECP384R1", "SECP521R1", "WEI25519", "BRAINPOOLP512R1", "SECP224R1"])
+def test_oracle_vs_reference_binary(curve):
+    """restatement == unmodified reference on random + edge inputs (SURVEY.md section 3.1 edge list)"""
+    rng = np.random.default_rng(13)
+    o, r = Oracle(curve), RefLib(curve)
+    q, order, p = CURVES[curve]["q"], CURVES[curve]["order"], CURVES[curve]["p"]
+    top = (1 << (8 * o.qlen)) - 1
+    edges = [0, 1, 2, q - 1, q, q + 1, order, order + 5, top]
+    sc = b"".join((v & top).to_bytes(o.qlen, "big") for v in edges) + rb(rng, o.qlen * 7)
+    a, b = o.scalar_mult(sc), r.scalar_mult(sc)
+    assert a == b
+    n = o.clen
+    pts = b"".join(a[0][i * 2 * n:(i + 1) * 2 * n] for i in range(len(a[1])) if a[1][i] == 0)
+    g = CURVES[curve]["gx"].to_bytes(n, "big") + ((CURVES[curve]["gy"] + 1) % p).to_bytes(n, "big")
+    pts = pts + g + p.to_bytes(n, "big") * 2
+    m = len(pts) // (2 * n)
+    sc2 = rb(rng, o.qlen * m)
+    assert o.scalar_mult(sc2, pts) == r.scalar_mult(sc2, pts)
+    # long scalars (m >= q^2 branch) and short ones
+    for slen in (1, 2 * o.qlen + 8):
+        s3 = rb(rng, slen * 3)
+        assert o.scalar_mult(s3, None, slen) == r.scalar_mult(s3, None, slen)
+    # group law
+    P = [pts[i * 2 * n:(i + 1) * 2 * n] for i in range(4)]
+    neg = [x[:n] + ((p - int.from_bytes(x[n:], "big")) % p).to_bytes(n, "big") for x in P]
+    p1, p2 = b"".join(P + P + P), b"".join(P[1:] + P[:1] + P + neg)
+    assert o.pt_add(p1, p2) == r.pt_add(p1, p2)
+    assert o.pt_add(p1) == r.pt_add(p1)
+    # field
+    xs = [int.from_bytes(rb(rng, n + 8), "big") % p for _ in range(16)]
+    ys = [int.from_bytes(rb(rng, n + 8), "big") % p for _ in range(16)]
+    for op in range(5):
+        assert o.fp_op(op, xs, ys) == r.fp_op(op, xs, ys)
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref/libecc_ref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("curve,h", [("SECP256R1", "SHA256"), ("SECP256R1", "SHA512"), ("SECP384R1", "SHA256"),
+                                     ("SECP521R1", "SHA512")])
+def test_oracle_protocols_vs_reference_binary(curve, h):
+    """ECDSA sign (fixed k) / verify (valid + corrupted) and ECC-CDH against ec_sign / ec_verify /
+    ecccdh_derive_secret of the unmodified reference"""
+    rng = np.random.default_rng(14)
+    o, r = Oracle(curve), RefLib(curve)
+    q = CURVES[curve]["q"]
+    n, mlen = 6, 24
+    privs = b"".join(((int.from_bytes(rb(rng, o.qlen + 8), "big") % (q - 1)) + 1).to_bytes(o.qlen, "big") for _ in range(n))
+    ks = b"".join(((int.from_bytes(rb(rng, o.qlen + 8), "big") % (q - 1)) + 1).to_bytes(o.qlen, "big") for _ in range(n))
+    msgs = rb(rng, n * mlen)
+    sig_r, pubs, st = r.ecdsa_sign(h, privs, ks, msgs, mlen)
+    assert set(st) == {0}
+    dg = b"".join(digest(h, msgs[i * mlen:(i + 1) * mlen]) for i in range(n))
+    hs = len(dg) // n
+    sig_o, st = o.ecdsa_sign(privs, ks, dg, hs)
+    assert set(st) == {0} and sig_o == sig_r
+    bad = bytearray(sig_r)
+    bad[5] ^= 0x40                         # corrupt r of item 0
+    bad[2 * o.qlen * 2 - 1] ^= 1           # corrupt s of item 1
+    bad[2 * o.qlen * 2:2 * o.qlen * 2 + o.qlen] = bytes(o.qlen)   # r = 0 for item 2
+    bad[2 * o.qlen * 3 + o.qlen:2 * o.qlen * 4] = q.to_bytes(o.qlen, "big")  # s = q for item 3
+    bad = bytes(bad)
+    assert o.ecdsa_verify(pubs, sig_r, dg, hs) == r.ecdsa_verify(h, pubs, sig_r, msgs, mlen) == bytes(n)
+    vo, vr = o.ecdsa_verify(pubs, bad, dg, hs), r.ecdsa_verify(h, pubs, bad, msgs, mlen)
+    assert vo == vr and vo[:4] == b"\1\1\1\1" and vo[4:] == b"\0\0"
+    so, sr = o.ecccdh(privs, pubs[2 * o.clen:] + pubs[:2 * o.clen]), r.ecccdh(privs, pubs[2 * o.clen:] + pubs[:2 * o.clen])
+    assert so == sr and set(so[1]) == {0}
