@@ -11,8 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libecc_amd.so")
-SOURCES = ["ecamd_kernels.hip", "ecamd_host.cpp"]
-DEPS = ["ecamd_field.cuh", "ecamd_point.cuh", "ecamd_internal.h", "ecamd_curve_table.inc",
+SOURCES = ["ecamd_kernels.hip", "ecamd_p256_kernel.hip", "ecamd_host.cpp"]
+DEPS = ["ecamd_field.cuh", "ecamd_point.cuh", "ecamd_u29.cuh", "ecamd_p256.cuh", "ecamd_internal.h",
+        "ecamd_curve_table.inc",
         os.path.join("..", "..", "include", "libecc_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"]

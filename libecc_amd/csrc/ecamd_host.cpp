@@ -208,8 +208,10 @@ struct ecamd_ctx {
 	hipStream_t stream;
 	uint32_t max_chunk;
 	// grow-only scratch
-	uint32_t *tbl;
+	uint32_t *tbl;      // complete-formula kernel: 16 x 3 x NW words per item, word-major
 	size_t tbl_bytes;
+	uint32_t *tbl_fast; // secp256r1 fast path: 8 x 28 words per item, item-major
+	size_t tbl_fast_bytes;
 	uint8_t *stage[4];
 	size_t stage_bytes[4];
 	bool slot_used[ECAMD_MAX_SLOTS_HOST];
@@ -225,6 +227,7 @@ struct ecamd_curve {
 	int pbits, qbits;
 	Big p, a, b, order, gx, gy, q;
 	uint8_t *d_gen;  // generator, affine X||Y big-endian, in HBM
+	bool is_p256;    // exactly secp256r1: eligible for the radix-2^29 Jacobian fast path
 };
 
 static const int k_widths[] = {6, 7, 8, 10, 12, 14, 16, 17};
@@ -268,6 +271,8 @@ extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
 	c->max_chunk = 1u << 20;
 	c->tbl = nullptr;
 	c->tbl_bytes = 0;
+	c->tbl_fast = nullptr;
+	c->tbl_fast_bytes = 0;
 	for (int i = 0; i < 4; i++) {
 		c->stage[i] = nullptr;
 		c->stage_bytes[i] = 0;
@@ -292,6 +297,9 @@ extern "C" void ecamd_ctx_destroy(ecamd_ctx *c)
 	(void)hipStreamSynchronize(c->stream);
 	if (c->tbl) {
 		(void)hipFree(c->tbl);
+	}
+	if (c->tbl_fast) {
+		(void)hipFree(c->tbl_fast);
 	}
 	for (int i = 0; i < 4; i++) {
 		if (c->stage[i]) {
@@ -400,6 +408,11 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	}
 	cv->clen = (cv->pbits + 7) / 8;
 	cv->qlen = (cv->qbits + 7) / 8;
+	cv->is_p256 =
+	    big_cmp(cv->p, big_from_hex("ffffffff00000001000000000000000000000000ffffffffffffffffffffffff")) == 0 &&
+	    big_cmp(cv->a, big_from_hex("ffffffff00000001000000000000000000000000fffffffffffffffffffffffc")) == 0 &&
+	    big_cmp(cv->b, big_from_hex("5ac635d8aa3a93e7b3ebbd55769886bc651d06b0cc53b0f63bce3c3e27d2604b")) == 0 &&
+	    big_cmp(cv->order, cv->q) == 0 && getenv("ECAMD_NO_FAST_PATH") == nullptr;
 	cv->ctx = ctx;
 	cv->d_gen = nullptr;
 	std::lock_guard<std::mutex> lk(ctx->mu);
@@ -510,13 +523,22 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 {
 	const uint32_t chunk = n < ctx->max_chunk ? n : ctx->max_chunk;
 	const uint32_t stride = (chunk + 63u) & ~63u;
+	const bool fast = cv->is_p256 && slen <= 32;
 	{
 		uint8_t *t = (uint8_t *)ctx->tbl;
-		if (ensure(&t, &ctx->tbl_bytes, tbl_bytes_for(cv, stride))) {
-			ctx->tbl = (uint32_t *)t;
+		const int rc = ensure(&t, &ctx->tbl_bytes, tbl_bytes_for(cv, stride));
+		ctx->tbl = (uint32_t *)t;
+		if (rc) {
 			return -1;
 		}
-		ctx->tbl = (uint32_t *)t;
+	}
+	if (fast) {
+		uint8_t *t = (uint8_t *)ctx->tbl_fast;
+		const int rc = ensure(&t, &ctx->tbl_fast_bytes, (size_t)stride * 8 * 28 * 4);
+		ctx->tbl_fast = (uint32_t *)t;
+		if (rc) {
+			return -1;
+		}
 	}
 	for (uint32_t off = 0; off < n; off += chunk) {
 		const uint32_t m = (n - off) < chunk ? (n - off) : chunk;
@@ -532,6 +554,15 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 		A.clen = (uint32_t)cv->clen;
 		A.stride = stride;
 		A.slot = cv->slot;
+		A.only_redo = 0;
+		if (fast) {
+			// Jacobian fast path; lanes that met an exceptional pair come back as ECAMD_STATUS_REDO and
+			// are recomputed by the complete-formula kernel (all other lanes exit at once)
+			EcamdSmulArgs Fa = A;
+			Fa.tbl = ctx->tbl_fast;
+			HIPCHK(ecamd_launch_smul_p256(Fa, s));
+			A.only_redo = 1;
+		}
 		HIPCHK(ecamd_launch_smul(cv->nw, A, s));
 	}
 	return 0;

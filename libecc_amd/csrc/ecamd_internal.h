@@ -6,6 +6,7 @@
 
 #define ECAMD_WINDOW 4
 #define ECAMD_TBL_ENTRIES (1 << ECAMD_WINDOW)
+#define ECAMD_STATUS_REDO 0xFE  /* internal: fast path met an exceptional pair, redo with complete formulas */
 #define ECAMD_MAX_SLOTS_HOST 8  /* == ECAMD_MAX_SLOTS in ecamd_field.cuh */
 
 struct EcamdSmulArgs {
@@ -16,6 +17,7 @@ struct EcamdSmulArgs {
 	uint32_t *tbl;           // scratch: ECAMD_TBL_ENTRIES x 3 x NW words x stride
 	uint32_t n, slen, clen, pstride, stride;
 	int slot;
+	int only_redo;           // generic kernel: process only items whose status is ECAMD_STATUS_REDO
 };
 
 struct EcamdFpArgs {
@@ -37,6 +39,7 @@ struct EcamdPtArgs {
 int ecamd_nw_supported(int nw);
 hipError_t ecamd_upload_curve(int nw, int slot, const void *curvek, size_t bytes);
 hipError_t ecamd_launch_smul(int nw, const EcamdSmulArgs &a, hipStream_t s);
+hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s);
 hipError_t ecamd_launch_fp(int nw, const EcamdFpArgs &a, hipStream_t s);
 hipError_t ecamd_launch_pt(int nw, const EcamdPtArgs &a, hipStream_t s);
 size_t ecamd_curvek_bytes(int nw);

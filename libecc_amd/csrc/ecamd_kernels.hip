@@ -59,6 +59,9 @@ template <int NW> __global__ __launch_bounds__(64) void k_smul(EcamdSmulArgs A)
 	if (i >= A.n) {
 		return;
 	}
+	if (A.only_redo && A.status[i] != ECAMD_STATUS_REDO) {
+		return;
+	}
 	const int slot = A.slot;
 	const int clen = (int)A.clen;
 	u8 *out = A.out + (size_t)i * 2 * clen;

@@ -155,6 +155,33 @@ def test_point_add_dbl_vs_oracle(gpu_ctx, curve):
         cv.free()
 
 
+def test_fast_path_exceptional_pairs(gpu_ctx):
+    """secp256r1 fast path (Jacobian, incomplete addition): scalars around the group order drive the
+    accumulator onto +-(table entry) -- k = q - 2 hits the doubling case, k = q the inverse case --
+    and must come back bit-exact through the complete-formula redo kernel."""
+    curve = "SECP256R1"
+    rng = np.random.default_rng(8)
+    cv = gpu_ctx.curve(curve)
+    o = Oracle(curve)
+    try:
+        q = CURVES[curve]["q"]
+        ks = [q + j for j in range(-40, 41)] + [(1 << 256) - 1 - j for j in range(8)] + list(range(0, 40))
+        ks += [16 * j + d for j in (1, 2, 3) for d in (-8, -1, 1, 7, 8)] + [(q - 2) >> 4, ((q - 2) >> 4) + 1]
+        sc = b"".join(k.to_bytes(32, "big") for k in ks)
+        exp = o.scalar_mult(sc)
+        assert cv.scalar_mult(sc) == exp
+        assert 2 in exp[1]
+        pts, st = o.scalar_mult(rand_bytes(rng, 32 * len(ks)))
+        assert set(st) == {0}
+        assert cv.scalar_mult(sc, pts) == o.scalar_mult(sc, pts)
+        # short scalars through the fast path
+        for slen in (1, 2, 5, 31):
+            s2 = rand_bytes(rng, slen * 33) + b"\xff" * slen + b"\x00" * slen + b"\x88" * slen + b"\x77" * slen
+            assert cv.scalar_mult(s2, None, slen) == o.scalar_mult(s2, None, slen), slen
+    finally:
+        cv.free()
+
+
 def test_linearity_large_batch(gpu_ctx):
     """size-independent property at a large batch: [a]P + [b]P == [a+b]P and [a]([b]G) == [ab mod q]G,
     plus a spot check of a random subset against the oracle and chunking across launches."""
