@@ -44,20 +44,27 @@ def popcount(x):
 
 
 def work_model(curve_params, nw, slen):
-    """Montgomery multiplications and 32x32 MADs the k_smul kernel executes per item
-    (libecc_amd/csrc/ecamd_kernels.hip): derived from the kernel's own parameters."""
+    """Field multiplications and 32x32 MADs (v_mad_u64_u32) executed per item, derived from the
+    kernels' own parameters.  secp256r1 takes the radix-2^29 Jacobian fast path
+    (libecc_amd/csrc/ecamd_p256_kernel.hip): a multiplication is 81 product + 36 reduction MADs,
+    a squaring 45 + 36; every other curve runs the complete-formula kernel k_smul<NW>."""
     p = curve_params["p"]
     pbits = p.bit_length()
     nwin = 2 * slen
-    mm_add, mm_dbl = 17, 16                     # RCB Alg. 1 / Alg. 3, generic a
-    mm = 0
-    mm += 2 + 3                                 # to Montgomery (x, y) + on-curve check
-    mm += 14 * mm_add                           # table [2..15]P
-    mm += (nwin - 1) * (4 * mm_dbl + mm_add)    # windows
-    mm += pbits + popcount(p - 2)               # Fermat inversion (square-and-multiply)
-    mm += 2 + 2                                 # X/Z, Y/Z, from Montgomery
-    mads_per_mm = 2 * nw * nw + nw              # FIPS Montgomery multiplication, 32-bit words
-    return mm, mm * mads_per_mm
+    if p == 2**256 - 2**224 + 2**192 + 2**96 - 1 and slen <= 32:
+        M, S = 117, 81
+        dbl, add = (4, 4), (12, 4)                       # (mults, squarings)
+        nm = 2 + 2 + 4 * dbl[0] + 3 * add[0] + nwin * (4 * dbl[0] + add[0]) + 1 + 13 + 1 + 2 + 2
+        ns = 2 + 4 * dbl[1] + 3 * add[1] + nwin * (4 * dbl[1] + add[1]) + 255 + 1
+        return nm + ns, nm * M + ns * S, "k_smul_p256"
+    mm_add, mm_dbl = 17, 16                              # RCB Alg. 1 / Alg. 3, generic a
+    mm = 2 + 3                                           # to Montgomery (x, y) + on-curve check
+    mm += 14 * mm_add                                    # table [2..15]P
+    mm += (nwin - 1) * (4 * mm_dbl + mm_add)             # windows
+    mm += pbits + popcount(p - 2)                        # Fermat inversion (square-and-multiply)
+    mm += 2 + 2                                          # X/Z, Y/Z, from Montgomery
+    mads_per_mm = 2 * nw * nw + nw                       # FIPS Montgomery multiplication, 32-bit words
+    return mm, mm * mads_per_mm, f"k_smul<{nw}>"
 
 
 def ref_equiv_mads():
@@ -82,6 +89,12 @@ def cpu_baseline(curve, scalars, points, slen):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    try:  # honour the container's CPU quota (cgroup v2): "max" or "<quota> <period>"
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
     nmax = len(scalars) // slen
     if have_ref():
         r = RefLib(curve)
@@ -224,7 +237,7 @@ def main():
     if rank == 0:
         total_items = B * world * args.steps
         value = total_items / elapsed
-        mm, mads = work_model(cp, cv.words, slen)
+        mm, mads, kname = work_model(cp, cv.words, slen)
         launch_ms = float(np.mean(kern_ms))           # HIP-event time of one step on the launch stream
         mad_rate = B * mads / (launch_ms * 1e-3)       # executed lane-MADs per second, one GPU
         peak, ub = (None, None)
@@ -237,11 +250,11 @@ def main():
             "metric": "scalar-mults/sec (secp256r1, batch=2^20, variable base, affine out, bit-exact vs CPU)",
             "value": value, "unit": "scalar-mults/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (v_mad_u64_u32 integer MAD)",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32 (29-bit limbs, v_mad_u64_u32 integer MAD, u64 accumulators)",
             "data": "synthetic (seeded): scalars uniform in [1,q-1], base points P_i=[t_i]G",
             "config": {"workload": f"{CURVE} prj_pt_mul+prj_pt_unique, batch 2^{args.batch_log2} per GPU "
                                    "(BASELINE.json configs[1])",
-                       "batch_per_gpu": B, "scalar_len": slen, "window": 4,
+                       "batch_per_gpu": B, "scalar_len": slen, "window": "signed fixed w=4",
                        "sharding": "contiguous per-rank shards" + (", RCCL all_gather of outputs per step" if world > 1 else ""),
                        "parity_gate": "128 random items byte-identical to the CPU oracle"},
             "roofline": {
@@ -249,8 +262,8 @@ def main():
                 "achieved": mad_rate / 1e9, "peak": (peak or nominal_quarter) / 1e9, "unit": "GMAD/s",
                 "frac": mad_rate / (peak or nominal_quarter),
                 "peak_source": "measured live by libecc_amd/lib/ubench" if peak else "nominal quarter-rate estimate",
-                "kernel": f"k_smul<{cv.words}>", "kernel_ms": launch_ms,
-                "mont_mults_per_item": mm, "mads_per_item": mads,
+                "kernel": kname, "kernel_ms": launch_ms,
+                "field_mults_per_item": mm, "mads_per_item": mads,
                 "ref_equivalent_mads_per_item": ref_equiv_mads(),
                 "traffic": None,
                 "hbm": {"achieved": hbm_rate / 1e9, "peak": 8000.0, "unit": "GB/s",

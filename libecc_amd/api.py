@@ -21,7 +21,8 @@ class EcamdError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, "lib", "libecc_amd.so")
+    # ECAMD_LIB_PATH: developer override to A/B-test an alternative build of the same library
+    return os.environ.get("ECAMD_LIB_PATH") or os.path.join(HERE, "lib", "libecc_amd.so")
 
 
 _LIB = None
