@@ -107,6 +107,23 @@ int ec_prj_pt_dbl_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, co
 int ec_fp_op_batch(ecamd_ctx *ctx, const ecamd_curve *curve, int op, uint32_t n, const uint64_t *a,
 		   const uint64_t *b, uint64_t *out);
 
+/*
+ * ---- protocol callers of the hot path ----
+ * ECDSA verification, batch of independent (public key, signature, digest) triples: per item
+ *   ec_pub_key_import_from_aff_buf(pub, params, pubkeys + i*2*clen, 2*clen, ECDSA)   sig/ec_key.c:181
+ *   ec_verify(sig, 2*qlen, pub, m, mlen, ECDSA, hash, NULL, 0)                       sig/sig_algs.c:655
+ * where the caller supplies h = H(m) (hashing stays on the host; the reference exposes the same
+ * split as ecdsa_verify_raw, sig/fuzzing_ecdsa.h).  sigs: n x 2*qlen (r || s big-endian),
+ * digests: n x digest_len.  result[i] = 0 accept / 1 reject (ec_verify's 0 / -1).
+ */
+int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *pubkeys_aff,
+			  const uint8_t *sigs, const uint8_t *digests, uint32_t digest_len, uint8_t *result);
+/* ECC-CDH, batch form of ecccdh_derive_secret (ecdh/ecccdh.c:167): privs n x qlen, peers n x 2*clen
+ * affine, secrets n x clen (x coordinate of d*Q), status[i] = 0 ok / 1 the reference returns -1.
+ * Cofactor-1 curves only for now. */
+int ec_ecccdh_derive_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *privs,
+			   const uint8_t *peers_aff, uint8_t *secrets, uint8_t *status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,7 +30,7 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 typedef uint8_t u8;
 
-#define ECAMD_MAX_SLOTS 8
+#define ECAMD_MAX_SLOTS 16
 
 template <int NW> struct Fe { u32 v[NW]; };
 

@@ -203,6 +203,7 @@ static const CurveRow g_curve_rows[] = {
 // ------------------------------------------------------------------------------------------
 // objects behind the opaque handles
 // ------------------------------------------------------------------------------------------
+#define ECAMD_NSTAGE 12
 struct ecamd_ctx {
 	int device;
 	hipStream_t stream;
@@ -212,8 +213,8 @@ struct ecamd_ctx {
 	size_t tbl_bytes;
 	uint32_t *tbl_fast; // secp256r1 fast path: 8 x 28 words per item, item-major
 	size_t tbl_fast_bytes;
-	uint8_t *stage[4];
-	size_t stage_bytes[4];
+	uint8_t *stage[ECAMD_NSTAGE];
+	size_t stage_bytes[ECAMD_NSTAGE];
 	bool slot_used[ECAMD_MAX_SLOTS_HOST];
 	std::mutex mu;
 };
@@ -221,7 +222,8 @@ struct ecamd_ctx {
 struct ecamd_curve {
 	ecamd_ctx *ctx;
 	int nw;     // 32-bit words per element
-	int slot;   // __constant__ slot
+	int slot;   // __constant__ slot: field of definition
+	int qslot;  // __constant__ slot: generator order q as a modulus (-1: protocol ops unavailable)
 	int clen;   // BYTECEIL(pbits)
 	int qlen;   // BYTECEIL(qbits)
 	int pbits, qbits;
@@ -273,7 +275,7 @@ extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
 	c->tbl_bytes = 0;
 	c->tbl_fast = nullptr;
 	c->tbl_fast_bytes = 0;
-	for (int i = 0; i < 4; i++) {
+	for (int i = 0; i < ECAMD_NSTAGE; i++) {
 		c->stage[i] = nullptr;
 		c->stage_bytes[i] = 0;
 	}
@@ -301,7 +303,7 @@ extern "C" void ecamd_ctx_destroy(ecamd_ctx *c)
 	if (c->tbl_fast) {
 		(void)hipFree(c->tbl_fast);
 	}
-	for (int i = 0; i < 4; i++) {
+	for (int i = 0; i < ECAMD_NSTAGE; i++) {
 		if (c->stage[i]) {
 			(void)hipFree(c->stage[i]);
 		}
@@ -346,10 +348,14 @@ static int ensure(uint8_t **buf, size_t *have, size_t need)
 
 // CurveK<NW> as a flat word image: p r2 one pm2 a b b3 fix64 (NW words each), then
 // mpinv pbits a_is_m3 fix_is_id -- must match ecamd_field.cuh.
-static int build_and_upload(ecamd_curve *cv)
+static int upload_modulus(int nw, int slot, const Big &p, const Big &a_in, const Big &b_in)
 {
-	const int nw = cv->nw;
-	const Big &p = cv->p;
+	Big a_red = big_mod(a_in, p), b_red = big_mod(b_in, p);
+	struct {
+		const Big &a, &b;
+		int pbits;
+	} cvv = {a_red, b_red, big_bitlen(p)};
+	auto *cv = &cvv;
 	const Big R = big_mod(big_pow2(32 * nw), p);
 	const Big R2 = big_mulmod(R, R, p);
 	Big two(1, 2), three(1, 3);
@@ -384,7 +390,23 @@ static int build_and_upload(ecamd_curve *cv)
 	if (img.size() * 4 != ecamd_curvek_bytes(nw)) {
 		return fail("internal: CurveK image size mismatch");
 	}
-	HIPCHK(ecamd_upload_curve(nw, cv->slot, img.data(), img.size() * 4));
+	HIPCHK(ecamd_upload_curve(nw, slot, img.data(), img.size() * 4));
+	return 0;
+}
+
+static int build_and_upload(ecamd_curve *cv)
+{
+	// slot: the field of definition (modulus p, curve coefficients);  qslot: Montgomery context of
+	// the generator order q for the mod-q algebra of the protocol layer (only when q fits NW words)
+	if (upload_modulus(cv->nw, cv->slot, cv->p, cv->a, cv->b)) {
+		return -1;
+	}
+	if (cv->qslot >= 0) {
+		Big zero(1, 0);
+		if (upload_modulus(cv->nw, cv->qslot, cv->q, zero, zero)) {
+			return -1;
+		}
+	}
 	return 0;
 }
 
@@ -429,6 +451,15 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 		return fail("curve: all constant-memory curve slots are in use (free a curve first)");
 	}
 	cv->slot = slot;
+	cv->qslot = -1;
+	if ((cv->q[0] & 1) && big_bitlen(cv->q) <= 32 * cv->nw) {
+		for (int i = 0; i < ECAMD_MAX_SLOTS_HOST; i++) {
+			if (!ctx->slot_used[i] && i != slot) {
+				cv->qslot = i;
+				break;
+			}
+		}
+	}
 	if (build_and_upload(cv)) {
 		delete cv;
 		return -1;
@@ -442,6 +473,9 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 		return fail("curve: generator upload failed");
 	}
 	ctx->slot_used[slot] = true;
+	if (cv->qslot >= 0) {
+		ctx->slot_used[cv->qslot] = true;
+	}
 	*out = cv;
 	return 0;
 }
@@ -501,6 +535,9 @@ extern "C" void ecamd_curve_free(ecamd_curve *cv)
 			(void)hipFree(cv->d_gen);
 		}
 		cv->ctx->slot_used[cv->slot] = false;
+		if (cv->qslot >= 0) {
+			cv->ctx->slot_used[cv->qslot] = false;
+		}
 	}
 	delete cv;
 }
@@ -517,10 +554,14 @@ static size_t tbl_bytes_for(const ecamd_curve *cv, uint32_t stride)
 	return (size_t)ECAMD_TBL_ENTRIES * 3 * (size_t)cv->nw * 4 * (size_t)stride;
 }
 
+// sstride = slen normally; 0 broadcasts one scalar to every item (subgroup / cofactor passes)
 static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_scalars,
 			   uint32_t slen, const uint8_t *d_points, uint8_t *d_out, uint8_t *d_status,
-			   hipStream_t s)
+			   hipStream_t s, uint32_t sstride = 0xffffffffu)
 {
+	if (sstride == 0xffffffffu) {
+		sstride = slen;
+	}
 	const uint32_t chunk = n < ctx->max_chunk ? n : ctx->max_chunk;
 	const uint32_t stride = (chunk + 63u) & ~63u;
 	const bool fast = cv->is_p256 && slen <= 32;
@@ -543,7 +584,8 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 	for (uint32_t off = 0; off < n; off += chunk) {
 		const uint32_t m = (n - off) < chunk ? (n - off) : chunk;
 		EcamdSmulArgs A;
-		A.scalars = d_scalars + (size_t)off * slen;
+		A.scalars = d_scalars + (size_t)off * sstride;
+		A.sstride = sstride;
 		A.pstride = d_points ? 2u * (uint32_t)cv->clen : 0u;
 		A.points = d_points ? d_points + (size_t)off * 2 * cv->clen : cv->d_gen;
 		A.out = d_out + (size_t)off * 2 * cv->clen;
@@ -712,5 +754,143 @@ extern "C" int ec_fp_op_batch(ecamd_ctx *ctx, const ecamd_curve *cv, int op, uin
 	HIPCHK(ecamd_launch_fp(cv->nw, A, s));
 	HIPCHK(hipMemcpyAsync(out, ctx->stage[2], bytes, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// batched ECDSA verification (digest supplied by the caller)
+// ------------------------------------------------------------------------------------------
+extern "C" int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys,
+				     const uint8_t *sigs, const uint8_t *digests, uint32_t hlen, uint8_t *result)
+{
+	if (!ctx || !cv || cv->ctx != ctx || (n && (!pubkeys || !sigs || !digests || !result))) {
+		return fail("ec_ecdsa_verify_batch: bad argument");
+	}
+	if (cv->qslot < 0) {
+		return fail("ec_ecdsa_verify_batch: generator order not supported for this curve");
+	}
+	if (hlen == 0 || hlen > 128) {
+		return fail("ec_ecdsa_verify_batch: digest length must be in 1..128");
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t plen = (size_t)2 * cv->clen, slen2 = (size_t)2 * cv->qlen, ql = (size_t)cv->qlen;
+	// stage: 0 pub, 1 sig, 2 digest, 3 u1, 4 u2, 5 A, 6 B, 7 stA, 8 stB, 9 flags, 10 result, 11 q scalar / tmp
+	const size_t need[ECAMD_NSTAGE] = {n * plen, n * slen2, (size_t)n * hlen, n * ql, n * ql, n * plen,
+					   n * plen, n, n, n, n, n * plen + 256};
+	for (int i = 0; i < ECAMD_NSTAGE; i++) {
+		if (ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
+			return -1;
+		}
+	}
+	uint8_t **S = ctx->stage;
+	hipStream_t s = ctx->stream;
+	HIPCHK(hipMemcpyAsync(S[0], pubkeys, n * plen, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(S[1], sigs, n * slen2, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(S[2], digests, (size_t)n * hlen, hipMemcpyHostToDevice, s));
+	EcamdEcdsaPrepArgs P;
+	P.sigs = S[1];
+	P.digests = S[2];
+	P.u1 = S[3];
+	P.u2 = S[4];
+	P.flags = S[9];
+	P.n = n;
+	P.qlen = (uint32_t)cv->qlen;
+	P.hlen = hlen;
+	P.qbits = (uint32_t)cv->qbits;
+	P.qslot = cv->qslot;
+	HIPCHK(ecamd_launch_ecdsa_prep(cv->nw, P, s));
+	// uG and vY: two independent prj_pt_mul, as in the reference (sig/ecdsa_common.c:788,793)
+	if (smul_dev_locked(ctx, cv, n, S[3], (uint32_t)cv->qlen, nullptr, S[5], S[7], s) ||
+	    smul_dev_locked(ctx, cv, n, S[4], (uint32_t)cv->qlen, S[0], S[6], S[8], s)) {
+		return -1;
+	}
+	if (big_cmp(cv->order, cv->q) != 0) {
+		// cofactor != 1: ec_pub_key_import_from_aff_buf also requires [q]Y == infinity
+		// (sig/ec_key.c:199-205).  One more pass with the broadcast scalar q; a key outside the
+		// subgroup is turned into an import error (status 1) for the final stage.
+		std::vector<uint8_t> qb(ql);
+		big_to_be(qb.data(), (int)ql, cv->q);
+		uint8_t *qs = S[11] + n * plen;
+		HIPCHK(hipMemcpyAsync(qs, qb.data(), ql, hipMemcpyHostToDevice, s));
+		HIPCHK(hipStreamSynchronize(s));
+		if (smul_dev_locked(ctx, cv, n, qs, (uint32_t)ql, S[0], S[11], S[10], s, 0)) {
+			return -1;
+		}
+		// S[10] holds 2 (infinity) for keys in the subgroup; anything else rejects: fold into stB
+		std::vector<uint8_t> sub(n), stb(n);
+		HIPCHK(hipMemcpyAsync(sub.data(), S[10], n, hipMemcpyDeviceToHost, s));
+		HIPCHK(hipMemcpyAsync(stb.data(), S[8], n, hipMemcpyDeviceToHost, s));
+		HIPCHK(hipStreamSynchronize(s));
+		for (uint32_t i = 0; i < n; i++) {
+			if (sub[i] != 2) {
+				stb[i] = 1;
+			}
+		}
+		HIPCHK(hipMemcpyAsync(S[8], stb.data(), n, hipMemcpyHostToDevice, s));
+		HIPCHK(hipStreamSynchronize(s));
+	}
+	EcamdEcdsaFinArgs Fn;
+	Fn.A = S[5];
+	Fn.stA = S[7];
+	Fn.B = S[6];
+	Fn.stB = S[8];
+	Fn.sigs = S[1];
+	Fn.flags = S[9];
+	Fn.result = S[10];
+	Fn.n = n;
+	Fn.clen = (uint32_t)cv->clen;
+	Fn.qlen = (uint32_t)cv->qlen;
+	{
+		// jmax = floor((p - 1) / q), tiny (1 for cofactor-1 curves with p > q, up to 8 for WEI25519)
+		uint32_t j = 0;
+		Big t = cv->q;
+		while (big_cmp(t, cv->p) < 0 && j < 64) {
+			t = big_add(t, cv->q);
+			j++;
+		}
+		Fn.jmax = j;
+	}
+	for (int w = 0; w < 17; w++) {
+		Fn.q[w] = (size_t)w < cv->q.size() ? cv->q[(size_t)w] : 0;
+	}
+	Fn.slot = cv->slot;
+	HIPCHK(ecamd_launch_ecdsa_fin(cv->nw, Fn, s));
+	HIPCHK(hipMemcpyAsync(result, S[10], n, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// batched ECC-CDH (ecccdh_derive_secret, ecdh/ecccdh.c:167-233)
+// ------------------------------------------------------------------------------------------
+extern "C" int ec_ecccdh_derive_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *privs,
+				      const uint8_t *peers, uint8_t *secrets, uint8_t *status)
+{
+	if (!ctx || !cv || cv->ctx != ctx || (n && (!privs || !peers || !secrets || !status))) {
+		return fail("ec_ecccdh_derive_batch: bad argument");
+	}
+	if (big_cmp(cv->order, cv->q) != 0) {
+		return fail("ec_ecccdh_derive_batch: cofactor != 1 curves are not supported yet");
+	}
+	if (n == 0) {
+		return 0;
+	}
+	const size_t plen = (size_t)2 * cv->clen;
+	std::vector<uint8_t> pts((size_t)n * plen);
+	if (ec_prj_pt_mul_batch(ctx, cv, n, privs, (uint32_t)cv->qlen, peers, pts.data(), status)) {
+		return -1;
+	}
+	for (uint32_t i = 0; i < n; i++) {
+		// infinity (st 2) and import errors (st 1) are both -1 in the reference (:202-217)
+		status[i] = status[i] ? 1 : 0;
+		memcpy(secrets + (size_t)i * cv->clen, pts.data() + (size_t)i * plen, (size_t)cv->clen);
+		if (status[i]) {
+			memset(secrets + (size_t)i * cv->clen, 0, (size_t)cv->clen);
+		}
+	}
 	return 0;
 }

@@ -7,7 +7,7 @@
 #define ECAMD_WINDOW 4
 #define ECAMD_TBL_ENTRIES (1 << ECAMD_WINDOW)
 #define ECAMD_STATUS_REDO 0xFE  /* internal: fast path met an exceptional pair, redo with complete formulas */
-#define ECAMD_MAX_SLOTS_HOST 8  /* == ECAMD_MAX_SLOTS in ecamd_field.cuh */
+#define ECAMD_MAX_SLOTS_HOST 16 /* == ECAMD_MAX_SLOTS in ecamd_field.cuh */
 
 struct EcamdSmulArgs {
 	const uint8_t *scalars;  // n x slen, big-endian
@@ -16,6 +16,7 @@ struct EcamdSmulArgs {
 	uint8_t *status;         // n : 0 ok, 1 error, 2 infinity
 	uint32_t *tbl;           // scratch: ECAMD_TBL_ENTRIES x 3 x NW words x stride
 	uint32_t n, slen, clen, pstride, stride;
+	uint32_t sstride;        // bytes between consecutive scalars (slen, or 0: one shared scalar)
 	int slot;
 	int only_redo;           // generic kernel: process only items whose status is ECAMD_STATUS_REDO
 };
@@ -34,6 +35,27 @@ struct EcamdPtArgs {
 	uint32_t n, clen;
 	int dbl, slot;
 };
+
+// ---- ECDSA verify (sig/ecdsa_common.c:619-840 of the reference), three stages around two scalar mults ----
+struct EcamdEcdsaPrepArgs {
+	const uint8_t *sigs;     // n x 2*qlen, r || s big-endian
+	const uint8_t *digests;  // n x hlen, H(m)
+	uint8_t *u1, *u2;        // n x qlen big-endian: e/s mod q, r/s mod q
+	uint8_t *flags;          // n: 0 ok, 1 reject (r or s not in [1, q-1])
+	uint32_t n, qlen, hlen, qbits;
+	int qslot;               // constant slot holding the Montgomery context of the generator order q
+};
+struct EcamdEcdsaFinArgs {
+	const uint8_t *A, *stA;  // [u1]G affine + status
+	const uint8_t *B, *stB;  // [u2]Q affine + status
+	const uint8_t *sigs, *flags;
+	uint8_t *result;         // n: 0 accept, 1 reject
+	uint32_t n, clen, qlen, jmax;  // jmax = floor((p-1)/q): candidates x = r + j q
+	uint32_t q[17];          // generator order, little-endian words, zero padded to NW
+	int slot;
+};
+hipError_t ecamd_launch_ecdsa_prep(int nw, const EcamdEcdsaPrepArgs &a, hipStream_t s);
+hipError_t ecamd_launch_ecdsa_fin(int nw, const EcamdEcdsaFinArgs &a, hipStream_t s);
 
 // nw: 32-bit words per field element; must be one of ecamd_supported_nw()
 int ecamd_nw_supported(int nw);

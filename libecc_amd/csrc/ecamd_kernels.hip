@@ -98,7 +98,7 @@ template <int NW> __global__ __launch_bounds__(64) void k_smul(EcamdSmulArgs A)
 	}
 
 	// ---- fixed-window left-to-right ----
-	const u8 *sc = A.scalars + (size_t)i * A.slen;
+	const u8 *sc = A.scalars + (size_t)i * A.sstride;
 	const int nwin = 2 * (int)A.slen;
 	acc = tbl_load<NW>(A.tbl, A.stride, i, (u32)(sc[0] >> 4));
 #pragma unroll 1
@@ -224,6 +224,122 @@ template <int NW> __global__ __launch_bounds__(64) void k_pt(EcamdPtArgs A)
 }
 
 // ------------------------------------------------------------------------------------------
+// ECDSA verification around the scalar multiplications
+//   __ecdsa_verify_init     sig/ecdsa_common.c:619-675  r, s in [1, q-1]
+//   __ecdsa_verify_finalize sig/ecdsa_common.c:702-840  e = OS2I(h) >> max(0, 8|h| - |q|) mod q,
+//                           u = e/s, v = r/s (mod q), W' = uG + vY, accept iff W'x mod q == r
+// ------------------------------------------------------------------------------------------
+template <int NW> static __device__ __forceinline__ bool fe_lt(const Fe<NW> &a, const u32 *m)
+{
+	u32 borrow = 0;
+#pragma unroll
+	for (int j = 0; j < NW; j++) {
+		u64 x = (u64)a.v[j] - m[j] - borrow;
+		borrow = (u32)(x >> 63);
+	}
+	return borrow != 0;
+}
+
+template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_prep(EcamdEcdsaPrepArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int qs = A.qslot;  // modulus of this slot is q
+	const int qlen = (int)A.qlen, hlen = (int)A.hlen;
+	const CurveK<NW> &Q = ConstTab<NW>::get(qs);
+	const u8 *sig = A.sigs + (size_t)i * 2 * qlen;
+	const Fe<NW> r = fe_load_be<NW>(sig, qlen), s = fe_load_be<NW>(sig + qlen, qlen);
+	const bool ok = !fe_is_zero<NW>(r) & !fe_is_zero<NW>(s) & fe_lt_p<NW>(r, qs) & fe_lt_p<NW>(s, qs);
+	// e: the leftmost min(hlen, qlen) bytes of the digest, shifted right to |q| bits, reduced once
+	const u8 *dg = A.digests + (size_t)i * hlen;
+	const int elen = hlen < qlen ? hlen : qlen;
+	Fe<NW> e = fe_load_be<NW>(dg, elen);
+	const int rshift = (8 * hlen > (int)A.qbits) ? (8 * elen - (int)A.qbits) : 0;  // 0..7
+	if (rshift > 0) {
+#pragma unroll
+		for (int j = 0; j < NW; j++) {
+			const u32 hi = (j + 1 < NW) ? e.v[j + 1] : 0u;
+			e.v[j] = (e.v[j] >> rshift) | (hi << (32 - rshift));
+		}
+	}
+	{
+		u32 qw[NW];
+#pragma unroll
+		for (int j = 0; j < NW; j++) {
+			qw[j] = Q.p[j];
+		}
+		e = fe_cond_sub<NW>(e.v, 0u, qw);  // e < 2^|q| < 2q: one conditional subtraction is nn_mod
+	}
+	// s^-1 = s^(q-2) (q prime): the unique inverse, equal to nn_modinv's (nn/nn_modinv.c:220)
+	const Fe<NW> sinv = fe_inv<NW>(fe_to_mont<NW>(s, qs), qs);   // Montgomery form of 1/s
+	const Fe<NW> u1 = fe_mul<NW>(e, sinv, qs);                   // plain * Montgomery = plain e/s
+	const Fe<NW> u2 = fe_mul<NW>(r, sinv, qs);
+	fe_store_be<NW>(A.u1 + (size_t)i * qlen, qlen, ok ? u1 : fe_zero<NW>());
+	fe_store_be<NW>(A.u2 + (size_t)i * qlen, qlen, ok ? u2 : fe_zero<NW>());
+	A.flags[i] = ok ? 0 : 1;
+}
+
+template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_fin(EcamdEcdsaFinArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int slot = A.slot;
+	const int clen = (int)A.clen, qlen = (int)A.qlen;
+	const u32 sa = A.stA[i], sb = A.stB[i];
+	// invalid signature range, invalid public key (import failed), or W' = infinity
+	if (A.flags[i] || sa == 1 || sb == 1 || (sa == 2 && sb == 2)) {
+		A.result[i] = 1;
+		return;
+	}
+	const Fe<NW> one = fe_const<NW>(ConstTab<NW>::get(slot).one);
+	Pt<NW> P, Q, W;
+	{
+		const u8 *pa = A.A + (size_t)i * 2 * clen, *pb = A.B + (size_t)i * 2 * clen;
+		P.X = fe_to_mont<NW>(fe_load_be<NW>(pa, clen), slot);
+		P.Y = fe_to_mont<NW>(fe_load_be<NW>(pa + clen, clen), slot);
+		P.Z = one;
+		Q.X = fe_to_mont<NW>(fe_load_be<NW>(pb, clen), slot);
+		Q.Y = fe_to_mont<NW>(fe_load_be<NW>(pb + clen, clen), slot);
+		Q.Z = one;
+	}
+	if (sa == 2) {
+		W = Q;
+	} else if (sb == 2) {
+		W = P;
+	} else {
+		W = pt_add<NW>(P, Q, slot);  // complete: also P == Q and P == -Q
+	}
+	if (fe_is_zero<NW>(W.Z)) {
+		A.result[i] = 1;
+		return;
+	}
+	// W'x mod q == r  <=>  x == r + j q for some j with r + j q < p  <=>  (r + j q) Z == X
+	Fe<NW> t = fe_load_be<NW>(A.sigs + (size_t)i * 2 * qlen, qlen);
+	bool acc = false;
+	for (u32 j = 0; j <= A.jmax; j++) {
+		if (fe_lt_p<NW>(t, slot)) {
+			const Fe<NW> lhs = fe_mul<NW>(fe_to_mont<NW>(t, slot), W.Z, slot);
+			acc = acc | fe_eq<NW>(lhs, W.X);
+		}
+		u32 carry = 0;
+#pragma unroll
+		for (int w = 0; w < NW; w++) {
+			const u64 x = (u64)t.v[w] + A.q[w] + carry;
+			t.v[w] = (u32)x;
+			carry = (u32)(x >> 32);
+		}
+		if (carry) {
+			break;  // r + j q no longer fits NW words, hence >= p
+		}
+	}
+	A.result[i] = acc ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side dispatch on the word count
 // ------------------------------------------------------------------------------------------
 #define ECAMD_FOR_NW(X) X(6) X(7) X(8) X(10) X(12) X(14) X(16) X(17)
@@ -268,6 +384,36 @@ hipError_t ecamd_launch_smul(int nw, const EcamdSmulArgs &a, hipStream_t s)
 	const dim3 grid((a.n + 63) / 64), block(64);
 	switch (nw) {
 #define X(N) case N: hipLaunchKernelGGL(k_smul<N>, grid, block, 0, s, a); break;
+		ECAMD_FOR_NW(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_ecdsa_prep(int nw, const EcamdEcdsaPrepArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	const dim3 grid((a.n + 63) / 64), block(64);
+	switch (nw) {
+#define X(N) case N: hipLaunchKernelGGL(k_ecdsa_prep<N>, grid, block, 0, s, a); break;
+		ECAMD_FOR_NW(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_ecdsa_fin(int nw, const EcamdEcdsaFinArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	const dim3 grid((a.n + 63) / 64), block(64);
+	switch (nw) {
+#define X(N) case N: hipLaunchKernelGGL(k_ecdsa_fin<N>, grid, block, 0, s, a); break;
 		ECAMD_FOR_NW(X)
 #undef X
 	default: return hipErrorInvalidValue;

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) void k_smul_p256(EcamdSmulArgs A)
 	}
 
 	// ---- scalar: k (<= 32 bytes big-endian) -> k' = k + 0x88..8 over its 2*slen nibbles ----
-	const u8 *sc = A.scalars + (size_t)i * A.slen;
+	const u8 *sc = A.scalars + (size_t)i * A.sstride;
 	const int slen = (int)A.slen;
 	u32 kw[8];
 	if (slen == 32) {

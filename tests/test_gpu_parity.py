@@ -6,7 +6,8 @@ import os
 import numpy as np
 import pytest
 
-from oracles import (CURVES, GOLDEN, Oracle, RefLib, clen, have_ref, py_smul_bytes, qlen)
+from oracles import (CURVES, GOLDEN, Oracle, RefLib, clen, digest, have_ref, py_smul_bytes, qlen,
+                     rfc6979_nonce)
 
 pytestmark = pytest.mark.gpu
 
@@ -260,3 +261,110 @@ def test_user_curve_from_params(gpu_ctx):
     finally:
         cv.free()
         cv2.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# protocol callers: ECDSA verify, ECC-CDH
+# ---------------------------------------------------------------------------------------------
+def make_sigs(curve, h, n, rng):
+    """n valid ECDSA signatures made by the CPU oracle (random key, nonce, 24-byte message)"""
+    o = Oracle(curve)
+    q = CURVES[curve]["q"]
+
+    def rs():
+        return ((int.from_bytes(rand_bytes(rng, o.qlen + 8), "big") % (q - 1)) + 1).to_bytes(o.qlen, "big")
+
+    privs = b"".join(rs() for _ in range(n))
+    ks = b"".join(rs() for _ in range(n))
+    msgs = [rand_bytes(rng, 24) for _ in range(n)]
+    dg = b"".join(digest(h, m) for m in msgs)
+    hl = len(dg) // n
+    sigs, st = o.ecdsa_sign(privs, ks, dg, hl)
+    assert set(st) == {0}
+    pubs, st = o.scalar_mult(privs)
+    assert set(st) == {0}
+    return o, pubs, sigs, dg, hl, b"".join(msgs)
+
+
+@pytest.mark.parametrize("curve,h", [("SECP256R1", "SHA256"), ("SECP256R1", "SHA512"), ("SECP384R1", "SHA384"),
+                                     ("SECP521R1", "SHA512"), ("SECP192R1", "SHA256"), ("BRAINPOOLP256R1", "SHA256"),
+                                     ("WEI25519", "SHA512"), ("SECP256K1", "SHA256")])
+def test_ecdsa_verify_vs_oracle(gpu_ctx, curve, h):
+    rng = np.random.default_rng(31)
+    n = 40
+    o, pubs, sigs, dg, hl, msgs = make_sigs(curve, h, n, rng)
+    c = CURVES[curve]
+    q, p, cl, ql = c["q"], c["p"], o.clen, o.qlen
+    pubs, sigs, dg = bytearray(pubs), bytearray(sigs), bytearray(dg)
+    # corrupt items 10.. in every way the reference distinguishes
+    sigs[10 * 2 * ql + 3] ^= 0x10                                  # r bit
+    sigs[11 * 2 * ql + ql + 5] ^= 0x01                             # s bit
+    dg[12 * hl] ^= 0x80                                            # digest bit
+    pubs[13 * 2 * cl + cl - 1] ^= 1                                # public key off curve
+    sigs[14 * 2 * ql:14 * 2 * ql + ql] = bytes(ql)                 # r = 0
+    sigs[15 * 2 * ql + ql:16 * 2 * ql] = bytes(ql)                 # s = 0
+    sigs[16 * 2 * ql:16 * 2 * ql + ql] = q.to_bytes(ql, "big")     # r = q
+    sigs[17 * 2 * ql + ql:18 * 2 * ql] = q.to_bytes(ql, "big")     # s = q
+    pubs[18 * 2 * cl:18 * 2 * cl + cl] = p.to_bytes(cl, "big")     # x = p
+    sigs[19 * 2 * ql:20 * 2 * ql] = sigs[20 * 2 * ql:21 * 2 * ql]  # someone else's signature
+    s21 = int.from_bytes(sigs[21 * 2 * ql + ql:22 * 2 * ql], "big")
+    sigs[21 * 2 * ql + ql:22 * 2 * ql] = (q - s21).to_bytes(ql, "big")   # (r, -s) is also valid
+    pubs[22 * 2 * cl:23 * 2 * cl] = bytes(2 * cl)                  # (0, 0)
+    pubs, sigs, dg = bytes(pubs), bytes(sigs), bytes(dg)
+    cv = gpu_ctx.curve(curve)
+    try:
+        got = cv.ecdsa_verify(pubs, sigs, dg, hl)
+        exp = o.ecdsa_verify(pubs, sigs, dg, hl)
+        assert got == exp
+        assert exp[:10] == bytes(10) and exp[21] == 0 and set(exp[10:20]) == {1} and exp[22] == 1
+        if have_ref() and h in ("SHA256", "SHA384", "SHA512"):
+            # the unmodified reference hashes the message itself; items with a corrupted digest differ by design
+            ref = RefLib(curve).ecdsa_verify(h, pubs, sigs, msgs, 24)
+            assert bytes(x for i, x in enumerate(ref) if i != 12) == bytes(x for i, x in enumerate(got) if i != 12)
+    finally:
+        cv.free()
+
+
+def test_ecdsa_verify_golden(gpu_ctx):
+    """every ECDSA / RFC 6979 signature vector of the reference must verify on the GPU (public key
+    derived on the GPU from the vector's private key), and must fail with one bit flipped"""
+    kats = json.load(open(os.path.join(GOLDEN, "ecdsa_kats.json")))
+    for curve in sorted({k["curve"] for k in kats}):
+        ks = [k for k in kats if k["curve"] == curve]
+        cv = gpu_ctx.curve(curve)
+        try:
+            for hname in sorted({k["hash"] for k in ks}):
+                sel = [k for k in ks if k["hash"] == hname]
+                privs = b"".join(bytes.fromhex(k["priv_key"]).rjust(cv.qlen, b"\0")[-cv.qlen:] for k in sel)
+                pubs, st = cv.scalar_mult(privs)
+                assert set(st) == {0}
+                dg = b"".join(digest(hname, bytes.fromhex(k["msg"])) for k in sel)
+                hl = len(dg) // len(sel)
+                sigs = b"".join(bytes.fromhex(k["exp_sig"]) for k in sel)
+                assert cv.ecdsa_verify(pubs, sigs, dg, hl) == bytes(len(sel)), (curve, hname)
+                bad = bytearray(sigs)
+                for i in range(len(sel)):
+                    bad[i * 2 * cv.qlen + 7] ^= 4
+                assert cv.ecdsa_verify(pubs, bytes(bad), dg, hl) == b"\1" * len(sel)
+        finally:
+            cv.free()
+
+
+@pytest.mark.parametrize("curve", ["SECP192R1", "SECP224R1", "SECP256R1", "SECP384R1", "SECP521R1"])
+def test_ecccdh_derive_golden_and_oracle(gpu_ctx, curve):
+    kats = [k for k in json.load(open(os.path.join(GOLDEN, "ecccdh_kats.json"))) if k["curve"] == curve]
+    cv = gpu_ctx.curve(curve)
+    o = Oracle(curve)
+    try:
+        d = b"".join(bytes.fromhex(k["our_priv_key"]) for k in kats)
+        if len(d) // len(kats) != cv.qlen:
+            pytest.skip("vector private keys are not qlen bytes")
+        peers = bytearray(b"".join(bytes.fromhex(k["peer_pub_key"]) for k in kats))
+        sec, st = cv.ecccdh(d, bytes(peers))
+        assert set(st) == {0}
+        assert sec == b"".join(bytes.fromhex(k["exp_shared_secret"]) for k in kats)
+        peers[5] ^= 1                                      # invalid peer key
+        d2 = bytes(cv.qlen) + d[cv.qlen:]                  # d = 0 -> infinity -> error
+        assert cv.ecccdh(d2, bytes(peers)) == o.ecccdh(d2, bytes(peers))
+    finally:
+        cv.free()
