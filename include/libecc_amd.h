@@ -118,6 +118,15 @@ int ec_fp_op_batch(ecamd_ctx *ctx, const ecamd_curve *curve, int op, uint32_t n,
  */
 int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *pubkeys_aff,
 			  const uint8_t *sigs, const uint8_t *digests, uint32_t digest_len, uint8_t *result);
+/* ECDSA signing with caller-supplied nonces: per item the tail of ec_sign / __ecdsa_sign_finalize
+ * (sig/ecdsa_common.c:318-586) -- kG = prj_pt_mul(k, G), r = kG.x mod q, s = k^-1 (x r + e) mod q --
+ * with h = H(m) and the nonce k supplied by the caller (random, or RFC 6979 computed on the host;
+ * the reference's KAT harness injects k through the same ctx->rand hook).  privs, nonces: n x qlen;
+ * sigs: n x 2*qlen.  status[i] = 1 where the reference would fail or restart (k not in [1, q-1],
+ * r = 0, e == x r, s = 0). */
+int ec_ecdsa_sign_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *privs,
+			const uint8_t *nonces, const uint8_t *digests, uint32_t digest_len, uint8_t *sigs,
+			uint8_t *status);
 /* ECC-CDH, batch form of ecccdh_derive_secret (ecdh/ecccdh.c:167): privs n x qlen, peers n x 2*clen
  * affine, secrets n x clen (x coordinate of d*Q), status[i] = 0 ok / 1 the reference returns -1.
  * Cofactor-1 curves only for now. */

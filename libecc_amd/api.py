@@ -12,7 +12,7 @@ EXPORTED_SYMBOLS = [
     "ecamd_ctx_set_max_chunk", "ecamd_curve_by_name", "ecamd_curve_from_params", "ecamd_curve_free",
     "ecamd_curve_coord_len", "ecamd_curve_order_len", "ecamd_curve_words", "ec_prj_pt_mul_batch",
     "ec_prj_pt_mul_batch_dev", "ecamd_ctx_synchronize", "ec_prj_pt_add_batch", "ec_prj_pt_dbl_batch",
-    "ec_fp_op_batch", "ec_ecdsa_verify_batch", "ec_ecccdh_derive_batch",
+    "ec_fp_op_batch", "ec_ecdsa_verify_batch", "ec_ecdsa_sign_batch", "ec_ecccdh_derive_batch",
 ]
 
 
@@ -56,6 +56,7 @@ def load_library():
         L.ec_prj_pt_dbl_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p]
         L.ec_fp_op_batch.argtypes = [vp, vp, C.c_int, u32, vp, vp, vp]
         L.ec_ecdsa_verify_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p]
+        L.ec_ecdsa_sign_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p, u8p]
         L.ec_ecccdh_derive_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
         _LIB = L
     return _LIB
@@ -161,6 +162,14 @@ class Curve:
         _chk(self.L, self.L.ec_ecdsa_verify_batch(self.ctx.h, self.h, n, pubs, sigs, digests, hlen, res),
              "ec_ecdsa_verify_batch")
         return res.raw[:n]
+
+    def ecdsa_sign(self, privs, nonces, digests, hlen):
+        n = len(privs) // self.qlen
+        sigs = C.create_string_buffer(max(1, 2 * self.qlen * n))
+        st = C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_ecdsa_sign_batch(self.ctx.h, self.h, n, privs, nonces, digests, hlen, sigs, st),
+             "ec_ecdsa_sign_batch")
+        return sigs.raw[:2 * self.qlen * n], st.raw[:n]
 
     def ecccdh(self, privs, peers):
         n = len(privs) // self.qlen

@@ -865,6 +865,73 @@ extern "C" int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint
 }
 
 // ------------------------------------------------------------------------------------------
+// batched ECDSA signing with caller-supplied nonces
+// ------------------------------------------------------------------------------------------
+extern "C" int ec_ecdsa_sign_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *privs,
+				   const uint8_t *nonces, const uint8_t *digests, uint32_t hlen, uint8_t *sigs,
+				   uint8_t *status)
+{
+	if (!ctx || !cv || cv->ctx != ctx || (n && (!privs || !nonces || !digests || !sigs || !status))) {
+		return fail("ec_ecdsa_sign_batch: bad argument");
+	}
+	if (cv->qslot < 0) {
+		return fail("ec_ecdsa_sign_batch: generator order not supported for this curve");
+	}
+	if (hlen == 0 || hlen > 128) {
+		return fail("ec_ecdsa_sign_batch: digest length must be in 1..128");
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t plen = (size_t)2 * cv->clen, ql = (size_t)cv->qlen;
+	// stage: 0 privs, 1 nonces, 2 digests, 3 kG, 4 st, 5 sigs, 6 status
+	const size_t need[7] = {n * ql, n * ql, (size_t)n * hlen, n * plen, n, n * 2 * ql, n};
+	for (int i = 0; i < 7; i++) {
+		if (ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
+			return -1;
+		}
+	}
+	uint8_t **S = ctx->stage;
+	hipStream_t s = ctx->stream;
+	HIPCHK(hipMemcpyAsync(S[0], privs, n * ql, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(S[1], nonces, n * ql, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(S[2], digests, (size_t)n * hlen, hipMemcpyHostToDevice, s));
+	if (smul_dev_locked(ctx, cv, n, S[1], (uint32_t)ql, nullptr, S[3], S[4], s)) {  // kG (:479)
+		return -1;
+	}
+	EcamdEcdsaSignArgs A;
+	A.privs = S[0];
+	A.nonces = S[1];
+	A.digests = S[2];
+	A.kG = S[3];
+	A.stkG = S[4];
+	A.sigs = S[5];
+	A.status = S[6];
+	A.n = n;
+	A.clen = (uint32_t)cv->clen;
+	A.qlen = (uint32_t)cv->qlen;
+	A.hlen = hlen;
+	A.qbits = (uint32_t)cv->qbits;
+	{
+		uint32_t j = 0;
+		Big t = cv->q;
+		while (big_cmp(t, cv->p) < 0 && j < 64) {
+			t = big_add(t, cv->q);
+			j++;
+		}
+		A.jmax = j;
+	}
+	A.qslot = cv->qslot;
+	HIPCHK(ecamd_launch_ecdsa_sign(cv->nw, A, s));
+	HIPCHK(hipMemcpyAsync(sigs, S[5], n * 2 * ql, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipMemcpyAsync(status, S[6], n, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // batched ECC-CDH (ecccdh_derive_secret, ecdh/ecccdh.c:167-233)
 // ------------------------------------------------------------------------------------------
 extern "C" int ec_ecccdh_derive_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *privs,

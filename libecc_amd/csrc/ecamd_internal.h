@@ -54,6 +54,14 @@ struct EcamdEcdsaFinArgs {
 	uint32_t q[17];          // generator order, little-endian words, zero padded to NW
 	int slot;
 };
+struct EcamdEcdsaSignArgs {
+	const uint8_t *privs, *nonces, *digests;  // n x qlen, n x qlen, n x hlen
+	const uint8_t *kG, *stkG;                 // [k]G affine + status
+	uint8_t *sigs, *status;                   // n x 2*qlen (r || s), n
+	uint32_t n, clen, qlen, hlen, qbits, jmax;
+	int qslot;
+};
+hipError_t ecamd_launch_ecdsa_sign(int nw, const EcamdEcdsaSignArgs &a, hipStream_t s);
 hipError_t ecamd_launch_ecdsa_prep(int nw, const EcamdEcdsaPrepArgs &a, hipStream_t s);
 hipError_t ecamd_launch_ecdsa_fin(int nw, const EcamdEcdsaFinArgs &a, hipStream_t s);
 

@@ -240,6 +240,28 @@ template <int NW> static __device__ __forceinline__ bool fe_lt(const Fe<NW> &a, 
 	return borrow != 0;
 }
 
+// digest -> e = (OS2I(h) >> max(0, 8|h| - |q|)) mod q   (sig/ecdsa_common.c:398-413, 760-778)
+template <int NW> static __device__ __forceinline__ Fe<NW> digest_to_e(const u8 *dg, int hlen, int qlen, int qbits, int qs)
+{
+	const CurveK<NW> &Q = ConstTab<NW>::get(qs);
+	const int elen = hlen < qlen ? hlen : qlen;
+	Fe<NW> e = fe_load_be<NW>(dg, elen);
+	const int rshift = (8 * hlen > qbits) ? (8 * elen - qbits) : 0;  // 0..7
+	if (rshift > 0) {
+#pragma unroll
+		for (int j = 0; j < NW; j++) {
+			const u32 hi = (j + 1 < NW) ? e.v[j + 1] : 0u;
+			e.v[j] = (e.v[j] >> rshift) | (hi << (32 - rshift));
+		}
+	}
+	u32 qw[NW];
+#pragma unroll
+	for (int j = 0; j < NW; j++) {
+		qw[j] = Q.p[j];
+	}
+	return fe_cond_sub<NW>(e.v, 0u, qw);  // e < 2^|q| < 2q: one conditional subtraction is nn_mod
+}
+
 template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_prep(EcamdEcdsaPrepArgs A)
 {
 	const u32 i = blockIdx.x * 64 + threadIdx.x;
@@ -248,30 +270,10 @@ template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_prep(EcamdEcdsaP
 	}
 	const int qs = A.qslot;  // modulus of this slot is q
 	const int qlen = (int)A.qlen, hlen = (int)A.hlen;
-	const CurveK<NW> &Q = ConstTab<NW>::get(qs);
 	const u8 *sig = A.sigs + (size_t)i * 2 * qlen;
 	const Fe<NW> r = fe_load_be<NW>(sig, qlen), s = fe_load_be<NW>(sig + qlen, qlen);
 	const bool ok = !fe_is_zero<NW>(r) & !fe_is_zero<NW>(s) & fe_lt_p<NW>(r, qs) & fe_lt_p<NW>(s, qs);
-	// e: the leftmost min(hlen, qlen) bytes of the digest, shifted right to |q| bits, reduced once
-	const u8 *dg = A.digests + (size_t)i * hlen;
-	const int elen = hlen < qlen ? hlen : qlen;
-	Fe<NW> e = fe_load_be<NW>(dg, elen);
-	const int rshift = (8 * hlen > (int)A.qbits) ? (8 * elen - (int)A.qbits) : 0;  // 0..7
-	if (rshift > 0) {
-#pragma unroll
-		for (int j = 0; j < NW; j++) {
-			const u32 hi = (j + 1 < NW) ? e.v[j + 1] : 0u;
-			e.v[j] = (e.v[j] >> rshift) | (hi << (32 - rshift));
-		}
-	}
-	{
-		u32 qw[NW];
-#pragma unroll
-		for (int j = 0; j < NW; j++) {
-			qw[j] = Q.p[j];
-		}
-		e = fe_cond_sub<NW>(e.v, 0u, qw);  // e < 2^|q| < 2q: one conditional subtraction is nn_mod
-	}
+	const Fe<NW> e = digest_to_e<NW>(A.digests + (size_t)i * hlen, hlen, qlen, (int)A.qbits, qs);
 	// s^-1 = s^(q-2) (q prime): the unique inverse, equal to nn_modinv's (nn/nn_modinv.c:220)
 	const Fe<NW> sinv = fe_inv<NW>(fe_to_mont<NW>(s, qs), qs);   // Montgomery form of 1/s
 	const Fe<NW> u1 = fe_mul<NW>(e, sinv, qs);                   // plain * Montgomery = plain e/s
@@ -279,6 +281,50 @@ template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_prep(EcamdEcdsaP
 	fe_store_be<NW>(A.u1 + (size_t)i * qlen, qlen, ok ? u1 : fe_zero<NW>());
 	fe_store_be<NW>(A.u2 + (size_t)i * qlen, qlen, ok ? u2 : fe_zero<NW>());
 	A.flags[i] = ok ? 0 : 1;
+}
+
+// __ecdsa_sign_finalize (sig/ecdsa_common.c:318-586) after kG: r = kG.x mod q, s = k^-1 (x r + e) mod q.
+// The nonce k is an input (the reference takes it from ctx->rand; its KAT harness injects it the same
+// way).  status 1: k not in [1, q-1], or one of the reference's restart conditions (r = 0, e == x r... no:
+// e + x r == 0 is checked as e == -(x r)?  the reference compares e with x r, :516), s = 0.
+template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_sign(EcamdEcdsaSignArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int qs = A.qslot;
+	const int qlen = (int)A.qlen, clen = (int)A.clen;
+	u8 *sig = A.sigs + (size_t)i * 2 * qlen;
+	const Fe<NW> k = fe_load_be<NW>(A.nonces + (size_t)i * qlen, qlen);
+	Fe<NW> x = fe_load_be<NW>(A.privs + (size_t)i * qlen, qlen);
+	bool ok = !fe_is_zero<NW>(k) & fe_lt_p<NW>(k, qs) & (A.stkG[i] == 0);
+	const CurveK<NW> &Q = ConstTab<NW>::get(qs);
+	u32 qw[NW];
+#pragma unroll
+	for (int j = 0; j < NW; j++) {
+		qw[j] = Q.p[j];
+	}
+	// r = kG.x mod q: x < p <= (jmax + 1) q, so jmax conditional subtractions
+	Fe<NW> r = fe_load_be<NW>(A.kG + (size_t)i * 2 * clen, clen);
+	for (u32 j = 0; j < A.jmax; j++) {
+		r = fe_cond_sub<NW>(r.v, 0u, qw);
+	}
+	ok = ok & !fe_is_zero<NW>(r);
+	for (u32 j = 0; j < 1; j++) {
+		x = fe_cond_sub<NW>(x.v, 0u, qw);  // private keys are < q in every sane use; one reduction step
+	}
+	const Fe<NW> e = digest_to_e<NW>(A.digests + (size_t)i * A.hlen, (int)A.hlen, qlen, (int)A.qbits, qs);
+	const Fe<NW> r2q = fe_const<NW>(Q.r2);
+	const Fe<NW> xr = fe_mul<NW>(fe_mul<NW>(x, r2q, qs), r, qs);       // x r mod q (plain)
+	ok = ok & !fe_eq<NW>(e, xr);                                          // :516 restart condition
+	const Fe<NW> t = fe_add<NW>(xr, e, qs);
+	const Fe<NW> kinv = fe_inv<NW>(fe_mul<NW>(k, r2q, qs), qs);          // Montgomery form of 1/k
+	const Fe<NW> s = fe_mul<NW>(t, kinv, qs);
+	ok = ok & !fe_is_zero<NW>(s);
+	fe_store_be<NW>(sig, qlen, ok ? r : fe_zero<NW>());
+	fe_store_be<NW>(sig + qlen, qlen, ok ? s : fe_zero<NW>());
+	A.status[i] = ok ? 0 : 1;
 }
 
 template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_fin(EcamdEcdsaFinArgs A)
@@ -399,6 +445,21 @@ hipError_t ecamd_launch_ecdsa_prep(int nw, const EcamdEcdsaPrepArgs &a, hipStrea
 	const dim3 grid((a.n + 63) / 64), block(64);
 	switch (nw) {
 #define X(N) case N: hipLaunchKernelGGL(k_ecdsa_prep<N>, grid, block, 0, s, a); break;
+		ECAMD_FOR_NW(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_ecdsa_sign(int nw, const EcamdEcdsaSignArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	const dim3 grid((a.n + 63) / 64), block(64);
+	switch (nw) {
+#define X(N) case N: hipLaunchKernelGGL(k_ecdsa_sign<N>, grid, block, 0, s, a); break;
 		ECAMD_FOR_NW(X)
 #undef X
 	default: return hipErrorInvalidValue;

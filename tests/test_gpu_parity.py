@@ -350,6 +350,34 @@ def test_ecdsa_verify_golden(gpu_ctx):
             cv.free()
 
 
+def test_ecdsa_sign_golden(gpu_ctx):
+    """the reference's ECDSA (fixed k) and RFC 6979 vectors: signature bytes must be identical"""
+    kats = json.load(open(os.path.join(GOLDEN, "ecdsa_kats.json")))
+    for curve in sorted({k["curve"] for k in kats}):
+        ks = [k for k in kats if k["curve"] == curve]
+        cv = gpu_ctx.curve(curve)
+        o = Oracle(curve)
+        try:
+            privs, nonces, dgs, exp = b"", b"", {}, b""
+            for hname in sorted({k["hash"] for k in ks}):
+                sel = [k for k in ks if k["hash"] == hname]
+                privs = b"".join(bytes.fromhex(k["priv_key"]).rjust(cv.qlen, b"\0")[-cv.qlen:] for k in sel)
+                nonces = b"".join((int(k["k"], 16) if k["k"] else rfc6979_nonce(curve, hname, bytes.fromhex(k["priv_key"]),
+                                                                                   bytes.fromhex(k["msg"]))).to_bytes(cv.qlen, "big") for k in sel)
+                dg = b"".join(digest(hname, bytes.fromhex(k["msg"])) for k in sel)
+                hl = len(dg) // len(sel)
+                sigs, st = cv.ecdsa_sign(privs, nonces, dg, hl)
+                assert set(st) == {0}
+                assert sigs == b"".join(bytes.fromhex(k["exp_sig"]) for k in sel), (curve, hname)
+                # edge nonces: 0, q, q-1, 1
+                q = CURVES[curve]["q"]
+                en = b"".join(v.to_bytes(cv.qlen, "big") for v in (0, q, q - 1, 1))
+                ep, ed = privs[:cv.qlen] * 4, dg[:hl] * 4
+                assert cv.ecdsa_sign(ep, en, ed, hl) == o.ecdsa_sign(ep, en, ed, hl)
+        finally:
+            cv.free()
+
+
 @pytest.mark.parametrize("curve", ["SECP192R1", "SECP224R1", "SECP256R1", "SECP384R1", "SECP521R1"])
 def test_ecccdh_derive_golden_and_oracle(gpu_ctx, curve):
     kats = [k for k in json.load(open(os.path.join(GOLDEN, "ecccdh_kats.json"))) if k["curve"] == curve]
