@@ -54,9 +54,14 @@ def work_model(curve_params, nw, slen):
     if p == 2**256 - 2**224 + 2**192 + 2**96 - 1 and slen <= 32:
         M, S = 117, 81
         dbl, add = (4, 4), (12, 4)                       # (mults, squarings)
-        nm = 2 + 2 + 4 * dbl[0] + 3 * add[0] + nwin * (4 * dbl[0] + add[0]) + 1 + 13 + 1 + 2 + 2
-        ns = 2 + 4 * dbl[1] + 3 * add[1] + nwin * (4 * dbl[1] + add[1]) + 255 + 1
-        return nm + ns, nm * M + ns * S, "k_smul_p256"
+        fin_k = 8                                        # k_p256_finalize: one inversion per 8 items
+        # k_smul_p256: to Montgomery 2M, on-curve 2M+2S, table 4 dbl + 3 add, nwin x (4 dbl + 1 add)
+        nm = 2 + 2 + 4 * dbl[0] + 3 * add[0] + nwin * (4 * dbl[0] + add[0])
+        ns = 2 + 4 * dbl[1] + 3 * add[1] + nwin * (4 * dbl[1] + add[1])
+        # k_p256_finalize: prefix 1M, (255S + 13M)/fin_k, back-substitution 2M, affine 1S + 3M, from Montgomery 2M
+        nm += 1 + 13 / fin_k + 2 + 3 + 2
+        ns += 255 / fin_k + 1
+        return nm + ns, nm * M + ns * S, "k_smul_p256 (+ k_p256_finalize)"
     mm_add, mm_dbl = 17, 16                              # RCB Alg. 1 / Alg. 3, generic a
     mm = 2 + 3                                           # to Montgomery (x, y) + on-curve check
     mm += 14 * mm_add                                    # table [2..15]P

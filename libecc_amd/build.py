@@ -16,7 +16,8 @@ DEPS = ["ecamd_field.cuh", "ecamd_point.cuh", "ecamd_u29.cuh", "ecamd_p256.cuh",
         "ecamd_curve_table.inc",
         os.path.join("..", "..", "include", "libecc_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-Wno-bitwise-instead-of-logical", "-DU29_ASM_MAD"]
 
 
 def _stale(target, inputs):

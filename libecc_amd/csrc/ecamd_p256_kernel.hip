@@ -122,7 +122,11 @@ template <class T> static __device__ __forceinline__ T sel(bool c, const T &a, c
 	return r;
 }
 
-__global__ __launch_bounds__(64) void k_smul_p256(EcamdSmulArgs A)
+// P256_WAVES (2, 3 or 4): register budget as waves per SIMD (512 / 256 -> 2 waves, 168 -> 3, 128 -> 4)
+#ifndef P256_WAVES
+#define P256_WAVES 3
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, P256_WAVES))) void k_smul_p256(EcamdSmulArgs A)
 {
 	const u32 i = blockIdx.x * 64 + threadIdx.x;
 	if (i >= A.n) {
@@ -168,21 +172,30 @@ __global__ __launch_bounds__(64) void k_smul_p256(EcamdSmulArgs A)
 	const TabEnt T1 = to_tab(P1);
 	const FYsel y1 = weaken<FYsel>(T1.Y);
 	tbl_store(tb, 0, T1);
-	const Jac P2 = dbl(P1);
-	tbl_store(tb, 1, to_tab(P2));
-	const Jac P3 = add_jac(P2, T1.X, y1, T1.Z, hz);
-	tbl_store(tb, 2, to_tab(P3));
-	const Jac P4 = dbl(P2);
-	tbl_store(tb, 3, to_tab(P4));
 	{
-		const Jac P5 = add_jac(P4, T1.X, y1, T1.Z, hz);
-		tbl_store(tb, 4, to_tab(P5));
-		const Jac P6 = dbl(P3);
-		tbl_store(tb, 5, to_tab(P6));
-		const Jac P7 = add_jac(P6, T1.X, y1, T1.Z, hz);
-		tbl_store(tb, 6, to_tab(P7));
-		const Jac P8 = dbl(P4);
-		tbl_store(tb, 7, to_tab(P8));
+		// [2..8]P; intermediate multiples are re-read from the table instead of being kept live
+		// (register pressure): 2P, 3P = 2P + P, 4P = 2(2P), 5P = 4P + P, 6P = 2(3P), 7P = 6P + P, 8P = 2(4P)
+		Jac Pa = dbl(P1);
+		tbl_store(tb, 1, to_tab(Pa));
+		Jac Pb = add_jac(Pa, T1.X, y1, T1.Z, hz);
+		tbl_store(tb, 2, to_tab(Pb));
+		Pa = dbl(Pa);
+		tbl_store(tb, 3, to_tab(Pa));
+		Pb = add_jac(Pa, T1.X, y1, T1.Z, hz);
+		tbl_store(tb, 4, to_tab(Pb));
+		{
+			const TabEnt t3 = tbl_load(tb, 2);
+			Jac P3;
+			P3.X = t3.X;
+			P3.Y = weaken<FY>(t3.Y);
+			P3.Z = t3.Z;
+			Pb = dbl(P3);
+		}
+		tbl_store(tb, 5, to_tab(Pb));
+		Pb = add_jac(Pb, T1.X, y1, T1.Z, hz);
+		tbl_store(tb, 6, to_tab(Pb));
+		Pa = dbl(Pa);
+		tbl_store(tb, 7, to_tab(Pa));
 	}
 
 	// ---- scalar: k (<= 32 bytes big-endian) -> k' = k + 0x88..8 over its 2*slen nibbles ----
@@ -264,6 +277,9 @@ __global__ __launch_bounds__(64) void k_smul_p256(EcamdSmulArgs A)
 		inf = inf & keep;
 	}
 
+	// ---- hand the Jacobian result to the finalisation kernel (k_p256_finalize) ----
+	// status: ECAMD_STATUS_REDO (exceptional pair met: the complete-formula kernel recomputes the item),
+	// 2 (infinity), or ECAMD_STATUS_JAC (finite: X, Y, Z stored in the item's first table slot)
 	if (bad) {
 		A.status[i] = ECAMD_STATUS_REDO;
 		return;
@@ -278,26 +294,107 @@ __global__ __launch_bounds__(64) void k_smul_p256(EcamdSmulArgs A)
 		}
 		return;
 	}
+	{
+		TabEnt R;  // same 28-word record as a table entry, Y left unfolded
+		R.X = acc.X;
+#pragma unroll
+		for (int w = 0; w < 9; w++) {
+			R.Y.l[w] = acc.Y.l[w];
+		}
+		R.Z = acc.Z;
+		tbl_store(tb, 0, R);
+	}
+	A.status[i] = ECAMD_STATUS_JAC;
+}
 
-	// ---- to affine: x = X / Z^2, y = Y / Z^3 (prj_pt_unique equivalent), out of Montgomery ----
+// ------------------------------------------------------------------------------------------
+// Finalisation: Jacobian -> affine for K items per lane with ONE field inversion (Montgomery's
+// trick): c_j = Z_0 ... Z_j, t = 1 / c_{K-1}, then Z_j^-1 = t c_{j-1}, t *= Z_j going down.
+// The scalar-multiplication kernel spends 255 S + 13 M per item on its inversion otherwise
+// (6 % of its time); here that cost is shared by K items and each item pays 3 extra mults.
+// Prefix products are parked in the item's second table slot.
+// ------------------------------------------------------------------------------------------
+#define FIN_K 8
+
+static __device__ __forceinline__ Jac load_jac(const u32 *tb)
+{
+	const TabEnt t = tbl_load(tb, 0);
+	Jac P;
+	P.X = t.X;
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		P.Y.l[w] = t.Y.l[w];
+	}
+	P.Z = t.Z;
+	return P;
+}
+
+__global__ __launch_bounds__(64) void k_p256_finalize(EcamdSmulArgs A, u32 nthreads)
+{
+	const u32 t = blockIdx.x * 64 + threadIdx.x;
+	if (t >= nthreads) {
+		return;
+	}
 	const Fcanon one = constant<Fcanon>(K::ONE);
-	const Fmul zc = weaken<Fmul>(mul(acc.Z, one));  // Z * 1 (Montgomery) = Z, exact digits
-	const Fmul zi = inv(zc);
-	const Fmul zi2 = weaken<Fmul>(sqr(zi));
-	const Fmul zi3 = weaken<Fmul>(mul(zi2, zi));
-	const auto ax = mul(acc.X, zi2);
-	const auto ay = mul(acc.Y, zi3);
+	// ---- up: prefix products ----
+	Fmul c = weaken<Fmul>(one);
+#pragma unroll 1
+	for (int j = 0; j < FIN_K; j++) {
+		const u32 i = t + (u32)j * nthreads;
+		if (i >= A.n) {
+			break;
+		}
+		u32 *tb = A.tbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
+		if (A.status[i] == ECAMD_STATUS_JAC) {
+			const Jac P = load_jac(tb);
+			c = weaken<Fmul>(mul(c, P.Z));
+		}
+		// park c_j (exact digits) in the second table slot
+		uint4 *d = (uint4 *)(tb + TBL_WORDS_PER_ENTRY);
+		d[0] = make_uint4(c.l[0], c.l[1], c.l[2], c.l[3]);
+		d[1] = make_uint4(c.l[4], c.l[5], c.l[6], c.l[7]);
+		d[2] = make_uint4(c.l[8], 0u, 0u, 0u);
+	}
+	// ---- one inversion ----
+	Fmul tinv = inv(c);
 	Fcanon plain1;
 #pragma unroll
 	for (int w = 0; w < 9; w++) {
 		plain1.l[w] = (w == 0) ? 1u : 0u;
 	}
-	u32 ow[8];
-	to_words(ow, canonical(mul(ax, plain1)));
-	store_be256(out, ow);
-	to_words(ow, canonical(mul(ay, plain1)));
-	store_be256(out + 32, ow);
-	A.status[i] = 0;
+	// ---- down ----
+#pragma unroll 1
+	for (int j = FIN_K - 1; j >= 0; j--) {
+		const u32 i = t + (u32)j * nthreads;
+		if (i >= A.n || A.status[i] != ECAMD_STATUS_JAC) {
+			continue;
+		}
+		u32 *tb = A.tbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
+		const Jac P = load_jac(tb);
+		Fmul zi = tinv;
+		if (j > 0) {
+			const u32 ip = t + (u32)(j - 1) * nthreads;
+			const uint4 *s = (const uint4 *)(A.tbl + (size_t)ip * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY) + TBL_WORDS_PER_ENTRY);
+			const uint4 a = s[0], b = s[1], cc = s[2];
+			Fmul cp;
+			cp.l[0] = a.x; cp.l[1] = a.y; cp.l[2] = a.z; cp.l[3] = a.w;
+			cp.l[4] = b.x; cp.l[5] = b.y; cp.l[6] = b.z; cp.l[7] = b.w;
+			cp.l[8] = cc.x;
+			zi = weaken<Fmul>(mul(tinv, cp));
+		}
+		tinv = weaken<Fmul>(mul(tinv, P.Z));
+		const Fmul zi2 = weaken<Fmul>(sqr(zi));
+		const Fmul zi3 = weaken<Fmul>(mul(zi2, zi));
+		const auto ax = mul(P.X, zi2);
+		const auto ay = mul(P.Y, zi3);
+		u8 *out = A.out + (size_t)i * 64;
+		u32 ow[8];
+		to_words(ow, canonical(mul(ax, plain1)));
+		store_be256(out, ow);
+		to_words(ow, canonical(mul(ay, plain1)));
+		store_be256(out + 32, ow);
+		A.status[i] = 0;
+	}
 }
 
 hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s)
@@ -306,5 +403,7 @@ hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s)
 		return hipSuccess;
 	}
 	hipLaunchKernelGGL(k_smul_p256, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+	const uint32_t nthreads = (a.n + FIN_K - 1) / FIN_K;
+	hipLaunchKernelGGL(k_p256_finalize, dim3((nthreads + 63) / 64), dim3(64), 0, s, a, nthreads);
 	return hipGetLastError();
 }

@@ -115,11 +115,31 @@ template <u64 VBO> struct MulOut {
 // cycles) where one v_mad_u64_u32 (5.3 cycles) does the job.  Passing the constants through
 // an empty asm makes them opaque SGPR values.
 #if defined(__HIPCC__)
+// keeps hipcc from re-associating "(acc >> 29) + products" into a separate product chain that
+// is merged back with a 64-bit add (15 extra v_lshl_add_u64 per multiplication)
+#define U29_PIN(acc) asm("" : "+v"(acc))
+#else
+#define U29_PIN(acc) (void)0
+#endif
+#if defined(__HIPCC__)
 #define U29_OPAQUE_Q() \
 	u32 q3 = P256::Q3, q6 = P256::Q6, q7 = P256::Q7, q8 = P256::Q8; \
 	asm volatile("" : "+s"(q3), "+s"(q6), "+s"(q7), "+s"(q8))
 #else
 #define U29_OPAQUE_Q() const u32 q3 = P256::Q3, q6 = P256::Q6, q7 = P256::Q7, q8 = P256::Q8
+#endif
+
+// acc += a * b.  With U29_ASM_MAD every product is an explicit v_mad_u64_u32 chained on the
+// column accumulator (hipcc otherwise splits a column into several chains and merges them with
+// 64-bit adds); the carry-out operand is a dead SGPR pair.
+#if defined(__HIPCC__) && defined(U29_ASM_MAD)
+#define U29_MAD_VV(acc, a, b) \
+	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(dead_) : "v"(a), "v"(b)); } while (0)
+#define U29_MAD_VS(acc, a, b) \
+	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(dead_) : "v"(a), "s"(b)); } while (0)
+#else
+#define U29_MAD_VV(acc, a, b) acc += (u64)(a) * (b)
+#define U29_MAD_VS(acc, a, b) acc += (u64)(a) * (b)
 #endif
 
 // raw kernels on plain arrays (bounds are checked by the typed wrappers below)
@@ -134,19 +154,20 @@ U29_FN void mul_raw(u32 *r, const u32 *a, const u32 *b)
 		const int hi = (k < 9) ? k : 8;
 #pragma unroll
 		for (int i = lo; i <= hi; i++) {
-			acc += (u64)a[i] * b[k - i];
+			U29_MAD_VV(acc, a[i], b[k - i]);
 		}
 		// reduction products m_i * q_j, i + j = k, j in {3, 6, 7, 8}, 0 <= i <= 8
-		if (k - 3 >= 0 && k - 3 <= 8) acc += (u64)m[k - 3] * q3;
-		if (k - 6 >= 0 && k - 6 <= 8) acc += (u64)m[k - 6] * q6;
-		if (k - 7 >= 0 && k - 7 <= 8) acc += (u64)m[k - 7] * q7;
-		if (k - 8 >= 0 && k - 8 <= 8) acc += (u64)m[k - 8] * q8;
+		if (k - 3 >= 0 && k - 3 <= 8) U29_MAD_VS(acc, m[k - 3], q3);
+		if (k - 6 >= 0 && k - 6 <= 8) U29_MAD_VS(acc, m[k - 6], q6);
+		if (k - 7 >= 0 && k - 7 <= 8) U29_MAD_VS(acc, m[k - 7], q7);
+		if (k - 8 >= 0 && k - 8 <= 8) U29_MAD_VS(acc, m[k - 8], q8);
 		if (k < 9) {
 			m[k] = (u32)acc & MASK;  // quotient digit (mpinv = 1); "- m_k" clears the digit
 		} else {
 			r[k - 9] = (u32)acc & MASK;
 		}
 		acc >>= W;
+		U29_PIN(acc);
 	}
 	r[8] = (u32)acc;
 }
@@ -168,21 +189,22 @@ U29_FN void sqr_raw(u32 *r, const u32 *a)
 		for (int i = lo; i <= hi; i++) {
 			const int j = k - i;
 			if (i < j) {
-				acc += (u64)a[i] * a2[j];
+				U29_MAD_VV(acc, a[i], a2[j]);
 			} else if (i == j) {
-				acc += (u64)a[i] * a[i];
+				U29_MAD_VV(acc, a[i], a[i]);
 			}
 		}
-		if (k - 3 >= 0 && k - 3 <= 8) acc += (u64)m[k - 3] * q3;
-		if (k - 6 >= 0 && k - 6 <= 8) acc += (u64)m[k - 6] * q6;
-		if (k - 7 >= 0 && k - 7 <= 8) acc += (u64)m[k - 7] * q7;
-		if (k - 8 >= 0 && k - 8 <= 8) acc += (u64)m[k - 8] * q8;
+		if (k - 3 >= 0 && k - 3 <= 8) U29_MAD_VS(acc, m[k - 3], q3);
+		if (k - 6 >= 0 && k - 6 <= 8) U29_MAD_VS(acc, m[k - 6], q6);
+		if (k - 7 >= 0 && k - 7 <= 8) U29_MAD_VS(acc, m[k - 7], q7);
+		if (k - 8 >= 0 && k - 8 <= 8) U29_MAD_VS(acc, m[k - 8], q8);
 		if (k < 9) {
 			m[k] = (u32)acc & MASK;
 		} else {
 			r[k - 9] = (u32)acc & MASK;
 		}
 		acc >>= W;
+		U29_PIN(acc);
 	}
 	r[8] = (u32)acc;
 }
