@@ -105,13 +105,13 @@ def cpu_baseline(curve, scalars, points, slen):
         r = RefLib(curve)
         probe = 64
         t0 = time.time()
-        r.scalar_mult(scalars[:probe * slen], points[:probe * 64], slen)
+        r.scalar_mult(scalars[:probe * slen], points[:probe * 2 * r.clen], slen)
         rate1 = probe / (time.time() - t0)
         # multi-thread probe (4 items per thread) to size the real sample: hosts rarely scale linearly
         n0 = min(nmax, 4 * cores)
-        _, _, el0, _ = r.scalar_mult(scalars[:n0 * slen], points[:n0 * 64], slen, nthreads=cores, timing=True)
+        _, _, el0, _ = r.scalar_mult(scalars[:n0 * slen], points[:n0 * 2 * r.clen], slen, nthreads=cores, timing=True)
         n = int(min(nmax, max(n0, (n0 / el0) * 12.0)))
-        _, st, el, _ = r.scalar_mult(scalars[:n * slen], points[:n * 64], slen, nthreads=cores, timing=True)
+        _, st, el, _ = r.scalar_mult(scalars[:n * slen], points[:n * 2 * r.clen], slen, nthreads=cores, timing=True)
         return {"value": n / el, "unit": "scalar-mults/s", "cores": cores, "kind": "reference",
                 "one_core_value": rate1,
                 "sample": f"first {n} items of the same batch, prj_pt_mul+prj_pt_unique of the unmodified "
@@ -120,7 +120,7 @@ def cpu_baseline(curve, scalars, points, slen):
     o = Oracle(curve)
     n = min(nmax, 4096)
     t0 = time.time()
-    o.scalar_mult(scalars[:n * slen], points[:n * 64], slen)
+    o.scalar_mult(scalars[:n * slen], points[:n * 2 * o.clen], slen)
     el = time.time() - t0
     return {"value": n / el, "unit": "scalar-mults/s", "cores": 1, "kind": "port",
             "sample": f"first {n} items of the same batch through oracle/ecc_oracle.c, 1 thread"}
@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-log2", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--curve", default=CURVE, help="ad-hoc runs on another built-in curve (the driver uses the default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -150,27 +151,29 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from oracles import CURVES, Oracle
-    cp = CURVES[CURVE]
+    curve = args.curve
+    cp = CURVES[curve]
     q = cp["q"]
     B = 1 << args.batch_log2
-    slen, clen = 32, 32
+    slen, clen = (q.bit_length() + 7) // 8, (cp["p"].bit_length() + 7) // 8
+    plen = 2 * clen
 
     ctx = libecc_amd.Context(local_rank)
-    cv = ctx.curve(CURVE)
+    cv = ctx.curve(curve)
 
     # ---- synthetic inputs (seeded; rank-dependent shard) ----
     rng = np.random.default_rng(SEED + rank)
 
     # uniform in [1, q-1]: rejection-free by reducing 320 random bits (bias 2^-64)
     t_setup = time.time()
-    raw = rng.integers(0, 256, size=(2, B, 40), dtype=np.uint8)
+    raw = rng.integers(0, 256, size=(2, B, slen + 8), dtype=np.uint8)
     qm1 = q - 1
 
     def reduce_rows(rows):
-        out = bytearray(B * 32)
+        out = bytearray(B * slen)
         for i in range(B):
             v = (int.from_bytes(rows[i].tobytes(), "big") % qm1) + 1
-            out[32 * i:32 * i + 32] = v.to_bytes(32, "big")
+            out[slen * i:slen * i + slen] = v.to_bytes(slen, "big")
         return bytes(out)
 
     scalars_h = reduce_rows(raw[0])
@@ -181,8 +184,8 @@ def main():
     torch.cuda.set_stream(stream)
     d_scalars = torch.frombuffer(bytearray(scalars_h), dtype=torch.uint8).to(dev)
     d_t = torch.frombuffer(bytearray(t_h), dtype=torch.uint8).to(dev)
-    d_points = torch.empty(B * 64, dtype=torch.uint8, device=dev)
-    d_out = torch.empty(B * 64, dtype=torch.uint8, device=dev)
+    d_points = torch.empty(B * plen, dtype=torch.uint8, device=dev)
+    d_out = torch.empty(B * plen, dtype=torch.uint8, device=dev)
     d_status = torch.empty(B, dtype=torch.uint8, device=dev)
     # base points P_i = [t_i]G, produced on the GPU by the same engine (fixed base), untimed
     cv.scalar_mult_dev(B, d_t.data_ptr(), slen, None, d_points.data_ptr(), d_status.data_ptr(), stream.cuda_stream)
@@ -190,7 +193,7 @@ def main():
     assert int(d_status.max().item()) == 0, "base-point generation produced an error status"
     gathered = None
     if world > 1:
-        gathered = torch.empty(world * B * 64, dtype=torch.uint8, device=dev)
+        gathered = torch.empty(world * B * plen, dtype=torch.uint8, device=dev)
 
     def step():
         cv.scalar_mult_dev(B, d_scalars.data_ptr(), slen, d_points.data_ptr(), d_out.data_ptr(),
@@ -206,11 +209,11 @@ def main():
     st_h = d_status.cpu().numpy().tobytes()
     assert set(st_h) == {0}, "unexpected status in the synthetic batch"
     idx = np.random.default_rng(1).choice(B, size=min(B, 128), replace=False)
-    o = Oracle(CURVE)
-    sub_s = b"".join(scalars_h[32 * i:32 * i + 32] for i in idx)
-    sub_p = b"".join(pts_h[64 * i:64 * i + 64] for i in idx)
+    o = Oracle(curve)
+    sub_s = b"".join(scalars_h[slen * i:slen * i + slen] for i in idx)
+    sub_p = b"".join(pts_h[plen * i:plen * i + plen] for i in idx)
     exp, est = o.scalar_mult(sub_s, sub_p)
-    got = b"".join(out_h[64 * i:64 * i + 64] for i in idx)
+    got = b"".join(out_h[plen * i:plen * i + plen] for i in idx)
     if got != exp or set(est) != {0}:
         raise SystemExit("PARITY FAILURE: GPU output differs from the CPU oracle")
     setup_s = time.time() - t_setup
@@ -249,15 +252,15 @@ def main():
         if world == 1:
             peak, ub = measured_mad_peak()
         nominal_quarter = 256 * 4 * 16 * 2.4e9 / 4.0   # SURVEY.md 8d planning figure (quarter rate)
-        alg_bytes = 160.0                              # 32 B scalar + 64 B point in + 64 B out
+        alg_bytes = float(slen + 2 * plen)             # scalar + affine point in + affine point out (160 B for P-256)
         hbm_rate = B * alg_bytes / (launch_ms * 1e-3)
         line = {
-            "metric": "scalar-mults/sec (secp256r1, batch=2^20, variable base, affine out, bit-exact vs CPU)",
+            "metric": f"scalar-mults/sec ({curve.lower()}, batch=2^{args.batch_log2}, variable base, affine out, bit-exact vs CPU)",
             "value": value, "unit": "scalar-mults/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32 (29-bit limbs, v_mad_u64_u32 integer MAD, u64 accumulators)",
             "data": "synthetic (seeded): scalars uniform in [1,q-1], base points P_i=[t_i]G",
-            "config": {"workload": f"{CURVE} prj_pt_mul+prj_pt_unique, batch 2^{args.batch_log2} per GPU "
+            "config": {"workload": f"{curve} prj_pt_mul+prj_pt_unique, batch 2^{args.batch_log2} per GPU "
                                    "(BASELINE.json configs[1])",
                        "batch_per_gpu": B, "scalar_len": slen, "window": "signed fixed w=4",
                        "sharding": "contiguous per-rank shards" + (", RCCL all_gather of outputs per step" if world > 1 else ""),
@@ -280,7 +283,7 @@ def main():
             line["ubench"] = {k: (v["cycles_per_wave_instr_per_simd"] if isinstance(v, dict) else v)
                               for k, v in ub.items() if k.startswith("v_")}
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(CURVE, scalars_h, pts_h, slen)
+            line["cpu_baseline"] = cpu_baseline(curve, scalars_h, pts_h, slen)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))
