@@ -12,7 +12,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libecc_amd.so")
 SOURCES = ["ecamd_kernels.hip", "ecamd_p256_kernel.hip", "ecamd_host.cpp"]
-DEPS = ["ecamd_field.cuh", "ecamd_point.cuh", "ecamd_u29.cuh", "ecamd_p256.cuh", "ecamd_internal.h",
+DEPS = ["ecamd_field.cuh", "ecamd_point.cuh", "ecamd_u29.cuh", "ecamd_p256.cuh", "ecamd_u29g.cuh", "ecamd_jacg.cuh",
+        "ecamd_internal.h",
         "ecamd_curve_table.inc",
         os.path.join("..", "..", "include", "libecc_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -27,24 +28,38 @@ def _stale(target, inputs):
     return any(os.path.getmtime(i) > t for i in inputs)
 
 
+G29_SIZES = [192, 224, 255, 256, 320, 384, 448, 511, 512, 521]
+
+
+def _jobs():
+    """(source, object, extra flags): ecamd_g29_kernel.hip is compiled once per field size and once
+    more as the dispatcher, so that the big template instantiations build in parallel."""
+    jobs = [(src, os.path.splitext(src)[0] + ".o", []) for src in SOURCES]
+    jobs += [("ecamd_g29_kernel.hip", f"ecamd_g29_{pb}.o", [f"-DG29_PB={pb}"]) for pb in G29_SIZES]
+    jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_dispatch.o", ["-DG29_DISPATCH"]))
+    return jobs
+
+
 def build(force=False, verbose=False):
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
     deps = [os.path.join(CSRC, d) for d in DEPS]
-    objs = []
-    for src in SOURCES:
-        spath = os.path.join(CSRC, src)
-        obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
-        if force or _stale(obj, [spath] + deps):
-            cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", spath, "-o", obj]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
-        objs.append(obj)
-    if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    todo, objs = [], []
+    for src, obj, extra in _jobs():
+        spath, opath = os.path.join(CSRC, src), os.path.join(LIBDIR, obj)
+        objs.append(opath)
+        if force or _stale(opath, [spath] + deps):
+            todo.append([HIPCC] + FLAGS + extra + ["-x", "hip", "-c", spath, "-o", opath])
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1))) as ex:
+        list(ex.map(run, todo))
+    if force or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
 
 

@@ -1,0 +1,458 @@
+// libecc_amd/csrc/ecamd_g29_kernel.hip -- radix-2^29 Jacobian fast path of the batched prj_pt_mul for
+// EVERY curve size (one instantiation per |p|; curves of equal size share the code, their
+// constants live in __constant__ memory).  Same pipeline as ecamd_p256_kernel.hip:
+//   k_smul_g<PB>      import + on-curve check, table [1..8]P, signed window w = 4, Jacobian result
+//   k_finalize_g<PB>  Jacobian -> affine, one inversion per 8 items (Montgomery's trick)
+// Lanes that meet an exceptional pair of the incomplete addition (including inputs of small order
+// on cofactor curves, or a zero Z at the end) are marked ECAMD_STATUS_REDO and recomputed by the
+// complete-formula kernel k_smul<NW>, so the observable result is the reference's for every input.
+// Replaces prj_pt_import_from_aff_buf -> prj_pt_mul -> prj_pt_unique -> prj_pt_export_to_aff_buf
+// (curves/prj_pt.c:511,1759,241,600 in /root/reference/src).
+#include <hip/hip_runtime.h>
+#include "ecamd_jacg.cuh"
+#include "ecamd_internal.h"
+
+using namespace jacg;
+typedef uint8_t u8;
+
+// This file is compiled once per field size (-DG29_PB=<bits>: the kernels of that size plus its own
+// copy of the constant table) and once more with -DG29_DISPATCH (the size -> launcher switch), so
+// that the instantiations build in parallel (libecc_amd/build.py).
+#define G29_SLOTS 8
+template <int NL> struct SlotsG { CurveG<NL> s[G29_SLOTS]; };
+
+template <int PB> struct TabGP;
+template <int PB> struct Lay {
+	static constexpr int NL = Cfg<PB>::NL;
+	static constexpr int NW = (PB + 31) / 32;          // saturated words of a coordinate
+	static constexpr int ENTW = ((3 * NL + 3) / 4) * 4;  // words per table entry (16-byte multiple)
+	static constexpr int KW = (PB + 31) / 32 + 1;      // words of the recoded scalar (fast path: slen <= 4 KW - 4)
+};
+
+// len bytes big-endian -> NW little-endian words
+template <int NW> static __device__ __forceinline__ void load_be(const u8 *src, int len, u32 *w)
+{
+#pragma unroll
+	for (int i = 0; i < NW; i++) {
+		u32 x = 0;
+#pragma unroll
+		for (int b = 0; b < 4; b++) {
+			const int pos = 4 * i + b;
+			if (pos < len) {
+				x |= (u32)src[len - 1 - pos] << (8 * b);
+			}
+		}
+		w[i] = x;
+	}
+}
+template <int NW> static __device__ __forceinline__ void store_be(u8 *dst, int len, const u32 *w)
+{
+#pragma unroll
+	for (int i = 0; i < NW; i++) {
+#pragma unroll
+		for (int b = 0; b < 4; b++) {
+			const int pos = 4 * i + b;
+			if (pos < len) {
+				dst[len - 1 - pos] = (u8)(w[i] >> (8 * b));
+			}
+		}
+	}
+}
+
+template <int PB> static __device__ __forceinline__ void tab_store(u32 *base, int e, const TabEnt<PB> &T)
+{
+	constexpr int NL = Lay<PB>::NL, ENTW = Lay<PB>::ENTW;
+	u32 buf[ENTW];
+#pragma unroll
+	for (int i = 0; i < NL; i++) {
+		buf[i] = T.X.l[i];
+		buf[NL + i] = T.Y.l[i];
+		buf[2 * NL + i] = T.Z.l[i];
+	}
+#pragma unroll
+	for (int i = 3 * NL; i < ENTW; i++) {
+		buf[i] = 0;
+	}
+	uint4 *d = (uint4 *)(base + (size_t)e * ENTW);
+#pragma unroll
+	for (int i = 0; i < ENTW / 4; i++) {
+		d[i] = make_uint4(buf[4 * i], buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3]);
+	}
+}
+template <int PB> static __device__ __forceinline__ TabEnt<PB> tab_load(const u32 *base, u32 e)
+{
+	constexpr int NL = Lay<PB>::NL, ENTW = Lay<PB>::ENTW;
+	u32 buf[ENTW];
+	const uint4 *s = (const uint4 *)(base + (size_t)e * ENTW);
+#pragma unroll
+	for (int i = 0; i < ENTW / 4; i++) {
+		const uint4 v = s[i];
+		buf[4 * i] = v.x;
+		buf[4 * i + 1] = v.y;
+		buf[4 * i + 2] = v.z;
+		buf[4 * i + 3] = v.w;
+	}
+	TabEnt<PB> T;
+#pragma unroll
+	for (int i = 0; i < NL; i++) {
+		T.X.l[i] = buf[i];
+		T.Y.l[i] = buf[NL + i];
+		T.Z.l[i] = buf[2 * NL + i];
+	}
+	return T;
+}
+// Jacobian result record (all three coordinates in class FA) in the first table slot
+template <int PB> static __device__ __forceinline__ void jac_store(u32 *base, const Jac<PB> &P)
+{
+	TabEnt<PB> T;
+	T.X = P.X;
+	T.Z = P.Z;
+#pragma unroll
+	for (int i = 0; i < Lay<PB>::NL; i++) {
+		T.Y.l[i] = P.Y.l[i];
+	}
+	tab_store<PB>(base, 0, T);
+}
+template <int PB> static __device__ __forceinline__ Jac<PB> jac_load(const u32 *base)
+{
+	const TabEnt<PB> T = tab_load<PB>(base, 0);
+	Jac<PB> P;
+	P.X = T.X;
+	P.Z = T.Z;
+#pragma unroll
+	for (int i = 0; i < Lay<PB>::NL; i++) {
+		P.Y.l[i] = T.Y.l[i];
+	}
+	return P;
+}
+
+template <class T> static __device__ __forceinline__ T selg(bool c, const T &a, const T &b)
+{
+	T r;
+#pragma unroll
+	for (int i = 0; i < T::C::NL; i++) {
+		r.l[i] = c ? a.l[i] : b.l[i];
+	}
+	return r;
+}
+
+template <int PB> __global__ __launch_bounds__(64) void k_smul_g(EcamdSmulArgs A, int gslot)
+{
+	typedef Lay<PB> L;
+	typedef typename Cls<PB>::FA FA;
+	typedef typename Cls<PB>::FM FM;
+	typedef typename Cls<PB>::FC FC;
+	constexpr int NL = L::NL, NW = L::NW, KW = L::KW;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	const int clen = (int)A.clen;
+	u8 *out = A.out + (size_t)i * 2 * clen;
+
+	// ---- import (curves/prj_pt.c:511-552): coordinates < p, on the curve ----
+	const u8 *pin = A.points + (size_t)i * A.pstride;
+	u32 xw[NW], yw[NW];
+	load_be<NW>(pin, clen, xw);
+	load_be<NW>(pin + clen, clen, yw);
+	const auto xd = from_words<PB, NW>(xw), yd = from_words<PB, NW>(yw);
+	bool ok;
+	{
+		u32 bx = 0, by = 0;
+#pragma unroll
+		for (int j = 0; j < NL; j++) {
+			bx = (xd.l[j] - K.p[j] - bx) >> 31;
+			by = (yd.l[j] - K.p[j] - by) >> 31;
+		}
+		ok = (bx != 0) & (by != 0);  // both strictly below p
+	}
+	const FC r2 = constant<FC>(K.r2), onec = constant<FC>(K.one);
+	const auto xm = mul(xd, r2, K), ym = mul(yd, r2, K);  // Montgomery form, < 2p, exact digits
+	{
+		// y^2 == (x^2 + a) x + b
+		const auto t = mulc(carry(add(sqr(xm, K), constant<FC>(K.a))), xm, K);
+		const auto rhs = add(t, constant<FC>(K.b));
+		const auto dif = carry(sub_auto<1>(rhs, sqr(ym, K), K));
+		ok = ok & is_zero_mulout(mulc(dif, onec, K), K);
+	}
+	if (!ok) {
+		A.status[i] = 1;
+		for (int b = 0; b < 2 * clen; b++) {
+			out[b] = 0;
+		}
+		return;
+	}
+
+	// ---- table [1..8]P ----
+	u32 *tb = A.tbl + (size_t)i * (8 * L::ENTW);
+	Jac<PB> P1;
+	P1.X = weaken<FA>(xm);
+	P1.Y = weaken<FA>(ym);
+	P1.Z = weaken<FA>(onec);
+	bool hz, bad = false;
+	TabEnt<PB> T1;
+	T1.X = P1.X;
+	T1.Y = weaken<FM>(ym);
+	T1.Z = P1.Z;
+	const FA y1 = weaken<FA>(T1.Y);
+	tab_store<PB>(tb, 0, T1);
+	{
+		Jac<PB> Pa = dbl(P1, K);
+		tab_store<PB>(tb, 1, to_tab(Pa, K));
+		Jac<PB> Pb = add_jac(Pa, T1.X, y1, T1.Z, hz, K);
+		bad |= hz;
+		tab_store<PB>(tb, 2, to_tab(Pb, K));
+		Pa = dbl(Pa, K);
+		tab_store<PB>(tb, 3, to_tab(Pa, K));
+		Pb = add_jac(Pa, T1.X, y1, T1.Z, hz, K);
+		bad |= hz;
+		tab_store<PB>(tb, 4, to_tab(Pb, K));
+		{
+			const TabEnt<PB> t3 = tab_load<PB>(tb, 2);
+			Jac<PB> P3;
+			P3.X = t3.X;
+			P3.Y = weaken<FA>(t3.Y);
+			P3.Z = t3.Z;
+			Pb = dbl(P3, K);
+		}
+		tab_store<PB>(tb, 5, to_tab(Pb, K));
+		Pb = add_jac(Pb, T1.X, y1, T1.Z, hz, K);
+		bad |= hz;
+		tab_store<PB>(tb, 6, to_tab(Pb, K));
+		Pa = dbl(Pa, K);
+		tab_store<PB>(tb, 7, to_tab(Pa, K));
+	}
+
+	// ---- scalar: k' = k + 0x88..8 over its 2*slen nibbles, left-aligned in KW words ----
+	const u8 *sc = A.scalars + (size_t)i * A.sstride;
+	const int slen = (int)A.slen;  // <= 4 * (KW - 1), checked by the host
+	u32 kw[KW];
+	load_be<KW>(sc, slen, kw);
+	u32 carry_bit;
+	{
+		uint64_t c = 0;
+#pragma unroll
+		for (int w = 0; w < KW; w++) {
+			const int nb = slen - 4 * w;
+			const u32 add8 = (nb >= 4) ? 0x88888888u : (nb == 3 ? 0x00888888u : (nb == 2 ? 0x00008888u : (nb == 1 ? 0x00000088u : 0u)));
+			c += (uint64_t)kw[w] + add8;
+			kw[w] = (u32)c;
+			c >>= 32;
+		}
+		const int bit = 8 * slen;  // the carry out of the top nibble sits just above the scalar's bytes
+		u32 cb = 0;
+#pragma unroll
+		for (int w = 0; w < KW; w++) {
+			if (w == (bit >> 5)) {
+				cb = (kw[w] >> (bit & 31)) & 1u;
+			}
+		}
+		carry_bit = cb;
+		// left-align: the scalar's top nibble becomes the top nibble of kw[KW-1]
+		for (int s = slen; s < 4 * KW; s++) {
+#pragma unroll
+			for (int w = KW - 1; w > 0; w--) {
+				kw[w] = (kw[w] << 8) | (kw[w - 1] >> 24);
+			}
+			kw[0] <<= 8;
+		}
+	}
+
+	// ---- signed fixed window, left to right ----
+	Jac<PB> acc = P1;
+	bool inf = (carry_bit == 0);
+	const int nwin = 2 * slen;
+#pragma unroll 1
+	for (int t = 0; t < nwin; t++) {
+#pragma unroll 1
+		for (int d = 0; d < 4; d++) {
+			acc = dbl(acc, K);
+		}
+		const int dig = (int)(kw[KW - 1] >> 28) - 8;
+#pragma unroll
+		for (int w = KW - 1; w > 0; w--) {
+			kw[w] = (kw[w] << 4) | (kw[w - 1] >> 28);
+		}
+		kw[0] <<= 4;
+		const u32 mag = (u32)(dig < 0 ? -dig : dig);
+		const TabEnt<PB> T = tab_load<PB>(tb, mag ? mag - 1 : 0);
+		const FA ty = selg(dig < 0, neg<PB>(T.Y, K), weaken<FA>(T.Y));
+		const Jac<PB> S = add_jac(acc, T.X, ty, T.Z, hz, K);
+		const bool use_t = inf & (mag != 0);
+		const bool keep = (mag == 0);
+		bad = bad | (!inf & !keep & hz);
+		acc.X = selg(keep, acc.X, selg(use_t, T.X, S.X));
+		acc.Y = selg(keep, acc.Y, selg(use_t, ty, S.Y));
+		acc.Z = selg(keep, acc.Z, selg(use_t, T.Z, S.Z));
+		inf = inf & keep;
+	}
+	// a doubling can reach infinity silently on curves with points of even order: exact test of Z
+	if (!inf) {
+		bad = bad | is_zero_mulout(mulc(acc.Z, onec, K), K);
+	}
+	if (bad) {
+		A.status[i] = ECAMD_STATUS_REDO;
+		return;
+	}
+	if (inf) {
+		A.status[i] = 2;
+		for (int b = 0; b < 2 * clen; b++) {
+			out[b] = 0;
+		}
+		return;
+	}
+	jac_store<PB>(tb, acc);
+	A.status[i] = ECAMD_STATUS_JAC;
+}
+
+#define FING_K 8
+template <int PB> __global__ __launch_bounds__(64) void k_finalize_g(EcamdSmulArgs A, int gslot, u32 nthreads)
+{
+	typedef Lay<PB> L;
+	typedef typename Cls<PB>::FM FM;
+	typedef typename Cls<PB>::FC FC;
+	constexpr int NL = L::NL, NW = L::NW, ENTW = L::ENTW;
+	const u32 t = blockIdx.x * 64 + threadIdx.x;
+	if (t >= nthreads) {
+		return;
+	}
+	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	const FC onec = constant<FC>(K.one);
+	const int clen = (int)A.clen;
+	FM c = weaken<FM>(onec);
+#pragma unroll 1
+	for (int j = 0; j < FING_K; j++) {
+		const u32 i = t + (u32)j * nthreads;
+		if (i >= A.n) {
+			break;
+		}
+		u32 *tb = A.tbl + (size_t)i * (8 * ENTW);
+		if (A.status[i] == ECAMD_STATUS_JAC) {
+			const Jac<PB> P = jac_load<PB>(tb);
+			c = weaken<FM>(mulc(c, P.Z, K));
+		}
+		u32 *d = tb + ENTW;  // park the prefix product in the second table slot
+#pragma unroll
+		for (int w = 0; w < NL; w++) {
+			d[w] = c.l[w];
+		}
+	}
+	FM tinv = inv<PB>(c, K);
+	FC plain1;
+#pragma unroll
+	for (int w = 0; w < NL; w++) {
+		plain1.l[w] = (w == 0) ? 1u : 0u;
+	}
+#pragma unroll 1
+	for (int j = FING_K - 1; j >= 0; j--) {
+		const u32 i = t + (u32)j * nthreads;
+		if (i >= A.n || A.status[i] != ECAMD_STATUS_JAC) {
+			continue;
+		}
+		u32 *tb = A.tbl + (size_t)i * (8 * ENTW);
+		const Jac<PB> P = jac_load<PB>(tb);
+		FM zi = tinv;
+		if (j > 0) {
+			const u32 ip = t + (u32)(j - 1) * nthreads;
+			const u32 *s = A.tbl + (size_t)ip * (8 * ENTW) + ENTW;
+			FM cp;
+#pragma unroll
+			for (int w = 0; w < NL; w++) {
+				cp.l[w] = s[w];
+			}
+			zi = weaken<FM>(mul(tinv, cp, K));
+		}
+		tinv = weaken<FM>(mulc(tinv, P.Z, K));
+		const FM zi2 = weaken<FM>(sqr(zi, K));
+		const FM zi3 = weaken<FM>(mul(zi2, zi, K));
+		const auto ax = mulc(P.X, zi2, K);
+		const auto ay = mulc(P.Y, zi3, K);
+		u8 *out = A.out + (size_t)i * 2 * clen;
+		u32 dg[NL], ow[NW];
+		canonical_digits(dg, mul(ax, plain1, K), K);
+		to_words<NL, NW>(ow, dg);
+		store_be<NW>(out, clen, ow);
+		canonical_digits(dg, mul(ay, plain1, K), K);
+		to_words<NL, NW>(ow, dg);
+		store_be<NW>(out + clen, clen, ow);
+		A.status[i] = 0;
+	}
+}
+
+#ifdef G29_PB
+// ---- one field size: constants + launch / upload entry points with the size in their name ----
+#define G29_CAT2(a, b) a##b
+#define G29_CAT(a, b) G29_CAT2(a, b)
+__constant__ SlotsG<Lay<G29_PB>::NL> G29_CAT(g_g29_, G29_PB);
+template <> struct TabGP<G29_PB> {
+	static __device__ __forceinline__ const CurveG<Lay<G29_PB>::NL> &get(int slot) { return G29_CAT(g_g29_, G29_PB).s[slot]; }
+};
+
+hipError_t G29_CAT(ecamd_g29_upload_, G29_PB)(int slot, const void *img, size_t bytes)
+{
+	typedef CurveG<Lay<G29_PB>::NL> CK;
+	if (bytes != sizeof(CK) || slot < 0 || slot >= G29_SLOTS) {
+		return hipErrorInvalidValue;
+	}
+	return hipMemcpyToSymbol(HIP_SYMBOL(G29_CAT(g_g29_, G29_PB)), img, bytes, (size_t)slot * sizeof(CK), hipMemcpyHostToDevice);
+}
+
+hipError_t G29_CAT(ecamd_g29_launch_, G29_PB)(int gslot, const EcamdSmulArgs &a, hipStream_t s)
+{
+	const dim3 grid((a.n + 63) / 64), block(64);
+	const uint32_t nthreads = (a.n + FING_K - 1) / FING_K;
+	const dim3 fgrid((nthreads + 63) / 64);
+	hipLaunchKernelGGL(k_smul_g<G29_PB>, grid, block, 0, s, a, gslot);
+	hipLaunchKernelGGL(k_finalize_g<G29_PB>, fgrid, block, 0, s, a, gslot, nthreads);
+	return hipGetLastError();
+}
+#endif
+
+#ifdef G29_DISPATCH
+// ---- host-side dispatch on |p| ----
+#define G29_FOR_PB(X) X(192) X(224) X(255) X(256) X(320) X(384) X(448) X(511) X(512) X(521)
+#define X(PB) \
+	hipError_t ecamd_g29_upload_##PB(int slot, const void *img, size_t bytes); \
+	hipError_t ecamd_g29_launch_##PB(int gslot, const EcamdSmulArgs &a, hipStream_t s);
+G29_FOR_PB(X)
+#undef X
+
+int ecamd_g29_supported(int pbits)
+{
+	switch (pbits) {
+#define X(PB) case PB: return 1;
+		G29_FOR_PB(X)
+#undef X
+	default: return 0;
+	}
+}
+int ecamd_g29_nl(int pbits) { return g29::nl_for(pbits); }
+int ecamd_g29_slots(void) { return G29_SLOTS; }
+uint32_t ecamd_g29_table_words(int pbits) { return 8u * (uint32_t)(((3 * g29::nl_for(pbits) + 3) / 4) * 4); }
+uint32_t ecamd_g29_max_slen(int pbits) { return 4u * (uint32_t)((pbits + 31) / 32); }
+size_t ecamd_g29_image_bytes(int pbits) { return (size_t)((6 + g29::NBIAS) * g29::nl_for(pbits) + 4) * 4; }
+
+hipError_t ecamd_g29_upload(int pbits, int slot, const void *img, size_t bytes)
+{
+	switch (pbits) {
+#define X(PB) case PB: return ecamd_g29_upload_##PB(slot, img, bytes);
+		G29_FOR_PB(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+}
+
+hipError_t ecamd_launch_smul_g29(int pbits, int gslot, const EcamdSmulArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	switch (pbits) {
+#define X(PB) case PB: return ecamd_g29_launch_##PB(gslot, a, s);
+		G29_FOR_PB(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+}
+#endif

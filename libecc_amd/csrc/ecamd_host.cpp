@@ -216,6 +216,7 @@ struct ecamd_ctx {
 	uint8_t *stage[ECAMD_NSTAGE];
 	size_t stage_bytes[ECAMD_NSTAGE];
 	bool slot_used[ECAMD_MAX_SLOTS_HOST];
+	bool gslot_used[640][8];  // radix-2^29 constant slots, indexed by |p| in bits
 	std::mutex mu;
 };
 
@@ -229,7 +230,8 @@ struct ecamd_curve {
 	int pbits, qbits;
 	Big p, a, b, order, gx, gy, q;
 	uint8_t *d_gen;  // generator, affine X||Y big-endian, in HBM
-	bool is_p256;    // exactly secp256r1: eligible for the radix-2^29 Jacobian fast path
+	bool is_p256;    // exactly secp256r1: hand-specialised radix-2^29 Jacobian kernel
+	int gslot;       // constant slot of the generic radix-2^29 Jacobian kernel (-1: none)
 };
 
 static const int k_widths[] = {6, 7, 8, 10, 12, 14, 16, 17};
@@ -282,6 +284,7 @@ extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
 	for (int i = 0; i < ECAMD_MAX_SLOTS_HOST; i++) {
 		c->slot_used[i] = false;
 	}
+	memset(c->gslot_used, 0, sizeof(c->gslot_used));
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
 		delete c;
 		return fail("ecamd_ctx_create: hipStreamCreate failed");
@@ -410,6 +413,72 @@ static int build_and_upload(ecamd_curve *cv)
 	return 0;
 }
 
+// 29-bit digits of a (nl of them, the last one takes whatever is left)
+static void big_digits29(uint32_t *dst, int nl, const Big &a)
+{
+	const int bits = big_bitlen(a);
+	for (int i = 0; i < nl; i++) {
+		uint64_t d = 0;
+		const int lo = 29 * i, hi = (i == nl - 1) ? (bits > lo + 29 ? bits : lo + 29) : lo + 29;
+		for (int b = lo; b < hi && b < bits; b++) {
+			if ((a[(size_t)b / 32] >> (b % 32)) & 1u) {
+				d |= 1ull << (b - lo);
+			}
+		}
+		dst[i] = (uint32_t)d;
+	}
+}
+static Big big_shl(const Big &a, int e)
+{
+	return big_mul(a, big_pow2(e));
+}
+
+// CurveG<NL> image of ecamd_u29g.cuh: p r2 one a b pm2 (NL digits each), 16 bias tables, mpinv pbits
+// a_is_m3 pad -- mirrored by tools/g29_consts.py, which the CPU tests use against Python integers
+static int upload_g29(ecamd_curve *cv)
+{
+	const int pbits = cv->pbits, nl = ecamd_g29_nl(pbits);
+	const Big &p = cv->p;
+	const Big R = big_mod(big_pow2(29 * nl), p);
+	Big two(1, 2), three(1, 3);
+	static const int step[16] = {2, 4, 6, 8, 10, 12, 14, 16, 2, 4, 6, 8, 10, 12, 14, 16};
+	static const int sv[16] = {1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2};
+	const int topsh = pbits - 29 * (nl - 1);
+	const int off = (1 - topsh) > 0 ? (1 - topsh) : 0;
+	std::vector<uint32_t> img((size_t)(6 + 16) * nl + 4, 0);
+	big_digits29(&img[0 * nl], nl, p);
+	big_digits29(&img[1 * nl], nl, big_mulmod(R, R, p));
+	big_digits29(&img[2 * nl], nl, R);
+	big_digits29(&img[3 * nl], nl, big_mulmod(cv->a, R, p));
+	big_digits29(&img[4 * nl], nl, big_mulmod(cv->b, R, p));
+	big_digits29(&img[5 * nl], nl, big_sub(p, two));
+	for (int t = 0; t < 16; t++) {
+		uint32_t *l = &img[(size_t)(6 + t) * nl];
+		big_digits29(l, nl, big_shl(p, step[t] + off));
+		const uint32_t M = 1u << (29 + sv[t]), BW = 1u << sv[t];
+		if (l[nl - 1] < BW) {
+			return fail("internal: bias table underflow");
+		}
+		l[0] += M;
+		for (int j = 1; j < nl - 1; j++) {
+			l[j] += M - BW;
+		}
+		l[nl - 1] -= BW;
+	}
+	uint32_t p0 = p[0], x = 1;
+	for (int i = 0; i < 5; i++) {
+		x *= 2u - p0 * x;
+	}
+	img[(size_t)22 * nl + 0] = (0u - x) & 0x1fffffffu;
+	img[(size_t)22 * nl + 1] = (uint32_t)pbits;
+	img[(size_t)22 * nl + 2] = (big_cmp(big_add(cv->a, three), p) == 0) ? 1u : 0u;
+	if (img.size() * 4 != ecamd_g29_image_bytes(pbits)) {
+		return fail("internal: CurveG image size mismatch");
+	}
+	HIPCHK(ecamd_g29_upload(pbits, cv->gslot, img.data(), img.size() * 4));
+	return 0;
+}
+
 static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 {
 	if (!(cv->p[0] & 1) || big_bitlen(cv->p) < 160) {
@@ -464,6 +533,19 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 		delete cv;
 		return -1;
 	}
+	cv->gslot = -1;
+	if (!cv->is_p256 && ecamd_g29_supported(cv->pbits) && cv->pbits < 640 && getenv("ECAMD_NO_FAST_PATH") == nullptr) {
+		for (int i = 0; i < ecamd_g29_slots(); i++) {
+			if (!ctx->gslot_used[cv->pbits][i]) {
+				cv->gslot = i;
+				break;
+			}
+		}
+		if (cv->gslot >= 0 && upload_g29(cv)) {
+			delete cv;
+			return -1;
+		}
+	}
 	std::vector<uint8_t> g((size_t)2 * cv->clen);
 	big_to_be(g.data(), cv->clen, cv->gx);
 	big_to_be(g.data() + cv->clen, cv->clen, cv->gy);
@@ -473,6 +555,9 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 		return fail("curve: generator upload failed");
 	}
 	ctx->slot_used[slot] = true;
+	if (cv->gslot >= 0) {
+		ctx->gslot_used[cv->pbits][cv->gslot] = true;
+	}
 	if (cv->qslot >= 0) {
 		ctx->slot_used[cv->qslot] = true;
 	}
@@ -535,6 +620,9 @@ extern "C" void ecamd_curve_free(ecamd_curve *cv)
 			(void)hipFree(cv->d_gen);
 		}
 		cv->ctx->slot_used[cv->slot] = false;
+		if (cv->gslot >= 0) {
+			cv->ctx->gslot_used[cv->pbits][cv->gslot] = false;
+		}
 		if (cv->qslot >= 0) {
 			cv->ctx->slot_used[cv->qslot] = false;
 		}
@@ -564,7 +652,9 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 	}
 	const uint32_t chunk = n < ctx->max_chunk ? n : ctx->max_chunk;
 	const uint32_t stride = (chunk + 63u) & ~63u;
-	const bool fast = cv->is_p256 && slen <= 32;
+	const bool fast256 = cv->is_p256 && slen <= 32;
+	const bool fastg = !fast256 && cv->gslot >= 0 && slen <= ecamd_g29_max_slen(cv->pbits);
+	const bool fast = fast256 || fastg;
 	{
 		uint8_t *t = (uint8_t *)ctx->tbl;
 		const int rc = ensure(&t, &ctx->tbl_bytes, tbl_bytes_for(cv, stride));
@@ -575,7 +665,8 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 	}
 	if (fast) {
 		uint8_t *t = (uint8_t *)ctx->tbl_fast;
-		const int rc = ensure(&t, &ctx->tbl_fast_bytes, (size_t)stride * 8 * 28 * 4);
+		const size_t per_item = fast256 ? (size_t)8 * 28 * 4 : (size_t)ecamd_g29_table_words(cv->pbits) * 4;
+		const int rc = ensure(&t, &ctx->tbl_fast_bytes, (size_t)stride * per_item);
 		ctx->tbl_fast = (uint32_t *)t;
 		if (rc) {
 			return -1;
@@ -602,7 +693,11 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 			// are recomputed by the complete-formula kernel (all other lanes exit at once)
 			EcamdSmulArgs Fa = A;
 			Fa.tbl = ctx->tbl_fast;
-			HIPCHK(ecamd_launch_smul_p256(Fa, s));
+			if (fast256) {
+				HIPCHK(ecamd_launch_smul_p256(Fa, s));
+			} else {
+				HIPCHK(ecamd_launch_smul_g29(cv->pbits, cv->gslot, Fa, s));
+			}
 			A.only_redo = 1;
 		}
 		HIPCHK(ecamd_launch_smul(cv->nw, A, s));

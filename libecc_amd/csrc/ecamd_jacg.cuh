@@ -1,0 +1,133 @@
+// libecc_amd/csrc/ecamd_jacg.cuh -- Jacobian group law over ecamd_u29g.cuh, any short-Weierstrass
+// curve y^2 = x^3 + a x + b (a = -3 shortcut and generic a), same structure as ecamd_p256.cuh.
+//   doubling  a = -3: 4M + 4S     generic a: 4M + 6S (M = 3 X^2 + a Z^4)
+//   addition 12M + 4S (add-1998-cmo-2)
+// Thanks to the headroom limb no value fold is needed; carry() is inserted where the
+// static_asserts of ecamd_u29g.cuh demand it.
+#pragma once
+#include "ecamd_u29g.cuh"
+
+namespace jacg {
+using namespace g29;
+
+template <int PB> struct Cls {
+	typedef Cfg<PB> C;
+	// generous cover for the largest bias the formulas below ever need ...
+	static constexpr int LC = pick_logc<PB, 2>(3ull * MASK, C::top_from_vb(8)) + 4;
+	static_assert(LC >= 0, "no bias table large enough for this field size");
+	// ... bounds every loop-carried coordinate: carried limbs, value < 4 * 2^LC p
+	static constexpr u64 VA = 4ull << LC;
+	typedef E<PB, MASK + 8, C::top_from_vb(VA), VA> FA;
+	typedef typename MulOut<PB, 2>::type FM;  // multiplication result (value < 2p, exact low digits)
+	typedef E<PB, MASK, MASK, 1> FC;          // canonical constant
+};
+
+template <int PB> struct Jac {
+	typename Cls<PB>::FA X, Y, Z;
+};
+
+#define JG_K const CurveG<Cfg<PB>::NL> &K
+
+template <int PB> G29_FN Jac<PB> dbl(const Jac<PB> &P, JG_K)
+{
+	typedef typename Cls<PB>::FA FA;
+	typedef typename Cls<PB>::FC FC;
+	const auto yy = sqrc(P.Y, K);
+	const auto s4 = mulc(P.X, mul_small<4>(yy), K);  // 4 X Y^2
+	const auto zz = sqrc(P.Z, K);
+	FA m;  // M = 3 X^2 + a Z^4
+	if (K.a_is_m3) {
+		const auto t1 = carry(sub_auto<1>(P.X, zz, K));
+		const auto t2 = carry(add(P.X, zz));
+		m = weaken<FA>(carry(mul_small<3>(mulc(t1, t2, K))));  // 3 (X - Z^2)(X + Z^2)
+	} else {
+		const auto xx = sqrc(P.X, K);
+		const auto az4 = mulc(sqrc(zz, K), constant<FC>(K.a), K);
+		m = weaken<FA>(carry(add(mul_small<3>(xx), az4)));
+	}
+	const auto m2 = sqrc(m, K);
+	const auto x3 = carry(sub_auto<1>(m2, mul_small<2>(s4), K));  // M^2 - 8 X Y^2
+	const auto y8 = mul_small<2>(sqrc(mul_small<2>(yy), K));       // 8 Y^4
+	const auto t4 = carry(sub_auto<1>(s4, x3, K));                // 4 X Y^2 - X3
+	const auto y3 = carry(sub_auto<1>(mulc(m, t4, K), y8, K));
+	const auto z3 = carry(mul_small<2>(mulc(P.Y, P.Z, K)));        // 2 Y Z
+	Jac<PB> R;
+	R.X = weaken<FA>(x3);
+	R.Y = weaken<FA>(y3);
+	R.Z = weaken<FA>(z3);
+	return R;
+}
+
+// (X1, Y1, Z1) + (X2, Y2, Z2); h_is_zero <=> the x coordinates coincide (P + P or P + (-P))
+template <int PB>
+G29_FN Jac<PB> add_jac(const Jac<PB> &P, const typename Cls<PB>::FA &X2, const typename Cls<PB>::FA &Y2,
+		       const typename Cls<PB>::FA &Z2, bool &h_is_zero, JG_K)
+{
+	typedef typename Cls<PB>::FA FA;
+	const auto z1z1 = sqrc(P.Z, K);
+	const auto z2z2 = sqrc(Z2, K);
+	const auto u1 = mulc(P.X, z2z2, K);
+	const auto u2 = mulc(X2, z1z1, K);
+	const auto s1 = mulc(mulc(P.Y, Z2, K), z2z2, K);
+	const auto s2 = mulc(mulc(Y2, P.Z, K), z1z1, K);
+	const auto h = carry(sub_auto<1>(u2, u1, K));
+	const auto r = carry(sub_auto<1>(s2, s1, K));
+	const auto hh = sqrc(h, K);
+	const auto hhh = mulc(h, hh, K);
+	const auto v = mulc(u1, hh, K);
+	const auto r2 = sqrc(r, K);
+	const auto x3 = carry(sub_auto<2>(r2, add(hhh, mul_small<2>(v)), K));
+	const auto t5 = carry(sub_auto<1>(v, x3, K));
+	const auto y3 = carry(sub_auto<1>(mulc(r, t5, K), mulc(s1, hhh, K), K));
+	const auto z3 = mulc(mulc(P.Z, Z2, K), h, K);
+	h_is_zero = is_zero_mulout(z3, K);
+	Jac<PB> R;
+	R.X = weaken<FA>(x3);
+	R.Y = weaken<FA>(y3);
+	R.Z = weaken<FA>(z3);
+	return R;
+}
+
+// -Y (+ a multiple of p), carried: the negated table entry of a negative window digit.  Table
+// entries keep Y as a multiplication result (value < 2p) so that the negation stays inside FA.
+template <int PB> G29_FN typename Cls<PB>::FA neg(const typename Cls<PB>::FM &y, JG_K)
+{
+	E<PB, 0, 0, 0> zero;
+#pragma unroll
+	for (int i = 0; i < Cfg<PB>::NL; i++) {
+		zero.l[i] = 0;
+	}
+	return weaken<typename Cls<PB>::FA>(carry(sub_auto<1>(zero, y, K)));
+}
+
+// table entry: X, Z as they come, Y normalised through one multiplication by 1
+template <int PB> struct TabEnt {
+	typename Cls<PB>::FA X;
+	typename Cls<PB>::FM Y;
+	typename Cls<PB>::FA Z;
+};
+template <int PB> G29_FN TabEnt<PB> to_tab(const Jac<PB> &P, JG_K)
+{
+	TabEnt<PB> T;
+	T.X = P.X;
+	T.Y = weaken<typename Cls<PB>::FM>(mul(P.Y, constant<typename Cls<PB>::FC>(K.one), K));
+	T.Z = P.Z;
+	return T;
+}
+
+// x^(p-2) by left-to-right square-and-multiply over the bits of p - 2 (wave-uniform exponent)
+template <int PB> G29_FN typename Cls<PB>::FM inv(const typename Cls<PB>::FM &x, JG_K)
+{
+	typedef typename Cls<PB>::FM FM;
+	FM r = weaken<FM>(constant<typename Cls<PB>::FC>(K.one));
+	for (int i = (int)K.pbits - 1; i >= 0; i--) {
+		r = weaken<FM>(sqr(r, K));
+		if ((K.pm2[i / W] >> (i % W)) & 1u) {
+			r = weaken<FM>(mul(r, x, K));
+		}
+	}
+	return r;
+}
+
+#undef JG_K
+}  // namespace jacg

@@ -1,0 +1,470 @@
+// libecc_amd/csrc/ecamd_u29g.cuh -- radix-2^29 lazy Montgomery arithmetic for ANY odd prime,
+// with compile-time bound tracking (generalisation of ecamd_u29.cuh, which stays the
+// hand-specialised secp256r1 path).
+//
+// Same idea: limbs of 29 bits in u32, 64-bit column accumulators, one v_mad_u64_u32 per
+// product and no carry instructions.  Differences to the P-256 special case:
+//   * dense Montgomery reduction: column k adds m_i * p_(k-i) for every digit of p (NL^2 MADs)
+//     and m_k = (acc * mpinv) mod 2^29 with a per-curve mpinv;
+//   * a "headroom limb": NL = ceil((|p| + 16) / 29), so R = 2^(29 NL) >= 2^16 p.  A product of
+//     values A, B comes back below (A B / (p^2 2^HEAD) + 1) p, i.e. essentially p, whatever small
+//     multiples of p the operands carried; no value fold is ever needed, only limb carries;
+//   * all per-curve numbers (digits of p, R^2, 1, a, b, bias tables, p - 2) live in __constant__
+//     memory; the compile-time bounds depend on |p| only, so curves of equal size share code.
+// Bounds per element type E<PB, LB, TB, VB>: LB >= limbs 0..NL-2, TB >= top limb, VB >= value / p.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define G29_FN __device__ __forceinline__
+#define G29_NOINLINE __device__ __noinline__
+#else
+#define G29_FN inline
+#define G29_NOINLINE inline
+#endif
+// Multiplications are inlined into the formulas for fields of up to 10 limbs (<= 256 bit: +25 % on
+// MI355X, see ecamd_u29.cuh) and called out of line from 12 limbs on, where a single multiplier is
+// already 300-800 instructions and inlining 25 of them per loop body only costs compile time and
+// instruction-cache misses.
+#ifndef G29_CALL_FROM_NL
+#define G29_CALL_FROM_NL 12
+#endif
+
+namespace g29 {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+constexpr int W = 29;
+constexpr u32 MASK = (1u << W) - 1;
+
+constexpr int nl_for(int pbits) { return (pbits + 16 + W - 1) / W; }
+constexpr u64 cmin(u64 a, u64 b) { return a < b ? a : b; }
+constexpr u64 cmax(u64 a, u64 b) { return a > b ? a : b; }
+// x * 2^e for any sign of e, rounded up
+constexpr u64 shl_ceil(u64 x, int e) { return e >= 0 ? (x << e) : ((x + ((1ull << -e) - 1)) >> -e); }
+// x * 2^e rounded down
+constexpr u64 shl_floor(u64 x, int e) { return e >= 0 ? (x << e) : (x >> -e); }
+
+template <int PB> struct Cfg {
+	static constexpr int PBITS = PB;
+	static constexpr int NL = nl_for(PB);
+	static constexpr int HEAD = W * NL - PB;           // R / p >= 2^HEAD, HEAD >= 16
+	static constexpr int TOPSH = PB - W * (NL - 1);    // p < 2^(29 (NL-1) + TOPSH); may be <= 0
+	static_assert(HEAD >= 16 && NL <= 19, "field size not supported");
+	// top limb of a non-negative-limb value < vb * p
+	static constexpr u64 top_from_vb(u64 vb) { return shl_ceil(vb, TOPSH) + 1; }
+	// bias multiples are 2^(BIAS_STEP + BIAS_OFF) p: with a (nearly) empty top limb the smallest
+	// useful multiple is the one whose top digit is at least a few units
+	static constexpr int BIAS_OFF = (1 - TOPSH) > 0 ? (1 - TOPSH) : 0;
+	// va * vb < 2^(2 HEAD - 2) without overflowing u64
+	static constexpr int PROD_E = (2 * HEAD - 2) > 62 ? 62 : (2 * HEAD - 2);
+	static constexpr bool prod_ok(u64 va, u64 vb) { return va == 0 || vb <= ((1ull << PROD_E) - 1) / va; }
+};
+
+// the (LOGC, S) combinations the formulas use for "a - b + C p": bias tables for exactly these
+// are precomputed per curve by the host
+constexpr int NBIAS = 16;
+constexpr int BIAS_STEP[NBIAS] = {2, 4, 6, 8, 10, 12, 14, 16, 2, 4, 6, 8, 10, 12, 14, 16};
+constexpr int BIAS_S[NBIAS] = {1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2};
+// table index of the multiple 2^logc p for a field with bias offset 'off' (logc = step + off)
+constexpr int bias_index(int logc, int s, int off)
+{
+	for (int i = 0; i < NBIAS; i++) {
+		if (BIAS_STEP[i] + off == logc && BIAS_S[i] == s) {
+			return i;
+		}
+	}
+	return -1;
+}
+
+// per-curve constants (one per slot, filled by ecamd_host.cpp; layout mirrored there)
+template <int NL> struct CurveG {
+	u32 p[NL];            // digits of p
+	u32 r2[NL];           // R^2 mod p
+	u32 one[NL];          // R mod p
+	u32 a[NL];            // a R mod p
+	u32 b[NL];            // b R mod p
+	u32 pm2[NL];          // digits of p - 2 (inversion exponent)
+	u32 bias[NBIAS][NL];  // limbs of 2^LOGC p re-balanced so that low limbs >= 2^(29+S) - 2^S
+	u32 mpinv;            // -p^-1 mod 2^29
+	u32 pbits;
+	u32 a_is_m3;
+	u32 pad;
+};
+
+template <int PB, u64 LB_, u64 TB_, u64 VB_> struct E {
+	typedef Cfg<PB> C;
+	static constexpr u64 LB = LB_;
+	static constexpr u64 VB = VB_;
+	static constexpr u64 TB = cmin(TB_, C::top_from_vb(VB_));
+	static_assert(LB_ < (1ull << 32) && TB < (1ull << 32), "limb does not fit 32 bits");
+	static_assert(VB_ < (1ull << 40), "value bound out of range");
+	u32 l[C::NL];
+};
+
+template <class T, class S> G29_FN T weaken(const S &s)
+{
+	static_assert(T::LB >= S::LB && T::TB >= S::TB && T::VB >= S::VB, "weaken() must not tighten bounds");
+	T r;
+#pragma unroll
+	for (int i = 0; i < T::C::NL; i++) {
+		r.l[i] = s.l[i];
+	}
+	return r;
+}
+
+// ---- multiplication ----
+template <int PB> constexpr u64 mul_vb(u64 va, u64 vb) { return shl_ceil(va * vb, -Cfg<PB>::HEAD) + 1; }
+template <int PB, u64 VBO> struct MulOut {
+	typedef E<PB, MASK, Cfg<PB>::top_from_vb(VBO), VBO> type;
+};
+template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
+{
+	// NL*la*lb + NL*2^58 + 2^36 < 2^64
+	return la == 0 || lb <= ((0xFFFFFFFFFFFFFFFFull - (u64)NL * (1ull << 58) - (1ull << 36)) / NL) / la;
+}
+
+#if defined(__HIPCC__) && defined(U29_ASM_MAD)
+#define G29_MAD_VV(acc, a, b) \
+	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(dead_) : "v"(a), "v"(b)); } while (0)
+#define G29_MAD_VS(acc, a, b) \
+	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(dead_) : "v"(a), "s"(b)); } while (0)
+#define G29_PIN(acc) asm("" : "+v"(acc))
+#else
+#define G29_MAD_VV(acc, a, b) acc += (u64)(a) * (b)
+#define G29_MAD_VS(acc, a, b) acc += (u64)(a) * (b)
+#define G29_PIN(acc) (void)0
+#endif
+
+// r = a b / R mod p (lazy): product scanning with the reduction interleaved.  SQR: a == b, the
+// off-diagonal products are taken once against the doubled operand.
+template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 *b, const u32 *p, u32 mpinv)
+{
+	u32 m[NL], a2[NL];
+	if (SQR) {
+#pragma unroll
+		for (int i = 0; i < NL; i++) {
+			a2[i] = a[i] << 1;
+		}
+	}
+	u64 acc = 0;
+#pragma unroll
+	for (int k = 0; k < 2 * NL - 1; k++) {
+		const int lo = (k < NL) ? 0 : (k - NL + 1);
+		const int hi = (k < NL) ? k : (NL - 1);
+#pragma unroll
+		for (int i = lo; i <= hi; i++) {
+			const int j = k - i;
+			if (!SQR) {
+				G29_MAD_VV(acc, a[i], b[j]);
+			} else if (i < j) {
+				G29_MAD_VV(acc, a[i], a2[j]);
+			} else if (i == j) {
+				G29_MAD_VV(acc, a[i], a[i]);
+			}
+		}
+		// m_i p_(k-i): i < k in the low half, the whole anti-diagonal in the high half
+#pragma unroll
+		for (int i = lo; i <= hi; i++) {
+			if (k >= NL || i < k) {
+				G29_MAD_VS(acc, m[i], p[k - i]);
+			}
+		}
+		if (k < NL) {
+			m[k] = ((u32)acc * mpinv) & MASK;
+			G29_MAD_VS(acc, m[k], p[0]);
+		} else {
+			r[k - NL] = (u32)acc & MASK;
+		}
+		acc >>= W;
+		G29_PIN(acc);
+	}
+	r[NL - 1] = (u32)acc;
+}
+
+template <int NL> struct RawN {
+	u32 l[NL];
+};
+template <int NL> G29_NOINLINE RawN<NL> mul_call(RawN<NL> a, RawN<NL> b, const CurveG<NL> *K)
+{
+	RawN<NL> r;
+	mul_raw<NL, false>(r.l, a.l, b.l, K->p, K->mpinv);
+	return r;
+}
+template <int NL> G29_NOINLINE RawN<NL> sqr_call(RawN<NL> a, const CurveG<NL> *K)
+{
+	RawN<NL> r;
+	mul_raw<NL, true>(r.l, a.l, a.l, K->p, K->mpinv);
+	return r;
+}
+
+template <class A, class B, int NLc> G29_FN typename MulOut<A::C::PBITS, mul_vb<A::C::PBITS>(A::VB, B::VB)>::type
+mul(const A &a, const B &b, const CurveG<NLc> &K)
+{
+	typedef typename A::C C;
+	static_assert(NLc == C::NL, "curve constants of the wrong width");
+	static_assert(mul_fits<C::NL>(cmax(A::LB, A::TB), cmax(B::LB, B::TB)), "mul: column accumulator could overflow");
+	static_assert(C::prod_ok(A::VB, B::VB), "mul: operands too large for R");
+	typename MulOut<C::PBITS, mul_vb<C::PBITS>(A::VB, B::VB)>::type r;
+	if constexpr (C::NL >= G29_CALL_FROM_NL) {
+		RawN<C::NL> x, y;
+#pragma unroll
+		for (int i = 0; i < C::NL; i++) {
+			x.l[i] = a.l[i];
+			y.l[i] = b.l[i];
+		}
+		const RawN<C::NL> z = mul_call<C::NL>(x, y, &K);
+#pragma unroll
+		for (int i = 0; i < C::NL; i++) {
+			r.l[i] = z.l[i];
+		}
+	} else {
+		mul_raw<C::NL, false>(r.l, a.l, b.l, K.p, K.mpinv);
+	}
+	return r;
+}
+
+template <class A, int NLc> G29_FN typename MulOut<A::C::PBITS, mul_vb<A::C::PBITS>(A::VB, A::VB)>::type
+sqr(const A &a, const CurveG<NLc> &K)
+{
+	typedef typename A::C C;
+	static_assert(NLc == C::NL, "curve constants of the wrong width");
+	static_assert(mul_fits<C::NL>(cmax(A::LB, A::TB), cmax(A::LB, A::TB)), "sqr: column accumulator could overflow");
+	static_assert(2 * cmax(A::LB, A::TB) < (1ull << 32), "sqr: doubled limb does not fit 32 bits");
+	static_assert(C::prod_ok(A::VB, A::VB), "sqr: operand too large for R");
+	typename MulOut<C::PBITS, mul_vb<C::PBITS>(A::VB, A::VB)>::type r;
+	if constexpr (C::NL >= G29_CALL_FROM_NL) {
+		RawN<C::NL> x;
+#pragma unroll
+		for (int i = 0; i < C::NL; i++) {
+			x.l[i] = a.l[i];
+		}
+		const RawN<C::NL> z = sqr_call<C::NL>(x, &K);
+#pragma unroll
+		for (int i = 0; i < C::NL; i++) {
+			r.l[i] = z.l[i];
+		}
+	} else {
+		mul_raw<C::NL, true>(r.l, a.l, a.l, K.p, K.mpinv);
+	}
+	return r;
+}
+
+// ---- add / small multiples / sub with bias / carry ----
+template <class A, class B> G29_FN E<A::C::PBITS, A::LB + B::LB, A::TB + B::TB, A::VB + B::VB> add(const A &a, const B &b)
+{
+	E<A::C::PBITS, A::LB + B::LB, A::TB + B::TB, A::VB + B::VB> r;
+#pragma unroll
+	for (int i = 0; i < A::C::NL; i++) {
+		r.l[i] = a.l[i] + b.l[i];
+	}
+	return r;
+}
+
+template <int K_, class A> G29_FN E<A::C::PBITS, K_ * A::LB, K_ * A::TB, K_ * A::VB> mul_small(const A &a)
+{
+	static_assert(K_ == 2 || K_ == 3 || K_ == 4 || K_ == 8, "small multiple");
+	E<A::C::PBITS, K_ * A::LB, K_ * A::TB, K_ * A::VB> r;
+#pragma unroll
+	for (int i = 0; i < A::C::NL; i++) {
+		r.l[i] = (K_ == 3) ? (a.l[i] + (a.l[i] << 1)) : (a.l[i] << (K_ == 2 ? 1 : (K_ == 4 ? 2 : 3)));
+	}
+	return r;
+}
+
+// bias(LOGC, S) = 2^LOGC p with limb i (< top) = digit_i + 2^(29+S) - (i ? 2^S : 0), top = digit_top - 2^S.
+// Compile-time facts that hold for EVERY prime of PB bits (2^(PB-1) <= p < 2^PB):
+template <int PB, int LOGC, int S> struct BiasB {
+	typedef Cfg<PB> C;
+	static constexpr u64 M = 1ull << (W + S);
+	static constexpr u64 BORROW = 1ull << S;
+	static constexpr u64 LOWMIN = M - BORROW;
+	static constexpr u64 LOWMAX = M + MASK;
+	// top digit of 2^LOGC p lies in [2^(LOGC + TOPSH - 1) - 1, 2^(LOGC + TOPSH)]
+	static constexpr u64 TOPDIG_MIN = shl_floor(1, LOGC + C::TOPSH - 1) == 0 ? 0 : shl_floor(1, LOGC + C::TOPSH - 1) - 1;
+	static constexpr u64 TOPDIG_MAX = shl_ceil(1, LOGC + C::TOPSH);
+	static_assert(TOPDIG_MIN >= BORROW + 1, "bias: 2^LOGC p too small for the borrow");
+	static constexpr u64 TOPMIN = TOPDIG_MIN - BORROW;
+	static constexpr u64 TOPMAX = TOPDIG_MAX;
+	static constexpr u64 VADD = 1ull << LOGC;
+	static_assert(LOGC < 39, "bias multiple out of range");
+};
+
+template <int LOGC, int S, class A, class B, int NLc>
+G29_FN E<A::C::PBITS, A::LB + BiasB<A::C::PBITS, LOGC, S>::LOWMAX, A::TB + BiasB<A::C::PBITS, LOGC, S>::TOPMAX,
+	 A::VB + BiasB<A::C::PBITS, LOGC, S>::VADD>
+sub(const A &a, const B &b, const CurveG<NLc> &K)
+{
+	typedef BiasB<A::C::PBITS, LOGC, S> BS;
+	static_assert(bias_index(LOGC, S, A::C::BIAS_OFF) >= 0, "sub: no bias table for this (LOGC, S)");
+	static_assert(BS::LOWMIN >= B::LB, "sub: bias limbs do not dominate b");
+	static_assert(BS::TOPMIN >= B::TB, "sub: bias top limb does not dominate b");
+	E<A::C::PBITS, A::LB + BS::LOWMAX, A::TB + BS::TOPMAX, A::VB + BS::VADD> r;
+	constexpr int bi = bias_index(LOGC, S, A::C::BIAS_OFF);
+#pragma unroll
+	for (int i = 0; i < A::C::NL; i++) {
+		r.l[i] = a.l[i] + (K.bias[bi][i] - b.l[i]);
+	}
+	return r;
+}
+
+// smallest tabulated multiple 2^LOGC p (for the given S) that dominates b limb by limb (which
+// implies domination in value, so the difference is a non-negative number with non-negative limbs)
+template <int PB, int S> constexpr int pick_logc(u64 lb_b, u64 tb_b)
+{
+	typedef Cfg<PB> C;
+	for (int i = 0; i < NBIAS; i++) {
+		if (BIAS_S[i] != S) {
+			continue;
+		}
+		const int logc = BIAS_STEP[i] + C::BIAS_OFF;
+		const u64 borrow = 1ull << S;
+		const u64 lowmin = (1ull << (W + S)) - borrow;
+		const u64 f = shl_floor(1, logc + C::TOPSH - 1);
+		const u64 topdig_min = f == 0 ? 0 : f - 1;
+		if (lowmin >= lb_b && topdig_min >= borrow + 1 && topdig_min - borrow >= tb_b) {
+			return logc;
+		}
+	}
+	return -1;
+}
+
+// a - b + (smallest sufficient tabulated multiple of p); S = 1 when b's limbs are < 2^30, 2 when < 2^31
+template <int S, class A, class B, int NLc> G29_FN auto sub_auto(const A &a, const B &b, const CurveG<NLc> &K)
+{
+	constexpr int logc = pick_logc<A::C::PBITS, S>(B::LB, B::TB);
+	static_assert(logc >= 0, "sub_auto: no tabulated bias dominates b (carry it first?)");
+	return sub<logc, S>(a, b, K);
+}
+
+template <class A> G29_FN E<A::C::PBITS, MASK + (A::LB >> W), A::TB + (A::LB >> W), A::VB> carry(const A &a)
+{
+	constexpr int NL = A::C::NL;
+	E<A::C::PBITS, MASK + (A::LB >> W), A::TB + (A::LB >> W), A::VB> r;
+	r.l[0] = a.l[0] & MASK;
+#pragma unroll
+	for (int i = 1; i < NL - 1; i++) {
+		r.l[i] = (a.l[i] & MASK) + (a.l[i - 1] >> W);
+	}
+	r.l[NL - 1] = a.l[NL - 1] + (a.l[NL - 2] >> W);
+	return r;
+}
+
+// ---- multiplication with the carries the operand bounds require (decided at compile time) ----
+template <class A> struct CarryT {
+	typedef E<A::C::PBITS, MASK + (A::LB >> W), A::TB + (A::LB >> W), A::VB> type;
+};
+template <class A, class B, int NLc> G29_FN auto mulc(const A &a, const B &b, const CurveG<NLc> &K)
+{
+	constexpr int NL = A::C::NL;
+	typedef typename CarryT<A>::type CA;
+	typedef typename CarryT<B>::type CB;
+	if constexpr (mul_fits<NL>(cmax(A::LB, A::TB), cmax(B::LB, B::TB))) {
+		return mul(a, b, K);
+	} else if constexpr (A::LB >= B::LB && mul_fits<NL>(cmax(CA::LB, CA::TB), cmax(B::LB, B::TB))) {
+		return mul(carry(a), b, K);
+	} else if constexpr (mul_fits<NL>(cmax(A::LB, A::TB), cmax(CB::LB, CB::TB))) {
+		return mul(a, carry(b), K);
+	} else if constexpr (mul_fits<NL>(cmax(CA::LB, CA::TB), cmax(B::LB, B::TB))) {
+		return mul(carry(a), b, K);
+	} else {
+		return mul(carry(a), carry(b), K);
+	}
+}
+template <class A, int NLc> G29_FN auto sqrc(const A &a, const CurveG<NLc> &K)
+{
+	constexpr int NL = A::C::NL;
+	if constexpr (mul_fits<NL>(cmax(A::LB, A::TB), cmax(A::LB, A::TB)) && 2 * cmax(A::LB, A::TB) < (1ull << 32)) {
+		return sqr(a, K);
+	} else {
+		return sqr(carry(a), K);
+	}
+}
+
+// ---- exact zero test and canonical form of a multiplication result ----
+// value < VB p with exact low digits: subtract p up to VB-1 times (VB is tiny: <= 3)
+template <class A, int NLc> G29_FN void canonical_digits(u32 *d, const A &a, const CurveG<NLc> &K)
+{
+	constexpr int NL = A::C::NL;
+	static_assert(A::LB == MASK && A::VB <= 3, "canonical_digits needs a multiplication result < 3p");
+#pragma unroll
+	for (int i = 0; i < NL; i++) {
+		d[i] = a.l[i];
+	}
+#pragma unroll
+	for (int rep = 0; rep + 1 < (int)A::VB; rep++) {
+		u32 t[NL];
+		u32 borrow = 0;
+#pragma unroll
+		for (int i = 0; i < NL; i++) {
+			const u32 x = d[i] - K.p[i] - borrow;
+			borrow = x >> 31;
+			t[i] = (i < NL - 1) ? (x & MASK) : x;
+		}
+#pragma unroll
+		for (int i = 0; i < NL; i++) {
+			d[i] = borrow ? d[i] : t[i];
+		}
+	}
+}
+
+template <class A, int NLc> G29_FN bool is_zero_mulout(const A &a, const CurveG<NLc> &K)
+{
+	constexpr int NL = A::C::NL;
+	u32 d[NL];
+	canonical_digits(d, a, K);
+	u32 z = 0;
+#pragma unroll
+	for (int i = 0; i < NL; i++) {
+		z |= d[i];
+	}
+	return z == 0;
+}
+
+// ---- saturated 32-bit words <-> 29-bit limbs (NW words; value < p) ----
+template <int PB, int NW> G29_FN E<PB, MASK, MASK, 1> from_words(const u32 *w)
+{
+	constexpr int NL = Cfg<PB>::NL;
+	E<PB, MASK, MASK, 1> r;
+#pragma unroll
+	for (int i = 0; i < NL; i++) {
+		const int bit = W * i, wi = bit >> 5, sh = bit & 31;
+		u32 x = (wi < NW) ? (w[wi] >> sh) : 0u;
+		if (sh > 3 && wi + 1 < NW) {
+			x |= w[wi + 1] << (32 - sh);
+		}
+		r.l[i] = x & MASK;
+	}
+	return r;
+}
+
+template <int NL, int NW> G29_FN void to_words(u32 *w, const u32 *d)  // d: canonical digits
+{
+#pragma unroll
+	for (int wi = 0; wi < NW; wi++) {
+		const int bit = 32 * wi, li = bit / W, sh = bit - W * li;
+		u32 x = (li < NL) ? (d[li] >> sh) : 0u;
+		if (li + 1 < NL) {
+			x |= d[li + 1] << (W - sh);
+		}
+		if (2 * W - sh < 32 && li + 2 < NL) {
+			x |= d[li + 2] << (2 * W - sh);
+		}
+		w[wi] = x;
+	}
+}
+
+template <class T, int NLc> G29_FN T constant(const u32 (&c)[NLc])
+{
+	static_assert(NLc == T::C::NL, "constant of the wrong width");
+	T r;
+#pragma unroll
+	for (int i = 0; i < NLc; i++) {
+		r.l[i] = c[i];
+	}
+	return r;
+}
+
+}  // namespace g29

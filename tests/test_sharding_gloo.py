@@ -52,13 +52,19 @@ def test_two_rank_gather_matches_single_process():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = q.get(timeout=120)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q), daemon=True) for r in range(2)]
+    try:
+        for p in procs:
+            p.start()
+        got = q.get(timeout=180)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:  # never leave a worker behind: a live child would block interpreter exit
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
     rng = np.random.default_rng(99)
     sc = rng.integers(0, 256, size=32 * n, dtype=np.uint8).tobytes()
     assert got == Oracle("SECP256R1").scalar_mult(sc)

@@ -1,0 +1,173 @@
+"""CPU tests of the generic radix-2^29 field / Jacobian code (ecamd_u29g.cuh, ecamd_jacg.cuh) for
+every field size libecc's curves use: host build of the product headers (tests/u29g_host_shim.cpp)
+against Python integers, with operands spread over their whole bound class."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import g29_consts as G  # noqa: E402
+from oracles import CURVES  # noqa: E402
+
+W, MASK = G.W, G.MASK
+BUILD = os.path.join(ROOT, "tests", "_build")
+CASES = ["SECP192R1", "SECP224R1", "WEI25519", "BRAINPOOLP256R1", "SECP256K1", "SECP256R1", "BRAINPOOLP320R1",
+         "SECP384R1", "WEI448", "GOST512", "BRAINPOOLP512R1", "SECP521R1"]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    os.makedirs(BUILD, exist_ok=True)
+    so = os.path.join(BUILD, "u29g_host.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so,
+                           os.path.join(ROOT, "tests", "u29g_host_shim.cpp")])
+    return C.CDLL(so)
+
+
+def val(l):
+    return sum(int(v) << (W * i) for i, v in enumerate(l))
+
+
+def arr(l):
+    assert all(0 <= v < 2**32 for v in l), l
+    return (C.c_uint32 * len(l))(*l)
+
+
+class Field:
+    def __init__(self, lib, curve):
+        c = CURVES[curve]
+        self.p, self.a, self.b = c["p"], c["a"], c["b"]
+        self.pb = self.p.bit_length()
+        img, self.nl = G.image(self.p, self.a, self.b)
+        self.k = arr(img)
+        self.lib = lib
+        info = (C.c_uint32 * 8)()
+        getattr(lib, f"g_info_{self.pb}")(info)
+        assert info[0] == self.nl and info[5] == 4 * len(img), (list(info), len(img))
+        self.head, self.va, self.fa_lb, self.fa_tb = info[1], info[4], info[6], info[7]
+        self.R = 1 << (W * self.nl)
+        self.Rinv = pow(self.R, self.p - 2, self.p)
+
+    def fn(self, name):
+        return getattr(self.lib, f"g_{name}_{self.pb}")
+
+    def loose(self, rng, v, lb, tb):
+        l = G.digits(v, self.nl)
+        for i in range(self.nl - 1):
+            room = (lb - l[i]) >> W
+            k = min(room, l[i + 1], int(rng.integers(0, 8)))
+            l[i] += k << W
+            l[i + 1] -= k
+        assert val(l) == v and max(l[:-1]) <= lb and l[-1] <= tb, (l, lb, tb)
+        return l
+
+    def fa(self, rng, residue, mult=None):
+        """an FA-class representation of `residue` mod p: value residue + mult*p, loose limbs"""
+        vmax = min(self.va, ((self.fa_tb - 1) << (W * (self.nl - 1))) // self.p)
+        mult = int(rng.integers(0, max(1, vmax - 1))) if mult is None else mult
+        return self.loose(rng, residue % self.p + mult * self.p, self.fa_lb, self.fa_tb)
+
+    def call(self, name, *ins, n_out=None):
+        out = (C.c_uint32 * (n_out or self.nl))()
+        r = self.fn(name)(self.k, *[arr(x) for x in ins], out)
+        return list(out), r
+
+
+@pytest.mark.parametrize("curve", CASES)
+def test_field_ops(lib, curve):
+    rng = np.random.default_rng(41)
+    f = Field(lib, curve)
+    p = f.p
+    for it in range(60):
+        x = int.from_bytes(rng.bytes(80), "big") % p
+        y = int.from_bytes(rng.bytes(80), "big") % p
+        lx, ly = f.fa(rng, x), f.fa(rng, y)
+        if it == 0:  # extreme: largest value the class allows, every low limb at its bound
+            vmax = min(f.va, ((f.fa_tb - 1) << (W * (f.nl - 1))) // p) - 1
+            lx = f.fa(rng, x, vmax)
+            ly = f.fa(rng, y, vmax)
+        out = (C.c_uint32 * f.nl)()
+        f.fn("mul")(f.k, arr(lx), arr(ly), out, 0)
+        assert val(out) % p == val(lx) * val(ly) * f.Rinv % p
+        assert val(out) < 2 * p + (val(lx) * val(ly) >> (W * f.nl)) and max(list(out)[:-1]) <= MASK
+        f.fn("mul")(f.k, arr(lx), arr(lx), out, 1)
+        assert val(out) % p == val(lx) ** 2 * f.Rinv % p
+    # canonical digits, negation, inversion
+    for v in (0, 1, p - 1, p, p + 1, 2 * p - 1, int.from_bytes(rng.bytes(80), "big") % (2 * p)):
+        d, _ = f.call("canon", G.digits(v, f.nl))
+        assert val(d) == v % p and max(d[:-1]) <= MASK
+        n, _ = f.call("neg", G.digits(v, f.nl))
+        assert (val(n) + v) % p == 0 and max(n[:-1]) <= f.fa_lb and n[-1] <= f.fa_tb
+    x = int.from_bytes(rng.bytes(80), "big") % p or 1
+    iv, _ = f.call("inv", G.digits(x * f.R % p, f.nl))
+    assert val(iv) % p == pow(x, p - 2, p) * f.R % p
+
+
+def aff_add(P, Q, a, p):
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    if P[0] == Q[0]:
+        if (P[1] + Q[1]) % p == 0:
+            return None
+        lam = (3 * P[0] * P[0] + a) * pow(2 * P[1], p - 2, p) % p
+    else:
+        lam = (Q[1] - P[1]) * pow(Q[0] - P[0], p - 2, p) % p
+    x = (lam * lam - P[0] - Q[0]) % p
+    return (x, (lam * (P[0] - x) - P[1]) % p)
+
+
+@pytest.mark.parametrize("curve", CASES)
+def test_jacobian(lib, curve):
+    rng = np.random.default_rng(42)
+    f = Field(lib, curve)
+    c = CURVES[curve]
+    p, a = f.p, f.a
+    G0 = (c["gx"], c["gy"])
+
+    def jac(P):
+        z = int.from_bytes(rng.bytes(80), "big") % p or 1
+        X, Y, Z = P[0] * z * z % p * f.R % p, P[1] * z * z * z % p * f.R % p, z * f.R % p
+        return f.fa(rng, X) + f.fa(rng, Y) + f.fa(rng, Z)
+
+    def aff(l):
+        nl = f.nl
+        X, Y, Z = (val(l[0:nl]) * f.Rinv % p, val(l[nl:2 * nl]) * f.Rinv % p, val(l[2 * nl:3 * nl]) * f.Rinv % p)
+        if Z == 0:
+            return None
+        zi = pow(Z, p - 2, p)
+        return (X * zi * zi % p, Y * zi * zi * zi % p)
+
+    def in_class(l):
+        nl = f.nl
+        for k in range(3):
+            part = l[k * nl:(k + 1) * nl]
+            assert max(part[:-1]) <= f.fa_lb and part[-1] <= f.fa_tb and val(part) < f.va * p
+
+    P = G0
+    Q = aff_add(G0, G0, a, p)
+    cur = jac(P)
+    acc = P
+    for it in range(24):
+        if it % 4 == 3:
+            Q = aff_add(Q, G0, a, p)
+            cur, hz = f.call("add", cur, jac(Q), n_out=3 * f.nl)
+            assert hz == 0
+            acc = aff_add(acc, Q, a, p)
+        else:
+            cur, _ = f.call("dbl", cur, n_out=3 * f.nl)
+            acc = aff_add(acc, acc, a, p)
+        assert aff(cur) == acc
+        in_class(cur)
+    # exceptional pairs are flagged
+    _, hz = f.call("add", jac(P), jac(P), n_out=3 * f.nl)
+    assert hz == 1
+    out, hz = f.call("add", jac(P), jac((P[0], p - P[1])), n_out=3 * f.nl)
+    assert hz == 1 and aff(out) is None

@@ -1,0 +1,112 @@
+// tests/u29g_host_shim.cpp -- TEST INFRASTRUCTURE: host build of the generic radix-2^29 headers
+// (ecamd_u29g.cuh, ecamd_jacg.cuh) for tests/test_u29g_host.py.  One set of entry points per
+// field size; the curve constants (CurveG image) are supplied by the test as a flat u32 array.
+#include <cstring>
+#include "../libecc_amd/csrc/ecamd_jacg.cuh"
+
+using namespace jacg;
+
+template <int PB> struct Shim {
+	typedef Cfg<PB> C;
+	static constexpr int NL = C::NL;
+	typedef CurveG<NL> CK;
+	static void mul_(const uint32_t *k, const uint32_t *a, const uint32_t *b, uint32_t *out, int sq)
+	{
+		const CK &K = *(const CK *)k;
+		typename Cls<PB>::FA x, y;
+		memcpy(x.l, a, 4 * NL);
+		memcpy(y.l, b, 4 * NL);
+		if (sq) {
+			auto r = sqr(x, K);
+			memcpy(out, r.l, 4 * NL);
+		} else {
+			auto r = mul(x, y, K);
+			memcpy(out, r.l, 4 * NL);
+		}
+	}
+	static void dbl_(const uint32_t *k, const uint32_t *p, uint32_t *out)
+	{
+		const CK &K = *(const CK *)k;
+		Jac<PB> P;
+		memcpy(P.X.l, p, 4 * NL);
+		memcpy(P.Y.l, p + NL, 4 * NL);
+		memcpy(P.Z.l, p + 2 * NL, 4 * NL);
+		Jac<PB> R = dbl(P, K);
+		memcpy(out, R.X.l, 4 * NL);
+		memcpy(out + NL, R.Y.l, 4 * NL);
+		memcpy(out + 2 * NL, R.Z.l, 4 * NL);
+	}
+	static int add_(const uint32_t *k, const uint32_t *p, const uint32_t *q, uint32_t *out)
+	{
+		const CK &K = *(const CK *)k;
+		Jac<PB> P;
+		typename Cls<PB>::FA X2, Y2, Z2;
+		memcpy(P.X.l, p, 4 * NL);
+		memcpy(P.Y.l, p + NL, 4 * NL);
+		memcpy(P.Z.l, p + 2 * NL, 4 * NL);
+		memcpy(X2.l, q, 4 * NL);
+		memcpy(Y2.l, q + NL, 4 * NL);
+		memcpy(Z2.l, q + 2 * NL, 4 * NL);
+		bool hz;
+		Jac<PB> R = add_jac(P, X2, Y2, Z2, hz, K);
+		memcpy(out, R.X.l, 4 * NL);
+		memcpy(out + NL, R.Y.l, 4 * NL);
+		memcpy(out + 2 * NL, R.Z.l, 4 * NL);
+		return hz ? 1 : 0;
+	}
+	static void neg_(const uint32_t *k, const uint32_t *a, uint32_t *out)
+	{
+		const CK &K = *(const CK *)k;
+		typename Cls<PB>::FM x;
+		memcpy(x.l, a, 4 * NL);
+		auto r = neg<PB>(x, K);
+		memcpy(out, r.l, 4 * NL);
+	}
+	static void inv_(const uint32_t *k, const uint32_t *a, uint32_t *out)
+	{
+		const CK &K = *(const CK *)k;
+		typename Cls<PB>::FM x;
+		memcpy(x.l, a, 4 * NL);
+		auto r = inv<PB>(x, K);
+		memcpy(out, r.l, 4 * NL);
+	}
+	static void canon_(const uint32_t *k, const uint32_t *a, uint32_t *digits)
+	{
+		const CK &K = *(const CK *)k;
+		typename Cls<PB>::FM x;
+		memcpy(x.l, a, 4 * NL);
+		canonical_digits(digits, x, K);
+	}
+	static void info_(uint32_t *out)
+	{
+		out[0] = NL;
+		out[1] = (uint32_t)C::HEAD;
+		out[2] = (uint32_t)(int32_t)C::TOPSH;
+		out[3] = (uint32_t)Cls<PB>::LC;
+		out[4] = (uint32_t)(Cls<PB>::VA & 0xffffffffu);
+		out[5] = (uint32_t)sizeof(CK);
+		out[6] = (uint32_t)Cls<PB>::FA::LB;
+		out[7] = (uint32_t)Cls<PB>::FA::TB;
+	}
+};
+
+#define SHIM(PB) \
+	extern "C" { \
+	void g_mul_##PB(const uint32_t *k, const uint32_t *a, const uint32_t *b, uint32_t *o, int sq) { Shim<PB>::mul_(k, a, b, o, sq); } \
+	void g_dbl_##PB(const uint32_t *k, const uint32_t *p, uint32_t *o) { Shim<PB>::dbl_(k, p, o); } \
+	int g_add_##PB(const uint32_t *k, const uint32_t *p, const uint32_t *q, uint32_t *o) { return Shim<PB>::add_(k, p, q, o); } \
+	void g_neg_##PB(const uint32_t *k, const uint32_t *a, uint32_t *o) { Shim<PB>::neg_(k, a, o); } \
+	void g_inv_##PB(const uint32_t *k, const uint32_t *a, uint32_t *o) { Shim<PB>::inv_(k, a, o); } \
+	void g_canon_##PB(const uint32_t *k, const uint32_t *a, uint32_t *o) { Shim<PB>::canon_(k, a, o); } \
+	void g_info_##PB(uint32_t *o) { Shim<PB>::info_(o); } \
+	}
+SHIM(192)
+SHIM(224)
+SHIM(255)
+SHIM(256)
+SHIM(320)
+SHIM(384)
+SHIM(448)
+SHIM(511)
+SHIM(512)
+SHIM(521)

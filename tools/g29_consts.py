@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Python mirror of the CurveG<NL> constant image of libecc_amd/csrc/ecamd_u29g.cuh (what
+ecamd_host.cpp uploads per curve).  Used by tests/test_u29g_host.py to drive the host build of the
+generic radix-2^29 code; tests/test_gpu_parity.py cross-checks the C++ builder through the GPU."""
+W = 29
+MASK = (1 << W) - 1
+BIAS_STEP = [2, 4, 6, 8, 10, 12, 14, 16] * 2
+BIAS_S = [1] * 8 + [2] * 8
+
+
+def nl_for(pbits):
+    return (pbits + 16 + W - 1) // W
+
+
+def digits(x, nl):
+    d = [(x >> (W * i)) & MASK for i in range(nl - 1)]
+    d.append(x >> (W * (nl - 1)))
+    return d
+
+
+def image(p, a, b):
+    pbits = p.bit_length()
+    nl = nl_for(pbits)
+    R = 1 << (W * nl)
+    topsh = pbits - W * (nl - 1)
+    off = max(0, 1 - topsh)
+    out = []
+    out += digits(p, nl)
+    out += digits(R * R % p, nl)
+    out += digits(R % p, nl)
+    out += digits(a * R % p, nl)
+    out += digits(b * R % p, nl)
+    out += digits(p - 2, nl)
+    for step, s in zip(BIAS_STEP, BIAS_S):
+        c = p << (step + off)
+        d = digits(c, nl)
+        M, BW = 1 << (W + s), 1 << s
+        l = [d[0] + M] + [d[j] + M - BW for j in range(1, nl - 1)] + [d[nl - 1] - BW]
+        assert l[-1] >= 0 and sum(v << (W * j) for j, v in enumerate(l)) == c
+        assert all(v < 2**32 for v in l)
+        out += l
+    mpinv = (-pow(p, -1, 1 << W)) % (1 << W)
+    out += [mpinv, pbits, 1 if a == p - 3 else 0, 0]
+    return out, nl
