@@ -166,6 +166,13 @@ template <int PB> __global__ __launch_bounds__(64) void k_smul_g(EcamdSmulArgs A
 			by = (yd.l[j] - K.p[j] - by) >> 31;
 		}
 		ok = (bx != 0) & (by != 0);  // both strictly below p
+		// y = 0 is a point of order 2: the reference's ladder fails on it for every scalar (see k_smul)
+		u32 ynz = 0;
+#pragma unroll
+		for (int j = 0; j < NL; j++) {
+			ynz |= yd.l[j];
+		}
+		ok = ok & (ynz != 0);
 	}
 	const FC r2 = constant<FC>(K.r2), onec = constant<FC>(K.one);
 	const auto xm = mul(xd, r2, K), ym = mul(yd, r2, K);  // Montgomery form, < 2p, exact digits

@@ -74,6 +74,10 @@ template <int NW> __global__ __launch_bounds__(64) void k_smul(EcamdSmulArgs A)
 	x = fe_to_mont<NW>(x, slot);
 	y = fe_to_mont<NW>(y, slot);
 	ok = ok & aff_on_curve<NW>(x, y, slot);
+	// A point of order exactly 2 (y = 0, only on curves of even order) makes every ladder step of the
+	// reference an "exceptional pair" (T1 - T0 = P, curves/prj_pt.c:1058-1060): prj_pt_mul returns -1
+	// for ANY scalar.  Mirror that.
+	ok = ok & !fe_is_zero<NW>(y);
 	if (!ok) {
 		A.status[i] = 1;
 		for (int b = 0; b < 2 * clen; b++) {
@@ -208,6 +212,14 @@ template <int NW> __global__ __launch_bounds__(64) void k_pt(EcamdPtArgs A)
 		return;
 	}
 	Pt<NW> R = A.dbl ? pt_dbl<NW>(P, slot) : pt_add<NW>(P, Q, slot);
+	if (!A.dbl && fe_is_zero<NW>(R.Z) && fe_is_zero<NW>(R.Y)) {
+		// "exceptional pair" (P - Q of order exactly 2): prj_pt_add returns -1 (curves/prj_pt.c:1058-1060)
+		A.status[i] = 1;
+		for (int b = 0; b < 2 * clen; b++) {
+			out[b] = 0;
+		}
+		return;
+	}
 	if (fe_is_zero<NW>(R.Z)) {
 		A.status[i] = 2;
 		for (int b = 0; b < 2 * clen; b++) {

@@ -183,6 +183,44 @@ def test_fast_path_exceptional_pairs(gpu_ctx):
         cv.free()
 
 
+def test_cofactor_curve_small_order_points(gpu_ctx):
+    """WEI25519 (cofactor 8): inputs of even order drive the Jacobian fast path through doublings that
+    reach infinity silently and additions with Z = 0; every such lane must be redone by the
+    complete-formula kernel and agree with the oracle"""
+    curve = "WEI25519"
+    c = CURVES[curve]
+    p, a, q, order = c["p"], c["a"], c["q"], c["order"]
+    # the 2-torsion point of Curve25519 (u, v) = (0, 0) is (A/3, 0) on the Weierstrass model
+    A = 486662
+    x2 = A * pow(3, p - 2, p) % p
+    assert (x2 ** 3 + a * x2 + c["b"]) % p == 0
+    n = 32
+    T2 = x2.to_bytes(n, "big") + bytes(n)
+    from oracles import py_add
+    GT = py_add((c["gx"], c["gy"]), (x2, 0), a, p)          # order 2q
+    GT = GT[0].to_bytes(n, "big") + GT[1].to_bytes(n, "big")
+    ks = [0, 1, 2, 3, 4, 8, q - 1, q, q + 1, 2 * q, 2 * q + 1, 4 * q, order - 1, order % (1 << 256), 16, 17, 255, 256]
+    rng = np.random.default_rng(9)
+    ks += [int.from_bytes(rand_bytes(rng, 32), "big") for _ in range(14)]
+    sc = b"".join((k % (1 << 256)).to_bytes(32, "big") for k in ks)
+    cv = gpu_ctx.curve(curve)
+    o = Oracle(curve)
+    try:
+        for P in (T2, GT):
+            pts = P * len(ks)
+            exp = o.scalar_mult(sc, pts, 32)
+            assert cv.scalar_mult(sc, pts, 32) == exp
+        # order 2: error for every scalar; order 2q: finite results and infinity at multiples of 2q
+        assert set(o.scalar_mult(sc, T2 * len(ks), 32)[1]) == {1}
+        st = o.scalar_mult(sc, GT * len(ks), 32)[1]
+        assert 2 in st and 0 in st
+        # prj_pt_add on an exceptional pair (difference of order exactly 2) is an error in the reference
+        G1 = c["gx"].to_bytes(n, "big") + c["gy"].to_bytes(n, "big")
+        assert cv.pt_add(G1 + T2 + GT, GT + T2 + T2) == o.pt_add(G1 + T2 + GT, GT + T2 + T2)
+    finally:
+        cv.free()
+
+
 def test_linearity_large_batch(gpu_ctx):
     """size-independent property at a large batch: [a]P + [b]P == [a+b]P and [a]([b]G) == [ab mod q]G,
     plus a spot check of a random subset against the oracle and chunking across launches."""
