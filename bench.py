@@ -45,9 +45,10 @@ def popcount(x):
 
 def work_model(curve_params, nw, slen):
     """Field multiplications and 32x32 MADs (v_mad_u64_u32) executed per item, derived from the
-    kernels' own parameters.  secp256r1 takes the radix-2^29 Jacobian fast path
-    (libecc_amd/csrc/ecamd_p256_kernel.hip): a multiplication is 81 product + 36 reduction MADs,
-    a squaring 45 + 36; every other curve runs the complete-formula kernel k_smul<NW>."""
+    kernels' own parameters.  secp256r1 takes the hand-specialised radix-2^29 Jacobian path
+    (ecamd_p256_kernel.hip: multiplication 81 product + 36 reduction MADs, squaring 45 + 36), every
+    other curve the generic radix-2^29 path (ecamd_g29_kernel.hip), scalars longer than the field the
+    saturated complete-formula kernel k_smul<NW>."""
     p = curve_params["p"]
     pbits = p.bit_length()
     nwin = 2 * slen
@@ -62,6 +63,22 @@ def work_model(curve_params, nw, slen):
         nm += 1 + 13 / fin_k + 2 + 3 + 2
         ns += 255 / fin_k + 1
         return nm + ns, nm * M + ns * S, "k_smul_p256 (+ k_p256_finalize)"
+    fin_k = 8
+    if slen <= 4 * ((pbits + 31) // 32):
+        # generic radix-2^29 Jacobian kernels k_smul_g<|p|> + k_finalize_g<|p|> (ecamd_g29_kernel.hip):
+        # NL = ceil((|p| + 16) / 29) limbs, multiplication NL^2 products + NL^2 reduction MADs,
+        # squaring NL (NL + 1) / 2 products + NL^2 reduction MADs
+        nl = (pbits + 16 + 28) // 29
+        M, S = 2 * nl * nl, nl * (nl + 1) // 2 + nl * nl
+        am3 = curve_params["a"] == p - 3
+        dbl = (4, 4) if am3 else (4, 6)
+        add = (12, 4)
+        nm = 2 + 2 + 4 * dbl[0] + 3 * add[0] + 7 + nwin * (4 * dbl[0] + add[0]) + 1   # import, table (+7 Y normalisations), loop, Z test
+        ns = 2 + 4 * dbl[1] + 3 * add[1] + nwin * (4 * dbl[1] + add[1])
+        inv_s, inv_m = pbits, popcount(p - 2)
+        nm += 1 + inv_m / fin_k + 2 + 3 + 2
+        ns += inv_s / fin_k + 1
+        return nm + ns, nm * M + ns * S, f"k_smul_g<{pbits}> (+ k_finalize_g)"
     mm_add, mm_dbl = 17, 16                              # RCB Alg. 1 / Alg. 3, generic a
     mm = 2 + 3                                           # to Montgomery (x, y) + on-curve check
     mm += 14 * mm_add                                    # table [2..15]P
