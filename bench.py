@@ -54,15 +54,21 @@ def work_model(curve_params, nw, slen):
     nwin = 2 * slen
     if p == 2**256 - 2**224 + 2**192 + 2**96 - 1 and slen <= 32:
         M, S = 117, 81
-        dbl, add = (4, 4), (12, 4)                       # (mults, squarings)
-        fin_k = 8                                        # k_p256_finalize: one inversion per 8 items
-        # k_smul_p256: to Montgomery 2M, on-curve 2M+2S, table 4 dbl + 3 add, nwin x (4 dbl + 1 add)
-        nm = 2 + 2 + 4 * dbl[0] + 3 * add[0] + nwin * (4 * dbl[0] + add[0])
-        ns = 2 + 4 * dbl[1] + 3 * add[1] + nwin * (4 * dbl[1] + add[1])
+        dbl, madd = (4, 4), (8, 3)                       # (mults, squarings); mixed addition: affine table
+        fin_k = aff_k = 8                                # items per lane sharing one inversion
+        # k_p256_table: to Montgomery 2M, on-curve 2M+2S, 4 dbl + 3 madd
+        nm = 2 + 2 + 4 * dbl[0] + 3 * madd[0]
+        ns = 2 + 4 * dbl[1] + 3 * madd[1]
+        # k_p256_affine: 7 entries x (prefix 1M, back-substitution 2M, affine 3M + 1S) + (255S + 13M)/aff_k
+        nm += 7 * 6 + 13 / aff_k
+        ns += 7 * 1 + 255 / aff_k
+        # k_p256_loop: nwin x (4 dbl + 1 madd)
+        nm += nwin * (4 * dbl[0] + madd[0])
+        ns += nwin * (4 * dbl[1] + madd[1])
         # k_p256_finalize: prefix 1M, (255S + 13M)/fin_k, back-substitution 2M, affine 1S + 3M, from Montgomery 2M
         nm += 1 + 13 / fin_k + 2 + 3 + 2
         ns += 255 / fin_k + 1
-        return nm + ns, nm * M + ns * S, "k_smul_p256 (+ k_p256_finalize)"
+        return nm + ns, nm * M + ns * S, "k_p256_loop (+ k_p256_table, k_p256_affine, k_p256_finalize)"
     fin_k = 8
     if slen <= 4 * ((pbits + 31) // 32):
         # generic radix-2^29 Jacobian kernels k_smul_g<|p|> + k_finalize_g<|p|> (ecamd_g29_kernel.hip):

@@ -665,7 +665,7 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 	}
 	if (fast) {
 		uint8_t *t = (uint8_t *)ctx->tbl_fast;
-		const size_t per_item = fast256 ? (size_t)8 * 28 * 4 : (size_t)ecamd_g29_table_words(cv->pbits) * 4;
+		const size_t per_item = fast256 ? (size_t)8 * 40 * 4 : (size_t)ecamd_g29_table_words(cv->pbits) * 4;
 		const int rc = ensure(&t, &ctx->tbl_fast_bytes, (size_t)stride * per_item);
 		ctx->tbl_fast = (uint32_t *)t;
 		if (rc) {

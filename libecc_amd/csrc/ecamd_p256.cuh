@@ -143,6 +143,41 @@ U29_FN Jac add_jac(const Jac &P, const FX2 &X2, const FY2 &Y2, const FZ2 &Z2, bo
 	return R;
 }
 
+// ---- mixed addition: (X1, Y1, Z1) + affine (x2, y2), 8M + 3S (madd): the window table is made
+//      affine by k_p256_affine (one shared inversion per 8 items), which saves 4M + 1S per window ----
+typedef F<(1ull << 29) + MASK, (3ull << 24), 48> FYaff;  // y2 or 2p - y2 of an affine (canonical) table entry
+template <class FY2> U29_FN Jac madd(const Jac &P, const Fcanon &X2, const FY2 &Y2, bool &h_is_zero)
+{
+	const auto z1z1 = sqr(P.Z);
+	const auto u2 = mul(X2, z1z1);
+	const auto s2 = mul(mul(Y2, P.Z), z1z1);
+	const auto h = carry(sub<1, 1>(u2, P.X));
+	const auto r = carry(sub<3, 1>(s2, P.Y));
+	const auto hh = sqr(h);
+	const auto hhh = mul(h, hh);
+	const auto v = mul(P.X, hh);
+	const auto r2 = sqr(r);
+	const auto x3 = fold(sub<2, 2>(r2, add(hhh, mul_small<2>(v))));
+	const auto t5 = sub<1, 1>(v, x3);
+	const auto y3 = carry(sub<1, 0>(mul(r, t5), mul(P.Y, hhh)));
+	const auto z3 = mul(P.Z, h);
+	h_is_zero = is_zero_mulout(z3);
+	Jac R;
+	R.X = weaken<FX>(x3);
+	R.Y = weaken<FY>(y3);
+	R.Z = weaken<FZ>(z3);
+	return R;
+}
+U29_FN FYaff neg_aff(const Fcanon &y)
+{
+	F<0, 0, 0> zero;
+#pragma unroll
+	for (int i = 0; i < 9; i++) {
+		zero.l[i] = 0;
+	}
+	return weaken<FYaff>(sub<1, 0>(zero, y));
+}
+
 // 2p - Y, limbs re-normalised: the negated table entry of a negative window digit
 U29_FN FYsel neg_y(const FX &y)
 {

@@ -5,10 +5,14 @@
 //   * field: radix-2^29 lazy Montgomery arithmetic (ecamd_u29.cuh), v_mad_u64_u32 only;
 //   * group: Jacobian a = -3 doubling (4M + 4S) and addition (12M + 4S) (ecamd_p256.cuh);
 //   * scalar: signed fixed window w = 4 over k' = k + 0x88...8 (digit = nibble - 8 in [-8, 7]),
-//     left to right, 4 doublings + 1 addition per window, table [1..8]P per lane;
-//   * table: per-lane contiguous 8 x 28 words in a global scratch buffer (7 x 16-byte
-//     loads per look-up, every fetched cache line fully used by the lane that fetched it);
-//   * output: one Fermat inversion by addition chain, affine X||Y big-endian.
+//     left to right, 4 doublings + 1 MIXED addition (8M + 3S) per window, AFFINE table [1..8]P;
+//   * four kernels per batch, all inversions shared by Montgomery's trick over 8 items per lane:
+//       k_p256_table     import + on-curve check, Jacobian multiples 2P..8P
+//       k_p256_affine    table -> affine (one inversion per 56 table entries)
+//       k_p256_loop      the window loop, Jacobian result
+//       k_p256_finalize  result -> affine X||Y big-endian (one inversion per 8 items)
+//   * table: per-item contiguous 8 x 40 words in a global scratch buffer; a look-up is 5 x 16-byte
+//     loads and every fetched cache line is fully used by the lane that fetched it.
 // Exceptional pairs of the incomplete Jacobian addition (accumulator == +-table entry) cannot be
 // produced by scalars below the group order and random points, but edge scalars (k >= q) can:
 // such a lane is detected exactly (Z3 == 0 with both inputs finite), marked ECAMD_REDO and
@@ -21,8 +25,12 @@ using namespace p256;
 
 typedef uint8_t u8;
 
-#define TBL_WORDS_PER_ENTRY 28
+#define TBL_WORDS_PER_ENTRY 40   /* build: X Y Z + prefix product (36 words); final: affine x y (18 words) */
 #define TBL_ENTRIES 8
+#define FIN_K 8                  /* items per lane in k_p256_finalize */
+#ifndef AFF_K
+#define AFF_K 8                  /* items per lane in k_p256_affine (x 7 table entries each); 2/4/8 measured equal */
+#endif
 
 // 32 big-endian bytes -> 8 little-endian words
 static __device__ __forceinline__ void load_be256(const u8 *src, u32 *w)
@@ -85,30 +93,51 @@ static __device__ __forceinline__ bool lt_p(const u32 *w)
 	return borrow != 0;
 }
 
-static __device__ __forceinline__ void tbl_store(u32 *base, int e, const TabEnt &P)
+// ---- table records ----
+static __device__ __forceinline__ void st9(u32 *d, const u32 *l0, const u32 *l1, const u32 *l2, const u32 *l3)
 {
-	uint4 *d = (uint4 *)(base + e * TBL_WORDS_PER_ENTRY);
-	d[0] = make_uint4(P.X.l[0], P.X.l[1], P.X.l[2], P.X.l[3]);
-	d[1] = make_uint4(P.X.l[4], P.X.l[5], P.X.l[6], P.X.l[7]);
-	d[2] = make_uint4(P.X.l[8], P.Y.l[0], P.Y.l[1], P.Y.l[2]);
-	d[3] = make_uint4(P.Y.l[3], P.Y.l[4], P.Y.l[5], P.Y.l[6]);
-	d[4] = make_uint4(P.Y.l[7], P.Y.l[8], P.Z.l[0], P.Z.l[1]);
-	d[5] = make_uint4(P.Z.l[2], P.Z.l[3], P.Z.l[4], P.Z.l[5]);
-	d[6] = make_uint4(P.Z.l[6], P.Z.l[7], P.Z.l[8], 0u);
+	// up to four 9-limb elements -> 36 words, 16-byte stores
+	u32 b[36];
+#pragma unroll
+	for (int i = 0; i < 9; i++) {
+		b[i] = l0[i];
+		b[9 + i] = l1 ? l1[i] : 0u;
+		b[18 + i] = l2 ? l2[i] : 0u;
+		b[27 + i] = l3 ? l3[i] : 0u;
+	}
+	uint4 *q = (uint4 *)d;
+	const int nq = l3 ? 9 : (l2 ? 7 : 5);
+#pragma unroll
+	for (int i = 0; i < 9; i++) {
+		if (i < nq) {
+			q[i] = make_uint4(b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]);
+		}
+	}
 }
-
-static __device__ __forceinline__ TabEnt tbl_load(const u32 *base, u32 e)
+template <int NQ> static __device__ __forceinline__ void ld(u32 *b, const u32 *s)
 {
-	const uint4 *s = (const uint4 *)(base + e * TBL_WORDS_PER_ENTRY);
-	const uint4 a = s[0], b = s[1], c = s[2], d = s[3], f = s[4], g = s[5], h = s[6];
-	TabEnt P;
-	P.X.l[0] = a.x; P.X.l[1] = a.y; P.X.l[2] = a.z; P.X.l[3] = a.w;
-	P.X.l[4] = b.x; P.X.l[5] = b.y; P.X.l[6] = b.z; P.X.l[7] = b.w;
-	P.X.l[8] = c.x; P.Y.l[0] = c.y; P.Y.l[1] = c.z; P.Y.l[2] = c.w;
-	P.Y.l[3] = d.x; P.Y.l[4] = d.y; P.Y.l[5] = d.z; P.Y.l[6] = d.w;
-	P.Y.l[7] = f.x; P.Y.l[8] = f.y; P.Z.l[0] = f.z; P.Z.l[1] = f.w;
-	P.Z.l[2] = g.x; P.Z.l[3] = g.y; P.Z.l[4] = g.z; P.Z.l[5] = g.w;
-	P.Z.l[6] = h.x; P.Z.l[7] = h.y; P.Z.l[8] = h.z;
+	const uint4 *q = (const uint4 *)s;
+#pragma unroll
+	for (int i = 0; i < NQ; i++) {
+		const uint4 v = q[i];
+		b[4 * i] = v.x;
+		b[4 * i + 1] = v.y;
+		b[4 * i + 2] = v.z;
+		b[4 * i + 3] = v.w;
+	}
+}
+static __device__ __forceinline__ void jac_store(u32 *d, const Jac &P) { st9(d, P.X.l, P.Y.l, P.Z.l, nullptr); }
+static __device__ __forceinline__ Jac jac_load(const u32 *s)
+{
+	u32 b[28];
+	ld<7>(b, s);
+	Jac P;
+#pragma unroll
+	for (int i = 0; i < 9; i++) {
+		P.X.l[i] = b[i];
+		P.Y.l[i] = b[9 + i];
+		P.Z.l[i] = b[18 + i];
+	}
 	return P;
 }
 
@@ -122,18 +151,25 @@ template <class T> static __device__ __forceinline__ T sel(bool c, const T &a, c
 	return r;
 }
 
-// P256_WAVES (2, 3 or 4): register budget as waves per SIMD (512 / 256 -> 2 waves, 168 -> 3, 128 -> 4)
-#ifndef P256_WAVES
-#define P256_WAVES 3
-#endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, P256_WAVES))) void k_smul_p256(EcamdSmulArgs A)
+static __device__ __forceinline__ void zero_out(u8 *out)
+{
+	const uint4 z = make_uint4(0, 0, 0, 0);
+	if ((((uintptr_t)out) & 15) == 0) {
+		((uint4 *)out)[0] = z; ((uint4 *)out)[1] = z; ((uint4 *)out)[2] = z; ((uint4 *)out)[3] = z;
+	} else {
+		for (int b = 0; b < 64; b++) out[b] = 0;
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// A. import + Jacobian multiples 2P..8P
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_p256_table(EcamdSmulArgs A)
 {
 	const u32 i = blockIdx.x * 64 + threadIdx.x;
 	if (i >= A.n) {
 		return;
 	}
-	u8 *out = A.out + (size_t)i * 64;
-
 	// ---- import: X||Y big-endian, coordinates < p, on the curve (curves/prj_pt.c:511-552) ----
 	const u8 *pin = A.points + (size_t)i * A.pstride;
 	u32 xw[8], yw[8];
@@ -153,51 +189,124 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 	}
 	if (!ok) {
 		A.status[i] = 1;
-		uint4 z = make_uint4(0, 0, 0, 0);
-		if ((((uintptr_t)out) & 15) == 0) {
-			((uint4 *)out)[0] = z; ((uint4 *)out)[1] = z; ((uint4 *)out)[2] = z; ((uint4 *)out)[3] = z;
-		} else {
-			for (int b = 0; b < 64; b++) out[b] = 0;
-		}
+		zero_out(A.out + (size_t)i * 64);
 		return;
 	}
-
-	// ---- table [1..8]P, Jacobian ----
 	u32 *tb = A.tbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
+	const Fcanon xa = canonical(xm), ya = canonical(ym);
+	st9(tb, xa.l, ya.l, nullptr, nullptr);  // entry 0: P itself, already affine
 	Jac P1;
 	P1.X = weaken<FX>(xm);
 	P1.Y = weaken<FY>(ym);
 	P1.Z = weaken<FZ>(constant<Fcanon>(K::ONE));
-	bool hz;
-	const TabEnt T1 = to_tab(P1);
-	const FYsel y1 = weaken<FYsel>(T1.Y);
-	tbl_store(tb, 0, T1);
-	{
-		// [2..8]P; intermediate multiples are re-read from the table instead of being kept live
-		// (register pressure): 2P, 3P = 2P + P, 4P = 2(2P), 5P = 4P + P, 6P = 2(3P), 7P = 6P + P, 8P = 2(4P)
-		Jac Pa = dbl(P1);
-		tbl_store(tb, 1, to_tab(Pa));
-		Jac Pb = add_jac(Pa, T1.X, y1, T1.Z, hz);
-		tbl_store(tb, 2, to_tab(Pb));
-		Pa = dbl(Pa);
-		tbl_store(tb, 3, to_tab(Pa));
-		Pb = add_jac(Pa, T1.X, y1, T1.Z, hz);
-		tbl_store(tb, 4, to_tab(Pb));
-		{
-			const TabEnt t3 = tbl_load(tb, 2);
-			Jac P3;
-			P3.X = t3.X;
-			P3.Y = weaken<FY>(t3.Y);
-			P3.Z = t3.Z;
-			Pb = dbl(P3);
-		}
-		tbl_store(tb, 5, to_tab(Pb));
-		Pb = add_jac(Pb, T1.X, y1, T1.Z, hz);
-		tbl_store(tb, 6, to_tab(Pb));
-		Pa = dbl(Pa);
-		tbl_store(tb, 7, to_tab(Pa));
-	}
+	bool hz;  // no exceptional pair can occur below: the group order is an odd prime > 8
+	const FYaff y1 = weaken<FYaff>(ya);
+	Jac Pa = dbl(P1);
+	jac_store(tb + 1 * TBL_WORDS_PER_ENTRY, Pa);
+	Jac Pb = madd(Pa, xa, y1, hz);
+	jac_store(tb + 2 * TBL_WORDS_PER_ENTRY, Pb);
+	Pa = dbl(Pa);
+	jac_store(tb + 3 * TBL_WORDS_PER_ENTRY, Pa);
+	Pb = madd(Pa, xa, y1, hz);
+	jac_store(tb + 4 * TBL_WORDS_PER_ENTRY, Pb);
+	Pb = dbl(jac_load(tb + 2 * TBL_WORDS_PER_ENTRY));
+	jac_store(tb + 5 * TBL_WORDS_PER_ENTRY, Pb);
+	Pb = madd(Pb, xa, y1, hz);
+	jac_store(tb + 6 * TBL_WORDS_PER_ENTRY, Pb);
+	Pa = dbl(Pa);
+	jac_store(tb + 7 * TBL_WORDS_PER_ENTRY, Pa);
+	A.status[i] = ECAMD_STATUS_TAB;
+}
 
+// ------------------------------------------------------------------------------------------
+// B. table -> affine: Montgomery's trick over the 7 Jacobian entries of FIN_K items per lane.
+//    up:   cb_k = c (prefix BEFORE entry k) parked in the entry, c *= Z_k
+//    down: 1/Z_k = t * cb_k, t *= Z_k        with t = 1 / (product of all Z)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_p256_affine(EcamdSmulArgs A, u32 nthreads)
+{
+	const u32 t = blockIdx.x * 64 + threadIdx.x;
+	if (t >= nthreads) {
+		return;
+	}
+	Fmul c = weaken<Fmul>(constant<Fcanon>(K::ONE));
+#pragma unroll 1
+	for (int j = 0; j < AFF_K; j++) {
+		const u32 i = t + (u32)j * nthreads;
+		if (i >= A.n) {
+			break;
+		}
+		if (A.status[i] != ECAMD_STATUS_TAB) {
+			continue;
+		}
+		u32 *tb = A.tbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
+#pragma unroll 1
+		for (int e = 1; e < TBL_ENTRIES; e++) {
+			u32 *ent = tb + e * TBL_WORDS_PER_ENTRY;
+			u32 zb[12];
+			ld<3>(zb, ent + 16);  // words 16..27 cover Z = words 18..26
+			FZ z;
+#pragma unroll
+			for (int w = 0; w < 9; w++) {
+				z.l[w] = zb[2 + w];
+			}
+			// park the prefix before this entry in words 28..36 (16-byte aligned)
+			uint4 *d = (uint4 *)(ent + 28);
+			d[0] = make_uint4(c.l[0], c.l[1], c.l[2], c.l[3]);
+			d[1] = make_uint4(c.l[4], c.l[5], c.l[6], c.l[7]);
+			d[2] = make_uint4(c.l[8], 0u, 0u, 0u);
+			c = weaken<Fmul>(mul(c, z));
+		}
+	}
+	Fmul tinv = inv(c);
+	Fcanon plain1;
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		plain1.l[w] = (w == 0) ? 1u : 0u;
+	}
+	(void)plain1;
+#pragma unroll 1
+	for (int j = AFF_K - 1; j >= 0; j--) {
+		const u32 i = t + (u32)j * nthreads;
+		if (i >= A.n || A.status[i] != ECAMD_STATUS_TAB) {
+			continue;
+		}
+		u32 *tb = A.tbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
+#pragma unroll 1
+		for (int e = TBL_ENTRIES - 1; e >= 1; e--) {
+			u32 *ent = tb + e * TBL_WORDS_PER_ENTRY;
+			const Jac P = jac_load(ent);
+			u32 cb[12];
+			ld<3>(cb, ent + 28);
+			Fmul cbf;
+#pragma unroll
+			for (int w = 0; w < 9; w++) {
+				cbf.l[w] = cb[w];
+			}
+			const Fmul zi = weaken<Fmul>(mul(tinv, cbf));
+			tinv = weaken<Fmul>(mul(tinv, P.Z));
+			const Fmul zi2 = weaken<Fmul>(sqr(zi));
+			const Fmul zi3 = weaken<Fmul>(mul(zi2, zi));
+			const Fcanon ax = canonical(mul(P.X, zi2));  // stays in the Montgomery domain
+			const Fcanon ay = canonical(mul(P.Y, zi3));
+			st9(ent, ax.l, ay.l, nullptr, nullptr);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// C. the window loop
+// ------------------------------------------------------------------------------------------
+#ifndef P256_WAVES
+#define P256_WAVES 3
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, P256_WAVES))) void k_p256_loop(EcamdSmulArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n || A.status[i] != ECAMD_STATUS_TAB) {
+		return;
+	}
+	u32 *tb = A.tbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
 	// ---- scalar: k (<= 32 bytes big-endian) -> k' = k + 0x88..8 over its 2*slen nibbles ----
 	const u8 *sc = A.scalars + (size_t)i * A.sstride;
 	const int slen = (int)A.slen;
@@ -223,8 +332,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 		uint64_t c = 0;
 #pragma unroll
 		for (int w = 0; w < 8; w++) {
-			// bytes of 0x88 only where the scalar has bytes
-			const int nb = slen - 4 * w;
+			const int nb = slen - 4 * w;  // bytes of 0x88 only where the scalar has bytes
 			const u32 add = (nb >= 4) ? 0x88888888u : (nb == 3 ? 0x00888888u : (nb == 2 ? 0x00008888u : (nb == 1 ? 0x00000088u : 0u)));
 			c += (uint64_t)kw[w] + add;
 			kw[w] = (u32)c;
@@ -232,11 +340,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 		}
 		carry_bit = (u32)c;  // only when slen == 32
 		if (slen < 32) {
-			// the carry out of the top nibble sits just above the scalar's bytes
-			const int bit = 8 * slen;
+			const int bit = 8 * slen;  // the carry out of the top nibble sits just above the scalar's bytes
 			carry_bit = (kw[bit >> 5] >> (bit & 31)) & 1u;
-			// left-align so that the top nibble of the scalar is bits 255..252
-			for (int s = slen; s < 32; s++) {
+			for (int s = slen; s < 32; s++) {  // left-align: top nibble of the scalar -> bits 255..252
 #pragma unroll
 				for (int w = 7; w > 0; w--) {
 					kw[w] = (kw[w] << 8) | (kw[w - 1] >> 24);
@@ -246,11 +352,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 		}
 	}
 
-	// ---- signed fixed window, left to right ----
-	Jac acc = P1;
-	bool inf = (carry_bit == 0);  // top digit is the carry: 0 or +1
-	bool bad = false;
+	// ---- signed fixed window, left to right; the top digit is the carry: 0 or +1 ----
+	Jac acc;
+	{
+		u32 b[20];
+		ld<5>(b, tb);
+#pragma unroll
+		for (int w = 0; w < 9; w++) {
+			acc.X.l[w] = b[w];
+			acc.Y.l[w] = b[9 + w];
+		}
+		acc.Z = weaken<FZ>(constant<Fcanon>(K::ONE));
+	}
+	bool inf = (carry_bit == 0);
+	bool bad = false, hz;
 	const int nwin = 2 * slen;
+	const FZ onez = weaken<FZ>(constant<Fcanon>(K::ONE));
 #pragma unroll 1
 	for (int t = 0; t < nwin; t++) {
 #pragma unroll 1
@@ -264,80 +381,49 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 		}
 		kw[0] <<= 4;
 		const u32 mag = (u32)(dig < 0 ? -dig : dig);
-		const TabEnt T = tbl_load(tb, mag ? mag - 1 : 0);
-		const FYsel ty = sel(dig < 0, neg_y(T.Y), weaken<FYsel>(T.Y));
-		const Jac S = add_jac(acc, T.X, ty, T.Z, hz);
+		u32 b[20];
+		ld<5>(b, tb + (mag ? mag - 1 : 0) * TBL_WORDS_PER_ENTRY);
+		Fcanon tx, tyc;
+#pragma unroll
+		for (int w = 0; w < 9; w++) {
+			tx.l[w] = b[w];
+			tyc.l[w] = b[9 + w];
+		}
+		const FYaff ty = sel(dig < 0, neg_aff(tyc), weaken<FYaff>(tyc));
+		const Jac S = madd(acc, tx, ty, hz);
 		const bool use_t = inf & (mag != 0);
 		const bool keep = (mag == 0);
 		bad = bad | (!inf & !keep & hz);
 		// acc = keep ? acc : (use_t ? +-T : S)
-		acc.X = sel(keep, acc.X, sel(use_t, T.X, S.X));
-		acc.Y = sel(keep, acc.Y, sel(use_t, weaken<FY>(ty), S.Y));
-		acc.Z = sel(keep, acc.Z, sel(use_t, T.Z, S.Z));
+		acc.X = sel(keep, acc.X, sel(use_t, weaken<FX>(tx), S.X));
+		acc.Y = sel(keep, acc.Y, sel(use_t, weaken<FY>(carry(ty)), S.Y));
+		acc.Z = sel(keep, acc.Z, sel(use_t, onez, S.Z));
 		inf = inf & keep;
 	}
-
-	// ---- hand the Jacobian result to the finalisation kernel (k_p256_finalize) ----
-	// status: ECAMD_STATUS_REDO (exceptional pair met: the complete-formula kernel recomputes the item),
-	// 2 (infinity), or ECAMD_STATUS_JAC (finite: X, Y, Z stored in the item's first table slot)
+	// ---- hand the Jacobian result to k_p256_finalize (entry 1 of the item's table area) ----
 	if (bad) {
-		A.status[i] = ECAMD_STATUS_REDO;
+		A.status[i] = ECAMD_STATUS_REDO;  // exceptional pair met: the complete-formula kernel recomputes the item
 		return;
 	}
 	if (inf) {
 		A.status[i] = 2;
-		uint4 z = make_uint4(0, 0, 0, 0);
-		if ((((uintptr_t)out) & 15) == 0) {
-			((uint4 *)out)[0] = z; ((uint4 *)out)[1] = z; ((uint4 *)out)[2] = z; ((uint4 *)out)[3] = z;
-		} else {
-			for (int b = 0; b < 64; b++) out[b] = 0;
-		}
+		zero_out(A.out + (size_t)i * 64);
 		return;
 	}
-	{
-		TabEnt R;  // same 28-word record as a table entry, Y left unfolded
-		R.X = acc.X;
-#pragma unroll
-		for (int w = 0; w < 9; w++) {
-			R.Y.l[w] = acc.Y.l[w];
-		}
-		R.Z = acc.Z;
-		tbl_store(tb, 0, R);
-	}
+	jac_store(tb + 1 * TBL_WORDS_PER_ENTRY, acc);
 	A.status[i] = ECAMD_STATUS_JAC;
 }
 
 // ------------------------------------------------------------------------------------------
-// Finalisation: Jacobian -> affine for K items per lane with ONE field inversion (Montgomery's
-// trick): c_j = Z_0 ... Z_j, t = 1 / c_{K-1}, then Z_j^-1 = t c_{j-1}, t *= Z_j going down.
-// The scalar-multiplication kernel spends 255 S + 13 M per item on its inversion otherwise
-// (6 % of its time); here that cost is shared by K items and each item pays 3 extra mults.
-// Prefix products are parked in the item's second table slot.
+// D. finalisation: Jacobian -> affine for FIN_K items per lane with ONE field inversion
 // ------------------------------------------------------------------------------------------
-#define FIN_K 8
-
-static __device__ __forceinline__ Jac load_jac(const u32 *tb)
-{
-	const TabEnt t = tbl_load(tb, 0);
-	Jac P;
-	P.X = t.X;
-#pragma unroll
-	for (int w = 0; w < 9; w++) {
-		P.Y.l[w] = t.Y.l[w];
-	}
-	P.Z = t.Z;
-	return P;
-}
-
 __global__ __launch_bounds__(64) void k_p256_finalize(EcamdSmulArgs A, u32 nthreads)
 {
 	const u32 t = blockIdx.x * 64 + threadIdx.x;
 	if (t >= nthreads) {
 		return;
 	}
-	const Fcanon one = constant<Fcanon>(K::ONE);
-	// ---- up: prefix products ----
-	Fmul c = weaken<Fmul>(one);
+	Fmul c = weaken<Fmul>(constant<Fcanon>(K::ONE));
 #pragma unroll 1
 	for (int j = 0; j < FIN_K; j++) {
 		const u32 i = t + (u32)j * nthreads;
@@ -345,24 +431,22 @@ __global__ __launch_bounds__(64) void k_p256_finalize(EcamdSmulArgs A, u32 nthre
 			break;
 		}
 		u32 *tb = A.tbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
-		if (A.status[i] == ECAMD_STATUS_JAC) {
-			const Jac P = load_jac(tb);
-			c = weaken<Fmul>(mul(c, P.Z));
-		}
-		// park c_j (exact digits) in the second table slot
-		uint4 *d = (uint4 *)(tb + TBL_WORDS_PER_ENTRY);
+		// park the prefix BEFORE this item in entry 2
+		uint4 *d = (uint4 *)(tb + 2 * TBL_WORDS_PER_ENTRY);
 		d[0] = make_uint4(c.l[0], c.l[1], c.l[2], c.l[3]);
 		d[1] = make_uint4(c.l[4], c.l[5], c.l[6], c.l[7]);
 		d[2] = make_uint4(c.l[8], 0u, 0u, 0u);
+		if (A.status[i] == ECAMD_STATUS_JAC) {
+			const Jac P = jac_load(tb + 1 * TBL_WORDS_PER_ENTRY);
+			c = weaken<Fmul>(mul(c, P.Z));
+		}
 	}
-	// ---- one inversion ----
 	Fmul tinv = inv(c);
 	Fcanon plain1;
 #pragma unroll
 	for (int w = 0; w < 9; w++) {
 		plain1.l[w] = (w == 0) ? 1u : 0u;
 	}
-	// ---- down ----
 #pragma unroll 1
 	for (int j = FIN_K - 1; j >= 0; j--) {
 		const u32 i = t + (u32)j * nthreads;
@@ -370,18 +454,15 @@ __global__ __launch_bounds__(64) void k_p256_finalize(EcamdSmulArgs A, u32 nthre
 			continue;
 		}
 		u32 *tb = A.tbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
-		const Jac P = load_jac(tb);
-		Fmul zi = tinv;
-		if (j > 0) {
-			const u32 ip = t + (u32)(j - 1) * nthreads;
-			const uint4 *s = (const uint4 *)(A.tbl + (size_t)ip * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY) + TBL_WORDS_PER_ENTRY);
-			const uint4 a = s[0], b = s[1], cc = s[2];
-			Fmul cp;
-			cp.l[0] = a.x; cp.l[1] = a.y; cp.l[2] = a.z; cp.l[3] = a.w;
-			cp.l[4] = b.x; cp.l[5] = b.y; cp.l[6] = b.z; cp.l[7] = b.w;
-			cp.l[8] = cc.x;
-			zi = weaken<Fmul>(mul(tinv, cp));
+		const Jac P = jac_load(tb + 1 * TBL_WORDS_PER_ENTRY);
+		u32 cb[12];
+		ld<3>(cb, tb + 2 * TBL_WORDS_PER_ENTRY);
+		Fmul cbf;
+#pragma unroll
+		for (int w = 0; w < 9; w++) {
+			cbf.l[w] = cb[w];
 		}
+		const Fmul zi = weaken<Fmul>(mul(tinv, cbf));
 		tinv = weaken<Fmul>(mul(tinv, P.Z));
 		const Fmul zi2 = weaken<Fmul>(sqr(zi));
 		const Fmul zi3 = weaken<Fmul>(mul(zi2, zi));
@@ -402,8 +483,13 @@ hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s)
 	if (a.n == 0) {
 		return hipSuccess;
 	}
-	hipLaunchKernelGGL(k_smul_p256, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+	const dim3 grid((a.n + 63) / 64), block(64);
 	const uint32_t nthreads = (a.n + FIN_K - 1) / FIN_K;
-	hipLaunchKernelGGL(k_p256_finalize, dim3((nthreads + 63) / 64), dim3(64), 0, s, a, nthreads);
+	const dim3 fgrid((nthreads + 63) / 64);
+	hipLaunchKernelGGL(k_p256_table, grid, block, 0, s, a);
+	const uint32_t athreads = (a.n + AFF_K - 1) / AFF_K;
+	hipLaunchKernelGGL(k_p256_affine, dim3((athreads + 63) / 64), block, 0, s, a, athreads);
+	hipLaunchKernelGGL(k_p256_loop, grid, block, 0, s, a);
+	hipLaunchKernelGGL(k_p256_finalize, fgrid, block, 0, s, a, nthreads);
 	return hipGetLastError();
 }

@@ -373,16 +373,16 @@ template <class A> U29_FN F<MASK + (A::LB >> W), A::TB + (A::LB >> W), A::VB> ca
 	return r;
 }
 
-// value < 7p  ->  value < (1 + 2^-20) p ... well below 17/16 p, limbs normalised by a second
+// value < 8p  ->  value < (1 + 2^-20) p ... well below 17/16 p, limbs normalised by a second
 // carry round.  q = value >> 256 (from the top limb), value -= q 2^256, value += q delta.
 template <class A> U29_FN F<MASK + 16, (1ull << 24) + 16, 17> fold(const A &a0)
 {
 	const auto a = carry(a0);
 	typedef decltype(a) C;
-	static_assert(C::LB <= MASK + 8, "fold: input limbs too loose");
-	static_assert((C::TB >> 24) <= 6, "fold: value too large (q must be <= 6)");
+	static_assert(C::LB <= MASK + 7, "fold: input limbs too loose");
+	static_assert((C::TB >> 24) <= 7, "fold: value too large (q must be <= 7)");
 	const u32 q = a.l[8] >> 24;
-	F<(u64)MASK + 8 + 6ull * MASK, (1ull << 24), 17> t;
+	F<(u64)MASK + 7 + 7ull * MASK, (1ull << 24), 17> t;  // <= 2^32 - 1
 	t.l[0] = a.l[0] + q;  // D[0] = 1
 	t.l[1] = a.l[1];
 	t.l[2] = a.l[2];

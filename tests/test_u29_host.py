@@ -208,6 +208,29 @@ def test_jacobian_dbl_add(lib):
     assert hz == 1 and jac_to_aff(out) is None
 
 
+def test_mixed_addition(lib):
+    rng = np.random.default_rng(26)
+    lib.t_madd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    for it in range(40):
+        P, Q = aff_mul(int(rng.integers(1, 2**40)), G), aff_mul(int(rng.integers(1, 2**40)), G)
+        Pj = jac_of(rng, P, 0, int(rng.integers(0, 5)), int(rng.integers(0, 3)), ACC)
+        flat = Pj[0] + Pj[1] + Pj[2]
+        qa = limbs(Q[0] * R % p) + limbs(Q[1] * R % p)
+        for negate in (0, 1):
+            out = (C.c_uint32 * 27)()
+            hz = lib.t_madd(arr(flat), arr(qa), out, negate)
+            Qs = (Q[0], (p - Q[1]) % p) if negate else Q
+            assert hz == 0 and jac_to_aff(list(out)) == aff_add(P, Qs)
+            o = list(out)
+            assert val(o[0:9]) * 16 < 17 * p and val(o[9:18]) < 6 * p and val(o[18:27]) * 2 < 7 * p
+    P = aff_mul(777, G)
+    Pj = jac_of(rng, P, 0, 3, 2, ACC)
+    qa = limbs(P[0] * R % p) + limbs(P[1] * R % p)
+    out = (C.c_uint32 * 27)()
+    assert lib.t_madd(arr(Pj[0] + Pj[1] + Pj[2]), arr(qa), out, 0) == 1
+    assert lib.t_madd(arr(Pj[0] + Pj[1] + Pj[2]), arr(qa), out, 1) == 1 and jac_to_aff(list(out)) is None
+
+
 def test_jacobian_chain_stays_in_bounds(lib):
     """200 consecutive doublings/additions through the loop-carried classes"""
     rng = np.random.default_rng(25)

@@ -96,6 +96,22 @@ int t_add(const uint32_t *p, const uint32_t *q, uint32_t *out)
 	memcpy(out + 18, R.Z.l, 36);
 	return hz ? 1 : 0;
 }
+int t_madd(const uint32_t *p, const uint32_t *q, uint32_t *out, int negate)
+{
+	Jac P;
+	memcpy(P.X.l, p, 36);
+	memcpy(P.Y.l, p + 9, 36);
+	memcpy(P.Z.l, p + 18, 36);
+	Fcanon X2, Y2;
+	memcpy(X2.l, q, 36);
+	memcpy(Y2.l, q + 9, 36);
+	bool hz;
+	Jac R = negate ? madd(P, X2, neg_aff(Y2), hz) : madd(P, X2, weaken<FYaff>(Y2), hz);
+	memcpy(out, R.X.l, 36);
+	memcpy(out + 9, R.Y.l, 36);
+	memcpy(out + 18, R.Z.l, 36);
+	return hz ? 1 : 0;
+}
 void t_consts(uint32_t *out)  // P, D, R2, ONE, BM (9 each), Q3 Q6 Q7 Q8
 {
 	memcpy(out, u29::P256::P, 36);
