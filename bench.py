@@ -68,7 +68,8 @@ def work_model(curve_params, nw, slen):
         # k_p256_finalize: prefix 1M, (255S + 13M)/fin_k, back-substitution 2M, affine 1S + 3M, from Montgomery 2M
         nm += 1 + 13 / fin_k + 2 + 3 + 2
         ns += 255 / fin_k + 1
-        return nm + ns, nm * M + ns * S, "k_p256_loop (+ k_p256_table, k_p256_affine, k_p256_finalize)"
+        loop_mads = nwin * ((4 * dbl[0] + madd[0]) * M + (4 * dbl[1] + madd[1]) * S)
+        return nm + ns, nm * M + ns * S, "k_p256_loop", loop_mads
     fin_k = 8
     if slen <= 4 * ((pbits + 31) // 32):
         # generic radix-2^29 Jacobian kernels k_smul_g<|p|> + k_finalize_g<|p|> (ecamd_g29_kernel.hip):
@@ -84,7 +85,8 @@ def work_model(curve_params, nw, slen):
         inv_s, inv_m = pbits, popcount(p - 2)
         nm += 1 + inv_m / fin_k + 2 + 3 + 2
         ns += inv_s / fin_k + 1
-        return nm + ns, nm * M + ns * S, f"k_smul_g<{pbits}> (+ k_finalize_g)"
+        loop_mads = (nm - (1 + inv_m / fin_k + 2 + 3 + 2)) * M + (ns - (inv_s / fin_k + 1)) * S
+        return nm + ns, nm * M + ns * S, f"k_smul_g<{pbits}>", loop_mads
     mm_add, mm_dbl = 17, 16                              # RCB Alg. 1 / Alg. 3, generic a
     mm = 2 + 3                                           # to Montgomery (x, y) + on-curve check
     mm += 14 * mm_add                                    # table [2..15]P
@@ -92,7 +94,7 @@ def work_model(curve_params, nw, slen):
     mm += pbits + popcount(p - 2)                        # Fermat inversion (square-and-multiply)
     mm += 2 + 2                                          # X/Z, Y/Z, from Montgomery
     mads_per_mm = 2 * nw * nw + nw                       # FIPS Montgomery multiplication, 32-bit words
-    return mm, mm * mads_per_mm, f"k_smul<{nw}>"
+    return mm, mm * mads_per_mm, f"k_smul<{nw}>", mm * mads_per_mm
 
 
 def ref_equiv_mads():
@@ -108,6 +110,21 @@ def measured_mad_peak():
         return j["v_mad_u64_u32"]["lane_ops_per_s"], j
     except Exception:
         return None, None
+
+
+def pmc_traffic(kernel, batch_log2):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_r1c.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected separately; gfx950 correction 2 x FETCH_SIZE).
+    Only valid for the batch size it was collected at; null otherwise.  It is window-table scratch
+    traffic (64 look-ups x 80 B per item), not re-reads of the 160 algorithmic bytes per item."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "pmc_r1c.json")))
+        k = j["kernels"][kernel]
+        if batch_log2 != 20:
+            return None
+        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
 
 
 def cpu_baseline(curve, scalars, points, slen):
@@ -249,11 +266,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    ctx.enable_kernel_timing(True)   # HIP events inside the library, on the stream the kernels run on
+    ktimes = []
     t0 = time.perf_counter()
     ev[0].record(stream)
     for k in range(args.steps):
         step()
         ev[k + 1].record(stream)
+        try:
+            ktimes.append(ctx.kernel_times())   # [table, affine, loop, finalize] ms of this launch
+        except libecc_amd.EcamdError:
+            pass
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -268,15 +291,21 @@ def main():
     if rank == 0:
         total_items = B * world * args.steps
         value = total_items / elapsed
-        mm, mads, kname = work_model(cp, cv.words, slen)
-        launch_ms = float(np.mean(kern_ms))           # HIP-event time of one step on the launch stream
-        mad_rate = B * mads / (launch_ms * 1e-3)       # executed lane-MADs per second, one GPU
+        mm, mads, kname, kmads = work_model(cp, cv.words, slen)
+        step_ms = float(np.mean(kern_ms))             # HIP-event time of one whole step on the launch stream
+        if ktimes:
+            kt = np.mean(np.array(ktimes), axis=0)     # per-kernel averages over the timed steps
+            launch_ms = float(kt[2])                   # the dominant kernel: the window loop
+            knames = ["table", "affine", "loop", "finalize"]
+        else:
+            kt, launch_ms, kmads = None, step_ms, mads
+        mad_rate = B * kmads / (launch_ms * 1e-3)      # executed lane-MADs per second of the dominant kernel
         peak, ub = (None, None)
         if world == 1:
             peak, ub = measured_mad_peak()
         nominal_quarter = 256 * 4 * 16 * 2.4e9 / 4.0   # SURVEY.md 8d planning figure (quarter rate)
         alg_bytes = float(slen + 2 * plen)             # scalar + affine point in + affine point out (160 B for P-256)
-        hbm_rate = B * alg_bytes / (launch_ms * 1e-3)
+        hbm_rate = B * alg_bytes / (step_ms * 1e-3)
         line = {
             "metric": f"scalar-mults/sec ({curve.lower()}, batch=2^{args.batch_log2}, variable base, affine out, bit-exact vs CPU)",
             "value": value, "unit": "scalar-mults/s", "n_gpus": world, "steps": args.steps,
@@ -293,10 +322,12 @@ def main():
                 "achieved": mad_rate / 1e9, "peak": (peak or nominal_quarter) / 1e9, "unit": "GMAD/s",
                 "frac": mad_rate / (peak or nominal_quarter),
                 "peak_source": "measured live by libecc_amd/lib/ubench" if peak else "nominal quarter-rate estimate",
-                "kernel": kname, "kernel_ms": launch_ms,
+                "kernel": kname, "kernel_ms": launch_ms, "kernel_mads_per_item": kmads,
+                "pipeline_ms": ({k_: float(v) for k_, v in zip(knames, kt)} if kt is not None else None),
+                "step_ms": step_ms, "pipeline_frac": (B * mads / (step_ms * 1e-3)) / (peak or nominal_quarter),
                 "field_mults_per_item": mm, "mads_per_item": mads,
                 "ref_equivalent_mads_per_item": ref_equiv_mads(),
-                "traffic": None,
+                "traffic": pmc_traffic(kname, args.batch_log2),
                 "hbm": {"achieved": hbm_rate / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": hbm_rate / 8e12, "algorithmic_bytes_per_item": alg_bytes},
             },

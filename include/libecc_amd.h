@@ -45,6 +45,12 @@ const char *ecamd_last_error(void);
 /* Upper bound on the items processed per kernel launch (bounds the per-lane window-table
  * scratch: 16 * 3 * 4*ceil(|p|/32) bytes per item).  Default 2^20. */
 int ecamd_ctx_set_max_chunk(ecamd_ctx *ctx, uint32_t max_items);
+/* Measurement hook: when enabled, HIP events are recorded (on the stream the kernels run on) around
+ * the kernels of the next ec_prj_pt_mul_batch[_dev] call; ecamd_ctx_kernel_times() waits for them and
+ * returns the 4 durations in ms: table, table->affine, window loop, finalisation (the generic
+ * radix-2^29 path reports 0, 0, loop, finalisation). */
+int ecamd_ctx_enable_kernel_timing(ecamd_ctx *ctx, int on);
+int ecamd_ctx_kernel_times(ecamd_ctx *ctx, double *ms, int n);
 
 /* ---- curves: ec_get_curve_params_by_name (curves/curves.h:21) + import_params
  *      (curves/ec_params.h:89).  Same 44 names as libecc's ec_maps[] ("SECP256R1", ...). ---- */

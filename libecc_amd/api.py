@@ -9,7 +9,7 @@ FP_MUL_MONTY, FP_ADD, FP_SUB, FP_MUL, FP_INV = 0, 1, 2, 3, 4
 # every symbol include/libecc_amd.h declares (tests check the .so exports exactly these)
 EXPORTED_SYMBOLS = [
     "ecamd_device_count", "ecamd_ctx_create", "ecamd_ctx_destroy", "ecamd_last_error",
-    "ecamd_ctx_set_max_chunk", "ecamd_curve_by_name", "ecamd_curve_from_params", "ecamd_curve_free",
+    "ecamd_ctx_set_max_chunk", "ecamd_ctx_enable_kernel_timing", "ecamd_ctx_kernel_times", "ecamd_curve_by_name", "ecamd_curve_from_params", "ecamd_curve_free",
     "ecamd_curve_coord_len", "ecamd_curve_order_len", "ecamd_curve_words", "ec_prj_pt_mul_batch",
     "ec_prj_pt_mul_batch_dev", "ecamd_ctx_synchronize", "ec_prj_pt_add_batch", "ec_prj_pt_dbl_batch",
     "ec_fp_op_batch", "ec_ecdsa_verify_batch", "ec_ecdsa_sign_batch", "ec_ecccdh_derive_batch",
@@ -44,6 +44,8 @@ def load_library():
         L.ecamd_ctx_destroy.restype = None
         L.ecamd_ctx_set_max_chunk.argtypes = [vp, u32]
         L.ecamd_ctx_synchronize.argtypes = [vp]
+        L.ecamd_ctx_enable_kernel_timing.argtypes = [vp, C.c_int]
+        L.ecamd_ctx_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
         L.ecamd_curve_by_name.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
         L.ecamd_curve_from_params.argtypes = [vp] + [u8p, u32] * 7 + [C.POINTER(vp)]
         L.ecamd_curve_free.argtypes = [vp]
@@ -82,6 +84,15 @@ class Context:
 
     def set_max_chunk(self, n):
         _chk(self.L, self.L.ecamd_ctx_set_max_chunk(self.h, n), "ecamd_ctx_set_max_chunk")
+
+    def enable_kernel_timing(self, on=True):
+        _chk(self.L, self.L.ecamd_ctx_enable_kernel_timing(self.h, 1 if on else 0), "ecamd_ctx_enable_kernel_timing")
+
+    def kernel_times(self):
+        """ms of [table, affine, loop, finalize] of the last fast-path batch (HIP events on its stream)"""
+        ms = (C.c_double * 4)()
+        _chk(self.L, self.L.ecamd_ctx_kernel_times(self.h, ms, 4), "ecamd_ctx_kernel_times")
+        return list(ms)
 
     def synchronize(self):
         _chk(self.L, self.L.ecamd_ctx_synchronize(self.h), "ecamd_ctx_synchronize")

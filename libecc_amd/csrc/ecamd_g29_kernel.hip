@@ -405,13 +405,25 @@ hipError_t G29_CAT(ecamd_g29_upload_, G29_PB)(int slot, const void *img, size_t 
 	return hipMemcpyToSymbol(HIP_SYMBOL(G29_CAT(g_g29_, G29_PB)), img, bytes, (size_t)slot * sizeof(CK), hipMemcpyHostToDevice);
 }
 
-hipError_t G29_CAT(ecamd_g29_launch_, G29_PB)(int gslot, const EcamdSmulArgs &a, hipStream_t s)
+hipError_t G29_CAT(ecamd_g29_launch_, G29_PB)(int gslot, const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev)
 {
 	const dim3 grid((a.n + 63) / 64), block(64);
 	const uint32_t nthreads = (a.n + FING_K - 1) / FING_K;
 	const dim3 fgrid((nthreads + 63) / 64);
+	// event slots as in ecamd_launch_smul_p256: [0] start, [3] after the loop kernel, [4] after finalisation
+	if (ev) {
+		(void)hipEventRecord(ev[0], s);
+		(void)hipEventRecord(ev[1], s);
+		(void)hipEventRecord(ev[2], s);
+	}
 	hipLaunchKernelGGL(k_smul_g<G29_PB>, grid, block, 0, s, a, gslot);
+	if (ev) {
+		(void)hipEventRecord(ev[3], s);
+	}
 	hipLaunchKernelGGL(k_finalize_g<G29_PB>, fgrid, block, 0, s, a, gslot, nthreads);
+	if (ev) {
+		(void)hipEventRecord(ev[4], s);
+	}
 	return hipGetLastError();
 }
 #endif
@@ -421,7 +433,7 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_PB)(int gslot, const EcamdSmulArgs &a,
 #define G29_FOR_PB(X) X(192) X(224) X(255) X(256) X(320) X(384) X(448) X(511) X(512) X(521)
 #define X(PB) \
 	hipError_t ecamd_g29_upload_##PB(int slot, const void *img, size_t bytes); \
-	hipError_t ecamd_g29_launch_##PB(int gslot, const EcamdSmulArgs &a, hipStream_t s);
+	hipError_t ecamd_g29_launch_##PB(int gslot, const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev);
 G29_FOR_PB(X)
 #undef X
 
@@ -450,13 +462,13 @@ hipError_t ecamd_g29_upload(int pbits, int slot, const void *img, size_t bytes)
 	}
 }
 
-hipError_t ecamd_launch_smul_g29(int pbits, int gslot, const EcamdSmulArgs &a, hipStream_t s)
+hipError_t ecamd_launch_smul_g29(int pbits, int gslot, const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev)
 {
 	if (a.n == 0) {
 		return hipSuccess;
 	}
 	switch (pbits) {
-#define X(PB) case PB: return ecamd_g29_launch_##PB(gslot, a, s);
+#define X(PB) case PB: return ecamd_g29_launch_##PB(gslot, a, s, ev);
 		G29_FOR_PB(X)
 #undef X
 	default: return hipErrorInvalidValue;

@@ -216,7 +216,10 @@ struct ecamd_ctx {
 	uint8_t *stage[ECAMD_NSTAGE];
 	size_t stage_bytes[ECAMD_NSTAGE];
 	bool slot_used[ECAMD_MAX_SLOTS_HOST];
-	bool gslot_used[640][8];  // radix-2^29 constant slots, indexed by |p| in bits
+	bool gslot_used[640][8];
+	bool timing;               // record HIP events around the kernels of the scalar-mult pipeline
+	hipEvent_t ev[ECAMD_NTIMED + 1];
+	bool ev_valid;  // radix-2^29 constant slots, indexed by |p| in bits
 	std::mutex mu;
 };
 
@@ -285,6 +288,14 @@ extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
 		c->slot_used[i] = false;
 	}
 	memset(c->gslot_used, 0, sizeof(c->gslot_used));
+	c->timing = false;
+	c->ev_valid = false;
+	for (int i = 0; i <= ECAMD_NTIMED; i++) {
+		if (hipEventCreate(&c->ev[i]) != hipSuccess) {
+			delete c;
+			return fail("ecamd_ctx_create: hipEventCreate failed");
+		}
+	}
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
 		delete c;
 		return fail("ecamd_ctx_create: hipStreamCreate failed");
@@ -311,6 +322,9 @@ extern "C" void ecamd_ctx_destroy(ecamd_ctx *c)
 			(void)hipFree(c->stage[i]);
 		}
 	}
+	for (int i = 0; i <= ECAMD_NTIMED; i++) {
+		(void)hipEventDestroy(c->ev[i]);
+	}
 	(void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -321,6 +335,36 @@ extern "C" int ecamd_ctx_set_max_chunk(ecamd_ctx *c, uint32_t max_items)
 		return fail("ecamd_ctx_set_max_chunk: bad argument");
 	}
 	c->max_chunk = max_items;
+	return 0;
+}
+
+extern "C" int ecamd_ctx_enable_kernel_timing(ecamd_ctx *c, int on)
+{
+	if (!c) {
+		return fail("ecamd_ctx_enable_kernel_timing: NULL context");
+	}
+	std::lock_guard<std::mutex> lk(c->mu);
+	c->timing = on != 0;
+	c->ev_valid = false;
+	return 0;
+}
+
+extern "C" int ecamd_ctx_kernel_times(ecamd_ctx *c, double *ms, int n)
+{
+	if (!c || !ms || n < ECAMD_NTIMED - 1) {
+		return fail("ecamd_ctx_kernel_times: bad argument (need room for 4 values)");
+	}
+	std::lock_guard<std::mutex> lk(c->mu);
+	if (!c->timing || !c->ev_valid) {
+		return fail("ecamd_ctx_kernel_times: timing not enabled or no fast-path batch ran since");
+	}
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipEventSynchronize(c->ev[ECAMD_NTIMED - 1]));
+	for (int i = 0; i < ECAMD_NTIMED - 1; i++) {
+		float f = 0.0f;
+		HIPCHK(hipEventElapsedTime(&f, c->ev[i], c->ev[i + 1]));
+		ms[i] = (double)f;
+	}
 	return 0;
 }
 
@@ -693,11 +737,13 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 			// are recomputed by the complete-formula kernel (all other lanes exit at once)
 			EcamdSmulArgs Fa = A;
 			Fa.tbl = ctx->tbl_fast;
+			hipEvent_t *ev = (ctx->timing && off == 0) ? ctx->ev : nullptr;  // first chunk of the call
 			if (fast256) {
-				HIPCHK(ecamd_launch_smul_p256(Fa, s));
+				HIPCHK(ecamd_launch_smul_p256(Fa, s, ev));
 			} else {
-				HIPCHK(ecamd_launch_smul_g29(cv->pbits, cv->gslot, Fa, s));
+				HIPCHK(ecamd_launch_smul_g29(cv->pbits, cv->gslot, Fa, s, ev));
 			}
+			ctx->ev_valid = ctx->ev_valid || (ev != nullptr);
 			A.only_redo = 1;
 		}
 		HIPCHK(ecamd_launch_smul(cv->nw, A, s));

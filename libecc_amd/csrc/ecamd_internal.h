@@ -71,7 +71,9 @@ hipError_t ecamd_launch_ecdsa_fin(int nw, const EcamdEcdsaFinArgs &a, hipStream_
 int ecamd_nw_supported(int nw);
 hipError_t ecamd_upload_curve(int nw, int slot, const void *curvek, size_t bytes);
 hipError_t ecamd_launch_smul(int nw, const EcamdSmulArgs &a, hipStream_t s);
-hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s);
+// ev (optional, 6 events): recorded before the first kernel and after each kernel of the pipeline
+#define ECAMD_NTIMED 5
+hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev);
 // radix-2^29 Jacobian fast path for every field size (ecamd_g29_kernel.hip)
 int ecamd_g29_supported(int pbits);
 int ecamd_g29_nl(int pbits);
@@ -80,7 +82,7 @@ uint32_t ecamd_g29_table_words(int pbits);   // scratch words per item
 uint32_t ecamd_g29_max_slen(int pbits);      // longest scalar (bytes) the fast path takes
 size_t ecamd_g29_image_bytes(int pbits);
 hipError_t ecamd_g29_upload(int pbits, int slot, const void *img, size_t bytes);
-hipError_t ecamd_launch_smul_g29(int pbits, int gslot, const EcamdSmulArgs &a, hipStream_t s);
+hipError_t ecamd_launch_smul_g29(int pbits, int gslot, const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev);
 hipError_t ecamd_launch_fp(int nw, const EcamdFpArgs &a, hipStream_t s);
 hipError_t ecamd_launch_pt(int nw, const EcamdPtArgs &a, hipStream_t s);
 size_t ecamd_curvek_bytes(int nw);

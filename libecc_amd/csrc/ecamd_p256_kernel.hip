@@ -478,7 +478,7 @@ __global__ __launch_bounds__(64) void k_p256_finalize(EcamdSmulArgs A, u32 nthre
 	}
 }
 
-hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s)
+hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev)
 {
 	if (a.n == 0) {
 		return hipSuccess;
@@ -486,10 +486,16 @@ hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s)
 	const dim3 grid((a.n + 63) / 64), block(64);
 	const uint32_t nthreads = (a.n + FIN_K - 1) / FIN_K;
 	const dim3 fgrid((nthreads + 63) / 64);
+#define P256_MARK(i) do { if (ev) (void)hipEventRecord(ev[i], s); } while (0)
+	P256_MARK(0);
 	hipLaunchKernelGGL(k_p256_table, grid, block, 0, s, a);
+	P256_MARK(1);
 	const uint32_t athreads = (a.n + AFF_K - 1) / AFF_K;
 	hipLaunchKernelGGL(k_p256_affine, dim3((athreads + 63) / 64), block, 0, s, a, athreads);
+	P256_MARK(2);
 	hipLaunchKernelGGL(k_p256_loop, grid, block, 0, s, a);
+	P256_MARK(3);
 	hipLaunchKernelGGL(k_p256_finalize, fgrid, block, 0, s, a, nthreads);
+	P256_MARK(4);
 	return hipGetLastError();
 }
