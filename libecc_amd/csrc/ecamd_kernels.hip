@@ -297,8 +297,8 @@ template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_prep(EcamdEcdsaP
 
 // __ecdsa_sign_finalize (sig/ecdsa_common.c:318-586) after kG: r = kG.x mod q, s = k^-1 (x r + e) mod q.
 // The nonce k is an input (the reference takes it from ctx->rand; its KAT harness injects it the same
-// way).  status 1: k not in [1, q-1], or one of the reference's restart conditions (r = 0, e == x r... no:
-// e + x r == 0 is checked as e == -(x r)?  the reference compares e with x r, :516), s = 0.
+// way).  status 1: k not in [1, q-1], or one of the reference's restart conditions, which a fixed
+// nonce cannot get past: r = 0 (:492), e == x r (:516), s = 0 (:548).
 template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_sign(EcamdEcdsaSignArgs A)
 {
 	const u32 i = blockIdx.x * 64 + threadIdx.x;

@@ -258,6 +258,37 @@ def test_linearity_large_batch(gpu_ctx):
         cv.free()
 
 
+def test_full_batch_properties(gpu_ctx):
+    """BASELINE.json's full size (2^20 items, one launch): every item is checked through
+    [a]([b]G) == [a b mod q]G, computed three ways on the GPU, plus 256 random items against the oracle"""
+    curve = "SECP256R1"
+    cv = gpu_ctx.curve(curve)
+    o = Oracle(curve)
+    try:
+        q = CURVES[curve]["q"]
+        n = 1 << 20
+        rng = np.random.default_rng(10)
+        raw = rng.integers(0, 256, size=(2, n, 40), dtype=np.uint8)
+        a = [int.from_bytes(raw[0, i].tobytes(), "big") % q for i in range(n)]
+        b = [int.from_bytes(raw[1, i].tobytes(), "big") % q for i in range(n)]
+        A = b"".join(x.to_bytes(32, "big") for x in a)
+        B = b"".join(x.to_bytes(32, "big") for x in b)
+        AB = b"".join((x * y % q).to_bytes(32, "big") for x, y in zip(a, b))
+        bG, st = cv.scalar_mult(B)
+        assert st == bytes(n) or set(st) <= {0, 2}
+        abG, st1 = cv.scalar_mult(A, bG)
+        abG2, st2 = cv.scalar_mult(AB)
+        assert st1 == st2 and abG == abG2
+        idx = rng.choice(n, size=256, replace=False)
+        sub = b"".join(A[i * 32:(i + 1) * 32] for i in idx)
+        subp = b"".join(bG[i * 64:(i + 1) * 64] for i in idx)
+        exp, est = o.scalar_mult(sub, subp)
+        assert exp == b"".join(abG[i * 64:(i + 1) * 64] for i in idx)
+        assert est == bytes(st1[i] for i in idx)
+    finally:
+        cv.free()
+
+
 def test_long_and_short_scalars(gpu_ctx):
     """scalar_len other than |q|: 1 byte, 8 bytes, 2|q|+8 bytes (blinded-size scalars, m >= q^2 branch)"""
     curve = "SECP256R1"
