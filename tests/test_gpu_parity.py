@@ -289,16 +289,18 @@ def test_full_batch_properties(gpu_ctx):
         cv.free()
 
 
-def test_long_and_short_scalars(gpu_ctx):
-    """scalar_len other than |q|: 1 byte, 8 bytes, 2|q|+8 bytes (blinded-size scalars, m >= q^2 branch)"""
-    curve = "SECP256R1"
+@pytest.mark.parametrize("curve", ["SECP256R1", "BRAINPOOLP256R1", "SECP384R1", "SECP521R1", "WEI25519"])
+def test_long_and_short_scalars(gpu_ctx, curve):
+    """scalar_len other than |q|: 1 byte ... the field size (fast paths, left-aligned recoding) and
+    beyond it (blinded-size scalars, m >= q^2 branch of the reference: saturated complete-formula kernel)"""
     rng = np.random.default_rng(6)
     cv = gpu_ctx.curve(curve)
     o = Oracle(curve)
     try:
-        for slen in (1, 8, 33, 72):
-            sc = rand_bytes(rng, slen * 16)
-            assert cv.scalar_mult(sc, None, slen) == o.scalar_mult(sc, None, slen), slen
+        for slen in (1, 2, 3, 8, o.qlen - 1, o.qlen + 1, 4 * ((CURVES[curve]["p"].bit_length() + 31) // 32),
+                     4 * ((CURVES[curve]["p"].bit_length() + 31) // 32) + 1, 2 * o.qlen + 8):
+            sc = rand_bytes(rng, slen * 13) + b"\xff" * slen + b"\x00" * slen + b"\x88" * slen
+            assert cv.scalar_mult(sc, None, slen) == o.scalar_mult(sc, None, slen), (curve, slen)
     finally:
         cv.free()
 
