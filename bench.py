@@ -300,9 +300,8 @@ def main():
         else:
             kt, launch_ms, kmads = None, step_ms, mads
         mad_rate = B * kmads / (launch_ms * 1e-3)      # executed lane-MADs per second of the dominant kernel
-        peak, ub = (None, None)
-        if world == 1:
-            peak, ub = measured_mad_peak()
+        # the MAD issue peak is a per-GPU number: measured on rank 0's GPU after the timed region
+        peak, ub = measured_mad_peak()
         nominal_quarter = 256 * 4 * 16 * 2.4e9 / 4.0   # SURVEY.md 8d planning figure (quarter rate)
         alg_bytes = float(slen + 2 * plen)             # scalar + affine point in + affine point out (160 B for P-256)
         hbm_rate = B * alg_bytes / (step_ms * 1e-3)
@@ -319,7 +318,7 @@ def main():
                        "parity_gate": "128 random items byte-identical to the CPU oracle"},
             "roofline": {
                 "bound": "valu-int-mad (v_mad_u64_u32 issue; not hbm, not mfma -- SURVEY.md 8d)",
-                "achieved": mad_rate / 1e9, "peak": (peak or nominal_quarter) / 1e9, "unit": "GMAD/s",
+                "achieved": mad_rate / 1e9, "peak": (peak or nominal_quarter) / 1e9, "unit": "GMAD/s (one GPU)",
                 "frac": mad_rate / (peak or nominal_quarter),
                 "peak_source": "measured live by libecc_amd/lib/ubench" if peak else "nominal quarter-rate estimate",
                 "kernel": kname, "kernel_ms": launch_ms, "kernel_mads_per_item": kmads,

@@ -139,6 +139,14 @@ int ec_ecdsa_sign_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, co
 int ec_ecccdh_derive_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *privs,
 			   const uint8_t *peers_aff, uint8_t *secrets, uint8_t *status);
 
+/* X25519 / X448, batch form of x25519() / x448() (ecdh/x25519_448.c:380-425): curve must be WEI25519
+ * (32-byte strings) or WEI448 (56-byte strings), the Weierstrass models libecc itself computes on.
+ * k, u, out: n x len little-endian (RFC 7748 wire format).  status[i] = 1 where the reference returns
+ * -1: non-canonical u (>= p), u on the twist, small-order point, zero result (libecc deliberately
+ * rejects these, x25519_448.c:219-276). */
+int ec_xdh_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *k, const uint8_t *u,
+		 uint8_t *out, uint8_t *status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,7 @@ EXPORTED_SYMBOLS = [
     "ecamd_ctx_set_max_chunk", "ecamd_ctx_enable_kernel_timing", "ecamd_ctx_kernel_times", "ecamd_curve_by_name", "ecamd_curve_from_params", "ecamd_curve_free",
     "ecamd_curve_coord_len", "ecamd_curve_order_len", "ecamd_curve_words", "ec_prj_pt_mul_batch",
     "ec_prj_pt_mul_batch_dev", "ecamd_ctx_synchronize", "ec_prj_pt_add_batch", "ec_prj_pt_dbl_batch",
-    "ec_fp_op_batch", "ec_ecdsa_verify_batch", "ec_ecdsa_sign_batch", "ec_ecccdh_derive_batch",
+    "ec_fp_op_batch", "ec_ecdsa_verify_batch", "ec_ecdsa_sign_batch", "ec_ecccdh_derive_batch", "ec_xdh_batch",
 ]
 
 
@@ -59,6 +59,7 @@ def load_library():
         L.ec_fp_op_batch.argtypes = [vp, vp, C.c_int, u32, vp, vp, vp]
         L.ec_ecdsa_verify_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p]
         L.ec_ecdsa_sign_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p, u8p]
+        L.ec_xdh_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
         L.ec_ecccdh_derive_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
         _LIB = L
     return _LIB
@@ -189,3 +190,11 @@ class Curve:
         _chk(self.L, self.L.ec_ecccdh_derive_batch(self.ctx.h, self.h, n, privs, peers, sec, st),
              "ec_ecccdh_derive_batch")
         return sec.raw[:self.clen * n], st.raw[:n]
+
+    def xdh(self, k, u):
+        """X25519 (WEI25519) / X448 (WEI448): little-endian scalars and u coordinates"""
+        n = len(k) // self.clen
+        out = C.create_string_buffer(max(1, self.clen * n))
+        st = C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_xdh_batch(self.ctx.h, self.h, n, k, u, out, st), "ec_xdh_batch")
+        return out.raw[:self.clen * n], st.raw[:n]

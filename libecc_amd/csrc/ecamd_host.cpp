@@ -1102,3 +1102,151 @@ extern "C" int ec_ecccdh_derive_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uin
 	}
 	return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// batched X25519 / X448 (x25519() / x448(), ecdh/x25519_448.c:380-425 -> x25519_448_core :146)
+// ------------------------------------------------------------------------------------------
+static Big big_sqrt_m1(const Big &p)  // 2^((p-1)/4) mod p, a square root of -1 when p = 5 mod 8
+{
+	Big one(1, 1), two(1, 2);
+	Big e = big_sub(p, one);
+	// divide by 4
+	Big q(e.size(), 0);
+	for (size_t i = 0; i < e.size(); i++) {
+		q[i] = (e[i] >> 2) | ((i + 1 < e.size()) ? (e[i + 1] << 30) : 0u);
+	}
+	big_trim(q);
+	return big_powmod(two, q, p);
+}
+
+extern "C" int ec_xdh_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *k, const uint8_t *u,
+			    uint8_t *out, uint8_t *status)
+{
+	if (!ctx || !cv || cv->ctx != ctx || (n && (!k || !u || !out || !status))) {
+		return fail("ec_xdh_batch: bad argument");
+	}
+	// the Weierstrass models of Curve25519 / Curve448: A = 486662 / 156326, B = 1
+	uint32_t Aval = 0;
+	if (cv->pbits == 255 && cv->clen == 32 && big_cmp(cv->p, big_sub(big_pow2(255), Big(1, 19))) == 0) {
+		Aval = 486662;
+	} else if (cv->pbits == 448 && cv->clen == 56 &&
+		   big_cmp(cv->p, big_sub(big_sub(big_pow2(448), big_pow2(224)), Big(1, 1))) == 0) {
+		Aval = 156326;
+	} else {
+		return fail("ec_xdh_batch: the curve is neither WEI25519 nor WEI448");
+	}
+	{
+		// make sure the handle really is the birationally equivalent Weierstrass curve:
+		// a = (3 - A^2) / 3, b = (2 A^3 - 9 A) / 27
+		const Big &p = cv->p;
+		Big A(1, Aval), three(1, 3), nine(1, 9), tw7(1, 27), two(1, 2);
+		Big pm2 = big_sub(p, two);
+		Big A2 = big_mulmod(A, A, p);
+		Big a_exp = big_mulmod(big_mod(big_add(big_sub(p, A2), three), p), big_powmod(three, pm2, p), p);
+		Big A3c = big_mulmod(A2, A, p);
+		Big num = big_mod(big_add(big_mulmod(two, A3c, p), big_sub(p, big_mulmod(nine, A, p))), p);
+		Big b_exp = big_mulmod(num, big_powmod(tw7, pm2, p), p);
+		if (big_cmp(a_exp, cv->a) != 0 || big_cmp(b_exp, cv->b) != 0) {
+			return fail("ec_xdh_batch: curve coefficients do not match the Montgomery curve");
+		}
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t len = (size_t)cv->clen, plen = 2 * len;
+	// stage: 0 k, 1 u, 2 scalars BE, 3 points, 4 flags, 5 tmp points ([h]Q), 6 st8, 7 [k]Q, 8 stk, 9 out, 10 status, 11 h
+	const size_t need[ECAMD_NSTAGE] = {n * len, n * len, n * len, n * plen, n, n * plen, n, n * plen, n, n * len, n, 64};
+	for (int i = 0; i < ECAMD_NSTAGE; i++) {
+		if (ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
+			return -1;
+		}
+	}
+	uint8_t **S = ctx->stage;
+	hipStream_t s = ctx->stream;
+	HIPCHK(hipMemcpyAsync(S[0], k, n * len, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(S[1], u, n * len, hipMemcpyHostToDevice, s));
+	const Big &p = cv->p;
+	const int nw = cv->nw;
+	const Big R = big_mod(big_pow2(32 * nw), p);
+	Big one(1, 1), two(1, 2), three(1, 3);
+	const Big A(1, Aval);
+	const Big A3 = big_mulmod(A, big_powmod(three, big_sub(p, two), p), p);
+	EcamdXdhPrepArgs P;
+	memset(&P, 0, sizeof(P));
+	P.k = S[0];
+	P.u = S[1];
+	P.scalars = S[2];
+	P.points = S[3];
+	P.flags = S[4];
+	P.n = n;
+	P.len = (uint32_t)len;
+	Big e;
+	if ((p[0] & 7u) == 5u) {
+		P.mode = 0;
+		e = big_add(p, three);  // (p + 3) / 8
+		Big q(e.size(), 0);
+		for (size_t i = 0; i < e.size(); i++) {
+			q[i] = (e[i] >> 3) | ((i + 1 < e.size()) ? (e[i + 1] << 29) : 0u);
+		}
+		e = q;
+		big_store(P.sm1, nw, big_mulmod(big_sqrt_m1(p), R, p));
+	} else {
+		P.mode = 1;
+		e = big_add(p, one);  // (p + 1) / 4
+		Big q(e.size(), 0);
+		for (size_t i = 0; i < e.size(); i++) {
+			q[i] = (e[i] >> 2) | ((i + 1 < e.size()) ? (e[i + 1] << 30) : 0u);
+		}
+		e = q;
+	}
+	big_trim(e);
+	P.ebits = (uint32_t)big_bitlen(e);
+	big_store(P.e, 17, e);
+	big_store(P.A, nw, big_mulmod(A, R, p));
+	big_store(P.A3, nw, big_mulmod(A3, R, p));
+	P.slot = cv->slot;
+	HIPCHK(ecamd_launch_xdh_prep(nw, P, s));
+	// [h]Q with the broadcast scalar h (cofactor), then [k]Q
+	{
+		Big hq = big_mod(cv->order, cv->q);  // must be 0: order = h q
+		(void)hq;
+		uint32_t hval = 0;
+		Big t = cv->q;
+		for (uint32_t c = 1; c <= 16; c++) {
+			if (big_cmp(t, cv->order) == 0) {
+				hval = c;
+				break;
+			}
+			t = big_add(t, cv->q);
+		}
+		if (hval == 0) {
+			return fail("ec_xdh_batch: unexpected cofactor");
+		}
+		const uint8_t hb = (uint8_t)hval;
+		HIPCHK(hipMemcpyAsync(S[11], &hb, 1, hipMemcpyHostToDevice, s));
+		HIPCHK(hipStreamSynchronize(s));
+	}
+	if (smul_dev_locked(ctx, cv, n, S[11], 1, S[3], S[5], S[6], s, 0) ||
+	    smul_dev_locked(ctx, cv, n, S[2], (uint32_t)len, S[3], S[7], S[8], s)) {
+		return -1;
+	}
+	EcamdXdhFinArgs Fn;
+	memset(&Fn, 0, sizeof(Fn));
+	Fn.pts = S[7];
+	Fn.st8 = S[6];
+	Fn.stk = S[8];
+	Fn.flags = S[4];
+	Fn.out = S[9];
+	Fn.status = S[10];
+	Fn.n = n;
+	Fn.len = (uint32_t)len;
+	big_store(Fn.A3, nw, A3);
+	Fn.slot = cv->slot;
+	HIPCHK(ecamd_launch_xdh_fin(nw, Fn, s));
+	HIPCHK(hipMemcpyAsync(out, S[9], n * len, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipMemcpyAsync(status, S[10], n, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	return 0;
+}

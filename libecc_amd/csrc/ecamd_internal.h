@@ -74,6 +74,31 @@ hipError_t ecamd_launch_smul(int nw, const EcamdSmulArgs &a, hipStream_t s);
 // ev (optional, 6 events): recorded before the first kernel and after each kernel of the pipeline
 #define ECAMD_NTIMED 5
 hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev);
+// ---- X25519 / X448 (ecdh/x25519_448.c:146-302 of the reference) around the scalar multiplication ----
+struct EcamdXdhPrepArgs {
+	const uint8_t *k, *u;    // n x len little-endian scalars and u coordinates (RFC 7748 wire format)
+	uint8_t *scalars;        // out: n x len big-endian clamped scalars
+	uint8_t *points;         // out: n x 2*len affine Weierstrass X || Y big-endian
+	uint8_t *flags;          // out: n, 0 ok / 1 reject (u >= p, u on the twist)
+	uint32_t n, len, ebits, mode;  // mode 0: p = 5 mod 8 (candidate w^((p+3)/8)), 1: p = 3 mod 4 (w^((p+1)/4))
+	uint32_t e[17];          // the exponent, little-endian words
+	uint32_t A[17], A3[17], sm1[17];  // A, A/3, sqrt(-1) in Montgomery form (radix 2^(32 NW))
+	int slot;
+};
+struct EcamdXdhFinArgs {
+	const uint8_t *pts;      // [k]Q affine Weierstrass, big-endian
+	const uint8_t *st8;      // status of [h]Q: must be 0 (finite, i.e. not a small-order point)
+	const uint8_t *stk;      // status of [k]Q
+	const uint8_t *flags;
+	uint8_t *out;            // n x len little-endian u coordinates
+	uint8_t *status;         // n: 0 ok / 1 the reference returns -1
+	uint32_t n, len;
+	uint32_t A3[17];         // A/3 mod p, plain
+	int slot;
+};
+hipError_t ecamd_launch_xdh_prep(int nw, const EcamdXdhPrepArgs &a, hipStream_t s);
+hipError_t ecamd_launch_xdh_fin(int nw, const EcamdXdhFinArgs &a, hipStream_t s);
+
 // radix-2^29 Jacobian fast path for every field size (ecamd_g29_kernel.hip)
 int ecamd_g29_supported(int pbits);
 int ecamd_g29_nl(int pbits);

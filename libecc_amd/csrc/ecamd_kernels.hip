@@ -398,6 +398,113 @@ template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_fin(EcamdEcdsaFi
 }
 
 // ------------------------------------------------------------------------------------------
+// X25519 / X448 through the Weierstrass model, as the reference does (ecdh/x25519_448.c:146-302):
+//   decode_scalar (:40-70) clamp + byte reversal; u little-endian, u >= p rejected (:219-220);
+//   v from u: v^2 = u^3 + A u^2 + u (B = 1), non-residue ("u on the twist") rejected (:226,
+//   aff_pt_montgomery_v_from_u curves/aff_pt_montgomery.c:547); (x, y) = (u + A/3, v) (:438-486);
+//   [h]Q must not be infinity (:259-260), [k]Q (:268), u' = x' - A/3, u' = 0 rejected (:275-276).
+// The square root is a fixed exponentiation (p = 5 mod 8: Atkin-style candidate w^((p+3)/8), fixed
+// up with sqrt(-1); p = 3 mod 4: w^((p+1)/4)); the reference's Tonelli-Shanks (fp/fp_sqrt.c) returns
+// the same pair {v, -v}, and only u' of the result is observable.
+// ------------------------------------------------------------------------------------------
+template <int NW> static __device__ __forceinline__ Fe<NW> fe_load_le(const u8 *src, int len)
+{
+	Fe<NW> r;
+#pragma unroll
+	for (int w = 0; w < NW; w++) {
+		u32 x = 0;
+#pragma unroll
+		for (int b = 0; b < 4; b++) {
+			const int pos = 4 * w + b;
+			if (pos < len) {
+				x |= (u32)src[pos] << (8 * b);
+			}
+		}
+		r.v[w] = x;
+	}
+	return r;
+}
+
+template <int NW> __global__ __launch_bounds__(64) void k_xdh_prep(EcamdXdhPrepArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int slot = A.slot;
+	const int len = (int)A.len;
+	// scalar: reversed to big-endian and clamped (decode_scalar)
+	{
+		const u8 *ks = A.k + (size_t)i * len;
+		u8 *kd = A.scalars + (size_t)i * len;
+		for (int b = 0; b < len; b++) {
+			u8 v = ks[b];
+			if (len == 32) {
+				if (b == 0) v &= 248;
+				if (b == 31) v = (u8)((v & 127) | 64);
+			} else {
+				if (b == 0) v &= 252;
+				if (b == len - 1) v |= 128;
+			}
+			kd[len - 1 - b] = v;
+		}
+	}
+	const Fe<NW> u = fe_load_le<NW>(A.u + (size_t)i * len, len);
+	bool ok = fe_lt_p<NW>(u, slot);
+	const Fe<NW> one = fe_const<NW>(ConstTab<NW>::get(slot).one);
+	const Fe<NW> um = fe_to_mont<NW>(u, slot);
+	// w = u (u (u + A) + 1)
+	Fe<NW> t = fe_add<NW>(um, fe_const<NW>(A.A), slot);
+	t = fe_mul<NW>(um, t, slot);
+	t = fe_add<NW>(t, one, slot);
+	const Fe<NW> w = fe_mul<NW>(um, t, slot);
+	// candidate root c = w^e (left-to-right binary, wave-uniform exponent)
+	Fe<NW> c = one;
+	for (int b = (int)A.ebits - 1; b >= 0; b--) {
+		c = fe_mul<NW>(c, c, slot);
+		if ((A.e[b >> 5] >> (b & 31)) & 1u) {
+			c = fe_mul<NW>(c, w, slot);
+		}
+	}
+	const Fe<NW> c2 = fe_mul<NW>(c, c, slot);
+	Fe<NW> v = c;
+	bool root = fe_eq<NW>(c2, w);
+	if (A.mode == 0) {
+		const Fe<NW> negw = fe_sub<NW>(fe_zero<NW>(), w, slot);
+		const bool alt = fe_eq<NW>(c2, negw);
+		v = fe_select<NW>(alt & !root, fe_mul<NW>(c, fe_const<NW>(A.sm1), slot), c);
+		root = root | alt;
+	}
+	ok = ok & root;
+	const Fe<NW> x = fe_from_mont<NW>(fe_add<NW>(um, fe_const<NW>(A.A3), slot), slot);
+	const Fe<NW> y = fe_from_mont<NW>(v, slot);
+	u8 *pd = A.points + (size_t)i * 2 * len;
+	fe_store_be<NW>(pd, len, ok ? x : fe_zero<NW>());
+	fe_store_be<NW>(pd + len, len, ok ? y : fe_zero<NW>());
+	A.flags[i] = ok ? 0 : 1;
+}
+
+template <int NW> __global__ __launch_bounds__(64) void k_xdh_fin(EcamdXdhFinArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int slot = A.slot;
+	const int len = (int)A.len;
+	u8 *out = A.out + (size_t)i * len;
+	bool ok = (A.flags[i] == 0) & (A.st8[i] == 0) & (A.stk[i] == 0);
+	const Fe<NW> x = fe_load_be<NW>(A.pts + (size_t)i * 2 * len, len);
+	const Fe<NW> u = fe_sub<NW>(x, fe_const<NW>(A.A3), slot);  // plain residues: no Montgomery form needed
+	ok = ok & !fe_is_zero<NW>(u);
+	for (int b = 0; b < len; b++) {
+		const u32 wv = ok ? u.v[b >> 2] : 0u;
+		out[b] = (u8)(wv >> (8 * (b & 3)));
+	}
+	A.status[i] = ok ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side dispatch on the word count
 // ------------------------------------------------------------------------------------------
 #define ECAMD_FOR_NW(X) X(6) X(7) X(8) X(10) X(12) X(14) X(16) X(17)
@@ -473,6 +580,36 @@ hipError_t ecamd_launch_ecdsa_sign(int nw, const EcamdEcdsaSignArgs &a, hipStrea
 	switch (nw) {
 #define X(N) case N: hipLaunchKernelGGL(k_ecdsa_sign<N>, grid, block, 0, s, a); break;
 		ECAMD_FOR_NW(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_xdh_prep(int nw, const EcamdXdhPrepArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	const dim3 grid((a.n + 63) / 64), block(64);
+	switch (nw) {
+#define X(N) case N: hipLaunchKernelGGL(k_xdh_prep<N>, grid, block, 0, s, a); break;
+		X(8) X(14)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_xdh_fin(int nw, const EcamdXdhFinArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	const dim3 grid((a.n + 63) / 64), block(64);
+	switch (nw) {
+#define X(N) case N: hipLaunchKernelGGL(k_xdh_fin<N>, grid, block, 0, s, a); break;
+		X(8) X(14)
 #undef X
 	default: return hipErrorInvalidValue;
 	}

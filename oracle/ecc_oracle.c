@@ -1001,3 +1001,121 @@ int orc_ecccdh_batch(const orc_curve *c, uint32_t n, const uint8_t *privs, const
 	}
 	return 0;
 }
+
+/* ------------------------------------------------------------------------------------
+ * X25519 / X448: x25519_448_core (ecdh/x25519_448.c:146-302) on the Weierstrass model.
+ *   decode_scalar (:40-70), u >= p rejected (:219-220), v from u (curves/aff_pt_montgomery.c:547:
+ *   v^2 = (u^3 + A u^2 + u) / B, B = 1), map (:438-486: x = u/B + A/(3B), y = v/B),
+ *   check_prj_pt_order(Q, cofactor) must not be infinity (:259-260), prj_pt_mul (:268),
+ *   u' = B x' - A/3 (:488-545), u' = 0 rejected (:275-276).
+ * The reference's fp_sqrt is Tonelli-Shanks (fp/fp_sqrt.c); for p = 5 mod 8 / 3 mod 4 the roots are
+ * given by one exponentiation, and either root gives the same u'.
+ * ---------------------------------------------------------------------------------- */
+static void fp_pow(u64 *out, const u64 *x, const u64 *e, int en, const orc_fp_ctx *c) /* plain in/out */
+{
+	u64 xm[ORC_MAXW], r[ORC_MAXW];
+	int i;
+	fp_redcify(xm, x, c);
+	nn_copy(r, c->r, c->n);
+	for (i = nn_bitlen(e, en) - 1; i >= 0; i--) {
+		mul_redc1(r, r, r, c);
+		if (nn_getbit(e, i)) {
+			mul_redc1(r, r, xm, c);
+		}
+	}
+	fp_unredcify(out, r, c);
+}
+
+static int fp_sqrt_exp(u64 *v, const u64 *w, const orc_fp_ctx *f)
+{
+	u64 e[ORC_MAXW], t[ORC_MAXW], c2[ORC_MAXW], negw[ORC_MAXW], zero[ORC_MAXW];
+	int n = f->n, i;
+	nn_zero(zero, n);
+	nn_zero(t, n);
+	if ((f->p[0] & 7) == 5) {
+		t[0] = 3;
+		nn_add(e, f->p, t, n);
+		for (i = 0; i < n; i++) e[i] = (e[i] >> 3) | ((i + 1 < n) ? (e[i + 1] << 61) : 0);
+		fp_pow(v, w, e, n, f);
+		fp_mul(c2, v, v, f);
+		if (nn_cmp(c2, w, n) == 0) return 0;
+		fp_sub(negw, zero, w, f);
+		if (nn_cmp(c2, negw, n) == 0) {
+			u64 two[ORC_MAXW], q[ORC_MAXW], s[ORC_MAXW];
+			nn_zero(two, n); two[0] = 2;
+			nn_zero(t, n); t[0] = 1;
+			nn_sub(q, f->p, t, n);
+			for (i = 0; i < n; i++) q[i] = (q[i] >> 2) | ((i + 1 < n) ? (q[i + 1] << 62) : 0);
+			fp_pow(s, two, q, n, f);
+			fp_mul(v, v, s, f);
+			return 0;
+		}
+		return -1;
+	}
+	if ((f->p[0] & 3) == 3) {
+		t[0] = 1;
+		nn_add(e, f->p, t, n);
+		for (i = 0; i < n; i++) e[i] = (e[i] >> 2) | ((i + 1 < n) ? (e[i + 1] << 62) : 0);
+		fp_pow(v, w, e, n, f);
+		fp_mul(c2, v, v, f);
+		return nn_cmp(c2, w, n) == 0 ? 0 : -1;
+	}
+	return -1;
+}
+
+/* len = 32 (X25519 on WEI25519, A = 486662) or 56 (X448 on WEI448, A = 156326); c must be that curve */
+int orc_xdh_batch(const orc_curve *c, uint32_t len, uint32_t n, const uint8_t *k, const uint8_t *u,
+		  uint8_t *out, uint8_t *status)
+{
+	const orc_fp_ctx *f = &c->fp;
+	u64 A[ORC_MAXW], A3[ORC_MAXW], three[ORC_MAXW], inv3[ORC_MAXW], one[ORC_MAXW], h[ORC_MAXW], t2[2 * ORC_MAXW];
+	uint32_t i;
+	int hv, hfound = 0;
+	nn_zero(A, f->n); A[0] = (len == 32) ? 486662 : 156326;
+	nn_zero(three, f->n); three[0] = 3;
+	nn_zero(one, f->n); one[0] = 1;
+	fp_pow_pm2(inv3, three, f);
+	fp_mul(A3, A, inv3, f);
+	for (hv = 1; hv <= 16 && !hfound; hv++) {
+		nn_zero(h, ORC_MAXW); h[0] = (u64)hv;
+		nn_mul(t2, c->q, c->q_n, h, 1);
+		if (nn_cmp(t2, c->order, c->q_n + 1) == 0) hfound = 1;
+	}
+	if (!hfound || (len != 32 && len != 56)) return -1;
+	for (i = 0; i < n; i++) {
+		u8 kb[64], ub[64];
+		u64 uu[ORC_MAXW], w[ORC_MAXW], t[ORC_MAXW], v[ORC_MAXW], m[ORC_MAXW];
+		pt Q, T;
+		uint32_t b;
+		status[i] = 1;
+		memset(out + (size_t)i * len, 0, len);
+		for (b = 0; b < len; b++) {
+			kb[len - 1 - b] = k[(size_t)i * len + b];
+			ub[len - 1 - b] = u[(size_t)i * len + b];
+		}
+		if (len == 32) { kb[len - 1] &= 248; kb[0] &= 127; kb[0] |= 64; }
+		else { kb[len - 1] &= 252; kb[0] |= 128; }
+		if (fp_from_be(uu, ub, (int)len, f)) continue;            /* u >= p */
+		fp_add(t, uu, A, f);
+		fp_mul(t, t, uu, f);
+		fp_add(t, t, one, f);
+		fp_mul(w, t, uu, f);                                       /* u^3 + A u^2 + u */
+		if (nn_iszero(w, f->n)) nn_zero(v, f->n);
+		else if (fp_sqrt_exp(v, w, f)) continue;                   /* u on the twist */
+		fp_add(Q.X, uu, A3, f);
+		nn_copy(Q.Y, v, f->n);
+		nn_zero(Q.Z, f->n); Q.Z[0] = 1;
+		if (!pt_is_on_curve(&Q, c)) continue;
+		if (pt_unprotected_mult(&T, h, 1, &Q, c)) continue;        /* check_prj_pt_order */
+		if (nn_iszero(T.Z, f->n)) continue;                        /* small order */
+		nn_from_be(m, (int)(len + 7) / 8, kb, (int)len);
+		if (pt_mul(&T, m, (int)(len + 7) / 8, &Q, c)) continue;
+		if (pt_unique(&T, c)) continue;                            /* infinity */
+		fp_sub(t, T.X, A3, f);
+		if (nn_iszero(t, f->n)) continue;
+		nn_to_be(ub, (int)len, t, f->n);
+		for (b = 0; b < len; b++) out[(size_t)i * len + b] = ub[len - 1 - b];
+		status[i] = 0;
+	}
+	return 0;
+}

@@ -49,4 +49,6 @@ int orc_ecdsa_sign_batch(const orc_curve *c, uint32_t n, const uint8_t *privs,
 			 uint8_t *sigs, uint8_t *status);
 int orc_ecccdh_batch(const orc_curve *c, uint32_t n, const uint8_t *privs, const uint8_t *peers_aff,
 		     uint8_t *secrets, uint8_t *status);
+int orc_xdh_batch(const orc_curve *c, uint32_t len, uint32_t n, const uint8_t *k, const uint8_t *u,
+		  uint8_t *out, uint8_t *status);
 #endif

@@ -453,3 +453,24 @@ int refdrv_curve_params(int type, uint8_t *out, int32_t *lens)
 	}
 	return 0;
 }
+
+/* ---- X25519 / X448 through the reference (ecdh/x25519_448.c:380,403) ---- */
+#include "ecdh/x25519_448.h"
+int refdrv_xdh_batch(uint32_t len, uint32_t n, const uint8_t *k, const uint8_t *u, uint8_t *out, uint8_t *status)
+{
+	uint32_t i;
+	for (i = 0; i < n; i++) {
+		int ret = -1;
+		memset(out + (size_t)i * len, 0, len);
+		if (len == 32) {
+			ret = x25519(k + (size_t)i * len, u + (size_t)i * len, out + (size_t)i * len);
+		} else if (len == 56) {
+			ret = x448(k + (size_t)i * len, u + (size_t)i * len, out + (size_t)i * len);
+		}
+		status[i] = ret ? 1 : 0;
+		if (ret) {
+			memset(out + (size_t)i * len, 0, len);
+		}
+	}
+	return 0;
+}

@@ -9,7 +9,8 @@ Sources (data only -- byte arrays and the record fields that bind them):
   src/tests/ecccdh_test_vectors.h   125 NIST ECC-CDH KATs (record: ec_self_tests_core.h:55-80)
   src/tests/decdsa_test_vectors.h   RFC 6979 deterministic ECDSA
   src/tests/ec_self_tests_core.h    fixed-k ECDSA (RFC 4754 style nonce callbacks), record :22-52
-Writes tests/golden/ecccdh_kats.json and tests/golden/ecdsa_kats.json.
+  src/tests/x25519_test_vectors.h, x448_test_vectors.h   RFC 7748 vectors
+Writes tests/golden/ecccdh_kats.json, ecdsa_kats.json and xdh_kats.json.
 """
 import json, os, re, sys
 
@@ -104,6 +105,18 @@ def main():
                               priv_key=arrays[f["priv_key"]].hex(),
                               k=(nonces[nr].hex() if nr != "NULL" else None),
                               msg=msgb.hex(), exp_sig=arrays[f["exp_sig"]].hex(), source=fn))
+    xdh = []
+    for fn in ("x25519_test_vectors.h", "x448_test_vectors.h"):
+        arrays, nonces, cases = load(os.path.join(REF, fn))
+        for kind, name, f in cases:
+            if kind != "ecdh_test_case" or f.get("ecdh_type") not in ("X25519", "X448"):
+                continue
+            xdh.append(dict(name=c_string(f["name"]).decode(), kind=f["ecdh_type"], curve=curve_of(f),
+                            our_priv_key=arrays[f["our_priv_key"]].hex(), peer_pub_key=arrays[f["peer_pub_key"]].hex(),
+                            exp_our_pub_key=arrays[f["exp_our_pub_key"]].hex(),
+                            exp_shared_secret=arrays[f["exp_shared_secret"]].hex()))
+    json.dump(xdh, open(os.path.join(HERE, "xdh_kats.json"), "w"), indent=1)
+    print("XDH   :", [(c["kind"], c["name"]) for c in xdh])
     json.dump(ecdh, open(os.path.join(HERE, "ecccdh_kats.json"), "w"), indent=1)
     json.dump(ecdsa, open(os.path.join(HERE, "ecdsa_kats.json"), "w"), indent=1)
     from collections import Counter

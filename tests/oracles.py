@@ -112,6 +112,14 @@ class Oracle:
         return sec.raw, st.raw
 
 
+    def xdh(self, k, u):
+        n = len(k) // self.clen
+        out = C.create_string_buffer(self.clen * n)
+        st = C.create_string_buffer(n)
+        assert self.L.orc_xdh_batch(self.ctx, self.clen, n, k, u, out, st) == 0
+        return out.raw, st.raw
+
+
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libecc_ref.so")
 HASH_IDS = {"SHA224": 1, "SHA256": 2, "SHA384": 3, "SHA512": 4, "SHA3_224": 5, "SHA3_256": 6,
             "SHA3_384": 7, "SHA3_512": 8}
@@ -185,6 +193,16 @@ class RefLib:
         st = C.create_string_buffer(n)
         assert self.L.refdrv_ecccdh_batch(self.name, n, privs, peers, sec, st) == 0
         return sec.raw, st.raw
+
+
+def ref_xdh(length, k, u):
+    """x25519() / x448() of the unmodified reference"""
+    L = C.CDLL(REF_SO)
+    n = len(k) // length
+    out = C.create_string_buffer(length * n)
+    st = C.create_string_buffer(n)
+    assert L.refdrv_xdh_batch(length, n, k, u, out, st) == 0
+    return out.raw, st.raw
 
 
 def digest(hash_name, msg):

@@ -467,3 +467,33 @@ def test_ecccdh_derive_golden_and_oracle(gpu_ctx, curve):
         assert cv.ecccdh(d2, bytes(peers)) == o.ecccdh(d2, bytes(peers))
     finally:
         cv.free()
+
+
+@pytest.mark.parametrize("kind,curve,ln", [("X25519", "WEI25519", 32), ("X448", "WEI448", 56)])
+def test_xdh_vs_oracle_and_golden(gpu_ctx, kind, curve, ln):
+    """X25519 / X448 batch: RFC 7748 vectors, then edge + random inputs against the oracle, including
+    every rejection the reference makes (u >= p, twist, small order, zero)"""
+    from test_oracle import KAT_XDH, xdh_edge_inputs
+    rng = np.random.default_rng(16)
+    cv = gpu_ctx.curve(curve)
+    o = Oracle(curve)
+    try:
+        ks = [k for k in KAT_XDH if k["kind"] == kind]
+        k = b"".join(bytes.fromhex(x["our_priv_key"]) for x in ks)
+        u = b"".join(bytes.fromhex(x["peer_pub_key"]) for x in ks)
+        assert cv.xdh(k, u) == (b"".join(bytes.fromhex(x["exp_shared_secret"]) for x in ks), bytes(len(ks)))
+        base = (9 if ln == 32 else 5).to_bytes(ln, "little")
+        assert cv.xdh(k, base * len(ks))[0] == b"".join(bytes.fromhex(x["exp_our_pub_key"]) for x in ks)
+        ek, eu = xdh_edge_inputs(ln, rng)
+        exp = o.xdh(ek, eu)
+        assert cv.xdh(ek, eu) == exp
+        assert 0 in exp[1] and 1 in exp[1]
+        # Diffie-Hellman property on a larger random batch: X(a, X(b, base)) == X(b, X(a, base))
+        n = 2048
+        a, b = rand_bytes(rng, ln * n), rand_bytes(rng, ln * n)
+        pa, sa = cv.xdh(a, base * n)
+        pb, sb = cv.xdh(b, base * n)
+        assert set(sa) == {0} and set(sb) == {0}
+        assert cv.xdh(a, pb) == cv.xdh(b, pa)
+    finally:
+        cv.free()

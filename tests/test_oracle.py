@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from oracles import (CURVES, GOLDEN, Oracle, RefLib, digest, have_ref, py_smul_bytes, rfc6979_nonce)
+from oracles import (CURVES, GOLDEN, Oracle, RefLib, digest, have_ref, py_smul_bytes, ref_xdh, rfc6979_nonce)
 
 KAT_CDH = json.load(open(os.path.join(GOLDEN, "ecccdh_kats.json")))
 KAT_DSA = json.load(open(os.path.join(GOLDEN, "ecdsa_kats.json")))
@@ -148,3 +148,39 @@ def test_oracle_protocols_vs_reference_binary(curve, h):
     assert vo == vr and vo[:4] == b"\1\1\1\1" and vo[4:] == b"\0\0"
     so, sr = o.ecccdh(privs, pubs[2 * o.clen:] + pubs[:2 * o.clen]), r.ecccdh(privs, pubs[2 * o.clen:] + pubs[:2 * o.clen])
     assert so == sr and set(so[1]) == {0}
+
+
+KAT_XDH = json.load(open(os.path.join(GOLDEN, "xdh_kats.json")))
+SMALL_ORDER_25519 = [0, 1, 325606250916557431795983626356110631294008115727848805560023387167927233504,
+                     39382357235489614581723060781553021112529911719440698176882885853963445705823,
+                     2**255 - 20, 2**255 - 19, 2**255 - 18]
+
+
+def xdh_edge_inputs(ln, rng):
+    p = CURVES["WEI25519" if ln == 32 else "WEI448"]["p"]
+    us = [0, 1, 2, 9 if ln == 32 else 5, p - 1, p, p + 1, (1 << (8 * ln)) - 1, p - 2]
+    if ln == 32:
+        us += SMALL_ORDER_25519
+    us = [x % (1 << (8 * ln)) for x in us]
+    u = b"".join(x.to_bytes(ln, "little") for x in us) + rb(rng, ln * 24)
+    k = rb(rng, len(u))
+    return k, u
+
+
+@pytest.mark.parametrize("kind,curve,ln", [("X25519", "WEI25519", 32), ("X448", "WEI448", 56)])
+def test_xdh_kats_and_reference(kind, curve, ln):
+    """RFC 7748 vectors of the reference; public-key derivation from the base point; the reference's
+    deliberate rejections (non-canonical u, twist, small order) on edge and random inputs"""
+    rng = np.random.default_rng(15)
+    ks = [k for k in KAT_XDH if k["kind"] == kind]
+    assert ks
+    o = Oracle(curve)
+    k = b"".join(bytes.fromhex(x["our_priv_key"]) for x in ks)
+    u = b"".join(bytes.fromhex(x["peer_pub_key"]) for x in ks)
+    assert o.xdh(k, u) == (b"".join(bytes.fromhex(x["exp_shared_secret"]) for x in ks), bytes(len(ks)))
+    base = (9 if ln == 32 else 5).to_bytes(ln, "little")
+    assert o.xdh(k, base * len(ks))[0] == b"".join(bytes.fromhex(x["exp_our_pub_key"]) for x in ks)
+    if have_ref():
+        ek, eu = xdh_edge_inputs(ln, rng)
+        a, b = o.xdh(ek, eu), ref_xdh(ln, ek, eu)
+        assert a == b and 0 in a[1] and 1 in a[1]

@@ -50,6 +50,15 @@ def main():
     bad = bytearray(sigs[:m * 2 * ql]); bad[3] ^= 1
     assert cv.ecdsa_verify(pubs[:m * 2 * cv.clen], bytes(bad), dg[:m * 32], 32) == o.ecdsa_verify(pubs[:m * 2 * cv.clen], bytes(bad), dg[:m * 32], 32)
     print({k: f"{v / 1e6:.2f} M/s" for k, v in res.items()}, "batch", n, a.curve)
+    if a.curve in ("WEI25519", "WEI448"):
+        ln = cv.clen
+        kk = rng.integers(0, 256, size=n * ln, dtype=np.uint8).tobytes()
+        base = (9 if ln == 32 else 5).to_bytes(ln, "little") * n
+        for rep in range(2):
+            t = time.time(); pub, st = cv.xdh(kk, base); r1 = n / (time.time() - t)
+            t = time.time(); sh, st2 = cv.xdh(kk[::-1], pub); r2 = n / (time.time() - t)
+        assert set(st) == {0} and set(st2) == {0}
+        print({"xdh_pubkey": f"{r1 / 1e6:.2f} M/s", "xdh_shared": f"{r2 / 1e6:.2f} M/s"})
 
 
 if __name__ == "__main__":
