@@ -135,7 +135,7 @@ int ec_ecdsa_sign_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, co
 			uint8_t *status);
 /* ECC-CDH, batch form of ecccdh_derive_secret (ecdh/ecccdh.c:167): privs n x qlen, peers n x 2*clen
  * affine, secrets n x clen (x coordinate of d*Q), status[i] = 0 ok / 1 the reference returns -1.
- * Cofactor-1 curves only for now. */
+ * Cofactor curves: subgroup check of the peer key and the [h]Q step as in the reference. */
 int ec_ecccdh_derive_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *privs,
 			   const uint8_t *peers_aff, uint8_t *secrets, uint8_t *status);
 

@@ -1081,16 +1081,50 @@ extern "C" int ec_ecccdh_derive_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uin
 	if (!ctx || !cv || cv->ctx != ctx || (n && (!privs || !peers || !secrets || !status))) {
 		return fail("ec_ecccdh_derive_batch: bad argument");
 	}
-	if (big_cmp(cv->order, cv->q) != 0) {
-		return fail("ec_ecccdh_derive_batch: cofactor != 1 curves are not supported yet");
-	}
 	if (n == 0) {
 		return 0;
 	}
-	const size_t plen = (size_t)2 * cv->clen;
+	const size_t plen = (size_t)2 * cv->clen, ql = (size_t)cv->qlen;
 	std::vector<uint8_t> pts((size_t)n * plen);
-	if (ec_prj_pt_mul_batch(ctx, cv, n, privs, (uint32_t)cv->qlen, peers, pts.data(), status)) {
-		return -1;
+	if (big_cmp(cv->order, cv->q) == 0) {
+		// cofactor 1: import + prj_pt_mul + prj_pt_unique in one pass
+		if (ec_prj_pt_mul_batch(ctx, cv, n, privs, (uint32_t)ql, peers, pts.data(), status)) {
+			return -1;
+		}
+	} else {
+		// cofactor h != 1 (ecdh/ecccdh.c:187-217): the peer key must lie in the subgroup ([q]Q = infinity,
+		// sig/ec_key.c:199-205), then Q' = [h]Q must not be infinity, then [d]Q'
+		uint32_t hval = 0;
+		Big t = cv->q;
+		for (uint32_t c = 1; c <= 255; c++) {
+			if (big_cmp(t, cv->order) == 0) {
+				hval = c;
+				break;
+			}
+			t = big_add(t, cv->q);
+		}
+		if (hval == 0) {
+			return fail("ec_ecccdh_derive_batch: unexpected cofactor");
+		}
+		std::vector<uint8_t> qb(ql), st_sub(n), st_h(n), hq((size_t)n * plen), sub((size_t)n * plen);
+		big_to_be(qb.data(), (int)ql, cv->q);
+		std::vector<uint8_t> qrep((size_t)n * ql), hrep(n, (uint8_t)hval);
+		for (uint32_t i = 0; i < n; i++) {
+			memcpy(&qrep[(size_t)i * ql], qb.data(), ql);
+		}
+		if (ec_prj_pt_mul_batch(ctx, cv, n, qrep.data(), (uint32_t)ql, peers, sub.data(), st_sub.data()) ||
+		    ec_prj_pt_mul_batch(ctx, cv, n, hrep.data(), 1, peers, hq.data(), st_h.data())) {
+			return -1;
+		}
+		// items that fail either check get an off-curve dummy point so that the last pass flags them
+		for (uint32_t i = 0; i < n; i++) {
+			if (st_sub[i] != 2 || st_h[i] != 0) {
+				memset(&hq[(size_t)i * plen], 0xff, plen);
+			}
+		}
+		if (ec_prj_pt_mul_batch(ctx, cv, n, privs, (uint32_t)ql, hq.data(), pts.data(), status)) {
+			return -1;
+		}
 	}
 	for (uint32_t i = 0; i < n; i++) {
 		// infinity (st 2) and import errors (st 1) are both -1 in the reference (:202-217)

@@ -497,3 +497,28 @@ def test_xdh_vs_oracle_and_golden(gpu_ctx, kind, curve, ln):
         assert cv.xdh(a, pb) == cv.xdh(b, pa)
     finally:
         cv.free()
+
+
+def test_ecccdh_cofactor_curve(gpu_ctx):
+    """ECC-CDH on WEI25519 (h = 8): peer keys inside the subgroup, outside it (G + 2-torsion) and of small order"""
+    curve = "WEI25519"
+    rng = np.random.default_rng(17)
+    cv = gpu_ctx.curve(curve)
+    o = Oracle(curve)
+    try:
+        c = CURVES[curve]
+        p, n = c["p"], 32
+        from oracles import py_add
+        x2 = 486662 * pow(3, p - 2, p) % p
+        T2 = x2.to_bytes(n, "big") + bytes(n)
+        GT = py_add((c["gx"], c["gy"]), (x2, 0), c["a"], p)
+        GT = GT[0].to_bytes(n, "big") + GT[1].to_bytes(n, "big")
+        good, st = o.scalar_mult(rand_bytes(rng, 32 * 10))
+        assert set(st) == {0}
+        peers = good + T2 + GT + bytes(64) + good[:64]
+        privs = rand_bytes(rng, 32 * 13) + bytes(32)
+        exp = o.ecccdh(privs, peers)
+        assert cv.ecccdh(privs, peers) == exp
+        assert exp[1][:10] == bytes(10) and set(exp[1][10:]) == {1}
+    finally:
+        cv.free()
