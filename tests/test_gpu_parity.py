@@ -258,6 +258,39 @@ def test_linearity_large_batch(gpu_ctx):
         cv.free()
 
 
+@pytest.mark.parametrize("curve", ["BRAINPOOLP256R1", "WEI25519", "SECP256K1", "SECP224R1", "BRAINPOOLP320R1", "SECP384R1",
+                                   "WEI448", "BRAINPOOLP512R1", "SECP521R1"])
+def test_generic_fast_path_properties(gpu_ctx, curve):
+    """generic radix-2^29 path: 2^13 random items per curve through [a]([b]G) == [a b mod q]G and
+    [a]G + [b]G == [a + b]G, plus 96 random items against the oracle"""
+    rng = np.random.default_rng(18)
+    cv = gpu_ctx.curve(curve)
+    o = Oracle(curve)
+    try:
+        q = CURVES[curve]["q"]
+        n, ql, pl = 1 << 13, o.qlen, 2 * o.clen
+        a = [int.from_bytes(rand_bytes(rng, ql + 8), "big") % q for _ in range(n)]
+        b = [int.from_bytes(rand_bytes(rng, ql + 8), "big") % q for _ in range(n)]
+        A = b"".join(x.to_bytes(ql, "big") for x in a)
+        B = b"".join(x.to_bytes(ql, "big") for x in b)
+        bG, st = cv.scalar_mult(B)
+        assert set(st) <= {0, 2}
+        abG, st1 = cv.scalar_mult(A, bG)
+        abG2, st2 = cv.scalar_mult(b"".join((x * y % q).to_bytes(ql, "big") for x, y in zip(a, b)))
+        ok = [i for i in range(n) if st[i] == 0]
+        assert all(st1[i] == st2[i] for i in ok)
+        assert all(abG[i * pl:(i + 1) * pl] == abG2[i * pl:(i + 1) * pl] for i in ok)
+        aG, _ = cv.scalar_mult(A)
+        sG, st3 = cv.scalar_mult(b"".join(((x + y) % q).to_bytes(ql, "big") for x, y in zip(a, b)))
+        sumG, st4 = cv.pt_add(aG, bG)
+        assert st3 == st4 and sG == sumG
+        idx = rng.choice(n, size=96, replace=False)
+        exp, est = o.scalar_mult(b"".join(A[i * ql:(i + 1) * ql] for i in idx), b"".join(bG[i * pl:(i + 1) * pl] for i in idx))
+        assert exp == b"".join(abG[i * pl:(i + 1) * pl] for i in idx)
+    finally:
+        cv.free()
+
+
 def test_full_batch_properties(gpu_ctx):
     """BASELINE.json's full size (2^20 items, one launch): every item is checked through
     [a]([b]G) == [a b mod q]G, computed three ways on the GPU, plus 256 random items against the oracle"""
