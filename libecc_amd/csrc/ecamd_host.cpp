@@ -235,6 +235,8 @@ struct ecamd_curve {
 	uint8_t *d_gen;  // generator, affine X||Y big-endian, in HBM
 	bool is_p256;    // exactly secp256r1: hand-specialised radix-2^29 Jacobian kernel
 	int gslot;       // constant slot of the generic radix-2^29 Jacobian kernel (-1: none)
+	uint32_t *d_gtab; // secp256r1: affine window table [1..8]G, radix-2^29 Montgomery digits, 8 x 40 words
+	uint32_t qdig[9]; // secp256r1: digits of the group order
 };
 
 static const int k_widths[] = {6, 7, 8, 10, 12, 14, 16, 17};
@@ -457,6 +459,10 @@ static int build_and_upload(ecamd_curve *cv)
 	return 0;
 }
 
+static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_scalars, uint32_t slen,
+			   const uint8_t *d_points, uint8_t *d_out, uint8_t *d_status, hipStream_t s,
+			   uint32_t sstride = 0xffffffffu);
+
 // 29-bit digits of a (nl of them, the last one takes whatever is left)
 static void big_digits29(uint32_t *dst, int nl, const Big &a)
 {
@@ -598,6 +604,45 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 		delete cv;
 		return fail("curve: generator upload failed");
 	}
+	cv->d_gtab = nullptr;
+	if (cv->is_p256) {
+		// affine window table of the generator for the interleaved ECDSA verification loop:
+		// [1..8]G through our own kernels, then x R mod p, y R mod p (R = 2^261) as 29-bit digits
+		uint8_t sc[8 * 32], pts[8 * 64], st[8];
+		memset(sc, 0, sizeof(sc));
+		for (int i = 0; i < 8; i++) {
+			sc[i * 32 + 31] = (uint8_t)(i + 1);
+		}
+		uint8_t *d = nullptr;
+		if (hipMalloc((void **)&d, sizeof(sc) + sizeof(pts) + sizeof(st)) != hipSuccess ||
+		    hipMemcpy(d, sc, sizeof(sc), hipMemcpyHostToDevice) != hipSuccess) {
+			delete cv;
+			return fail("curve: generator table allocation failed");
+		}
+		int rc = smul_dev_locked(ctx, cv, 8, d, 32, nullptr, d + sizeof(sc), d + sizeof(sc) + sizeof(pts), ctx->stream);
+		if (!rc && (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+			    hipMemcpy(pts, d + sizeof(sc), sizeof(pts), hipMemcpyDeviceToHost) != hipSuccess ||
+			    hipMemcpy(st, d + sizeof(sc) + sizeof(pts), sizeof(st), hipMemcpyDeviceToHost) != hipSuccess)) {
+			rc = -1;
+		}
+		(void)hipFree(d);
+		std::vector<uint32_t> tab(8 * 40, 0);
+		const Big R261 = big_mod(big_pow2(261), cv->p);
+		for (int i = 0; i < 8 && !rc; i++) {
+			if (st[i] != 0) {
+				rc = -1;
+				break;
+			}
+			big_digits29(&tab[(size_t)i * 40], 9, big_mulmod(big_from_be(pts + i * 64, 32), R261, cv->p));
+			big_digits29(&tab[(size_t)i * 40 + 9], 9, big_mulmod(big_from_be(pts + i * 64 + 32, 32), R261, cv->p));
+		}
+		if (rc || hipMalloc((void **)&cv->d_gtab, tab.size() * 4) != hipSuccess ||
+		    hipMemcpy(cv->d_gtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+			delete cv;
+			return fail("curve: generator table construction failed");
+		}
+		big_digits29(cv->qdig, 9, cv->q);
+	}
 	ctx->slot_used[slot] = true;
 	if (cv->gslot >= 0) {
 		ctx->gslot_used[cv->pbits][cv->gslot] = true;
@@ -663,6 +708,9 @@ extern "C" void ecamd_curve_free(ecamd_curve *cv)
 		if (cv->d_gen) {
 			(void)hipFree(cv->d_gen);
 		}
+		if (cv->d_gtab) {
+			(void)hipFree(cv->d_gtab);
+		}
 		cv->ctx->slot_used[cv->slot] = false;
 		if (cv->gslot >= 0) {
 			cv->ctx->gslot_used[cv->pbits][cv->gslot] = false;
@@ -689,7 +737,7 @@ static size_t tbl_bytes_for(const ecamd_curve *cv, uint32_t stride)
 // sstride = slen normally; 0 broadcasts one scalar to every item (subgroup / cofactor passes)
 static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_scalars,
 			   uint32_t slen, const uint8_t *d_points, uint8_t *d_out, uint8_t *d_status,
-			   hipStream_t s, uint32_t sstride = 0xffffffffu)
+			   hipStream_t s, uint32_t sstride)
 {
 	if (sstride == 0xffffffffu) {
 		sstride = slen;
@@ -901,23 +949,10 @@ extern "C" int ec_fp_op_batch(ecamd_ctx *ctx, const ecamd_curve *cv, int op, uin
 // ------------------------------------------------------------------------------------------
 // batched ECDSA verification (digest supplied by the caller)
 // ------------------------------------------------------------------------------------------
-extern "C" int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys,
-				     const uint8_t *sigs, const uint8_t *digests, uint32_t hlen, uint8_t *result)
+// the reference's structure: two independent scalar multiplications and one addition per item
+static int ecdsa_verify_two_smul(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys,
+				 const uint8_t *sigs, const uint8_t *digests, uint32_t hlen, uint8_t *result)
 {
-	if (!ctx || !cv || cv->ctx != ctx || (n && (!pubkeys || !sigs || !digests || !result))) {
-		return fail("ec_ecdsa_verify_batch: bad argument");
-	}
-	if (cv->qslot < 0) {
-		return fail("ec_ecdsa_verify_batch: generator order not supported for this curve");
-	}
-	if (hlen == 0 || hlen > 128) {
-		return fail("ec_ecdsa_verify_batch: digest length must be in 1..128");
-	}
-	if (n == 0) {
-		return 0;
-	}
-	std::lock_guard<std::mutex> lk(ctx->mu);
-	HIPCHK(hipSetDevice(ctx->device));
 	const size_t plen = (size_t)2 * cv->clen, slen2 = (size_t)2 * cv->qlen, ql = (size_t)cv->qlen;
 	// stage: 0 pub, 1 sig, 2 digest, 3 u1, 4 u2, 5 A, 6 B, 7 stA, 8 stB, 9 flags, 10 result, 11 q scalar / tmp
 	const size_t need[ECAMD_NSTAGE] = {n * plen, n * slen2, (size_t)n * hlen, n * ql, n * ql, n * plen,
@@ -1002,6 +1037,103 @@ extern "C" int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint
 	HIPCHK(ecamd_launch_ecdsa_fin(cv->nw, Fn, s));
 	HIPCHK(hipMemcpyAsync(result, S[10], n, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
+	return 0;
+}
+
+
+extern "C" int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys,
+				     const uint8_t *sigs, const uint8_t *digests, uint32_t hlen, uint8_t *result)
+{
+	if (!ctx || !cv || cv->ctx != ctx || (n && (!pubkeys || !sigs || !digests || !result))) {
+		return fail("ec_ecdsa_verify_batch: bad argument");
+	}
+	if (cv->qslot < 0) {
+		return fail("ec_ecdsa_verify_batch: generator order not supported for this curve");
+	}
+	if (hlen == 0 || hlen > 128) {
+		return fail("ec_ecdsa_verify_batch: digest length must be in 1..128");
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	if (!cv->is_p256 || !cv->d_gtab) {
+		return ecdsa_verify_two_smul(ctx, cv, n, pubkeys, sigs, digests, hlen, result);
+	}
+	// secp256r1: interleaved [u1]G + [u2]Q loop (ecamd_launch_verify_p256), in chunks
+	const uint32_t chunk = n < ctx->max_chunk ? n : ctx->max_chunk;
+	{
+		uint8_t *t = (uint8_t *)ctx->tbl_fast;
+		const int rc = ensure(&t, &ctx->tbl_fast_bytes, (size_t)((chunk + 63u) & ~63u) * 8 * 40 * 4);
+		ctx->tbl_fast = (uint32_t *)t;
+		if (rc) {
+			return -1;
+		}
+	}
+	const size_t need[8] = {(size_t)chunk * 64, (size_t)chunk * 64, (size_t)chunk * hlen, (size_t)chunk * 32,
+				(size_t)chunk * 32, chunk, chunk, (size_t)chunk * 64 + chunk};
+	for (int i = 0; i < 8; i++) {
+		if (ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
+			return -1;
+		}
+	}
+	uint8_t **S = ctx->stage;
+	hipStream_t s = ctx->stream;
+	std::vector<uint32_t> redo;
+	for (uint32_t off = 0; off < n; off += chunk) {
+		const uint32_t m = (n - off) < chunk ? (n - off) : chunk;
+		HIPCHK(hipMemcpyAsync(S[0], pubkeys + (size_t)off * 64, (size_t)m * 64, hipMemcpyHostToDevice, s));
+		HIPCHK(hipMemcpyAsync(S[1], sigs + (size_t)off * 64, (size_t)m * 64, hipMemcpyHostToDevice, s));
+		HIPCHK(hipMemcpyAsync(S[2], digests + (size_t)off * hlen, (size_t)m * hlen, hipMemcpyHostToDevice, s));
+		EcamdEcdsaPrepArgs P;
+		P.sigs = S[1];
+		P.digests = S[2];
+		P.u1 = S[3];
+		P.u2 = S[4];
+		P.flags = S[5];
+		P.n = m;
+		P.qlen = 32;
+		P.hlen = hlen;
+		P.qbits = (uint32_t)cv->qbits;
+		P.qslot = cv->qslot;
+		HIPCHK(ecamd_launch_ecdsa_prep(cv->nw, P, s));
+		EcamdSmulArgs K;
+		memset(&K, 0, sizeof(K));
+		K.points = S[0];
+		K.pstride = 64;
+		K.out = S[7];           // zeroed for rejected keys; otherwise unused
+		K.status = S[7] + (size_t)m * 64;
+		K.tbl = ctx->tbl_fast;
+		K.n = m;
+		K.clen = 32;
+		K.slot = cv->slot;
+		HIPCHK(ecamd_launch_verify_p256(K, S[3], S[4], S[1], S[5], cv->d_gtab, cv->qdig, S[6], s));
+		HIPCHK(hipMemcpyAsync(result + off, S[6], m, hipMemcpyDeviceToHost, s));
+		HIPCHK(hipStreamSynchronize(s));
+		for (uint32_t i = 0; i < m; i++) {
+			if (result[off + i] == ECAMD_STATUS_REDO) {
+				redo.push_back(off + i);
+			}
+		}
+	}
+	if (!redo.empty()) {
+		// exceptional pairs inside the interleaved loop (never for honest signatures): re-verify those
+		// items the reference's way
+		const uint32_t r = (uint32_t)redo.size();
+		std::vector<uint8_t> pk((size_t)r * 64), sg((size_t)r * 64), dg((size_t)r * hlen), res(r);
+		for (uint32_t j = 0; j < r; j++) {
+			memcpy(&pk[(size_t)j * 64], pubkeys + (size_t)redo[j] * 64, 64);
+			memcpy(&sg[(size_t)j * 64], sigs + (size_t)redo[j] * 64, 64);
+			memcpy(&dg[(size_t)j * hlen], digests + (size_t)redo[j] * hlen, hlen);
+		}
+		if (ecdsa_verify_two_smul(ctx, cv, r, pk.data(), sg.data(), dg.data(), hlen, res.data())) {
+			return -1;
+		}
+		for (uint32_t j = 0; j < r; j++) {
+			result[redo[j]] = res[j];
+		}
+	}
 	return 0;
 }
 

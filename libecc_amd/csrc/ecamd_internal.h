@@ -74,6 +74,12 @@ hipError_t ecamd_launch_smul(int nw, const EcamdSmulArgs &a, hipStream_t s);
 // ev (optional, 6 events): recorded before the first kernel and after each kernel of the pipeline
 #define ECAMD_NTIMED 5
 hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev);
+// secp256r1 ECDSA verification core: pubkeys.{points,status,tbl,out,n,pstride} describe the public keys
+// (table kernels), u1/u2/sigs/flags come from k_ecdsa_prep, gtbl = affine table of G (8 x 40 words),
+// qdigits = group order in radix 2^29; result 0 accept / 1 reject / ECAMD_STATUS_REDO
+hipError_t ecamd_launch_verify_p256(const EcamdSmulArgs &pubkeys, const uint8_t *u1, const uint8_t *u2, const uint8_t *sigs,
+				    const uint8_t *flags, const uint32_t *gtbl, const uint32_t *qdigits, uint8_t *result,
+				    hipStream_t s);
 // ---- X25519 / X448 (ecdh/x25519_448.c:146-302 of the reference) around the scalar multiplication ----
 struct EcamdXdhPrepArgs {
 	const uint8_t *k, *u;    // n x len little-endian scalars and u coordinates (RFC 7748 wire format)

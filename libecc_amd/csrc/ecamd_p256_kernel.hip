@@ -478,6 +478,186 @@ __global__ __launch_bounds__(64) void k_p256_finalize(EcamdSmulArgs A, u32 nthre
 	}
 }
 
+// ------------------------------------------------------------------------------------------
+// ECDSA verification core: W' = [u1]G + [u2]Q by one interleaved window loop (Shamir / Straus):
+// 4 doublings + 2 mixed additions per window instead of two separate scalar multiplications, and
+// the final check x(W') mod q == r done projectively (r Z^2 == X, or (r + q) Z^2 == X when r + q < p),
+// so no inversion at all.  The reference computes uG and vY separately and adds them
+// (sig/ecdsa_common.c:786-810); only x mod q is observable.  Q's affine window table comes from
+// k_p256_table / k_p256_affine, G's is a constant table built once per curve handle.
+// result: 0 accept, 1 reject, ECAMD_STATUS_REDO when an exceptional pair was met (the host then
+// re-verifies that item through the two-scalar-mult path).
+// ------------------------------------------------------------------------------------------
+static __device__ __forceinline__ u32 recode(u32 *kw, const u8 *sc)
+{
+	// 32-byte big-endian scalar -> k' = k + 0x88..8; returns the carry (top digit 0 / +1)
+	load_be256(sc, kw);
+	uint64_t c = 0;
+#pragma unroll
+	for (int w = 0; w < 8; w++) {
+		c += (uint64_t)kw[w] + 0x88888888u;
+		kw[w] = (u32)c;
+		c >>= 32;
+	}
+	return (u32)c;
+}
+
+struct P256VerifyArgs {
+	const u8 *u1, *u2;      // n x 32 big-endian (k_ecdsa_prep)
+	const u8 *sigs;         // n x 64, r || s
+	const u8 *flags;        // n: r/s range check of k_ecdsa_prep
+	const u8 *status;       // n: ECAMD_STATUS_TAB where Q's table is ready, 1 where the key is invalid
+	const u32 *qtbl;        // per-item affine tables of Q
+	const u32 *gtbl;        // affine table of G, 8 entries
+	u8 *result;
+	u32 n;
+	u32 qd[9];              // digits of the group order q (canonical, radix 2^29)
+};
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, P256_WAVES))) void k_p256_verify_loop(P256VerifyArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	if (A.flags[i] || A.status[i] != ECAMD_STATUS_TAB) {
+		A.result[i] = 1;  // r or s out of range, or public key rejected at import
+		return;
+	}
+	const u32 *tb = A.qtbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
+	u32 k1[8], k2[8];
+	const u32 c1 = recode(k1, A.u1 + (size_t)i * 32), c2 = recode(k2, A.u2 + (size_t)i * 32);
+	const FZ onez = weaken<FZ>(constant<Fcanon>(K::ONE));
+	Jac acc;
+	bool inf = true, bad = false, hz;
+	// top digits (carries): acc = c1 G + c2 Q
+	{
+		u32 b[20];
+		Fcanon gx, gy, qx, qy;
+		ld<5>(b, A.gtbl);
+#pragma unroll
+		for (int w = 0; w < 9; w++) { gx.l[w] = b[w]; gy.l[w] = b[9 + w]; }
+		ld<5>(b, tb);
+#pragma unroll
+		for (int w = 0; w < 9; w++) { qx.l[w] = b[w]; qy.l[w] = b[9 + w]; }
+		acc.X = weaken<FX>(gx);
+		acc.Y = weaken<FY>(gy);
+		acc.Z = onez;
+		inf = (c1 == 0);
+		const Jac S = madd(acc, qx, weaken<FYaff>(qy), hz);
+		const bool addq = (c2 != 0);
+		bad = bad | (addq & !inf & hz);
+		acc.X = sel(addq, sel(inf, weaken<FX>(qx), S.X), acc.X);
+		acc.Y = sel(addq, sel(inf, weaken<FY>(qy), S.Y), acc.Y);
+		acc.Z = sel(addq, sel(inf, onez, S.Z), acc.Z);
+		inf = inf & !addq;
+	}
+#pragma unroll 1
+	for (int t = 0; t < 64; t++) {
+#pragma unroll 1
+		for (int d = 0; d < 4; d++) {
+			acc = dbl(acc);
+		}
+#pragma unroll 1
+		for (int which = 0; which < 2; which++) {
+			u32 *kw = which ? k2 : k1;
+			const u32 *base = which ? tb : A.gtbl;
+			const int dig = (int)(kw[7] >> 28) - 8;
+#pragma unroll
+			for (int w = 7; w > 0; w--) {
+				kw[w] = (kw[w] << 4) | (kw[w - 1] >> 28);
+			}
+			kw[0] <<= 4;
+			const u32 mag = (u32)(dig < 0 ? -dig : dig);
+			u32 b[20];
+			ld<5>(b, base + (mag ? mag - 1 : 0) * TBL_WORDS_PER_ENTRY);
+			Fcanon tx, tyc;
+#pragma unroll
+			for (int w = 0; w < 9; w++) {
+				tx.l[w] = b[w];
+				tyc.l[w] = b[9 + w];
+			}
+			const FYaff ty = sel(dig < 0, neg_aff(tyc), weaken<FYaff>(tyc));
+			const Jac S = madd(acc, tx, ty, hz);
+			const bool use_t = inf & (mag != 0);
+			const bool keep = (mag == 0);
+			bad = bad | (!inf & !keep & hz);
+			acc.X = sel(keep, acc.X, sel(use_t, weaken<FX>(tx), S.X));
+			acc.Y = sel(keep, acc.Y, sel(use_t, weaken<FY>(carry(ty)), S.Y));
+			acc.Z = sel(keep, acc.Z, sel(use_t, onez, S.Z));
+			inf = inf & keep;
+		}
+	}
+	if (bad) {
+		A.result[i] = ECAMD_STATUS_REDO;
+		return;
+	}
+	if (inf) {
+		A.result[i] = 1;  // W' = infinity (sig/ecdsa_common.c:798-800)
+		return;
+	}
+	// x(W') mod q == r  <=>  X == r Z^2 or X == (r + q) Z^2 with r + q < p
+	u32 rw[8];
+	load_be256(A.sigs + (size_t)i * 64, rw);
+	const Fcanon r2c = constant<Fcanon>(K::R2), onec = constant<Fcanon>(K::ONE);
+	const auto z2 = sqr(acc.Z);
+	const Fcanon rd = from_words(rw);
+	const auto t1 = mul(mul(rd, r2c), z2);                       // r Z^2 (Montgomery domain)
+	bool acc_ok = is_zero_mulout(mul(carry(sub<1, 1>(t1, acc.X)), onec));
+	{
+		// r + q as digits, and whether it is below p (p - q < 2^128, so at most one extra candidate)
+		u32 sdg[9];
+		u32 cy = 0;
+#pragma unroll
+		for (int w = 0; w < 9; w++) {
+			const u32 x = rd.l[w] + A.qd[w] + cy;
+			cy = (w < 8) ? (x >> 29) : 0u;
+			sdg[w] = (w < 8) ? (x & MASK) : x;
+		}
+		u32 bw = 0;
+#pragma unroll
+		for (int w = 0; w < 9; w++) {
+			bw = (sdg[w] - P256::P[w] - bw) >> 31;
+		}
+		Fcanon rq;
+#pragma unroll
+		for (int w = 0; w < 9; w++) {
+			rq.l[w] = bw ? sdg[w] : 0u;
+		}
+		const auto t2 = mul(mul(rq, r2c), z2);
+		acc_ok = acc_ok | ((bw != 0) & is_zero_mulout(mul(carry(sub<1, 1>(t2, acc.X)), onec)));
+	}
+	A.result[i] = acc_ok ? 0 : 1;
+}
+
+hipError_t ecamd_launch_verify_p256(const EcamdSmulArgs &pubkeys, const uint8_t *u1, const uint8_t *u2, const uint8_t *sigs,
+				    const uint8_t *flags, const uint32_t *gtbl, const uint32_t *qdigits, uint8_t *result,
+				    hipStream_t s)
+{
+	if (pubkeys.n == 0) {
+		return hipSuccess;
+	}
+	const dim3 grid((pubkeys.n + 63) / 64), block(64);
+	const uint32_t athreads = (pubkeys.n + AFF_K - 1) / AFF_K;
+	hipLaunchKernelGGL(k_p256_table, grid, block, 0, s, pubkeys);
+	hipLaunchKernelGGL(k_p256_affine, dim3((athreads + 63) / 64), block, 0, s, pubkeys, athreads);
+	P256VerifyArgs V;
+	V.u1 = u1;
+	V.u2 = u2;
+	V.sigs = sigs;
+	V.flags = flags;
+	V.status = pubkeys.status;
+	V.qtbl = pubkeys.tbl;
+	V.gtbl = gtbl;
+	V.result = result;
+	V.n = pubkeys.n;
+	for (int w = 0; w < 9; w++) {
+		V.qd[w] = qdigits[w];
+	}
+	hipLaunchKernelGGL(k_p256_verify_loop, grid, block, 0, s, V);
+	return hipGetLastError();
+}
+
 hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev)
 {
 	if (a.n == 0) {

@@ -555,3 +555,42 @@ def test_ecccdh_cofactor_curve(gpu_ctx):
         assert exp[1][:10] == bytes(10) and set(exp[1][10:]) == {1}
     finally:
         cv.free()
+
+
+def test_ecdsa_verify_exceptional_pairs(gpu_ctx):
+    """secp256r1 interleaved verification loop: public key G (or -G) with u1 == u2 makes every window
+    add the same point twice (doubling / inverse cases of the incomplete addition); such items must be
+    re-verified through the two-scalar-mult path and agree with the oracle"""
+    curve = "SECP256R1"
+    c = CURVES[curve]
+    q, p = c["q"], c["p"]
+    o = Oracle(curve)
+    cv = gpu_ctx.curve(curve)
+    try:
+        G = c["gx"].to_bytes(32, "big") + c["gy"].to_bytes(32, "big")
+        negG = c["gx"].to_bytes(32, "big") + (p - c["gy"]).to_bytes(32, "big")
+        pubs, sigs, dgs = b"", b"", b""
+        for k in (5, 0x1234567, q - 3, (q + 1) // 2, 2**200 + 17):
+            kG, st = o.scalar_mult(k.to_bytes(32, "big"))
+            r = int.from_bytes(kG[:32], "big") % q
+            kinv = pow(k, q - 2, q)
+            # key d = 1 (Q = G), digest e = r: s = k^-1 (e + r d) = 2 r / k, u1 = u2 = k / 2
+            s = kinv * (2 * r) % q
+            pubs += G
+            sigs += r.to_bytes(32, "big") + s.to_bytes(32, "big")
+            dgs += r.to_bytes(32, "big")
+            # key d = q - 1 (Q = -G), digest e = r: s = k^-1 (r - r) = 0 is invalid, so use e = 3 r:
+            # s = k^-1 (3 r - r) = 2 r / k, u1 = 3k/2, u2 = k/2 -> W' = [3k/2]G - [k/2]G = [k]G
+            pubs += negG
+            sigs += r.to_bytes(32, "big") + s.to_bytes(32, "big")
+            dgs += (3 * r % q).to_bytes(32, "big")
+            # and a rejected one: Q = -G with e = r gives u1 == u2, W' = infinity
+            pubs += negG
+            sigs += r.to_bytes(32, "big") + s.to_bytes(32, "big")
+            dgs += r.to_bytes(32, "big")
+        exp = o.ecdsa_verify(pubs, sigs, dgs, 32)
+        got = cv.ecdsa_verify(pubs, sigs, dgs, 32)
+        assert got == exp
+        assert exp == bytes([0, 0, 1] * 5)
+    finally:
+        cv.free()
