@@ -780,11 +780,13 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 		A.stride = stride;
 		A.slot = cv->slot;
 		A.only_redo = 0;
+		A.lut = nullptr;
 		if (fast) {
 			// Jacobian fast path; lanes that met an exceptional pair come back as ECAMD_STATUS_REDO and
 			// are recomputed by the complete-formula kernel (all other lanes exit at once)
 			EcamdSmulArgs Fa = A;
 			Fa.tbl = ctx->tbl_fast;
+			Fa.lut = (fast256 && !d_points) ? cv->d_gtab : nullptr;  // fixed base: skip the table kernels
 			hipEvent_t *ev = (ctx->timing && off == 0) ? ctx->ev : nullptr;  // first chunk of the call
 			if (fast256) {
 				HIPCHK(ecamd_launch_smul_p256(Fa, s, ev));

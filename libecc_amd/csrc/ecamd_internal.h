@@ -21,6 +21,7 @@ struct EcamdSmulArgs {
 	uint32_t sstride;        // bytes between consecutive scalars (slen, or 0: one shared scalar)
 	int slot;
 	int only_redo;           // generic kernel: process only items whose status is ECAMD_STATUS_REDO
+	const uint32_t *lut;     // secp256r1 fixed base: shared affine window table of G (NULL: per-item tables)
 };
 
 struct EcamdFpArgs {

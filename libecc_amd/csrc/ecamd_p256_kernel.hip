@@ -307,6 +307,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 		return;
 	}
 	u32 *tb = A.tbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
+	const u32 *lut = A.lut ? A.lut : tb;  // fixed base: one shared table for every lane
 	// ---- scalar: k (<= 32 bytes big-endian) -> k' = k + 0x88..8 over its 2*slen nibbles ----
 	const u8 *sc = A.scalars + (size_t)i * A.sstride;
 	const int slen = (int)A.slen;
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 	Jac acc;
 	{
 		u32 b[20];
-		ld<5>(b, tb);
+		ld<5>(b, lut);
 #pragma unroll
 		for (int w = 0; w < 9; w++) {
 			acc.X.l[w] = b[w];
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 		kw[0] <<= 4;
 		const u32 mag = (u32)(dig < 0 ? -dig : dig);
 		u32 b[20];
-		ld<5>(b, tb + (mag ? mag - 1 : 0) * TBL_WORDS_PER_ENTRY);
+		ld<5>(b, lut + (mag ? mag - 1 : 0) * TBL_WORDS_PER_ENTRY);
 		Fcanon tx, tyc;
 #pragma unroll
 		for (int w = 0; w < 9; w++) {
@@ -668,10 +669,16 @@ hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s, hipEven
 	const dim3 fgrid((nthreads + 63) / 64);
 #define P256_MARK(i) do { if (ev) (void)hipEventRecord(ev[i], s); } while (0)
 	P256_MARK(0);
-	hipLaunchKernelGGL(k_p256_table, grid, block, 0, s, a);
-	P256_MARK(1);
-	const uint32_t athreads = (a.n + AFF_K - 1) / AFF_K;
-	hipLaunchKernelGGL(k_p256_affine, dim3((athreads + 63) / 64), block, 0, s, a, athreads);
+	if (a.lut) {
+		// fixed base: the generator's affine table is a constant of the curve handle; every item is valid
+		(void)hipMemsetAsync(a.status, ECAMD_STATUS_TAB, a.n, s);
+		P256_MARK(1);
+	} else {
+		hipLaunchKernelGGL(k_p256_table, grid, block, 0, s, a);
+		P256_MARK(1);
+		const uint32_t athreads = (a.n + AFF_K - 1) / AFF_K;
+		hipLaunchKernelGGL(k_p256_affine, dim3((athreads + 63) / 64), block, 0, s, a, athreads);
+	}
 	P256_MARK(2);
 	hipLaunchKernelGGL(k_p256_loop, grid, block, 0, s, a);
 	P256_MARK(3);
