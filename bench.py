@@ -77,6 +77,8 @@ def work_model(curve_params, nw, slen):
         # squaring NL (NL + 1) / 2 products + NL^2 reduction MADs
         nl = (pbits + 16 + 28) // 29
         M, S = 2 * nl * nl, nl * (nl + 1) // 2 + nl * nl
+        if p == 2**521 - 1:                          # secp521r1 flavour: one reduction MAD per digit
+            M, S = nl * nl + nl, nl * (nl + 1) // 2 + nl
         am3 = curve_params["a"] == p - 3
         dbl = (4, 4) if am3 else (4, 6)
         add = (12, 4)

@@ -36,6 +36,7 @@ def _jobs():
     more as the dispatcher, so that the big template instantiations build in parallel."""
     jobs = [(src, os.path.splitext(src)[0] + ".o", []) for src in SOURCES]
     jobs += [("ecamd_g29_kernel.hip", f"ecamd_g29_{pb}.o", [f"-DG29_PB={pb}"]) for pb in G29_SIZES]
+    jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_521m.o", ["-DG29_PB=521", "-DG29_MERSENNE521"]))
     jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_dispatch.o", ["-DG29_DISPATCH"]))
     return jobs
 

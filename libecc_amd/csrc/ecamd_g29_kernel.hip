@@ -136,7 +136,8 @@ template <class T> static __device__ __forceinline__ T selg(bool c, const T &a, 
 	return r;
 }
 
-template <int PB> __global__ __launch_bounds__(64) void k_smul_g(EcamdSmulArgs A, int gslot)
+// FLAV only makes the kernel symbols of the two 521-bit translation units distinct (0 dense, 1 secp521r1)
+template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_smul_g(EcamdSmulArgs A, int gslot)
 {
 	typedef Lay<PB> L;
 	typedef typename Cls<PB>::FA FA;
@@ -314,7 +315,7 @@ template <int PB> __global__ __launch_bounds__(64) void k_smul_g(EcamdSmulArgs A
 }
 
 #define FING_K 8
-template <int PB> __global__ __launch_bounds__(64) void k_finalize_g(EcamdSmulArgs A, int gslot, u32 nthreads)
+template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_finalize_g(EcamdSmulArgs A, int gslot, u32 nthreads)
 {
 	typedef Lay<PB> L;
 	typedef typename Cls<PB>::FM FM;
@@ -391,21 +392,26 @@ template <int PB> __global__ __launch_bounds__(64) void k_finalize_g(EcamdSmulAr
 // ---- one field size: constants + launch / upload entry points with the size in their name ----
 #define G29_CAT2(a, b) a##b
 #define G29_CAT(a, b) G29_CAT2(a, b)
-__constant__ SlotsG<Lay<G29_PB>::NL> G29_CAT(g_g29_, G29_PB);
+#ifdef G29_MERSENNE521
+#define G29_TAG G29_CAT(G29_PB, m)   /* 521m: the secp521r1 flavour lives beside the dense 521 one */
+#else
+#define G29_TAG G29_PB
+#endif
+__constant__ SlotsG<Lay<G29_PB>::NL> G29_CAT(g_g29_, G29_TAG);
 template <> struct TabGP<G29_PB> {
-	static __device__ __forceinline__ const CurveG<Lay<G29_PB>::NL> &get(int slot) { return G29_CAT(g_g29_, G29_PB).s[slot]; }
+	static __device__ __forceinline__ const CurveG<Lay<G29_PB>::NL> &get(int slot) { return G29_CAT(g_g29_, G29_TAG).s[slot]; }
 };
 
-hipError_t G29_CAT(ecamd_g29_upload_, G29_PB)(int slot, const void *img, size_t bytes)
+hipError_t G29_CAT(ecamd_g29_upload_, G29_TAG)(int slot, const void *img, size_t bytes)
 {
 	typedef CurveG<Lay<G29_PB>::NL> CK;
 	if (bytes != sizeof(CK) || slot < 0 || slot >= G29_SLOTS) {
 		return hipErrorInvalidValue;
 	}
-	return hipMemcpyToSymbol(HIP_SYMBOL(G29_CAT(g_g29_, G29_PB)), img, bytes, (size_t)slot * sizeof(CK), hipMemcpyHostToDevice);
+	return hipMemcpyToSymbol(HIP_SYMBOL(G29_CAT(g_g29_, G29_TAG)), img, bytes, (size_t)slot * sizeof(CK), hipMemcpyHostToDevice);
 }
 
-hipError_t G29_CAT(ecamd_g29_launch_, G29_PB)(int gslot, const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev)
+hipError_t G29_CAT(ecamd_g29_launch_, G29_TAG)(int gslot, const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev)
 {
 	const dim3 grid((a.n + 63) / 64), block(64);
 	const uint32_t nthreads = (a.n + FING_K - 1) / FING_K;
@@ -416,11 +422,11 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_PB)(int gslot, const EcamdSmulArgs &a,
 		(void)hipEventRecord(ev[1], s);
 		(void)hipEventRecord(ev[2], s);
 	}
-	hipLaunchKernelGGL(k_smul_g<G29_PB>, grid, block, 0, s, a, gslot);
+	hipLaunchKernelGGL((k_smul_g<G29_PB, g29::MERSENNE521 ? 1 : 0>), grid, block, 0, s, a, gslot);
 	if (ev) {
 		(void)hipEventRecord(ev[3], s);
 	}
-	hipLaunchKernelGGL(k_finalize_g<G29_PB>, fgrid, block, 0, s, a, gslot, nthreads);
+	hipLaunchKernelGGL((k_finalize_g<G29_PB, g29::MERSENNE521 ? 1 : 0>), fgrid, block, 0, s, a, gslot, nthreads);
 	if (ev) {
 		(void)hipEventRecord(ev[4], s);
 	}
@@ -435,6 +441,7 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_PB)(int gslot, const EcamdSmulArgs &a,
 	hipError_t ecamd_g29_upload_##PB(int slot, const void *img, size_t bytes); \
 	hipError_t ecamd_g29_launch_##PB(int gslot, const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev);
 G29_FOR_PB(X)
+X(521m)
 #undef X
 
 int ecamd_g29_supported(int pbits)
@@ -452,8 +459,12 @@ uint32_t ecamd_g29_table_words(int pbits) { return 8u * (uint32_t)(((3 * g29::nl
 uint32_t ecamd_g29_max_slen(int pbits) { return 4u * (uint32_t)((pbits + 31) / 32); }
 size_t ecamd_g29_image_bytes(int pbits) { return (size_t)((6 + g29::NBIAS) * g29::nl_for(pbits) + 4) * 4; }
 
-hipError_t ecamd_g29_upload(int pbits, int slot, const void *img, size_t bytes)
+// 'flavour' 1 selects the secp521r1 (p = 2^521 - 1) instantiation
+hipError_t ecamd_g29_upload(int pbits, int slot, const void *img, size_t bytes, int flavour)
 {
+	if (pbits == 521 && flavour == 1) {
+		return ecamd_g29_upload_521m(slot, img, bytes);
+	}
 	switch (pbits) {
 #define X(PB) case PB: return ecamd_g29_upload_##PB(slot, img, bytes);
 		G29_FOR_PB(X)
@@ -462,10 +473,13 @@ hipError_t ecamd_g29_upload(int pbits, int slot, const void *img, size_t bytes)
 	}
 }
 
-hipError_t ecamd_launch_smul_g29(int pbits, int gslot, const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev)
+hipError_t ecamd_launch_smul_g29(int pbits, int gslot, const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev, int flavour)
 {
 	if (a.n == 0) {
 		return hipSuccess;
+	}
+	if (pbits == 521 && flavour == 1) {
+		return ecamd_g29_launch_521m(gslot, a, s, ev);
 	}
 	switch (pbits) {
 #define X(PB) case PB: return ecamd_g29_launch_##PB(gslot, a, s, ev);

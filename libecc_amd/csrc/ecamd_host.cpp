@@ -235,6 +235,7 @@ struct ecamd_curve {
 	uint8_t *d_gen;  // generator, affine X||Y big-endian, in HBM
 	bool is_p256;    // exactly secp256r1: hand-specialised radix-2^29 Jacobian kernel
 	int gslot;       // constant slot of the generic radix-2^29 Jacobian kernel (-1: none)
+	int gflavour;    // 0 dense reduction, 1 secp521r1 (p = 2^521 - 1) single-digit reduction
 	uint32_t *d_gtab; // secp256r1: affine window table [1..8]G, radix-2^29 Montgomery digits, 8 x 40 words
 	uint32_t qdig[9]; // secp256r1: digits of the group order
 };
@@ -525,7 +526,7 @@ static int upload_g29(ecamd_curve *cv)
 	if (img.size() * 4 != ecamd_g29_image_bytes(pbits)) {
 		return fail("internal: CurveG image size mismatch");
 	}
-	HIPCHK(ecamd_g29_upload(pbits, cv->gslot, img.data(), img.size() * 4));
+	HIPCHK(ecamd_g29_upload(pbits, cv->gslot, img.data(), img.size() * 4, cv->gflavour));
 	return 0;
 }
 
@@ -584,9 +585,10 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 		return -1;
 	}
 	cv->gslot = -1;
+	cv->gflavour = (cv->pbits == 521 && big_cmp(big_add(cv->p, Big(1, 1)), big_pow2(521)) == 0) ? 1 : 0;
 	if (!cv->is_p256 && ecamd_g29_supported(cv->pbits) && cv->pbits < 640 && getenv("ECAMD_NO_FAST_PATH") == nullptr) {
 		for (int i = 0; i < ecamd_g29_slots(); i++) {
-			if (!ctx->gslot_used[cv->pbits][i]) {
+			if (!ctx->gslot_used[cv->pbits + cv->gflavour][i]) {
 				cv->gslot = i;
 				break;
 			}
@@ -645,7 +647,7 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	}
 	ctx->slot_used[slot] = true;
 	if (cv->gslot >= 0) {
-		ctx->gslot_used[cv->pbits][cv->gslot] = true;
+		ctx->gslot_used[cv->pbits + cv->gflavour][cv->gslot] = true;
 	}
 	if (cv->qslot >= 0) {
 		ctx->slot_used[cv->qslot] = true;
@@ -713,7 +715,7 @@ extern "C" void ecamd_curve_free(ecamd_curve *cv)
 		}
 		cv->ctx->slot_used[cv->slot] = false;
 		if (cv->gslot >= 0) {
-			cv->ctx->gslot_used[cv->pbits][cv->gslot] = false;
+			cv->ctx->gslot_used[cv->pbits + cv->gflavour][cv->gslot] = false;
 		}
 		if (cv->qslot >= 0) {
 			cv->ctx->slot_used[cv->qslot] = false;
@@ -791,7 +793,7 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 			if (fast256) {
 				HIPCHK(ecamd_launch_smul_p256(Fa, s, ev));
 			} else {
-				HIPCHK(ecamd_launch_smul_g29(cv->pbits, cv->gslot, Fa, s, ev));
+				HIPCHK(ecamd_launch_smul_g29(cv->pbits, cv->gslot, Fa, s, ev, cv->gflavour));
 			}
 			ctx->ev_valid = ctx->ev_valid || (ev != nullptr);
 			A.only_redo = 1;

@@ -113,8 +113,8 @@ int ecamd_g29_slots(void);
 uint32_t ecamd_g29_table_words(int pbits);   // scratch words per item
 uint32_t ecamd_g29_max_slen(int pbits);      // longest scalar (bytes) the fast path takes
 size_t ecamd_g29_image_bytes(int pbits);
-hipError_t ecamd_g29_upload(int pbits, int slot, const void *img, size_t bytes);
-hipError_t ecamd_launch_smul_g29(int pbits, int gslot, const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev);
+hipError_t ecamd_g29_upload(int pbits, int slot, const void *img, size_t bytes, int flavour);
+hipError_t ecamd_launch_smul_g29(int pbits, int gslot, const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev, int flavour);
 hipError_t ecamd_launch_fp(int nw, const EcamdFpArgs &a, hipStream_t s);
 hipError_t ecamd_launch_pt(int nw, const EcamdPtArgs &a, hipStream_t s);
 size_t ecamd_curvek_bytes(int nw);

@@ -138,10 +138,21 @@ template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
 #define G29_PIN(acc) (void)0
 #endif
 
+// Reduction flavour of a translation unit: dense (any prime) or, with -DG29_MERSENNE521, the
+// special case p = 2^521 - 1 (secp521r1): p = -1 mod 2^29 so the quotient digit is the column's
+// low 29 bits, and "+ m p" is "- m + m (p + 1)" with p + 1 = 2^521 = 2^28 * 2^(29*17): ONE
+// reduction MAD per digit instead of NL (380 MADs per multiplication instead of 722).
+#if defined(G29_MERSENNE521)
+constexpr bool MERSENNE521 = true;
+#else
+constexpr bool MERSENNE521 = false;
+#endif
+
 // r = a b / R mod p (lazy): product scanning with the reduction interleaved.  SQR: a == b, the
 // off-diagonal products are taken once against the doubled operand.
 template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 *b, const u32 *p, u32 mpinv)
 {
+	static_assert(!MERSENNE521 || NL == 19, "the Mersenne flavour is only for secp521r1");
 	u32 m[NL], a2[NL];
 	if (SQR) {
 #pragma unroll
@@ -165,18 +176,34 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 				G29_MAD_VV(acc, a[i], a[i]);
 			}
 		}
-		// m_i p_(k-i): i < k in the low half, the whole anti-diagonal in the high half
-#pragma unroll
-		for (int i = lo; i <= hi; i++) {
-			if (k >= NL || i < k) {
-				G29_MAD_VS(acc, m[i], p[k - i]);
+		if (MERSENNE521) {
+			// m_(k-17) * 2^28 (p + 1 has its only non-zero digit at limb 17); "- m_k" clears the digit
+			u32 q17 = 1u << 28;
+#if defined(__HIPCC__)
+			asm volatile("" : "+s"(q17));  // keep it a MAD, not a 64-bit shift + add
+#endif
+			if (k - 17 >= 0 && k - 17 < NL) {
+				G29_MAD_VS(acc, m[k - 17], q17);
 			}
-		}
-		if (k < NL) {
-			m[k] = ((u32)acc * mpinv) & MASK;
-			G29_MAD_VS(acc, m[k], p[0]);
+			if (k < NL) {
+				m[k] = (u32)acc & MASK;
+			} else {
+				r[k - NL] = (u32)acc & MASK;
+			}
 		} else {
-			r[k - NL] = (u32)acc & MASK;
+			// m_i p_(k-i): i < k in the low half, the whole anti-diagonal in the high half
+#pragma unroll
+			for (int i = lo; i <= hi; i++) {
+				if (k >= NL || i < k) {
+					G29_MAD_VS(acc, m[i], p[k - i]);
+				}
+			}
+			if (k < NL) {
+				m[k] = ((u32)acc * mpinv) & MASK;
+				G29_MAD_VS(acc, m[k], p[0]);
+			} else {
+				r[k - NL] = (u32)acc & MASK;
+			}
 		}
 		acc >>= W;
 		G29_PIN(acc);

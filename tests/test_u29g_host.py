@@ -30,6 +30,16 @@ def lib():
     return C.CDLL(so)
 
 
+@pytest.fixture(scope="module")
+def lib_m521():
+    """the secp521r1 flavour (single-digit reduction) of the same headers"""
+    os.makedirs(BUILD, exist_ok=True)
+    so = os.path.join(BUILD, "u29g_host_m521.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DG29_MERSENNE521", "-DSHIM_ONLY_521", "-o", so,
+                           os.path.join(ROOT, "tests", "u29g_host_shim.cpp")])
+    return C.CDLL(so)
+
+
 def val(l):
     return sum(int(v) << (W * i) for i, v in enumerate(l))
 
@@ -171,3 +181,8 @@ def test_jacobian(lib, curve):
     assert hz == 1
     out, hz = f.call("add", jac(P), jac((P[0], p - P[1])), n_out=3 * f.nl)
     assert hz == 1 and aff(out) is None
+
+
+def test_secp521r1_mersenne_flavour(lib_m521):
+    test_field_ops(lib_m521, "SECP521R1")
+    test_jacobian(lib_m521, "SECP521R1")

@@ -100,6 +100,7 @@ template <int PB> struct Shim {
 	void g_canon_##PB(const uint32_t *k, const uint32_t *a, uint32_t *o) { Shim<PB>::canon_(k, a, o); } \
 	void g_info_##PB(uint32_t *o) { Shim<PB>::info_(o); } \
 	}
+#ifndef SHIM_ONLY_521
 SHIM(192)
 SHIM(224)
 SHIM(255)
@@ -109,4 +110,5 @@ SHIM(384)
 SHIM(448)
 SHIM(511)
 SHIM(512)
+#endif
 SHIM(521)
