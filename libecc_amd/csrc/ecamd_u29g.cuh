@@ -23,12 +23,12 @@
 #define G29_FN inline
 #define G29_NOINLINE inline
 #endif
-// Multiplications are inlined into the formulas for fields of up to 10 limbs (<= 256 bit: +25 % on
-// MI355X, see ecamd_u29.cuh) and called out of line from 12 limbs on, where a single multiplier is
-// already 300-800 instructions and inlining 25 of them per loop body only costs compile time and
-// instruction-cache misses.
+// Multiplications are inlined into the formulas for fields of up to 14 limbs (<= 384 bit: +25 % on
+// secp256r1, +23 % on secp384r1 on MI355X) and called out of line from 16 limbs on, where a single
+// multiplier is 500-800 instructions and inlining 25 of them per loop body mostly costs compile
+// time (the 384-bit unit already takes 90 s) and instruction-cache misses.
 #ifndef G29_CALL_FROM_NL
-#define G29_CALL_FROM_NL 12
+#define G29_CALL_FROM_NL 16
 #endif
 
 namespace g29 {
