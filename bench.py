@@ -192,7 +192,12 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    from oracles import CURVES, Oracle
+    from oracles import CURVES, Oracle, build_oracle
+    # the CPU checker is compiled on first use: let rank 0 do it alone, the others wait
+    if rank == 0:
+        build_oracle()
+    if dist is not None:
+        dist.barrier()
     curve = args.curve
     cp = CURVES[curve]
     q = cp["q"]
