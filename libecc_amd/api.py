@@ -13,6 +13,7 @@ EXPORTED_SYMBOLS = [
     "ecamd_curve_coord_len", "ecamd_curve_order_len", "ecamd_curve_words", "ec_prj_pt_mul_batch",
     "ec_prj_pt_mul_batch_dev", "ecamd_ctx_synchronize", "ec_prj_pt_add_batch", "ec_prj_pt_dbl_batch",
     "ec_fp_op_batch", "ec_ecdsa_verify_batch", "ec_ecdsa_sign_batch", "ec_ecccdh_derive_batch", "ec_xdh_batch",
+    "ec_eddsa_verify_batch",
 ]
 
 
@@ -60,6 +61,7 @@ def load_library():
         L.ec_ecdsa_verify_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p]
         L.ec_ecdsa_sign_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p, u8p]
         L.ec_xdh_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
+        L.ec_eddsa_verify_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p]
         L.ec_ecccdh_derive_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
         _LIB = L
     return _LIB
@@ -198,3 +200,11 @@ class Curve:
         st = C.create_string_buffer(max(1, n))
         _chk(self.L, self.L.ec_xdh_batch(self.ctx.h, self.h, n, k, u, out, st), "ec_xdh_batch")
         return out.raw[:self.clen * n], st.raw[:n]
+
+    def eddsa_verify(self, pubkeys, sigs, hram, hram_len=64):
+        """Ed25519 (WEI25519 handle): 32-byte keys, 64-byte signatures, hram = SHA-512(dom2 || R || A || PH(M))"""
+        n = len(pubkeys) // self.clen
+        res = C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_eddsa_verify_batch(self.ctx.h, self.h, n, pubkeys, sigs, hram, hram_len, res),
+             "ec_eddsa_verify_batch")
+        return res.raw[:n]

@@ -203,7 +203,7 @@ static const CurveRow g_curve_rows[] = {
 // ------------------------------------------------------------------------------------------
 // objects behind the opaque handles
 // ------------------------------------------------------------------------------------------
-#define ECAMD_NSTAGE 12
+#define ECAMD_NSTAGE 20
 struct ecamd_ctx {
 	int device;
 	hipStream_t stream;
@@ -1417,6 +1417,178 @@ extern "C" int ec_xdh_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, c
 	HIPCHK(ecamd_launch_xdh_fin(nw, Fn, s));
 	HIPCHK(hipMemcpyAsync(out, S[9], n * len, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipMemcpyAsync(status, S[10], n, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Ed25519 verification: eddsa_import_pub_key (sig/eddsa.c:862) + _eddsa_verify_init (:1846) +
+// _eddsa_verify_finalize (:2130) with the hash H(dom || R || A || M) supplied by the caller.
+// ------------------------------------------------------------------------------------------
+static Big big_inv_p(const Big &a, const Big &p) { return big_powmod(a, big_sub(p, Big(1, 2)), p); }
+static Big big_negmod(const Big &a, const Big &p) { return big_mod(big_sub(p, big_mod(a, p)), p); }
+
+// square root for p = 5 mod 8; returns false when n is a non-residue
+static bool big_sqrt_5mod8(const Big &n, const Big &p, Big *out)
+{
+	Big e = big_add(p, Big(1, 3));
+	Big q(e.size(), 0);
+	for (size_t i = 0; i < e.size(); i++) {
+		q[i] = (e[i] >> 3) | ((i + 1 < e.size()) ? (e[i + 1] << 29) : 0u);
+	}
+	big_trim(q);
+	Big c = big_powmod(n, q, p);
+	if (big_cmp(big_mulmod(c, c, p), big_mod(n, p)) != 0) {
+		c = big_mulmod(c, big_sqrt_m1(p), p);
+	}
+	*out = c;
+	return big_cmp(big_mulmod(c, c, p), big_mod(n, p)) == 0;
+}
+
+extern "C" int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys,
+				     const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, uint8_t *result)
+{
+	if (!ctx || !cv || cv->ctx != ctx || (n && (!pubkeys || !sigs || !hram || !result))) {
+		return fail("ec_eddsa_verify_batch: bad argument");
+	}
+	if (!(cv->pbits == 255 && cv->clen == 32 && cv->nw == 8 && cv->qslot >= 0 &&
+	      big_cmp(cv->p, big_sub(big_pow2(255), Big(1, 19))) == 0)) {
+		return fail("ec_eddsa_verify_batch: only Ed25519 (the WEI25519 curve handle) is supported");
+	}
+	if (hram_len != 64) {
+		return fail("ec_eddsa_verify_batch: Ed25519 hashes with SHA-512: hram_len must be 64");
+	}
+	const Big &p = cv->p;
+	const Big one(1, 1), two(1, 2), three(1, 3);
+	const Big A(1, 486662);
+	const Big A3 = big_mulmod(A, big_inv_p(three, p), p);
+	// edwards25519: a = -1, d = -121665/121666; alpha_edwards^2 = -(A + 2) (B = 1 Montgomery model)
+	const Big a_ed = big_sub(p, one);
+	const Big d_ed = big_negmod(big_mulmod(Big(1, 121665), big_inv_p(Big(1, 121666), p), p), p);
+	Big alpha;
+	if (!big_sqrt_5mod8(big_negmod(big_add(A, two), p), p, &alpha)) {
+		return fail("ec_eddsa_verify_batch: internal: alpha");
+	}
+	{
+		// the handle must be the Weierstrass model whose generator is the image of the Ed25519 base
+		// point (y = 4/5, x even); this also fixes the sign of alpha_edwards
+		const Big yb = big_mulmod(Big(1, 4), big_inv_p(Big(1, 5), p), p);
+		const Big y2 = big_mulmod(yb, yb, p);
+		const Big num = big_mod(big_add(one, big_sub(p, y2)), p);
+		const Big den = big_mod(big_add(a_ed, big_sub(p, big_mulmod(d_ed, y2, p))), p);
+		Big xb;
+		if (!big_sqrt_5mod8(big_mulmod(num, big_inv_p(den, p), p), p, &xb)) {
+			return fail("ec_eddsa_verify_batch: internal: base point");
+		}
+		if (xb[0] & 1u) {
+			xb = big_sub(p, xb);
+		}
+		const Big um = big_mulmod(big_mod(big_add(one, yb), p), big_inv_p(big_mod(big_add(one, big_sub(p, yb)), p), p), p);
+		const Big X = big_mod(big_add(um, A3), p);
+		Big vm = big_mulmod(big_mulmod(alpha, um, p), big_inv_p(xb, p), p);
+		if (big_cmp(vm, cv->gy) != 0) {
+			alpha = big_sub(p, alpha);
+			vm = big_sub(p, vm);
+		}
+		if (big_cmp(X, cv->gx) != 0 || big_cmp(vm, cv->gy) != 0) {
+			return fail("ec_eddsa_verify_batch: the curve generator is not the image of the Ed25519 base point");
+		}
+	}
+	uint32_t cof_dbl = 0;
+	{
+		Big t = cv->q;
+		for (uint32_t c = 0; c <= 4; c++) {
+			if (big_cmp(t, cv->order) == 0) {
+				cof_dbl = c;
+				break;
+			}
+			t = big_add(t, t);
+			if (c == 4) {
+				return fail("ec_eddsa_verify_batch: unexpected cofactor");
+			}
+		}
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t len = 32, plen = 64;
+	// stage: 0 pubkeys, 1 sigs, 2 hram, 3 A (Weierstrass), 4 R, 5 flagsA, 6 flagsR, 7 flagsS, 8 S, 9 h,
+	//        10 [8]A, 11 st8, 12 [h]A, 13 sthA, 14 [S]G, 15 stSG, 16 result, 17 cofactor scalar
+	const size_t need[ECAMD_NSTAGE] = {n * len, n * plen, (size_t)n * hram_len, n * plen, n * plen, n, n, n, n * len, n * len,
+					   n * plen, n, n * plen, n, n * plen, n, n, 64};
+	for (int i = 0; i < ECAMD_NSTAGE; i++) {
+		if (ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
+			return -1;
+		}
+	}
+	uint8_t **S = ctx->stage;
+	hipStream_t s = ctx->stream;
+	HIPCHK(hipMemcpyAsync(S[0], pubkeys, n * len, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(S[1], sigs, n * plen, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(S[2], hram, (size_t)n * hram_len, hipMemcpyHostToDevice, s));
+	const uint8_t cofb = (uint8_t)(1u << cof_dbl);
+	HIPCHK(hipMemcpyAsync(S[17], &cofb, 1, hipMemcpyHostToDevice, s));
+	HIPCHK(hipStreamSynchronize(s));  // cofb lives on this stack frame
+	const int nw = cv->nw;
+	const Big R = big_mod(big_pow2(32 * nw), p);
+	EcamdEdDecodeArgs D;
+	memset(&D, 0, sizeof(D));
+	D.n = n;
+	D.len = (uint32_t)len;
+	D.slot = cv->slot;
+	big_store(D.a, nw, big_mulmod(a_ed, R, p));
+	big_store(D.d, nw, big_mulmod(d_ed, R, p));
+	big_store(D.sm1, nw, big_mulmod(big_sqrt_m1(p), R, p));
+	big_store(D.alpha, nw, big_mulmod(alpha, R, p));
+	big_store(D.A3, nw, big_mulmod(A3, R, p));
+	D.enc = S[0];
+	D.estride = (uint32_t)len;
+	D.points = S[3];
+	D.flags = S[5];
+	HIPCHK(ecamd_launch_ed_decode(nw, D, s));
+	D.enc = S[1];
+	D.estride = (uint32_t)plen;
+	D.points = S[4];
+	D.flags = S[6];
+	HIPCHK(ecamd_launch_ed_decode(nw, D, s));
+	EcamdEdScalArgs C;
+	memset(&C, 0, sizeof(C));
+	C.sigs = S[1];
+	C.hram = S[2];
+	C.S_be = S[8];
+	C.h_be = S[9];
+	C.flags = S[7];
+	C.n = n;
+	C.len = (uint32_t)len;
+	C.hlen = hram_len;
+	C.qslot = cv->qslot;
+	HIPCHK(ecamd_launch_ed_scal(nw, C, s));
+	// [8]A (small-order check), [h]A, [S]G
+	if (smul_dev_locked(ctx, cv, n, S[17], 1, S[3], S[10], S[11], s, 0) ||
+	    smul_dev_locked(ctx, cv, n, S[9], (uint32_t)len, S[3], S[12], S[13], s) ||
+	    smul_dev_locked(ctx, cv, n, S[8], (uint32_t)len, nullptr, S[14], S[15], s)) {
+		return -1;
+	}
+	EcamdEdFinArgs F;
+	memset(&F, 0, sizeof(F));
+	F.SG = S[14];
+	F.stSG = S[15];
+	F.hA = S[12];
+	F.sthA = S[13];
+	F.R = S[4];
+	F.flagsA = S[5];
+	F.flagsR = S[6];
+	F.flagsS = S[7];
+	F.st8 = S[11];
+	F.result = S[16];
+	F.n = n;
+	F.clen = (uint32_t)len;
+	F.cof_dbl = cof_dbl;
+	F.slot = cv->slot;
+	HIPCHK(ecamd_launch_ed_fin(nw, F, s));
+	HIPCHK(hipMemcpyAsync(result, S[16], n, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
 	return 0;
 }

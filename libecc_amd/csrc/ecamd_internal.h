@@ -106,6 +106,38 @@ struct EcamdXdhFinArgs {
 hipError_t ecamd_launch_xdh_prep(int nw, const EcamdXdhPrepArgs &a, hipStream_t s);
 hipError_t ecamd_launch_xdh_fin(int nw, const EcamdXdhFinArgs &a, hipStream_t s);
 
+// ---- Ed25519 verification (sig/eddsa.c of the reference) through the Weierstrass model ----
+struct EcamdEdDecodeArgs {
+	const uint8_t *enc;      // n compressed Edwards points: len bytes little-endian y, sign of x in the top bit
+	uint32_t estride;        // bytes between consecutive encodings
+	uint8_t *points;         // out: n x 2*len affine Weierstrass X || Y big-endian
+	uint8_t *flags;          // out: n, 0 ok / 1 the reference's decode / map returns -1
+	uint32_t n, len;
+	uint32_t a[17], d[17], sm1[17], alpha[17], A3[17];  // Edwards a, d; sqrt(-1); alpha_edwards; A/3 (Montgomery form)
+	int slot;
+};
+struct EcamdEdScalArgs {
+	const uint8_t *sigs;     // n x 2*len: R || S
+	const uint8_t *hram;     // n x hlen: H(dom || R || A || M), little-endian integer
+	uint8_t *S_be, *h_be;    // out: n x len big-endian scalars S and h mod q
+	uint8_t *flags;          // out: n, 1 when S >= q
+	uint32_t n, len, hlen;
+	int qslot;
+};
+struct EcamdEdFinArgs {
+	const uint8_t *SG, *stSG;   // [S]G
+	const uint8_t *hA, *sthA;   // [h]A
+	const uint8_t *R;           // decoded R (Weierstrass affine)
+	const uint8_t *flagsA, *flagsR, *flagsS;
+	const uint8_t *st8;         // status of [8]A: must be 0 (finite)
+	uint8_t *result;            // n: 0 accept / 1 reject
+	uint32_t n, clen, cof_dbl;  // cof_dbl = log2(cofactor)
+	int slot;
+};
+hipError_t ecamd_launch_ed_decode(int nw, const EcamdEdDecodeArgs &a, hipStream_t s);
+hipError_t ecamd_launch_ed_scal(int nw, const EcamdEdScalArgs &a, hipStream_t s);
+hipError_t ecamd_launch_ed_fin(int nw, const EcamdEdFinArgs &a, hipStream_t s);
+
 // radix-2^29 Jacobian fast path for every field size (ecamd_g29_kernel.hip)
 int ecamd_g29_supported(int pbits);
 int ecamd_g29_nl(int pbits);

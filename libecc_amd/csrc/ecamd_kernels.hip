@@ -505,6 +505,165 @@ template <int NW> __global__ __launch_bounds__(64) void k_xdh_fin(EcamdXdhFinArg
 }
 
 // ------------------------------------------------------------------------------------------
+// Ed25519 verification (sig/eddsa.c of the reference) through the Weierstrass model WEI25519:
+//   eddsa_decode_point (:424-556): y little-endian with the sign of x in the top bit, y >= p rejected,
+//     x^2 = (1 - y^2) / (a - d y^2) (aff_pt_edwards_x_from_y, curves/aff_pt_edwards.c:816), no root ->
+//     error, the root whose parity is the sign bit, x = 0 with sign 1 rejected;
+//   aff_pt_edwards_to_montgomery (curves/aff_pt_edwards.c:520-614): the neutral (0, 1) is rejected,
+//     (0, -1) dies in fp_inv(0); (u, v) = ((1 + y) / (1 - y), alpha u / x);
+//   aff_pt_montgomery_to_shortw (curves/aff_pt_montgomery.c:445): (X, Y) = (u + A/3, v) for B = 1;
+//   _eddsa_verify_init (:1846-1990): S < q, [8]A != infinity;
+//   _eddsa_verify_finalize (:2130-2290): h = H(R || A || M) little-endian mod q (the caller hashes),
+//     W = [S]G - R - [h]A, accept iff [8]W is the point at infinity.
+// Field exponentiations use the fixed addition chain for p = 2^255 - 19 (z^(2^250 - 1) shared by the
+// inversion exponent p - 2 and the square-root exponent (p - 5) / 8).
+// ------------------------------------------------------------------------------------------
+template <int NW> static __device__ __forceinline__ Fe<NW> fe_sqr_n(Fe<NW> a, int n, int slot)
+{
+	for (int k = 0; k < n; k++) {
+		a = fe_mul<NW>(a, a, slot);
+	}
+	return a;
+}
+
+// z^(2^250 - 1); *z11 = z^11
+template <int NW> static __device__ Fe<NW> fe_pow_2_250m1(const Fe<NW> &z, Fe<NW> *z11, int slot)
+{
+	const Fe<NW> z2 = fe_mul<NW>(z, z, slot);
+	const Fe<NW> z9 = fe_mul<NW>(fe_sqr_n<NW>(z2, 2, slot), z, slot);
+	*z11 = fe_mul<NW>(z9, z2, slot);
+	const Fe<NW> a5 = fe_mul<NW>(fe_mul<NW>(*z11, *z11, slot), z9, slot);             // 2^5 - 1
+	const Fe<NW> a10 = fe_mul<NW>(fe_sqr_n<NW>(a5, 5, slot), a5, slot);               // 2^10 - 1
+	const Fe<NW> a20 = fe_mul<NW>(fe_sqr_n<NW>(a10, 10, slot), a10, slot);            // 2^20 - 1
+	const Fe<NW> a40 = fe_mul<NW>(fe_sqr_n<NW>(a20, 20, slot), a20, slot);            // 2^40 - 1
+	const Fe<NW> a50 = fe_mul<NW>(fe_sqr_n<NW>(a40, 10, slot), a10, slot);            // 2^50 - 1
+	const Fe<NW> a100 = fe_mul<NW>(fe_sqr_n<NW>(a50, 50, slot), a50, slot);           // 2^100 - 1
+	const Fe<NW> a200 = fe_mul<NW>(fe_sqr_n<NW>(a100, 100, slot), a100, slot);        // 2^200 - 1
+	return fe_mul<NW>(fe_sqr_n<NW>(a200, 50, slot), a50, slot);                        // 2^250 - 1
+}
+
+template <int NW> __global__ __launch_bounds__(64) void k_ed_decode(EcamdEdDecodeArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int slot = A.slot;
+	const int len = (int)A.len;
+	Fe<NW> y = fe_load_le<NW>(A.enc + (size_t)i * A.estride, len);
+	const int sbit = 8 * len - 1;
+	const u32 x0 = (y.v[sbit >> 5] >> (sbit & 31)) & 1u;
+	y.v[sbit >> 5] &= ~(1u << (sbit & 31));
+	bool ok = fe_lt_p<NW>(y, slot);
+	const Fe<NW> one = fe_const<NW>(ConstTab<NW>::get(slot).one);
+	const Fe<NW> zero = fe_zero<NW>();
+	const Fe<NW> ym = fe_to_mont<NW>(y, slot);
+	const Fe<NW> y2 = fe_mul<NW>(ym, ym, slot);
+	const Fe<NW> u = fe_sub<NW>(one, y2, slot);                                         // 1 - y^2
+	const Fe<NW> v = fe_sub<NW>(fe_const<NW>(A.a), fe_mul<NW>(fe_const<NW>(A.d), y2, slot), slot);  // a - d y^2
+	// beta = u v^3 (u v^7)^((p - 5) / 8), (p - 5) / 8 = 2^252 - 3
+	const Fe<NW> v3 = fe_mul<NW>(fe_mul<NW>(v, v, slot), v, slot);
+	const Fe<NW> v7 = fe_mul<NW>(fe_mul<NW>(v3, v3, slot), v, slot);
+	const Fe<NW> t = fe_mul<NW>(u, v7, slot);
+	Fe<NW> t11;
+	const Fe<NW> pw = fe_mul<NW>(fe_sqr_n<NW>(fe_pow_2_250m1<NW>(t, &t11, slot), 2, slot), t, slot);
+	const Fe<NW> beta = fe_mul<NW>(fe_mul<NW>(u, v3, slot), pw, slot);
+	const Fe<NW> chk = fe_mul<NW>(v, fe_mul<NW>(beta, beta, slot), slot);
+	const bool root = fe_eq<NW>(chk, u);
+	const bool alt = fe_eq<NW>(chk, fe_sub<NW>(zero, u, slot));
+	ok = ok & (root | alt);
+	Fe<NW> x = fe_select<NW>(alt & !root, fe_mul<NW>(beta, fe_const<NW>(A.sm1), slot), beta);
+	const Fe<NW> xp = fe_from_mont<NW>(x, slot);
+	x = fe_select<NW>((xp.v[0] & 1u) != x0, fe_sub<NW>(zero, x, slot), x);
+	ok = ok & !fe_is_zero<NW>(x);
+	// (1 - y)^-1 and x^-1 from one inversion
+	const Fe<NW> omy = fe_sub<NW>(one, ym, slot);
+	const Fe<NW> den = fe_mul<NW>(omy, x, slot);
+	Fe<NW> d11;
+	const Fe<NW> dinv = fe_mul<NW>(fe_sqr_n<NW>(fe_pow_2_250m1<NW>(den, &d11, slot), 5, slot), d11, slot);  // den^(p-2)
+	const Fe<NW> um = fe_mul<NW>(fe_add<NW>(one, ym, slot), fe_mul<NW>(dinv, x, slot), slot);
+	const Fe<NW> vm = fe_mul<NW>(fe_mul<NW>(fe_const<NW>(A.alpha), um, slot), fe_mul<NW>(dinv, omy, slot), slot);
+	const Fe<NW> X = fe_from_mont<NW>(fe_add<NW>(um, fe_const<NW>(A.A3), slot), slot);
+	const Fe<NW> Y = fe_from_mont<NW>(vm, slot);
+	u8 *pd = A.points + (size_t)i * 2 * len;
+	fe_store_be<NW>(pd, len, ok ? X : zero);
+	fe_store_be<NW>(pd + len, len, ok ? Y : zero);
+	A.flags[i] = ok ? 0 : 1;
+}
+
+// S (second half of the signature, little-endian) must be < q; h = hram (little-endian, up to 2 NW words) mod q
+template <int NW> __global__ __launch_bounds__(64) void k_ed_scal(EcamdEdScalArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int qs = A.qslot;
+	const int len = (int)A.len, hlen = (int)A.hlen;
+	const CurveK<NW> &Q = ConstTab<NW>::get(qs);
+	const Fe<NW> S = fe_load_le<NW>(A.sigs + (size_t)i * 2 * len + len, len);
+	const bool ok = fe_lt_p<NW>(S, qs);
+	const u8 *hp = A.hram + (size_t)i * hlen;
+	const int lo_len = hlen < 4 * NW ? hlen : 4 * NW;
+	const Fe<NW> lo = fe_load_le<NW>(hp, lo_len);
+	const Fe<NW> hi = fe_load_le<NW>(hp + lo_len, hlen - lo_len);
+	const Fe<NW> r2 = fe_const<NW>(Q.r2);
+	Fe<NW> onep = fe_zero<NW>();
+	onep.v[0] = 1u;
+	// Montgomery products with R = 2^(32 NW): hi R2 / R = hi 2^(32 NW), (lo R2 / R) * 1 / R = lo  (mod q)
+	const Fe<NW> hiR = fe_mul<NW>(hi, r2, qs);
+	const Fe<NW> lor = fe_mul<NW>(fe_mul<NW>(lo, r2, qs), onep, qs);
+	const Fe<NW> h = fe_add<NW>(hiR, lor, qs);
+	fe_store_be<NW>(A.S_be + (size_t)i * len, len, ok ? S : fe_zero<NW>());
+	fe_store_be<NW>(A.h_be + (size_t)i * len, len, h);
+	A.flags[i] = ok ? 0 : 1;
+}
+
+template <int NW> static __device__ __forceinline__ Pt<NW> ed_load_neg(const u8 *src, u32 st, int clen, bool neg, int slot)
+{
+	Pt<NW> P;
+	if (st == 2) {
+		return pt_infinity<NW>(slot);
+	}
+	P.X = fe_to_mont<NW>(fe_load_be<NW>(src, clen), slot);
+	P.Y = fe_to_mont<NW>(fe_load_be<NW>(src + clen, clen), slot);
+	if (neg) {
+		P.Y = fe_sub<NW>(fe_zero<NW>(), P.Y, slot);
+	}
+	P.Z = fe_const<NW>(ConstTab<NW>::get(slot).one);
+	return P;
+}
+
+template <int NW> __global__ __launch_bounds__(64) void k_ed_fin(EcamdEdFinArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int slot = A.slot;
+	const int clen = (int)A.clen;
+	const u32 sSG = A.stSG[i], shA = A.sthA[i];
+	// bad encodings, S >= q, small-order public key ([8]A = infinity), or a failed multiplication
+	if (A.flagsA[i] || A.flagsR[i] || A.flagsS[i] || A.st8[i] != 0 || sSG == 1 || shA == 1) {
+		A.result[i] = 1;
+		return;
+	}
+	Pt<NW> W = ed_load_neg<NW>(A.SG + (size_t)i * 2 * clen, sSG, clen, false, slot);
+	const Pt<NW> Rn = ed_load_neg<NW>(A.R + (size_t)i * 2 * clen, 0, clen, true, slot);
+	const Pt<NW> Hn = ed_load_neg<NW>(A.hA + (size_t)i * 2 * clen, shA, clen, true, slot);
+	// prj_pt_add returns -1 on an exceptional pair (curves/prj_pt.c:1058-1060): the signature is rejected
+	W = pt_add<NW>(W, Rn, slot);
+	bool bad = fe_is_zero<NW>(W.Z) & fe_is_zero<NW>(W.Y);
+	W = pt_add<NW>(W, Hn, slot);
+	bad = bad | (fe_is_zero<NW>(W.Z) & fe_is_zero<NW>(W.Y));
+	// _prj_pt_unprotected_mult by the cofactor 8 = 1000b: three doublings (curves/prj_pt.c:1862-1905)
+	for (u32 k = 0; k < A.cof_dbl; k++) {
+		W = pt_dbl<NW>(W, slot);
+	}
+	A.result[i] = (!bad && fe_is_zero<NW>(W.Z)) ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side dispatch on the word count
 // ------------------------------------------------------------------------------------------
 #define ECAMD_FOR_NW(X) X(6) X(7) X(8) X(10) X(12) X(14) X(16) X(17)
@@ -658,5 +817,41 @@ hipError_t ecamd_launch_pt(int nw, const EcamdPtArgs &a, hipStream_t s)
 #undef X
 	default: return hipErrorInvalidValue;
 	}
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_ed_decode(int nw, const EcamdEdDecodeArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	if (nw != 8) {
+		return hipErrorInvalidValue;
+	}
+	hipLaunchKernelGGL(k_ed_decode<8>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_ed_scal(int nw, const EcamdEdScalArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	if (nw != 8) {
+		return hipErrorInvalidValue;
+	}
+	hipLaunchKernelGGL(k_ed_scal<8>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_ed_fin(int nw, const EcamdEdFinArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	if (nw != 8) {
+		return hipErrorInvalidValue;
+	}
+	hipLaunchKernelGGL(k_ed_fin<8>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
 	return hipGetLastError();
 }

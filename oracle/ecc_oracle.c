@@ -823,20 +823,35 @@ static int import_rs(u64 *r, u64 *s, const u8 *sig, const orc_curve *c)
 }
 
 /* check_prj_pt_order (curves/prj_pt.c:1909): [q]P == infinity, plain double-and-add
- * (_prj_pt_unprotected_mult :1835-1880, MSB first with prj_pt_dbl / prj_pt_add). */
+ * (__prj_pt_unprotected_mult :1835-1880): input on the curve, scalar 0 -> infinity, otherwise
+ * out = P, then for every bit below the top one prj_pt_dbl and, if set, prj_pt_add; the result must
+ * be on the curve.  (Starting from P rather than from infinity matters on even-order curves, where
+ * adding a point of order 2 to infinity is an exceptional pair of the complete formulas.) */
 static int pt_unprotected_mult(pt *out, const u64 *m, int mn, const pt *in, const orc_curve *c)
 {
 	pt R;
-	int bits = nn_bitlen(m, mn), i, ret = 0;
-	pt_zero(&R, c);
-	for (i = bits - 1; i >= 0; i--) {
-		ret |= pt_dbl(&R, &R, c);
-		if (nn_getbit(m, i)) {
-			ret |= pt_add(&R, &R, in, c);
+	int bits = nn_bitlen(m, mn), i;
+	if (!pt_is_on_curve(in, c)) {
+		return -1;
+	}
+	if (bits == 0) {
+		pt_zero(out, c);
+		return 0;
+	}
+	R = *in;
+	for (i = bits - 2; i >= 0; i--) {
+		if (pt_dbl(&R, &R, c)) {
+			return -1;
+		}
+		if (nn_getbit(m, i) && pt_add(&R, &R, in, c)) {
+			return -1;
 		}
 	}
+	if (!pt_is_on_curve(&R, c)) {
+		return -1;
+	}
 	*out = R;
-	return ret ? -1 : 0;
+	return 0;
 }
 
 /* ec_pub_key_import_from_aff_buf (sig/ec_key.c:181-214): subgroup check iff cofactor != 1 */
@@ -1116,6 +1131,155 @@ int orc_xdh_batch(const orc_curve *c, uint32_t len, uint32_t n, const uint8_t *k
 		nn_to_be(ub, (int)len, t, f->n);
 		for (b = 0; b < len; b++) out[(size_t)i * len + b] = ub[len - 1 - b];
 		status[i] = 0;
+	}
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Ed25519 verification on the Weierstrass model WEI25519 (sig/eddsa.c), hash supplied by the caller.
+ *   eddsa_import_pub_key (:862-950) / _eddsa_verify_init (:1846-1990):
+ *     eddsa_decode_point (:424-556): y little-endian, bit 255 = sign of x, y >= p rejected
+ *       (fp_init_from_buf), x^2 = (1 - y^2) / (a - d y^2) (aff_pt_edwards_x_from_y,
+ *       curves/aff_pt_edwards.c:816-850), fp_sqrt error when there is no root, root with lsb == sign,
+ *       (x == 0 && sign == 1) rejected;
+ *     aff_pt_edwards_to_montgomery (curves/aff_pt_edwards.c:520-614): (0, 1) rejected, fp_inv(0) = -1
+ *       rejects (0, -1); u = (1 + y) / (1 - y), v = alpha_edwards u / x;
+ *     aff_pt_montgomery_to_shortw (curves/aff_pt_montgomery.c:445-490): X = u / B + A / (3 B), Y = v / B
+ *       with B = 1;
+ *     S < q (:1960-1962); [cofactor]A != infinity (:1966-1969);
+ *   _eddsa_verify_finalize (:2130-2290): h = hash little-endian mod q (eddsa_decode_integer :229),
+ *     [S]G - R - [h]A, times the cofactor with _prj_pt_unprotected_mult, must be infinity.
+ * alpha_edwards comes from the curve parameters in the reference; here it is the square root of
+ * -(A + 2) under which the Ed25519 base point (y = 4/5, x even) maps to the generator of the curve.
+ * ---------------------------------------------------------------------------------- */
+typedef struct { u64 d[ORC_MAXW], alpha[ORC_MAXW], A3[ORC_MAXW], am[ORC_MAXW]; } ed_consts;
+
+static int ed_decode_to_shortw(pt *out, const u8 *enc, const orc_curve *c, const ed_consts *k)
+{
+	const orc_fp_ctx *f = &c->fp;
+	u64 y[ORC_MAXW], one[ORC_MAXW], zero[ORC_MAXW], x1[ORC_MAXW], x2[ORC_MAXW], t[ORC_MAXW], s1[ORC_MAXW],
+	    s2[ORC_MAXW], x[ORC_MAXW], u[ORC_MAXW], v[ORC_MAXW];
+	u8 be[32];
+	const int n = f->n;
+	const int x0 = enc[31] >> 7;
+	int b;
+	for (b = 0; b < 32; b++) be[b] = enc[31 - b];
+	be[0] &= 0x7f;
+	if (fp_from_be(y, be, 32, f)) return -1;
+	nn_zero(one, n); one[0] = 1;
+	nn_zero(zero, n);
+	fp_mul(x1, y, y, f);
+	fp_sub(x1, one, x1, f);
+	fp_mul(x2, y, k->d, f);
+	fp_mul(x2, x2, y, f);
+	fp_sub(x2, k->am, x2, f);
+	if (nn_iszero(x2, n)) return -1;            /* fp_inv(0) */
+	fp_pow_pm2(x2, x2, f);
+	fp_mul(t, x1, x2, f);
+	if (nn_iszero(t, n)) nn_zero(s1, n);
+	else if (fp_sqrt_exp(s1, t, f)) return -1;  /* not a square */
+	fp_sub(s2, zero, s1, f);
+	nn_copy(x, ((int)(s1[0] & 1) == x0) ? s1 : s2, n);
+	if (nn_iszero(x, n) && x0 == 1) return -1;
+	if (nn_iszero(x, n)) return -1;             /* (0, 1) rejected; (0, -1): fp_inv(x) fails */
+	fp_sub(t, one, y, f);
+	fp_pow_pm2(t, t, f);
+	fp_add(u, one, y, f);
+	fp_mul(u, t, u, f);
+	fp_pow_pm2(v, x, f);
+	fp_mul(v, v, k->alpha, f);
+	fp_mul(v, u, v, f);
+	fp_add(out->X, u, k->A3, f);
+	nn_copy(out->Y, v, n);
+	nn_zero(out->Z, n); out->Z[0] = 1;
+	return pt_is_on_curve(out, c) ? 0 : -1;
+}
+
+static int ed_consts_init(ed_consts *k, const orc_curve *c)
+{
+	const orc_fp_ctx *f = &c->fp;
+	const int n = f->n;
+	u64 t[ORC_MAXW], t2[ORC_MAXW], zero[ORC_MAXW], one[ORC_MAXW], enc_y[ORC_MAXW];
+	u8 base[32];
+	pt B;
+	int b;
+	nn_zero(zero, n);
+	nn_zero(one, n); one[0] = 1;
+	fp_sub(k->am, zero, one, f);                 /* a = -1 */
+	nn_zero(t, n); t[0] = 121666;
+	fp_pow_pm2(t, t, f);
+	nn_zero(t2, n); t2[0] = 121665;
+	fp_mul(t, t, t2, f);
+	fp_sub(k->d, zero, t, f);                    /* d = -121665/121666 */
+	nn_zero(t, n); t[0] = 3;
+	fp_pow_pm2(t, t, f);
+	nn_zero(t2, n); t2[0] = 486662;
+	fp_mul(k->A3, t, t2, f);
+	nn_zero(t, n); t[0] = 486664;
+	fp_sub(t, zero, t, f);
+	if (fp_sqrt_exp(k->alpha, t, f)) return -1;
+	/* base point: y = 4/5, sign bit 0 */
+	nn_zero(t, n); t[0] = 5;
+	fp_pow_pm2(t, t, f);
+	nn_zero(t2, n); t2[0] = 4;
+	fp_mul(enc_y, t, t2, f);
+	nn_to_be(base, 32, enc_y, n);
+	for (b = 0; b < 16; b++) { u8 s = base[b]; base[b] = base[31 - b]; base[31 - b] = s; }
+	if (ed_decode_to_shortw(&B, base, c, k)) return -1;
+	if (nn_cmp(B.Y, c->gy, n) != 0) {
+		fp_sub(k->alpha, zero, k->alpha, f);
+		if (ed_decode_to_shortw(&B, base, c, k)) return -1;
+	}
+	return (nn_cmp(B.X, c->gx, n) == 0 && nn_cmp(B.Y, c->gy, n) == 0) ? 0 : -1;
+}
+
+/* pubs n x 32, sigs n x 64 (R || S), hram n x hlen (hlen <= 64) = H(dom2 || R || A || PH(M));
+ * result 0 accept / 1 reject */
+int orc_eddsa25519_verify_batch(const orc_curve *c, uint32_t n, const uint8_t *pubs, const uint8_t *sigs,
+				const uint8_t *hram, uint32_t hlen, uint8_t *result)
+{
+	const orc_fp_ctx *f = &c->fp;
+	ed_consts k;
+	u64 cof[ORC_MAXW], t2[2 * ORC_MAXW], zero[ORC_MAXW];
+	pt G;
+	uint32_t i;
+	int hv, found = 0;
+	if (f->pbits != 255 || hlen > 64 || ed_consts_init(&k, c)) return -1;
+	for (hv = 1; hv <= 16 && !found; hv++) {
+		nn_zero(cof, ORC_MAXW); cof[0] = (u64)hv;
+		nn_mul(t2, c->q, c->q_n, cof, 1);
+		if (nn_cmp(t2, c->order, c->q_n + 1) == 0) found = 1;
+	}
+	if (!found) return -1;
+	nn_zero(zero, f->n);
+	load_gen(&G, c);
+	for (i = 0; i < n; i++) {
+		pt A, R, T1, T2;
+		u64 S[ORC_MAXW], h[ORC_MAXW], hw[ORC_MAXW];
+		u8 be[64];
+		uint32_t b;
+		result[i] = 1;
+		if (ed_decode_to_shortw(&A, pubs + (size_t)i * 32, c, &k)) continue;
+		if (ed_decode_to_shortw(&R, sigs + (size_t)i * 64, c, &k)) continue;
+		for (b = 0; b < 32; b++) be[b] = sigs[(size_t)i * 64 + 63 - b];
+		nn_zero(S, ORC_MAXW);
+		nn_from_be(S, c->q_n, be, 32);
+		if (nn_cmp(S, c->q, c->q_n) >= 0) continue;
+		if (pt_unprotected_mult(&T1, cof, 1, &A, c)) continue;
+		if (nn_iszero(T1.Z, f->n)) continue;
+		for (b = 0; b < hlen; b++) be[b] = hram[(size_t)i * hlen + hlen - 1 - b];
+		nn_zero(hw, ORC_MAXW);
+		nn_from_be(hw, 8, be, (int)hlen);
+		nn_zero(h, ORC_MAXW);
+		nn_mod(h, hw, 8, c->q, c->q_n);
+		if (pt_mul(&T1, S, c->q_n, &G, c)) continue;
+		fp_sub(R.Y, zero, R.Y, f);
+		if (pt_add(&T1, &T1, &R, c)) continue;
+		if (pt_mul(&T2, h, c->q_n, &A, c)) continue;
+		fp_sub(T2.Y, zero, T2.Y, f);
+		if (pt_add(&T1, &T1, &T2, c)) continue;
+		if (pt_unprotected_mult(&T2, cof, 1, &T1, c)) continue;
+		result[i] = nn_iszero(T2.Z, f->n) ? 0 : 1;
 	}
 	return 0;
 }

@@ -51,4 +51,6 @@ int orc_ecccdh_batch(const orc_curve *c, uint32_t n, const uint8_t *privs, const
 		     uint8_t *secrets, uint8_t *status);
 int orc_xdh_batch(const orc_curve *c, uint32_t len, uint32_t n, const uint8_t *k, const uint8_t *u,
 		  uint8_t *out, uint8_t *status);
+int orc_eddsa25519_verify_batch(const orc_curve *c, uint32_t n, const uint8_t *pubs, const uint8_t *sigs,
+				const uint8_t *hram, uint32_t hlen, uint8_t *result);
 #endif

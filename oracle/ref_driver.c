@@ -474,3 +474,56 @@ int refdrv_xdh_batch(uint32_t len, uint32_t n, const uint8_t *k, const uint8_t *
 	}
 	return 0;
 }
+
+/* ---- Ed25519 through the protocol API (sig/eddsa.c) ---- */
+/* keys from 32-byte seeds, signatures over msgs; pubs: n x 32 (RFC 8032 encoding), sigs: n x 64 */
+int refdrv_eddsa25519_sign_batch(uint32_t n, const uint8_t *seeds, const uint8_t *msgs, uint32_t msg_len,
+				 uint8_t *pubs, uint8_t *sigs, uint8_t *status)
+{
+	ec_params params;
+	uint32_t i;
+	if (load_params("WEI25519", &params)) {
+		return -1;
+	}
+	for (i = 0; i < n; i++) {
+		ec_key_pair kp;
+		int ret;
+		status[i] = 1;
+		ret = eddsa_import_key_pair_from_priv_key_buf(&kp, seeds + (size_t)i * 32, 32, &params, EDDSA25519);
+		if (ret) {
+			continue;
+		}
+		ret = eddsa_export_pub_key(&kp.pub_key, pubs + (size_t)i * 32, 32);
+		if (ret) {
+			continue;
+		}
+		ret = ec_sign(sigs + (size_t)i * 64, 64, &kp, msgs + (size_t)i * msg_len, msg_len, EDDSA25519,
+			      SHA512, NULL, 0);
+		status[i] = ret ? 1 : 0;
+	}
+	return 0;
+}
+
+/* result[i] = 0 accept, 1 reject (eddsa_import_pub_key or ec_verify returned -1) */
+int refdrv_eddsa25519_verify_batch(uint32_t n, const uint8_t *pubs, const uint8_t *sigs, const uint8_t *msgs,
+				   uint32_t msg_len, uint8_t *result)
+{
+	ec_params params;
+	uint32_t i;
+	if (load_params("WEI25519", &params)) {
+		return -1;
+	}
+	for (i = 0; i < n; i++) {
+		ec_pub_key pub;
+		int ret;
+		result[i] = 1;
+		ret = eddsa_import_pub_key(&pub, pubs + (size_t)i * 32, 32, &params, EDDSA25519);
+		if (ret) {
+			continue;
+		}
+		ret = ec_verify(sigs + (size_t)i * 64, 64, &pub, msgs + (size_t)i * msg_len, msg_len, EDDSA25519,
+				SHA512, NULL, 0);
+		result[i] = ret ? 1 : 0;
+	}
+	return 0;
+}

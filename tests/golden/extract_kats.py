@@ -10,7 +10,8 @@ Sources (data only -- byte arrays and the record fields that bind them):
   src/tests/decdsa_test_vectors.h   RFC 6979 deterministic ECDSA
   src/tests/ec_self_tests_core.h    fixed-k ECDSA (RFC 4754 style nonce callbacks), record :22-52
   src/tests/x25519_test_vectors.h, x448_test_vectors.h   RFC 7748 vectors
-Writes tests/golden/ecccdh_kats.json, ecdsa_kats.json and xdh_kats.json.
+  src/tests/ed25519ctx_test_vectors.h, ed25519ph_test_vectors.h   RFC 8032 vectors
+Writes tests/golden/ecccdh_kats.json, ecdsa_kats.json, xdh_kats.json and eddsa_kats.json.
 """
 import json, os, re, sys
 
@@ -115,6 +116,28 @@ def main():
                             our_priv_key=arrays[f["our_priv_key"]].hex(), peer_pub_key=arrays[f["peer_pub_key"]].hex(),
                             exp_our_pub_key=arrays[f["exp_our_pub_key"]].hex(),
                             exp_shared_secret=arrays[f["exp_shared_secret"]].hex()))
+    # RFC 8032 Ed25519ctx / Ed25519ph vectors (the snapshot's ed25519_test_vectors.h is absent).  The
+    # records hold only the private seed; the public key is exported by the reference itself
+    # (oracle/_ref, eddsa_import_key_pair_from_priv_key_buf + eddsa_export_pub_key).
+    import ctypes
+    ref = ctypes.CDLL(os.path.join(HERE, "..", "..", "oracle", "_ref", "libecc_ref.so"))
+    eddsa = []
+    for fn in ("ed25519ctx_test_vectors.h", "ed25519ph_test_vectors.h"):
+        arrays, nonces, cases = load(os.path.join(REF, fn))
+        for kind, name, f in cases:
+            if kind != "ec_test_case" or f.get("sig_type") not in ("EDDSA25519CTX", "EDDSA25519PH"):
+                continue
+            msgb = arrays[re.sub(r"^\(const char \*\)\s*", "", f["msg"])]
+            seed = arrays[f["priv_key"]]
+            ad = f.get("adata", "NULL")
+            pub, sig, st = ctypes.create_string_buffer(32), ctypes.create_string_buffer(64), ctypes.create_string_buffer(1)
+            assert ref.refdrv_eddsa25519_sign_batch(1, seed, b"", 0, pub, sig, st) == 0 and st.raw == b"\0"
+            eddsa.append(dict(name=c_string(f["name"]).decode(), sig_type=f["sig_type"], priv_key=seed.hex(),
+                              pub_key=pub.raw.hex(), msg=msgb.hex(),
+                              adata=(arrays[ad].hex() if ad != "NULL" else ""),
+                              exp_sig=arrays[f["exp_sig"]].hex(), source=fn))
+    json.dump(eddsa, open(os.path.join(HERE, "eddsa_kats.json"), "w"), indent=1)
+    print("EDDSA :", [(c["sig_type"], c["name"]) for c in eddsa])
     json.dump(xdh, open(os.path.join(HERE, "xdh_kats.json"), "w"), indent=1)
     print("XDH   :", [(c["kind"], c["name"]) for c in xdh])
     json.dump(ecdh, open(os.path.join(HERE, "ecccdh_kats.json"), "w"), indent=1)

@@ -119,6 +119,13 @@ class Oracle:
         assert self.L.orc_xdh_batch(self.ctx, self.clen, n, k, u, out, st) == 0
         return out.raw, st.raw
 
+    def eddsa_verify(self, pubs, sigs, hram, hlen=64):
+        """Ed25519 on the WEI25519 curve; hram = SHA-512(dom2 || R || A || PH(M)) per item"""
+        n = len(pubs) // 32
+        res = C.create_string_buffer(max(1, n))
+        assert self.L.orc_eddsa25519_verify_batch(self.ctx, n, pubs, sigs, hram, hlen, res) == 0
+        return res.raw[:n]
+
 
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libecc_ref.so")
 HASH_IDS = {"SHA224": 1, "SHA256": 2, "SHA384": 3, "SHA512": 4, "SHA3_224": 5, "SHA3_256": 6,
@@ -205,6 +212,23 @@ def ref_xdh(length, k, u):
     return out.raw, st.raw
 
 
+def ref_ed25519_sign(seeds, msgs, msg_len):
+    """keys from 32-byte seeds and pure-Ed25519 signatures by the unmodified reference"""
+    L = C.CDLL(REF_SO)
+    n = len(seeds) // 32
+    pubs, sigs, st = C.create_string_buffer(32 * n), C.create_string_buffer(64 * n), C.create_string_buffer(n)
+    assert L.refdrv_eddsa25519_sign_batch(n, seeds, msgs, msg_len, pubs, sigs, st) == 0
+    return pubs.raw, sigs.raw, st.raw
+
+
+def ref_ed25519_verify(pubs, sigs, msgs, msg_len):
+    L = C.CDLL(REF_SO)
+    n = len(pubs) // 32
+    res = C.create_string_buffer(max(1, n))
+    assert L.refdrv_eddsa25519_verify_batch(n, pubs, sigs, msgs, msg_len, res) == 0
+    return res.raw[:n]
+
+
 def digest(hash_name, msg):
     return hashlib.new(HASHLIB[hash_name], msg).digest()
 
@@ -281,3 +305,93 @@ def rand_points(curve, rng, n):
     pts, st = o.scalar_mult(sc)
     assert set(st) == {0}
     return pts
+
+
+def ed25519_hram(pubs, sigs, msgs, msg_len):
+    """SHA-512(R || A || M) per item (pure Ed25519: empty dom2), the hash the batch verifiers take"""
+    import hashlib
+    n = len(pubs) // 32
+    out = bytearray()
+    for i in range(n):
+        out += hashlib.sha512(sigs[64 * i:64 * i + 32] + pubs[32 * i:32 * i + 32] +
+                              msgs[msg_len * i:msg_len * (i + 1)]).digest()
+    return bytes(out)
+
+
+# ---- a small RFC 8032 Ed25519 signer (test input generator; python ints, extended coordinates) ----
+ED_P = 2**255 - 19
+ED_Q = 2**252 + 27742317777372353535851937790883648493
+ED_D = (-121665 * pow(121666, ED_P - 2, ED_P)) % ED_P
+ED_I = pow(2, (ED_P - 1) // 4, ED_P)
+
+
+def ed_add(P, Q):
+    x1, y1, z1, t1 = P
+    x2, y2, z2, t2 = Q
+    a = (y1 - x1) * (y2 - x2) % ED_P
+    b = (y1 + x1) * (y2 + x2) % ED_P
+    c = 2 * t1 * t2 * ED_D % ED_P
+    d = 2 * z1 * z2 % ED_P
+    e, f, g, h = b - a, d - c, d + c, b + a
+    return (e * f % ED_P, g * h % ED_P, f * g % ED_P, e * h % ED_P)
+
+
+def ed_mul(k, P):
+    R = (0, 1, 1, 0)
+    while k:
+        if k & 1:
+            R = ed_add(R, P)
+        P = ed_add(P, P)
+        k >>= 1
+    return R
+
+
+def ed_encode(P):
+    zi = pow(P[2], ED_P - 2, ED_P)
+    x, y = P[0] * zi % ED_P, P[1] * zi % ED_P
+    return (y | ((x & 1) << 255)).to_bytes(32, "little")
+
+
+def ed_decode(b):
+    y = int.from_bytes(b, "little")
+    sign, y = y >> 255, y & ((1 << 255) - 1)
+    if y >= ED_P:
+        return None
+    x2 = (y * y - 1) * pow(ED_D * y * y + 1, ED_P - 2, ED_P) % ED_P
+    x = pow(x2, (ED_P + 3) // 8, ED_P)
+    if (x * x - x2) % ED_P:
+        x = x * ED_I % ED_P
+    if (x * x - x2) % ED_P or (x == 0 and sign):
+        return None
+    if (x & 1) != sign:
+        x = ED_P - x
+    return (x, y, 1, x * y % ED_P)
+
+
+ED_B = ed_decode((4 * pow(5, ED_P - 2, ED_P) % ED_P).to_bytes(32, "little"))
+ED_TORSION8 = bytes.fromhex("26e8958fc2b227b045c3f489f2ef98f0d5dfac05d3c63339b13802886d53fc05")
+
+
+def ed_dom2(flag, ctx):
+    return b"SigEd25519 no Ed25519 collisions" + bytes([flag, len(ctx)]) + ctx
+
+
+def ed25519_sign(seed, msg, dom=b"", prehash=False, add_R=None, add_A=None):
+    """RFC 8032 5.1.6; add_R / add_A (points) shift R or the public key by a torsion point, giving
+    signatures that only the cofactored verification equation accepts.  Returns (A, R || S, hram)."""
+    hk = hashlib.sha512(seed).digest()
+    a = int.from_bytes(hk[:32], "little")
+    a = (a & ((1 << 254) - 8)) | (1 << 254)
+    m = hashlib.sha512(msg).digest() if prehash else msg
+    A = ed_mul(a, ED_B)
+    if add_A is not None:
+        A = ed_add(A, add_A)
+    Aenc = ed_encode(A)
+    r = int.from_bytes(hashlib.sha512(dom + hk[32:] + m).digest(), "little") % ED_Q
+    R = ed_mul(r, ED_B)
+    if add_R is not None:
+        R = ed_add(R, add_R)
+    Renc = ed_encode(R)
+    hram = hashlib.sha512(dom + Renc + Aenc + m).digest()
+    S = (r + int.from_bytes(hram, "little") * a) % ED_Q
+    return Aenc, Renc + S.to_bytes(32, "little"), hram

@@ -599,3 +599,44 @@ def test_ecdsa_verify_exceptional_pairs(gpu_ctx):
         assert exp == bytes([0, 0, 1] * 5)
     finally:
         cv.free()
+
+
+def test_eddsa25519_verify_vs_oracle_and_golden(gpu_ctx):
+    """Ed25519 batch verification: the reference's RFC 8032 Ed25519ctx / Ed25519ph vectors, then valid,
+    torsion-shifted (accepted only by libecc's cofactored equation) and every class of rejected input
+    against the oracle; finally a large tiled batch with corruptions at known positions"""
+    from test_oracle import KAT_EDDSA, ed25519_cases, eddsa_kat_inputs
+    rng = np.random.default_rng(34)
+    cv = gpu_ctx.curve("WEI25519")
+    o = Oracle("WEI25519")
+    try:
+        pubs, sigs, hram = eddsa_kat_inputs()
+        assert cv.eddsa_verify(pubs, sigs, hram) == bytes(len(KAT_EDDSA))
+        bad = bytearray(sigs)
+        bad[64 + 3] ^= 1
+        assert cv.eddsa_verify(pubs, bytes(bad), hram) == bytes([0, 1, 0, 0, 0])
+        pubs, sigs, msgs, hram = ed25519_cases(rng, nvalid=40)
+        exp = o.eddsa_verify(pubs, sigs, hram)
+        assert 0 in exp and 1 in exp and exp[:52] == bytes(52)
+        assert cv.eddsa_verify(pubs, sigs, hram) == exp
+        assert cv.eddsa_verify(b"", b"", b"") == b""
+        # 2^15 items: the cases tiled, with extra corruption of the hash at every 97th item
+        n0 = len(exp)
+        reps = (1 << 15) // n0 + 1
+        P, S, H = pubs * reps, sigs * reps, bytearray(hram * reps)
+        want = bytearray(exp * reps)
+        for i in range(0, n0 * reps, 97):
+            H[64 * i + 9] ^= 0x20
+            want[i] = 1
+        assert cv.eddsa_verify(P, S, bytes(H)) == bytes(want)
+    finally:
+        cv.free()
+
+
+def test_eddsa_verify_rejects_other_curves(gpu_ctx):
+    cv = gpu_ctx.curve("SECP256R1")
+    try:
+        with pytest.raises(Exception):
+            cv.eddsa_verify(bytes(32), bytes(64), bytes(64))
+    finally:
+        cv.free()

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from oracles import (CURVES, GOLDEN, Oracle, RefLib, digest, have_ref, py_smul_bytes, ref_xdh, rfc6979_nonce)
+import oracles as O
 
 KAT_CDH = json.load(open(os.path.join(GOLDEN, "ecccdh_kats.json")))
 KAT_DSA = json.load(open(os.path.join(GOLDEN, "ecdsa_kats.json")))
@@ -184,3 +185,114 @@ def test_xdh_kats_and_reference(kind, curve, ln):
         ek, eu = xdh_edge_inputs(ln, rng)
         a, b = o.xdh(ek, eu), ref_xdh(ln, ek, eu)
         assert a == b and 0 in a[1] and 1 in a[1]
+
+
+KAT_EDDSA = json.load(open(os.path.join(GOLDEN, "eddsa_kats.json")))
+ED_MSG_LEN = 24
+
+
+def eddsa_kat_inputs():
+    """(pubs, sigs, hram) of the reference's RFC 8032 Ed25519ctx / Ed25519ph vectors; the hash input is
+    dom2(flag, context) || R || A || PH(M) (sig/eddsa.c dom2 :322-360)"""
+    import hashlib
+    pubs, sigs, hram = b"", b"", b""
+    for k in KAT_EDDSA:
+        ph = k["sig_type"] == "EDDSA25519PH"
+        msg, sig, pub = bytes.fromhex(k["msg"]), bytes.fromhex(k["exp_sig"]), bytes.fromhex(k["pub_key"])
+        m = hashlib.sha512(msg).digest() if ph else msg
+        hram += hashlib.sha512(O.ed_dom2(1 if ph else 0, bytes.fromhex(k["adata"])) + sig[:32] + pub + m).digest()
+        pubs += pub
+        sigs += sig
+    return pubs, sigs, hram
+
+
+def ed25519_cases(rng, nvalid=12):
+    """valid signatures, every rejection class of the reference, and torsion-shifted signatures that
+    only a cofactored check accepts.  Returns (pubs, sigs, msgs, hram); messages are ED_MSG_LEN bytes."""
+    import hashlib
+    P, Q = O.ED_P, O.ED_Q
+    t8 = O.ed_decode(O.ED_TORSION8)
+    t4, t2 = O.ed_mul(2, t8), O.ed_mul(4, t8)
+    items = []
+
+    def signed(**kw):
+        seed, msg = rb(rng, 32), rb(rng, ED_MSG_LEN)
+        a, sg, _ = O.ed25519_sign(seed, msg, **kw)
+        return [bytearray(a), bytearray(sg), bytearray(msg)]
+
+    for _ in range(nvalid):
+        items.append(signed())
+    for tp in (t8, t4, t2, O.ed_mul(3, t8)):
+        items.append(signed(add_R=tp))           # accepted: [8] kills the torsion part of R
+        items.append(signed(add_A=tp))           # accepted: mixed-order public key
+        items.append(signed(add_R=tp, add_A=t8))
+    def mod(fn):
+        it = signed()
+        fn(it)
+        items.append(it)
+    mod(lambda it: it[1].__setitem__(5, it[1][5] ^ 1))          # R changed
+    mod(lambda it: it[1].__setitem__(40, it[1][40] ^ 1))        # S changed
+    mod(lambda it: it[2].__setitem__(0, it[2][0] ^ 1))          # message changed
+    mod(lambda it: it[0].__setitem__(2, it[0][2] ^ 4))          # A changed
+    mod(lambda it: it[1].__setitem__(slice(32, 64), (int.from_bytes(it[1][32:], "little") + Q).to_bytes(32, "little")))  # S + q
+    mod(lambda it: it[1].__setitem__(slice(32, 64), Q.to_bytes(32, "little")))       # S = q
+    mod(lambda it: it[1].__setitem__(slice(32, 64), (Q - 1).to_bytes(32, "little")))
+    mod(lambda it: it[1].__setitem__(slice(32, 64), bytes(32)))                      # S = 0
+    mod(lambda it: it[0].__setitem__(slice(0, 32), (1).to_bytes(32, "little")))      # A neutral
+    mod(lambda it: it[1].__setitem__(slice(0, 32), (1).to_bytes(32, "little")))      # R neutral
+    mod(lambda it: it[1].__setitem__(slice(0, 32), (P - 1).to_bytes(32, "little")))  # R = (0, -1)
+    mod(lambda it: it[0].__setitem__(slice(0, 32), (P - 1).to_bytes(32, "little")))  # A = (0, -1)
+    mod(lambda it: it[1].__setitem__(slice(0, 32), (P + 3).to_bytes(32, "little")))  # non-canonical y
+    mod(lambda it: it[0].__setitem__(slice(0, 32), (P + 3).to_bytes(32, "little")))
+    mod(lambda it: it[1].__setitem__(slice(0, 32), (P).to_bytes(32, "little")))      # y = p
+    mod(lambda it: it[0].__setitem__(slice(0, 32), O.ED_TORSION8))                   # small-order A
+    mod(lambda it: it[0].__setitem__(slice(0, 32), bytes(32)))                       # y = 0: order 4
+    mod(lambda it: it[1].__setitem__(slice(0, 32), bytes(32)))                       # R of order 4
+    mod(lambda it: it[1].__setitem__(slice(0, 32), O.ED_TORSION8))                   # R of order 8
+    mod(lambda it: it[1].__setitem__(31, it[1][31] ^ 0x80))                          # sign of R flipped
+    mod(lambda it: it[0].__setitem__(31, it[0][31] ^ 0x80))                          # sign of A flipped
+    mod(lambda it: it[1].__setitem__(slice(0, 32), (1 | (1 << 255)).to_bytes(32, "little")))  # x = 0, sign 1
+    mod(lambda it: it[0].__setitem__(slice(0, 32), (2).to_bytes(32, "little")))      # y = 2: no x
+    mod(lambda it: it[1].__setitem__(slice(0, 32), (2).to_bytes(32, "little")))
+    mod(lambda it: it[1].__setitem__(slice(0, 32), b"\xff" * 32))
+    pubs = b"".join(bytes(i[0]) for i in items)
+    sigs = b"".join(bytes(i[1]) for i in items)
+    msgs = b"".join(bytes(i[2]) for i in items)
+    return pubs, sigs, msgs, O.ed25519_hram(pubs, sigs, msgs, ED_MSG_LEN)
+
+
+def test_eddsa25519_kats():
+    """the reference's RFC 8032 Ed25519ctx / Ed25519ph vectors verify; any flipped bit does not"""
+    o = Oracle("WEI25519")
+    pubs, sigs, hram = eddsa_kat_inputs()
+    n = len(KAT_EDDSA)
+    assert n == 5
+    assert o.eddsa_verify(pubs, sigs, hram) == bytes(n)
+    for pos in (0, 31, 32, 63):
+        bad = bytearray(sigs)
+        for i in range(n):
+            bad[64 * i + pos] ^= 0x10
+        assert o.eddsa_verify(pubs, bytes(bad), hram) == b"\x01" * n
+    badh = bytes(b ^ 1 if i % 64 == 7 else b for i, b in enumerate(hram))
+    assert o.eddsa_verify(pubs, sigs, badh) == b"\x01" * n
+
+
+def test_eddsa25519_vs_reference():
+    """restatement against the unmodified reference (eddsa_import_pub_key + ec_verify, which hashes by
+    itself) on valid, invalid, non-canonical, small-order and mixed-order inputs; the python signer used
+    for test inputs is checked against the reference's signer on the way"""
+    rng = np.random.default_rng(33)
+    o = Oracle("WEI25519")
+    pubs, sigs, msgs, hram = ed25519_cases(rng)
+    n = len(pubs) // 32
+    got = o.eddsa_verify(pubs, sigs, hram)
+    assert got[:12] == bytes(12) and got[12:24] == bytes(12)   # valid and torsion-shifted: accepted
+    assert 1 in got
+    if have_ref():
+        assert got == O.ref_ed25519_verify(pubs, sigs, msgs, ED_MSG_LEN)
+        seeds, m = rb(rng, 32 * 6), rb(rng, ED_MSG_LEN * 6)
+        rp, rs, st = O.ref_ed25519_sign(seeds, m, ED_MSG_LEN)
+        assert st == bytes(6)
+        for i in range(6):
+            a, sg, _ = O.ed25519_sign(seeds[32 * i:32 * i + 32], m[ED_MSG_LEN * i:ED_MSG_LEN * (i + 1)])
+            assert (a, sg) == (rp[32 * i:32 * i + 32], rs[64 * i:64 * i + 64])
