@@ -136,7 +136,7 @@ template <class T> static __device__ __forceinline__ T selg(bool c, const T &a, 
 	return r;
 }
 
-// FLAV only makes the kernel symbols of the two 521-bit translation units distinct (0 dense, 1 secp521r1)
+// FLAV only makes the kernel symbols of the translation units of one size distinct (0 dense, 1 secp521r1, 2 2^255 - 19)
 template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_smul_g(EcamdSmulArgs A, int gslot)
 {
 	typedef Lay<PB> L;
@@ -392,9 +392,14 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_finalize_g(E
 // ---- one field size: constants + launch / upload entry points with the size in their name ----
 #define G29_CAT2(a, b) a##b
 #define G29_CAT(a, b) G29_CAT2(a, b)
-#ifdef G29_MERSENNE521
+#if defined(G29_MERSENNE521)
 #define G29_TAG G29_CAT(G29_PB, m)   /* 521m: the secp521r1 flavour lives beside the dense 521 one */
+#define G29_FLAV 1
+#elif defined(G29_P25519)
+#define G29_TAG G29_CAT(G29_PB, c)   /* 255c: p = 2^255 - 19 beside the dense 255-bit unit */
+#define G29_FLAV 2
 #else
+#define G29_FLAV 0
 #define G29_TAG G29_PB
 #endif
 __constant__ SlotsG<Lay<G29_PB>::NL> G29_CAT(g_g29_, G29_TAG);
@@ -422,11 +427,11 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_TAG)(int gslot, const EcamdSmulArgs &a
 		(void)hipEventRecord(ev[1], s);
 		(void)hipEventRecord(ev[2], s);
 	}
-	hipLaunchKernelGGL((k_smul_g<G29_PB, g29::MERSENNE521 ? 1 : 0>), grid, block, 0, s, a, gslot);
+	hipLaunchKernelGGL((k_smul_g<G29_PB, G29_FLAV>), grid, block, 0, s, a, gslot);
 	if (ev) {
 		(void)hipEventRecord(ev[3], s);
 	}
-	hipLaunchKernelGGL((k_finalize_g<G29_PB, g29::MERSENNE521 ? 1 : 0>), fgrid, block, 0, s, a, gslot, nthreads);
+	hipLaunchKernelGGL((k_finalize_g<G29_PB, G29_FLAV>), fgrid, block, 0, s, a, gslot, nthreads);
 	if (ev) {
 		(void)hipEventRecord(ev[4], s);
 	}
@@ -442,6 +447,7 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_TAG)(int gslot, const EcamdSmulArgs &a
 	hipError_t ecamd_g29_launch_##PB(int gslot, const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev);
 G29_FOR_PB(X)
 X(521m)
+X(255c)
 #undef X
 
 int ecamd_g29_supported(int pbits)
@@ -453,17 +459,26 @@ int ecamd_g29_supported(int pbits)
 	default: return 0;
 	}
 }
-int ecamd_g29_nl(int pbits) { return g29::nl_for(pbits); }
+int ecamd_g29_nl(int pbits, int flavour) { return g29::nl_for_flavour(pbits, flavour); }
 int ecamd_g29_slots(void) { return G29_SLOTS; }
-uint32_t ecamd_g29_table_words(int pbits) { return 8u * (uint32_t)(((3 * g29::nl_for(pbits) + 3) / 4) * 4); }
+uint32_t ecamd_g29_table_words(int pbits, int flavour)
+{
+	return 8u * (uint32_t)(((3 * g29::nl_for_flavour(pbits, flavour) + 3) / 4) * 4);
+}
 uint32_t ecamd_g29_max_slen(int pbits) { return 4u * (uint32_t)((pbits + 31) / 32); }
-size_t ecamd_g29_image_bytes(int pbits) { return (size_t)((6 + g29::NBIAS) * g29::nl_for(pbits) + 4) * 4; }
+size_t ecamd_g29_image_bytes(int pbits, int flavour)
+{
+	return (size_t)((6 + g29::NBIAS) * g29::nl_for_flavour(pbits, flavour) + 4) * 4;
+}
 
-// 'flavour' 1 selects the secp521r1 (p = 2^521 - 1) instantiation
+// 'flavour' 1 selects the secp521r1 (p = 2^521 - 1) instantiation, 2 the p = 2^255 - 19 one
 hipError_t ecamd_g29_upload(int pbits, int slot, const void *img, size_t bytes, int flavour)
 {
 	if (pbits == 521 && flavour == 1) {
 		return ecamd_g29_upload_521m(slot, img, bytes);
+	}
+	if (pbits == 255 && flavour == 2) {
+		return ecamd_g29_upload_255c(slot, img, bytes);
 	}
 	switch (pbits) {
 #define X(PB) case PB: return ecamd_g29_upload_##PB(slot, img, bytes);
@@ -480,6 +495,9 @@ hipError_t ecamd_launch_smul_g29(int pbits, int gslot, const EcamdSmulArgs &a, h
 	}
 	if (pbits == 521 && flavour == 1) {
 		return ecamd_g29_launch_521m(gslot, a, s, ev);
+	}
+	if (pbits == 255 && flavour == 2) {
+		return ecamd_g29_launch_255c(gslot, a, s, ev);
 	}
 	switch (pbits) {
 #define X(PB) case PB: return ecamd_g29_launch_##PB(gslot, a, s, ev);

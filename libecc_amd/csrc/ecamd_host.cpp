@@ -233,6 +233,16 @@ struct ecamd_curve {
 	int pbits, qbits;
 	Big p, a, b, order, gx, gy, q;
 	uint8_t *d_gen;  // generator, affine X||Y big-endian, in HBM
+	// per-curve constants of the Ed25519 / X25519 / X448 entry points, computed on first use (ctx->mu held)
+	int ed_state;    // 0 not yet, 1 ready, -1 this handle is not the Ed25519 model (ed_err says why)
+	const char *ed_err;
+	EcamdEdDecodeArgs ed_tmpl;
+	uint32_t ed_cof_dbl;
+	int xdh_state;
+	const char *xdh_err;
+	EcamdXdhPrepArgs xdh_tmpl;
+	uint32_t xdh_A3[17];
+	uint8_t xdh_cof;
 	bool is_p256;    // exactly secp256r1: hand-specialised radix-2^29 Jacobian kernel
 	int gslot;       // constant slot of the generic radix-2^29 Jacobian kernel (-1: none)
 	int gflavour;    // 0 dense reduction, 1 secp521r1 (p = 2^521 - 1) single-digit reduction
@@ -488,9 +498,10 @@ static Big big_shl(const Big &a, int e)
 // a_is_m3 pad -- mirrored by tools/g29_consts.py, which the CPU tests use against Python integers
 static int upload_g29(ecamd_curve *cv)
 {
-	const int pbits = cv->pbits, nl = ecamd_g29_nl(pbits);
+	const int pbits = cv->pbits, nl = ecamd_g29_nl(pbits, cv->gflavour);
 	const Big &p = cv->p;
-	const Big R = big_mod(big_pow2(29 * nl), p);
+	// flavour 2 (p = 2^255 - 19) keeps plain residues: R = 1
+	const Big R = cv->gflavour == 2 ? Big(1, 1) : big_mod(big_pow2(29 * nl), p);
 	Big two(1, 2), three(1, 3);
 	static const int step[16] = {2, 4, 6, 8, 10, 12, 14, 16, 2, 4, 6, 8, 10, 12, 14, 16};
 	static const int sv[16] = {1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2};
@@ -505,6 +516,9 @@ static int upload_g29(ecamd_curve *cv)
 	big_digits29(&img[5 * nl], nl, big_sub(p, two));
 	for (int t = 0; t < 16; t++) {
 		uint32_t *l = &img[(size_t)(6 + t) * nl];
+		if (big_bitlen(p) + step[t] + off > 29 * (nl - 1) + 32) {
+			continue;  // this multiple does not fit the limbs (only without a headroom limb); never selected
+		}
 		big_digits29(l, nl, big_shl(p, step[t] + off));
 		const uint32_t M = 1u << (29 + sv[t]), BW = 1u << sv[t];
 		if (l[nl - 1] < BW) {
@@ -523,7 +537,7 @@ static int upload_g29(ecamd_curve *cv)
 	img[(size_t)22 * nl + 0] = (0u - x) & 0x1fffffffu;
 	img[(size_t)22 * nl + 1] = (uint32_t)pbits;
 	img[(size_t)22 * nl + 2] = (big_cmp(big_add(cv->a, three), p) == 0) ? 1u : 0u;
-	if (img.size() * 4 != ecamd_g29_image_bytes(pbits)) {
+	if (img.size() * 4 != ecamd_g29_image_bytes(pbits, cv->gflavour)) {
 		return fail("internal: CurveG image size mismatch");
 	}
 	HIPCHK(ecamd_g29_upload(pbits, cv->gslot, img.data(), img.size() * 4, cv->gflavour));
@@ -586,6 +600,9 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	}
 	cv->gslot = -1;
 	cv->gflavour = (cv->pbits == 521 && big_cmp(big_add(cv->p, Big(1, 1)), big_pow2(521)) == 0) ? 1 : 0;
+	if (cv->pbits == 255 && big_cmp(big_add(cv->p, Big(1, 19)), big_pow2(255)) == 0 && getenv("ECAMD_NO_P25519") == nullptr) {
+		cv->gflavour = 2;
+	}
 	if (!cv->is_p256 && ecamd_g29_supported(cv->pbits) && cv->pbits < 640 && getenv("ECAMD_NO_FAST_PATH") == nullptr) {
 		for (int i = 0; i < ecamd_g29_slots(); i++) {
 			if (!ctx->gslot_used[cv->pbits + cv->gflavour][i]) {
@@ -607,6 +624,9 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 		return fail("curve: generator upload failed");
 	}
 	cv->d_gtab = nullptr;
+	cv->ed_state = 0;
+	cv->xdh_state = 0;
+	cv->ed_err = cv->xdh_err = nullptr;
 	if (cv->is_p256) {
 		// affine window table of the generator for the interleaved ECDSA verification loop:
 		// [1..8]G through our own kernels, then x R mod p, y R mod p (R = 2^261) as 29-bit digits
@@ -759,7 +779,7 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 	}
 	if (fast) {
 		uint8_t *t = (uint8_t *)ctx->tbl_fast;
-		const size_t per_item = fast256 ? (size_t)8 * 40 * 4 : (size_t)ecamd_g29_table_words(cv->pbits) * 4;
+		const size_t per_item = fast256 ? (size_t)8 * 40 * 4 : (size_t)ecamd_g29_table_words(cv->pbits, cv->gflavour) * 4;
 		const int rc = ensure(&t, &ctx->tbl_fast_bytes, (size_t)stride * per_item);
 		ctx->tbl_fast = (uint32_t *)t;
 		if (rc) {
@@ -1289,12 +1309,10 @@ static Big big_sqrt_m1(const Big &p)  // 2^((p-1)/4) mod p, a square root of -1 
 	return big_powmod(two, q, p);
 }
 
-extern "C" int ec_xdh_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *k, const uint8_t *u,
-			    uint8_t *out, uint8_t *status)
+// constants of the X25519 / X448 path for this handle; ctx->mu held
+static void xdh_setup(ecamd_curve *cv)
 {
-	if (!ctx || !cv || cv->ctx != ctx || (n && (!k || !u || !out || !status))) {
-		return fail("ec_xdh_batch: bad argument");
-	}
+	cv->xdh_state = -1;
 	// the Weierstrass models of Curve25519 / Curve448: A = 486662 / 156326, B = 1
 	uint32_t Aval = 0;
 	if (cv->pbits == 255 && cv->clen == 32 && big_cmp(cv->p, big_sub(big_pow2(255), Big(1, 19))) == 0) {
@@ -1303,55 +1321,31 @@ extern "C" int ec_xdh_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, c
 		   big_cmp(cv->p, big_sub(big_sub(big_pow2(448), big_pow2(224)), Big(1, 1))) == 0) {
 		Aval = 156326;
 	} else {
-		return fail("ec_xdh_batch: the curve is neither WEI25519 nor WEI448");
+		cv->xdh_err = "ec_xdh_batch: the curve is neither WEI25519 nor WEI448";
+		return;
 	}
+	const Big &p = cv->p;
+	const int nw = cv->nw;
+	const Big A(1, Aval), one(1, 1), two(1, 2), three(1, 3), nine(1, 9), tw7(1, 27);
+	const Big pm2 = big_sub(p, two);
 	{
 		// make sure the handle really is the birationally equivalent Weierstrass curve:
 		// a = (3 - A^2) / 3, b = (2 A^3 - 9 A) / 27
-		const Big &p = cv->p;
-		Big A(1, Aval), three(1, 3), nine(1, 9), tw7(1, 27), two(1, 2);
-		Big pm2 = big_sub(p, two);
 		Big A2 = big_mulmod(A, A, p);
 		Big a_exp = big_mulmod(big_mod(big_add(big_sub(p, A2), three), p), big_powmod(three, pm2, p), p);
 		Big A3c = big_mulmod(A2, A, p);
 		Big num = big_mod(big_add(big_mulmod(two, A3c, p), big_sub(p, big_mulmod(nine, A, p))), p);
 		Big b_exp = big_mulmod(num, big_powmod(tw7, pm2, p), p);
 		if (big_cmp(a_exp, cv->a) != 0 || big_cmp(b_exp, cv->b) != 0) {
-			return fail("ec_xdh_batch: curve coefficients do not match the Montgomery curve");
+			cv->xdh_err = "ec_xdh_batch: curve coefficients do not match the Montgomery curve";
+			return;
 		}
 	}
-	if (n == 0) {
-		return 0;
-	}
-	std::lock_guard<std::mutex> lk(ctx->mu);
-	HIPCHK(hipSetDevice(ctx->device));
-	const size_t len = (size_t)cv->clen, plen = 2 * len;
-	// stage: 0 k, 1 u, 2 scalars BE, 3 points, 4 flags, 5 tmp points ([h]Q), 6 st8, 7 [k]Q, 8 stk, 9 out, 10 status, 11 h
-	const size_t need[ECAMD_NSTAGE] = {n * len, n * len, n * len, n * plen, n, n * plen, n, n * plen, n, n * len, n, 64};
-	for (int i = 0; i < ECAMD_NSTAGE; i++) {
-		if (ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
-			return -1;
-		}
-	}
-	uint8_t **S = ctx->stage;
-	hipStream_t s = ctx->stream;
-	HIPCHK(hipMemcpyAsync(S[0], k, n * len, hipMemcpyHostToDevice, s));
-	HIPCHK(hipMemcpyAsync(S[1], u, n * len, hipMemcpyHostToDevice, s));
-	const Big &p = cv->p;
-	const int nw = cv->nw;
 	const Big R = big_mod(big_pow2(32 * nw), p);
-	Big one(1, 1), two(1, 2), three(1, 3);
-	const Big A(1, Aval);
-	const Big A3 = big_mulmod(A, big_powmod(three, big_sub(p, two), p), p);
-	EcamdXdhPrepArgs P;
+	const Big A3 = big_mulmod(A, big_powmod(three, pm2, p), p);
+	EcamdXdhPrepArgs &P = cv->xdh_tmpl;
 	memset(&P, 0, sizeof(P));
-	P.k = S[0];
-	P.u = S[1];
-	P.scalars = S[2];
-	P.points = S[3];
-	P.flags = S[4];
-	P.n = n;
-	P.len = (uint32_t)len;
+	P.len = (uint32_t)cv->clen;
 	Big e;
 	if ((p[0] & 7u) == 5u) {
 		P.mode = 0;
@@ -1377,27 +1371,66 @@ extern "C" int ec_xdh_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, c
 	big_store(P.A, nw, big_mulmod(A, R, p));
 	big_store(P.A3, nw, big_mulmod(A3, R, p));
 	P.slot = cv->slot;
+	big_store(cv->xdh_A3, 17, A3);
+	// cofactor h: order = h q
+	uint32_t hval = 0;
+	Big t = cv->q;
+	for (uint32_t c = 1; c <= 16; c++) {
+		if (big_cmp(t, cv->order) == 0) {
+			hval = c;
+			break;
+		}
+		t = big_add(t, cv->q);
+	}
+	if (hval == 0) {
+		cv->xdh_err = "ec_xdh_batch: unexpected cofactor";
+		return;
+	}
+	cv->xdh_cof = (uint8_t)hval;
+	cv->xdh_state = 1;
+}
+
+extern "C" int ec_xdh_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const uint8_t *k, const uint8_t *u,
+			    uint8_t *out, uint8_t *status)
+{
+	if (!ctx || !cv_in || cv_in->ctx != ctx || (n && (!k || !u || !out || !status))) {
+		return fail("ec_xdh_batch: bad argument");
+	}
+	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (cv->xdh_state == 0) {
+		xdh_setup(cv);
+	}
+	if (cv->xdh_state < 0) {
+		return fail(cv->xdh_err);
+	}
+	if (n == 0) {
+		return 0;
+	}
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t len = (size_t)cv->clen, plen = 2 * len;
+	// stage: 0 k, 1 u, 2 scalars BE, 3 points, 4 flags, 5 tmp points ([h]Q), 6 st8, 7 [k]Q, 8 stk, 9 out, 10 status, 11 h
+	const size_t need[ECAMD_NSTAGE] = {n * len, n * len, n * len, n * plen, n, n * plen, n, n * plen, n, n * len, n, 64};
+	for (int i = 0; i < ECAMD_NSTAGE; i++) {
+		if (ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
+			return -1;
+		}
+	}
+	uint8_t **S = ctx->stage;
+	hipStream_t s = ctx->stream;
+	HIPCHK(hipMemcpyAsync(S[0], k, n * len, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(S[1], u, n * len, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(S[11], &cv->xdh_cof, 1, hipMemcpyHostToDevice, s));
+	const int nw = cv->nw;
+	EcamdXdhPrepArgs P = cv->xdh_tmpl;
+	P.k = S[0];
+	P.u = S[1];
+	P.scalars = S[2];
+	P.points = S[3];
+	P.flags = S[4];
+	P.n = n;
 	HIPCHK(ecamd_launch_xdh_prep(nw, P, s));
 	// [h]Q with the broadcast scalar h (cofactor), then [k]Q
-	{
-		Big hq = big_mod(cv->order, cv->q);  // must be 0: order = h q
-		(void)hq;
-		uint32_t hval = 0;
-		Big t = cv->q;
-		for (uint32_t c = 1; c <= 16; c++) {
-			if (big_cmp(t, cv->order) == 0) {
-				hval = c;
-				break;
-			}
-			t = big_add(t, cv->q);
-		}
-		if (hval == 0) {
-			return fail("ec_xdh_batch: unexpected cofactor");
-		}
-		const uint8_t hb = (uint8_t)hval;
-		HIPCHK(hipMemcpyAsync(S[11], &hb, 1, hipMemcpyHostToDevice, s));
-		HIPCHK(hipStreamSynchronize(s));
-	}
 	if (smul_dev_locked(ctx, cv, n, S[11], 1, S[3], S[5], S[6], s, 0) ||
 	    smul_dev_locked(ctx, cv, n, S[2], (uint32_t)len, S[3], S[7], S[8], s)) {
 		return -1;
@@ -1412,7 +1445,7 @@ extern "C" int ec_xdh_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, c
 	Fn.status = S[10];
 	Fn.n = n;
 	Fn.len = (uint32_t)len;
-	big_store(Fn.A3, nw, A3);
+	memcpy(Fn.A3, cv->xdh_A3, sizeof(Fn.A3));
 	Fn.slot = cv->slot;
 	HIPCHK(ecamd_launch_xdh_fin(nw, Fn, s));
 	HIPCHK(hipMemcpyAsync(out, S[9], n * len, hipMemcpyDeviceToHost, s));
@@ -1445,18 +1478,14 @@ static bool big_sqrt_5mod8(const Big &n, const Big &p, Big *out)
 	return big_cmp(big_mulmod(c, c, p), big_mod(n, p)) == 0;
 }
 
-extern "C" int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys,
-				     const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, uint8_t *result)
+// constants of the Ed25519 path for this handle; ctx->mu held
+static void ed_setup(ecamd_curve *cv)
 {
-	if (!ctx || !cv || cv->ctx != ctx || (n && (!pubkeys || !sigs || !hram || !result))) {
-		return fail("ec_eddsa_verify_batch: bad argument");
-	}
+	cv->ed_state = -1;
 	if (!(cv->pbits == 255 && cv->clen == 32 && cv->nw == 8 && cv->qslot >= 0 &&
 	      big_cmp(cv->p, big_sub(big_pow2(255), Big(1, 19))) == 0)) {
-		return fail("ec_eddsa_verify_batch: only Ed25519 (the WEI25519 curve handle) is supported");
-	}
-	if (hram_len != 64) {
-		return fail("ec_eddsa_verify_batch: Ed25519 hashes with SHA-512: hram_len must be 64");
+		cv->ed_err = "ec_eddsa_verify_batch: only Ed25519 (the WEI25519 curve handle) is supported";
+		return;
 	}
 	const Big &p = cv->p;
 	const Big one(1, 1), two(1, 2), three(1, 3);
@@ -1467,7 +1496,8 @@ extern "C" int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint
 	const Big d_ed = big_negmod(big_mulmod(Big(1, 121665), big_inv_p(Big(1, 121666), p), p), p);
 	Big alpha;
 	if (!big_sqrt_5mod8(big_negmod(big_add(A, two), p), p, &alpha)) {
-		return fail("ec_eddsa_verify_batch: internal: alpha");
+		cv->ed_err = "ec_eddsa_verify_batch: internal: alpha";
+		return;
 	}
 	{
 		// the handle must be the Weierstrass model whose generator is the image of the Ed25519 base
@@ -1478,7 +1508,8 @@ extern "C" int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint
 		const Big den = big_mod(big_add(a_ed, big_sub(p, big_mulmod(d_ed, y2, p))), p);
 		Big xb;
 		if (!big_sqrt_5mod8(big_mulmod(num, big_inv_p(den, p), p), p, &xb)) {
-			return fail("ec_eddsa_verify_batch: internal: base point");
+			cv->ed_err = "ec_eddsa_verify_batch: internal: base point";
+			return;
 		}
 		if (xb[0] & 1u) {
 			xb = big_sub(p, xb);
@@ -1491,29 +1522,62 @@ extern "C" int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint
 			vm = big_sub(p, vm);
 		}
 		if (big_cmp(X, cv->gx) != 0 || big_cmp(vm, cv->gy) != 0) {
-			return fail("ec_eddsa_verify_batch: the curve generator is not the image of the Ed25519 base point");
+			cv->ed_err = "ec_eddsa_verify_batch: the curve generator is not the image of the Ed25519 base point";
+			return;
 		}
 	}
-	uint32_t cof_dbl = 0;
+	cv->ed_cof_dbl = 0xffffffffu;
 	{
 		Big t = cv->q;
 		for (uint32_t c = 0; c <= 4; c++) {
 			if (big_cmp(t, cv->order) == 0) {
-				cof_dbl = c;
+				cv->ed_cof_dbl = c;
 				break;
 			}
 			t = big_add(t, t);
-			if (c == 4) {
-				return fail("ec_eddsa_verify_batch: unexpected cofactor");
-			}
 		}
+	}
+	if (cv->ed_cof_dbl == 0xffffffffu) {
+		cv->ed_err = "ec_eddsa_verify_batch: unexpected cofactor";
+		return;
+	}
+	const int nw = cv->nw;
+	const Big R = big_mod(big_pow2(32 * nw), p);
+	EcamdEdDecodeArgs &D = cv->ed_tmpl;
+	memset(&D, 0, sizeof(D));
+	D.len = 32;
+	D.slot = cv->slot;
+	big_store(D.a, nw, big_mulmod(a_ed, R, p));
+	big_store(D.d, nw, big_mulmod(d_ed, R, p));
+	big_store(D.sm1, nw, big_mulmod(big_sqrt_m1(p), R, p));
+	big_store(D.alpha, nw, big_mulmod(alpha, R, p));
+	big_store(D.A3, nw, big_mulmod(A3, R, p));
+	cv->ed_state = 1;
+}
+
+extern "C" int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const uint8_t *pubkeys,
+				     const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, uint8_t *result)
+{
+	if (!ctx || !cv_in || cv_in->ctx != ctx || (n && (!pubkeys || !sigs || !hram || !result))) {
+		return fail("ec_eddsa_verify_batch: bad argument");
+	}
+	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (cv->ed_state == 0) {
+		ed_setup(cv);
+	}
+	if (cv->ed_state < 0) {
+		return fail(cv->ed_err);
+	}
+	if (hram_len != 64) {
+		return fail("ec_eddsa_verify_batch: Ed25519 hashes with SHA-512: hram_len must be 64");
 	}
 	if (n == 0) {
 		return 0;
 	}
-	std::lock_guard<std::mutex> lk(ctx->mu);
 	HIPCHK(hipSetDevice(ctx->device));
 	const size_t len = 32, plen = 64;
+	const uint32_t cof_dbl = cv->ed_cof_dbl;
 	// stage: 0 pubkeys, 1 sigs, 2 hram, 3 A (Weierstrass), 4 R, 5 flagsA, 6 flagsR, 7 flagsS, 8 S, 9 h,
 	//        10 [8]A, 11 st8, 12 [h]A, 13 sthA, 14 [S]G, 15 stSG, 16 result, 17 cofactor scalar
 	const size_t need[ECAMD_NSTAGE] = {n * len, n * plen, (size_t)n * hram_len, n * plen, n * plen, n, n, n, n * len, n * len,
@@ -1532,17 +1596,8 @@ extern "C" int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint
 	HIPCHK(hipMemcpyAsync(S[17], &cofb, 1, hipMemcpyHostToDevice, s));
 	HIPCHK(hipStreamSynchronize(s));  // cofb lives on this stack frame
 	const int nw = cv->nw;
-	const Big R = big_mod(big_pow2(32 * nw), p);
-	EcamdEdDecodeArgs D;
-	memset(&D, 0, sizeof(D));
+	EcamdEdDecodeArgs D = cv->ed_tmpl;
 	D.n = n;
-	D.len = (uint32_t)len;
-	D.slot = cv->slot;
-	big_store(D.a, nw, big_mulmod(a_ed, R, p));
-	big_store(D.d, nw, big_mulmod(d_ed, R, p));
-	big_store(D.sm1, nw, big_mulmod(big_sqrt_m1(p), R, p));
-	big_store(D.alpha, nw, big_mulmod(alpha, R, p));
-	big_store(D.A3, nw, big_mulmod(A3, R, p));
 	D.enc = S[0];
 	D.estride = (uint32_t)len;
 	D.points = S[3];

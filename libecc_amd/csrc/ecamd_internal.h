@@ -140,11 +140,11 @@ hipError_t ecamd_launch_ed_fin(int nw, const EcamdEdFinArgs &a, hipStream_t s);
 
 // radix-2^29 Jacobian fast path for every field size (ecamd_g29_kernel.hip)
 int ecamd_g29_supported(int pbits);
-int ecamd_g29_nl(int pbits);
+int ecamd_g29_nl(int pbits, int flavour);
 int ecamd_g29_slots(void);
-uint32_t ecamd_g29_table_words(int pbits);   // scratch words per item
+uint32_t ecamd_g29_table_words(int pbits, int flavour);   // scratch words per item
 uint32_t ecamd_g29_max_slen(int pbits);      // longest scalar (bytes) the fast path takes
-size_t ecamd_g29_image_bytes(int pbits);
+size_t ecamd_g29_image_bytes(int pbits, int flavour);
 hipError_t ecamd_g29_upload(int pbits, int slot, const void *img, size_t bytes, int flavour);
 hipError_t ecamd_launch_smul_g29(int pbits, int gslot, const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev, int flavour);
 hipError_t ecamd_launch_fp(int nw, const EcamdFpArgs &a, hipStream_t s);

@@ -16,7 +16,9 @@ template <int PB> struct Cls {
 	static constexpr int LC = pick_logc<PB, 2>(3ull * MASK, C::top_from_vb(8)) + 4;
 	static_assert(LC >= 0, "no bias table large enough for this field size");
 	// ... bounds every loop-carried coordinate: carried limbs, value < 4 * 2^LC p
-	static constexpr u64 VA = 4ull << LC;
+	// (2^255 - 19 flavour: no headroom limb, the top limb holds values below 512 p, and products want
+	// va * vb <= 2^14; the formulas stay well inside 48 p)
+	static constexpr u64 VA = P25519 ? 48 : (4ull << LC);
 	typedef E<PB, MASK + 8, C::top_from_vb(VA), VA> FA;
 	typedef typename MulOut<PB, 2>::type FM;  // multiplication result (value < 2p, exact low digits)
 	typedef E<PB, MASK, MASK, 1> FC;          // canonical constant

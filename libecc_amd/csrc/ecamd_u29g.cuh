@@ -39,7 +39,24 @@ typedef uint64_t u64;
 constexpr int W = 29;
 constexpr u32 MASK = (1u << W) - 1;
 
+// Reduction flavour of a translation unit: dense Montgomery (any prime), or one of the special cases
+//   -DG29_MERSENNE521  p = 2^521 - 1 (secp521r1), still Montgomery form;
+//   -DG29_P25519       p = 2^255 - 19 (WEI25519 / Ed25519 / X25519): NO Montgomery form (R = 1) and no
+//                      headroom limb: 9 limbs, the 18-limb product is folded with 2^261 = 1216 and
+//                      2^255 = 19 (mod p), see mul_raw.
+#if defined(G29_MERSENNE521)
+constexpr bool MERSENNE521 = true;
+#else
+constexpr bool MERSENNE521 = false;
+#endif
+#if defined(G29_P25519)
+constexpr bool P25519 = true;
+#else
+constexpr bool P25519 = false;
+#endif
+
 constexpr int nl_for(int pbits) { return (pbits + 16 + W - 1) / W; }
+constexpr int nl_for_flavour(int pbits, int flavour) { return flavour == 2 ? 9 : nl_for(pbits); }
 constexpr u64 cmin(u64 a, u64 b) { return a < b ? a : b; }
 constexpr u64 cmax(u64 a, u64 b) { return a > b ? a : b; }
 // x * 2^e for any sign of e, rounded up
@@ -49,18 +66,20 @@ constexpr u64 shl_floor(u64 x, int e) { return e >= 0 ? (x << e) : (x >> -e); }
 
 template <int PB> struct Cfg {
 	static constexpr int PBITS = PB;
-	static constexpr int NL = nl_for(PB);
-	static constexpr int HEAD = W * NL - PB;           // R / p >= 2^HEAD, HEAD >= 16
+	static_assert(!P25519 || PB == 255, "the 2^255 - 19 flavour is only for 255-bit fields");
+	static constexpr int NL = P25519 ? 9 : nl_for(PB);
+	static constexpr int HEAD = W * NL - PB;           // R / p >= 2^HEAD, HEAD >= 16 (Montgomery flavours)
 	static constexpr int TOPSH = PB - W * (NL - 1);    // p < 2^(29 (NL-1) + TOPSH); may be <= 0
-	static_assert(HEAD >= 16 && NL <= 19, "field size not supported");
+	static_assert((HEAD >= 16 || P25519) && NL <= 19, "field size not supported");
 	// top limb of a non-negative-limb value < vb * p
 	static constexpr u64 top_from_vb(u64 vb) { return shl_ceil(vb, TOPSH) + 1; }
 	// bias multiples are 2^(BIAS_STEP + BIAS_OFF) p: with a (nearly) empty top limb the smallest
 	// useful multiple is the one whose top digit is at least a few units
 	static constexpr int BIAS_OFF = (1 - TOPSH) > 0 ? (1 - TOPSH) : 0;
 	// va * vb < 2^(2 HEAD - 2) without overflowing u64
-	static constexpr int PROD_E = (2 * HEAD - 2) > 62 ? 62 : (2 * HEAD - 2);
-	static constexpr bool prod_ok(u64 va, u64 vb) { return va == 0 || vb <= ((1ull << PROD_E) - 1) / va; }
+	// (2^255 - 19 flavour: va * vb <= 2^14 keeps the last product limb and the fold quotient in 32 bits)
+	static constexpr int PROD_E = P25519 ? 14 : ((2 * HEAD - 2) > 62 ? 62 : (2 * HEAD - 2));
+	static constexpr bool prod_ok(u64 va, u64 vb) { return va == 0 || vb <= ((1ull << PROD_E) - (P25519 ? 0 : 1)) / va; }
 };
 
 // the (LOGC, S) combinations the formulas use for "a - b + C p": bias tables for exactly these
@@ -116,9 +135,10 @@ template <class T, class S> G29_FN T weaken(const S &s)
 }
 
 // ---- multiplication ----
-template <int PB> constexpr u64 mul_vb(u64 va, u64 vb) { return shl_ceil(va * vb, -Cfg<PB>::HEAD) + 1; }
+template <int PB> constexpr u64 mul_vb(u64 va, u64 vb) { return P25519 ? 2 : shl_ceil(va * vb, -Cfg<PB>::HEAD) + 1; }
 template <int PB, u64 VBO> struct MulOut {
-	typedef E<PB, MASK, Cfg<PB>::top_from_vb(VBO), VBO> type;
+	// 2^255 - 19 flavour: exact low digits, top limb < 2^23 + 2^12 (see mul_raw), value < 2p
+	typedef E<PB, MASK, P25519 ? ((1ull << 23) + (1ull << 12)) : Cfg<PB>::top_from_vb(VBO), VBO> type;
 };
 template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
 {
@@ -138,16 +158,9 @@ template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
 #define G29_PIN(acc) (void)0
 #endif
 
-// Reduction flavour of a translation unit: dense (any prime) or, with -DG29_MERSENNE521, the
-// special case p = 2^521 - 1 (secp521r1): p = -1 mod 2^29 so the quotient digit is the column's
-// low 29 bits, and "+ m p" is "- m + m (p + 1)" with p + 1 = 2^521 = 2^28 * 2^(29*17): ONE
-// reduction MAD per digit instead of NL (380 MADs per multiplication instead of 722).
-#if defined(G29_MERSENNE521)
-constexpr bool MERSENNE521 = true;
-#else
-constexpr bool MERSENNE521 = false;
-#endif
-
+// secp521r1 flavour: p = -1 mod 2^29 so the quotient digit is the column's low 29 bits, and "+ m p"
+// is "- m + m (p + 1)" with p + 1 = 2^521 = 2^28 * 2^(29*17): ONE reduction MAD per digit instead of
+// NL (380 MADs per multiplication instead of 722).
 // r = a b / R mod p (lazy): product scanning with the reduction interleaved.  SQR: a == b, the
 // off-diagonal products are taken once against the doubled operand.
 template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 *b, const u32 *p, u32 mpinv)
@@ -161,6 +174,50 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 		}
 	}
 	u64 acc = 0;
+	if constexpr (P25519) {
+		// r = a b mod p, p = 2^255 - 19, value < 2p: 81 product MADs into 18 limbs t, then
+		// t[j] + 1216 t[j + 9] (2^261 = 64 * 2^255 = 1216) with 19 * (bits from 2^255 up) fed in at limb 0.
+		static_assert(NL == 9, "2^255 - 19 flavour: 9 limbs");
+		u32 t[2 * NL];
+#pragma unroll
+		for (int k = 0; k < 2 * NL - 1; k++) {
+			const int lo = (k < NL) ? 0 : (k - NL + 1);
+			const int hi = (k < NL) ? k : (NL - 1);
+#pragma unroll
+			for (int i = lo; i <= hi; i++) {
+				const int j = k - i;
+				if (!SQR) {
+					G29_MAD_VV(acc, a[i], b[j]);
+				} else if (i < j) {
+					G29_MAD_VV(acc, a[i], a2[j]);
+				} else if (i == j) {
+					G29_MAD_VV(acc, a[i], a[i]);
+				}
+			}
+			t[k] = (u32)acc & MASK;
+			acc >>= W;
+			G29_PIN(acc);
+		}
+		t[2 * NL - 1] = (u32)acc;  // < va vb 2^17 <= 2^31 (Cfg::prod_ok)
+		u32 f = 1216u;
+#if defined(__HIPCC__)
+		asm volatile("" : "+s"(f));  // keep the folds MADs
+#endif
+		// limb 8 without the carry from below: its bits from 23 up are multiples of 2^255 = 19
+		u64 top = t[NL - 1];
+		G29_MAD_VS(top, t[2 * NL - 1], f);
+		acc = (u64)((u32)(top >> 23)) * 19u;  // quotient < 64 + 19 va vb, times 19 < 2^23
+#pragma unroll
+		for (int j = 0; j < NL - 1; j++) {
+			acc += t[j];
+			G29_MAD_VS(acc, t[j + NL], f);
+			r[j] = (u32)acc & MASK;
+			acc >>= W;
+			G29_PIN(acc);
+		}
+		r[NL - 1] = ((u32)top & ((1u << 23) - 1)) + (u32)acc;  // carry in < 2^12
+		return;
+	}
 #pragma unroll
 	for (int k = 0; k < 2 * NL - 1; k++) {
 		const int lo = (k < NL) ? 0 : (k - NL + 1);

@@ -40,6 +40,16 @@ def lib_m521():
     return C.CDLL(so)
 
 
+@pytest.fixture(scope="module")
+def lib_p25519():
+    """the 2^255 - 19 flavour (nine limbs, plain residues, pseudo-Mersenne folds) of the same headers"""
+    os.makedirs(BUILD, exist_ok=True)
+    so = os.path.join(BUILD, "u29g_host_p25519.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DG29_P25519", "-DSHIM_ONLY_255", "-o", so,
+                           os.path.join(ROOT, "tests", "u29g_host_shim.cpp")])
+    return C.CDLL(so)
+
+
 def val(l):
     return sum(int(v) << (W * i) for i, v in enumerate(l))
 
@@ -50,18 +60,18 @@ def arr(l):
 
 
 class Field:
-    def __init__(self, lib, curve):
+    def __init__(self, lib, curve, flavour=0):
         c = CURVES[curve]
         self.p, self.a, self.b = c["p"], c["a"], c["b"]
         self.pb = self.p.bit_length()
-        img, self.nl = G.image(self.p, self.a, self.b)
+        img, self.nl = G.image(self.p, self.a, self.b, flavour)
         self.k = arr(img)
         self.lib = lib
         info = (C.c_uint32 * 8)()
         getattr(lib, f"g_info_{self.pb}")(info)
         assert info[0] == self.nl and info[5] == 4 * len(img), (list(info), len(img))
         self.head, self.va, self.fa_lb, self.fa_tb = info[1], info[4], info[6], info[7]
-        self.R = 1 << (W * self.nl)
+        self.R = 1 if flavour == 2 else 1 << (W * self.nl)
         self.Rinv = pow(self.R, self.p - 2, self.p)
 
     def fn(self, name):
@@ -90,9 +100,9 @@ class Field:
 
 
 @pytest.mark.parametrize("curve", CASES)
-def test_field_ops(lib, curve):
+def test_field_ops(lib, curve, flavour=0):
     rng = np.random.default_rng(41)
-    f = Field(lib, curve)
+    f = Field(lib, curve, flavour)
     p = f.p
     for it in range(60):
         x = int.from_bytes(rng.bytes(80), "big") % p
@@ -135,9 +145,9 @@ def aff_add(P, Q, a, p):
 
 
 @pytest.mark.parametrize("curve", CASES)
-def test_jacobian(lib, curve):
+def test_jacobian(lib, curve, flavour=0):
     rng = np.random.default_rng(42)
-    f = Field(lib, curve)
+    f = Field(lib, curve, flavour)
     c = CURVES[curve]
     p, a = f.p, f.a
     G0 = (c["gx"], c["gy"])
@@ -186,3 +196,8 @@ def test_jacobian(lib, curve):
 def test_secp521r1_mersenne_flavour(lib_m521):
     test_field_ops(lib_m521, "SECP521R1")
     test_jacobian(lib_m521, "SECP521R1")
+
+
+def test_p25519_flavour(lib_p25519):
+    test_field_ops(lib_p25519, "WEI25519", 2)
+    test_jacobian(lib_p25519, "WEI25519", 2)

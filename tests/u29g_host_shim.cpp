@@ -100,7 +100,9 @@ template <int PB> struct Shim {
 	void g_canon_##PB(const uint32_t *k, const uint32_t *a, uint32_t *o) { Shim<PB>::canon_(k, a, o); } \
 	void g_info_##PB(uint32_t *o) { Shim<PB>::info_(o); } \
 	}
-#ifndef SHIM_ONLY_521
+#if defined(SHIM_ONLY_255)
+SHIM(255)
+#elif !defined(SHIM_ONLY_521)
 SHIM(192)
 SHIM(224)
 SHIM(255)
@@ -111,4 +113,6 @@ SHIM(448)
 SHIM(511)
 SHIM(512)
 #endif
+#if !defined(SHIM_ONLY_255)
 SHIM(521)
+#endif

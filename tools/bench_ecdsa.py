@@ -59,6 +59,18 @@ def main():
             t = time.time(); sh, st2 = cv.xdh(kk[::-1], pub); r2 = n / (time.time() - t)
         assert set(st) == {0} and set(st2) == {0}
         print({"xdh_pubkey": f"{r1 / 1e6:.2f} M/s", "xdh_shared": f"{r2 / 1e6:.2f} M/s"})
+    if a.curve == "WEI25519":
+        import oracles as O
+        m = 128
+        items = [O.ed25519_sign(rng.integers(0, 256, 32, dtype=np.uint8).tobytes(), bytes([i]) * 16) for i in range(m)]
+        reps = n // m
+        P = b"".join(i[0] for i in items) * reps
+        S = b"".join(i[1] for i in items) * reps
+        H = b"".join(i[2] for i in items) * reps
+        for rep in range(2):
+            t = time.time(); ok = cv.eddsa_verify(P, S, H); r = len(ok) / (time.time() - t)
+        assert set(ok) == {0}
+        print({"ed25519_verify": f"{r / 1e6:.2f} M/s"})
 
 
 if __name__ == "__main__":

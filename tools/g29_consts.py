@@ -18,10 +18,12 @@ def digits(x, nl):
     return d
 
 
-def image(p, a, b):
+def image(p, a, b, flavour=0):
+    """flavour 0: dense Montgomery (also what the secp521r1 flavour uses); 2: p = 2^255 - 19, nine limbs
+    and plain residues (R = 1)"""
     pbits = p.bit_length()
-    nl = nl_for(pbits)
-    R = 1 << (W * nl)
+    nl = 9 if flavour == 2 else nl_for(pbits)
+    R = 1 if flavour == 2 else 1 << (W * nl)
     topsh = pbits - W * (nl - 1)
     off = max(0, 1 - topsh)
     out = []
@@ -33,6 +35,9 @@ def image(p, a, b):
     out += digits(p - 2, nl)
     for step, s in zip(BIAS_STEP, BIAS_S):
         c = p << (step + off)
+        if c.bit_length() > W * (nl - 1) + 32:
+            out += [0] * nl   # does not fit the limbs (only without a headroom limb); never selected
+            continue
         d = digits(c, nl)
         M, BW = 1 << (W + s), 1 << s
         l = [d[0] + M] + [d[j] + M - BW for j in range(1, nl - 1)] + [d[nl - 1] - BW]
