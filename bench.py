@@ -79,6 +79,9 @@ def work_model(curve_params, nw, slen):
         M, S = 2 * nl * nl, nl * (nl + 1) // 2 + nl * nl
         if p == 2**521 - 1:                          # secp521r1 flavour: one reduction MAD per digit
             M, S = nl * nl + nl, nl * (nl + 1) // 2 + nl
+        if p == 2**255 - 19:                         # 2^255 - 19 flavour: 9 limbs, 9 + 1 fold MADs + 1 (x 19)
+            nl = 9
+            M, S = nl * nl + nl + 2, nl * (nl + 1) // 2 + nl + 2
         am3 = curve_params["a"] == p - 3
         dbl = (4, 4) if am3 else (4, 6)
         add = (12, 4)
