@@ -157,6 +157,21 @@ int ec_xdh_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uin
 int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *pubkeys,
 			  const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, uint8_t *result);
 
+/* Device-pointer forms of the verification / key-agreement entry points, for callers whose batches
+ * already live in HBM (and for sharding a batch over GPUs, one context per device): same semantics and
+ * layouts as the host-pointer forms above, every buffer a device pointer, kernels enqueued on
+ * hip_stream (a hipStream_t; NULL = the context's stream).  ec_ecdsa_verify_batch_dev returns with the
+ * results complete (it synchronises the stream to re-check exceptional items); the other two only
+ * enqueue -- synchronise the stream (or ecamd_ctx_synchronize for the context's stream) before reading. */
+int ec_ecdsa_verify_batch_dev(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const void *d_pubkeys_aff,
+			      const void *d_sigs, const void *d_digests, uint32_t digest_len, void *d_result,
+			      void *hip_stream);
+int ec_eddsa_verify_batch_dev(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const void *d_pubkeys,
+			      const void *d_sigs, const void *d_hram, uint32_t hram_len, void *d_result,
+			      void *hip_stream);
+int ec_xdh_batch_dev(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const void *d_k, const void *d_u,
+		     void *d_out, void *d_status, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,7 @@ EXPORTED_SYMBOLS = [
     "ecamd_curve_coord_len", "ecamd_curve_order_len", "ecamd_curve_words", "ec_prj_pt_mul_batch",
     "ec_prj_pt_mul_batch_dev", "ecamd_ctx_synchronize", "ec_prj_pt_add_batch", "ec_prj_pt_dbl_batch",
     "ec_fp_op_batch", "ec_ecdsa_verify_batch", "ec_ecdsa_sign_batch", "ec_ecccdh_derive_batch", "ec_xdh_batch",
-    "ec_eddsa_verify_batch",
+    "ec_eddsa_verify_batch", "ec_ecdsa_verify_batch_dev", "ec_eddsa_verify_batch_dev", "ec_xdh_batch_dev",
 ]
 
 
@@ -62,6 +62,9 @@ def load_library():
         L.ec_ecdsa_sign_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p, u8p]
         L.ec_xdh_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
         L.ec_eddsa_verify_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p]
+        L.ec_ecdsa_verify_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp]
+        L.ec_eddsa_verify_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp]
+        L.ec_xdh_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp]
         L.ec_ecccdh_derive_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
         _LIB = L
     return _LIB
@@ -208,3 +211,16 @@ class Curve:
         _chk(self.L, self.L.ec_eddsa_verify_batch(self.ctx.h, self.h, n, pubkeys, sigs, hram, hram_len, res),
              "ec_eddsa_verify_batch")
         return res.raw[:n]
+
+    # -- device-pointer forms (torch tensors' data_ptr()); see include/libecc_amd.h for which ones synchronise --
+    def ecdsa_verify_dev(self, n, d_pubs, d_sigs, d_digests, hlen, d_result, stream=None):
+        _chk(self.L, self.L.ec_ecdsa_verify_batch_dev(self.ctx.h, self.h, n, d_pubs, d_sigs, d_digests, hlen, d_result,
+                                                       stream), "ec_ecdsa_verify_batch_dev")
+
+    def eddsa_verify_dev(self, n, d_pubs, d_sigs, d_hram, d_result, stream=None, hram_len=64):
+        _chk(self.L, self.L.ec_eddsa_verify_batch_dev(self.ctx.h, self.h, n, d_pubs, d_sigs, d_hram, hram_len, d_result,
+                                                       stream), "ec_eddsa_verify_batch_dev")
+
+    def xdh_dev(self, n, d_k, d_u, d_out, d_status, stream=None):
+        _chk(self.L, self.L.ec_xdh_batch_dev(self.ctx.h, self.h, n, d_k, d_u, d_out, d_status, stream),
+             "ec_xdh_batch_dev")

@@ -973,27 +973,23 @@ extern "C" int ec_fp_op_batch(ecamd_ctx *ctx, const ecamd_curve *cv, int op, uin
 // ------------------------------------------------------------------------------------------
 // batched ECDSA verification (digest supplied by the caller)
 // ------------------------------------------------------------------------------------------
-// the reference's structure: two independent scalar multiplications and one addition per item
-static int ecdsa_verify_two_smul(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys,
-				 const uint8_t *sigs, const uint8_t *digests, uint32_t hlen, uint8_t *result)
+// The reference's structure: two independent scalar multiplications and one addition per item.
+// All pointers are device pointers; intermediates live in stage[3..11].
+static int ecdsa_two_smul_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_pub,
+			      const uint8_t *d_sig, const uint8_t *d_dig, uint32_t hlen, uint8_t *d_res, hipStream_t s)
 {
-	const size_t plen = (size_t)2 * cv->clen, slen2 = (size_t)2 * cv->qlen, ql = (size_t)cv->qlen;
-	// stage: 0 pub, 1 sig, 2 digest, 3 u1, 4 u2, 5 A, 6 B, 7 stA, 8 stB, 9 flags, 10 result, 11 q scalar / tmp
-	const size_t need[ECAMD_NSTAGE] = {n * plen, n * slen2, (size_t)n * hlen, n * ql, n * ql, n * plen,
-					   n * plen, n, n, n, n, n * plen + 256};
-	for (int i = 0; i < ECAMD_NSTAGE; i++) {
+	const size_t plen = (size_t)2 * cv->clen, ql = (size_t)cv->qlen;
+	// stage: 3 u1, 4 u2, 5 A, 6 B, 7 stA, 8 stB, 9 flags, 10 subgroup status, 11 q scalar / tmp
+	const size_t need[12] = {0, 0, 0, n * ql, n * ql, n * plen, n * plen, n, n, n, n, n * plen + 256};
+	for (int i = 3; i < 12; i++) {
 		if (ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
 			return -1;
 		}
 	}
 	uint8_t **S = ctx->stage;
-	hipStream_t s = ctx->stream;
-	HIPCHK(hipMemcpyAsync(S[0], pubkeys, n * plen, hipMemcpyHostToDevice, s));
-	HIPCHK(hipMemcpyAsync(S[1], sigs, n * slen2, hipMemcpyHostToDevice, s));
-	HIPCHK(hipMemcpyAsync(S[2], digests, (size_t)n * hlen, hipMemcpyHostToDevice, s));
 	EcamdEcdsaPrepArgs P;
-	P.sigs = S[1];
-	P.digests = S[2];
+	P.sigs = d_sig;
+	P.digests = d_dig;
 	P.u1 = S[3];
 	P.u2 = S[4];
 	P.flags = S[9];
@@ -1005,7 +1001,7 @@ static int ecdsa_verify_two_smul(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t
 	HIPCHK(ecamd_launch_ecdsa_prep(cv->nw, P, s));
 	// uG and vY: two independent prj_pt_mul, as in the reference (sig/ecdsa_common.c:788,793)
 	if (smul_dev_locked(ctx, cv, n, S[3], (uint32_t)cv->qlen, nullptr, S[5], S[7], s) ||
-	    smul_dev_locked(ctx, cv, n, S[4], (uint32_t)cv->qlen, S[0], S[6], S[8], s)) {
+	    smul_dev_locked(ctx, cv, n, S[4], (uint32_t)cv->qlen, d_pub, S[6], S[8], s)) {
 		return -1;
 	}
 	if (big_cmp(cv->order, cv->q) != 0) {
@@ -1017,7 +1013,7 @@ static int ecdsa_verify_two_smul(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t
 		uint8_t *qs = S[11] + n * plen;
 		HIPCHK(hipMemcpyAsync(qs, qb.data(), ql, hipMemcpyHostToDevice, s));
 		HIPCHK(hipStreamSynchronize(s));
-		if (smul_dev_locked(ctx, cv, n, qs, (uint32_t)ql, S[0], S[11], S[10], s, 0)) {
+		if (smul_dev_locked(ctx, cv, n, qs, (uint32_t)ql, d_pub, S[11], S[10], s, 0)) {
 			return -1;
 		}
 		// S[10] holds 2 (infinity) for keys in the subgroup; anything else rejects: fold into stB
@@ -1038,9 +1034,9 @@ static int ecdsa_verify_two_smul(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t
 	Fn.stA = S[7];
 	Fn.B = S[6];
 	Fn.stB = S[8];
-	Fn.sigs = S[1];
+	Fn.sigs = d_sig;
 	Fn.flags = S[9];
-	Fn.result = S[10];
+	Fn.result = d_res;
 	Fn.n = n;
 	Fn.clen = (uint32_t)cv->clen;
 	Fn.qlen = (uint32_t)cv->qlen;
@@ -1059,31 +1055,19 @@ static int ecdsa_verify_two_smul(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t
 	}
 	Fn.slot = cv->slot;
 	HIPCHK(ecamd_launch_ecdsa_fin(cv->nw, Fn, s));
-	HIPCHK(hipMemcpyAsync(result, S[10], n, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
 	return 0;
 }
 
-
-extern "C" int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys,
-				     const uint8_t *sigs, const uint8_t *digests, uint32_t hlen, uint8_t *result)
+// device pointers in and out; returns with the results complete (the stream is synchronised)
+static int ecdsa_verify_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_pub,
+				   const uint8_t *d_sig, const uint8_t *d_dig, uint32_t hlen, uint8_t *d_res, hipStream_t s)
 {
-	if (!ctx || !cv || cv->ctx != ctx || (n && (!pubkeys || !sigs || !digests || !result))) {
-		return fail("ec_ecdsa_verify_batch: bad argument");
-	}
-	if (cv->qslot < 0) {
-		return fail("ec_ecdsa_verify_batch: generator order not supported for this curve");
-	}
-	if (hlen == 0 || hlen > 128) {
-		return fail("ec_ecdsa_verify_batch: digest length must be in 1..128");
-	}
-	if (n == 0) {
-		return 0;
-	}
-	std::lock_guard<std::mutex> lk(ctx->mu);
-	HIPCHK(hipSetDevice(ctx->device));
 	if (!cv->is_p256 || !cv->d_gtab) {
-		return ecdsa_verify_two_smul(ctx, cv, n, pubkeys, sigs, digests, hlen, result);
+		if (ecdsa_two_smul_dev(ctx, cv, n, d_pub, d_sig, d_dig, hlen, d_res, s)) {
+			return -1;
+		}
+		HIPCHK(hipStreamSynchronize(s));
+		return 0;
 	}
 	// secp256r1: interleaved [u1]G + [u2]Q loop (ecamd_launch_verify_p256), in chunks
 	const uint32_t chunk = n < ctx->max_chunk ? n : ctx->max_chunk;
@@ -1095,24 +1079,19 @@ extern "C" int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint
 			return -1;
 		}
 	}
-	const size_t need[8] = {(size_t)chunk * 64, (size_t)chunk * 64, (size_t)chunk * hlen, (size_t)chunk * 32,
-				(size_t)chunk * 32, chunk, chunk, (size_t)chunk * 64 + chunk};
-	for (int i = 0; i < 8; i++) {
+	// stage: 3 u1, 4 u2, 5 flags, 7 zeroed points of rejected keys + key status
+	const size_t need[8] = {0, 0, 0, (size_t)chunk * 32, (size_t)chunk * 32, chunk, 0, (size_t)chunk * 64 + chunk};
+	for (int i = 3; i < 8; i++) {
 		if (ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
 			return -1;
 		}
 	}
 	uint8_t **S = ctx->stage;
-	hipStream_t s = ctx->stream;
-	std::vector<uint32_t> redo;
 	for (uint32_t off = 0; off < n; off += chunk) {
 		const uint32_t m = (n - off) < chunk ? (n - off) : chunk;
-		HIPCHK(hipMemcpyAsync(S[0], pubkeys + (size_t)off * 64, (size_t)m * 64, hipMemcpyHostToDevice, s));
-		HIPCHK(hipMemcpyAsync(S[1], sigs + (size_t)off * 64, (size_t)m * 64, hipMemcpyHostToDevice, s));
-		HIPCHK(hipMemcpyAsync(S[2], digests + (size_t)off * hlen, (size_t)m * hlen, hipMemcpyHostToDevice, s));
 		EcamdEcdsaPrepArgs P;
-		P.sigs = S[1];
-		P.digests = S[2];
+		P.sigs = d_sig + (size_t)off * 64;
+		P.digests = d_dig + (size_t)off * hlen;
 		P.u1 = S[3];
 		P.u2 = S[4];
 		P.flags = S[5];
@@ -1124,7 +1103,7 @@ extern "C" int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint
 		HIPCHK(ecamd_launch_ecdsa_prep(cv->nw, P, s));
 		EcamdSmulArgs K;
 		memset(&K, 0, sizeof(K));
-		K.points = S[0];
+		K.points = d_pub + (size_t)off * 64;
 		K.pstride = 64;
 		K.out = S[7];           // zeroed for rejected keys; otherwise unused
 		K.status = S[7] + (size_t)m * 64;
@@ -1132,32 +1111,107 @@ extern "C" int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint
 		K.n = m;
 		K.clen = 32;
 		K.slot = cv->slot;
-		HIPCHK(ecamd_launch_verify_p256(K, S[3], S[4], S[1], S[5], cv->d_gtab, cv->qdig, S[6], s));
-		HIPCHK(hipMemcpyAsync(result + off, S[6], m, hipMemcpyDeviceToHost, s));
-		HIPCHK(hipStreamSynchronize(s));
-		for (uint32_t i = 0; i < m; i++) {
-			if (result[off + i] == ECAMD_STATUS_REDO) {
-				redo.push_back(off + i);
-			}
+		HIPCHK(ecamd_launch_verify_p256(K, S[3], S[4], d_sig + (size_t)off * 64, S[5], cv->d_gtab, cv->qdig,
+						d_res + off, s));
+	}
+	// exceptional pairs inside the interleaved loop (never for honest signatures) come back as
+	// ECAMD_STATUS_REDO: re-verify those items the reference's way
+	std::vector<uint8_t> hres(n);
+	HIPCHK(hipMemcpyAsync(hres.data(), d_res, n, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	std::vector<uint32_t> redo;
+	for (uint32_t i = 0; i < n; i++) {
+		if (hres[i] == ECAMD_STATUS_REDO) {
+			redo.push_back(i);
 		}
 	}
 	if (!redo.empty()) {
-		// exceptional pairs inside the interleaved loop (never for honest signatures): re-verify those
-		// items the reference's way
 		const uint32_t r = (uint32_t)redo.size();
-		std::vector<uint8_t> pk((size_t)r * 64), sg((size_t)r * 64), dg((size_t)r * hlen), res(r);
-		for (uint32_t j = 0; j < r; j++) {
-			memcpy(&pk[(size_t)j * 64], pubkeys + (size_t)redo[j] * 64, 64);
-			memcpy(&sg[(size_t)j * 64], sigs + (size_t)redo[j] * 64, 64);
-			memcpy(&dg[(size_t)j * hlen], digests + (size_t)redo[j] * hlen, hlen);
+		const size_t gneed[4] = {(size_t)r * 64, (size_t)r * 64, (size_t)r * hlen, r};
+		for (int i = 0; i < 4; i++) {
+			if (ensure(&ctx->stage[13 + i], &ctx->stage_bytes[13 + i], gneed[i])) {
+				return -1;
+			}
 		}
-		if (ecdsa_verify_two_smul(ctx, cv, r, pk.data(), sg.data(), dg.data(), hlen, res.data())) {
+		for (uint32_t j = 0; j < r; j++) {
+			HIPCHK(hipMemcpyAsync(S[13] + (size_t)j * 64, d_pub + (size_t)redo[j] * 64, 64, hipMemcpyDeviceToDevice, s));
+			HIPCHK(hipMemcpyAsync(S[14] + (size_t)j * 64, d_sig + (size_t)redo[j] * 64, 64, hipMemcpyDeviceToDevice, s));
+			HIPCHK(hipMemcpyAsync(S[15] + (size_t)j * hlen, d_dig + (size_t)redo[j] * hlen, hlen, hipMemcpyDeviceToDevice, s));
+		}
+		if (ecdsa_two_smul_dev(ctx, cv, r, S[13], S[14], S[15], hlen, S[16], s)) {
 			return -1;
 		}
 		for (uint32_t j = 0; j < r; j++) {
-			result[redo[j]] = res[j];
+			HIPCHK(hipMemcpyAsync(d_res + redo[j], S[16] + j, 1, hipMemcpyDeviceToDevice, s));
 		}
+		HIPCHK(hipStreamSynchronize(s));
 	}
+	return 0;
+}
+
+static int ecdsa_verify_args_ok(const char *fn, ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const void *a,
+				const void *b, const void *c, const void *d, uint32_t hlen)
+{
+	static thread_local char msg[160];
+	if (!ctx || !cv || cv->ctx != ctx || (n && (!a || !b || !c || !d))) {
+		snprintf(msg, sizeof(msg), "%s: bad argument", fn);
+		return fail(msg);
+	}
+	if (cv->qslot < 0) {
+		snprintf(msg, sizeof(msg), "%s: generator order not supported for this curve", fn);
+		return fail(msg);
+	}
+	if (hlen == 0 || hlen > 128) {
+		snprintf(msg, sizeof(msg), "%s: digest length must be in 1..128", fn);
+		return fail(msg);
+	}
+	return 0;
+}
+
+extern "C" int ec_ecdsa_verify_batch_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const void *d_pubkeys,
+					 const void *d_sigs, const void *d_digests, uint32_t hlen, void *d_result,
+					 void *hip_stream)
+{
+	if (ecdsa_verify_args_ok("ec_ecdsa_verify_batch_dev", ctx, cv, n, d_pubkeys, d_sigs, d_digests, d_result, hlen)) {
+		return -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+	return ecdsa_verify_dev_locked(ctx, cv, n, (const uint8_t *)d_pubkeys, (const uint8_t *)d_sigs,
+				       (const uint8_t *)d_digests, hlen, (uint8_t *)d_result, s);
+}
+
+extern "C" int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys,
+				     const uint8_t *sigs, const uint8_t *digests, uint32_t hlen, uint8_t *result)
+{
+	if (ecdsa_verify_args_ok("ec_ecdsa_verify_batch", ctx, cv, n, pubkeys, sigs, digests, result, hlen)) {
+		return -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t plen = (size_t)2 * cv->clen, slen2 = (size_t)2 * cv->qlen;
+	// stage: 0 pubkeys, 1 signatures, 2 digests, 12 results (3..11 and 13..16 belong to the device core)
+	if (ensure(&ctx->stage[0], &ctx->stage_bytes[0], n * plen) || ensure(&ctx->stage[1], &ctx->stage_bytes[1], n * slen2) ||
+	    ensure(&ctx->stage[2], &ctx->stage_bytes[2], (size_t)n * hlen) || ensure(&ctx->stage[12], &ctx->stage_bytes[12], n)) {
+		return -1;
+	}
+	uint8_t **S = ctx->stage;
+	hipStream_t s = ctx->stream;
+	HIPCHK(hipMemcpyAsync(S[0], pubkeys, n * plen, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(S[1], sigs, n * slen2, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(S[2], digests, (size_t)n * hlen, hipMemcpyHostToDevice, s));
+	if (ecdsa_verify_dev_locked(ctx, cv, n, S[0], S[1], S[2], hlen, S[12], s)) {
+		return -1;
+	}
+	HIPCHK(hipMemcpyAsync(result, S[12], n, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
 	return 0;
 }
 
@@ -1390,41 +1444,25 @@ static void xdh_setup(ecamd_curve *cv)
 	cv->xdh_state = 1;
 }
 
-extern "C" int ec_xdh_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const uint8_t *k, const uint8_t *u,
-			    uint8_t *out, uint8_t *status)
+// device pointers in and out; only enqueues on s
+static int xdh_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_k, const uint8_t *d_u,
+			  uint8_t *d_out, uint8_t *d_status, hipStream_t s)
 {
-	if (!ctx || !cv_in || cv_in->ctx != ctx || (n && (!k || !u || !out || !status))) {
-		return fail("ec_xdh_batch: bad argument");
-	}
-	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
-	std::lock_guard<std::mutex> lk(ctx->mu);
-	if (cv->xdh_state == 0) {
-		xdh_setup(cv);
-	}
-	if (cv->xdh_state < 0) {
-		return fail(cv->xdh_err);
-	}
-	if (n == 0) {
-		return 0;
-	}
-	HIPCHK(hipSetDevice(ctx->device));
 	const size_t len = (size_t)cv->clen, plen = 2 * len;
-	// stage: 0 k, 1 u, 2 scalars BE, 3 points, 4 flags, 5 tmp points ([h]Q), 6 st8, 7 [k]Q, 8 stk, 9 out, 10 status, 11 h
-	const size_t need[ECAMD_NSTAGE] = {n * len, n * len, n * len, n * plen, n, n * plen, n, n * plen, n, n * len, n, 64};
+	// stage: 2 scalars BE, 3 points, 4 flags, 5 tmp points ([h]Q), 6 st8, 7 [k]Q, 8 stk, 11 h
+	//        (0, 1, 9, 10 belong to the host-pointer wrapper)
+	const size_t need[ECAMD_NSTAGE] = {0, 0, n * len, n * plen, n, n * plen, n, n * plen, n, 0, 0, 64};
 	for (int i = 0; i < ECAMD_NSTAGE; i++) {
 		if (ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
 			return -1;
 		}
 	}
 	uint8_t **S = ctx->stage;
-	hipStream_t s = ctx->stream;
-	HIPCHK(hipMemcpyAsync(S[0], k, n * len, hipMemcpyHostToDevice, s));
-	HIPCHK(hipMemcpyAsync(S[1], u, n * len, hipMemcpyHostToDevice, s));
-	HIPCHK(hipMemcpyAsync(S[11], &cv->xdh_cof, 1, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(S[11], &cv->xdh_cof, 1, hipMemcpyHostToDevice, s));  // lives in the curve handle
 	const int nw = cv->nw;
 	EcamdXdhPrepArgs P = cv->xdh_tmpl;
-	P.k = S[0];
-	P.u = S[1];
+	P.k = d_k;
+	P.u = d_u;
 	P.scalars = S[2];
 	P.points = S[3];
 	P.flags = S[4];
@@ -1441,13 +1479,78 @@ extern "C" int ec_xdh_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n
 	Fn.st8 = S[6];
 	Fn.stk = S[8];
 	Fn.flags = S[4];
-	Fn.out = S[9];
-	Fn.status = S[10];
+	Fn.out = d_out;
+	Fn.status = d_status;
 	Fn.n = n;
 	Fn.len = (uint32_t)len;
 	memcpy(Fn.A3, cv->xdh_A3, sizeof(Fn.A3));
 	Fn.slot = cv->slot;
 	HIPCHK(ecamd_launch_xdh_fin(nw, Fn, s));
+	return 0;
+}
+
+static int xdh_args_ok(const char *fn, ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const void *a, const void *b,
+		       const void *c, const void *d)
+{
+	if (!ctx || !cv_in || cv_in->ctx != ctx || (n && (!a || !b || !c || !d))) {
+		return fail(std::string(fn) + ": bad argument");
+	}
+	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
+	if (cv->xdh_state == 0) {
+		xdh_setup(cv);
+	}
+	if (cv->xdh_state < 0) {
+		return fail(cv->xdh_err);
+	}
+	return 0;
+}
+
+extern "C" int ec_xdh_batch_dev(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const void *d_k, const void *d_u,
+				void *d_out, void *d_status, void *hip_stream)
+{
+	if (!ctx) {
+		return fail("ec_xdh_batch_dev: bad argument");
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (xdh_args_ok("ec_xdh_batch_dev", ctx, cv_in, n, d_k, d_u, d_out, d_status)) {
+		return -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	HIPCHK(hipSetDevice(ctx->device));
+	hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+	return xdh_dev_locked(ctx, const_cast<ecamd_curve *>(cv_in), n, (const uint8_t *)d_k, (const uint8_t *)d_u,
+			      (uint8_t *)d_out, (uint8_t *)d_status, s);
+}
+
+extern "C" int ec_xdh_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const uint8_t *k, const uint8_t *u,
+			    uint8_t *out, uint8_t *status)
+{
+	if (!ctx) {
+		return fail("ec_xdh_batch: bad argument");
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (xdh_args_ok("ec_xdh_batch", ctx, cv_in, n, k, u, out, status)) {
+		return -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	HIPCHK(hipSetDevice(ctx->device));
+	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
+	const size_t len = (size_t)cv->clen;
+	if (ensure(&ctx->stage[0], &ctx->stage_bytes[0], n * len) || ensure(&ctx->stage[1], &ctx->stage_bytes[1], n * len) ||
+	    ensure(&ctx->stage[9], &ctx->stage_bytes[9], n * len) || ensure(&ctx->stage[10], &ctx->stage_bytes[10], n)) {
+		return -1;
+	}
+	uint8_t **S = ctx->stage;
+	hipStream_t s = ctx->stream;
+	HIPCHK(hipMemcpyAsync(S[0], k, n * len, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(S[1], u, n * len, hipMemcpyHostToDevice, s));
+	if (xdh_dev_locked(ctx, cv, n, S[0], S[1], S[9], S[10], s)) {
+		return -1;
+	}
 	HIPCHK(hipMemcpyAsync(out, S[9], n * len, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipMemcpyAsync(status, S[10], n, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
@@ -1555,63 +1658,41 @@ static void ed_setup(ecamd_curve *cv)
 	cv->ed_state = 1;
 }
 
-extern "C" int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const uint8_t *pubkeys,
-				     const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, uint8_t *result)
+// device pointers in and out; only enqueues on s
+static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig,
+				   const uint8_t *d_hram, uint32_t hram_len, uint8_t *d_res, hipStream_t s)
 {
-	if (!ctx || !cv_in || cv_in->ctx != ctx || (n && (!pubkeys || !sigs || !hram || !result))) {
-		return fail("ec_eddsa_verify_batch: bad argument");
-	}
-	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
-	std::lock_guard<std::mutex> lk(ctx->mu);
-	if (cv->ed_state == 0) {
-		ed_setup(cv);
-	}
-	if (cv->ed_state < 0) {
-		return fail(cv->ed_err);
-	}
-	if (hram_len != 64) {
-		return fail("ec_eddsa_verify_batch: Ed25519 hashes with SHA-512: hram_len must be 64");
-	}
-	if (n == 0) {
-		return 0;
-	}
-	HIPCHK(hipSetDevice(ctx->device));
 	const size_t len = 32, plen = 64;
 	const uint32_t cof_dbl = cv->ed_cof_dbl;
-	// stage: 0 pubkeys, 1 sigs, 2 hram, 3 A (Weierstrass), 4 R, 5 flagsA, 6 flagsR, 7 flagsS, 8 S, 9 h,
-	//        10 [8]A, 11 st8, 12 [h]A, 13 sthA, 14 [S]G, 15 stSG, 16 result, 17 cofactor scalar
-	const size_t need[ECAMD_NSTAGE] = {n * len, n * plen, (size_t)n * hram_len, n * plen, n * plen, n, n, n, n * len, n * len,
-					   n * plen, n, n * plen, n, n * plen, n, n, 64};
+	// stage: 3 A (Weierstrass), 4 R, 5 flagsA, 6 flagsR, 7 flagsS, 8 S, 9 h, 10 [8]A, 11 st8, 12 [h]A, 13 sthA,
+	//        14 [S]G, 15 stSG, 17 cofactor scalar   (0..2 and 16 belong to the host-pointer wrapper)
+	const size_t need[ECAMD_NSTAGE] = {0, 0, 0, n * plen, n * plen, n, n, n, n * len, n * len,
+					   n * plen, n, n * plen, n, n * plen, n, 0, 64};
 	for (int i = 0; i < ECAMD_NSTAGE; i++) {
 		if (ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
 			return -1;
 		}
 	}
 	uint8_t **S = ctx->stage;
-	hipStream_t s = ctx->stream;
-	HIPCHK(hipMemcpyAsync(S[0], pubkeys, n * len, hipMemcpyHostToDevice, s));
-	HIPCHK(hipMemcpyAsync(S[1], sigs, n * plen, hipMemcpyHostToDevice, s));
-	HIPCHK(hipMemcpyAsync(S[2], hram, (size_t)n * hram_len, hipMemcpyHostToDevice, s));
-	const uint8_t cofb = (uint8_t)(1u << cof_dbl);
-	HIPCHK(hipMemcpyAsync(S[17], &cofb, 1, hipMemcpyHostToDevice, s));
-	HIPCHK(hipStreamSynchronize(s));  // cofb lives on this stack frame
+	static const uint8_t cof_bytes[5] = {1, 2, 4, 8, 16};  // static storage: the async copy may outlive this frame
+	HIPCHK(hipMemcpyAsync(S[17], &cof_bytes[cof_dbl], 1, hipMemcpyHostToDevice, s));
 	const int nw = cv->nw;
 	EcamdEdDecodeArgs D = cv->ed_tmpl;
 	D.n = n;
-	D.enc = S[0];
+	D.enc = d_pub;
 	D.estride = (uint32_t)len;
 	D.points = S[3];
 	D.flags = S[5];
 	HIPCHK(ecamd_launch_ed_decode(nw, D, s));
-	D.enc = S[1];
+	D.enc = d_sig;
 	D.estride = (uint32_t)plen;
 	D.points = S[4];
 	D.flags = S[6];
 	HIPCHK(ecamd_launch_ed_decode(nw, D, s));
 	EcamdEdScalArgs C;
 	memset(&C, 0, sizeof(C));
-	C.sigs = S[1];
-	C.hram = S[2];
+	C.sigs = d_sig;
+	C.hram = d_hram;
 	C.S_be = S[8];
 	C.h_be = S[9];
 	C.flags = S[7];
@@ -1637,12 +1718,82 @@ extern "C" int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, u
 	F.flagsR = S[6];
 	F.flagsS = S[7];
 	F.st8 = S[11];
-	F.result = S[16];
+	F.result = d_res;
 	F.n = n;
 	F.clen = (uint32_t)len;
 	F.cof_dbl = cof_dbl;
 	F.slot = cv->slot;
 	HIPCHK(ecamd_launch_ed_fin(nw, F, s));
+	return 0;
+}
+
+static int eddsa_args_ok(const char *fn, ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const void *a, const void *b,
+			 const void *c, const void *d, uint32_t hram_len)
+{
+	if (!ctx || !cv_in || cv_in->ctx != ctx || (n && (!a || !b || !c || !d))) {
+		return fail(std::string(fn) + ": bad argument");
+	}
+	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
+	if (cv->ed_state == 0) {
+		ed_setup(cv);
+	}
+	if (cv->ed_state < 0) {
+		return fail(cv->ed_err);
+	}
+	if (hram_len != 64) {
+		return fail(std::string(fn) + ": Ed25519 hashes with SHA-512: hram_len must be 64");
+	}
+	return 0;
+}
+
+extern "C" int ec_eddsa_verify_batch_dev(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const void *d_pubkeys,
+					 const void *d_sigs, const void *d_hram, uint32_t hram_len, void *d_result,
+					 void *hip_stream)
+{
+	if (!ctx) {
+		return fail("ec_eddsa_verify_batch_dev: bad argument");
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (eddsa_args_ok("ec_eddsa_verify_batch_dev", ctx, cv_in, n, d_pubkeys, d_sigs, d_hram, d_result, hram_len)) {
+		return -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	HIPCHK(hipSetDevice(ctx->device));
+	hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+	return eddsa_verify_dev_locked(ctx, const_cast<ecamd_curve *>(cv_in), n, (const uint8_t *)d_pubkeys,
+				       (const uint8_t *)d_sigs, (const uint8_t *)d_hram, hram_len, (uint8_t *)d_result, s);
+}
+
+extern "C" int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const uint8_t *pubkeys,
+				     const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, uint8_t *result)
+{
+	if (!ctx) {
+		return fail("ec_eddsa_verify_batch: bad argument");
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (eddsa_args_ok("ec_eddsa_verify_batch", ctx, cv_in, n, pubkeys, sigs, hram, result, hram_len)) {
+		return -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	HIPCHK(hipSetDevice(ctx->device));
+	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
+	const size_t len = 32, plen = 64;
+	if (ensure(&ctx->stage[0], &ctx->stage_bytes[0], n * len) || ensure(&ctx->stage[1], &ctx->stage_bytes[1], n * plen) ||
+	    ensure(&ctx->stage[2], &ctx->stage_bytes[2], (size_t)n * hram_len) || ensure(&ctx->stage[16], &ctx->stage_bytes[16], n)) {
+		return -1;
+	}
+	uint8_t **S = ctx->stage;
+	hipStream_t s = ctx->stream;
+	HIPCHK(hipMemcpyAsync(S[0], pubkeys, n * len, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(S[1], sigs, n * plen, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(S[2], hram, (size_t)n * hram_len, hipMemcpyHostToDevice, s));
+	if (eddsa_verify_dev_locked(ctx, cv, n, S[0], S[1], S[2], hram_len, S[16], s)) {
+		return -1;
+	}
 	HIPCHK(hipMemcpyAsync(result, S[16], n, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
 	return 0;

@@ -640,3 +640,81 @@ def test_eddsa_verify_rejects_other_curves(gpu_ctx):
             cv.eddsa_verify(bytes(32), bytes(64), bytes(64))
     finally:
         cv.free()
+
+
+def test_device_pointer_entry_points(gpu_ctx):
+    """the *_dev forms (buffers already in HBM, caller's stream) give the same bytes as the host-pointer
+    forms: scalar mult, ECDSA verify (interleaved secp256r1 loop incl. exceptional items, and the
+    two-scalar-mult path of another curve), Ed25519 verify, X25519"""
+    import torch
+    from test_oracle import ed25519_cases
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(35)
+    stream = torch.cuda.Stream(device=dev)
+
+    def t(b):
+        return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+
+    def empty(n):
+        return torch.full((n,), 0xAA, dtype=torch.uint8, device=dev)
+
+    for curve, h in (("SECP256R1", "SHA256"), ("BRAINPOOLP256R1", "SHA256")):
+        n = 96
+        o, pubs, sigs, dg, hl, _ = make_sigs(curve, h, n, rng)
+        sigs = bytearray(sigs)
+        sigs[5 * 2 * o.qlen + 2] ^= 4
+        sigs = bytes(sigs)
+        if curve == "SECP256R1":
+            # items that leave the interleaved loop through the exceptional-pair path (Q = G, u1 == u2)
+            c = CURVES[curve]
+            q = c["q"]
+            G = c["gx"].to_bytes(32, "big") + c["gy"].to_bytes(32, "big")
+            for k in (7, q - 5):
+                kG, _ = o.scalar_mult(k.to_bytes(32, "big"))
+                r = int.from_bytes(kG[:32], "big") % q
+                s = pow(k, q - 2, q) * (2 * r) % q
+                pubs += G
+                sigs += r.to_bytes(32, "big") + s.to_bytes(32, "big")
+                dg += r.to_bytes(32, "big")
+            n += 2
+        cv = gpu_ctx.curve(curve)
+        try:
+            exp = cv.ecdsa_verify(pubs, sigs, dg, hl)
+            assert exp == o.ecdsa_verify(pubs, sigs, dg, hl) and exp[5] == 1 and exp[0] == 0
+            dp, ds, dd, dr = t(pubs), t(sigs), t(dg), empty(n)
+            torch.cuda.synchronize()
+            cv.ecdsa_verify_dev(n, dp.data_ptr(), ds.data_ptr(), dd.data_ptr(), hl, dr.data_ptr(), stream.cuda_stream)
+            assert bytes(dr.cpu().numpy()) == exp
+            # scalar multiplication on the caller's stream
+            sc = rand_bytes(rng, n * o.qlen)
+            e_out, e_st = cv.scalar_mult(sc, pubs[:n * 2 * o.clen])
+            dsc, dout, dst = t(sc), empty(n * 2 * o.clen), empty(n)
+            torch.cuda.synchronize()
+            cv.scalar_mult_dev(n, dsc.data_ptr(), o.qlen, dp.data_ptr(), dout.data_ptr(), dst.data_ptr(), stream.cuda_stream)
+            stream.synchronize()
+            assert (bytes(dout.cpu().numpy()), bytes(dst.cpu().numpy())) == (e_out, e_st)
+        finally:
+            cv.free()
+    cv = gpu_ctx.curve("WEI25519")
+    try:
+        pubs, sigs, msgs, hram = ed25519_cases(rng, nvalid=20)
+        n = len(pubs) // 32
+        exp = cv.eddsa_verify(pubs, sigs, hram)
+        assert 0 in exp and 1 in exp
+        dp, ds, dh, dr = t(pubs), t(sigs), t(hram), empty(n)
+        torch.cuda.synchronize()
+        cv.eddsa_verify_dev(n, dp.data_ptr(), ds.data_ptr(), dh.data_ptr(), dr.data_ptr(), stream.cuda_stream)
+        stream.synchronize()
+        assert bytes(dr.cpu().numpy()) == exp
+        n = 200
+        k, base = rand_bytes(rng, 32 * n), (9).to_bytes(32, "little") * n
+        pub, st = cv.xdh(k, base)
+        k2 = rand_bytes(rng, 32 * n)
+        exp = cv.xdh(k2, pub)
+        dk, du, dout, dst = t(k2), t(pub), empty(32 * n), empty(n)
+        torch.cuda.synchronize()
+        cv.xdh_dev(n, dk.data_ptr(), du.data_ptr(), dout.data_ptr(), dst.data_ptr(), stream.cuda_stream)
+        stream.synchronize()
+        assert (bytes(dout.cpu().numpy()), bytes(dst.cpu().numpy())) == exp
+    finally:
+        cv.free()
