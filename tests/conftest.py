@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+try:
+    # torch first: it brings its own HIP runtime, which must be the one the process initialises when a
+    # test mixes torch device tensors with the library (tests of the *_dev entry points, bench.py order)
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
