@@ -1664,30 +1664,28 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 {
 	const size_t len = 32, plen = 64;
 	const uint32_t cof_dbl = cv->ed_cof_dbl;
-	// stage: 3 A (Weierstrass), 4 R, 5 flagsA, 6 flagsR, 7 flagsS, 8 S, 9 h, 10 [8]A, 11 st8, 12 [h]A, 13 sthA,
-	//        14 [S]G, 15 stSG, 17 cofactor scalar   (0..2 and 16 belong to the host-pointer wrapper)
+	// stage: 3 A (Weierstrass), 4 R, 5 flagsA, 6 flagsR, 7 flagsS, 8 S, 9 h, 12 [h]A, 13 sthA, 14 [S]G, 15 stSG
+	//        (0..2 and 16 belong to the host-pointer wrapper)
 	const size_t need[ECAMD_NSTAGE] = {0, 0, 0, n * plen, n * plen, n, n, n, n * len, n * len,
-					   n * plen, n, n * plen, n, n * plen, n, 0, 64};
+					   0, 0, n * plen, n, n * plen, n, 0, 0};
 	for (int i = 0; i < ECAMD_NSTAGE; i++) {
 		if (ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
 			return -1;
 		}
 	}
 	uint8_t **S = ctx->stage;
-	static const uint8_t cof_bytes[5] = {1, 2, 4, 8, 16};  // static storage: the async copy may outlive this frame
-	HIPCHK(hipMemcpyAsync(S[17], &cof_bytes[cof_dbl], 1, hipMemcpyHostToDevice, s));
 	const int nw = cv->nw;
 	EcamdEdDecodeArgs D = cv->ed_tmpl;
 	D.n = n;
-	D.enc = d_pub;
-	D.estride = (uint32_t)len;
-	D.points = S[3];
-	D.flags = S[5];
-	HIPCHK(ecamd_launch_ed_decode(nw, D, s));
-	D.enc = d_sig;
-	D.estride = (uint32_t)plen;
-	D.points = S[4];
-	D.flags = S[6];
+	D.encA = d_pub;
+	D.strideA = (uint32_t)len;
+	D.encR = d_sig;
+	D.strideR = (uint32_t)plen;
+	D.pointsA = S[3];
+	D.pointsR = S[4];
+	D.flagsA = S[5];
+	D.flagsR = S[6];
+	D.cof_dbl = cof_dbl;
 	HIPCHK(ecamd_launch_ed_decode(nw, D, s));
 	EcamdEdScalArgs C;
 	memset(&C, 0, sizeof(C));
@@ -1701,9 +1699,8 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 	C.hlen = hram_len;
 	C.qslot = cv->qslot;
 	HIPCHK(ecamd_launch_ed_scal(nw, C, s));
-	// [8]A (small-order check), [h]A, [S]G
-	if (smul_dev_locked(ctx, cv, n, S[17], 1, S[3], S[10], S[11], s, 0) ||
-	    smul_dev_locked(ctx, cv, n, S[9], (uint32_t)len, S[3], S[12], S[13], s) ||
+	// [h]A, [S]G  ([8]A != infinity was checked by the decode kernel)
+	if (smul_dev_locked(ctx, cv, n, S[9], (uint32_t)len, S[3], S[12], S[13], s) ||
 	    smul_dev_locked(ctx, cv, n, S[8], (uint32_t)len, nullptr, S[14], S[15], s)) {
 		return -1;
 	}
@@ -1717,7 +1714,6 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 	F.flagsA = S[5];
 	F.flagsR = S[6];
 	F.flagsS = S[7];
-	F.st8 = S[11];
 	F.result = d_res;
 	F.n = n;
 	F.clen = (uint32_t)len;

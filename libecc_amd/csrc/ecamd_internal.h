@@ -108,11 +108,12 @@ hipError_t ecamd_launch_xdh_fin(int nw, const EcamdXdhFinArgs &a, hipStream_t s)
 
 // ---- Ed25519 verification (sig/eddsa.c of the reference) through the Weierstrass model ----
 struct EcamdEdDecodeArgs {
-	const uint8_t *enc;      // n compressed Edwards points: len bytes little-endian y, sign of x in the top bit
-	uint32_t estride;        // bytes between consecutive encodings
-	uint8_t *points;         // out: n x 2*len affine Weierstrass X || Y big-endian
-	uint8_t *flags;          // out: n, 0 ok / 1 the reference's decode / map returns -1
-	uint32_t n, len;
+	const uint8_t *encA;     // n compressed public keys: len bytes little-endian y, sign of x in the top bit
+	const uint8_t *encR;     // n compressed R (first half of each signature)
+	uint32_t strideA, strideR;  // bytes between consecutive encodings
+	uint8_t *pointsA, *pointsR; // out: n x 2*len affine Weierstrass X || Y big-endian
+	uint8_t *flagsA, *flagsR;   // out: n, 0 ok / 1 the reference's decode / map returns -1 (A: or [cofactor]A = infinity)
+	uint32_t n, len, cof_dbl;   // cof_dbl = log2(cofactor)
 	uint32_t a[17], d[17], sm1[17], alpha[17], A3[17];  // Edwards a, d; sqrt(-1); alpha_edwards; A/3 (Montgomery form)
 	int slot;
 };
@@ -129,7 +130,6 @@ struct EcamdEdFinArgs {
 	const uint8_t *hA, *sthA;   // [h]A
 	const uint8_t *R;           // decoded R (Weierstrass affine)
 	const uint8_t *flagsA, *flagsR, *flagsS;
-	const uint8_t *st8;         // status of [8]A: must be 0 (finite)
 	uint8_t *result;            // n: 0 accept / 1 reject
 	uint32_t n, clen, cof_dbl;  // cof_dbl = log2(cofactor)
 	int slot;

@@ -542,15 +542,12 @@ template <int NW> static __device__ Fe<NW> fe_pow_2_250m1(const Fe<NW> &z, Fe<NW
 	return fe_mul<NW>(fe_sqr_n<NW>(a200, 50, slot), a50, slot);                        // 2^250 - 1
 }
 
-template <int NW> __global__ __launch_bounds__(64) void k_ed_decode(EcamdEdDecodeArgs A)
+// x of a compressed point: returns false where the reference's decode / map fails
+template <int NW> static __device__ bool ed_decode_xy(const EcamdEdDecodeArgs &A, const u8 *src, Fe<NW> *xo, Fe<NW> *ymo)
 {
-	const u32 i = blockIdx.x * 64 + threadIdx.x;
-	if (i >= A.n) {
-		return;
-	}
 	const int slot = A.slot;
 	const int len = (int)A.len;
-	Fe<NW> y = fe_load_le<NW>(A.enc + (size_t)i * A.estride, len);
+	Fe<NW> y = fe_load_le<NW>(src, len);
 	const int sbit = 8 * len - 1;
 	const u32 x0 = (y.v[sbit >> 5] >> (sbit & 31)) & 1u;
 	y.v[sbit >> 5] &= ~(1u << (sbit & 31));
@@ -575,20 +572,59 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed_decode(EcamdEdDecod
 	Fe<NW> x = fe_select<NW>(alt & !root, fe_mul<NW>(beta, fe_const<NW>(A.sm1), slot), beta);
 	const Fe<NW> xp = fe_from_mont<NW>(x, slot);
 	x = fe_select<NW>((xp.v[0] & 1u) != x0, fe_sub<NW>(zero, x, slot), x);
-	ok = ok & !fe_is_zero<NW>(x);
-	// (1 - y)^-1 and x^-1 from one inversion
-	const Fe<NW> omy = fe_sub<NW>(one, ym, slot);
-	const Fe<NW> den = fe_mul<NW>(omy, x, slot);
+	ok = ok & !fe_is_zero<NW>(x);  // x = 0: the neutral point is rejected, (0, -1) dies in fp_inv(0)
+	*xo = x;
+	*ymo = ym;
+	return ok;
+}
+
+// One lane decodes the public key A and the signature's R of one item (one shared inversion), maps
+// both to the Weierstrass model and checks [cofactor]A != infinity by doublings, as
+// _prj_pt_unprotected_mult does for the cofactor 8 = 1000b (curves/prj_pt.c:1862-1905).
+template <int NW> __global__ __launch_bounds__(64) void k_ed_decode(EcamdEdDecodeArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int slot = A.slot;
+	const int len = (int)A.len;
+	const Fe<NW> one = fe_const<NW>(ConstTab<NW>::get(slot).one);
+	const Fe<NW> zero = fe_zero<NW>();
+	Fe<NW> x[2], ym[2], omy[2], den[2];
+	bool ok[2];
+	ok[0] = ed_decode_xy<NW>(A, A.encA + (size_t)i * A.strideA, &x[0], &ym[0]);
+	ok[1] = ed_decode_xy<NW>(A, A.encR + (size_t)i * A.strideR, &x[1], &ym[1]);
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		omy[k] = fe_sub<NW>(one, ym[k], slot);
+		den[k] = fe_select<NW>(ok[k], fe_mul<NW>(omy[k], x[k], slot), one);  // (1 - y) x, non-zero when ok
+	}
 	Fe<NW> d11;
-	const Fe<NW> dinv = fe_mul<NW>(fe_sqr_n<NW>(fe_pow_2_250m1<NW>(den, &d11, slot), 5, slot), d11, slot);  // den^(p-2)
-	const Fe<NW> um = fe_mul<NW>(fe_add<NW>(one, ym, slot), fe_mul<NW>(dinv, x, slot), slot);
-	const Fe<NW> vm = fe_mul<NW>(fe_mul<NW>(fe_const<NW>(A.alpha), um, slot), fe_mul<NW>(dinv, omy, slot), slot);
-	const Fe<NW> X = fe_from_mont<NW>(fe_add<NW>(um, fe_const<NW>(A.A3), slot), slot);
-	const Fe<NW> Y = fe_from_mont<NW>(vm, slot);
-	u8 *pd = A.points + (size_t)i * 2 * len;
-	fe_store_be<NW>(pd, len, ok ? X : zero);
-	fe_store_be<NW>(pd + len, len, ok ? Y : zero);
-	A.flags[i] = ok ? 0 : 1;
+	const Fe<NW> dd = fe_mul<NW>(den[0], den[1], slot);
+	const Fe<NW> dinv = fe_mul<NW>(fe_sqr_n<NW>(fe_pow_2_250m1<NW>(dd, &d11, slot), 5, slot), d11, slot);  // dd^(p-2)
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const Fe<NW> inv = fe_mul<NW>(dinv, den[1 - k], slot);                        // 1 / ((1 - y) x)
+		const Fe<NW> um = fe_mul<NW>(fe_add<NW>(one, ym[k], slot), fe_mul<NW>(inv, x[k], slot), slot);
+		const Fe<NW> vm = fe_mul<NW>(fe_mul<NW>(fe_const<NW>(A.alpha), um, slot), fe_mul<NW>(inv, omy[k], slot), slot);
+		const Fe<NW> Xm = fe_add<NW>(um, fe_const<NW>(A.A3), slot);
+		bool good = ok[k];
+		if (k == 0) {
+			Pt<NW> P;
+			P.X = Xm;
+			P.Y = vm;
+			P.Z = one;
+			for (u32 r = 0; r < A.cof_dbl; r++) {
+				P = pt_dbl<NW>(P, slot);
+			}
+			good = good & !fe_is_zero<NW>(P.Z);                                        // small-order key
+		}
+		u8 *pd = (k == 0 ? A.pointsA : A.pointsR) + (size_t)i * 2 * len;
+		fe_store_be<NW>(pd, len, good ? fe_from_mont<NW>(Xm, slot) : zero);
+		fe_store_be<NW>(pd + len, len, good ? fe_from_mont<NW>(vm, slot) : zero);
+		(k == 0 ? A.flagsA : A.flagsR)[i] = good ? 0 : 1;
+	}
 }
 
 // S (second half of the signature, little-endian) must be < q; h = hram (little-endian, up to 2 NW words) mod q
@@ -643,8 +679,8 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed_fin(EcamdEdFinArgs 
 	const int slot = A.slot;
 	const int clen = (int)A.clen;
 	const u32 sSG = A.stSG[i], shA = A.sthA[i];
-	// bad encodings, S >= q, small-order public key ([8]A = infinity), or a failed multiplication
-	if (A.flagsA[i] || A.flagsR[i] || A.flagsS[i] || A.st8[i] != 0 || sSG == 1 || shA == 1) {
+	// bad encodings, small-order public key ([8]A = infinity, folded into flagsA), S >= q, or a failed multiplication
+	if (A.flagsA[i] || A.flagsR[i] || A.flagsS[i] || sSG == 1 || shA == 1) {
 		A.result[i] = 1;
 		return;
 	}
