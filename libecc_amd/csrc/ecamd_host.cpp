@@ -1436,11 +1436,12 @@ static void xdh_setup(ecamd_curve *cv)
 		}
 		t = big_add(t, cv->q);
 	}
-	if (hval == 0) {
+	if (hval != 4 && hval != 8) {
 		cv->xdh_err = "ec_xdh_batch: unexpected cofactor";
 		return;
 	}
 	cv->xdh_cof = (uint8_t)hval;
+	P.cof_dbl = hval == 8 ? 3u : 2u;
 	cv->xdh_state = 1;
 }
 
@@ -1449,16 +1450,14 @@ static int xdh_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uin
 			  uint8_t *d_out, uint8_t *d_status, hipStream_t s)
 {
 	const size_t len = (size_t)cv->clen, plen = 2 * len;
-	// stage: 2 scalars BE, 3 points, 4 flags, 5 tmp points ([h]Q), 6 st8, 7 [k]Q, 8 stk, 11 h
-	//        (0, 1, 9, 10 belong to the host-pointer wrapper)
-	const size_t need[ECAMD_NSTAGE] = {0, 0, n * len, n * plen, n, n * plen, n, n * plen, n, 0, 0, 64};
+	// stage: 2 scalars BE, 3 points, 4 flags, 7 [k]Q, 8 stk   (0, 1, 9, 10 belong to the host-pointer wrapper)
+	const size_t need[ECAMD_NSTAGE] = {0, 0, n * len, n * plen, n, 0, 0, n * plen, n};
 	for (int i = 0; i < ECAMD_NSTAGE; i++) {
 		if (ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
 			return -1;
 		}
 	}
 	uint8_t **S = ctx->stage;
-	HIPCHK(hipMemcpyAsync(S[11], &cv->xdh_cof, 1, hipMemcpyHostToDevice, s));  // lives in the curve handle
 	const int nw = cv->nw;
 	EcamdXdhPrepArgs P = cv->xdh_tmpl;
 	P.k = d_k;
@@ -1468,15 +1467,13 @@ static int xdh_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uin
 	P.flags = S[4];
 	P.n = n;
 	HIPCHK(ecamd_launch_xdh_prep(nw, P, s));
-	// [h]Q with the broadcast scalar h (cofactor), then [k]Q
-	if (smul_dev_locked(ctx, cv, n, S[11], 1, S[3], S[5], S[6], s, 0) ||
-	    smul_dev_locked(ctx, cv, n, S[2], (uint32_t)len, S[3], S[7], S[8], s)) {
+	// [k]Q  ([h]Q != infinity was checked by the prep kernel)
+	if (smul_dev_locked(ctx, cv, n, S[2], (uint32_t)len, S[3], S[7], S[8], s)) {
 		return -1;
 	}
 	EcamdXdhFinArgs Fn;
 	memset(&Fn, 0, sizeof(Fn));
 	Fn.pts = S[7];
-	Fn.st8 = S[6];
 	Fn.stk = S[8];
 	Fn.flags = S[4];
 	Fn.out = d_out;

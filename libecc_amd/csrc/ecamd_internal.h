@@ -86,15 +86,15 @@ struct EcamdXdhPrepArgs {
 	const uint8_t *k, *u;    // n x len little-endian scalars and u coordinates (RFC 7748 wire format)
 	uint8_t *scalars;        // out: n x len big-endian clamped scalars
 	uint8_t *points;         // out: n x 2*len affine Weierstrass X || Y big-endian
-	uint8_t *flags;          // out: n, 0 ok / 1 reject (u >= p, u on the twist)
+	uint8_t *flags;          // out: n, 0 ok / 1 reject (u >= p, u on the twist, [cofactor]Q = infinity)
 	uint32_t n, len, ebits, mode;  // mode 0: p = 5 mod 8 (candidate w^((p+3)/8)), 1: p = 3 mod 4 (w^((p+1)/4))
+	uint32_t cof_dbl;        // log2(cofactor)
 	uint32_t e[17];          // the exponent, little-endian words
 	uint32_t A[17], A3[17], sm1[17];  // A, A/3, sqrt(-1) in Montgomery form (radix 2^(32 NW))
 	int slot;
 };
 struct EcamdXdhFinArgs {
 	const uint8_t *pts;      // [k]Q affine Weierstrass, big-endian
-	const uint8_t *st8;      // status of [h]Q: must be 0 (finite, i.e. not a small-order point)
 	const uint8_t *stk;      // status of [k]Q
 	const uint8_t *flags;
 	uint8_t *out;            // n x len little-endian u coordinates

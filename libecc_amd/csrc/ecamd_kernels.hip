@@ -476,7 +476,20 @@ template <int NW> __global__ __launch_bounds__(64) void k_xdh_prep(EcamdXdhPrepA
 		root = root | alt;
 	}
 	ok = ok & root;
-	const Fe<NW> x = fe_from_mont<NW>(fe_add<NW>(um, fe_const<NW>(A.A3), slot), slot);
+	const Fe<NW> xm = fe_add<NW>(um, fe_const<NW>(A.A3), slot);
+	{
+		// [h]Q must not be infinity (x25519_448.c:259-260): h = 2^cof_dbl, so _prj_pt_unprotected_mult is
+		// cof_dbl doublings of Q
+		Pt<NW> P;
+		P.X = xm;
+		P.Y = v;
+		P.Z = one;
+		for (u32 r = 0; r < A.cof_dbl; r++) {
+			P = pt_dbl<NW>(P, slot);
+		}
+		ok = ok & !fe_is_zero<NW>(P.Z);
+	}
+	const Fe<NW> x = fe_from_mont<NW>(xm, slot);
 	const Fe<NW> y = fe_from_mont<NW>(v, slot);
 	u8 *pd = A.points + (size_t)i * 2 * len;
 	fe_store_be<NW>(pd, len, ok ? x : fe_zero<NW>());
@@ -493,7 +506,7 @@ template <int NW> __global__ __launch_bounds__(64) void k_xdh_fin(EcamdXdhFinArg
 	const int slot = A.slot;
 	const int len = (int)A.len;
 	u8 *out = A.out + (size_t)i * len;
-	bool ok = (A.flags[i] == 0) & (A.st8[i] == 0) & (A.stk[i] == 0);
+	bool ok = (A.flags[i] == 0) & (A.stk[i] == 0);
 	const Fe<NW> x = fe_load_be<NW>(A.pts + (size_t)i * 2 * len, len);
 	const Fe<NW> u = fe_sub<NW>(x, fe_const<NW>(A.A3), slot);  // plain residues: no Montgomery form needed
 	ok = ok & !fe_is_zero<NW>(u);
