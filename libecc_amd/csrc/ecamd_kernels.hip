@@ -274,25 +274,56 @@ template <int NW> static __device__ __forceinline__ Fe<NW> digest_to_e(const u8 
 	return fe_cond_sub<NW>(e.v, 0u, qw);  // e < 2^|q| < 2q: one conditional subtraction is nn_mod
 }
 
+// One lane prepares ECDSA_PREP_K consecutive items and shares one Fermat inversion among them
+// (Montgomery's trick: prefix products, one x^(q-2), back-substitution): 3 multiplications + 1/K of an
+// inversion per item instead of a whole one.  Items whose s is out of range take part with 1.
+#define ECDSA_PREP_K 8
 template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_prep(EcamdEcdsaPrepArgs A)
 {
-	const u32 i = blockIdx.x * 64 + threadIdx.x;
-	if (i >= A.n) {
+	const u32 t = blockIdx.x * 64 + threadIdx.x;
+	const u32 first = t * ECDSA_PREP_K;
+	if (first >= A.n) {
 		return;
 	}
 	const int qs = A.qslot;  // modulus of this slot is q
 	const int qlen = (int)A.qlen, hlen = (int)A.hlen;
-	const u8 *sig = A.sigs + (size_t)i * 2 * qlen;
-	const Fe<NW> r = fe_load_be<NW>(sig, qlen), s = fe_load_be<NW>(sig + qlen, qlen);
-	const bool ok = !fe_is_zero<NW>(r) & !fe_is_zero<NW>(s) & fe_lt_p<NW>(r, qs) & fe_lt_p<NW>(s, qs);
-	const Fe<NW> e = digest_to_e<NW>(A.digests + (size_t)i * hlen, hlen, qlen, (int)A.qbits, qs);
-	// s^-1 = s^(q-2) (q prime): the unique inverse, equal to nn_modinv's (nn/nn_modinv.c:220)
-	const Fe<NW> sinv = fe_inv<NW>(fe_to_mont<NW>(s, qs), qs);   // Montgomery form of 1/s
-	const Fe<NW> u1 = fe_mul<NW>(e, sinv, qs);                   // plain * Montgomery = plain e/s
-	const Fe<NW> u2 = fe_mul<NW>(r, sinv, qs);
-	fe_store_be<NW>(A.u1 + (size_t)i * qlen, qlen, ok ? u1 : fe_zero<NW>());
-	fe_store_be<NW>(A.u2 + (size_t)i * qlen, qlen, ok ? u2 : fe_zero<NW>());
-	A.flags[i] = ok ? 0 : 1;
+	const Fe<NW> one = fe_const<NW>(ConstTab<NW>::get(qs).one);
+	Fe<NW> pre[ECDSA_PREP_K];  // pre[k] = s_0 ... s_k (Montgomery form)
+	u32 okmask = 0;
+	Fe<NW> acc = one;
+#pragma unroll
+	for (int k = 0; k < ECDSA_PREP_K; k++) {
+		const u32 i = first + k;
+		if (i < A.n) {
+			const u8 *sig = A.sigs + (size_t)i * 2 * qlen;
+			const Fe<NW> r = fe_load_be<NW>(sig, qlen), sv = fe_load_be<NW>(sig + qlen, qlen);
+			const bool ok = !fe_is_zero<NW>(r) & !fe_is_zero<NW>(sv) & fe_lt_p<NW>(r, qs) & fe_lt_p<NW>(sv, qs);
+			okmask |= ok ? (1u << k) : 0u;
+			acc = fe_mul<NW>(acc, ok ? fe_to_mont<NW>(sv, qs) : one, qs);
+		}
+		pre[k] = acc;
+	}
+	// (s_0 ... s_last)^-1 = x^(q-2) (q prime): the unique inverse, equal to nn_modinv's (nn/nn_modinv.c:220)
+	Fe<NW> inv = fe_inv<NW>(acc, qs);
+#pragma unroll
+	for (int k = ECDSA_PREP_K - 1; k >= 0; k--) {
+		const u32 i = first + k;
+		if (i >= A.n) {
+			continue;
+		}
+		const bool ok = (okmask >> k) & 1u;
+		const u8 *sig = A.sigs + (size_t)i * 2 * qlen;
+		const Fe<NW> r = fe_load_be<NW>(sig, qlen), sv = fe_load_be<NW>(sig + qlen, qlen);
+		const Fe<NW> sm = ok ? fe_to_mont<NW>(sv, qs) : one;
+		const Fe<NW> sinv = (k > 0) ? fe_mul<NW>(inv, pre[k - 1], qs) : inv;   // Montgomery form of 1/s_k
+		inv = fe_mul<NW>(inv, sm, qs);
+		const Fe<NW> e = digest_to_e<NW>(A.digests + (size_t)i * hlen, hlen, qlen, (int)A.qbits, qs);
+		const Fe<NW> u1 = fe_mul<NW>(e, sinv, qs);                               // plain * Montgomery = plain e/s
+		const Fe<NW> u2 = fe_mul<NW>(r, sinv, qs);
+		fe_store_be<NW>(A.u1 + (size_t)i * qlen, qlen, ok ? u1 : fe_zero<NW>());
+		fe_store_be<NW>(A.u2 + (size_t)i * qlen, qlen, ok ? u2 : fe_zero<NW>());
+		A.flags[i] = ok ? 0 : 1;
+	}
 }
 
 // __ecdsa_sign_finalize (sig/ecdsa_common.c:318-586) after kG: r = kG.x mod q, s = k^-1 (x r + e) mod q.
@@ -769,7 +800,8 @@ hipError_t ecamd_launch_ecdsa_prep(int nw, const EcamdEcdsaPrepArgs &a, hipStrea
 	if (a.n == 0) {
 		return hipSuccess;
 	}
-	const dim3 grid((a.n + 63) / 64), block(64);
+	const uint32_t lanes = (a.n + ECDSA_PREP_K - 1) / ECDSA_PREP_K;
+	const dim3 grid((lanes + 63) / 64), block(64);
 	switch (nw) {
 #define X(N) case N: hipLaunchKernelGGL(k_ecdsa_prep<N>, grid, block, 0, s, a); break;
 		ECAMD_FOR_NW(X)
