@@ -332,42 +332,67 @@ template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_prep(EcamdEcdsaP
 // nonce cannot get past: r = 0 (:492), e == x r (:516), s = 0 (:548).
 template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_sign(EcamdEcdsaSignArgs A)
 {
-	const u32 i = blockIdx.x * 64 + threadIdx.x;
-	if (i >= A.n) {
+	const u32 t = blockIdx.x * 64 + threadIdx.x;
+	const u32 first = t * ECDSA_PREP_K;
+	if (first >= A.n) {
 		return;
 	}
 	const int qs = A.qslot;
 	const int qlen = (int)A.qlen, clen = (int)A.clen;
-	u8 *sig = A.sigs + (size_t)i * 2 * qlen;
-	const Fe<NW> k = fe_load_be<NW>(A.nonces + (size_t)i * qlen, qlen);
-	Fe<NW> x = fe_load_be<NW>(A.privs + (size_t)i * qlen, qlen);
-	bool ok = !fe_is_zero<NW>(k) & fe_lt_p<NW>(k, qs) & (A.stkG[i] == 0);
 	const CurveK<NW> &Q = ConstTab<NW>::get(qs);
+	const Fe<NW> one = fe_const<NW>(Q.one);
+	const Fe<NW> r2q = fe_const<NW>(Q.r2);
 	u32 qw[NW];
 #pragma unroll
 	for (int j = 0; j < NW; j++) {
 		qw[j] = Q.p[j];
 	}
-	// r = kG.x mod q: x < p <= (jmax + 1) q, so jmax conditional subtractions
-	Fe<NW> r = fe_load_be<NW>(A.kG + (size_t)i * 2 * clen, clen);
-	for (u32 j = 0; j < A.jmax; j++) {
-		r = fe_cond_sub<NW>(r.v, 0u, qw);
+	// k^-1 for ECDSA_PREP_K consecutive items from one inversion (nonces out of range take part with 1)
+	Fe<NW> pre[ECDSA_PREP_K];
+	u32 okmask = 0;
+	Fe<NW> acc = one;
+#pragma unroll
+	for (int k = 0; k < ECDSA_PREP_K; k++) {
+		const u32 i = first + k;
+		if (i < A.n) {
+			const Fe<NW> kk = fe_load_be<NW>(A.nonces + (size_t)i * qlen, qlen);
+			const bool ok = !fe_is_zero<NW>(kk) & fe_lt_p<NW>(kk, qs);
+			okmask |= ok ? (1u << k) : 0u;
+			acc = fe_mul<NW>(acc, ok ? fe_mul<NW>(kk, r2q, qs) : one, qs);
+		}
+		pre[k] = acc;
 	}
-	ok = ok & !fe_is_zero<NW>(r);
-	for (u32 j = 0; j < 1; j++) {
+	Fe<NW> inv = fe_inv<NW>(acc, qs);
+#pragma unroll
+	for (int k = ECDSA_PREP_K - 1; k >= 0; k--) {
+		const u32 i = first + k;
+		if (i >= A.n) {
+			continue;
+		}
+		u8 *sig = A.sigs + (size_t)i * 2 * qlen;
+		const Fe<NW> kk = fe_load_be<NW>(A.nonces + (size_t)i * qlen, qlen);
+		bool ok = ((okmask >> k) & 1u) & (A.stkG[i] == 0);
+		const Fe<NW> km = ((okmask >> k) & 1u) ? fe_mul<NW>(kk, r2q, qs) : one;
+		const Fe<NW> kinv = (k > 0) ? fe_mul<NW>(inv, pre[k - 1], qs) : inv;     // Montgomery form of 1/k
+		inv = fe_mul<NW>(inv, km, qs);
+		Fe<NW> x = fe_load_be<NW>(A.privs + (size_t)i * qlen, qlen);
+		// r = kG.x mod q: x < p <= (jmax + 1) q, so jmax conditional subtractions
+		Fe<NW> r = fe_load_be<NW>(A.kG + (size_t)i * 2 * clen, clen);
+		for (u32 j = 0; j < A.jmax; j++) {
+			r = fe_cond_sub<NW>(r.v, 0u, qw);
+		}
+		ok = ok & !fe_is_zero<NW>(r);
 		x = fe_cond_sub<NW>(x.v, 0u, qw);  // private keys are < q in every sane use; one reduction step
+		const Fe<NW> e = digest_to_e<NW>(A.digests + (size_t)i * A.hlen, (int)A.hlen, qlen, (int)A.qbits, qs);
+		const Fe<NW> xr = fe_mul<NW>(fe_mul<NW>(x, r2q, qs), r, qs);         // x r mod q (plain)
+		ok = ok & !fe_eq<NW>(e, xr);                                            // :516 restart condition
+		const Fe<NW> tt = fe_add<NW>(xr, e, qs);
+		const Fe<NW> sv = fe_mul<NW>(tt, kinv, qs);
+		ok = ok & !fe_is_zero<NW>(sv);
+		fe_store_be<NW>(sig, qlen, ok ? r : fe_zero<NW>());
+		fe_store_be<NW>(sig + qlen, qlen, ok ? sv : fe_zero<NW>());
+		A.status[i] = ok ? 0 : 1;
 	}
-	const Fe<NW> e = digest_to_e<NW>(A.digests + (size_t)i * A.hlen, (int)A.hlen, qlen, (int)A.qbits, qs);
-	const Fe<NW> r2q = fe_const<NW>(Q.r2);
-	const Fe<NW> xr = fe_mul<NW>(fe_mul<NW>(x, r2q, qs), r, qs);       // x r mod q (plain)
-	ok = ok & !fe_eq<NW>(e, xr);                                          // :516 restart condition
-	const Fe<NW> t = fe_add<NW>(xr, e, qs);
-	const Fe<NW> kinv = fe_inv<NW>(fe_mul<NW>(k, r2q, qs), qs);          // Montgomery form of 1/k
-	const Fe<NW> s = fe_mul<NW>(t, kinv, qs);
-	ok = ok & !fe_is_zero<NW>(s);
-	fe_store_be<NW>(sig, qlen, ok ? r : fe_zero<NW>());
-	fe_store_be<NW>(sig + qlen, qlen, ok ? s : fe_zero<NW>());
-	A.status[i] = ok ? 0 : 1;
 }
 
 template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_fin(EcamdEcdsaFinArgs A)
@@ -816,7 +841,8 @@ hipError_t ecamd_launch_ecdsa_sign(int nw, const EcamdEcdsaSignArgs &a, hipStrea
 	if (a.n == 0) {
 		return hipSuccess;
 	}
-	const dim3 grid((a.n + 63) / 64), block(64);
+	const uint32_t lanes = (a.n + ECDSA_PREP_K - 1) / ECDSA_PREP_K;
+	const dim3 grid((lanes + 63) / 64), block(64);
 	switch (nw) {
 #define X(N) case N: hipLaunchKernelGGL(k_ecdsa_sign<N>, grid, block, 0, s, a); break;
 		ECAMD_FOR_NW(X)
