@@ -157,6 +157,25 @@ int ec_xdh_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uin
 int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *pubkeys,
 			  const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, uint8_t *result);
 
+/* Point wire formats (curves/prj_pt.c:462-624): affine X || Y (2*clen bytes, what the entry points above
+ * use) and projective X || Y || Z (3*clen bytes: prj_pt_import_from_buf / prj_pt_export_to_buf, the format
+ * of `ec_utils scalar_mult` and of structured public keys). */
+#define ECAMD_PT_AFFINE 0
+#define ECAMD_PT_PROJECTIVE 1
+/* ec_prj_pt_mul_batch with a choice of formats: import (prj_pt_import_from_buf :462 or
+ * prj_pt_import_from_aff_buf :511), prj_pt_mul, prj_pt_unique, export (prj_pt_export_to_buf :562 gives
+ * X/Z || Y/Z || 1, or prj_pt_export_to_aff_buf :600).  Projective inputs: every coordinate < p and the
+ * projective curve equation must hold; Z = 0 is the point at infinity (status ECAMD_INF); the degenerate
+ * triple (0:0:0) passes the reference's import but fails in its ladder (status ECAMD_ERR). */
+int ec_prj_pt_mul_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *scalars,
+			    uint32_t scalar_len, const uint8_t *points, int in_fmt, uint8_t *out, int out_fmt,
+			    uint8_t *status);
+/* prj_pt_import_from_[aff_]buf + prj_pt_unique / prj_pt_to_aff (:241, :218) + export: validates and
+ * normalises n points (one inversion each on the device).  ECAMD_INF for Z = 0 (including (0:0:0),
+ * which prj_pt_unique reports as infinity). */
+int ec_prj_pt_unique_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *points, int in_fmt,
+			   uint8_t *out, int out_fmt, uint8_t *status);
+
 /* Device-pointer forms of the verification / key-agreement entry points, for callers whose batches
  * already live in HBM (and for sharding a batch over GPUs, one context per device): same semantics and
  * layouts as the host-pointer forms above, every buffer a device pointer, kernels enqueued on

@@ -13,6 +13,7 @@ EXPORTED_SYMBOLS = [
     "ecamd_curve_coord_len", "ecamd_curve_order_len", "ecamd_curve_words", "ec_prj_pt_mul_batch",
     "ec_prj_pt_mul_batch_dev", "ecamd_ctx_synchronize", "ec_prj_pt_add_batch", "ec_prj_pt_dbl_batch",
     "ec_fp_op_batch", "ec_ecdsa_verify_batch", "ec_ecdsa_sign_batch", "ec_ecccdh_derive_batch", "ec_xdh_batch",
+    "ec_prj_pt_mul_batch_fmt", "ec_prj_pt_unique_batch",
     "ec_eddsa_verify_batch", "ec_ecdsa_verify_batch_dev", "ec_eddsa_verify_batch_dev", "ec_xdh_batch_dev",
 ]
 
@@ -62,6 +63,8 @@ def load_library():
         L.ec_ecdsa_sign_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p, u8p]
         L.ec_xdh_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
         L.ec_eddsa_verify_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p]
+        L.ec_prj_pt_mul_batch_fmt.argtypes = [vp, vp, u32, u8p, u32, u8p, C.c_int, u8p, C.c_int, u8p]
+        L.ec_prj_pt_unique_batch.argtypes = [vp, vp, u32, u8p, C.c_int, u8p, C.c_int, u8p]
         L.ec_ecdsa_verify_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp]
         L.ec_eddsa_verify_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp]
         L.ec_xdh_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp]
@@ -224,3 +227,21 @@ class Curve:
     def xdh_dev(self, n, d_k, d_u, d_out, d_status, stream=None):
         _chk(self.L, self.L.ec_xdh_batch_dev(self.ctx.h, self.h, n, d_k, d_u, d_out, d_status, stream),
              "ec_xdh_batch_dev")
+
+    # -- point wire formats: 0 affine X || Y, 1 projective X || Y || Z --
+    def scalar_mult_fmt(self, scalars, points, in_fmt, out_fmt, slen=None):
+        slen = slen or self.qlen
+        n = len(scalars) // slen
+        w = (3 if out_fmt else 2) * self.clen
+        out, st = C.create_string_buffer(max(1, w * n)), C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_prj_pt_mul_batch_fmt(self.ctx.h, self.h, n, scalars, slen, points, in_fmt, out, out_fmt, st),
+             "ec_prj_pt_mul_batch_fmt")
+        return out.raw[:w * n], st.raw[:n]
+
+    def unique(self, points, in_fmt, out_fmt):
+        n = len(points) // ((3 if in_fmt else 2) * self.clen)
+        w = (3 if out_fmt else 2) * self.clen
+        out, st = C.create_string_buffer(max(1, w * n)), C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_prj_pt_unique_batch(self.ctx.h, self.h, n, points, in_fmt, out, out_fmt, st),
+             "ec_prj_pt_unique_batch")
+        return out.raw[:w * n], st.raw[:n]

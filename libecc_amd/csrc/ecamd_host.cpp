@@ -1791,3 +1791,117 @@ extern "C" int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, u
 	HIPCHK(hipStreamSynchronize(s));
 	return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// scalar multiplication / normalisation with a choice of point wire formats
+// ------------------------------------------------------------------------------------------
+static int pt_fmt_batch(const char *fn, ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *scalars,
+			uint32_t slen, const uint8_t *points, int in_fmt, uint8_t *out, int out_fmt, uint8_t *status,
+			bool mul)
+{
+	if (!ctx || !cv || cv->ctx != ctx || (n && (!out || !status || (mul && !scalars) || (!mul && !points)))) {
+		return fail(std::string(fn) + ": bad argument");
+	}
+	if ((in_fmt != 0 && in_fmt != 1) || (out_fmt != 0 && out_fmt != 1)) {
+		return fail(std::string(fn) + ": point format must be ECAMD_PT_AFFINE or ECAMD_PT_PROJECTIVE");
+	}
+	if (mul && (slen == 0 || slen > 1024)) {
+		return fail(std::string(fn) + ": scalar_len must be in 1..1024");
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t clen = (size_t)cv->clen, alen = 2 * clen;
+	const size_t ilen = (in_fmt ? 3 : 2) * clen, olen = (out_fmt ? 3 : 2) * clen;
+	// stage: 0 scalars, 1 points as given, 2 affine inputs, 3 import status, 4 affine results, 5 their status,
+	//        6 output, 7 output status
+	const size_t need[8] = {mul ? (size_t)n * slen : 0, points ? n * ilen : 0, n * alen, n, n * alen, n, n * olen, n};
+	for (int i = 0; i < 8; i++) {
+		if (ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
+			return -1;
+		}
+	}
+	uint8_t **S = ctx->stage;
+	hipStream_t s = ctx->stream;
+	if (mul) {
+		HIPCHK(hipMemcpyAsync(S[0], scalars, (size_t)n * slen, hipMemcpyHostToDevice, s));
+	}
+	if (points) {
+		HIPCHK(hipMemcpyAsync(S[1], points, n * ilen, hipMemcpyHostToDevice, s));
+	}
+	const uint8_t *d_aff = points ? S[1] : nullptr;  // affine inputs of the scalar multiplication (NULL: generator)
+	const uint8_t *d_pre = nullptr;
+	if (points && in_fmt == 1) {
+		EcamdPrjInArgs I;
+		I.in = S[1];
+		I.aff = S[2];
+		I.pre = S[3];
+		I.n = n;
+		I.clen = (uint32_t)clen;
+		I.for_mul = mul ? 1 : 0;
+		I.slot = cv->slot;
+		HIPCHK(ecamd_launch_prj_import(cv->nw, I, s));
+		d_aff = S[2];
+		d_pre = S[3];
+	}
+	const uint8_t *d_res = d_aff, *d_st = nullptr;
+	if (mul) {
+		if (smul_dev_locked(ctx, cv, n, S[0], slen, d_aff, S[4], S[5], s)) {
+			return -1;
+		}
+		d_res = S[4];
+		d_st = S[5];
+	} else if (in_fmt == 0) {
+		// affine in, no multiplication: validation only, through the group-law kernel's import checks
+		// (P + P is computed and dropped; its status carries the import result)
+		EcamdPtArgs A;
+		A.p1 = S[1];
+		A.p2 = nullptr;
+		A.out = S[4];
+		A.status = S[5];
+		A.n = n;
+		A.clen = (uint32_t)clen;
+		A.dbl = 1;
+		A.slot = cv->slot;
+		HIPCHK(ecamd_launch_pt(cv->nw, A, s));
+		// a valid point may double to infinity (order 2): only the import error matters here
+		std::vector<uint8_t> st(n);
+		HIPCHK(hipMemcpyAsync(st.data(), S[5], n, hipMemcpyDeviceToHost, s));
+		HIPCHK(hipStreamSynchronize(s));
+		for (uint32_t i = 0; i < n; i++) {
+			st[i] = st[i] == 1 ? 1 : 0;
+		}
+		HIPCHK(hipMemcpyAsync(S[5], st.data(), n, hipMemcpyHostToDevice, s));
+		HIPCHK(hipStreamSynchronize(s));
+		d_st = S[5];
+	}
+	EcamdPrjOutArgs O;
+	O.aff = d_res;
+	O.st = d_st;
+	O.pre = d_pre;
+	O.out = S[6];
+	O.status = S[7];
+	O.n = n;
+	O.clen = (uint32_t)clen;
+	O.out_prj = out_fmt;
+	HIPCHK(ecamd_launch_prj_export(O, s));
+	HIPCHK(hipMemcpyAsync(out, S[6], n * olen, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipMemcpyAsync(status, S[7], n, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	return 0;
+}
+
+extern "C" int ec_prj_pt_mul_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *scalars,
+				       uint32_t slen, const uint8_t *points, int in_fmt, uint8_t *out, int out_fmt,
+				       uint8_t *status)
+{
+	return pt_fmt_batch("ec_prj_pt_mul_batch_fmt", ctx, cv, n, scalars, slen, points, in_fmt, out, out_fmt, status, true);
+}
+
+extern "C" int ec_prj_pt_unique_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *points, int in_fmt,
+				      uint8_t *out, int out_fmt, uint8_t *status)
+{
+	return pt_fmt_batch("ec_prj_pt_unique_batch", ctx, cv, n, nullptr, 0, points, in_fmt, out, out_fmt, status, false);
+}

@@ -138,6 +138,27 @@ hipError_t ecamd_launch_ed_decode(int nw, const EcamdEdDecodeArgs &a, hipStream_
 hipError_t ecamd_launch_ed_scal(int nw, const EcamdEdScalArgs &a, hipStream_t s);
 hipError_t ecamd_launch_ed_fin(int nw, const EcamdEdFinArgs &a, hipStream_t s);
 
+// ---- projective wire format X || Y || Z (curves/prj_pt.c:462, 562) ----
+struct EcamdPrjInArgs {
+	const uint8_t *in;       // n x 3*clen
+	uint8_t *aff;            // out: n x 2*clen affine X || Y (zeros unless pre == 0)
+	uint8_t *pre;            // out: n, 0 finite / 1 import error / 2 infinity
+	uint32_t n, clen;
+	int for_mul;             // (0:0:0): error under prj_pt_mul, "infinity" under prj_pt_unique alone
+	int slot;
+};
+struct EcamdPrjOutArgs {
+	const uint8_t *aff;      // n x 2*clen
+	const uint8_t *st;       // n (may be NULL: all 0)
+	const uint8_t *pre;      // n import status that overrides st when non-zero (may be NULL)
+	uint8_t *out;            // n x (out_prj ? 3 : 2)*clen
+	uint8_t *status;
+	uint32_t n, clen;
+	int out_prj;
+};
+hipError_t ecamd_launch_prj_import(int nw, const EcamdPrjInArgs &a, hipStream_t s);
+hipError_t ecamd_launch_prj_export(const EcamdPrjOutArgs &a, hipStream_t s);
+
 // radix-2^29 Jacobian fast path for every field size (ecamd_g29_kernel.hip)
 int ecamd_g29_supported(int pbits);
 int ecamd_g29_nl(int pbits, int flavour);

@@ -769,6 +769,76 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed_fin(EcamdEdFinArgs 
 }
 
 // ------------------------------------------------------------------------------------------
+// Projective wire format X || Y || Z (prj_pt_import_from_buf / prj_pt_export_to_buf, curves/prj_pt.c:462,562)
+//   k_prj_import: each coordinate < p, projective on-curve check Y^2 Z = X^3 + a X Z^2 + b Z^3 in the
+//     reference's operation order (:144-190); Z = 0 on the curve is the point at infinity -- (0:0:0) also
+//     satisfies the equation: prj_pt_unique of it fails as "infinity", prj_pt_mul of it fails in the
+//     ladder (error); finite points are normalised to affine for the scalar-mult pipeline;
+//   k_prj_export: affine + status -> X || Y || 1 (the unique representative prj_pt_unique yields).
+// ------------------------------------------------------------------------------------------
+template <int NW> __global__ __launch_bounds__(64) void k_prj_import(EcamdPrjInArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int slot = A.slot;
+	const int clen = (int)A.clen;
+	const CurveK<NW> &K = ConstTab<NW>::get(slot);
+	const u8 *src = A.in + (size_t)i * 3 * clen;
+	u8 *dst = A.aff + (size_t)i * 2 * clen;
+	const Fe<NW> X = fe_load_be<NW>(src, clen), Y = fe_load_be<NW>(src + clen, clen), Z = fe_load_be<NW>(src + 2 * clen, clen);
+	bool ok = fe_lt_p<NW>(X, slot) & fe_lt_p<NW>(Y, slot) & fe_lt_p<NW>(Z, slot);
+	const Fe<NW> Xm = fe_to_mont<NW>(X, slot), Ym = fe_to_mont<NW>(Y, slot), Zm = fe_to_mont<NW>(Z, slot);
+	{
+		const Fe<NW> z2 = fe_mul<NW>(Zm, Zm, slot);
+		const Fe<NW> x2 = fe_mul<NW>(Xm, Xm, slot);
+		Fe<NW> rhs = fe_add<NW>(x2, fe_mul<NW>(fe_const<NW>(K.a), z2, slot), slot);      // X^2 + a Z^2
+		rhs = fe_mul<NW>(rhs, Xm, slot);
+		rhs = fe_add<NW>(rhs, fe_mul<NW>(fe_mul<NW>(fe_const<NW>(K.b), z2, slot), Zm, slot), slot);
+		const Fe<NW> lhs = fe_mul<NW>(fe_mul<NW>(Ym, Ym, slot), Zm, slot);
+		ok = ok & fe_eq<NW>(lhs, rhs);
+	}
+	u32 st = 0;
+	if (!ok) {
+		st = 1;
+	} else if (fe_is_zero<NW>(Z)) {
+		st = (A.for_mul && fe_is_zero<NW>(X) && fe_is_zero<NW>(Y)) ? 1u : 2u;
+	}
+	Fe<NW> ax = fe_zero<NW>(), ay = fe_zero<NW>();
+	if (st == 0) {
+		const Fe<NW> zi = fe_inv<NW>(Zm, slot);
+		ax = fe_from_mont<NW>(fe_mul<NW>(Xm, zi, slot), slot);
+		ay = fe_from_mont<NW>(fe_mul<NW>(Ym, zi, slot), slot);
+	}
+	fe_store_be<NW>(dst, clen, ax);
+	fe_store_be<NW>(dst + clen, clen, ay);
+	A.pre[i] = (u8)st;
+}
+
+__global__ __launch_bounds__(256) void k_prj_export(EcamdPrjOutArgs A)
+{
+	const u32 i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const u32 clen = A.clen;
+	const u32 ow = A.out_prj ? 3 * clen : 2 * clen;
+	const u32 pre = A.pre ? A.pre[i] : 0u;
+	const u32 st = pre ? pre : (A.st ? A.st[i] : 0u);
+	const u8 *src = A.aff + (size_t)i * 2 * clen;
+	u8 *dst = A.out + (size_t)i * ow;
+	for (u32 b = 0; b < ow; b++) {
+		u8 v = 0;
+		if (st == 0) {
+			v = (b < 2 * clen) ? src[b] : (u8)(b == ow - 1 ? 1 : 0);
+		}
+		dst[b] = v;
+	}
+	A.status[i] = (u8)st;
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side dispatch on the word count
 // ------------------------------------------------------------------------------------------
 #define ECAMD_FOR_NW(X) X(6) X(7) X(8) X(10) X(12) X(14) X(16) X(17)
@@ -960,5 +1030,29 @@ hipError_t ecamd_launch_ed_fin(int nw, const EcamdEdFinArgs &a, hipStream_t s)
 		return hipErrorInvalidValue;
 	}
 	hipLaunchKernelGGL(k_ed_fin<8>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_prj_import(int nw, const EcamdPrjInArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	const dim3 grid((a.n + 63) / 64), block(64);
+	switch (nw) {
+#define X(N) case N: hipLaunchKernelGGL(k_prj_import<N>, grid, block, 0, s, a); break;
+		ECAMD_FOR_NW(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_prj_export(const EcamdPrjOutArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_prj_export, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
 	return hipGetLastError();
 }

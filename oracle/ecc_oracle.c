@@ -1283,3 +1283,45 @@ int orc_eddsa25519_verify_batch(const orc_curve *c, uint32_t n, const uint8_t *p
 	}
 	return 0;
 }
+
+/* ------------------------------------------------------------------------------------
+ * Projective wire format (the chain of `ec_utils scalar_mult`, tests/ec_utils.c:1380-1538):
+ *   prj_pt_import_from_buf (curves/prj_pt.c:462-500): X, Y, Z big-endian, each < p (fp_init_from_buf),
+ *     projective on-curve check -- Z = 0 is accepted when it satisfies the equation;
+ *   [prj_pt_mul (:1759)], prj_pt_iszero, prj_pt_unique (:241), prj_pt_export_to_buf (:562): X/Z || Y/Z || 1.
+ * scalars == NULL: normalisation only.  status 0 ok / 1 error / 2 infinity.
+ * ---------------------------------------------------------------------------------- */
+int orc_prj_batch(const orc_curve *c, uint32_t n, const uint8_t *scalars, uint32_t slen, const uint8_t *points,
+		  uint8_t *out, uint8_t *status)
+{
+	const orc_fp_ctx *f = &c->fp;
+	const int clen = c->clen;
+	const int mn = words_for((int)slen);
+	uint32_t i;
+	if (scalars && mn > ORC_MAXW) return -1;
+	for (i = 0; i < n; i++) {
+		pt P, Q;
+		u64 m[ORC_MAXW + 1];
+		const u8 *src = points + (size_t)i * 3 * clen;
+		u8 *dst = out + (size_t)i * 3 * clen;
+		status[i] = 1;
+		memset(dst, 0, (size_t)3 * clen);
+		if (fp_from_be(P.X, src, clen, f) || fp_from_be(P.Y, src + clen, clen, f) ||
+		    fp_from_be(P.Z, src + 2 * clen, clen, f)) continue;
+		if (!pt_is_on_curve(&P, c)) continue;
+		if (scalars) {
+			nn_zero(m, ORC_MAXW + 1);
+			if (nn_from_be(m, mn, scalars + (size_t)i * slen, (int)slen)) continue;
+			if (pt_mul(&Q, m, mn, &P, c)) continue;
+		} else {
+			Q = P;
+		}
+		if (nn_iszero(Q.Z, f->n)) { status[i] = 2; continue; }
+		if (pt_unique(&Q, c)) continue;
+		nn_to_be(dst, clen, Q.X, f->n);
+		nn_to_be(dst + clen, clen, Q.Y, f->n);
+		nn_to_be(dst + 2 * clen, clen, Q.Z, f->n);
+		status[i] = 0;
+	}
+	return 0;
+}

@@ -527,3 +527,58 @@ int refdrv_eddsa25519_verify_batch(uint32_t n, const uint8_t *pubs, const uint8_
 	}
 	return 0;
 }
+
+/* ---- projective wire format: prj_pt_import_from_buf -> [prj_pt_mul] -> prj_pt_unique -> prj_pt_export_to_buf,
+ * the chain of `ec_utils scalar_mult` (tests/ec_utils.c:1380-1538).  scalars == NULL: normalisation only.
+ * points: n x 3*clen (X || Y || Z), out: n x 3*clen unique representative (Z = 1); status 0 / 1 error / 2 infinity */
+int refdrv_prj_batch(const char *curve, uint32_t n, const uint8_t *scalars, uint32_t slen, const uint8_t *points,
+		     uint8_t *out, uint8_t *status)
+{
+	ec_params params;
+	uint32_t i, clen;
+	if (load_params(curve, &params)) {
+		return -1;
+	}
+	clen = (uint32_t)BYTECEIL(params.ec_fp.p_bitlen);
+	refdrv_seed(0x5EC9256ULL);
+	for (i = 0; i < n; i++) {
+		prj_pt P, Q;
+		nn m;
+		int ret, iszero = 0;
+		P.magic = Q.magic = WORD(0);
+		m.magic = WORD(0);
+		status[i] = 1;
+		memset(out + (size_t)i * 3 * clen, 0, 3 * clen);
+		ret = prj_pt_import_from_buf(&P, points + (size_t)i * 3 * clen, (u16)(3 * clen), &params.ec_curve);
+		if (ret) {
+			continue;
+		}
+		if (scalars) {
+			ret = nn_init_from_buf(&m, scalars + (size_t)i * slen, (u16)slen);
+			if (ret) {
+				continue;
+			}
+			ret = prj_pt_mul(&Q, &m, &P);
+		} else {
+			ret = prj_pt_copy(&Q, &P);
+		}
+		if (ret) {
+			continue;
+		}
+		ret = prj_pt_iszero(&Q, &iszero);
+		if (ret) {
+			continue;
+		}
+		if (iszero) {
+			status[i] = 2;
+			continue;
+		}
+		ret = prj_pt_unique(&Q, &Q);
+		if (ret) {
+			continue;
+		}
+		ret = prj_pt_export_to_buf(&Q, out + (size_t)i * 3 * clen, 3 * clen);
+		status[i] = ret ? 1 : 0;
+	}
+	return 0;
+}

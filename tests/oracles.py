@@ -119,6 +119,15 @@ class Oracle:
         assert self.L.orc_xdh_batch(self.ctx, self.clen, n, k, u, out, st) == 0
         return out.raw, st.raw
 
+    def prj(self, points, scalars=None, slen=None):
+        """projective X || Y || Z in and out (scalars None: normalisation only)"""
+        n = len(points) // (3 * self.clen)
+        slen = slen or self.qlen
+        out = C.create_string_buffer(max(1, 3 * self.clen * n))
+        st = C.create_string_buffer(max(1, n))
+        assert self.L.orc_prj_batch(self.ctx, n, scalars, slen, points, out, st) == 0
+        return out.raw[:3 * self.clen * n], st.raw[:n]
+
     def eddsa_verify(self, pubs, sigs, hram, hlen=64):
         """Ed25519 on the WEI25519 curve; hram = SHA-512(dom2 || R || A || PH(M)) per item"""
         n = len(pubs) // 32
@@ -210,6 +219,16 @@ def ref_xdh(length, k, u):
     st = C.create_string_buffer(n)
     assert L.refdrv_xdh_batch(length, n, k, u, out, st) == 0
     return out.raw, st.raw
+
+
+def ref_prj(curve, points, scalars=None, slen=None):
+    """the unmodified reference on the projective wire format (oracle/ref_driver.c:refdrv_prj_batch)"""
+    L = C.CDLL(REF_SO)
+    cl = clen(curve)
+    n = len(points) // (3 * cl)
+    out, st = C.create_string_buffer(max(1, 3 * cl * n)), C.create_string_buffer(max(1, n))
+    assert L.refdrv_prj_batch(curve.encode(), n, scalars, slen or qlen(curve), points, out, st) == 0
+    return out.raw[:3 * cl * n], st.raw[:n]
 
 
 def ref_ed25519_sign(seeds, msgs, msg_len):

@@ -718,3 +718,43 @@ def test_device_pointer_entry_points(gpu_ctx):
         assert (bytes(dout.cpu().numpy()), bytes(dst.cpu().numpy())) == exp
     finally:
         cv.free()
+
+
+@pytest.mark.parametrize("curve", ["SECP256R1", "SECP521R1", "WEI25519", "BRAINPOOLP256R1"])
+def test_projective_wire_format(gpu_ctx, curve):
+    """projective X || Y || Z in / out (prj_pt_import_from_buf, prj_pt_export_to_buf) against the oracle:
+    scaled representatives, infinity, (0:0:0), off-curve and out-of-range triples; format mixes"""
+    from test_oracle import prj_cases
+    rng = np.random.default_rng(52)
+    pts, scal, ql = prj_cases(curve, rng, nrand=80)
+    o = Oracle(curve)
+    cl = o.clen
+    n = len(pts) // (3 * cl)
+    cv = gpu_ctx.curve(curve)
+    try:
+        exp = o.prj(pts, scal, ql)
+        got = cv.scalar_mult_fmt(scal, pts, 1, 1, ql)
+        assert got == exp
+        # projective in, affine out: the same points without the trailing 0..01
+        ga, sa = cv.scalar_mult_fmt(scal, pts, 1, 0, ql)
+        assert sa == exp[1]
+        assert ga == b"".join(exp[0][3 * cl * i:3 * cl * i + 2 * cl] for i in range(n))
+        # affine in, projective out == the classic entry point plus Z = 1
+        aff_in = b"".join(ga[2 * cl * i:2 * cl * (i + 1)] for i in range(n))
+        ca, cs = cv.scalar_mult(scal, aff_in, ql)
+        pa, ps = cv.scalar_mult_fmt(scal, aff_in, 0, 1, ql)
+        assert ps == cs
+        one = (1).to_bytes(cl, "big")
+        assert pa == b"".join((ca[2 * cl * i:2 * cl * (i + 1)] + one) if cs[i] == 0 else bytes(3 * cl) for i in range(n))
+        # generator with projective output
+        g3, gs = cv.scalar_mult_fmt(scal, None, 0, 1, ql)
+        g2, gs2 = cv.scalar_mult(scal, None, ql)
+        assert gs == gs2 and g3[:3 * cl] == g2[:2 * cl] + one
+        # normalisation only
+        assert cv.unique(pts, 1, 1) == o.prj(pts)
+        ua, us = cv.unique(pts, 1, 0)
+        assert us == o.prj(pts)[1]
+        va, vs = cv.unique(aff_in, 0, 1)
+        assert vs == bytes(1 if (sa[i] != 0) else 0 for i in range(n))   # zeros stand for failed items: (0, 0) is off the curve
+    finally:
+        cv.free()

@@ -296,3 +296,48 @@ def test_eddsa25519_vs_reference():
         for i in range(6):
             a, sg, _ = O.ed25519_sign(seeds[32 * i:32 * i + 32], m[ED_MSG_LEN * i:ED_MSG_LEN * (i + 1)])
             assert (a, sg) == (rp[32 * i:32 * i + 32], rs[64 * i:64 * i + 64])
+
+
+def prj_cases(curve, rng, nrand=24):
+    """projective X || Y || Z inputs: scaled representatives of random points, infinity in several
+    spellings, the degenerate (0:0:0), off-curve triples, coordinates >= p; with matching scalars"""
+    c = CURVES[curve]
+    p, q, cl = c["p"], c["q"], (c["p"].bit_length() + 7) // 8
+    ql = (q.bit_length() + 7) // 8
+    o = Oracle(curve)
+
+    def enc(X, Y, Z):
+        return b"".join((v % (1 << (8 * cl))).to_bytes(cl, "big") for v in (X, Y, Z))
+
+    ks = b"".join(((int.from_bytes(rb(rng, ql + 8), "big") % (q - 1)) + 1).to_bytes(ql, "big") for _ in range(nrand))
+    aff, st = o.scalar_mult(ks)
+    assert set(st) == {0}
+    pts, scal = [], []
+    for i in range(nrand):
+        x, y = int.from_bytes(aff[2 * cl * i:2 * cl * i + cl], "big"), int.from_bytes(aff[2 * cl * i + cl:2 * cl * (i + 1)], "big")
+        z = 1 if i % 5 == 0 else int.from_bytes(rb(rng, cl + 8), "big") % (p - 1) + 1
+        pts.append(enc(x * z % p, y * z % p, z))
+        scal.append(((int.from_bytes(rb(rng, ql + 8), "big") % (q - 1)) + 1).to_bytes(ql, "big"))
+    gx, gy = c["gx"], c["gy"]
+    edge_pts = [enc(0, 1, 0), enc(0, 5, 0), enc(0, p - 1, 0), enc(0, 0, 0), enc(1, 0, 0), enc(1, 1, 0), enc(gx, gy, 2),
+                enc(gx, gy, 0), enc(p, 1, 0), enc(gx, gy, p), enc(gx, p + gy, 1) if p + gy < (1 << (8 * cl)) else enc(gx, gy, 1),
+                enc(gx, gy, 1), enc(gx, p - gy, 1), enc(2 * gx % p, 2 * gy % p, 2)]
+    for j, e in enumerate(edge_pts):
+        pts.append(e)
+        scal.append([1, 0, q, 5, 7, 3, 9, 2, 4, 6, 8, q - 1, q + 1, 2][j].to_bytes(ql, "big"))
+    return b"".join(pts), b"".join(scal), ql
+
+
+@pytest.mark.parametrize("curve", ["SECP256R1", "SECP521R1", "WEI25519"])
+def test_projective_wire_format_vs_reference(curve):
+    """prj_pt_import_from_buf -> [prj_pt_mul] -> prj_pt_unique -> prj_pt_export_to_buf (the chain of
+    `ec_utils scalar_mult`): restatement against the unmodified reference"""
+    rng = np.random.default_rng(51)
+    pts, scal, ql = prj_cases(curve, rng)
+    o = Oracle(curve)
+    a = o.prj(pts, scal, ql)
+    b = o.prj(pts)
+    assert 0 in a[1] and 1 in a[1] and 2 in a[1]
+    if have_ref():
+        assert a == O.ref_prj(curve, pts, scal, ql)
+        assert b == O.ref_prj(curve, pts)
