@@ -228,6 +228,7 @@ struct ecamd_curve {
 	int nw;     // 32-bit words per element
 	int slot;   // __constant__ slot: field of definition
 	int qslot;  // __constant__ slot: generator order q as a modulus (-1: protocol ops unavailable)
+	int qnw;    // words of the mod-q kernels: nw, or more when q is longer than p (secp224k1: |q| = 225 > 224)
 	int clen;   // BYTECEIL(pbits)
 	int qlen;   // BYTECEIL(qbits)
 	int pbits, qbits;
@@ -463,7 +464,7 @@ static int build_and_upload(ecamd_curve *cv)
 	}
 	if (cv->qslot >= 0) {
 		Big zero(1, 0);
-		if (upload_modulus(cv->nw, cv->qslot, cv->q, zero, zero)) {
+		if (upload_modulus(cv->qnw, cv->qslot, cv->q, zero, zero)) {
 			return -1;
 		}
 	}
@@ -586,7 +587,8 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	}
 	cv->slot = slot;
 	cv->qslot = -1;
-	if ((cv->q[0] & 1) && big_bitlen(cv->q) <= 32 * cv->nw) {
+	cv->qnw = big_bitlen(cv->q) <= 32 * cv->nw ? cv->nw : pick_nw(big_bitlen(cv->q));
+	if ((cv->q[0] & 1) && cv->qnw && ecamd_nw_supported(cv->qnw)) {
 		for (int i = 0; i < ECAMD_MAX_SLOTS_HOST; i++) {
 			if (!ctx->slot_used[i] && i != slot) {
 				cv->qslot = i;
@@ -998,7 +1000,7 @@ static int ecdsa_two_smul_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n,
 	P.hlen = hlen;
 	P.qbits = (uint32_t)cv->qbits;
 	P.qslot = cv->qslot;
-	HIPCHK(ecamd_launch_ecdsa_prep(cv->nw, P, s));
+	HIPCHK(ecamd_launch_ecdsa_prep(cv->qnw, P, s));
 	// uG and vY: two independent prj_pt_mul, as in the reference (sig/ecdsa_common.c:788,793)
 	if (smul_dev_locked(ctx, cv, n, S[3], (uint32_t)cv->qlen, nullptr, S[5], S[7], s) ||
 	    smul_dev_locked(ctx, cv, n, S[4], (uint32_t)cv->qlen, d_pub, S[6], S[8], s)) {
@@ -1100,7 +1102,7 @@ static int ecdsa_verify_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 		P.hlen = hlen;
 		P.qbits = (uint32_t)cv->qbits;
 		P.qslot = cv->qslot;
-		HIPCHK(ecamd_launch_ecdsa_prep(cv->nw, P, s));
+		HIPCHK(ecamd_launch_ecdsa_prep(cv->qnw, P, s));
 		EcamdSmulArgs K;
 		memset(&K, 0, sizeof(K));
 		K.points = d_pub + (size_t)off * 64;
@@ -1275,7 +1277,7 @@ extern "C" int ec_ecdsa_sign_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 		A.jmax = j;
 	}
 	A.qslot = cv->qslot;
-	HIPCHK(ecamd_launch_ecdsa_sign(cv->nw, A, s));
+	HIPCHK(ecamd_launch_ecdsa_sign(cv->qnw, A, s));
 	HIPCHK(hipMemcpyAsync(sigs, S[5], n * 2 * ql, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipMemcpyAsync(status, S[6], n, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));

@@ -432,7 +432,18 @@ template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_fin(EcamdEcdsaFi
 		return;
 	}
 	// W'x mod q == r  <=>  x == r + j q for some j with r + j q < p  <=>  (r + j q) Z == X
-	Fe<NW> t = fe_load_be<NW>(A.sigs + (size_t)i * 2 * qlen, qlen);
+	const u8 *rp = A.sigs + (size_t)i * 2 * qlen;
+	int rlen = qlen;
+	while (rlen > 4 * NW) {
+		// q longer than the field words (secp224k1): r beyond them cannot equal any x < p
+		if (*rp != 0) {
+			A.result[i] = 1;
+			return;
+		}
+		rp++;
+		rlen--;
+	}
+	Fe<NW> t = fe_load_be<NW>(rp, rlen);
 	bool acc = false;
 	for (u32 j = 0; j <= A.jmax; j++) {
 		if (fe_lt_p<NW>(t, slot)) {

@@ -758,3 +758,36 @@ def test_projective_wire_format(gpu_ctx, curve):
         assert vs == bytes(1 if (sa[i] != 0) else 0 for i in range(n))   # zeros stand for failed items: (0, 0) is off the curve
     finally:
         cv.free()
+
+
+def test_every_builtin_curve(gpu_ctx):
+    """all 44 curves libecc ships (tests/golden/curves.json): fixed- and variable-base scalar mult with
+    random and edge scalars, one ECDSA verification and one ECC-CDH each, against the oracle"""
+    rng = np.random.default_rng(53)
+    assert len(CURVES) == 44
+    for curve in sorted(CURVES):
+        o = Oracle(curve)
+        cv = gpu_ctx.curve(curve)
+        try:
+            ql, cl = o.qlen, o.clen
+            n = 12
+            sc = rand_bytes(rng, ql * (n - 4)) + b"".join(v.to_bytes(ql, "big") for v in
+                                                         (0, 1, CURVES[curve]["q"] % (1 << (8 * ql)), (1 << (8 * ql)) - 1))
+            pub = o.scalar_mult(sc)
+            assert cv.scalar_mult(sc) == pub, curve
+            base = pub[0][:2 * cl] * n
+            sc2 = rand_bytes(rng, ql * n)
+            assert cv.scalar_mult(sc2, base) == o.scalar_mult(sc2, base), curve
+            if CURVES[curve]["q"].bit_length() >= 160:
+                _, pubs, sigs, dg, hl, _ = make_sigs(curve, "SHA256", 4, rng)
+                bad = bytearray(sigs)
+                bad[2 * ql + 1] ^= 2
+                assert cv.ecdsa_verify(pubs, bytes(bad), dg, hl) == o.ecdsa_verify(pubs, bytes(bad), dg, hl) == bytes([0, 1, 0, 0]), curve
+                d = b"".join(((int.from_bytes(rand_bytes(rng, ql + 8), "big") % (CURVES[curve]["q"] - 1)) + 1).to_bytes(ql, "big")
+                             for _ in range(4))
+                assert cv.ecccdh(d, pubs) == o.ecccdh(d, pubs), curve
+                ks = b"".join(((int.from_bytes(rand_bytes(rng, ql + 8), "big") % (CURVES[curve]["q"] - 1)) + 1).to_bytes(ql, "big")
+                              for _ in range(4))
+                assert cv.ecdsa_sign(d, ks, dg, hl) == o.ecdsa_sign(d, ks, dg, hl), curve
+        finally:
+            cv.free()
