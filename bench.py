@@ -241,20 +241,37 @@ def main():
     cv.scalar_mult_dev(B, d_t.data_ptr(), slen, None, d_points.data_ptr(), d_status.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
     assert int(d_status.max().item()) == 0, "base-point generation produced an error status"
+    # N > 1: every step ends with ONE all-gather of the output shards.  It runs on RCCL's own stream
+    # (async_op) and overlaps the next step's kernels; outputs are double-buffered so that a shard is not
+    # overwritten while it is still being gathered.  All gathers are waited for inside the timed region.
     gathered = None
+    d_outs = [d_out]
+    pending = []
     if world > 1:
         gathered = torch.empty(world * B * plen, dtype=torch.uint8, device=dev)
+        d_outs.append(torch.empty(B * plen, dtype=torch.uint8, device=dev))
+    nstep = [0]
 
     def step():
-        cv.scalar_mult_dev(B, d_scalars.data_ptr(), slen, d_points.data_ptr(), d_out.data_ptr(),
+        k = nstep[0]
+        nstep[0] += 1
+        buf = d_outs[k % len(d_outs)]
+        if world > 1 and len(pending) >= 2:
+            pending.pop(0).wait()          # the gather that last read this buffer (stream-level wait, not a host block)
+        cv.scalar_mult_dev(B, d_scalars.data_ptr(), slen, d_points.data_ptr(), buf.data_ptr(),
                            d_status.data_ptr(), stream.cuda_stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, d_out)
+            pending.append(dist.all_gather_into_tensor(gathered, buf, async_op=True))
+
+    def drain():
+        while pending:
+            pending.pop(0).wait()
 
     # ---- parity gate: random subset vs the CPU oracle, byte for byte ----
     step()
+    drain()
     torch.cuda.synchronize()
-    out_h = d_out.cpu().numpy().tobytes()
+    out_h = d_outs[0].cpu().numpy().tobytes()
     pts_h = d_points.cpu().numpy().tobytes()
     st_h = d_status.cpu().numpy().tobytes()
     assert set(st_h) == {0}, "unexpected status in the synthetic batch"
@@ -271,6 +288,7 @@ def main():
     # ---- warmup, then exactly K timed steps ----
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -287,6 +305,7 @@ def main():
             ktimes.append(ctx.kernel_times())   # [table, affine, loop, finalize] ms of this launch
         except libecc_amd.EcamdError:
             pass
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -324,7 +343,7 @@ def main():
             "config": {"workload": f"{curve} prj_pt_mul+prj_pt_unique, batch 2^{args.batch_log2} per GPU "
                                    "(BASELINE.json configs[1])",
                        "batch_per_gpu": B, "scalar_len": slen, "window": "signed fixed w=4",
-                       "sharding": "contiguous per-rank shards" + (", RCCL all_gather of outputs per step" if world > 1 else ""),
+                       "sharding": "contiguous per-rank shards" + (", one RCCL all_gather of the output shards per step, overlapped with the next step's kernels" if world > 1 else ""),
                        "parity_gate": "128 random items byte-identical to the CPU oracle"},
             "roofline": {
                 "bound": "valu-int-mad (v_mad_u64_u32 issue; not hbm, not mfma -- SURVEY.md 8d)",
