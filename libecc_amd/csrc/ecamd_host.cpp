@@ -248,6 +248,7 @@ struct ecamd_curve {
 	int gslot;       // constant slot of the generic radix-2^29 Jacobian kernel (-1: none)
 	int gflavour;    // 0 dense reduction, 1 secp521r1 (p = 2^521 - 1) single-digit reduction
 	uint32_t *d_gtab; // secp256r1: affine window table [1..8]G, radix-2^29 Montgomery digits, 8 x 40 words
+	uint32_t *d_comb; // secp256r1: 16-bit comb table of G (ECAMD_COMB_ENTRIES x 20 words, 42 MB), NULL when disabled
 	uint32_t qdig[9]; // secp256r1: digits of the group order
 };
 
@@ -626,6 +627,7 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 		return fail("curve: generator upload failed");
 	}
 	cv->d_gtab = nullptr;
+	cv->d_comb = nullptr;
 	cv->ed_state = 0;
 	cv->xdh_state = 0;
 	cv->ed_err = cv->xdh_err = nullptr;
@@ -666,6 +668,45 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 			return fail("curve: generator table construction failed");
 		}
 		big_digits29(cv->qdig, 9, cv->q);
+		if (getenv("ECAMD_NO_COMB") == nullptr) {
+			// 16-bit comb table of the generator: [m 2^(16 j)]G, m = 1..32768, j = 0..15, and [2^256]G,
+			// computed by this engine itself (fixed-base window path) and converted on the device
+			const uint32_t ne = ECAMD_COMB_ENTRIES;
+			std::vector<uint8_t> hs((size_t)ne * 32, 0);
+			for (uint32_t j = 0; j < 16; j++) {
+				for (uint32_t m = 1; m <= 32768; m++) {
+					uint8_t *e = &hs[((size_t)j * 32768 + (m - 1)) * 32];
+					e[31 - 2 * j] = (uint8_t)(m & 0xff);
+					e[31 - 2 * j - 1] = (uint8_t)(m >> 8);
+				}
+			}
+			big_to_be(&hs[(size_t)16 * 32768 * 32], 32, big_mod(big_pow2(256), cv->q));
+			uint8_t *dsc = nullptr, *dpt = nullptr, *dst = nullptr;
+			std::vector<uint8_t> st(ne);
+			bool ok = hipMalloc((void **)&dsc, (size_t)ne * 32) == hipSuccess &&
+				  hipMalloc((void **)&dpt, (size_t)ne * 64) == hipSuccess &&
+				  hipMalloc((void **)&dst, ne) == hipSuccess &&
+				  hipMalloc((void **)&cv->d_comb, (size_t)ne * 20 * 4) == hipSuccess &&
+				  hipMemcpy(dsc, hs.data(), hs.size(), hipMemcpyHostToDevice) == hipSuccess;
+			uint32_t *table = cv->d_comb;
+			cv->d_comb = nullptr;  // the build itself runs through the window path
+			ok = ok && smul_dev_locked(ctx, cv, ne, dsc, 32, nullptr, dpt, dst, ctx->stream) == 0 &&
+			     ecamd_launch_comb_build_p256(dpt, ne, table, ctx->stream) == hipSuccess &&
+			     hipMemcpyAsync(st.data(), dst, ne, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+			     hipStreamSynchronize(ctx->stream) == hipSuccess;
+			for (uint32_t i = 0; ok && i < ne; i++) {
+				ok = (st[i] == 0);
+			}
+			(void)hipFree(dsc);
+			(void)hipFree(dpt);
+			(void)hipFree(dst);
+			if (!ok) {
+				(void)hipFree(table);
+				delete cv;
+				return fail("curve: generator comb table construction failed");
+			}
+			cv->d_comb = table;
+		}
 	}
 	ctx->slot_used[slot] = true;
 	if (cv->gslot >= 0) {
@@ -731,6 +772,9 @@ extern "C" void ecamd_curve_free(ecamd_curve *cv)
 		(void)hipSetDevice(cv->ctx->device);
 		if (cv->d_gen) {
 			(void)hipFree(cv->d_gen);
+		}
+		if (cv->d_comb) {
+			(void)hipFree(cv->d_comb);
 		}
 		if (cv->d_gtab) {
 			(void)hipFree(cv->d_gtab);
@@ -805,12 +849,15 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 		A.slot = cv->slot;
 		A.only_redo = 0;
 		A.lut = nullptr;
+		A.lut_kind = 0;
 		if (fast) {
 			// Jacobian fast path; lanes that met an exceptional pair come back as ECAMD_STATUS_REDO and
 			// are recomputed by the complete-formula kernel (all other lanes exit at once)
 			EcamdSmulArgs Fa = A;
 			Fa.tbl = ctx->tbl_fast;
-			Fa.lut = (fast256 && !d_points) ? cv->d_gtab : nullptr;  // fixed base: skip the table kernels
+			// fixed base: a constant table of the generator replaces the per-item table kernels
+			Fa.lut = (fast256 && !d_points) ? (cv->d_comb ? cv->d_comb : cv->d_gtab) : nullptr;
+			Fa.lut_kind = (Fa.lut && cv->d_comb) ? 1u : 0u;
 			hipEvent_t *ev = (ctx->timing && off == 0) ? ctx->ev : nullptr;  // first chunk of the call
 			if (fast256) {
 				HIPCHK(ecamd_launch_smul_p256(Fa, s, ev));
@@ -1113,8 +1160,8 @@ static int ecdsa_verify_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 		K.n = m;
 		K.clen = 32;
 		K.slot = cv->slot;
-		HIPCHK(ecamd_launch_verify_p256(K, S[3], S[4], d_sig + (size_t)off * 64, S[5], cv->d_gtab, cv->qdig,
-						d_res + off, s));
+		HIPCHK(ecamd_launch_verify_p256(K, S[3], S[4], d_sig + (size_t)off * 64, S[5],
+						cv->d_comb ? cv->d_comb : cv->d_gtab, cv->d_comb ? 1 : 0, cv->qdig, d_res + off, s));
 	}
 	// exceptional pairs inside the interleaved loop (never for honest signatures) come back as
 	// ECAMD_STATUS_REDO: re-verify those items the reference's way

@@ -21,8 +21,10 @@ struct EcamdSmulArgs {
 	uint32_t sstride;        // bytes between consecutive scalars (slen, or 0: one shared scalar)
 	int slot;
 	int only_redo;           // generic kernel: process only items whose status is ECAMD_STATUS_REDO
-	const uint32_t *lut;     // secp256r1 fixed base: shared affine window table of G (NULL: per-item tables)
+	const uint32_t *lut;     // secp256r1 fixed base: shared affine table of G (NULL: per-item tables)
+	uint32_t lut_kind;       // 0: window table [1..8]G (8 x 40 words), 1: 16-bit comb table (ECAMD_COMB_ENTRIES x 20 words)
 };
+#define ECAMD_COMB_ENTRIES (16u * 32768u + 1u)
 
 struct EcamdFpArgs {
 	const uint32_t *a, *b;   // n x NW little-endian 32-bit words
@@ -79,8 +81,10 @@ hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s, hipEven
 // (table kernels), u1/u2/sigs/flags come from k_ecdsa_prep, gtbl = affine table of G (8 x 40 words),
 // qdigits = group order in radix 2^29; result 0 accept / 1 reject / ECAMD_STATUS_REDO
 hipError_t ecamd_launch_verify_p256(const EcamdSmulArgs &pubkeys, const uint8_t *u1, const uint8_t *u2, const uint8_t *sigs,
-				    const uint8_t *flags, const uint32_t *gtbl, const uint32_t *qdigits, uint8_t *result,
-				    hipStream_t s);
+				    const uint8_t *flags, const uint32_t *gtbl, int gtbl_is_comb, const uint32_t *qdigits,
+				    uint8_t *result, hipStream_t s);
+// affine big-endian points -> comb table entries (Montgomery radix-2^29 digits, 20 words each)
+hipError_t ecamd_launch_comb_build_p256(const uint8_t *points, uint32_t n, uint32_t *table, hipStream_t s);
 // ---- X25519 / X448 (ecdh/x25519_448.c:146-302 of the reference) around the scalar multiplication ----
 struct EcamdXdhPrepArgs {
 	const uint8_t *k, *u;    // n x len little-endian scalars and u coordinates (RFC 7748 wire format)

@@ -416,6 +416,136 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 }
 
 // ------------------------------------------------------------------------------------------
+// C'. fixed base: 16-bit comb over a precomputed table of the generator (no doublings at all)
+//   k = sum_j s_j 2^(16 j) + D_16 2^256 with s_j = D_j - 0x8000 in [-32768, 32767], D = digits of
+//   K = k + 0x8000...8000;  table T[j][m-1] = [m 2^(16 j)]G for m = 1..32768 (affine, Montgomery
+//   radix-2^29 digits, 80 bytes each, 16 x 32768 entries + [2^256]G = 42 MB per curve handle: HBM is
+//   plentiful and the whole table sits in the 256 MB Infinity Cache);  [k]G = 17 mixed additions.
+//   Partial sums are smaller in magnitude than the next term, so the only exceptional pair possible is
+//   the last addition of a scalar >= q (e.g. k = q): flagged and recomputed by the complete kernel.
+// ------------------------------------------------------------------------------------------
+#define COMB_ENT_WORDS 20
+#define COMB_PER_WIN 32768
+
+__global__ __launch_bounds__(64) void k_p256_comb_build(const u8 *pts, u32 n, u32 *table)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= n) {
+		return;
+	}
+	u32 xw[8], yw[8];
+	load_be256(pts + (size_t)i * 64, xw);
+	load_be256(pts + (size_t)i * 64 + 32, yw);
+	const Fcanon r2 = constant<Fcanon>(K::R2);
+	const Fcanon xa = canonical(mul(from_words(xw), r2)), ya = canonical(mul(from_words(yw), r2));
+	u32 b[20];
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		b[w] = xa.l[w];
+		b[9 + w] = ya.l[w];
+	}
+	b[18] = b[19] = 0;
+	uint4 *d = (uint4 *)(table + (size_t)i * COMB_ENT_WORDS);
+#pragma unroll
+	for (int q = 0; q < 5; q++) {
+		d[q] = make_uint4(b[4 * q], b[4 * q + 1], b[4 * q + 2], b[4 * q + 3]);
+	}
+}
+
+// scalar (<= 32 bytes big-endian) -> K = k + 0x8000..8000 (8 words) and the carry D_16
+static __device__ __forceinline__ u32 comb_recode(u32 *kw, const u8 *sc, int slen)
+{
+	if (slen == 32) {
+		load_be256(sc, kw);
+	} else {
+#pragma unroll
+		for (int w = 0; w < 8; w++) {
+			u32 x = 0;
+#pragma unroll
+			for (int b = 0; b < 4; b++) {
+				const int pos = 4 * w + b;
+				if (pos < slen) {
+					x |= (u32)sc[slen - 1 - pos] << (8 * b);
+				}
+			}
+			kw[w] = x;
+		}
+	}
+	uint64_t c = 0;
+#pragma unroll
+	for (int w = 0; w < 8; w++) {
+		c += (uint64_t)kw[w] + 0x80008000u;
+		kw[w] = (u32)c;
+		c >>= 32;
+	}
+	return (u32)c;
+}
+
+// acc += [k]G for the recoded scalar (kw, top); inf / bad as in the window loop
+static __device__ __forceinline__ void comb_accumulate(Jac &acc, bool &inf, bool &bad, const u32 *kw, u32 top, const u32 *comb)
+{
+	const FZ onez = weaken<FZ>(constant<Fcanon>(K::ONE));
+#pragma unroll 1
+	for (int j = 0; j <= 16; j++) {
+		const int dig = (j < 16) ? (int)((kw[j >> 1] >> (16 * (j & 1))) & 0xffffu) - 0x8000 : (int)top;
+		const u32 mag = (u32)(dig < 0 ? -dig : dig);
+		u32 b[20];
+		ld<5>(b, comb + ((size_t)j * COMB_PER_WIN + (mag ? mag - 1 : 0)) * COMB_ENT_WORDS);
+		Fcanon tx, tyc;
+#pragma unroll
+		for (int w = 0; w < 9; w++) {
+			tx.l[w] = b[w];
+			tyc.l[w] = b[9 + w];
+		}
+		const FYaff ty = sel(dig < 0, neg_aff(tyc), weaken<FYaff>(tyc));
+		bool hz;
+		const Jac S = madd(acc, tx, ty, hz);
+		const bool use_t = inf & (mag != 0);
+		const bool keep = (mag == 0);
+		bad = bad | (!inf & !keep & hz);
+		acc.X = sel(keep, acc.X, sel(use_t, weaken<FX>(tx), S.X));
+		acc.Y = sel(keep, acc.Y, sel(use_t, weaken<FY>(carry(ty)), S.Y));
+		acc.Z = sel(keep, acc.Z, sel(use_t, onez, S.Z));
+		inf = inf & keep;
+	}
+}
+
+__global__ __launch_bounds__(64) void k_p256_comb(EcamdSmulArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	u32 kw[8];
+	const u32 top = comb_recode(kw, A.scalars + (size_t)i * A.sstride, (int)A.slen);
+	Jac acc;
+	{
+		u32 b[20];
+		ld<5>(b, A.lut);  // any finite point: replaced by the first non-zero digit
+#pragma unroll
+		for (int w = 0; w < 9; w++) {
+			acc.X.l[w] = b[w];
+			acc.Y.l[w] = b[9 + w];
+		}
+		acc.Z = weaken<FZ>(constant<Fcanon>(K::ONE));
+	}
+	bool inf = true, bad = false;
+	comb_accumulate(acc, inf, bad, kw, top, A.lut);
+	if (bad) {
+		A.status[i] = ECAMD_STATUS_REDO;
+		return;
+	}
+	if (inf) {
+		A.status[i] = 2;
+		zero_out(A.out + (size_t)i * 64);
+		return;
+	}
+	u32 *tb = A.tbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
+	jac_store(tb + 1 * TBL_WORDS_PER_ENTRY, acc);
+	A.status[i] = ECAMD_STATUS_JAC;
+}
+
+// ------------------------------------------------------------------------------------------
 // D. finalisation: Jacobian -> affine for FIN_K items per lane with ONE field inversion
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_p256_finalize(EcamdSmulArgs A, u32 nthreads)
@@ -509,12 +639,15 @@ struct P256VerifyArgs {
 	const u8 *flags;        // n: r/s range check of k_ecdsa_prep
 	const u8 *status;       // n: ECAMD_STATUS_TAB where Q's table is ready, 1 where the key is invalid
 	const u32 *qtbl;        // per-item affine tables of Q
-	const u32 *gtbl;        // affine table of G, 8 entries
+	const u32 *gtbl;        // affine table of G, 8 entries (window form) or the 16-bit comb table (COMB)
 	u8 *result;
 	u32 n;
 	u32 qd[9];              // digits of the group order q (canonical, radix 2^29)
 };
 
+// COMB: [u1]G is added after the window loop of [u2]Q from the comb table (17 mixed additions)
+// instead of one mixed addition per window (64)
+template <bool COMB>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, P256_WAVES))) void k_p256_verify_loop(P256VerifyArgs A)
 {
 	const u32 i = blockIdx.x * 64 + threadIdx.x;
@@ -527,7 +660,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 	}
 	const u32 *tb = A.qtbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
 	u32 k1[8], k2[8];
-	const u32 c1 = recode(k1, A.u1 + (size_t)i * 32), c2 = recode(k2, A.u2 + (size_t)i * 32);
+	const u32 c1 = COMB ? comb_recode(k1, A.u1 + (size_t)i * 32, 32) : recode(k1, A.u1 + (size_t)i * 32);
+	const u32 c2 = recode(k2, A.u2 + (size_t)i * 32);
 	const FZ onez = weaken<FZ>(constant<Fcanon>(K::ONE));
 	Jac acc;
 	bool inf = true, bad = false, hz;
@@ -544,7 +678,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 		acc.X = weaken<FX>(gx);
 		acc.Y = weaken<FY>(gy);
 		acc.Z = onez;
-		inf = (c1 == 0);
+		inf = COMB ? true : (c1 == 0);
 		const Jac S = madd(acc, qx, weaken<FYaff>(qy), hz);
 		const bool addq = (c2 != 0);
 		bad = bad | (addq & !inf & hz);
@@ -560,7 +694,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 			acc = dbl(acc);
 		}
 #pragma unroll 1
-		for (int which = 0; which < 2; which++) {
+		for (int which = COMB ? 1 : 0; which < 2; which++) {
 			u32 *kw = which ? k2 : k1;
 			const u32 *base = which ? tb : A.gtbl;
 			const int dig = (int)(kw[7] >> 28) - 8;
@@ -588,6 +722,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 			acc.Z = sel(keep, acc.Z, sel(use_t, onez, S.Z));
 			inf = inf & keep;
 		}
+	}
+	if (COMB) {
+		comb_accumulate(acc, inf, bad, k1, c1, A.gtbl);
 	}
 	if (bad) {
 		A.result[i] = ECAMD_STATUS_REDO;
@@ -632,8 +769,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 }
 
 hipError_t ecamd_launch_verify_p256(const EcamdSmulArgs &pubkeys, const uint8_t *u1, const uint8_t *u2, const uint8_t *sigs,
-				    const uint8_t *flags, const uint32_t *gtbl, const uint32_t *qdigits, uint8_t *result,
-				    hipStream_t s)
+				    const uint8_t *flags, const uint32_t *gtbl, int gtbl_is_comb, const uint32_t *qdigits,
+				    uint8_t *result, hipStream_t s)
 {
 	if (pubkeys.n == 0) {
 		return hipSuccess;
@@ -655,7 +792,11 @@ hipError_t ecamd_launch_verify_p256(const EcamdSmulArgs &pubkeys, const uint8_t 
 	for (int w = 0; w < 9; w++) {
 		V.qd[w] = qdigits[w];
 	}
-	hipLaunchKernelGGL(k_p256_verify_loop, grid, block, 0, s, V);
+	if (gtbl_is_comb) {
+		hipLaunchKernelGGL(k_p256_verify_loop<true>, grid, block, 0, s, V);
+	} else {
+		hipLaunchKernelGGL(k_p256_verify_loop<false>, grid, block, 0, s, V);
+	}
 	return hipGetLastError();
 }
 
@@ -680,9 +821,22 @@ hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s, hipEven
 		hipLaunchKernelGGL(k_p256_affine, dim3((athreads + 63) / 64), block, 0, s, a, athreads);
 	}
 	P256_MARK(2);
-	hipLaunchKernelGGL(k_p256_loop, grid, block, 0, s, a);
+	if (a.lut && a.lut_kind == 1) {
+		hipLaunchKernelGGL(k_p256_comb, grid, block, 0, s, a);
+	} else {
+		hipLaunchKernelGGL(k_p256_loop, grid, block, 0, s, a);
+	}
 	P256_MARK(3);
 	hipLaunchKernelGGL(k_p256_finalize, fgrid, block, 0, s, a, nthreads);
 	P256_MARK(4);
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_comb_build_p256(const uint8_t *points, uint32_t n, uint32_t *table, hipStream_t s)
+{
+	if (n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_p256_comb_build, dim3((n + 63) / 64), dim3(64), 0, s, points, n, table);
 	return hipGetLastError();
 }
