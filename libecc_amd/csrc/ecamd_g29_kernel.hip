@@ -314,6 +314,132 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_smul_g(Ecamd
 	A.status[i] = ECAMD_STATUS_JAC;
 }
 
+// ---- fixed base: 16-bit comb over a precomputed table of the generator (see ecamd_p256_kernel.hip C') ----
+//   k = sum_j s_j 2^(16 j) + D_top 2^(32 NW), s_j = D_j - 0x8000, D = 16-bit digits of K = k + 0x8000..8000
+//   (2 NW windows cover every scalar length the fast path takes); table T[j][m-1] = [m 2^(16 j)]G, m = 1..32768,
+//   plus [2^(32 NW)]G; entries are affine (x, y) in the field representation of this unit, CENTW words each.
+//   [k]G = 2 NW + 1 additions and no doubling.  Partial sums are smaller in magnitude than the next term, so
+//   an exceptional pair can only be the last addition of a scalar >= q: flagged, recomputed by k_smul<NW>.
+template <int PB> struct CombLay {
+	static constexpr int NL = Cfg<PB>::NL;
+	static constexpr int NW = (PB + 31) / 32;
+	static constexpr int CENTW = ((2 * NL + 3) / 4) * 4;
+	static constexpr int NWIN = 2 * NW;
+};
+#define COMB_PER_WIN 32768
+
+template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_build_g(const u8 *pts, u32 n, u32 clen, u32 *table, int gslot)
+{
+	typedef typename Cls<PB>::FC FC;
+	constexpr int NL = CombLay<PB>::NL, NW = CombLay<PB>::NW, CENTW = CombLay<PB>::CENTW;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= n) {
+		return;
+	}
+	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	u32 xw[NW], yw[NW];
+	load_be<NW>(pts + (size_t)i * 2 * clen, (int)clen, xw);
+	load_be<NW>(pts + (size_t)i * 2 * clen + clen, (int)clen, yw);
+	const FC r2 = constant<FC>(K.r2);
+	u32 buf[CENTW];
+	canonical_digits(buf, mul(from_words<PB, NW>(xw), r2, K), K);
+	canonical_digits(buf + NL, mul(from_words<PB, NW>(yw), r2, K), K);
+#pragma unroll
+	for (int w = 2 * NL; w < CENTW; w++) {
+		buf[w] = 0;
+	}
+	uint4 *d = (uint4 *)(table + (size_t)i * CENTW);
+#pragma unroll
+	for (int q = 0; q < CENTW / 4; q++) {
+		d[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
+	}
+}
+
+template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_g(EcamdSmulArgs A, int gslot)
+{
+	typedef Lay<PB> L;
+	typedef typename Cls<PB>::FA FA;
+	typedef typename Cls<PB>::FM FM;
+	typedef typename Cls<PB>::FC FC;
+	constexpr int NL = L::NL, NW = L::NW, KW = L::KW, CENTW = CombLay<PB>::CENTW, NWIN = CombLay<PB>::NWIN;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	const int clen = (int)A.clen;
+	u8 *out = A.out + (size_t)i * 2 * clen;
+	const int slen = (int)A.slen;  // <= 4 * NW, checked by the host
+	u32 kw[KW];
+	load_be<KW>(A.scalars + (size_t)i * A.sstride, slen, kw);
+	{
+		uint64_t c = 0;
+#pragma unroll
+		for (int w = 0; w < NW; w++) {
+			c += (uint64_t)kw[w] + 0x80008000u;
+			kw[w] = (u32)c;
+			c >>= 32;
+		}
+		kw[NW] = (u32)c;  // top digit: 0 or 1
+	}
+	const FA onez = weaken<FA>(constant<FC>(K.one));
+	Jac<PB> acc;
+	acc.X = onez;  // placeholder, replaced by the first non-zero digit
+	acc.Y = onez;
+	acc.Z = onez;
+	bool inf = true, bad = false, hz;
+#pragma unroll 1
+	for (int j = 0; j <= NWIN; j++) {
+		u32 word = 0;
+#pragma unroll
+		for (int w = 0; w < KW; w++) {
+			word = (w == (j >> 1)) ? kw[w] : word;
+		}
+		const int dig = (j < NWIN) ? (int)((word >> (16 * (j & 1))) & 0xffffu) - 0x8000 : (int)word;
+		const u32 mag = (u32)(dig < 0 ? -dig : dig);
+		const uint4 *src = (const uint4 *)(A.lut + ((size_t)j * COMB_PER_WIN + (mag ? mag - 1 : 0)) * CENTW);
+		u32 buf[CENTW];
+#pragma unroll
+		for (int q = 0; q < CENTW / 4; q++) {
+			const uint4 v = src[q];
+			buf[4 * q] = v.x;
+			buf[4 * q + 1] = v.y;
+			buf[4 * q + 2] = v.z;
+			buf[4 * q + 3] = v.w;
+		}
+		FM tx, tyc;
+#pragma unroll
+		for (int w = 0; w < NL; w++) {
+			tx.l[w] = buf[w];
+			tyc.l[w] = buf[NL + w];
+		}
+		const FA txa = weaken<FA>(tx);
+		const FA ty = selg(dig < 0, neg<PB>(tyc, K), weaken<FA>(tyc));
+		const Jac<PB> S = add_jac(acc, txa, ty, onez, hz, K);
+		const bool use_t = inf & (mag != 0);
+		const bool keep = (mag == 0);
+		bad = bad | (!inf & !keep & hz);
+		acc.X = selg(keep, acc.X, selg(use_t, txa, S.X));
+		acc.Y = selg(keep, acc.Y, selg(use_t, ty, S.Y));
+		acc.Z = selg(keep, acc.Z, selg(use_t, onez, S.Z));
+		inf = inf & keep;
+	}
+	if (bad) {
+		A.status[i] = ECAMD_STATUS_REDO;
+		return;
+	}
+	if (inf) {
+		A.status[i] = 2;
+		for (int b = 0; b < 2 * clen; b++) {
+			out[b] = 0;
+		}
+		return;
+	}
+	u32 *tb = A.tbl + (size_t)i * (8 * L::ENTW);
+	jac_store<PB>(tb, acc);
+	A.status[i] = ECAMD_STATUS_JAC;
+}
+
 #define FING_K 8
 template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_finalize_g(EcamdSmulArgs A, int gslot, u32 nthreads)
 {
@@ -427,7 +553,11 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_TAG)(int gslot, const EcamdSmulArgs &a
 		(void)hipEventRecord(ev[1], s);
 		(void)hipEventRecord(ev[2], s);
 	}
-	hipLaunchKernelGGL((k_smul_g<G29_PB, G29_FLAV>), grid, block, 0, s, a, gslot);
+	if (a.lut && a.lut_kind == 1) {
+		hipLaunchKernelGGL((k_comb_g<G29_PB, G29_FLAV>), grid, block, 0, s, a, gslot);
+	} else {
+		hipLaunchKernelGGL((k_smul_g<G29_PB, G29_FLAV>), grid, block, 0, s, a, gslot);
+	}
 	if (ev) {
 		(void)hipEventRecord(ev[3], s);
 	}
@@ -437,6 +567,15 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_TAG)(int gslot, const EcamdSmulArgs &a
 	}
 	return hipGetLastError();
 }
+
+hipError_t G29_CAT(ecamd_g29_comb_build_, G29_TAG)(int gslot, const uint8_t *pts, uint32_t n, uint32_t clen, uint32_t *table, hipStream_t s)
+{
+	if (n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL((k_comb_build_g<G29_PB, G29_FLAV>), dim3((n + 63) / 64), dim3(64), 0, s, pts, n, clen, table, gslot);
+	return hipGetLastError();
+}
 #endif
 
 #ifdef G29_DISPATCH
@@ -444,7 +583,8 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_TAG)(int gslot, const EcamdSmulArgs &a
 #define G29_FOR_PB(X) X(192) X(224) X(255) X(256) X(320) X(384) X(448) X(511) X(512) X(521)
 #define X(PB) \
 	hipError_t ecamd_g29_upload_##PB(int slot, const void *img, size_t bytes); \
-	hipError_t ecamd_g29_launch_##PB(int gslot, const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev);
+	hipError_t ecamd_g29_launch_##PB(int gslot, const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev); \
+	hipError_t ecamd_g29_comb_build_##PB(int gslot, const uint8_t *pts, uint32_t n, uint32_t clen, uint32_t *table, hipStream_t s);
 G29_FOR_PB(X)
 X(521m)
 X(255c)
@@ -501,6 +641,31 @@ hipError_t ecamd_launch_smul_g29(int pbits, int gslot, const EcamdSmulArgs &a, h
 	}
 	switch (pbits) {
 #define X(PB) case PB: return ecamd_g29_launch_##PB(gslot, a, s, ev);
+		G29_FOR_PB(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+}
+#endif
+
+#ifdef G29_DISPATCH
+// comb table geometry: 2 NW windows of 32768 entries + 1, entry = 2 NL digits padded to 4 words
+uint32_t ecamd_g29_comb_entries(int pbits) { return (uint32_t)(2 * ((pbits + 31) / 32)) * 32768u + 1u; }
+uint32_t ecamd_g29_comb_entry_words(int pbits, int flavour)
+{
+	return (uint32_t)(((2 * g29::nl_for_flavour(pbits, flavour) + 3) / 4) * 4);
+}
+hipError_t ecamd_g29_comb_build(int pbits, int gslot, const uint8_t *pts, uint32_t n, uint32_t clen, uint32_t *table,
+				hipStream_t s, int flavour)
+{
+	if (pbits == 521 && flavour == 1) {
+		return ecamd_g29_comb_build_521m(gslot, pts, n, clen, table, s);
+	}
+	if (pbits == 255 && flavour == 2) {
+		return ecamd_g29_comb_build_255c(gslot, pts, n, clen, table, s);
+	}
+	switch (pbits) {
+#define X(PB) case PB: return ecamd_g29_comb_build_##PB(gslot, pts, n, clen, table, s);
 		G29_FOR_PB(X)
 #undef X
 	default: return hipErrorInvalidValue;

@@ -217,6 +217,7 @@ struct ecamd_ctx {
 	size_t stage_bytes[ECAMD_NSTAGE];
 	bool slot_used[ECAMD_MAX_SLOTS_HOST];
 	bool gslot_used[640][8];
+	uint32_t comb_min_batch;   // fixed-base batches of at least this many items build / use the generator's comb table (0: never)
 	bool timing;               // record HIP events around the kernels of the scalar-mult pipeline
 	hipEvent_t ev[ECAMD_NTIMED + 1];
 	bool ev_valid;  // radix-2^29 constant slots, indexed by |p| in bits
@@ -248,7 +249,8 @@ struct ecamd_curve {
 	int gslot;       // constant slot of the generic radix-2^29 Jacobian kernel (-1: none)
 	int gflavour;    // 0 dense reduction, 1 secp521r1 (p = 2^521 - 1) single-digit reduction
 	uint32_t *d_gtab; // secp256r1: affine window table [1..8]G, radix-2^29 Montgomery digits, 8 x 40 words
-	uint32_t *d_comb; // secp256r1: 16-bit comb table of G (ECAMD_COMB_ENTRIES x 20 words, 42 MB), NULL when disabled
+	uint32_t *d_comb; // fast paths: 16-bit comb table of G, built on the first large fixed-base batch (NULL before / disabled)
+	bool comb_off;    // construction failed or is in progress: do not try (again)
 	uint32_t qdig[9]; // secp256r1: digits of the group order
 };
 
@@ -291,6 +293,15 @@ extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
 	ecamd_ctx *c = new ecamd_ctx();
 	c->device = device;
 	c->max_chunk = 1u << 20;
+	{
+		// fixed-base comb tables: built on the first fixed-base batch of at least this many items
+		// (ECAMD_COMB_MIN_BATCH, default 4096; ECAMD_NO_COMB disables them)
+		const char *e = getenv("ECAMD_COMB_MIN_BATCH");
+		c->comb_min_batch = e ? (uint32_t)strtoul(e, nullptr, 10) : 4096u;
+		if (getenv("ECAMD_NO_COMB") != nullptr) {
+			c->comb_min_batch = 0;
+		}
+	}
 	c->tbl = nullptr;
 	c->tbl_bytes = 0;
 	c->tbl_fast = nullptr;
@@ -628,6 +639,7 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	}
 	cv->d_gtab = nullptr;
 	cv->d_comb = nullptr;
+	cv->comb_off = false;
 	cv->ed_state = 0;
 	cv->xdh_state = 0;
 	cv->ed_err = cv->xdh_err = nullptr;
@@ -668,45 +680,6 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 			return fail("curve: generator table construction failed");
 		}
 		big_digits29(cv->qdig, 9, cv->q);
-		if (getenv("ECAMD_NO_COMB") == nullptr) {
-			// 16-bit comb table of the generator: [m 2^(16 j)]G, m = 1..32768, j = 0..15, and [2^256]G,
-			// computed by this engine itself (fixed-base window path) and converted on the device
-			const uint32_t ne = ECAMD_COMB_ENTRIES;
-			std::vector<uint8_t> hs((size_t)ne * 32, 0);
-			for (uint32_t j = 0; j < 16; j++) {
-				for (uint32_t m = 1; m <= 32768; m++) {
-					uint8_t *e = &hs[((size_t)j * 32768 + (m - 1)) * 32];
-					e[31 - 2 * j] = (uint8_t)(m & 0xff);
-					e[31 - 2 * j - 1] = (uint8_t)(m >> 8);
-				}
-			}
-			big_to_be(&hs[(size_t)16 * 32768 * 32], 32, big_mod(big_pow2(256), cv->q));
-			uint8_t *dsc = nullptr, *dpt = nullptr, *dst = nullptr;
-			std::vector<uint8_t> st(ne);
-			bool ok = hipMalloc((void **)&dsc, (size_t)ne * 32) == hipSuccess &&
-				  hipMalloc((void **)&dpt, (size_t)ne * 64) == hipSuccess &&
-				  hipMalloc((void **)&dst, ne) == hipSuccess &&
-				  hipMalloc((void **)&cv->d_comb, (size_t)ne * 20 * 4) == hipSuccess &&
-				  hipMemcpy(dsc, hs.data(), hs.size(), hipMemcpyHostToDevice) == hipSuccess;
-			uint32_t *table = cv->d_comb;
-			cv->d_comb = nullptr;  // the build itself runs through the window path
-			ok = ok && smul_dev_locked(ctx, cv, ne, dsc, 32, nullptr, dpt, dst, ctx->stream) == 0 &&
-			     ecamd_launch_comb_build_p256(dpt, ne, table, ctx->stream) == hipSuccess &&
-			     hipMemcpyAsync(st.data(), dst, ne, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-			     hipStreamSynchronize(ctx->stream) == hipSuccess;
-			for (uint32_t i = 0; ok && i < ne; i++) {
-				ok = (st[i] == 0);
-			}
-			(void)hipFree(dsc);
-			(void)hipFree(dpt);
-			(void)hipFree(dst);
-			if (!ok) {
-				(void)hipFree(table);
-				delete cv;
-				return fail("curve: generator comb table construction failed");
-			}
-			cv->d_comb = table;
-		}
 	}
 	ctx->slot_used[slot] = true;
 	if (cv->gslot >= 0) {
@@ -802,6 +775,66 @@ static size_t tbl_bytes_for(const ecamd_curve *cv, uint32_t stride)
 	return (size_t)ECAMD_TBL_ENTRIES * 3 * (size_t)cv->nw * 4 * (size_t)stride;
 }
 
+// 16-bit comb table of the generator: T[j][m-1] = [m 2^(16 j)]G (m = 1..32768, j over every 16-bit window of
+// the longest scalar the fast path takes) plus [2^(8 slen)]G, computed by this engine itself through the
+// window path and converted to the kernels' field representation on the device.  42 MB (256-bit curves) to
+// 183 MB (521 bits) of the 288 GB per curve handle; turns [k]G into 2 NW + 1 additions.  ctx->mu held.
+static void maybe_build_comb(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n)
+{
+	if (cv->d_comb || cv->comb_off || ctx->comb_min_batch == 0 || n < ctx->comb_min_batch) {
+		return;
+	}
+	const bool p256 = cv->is_p256;
+	if (!p256 && cv->gslot < 0) {
+		return;
+	}
+	cv->comb_off = true;  // no recursion while building; stays set if anything fails
+	const uint32_t nwords = (uint32_t)((cv->pbits + 31) / 32);
+	const uint32_t slen = 4 * nwords, nwin = 2 * nwords;
+	const uint32_t ne = nwin * 32768u + 1u;
+	const uint32_t ew = p256 ? 20u : ecamd_g29_comb_entry_words(cv->pbits, cv->gflavour);
+	if (!p256 && ne != ecamd_g29_comb_entries(cv->pbits)) {
+		return;
+	}
+	std::vector<uint8_t> hs((size_t)ne * slen, 0);
+	for (uint32_t j = 0; j < nwin; j++) {
+		for (uint32_t m = 1; m <= 32768; m++) {
+			uint8_t *e = &hs[((size_t)j * 32768 + (m - 1)) * slen];
+			e[slen - 1 - 2 * j] = (uint8_t)(m & 0xff);
+			e[slen - 2 - 2 * j] = (uint8_t)(m >> 8);
+		}
+	}
+	big_to_be(&hs[(size_t)nwin * 32768 * slen], (int)slen, big_mod(big_pow2(8 * (int)slen), cv->q));
+	const size_t plen = (size_t)2 * cv->clen;
+	uint8_t *dsc = nullptr, *dpt = nullptr, *dst = nullptr;
+	uint32_t *table = nullptr;
+	std::vector<uint8_t> st(ne);
+	hipStream_t s = ctx->stream;
+	bool ok = hipMalloc((void **)&dsc, hs.size()) == hipSuccess && hipMalloc((void **)&dpt, (size_t)ne * plen) == hipSuccess &&
+		  hipMalloc((void **)&dst, ne) == hipSuccess && hipMalloc((void **)&table, (size_t)ne * ew * 4) == hipSuccess &&
+		  hipMemcpy(dsc, hs.data(), hs.size(), hipMemcpyHostToDevice) == hipSuccess;
+	ok = ok && smul_dev_locked(ctx, cv, ne, dsc, slen, nullptr, dpt, dst, s) == 0;
+	if (ok) {
+		const hipError_t e = p256 ? ecamd_launch_comb_build_p256(dpt, ne, table, s)
+					  : ecamd_g29_comb_build(cv->pbits, cv->gslot, dpt, ne, (uint32_t)cv->clen, table, s, cv->gflavour);
+		ok = e == hipSuccess && hipMemcpyAsync(st.data(), dst, ne, hipMemcpyDeviceToHost, s) == hipSuccess &&
+		     hipStreamSynchronize(s) == hipSuccess;
+	}
+	for (uint32_t i = 0; ok && i < ne; i++) {
+		ok = (st[i] == 0);
+	}
+	(void)hipFree(dsc);
+	(void)hipFree(dpt);
+	(void)hipFree(dst);
+	if (!ok) {
+		(void)hipFree(table);
+		(void)hipGetLastError();
+		return;  // the window path keeps serving fixed-base calls
+	}
+	cv->d_comb = table;
+	cv->comb_off = false;
+}
+
 // sstride = slen normally; 0 broadcasts one scalar to every item (subgroup / cofactor passes)
 static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_scalars,
 			   uint32_t slen, const uint8_t *d_points, uint8_t *d_out, uint8_t *d_status,
@@ -815,6 +848,9 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 	const bool fast256 = cv->is_p256 && slen <= 32;
 	const bool fastg = !fast256 && cv->gslot >= 0 && slen <= ecamd_g29_max_slen(cv->pbits);
 	const bool fast = fast256 || fastg;
+	if (fast && !d_points) {
+		maybe_build_comb(ctx, const_cast<ecamd_curve *>(cv), n);
+	}
 	{
 		uint8_t *t = (uint8_t *)ctx->tbl;
 		const int rc = ensure(&t, &ctx->tbl_bytes, tbl_bytes_for(cv, stride));
@@ -856,8 +892,10 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 			EcamdSmulArgs Fa = A;
 			Fa.tbl = ctx->tbl_fast;
 			// fixed base: a constant table of the generator replaces the per-item table kernels
-			Fa.lut = (fast256 && !d_points) ? (cv->d_comb ? cv->d_comb : cv->d_gtab) : nullptr;
-			Fa.lut_kind = (Fa.lut && cv->d_comb) ? 1u : 0u;
+			if (!d_points) {
+				Fa.lut = cv->d_comb ? cv->d_comb : (fast256 ? cv->d_gtab : nullptr);
+				Fa.lut_kind = cv->d_comb ? 1u : 0u;
+			}
 			hipEvent_t *ev = (ctx->timing && off == 0) ? ctx->ev : nullptr;  // first chunk of the call
 			if (fast256) {
 				HIPCHK(ecamd_launch_smul_p256(Fa, s, ev));
@@ -1119,6 +1157,7 @@ static int ecdsa_verify_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 		return 0;
 	}
 	// secp256r1: interleaved [u1]G + [u2]Q loop (ecamd_launch_verify_p256), in chunks
+	maybe_build_comb(ctx, const_cast<ecamd_curve *>(cv), n);
 	const uint32_t chunk = n < ctx->max_chunk ? n : ctx->max_chunk;
 	{
 		uint8_t *t = (uint8_t *)ctx->tbl_fast;

@@ -22,7 +22,7 @@ struct EcamdSmulArgs {
 	int slot;
 	int only_redo;           // generic kernel: process only items whose status is ECAMD_STATUS_REDO
 	const uint32_t *lut;     // secp256r1 fixed base: shared affine table of G (NULL: per-item tables)
-	uint32_t lut_kind;       // 0: window table [1..8]G (8 x 40 words), 1: 16-bit comb table (ECAMD_COMB_ENTRIES x 20 words)
+	uint32_t lut_kind;       // 0: window table [1..8]G (8 x 40 words), 1: 16-bit comb table of the generator
 };
 #define ECAMD_COMB_ENTRIES (16u * 32768u + 1u)
 
@@ -172,6 +172,11 @@ uint32_t ecamd_g29_max_slen(int pbits);      // longest scalar (bytes) the fast 
 size_t ecamd_g29_image_bytes(int pbits, int flavour);
 hipError_t ecamd_g29_upload(int pbits, int slot, const void *img, size_t bytes, int flavour);
 hipError_t ecamd_launch_smul_g29(int pbits, int gslot, const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev, int flavour);
+// fixed-base comb tables of the radix-2^29 path (lut_kind 1): geometry and construction from affine big-endian points
+uint32_t ecamd_g29_comb_entries(int pbits);
+uint32_t ecamd_g29_comb_entry_words(int pbits, int flavour);
+hipError_t ecamd_g29_comb_build(int pbits, int gslot, const uint8_t *pts, uint32_t n, uint32_t clen, uint32_t *table,
+				hipStream_t s, int flavour);
 hipError_t ecamd_launch_fp(int nw, const EcamdFpArgs &a, hipStream_t s);
 hipError_t ecamd_launch_pt(int nw, const EcamdPtArgs &a, hipStream_t s);
 size_t ecamd_curvek_bytes(int nw);

@@ -23,6 +23,8 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def gpu_ctx():
     import libecc_amd
+    # build the fixed-base comb tables already for the small batches the tests use (default: 4096 items)
+    os.environ.setdefault("ECAMD_COMB_MIN_BATCH", "48")
     ctx = libecc_amd.Context(0)  # raises if no device / library: no silent fallback
     yield ctx
     ctx.close()

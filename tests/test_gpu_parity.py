@@ -793,35 +793,38 @@ def test_every_builtin_curve(gpu_ctx):
             cv.free()
 
 
-def test_p256_fixed_base_comb_edges(gpu_ctx):
-    """secp256r1 fixed base runs on the 16-bit comb table: scalars that stress the signed recoding
-    (digits 0x0000 / 0x7fff / 0x8000 / 0xffff in every window, powers of two around the window
-    boundaries, q-1, q, q+1, 2^256-1, zero) and every scalar length 1..32, against the oracle; the same
-    through ECDSA signing and verification"""
+@pytest.mark.parametrize("curve", ["SECP256R1", "WEI25519", "SECP224R1", "BRAINPOOLP256R1", "SECP384R1", "SECP521R1", "WEI448"])
+def test_fixed_base_comb_edges(gpu_ctx, curve):
+    """fixed base runs on the 16-bit comb table of the generator once a batch is large enough: scalars
+    that stress the signed recoding (digits 0x0000 / 0x7fff / 0x8000 / 0xffff in every window, powers of
+    two around the window boundaries, q-1, q, q+1, all ones, zero) and every scalar length, against the
+    oracle; the same through ECDSA signing and verification"""
     rng = np.random.default_rng(54)
-    curve = "SECP256R1"
     q = CURVES[curve]["q"]
     o = Oracle(curve)
     cv = gpu_ctx.curve(curve)
     try:
-        vals = [0, 1, 2, q - 1, q, q + 1, 2**256 - 1, 2**255, 2**255 - 1, 2**256 - 2**240, 2**240 - 1]
+        ql = o.qlen
+        top = 1 << (8 * ql)
+        nwin = (8 * ql + 15) // 16
+        vals = [0, 1, 2, q - 1, q, q + 1, top - 1, top >> 1, (top >> 1) - 1, top - (top >> 16), (top >> 16) - 1, 2 * q, 3 * q + 5]
         for pat in (0x0000, 0x0001, 0x7fff, 0x8000, 0x8001, 0xffff):
-            vals.append(sum(pat << (16 * j) for j in range(16)))
-            vals.append(sum((pat if j % 2 else 0x8000) << (16 * j) for j in range(16)))
-        for j in range(16):
+            vals.append(sum(pat << (16 * j) for j in range(nwin)))
+            vals.append(sum((pat if j % 2 else 0x8000) << (16 * j) for j in range(nwin)))
+        for j in range(nwin):
             vals += [1 << (16 * j), (1 << (16 * j)) - 1, 0x8000 << (16 * j), (0x8000 << (16 * j)) - 1, 0x7fff << (16 * j)]
-        vals = [v % 2**256 for v in vals]
-        sc = b"".join(v.to_bytes(32, "big") for v in vals) + rand_bytes(rng, 32 * 64)
+        vals = [v % top for v in vals]
+        sc = b"".join(v.to_bytes(ql, "big") for v in vals) + rand_bytes(rng, ql * 64)
         exp = o.scalar_mult(sc)
         assert cv.scalar_mult(sc) == exp
         assert 2 in exp[1] and 0 in exp[1]
-        for slen in list(range(1, 32)):
-            s2 = rand_bytes(rng, slen * 6) + b"\xff" * slen + b"\x00" * slen + b"\x80" * slen
+        for slen in range(1, 4 * ((CURVES[curve]["p"].bit_length() + 31) // 32) + 1, 1 if ql <= 32 else 5):
+            s2 = rand_bytes(rng, slen * 45) + b"\xff" * slen + b"\x00" * slen + b"\x80" * slen
             assert cv.scalar_mult(s2, None, slen) == o.scalar_mult(s2, None, slen), slen
         # sign with nonces of those shapes, verify what was signed
-        ks = b"".join(v.to_bytes(32, "big") for v in vals if 0 < v < q)
-        n = len(ks) // 32
-        d = b"".join(((int.from_bytes(rand_bytes(rng, 40), "big") % (q - 1)) + 1).to_bytes(32, "big") for _ in range(n))
+        ks = b"".join(v.to_bytes(ql, "big") for v in vals if 0 < v < q)
+        n = len(ks) // ql
+        d = b"".join(((int.from_bytes(rand_bytes(rng, ql + 8), "big") % (q - 1)) + 1).to_bytes(ql, "big") for _ in range(n))
         dg = rand_bytes(rng, 32 * n)
         sigs = cv.ecdsa_sign(d, ks, dg, 32)
         assert sigs == o.ecdsa_sign(d, ks, dg, 32)
