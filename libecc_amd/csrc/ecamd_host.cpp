@@ -789,6 +789,11 @@ static void maybe_build_comb(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n)
 		return;
 	}
 	cv->comb_off = true;  // no recursion while building; stays set if anything fails
+	// the build reuses the context's scratch tables on the context's stream: let kernels the caller has in
+	// flight on other streams (earlier stages of the same entry point) finish first -- a one-time event
+	if (hipDeviceSynchronize() != hipSuccess) {
+		return;
+	}
 	const uint32_t nwords = (uint32_t)((cv->pbits + 31) / 32);
 	const uint32_t slen = 4 * nwords, nwin = 2 * nwords;
 	const uint32_t ne = nwin * 32768u + 1u;

@@ -833,3 +833,33 @@ def test_fixed_base_comb_edges(gpu_ctx, curve):
         assert cv.ecdsa_verify(pubs, sigs[0], dg, 32) == o.ecdsa_verify(pubs, sigs[0], dg, 32)
     finally:
         cv.free()
+
+
+def test_first_large_dev_call_builds_comb_safely():
+    """a fresh context whose very first call is a large device-pointer Ed25519 verification on the caller's
+    stream: the comb table of the generator is built in the middle of that call (after the [h]A
+    multiplication was enqueued) and must not disturb it"""
+    import torch
+    import libecc_amd
+    from test_oracle import ed25519_cases
+    rng = np.random.default_rng(36)
+    dev = torch.device("cuda:0")
+    pubs, sigs, msgs, hram = ed25519_cases(rng, nvalid=30)
+    exp = Oracle("WEI25519").eddsa_verify(pubs, sigs, hram)
+    n0 = len(exp)
+    reps = (1 << 16) // n0 + 1
+    n = n0 * reps
+    ctx = libecc_amd.Context(0)
+    cv = ctx.curve("WEI25519")
+    try:
+        stream = torch.cuda.Stream(device=dev)
+        t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+        dp, ds, dh = t(pubs * reps), t(sigs * reps), t(hram * reps)
+        dr = torch.full((n,), 0xAA, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        cv.eddsa_verify_dev(n, dp.data_ptr(), ds.data_ptr(), dh.data_ptr(), dr.data_ptr(), stream.cuda_stream)
+        stream.synchronize()
+        assert bytes(dr.cpu().numpy()) == exp * reps
+    finally:
+        cv.free()
+        ctx.close()
