@@ -533,6 +533,270 @@ template <> struct TabGP<G29_PB> {
 	static __device__ __forceinline__ const CurveG<Lay<G29_PB>::NL> &get(int slot) { return G29_CAT(g_g29_, G29_TAG).s[slot]; }
 };
 
+#ifdef G29_P25519
+// ------------------------------------------------------------------------------------------
+// Ed25519 point decoding and the X25519 front end on the 2^255 - 19 field of this unit (the same
+// computations as k_ed_decode<8> / k_xdh_prep<8> in ecamd_kernels.hip, which stay the reference
+// implementation and serve when this unit has no slot): residues are plain here (R = 1).
+// ------------------------------------------------------------------------------------------
+namespace c25519 {
+constexpr int PB = 255;
+typedef Cls<PB>::FA FA;
+typedef Cls<PB>::FM FM;
+typedef Cls<PB>::FC FC;
+typedef CurveG<9> CK;
+
+static __device__ __forceinline__ FM sqr_n(FM a, int n, const CK &K)
+{
+	for (int k = 0; k < n; k++) {
+		a = weaken<FM>(sqr(a, K));
+	}
+	return a;
+}
+#define M_(a, b) weaken<FM>(mul(a, b, K))
+// z^(2^250 - 1); *z11 = z^11
+static __device__ FM pow_2_250m1(const FM &z, FM *z11, const CK &K)
+{
+	const FM z2 = sqr_n(z, 1, K);
+	const FM z9 = M_(sqr_n(z2, 2, K), z);
+	*z11 = M_(z9, z2);
+	const FM a5 = M_(sqr_n(*z11, 1, K), z9);
+	const FM a10 = M_(sqr_n(a5, 5, K), a5);
+	const FM a20 = M_(sqr_n(a10, 10, K), a10);
+	const FM a40 = M_(sqr_n(a20, 20, K), a20);
+	const FM a50 = M_(sqr_n(a40, 10, K), a10);
+	const FM a100 = M_(sqr_n(a50, 50, K), a50);
+	const FM a200 = M_(sqr_n(a100, 100, K), a100);
+	return M_(sqr_n(a200, 50, K), a50);
+}
+// exact comparisons of lazily reduced values: a == b, a == -b
+template <class A, class B> static __device__ __forceinline__ bool eq(const A &a, const B &b, const CK &K)
+{
+	return is_zero_mulout(mulc(carry(sub_auto<1>(a, b, K)), constant<FC>(K.one), K), K);
+}
+template <class A, class B> static __device__ __forceinline__ bool eq_neg(const A &a, const B &b, const CK &K)
+{
+	return is_zero_mulout(mulc(carry(add(a, b)), constant<FC>(K.one), K), K);
+}
+static __device__ __forceinline__ FC digits9(const u32 *d)
+{
+	FC r;
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		r.l[w] = d[w];
+	}
+	return r;
+}
+// little-endian 32 bytes -> 8 words
+static __device__ __forceinline__ void load_le256(const u8 *src, u32 *w)
+{
+#pragma unroll
+	for (int i = 0; i < 8; i++) {
+		w[i] = (u32)src[4 * i] | ((u32)src[4 * i + 1] << 8) | ((u32)src[4 * i + 2] << 16) | ((u32)src[4 * i + 3] << 24);
+	}
+}
+static __device__ __forceinline__ bool below_p(const E<PB, MASK, MASK, 1> &v, const CK &K)
+{
+	u32 b = 0;
+#pragma unroll
+	for (int j = 0; j < 9; j++) {
+		b = (v.l[j] - K.p[j] - b) >> 31;
+	}
+	return b != 0;
+}
+// value (any class the multiplier takes) -> canonical big-endian bytes
+template <class A> static __device__ __forceinline__ void store_canon_be(u8 *dst, const A &a, bool ok, const CK &K)
+{
+	u32 d[9], w[8];
+	canonical_digits(d, mulc(a, constant<FC>(K.one), K), K);
+	to_words<9, 8>(w, d);
+#pragma unroll
+	for (int i = 0; i < 8; i++) {
+		w[i] = ok ? w[i] : 0u;
+	}
+	store_be<8>(dst, 32, w);
+}
+// [2^r]P == infinity for the affine point (x, y)?  (r complete-free Jacobian doublings: a doubling reaches
+// infinity exactly when Y = 0, which shows as Z = 0 one step later, or at once for y = 0)
+template <class AX, class AY> static __device__ __forceinline__ bool small_order(const AX &x, const AY &y, u32 r, const CK &K)
+{
+	Jac<PB> P;
+	P.X = weaken<FA>(x);
+	P.Y = weaken<FA>(y);
+	P.Z = weaken<FA>(constant<FC>(K.one));
+	for (u32 k = 0; k < r; k++) {
+		P = dbl(P, K);
+	}
+	return is_zero_mulout(mulc(P.Z, constant<FC>(K.one), K), K);
+}
+
+struct DecXY {
+	FA x;      // the selected root (or its negation), class FA
+	FM ym;
+	bool ok;
+};
+static __device__ DecXY decode_xy(const EcamdEdDecodeArgs &A, const u8 *src, const CK &K)
+{
+	DecXY R;
+	u32 yw[8];
+	load_le256(src, yw);
+	const u32 x0 = yw[7] >> 31;
+	yw[7] &= 0x7fffffffu;
+	const auto yd = from_words<PB, 8>(yw);
+	bool ok = below_p(yd, K);
+	const FC onec = constant<FC>(K.one);
+	const FM ym = M_(yd, onec);
+	const FM y2 = sqr_n(ym, 1, K);
+	const auto u = carry(sub_auto<1>(onec, y2, K));                                    // 1 - y^2
+	FC am1;                                                                             // a = -1 = p - 1
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		am1.l[w] = K.p[w] - (w == 0 ? 1u : 0u);
+	}
+	const auto v = carry(sub_auto<1>(am1, M_(digits9(A.g_d), y2), K));                // a - d y^2
+	const FM v3 = M_(weaken<FM>(sqrc(v, K)), v);
+	const FM v7 = M_(sqr_n(v3, 1, K), v);
+	const FM t = M_(u, v7);
+	FM t11;
+	const FM pw = M_(sqr_n(pow_2_250m1(t, &t11, K), 2, K), t);                         // t^(2^252 - 3)
+	const FM beta = M_(M_(u, v3), pw);
+	const FM chk = M_(v, sqr_n(beta, 1, K));
+	const bool root = eq(chk, u, K);
+	const bool alt = eq_neg(chk, u, K);
+	ok = ok & (root | alt);
+	const FM xs = selg(alt & !root, M_(beta, digits9(A.g_sm1)), beta);
+	u32 xd[9];
+	canonical_digits(xd, xs, K);
+	u32 nz = 0;
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		nz |= xd[w];
+	}
+	ok = ok & (nz != 0);  // x = 0: the neutral point is rejected, (0, -1) dies in fp_inv(0)
+	R.x = selg((xd[0] & 1u) != x0, neg<PB>(xs, K), weaken<FA>(xs));
+	R.ym = ym;
+	R.ok = ok;
+	return R;
+}
+#undef M_
+}  // namespace c25519
+
+__global__ __launch_bounds__(64) void k_ed_decode_c25519(EcamdEdDecodeArgs A, int gslot)
+{
+	using namespace c25519;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const FC onec = constant<FC>(K.one);
+	const FM onem = weaken<FM>(onec);
+	DecXY P[2];
+	P[0] = decode_xy(A, A.encA + (size_t)i * A.strideA, K);
+	P[1] = decode_xy(A, A.encR + (size_t)i * A.strideR, K);
+	FM den[2];
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const auto omy = carry(sub_auto<1>(onec, P[k].ym, K));
+		den[k] = selg(P[k].ok, weaken<FM>(mulc(omy, P[k].x, K)), onem);                // (1 - y) x, non-zero when ok
+	}
+	FM d11;
+	const FM dd = weaken<FM>(mul(den[0], den[1], K));
+	const FM dinv = weaken<FM>(mul(sqr_n(pow_2_250m1(dd, &d11, K), 5, K), d11, K));    // dd^(p-2)
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const auto omy = carry(sub_auto<1>(onec, P[k].ym, K));
+		const FM inv = weaken<FM>(mul(dinv, den[1 - k], K));                           // 1 / ((1 - y) x)
+		const FM um = weaken<FM>(mulc(carry(add(onec, P[k].ym)), mulc(inv, P[k].x, K), K));
+		const FM vm = weaken<FM>(mul(mul(digits9(A.g_alpha), um, K), mulc(inv, omy, K), K));
+		const auto Xm = carry(add(um, digits9(A.g_A3)));
+		bool good = P[k].ok;
+		if (k == 0) {
+			good = good & !small_order(Xm, vm, A.cof_dbl, K);
+		}
+		u8 *pd = (k == 0 ? A.pointsA : A.pointsR) + (size_t)i * 64;
+		store_canon_be(pd, Xm, good, K);
+		store_canon_be(pd + 32, vm, good, K);
+		(k == 0 ? A.flagsA : A.flagsR)[i] = good ? 0 : 1;
+	}
+}
+
+__global__ __launch_bounds__(64) void k_xdh_prep_c25519(EcamdXdhPrepArgs A, int gslot)
+{
+	using namespace c25519;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const FC onec = constant<FC>(K.one);
+	// scalar: reversed to big-endian and clamped (decode_scalar)
+	{
+		const u8 *ks = A.k + (size_t)i * 32;
+		u8 *kd = A.scalars + (size_t)i * 32;
+		for (int b = 0; b < 32; b++) {
+			u8 v = ks[b];
+			if (b == 0) v &= 248;
+			if (b == 31) v = (u8)((v & 127) | 64);
+			kd[31 - b] = v;
+		}
+	}
+	u32 uw[8];
+	load_le256(A.u + (size_t)i * 32, uw);
+	bool ok = true;
+	{
+		// u >= p is rejected (only the eight words are significant: the top bit counts)
+		constexpr u32 pw[8] = {0xffffffedu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x7fffffffu};
+		u32 bw = 0;
+#pragma unroll
+		for (int w = 0; w < 8; w++) {
+			const uint64_t x = (uint64_t)uw[w] - pw[w] - bw;
+			bw = (u32)(x >> 63);
+		}
+		ok = bw != 0;
+	}
+	uw[7] &= ok ? 0xffffffffu : 0x7fffffffu;  // keep from_words inside its input class when rejected
+	const auto ud = from_words<PB, 8>(uw);
+	const FM um = weaken<FM>(mul(ud, onec, K));
+	// w = u (u (u + A) + 1)
+	const auto t1 = carry(add(um, digits9(A.g_A)));
+	const auto t2 = carry(add(mulc(um, t1, K), onec));
+	const FM w = weaken<FM>(mulc(um, t2, K));
+	// candidate root c = w^((p + 3) / 8) = w * w^((p - 5) / 8)
+	FM w11;
+	const FM pw22523 = weaken<FM>(mul(sqr_n(pow_2_250m1(w, &w11, K), 2, K), w, K));
+	const FM c = weaken<FM>(mul(pw22523, w, K));
+	const FM c2 = sqr_n(c, 1, K);
+	const bool root = eq(c2, w, K);
+	const bool alt = eq_neg(c2, w, K);
+	const FM v = selg(alt & !root, weaken<FM>(mul(c, digits9(A.g_sm1), K)), c);
+	ok = ok & (root | alt);
+	const auto xm = carry(add(um, digits9(A.g_A3)));
+	ok = ok & !small_order(xm, v, A.cof_dbl, K);
+	u8 *pd = A.points + (size_t)i * 64;
+	store_canon_be(pd, xm, ok, K);
+	store_canon_be(pd + 32, v, ok, K);
+	A.flags[i] = ok ? 0 : 1;
+}
+
+hipError_t ecamd_launch_ed_decode_c25519(const EcamdEdDecodeArgs &a, int gslot, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_ed_decode_c25519, dim3((a.n + 63) / 64), dim3(64), 0, s, a, gslot);
+	return hipGetLastError();
+}
+hipError_t ecamd_launch_xdh_prep_c25519(const EcamdXdhPrepArgs &a, int gslot, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_xdh_prep_c25519, dim3((a.n + 63) / 64), dim3(64), 0, s, a, gslot);
+	return hipGetLastError();
+}
+#endif  // G29_P25519
+
 hipError_t G29_CAT(ecamd_g29_upload_, G29_TAG)(int slot, const void *img, size_t bytes)
 {
 	typedef CurveG<Lay<G29_PB>::NL> CK;

@@ -1517,6 +1517,11 @@ static void xdh_setup(ecamd_curve *cv)
 	big_store(P.e, 17, e);
 	big_store(P.A, nw, big_mulmod(A, R, p));
 	big_store(P.A3, nw, big_mulmod(A3, R, p));
+	if (Aval == 486662) {
+		big_digits29(P.g_A, 9, A);
+		big_digits29(P.g_A3, 9, A3);
+		big_digits29(P.g_sm1, 9, big_sqrt_m1(p));
+	}
 	P.slot = cv->slot;
 	big_store(cv->xdh_A3, 17, A3);
 	// cofactor h: order = h q
@@ -1559,7 +1564,11 @@ static int xdh_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uin
 	P.points = S[3];
 	P.flags = S[4];
 	P.n = n;
-	HIPCHK(ecamd_launch_xdh_prep(nw, P, s));
+	if (cv->gflavour == 2 && cv->gslot >= 0) {
+		HIPCHK(ecamd_launch_xdh_prep_c25519(P, cv->gslot, s));  // the same front end on the radix-2^29 field
+	} else {
+		HIPCHK(ecamd_launch_xdh_prep(nw, P, s));
+	}
 	// [k]Q  ([h]Q != infinity was checked by the prep kernel)
 	if (smul_dev_locked(ctx, cv, n, S[2], (uint32_t)len, S[3], S[7], S[8], s)) {
 		return -1;
@@ -1745,6 +1754,10 @@ static void ed_setup(ecamd_curve *cv)
 	big_store(D.sm1, nw, big_mulmod(big_sqrt_m1(p), R, p));
 	big_store(D.alpha, nw, big_mulmod(alpha, R, p));
 	big_store(D.A3, nw, big_mulmod(A3, R, p));
+	big_digits29(D.g_d, 9, d_ed);
+	big_digits29(D.g_sm1, 9, big_sqrt_m1(p));
+	big_digits29(D.g_alpha, 9, alpha);
+	big_digits29(D.g_A3, 9, A3);
 	cv->ed_state = 1;
 }
 
@@ -1776,7 +1789,11 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 	D.flagsA = S[5];
 	D.flagsR = S[6];
 	D.cof_dbl = cof_dbl;
-	HIPCHK(ecamd_launch_ed_decode(nw, D, s));
+	if (cv->gflavour == 2 && cv->gslot >= 0) {
+		HIPCHK(ecamd_launch_ed_decode_c25519(D, cv->gslot, s));  // the same decoding on the radix-2^29 field
+	} else {
+		HIPCHK(ecamd_launch_ed_decode(nw, D, s));
+	}
 	EcamdEdScalArgs C;
 	memset(&C, 0, sizeof(C));
 	C.sigs = d_sig;

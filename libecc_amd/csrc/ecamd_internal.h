@@ -95,6 +95,7 @@ struct EcamdXdhPrepArgs {
 	uint32_t cof_dbl;        // log2(cofactor)
 	uint32_t e[17];          // the exponent, little-endian words
 	uint32_t A[17], A3[17], sm1[17];  // A, A/3, sqrt(-1) in Montgomery form (radix 2^(32 NW))
+	uint32_t g_A[9], g_A3[9], g_sm1[9];  // the same as plain radix-2^29 digits (2^255 - 19 unit, X25519 only)
 	int slot;
 };
 struct EcamdXdhFinArgs {
@@ -119,6 +120,7 @@ struct EcamdEdDecodeArgs {
 	uint8_t *flagsA, *flagsR;   // out: n, 0 ok / 1 the reference's decode / map returns -1 (A: or [cofactor]A = infinity)
 	uint32_t n, len, cof_dbl;   // cof_dbl = log2(cofactor)
 	uint32_t a[17], d[17], sm1[17], alpha[17], A3[17];  // Edwards a, d; sqrt(-1); alpha_edwards; A/3 (Montgomery form)
+	uint32_t g_d[9], g_sm1[9], g_alpha[9], g_A3[9];     // the same as plain radix-2^29 digits (2^255 - 19 unit)
 	int slot;
 };
 struct EcamdEdScalArgs {
@@ -139,6 +141,9 @@ struct EcamdEdFinArgs {
 	int slot;
 };
 hipError_t ecamd_launch_ed_decode(int nw, const EcamdEdDecodeArgs &a, hipStream_t s);
+// the same two front-end kernels on the radix-2^29 field of the 2^255 - 19 unit (gslot: its constant slot)
+hipError_t ecamd_launch_ed_decode_c25519(const EcamdEdDecodeArgs &a, int gslot, hipStream_t s);
+hipError_t ecamd_launch_xdh_prep_c25519(const EcamdXdhPrepArgs &a, int gslot, hipStream_t s);
 hipError_t ecamd_launch_ed_scal(int nw, const EcamdEdScalArgs &a, hipStream_t s);
 hipError_t ecamd_launch_ed_fin(int nw, const EcamdEdFinArgs &a, hipStream_t s);
 
