@@ -23,12 +23,14 @@
 #define G29_FN inline
 #define G29_NOINLINE inline
 #endif
-// Multiplications are inlined into the formulas for fields of up to 14 limbs (<= 384 bit: +25 % on
-// secp256r1, +23 % on secp384r1 on MI355X) and called out of line from 16 limbs on, where a single
-// multiplier is 500-800 instructions and inlining 25 of them per loop body mostly costs compile
-// time (the 384-bit unit already takes 90 s) and instruction-cache misses.
+// Multiplications are inlined into the formulas for every field size: measured on MI355X against an
+// out-of-line multiplier (arguments and result in VGPRs), inlining gives +25 % on 256-bit fields, +23 % on
+// secp384r1, +16 % on 448 bits, +42 % on brainpoolP512r1 and +69 % on secp521r1 (calls cost the caller its
+// register allocation: 240 bytes of scratch and one wave per SIMD).  The price is compile time (the three
+// 19-limb units take 3-4 minutes each; libecc_amd/build.py compiles the units in parallel).
+// -DG29_CALL_FROM_NL=<limbs> switches to calls from that size on.
 #ifndef G29_CALL_FROM_NL
-#define G29_CALL_FROM_NL 16
+#define G29_CALL_FROM_NL 99
 #endif
 
 namespace g29 {
@@ -151,8 +153,14 @@ template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
 	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(dead_) : "v"(a), "v"(b)); } while (0)
 #define G29_MAD_VS(acc, a, b) \
 	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(dead_) : "v"(a), "s"(b)); } while (0)
+#define G29_MUL_VV(acc, a, b) \
+	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(acc), "=s"(dead_) : "v"(a), "v"(b)); } while (0)
+#define G29_MUL_VS(acc, a, b) \
+	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(acc), "=s"(dead_) : "v"(a), "s"(b)); } while (0)
 #define G29_PIN(acc) asm("" : "+v"(acc))
 #else
+#define G29_MUL_VV(acc, a, b) acc = (u64)(a) * (b)
+#define G29_MUL_VS(acc, a, b) acc = (u64)(a) * (b)
 #define G29_MAD_VV(acc, a, b) acc += (u64)(a) * (b)
 #define G29_MAD_VS(acc, a, b) acc += (u64)(a) * (b)
 #define G29_PIN(acc) (void)0
@@ -161,6 +169,14 @@ template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
 // secp521r1 flavour: p = -1 mod 2^29 so the quotient digit is the column's low 29 bits, and "+ m p"
 // is "- m + m (p + 1)" with p + 1 = 2^521 = 2^28 * 2^(29*17): ONE reduction MAD per digit instead of
 // NL (380 MADs per multiplication instead of 722).
+// Large fields run at one or two waves per SIMD (256 VGPRs), where the single running accumulator of
+// product scanning is one long dependent chain of v_mad_u64_u32 (10 cycles latency against 5.3 issue):
+// from G29_DUAL_FROM_NL limbs on, every column alternates between two accumulators that are added at
+// the end of the column.
+#ifndef G29_DUAL_FROM_NL
+#define G29_DUAL_FROM_NL 12
+#endif
+
 // r = a b / R mod p (lazy): product scanning with the reduction interleaved.  SQR: a == b, the
 // off-diagonal products are taken once against the doubled operand.
 template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 *b, const u32 *p, u32 mpinv)
@@ -218,19 +234,33 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 		r[NL - 1] = ((u32)top & ((1u << 23) - 1)) + (u32)acc;  // carry in < 2^12
 		return;
 	}
+	constexpr bool DUAL = NL >= G29_DUAL_FROM_NL;
+	u64 acc2 = 0;
+	// one multiply-accumulate of the current column, on alternating accumulators when DUAL
+#define G29_COL_MAD(KIND, x_, y_) \
+	do { \
+		if (DUAL && (cnt & 1)) { \
+			if (first2) { G29_MUL_##KIND(acc2, x_, y_); first2 = false; } else { G29_MAD_##KIND(acc2, x_, y_); } \
+		} else { \
+			G29_MAD_##KIND(acc, x_, y_); \
+		} \
+		cnt++; \
+	} while (0)
 #pragma unroll
 	for (int k = 0; k < 2 * NL - 1; k++) {
 		const int lo = (k < NL) ? 0 : (k - NL + 1);
 		const int hi = (k < NL) ? k : (NL - 1);
+		int cnt = 0;
+		bool first2 = true;
 #pragma unroll
 		for (int i = lo; i <= hi; i++) {
 			const int j = k - i;
 			if (!SQR) {
-				G29_MAD_VV(acc, a[i], b[j]);
+				G29_COL_MAD(VV, a[i], b[j]);
 			} else if (i < j) {
-				G29_MAD_VV(acc, a[i], a2[j]);
+				G29_COL_MAD(VV, a[i], a2[j]);
 			} else if (i == j) {
-				G29_MAD_VV(acc, a[i], a[i]);
+				G29_COL_MAD(VV, a[i], a[i]);
 			}
 		}
 		if (MERSENNE521) {
@@ -240,7 +270,10 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 			asm volatile("" : "+s"(q17));  // keep it a MAD, not a 64-bit shift + add
 #endif
 			if (k - 17 >= 0 && k - 17 < NL) {
-				G29_MAD_VS(acc, m[k - 17], q17);
+				G29_COL_MAD(VS, m[k - 17], q17);
+			}
+			if (DUAL && !first2) {
+				acc += acc2;
 			}
 			if (k < NL) {
 				m[k] = (u32)acc & MASK;
@@ -252,8 +285,11 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 #pragma unroll
 			for (int i = lo; i <= hi; i++) {
 				if (k >= NL || i < k) {
-					G29_MAD_VS(acc, m[i], p[k - i]);
+					G29_COL_MAD(VS, m[i], p[k - i]);
 				}
+			}
+			if (DUAL && !first2) {
+				acc += acc2;
 			}
 			if (k < NL) {
 				m[k] = ((u32)acc * mpinv) & MASK;
@@ -265,6 +301,7 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 		acc >>= W;
 		G29_PIN(acc);
 	}
+#undef G29_COL_MAD
 	r[NL - 1] = (u32)acc;
 }
 
