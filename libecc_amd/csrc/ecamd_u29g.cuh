@@ -14,6 +14,7 @@
 // Bounds per element type E<PB, LB, TB, VB>: LB >= limbs 0..NL-2, TB >= top limb, VB >= value / p.
 #pragma once
 #include <stdint.h>
+#include <utility>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -166,23 +167,202 @@ template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
 #define G29_PIN(acc) (void)0
 #endif
 
-// secp521r1 flavour: p = -1 mod 2^29 so the quotient digit is the column's low 29 bits, and "+ m p"
-// is "- m + m (p + 1)" with p + 1 = 2^521 = 2^28 * 2^(29*17): ONE reduction MAD per digit instead of
-// NL (380 MADs per multiplication instead of 722).
-// Large fields run at one or two waves per SIMD (256 VGPRs), where the single running accumulator of
-// product scanning is one long dependent chain of v_mad_u64_u32 (10 cycles latency against 5.3 issue):
-// from G29_DUAL_FROM_NL limbs on, every column alternates between two accumulators that are added at
-// the end of the column.
+// ---- multiply-accumulate chains ----
+// hipcc pads every inline-asm statement that defines registers with an s_nop; with one statement per
+// product that is one s_nop per v_mad_u64_u32, which a kernel running one wave per SIMD (the large
+// fields: 256 VGPRs) cannot hide -- measured ~30 % of its time.  A column's products are therefore emitted
+// in statements of up to four.  DUAL: the products alternate between two accumulators (10 cycles result
+// latency against 5.3 cycles issue: two independent chains keep a lone wave issuing); the caller adds
+// them at the end of the column.  YS: the second factors are wave-uniform (digits of p) and go in SGPRs.
 #ifndef G29_DUAL_FROM_NL
 #define G29_DUAL_FROM_NL 12
 #endif
+#if defined(__HIPCC__) && defined(U29_ASM_MAD)
+template <int N, bool DUAL, bool YS> G29_FN void mad_chain(u64 &acc, u64 &acc2, const u32 *x, const u32 *y)
+{
+	u64 dead_;
+	(void)acc2;
+	if constexpr (N >= 4) {
+		if constexpr (DUAL && YS) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]));
+		} else if constexpr (DUAL && !YS) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]));
+		} else if constexpr (!DUAL && YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]));
+		} else if constexpr (!DUAL && !YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]));
+		}
+		mad_chain<N - 4, DUAL, YS>(acc, acc2, x + 4, y + 4);
+	} else if constexpr (N == 3) {
+		if constexpr (DUAL && YS) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]));
+		} else if constexpr (DUAL && !YS) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]));
+		} else if constexpr (!DUAL && YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]));
+		} else if constexpr (!DUAL && !YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]));
+		}
+	} else if constexpr (N == 2) {
+		if constexpr (DUAL && YS) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]));
+		} else if constexpr (DUAL && !YS) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]));
+		} else if constexpr (!DUAL && YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]));
+		} else if constexpr (!DUAL && !YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]));
+		}
+	} else if constexpr (N == 1) {
+		if constexpr (YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]));
+		} else if constexpr (!YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]));
+		}
+	}
+}
+#else
+template <int N, bool DUAL, bool YS> G29_FN void mad_chain(u64 &acc, u64 &acc2, const u32 *x, const u32 *y)
+{
+	for (int i = 0; i < N; i++) {
+		if (DUAL && (i & 1)) {
+			acc2 += (u64)x[i] * y[i];
+		} else {
+			acc += (u64)x[i] * y[i];
+		}
+	}
+}
+#endif
+
+// secp521r1 flavour: p = -1 mod 2^29 so the quotient digit is the column's low 29 bits, and "+ m p"
+// is "- m + m (p + 1)" with p + 1 = 2^521 = 2^28 * 2^(29*17): ONE reduction MAD per digit instead of
+// NL (380 MADs per multiplication instead of 722).
+
+// One column k of the product a b (SQR: off-diagonal products once, against the doubled operand a2) plus,
+// for the dense flavour, the reduction products m_i p_(k-i) known so far, accumulated into acc (+ acc2).
+template <int NL, bool SQR, int K_> struct Column {
+	static constexpr int LO = (K_ < NL) ? 0 : (K_ - NL + 1);
+	static constexpr int HI = (K_ < NL) ? K_ : (NL - 1);
+	static constexpr int HALF = K_ / 2;  // SQR: i <= j  <=>  i <= K/2
+	static constexpr int NPROD = SQR ? ((HALF >= LO) ? (HALF - LO + 1) : 0) : (HI - LO + 1);
+	// dense reduction: i < K in the low half, the whole anti-diagonal in the high half
+	static constexpr int RLO = LO;
+	static constexpr int RHI = (K_ < NL) ? (K_ - 1) : HI;
+	static constexpr int NRED = (RHI >= RLO) ? (RHI - RLO + 1) : 0;
+	static constexpr bool DUAL = NL >= G29_DUAL_FROM_NL;
+
+	static G29_FN void products(u64 &acc, u64 &acc2, const u32 *a, const u32 *b, const u32 *a2)
+	{
+		if constexpr (NPROD > 0) {
+			u32 x[NPROD], y[NPROD];
+#pragma unroll
+			for (int n = 0; n < NPROD; n++) {
+				const int i = LO + n, j = K_ - i;
+				x[n] = a[i];
+				y[n] = !SQR ? b[j] : (i < j ? a2[j] : a[i]);
+			}
+			mad_chain<NPROD, DUAL, false>(acc, acc2, x, y);
+		}
+	}
+	static G29_FN void reduction(u64 &acc, u64 &acc2, const u32 *m, const u32 *p)
+	{
+		if constexpr (NRED > 0) {
+			u32 x[NRED], y[NRED];
+#pragma unroll
+			for (int n = 0; n < NRED; n++) {
+				x[n] = m[RLO + n];
+				y[n] = p[K_ - (RLO + n)];
+			}
+			mad_chain<NRED, DUAL, true>(acc, acc2, x, y);
+		}
+	}
+};
+
+template <int NL, bool SQR, int K_> G29_FN void mul_column(u64 &acc, u32 *m, u32 *r, u32 *t, const u32 *a, const u32 *b,
+							   const u32 *a2, const u32 *p, u32 mpinv)
+{
+	typedef Column<NL, SQR, K_> C;
+	u64 acc2 = 0;
+	C::products(acc, acc2, a, b, a2);
+	if constexpr (P25519) {
+		if (C::DUAL) {
+			acc += acc2;
+		}
+		t[K_] = (u32)acc & MASK;
+	} else if constexpr (MERSENNE521) {
+		// m_(k-17) * 2^28 (p + 1 has its only non-zero digit at limb 17); "- m_k" clears the digit
+		if constexpr (K_ - 17 >= 0 && K_ - 17 < NL) {
+			u32 q17 = 1u << 28;
+#if defined(__HIPCC__)
+			asm volatile("" : "+s"(q17));  // keep it a MAD, not a 64-bit shift + add
+#endif
+			mad_chain<1, false, true>(acc, acc2, &m[K_ - 17], &q17);
+		}
+		if (C::DUAL) {
+			acc += acc2;
+		}
+		if constexpr (K_ < NL) {
+			m[K_] = (u32)acc & MASK;
+		} else {
+			r[K_ - NL] = (u32)acc & MASK;
+		}
+	} else {
+		C::reduction(acc, acc2, m, p);
+		if (C::DUAL) {
+			acc += acc2;
+		}
+		if constexpr (K_ < NL) {
+			m[K_] = ((u32)acc * mpinv) & MASK;
+			mad_chain<1, false, true>(acc, acc2, &m[K_], &p[0]);
+		} else {
+			r[K_ - NL] = (u32)acc & MASK;
+		}
+	}
+	acc >>= W;
+	G29_PIN(acc);
+}
+
+template <int NL, bool SQR, int... Ks>
+G29_FN void mul_columns(u64 &acc, u32 *m, u32 *r, u32 *t, const u32 *a, const u32 *b, const u32 *a2, const u32 *p, u32 mpinv,
+			std::integer_sequence<int, Ks...>)
+{
+	(mul_column<NL, SQR, Ks>(acc, m, r, t, a, b, a2, p, mpinv), ...);
+}
 
 // r = a b / R mod p (lazy): product scanning with the reduction interleaved.  SQR: a == b, the
 // off-diagonal products are taken once against the doubled operand.
 template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 *b, const u32 *p, u32 mpinv)
 {
 	static_assert(!MERSENNE521 || NL == 19, "the Mersenne flavour is only for secp521r1");
-	u32 m[NL], a2[NL];
+	u32 m[NL], a2[NL], t[2 * NL];
 	if (SQR) {
 #pragma unroll
 		for (int i = 0; i < NL; i++) {
@@ -190,30 +370,12 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 		}
 	}
 	u64 acc = 0;
+	mul_columns<NL, SQR>(acc, m, r, t, a, b, a2, p, mpinv, std::make_integer_sequence<int, 2 * NL - 1>());
 	if constexpr (P25519) {
-		// r = a b mod p, p = 2^255 - 19, value < 2p: 81 product MADs into 18 limbs t, then
-		// t[j] + 1216 t[j + 9] (2^261 = 64 * 2^255 = 1216) with 19 * (bits from 2^255 up) fed in at limb 0.
+		// r = a b mod p, p = 2^255 - 19, value < 2p: the 81 product MADs gave 18 limbs t (17 columns + the
+		// last carry); now t[j] + 1216 t[j + 9] (2^261 = 64 * 2^255 = 1216) with 19 * (bits from 2^255 up)
+		// fed in at limb 0.
 		static_assert(NL == 9, "2^255 - 19 flavour: 9 limbs");
-		u32 t[2 * NL];
-#pragma unroll
-		for (int k = 0; k < 2 * NL - 1; k++) {
-			const int lo = (k < NL) ? 0 : (k - NL + 1);
-			const int hi = (k < NL) ? k : (NL - 1);
-#pragma unroll
-			for (int i = lo; i <= hi; i++) {
-				const int j = k - i;
-				if (!SQR) {
-					G29_MAD_VV(acc, a[i], b[j]);
-				} else if (i < j) {
-					G29_MAD_VV(acc, a[i], a2[j]);
-				} else if (i == j) {
-					G29_MAD_VV(acc, a[i], a[i]);
-				}
-			}
-			t[k] = (u32)acc & MASK;
-			acc >>= W;
-			G29_PIN(acc);
-		}
 		t[2 * NL - 1] = (u32)acc;  // < va vb 2^17 <= 2^31 (Cfg::prod_ok)
 		u32 f = 1216u;
 #if defined(__HIPCC__)
@@ -232,77 +394,9 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 			G29_PIN(acc);
 		}
 		r[NL - 1] = ((u32)top & ((1u << 23) - 1)) + (u32)acc;  // carry in < 2^12
-		return;
+	} else {
+		r[NL - 1] = (u32)acc;
 	}
-	constexpr bool DUAL = NL >= G29_DUAL_FROM_NL;
-	u64 acc2 = 0;
-	// one multiply-accumulate of the current column, on alternating accumulators when DUAL
-#define G29_COL_MAD(KIND, x_, y_) \
-	do { \
-		if (DUAL && (cnt & 1)) { \
-			if (first2) { G29_MUL_##KIND(acc2, x_, y_); first2 = false; } else { G29_MAD_##KIND(acc2, x_, y_); } \
-		} else { \
-			G29_MAD_##KIND(acc, x_, y_); \
-		} \
-		cnt++; \
-	} while (0)
-#pragma unroll
-	for (int k = 0; k < 2 * NL - 1; k++) {
-		const int lo = (k < NL) ? 0 : (k - NL + 1);
-		const int hi = (k < NL) ? k : (NL - 1);
-		int cnt = 0;
-		bool first2 = true;
-#pragma unroll
-		for (int i = lo; i <= hi; i++) {
-			const int j = k - i;
-			if (!SQR) {
-				G29_COL_MAD(VV, a[i], b[j]);
-			} else if (i < j) {
-				G29_COL_MAD(VV, a[i], a2[j]);
-			} else if (i == j) {
-				G29_COL_MAD(VV, a[i], a[i]);
-			}
-		}
-		if (MERSENNE521) {
-			// m_(k-17) * 2^28 (p + 1 has its only non-zero digit at limb 17); "- m_k" clears the digit
-			u32 q17 = 1u << 28;
-#if defined(__HIPCC__)
-			asm volatile("" : "+s"(q17));  // keep it a MAD, not a 64-bit shift + add
-#endif
-			if (k - 17 >= 0 && k - 17 < NL) {
-				G29_COL_MAD(VS, m[k - 17], q17);
-			}
-			if (DUAL && !first2) {
-				acc += acc2;
-			}
-			if (k < NL) {
-				m[k] = (u32)acc & MASK;
-			} else {
-				r[k - NL] = (u32)acc & MASK;
-			}
-		} else {
-			// m_i p_(k-i): i < k in the low half, the whole anti-diagonal in the high half
-#pragma unroll
-			for (int i = lo; i <= hi; i++) {
-				if (k >= NL || i < k) {
-					G29_COL_MAD(VS, m[i], p[k - i]);
-				}
-			}
-			if (DUAL && !first2) {
-				acc += acc2;
-			}
-			if (k < NL) {
-				m[k] = ((u32)acc * mpinv) & MASK;
-				G29_MAD_VS(acc, m[k], p[0]);
-			} else {
-				r[k - NL] = (u32)acc & MASK;
-			}
-		}
-		acc >>= W;
-		G29_PIN(acc);
-	}
-#undef G29_COL_MAD
-	r[NL - 1] = (u32)acc;
 }
 
 template <int NL> struct RawN {
