@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libecc_amd.so")
 SOURCES = ["ecamd_kernels.hip", "ecamd_p256_kernel.hip", "ecamd_host.cpp"]
-DEPS = ["ecamd_field.cuh", "ecamd_point.cuh", "ecamd_u29.cuh", "ecamd_p256.cuh", "ecamd_u29g.cuh", "ecamd_jacg.cuh",
+DEPS = ["ecamd_madchain.cuh", "ecamd_field.cuh", "ecamd_point.cuh", "ecamd_u29.cuh", "ecamd_p256.cuh", "ecamd_u29g.cuh", "ecamd_jacg.cuh",
         "ecamd_internal.h",
         "ecamd_curve_table.inc",
         os.path.join("..", "..", "include", "libecc_amd.h")]

@@ -1,0 +1,106 @@
+// libecc_amd/csrc/ecamd_madchain.cuh -- chains of v_mad_u64_u32 as single inline-asm statements, shared by
+// the secp256r1 field (ecamd_u29.cuh) and the generic radix-2^29 field (ecamd_u29g.cuh).
+//
+// hipcc pads every inline-asm statement that defines registers with an s_nop; with one statement per
+// product that is one s_nop per v_mad_u64_u32, which a kernel running one wave per SIMD (the large
+// fields: 256 VGPRs) cannot hide -- measured ~30 % of its time there.  ecamd_mad_chain<N, DUAL, YS> adds N
+// products x[i] * y[i] to the 64-bit accumulator(s) in statements of up to four instructions.
+//   DUAL: products alternate between acc and acc2 (10 cycles result latency against 5.3 cycles issue: two
+//         independent chains keep a lone wave issuing); the caller adds the two at the end of a column;
+//   YS:   the second factors are wave-uniform and go in SGPRs (digits of p, reduction constants).
+// The carry-out SGPR pair of the instruction is dead; it is an early-clobber output because a statement
+// holds several instructions and the later ones still read their scalar inputs.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define ECAMD_CHAIN_FN __device__ __forceinline__
+#else
+#define ECAMD_CHAIN_FN inline
+#endif
+
+#if defined(__HIPCC__) && defined(U29_ASM_MAD)
+template <int N, bool DUAL, bool YS> ECAMD_CHAIN_FN void ecamd_mad_chain(uint64_t &acc, uint64_t &acc2, const uint32_t *x, const uint32_t *y)
+{
+	uint64_t dead_;
+	(void)acc2;
+	if constexpr (N >= 4) {
+		if constexpr (DUAL && YS) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]));
+		} else if constexpr (DUAL && !YS) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]));
+		} else if constexpr (!DUAL && YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]));
+		} else if constexpr (!DUAL && !YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]));
+		}
+		ecamd_mad_chain<N - 4, DUAL, YS>(acc, acc2, x + 4, y + 4);
+	} else if constexpr (N == 3) {
+		if constexpr (DUAL && YS) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]));
+		} else if constexpr (DUAL && !YS) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]));
+		} else if constexpr (!DUAL && YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]));
+		} else if constexpr (!DUAL && !YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]));
+		}
+	} else if constexpr (N == 2) {
+		if constexpr (DUAL && YS) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]));
+		} else if constexpr (DUAL && !YS) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]));
+		} else if constexpr (!DUAL && YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]));
+		} else if constexpr (!DUAL && !YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]));
+		}
+	} else if constexpr (N == 1) {
+		if constexpr (YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]));
+		} else if constexpr (!YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]));
+		}
+	}
+}
+#else
+template <int N, bool DUAL, bool YS> ECAMD_CHAIN_FN void ecamd_mad_chain(uint64_t &acc, uint64_t &acc2, const uint32_t *x, const uint32_t *y)
+{
+	for (int i = 0; i < N; i++) {
+		if (DUAL && (i & 1)) {
+			acc2 += (uint64_t)x[i] * y[i];
+		} else {
+			acc += (uint64_t)x[i] * y[i];
+		}
+	}
+}
+#endif
+

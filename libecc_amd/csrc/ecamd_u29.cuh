@@ -30,6 +30,8 @@
 // observable byte is identical to the reference's.
 #pragma once
 #include <stdint.h>
+#include <utility>
+#include "ecamd_madchain.cuh"
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -142,33 +144,66 @@ template <u64 VBO> struct MulOut {
 #define U29_MAD_VS(acc, a, b) acc += (u64)(a) * (b)
 #endif
 
-// raw kernels on plain arrays (bounds are checked by the typed wrappers below)
+// raw kernels on plain arrays (bounds are checked by the typed wrappers below).  Columns are compile-time
+// indexed so that each one's products and reduction terms go out as asm statements of up to four MADs
+// (ecamd_madchain.cuh: one padding s_nop per statement instead of one per MAD).
+template <bool SQR, int K_> struct Col9 {
+	static constexpr int LO = (K_ < 9) ? 0 : (K_ - 8);
+	static constexpr int HI = (K_ < 9) ? K_ : 8;
+	static constexpr int HALF = K_ / 2;
+	static constexpr int NPROD = SQR ? ((HALF >= LO) ? (HALF - LO + 1) : 0) : (HI - LO + 1);
+	// reduction products m_i * q_j, i + j = k, j in {3, 6, 7, 8}, 0 <= i <= 8
+	static constexpr bool R3 = (K_ - 3 >= 0 && K_ - 3 <= 8), R6 = (K_ - 6 >= 0 && K_ - 6 <= 8);
+	static constexpr bool R7 = (K_ - 7 >= 0 && K_ - 7 <= 8), R8 = (K_ - 8 >= 0 && K_ - 8 <= 8);
+	static constexpr int NRED = (R3 ? 1 : 0) + (R6 ? 1 : 0) + (R7 ? 1 : 0) + (R8 ? 1 : 0);
+};
+
+template <bool SQR, int K_>
+U29_FN void mul_col9(u64 &acc, u32 *m, u32 *r, const u32 *a, const u32 *b, const u32 *a2, u32 q3, u32 q6, u32 q7, u32 q8)
+{
+	typedef Col9<SQR, K_> C;
+	u64 unused = 0;
+	if constexpr (C::NPROD > 0) {
+		u32 x[C::NPROD], y[C::NPROD];
+#pragma unroll
+		for (int n = 0; n < C::NPROD; n++) {
+			const int i = C::LO + n, j = K_ - i;
+			x[n] = a[i];
+			y[n] = !SQR ? b[j] : (i < j ? a2[j] : a[i]);
+		}
+		ecamd_mad_chain<C::NPROD, false, false>(acc, unused, x, y);
+	}
+	if constexpr (C::NRED > 0) {
+		u32 x[C::NRED], y[C::NRED];
+		int n = 0;
+		if (C::R3) { x[n] = m[K_ - 3]; y[n] = q3; n++; }
+		if (C::R6) { x[n] = m[K_ - 6]; y[n] = q6; n++; }
+		if (C::R7) { x[n] = m[K_ - 7]; y[n] = q7; n++; }
+		if (C::R8) { x[n] = m[K_ - 8]; y[n] = q8; n++; }
+		ecamd_mad_chain<C::NRED, false, true>(acc, unused, x, y);
+	}
+	if constexpr (K_ < 9) {
+		m[K_] = (u32)acc & MASK;  // quotient digit (mpinv = 1); "- m_k" clears the digit
+	} else {
+		r[K_ - 9] = (u32)acc & MASK;
+	}
+	acc >>= W;
+	U29_PIN(acc);
+}
+
+template <bool SQR, int... Ks>
+U29_FN void mul_cols9(u64 &acc, u32 *m, u32 *r, const u32 *a, const u32 *b, const u32 *a2, u32 q3, u32 q6, u32 q7, u32 q8,
+		      std::integer_sequence<int, Ks...>)
+{
+	(mul_col9<SQR, Ks>(acc, m, r, a, b, a2, q3, q6, q7, q8), ...);
+}
+
 U29_FN void mul_raw(u32 *r, const u32 *a, const u32 *b)
 {
 	u32 m[9];
 	U29_OPAQUE_Q();
 	u64 acc = 0;
-#pragma unroll
-	for (int k = 0; k < 17; k++) {
-		const int lo = (k < 9) ? 0 : (k - 8);
-		const int hi = (k < 9) ? k : 8;
-#pragma unroll
-		for (int i = lo; i <= hi; i++) {
-			U29_MAD_VV(acc, a[i], b[k - i]);
-		}
-		// reduction products m_i * q_j, i + j = k, j in {3, 6, 7, 8}, 0 <= i <= 8
-		if (k - 3 >= 0 && k - 3 <= 8) U29_MAD_VS(acc, m[k - 3], q3);
-		if (k - 6 >= 0 && k - 6 <= 8) U29_MAD_VS(acc, m[k - 6], q6);
-		if (k - 7 >= 0 && k - 7 <= 8) U29_MAD_VS(acc, m[k - 7], q7);
-		if (k - 8 >= 0 && k - 8 <= 8) U29_MAD_VS(acc, m[k - 8], q8);
-		if (k < 9) {
-			m[k] = (u32)acc & MASK;  // quotient digit (mpinv = 1); "- m_k" clears the digit
-		} else {
-			r[k - 9] = (u32)acc & MASK;
-		}
-		acc >>= W;
-		U29_PIN(acc);
-	}
+	mul_cols9<false>(acc, m, r, a, b, a, q3, q6, q7, q8, std::make_integer_sequence<int, 17>());
 	r[8] = (u32)acc;
 }
 
@@ -181,31 +216,7 @@ U29_FN void sqr_raw(u32 *r, const u32 *a)
 		a2[i] = a[i] << 1;
 	}
 	u64 acc = 0;
-#pragma unroll
-	for (int k = 0; k < 17; k++) {
-		const int lo = (k < 9) ? 0 : (k - 8);
-		const int hi = (k < 9) ? k : 8;
-#pragma unroll
-		for (int i = lo; i <= hi; i++) {
-			const int j = k - i;
-			if (i < j) {
-				U29_MAD_VV(acc, a[i], a2[j]);
-			} else if (i == j) {
-				U29_MAD_VV(acc, a[i], a[i]);
-			}
-		}
-		if (k - 3 >= 0 && k - 3 <= 8) U29_MAD_VS(acc, m[k - 3], q3);
-		if (k - 6 >= 0 && k - 6 <= 8) U29_MAD_VS(acc, m[k - 6], q6);
-		if (k - 7 >= 0 && k - 7 <= 8) U29_MAD_VS(acc, m[k - 7], q7);
-		if (k - 8 >= 0 && k - 8 <= 8) U29_MAD_VS(acc, m[k - 8], q8);
-		if (k < 9) {
-			m[k] = (u32)acc & MASK;
-		} else {
-			r[k - 9] = (u32)acc & MASK;
-		}
-		acc >>= W;
-		U29_PIN(acc);
-	}
+	mul_cols9<true>(acc, m, r, a, a, a2, q3, q6, q7, q8, std::make_integer_sequence<int, 17>());
 	r[8] = (u32)acc;
 }
 

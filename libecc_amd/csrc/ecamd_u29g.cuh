@@ -15,6 +15,7 @@
 #pragma once
 #include <stdint.h>
 #include <utility>
+#include "ecamd_madchain.cuh"
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -167,100 +168,15 @@ template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
 #define G29_PIN(acc) (void)0
 #endif
 
-// ---- multiply-accumulate chains ----
-// hipcc pads every inline-asm statement that defines registers with an s_nop; with one statement per
-// product that is one s_nop per v_mad_u64_u32, which a kernel running one wave per SIMD (the large
-// fields: 256 VGPRs) cannot hide -- measured ~30 % of its time.  A column's products are therefore emitted
-// in statements of up to four.  DUAL: the products alternate between two accumulators (10 cycles result
-// latency against 5.3 cycles issue: two independent chains keep a lone wave issuing); the caller adds
-// them at the end of the column.  YS: the second factors are wave-uniform (digits of p) and go in SGPRs.
+// ---- multiply-accumulate chains (ecamd_madchain.cuh): a column's products go out in asm statements of up
+// to four MADs; from G29_DUAL_FROM_NL limbs on (one or two waves per SIMD) on two alternating accumulators ----
 #ifndef G29_DUAL_FROM_NL
 #define G29_DUAL_FROM_NL 12
 #endif
-#if defined(__HIPCC__) && defined(U29_ASM_MAD)
 template <int N, bool DUAL, bool YS> G29_FN void mad_chain(u64 &acc, u64 &acc2, const u32 *x, const u32 *y)
 {
-	u64 dead_;
-	(void)acc2;
-	if constexpr (N >= 4) {
-		if constexpr (DUAL && YS) {
-			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1"
-			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
-			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]));
-		} else if constexpr (DUAL && !YS) {
-			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1"
-			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
-			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]));
-		} else if constexpr (!DUAL && YS) {
-			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-			    : "+v"(acc), "=&s"(dead_)
-			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]));
-		} else if constexpr (!DUAL && !YS) {
-			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-			    : "+v"(acc), "=&s"(dead_)
-			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]));
-		}
-		mad_chain<N - 4, DUAL, YS>(acc, acc2, x + 4, y + 4);
-	} else if constexpr (N == 3) {
-		if constexpr (DUAL && YS) {
-			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0"
-			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
-			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]));
-		} else if constexpr (DUAL && !YS) {
-			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0"
-			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
-			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]));
-		} else if constexpr (!DUAL && YS) {
-			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-			    : "+v"(acc), "=&s"(dead_)
-			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]));
-		} else if constexpr (!DUAL && !YS) {
-			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-			    : "+v"(acc), "=&s"(dead_)
-			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]));
-		}
-	} else if constexpr (N == 2) {
-		if constexpr (DUAL && YS) {
-			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1"
-			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
-			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]));
-		} else if constexpr (DUAL && !YS) {
-			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1"
-			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
-			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]));
-		} else if constexpr (!DUAL && YS) {
-			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
-			    : "+v"(acc), "=&s"(dead_)
-			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]));
-		} else if constexpr (!DUAL && !YS) {
-			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
-			    : "+v"(acc), "=&s"(dead_)
-			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]));
-		}
-	} else if constexpr (N == 1) {
-		if constexpr (YS) {
-			asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
-			    : "+v"(acc), "=&s"(dead_)
-			    : "v"(x[0]), "s"(y[0]));
-		} else if constexpr (!YS) {
-			asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
-			    : "+v"(acc), "=&s"(dead_)
-			    : "v"(x[0]), "v"(y[0]));
-		}
-	}
+	ecamd_mad_chain<N, DUAL, YS>(acc, acc2, x, y);
 }
-#else
-template <int N, bool DUAL, bool YS> G29_FN void mad_chain(u64 &acc, u64 &acc2, const u32 *x, const u32 *y)
-{
-	for (int i = 0; i < N; i++) {
-		if (DUAL && (i & 1)) {
-			acc2 += (u64)x[i] * y[i];
-		} else {
-			acc += (u64)x[i] * y[i];
-		}
-	}
-}
-#endif
 
 // secp521r1 flavour: p = -1 mod 2^29 so the quotient digit is the column's low 29 bits, and "+ m p"
 // is "- m + m (p + 1)" with p + 1 = 2^521 = 2^28 * 2^(29*17): ONE reduction MAD per digit instead of
