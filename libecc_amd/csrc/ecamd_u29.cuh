@@ -188,7 +188,7 @@ U29_FN void mul_col9(u64 &acc, u32 *m, u32 *r, const u32 *a, const u32 *b, const
 		r[K_ - 9] = (u32)acc & MASK;
 	}
 	acc >>= W;
-	U29_PIN(acc);
+	// (no pin needed: the next column starts with an asm statement that takes acc as an operand)
 }
 
 template <bool SQR, int... Ks>

@@ -263,7 +263,7 @@ template <int NL, bool SQR, int K_> G29_FN void mul_column(u64 &acc, u32 *m, u32
 		}
 	}
 	acc >>= W;
-	G29_PIN(acc);
+	// (no pin needed: the next column starts with an asm statement that takes acc as an operand)
 }
 
 template <int NL, bool SQR, int... Ks>
