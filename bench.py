@@ -118,12 +118,12 @@ def measured_mad_peak():
 
 
 def pmc_traffic(kernel, batch_log2):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_r1c.json:
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_r1d.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected separately; gfx950 correction 2 x FETCH_SIZE).
     Only valid for the batch size it was collected at; null otherwise.  It is window-table scratch
     traffic (64 look-ups x 80 B per item), not re-reads of the 160 algorithmic bytes per item."""
     try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "pmc_r1c.json")))
+        j = json.load(open(os.path.join(ROOT, "profiles", "pmc_r1d.json")))
         k = j["kernels"][kernel]
         if batch_log2 != 20:
             return None
