@@ -863,3 +863,16 @@ def test_first_large_dev_call_builds_comb_safely():
     finally:
         cv.free()
         ctx.close()
+
+
+def test_libecc_glue_demo():
+    """examples/libecc_glue_demo.c -- the struct-array binding a libecc application would add, linked to
+    the UNMODIFIED libecc (prebuilt in the authoring container as oracle/_ref/glue_demo): libecc's own nn /
+    prj_pt / ec_pub_key objects in, GPU batch, results compared with libecc's prj_pt_mul and ec_verify"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "glue_demo")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/glue_demo not built (needs the reference sources at build time)")
+    r = subprocess.run([exe, "384"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "384 items, 0 mismatches" in r.stdout and "64 items, 0 mismatches" in r.stdout
