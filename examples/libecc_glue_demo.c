@@ -55,7 +55,7 @@ static int prj_pt_mul_batch(prj_pt *out, int *ok, const nn *m, const prj_pt *in,
 		if (st[i] == ECAMD_OK) {
 			ok[i] = prj_pt_import_from_buf(&out[i], pout + (size_t)i * 3 * clen, (u16)(3 * clen), &params->ec_curve);
 		} else if (st[i] == ECAMD_INF) {
-			ok[i] = prj_pt_zero(&out[i]) ? -1 : 1; /* 1: the point at infinity (prj_pt_unique would refuse it) */
+			ok[i] = (prj_pt_init(&out[i], &params->ec_curve) || prj_pt_zero(&out[i])) ? -1 : 1; /* 1: the point at infinity */
 		}
 	}
 	ret = 0;
