@@ -235,37 +235,25 @@ def main():
     d_scalars = torch.frombuffer(bytearray(scalars_h), dtype=torch.uint8).to(dev)
     d_t = torch.frombuffer(bytearray(t_h), dtype=torch.uint8).to(dev)
     d_points = torch.empty(B * plen, dtype=torch.uint8, device=dev)
-    d_out = torch.empty(B * plen, dtype=torch.uint8, device=dev)
     d_status = torch.empty(B, dtype=torch.uint8, device=dev)
     # base points P_i = [t_i]G, produced on the GPU by the same engine (fixed base), untimed
     cv.scalar_mult_dev(B, d_t.data_ptr(), slen, None, d_points.data_ptr(), d_status.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
     assert int(d_status.max().item()) == 0, "base-point generation produced an error status"
-    # N > 1: every step ends with ONE all-gather of the output shards.  It runs on RCCL's own stream
-    # (async_op) and overlaps the next step's kernels; outputs are double-buffered so that a shard is not
-    # overwritten while it is still being gathered.  All gathers are waited for inside the timed region.
-    gathered = None
-    d_outs = [d_out]
-    pending = []
-    if world > 1:
-        gathered = torch.empty(world * B * plen, dtype=torch.uint8, device=dev)
-        d_outs.append(torch.empty(B * plen, dtype=torch.uint8, device=dev))
-    nstep = [0]
+    # N > 1: every step ends with ONE all-gather of the output shards, issued asynchronously so that it
+    # overlaps the next step's kernels; outputs are double-buffered (libecc_amd/shard.py:OverlappedGather,
+    # covered by a world-size-2 gloo test).  All gathers are waited for inside the timed region.
+    from libecc_amd.shard import OverlappedGather
+    og = OverlappedGather(world, B * plen, dev)
+    d_outs = og.bufs
 
     def step():
-        k = nstep[0]
-        nstep[0] += 1
-        buf = d_outs[k % len(d_outs)]
-        if world > 1 and len(pending) >= 2:
-            pending.pop(0).wait()          # the gather that last read this buffer (stream-level wait, not a host block)
+        buf = og.next_buffer()
         cv.scalar_mult_dev(B, d_scalars.data_ptr(), slen, d_points.data_ptr(), buf.data_ptr(),
                            d_status.data_ptr(), stream.cuda_stream)
-        if world > 1:
-            pending.append(dist.all_gather_into_tensor(gathered, buf, async_op=True))
+        og.submit(buf)
 
-    def drain():
-        while pending:
-            pending.pop(0).wait()
+    drain = og.drain
 
     # ---- parity gate: random subset vs the CPU oracle, byte for byte ----
     step()

@@ -29,3 +29,42 @@ def all_gather_shards(local, n, item_bytes, group=None):
     dist.all_gather_into_tensor(buf, pad, group=group)
     parts = [buf[r * mx:r * mx + (hi - lo) * item_bytes] for r, (lo, hi) in enumerate(sizes)]
     return torch.cat(parts)
+
+
+class OverlappedGather:
+    """One all-gather of equal-size output shards per step, overlapped with the next step's kernels.
+
+    The collective is issued with async_op=True (on RCCL's own stream for GPU tensors; it starts once the work
+    already enqueued on the current stream has finished) and outputs are double-buffered, so a shard is never
+    overwritten while it is still being gathered:
+
+        buf = og.next_buffer()     # waits (stream-level, not a host block) for the gather that last read buf
+        ... enqueue the kernels that fill buf ...
+        og.submit(buf)             # async all_gather_into_tensor(gathered, buf)
+        ...
+        og.drain()                 # before reading `gathered` / closing a timed region
+
+    With world == 1 there is one buffer and no collective."""
+
+    def __init__(self, world, shard_numel, device, group=None):
+        self.world = world
+        self.group = group
+        self.bufs = [torch.empty(shard_numel, dtype=torch.uint8, device=device) for _ in range(2 if world > 1 else 1)]
+        self.gathered = torch.empty(world * shard_numel, dtype=torch.uint8, device=device) if world > 1 else None
+        self.pending = []
+        self.k = 0
+
+    def next_buffer(self):
+        buf = self.bufs[self.k % len(self.bufs)]
+        self.k += 1
+        if self.world > 1 and len(self.pending) >= len(self.bufs):
+            self.pending.pop(0).wait()
+        return buf
+
+    def submit(self, buf):
+        if self.world > 1:
+            self.pending.append(dist.all_gather_into_tensor(self.gathered, buf, group=self.group, async_op=True))
+
+    def drain(self):
+        while self.pending:
+            self.pending.pop(0).wait()

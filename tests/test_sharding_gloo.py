@@ -68,3 +68,66 @@ def test_two_rank_gather_matches_single_process():
     rng = np.random.default_rng(99)
     sc = rng.integers(0, 256, size=32 * n, dtype=np.uint8).tobytes()
     assert got == Oracle("SECP256R1").scalar_mult(sc)
+
+
+def _og_worker(rank, world, port, steps, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from libecc_amd.shard import OverlappedGather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 1000
+    og = OverlappedGather(world, n, torch.device("cpu"))
+    seen = []
+    for k in range(steps):
+        buf = og.next_buffer()
+        buf.fill_((17 * rank + k) % 251)          # stands for the kernels that fill the shard
+        og.submit(buf)
+        if k % 3 == 2:                            # a reader in the middle of the run must drain first
+            og.drain()
+            seen.append(og.gathered.clone())
+    og.drain()
+    seen.append(og.gathered.clone())
+    if rank == 0:
+        q.put([t.numpy().tobytes() for t in seen])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_gather_two_ranks():
+    """bench.py's per-step all-gather (async, double-buffered shards) delivers every step's shards in rank order"""
+    steps, world, n = 8, 2, 1000
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_og_worker, args=(r, world, port, steps, q), daemon=True) for r in range(world)]
+    try:
+        for p in procs:
+            p.start()
+        got = q.get(timeout=180)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
+    checks = [k for k in range(steps) if k % 3 == 2] + [steps - 1]
+    assert len(got) == len(checks)
+    for blob, k in zip(got, checks):
+        exp = b"".join(bytes([(17 * r + k) % 251]) * n for r in range(world))
+        assert blob == exp, k
+
+
+def test_overlapped_gather_single_rank_is_a_plain_buffer():
+    from libecc_amd.shard import OverlappedGather
+    og = OverlappedGather(1, 16, torch.device("cpu"))
+    b0 = og.next_buffer()
+    og.submit(b0)
+    assert og.next_buffer() is b0 and og.gathered is None
+    og.drain()
