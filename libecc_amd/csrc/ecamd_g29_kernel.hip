@@ -779,6 +779,192 @@ __global__ __launch_bounds__(64) void k_xdh_prep_c25519(EcamdXdhPrepArgs A, int 
 	A.flags[i] = ok ? 0 : 1;
 }
 
+// ------------------------------------------------------------------------------------------
+// X25519: the x-only Montgomery ladder on v^2 = u^3 + A u^2 + u itself (RFC 7748 section 5), for inputs
+// k_xdh_prep_c25519 accepted.  [k]Q's u coordinate is all the reference exposes (it computes [k]Q on the
+// Weierstrass model and maps back, ecdh/x25519_448.c:268-276), so the ladder is observably identical:
+// u' = X2 / Z2, with Z2 = 0 (the point at infinity) and u' = 0 rejected as the reference does.
+// 255 steps of 5M + 4S + one multiplication by a24 = 121665; the divisions are shared by 8 items per lane.
+// ------------------------------------------------------------------------------------------
+#define XDH_REC_WORDS 20   /* X2 (9 limbs), Z2 (9 limbs), padding */
+#define XDH_FIN_K 8
+
+__global__ __launch_bounds__(64) void k_x25519_ladder(EcamdXdhLadderArgs A, int gslot)
+{
+	using namespace c25519;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n || A.flags[i]) {
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const FC onec = constant<FC>(K.one);
+	u32 uw[8], kw[8];
+	load_le256(A.u + (size_t)i * 32, uw);
+	load_be<8>(A.scalars + (size_t)i * 32, 32, kw);           // clamped by the prep kernel
+	const FM x1 = weaken<FM>(mul(from_words<PB, 8>(uw), onec, K));
+	FM x2 = weaken<FM>(onec), z2, x3 = x1, z3 = weaken<FM>(onec);
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		z2.l[w] = 0;
+	}
+	FC a24;
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		a24.l[w] = (w == 0) ? 121665u : 0u;
+	}
+	u32 swap = 0;
+#pragma unroll 1
+	for (int t = 254; t >= 0; t--) {
+		u32 word = 0;
+#pragma unroll
+		for (int w = 0; w < 8; w++) {
+			word = (w == (t >> 5)) ? kw[w] : word;
+		}
+		const u32 kt = (word >> (t & 31)) & 1u;
+		swap ^= kt;
+		{
+			const FM tx = selg(swap != 0, x3, x2), tz = selg(swap != 0, z3, z2);
+			x3 = selg(swap != 0, x2, x3);
+			z3 = selg(swap != 0, z2, z3);
+			x2 = tx;
+			z2 = tz;
+		}
+		swap = kt;
+		const auto a = carry(add(x2, z2));
+		const auto b = carry(sub_auto<1>(x2, z2, K));
+		const FM aa = weaken<FM>(sqrc(a, K));
+		const FM bb = weaken<FM>(sqrc(b, K));
+		const auto e = carry(sub_auto<1>(aa, bb, K));
+		const auto c = carry(add(x3, z3));
+		const auto d = carry(sub_auto<1>(x3, z3, K));
+		const FM da = weaken<FM>(mulc(d, a, K));
+		const FM cb = weaken<FM>(mulc(c, b, K));
+		x3 = weaken<FM>(sqrc(carry(add(da, cb)), K));
+		z3 = weaken<FM>(mulc(x1, sqrc(carry(sub_auto<1>(da, cb, K)), K), K));
+		x2 = weaken<FM>(mul(aa, bb, K));
+		z2 = weaken<FM>(mulc(e, carry(add(aa, mulc(a24, e, K))), K));
+	}
+	{
+		const FM tx = selg(swap != 0, x3, x2), tz = selg(swap != 0, z3, z2);
+		x2 = tx;
+		z2 = tz;
+	}
+	u32 buf[XDH_REC_WORDS];
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		buf[w] = x2.l[w];
+		buf[9 + w] = z2.l[w];
+	}
+	buf[18] = buf[19] = 0;
+	uint4 *dst = (uint4 *)(A.rec + (size_t)i * XDH_REC_WORDS);
+#pragma unroll
+	for (int q = 0; q < XDH_REC_WORDS / 4; q++) {
+		dst[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
+	}
+}
+
+__global__ __launch_bounds__(64) void k_x25519_fin(EcamdXdhLadderArgs A, int gslot, u32 nthreads)
+{
+	using namespace c25519;
+	const u32 t = blockIdx.x * 64 + threadIdx.x;
+	if (t >= nthreads) {
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const FC onec = constant<FC>(K.one);
+	const FM onem = weaken<FM>(onec);
+	// prefix products of the Z2 of this lane's items (rejected items and Z2 = 0 take part with 1)
+	FM pre[XDH_FIN_K];
+	u32 live = 0;
+	FM acc = onem;
+#pragma unroll 1
+	for (int j = 0; j < XDH_FIN_K; j++) {
+		const u32 i = t + (u32)j * nthreads;
+		pre[j] = acc;
+		if (i >= A.n || A.flags[i]) {
+			continue;
+		}
+		const uint4 *src = (const uint4 *)(A.rec + (size_t)i * XDH_REC_WORDS);
+		u32 buf[XDH_REC_WORDS];
+#pragma unroll
+		for (int q = 0; q < XDH_REC_WORDS / 4; q++) {
+			const uint4 v = src[q];
+			buf[4 * q] = v.x; buf[4 * q + 1] = v.y; buf[4 * q + 2] = v.z; buf[4 * q + 3] = v.w;
+		}
+		FM z;
+#pragma unroll
+		for (int w = 0; w < 9; w++) {
+			z.l[w] = buf[9 + w];
+		}
+		if (!is_zero_mulout(z, K)) {
+			live |= 1u << j;
+			acc = weaken<FM>(mul(acc, z, K));
+		}
+	}
+	FM a11;
+	FM inv = weaken<FM>(mul(sqr_n(pow_2_250m1(acc, &a11, K), 5, K), a11, K));  // (product)^(p-2)
+#pragma unroll 1
+	for (int j = XDH_FIN_K - 1; j >= 0; j--) {
+		const u32 i = t + (u32)j * nthreads;
+		if (i >= A.n) {
+			continue;
+		}
+		u8 *out = A.out + (size_t)i * 32;
+		bool ok = ((live >> j) & 1u) != 0;
+		u32 w8[8];
+#pragma unroll
+		for (int w = 0; w < 8; w++) {
+			w8[w] = 0;
+		}
+		if (ok) {
+			const uint4 *src = (const uint4 *)(A.rec + (size_t)i * XDH_REC_WORDS);
+			u32 buf[XDH_REC_WORDS];
+#pragma unroll
+			for (int q = 0; q < XDH_REC_WORDS / 4; q++) {
+				const uint4 v = src[q];
+				buf[4 * q] = v.x; buf[4 * q + 1] = v.y; buf[4 * q + 2] = v.z; buf[4 * q + 3] = v.w;
+			}
+			FM x, z;
+#pragma unroll
+			for (int w = 0; w < 9; w++) {
+				x.l[w] = buf[w];
+				z.l[w] = buf[9 + w];
+			}
+			const FM zi = weaken<FM>(mul(inv, pre[j], K));
+			inv = weaken<FM>(mul(inv, z, K));
+			u32 d[9];
+			canonical_digits(d, mul(x, zi, K), K);
+			to_words<9, 8>(w8, d);
+			u32 nz = 0;
+#pragma unroll
+			for (int w = 0; w < 8; w++) {
+				nz |= w8[w];
+			}
+			ok = nz != 0;   // an all-zero output is rejected (x25519_448.c:275-276)
+		}
+#pragma unroll
+		for (int w = 0; w < 8; w++) {
+			const u32 v = ok ? w8[w] : 0u;
+			out[4 * w] = (u8)v;
+			out[4 * w + 1] = (u8)(v >> 8);
+			out[4 * w + 2] = (u8)(v >> 16);
+			out[4 * w + 3] = (u8)(v >> 24);
+		}
+		A.status[i] = ok ? 0 : 1;
+	}
+}
+
+hipError_t ecamd_launch_x25519_ladder(const EcamdXdhLadderArgs &a, int gslot, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_x25519_ladder, dim3((a.n + 63) / 64), dim3(64), 0, s, a, gslot);
+	const uint32_t nthreads = (a.n + XDH_FIN_K - 1) / XDH_FIN_K;
+	hipLaunchKernelGGL(k_x25519_fin, dim3((nthreads + 63) / 64), dim3(64), 0, s, a, gslot, nthreads);
+	return hipGetLastError();
+}
+
 hipError_t ecamd_launch_ed_decode_c25519(const EcamdEdDecodeArgs &a, int gslot, hipStream_t s)
 {
 	if (a.n == 0) {

@@ -1565,7 +1565,24 @@ static int xdh_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uin
 	P.flags = S[4];
 	P.n = n;
 	if (cv->gflavour == 2 && cv->gslot >= 0) {
-		HIPCHK(ecamd_launch_xdh_prep_c25519(P, cv->gslot, s));  // the same front end on the radix-2^29 field
+		// X25519 on the radix-2^29 field of the 2^255 - 19 unit: validation + clamping, then the x-only
+		// Montgomery ladder with a shared inversion (the u coordinate is all the reference exposes)
+		HIPCHK(ecamd_launch_xdh_prep_c25519(P, cv->gslot, s));
+		if (getenv("ECAMD_NO_X25519_LADDER") == nullptr) {
+			if (ensure(&ctx->stage[5], &ctx->stage_bytes[5], (size_t)n * ECAMD_XDH_REC_WORDS * 4)) {
+				return -1;
+			}
+			EcamdXdhLadderArgs L;
+			L.u = d_u;
+			L.scalars = S[2];
+			L.flags = S[4];
+			L.rec = (uint32_t *)S[5];
+			L.out = d_out;
+			L.status = d_status;
+			L.n = n;
+			HIPCHK(ecamd_launch_x25519_ladder(L, cv->gslot, s));
+			return 0;
+		}
 	} else {
 		HIPCHK(ecamd_launch_xdh_prep(nw, P, s));
 	}

@@ -144,6 +144,17 @@ hipError_t ecamd_launch_ed_decode(int nw, const EcamdEdDecodeArgs &a, hipStream_
 // the same two front-end kernels on the radix-2^29 field of the 2^255 - 19 unit (gslot: its constant slot)
 hipError_t ecamd_launch_ed_decode_c25519(const EcamdEdDecodeArgs &a, int gslot, hipStream_t s);
 hipError_t ecamd_launch_xdh_prep_c25519(const EcamdXdhPrepArgs &a, int gslot, hipStream_t s);
+// X25519 x-only Montgomery ladder + shared inversion (after k_xdh_prep_c25519 validated and clamped)
+struct EcamdXdhLadderArgs {
+	const uint8_t *u;        // n x 32 little-endian u coordinates (as given by the caller)
+	const uint8_t *scalars;  // n x 32 big-endian clamped scalars (prep kernel)
+	const uint8_t *flags;    // n, non-zero: rejected by the prep kernel
+	uint32_t *rec;           // scratch: n x ECAMD_XDH_REC_WORDS (X2, Z2)
+	uint8_t *out, *status;   // n x 32 little-endian u', n
+	uint32_t n;
+};
+#define ECAMD_XDH_REC_WORDS 20
+hipError_t ecamd_launch_x25519_ladder(const EcamdXdhLadderArgs &a, int gslot, hipStream_t s);
 hipError_t ecamd_launch_ed_scal(int nw, const EcamdEdScalArgs &a, hipStream_t s);
 hipError_t ecamd_launch_ed_fin(int nw, const EcamdEdFinArgs &a, hipStream_t s);
 
