@@ -718,6 +718,18 @@ __global__ __launch_bounds__(64) void k_ed_decode_c25519(EcamdEdDecodeArgs A, in
 		store_canon_be(pd, Xm, good, K);
 		store_canon_be(pd + 32, vm, good, K);
 		(k == 0 ? A.flagsA : A.flagsR)[i] = good ? 0 : 1;
+		if (k == 0 && A.edA != nullptr) {
+			// the key on the Edwards curve itself (canonical digits), for k_ed_smul_c25519
+			u32 buf[20];
+			canonical_digits(buf, mulc(P[0].x, onec, K), K);
+			canonical_digits(buf + 9, P[0].ym, K);
+			buf[18] = buf[19] = 0;
+			uint4 *dst = (uint4 *)(A.edA + (size_t)i * 20);
+#pragma unroll
+			for (int q = 0; q < 5; q++) {
+				dst[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
+			}
+		}
 	}
 }
 
@@ -962,6 +974,355 @@ hipError_t ecamd_launch_x25519_ladder(const EcamdXdhLadderArgs &a, int gslot, hi
 	hipLaunchKernelGGL(k_x25519_ladder, dim3((a.n + 63) / 64), dim3(64), 0, s, a, gslot);
 	const uint32_t nthreads = (a.n + XDH_FIN_K - 1) / XDH_FIN_K;
 	hipLaunchKernelGGL(k_x25519_fin, dim3((nthreads + 63) / 64), dim3(64), 0, s, a, gslot, nthreads);
+	return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Ed25519: [h]A on the twisted Edwards curve -x^2 + y^2 = 1 + d x^2 y^2 itself, in extended coordinates
+// (Hisil-Wong-Carter-Dawson): doubling 4M + 4S (3M + 4S when no addition follows), addition 8M against a
+// precomputed (Y-X, Y+X, 2dT, 2Z) entry, both COMPLETE for a = -1 and non-square d -- no exceptional pairs
+// and no special case for the neutral element.  The reference computes the same group element on the
+// Weierstrass model (prj_pt_mul, which cannot fail for a decoded key); the result is mapped to that model
+// (k_ed_hA_fin: one inversion per 8 items) and the reference-exact tail (k_ed_fin: complete additions with
+// their exceptional-pair rejections, cofactor doublings, infinity test) runs on it unchanged.
+// Per window 13M + 16S + 8M = 2828 MADs against 4144 on the Weierstrass model (generic a).
+// ------------------------------------------------------------------------------------------
+#define EDT_ENT_WORDS 40                 /* ymx, ypx, t2d, z2: 4 x 9 limbs, padded */
+#define EDT_ITEM_WORDS (8 * EDT_ENT_WORDS)
+#define EDR_REC_WORDS 28                 /* X, Y, Z: 3 x 9 limbs, padded */
+
+namespace c25519 {
+struct Ext {
+	FM X, Y, Z, T;
+};
+struct Pre {
+	FM ymx, ypx, t2d, z2;
+};
+#define M_(a, b) weaken<FM>(mulc(a, b, K))
+#define S_(a) weaken<FM>(sqrc(a, K))
+
+template <bool WITH_T> static __device__ __forceinline__ Ext ed_dbl(const Ext &P, const CK &K)
+{
+	const FM a = S_(P.X), b = S_(P.Y);
+	const auto c = mul_small<2>(S_(P.Z));
+	const auto apb = add(a, b);
+	const auto e = carry(sub_auto<1>(S_(carry(add(P.X, P.Y))), apb, K));      // 2XY
+	const auto g = carry(sub_auto<1>(b, a, K));                                // B - A
+	const auto f = carry(sub_auto<1>(g, c, K));                                // G - C
+	E<PB, 0, 0, 0> zero;
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		zero.l[w] = 0;
+	}
+	const auto h = carry(sub_auto<1>(zero, apb, K));                           // -A - B
+	Ext R;
+	R.X = M_(e, f);
+	R.Y = M_(g, h);
+	R.Z = M_(f, g);
+	if (WITH_T) {
+		R.T = M_(e, h);
+	} else {
+		R.T = P.T;  // not used by a following doubling
+	}
+	return R;
+}
+
+// P + (+-Q) for the precomputed entry Q (negated when neg)
+static __device__ __forceinline__ Ext ed_add(const Ext &P, const Pre &Q, bool neg, const CK &K)
+{
+	const FM qa = selg(neg, Q.ypx, Q.ymx), qb = selg(neg, Q.ymx, Q.ypx);
+	const FM a = M_(carry(sub_auto<1>(P.Y, P.X, K)), qa);
+	const FM b = M_(carry(add(P.Y, P.X)), qb);
+	const FM c = M_(P.T, Q.t2d);
+	const FM d = M_(P.Z, Q.z2);
+	const auto e = carry(sub_auto<1>(b, a, K));
+	const auto hh = carry(add(b, a));
+	const auto dmc = carry(sub_auto<1>(d, c, K));
+	const auto dpc = carry(add(d, c));
+	typedef decltype(dmc) TS;
+	typedef decltype(dpc) TA;
+	typedef E<PB, cmax(TS::LB, TA::LB), cmax(TS::TB, TA::TB), cmax(TS::VB, TA::VB)> TU;
+	const TU f = selg(neg, weaken<TU>(dpc), weaken<TU>(dmc));
+	const TU g = selg(neg, weaken<TU>(dmc), weaken<TU>(dpc));
+	Ext R;
+	R.X = M_(e, f);
+	R.Y = M_(g, hh);
+	R.T = M_(e, hh);
+	R.Z = M_(f, g);
+	return R;
+}
+
+static __device__ __forceinline__ Pre ed_pre(const Ext &P, const FC &d2, const CK &K)
+{
+	const FC onec = constant<FC>(K.one);
+	Pre Q;
+	Q.ymx = M_(carry(sub_auto<1>(P.Y, P.X, K)), onec);
+	Q.ypx = M_(carry(add(P.Y, P.X)), onec);
+	Q.t2d = M_(P.T, d2);
+	Q.z2 = M_(carry(mul_small<2>(P.Z)), onec);
+	return Q;
+}
+
+static __device__ __forceinline__ void pre_store(u32 *base, int e, const Pre &Q)
+{
+	u32 buf[EDT_ENT_WORDS];
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		buf[w] = Q.ymx.l[w];
+		buf[9 + w] = Q.ypx.l[w];
+		buf[18 + w] = Q.t2d.l[w];
+		buf[27 + w] = Q.z2.l[w];
+	}
+#pragma unroll
+	for (int w = 36; w < EDT_ENT_WORDS; w++) {
+		buf[w] = 0;
+	}
+	uint4 *dst = (uint4 *)(base + (size_t)e * EDT_ENT_WORDS);
+#pragma unroll
+	for (int q = 0; q < 9; q++) {
+		dst[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
+	}
+}
+static __device__ __forceinline__ Pre pre_load(const u32 *base, u32 e)
+{
+	u32 buf[36];
+	const uint4 *src = (const uint4 *)(base + (size_t)e * EDT_ENT_WORDS);
+#pragma unroll
+	for (int q = 0; q < 9; q++) {
+		const uint4 v = src[q];
+		buf[4 * q] = v.x; buf[4 * q + 1] = v.y; buf[4 * q + 2] = v.z; buf[4 * q + 3] = v.w;
+	}
+	Pre Q;
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		Q.ymx.l[w] = buf[w];
+		Q.ypx.l[w] = buf[9 + w];
+		Q.t2d.l[w] = buf[18 + w];
+		Q.z2.l[w] = buf[27 + w];
+	}
+	return Q;
+}
+#undef M_
+#undef S_
+}  // namespace c25519
+
+// [h]A per lane: table [1..8]A, signed window w = 4; the extended result goes to rec
+__global__ __launch_bounds__(64) void k_ed_smul_c25519(EcamdEdSmulArgs A, int gslot)
+{
+	using namespace c25519;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n || A.flags[i]) {
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const FC onec = constant<FC>(K.one);
+	const FM onem = weaken<FM>(onec);
+	const FC d2 = digits9(A.g_2d);
+	u32 *tb = A.tbl + (size_t)i * EDT_ITEM_WORDS;
+	Ext P1;
+	{
+		u32 buf[20];
+		const uint4 *src = (const uint4 *)(A.edA + (size_t)i * 20);
+#pragma unroll
+		for (int q = 0; q < 5; q++) {
+			const uint4 v = src[q];
+			buf[4 * q] = v.x; buf[4 * q + 1] = v.y; buf[4 * q + 2] = v.z; buf[4 * q + 3] = v.w;
+		}
+#pragma unroll
+		for (int w = 0; w < 9; w++) {
+			P1.X.l[w] = buf[w];
+			P1.Y.l[w] = buf[9 + w];
+		}
+		P1.Z = onem;
+		P1.T = weaken<FM>(mul(P1.X, P1.Y, K));
+	}
+	const Pre Q1 = ed_pre(P1, d2, K);
+	pre_store(tb, 0, Q1);
+	{
+		const Ext P2 = ed_dbl<true>(P1, K);
+		pre_store(tb, 1, ed_pre(P2, d2, K));
+		const Ext P3 = ed_add(P2, Q1, false, K);
+		pre_store(tb, 2, ed_pre(P3, d2, K));
+		const Ext P4 = ed_dbl<true>(P2, K);
+		pre_store(tb, 3, ed_pre(P4, d2, K));
+		const Ext P5 = ed_add(P4, Q1, false, K);
+		pre_store(tb, 4, ed_pre(P5, d2, K));
+		const Ext P6 = ed_dbl<true>(P3, K);
+		pre_store(tb, 5, ed_pre(P6, d2, K));
+		const Ext P7 = ed_add(P6, Q1, false, K);
+		pre_store(tb, 6, ed_pre(P7, d2, K));
+		const Ext P8 = ed_dbl<true>(P4, K);
+		pre_store(tb, 7, ed_pre(P8, d2, K));
+	}
+	// scalar: 32 bytes big-endian, k' = k + 0x88..8, top digit = the carry (0 / +1)
+	u32 kw[8];
+	load_be<8>(A.scalars + (size_t)i * 32, 32, kw);
+	u32 carry_bit;
+	{
+		uint64_t c = 0;
+#pragma unroll
+		for (int w = 0; w < 8; w++) {
+			c += (uint64_t)kw[w] + 0x88888888u;
+			kw[w] = (u32)c;
+			c >>= 32;
+		}
+		carry_bit = (u32)c;
+	}
+	Ext acc;
+	{
+		FM zero;
+#pragma unroll
+		for (int w = 0; w < 9; w++) {
+			zero.l[w] = 0;
+		}
+		// neutral element (0, 1), or A when the top digit is 1
+		acc.X = selg(carry_bit != 0, P1.X, zero);
+		acc.Y = selg(carry_bit != 0, P1.Y, onem);
+		acc.Z = onem;
+		acc.T = selg(carry_bit != 0, P1.T, zero);
+	}
+#pragma unroll 1
+	for (int t = 0; t < 64; t++) {
+		acc = ed_dbl<false>(acc, K);
+		acc = ed_dbl<false>(acc, K);
+		acc = ed_dbl<false>(acc, K);
+		acc = ed_dbl<true>(acc, K);
+		const int dig = (int)(kw[7] >> 28) - 8;
+#pragma unroll
+		for (int w = 7; w > 0; w--) {
+			kw[w] = (kw[w] << 4) | (kw[w - 1] >> 28);
+		}
+		kw[0] <<= 4;
+		const u32 mag = (u32)(dig < 0 ? -dig : dig);
+		const Pre Q = pre_load(tb, mag ? mag - 1 : 0);
+		const Ext S = ed_add(acc, Q, dig < 0, K);
+		const bool keep = (mag == 0);
+		acc.X = selg(keep, acc.X, S.X);
+		acc.Y = selg(keep, acc.Y, S.Y);
+		acc.Z = selg(keep, acc.Z, S.Z);
+		acc.T = selg(keep, acc.T, S.T);
+	}
+	u32 buf[EDR_REC_WORDS];
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		buf[w] = acc.X.l[w];
+		buf[9 + w] = acc.Y.l[w];
+		buf[18 + w] = acc.Z.l[w];
+	}
+	buf[27] = 0;
+	uint4 *dst = (uint4 *)(A.rec + (size_t)i * EDR_REC_WORDS);
+#pragma unroll
+	for (int q = 0; q < EDR_REC_WORDS / 4; q++) {
+		dst[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
+	}
+}
+
+// extended Edwards (X : Y : Z) -> the Weierstrass model, affine big-endian + status, 8 items per inversion:
+//   u = (Z + Y) / (Z - Y), v = alpha u Z / X, (x, y) = (u + A/3, v); with w = ((Z - Y) X)^-1:
+//   u = (Z + Y) X w, v = alpha (Z + Y) Z w.   X = 0: the neutral element (Y = Z: infinity, status 2) or the
+//   point of order two (Y = -Z: (A/3, 0)).
+#define EDF_K 8
+__global__ __launch_bounds__(64) void k_ed_hA_fin(EcamdEdSmulArgs A, int gslot, u32 nthreads)
+{
+	using namespace c25519;
+	const u32 t = blockIdx.x * 64 + threadIdx.x;
+	if (t >= nthreads) {
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const FC onec = constant<FC>(K.one);
+	const FM onem = weaken<FM>(onec);
+	FM pre[EDF_K];
+	u32 live = 0;
+	FM acc = onem;
+#pragma unroll 1
+	for (int j = 0; j < EDF_K; j++) {
+		const u32 i = t + (u32)j * nthreads;
+		pre[j] = acc;
+		if (i >= A.n || A.flags[i]) {
+			continue;
+		}
+		u32 buf[EDR_REC_WORDS];
+		const uint4 *src = (const uint4 *)(A.rec + (size_t)i * EDR_REC_WORDS);
+#pragma unroll
+		for (int q = 0; q < EDR_REC_WORDS / 4; q++) {
+			const uint4 v = src[q];
+			buf[4 * q] = v.x; buf[4 * q + 1] = v.y; buf[4 * q + 2] = v.z; buf[4 * q + 3] = v.w;
+		}
+		FM X, Y, Z;
+#pragma unroll
+		for (int w = 0; w < 9; w++) {
+			X.l[w] = buf[w];
+			Y.l[w] = buf[9 + w];
+			Z.l[w] = buf[18 + w];
+		}
+		const FM den = weaken<FM>(mulc(carry(sub_auto<1>(Z, Y, K)), X, K));
+		if (!is_zero_mulout(den, K)) {
+			live |= 1u << j;
+			acc = weaken<FM>(mul(acc, den, K));
+		}
+	}
+	FM a11;
+	FM inv = weaken<FM>(mul(sqr_n(pow_2_250m1(acc, &a11, K), 5, K), a11, K));
+#pragma unroll 1
+	for (int j = EDF_K - 1; j >= 0; j--) {
+		const u32 i = t + (u32)j * nthreads;
+		if (i >= A.n) {
+			continue;
+		}
+		u8 *out = A.out + (size_t)i * 64;
+		if (A.flags[i]) {
+			for (int b = 0; b < 64; b++) {
+				out[b] = 0;
+			}
+			A.status[i] = 1;
+			continue;
+		}
+		u32 buf[EDR_REC_WORDS];
+		const uint4 *src = (const uint4 *)(A.rec + (size_t)i * EDR_REC_WORDS);
+#pragma unroll
+		for (int q = 0; q < EDR_REC_WORDS / 4; q++) {
+			const uint4 v = src[q];
+			buf[4 * q] = v.x; buf[4 * q + 1] = v.y; buf[4 * q + 2] = v.z; buf[4 * q + 3] = v.w;
+		}
+		FM X, Y, Z;
+#pragma unroll
+		for (int w = 0; w < 9; w++) {
+			X.l[w] = buf[w];
+			Y.l[w] = buf[9 + w];
+			Z.l[w] = buf[18 + w];
+		}
+		if ((live >> j) & 1u) {
+			const FM den = weaken<FM>(mulc(carry(sub_auto<1>(Z, Y, K)), X, K));
+			const FM w_ = weaken<FM>(mul(inv, pre[j], K));
+			inv = weaken<FM>(mul(inv, den, K));
+			const FM zpy = weaken<FM>(mulc(carry(add(Z, Y)), w_, K));          // (Z + Y) w
+			const FM um = weaken<FM>(mul(zpy, X, K));
+			const FM vm = weaken<FM>(mul(mul(digits9(A.g_alpha), zpy, K), Z, K));
+			store_canon_be(out, carry(add(um, digits9(A.g_A3))), true, K);
+			store_canon_be(out + 32, vm, true, K);
+			A.status[i] = 0;
+		} else {
+			// X = 0 or Y = Z (only together with X = 0 on the curve): neutral element or the point of order two
+			const bool neutral = eq(Y, Z, K);
+			FC a3 = digits9(A.g_A3);
+			store_canon_be(out, a3, !neutral, K);
+			for (int b = 32; b < 64; b++) {
+				out[b] = 0;
+			}
+			A.status[i] = neutral ? 2 : 0;
+		}
+	}
+}
+
+hipError_t ecamd_launch_ed_smul_c25519(const EcamdEdSmulArgs &a, int gslot, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_ed_smul_c25519, dim3((a.n + 63) / 64), dim3(64), 0, s, a, gslot);
+	const uint32_t nthreads = (a.n + EDF_K - 1) / EDF_K;
+	hipLaunchKernelGGL(k_ed_hA_fin, dim3((nthreads + 63) / 64), dim3(64), 0, s, a, gslot, nthreads);
 	return hipGetLastError();
 }
 

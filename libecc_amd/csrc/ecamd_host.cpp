@@ -240,6 +240,7 @@ struct ecamd_curve {
 	const char *ed_err;
 	EcamdEdDecodeArgs ed_tmpl;
 	uint32_t ed_cof_dbl;
+	uint32_t ed_2d[9];   // 2 d mod p, plain radix-2^29 digits (Edwards arithmetic of the 2^255 - 19 unit)
 	int xdh_state;
 	const char *xdh_err;
 	EcamdXdhPrepArgs xdh_tmpl;
@@ -1775,6 +1776,7 @@ static void ed_setup(ecamd_curve *cv)
 	big_digits29(D.g_sm1, 9, big_sqrt_m1(p));
 	big_digits29(D.g_alpha, 9, alpha);
 	big_digits29(D.g_A3, 9, A3);
+	big_digits29(cv->ed_2d, 9, big_mod(big_add(d_ed, d_ed), p));
 	cv->ed_state = 1;
 }
 
@@ -1806,7 +1808,19 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 	D.flagsA = S[5];
 	D.flagsR = S[6];
 	D.cof_dbl = cof_dbl;
-	if (cv->gflavour == 2 && cv->gslot >= 0) {
+	const bool unit25519 = cv->gflavour == 2 && cv->gslot >= 0;
+	const bool edwards_hA = unit25519 && getenv("ECAMD_NO_EDWARDS_SMUL") == nullptr;
+	D.edA = nullptr;
+	if (edwards_hA) {
+		// stage 10: A on the Edwards curve, 11: extended result records, 18: window tables
+		if (ensure(&ctx->stage[10], &ctx->stage_bytes[10], (size_t)n * 20 * 4) ||
+		    ensure(&ctx->stage[11], &ctx->stage_bytes[11], (size_t)n * ECAMD_EDR_REC_WORDS * 4) ||
+		    ensure(&ctx->stage[18], &ctx->stage_bytes[18], (size_t)n * ECAMD_EDT_ITEM_WORDS * 4)) {
+			return -1;
+		}
+		D.edA = (uint32_t *)S[10];
+	}
+	if (unit25519) {
 		HIPCHK(ecamd_launch_ed_decode_c25519(D, cv->gslot, s));  // the same decoding on the radix-2^29 field
 	} else {
 		HIPCHK(ecamd_launch_ed_decode(nw, D, s));
@@ -1824,7 +1838,24 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 	C.qslot = cv->qslot;
 	HIPCHK(ecamd_launch_ed_scal(nw, C, s));
 	// [h]A, [S]G  ([8]A != infinity was checked by the decode kernel)
-	if (smul_dev_locked(ctx, cv, n, S[9], (uint32_t)len, S[3], S[12], S[13], s) ||
+	if (edwards_hA) {
+		// [h]A on the Edwards curve itself (complete extended-coordinate formulas), mapped to the Weierstrass model
+		EcamdEdSmulArgs E;
+		memset(&E, 0, sizeof(E));
+		E.edA = (const uint32_t *)S[10];
+		E.scalars = S[9];
+		E.flags = S[5];
+		E.tbl = (uint32_t *)S[18];
+		E.rec = (uint32_t *)S[11];
+		E.out = S[12];
+		E.status = S[13];
+		E.n = n;
+		memcpy(E.g_2d, cv->ed_2d, sizeof(E.g_2d));
+		memcpy(E.g_alpha, cv->ed_tmpl.g_alpha, sizeof(E.g_alpha));
+		memcpy(E.g_A3, cv->ed_tmpl.g_A3, sizeof(E.g_A3));
+		HIPCHK(ecamd_launch_ed_smul_c25519(E, cv->gslot, s));
+	}
+	if ((!edwards_hA && smul_dev_locked(ctx, cv, n, S[9], (uint32_t)len, S[3], S[12], S[13], s)) ||
 	    smul_dev_locked(ctx, cv, n, S[8], (uint32_t)len, nullptr, S[14], S[15], s)) {
 		return -1;
 	}

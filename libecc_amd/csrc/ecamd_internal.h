@@ -121,8 +121,23 @@ struct EcamdEdDecodeArgs {
 	uint32_t n, len, cof_dbl;   // cof_dbl = log2(cofactor)
 	uint32_t a[17], d[17], sm1[17], alpha[17], A3[17];  // Edwards a, d; sqrt(-1); alpha_edwards; A/3 (Montgomery form)
 	uint32_t g_d[9], g_sm1[9], g_alpha[9], g_A3[9];     // the same as plain radix-2^29 digits (2^255 - 19 unit)
+	uint32_t *edA;              // 2^255 - 19 unit only, may be NULL: n x 20 words, A on the Edwards curve (x, y digits)
 	int slot;
 };
+// [h]A on the Edwards curve (extended coordinates) and its map to the Weierstrass model (2^255 - 19 unit)
+struct EcamdEdSmulArgs {
+	const uint32_t *edA;     // n x 20 words (k_ed_decode_c25519)
+	const uint8_t *scalars;  // n x 32 big-endian
+	const uint8_t *flags;    // n, non-zero: key rejected
+	uint32_t *tbl;           // scratch: n x 320 words
+	uint32_t *rec;           // scratch: n x 28 words
+	uint8_t *out, *status;   // n x 64 affine Weierstrass big-endian, n (0 ok / 1 rejected key / 2 infinity)
+	uint32_t n;
+	uint32_t g_2d[9], g_alpha[9], g_A3[9];
+};
+#define ECAMD_EDT_ITEM_WORDS 320
+#define ECAMD_EDR_REC_WORDS 28
+hipError_t ecamd_launch_ed_smul_c25519(const EcamdEdSmulArgs &a, int gslot, hipStream_t s);
 struct EcamdEdScalArgs {
 	const uint8_t *sigs;     // n x 2*len: R || S
 	const uint8_t *hram;     // n x hlen: H(dom || R || A || M), little-endian integer

@@ -876,3 +876,34 @@ def test_libecc_glue_demo():
     r = subprocess.run([exe, "384"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "384 items, 0 mismatches" in r.stdout and "64 items, 0 mismatches" in r.stdout
+
+
+def test_eddsa25519_zero_challenge(gpu_ctx):
+    """h = 0 mod q (the caller supplies the hash, so this is reachable through the API): [h]A is the point at
+    infinity / the Edwards neutral element, and the equation degenerates to 8([S]B - R) = infinity"""
+    import oracles as O
+    rng = np.random.default_rng(37)
+    q = O.ED_Q
+    t8 = O.ed_decode(O.ED_TORSION8)
+    pubs, sigs, hram = b"", b"", b""
+    for i in range(24):
+        a_enc, _, _ = O.ed25519_sign(rand_bytes(rng, 32), b"x")
+        S = int.from_bytes(rand_bytes(rng, 40), "little") % q
+        R = O.ed_mul(S, O.ED_B) if S else (0, 1, 1, 0)
+        if i % 4 == 1:
+            R = O.ed_add(R, t8)                       # torsion-shifted R: still accepted
+        if i % 4 == 2:
+            R = O.ed_add(R, O.ED_B)                   # wrong R: rejected
+        if i % 4 == 3:
+            a_enc = O.ed_encode(O.ed_add(O.ed_decode(a_enc), t8))   # mixed-order key
+        h = [0, q, 5 * q, (2**512 - 1) // q * q][i % 4] if i < 20 else [1, q - 1, q + 1, 2**512 - 1][i - 20]
+        pubs += a_enc
+        sigs += O.ed_encode(R) + S.to_bytes(32, "little")
+        hram += h.to_bytes(64, "little")
+    exp = Oracle("WEI25519").eddsa_verify(pubs, sigs, hram)
+    assert exp[:20] == bytes([0, 0, 1, 0] * 5)
+    cv = gpu_ctx.curve("WEI25519")
+    try:
+        assert cv.eddsa_verify(pubs, sigs, hram) == exp
+    finally:
+        cv.free()
