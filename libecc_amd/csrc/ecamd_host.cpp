@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string>
 #include <vector>
+#include <functional>
 #include <mutex>
 
 #include "../../include/libecc_amd.h"
@@ -217,6 +218,12 @@ struct ecamd_ctx {
 	size_t stage_bytes[ECAMD_NSTAGE];
 	bool slot_used[ECAMD_MAX_SLOTS_HOST];
 	bool gslot_used[640][8];
+	// host-pointer entry points: chunks of host_chunk items, the copy of chunk c+1 overlaps the kernels of chunk c
+	hipStream_t copy_stream;
+	hipEvent_t in_ready[2];
+	uint32_t host_chunk;
+	uint8_t *hbuf[2][6];       // double-buffered device staging of the caller's arrays (inputs and outputs)
+	size_t hbuf_bytes[2][6];
 	uint32_t comb_min_batch;   // fixed-base batches of at least this many items build / use the generator's comb table (0: never)
 	bool timing;               // record HIP events around the kernels of the scalar-mult pipeline
 	hipEvent_t ev[ECAMD_NTIMED + 1];
@@ -323,6 +330,21 @@ extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
 			return fail("ecamd_ctx_create: hipEventCreate failed");
 		}
 	}
+	memset(c->hbuf, 0, sizeof(c->hbuf));
+	memset(c->hbuf_bytes, 0, sizeof(c->hbuf_bytes));
+	{
+		const char *e = getenv("ECAMD_HOST_CHUNK");
+		c->host_chunk = e ? (uint32_t)strtoul(e, nullptr, 10) : (1u << 18);
+		if (c->host_chunk == 0) {
+			c->host_chunk = 1u << 18;
+		}
+	}
+	if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->in_ready[0], hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->in_ready[1], hipEventDisableTiming) != hipSuccess) {
+		delete c;
+		return fail("ecamd_ctx_create: copy stream creation failed");
+	}
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
 		delete c;
 		return fail("ecamd_ctx_create: hipStreamCreate failed");
@@ -353,6 +375,16 @@ extern "C" void ecamd_ctx_destroy(ecamd_ctx *c)
 		(void)hipEventDestroy(c->ev[i]);
 	}
 	(void)hipStreamDestroy(c->stream);
+	(void)hipStreamDestroy(c->copy_stream);
+	(void)hipEventDestroy(c->in_ready[0]);
+	(void)hipEventDestroy(c->in_ready[1]);
+	for (int b = 0; b < 2; b++) {
+		for (int k = 0; k < 6; k++) {
+			if (c->hbuf[b][k]) {
+				(void)hipFree(c->hbuf[b][k]);
+			}
+		}
+	}
 	delete c;
 }
 
@@ -916,6 +948,86 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 	return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Host-pointer entry points = the device-pointer cores behind copies of the caller's arrays.  The batch goes
+// through in chunks of ctx->host_chunk items with double-buffered device staging: while the kernels of chunk
+// c run on the compute stream, the host thread is inside the (pageable, hence host-blocking) copy of chunk
+// c+1 on the copy stream, so PCIe and the GPU work concurrently.  `ins` / `outs`: the caller's arrays with
+// their per-item strides (a NULL input is passed on as NULL); core(m, in_ptrs, out_ptrs, stream) enqueues one
+// chunk and may synchronise (after calling `between`).  ctx->mu held.
+// ------------------------------------------------------------------------------------------
+struct HostArr {
+	const uint8_t *in;   // input array (or NULL)
+	uint8_t *out;        // output array (or NULL)
+	size_t stride;       // bytes per item
+};
+
+template <class Core>
+static int host_pipeline(ecamd_ctx *ctx, uint32_t n, const std::vector<HostArr> &arrs, Core core)
+{
+	const uint32_t chunk = n < ctx->host_chunk ? n : ctx->host_chunk;
+	const size_t na = arrs.size();
+	if (na > 6) {
+		return fail("internal: too many host arrays");
+	}
+	const int nbuf = (n > chunk) ? 2 : 1;
+	for (int b = 0; b < nbuf; b++) {
+		for (size_t k = 0; k < na; k++) {
+			if (ensure(&ctx->hbuf[b][k], &ctx->hbuf_bytes[b][k], (size_t)chunk * arrs[k].stride)) {
+				return -1;
+			}
+		}
+	}
+	hipStream_t cs = ctx->copy_stream, s = ctx->stream;
+	auto copy_in = [&](uint32_t off, uint32_t m, int b) -> int {
+		for (size_t k = 0; k < na; k++) {
+			if (arrs[k].in) {
+				HIPCHK(hipMemcpyAsync(ctx->hbuf[b][k], arrs[k].in + (size_t)off * arrs[k].stride, (size_t)m * arrs[k].stride,
+						      hipMemcpyHostToDevice, cs));
+			}
+		}
+		HIPCHK(hipEventRecord(ctx->in_ready[b], cs));
+		return 0;
+	};
+	if (copy_in(0, chunk, 0)) {
+		return -1;
+	}
+	int b = 0;
+	for (uint32_t off = 0; off < n; off += chunk, b ^= (nbuf - 1)) {
+		const uint32_t m = (n - off) < chunk ? (n - off) : chunk;
+		std::vector<const uint8_t *> ip(na, nullptr);
+		std::vector<uint8_t *> op(na, nullptr);
+		for (size_t k = 0; k < na; k++) {
+			ip[k] = arrs[k].in ? ctx->hbuf[b][k] : nullptr;
+			op[k] = arrs[k].out ? ctx->hbuf[b][k] : nullptr;
+		}
+		HIPCHK(hipStreamWaitEvent(s, ctx->in_ready[b], 0));
+		// `between`: called once this chunk's kernels are enqueued and before anything waits for them -- by the
+		// core itself if it has to synchronise (ECDSA re-checks exceptional items), otherwise right after it
+		bool next_issued = false;
+		const uint32_t noff = off + chunk;
+		const std::function<int()> between = [&]() -> int {
+			if (next_issued || noff >= n) {
+				return 0;
+			}
+			next_issued = true;
+			// the other staging set is free: its chunk was drained at the end of the previous iteration
+			return copy_in(noff, (n - noff) < chunk ? (n - noff) : chunk, b ^ 1);
+		};
+		if (core(m, ip, op, s, between) || between()) {
+			return -1;
+		}
+		for (size_t k = 0; k < na; k++) {
+			if (arrs[k].out) {
+				HIPCHK(hipMemcpyAsync(arrs[k].out + (size_t)off * arrs[k].stride, ctx->hbuf[b][k], (size_t)m * arrs[k].stride,
+						      hipMemcpyDeviceToHost, s));
+			}
+		}
+		HIPCHK(hipStreamSynchronize(s));
+	}
+	return 0;
+}
+
 extern "C" int ec_prj_pt_mul_batch_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n,
 				       const void *d_scalars, uint32_t slen, const void *d_points,
 				       void *d_out, void *d_status, void *hip_stream)
@@ -951,25 +1063,11 @@ extern "C" int ec_prj_pt_mul_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 	std::lock_guard<std::mutex> lk(ctx->mu);
 	HIPCHK(hipSetDevice(ctx->device));
 	const size_t plen = (size_t)2 * cv->clen;
-	if (ensure(&ctx->stage[0], &ctx->stage_bytes[0], (size_t)n * slen) ||
-	    ensure(&ctx->stage[1], &ctx->stage_bytes[1], (size_t)n * plen) ||
-	    ensure(&ctx->stage[2], &ctx->stage_bytes[2], (size_t)n * plen) ||
-	    ensure(&ctx->stage[3], &ctx->stage_bytes[3], (size_t)n)) {
-		return -1;
-	}
-	hipStream_t s = ctx->stream;
-	HIPCHK(hipMemcpyAsync(ctx->stage[0], scalars, (size_t)n * slen, hipMemcpyHostToDevice, s));
-	if (points) {
-		HIPCHK(hipMemcpyAsync(ctx->stage[1], points, (size_t)n * plen, hipMemcpyHostToDevice, s));
-	}
-	if (smul_dev_locked(ctx, cv, n, ctx->stage[0], slen, points ? ctx->stage[1] : nullptr, ctx->stage[2],
-			    ctx->stage[3], s)) {
-		return -1;
-	}
-	HIPCHK(hipMemcpyAsync(out, ctx->stage[2], (size_t)n * plen, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipMemcpyAsync(status, ctx->stage[3], (size_t)n, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
-	return 0;
+	const std::vector<HostArr> arrs = {{scalars, nullptr, slen}, {points, nullptr, plen}, {nullptr, out, plen}, {nullptr, status, 1}};
+	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+					       hipStream_t s, const std::function<int()> &) {
+		return smul_dev_locked(ctx, cv, m, ip[0], slen, ip[1], op[2], op[3], s);
+	});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1153,10 +1251,14 @@ static int ecdsa_two_smul_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n,
 
 // device pointers in and out; returns with the results complete (the stream is synchronised)
 static int ecdsa_verify_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_pub,
-				   const uint8_t *d_sig, const uint8_t *d_dig, uint32_t hlen, uint8_t *d_res, hipStream_t s)
+				   const uint8_t *d_sig, const uint8_t *d_dig, uint32_t hlen, uint8_t *d_res, hipStream_t s,
+				   const std::function<int()> *between = nullptr)
 {
 	if (!cv->is_p256 || !cv->d_gtab) {
 		if (ecdsa_two_smul_dev(ctx, cv, n, d_pub, d_sig, d_dig, hlen, d_res, s)) {
+			return -1;
+		}
+		if (between && (*between)()) {
 			return -1;
 		}
 		HIPCHK(hipStreamSynchronize(s));
@@ -1210,6 +1312,9 @@ static int ecdsa_verify_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 	}
 	// exceptional pairs inside the interleaved loop (never for honest signatures) come back as
 	// ECAMD_STATUS_REDO: re-verify those items the reference's way
+	if (between && (*between)()) {
+		return -1;
+	}
 	std::vector<uint8_t> hres(n);
 	HIPCHK(hipMemcpyAsync(hres.data(), d_res, n, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
@@ -1291,22 +1396,11 @@ extern "C" int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint
 	std::lock_guard<std::mutex> lk(ctx->mu);
 	HIPCHK(hipSetDevice(ctx->device));
 	const size_t plen = (size_t)2 * cv->clen, slen2 = (size_t)2 * cv->qlen;
-	// stage: 0 pubkeys, 1 signatures, 2 digests, 12 results (3..11 and 13..16 belong to the device core)
-	if (ensure(&ctx->stage[0], &ctx->stage_bytes[0], n * plen) || ensure(&ctx->stage[1], &ctx->stage_bytes[1], n * slen2) ||
-	    ensure(&ctx->stage[2], &ctx->stage_bytes[2], (size_t)n * hlen) || ensure(&ctx->stage[12], &ctx->stage_bytes[12], n)) {
-		return -1;
-	}
-	uint8_t **S = ctx->stage;
-	hipStream_t s = ctx->stream;
-	HIPCHK(hipMemcpyAsync(S[0], pubkeys, n * plen, hipMemcpyHostToDevice, s));
-	HIPCHK(hipMemcpyAsync(S[1], sigs, n * slen2, hipMemcpyHostToDevice, s));
-	HIPCHK(hipMemcpyAsync(S[2], digests, (size_t)n * hlen, hipMemcpyHostToDevice, s));
-	if (ecdsa_verify_dev_locked(ctx, cv, n, S[0], S[1], S[2], hlen, S[12], s)) {
-		return -1;
-	}
-	HIPCHK(hipMemcpyAsync(result, S[12], n, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
-	return 0;
+	const std::vector<HostArr> arrs = {{pubkeys, nullptr, plen}, {sigs, nullptr, slen2}, {digests, nullptr, hlen}, {nullptr, result, 1}};
+	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+					       hipStream_t s, const std::function<int()> &between) {
+		return ecdsa_verify_dev_locked(ctx, cv, m, ip[0], ip[1], ip[2], hlen, op[3], s, &between);
+	});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1657,21 +1751,11 @@ extern "C" int ec_xdh_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n
 	HIPCHK(hipSetDevice(ctx->device));
 	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
 	const size_t len = (size_t)cv->clen;
-	if (ensure(&ctx->stage[0], &ctx->stage_bytes[0], n * len) || ensure(&ctx->stage[1], &ctx->stage_bytes[1], n * len) ||
-	    ensure(&ctx->stage[9], &ctx->stage_bytes[9], n * len) || ensure(&ctx->stage[10], &ctx->stage_bytes[10], n)) {
-		return -1;
-	}
-	uint8_t **S = ctx->stage;
-	hipStream_t s = ctx->stream;
-	HIPCHK(hipMemcpyAsync(S[0], k, n * len, hipMemcpyHostToDevice, s));
-	HIPCHK(hipMemcpyAsync(S[1], u, n * len, hipMemcpyHostToDevice, s));
-	if (xdh_dev_locked(ctx, cv, n, S[0], S[1], S[9], S[10], s)) {
-		return -1;
-	}
-	HIPCHK(hipMemcpyAsync(out, S[9], n * len, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipMemcpyAsync(status, S[10], n, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
-	return 0;
+	const std::vector<HostArr> arrs = {{k, nullptr, len}, {u, nullptr, len}, {nullptr, out, len}, {nullptr, status, 1}};
+	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+					       hipStream_t s, const std::function<int()> &) {
+		return xdh_dev_locked(ctx, cv, m, ip[0], ip[1], op[2], op[3], s);
+	});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1932,22 +2016,11 @@ extern "C" int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, u
 	}
 	HIPCHK(hipSetDevice(ctx->device));
 	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
-	const size_t len = 32, plen = 64;
-	if (ensure(&ctx->stage[0], &ctx->stage_bytes[0], n * len) || ensure(&ctx->stage[1], &ctx->stage_bytes[1], n * plen) ||
-	    ensure(&ctx->stage[2], &ctx->stage_bytes[2], (size_t)n * hram_len) || ensure(&ctx->stage[16], &ctx->stage_bytes[16], n)) {
-		return -1;
-	}
-	uint8_t **S = ctx->stage;
-	hipStream_t s = ctx->stream;
-	HIPCHK(hipMemcpyAsync(S[0], pubkeys, n * len, hipMemcpyHostToDevice, s));
-	HIPCHK(hipMemcpyAsync(S[1], sigs, n * plen, hipMemcpyHostToDevice, s));
-	HIPCHK(hipMemcpyAsync(S[2], hram, (size_t)n * hram_len, hipMemcpyHostToDevice, s));
-	if (eddsa_verify_dev_locked(ctx, cv, n, S[0], S[1], S[2], hram_len, S[16], s)) {
-		return -1;
-	}
-	HIPCHK(hipMemcpyAsync(result, S[16], n, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
-	return 0;
+	const std::vector<HostArr> arrs = {{pubkeys, nullptr, 32}, {sigs, nullptr, 64}, {hram, nullptr, hram_len}, {nullptr, result, 1}};
+	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+					       hipStream_t s, const std::function<int()> &) {
+		return eddsa_verify_dev_locked(ctx, cv, m, ip[0], ip[1], ip[2], hram_len, op[3], s);
+	});
 }
 
 // ------------------------------------------------------------------------------------------

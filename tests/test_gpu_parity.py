@@ -907,3 +907,69 @@ def test_eddsa25519_zero_challenge(gpu_ctx):
         assert cv.eddsa_verify(pubs, sigs, hram) == exp
     finally:
         cv.free()
+
+
+def test_host_pipeline_multi_chunk(gpu_ctx):
+    """host-pointer entry points split a batch into chunks and overlap the copy of the next chunk with the
+    kernels of the current one: a context with a tiny chunk (ECAMD_HOST_CHUNK) must give the same bytes as the
+    session context, on ragged batch sizes, for scalar mult, ECDSA verify (incl. exceptional items), Ed25519
+    verify and X25519"""
+    import libecc_amd
+    from test_oracle import ed25519_cases
+    rng = np.random.default_rng(38)
+    old = os.environ.get("ECAMD_HOST_CHUNK")
+    os.environ["ECAMD_HOST_CHUNK"] = "700"
+    try:
+        ctx2 = libecc_amd.Context(0)
+    finally:
+        if old is None:
+            del os.environ["ECAMD_HOST_CHUNK"]
+        else:
+            os.environ["ECAMD_HOST_CHUNK"] = old
+    try:
+        n = 3 * 700 + 123
+        a, b = gpu_ctx.curve("SECP256R1"), ctx2.curve("SECP256R1")
+        try:
+            sc = rand_bytes(rng, 32 * n)
+            pa = a.scalar_mult(sc)
+            assert b.scalar_mult(sc) == pa and set(pa[1]) == {0}
+            sc2 = rand_bytes(rng, 32 * n)
+            assert b.scalar_mult(sc2, pa[0]) == a.scalar_mult(sc2, pa[0])
+            o, pubs, sigs, dg, hl, _ = make_sigs("SECP256R1", "SHA256", 64, rng)
+            reps = n // 64 + 1
+            P, S, D = (pubs * reps)[:64 * n], bytearray((sigs * reps)[:64 * n]), (dg * reps)[:32 * n]
+            for i in range(0, n, 9):
+                S[64 * i + 40] ^= 2
+            c = CURVES["SECP256R1"]
+            G = c["gx"].to_bytes(32, "big") + c["gy"].to_bytes(32, "big")
+            kG, _ = o.scalar_mult((7).to_bytes(32, "big"))
+            r = int.from_bytes(kG[:32], "big") % c["q"]
+            sv = pow(7, c["q"] - 2, c["q"]) * (2 * r) % c["q"]
+            for i in (5, 701, 2100):    # exceptional items (Q = G, u1 == u2) in different chunks
+                P = P[:64 * i] + G + P[64 * i + 64:]
+                S[64 * i:64 * i + 64] = r.to_bytes(32, "big") + sv.to_bytes(32, "big")
+                D = D[:32 * i] + r.to_bytes(32, "big") + D[32 * i + 32:]
+            ra = a.ecdsa_verify(P, bytes(S), D, 32)
+            assert b.ecdsa_verify(P, bytes(S), D, 32) == ra and 0 in ra and 1 in ra and ra[5] == 0
+        finally:
+            a.free()
+            b.free()
+        a, b = gpu_ctx.curve("WEI25519"), ctx2.curve("WEI25519")
+        try:
+            pubs, sigs, msgs, hram = ed25519_cases(rng, nvalid=10)
+            n0 = len(pubs) // 32
+            reps = n // n0 + 1
+            P, S, H = (pubs * reps)[:32 * n], (sigs * reps)[:64 * n], (hram * reps)[:64 * n]
+            ra = a.eddsa_verify(P, S, H)
+            assert b.eddsa_verify(P, S, H) == ra and 0 in ra and 1 in ra
+            k = rand_bytes(rng, 32 * n)
+            base = (9).to_bytes(32, "little") * n
+            pa = a.xdh(k, base)
+            assert b.xdh(k, base) == pa
+            k2 = rand_bytes(rng, 32 * n)
+            assert b.xdh(k2, pa[0]) == a.xdh(k2, pa[0])
+        finally:
+            a.free()
+            b.free()
+    finally:
+        ctx2.close()
