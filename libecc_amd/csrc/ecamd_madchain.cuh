@@ -20,16 +20,26 @@
 #endif
 
 #if defined(__HIPCC__) && defined(U29_ASM_MAD)
-template <int N, bool DUAL, bool YS> ECAMD_CHAIN_FN void ecamd_mad_chain(uint64_t &acc, uint64_t &acc2, const uint32_t *x, const uint32_t *y)
+// Z2: acc2 holds nothing yet -- its first product is written with a zero addend instead of being accumulated
+template <int N, bool DUAL, bool YS, bool Z2 = false>
+ECAMD_CHAIN_FN void ecamd_mad_chain(uint64_t &acc, uint64_t &acc2, const uint32_t *x, const uint32_t *y)
 {
 	uint64_t dead_;
 	(void)acc2;
 	if constexpr (N >= 8) {
-		if constexpr (DUAL && YS) {
+		if constexpr (DUAL && YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]));
+		} else if constexpr (DUAL && YS && !Z2) {
 			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1"
 			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
 			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]));
-		} else if constexpr (DUAL && !YS) {
+		} else if constexpr (DUAL && !YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]));
+		} else if constexpr (DUAL && !YS && !Z2) {
 			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1"
 			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
 			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]));
@@ -42,13 +52,21 @@ template <int N, bool DUAL, bool YS> ECAMD_CHAIN_FN void ecamd_mad_chain(uint64_
 			    : "+v"(acc), "=&s"(dead_)
 			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]));
 		}
-		ecamd_mad_chain<N - 8, DUAL, YS>(acc, acc2, x + 8, y + 8);
+		ecamd_mad_chain<N - 8, DUAL, YS, false>(acc, acc2, x + 8, y + 8);
 	} else if constexpr (N == 7) {
-		if constexpr (DUAL && YS) {
+		if constexpr (DUAL && YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]));
+		} else if constexpr (DUAL && YS && !Z2) {
 			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0"
 			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
 			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]));
-		} else if constexpr (DUAL && !YS) {
+		} else if constexpr (DUAL && !YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]));
+		} else if constexpr (DUAL && !YS && !Z2) {
 			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0"
 			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
 			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]));
@@ -62,11 +80,19 @@ template <int N, bool DUAL, bool YS> ECAMD_CHAIN_FN void ecamd_mad_chain(uint64_
 			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]));
 		}
 	} else if constexpr (N == 6) {
-		if constexpr (DUAL && YS) {
+		if constexpr (DUAL && YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]));
+		} else if constexpr (DUAL && YS && !Z2) {
 			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1"
 			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
 			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]));
-		} else if constexpr (DUAL && !YS) {
+		} else if constexpr (DUAL && !YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]));
+		} else if constexpr (DUAL && !YS && !Z2) {
 			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1"
 			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
 			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]));
@@ -80,11 +106,19 @@ template <int N, bool DUAL, bool YS> ECAMD_CHAIN_FN void ecamd_mad_chain(uint64_
 			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]));
 		}
 	} else if constexpr (N == 5) {
-		if constexpr (DUAL && YS) {
+		if constexpr (DUAL && YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]));
+		} else if constexpr (DUAL && YS && !Z2) {
 			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0"
 			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
 			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]));
-		} else if constexpr (DUAL && !YS) {
+		} else if constexpr (DUAL && !YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]));
+		} else if constexpr (DUAL && !YS && !Z2) {
 			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0"
 			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
 			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]));
@@ -98,11 +132,19 @@ template <int N, bool DUAL, bool YS> ECAMD_CHAIN_FN void ecamd_mad_chain(uint64_
 			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]));
 		}
 	} else if constexpr (N == 4) {
-		if constexpr (DUAL && YS) {
+		if constexpr (DUAL && YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]));
+		} else if constexpr (DUAL && YS && !Z2) {
 			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1"
 			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
 			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]));
-		} else if constexpr (DUAL && !YS) {
+		} else if constexpr (DUAL && !YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]));
+		} else if constexpr (DUAL && !YS && !Z2) {
 			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1"
 			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
 			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]));
@@ -116,11 +158,19 @@ template <int N, bool DUAL, bool YS> ECAMD_CHAIN_FN void ecamd_mad_chain(uint64_
 			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]));
 		}
 	} else if constexpr (N == 3) {
-		if constexpr (DUAL && YS) {
+		if constexpr (DUAL && YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]));
+		} else if constexpr (DUAL && YS && !Z2) {
 			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0"
 			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
 			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]));
-		} else if constexpr (DUAL && !YS) {
+		} else if constexpr (DUAL && !YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]));
+		} else if constexpr (DUAL && !YS && !Z2) {
 			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0"
 			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
 			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]));
@@ -134,11 +184,19 @@ template <int N, bool DUAL, bool YS> ECAMD_CHAIN_FN void ecamd_mad_chain(uint64_
 			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]));
 		}
 	} else if constexpr (N == 2) {
-		if constexpr (DUAL && YS) {
+		if constexpr (DUAL && YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]));
+		} else if constexpr (DUAL && YS && !Z2) {
 			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1"
 			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
 			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]));
-		} else if constexpr (DUAL && !YS) {
+		} else if constexpr (DUAL && !YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]));
+		} else if constexpr (DUAL && !YS && !Z2) {
 			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1"
 			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
 			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]));
@@ -164,8 +222,12 @@ template <int N, bool DUAL, bool YS> ECAMD_CHAIN_FN void ecamd_mad_chain(uint64_
 	}
 }
 #else
-template <int N, bool DUAL, bool YS> ECAMD_CHAIN_FN void ecamd_mad_chain(uint64_t &acc, uint64_t &acc2, const uint32_t *x, const uint32_t *y)
+template <int N, bool DUAL, bool YS, bool Z2 = false>
+ECAMD_CHAIN_FN void ecamd_mad_chain(uint64_t &acc, uint64_t &acc2, const uint32_t *x, const uint32_t *y)
 {
+	if (Z2 && DUAL && N > 1) {
+		acc2 = 0;
+	}
 	for (int i = 0; i < N; i++) {
 		if (DUAL && (i & 1)) {
 			acc2 += (uint64_t)x[i] * y[i];

@@ -173,9 +173,9 @@ template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
 #ifndef G29_DUAL_FROM_NL
 #define G29_DUAL_FROM_NL 12
 #endif
-template <int N, bool DUAL, bool YS> G29_FN void mad_chain(u64 &acc, u64 &acc2, const u32 *x, const u32 *y)
+template <int N, bool DUAL, bool YS, bool Z2 = false> G29_FN void mad_chain(u64 &acc, u64 &acc2, const u32 *x, const u32 *y)
 {
-	ecamd_mad_chain<N, DUAL, YS>(acc, acc2, x, y);
+	ecamd_mad_chain<N, DUAL, YS, Z2>(acc, acc2, x, y);
 }
 
 // secp521r1 flavour: p = -1 mod 2^29 so the quotient digit is the column's low 29 bits, and "+ m p"
@@ -194,6 +194,9 @@ template <int NL, bool SQR, int K_> struct Column {
 	static constexpr int RHI = (K_ < NL) ? (K_ - 1) : HI;
 	static constexpr int NRED = (RHI >= RLO) ? (RHI - RLO + 1) : 0;
 	static constexpr bool DUAL = NL >= G29_DUAL_FROM_NL;
+	// which chains touch the second accumulator (a chain of one product only uses the first)
+	static constexpr bool USES2_PROD = DUAL && NPROD >= 2;
+	static constexpr bool USES2_RED = DUAL && NRED >= 2;
 
 	static G29_FN void products(u64 &acc, u64 &acc2, const u32 *a, const u32 *b, const u32 *a2)
 	{
@@ -205,7 +208,7 @@ template <int NL, bool SQR, int K_> struct Column {
 				x[n] = a[i];
 				y[n] = !SQR ? b[j] : (i < j ? a2[j] : a[i]);
 			}
-			mad_chain<NPROD, DUAL, false>(acc, acc2, x, y);
+			mad_chain<NPROD, DUAL, false, true>(acc, acc2, x, y);   // acc2 starts here (zero addend), if it is used at all
 		}
 	}
 	static G29_FN void reduction(u64 &acc, u64 &acc2, const u32 *m, const u32 *p)
@@ -217,7 +220,7 @@ template <int NL, bool SQR, int K_> struct Column {
 				x[n] = m[RLO + n];
 				y[n] = p[K_ - (RLO + n)];
 			}
-			mad_chain<NRED, DUAL, true>(acc, acc2, x, y);
+			mad_chain<NRED, DUAL, true, !USES2_PROD>(acc, acc2, x, y);
 		}
 	}
 };
@@ -226,10 +229,10 @@ template <int NL, bool SQR, int K_> G29_FN void mul_column(u64 &acc, u32 *m, u32
 							   const u32 *a2, const u32 *p, u32 mpinv)
 {
 	typedef Column<NL, SQR, K_> C;
-	u64 acc2 = 0;
+	u64 acc2;  // written by the first chain that uses it (Z2), never read otherwise
 	C::products(acc, acc2, a, b, a2);
 	if constexpr (P25519) {
-		if (C::DUAL) {
+		if constexpr (C::USES2_PROD) {
 			acc += acc2;
 		}
 		t[K_] = (u32)acc & MASK;
@@ -242,7 +245,7 @@ template <int NL, bool SQR, int K_> G29_FN void mul_column(u64 &acc, u32 *m, u32
 #endif
 			mad_chain<1, false, true>(acc, acc2, &m[K_ - 17], &q17);
 		}
-		if (C::DUAL) {
+		if constexpr (C::USES2_PROD) {
 			acc += acc2;
 		}
 		if constexpr (K_ < NL) {
@@ -252,7 +255,7 @@ template <int NL, bool SQR, int K_> G29_FN void mul_column(u64 &acc, u32 *m, u32
 		}
 	} else {
 		C::reduction(acc, acc2, m, p);
-		if (C::DUAL) {
+		if constexpr (C::USES2_PROD || C::USES2_RED) {
 			acc += acc2;
 		}
 		if constexpr (K_ < NL) {
