@@ -590,9 +590,27 @@ static int upload_g29(ecamd_curve *cv)
 	return 0;
 }
 
+// device allocations of a curve handle (also used on the failure paths of its construction)
+static void curve_free_device(ecamd_curve *cv)
+{
+	if (cv->d_gen) {
+		(void)hipFree(cv->d_gen);
+		cv->d_gen = nullptr;
+	}
+	if (cv->d_comb) {
+		(void)hipFree(cv->d_comb);
+		cv->d_comb = nullptr;
+	}
+	if (cv->d_gtab) {
+		(void)hipFree(cv->d_gtab);
+		cv->d_gtab = nullptr;
+	}
+}
+
 static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 {
 	if (!(cv->p[0] & 1) || big_bitlen(cv->p) < 160) {
+		curve_free_device(cv);
 		delete cv;
 		return fail("curve: p must be odd and at least 160 bits");
 	}
@@ -600,11 +618,13 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	cv->qbits = big_bitlen(cv->q);
 	cv->nw = pick_nw(cv->pbits);
 	if (!cv->nw || !ecamd_nw_supported(cv->nw)) {
+		curve_free_device(cv);
 		delete cv;
 		return fail("curve: field size not supported (max 544 bits)");
 	}
 	if (big_cmp(cv->a, cv->p) >= 0 || big_cmp(cv->b, cv->p) >= 0 || big_cmp(cv->gx, cv->p) >= 0 ||
 	    big_cmp(cv->gy, cv->p) >= 0) {
+		curve_free_device(cv);
 		delete cv;
 		return fail("curve: a, b, gx, gy must be < p");
 	}
@@ -627,6 +647,7 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 		}
 	}
 	if (slot < 0) {
+		curve_free_device(cv);
 		delete cv;
 		return fail("curve: all constant-memory curve slots are in use (free a curve first)");
 	}
@@ -642,6 +663,7 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 		}
 	}
 	if (build_and_upload(cv)) {
+		curve_free_device(cv);
 		delete cv;
 		return -1;
 	}
@@ -658,7 +680,8 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 			}
 		}
 		if (cv->gslot >= 0 && upload_g29(cv)) {
-			delete cv;
+			curve_free_device(cv);
+		delete cv;
 			return -1;
 		}
 	}
@@ -667,6 +690,7 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	big_to_be(g.data() + cv->clen, cv->clen, cv->gy);
 	if (hipMalloc((void **)&cv->d_gen, g.size()) != hipSuccess ||
 	    hipMemcpy(cv->d_gen, g.data(), g.size(), hipMemcpyHostToDevice) != hipSuccess) {
+		curve_free_device(cv);
 		delete cv;
 		return fail("curve: generator upload failed");
 	}
@@ -687,7 +711,8 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 		uint8_t *d = nullptr;
 		if (hipMalloc((void **)&d, sizeof(sc) + sizeof(pts) + sizeof(st)) != hipSuccess ||
 		    hipMemcpy(d, sc, sizeof(sc), hipMemcpyHostToDevice) != hipSuccess) {
-			delete cv;
+			curve_free_device(cv);
+		delete cv;
 			return fail("curve: generator table allocation failed");
 		}
 		int rc = smul_dev_locked(ctx, cv, 8, d, 32, nullptr, d + sizeof(sc), d + sizeof(sc) + sizeof(pts), ctx->stream);
@@ -709,7 +734,8 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 		}
 		if (rc || hipMalloc((void **)&cv->d_gtab, tab.size() * 4) != hipSuccess ||
 		    hipMemcpy(cv->d_gtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-			delete cv;
+			curve_free_device(cv);
+		delete cv;
 			return fail("curve: generator table construction failed");
 		}
 		big_digits29(cv->qdig, 9, cv->q);
@@ -776,15 +802,7 @@ extern "C" void ecamd_curve_free(ecamd_curve *cv)
 	{
 		std::lock_guard<std::mutex> lk(cv->ctx->mu);
 		(void)hipSetDevice(cv->ctx->device);
-		if (cv->d_gen) {
-			(void)hipFree(cv->d_gen);
-		}
-		if (cv->d_comb) {
-			(void)hipFree(cv->d_comb);
-		}
-		if (cv->d_gtab) {
-			(void)hipFree(cv->d_gtab);
-		}
+		curve_free_device(cv);
 		cv->ctx->slot_used[cv->slot] = false;
 		if (cv->gslot >= 0) {
 			cv->ctx->gslot_used[cv->pbits + cv->gflavour][cv->gslot] = false;
