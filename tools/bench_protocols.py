@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-log2", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -179,6 +180,26 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and O.have_ref():
+        # the unmodified reference on this host, one thread, on a bounded sample of the same inputs
+        m = 1536 if a.workload != "x25519" else 3072
+        t0 = time.time()
+        if a.workload == "ecdsa_verify":
+            # ec_verify hashes the message itself: time it on messages of the digest's length (SHA-256 of 32 bytes
+            # is noise next to the two scalar multiplications); accept bits are not compared here
+            O.RefLib(curve).ecdsa_verify("SHA256", pubs[:64 * m], sigs[:64 * m], dg[:32 * m], 32)
+            what = "ec_pub_key_import_from_aff_buf + ec_verify (ECDSA, SHA-256 over 32-byte messages)"
+        elif a.workload == "ed25519_verify":
+            O.ref_ed25519_verify(pubs[:32 * m], sigs[:64 * m], hram[:64 * m], 64)
+            what = "eddsa_import_pub_key + ec_verify (EDDSA25519, SHA-512 over 64-byte messages)"
+        else:
+            O.ref_xdh(32, k2[:32 * m], pub[:32 * m])
+            what = "x25519()"
+        el = time.time() - t0
+        cpu = {"value": m / el, "unit": unit, "cores": 1, "kind": "reference",
+               "sample": f"first {m} items of the same batch through {what} of the unmodified reference (oracle/_ref), "
+                         f"1 thread, {el:.1f} s"}
     if rank == 0:
         print(json.dumps({
             "metric": metric, "value": B * world * a.steps / elapsed, "unit": unit, "n_gpus": world, "steps": a.steps,
@@ -189,7 +210,7 @@ def main():
             "config": {"workload": f"{a.workload} (BASELINE.json configs[{cfg}]), batch 2^{a.batch_log2} per GPU",
                        "sharding": "contiguous per-rank shards" + (", RCCL all_gather of result bytes per step" if world > 1 else ""),
                        "parity_gate": "all accept/reject bits as constructed; 128 random items identical to the CPU oracle"},
-            "setup_s": setup_s}))
+            "cpu_baseline": cpu, "setup_s": setup_s}))
     cv.free()
     ctx.close()
     if world > 1:
