@@ -973,3 +973,48 @@ def test_host_pipeline_multi_chunk(gpu_ctx):
             b.free()
     finally:
         ctx2.close()
+
+
+@pytest.mark.parametrize("env", ["ECAMD_NO_COMB", "ECAMD_NO_P25519", "ECAMD_NO_X25519_LADDER", "ECAMD_NO_EDWARDS_SMUL",
+                                 "ECAMD_NO_FAST_PATH"])
+def test_fallback_paths_stay_correct(env):
+    """every fast path has a switch that routes around it (A/B measurements, fallbacks): the slower routes
+    must give the same bytes -- fixed-base without the comb, WEI25519 on the dense field, X25519 and Ed25519
+    through the Weierstrass scalar multiplication, everything on the complete-formula kernel"""
+    import libecc_amd
+    from test_oracle import ed25519_cases, xdh_edge_inputs
+    rng = np.random.default_rng(39)
+    old = os.environ.get(env)
+    os.environ[env] = "1"
+    try:
+        ctx = libecc_amd.Context(0)
+        try:
+            cv = ctx.curve("WEI25519")
+            try:
+                pubs, sigs, msgs, hram = ed25519_cases(rng, nvalid=6)
+                assert cv.eddsa_verify(pubs, sigs, hram) == Oracle("WEI25519").eddsa_verify(pubs, sigs, hram)
+                ek, eu = xdh_edge_inputs(32, rng)
+                assert cv.xdh(ek, eu) == Oracle("WEI25519").xdh(ek, eu)
+            finally:
+                cv.free()
+            cv = ctx.curve("SECP256R1")
+            try:
+                o = Oracle("SECP256R1")
+                sc = rand_bytes(rng, 32 * 96)
+                pub = cv.scalar_mult(sc)
+                assert pub == o.scalar_mult(sc)
+                sc2 = rand_bytes(rng, 32 * 96)
+                assert cv.scalar_mult(sc2, pub[0]) == o.scalar_mult(sc2, pub[0])
+                _, pubs, sigs, dg, hl, _ = make_sigs("SECP256R1", "SHA256", 64, rng)
+                bad = bytearray(sigs)
+                bad[64 * 3 + 1] ^= 1
+                assert cv.ecdsa_verify(pubs, bytes(bad), dg, hl) == o.ecdsa_verify(pubs, bytes(bad), dg, hl)
+            finally:
+                cv.free()
+        finally:
+            ctx.close()
+    finally:
+        if old is None:
+            del os.environ[env]
+        else:
+            os.environ[env] = old
