@@ -82,7 +82,7 @@ def work_model(curve_params, nw, slen):
         if p == 2**255 - 19:                         # 2^255 - 19 flavour: 9 limbs, 9 + 1 fold MADs + 1 (x 19)
             nl = 9
             M, S = nl * nl + nl + 2, nl * (nl + 1) // 2 + nl + 2
-        am3 = curve_params["a"] == p - 3
+        am3 = curve_params["a"] == p - 3 or iso_to_am3(p, curve_params["a"])
         dbl = (4, 4) if am3 else (4, 6)
         add = (12, 4)
         nm = 2 + 2 + 4 * dbl[0] + 3 * add[0] + 7 + nwin * (4 * dbl[0] + add[0]) + 1   # import, table (+7 Y normalisations), loop, Z test
@@ -100,6 +100,17 @@ def work_model(curve_params, nw, slen):
     mm += 2 + 2                                          # X/Z, Y/Z, from Montgomery
     mads_per_mm = 2 * nw * nw + nw                       # FIPS Montgomery multiplication, 32-bit words
     return mm, mm * mads_per_mm, f"k_smul<{nw}>", mm * mads_per_mm
+
+
+def iso_to_am3(p, a):
+    """does ecamd_host.cpp:upload_g29 move the curve onto an isomorphic one with a = -3 (u^4 a = -3, p = 3 mod 4)?"""
+    if p % 4 != 3 or a == 0 or p == 2**255 - 19:
+        return False
+    t = (-3 * pow(a, p - 2, p)) % p
+    s1 = pow(t, (p + 1) // 4, p)
+    if s1 * s1 % p != t:
+        return False
+    return any(pow(c, (p + 1) // 4, p) ** 2 % p == c for c in (s1, p - s1))
 
 
 def ref_equiv_mads():

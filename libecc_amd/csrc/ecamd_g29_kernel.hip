@@ -175,8 +175,9 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_smul_g(Ecamd
 		}
 		ok = ok & (ynz != 0);
 	}
-	const FC r2 = constant<FC>(K.r2), onec = constant<FC>(K.one);
-	const auto xm = mul(xd, r2, K), ym = mul(yd, r2, K);  // Montgomery form, < 2p, exact digits
+	const FC onec = constant<FC>(K.one);
+	// Montgomery form (and onto the isomorphic a = -3 curve when there is one), < 2p, exact digits
+	const auto xm = mul(xd, constant<FC>(K.ix), K), ym = mul(yd, constant<FC>(K.iy), K);
 	{
 		// y^2 == (x^2 + a) x + b
 		const auto t = mulc(carry(add(sqr(xm, K), constant<FC>(K.a))), xm, K);
@@ -340,10 +341,9 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_build_g
 	u32 xw[NW], yw[NW];
 	load_be<NW>(pts + (size_t)i * 2 * clen, (int)clen, xw);
 	load_be<NW>(pts + (size_t)i * 2 * clen + clen, (int)clen, yw);
-	const FC r2 = constant<FC>(K.r2);
 	u32 buf[CENTW];
-	canonical_digits(buf, mul(from_words<PB, NW>(xw), r2, K), K);
-	canonical_digits(buf + NL, mul(from_words<PB, NW>(yw), r2, K), K);
+	canonical_digits(buf, mul(from_words<PB, NW>(xw), constant<FC>(K.ix), K), K);
+	canonical_digits(buf + NL, mul(from_words<PB, NW>(yw), constant<FC>(K.iy), K), K);
 #pragma unroll
 	for (int w = 2 * NL; w < CENTW; w++) {
 		buf[w] = 0;
@@ -473,11 +473,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_finalize_g(E
 		}
 	}
 	FM tinv = inv<PB>(c, K);
-	FC plain1;
-#pragma unroll
-	for (int w = 0; w < NL; w++) {
-		plain1.l[w] = (w == 0) ? 1u : 0u;
-	}
+	const FC ex = constant<FC>(K.ex), ey = constant<FC>(K.ey);  // out of the Montgomery domain (and back from the isomorphic curve)
 #pragma unroll 1
 	for (int j = FING_K - 1; j >= 0; j--) {
 		const u32 i = t + (u32)j * nthreads;
@@ -504,10 +500,10 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_finalize_g(E
 		const auto ay = mulc(P.Y, zi3, K);
 		u8 *out = A.out + (size_t)i * 2 * clen;
 		u32 dg[NL], ow[NW];
-		canonical_digits(dg, mul(ax, plain1, K), K);
+		canonical_digits(dg, mul(ax, ex, K), K);
 		to_words<NL, NW>(ow, dg);
 		store_be<NW>(out, clen, ow);
-		canonical_digits(dg, mul(ay, plain1, K), K);
+		canonical_digits(dg, mul(ay, ey, K), K);
 		to_words<NL, NW>(ow, dg);
 		store_be<NW>(out + clen, clen, ow);
 		A.status[i] = 0;
@@ -1419,7 +1415,7 @@ uint32_t ecamd_g29_table_words(int pbits, int flavour)
 uint32_t ecamd_g29_max_slen(int pbits) { return 4u * (uint32_t)((pbits + 31) / 32); }
 size_t ecamd_g29_image_bytes(int pbits, int flavour)
 {
-	return (size_t)((6 + g29::NBIAS) * g29::nl_for_flavour(pbits, flavour) + 4) * 4;
+	return (size_t)((10 + g29::NBIAS) * g29::nl_for_flavour(pbits, flavour) + 4) * 4;
 }
 
 // 'flavour' 1 selects the secp521r1 (p = 2^521 - 1) instantiation, 2 the p = 2^255 - 19 one

@@ -540,7 +540,7 @@ static Big big_shl(const Big &a, int e)
 	return big_mul(a, big_pow2(e));
 }
 
-// CurveG<NL> image of ecamd_u29g.cuh: p r2 one a b pm2 (NL digits each), 16 bias tables, mpinv pbits
+// CurveG<NL> image of ecamd_u29g.cuh: p r2 one a b pm2 (NL digits each), 16 bias tables, ix iy ex ey, mpinv pbits
 // a_is_m3 pad -- mirrored by tools/g29_consts.py, which the CPU tests use against Python integers
 static int upload_g29(ecamd_curve *cv)
 {
@@ -553,13 +553,51 @@ static int upload_g29(ecamd_curve *cv)
 	static const int sv[16] = {1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2};
 	const int topsh = pbits - 29 * (nl - 1);
 	const int off = (1 - topsh) > 0 ? (1 - topsh) : 0;
-	std::vector<uint32_t> img((size_t)(6 + 16) * nl + 4, 0);
+	// Isomorphism onto a curve with a = -3 (cheaper doubling): (x, y) -> (u^2 x, u^3 y) with u^4 a = -3, when such a u
+	// exists.  Tried for p = 3 mod 4, where square roots are one exponentiation and exactly one of +-s is a square
+	// (the brainpool r1 curves -- their t1 twins are these images --, two GOST 512-bit sets); ECAMD_NO_ISO disables it.
+	Big u(1, 1);
+	Big a_img = cv->a, b_img = cv->b;
+	if (cv->gflavour == 0 && (p[0] & 3u) == 3u && big_bitlen(cv->a) > 0 && big_cmp(big_add(cv->a, three), p) != 0 &&
+	    getenv("ECAMD_NO_ISO") == nullptr) {
+		Big e = big_add(p, Big(1, 1));  // (p + 1) / 4
+		Big q4(e.size(), 0);
+		for (size_t i = 0; i < e.size(); i++) {
+			q4[i] = (e[i] >> 2) | ((i + 1 < e.size()) ? (e[i + 1] << 30) : 0u);
+		}
+		big_trim(q4);
+		const Big t = big_mulmod(big_sub(p, three), big_powmod(cv->a, big_sub(p, two), p), p);  // -3 / a
+		Big s1 = big_powmod(t, q4, p);
+		if (big_cmp(big_mulmod(s1, s1, p), t) == 0) {
+			Big r = big_powmod(s1, q4, p);
+			if (big_cmp(big_mulmod(r, r, p), s1) != 0) {
+				s1 = big_sub(p, s1);
+				r = big_powmod(s1, q4, p);
+			}
+			if (big_cmp(big_mulmod(r, r, p), s1) == 0) {
+				u = r;
+				const Big u2 = big_mulmod(u, u, p), u4 = big_mulmod(u2, u2, p);
+				a_img = big_mulmod(cv->a, u4, p);
+				b_img = big_mulmod(cv->b, big_mulmod(u4, u2, p), p);
+				if (big_cmp(big_add(a_img, three), p) != 0) {
+					return fail("internal: isomorphism onto a = -3 failed");
+				}
+			}
+		}
+	}
+	const Big u2 = big_mulmod(u, u, p), u3 = big_mulmod(u2, u, p);
+	const Big RR = big_mulmod(R, R, p);
+	std::vector<uint32_t> img((size_t)(10 + 16) * nl + 4, 0);
 	big_digits29(&img[0 * nl], nl, p);
-	big_digits29(&img[1 * nl], nl, big_mulmod(R, R, p));
+	big_digits29(&img[1 * nl], nl, RR);
 	big_digits29(&img[2 * nl], nl, R);
-	big_digits29(&img[3 * nl], nl, big_mulmod(cv->a, R, p));
-	big_digits29(&img[4 * nl], nl, big_mulmod(cv->b, R, p));
+	big_digits29(&img[3 * nl], nl, big_mulmod(a_img, R, p));
+	big_digits29(&img[4 * nl], nl, big_mulmod(b_img, R, p));
 	big_digits29(&img[5 * nl], nl, big_sub(p, two));
+	big_digits29(&img[22 * nl], nl, big_mulmod(u2, RR, p));                             // ix
+	big_digits29(&img[23 * nl], nl, big_mulmod(u3, RR, p));                             // iy
+	big_digits29(&img[24 * nl], nl, big_powmod(u2, big_sub(p, two), p));                // ex = u^-2
+	big_digits29(&img[25 * nl], nl, big_powmod(u3, big_sub(p, two), p));                // ey = u^-3
 	for (int t = 0; t < 16; t++) {
 		uint32_t *l = &img[(size_t)(6 + t) * nl];
 		if (big_bitlen(p) + step[t] + off > 29 * (nl - 1) + 32) {
@@ -580,9 +618,9 @@ static int upload_g29(ecamd_curve *cv)
 	for (int i = 0; i < 5; i++) {
 		x *= 2u - p0 * x;
 	}
-	img[(size_t)22 * nl + 0] = (0u - x) & 0x1fffffffu;
-	img[(size_t)22 * nl + 1] = (uint32_t)pbits;
-	img[(size_t)22 * nl + 2] = (big_cmp(big_add(cv->a, three), p) == 0) ? 1u : 0u;
+	img[(size_t)26 * nl + 0] = (0u - x) & 0x1fffffffu;
+	img[(size_t)26 * nl + 1] = (uint32_t)pbits;
+	img[(size_t)26 * nl + 2] = (big_cmp(big_add(a_img, three), p) == 0) ? 1u : 0u;
 	if (img.size() * 4 != ecamd_g29_image_bytes(pbits, cv->gflavour)) {
 		return fail("internal: CurveG image size mismatch");
 	}

@@ -111,6 +111,11 @@ template <int NL> struct CurveG {
 	u32 b[NL];            // b R mod p
 	u32 pm2[NL];          // digits of p - 2 (inversion exponent)
 	u32 bias[NBIAS][NL];  // limbs of 2^LOGC p re-balanced so that low limbs >= 2^(29+S) - 2^S
+	// coordinate import / export factors.  Normally R^2, R^2 (into the Montgomery domain) and 1, 1 (out of it).
+	// When the curve is isomorphic to one with a = -3 ((x, y) -> (u^2 x, u^3 y), u^4 a = -3: the brainpool
+	// r1 curves, some GOST ones) the kernels compute on that curve (a, b above are a u^4 = -3 and b u^6) and the
+	// map rides on the conversions for free: ix = u^2 R^2, iy = u^3 R^2, ex = u^-2, ey = u^-3.
+	u32 ix[NL], iy[NL], ex[NL], ey[NL];
 	u32 mpinv;            // -p^-1 mod 2^29
 	u32 pbits;
 	u32 a_is_m3;

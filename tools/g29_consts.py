@@ -44,6 +44,8 @@ def image(p, a, b, flavour=0):
         assert l[-1] >= 0 and sum(v << (W * j) for j, v in enumerate(l)) == c
         assert all(v < 2**32 for v in l)
         out += l
+    # coordinate import / export factors (no isomorphism here: R^2, R^2, 1, 1)
+    out += digits(R * R % p, nl) * 2 + digits(1, nl) * 2
     mpinv = (-pow(p, -1, 1 << W)) % (1 << W)
     out += [mpinv, pbits, 1 if a == p - 3 else 0, 0]
     return out, nl
