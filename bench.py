@@ -83,7 +83,7 @@ def work_model(curve_params, nw, slen):
             nl = 9
             M, S = nl * nl + nl + 2, nl * (nl + 1) // 2 + nl + 2
         am3 = curve_params["a"] == p - 3 or iso_to_am3(p, curve_params["a"])
-        dbl = (4, 4) if am3 else (4, 6)
+        dbl = (3, 4) if curve_params["a"] == 0 else ((4, 4) if am3 else (4, 6))
         add = (12, 4)
         nm = 2 + 2 + 4 * dbl[0] + 3 * add[0] + 7 + nwin * (4 * dbl[0] + add[0]) + 1   # import, table (+7 Y normalisations), loop, Z test
         ns = 2 + 4 * dbl[1] + 3 * add[1] + nwin * (4 * dbl[1] + add[1])

@@ -621,6 +621,7 @@ static int upload_g29(ecamd_curve *cv)
 	img[(size_t)26 * nl + 0] = (0u - x) & 0x1fffffffu;
 	img[(size_t)26 * nl + 1] = (uint32_t)pbits;
 	img[(size_t)26 * nl + 2] = (big_cmp(big_add(a_img, three), p) == 0) ? 1u : 0u;
+	img[(size_t)26 * nl + 3] = (big_bitlen(a_img) == 0) ? 1u : 0u;
 	if (img.size() * 4 != ecamd_g29_image_bytes(pbits, cv->gflavour)) {
 		return fail("internal: CurveG image size mismatch");
 	}

@@ -1,6 +1,6 @@
 // libecc_amd/csrc/ecamd_jacg.cuh -- Jacobian group law over ecamd_u29g.cuh, any short-Weierstrass
 // curve y^2 = x^3 + a x + b (a = -3 shortcut and generic a), same structure as ecamd_p256.cuh.
-//   doubling  a = -3: 4M + 4S     generic a: 4M + 6S (M = 3 X^2 + a Z^4)
+//   doubling  a = -3: 4M + 4S     a = 0: 3M + 4S     generic a: 4M + 6S (M = 3 X^2 + a Z^4)
 //   addition 12M + 4S (add-1998-cmo-2)
 // Thanks to the headroom limb no value fold is needed; carry() is inserted where the
 // static_asserts of ecamd_u29g.cuh demand it.
@@ -36,13 +36,16 @@ template <int PB> G29_FN Jac<PB> dbl(const Jac<PB> &P, JG_K)
 	typedef typename Cls<PB>::FC FC;
 	const auto yy = sqrc(P.Y, K);
 	const auto s4 = mulc(P.X, mul_small<4>(yy), K);  // 4 X Y^2
-	const auto zz = sqrc(P.Z, K);
 	FA m;  // M = 3 X^2 + a Z^4
-	if (K.a_is_m3) {
+	if (K.a_is_zero) {
+		m = weaken<FA>(carry(mul_small<3>(sqrc(P.X, K))));                     // a = 0: 3 X^2 (3M + 4S in all)
+	} else if (K.a_is_m3) {
+		const auto zz = sqrc(P.Z, K);
 		const auto t1 = carry(sub_auto<1>(P.X, zz, K));
 		const auto t2 = carry(add(P.X, zz));
 		m = weaken<FA>(carry(mul_small<3>(mulc(t1, t2, K))));  // 3 (X - Z^2)(X + Z^2)
 	} else {
+		const auto zz = sqrc(P.Z, K);
 		const auto xx = sqrc(P.X, K);
 		const auto az4 = mulc(sqrc(zz, K), constant<FC>(K.a), K);
 		m = weaken<FA>(carry(add(mul_small<3>(xx), az4)));

@@ -119,7 +119,7 @@ template <int NL> struct CurveG {
 	u32 mpinv;            // -p^-1 mod 2^29
 	u32 pbits;
 	u32 a_is_m3;
-	u32 pad;
+	u32 a_is_zero;        // a == 0 (the secp k1 curves): the doubling drops its a Z^4 term
 };
 
 template <int PB, u64 LB_, u64 TB_, u64 VB_> struct E {

@@ -47,5 +47,5 @@ def image(p, a, b, flavour=0):
     # coordinate import / export factors (no isomorphism here: R^2, R^2, 1, 1)
     out += digits(R * R % p, nl) * 2 + digits(1, nl) * 2
     mpinv = (-pow(p, -1, 1 << W)) % (1 << W)
-    out += [mpinv, pbits, 1 if a == p - 3 else 0, 0]
+    out += [mpinv, pbits, 1 if a == p - 3 else 0, 1 if a == 0 else 0]
     return out, nl
