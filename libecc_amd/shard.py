@@ -35,22 +35,25 @@ class OverlappedGather:
     """One all-gather of equal-size output shards per step, overlapped with the next step's kernels.
 
     The collective is issued with async_op=True (on RCCL's own stream for GPU tensors; it starts once the work
-    already enqueued on the current stream has finished) and outputs are double-buffered, so a shard is never
-    overwritten while it is still being gathered:
+    already enqueued on the current stream has finished).  Shards AND gathered outputs are double-buffered, so
+    a shard is never overwritten while it is still being gathered and two gathers in flight never write the
+    same tensor (backends such as gloo may complete them out of order):
 
         buf = og.next_buffer()     # waits (stream-level, not a host block) for the gather that last read buf
         ... enqueue the kernels that fill buf ...
-        og.submit(buf)             # async all_gather_into_tensor(gathered, buf)
+        og.submit(buf)             # async all_gather_into_tensor(<next gathered buffer>, buf)
         ...
-        og.drain()                 # before reading `gathered` / closing a timed region
+        og.drain()                 # before reading og.gathered (the latest step's result) / closing a timed region
 
     With world == 1 there is one buffer and no collective."""
 
     def __init__(self, world, shard_numel, device, group=None):
         self.world = world
         self.group = group
-        self.bufs = [torch.empty(shard_numel, dtype=torch.uint8, device=device) for _ in range(2 if world > 1 else 1)]
-        self.gathered = torch.empty(world * shard_numel, dtype=torch.uint8, device=device) if world > 1 else None
+        nb = 2 if world > 1 else 1
+        self.bufs = [torch.empty(shard_numel, dtype=torch.uint8, device=device) for _ in range(nb)]
+        self.gbufs = [torch.empty(world * shard_numel, dtype=torch.uint8, device=device) for _ in range(nb)] if world > 1 else []
+        self.gathered = None       # result of the most recently submitted step, valid after drain()
         self.pending = []
         self.k = 0
 
@@ -63,7 +66,9 @@ class OverlappedGather:
 
     def submit(self, buf):
         if self.world > 1:
-            self.pending.append(dist.all_gather_into_tensor(self.gathered, buf, group=self.group, async_op=True))
+            g = self.gbufs[(self.k - 1) % len(self.gbufs)]
+            self.pending.append(dist.all_gather_into_tensor(g, buf, group=self.group, async_op=True))
+            self.gathered = g
 
     def drain(self):
         while self.pending:
