@@ -1325,3 +1325,191 @@ int orc_prj_batch(const orc_curve *c, uint32_t n, const uint8_t *scalars, uint32
 	}
 	return 0;
 }
+
+/* ------------------------------------------------------------------------------------
+ * Ed448 verification on the Weierstrass model WEI448 (sig/eddsa.c), hash supplied by the caller.
+ *   eddsa_decode_point, EDDSA448 branch (:424-556): y little-endian (57 bytes, bit 455 = sign of x), y >= p
+ *     rejected, x from y on Ed448 itself (a = 1, d = -39081: x^2 = (1 - y^2) / (1 - d y^2), root with the sign's
+ *     parity, x = 0 with sign 1 rejected), then the 4-isogeny to the Edwards model of curve448:
+ *       x' = alpha x y / (2 - x^2 - y^2),  y' = (x^2 + y^2) / (y^2 - x^2)       (fp_inv(0) -> error)
+ *     and aff_pt_edwards_init_from_coords (on-curve check on that model: a = 1, d' = (A + 2) / alpha^2);
+ *   aff_pt_edwards_to_montgomery / aff_pt_montgomery_to_shortw as for Ed25519 (A = 156326, B = 1);
+ *   eddsa_import_pub_key (:925-937): the key is multiplied by 4^-1 mod q (prj_pt_mul);
+ *   _eddsa_verify_init: S < q, [cofactor]A != infinity;  _eddsa_verify_finalize: h = hash mod q, then 4 h mod q
+ *     (:2226-2229), [S]G - R - [h]A, times the cofactor, must be infinity.
+ * alpha_edwards (alpha^2 = A - 2) comes from the curve parameters in the reference; here its sign is fixed by
+ * requiring that the Ed448 base point maps to the generator.
+ * ---------------------------------------------------------------------------------- */
+typedef struct { u64 d448[ORC_MAXW], diso[ORC_MAXW], alpha[ORC_MAXW], A3[ORC_MAXW]; } ed448_consts;
+
+static int ed448_decode_to_shortw(pt *out, const u8 *enc, const orc_curve *c, const ed448_consts *k)
+{
+	const orc_fp_ctx *f = &c->fp;
+	const int n = f->n;
+	u64 y[ORC_MAXW], one[ORC_MAXW], two[ORC_MAXW], zero[ORC_MAXW], x1[ORC_MAXW], x2[ORC_MAXW], t[ORC_MAXW], s1[ORC_MAXW],
+	    s2[ORC_MAXW], x[ORC_MAXW], xx[ORC_MAXW], yy[ORC_MAXW], X[ORC_MAXW], Y[ORC_MAXW], u[ORC_MAXW], v[ORC_MAXW];
+	u8 be[57];
+	const int x0 = enc[56] >> 7;
+	int b;
+	for (b = 0; b < 57; b++) be[b] = enc[56 - b];
+	be[0] &= 0x7f;
+	if (fp_from_be(y, be, 57, f)) return -1;
+	nn_zero(one, n); one[0] = 1;
+	nn_zero(two, n); two[0] = 2;
+	nn_zero(zero, n);
+	fp_mul(yy, y, y, f);
+	fp_sub(x1, one, yy, f);
+	fp_mul(x2, yy, k->d448, f);
+	fp_sub(x2, one, x2, f);                       /* a - d y^2, a = 1 */
+	if (nn_iszero(x2, n)) return -1;
+	fp_pow_pm2(x2, x2, f);
+	fp_mul(t, x1, x2, f);
+	if (nn_iszero(t, n)) nn_zero(s1, n);
+	else if (fp_sqrt_exp(s1, t, f)) return -1;
+	fp_sub(s2, zero, s1, f);
+	nn_copy(x, ((int)(s1[0] & 1) == x0) ? s1 : s2, n);
+	if (nn_iszero(x, n) && x0 == 1) return -1;
+	/* 4-isogeny */
+	fp_mul(xx, x, x, f);
+	fp_sub(t, two, xx, f);
+	fp_sub(t, t, yy, f);                          /* 2 - x^2 - y^2 */
+	if (nn_iszero(t, n)) return -1;
+	fp_pow_pm2(t, t, f);
+	fp_mul(X, t, x, f);
+	fp_mul(X, X, y, f);
+	fp_mul(X, X, k->alpha, f);
+	fp_sub(t, yy, xx, f);                         /* y^2 - x^2 */
+	if (nn_iszero(t, n)) return -1;
+	fp_pow_pm2(t, t, f);
+	fp_add(Y, xx, yy, f);
+	fp_mul(Y, Y, t, f);
+	{   /* on the Edwards model of curve448: x^2 + y^2 = 1 + d' x^2 y^2 */
+		u64 l[ORC_MAXW], r[ORC_MAXW], X2[ORC_MAXW], Y2[ORC_MAXW];
+		fp_mul(X2, X, X, f);
+		fp_mul(Y2, Y, Y, f);
+		fp_add(l, X2, Y2, f);
+		fp_mul(r, X2, Y2, f);
+		fp_mul(r, r, k->diso, f);
+		fp_add(r, r, one, f);
+		if (nn_cmp(l, r, n) != 0) return -1;
+	}
+	/* Edwards -> Montgomery -> Weierstrass */
+	if (nn_iszero(X, n)) return -1;               /* (0, 1) rejected; (0, -1): fp_inv(x) fails */
+	fp_sub(t, one, Y, f);
+	if (nn_iszero(t, n)) return -1;
+	fp_pow_pm2(t, t, f);
+	fp_add(u, one, Y, f);
+	fp_mul(u, t, u, f);
+	fp_pow_pm2(v, X, f);
+	fp_mul(v, v, k->alpha, f);
+	fp_mul(v, u, v, f);
+	/* libecc's Montgomery model of WEI448 is (A, B) = (-156326, -1) (u = -u_RFC7748): x = u / B + A / (3 B), y = v / B */
+	fp_sub(out->X, k->A3, u, f);
+	fp_sub(out->Y, zero, v, f);
+	nn_zero(out->Z, n); out->Z[0] = 1;
+	return pt_is_on_curve(out, c) ? 0 : -1;
+}
+
+static const u8 ed448_base_enc[57] = {
+	0x14, 0xfa, 0x30, 0xf2, 0x5b, 0x79, 0x08, 0x98, 0xad, 0xc8, 0xd7, 0x4e, 0x2c, 0x13, 0xbd, 0xfd, 0xc4, 0x39, 0x7c, 0xe6,
+	0x1c, 0xff, 0xd3, 0x3a, 0xd7, 0xc2, 0xa0, 0x05, 0x1e, 0x9c, 0x78, 0x87, 0x40, 0x98, 0xa3, 0x6c, 0x73, 0x73, 0xea, 0x4b,
+	0x62, 0xc7, 0xc9, 0x56, 0x37, 0x20, 0x76, 0x88, 0x24, 0xbc, 0xb6, 0x6e, 0x71, 0x46, 0x3f, 0x69, 0x00
+};
+
+static int ed448_consts_init(ed448_consts *k, const orc_curve *c)
+{
+	const orc_fp_ctx *f = &c->fp;
+	const int n = f->n;
+	u64 t[ORC_MAXW], t2[ORC_MAXW], zero[ORC_MAXW];
+	pt B, G4;
+	nn_zero(zero, n);
+	nn_zero(t, n); t[0] = 39081;
+	fp_sub(k->d448, zero, t, f);
+	nn_zero(t, n); t[0] = 3;
+	fp_pow_pm2(t, t, f);
+	nn_zero(t2, n); t2[0] = 156326;
+	fp_mul(k->A3, t, t2, f);
+	nn_zero(t, n); t[0] = 156324;                /* alpha^2 = A - 2 */
+	if (fp_sqrt_exp(k->alpha, t, f)) return -1;
+	fp_pow_pm2(t, t, f);
+	nn_zero(t2, n); t2[0] = 156328;
+	fp_mul(k->diso, t, t2, f);                   /* d' = (A + 2) / alpha^2 */
+	load_gen(&G4, c);                            /* the Ed448 base point maps to the generator itself */
+	if (ed448_decode_to_shortw(&B, ed448_base_enc, c, k)) return -1;
+	if (nn_cmp(B.Y, G4.Y, n) != 0) {
+		fp_sub(k->alpha, zero, k->alpha, f);
+		if (ed448_decode_to_shortw(&B, ed448_base_enc, c, k)) return -1;
+	}
+	return (nn_cmp(B.X, G4.X, n) == 0 && nn_cmp(B.Y, G4.Y, n) == 0) ? 0 : -1;
+}
+
+/* pubs n x 57, sigs n x 114 (R || S), hram n x hlen (hlen <= 114) = SHAKE256(dom4 || R || A || PH(M), 114);
+ * result 0 accept / 1 reject */
+int orc_eddsa448_verify_batch(const orc_curve *c, uint32_t n, const uint8_t *pubs, const uint8_t *sigs,
+			      const uint8_t *hram, uint32_t hlen, uint8_t *result)
+{
+	const orc_fp_ctx *f = &c->fp;
+	ed448_consts k;
+	u64 cof[ORC_MAXW], c4[ORC_MAXW], t2[2 * ORC_MAXW], zero[ORC_MAXW];
+	pt G;
+	uint32_t i;
+	int j;
+	if (f->pbits != 448 || hlen > 114 || ed448_consts_init(&k, c)) return -1;
+	nn_zero(cof, ORC_MAXW); cof[0] = 4;
+	nn_mul(t2, c->q, c->q_n, cof, 1);
+	if (nn_cmp(t2, c->order, c->q_n + 1) != 0) return -1;
+	/* 4^-1 mod q = (j q + 1) / 4 for the j in 1..3 that makes it an integer */
+	for (j = 1; j <= 3; j++) {
+		u64 jq[ORC_MAXW + 1], m[ORC_MAXW], one[ORC_MAXW];
+		int w;
+		nn_zero(m, ORC_MAXW); m[0] = (u64)j;
+		nn_zero(jq, ORC_MAXW + 1);
+		nn_mul(jq, c->q, c->q_n, m, 1);
+		nn_zero(one, ORC_MAXW); one[0] = 1;
+		nn_add(jq, jq, one, c->q_n + 1);
+		if ((jq[0] & 3) == 0) {
+			for (w = 0; w < c->q_n; w++) c4[w] = (jq[w] >> 2) | (jq[w + 1] << 62);
+			break;
+		}
+	}
+	if (j > 3) return -1;
+	nn_zero(zero, f->n);
+	load_gen(&G, c);
+	for (i = 0; i < n; i++) {
+		pt A, R, T1, T2;
+		u64 S[ORC_MAXW], h[ORC_MAXW], hw[ORC_MAXW];
+		u8 be[114];
+		uint32_t b;
+		result[i] = 1;
+		if (ed448_decode_to_shortw(&A, pubs + (size_t)i * 57, c, &k)) continue;
+		if (pt_mul(&A, c4, c->q_n, &A, c)) continue;                 /* eddsa_import_pub_key: times 4^-1 mod q */
+		if (ed448_decode_to_shortw(&R, sigs + (size_t)i * 114, c, &k)) continue;
+		for (b = 0; b < 57; b++) be[b] = sigs[(size_t)i * 114 + 113 - b];
+		nn_zero(S, ORC_MAXW);
+		if (nn_from_be(S, 8, be, 57)) continue;
+		if (nn_cmp(S, c->q, 8) >= 0) continue;
+		if (pt_unprotected_mult(&T1, cof, 1, &A, c)) continue;
+		if (nn_iszero(T1.Z, f->n)) continue;
+		for (b = 0; b < hlen; b++) be[b] = hram[(size_t)i * hlen + hlen - 1 - b];
+		nn_zero(hw, ORC_MAXW);
+		nn_from_be(hw, 15, be, (int)hlen);
+		nn_zero(h, ORC_MAXW);
+		nn_mod(h, hw, 15, c->q, c->q_n);
+		{   /* h <- 4 h mod q */
+			u64 h4[ORC_MAXW + 1];
+			nn_zero(h4, ORC_MAXW + 1);
+			nn_mul(h4, h, c->q_n, cof, 1);
+			nn_zero(h, ORC_MAXW);
+			nn_mod(h, h4, c->q_n + 1, c->q, c->q_n);
+		}
+		if (pt_mul(&T1, S, c->q_n, &G, c)) continue;
+		fp_sub(R.Y, zero, R.Y, f);
+		if (pt_add(&T1, &T1, &R, c)) continue;
+		if (pt_mul(&T2, h, c->q_n, &A, c)) continue;
+		fp_sub(T2.Y, zero, T2.Y, f);
+		if (pt_add(&T1, &T1, &T2, c)) continue;
+		if (pt_unprotected_mult(&T2, cof, 1, &T1, c)) continue;
+		result[i] = nn_iszero(T2.Z, f->n) ? 0 : 1;
+	}
+	return 0;
+}

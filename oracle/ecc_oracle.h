@@ -55,4 +55,6 @@ int orc_eddsa25519_verify_batch(const orc_curve *c, uint32_t n, const uint8_t *p
 				const uint8_t *hram, uint32_t hlen, uint8_t *result);
 int orc_prj_batch(const orc_curve *c, uint32_t n, const uint8_t *scalars, uint32_t slen, const uint8_t *points,
 		  uint8_t *out, uint8_t *status);
+int orc_eddsa448_verify_batch(const orc_curve *c, uint32_t n, const uint8_t *pubs, const uint8_t *sigs,
+			      const uint8_t *hram, uint32_t hlen, uint8_t *result);
 #endif

@@ -582,3 +582,54 @@ int refdrv_prj_batch(const char *curve, uint32_t n, const uint8_t *scalars, uint
 	}
 	return 0;
 }
+
+/* ---- Ed448 through the protocol API (sig/eddsa.c); keys from 57-byte seeds, pubs n x 57, sigs n x 114 ---- */
+int refdrv_eddsa448_sign_batch(uint32_t n, const uint8_t *seeds, const uint8_t *msgs, uint32_t msg_len,
+			       uint8_t *pubs, uint8_t *sigs, uint8_t *status)
+{
+	ec_params params;
+	uint32_t i;
+	if (load_params("WEI448", &params)) {
+		return -1;
+	}
+	for (i = 0; i < n; i++) {
+		ec_key_pair kp;
+		int ret;
+		status[i] = 1;
+		ret = eddsa_import_key_pair_from_priv_key_buf(&kp, seeds + (size_t)i * 57, 57, &params, EDDSA448);
+		if (ret) {
+			continue;
+		}
+		ret = eddsa_export_pub_key(&kp.pub_key, pubs + (size_t)i * 57, 57);
+		if (ret) {
+			continue;
+		}
+		ret = ec_sign(sigs + (size_t)i * 114, 114, &kp, msgs + (size_t)i * msg_len, msg_len, EDDSA448,
+			      SHAKE256, NULL, 0);
+		status[i] = ret ? 1 : 0;
+	}
+	return 0;
+}
+
+int refdrv_eddsa448_verify_batch(uint32_t n, const uint8_t *pubs, const uint8_t *sigs, const uint8_t *msgs,
+				 uint32_t msg_len, uint8_t *result)
+{
+	ec_params params;
+	uint32_t i;
+	if (load_params("WEI448", &params)) {
+		return -1;
+	}
+	for (i = 0; i < n; i++) {
+		ec_pub_key pub;
+		int ret;
+		result[i] = 1;
+		ret = eddsa_import_pub_key(&pub, pubs + (size_t)i * 57, 57, &params, EDDSA448);
+		if (ret) {
+			continue;
+		}
+		ret = ec_verify(sigs + (size_t)i * 114, 114, &pub, msgs + (size_t)i * msg_len, msg_len, EDDSA448,
+				SHAKE256, NULL, 0);
+		result[i] = ret ? 1 : 0;
+	}
+	return 0;
+}

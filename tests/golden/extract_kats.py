@@ -11,7 +11,8 @@ Sources (data only -- byte arrays and the record fields that bind them):
   src/tests/ec_self_tests_core.h    fixed-k ECDSA (RFC 4754 style nonce callbacks), record :22-52
   src/tests/x25519_test_vectors.h, x448_test_vectors.h   RFC 7748 vectors
   src/tests/ed25519ctx_test_vectors.h, ed25519ph_test_vectors.h   RFC 8032 vectors
-Writes tests/golden/ecccdh_kats.json, ecdsa_kats.json, xdh_kats.json and eddsa_kats.json.
+  src/tests/ed448_test_vectors.h, ed448ph_test_vectors.h   RFC 8032 vectors
+Writes tests/golden/ecccdh_kats.json, ecdsa_kats.json, xdh_kats.json, eddsa_kats.json and eddsa448_kats.json.
 """
 import json, os, re, sys
 
@@ -136,6 +137,24 @@ def main():
                               pub_key=pub.raw.hex(), msg=msgb.hex(),
                               adata=(arrays[ad].hex() if ad != "NULL" else ""),
                               exp_sig=arrays[f["exp_sig"]].hex(), source=fn))
+    # RFC 8032 Ed448 / Ed448ph vectors; public keys exported by the reference as above
+    eddsa448 = []
+    for fn in ("ed448_test_vectors.h", "ed448ph_test_vectors.h"):
+        arrays, nonces, cases = load(os.path.join(REF, fn))
+        for kind, name, f in cases:
+            if kind != "ec_test_case" or f.get("sig_type") not in ("EDDSA448", "EDDSA448PH"):
+                continue
+            msgb = c_string(f["msg"]) if f["msg"].startswith('"') else arrays[re.sub(r"^\(const char \*\)\s*", "", f["msg"])]
+            seed = arrays[f["priv_key"]]
+            ad = f.get("adata", "NULL")
+            pub, sig, st = ctypes.create_string_buffer(57), ctypes.create_string_buffer(114), ctypes.create_string_buffer(1)
+            assert ref.refdrv_eddsa448_sign_batch(1, seed, b"", 0, pub, sig, st) == 0 and st.raw == b"\0"
+            eddsa448.append(dict(name=c_string(f["name"]).decode(), sig_type=f["sig_type"], priv_key=seed.hex(),
+                                 pub_key=pub.raw.hex(), msg=msgb.hex(),
+                                 adata=(arrays[ad].hex() if ad != "NULL" else ""),
+                                 exp_sig=arrays[f["exp_sig"]].hex(), source=fn))
+    json.dump(eddsa448, open(os.path.join(HERE, "eddsa448_kats.json"), "w"), indent=1)
+    print("EDDSA448:", [(c["sig_type"], c["name"]) for c in eddsa448])
     json.dump(eddsa, open(os.path.join(HERE, "eddsa_kats.json"), "w"), indent=1)
     print("EDDSA :", [(c["sig_type"], c["name"]) for c in eddsa])
     json.dump(xdh, open(os.path.join(HERE, "xdh_kats.json"), "w"), indent=1)

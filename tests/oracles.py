@@ -128,11 +128,17 @@ class Oracle:
         assert self.L.orc_prj_batch(self.ctx, n, scalars, slen, points, out, st) == 0
         return out.raw[:3 * self.clen * n], st.raw[:n]
 
-    def eddsa_verify(self, pubs, sigs, hram, hlen=64):
-        """Ed25519 on the WEI25519 curve; hram = SHA-512(dom2 || R || A || PH(M)) per item"""
+    def eddsa_verify(self, pubs, sigs, hram, hlen=None):
+        """Ed25519 on WEI25519 (hram = SHA-512(dom2 || R || A || PH(M)), 64 bytes) or Ed448 on WEI448
+        (hram = SHAKE256(dom4 || R || A || PH(M), 114)), one hash per item"""
+        if self.curve == "WEI448":
+            n = len(pubs) // 57
+            res = C.create_string_buffer(max(1, n))
+            assert self.L.orc_eddsa448_verify_batch(self.ctx, n, pubs, sigs, hram, hlen or 114, res) == 0
+            return res.raw[:n]
         n = len(pubs) // 32
         res = C.create_string_buffer(max(1, n))
-        assert self.L.orc_eddsa25519_verify_batch(self.ctx, n, pubs, sigs, hram, hlen, res) == 0
+        assert self.L.orc_eddsa25519_verify_batch(self.ctx, n, pubs, sigs, hram, hlen or 64, res) == 0
         return res.raw[:n]
 
 
@@ -414,3 +420,106 @@ def ed25519_sign(seed, msg, dom=b"", prehash=False, add_R=None, add_A=None):
     hram = hashlib.sha512(dom + Renc + Aenc + m).digest()
     S = (r + int.from_bytes(hram, "little") * a) % ED_Q
     return Aenc, Renc + S.to_bytes(32, "little"), hram
+
+
+# ---- a small RFC 8032 Ed448 signer (test input generator; python ints, projective coordinates) ----
+E4_P = 2**448 - 2**224 - 1
+E4_Q = 2**446 - 13818066809895115352007386748515426880336692474882178609894547503885
+E4_D = (-39081) % E4_P
+
+
+def e4_add(P, Q):
+    # add-2008-bbjlp, a = 1
+    x1, y1, z1 = P
+    x2, y2, z2 = Q
+    a = z1 * z2 % E4_P
+    b = a * a % E4_P
+    c = x1 * x2 % E4_P
+    d = y1 * y2 % E4_P
+    e = E4_D * c * d % E4_P
+    f, g = (b - e) % E4_P, (b + e) % E4_P
+    x3 = a * f * ((x1 + y1) * (x2 + y2) - c - d) % E4_P
+    y3 = a * g * (d - c) % E4_P
+    return (x3, y3, f * g % E4_P)
+
+
+def e4_mul(k, P):
+    R = (0, 1, 1)
+    while k:
+        if k & 1:
+            R = e4_add(R, P)
+        P = e4_add(P, P)
+        k >>= 1
+    return R
+
+
+def e4_encode(P):
+    zi = pow(P[2], E4_P - 2, E4_P)
+    x, y = P[0] * zi % E4_P, P[1] * zi % E4_P
+    return (y | ((x & 1) << 455)).to_bytes(57, "little")
+
+
+def e4_decode(b):
+    y = int.from_bytes(b, "little")
+    sign, y = y >> 455, y & ((1 << 455) - 1)
+    if y >= E4_P:
+        return None
+    u, v = (y * y - 1) % E4_P, (E4_D * y * y - 1) % E4_P
+    x2 = u * pow(v, E4_P - 2, E4_P) % E4_P
+    x = pow(x2, (E4_P + 1) // 4, E4_P)
+    if (x * x - x2) % E4_P or (x == 0 and sign):
+        return None
+    if (x & 1) != sign:
+        x = E4_P - x
+    return (x, y, 1)
+
+
+E4_B = e4_decode(bytes.fromhex("14fa30f25b790898adc8d74e2c13bdfdc4397ce61cffd33ad7c2a0051e9c78874098a36c7373ea4b"
+                               "62c7c9563720768824bcb66e71463f6900"))
+
+
+def ed_dom4(flag, ctx):
+    return b"SigEd448" + bytes([flag, len(ctx)]) + ctx
+
+
+def ed448_sign(seed, msg, ctx=b"", prehash=False, add_R=None, add_A=None):
+    """RFC 8032 5.2.6; add_R / add_A shift R or the public key by a torsion point.  Returns (A, R || S, hram)
+    with hram = SHAKE256(dom4 || R || A || PH(M), 114)."""
+    def H(x):
+        return hashlib.shake_256(x).digest(114)
+    hk = H(seed)
+    ab = bytearray(hk[:57])
+    ab[0] &= 0xFC
+    ab[55] |= 0x80
+    ab[56] = 0
+    a = int.from_bytes(ab, "little")
+    m = hashlib.shake_256(msg).digest(64) if prehash else msg
+    dom = ed_dom4(1 if prehash else 0, ctx)
+    A = e4_mul(a, E4_B)
+    if add_A is not None:
+        A = e4_add(A, add_A)
+    Aenc = e4_encode(A)
+    r = int.from_bytes(H(dom + hk[57:] + m), "little") % E4_Q
+    R = e4_mul(r, E4_B)
+    if add_R is not None:
+        R = e4_add(R, add_R)
+    Renc = e4_encode(R)
+    hram = H(dom + Renc + Aenc + m)
+    S = (r + int.from_bytes(hram, "little") * a) % E4_Q
+    return Aenc, Renc + S.to_bytes(57, "little"), hram
+
+
+def ref_ed448_sign(seeds, msgs, msg_len):
+    L = C.CDLL(REF_SO)
+    n = len(seeds) // 57
+    pubs, sigs, st = C.create_string_buffer(57 * n), C.create_string_buffer(114 * n), C.create_string_buffer(n)
+    assert L.refdrv_eddsa448_sign_batch(n, seeds, msgs, msg_len, pubs, sigs, st) == 0
+    return pubs.raw, sigs.raw, st.raw
+
+
+def ref_ed448_verify(pubs, sigs, msgs, msg_len):
+    L = C.CDLL(REF_SO)
+    n = len(pubs) // 57
+    res = C.create_string_buffer(max(1, n))
+    assert L.refdrv_eddsa448_verify_batch(n, pubs, sigs, msgs, msg_len, res) == 0
+    return res.raw[:n]
