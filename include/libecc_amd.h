@@ -147,13 +147,17 @@ int ec_ecccdh_derive_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n,
 int ec_xdh_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *k, const uint8_t *u,
 		 uint8_t *out, uint8_t *status);
 
-/* Ed25519 verification, batch form of eddsa_import_pub_key (sig/eddsa.c:862) + ec_verify for
- * EDDSA25519 / EDDSA25519CTX / EDDSA25519PH (_eddsa_verify_init :1846, _eddsa_verify_finalize :2130);
- * curve must be WEI25519, the Weierstrass model libecc itself computes on.  pubkeys: n x 32 (RFC 8032
- * encoding of A), sigs: n x 64 (R || S), hram: n x 64 = SHA-512(dom2 || R || A || PH(M)) computed by
- * the caller (the three variants differ only in that hash input).  result[i] = 0 accept / 1 where the
- * reference returns -1: non-canonical or undecodable A or R, the neutral point, S >= q, [8]A = infinity,
- * or [8]([S]G - R - [h]A) != infinity (libecc checks the cofactored equation). */
+/* EdDSA verification, batch form of eddsa_import_pub_key (sig/eddsa.c:862) + ec_verify (_eddsa_verify_init :1846,
+ * _eddsa_verify_finalize :2130), on the Weierstrass models libecc itself computes on:
+ *   curve = WEI25519: EDDSA25519 / EDDSA25519CTX / EDDSA25519PH.  pubkeys n x 32 (RFC 8032 encoding of A), sigs n x 64
+ *     (R || S), hram n x 64 = SHA-512(dom2 || R || A || PH(M)), hram_len = 64;
+ *   curve = WEI448:   EDDSA448 / EDDSA448PH.  pubkeys n x 57, sigs n x 114, hram n x 114 =
+ *     SHAKE256(dom4 || R || A || PH(M), 114), hram_len = 114.
+ * The hash is computed by the caller (the variants differ only in that hash input).  Note for Ed448: libecc stores
+ * [4^-1 mod q]A and hashes the key RE-ENCODED from it, which differs from the given bytes when A has a torsion
+ * component; hash those bytes to reproduce it (for keys in the prime-order subgroup they are the key itself).
+ * result[i] = 0 accept / 1 where the reference returns -1: non-canonical or undecodable A or R, the neutral point,
+ * S >= q, [cofactor]A = infinity, or [cofactor]([S]G - R - [h]A) != infinity (libecc checks the cofactored equation). */
 int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *pubkeys,
 			  const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, uint8_t *result);
 

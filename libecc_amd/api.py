@@ -207,9 +207,12 @@ class Curve:
         _chk(self.L, self.L.ec_xdh_batch(self.ctx.h, self.h, n, k, u, out, st), "ec_xdh_batch")
         return out.raw[:self.clen * n], st.raw[:n]
 
-    def eddsa_verify(self, pubkeys, sigs, hram, hram_len=64):
-        """Ed25519 (WEI25519 handle): 32-byte keys, 64-byte signatures, hram = SHA-512(dom2 || R || A || PH(M))"""
-        n = len(pubkeys) // self.clen
+    def eddsa_verify(self, pubkeys, sigs, hram, hram_len=None):
+        """Ed25519 (WEI25519 handle): 32-byte keys, 64-byte signatures, hram = SHA-512(dom2 || R || A || PH(M));
+        Ed448 (WEI448 handle): 57-byte keys, 114-byte signatures, hram = SHAKE256(dom4 || R || A || PH(M), 114)"""
+        klen = 57 if self.clen == 56 else self.clen
+        hram_len = hram_len or (114 if self.clen == 56 else 64)
+        n = len(pubkeys) // klen
         res = C.create_string_buffer(max(1, n))
         _chk(self.L, self.L.ec_eddsa_verify_batch(self.ctx.h, self.h, n, pubkeys, sigs, hram, hram_len, res),
              "ec_eddsa_verify_batch")

@@ -247,6 +247,10 @@ struct ecamd_curve {
 	const char *ed_err;
 	EcamdEdDecodeArgs ed_tmpl;
 	uint32_t ed_cof_dbl;
+	int ed448_state;     // Ed448 on the WEI448 handle: 0 not yet, 1 ready, -1 not that curve
+	const char *ed448_err;
+	EcamdEd448DecodeArgs ed448_tmpl;
+	uint8_t ed448_c4[56]; // 4^-1 mod q, big-endian (eddsa_import_pub_key multiplies the key by it)
 	uint32_t ed_2d[9];   // 2 d mod p, plain radix-2^29 digits (Edwards arithmetic of the 2^255 - 19 unit)
 	int xdh_state;
 	const char *xdh_err;
@@ -737,6 +741,8 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	cv->d_comb = nullptr;
 	cv->comb_off = false;
 	cv->ed_state = 0;
+	cv->ed448_state = 0;
+	cv->ed448_err = nullptr;
 	cv->xdh_state = 0;
 	cv->ed_err = cv->xdh_err = nullptr;
 	if (cv->is_p256) {
@@ -2019,6 +2025,173 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 	return 0;
 }
 
+// ---- Ed448 (EDDSA448 branches of sig/eddsa.c) on the WEI448 handle ----
+static Big big_div4(const Big &x)
+{
+	Big q(x.size(), 0);
+	for (size_t i = 0; i < x.size(); i++) {
+		q[i] = (x[i] >> 2) | ((i + 1 < x.size()) ? (x[i + 1] << 30) : 0u);
+	}
+	big_trim(q);
+	return q;
+}
+
+static void ed448_setup(ecamd_curve *cv)
+{
+	cv->ed448_state = -1;
+	const Big p448 = big_sub(big_sub(big_pow2(448), big_pow2(224)), Big(1, 1));
+	if (!(cv->pbits == 448 && cv->clen == 56 && cv->nw == 14 && cv->qslot >= 0 && cv->qnw == 14 && cv->qlen == 56 &&
+	      big_cmp(cv->p, p448) == 0)) {
+		cv->ed448_err = "ec_eddsa_verify_batch: Ed448 needs the WEI448 curve handle";
+		return;
+	}
+	const Big &p = cv->p;
+	const Big one(1, 1), two(1, 2), three(1, 3);
+	const Big A(1, 156326);
+	const Big A3 = big_mulmod(A, big_inv_p(three, p), p);
+	const Big d448 = big_sub(p, Big(1, 39081));
+	const Big e4 = big_div4(big_add(p, one));                    // (p + 1) / 4: square roots for p = 3 mod 4
+	Big alpha = big_powmod(Big(1, 156324), e4, p);               // alpha^2 = A - 2
+	if (big_cmp(big_mulmod(alpha, alpha, p), Big(1, 156324)) != 0) {
+		cv->ed448_err = "ec_eddsa_verify_batch: internal: alpha";
+		return;
+	}
+	const Big diso = big_mulmod(Big(1, 156328), big_inv_p(Big(1, 156324), p), p);
+	{
+		// the Ed448 base point (RFC 8032) must map to the generator of the handle; this fixes the sign of alpha
+		static const uint8_t yb_le[56] = {
+			0x14, 0xfa, 0x30, 0xf2, 0x5b, 0x79, 0x08, 0x98, 0xad, 0xc8, 0xd7, 0x4e, 0x2c, 0x13, 0xbd, 0xfd, 0xc4, 0x39, 0x7c,
+			0xe6, 0x1c, 0xff, 0xd3, 0x3a, 0xd7, 0xc2, 0xa0, 0x05, 0x1e, 0x9c, 0x78, 0x87, 0x40, 0x98, 0xa3, 0x6c, 0x73, 0x73,
+			0xea, 0x4b, 0x62, 0xc7, 0xc9, 0x56, 0x37, 0x20, 0x76, 0x88, 0x24, 0xbc, 0xb6, 0x6e, 0x71, 0x46, 0x3f, 0x69};
+		uint8_t yb_be[56];
+		for (int i = 0; i < 56; i++) {
+			yb_be[i] = yb_le[55 - i];
+		}
+		const Big y = big_from_be(yb_be, 56);
+		const Big yy = big_mulmod(y, y, p);
+		auto sub = [&](const Big &a, const Big &b) { return big_mod(big_add(a, big_sub(p, big_mod(b, p))), p); };
+		const Big t = big_mulmod(sub(one, yy), big_inv_p(sub(one, big_mulmod(d448, yy, p)), p), p);
+		Big x = big_powmod(t, e4, p);
+		if (big_cmp(big_mulmod(x, x, p), t) != 0) {
+			cv->ed448_err = "ec_eddsa_verify_batch: internal: base point";
+			return;
+		}
+		if (x[0] & 1u) {
+			x = big_sub(p, x);                                   // the encoding's sign bit is 0
+		}
+		const Big xx = big_mulmod(x, x, p);
+		const Big X = big_mulmod(big_mulmod(alpha, big_mulmod(x, y, p), p), big_inv_p(sub(sub(two, xx), yy), p), p);
+		const Big Y = big_mulmod(big_mod(big_add(xx, yy), p), big_inv_p(sub(yy, xx), p), p);
+		const Big u = big_mulmod(big_mod(big_add(one, Y), p), big_inv_p(sub(one, Y), p), p);
+		Big v = big_mulmod(big_mulmod(alpha, u, p), big_inv_p(X, p), p);
+		const Big Xw = sub(A3, u);
+		Big Yw = sub(Big(1, 0), v);
+		if (big_cmp(Yw, cv->gy) != 0) {
+			alpha = big_sub(p, alpha);
+			Yw = sub(Big(1, 0), Yw);
+		}
+		if (big_cmp(Xw, cv->gx) != 0 || big_cmp(Yw, cv->gy) != 0) {
+			cv->ed448_err = "ec_eddsa_verify_batch: the curve generator is not the image of the Ed448 base point";
+			return;
+		}
+	}
+	{
+		Big t = big_add(cv->q, cv->q);
+		t = big_add(t, t);
+		if (big_cmp(t, cv->order) != 0) {
+			cv->ed448_err = "ec_eddsa_verify_batch: unexpected cofactor";
+			return;
+		}
+	}
+	Big c4;
+	for (uint32_t j = 1; j <= 3; j++) {
+		Big jq = big_add(big_mul(cv->q, Big(1, j)), one);
+		if ((jq[0] & 3u) == 0) {
+			c4 = big_div4(jq);
+			break;
+		}
+	}
+	big_to_be(cv->ed448_c4, 56, c4);
+	const int nw = cv->nw;
+	const Big R = big_mod(big_pow2(32 * nw), p);
+	EcamdEd448DecodeArgs &D = cv->ed448_tmpl;
+	memset(&D, 0, sizeof(D));
+	D.slot = cv->slot;
+	D.ebits = (uint32_t)big_bitlen(e4);
+	big_store(D.e, 17, e4);
+	big_store(D.d448, nw, big_mulmod(d448, R, p));
+	big_store(D.diso, nw, big_mulmod(diso, R, p));
+	big_store(D.alpha, nw, big_mulmod(alpha, R, p));
+	big_store(D.A3, nw, big_mulmod(A3, R, p));
+	cv->ed448_state = 1;
+}
+
+// device pointers in and out; pubs n x 57, sigs n x 114, hram n x 114
+static int eddsa448_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig,
+				      const uint8_t *d_hram, uint8_t *d_res, hipStream_t s)
+{
+	const size_t len = 56, plen = 112;
+	// stage: 3 A (Weierstrass), 4 R, 5 flagsA, 6 flagsR, 7 flagsS, 8 S, 9 h, 10 [4^-1]A, 11 its status, 12 [h]A, 13 sthA,
+	//        14 [S]G, 15 stSG, 17 the scalar 4^-1 mod q   (0..2 and 16 belong to the host-pointer wrapper)
+	const size_t need[ECAMD_NSTAGE] = {0, 0, 0, n * plen, n * plen, n, n, n, n * len, n * len,
+					   n * plen, n, n * plen, n, n * plen, n, 0, 64};
+	for (int i = 0; i < ECAMD_NSTAGE; i++) {
+		if (ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
+			return -1;
+		}
+	}
+	uint8_t **S = ctx->stage;
+	HIPCHK(hipMemcpyAsync(S[17], cv->ed448_c4, 56, hipMemcpyHostToDevice, s));   // lives in the curve handle
+	EcamdEd448DecodeArgs D = cv->ed448_tmpl;
+	D.n = n;
+	D.encA = d_pub;
+	D.strideA = 57;
+	D.encR = d_sig;
+	D.strideR = 114;
+	D.pointsA = S[3];
+	D.pointsR = S[4];
+	D.flagsA = S[5];
+	D.flagsR = S[6];
+	HIPCHK(ecamd_launch_ed448_decode(D, s));
+	EcamdEdScalArgs C;
+	memset(&C, 0, sizeof(C));
+	C.sigs = d_sig;
+	C.hram = d_hram;
+	C.S_be = S[8];
+	C.h_be = S[9];
+	C.flags = S[7];
+	C.n = n;
+	C.len = 57;
+	C.hlen = 114;
+	C.qslot = cv->qslot;
+	HIPCHK(ecamd_launch_ed448_scal(C, s));
+	// the stored key [4^-1 mod q]A (eddsa_import_pub_key), then [h]A and [S]G
+	if (smul_dev_locked(ctx, cv, n, S[17], (uint32_t)len, S[3], S[10], S[11], s, 0) ||
+	    smul_dev_locked(ctx, cv, n, S[9], (uint32_t)len, S[10], S[12], S[13], s) ||
+	    smul_dev_locked(ctx, cv, n, S[8], (uint32_t)len, nullptr, S[14], S[15], s)) {
+		return -1;
+	}
+	EcamdEdFinArgs F;
+	memset(&F, 0, sizeof(F));
+	F.SG = S[14];
+	F.stSG = S[15];
+	F.hA = S[12];
+	F.sthA = S[13];
+	F.R = S[4];
+	F.flagsA = S[5];
+	F.flagsR = S[6];
+	F.flagsS = S[7];
+	F.result = d_res;
+	F.n = n;
+	F.clen = (uint32_t)len;
+	F.cof_dbl = 2;
+	F.Akey = S[10];
+	F.stA = S[11];
+	F.slot = cv->slot;
+	HIPCHK(ecamd_launch_ed_fin(cv->nw, F, s));
+	return 0;
+}
+
 static int eddsa_args_ok(const char *fn, ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const void *a, const void *b,
 			 const void *c, const void *d, uint32_t hram_len)
 {
@@ -2026,6 +2199,18 @@ static int eddsa_args_ok(const char *fn, ecamd_ctx *ctx, const ecamd_curve *cv_i
 		return fail(std::string(fn) + ": bad argument");
 	}
 	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
+	if (cv->pbits == 448) {
+		if (cv->ed448_state == 0) {
+			ed448_setup(cv);
+		}
+		if (cv->ed448_state < 0) {
+			return fail(cv->ed448_err);
+		}
+		if (hram_len != 114) {
+			return fail(std::string(fn) + ": Ed448 hashes with SHAKE256 (114 bytes): hram_len must be 114");
+		}
+		return 0;
+	}
 	if (cv->ed_state == 0) {
 		ed_setup(cv);
 	}
@@ -2054,6 +2239,10 @@ extern "C" int ec_eddsa_verify_batch_dev(ecamd_ctx *ctx, const ecamd_curve *cv_i
 	}
 	HIPCHK(hipSetDevice(ctx->device));
 	hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+	if (cv_in->pbits == 448) {
+		return eddsa448_verify_dev_locked(ctx, const_cast<ecamd_curve *>(cv_in), n, (const uint8_t *)d_pubkeys,
+						  (const uint8_t *)d_sigs, (const uint8_t *)d_hram, (uint8_t *)d_result, s);
+	}
 	return eddsa_verify_dev_locked(ctx, const_cast<ecamd_curve *>(cv_in), n, (const uint8_t *)d_pubkeys,
 				       (const uint8_t *)d_sigs, (const uint8_t *)d_hram, hram_len, (uint8_t *)d_result, s);
 }
@@ -2073,10 +2262,13 @@ extern "C" int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, u
 	}
 	HIPCHK(hipSetDevice(ctx->device));
 	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
-	const std::vector<HostArr> arrs = {{pubkeys, nullptr, 32}, {sigs, nullptr, 64}, {hram, nullptr, hram_len}, {nullptr, result, 1}};
+	const bool e448 = cv->pbits == 448;
+	const std::vector<HostArr> arrs = {{pubkeys, nullptr, e448 ? 57u : 32u}, {sigs, nullptr, e448 ? 114u : 64u},
+					   {hram, nullptr, hram_len}, {nullptr, result, 1}};
 	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
-		return eddsa_verify_dev_locked(ctx, cv, m, ip[0], ip[1], ip[2], hram_len, op[3], s);
+		return e448 ? eddsa448_verify_dev_locked(ctx, cv, m, ip[0], ip[1], ip[2], op[3], s)
+			    : eddsa_verify_dev_locked(ctx, cv, m, ip[0], ip[1], ip[2], hram_len, op[3], s);
 	});
 }
 

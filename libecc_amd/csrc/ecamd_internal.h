@@ -153,8 +153,22 @@ struct EcamdEdFinArgs {
 	const uint8_t *flagsA, *flagsR, *flagsS;
 	uint8_t *result;            // n: 0 accept / 1 reject
 	uint32_t n, clen, cof_dbl;  // cof_dbl = log2(cofactor)
+	const uint8_t *Akey, *stA;  // Ed448: the stored key [4^-1]A (affine) + its status, checked for small order here; NULL otherwise
 	int slot;
 };
+// Ed448 point decoding (EDDSA448 branch of eddsa_decode_point) + maps to the Weierstrass model WEI448
+struct EcamdEd448DecodeArgs {
+	const uint8_t *encA, *encR;   // n x 57-byte encodings
+	uint32_t strideA, strideR;
+	uint8_t *pointsA, *pointsR;   // out: n x 112 affine Weierstrass X || Y big-endian
+	uint8_t *flagsA, *flagsR;
+	uint32_t n, ebits;
+	uint32_t e[17];               // (p + 1) / 4
+	uint32_t d448[17], diso[17], alpha[17], A3[17];   // Montgomery form (radix 2^448)
+	int slot;
+};
+hipError_t ecamd_launch_ed448_decode(const EcamdEd448DecodeArgs &a, hipStream_t s);
+hipError_t ecamd_launch_ed448_scal(const EcamdEdScalArgs &a, hipStream_t s);
 hipError_t ecamd_launch_ed_decode(int nw, const EcamdEdDecodeArgs &a, hipStream_t s);
 // the same two front-end kernels on the radix-2^29 field of the 2^255 - 19 unit (gslot: its constant slot)
 hipError_t ecamd_launch_ed_decode_c25519(const EcamdEdDecodeArgs &a, int gslot, hipStream_t s);

@@ -764,6 +764,21 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed_fin(EcamdEdFinArgs 
 		A.result[i] = 1;
 		return;
 	}
+	if (A.Akey != nullptr) {
+		// [cofactor]A != infinity for the stored key (Ed448: after its multiplication by 4^-1 mod q)
+		if (A.stA[i] != 0) {
+			A.result[i] = 1;
+			return;
+		}
+		Pt<NW> K4 = ed_load_neg<NW>(A.Akey + (size_t)i * 2 * clen, 0, clen, false, slot);
+		for (u32 k = 0; k < A.cof_dbl; k++) {
+			K4 = pt_dbl<NW>(K4, slot);
+		}
+		if (fe_is_zero<NW>(K4.Z)) {
+			A.result[i] = 1;
+			return;
+		}
+	}
 	Pt<NW> W = ed_load_neg<NW>(A.SG + (size_t)i * 2 * clen, sSG, clen, false, slot);
 	const Pt<NW> Rn = ed_load_neg<NW>(A.R + (size_t)i * 2 * clen, 0, clen, true, slot);
 	const Pt<NW> Hn = ed_load_neg<NW>(A.hA + (size_t)i * 2 * clen, shA, clen, true, slot);
@@ -777,6 +792,125 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed_fin(EcamdEdFinArgs 
 		W = pt_dbl<NW>(W, slot);
 	}
 	A.result[i] = (!bad && fe_is_zero<NW>(W.Z)) ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// Ed448 verification (sig/eddsa.c, EDDSA448 branches) through the Weierstrass model WEI448:
+//   eddsa_decode_point (:424-556): y little-endian in 57 bytes, bit 455 = sign of x, y >= p rejected; x from y on
+//     Ed448 itself (a = 1, d = -39081); the 4-isogeny x' = alpha x y / (2 - x^2 - y^2), y' = (x^2 + y^2) / (y^2 - x^2)
+//     (a zero denominator is an fp_inv error); on-curve check on the Edwards model of curve448;
+//   aff_pt_edwards_to_montgomery / aff_pt_montgomery_to_shortw with libecc's Montgomery model (A, B) = (-156326, -1):
+//     u = (1 + y') / (1 - y'), v = alpha u / x', (X, Y) = (A/3 - u, -v); x' = 0 is rejected as for Ed25519;
+//   eddsa_import_pub_key (:925-937): A <- [4^-1 mod q]A (a scalar multiplication, done by the host between kernels);
+//   _eddsa_verify_init: S < q, [4]A != infinity; _eddsa_verify_finalize: h = hash mod q, then 4 h mod q,
+//     [S]G - R - [h]A, two cofactor doublings, must be infinity.
+// Square root: p = 3 mod 4, candidate w^((p + 1) / 4) (wave-uniform exponent bits).
+// ------------------------------------------------------------------------------------------
+template <int NW> static __device__ Fe<NW> fe_pow_bits(const Fe<NW> &w, const u32 *e, int ebits, int slot)
+{
+	Fe<NW> c = fe_const<NW>(ConstTab<NW>::get(slot).one);
+	for (int b = ebits - 1; b >= 0; b--) {
+		c = fe_mul<NW>(c, c, slot);
+		if ((e[b >> 5] >> (b & 31)) & 1u) {
+			c = fe_mul<NW>(c, w, slot);
+		}
+	}
+	return c;
+}
+
+template <int NW> static __device__ bool ed448_decode_point(const EcamdEd448DecodeArgs &A, const u8 *src, Fe<NW> *Xw, Fe<NW> *Yw)
+{
+	const int slot = A.slot;
+	Fe<NW> y = fe_load_le<NW>(src, 56);
+	const u32 last = src[56];
+	const u32 x0 = last >> 7;
+	bool ok = ((last & 0x7fu) == 0) & fe_lt_p<NW>(y, slot);       // the 57th byte only carries the sign
+	const Fe<NW> one = fe_const<NW>(ConstTab<NW>::get(slot).one);
+	const Fe<NW> zero = fe_zero<NW>();
+	const Fe<NW> ym = fe_to_mont<NW>(y, slot);
+	const Fe<NW> yy = fe_mul<NW>(ym, ym, slot);
+	const Fe<NW> x1 = fe_sub<NW>(one, yy, slot);
+	const Fe<NW> x2 = fe_sub<NW>(one, fe_mul<NW>(fe_const<NW>(A.d448), yy, slot), slot);     // a - d y^2, a = 1
+	ok = ok & !fe_is_zero<NW>(x2);
+	const Fe<NW> t = fe_mul<NW>(x1, fe_inv<NW>(x2, slot), slot);
+	Fe<NW> x = fe_pow_bits<NW>(t, A.e, (int)A.ebits, slot);
+	ok = ok & fe_eq<NW>(fe_mul<NW>(x, x, slot), t);                                          // no root: error
+	const Fe<NW> xp = fe_from_mont<NW>(x, slot);
+	x = fe_select<NW>((xp.v[0] & 1u) != x0, fe_sub<NW>(zero, x, slot), x);
+	ok = ok & !(fe_is_zero<NW>(x) & (x0 == 1u));
+	// 4-isogeny, both denominators from one inversion
+	const Fe<NW> xx = fe_mul<NW>(x, x, slot);
+	const Fe<NW> two = fe_add<NW>(one, one, slot);
+	const Fe<NW> d1 = fe_sub<NW>(fe_sub<NW>(two, xx, slot), yy, slot);                       // 2 - x^2 - y^2
+	const Fe<NW> d2 = fe_sub<NW>(yy, xx, slot);                                              // y^2 - x^2
+	ok = ok & !fe_is_zero<NW>(d1) & !fe_is_zero<NW>(d2);
+	const Fe<NW> di = fe_inv<NW>(fe_mul<NW>(d1, d2, slot), slot);
+	const Fe<NW> X = fe_mul<NW>(fe_mul<NW>(fe_const<NW>(A.alpha), fe_mul<NW>(x, ym, slot), slot), fe_mul<NW>(di, d2, slot), slot);
+	const Fe<NW> Y = fe_mul<NW>(fe_add<NW>(xx, yy, slot), fe_mul<NW>(di, d1, slot), slot);
+	{
+		const Fe<NW> X2 = fe_mul<NW>(X, X, slot), Y2 = fe_mul<NW>(Y, Y, slot);
+		const Fe<NW> l = fe_add<NW>(X2, Y2, slot);
+		const Fe<NW> r = fe_add<NW>(one, fe_mul<NW>(fe_const<NW>(A.diso), fe_mul<NW>(X2, Y2, slot), slot), slot);
+		ok = ok & fe_eq<NW>(l, r);
+	}
+	// Edwards -> Montgomery -> Weierstrass; X = 0 (neutral element, order-2 point) and Y = 1 are errors
+	const Fe<NW> omy = fe_sub<NW>(one, Y, slot);
+	ok = ok & !fe_is_zero<NW>(X) & !fe_is_zero<NW>(omy);
+	const Fe<NW> mi = fe_inv<NW>(fe_mul<NW>(omy, X, slot), slot);
+	const Fe<NW> u = fe_mul<NW>(fe_add<NW>(one, Y, slot), fe_mul<NW>(mi, X, slot), slot);
+	const Fe<NW> v = fe_mul<NW>(fe_mul<NW>(fe_const<NW>(A.alpha), u, slot), fe_mul<NW>(mi, omy, slot), slot);
+	*Xw = fe_sub<NW>(fe_const<NW>(A.A3), u, slot);
+	*Yw = fe_sub<NW>(zero, v, slot);
+	return ok;
+}
+
+template <int NW> __global__ __launch_bounds__(64) void k_ed448_decode(EcamdEd448DecodeArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int slot = A.slot;
+	const Fe<NW> zero = fe_zero<NW>();
+#pragma unroll 1
+	for (int k = 0; k < 2; k++) {
+		Fe<NW> X, Y;
+		const u8 *src = (k == 0) ? A.encA + (size_t)i * A.strideA : A.encR + (size_t)i * A.strideR;
+		const bool ok = ed448_decode_point<NW>(A, src, &X, &Y);
+		u8 *pd = (k == 0 ? A.pointsA : A.pointsR) + (size_t)i * 112;
+		fe_store_be<NW>(pd, 56, ok ? fe_from_mont<NW>(X, slot) : zero);
+		fe_store_be<NW>(pd + 56, 56, ok ? fe_from_mont<NW>(Y, slot) : zero);
+		(k == 0 ? A.flagsA : A.flagsR)[i] = ok ? 0 : 1;
+	}
+}
+
+// S < q (57 bytes little-endian, the last one must be 0); h = 114-byte hash mod q, then 4 h mod q
+template <int NW> __global__ __launch_bounds__(64) void k_ed448_scal(EcamdEdScalArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int qs = A.qslot;
+	const CurveK<NW> &Q = ConstTab<NW>::get(qs);
+	const u8 *sp = A.sigs + (size_t)i * 114 + 57;
+	const Fe<NW> S = fe_load_le<NW>(sp, 56);
+	const bool ok = (sp[56] == 0) & fe_lt_p<NW>(S, qs);
+	const u8 *hp = A.hram + (size_t)i * 114;
+	const Fe<NW> lo = fe_load_le<NW>(hp, 56), mid = fe_load_le<NW>(hp + 56, 56), hi = fe_load_le<NW>(hp + 112, 2);
+	const Fe<NW> r2 = fe_const<NW>(Q.r2);
+	Fe<NW> onep = fe_zero<NW>();
+	onep.v[0] = 1u;
+	// R = 2^448: x R2 / R = x 2^448 (mod q); lo, mid need one reduction step first (they may exceed q)
+	const Fe<NW> lor = fe_mul<NW>(fe_mul<NW>(lo, r2, qs), onep, qs);                        // lo mod q
+	const Fe<NW> midr = fe_mul<NW>(mid, r2, qs);                                             // mid 2^448 mod q
+	const Fe<NW> hir = fe_mul<NW>(fe_mul<NW>(hi, r2, qs), r2, qs);                           // hi 2^896 mod q
+	Fe<NW> h = fe_add<NW>(fe_add<NW>(lor, midr, qs), hir, qs);
+	h = fe_add<NW>(h, h, qs);
+	h = fe_add<NW>(h, h, qs);                                                                // 4 h mod q
+	fe_store_be<NW>(A.S_be + (size_t)i * 56, 56, ok ? S : fe_zero<NW>());
+	fe_store_be<NW>(A.h_be + (size_t)i * 56, 56, h);
+	A.flags[i] = ok ? 0 : 1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1037,10 +1171,31 @@ hipError_t ecamd_launch_ed_fin(int nw, const EcamdEdFinArgs &a, hipStream_t s)
 	if (a.n == 0) {
 		return hipSuccess;
 	}
-	if (nw != 8) {
+	if (nw == 8) {
+		hipLaunchKernelGGL(k_ed_fin<8>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+	} else if (nw == 14) {
+		hipLaunchKernelGGL(k_ed_fin<14>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+	} else {
 		return hipErrorInvalidValue;
 	}
-	hipLaunchKernelGGL(k_ed_fin<8>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_ed448_decode(const EcamdEd448DecodeArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_ed448_decode<14>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_ed448_scal(const EcamdEdScalArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_ed448_scal<14>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
 	return hipGetLastError();
 }
 

@@ -1018,3 +1018,36 @@ def test_fallback_paths_stay_correct(env):
             del os.environ[env]
         else:
             os.environ[env] = old
+
+
+def test_eddsa448_verify_vs_oracle_and_golden(gpu_ctx):
+    """Ed448 batch verification on the WEI448 handle: the reference's RFC 8032 Ed448 / Ed448ph vectors, then valid,
+    torsion-shifted and every class of rejected input against the oracle (device- and host-pointer forms)"""
+    import torch
+    from test_oracle import KAT_EDDSA448, ed448_cases, eddsa448_kat_inputs
+    rng = np.random.default_rng(44)
+    cv = gpu_ctx.curve("WEI448")
+    o = Oracle("WEI448")
+    try:
+        pubs, sigs, hram = eddsa448_kat_inputs()
+        n = len(KAT_EDDSA448)
+        assert cv.eddsa_verify(pubs, sigs, hram) == bytes(n)
+        bad = bytearray(sigs)
+        bad[114 + 3] ^= 1
+        assert cv.eddsa_verify(pubs, bytes(bad), hram) == bytes([0, 1] + [0] * (n - 2))
+        pubs, sigs, msgs, hram = ed448_cases(rng, nvalid=16)
+        exp = o.eddsa_verify(pubs, sigs, hram)
+        assert 0 in exp and 1 in exp and exp[:16] == bytes(16)
+        assert cv.eddsa_verify(pubs, sigs, hram) == exp
+        assert cv.eddsa_verify(b"", b"", b"") == b""
+        n = len(exp)
+        dev = torch.device("cuda:0")
+        t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+        dp, ds, dh = t(pubs), t(sigs), t(hram)
+        dr = torch.full((n,), 0xAA, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        cv.eddsa_verify_dev(n, dp.data_ptr(), ds.data_ptr(), dh.data_ptr(), dr.data_ptr(), None, 114)
+        gpu_ctx.synchronize()
+        assert bytes(dr.cpu().numpy()) == exp
+    finally:
+        cv.free()
