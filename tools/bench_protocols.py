@@ -26,7 +26,7 @@ SEED = 0x5EC9256
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", required=True, choices=["ecdsa_verify", "ed25519_verify", "x25519"])
+    ap.add_argument("--workload", required=True, choices=["ecdsa_verify", "ed25519_verify", "ed448_verify", "x25519"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
@@ -121,6 +121,31 @@ def main():
             return o.eddsa_verify(b"".join(pubs[32 * i:32 * i + 32] for i in idx), b"".join(sigs[64 * i:64 * i + 64] for i in idx),
                                   b"".join(hram[64 * i:64 * i + 64] for i in idx))
         metric, unit, cfg = "Ed25519 verifications/sec (batch=2^%d, %d distinct signatures tiled)" % (a.batch_log2, m), "verifications/s", 4
+    elif a.workload == "ed448_verify":
+        cv = ctx.curve("WEI448")
+        m = 128
+        items = [O.ed448_sign(rb(57), rb(32)) for _ in range(m)]
+        reps = B // m
+        pubs = b"".join(i[0] for i in items) * reps
+        sigs = b"".join(i[1] for i in items) * reps
+        hram = bytearray(b"".join(i[2] for i in items) * reps)
+        bad = np.zeros(B, dtype=np.uint8)
+        for i in range(0, B, 10):
+            hram[114 * i + (i % 114)] ^= 1 << (i % 8)
+            bad[i] = 1
+        hram = bytes(hram)
+        ins = [t(pubs), t(sigs), t(hram)]
+        d_res = torch.empty(B, dtype=torch.uint8, device=dev)
+
+        def step():
+            cv.eddsa_verify_dev(B, ins[0].data_ptr(), ins[1].data_ptr(), ins[2].data_ptr(), d_res.data_ptr(), stream.cuda_stream, 114)
+        expected = bad.tobytes()
+
+        def oracle_subset(idx):
+            o = O.Oracle("WEI448")
+            return o.eddsa_verify(b"".join(pubs[57 * i:57 * i + 57] for i in idx), b"".join(sigs[114 * i:114 * i + 114] for i in idx),
+                                  b"".join(hram[114 * i:114 * i + 114] for i in idx))
+        metric, unit, cfg = "Ed448 verifications/sec (batch=2^%d, %d distinct signatures tiled)" % (a.batch_log2, m), "verifications/s", 4
     else:
         cv = ctx.curve("WEI25519")
         k1, k2 = rb(32 * B), rb(32 * B)
@@ -193,6 +218,10 @@ def main():
         elif a.workload == "ed25519_verify":
             O.ref_ed25519_verify(pubs[:32 * m], sigs[:64 * m], hram[:64 * m], 64)
             what = "eddsa_import_pub_key + ec_verify (EDDSA25519, SHA-512 over 64-byte messages)"
+        elif a.workload == "ed448_verify":
+            m = 256
+            O.ref_ed448_verify(pubs[:57 * m], sigs[:114 * m], hram[:114 * m], 114)
+            what = "eddsa_import_pub_key + ec_verify (EDDSA448, SHAKE256 over 114-byte messages)"
         else:
             O.ref_xdh(32, k2[:32 * m], pub[:32 * m])
             what = "x25519()"
