@@ -145,7 +145,7 @@ def main():
             o = O.Oracle("WEI448")
             return o.eddsa_verify(b"".join(pubs[57 * i:57 * i + 57] for i in idx), b"".join(sigs[114 * i:114 * i + 114] for i in idx),
                                   b"".join(hram[114 * i:114 * i + 114] for i in idx))
-        metric, unit, cfg = "Ed448 verifications/sec (batch=2^%d, %d distinct signatures tiled)" % (a.batch_log2, m), "verifications/s", 4
+        metric, unit, cfg = "Ed448 verifications/sec (batch=2^%d, %d distinct signatures tiled)" % (a.batch_log2, m), "verifications/s", "4], Ed448 counterpart [not in BASELINE"
     else:
         cv = ctx.curve("WEI25519")
         k1, k2 = rb(32 * B), rb(32 * B)
