@@ -1078,6 +1078,9 @@ static int host_pipeline(ecamd_ctx *ctx, uint32_t n, const std::vector<HostArr> 
 			return copy_in(noff, (n - noff) < chunk ? (n - noff) : chunk, b ^ 1);
 		};
 		if (core(m, ip, op, s, between) || between()) {
+			// leave nothing in flight on the staging buffers of a failed call
+			(void)hipStreamSynchronize(cs);
+			(void)hipStreamSynchronize(s);
 			return -1;
 		}
 		for (size_t k = 0; k < na; k++) {
