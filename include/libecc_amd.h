@@ -19,6 +19,17 @@
  * Every function returns 0 on success and -1 on failure of the call itself (bad argument, no
  * device, HIP error); ecamd_last_error() then describes it.  There is NO CPU fallback: without
  * a gfx950 device ecamd_ctx_create() fails.
+ *
+ * Threads: a context serialises its calls with a mutex; use one context per thread (or per GPU) for
+ * concurrency.  Memory: scratch grows with the largest batch seen (about 2.8 KB per item of a chunk of
+ * <= 2^20 items); a curve handle that has served a fixed-base batch of >= 4096 items keeps a table of
+ * multiples of the generator in HBM (42 MB for 256-bit curves, 183 MB for 521 bits).
+ *
+ * Environment (read when a context / curve handle is created; for measurements and fallbacks):
+ *   ECAMD_HOST_CHUNK=<items>      chunk size of the host-pointer entry points (default 2^18)
+ *   ECAMD_COMB_MIN_BATCH=<items>  smallest fixed-base batch that builds / uses the generator table (default 4096)
+ *   ECAMD_NO_COMB, ECAMD_NO_FAST_PATH, ECAMD_NO_P25519, ECAMD_NO_ISO, ECAMD_NO_X25519_LADDER,
+ *   ECAMD_NO_EDWARDS_SMUL         route around one fast path each (results are identical)
  */
 #ifndef LIBECC_AMD_H
 #define LIBECC_AMD_H
