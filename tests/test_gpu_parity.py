@@ -976,7 +976,7 @@ def test_host_pipeline_multi_chunk(gpu_ctx):
 
 
 @pytest.mark.parametrize("env", ["ECAMD_NO_COMB", "ECAMD_NO_P25519", "ECAMD_NO_X25519_LADDER", "ECAMD_NO_EDWARDS_SMUL",
-                                 "ECAMD_NO_FAST_PATH"])
+                                 "ECAMD_NO_FAST_PATH", "ECAMD_NO_ISO"])
 def test_fallback_paths_stay_correct(env):
     """every fast path has a switch that routes around it (A/B measurements, fallbacks): the slower routes
     must give the same bytes -- fixed-base without the comb, WEI25519 on the dense field, X25519 and Ed25519
@@ -995,6 +995,16 @@ def test_fallback_paths_stay_correct(env):
                 assert cv.eddsa_verify(pubs, sigs, hram) == Oracle("WEI25519").eddsa_verify(pubs, sigs, hram)
                 ek, eu = xdh_edge_inputs(32, rng)
                 assert cv.xdh(ek, eu) == Oracle("WEI25519").xdh(ek, eu)
+            finally:
+                cv.free()
+            cv = ctx.curve("BRAINPOOLP256R1")       # computed on its a = -3 image unless ECAMD_NO_ISO
+            try:
+                o = Oracle("BRAINPOOLP256R1")
+                sc = rand_bytes(rng, 32 * 80)
+                pub = cv.scalar_mult(sc)
+                assert pub == o.scalar_mult(sc)
+                sc2 = rand_bytes(rng, 32 * 80)
+                assert cv.scalar_mult(sc2, pub[0]) == o.scalar_mult(sc2, pub[0])
             finally:
                 cv.free()
             cv = ctx.curve("SECP256R1")
