@@ -804,7 +804,7 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed_fin(EcamdEdFinArgs 
 //   eddsa_import_pub_key (:925-937): A <- [4^-1 mod q]A (a scalar multiplication, done by the host between kernels);
 //   _eddsa_verify_init: S < q, [4]A != infinity; _eddsa_verify_finalize: h = hash mod q, then 4 h mod q,
 //     [S]G - R - [h]A, two cofactor doublings, must be infinity.
-// Square root: p = 3 mod 4, candidate w^((p + 1) / 4) (wave-uniform exponent bits).
+// Square root: p = 3 mod 4 (wave-uniform exponent bits).
 // ------------------------------------------------------------------------------------------
 template <int NW> static __device__ Fe<NW> fe_pow_bits(const Fe<NW> &w, const u32 *e, int ebits, int slot)
 {
@@ -818,52 +818,9 @@ template <int NW> static __device__ Fe<NW> fe_pow_bits(const Fe<NW> &w, const u3
 	return c;
 }
 
-template <int NW> static __device__ bool ed448_decode_point(const EcamdEd448DecodeArgs &A, const u8 *src, Fe<NW> *Xw, Fe<NW> *Yw)
-{
-	const int slot = A.slot;
-	Fe<NW> y = fe_load_le<NW>(src, 56);
-	const u32 last = src[56];
-	const u32 x0 = last >> 7;
-	bool ok = ((last & 0x7fu) == 0) & fe_lt_p<NW>(y, slot);       // the 57th byte only carries the sign
-	const Fe<NW> one = fe_const<NW>(ConstTab<NW>::get(slot).one);
-	const Fe<NW> zero = fe_zero<NW>();
-	const Fe<NW> ym = fe_to_mont<NW>(y, slot);
-	const Fe<NW> yy = fe_mul<NW>(ym, ym, slot);
-	const Fe<NW> x1 = fe_sub<NW>(one, yy, slot);
-	const Fe<NW> x2 = fe_sub<NW>(one, fe_mul<NW>(fe_const<NW>(A.d448), yy, slot), slot);     // a - d y^2, a = 1
-	ok = ok & !fe_is_zero<NW>(x2);
-	const Fe<NW> t = fe_mul<NW>(x1, fe_inv<NW>(x2, slot), slot);
-	Fe<NW> x = fe_pow_bits<NW>(t, A.e, (int)A.ebits, slot);
-	ok = ok & fe_eq<NW>(fe_mul<NW>(x, x, slot), t);                                          // no root: error
-	const Fe<NW> xp = fe_from_mont<NW>(x, slot);
-	x = fe_select<NW>((xp.v[0] & 1u) != x0, fe_sub<NW>(zero, x, slot), x);
-	ok = ok & !(fe_is_zero<NW>(x) & (x0 == 1u));
-	// 4-isogeny, both denominators from one inversion
-	const Fe<NW> xx = fe_mul<NW>(x, x, slot);
-	const Fe<NW> two = fe_add<NW>(one, one, slot);
-	const Fe<NW> d1 = fe_sub<NW>(fe_sub<NW>(two, xx, slot), yy, slot);                       // 2 - x^2 - y^2
-	const Fe<NW> d2 = fe_sub<NW>(yy, xx, slot);                                              // y^2 - x^2
-	ok = ok & !fe_is_zero<NW>(d1) & !fe_is_zero<NW>(d2);
-	const Fe<NW> di = fe_inv<NW>(fe_mul<NW>(d1, d2, slot), slot);
-	const Fe<NW> X = fe_mul<NW>(fe_mul<NW>(fe_const<NW>(A.alpha), fe_mul<NW>(x, ym, slot), slot), fe_mul<NW>(di, d2, slot), slot);
-	const Fe<NW> Y = fe_mul<NW>(fe_add<NW>(xx, yy, slot), fe_mul<NW>(di, d1, slot), slot);
-	{
-		const Fe<NW> X2 = fe_mul<NW>(X, X, slot), Y2 = fe_mul<NW>(Y, Y, slot);
-		const Fe<NW> l = fe_add<NW>(X2, Y2, slot);
-		const Fe<NW> r = fe_add<NW>(one, fe_mul<NW>(fe_const<NW>(A.diso), fe_mul<NW>(X2, Y2, slot), slot), slot);
-		ok = ok & fe_eq<NW>(l, r);
-	}
-	// Edwards -> Montgomery -> Weierstrass; X = 0 (neutral element, order-2 point) and Y = 1 are errors
-	const Fe<NW> omy = fe_sub<NW>(one, Y, slot);
-	ok = ok & !fe_is_zero<NW>(X) & !fe_is_zero<NW>(omy);
-	const Fe<NW> mi = fe_inv<NW>(fe_mul<NW>(omy, X, slot), slot);
-	const Fe<NW> u = fe_mul<NW>(fe_add<NW>(one, Y, slot), fe_mul<NW>(mi, X, slot), slot);
-	const Fe<NW> v = fe_mul<NW>(fe_mul<NW>(fe_const<NW>(A.alpha), u, slot), fe_mul<NW>(mi, omy, slot), slot);
-	*Xw = fe_sub<NW>(fe_const<NW>(A.A3), u, slot);
-	*Yw = fe_sub<NW>(zero, v, slot);
-	return ok;
-}
-
+// One lane decodes A and R of an item; the four field inversions of each point (a - d y^2, the two isogeny
+// denominators, 1 - y', x') shrink to two per ITEM by Montgomery's trick, and the first one rides on the square
+// root: x = u^3 v (u^5 v^3)^((p - 3) / 4) for x^2 = u / v (RFC 8032 5.2.3), valid iff v x^2 == u.
 template <int NW> __global__ __launch_bounds__(64) void k_ed448_decode(EcamdEd448DecodeArgs A)
 {
 	const u32 i = blockIdx.x * 64 + threadIdx.x;
@@ -871,16 +828,77 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed448_decode(EcamdEd44
 		return;
 	}
 	const int slot = A.slot;
+	const Fe<NW> one = fe_const<NW>(ConstTab<NW>::get(slot).one);
 	const Fe<NW> zero = fe_zero<NW>();
+	const Fe<NW> two = fe_add<NW>(one, one, slot);
+	Fe<NW> x[2], ym[2], xx[2], yy[2], d1[2], d2[2];
+	bool ok[2];
 #pragma unroll 1
 	for (int k = 0; k < 2; k++) {
-		Fe<NW> X, Y;
 		const u8 *src = (k == 0) ? A.encA + (size_t)i * A.strideA : A.encR + (size_t)i * A.strideR;
-		const bool ok = ed448_decode_point<NW>(A, src, &X, &Y);
-		u8 *pd = (k == 0 ? A.pointsA : A.pointsR) + (size_t)i * 112;
-		fe_store_be<NW>(pd, 56, ok ? fe_from_mont<NW>(X, slot) : zero);
-		fe_store_be<NW>(pd + 56, 56, ok ? fe_from_mont<NW>(Y, slot) : zero);
-		(k == 0 ? A.flagsA : A.flagsR)[i] = ok ? 0 : 1;
+		const Fe<NW> y = fe_load_le<NW>(src, 56);
+		const u32 last = src[56];
+		const u32 x0 = last >> 7;
+		bool good = ((last & 0x7fu) == 0) & fe_lt_p<NW>(y, slot);       // the 57th byte only carries the sign
+		ym[k] = fe_to_mont<NW>(y, slot);
+		yy[k] = fe_mul<NW>(ym[k], ym[k], slot);
+		const Fe<NW> u = fe_sub<NW>(one, yy[k], slot);                                     // 1 - y^2
+		const Fe<NW> v = fe_sub<NW>(one, fe_mul<NW>(fe_const<NW>(A.d448), yy[k], slot), slot);  // a - d y^2, a = 1
+		good = good & !fe_is_zero<NW>(v);                                                  // fp_inv(0)
+		const Fe<NW> v2 = fe_mul<NW>(v, v, slot), u2 = fe_mul<NW>(u, u, slot);
+		const Fe<NW> u3v = fe_mul<NW>(fe_mul<NW>(u2, u, slot), v, slot);
+		const Fe<NW> u5v3 = fe_mul<NW>(fe_mul<NW>(u3v, u2, slot), v2, slot);
+		Fe<NW> r = fe_mul<NW>(u3v, fe_pow_bits<NW>(u5v3, A.e, (int)A.ebits, slot), slot);
+		good = good & fe_eq<NW>(fe_mul<NW>(v, fe_mul<NW>(r, r, slot), slot), u);           // u / v has no root: error
+		const Fe<NW> rp = fe_from_mont<NW>(r, slot);
+		r = fe_select<NW>((rp.v[0] & 1u) != x0, fe_sub<NW>(zero, r, slot), r);
+		good = good & !(fe_is_zero<NW>(r) & (x0 == 1u));
+		x[k] = r;
+		xx[k] = fe_mul<NW>(r, r, slot);
+		d1[k] = fe_sub<NW>(fe_sub<NW>(two, xx[k], slot), yy[k], slot);                     // 2 - x^2 - y^2
+		d2[k] = fe_sub<NW>(yy[k], xx[k], slot);                                            // y^2 - x^2
+		good = good & !fe_is_zero<NW>(d1[k]) & !fe_is_zero<NW>(d2[k]);                     // fp_inv(0)
+		ok[k] = good;
+		d1[k] = fe_select<NW>(good, d1[k], one);
+		d2[k] = fe_select<NW>(good, d2[k], one);
+	}
+	// isogeny: 1 / (d1 d2) for both points from one inversion
+	Fe<NW> X[2], Y[2], omy[2];
+	{
+		const Fe<NW> pa = fe_mul<NW>(d1[0], d2[0], slot), pr = fe_mul<NW>(d1[1], d2[1], slot);
+		const Fe<NW> inv = fe_inv<NW>(fe_mul<NW>(pa, pr, slot), slot);
+		const Fe<NW> ia = fe_mul<NW>(inv, pr, slot), ir = fe_mul<NW>(inv, pa, slot);       // 1 / (d1 d2) of A, of R
+#pragma unroll 1
+		for (int k = 0; k < 2; k++) {
+			const Fe<NW> di = (k == 0) ? ia : ir;
+			X[k] = fe_mul<NW>(fe_mul<NW>(fe_const<NW>(A.alpha), fe_mul<NW>(x[k], ym[k], slot), slot), fe_mul<NW>(di, d2[k], slot), slot);
+			Y[k] = fe_mul<NW>(fe_add<NW>(xx[k], yy[k], slot), fe_mul<NW>(di, d1[k], slot), slot);
+			const Fe<NW> X2 = fe_mul<NW>(X[k], X[k], slot), Y2 = fe_mul<NW>(Y[k], Y[k], slot);
+			const Fe<NW> l = fe_add<NW>(X2, Y2, slot);
+			const Fe<NW> r = fe_add<NW>(one, fe_mul<NW>(fe_const<NW>(A.diso), fe_mul<NW>(X2, Y2, slot), slot), slot);
+			omy[k] = fe_sub<NW>(one, Y[k], slot);
+			// on the Edwards model of curve448; X = 0 (neutral element, order-2 point) and Y = 1 are errors
+			ok[k] = ok[k] & fe_eq<NW>(l, r) & !fe_is_zero<NW>(X[k]) & !fe_is_zero<NW>(omy[k]);
+			X[k] = fe_select<NW>(ok[k], X[k], one);
+			omy[k] = fe_select<NW>(ok[k], omy[k], one);
+		}
+	}
+	{
+		const Fe<NW> pa = fe_mul<NW>(omy[0], X[0], slot), pr = fe_mul<NW>(omy[1], X[1], slot);
+		const Fe<NW> inv = fe_inv<NW>(fe_mul<NW>(pa, pr, slot), slot);
+		const Fe<NW> ia = fe_mul<NW>(inv, pr, slot), ir = fe_mul<NW>(inv, pa, slot);       // 1 / ((1 - Y) X) of A, of R
+#pragma unroll 1
+		for (int k = 0; k < 2; k++) {
+			const Fe<NW> mi = (k == 0) ? ia : ir;
+			const Fe<NW> u = fe_mul<NW>(fe_add<NW>(one, Y[k], slot), fe_mul<NW>(mi, X[k], slot), slot);
+			const Fe<NW> v = fe_mul<NW>(fe_mul<NW>(fe_const<NW>(A.alpha), u, slot), fe_mul<NW>(mi, omy[k], slot), slot);
+			const Fe<NW> Xw = fe_sub<NW>(fe_const<NW>(A.A3), u, slot);                       // (A, B) = (-156326, -1)
+			const Fe<NW> Yw = fe_sub<NW>(zero, v, slot);
+			u8 *pd = (k == 0 ? A.pointsA : A.pointsR) + (size_t)i * 112;
+			fe_store_be<NW>(pd, 56, ok[k] ? fe_from_mont<NW>(Xw, slot) : zero);
+			fe_store_be<NW>(pd + 56, 56, ok[k] ? fe_from_mont<NW>(Yw, slot) : zero);
+			(k == 0 ? A.flagsA : A.flagsR)[i] = ok[k] ? 0 : 1;
+		}
 	}
 }
 
