@@ -61,15 +61,25 @@ class OverlappedGather:
         buf = self.bufs[self.k % len(self.bufs)]
         self.k += 1
         if self.world > 1 and len(self.pending) >= len(self.bufs):
-            self.pending.pop(0).wait()
+            self._wait(self.pending.pop(0))
         return buf
+
+    @staticmethod
+    def _wait(work):
+        if work is not None:
+            work.wait()
 
     def submit(self, buf):
         if self.world > 1:
             g = self.gbufs[(self.k - 1) % len(self.gbufs)]
-            self.pending.append(dist.all_gather_into_tensor(g, buf, group=self.group, async_op=True))
+            try:
+                work = dist.all_gather_into_tensor(g, buf, group=self.group, async_op=True)
+            except (RuntimeError, NotImplementedError):   # a backend without async collectives: gather in line
+                dist.all_gather_into_tensor(g, buf, group=self.group)
+                work = None
+            self.pending.append(work)
             self.gathered = g
 
     def drain(self):
         while self.pending:
-            self.pending.pop(0).wait()
+            self._wait(self.pending.pop(0))
