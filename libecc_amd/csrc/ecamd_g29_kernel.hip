@@ -631,7 +631,7 @@ struct DecXY {
 	FM ym;
 	bool ok;
 };
-static __device__ DecXY decode_xy(const EcamdEdDecodeArgs &A, const u8 *src, const CK &K)
+static __device__ __forceinline__ DecXY decode_xy(const EcamdEdDecodeArgs &A, const u8 *src, const CK &K)
 {
 	DecXY R;
 	u32 yw[8];
