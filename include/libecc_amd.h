@@ -191,6 +191,15 @@ int ec_prj_pt_mul_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n
 int ec_prj_pt_unique_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *points, int in_fmt,
 			   uint8_t *out, int out_fmt, uint8_t *status);
 
+/* Structured public keys, batch form of ec_structured_pub_key_import_from_buf (sig/ec_key.c:312): each key is
+ * 3 header bytes -- EC_PUBKEY (0), the ec_alg_type the key is for (ECDSA = 1, ...), libecc's ec_curve_type -- followed by
+ * the projective X || Y || Z of ec_pub_key_export_to_buf.  Checks the header, imports (prj_pt_import_from_buf), checks the
+ * subgroup on cofactor curves (ec_pub_key_import_from_buf :216) and hands back affine X || Y, the format the verification
+ * entry points take.  status ECAMD_ERR where libecc returns -1, ECAMD_INF for a key that is the point at infinity (libecc
+ * imports it; it has no affine form).  Built-in curves only (a user curve has no ec_curve_type). */
+int ec_structured_pub_key_import_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *keys,
+				       uint32_t key_len, int alg_type, uint8_t *out_aff, uint8_t *status);
+
 /* Device-pointer forms of the verification / key-agreement entry points, for callers whose batches
  * already live in HBM (and for sharding a batch over GPUs, one context per device): same semantics and
  * layouts as the host-pointer forms above, every buffer a device pointer, kernels enqueued on

@@ -13,7 +13,7 @@ EXPORTED_SYMBOLS = [
     "ecamd_curve_coord_len", "ecamd_curve_order_len", "ecamd_curve_words", "ec_prj_pt_mul_batch",
     "ec_prj_pt_mul_batch_dev", "ecamd_ctx_synchronize", "ec_prj_pt_add_batch", "ec_prj_pt_dbl_batch",
     "ec_fp_op_batch", "ec_ecdsa_verify_batch", "ec_ecdsa_sign_batch", "ec_ecccdh_derive_batch", "ec_xdh_batch",
-    "ec_prj_pt_mul_batch_fmt", "ec_prj_pt_unique_batch",
+    "ec_prj_pt_mul_batch_fmt", "ec_prj_pt_unique_batch", "ec_structured_pub_key_import_batch",
     "ec_eddsa_verify_batch", "ec_ecdsa_verify_batch_dev", "ec_eddsa_verify_batch_dev", "ec_xdh_batch_dev",
 ]
 
@@ -65,6 +65,7 @@ def load_library():
         L.ec_eddsa_verify_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p]
         L.ec_prj_pt_mul_batch_fmt.argtypes = [vp, vp, u32, u8p, u32, u8p, C.c_int, u8p, C.c_int, u8p]
         L.ec_prj_pt_unique_batch.argtypes = [vp, vp, u32, u8p, C.c_int, u8p, C.c_int, u8p]
+        L.ec_structured_pub_key_import_batch.argtypes = [vp, vp, u32, u8p, u32, C.c_int, u8p, u8p]
         L.ec_ecdsa_verify_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp]
         L.ec_eddsa_verify_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp]
         L.ec_xdh_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp]
@@ -248,3 +249,12 @@ class Curve:
         _chk(self.L, self.L.ec_prj_pt_unique_batch(self.ctx.h, self.h, n, points, in_fmt, out, out_fmt, st),
              "ec_prj_pt_unique_batch")
         return out.raw[:w * n], st.raw[:n]
+
+    def structured_pub_keys(self, keys, alg_type):
+        """libecc's structured public keys (3 header bytes + X || Y || Z) -> affine X || Y + status"""
+        klen = 3 + 3 * self.clen
+        n = len(keys) // klen
+        out, st = C.create_string_buffer(max(1, 2 * self.clen * n)), C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_structured_pub_key_import_batch(self.ctx.h, self.h, n, keys, klen, alg_type, out, st),
+             "ec_structured_pub_key_import_batch")
+        return out.raw[:2 * self.clen * n], st.raw[:n]

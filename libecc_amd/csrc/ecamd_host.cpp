@@ -236,6 +236,7 @@ struct ecamd_curve {
 	int nw;     // 32-bit words per element
 	int slot;   // __constant__ slot: field of definition
 	int qslot;  // __constant__ slot: generator order q as a modulus (-1: protocol ops unavailable)
+	int curve_type;  // libecc's ec_curve_type of a built-in curve (structured keys carry it), 0 for user curves
 	int qnw;    // words of the mod-q kernels: nw, or more when q is longer than p (secp224k1: |q| = 225 > 224)
 	int clen;   // BYTECEIL(pbits)
 	int qlen;   // BYTECEIL(qbits)
@@ -805,6 +806,7 @@ extern "C" int ecamd_curve_by_name(ecamd_ctx *ctx, const char *name, ecamd_curve
 	for (const CurveRow &r : g_curve_rows) {
 		if (strcasecmp(r.name, name) == 0) {
 			ecamd_curve *cv = new ecamd_curve();
+			cv->curve_type = r.type;
 			cv->p = big_from_hex(r.p);
 			cv->a = big_from_hex(r.a);
 			cv->b = big_from_hex(r.b);
@@ -2388,4 +2390,69 @@ extern "C" int ec_prj_pt_unique_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uin
 				      uint8_t *out, int out_fmt, uint8_t *status)
 {
 	return pt_fmt_batch("ec_prj_pt_unique_batch", ctx, cv, n, nullptr, 0, points, in_fmt, out, out_fmt, status, false);
+}
+
+// ------------------------------------------------------------------------------------------
+// structured public keys: ec_structured_pub_key_import_from_buf (sig/ec_key.c:312-345)
+// ------------------------------------------------------------------------------------------
+extern "C" int ec_structured_pub_key_import_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *keys,
+						  uint32_t key_len, int alg_type, uint8_t *out_aff, uint8_t *status)
+{
+	if (!ctx || !cv || cv->ctx != ctx || (n && (!keys || !out_aff || !status))) {
+		return fail("ec_structured_pub_key_import_batch: bad argument");
+	}
+	const size_t clen = (size_t)cv->clen, plen = 3 * clen, alen = 2 * clen;
+	if (key_len != 3 + plen) {
+		return fail("ec_structured_pub_key_import_batch: key_len must be 3 + 3 * coordinate length");
+	}
+	if (cv->curve_type <= 0) {
+		return fail("ec_structured_pub_key_import_batch: the curve handle is not one of libecc's built-in curves");
+	}
+	if (n == 0) {
+		return 0;
+	}
+	// header: EC_PUBKEY (0), the signature / ECDH algorithm, the curve type (sig/ec_key.h:31, lib_ecc_types.h)
+	std::vector<uint8_t> hdr_bad(n), packed((size_t)n * plen);
+	for (uint32_t i = 0; i < n; i++) {
+		const uint8_t *k = keys + (size_t)i * key_len;
+		hdr_bad[i] = (k[0] != 0 || k[1] != (uint8_t)alg_type || k[2] != (uint8_t)cv->curve_type) ? 1 : 0;
+		memcpy(&packed[(size_t)i * plen], k + 3, plen);
+	}
+	// ec_pub_key_import_from_buf (:216-245): prj_pt_import_from_buf, then [q]Y = infinity when the cofactor is not 1
+	if (pt_fmt_batch("ec_structured_pub_key_import_batch", ctx, cv, n, nullptr, 0, packed.data(), 1, out_aff, 0, status, false)) {
+		return -1;
+	}
+	if (big_cmp(cv->order, cv->q) != 0) {
+		std::vector<uint8_t> qb((size_t)n * cv->qlen), tmp((size_t)n * alen), st(n);
+		for (uint32_t i = 0; i < n; i++) {
+			big_to_be(&qb[(size_t)i * cv->qlen], cv->qlen, cv->q);
+		}
+		if (ec_prj_pt_mul_batch(ctx, cv, n, qb.data(), (uint32_t)cv->qlen, out_aff, tmp.data(), st.data())) {
+			return -1;
+		}
+		for (uint32_t i = 0; i < n; i++) {
+			if (status[i] == 0 && st[i] != 2) {
+				status[i] = 1;  // not in the subgroup of the generator
+			}
+			if (status[i] == 2) {
+				// infinity (0 : Y : 0) passes check_prj_pt_order; the degenerate (0 : 0 : 0) fails in its additions
+				bool allzero = true;
+				for (size_t b = 0; b < plen && allzero; b++) {
+					allzero = packed[(size_t)i * plen + b] == 0;
+				}
+				if (allzero) {
+					status[i] = 1;
+				}
+			}
+		}
+	}
+	for (uint32_t i = 0; i < n; i++) {
+		if (hdr_bad[i]) {
+			status[i] = 1;
+		}
+		if (status[i] != 0) {
+			memset(out_aff + (size_t)i * alen, 0, alen);
+		}
+	}
+	return 0;
 }

@@ -633,3 +633,37 @@ int refdrv_eddsa448_verify_batch(uint32_t n, const uint8_t *pubs, const uint8_t 
 	}
 	return 0;
 }
+
+/* ---- structured public keys: ec_structured_pub_key_import_from_buf (sig/ec_key.c:312) -> affine X || Y ----
+ * status 0 ok / 1 the import returned -1 / 2 imported, but the key is the point at infinity (no affine form) */
+int refdrv_structured_pub_import_batch(const char *curve, int alg, uint32_t n, const uint8_t *keys, uint32_t klen,
+				       uint8_t *out_aff, uint8_t *status)
+{
+	ec_params params;
+	uint32_t i, clen;
+	if (load_params(curve, &params)) {
+		return -1;
+	}
+	clen = (uint32_t)BYTECEIL(params.ec_fp.p_bitlen);
+	for (i = 0; i < n; i++) {
+		ec_pub_key pub;
+		int ret, iszero = 0;
+		status[i] = 1;
+		memset(out_aff + (size_t)i * 2 * clen, 0, 2 * clen);
+		ret = ec_structured_pub_key_import_from_buf(&pub, &params, keys + (size_t)i * klen, (u8)klen, (ec_alg_type)alg);
+		if (ret) {
+			continue;
+		}
+		ret = prj_pt_iszero(&pub.y, &iszero);
+		if (ret) {
+			continue;
+		}
+		if (iszero) {
+			status[i] = 2;
+			continue;
+		}
+		ret = ec_pub_key_export_to_aff_buf(&pub, out_aff + (size_t)i * 2 * clen, (u8)(2 * clen));
+		status[i] = ret ? 1 : 0;
+	}
+	return 0;
+}

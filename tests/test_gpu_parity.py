@@ -1061,3 +1061,20 @@ def test_eddsa448_verify_vs_oracle_and_golden(gpu_ctx):
         assert bytes(dr.cpu().numpy()) == exp
     finally:
         cv.free()
+
+
+@pytest.mark.parametrize("curve", ["SECP256R1", "BRAINPOOLP384R1", "WEI25519"])
+def test_structured_pub_keys(gpu_ctx, curve):
+    """ec_structured_pub_key_import_from_buf as a batch: header, projective import, subgroup check; the affine keys
+    it returns feed ECDSA verification"""
+    import oracles as O
+    from test_oracle import structured_key_cases
+    rng = np.random.default_rng(61)
+    keys = structured_key_cases(curve, rng, nrand=40)
+    exp = O.structured_pub_expect(curve, keys, 1)
+    cv = gpu_ctx.curve(curve)
+    try:
+        assert cv.structured_pub_keys(keys, 1) == exp
+        assert cv.structured_pub_keys(keys, 6)[1][0] == 1      # keys made for another algorithm
+    finally:
+        cv.free()

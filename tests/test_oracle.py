@@ -461,3 +461,47 @@ def test_eddsa448_vs_reference():
     assert got[:8] == bytes(8) and got[8] == 0 and got[11] == 0 and got[14] == 0 and 1 in got
     if have_ref():
         assert got == O.ref_ed448_verify(pubs, sigs, msgs, ED448_MSG_LEN)
+
+
+def structured_key_cases(curve, rng, nrand=12):
+    """libecc structured public keys: 3 header bytes + X || Y || Z.  Valid keys in scaled projective form, wrong
+    header bytes, keys outside the subgroup (cofactor curves), off-curve triples, infinity"""
+    pts, _, _ = prj_cases(curve, rng, nrand)
+    c = CURVES[curve]
+    cl = (c["p"].bit_length() + 7) // 8
+    n = len(pts) // (3 * cl)
+    keys = bytearray()
+    for i in range(n):
+        hdr = bytearray([0, 1, c["type"]])
+        if i == 1:
+            hdr[0] = 1          # EC_PRIVKEY
+        if i == 2:
+            hdr[1] = 6          # another algorithm
+        if i == 3:
+            hdr[2] = (c["type"] % 40) + 1   # another curve
+        keys += hdr + pts[3 * cl * i:3 * cl * (i + 1)]
+    if c["order"] != c["q"]:
+        # a point outside the generator's subgroup: G + (point of order 2), projective with Z = 1
+        o = Oracle(curve)
+        p, a = c["p"], c["a"]
+        # the order-2 point of the Weierstrass models of curve25519 / curve448 is (A/3, 0)
+        A = 486662 if cl == 32 else 156326
+        t2x = A * pow(3, p - 2, p) % p
+        assert (t2x ** 3 + a * t2x + c["b"]) % p == 0
+        gx, gy = c["gx"], c["gy"]
+        lam = (0 - gy) * pow(t2x - gx, p - 2, p) % p
+        x3 = (lam * lam - gx - t2x) % p
+        y3 = (lam * (gx - x3) - gy) % p
+        keys += bytes([0, 1, c["type"]]) + b"".join(v.to_bytes(cl, "big") for v in (x3, y3, 1))
+    return bytes(keys)
+
+
+@pytest.mark.parametrize("curve", ["SECP256R1", "BRAINPOOLP384R1", "WEI25519"])
+def test_structured_pub_keys_vs_reference(curve):
+    """the python expectation used by the GPU test (header, import, subgroup) against the unmodified reference"""
+    rng = np.random.default_rng(61)
+    keys = structured_key_cases(curve, rng)
+    exp = O.structured_pub_expect(curve, keys, 1)
+    assert 0 in exp[1] and 1 in exp[1] and 2 in exp[1] and exp[1][1:4] == bytes([1, 1, 1])
+    if have_ref():
+        assert exp == O.ref_structured_pub_import(curve, keys, 1)
