@@ -505,3 +505,26 @@ def test_structured_pub_keys_vs_reference(curve):
     assert 0 in exp[1] and 1 in exp[1] and 2 in exp[1] and exp[1][1:4] == bytes([1, 1, 1])
     if have_ref():
         assert exp == O.ref_structured_pub_import(curve, keys, 1)
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref/libecc_ref.so not built")
+def test_oracle_vs_reference_property():
+    """property test (hypothesis): for arbitrary scalar bytes of arbitrary length and points [t]G, on curves of
+    different shapes, the restatement and the unmodified reference return the same bytes and status"""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    curves = ["SECP256R1", "BRAINPOOLP256R1", "WEI25519", "SECP224K1"]
+    libs = {c: (Oracle(c), RefLib(c)) for c in curves}
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(st.sampled_from(curves), st.binary(min_size=1, max_size=40), st.binary(min_size=1, max_size=33))
+    def check(curve, scalar, tbytes):
+        o, r = libs[curve]
+        t = tbytes.rjust(o.qlen, b"\0")[-o.qlen:]
+        base = o.scalar_mult(t)
+        assert base == r.scalar_mult(t)
+        if base[1] == b"\0":
+            assert o.scalar_mult(scalar, base[0], len(scalar)) == r.scalar_mult(scalar, base[0], len(scalar))
+        assert o.scalar_mult(scalar, None, len(scalar)) == r.scalar_mult(scalar, None, len(scalar))
+
+    check()
