@@ -1237,6 +1237,16 @@ extern "C" int ec_fp_op_batch(ecamd_ctx *ctx, const ecamd_curve *cv, int op, uin
 static int ecdsa_two_smul_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_pub,
 			      const uint8_t *d_sig, const uint8_t *d_dig, uint32_t hlen, uint8_t *d_res, hipStream_t s)
 {
+	if (n > ctx->max_chunk) {  // bound the scratch: pieces of max_chunk items, in order on the stream
+		for (uint32_t off = 0; off < n; off += ctx->max_chunk) {
+			const uint32_t m = (n - off) < ctx->max_chunk ? (n - off) : ctx->max_chunk;
+			if (ecdsa_two_smul_dev(ctx, cv, m, d_pub + (size_t)off * 2 * cv->clen, d_sig + (size_t)off * 2 * cv->qlen,
+					       d_dig + (size_t)off * hlen, hlen, d_res + off, s)) {
+				return -1;
+			}
+		}
+		return 0;
+	}
 	const size_t plen = (size_t)2 * cv->clen, ql = (size_t)cv->qlen;
 	// stage: 3 u1, 4 u2, 5 A, 6 B, 7 stA, 8 stB, 9 flags, 10 subgroup status, 11 q scalar / tmp
 	const size_t need[12] = {0, 0, 0, n * ql, n * ql, n * plen, n * plen, n, n, n, n, n * plen + 256};
@@ -1710,6 +1720,16 @@ static void xdh_setup(ecamd_curve *cv)
 static int xdh_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_k, const uint8_t *d_u,
 			  uint8_t *d_out, uint8_t *d_status, hipStream_t s)
 {
+	if (n > ctx->max_chunk) {  // bound the scratch: pieces of max_chunk items, in order on the stream
+		for (uint32_t off = 0; off < n; off += ctx->max_chunk) {
+			const uint32_t m = (n - off) < ctx->max_chunk ? (n - off) : ctx->max_chunk;
+			const size_t l = (size_t)cv->clen;
+			if (xdh_dev_locked(ctx, cv, m, d_k + off * l, d_u + off * l, d_out + off * l, d_status + off, s)) {
+				return -1;
+			}
+		}
+		return 0;
+	}
 	const size_t len = (size_t)cv->clen, plen = 2 * len;
 	// stage: 2 scalars BE, 3 points, 4 flags, 7 [k]Q, 8 stk   (0, 1, 9, 10 belong to the host-pointer wrapper)
 	const size_t need[ECAMD_NSTAGE] = {0, 0, n * len, n * plen, n, 0, 0, n * plen, n};
@@ -1936,6 +1956,16 @@ static void ed_setup(ecamd_curve *cv)
 static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig,
 				   const uint8_t *d_hram, uint32_t hram_len, uint8_t *d_res, hipStream_t s)
 {
+	if (n > ctx->max_chunk) {  // bound the scratch: pieces of max_chunk items, in order on the stream
+		for (uint32_t off = 0; off < n; off += ctx->max_chunk) {
+			const uint32_t m = (n - off) < ctx->max_chunk ? (n - off) : ctx->max_chunk;
+			if (eddsa_verify_dev_locked(ctx, cv, m, d_pub + (size_t)off * 32, d_sig + (size_t)off * 64,
+						    d_hram + (size_t)off * hram_len, hram_len, d_res + off, s)) {
+				return -1;
+			}
+		}
+		return 0;
+	}
 	const size_t len = 32, plen = 64;
 	const uint32_t cof_dbl = cv->ed_cof_dbl;
 	// stage: 3 A (Weierstrass), 4 R, 5 flagsA, 6 flagsR, 7 flagsS, 8 S, 9 h, 12 [h]A, 13 sthA, 14 [S]G, 15 stSG
@@ -2136,6 +2166,16 @@ static void ed448_setup(ecamd_curve *cv)
 static int eddsa448_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig,
 				      const uint8_t *d_hram, uint8_t *d_res, hipStream_t s)
 {
+	if (n > ctx->max_chunk) {  // bound the scratch: pieces of max_chunk items, in order on the stream
+		for (uint32_t off = 0; off < n; off += ctx->max_chunk) {
+			const uint32_t m = (n - off) < ctx->max_chunk ? (n - off) : ctx->max_chunk;
+			if (eddsa448_verify_dev_locked(ctx, cv, m, d_pub + (size_t)off * 57, d_sig + (size_t)off * 114,
+						       d_hram + (size_t)off * 114, d_res + off, s)) {
+				return -1;
+			}
+		}
+		return 0;
+	}
 	const size_t len = 56, plen = 112;
 	// stage: 3 A (Weierstrass), 4 R, 5 flagsA, 6 flagsR, 7 flagsS, 8 S, 9 h, 10 [4^-1]A, 11 its status, 12 [h]A, 13 sthA,
 	//        14 [S]G, 15 stSG, 17 the scalar 4^-1 mod q   (0..2 and 16 belong to the host-pointer wrapper)

@@ -1078,3 +1078,64 @@ def test_structured_pub_keys(gpu_ctx, curve):
         assert cv.structured_pub_keys(keys, 6)[1][0] == 1      # keys made for another algorithm
     finally:
         cv.free()
+
+
+def test_device_cores_chunked_by_max_chunk(gpu_ctx):
+    """device-pointer forms bound their scratch by processing at most max_chunk items at a time: a context with a
+    small max_chunk gives the same bytes (Ed25519, Ed448, X25519, ECDSA on a two-scalar-mult curve and on secp256r1)"""
+    import torch
+    import libecc_amd
+    from test_oracle import ed25519_cases, ed448_cases
+    rng = np.random.default_rng(40)
+    dev = torch.device("cuda:0")
+    ctx2 = libecc_amd.Context(0)
+    ctx2.set_max_chunk(300)
+    t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    try:
+        n = 1000
+        for curve, gen, kl, sl, hl in (("WEI25519", ed25519_cases, 32, 64, 64), ("WEI448", ed448_cases, 57, 114, 114)):
+            pubs, sigs, msgs, hram = gen(rng, 6)
+            n0 = len(pubs) // kl
+            reps = n // n0 + 1
+            P, S, H = (pubs * reps)[:kl * n], (sigs * reps)[:sl * n], (hram * reps)[:hl * n]
+            a, b = gpu_ctx.curve(curve), ctx2.curve(curve)
+            try:
+                exp = a.eddsa_verify(P, S, H)
+                dp, ds, dh = t(P), t(S), t(H)
+                dr = torch.full((n,), 0xAA, dtype=torch.uint8, device=dev)
+                torch.cuda.synchronize()
+                b.eddsa_verify_dev(n, dp.data_ptr(), ds.data_ptr(), dh.data_ptr(), dr.data_ptr(), None, hl)
+                ctx2.synchronize()
+                assert bytes(dr.cpu().numpy()) == exp and 0 in exp and 1 in exp
+                if curve == "WEI25519":
+                    k = rand_bytes(rng, 32 * n)
+                    pub, st = a.xdh(k, (9).to_bytes(32, "little") * n)
+                    exp2 = a.xdh(k[::-1], pub)
+                    dk, du = t(k[::-1]), t(pub)
+                    do, dst = torch.empty(32 * n, dtype=torch.uint8, device=dev), torch.empty(n, dtype=torch.uint8, device=dev)
+                    torch.cuda.synchronize()
+                    b.xdh_dev(n, dk.data_ptr(), du.data_ptr(), do.data_ptr(), dst.data_ptr(), None)
+                    ctx2.synchronize()
+                    assert (bytes(do.cpu().numpy()), bytes(dst.cpu().numpy())) == exp2
+            finally:
+                a.free()
+                b.free()
+        for curve in ("BRAINPOOLP256R1", "SECP256R1"):
+            o, pubs, sigs, dg, hl, _ = make_sigs(curve, "SHA256", 50, rng)
+            reps = n // 50
+            P, S, D = pubs * reps, bytearray(sigs * reps), dg * reps
+            for i in range(0, n, 7):
+                S[2 * o.qlen * i + 9] ^= 1
+            a, b = gpu_ctx.curve(curve), ctx2.curve(curve)
+            try:
+                exp = a.ecdsa_verify(P, bytes(S), D, hl)
+                dp, ds, dd = t(P), t(bytes(S)), t(D)
+                dr = torch.full((n,), 0xAA, dtype=torch.uint8, device=dev)
+                torch.cuda.synchronize()
+                b.ecdsa_verify_dev(n, dp.data_ptr(), ds.data_ptr(), dd.data_ptr(), hl, dr.data_ptr(), None)
+                assert bytes(dr.cpu().numpy()) == exp and 0 in exp and 1 in exp
+            finally:
+                a.free()
+                b.free()
+    finally:
+        ctx2.close()
