@@ -916,7 +916,13 @@ static void maybe_build_comb(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n)
 	bool ok = hipMalloc((void **)&dsc, hs.size()) == hipSuccess && hipMalloc((void **)&dpt, (size_t)ne * plen) == hipSuccess &&
 		  hipMalloc((void **)&dst, ne) == hipSuccess && hipMalloc((void **)&table, (size_t)ne * ew * 4) == hipSuccess &&
 		  hipMemcpy(dsc, hs.data(), hs.size(), hipMemcpyHostToDevice) == hipSuccess;
-	ok = ok && smul_dev_locked(ctx, cv, ne, dsc, slen, nullptr, dpt, dst, s) == 0;
+	{
+		// the build is one big batch of its own: do not let a small user chunk turn it into thousands of launches
+		const uint32_t user_chunk = ctx->max_chunk;
+		ctx->max_chunk = user_chunk < (1u << 20) ? (1u << 20) : user_chunk;
+		ok = ok && smul_dev_locked(ctx, cv, ne, dsc, slen, nullptr, dpt, dst, s) == 0;
+		ctx->max_chunk = user_chunk;
+	}
 	if (ok) {
 		const hipError_t e = p256 ? ecamd_launch_comb_build_p256(dpt, ne, table, s)
 					  : ecamd_g29_comb_build(cv->pbits, cv->gslot, dpt, ne, (uint32_t)cv->clen, table, s, cv->gflavour);
