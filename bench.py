@@ -79,6 +79,8 @@ def work_model(curve_params, nw, slen):
         M, S = 2 * nl * nl, nl * (nl + 1) // 2 + nl * nl
         if p == 2**521 - 1:                          # secp521r1 flavour: one reduction MAD per digit
             M, S = nl * nl + nl, nl * (nl + 1) // 2 + nl
+        if pbits == 384 and p % (1 << 29) == (1 << 29) - 1:   # p = -1 mod 2^29 flavour: no m p_0 product per quotient digit
+            M, S = M - nl, S - nl
         if p == 2**255 - 19:                         # 2^255 - 19 flavour: 9 limbs, 9 + 1 fold MADs + 1 (x 19)
             nl = 9
             M, S = nl * nl + nl + 2, nl * (nl + 1) // 2 + nl + 2

@@ -520,6 +520,9 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_finalize_g(E
 #elif defined(G29_P25519)
 #define G29_TAG G29_CAT(G29_PB, c)   /* 255c: p = 2^255 - 19 beside the dense 255-bit unit */
 #define G29_FLAV 2
+#elif defined(G29_MPINV1)
+#define G29_TAG G29_CAT(G29_PB, n)   /* 384n: primes that are -1 mod 2^29 (secp384r1) beside the dense 384-bit unit */
+#define G29_FLAV 3
 #else
 #define G29_FLAV 0
 #define G29_TAG G29_PB
@@ -1395,6 +1398,7 @@ hipError_t G29_CAT(ecamd_g29_comb_build_, G29_TAG)(int gslot, const uint8_t *pts
 G29_FOR_PB(X)
 X(521m)
 X(255c)
+X(384n)
 #undef X
 
 int ecamd_g29_supported(int pbits)
@@ -1427,6 +1431,9 @@ hipError_t ecamd_g29_upload(int pbits, int slot, const void *img, size_t bytes, 
 	if (pbits == 255 && flavour == 2) {
 		return ecamd_g29_upload_255c(slot, img, bytes);
 	}
+	if (pbits == 384 && flavour == 3) {
+		return ecamd_g29_upload_384n(slot, img, bytes);
+	}
 	switch (pbits) {
 #define X(PB) case PB: return ecamd_g29_upload_##PB(slot, img, bytes);
 		G29_FOR_PB(X)
@@ -1445,6 +1452,9 @@ hipError_t ecamd_launch_smul_g29(int pbits, int gslot, const EcamdSmulArgs &a, h
 	}
 	if (pbits == 255 && flavour == 2) {
 		return ecamd_g29_launch_255c(gslot, a, s, ev);
+	}
+	if (pbits == 384 && flavour == 3) {
+		return ecamd_g29_launch_384n(gslot, a, s, ev);
 	}
 	switch (pbits) {
 #define X(PB) case PB: return ecamd_g29_launch_##PB(gslot, a, s, ev);
@@ -1470,6 +1480,9 @@ hipError_t ecamd_g29_comb_build(int pbits, int gslot, const uint8_t *pts, uint32
 	}
 	if (pbits == 255 && flavour == 2) {
 		return ecamd_g29_comb_build_255c(gslot, pts, n, clen, table, s);
+	}
+	if (pbits == 384 && flavour == 3) {
+		return ecamd_g29_comb_build_384n(gslot, pts, n, clen, table, s);
 	}
 	switch (pbits) {
 #define X(PB) case PB: return ecamd_g29_comb_build_##PB(gslot, pts, n, clen, table, s);

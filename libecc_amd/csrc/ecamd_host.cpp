@@ -260,7 +260,7 @@ struct ecamd_curve {
 	uint8_t xdh_cof;
 	bool is_p256;    // exactly secp256r1: hand-specialised radix-2^29 Jacobian kernel
 	int gslot;       // constant slot of the generic radix-2^29 Jacobian kernel (-1: none)
-	int gflavour;    // 0 dense reduction, 1 secp521r1 (p = 2^521 - 1) single-digit reduction
+	int gflavour;    // 0 dense reduction, 1 secp521r1 (p = 2^521 - 1), 2 p = 2^255 - 19, 3 p = -1 mod 2^29 at 384 bits
 	uint32_t *d_gtab; // secp256r1: affine window table [1..8]G, radix-2^29 Montgomery digits, 8 x 40 words
 	uint32_t *d_comb; // fast paths: 16-bit comb table of G, built on the first large fixed-base batch (NULL before / disabled)
 	bool comb_off;    // construction failed or is in progress: do not try (again)
@@ -563,7 +563,7 @@ static int upload_g29(ecamd_curve *cv)
 	// (the brainpool r1 curves -- their t1 twins are these images --, two GOST 512-bit sets); ECAMD_NO_ISO disables it.
 	Big u(1, 1);
 	Big a_img = cv->a, b_img = cv->b;
-	if (cv->gflavour == 0 && (p[0] & 3u) == 3u && big_bitlen(cv->a) > 0 && big_cmp(big_add(cv->a, three), p) != 0 &&
+	if ((cv->gflavour == 0 || cv->gflavour == 3) && (p[0] & 3u) == 3u && big_bitlen(cv->a) > 0 && big_cmp(big_add(cv->a, three), p) != 0 &&
 	    getenv("ECAMD_NO_ISO") == nullptr) {
 		Big e = big_add(p, Big(1, 1));  // (p + 1) / 4
 		Big q4(e.size(), 0);
@@ -715,6 +715,9 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	cv->gflavour = (cv->pbits == 521 && big_cmp(big_add(cv->p, Big(1, 1)), big_pow2(521)) == 0) ? 1 : 0;
 	if (cv->pbits == 255 && big_cmp(big_add(cv->p, Big(1, 19)), big_pow2(255)) == 0 && getenv("ECAMD_NO_P25519") == nullptr) {
 		cv->gflavour = 2;
+	}
+	if (cv->pbits == 384 && (cv->p[0] & 0x1fffffffu) == 0x1fffffffu && getenv("ECAMD_NO_MPINV1") == nullptr) {
+		cv->gflavour = 3;  // p = -1 mod 2^29 (secp384r1): quotient digits without a multiplication
 	}
 	if (!cv->is_p256 && ecamd_g29_supported(cv->pbits) && cv->pbits < 640 && getenv("ECAMD_NO_FAST_PATH") == nullptr) {
 		for (int i = 0; i < ecamd_g29_slots(); i++) {

@@ -58,6 +58,14 @@ constexpr bool P25519 = true;
 #else
 constexpr bool P25519 = false;
 #endif
+//   -DG29_MPINV1       p = -1 mod 2^29 (secp384r1): the Montgomery quotient digit of a column is its low digit and
+//                      "+ m p_0" = "- m + m 2^29" clears it -- no multiplication in the quotient step.  (It has to be a
+//                      compile-time flavour: a wave-uniform branch inside the multiplier cost 25-45 %.)
+#if defined(G29_MPINV1)
+constexpr bool MPINV1 = true;
+#else
+constexpr bool MPINV1 = false;
+#endif
 
 constexpr int nl_for(int pbits) { return (pbits + 16 + W - 1) / W; }
 constexpr int nl_for_flavour(int pbits, int flavour) { return flavour == 2 ? 9 : nl_for(pbits); }
@@ -263,7 +271,12 @@ template <int NL, bool SQR, int K_> G29_FN void mul_column(u64 &acc, u32 *m, u32
 		if constexpr (C::USES2_PROD || C::USES2_RED) {
 			acc += acc2;
 		}
-		if constexpr (K_ < NL) {
+		if constexpr (K_ < NL && MPINV1) {
+			const u32 mk = (u32)acc & MASK;
+			m[K_] = mk;
+			acc = (acc >> W) + mk;
+			return;
+		} else if constexpr (K_ < NL) {
 			m[K_] = ((u32)acc * mpinv) & MASK;
 			mad_chain<1, false, true>(acc, acc2, &m[K_], &p[0]);
 		} else {

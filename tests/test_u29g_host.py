@@ -201,3 +201,19 @@ def test_secp521r1_mersenne_flavour(lib_m521):
 def test_p25519_flavour(lib_p25519):
     test_field_ops(lib_p25519, "WEI25519", 2)
     test_jacobian(lib_p25519, "WEI25519", 2)
+
+
+@pytest.fixture(scope="module")
+def lib_n384():
+    """the p = -1 mod 2^29 flavour (quotient digits without a multiplication) of the 384-bit unit"""
+    os.makedirs(BUILD, exist_ok=True)
+    so = os.path.join(BUILD, "u29g_host_n384.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DG29_MPINV1", "-DSHIM_ONLY_384", "-o", so,
+                           os.path.join(ROOT, "tests", "u29g_host_shim.cpp")])
+    return C.CDLL(so)
+
+
+def test_secp384r1_mpinv1_flavour(lib_n384):
+    assert CURVES["SECP384R1"]["p"] % (1 << 29) == (1 << 29) - 1
+    test_field_ops(lib_n384, "SECP384R1")
+    test_jacobian(lib_n384, "SECP384R1")

@@ -102,6 +102,8 @@ template <int PB> struct Shim {
 	}
 #if defined(SHIM_ONLY_255)
 SHIM(255)
+#elif defined(SHIM_ONLY_384)
+SHIM(384)
 #elif !defined(SHIM_ONLY_521)
 SHIM(192)
 SHIM(224)
@@ -113,6 +115,6 @@ SHIM(448)
 SHIM(511)
 SHIM(512)
 #endif
-#if !defined(SHIM_ONLY_255)
+#if !defined(SHIM_ONLY_255) && !defined(SHIM_ONLY_384)
 SHIM(521)
 #endif
