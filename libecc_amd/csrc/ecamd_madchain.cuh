@@ -4,7 +4,7 @@
 // hipcc pads every inline-asm statement that defines registers with an s_nop; with one statement per
 // product that is one s_nop per v_mad_u64_u32, which a kernel running one wave per SIMD (the large
 // fields: 256 VGPRs) cannot hide -- measured ~30 % of its time there.  ecamd_mad_chain<N, DUAL, YS> adds N
-// products x[i] * y[i] to the 64-bit accumulator(s) in statements of up to eight instructions.
+// products x[i] * y[i] to the 64-bit accumulator(s) in statements of up to twelve instructions (the operand limit of an asm statement is 30).
 //   DUAL: products alternate between acc and acc2 (10 cycles result latency against 5.3 cycles issue: two
 //         independent chains keep a lone wave issuing); the caller adds the two at the end of a column;
 //   YS:   the second factors are wave-uniform and go in SGPRs (digits of p, reduction constants).
@@ -26,7 +26,112 @@ ECAMD_CHAIN_FN void ecamd_mad_chain(uint64_t &acc, uint64_t &acc2, const uint32_
 {
 	uint64_t dead_;
 	(void)acc2;
-	if constexpr (N >= 8) {
+	if constexpr (N >= 12) {
+		if constexpr (DUAL && YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_mad_u64_u32 %1, %2, %21, %22, %1\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_mad_u64_u32 %1, %2, %25, %26, %1"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]), "v"(x[10]), "s"(y[10]), "v"(x[11]), "s"(y[11]));
+		} else if constexpr (DUAL && YS && !Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_mad_u64_u32 %1, %2, %21, %22, %1\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_mad_u64_u32 %1, %2, %25, %26, %1"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]), "v"(x[10]), "s"(y[10]), "v"(x[11]), "s"(y[11]));
+		} else if constexpr (DUAL && !YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_mad_u64_u32 %1, %2, %21, %22, %1\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_mad_u64_u32 %1, %2, %25, %26, %1"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10]), "v"(x[11]), "v"(y[11]));
+		} else if constexpr (DUAL && !YS && !Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_mad_u64_u32 %1, %2, %21, %22, %1\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_mad_u64_u32 %1, %2, %25, %26, %1"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10]), "v"(x[11]), "v"(y[11]));
+		} else if constexpr (!DUAL && YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]), "v"(x[10]), "s"(y[10]), "v"(x[11]), "s"(y[11]));
+		} else if constexpr (!DUAL && !YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10]), "v"(x[11]), "v"(y[11]));
+		}
+		ecamd_mad_chain<N - 12, DUAL, YS, false>(acc, acc2, x + 12, y + 12);
+	} else if constexpr (N == 11) {
+		if constexpr (DUAL && YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_mad_u64_u32 %1, %2, %21, %22, %1\n\tv_mad_u64_u32 %0, %2, %23, %24, %0"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]), "v"(x[10]), "s"(y[10]));
+		} else if constexpr (DUAL && YS && !Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_mad_u64_u32 %1, %2, %21, %22, %1\n\tv_mad_u64_u32 %0, %2, %23, %24, %0"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]), "v"(x[10]), "s"(y[10]));
+		} else if constexpr (DUAL && !YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_mad_u64_u32 %1, %2, %21, %22, %1\n\tv_mad_u64_u32 %0, %2, %23, %24, %0"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10]));
+		} else if constexpr (DUAL && !YS && !Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_mad_u64_u32 %1, %2, %21, %22, %1\n\tv_mad_u64_u32 %0, %2, %23, %24, %0"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10]));
+		} else if constexpr (!DUAL && YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]), "v"(x[10]), "s"(y[10]));
+		} else if constexpr (!DUAL && !YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10]));
+		}
+	} else if constexpr (N == 10) {
+		if constexpr (DUAL && YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_mad_u64_u32 %1, %2, %21, %22, %1"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]));
+		} else if constexpr (DUAL && YS && !Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_mad_u64_u32 %1, %2, %21, %22, %1"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]));
+		} else if constexpr (DUAL && !YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_mad_u64_u32 %1, %2, %21, %22, %1"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]));
+		} else if constexpr (DUAL && !YS && !Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_mad_u64_u32 %1, %2, %21, %22, %1"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]));
+		} else if constexpr (!DUAL && YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]));
+		} else if constexpr (!DUAL && !YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]));
+		}
+	} else if constexpr (N == 9) {
+		if constexpr (DUAL && YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1\n\tv_mad_u64_u32 %0, %2, %19, %20, %0"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]));
+		} else if constexpr (DUAL && YS && !Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1\n\tv_mad_u64_u32 %0, %2, %19, %20, %0"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]));
+		} else if constexpr (DUAL && !YS && Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1\n\tv_mad_u64_u32 %0, %2, %19, %20, %0"
+			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]));
+		} else if constexpr (DUAL && !YS && !Z2) {
+			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, %1\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1\n\tv_mad_u64_u32 %0, %2, %19, %20, %0"
+			    : "+v"(acc), "+v"(acc2), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]));
+		} else if constexpr (!DUAL && YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]));
+		} else if constexpr (!DUAL && !YS) {
+			asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
+			    : "+v"(acc), "=&s"(dead_)
+			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]));
+		}
+	} else if constexpr (N == 8) {
 		if constexpr (DUAL && YS && Z2) {
 			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_mad_u64_u32 %1, %2, %17, %18, %1"
 			    : "+v"(acc), "=&v"(acc2), "=&s"(dead_)
@@ -52,7 +157,6 @@ ECAMD_CHAIN_FN void ecamd_mad_chain(uint64_t &acc, uint64_t &acc2, const uint32_
 			    : "+v"(acc), "=&s"(dead_)
 			    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]));
 		}
-		ecamd_mad_chain<N - 8, DUAL, YS, false>(acc, acc2, x + 8, y + 8);
 	} else if constexpr (N == 7) {
 		if constexpr (DUAL && YS && Z2) {
 			asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_mad_u64_u32 %1, %2, %5, %6, 0\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_mad_u64_u32 %1, %2, %9, %10, %1\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_mad_u64_u32 %1, %2, %13, %14, %1\n\tv_mad_u64_u32 %0, %2, %15, %16, %0"

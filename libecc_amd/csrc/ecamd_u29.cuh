@@ -145,7 +145,7 @@ template <u64 VBO> struct MulOut {
 #endif
 
 // raw kernels on plain arrays (bounds are checked by the typed wrappers below).  Columns are compile-time
-// indexed so that each one's products and reduction terms go out as asm statements of up to eight MADs
+// indexed so that each one's products and reduction terms go out as asm statements of up to twelve MADs
 // (ecamd_madchain.cuh: one padding s_nop per statement instead of one per MAD).
 template <bool SQR, int K_> struct Col9 {
 	static constexpr int LO = (K_ < 9) ? 0 : (K_ - 8);

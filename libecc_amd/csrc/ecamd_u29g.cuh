@@ -208,20 +208,28 @@ template <int NL, bool SQR, int K_> struct Column {
 	static constexpr int NRED = (RHI >= RLO) ? (RHI - RLO + 1) : 0;
 	static constexpr bool DUAL = NL >= G29_DUAL_FROM_NL;
 	// which chains touch the second accumulator (a chain of one product only uses the first)
-	static constexpr bool USES2_PROD = DUAL && NPROD >= 2;
+	static constexpr bool USES2_PROD = DUAL && (NPROD + ((MERSENNE521 && (K_ - 17 >= 0) && (K_ - 17 < NL)) ? 1 : 0)) >= 2;
 	static constexpr bool USES2_RED = DUAL && NRED >= 2;
 
-	static G29_FN void products(u64 &acc, u64 &acc2, const u32 *a, const u32 *b, const u32 *a2)
+	// secp521r1 flavour: the single reduction product m_(k-17) 2^28 of the column rides in the same chain (its
+	// constant factor sits in a VGPR for that), so a column is one or two asm statements
+	static constexpr bool M521 = MERSENNE521 && (K_ - 17 >= 0) && (K_ - 17 < NL);
+	static constexpr int NCHAIN = NPROD + (M521 ? 1 : 0);
+	static G29_FN void products(u64 &acc, u64 &acc2, const u32 *a, const u32 *b, const u32 *a2, const u32 *m, u32 q17v)
 	{
-		if constexpr (NPROD > 0) {
-			u32 x[NPROD], y[NPROD];
+		if constexpr (NCHAIN > 0) {
+			u32 x[NCHAIN], y[NCHAIN];
 #pragma unroll
 			for (int n = 0; n < NPROD; n++) {
 				const int i = LO + n, j = K_ - i;
 				x[n] = a[i];
 				y[n] = !SQR ? b[j] : (i < j ? a2[j] : a[i]);
 			}
-			mad_chain<NPROD, DUAL, false, true>(acc, acc2, x, y);   // acc2 starts here (zero addend), if it is used at all
+			if constexpr (M521) {
+				x[NPROD] = m[K_ - 17];
+				y[NPROD] = q17v;
+			}
+			mad_chain<NCHAIN, DUAL, false, true>(acc, acc2, x, y);   // acc2 starts here (zero addend), if it is used at all
 		}
 	}
 	static G29_FN void reduction(u64 &acc, u64 &acc2, const u32 *m, const u32 *p)
@@ -239,25 +247,18 @@ template <int NL, bool SQR, int K_> struct Column {
 };
 
 template <int NL, bool SQR, int K_> G29_FN void mul_column(u64 &acc, u32 *m, u32 *r, u32 *t, const u32 *a, const u32 *b,
-							   const u32 *a2, const u32 *p, u32 mpinv)
+							   const u32 *a2, const u32 *p, u32 mpinv, u32 q17v)
 {
 	typedef Column<NL, SQR, K_> C;
 	u64 acc2;  // written by the first chain that uses it (Z2), never read otherwise
-	C::products(acc, acc2, a, b, a2);
+	C::products(acc, acc2, a, b, a2, m, q17v);
 	if constexpr (P25519) {
 		if constexpr (C::USES2_PROD) {
 			acc += acc2;
 		}
 		t[K_] = (u32)acc & MASK;
 	} else if constexpr (MERSENNE521) {
-		// m_(k-17) * 2^28 (p + 1 has its only non-zero digit at limb 17); "- m_k" clears the digit
-		if constexpr (K_ - 17 >= 0 && K_ - 17 < NL) {
-			u32 q17 = 1u << 28;
-#if defined(__HIPCC__)
-			asm volatile("" : "+s"(q17));  // keep it a MAD, not a 64-bit shift + add
-#endif
-			mad_chain<1, false, true>(acc, acc2, &m[K_ - 17], &q17);
-		}
+		// m_(k-17) * 2^28 (p + 1 has its only non-zero digit at limb 17) went in with the products; "- m_k" clears the digit
 		if constexpr (C::USES2_PROD) {
 			acc += acc2;
 		}
@@ -289,9 +290,9 @@ template <int NL, bool SQR, int K_> G29_FN void mul_column(u64 &acc, u32 *m, u32
 
 template <int NL, bool SQR, int... Ks>
 G29_FN void mul_columns(u64 &acc, u32 *m, u32 *r, u32 *t, const u32 *a, const u32 *b, const u32 *a2, const u32 *p, u32 mpinv,
-			std::integer_sequence<int, Ks...>)
+			u32 q17v, std::integer_sequence<int, Ks...>)
 {
-	(mul_column<NL, SQR, Ks>(acc, m, r, t, a, b, a2, p, mpinv), ...);
+	(mul_column<NL, SQR, Ks>(acc, m, r, t, a, b, a2, p, mpinv, q17v), ...);
 }
 
 // r = a b / R mod p (lazy): product scanning with the reduction interleaved.  SQR: a == b, the
@@ -307,7 +308,13 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 		}
 	}
 	u64 acc = 0;
-	mul_columns<NL, SQR>(acc, m, r, t, a, b, a2, p, mpinv, std::make_integer_sequence<int, 2 * NL - 1>());
+	u32 q17v = 1u << 28;  // secp521r1 flavour: the non-zero digit of p + 1, kept opaque so that it stays a MAD operand
+#if defined(__HIPCC__)
+	if (MERSENNE521) {
+		asm volatile("" : "+v"(q17v));
+	}
+#endif
+	mul_columns<NL, SQR>(acc, m, r, t, a, b, a2, p, mpinv, q17v, std::make_integer_sequence<int, 2 * NL - 1>());
 	if constexpr (P25519) {
 		// r = a b mod p, p = 2^255 - 19, value < 2p: the 81 product MADs gave 18 limbs t (17 columns + the
 		// last carry); now t[j] + 1216 t[j + 9] (2^261 = 64 * 2^255 = 1216) with 19 * (bits from 2^255 up)
