@@ -172,6 +172,16 @@ int ec_xdh_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uin
 int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *pubkeys,
 			  const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, uint8_t *result);
 
+/* Whole-batch predicate of ec_verify_batch (sig/sig_algs.c:675; eddsa_verify_batch sig/eddsa.c:2904,
+ * _eddsa_verify_batch_no_memory :2278) for the EdDSA variants: *all_valid = 1 iff libecc's per-signature verification
+ * accepts every item.  libecc decides the same predicate with one random linear combination of the cofactored equations
+ * (it may accept a bad batch with probability ~2^-128; this entry point never does) and rejects num = 0, as this does
+ * (-1).  first_rejected (may be NULL) receives the lowest rejected index, n if none -- the reference gives no such hint and
+ * callers re-verify one by one.  Same inputs as ec_eddsa_verify_batch. */
+int ec_eddsa_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *pubkeys,
+			      const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, int *all_valid,
+			      uint32_t *first_rejected);
+
 /* Point wire formats (curves/prj_pt.c:462-624): affine X || Y (2*clen bytes, what the entry points above
  * use) and projective X || Y || Z (3*clen bytes: prj_pt_import_from_buf / prj_pt_export_to_buf, the format
  * of `ec_utils scalar_mult` and of structured public keys). */

@@ -14,7 +14,7 @@ EXPORTED_SYMBOLS = [
     "ec_prj_pt_mul_batch_dev", "ecamd_ctx_synchronize", "ec_prj_pt_add_batch", "ec_prj_pt_dbl_batch",
     "ec_fp_op_batch", "ec_ecdsa_verify_batch", "ec_ecdsa_sign_batch", "ec_ecccdh_derive_batch", "ec_xdh_batch",
     "ec_prj_pt_mul_batch_fmt", "ec_prj_pt_unique_batch", "ec_structured_pub_key_import_batch",
-    "ec_eddsa_verify_batch", "ec_ecdsa_verify_batch_dev", "ec_eddsa_verify_batch_dev", "ec_xdh_batch_dev",
+    "ec_eddsa_verify_batch", "ec_eddsa_verify_all_batch", "ec_ecdsa_verify_batch_dev", "ec_eddsa_verify_batch_dev", "ec_xdh_batch_dev",
 ]
 
 
@@ -63,6 +63,7 @@ def load_library():
         L.ec_ecdsa_sign_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p, u8p]
         L.ec_xdh_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
         L.ec_eddsa_verify_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p]
+        L.ec_eddsa_verify_all_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
         L.ec_prj_pt_mul_batch_fmt.argtypes = [vp, vp, u32, u8p, u32, u8p, C.c_int, u8p, C.c_int, u8p]
         L.ec_prj_pt_unique_batch.argtypes = [vp, vp, u32, u8p, C.c_int, u8p, C.c_int, u8p]
         L.ec_structured_pub_key_import_batch.argtypes = [vp, vp, u32, u8p, u32, C.c_int, u8p, u8p]
@@ -218,6 +219,16 @@ class Curve:
         _chk(self.L, self.L.ec_eddsa_verify_batch(self.ctx.h, self.h, n, pubkeys, sigs, hram, hram_len, res),
              "ec_eddsa_verify_batch")
         return res.raw[:n]
+
+    def eddsa_verify_all(self, pubkeys, sigs, hram, hram_len=None):
+        """ec_verify_batch's whole-batch predicate: (all_valid, index of the first rejected item or n)"""
+        klen = 57 if self.clen == 56 else self.clen
+        hram_len = hram_len or (114 if self.clen == 56 else 64)
+        n = len(pubkeys) // klen
+        ok, first = C.c_int(0), C.c_uint32(0)
+        _chk(self.L, self.L.ec_eddsa_verify_all_batch(self.ctx.h, self.h, n, pubkeys, sigs, hram, hram_len,
+                                                       C.byref(ok), C.byref(first)), "ec_eddsa_verify_all_batch")
+        return bool(ok.value), first.value
 
     # -- device-pointer forms (torch tensors' data_ptr()); see include/libecc_amd.h for which ones synchronise --
     def ecdsa_verify_dev(self, n, d_pubs, d_sigs, d_digests, hlen, d_result, stream=None):

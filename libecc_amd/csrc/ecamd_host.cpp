@@ -2327,6 +2327,36 @@ extern "C" int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, u
 	});
 }
 
+// Whole-batch predicate of ec_verify_batch (sig/sig_algs.c:675, eddsa_verify_batch sig/eddsa.c:2904): libecc accepts the
+// batch when one random linear combination of the cofactored equations vanishes, which holds when every signature verifies
+// and fails otherwise except with probability ~2^-128 over its random z_i.  Here every item is verified (the batch is the
+// parallel dimension already), so the bit is the exact conjunction and the first rejected index comes for free.
+extern "C" int ec_eddsa_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys,
+					 const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, int *all_valid,
+					 uint32_t *first_rejected)
+{
+	if (!all_valid || n == 0) {
+		return fail("ec_eddsa_verify_all_batch: bad argument (the reference rejects num = 0 too)");
+	}
+	*all_valid = 0;
+	if (first_rejected) {
+		*first_rejected = n;
+	}
+	std::vector<uint8_t> res(n, 1);
+	if (ec_eddsa_verify_batch(ctx, cv, n, pubkeys, sigs, hram, hram_len, res.data())) {
+		return -1;
+	}
+	uint32_t i = 0;
+	while (i < n && res[i] == 0) {   // any non-zero byte is a rejection
+		i++;
+	}
+	*all_valid = (i == n) ? 1 : 0;
+	if (first_rejected) {
+		*first_rejected = i;
+	}
+	return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // scalar multiplication / normalisation with a choice of point wire formats
 // ------------------------------------------------------------------------------------------

@@ -667,3 +667,61 @@ int refdrv_structured_pub_import_batch(const char *curve, int alg, uint32_t n, c
 	}
 	return 0;
 }
+
+/* ---- ec_verify_batch (sig/sig_algs.c:675 -> eddsa_verify_batch, sig/eddsa.c:2904; with or without the scratch pad): one accept bit for
+ * the whole batch of pure Ed25519 / Ed448 signatures.  *all_valid = 1 iff every import succeeded and ec_verify_batch returned 0. */
+int refdrv_eddsa_verify_batch_all(int is448, int use_scratch, uint32_t n, const uint8_t *pubs, const uint8_t *sigs, const uint8_t *msgs,
+				       uint32_t msg_len, int *all_valid)
+{
+	ec_params params;
+	ec_pub_key *keys;
+	const ec_pub_key **kp;
+	const u8 **sp, **mp, **ad;
+	u8 *sl;
+	u16 *al;
+	u32 *ml;
+	uint32_t i;
+	int ret = 0;
+	const size_t klen = is448 ? 57 : 32, slen = is448 ? 114 : 64;
+	const ec_alg_type alg = is448 ? EDDSA448 : EDDSA25519;
+	*all_valid = 0;
+	if (load_params(is448 ? "WEI448" : "WEI25519", &params) || n == 0) {
+		return -1;
+	}
+	keys = calloc(n, sizeof(ec_pub_key));
+	kp = calloc(n, sizeof(*kp));
+	sp = calloc(n, sizeof(*sp));
+	mp = calloc(n, sizeof(*mp));
+	sl = calloc(n, 1);
+	ml = calloc(n, sizeof(u32));
+	ad = calloc(n, sizeof(*ad));   /* the batch API wants the arrays even when no context is used */
+	al = calloc(n, sizeof(u16));
+	if (!keys || !kp || !sp || !mp || !sl || !ml || !ad || !al) {
+		return -1;
+	}
+	refdrv_seed(0x5EC9256ULL);
+	for (i = 0; i < n && !ret; i++) {
+		ret = eddsa_import_pub_key(&keys[i], pubs + (size_t)i * klen, (u16)klen, &params, alg);
+		kp[i] = &keys[i];
+		sp[i] = sigs + (size_t)i * slen;
+		mp[i] = msgs + (size_t)i * msg_len;
+		sl[i] = (u8)slen;
+		ml[i] = msg_len;
+	}
+	if (!ret) {
+		if (use_scratch) {   /* the Bos-Coster multi-scalar path, (2n+1) scratch entries */
+			u32 pad_len = (u32)((2 * (size_t)n + 1) * sizeof(verify_batch_scratch_pad));
+			verify_batch_scratch_pad *pad = calloc(1, pad_len);
+			if (!pad) {
+				return -1;
+			}
+			ret = ec_verify_batch(sp, sl, kp, mp, ml, n, alg, is448 ? SHAKE256 : SHA512, ad, al, pad, &pad_len);
+			free(pad);
+		} else {
+			ret = ec_verify_batch(sp, sl, kp, mp, ml, n, alg, is448 ? SHAKE256 : SHA512, ad, al, NULL, NULL);
+		}
+	}
+	*all_valid = ret ? 0 : 1;
+	free(keys); free(kp); free(sp); free(mp); free(sl); free(ml); free(ad); free(al);
+	return 0;
+}

@@ -254,6 +254,15 @@ def ref_ed25519_verify(pubs, sigs, msgs, msg_len):
     return res.raw[:n]
 
 
+def ref_eddsa_verify_all(pubs, sigs, msgs, msg_len, ed448=False, scratch=False):
+    """the reference's ec_verify_batch on pure Ed25519 / Ed448 signatures: True iff it accepts the whole batch"""
+    L = C.CDLL(REF_SO)
+    n = len(pubs) // (57 if ed448 else 32)
+    ok = C.c_int(0)
+    assert L.refdrv_eddsa_verify_batch_all(int(ed448), int(scratch), n, pubs, sigs, msgs, msg_len, C.byref(ok)) == 0
+    return bool(ok.value)
+
+
 def digest(hash_name, msg):
     return hashlib.new(HASHLIB[hash_name], msg).digest()
 

@@ -865,6 +865,41 @@ def test_first_large_dev_call_builds_comb_safely():
         ctx.close()
 
 
+@pytest.mark.parametrize("curve", ["WEI25519", "WEI448"])
+def test_eddsa_verify_all_batch(gpu_ctx, curve):
+    """ec_eddsa_verify_all_batch = the whole-batch predicate of the reference's ec_verify_batch (pinned in
+    tests/test_oracle.py::test_eddsa_batch_predicate_vs_reference): accept iff the oracle accepts every item; the
+    first rejected index is the oracle's; n = 0 is an error as in the reference"""
+    import libecc_amd
+    from test_oracle import ed25519_cases, ed448_cases, eddsa_subset, ED_MSG_LEN, ED448_MSG_LEN
+    e448 = curve == "WEI448"
+    rng = np.random.default_rng(72)
+    kl, sl, ml, hl = (57, 114, ED448_MSG_LEN, 114) if e448 else (32, 64, ED_MSG_LEN, 64)
+    pubs, sigs, msgs, hram = (ed448_cases if e448 else ed25519_cases)(rng, 10)
+    n = len(pubs) // kl
+    one = Oracle(curve).eddsa_verify(pubs, sigs, hram)
+    good = [i for i in range(n) if one[i] == 0]
+    bad = [i for i in range(n) if one[i]]
+    cv = gpu_ctx.curve(curve)
+    try:
+        def run(idx):
+            P, S, _, H = eddsa_subset(idx, pubs, sigs, msgs, hram, kl, sl, ml, hl)
+            return cv.eddsa_verify_all(P, S, H)
+        assert run(good) == (True, len(good))
+        assert run(good[:1]) == (True, 1)
+        big = good * 40                                   # several hundred items, all valid
+        assert run(big) == (True, len(big))
+        for b in bad:
+            assert run([b]) == (False, 0)
+            assert run(good[:5] + [b] + good[5:]) == (False, 5)
+        assert run(big + [bad[0]] + good + [bad[1]]) == (False, len(big))
+        assert run(list(range(n))) == (False, bad[0])
+        with pytest.raises(libecc_amd.EcamdError):
+            cv.eddsa_verify_all(b"", b"", b"")
+    finally:
+        cv.free()
+
+
 def test_libecc_glue_demo():
     """examples/libecc_glue_demo.c -- the struct-array binding a libecc application would add, linked to
     the UNMODIFIED libecc (prebuilt in the authoring container as oracle/_ref/glue_demo): libecc's own nn /

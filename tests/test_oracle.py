@@ -463,6 +463,41 @@ def test_eddsa448_vs_reference():
         assert got == O.ref_ed448_verify(pubs, sigs, msgs, ED448_MSG_LEN)
 
 
+def eddsa_subset(idx, pubs, sigs, msgs, hram, kl, sl, ml, hl):
+    cut = lambda b, w: b"".join(b[w * i:w * i + w] for i in idx)
+    return cut(pubs, kl), cut(sigs, sl), cut(msgs, ml), cut(hram, hl)
+
+
+@pytest.mark.parametrize("curve", ["WEI25519", "WEI448"])
+def test_eddsa_batch_predicate_vs_reference(curve):
+    """ec_verify_batch (sig/sig_algs.c:675 -> eddsa_verify_batch, sig/eddsa.c:2904): the whole-batch accept bit of
+    the reference equals the conjunction of the per-signature results, which is what ec_eddsa_verify_all_batch returns.
+    Pinned on the sound variant (no scratch pad, _eddsa_verify_batch_no_memory :2278), over every rejection class
+    mixed into otherwise valid batches.  The scratch-pad variant is only checked never to reject a valid batch: in
+    this snapshot its Bos-Coster loop (ec_verify_bos_coster, sig/sig_algs.c) stops when the two largest scalars are
+    equal and multiplies by the zero that is left, so it also accepts batches holding bad signatures."""
+    if not have_ref():
+        pytest.skip("oracle/_ref not built")
+    e448 = curve == "WEI448"
+    rng = np.random.default_rng(71)
+    kl, sl, ml, hl = (57, 114, ED448_MSG_LEN, 114) if e448 else (32, 64, ED_MSG_LEN, 64)
+    pubs, sigs, msgs, hram = (ed448_cases if e448 else ed25519_cases)(rng, 6)
+    n = len(pubs) // kl
+    one = Oracle(curve).eddsa_verify(pubs, sigs, hram)
+    good = [i for i in range(n) if one[i] == 0]
+    bad = [i for i in range(n) if one[i]]
+    assert len(good) >= 8 and len(bad) >= 20
+    def ref_all(idx, scratch=False):
+        P, S, M, _ = eddsa_subset(idx, pubs, sigs, msgs, hram, kl, sl, ml, hl)
+        return O.ref_eddsa_verify_all(P, S, M, ml, e448, scratch)
+    assert ref_all(good) and ref_all(good[:1]) and ref_all(good[3:5])
+    assert ref_all(good, scratch=True) and ref_all(good[:2], scratch=True)
+    for b in bad:
+        for idx in ([b], good[:3] + [b], [b] + good[2:4], good[:2] + [b] + good[2:5]):
+            assert ref_all(idx) is False, (b, idx)
+    assert ref_all(bad) is False
+
+
 def structured_key_cases(curve, rng, nrand=12):
     """libecc structured public keys: 3 header bytes + X || Y || Z.  Valid keys in scaled projective form, wrong
     header bytes, keys outside the subgroup (cofactor curves), off-curve triples, infinity"""
