@@ -214,7 +214,7 @@ int ec_structured_pub_key_import_batch(ecamd_ctx *ctx, const ecamd_curve *curve,
  * already live in HBM (and for sharding a batch over GPUs, one context per device): same semantics and
  * layouts as the host-pointer forms above, every buffer a device pointer, kernels enqueued on
  * hip_stream (a hipStream_t; NULL = the context's stream).  ec_ecdsa_verify_batch_dev returns with the
- * results complete (it synchronises the stream to re-check exceptional items); the other two only
+ * results complete (it synchronises the stream to re-check exceptional items); the others only
  * enqueue -- synchronise the stream (or ecamd_ctx_synchronize for the context's stream) before reading. */
 int ec_ecdsa_verify_batch_dev(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const void *d_pubkeys_aff,
 			      const void *d_sigs, const void *d_digests, uint32_t digest_len, void *d_result,
@@ -224,6 +224,12 @@ int ec_eddsa_verify_batch_dev(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t
 			      void *hip_stream);
 int ec_xdh_batch_dev(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const void *d_k, const void *d_u,
 		     void *d_out, void *d_status, void *hip_stream);
+/* ec_ecdsa_sign_batch / ec_ecccdh_derive_batch with device pointers: enqueue only. */
+int ec_ecdsa_sign_batch_dev(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const void *d_privs,
+			    const void *d_nonces, const void *d_digests, uint32_t digest_len, void *d_sigs,
+			    void *d_status, void *hip_stream);
+int ec_ecccdh_derive_batch_dev(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const void *d_privs,
+			       const void *d_peers_aff, void *d_secrets, void *d_status, void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@ EXPORTED_SYMBOLS = [
     "ec_fp_op_batch", "ec_ecdsa_verify_batch", "ec_ecdsa_sign_batch", "ec_ecccdh_derive_batch", "ec_xdh_batch",
     "ec_prj_pt_mul_batch_fmt", "ec_prj_pt_unique_batch", "ec_structured_pub_key_import_batch",
     "ec_eddsa_verify_batch", "ec_eddsa_verify_all_batch", "ec_ecdsa_verify_batch_dev", "ec_eddsa_verify_batch_dev", "ec_xdh_batch_dev",
+    "ec_ecdsa_sign_batch_dev", "ec_ecccdh_derive_batch_dev",
 ]
 
 
@@ -69,6 +70,8 @@ def load_library():
         L.ec_structured_pub_key_import_batch.argtypes = [vp, vp, u32, u8p, u32, C.c_int, u8p, u8p]
         L.ec_ecdsa_verify_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp]
         L.ec_eddsa_verify_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp]
+        L.ec_ecdsa_sign_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp, vp]
+        L.ec_ecccdh_derive_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp]
         L.ec_xdh_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp]
         L.ec_ecccdh_derive_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
         _LIB = L
@@ -238,6 +241,14 @@ class Curve:
     def eddsa_verify_dev(self, n, d_pubs, d_sigs, d_hram, d_result, stream=None, hram_len=64):
         _chk(self.L, self.L.ec_eddsa_verify_batch_dev(self.ctx.h, self.h, n, d_pubs, d_sigs, d_hram, hram_len, d_result,
                                                        stream), "ec_eddsa_verify_batch_dev")
+
+    def ecdsa_sign_dev(self, n, d_privs, d_nonces, d_digests, hlen, d_sigs, d_status, stream=None):
+        _chk(self.L, self.L.ec_ecdsa_sign_batch_dev(self.ctx.h, self.h, n, d_privs, d_nonces, d_digests, hlen, d_sigs,
+                                                     d_status, stream), "ec_ecdsa_sign_batch_dev")
+
+    def ecccdh_dev(self, n, d_privs, d_peers, d_secrets, d_status, stream=None):
+        _chk(self.L, self.L.ec_ecccdh_derive_batch_dev(self.ctx.h, self.h, n, d_privs, d_peers, d_secrets, d_status,
+                                                        stream), "ec_ecccdh_derive_batch_dev")
 
     def xdh_dev(self, n, d_k, d_u, d_out, d_status, stream=None):
         _chk(self.L, self.L.ec_xdh_batch_dev(self.ctx.h, self.h, n, d_k, d_u, d_out, d_status, stream),

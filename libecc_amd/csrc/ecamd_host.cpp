@@ -242,7 +242,8 @@ struct ecamd_curve {
 	int qlen;   // BYTECEIL(qbits)
 	int pbits, qbits;
 	Big p, a, b, order, gx, gy, q;
-	uint8_t *d_gen;  // generator, affine X||Y big-endian, in HBM
+	uint8_t *d_gen;  // generator, affine X||Y big-endian, in HBM; followed by q (qlen bytes) and the cofactor byte
+	uint32_t cofactor; // order / q when that is 1..255, else 0
 	// per-curve constants of the Ed25519 / X25519 / X448 entry points, computed on first use (ctx->mu held)
 	int ed_state;    // 0 not yet, 1 ready, -1 this handle is not the Ed25519 model (ed_err says why)
 	const char *ed_err;
@@ -732,9 +733,22 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 			return -1;
 		}
 	}
-	std::vector<uint8_t> g((size_t)2 * cv->clen);
+	// generator X || Y, then the two broadcast scalars of the subgroup / cofactor passes: q (qlen bytes) and h (1 byte)
+	std::vector<uint8_t> g((size_t)2 * cv->clen + cv->qlen + 1, 0);
 	big_to_be(g.data(), cv->clen, cv->gx);
 	big_to_be(g.data() + cv->clen, cv->clen, cv->gy);
+	big_to_be(g.data() + 2 * cv->clen, cv->qlen, cv->q);
+	{
+		Big t = cv->q;
+		for (uint32_t c = 1; c <= 255; c++) {
+			if (big_cmp(t, cv->order) == 0) {
+				g[(size_t)2 * cv->clen + cv->qlen] = (uint8_t)c;   // stays 0 when order is not a small multiple of q
+				cv->cofactor = c;
+				break;
+			}
+			t = big_add(t, cv->q);
+		}
+	}
 	if (hipMalloc((void **)&cv->d_gen, g.size()) != hipSuccess ||
 	    hipMemcpy(cv->d_gen, g.data(), g.size(), hipMemcpyHostToDevice) != hipSuccess) {
 		curve_free_device(cv);
@@ -1493,48 +1507,37 @@ extern "C" int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint
 // ------------------------------------------------------------------------------------------
 // batched ECDSA signing with caller-supplied nonces
 // ------------------------------------------------------------------------------------------
-extern "C" int ec_ecdsa_sign_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *privs,
-				   const uint8_t *nonces, const uint8_t *digests, uint32_t hlen, uint8_t *sigs,
-				   uint8_t *status)
+// Device core of ECDSA signing: every pointer a device pointer; kG and its status live in stage[3], stage[4].
+static int ecdsa_sign_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_privs,
+				 const uint8_t *d_nonces, const uint8_t *d_digests, uint32_t hlen, uint8_t *d_sigs,
+				 uint8_t *d_status, hipStream_t s)
 {
-	if (!ctx || !cv || cv->ctx != ctx || (n && (!privs || !nonces || !digests || !sigs || !status))) {
-		return fail("ec_ecdsa_sign_batch: bad argument");
-	}
-	if (cv->qslot < 0) {
-		return fail("ec_ecdsa_sign_batch: generator order not supported for this curve");
-	}
-	if (hlen == 0 || hlen > 128) {
-		return fail("ec_ecdsa_sign_batch: digest length must be in 1..128");
-	}
-	if (n == 0) {
+	const size_t plen = (size_t)2 * cv->clen, ql = (size_t)cv->qlen;
+	if (n > ctx->max_chunk) {  // bound the scratch: pieces of max_chunk items, in order on the stream
+		for (uint32_t off = 0; off < n; off += ctx->max_chunk) {
+			const uint32_t m = (n - off) < ctx->max_chunk ? (n - off) : ctx->max_chunk;
+			if (ecdsa_sign_dev_locked(ctx, cv, m, d_privs + off * ql, d_nonces + off * ql, d_digests + (size_t)off * hlen,
+						  hlen, d_sigs + off * 2 * ql, d_status + off, s)) {
+				return -1;
+			}
+		}
 		return 0;
 	}
-	std::lock_guard<std::mutex> lk(ctx->mu);
-	HIPCHK(hipSetDevice(ctx->device));
-	const size_t plen = (size_t)2 * cv->clen, ql = (size_t)cv->qlen;
-	// stage: 0 privs, 1 nonces, 2 digests, 3 kG, 4 st, 5 sigs, 6 status
-	const size_t need[7] = {n * ql, n * ql, (size_t)n * hlen, n * plen, n, n * 2 * ql, n};
-	for (int i = 0; i < 7; i++) {
-		if (ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
-			return -1;
-		}
+	if (ensure(&ctx->stage[3], &ctx->stage_bytes[3], n * plen) || ensure(&ctx->stage[4], &ctx->stage_bytes[4], n)) {
+		return -1;
 	}
 	uint8_t **S = ctx->stage;
-	hipStream_t s = ctx->stream;
-	HIPCHK(hipMemcpyAsync(S[0], privs, n * ql, hipMemcpyHostToDevice, s));
-	HIPCHK(hipMemcpyAsync(S[1], nonces, n * ql, hipMemcpyHostToDevice, s));
-	HIPCHK(hipMemcpyAsync(S[2], digests, (size_t)n * hlen, hipMemcpyHostToDevice, s));
-	if (smul_dev_locked(ctx, cv, n, S[1], (uint32_t)ql, nullptr, S[3], S[4], s)) {  // kG (:479)
+	if (smul_dev_locked(ctx, cv, n, d_nonces, (uint32_t)ql, nullptr, S[3], S[4], s)) {  // kG (:479)
 		return -1;
 	}
 	EcamdEcdsaSignArgs A;
-	A.privs = S[0];
-	A.nonces = S[1];
-	A.digests = S[2];
+	A.privs = d_privs;
+	A.nonces = d_nonces;
+	A.digests = d_digests;
 	A.kG = S[3];
 	A.stkG = S[4];
-	A.sigs = S[5];
-	A.status = S[6];
+	A.sigs = d_sigs;
+	A.status = d_status;
 	A.n = n;
 	A.clen = (uint32_t)cv->clen;
 	A.qlen = (uint32_t)cv->qlen;
@@ -1551,75 +1554,165 @@ extern "C" int ec_ecdsa_sign_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 	}
 	A.qslot = cv->qslot;
 	HIPCHK(ecamd_launch_ecdsa_sign(cv->qnw, A, s));
-	HIPCHK(hipMemcpyAsync(sigs, S[5], n * 2 * ql, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipMemcpyAsync(status, S[6], n, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
 	return 0;
+}
+
+static int ecdsa_sign_args_ok(const char *fn, ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const void *a,
+			      const void *b, const void *c, const void *d, const void *e, uint32_t hlen)
+{
+	if (!ctx || !cv || cv->ctx != ctx || (n && (!a || !b || !c || !d || !e))) {
+		return fail(std::string(fn) + ": bad argument");
+	}
+	if (cv->qslot < 0) {
+		return fail(std::string(fn) + ": generator order not supported for this curve");
+	}
+	if (hlen == 0 || hlen > 128) {
+		return fail(std::string(fn) + ": digest length must be in 1..128");
+	}
+	return 0;
+}
+
+extern "C" int ec_ecdsa_sign_batch_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const void *d_privs,
+				       const void *d_nonces, const void *d_digests, uint32_t hlen, void *d_sigs,
+				       void *d_status, void *hip_stream)
+{
+	if (ecdsa_sign_args_ok("ec_ecdsa_sign_batch_dev", ctx, cv, n, d_privs, d_nonces, d_digests, d_sigs, d_status, hlen)) {
+		return -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+	return ecdsa_sign_dev_locked(ctx, cv, n, (const uint8_t *)d_privs, (const uint8_t *)d_nonces, (const uint8_t *)d_digests,
+				     hlen, (uint8_t *)d_sigs, (uint8_t *)d_status, s);
+}
+
+extern "C" int ec_ecdsa_sign_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *privs,
+				   const uint8_t *nonces, const uint8_t *digests, uint32_t hlen, uint8_t *sigs,
+				   uint8_t *status)
+{
+	if (ecdsa_sign_args_ok("ec_ecdsa_sign_batch", ctx, cv, n, privs, nonces, digests, sigs, status, hlen)) {
+		return -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t ql = (size_t)cv->qlen;
+	const std::vector<HostArr> arrs = {{privs, nullptr, ql}, {nonces, nullptr, ql}, {digests, nullptr, hlen},
+					   {nullptr, sigs, 2 * ql}, {nullptr, status, 1}};
+	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+					       hipStream_t s, const std::function<int()> &) {
+		return ecdsa_sign_dev_locked(ctx, cv, m, ip[0], ip[1], ip[2], hlen, op[3], op[4], s);
+	});
 }
 
 // ------------------------------------------------------------------------------------------
 // batched ECC-CDH (ecccdh_derive_secret, ecdh/ecccdh.c:167-233)
 // ------------------------------------------------------------------------------------------
-extern "C" int ec_ecccdh_derive_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *privs,
-				      const uint8_t *peers, uint8_t *secrets, uint8_t *status)
+// Device core: stage 3 [d]Q', 4 its status, 5 [h]Q, 6 status of [h]Q, 7 [q]Q (discarded), 8 its status.
+static int ecccdh_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_privs,
+			     const uint8_t *d_peers, uint8_t *d_secrets, uint8_t *d_status, hipStream_t s)
 {
-	if (!ctx || !cv || cv->ctx != ctx || (n && (!privs || !peers || !secrets || !status))) {
-		return fail("ec_ecccdh_derive_batch: bad argument");
+	const size_t plen = (size_t)2 * cv->clen, ql = (size_t)cv->qlen;
+	if (n > ctx->max_chunk) {  // bound the scratch: pieces of max_chunk items, in order on the stream
+		for (uint32_t off = 0; off < n; off += ctx->max_chunk) {
+			const uint32_t m = (n - off) < ctx->max_chunk ? (n - off) : ctx->max_chunk;
+			if (ecccdh_dev_locked(ctx, cv, m, d_privs + off * ql, d_peers + off * plen,
+					      d_secrets + (size_t)off * cv->clen, d_status + off, s)) {
+				return -1;
+			}
+		}
+		return 0;
+	}
+	const bool cof = cv->cofactor != 1;
+	const size_t need[9] = {0, 0, 0, n * plen, n, cof ? n * plen : 0, cof ? n : 0, cof ? n * plen : 0, cof ? n : 0};
+	for (int i = 3; i < 9; i++) {
+		if (need[i] && ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
+			return -1;
+		}
+	}
+	uint8_t **S = ctx->stage;
+	EcamdCdhArgs A;
+	memset(&A, 0, sizeof(A));
+	A.n = n;
+	A.clen = (uint32_t)cv->clen;
+	const uint8_t *pts_in = d_peers;
+	if (cof) {
+		// cofactor h != 1 (ecdh/ecccdh.c:187-217): the peer key must lie in the subgroup ([q]Q = infinity,
+		// sig/ec_key.c:199-205), then Q' = [h]Q must not be infinity, then [d]Q'
+		const uint8_t *d_q = cv->d_gen + plen, *d_h = d_q + ql;
+		if (smul_dev_locked(ctx, cv, n, d_q, (uint32_t)ql, d_peers, S[7], S[8], s, 0) ||
+		    smul_dev_locked(ctx, cv, n, d_h, 1, d_peers, S[5], S[6], s, 0)) {
+			return -1;
+		}
+		A.st_sub = S[8];
+		A.st_h = S[6];
+		A.hq = S[5];
+		HIPCHK(ecamd_launch_cdh_gate(A, s));
+		pts_in = S[5];
+	}
+	// cofactor 1: import + prj_pt_mul + prj_pt_unique in one pass
+	if (smul_dev_locked(ctx, cv, n, d_privs, (uint32_t)ql, pts_in, S[3], S[4], s)) {
+		return -1;
+	}
+	A.pts = S[3];
+	A.st = S[4];
+	A.secrets = d_secrets;
+	A.status = d_status;
+	HIPCHK(ecamd_launch_cdh_fin(A, s));
+	return 0;
+}
+
+static int ecccdh_args_ok(const char *fn, ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const void *a, const void *b,
+			  const void *c, const void *d)
+{
+	if (!ctx || !cv || cv->ctx != ctx || (n && (!a || !b || !c || !d))) {
+		return fail(std::string(fn) + ": bad argument");
+	}
+	if (cv->cofactor == 0) {
+		return fail(std::string(fn) + ": unexpected cofactor");
+	}
+	return 0;
+}
+
+extern "C" int ec_ecccdh_derive_batch_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const void *d_privs,
+					  const void *d_peers, void *d_secrets, void *d_status, void *hip_stream)
+{
+	if (ecccdh_args_ok("ec_ecccdh_derive_batch_dev", ctx, cv, n, d_privs, d_peers, d_secrets, d_status)) {
+		return -1;
 	}
 	if (n == 0) {
 		return 0;
 	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+	return ecccdh_dev_locked(ctx, cv, n, (const uint8_t *)d_privs, (const uint8_t *)d_peers, (uint8_t *)d_secrets,
+				 (uint8_t *)d_status, s);
+}
+
+extern "C" int ec_ecccdh_derive_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *privs,
+				      const uint8_t *peers, uint8_t *secrets, uint8_t *status)
+{
+	if (ecccdh_args_ok("ec_ecccdh_derive_batch", ctx, cv, n, privs, peers, secrets, status)) {
+		return -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
 	const size_t plen = (size_t)2 * cv->clen, ql = (size_t)cv->qlen;
-	std::vector<uint8_t> pts((size_t)n * plen);
-	if (big_cmp(cv->order, cv->q) == 0) {
-		// cofactor 1: import + prj_pt_mul + prj_pt_unique in one pass
-		if (ec_prj_pt_mul_batch(ctx, cv, n, privs, (uint32_t)ql, peers, pts.data(), status)) {
-			return -1;
-		}
-	} else {
-		// cofactor h != 1 (ecdh/ecccdh.c:187-217): the peer key must lie in the subgroup ([q]Q = infinity,
-		// sig/ec_key.c:199-205), then Q' = [h]Q must not be infinity, then [d]Q'
-		uint32_t hval = 0;
-		Big t = cv->q;
-		for (uint32_t c = 1; c <= 255; c++) {
-			if (big_cmp(t, cv->order) == 0) {
-				hval = c;
-				break;
-			}
-			t = big_add(t, cv->q);
-		}
-		if (hval == 0) {
-			return fail("ec_ecccdh_derive_batch: unexpected cofactor");
-		}
-		std::vector<uint8_t> qb(ql), st_sub(n), st_h(n), hq((size_t)n * plen), sub((size_t)n * plen);
-		big_to_be(qb.data(), (int)ql, cv->q);
-		std::vector<uint8_t> qrep((size_t)n * ql), hrep(n, (uint8_t)hval);
-		for (uint32_t i = 0; i < n; i++) {
-			memcpy(&qrep[(size_t)i * ql], qb.data(), ql);
-		}
-		if (ec_prj_pt_mul_batch(ctx, cv, n, qrep.data(), (uint32_t)ql, peers, sub.data(), st_sub.data()) ||
-		    ec_prj_pt_mul_batch(ctx, cv, n, hrep.data(), 1, peers, hq.data(), st_h.data())) {
-			return -1;
-		}
-		// items that fail either check get an off-curve dummy point so that the last pass flags them
-		for (uint32_t i = 0; i < n; i++) {
-			if (st_sub[i] != 2 || st_h[i] != 0) {
-				memset(&hq[(size_t)i * plen], 0xff, plen);
-			}
-		}
-		if (ec_prj_pt_mul_batch(ctx, cv, n, privs, (uint32_t)ql, hq.data(), pts.data(), status)) {
-			return -1;
-		}
-	}
-	for (uint32_t i = 0; i < n; i++) {
-		// infinity (st 2) and import errors (st 1) are both -1 in the reference (:202-217)
-		status[i] = status[i] ? 1 : 0;
-		memcpy(secrets + (size_t)i * cv->clen, pts.data() + (size_t)i * plen, (size_t)cv->clen);
-		if (status[i]) {
-			memset(secrets + (size_t)i * cv->clen, 0, (size_t)cv->clen);
-		}
-	}
-	return 0;
+	const std::vector<HostArr> arrs = {{privs, nullptr, ql}, {peers, nullptr, plen}, {nullptr, secrets, (size_t)cv->clen},
+					   {nullptr, status, 1}};
+	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+					       hipStream_t s, const std::function<int()> &) {
+		return ecccdh_dev_locked(ctx, cv, m, ip[0], ip[1], op[2], op[3], s);
+	});
 }
 
 // ------------------------------------------------------------------------------------------

@@ -205,6 +205,19 @@ struct EcamdPrjOutArgs {
 	uint32_t n, clen;
 	int out_prj;
 };
+// ECC-CDH glue around the scalar multiplications (ecdh/ecccdh.c:187-224)
+struct EcamdCdhArgs {
+	const uint8_t *st_sub;   // gate: status of [q]Q (2 = in the subgroup) ...
+	const uint8_t *st_h;     // ... and of [h]Q (0 = not infinity); both NULL for the final step
+	uint8_t *hq;             // gate: n x 2*clen, [h]Q, overwritten with 0xff.. (an import error) when a check fails
+	const uint8_t *pts;      // fin: n x 2*clen, [d]Q'
+	const uint8_t *st;       // fin: its status
+	uint8_t *secrets;        // fin: n x clen, the x coordinate (zeros on failure)
+	uint8_t *status;         // fin: 0 / 1
+	uint32_t n, clen;
+};
+hipError_t ecamd_launch_cdh_gate(const EcamdCdhArgs &a, hipStream_t s);
+hipError_t ecamd_launch_cdh_fin(const EcamdCdhArgs &a, hipStream_t s);
 hipError_t ecamd_launch_prj_import(int nw, const EcamdPrjInArgs &a, hipStream_t s);
 hipError_t ecamd_launch_prj_export(const EcamdPrjOutArgs &a, hipStream_t s);
 

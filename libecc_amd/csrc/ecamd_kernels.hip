@@ -1002,6 +1002,60 @@ __global__ __launch_bounds__(256) void k_prj_export(EcamdPrjOutArgs A)
 }
 
 // ------------------------------------------------------------------------------------------
+// ECC-CDH glue (ecccdh_derive_secret, ecdh/ecccdh.c:187-224): byte moves only, one thread per item.
+//   k_cdh_gate: cofactor curves -- the peer key must be in the subgroup ([q]Q = infinity, sig/ec_key.c:199-205) and
+//               [h]Q must not be infinity (:202-207); an item failing either gets an undecodable point so that the
+//               last scalar multiplication reports it as an import error.
+//   k_cdh_fin:  shared secret = x coordinate of [d]Q' (:222-224); infinity and import errors are both -1 there.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cdh_gate(EcamdCdhArgs A)
+{
+	const u32 i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	if (A.st_sub[i] != 2 || A.st_h[i] != 0) {
+		u8 *dst = A.hq + (size_t)i * 2 * A.clen;
+		for (u32 b = 0; b < 2 * A.clen; b++) {
+			dst[b] = 0xff;
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_cdh_fin(EcamdCdhArgs A)
+{
+	const u32 i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const u32 bad = A.st[i] ? 1u : 0u;
+	const u8 *src = A.pts + (size_t)i * 2 * A.clen;
+	u8 *dst = A.secrets + (size_t)i * A.clen;
+	for (u32 b = 0; b < A.clen; b++) {
+		dst[b] = bad ? (u8)0 : src[b];
+	}
+	A.status[i] = (u8)bad;
+}
+
+hipError_t ecamd_launch_cdh_gate(const EcamdCdhArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_cdh_gate, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_cdh_fin(const EcamdCdhArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_cdh_fin, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+	return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side dispatch on the word count
 // ------------------------------------------------------------------------------------------
 #define ECAMD_FOR_NW(X) X(6) X(7) X(8) X(10) X(12) X(14) X(16) X(17)

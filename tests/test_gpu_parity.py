@@ -900,6 +900,75 @@ def test_eddsa_verify_all_batch(gpu_ctx, curve):
         cv.free()
 
 
+@pytest.mark.parametrize("curve", ["SECP256R1", "BRAINPOOLP384R1", "WEI25519"])
+def test_sign_and_ecccdh_device_pointer_forms(gpu_ctx, curve):
+    """ec_ecdsa_sign_batch_dev / ec_ecccdh_derive_batch_dev: device pointers on a caller's stream, scratch bounded by a
+    small max_chunk, against the oracle (edge nonces, bad and out-of-subgroup peer keys, d = 0 included)"""
+    import torch
+    import libecc_amd
+    rng = np.random.default_rng(73)
+    dev = torch.device("cuda:0")
+    c = CURVES[curve]
+    o = Oracle(curve)
+    ctx2 = libecc_amd.Context(0)
+    ctx2.set_max_chunk(192)
+    cv = ctx2.curve(curve)
+    t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    try:
+        n, ql, cl, q = 500, cv.qlen, cv.clen, c["q"]
+        stream = torch.cuda.Stream(device=dev)
+        # signing
+        hl = 32
+        privs = b"".join(int(rng.integers(1, 1 << 62)).to_bytes(ql, "big") for _ in range(n))
+        raw = rand_bytes(rng, (ql + 8) * n)
+        nonces = bytearray(b"".join((int.from_bytes(raw[(ql + 8) * i:(ql + 8) * (i + 1)], "big") % (q - 1) + 1).to_bytes(ql, "big")
+                                    for i in range(n)))
+        for i, v in enumerate((0, q, q - 1, 1, q + 1)):
+            nonces[ql * i:ql * i + ql] = (v % (1 << (8 * ql))).to_bytes(ql, "big")
+        nonces, dg = bytes(nonces), rand_bytes(rng, hl * n)
+        exp = o.ecdsa_sign(privs, nonces, dg, hl)
+        dp, dn, dd = t(privs), t(nonces), t(dg)
+        dsig = torch.full((2 * ql * n,), 0xAA, dtype=torch.uint8, device=dev)
+        dst = torch.full((n,), 0xAA, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        cv.ecdsa_sign_dev(n, dp.data_ptr(), dn.data_ptr(), dd.data_ptr(), hl, dsig.data_ptr(), dst.data_ptr(), stream.cuda_stream)
+        stream.synchronize()
+        got = (bytes(dsig.cpu().numpy()), bytes(dst.cpu().numpy()))
+        ok = [i for i in range(n) if exp[1][i] == 0]
+        assert got[1] == exp[1] and 1 in exp[1] and len(ok) > n - 10
+        assert all(got[0][2 * ql * i:2 * ql * (i + 1)] == exp[0][2 * ql * i:2 * ql * (i + 1)] for i in ok)
+        assert cv.ecdsa_sign(privs, nonces, dg, hl)[1] == exp[1]
+        # key agreement
+        peers, st = o.scalar_mult(rand_bytes(rng, ql * n))
+        peers = bytearray(peers)
+        peers[5] ^= 1                                            # off the curve
+        peers[2 * cl * 3:2 * cl * 4] = b"\xff" * (2 * cl)       # coordinates >= p
+        if curve == "WEI25519":
+            from oracles import py_add
+            x2 = 486662 * pow(3, c["p"] - 2, c["p"]) % c["p"]
+            GT = py_add((c["gx"], c["gy"]), (x2, 0), c["a"], c["p"])
+            peers[2 * cl * 7:2 * cl * 8] = GT[0].to_bytes(cl, "big") + GT[1].to_bytes(cl, "big")   # outside the subgroup
+            peers[2 * cl * 8:2 * cl * 9] = x2.to_bytes(cl, "big") + bytes(cl)                        # order 2
+        peers = bytes(peers)
+        d = bytearray(rand_bytes(rng, ql * n))
+        d[ql * 9:ql * 10] = bytes(ql)                            # d = 0: infinity
+        d[ql * 10:ql * 11] = q.to_bytes(ql, "big")
+        d = bytes(d)
+        exp = o.ecccdh(d, peers)
+        dk, dq = t(d), t(peers)
+        dsec = torch.full((cl * n,), 0xAA, dtype=torch.uint8, device=dev)
+        dst = torch.full((n,), 0xAA, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        cv.ecccdh_dev(n, dk.data_ptr(), dq.data_ptr(), dsec.data_ptr(), dst.data_ptr(), stream.cuda_stream)
+        stream.synchronize()
+        assert (bytes(dsec.cpu().numpy()), bytes(dst.cpu().numpy())) == exp
+        assert cv.ecccdh(d, peers) == exp
+        assert exp[1].count(1) >= (6 if curve == "WEI25519" else 4)
+    finally:
+        cv.free()
+        ctx2.close()
+
+
 def test_libecc_glue_demo():
     """examples/libecc_glue_demo.c -- the struct-array binding a libecc application would add, linked to
     the UNMODIFIED libecc (prebuilt in the authoring container as oracle/_ref/glue_demo): libecc's own nn /

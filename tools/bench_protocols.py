@@ -5,7 +5,7 @@ X25519).  Same launch contract and JSON line as bench.py (one process per GPU un
 torch.distributed.run, weak scaling, contiguous shards, one RCCL all-gather of the per-rank result
 bytes per step); not the driver's headline bench.
 
-    python tools/bench_protocols.py --workload ecdsa_verify|ed25519_verify|x25519 [--gpus N --steps K --warmup W]
+    python tools/bench_protocols.py --workload ecdsa_verify|ecdsa_sign|ecccdh|ed25519_verify|ed448_verify|x25519 [--gpus N --steps K --warmup W]
 """
 import argparse
 import json
@@ -26,7 +26,7 @@ SEED = 0x5EC9256
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", required=True, choices=["ecdsa_verify", "ed25519_verify", "ed448_verify", "x25519"])
+    ap.add_argument("--workload", required=True, choices=["ecdsa_verify", "ecdsa_sign", "ecccdh", "ed25519_verify", "ed448_verify", "x25519"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
@@ -96,6 +96,46 @@ def main():
             return o.ecdsa_verify(b"".join(pubs[64 * i:64 * i + 64] for i in idx), b"".join(sigs[64 * i:64 * i + 64] for i in idx),
                                   b"".join(dg[32 * i:32 * i + 32] for i in idx), 32)
         metric, unit, cfg = "ECDSA verifications/sec (secp256r1, SHA-256 digests, batch=2^%d)" % a.batch_log2, "verifications/s", 3
+    elif a.workload in ("ecdsa_sign", "ecccdh"):
+        # secp256r1: signing with caller-supplied nonces (the tail of ec_sign) / ECC-CDH shared secrets
+        curve = "SECP256R1"
+        cv = ctx.curve(curve)
+        q = O.CURVES[curve]["q"]
+        raw = rng.integers(0, 256, size=(2, B, 40), dtype=np.uint8)
+
+        def scal(rows):
+            return b"".join(((int.from_bytes(rows[i].tobytes(), "big") % (q - 1)) + 1).to_bytes(32, "big") for i in range(B))
+        privs, other = scal(raw[0]), scal(raw[1])
+        d_res = torch.empty(B, dtype=torch.uint8, device=dev)
+        expected = bytes(B)
+        if a.workload == "ecdsa_sign":
+            dg = rb(32 * B)
+            ins = [t(privs), t(other), t(dg)]
+            out_w = 64
+            d_out = torch.empty(out_w * B, dtype=torch.uint8, device=dev)
+
+            def step():
+                cv.ecdsa_sign_dev(B, ins[0].data_ptr(), ins[1].data_ptr(), ins[2].data_ptr(), 32, d_out.data_ptr(),
+                                  d_res.data_ptr(), stream.cuda_stream)
+
+            def oracle_subset(idx):
+                cut = lambda b: b"".join(b[32 * i:32 * i + 32] for i in idx)
+                return O.Oracle(curve).ecdsa_sign(cut(privs), cut(other), cut(dg), 32)
+            metric, unit, cfg = "ECDSA signatures/sec (secp256r1, nonces supplied, batch=2^%d)" % a.batch_log2, "signatures/s", 3
+        else:
+            peers, st = cv.scalar_mult(other)
+            assert set(st) == {0}
+            ins = [t(privs), t(peers)]
+            out_w = 32
+            d_out = torch.empty(out_w * B, dtype=torch.uint8, device=dev)
+
+            def step():
+                cv.ecccdh_dev(B, ins[0].data_ptr(), ins[1].data_ptr(), d_out.data_ptr(), d_res.data_ptr(), stream.cuda_stream)
+
+            def oracle_subset(idx):
+                return O.Oracle(curve).ecccdh(b"".join(privs[32 * i:32 * i + 32] for i in idx),
+                                              b"".join(peers[64 * i:64 * i + 64] for i in idx))
+            metric, unit, cfg = "ECC-CDH shared secrets/sec (secp256r1, batch=2^%d)" % a.batch_log2, "shared-secrets/s", 3
     elif a.workload == "ed25519_verify":
         cv = ctx.curve("WEI25519")
         m = 512
@@ -162,6 +202,7 @@ def main():
         def oracle_subset(idx):
             o = O.Oracle("WEI25519")
             return o.xdh(b"".join(k2[32 * i:32 * i + 32] for i in idx), b"".join(pub[32 * i:32 * i + 32] for i in idx))
+        out_w = 32
         metric, unit, cfg = "X25519 shared secrets/sec (batch=2^%d)" % a.batch_log2, "shared-secrets/s", 4
     gathered = torch.empty(world * B, dtype=torch.uint8, device=dev) if world > 1 else None
 
@@ -178,9 +219,10 @@ def main():
         raise SystemExit("PARITY FAILURE: accept/reject bits differ from the construction of the batch")
     idx = [int(i) for i in np.random.default_rng(1).choice(B, size=128, replace=False)]
     exp = oracle_subset(idx)
-    if a.workload == "x25519":
+    payload = a.workload in ("x25519", "ecdsa_sign", "ecccdh")
+    if payload:
         out = d_out.cpu().numpy().tobytes()
-        got = (b"".join(out[32 * i:32 * i + 32] for i in idx), bytes(res[i] for i in idx))
+        got = (b"".join(out[out_w * i:out_w * i + out_w] for i in idx), bytes(res[i] for i in idx))
     else:
         got = bytes(res[i] for i in idx)
     if got != exp:
@@ -215,6 +257,12 @@ def main():
             # is noise next to the two scalar multiplications); accept bits are not compared here
             O.RefLib(curve).ecdsa_verify("SHA256", pubs[:64 * m], sigs[:64 * m], dg[:32 * m], 32)
             what = "ec_pub_key_import_from_aff_buf + ec_verify (ECDSA, SHA-256 over 32-byte messages)"
+        elif a.workload == "ecdsa_sign":
+            O.RefLib(curve).ecdsa_sign("SHA256", privs[:32 * m], other[:32 * m], dg[:32 * m], 32)
+            what = "ec_key_pair_import_from_priv_key_buf + ec_sign (ECDSA, SHA-256 over 32-byte messages, nonce supplied)"
+        elif a.workload == "ecccdh":
+            O.RefLib(curve).ecccdh(privs[:32 * m], peers[:64 * m])
+            what = "ecccdh_derive_secret"
         elif a.workload == "ed25519_verify":
             O.ref_ed25519_verify(pubs[:32 * m], sigs[:64 * m], hram[:64 * m], 64)
             what = "eddsa_import_pub_key + ec_verify (EDDSA25519, SHA-512 over 64-byte messages)"
@@ -234,8 +282,8 @@ def main():
             "metric": metric, "value": B * world * a.steps / elapsed, "unit": unit, "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 (29-bit limbs, v_mad_u64_u32 integer MAD, u64 accumulators)",
-            "data": "synthetic (seeded), inputs resident in HBM; 10 % of the signatures corrupted" if a.workload != "x25519"
-                    else "synthetic (seeded), inputs resident in HBM; peer keys on the curve",
+            "data": "synthetic (seeded), inputs resident in HBM; 10 % of the signatures corrupted" if not payload
+                    else "synthetic (seeded), inputs resident in HBM; valid keys",
             "config": {"workload": f"{a.workload} (BASELINE.json configs[{cfg}]), batch 2^{a.batch_log2} per GPU",
                        "sharding": "contiguous per-rank shards" + (", RCCL all_gather of result bytes per step" if world > 1 else ""),
                        "parity_gate": "all accept/reject bits as constructed; 128 random items identical to the CPU oracle"},
