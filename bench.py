@@ -84,6 +84,9 @@ def work_model(curve_params, nw, slen):
         if p == 2**255 - 19:                         # 2^255 - 19 flavour: 9 limbs, 9 + 1 fold MADs + 1 (x 19)
             nl = 9
             M, S = nl * nl + nl + 2, nl * (nl + 1) // 2 + nl + 2
+        if p == 2**256 - 2**32 - 977:                # secp256k1 flavour: 9 limbs, 2 + 3 + 3 + 6 * 2 = 20 fold MADs
+            nl = 9
+            M, S = nl * nl + 20, nl * (nl + 1) // 2 + 20
         am3 = curve_params["a"] == p - 3 or iso_to_am3(p, curve_params["a"])
         dbl = (3, 4) if curve_params["a"] == 0 else ((4, 4) if am3 else (4, 6))
         add = (12, 4)

@@ -58,6 +58,14 @@ constexpr bool P25519 = true;
 #else
 constexpr bool P25519 = false;
 #endif
+//   -DG29_K256         p = 2^256 - 2^32 - 977 (secp256k1): plain residues on 9 limbs like the flavour above; the
+//                      product is folded with 2^261 = 2^37 + 31264 and 2^256 = 2^32 + 977 (mod p), see mul_raw.
+#if defined(G29_K256)
+constexpr bool K256 = true;
+#else
+constexpr bool K256 = false;
+#endif
+constexpr bool PLAIN = P25519 || K256;   // R = 1, no headroom limb
 //   -DG29_MPINV1       p = -1 mod 2^29 (secp384r1): the Montgomery quotient digit of a column is its low digit and
 //                      "+ m p_0" = "- m + m 2^29" clears it -- no multiplication in the quotient step.  (It has to be a
 //                      compile-time flavour: a wave-uniform branch inside the multiplier cost 25-45 %.)
@@ -68,7 +76,7 @@ constexpr bool MPINV1 = false;
 #endif
 
 constexpr int nl_for(int pbits) { return (pbits + 16 + W - 1) / W; }
-constexpr int nl_for_flavour(int pbits, int flavour) { return flavour == 2 ? 9 : nl_for(pbits); }
+constexpr int nl_for_flavour(int pbits, int flavour) { return (flavour == 2 || flavour == 4) ? 9 : nl_for(pbits); }
 constexpr u64 cmin(u64 a, u64 b) { return a < b ? a : b; }
 constexpr u64 cmax(u64 a, u64 b) { return a > b ? a : b; }
 // x * 2^e for any sign of e, rounded up
@@ -79,10 +87,11 @@ constexpr u64 shl_floor(u64 x, int e) { return e >= 0 ? (x << e) : (x >> -e); }
 template <int PB> struct Cfg {
 	static constexpr int PBITS = PB;
 	static_assert(!P25519 || PB == 255, "the 2^255 - 19 flavour is only for 255-bit fields");
-	static constexpr int NL = P25519 ? 9 : nl_for(PB);
+	static_assert(!K256 || PB == 256, "the secp256k1 flavour is only for 256-bit fields");
+	static constexpr int NL = PLAIN ? 9 : nl_for(PB);
 	static constexpr int HEAD = W * NL - PB;           // R / p >= 2^HEAD, HEAD >= 16 (Montgomery flavours)
 	static constexpr int TOPSH = PB - W * (NL - 1);    // p < 2^(29 (NL-1) + TOPSH); may be <= 0
-	static_assert((HEAD >= 16 || P25519) && NL <= 19, "field size not supported");
+	static_assert((HEAD >= 16 || PLAIN) && NL <= 19, "field size not supported");
 	// top limb of a non-negative-limb value < vb * p
 	static constexpr u64 top_from_vb(u64 vb) { return shl_ceil(vb, TOPSH) + 1; }
 	// bias multiples are 2^(BIAS_STEP + BIAS_OFF) p: with a (nearly) empty top limb the smallest
@@ -90,8 +99,9 @@ template <int PB> struct Cfg {
 	static constexpr int BIAS_OFF = (1 - TOPSH) > 0 ? (1 - TOPSH) : 0;
 	// va * vb < 2^(2 HEAD - 2) without overflowing u64
 	// (2^255 - 19 flavour: va * vb <= 2^14 keeps the last product limb and the fold quotient in 32 bits)
-	static constexpr int PROD_E = P25519 ? 14 : ((2 * HEAD - 2) > 62 ? 62 : (2 * HEAD - 2));
-	static constexpr bool prod_ok(u64 va, u64 vb) { return va == 0 || vb <= ((1ull << PROD_E) - (P25519 ? 0 : 1)) / va; }
+	// (secp256k1 flavour: the last product limb is < va vb 2^19, so va * vb <= 2^12)
+	static constexpr int PROD_E = P25519 ? 14 : (K256 ? 12 : ((2 * HEAD - 2) > 62 ? 62 : (2 * HEAD - 2)));
+	static constexpr bool prod_ok(u64 va, u64 vb) { return va == 0 || vb <= ((1ull << PROD_E) - (PLAIN ? 0 : 1)) / va; }
 };
 
 // the (LOGC, S) combinations the formulas use for "a - b + C p": bias tables for exactly these
@@ -152,10 +162,11 @@ template <class T, class S> G29_FN T weaken(const S &s)
 }
 
 // ---- multiplication ----
-template <int PB> constexpr u64 mul_vb(u64 va, u64 vb) { return P25519 ? 2 : shl_ceil(va * vb, -Cfg<PB>::HEAD) + 1; }
+template <int PB> constexpr u64 mul_vb(u64 va, u64 vb) { return PLAIN ? 2 : shl_ceil(va * vb, -Cfg<PB>::HEAD) + 1; }
 template <int PB, u64 VBO> struct MulOut {
 	// 2^255 - 19 flavour: exact low digits, top limb < 2^23 + 2^12 (see mul_raw), value < 2p
-	typedef E<PB, MASK, P25519 ? ((1ull << 23) + (1ull << 12)) : Cfg<PB>::top_from_vb(VBO), VBO> type;
+	// secp256k1 flavour: exact low digits, top limb < 2^24 + 2^17, value < 2p
+	typedef E<PB, MASK, P25519 ? ((1ull << 23) + (1ull << 12)) : (K256 ? ((1ull << 24) + (1ull << 17)) : Cfg<PB>::top_from_vb(VBO)), VBO> type;
 };
 template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
 {
@@ -252,7 +263,7 @@ template <int NL, bool SQR, int K_> G29_FN void mul_column(u64 &acc, u32 *m, u32
 	typedef Column<NL, SQR, K_> C;
 	u64 acc2;  // written by the first chain that uses it (Z2), never read otherwise
 	C::products(acc, acc2, a, b, a2, m, q17v);
-	if constexpr (P25519) {
+	if constexpr (PLAIN) {
 		if constexpr (C::USES2_PROD) {
 			acc += acc2;
 		}
@@ -338,6 +349,46 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 			G29_PIN(acc);
 		}
 		r[NL - 1] = ((u32)top & ((1u << 23) - 1)) + (u32)acc;  // carry in < 2^12
+	} else if constexpr (K256) {
+		// r = a b mod p, p = 2^256 - c, c = 2^32 + 977, value < 2p.  18 product limbs t; modulo p
+		//   2^261 = 32 c = 2^8 2^29 + 31264:          t[j + 9] goes to limb j (x 31264) and limb j + 1 (x 256), j = 0..7
+		//   2^493 = 2^16 2^29 + 977 2^13 + 31264 2^232: t[17] goes to limbs 1 (x 2^16), 0 (x 8003584) and 8 (x 31264)
+		//   2^256 = 8 2^29 + 977:                       the bits of limb 8 from 24 up (q) go to limbs 1 (x 8) and 0 (x 977)
+		static_assert(NL == 9, "secp256k1 flavour: 9 limbs");
+		t[2 * NL - 1] = (u32)acc;  // < va vb 2^19 <= 2^31 (Cfg::prod_ok)
+		u32 f = 31264u, g = 256u, f17 = 8003584u, g17 = 65536u, fq = 977u;
+#if defined(__HIPCC__)
+		asm volatile("" : "+s"(f), "+s"(g), "+s"(f17), "+s"(g17), "+s"(fq));  // keep the folds MADs
+#endif
+		// limb 8 without the carry from below: < 2^29 + 2^37 + 2^46
+		u64 top = t[NL - 1];
+		G29_MAD_VS(top, t[2 * NL - 2], g);
+		G29_MAD_VS(top, t[2 * NL - 1], f);
+		const u32 q = (u32)(top >> 24);  // < 2^23
+		G29_MUL_VS(acc, q, fq);
+		acc += t[0];
+		G29_MAD_VS(acc, t[NL], f);
+		G29_MAD_VS(acc, t[2 * NL - 1], f17);
+		r[0] = (u32)acc & MASK;
+		acc >>= W;
+		G29_PIN(acc);
+		acc += t[1] + ((u64)q << 3);
+		G29_MAD_VS(acc, t[NL + 1], f);
+		G29_MAD_VS(acc, t[NL], g);
+		G29_MAD_VS(acc, t[2 * NL - 1], g17);
+		r[1] = (u32)acc & MASK;
+		acc >>= W;
+		G29_PIN(acc);
+#pragma unroll
+		for (int j = 2; j < NL - 1; j++) {
+			acc += t[j];
+			G29_MAD_VS(acc, t[j + NL], f);
+			G29_MAD_VS(acc, t[j + NL - 1], g);
+			r[j] = (u32)acc & MASK;
+			acc >>= W;
+			G29_PIN(acc);
+		}
+		r[NL - 1] = ((u32)top & ((1u << 24) - 1)) + (u32)acc;  // carry in < 2^17
 	} else {
 		r[NL - 1] = (u32)acc;
 	}

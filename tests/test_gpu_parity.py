@@ -969,6 +969,49 @@ def test_sign_and_ecccdh_device_pointer_forms(gpu_ctx, curve):
         ctx2.close()
 
 
+def test_secp256k1_field_edges(gpu_ctx):
+    """secp256k1 runs on the plain-residue field with folds by 2^256 = 2^32 + 977: coordinates whose limbs sit at the
+    edges of that reduction (x or y close to 0, to p, to 2^32 + 977 multiples) and scalars at the edges of the group
+    order, against the oracle; plus ECDSA verification (mod-q algebra next to the new mod-p field)"""
+    curve = "SECP256K1"
+    c = CURVES[curve]
+    p, q = c["p"], c["q"]
+    rng = np.random.default_rng(74)
+    cv = gpu_ctx.curve(curve)
+    o = Oracle(curve)
+    try:
+        def lift(x):
+            """smallest x' >= x with a point (x', y) on y^2 = x^3 + 7"""
+            while True:
+                t = (pow(x, 3, p) + 7) % p
+                y = pow(t, (p + 1) // 4, p)
+                if y * y % p == t:
+                    return x, y
+                x += 1
+        pts = []
+        for x0 in (1, 2**32 + 977, 2**29, 2**232, 2**255, p - 2**33, p - 1000, (p - 1) // 2, 2**256 - 2**33 - 5000, 3 * 2**224):
+            x, y = lift(x0 % p)
+            pts.append(x.to_bytes(32, "big") + y.to_bytes(32, "big"))
+            pts.append(x.to_bytes(32, "big") + (p - y).to_bytes(32, "big"))
+        pts.append((p).to_bytes(32, "big") + bytes(32))                 # x = p: rejected
+        pts.append(bytes(31) + b"\x01" + bytes(32))                    # off the curve
+        n = len(pts)
+        scal = [1, 2, q - 1, q, q + 1, 2**255, 2**256 - 1, 0, (q - 1) // 2, 3]
+        S = b"".join((scal[i % len(scal)]).to_bytes(32, "big") for i in range(n))
+        P = b"".join(pts)
+        assert cv.scalar_mult(S, P) == o.scalar_mult(S, P)
+        R = rand_bytes(rng, 32 * n)
+        assert cv.scalar_mult(R, P) == o.scalar_mult(R, P)
+        G3 = cv.scalar_mult(S)
+        assert G3 == o.scalar_mult(S)
+        o2, pubs, sigs, dg, hl, _ = make_sigs(curve, "SHA256", 64, rng)
+        bad = bytearray(sigs)
+        bad[64 * 5 + 2] ^= 1
+        assert cv.ecdsa_verify(pubs, bytes(bad), dg, hl) == o.ecdsa_verify(pubs, bytes(bad), dg, hl)
+    finally:
+        cv.free()
+
+
 def test_libecc_glue_demo():
     """examples/libecc_glue_demo.c -- the struct-array binding a libecc application would add, linked to
     the UNMODIFIED libecc (prebuilt in the authoring container as oracle/_ref/glue_demo): libecc's own nn /
@@ -1080,7 +1123,7 @@ def test_host_pipeline_multi_chunk(gpu_ctx):
 
 
 @pytest.mark.parametrize("env", ["ECAMD_NO_COMB", "ECAMD_NO_P25519", "ECAMD_NO_X25519_LADDER", "ECAMD_NO_EDWARDS_SMUL",
-                                 "ECAMD_NO_FAST_PATH", "ECAMD_NO_ISO"])
+                                 "ECAMD_NO_FAST_PATH", "ECAMD_NO_ISO", "ECAMD_NO_K256"])
 def test_fallback_paths_stay_correct(env):
     """every fast path has a switch that routes around it (A/B measurements, fallbacks): the slower routes
     must give the same bytes -- fixed-base without the comb, WEI25519 on the dense field, X25519 and Ed25519
@@ -1104,6 +1147,16 @@ def test_fallback_paths_stay_correct(env):
             cv = ctx.curve("BRAINPOOLP256R1")       # computed on its a = -3 image unless ECAMD_NO_ISO
             try:
                 o = Oracle("BRAINPOOLP256R1")
+                sc = rand_bytes(rng, 32 * 80)
+                pub = cv.scalar_mult(sc)
+                assert pub == o.scalar_mult(sc)
+                sc2 = rand_bytes(rng, 32 * 80)
+                assert cv.scalar_mult(sc2, pub[0]) == o.scalar_mult(sc2, pub[0])
+            finally:
+                cv.free()
+            cv = ctx.curve("SECP256K1")             # pseudo-Mersenne field unless ECAMD_NO_K256
+            try:
+                o = Oracle("SECP256K1")
                 sc = rand_bytes(rng, 32 * 80)
                 pub = cv.scalar_mult(sc)
                 assert pub == o.scalar_mult(sc)

@@ -104,6 +104,8 @@ template <int PB> struct Shim {
 SHIM(255)
 #elif defined(SHIM_ONLY_384)
 SHIM(384)
+#elif defined(SHIM_ONLY_256)
+SHIM(256)
 #elif !defined(SHIM_ONLY_521)
 SHIM(192)
 SHIM(224)
@@ -115,6 +117,6 @@ SHIM(448)
 SHIM(511)
 SHIM(512)
 #endif
-#if !defined(SHIM_ONLY_255) && !defined(SHIM_ONLY_384)
+#if !defined(SHIM_ONLY_255) && !defined(SHIM_ONLY_384) && !defined(SHIM_ONLY_256)
 SHIM(521)
 #endif

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-log2", type=int, default=20)
+    ap.add_argument("--curve", default="SECP256R1", help="ecdsa_verify / ecdsa_sign / ecccdh: any 256-bit prime-order curve libecc names")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -65,7 +66,8 @@ def main():
 
     t_setup = time.time()
     if a.workload == "ecdsa_verify":
-        curve = "SECP256R1"
+        curve = a.curve
+        assert O.CURVES[curve]["p"].bit_length() == 256 and O.CURVES[curve]["q"].bit_length() == 256
         cv = ctx.curve(curve)
         q = O.CURVES[curve]["q"]
         raw = rng.integers(0, 256, size=(2, B, 40), dtype=np.uint8)
@@ -95,10 +97,11 @@ def main():
             o = O.Oracle(curve)
             return o.ecdsa_verify(b"".join(pubs[64 * i:64 * i + 64] for i in idx), b"".join(sigs[64 * i:64 * i + 64] for i in idx),
                                   b"".join(dg[32 * i:32 * i + 32] for i in idx), 32)
-        metric, unit, cfg = "ECDSA verifications/sec (secp256r1, SHA-256 digests, batch=2^%d)" % a.batch_log2, "verifications/s", 3
+        metric, unit, cfg = "ECDSA verifications/sec (%s, SHA-256 digests, batch=2^%d)" % (curve.lower(), a.batch_log2), "verifications/s", 3
     elif a.workload in ("ecdsa_sign", "ecccdh"):
         # secp256r1: signing with caller-supplied nonces (the tail of ec_sign) / ECC-CDH shared secrets
-        curve = "SECP256R1"
+        curve = a.curve
+        assert O.CURVES[curve]["p"].bit_length() == 256 and O.CURVES[curve]["q"].bit_length() == 256
         cv = ctx.curve(curve)
         q = O.CURVES[curve]["q"]
         raw = rng.integers(0, 256, size=(2, B, 40), dtype=np.uint8)
@@ -121,7 +124,7 @@ def main():
             def oracle_subset(idx):
                 cut = lambda b: b"".join(b[32 * i:32 * i + 32] for i in idx)
                 return O.Oracle(curve).ecdsa_sign(cut(privs), cut(other), cut(dg), 32)
-            metric, unit, cfg = "ECDSA signatures/sec (secp256r1, nonces supplied, batch=2^%d)" % a.batch_log2, "signatures/s", 3
+            metric, unit, cfg = "ECDSA signatures/sec (%s, nonces supplied, batch=2^%d)" % (curve.lower(), a.batch_log2), "signatures/s", 3
         else:
             peers, st = cv.scalar_mult(other)
             assert set(st) == {0}
@@ -135,7 +138,7 @@ def main():
             def oracle_subset(idx):
                 return O.Oracle(curve).ecccdh(b"".join(privs[32 * i:32 * i + 32] for i in idx),
                                               b"".join(peers[64 * i:64 * i + 64] for i in idx))
-            metric, unit, cfg = "ECC-CDH shared secrets/sec (secp256r1, batch=2^%d)" % a.batch_log2, "shared-secrets/s", 3
+            metric, unit, cfg = "ECC-CDH shared secrets/sec (%s, batch=2^%d)" % (curve.lower(), a.batch_log2), "shared-secrets/s", 3
     elif a.workload == "ed25519_verify":
         cv = ctx.curve("WEI25519")
         m = 512

@@ -20,10 +20,11 @@ def digits(x, nl):
 
 def image(p, a, b, flavour=0):
     """flavour 0: dense Montgomery (also what the secp521r1 flavour uses); 2: p = 2^255 - 19, nine limbs
-    and plain residues (R = 1)"""
+    and plain residues (R = 1); 4: p = 2^256 - 2^32 - 977 (secp256k1), the same shape"""
     pbits = p.bit_length()
-    nl = 9 if flavour == 2 else nl_for(pbits)
-    R = 1 if flavour == 2 else 1 << (W * nl)
+    plain = flavour in (2, 4)
+    nl = 9 if plain else nl_for(pbits)
+    R = 1 if plain else 1 << (W * nl)
     topsh = pbits - W * (nl - 1)
     off = max(0, 1 - topsh)
     out = []
