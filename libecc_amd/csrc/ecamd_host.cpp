@@ -2283,17 +2283,16 @@ static int eddsa448_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t 
 		return 0;
 	}
 	const size_t len = 56, plen = 112;
-	// stage: 3 A (Weierstrass), 4 R, 5 flagsA, 6 flagsR, 7 flagsS, 8 S, 9 h, 10 [4^-1]A, 11 its status, 12 [h]A, 13 sthA,
-	//        14 [S]G, 15 stSG, 17 the scalar 4^-1 mod q   (0..2 and 16 belong to the host-pointer wrapper)
+	// stage: 3 A (Weierstrass), 4 R, 5 flagsA, 6 flagsR, 7 flagsS, 8 S, 9 k = 4h 4^-1 mod 4q, 12 [k]A, 13 its status,
+	//        14 [S]G, 15 stSG
 	const size_t need[ECAMD_NSTAGE] = {0, 0, 0, n * plen, n * plen, n, n, n, n * len, n * len,
-					   n * plen, n, n * plen, n, n * plen, n, 0, 64};
+					   0, 0, n * plen, n, n * plen, n};
 	for (int i = 0; i < ECAMD_NSTAGE; i++) {
 		if (ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
 			return -1;
 		}
 	}
 	uint8_t **S = ctx->stage;
-	HIPCHK(hipMemcpyAsync(S[17], cv->ed448_c4, 56, hipMemcpyHostToDevice, s));   // lives in the curve handle
 	EcamdEd448DecodeArgs D = cv->ed448_tmpl;
 	D.n = n;
 	D.encA = d_pub;
@@ -2316,10 +2315,10 @@ static int eddsa448_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t 
 	C.len = 57;
 	C.hlen = 114;
 	C.qslot = cv->qslot;
+	C.c4_mod4 = cv->ed448_c4[55] & 3u;
 	HIPCHK(ecamd_launch_ed448_scal(C, s));
-	// the stored key [4^-1 mod q]A (eddsa_import_pub_key), then [h]A and [S]G
-	if (smul_dev_locked(ctx, cv, n, S[17], (uint32_t)len, S[3], S[10], S[11], s, 0) ||
-	    smul_dev_locked(ctx, cv, n, S[9], (uint32_t)len, S[10], S[12], S[13], s) ||
+	// the reference's [4h mod q]([4^-1 mod q]A) as one multiplication of A (k_ed448_scal), and [S]G
+	if (smul_dev_locked(ctx, cv, n, S[9], (uint32_t)len, S[3], S[12], S[13], s) ||
 	    smul_dev_locked(ctx, cv, n, S[8], (uint32_t)len, nullptr, S[14], S[15], s)) {
 		return -1;
 	}
@@ -2337,8 +2336,8 @@ static int eddsa448_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t 
 	F.n = n;
 	F.clen = (uint32_t)len;
 	F.cof_dbl = 2;
-	F.Akey = S[10];
-	F.stA = S[11];
+	F.Akey = S[3];      // [4]A = infinity <=> the stored key [4^-1 mod q]A has small order
+	F.stA = nullptr;
 	F.slot = cv->slot;
 	HIPCHK(ecamd_launch_ed_fin(cv->nw, F, s));
 	return 0;

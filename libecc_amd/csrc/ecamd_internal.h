@@ -145,6 +145,7 @@ struct EcamdEdScalArgs {
 	uint8_t *flags;          // out: n, 1 when S >= q
 	uint32_t n, len, hlen;
 	int qslot;
+	uint32_t c4_mod4;        // Ed448: (4^-1 mod q) mod 4, see k_ed448_scal
 };
 struct EcamdEdFinArgs {
 	const uint8_t *SG, *stSG;   // [S]G
@@ -153,7 +154,8 @@ struct EcamdEdFinArgs {
 	const uint8_t *flagsA, *flagsR, *flagsS;
 	uint8_t *result;            // n: 0 accept / 1 reject
 	uint32_t n, clen, cof_dbl;  // cof_dbl = log2(cofactor)
-	const uint8_t *Akey, *stA;  // Ed448: the stored key [4^-1]A (affine) + its status, checked for small order here; NULL otherwise
+	const uint8_t *Akey, *stA;  // Ed448: the decoded key A (affine; [4]A = infinity <=> the stored key [4^-1]A has small order), checked here;
+	                            // stA: optional status bytes that reject when non-zero; both NULL otherwise
 	int slot;
 };
 // Ed448 point decoding (EDDSA448 branch of eddsa_decode_point) + maps to the Weierstrass model WEI448

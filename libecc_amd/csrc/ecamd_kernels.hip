@@ -765,8 +765,8 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed_fin(EcamdEdFinArgs 
 		return;
 	}
 	if (A.Akey != nullptr) {
-		// [cofactor]A != infinity for the stored key (Ed448: after its multiplication by 4^-1 mod q)
-		if (A.stA[i] != 0) {
+		// [cofactor]A != infinity for the key (Ed448: the stored key [4^-1 mod q]A has small order iff A has)
+		if (A.stA != nullptr && A.stA[i] != 0) {
 			A.result[i] = 1;
 			return;
 		}
@@ -801,9 +801,10 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed_fin(EcamdEdFinArgs 
 //     (a zero denominator is an fp_inv error); on-curve check on the Edwards model of curve448;
 //   aff_pt_edwards_to_montgomery / aff_pt_montgomery_to_shortw with libecc's Montgomery model (A, B) = (-156326, -1):
 //     u = (1 + y') / (1 - y'), v = alpha u / x', (X, Y) = (A/3 - u, -v); x' = 0 is rejected as for Ed25519;
-//   eddsa_import_pub_key (:925-937): A <- [4^-1 mod q]A (a scalar multiplication, done by the host between kernels);
-//   _eddsa_verify_init: S < q, [4]A != infinity; _eddsa_verify_finalize: h = hash mod q, then 4 h mod q,
-//     [S]G - R - [h]A, two cofactor doublings, must be infinity.
+//   eddsa_import_pub_key (:925-937): A' <- [4^-1 mod q]A; _eddsa_verify_init: S < q, [4]A' != infinity;
+//   _eddsa_verify_finalize: h = hash mod q, then a = 4 h mod q, [S]G - R - [a]A', two cofactor doublings, must be infinity.
+//   Here [a]A' is ONE multiplication of the decoded A by a 4^-1 mod 4q (k_ed448_scal), and the small-order test is
+//   [4]A = infinity (A' = [c4]A with c4 prime to q has small order exactly when A has).
 // Square root: p = 3 mod 4 (wave-uniform exponent bits).
 // ------------------------------------------------------------------------------------------
 template <int NW> static __device__ Fe<NW> fe_pow_bits(const Fe<NW> &w, const u32 *e, int ebits, int slot)
@@ -902,7 +903,10 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed448_decode(EcamdEd44
 	}
 }
 
-// S < q (57 bytes little-endian, the last one must be 0); h = 114-byte hash mod q, then 4 h mod q
+// S < q (57 bytes little-endian, the last one must be 0); h = 114-byte hash mod q, then a = 4 h mod q as the reference does.
+// The reference multiplies the STORED key A' = [c4]A (c4 = 4^-1 mod q, eddsa_import_pub_key) by a.  [a]([c4]A) = [a c4]A,
+// and the order of A divides 4q, so one multiplication of the decoded A by k = a c4 mod 4q gives the same point:
+// k = h (mod q) and k = (a mod 4)(c4 mod 4) (mod 4), i.e. k = h + t q with t in 0..3 -- written out instead of a.
 template <int NW> __global__ __launch_bounds__(64) void k_ed448_scal(EcamdEdScalArgs A)
 {
 	const u32 i = blockIdx.x * 64 + threadIdx.x;
@@ -923,11 +927,21 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed448_scal(EcamdEdScal
 	const Fe<NW> lor = fe_mul<NW>(fe_mul<NW>(lo, r2, qs), onep, qs);                        // lo mod q
 	const Fe<NW> midr = fe_mul<NW>(mid, r2, qs);                                             // mid 2^448 mod q
 	const Fe<NW> hir = fe_mul<NW>(fe_mul<NW>(hi, r2, qs), r2, qs);                           // hi 2^896 mod q
-	Fe<NW> h = fe_add<NW>(fe_add<NW>(lor, midr, qs), hir, qs);
-	h = fe_add<NW>(h, h, qs);
-	h = fe_add<NW>(h, h, qs);                                                                // 4 h mod q
+	const Fe<NW> h = fe_add<NW>(fe_add<NW>(lor, midr, qs), hir, qs);                        // h mod q, canonical
+	Fe<NW> a4 = fe_add<NW>(h, h, qs);
+	a4 = fe_add<NW>(a4, a4, qs);                                                             // a = 4 h mod q, canonical
+	const u32 r4 = ((a4.v[0] & 3u) * A.c4_mod4) & 3u;                                        // k mod 4
+	const u32 t = ((r4 - (h.v[0] & 3u)) * (Q.p[0] & 3u)) & 3u;                               // q^-1 = q (mod 4)
+	Fe<NW> k = h;                                                                            // h + t q < 4q < 2^448
+	u64 cy = 0;
+#pragma unroll
+	for (int w = 0; w < NW; w++) {
+		const u64 sum = (u64)k.v[w] + (u64)t * Q.p[w] + cy;
+		k.v[w] = (u32)sum;
+		cy = sum >> 32;
+	}
 	fe_store_be<NW>(A.S_be + (size_t)i * 56, 56, ok ? S : fe_zero<NW>());
-	fe_store_be<NW>(A.h_be + (size_t)i * 56, 56, h);
+	fe_store_be<NW>(A.h_be + (size_t)i * 56, 56, k);
 	A.flags[i] = ok ? 0 : 1;
 }
 
