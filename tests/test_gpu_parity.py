@@ -1012,6 +1012,46 @@ def test_secp256k1_field_edges(gpu_ctx):
         cv.free()
 
 
+@pytest.mark.parametrize("curve,log2n", [("SECP256R1", 17), ("SECP256K1", 17), ("SECP384R1", 15), ("BRAINPOOLP256R1", 15)])
+def test_protocol_round_trips_large(gpu_ctx, curve, log2n):
+    """size-independent properties of the protocol entry points on batches far beyond what the oracle covers:
+    sign -> verify accepts every signature and rejects exactly the corrupted ones; ECC-CDH is symmetric
+    (x([a][b]G) both ways); 64 random items of each result are compared with the oracle"""
+    rng = np.random.default_rng(75)
+    cv = gpu_ctx.curve(curve)
+    o = Oracle(curve)
+    try:
+        n, ql, cl, q = 1 << log2n, cv.qlen, cv.clen, CURVES[curve]["q"]
+        raw = rng.integers(0, 256, size=(3, n, ql + 8), dtype=np.uint8)
+        scal = lambda r: b"".join(((int.from_bytes(r[i].tobytes(), "big") % (q - 1)) + 1).to_bytes(ql, "big") for i in range(n))
+        da, db, ks = scal(raw[0]), scal(raw[1]), scal(raw[2])
+        hl = 32
+        dg = rand_bytes(rng, hl * n)
+        pa, st = cv.scalar_mult(da)
+        assert set(st) == {0}
+        pb, st = cv.scalar_mult(db)
+        assert set(st) == {0}
+        sigs, st = cv.ecdsa_sign(da, ks, dg, hl)
+        assert set(st) == {0}
+        assert cv.ecdsa_verify(pa, sigs, dg, hl) == bytes(n)
+        bad = np.frombuffer(sigs, dtype=np.uint8).copy().reshape(n, 2 * ql)
+        which = np.arange(n) % 7 == 3
+        bad[which, (np.arange(n) % (2 * ql))[which]] ^= 0x20
+        res = cv.ecdsa_verify(pa, bad.tobytes(), dg, hl)
+        assert res == bytes(which.astype(np.uint8))
+        assert cv.ecdsa_verify(pb, sigs, dg, hl) == bytes([1]) * n        # someone else's key
+        s1, st1 = cv.ecccdh(da, pb)
+        s2, st2 = cv.ecccdh(db, pa)
+        assert set(st1) == {0} and (s1, st1) == (s2, st2)
+        idx = [int(i) for i in rng.choice(n, size=64, replace=False)]
+        cut = lambda b, w: b"".join(b[w * i:w * i + w] for i in idx)
+        assert o.ecdsa_sign(cut(da, ql), cut(ks, ql), cut(dg, hl), hl)[0] == cut(sigs, 2 * ql)
+        assert o.ecdsa_verify(cut(pa, 2 * cl), cut(bad.tobytes(), 2 * ql), cut(dg, hl), hl) == bytes(res[i] for i in idx)
+        assert o.ecccdh(cut(da, ql), cut(pb, 2 * cl))[0] == cut(s1, cl)
+    finally:
+        cv.free()
+
+
 def test_libecc_glue_demo():
     """examples/libecc_glue_demo.c -- the struct-array binding a libecc application would add, linked to
     the UNMODIFIED libecc (prebuilt in the authoring container as oracle/_ref/glue_demo): libecc's own nn /
