@@ -2258,9 +2258,6 @@ static void ed448_setup(ecamd_curve *cv)
 	EcamdEd448DecodeArgs &D = cv->ed448_tmpl;
 	memset(&D, 0, sizeof(D));
 	D.slot = cv->slot;
-	const Big e34 = big_div4(big_sub(p, three));                 // (p - 3) / 4: x = u^3 v (u^5 v^3)^((p-3)/4) for x^2 = u / v
-	D.ebits = (uint32_t)big_bitlen(e34);
-	big_store(D.e, 17, e34);
 	big_store(D.d448, nw, big_mulmod(d448, R, p));
 	big_store(D.diso, nw, big_mulmod(diso, R, p));
 	big_store(D.alpha, nw, big_mulmod(alpha, R, p));

@@ -164,8 +164,7 @@ struct EcamdEd448DecodeArgs {
 	uint32_t strideA, strideR;
 	uint8_t *pointsA, *pointsR;   // out: n x 112 affine Weierstrass X || Y big-endian
 	uint8_t *flagsA, *flagsR;
-	uint32_t n, ebits;
-	uint32_t e[17];               // (p - 3) / 4
+	uint32_t n;
 	uint32_t d448[17], diso[17], alpha[17], A3[17];   // Montgomery form (radix 2^448)
 	int slot;
 };

@@ -807,16 +807,29 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed_fin(EcamdEdFinArgs 
 //   [4]A = infinity (A' = [c4]A with c4 prime to q has small order exactly when A has).
 // Square root: p = 3 mod 4 (wave-uniform exponent bits).
 // ------------------------------------------------------------------------------------------
-template <int NW> static __device__ Fe<NW> fe_pow_bits(const Fe<NW> &w, const u32 *e, int ebits, int slot)
+// Fixed exponents of p = 2^448 - 2^224 - 1 by addition chains (the prime is pinned by ed448_setup):
+//   f(k) = w^(2^k - 1): f(2k) = f(k)^(2^k) f(k), f(k + 1) = f(k)^2 w; 222 = 2 x (2 x (2 x (2 x (2 x (2 x 3 + 1)) + 1) + 1) + 1)
+//   (p - 3) / 4 = 2^446 - 2^222 - 1 = 2^223 (2^223 - 1) + (2^222 - 1):  w^((p-3)/4) = f(223)^(2^223) f(222)     446 S + 14 M
+//   p - 2 = 4 (p - 3) / 4 + 1:                                            w^(p-2) = (w^((p-3)/4))^4 w              448 S + 15 M
+// instead of ~890 multiplications each with square-and-multiply.
+template <int NW> static __device__ Fe<NW> fe_pow_p448_e34(const Fe<NW> &w, int slot)
 {
-	Fe<NW> c = fe_const<NW>(ConstTab<NW>::get(slot).one);
-	for (int b = ebits - 1; b >= 0; b--) {
-		c = fe_mul<NW>(c, c, slot);
-		if ((e[b >> 5] >> (b & 31)) & 1u) {
-			c = fe_mul<NW>(c, w, slot);
-		}
+	// steps from f(1) = w to f(222): k > 0 doubles f(k) -> f(2k), k = 0 increments f(k) -> f(k + 1)
+	const int steps[12] = {1, 0, 3, 6, 0, 13, 0, 27, 0, 55, 0, 111};
+	Fe<NW> f = w;
+#pragma unroll 1
+	for (int s = 0; s < 12; s++) {
+		const int k = steps[s];
+		const Fe<NW> g = (k == 0) ? w : f;
+		f = fe_mul<NW>(fe_sqr_n<NW>(f, k == 0 ? 1 : k, slot), g, slot);
 	}
-	return c;
+	const Fe<NW> f223 = fe_mul<NW>(fe_mul<NW>(f, f, slot), w, slot);
+	return fe_mul<NW>(fe_sqr_n<NW>(f223, 223, slot), f, slot);
+}
+
+template <int NW> static __device__ Fe<NW> fe_inv_p448(const Fe<NW> &w, int slot)   // 0 -> 0, like Fermat's
+{
+	return fe_mul<NW>(fe_sqr_n<NW>(fe_pow_p448_e34<NW>(w, slot), 2, slot), w, slot);
 }
 
 // One lane decodes A and R of an item; the four field inversions of each point (a - d y^2, the two isogeny
@@ -849,7 +862,7 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed448_decode(EcamdEd44
 		const Fe<NW> v2 = fe_mul<NW>(v, v, slot), u2 = fe_mul<NW>(u, u, slot);
 		const Fe<NW> u3v = fe_mul<NW>(fe_mul<NW>(u2, u, slot), v, slot);
 		const Fe<NW> u5v3 = fe_mul<NW>(fe_mul<NW>(u3v, u2, slot), v2, slot);
-		Fe<NW> r = fe_mul<NW>(u3v, fe_pow_bits<NW>(u5v3, A.e, (int)A.ebits, slot), slot);
+		Fe<NW> r = fe_mul<NW>(u3v, fe_pow_p448_e34<NW>(u5v3, slot), slot);
 		good = good & fe_eq<NW>(fe_mul<NW>(v, fe_mul<NW>(r, r, slot), slot), u);           // u / v has no root: error
 		const Fe<NW> rp = fe_from_mont<NW>(r, slot);
 		r = fe_select<NW>((rp.v[0] & 1u) != x0, fe_sub<NW>(zero, r, slot), r);
@@ -867,7 +880,7 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed448_decode(EcamdEd44
 	Fe<NW> X[2], Y[2], omy[2];
 	{
 		const Fe<NW> pa = fe_mul<NW>(d1[0], d2[0], slot), pr = fe_mul<NW>(d1[1], d2[1], slot);
-		const Fe<NW> inv = fe_inv<NW>(fe_mul<NW>(pa, pr, slot), slot);
+		const Fe<NW> inv = fe_inv_p448<NW>(fe_mul<NW>(pa, pr, slot), slot);
 		const Fe<NW> ia = fe_mul<NW>(inv, pr, slot), ir = fe_mul<NW>(inv, pa, slot);       // 1 / (d1 d2) of A, of R
 #pragma unroll 1
 		for (int k = 0; k < 2; k++) {
@@ -886,7 +899,7 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed448_decode(EcamdEd44
 	}
 	{
 		const Fe<NW> pa = fe_mul<NW>(omy[0], X[0], slot), pr = fe_mul<NW>(omy[1], X[1], slot);
-		const Fe<NW> inv = fe_inv<NW>(fe_mul<NW>(pa, pr, slot), slot);
+		const Fe<NW> inv = fe_inv_p448<NW>(fe_mul<NW>(pa, pr, slot), slot);
 		const Fe<NW> ia = fe_mul<NW>(inv, pr, slot), ir = fe_mul<NW>(inv, pa, slot);       // 1 / ((1 - Y) X) of A, of R
 #pragma unroll 1
 		for (int k = 0; k < 2; k++) {
