@@ -84,6 +84,8 @@ def work_model(curve_params, nw, slen):
         if p == 2**255 - 19:                         # 2^255 - 19 flavour: 9 limbs, 9 + 1 fold MADs + 1 (x 19)
             nl = 9
             M, S = nl * nl + nl + 2, nl * (nl + 1) // 2 + nl + 2
+        if p == 2**448 - 2**224 - 1:                 # Goldilocks flavour: 16 limbs, 34 fold MADs (+ a MAD-free carry pass)
+            M, S = nl * nl + 34, nl * (nl + 1) // 2 + 34
         if p == 2**256 - 2**32 - 977:                # secp256k1 flavour: 9 limbs, 2 + 3 + 3 + 6 * 2 = 20 fold MADs
             nl = 9
             M, S = nl * nl + 20, nl * (nl + 1) // 2 + 20

@@ -28,7 +28,7 @@
  * Environment (read when a context / curve handle is created; for measurements and fallbacks):
  *   ECAMD_HOST_CHUNK=<items>      chunk size of the host-pointer entry points (default 2^18)
  *   ECAMD_COMB_MIN_BATCH=<items>  smallest fixed-base batch that builds / uses the generator table (default 4096)
- *   ECAMD_NO_COMB, ECAMD_NO_FAST_PATH, ECAMD_NO_P25519, ECAMD_NO_K256, ECAMD_NO_MPINV1, ECAMD_NO_ISO, ECAMD_NO_X25519_LADDER,
+ *   ECAMD_NO_COMB, ECAMD_NO_FAST_PATH, ECAMD_NO_P25519, ECAMD_NO_K256, ECAMD_NO_P448, ECAMD_NO_MPINV1, ECAMD_NO_ISO, ECAMD_NO_X25519_LADDER,
  *   ECAMD_NO_EDWARDS_SMUL         route around one fast path each (results are identical)
  */
 #ifndef LIBECC_AMD_H

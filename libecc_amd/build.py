@@ -39,6 +39,7 @@ def _jobs():
     jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_521m.o", ["-DG29_PB=521", "-DG29_MERSENNE521"]))
     jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_255c.o", ["-DG29_PB=255", "-DG29_P25519"]))
     jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_256k.o", ["-DG29_PB=256", "-DG29_K256"]))
+    jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_448g.o", ["-DG29_PB=448", "-DG29_P448"]))
     jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_384n.o", ["-DG29_PB=384", "-DG29_MPINV1"]))
     jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_dispatch.o", ["-DG29_DISPATCH"]))
     return jobs

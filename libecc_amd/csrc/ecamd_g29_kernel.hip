@@ -520,6 +520,9 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_finalize_g(E
 #elif defined(G29_P25519)
 #define G29_TAG G29_CAT(G29_PB, c)   /* 255c: p = 2^255 - 19 beside the dense 255-bit unit */
 #define G29_FLAV 2
+#elif defined(G29_P448)
+#define G29_TAG G29_CAT(G29_PB, g)   /* 448g: p = 2^448 - 2^224 - 1 (WEI448) beside the dense 448-bit unit */
+#define G29_FLAV 5
 #elif defined(G29_K256)
 #define G29_TAG G29_CAT(G29_PB, k)   /* 256k: p = 2^256 - 2^32 - 977 (secp256k1) beside the dense 256-bit unit */
 #define G29_FLAV 4
@@ -1403,6 +1406,7 @@ X(521m)
 X(255c)
 X(384n)
 X(256k)
+X(448g)
 #undef X
 
 int ecamd_g29_supported(int pbits)
@@ -1426,7 +1430,7 @@ size_t ecamd_g29_image_bytes(int pbits, int flavour)
 	return (size_t)((10 + g29::NBIAS) * g29::nl_for_flavour(pbits, flavour) + 4) * 4;
 }
 
-// 'flavour' 1 selects the secp521r1 (p = 2^521 - 1) instantiation, 2 the p = 2^255 - 19 one, 3 secp384r1's, 4 secp256k1's
+// 'flavour' 1 selects the secp521r1 (p = 2^521 - 1) instantiation, 2 the p = 2^255 - 19 one, 3 secp384r1's, 4 secp256k1's, 5 WEI448's
 hipError_t ecamd_g29_upload(int pbits, int slot, const void *img, size_t bytes, int flavour)
 {
 	if (pbits == 521 && flavour == 1) {
@@ -1440,6 +1444,9 @@ hipError_t ecamd_g29_upload(int pbits, int slot, const void *img, size_t bytes, 
 	}
 	if (pbits == 256 && flavour == 4) {
 		return ecamd_g29_upload_256k(slot, img, bytes);
+	}
+	if (pbits == 448 && flavour == 5) {
+		return ecamd_g29_upload_448g(slot, img, bytes);
 	}
 	switch (pbits) {
 #define X(PB) case PB: return ecamd_g29_upload_##PB(slot, img, bytes);
@@ -1465,6 +1472,9 @@ hipError_t ecamd_launch_smul_g29(int pbits, int gslot, const EcamdSmulArgs &a, h
 	}
 	if (pbits == 256 && flavour == 4) {
 		return ecamd_g29_launch_256k(gslot, a, s, ev);
+	}
+	if (pbits == 448 && flavour == 5) {
+		return ecamd_g29_launch_448g(gslot, a, s, ev);
 	}
 	switch (pbits) {
 #define X(PB) case PB: return ecamd_g29_launch_##PB(gslot, a, s, ev);
@@ -1496,6 +1506,9 @@ hipError_t ecamd_g29_comb_build(int pbits, int gslot, const uint8_t *pts, uint32
 	}
 	if (pbits == 256 && flavour == 4) {
 		return ecamd_g29_comb_build_256k(gslot, pts, n, clen, table, s);
+	}
+	if (pbits == 448 && flavour == 5) {
+		return ecamd_g29_comb_build_448g(gslot, pts, n, clen, table, s);
 	}
 	switch (pbits) {
 #define X(PB) case PB: return ecamd_g29_comb_build_##PB(gslot, pts, n, clen, table, s);

@@ -261,7 +261,7 @@ struct ecamd_curve {
 	uint8_t xdh_cof;
 	bool is_p256;    // exactly secp256r1: hand-specialised radix-2^29 Jacobian kernel
 	int gslot;       // constant slot of the generic radix-2^29 Jacobian kernel (-1: none)
-	int gflavour;    // 0 dense reduction, 1 secp521r1 (p = 2^521 - 1), 2 p = 2^255 - 19, 3 p = -1 mod 2^29 at 384 bits, 4 secp256k1's prime
+	int gflavour;    // 0 dense reduction, 1 secp521r1 (p = 2^521 - 1), 2 p = 2^255 - 19, 3 p = -1 mod 2^29 at 384 bits, 4 secp256k1's prime, 5 p = 2^448 - 2^224 - 1
 	uint32_t *d_gtab; // secp256r1: affine window table [1..8]G, radix-2^29 Montgomery digits, 8 x 40 words
 	uint32_t *d_comb; // fast paths: 16-bit comb table of G, built on the first large fixed-base batch (NULL before / disabled)
 	bool comb_off;    // construction failed or is in progress: do not try (again)
@@ -552,8 +552,8 @@ static int upload_g29(ecamd_curve *cv)
 {
 	const int pbits = cv->pbits, nl = ecamd_g29_nl(pbits, cv->gflavour);
 	const Big &p = cv->p;
-	// flavours 2 (p = 2^255 - 19) and 4 (secp256k1's prime) keep plain residues: R = 1
-	const Big R = (cv->gflavour == 2 || cv->gflavour == 4) ? Big(1, 1) : big_mod(big_pow2(29 * nl), p);
+	// flavours 2 (p = 2^255 - 19), 4 (secp256k1's prime) and 5 (p = 2^448 - 2^224 - 1) keep plain residues: R = 1
+	const Big R = (cv->gflavour == 2 || cv->gflavour == 4 || cv->gflavour == 5) ? Big(1, 1) : big_mod(big_pow2(29 * nl), p);
 	Big two(1, 2), three(1, 3);
 	static const int step[16] = {2, 4, 6, 8, 10, 12, 14, 16, 2, 4, 6, 8, 10, 12, 14, 16};
 	static const int sv[16] = {1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2};
@@ -564,7 +564,7 @@ static int upload_g29(ecamd_curve *cv)
 	// (the brainpool r1 curves -- their t1 twins are these images --, two GOST 512-bit sets); ECAMD_NO_ISO disables it.
 	Big u(1, 1);
 	Big a_img = cv->a, b_img = cv->b;
-	if ((cv->gflavour == 0 || cv->gflavour == 3) && (p[0] & 3u) == 3u && big_bitlen(cv->a) > 0 && big_cmp(big_add(cv->a, three), p) != 0 &&
+	if ((cv->gflavour == 0 || cv->gflavour == 3 || cv->gflavour == 5) && (p[0] & 3u) == 3u && big_bitlen(cv->a) > 0 && big_cmp(big_add(cv->a, three), p) != 0 &&
 	    getenv("ECAMD_NO_ISO") == nullptr) {
 		Big e = big_add(p, Big(1, 1));  // (p + 1) / 4
 		Big q4(e.size(), 0);
@@ -720,6 +720,10 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	if (cv->pbits == 256 && getenv("ECAMD_NO_K256") == nullptr &&
 	    big_cmp(cv->p, big_from_hex("fffffffffffffffffffffffffffffffffffffffffffffffffffffffefffffc2f")) == 0) {
 		cv->gflavour = 4;  // p = 2^256 - 2^32 - 977 (secp256k1): plain residues, pseudo-Mersenne folds
+	}
+	if (cv->pbits == 448 && getenv("ECAMD_NO_P448") == nullptr &&
+	    big_cmp(cv->p, big_sub(big_sub(big_pow2(448), big_pow2(224)), Big(1, 1))) == 0) {
+		cv->gflavour = 5;  // p = 2^448 - 2^224 - 1 (WEI448): plain residues, Goldilocks folds
 	}
 	if (cv->pbits == 384 && (cv->p[0] & 0x1fffffffu) == 0x1fffffffu && getenv("ECAMD_NO_MPINV1") == nullptr) {
 		cv->gflavour = 3;  // p = -1 mod 2^29 (secp384r1): quotient digits without a multiplication

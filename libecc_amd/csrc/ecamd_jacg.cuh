@@ -18,7 +18,7 @@ template <int PB> struct Cls {
 	// ... bounds every loop-carried coordinate: carried limbs, value < 4 * 2^LC p
 	// (2^255 - 19 flavour: no headroom limb, the top limb holds values below 512 p, and products want
 	// va * vb <= 2^14; the formulas stay well inside 48 p)
-	static constexpr u64 VA = PLAIN ? 48 : (4ull << LC);
+	static constexpr u64 VA = PLAIN9 ? 48 : (4ull << LC);
 	typedef E<PB, MASK + 8, C::top_from_vb(VA), VA> FA;
 	typedef typename MulOut<PB, 2>::type FM;  // multiplication result (value < 2p, exact low digits)
 	typedef E<PB, MASK, MASK, 1> FC;          // canonical constant

@@ -65,7 +65,15 @@ constexpr bool K256 = true;
 #else
 constexpr bool K256 = false;
 #endif
-constexpr bool PLAIN = P25519 || K256;   // R = 1, no headroom limb
+//   -DG29_P448         p = 2^448 - 2^224 - 1 (WEI448 / Ed448 / X448): plain residues on the usual 16 limbs (16 bits of
+//                      headroom stay); the product is folded with 2^464 = 2^8 2^(29*8) + 2^16 and 2^448 = 2^21 2^(29*7) + 1.
+#if defined(G29_P448)
+constexpr bool P448 = true;
+#else
+constexpr bool P448 = false;
+#endif
+constexpr bool PLAIN9 = P25519 || K256;  // R = 1 on nine limbs, no headroom limb
+constexpr bool PLAIN = PLAIN9 || P448;   // R = 1
 //   -DG29_MPINV1       p = -1 mod 2^29 (secp384r1): the Montgomery quotient digit of a column is its low digit and
 //                      "+ m p_0" = "- m + m 2^29" clears it -- no multiplication in the quotient step.  (It has to be a
 //                      compile-time flavour: a wave-uniform branch inside the multiplier cost 25-45 %.)
@@ -88,10 +96,11 @@ template <int PB> struct Cfg {
 	static constexpr int PBITS = PB;
 	static_assert(!P25519 || PB == 255, "the 2^255 - 19 flavour is only for 255-bit fields");
 	static_assert(!K256 || PB == 256, "the secp256k1 flavour is only for 256-bit fields");
-	static constexpr int NL = PLAIN ? 9 : nl_for(PB);
+	static_assert(!P448 || PB == 448, "the Goldilocks flavour is only for 448-bit fields");
+	static constexpr int NL = PLAIN9 ? 9 : nl_for(PB);
 	static constexpr int HEAD = W * NL - PB;           // R / p >= 2^HEAD, HEAD >= 16 (Montgomery flavours)
 	static constexpr int TOPSH = PB - W * (NL - 1);    // p < 2^(29 (NL-1) + TOPSH); may be <= 0
-	static_assert((HEAD >= 16 || PLAIN) && NL <= 19, "field size not supported");
+	static_assert((HEAD >= 16 || PLAIN9) && NL <= 19, "field size not supported");
 	// top limb of a non-negative-limb value < vb * p
 	static constexpr u64 top_from_vb(u64 vb) { return shl_ceil(vb, TOPSH) + 1; }
 	// bias multiples are 2^(BIAS_STEP + BIAS_OFF) p: with a (nearly) empty top limb the smallest
@@ -101,7 +110,7 @@ template <int PB> struct Cfg {
 	// (2^255 - 19 flavour: va * vb <= 2^14 keeps the last product limb and the fold quotient in 32 bits)
 	// (secp256k1 flavour: the last product limb is < va vb 2^19, so va * vb <= 2^12)
 	static constexpr int PROD_E = P25519 ? 14 : (K256 ? 12 : ((2 * HEAD - 2) > 62 ? 62 : (2 * HEAD - 2)));
-	static constexpr bool prod_ok(u64 va, u64 vb) { return va == 0 || vb <= ((1ull << PROD_E) - (PLAIN ? 0 : 1)) / va; }
+	static constexpr bool prod_ok(u64 va, u64 vb) { return va == 0 || vb <= ((1ull << PROD_E) - (PLAIN9 ? 0 : 1)) / va; }
 };
 
 // the (LOGC, S) combinations the formulas use for "a - b + C p": bias tables for exactly these
@@ -349,6 +358,63 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 			G29_PIN(acc);
 		}
 		r[NL - 1] = ((u32)top & ((1u << 23) - 1)) + (u32)acc;  // carry in < 2^12
+	} else if constexpr (P448) {
+		// r = a b mod p, p = 2^448 - 2^224 - 1, value < 2p.  32 product limbs t; modulo p
+		//   2^464 = 2^8 2^(29*8) + 2^16:  t[16 + j] goes to limb j (x 2^16) and limb j + 8 (x 2^8); for j >= 8 the second
+		//   target is limb 16 + i (i = j - 8) again, i.e. limb i (x 2^24 in all) and limb i + 8 (x 2^16 more):
+		//     limb i     (0..7):  t[i]     + 2^16 t[16 + i] + 2^24 t[24 + i]
+		//     limb i + 8 (8..15): t[i + 8] + 2^8  t[16 + i] + 2^17 t[24 + i]
+		//   then the bits of limb 15 from 2^13 up (q, multiples of 2^448 = 2^21 2^(29*7) + 1) go to limbs 7 and 0 in a
+		//   second, MAD-free carry pass.
+		static_assert(NL == 16, "Goldilocks flavour: 16 limbs");
+		t[2 * NL - 1] = (u32)acc;  // < va vb / 8 (Cfg::prod_ok: < 2^27)
+		u32 c16 = 1u << 16, c24 = 1u << 24, c8 = 1u << 8, c17 = 1u << 17;
+#if defined(__HIPCC__)
+		asm volatile("" : "+s"(c16), "+s"(c24), "+s"(c8), "+s"(c17));  // keep the folds MADs
+#endif
+		acc = 0;
+#pragma unroll
+		for (int i = 0; i < 8; i++) {
+			acc += t[i];
+			G29_MAD_VS(acc, t[16 + i], c16);
+			G29_MAD_VS(acc, t[24 + i], c24);
+			r[i] = (u32)acc & MASK;
+			acc >>= W;
+			G29_PIN(acc);
+		}
+#pragma unroll
+		for (int i = 0; i < 7; i++) {
+			acc += t[i + 8];
+			G29_MAD_VS(acc, t[16 + i], c8);
+			G29_MAD_VS(acc, t[24 + i], c17);
+			r[i + 8] = (u32)acc & MASK;
+			acc >>= W;
+			G29_PIN(acc);
+		}
+		acc += t[15];
+		G29_MAD_VS(acc, t[23], c8);
+		G29_MAD_VS(acc, t[31], c17);               // < 2^29 + 2^37 + 2^44 + 2^25
+		const u32 q = (u32)(acc >> 13);           // < 2^32
+		const u32 top = (u32)acc & ((1u << 13) - 1);
+		u64 c = (u64)r[0] + q;
+		r[0] = (u32)c & MASK;
+		u32 cy = (u32)(c >> W);
+#pragma unroll
+		for (int i = 1; i < 7; i++) {
+			const u32 x = r[i] + cy;
+			r[i] = x & MASK;
+			cy = x >> W;
+		}
+		c = (u64)r[7] + cy + ((u64)q << 21);
+		r[7] = (u32)c & MASK;
+		cy = (u32)(c >> W);                        // < 2^25
+#pragma unroll
+		for (int i = 8; i < NL - 1; i++) {
+			const u32 x = r[i] + cy;
+			r[i] = x & MASK;
+			cy = x >> W;
+		}
+		r[NL - 1] = top + cy;                      // <= 2^13
 	} else if constexpr (K256) {
 		// r = a b mod p, p = 2^256 - c, c = 2^32 + 977, value < 2p.  18 product limbs t; modulo p
 		//   2^261 = 32 c = 2^8 2^29 + 31264:          t[j + 9] goes to limb j (x 31264) and limb j + 1 (x 256), j = 0..7

@@ -1163,7 +1163,7 @@ def test_host_pipeline_multi_chunk(gpu_ctx):
 
 
 @pytest.mark.parametrize("env", ["ECAMD_NO_COMB", "ECAMD_NO_P25519", "ECAMD_NO_X25519_LADDER", "ECAMD_NO_EDWARDS_SMUL",
-                                 "ECAMD_NO_FAST_PATH", "ECAMD_NO_ISO", "ECAMD_NO_K256"])
+                                 "ECAMD_NO_FAST_PATH", "ECAMD_NO_ISO", "ECAMD_NO_K256", "ECAMD_NO_P448"])
 def test_fallback_paths_stay_correct(env):
     """every fast path has a switch that routes around it (A/B measurements, fallbacks): the slower routes
     must give the same bytes -- fixed-base without the comb, WEI25519 on the dense field, X25519 and Ed25519
@@ -1191,6 +1191,16 @@ def test_fallback_paths_stay_correct(env):
                 pub = cv.scalar_mult(sc)
                 assert pub == o.scalar_mult(sc)
                 sc2 = rand_bytes(rng, 32 * 80)
+                assert cv.scalar_mult(sc2, pub[0]) == o.scalar_mult(sc2, pub[0])
+            finally:
+                cv.free()
+            cv = ctx.curve("WEI448")                # Goldilocks field unless ECAMD_NO_P448
+            try:
+                o = Oracle("WEI448")
+                sc = rand_bytes(rng, 56 * 40)
+                pub = cv.scalar_mult(sc)
+                assert pub == o.scalar_mult(sc)
+                sc2 = rand_bytes(rng, 56 * 40)
                 assert cv.scalar_mult(sc2, pub[0]) == o.scalar_mult(sc2, pub[0])
             finally:
                 cv.free()

@@ -71,7 +71,7 @@ class Field:
         getattr(lib, f"g_info_{self.pb}")(info)
         assert info[0] == self.nl and info[5] == 4 * len(img), (list(info), len(img))
         self.head, self.va, self.fa_lb, self.fa_tb = info[1], info[4], info[6], info[7]
-        self.R = 1 if flavour in (2, 4) else 1 << (W * self.nl)
+        self.R = 1 if flavour in (2, 4, 5) else 1 << (W * self.nl)
         self.Rinv = pow(self.R, self.p - 2, self.p)
 
     def fn(self, name):
@@ -233,3 +233,19 @@ def test_secp256k1_flavour(lib_k256):
     assert CURVES["SECP256K1"]["p"] == 2**256 - 2**32 - 977
     test_field_ops(lib_k256, "SECP256K1", 4)
     test_jacobian(lib_k256, "SECP256K1", 4)
+
+
+@pytest.fixture(scope="module")
+def lib_p448():
+    """the Goldilocks flavour (16 limbs, plain residues, folds with 2^448 = 2^224 + 1) of the 448-bit unit"""
+    os.makedirs(BUILD, exist_ok=True)
+    so = os.path.join(BUILD, "u29g_host_p448.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DG29_P448", "-DSHIM_ONLY_448", "-o", so,
+                           os.path.join(ROOT, "tests", "u29g_host_shim.cpp")])
+    return C.CDLL(so)
+
+
+def test_p448_flavour(lib_p448):
+    assert CURVES["WEI448"]["p"] == 2**448 - 2**224 - 1
+    test_field_ops(lib_p448, "WEI448", 5)
+    test_jacobian(lib_p448, "WEI448", 5)

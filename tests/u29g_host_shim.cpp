@@ -106,6 +106,8 @@ SHIM(255)
 SHIM(384)
 #elif defined(SHIM_ONLY_256)
 SHIM(256)
+#elif defined(SHIM_ONLY_448)
+SHIM(448)
 #elif !defined(SHIM_ONLY_521)
 SHIM(192)
 SHIM(224)
@@ -117,6 +119,6 @@ SHIM(448)
 SHIM(511)
 SHIM(512)
 #endif
-#if !defined(SHIM_ONLY_255) && !defined(SHIM_ONLY_384) && !defined(SHIM_ONLY_256)
+#if !defined(SHIM_ONLY_255) && !defined(SHIM_ONLY_384) && !defined(SHIM_ONLY_256) && !defined(SHIM_ONLY_448)
 SHIM(521)
 #endif

@@ -20,10 +20,10 @@ def digits(x, nl):
 
 def image(p, a, b, flavour=0):
     """flavour 0: dense Montgomery (also what the secp521r1 flavour uses); 2: p = 2^255 - 19, nine limbs
-    and plain residues (R = 1); 4: p = 2^256 - 2^32 - 977 (secp256k1), the same shape"""
+    and plain residues (R = 1); 4: p = 2^256 - 2^32 - 977 (secp256k1), the same shape; 5: p = 2^448 - 2^224 - 1, plain residues on the usual 16 limbs"""
     pbits = p.bit_length()
-    plain = flavour in (2, 4)
-    nl = 9 if plain else nl_for(pbits)
+    plain = flavour in (2, 4, 5)
+    nl = 9 if flavour in (2, 4) else nl_for(pbits)
     R = 1 if plain else 1 << (W * nl)
     topsh = pbits - W * (nl - 1)
     off = max(0, 1 - topsh)
