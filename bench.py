@@ -192,8 +192,8 @@ def cpu_baseline(curve, scalars, points, slen):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)   # the first launches after the setup run at ramping clocks (profiles/r1f_bench_kernels.md)
     ap.add_argument("--batch-log2", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--curve", default=CURVE, help="ad-hoc runs on another built-in curve (the driver uses the default)")
