@@ -434,6 +434,28 @@ def test_ecdsa_verify_vs_oracle(gpu_ctx, curve, h):
         cv.free()
 
 
+@pytest.mark.parametrize("curve,h", [("SECP256R1", "SHA256"), ("SECP256K1", "SHA256"), ("BRAINPOOLP256R1", "SHA256"),
+                                     ("SECP384R1", "SHA384"), ("SECP256R1", "SHA512")])
+def test_ecdsa_crafted_signatures(gpu_ctx, curve, h):
+    """Wycheproof-style family built by key recovery (tests/test_oracle.py::ecdsa_crafted_cases, pinned there against the
+    unmodified reference): valid signatures whose R has x >= q (only "x mod q == r" accepts them -- on secp256r1 that is the
+    projective comparison of k_p256_verify_loop), tiny / huge r and s, digests 0, 1, q, q - 1, all-ones, and their invalid
+    twins; both through host buffers and tiled to a batch that takes the comb + interleaved-loop path"""
+    from test_oracle import ecdsa_crafted_cases
+    rng = np.random.default_rng(82)
+    cv = gpu_ctx.curve(curve)
+    try:
+        for hash_name in (None, h):
+            case = ecdsa_crafted_cases(curve, rng, hash_name)
+            pubs, sigs, dgs, hl, exp = case[:5]
+            assert exp.count(0) >= 12 and exp.count(1) >= 20
+            assert cv.ecdsa_verify(pubs, sigs, dgs, hl) == exp
+            reps = 6000 // len(exp) + 1
+            assert cv.ecdsa_verify(pubs * reps, sigs * reps, dgs * reps, hl) == exp * reps
+    finally:
+        cv.free()
+
+
 def test_ecdsa_verify_golden(gpu_ctx):
     """every ECDSA / RFC 6979 signature vector of the reference must verify on the GPU (public key
     derived on the GPU from the vector's private key), and must fail with one bit flipped"""

@@ -151,6 +151,124 @@ def test_oracle_protocols_vs_reference_binary(curve, h):
     assert so == sr and set(so[1]) == {0}
 
 
+def ecdsa_crafted_cases(curve, rng, hash_name=None):
+    """Wycheproof-style ECDSA cases built by public-key recovery (the reference snapshot ships the Wycheproof harness but
+    not its vectors): for chosen (r, s, e) and a point R with x(R) = r (mod q), the key Q = r^-1 (s R - e G) makes the
+    signature VALID.  That gives valid signatures with
+      * x(R) >= q, so that only "x mod q == r" accepts them (secp256r1 / secp256k1: x = q + small; the brainpool gap is wide),
+      * tiny and huge r and s (1, 2, 3, q - 1, q - 2, 2^k), digests 0, 1, q, q - 1, 2^l - 1 (e is reduced mod q),
+    next to the invalid twins obtained by adding q to r or s, swapping r and s, or using -R's twin key wrongly.
+    Returns (pubs, sigs, digests, hlen, expected) with expected[i] = 0 accept / 1 reject by construction.  With hash_name
+    every digest is the hash of a random 24-byte message (so the unmodified reference, which hashes by itself, can be asked
+    too) and the messages are returned as a sixth element."""
+    c = CURVES[curve]
+    p, q, a, b = c["p"], c["q"], c["a"], c["b"]
+    cl, ql = (p.bit_length() + 7) // 8, (q.bit_length() + 7) // 8
+    hl = ql if hash_name is None else len(digest(hash_name, b""))
+    G = (c["gx"], c["gy"])
+    assert p % 4 == 3
+    msgs = {}
+
+    def new_digest():
+        if hash_name is None:
+            return rb(rng, hl)
+        m = rb(rng, 24)
+        d = digest(hash_name, m)
+        msgs[d] = m
+        return d
+
+    def lift(x):
+        t = (pow(x, 3, p) + a * x + b) % p
+        y = pow(t, (p + 1) // 4, p)
+        return (x, y) if y * y % p == t else None
+
+    def neg(P):
+        return None if P is None else (P[0], (p - P[1]) % p)
+
+    def recover(R, r, s_, e):
+        ri = pow(r, q - 2, q)
+        return O.py_add(O.py_mul(s_ * ri % q, R, a, p), neg(O.py_mul(e * ri % q, G, a, p)), a, p)
+
+    items = []
+
+    def emit(Q, r, s_, e_bytes, ok):
+        if Q is None:
+            return
+        items.append((Q[0].to_bytes(cl, "big") + Q[1].to_bytes(cl, "big"),
+                      (r % (1 << (8 * ql))).to_bytes(ql, "big") + (s_ % (1 << (8 * ql))).to_bytes(ql, "big"), e_bytes, ok))
+
+    def e_of(db):   # the reference's digest -> integer: leftmost bitlen(q) bits, then mod q
+        v = int.from_bytes(db, "big")
+        if 8 * len(db) > q.bit_length():
+            v >>= 8 * len(db) - q.bit_length()
+        return v % q
+
+    def rnd():
+        return int.from_bytes(rb(rng, ql + 8), "big") % (q - 1) + 1
+
+    # x(R) in [q, p): r = x - q
+    found, x = 0, q
+    while found < 4 and x < p and x < q + 4000:
+        R = lift(x)
+        if R is not None:
+            r, s_, db = x - q, rnd(), new_digest()
+            if r != 0:
+                Q = recover(R, r, s_, e_of(db))
+                emit(Q, r, s_, db, 0)
+                emit(Q, r + 1, s_, db, 1)
+                found += 1
+        x += 1
+    # special r / s / digest values
+    specials = [1, 2, 3, q - 1, q - 2, 1 << (q.bit_length() - 1), (1 << (q.bit_length() - 1)) - 1]
+    digests = [bytes(hl), (1).to_bytes(hl, "big"), q.to_bytes(hl, "big"), (q - 1).to_bytes(hl, "big"), b"\xff" * hl,
+               rb(rng, hl)] if hash_name is None else [new_digest() for _ in range(6)]
+    k = 0
+    for r0 in specials:
+        x = r0
+        R = lift(x)
+        while R is None:       # the next r that is an x coordinate
+            x += 1
+            R = lift(x)
+        r = x % q
+        if r == 0:
+            continue
+        for s_ in (specials[k % len(specials)], rnd()):
+            db = digests[k % len(digests)]
+            k += 1
+            Q = recover(R, r, s_, e_of(db))
+            emit(Q, r, s_, db, 0)
+            if r != s_:
+                emit(Q, s_, r, db, 1)                   # r and s swapped
+            if r + q < (1 << (8 * ql)):
+                emit(Q, r + q, s_, db, 1)               # r + q: same residue, must be rejected (r < q required)
+            if s_ + q < (1 << (8 * ql)):
+                emit(Q, r, s_ + q, db, 1)
+            if e_of(db) != 0:                           # (with e = 0 the negated key gives -R, same x: still valid)
+                emit(neg(Q), r, s_, db, 1)              # the negated key
+    pubs = b"".join(i[0] for i in items)
+    sigs = b"".join(i[1] for i in items)
+    dgs = b"".join(i[2] for i in items)
+    if hash_name is not None:
+        return pubs, sigs, dgs, hl, bytes(i[3] for i in items), b"".join(msgs[i[2]] for i in items)
+    return pubs, sigs, dgs, hl, bytes(i[3] for i in items)
+
+
+@pytest.mark.parametrize("curve,h", [("SECP256R1", "SHA256"), ("SECP256K1", "SHA256"), ("BRAINPOOLP256R1", "SHA256"),
+                                     ("SECP384R1", "SHA384"), ("SECP256R1", "SHA512")])
+def test_ecdsa_crafted_signatures(curve, h):
+    """the restatement accepts / rejects the crafted family exactly as constructed (special digests included), and so does
+    the unmodified reference on the variant whose digests are hashes of messages"""
+    rng = np.random.default_rng(81)
+    pubs, sigs, dgs, hl, exp = ecdsa_crafted_cases(curve, rng)
+    assert len(exp) >= 40 and exp.count(0) >= 12
+    got = Oracle(curve).ecdsa_verify(pubs, sigs, dgs, hl)
+    assert got == exp, [i for i in range(len(exp)) if got[i] != exp[i]]
+    pubs, sigs, dgs, hl, exp, msgs = ecdsa_crafted_cases(curve, rng, h)
+    assert Oracle(curve).ecdsa_verify(pubs, sigs, dgs, hl) == exp and exp.count(0) >= 12
+    if have_ref():
+        assert RefLib(curve).ecdsa_verify(h, pubs, sigs, msgs, 24) == exp
+
+
 KAT_XDH = json.load(open(os.path.join(GOLDEN, "xdh_kats.json")))
 SMALL_ORDER_25519 = [0, 1, 325606250916557431795983626356110631294008115727848805560023387167927233504,
                      39382357235489614581723060781553021112529911719440698176882885853963445705823,
