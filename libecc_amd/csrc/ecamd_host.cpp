@@ -652,26 +652,28 @@ static void curve_free_device(ecamd_curve *cv)
 	}
 }
 
+// failure exit of curve construction: releases the handle; msg == NULL keeps the error already recorded
+static int curve_abort(ecamd_curve *cv, const char *msg)
+{
+	curve_free_device(cv);
+	delete cv;
+	return msg ? fail(msg) : -1;
+}
+
 static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 {
 	if (!(cv->p[0] & 1) || big_bitlen(cv->p) < 160) {
-		curve_free_device(cv);
-		delete cv;
-		return fail("curve: p must be odd and at least 160 bits");
+		return curve_abort(cv, "curve: p must be odd and at least 160 bits");
 	}
 	cv->pbits = big_bitlen(cv->p);
 	cv->qbits = big_bitlen(cv->q);
 	cv->nw = pick_nw(cv->pbits);
 	if (!cv->nw || !ecamd_nw_supported(cv->nw)) {
-		curve_free_device(cv);
-		delete cv;
-		return fail("curve: field size not supported (max 544 bits)");
+		return curve_abort(cv, "curve: field size not supported (max 544 bits)");
 	}
 	if (big_cmp(cv->a, cv->p) >= 0 || big_cmp(cv->b, cv->p) >= 0 || big_cmp(cv->gx, cv->p) >= 0 ||
 	    big_cmp(cv->gy, cv->p) >= 0) {
-		curve_free_device(cv);
-		delete cv;
-		return fail("curve: a, b, gx, gy must be < p");
+		return curve_abort(cv, "curve: a, b, gx, gy must be < p");
 	}
 	cv->clen = (cv->pbits + 7) / 8;
 	cv->qlen = (cv->qbits + 7) / 8;
@@ -692,9 +694,7 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 		}
 	}
 	if (slot < 0) {
-		curve_free_device(cv);
-		delete cv;
-		return fail("curve: all constant-memory curve slots are in use (free a curve first)");
+		return curve_abort(cv, "curve: all constant-memory curve slots are in use (free a curve first)");
 	}
 	cv->slot = slot;
 	cv->qslot = -1;
@@ -708,9 +708,7 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 		}
 	}
 	if (build_and_upload(cv)) {
-		curve_free_device(cv);
-		delete cv;
-		return -1;
+		return curve_abort(cv, nullptr);
 	}
 	cv->gslot = -1;
 	cv->gflavour = (cv->pbits == 521 && big_cmp(big_add(cv->p, Big(1, 1)), big_pow2(521)) == 0) ? 1 : 0;
@@ -736,9 +734,7 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 			}
 		}
 		if (cv->gslot >= 0 && upload_g29(cv)) {
-			curve_free_device(cv);
-		delete cv;
-			return -1;
+			return curve_abort(cv, nullptr);
 		}
 	}
 	// generator X || Y, then the two broadcast scalars of the subgroup / cofactor passes: q (qlen bytes) and h (1 byte)
@@ -759,9 +755,7 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	}
 	if (hipMalloc((void **)&cv->d_gen, g.size()) != hipSuccess ||
 	    hipMemcpy(cv->d_gen, g.data(), g.size(), hipMemcpyHostToDevice) != hipSuccess) {
-		curve_free_device(cv);
-		delete cv;
-		return fail("curve: generator upload failed");
+		return curve_abort(cv, "curve: generator upload failed");
 	}
 	cv->d_gtab = nullptr;
 	cv->d_comb = nullptr;
@@ -780,11 +774,12 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 			sc[i * 32 + 31] = (uint8_t)(i + 1);
 		}
 		uint8_t *d = nullptr;
-		if (hipMalloc((void **)&d, sizeof(sc) + sizeof(pts) + sizeof(st)) != hipSuccess ||
-		    hipMemcpy(d, sc, sizeof(sc), hipMemcpyHostToDevice) != hipSuccess) {
-			curve_free_device(cv);
-		delete cv;
-			return fail("curve: generator table allocation failed");
+		if (hipMalloc((void **)&d, sizeof(sc) + sizeof(pts) + sizeof(st)) != hipSuccess) {
+			return curve_abort(cv, "curve: generator table allocation failed");
+		}
+		if (hipMemcpy(d, sc, sizeof(sc), hipMemcpyHostToDevice) != hipSuccess) {
+			(void)hipFree(d);
+			return curve_abort(cv, "curve: generator table upload failed");
 		}
 		int rc = smul_dev_locked(ctx, cv, 8, d, 32, nullptr, d + sizeof(sc), d + sizeof(sc) + sizeof(pts), ctx->stream);
 		if (!rc && (hipStreamSynchronize(ctx->stream) != hipSuccess ||
@@ -805,9 +800,7 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 		}
 		if (rc || hipMalloc((void **)&cv->d_gtab, tab.size() * 4) != hipSuccess ||
 		    hipMemcpy(cv->d_gtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-			curve_free_device(cv);
-		delete cv;
-			return fail("curve: generator table construction failed");
+			return curve_abort(cv, "curve: generator table construction failed");
 		}
 		big_digits29(cv->qdig, 9, cv->q);
 	}
