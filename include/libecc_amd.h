@@ -182,6 +182,22 @@ int ec_eddsa_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t
 			      const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, int *all_valid,
 			      uint32_t *first_rejected);
 
+/* Ed25519 signing (EDDSA25519 / EDDSA25519CTX / EDDSA25519PH on the WEI25519 handle), the device-side steps of ec_sign ->
+ * _eddsa_sign (sig/eddsa.c:1554-1870) around the caller's two hashes -- the split ec_eddsa_verify_batch uses:
+ *   1. the caller derives (a, prefix) from each key (eddsa_get_digest_from_priv_key :306 + eddsa_derive_priv_key :611: SHA-512, clamping) and hashes
+ *      r_hash = SHA-512(dom2 || prefix || PH(M))                                          n x 64 bytes
+ *   2. ec_eddsa_sign_R_batch: r = r_hash mod q (:1731), R = prj_pt_mul(r, G) (:1776), prj_pt_shortw_to_aff_pt_edwards +
+ *      eddsa_encode_point (:1786-1791) -> R_enc n x 32 (the first half of each signature).  status 1 only if the
+ *      multiplication failed (it cannot for the generator); r = 0 mod q encodes the neutral element as the reference does.
+ *   3. the caller hashes hram = SHA-512(dom2 || R || A || PH(M))                           n x 64 bytes
+ *   4. ec_eddsa_sign_S_batch: S = (r + hram a) mod q (:1847-1857), a_scalars n x 32 little-endian (the clamped secret
+ *      scalars) -> S_out n x 32 little-endian (the second half).
+ * Ed448 signing is not provided. */
+int ec_eddsa_sign_R_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *r_hash, uint8_t *R_enc,
+			  uint8_t *status);
+int ec_eddsa_sign_S_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *r_hash, const uint8_t *hram,
+			  const uint8_t *a_scalars, uint8_t *S_out);
+
 /* Point wire formats (curves/prj_pt.c:462-624): affine X || Y (2*clen bytes, what the entry points above
  * use) and projective X || Y || Z (3*clen bytes: prj_pt_import_from_buf / prj_pt_export_to_buf, the format
  * of `ec_utils scalar_mult` and of structured public keys). */

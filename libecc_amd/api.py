@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "ec_fp_op_batch", "ec_ecdsa_verify_batch", "ec_ecdsa_sign_batch", "ec_ecccdh_derive_batch", "ec_xdh_batch",
     "ec_prj_pt_mul_batch_fmt", "ec_prj_pt_unique_batch", "ec_structured_pub_key_import_batch",
     "ec_eddsa_verify_batch", "ec_eddsa_verify_all_batch", "ec_ecdsa_verify_batch_dev", "ec_eddsa_verify_batch_dev", "ec_xdh_batch_dev",
-    "ec_ecdsa_sign_batch_dev", "ec_ecccdh_derive_batch_dev",
+    "ec_ecdsa_sign_batch_dev", "ec_ecccdh_derive_batch_dev", "ec_eddsa_sign_R_batch", "ec_eddsa_sign_S_batch",
 ]
 
 
@@ -70,6 +70,8 @@ def load_library():
         L.ec_structured_pub_key_import_batch.argtypes = [vp, vp, u32, u8p, u32, C.c_int, u8p, u8p]
         L.ec_ecdsa_verify_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp]
         L.ec_eddsa_verify_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp]
+        L.ec_eddsa_sign_R_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p]
+        L.ec_eddsa_sign_S_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
         L.ec_ecdsa_sign_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp, vp]
         L.ec_ecccdh_derive_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp]
         L.ec_xdh_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp]
@@ -222,6 +224,20 @@ class Curve:
         _chk(self.L, self.L.ec_eddsa_verify_batch(self.ctx.h, self.h, n, pubkeys, sigs, hram, hram_len, res),
              "ec_eddsa_verify_batch")
         return res.raw[:n]
+
+    def eddsa_sign_R(self, r_hash):
+        """Ed25519 signing, step 1: n x 64-byte SHA-512(dom2 || prefix || PH(M)) -> (n x 32 encoded R, status)"""
+        n = len(r_hash) // 64
+        out, st = C.create_string_buffer(max(1, 32 * n)), C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_eddsa_sign_R_batch(self.ctx.h, self.h, n, r_hash, out, st), "ec_eddsa_sign_R_batch")
+        return out.raw[:32 * n], st.raw[:n]
+
+    def eddsa_sign_S(self, r_hash, hram, a_scalars):
+        """Ed25519 signing, step 2: S = (r + hram * a) mod q, n x 32 bytes little-endian"""
+        n = len(r_hash) // 64
+        out = C.create_string_buffer(max(1, 32 * n))
+        _chk(self.L, self.L.ec_eddsa_sign_S_batch(self.ctx.h, self.h, n, r_hash, hram, a_scalars, out), "ec_eddsa_sign_S_batch")
+        return out.raw[:32 * n]
 
     def eddsa_verify_all(self, pubkeys, sigs, hram, hram_len=None):
         """ec_verify_batch's whole-batch predicate: (all_valid, index of the first rejected item or n)"""

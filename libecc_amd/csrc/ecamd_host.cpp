@@ -2448,6 +2448,115 @@ extern "C" int ec_eddsa_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *cv, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Ed25519 signing: the two device-side steps of _eddsa_sign (sig/eddsa.c:1554-1870) around the caller's hashes
+// ------------------------------------------------------------------------------------------
+static int eddsa_sign_setup(const char *fn, ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const void *a, const void *b,
+			    const void *c, EcamdEdSignArgs *T)
+{
+	if (!ctx || !cv_in || cv_in->ctx != ctx || (n && (!a || !b || !c))) {
+		return fail(std::string(fn) + ": bad argument");
+	}
+	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
+	if (cv->ed_state == 0) {
+		ed_setup(cv);
+	}
+	if (cv->ed_state < 0) {
+		return fail(std::string(fn) + ": Ed25519 signing needs the WEI25519 curve handle");
+	}
+	memset(T, 0, sizeof(*T));
+	memcpy(T->alpha, cv->ed_tmpl.alpha, sizeof(T->alpha));
+	memcpy(T->A3, cv->ed_tmpl.A3, sizeof(T->A3));
+	T->slot = cv->slot;
+	T->qslot = cv->qslot;
+	return 0;
+}
+
+// stage: 3 r big-endian, 4 [r]G, 5 its status
+static int eddsa_sign_R_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, const EcamdEdSignArgs &T, uint32_t n,
+				   const uint8_t *d_rhash, uint8_t *d_Renc, uint8_t *d_status, hipStream_t s)
+{
+	if (n > ctx->max_chunk) {  // bound the scratch: pieces of max_chunk items, in order on the stream
+		for (uint32_t off = 0; off < n; off += ctx->max_chunk) {
+			const uint32_t m = (n - off) < ctx->max_chunk ? (n - off) : ctx->max_chunk;
+			if (eddsa_sign_R_dev_locked(ctx, cv, T, m, d_rhash + (size_t)off * 64, d_Renc + (size_t)off * 32, d_status + off, s)) {
+				return -1;
+			}
+		}
+		return 0;
+	}
+	if (ensure(&ctx->stage[3], &ctx->stage_bytes[3], (size_t)n * 32) || ensure(&ctx->stage[4], &ctx->stage_bytes[4], (size_t)n * 64) ||
+	    ensure(&ctx->stage[5], &ctx->stage_bytes[5], n)) {
+		return -1;
+	}
+	uint8_t **S = ctx->stage;
+	EcamdEdSignArgs A = T;
+	A.n = n;
+	A.r_hash = d_rhash;
+	A.r_be = S[3];
+	HIPCHK(ecamd_launch_ed_sign_r(A, s));
+	if (smul_dev_locked(ctx, cv, n, S[3], 32, nullptr, S[4], S[5], s)) {   // prj_pt_mul(r, G) (:1776)
+		return -1;
+	}
+	A.Rw = S[4];
+	A.stR = S[5];
+	A.out = d_Renc;
+	A.status = d_status;
+	HIPCHK(ecamd_launch_ed_sign_enc(A, s));
+	return 0;
+}
+
+extern "C" int ec_eddsa_sign_R_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *r_hash, uint8_t *R_enc,
+				     uint8_t *status)
+{
+	if (!ctx) {
+		return fail("ec_eddsa_sign_R_batch: bad argument");
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	EcamdEdSignArgs T;
+	if (eddsa_sign_setup("ec_eddsa_sign_R_batch", ctx, cv, n, r_hash, R_enc, status, &T)) {
+		return -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	HIPCHK(hipSetDevice(ctx->device));
+	const std::vector<HostArr> arrs = {{r_hash, nullptr, 64}, {nullptr, R_enc, 32}, {nullptr, status, 1}};
+	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+					       hipStream_t s, const std::function<int()> &) {
+		return eddsa_sign_R_dev_locked(ctx, cv, T, m, ip[0], op[1], op[2], s);
+	});
+}
+
+extern "C" int ec_eddsa_sign_S_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *r_hash,
+				     const uint8_t *hram, const uint8_t *a_scalars, uint8_t *S_out)
+{
+	if (!ctx || (n && !S_out)) {
+		return fail("ec_eddsa_sign_S_batch: bad argument");
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	EcamdEdSignArgs T;
+	if (eddsa_sign_setup("ec_eddsa_sign_S_batch", ctx, cv, n, r_hash, hram, a_scalars, &T)) {
+		return -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	HIPCHK(hipSetDevice(ctx->device));
+	const std::vector<HostArr> arrs = {{r_hash, nullptr, 64}, {hram, nullptr, 64}, {a_scalars, nullptr, 32}, {nullptr, S_out, 32}};
+	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+					       hipStream_t s, const std::function<int()> &) {
+		EcamdEdSignArgs A = T;
+		A.n = m;
+		A.r_hash = ip[0];
+		A.hram = ip[1];
+		A.a = ip[2];
+		A.out = op[3];
+		HIPCHK(ecamd_launch_ed_sign_S(A, s));
+		return 0;
+	});
+}
+
+// ------------------------------------------------------------------------------------------
 // scalar multiplication / normalisation with a choice of point wire formats
 // ------------------------------------------------------------------------------------------
 static int pt_fmt_batch(const char *fn, ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *scalars,

@@ -168,6 +168,23 @@ struct EcamdEd448DecodeArgs {
 	uint32_t d448[17], diso[17], alpha[17], A3[17];   // Montgomery form (radix 2^448)
 	int slot;
 };
+// Ed25519 signing, the device-side steps around the caller's two hashes (sig/eddsa.c:1554-1870)
+struct EcamdEdSignArgs {
+	const uint8_t *r_hash;   // n x 64 little-endian: H(dom2 || prefix || PH(M))
+	const uint8_t *hram;     // S step: n x 64 little-endian H(dom2 || R || A || PH(M))
+	const uint8_t *a;        // S step: n x 32 little-endian clamped secret scalars
+	uint8_t *r_be;           // r step: n x 32 big-endian r mod q (the scalar of [r]G)
+	const uint8_t *Rw;       // encode step: n x 64 affine Weierstrass [r]G
+	const uint8_t *stR;      // encode step: its status
+	uint8_t *out;            // encode step: n x 32 encoded R; S step: n x 32 little-endian S
+	uint8_t *status;         // encode step: n
+	uint32_t n;
+	uint32_t alpha[17], A3[17];   // Montgomery form, as in EcamdEdDecodeArgs
+	int slot, qslot;
+};
+hipError_t ecamd_launch_ed_sign_r(const EcamdEdSignArgs &a, hipStream_t s);
+hipError_t ecamd_launch_ed_sign_enc(const EcamdEdSignArgs &a, hipStream_t s);
+hipError_t ecamd_launch_ed_sign_S(const EcamdEdSignArgs &a, hipStream_t s);
 hipError_t ecamd_launch_ed448_decode(const EcamdEd448DecodeArgs &a, hipStream_t s);
 hipError_t ecamd_launch_ed448_scal(const EcamdEdScalArgs &a, hipStream_t s);
 hipError_t ecamd_launch_ed_decode(int nw, const EcamdEdDecodeArgs &a, hipStream_t s);

@@ -807,6 +807,91 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed_fin(EcamdEdFinArgs 
 //   [4]A = infinity (A' = [c4]A with c4 prime to q has small order exactly when A has).
 // Square root: p = 3 mod 4 (wave-uniform exponent bits).
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// Ed25519 signing around the caller's hashes (_eddsa_sign, sig/eddsa.c:1554-1870):
+//   k_ed_sign_r:   r = H(dom2 || prefix || PH(M)) little-endian mod q (:1731), big-endian for prj_pt_mul(r, G) (:1776)
+//   k_ed_sign_enc: prj_pt_shortw_to_aff_pt_edwards (curves/prj_pt.c:2004: infinity -> (0, 1); else (u, v) = (X - A/3, Y),
+//                  x = alpha u / v, y = (u - 1) / (u + 1), curves/aff_pt_edwards.c:620) + eddsa_encode_point (:330);
+//                  [r]G with 0 < r < q is never 2-torsion, so v and u + 1 are invertible (one shared inversion)
+//   k_ed_sign_S:   S = (r + h a) mod q (:1847-1857), a = the clamped secret scalar, little-endian out
+// ------------------------------------------------------------------------------------------
+template <int NW> static __device__ Fe<NW> ed_le64_mod_q(const u8 *hp, int qs)
+{
+	const CurveK<NW> &Q = ConstTab<NW>::get(qs);
+	const Fe<NW> lo = fe_load_le<NW>(hp, 32), hi = fe_load_le<NW>(hp + 32, 32);
+	const Fe<NW> r2 = fe_const<NW>(Q.r2);
+	Fe<NW> onep = fe_zero<NW>();
+	onep.v[0] = 1u;
+	// Montgomery products with R = 2^256: hi R2 / R = hi 2^256, (lo R2 / R) * 1 / R = lo  (mod q), as in k_ed_scal
+	return fe_add<NW>(fe_mul<NW>(hi, r2, qs), fe_mul<NW>(fe_mul<NW>(lo, r2, qs), onep, qs), qs);
+}
+
+template <int NW> static __device__ void ed_store_le32(u8 *out, const Fe<NW> &v)
+{
+	for (int b = 0; b < 32; b++) {
+		out[b] = (u8)(v.v[b >> 2] >> (8 * (b & 3)));
+	}
+}
+
+template <int NW> __global__ __launch_bounds__(64) void k_ed_sign_r(EcamdEdSignArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	fe_store_be<NW>(A.r_be + (size_t)i * 32, 32, ed_le64_mod_q<NW>(A.r_hash + (size_t)i * 64, A.qslot));
+}
+
+template <int NW> __global__ __launch_bounds__(64) void k_ed_sign_enc(EcamdEdSignArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int slot = A.slot;
+	u8 *out = A.out + (size_t)i * 32;
+	const u32 st = A.stR[i];
+	if (st != 0) {
+		// r = 0 mod q: the neutral element (0, 1); a failed multiplication: an error
+		for (int b = 0; b < 32; b++) {
+			out[b] = (u8)((st == 2 && b == 0) ? 1 : 0);
+		}
+		A.status[i] = (st == 2) ? 0 : 1;
+		return;
+	}
+	const Fe<NW> one = fe_const<NW>(ConstTab<NW>::get(slot).one);
+	const u8 *src = A.Rw + (size_t)i * 64;
+	const Fe<NW> X = fe_to_mont<NW>(fe_load_be<NW>(src, 32), slot), v = fe_to_mont<NW>(fe_load_be<NW>(src + 32, 32), slot);
+	const Fe<NW> u = fe_sub<NW>(X, fe_const<NW>(A.A3), slot);
+	const Fe<NW> up1 = fe_add<NW>(u, one, slot);
+	Fe<NW> d11;
+	const Fe<NW> dd = fe_mul<NW>(up1, v, slot);
+	const Fe<NW> dinv = fe_mul<NW>(fe_sqr_n<NW>(fe_pow_2_250m1<NW>(dd, &d11, slot), 5, slot), d11, slot);  // dd^(p-2)
+	const Fe<NW> vinv = fe_mul<NW>(dinv, up1, slot), uinv = fe_mul<NW>(dinv, v, slot);   // 1 / v, 1 / (u + 1)
+	const Fe<NW> xe = fe_mul<NW>(fe_mul<NW>(fe_const<NW>(A.alpha), u, slot), vinv, slot);
+	const Fe<NW> ye = fe_mul<NW>(fe_sub<NW>(u, one, slot), uinv, slot);
+	const Fe<NW> xp = fe_from_mont<NW>(xe, slot);
+	Fe<NW> yp = fe_from_mont<NW>(ye, slot);
+	yp.v[7] |= (xp.v[0] & 1u) << 31;                 // y < 2^255; bit 255 carries the parity of x
+	ed_store_le32<NW>(out, yp);
+	A.status[i] = fe_is_zero<NW>(dd) ? 1 : 0;        // cannot happen for points of the prime-order subgroup
+}
+
+template <int NW> __global__ __launch_bounds__(64) void k_ed_sign_S(EcamdEdSignArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int qs = A.qslot;
+	const Fe<NW> r2 = fe_const<NW>(ConstTab<NW>::get(qs).r2);
+	const Fe<NW> r = ed_le64_mod_q<NW>(A.r_hash + (size_t)i * 64, qs);
+	const Fe<NW> h = ed_le64_mod_q<NW>(A.hram + (size_t)i * 64, qs);
+	const Fe<NW> a = fe_load_le<NW>(A.a + (size_t)i * 32, 32);                       // < 2^256, reduced by the product with R^2
+	const Fe<NW> ha = fe_mul<NW>(h, fe_mul<NW>(a, r2, qs), qs);                      // h (a R) / R = h a mod q
+	ed_store_le32<NW>(A.out + (size_t)i * 32, fe_add<NW>(r, ha, qs));
+}
+
 // Fixed exponents of p = 2^448 - 2^224 - 1 by addition chains (the prime is pinned by ed448_setup):
 //   f(k) = w^(2^k - 1): f(2k) = f(k)^(2^k) f(k), f(k + 1) = f(k)^2 w; 222 = 2 x (2 x (2 x (2 x (2 x (2 x 3 + 1)) + 1) + 1) + 1)
 //   (p - 3) / 4 = 2^446 - 2^222 - 1 = 2^223 (2^223 - 1) + (2^222 - 1):  w^((p-3)/4) = f(223)^(2^223) f(222)     446 S + 14 M
@@ -1277,6 +1362,33 @@ hipError_t ecamd_launch_ed_fin(int nw, const EcamdEdFinArgs &a, hipStream_t s)
 	} else {
 		return hipErrorInvalidValue;
 	}
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_ed_sign_r(const EcamdEdSignArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_ed_sign_r<8>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_ed_sign_enc(const EcamdEdSignArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_ed_sign_enc<8>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_ed_sign_S(const EcamdEdSignArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_ed_sign_S<8>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
 	return hipGetLastError();
 }
 

@@ -1074,6 +1074,75 @@ def test_protocol_round_trips_large(gpu_ctx, curve, log2n):
         cv.free()
 
 
+def test_eddsa25519_sign_steps(gpu_ctx):
+    """ec_eddsa_sign_R_batch / ec_eddsa_sign_S_batch: with the two hashes done here, R || S must be the signature bytes of
+    the RFC 8032 signer of tests/oracles.py (itself pinned against the reference's ec_sign in tests/test_oracle.py) and, when
+    oracle/_ref is there, of the unmodified reference; Ed25519ctx-style dom2 prefixes only change the hashes; edge values of
+    the 64-byte hash (0, q, all ones) and of the secret scalar"""
+    import hashlib
+    import libecc_amd
+    import oracles as O
+    from test_oracle import ED_MSG_LEN
+    rng = np.random.default_rng(76)
+    q = O.ED_Q
+    cv = gpu_ctx.curve("WEI25519")
+    try:
+        n = 300
+        seeds, msgs = rand_bytes(rng, 32 * n), rand_bytes(rng, ED_MSG_LEN * n)
+        doms = [b"" if i % 3 else b"SigEd25519 no Ed25519 collisions" + bytes([0, 3]) + b"ctx" for i in range(n)]
+        A, sig, a_sc, r_hash = [], [], [], []
+        for i in range(n):
+            seed, m = seeds[32 * i:32 * i + 32], msgs[ED_MSG_LEN * i:ED_MSG_LEN * (i + 1)]
+            pub, sg, _ = O.ed25519_sign(seed, m, dom=doms[i])
+            hk = hashlib.sha512(seed).digest()
+            a = (int.from_bytes(hk[:32], "little") & ((1 << 254) - 8)) | (1 << 254)
+            A.append(pub)
+            sig.append(sg)
+            a_sc.append(a.to_bytes(32, "little"))
+            r_hash.append(hashlib.sha512(doms[i] + hk[32:] + m).digest())
+        R, st = cv.eddsa_sign_R(b"".join(r_hash))
+        assert st == bytes(n)
+        assert R == b"".join(sg[:32] for sg in sig)
+        hram = [hashlib.sha512(doms[i] + R[32 * i:32 * i + 32] + A[i] + msgs[ED_MSG_LEN * i:ED_MSG_LEN * (i + 1)]).digest()
+                for i in range(n)]
+        S = cv.eddsa_sign_S(b"".join(r_hash), b"".join(hram), b"".join(a_sc))
+        assert S == b"".join(sg[32:] for sg in sig)
+        if have_ref():
+            idx = [i for i in range(n) if doms[i] == b""][:24]
+            rp, rs, rst = O.ref_ed25519_sign(b"".join(seeds[32 * i:32 * i + 32] for i in idx),
+                                             b"".join(msgs[ED_MSG_LEN * i:ED_MSG_LEN * (i + 1)] for i in idx), ED_MSG_LEN)
+            assert rst == bytes(len(idx))
+            assert rs == b"".join(R[32 * i:32 * i + 32] + S[32 * i:32 * i + 32] for i in idx)
+        # the signatures verify on the GPU as well
+        plain = [i for i in range(n) if doms[i] == b""]
+        cut = lambda b, w: b"".join(b[w * i:w * i + w] for i in plain)
+        sigs = b"".join(R[32 * i:32 * i + 32] + S[32 * i:32 * i + 32] for i in plain)
+        assert cv.eddsa_verify(b"".join(A[i] for i in plain), sigs, b"".join(hram[i] for i in plain)) == bytes(len(plain))
+        # edge values
+        eh = [bytes(64), q.to_bytes(64, "little"), (q - 1).to_bytes(64, "little"), (q + 1).to_bytes(64, "little"), b"\xff" * 64,
+              (1).to_bytes(64, "little"), (1 << 511).to_bytes(64, "little")]
+        ea = [bytes(32), b"\xff" * 32, (1 << 254).to_bytes(32, "little"), q.to_bytes(32, "little"), (q - 1).to_bytes(32, "little"),
+              a_sc[0], a_sc[1]]
+        R2, st2 = cv.eddsa_sign_R(b"".join(eh))
+        assert st2 == bytes(len(eh))
+        for i, h in enumerate(eh):
+            r = int.from_bytes(h, "little") % q
+            exp = (1).to_bytes(32, "little") if r == 0 else O.ed_encode(O.ed_mul(r, O.ED_B))
+            assert R2[32 * i:32 * i + 32] == exp, i
+        S2 = cv.eddsa_sign_S(b"".join(eh), b"".join(reversed(eh)), b"".join(ea))
+        for i in range(len(eh)):
+            r, h, a = (int.from_bytes(x, "little") for x in (eh[i], eh[len(eh) - 1 - i], ea[i]))
+            assert S2[32 * i:32 * i + 32] == ((r + h * a) % q).to_bytes(32, "little"), i
+        other = gpu_ctx.curve("SECP256R1")
+        try:
+            with pytest.raises(libecc_amd.EcamdError):
+                other.eddsa_sign_R(bytes(64))
+        finally:
+            other.free()
+    finally:
+        cv.free()
+
+
 def test_libecc_glue_demo():
     """examples/libecc_glue_demo.c -- the struct-array binding a libecc application would add, linked to
     the UNMODIFIED libecc (prebuilt in the authoring container as oracle/_ref/glue_demo): libecc's own nn /

@@ -90,6 +90,15 @@ def main():
         res.clear()
         timed("ed25519_verify", lambda: L.ec_eddsa_verify_batch(cv.ctx.h, cv.h, n, P, S, H, 64, b_ok))
         assert set(b_ok.raw[:n]) == {0}
+        # signing steps on random 64-byte hashes / 32-byte scalars (the hashes themselves are the caller's)
+        rh, hh, aa = (rng.integers(0, 256, size=n * w, dtype=np.uint8).tobytes() for w in (64, 64, 32))
+        b_R, b_S = C.create_string_buffer(b"\1" * (32 * n)), C.create_string_buffer(b"\1" * (32 * n))
+        timed("ed25519_sign_R", lambda: L.ec_eddsa_sign_R_batch(cv.ctx.h, cv.h, n, rh, b_R, b_st))
+        assert set(b_st.raw[:n]) == {0}
+        timed("ed25519_sign_S", lambda: L.ec_eddsa_sign_S_batch(cv.ctx.h, cv.h, n, rh, hh, aa, b_S))
+        r0 = int.from_bytes(rh[:64], "little") % O.ED_Q
+        assert b_R.raw[:32] == O.ed_encode(O.ed_mul(r0, O.ED_B))
+        assert b_S.raw[:32] == ((r0 + int.from_bytes(hh[:64], "little") * int.from_bytes(aa[:32], "little")) % O.ED_Q).to_bytes(32, "little")
         print({k: f"{v / 1e6:.2f} M/s" for k, v in res.items()})
 
 
