@@ -1285,6 +1285,105 @@ int orc_eddsa25519_verify_batch(const orc_curve *c, uint32_t n, const uint8_t *p
 }
 
 /* ------------------------------------------------------------------------------------
+ * Ed25519 signing (_eddsa_sign, sig/eddsa.c:1554-1870), the part between and after the two hashes:
+ *   r = H(dom2 || prefix || PH(M)) little-endian (eddsa_decode_integer :1710), mod q (:1731);
+ *   R = prj_pt_mul(r, G) (:1776); prj_pt_shortw_to_aff_pt_edwards (curves/prj_pt.c:2004): infinity -> (0, 1), otherwise
+ *     prj_pt_to_aff, aff_pt_shortw_to_montgomery (u, v) = (X - A/3, Y), aff_pt_montgomery_to_edwards
+ *     (curves/aff_pt_edwards.c:620-686): (0, 0) -> (0, -1), x = alpha u / v, y = (u - 1) / (u + 1) with fp_inv(0) an
+ *     error, final on-curve check; eddsa_encode_point (:330): y little-endian, top bit = x mod 2;
+ *   S = (r + h a) mod q with h = H(dom2 || R || A || PH(M)) mod q and a the clamped secret scalar (:1847-1857).
+ * ---------------------------------------------------------------------------------- */
+static void le_to_nn_mod_q(u64 *out, const u8 *le, int len, const orc_curve *c)
+{
+	u64 w[ORC_MAXW];
+	u8 be[64];
+	int b;
+	for (b = 0; b < len; b++) be[b] = le[len - 1 - b];
+	nn_zero(w, ORC_MAXW);
+	nn_from_be(w, 8, be, len);
+	nn_zero(out, ORC_MAXW);
+	nn_mod(out, w, 8, c->q, c->q_n);
+}
+
+int orc_eddsa25519_sign_R_batch(const orc_curve *c, uint32_t n, const uint8_t *r_hash, uint8_t *R_enc, uint8_t *status)
+{
+	const orc_fp_ctx *f = &c->fp;
+	const int fn = f->n;
+	ed_consts k;
+	u64 zero[ORC_MAXW], one[ORC_MAXW];
+	pt G;
+	uint32_t i;
+	if (f->pbits != 255 || ed_consts_init(&k, c)) return -1;
+	nn_zero(zero, fn);
+	nn_zero(one, fn); one[0] = 1;
+	load_gen(&G, c);
+	for (i = 0; i < n; i++) {
+		u64 r[ORC_MAXW], u[ORC_MAXW], v[ORC_MAXW], x[ORC_MAXW], y[ORC_MAXW], t[ORC_MAXW], l[ORC_MAXW], rr[ORC_MAXW];
+		u8 be[32];
+		pt R;
+		int b;
+		status[i] = 1;
+		memset(R_enc + (size_t)i * 32, 0, 32);
+		le_to_nn_mod_q(r, r_hash + (size_t)i * 64, 64, c);
+		if (pt_mul(&R, r, c->q_n, &G, c)) continue;
+		if (nn_iszero(R.Z, fn)) {
+			nn_zero(x, fn);
+			nn_copy(y, one, fn);
+		} else {
+			if (pt_unique(&R, c)) continue;
+			fp_sub(u, R.X, k.A3, f);
+			nn_copy(v, R.Y, fn);
+			if (nn_iszero(u, fn) && nn_iszero(v, fn)) nn_copy(v, one, fn);   /* (0, 0) -> (0, -1) */
+			if (nn_iszero(v, fn)) continue;                                    /* fp_inv(0) */
+			fp_pow_pm2(x, v, f);
+			fp_mul(x, x, k.alpha, f);
+			fp_mul(x, x, u, f);
+			fp_add(t, u, one, f);
+			if (nn_iszero(t, fn)) continue;                                    /* fp_inv(0) */
+			fp_pow_pm2(y, t, f);
+			fp_sub(t, u, one, f);
+			fp_mul(y, y, t, f);
+			/* a x^2 + y^2 == 1 + d x^2 y^2 */
+			fp_mul(t, x, x, f);
+			fp_mul(l, y, y, f);
+			fp_mul(rr, t, l, f);
+			fp_mul(rr, rr, k.d, f);
+			fp_add(rr, rr, one, f);
+			fp_mul(t, t, k.am, f);
+			fp_add(l, l, t, f);
+			if (nn_cmp(l, rr, fn) != 0) continue;
+		}
+		nn_to_be(be, 32, y, fn);
+		for (b = 0; b < 32; b++) R_enc[(size_t)i * 32 + b] = be[31 - b];
+		R_enc[(size_t)i * 32 + 31] |= (u8)((x[0] & 1) << 7);
+		status[i] = 0;
+	}
+	return 0;
+}
+
+int orc_eddsa25519_sign_S_batch(const orc_curve *c, uint32_t n, const uint8_t *r_hash, const uint8_t *hram,
+				const uint8_t *a_scalars, uint8_t *S_out)
+{
+	uint32_t i;
+	if (c->fp.pbits != 255) return -1;
+	for (i = 0; i < n; i++) {
+		u64 r[ORC_MAXW], h[ORC_MAXW], a[ORC_MAXW], S[ORC_MAXW], t[ORC_MAXW + 1];
+		u8 be[32];
+		int b;
+		le_to_nn_mod_q(r, r_hash + (size_t)i * 64, 64, c);
+		le_to_nn_mod_q(h, hram + (size_t)i * 64, 64, c);
+		le_to_nn_mod_q(a, a_scalars + (size_t)i * 32, 32, c);
+		q_mul(S, h, a, c);
+		nn_zero(t, ORC_MAXW + 1);
+		t[c->q_n] = nn_add(t, S, r, c->q_n);
+		nn_mod(S, t, c->q_n + 1, c->q, c->q_n);
+		nn_to_be(be, 32, S, c->q_n);
+		for (b = 0; b < 32; b++) S_out[(size_t)i * 32 + b] = be[31 - b];
+	}
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------
  * Projective wire format (the chain of `ec_utils scalar_mult`, tests/ec_utils.c:1380-1538):
  *   prj_pt_import_from_buf (curves/prj_pt.c:462-500): X, Y, Z big-endian, each < p (fp_init_from_buf),
  *     projective on-curve check -- Z = 0 is accepted when it satisfies the equation;

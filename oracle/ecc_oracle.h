@@ -53,6 +53,9 @@ int orc_xdh_batch(const orc_curve *c, uint32_t len, uint32_t n, const uint8_t *k
 		  uint8_t *out, uint8_t *status);
 int orc_eddsa25519_verify_batch(const orc_curve *c, uint32_t n, const uint8_t *pubs, const uint8_t *sigs,
 				const uint8_t *hram, uint32_t hlen, uint8_t *result);
+int orc_eddsa25519_sign_R_batch(const orc_curve *c, uint32_t n, const uint8_t *r_hash, uint8_t *R_enc, uint8_t *status);
+int orc_eddsa25519_sign_S_batch(const orc_curve *c, uint32_t n, const uint8_t *r_hash, const uint8_t *hram,
+				const uint8_t *a_scalars, uint8_t *S_out);
 int orc_prj_batch(const orc_curve *c, uint32_t n, const uint8_t *scalars, uint32_t slen, const uint8_t *points,
 		  uint8_t *out, uint8_t *status);
 int orc_eddsa448_verify_batch(const orc_curve *c, uint32_t n, const uint8_t *pubs, const uint8_t *sigs,

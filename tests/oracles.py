@@ -112,6 +112,18 @@ class Oracle:
         return sec.raw, st.raw
 
 
+    def eddsa_sign_R(self, r_hash):
+        n = len(r_hash) // 64
+        out, st = C.create_string_buffer(max(1, 32 * n)), C.create_string_buffer(max(1, n))
+        assert self.L.orc_eddsa25519_sign_R_batch(self.ctx, n, r_hash, out, st) == 0
+        return out.raw[:32 * n], st.raw[:n]
+
+    def eddsa_sign_S(self, r_hash, hram, a_scalars):
+        n = len(r_hash) // 64
+        out = C.create_string_buffer(max(1, 32 * n))
+        assert self.L.orc_eddsa25519_sign_S_batch(self.ctx, n, r_hash, hram, a_scalars, out) == 0
+        return out.raw[:32 * n]
+
     def xdh(self, k, u):
         n = len(k) // self.clen
         out = C.create_string_buffer(self.clen * n)

@@ -1075,9 +1075,9 @@ def test_protocol_round_trips_large(gpu_ctx, curve, log2n):
 
 
 def test_eddsa25519_sign_steps(gpu_ctx):
-    """ec_eddsa_sign_R_batch / ec_eddsa_sign_S_batch: with the two hashes done here, R || S must be the signature bytes of
-    the RFC 8032 signer of tests/oracles.py (itself pinned against the reference's ec_sign in tests/test_oracle.py) and, when
-    oracle/_ref is there, of the unmodified reference; Ed25519ctx-style dom2 prefixes only change the hashes; edge values of
+    """ec_eddsa_sign_R_batch / ec_eddsa_sign_S_batch against the oracle (orc_eddsa25519_sign_R/S_batch, pinned against the
+    reference's ec_sign in tests/test_oracle.py): with the two hashes done here, R || S must also be the signature bytes of
+    the RFC 8032 signer of tests/oracles.py and, when oracle/_ref is there, of the unmodified reference; Ed25519ctx-style dom2 prefixes only change the hashes; edge values of
     the 64-byte hash (0, q, all ones) and of the secret scalar"""
     import hashlib
     import libecc_amd
@@ -1103,10 +1103,13 @@ def test_eddsa25519_sign_steps(gpu_ctx):
         R, st = cv.eddsa_sign_R(b"".join(r_hash))
         assert st == bytes(n)
         assert R == b"".join(sg[:32] for sg in sig)
+        o = Oracle("WEI25519")
+        assert (R, st) == o.eddsa_sign_R(b"".join(r_hash))
         hram = [hashlib.sha512(doms[i] + R[32 * i:32 * i + 32] + A[i] + msgs[ED_MSG_LEN * i:ED_MSG_LEN * (i + 1)]).digest()
                 for i in range(n)]
         S = cv.eddsa_sign_S(b"".join(r_hash), b"".join(hram), b"".join(a_sc))
         assert S == b"".join(sg[32:] for sg in sig)
+        assert S == o.eddsa_sign_S(b"".join(r_hash), b"".join(hram), b"".join(a_sc))
         if have_ref():
             idx = [i for i in range(n) if doms[i] == b""][:24]
             rp, rs, rst = O.ref_ed25519_sign(b"".join(seeds[32 * i:32 * i + 32] for i in idx),
@@ -1124,12 +1127,13 @@ def test_eddsa25519_sign_steps(gpu_ctx):
         ea = [bytes(32), b"\xff" * 32, (1 << 254).to_bytes(32, "little"), q.to_bytes(32, "little"), (q - 1).to_bytes(32, "little"),
               a_sc[0], a_sc[1]]
         R2, st2 = cv.eddsa_sign_R(b"".join(eh))
-        assert st2 == bytes(len(eh))
+        assert st2 == bytes(len(eh)) and (R2, st2) == o.eddsa_sign_R(b"".join(eh))
         for i, h in enumerate(eh):
             r = int.from_bytes(h, "little") % q
             exp = (1).to_bytes(32, "little") if r == 0 else O.ed_encode(O.ed_mul(r, O.ED_B))
             assert R2[32 * i:32 * i + 32] == exp, i
         S2 = cv.eddsa_sign_S(b"".join(eh), b"".join(reversed(eh)), b"".join(ea))
+        assert S2 == o.eddsa_sign_S(b"".join(eh), b"".join(reversed(eh)), b"".join(ea))
         for i in range(len(eh)):
             r, h, a = (int.from_bytes(x, "little") for x in (eh[i], eh[len(eh) - 1 - i], ea[i]))
             assert S2[32 * i:32 * i + 32] == ((r + h * a) % q).to_bytes(32, "little"), i

@@ -416,6 +416,46 @@ def test_eddsa25519_vs_reference():
             assert (a, sg) == (rp[32 * i:32 * i + 32], rs[64 * i:64 * i + 64])
 
 
+def test_eddsa25519_sign_restatement_vs_reference():
+    """orc_eddsa25519_sign_R_batch / _S_batch (the steps of _eddsa_sign between and after the two hashes) give the signature
+    bytes of the unmodified reference's ec_sign (pure Ed25519) and of the RFC 8032 signer used for test inputs (also with a
+    dom2 prefix, i.e. Ed25519ctx); edge values of the hashes and of the secret scalar against Python integers"""
+    import hashlib
+    rng = np.random.default_rng(77)
+    o = Oracle("WEI25519")
+    q, n = O.ED_Q, 12
+    seeds, msgs = rb(rng, 32 * n), rb(rng, ED_MSG_LEN * n)
+    ctx_dom = b"SigEd25519 no Ed25519 collisions" + bytes([0, 3]) + b"ctx"
+    for dom in (b"", ctx_dom):
+        hk = [hashlib.sha512(seeds[32 * i:32 * i + 32]).digest() for i in range(n)]
+        a = b"".join(((int.from_bytes(h[:32], "little") & ((1 << 254) - 8)) | (1 << 254)).to_bytes(32, "little") for h in hk)
+        m = [msgs[ED_MSG_LEN * i:ED_MSG_LEN * (i + 1)] for i in range(n)]
+        r_hash = b"".join(hashlib.sha512(dom + hk[i][32:] + m[i]).digest() for i in range(n))
+        R, st = o.eddsa_sign_R(r_hash)
+        assert st == bytes(n)
+        signed = [O.ed25519_sign(seeds[32 * i:32 * i + 32], m[i], dom=dom) for i in range(n)]
+        hram = b"".join(hashlib.sha512(dom + R[32 * i:32 * i + 32] + signed[i][0] + m[i]).digest() for i in range(n))
+        S = o.eddsa_sign_S(r_hash, hram, a)
+        sig = b"".join(R[32 * i:32 * i + 32] + S[32 * i:32 * i + 32] for i in range(n))
+        assert sig == b"".join(x[1] for x in signed)
+        if dom == b"" and have_ref():
+            rp, rs, rst = O.ref_ed25519_sign(seeds, msgs, ED_MSG_LEN)
+            assert rst == bytes(n) and rs == sig and rp == b"".join(x[0] for x in signed)
+    eh = [bytes(64), q.to_bytes(64, "little"), (q - 1).to_bytes(64, "little"), (q + 1).to_bytes(64, "little"), b"\xff" * 64,
+          (1).to_bytes(64, "little"), (1 << 511).to_bytes(64, "little")]
+    ea = [bytes(32), b"\xff" * 32, (1 << 254).to_bytes(32, "little"), q.to_bytes(32, "little"), (q - 1).to_bytes(32, "little"),
+          rb(rng, 32), rb(rng, 32)]
+    R2, st2 = o.eddsa_sign_R(b"".join(eh))
+    assert st2 == bytes(len(eh))
+    for i, h in enumerate(eh):
+        r = int.from_bytes(h, "little") % q
+        assert R2[32 * i:32 * i + 32] == ((1).to_bytes(32, "little") if r == 0 else O.ed_encode(O.ed_mul(r, O.ED_B))), i
+    S2 = o.eddsa_sign_S(b"".join(eh), b"".join(reversed(eh)), b"".join(ea))
+    for i in range(len(eh)):
+        r, h, a_ = (int.from_bytes(x, "little") for x in (eh[i], eh[len(eh) - 1 - i], ea[i]))
+        assert S2[32 * i:32 * i + 32] == ((r + h * a_) % q).to_bytes(32, "little"), i
+
+
 def prj_cases(curve, rng, nrand=24):
     """projective X || Y || Z inputs: scaled representatives of random points, infinity in several
     spellings, the degenerate (0:0:0), off-curve triples, coordinates >= p; with matching scalars"""
