@@ -3,14 +3,18 @@
  *
  * Plain-C CPU restatement of the reference's algorithm for the hot path
  *   nn_mul_redc1 -> fp_{add,sub,mul_monty,inv} -> prj_pt_add -> prj_pt_mul
- * and its three protocol callers (ECDSA sign/verify, ECC-CDH).  Every function cites the
+ * and its protocol callers: ECDSA sign / verify, ECC-CDH, X25519 / X448, Ed25519 / Ed448 verification,
+ * the Ed25519 signing steps around the hashes, the projective wire format.  Every function cites the
  * reference file:line it follows (paths relative to /root/reference/src).
  *
  * PINNED: checked (tests/test_oracle.py) against
  *   - the reference's own known-answer vectors extracted to tests/golden/*.json
- *     (ECC-CDH NIST KATs, RFC 6979 / fixed-k ECDSA vectors), and
+ *     (ECC-CDH NIST KATs, RFC 6979 / fixed-k ECDSA vectors, RFC 7748 X25519 / X448 vectors,
+ *     RFC 8032 Ed25519ctx / Ed25519ph / Ed448 / Ed448ph vectors), and
  *   - the unmodified reference itself built into oracle/_ref/libecc_ref.so
- *     (random batches + the edge list of SURVEY.md section 3.1).
+ *     (random batches + the edge list of SURVEY.md section 3.1, the crafted ECDSA family, the
+ *     non-canonical / small-order / torsion-shifted EdDSA and XDH inputs, ec_sign for Ed25519).
+ *   NOT pinned: Wycheproof vectors -- the reference snapshot ships the harness without the data.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
  * The product (libecc_amd/) never links, loads or falls back to it.
