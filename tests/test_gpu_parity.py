@@ -1441,3 +1441,16 @@ def test_device_cores_chunked_by_max_chunk(gpu_ctx):
                 b.free()
     finally:
         ctx2.close()
+
+
+def test_ecdsa_crafted_fixture_gpu(gpu_ctx):
+    """tests/golden/ecdsa_crafted.json: the verdicts the unmodified reference gave on the crafted ECDSA family (x(R) >= q,
+    extreme r, s and digests, invalid twins) must come back from the GPU, item for item"""
+    from test_oracle import crafted_fixture
+    for curve, h, pubs, sigs, dgs, hl, ref in crafted_fixture():
+        cv = gpu_ctx.curve(curve)
+        try:
+            assert cv.ecdsa_verify(pubs, sigs, dgs, hl) == ref, (curve, h)
+        finally:
+            cv.free()
+
