@@ -1454,3 +1454,10 @@ def test_ecdsa_crafted_fixture_gpu(gpu_ctx):
         finally:
             cv.free()
 
+
+def test_edge_fixtures_gpu(gpu_ctx):
+    """tests/golden/edge_fixtures.json: the reference's recorded answers on the EdDSA verification, X25519 / X448 and Ed25519
+    signing edge families must come back from the GPU byte for byte (same checks as tests/test_oracle.py::test_edge_fixtures)"""
+    from test_oracle import check_edge_fixtures
+    check_edge_fixtures(gpu_ctx.curve)
+

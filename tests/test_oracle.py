@@ -479,6 +479,45 @@ def test_eddsa25519_sign_restatement_vs_reference():
         assert S2[32 * i:32 * i + 32] == ((r + h * a_) % q).to_bytes(32, "little"), i
 
 
+def check_edge_fixtures(open_curve):
+    """tests/golden/edge_fixtures.json (tests/golden/make_edge_fixtures.py): the answers the unmodified reference gave on the
+    EdDSA verification, X25519 / X448 and Ed25519 signing edge families; open_curve(name) gives the implementation under
+    test (the restatement here, a GPU curve handle in tests/test_gpu_parity.py), which must reproduce every byte"""
+    import hashlib
+    fx = json.load(open(os.path.join(GOLDEN, "edge_fixtures.json")))
+    for curve, vname, xname in (("WEI25519", "ed25519_verify", "x25519"), ("WEI448", "ed448_verify", "x448")):
+        cv = open_curve(curve)
+        try:
+            c = fx[vname]
+            pubs, sigs, hram, ref = (bytes.fromhex(c[k]) for k in ("pubs", "sigs", "hram", "reference_result"))
+            assert cv.eddsa_verify(pubs, sigs, hram) == ref and 0 in ref and ref.count(1) >= 20
+            c = fx[xname]
+            k, u, ro, rs = (bytes.fromhex(c[x]) for x in ("k", "u", "reference_out", "reference_status"))
+            assert cv.xdh(k, u) == (ro, rs) and 0 in rs and 1 in rs
+            if curve == "WEI25519":
+                c = fx["ed25519_sign"]
+                seeds, msgs, rp, rsig = (bytes.fromhex(c[x]) for x in ("seeds", "msgs", "reference_pubs", "reference_sigs"))
+                ml, n = c["msg_len"], len(seeds) // 32
+                hk = [hashlib.sha512(seeds[32 * i:32 * i + 32]).digest() for i in range(n)]
+                a = b"".join(((int.from_bytes(h[:32], "little") & ((1 << 254) - 8)) | (1 << 254)).to_bytes(32, "little") for h in hk)
+                r_hash = b"".join(hashlib.sha512(hk[i][32:] + msgs[ml * i:ml * (i + 1)]).digest() for i in range(n))
+                R, st = cv.eddsa_sign_R(r_hash)
+                assert st == bytes(n)
+                hram = b"".join(hashlib.sha512(R[32 * i:32 * i + 32] + rp[32 * i:32 * i + 32] + msgs[ml * i:ml * (i + 1)]).digest()
+                                for i in range(n))
+                S = cv.eddsa_sign_S(r_hash, hram, a)
+                assert b"".join(R[32 * i:32 * i + 32] + S[32 * i:32 * i + 32] for i in range(n)) == rsig
+                assert cv.eddsa_verify(rp, rsig, hram) == bytes(n)
+        finally:
+            if hasattr(cv, "free"):
+                cv.free()
+
+
+def test_edge_fixtures():
+    """the restatement reproduces the reference's recorded answers; this pin does not need oracle/_ref"""
+    check_edge_fixtures(Oracle)
+
+
 def prj_cases(curve, rng, nrand=24):
     """projective X || Y || Z inputs: scaled representatives of random points, infinity in several
     spellings, the degenerate (0:0:0), off-curve triples, coordinates >= p; with matching scalars"""
