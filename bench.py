@@ -153,16 +153,7 @@ def pmc_traffic(kernel, batch_log2):
 def cpu_baseline(curve, scalars, points, slen):
     """Reference CPU path on this box's host cores, bounded to ~10-20 s of wall time."""
     from oracles import Oracle, RefLib, have_ref
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    try:  # honour the container's CPU quota (cgroup v2): "max" or "<quota> <period>"
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            cores = max(1, min(cores, int(int(quota) / int(period))))
-    except Exception:
-        pass
+    cores = host_cores()
     nmax = len(scalars) // slen
     if have_ref():
         r = RefLib(curve)
@@ -189,6 +180,93 @@ def cpu_baseline(curve, scalars, points, slen):
             "sample": f"first {n} items of the same batch through oracle/ecc_oracle.c, 1 thread"}
 
 
+def host_cores():
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:  # honour the container's CPU quota (cgroup v2): "max" or "<quota> <period>"
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return cores
+
+
+def edge_slice(curve_params, slen, clen, pts_h, n=4096):
+    """The 4096-item edge slice of SURVEY.md 8d cfg-2: m in {0, 1, 2, q-1, q, q+1, 2^(8 slen)-1} on P in {G, -G} and on
+    points of the batch; coordinates >= p; points off the curve (all must be rejected); the rest random scalars."""
+    p, q = curve_params["p"], curve_params["q"]
+    plen = 2 * clen
+    top = (1 << (8 * slen)) - 1
+    G = curve_params["gx"].to_bytes(clen, "big") + curve_params["gy"].to_bytes(clen, "big")
+    mG = curve_params["gx"].to_bytes(clen, "big") + (p - curve_params["gy"]).to_bytes(clen, "big")
+    ms = [0, 1, 2, q - 1, q, q + 1, top, (q + 2) & top, q - 2, 3]
+    rng = np.random.default_rng(4096)
+    sc, pt = bytearray(), bytearray()
+    for i in range(n):
+        P = pts_h[plen * i:plen * (i + 1)]
+        m = int.from_bytes(rng.integers(0, 256, size=slen, dtype=np.uint8).tobytes(), "big")
+        kind = i % 8
+        if kind < 2:
+            m = ms[(i // 8) % len(ms)]
+            P = (G, mG)[kind]
+        elif kind == 2:
+            m = ms[(i // 8) % len(ms)]
+        elif kind == 3:                                   # x >= p (p itself, p + small, all ones)
+            x = (p, p + 1 + (i % 5), (1 << (8 * clen)) - 1)[(i // 8) % 3]
+            if x >> (8 * clen):
+                x = (1 << (8 * clen)) - 1
+            P = x.to_bytes(clen, "big") + P[clen:]
+        elif kind == 4:                                   # y >= p
+            P = P[:clen] + ((1 << (8 * clen)) - 1 - (i % 3)).to_bytes(clen, "big")
+        elif kind == 5:                                   # off the curve: y + 1, or x and y swapped
+            y = int.from_bytes(P[clen:], "big")
+            P = (P[:clen] + ((y + 1) % p).to_bytes(clen, "big")) if (i // 8) % 2 else (P[clen:] + P[:clen])
+        elif kind == 6:                                   # (0, 0) and (0, y)
+            P = bytes(clen) + (bytes(clen) if (i // 8) % 2 else P[clen:])
+        sc += m.to_bytes(slen, "big")
+        pt += P
+    return bytes(sc), bytes(pt)
+
+
+def parity_gate(curve, cv, scalars_h, pts_h, out_h, slen, plen, B, nrand):
+    from oracles import CURVES, Oracle, RefLib, have_ref
+    clen = plen // 2
+    use_ref = have_ref()
+    if not use_ref:
+        nrand = min(nrand, 2048)
+    nrand = min(nrand, B)
+    idx = np.sort(np.random.default_rng(1).choice(B, size=nrand, replace=False))
+    sub_s = b"".join(scalars_h[slen * i:slen * i + slen] for i in idx)
+    sub_p = b"".join(pts_h[plen * i:plen * i + plen] for i in idx)
+    got = b"".join(out_h[plen * i:plen * i + plen] for i in idx)
+    e_sc, e_pt = edge_slice(CURVES[curve], slen, clen, pts_h, 4096 if B >= 4096 else B)
+    e_got = cv.scalar_mult(e_sc, e_pt, slen)
+    t0 = time.time()
+    if use_ref:
+        r = RefLib(curve)
+        cores = host_cores()
+        exp, est = r.scalar_mult(sub_s, sub_p, slen, nthreads=cores)[:2]
+        e_exp = tuple(r.scalar_mult(e_sc, e_pt, slen, nthreads=cores)[:2])
+        who = f"the unmodified reference (oracle/_ref) on {cores} threads"
+    else:
+        o = Oracle(curve)
+        exp, est = o.scalar_mult(sub_s, sub_p, slen)
+        e_exp = tuple(o.scalar_mult(e_sc, e_pt, slen))
+        who = "the C restatement oracle (oracle/_ref absent)"
+    if got != exp or set(est) != {0}:
+        raise SystemExit("PARITY FAILURE: GPU output differs from the CPU reference on the random subset")
+    if tuple(e_got) != e_exp:
+        bad = [i for i in range(len(e_exp[1])) if e_got[1][i] != e_exp[1][i] or
+               e_got[0][plen * i:plen * (i + 1)] != e_exp[0][plen * i:plen * (i + 1)]]
+        raise SystemExit(f"PARITY FAILURE: edge slice differs from the CPU reference at items {bad[:8]}")
+    st = e_exp[1]
+    return (f"{nrand} random items of the timed batch + {len(st)} edge items ({st.count(1)} rejected, {st.count(2)} at infinity) "
+            f"byte-identical to {who}, {time.time() - t0:.1f} s")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,14 +274,34 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)   # the first launches after the setup run at ramping clocks (profiles/r1f_bench_kernels.md)
     ap.add_argument("--batch-log2", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-items", type=int, default=1 << 16, help="random items of the batch checked against the CPU reference before timing")
     ap.add_argument("--curve", default=CURVE, help="ad-hoc runs on another built-in curve (the driver uses the default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started as plain `python bench.py --gpus N`: become the launcher of N ranks (one per GPU) and hand back
+        # their exit status -- never fall through to a silent 1-GPU run
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible")
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch one rank per GPU, or let "
+                         "`python bench.py --gpus N` spawn them)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but {torch.cuda.device_count()} are visible")
     dist = None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -273,7 +371,9 @@ def main():
 
     drain = og.drain
 
-    # ---- parity gate: random subset vs the CPU oracle, byte for byte ----
+    # ---- parity gate: >= 2^16 random items of the timed batch AND a 4096-item edge slice, byte for
+    #      byte against the unmodified reference on all host threads (oracle/_ref); without it, the C restatement on
+    #      a smaller sample ----
     step()
     drain()
     torch.cuda.synchronize()
@@ -281,14 +381,8 @@ def main():
     pts_h = d_points.cpu().numpy().tobytes()
     st_h = d_status.cpu().numpy().tobytes()
     assert set(st_h) == {0}, "unexpected status in the synthetic batch"
-    idx = np.random.default_rng(1).choice(B, size=min(B, 128), replace=False)
-    o = Oracle(curve)
-    sub_s = b"".join(scalars_h[slen * i:slen * i + slen] for i in idx)
-    sub_p = b"".join(pts_h[plen * i:plen * i + plen] for i in idx)
-    exp, est = o.scalar_mult(sub_s, sub_p)
-    got = b"".join(out_h[plen * i:plen * i + plen] for i in idx)
-    if got != exp or set(est) != {0}:
-        raise SystemExit("PARITY FAILURE: GPU output differs from the CPU oracle")
+    gate = parity_gate(curve, cv, scalars_h, pts_h, out_h, slen, plen, B, args.parity_items if rank == 0 else 256)
+    setup_s = time.time() - t_setup
     setup_s = time.time() - t_setup
 
     # ---- warmup, then exactly K timed steps ----
@@ -323,6 +417,14 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # which device every rank ran on (the RCCL world, as the job saw it)
+    props = torch.cuda.get_device_properties(dev)
+    mine = f"rank {rank}: cuda:{local_rank} {props.name} ({getattr(props, 'gcnArchName', '?')}, {props.multi_processor_count} CUs)"
+    if world > 1:
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, mine)
+    else:
+        rank_devices = [mine]
     if rank == 0:
         total_items = B * world * args.steps
         value = total_items / elapsed
@@ -350,7 +452,8 @@ def main():
                                    "(BASELINE.json configs[1])",
                        "batch_per_gpu": B, "scalar_len": slen, "window": "signed fixed w=4",
                        "sharding": "contiguous per-rank shards" + (", one RCCL all_gather of the output shards per step, overlapped with the next step's kernels" if world > 1 else ""),
-                       "parity_gate": "128 random items byte-identical to the CPU oracle"},
+                       "parity_gate": gate,
+                       "world_size": world, "rank_devices": rank_devices},
             "roofline": {
                 "bound": "valu-int-mad (v_mad_u64_u32 issue; not hbm, not mfma -- SURVEY.md 8d)",
                 "achieved": mad_rate / 1e9, "peak": (peak or nominal_quarter) / 1e9, "unit": "GMAD/s (one GPU)",

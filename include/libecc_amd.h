@@ -21,7 +21,10 @@
  * a gfx950 device ecamd_ctx_create() fails.
  *
  * Threads: a context serialises its calls with a mutex; use one context per thread (or per GPU) for
- * concurrency.  Memory: scratch grows with the largest batch seen (about 2.8 KB per item of a chunk of
+ * concurrency -- any number of contexts may share a device (the __constant__ curve slots are managed per
+ * device, not per context).  Streams: a context owns ONE set of scratch buffers, so its calls execute one
+ * after the other on the device even when they are enqueued on different streams (each call makes its stream
+ * wait for the previous call's last kernel); use two contexts for two concurrent streams.  Memory: scratch grows with the largest batch seen (about 2.8 KB per item of a chunk of
  * <= 2^20 items); a curve handle that has served a fixed-base batch of >= 4096 items keeps a table of
  * multiples of the generator in HBM (42 MB for 256-bit curves, 183 MB for 521 bits).
  *
@@ -135,6 +138,11 @@ int ec_fp_op_batch(ecamd_ctx *ctx, const ecamd_curve *curve, int op, uint32_t n,
  */
 int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *pubkeys_aff,
 			  const uint8_t *sigs, const uint8_t *digests, uint32_t digest_len, uint8_t *result);
+/* The same with a choice of public-key format: ECAMD_PT_PROJECTIVE keys are n x 3*clen, X || Y || Z as ec_pub_key_export_to_buf
+ * writes pub_key->y (sig/ec_key.c:254): imported like prj_pt_import_from_buf, normalised on the device.  A key that is the point
+ * at infinity is a key for libecc (its import accepts (0 : 1 : 0)); verification against it is W' = uG, reproduced here. */
+int ec_ecdsa_verify_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *pubkeys, int pub_fmt,
+			      const uint8_t *sigs, const uint8_t *digests, uint32_t digest_len, uint8_t *result);
 /* ECDSA signing with caller-supplied nonces: per item the tail of ec_sign / __ecdsa_sign_finalize
  * (sig/ecdsa_common.c:318-586) -- kG = prj_pt_mul(k, G), r = kG.x mod q, s = k^-1 (x r + e) mod q --
  * with h = H(m) and the nonce k supplied by the caller (random, or RFC 6979 computed on the host;
@@ -246,6 +254,58 @@ int ec_ecdsa_sign_batch_dev(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n
 			    void *d_status, void *hip_stream);
 int ec_ecccdh_derive_batch_dev(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const void *d_privs,
 			       const void *d_peers_aff, void *d_secrets, void *d_status, void *hip_stream);
+
+/*
+ * ---- several GPUs from C ----
+ * One context and one host thread per device; a batch of n items is cut into contiguous shards (rank r of N owns
+ * items [r*n/N, (r+1)*n/N): the work per item is constant, so equal counts are balanced); nothing is exchanged to
+ * compute.  The host-pointer entry points below are the single-device ones run on every shard at once, each
+ * device copying its results straight into the caller's arrays, so outputs and status bytes are exactly those of
+ * the single-device call.  devices == NULL (or ndev <= 0): every visible device.  A device may be listed more than
+ * once (one context and one shard per entry; they then share that GPU).
+ */
+typedef struct ecamd_multi ecamd_multi;
+typedef struct ecamd_mcurve ecamd_mcurve; /* one ecamd_curve per rank */
+int ecamd_multi_create(ecamd_multi **m, const int *devices, int ndev);
+void ecamd_multi_destroy(ecamd_multi *m);
+int ecamd_multi_size(const ecamd_multi *m);                 /* number of ranks */
+int ecamd_multi_device(const ecamd_multi *m, int rank);     /* HIP device of a rank */
+ecamd_ctx *ecamd_multi_ctx(ecamd_multi *m, int rank);       /* its context (device-pointer entry points, streams) */
+void ecamd_multi_shard_range(uint32_t n, int rank, int nranks, uint32_t *lo, uint32_t *hi);
+int ecamd_multi_curve_by_name(ecamd_multi *m, const char *name, ecamd_mcurve **curve);
+int ecamd_multi_curve_from_params(ecamd_multi *m, const uint8_t *p, uint32_t p_len, const uint8_t *a, uint32_t a_len,
+				  const uint8_t *b, uint32_t b_len, const uint8_t *curve_order, uint32_t curve_order_len,
+				  const uint8_t *gx, uint32_t gx_len, const uint8_t *gy, uint32_t gy_len,
+				  const uint8_t *gen_order, uint32_t gen_order_len, ecamd_mcurve **curve);
+void ecamd_multi_curve_free(ecamd_mcurve *curve);
+const ecamd_curve *ecamd_multi_curve_handle(const ecamd_mcurve *curve, int rank);
+int ecamd_multi_curve_coord_len(const ecamd_mcurve *curve);
+int ecamd_multi_curve_order_len(const ecamd_mcurve *curve);
+/* sharded forms: same arguments and results as the single-device entry points of the same name */
+int ecamd_multi_prj_pt_mul_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *scalars,
+				 uint32_t scalar_len, const uint8_t *points_aff, uint8_t *out_aff, uint8_t *status);
+int ecamd_multi_prj_pt_mul_batch_fmt(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *scalars,
+				     uint32_t scalar_len, const uint8_t *points, int in_fmt, uint8_t *out, int out_fmt,
+				     uint8_t *status);
+int ecamd_multi_prj_pt_unique_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *points, int in_fmt,
+				    uint8_t *out, int out_fmt, uint8_t *status);
+int ecamd_multi_ecdsa_verify_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *pubkeys_aff,
+				   const uint8_t *sigs, const uint8_t *digests, uint32_t digest_len, uint8_t *result);
+int ecamd_multi_ecdsa_verify_batch_fmt(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *pubkeys, int pub_fmt,
+				       const uint8_t *sigs, const uint8_t *digests, uint32_t digest_len, uint8_t *result);
+int ecamd_multi_ecdsa_sign_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *privs,
+				 const uint8_t *nonces, const uint8_t *digests, uint32_t digest_len, uint8_t *sigs,
+				 uint8_t *status);
+int ecamd_multi_ecccdh_derive_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *privs,
+				    const uint8_t *peers_aff, uint8_t *secrets, uint8_t *status);
+int ecamd_multi_xdh_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *k, const uint8_t *u,
+			  uint8_t *out, uint8_t *status);
+int ecamd_multi_eddsa_verify_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *pubkeys,
+				   const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, uint8_t *result);
+/* The one collective, for callers that keep device-resident outputs on every GPU: an RCCL all-gather (over xGMI) of
+ * equal-size shards.  d_send[r]: bytes_per_rank bytes on rank r's device; d_recv[r]: nranks * bytes_per_rank bytes
+ * there.  librccl is loaded on first use; needs distinct devices.  Synchronous. */
+int ecamd_multi_allgather(ecamd_multi *m, const void *const *d_send, void *const *d_recv, size_t bytes_per_rank);
 
 #ifdef __cplusplus
 }

@@ -6,8 +6,8 @@ The product is the C-ABI shared library `libecc_amd/lib/libecc_amd.so` (header:
 binding used by the tests and the benchmark; it contains no arithmetic and NO CPU fallback:
 if the HIP library is missing or there is no GPU, calls raise.
 """
-from .api import (Context, Curve, EcamdError, lib_path, load_library, ECAMD_OK, ECAMD_ERR, ECAMD_INF,
+from .api import (Context, Curve, Multi, MultiCurve, EcamdError, lib_path, load_library, ECAMD_OK, ECAMD_ERR, ECAMD_INF,
                   FP_MUL_MONTY, FP_ADD, FP_SUB, FP_MUL, FP_INV, EXPORTED_SYMBOLS)
 
-__all__ = ["Context", "Curve", "EcamdError", "lib_path", "load_library", "ECAMD_OK", "ECAMD_ERR",
+__all__ = ["Context", "Curve", "Multi", "MultiCurve", "EcamdError", "lib_path", "load_library", "ECAMD_OK", "ECAMD_ERR",
            "ECAMD_INF", "FP_MUL_MONTY", "FP_ADD", "FP_SUB", "FP_MUL", "FP_INV", "EXPORTED_SYMBOLS"]

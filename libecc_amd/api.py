@@ -12,10 +12,16 @@ EXPORTED_SYMBOLS = [
     "ecamd_ctx_set_max_chunk", "ecamd_ctx_enable_kernel_timing", "ecamd_ctx_kernel_times", "ecamd_curve_by_name", "ecamd_curve_from_params", "ecamd_curve_free",
     "ecamd_curve_coord_len", "ecamd_curve_order_len", "ecamd_curve_words", "ec_prj_pt_mul_batch",
     "ec_prj_pt_mul_batch_dev", "ecamd_ctx_synchronize", "ec_prj_pt_add_batch", "ec_prj_pt_dbl_batch",
-    "ec_fp_op_batch", "ec_ecdsa_verify_batch", "ec_ecdsa_sign_batch", "ec_ecccdh_derive_batch", "ec_xdh_batch",
+    "ec_fp_op_batch", "ec_ecdsa_verify_batch", "ec_ecdsa_verify_batch_fmt", "ec_ecdsa_sign_batch", "ec_ecccdh_derive_batch", "ec_xdh_batch",
     "ec_prj_pt_mul_batch_fmt", "ec_prj_pt_unique_batch", "ec_structured_pub_key_import_batch",
     "ec_eddsa_verify_batch", "ec_eddsa_verify_all_batch", "ec_ecdsa_verify_batch_dev", "ec_eddsa_verify_batch_dev", "ec_xdh_batch_dev",
     "ec_ecdsa_sign_batch_dev", "ec_ecccdh_derive_batch_dev", "ec_eddsa_sign_R_batch", "ec_eddsa_sign_S_batch",
+    "ecamd_multi_create", "ecamd_multi_destroy", "ecamd_multi_size", "ecamd_multi_device", "ecamd_multi_ctx",
+    "ecamd_multi_shard_range", "ecamd_multi_curve_by_name", "ecamd_multi_curve_from_params", "ecamd_multi_curve_free",
+    "ecamd_multi_curve_handle", "ecamd_multi_curve_coord_len", "ecamd_multi_curve_order_len",
+    "ecamd_multi_prj_pt_mul_batch", "ecamd_multi_prj_pt_mul_batch_fmt", "ecamd_multi_prj_pt_unique_batch",
+    "ecamd_multi_ecdsa_verify_batch", "ecamd_multi_ecdsa_verify_batch_fmt", "ecamd_multi_ecdsa_sign_batch", "ecamd_multi_ecccdh_derive_batch",
+    "ecamd_multi_xdh_batch", "ecamd_multi_eddsa_verify_batch", "ecamd_multi_allgather",
 ]
 
 
@@ -62,6 +68,7 @@ def load_library():
         L.ec_fp_op_batch.argtypes = [vp, vp, C.c_int, u32, vp, vp, vp]
         L.ec_ecdsa_verify_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p]
         L.ec_ecdsa_sign_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p, u8p]
+        L.ec_ecdsa_verify_batch_fmt.argtypes = [vp, vp, u32, u8p, C.c_int, u8p, u8p, u32, u8p]
         L.ec_xdh_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
         L.ec_eddsa_verify_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p]
         L.ec_eddsa_verify_all_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
@@ -76,6 +83,34 @@ def load_library():
         L.ec_ecccdh_derive_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp]
         L.ec_xdh_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp]
         L.ec_ecccdh_derive_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
+        # several GPUs from C
+        L.ecamd_multi_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
+        L.ecamd_multi_destroy.argtypes = [vp]
+        L.ecamd_multi_destroy.restype = None
+        L.ecamd_multi_size.argtypes = [vp]
+        L.ecamd_multi_device.argtypes = [vp, C.c_int]
+        L.ecamd_multi_ctx.argtypes = [vp, C.c_int]
+        L.ecamd_multi_ctx.restype = vp
+        L.ecamd_multi_shard_range.argtypes = [u32, C.c_int, C.c_int, C.POINTER(u32), C.POINTER(u32)]
+        L.ecamd_multi_shard_range.restype = None
+        L.ecamd_multi_curve_by_name.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+        L.ecamd_multi_curve_from_params.argtypes = [vp] + [u8p, u32] * 7 + [C.POINTER(vp)]
+        L.ecamd_multi_curve_free.argtypes = [vp]
+        L.ecamd_multi_curve_free.restype = None
+        L.ecamd_multi_curve_handle.argtypes = [vp, C.c_int]
+        L.ecamd_multi_curve_handle.restype = vp
+        L.ecamd_multi_curve_coord_len.argtypes = [vp]
+        L.ecamd_multi_curve_order_len.argtypes = [vp]
+        L.ecamd_multi_prj_pt_mul_batch.argtypes = [vp, vp, u32, u8p, u32, u8p, u8p, u8p]
+        L.ecamd_multi_prj_pt_mul_batch_fmt.argtypes = [vp, vp, u32, u8p, u32, u8p, C.c_int, u8p, C.c_int, u8p]
+        L.ecamd_multi_prj_pt_unique_batch.argtypes = [vp, vp, u32, u8p, C.c_int, u8p, C.c_int, u8p]
+        L.ecamd_multi_ecdsa_verify_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p]
+        L.ecamd_multi_ecdsa_verify_batch_fmt.argtypes = [vp, vp, u32, u8p, C.c_int, u8p, u8p, u32, u8p]
+        L.ecamd_multi_ecdsa_sign_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p, u8p]
+        L.ecamd_multi_ecccdh_derive_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
+        L.ecamd_multi_xdh_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
+        L.ecamd_multi_eddsa_verify_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p]
+        L.ecamd_multi_allgather.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.c_size_t]
         _LIB = L
     return _LIB
 
@@ -190,6 +225,13 @@ class Curve:
              "ec_ecdsa_verify_batch")
         return res.raw[:n]
 
+    def ecdsa_verify_fmt(self, pubs, pub_fmt, sigs, digests, hlen):
+        n = len(pubs) // ((3 if pub_fmt else 2) * self.clen)
+        res = C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_ecdsa_verify_batch_fmt(self.ctx.h, self.h, n, pubs, pub_fmt, sigs, digests, hlen, res),
+             "ec_ecdsa_verify_batch_fmt")
+        return res.raw[:n]
+
     def ecdsa_sign(self, privs, nonces, digests, hlen):
         n = len(privs) // self.qlen
         sigs = C.create_string_buffer(max(1, 2 * self.qlen * n))
@@ -296,3 +338,91 @@ class Curve:
         _chk(self.L, self.L.ec_structured_pub_key_import_batch(self.ctx.h, self.h, n, keys, klen, alg_type, out, st),
              "ec_structured_pub_key_import_batch")
         return out.raw[:2 * self.clen * n], st.raw[:n]
+
+
+
+class Multi:
+    """ecamd_multi: one context and one host thread per listed device; batches are cut into contiguous shards.
+    A device may be listed several times (its shards then share that GPU)."""
+
+    def __init__(self, devices=None):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        if devices is None:
+            rc = self.L.ecamd_multi_create(C.byref(self.h), None, 0)
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            rc = self.L.ecamd_multi_create(C.byref(self.h), arr, len(devices))
+        _chk(self.L, rc, "ecamd_multi_create")
+        self.size = self.L.ecamd_multi_size(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.ecamd_multi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def shard_range(self, n, rank):
+        lo, hi = C.c_uint32(0), C.c_uint32(0)
+        self.L.ecamd_multi_shard_range(n, rank, self.size, C.byref(lo), C.byref(hi))
+        return lo.value, hi.value
+
+    def curve(self, name):
+        return MultiCurve(self, name)
+
+
+class MultiCurve:
+    def __init__(self, multi, name):
+        self.m, self.L = multi, multi.L
+        self.h = C.c_void_p()
+        _chk(self.L, self.L.ecamd_multi_curve_by_name(multi.h, name.encode(), C.byref(self.h)), "ecamd_multi_curve_by_name")
+        self.clen = self.L.ecamd_multi_curve_coord_len(self.h)
+        self.qlen = self.L.ecamd_multi_curve_order_len(self.h)
+
+    def free(self):
+        if self.h:
+            self.L.ecamd_multi_curve_free(self.h)
+            self.h = C.c_void_p()
+
+    def scalar_mult(self, scalars, points=None, slen=None):
+        slen = slen or self.qlen
+        n = len(scalars) // slen
+        out, st = C.create_string_buffer(max(1, 2 * self.clen * n)), C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ecamd_multi_prj_pt_mul_batch(self.m.h, self.h, n, scalars, slen, points, out, st),
+             "ecamd_multi_prj_pt_mul_batch")
+        return out.raw[:2 * self.clen * n], st.raw[:n]
+
+    def ecdsa_verify(self, pubs, sigs, digests, hlen):
+        n = len(pubs) // (2 * self.clen)
+        res = C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ecamd_multi_ecdsa_verify_batch(self.m.h, self.h, n, pubs, sigs, digests, hlen, res),
+             "ecamd_multi_ecdsa_verify_batch")
+        return res.raw[:n]
+
+    def ecdsa_sign(self, privs, nonces, digests, hlen):
+        n = len(privs) // self.qlen
+        sigs, st = C.create_string_buffer(max(1, 2 * self.qlen * n)), C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ecamd_multi_ecdsa_sign_batch(self.m.h, self.h, n, privs, nonces, digests, hlen, sigs, st),
+             "ecamd_multi_ecdsa_sign_batch")
+        return sigs.raw[:2 * self.qlen * n], st.raw[:n]
+
+    def ecccdh(self, privs, peers):
+        n = len(privs) // self.qlen
+        sec, st = C.create_string_buffer(max(1, self.clen * n)), C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ecamd_multi_ecccdh_derive_batch(self.m.h, self.h, n, privs, peers, sec, st),
+             "ecamd_multi_ecccdh_derive_batch")
+        return sec.raw[:self.clen * n], st.raw[:n]
+
+    def xdh(self, k, u):
+        n = len(k) // self.clen
+        out, st = C.create_string_buffer(max(1, self.clen * n)), C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ecamd_multi_xdh_batch(self.m.h, self.h, n, k, u, out, st), "ecamd_multi_xdh_batch")
+        return out.raw[:self.clen * n], st.raw[:n]
+
+    def eddsa_verify(self, pubkeys, sigs, hram, hram_len=None):
+        klen = 57 if self.clen == 56 else self.clen
+        hram_len = hram_len or (114 if self.clen == 56 else 64)
+        n = len(pubkeys) // klen
+        res = C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ecamd_multi_eddsa_verify_batch(self.m.h, self.h, n, pubkeys, sigs, hram, hram_len, res),
+             "ecamd_multi_eddsa_verify_batch")
+        return res.raw[:n]

@@ -11,11 +11,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libecc_amd.so")
-SOURCES = ["ecamd_kernels.hip", "ecamd_p256_kernel.hip", "ecamd_host.cpp"]
+SOURCES = ["ecamd_kernels.hip", "ecamd_p256_kernel.hip", "ecamd_host.cpp", "ecamd_multi.cpp"]
 DEPS = ["ecamd_madchain.cuh", "ecamd_field.cuh", "ecamd_point.cuh", "ecamd_u29.cuh", "ecamd_p256.cuh", "ecamd_u29g.cuh", "ecamd_jacg.cuh",
         "ecamd_internal.h",
-        "ecamd_curve_table.inc",
-        os.path.join("..", "..", "include", "libecc_amd.h")]
+        "ecamd_curve_table.inc"]
+# the public header only matters to the host-side translation units (the kernels see ecamd_internal.h)
+HOST_DEPS = [os.path.join("..", "..", "include", "libecc_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-bitwise-instead-of-logical", "-DU29_ASM_MAD"]
@@ -49,11 +50,12 @@ def build(force=False, verbose=False):
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
     deps = [os.path.join(CSRC, d) for d in DEPS]
+    hdeps = [os.path.join(CSRC, d) for d in HOST_DEPS]
     todo, objs = [], []
     for src, obj, extra in _jobs():
         spath, opath = os.path.join(CSRC, src), os.path.join(LIBDIR, obj)
         objs.append(opath)
-        if force or _stale(opath, [spath] + deps):
+        if force or _stale(opath, [spath] + deps + (hdeps if src.endswith(".cpp") else [])):
             todo.append([HIPCC] + FLAGS + extra + ["-x", "hip", "-c", spath, "-o", opath])
 
     def run(cmd):
@@ -64,7 +66,7 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1))) as ex:
         list(ex.map(run, todo))
     if force or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"])
     return LIB
 
 

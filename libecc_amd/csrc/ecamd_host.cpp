@@ -39,6 +39,8 @@ static int fail(const std::string &m)
 	} while (0)
 
 extern "C" const char *ecamd_last_error(void) { return g_err.c_str(); }
+// for the other translation units of the library (ecamd_multi.cpp): not part of the public ABI
+__attribute__((visibility("default"))) void ecamd_set_error(const char *msg) { g_err = msg ? msg : ""; }
 
 // ------------------------------------------------------------------------------------------
 // small host big integers (little-endian 32-bit words); only used to derive constants
@@ -216,8 +218,11 @@ struct ecamd_ctx {
 	size_t tbl_fast_bytes;
 	uint8_t *stage[ECAMD_NSTAGE];
 	size_t stage_bytes[ECAMD_NSTAGE];
-	bool slot_used[ECAMD_MAX_SLOTS_HOST];
-	bool gslot_used[640][8];
+	// the scratch above is shared by every call: a call enqueued on another stream than the previous one first waits
+	// for `busy`, recorded behind the previous call's last kernel (StreamScope)
+	hipEvent_t busy;
+	hipStream_t last_stream;
+	bool inflight;
 	// host-pointer entry points: chunks of host_chunk items, the copy of chunk c+1 overlaps the kernels of chunk c
 	hipStream_t copy_stream;
 	hipEvent_t in_ready[2];
@@ -324,10 +329,12 @@ extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
 		c->stage[i] = nullptr;
 		c->stage_bytes[i] = 0;
 	}
-	for (int i = 0; i < ECAMD_MAX_SLOTS_HOST; i++) {
-		c->slot_used[i] = false;
+	c->last_stream = nullptr;
+	c->inflight = false;
+	if (hipEventCreateWithFlags(&c->busy, hipEventDisableTiming) != hipSuccess) {
+		delete c;
+		return fail("ecamd_ctx_create: hipEventCreate failed");
 	}
-	memset(c->gslot_used, 0, sizeof(c->gslot_used));
 	c->timing = false;
 	c->ev_valid = false;
 	for (int i = 0; i <= ECAMD_NTIMED; i++) {
@@ -384,6 +391,7 @@ extern "C" void ecamd_ctx_destroy(ecamd_ctx *c)
 	(void)hipStreamDestroy(c->copy_stream);
 	(void)hipEventDestroy(c->in_ready[0]);
 	(void)hipEventDestroy(c->in_ready[1]);
+	(void)hipEventDestroy(c->busy);
 	for (int b = 0; b < 2; b++) {
 		for (int k = 0; k < 6; k++) {
 			if (c->hbuf[b][k]) {
@@ -443,6 +451,27 @@ extern "C" int ecamd_ctx_synchronize(ecamd_ctx *c)
 	return 0;
 }
 
+// Every call works in the context's shared scratch (window tables, stage[] buffers).  A call enqueued on another
+// stream than the previous one therefore first makes its stream wait for the previous call's last kernel, and
+// leaves an event behind its own last kernel (ctx->mu held for the lifetime of the scope).
+struct StreamScope {
+	ecamd_ctx *c;
+	hipStream_t s;
+	StreamScope(ecamd_ctx *ctx, hipStream_t stream) : c(ctx), s(stream)
+	{
+		if (c->inflight && c->last_stream != s) {
+			(void)hipStreamWaitEvent(s, c->busy, 0);
+		}
+	}
+	~StreamScope()
+	{
+		if (hipEventRecord(c->busy, s) == hipSuccess) {
+			c->last_stream = s;
+			c->inflight = true;
+		}
+	}
+};
+
 static int ensure(uint8_t **buf, size_t *have, size_t need)
 {
 	if (*have >= need) {
@@ -458,9 +487,81 @@ static int ensure(uint8_t **buf, size_t *have, size_t need)
 	return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// __constant__ curve slots.  The tables the kernels index (g_curves_<NW>[slot], g_g29_<unit>[slot]) exist once per
+// DEVICE and per process, whatever the number of contexts opened on that device, so their bookkeeping is
+// process-global: one registry per device under one mutex, reference-counted, and handles whose constant image is
+// byte-identical share a slot (two contexts that both load SECP256R1 use the same constants; two contexts that load
+// different curves of one width get different slots instead of overwriting each other).  A slot is only written
+// while no live handle refers to it, so an upload never races with a kernel that reads it.
+// ------------------------------------------------------------------------------------------
+#define ECAMD_MAX_DEVICES 64
+#define ECAMD_G29_KEYS 640  /* pbits + flavour */
+struct SlotEnt {
+	int ref = 0;
+	std::vector<uint32_t> img;  // what the slot holds (kept after the last release: a re-acquire needs no upload)
+};
+struct SlotRegistry {
+	SlotEnt s[18][ECAMD_MAX_SLOTS_HOST];  // [nw][slot]: saturated-word units
+	SlotEnt g[ECAMD_G29_KEYS][8];         // [pbits + flavour][slot]: radix-2^29 units
+};
+static std::mutex g_slot_mu;
+static SlotRegistry *g_slots[ECAMD_MAX_DEVICES];
+
+// find (or fill) a slot of `row` holding `img`; returns the slot or -1 (none free) / -2 (upload failed)
+template <class Upload> static int slot_acquire(SlotEnt *row, int nslots, const std::vector<uint32_t> &img, Upload upload)
+{
+	for (int i = 0; i < nslots; i++) {
+		if (row[i].ref > 0 && row[i].img == img) {
+			row[i].ref++;
+			return i;
+		}
+	}
+	int pick = -1;
+	for (int i = 0; i < nslots && pick < 0; i++) {
+		if (row[i].ref == 0 && row[i].img == img) {
+			pick = i;  // still resident from an earlier handle
+		}
+	}
+	bool need_upload = pick < 0;
+	for (int i = 0; i < nslots && pick < 0; i++) {
+		if (row[i].ref == 0 && row[i].img.empty()) {
+			pick = i;
+		}
+	}
+	for (int i = 0; i < nslots && pick < 0; i++) {
+		if (row[i].ref == 0) {
+			pick = i;
+		}
+	}
+	if (pick < 0) {
+		return -1;
+	}
+	if (need_upload) {
+		row[pick].img.clear();
+		if (upload(pick) != hipSuccess) {
+			return -2;
+		}
+		row[pick].img = img;
+	}
+	row[pick].ref = 1;
+	return pick;
+}
+static SlotRegistry *slot_registry(int device)
+{
+	if (device < 0 || device >= ECAMD_MAX_DEVICES) {
+		return nullptr;
+	}
+	if (!g_slots[device]) {
+		g_slots[device] = new SlotRegistry();
+	}
+	return g_slots[device];
+}
+
 // CurveK<NW> as a flat word image: p r2 one pm2 a b b3 fix64 (NW words each), then
-// mpinv pbits a_is_m3 fix_is_id -- must match ecamd_field.cuh.
-static int upload_modulus(int nw, int slot, const Big &p, const Big &a_in, const Big &b_in)
+// mpinv pbits a_is_m3 fix_is_id -- must match ecamd_field.cuh.  Returns the slot holding it (g_slot_mu held).
+static int acquire_modulus(int device, int nw, const Big &p, const Big &a_in, const Big &b_in, int *slot_out)
 {
 	Big a_red = big_mod(a_in, p), b_red = big_mod(b_in, p);
 	struct {
@@ -502,24 +603,27 @@ static int upload_modulus(int nw, int slot, const Big &p, const Big &a_in, const
 	if (img.size() * 4 != ecamd_curvek_bytes(nw)) {
 		return fail("internal: CurveK image size mismatch");
 	}
-	HIPCHK(ecamd_upload_curve(nw, slot, img.data(), img.size() * 4));
+	SlotRegistry *reg = slot_registry(device);
+	if (!reg || nw < 0 || nw >= 18) {
+		return fail("internal: no slot registry for this device / width");
+	}
+	const int slot = slot_acquire(reg->s[nw], ECAMD_MAX_SLOTS_HOST, img,
+				      [&](int sl) { return ecamd_upload_curve(nw, sl, img.data(), img.size() * 4); });
+	if (slot == -1) {
+		return fail("curve: all constant-memory curve slots of this width are in use on this device (free a curve first)");
+	}
+	if (slot < 0) {
+		return fail("curve: upload of the curve constants failed");
+	}
+	*slot_out = slot;
 	return 0;
 }
-
-static int build_and_upload(ecamd_curve *cv)
+static void release_modulus(int device, int nw, int slot)
 {
-	// slot: the field of definition (modulus p, curve coefficients);  qslot: Montgomery context of
-	// the generator order q for the mod-q algebra of the protocol layer (only when q fits NW words)
-	if (upload_modulus(cv->nw, cv->slot, cv->p, cv->a, cv->b)) {
-		return -1;
+	SlotRegistry *reg = slot_registry(device);
+	if (reg && nw >= 0 && nw < 18 && slot >= 0 && slot < ECAMD_MAX_SLOTS_HOST && reg->s[nw][slot].ref > 0) {
+		reg->s[nw][slot].ref--;
 	}
-	if (cv->qslot >= 0) {
-		Big zero(1, 0);
-		if (upload_modulus(cv->qnw, cv->qslot, cv->q, zero, zero)) {
-			return -1;
-		}
-	}
-	return 0;
 }
 
 static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_scalars, uint32_t slen,
@@ -631,7 +735,18 @@ static int upload_g29(ecamd_curve *cv)
 	if (img.size() * 4 != ecamd_g29_image_bytes(pbits, cv->gflavour)) {
 		return fail("internal: CurveG image size mismatch");
 	}
-	HIPCHK(ecamd_g29_upload(pbits, cv->gslot, img.data(), img.size() * 4, cv->gflavour));
+	SlotRegistry *reg = slot_registry(cv->ctx->device);
+	const int key = pbits + cv->gflavour;
+	if (!reg || key >= ECAMD_G29_KEYS) {
+		return fail("internal: no slot registry for this device / field size");
+	}
+	const int flavour = cv->gflavour;
+	const int slot = slot_acquire(reg->g[key], ecamd_g29_slots() < 8 ? ecamd_g29_slots() : 8, img,
+				      [&](int sl) { return ecamd_g29_upload(pbits, sl, img.data(), img.size() * 4, flavour); });
+	if (slot == -2) {
+		return fail("curve: upload of the radix-2^29 curve constants failed");
+	}
+	cv->gslot = slot < 0 ? -1 : slot;  // no free slot: the saturated-word kernels serve this handle
 	return 0;
 }
 
@@ -652,16 +767,40 @@ static void curve_free_device(ecamd_curve *cv)
 	}
 }
 
+// constant slots of a handle back to the device's registry (g_slot_mu NOT held by the caller)
+static void curve_release_slots(ecamd_curve *cv)
+{
+	if (!cv->ctx) {
+		return;
+	}
+	std::lock_guard<std::mutex> lk(g_slot_mu);
+	const int dev = cv->ctx->device;
+	release_modulus(dev, cv->nw, cv->slot);
+	release_modulus(dev, cv->qnw, cv->qslot);
+	SlotRegistry *reg = slot_registry(dev);
+	const int key = cv->pbits + cv->gflavour;
+	if (reg && cv->gslot >= 0 && cv->gslot < 8 && key < ECAMD_G29_KEYS && reg->g[key][cv->gslot].ref > 0) {
+		reg->g[key][cv->gslot].ref--;
+	}
+	cv->slot = cv->qslot = cv->gslot = -1;
+}
+
 // failure exit of curve construction: releases the handle; msg == NULL keeps the error already recorded
 static int curve_abort(ecamd_curve *cv, const char *msg)
 {
 	curve_free_device(cv);
+	curve_release_slots(cv);
 	delete cv;
 	return msg ? fail(msg) : -1;
 }
 
 static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 {
+	cv->ctx = nullptr;
+	cv->slot = cv->qslot = cv->gslot = -1;
+	cv->d_gen = nullptr;
+	cv->d_comb = nullptr;
+	cv->d_gtab = nullptr;
 	if (!(cv->p[0] & 1) || big_bitlen(cv->p) < 160) {
 		return curve_abort(cv, "curve: p must be odd and at least 160 bits");
 	}
@@ -683,34 +822,27 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	    big_cmp(cv->b, big_from_hex("5ac635d8aa3a93e7b3ebbd55769886bc651d06b0cc53b0f63bce3c3e27d2604b")) == 0 &&
 	    big_cmp(cv->order, cv->q) == 0 && getenv("ECAMD_NO_FAST_PATH") == nullptr;
 	cv->ctx = ctx;
-	cv->d_gen = nullptr;
 	std::lock_guard<std::mutex> lk(ctx->mu);
-	HIPCHK(hipSetDevice(ctx->device));
-	int slot = -1;
-	for (int i = 0; i < ECAMD_MAX_SLOTS_HOST; i++) {
-		if (!ctx->slot_used[i]) {
-			slot = i;
-			break;
-		}
+	if (hipSetDevice(ctx->device) != hipSuccess) {
+		return curve_abort(cv, "curve: hipSetDevice failed");
 	}
-	if (slot < 0) {
-		return curve_abort(cv, "curve: all constant-memory curve slots are in use (free a curve first)");
-	}
-	cv->slot = slot;
-	cv->qslot = -1;
 	cv->qnw = big_bitlen(cv->q) <= 32 * cv->nw ? cv->nw : pick_nw(big_bitlen(cv->q));
-	if ((cv->q[0] & 1) && cv->qnw && ecamd_nw_supported(cv->qnw)) {
-		for (int i = 0; i < ECAMD_MAX_SLOTS_HOST; i++) {
-			if (!ctx->slot_used[i] && i != slot) {
-				cv->qslot = i;
-				break;
+	{
+		// slot: the field of definition (modulus p, curve coefficients);  qslot: Montgomery context of the generator
+		// order q for the mod-q algebra of the protocol layer (only when q is odd and fits a supported width)
+		std::lock_guard<std::mutex> sl(g_slot_mu);
+		if (acquire_modulus(ctx->device, cv->nw, cv->p, cv->a, cv->b, &cv->slot)) {
+			cv->slot = -1;
+		} else if ((cv->q[0] & 1) && cv->qnw && ecamd_nw_supported(cv->qnw)) {
+			Big zero(1, 0);
+			if (acquire_modulus(ctx->device, cv->qnw, cv->q, zero, zero, &cv->qslot)) {
+				cv->qslot = -1;  // protocol entry points unavailable on this handle
 			}
 		}
 	}
-	if (build_and_upload(cv)) {
+	if (cv->slot < 0) {
 		return curve_abort(cv, nullptr);
 	}
-	cv->gslot = -1;
 	cv->gflavour = (cv->pbits == 521 && big_cmp(big_add(cv->p, Big(1, 1)), big_pow2(521)) == 0) ? 1 : 0;
 	if (cv->pbits == 255 && big_cmp(big_add(cv->p, Big(1, 19)), big_pow2(255)) == 0 && getenv("ECAMD_NO_P25519") == nullptr) {
 		cv->gflavour = 2;
@@ -726,14 +858,13 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	if (cv->pbits == 384 && (cv->p[0] & 0x1fffffffu) == 0x1fffffffu && getenv("ECAMD_NO_MPINV1") == nullptr) {
 		cv->gflavour = 3;  // p = -1 mod 2^29 (secp384r1): quotient digits without a multiplication
 	}
-	if (!cv->is_p256 && ecamd_g29_supported(cv->pbits) && cv->pbits < 640 && getenv("ECAMD_NO_FAST_PATH") == nullptr) {
-		for (int i = 0; i < ecamd_g29_slots(); i++) {
-			if (!ctx->gslot_used[cv->pbits + cv->gflavour][i]) {
-				cv->gslot = i;
-				break;
-			}
+	if (!cv->is_p256 && ecamd_g29_supported(cv->pbits) && cv->pbits + 8 < ECAMD_G29_KEYS && getenv("ECAMD_NO_FAST_PATH") == nullptr) {
+		int rc;
+		{
+			std::lock_guard<std::mutex> sl(g_slot_mu);
+			rc = upload_g29(cv);
 		}
-		if (cv->gslot >= 0 && upload_g29(cv)) {
+		if (rc) {
 			return curve_abort(cv, nullptr);
 		}
 	}
@@ -804,13 +935,6 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 		}
 		big_digits29(cv->qdig, 9, cv->q);
 	}
-	ctx->slot_used[slot] = true;
-	if (cv->gslot >= 0) {
-		ctx->gslot_used[cv->pbits + cv->gflavour][cv->gslot] = true;
-	}
-	if (cv->qslot >= 0) {
-		ctx->slot_used[cv->qslot] = true;
-	}
 	*out = cv;
 	return 0;
 }
@@ -867,15 +991,12 @@ extern "C" void ecamd_curve_free(ecamd_curve *cv)
 	{
 		std::lock_guard<std::mutex> lk(cv->ctx->mu);
 		(void)hipSetDevice(cv->ctx->device);
+		// kernels of this handle may still be in flight on the context's stream: let them finish before its constant
+		// slots can be handed to another curve
+		(void)hipStreamSynchronize(cv->ctx->stream);
 		curve_free_device(cv);
-		cv->ctx->slot_used[cv->slot] = false;
-		if (cv->gslot >= 0) {
-			cv->ctx->gslot_used[cv->pbits + cv->gflavour][cv->gslot] = false;
-		}
-		if (cv->qslot >= 0) {
-			cv->ctx->slot_used[cv->qslot] = false;
-		}
 	}
+	curve_release_slots(cv);
 	delete cv;
 }
 
@@ -1068,6 +1189,7 @@ static int host_pipeline(ecamd_ctx *ctx, uint32_t n, const std::vector<HostArr> 
 		}
 	}
 	hipStream_t cs = ctx->copy_stream, s = ctx->stream;
+	StreamScope scope(ctx, s);
 	auto copy_in = [&](uint32_t off, uint32_t m, int b) -> int {
 		for (size_t k = 0; k < na; k++) {
 			if (arrs[k].in) {
@@ -1136,6 +1258,7 @@ extern "C" int ec_prj_pt_mul_batch_dev(ecamd_ctx *ctx, const ecamd_curve *cv, ui
 	std::lock_guard<std::mutex> lk(ctx->mu);
 	HIPCHK(hipSetDevice(ctx->device));
 	hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+	StreamScope scope(ctx, s);
 	return smul_dev_locked(ctx, cv, n, (const uint8_t *)d_scalars, slen, (const uint8_t *)d_points,
 			       (uint8_t *)d_out, (uint8_t *)d_status, s);
 }
@@ -1184,6 +1307,7 @@ static int pt_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uin
 		return -1;
 	}
 	hipStream_t s = ctx->stream;
+	StreamScope scope(ctx, s);
 	HIPCHK(hipMemcpyAsync(ctx->stage[0], p1, (size_t)n * plen, hipMemcpyHostToDevice, s));
 	if (!dbl) {
 		HIPCHK(hipMemcpyAsync(ctx->stage[1], p2, (size_t)n * plen, hipMemcpyHostToDevice, s));
@@ -1237,6 +1361,7 @@ extern "C" int ec_fp_op_batch(ecamd_ctx *ctx, const ecamd_curve *cv, int op, uin
 		return -1;
 	}
 	hipStream_t s = ctx->stream;
+	StreamScope scope(ctx, s);
 	HIPCHK(hipMemcpyAsync(ctx->stage[0], a, bytes, hipMemcpyHostToDevice, s));
 	HIPCHK(hipMemcpyAsync(ctx->stage[1], b, bytes, hipMemcpyHostToDevice, s));
 	EcamdFpArgs A;
@@ -1258,13 +1383,15 @@ extern "C" int ec_fp_op_batch(ecamd_ctx *ctx, const ecamd_curve *cv, int op, uin
 // ------------------------------------------------------------------------------------------
 // The reference's structure: two independent scalar multiplications and one addition per item.
 // All pointers are device pointers; intermediates live in stage[3..11].
+// d_pub == NULL: every public key is the point at infinity (libecc imports (0 : 1 : 0) as a key, and its verification
+// then computes W' = uG + v*infinity = uG, sig/ecdsa_common.c:788-800): [u2]Y is not computed and W' = [u1]G.
 static int ecdsa_two_smul_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_pub,
 			      const uint8_t *d_sig, const uint8_t *d_dig, uint32_t hlen, uint8_t *d_res, hipStream_t s)
 {
 	if (n > ctx->max_chunk) {  // bound the scratch: pieces of max_chunk items, in order on the stream
 		for (uint32_t off = 0; off < n; off += ctx->max_chunk) {
 			const uint32_t m = (n - off) < ctx->max_chunk ? (n - off) : ctx->max_chunk;
-			if (ecdsa_two_smul_dev(ctx, cv, m, d_pub + (size_t)off * 2 * cv->clen, d_sig + (size_t)off * 2 * cv->qlen,
+			if (ecdsa_two_smul_dev(ctx, cv, m, d_pub ? d_pub + (size_t)off * 2 * cv->clen : nullptr, d_sig + (size_t)off * 2 * cv->qlen,
 					       d_dig + (size_t)off * hlen, hlen, d_res + off, s)) {
 				return -1;
 			}
@@ -1293,11 +1420,16 @@ static int ecdsa_two_smul_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n,
 	P.qslot = cv->qslot;
 	HIPCHK(ecamd_launch_ecdsa_prep(cv->qnw, P, s));
 	// uG and vY: two independent prj_pt_mul, as in the reference (sig/ecdsa_common.c:788,793)
-	if (smul_dev_locked(ctx, cv, n, S[3], (uint32_t)cv->qlen, nullptr, S[5], S[7], s) ||
-	    smul_dev_locked(ctx, cv, n, S[4], (uint32_t)cv->qlen, d_pub, S[6], S[8], s)) {
+	if (smul_dev_locked(ctx, cv, n, S[3], (uint32_t)cv->qlen, nullptr, S[5], S[7], s)) {
 		return -1;
 	}
-	if (big_cmp(cv->order, cv->q) != 0) {
+	if (!d_pub) {
+		HIPCHK(hipMemsetAsync(S[6], 0, n * plen, s));
+		HIPCHK(hipMemsetAsync(S[8], 2, n, s));   // [u2]Y = infinity
+	} else if (smul_dev_locked(ctx, cv, n, S[4], (uint32_t)cv->qlen, d_pub, S[6], S[8], s)) {
+		return -1;
+	}
+	if (d_pub && big_cmp(cv->order, cv->q) != 0) {
 		// cofactor != 1: ec_pub_key_import_from_aff_buf also requires [q]Y == infinity
 		// (sig/ec_key.c:199-205).  One more pass with the broadcast scalar q; a key outside the
 		// subgroup is turned into an import error (status 1) for the final stage.
@@ -1482,6 +1614,7 @@ extern "C" int ec_ecdsa_verify_batch_dev(ecamd_ctx *ctx, const ecamd_curve *cv, 
 	std::lock_guard<std::mutex> lk(ctx->mu);
 	HIPCHK(hipSetDevice(ctx->device));
 	hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+	StreamScope scope(ctx, s);
 	return ecdsa_verify_dev_locked(ctx, cv, n, (const uint8_t *)d_pubkeys, (const uint8_t *)d_sigs,
 				       (const uint8_t *)d_digests, hlen, (uint8_t *)d_result, s);
 }
@@ -1503,6 +1636,81 @@ extern "C" int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint
 					       hipStream_t s, const std::function<int()> &between) {
 		return ecdsa_verify_dev_locked(ctx, cv, m, ip[0], ip[1], ip[2], hlen, op[3], s, &between);
 	});
+}
+
+// ECDSA verification with the public keys in either point wire format.  ECAMD_PT_PROJECTIVE is what an ec_pub_key holds
+// (ec_pub_key_export_to_buf: X || Y || Z of pub_key->y): imported as prj_pt_import_from_buf does, normalised on the device,
+// and a key that is the point at infinity -- which libecc imports and verifies against, W' = uG -- is handled as the
+// reference does.
+extern "C" int ec_ecdsa_verify_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys, int pub_fmt,
+					 const uint8_t *sigs, const uint8_t *digests, uint32_t hlen, uint8_t *result)
+{
+	if (pub_fmt == ECAMD_PT_AFFINE) {
+		return ec_ecdsa_verify_batch(ctx, cv, n, pubkeys, sigs, digests, hlen, result);
+	}
+	if (pub_fmt != ECAMD_PT_PROJECTIVE) {
+		return fail("ec_ecdsa_verify_batch_fmt: point format must be ECAMD_PT_AFFINE or ECAMD_PT_PROJECTIVE");
+	}
+	if (ecdsa_verify_args_ok("ec_ecdsa_verify_batch_fmt", ctx, cv, n, pubkeys, sigs, digests, result, hlen)) {
+		return -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	const size_t alen = (size_t)2 * cv->clen, sl = (size_t)2 * cv->qlen;
+	std::vector<uint8_t> aff((size_t)n * alen), st(n);
+	if (ec_prj_pt_unique_batch(ctx, cv, n, pubkeys, ECAMD_PT_PROJECTIVE, aff.data(), ECAMD_PT_AFFINE, st.data()) ||
+	    ec_ecdsa_verify_batch(ctx, cv, n, aff.data(), sigs, digests, hlen, result)) {
+		return -1;
+	}
+	std::vector<uint32_t> inf;
+	for (uint32_t i = 0; i < n; i++) {
+		if (st[i] == ECAMD_ERR) {
+			result[i] = 1;
+		} else if (st[i] == ECAMD_INF) {
+			// (0 : 0 : 0) passes prj_pt_import_from_buf too; the reference's scalar multiplication then fails on it
+			bool allzero = true;
+			for (size_t b = 0; b < 3 * (size_t)cv->clen && allzero; b++) {
+				allzero = pubkeys[(size_t)i * 3 * cv->clen + b] == 0;
+			}
+			result[i] = 1;
+			if (!allzero) {
+				inf.push_back(i);
+			}
+		}
+	}
+	if (inf.empty()) {
+		return 0;
+	}
+	// keys at infinity: W' = [u1]G
+	const uint32_t r = (uint32_t)inf.size();
+	std::vector<uint8_t> hs((size_t)r * sl), hd((size_t)r * hlen), hr(r);
+	for (uint32_t j = 0; j < r; j++) {
+		memcpy(&hs[(size_t)j * sl], sigs + (size_t)inf[j] * sl, sl);
+		memcpy(&hd[(size_t)j * hlen], digests + (size_t)inf[j] * hlen, hlen);
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t gneed[3] = {(size_t)r * sl, (size_t)r * hlen, r};
+	for (int i = 0; i < 3; i++) {
+		if (ensure(&ctx->stage[14 + i], &ctx->stage_bytes[14 + i], gneed[i])) {
+			return -1;
+		}
+	}
+	hipStream_t s = ctx->stream;
+	StreamScope scope(ctx, s);
+	uint8_t **S = ctx->stage;
+	HIPCHK(hipMemcpyAsync(S[14], hs.data(), hs.size(), hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(S[15], hd.data(), hd.size(), hipMemcpyHostToDevice, s));
+	if (ecdsa_two_smul_dev(ctx, cv, r, nullptr, S[14], S[15], hlen, S[16], s)) {
+		return -1;
+	}
+	HIPCHK(hipMemcpyAsync(hr.data(), S[16], r, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	for (uint32_t j = 0; j < r; j++) {
+		result[inf[j]] = hr[j];
+	}
+	return 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1586,6 +1794,7 @@ extern "C" int ec_ecdsa_sign_batch_dev(ecamd_ctx *ctx, const ecamd_curve *cv, ui
 	std::lock_guard<std::mutex> lk(ctx->mu);
 	HIPCHK(hipSetDevice(ctx->device));
 	hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+	StreamScope scope(ctx, s);
 	return ecdsa_sign_dev_locked(ctx, cv, n, (const uint8_t *)d_privs, (const uint8_t *)d_nonces, (const uint8_t *)d_digests,
 				     hlen, (uint8_t *)d_sigs, (uint8_t *)d_status, s);
 }
@@ -1692,6 +1901,7 @@ extern "C" int ec_ecccdh_derive_batch_dev(ecamd_ctx *ctx, const ecamd_curve *cv,
 	std::lock_guard<std::mutex> lk(ctx->mu);
 	HIPCHK(hipSetDevice(ctx->device));
 	hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+	StreamScope scope(ctx, s);
 	return ecccdh_dev_locked(ctx, cv, n, (const uint8_t *)d_privs, (const uint8_t *)d_peers, (uint8_t *)d_secrets,
 				 (uint8_t *)d_status, s);
 }
@@ -1922,6 +2132,7 @@ extern "C" int ec_xdh_batch_dev(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32
 	}
 	HIPCHK(hipSetDevice(ctx->device));
 	hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+	StreamScope scope(ctx, s);
 	return xdh_dev_locked(ctx, const_cast<ecamd_curve *>(cv_in), n, (const uint8_t *)d_k, (const uint8_t *)d_u,
 			      (uint8_t *)d_out, (uint8_t *)d_status, s);
 }
@@ -2384,6 +2595,7 @@ extern "C" int ec_eddsa_verify_batch_dev(ecamd_ctx *ctx, const ecamd_curve *cv_i
 	}
 	HIPCHK(hipSetDevice(ctx->device));
 	hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+	StreamScope scope(ctx, s);
 	if (cv_in->pbits == 448) {
 		return eddsa448_verify_dev_locked(ctx, const_cast<ecamd_curve *>(cv_in), n, (const uint8_t *)d_pubkeys,
 						  (const uint8_t *)d_sigs, (const uint8_t *)d_hram, (uint8_t *)d_result, s);
@@ -2589,6 +2801,7 @@ static int pt_fmt_batch(const char *fn, ecamd_ctx *ctx, const ecamd_curve *cv, u
 	}
 	uint8_t **S = ctx->stage;
 	hipStream_t s = ctx->stream;
+	StreamScope scope(ctx, s);
 	if (mul) {
 		HIPCHK(hipMemcpyAsync(S[0], scalars, (size_t)n * slen, hipMemcpyHostToDevice, s));
 	}

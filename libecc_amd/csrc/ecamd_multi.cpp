@@ -1,0 +1,408 @@
+// libecc_amd/csrc/ecamd_multi.cpp -- the multi-GPU form of the C ABI: one context and
+// one host thread per device, the batch cut into contiguous shards (rank r of N owns items
+// [r*n/N, (r+1)*n/N) -- work per item is constant, so equal counts are balanced), no collective on the
+// compute path.  Host-pointer results land in the caller's arrays straight from each device (N independent
+// D2H copies); ecamd_multi_allgather is the one RCCL all-gather over xGMI for callers that keep the outputs
+// device-resident on every GPU (north_star).  Built only on the public single-device entry points of
+// include/libecc_amd.h, so every shard runs exactly the code the single-GPU tests pin.
+//
+// A device may be listed several times (one context and one shard each): the shards then share that GPU.
+// That is how the 1-GPU development box exercises this file (tests/test_gpu_parity.py::test_multi_*).
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/libecc_amd.h"
+
+void ecamd_set_error(const char *msg);  // ecamd_host.cpp: the thread-local string behind ecamd_last_error()
+
+struct ecamd_multi {
+	std::vector<int> devices;
+	std::vector<ecamd_ctx *> ctx;
+	std::mutex mu;              // one multi-call at a time (the per-device contexts serialise anyway)
+	// RCCL, loaded on the first all-gather
+	void *rccl = nullptr;
+	std::vector<void *> comms;  // ncclComm_t per rank
+	std::vector<hipStream_t> cstreams;
+};
+
+struct ecamd_mcurve {
+	ecamd_multi *m;
+	std::vector<ecamd_curve *> cv;  // one handle per rank
+};
+
+static int mfail(const std::string &s)
+{
+	ecamd_set_error(s.c_str());
+	return -1;
+}
+
+static inline uint32_t shard_lo(uint32_t n, int r, int N) { return (uint32_t)(((uint64_t)n * (uint64_t)r) / (uint64_t)N); }
+
+extern "C" void ecamd_multi_shard_range(uint32_t n, int rank, int nranks, uint32_t *lo, uint32_t *hi)
+{
+	if (nranks <= 0 || rank < 0 || rank >= nranks) {
+		*lo = *hi = 0;
+		return;
+	}
+	*lo = shard_lo(n, rank, nranks);
+	*hi = shard_lo(n, rank + 1, nranks);
+}
+
+extern "C" int ecamd_multi_create(ecamd_multi **out, const int *devices, int ndev)
+{
+	if (!out) {
+		return mfail("ecamd_multi_create: NULL out pointer");
+	}
+	*out = nullptr;
+	std::vector<int> devs;
+	if (!devices || ndev <= 0) {
+		const int n = ecamd_device_count();
+		for (int i = 0; i < n; i++) {
+			devs.push_back(i);
+		}
+	} else {
+		devs.assign(devices, devices + ndev);
+	}
+	if (devs.empty()) {
+		return mfail("ecamd_multi_create: no HIP device available (this library has no CPU fallback)");
+	}
+	ecamd_multi *m = new ecamd_multi();
+	m->devices = devs;
+	for (int d : devs) {
+		ecamd_ctx *c = nullptr;
+		if (ecamd_ctx_create(&c, d)) {
+			for (ecamd_ctx *x : m->ctx) {
+				ecamd_ctx_destroy(x);
+			}
+			delete m;
+			return -1;  // ecamd_last_error() already says why
+		}
+		m->ctx.push_back(c);
+	}
+	*out = m;
+	return 0;
+}
+
+typedef int (*nccl_destroy_fn)(void *);
+
+extern "C" void ecamd_multi_destroy(ecamd_multi *m)
+{
+	if (!m) {
+		return;
+	}
+	if (m->rccl) {
+		nccl_destroy_fn destroy = (nccl_destroy_fn)dlsym(m->rccl, "ncclCommDestroy");
+		for (size_t r = 0; r < m->comms.size(); r++) {
+			(void)hipSetDevice(m->devices[r]);
+			if (destroy && m->comms[r]) {
+				(void)destroy(m->comms[r]);
+			}
+			if (r < m->cstreams.size() && m->cstreams[r]) {
+				(void)hipStreamDestroy(m->cstreams[r]);
+			}
+		}
+	}
+	for (ecamd_ctx *c : m->ctx) {
+		ecamd_ctx_destroy(c);
+	}
+	delete m;
+}
+
+extern "C" int ecamd_multi_size(const ecamd_multi *m) { return m ? (int)m->ctx.size() : 0; }
+extern "C" int ecamd_multi_device(const ecamd_multi *m, int rank)
+{
+	return (m && rank >= 0 && rank < (int)m->devices.size()) ? m->devices[(size_t)rank] : -1;
+}
+extern "C" ecamd_ctx *ecamd_multi_ctx(ecamd_multi *m, int rank)
+{
+	return (m && rank >= 0 && rank < (int)m->ctx.size()) ? m->ctx[(size_t)rank] : nullptr;
+}
+
+extern "C" void ecamd_multi_curve_free(ecamd_mcurve *c)
+{
+	if (!c) {
+		return;
+	}
+	for (ecamd_curve *cv : c->cv) {
+		ecamd_curve_free(cv);
+	}
+	delete c;
+}
+
+static int mcurve_make(ecamd_multi *m, ecamd_mcurve **out, const std::function<int(ecamd_ctx *, ecamd_curve **)> &make)
+{
+	if (!m || !out) {
+		return mfail("ecamd_multi_curve: NULL argument");
+	}
+	*out = nullptr;
+	ecamd_mcurve *c = new ecamd_mcurve();
+	c->m = m;
+	for (ecamd_ctx *x : m->ctx) {
+		ecamd_curve *cv = nullptr;
+		if (make(x, &cv)) {
+			ecamd_multi_curve_free(c);
+			return -1;
+		}
+		c->cv.push_back(cv);
+	}
+	*out = c;
+	return 0;
+}
+
+extern "C" int ecamd_multi_curve_by_name(ecamd_multi *m, const char *name, ecamd_mcurve **out)
+{
+	return mcurve_make(m, out, [&](ecamd_ctx *x, ecamd_curve **cv) { return ecamd_curve_by_name(x, name, cv); });
+}
+
+extern "C" int ecamd_multi_curve_from_params(ecamd_multi *m, const uint8_t *p, uint32_t p_len, const uint8_t *a, uint32_t a_len,
+					     const uint8_t *b, uint32_t b_len, const uint8_t *curve_order, uint32_t curve_order_len,
+					     const uint8_t *gx, uint32_t gx_len, const uint8_t *gy, uint32_t gy_len,
+					     const uint8_t *gen_order, uint32_t gen_order_len, ecamd_mcurve **out)
+{
+	return mcurve_make(m, out, [&](ecamd_ctx *x, ecamd_curve **cv) {
+		return ecamd_curve_from_params(x, p, p_len, a, a_len, b, b_len, curve_order, curve_order_len, gx, gx_len, gy, gy_len,
+					       gen_order, gen_order_len, cv);
+	});
+}
+
+extern "C" const ecamd_curve *ecamd_multi_curve_handle(const ecamd_mcurve *c, int rank)
+{
+	return (c && rank >= 0 && rank < (int)c->cv.size()) ? c->cv[(size_t)rank] : nullptr;
+}
+extern "C" int ecamd_multi_curve_coord_len(const ecamd_mcurve *c) { return (c && !c->cv.empty()) ? ecamd_curve_coord_len(c->cv[0]) : -1; }
+extern "C" int ecamd_multi_curve_order_len(const ecamd_mcurve *c) { return (c && !c->cv.empty()) ? ecamd_curve_order_len(c->cv[0]) : -1; }
+
+// run shard(rank, lo, hi) on one host thread per rank; the first failing rank's message becomes the caller's error
+static int run_sharded(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const char *fn,
+		       const std::function<int(int, uint32_t, uint32_t)> &shard)
+{
+	if (!m || !c || c->m != m) {
+		return mfail(std::string(fn) + ": bad argument");
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(m->mu);
+	const int N = (int)m->ctx.size();
+	std::vector<int> rc((size_t)N, 0);
+	std::vector<std::string> err((size_t)N);
+	auto body = [&](int r) {
+		const uint32_t lo = shard_lo(n, r, N), hi = shard_lo(n, r + 1, N);
+		if (hi > lo) {
+			rc[(size_t)r] = shard(r, lo, hi);
+			if (rc[(size_t)r]) {
+				err[(size_t)r] = ecamd_last_error();  // thread-local of the worker
+			}
+		}
+	};
+	if (N == 1) {
+		body(0);
+	} else {
+		std::vector<std::thread> th;
+		for (int r = 0; r < N; r++) {
+			th.emplace_back(body, r);
+		}
+		for (std::thread &t : th) {
+			t.join();
+		}
+	}
+	for (int r = 0; r < N; r++) {
+		if (rc[(size_t)r]) {
+			char pre[64];
+			snprintf(pre, sizeof(pre), "%s: rank %d (device %d): ", fn, r, m->devices[(size_t)r]);
+			return mfail(pre + err[(size_t)r]);
+		}
+	}
+	return 0;
+}
+
+#define OFF(p, stride) ((p) ? (p) + (size_t)lo * (stride) : nullptr)
+
+extern "C" int ecamd_multi_prj_pt_mul_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *scalars,
+					    uint32_t scalar_len, const uint8_t *points_aff, uint8_t *out_aff, uint8_t *status)
+{
+	const size_t plen = 2 * (size_t)ecamd_multi_curve_coord_len(c);
+	return run_sharded(m, c, n, "ecamd_multi_prj_pt_mul_batch", [&](int r, uint32_t lo, uint32_t hi) {
+		return ec_prj_pt_mul_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(scalars, scalar_len), scalar_len, OFF(points_aff, plen),
+					   OFF(out_aff, plen), OFF(status, 1));
+	});
+}
+
+extern "C" int ecamd_multi_prj_pt_mul_batch_fmt(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *scalars,
+						uint32_t scalar_len, const uint8_t *points, int in_fmt, uint8_t *out, int out_fmt,
+						uint8_t *status)
+{
+	const size_t cl = (size_t)ecamd_multi_curve_coord_len(c), il = (in_fmt ? 3 : 2) * cl, ol = (out_fmt ? 3 : 2) * cl;
+	return run_sharded(m, c, n, "ecamd_multi_prj_pt_mul_batch_fmt", [&](int r, uint32_t lo, uint32_t hi) {
+		return ec_prj_pt_mul_batch_fmt(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(scalars, scalar_len), scalar_len, OFF(points, il),
+					       in_fmt, OFF(out, ol), out_fmt, OFF(status, 1));
+	});
+}
+
+extern "C" int ecamd_multi_ecdsa_verify_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys_aff,
+					      const uint8_t *sigs, const uint8_t *digests, uint32_t digest_len, uint8_t *result)
+{
+	const size_t plen = 2 * (size_t)ecamd_multi_curve_coord_len(c), sl = 2 * (size_t)ecamd_multi_curve_order_len(c);
+	return run_sharded(m, c, n, "ecamd_multi_ecdsa_verify_batch", [&](int r, uint32_t lo, uint32_t hi) {
+		return ec_ecdsa_verify_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(pubkeys_aff, plen), OFF(sigs, sl),
+					     OFF(digests, digest_len), digest_len, OFF(result, 1));
+	});
+}
+
+extern "C" int ecamd_multi_ecdsa_verify_batch_fmt(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys, int pub_fmt,
+						  const uint8_t *sigs, const uint8_t *digests, uint32_t digest_len, uint8_t *result)
+{
+	const size_t plen = (pub_fmt ? 3 : 2) * (size_t)ecamd_multi_curve_coord_len(c), sl = 2 * (size_t)ecamd_multi_curve_order_len(c);
+	return run_sharded(m, c, n, "ecamd_multi_ecdsa_verify_batch_fmt", [&](int r, uint32_t lo, uint32_t hi) {
+		return ec_ecdsa_verify_batch_fmt(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(pubkeys, plen), pub_fmt, OFF(sigs, sl),
+						 OFF(digests, digest_len), digest_len, OFF(result, 1));
+	});
+}
+
+extern "C" int ecamd_multi_ecdsa_sign_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *privs,
+					    const uint8_t *nonces, const uint8_t *digests, uint32_t digest_len, uint8_t *sigs,
+					    uint8_t *status)
+{
+	const size_t ql = (size_t)ecamd_multi_curve_order_len(c);
+	return run_sharded(m, c, n, "ecamd_multi_ecdsa_sign_batch", [&](int r, uint32_t lo, uint32_t hi) {
+		return ec_ecdsa_sign_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(privs, ql), OFF(nonces, ql), OFF(digests, digest_len),
+					   digest_len, OFF(sigs, 2 * ql), OFF(status, 1));
+	});
+}
+
+extern "C" int ecamd_multi_ecccdh_derive_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *privs,
+					       const uint8_t *peers_aff, uint8_t *secrets, uint8_t *status)
+{
+	const size_t cl = (size_t)ecamd_multi_curve_coord_len(c), ql = (size_t)ecamd_multi_curve_order_len(c);
+	return run_sharded(m, c, n, "ecamd_multi_ecccdh_derive_batch", [&](int r, uint32_t lo, uint32_t hi) {
+		return ec_ecccdh_derive_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(privs, ql), OFF(peers_aff, 2 * cl), OFF(secrets, cl),
+					      OFF(status, 1));
+	});
+}
+
+extern "C" int ecamd_multi_xdh_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *k, const uint8_t *u,
+				     uint8_t *out, uint8_t *status)
+{
+	const size_t cl = (size_t)ecamd_multi_curve_coord_len(c);
+	return run_sharded(m, c, n, "ecamd_multi_xdh_batch", [&](int r, uint32_t lo, uint32_t hi) {
+		return ec_xdh_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(k, cl), OFF(u, cl), OFF(out, cl), OFF(status, 1));
+	});
+}
+
+extern "C" int ecamd_multi_eddsa_verify_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys,
+					      const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, uint8_t *result)
+{
+	// Ed25519: 32-byte keys, 64-byte signatures; Ed448: 57 / 114 (coordinate length 56)
+	const size_t cl = (size_t)ecamd_multi_curve_coord_len(c), kl = (cl == 56) ? 57 : cl;
+	return run_sharded(m, c, n, "ecamd_multi_eddsa_verify_batch", [&](int r, uint32_t lo, uint32_t hi) {
+		return ec_eddsa_verify_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(pubkeys, kl), OFF(sigs, 2 * kl), OFF(hram, hram_len),
+					     hram_len, OFF(result, 1));
+	});
+}
+
+extern "C" int ecamd_multi_prj_pt_unique_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *points, int in_fmt,
+					       uint8_t *out, int out_fmt, uint8_t *status)
+{
+	const size_t cl = (size_t)ecamd_multi_curve_coord_len(c), il = (in_fmt ? 3 : 2) * cl, ol = (out_fmt ? 3 : 2) * cl;
+	return run_sharded(m, c, n, "ecamd_multi_prj_pt_unique_batch", [&](int r, uint32_t lo, uint32_t hi) {
+		return ec_prj_pt_unique_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(points, il), in_fmt, OFF(out, ol), out_fmt,
+					      OFF(status, 1));
+	});
+}
+
+// ------------------------------------------------------------------------------------------
+// the one collective: RCCL all-gather of equal-size device-resident shards (north_star: "RCCL gather over xGMI
+// for the output points").  d_send[r]: bytes_per_rank bytes on device r; d_recv[r]: nranks * bytes_per_rank bytes
+// on device r.  librccl is loaded on first use (dlopen), one communicator per rank of this process
+// (ncclCommInitAll), the gathers of all ranks issued inside one group call.
+// ------------------------------------------------------------------------------------------
+typedef int (*nccl_init_all_fn)(void **, int, const int *);
+typedef int (*nccl_group_fn)(void);
+typedef int (*nccl_allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef const char *(*nccl_err_fn)(int);
+
+extern "C" int ecamd_multi_allgather(ecamd_multi *m, const void *const *d_send, void *const *d_recv, size_t bytes_per_rank)
+{
+	if (!m || !d_send || !d_recv) {
+		return mfail("ecamd_multi_allgather: NULL argument");
+	}
+	std::lock_guard<std::mutex> lk(m->mu);
+	const int N = (int)m->ctx.size();
+	if (N == 1) {
+		if (hipSetDevice(m->devices[0]) != hipSuccess ||
+		    hipMemcpy(d_recv[0], d_send[0], bytes_per_rank, hipMemcpyDeviceToDevice) != hipSuccess) {
+			return mfail("ecamd_multi_allgather: device copy failed");
+		}
+		return 0;
+	}
+	for (int r = 0; r < N; r++) {
+		for (int q = 0; q < r; q++) {
+			if (m->devices[(size_t)r] == m->devices[(size_t)q]) {
+				return mfail("ecamd_multi_allgather: RCCL needs distinct devices (a device is listed twice in this multi-context)");
+			}
+		}
+	}
+	if (!m->rccl) {
+		void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+		if (!h) {
+			h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+		}
+		if (!h) {
+			return mfail(std::string("ecamd_multi_allgather: cannot load librccl: ") + dlerror());
+		}
+		nccl_init_all_fn init_all = (nccl_init_all_fn)dlsym(h, "ncclCommInitAll");
+		if (!init_all) {
+			dlclose(h);
+			return mfail("ecamd_multi_allgather: librccl has no ncclCommInitAll");
+		}
+		m->comms.assign((size_t)N, nullptr);
+		const int e = init_all(m->comms.data(), N, m->devices.data());
+		if (e != 0) {
+			nccl_err_fn es = (nccl_err_fn)dlsym(h, "ncclGetErrorString");
+			const std::string msg = std::string("ecamd_multi_allgather: ncclCommInitAll: ") + (es ? es(e) : "error");
+			dlclose(h);
+			m->comms.clear();
+			return mfail(msg);
+		}
+		m->cstreams.assign((size_t)N, nullptr);
+		for (int r = 0; r < N; r++) {
+			if (hipSetDevice(m->devices[(size_t)r]) != hipSuccess ||
+			    hipStreamCreateWithFlags(&m->cstreams[(size_t)r], hipStreamNonBlocking) != hipSuccess) {
+				return mfail("ecamd_multi_allgather: stream creation failed");
+			}
+		}
+		m->rccl = h;
+	}
+	nccl_group_fn gstart = (nccl_group_fn)dlsym(m->rccl, "ncclGroupStart"), gend = (nccl_group_fn)dlsym(m->rccl, "ncclGroupEnd");
+	nccl_allgather_fn ag = (nccl_allgather_fn)dlsym(m->rccl, "ncclAllGather");
+	nccl_err_fn es = (nccl_err_fn)dlsym(m->rccl, "ncclGetErrorString");
+	if (!gstart || !gend || !ag) {
+		return mfail("ecamd_multi_allgather: librccl misses ncclGroupStart / ncclGroupEnd / ncclAllGather");
+	}
+	int e = gstart();
+	for (int r = 0; r < N && e == 0; r++) {
+		// ncclUint8 = 1 in rccl.h's ncclDataType_t (ncclInt8 = ncclChar = 0)
+		e = ag(d_send[r], d_recv[r], bytes_per_rank, 1, m->comms[(size_t)r], m->cstreams[(size_t)r]);
+	}
+	const int e2 = gend();
+	if (e == 0) {
+		e = e2;
+	}
+	if (e != 0) {
+		return mfail(std::string("ecamd_multi_allgather: ") + (es ? es(e) : "RCCL error"));
+	}
+	for (int r = 0; r < N; r++) {
+		if (hipSetDevice(m->devices[(size_t)r]) != hipSuccess || hipStreamSynchronize(m->cstreams[(size_t)r]) != hipSuccess) {
+			return mfail("ecamd_multi_allgather: stream synchronisation failed");
+		}
+	}
+	return 0;
+}

@@ -1,0 +1,153 @@
+"""BASELINE.json configs[3] and [4] at their full size (2^20 items in one call) -- ECDSA verification on secp256r1,
+Ed25519 verification and X25519 -- with (i) size-independent properties over every item and (ii) 2^12 items of each
+result compared with the UNMODIFIED reference binary (oracle/_ref: ec_verify, ec_sign, x25519 of libecc itself), not
+with the restatement.  configs[1] / [2] at full size are tests/test_gpu_parity.py::test_full_batch_properties."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracles as O
+from oracles import CURVES, RefLib, have_ref
+from test_gpu_parity import rand_bytes
+
+pytestmark = pytest.mark.gpu
+
+LOG2N = int(os.environ.get("ECAMD_TEST_FULL_LOG2", "20"))
+NREF = int(os.environ.get("ECAMD_TEST_REF_ITEMS", str(1 << 12)))
+
+
+def cut(b, w, idx):
+    return b"".join(b[w * i:w * i + w] for i in idx)
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref/libecc_ref.so not built")
+def test_ecdsa_secp256r1_full_size_vs_reference_binary(gpu_ctx):
+    """configs[3]: 2^20 (public key, signature, digest) triples, 10 % corrupted in r, s, the digest or the key.
+    Every valid item is accepted and every corrupted one rejected; 2^12 items against libecc's ec_verify (which hashes the
+    messages itself) and 2^11 signatures against libecc's ec_sign with the same nonces."""
+    curve, h, ml = "SECP256R1", "SHA256", 24
+    rng = np.random.default_rng(401)
+    cv = gpu_ctx.curve(curve)
+    r = RefLib(curve)
+    try:
+        n, q = 1 << LOG2N, CURVES[curve]["q"]
+        raw = rng.integers(0, 256, size=(2, n, 40), dtype=np.uint8)
+        scal = lambda a: b"".join(((int.from_bytes(a[i].tobytes(), "big") % (q - 1)) + 1).to_bytes(32, "big") for i in range(n))
+        d, ks = scal(raw[0]), scal(raw[1])
+        msgs = rand_bytes(rng, ml * n)
+        dg = b"".join(hashlib.sha256(msgs[ml * i:ml * (i + 1)]).digest() for i in range(n))
+        pubs, st = cv.scalar_mult(d)
+        assert set(st) == {0}
+        sigs, st = cv.ecdsa_sign(d, ks, dg, 32)
+        assert set(st) == {0}
+        assert cv.ecdsa_verify(pubs, sigs, dg, 32) == bytes(n)
+        # corrupt 10 %: r, s, digest (= another message), key
+        S = np.frombuffer(sigs, dtype=np.uint8).copy().reshape(n, 64)
+        D = np.frombuffer(dg, dtype=np.uint8).copy().reshape(n, 32)
+        M = np.frombuffer(msgs, dtype=np.uint8).copy().reshape(n, ml)
+        P = np.frombuffer(pubs, dtype=np.uint8).copy().reshape(n, 64)
+        i = np.arange(n)
+        bad = (i % 10) == 7
+        kind = (i // 10) % 4
+        S[bad & (kind == 0), 5] ^= 0x40
+        S[bad & (kind == 1), 40] ^= 0x02
+        m2 = bad & (kind == 2)
+        M[m2, 3] ^= 0x80
+        for j in np.nonzero(m2)[0]:
+            D[j] = np.frombuffer(hashlib.sha256(M[j].tobytes()).digest(), dtype=np.uint8)
+        P[bad & (kind == 3), 63] ^= 0x01          # off the curve (or, rarely, another valid key): rejected either way
+        res = cv.ecdsa_verify(P.tobytes(), S.tobytes(), D.tobytes(), 32)
+        assert res == bytes(bad.astype(np.uint8))
+        # against the reference binary
+        idx = [int(x) for x in np.sort(rng.choice(n, size=min(n, NREF), replace=False))]
+        exp = r.ecdsa_verify(h, cut(P.tobytes(), 64, idx), cut(S.tobytes(), 64, idx), cut(M.tobytes(), ml, idx), ml)
+        assert exp == bytes(res[j] for j in idx) and 0 < sum(exp) < len(idx)
+        idx2 = idx[:len(idx) // 2]
+        rs, rp, rst = r.ecdsa_sign(h, cut(d, 32, idx2), cut(ks, 32, idx2), cut(msgs, ml, idx2), ml)
+        assert set(rst) == {0} and rs == cut(sigs, 64, idx2) and rp == cut(pubs, 64, idx2)
+    finally:
+        cv.free()
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref/libecc_ref.so not built")
+def test_ed25519_full_size_vs_reference_binary(gpu_ctx):
+    """configs[4], Ed25519: 2^20 signatures made through the device-side signing steps (keys, R and S on the GPU, the three
+    SHA-512 per item on the host), verified on the GPU with 10 % corrupted; 2^12 verdicts against libecc's ec_verify and
+    2^10 (key, signature) pairs byte for byte against libecc's key derivation + ec_sign from the same seeds"""
+    rng = np.random.default_rng(402)
+    ml = 16
+    cv = gpu_ctx.curve("WEI25519")
+    try:
+        n = 1 << LOG2N
+        seeds = rand_bytes(rng, 32 * n)
+        msgs = rand_bytes(rng, ml * n)
+        hk = [hashlib.sha512(seeds[32 * i:32 * i + 32]).digest() for i in range(n)]
+        a = bytearray()
+        for x in hk:
+            v = (int.from_bytes(x[:32], "little") & ((1 << 254) - 8)) | (1 << 254)
+            a += v.to_bytes(32, "little")
+        a = bytes(a)
+        # public keys: [a]B encoded -- the R step applied to the secret scalar (B has order q)
+        A, st = cv.eddsa_sign_R(b"".join(a[32 * i:32 * i + 32] + bytes(32) for i in range(n)))
+        assert set(st) == {0}
+        r_hash = b"".join(hashlib.sha512(hk[i][32:] + msgs[ml * i:ml * (i + 1)]).digest() for i in range(n))
+        R, st = cv.eddsa_sign_R(r_hash)
+        assert set(st) == {0}
+        hram = b"".join(hashlib.sha512(R[32 * i:32 * i + 32] + A[32 * i:32 * i + 32] + msgs[ml * i:ml * (i + 1)]).digest() for i in range(n))
+        Sb = cv.eddsa_sign_S(r_hash, hram, a)
+        sigs = np.concatenate([np.frombuffer(R, dtype=np.uint8).reshape(n, 32), np.frombuffer(Sb, dtype=np.uint8).reshape(n, 32)], axis=1)
+        assert cv.eddsa_verify(A, sigs.tobytes(), hram) == bytes(n)
+        i = np.arange(n)
+        bad = (i % 10) == 3
+        kind = (i // 10) % 3
+        S = sigs.copy()
+        S[bad & (kind == 0), 7] ^= 0x10           # R
+        S[bad & (kind == 1), 33] ^= 0x01          # S
+        H = np.frombuffer(hram, dtype=np.uint8).copy().reshape(n, 64)
+        M = np.frombuffer(msgs, dtype=np.uint8).copy().reshape(n, ml)
+        m2 = bad & (kind == 2)
+        M[m2, 0] ^= 1                               # another message
+        # the hash binds R: recompute it where R or the message changed
+        for j in np.nonzero(bad)[0]:
+            H[j] = np.frombuffer(hashlib.sha512(S[j, :32].tobytes() + A[32 * j:32 * j + 32] + M[j].tobytes()).digest(), dtype=np.uint8)
+        res = cv.eddsa_verify(A, S.tobytes(), H.tobytes())
+        assert res == bytes(bad.astype(np.uint8))
+        idx = [int(x) for x in np.sort(rng.choice(n, size=min(n, NREF), replace=False))]
+        exp = O.ref_ed25519_verify(cut(A, 32, idx), cut(S.tobytes(), 64, idx), cut(M.tobytes(), ml, idx), ml)
+        assert exp == bytes(res[j] for j in idx) and 0 < sum(exp) < len(idx)
+        idx2 = idx[:len(idx) // 4]
+        rp, rs, rst = O.ref_ed25519_sign(cut(seeds, 32, idx2), cut(msgs, ml, idx2), ml)
+        assert set(rst) == {0} and rp == cut(A, 32, idx2) and rs == cut(sigs.tobytes(), 64, idx2)
+    finally:
+        cv.free()
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref/libecc_ref.so not built")
+def test_x25519_full_size_vs_reference_binary(gpu_ctx):
+    """configs[4], X25519: 2^20 key agreements -- X25519(a, X25519(b, 9)) == X25519(b, X25519(a, 9)) for every pair -- and
+    2^20 random (k, u) inputs (about half of them on the twist, which libecc rejects), 2^12 of each against libecc's x25519()"""
+    rng = np.random.default_rng(403)
+    cv = gpu_ctx.curve("WEI25519")
+    try:
+        n = 1 << LOG2N
+        ka, kb = rand_bytes(rng, 32 * n), rand_bytes(rng, 32 * n)
+        nine = (9).to_bytes(32, "little") * n
+        pa, sa = cv.xdh(ka, nine)
+        pb, sb = cv.xdh(kb, nine)
+        assert set(sa) == {0} and set(sb) == {0}
+        s1, st1 = cv.xdh(ka, pb)
+        s2, st2 = cv.xdh(kb, pa)
+        assert set(st1) == {0} and (s1, st1) == (s2, st2)
+        u = np.frombuffer(rand_bytes(rng, 32 * n), dtype=np.uint8).copy().reshape(n, 32)
+        u[:, 31] &= 0x7f
+        u[::97] = 0xff                              # non-canonical: >= p (top bit set as well)
+        u[5::97] = 0                                # u = 0: small order
+        out, st = cv.xdh(ka, u.tobytes())
+        assert 0.3 * n < st.count(1) < 0.7 * n
+        idx = [int(x) for x in np.sort(rng.choice(n, size=min(n, NREF), replace=False))]
+        assert O.ref_xdh(32, cut(ka, 32, idx), cut(u.tobytes(), 32, idx)) == (cut(out, 32, idx), bytes(st[j] for j in idx))
+        assert O.ref_xdh(32, cut(ka, 32, idx), cut(pb, 32, idx)) == (cut(s1, 32, idx), bytes(len(idx)))
+    finally:
+        cv.free()

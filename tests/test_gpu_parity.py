@@ -11,6 +11,9 @@ from oracles import (CURVES, GOLDEN, Oracle, RefLib, clen, digest, have_ref, py_
 
 pytestmark = pytest.mark.gpu
 
+# random items of a full-size batch that are compared with the unmodified reference (>= 2^16)
+FULL_PARITY_ITEMS = int(os.environ.get("ECAMD_TEST_PARITY_ITEMS", str(1 << 16)))
+
 MAIN = ["SECP256R1", "SECP384R1", "SECP521R1", "WEI25519"]
 WIDTHS = ["SECP192R1", "SECP224R1", "BRAINPOOLP320R1", "WEI448", "BRAINPOOLP512R1", "SECP256K1"]
 
@@ -295,7 +298,7 @@ def test_generic_fast_path_properties(gpu_ctx, curve):
 def test_full_batch_properties(gpu_ctx, curve):
     """BASELINE.json configs[1] and [2] at their full size (2^20 items in one call, 4 / 6 / 9 x 64-bit
     limb curves): every item is checked through [a]([b]G) == [a b mod q]G computed two ways on the GPU,
-    plus 128 random items against the oracle"""
+    and 2^16 random items + a 4096-item edge slice against the unmodified reference binary"""
     cv = gpu_ctx.curve(curve)
     o = Oracle(curve)
     try:
@@ -317,12 +320,23 @@ def test_full_batch_properties(gpu_ctx, curve):
         else:
             ok = [i for i in range(n) if st[i] == 0]
             assert all(st1[i] == st2[i] and abG[i * pl:(i + 1) * pl] == abG2[i * pl:(i + 1) * pl] for i in ok)
-        idx = rng.choice(n, size=128, replace=False)
+        # >= 2^16 random items of the batch and the whole 4096-item edge slice, byte for byte
+        # against the unmodified reference (prj_pt_mul + prj_pt_unique) on all host threads
+        from bench import edge_slice, host_cores
+        ns = FULL_PARITY_ITEMS if have_ref() else 2048
+        idx = np.sort(rng.choice(n, size=ns, replace=False))
         sub = b"".join(A[i * ql:(i + 1) * ql] for i in idx)
         subp = b"".join(bG[i * pl:(i + 1) * pl] for i in idx)
-        exp, est = o.scalar_mult(sub, subp)
+        ref = RefLib(curve) if have_ref() else None
+        smul = (lambda s_, p_: ref.scalar_mult(s_, p_, ql, nthreads=host_cores())) if ref else (lambda s_, p_: o.scalar_mult(s_, p_))
+        exp, est = smul(sub, subp)
         assert exp == b"".join(abG[i * pl:(i + 1) * pl] for i in idx)
         assert est == bytes(st1[i] for i in idx)
+        e_sc, e_pt = edge_slice(CURVES[curve], ql, o.clen, bG, 4096)
+        got = cv.scalar_mult(e_sc, e_pt)
+        exp = smul(e_sc, e_pt)
+        assert got[1] == exp[1] and got[0] == exp[0]
+        assert got[1].count(1) > 1000 and got[1].count(2) > 100 and got[1].count(0) > 1500
     finally:
         cv.free()
 
@@ -344,15 +358,24 @@ def test_long_and_short_scalars(gpu_ctx, curve):
 
 
 @pytest.mark.skipif(not have_ref(), reason="oracle/_ref/libecc_ref.so not built")
-@pytest.mark.parametrize("curve", ["SECP256R1", "SECP384R1"])
+@pytest.mark.parametrize("curve", ["SECP256R1", "SECP384R1", "SECP521R1", "WEI25519", "BRAINPOOLP256R1", "SECP256K1", "WEI448"])
 def test_scalar_mult_vs_reference_binary(gpu_ctx, curve):
-    """directly against the unmodified reference (prj_pt_mul + prj_pt_unique)"""
+    """directly against the unmodified reference (prj_pt_mul + prj_pt_unique), no restatement in between: fixed base and
+    variable base, edge and random scalars, 2048 items each way"""
+    from bench import host_cores
     rng = np.random.default_rng(7)
     cv = gpu_ctx.curve(curve)
     r = RefLib(curve)
+    nt = host_cores()
     try:
-        sc = edge_scalars(curve, r.qlen) + rand_bytes(rng, r.qlen * 15)
-        assert cv.scalar_mult(sc) == r.scalar_mult(sc)
+        sc = edge_scalars(curve, r.qlen) + rand_bytes(rng, r.qlen * 2031)
+        got = cv.scalar_mult(sc)
+        assert got == r.scalar_mult(sc, None, r.qlen, nthreads=nt)
+        pl = 2 * r.clen
+        pts = b"".join(got[0][i * pl:(i + 1) * pl] for i in range(len(got[1])) if got[1][i] == 0)
+        npts = len(pts) // pl
+        sc2 = (edge_scalars(curve, r.qlen) * 3 + rand_bytes(rng, r.qlen * npts))[:r.qlen * npts]
+        assert cv.scalar_mult(sc2, pts) == r.scalar_mult(sc2, pts, r.qlen, nthreads=nt)
     finally:
         cv.free()
 
@@ -515,9 +538,11 @@ def test_ecccdh_derive_golden_and_oracle(gpu_ctx, curve):
     cv = gpu_ctx.curve(curve)
     o = Oracle(curve)
     try:
-        d = b"".join(bytes.fromhex(k["our_priv_key"]) for k in kats)
-        if len(d) // len(kats) != cv.qlen:
-            pytest.skip("vector private keys are not qlen bytes")
+        # the vectors of secp521r1 carry their private keys on 68 bytes (two leading zero bytes): nn_init_from_buf takes any
+        # length, the batch entry point takes BYTECEIL(|q|) = 66 bytes
+        ds = [bytes.fromhex(k["our_priv_key"]) for k in kats]
+        assert all(len(x) >= cv.qlen and not any(x[:len(x) - cv.qlen]) for x in ds)
+        d = b"".join(x[len(x) - cv.qlen:] for x in ds)
         peers = bytearray(b"".join(bytes.fromhex(k["peer_pub_key"]) for k in kats))
         sec, st = cv.ecccdh(d, bytes(peers))
         assert set(st) == {0}
@@ -1147,17 +1172,41 @@ def test_eddsa25519_sign_steps(gpu_ctx):
         cv.free()
 
 
-def test_libecc_glue_demo():
-    """examples/libecc_glue_demo.c -- the struct-array binding a libecc application would add, linked to
-    the UNMODIFIED libecc (prebuilt in the authoring container as oracle/_ref/glue_demo): libecc's own nn /
-    prj_pt / ec_pub_key objects in, GPU batch, results compared with libecc's prj_pt_mul and ec_verify"""
+LIBDIR = os.path.join(os.path.dirname(GOLDEN), "..", "libecc_amd", "lib")
+
+
+def test_libecc_typed_boundary_vs_scalar_api():
+    """include/libecc_amd_compat.h through libsign_amd.so, driven by a libecc application (libecc_amd/compat/compat_check.c):
+    prj_pt_mul_batch(prj_pt[], nn[], prj_pt[]), ecccdh_derive_secret_batch and ec_verify_batch -- called with const u8 **,
+    const ec_pub_key ** arrays exactly as tests/ec_self_tests_core.c:373-383, 556-616 call it -- for ECDSA, DECDSA and the
+    five EdDSA variants, every result compared with libecc's own scalar prj_pt_mul / ecccdh_derive_secret / ec_verify
+    (the CPU code of the libecc the library was linked from) on the same structures"""
     import subprocess
-    exe = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "glue_demo")
+    exe = os.path.join(LIBDIR, "compat_check")
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/glue_demo not built (needs the reference sources at build time)")
-    r = subprocess.run([exe, "384"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert "384 items, 0 mismatches" in r.stdout and "64 items, 0 mismatches" in r.stdout
+        pytest.skip("libecc_amd/lib/compat_check not built (needs the libecc sources at build time)")
+    r = subprocess.run([exe, "640"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert "compat_check: all ok" in r.stdout
+    assert r.stdout.count(": ok") >= 19 and "FAILED" not in r.stdout and "MISMATCH" not in r.stdout
+    sent = int(r.stdout.split("items sent to the GPU:")[1].split()[0])
+    assert sent >= 640 * 20, sent          # the batch forms did run on the GPU (there is no CPU fallback to hide behind)
+
+
+def test_libecc_self_tests_against_libsign_amd():
+    """The drop-in check SURVEY.md section 8b names: libecc's OWN self-test program (tests/ec_self_tests.c, unmodified),
+    linked against libsign_amd.so instead of libsign.so.  `vectors` runs every known-answer test of the snapshot; each
+    signature case also calls ec_verify_batch (batch of 1) when is_verify_batch_mode_supported says so -- EdDSA, and with
+    this library ECDSA / DECDSA -- and those calls run on the GPU."""
+    import subprocess
+    exe = os.path.join(LIBDIR, "ec_self_tests_amd")
+    if not os.path.exists(exe):
+        pytest.skip("libecc_amd/lib/ec_self_tests_amd not built (needs the libecc sources at build time)")
+    r = subprocess.run([exe, "vectors"], capture_output=True, text=True, timeout=1500)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-4000:]
+    assert "[-]" not in out and "failed" not in out, out[-4000:]
+    assert out.count("[+]") >= 200, out[-2000:]     # 256 cases in this snapshot (the plain-Ed25519 vector file is absent)
 
 
 def test_eddsa25519_zero_challenge(gpu_ctx):
