@@ -274,6 +274,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)   # the first launches after the setup run at ramping clocks (profiles/r1f_bench_kernels.md)
     ap.add_argument("--batch-log2", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ubench-json", default=None, help="also write the raw micro-benchmark output (instruction rates, sustained clock) here")
     ap.add_argument("--parity-items", type=int, default=1 << 16, help="random items of the batch checked against the CPU reference before timing")
     ap.add_argument("--curve", default=CURVE, help="ad-hoc runs on another built-in curve (the driver uses the default)")
     args = ap.parse_args()
@@ -472,7 +473,22 @@ def main():
         }
         if ub:
             line["ubench"] = {k: (v["cycles_per_wave_instr_per_simd"] if isinstance(v, dict) else v)
-                              for k, v in ub.items() if k.startswith("v_")}
+                              for k, v in ub.items() if k.startswith("v_") or k.startswith("mix_")}
+            sclk = ub.get("v_mad_u64_u32", {}).get("sustained_sclk_mhz", 0.0)
+            if sclk and abs(sclk - ub.get("wall_clock_khz", 0) / 1e3) > 1.0:      # the two counters do tick differently
+                # two views of the same ceiling: the measured v_mad_u64_u32 stream, and 1024 SIMDs x 16 lane-MADs per clock
+                # at the shader clock the part sustained under that stream
+                line["ubench"]["sustained_sclk_mhz"] = {k: v.get("sustained_sclk_mhz") for k, v in ub.items() if isinstance(v, dict)}
+                line["ubench"]["cycles_at_sustained_clock"] = {k: v.get("cycles_at_sustained_clock") for k, v in ub.items() if isinstance(v, dict)}
+                ana = ub.get("analytic_mad_peak_at_sustained_clock")
+                if ana:
+                    line["roofline"]["peak_analytic_at_sustained_clock"] = ana / 1e9
+                    line["roofline"]["frac_of_analytic_peak"] = mad_rate / ana
+            if args.ubench_json:
+                try:
+                    json.dump(ub, open(args.ubench_json, "w"), indent=1)
+                except OSError:
+                    pass
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(curve, scalars_h, pts_h, slen)
         else:

@@ -59,6 +59,14 @@ const char *ecamd_last_error(void);
 /* Upper bound on the items processed per kernel launch (bounds the per-lane window-table
  * scratch: 16 * 3 * 4*ceil(|p|/32) bytes per item).  Default 2^20. */
 int ecamd_ctx_set_max_chunk(ecamd_ctx *ctx, uint32_t max_items);
+/* Secret scalars.  By default the kernels index their window / comb tables with the scalar's digits (fastest; fine for public
+ * scalars: verification, public-key checks).  With this switch on, every scalar multiplication issued through the context --
+ * ec_prj_pt_mul_batch*, and inside ec_ecdsa_sign_batch, ec_ecccdh_derive_batch, ec_eddsa_sign_R_batch, key-pair import -- runs on
+ * the complete-formula kernel with constant-address table look-ups (every entry read, the wanted one kept by masking: the posture
+ * of the reference's masked ladder, curves/prj_pt.c:1225-1260, and nn_tabselect, nn/nn.c:564), a fixed window count and no
+ * scalar-dependent kernel choice.  Results are identical; the cost is the difference between the two kernels.
+ * X25519 / X448 ladders are address-independent in either mode. */
+int ecamd_ctx_set_secret_scalars(ecamd_ctx *ctx, int on);
 /* Measurement hook: when enabled, HIP events are recorded (on the stream the kernels run on) around
  * the kernels of the next ec_prj_pt_mul_batch[_dev] call; ecamd_ctx_kernel_times() waits for them and
  * returns the 4 durations in ms: table, table->affine, window loop, finalisation (the generic
@@ -97,6 +105,13 @@ int ecamd_curve_words(const ecamd_curve *curve);     /* 32-bit words per field e
 int ec_prj_pt_mul_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n,
 			const uint8_t *scalars, uint32_t scalar_len, const uint8_t *points_aff,
 			uint8_t *out_aff, uint8_t *status);
+/* Batch form of prj_pt_mul_blind (curves/prj_pt.c:1782-1822): per item the scalar actually multiplied is m + b * #E (#E = the curve
+ * order, cofactor included), b = blinds + i*blind_len big-endian, supplied by the caller (the reference draws b at random in
+ * [1, #E); randomness stays on the host here, as for nonces).  Since [#E]P is the point at infinity the result equals
+ * ec_prj_pt_mul_batch's; what changes is the scalar the device walks through -- about 2 |q| bits, which on secp256r1 still runs on
+ * the radix-2^29 window kernel.  status ECAMD_ERR also where b = 0 or b >= #E. */
+int ec_prj_pt_mul_blind_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *scalars, uint32_t scalar_len,
+			      const uint8_t *blinds, uint32_t blind_len, const uint8_t *points_aff, uint8_t *out_aff, uint8_t *status);
 /* Device-pointer form: all four buffers already live in HBM; the kernel is enqueued on
  * hip_stream (a hipStream_t, NULL = the context's stream) and the call returns without
  * synchronising. */
@@ -147,7 +162,7 @@ int ec_ecdsa_verify_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t
  * (sig/ecdsa_common.c:318-586) -- kG = prj_pt_mul(k, G), r = kG.x mod q, s = k^-1 (x r + e) mod q --
  * with h = H(m) and the nonce k supplied by the caller (random, or RFC 6979 computed on the host;
  * the reference's KAT harness injects k through the same ctx->rand hook).  privs, nonces: n x qlen;
- * sigs: n x 2*qlen.  status[i] = 1 where the reference would fail or restart (k not in [1, q-1],
+ * sigs: n x 2*qlen.  status[i] = 1 where the reference would fail or restart (private key >= q, k not in [1, q-1],
  * r = 0, e == x r, s = 0). */
 int ec_ecdsa_sign_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *privs,
 			const uint8_t *nonces, const uint8_t *digests, uint32_t digest_len, uint8_t *sigs,
@@ -233,6 +248,29 @@ int ec_prj_pt_unique_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n,
  * imports it; it has no affine form).  Built-in curves only (a user curve has no ec_curve_type). */
 int ec_structured_pub_key_import_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *keys,
 				       uint32_t key_len, int alg_type, uint8_t *out_aff, uint8_t *status);
+
+/* Point decompression.  ec_aff_pt_y_from_x_batch is the batch form of aff_pt_y_from_x (curves/aff_pt.c:102): x n x clen big-endian ->
+ * the two roots y1, y2 (n x clen each) of x^3 + a x + b IN THE REFERENCE'S ORDER -- y1 is the root its fp_sqrt (fp/fp_sqrt.c:107,
+ * Tonelli-Shanks with the smallest non-residue) returns first, y2 = p - y1 (both 0 when the right-hand side is 0); status 1 where
+ * the reference returns -1 (x >= p, not a square).  ec_point_decompress_batch takes SEC 1 compressed points (n x (1 + clen): 0x02 /
+ * 0x03, then x) and writes the affine X || Y whose y has the parity the prefix asks for -- the format the other entry points take. */
+int ec_aff_pt_y_from_x_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *x, uint8_t *y1, uint8_t *y2,
+			     uint8_t *status);
+int ec_point_decompress_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *compressed, uint8_t *out_aff,
+			      uint8_t *status);
+/* Structured signatures (ec_structured_sig_import_from_buf, sig/sig_algs.c:702: 3 bytes -- ec_alg_type, hash_alg_type, ec_curve_type --
+ * in front of the raw signature): checks the three bytes against what the caller expects and the handle's curve, strips them
+ * (raw_sigs: n x (structured_len - 3)); host-side framing, no device work.  Built-in curves only. */
+int ec_structured_sig_import_batch(const ecamd_curve *curve, uint32_t n, const uint8_t *structured, uint32_t structured_len,
+				   int alg_type, int hash_type, uint8_t *raw_sigs, uint8_t *status);
+/* Structured private keys -> key pairs, batch form of ec_structured_key_pair_import_from_priv_key_buf (sig/ec_key.c:443) for the
+ * algorithms whose public key is Y = xG (ECDSA, DECDSA: __ecdsa_init_pub_key, sig/ecdsa_common.c:172): each key is EC_PRIVKEY (1),
+ * the ec_alg_type, the ec_curve_type, then the private scalar (key_len - 3 bytes, any length).  Header and x < q checked;
+ * priv_out (may be NULL): n x qlen, the scalar as the signing entry points take it; pub_prj_out: n x 3*clen, Y = [x]G as
+ * X || Y || 1 (the format of ec_pub_key_export_to_buf and of ec_ecdsa_verify_batch_fmt).  status ECAMD_ERR where libecc
+ * returns -1, ECAMD_INF for x = 0 (libecc's key at infinity). */
+int ec_structured_key_pair_import_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *priv_keys,
+					uint32_t key_len, int alg_type, uint8_t *priv_out, uint8_t *pub_prj_out, uint8_t *status);
 
 /* Device-pointer forms of the verification / key-agreement entry points, for callers whose batches
  * already live in HBM (and for sharding a batch over GPUs, one context per device): same semantics and

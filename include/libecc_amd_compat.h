@@ -43,6 +43,10 @@ unsigned long long ecamd_compat_gpu_items(void);
  */
 int prj_pt_mul_batch(prj_pt *out, const nn *m, const prj_pt *in, u32 n, int *ret_items);
 
+/* Batch form of prj_pt_mul_blind (curves/prj_pt.h:62, curves/prj_pt.c:1782): per item a fresh b in [1, #E) from libecc's own
+ * nn_get_random_mod, and the device multiplies by m + b * #E (on secp256r1 still on the fast window kernel). */
+int prj_pt_mul_blind_batch(prj_pt *out, const nn *m, const prj_pt *in, u32 n, int *ret_items);
+
 /*
  * Batch form of ecccdh_derive_secret (ecdh/ecccdh.h:57, ecdh/ecccdh.c:167): item i derives
  * shared_secrets[i] (shared_secret_len bytes, = ecccdh_shared_secret_size) from our_priv_keys[i] and the serialised

@@ -9,11 +9,12 @@ FP_MUL_MONTY, FP_ADD, FP_SUB, FP_MUL, FP_INV = 0, 1, 2, 3, 4
 # every symbol include/libecc_amd.h declares (tests check the .so exports exactly these)
 EXPORTED_SYMBOLS = [
     "ecamd_device_count", "ecamd_ctx_create", "ecamd_ctx_destroy", "ecamd_last_error",
-    "ecamd_ctx_set_max_chunk", "ecamd_ctx_enable_kernel_timing", "ecamd_ctx_kernel_times", "ecamd_curve_by_name", "ecamd_curve_from_params", "ecamd_curve_free",
-    "ecamd_curve_coord_len", "ecamd_curve_order_len", "ecamd_curve_words", "ec_prj_pt_mul_batch",
+    "ecamd_ctx_set_max_chunk", "ecamd_ctx_set_secret_scalars", "ecamd_ctx_enable_kernel_timing", "ecamd_ctx_kernel_times", "ecamd_curve_by_name", "ecamd_curve_from_params", "ecamd_curve_free",
+    "ecamd_curve_coord_len", "ecamd_curve_order_len", "ecamd_curve_words", "ec_prj_pt_mul_batch", "ec_prj_pt_mul_blind_batch",
     "ec_prj_pt_mul_batch_dev", "ecamd_ctx_synchronize", "ec_prj_pt_add_batch", "ec_prj_pt_dbl_batch",
     "ec_fp_op_batch", "ec_ecdsa_verify_batch", "ec_ecdsa_verify_batch_fmt", "ec_ecdsa_sign_batch", "ec_ecccdh_derive_batch", "ec_xdh_batch",
     "ec_prj_pt_mul_batch_fmt", "ec_prj_pt_unique_batch", "ec_structured_pub_key_import_batch",
+    "ec_aff_pt_y_from_x_batch", "ec_point_decompress_batch", "ec_structured_sig_import_batch", "ec_structured_key_pair_import_batch",
     "ec_eddsa_verify_batch", "ec_eddsa_verify_all_batch", "ec_ecdsa_verify_batch_dev", "ec_eddsa_verify_batch_dev", "ec_xdh_batch_dev",
     "ec_ecdsa_sign_batch_dev", "ec_ecccdh_derive_batch_dev", "ec_eddsa_sign_R_batch", "ec_eddsa_sign_S_batch",
     "ecamd_multi_create", "ecamd_multi_destroy", "ecamd_multi_size", "ecamd_multi_device", "ecamd_multi_ctx",
@@ -52,6 +53,7 @@ def load_library():
         L.ecamd_ctx_destroy.argtypes = [vp]
         L.ecamd_ctx_destroy.restype = None
         L.ecamd_ctx_set_max_chunk.argtypes = [vp, u32]
+        L.ecamd_ctx_set_secret_scalars.argtypes = [vp, C.c_int]
         L.ecamd_ctx_synchronize.argtypes = [vp]
         L.ecamd_ctx_enable_kernel_timing.argtypes = [vp, C.c_int]
         L.ecamd_ctx_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
@@ -62,6 +64,7 @@ def load_library():
         for f in ("ecamd_curve_coord_len", "ecamd_curve_order_len", "ecamd_curve_words"):
             getattr(L, f).argtypes = [vp]
         L.ec_prj_pt_mul_batch.argtypes = [vp, vp, u32, u8p, u32, u8p, u8p, u8p]
+        L.ec_prj_pt_mul_blind_batch.argtypes = [vp, vp, u32, u8p, u32, u8p, u32, u8p, u8p, u8p]
         L.ec_prj_pt_mul_batch_dev.argtypes = [vp, vp, u32, vp, u32, vp, vp, vp, vp]
         L.ec_prj_pt_add_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
         L.ec_prj_pt_dbl_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p]
@@ -75,6 +78,10 @@ def load_library():
         L.ec_prj_pt_mul_batch_fmt.argtypes = [vp, vp, u32, u8p, u32, u8p, C.c_int, u8p, C.c_int, u8p]
         L.ec_prj_pt_unique_batch.argtypes = [vp, vp, u32, u8p, C.c_int, u8p, C.c_int, u8p]
         L.ec_structured_pub_key_import_batch.argtypes = [vp, vp, u32, u8p, u32, C.c_int, u8p, u8p]
+        L.ec_aff_pt_y_from_x_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
+        L.ec_point_decompress_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p]
+        L.ec_structured_sig_import_batch.argtypes = [vp, u32, u8p, u32, C.c_int, C.c_int, u8p, u8p]
+        L.ec_structured_key_pair_import_batch.argtypes = [vp, vp, u32, u8p, u32, C.c_int, u8p, u8p, u8p]
         L.ec_ecdsa_verify_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp]
         L.ec_eddsa_verify_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp]
         L.ec_eddsa_sign_R_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p]
@@ -136,6 +143,9 @@ class Context:
     def set_max_chunk(self, n):
         _chk(self.L, self.L.ecamd_ctx_set_max_chunk(self.h, n), "ecamd_ctx_set_max_chunk")
 
+    def set_secret_scalars(self, on=True):
+        _chk(self.L, self.L.ecamd_ctx_set_secret_scalars(self.h, 1 if on else 0), "ecamd_ctx_set_secret_scalars")
+
     def enable_kernel_timing(self, on=True):
         _chk(self.L, self.L.ecamd_ctx_enable_kernel_timing(self.h, 1 if on else 0), "ecamd_ctx_enable_kernel_timing")
 
@@ -187,6 +197,15 @@ class Curve:
         st = C.create_string_buffer(max(1, n))
         _chk(self.L, self.L.ec_prj_pt_mul_batch(self.ctx.h, self.h, n, scalars, slen, points, out, st),
              "ec_prj_pt_mul_batch")
+        return out.raw[:2 * self.clen * n], st.raw[:n]
+
+    def scalar_mult_blind(self, scalars, blinds, points=None, slen=None, blen=None):
+        """prj_pt_mul_blind: the device multiplies by m + b #E"""
+        slen, blen = slen or self.qlen, blen or self.qlen
+        n = len(scalars) // slen
+        out, st = C.create_string_buffer(max(1, 2 * self.clen * n)), C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_prj_pt_mul_blind_batch(self.ctx.h, self.h, n, scalars, slen, blinds, blen, points, out, st),
+             "ec_prj_pt_mul_blind_batch")
         return out.raw[:2 * self.clen * n], st.raw[:n]
 
     # -- batched prj_pt_mul, device pointers (e.g. torch tensors' data_ptr()), asynchronous --
@@ -329,6 +348,37 @@ class Curve:
         _chk(self.L, self.L.ec_prj_pt_unique_batch(self.ctx.h, self.h, n, points, in_fmt, out, out_fmt, st),
              "ec_prj_pt_unique_batch")
         return out.raw[:w * n], st.raw[:n]
+
+    def y_from_x(self, xs):
+        """aff_pt_y_from_x: (y1, y2, status), y1 the root the reference's fp_sqrt returns first"""
+        n = len(xs) // self.clen
+        y1, y2 = C.create_string_buffer(max(1, self.clen * n)), C.create_string_buffer(max(1, self.clen * n))
+        st = C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_aff_pt_y_from_x_batch(self.ctx.h, self.h, n, xs, y1, y2, st), "ec_aff_pt_y_from_x_batch")
+        return y1.raw[:self.clen * n], y2.raw[:self.clen * n], st.raw[:n]
+
+    def decompress(self, comp):
+        """SEC 1 compressed points (0x02 / 0x03 || x) -> affine X || Y + status"""
+        n = len(comp) // (self.clen + 1)
+        out, st = C.create_string_buffer(max(1, 2 * self.clen * n)), C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_point_decompress_batch(self.ctx.h, self.h, n, comp, out, st), "ec_point_decompress_batch")
+        return out.raw[:2 * self.clen * n], st.raw[:n]
+
+    def structured_sigs(self, sigs, slen, alg_type, hash_type):
+        n = len(sigs) // slen
+        out, st = C.create_string_buffer(max(1, (slen - 3) * n)), C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_structured_sig_import_batch(self.h, n, sigs, slen, alg_type, hash_type, out, st),
+             "ec_structured_sig_import_batch")
+        return out.raw[:(slen - 3) * n], st.raw[:n]
+
+    def structured_key_pairs(self, keys, klen, alg_type):
+        """structured private keys -> (private scalars n x qlen, public keys X || Y || Z, status)"""
+        n = len(keys) // klen
+        pv, pb, st = (C.create_string_buffer(max(1, self.qlen * n)), C.create_string_buffer(max(1, 3 * self.clen * n)),
+                      C.create_string_buffer(max(1, n)))
+        _chk(self.L, self.L.ec_structured_key_pair_import_batch(self.ctx.h, self.h, n, keys, klen, alg_type, pv, pb, st),
+             "ec_structured_key_pair_import_batch")
+        return pv.raw[:self.qlen * n], pb.raw[:3 * self.clen * n], st.raw[:n]
 
     def structured_pub_keys(self, keys, alg_type):
         """libecc's structured public keys (3 header bytes + X || Y || Z) -> affine X || Y + status"""

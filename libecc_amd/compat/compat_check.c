@@ -27,7 +27,7 @@ static int load_params(const char *name, ec_params *params)
 }
 
 /* ---- prj_pt_mul_batch against prj_pt_mul ---- */
-static void check_mul(const char *curve, u32 n)
+static void check_mul(const char *curve, u32 n, int blind)
 {
 	ec_params params;
 	prj_pt *in = calloc(n, sizeof(prj_pt)), *out = calloc(n, sizeof(prj_pt));
@@ -67,8 +67,8 @@ static void check_mul(const char *curve, u32 n)
 		/* a point that is not on the curve: Y + 1 */
 		fp_inc(&in[11].Y, &in[11].Y);
 	}
-	if (prj_pt_mul_batch(out, m, in, n, rets)) {
-		CHECK(0, "%s: prj_pt_mul_batch failed", curve);
+	if (blind ? prj_pt_mul_blind_batch(out, m, in, n, rets) : prj_pt_mul_batch(out, m, in, n, rets)) {
+		CHECK(0, "%s: prj_pt_mul%s_batch failed", curve, blind ? "_blind" : "");
 		return;
 	}
 	for (i = 0; i < n; i++) {
@@ -97,7 +97,7 @@ static void check_mul(const char *curve, u32 n)
 			CHECK(0, "%s: item %u differs from prj_pt_mul", curve, i);
 		}
 	}
-	printf("prj_pt_mul_batch %-16s %u items, %u errors, %u at infinity: %s\n", curve, n, nerr, ninf, failures == before ? "ok" : "FAILED");
+	printf("prj_pt_mul%s_batch %-16s %u items, %u errors, %u at infinity: %s\n", blind ? "_blind" : "", curve, n, nerr, ninf, failures == before ? "ok" : "FAILED");
 	(void)bad;
 	free(in); free(out); free(m); free(rets);
 }
@@ -326,11 +326,14 @@ int main(int argc, char **argv)
 		printf("no GPU path\n");
 		return 3;
 	}
-	check_mul("SECP256R1", n);
-	check_mul("SECP384R1", n);
-	check_mul("SECP521R1", n);
-	check_mul("BRAINPOOLP256R1", n);
-	check_mul("WEI25519", n);
+	check_mul("SECP256R1", n, 0);
+	check_mul("SECP384R1", n, 0);
+	check_mul("SECP521R1", n, 0);
+	check_mul("BRAINPOOLP256R1", n, 0);
+	check_mul("WEI25519", n, 0);
+	check_mul("SECP256R1", n, 1);
+	check_mul("SECP384R1", n < 128 ? n : 128, 1);
+	check_mul("WEI25519", n < 128 ? n : 128, 1);
 	check_cdh("SECP256R1", n);
 	check_cdh("SECP384R1", n);
 	check_cdh("WEI25519", n);

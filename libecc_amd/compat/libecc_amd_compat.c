@@ -348,7 +348,68 @@ static void mul_import(u32 lo, u32 hi, void *arg)
 	}
 }
 
+static int mul_batch_common(prj_pt *out, const nn *m, const prj_pt *in, u32 n, int *ret_items);
+
 int prj_pt_mul_batch(prj_pt *out, const nn *m, const prj_pt *in, u32 n, int *ret_items)
+{
+	return mul_batch_common(out, m, in, n, ret_items);
+}
+
+typedef struct {
+	const nn *m;
+	nn *mb;
+	nn_src_t order;
+	int failed;
+} blind_job;
+
+static void blind_scalars(u32 lo, u32 hi, void *arg)
+{
+	blind_job *B = (blind_job *)arg;
+	u32 i;
+	for (i = lo; i < hi; i++) {
+		/* the scalar arithmetic of prj_pt_mul_blind (curves/prj_pt.c:1795-1806), done by the application's own libecc:
+		 * b random in [1, #E), scalar = m + b * #E */
+		nn b;
+		b.magic = WORD(0);
+		if (nn_get_random_mod(&b, B->order) || nn_mul(&b, &b, B->order) || nn_add(&B->mb[i], &B->m[i], &b)) {
+			B->failed = 1;
+		}
+		nn_uninit(&b);
+	}
+}
+
+int prj_pt_mul_blind_batch(prj_pt *out, const nn *m, const prj_pt *in, u32 n, int *ret_items)
+{
+	blind_job B;
+	int ret;
+	if (!out || !m || !in) {
+		return -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	if (prj_pt_check_initialized(&in[0])) {
+		return -1;
+	}
+	B.m = m;
+	B.order = &(in[0].crv->order);
+	B.failed = 0;
+	B.mb = (nn *)calloc(n, sizeof(nn));
+	if (!B.mb) {
+		return -1;
+	}
+	if (ecamd_compat_init(NULL, 0, 0)) {
+		free(B.mb);
+		return -1;
+	}
+	parallel_for(n, blind_scalars, &B);
+	ret = B.failed ? -1 : mul_batch_common(out, B.mb, in, n, ret_items);
+	memset(B.mb, 0, (size_t)n * sizeof(nn));
+	free(B.mb);
+	return ret;
+}
+
+static int mul_batch_common(prj_pt *out, const nn *m, const prj_pt *in, u32 n, int *ret_items)
 {
 	mul_job J;
 	curve_ent *e;

@@ -639,6 +639,7 @@ struct DecXY {
 	FA x;      // the selected root (or its negation), class FA
 	FM ym;
 	bool ok;
+	bool neutral;   // the encoding of (0, 1): the reference maps it to the point at infinity (see ed_decode_xy in ecamd_kernels.hip)
 };
 static __device__ __forceinline__ DecXY decode_xy(const EcamdEdDecodeArgs &A, const u8 *src, const CK &K)
 {
@@ -677,7 +678,8 @@ static __device__ __forceinline__ DecXY decode_xy(const EcamdEdDecodeArgs &A, co
 	for (int w = 0; w < 9; w++) {
 		nz |= xd[w];
 	}
-	ok = ok & (nz != 0);  // x = 0: the neutral point is rejected, (0, -1) dies in fp_inv(0)
+	R.neutral = ok & (nz == 0) & (x0 == 0) & (yw[0] == 1u) & ((yw[1] | yw[2] | yw[3] | yw[4] | yw[5] | yw[6] | yw[7]) == 0u);
+	ok = ok & (nz != 0);  // x = 0: (0, 1) is the neutral element (flagged above), (0, -1) dies in fp_inv(0)
 	R.x = selg((xd[0] & 1u) != x0, neg<PB>(xs, K), weaken<FA>(xs));
 	R.ym = ym;
 	R.ok = ok;
@@ -722,7 +724,7 @@ __global__ __launch_bounds__(64) void k_ed_decode_c25519(EcamdEdDecodeArgs A, in
 		u8 *pd = (k == 0 ? A.pointsA : A.pointsR) + (size_t)i * 64;
 		store_canon_be(pd, Xm, good, K);
 		store_canon_be(pd + 32, vm, good, K);
-		(k == 0 ? A.flagsA : A.flagsR)[i] = good ? 0 : 1;
+		(k == 0 ? A.flagsA : A.flagsR)[i] = good ? 0 : ((k == 1 && P[1].neutral) ? 2 : 1);   // 2: R is the point at infinity
 		if (k == 0 && A.edA != nullptr) {
 			// the key on the Edwards curve itself (canonical digits), for k_ed_smul_c25519
 			u32 buf[20];

@@ -230,6 +230,7 @@ struct ecamd_ctx {
 	uint8_t *hbuf[2][6];       // double-buffered device staging of the caller's arrays (inputs and outputs)
 	size_t hbuf_bytes[2][6];
 	uint32_t comb_min_batch;   // fixed-base batches of at least this many items build / use the generator's comb table (0: never)
+	bool secret_scalars;       // ecamd_ctx_set_secret_scalars: constant-address look-ups, no data-dependent kernel choice
 	bool timing;               // record HIP events around the kernels of the scalar-mult pipeline
 	hipEvent_t ev[ECAMD_NTIMED + 1];
 	bool ev_valid;  // radix-2^29 constant slots, indexed by |p| in bits
@@ -264,6 +265,8 @@ struct ecamd_curve {
 	EcamdXdhPrepArgs xdh_tmpl;
 	uint32_t xdh_A3[17];
 	uint8_t xdh_cof;
+	int sqrt_state;  // Tonelli-Shanks constants of fp_sqrt for this field: 0 not yet, 1 ready (ctx->mu held)
+	EcamdYfromXArgs sqrt_tmpl;
 	bool is_p256;    // exactly secp256r1: hand-specialised radix-2^29 Jacobian kernel
 	int gslot;       // constant slot of the generic radix-2^29 Jacobian kernel (-1: none)
 	int gflavour;    // 0 dense reduction, 1 secp521r1 (p = 2^521 - 1), 2 p = 2^255 - 19, 3 p = -1 mod 2^29 at 384 bits, 4 secp256k1's prime, 5 p = 2^448 - 2^224 - 1
@@ -336,6 +339,7 @@ extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
 		return fail("ecamd_ctx_create: hipEventCreate failed");
 	}
 	c->timing = false;
+	c->secret_scalars = false;
 	c->ev_valid = false;
 	for (int i = 0; i <= ECAMD_NTIMED; i++) {
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) {
@@ -408,6 +412,16 @@ extern "C" int ecamd_ctx_set_max_chunk(ecamd_ctx *c, uint32_t max_items)
 		return fail("ecamd_ctx_set_max_chunk: bad argument");
 	}
 	c->max_chunk = max_items;
+	return 0;
+}
+
+extern "C" int ecamd_ctx_set_secret_scalars(ecamd_ctx *c, int on)
+{
+	if (!c) {
+		return fail("ecamd_ctx_set_secret_scalars: NULL context");
+	}
+	std::lock_guard<std::mutex> lk(c->mu);
+	c->secret_scalars = on != 0;
 	return 0;
 }
 
@@ -891,6 +905,7 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	cv->d_gtab = nullptr;
 	cv->d_comb = nullptr;
 	cv->comb_off = false;
+	cv->sqrt_state = 0;
 	cv->ed_state = 0;
 	cv->ed448_state = 0;
 	cv->ed448_err = nullptr;
@@ -1093,10 +1108,16 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 	}
 	const uint32_t chunk = n < ctx->max_chunk ? n : ctx->max_chunk;
 	const uint32_t stride = (chunk + 63u) & ~63u;
-	const bool fast256 = cv->is_p256 && slen <= 32;
-	const bool fastg = !fast256 && cv->gslot >= 0 && slen <= ecamd_g29_max_slen(cv->pbits);
+	// secp256r1: the window loop takes scalars of up to 68 bytes (blinded scalars m + b #E of about 2 |q| bits stay on the fast
+	// kernel); the fixed-base comb covers the 32-byte ones
+	// secret-scalar mode: every item goes through the complete-formula kernel with masked full-table look-ups -- no digit-indexed
+	// address (window or comb table), no exceptional-pair detour whose occurrence depends on the scalar
+	const bool secret = ctx->secret_scalars;
+	const bool fast256 = !secret && cv->is_p256 && slen <= 68;
+	const bool comb_ok = !cv->is_p256 || slen <= 32;
+	const bool fastg = !secret && !fast256 && cv->gslot >= 0 && slen <= ecamd_g29_max_slen(cv->pbits);
 	const bool fast = fast256 || fastg;
-	if (fast && !d_points) {
+	if (fast && !d_points && comb_ok) {
 		maybe_build_comb(ctx, const_cast<ecamd_curve *>(cv), n);
 	}
 	{
@@ -1134,6 +1155,7 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 		A.only_redo = 0;
 		A.lut = nullptr;
 		A.lut_kind = 0;
+		A.masked = secret ? 1 : 0;
 		if (fast) {
 			// Jacobian fast path; lanes that met an exceptional pair come back as ECAMD_STATUS_REDO and
 			// are recomputed by the complete-formula kernel (all other lanes exit at once)
@@ -1141,8 +1163,9 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 			Fa.tbl = ctx->tbl_fast;
 			// fixed base: a constant table of the generator replaces the per-item table kernels
 			if (!d_points) {
-				Fa.lut = cv->d_comb ? cv->d_comb : (fast256 ? cv->d_gtab : nullptr);
-				Fa.lut_kind = cv->d_comb ? 1u : 0u;
+				const bool use_comb = cv->d_comb && comb_ok;
+				Fa.lut = use_comb ? cv->d_comb : (fast256 ? cv->d_gtab : nullptr);
+				Fa.lut_kind = use_comb ? 1u : 0u;
 			}
 			hipEvent_t *ev = (ctx->timing && off == 0) ? ctx->ev : nullptr;  // first chunk of the call
 			if (fast256) {
@@ -1282,6 +1305,58 @@ extern "C" int ec_prj_pt_mul_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
 		return smul_dev_locked(ctx, cv, m, ip[0], slen, ip[1], op[2], op[3], s);
+	});
+}
+
+// prj_pt_mul_blind in batch: the scalar multiplied is m + b #E (curves/prj_pt.c:1782-1822), b supplied by the caller
+extern "C" int ec_prj_pt_mul_blind_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *scalars, uint32_t slen,
+					 const uint8_t *blinds, uint32_t blen, const uint8_t *points, uint8_t *out, uint8_t *status)
+{
+	if (!ctx || !cv || cv->ctx != ctx || (n && (!scalars || !blinds || !out || !status))) {
+		return fail("ec_prj_pt_mul_blind_batch: bad argument");
+	}
+	if (slen == 0 || slen > 128 || blen == 0 || blen > 72) {
+		return fail("ec_prj_pt_mul_blind_batch: scalar_len must be in 1..128, blind_len in 1..72");
+	}
+	if (n == 0) {
+		return 0;
+	}
+	const uint32_t ow = (uint32_t)((big_bitlen(cv->order) + 31) / 32);
+	uint32_t outlen = blen + 4 * ow;
+	outlen = (outlen > slen ? outlen : slen) + 1;
+	if (ow > 18 || (outlen + 3) / 4 > 72) {
+		return fail("ec_prj_pt_mul_blind_batch: blinded scalar too long");
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t plen = (size_t)2 * cv->clen;
+	// stage: 12 blinded scalars, 13 "bad blind" flags (beside the host pipeline's own buffers)
+	const std::vector<HostArr> arrs = {{scalars, nullptr, slen}, {blinds, nullptr, blen}, {points, nullptr, plen}, {nullptr, out, plen}, {nullptr, status, 1}};
+	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op, hipStream_t s,
+					       const std::function<int()> &) {
+		if (ensure(&ctx->stage[12], &ctx->stage_bytes[12], (size_t)m * outlen) || ensure(&ctx->stage[13], &ctx->stage_bytes[13], m)) {
+			return -1;
+		}
+		EcamdBlindArgs B;
+		B.m = ip[0];
+		B.b = ip[1];
+		B.out = ctx->stage[12];
+		B.bad = ctx->stage[13];
+		B.n = m;
+		B.mlen = slen;
+		B.blen = blen;
+		B.outlen = outlen;
+		B.owords = ow;
+		for (uint32_t w = 0; w < 18; w++) {
+			B.order[w] = w < cv->order.size() ? cv->order[w] : 0u;
+		}
+		HIPCHK(ecamd_launch_blind_scalar(B, s));
+		if (smul_dev_locked(ctx, cv, m, ctx->stage[12], outlen, ip[2], op[3], op[4], s)) {
+			return -1;
+		}
+		// a blind outside [1, #E) is not something the reference would have drawn: report it as an error of the item
+		HIPCHK(ecamd_launch_status_or(op[4], ctx->stage[13], op[3], (uint32_t)plen, m, s));
+		return 0;
 	});
 }
 
@@ -2881,6 +2956,215 @@ extern "C" int ec_prj_pt_unique_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uin
 				      uint8_t *out, int out_fmt, uint8_t *status)
 {
 	return pt_fmt_batch("ec_prj_pt_unique_batch", ctx, cv, n, nullptr, 0, points, in_fmt, out, out_fmt, status, false);
+}
+
+// ------------------------------------------------------------------------------------------
+// point decompression: aff_pt_y_from_x (curves/aff_pt.c:102) / fp_sqrt (fp/fp_sqrt.c:107)
+// ------------------------------------------------------------------------------------------
+static int sqrt_setup(ecamd_curve *cv)
+{
+	if (cv->sqrt_state == 1) {
+		return 0;
+	}
+	const Big &p = cv->p;
+	const Big one(1, 1);
+	Big q = big_sub(p, one);
+	uint32_t s = 0;
+	while (!(q[0] & 1u)) {           // p - 1 = q 2^s
+		Big t(q.size(), 0);
+		for (size_t i = 0; i < q.size(); i++) {
+			t[i] = (q[i] >> 1) | ((i + 1 < q.size()) ? (q[i + 1] << 31) : 0u);
+		}
+		big_trim(t);
+		q = t;
+		s++;
+	}
+	// z: the smallest quadratic non-residue, found as fp_sqrt finds it (counting up from 0, fp/fp_sqrt.c:197-200)
+	Big half = big_sub(p, one);
+	{
+		Big t(half.size(), 0);
+		for (size_t i = 0; i < half.size(); i++) {
+			t[i] = (half[i] >> 1) | ((i + 1 < half.size()) ? (half[i + 1] << 31) : 0u);
+		}
+		big_trim(t);
+		half = t;
+	}
+	Big z(1, 2);
+	const Big pm1 = big_sub(p, one);
+	for (uint32_t zz = 2; zz < 100000; zz++) {
+		z = Big(1, zz);
+		if (big_cmp(big_powmod(z, half, p), pm1) == 0) {
+			break;
+		}
+	}
+	if (big_cmp(big_powmod(z, half, p), pm1) != 0) {
+		return fail("ec_aff_pt_y_from_x_batch: no small quadratic non-residue (is p prime?)");
+	}
+	EcamdYfromXArgs &T = cv->sqrt_tmpl;
+	memset(&T, 0, sizeof(T));
+	T.s = s;
+	Big e = big_sub(q, one);         // (q - 1) / 2
+	{
+		Big t(e.size(), 0);
+		for (size_t i = 0; i < e.size(); i++) {
+			t[i] = (e[i] >> 1) | ((i + 1 < e.size()) ? (e[i + 1] << 31) : 0u);
+		}
+		big_trim(t);
+		e = t;
+	}
+	T.ebits = (uint32_t)big_bitlen(e);
+	big_store(T.e, 17, e);
+	const Big R = big_mod(big_pow2(32 * cv->nw), p);
+	big_store(T.c, 17, big_mulmod(big_powmod(z, q, p), R, p));
+	T.clen = (uint32_t)cv->clen;
+	T.slot = cv->slot;
+	cv->sqrt_state = 1;
+	return 0;
+}
+
+static int y_from_x_common(const char *fn, ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const uint8_t *in, uint32_t in_stride,
+			   uint8_t *o1, uint8_t *o2, uint8_t *status, uint32_t mode)
+{
+	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
+	if (!ctx || !cv || cv->ctx != ctx || (n && (!in || !o1 || !status || (mode == 0 && !o2)))) {
+		return fail(std::string(fn) + ": bad argument");
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	if (sqrt_setup(cv)) {
+		return -1;
+	}
+	const size_t cl = (size_t)cv->clen;
+	const size_t need[4] = {(size_t)n * in_stride, (size_t)n * cl * (mode ? 2 : 1), (size_t)n * cl, n};
+	for (int i = 0; i < 4; i++) {
+		if (ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
+			return -1;
+		}
+	}
+	hipStream_t s = ctx->stream;
+	StreamScope scope(ctx, s);
+	uint8_t **S = ctx->stage;
+	HIPCHK(hipMemcpyAsync(S[0], in, need[0], hipMemcpyHostToDevice, s));
+	EcamdYfromXArgs A = cv->sqrt_tmpl;
+	A.x = S[0];
+	A.xstride = in_stride;
+	A.y1 = S[1];
+	A.y2 = S[2];
+	A.aff = S[1];
+	A.status = S[3];
+	A.n = n;
+	A.mode = mode;
+	HIPCHK(ecamd_launch_y_from_x(cv->nw, A, s));
+	HIPCHK(hipMemcpyAsync(o1, S[1], need[1], hipMemcpyDeviceToHost, s));
+	if (mode == 0) {
+		HIPCHK(hipMemcpyAsync(o2, S[2], need[2], hipMemcpyDeviceToHost, s));
+	}
+	HIPCHK(hipMemcpyAsync(status, S[3], n, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	return 0;
+}
+
+extern "C" int ec_aff_pt_y_from_x_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *x, uint8_t *y1, uint8_t *y2,
+					uint8_t *status)
+{
+	return y_from_x_common("ec_aff_pt_y_from_x_batch", ctx, cv, n, x, cv ? (uint32_t)cv->clen : 0, y1, y2, status, 0);
+}
+
+extern "C" int ec_point_decompress_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *compressed, uint8_t *out_aff,
+					 uint8_t *status)
+{
+	return y_from_x_common("ec_point_decompress_batch", ctx, cv, n, compressed, cv ? (uint32_t)cv->clen + 1 : 0, out_aff, nullptr, status, 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// structured signatures and private keys: 3 header bytes in front of the raw bytes (sig/sig_algs.c:702-780, sig/ec_key.c:312-360)
+// ------------------------------------------------------------------------------------------
+extern "C" int ec_structured_sig_import_batch(const ecamd_curve *cv, uint32_t n, const uint8_t *structured, uint32_t structured_len,
+					      int alg_type, int hash_type, uint8_t *raw_sigs, uint8_t *status)
+{
+	if (!cv || (n && (!structured || !raw_sigs || !status)) || structured_len <= 3 || structured_len > 3 + 255) {
+		return fail("ec_structured_sig_import_batch: bad argument");
+	}
+	if (cv->curve_type <= 0) {
+		return fail("ec_structured_sig_import_batch: the curve handle is not one of libecc's built-in curves");
+	}
+	const size_t raw = structured_len - 3;
+	for (uint32_t i = 0; i < n; i++) {
+		const uint8_t *k = structured + (size_t)i * structured_len;
+		// ec_structured_sig_import_from_buf hands the three bytes back; a caller then checks them against what it expects
+		// (tests/ec_utils.c:verify_bin_file): algorithm, hash, curve
+		const bool ok = k[0] == (uint8_t)alg_type && k[1] == (uint8_t)hash_type && k[2] == (uint8_t)cv->curve_type;
+		status[i] = ok ? 0 : 1;
+		if (ok) {
+			memcpy(raw_sigs + (size_t)i * raw, k + 3, raw);
+		} else {
+			memset(raw_sigs + (size_t)i * raw, 0, raw);
+		}
+	}
+	return 0;
+}
+
+// ec_structured_key_pair_import_from_priv_key_buf (sig/ec_key.c:443-470) for the algorithms whose public key is Y = xG
+// (ECDSA = 1, DECDSA = 14 in lib_ecc_types.h; __ecdsa_init_pub_key, sig/ecdsa_common.c:172-200): header EC_PRIVKEY (1), algorithm, curve;
+// x < q or error; Y = [x]G on the device (x = 0 gives the key at infinity, as the reference's prj_pt_mul_blind does).
+extern "C" int ec_structured_key_pair_import_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *priv_keys,
+						   uint32_t key_len, int alg_type, uint8_t *priv_out, uint8_t *pub_prj_out, uint8_t *status)
+{
+	if (!ctx || !cv || cv->ctx != ctx || (n && (!priv_keys || !pub_prj_out || !status))) {
+		return fail("ec_structured_key_pair_import_batch: bad argument");
+	}
+	if (cv->curve_type <= 0) {
+		return fail("ec_structured_key_pair_import_batch: the curve handle is not one of libecc's built-in curves");
+	}
+	const size_t ql = (size_t)cv->qlen, cl = (size_t)cv->clen;
+	if (key_len <= 3 || key_len > 3 + 255) {
+		return fail("ec_structured_key_pair_import_batch: key_len must be 3 + the private key length");
+	}
+	if (n == 0) {
+		return 0;
+	}
+	const size_t xl = key_len - 3;
+	std::vector<uint8_t> x((size_t)n * ql, 0), bad(n, 0), pts((size_t)n * 3 * cl), st(n);
+	for (uint32_t i = 0; i < n; i++) {
+		const uint8_t *k = priv_keys + (size_t)i * key_len;
+		bool ok = k[0] == 1 && k[1] == (uint8_t)alg_type && k[2] == (uint8_t)cv->curve_type;
+		const Big xv = big_from_be(k + 3, xl);       // nn_init_from_buf takes any length
+		ok = ok && big_cmp(xv, cv->q) < 0;           // "Sanity check on key compliance"
+		bad[i] = ok ? 0 : 1;
+		if (ok) {
+			big_to_be(&x[(size_t)i * ql], (int)ql, xv);
+		}
+		if (priv_out) {
+			if (ok) {
+				memcpy(priv_out + (size_t)i * ql, &x[(size_t)i * ql], ql);
+			} else {
+				memset(priv_out + (size_t)i * ql, 0, ql);
+			}
+		}
+	}
+	const int rc = ec_prj_pt_mul_batch_fmt(ctx, cv, n, x.data(), (uint32_t)ql, nullptr, ECAMD_PT_AFFINE, pts.data(), ECAMD_PT_PROJECTIVE, st.data());
+	std::fill(x.begin(), x.end(), 0);   // private scalars
+	if (rc) {
+		return -1;
+	}
+	for (uint32_t i = 0; i < n; i++) {
+		uint8_t *o = pub_prj_out + (size_t)i * 3 * cl;
+		if (bad[i] || st[i] == ECAMD_ERR) {
+			status[i] = ECAMD_ERR;
+			memset(o, 0, 3 * cl);
+		} else if (st[i] == ECAMD_INF) {
+			status[i] = ECAMD_INF;          // x = 0: the key is the point at infinity (0 : 1 : 0)
+			memset(o, 0, 3 * cl);
+			o[2 * cl - 1] = 1;
+		} else {
+			status[i] = ECAMD_OK;
+			memcpy(o, &pts[(size_t)i * 3 * cl], 3 * cl);
+		}
+	}
+	return 0;
 }
 
 // ------------------------------------------------------------------------------------------

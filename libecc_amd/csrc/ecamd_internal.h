@@ -23,6 +23,7 @@ struct EcamdSmulArgs {
 	int only_redo;           // generic kernel: process only items whose status is ECAMD_STATUS_REDO
 	const uint32_t *lut;     // secp256r1 fixed base: shared affine table of G (NULL: per-item tables)
 	uint32_t lut_kind;       // 0: window table [1..8]G (8 x 40 words), 1: 16-bit comb table of the generator
+	int masked;              // generic kernel: secret scalars -- constant-address (full-scan, masked) table look-ups
 };
 #define ECAMD_COMB_ENTRIES (16u * 32768u + 1u)
 
@@ -236,6 +237,34 @@ struct EcamdCdhArgs {
 };
 hipError_t ecamd_launch_cdh_gate(const EcamdCdhArgs &a, hipStream_t s);
 hipError_t ecamd_launch_cdh_fin(const EcamdCdhArgs &a, hipStream_t s);
+// aff_pt_y_from_x (curves/aff_pt.c:102) + fp_sqrt (fp/fp_sqrt.c:107: Tonelli-Shanks with the reference's choice of the
+// non-residue z = the smallest one, hence its choice of which root is "sqrt1")
+struct EcamdYfromXArgs {
+	const uint8_t *x;        // n x xstride bytes; the coordinate is the LAST clen bytes of each record
+	uint32_t xstride;        // clen, or 1 + clen for SEC1 compressed points (prefix byte 0x02 / 0x03 first)
+	uint8_t *y1, *y2;        // out, n x clen big-endian: sqrt1 and sqrt2 = p - sqrt1 (mode 0)
+	uint8_t *aff;            // out, n x 2*clen: X || Y with the root whose parity matches the prefix (mode 1)
+	uint8_t *status;         // n: 0 ok / 1 (x >= p, no square root, bad prefix)
+	uint32_t n, clen, mode;
+	uint32_t s;              // p - 1 = q 2^s, q odd
+	uint32_t ebits;          // bits of (q - 1) / 2
+	uint32_t e[17];          // (q - 1) / 2, little-endian words
+	uint32_t c[17];          // z^q in Montgomery form (radix 2^(32 NW)), z the smallest non-residue
+	int slot;
+};
+hipError_t ecamd_launch_y_from_x(int nw, const EcamdYfromXArgs &a, hipStream_t s);
+// scalar blinding of prj_pt_mul_blind (curves/prj_pt.c:1782-1822): m' = m + b * #E as a big-endian string of outlen bytes
+struct EcamdBlindArgs {
+	const uint8_t *m;        // n x mlen big-endian scalars
+	const uint8_t *b;        // n x blen big-endian blinding values
+	uint8_t *out;            // n x outlen big-endian, outlen >= max(mlen, blen + 4 * owords) + 1
+	uint8_t *bad;            // n: 1 where b = 0 or b >= #E (the reference draws b in [1, #E))
+	uint32_t n, mlen, blen, outlen, owords;
+	uint32_t order[18];      // #E (the CURVE order, cofactor included), little-endian words
+};
+hipError_t ecamd_launch_blind_scalar(const EcamdBlindArgs &a, hipStream_t s);
+// status[i] = 1 and out[i] zeroed where bad[i] != 0
+hipError_t ecamd_launch_status_or(uint8_t *status, const uint8_t *bad, uint8_t *out, uint32_t out_stride, uint32_t n, hipStream_t s);
 hipError_t ecamd_launch_prj_import(int nw, const EcamdPrjInArgs &a, hipStream_t s);
 hipError_t ecamd_launch_prj_export(const EcamdPrjOutArgs &a, hipStream_t s);
 

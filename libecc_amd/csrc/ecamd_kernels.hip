@@ -53,7 +53,34 @@ template <int NW> static __device__ __forceinline__ Pt<NW> tbl_load(const u32 *t
 	return P;
 }
 
-template <int NW> __global__ __launch_bounds__(64) void k_smul(EcamdSmulArgs A)
+// Constant-address look-up for SECRET digits: every entry of the lane's table is read, in the same order whatever the digit,
+// and the wanted one is kept by masking -- the counterpart of the reference's nn_tabselect (nn/nn.c:564) / masked ladder steps
+// (curves/prj_pt.c:1225-1260).  In this table layout (word-major, lane-minor) every one of these loads is coalesced across
+// the wave, because all lanes read the same entry at the same time.
+template <int NW> static __device__ __forceinline__ Pt<NW> tbl_load_masked(const u32 *tbl, u32 stride, u32 lane, u32 dig)
+{
+	Pt<NW> R;
+#pragma unroll
+	for (int w = 0; w < NW; w++) {
+		R.X.v[w] = R.Y.v[w] = R.Z.v[w] = 0;
+	}
+#pragma unroll 1
+	for (u32 e = 0; e < ECAMD_TBL_ENTRIES; e++) {
+		const Pt<NW> T = tbl_load<NW>(tbl, stride, lane, e);
+		const u32 m = 0u - (u32)(e == dig);
+#pragma unroll
+		for (int w = 0; w < NW; w++) {
+			R.X.v[w] |= T.X.v[w] & m;
+			R.Y.v[w] |= T.Y.v[w] & m;
+			R.Z.v[w] |= T.Z.v[w] & m;
+		}
+	}
+	return R;
+}
+
+// MASKED: the scalar is secret -- table look-ups by full scan (above); the rest of the kernel is already uniform (complete
+// formulas, fixed window count, no digit-dependent branch)
+template <int NW, bool MASKED = false> __global__ __launch_bounds__(64) void k_smul(EcamdSmulArgs A)
 {
 	const u32 i = blockIdx.x * 64 + threadIdx.x;
 	if (i >= A.n) {
@@ -104,7 +131,7 @@ template <int NW> __global__ __launch_bounds__(64) void k_smul(EcamdSmulArgs A)
 	// ---- fixed-window left-to-right ----
 	const u8 *sc = A.scalars + (size_t)i * A.sstride;
 	const int nwin = 2 * (int)A.slen;
-	acc = tbl_load<NW>(A.tbl, A.stride, i, (u32)(sc[0] >> 4));
+	acc = MASKED ? tbl_load_masked<NW>(A.tbl, A.stride, i, (u32)(sc[0] >> 4)) : tbl_load<NW>(A.tbl, A.stride, i, (u32)(sc[0] >> 4));
 #pragma unroll 1
 	for (int t = 1; t < nwin; t++) {
 #pragma unroll 1
@@ -113,7 +140,7 @@ template <int NW> __global__ __launch_bounds__(64) void k_smul(EcamdSmulArgs A)
 		}
 		const u32 byte = sc[t >> 1];
 		const u32 dig = (t & 1) ? (byte & 15u) : (byte >> 4);
-		const Pt<NW> T = tbl_load<NW>(A.tbl, A.stride, i, dig);
+		const Pt<NW> T = MASKED ? tbl_load_masked<NW>(A.tbl, A.stride, i, dig) : tbl_load<NW>(A.tbl, A.stride, i, dig);
 		acc = pt_add<NW>(acc, T, slot);
 	}
 
@@ -375,14 +402,14 @@ template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_sign(EcamdEcdsaS
 		const Fe<NW> km = ((okmask >> k) & 1u) ? fe_mul<NW>(kk, r2q, qs) : one;
 		const Fe<NW> kinv = (k > 0) ? fe_mul<NW>(inv, pre[k - 1], qs) : inv;     // Montgomery form of 1/k
 		inv = fe_mul<NW>(inv, km, qs);
-		Fe<NW> x = fe_load_be<NW>(A.privs + (size_t)i * qlen, qlen);
+		const Fe<NW> x = fe_load_be<NW>(A.privs + (size_t)i * qlen, qlen);
 		// r = kG.x mod q: x < p <= (jmax + 1) q, so jmax conditional subtractions
 		Fe<NW> r = fe_load_be<NW>(A.kG + (size_t)i * 2 * clen, clen);
 		for (u32 j = 0; j < A.jmax; j++) {
 			r = fe_cond_sub<NW>(r.v, 0u, qw);
 		}
 		ok = ok & !fe_is_zero<NW>(r);
-		x = fe_cond_sub<NW>(x.v, 0u, qw);  // private keys are < q in every sane use; one reduction step
+		ok = ok & fe_lt_p<NW>(x, qs);      // __ecdsa_sign_init fails on a private key >= q (sig/ecdsa_common.c:367-371)
 		const Fe<NW> e = digest_to_e<NW>(A.digests + (size_t)i * A.hlen, (int)A.hlen, qlen, (int)A.qbits, qs);
 		const Fe<NW> xr = fe_mul<NW>(fe_mul<NW>(x, r2q, qs), r, qs);         // x r mod q (plain)
 		ok = ok & !fe_eq<NW>(e, xr);                                            // :516 restart condition
@@ -623,7 +650,10 @@ template <int NW> static __device__ Fe<NW> fe_pow_2_250m1(const Fe<NW> &z, Fe<NW
 }
 
 // x of a compressed point: returns false where the reference's decode / map fails
-template <int NW> static __device__ bool ed_decode_xy(const EcamdEdDecodeArgs &A, const u8 *src, Fe<NW> *xo, Fe<NW> *ymo)
+// *neutral: the encoding is that of the neutral element (0, 1) (x = 0 with the sign bit clear, y = 1), which the reference
+// decodes and maps to the point at infinity (aff_pt_edwards_to_prj_pt_shortw, curves/prj_pt.c:1976-1982): fine for R
+// (the verification goes on with R = infinity), while a key is then rejected by the small-order test.
+template <int NW> static __device__ bool ed_decode_xy(const EcamdEdDecodeArgs &A, const u8 *src, Fe<NW> *xo, Fe<NW> *ymo, bool *neutral)
 {
 	const int slot = A.slot;
 	const int len = (int)A.len;
@@ -652,7 +682,10 @@ template <int NW> static __device__ bool ed_decode_xy(const EcamdEdDecodeArgs &A
 	Fe<NW> x = fe_select<NW>(alt & !root, fe_mul<NW>(beta, fe_const<NW>(A.sm1), slot), beta);
 	const Fe<NW> xp = fe_from_mont<NW>(x, slot);
 	x = fe_select<NW>((xp.v[0] & 1u) != x0, fe_sub<NW>(zero, x, slot), x);
-	ok = ok & !fe_is_zero<NW>(x);  // x = 0: the neutral point is rejected, (0, -1) dies in fp_inv(0)
+	// x = 0: (0, 1) is the neutral element (see above; x_0 = 1 with x = 0 is a decoding error, sig/eddsa.c:511-513),
+	// (0, -1) dies in fp_inv(0) of the map to the Montgomery model
+	*neutral = ok & fe_is_zero<NW>(x) & (x0 == 0) & fe_eq<NW>(ym, one);
+	ok = ok & !fe_is_zero<NW>(x);
 	*xo = x;
 	*ymo = ym;
 	return ok;
@@ -672,9 +705,9 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed_decode(EcamdEdDecod
 	const Fe<NW> one = fe_const<NW>(ConstTab<NW>::get(slot).one);
 	const Fe<NW> zero = fe_zero<NW>();
 	Fe<NW> x[2], ym[2], omy[2], den[2];
-	bool ok[2];
-	ok[0] = ed_decode_xy<NW>(A, A.encA + (size_t)i * A.strideA, &x[0], &ym[0]);
-	ok[1] = ed_decode_xy<NW>(A, A.encR + (size_t)i * A.strideR, &x[1], &ym[1]);
+	bool ok[2], neutral[2];
+	ok[0] = ed_decode_xy<NW>(A, A.encA + (size_t)i * A.strideA, &x[0], &ym[0], &neutral[0]);
+	ok[1] = ed_decode_xy<NW>(A, A.encR + (size_t)i * A.strideR, &x[1], &ym[1], &neutral[1]);
 #pragma unroll
 	for (int k = 0; k < 2; k++) {
 		omy[k] = fe_sub<NW>(one, ym[k], slot);
@@ -703,7 +736,7 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed_decode(EcamdEdDecod
 		u8 *pd = (k == 0 ? A.pointsA : A.pointsR) + (size_t)i * 2 * len;
 		fe_store_be<NW>(pd, len, good ? fe_from_mont<NW>(Xm, slot) : zero);
 		fe_store_be<NW>(pd + len, len, good ? fe_from_mont<NW>(vm, slot) : zero);
-		(k == 0 ? A.flagsA : A.flagsR)[i] = good ? 0 : 1;
+		(k == 0 ? A.flagsA : A.flagsR)[i] = good ? 0 : ((k == 1 && neutral[1]) ? 2 : 1);   // 2: R is the point at infinity
 	}
 }
 
@@ -760,7 +793,8 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed_fin(EcamdEdFinArgs 
 	const int clen = (int)A.clen;
 	const u32 sSG = A.stSG[i], shA = A.sthA[i];
 	// bad encodings, small-order public key ([8]A = infinity, folded into flagsA), S >= q, or a failed multiplication
-	if (A.flagsA[i] || A.flagsR[i] || A.flagsS[i] || sSG == 1 || shA == 1) {
+	const u32 fR = A.flagsR[i];   // 2: R decoded to the neutral element, i.e. the point at infinity
+	if (A.flagsA[i] || fR == 1 || A.flagsS[i] || sSG == 1 || shA == 1) {
 		A.result[i] = 1;
 		return;
 	}
@@ -780,7 +814,7 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed_fin(EcamdEdFinArgs 
 		}
 	}
 	Pt<NW> W = ed_load_neg<NW>(A.SG + (size_t)i * 2 * clen, sSG, clen, false, slot);
-	const Pt<NW> Rn = ed_load_neg<NW>(A.R + (size_t)i * 2 * clen, 0, clen, true, slot);
+	const Pt<NW> Rn = ed_load_neg<NW>(A.R + (size_t)i * 2 * clen, fR, clen, true, slot);
 	const Pt<NW> Hn = ed_load_neg<NW>(A.hA + (size_t)i * 2 * clen, shA, clen, true, slot);
 	// prj_pt_add returns -1 on an exceptional pair (curves/prj_pt.c:1058-1060): the signature is rejected
 	W = pt_add<NW>(W, Rn, slot);
@@ -931,7 +965,7 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed448_decode(EcamdEd44
 	const Fe<NW> zero = fe_zero<NW>();
 	const Fe<NW> two = fe_add<NW>(one, one, slot);
 	Fe<NW> x[2], ym[2], xx[2], yy[2], d1[2], d2[2];
-	bool ok[2];
+	bool ok[2], neutral[2] = {false, false};
 #pragma unroll 1
 	for (int k = 0; k < 2; k++) {
 		const u8 *src = (k == 0) ? A.encA + (size_t)i * A.strideA : A.encR + (size_t)i * A.strideR;
@@ -976,7 +1010,10 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed448_decode(EcamdEd44
 			const Fe<NW> l = fe_add<NW>(X2, Y2, slot);
 			const Fe<NW> r = fe_add<NW>(one, fe_mul<NW>(fe_const<NW>(A.diso), fe_mul<NW>(X2, Y2, slot), slot), slot);
 			omy[k] = fe_sub<NW>(one, Y[k], slot);
-			// on the Edwards model of curve448; X = 0 (neutral element, order-2 point) and Y = 1 are errors
+			// on the Edwards model of curve448.  (0, 1) -- the image of both (0, 1) and (0, -1) of Ed448 -- is the neutral
+			// element: aff_pt_edwards_to_prj_pt_shortw maps it to the point at infinity (fine for R; a key is then rejected
+			// as small-order).  X = 0 with Y = -1 (order 2) dies in fp_inv(0) of the map to the Montgomery model.
+			neutral[k] = ok[k] & fe_eq<NW>(l, r) & fe_is_zero<NW>(X[k]) & fe_is_zero<NW>(omy[k]);
 			ok[k] = ok[k] & fe_eq<NW>(l, r) & !fe_is_zero<NW>(X[k]) & !fe_is_zero<NW>(omy[k]);
 			X[k] = fe_select<NW>(ok[k], X[k], one);
 			omy[k] = fe_select<NW>(ok[k], omy[k], one);
@@ -996,7 +1033,7 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed448_decode(EcamdEd44
 			u8 *pd = (k == 0 ? A.pointsA : A.pointsR) + (size_t)i * 112;
 			fe_store_be<NW>(pd, 56, ok[k] ? fe_from_mont<NW>(Xw, slot) : zero);
 			fe_store_be<NW>(pd + 56, 56, ok[k] ? fe_from_mont<NW>(Yw, slot) : zero);
-			(k == 0 ? A.flagsA : A.flagsR)[i] = ok[k] ? 0 : 1;
+			(k == 0 ? A.flagsA : A.flagsR)[i] = ok[k] ? 0 : ((k == 1 && neutral[1]) ? 2 : 1);   // 2: R is the point at infinity
 		}
 	}
 }
@@ -1041,6 +1078,100 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed448_scal(EcamdEdScal
 	fe_store_be<NW>(A.S_be + (size_t)i * 56, 56, ok ? S : fe_zero<NW>());
 	fe_store_be<NW>(A.h_be + (size_t)i * 56, 56, k);
 	A.flags[i] = ok ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// Point decompression: aff_pt_y_from_x (curves/aff_pt.c:102-131) = the two roots of x^3 + a x + b through fp_sqrt
+// (fp/fp_sqrt.c:107-251).  fp_sqrt is Tonelli-Shanks with z = the smallest quadratic non-residue (found by counting up
+// from 0, :197-200), so WHICH root it returns as sqrt1 is a fixed function of the input; the steps below are its steps
+// with the two exponentiations n^((q+1)/2), n^q (p - 1 = q 2^s) sharing w = n^((q-1)/2):
+//   n = 0 -> both roots 0;  r = w n, t = r w;  Legendre symbol = t^(2^(s-1)) must be 1 (else fp_sqrt returns -1);
+//   while t != 1: i = least i with t^(2^i) = 1;  b = c^(2^(m-i-1));  r = r b;  c = b^2;  t = t c;  m = i.
+// For p = 3 mod 4 (s = 1) the loop never runs and r = n^((p+1)/4), the reference's shortcut (:184-192).
+// The control flow after the exponentiation is per lane (data dependent, bounded by s^2 squarings: secp224r1 has s = 96).
+// ------------------------------------------------------------------------------------------
+template <int NW> __global__ __launch_bounds__(64) void k_y_from_x(EcamdYfromXArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int slot = A.slot;
+	const int clen = (int)A.clen;
+	const CurveK<NW> &K = ConstTab<NW>::get(slot);
+	const u8 *rec = A.x + (size_t)i * A.xstride;
+	const u8 *xp = rec + (A.xstride - A.clen);
+	const Fe<NW> zero = fe_zero<NW>();
+	const Fe<NW> one = fe_const<NW>(K.one);
+	const Fe<NW> x = fe_load_be<NW>(xp, clen);
+	bool ok = fe_lt_p<NW>(x, slot);                                 // fp_init_from_buf rejects x >= p (fp/fp.c:441-442)
+	u32 want = 0;
+	if (A.mode == 1) {
+		const u32 pre = rec[0];
+		ok = ok & (A.xstride == A.clen + 1) & ((pre == 2u) | (pre == 3u));
+		want = pre & 1u;
+	}
+	const Fe<NW> xm = fe_to_mont<NW>(x, slot);
+	// x^3 + a x + b in the reference's order (:118-122)
+	Fe<NW> n = fe_mul<NW>(fe_mul<NW>(xm, xm, slot), xm, slot);
+	n = fe_add<NW>(n, fe_mul<NW>(xm, fe_const<NW>(K.a), slot), slot);
+	n = fe_add<NW>(n, fe_const<NW>(K.b), slot);
+	// w = n^((q-1)/2), wave-uniform exponent
+	Fe<NW> w = one;
+	for (int b = (int)A.ebits - 1; b >= 0; b--) {
+		w = fe_mul<NW>(w, w, slot);
+		if ((A.e[b >> 5] >> (b & 31)) & 1u) {
+			w = fe_mul<NW>(w, n, slot);
+		}
+	}
+	Fe<NW> r = fe_mul<NW>(w, n, slot);
+	Fe<NW> t = fe_mul<NW>(r, w, slot);
+	const bool nzero = fe_is_zero<NW>(n);
+	{
+		Fe<NW> l = t;
+		for (u32 k = 1; k < A.s; k++) {
+			l = fe_mul<NW>(l, l, slot);
+		}
+		ok = ok & (nzero | fe_eq<NW>(l, one));                     // not a square: fp_sqrt fails
+	}
+	if (ok && !nzero) {
+		Fe<NW> c = fe_const<NW>(A.c);
+		u32 m = A.s;
+		while (!fe_eq<NW>(t, one)) {
+			u32 ii = 1;
+			Fe<NW> tt = fe_mul<NW>(t, t, slot);
+			while (!fe_eq<NW>(tt, one) && ii < m) {
+				tt = fe_mul<NW>(tt, tt, slot);
+				ii++;
+			}
+			if (ii >= m) {
+				ok = false;                                       // "should not happen" (:222-226)
+				break;
+			}
+			Fe<NW> b = c;
+			for (u32 k = 0; k < m - ii - 1; k++) {
+				b = fe_mul<NW>(b, b, slot);
+			}
+			r = fe_mul<NW>(r, b, slot);
+			c = fe_mul<NW>(b, b, slot);
+			t = fe_mul<NW>(t, c, slot);
+			m = ii;
+		}
+	}
+	const Fe<NW> r1 = (ok && !nzero) ? fe_from_mont<NW>(r, slot) : zero;
+	const Fe<NW> r2 = (ok && !nzero) ? fe_from_mont<NW>(fe_sub<NW>(zero, r, slot), slot) : zero;
+	if (A.mode == 0) {
+		fe_store_be<NW>(A.y1 + (size_t)i * clen, clen, r1);
+		fe_store_be<NW>(A.y2 + (size_t)i * clen, clen, r2);
+	} else {
+		// SEC 1 section 2.3.4: the prefix carries y mod 2.  y = 0 has no odd form: 0x03 with n = 0 is an error.
+		const bool pick1 = ((r1.v[0] & 1u) == want);
+		ok = ok & !(nzero & (want == 1u));
+		u8 *o = A.aff + (size_t)i * 2 * clen;
+		fe_store_be<NW>(o, clen, ok ? x : zero);
+		fe_store_be<NW>(o + clen, clen, ok ? (pick1 ? r1 : r2) : zero);
+	}
+	A.status[i] = ok ? 0 : 1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1210,8 +1341,17 @@ hipError_t ecamd_launch_smul(int nw, const EcamdSmulArgs &a, hipStream_t s)
 		return hipSuccess;
 	}
 	const dim3 grid((a.n + 63) / 64), block(64);
+	if (a.masked) {
+		switch (nw) {
+#define X(N) case N: hipLaunchKernelGGL((k_smul<N, true>), grid, block, 0, s, a); break;
+			ECAMD_FOR_NW(X)
+#undef X
+		default: return hipErrorInvalidValue;
+		}
+		return hipGetLastError();
+	}
 	switch (nw) {
-#define X(N) case N: hipLaunchKernelGGL(k_smul<N>, grid, block, 0, s, a); break;
+#define X(N) case N: hipLaunchKernelGGL((k_smul<N, false>), grid, block, 0, s, a); break;
 		ECAMD_FOR_NW(X)
 #undef X
 	default: return hipErrorInvalidValue;
@@ -1289,6 +1429,129 @@ hipError_t ecamd_launch_ecdsa_fin(int nw, const EcamdEcdsaFinArgs &a, hipStream_
 	const dim3 grid((a.n + 63) / 64), block(64);
 	switch (nw) {
 #define X(N) case N: hipLaunchKernelGGL(k_ecdsa_fin<N>, grid, block, 0, s, a); break;
+		ECAMD_FOR_NW(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// prj_pt_mul_blind (curves/prj_pt.c:1782-1822): the scalar actually multiplied is m + b * #E with b random in [1, #E);
+// here b is the caller's (randomness stays on the host, as for nonces).  Plain multi-precision arithmetic per lane.
+// ------------------------------------------------------------------------------------------
+#define BLIND_MAXW 72
+__global__ __launch_bounds__(64) void k_blind_scalar(EcamdBlindArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	u32 acc[BLIND_MAXW];
+	const u32 ow = A.owords, bw = (A.blen + 3) / 4, mw = (A.mlen + 3) / 4, tw = (A.outlen + 3) / 4;
+	for (u32 w = 0; w < tw; w++) {
+		acc[w] = 0;
+	}
+	const u8 *bp = A.b + (size_t)i * A.blen, *mp = A.m + (size_t)i * A.mlen;
+	u32 nz = 0, lt = 0;    // b != 0;  b < #E (decided by the most significant differing word)
+	bool decided = false;
+	for (int w = (int)(bw > ow ? bw : ow) - 1; w >= 0; w--) {
+		u32 x = 0;
+		for (u32 k = 0; k < 4; k++) {
+			const u32 pos = 4 * (u32)w + k;
+			if (pos < A.blen) {
+				x |= (u32)bp[A.blen - 1 - pos] << (8 * k);
+			}
+		}
+		nz |= x;
+		const u32 o = ((u32)w < ow) ? A.order[w] : 0u;
+		if (!decided && x != o) {
+			lt = (x < o) ? 1u : 0u;
+			decided = true;
+		}
+	}
+	for (u32 w = 0; w < bw; w++) {
+		u32 x = 0;
+		for (u32 k = 0; k < 4; k++) {
+			const u32 pos = 4 * w + k;
+			if (pos < A.blen) {
+				x |= (u32)bp[A.blen - 1 - pos] << (8 * k);
+			}
+		}
+		u64 carry = 0;
+		for (u32 j = 0; j < ow && w + j < tw; j++) {
+			const u64 t = (u64)x * A.order[j] + acc[w + j] + carry;
+			acc[w + j] = (u32)t;
+			carry = t >> 32;
+		}
+		for (u32 j = w + ow; carry && j < tw; j++) {
+			const u64 t = (u64)acc[j] + carry;
+			acc[j] = (u32)t;
+			carry = t >> 32;
+		}
+	}
+	u64 carry = 0;
+	for (u32 w = 0; w < tw; w++) {
+		u32 x = 0;
+		if (w < mw) {
+			for (u32 k = 0; k < 4; k++) {
+				const u32 pos = 4 * w + k;
+				if (pos < A.mlen) {
+					x |= (u32)mp[A.mlen - 1 - pos] << (8 * k);
+				}
+			}
+		}
+		const u64 t = (u64)acc[w] + x + carry;
+		acc[w] = (u32)t;
+		carry = t >> 32;
+	}
+	u8 *o = A.out + (size_t)i * A.outlen;
+	for (u32 k = 0; k < A.outlen; k++) {
+		o[A.outlen - 1 - k] = (u8)(acc[k >> 2] >> (8 * (k & 3)));
+	}
+	A.bad[i] = (nz != 0 && decided && lt) ? 0 : 1;
+}
+
+__global__ __launch_bounds__(64) void k_status_or(u8 *status, const u8 *bad, u8 *out, u32 stride, u32 n)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i < n && bad[i]) {
+		status[i] = 1;
+		for (u32 k = 0; k < stride; k++) {
+			out[(size_t)i * stride + k] = 0;
+		}
+	}
+}
+
+hipError_t ecamd_launch_status_or(uint8_t *status, const uint8_t *bad, uint8_t *out, uint32_t out_stride, uint32_t n, hipStream_t s)
+{
+	if (n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_status_or, dim3((n + 63) / 64), dim3(64), 0, s, status, bad, out, out_stride, n);
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_blind_scalar(const EcamdBlindArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	if ((a.outlen + 3) / 4 > BLIND_MAXW) {
+		return hipErrorInvalidValue;
+	}
+	hipLaunchKernelGGL(k_blind_scalar, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_y_from_x(int nw, const EcamdYfromXArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	const dim3 grid((a.n + 63) / 64), block(64);
+	switch (nw) {
+#define X(N) case N: hipLaunchKernelGGL(k_y_from_x<N>, grid, block, 0, s, a); break;
 		ECAMD_FOR_NW(X)
 #undef X
 	default: return hipErrorInvalidValue;

@@ -300,23 +300,15 @@ __global__ __launch_bounds__(64) void k_p256_affine(EcamdSmulArgs A, u32 nthread
 #ifndef P256_WAVES
 #define P256_WAVES 3
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, P256_WAVES))) void k_p256_loop(EcamdSmulArgs A)
+// scalar k (slen <= 4 KW bytes big-endian) -> k' = k + 0x88..8 over its 2 slen nibbles, left-aligned in kw[KW] (the top
+// nibble of the scalar in bits 31..28 of kw[KW-1]); returns the carry out of the top nibble (the leading digit, 0 or +1)
+template <int KW> static __device__ __forceinline__ u32 recode_window(u32 *kw, const u8 *sc, int slen)
 {
-	const u32 i = blockIdx.x * 64 + threadIdx.x;
-	if (i >= A.n || A.status[i] != ECAMD_STATUS_TAB) {
-		return;
-	}
-	u32 *tb = A.tbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
-	const u32 *lut = A.lut ? A.lut : tb;  // fixed base: one shared table for every lane
-	// ---- scalar: k (<= 32 bytes big-endian) -> k' = k + 0x88..8 over its 2*slen nibbles ----
-	const u8 *sc = A.scalars + (size_t)i * A.sstride;
-	const int slen = (int)A.slen;
-	u32 kw[8];
-	if (slen == 32) {
+	if (KW == 8 && slen == 32) {
 		load_be256(sc, kw);
 	} else {
 #pragma unroll
-		for (int w = 0; w < 8; w++) {
+		for (int w = 0; w < KW; w++) {
 			u32 x = 0;
 #pragma unroll
 			for (int b = 0; b < 4; b++) {
@@ -328,30 +320,49 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 			kw[w] = x;
 		}
 	}
-	u32 carry_bit = 0;
-	{
-		uint64_t c = 0;
+	uint64_t c = 0;
 #pragma unroll
-		for (int w = 0; w < 8; w++) {
-			const int nb = slen - 4 * w;  // bytes of 0x88 only where the scalar has bytes
-			const u32 add = (nb >= 4) ? 0x88888888u : (nb == 3 ? 0x00888888u : (nb == 2 ? 0x00008888u : (nb == 1 ? 0x00000088u : 0u)));
-			c += (uint64_t)kw[w] + add;
-			kw[w] = (u32)c;
-			c >>= 32;
+	for (int w = 0; w < KW; w++) {
+		const int nb = slen - 4 * w;  // bytes of 0x88 only where the scalar has bytes
+		const u32 add = (nb >= 4) ? 0x88888888u : (nb == 3 ? 0x00888888u : (nb == 2 ? 0x00008888u : (nb == 1 ? 0x00000088u : 0u)));
+		c += (uint64_t)kw[w] + add;
+		kw[w] = (u32)c;
+		c >>= 32;
+	}
+	u32 carry_bit = (u32)c;  // only when slen == 4 KW
+	if (slen < 4 * KW) {
+		const int bit = 8 * slen;  // the carry out of the top nibble sits just above the scalar's bytes
+		u32 word = 0;
+#pragma unroll
+		for (int w = 0; w < KW; w++) {
+			word = (w == (bit >> 5)) ? kw[w] : word;
 		}
-		carry_bit = (u32)c;  // only when slen == 32
-		if (slen < 32) {
-			const int bit = 8 * slen;  // the carry out of the top nibble sits just above the scalar's bytes
-			carry_bit = (kw[bit >> 5] >> (bit & 31)) & 1u;
-			for (int s = slen; s < 32; s++) {  // left-align: top nibble of the scalar -> bits 255..252
+		carry_bit = (word >> (bit & 31)) & 1u;
+		for (int s = slen; s < 4 * KW; s++) {  // left-align: top nibble of the scalar -> bits 31..28 of kw[KW-1]
 #pragma unroll
-				for (int w = 7; w > 0; w--) {
-					kw[w] = (kw[w] << 8) | (kw[w - 1] >> 24);
-				}
-				kw[0] <<= 8;
+			for (int w = KW - 1; w > 0; w--) {
+				kw[w] = (kw[w] << 8) | (kw[w - 1] >> 24);
 			}
+			kw[0] <<= 8;
 		}
 	}
+	return carry_bit;
+}
+
+// KW = 8: scalars of up to 32 bytes (everything below the group order's length); KW = 17: up to 68 bytes -- blinded scalars
+// m + b #E of prj_pt_mul_blind (curves/prj_pt.c:1782-1822, about 2 |q| bits) stay on this kernel instead of the saturated one
+template <int KW>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, P256_WAVES))) void k_p256_loop(EcamdSmulArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n || A.status[i] != ECAMD_STATUS_TAB) {
+		return;
+	}
+	u32 *tb = A.tbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
+	const u32 *lut = A.lut ? A.lut : tb;  // fixed base: one shared table for every lane
+	const int slen = (int)A.slen;
+	u32 kw[KW];
+	const u32 carry_bit = recode_window<KW>(kw, A.scalars + (size_t)i * A.sstride, slen);
 
 	// ---- signed fixed window, left to right; the top digit is the carry: 0 or +1 ----
 	Jac acc;
@@ -375,9 +386,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 		for (int d = 0; d < 4; d++) {
 			acc = dbl(acc);
 		}
-		const int dig = (int)(kw[7] >> 28) - 8;  // [-8, 7]
+		const int dig = (int)(kw[KW - 1] >> 28) - 8;  // [-8, 7]
 #pragma unroll
-		for (int w = 7; w > 0; w--) {
+		for (int w = KW - 1; w > 0; w--) {
 			kw[w] = (kw[w] << 4) | (kw[w - 1] >> 28);
 		}
 		kw[0] <<= 4;
@@ -824,7 +835,11 @@ hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s, hipEven
 	if (a.lut && a.lut_kind == 1) {
 		hipLaunchKernelGGL(k_p256_comb, grid, block, 0, s, a);
 	} else {
-		hipLaunchKernelGGL(k_p256_loop, grid, block, 0, s, a);
+		if (a.slen <= 32) {
+			hipLaunchKernelGGL(k_p256_loop<8>, grid, block, 0, s, a);
+		} else {
+			hipLaunchKernelGGL(k_p256_loop<17>, grid, block, 0, s, a);
+		}
 	}
 	P256_MARK(3);
 	hipLaunchKernelGGL(k_p256_finalize, fgrid, block, 0, s, a, nthreads);

@@ -187,7 +187,18 @@ U29_FN void mul_col9(u64 &acc, u32 *m, u32 *r, const u32 *a, const u32 *b, const
 	} else {
 		r[K_ - 9] = (u32)acc & MASK;
 	}
+#if defined(__HIPCC__) && defined(U29_SHIFT_PAIR)
+	{
+		// the 64-bit shift as v_alignbit_b32 + v_lshrrev_b32 instead of v_lshrrev_b64 (A/B: tools/build_variant.py)
+		u32 lo_ = (u32)acc, hi_ = (u32)(acc >> 32);
+		lo_ = __builtin_amdgcn_alignbit(hi_, lo_, W);
+		hi_ >>= W;
+		asm("" : "+v"(lo_), "+v"(hi_));
+		acc = ((u64)hi_ << 32) | lo_;
+	}
+#else
 	acc >>= W;
+#endif
 	// (no pin needed: the next column starts with an asm statement that takes acc as an operand)
 }
 

@@ -14,9 +14,22 @@ typedef uint64_t u64;
 
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
-// 8 independent accumulators, each iteration issues 8*4 = 32 instructions of the kind
-template <int KIND> __global__ __launch_bounds__(256) void k_rate(u32 *out, u32 seed, int iters)
+// In-kernel clocks: s_memtime (clock64: shader-clock counter) and s_memrealtime (wall_clock64: constant-rate
+// counter, hipDeviceAttributeWallClockRate kHz).  Their ratio over a kernel is the SUSTAINED shader clock under that
+// instruction stream, which turns "instructions per second" into cycles per instruction without assuming the
+// nominal 2.4 GHz.  ticks[4 b .. 4 b + 3] = {memtime start, memtime end, realtime start, realtime end} of block b.
+static __device__ __forceinline__ void tick(u64 *ticks, int which)
 {
+	if (ticks && threadIdx.x == 0) {
+		ticks[4 * (size_t)blockIdx.x + which] = (u64)clock64();
+		ticks[4 * (size_t)blockIdx.x + 2 + which] = (u64)wall_clock64();
+	}
+}
+
+// 8 independent accumulators, each iteration issues 8*4 = 32 instructions of the kind
+template <int KIND> __global__ __launch_bounds__(256) void k_rate(u32 *out, u32 seed, int iters, u64 *ticks)
+{
+	tick(ticks, 0);
 	u32 a = seed ^ threadIdx.x, b = seed * 2654435761u + blockIdx.x;
 	u64 acc[8];
 	u32 w[8];
@@ -67,6 +80,34 @@ template <int KIND> __global__ __launch_bounds__(256) void k_rate(u32 *out, u32 
 					asm volatile("v_xor_b32 %0, %1, %0" : "+v"(w[i]) : "v"(a));
 				} else if (KIND == 14) {  // v_add3_u32 (VOP3, 8-byte encoding)
 					asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(w[i]) : "v"(a), "v"(b));
+				} else if (KIND == 16) {  // 64-bit logical shift right (what hipcc emits for "acc >>= 29")
+					asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(acc[i]));
+				} else if (KIND == 17) {  // the same shift as two 32-bit instructions
+					u32 lo_ = (u32)acc[i], hi_ = (u32)(acc[i] >> 32);
+					asm volatile("v_alignbit_b32 %0, %1, %0, 29\n\tv_lshrrev_b32 %1, 29, %1" : "+v"(lo_), "+v"(hi_));
+					acc[i] = ((u64)hi_ << 32) | lo_;
+				} else if (KIND == 18) {  // v_and_b32 with an inline constant
+					asm volatile("v_and_b32 %0, 0x1fffffff, %0" : "+v"(w[i]));
+				} else if (KIND == 19) {  // v_lshrrev_b32
+					asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(w[i]));
+				} else if (KIND == 20) {  // v_sub_u32
+					asm volatile("v_sub_u32 %0, %1, %0" : "+v"(w[i]) : "v"(a));
+				} else if (KIND == 21) {  // v_mad_u64_u32 with an SGPR multiplier (reduction constants)
+					asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(w[i]), "s"((u32)mask) : "vcc");
+				} else if (KIND == 22) {  // v_mul_u32_u24 (24-bit multiply, VOP2)
+					asm volatile("v_mul_u32_u24 %0, %1, %0" : "+v"(w[i]) : "v"(a));
+				} else if (KIND == 23) {  // v_and_or_b32 (VOP3)
+					asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(w[i]) : "v"(a), "v"(b));
+				} else if (KIND == 15) {
+					// the window loop's instruction mix (profiles/r1c: 278 k MADs of 468 k VALU instructions per wave, the
+					// rest mostly VOP2 add / and / shift with some VOP3 alignbit / cndmask): per 8 slots 5 MADs, 2 VOP2, 1 VOP3
+					if ((i & 7) < 5) {
+						asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(w[i]) : "vcc");
+					} else if ((i & 7) < 7) {
+						asm volatile("v_add_u32 %0, %1, %0" : "+v"(w[i]) : "v"(a));
+					} else {
+						asm volatile("v_alignbit_b32 %0, %0, %1, 29" : "+v"(w[i]) : "v"(a));
+					}
 				}
 			}
 		}
@@ -77,6 +118,7 @@ template <int KIND> __global__ __launch_bounds__(256) void k_rate(u32 *out, u32 
 		r ^= (u32)acc[i] ^ (u32)(acc[i] >> 32) ^ w[i];
 	}
 	out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+	tick(ticks, 1);
 }
 
 // one dependent chain: latency of a v_mad_u64_u32 feeding the next one's addend
@@ -93,19 +135,34 @@ __global__ __launch_bounds__(64) void k_dep(u32 *out, u32 seed, int iters)
 	out[blockIdx.x * blockDim.x + threadIdx.x] = (u32)acc ^ (u32)(acc >> 32);
 }
 
-template <int KIND> static double run_rate(u32 *d_out, int blocks, int iters)
+static u64 *g_ticks;       // device
+static double g_wall_khz;  // rate of s_memrealtime
+
+// sclk_mhz: sustained shader clock during the timed launch (s_memtime ticks per s_memrealtime tick, averaged over blocks)
+template <int KIND> static double run_rate(u32 *d_out, int blocks, int iters, double *sclk_mhz)
 {
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0);
 	hipEventCreate(&e1);
-	hipLaunchKernelGGL(k_rate<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, 12345u, 16);
+	hipLaunchKernelGGL(k_rate<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, 12345u, 16, (u64 *)nullptr);
 	hipDeviceSynchronize();
 	hipEventRecord(e0);
-	hipLaunchKernelGGL(k_rate<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, 12345u, iters);
+	hipLaunchKernelGGL(k_rate<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, 12345u, iters, g_ticks);
 	hipEventRecord(e1);
 	hipEventSynchronize(e1);
 	float ms = 0;
 	hipEventElapsedTime(&ms, e0, e1);
+	if (sclk_mhz) {
+		static u64 h[4 * 4096];
+		const int nb = blocks < 4096 ? blocks : 4096;
+		hipMemcpy(h, g_ticks, sizeof(u64) * 4 * nb, hipMemcpyDeviceToHost);
+		double dm = 0, dr = 0;
+		for (int b = 0; b < nb; b++) {
+			dm += (double)(h[4 * b + 1] - h[4 * b]);
+			dr += (double)(h[4 * b + 3] - h[4 * b + 2]);
+		}
+		*sclk_mhz = dr > 0 ? (dm / dr) * g_wall_khz / 1e3 : 0.0;
+	}
 	const double lane_ops = (double)blocks * 256 * iters * 32.0;
 	return lane_ops / (ms * 1e-3);  // lane-ops per second
 }
@@ -123,26 +180,45 @@ int main(int argc, char **argv)
 	const int iters = (argc > 1) ? atoi(argv[1]) : 4000;
 	u32 *d_out;
 	hipMalloc(&d_out, (size_t)blocks * 256 * 4);
-	const int NK = 15;
+	hipMalloc(&g_ticks, sizeof(u64) * 4 * (size_t)blocks);
+	{
+		int khz = 0;
+		if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) {
+			khz = 100000;  // 100 MHz
+		}
+		g_wall_khz = (double)khz;
+	}
+	const int NK = 24;
 	const char *names[NK] = {"v_mad_u64_u32", "v_add_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_lshl_add_u64",
 				 "v_mad_u32_u24", "v_addc_co_u32_vccchain", "v_cndmask_b32_vcc", "v_mad_u64_u32_b", "v_alignbit_b32",
-				 "v_cndmask_b32_sgpr", "v_add_co_u32", "v_addc_co_u32_sgprpairs", "v_xor_b32", "v_add3_u32"};
-	double r[NK];
-	r[0] = run_rate<0>(d_out, blocks, iters);
-	r[1] = run_rate<1>(d_out, blocks, iters);
-	r[2] = run_rate<2>(d_out, blocks, iters);
-	r[3] = run_rate<3>(d_out, blocks, iters);
-	r[4] = run_rate<4>(d_out, blocks, iters);
-	r[5] = run_rate<5>(d_out, blocks, iters);
-	r[6] = run_rate<6>(d_out, blocks, iters);
-	r[7] = run_rate<7>(d_out, blocks, iters);
-	r[8] = run_rate<8>(d_out, blocks, iters);
-	r[9] = run_rate<9>(d_out, blocks, iters);
-	r[10] = run_rate<10>(d_out, blocks, iters);
-	r[11] = run_rate<11>(d_out, blocks, iters);
-	r[12] = run_rate<12>(d_out, blocks, iters);
-	r[13] = run_rate<13>(d_out, blocks, iters);
-	r[14] = run_rate<14>(d_out, blocks, iters);
+				 "v_cndmask_b32_sgpr", "v_add_co_u32", "v_addc_co_u32_sgprpairs", "v_xor_b32", "v_add3_u32",
+				 "mix_5mad_2vop2_1vop3", "v_lshrrev_b64", "pair_alignbit_lshr", "v_and_b32_const", "v_lshrrev_b32", "v_sub_u32",
+				 "v_mad_u64_u32_sgpr", "v_mul_u32_u24", "v_and_or_b32"};
+	double r[NK], f[NK];
+	r[0] = run_rate<0>(d_out, blocks, iters, &f[0]);
+	r[1] = run_rate<1>(d_out, blocks, iters, &f[1]);
+	r[2] = run_rate<2>(d_out, blocks, iters, &f[2]);
+	r[3] = run_rate<3>(d_out, blocks, iters, &f[3]);
+	r[4] = run_rate<4>(d_out, blocks, iters, &f[4]);
+	r[5] = run_rate<5>(d_out, blocks, iters, &f[5]);
+	r[6] = run_rate<6>(d_out, blocks, iters, &f[6]);
+	r[7] = run_rate<7>(d_out, blocks, iters, &f[7]);
+	r[8] = run_rate<8>(d_out, blocks, iters, &f[8]);
+	r[9] = run_rate<9>(d_out, blocks, iters, &f[9]);
+	r[10] = run_rate<10>(d_out, blocks, iters, &f[10]);
+	r[11] = run_rate<11>(d_out, blocks, iters, &f[11]);
+	r[12] = run_rate<12>(d_out, blocks, iters, &f[12]);
+	r[13] = run_rate<13>(d_out, blocks, iters, &f[13]);
+	r[14] = run_rate<14>(d_out, blocks, iters, &f[14]);
+	r[15] = run_rate<15>(d_out, blocks, iters, &f[15]);
+	r[16] = run_rate<16>(d_out, blocks, iters, &f[16]);
+	r[17] = run_rate<17>(d_out, blocks, iters, &f[17]);   // counts one "instruction" per pair
+	r[18] = run_rate<18>(d_out, blocks, iters, &f[18]);
+	r[19] = run_rate<19>(d_out, blocks, iters, &f[19]);
+	r[20] = run_rate<20>(d_out, blocks, iters, &f[20]);
+	r[21] = run_rate<21>(d_out, blocks, iters, &f[21]);
+	r[22] = run_rate<22>(d_out, blocks, iters, &f[22]);
+	r[23] = run_rate<23>(d_out, blocks, iters, &f[23]);
 	// dependent chain, one wave per SIMD
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0);
@@ -157,14 +233,19 @@ int main(int argc, char **argv)
 	hipEventElapsedTime(&ms, e0, e1);
 	const double clk_hz = (double)prop.clockRate * 1e3;
 	const double dep_cycles = (ms * 1e-3) * clk_hz / ((double)iters * 32.0);
-	printf("{\"device\": \"%s\", \"gcn_arch\": \"%s\", \"cus\": %d, \"clock_mhz\": %.0f, \"iters\": %d,\n", prop.name,
-	       prop.gcnArchName, cus, clk_hz / 1e6, iters);
+	printf("{\"device\": \"%s\", \"gcn_arch\": \"%s\", \"cus\": %d, \"clock_mhz\": %.0f, \"wall_clock_khz\": %.0f, \"iters\": %d,\n", prop.name,
+	       prop.gcnArchName, cus, clk_hz / 1e6, g_wall_khz, iters);
 	for (int i = 0; i < NK; i++) {
-		// cycles per wave64 instruction per SIMD at the nominal clock
+		// cycles per wave64 instruction per SIMD: at the nominal clock, and at the shader clock sustained under this stream
+		// (s_memtime against s_memrealtime inside the kernel; 0 when the two counters tick alike on this part)
 		const double per_simd = r[i] / ((double)cus * 4.0);          // lane-ops/s per SIMD
 		const double cyc = 64.0 * clk_hz / per_simd;
-		printf(" \"%s\": {\"lane_ops_per_s\": %.4e, \"cycles_per_wave_instr_per_simd\": %.3f},\n", names[i], r[i], cyc);
+		const double cyc_s = 64.0 * (f[i] * 1e6) / per_simd;
+		printf(" \"%s\": {\"lane_ops_per_s\": %.4e, \"cycles_per_wave_instr_per_simd\": %.3f, \"sustained_sclk_mhz\": %.1f, "
+		       "\"cycles_at_sustained_clock\": %.3f},\n", names[i], r[i], cyc, f[i], cyc_s);
 	}
+	// analytic MAD peak at the sustained clock: 1024 SIMDs x 16 lane-MADs per clock (a wave64 v_mad_u64_u32 = 4 cycles)
+	printf(" \"analytic_mad_peak_at_sustained_clock\": %.4e,\n", (double)cus * 4.0 * 16.0 * f[0] * 1e6);
 	printf(" \"v_mad_u64_u32_dependent_latency_cycles\": %.2f}\n", dep_cycles);
 	hipFree(d_out);
 	return 0;

@@ -943,6 +943,9 @@ int orc_ecdsa_sign_batch(const orc_curve *c, uint32_t n, const uint8_t *privs,
 		if (nn_iszero(k, c->q_n) || nn_cmp(k, c->q, c->q_n) >= 0) {
 			continue;
 		}
+		if (nn_cmp(x, c->q, c->q_n) >= 0) {
+			continue;   /* __ecdsa_sign_init: MUST_HAVE(x < q) (sig/ecdsa_common.c:367-371) */
+		}
 		if (digest_to_e(e, digests + (size_t)i * hsize, hsize, c)) {
 			continue;
 		}
@@ -1146,7 +1149,9 @@ int orc_xdh_batch(const orc_curve *c, uint32_t len, uint32_t n, const uint8_t *k
  *       (fp_init_from_buf), x^2 = (1 - y^2) / (a - d y^2) (aff_pt_edwards_x_from_y,
  *       curves/aff_pt_edwards.c:816-850), fp_sqrt error when there is no root, root with lsb == sign,
  *       (x == 0 && sign == 1) rejected;
- *     aff_pt_edwards_to_montgomery (curves/aff_pt_edwards.c:520-614): (0, 1) rejected, fp_inv(0) = -1
+ *     aff_pt_edwards_to_prj_pt_shortw (curves/prj_pt.c:1952-2000): the neutral element (0, 1) becomes the point at
+ *       infinity and the call SUCCEEDS (:1976-1982) -- a key is then rejected as small-order, but a signature's R is
+ *       taken as infinity; otherwise aff_pt_edwards_to_montgomery (curves/aff_pt_edwards.c:520-614): fp_inv(0) = -1
  *       rejects (0, -1); u = (1 + y) / (1 - y), v = alpha_edwards u / x;
  *     aff_pt_montgomery_to_shortw (curves/aff_pt_montgomery.c:445-490): X = u / B + A / (3 B), Y = v / B
  *       with B = 1;
@@ -1185,7 +1190,13 @@ static int ed_decode_to_shortw(pt *out, const u8 *enc, const orc_curve *c, const
 	fp_sub(s2, zero, s1, f);
 	nn_copy(x, ((int)(s1[0] & 1) == x0) ? s1 : s2, n);
 	if (nn_iszero(x, n) && x0 == 1) return -1;
-	if (nn_iszero(x, n)) return -1;             /* (0, 1) rejected; (0, -1): fp_inv(x) fails */
+	if (nn_iszero(x, n)) {
+		if (nn_cmp(y, one, n) != 0) return -1;  /* (0, -1): fp_inv(x) fails */
+		nn_zero(out->X, n);                     /* (0, 1) -> (0 : 1 : 0), the call succeeds (curves/prj_pt.c:1976-1982) */
+		nn_copy(out->Y, one, n);
+		nn_zero(out->Z, n);
+		return 0;
+	}
 	fp_sub(t, one, y, f);
 	fp_pow_pm2(t, t, f);
 	fp_add(u, one, y, f);
@@ -1497,7 +1508,13 @@ static int ed448_decode_to_shortw(pt *out, const u8 *enc, const orc_curve *c, co
 		if (nn_cmp(l, r, n) != 0) return -1;
 	}
 	/* Edwards -> Montgomery -> Weierstrass */
-	if (nn_iszero(X, n)) return -1;               /* (0, 1) rejected; (0, -1): fp_inv(x) fails */
+	if (nn_iszero(X, n)) {
+		if (nn_cmp(Y, one, n) != 0) return -1;    /* (0, -1): fp_inv(x) fails */
+		nn_zero(out->X, n);                       /* (0, 1) -> the point at infinity, the call succeeds */
+		nn_copy(out->Y, one, n);
+		nn_zero(out->Z, n);
+		return 0;
+	}
 	fp_sub(t, one, Y, f);
 	if (nn_iszero(t, n)) return -1;
 	fp_pow_pm2(t, t, f);
@@ -1613,6 +1630,116 @@ int orc_eddsa448_verify_batch(const orc_curve *c, uint32_t n, const uint8_t *pub
 		if (pt_add(&T1, &T1, &T2, c)) continue;
 		if (pt_unprotected_mult(&T2, cof, 1, &T1, c)) continue;
 		result[i] = nn_iszero(T2.Z, f->n) ? 0 : 1;
+	}
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * aff_pt_y_from_x (curves/aff_pt.c:102-131): y1, y2 = fp_sqrt(x^3 + a x + b); fp_sqrt (fp/fp_sqrt.c:107-251) restated:
+ *   n = 0 -> (0, 0);  Legendre symbol != 1 -> error (:160-164, legendre() = n^((p-1)/2));
+ *   p - 1 = q 2^s (:165-182);  s = 1 -> r = n^((p+1)/4) (:184-192);
+ *   z = the first non-residue counting up from 0 (:195-199), c = z^q;  r = n^((q+1)/2), t = n^q, m = s (:201-206);
+ *   loop (:209-250): t = 1 -> (r, p - r);  i = least i in (0, m) with t^(2^i) = 1 (i reaching m: error -2);
+ *   b = c^(2^(m-i-1)), r = r b, c = b^2, t = t c, m = i.
+ * x: n x clen big-endian (x >= p: fp_init_from_buf fails), y1 / y2: n x clen, status 0 / 1.
+ * ---------------------------------------------------------------------------------- */
+static void nn_shr1(u64 *a, int n)
+{
+	int i;
+	for (i = 0; i < n; i++) a[i] = (a[i] >> 1) | ((i + 1 < n) ? (a[i + 1] << 63) : 0);
+}
+
+static int fp_legendre(const u64 *x, const orc_fp_ctx *f)   /* 1, 0, -1 */
+{
+	u64 e[ORC_MAXW], one[ORC_MAXW], r[ORC_MAXW];
+	const int n = f->n;
+	nn_zero(one, n); one[0] = 1;
+	nn_sub(e, f->p, one, n);
+	nn_shr1(e, n);
+	fp_pow(r, x, e, n, f);
+	if (nn_iszero(r, n)) return 0;
+	return nn_cmp(r, one, n) == 0 ? 1 : -1;
+}
+
+static int fp_sqrt_ts(u64 *s1, u64 *s2, const u64 *nv, const orc_fp_ctx *f)
+{
+	u64 q[ORC_MAXW], one[ORC_MAXW], zero[ORC_MAXW], e[ORC_MAXW], z[ORC_MAXW], c[ORC_MAXW], r[ORC_MAXW], t[ORC_MAXW], b[ORC_MAXW],
+	    tmp[ORC_MAXW];
+	const int n = f->n;
+	int s = 0, m, i, k;
+	nn_zero(one, n); one[0] = 1;
+	nn_zero(zero, n);
+	if (nn_iszero(nv, n)) {
+		nn_zero(s1, n);
+		nn_zero(s2, n);
+		return 0;
+	}
+	if (fp_legendre(nv, f) != 1) return -1;
+	nn_sub(q, f->p, one, n);
+	do {
+		nn_shr1(q, n);
+		s++;
+	} while (!(q[0] & 1));
+	if (s == 1) {
+		nn_add(e, f->p, one, n);
+		nn_shr1(e, n);
+		nn_shr1(e, n);
+		fp_pow(s1, nv, e, n, f);
+		fp_sub(s2, zero, s1, f);
+		return 0;
+	}
+	nn_zero(z, n);
+	while (fp_legendre(z, f) != -1) {
+		nn_add(z, z, one, n);
+	}
+	fp_pow(c, z, q, n, f);
+	nn_add(e, q, one, n);
+	nn_shr1(e, n);
+	fp_pow(r, nv, e, n, f);
+	fp_pow(t, nv, q, n, f);
+	m = s;
+	for (;;) {
+		if (nn_cmp(t, one, n) == 0) {
+			nn_copy(s1, r, n);
+			fp_sub(s2, zero, s1, f);
+			return 0;
+		}
+		i = 1;
+		nn_copy(tmp, t, n);
+		for (;;) {
+			fp_mul(tmp, tmp, tmp, f);
+			if (nn_cmp(tmp, one, n) == 0) break;
+			i++;
+			if (i == m) return -2;
+		}
+		nn_copy(b, c, n);
+		for (k = 0; k < m - i - 1; k++) fp_mul(b, b, b, f);
+		fp_mul(r, r, b, f);
+		fp_mul(c, b, b, f);
+		fp_mul(t, t, c, f);
+		m = i;
+	}
+}
+
+int orc_y_from_x_batch(const orc_curve *c, uint32_t n, const uint8_t *xs, uint8_t *y1, uint8_t *y2, uint8_t *status)
+{
+	const orc_fp_ctx *f = &c->fp;
+	uint32_t i;
+	for (i = 0; i < n; i++) {
+		u64 x[ORC_MAXW], t[ORC_MAXW], u[ORC_MAXW], r1[ORC_MAXW], r2[ORC_MAXW];
+		status[i] = 1;
+		memset(y1 + (size_t)i * c->clen, 0, (size_t)c->clen);
+		memset(y2 + (size_t)i * c->clen, 0, (size_t)c->clen);
+		if (fp_from_be(x, xs + (size_t)i * c->clen, c->clen, f)) continue;
+		fp_mul(t, x, x, f);
+		fp_mul(t, t, x, f);
+		fp_mul(u, x, c->a, f);
+		fp_add(t, t, u, f);
+		fp_add(t, t, c->b, f);
+		if (fp_sqrt_ts(r1, r2, t, f)) continue;
+		nn_to_be(y1 + (size_t)i * c->clen, c->clen, r1, f->n);
+		nn_to_be(y2 + (size_t)i * c->clen, c->clen, r2, f->n);
+		status[i] = 0;
 	}
 	return 0;
 }

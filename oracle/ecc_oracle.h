@@ -60,4 +60,5 @@ int orc_prj_batch(const orc_curve *c, uint32_t n, const uint8_t *scalars, uint32
 		  uint8_t *out, uint8_t *status);
 int orc_eddsa448_verify_batch(const orc_curve *c, uint32_t n, const uint8_t *pubs, const uint8_t *sigs,
 			      const uint8_t *hram, uint32_t hlen, uint8_t *result);
+int orc_y_from_x_batch(const orc_curve *c, uint32_t n, const uint8_t *xs, uint8_t *y1, uint8_t *y2, uint8_t *status);
 #endif

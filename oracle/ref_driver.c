@@ -725,3 +725,91 @@ int refdrv_eddsa_verify_batch_all(int is448, int use_scratch, uint32_t n, const 
 	free(keys); free(kp); free(sp); free(mp); free(sl); free(ml); free(ad); free(al);
 	return 0;
 }
+
+/* ---- aff_pt_y_from_x (curves/aff_pt.c:102): the two square roots of x^3 + a x + b in the order fp_sqrt returns them ---- */
+int refdrv_y_from_x_batch(const char *curve, uint32_t n, const uint8_t *xs, uint8_t *y1, uint8_t *y2, uint8_t *status)
+{
+	ec_params params;
+	uint32_t i, clen;
+	if (load_params(curve, &params)) {
+		return -1;
+	}
+	clen = (uint32_t)BYTECEIL(params.ec_fp.p_bitlen);
+	for (i = 0; i < n; i++) {
+		fp x, r1, r2;
+		int ret;
+		status[i] = 1;
+		memset(y1 + (size_t)i * clen, 0, clen);
+		memset(y2 + (size_t)i * clen, 0, clen);
+		ret = fp_init_from_buf(&x, &params.ec_fp, xs + (size_t)i * clen, (u16)clen);
+		if (ret) {
+			continue;
+		}
+		ret = fp_init(&r1, &params.ec_fp) || fp_init(&r2, &params.ec_fp) || aff_pt_y_from_x(&r1, &r2, &x, &params.ec_curve);
+		if (ret) {
+			continue;
+		}
+		ret = fp_export_to_buf(y1 + (size_t)i * clen, (u16)clen, &r1) || fp_export_to_buf(y2 + (size_t)i * clen, (u16)clen, &r2);
+		status[i] = ret ? 1 : 0;
+	}
+	return 0;
+}
+
+/* ---- ec_structured_key_pair_import_from_priv_key_buf (sig/ec_key.c:443) + ec_pub_key_export_to_aff_buf ----
+ * status 0 ok (pub_aff = the affine public key), 1 the import failed, 2 the public key is the point at infinity */
+int refdrv_structured_key_pair_batch(const char *curve, int alg, uint32_t n, const uint8_t *keys, uint32_t klen, uint8_t *priv_out,
+				     uint8_t *pub_aff, uint8_t *status)
+{
+	ec_params params;
+	uint32_t i, clen, qlen;
+	if (load_params(curve, &params)) {
+		return -1;
+	}
+	clen = (uint32_t)BYTECEIL(params.ec_fp.p_bitlen);
+	qlen = (uint32_t)BYTECEIL(params.ec_gen_order_bitlen);
+	for (i = 0; i < n; i++) {
+		ec_key_pair kp;
+		int ret, iszero = 0;
+		status[i] = 1;
+		memset(pub_aff + (size_t)i * 2 * clen, 0, 2 * clen);
+		memset(priv_out + (size_t)i * qlen, 0, qlen);
+		ret = ec_structured_key_pair_import_from_priv_key_buf(&kp, &params, keys + (size_t)i * klen, (u8)klen, (ec_alg_type)alg);
+		if (ret) {
+			continue;
+		}
+		if (nn_export_to_buf(priv_out + (size_t)i * qlen, (u16)qlen, &kp.priv_key.x) || prj_pt_iszero(&kp.pub_key.y, &iszero)) {
+			continue;
+		}
+		if (iszero) {
+			status[i] = 2;
+			continue;
+		}
+		ret = ec_pub_key_export_to_aff_buf(&kp.pub_key, pub_aff + (size_t)i * 2 * clen, (u8)(2 * clen));
+		status[i] = ret ? 1 : 0;
+	}
+	return 0;
+}
+
+/* ---- ec_structured_sig_import_from_buf (sig/sig_algs.c:702): the three header bytes it hands back + the raw signature ---- */
+int refdrv_structured_sig_batch(uint32_t n, const uint8_t *in, uint32_t in_len, uint8_t *raw, uint8_t *hdr, uint8_t *status)
+{
+	uint32_t i;
+	for (i = 0; i < n; i++) {
+		ec_alg_type st = UNKNOWN_ALG;
+		hash_alg_type ht = UNKNOWN_HASH_ALG;
+		u8 name[MAX_CURVE_NAME_LEN];
+		ec_curve_type ct = UNKNOWN_CURVE;
+		u32 l = 0;
+		int ret = ec_structured_sig_import_from_buf(raw + (size_t)i * (in_len - 3), in_len - 3, in + (size_t)i * in_len, in_len, &st, &ht, name);
+		status[i] = ret ? 1 : 0;
+		hdr[3 * i] = hdr[3 * i + 1] = hdr[3 * i + 2] = 0;
+		if (!ret) {
+			local_strlen((const char *)name, &l);
+			ret = ec_get_curve_type_by_name(name, (u8)(l + 1), &ct);
+			hdr[3 * i] = (uint8_t)st;
+			hdr[3 * i + 1] = (uint8_t)ht;
+			hdr[3 * i + 2] = (uint8_t)ct;
+		}
+	}
+	return 0;
+}

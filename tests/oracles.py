@@ -29,6 +29,11 @@ def curves():
 CURVES = curves()
 
 
+def curve_type(curve):
+    """libecc's ec_curve_type of a built-in curve (the byte structured keys / signatures carry)"""
+    return int(CURVES[curve]["type"])
+
+
 def clen(curve):
     return (CURVES[curve]["p"].bit_length() + 7) // 8
 
@@ -140,6 +145,12 @@ class Oracle:
         assert self.L.orc_prj_batch(self.ctx, n, scalars, slen, points, out, st) == 0
         return out.raw[:3 * self.clen * n], st.raw[:n]
 
+    def y_from_x(self, xs):
+        n = len(xs) // self.clen
+        y1, y2, st = C.create_string_buffer(max(1, self.clen * n)), C.create_string_buffer(max(1, self.clen * n)), C.create_string_buffer(max(1, n))
+        assert self.L.orc_y_from_x_batch(self.ctx, n, xs, y1, y2, st) == 0
+        return y1.raw[:self.clen * n], y2.raw[:self.clen * n], st.raw[:n]
+
     def eddsa_verify(self, pubs, sigs, hram, hlen=None):
         """Ed25519 on WEI25519 (hram = SHA-512(dom2 || R || A || PH(M)), 64 bytes) or Ed448 on WEI448
         (hram = SHAKE256(dom4 || R || A || PH(M), 114)), one hash per item"""
@@ -227,6 +238,35 @@ class RefLib:
         st = C.create_string_buffer(n)
         assert self.L.refdrv_ecccdh_batch(self.name, n, privs, peers, sec, st) == 0
         return sec.raw, st.raw
+
+
+def ref_y_from_x(curve, xs):
+    """aff_pt_y_from_x of the unmodified reference: (y1, y2, status)"""
+    L = C.CDLL(REF_SO)
+    cl = clen(curve)
+    n = len(xs) // cl
+    y1, y2, st = C.create_string_buffer(max(1, cl * n)), C.create_string_buffer(max(1, cl * n)), C.create_string_buffer(max(1, n))
+    assert L.refdrv_y_from_x_batch(curve.encode(), n, xs, y1, y2, st) == 0
+    return y1.raw[:cl * n], y2.raw[:cl * n], st.raw[:n]
+
+
+def ref_structured_key_pairs(curve, keys, klen, alg):
+    """ec_structured_key_pair_import_from_priv_key_buf: (private scalars n x qlen, affine public keys, status 0 / 1 / 2)"""
+    L = C.CDLL(REF_SO)
+    cl, ql = clen(curve), qlen(curve)
+    n = len(keys) // klen
+    pv, pb, st = C.create_string_buffer(max(1, ql * n)), C.create_string_buffer(max(1, 2 * cl * n)), C.create_string_buffer(max(1, n))
+    assert L.refdrv_structured_key_pair_batch(curve.encode(), alg, n, keys, klen, pv, pb, st) == 0
+    return pv.raw[:ql * n], pb.raw[:2 * cl * n], st.raw[:n]
+
+
+def ref_structured_sigs(sigs, slen):
+    """ec_structured_sig_import_from_buf: (raw signatures, the three header bytes it hands back per item, status)"""
+    L = C.CDLL(REF_SO)
+    n = len(sigs) // slen
+    raw, hdr, st = C.create_string_buffer(max(1, (slen - 3) * n)), C.create_string_buffer(max(1, 3 * n)), C.create_string_buffer(max(1, n))
+    assert L.refdrv_structured_sig_batch(n, sigs, slen, raw, hdr, st) == 0
+    return raw.raw[:(slen - 3) * n], hdr.raw[:3 * n], st.raw[:n]
 
 
 def ref_xdh(length, k, u):
@@ -422,9 +462,11 @@ def ed_dom2(flag, ctx):
     return b"SigEd25519 no Ed25519 collisions" + bytes([flag, len(ctx)]) + ctx
 
 
-def ed25519_sign(seed, msg, dom=b"", prehash=False, add_R=None, add_A=None):
+def ed25519_sign(seed, msg, dom=b"", prehash=False, add_R=None, add_A=None, r_enc=None):
     """RFC 8032 5.1.6; add_R / add_A (points) shift R or the public key by a torsion point, giving
-    signatures that only the cofactored verification equation accepts.  Returns (A, R || S, hram)."""
+    signatures that only the cofactored verification equation accepts.  r_enc: sign with r = 0 and put these
+    bytes where R goes (an encoding of the neutral element: valid for a verifier that decodes it to infinity).
+    Returns (A, R || S, hram)."""
     hk = hashlib.sha512(seed).digest()
     a = int.from_bytes(hk[:32], "little")
     a = (a & ((1 << 254) - 8)) | (1 << 254)
@@ -438,6 +480,8 @@ def ed25519_sign(seed, msg, dom=b"", prehash=False, add_R=None, add_A=None):
     if add_R is not None:
         R = ed_add(R, add_R)
     Renc = ed_encode(R)
+    if r_enc is not None:
+        r, Renc = 0, bytes(r_enc)
     hram = hashlib.sha512(dom + Renc + Aenc + m).digest()
     S = (r + int.from_bytes(hram, "little") * a) % ED_Q
     return Aenc, Renc + S.to_bytes(32, "little"), hram
@@ -503,9 +547,9 @@ def ed_dom4(flag, ctx):
     return b"SigEd448" + bytes([flag, len(ctx)]) + ctx
 
 
-def ed448_sign(seed, msg, ctx=b"", prehash=False, add_R=None, add_A=None):
-    """RFC 8032 5.2.6; add_R / add_A shift R or the public key by a torsion point.  Returns (A, R || S, hram)
-    with hram = SHAKE256(dom4 || R || A || PH(M), 114)."""
+def ed448_sign(seed, msg, ctx=b"", prehash=False, add_R=None, add_A=None, r_enc=None):
+    """RFC 8032 5.2.6; add_R / add_A shift R or the public key by a torsion point; r_enc as in ed25519_sign.
+    Returns (A, R || S, hram) with hram = SHAKE256(dom4 || R || A || PH(M), 114)."""
     def H(x):
         return hashlib.shake_256(x).digest(114)
     hk = H(seed)
@@ -525,6 +569,8 @@ def ed448_sign(seed, msg, ctx=b"", prehash=False, add_R=None, add_A=None):
     if add_R is not None:
         R = e4_add(R, add_R)
     Renc = e4_encode(R)
+    if r_enc is not None:
+        r, Renc = 0, bytes(r_enc)
     hram = H(dom + Renc + Aenc + m)
     S = (r + int.from_bytes(hram, "little") * a) % E4_Q
     return Aenc, Renc + S.to_bytes(57, "little"), hram

@@ -1,0 +1,149 @@
+"""GPU tests of the wire formats around the hot path: point decompression (aff_pt_y_from_x with the
+reference's Tonelli-Shanks root order), structured signatures and structured private keys -> key pairs, each against the
+unmodified reference binary, the restatement oracle and the recorded reference answers."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracles as O
+from oracles import CURVES, GOLDEN, Oracle, have_ref
+from test_gpu_parity import rand_bytes
+
+pytestmark = pytest.mark.gpu
+
+DECOMP = json.load(open(os.path.join(GOLDEN, "decompress_fixture.json")))
+
+
+@pytest.mark.parametrize("curve", sorted(DECOMP))
+def test_y_from_x_recorded_reference_answers(gpu_ctx, curve):
+    f = DECOMP[curve]
+    cv = gpu_ctx.curve(curve)
+    try:
+        y1, y2, st = cv.y_from_x(bytes.fromhex(f["x"]))
+        assert (y1.hex(), y2.hex(), st.hex()) == (f["y1"], f["y2"], f["status"])
+    finally:
+        cv.free()
+
+
+@pytest.mark.parametrize("curve", ["SECP224R1", "SECP256R1", "SECP256K1", "BRAINPOOLP320R1", "SECP384R1", "SECP521R1", "WEI25519", "WEI448"])
+def test_y_from_x_and_decompression(gpu_ctx, curve):
+    """4096 random x (about half of them on the curve) + edge values against the oracle and the reference binary; SEC 1
+    decompression of compressed valid points gives the points back, bad prefixes / x >= p / non-residues are errors"""
+    rng = np.random.default_rng(81)
+    o = Oracle(curve)
+    c = CURVES[curve]
+    p, cl = c["p"], o.clen
+    n = 4096
+    raw = rng.integers(0, 256, size=(n, cl + 8), dtype=np.uint8)
+    vals = [int.from_bytes(raw[i].tobytes(), "big") % p for i in range(n)]
+    vals[:6] = [0, 1, p - 1, p, min(p + 5, (1 << (8 * cl)) - 1), c["gx"]]
+    xs = b"".join(v.to_bytes(cl, "big") for v in vals)
+    cv = gpu_ctx.curve(curve)
+    try:
+        got = cv.y_from_x(xs)
+        assert got == o.y_from_x(xs)
+        if have_ref():
+            k = 512
+            assert tuple(x[:cl * k] if len(x) > k else x[:k] for x in got) == tuple(
+                x[:cl * k] if len(x) > k else x[:k] for x in O.ref_y_from_x(curve, xs[:cl * k]))
+        assert 0.3 * n < got[2].count(0) < 0.7 * n
+        # compress -> decompress
+        sc = rand_bytes(rng, o.qlen * 600)
+        pts, st = cv.scalar_mult(sc)
+        pts = b"".join(pts[2 * cl * i:2 * cl * (i + 1)] for i in range(600) if st[i] == 0)
+        m = len(pts) // (2 * cl)
+        comp = b"".join(bytes([2 + (pts[2 * cl * i + 2 * cl - 1] & 1)]) + pts[2 * cl * i:2 * cl * i + cl] for i in range(m))
+        out, st = cv.decompress(comp)
+        assert st == bytes(m) and out == pts
+        # the other parity gives the negated point; prefixes other than 02 / 03 and x >= p are errors
+        flip = bytearray(comp)
+        for i in range(m):
+            flip[(cl + 1) * i] ^= 1
+        out2, st2 = cv.decompress(bytes(flip))
+        assert st2 == bytes(m)
+        for i in range(0, m, 37):
+            y = int.from_bytes(pts[2 * cl * i + cl:2 * cl * (i + 1)], "big")
+            assert int.from_bytes(out2[2 * cl * i + cl:2 * cl * (i + 1)], "big") == (p - y) % p
+        bad = bytearray(comp[:(cl + 1) * 8])
+        bad[0] = 4
+        bad[cl + 1] = 0
+        bad[2 * (cl + 1)] = 0x82
+        bad[3 * (cl + 1) + 1:4 * (cl + 1)] = p.to_bytes(cl, "big")
+        out3, st3 = cv.decompress(bytes(bad))
+        assert list(st3[:4]) == [1, 1, 1, 1] and list(st3[4:]) == [0] * 4 and out3[:4 * 2 * cl] == bytes(4 * 2 * cl)
+    finally:
+        cv.free()
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref/libecc_ref.so not built")
+@pytest.mark.parametrize("curve,alg", [("SECP256R1", 1), ("BRAINPOOLP384R1", 1), ("SECP521R1", 14)])
+def test_structured_private_keys_to_key_pairs(gpu_ctx, curve, alg):
+    """ec_structured_key_pair_import_from_priv_key_buf in batch: header checks, x < q, Y = [x]G -- private scalars, public
+    keys (compared in affine form) and status against the unmodified reference"""
+    rng = np.random.default_rng(82)
+    o = Oracle(curve)
+    c = CURVES[curve]
+    q, ql, cl = c["q"], o.qlen, o.clen
+    ctype = O.curve_type(curve)
+    n = 300
+    xs = [int.from_bytes(rand_bytes(rng, ql + 8), "big") % q for _ in range(n)]
+    xs[:6] = [0, 1, q - 1, q, q + 1, (1 << (8 * ql)) - 1]
+    keys = bytearray()
+    for i, x in enumerate(xs):
+        keys += bytes([1, alg, ctype]) + x.to_bytes(ql, "big")
+    klen = 3 + ql
+    keys[10 * klen] = 0            # EC_PUBKEY where EC_PRIVKEY is expected
+    keys[11 * klen + 1] ^= 2       # another algorithm
+    keys[12 * klen + 2] ^= 1       # another curve
+    cv = gpu_ctx.curve(curve)
+    try:
+        pv, pb, st = cv.structured_key_pairs(bytes(keys), klen, alg)
+        rpv, rpb, rst = O.ref_structured_key_pairs(curve, bytes(keys), klen, alg)
+        assert st == rst and pv == rpv
+        assert list(st[:6]) == [2, 0, 0, 1, 1, 1] and list(st[10:13]) == [1, 1, 1]
+        for i in range(n):
+            rec = pb[3 * cl * i:3 * cl * (i + 1)]
+            if st[i] == 0:
+                assert rec[:2 * cl] == rpb[2 * cl * i:2 * cl * (i + 1)] and int.from_bytes(rec[2 * cl:], "big") == 1
+            elif st[i] == 2:
+                assert int.from_bytes(rec[:cl], "big") == 0 and int.from_bytes(rec[2 * cl:], "big") == 0 and any(rec[cl:2 * cl])
+        # the exported keys verify what the exported scalars sign
+        dg = rand_bytes(rng, 32 * n)
+        ks = b"".join((int.from_bytes(rand_bytes(rng, ql + 8), "big") % (q - 1) + 1).to_bytes(ql, "big") for _ in range(n))
+        sigs, sst = cv.ecdsa_sign(pv, ks, dg, 32)
+        res = cv.ecdsa_verify_fmt(pb, 1, sigs, dg, 32)
+        for i in range(n):
+            if st[i] == 0 and sst[i] == 0:
+                assert res[i] == 0
+    finally:
+        cv.free()
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref/libecc_ref.so not built")
+def test_structured_signatures(gpu_ctx):
+    """the 3 header bytes of ec_structured_sig_export_to_buf (algorithm, hash, curve) checked and stripped, against what
+    ec_structured_sig_import_from_buf hands back"""
+    rng = np.random.default_rng(83)
+    curve = "SECP256R1"
+    ctype = O.curve_type(curve)
+    n, sl = 64, 64
+    recs = bytearray()
+    for i in range(n):
+        recs += bytes([1, 2, ctype]) + rand_bytes(rng, sl)      # ECDSA = 1, SHA256 = 2 in libecc's enums
+    recs[5 * (sl + 3)] = 3
+    recs[6 * (sl + 3) + 1] = 5
+    recs[7 * (sl + 3) + 2] ^= 1
+    cv = gpu_ctx.curve(curve)
+    try:
+        raw, st = cv.structured_sigs(bytes(recs), sl + 3, 1, 2)
+        rraw, hdr, rst = O.ref_structured_sigs(bytes(recs), sl + 3)
+        for i in range(n):
+            same = rst[i] == 0 and hdr[3 * i:3 * i + 3] == bytes([1, 2, ctype])
+            assert st[i] == (0 if same else 1)
+            if same:
+                assert raw[sl * i:sl * (i + 1)] == rraw[sl * i:sl * (i + 1)]
+        assert list(st[5:8]) == [1, 1, 1] and st.count(1) == 3
+    finally:
+        cv.free()

@@ -271,3 +271,111 @@ def test_ecdsa_verify_with_projective_keys(gpu_ctx, curve):
         assert cv.ecdsa_verify_fmt(pubs, 0, sigs, dg, hl) == cv.ecdsa_verify(pubs, sigs, dg, hl)
     finally:
         cv.free()
+
+
+@pytest.mark.parametrize("curve", ["SECP256R1", "SECP384R1", "BRAINPOOLP256R1"])
+def test_ecdsa_sign_rejects_private_key_not_below_q(gpu_ctx, curve):
+    """__ecdsa_sign_init fails on x >= q (sig/ecdsa_common.c:367-371): status 1, not a signature under x mod q"""
+    from oracles import RefLib, have_ref
+    import hashlib
+    rng = np.random.default_rng(75)
+    o = Oracle(curve)
+    q, ql = CURVES[curve]["q"], o.qlen
+    top = (1 << (8 * ql)) - 1
+    xs = [1, 2, q - 1, q, q + 1, min(top, 2 * q - 1), top] + [int.from_bytes(rand_bytes(rng, ql), "big") % (q - 1) + 1 for _ in range(9)]
+    privs = b"".join(x.to_bytes(ql, "big") for x in xs)
+    n = len(xs)
+    ks = b"".join((int.from_bytes(rand_bytes(rng, ql + 8), "big") % (q - 1) + 1).to_bytes(ql, "big") for _ in range(n))
+    msgs = rand_bytes(rng, 20 * n)
+    dg = b"".join(hashlib.sha256(msgs[20 * i:20 * i + 20]).digest() for i in range(n))
+    cv = gpu_ctx.curve(curve)
+    try:
+        got = cv.ecdsa_sign(privs, ks, dg, 32)
+        assert got == o.ecdsa_sign(privs, ks, dg, 32)
+        assert list(got[1][:7]) == [0, 0, 0, 1, 1, 1 if 2 * q - 1 <= top else 1, 1]
+        if have_ref():
+            rs, _, rst = RefLib(curve).ecdsa_sign("SHA256", privs, ks, msgs, 20)
+            assert rst == got[1] and rs == got[0]
+    finally:
+        cv.free()
+
+
+@pytest.mark.parametrize("curve", ["SECP256R1", "SECP384R1", "WEI25519", "SECP521R1"])
+def test_blinded_scalar_mult(gpu_ctx, curve):
+    """ec_prj_pt_mul_blind_batch multiplies by m + b #E (prj_pt_mul_blind, curves/prj_pt.c:1782-1822): same points as the plain
+    multiplication for every b in [1, #E); b = 0 and b >= #E are refused; on secp256r1 the ~2|q|-bit scalar stays on the
+    radix-2^29 window kernel (k_p256_loop<17>), whose long-scalar recoding is also exercised directly with edge scalars"""
+    rng = np.random.default_rng(76)
+    o = Oracle(curve)
+    c = CURVES[curve]
+    q, order, ql, cl = c["q"], c["order"], o.qlen, o.clen
+    ol = (order.bit_length() + 7) // 8
+    n = 200
+    sc = rand_bytes(rng, ql * n)
+    cv = gpu_ctx.curve(curve)
+    try:
+        base, st = cv.scalar_mult(rand_bytes(rng, ql * n))
+        assert set(st) <= {0, 2}
+        base = b"".join(base[2 * cl * i:2 * cl * (i + 1)] if st[i] == 0 else base[:2 * cl] for i in range(n))
+        bl = [int.from_bytes(rand_bytes(rng, ol + 8), "big") % (order - 1) + 1 for _ in range(n)]
+        bl[:6] = [1, 2, order - 1, order - 2, 1 << (8 * ol - 9), 3]
+        blinds = b"".join(b.to_bytes(ol, "big") for b in bl)
+        exp_v, exp_f = cv.scalar_mult(sc, base), cv.scalar_mult(sc)
+        assert cv.scalar_mult_blind(sc, blinds, base, ql, ol) == exp_v == o.scalar_mult(sc, base)
+        assert cv.scalar_mult_blind(sc, blinds, None, ql, ol) == exp_f
+        bad = bytearray(blinds)
+        bad[0:ol] = bytes(ol)                                   # b = 0
+        bad[ol:2 * ol] = order.to_bytes(ol, "big")              # b = #E
+        bad[2 * ol:3 * ol] = b"\xff" * ol                       # b > #E
+        got = cv.scalar_mult_blind(sc, bytes(bad), base, ql, ol)
+        assert list(got[1][:3]) == [1, 1, 1] and got[0][:3 * 2 * cl] == bytes(3 * 2 * cl)
+        assert got[0][3 * 2 * cl:] == exp_v[0][3 * 2 * cl:] and got[1][3:] == exp_v[1][3:]
+        # long scalars given directly (what the blinding produces), incl. edge values, against the oracle
+        for slen in (ql + 1, ql + ol + 1, 2 * ql + 3):
+            if slen > 68 and curve == "SECP256R1":
+                continue
+            vals = [0, 1, q, q + 1, (1 << (8 * slen)) - 1, 5 * q, order * 7 + 3, 1 << (8 * slen - 1)]
+            vals += [int.from_bytes(rand_bytes(rng, slen), "big") for _ in range(24)]
+            ss = b"".join((v & ((1 << (8 * slen)) - 1)).to_bytes(slen, "big") for v in vals)
+            k = len(vals)
+            assert cv.scalar_mult(ss, base[:2 * cl * k], slen) == o.scalar_mult(ss, base[:2 * cl * k], slen), slen
+            assert cv.scalar_mult(ss, None, slen) == o.scalar_mult(ss, None, slen), slen
+    finally:
+        cv.free()
+
+
+def test_secret_scalar_mode_gives_identical_results():
+    """ecamd_ctx_set_secret_scalars: constant-address (masked full-scan) table look-ups on the complete-formula kernel for
+    every scalar multiplication of the context -- scalar mult (fixed and variable base, edge scalars), ECDSA signing, ECC-CDH,
+    Ed25519 signing step R, key-pair import -- same bytes as the default mode"""
+    rng = np.random.default_rng(77)
+    ctx_s, ctx_d = libecc_amd.Context(0), libecc_amd.Context(0)
+    ctx_s.set_secret_scalars(True)
+    try:
+        for curve in ("SECP256R1", "BRAINPOOLP256R1", "SECP384R1", "WEI25519"):
+            o = Oracle(curve)
+            q, ql, cl = CURVES[curve]["q"], o.qlen, o.clen
+            n = 96
+            cs, cd = ctx_s.curve(curve), ctx_d.curve(curve)
+            try:
+                vals = [0, 1, 2, q - 1, q, q + 1, (1 << (8 * ql)) - 1] + [int.from_bytes(rand_bytes(rng, ql), "big") for _ in range(n - 7)]
+                sc = b"".join(v.to_bytes(ql, "big") for v in vals)
+                assert cs.scalar_mult(sc) == cd.scalar_mult(sc) == o.scalar_mult(sc)
+                base, st = cd.scalar_mult(rand_bytes(rng, ql * n))
+                assert cs.scalar_mult(sc, base) == cd.scalar_mult(sc, base)
+                privs = b"".join((int.from_bytes(rand_bytes(rng, ql + 8), "big") % (q - 1) + 1).to_bytes(ql, "big") for _ in range(n))
+                ks = b"".join((int.from_bytes(rand_bytes(rng, ql + 8), "big") % (q - 1) + 1).to_bytes(ql, "big") for _ in range(n))
+                dg = rand_bytes(rng, 32 * n)
+                assert cs.ecdsa_sign(privs, ks, dg, 32) == cd.ecdsa_sign(privs, ks, dg, 32) == o.ecdsa_sign(privs, ks, dg, 32)
+                assert cs.ecccdh(privs, base) == cd.ecccdh(privs, base)
+                if curve == "WEI25519":
+                    rh = rand_bytes(rng, 64 * n)
+                    assert cs.eddsa_sign_R(rh) == cd.eddsa_sign_R(rh)
+                    k, u = rand_bytes(rng, 32 * n), (9).to_bytes(32, "little") * n
+                    assert cs.xdh(k, u) == cd.xdh(k, u)
+            finally:
+                cs.free()
+                cd.free()
+    finally:
+        ctx_s.close()
+        ctx_d.close()

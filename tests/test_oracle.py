@@ -367,6 +367,15 @@ def ed25519_cases(rng, nvalid=12):
         items.append(signed(add_R=tp))           # accepted: [8] kills the torsion part of R
         items.append(signed(add_A=tp))           # accepted: mixed-order public key
         items.append(signed(add_R=tp, add_A=t8))
+    # r = 0: R is the neutral element (0, 1), which the reference decodes to the point at infinity and goes on with
+    # (curves/prj_pt.c:1976-1982): S = h a verifies.  Valid twice, then spoiled in S and in the message.
+    neutral = (1).to_bytes(32, "little")
+    items.append(signed(r_enc=neutral))
+    items.append(signed(r_enc=neutral, add_A=t8))
+    items.append(signed(r_enc=neutral))
+    items[-1][1][40] ^= 1
+    items.append(signed(r_enc=neutral))
+    items[-1][2][0] ^= 1
     def mod(fn):
         it = signed()
         fn(it)
@@ -602,6 +611,12 @@ def ed448_cases(rng, nvalid=8):
         items.append(signed(add_R=tp))
         items.append(signed(add_A=tp))
         items.append(signed(add_R=tp, add_A=t4))
+    # r = 0: both (0, 1) and (0, -1) of Ed448 land on the neutral element of the model libecc computes on (the 4-isogeny
+    # sends x = 0 to (0, 1)), which becomes the point at infinity: S = h a verifies under either encoding of R
+    for enc in ((1).to_bytes(57, "little"), (P - 1).to_bytes(57, "little")):
+        items.append(signed(r_enc=enc))
+        items.append(signed(r_enc=enc))
+        items[-1][1][70] ^= 1
 
     def mod(fn):
         it = signed()
@@ -783,3 +798,39 @@ def test_oracle_vs_reference_property():
         assert o.scalar_mult(scalar, None, len(scalar)) == r.scalar_mult(scalar, None, len(scalar))
 
     check()
+
+
+# ---------------------------------------------------------------------------------------------
+# point decompression: aff_pt_y_from_x / fp_sqrt (Tonelli-Shanks with the reference's choice of roots)
+# ---------------------------------------------------------------------------------------------
+DECOMP = json.load(open(os.path.join(GOLDEN, "decompress_fixture.json")))
+
+
+@pytest.mark.parametrize("curve", sorted(DECOMP))
+def test_y_from_x_restatement_vs_recorded_reference(curve):
+    """both roots in fp_sqrt's order and every failure, against the reference's recorded answers (incl. secp224r1, whose
+    p - 1 = q 2^96 takes the full Tonelli-Shanks loop)"""
+    f = DECOMP[curve]
+    o = Oracle(curve)
+    y1, y2, st = o.y_from_x(bytes.fromhex(f["x"]))
+    assert (y1.hex(), y2.hex(), st.hex()) == (f["y1"], f["y2"], f["status"])
+    p, cl = CURVES[curve]["p"], o.clen
+    a, b = CURVES[curve]["a"], CURVES[curve]["b"]
+    xs = bytes.fromhex(f["x"])
+    for i in range(len(st)):
+        x = int.from_bytes(xs[cl * i:cl * (i + 1)], "big")
+        if st[i] == 0:
+            v1, v2 = int.from_bytes(y1[cl * i:cl * (i + 1)], "big"), int.from_bytes(y2[cl * i:cl * (i + 1)], "big")
+            assert v1 * v1 % p == (x ** 3 + a * x + b) % p and (v1 + v2) % p == 0
+        else:
+            assert x >= p or pow((x ** 3 + a * x + b) % p, (p - 1) // 2, p) == p - 1
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref/libecc_ref.so not built")
+@pytest.mark.parametrize("curve", ["SECP224R1", "SECP256R1", "WEI25519", "BRAINPOOLP384R1", "SECP521R1"])
+def test_y_from_x_restatement_vs_reference(curve):
+    rng = np.random.default_rng(41)
+    o = Oracle(curve)
+    p = CURVES[curve]["p"]
+    xs = b"".join((int.from_bytes(rb(rng, o.clen + 8), "big") % p).to_bytes(o.clen, "big") for _ in range(200))
+    assert o.y_from_x(xs) == O.ref_y_from_x(curve, xs)
