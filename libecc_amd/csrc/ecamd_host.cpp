@@ -214,7 +214,7 @@ struct ecamd_ctx {
 	// grow-only scratch
 	uint32_t *tbl;      // complete-formula kernel: 16 x 3 x NW words per item, word-major
 	size_t tbl_bytes;
-	uint32_t *tbl_fast; // secp256r1 fast path: 8 x 28 words per item, item-major
+	uint32_t *tbl_fast; // fast paths: per-item window tables (secp256r1: 512 B affine table + 1120 B staging per item)
 	size_t tbl_fast_bytes;
 	uint8_t *stage[ECAMD_NSTAGE];
 	size_t stage_bytes[ECAMD_NSTAGE];
@@ -1022,6 +1022,10 @@ extern "C" int ecamd_curve_words(const ecamd_curve *cv) { return cv ? cv->nw : -
 // ------------------------------------------------------------------------------------------
 // batched prj_pt_mul
 // ------------------------------------------------------------------------------------------
+// secp256r1 fast path scratch (ecamd_p256_kernel.hip): 8 x 64-byte affine records + 70 x 16-byte staging quads per item
+#define P256_TAB_BYTES 512u
+#define P256_SCRATCH_PER_ITEM ((size_t)P256_TAB_BYTES + 70u * 16u)
+
 static size_t tbl_bytes_for(const ecamd_curve *cv, uint32_t stride)
 {
 	return (size_t)ECAMD_TBL_ENTRIES * 3 * (size_t)cv->nw * 4 * (size_t)stride;
@@ -1130,7 +1134,7 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 	}
 	if (fast) {
 		uint8_t *t = (uint8_t *)ctx->tbl_fast;
-		const size_t per_item = fast256 ? (size_t)8 * 40 * 4 : (size_t)ecamd_g29_table_words(cv->pbits, cv->gflavour) * 4;
+		const size_t per_item = fast256 ? P256_SCRATCH_PER_ITEM : (size_t)ecamd_g29_table_words(cv->pbits, cv->gflavour) * 4;
 		const int rc = ensure(&t, &ctx->tbl_fast_bytes, (size_t)stride * per_item);
 		ctx->tbl_fast = (uint32_t *)t;
 		if (rc) {
@@ -1155,12 +1159,14 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 		A.only_redo = 0;
 		A.lut = nullptr;
 		A.lut_kind = 0;
+		A.stg = nullptr;
 		A.masked = secret ? 1 : 0;
 		if (fast) {
 			// Jacobian fast path; lanes that met an exceptional pair come back as ECAMD_STATUS_REDO and
 			// are recomputed by the complete-formula kernel (all other lanes exit at once)
 			EcamdSmulArgs Fa = A;
 			Fa.tbl = ctx->tbl_fast;
+			Fa.stg = fast256 ? ctx->tbl_fast + (size_t)stride * (P256_TAB_BYTES / 4) : nullptr;
 			// fixed base: a constant table of the generator replaces the per-item table kernels
 			if (!d_points) {
 				const bool use_comb = cv->d_comb && comb_ok;
@@ -1578,7 +1584,7 @@ static int ecdsa_verify_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 	const uint32_t chunk = n < ctx->max_chunk ? n : ctx->max_chunk;
 	{
 		uint8_t *t = (uint8_t *)ctx->tbl_fast;
-		const int rc = ensure(&t, &ctx->tbl_fast_bytes, (size_t)((chunk + 63u) & ~63u) * 8 * 40 * 4);
+		const int rc = ensure(&t, &ctx->tbl_fast_bytes, (size_t)((chunk + 63u) & ~63u) * P256_SCRATCH_PER_ITEM);
 		ctx->tbl_fast = (uint32_t *)t;
 		if (rc) {
 			return -1;
@@ -1613,6 +1619,7 @@ static int ecdsa_verify_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 		K.out = S[7];           // zeroed for rejected keys; otherwise unused
 		K.status = S[7] + (size_t)m * 64;
 		K.tbl = ctx->tbl_fast;
+		K.stg = ctx->tbl_fast + (size_t)((chunk + 63u) & ~63u) * (P256_TAB_BYTES / 4);
 		K.n = m;
 		K.clen = 32;
 		K.slot = cv->slot;

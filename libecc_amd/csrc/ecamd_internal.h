@@ -16,7 +16,8 @@ struct EcamdSmulArgs {
 	const uint8_t *points;   // n x 2*clen affine X||Y big-endian (pstride = 0: one shared point)
 	uint8_t *out;            // n x 2*clen affine X||Y big-endian
 	uint8_t *status;         // n : 0 ok, 1 error, 2 infinity
-	uint32_t *tbl;           // scratch: ECAMD_TBL_ENTRIES x 3 x NW words x stride
+	uint32_t *tbl;           // scratch: ECAMD_TBL_ENTRIES x 3 x NW words x stride (secp256r1 fast path: the affine window tables)
+	uint32_t *stg;           // secp256r1 fast path: staging area (Jacobian multiples, prefix products, loop results)
 	uint32_t n, slen, clen, pstride, stride;
 	uint32_t sstride;        // bytes between consecutive scalars (slen, or 0: one shared scalar)
 	int slot;

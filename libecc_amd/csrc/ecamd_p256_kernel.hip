@@ -11,8 +11,14 @@
 //       k_p256_affine    table -> affine (one inversion per 56 table entries)
 //       k_p256_loop      the window loop, Jacobian result
 //       k_p256_finalize  result -> affine X||Y big-endian (one inversion per 8 items)
-//   * table: per-item contiguous 8 x 40 words in a global scratch buffer; a look-up is 5 x 16-byte
-//     loads and every fetched cache line is fully used by the lane that fetched it.
+//   * scratch, two areas (EcamdSmulArgs.tbl / .stg):
+//       tab  the final AFFINE window table, item-major: 8 entries x 16 words per item, x || y as the canonical Montgomery
+//            residues in eight saturated words each.  A look-up is one 64-byte record -- four 16-byte loads, never
+//            straddling a 128-byte line (two entries per line) -- turned back into nine 29-bit digits on the fly;
+//       stg  staging for the Jacobian multiples 2P..8P, their prefix products and the loop's result: per block of 64 items
+//            (one wave), quad-major / lane-minor -- every 16-byte access of the table, affine and finalisation kernels is
+//            coalesced across the wave (64 x 16 B contiguous), because there all lanes walk the entries in the same order.
+//            Only the window loop looks up entries by a per-lane digit, and it reads tab.
 // Exceptional pairs of the incomplete Jacobian addition (accumulator == +-table entry) cannot be
 // produced by scalars below the group order and random points, but edge scalars (k >= q) can:
 // such a lane is detected exactly (Z3 == 0 with both inputs finite), marked ECAMD_REDO and
@@ -25,8 +31,12 @@ using namespace p256;
 
 typedef uint8_t u8;
 
-#define TBL_WORDS_PER_ENTRY 40   /* build: X Y Z + prefix product (36 words); final: affine x y (18 words) */
+#define TBL_WORDS_PER_ENTRY 40   /* shared tables of the generator (window table, comb): affine x y as 2 x 9 digits, padded */
 #define TBL_ENTRIES 8
+#define TAB_ENT_WORDS 16         /* per-item table: x || y, 8 saturated words each (64 bytes) */
+#define TAB_ITEM_WORDS (TBL_ENTRIES * TAB_ENT_WORDS)
+#define STG_ENT_QUADS 10         /* staging record: X 0-8, Y 9-17, Z 18-26, (27), prefix product 28-36, (37-39) */
+#define STG_ITEM_QUADS (7 * STG_ENT_QUADS)
 #define FIN_K 8                  /* items per lane in k_p256_finalize */
 #ifndef AFF_K
 #define AFF_K 8                  /* items per lane in k_p256_affine (x 7 table entries each); 2/4/8 measured equal */
@@ -93,27 +103,99 @@ static __device__ __forceinline__ bool lt_p(const u32 *w)
 	return borrow != 0;
 }
 
-// ---- table records ----
-static __device__ __forceinline__ void st9(u32 *d, const u32 *l0, const u32 *l1, const u32 *l2, const u32 *l3)
+// ---- staging records (block-of-64 / quad-major / lane-minor) ----
+static __device__ __forceinline__ uint4 *stg_quad(u32 *stg, u32 i, int slot, int q)
 {
-	// up to four 9-limb elements -> 36 words, 16-byte stores
-	u32 b[36];
+	return (uint4 *)stg + ((size_t)(i >> 6) * STG_ITEM_QUADS + (size_t)(slot * STG_ENT_QUADS + q)) * 64 + (i & 63u);
+}
+static __device__ __forceinline__ void jac_store(u32 *stg, u32 i, int slot, const Jac &P)
+{
+	u32 b[28];
 #pragma unroll
-	for (int i = 0; i < 9; i++) {
-		b[i] = l0[i];
-		b[9 + i] = l1 ? l1[i] : 0u;
-		b[18 + i] = l2 ? l2[i] : 0u;
-		b[27 + i] = l3 ? l3[i] : 0u;
+	for (int w = 0; w < 9; w++) {
+		b[w] = P.X.l[w];
+		b[9 + w] = P.Y.l[w];
+		b[18 + w] = P.Z.l[w];
 	}
-	uint4 *q = (uint4 *)d;
-	const int nq = l3 ? 9 : (l2 ? 7 : 5);
+	b[27] = 0;
 #pragma unroll
-	for (int i = 0; i < 9; i++) {
-		if (i < nq) {
-			q[i] = make_uint4(b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]);
-		}
+	for (int q = 0; q < 7; q++) {
+		*stg_quad(stg, i, slot, q) = make_uint4(b[4 * q], b[4 * q + 1], b[4 * q + 2], b[4 * q + 3]);
 	}
 }
+static __device__ __forceinline__ Jac jac_load(u32 *stg, u32 i, int slot)
+{
+	u32 b[28];
+#pragma unroll
+	for (int q = 0; q < 7; q++) {
+		const uint4 v = *stg_quad(stg, i, slot, q);
+		b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+	}
+	Jac P;
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		P.X.l[w] = b[w];
+		P.Y.l[w] = b[9 + w];
+		P.Z.l[w] = b[18 + w];
+	}
+	return P;
+}
+static __device__ __forceinline__ FZ z_load(u32 *stg, u32 i, int slot)
+{
+	u32 b[12];  // quads 4..6 = words 16..27 cover Z = words 18..26
+#pragma unroll
+	for (int q = 0; q < 3; q++) {
+		const uint4 v = *stg_quad(stg, i, slot, 4 + q);
+		b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+	}
+	FZ z;
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		z.l[w] = b[2 + w];
+	}
+	return z;
+}
+static __device__ __forceinline__ void prefix_store(u32 *stg, u32 i, int slot, const Fmul &c)
+{
+	*stg_quad(stg, i, slot, 7) = make_uint4(c.l[0], c.l[1], c.l[2], c.l[3]);
+	*stg_quad(stg, i, slot, 8) = make_uint4(c.l[4], c.l[5], c.l[6], c.l[7]);
+	*stg_quad(stg, i, slot, 9) = make_uint4(c.l[8], 0u, 0u, 0u);
+}
+static __device__ __forceinline__ Fmul prefix_load(u32 *stg, u32 i, int slot)
+{
+	const uint4 a = *stg_quad(stg, i, slot, 7), b = *stg_quad(stg, i, slot, 8), c = *stg_quad(stg, i, slot, 9);
+	Fmul r;
+	r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+	r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+	r.l[8] = c.x;
+	return r;
+}
+
+// ---- per-item affine table records: x || y, eight saturated words each ----
+static __device__ __forceinline__ void tab_store(u32 *tab, u32 i, int e, const Fcanon &x, const Fcanon &y)
+{
+	u32 w[16];
+	to_words(w, x);
+	to_words(w + 8, y);
+	uint4 *d = (uint4 *)(tab + (size_t)i * TAB_ITEM_WORDS + e * TAB_ENT_WORDS);
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		d[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+	}
+}
+static __device__ __forceinline__ void tab_load(const u32 *tab, u32 e, Fcanon &x, Fcanon &y)
+{
+	u32 w[16];
+	const uint4 *s = (const uint4 *)(tab + (size_t)e * TAB_ENT_WORDS);
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		const uint4 v = s[q];
+		w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+	}
+	x = from_words(w);
+	y = from_words(w + 8);
+}
+// entries of the shared tables of the generator: 2 x 9 digits in 20 words
 template <int NQ> static __device__ __forceinline__ void ld(u32 *b, const u32 *s)
 {
 	const uint4 *q = (const uint4 *)s;
@@ -126,19 +208,15 @@ template <int NQ> static __device__ __forceinline__ void ld(u32 *b, const u32 *s
 		b[4 * i + 3] = v.w;
 	}
 }
-static __device__ __forceinline__ void jac_store(u32 *d, const Jac &P) { st9(d, P.X.l, P.Y.l, P.Z.l, nullptr); }
-static __device__ __forceinline__ Jac jac_load(const u32 *s)
+static __device__ __forceinline__ void lut_load(const u32 *lut, size_t e, Fcanon &x, Fcanon &y)
 {
-	u32 b[28];
-	ld<7>(b, s);
-	Jac P;
+	u32 b[20];
+	ld<5>(b, lut + e * TBL_WORDS_PER_ENTRY);
 #pragma unroll
-	for (int i = 0; i < 9; i++) {
-		P.X.l[i] = b[i];
-		P.Y.l[i] = b[9 + i];
-		P.Z.l[i] = b[18 + i];
+	for (int w = 0; w < 9; w++) {
+		x.l[w] = b[w];
+		y.l[w] = b[9 + w];
 	}
-	return P;
 }
 
 template <class T> static __device__ __forceinline__ T sel(bool c, const T &a, const T &b)
@@ -192,29 +270,29 @@ __global__ __launch_bounds__(64) void k_p256_table(EcamdSmulArgs A)
 		zero_out(A.out + (size_t)i * 64);
 		return;
 	}
-	u32 *tb = A.tbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
 	const Fcanon xa = canonical(xm), ya = canonical(ym);
-	st9(tb, xa.l, ya.l, nullptr, nullptr);  // entry 0: P itself, already affine
+	tab_store(A.tbl, i, 0, xa, ya);  // entry 0: P itself, already affine
 	Jac P1;
 	P1.X = weaken<FX>(xm);
 	P1.Y = weaken<FY>(ym);
 	P1.Z = weaken<FZ>(constant<Fcanon>(K::ONE));
 	bool hz;  // no exceptional pair can occur below: the group order is an odd prime > 8
 	const FYaff y1 = weaken<FYaff>(ya);
+	// entries 2P..8P go to staging slots 0..6
 	Jac Pa = dbl(P1);
-	jac_store(tb + 1 * TBL_WORDS_PER_ENTRY, Pa);
+	jac_store(A.stg, i, 0, Pa);
 	Jac Pb = madd(Pa, xa, y1, hz);
-	jac_store(tb + 2 * TBL_WORDS_PER_ENTRY, Pb);
+	jac_store(A.stg, i, 1, Pb);
 	Pa = dbl(Pa);
-	jac_store(tb + 3 * TBL_WORDS_PER_ENTRY, Pa);
+	jac_store(A.stg, i, 2, Pa);
 	Pb = madd(Pa, xa, y1, hz);
-	jac_store(tb + 4 * TBL_WORDS_PER_ENTRY, Pb);
-	Pb = dbl(jac_load(tb + 2 * TBL_WORDS_PER_ENTRY));
-	jac_store(tb + 5 * TBL_WORDS_PER_ENTRY, Pb);
+	jac_store(A.stg, i, 3, Pb);
+	Pb = dbl(jac_load(A.stg, i, 1));
+	jac_store(A.stg, i, 4, Pb);
 	Pb = madd(Pb, xa, y1, hz);
-	jac_store(tb + 6 * TBL_WORDS_PER_ENTRY, Pb);
+	jac_store(A.stg, i, 5, Pb);
 	Pa = dbl(Pa);
-	jac_store(tb + 7 * TBL_WORDS_PER_ENTRY, Pa);
+	jac_store(A.stg, i, 6, Pa);
 	A.status[i] = ECAMD_STATUS_TAB;
 }
 
@@ -225,6 +303,8 @@ __global__ __launch_bounds__(64) void k_p256_table(EcamdSmulArgs A)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_p256_affine(EcamdSmulArgs A, u32 nthreads)
 {
+	// nthreads is a multiple of 64: the AFF_K items of a lane keep its lane index, so a wave's accesses to one staging
+	// slot are 64 consecutive 16-byte words
 	const u32 t = blockIdx.x * 64 + threadIdx.x;
 	if (t >= nthreads) {
 		return;
@@ -239,57 +319,31 @@ __global__ __launch_bounds__(64) void k_p256_affine(EcamdSmulArgs A, u32 nthread
 		if (A.status[i] != ECAMD_STATUS_TAB) {
 			continue;
 		}
-		u32 *tb = A.tbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
 #pragma unroll 1
-		for (int e = 1; e < TBL_ENTRIES; e++) {
-			u32 *ent = tb + e * TBL_WORDS_PER_ENTRY;
-			u32 zb[12];
-			ld<3>(zb, ent + 16);  // words 16..27 cover Z = words 18..26
-			FZ z;
-#pragma unroll
-			for (int w = 0; w < 9; w++) {
-				z.l[w] = zb[2 + w];
-			}
-			// park the prefix before this entry in words 28..36 (16-byte aligned)
-			uint4 *d = (uint4 *)(ent + 28);
-			d[0] = make_uint4(c.l[0], c.l[1], c.l[2], c.l[3]);
-			d[1] = make_uint4(c.l[4], c.l[5], c.l[6], c.l[7]);
-			d[2] = make_uint4(c.l[8], 0u, 0u, 0u);
+		for (int e = 0; e < 7; e++) {
+			const FZ z = z_load(A.stg, i, e);
+			prefix_store(A.stg, i, e, c);  // the prefix BEFORE this entry
 			c = weaken<Fmul>(mul(c, z));
 		}
 	}
 	Fmul tinv = inv(c);
-	Fcanon plain1;
-#pragma unroll
-	for (int w = 0; w < 9; w++) {
-		plain1.l[w] = (w == 0) ? 1u : 0u;
-	}
-	(void)plain1;
 #pragma unroll 1
 	for (int j = AFF_K - 1; j >= 0; j--) {
 		const u32 i = t + (u32)j * nthreads;
 		if (i >= A.n || A.status[i] != ECAMD_STATUS_TAB) {
 			continue;
 		}
-		u32 *tb = A.tbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
 #pragma unroll 1
-		for (int e = TBL_ENTRIES - 1; e >= 1; e--) {
-			u32 *ent = tb + e * TBL_WORDS_PER_ENTRY;
-			const Jac P = jac_load(ent);
-			u32 cb[12];
-			ld<3>(cb, ent + 28);
-			Fmul cbf;
-#pragma unroll
-			for (int w = 0; w < 9; w++) {
-				cbf.l[w] = cb[w];
-			}
+		for (int e = 6; e >= 0; e--) {
+			const Jac P = jac_load(A.stg, i, e);
+			const Fmul cbf = prefix_load(A.stg, i, e);
 			const Fmul zi = weaken<Fmul>(mul(tinv, cbf));
 			tinv = weaken<Fmul>(mul(tinv, P.Z));
 			const Fmul zi2 = weaken<Fmul>(sqr(zi));
 			const Fmul zi3 = weaken<Fmul>(mul(zi2, zi));
 			const Fcanon ax = canonical(mul(P.X, zi2));  // stays in the Montgomery domain
 			const Fcanon ay = canonical(mul(P.Y, zi3));
-			st9(ent, ax.l, ay.l, nullptr, nullptr);
+			tab_store(A.tbl, i, e + 1, ax, ay);
 		}
 	}
 }
@@ -358,8 +412,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 	if (i >= A.n || A.status[i] != ECAMD_STATUS_TAB) {
 		return;
 	}
-	u32 *tb = A.tbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
-	const u32 *lut = A.lut ? A.lut : tb;  // fixed base: one shared table for every lane
+	const u32 *tabi = A.tbl + (size_t)i * TAB_ITEM_WORDS;  // this item's affine table
+	const bool shared = A.lut != nullptr;                 // fixed base: one table of the generator for every lane (wave-uniform)
 	const int slen = (int)A.slen;
 	u32 kw[KW];
 	const u32 carry_bit = recode_window<KW>(kw, A.scalars + (size_t)i * A.sstride, slen);
@@ -367,13 +421,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 	// ---- signed fixed window, left to right; the top digit is the carry: 0 or +1 ----
 	Jac acc;
 	{
-		u32 b[20];
-		ld<5>(b, lut);
-#pragma unroll
-		for (int w = 0; w < 9; w++) {
-			acc.X.l[w] = b[w];
-			acc.Y.l[w] = b[9 + w];
+		Fcanon px, py;
+		if (shared) {
+			lut_load(A.lut, 0, px, py);
+		} else {
+			tab_load(tabi, 0, px, py);
 		}
+		acc.X = weaken<FX>(px);
+		acc.Y = weaken<FY>(py);
 		acc.Z = weaken<FZ>(constant<Fcanon>(K::ONE));
 	}
 	bool inf = (carry_bit == 0);
@@ -393,13 +448,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 		}
 		kw[0] <<= 4;
 		const u32 mag = (u32)(dig < 0 ? -dig : dig);
-		u32 b[20];
-		ld<5>(b, lut + (mag ? mag - 1 : 0) * TBL_WORDS_PER_ENTRY);
 		Fcanon tx, tyc;
-#pragma unroll
-		for (int w = 0; w < 9; w++) {
-			tx.l[w] = b[w];
-			tyc.l[w] = b[9 + w];
+		if (shared) {
+			lut_load(A.lut, mag ? mag - 1 : 0, tx, tyc);
+		} else {
+			tab_load(tabi, mag ? mag - 1 : 0, tx, tyc);
 		}
 		const FYaff ty = sel(dig < 0, neg_aff(tyc), weaken<FYaff>(tyc));
 		const Jac S = madd(acc, tx, ty, hz);
@@ -412,7 +465,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 		acc.Z = sel(keep, acc.Z, sel(use_t, onez, S.Z));
 		inf = inf & keep;
 	}
-	// ---- hand the Jacobian result to k_p256_finalize (entry 1 of the item's table area) ----
+	// ---- hand the Jacobian result to k_p256_finalize (staging slot 0 of the item) ----
 	if (bad) {
 		A.status[i] = ECAMD_STATUS_REDO;  // exceptional pair met: the complete-formula kernel recomputes the item
 		return;
@@ -422,7 +475,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 		zero_out(A.out + (size_t)i * 64);
 		return;
 	}
-	jac_store(tb + 1 * TBL_WORDS_PER_ENTRY, acc);
+	jac_store(A.stg, i, 0, acc);
 	A.status[i] = ECAMD_STATUS_JAC;
 }
 
@@ -551,8 +604,7 @@ __global__ __launch_bounds__(64) void k_p256_comb(EcamdSmulArgs A)
 		zero_out(A.out + (size_t)i * 64);
 		return;
 	}
-	u32 *tb = A.tbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
-	jac_store(tb + 1 * TBL_WORDS_PER_ENTRY, acc);
+	jac_store(A.stg, i, 0, acc);
 	A.status[i] = ECAMD_STATUS_JAC;
 }
 
@@ -561,6 +613,7 @@ __global__ __launch_bounds__(64) void k_p256_comb(EcamdSmulArgs A)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_p256_finalize(EcamdSmulArgs A, u32 nthreads)
 {
+	// nthreads is a multiple of 64 (coalesced staging accesses, as in k_p256_affine)
 	const u32 t = blockIdx.x * 64 + threadIdx.x;
 	if (t >= nthreads) {
 		return;
@@ -572,15 +625,9 @@ __global__ __launch_bounds__(64) void k_p256_finalize(EcamdSmulArgs A, u32 nthre
 		if (i >= A.n) {
 			break;
 		}
-		u32 *tb = A.tbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
-		// park the prefix BEFORE this item in entry 2
-		uint4 *d = (uint4 *)(tb + 2 * TBL_WORDS_PER_ENTRY);
-		d[0] = make_uint4(c.l[0], c.l[1], c.l[2], c.l[3]);
-		d[1] = make_uint4(c.l[4], c.l[5], c.l[6], c.l[7]);
-		d[2] = make_uint4(c.l[8], 0u, 0u, 0u);
+		prefix_store(A.stg, i, 0, c);  // the prefix BEFORE this item
 		if (A.status[i] == ECAMD_STATUS_JAC) {
-			const Jac P = jac_load(tb + 1 * TBL_WORDS_PER_ENTRY);
-			c = weaken<Fmul>(mul(c, P.Z));
+			c = weaken<Fmul>(mul(c, z_load(A.stg, i, 0)));
 		}
 	}
 	Fmul tinv = inv(c);
@@ -595,15 +642,8 @@ __global__ __launch_bounds__(64) void k_p256_finalize(EcamdSmulArgs A, u32 nthre
 		if (i >= A.n || A.status[i] != ECAMD_STATUS_JAC) {
 			continue;
 		}
-		u32 *tb = A.tbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
-		const Jac P = jac_load(tb + 1 * TBL_WORDS_PER_ENTRY);
-		u32 cb[12];
-		ld<3>(cb, tb + 2 * TBL_WORDS_PER_ENTRY);
-		Fmul cbf;
-#pragma unroll
-		for (int w = 0; w < 9; w++) {
-			cbf.l[w] = cb[w];
-		}
+		const Jac P = jac_load(A.stg, i, 0);
+		const Fmul cbf = prefix_load(A.stg, i, 0);
 		const Fmul zi = weaken<Fmul>(mul(tinv, cbf));
 		tinv = weaken<Fmul>(mul(tinv, P.Z));
 		const Fmul zi2 = weaken<Fmul>(sqr(zi));
@@ -669,7 +709,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 		A.result[i] = 1;  // r or s out of range, or public key rejected at import
 		return;
 	}
-	const u32 *tb = A.qtbl + (size_t)i * (TBL_ENTRIES * TBL_WORDS_PER_ENTRY);
+	const u32 *tb = A.qtbl + (size_t)i * TAB_ITEM_WORDS;  // Q's affine table (64-byte records)
 	u32 k1[8], k2[8];
 	const u32 c1 = COMB ? comb_recode(k1, A.u1 + (size_t)i * 32, 32) : recode(k1, A.u1 + (size_t)i * 32);
 	const u32 c2 = recode(k2, A.u2 + (size_t)i * 32);
@@ -678,14 +718,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 	bool inf = true, bad = false, hz;
 	// top digits (carries): acc = c1 G + c2 Q
 	{
-		u32 b[20];
 		Fcanon gx, gy, qx, qy;
-		ld<5>(b, A.gtbl);
-#pragma unroll
-		for (int w = 0; w < 9; w++) { gx.l[w] = b[w]; gy.l[w] = b[9 + w]; }
-		ld<5>(b, tb);
-#pragma unroll
-		for (int w = 0; w < 9; w++) { qx.l[w] = b[w]; qy.l[w] = b[9 + w]; }
+		lut_load(A.gtbl, 0, gx, gy);
+		tab_load(tb, 0, qx, qy);
 		acc.X = weaken<FX>(gx);
 		acc.Y = weaken<FY>(gy);
 		acc.Z = onez;
@@ -707,7 +742,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 #pragma unroll 1
 		for (int which = COMB ? 1 : 0; which < 2; which++) {
 			u32 *kw = which ? k2 : k1;
-			const u32 *base = which ? tb : A.gtbl;
 			const int dig = (int)(kw[7] >> 28) - 8;
 #pragma unroll
 			for (int w = 7; w > 0; w--) {
@@ -715,13 +749,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 			}
 			kw[0] <<= 4;
 			const u32 mag = (u32)(dig < 0 ? -dig : dig);
-			u32 b[20];
-			ld<5>(b, base + (mag ? mag - 1 : 0) * TBL_WORDS_PER_ENTRY);
 			Fcanon tx, tyc;
-#pragma unroll
-			for (int w = 0; w < 9; w++) {
-				tx.l[w] = b[w];
-				tyc.l[w] = b[9 + w];
+			if (which) {
+				tab_load(tb, mag ? mag - 1 : 0, tx, tyc);
+			} else {
+				lut_load(A.gtbl, mag ? mag - 1 : 0, tx, tyc);
 			}
 			const FYaff ty = sel(dig < 0, neg_aff(tyc), weaken<FYaff>(tyc));
 			const Jac S = madd(acc, tx, ty, hz);
@@ -787,7 +819,7 @@ hipError_t ecamd_launch_verify_p256(const EcamdSmulArgs &pubkeys, const uint8_t 
 		return hipSuccess;
 	}
 	const dim3 grid((pubkeys.n + 63) / 64), block(64);
-	const uint32_t athreads = (pubkeys.n + AFF_K - 1) / AFF_K;
+	const uint32_t athreads = (((pubkeys.n + AFF_K - 1) / AFF_K) + 63u) & ~63u;
 	hipLaunchKernelGGL(k_p256_table, grid, block, 0, s, pubkeys);
 	hipLaunchKernelGGL(k_p256_affine, dim3((athreads + 63) / 64), block, 0, s, pubkeys, athreads);
 	P256VerifyArgs V;
@@ -817,7 +849,7 @@ hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s, hipEven
 		return hipSuccess;
 	}
 	const dim3 grid((a.n + 63) / 64), block(64);
-	const uint32_t nthreads = (a.n + FIN_K - 1) / FIN_K;
+	const uint32_t nthreads = (((a.n + FIN_K - 1) / FIN_K) + 63u) & ~63u;
 	const dim3 fgrid((nthreads + 63) / 64);
 #define P256_MARK(i) do { if (ev) (void)hipEventRecord(ev[i], s); } while (0)
 	P256_MARK(0);
@@ -828,7 +860,7 @@ hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s, hipEven
 	} else {
 		hipLaunchKernelGGL(k_p256_table, grid, block, 0, s, a);
 		P256_MARK(1);
-		const uint32_t athreads = (a.n + AFF_K - 1) / AFF_K;
+		const uint32_t athreads = (((a.n + AFF_K - 1) / AFF_K) + 63u) & ~63u;
 		hipLaunchKernelGGL(k_p256_affine, dim3((athreads + 63) / 64), block, 0, s, a, athreads);
 	}
 	P256_MARK(2);

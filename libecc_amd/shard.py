@@ -9,10 +9,9 @@ import torch.distributed as dist
 
 
 def shard_range(n, rank, world):
-    """Contiguous, balanced: sizes differ by at most one and concatenate to range(n)."""
-    base, rem = divmod(n, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    """Contiguous, balanced: rank r of N owns [r*n//N, (r+1)*n//N) -- sizes differ by at most one and concatenate to
+    range(n).  The same partition as the C layer's ecamd_multi_shard_range (libecc_amd/csrc/ecamd_multi.cpp)."""
+    return (n * rank) // world, (n * (rank + 1)) // world
 
 
 def all_gather_shards(local, n, item_bytes, group=None):

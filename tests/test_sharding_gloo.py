@@ -22,6 +22,116 @@ def test_shard_ranges_cover_batch():
             assert max(hi - lo for lo, hi in r) - min(hi - lo for lo, hi in r) <= 1
 
 
+def test_python_and_c_layers_partition_alike():
+    """libecc_amd/shard.py (bench.py, torch.distributed) and ecamd_multi (C, one thread per device) cut a batch the same way"""
+    import ctypes as C
+    import libecc_amd
+    L = libecc_amd.load_library()
+    lo, hi = C.c_uint32(), C.c_uint32()
+    for n in (0, 1, 7, 64, 1000, 1001, (1 << 20) + 3, (1 << 32) - 1):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                L.ecamd_multi_shard_range(n, r, world, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == shard_range(n, r, world)
+
+
+def _proto_worker(rank, world, port, n, q):
+    """the protocol workloads of tools/bench_protocols.py sharded the same way: every rank verifies / derives its own
+    contiguous shard, the per-item result bytes (1 byte per verification, clen bytes per secret) are gathered"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oracles as O
+    from oracles import Oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pubs, sigs, dg, privs, k, u, epubs, esigs, ehram = _proto_inputs(n)
+    lo, hi = shard_range(n, rank, world)
+    o = Oracle("SECP256R1")
+    res = o.ecdsa_verify(pubs[64 * lo:64 * hi], sigs[64 * lo:64 * hi], dg[32 * lo:32 * hi], 32)
+    sec, st = o.ecccdh(privs[32 * lo:32 * hi], pubs[64 * lo:64 * hi])
+    o25 = Oracle("WEI25519")
+    xo, xs = o25.xdh(k[32 * lo:32 * hi], u[32 * lo:32 * hi])
+    er = o25.eddsa_verify(epubs[32 * lo:32 * hi], esigs[64 * lo:64 * hi], ehram[64 * lo:64 * hi])
+
+    def t(b):
+        return torch.frombuffer(bytearray(b), dtype=torch.uint8)
+    out = [all_gather_shards(t(res), n, 1), all_gather_shards(t(sec), n, 32), all_gather_shards(t(st), n, 1),
+           all_gather_shards(t(xo), n, 32), all_gather_shards(t(xs), n, 1), all_gather_shards(t(er), n, 1)]
+    if rank == 0:
+        q.put([x.numpy().tobytes() for x in out])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _proto_inputs(n):
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oracles as O
+    from oracles import CURVES, Oracle
+    rng = np.random.default_rng(123)
+    o = Oracle("SECP256R1")
+    q = CURVES["SECP256R1"]["q"]
+    rs = lambda: ((int.from_bytes(rng.integers(0, 256, size=40, dtype=np.uint8).tobytes(), "big") % (q - 1)) + 1).to_bytes(32, "big")
+    privs = b"".join(rs() for _ in range(n))
+    ks = b"".join(rs() for _ in range(n))
+    dg = rng.integers(0, 256, size=32 * n, dtype=np.uint8).tobytes()
+    sigs, st = o.ecdsa_sign(privs, ks, dg, 32)
+    pubs, _ = o.scalar_mult(privs)
+    sigs = bytearray(sigs)
+    for i in range(0, n, 3):
+        sigs[64 * i + 7] ^= 1
+    k = rng.integers(0, 256, size=32 * n, dtype=np.uint8).tobytes()
+    u = bytearray(rng.integers(0, 256, size=32 * n, dtype=np.uint8).tobytes())
+    for i in range(n):
+        u[32 * i + 31] &= 0x7f
+    epubs, esigs, ehram = b"", b"", b""
+    for i in range(n):
+        a, sg, _ = O.ed25519_sign(bytes([i + 1]) * 32, b"msg%d" % i)
+        if i % 4 == 1:
+            sg = sg[:33] + bytes([sg[33] ^ 2]) + sg[34:]
+        epubs += a
+        esigs += sg
+        ehram += hashlib.sha512(sg[:32] + a + b"msg%d" % i).digest()
+    return pubs, bytes(sigs), dg, privs, k, bytes(u), epubs, esigs, ehram
+
+
+def test_protocol_workloads_shard_like_the_headline_one():
+    """ECDSA verification, ECC-CDH, X25519 and Ed25519 verification over two ranks: contiguous shards + gather of the per-item
+    result bytes give the single-process answers in batch order (ragged split: 11 = 5 + 6)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracles import Oracle
+    n = 11
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_proto_worker, args=(r, 2, port, n, q), daemon=True) for r in range(2)]
+    try:
+        for p in procs:
+            p.start()
+        got = q.get(timeout=240)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
+    pubs, sigs, dg, privs, k, u, epubs, esigs, ehram = _proto_inputs(n)
+    o, o25 = Oracle("SECP256R1"), Oracle("WEI25519")
+    sec, st = o.ecccdh(privs, pubs)
+    xo, xs = o25.xdh(k, u)
+    exp = [o.ecdsa_verify(pubs, sigs, dg, 32), sec, st, xo, xs, o25.eddsa_verify(epubs, esigs, ehram)]
+    assert got == exp
+    assert 0 < sum(exp[0]) < n and 0 < sum(exp[5]) < n
+
+
 def _worker(rank, world, port, n, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
