@@ -215,7 +215,9 @@ int ec_eddsa_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t
  *   3. the caller hashes hram = SHA-512(dom2 || R || A || PH(M))                           n x 64 bytes
  *   4. ec_eddsa_sign_S_batch: S = (r + hram a) mod q (:1847-1857), a_scalars n x 32 little-endian (the clamped secret
  *      scalars) -> S_out n x 32 little-endian (the second half).
- * Ed448 signing is not provided. */
+ * Ed448 (EDDSA448 / EDDSA448PH) on the WEI448 handle, same two calls: r_hash and hram are n x 114 (SHAKE256 with 114 bytes of
+ * output), R_enc, a_scalars and S_out n x 57; the device multiplies the generator by r / 4 mod q and encodes through the 4-isogeny
+ * back to Edwards448, as _eddsa_sign does (:1737-1746, eddsa_encode_point :350-395). */
 int ec_eddsa_sign_R_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *r_hash, uint8_t *R_enc,
 			  uint8_t *status);
 int ec_eddsa_sign_S_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *r_hash, const uint8_t *hram,

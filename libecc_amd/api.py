@@ -287,18 +287,21 @@ class Curve:
         return res.raw[:n]
 
     def eddsa_sign_R(self, r_hash):
-        """Ed25519 signing, step 1: n x 64-byte SHA-512(dom2 || prefix || PH(M)) -> (n x 32 encoded R, status)"""
-        n = len(r_hash) // 64
-        out, st = C.create_string_buffer(max(1, 32 * n)), C.create_string_buffer(max(1, n))
+        """EdDSA signing, step 1: n x 64-byte SHA-512(dom2 || prefix || PH(M)) -> (n x 32 encoded R, status); on the WEI448
+        handle n x 114-byte SHAKE256(dom4 || prefix || PH(M)) -> n x 57"""
+        hl, kl = (114, 57) if self.clen == 56 else (64, 32)
+        n = len(r_hash) // hl
+        out, st = C.create_string_buffer(max(1, kl * n)), C.create_string_buffer(max(1, n))
         _chk(self.L, self.L.ec_eddsa_sign_R_batch(self.ctx.h, self.h, n, r_hash, out, st), "ec_eddsa_sign_R_batch")
-        return out.raw[:32 * n], st.raw[:n]
+        return out.raw[:kl * n], st.raw[:n]
 
     def eddsa_sign_S(self, r_hash, hram, a_scalars):
-        """Ed25519 signing, step 2: S = (r + hram * a) mod q, n x 32 bytes little-endian"""
-        n = len(r_hash) // 64
-        out = C.create_string_buffer(max(1, 32 * n))
+        """EdDSA signing, step 2: S = (r + hram * a) mod q, n x 32 (Ed25519) / n x 57 (Ed448) bytes little-endian"""
+        hl, kl = (114, 57) if self.clen == 56 else (64, 32)
+        n = len(r_hash) // hl
+        out = C.create_string_buffer(max(1, kl * n))
         _chk(self.L, self.L.ec_eddsa_sign_S_batch(self.ctx.h, self.h, n, r_hash, hram, a_scalars, out), "ec_eddsa_sign_S_batch")
-        return out.raw[:32 * n]
+        return out.raw[:kl * n]
 
     def eddsa_verify_all(self, pubkeys, sigs, hram, hram_len=None):
         """ec_verify_batch's whole-batch predicate: (all_valid, index of the first rejected item or n)"""

@@ -38,8 +38,9 @@ def _jobs():
     jobs = [(src, os.path.splitext(src)[0] + ".o", []) for src in SOURCES]
     jobs += [("ecamd_g29_kernel.hip", f"ecamd_g29_{pb}.o", [f"-DG29_PB={pb}"]) for pb in G29_SIZES]
     jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_521m.o", ["-DG29_PB=521", "-DG29_MERSENNE521"]))
-    jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_255c.o", ["-DG29_PB=255", "-DG29_P25519"]))
-    jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_256k.o", ["-DG29_PB=256", "-DG29_K256"]))
+    # the two nine-limb plain-residue units run best at three waves per SIMD (profiles/r2e_variants.md: 62.7 -> 63.5 and 68.0 -> 69.6 M/s)
+    jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_255c.o", ["-DG29_PB=255", "-DG29_P25519", "-DG29_WAVES=3"]))
+    jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_256k.o", ["-DG29_PB=256", "-DG29_K256", "-DG29_WAVES=3"]))
     jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_448g.o", ["-DG29_PB=448", "-DG29_P448"]))
     jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_384n.o", ["-DG29_PB=384", "-DG29_MPINV1"]))
     jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_dispatch.o", ["-DG29_DISPATCH"]))

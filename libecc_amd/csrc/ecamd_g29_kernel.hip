@@ -137,7 +137,13 @@ template <class T> static __device__ __forceinline__ T selg(bool c, const T &a, 
 }
 
 // FLAV only makes the kernel symbols of the translation units of one size distinct (0 dense, 1 secp521r1, 2 2^255 - 19)
-template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_smul_g(EcamdSmulArgs A, int gslot)
+// G29_WAVES (build flag, A/B tests through tools/build_variant.py): pin the waves per SIMD of the window kernel
+#ifdef G29_WAVES
+#define G29_OCC __attribute__((amdgpu_waves_per_eu(G29_WAVES, G29_WAVES)))
+#else
+#define G29_OCC
+#endif
+template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_smul_g(EcamdSmulArgs A, int gslot)
 {
 	typedef Lay<PB> L;
 	typedef typename Cls<PB>::FA FA;

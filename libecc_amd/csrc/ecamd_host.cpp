@@ -2751,15 +2751,28 @@ static int eddsa_sign_setup(const char *fn, ecamd_ctx *ctx, const ecamd_curve *c
 		return fail(std::string(fn) + ": bad argument");
 	}
 	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
-	if (cv->ed_state == 0) {
-		ed_setup(cv);
-	}
-	if (cv->ed_state < 0) {
-		return fail(std::string(fn) + ": Ed25519 signing needs the WEI25519 curve handle");
-	}
 	memset(T, 0, sizeof(*T));
-	memcpy(T->alpha, cv->ed_tmpl.alpha, sizeof(T->alpha));
-	memcpy(T->A3, cv->ed_tmpl.A3, sizeof(T->A3));
+	if (cv->pbits == 448) {
+		if (cv->ed448_state == 0) {
+			ed448_setup(cv);
+		}
+		if (cv->ed448_state < 0) {
+			return fail(std::string(fn) + ": Ed448 signing needs the WEI448 curve handle");
+		}
+		memcpy(T->alpha, cv->ed448_tmpl.alpha, sizeof(T->alpha));
+		memcpy(T->A3, cv->ed448_tmpl.A3, sizeof(T->A3));
+		big_store(T->c4, 17, big_from_be(cv->ed448_c4, 56));
+		T->is448 = 1;
+	} else {
+		if (cv->ed_state == 0) {
+			ed_setup(cv);
+		}
+		if (cv->ed_state < 0) {
+			return fail(std::string(fn) + ": EdDSA signing needs the WEI25519 or the WEI448 curve handle");
+		}
+		memcpy(T->alpha, cv->ed_tmpl.alpha, sizeof(T->alpha));
+		memcpy(T->A3, cv->ed_tmpl.A3, sizeof(T->A3));
+	}
 	T->slot = cv->slot;
 	T->qslot = cv->qslot;
 	return 0;
@@ -2772,13 +2785,15 @@ static int eddsa_sign_R_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, const 
 	if (n > ctx->max_chunk) {  // bound the scratch: pieces of max_chunk items, in order on the stream
 		for (uint32_t off = 0; off < n; off += ctx->max_chunk) {
 			const uint32_t m = (n - off) < ctx->max_chunk ? (n - off) : ctx->max_chunk;
-			if (eddsa_sign_R_dev_locked(ctx, cv, T, m, d_rhash + (size_t)off * 64, d_Renc + (size_t)off * 32, d_status + off, s)) {
+			if (eddsa_sign_R_dev_locked(ctx, cv, T, m, d_rhash + (size_t)off * (T.is448 ? 114 : 64), d_Renc + (size_t)off * (T.is448 ? 57 : 32),
+						    d_status + off, s)) {
 				return -1;
 			}
 		}
 		return 0;
 	}
-	if (ensure(&ctx->stage[3], &ctx->stage_bytes[3], (size_t)n * 32) || ensure(&ctx->stage[4], &ctx->stage_bytes[4], (size_t)n * 64) ||
+	const uint32_t cl = (uint32_t)cv->clen;   // 32 / 56
+	if (ensure(&ctx->stage[3], &ctx->stage_bytes[3], (size_t)n * cl) || ensure(&ctx->stage[4], &ctx->stage_bytes[4], (size_t)n * 2 * cl) ||
 	    ensure(&ctx->stage[5], &ctx->stage_bytes[5], n)) {
 		return -1;
 	}
@@ -2788,7 +2803,7 @@ static int eddsa_sign_R_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, const 
 	A.r_hash = d_rhash;
 	A.r_be = S[3];
 	HIPCHK(ecamd_launch_ed_sign_r(A, s));
-	if (smul_dev_locked(ctx, cv, n, S[3], 32, nullptr, S[4], S[5], s)) {   // prj_pt_mul(r, G) (:1776)
+	if (smul_dev_locked(ctx, cv, n, S[3], cl, nullptr, S[4], S[5], s)) {   // prj_pt_mul(r, G) (:1776; Ed448: r / 4, :1746)
 		return -1;
 	}
 	A.Rw = S[4];
@@ -2814,7 +2829,7 @@ extern "C" int ec_eddsa_sign_R_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint
 		return 0;
 	}
 	HIPCHK(hipSetDevice(ctx->device));
-	const std::vector<HostArr> arrs = {{r_hash, nullptr, 64}, {nullptr, R_enc, 32}, {nullptr, status, 1}};
+	const std::vector<HostArr> arrs = {{r_hash, nullptr, (size_t)(T.is448 ? 114 : 64)}, {nullptr, R_enc, (size_t)(T.is448 ? 57 : 32)}, {nullptr, status, 1}};
 	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
 		return eddsa_sign_R_dev_locked(ctx, cv, T, m, ip[0], op[1], op[2], s);
@@ -2836,7 +2851,8 @@ extern "C" int ec_eddsa_sign_S_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint
 		return 0;
 	}
 	HIPCHK(hipSetDevice(ctx->device));
-	const std::vector<HostArr> arrs = {{r_hash, nullptr, 64}, {hram, nullptr, 64}, {a_scalars, nullptr, 32}, {nullptr, S_out, 32}};
+	const size_t hl = T.is448 ? 114 : 64, kl = T.is448 ? 57 : 32;
+	const std::vector<HostArr> arrs = {{r_hash, nullptr, hl}, {hram, nullptr, hl}, {a_scalars, nullptr, kl}, {nullptr, S_out, kl}};
 	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
 		EcamdEdSignArgs A = T;

@@ -182,7 +182,9 @@ struct EcamdEdSignArgs {
 	uint8_t *status;         // encode step: n
 	uint32_t n;
 	uint32_t alpha[17], A3[17];   // Montgomery form, as in EcamdEdDecodeArgs
+	uint32_t c4[17];              // Ed448: 4^-1 mod q, plain little-endian words (the scalar of [r]G is r / 4, sig/eddsa.c:1737-1746)
 	int slot, qslot;
+	int is448;                    // Ed448 on WEI448: 114-byte hashes, 57-byte encodings (the launchers pick the 448-bit kernels)
 };
 hipError_t ecamd_launch_ed_sign_r(const EcamdEdSignArgs &a, hipStream_t s);
 hipError_t ecamd_launch_ed_sign_enc(const EcamdEdSignArgs &a, hipStream_t s);

@@ -1038,6 +1038,116 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed448_decode(EcamdEd44
 	}
 }
 
+// ------------------------------------------------------------------------------------------
+// Ed448 signing around the caller's hashes (_eddsa_sign, sig/eddsa.c:1554-1870, the EDDSA448 branches):
+//   k_ed448_sign_r:   r = SHAKE256(dom4 || prefix || PH(M), 114) little-endian mod q (:1731); the scalar of the multiplication
+//                     is r 4^-1 mod q (:1737-1746: "because of the 4-isogeny we must divide our scalar by 4"), big-endian out
+//   k_ed448_sign_enc: [r/4]G on WEI448 -> prj_pt_shortw_to_aff_pt_edwards (infinity -> (0, 1); (u, v) = (A/3 - X, -Y) on libecc's
+//                     Montgomery model (A, B) = (-156326, -1); x = alpha u / v, y = (u - 1) / (u + 1)) -> eddsa_encode_point
+//                     (:350-395): the 4-isogeny back to Edwards448, x1 = (4 x y / alpha) / (y^2 - x^2),
+//                     y1 = (2 - x^2 - y^2) / (x^2 + y^2); 57 bytes: y1 little-endian, the parity of x1 in bit 7 of the last one.
+//                     Two inversions per item (the five denominators by Montgomery's trick), addition chains for p - 2.
+//   k_ed448_sign_S:   S = (r + h a) mod q with h = SHAKE256(dom4 || R || A || PH(M), 114) mod q, a = the clamped secret
+//                     scalar (57 bytes little-endian, the last one 0), 57 bytes little-endian out
+// ------------------------------------------------------------------------------------------
+template <int NW> static __device__ Fe<NW> ed448_le114_mod_q(const u8 *hp, int qs)
+{
+	const CurveK<NW> &Q = ConstTab<NW>::get(qs);
+	const Fe<NW> lo = fe_load_le<NW>(hp, 56), mid = fe_load_le<NW>(hp + 56, 56), hi = fe_load_le<NW>(hp + 112, 2);
+	const Fe<NW> r2 = fe_const<NW>(Q.r2);
+	Fe<NW> onep = fe_zero<NW>();
+	onep.v[0] = 1u;
+	// R = 2^448: x R2 / R = x 2^448 (mod q); lo needs one more reduction step (it may exceed q)
+	const Fe<NW> lor = fe_mul<NW>(fe_mul<NW>(lo, r2, qs), onep, qs);
+	const Fe<NW> midr = fe_mul<NW>(mid, r2, qs);
+	const Fe<NW> hir = fe_mul<NW>(fe_mul<NW>(hi, r2, qs), r2, qs);
+	return fe_add<NW>(fe_add<NW>(lor, midr, qs), hir, qs);
+}
+
+template <int NW> __global__ __launch_bounds__(64) void k_ed448_sign_r(EcamdEdSignArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int qs = A.qslot;
+	const Fe<NW> r = ed448_le114_mod_q<NW>(A.r_hash + (size_t)i * 114, qs);
+	const Fe<NW> r2 = fe_const<NW>(ConstTab<NW>::get(qs).r2);
+	const Fe<NW> r4 = fe_mul<NW>(fe_mul<NW>(r, r2, qs), fe_const<NW>(A.c4), qs);      // (r R) c4 / R = r / 4 mod q
+	fe_store_be<NW>(A.r_be + (size_t)i * 56, 56, r4);
+}
+
+template <int NW> __global__ __launch_bounds__(64) void k_ed448_sign_enc(EcamdEdSignArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int slot = A.slot;
+	u8 *out = A.out + (size_t)i * 57;
+	const u32 st = A.stR[i];
+	if (st != 0) {
+		// r = 0 mod q: the neutral element, encoded as y1 = 1; a failed multiplication: an error
+		for (int b = 0; b < 57; b++) {
+			out[b] = (u8)((st == 2 && b == 0) ? 1 : 0);
+		}
+		A.status[i] = (st == 2) ? 0 : 1;
+		return;
+	}
+	const Fe<NW> zero = fe_zero<NW>();
+	const Fe<NW> one = fe_const<NW>(ConstTab<NW>::get(slot).one);
+	const Fe<NW> two = fe_add<NW>(one, one, slot);
+	const Fe<NW> alpha = fe_const<NW>(A.alpha);
+	const u8 *src = A.Rw + (size_t)i * 112;
+	const Fe<NW> Xw = fe_to_mont<NW>(fe_load_be<NW>(src, 56), slot), Yw = fe_to_mont<NW>(fe_load_be<NW>(src + 56, 56), slot);
+	const Fe<NW> u = fe_sub<NW>(fe_const<NW>(A.A3), Xw, slot), v = fe_sub<NW>(zero, Yw, slot);
+	const Fe<NW> up1 = fe_add<NW>(u, one, slot);
+	const Fe<NW> d1 = fe_mul<NW>(up1, v, slot);
+	bool ok = !fe_is_zero<NW>(d1);                                                      // fp_inv(0)
+	const Fe<NW> i1 = fe_inv_p448<NW>(d1, slot);
+	const Fe<NW> x = fe_mul<NW>(fe_mul<NW>(alpha, u, slot), fe_mul<NW>(i1, up1, slot), slot);   // alpha u / v
+	const Fe<NW> y = fe_mul<NW>(fe_sub<NW>(u, one, slot), fe_mul<NW>(i1, v, slot), slot);       // (u - 1) / (u + 1)
+	const Fe<NW> xx = fe_mul<NW>(x, x, slot), yy = fe_mul<NW>(y, y, slot);
+	const Fe<NW> den1 = fe_sub<NW>(yy, xx, slot), den2 = fe_add<NW>(xx, yy, slot);
+	const Fe<NW> d12 = fe_mul<NW>(den1, den2, slot);
+	ok = ok & !fe_is_zero<NW>(d12);
+	const Fe<NW> i2 = fe_inv_p448<NW>(fe_mul<NW>(d12, alpha, slot), slot);               // 1 / (den1 den2 alpha)
+	const Fe<NW> inv1 = fe_mul<NW>(i2, fe_mul<NW>(den2, alpha, slot), slot);             // 1 / den1
+	const Fe<NW> inv2 = fe_mul<NW>(i2, fe_mul<NW>(den1, alpha, slot), slot);             // 1 / den2
+	const Fe<NW> inva = fe_mul<NW>(i2, d12, slot);                                       // 1 / alpha
+	Fe<NW> x1 = fe_mul<NW>(x, y, slot);
+	x1 = fe_add<NW>(x1, x1, slot);
+	x1 = fe_add<NW>(x1, x1, slot);                                                       // 4 x y
+	x1 = fe_mul<NW>(fe_mul<NW>(x1, inv1, slot), inva, slot);
+	const Fe<NW> y1 = fe_mul<NW>(fe_sub<NW>(fe_sub<NW>(two, xx, slot), yy, slot), inv2, slot);
+	const Fe<NW> x1p = fe_from_mont<NW>(x1, slot), y1p = fe_from_mont<NW>(y1, slot);
+	for (int b = 0; b < 56; b++) {
+		out[b] = ok ? (u8)(y1p.v[b >> 2] >> (8 * (b & 3))) : 0;
+	}
+	out[56] = ok ? (u8)((x1p.v[0] & 1u) << 7) : 0;
+	A.status[i] = ok ? 0 : 1;
+}
+
+template <int NW> __global__ __launch_bounds__(64) void k_ed448_sign_S(EcamdEdSignArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int qs = A.qslot;
+	const Fe<NW> r2 = fe_const<NW>(ConstTab<NW>::get(qs).r2);
+	const Fe<NW> r = ed448_le114_mod_q<NW>(A.r_hash + (size_t)i * 114, qs);
+	const Fe<NW> h = ed448_le114_mod_q<NW>(A.hram + (size_t)i * 114, qs);
+	const Fe<NW> a = fe_load_le<NW>(A.a + (size_t)i * 57, 56);                          // byte 56 of the clamped scalar is 0
+	const Fe<NW> ha = fe_mul<NW>(h, fe_mul<NW>(a, r2, qs), qs);
+	const Fe<NW> S = fe_add<NW>(r, ha, qs);
+	u8 *out = A.out + (size_t)i * 57;
+	for (int b = 0; b < 56; b++) {
+		out[b] = (u8)(S.v[b >> 2] >> (8 * (b & 3)));
+	}
+	out[56] = 0;
+}
+
 // S < q (57 bytes little-endian, the last one must be 0); h = 114-byte hash mod q, then a = 4 h mod q as the reference does.
 // The reference multiplies the STORED key A' = [c4]A (c4 = 4^-1 mod q, eddsa_import_pub_key) by a.  [a]([c4]A) = [a c4]A,
 // and the order of A divides 4q, so one multiplication of the decoded A by k = a c4 mod 4q gives the same point:
@@ -1633,6 +1743,10 @@ hipError_t ecamd_launch_ed_sign_r(const EcamdEdSignArgs &a, hipStream_t s)
 	if (a.n == 0) {
 		return hipSuccess;
 	}
+	if (a.is448) {
+		hipLaunchKernelGGL(k_ed448_sign_r<14>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+		return hipGetLastError();
+	}
 	hipLaunchKernelGGL(k_ed_sign_r<8>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
 	return hipGetLastError();
 }
@@ -1642,6 +1756,10 @@ hipError_t ecamd_launch_ed_sign_enc(const EcamdEdSignArgs &a, hipStream_t s)
 	if (a.n == 0) {
 		return hipSuccess;
 	}
+	if (a.is448) {
+		hipLaunchKernelGGL(k_ed448_sign_enc<14>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+		return hipGetLastError();
+	}
 	hipLaunchKernelGGL(k_ed_sign_enc<8>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
 	return hipGetLastError();
 }
@@ -1650,6 +1768,10 @@ hipError_t ecamd_launch_ed_sign_S(const EcamdEdSignArgs &a, hipStream_t s)
 {
 	if (a.n == 0) {
 		return hipSuccess;
+	}
+	if (a.is448) {
+		hipLaunchKernelGGL(k_ed448_sign_S<14>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+		return hipGetLastError();
 	}
 	hipLaunchKernelGGL(k_ed_sign_S<8>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
 	return hipGetLastError();

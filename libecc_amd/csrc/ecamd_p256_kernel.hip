@@ -37,7 +37,9 @@ typedef uint8_t u8;
 #define TAB_ITEM_WORDS (TBL_ENTRIES * TAB_ENT_WORDS)
 #define STG_ENT_QUADS 10         /* staging record: X 0-8, Y 9-17, Z 18-26, (27), prefix product 28-36, (37-39) */
 #define STG_ITEM_QUADS (7 * STG_ENT_QUADS)
+#ifndef FIN_K
 #define FIN_K 8                  /* items per lane in k_p256_finalize */
+#endif
 #ifndef AFF_K
 #define AFF_K 8                  /* items per lane in k_p256_affine (x 7 table entries each); 2/4/8 measured equal */
 #endif

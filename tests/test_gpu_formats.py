@@ -146,3 +146,54 @@ def test_structured_signatures(gpu_ctx):
         assert list(st[5:8]) == [1, 1, 1] and st.count(1) == 3
     finally:
         cv.free()
+
+
+def test_eddsa448_sign_steps(gpu_ctx):
+    """Ed448 signing as the two device-side steps around the caller's SHAKE256 hashes (the split Ed25519 signing uses):
+    R = encode([r / 4]G through the 4-isogeny), S = (r + h a) mod q -- signature bytes equal those of an RFC 8032 signer
+    (python integers) and of the unmodified reference's ec_sign (EDDSA448) from the same seeds; the signatures verify on the
+    GPU; edge values of the hashes (r = 0 mod q: the neutral element; all ones) go through"""
+    import hashlib
+    rng = np.random.default_rng(84)
+    n, ml = 64, 21
+    seeds = [rand_bytes(rng, 57) for _ in range(n)]
+    msgs = [rand_bytes(rng, ml) for _ in range(n)]
+    H = lambda x: hashlib.shake_256(x).digest(114)
+    dom = O.ed_dom4(0, b"")
+    A, sigs, a_all, rh = b"", b"", b"", b""
+    for sd, m in zip(seeds, msgs):
+        hk = H(sd)
+        ab = bytearray(hk[:57])
+        ab[0] &= 0xFC
+        ab[55] |= 0x80
+        ab[56] = 0
+        a_all += bytes(ab)
+        rh += H(dom + hk[57:] + m)
+        pk, sg, _ = O.ed448_sign(sd, m)
+        A += pk
+        sigs += sg
+    cv = gpu_ctx.curve("WEI448")
+    try:
+        R, st = cv.eddsa_sign_R(rh)
+        assert st == bytes(n)
+        assert R == b"".join(sigs[114 * i:114 * i + 57] for i in range(n))
+        hram = b"".join(H(dom + R[57 * i:57 * (i + 1)] + A[57 * i:57 * (i + 1)] + msgs[i]) for i in range(n))
+        S = cv.eddsa_sign_S(rh, hram, a_all)
+        assert S == b"".join(sigs[114 * i + 57:114 * (i + 1)] for i in range(n))
+        full = b"".join(R[57 * i:57 * (i + 1)] + S[57 * i:57 * (i + 1)] for i in range(n))
+        assert cv.eddsa_verify(A, full, hram) == bytes(n)
+        if have_ref():
+            rp, rs, rst = O.ref_ed448_sign(b"".join(seeds), b"".join(msgs), ml)
+            assert set(rst) == {0} and rp == A and rs == full
+        # edge hashes: r = 0 mod q encodes the neutral element (y = 1); r = q, 2^912 - 1
+        q = O.E4_Q
+        edge = [(0).to_bytes(114, "little"), q.to_bytes(114, "little"), b"\xff" * 114, (q + 1).to_bytes(114, "little"),
+                (4).to_bytes(114, "little")]
+        R2, st2 = cv.eddsa_sign_R(b"".join(edge))
+        assert st2 == bytes(len(edge))
+        neutral = (1).to_bytes(57, "little")
+        assert R2[:57] == neutral and R2[57:114] == neutral
+        exp = [O.e4_encode(O.e4_mul(int.from_bytes(e, "little") % q, O.E4_B)) for e in edge]
+        assert R2 == b"".join(exp)
+    finally:
+        cv.free()
