@@ -139,6 +139,117 @@ static u64 *g_ticks;       // device
 static double g_wall_khz;  // rate of s_memrealtime
 
 // sclk_mhz: sustained shader clock during the timed launch (s_memtime ticks per s_memrealtime tick, averaged over blocks)
+
+// ------------------------------------------------------------------------------------------
+// A/B the north_star asks for: ONE field multiplication spread over the lanes of a wavefront (cross-lane sums through DPP) against
+// one multiplication PER LANE.  Both compute the 17 column sums of a 9 x 9-limb (29-bit) schoolbook product -- the part of a
+// multiplication that is pure MADs in the per-lane layout; the carry pass and the reduction that follow would add the same kind of
+// cross-lane steps again on the spread side.
+//   per lane:    81 v_mad_u64_u32 per multiplication, no data movement (what ecamd_u29.cuh does);
+//   lane spread: a DPP row of 16 lanes holds one multiplication; lane r (r < 9) forms its row a_r * b_j (9 MADs), then column c
+//                is gathered by lane c with eight row_shr / row_shl steps of 64-bit values (two v_mov_dpp + a 64-bit add each),
+//                for the low and for the high half: 4 multiplications per wave instruction stream instead of 64.
+// Both kernels are checked against each other on the host before they are timed.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mul_perlane(const u32 *in, u64 *out, int iters)
+{
+	const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+	u32 a[9], b[9];
+#pragma unroll
+	for (int i = 0; i < 9; i++) {
+		a[i] = in[(t % 64) * 18 + i] & 0x1fffffffu;
+		b[i] = in[(t % 64) * 18 + 9 + i] & 0x1fffffffu;
+	}
+	u64 col[17];
+	for (int it = 0; it < iters; it++) {
+#pragma unroll
+		for (int k = 0; k < 17; k++) {
+			u64 acc = 0;
+#pragma unroll
+			for (int i = 0; i < 9; i++) {
+				const int j = k - i;
+				if (j >= 0 && j < 9) {
+					asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a[i]), "v"(b[j]) : "vcc");
+				}
+			}
+			col[k] = acc;
+		}
+		a[0] ^= (u32)col[16] & 1u;  // keep the iterations dependent, value unchanged in practice (col[16] < 2^58 is even or odd...)
+		a[0] &= 0x1fffffffu;
+	}
+	if (out) {
+#pragma unroll
+		for (int k = 0; k < 17; k++) {
+			out[(size_t)t * 17 + k] = col[k];
+		}
+	}
+}
+
+static __device__ __forceinline__ u64 dpp_shr64(u64 v, int d)   // value of lane (l - d) of the row, 0 where there is none
+{
+	u32 lo = (u32)v, hi = (u32)(v >> 32), rlo = 0, rhi = 0;
+	switch (d) {
+#define SHR(D) case D: rlo = __builtin_amdgcn_update_dpp(0u, lo, 0x110 + D, 0xf, 0xf, true); rhi = __builtin_amdgcn_update_dpp(0u, hi, 0x110 + D, 0xf, 0xf, true); break;
+		SHR(1) SHR(2) SHR(3) SHR(4) SHR(5) SHR(6) SHR(7) SHR(8)
+#undef SHR
+	default: rlo = lo; rhi = hi; break;
+	}
+	return ((u64)rhi << 32) | rlo;
+}
+static __device__ __forceinline__ u64 dpp_shl64(u64 v, int d)   // value of lane (l + d) of the row
+{
+	u32 lo = (u32)v, hi = (u32)(v >> 32), rlo = 0, rhi = 0;
+	switch (d) {
+#define SHL(D) case D: rlo = __builtin_amdgcn_update_dpp(0u, lo, 0x100 + D, 0xf, 0xf, true); rhi = __builtin_amdgcn_update_dpp(0u, hi, 0x100 + D, 0xf, 0xf, true); break;
+		SHL(1) SHL(2) SHL(3) SHL(4) SHL(5) SHL(6) SHL(7) SHL(8)
+#undef SHL
+	default: rlo = lo; rhi = hi; break;
+	}
+	return ((u64)rhi << 32) | rlo;
+}
+
+// one multiplication per DPP row of 16 lanes; item index = global row index; lane r < 9 ends up with columns r and r + 9
+__global__ __launch_bounds__(256) void k_mul_lanespread(const u32 *in, u64 *out, int iters)
+{
+	const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+	const u32 row = t / 16, r = t % 16;
+	u32 b[9];
+#pragma unroll
+	for (int i = 0; i < 9; i++) {
+		b[i] = in[(row % 64) * 18 + 9 + i] & 0x1fffffffu;
+	}
+	u32 ar = (r < 9) ? (in[(row % 64) * 18 + r] & 0x1fffffffu) : 0u;
+	u64 lo_col = 0, hi_col = 0;
+	for (int it = 0; it < iters; it++) {
+		u64 prod[9];
+#pragma unroll
+		for (int j = 0; j < 9; j++) {
+			u64 z = 0;
+			asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(z) : "v"(ar), "v"(b[j]) : "vcc");
+			prod[j] = z;
+		}
+		// column c (< 9), owned by lane c: sum over d of prod[d] of lane c - d
+		lo_col = prod[0];
+#pragma unroll
+		for (int d = 1; d < 9; d++) {
+			lo_col += dpp_shr64(prod[d], d);
+		}
+		// column c + 9, owned by lane c: prod[9 - e] of lane c + e, e = 1..8
+		hi_col = 0;
+#pragma unroll
+		for (int e = 1; e < 9; e++) {
+			hi_col += dpp_shl64((r + 0 < 16) ? prod[9 - e] : 0, e);
+		}
+		ar ^= (u32)hi_col & 1u & (u32)(it >> 30);  // dependency between iterations, never changes the value
+	}
+	if (out && r < 9) {
+		out[(size_t)row * 17 + r] = lo_col;
+		if (r < 8) {
+			out[(size_t)row * 17 + 9 + r] = hi_col;
+		}
+	}
+}
+
 template <int KIND> static double run_rate(u32 *d_out, int blocks, int iters, double *sclk_mhz)
 {
 	hipEvent_t e0, e1;
@@ -243,6 +354,56 @@ int main(int argc, char **argv)
 		const double cyc_s = 64.0 * (f[i] * 1e6) / per_simd;
 		printf(" \"%s\": {\"lane_ops_per_s\": %.4e, \"cycles_per_wave_instr_per_simd\": %.3f, \"sustained_sclk_mhz\": %.1f, "
 		       "\"cycles_at_sustained_clock\": %.3f},\n", names[i], r[i], cyc, f[i], cyc_s);
+	}
+	{
+		// per-lane against lane-spread multiplication (see above): correctness first, then rates
+		const int nb = cus * 8;
+		const size_t nt = (size_t)nb * 256;
+		u32 *d_in;
+		u64 *d_o1, *d_o2;
+		static u32 h_in[64 * 18];
+		for (int i = 0; i < 64 * 18; i++) {
+			h_in[i] = (u32)(2654435761u * (u32)(i + 12345)) ^ (u32)(i * 40503u);
+		}
+		hipMalloc(&d_in, sizeof(h_in));
+		hipMalloc(&d_o1, nt * 17 * sizeof(u64));
+		hipMalloc(&d_o2, (nt / 16) * 17 * sizeof(u64));
+		hipMemcpy(d_in, h_in, sizeof(h_in), hipMemcpyHostToDevice);
+		hipLaunchKernelGGL(k_mul_perlane, dim3(1), dim3(64), 0, 0, d_in, d_o1, 1);
+		hipLaunchKernelGGL(k_mul_lanespread, dim3(4), dim3(256), 0, 0, d_in, d_o2, 1);
+		hipDeviceSynchronize();
+		static u64 h1[64 * 17], h2[64 * 17];
+		hipMemcpy(h1, d_o1, sizeof(h1), hipMemcpyDeviceToHost);
+		hipMemcpy(h2, d_o2, sizeof(h2), hipMemcpyDeviceToHost);
+		int same = 1;
+		for (int i = 0; i < 64 * 17; i++) {
+			same &= (h1[i] == h2[i]);
+		}
+		hipEvent_t e0, e1;
+		hipEventCreate(&e0);
+		hipEventCreate(&e1);
+		float ms1 = 0, ms2 = 0;
+		const int it = iters / 4 > 0 ? iters / 4 : 1;
+		hipLaunchKernelGGL(k_mul_perlane, dim3(nb), dim3(256), 0, 0, d_in, (u64 *)nullptr, 8);
+		hipDeviceSynchronize();
+		hipEventRecord(e0);
+		hipLaunchKernelGGL(k_mul_perlane, dim3(nb), dim3(256), 0, 0, d_in, (u64 *)nullptr, it);
+		hipEventRecord(e1);
+		hipEventSynchronize(e1);
+		hipEventElapsedTime(&ms1, e0, e1);
+		hipLaunchKernelGGL(k_mul_lanespread, dim3(nb), dim3(256), 0, 0, d_in, (u64 *)nullptr, 8);
+		hipDeviceSynchronize();
+		hipEventRecord(e0);
+		hipLaunchKernelGGL(k_mul_lanespread, dim3(nb), dim3(256), 0, 0, d_in, (u64 *)nullptr, it);
+		hipEventRecord(e1);
+		hipEventSynchronize(e1);
+		hipEventElapsedTime(&ms2, e0, e1);
+		const double r1 = (double)nt * it / (ms1 * 1e-3), r2 = (double)(nt / 16) * it / (ms2 * 1e-3);
+		printf(" \"mul256_column_sums\": {\"layouts_agree\": %d, \"per_lane_products_per_s\": %.4e, \"lane_spread_products_per_s\": %.4e, "
+		       "\"per_lane_over_lane_spread\": %.1f},\n", same, r1, r2, r2 > 0 ? r1 / r2 : 0.0);
+		hipFree(d_in);
+		hipFree(d_o1);
+		hipFree(d_o2);
 	}
 	// analytic MAD peak at the sustained clock: 1024 SIMDs x 16 lane-MADs per clock (a wave64 v_mad_u64_u32 = 4 cycles)
 	printf(" \"analytic_mad_peak_at_sustained_clock\": %.4e,\n", (double)cus * 4.0 * 16.0 * f[0] * 1e6);
