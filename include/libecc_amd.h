@@ -61,10 +61,11 @@ const char *ecamd_last_error(void);
 int ecamd_ctx_set_max_chunk(ecamd_ctx *ctx, uint32_t max_items);
 /* Secret scalars.  By default the kernels index their window / comb tables with the scalar's digits (fastest; fine for public
  * scalars: verification, public-key checks).  With this switch on, every scalar multiplication issued through the context --
- * ec_prj_pt_mul_batch*, and inside ec_ecdsa_sign_batch, ec_ecccdh_derive_batch, ec_eddsa_sign_R_batch, key-pair import -- runs on
- * the complete-formula kernel with constant-address table look-ups (every entry read, the wanted one kept by masking: the posture
- * of the reference's masked ladder, curves/prj_pt.c:1225-1260, and nn_tabselect, nn/nn.c:564), a fixed window count and no
- * scalar-dependent kernel choice.  Results are identical; the cost is the difference between the two kernels.
+ * ec_prj_pt_mul_batch*, and inside ec_ecdsa_sign_batch, ec_ecccdh_derive_batch, ec_eddsa_sign_R_batch, key-pair import -- uses
+ * constant-address table look-ups (every entry read, the wanted one kept by masking: the posture of the reference's masked
+ * ladder, curves/prj_pt.c:1225-1260, and nn_tabselect, nn/nn.c:564), a fixed window count and no comb table: on secp256r1 the
+ * radix-2^29 pipeline with eight-entry scans, on the other curves the complete-formula kernel with sixteen-entry scans.
+ * Results are identical; DESIGN.md 2.3 has the cost.
  * X25519 / X448 ladders are address-independent in either mode. */
 int ecamd_ctx_set_secret_scalars(ecamd_ctx *ctx, int on);
 /* Measurement hook: when enabled, HIP events are recorded (on the stream the kernels run on) around

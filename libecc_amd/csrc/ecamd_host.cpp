@@ -1116,9 +1116,10 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 	// kernel); the fixed-base comb covers the 32-byte ones
 	// secret-scalar mode: every item goes through the complete-formula kernel with masked full-table look-ups -- no digit-indexed
 	// address (window or comb table), no exceptional-pair detour whose occurrence depends on the scalar
+	// (secp256r1 keeps its radix-2^29 pipeline in this mode: k_p256_loop<KW, MASKED> scans the eight-entry tables, the comb is off)
 	const bool secret = ctx->secret_scalars;
-	const bool fast256 = !secret && cv->is_p256 && slen <= 68;
-	const bool comb_ok = !cv->is_p256 || slen <= 32;
+	const bool fast256 = cv->is_p256 && slen <= 68;
+	const bool comb_ok = !secret && (!cv->is_p256 || slen <= 32);
 	const bool fastg = !secret && !fast256 && cv->gslot >= 0 && slen <= ecamd_g29_max_slen(cv->pbits);
 	const bool fast = fast256 || fastg;
 	if (fast && !d_points && comb_ok) {
@@ -1160,7 +1161,7 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 		A.lut = nullptr;
 		A.lut_kind = 0;
 		A.stg = nullptr;
-		A.masked = secret ? 1 : 0;
+		A.masked = secret ? 1 : 0;   // (copied into Fa below: the secp256r1 loop honours it too)
 		if (fast) {
 			// Jacobian fast path; lanes that met an exceptional pair come back as ECAMD_STATUS_REDO and
 			// are recomputed by the complete-formula kernel (all other lanes exit at once)

@@ -197,6 +197,28 @@ static __device__ __forceinline__ void tab_load(const u32 *tab, u32 e, Fcanon &x
 	x = from_words(w);
 	y = from_words(w + 8);
 }
+// Constant-address look-ups for secret digits (ecamd_ctx_set_secret_scalars): all eight entries are read, in the same order
+// whatever the digit, and the wanted one is kept by masking (cf. tbl_load_masked in ecamd_kernels.hip)
+static __device__ __forceinline__ void tab_load_masked(const u32 *tab, u32 idx, Fcanon &x, Fcanon &y)
+{
+	u32 w[16];
+#pragma unroll
+	for (int k = 0; k < 16; k++) {
+		w[k] = 0;
+	}
+#pragma unroll 1
+	for (u32 e = 0; e < TBL_ENTRIES; e++) {
+		const uint4 *s = (const uint4 *)(tab + (size_t)e * TAB_ENT_WORDS);
+		const u32 m = 0u - (u32)(e == idx);
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			const uint4 v = s[q];
+			w[4 * q] |= v.x & m; w[4 * q + 1] |= v.y & m; w[4 * q + 2] |= v.z & m; w[4 * q + 3] |= v.w & m;
+		}
+	}
+	x = from_words(w);
+	y = from_words(w + 8);
+}
 // entries of the shared tables of the generator: 2 x 9 digits in 20 words
 template <int NQ> static __device__ __forceinline__ void ld(u32 *b, const u32 *s)
 {
@@ -210,6 +232,7 @@ template <int NQ> static __device__ __forceinline__ void ld(u32 *b, const u32 *s
 		b[4 * i + 3] = v.w;
 	}
 }
+static __device__ __forceinline__ void lut_load_masked(const u32 *lut, u32 idx, Fcanon &x, Fcanon &y);
 static __device__ __forceinline__ void lut_load(const u32 *lut, size_t e, Fcanon &x, Fcanon &y)
 {
 	u32 b[20];
@@ -407,7 +430,33 @@ template <int KW> static __device__ __forceinline__ u32 recode_window(u32 *kw, c
 
 // KW = 8: scalars of up to 32 bytes (everything below the group order's length); KW = 17: up to 68 bytes -- blinded scalars
 // m + b #E of prj_pt_mul_blind (curves/prj_pt.c:1782-1822, about 2 |q| bits) stay on this kernel instead of the saturated one
-template <int KW>
+static __device__ __forceinline__ void lut_load_masked(const u32 *lut, u32 idx, Fcanon &x, Fcanon &y)
+{
+	u32 b[20];
+#pragma unroll
+	for (int k = 0; k < 20; k++) {
+		b[k] = 0;
+	}
+#pragma unroll 1
+	for (u32 e = 0; e < TBL_ENTRIES; e++) {
+		u32 t[20];
+		ld<5>(t, lut + (size_t)e * TBL_WORDS_PER_ENTRY);
+		const u32 m = 0u - (u32)(e == idx);
+#pragma unroll
+		for (int k = 0; k < 18; k++) {
+			b[k] |= t[k] & m;
+		}
+	}
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		x.l[w] = b[w];
+		y.l[w] = b[9 + w];
+	}
+}
+
+// MASKED: secret scalars -- every look-up scans its eight-entry table (per-item records or the shared window table of the
+// generator; the comb table is not used in this mode)
+template <int KW, bool MASKED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, P256_WAVES))) void k_p256_loop(EcamdSmulArgs A)
 {
 	const u32 i = blockIdx.x * 64 + threadIdx.x;
@@ -451,10 +500,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 		kw[0] <<= 4;
 		const u32 mag = (u32)(dig < 0 ? -dig : dig);
 		Fcanon tx, tyc;
-		if (shared) {
-			lut_load(A.lut, mag ? mag - 1 : 0, tx, tyc);
+		const u32 idx = mag ? mag - 1 : 0;
+		if (MASKED) {
+			if (shared) {
+				lut_load_masked(A.lut, idx, tx, tyc);
+			} else {
+				tab_load_masked(tabi, idx, tx, tyc);
+			}
+		} else if (shared) {
+			lut_load(A.lut, idx, tx, tyc);
 		} else {
-			tab_load(tabi, mag ? mag - 1 : 0, tx, tyc);
+			tab_load(tabi, idx, tx, tyc);
 		}
 		const FYaff ty = sel(dig < 0, neg_aff(tyc), weaken<FYaff>(tyc));
 		const Jac S = madd(acc, tx, ty, hz);
@@ -869,10 +925,16 @@ hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s, hipEven
 	if (a.lut && a.lut_kind == 1) {
 		hipLaunchKernelGGL(k_p256_comb, grid, block, 0, s, a);
 	} else {
-		if (a.slen <= 32) {
-			hipLaunchKernelGGL(k_p256_loop<8>, grid, block, 0, s, a);
+		if (a.masked) {
+			if (a.slen <= 32) {
+				hipLaunchKernelGGL((k_p256_loop<8, true>), grid, block, 0, s, a);
+			} else {
+				hipLaunchKernelGGL((k_p256_loop<17, true>), grid, block, 0, s, a);
+			}
+		} else if (a.slen <= 32) {
+			hipLaunchKernelGGL((k_p256_loop<8, false>), grid, block, 0, s, a);
 		} else {
-			hipLaunchKernelGGL(k_p256_loop<17>, grid, block, 0, s, a);
+			hipLaunchKernelGGL((k_p256_loop<17, false>), grid, block, 0, s, a);
 		}
 	}
 	P256_MARK(3);
