@@ -59,6 +59,10 @@ const char *ecamd_last_error(void);
 /* Upper bound on the items processed per kernel launch (bounds the per-lane window-table
  * scratch: 16 * 3 * 4*ceil(|p|/32) bytes per item).  Default 2^20. */
 int ecamd_ctx_set_max_chunk(ecamd_ctx *ctx, uint32_t max_items);
+/* Ed25519 whole-batch verification (ec_eddsa_verify_all_batch) through the multi-scalar multiplication: mode 0 never, 1 for
+ * batches of at least min_items (default; min_items = 0 keeps the current threshold, initially 2^18 or $ECAMD_MSM_MIN),
+ * 2 always.  items_per_lane: signatures that share one lane's doublings, 0 = chosen from the batch size (1 .. 8). */
+int ecamd_ctx_set_eddsa_msm(ecamd_ctx *ctx, int mode, uint32_t min_items, uint32_t items_per_lane);
 /* Secret scalars.  By default the kernels index their window / comb tables with the scalar's digits (fastest; fine for public
  * scalars: verification, public-key checks).  With this switch on, every scalar multiplication issued through the context --
  * ec_prj_pt_mul_batch*, and inside ec_ecdsa_sign_batch, ec_ecccdh_derive_batch, ec_eddsa_sign_R_batch, key-pair import -- uses
@@ -197,14 +201,24 @@ int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, 
 			  const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, uint8_t *result);
 
 /* Whole-batch predicate of ec_verify_batch (sig/sig_algs.c:675; eddsa_verify_batch sig/eddsa.c:2904,
- * _eddsa_verify_batch_no_memory :2278) for the EdDSA variants: *all_valid = 1 iff libecc's per-signature verification
- * accepts every item.  libecc decides the same predicate with one random linear combination of the cofactored equations
- * (it may accept a bad batch with probability ~2^-128; this entry point never does) and rejects num = 0, as this does
- * (-1).  first_rejected (may be NULL) receives the lowest rejected index, n if none -- the reference gives no such hint and
- * callers re-verify one by one.  Same inputs as ec_eddsa_verify_batch. */
+ * _eddsa_verify_batch_no_memory :2278) for the EdDSA variants: *all_valid = 1 iff libecc's batch verification accepts.
+ * libecc rejects num = 0, as this does (-1).  first_rejected (may be NULL) receives the lowest rejected index, n if none --
+ * the reference gives no such hint and callers re-verify one by one.  Same inputs as ec_eddsa_verify_batch.
+ *   Ed25519 batches of at least 2^18 items (ecamd_ctx_set_eddsa_msm): the reference's own equation
+ *     [8]([-sum z_i S_i]B + sum [z_i h_i]A_i + sum [z_i]R_i) = 0, z_i 128 random bits (ChaCha20 on the device, keyed by 32
+ *     bytes of getrandom per call), after the reference's per-item rejections (decoding, S >= q, [8]A_i = 0) -- evaluated as
+ *     ONE multi-scalar multiplication on the Edwards curve (Straus, the 256 doublings shared by up to 8 signatures per lane).
+ *     Like libecc's, this test accepts a batch with a bad signature with probability ~2^-128.  A batch it rejects is then
+ *     verified item by item, which yields first_rejected.
+ *   otherwise (small batches, Ed448): every item is verified; the bit is the exact conjunction. */
 int ec_eddsa_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *pubkeys,
 			      const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, int *all_valid,
 			      uint32_t *first_rejected);
+
+/* The multi-scalar multiplication alone, device pointers (WEI25519 handle; any n > 0): d_verdict[0] = 0 when libecc's batch
+ * equation holds and no item is rejected beforehand, 1 otherwise.  Only enqueues on the stream. */
+int ec_eddsa_verify_all_batch_dev(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const void *d_pubkeys,
+				  const void *d_sigs, const void *d_hram, uint32_t hram_len, void *d_verdict, void *hip_stream);
 
 /* Ed25519 signing (EDDSA25519 / EDDSA25519CTX / EDDSA25519PH on the WEI25519 handle), the device-side steps of ec_sign ->
  * _eddsa_sign (sig/eddsa.c:1554-1870) around the caller's two hashes -- the split ec_eddsa_verify_batch uses:
@@ -347,6 +361,12 @@ int ecamd_multi_eddsa_verify_batch(ecamd_multi *m, const ecamd_mcurve *curve, ui
  * equal-size shards.  d_send[r]: bytes_per_rank bytes on rank r's device; d_recv[r]: nranks * bytes_per_rank bytes
  * there.  librccl is loaded on first use; needs distinct devices.  Synchronous. */
 int ecamd_multi_allgather(ecamd_multi *m, const void *const *d_send, void *const *d_recv, size_t bytes_per_rank);
+
+/* Test hook of the Ed25519 multi-scalar multiplication: the combination with a caller-chosen 32-byte seed.  z_out (n x 16
+ * little-endian z_i) and sum_out (36 words: X, Y, Z, T of the sum before the cofactor, nine radix-2^29 digits each of lazily
+ * reduced residues mod 2^255 - 19) may be NULL.  n <= the context's max_chunk. */
+int ecamd_debug_eddsa_msm(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs,
+			  const uint8_t *hram, const uint8_t seed[32], int *accept, uint8_t *z_out, uint32_t *sum_out);
 
 #ifdef __cplusplus
 }

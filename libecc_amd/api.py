@@ -9,7 +9,7 @@ FP_MUL_MONTY, FP_ADD, FP_SUB, FP_MUL, FP_INV = 0, 1, 2, 3, 4
 # every symbol include/libecc_amd.h declares (tests check the .so exports exactly these)
 EXPORTED_SYMBOLS = [
     "ecamd_device_count", "ecamd_ctx_create", "ecamd_ctx_destroy", "ecamd_last_error",
-    "ecamd_ctx_set_max_chunk", "ecamd_ctx_set_secret_scalars", "ecamd_ctx_enable_kernel_timing", "ecamd_ctx_kernel_times", "ecamd_curve_by_name", "ecamd_curve_from_params", "ecamd_curve_free",
+    "ecamd_ctx_set_max_chunk", "ecamd_ctx_set_secret_scalars", "ecamd_ctx_set_eddsa_msm", "ec_eddsa_verify_all_batch_dev", "ecamd_debug_eddsa_msm", "ecamd_ctx_enable_kernel_timing", "ecamd_ctx_kernel_times", "ecamd_curve_by_name", "ecamd_curve_from_params", "ecamd_curve_free",
     "ecamd_curve_coord_len", "ecamd_curve_order_len", "ecamd_curve_words", "ec_prj_pt_mul_batch", "ec_prj_pt_mul_blind_batch",
     "ec_prj_pt_mul_batch_dev", "ecamd_ctx_synchronize", "ec_prj_pt_add_batch", "ec_prj_pt_dbl_batch",
     "ec_fp_op_batch", "ec_ecdsa_verify_batch", "ec_ecdsa_verify_batch_fmt", "ec_ecdsa_sign_batch", "ec_ecccdh_derive_batch", "ec_xdh_batch",
@@ -75,6 +75,9 @@ def load_library():
         L.ec_xdh_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
         L.ec_eddsa_verify_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p]
         L.ec_eddsa_verify_all_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
+        L.ecamd_debug_eddsa_msm.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p, C.POINTER(C.c_int), vp, vp]
+        L.ecamd_ctx_set_eddsa_msm.argtypes = [vp, C.c_int, u32, u32]
+        L.ec_eddsa_verify_all_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp]
         L.ec_prj_pt_mul_batch_fmt.argtypes = [vp, vp, u32, u8p, u32, u8p, C.c_int, u8p, C.c_int, u8p]
         L.ec_prj_pt_unique_batch.argtypes = [vp, vp, u32, u8p, C.c_int, u8p, C.c_int, u8p]
         L.ec_structured_pub_key_import_batch.argtypes = [vp, vp, u32, u8p, u32, C.c_int, u8p, u8p]
@@ -145,6 +148,10 @@ class Context:
 
     def set_secret_scalars(self, on=True):
         _chk(self.L, self.L.ecamd_ctx_set_secret_scalars(self.h, 1 if on else 0), "ecamd_ctx_set_secret_scalars")
+
+    def set_eddsa_msm(self, mode=1, min_items=0, items_per_lane=0):
+        """Ed25519 whole-batch verification through the multi-scalar multiplication: 0 never, 1 large batches, 2 always"""
+        _chk(self.L, self.L.ecamd_ctx_set_eddsa_msm(self.h, mode, min_items, items_per_lane), "ecamd_ctx_set_eddsa_msm")
 
     def enable_kernel_timing(self, on=True):
         _chk(self.L, self.L.ecamd_ctx_enable_kernel_timing(self.h, 1 if on else 0), "ecamd_ctx_enable_kernel_timing")
@@ -313,7 +320,23 @@ class Curve:
                                                        C.byref(ok), C.byref(first)), "ec_eddsa_verify_all_batch")
         return bool(ok.value), first.value
 
+    def debug_eddsa_msm(self, pubkeys, sigs, hram, seed):
+        """test hook: (accept, z_i as n x 16 bytes little-endian, [X, Y, Z, T] of the sum before the cofactor as integers mod p)"""
+        n = len(pubkeys) // 32
+        acc = C.c_int(0)
+        z = C.create_string_buffer(16 * n)
+        w = (C.c_uint32 * 36)()
+        _chk(self.L, self.L.ecamd_debug_eddsa_msm(self.ctx.h, self.h, n, pubkeys, sigs, hram, seed, C.byref(acc),
+                                                   C.cast(z, C.c_void_p), C.cast(w, C.c_void_p)), "ecamd_debug_eddsa_msm")
+        p = 2 ** 255 - 19
+        coords = [sum(int(w[9 * c + i]) << (29 * i) for i in range(9)) % p for c in range(4)]
+        return bool(acc.value), z.raw, coords
+
     # -- device-pointer forms (torch tensors' data_ptr()); see include/libecc_amd.h for which ones synchronise --
+    def eddsa_verify_all_dev(self, n, d_pubs, d_sigs, d_hram, d_verdict, stream=None):
+        _chk(self.L, self.L.ec_eddsa_verify_all_batch_dev(self.ctx.h, self.h, n, d_pubs, d_sigs, d_hram, 64, d_verdict, stream),
+             "ec_eddsa_verify_all_batch_dev")
+
     def ecdsa_verify_dev(self, n, d_pubs, d_sigs, d_digests, hlen, d_result, stream=None):
         _chk(self.L, self.L.ec_ecdsa_verify_batch_dev(self.ctx.h, self.h, n, d_pubs, d_sigs, d_digests, hlen, d_result,
                                                        stream), "ec_ecdsa_verify_batch_dev")

@@ -1115,6 +1115,96 @@ static __device__ __forceinline__ Pre pre_load(const u32 *base, u32 e)
 	}
 	return Q;
 }
+// window table [1..8]P of the signed w = 4 recoding
+static __device__ void ed_table(u32 *tb, const Ext &P1, const FC &d2, const CK &K)
+{
+	const Pre Q1 = ed_pre(P1, d2, K);
+	pre_store(tb, 0, Q1);
+	const Ext P2 = ed_dbl<true>(P1, K);
+	pre_store(tb, 1, ed_pre(P2, d2, K));
+	const Ext P3 = ed_add(P2, Q1, false, K);
+	pre_store(tb, 2, ed_pre(P3, d2, K));
+	const Ext P4 = ed_dbl<true>(P2, K);
+	pre_store(tb, 3, ed_pre(P4, d2, K));
+	const Ext P5 = ed_add(P4, Q1, false, K);
+	pre_store(tb, 4, ed_pre(P5, d2, K));
+	const Ext P6 = ed_dbl<true>(P3, K);
+	pre_store(tb, 5, ed_pre(P6, d2, K));
+	const Ext P7 = ed_add(P6, Q1, false, K);
+	pre_store(tb, 6, ed_pre(P7, d2, K));
+	const Ext P8 = ed_dbl<true>(P4, K);
+	pre_store(tb, 7, ed_pre(P8, d2, K));
+}
+static __device__ __forceinline__ Ext ed_neutral(const CK &K)
+{
+	Ext N;
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		N.X.l[w] = 0;
+		N.T.l[w] = 0;
+	}
+	N.Y = weaken<FM>(constant<FC>(K.one));
+	N.Z = N.Y;
+	return N;
+}
+// affine (x, y) -> extended
+template <class AX> static __device__ __forceinline__ Ext ed_from_affine(const AX &x, const FM &y, const CK &K)
+{
+	Ext P;
+	P.X = M_(x, constant<FC>(K.one));
+	P.Y = y;
+	P.Z = weaken<FM>(constant<FC>(K.one));
+	P.T = M_(P.X, y);
+	return P;
+}
+static __device__ __forceinline__ void ext_store(u32 *dst, const Ext &P)
+{
+	u32 buf[36];
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		buf[w] = P.X.l[w];
+		buf[9 + w] = P.Y.l[w];
+		buf[18 + w] = P.Z.l[w];
+		buf[27 + w] = P.T.l[w];
+	}
+	uint4 *d = (uint4 *)dst;
+#pragma unroll
+	for (int q = 0; q < 9; q++) {
+		d[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
+	}
+}
+static __device__ __forceinline__ Ext ext_load(const u32 *src)
+{
+	u32 buf[36];
+	const uint4 *p = (const uint4 *)src;
+#pragma unroll
+	for (int q = 0; q < 9; q++) {
+		const uint4 v = p[q];
+		buf[4 * q] = v.x; buf[4 * q + 1] = v.y; buf[4 * q + 2] = v.z; buf[4 * q + 3] = v.w;
+	}
+	Ext P;
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		P.X.l[w] = buf[w];
+		P.Y.l[w] = buf[9 + w];
+		P.Z.l[w] = buf[18 + w];
+		P.T.l[w] = buf[27 + w];
+	}
+	return P;
+}
+// acc += [nib - 8]P for the table tb of P (nib: one nibble of the recoded scalar)
+static __device__ __forceinline__ void ed_window_add(Ext &acc, const u32 *tb, u32 nib, const CK &K)
+{
+	const int dig = (int)nib - 8;
+	const u32 mag = (u32)(dig < 0 ? -dig : dig);
+	const Pre Q = pre_load(tb, mag ? mag - 1 : 0);
+	const Ext S = ed_add(acc, Q, dig < 0, K);
+	const bool keep = (mag == 0);
+	acc.X = selg(keep, acc.X, S.X);
+	acc.Y = selg(keep, acc.Y, S.Y);
+	acc.Z = selg(keep, acc.Z, S.Z);
+	acc.T = selg(keep, acc.T, S.T);
+}
 #undef M_
 #undef S_
 }  // namespace c25519
@@ -1149,24 +1239,7 @@ __global__ __launch_bounds__(64) void k_ed_smul_c25519(EcamdEdSmulArgs A, int gs
 		P1.Z = onem;
 		P1.T = weaken<FM>(mul(P1.X, P1.Y, K));
 	}
-	const Pre Q1 = ed_pre(P1, d2, K);
-	pre_store(tb, 0, Q1);
-	{
-		const Ext P2 = ed_dbl<true>(P1, K);
-		pre_store(tb, 1, ed_pre(P2, d2, K));
-		const Ext P3 = ed_add(P2, Q1, false, K);
-		pre_store(tb, 2, ed_pre(P3, d2, K));
-		const Ext P4 = ed_dbl<true>(P2, K);
-		pre_store(tb, 3, ed_pre(P4, d2, K));
-		const Ext P5 = ed_add(P4, Q1, false, K);
-		pre_store(tb, 4, ed_pre(P5, d2, K));
-		const Ext P6 = ed_dbl<true>(P3, K);
-		pre_store(tb, 5, ed_pre(P6, d2, K));
-		const Ext P7 = ed_add(P6, Q1, false, K);
-		pre_store(tb, 6, ed_pre(P7, d2, K));
-		const Ext P8 = ed_dbl<true>(P4, K);
-		pre_store(tb, 7, ed_pre(P8, d2, K));
-	}
+	ed_table(tb, P1, d2, K);
 	// scalar: 32 bytes big-endian, k' = k + 0x88..8, top digit = the carry (0 / +1)
 	u32 kw[8];
 	load_be<8>(A.scalars + (size_t)i * 32, 32, kw);
@@ -1326,6 +1399,194 @@ __global__ __launch_bounds__(64) void k_ed_hA_fin(EcamdEdSmulArgs A, int gslot, 
 			A.status[i] = neutral ? 2 : 0;
 		}
 	}
+}
+
+// ------------------------------------------------------------------------------------------
+// Ed25519 whole-batch verification (ec_verify_batch's EdDSA branch, sig/eddsa.c:2278-2545) as one multi-scalar
+// multiplication on the Edwards curve: T = [q - sum z_i S_i]B + sum_i ([z_i h_i]A_i + [z_i]R_i), accepted when [8]T is the
+// neutral element.  The formulas are complete, so no pair of inputs is exceptional.
+//   k_edmsm_prep    per item: decode A_i and R_i (no Weierstrass map, no inversion), the reference's per-item rejections
+//                   (decoding, [8]A_i = neutral), window tables [1..8]A_i and [1..8]R_i
+//   k_edmsm_loop    per lane: the items j * L + lane, j < K, and the base point share 64 x 4 doublings (Straus); R_i only
+//                   enters the last 33 windows (z_i has 128 bits)
+//   k_edmsm_reduce  tree sum of the lane results, cofactor, verdict
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_edmsm_btable(EcamdEdMsmArgs A, u32 *tblB, int gslot)
+{
+	using namespace c25519;
+	if (blockIdx.x != 0 || threadIdx.x != 0) {
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const FM ym = weaken<FM>(mul(digits9(A.g_By), constant<FC>(K.one), K));
+	ed_table(tblB, ed_from_affine(digits9(A.g_Bx), ym, K), digits9(A.g_2d), K);
+}
+
+__global__ __launch_bounds__(64) void k_edmsm_prep(EcamdEdMsmArgs A, int gslot)
+{
+	using namespace c25519;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const FC d2 = digits9(A.g_2d);
+	EcamdEdDecodeArgs D;   // decode_xy reads the two constants only
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		D.g_d[w] = A.g_d[w];
+		D.g_sm1[w] = A.g_sm1[w];
+	}
+	u32 *tb = A.tbl + (size_t)i * (2 * EDT_ITEM_WORDS);
+	u8 flag = 0;
+#pragma unroll 1
+	for (int k = 0; k < 2; k++) {
+		const DecXY P = decode_xy(D, k == 0 ? A.encA + (size_t)i * A.strideA : A.encR + (size_t)i * A.strideR, K);
+		// R = (0, 1) is accepted by the reference (it becomes the point at infinity of the Weierstrass model)
+		bool good = P.ok | (k == 1 && P.neutral);
+		Ext P1 = ed_neutral(K);
+		if (P.ok) {
+			P1 = ed_from_affine(P.x, P.ym, K);
+		}
+		if (k == 0 && good) {
+			// the reference rejects a key with [cofactor]A = infinity (sig/eddsa.c:2463-2472)
+			Ext Q = P1;
+			for (u32 r = 0; r < A.cof_dbl; r++) {
+				Q = ed_dbl<false>(Q, K);
+			}
+			good = !is_zero_mulout(Q.X, K);
+			if (!good) {
+				P1 = ed_neutral(K);
+			}
+		}
+		ed_table(tb + k * EDT_ITEM_WORDS, P1, d2, K);
+		flag |= good ? 0 : 1;
+	}
+	A.flags[i] = flag;
+}
+
+__global__ __launch_bounds__(64) void k_edmsm_loop(EcamdEdMsmArgs A, int gslot)
+{
+	using namespace c25519;
+	const u32 lane = blockIdx.x * 64 + threadIdx.x;
+	if (lane >= A.L) {
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	Ext acc = ed_neutral(K);
+#pragma unroll 1
+	for (int t = 0; t < 64; t++) {
+		acc = ed_dbl<false>(acc, K);
+		acc = ed_dbl<false>(acc, K);
+		acc = ed_dbl<false>(acc, K);
+		acc = ed_dbl<true>(acc, K);
+		const u32 wsel = 7u - ((u32)t >> 3);
+		const u32 sh = 28u - 4u * ((u32)t & 7u);
+#pragma unroll 1
+		for (u32 j = 0; j < A.K; j++) {
+			const u32 item = j * A.L + lane;
+			if (item < A.n) {
+				const u32 word = A.cA[(size_t)wsel * A.n + item];
+				ed_window_add(acc, A.tbl + (size_t)item * (2 * EDT_ITEM_WORDS), (word >> sh) & 15u, K);
+			}
+		}
+		{
+			const u32 word = A.sB[(size_t)wsel * A.L + lane];
+			ed_window_add(acc, A.tblB, (word >> sh) & 15u, K);
+		}
+		if (t >= 31) {   // z_i + 0x8 88..8 has 132 bits: windows 31..63
+#pragma unroll 1
+			for (u32 j = 0; j < A.K; j++) {
+				const u32 item = j * A.L + lane;
+				if (item < A.n) {
+					const u32 word = A.zR[(size_t)wsel * A.n + item];
+					ed_window_add(acc, A.tbl + (size_t)item * (2 * EDT_ITEM_WORDS) + EDT_ITEM_WORDS, (word >> sh) & 15u, K);
+				}
+			}
+		}
+	}
+	ext_store(A.rec + (size_t)lane * ECAMD_EDM_REC_WORDS, acc);
+}
+
+#define EDM_FAN 16
+// out[t] = in[t] + in[t + T] + in[t + 2T] + ...
+__global__ __launch_bounds__(64) void k_edmsm_sum(EcamdEdMsmArgs A, const u32 *in, u32 count, u32 *out, u32 T, int gslot)
+{
+	using namespace c25519;
+	const u32 t = blockIdx.x * 64 + threadIdx.x;
+	if (t >= T) {
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const FC d2 = digits9(A.g_2d);
+	Ext acc = ext_load(in + (size_t)t * ECAMD_EDM_REC_WORDS);
+#pragma unroll 1
+	for (u32 i = t + T; i < count; i += T) {
+		const Ext P = ext_load(in + (size_t)i * ECAMD_EDM_REC_WORDS);
+		acc = ed_add(acc, ed_pre(P, d2, K), false, K);
+	}
+	ext_store(out + (size_t)t * ECAMD_EDM_REC_WORDS, acc);
+}
+__global__ __launch_bounds__(64) void k_edmsm_final(EcamdEdMsmArgs A, const u32 *in, u32 count, const u32 *flagword, u8 *verdict,
+						    u32 *sum_out, int gslot)
+{
+	using namespace c25519;
+	if (blockIdx.x != 0 || threadIdx.x != 0) {
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const FC d2 = digits9(A.g_2d);
+	Ext acc = ext_load(in);
+#pragma unroll 1
+	for (u32 i = 1; i < count; i++) {
+		const Ext P = ext_load(in + (size_t)i * ECAMD_EDM_REC_WORDS);
+		acc = ed_add(acc, ed_pre(P, d2, K), false, K);
+	}
+	if (sum_out != nullptr) {
+		ext_store(sum_out, acc);
+	}
+	for (u32 r = 0; r < A.cof_dbl; r++) {
+		acc = ed_dbl<false>(acc, K);
+	}
+	// a point of the prime-order subgroup with X = 0 is the neutral element
+	const bool neutral = is_zero_mulout(acc.X, K) & eq(acc.Y, acc.Z, K);
+	if (!(neutral && flagword[0] == 0)) {
+		verdict[0] = 1;   // the host cleared the byte; several pieces may share it
+	}
+}
+
+hipError_t ecamd_launch_edmsm_btable(const EcamdEdMsmArgs &a, uint32_t *tblB, int gslot, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_edmsm_btable, dim3(1), dim3(64), 0, s, a, tblB, gslot);
+	return hipGetLastError();
+}
+hipError_t ecamd_launch_edmsm_prep(const EcamdEdMsmArgs &a, int gslot, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_edmsm_prep, dim3((a.n + 63) / 64), dim3(64), 0, s, a, gslot);
+	return hipGetLastError();
+}
+hipError_t ecamd_launch_edmsm_loop(const EcamdEdMsmArgs &a, int gslot, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_edmsm_loop, dim3((a.L + 63) / 64), dim3(64), 0, s, a, gslot);
+	return hipGetLastError();
+}
+hipError_t ecamd_launch_edmsm_reduce(const EcamdEdMsmArgs &a, uint32_t *tmp, const uint32_t *flagword, uint8_t *verdict,
+				     uint32_t *sum_out, int gslot, hipStream_t s)
+{
+	// ping-pong: rec -> tmp -> rec ... (the second buffer needs ceil(L / EDM_FAN) records)
+	const uint32_t *in = a.rec;
+	uint32_t *bufs[2] = {tmp, a.rec};
+	uint32_t count = a.L;
+	int b = 0;
+	while (count > 32) {
+		const uint32_t T = (count + EDM_FAN - 1) / EDM_FAN;
+		hipLaunchKernelGGL(k_edmsm_sum, dim3((T + 63) / 64), dim3(64), 0, s, a, in, count, bufs[b], T, gslot);
+		in = bufs[b];
+		b ^= 1;
+		count = T;
+	}
+	hipLaunchKernelGGL(k_edmsm_final, dim3(1), dim3(64), 0, s, a, in, count, flagword, verdict, sum_out, gslot);
+	return hipGetLastError();
 }
 
 hipError_t ecamd_launch_ed_smul_c25519(const EcamdEdSmulArgs &a, int gslot, hipStream_t s)

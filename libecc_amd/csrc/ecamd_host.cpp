@@ -17,6 +17,7 @@
 #include <vector>
 #include <functional>
 #include <mutex>
+#include <sys/random.h>
 
 #include "../../include/libecc_amd.h"
 #include "ecamd_internal.h"
@@ -231,6 +232,10 @@ struct ecamd_ctx {
 	size_t hbuf_bytes[2][6];
 	uint32_t comb_min_batch;   // fixed-base batches of at least this many items build / use the generator's comb table (0: never)
 	bool secret_scalars;       // ecamd_ctx_set_secret_scalars: constant-address look-ups, no data-dependent kernel choice
+	int eddsa_msm;             // ecamd_ctx_set_eddsa_msm: 0 never, 1 batches of at least msm_min items, 2 always
+	uint32_t msm_min, msm_k;   // msm_k: items per lane of the Straus evaluation (0: chosen from the batch size)
+	uint8_t *msm;              // scratch of the multi-scalar multiplication
+	size_t msm_bytes;
 	bool timing;               // record HIP events around the kernels of the scalar-mult pipeline
 	hipEvent_t ev[ECAMD_NTIMED + 1];
 	bool ev_valid;  // radix-2^29 constant slots, indexed by |p| in bits
@@ -260,6 +265,7 @@ struct ecamd_curve {
 	EcamdEd448DecodeArgs ed448_tmpl;
 	uint8_t ed448_c4[56]; // 4^-1 mod q, big-endian (eddsa_import_pub_key multiplies the key by it)
 	uint32_t ed_2d[9];   // 2 d mod p, plain radix-2^29 digits (Edwards arithmetic of the 2^255 - 19 unit)
+	uint32_t ed_Bx[9], ed_By[9];  // the Ed25519 base point, the same digits
 	int xdh_state;
 	const char *xdh_err;
 	EcamdXdhPrepArgs xdh_tmpl;
@@ -340,6 +346,21 @@ extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
 	}
 	c->timing = false;
 	c->secret_scalars = false;
+	c->eddsa_msm = 1;
+	c->msm_min = 1u << 18;
+	c->msm_k = 0;
+	{
+		const char *e = getenv("ECAMD_MSM_MIN");
+		if (e) {
+			c->msm_min = (uint32_t)strtoul(e, nullptr, 10);
+		}
+		e = getenv("ECAMD_MSM_K");
+		if (e) {
+			c->msm_k = (uint32_t)strtoul(e, nullptr, 10);
+		}
+	}
+	c->msm = nullptr;
+	c->msm_bytes = 0;
 	c->ev_valid = false;
 	for (int i = 0; i <= ECAMD_NTIMED; i++) {
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) {
@@ -383,6 +404,9 @@ extern "C" void ecamd_ctx_destroy(ecamd_ctx *c)
 	if (c->tbl_fast) {
 		(void)hipFree(c->tbl_fast);
 	}
+	if (c->msm) {
+		(void)hipFree(c->msm);
+	}
 	for (int i = 0; i < ECAMD_NSTAGE; i++) {
 		if (c->stage[i]) {
 			(void)hipFree(c->stage[i]);
@@ -412,6 +436,20 @@ extern "C" int ecamd_ctx_set_max_chunk(ecamd_ctx *c, uint32_t max_items)
 		return fail("ecamd_ctx_set_max_chunk: bad argument");
 	}
 	c->max_chunk = max_items;
+	return 0;
+}
+
+extern "C" int ecamd_ctx_set_eddsa_msm(ecamd_ctx *c, int mode, uint32_t min_items, uint32_t items_per_lane)
+{
+	if (!c || mode < 0 || mode > 2 || items_per_lane > 64) {
+		return fail("ecamd_ctx_set_eddsa_msm: bad argument");
+	}
+	std::lock_guard<std::mutex> lk(c->mu);
+	c->eddsa_msm = mode;
+	if (min_items) {
+		c->msm_min = min_items;
+	}
+	c->msm_k = items_per_lane;
 	return 0;
 }
 
@@ -2314,6 +2352,8 @@ static void ed_setup(ecamd_curve *cv)
 			cv->ed_err = "ec_eddsa_verify_batch: the curve generator is not the image of the Ed25519 base point";
 			return;
 		}
+		big_digits29(cv->ed_Bx, 9, xb);
+		big_digits29(cv->ed_By, 9, yb);
 	}
 	cv->ed_cof_dbl = 0xffffffffu;
 	{
@@ -2712,6 +2752,230 @@ extern "C" int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, u
 	});
 }
 
+// ------------------------------------------------------------------------------------------
+// Ed25519 whole-batch verification as one multi-scalar multiplication (the equation of _eddsa_verify_batch_no_memory,
+// sig/eddsa.c:2278-2545, on the Edwards curve; kernels k_edmsm_* of ecamd_g29_kernel.hip / ecamd_kernels.hip).
+// verdict byte: 0 = the combination vanishes and no item was rejected beforehand, 1 otherwise.  Only enqueues.
+// ------------------------------------------------------------------------------------------
+static size_t msm_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static bool eddsa_msm_available(const ecamd_curve *cv)
+{
+	return cv->pbits == 255 && cv->ed_state == 1 && cv->gflavour == 2 && cv->gslot >= 0;
+}
+
+static uint32_t eddsa_msm_pick_k(const ecamd_ctx *ctx, uint32_t n)
+{
+	if (ctx->msm_k) {
+		return ctx->msm_k;
+	}
+	// one wave per SIMD needs 65536 lanes; two or more hide the table look-ups better
+	uint32_t k = n >> 17;
+	if (k < 1) {
+		k = 1;
+	}
+	return k > 8 ? 8 : k;
+}
+
+static int eddsa_msm_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig,
+				const uint8_t *d_hram, const uint8_t seed[32], uint32_t piece, uint8_t *d_verdict, uint8_t *d_z_dump,
+				uint32_t *d_sum_dump, hipStream_t s)
+{
+	const uint32_t K = eddsa_msm_pick_k(ctx, n);
+	const uint32_t L = (n + K - 1) / K;
+	size_t off = 0;
+	auto carve = [&](size_t bytes) {
+		const size_t o = off;
+		off += msm_align(bytes);
+		return o;
+	};
+	const size_t o_tbl = carve((size_t)n * 2 * ECAMD_EDT_ITEM_WORDS * 4);
+	const size_t o_cA = carve((size_t)n * 32), o_zR = carve((size_t)n * 20), o_zs = carve((size_t)n * 32);
+	const size_t o_flags = carve(n), o_flagsS = carve(n);
+	const size_t o_sB = carve((size_t)L * 32), o_rec = carve((size_t)L * ECAMD_EDM_REC_WORDS * 4);
+	const size_t o_tmp = carve(((size_t)L / 16 + 1) * ECAMD_EDM_REC_WORDS * 4);
+	const size_t o_tblB = carve((size_t)ECAMD_EDT_ITEM_WORDS * 4), o_word = carve(4);
+	if (ensure(&ctx->msm, &ctx->msm_bytes, off)) {
+		return -1;
+	}
+	uint8_t *M = ctx->msm;
+	HIPCHK(hipMemsetAsync(M + o_word, 0, 4, s));
+	EcamdEdMsmArgs A;
+	memset(&A, 0, sizeof(A));
+	A.encA = d_pub;
+	A.strideA = 32;
+	A.encR = d_sig;
+	A.strideR = 64;
+	A.tbl = (uint32_t *)(M + o_tbl);
+	A.flags = M + o_flags;
+	A.cA = (const uint32_t *)(M + o_cA);
+	A.zR = (const uint32_t *)(M + o_zR);
+	A.sB = (const uint32_t *)(M + o_sB);
+	A.tblB = (const uint32_t *)(M + o_tblB);
+	A.rec = (uint32_t *)(M + o_rec);
+	A.n = n;
+	A.K = K;
+	A.L = L;
+	A.cof_dbl = cv->ed_cof_dbl;
+	memcpy(A.g_d, cv->ed_tmpl.g_d, sizeof(A.g_d));
+	memcpy(A.g_sm1, cv->ed_tmpl.g_sm1, sizeof(A.g_sm1));
+	memcpy(A.g_2d, cv->ed_2d, sizeof(A.g_2d));
+	memcpy(A.g_Bx, cv->ed_Bx, sizeof(A.g_Bx));
+	memcpy(A.g_By, cv->ed_By, sizeof(A.g_By));
+	HIPCHK(ecamd_launch_edmsm_btable(A, (uint32_t *)(M + o_tblB), cv->gslot, s));
+	HIPCHK(ecamd_launch_edmsm_prep(A, cv->gslot, s));
+	EcamdEdMsmScalArgs C;
+	memset(&C, 0, sizeof(C));
+	C.sigs = d_sig;
+	C.hram = d_hram;
+	C.cA = (uint32_t *)(M + o_cA);
+	C.zR = (uint32_t *)(M + o_zR);
+	C.zs = (uint32_t *)(M + o_zs);
+	C.flagsS = M + o_flagsS;
+	C.z_dump = d_z_dump;
+	memcpy(C.seed, seed, 32);
+	C.nonce[0] = piece;
+	C.n = n;
+	C.qslot = cv->qslot;
+	HIPCHK(ecamd_launch_edmsm_scal(C, s));
+	EcamdEdMsmLaneArgs N;
+	memset(&N, 0, sizeof(N));
+	N.zs = (const uint32_t *)(M + o_zs);
+	N.flags = M + o_flags;
+	N.flagsS = M + o_flagsS;
+	N.sB = (uint32_t *)(M + o_sB);
+	N.flagword = (uint32_t *)(M + o_word);
+	N.n = n;
+	N.K = K;
+	N.L = L;
+	N.qslot = cv->qslot;
+	HIPCHK(ecamd_launch_edmsm_lane(N, s));
+	HIPCHK(ecamd_launch_edmsm_loop(A, cv->gslot, s));
+	HIPCHK(ecamd_launch_edmsm_reduce(A, (uint32_t *)(M + o_tmp), (const uint32_t *)(M + o_word), d_verdict, d_sum_dump, cv->gslot, s));
+	return 0;
+}
+
+static int msm_seed(uint8_t seed[32])
+{
+	size_t got = 0;
+	while (got < 32) {
+		const ssize_t r = getrandom(seed + got, 32 - got, 0);
+		if (r <= 0) {
+			return fail("ec_eddsa_verify_all_batch: getrandom failed (the z_i of the batch equation must be unpredictable)");
+		}
+		got += (size_t)r;
+	}
+	return 0;
+}
+
+// host arrays -> one verdict: pieces of max_chunk items, each with its own combination.  *accept = 1 when every piece accepts.
+static int eddsa_msm_host_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs,
+				 const uint8_t *hram, const uint8_t *fixed_seed, int *accept, uint8_t *z_out, uint32_t *sum_out)
+{
+	uint8_t seed[32];
+	if (fixed_seed) {
+		memcpy(seed, fixed_seed, 32);
+	} else if (msm_seed(seed)) {
+		return -1;
+	}
+	hipStream_t s = ctx->stream;
+	StreamScope scope(ctx, s);
+	const uint32_t chunk = n < ctx->max_chunk ? n : ctx->max_chunk;
+	const uint32_t pieces = (n + chunk - 1) / chunk;
+	if (ensure(&ctx->stage[0], &ctx->stage_bytes[0], (size_t)chunk * 32) || ensure(&ctx->stage[1], &ctx->stage_bytes[1], (size_t)chunk * 64) ||
+	    ensure(&ctx->stage[2], &ctx->stage_bytes[2], (size_t)chunk * 64) ||
+	    ensure(&ctx->stage[3], &ctx->stage_bytes[3], (size_t)pieces + (z_out ? (size_t)chunk * 16 : 0) + 256 + ECAMD_EDM_REC_WORDS * 4)) {
+		return -1;
+	}
+	uint8_t *d_verdicts = ctx->stage[3];
+	HIPCHK(hipMemsetAsync(d_verdicts, 0, pieces, s));
+	uint32_t *d_sum = (uint32_t *)(ctx->stage[3] + ((pieces + 255) & ~(size_t)255));
+	uint8_t *d_z = z_out ? (uint8_t *)(d_sum + ECAMD_EDM_REC_WORDS) : nullptr;
+	for (uint32_t off = 0, pc = 0; off < n; off += chunk, pc++) {
+		const uint32_t m = (n - off) < chunk ? (n - off) : chunk;
+		HIPCHK(hipMemcpyAsync(ctx->stage[0], pubkeys + (size_t)off * 32, (size_t)m * 32, hipMemcpyHostToDevice, s));
+		HIPCHK(hipMemcpyAsync(ctx->stage[1], sigs + (size_t)off * 64, (size_t)m * 64, hipMemcpyHostToDevice, s));
+		HIPCHK(hipMemcpyAsync(ctx->stage[2], hram + (size_t)off * 64, (size_t)m * 64, hipMemcpyHostToDevice, s));
+		if (eddsa_msm_dev_locked(ctx, cv, m, ctx->stage[0], ctx->stage[1], ctx->stage[2], seed, pc, d_verdicts + pc, d_z,
+					 sum_out ? d_sum : nullptr, s)) {
+			(void)hipStreamSynchronize(s);
+			return -1;
+		}
+		if (z_out) {
+			HIPCHK(hipMemcpyAsync(z_out + (size_t)off * 16, d_z, (size_t)m * 16, hipMemcpyDeviceToHost, s));
+		}
+	}
+	std::vector<uint8_t> v(pieces, 1);
+	HIPCHK(hipMemcpyAsync(v.data(), d_verdicts, pieces, hipMemcpyDeviceToHost, s));
+	if (sum_out) {
+		HIPCHK(hipMemcpyAsync(sum_out, d_sum, ECAMD_EDM_REC_WORDS * 4, hipMemcpyDeviceToHost, s));
+	}
+	HIPCHK(hipStreamSynchronize(s));
+	*accept = 1;
+	for (uint32_t pc = 0; pc < pieces; pc++) {
+		if (v[pc] != 0) {
+			*accept = 0;
+		}
+	}
+	return 0;
+}
+
+extern "C" int ec_eddsa_verify_all_batch_dev(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const void *d_pubkeys,
+					     const void *d_sigs, const void *d_hram, uint32_t hram_len, void *d_verdict,
+					     void *hip_stream)
+{
+	if (!ctx) {
+		return fail("ec_eddsa_verify_all_batch_dev: bad argument");
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (eddsa_args_ok("ec_eddsa_verify_all_batch_dev", ctx, cv_in, n, d_pubkeys, d_sigs, d_hram, d_verdict, hram_len)) {
+		return -1;
+	}
+	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
+	if (n == 0 || !eddsa_msm_available(cv)) {
+		return fail("ec_eddsa_verify_all_batch_dev: needs n > 0 and Ed25519 (the WEI25519 handle on the 2^255 - 19 unit)");
+	}
+	uint8_t seed[32];
+	if (msm_seed(seed)) {
+		return -1;
+	}
+	HIPCHK(hipSetDevice(ctx->device));
+	hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+	StreamScope scope(ctx, s);
+	HIPCHK(hipMemsetAsync(d_verdict, 0, 1, s));
+	uint32_t pc = 0;
+	for (uint32_t off = 0; off < n; off += ctx->max_chunk, pc++) {
+		const uint32_t m = (n - off) < ctx->max_chunk ? (n - off) : ctx->max_chunk;
+		if (eddsa_msm_dev_locked(ctx, cv, m, (const uint8_t *)d_pubkeys + (size_t)off * 32, (const uint8_t *)d_sigs + (size_t)off * 64,
+					 (const uint8_t *)d_hram + (size_t)off * 64, seed, pc, (uint8_t *)d_verdict, nullptr, nullptr, s)) {
+			return -1;
+		}
+	}
+	return 0;
+}
+
+// test hook: the combination with a caller-chosen seed; z_out (n x 16 little-endian z_i) and sum_out (36 words: X, Y, Z, T of
+// the sum before the cofactor, radix-2^29 digits of lazily reduced residues) may be NULL.  n <= the context's max_chunk.
+extern "C" int ecamd_debug_eddsa_msm(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const uint8_t *pubkeys,
+				     const uint8_t *sigs, const uint8_t *hram, const uint8_t seed[32], int *accept, uint8_t *z_out,
+				     uint32_t *sum_out)
+{
+	if (!ctx || !accept || !seed) {
+		return fail("ecamd_debug_eddsa_msm: bad argument");
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	uint8_t dummy = 0;
+	if (eddsa_args_ok("ecamd_debug_eddsa_msm", ctx, cv_in, n, pubkeys, sigs, hram, &dummy, 64)) {
+		return -1;
+	}
+	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
+	if (n == 0 || n > ctx->max_chunk || !eddsa_msm_available(cv)) {
+		return fail("ecamd_debug_eddsa_msm: needs Ed25519 on the 2^255 - 19 unit and 0 < n <= max_chunk");
+	}
+	HIPCHK(hipSetDevice(ctx->device));
+	return eddsa_msm_host_locked(ctx, cv, n, pubkeys, sigs, hram, seed, accept, z_out, sum_out);
+}
+
 // Whole-batch predicate of ec_verify_batch (sig/sig_algs.c:675, eddsa_verify_batch sig/eddsa.c:2904): libecc accepts the
 // batch when one random linear combination of the cofactored equations vanishes, which holds when every signature verifies
 // and fails otherwise except with probability ~2^-128 over its random z_i.  Here every item is verified (the batch is the
@@ -2726,6 +2990,29 @@ extern "C" int ec_eddsa_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *cv, 
 	*all_valid = 0;
 	if (first_rejected) {
 		*first_rejected = n;
+	}
+	// large Ed25519 batches: the reference's own batch equation as one multi-scalar multiplication first; only a batch it
+	// rejects is verified item by item (for the first rejected index, and because a rejection of the combination proves
+	// that some item fails while the item-by-item results say which)
+	if (ctx && cv && cv->ctx == ctx && pubkeys && sigs && hram && hram_len == 64 && cv->pbits == 255) {
+		std::lock_guard<std::mutex> lk(ctx->mu);
+		ecamd_curve *cw = const_cast<ecamd_curve *>(cv);
+		if (ctx->eddsa_msm != 0 && (ctx->eddsa_msm == 2 || n >= ctx->msm_min)) {
+			if (cw->ed_state == 0) {
+				ed_setup(cw);
+			}
+			if (eddsa_msm_available(cw)) {
+				HIPCHK(hipSetDevice(ctx->device));
+				int accept = 0;
+				if (eddsa_msm_host_locked(ctx, cw, n, pubkeys, sigs, hram, nullptr, &accept, nullptr, nullptr)) {
+					return -1;
+				}
+				if (accept) {
+					*all_valid = 1;
+					return 0;
+				}
+			}
+		}
 	}
 	std::vector<uint8_t> res(n, 1);
 	if (ec_eddsa_verify_batch(ctx, cv, n, pubkeys, sigs, hram, hram_len, res.data())) {

@@ -140,6 +140,54 @@ struct EcamdEdSmulArgs {
 #define ECAMD_EDT_ITEM_WORDS 320
 #define ECAMD_EDR_REC_WORDS 28
 hipError_t ecamd_launch_ed_smul_c25519(const EcamdEdSmulArgs &a, int gslot, hipStream_t s);
+// ---- Ed25519 whole-batch verification as ONE multi-scalar multiplication on the Edwards curve (2^255 - 19 unit) ----
+// T = [q - sum z_i S_i]B + sum_i ([z_i h_i mod q]A_i + [z_i]R_i), accepted when [8]T is the neutral element
+// (_eddsa_verify_batch_no_memory, sig/eddsa.c:2278-2545).  Straus evaluation: lane l owns the items j * L + l (j < K) and
+// shares the 256 doublings between their 2K + 1 points.
+struct EcamdEdMsmArgs {
+	const uint8_t *encA, *encR;  // n compressed keys / signatures (R in the first half)
+	uint32_t strideA, strideR;
+	uint32_t *tbl;               // n x 2 x ECAMD_EDT_ITEM_WORDS: window tables [1..8]A_i, [1..8]R_i
+	uint8_t *flags;              // n: non-zero = the reference rejects the item before the equation (decode, small-order key)
+	const uint32_t *cA;          // 8 x n words, word-major: z_i h_i mod q + 0x88..8 (signed-window recoding)
+	const uint32_t *zR;          // 5 x n words, word-major: z_i + 0x8 88..8 (132 bits)
+	const uint32_t *sB;          // 8 x L words, word-major: (q - sum of the lane's z_i S_i) + 0x88..8
+	const uint32_t *tblB;        // ECAMD_EDT_ITEM_WORDS: [1..8]B
+	uint32_t *rec;               // L x ECAMD_EDM_REC_WORDS: the lanes' sums (X, Y, Z, T)
+	uint32_t n, K, L;
+	uint32_t cof_dbl;
+	uint32_t g_d[9], g_sm1[9], g_2d[9], g_Bx[9], g_By[9];
+};
+#define ECAMD_EDM_REC_WORDS 36
+hipError_t ecamd_launch_edmsm_btable(const EcamdEdMsmArgs &a, uint32_t *tblB, int gslot, hipStream_t s);
+hipError_t ecamd_launch_edmsm_prep(const EcamdEdMsmArgs &a, int gslot, hipStream_t s);
+hipError_t ecamd_launch_edmsm_loop(const EcamdEdMsmArgs &a, int gslot, hipStream_t s);
+// sums the L lane records (tree, fan-in 16, ping-pong between rec and tmp), multiplies by the cofactor and writes
+// verdict[0] = 0 (neutral element and *flagword == 0) / 1; sum_out (may be NULL): the sum before the cofactor, 36 words
+hipError_t ecamd_launch_edmsm_reduce(const EcamdEdMsmArgs &a, uint32_t *tmp, const uint32_t *flagword, uint8_t *verdict,
+				     uint32_t *sum_out, int gslot, hipStream_t s);
+// scalars of the combination (mod q, saturated unit): z_i from ChaCha20(seed; counter = item), c_i, z_i S_i
+struct EcamdEdMsmScalArgs {
+	const uint8_t *sigs;         // n x 64: R || S
+	const uint8_t *hram;         // n x 64
+	uint32_t *cA, *zR;           // as above
+	uint32_t *zs;                // n x 8 words: z_i S_i mod q
+	uint8_t *flagsS;             // n: S >= q
+	uint8_t *z_dump;             // may be NULL: n x 16 little-endian z_i (tests)
+	uint32_t seed[8], nonce[3];
+	uint32_t n;
+	int qslot;
+};
+struct EcamdEdMsmLaneArgs {
+	const uint32_t *zs;
+	const uint8_t *flags, *flagsS;
+	uint32_t *sB;
+	uint32_t *flagword;          // |= 1 when any item of the lane is flagged
+	uint32_t n, K, L;
+	int qslot;
+};
+hipError_t ecamd_launch_edmsm_scal(const EcamdEdMsmScalArgs &a, hipStream_t s);
+hipError_t ecamd_launch_edmsm_lane(const EcamdEdMsmLaneArgs &a, hipStream_t s);
 struct EcamdEdScalArgs {
 	const uint8_t *sigs;     // n x 2*len: R || S
 	const uint8_t *hram;     // n x hlen: H(dom || R || A || M), little-endian integer

@@ -768,6 +768,137 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed_scal(EcamdEdScalArg
 	A.flags[i] = ok ? 0 : 1;
 }
 
+// ------------------------------------------------------------------------------------------
+// Scalars of the Ed25519 batch equation (ecamd_g29_kernel.hip, k_edmsm_*): z_i = 128 bits of ChaCha20(seed; counter = item)
+// (the reference draws hsize / 4 = 16 random bytes per signature, sig/eddsa.c:2388), c_i = z_i h_i mod q, z_i S_i mod q.
+// ------------------------------------------------------------------------------------------
+static __device__ __forceinline__ u32 rotl32(u32 x, int r) { return (x << r) | (x >> (32 - r)); }
+#define CHACHA_QR(a, b, c, d)                   \
+	a += b; d ^= a; d = rotl32(d, 16);      \
+	c += d; b ^= c; b = rotl32(b, 12);      \
+	a += b; d ^= a; d = rotl32(d, 8);       \
+	c += d; b ^= c; b = rotl32(b, 7);
+// first four words of the ChaCha20 block (RFC 8439 section 2.3) for key `key`, block counter `ctr` and nonce `nonce`
+static __device__ void chacha20_block4(const u32 *key, u32 ctr, const u32 *nonce, u32 *out4)
+{
+	const u32 in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
+			    key[4], key[5], key[6], key[7], ctr, nonce[0], nonce[1], nonce[2]};
+	u32 x0 = in[0], x1 = in[1], x2 = in[2], x3 = in[3], x4 = in[4], x5 = in[5], x6 = in[6], x7 = in[7];
+	u32 x8 = in[8], x9 = in[9], x10 = in[10], x11 = in[11], x12 = in[12], x13 = in[13], x14 = in[14], x15 = in[15];
+#pragma unroll 1
+	for (int r = 0; r < 10; r++) {
+		CHACHA_QR(x0, x4, x8, x12)
+		CHACHA_QR(x1, x5, x9, x13)
+		CHACHA_QR(x2, x6, x10, x14)
+		CHACHA_QR(x3, x7, x11, x15)
+		CHACHA_QR(x0, x5, x10, x15)
+		CHACHA_QR(x1, x6, x11, x12)
+		CHACHA_QR(x2, x7, x8, x13)
+		CHACHA_QR(x3, x4, x9, x14)
+	}
+	out4[0] = x0 + in[0];
+	out4[1] = x1 + in[1];
+	out4[2] = x2 + in[2];
+	out4[3] = x3 + in[3];
+}
+#undef CHACHA_QR
+
+template <int NW> __global__ __launch_bounds__(64) void k_edmsm_scal(EcamdEdMsmScalArgs A)
+{
+	static_assert(NW == 8, "Ed25519 only");
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int qs = A.qslot;
+	const CurveK<NW> &Q = ConstTab<NW>::get(qs);
+	const Fe<NW> S = fe_load_le<NW>(A.sigs + (size_t)i * 64 + 32, 32);
+	const bool ok = fe_lt_p<NW>(S, qs);
+	const u8 *hp = A.hram + (size_t)i * 64;
+	const Fe<NW> lo = fe_load_le<NW>(hp, 32);
+	const Fe<NW> hi = fe_load_le<NW>(hp + 32, 32);
+	const Fe<NW> r2 = fe_const<NW>(Q.r2);
+	Fe<NW> onep = fe_zero<NW>();
+	onep.v[0] = 1u;
+	const Fe<NW> h = fe_add<NW>(fe_mul<NW>(hi, r2, qs), fe_mul<NW>(fe_mul<NW>(lo, r2, qs), onep, qs), qs);   // as k_ed_scal
+	u32 z4[4];
+	chacha20_block4(A.seed, i, A.nonce, z4);
+	if ((z4[0] | z4[1] | z4[2] | z4[3]) == 0u) {
+		z4[0] = 1u;   // the reference draws again on z = 0
+	}
+	Fe<NW> z = fe_zero<NW>();
+#pragma unroll
+	for (int w = 0; w < 4; w++) {
+		z.v[w] = z4[w];
+	}
+	const Fe<NW> zR = fe_mul<NW>(z, r2, qs);                          // z in Montgomery form
+	const Fe<NW> c = fe_mul<NW>(zR, h, qs);                           // z h mod q
+	const Fe<NW> zs = fe_mul<NW>(zR, ok ? S : fe_zero<NW>(), qs);     // z S mod q
+	// signed-window recoding: + 0x88..8 (c < 2^253: no carry out; z: 33 nibbles)
+	uint64_t cy = 0;
+#pragma unroll
+	for (int w = 0; w < 8; w++) {
+		cy += (uint64_t)c.v[w] + 0x88888888u;
+		A.cA[(size_t)w * A.n + i] = (u32)cy;
+		cy >>= 32;
+	}
+	cy = 0;
+#pragma unroll
+	for (int w = 0; w < 4; w++) {
+		cy += (uint64_t)z4[w] + 0x88888888u;
+		A.zR[(size_t)w * A.n + i] = (u32)cy;
+		cy >>= 32;
+	}
+	A.zR[(size_t)4 * A.n + i] = (u32)cy + 8u;
+#pragma unroll
+	for (int w = 0; w < 8; w++) {
+		A.zs[(size_t)i * 8 + w] = zs.v[w];
+	}
+	A.flagsS[i] = ok ? 0 : 1;
+	if (A.z_dump != nullptr) {
+#pragma unroll
+		for (int b = 0; b < 16; b++) {
+			A.z_dump[(size_t)i * 16 + b] = (u8)(z4[b >> 2] >> (8 * (b & 3)));
+		}
+	}
+}
+
+// lane l of the Straus evaluation owns the items j * L + l: its share of the base-point scalar, q - sum z_i S_i
+template <int NW> __global__ __launch_bounds__(64) void k_edmsm_lane(EcamdEdMsmLaneArgs A)
+{
+	const u32 lane = blockIdx.x * 64 + threadIdx.x;
+	if (lane >= A.L) {
+		return;
+	}
+	const int qs = A.qslot;
+	Fe<NW> sum = fe_zero<NW>();
+	u32 bad = 0;
+	for (u32 j = 0; j < A.K; j++) {
+		const u32 item = j * A.L + lane;
+		if (item >= A.n) {
+			break;
+		}
+		Fe<NW> t;
+#pragma unroll
+		for (int w = 0; w < NW; w++) {
+			t.v[w] = A.zs[(size_t)item * 8 + w];
+		}
+		sum = fe_add<NW>(sum, t, qs);
+		bad |= (u32)A.flags[item] | (u32)A.flagsS[item];
+	}
+	const Fe<NW> neg = fe_sub<NW>(fe_zero<NW>(), sum, qs);
+	uint64_t cy = 0;
+#pragma unroll
+	for (int w = 0; w < 8; w++) {
+		cy += (uint64_t)neg.v[w] + 0x88888888u;
+		A.sB[(size_t)w * A.L + lane] = (u32)cy;
+		cy >>= 32;
+	}
+	if (bad) {
+		atomicOr(A.flagword, 1u);
+	}
+}
+
 template <int NW> static __device__ __forceinline__ Pt<NW> ed_load_neg(const u8 *src, u32 st, int clen, bool neg, int slot)
 {
 	Pt<NW> P;
@@ -1723,6 +1854,16 @@ hipError_t ecamd_launch_ed_scal(int nw, const EcamdEdScalArgs &a, hipStream_t s)
 	return hipGetLastError();
 }
 
+hipError_t ecamd_launch_edmsm_scal(const EcamdEdMsmScalArgs &a, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_edmsm_scal<8>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+	return hipGetLastError();
+}
+hipError_t ecamd_launch_edmsm_lane(const EcamdEdMsmLaneArgs &a, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_edmsm_lane<8>, dim3((a.L + 63) / 64), dim3(64), 0, s, a);
+	return hipGetLastError();
+}
 hipError_t ecamd_launch_ed_fin(int nw, const EcamdEdFinArgs &a, hipStream_t s)
 {
 	if (a.n == 0) {
