@@ -26,7 +26,11 @@ template <int PB> struct Lay {
 	static constexpr int NL = Cfg<PB>::NL;
 	static constexpr int NW = (PB + 31) / 32;          // saturated words of a coordinate
 	static constexpr int ENTW = ((3 * NL + 3) / 4) * 4;  // words per table entry (16-byte multiple)
-	static constexpr int KW = (PB + 31) / 32 + 1;      // words of the recoded scalar (fast path: slen <= 4 KW - 4)
+	static constexpr int KW = (PB + 31) / 32 + 1;      // words of the recoded scalar of the comb kernel (slen <= 4 KW - 4)
+	// k_smul_g keeps its recoded scalar in the item's scratch, behind the table: scalars of up to 8 NW + 4 bytes
+	// (a blinded scalar m + b #E, curves/prj_pt.c:1782-1822, has about 2 |#E| bits)
+	static constexpr int KRECW = ((2 * NW + 2 + 3) / 4) * 4;
+	static constexpr int ITEMW = 8 * ENTW + KRECW;     // scratch words per item
 };
 
 // len bytes big-endian -> NW little-endian words
@@ -101,6 +105,38 @@ template <int PB> static __device__ __forceinline__ TabEnt<PB> tab_load(const u3
 	}
 	return T;
 }
+// the same entry without a digit-dependent address: every entry is read, the wanted one kept by masking
+// (secret-scalar mode; the reference's posture is nn_tabselect, nn/nn.c:564)
+template <int PB> static __device__ __forceinline__ TabEnt<PB> tab_load_masked(const u32 *base, u32 e)
+{
+	constexpr int NL = Lay<PB>::NL, ENTW = Lay<PB>::ENTW;
+	u32 buf[ENTW];
+#pragma unroll
+	for (int i = 0; i < ENTW; i++) {
+		buf[i] = 0;
+	}
+#pragma unroll 1
+	for (u32 ee = 0; ee < 8; ee++) {
+		const u32 m = (ee == e) ? 0xffffffffu : 0u;
+		const uint4 *s = (const uint4 *)(base + (size_t)ee * ENTW);
+#pragma unroll
+		for (int i = 0; i < ENTW / 4; i++) {
+			const uint4 v = s[i];
+			buf[4 * i] |= v.x & m;
+			buf[4 * i + 1] |= v.y & m;
+			buf[4 * i + 2] |= v.z & m;
+			buf[4 * i + 3] |= v.w & m;
+		}
+	}
+	TabEnt<PB> T;
+#pragma unroll
+	for (int i = 0; i < NL; i++) {
+		T.X.l[i] = buf[i];
+		T.Y.l[i] = buf[NL + i];
+		T.Z.l[i] = buf[2 * NL + i];
+	}
+	return T;
+}
 // Jacobian result record (all three coordinates in class FA) in the first table slot
 template <int PB> static __device__ __forceinline__ void jac_store(u32 *base, const Jac<PB> &P)
 {
@@ -149,7 +185,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_smul
 	typedef typename Cls<PB>::FA FA;
 	typedef typename Cls<PB>::FM FM;
 	typedef typename Cls<PB>::FC FC;
-	constexpr int NL = L::NL, NW = L::NW, KW = L::KW;
+	constexpr int NL = L::NL, NW = L::NW;
 	const u32 i = blockIdx.x * 64 + threadIdx.x;
 	if (i >= A.n) {
 		return;
@@ -200,7 +236,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_smul
 	}
 
 	// ---- table [1..8]P ----
-	u32 *tb = A.tbl + (size_t)i * (8 * L::ENTW);
+	u32 *tb = A.tbl + (size_t)i * L::ITEMW;
 	Jac<PB> P1;
 	P1.X = weaken<FA>(xm);
 	P1.Y = weaken<FA>(ym);
@@ -239,39 +275,36 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_smul
 		tab_store<PB>(tb, 7, to_tab(Pa, K));
 	}
 
-	// ---- scalar: k' = k + 0x88..8 over its 2*slen nibbles, left-aligned in KW words ----
+	// ---- scalar: k' = k + 0x88..8 over its 2*slen nibbles, kept in the item's scratch behind the table (any length the
+	//      host lets through: slen <= 4 KRECW - 4) ----
 	const u8 *sc = A.scalars + (size_t)i * A.sstride;
-	const int slen = (int)A.slen;  // <= 4 * (KW - 1), checked by the host
-	u32 kw[KW];
-	load_be<KW>(sc, slen, kw);
+	const int slen = (int)A.slen;
+	u32 *kr = tb + 8 * L::ENTW;
 	u32 carry_bit;
 	{
+		const int nwords = (slen + 3) >> 2;
 		uint64_t c = 0;
+		u32 last = 0;
+#pragma unroll 1
+		for (int w = 0; w < nwords; w++) {
+			u32 x = 0;
 #pragma unroll
-		for (int w = 0; w < KW; w++) {
+			for (int b = 0; b < 4; b++) {
+				const int pos = 4 * w + b;
+				if (pos < slen) {
+					x |= (u32)sc[slen - 1 - pos] << (8 * b);
+				}
+			}
 			const int nb = slen - 4 * w;
-			const u32 add8 = (nb >= 4) ? 0x88888888u : (nb == 3 ? 0x00888888u : (nb == 2 ? 0x00008888u : (nb == 1 ? 0x00000088u : 0u)));
-			c += (uint64_t)kw[w] + add8;
-			kw[w] = (u32)c;
+			const u32 add8 = (nb >= 4) ? 0x88888888u : (nb == 3 ? 0x00888888u : (nb == 2 ? 0x00008888u : 0x00000088u));
+			c += (uint64_t)x + add8;
+			last = (u32)c;
+			kr[w] = last;
 			c >>= 32;
 		}
-		const int bit = 8 * slen;  // the carry out of the top nibble sits just above the scalar's bytes
-		u32 cb = 0;
-#pragma unroll
-		for (int w = 0; w < KW; w++) {
-			if (w == (bit >> 5)) {
-				cb = (kw[w] >> (bit & 31)) & 1u;
-			}
-		}
-		carry_bit = cb;
-		// left-align: the scalar's top nibble becomes the top nibble of kw[KW-1]
-		for (int s = slen; s < 4 * KW; s++) {
-#pragma unroll
-			for (int w = KW - 1; w > 0; w--) {
-				kw[w] = (kw[w] << 8) | (kw[w - 1] >> 24);
-			}
-			kw[0] <<= 8;
-		}
+		// the carry out of the top nibble sits just above the scalar's bytes
+		const int bit = 8 * slen;
+		carry_bit = (bit & 31) ? ((last >> (bit & 31)) & 1u) : (u32)c;
 	}
 
 	// ---- signed fixed window, left to right ----
@@ -284,14 +317,11 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_smul
 		for (int d = 0; d < 4; d++) {
 			acc = dbl(acc, K);
 		}
-		const int dig = (int)(kw[KW - 1] >> 28) - 8;
-#pragma unroll
-		for (int w = KW - 1; w > 0; w--) {
-			kw[w] = (kw[w] << 4) | (kw[w - 1] >> 28);
-		}
-		kw[0] <<= 4;
+		const int pos = nwin - 1 - t;
+		const int dig = (int)((kr[pos >> 3] >> (4 * (pos & 7))) & 15u) - 8;
 		const u32 mag = (u32)(dig < 0 ? -dig : dig);
-		const TabEnt<PB> T = tab_load<PB>(tb, mag ? mag - 1 : 0);
+		// secret-scalar mode (a wave-uniform kernel argument): constant-address scan of the eight entries
+		const TabEnt<PB> T = A.masked ? tab_load_masked<PB>(tb, mag ? mag - 1 : 0) : tab_load<PB>(tb, mag ? mag - 1 : 0);
 		const FA ty = selg(dig < 0, neg<PB>(T.Y, K), weaken<FA>(T.Y));
 		const Jac<PB> S = add_jac(acc, T.X, ty, T.Z, hz, K);
 		const bool use_t = inf & (mag != 0);
@@ -441,7 +471,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_g(Ecamd
 		}
 		return;
 	}
-	u32 *tb = A.tbl + (size_t)i * (8 * L::ENTW);
+	u32 *tb = A.tbl + (size_t)i * L::ITEMW;
 	jac_store<PB>(tb, acc);
 	A.status[i] = ECAMD_STATUS_JAC;
 }
@@ -467,7 +497,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_finalize_g(E
 		if (i >= A.n) {
 			break;
 		}
-		u32 *tb = A.tbl + (size_t)i * (8 * ENTW);
+		u32 *tb = A.tbl + (size_t)i * Lay<PB>::ITEMW;
 		if (A.status[i] == ECAMD_STATUS_JAC) {
 			const Jac<PB> P = jac_load<PB>(tb);
 			c = weaken<FM>(mulc(c, P.Z, K));
@@ -486,12 +516,12 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_finalize_g(E
 		if (i >= A.n || A.status[i] != ECAMD_STATUS_JAC) {
 			continue;
 		}
-		u32 *tb = A.tbl + (size_t)i * (8 * ENTW);
+		u32 *tb = A.tbl + (size_t)i * Lay<PB>::ITEMW;
 		const Jac<PB> P = jac_load<PB>(tb);
 		FM zi = tinv;
 		if (j > 0) {
 			const u32 ip = t + (u32)(j - 1) * nthreads;
-			const u32 *s = A.tbl + (size_t)ip * (8 * ENTW) + ENTW;
+			const u32 *s = A.tbl + (size_t)ip * Lay<PB>::ITEMW + ENTW;
 			FM cp;
 #pragma unroll
 			for (int w = 0; w < NL; w++) {
@@ -1691,9 +1721,11 @@ int ecamd_g29_nl(int pbits, int flavour) { return g29::nl_for_flavour(pbits, fla
 int ecamd_g29_slots(void) { return G29_SLOTS; }
 uint32_t ecamd_g29_table_words(int pbits, int flavour)
 {
-	return 8u * (uint32_t)(((3 * g29::nl_for_flavour(pbits, flavour) + 3) / 4) * 4);
+	const uint32_t nw = (uint32_t)((pbits + 31) / 32);
+	return 8u * (uint32_t)(((3 * g29::nl_for_flavour(pbits, flavour) + 3) / 4) * 4) + ((2u * nw + 2u + 3u) / 4u) * 4u;   // Lay<PB>::ITEMW
 }
-uint32_t ecamd_g29_max_slen(int pbits) { return 4u * (uint32_t)((pbits + 31) / 32); }
+uint32_t ecamd_g29_max_slen(int pbits) { return 8u * (uint32_t)((pbits + 31) / 32) + 4u; }
+uint32_t ecamd_g29_comb_max_slen(int pbits) { return 4u * (uint32_t)((pbits + 31) / 32); }
 size_t ecamd_g29_image_bytes(int pbits, int flavour)
 {
 	return (size_t)((10 + g29::NBIAS) * g29::nl_for_flavour(pbits, flavour) + 4) * 4;

@@ -1157,8 +1157,8 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 	// (secp256r1 keeps its radix-2^29 pipeline in this mode: k_p256_loop<KW, MASKED> scans the eight-entry tables, the comb is off)
 	const bool secret = ctx->secret_scalars;
 	const bool fast256 = cv->is_p256 && slen <= 68;
-	const bool comb_ok = !secret && (!cv->is_p256 || slen <= 32);
-	const bool fastg = !secret && !fast256 && cv->gslot >= 0 && slen <= ecamd_g29_max_slen(cv->pbits);
+	const bool fastg = !fast256 && cv->gslot >= 0 && slen <= ecamd_g29_max_slen(cv->pbits);
+	const bool comb_ok = !secret && (cv->is_p256 ? slen <= 32 : slen <= ecamd_g29_comb_max_slen(cv->pbits));
 	const bool fast = fast256 || fastg;
 	if (fast && !d_points && comb_ok) {
 		maybe_build_comb(ctx, const_cast<ecamd_curve *>(cv), n);

@@ -324,7 +324,8 @@ int ecamd_g29_supported(int pbits);
 int ecamd_g29_nl(int pbits, int flavour);
 int ecamd_g29_slots(void);
 uint32_t ecamd_g29_table_words(int pbits, int flavour);   // scratch words per item
-uint32_t ecamd_g29_max_slen(int pbits);      // longest scalar (bytes) the fast path takes
+uint32_t ecamd_g29_max_slen(int pbits);      // longest scalar (bytes) the window kernel takes (blinded scalars included)
+uint32_t ecamd_g29_comb_max_slen(int pbits); // longest scalar the fixed-base comb takes
 size_t ecamd_g29_image_bytes(int pbits, int flavour);
 hipError_t ecamd_g29_upload(int pbits, int slot, const void *img, size_t bytes, int flavour);
 hipError_t ecamd_launch_smul_g29(int pbits, int gslot, const EcamdSmulArgs &a, hipStream_t s, hipEvent_t *ev, int flavour);

@@ -300,7 +300,7 @@ def test_ecdsa_sign_rejects_private_key_not_below_q(gpu_ctx, curve):
         cv.free()
 
 
-@pytest.mark.parametrize("curve", ["SECP256R1", "SECP384R1", "WEI25519", "SECP521R1"])
+@pytest.mark.parametrize("curve", ["SECP256R1", "SECP384R1", "WEI25519", "SECP521R1", "SECP256K1", "WEI448", "BRAINPOOLP512R1"])
 def test_blinded_scalar_mult(gpu_ctx, curve):
     """ec_prj_pt_mul_blind_batch multiplies by m + b #E (prj_pt_mul_blind, curves/prj_pt.c:1782-1822): same points as the plain
     multiplication for every b in [1, #E); b = 0 and b >= #E are refused; on secp256r1 the ~2|q|-bit scalar stays on the
@@ -352,7 +352,7 @@ def test_secret_scalar_mode_gives_identical_results():
     ctx_s, ctx_d = libecc_amd.Context(0), libecc_amd.Context(0)
     ctx_s.set_secret_scalars(True)
     try:
-        for curve in ("SECP256R1", "BRAINPOOLP256R1", "SECP384R1", "WEI25519"):
+        for curve in ("SECP256R1", "BRAINPOOLP256R1", "SECP384R1", "WEI25519", "SECP256K1", "SECP521R1", "WEI448", "SECP224R1"):
             o = Oracle(curve)
             q, ql, cl = CURVES[curve]["q"], o.qlen, o.clen
             n = 96
