@@ -9,6 +9,7 @@
 // Replaces prj_pt_import_from_aff_buf -> prj_pt_mul -> prj_pt_unique -> prj_pt_export_to_aff_buf
 // (curves/prj_pt.c:511,1759,241,600 in /root/reference/src).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "ecamd_jacg.cuh"
 #include "ecamd_internal.h"
 
@@ -172,29 +173,16 @@ template <class T> static __device__ __forceinline__ T selg(bool c, const T &a, 
 	return r;
 }
 
-// FLAV only makes the kernel symbols of the translation units of one size distinct (0 dense, 1 secp521r1, 2 2^255 - 19)
-// G29_WAVES (build flag, A/B tests through tools/build_variant.py): pin the waves per SIMD of the window kernel
-#ifdef G29_WAVES
-#define G29_OCC __attribute__((amdgpu_waves_per_eu(G29_WAVES, G29_WAVES)))
-#else
-#define G29_OCC
-#endif
-template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_smul_g(EcamdSmulArgs A, int gslot)
+// import of item i (curves/prj_pt.c:511-552): coordinates < p, y != 0, on the curve; (xm, ym) in the field representation
+// of this unit (Montgomery form, and on the isomorphic a = -3 curve when there is one), values < 2p with exact digits
+template <int PB> static __device__ __forceinline__ bool import_point(const EcamdSmulArgs &A, u32 i, typename Cls<PB>::FM &xo,
+								       typename Cls<PB>::FM &yo, const CurveG<Cfg<PB>::NL> &K)
 {
 	typedef Lay<PB> L;
-	typedef typename Cls<PB>::FA FA;
 	typedef typename Cls<PB>::FM FM;
 	typedef typename Cls<PB>::FC FC;
 	constexpr int NL = L::NL, NW = L::NW;
-	const u32 i = blockIdx.x * 64 + threadIdx.x;
-	if (i >= A.n) {
-		return;
-	}
-	const CurveG<NL> &K = TabGP<PB>::get(gslot);
 	const int clen = (int)A.clen;
-	u8 *out = A.out + (size_t)i * 2 * clen;
-
-	// ---- import (curves/prj_pt.c:511-552): coordinates < p, on the curve ----
 	const u8 *pin = A.points + (size_t)i * A.pstride;
 	u32 xw[NW], yw[NW];
 	load_be<NW>(pin, clen, xw);
@@ -218,7 +206,6 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_smul
 		ok = ok & (ynz != 0);
 	}
 	const FC onec = constant<FC>(K.one);
-	// Montgomery form (and onto the isomorphic a = -3 curve when there is one), < 2p, exact digits
 	const auto xm = mul(xd, constant<FC>(K.ix), K), ym = mul(yd, constant<FC>(K.iy), K);
 	{
 		// y^2 == (x^2 + a) x + b
@@ -227,6 +214,66 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_smul
 		const auto dif = carry(sub_auto<1>(rhs, sqr(ym, K), K));
 		ok = ok & is_zero_mulout(mulc(dif, onec, K), K);
 	}
+	xo = weaken<FM>(xm);
+	yo = weaken<FM>(ym);
+	return ok;
+}
+
+// k' = k + 0x88..8 over the 2*slen nibbles of item i's big-endian scalar, little-endian words into kr (any length the host
+// lets through: slen <= 4 KRECW - 4); returns the carry out of the top nibble (the leading digit 0 / 1)
+static __device__ __forceinline__ u32 recode_scalar(const u8 *sc, int slen, u32 *kr)
+{
+	const int nwords = (slen + 3) >> 2;
+	uint64_t c = 0;
+	u32 last = 0;
+#pragma unroll 1
+	for (int w = 0; w < nwords; w++) {
+		u32 x = 0;
+#pragma unroll
+		for (int b = 0; b < 4; b++) {
+			const int pos = 4 * w + b;
+			if (pos < slen) {
+				x |= (u32)sc[slen - 1 - pos] << (8 * b);
+			}
+		}
+		const int nb = slen - 4 * w;
+		const u32 add8 = (nb >= 4) ? 0x88888888u : (nb == 3 ? 0x00888888u : (nb == 2 ? 0x00008888u : 0x00000088u));
+		c += (uint64_t)x + add8;
+		last = (u32)c;
+		kr[w] = last;
+		c >>= 32;
+	}
+	// the carry out of the top nibble sits just above the scalar's bytes
+	const int bit = 8 * slen;
+	return (bit & 31) ? ((last >> (bit & 31)) & 1u) : (u32)c;
+}
+
+// FLAV only makes the kernel symbols of the translation units of one size distinct (0 dense, 1 secp521r1, 2 2^255 - 19)
+// G29_WAVES (build flag, A/B tests through tools/build_variant.py): pin the waves per SIMD of the window kernel
+#ifdef G29_WAVES
+#define G29_OCC __attribute__((amdgpu_waves_per_eu(G29_WAVES, G29_WAVES)))
+#else
+#define G29_OCC
+#endif
+template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_smul_g(EcamdSmulArgs A, int gslot)
+{
+	typedef Lay<PB> L;
+	typedef typename Cls<PB>::FA FA;
+	typedef typename Cls<PB>::FM FM;
+	typedef typename Cls<PB>::FC FC;
+	constexpr int NL = L::NL, NW = L::NW;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	const int clen = (int)A.clen;
+	u8 *out = A.out + (size_t)i * 2 * clen;
+
+	// ---- import (curves/prj_pt.c:511-552): coordinates < p, on the curve ----
+	const FC onec = constant<FC>(K.one);
+	FM xm, ym;
+	const bool ok = import_point<PB>(A, i, xm, ym, K);
 	if (!ok) {
 		A.status[i] = 1;
 		for (int b = 0; b < 2 * clen; b++) {
@@ -275,53 +322,38 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_smul
 		tab_store<PB>(tb, 7, to_tab(Pa, K));
 	}
 
-	// ---- scalar: k' = k + 0x88..8 over its 2*slen nibbles, kept in the item's scratch behind the table (any length the
-	//      host lets through: slen <= 4 KRECW - 4) ----
-	const u8 *sc = A.scalars + (size_t)i * A.sstride;
+	// ---- scalar: recoded into the item's scratch behind the table ----
 	const int slen = (int)A.slen;
 	u32 *kr = tb + 8 * L::ENTW;
-	u32 carry_bit;
-	{
-		const int nwords = (slen + 3) >> 2;
-		uint64_t c = 0;
-		u32 last = 0;
-#pragma unroll 1
-		for (int w = 0; w < nwords; w++) {
-			u32 x = 0;
-#pragma unroll
-			for (int b = 0; b < 4; b++) {
-				const int pos = 4 * w + b;
-				if (pos < slen) {
-					x |= (u32)sc[slen - 1 - pos] << (8 * b);
-				}
-			}
-			const int nb = slen - 4 * w;
-			const u32 add8 = (nb >= 4) ? 0x88888888u : (nb == 3 ? 0x00888888u : (nb == 2 ? 0x00008888u : 0x00000088u));
-			c += (uint64_t)x + add8;
-			last = (u32)c;
-			kr[w] = last;
-			c >>= 32;
-		}
-		// the carry out of the top nibble sits just above the scalar's bytes
-		const int bit = 8 * slen;
-		carry_bit = (bit & 31) ? ((last >> (bit & 31)) & 1u) : (u32)c;
-	}
+	const u32 carry_bit = recode_scalar(A.scalars + (size_t)i * A.sstride, slen, kr);
 
 	// ---- signed fixed window, left to right ----
 	Jac<PB> acc = P1;
 	bool inf = (carry_bit == 0);
 	const int nwin = 2 * slen;
+	// the word of the recoded scalar that holds the current nibble; its successor is fetched one window ahead, so
+	// that the digit -- and with it the address of the table entry -- never waits for memory
+	u32 wcur = nwin ? kr[(nwin - 1) >> 3] : 0u, wnext = 0u;
 #pragma unroll 1
 	for (int t = 0; t < nwin; t++) {
+		const int pos = nwin - 1 - t;
+		const int dig = (int)((wcur >> (4 * (pos & 7))) & 15u) - 8;
+		const u32 mag = (u32)(dig < 0 ? -dig : dig);
+		if ((pos & 7) == 0 && pos != 0) {
+			wnext = kr[(pos >> 3) - 1];
+		}
+#ifdef G29_PRELOAD
+		// secret-scalar mode (a wave-uniform kernel argument): constant-address scan of the eight entries
+		const TabEnt<PB> T = A.masked ? tab_load_masked<PB>(tb, mag ? mag - 1 : 0) : tab_load<PB>(tb, mag ? mag - 1 : 0);
+#endif
 #pragma unroll 1
 		for (int d = 0; d < 4; d++) {
 			acc = dbl(acc, K);
 		}
-		const int pos = nwin - 1 - t;
-		const int dig = (int)((kr[pos >> 3] >> (4 * (pos & 7))) & 15u) - 8;
-		const u32 mag = (u32)(dig < 0 ? -dig : dig);
-		// secret-scalar mode (a wave-uniform kernel argument): constant-address scan of the eight entries
+#ifndef G29_PRELOAD
 		const TabEnt<PB> T = A.masked ? tab_load_masked<PB>(tb, mag ? mag - 1 : 0) : tab_load<PB>(tb, mag ? mag - 1 : 0);
+#endif
+		wcur = ((pos & 7) == 0) ? wnext : wcur;
 		const FA ty = selg(dig < 0, neg<PB>(T.Y, K), weaken<FA>(T.Y));
 		const Jac<PB> S = add_jac(acc, T.X, ty, T.Z, hz, K);
 		const bool use_t = inf & (mag != 0);
@@ -348,6 +380,313 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_smul
 		return;
 	}
 	jac_store<PB>(tb, acc);
+	A.status[i] = ECAMD_STATUS_JAC;
+}
+
+// ------------------------------------------------------------------------------------------
+// Affine-table pipeline (every flavour except the nine-limb plain-residue ones): the pipeline of ecamd_p256_kernel.hip
+//   k_table_g    import + on-curve check, Jacobian multiples 2P..8P into the item's staging slots, recoded scalar
+//   k_affine_g   2P..8P -> affine with ONE inversion per AFFG_K items x 7 entries (Montgomery's trick; the prefix products
+//                rest in the affine slots they are about to be replaced by)
+//   k_loop_g     signed window w = 4 with the mixed addition madd_jac (8M + 3S instead of 12M + 4S) on the tight accumulator
+//                class JacT; one exact test of the final Z replaces the per-window exceptional-pair flags
+//   k_finalize_g unchanged
+// Affine table: 8 entries (x, y) of NL digits each (multiplication results, value < 2p), AENTW words per entry.
+// ------------------------------------------------------------------------------------------
+template <int PB> struct LayA {
+	static constexpr int NL = Cfg<PB>::NL;
+	static constexpr int AENTW = ((2 * NL + 3) / 4) * 4;
+	static constexpr int AITEMW = 8 * AENTW;
+};
+template <int PB> static __device__ __forceinline__ void aff_store(u32 *base, int e, const typename Cls<PB>::FM &x, const typename Cls<PB>::FM &y)
+{
+	constexpr int NL = LayA<PB>::NL, AENTW = LayA<PB>::AENTW;
+	u32 buf[AENTW];
+#pragma unroll
+	for (int i = 0; i < NL; i++) {
+		buf[i] = x.l[i];
+		buf[NL + i] = y.l[i];
+	}
+#pragma unroll
+	for (int i = 2 * NL; i < AENTW; i++) {
+		buf[i] = 0;
+	}
+	uint4 *d = (uint4 *)(base + (size_t)e * AENTW);
+#pragma unroll
+	for (int i = 0; i < AENTW / 4; i++) {
+		d[i] = make_uint4(buf[4 * i], buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3]);
+	}
+}
+// MASKED: every entry is read, the wanted one kept by masking (secret-scalar mode)
+template <int PB, bool MASKED>
+static __device__ __forceinline__ void aff_load(const u32 *base, u32 e, typename Cls<PB>::FM &x, typename Cls<PB>::FM &y)
+{
+	constexpr int NL = LayA<PB>::NL, AENTW = LayA<PB>::AENTW;
+	u32 buf[AENTW];
+	if (MASKED) {
+#pragma unroll
+		for (int i = 0; i < AENTW; i++) {
+			buf[i] = 0;
+		}
+#pragma unroll 1
+		for (u32 ee = 0; ee < 8; ee++) {
+			const u32 m = (ee == e) ? 0xffffffffu : 0u;
+			const uint4 *sp = (const uint4 *)(base + (size_t)ee * AENTW);
+#pragma unroll
+			for (int i = 0; i < AENTW / 4; i++) {
+				const uint4 v = sp[i];
+				buf[4 * i] |= v.x & m;
+				buf[4 * i + 1] |= v.y & m;
+				buf[4 * i + 2] |= v.z & m;
+				buf[4 * i + 3] |= v.w & m;
+			}
+		}
+	} else {
+		const uint4 *sp = (const uint4 *)(base + (size_t)e * AENTW);
+#pragma unroll
+		for (int i = 0; i < AENTW / 4; i++) {
+			const uint4 v = sp[i];
+			buf[4 * i] = v.x;
+			buf[4 * i + 1] = v.y;
+			buf[4 * i + 2] = v.z;
+			buf[4 * i + 3] = v.w;
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < NL; i++) {
+		x.l[i] = buf[i];
+		y.l[i] = buf[NL + i];
+	}
+}
+// one field element in the x half of an affine slot (prefix products of the shared inversion)
+template <int PB> static __device__ __forceinline__ void fe_store(u32 *dst, const typename Cls<PB>::FM &v)
+{
+#pragma unroll
+	for (int i = 0; i < Cfg<PB>::NL; i++) {
+		dst[i] = v.l[i];
+	}
+}
+template <int PB> static __device__ __forceinline__ typename Cls<PB>::FM fe_load(const u32 *src)
+{
+	typename Cls<PB>::FM v;
+#pragma unroll
+	for (int i = 0; i < Cfg<PB>::NL; i++) {
+		v.l[i] = src[i];
+	}
+	return v;
+}
+// Jacobian point (class FA) in staging slot e
+template <int PB> static __device__ __forceinline__ void jac_store_at(u32 *base, int e, const Jac<PB> &P)
+{
+	TabEnt<PB> T;
+	T.X = P.X;
+	T.Z = P.Z;
+#pragma unroll
+	for (int i = 0; i < Lay<PB>::NL; i++) {
+		T.Y.l[i] = P.Y.l[i];
+	}
+	tab_store<PB>(base, e, T);
+}
+template <int PB> static __device__ __forceinline__ Jac<PB> jac_load_at(const u32 *base, int e)
+{
+	const TabEnt<PB> T = tab_load<PB>(base, (u32)e);
+	Jac<PB> P;
+	P.X = T.X;
+	P.Z = T.Z;
+#pragma unroll
+	for (int i = 0; i < Lay<PB>::NL; i++) {
+		P.Y.l[i] = T.Y.l[i];
+	}
+	return P;
+}
+
+template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_table_g(EcamdSmulArgs A, int gslot)
+{
+	typedef Lay<PB> L;
+	typedef typename Cls<PB>::FA FA;
+	typedef typename Cls<PB>::FM FM;
+	typedef typename Cls<PB>::FC FC;
+	constexpr int NL = L::NL;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	const int clen = (int)A.clen;
+	const FC onec = constant<FC>(K.one);
+	FM xm, ym;
+	const bool ok = import_point<PB>(A, i, xm, ym, K);
+	if (!ok) {
+		u8 *out = A.out + (size_t)i * 2 * clen;
+		A.status[i] = 1;
+		for (int b = 0; b < 2 * clen; b++) {
+			out[b] = 0;
+		}
+		return;
+	}
+	u32 *tb = A.tbl + (size_t)i * L::ITEMW;
+	aff_store<PB>(A.stg + (size_t)i * LayA<PB>::AITEMW, 0, xm, ym);
+	Jac<PB> P1;
+	P1.X = weaken<FA>(xm);
+	P1.Y = weaken<FA>(ym);
+	P1.Z = weaken<FA>(onec);
+	bool hz, bad = false;
+	{
+		// staging slot e - 1 holds [e]P, e = 2..8
+		Jac<PB> Pa = dbl(P1, K);                                   // 2P
+		jac_store_at<PB>(tb, 1, Pa);
+		Jac<PB> Pb = add_jac(Pa, P1.X, P1.Y, P1.Z, hz, K);          // 3P
+		bad |= hz;
+		jac_store_at<PB>(tb, 2, Pb);
+		Pa = dbl(Pa, K);                                            // 4P
+		jac_store_at<PB>(tb, 3, Pa);
+		Pb = add_jac(Pa, P1.X, P1.Y, P1.Z, hz, K);                  // 5P
+		bad |= hz;
+		jac_store_at<PB>(tb, 4, Pb);
+		Pb = dbl(jac_load_at<PB>(tb, 2), K);                        // 6P
+		jac_store_at<PB>(tb, 5, Pb);
+		Pb = add_jac(Pb, P1.X, P1.Y, P1.Z, hz, K);                  // 7P
+		bad |= hz;
+		jac_store_at<PB>(tb, 6, Pb);
+		Pa = dbl(Pa, K);                                            // 8P
+		jac_store_at<PB>(tb, 7, Pa);
+		// a doubling reaches infinity silently (points of even order): exact test of the last Z's
+		bad = bad | is_zero_mulout(mulc(mulc(Pa.Z, Pb.Z, K), onec, K), K);
+	}
+	if (bad) {
+		A.status[i] = ECAMD_STATUS_REDO;   // a multiple below 9P is infinity: the complete-formula kernel takes the item
+		return;
+	}
+	u32 *kr = tb + 8 * L::ENTW;
+	kr[L::KRECW - 1] = recode_scalar(A.scalars + (size_t)i * A.sstride, (int)A.slen, kr);   // (the scalar fills at most KRECW - 1 words)
+	A.status[i] = ECAMD_STATUS_TAB;
+}
+
+#define AFFG_K 8
+template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_affine_g(EcamdSmulArgs A, int gslot, u32 nthreads)
+{
+	typedef Lay<PB> L;
+	typedef typename Cls<PB>::FM FM;
+	typedef typename Cls<PB>::FC FC;
+	constexpr int NL = L::NL, AENTW = LayA<PB>::AENTW;
+	const u32 t = blockIdx.x * 64 + threadIdx.x;
+	if (t >= nthreads) {
+		return;
+	}
+	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	FM c = weaken<FM>(constant<FC>(K.one));
+#pragma unroll 1
+	for (int j = 0; j < AFFG_K; j++) {
+		const u32 i = t + (u32)j * nthreads;
+		if (i >= A.n || A.status[i] != ECAMD_STATUS_TAB) {
+			continue;
+		}
+		const u32 *tb = A.tbl + (size_t)i * L::ITEMW;
+		u32 *af = A.stg + (size_t)i * LayA<PB>::AITEMW;
+#pragma unroll 1
+		for (int e = 1; e < 8; e++) {
+			fe_store<PB>(af + (size_t)e * AENTW, c);   // the product of everything before this entry
+			const Jac<PB> P = jac_load_at<PB>(tb, e);
+			c = weaken<FM>(mulc(c, P.Z, K));
+		}
+	}
+	FM tinv = inv<PB>(c, K);
+#pragma unroll 1
+	for (int j = AFFG_K - 1; j >= 0; j--) {
+		const u32 i = t + (u32)j * nthreads;
+		if (i >= A.n || A.status[i] != ECAMD_STATUS_TAB) {
+			continue;
+		}
+		const u32 *tb = A.tbl + (size_t)i * L::ITEMW;
+		u32 *af = A.stg + (size_t)i * LayA<PB>::AITEMW;
+#pragma unroll 1
+		for (int e = 7; e >= 1; e--) {
+			const Jac<PB> P = jac_load_at<PB>(tb, e);
+			const FM zi = weaken<FM>(mul(tinv, fe_load<PB>(af + (size_t)e * AENTW), K));
+			tinv = weaken<FM>(mulc(tinv, P.Z, K));
+			const FM zi2 = weaken<FM>(sqr(zi, K));
+			const FM zi3 = weaken<FM>(mul(zi2, zi, K));
+			aff_store<PB>(af, e, weaken<FM>(mulc(P.X, zi2, K)), weaken<FM>(mulc(P.Y, zi3, K)));
+		}
+	}
+}
+
+template <int PB, int FLAV, bool MASKED> __global__ __launch_bounds__(64) G29_OCC void k_loop_g(EcamdSmulArgs A, int gslot)
+{
+	typedef Lay<PB> L;
+	typedef typename Cls<PB>::FA FA;
+	typedef typename Cls<PB>::FM FM;
+	typedef typename Cls<PB>::FC FC;
+	typedef typename ClsT<PB>::FT FT;
+	constexpr int NL = L::NL;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n || A.status[i] != ECAMD_STATUS_TAB) {
+		return;
+	}
+	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	const FC onec = constant<FC>(K.one);
+	u32 *tb = A.tbl + (size_t)i * L::ITEMW;
+	const u32 *af = A.stg + (size_t)i * LayA<PB>::AITEMW;
+	const u32 *kr = tb + 8 * L::ENTW;
+	const int slen = (int)A.slen;
+	const int nwin = 2 * slen;
+	const u32 carry_bit = kr[L::KRECW - 1];   // the leading digit 0 / 1 (k_table_g)
+	JacT<PB> acc;
+	FM x1, y1;
+	aff_load<PB, false>(af, 0, x1, y1);
+	acc.X = weaken<FT>(x1);
+	acc.Y = weaken<FT>(y1);
+	acc.Z = weaken<FT>(onec);
+	bool inf = (carry_bit == 0);
+	u32 wcur = nwin ? kr[(nwin - 1) >> 3] : 0u, wnext = 0u;
+#pragma unroll 1
+	for (int t = 0; t < nwin; t++) {
+		const int pos = nwin - 1 - t;
+		const int dig = (int)((wcur >> (4 * (pos & 7))) & 15u) - 8;
+		const u32 mag = (u32)(dig < 0 ? -dig : dig);
+		if ((pos & 7) == 0 && pos != 0) {
+			wnext = kr[(pos >> 3) - 1];
+		}
+		FM tx, tyc;
+#ifdef G29_PRELOAD
+		aff_load<PB, MASKED>(af, mag ? mag - 1 : 0, tx, tyc);   // A/B: the entry travels while the doublings run
+#endif
+#pragma unroll 1
+		for (int d = 0; d < 4; d++) {
+			acc = dbl(acc, K);
+		}
+#ifndef G29_PRELOAD
+		aff_load<PB, MASKED>(af, mag ? mag - 1 : 0, tx, tyc);
+#endif
+		wcur = ((pos & 7) == 0) ? wnext : wcur;
+		const FT tyt = selg(dig < 0, neg_t<PB>(tyc, K), weaken<FT>(tyc));
+		const JacT<PB> S = madd_jac(acc, weaken<FA>(tx), weaken<FA>(tyt), K);
+		const bool use_t = inf & (mag != 0);
+		const bool keep = (mag == 0);
+		acc.X = selg(keep, acc.X, selg(use_t, weaken<FT>(tx), S.X));
+		acc.Y = selg(keep, acc.Y, selg(use_t, tyt, S.Y));
+		acc.Z = selg(keep, acc.Z, selg(use_t, weaken<FT>(onec), S.Z));
+		inf = inf & keep;
+	}
+	// an exceptional pair of the mixed addition, or a doubling that reached infinity, leaves Z = 0 for good: one exact test
+	if (!inf && is_zero_mulout(mulc(acc.Z, onec, K), K)) {
+		A.status[i] = ECAMD_STATUS_REDO;
+		return;
+	}
+	if (inf) {
+		const int clen = (int)A.clen;
+		u8 *out = A.out + (size_t)i * 2 * clen;
+		A.status[i] = 2;
+		for (int b = 0; b < 2 * clen; b++) {
+			out[b] = 0;
+		}
+		return;
+	}
+	Jac<PB> R;
+	R.X = weaken<FA>(acc.X);
+	R.Y = weaken<FA>(acc.Y);
+	R.Z = weaken<FA>(acc.Z);
+	jac_store<PB>(tb, R);
 	A.status[i] = ECAMD_STATUS_JAC;
 }
 
@@ -418,12 +757,15 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_g(Ecamd
 		}
 		kw[NW] = (u32)c;  // top digit: 0 or 1
 	}
-	const FA onez = weaken<FA>(constant<FC>(K.one));
-	Jac<PB> acc;
+	// accumulator: the tight class and the mixed addition where the flavour has them (see k_loop_g), else Jac / add_jac
+	typedef typename std::conditional<PLAIN9, Jac<PB>, JacT<PB>>::type JA;
+	typedef decltype(JA::X) FX;
+	const FX onez = weaken<FX>(constant<FC>(K.one));
+	JA acc;
 	acc.X = onez;  // placeholder, replaced by the first non-zero digit
 	acc.Y = onez;
 	acc.Z = onez;
-	bool inf = true, bad = false, hz;
+	bool inf = true, bad = false, hz = false;
 #pragma unroll 1
 	for (int j = 0; j <= NWIN; j++) {
 		u32 word = 0;
@@ -449,9 +791,16 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_g(Ecamd
 			tx.l[w] = buf[w];
 			tyc.l[w] = buf[NL + w];
 		}
-		const FA txa = weaken<FA>(tx);
-		const FA ty = selg(dig < 0, neg<PB>(tyc, K), weaken<FA>(tyc));
-		const Jac<PB> S = add_jac(acc, txa, ty, onez, hz, K);
+		const FX txa = weaken<FX>(tx);
+		FX ty;
+		JA S;
+		if constexpr (PLAIN9) {
+			ty = selg(dig < 0, neg<PB>(tyc, K), weaken<FA>(tyc));
+			S = add_jac(acc, txa, ty, onez, hz, K);
+		} else {
+			ty = selg(dig < 0, neg_t<PB>(tyc, K), weaken<FX>(tyc));
+			S = madd_jac(acc, weaken<FA>(txa), weaken<FA>(ty), K);   // an exceptional pair leaves Z = 0: tested once below
+		}
 		const bool use_t = inf & (mag != 0);
 		const bool keep = (mag == 0);
 		bad = bad | (!inf & !keep & hz);
@@ -459,6 +808,9 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_g(Ecamd
 		acc.Y = selg(keep, acc.Y, selg(use_t, ty, S.Y));
 		acc.Z = selg(keep, acc.Z, selg(use_t, onez, S.Z));
 		inf = inf & keep;
+	}
+	if constexpr (!PLAIN9) {
+		bad = !inf && is_zero_mulout(mulc(acc.Z, constant<FC>(K.one), K), K);
 	}
 	if (bad) {
 		A.status[i] = ECAMD_STATUS_REDO;
@@ -472,7 +824,11 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_g(Ecamd
 		return;
 	}
 	u32 *tb = A.tbl + (size_t)i * L::ITEMW;
-	jac_store<PB>(tb, acc);
+	Jac<PB> R;
+	R.X = weaken<FA>(acc.X);
+	R.Y = weaken<FA>(acc.Y);
+	R.Z = weaken<FA>(acc.Z);
+	jac_store<PB>(tb, R);
 	A.status[i] = ECAMD_STATUS_JAC;
 }
 
@@ -1663,15 +2019,42 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_TAG)(int gslot, const EcamdSmulArgs &a
 	const uint32_t nthreads = (a.n + FING_K - 1) / FING_K;
 	const dim3 fgrid((nthreads + 63) / 64);
 	// event slots as in ecamd_launch_smul_p256: [0] start, [3] after the loop kernel, [4] after finalisation
+	const bool pipeline_events =
+#if defined(G29_P25519) || defined(G29_K256) || defined(G29_JACTAB)
+		false;
+#else
+		!(a.lut && a.lut_kind == 1);
+#endif
 	if (ev) {
 		(void)hipEventRecord(ev[0], s);
-		(void)hipEventRecord(ev[1], s);
-		(void)hipEventRecord(ev[2], s);
+		if (!pipeline_events) {
+			(void)hipEventRecord(ev[1], s);
+			(void)hipEventRecord(ev[2], s);
+		}
 	}
 	if (a.lut && a.lut_kind == 1) {
 		hipLaunchKernelGGL((k_comb_g<G29_PB, G29_FLAV>), grid, block, 0, s, a, gslot);
 	} else {
+#if defined(G29_P25519) || defined(G29_K256) || defined(G29_JACTAB)
+		// nine-limb plain-residue flavours: Jacobian table, one kernel
 		hipLaunchKernelGGL((k_smul_g<G29_PB, G29_FLAV>), grid, block, 0, s, a, gslot);
+#else
+		// affine-table pipeline; a.stg: n x LayA::AITEMW words
+		hipLaunchKernelGGL((k_table_g<G29_PB, G29_FLAV>), grid, block, 0, s, a, gslot);
+		if (ev) {
+			(void)hipEventRecord(ev[1], s);
+		}
+		const uint32_t athreads = (a.n + AFFG_K - 1) / AFFG_K;
+		hipLaunchKernelGGL((k_affine_g<G29_PB, G29_FLAV>), dim3((athreads + 63) / 64), block, 0, s, a, gslot, athreads);
+		if (ev) {
+			(void)hipEventRecord(ev[2], s);
+		}
+		if (a.masked) {
+			hipLaunchKernelGGL((k_loop_g<G29_PB, G29_FLAV, true>), grid, block, 0, s, a, gslot);
+		} else {
+			hipLaunchKernelGGL((k_loop_g<G29_PB, G29_FLAV, false>), grid, block, 0, s, a, gslot);
+		}
+#endif
 	}
 	if (ev) {
 		(void)hipEventRecord(ev[3], s);
@@ -1723,6 +2106,11 @@ uint32_t ecamd_g29_table_words(int pbits, int flavour)
 {
 	const uint32_t nw = (uint32_t)((pbits + 31) / 32);
 	return 8u * (uint32_t)(((3 * g29::nl_for_flavour(pbits, flavour) + 3) / 4) * 4) + ((2u * nw + 2u + 3u) / 4u) * 4u;   // Lay<PB>::ITEMW
+}
+// affine window table of the mixed-addition pipeline: 8 entries of 2 NL digits, padded to 16 bytes (LayA<PB>::AITEMW)
+uint32_t ecamd_g29_affine_words(int pbits, int flavour)
+{
+	return 8u * (uint32_t)(((2 * g29::nl_for_flavour(pbits, flavour) + 3) / 4) * 4);
 }
 uint32_t ecamd_g29_max_slen(int pbits) { return 8u * (uint32_t)((pbits + 31) / 32) + 4u; }
 uint32_t ecamd_g29_comb_max_slen(int pbits) { return 4u * (uint32_t)((pbits + 31) / 32); }

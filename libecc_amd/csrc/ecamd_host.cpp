@@ -1173,7 +1173,8 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 	}
 	if (fast) {
 		uint8_t *t = (uint8_t *)ctx->tbl_fast;
-		const size_t per_item = fast256 ? P256_SCRATCH_PER_ITEM : (size_t)ecamd_g29_table_words(cv->pbits, cv->gflavour) * 4;
+		const size_t per_item = fast256 ? P256_SCRATCH_PER_ITEM
+						: ((size_t)ecamd_g29_table_words(cv->pbits, cv->gflavour) + ecamd_g29_affine_words(cv->pbits, cv->gflavour)) * 4;
 		const int rc = ensure(&t, &ctx->tbl_fast_bytes, (size_t)stride * per_item);
 		ctx->tbl_fast = (uint32_t *)t;
 		if (rc) {
@@ -1205,7 +1206,7 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 			// are recomputed by the complete-formula kernel (all other lanes exit at once)
 			EcamdSmulArgs Fa = A;
 			Fa.tbl = ctx->tbl_fast;
-			Fa.stg = fast256 ? ctx->tbl_fast + (size_t)stride * (P256_TAB_BYTES / 4) : nullptr;
+			Fa.stg = ctx->tbl_fast + (size_t)stride * (fast256 ? (size_t)(P256_TAB_BYTES / 4) : (size_t)ecamd_g29_table_words(cv->pbits, cv->gflavour));
 			// fixed base: a constant table of the generator replaces the per-item table kernels
 			if (!d_points) {
 				const bool use_comb = cv->d_comb && comb_ok;

@@ -324,6 +324,7 @@ int ecamd_g29_supported(int pbits);
 int ecamd_g29_nl(int pbits, int flavour);
 int ecamd_g29_slots(void);
 uint32_t ecamd_g29_table_words(int pbits, int flavour);   // scratch words per item
+uint32_t ecamd_g29_affine_words(int pbits, int flavour);  // affine window table words per item (EcamdSmulArgs.stg)
 uint32_t ecamd_g29_max_slen(int pbits);      // longest scalar (bytes) the window kernel takes (blinded scalars included)
 uint32_t ecamd_g29_comb_max_slen(int pbits); // longest scalar the fixed-base comb takes
 size_t ecamd_g29_image_bytes(int pbits, int flavour);

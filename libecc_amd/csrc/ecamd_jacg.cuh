@@ -30,9 +30,20 @@ template <int PB> struct Jac {
 
 #define JG_K const CurveG<Cfg<PB>::NL> &K
 
-template <int PB> G29_FN Jac<PB> dbl(const Jac<PB> &P, JG_K)
+// Tight class for the accumulator of the mixed-addition loop (madd_jac below subtracts X1 and Y1 themselves, so their
+// declared bound becomes the bias, and everything after it, of that addition): doublings and mixed additions map it into
+// itself for every field size (checked by the static_asserts of weaken / sub_auto / mul).
+template <int PB> struct ClsT {
+	static constexpr u64 VT = PLAIN9 ? Cls<PB>::VA : (128ull << Cfg<PB>::BIAS_OFF);
+	typedef E<PB, MASK + 8, Cfg<PB>::top_from_vb(VT), VT> FT;
+};
+template <int PB> struct JacT {
+	typename ClsT<PB>::FT X, Y, Z;
+};
+
+template <int PB, class J> G29_FN J dbl_any(const J &P, JG_K)
 {
-	typedef typename Cls<PB>::FA FA;
+	typedef decltype(J::X) FA;
 	typedef typename Cls<PB>::FC FC;
 	const auto yy = sqrc(P.Y, K);
 	const auto s4 = mulc(P.X, mul_small<4>(yy), K);  // 4 X Y^2
@@ -56,12 +67,14 @@ template <int PB> G29_FN Jac<PB> dbl(const Jac<PB> &P, JG_K)
 	const auto t4 = carry(sub_auto<1>(s4, x3, K));                // 4 X Y^2 - X3
 	const auto y3 = carry(sub_auto<1>(mulc(m, t4, K), y8, K));
 	const auto z3 = carry(mul_small<2>(mulc(P.Y, P.Z, K)));        // 2 Y Z
-	Jac<PB> R;
+	J R;
 	R.X = weaken<FA>(x3);
 	R.Y = weaken<FA>(y3);
 	R.Z = weaken<FA>(z3);
 	return R;
 }
+template <int PB> G29_FN Jac<PB> dbl(const Jac<PB> &P, JG_K) { return dbl_any<PB, Jac<PB>>(P, K); }
+template <int PB> G29_FN JacT<PB> dbl(const JacT<PB> &P, JG_K) { return dbl_any<PB, JacT<PB>>(P, K); }
 
 // (X1, Y1, Z1) + (X2, Y2, Z2); h_is_zero <=> the x coordinates coincide (P + P or P + (-P))
 template <int PB>
@@ -93,6 +106,33 @@ G29_FN Jac<PB> add_jac(const Jac<PB> &P, const typename Cls<PB>::FA &X2, const t
 	return R;
 }
 
+// (X1, Y1, Z1) + (x2, y2) with the second point affine (Z2 = 1): 8M + 3S (the Z2 terms of add_jac dropped).
+// No exceptional-pair flag: H = 0 (the same x: P + P or P + (-P)) gives Z3 = Z1 H = 0, and a zero Z survives every later
+// doubling (Z3 = 2 Y Z) and addition (Z3 = Z1 H), so ONE exact test of the final Z catches it (the callers' redo lane).
+template <int PB>
+G29_FN JacT<PB> madd_jac(const JacT<PB> &P, const typename Cls<PB>::FA &X2, const typename Cls<PB>::FA &Y2, JG_K)
+{
+	typedef typename ClsT<PB>::FT FT;
+	const auto z1z1 = sqrc(P.Z, K);
+	const auto u2 = mulc(X2, z1z1, K);
+	const auto s2 = mulc(mulc(Y2, P.Z, K), z1z1, K);
+	const auto h = carry(sub_auto<1>(u2, P.X, K));
+	const auto r = carry(sub_auto<1>(s2, P.Y, K));
+	const auto hh = sqrc(h, K);
+	const auto hhh = mulc(h, hh, K);
+	const auto v = mulc(P.X, hh, K);
+	const auto r2 = sqrc(r, K);
+	const auto x3 = carry(sub_auto<2>(r2, add(hhh, mul_small<2>(v)), K));
+	const auto t5 = carry(sub_auto<1>(v, x3, K));
+	const auto y3 = carry(sub_auto<1>(mulc(r, t5, K), mulc(P.Y, hhh, K), K));
+	const auto z3 = mulc(P.Z, h, K);
+	JacT<PB> R;
+	R.X = weaken<FT>(x3);
+	R.Y = weaken<FT>(y3);
+	R.Z = weaken<FT>(z3);
+	return R;
+}
+
 // -Y (+ a multiple of p), carried: the negated table entry of a negative window digit.  Table
 // entries keep Y as a multiplication result (value < 2p) so that the negation stays inside FA.
 template <int PB> G29_FN typename Cls<PB>::FA neg(const typename Cls<PB>::FM &y, JG_K)
@@ -103,6 +143,17 @@ template <int PB> G29_FN typename Cls<PB>::FA neg(const typename Cls<PB>::FM &y,
 		zero.l[i] = 0;
 	}
 	return weaken<typename Cls<PB>::FA>(carry(sub_auto<1>(zero, y, K)));
+}
+
+// the same in the tight accumulator class (a digit's first table entry becomes the accumulator)
+template <int PB> G29_FN typename ClsT<PB>::FT neg_t(const typename Cls<PB>::FM &y, JG_K)
+{
+	E<PB, 0, 0, 0> zero;
+#pragma unroll
+	for (int i = 0; i < Cfg<PB>::NL; i++) {
+		zero.l[i] = 0;
+	}
+	return weaken<typename ClsT<PB>::FT>(carry(sub_auto<1>(zero, y, K)));
 }
 
 // table entry: X, Z as they come, Y normalised through one multiplication by 1

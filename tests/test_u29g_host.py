@@ -186,6 +186,54 @@ def test_jacobian(lib, curve, flavour=0):
             acc = aff_add(acc, acc, a, p)
         assert aff(cur) == acc
         in_class(cur)
+    # mixed addition and doubling on the tight accumulator class of the affine-table kernels (not for the nine-limb
+    # plain-residue flavours, which keep the Jacobian table)
+    it3 = (C.c_uint32 * 3)()
+    getattr(lib, f"g_infot_{f.pb}")(it3)
+    if it3[0]:
+        vt, ft_lb, ft_tb = it3[0], it3[1], it3[2]
+
+        def ft(residue):
+            vmax = min(vt, ((ft_tb - 1) << (W * (f.nl - 1))) // p)
+            mult = int(rng.integers(0, max(1, vmax - 1)))
+            return f.loose(rng, residue % p + mult * p, ft_lb, ft_tb)
+
+        def jac_t(P):
+            z = int.from_bytes(rng.bytes(80), "big") % p or 1
+            return ft(P[0] * z * z % p * f.R % p) + ft(P[1] * z * z * z % p * f.R % p) + ft(z * f.R % p)
+
+        def in_class_t(l):
+            for k in range(3):
+                part = l[k * f.nl:(k + 1) * f.nl]
+                assert max(part[:-1]) <= ft_lb and part[-1] <= ft_tb and val(part) < vt * p
+
+        def affine_fa(P):
+            return f.fa(rng, P[0] * f.R % p) + f.fa(rng, P[1] * f.R % p)
+        cur, acc = jac_t(acc), acc
+        for it in range(16):
+            if it % 3 == 2:
+                cur, _ = f.call("dblt", cur, n_out=3 * f.nl)
+                acc = aff_add(acc, acc, a, p)
+            else:
+                Q = aff_add(Q, G0, a, p)
+                T = Q if it % 2 else (Q[0], p - Q[1])
+                cur, _ = f.call("madd", cur, affine_fa(T), n_out=3 * f.nl)
+                acc = aff_add(acc, T, a, p)
+            assert aff(cur) == acc
+            in_class_t(cur)
+            if it % 5 == 4:
+                cur = jac_t(acc)      # a fresh loose representative of the class
+        # the same x: Z3 = 0, and it stays 0 through later doublings and additions (the kernels test the final Z once)
+        for T in (P, (P[0], p - P[1])):
+            out, _ = f.call("madd", jac_t(P), affine_fa(T), n_out=3 * f.nl)
+            assert aff(out) is None
+            in_class_t(out)
+            out, _ = f.call("dblt", out, n_out=3 * f.nl)
+            assert aff(out) is None
+            in_class_t(out)
+            out, _ = f.call("madd", out, affine_fa(Q), n_out=3 * f.nl)
+            assert aff(out) is None
+            in_class_t(out)
     # exceptional pairs are flagged
     _, hz = f.call("add", jac(P), jac(P), n_out=3 * f.nl)
     assert hz == 1

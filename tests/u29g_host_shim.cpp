@@ -54,6 +54,49 @@ template <int PB> struct Shim {
 		memcpy(out + 2 * NL, R.Z.l, 4 * NL);
 		return hz ? 1 : 0;
 	}
+#if !defined(G29_P25519) && !defined(G29_K256)
+	// mixed addition / doubling on the tight accumulator class JacT (the window loop of the affine-table kernels)
+	static int madd_(const uint32_t *k, const uint32_t *p, const uint32_t *q, uint32_t *out)
+	{
+		const CK &K = *(const CK *)k;
+		JacT<PB> P;
+		typename Cls<PB>::FA X2, Y2;
+		memcpy(P.X.l, p, 4 * NL);
+		memcpy(P.Y.l, p + NL, 4 * NL);
+		memcpy(P.Z.l, p + 2 * NL, 4 * NL);
+		memcpy(X2.l, q, 4 * NL);
+		memcpy(Y2.l, q + NL, 4 * NL);
+		JacT<PB> R = madd_jac(P, X2, Y2, K);
+		memcpy(out, R.X.l, 4 * NL);
+		memcpy(out + NL, R.Y.l, 4 * NL);
+		memcpy(out + 2 * NL, R.Z.l, 4 * NL);
+		return 0;
+	}
+	static void dblt_(const uint32_t *k, const uint32_t *p, uint32_t *out)
+	{
+		const CK &K = *(const CK *)k;
+		JacT<PB> P;
+		memcpy(P.X.l, p, 4 * NL);
+		memcpy(P.Y.l, p + NL, 4 * NL);
+		memcpy(P.Z.l, p + 2 * NL, 4 * NL);
+		JacT<PB> R = dbl(P, K);
+		memcpy(out, R.X.l, 4 * NL);
+		memcpy(out + NL, R.Y.l, 4 * NL);
+		memcpy(out + 2 * NL, R.Z.l, 4 * NL);
+	}
+	static void infot_(uint32_t *out)
+	{
+		out[0] = (uint32_t)ClsT<PB>::VT;
+		out[1] = (uint32_t)ClsT<PB>::FT::LB;
+		out[2] = (uint32_t)ClsT<PB>::FT::TB;
+	}
+#else
+	// the nine-limb plain-residue flavours keep the Jacobian-table kernel (their products leave no room for the bias of a
+	// subtraction from the accumulator itself)
+	static int madd_(const uint32_t *, const uint32_t *, const uint32_t *, uint32_t *) { return -1; }
+	static void dblt_(const uint32_t *, const uint32_t *, uint32_t *) {}
+	static void infot_(uint32_t *out) { out[0] = 0; }
+#endif
 	static void neg_(const uint32_t *k, const uint32_t *a, uint32_t *out)
 	{
 		const CK &K = *(const CK *)k;
@@ -95,6 +138,9 @@ template <int PB> struct Shim {
 	void g_mul_##PB(const uint32_t *k, const uint32_t *a, const uint32_t *b, uint32_t *o, int sq) { Shim<PB>::mul_(k, a, b, o, sq); } \
 	void g_dbl_##PB(const uint32_t *k, const uint32_t *p, uint32_t *o) { Shim<PB>::dbl_(k, p, o); } \
 	int g_add_##PB(const uint32_t *k, const uint32_t *p, const uint32_t *q, uint32_t *o) { return Shim<PB>::add_(k, p, q, o); } \
+	int g_madd_##PB(const uint32_t *k, const uint32_t *p, const uint32_t *q, uint32_t *o) { return Shim<PB>::madd_(k, p, q, o); } \
+	void g_dblt_##PB(const uint32_t *k, const uint32_t *p, uint32_t *o) { Shim<PB>::dblt_(k, p, o); } \
+	void g_infot_##PB(uint32_t *o) { Shim<PB>::infot_(o); } \
 	void g_neg_##PB(const uint32_t *k, const uint32_t *a, uint32_t *o) { Shim<PB>::neg_(k, a, o); } \
 	void g_inv_##PB(const uint32_t *k, const uint32_t *a, uint32_t *o) { Shim<PB>::inv_(k, a, o); } \
 	void g_canon_##PB(const uint32_t *k, const uint32_t *a, uint32_t *o) { Shim<PB>::canon_(k, a, o); } \
