@@ -1,4 +1,4 @@
-// libecc_amd/csrc/ecamd_field.cuh -- prime-field arithmetic on gfx950, one element per lane.
+// libecc_amd/csrc/ecamd_field.h -- prime-field arithmetic on gfx950, one element per lane.
 //
 // Replaces the reference's nn/fp hot loop (paths relative to /root/reference/src):
 //   nn_mul_redc1   nn/nn_mul_redc1.c:124-218   CIOS Montgomery multiplication  -> fe_mul / fe_sqr

@@ -10,7 +10,7 @@
 // (curves/prj_pt.c:511,1759,241,600 in /root/reference/src).
 #include <hip/hip_runtime.h>
 #include <type_traits>
-#include "ecamd_jacg.cuh"
+#include "ecamd_jacg.h"
 #include "ecamd_internal.h"
 
 using namespace jacg;

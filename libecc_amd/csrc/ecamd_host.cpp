@@ -612,7 +612,7 @@ static SlotRegistry *slot_registry(int device)
 }
 
 // CurveK<NW> as a flat word image: p r2 one pm2 a b b3 fix64 (NW words each), then
-// mpinv pbits a_is_m3 fix_is_id -- must match ecamd_field.cuh.  Returns the slot holding it (g_slot_mu held).
+// mpinv pbits a_is_m3 fix_is_id -- must match ecamd_field.h.  Returns the slot holding it (g_slot_mu held).
 static int acquire_modulus(int device, int nw, const Big &p, const Big &a_in, const Big &b_in, int *slot_out)
 {
 	Big a_red = big_mod(a_in, p), b_red = big_mod(b_in, p);
@@ -702,7 +702,7 @@ static Big big_shl(const Big &a, int e)
 	return big_mul(a, big_pow2(e));
 }
 
-// CurveG<NL> image of ecamd_u29g.cuh: p r2 one a b pm2 (NL digits each), 16 bias tables, ix iy ex ey, mpinv pbits
+// CurveG<NL> image of ecamd_u29g.h: p r2 one a b pm2 (NL digits each), 16 bias tables, ix iy ex ey, mpinv pbits
 // a_is_m3 pad -- mirrored by tools/g29_consts.py, which the CPU tests use against Python integers
 static int upload_g29(ecamd_curve *cv)
 {

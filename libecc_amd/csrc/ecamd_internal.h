@@ -9,7 +9,7 @@
 #define ECAMD_STATUS_TAB 0xFC   /* internal: fast path built the item's window table, loop pending */
 #define ECAMD_STATUS_JAC 0xFD   /* internal: fast path stored a finite Jacobian result, finalisation pending */
 #define ECAMD_STATUS_REDO 0xFE  /* internal: fast path met an exceptional pair, redo with complete formulas */
-#define ECAMD_MAX_SLOTS_HOST 16 /* == ECAMD_MAX_SLOTS in ecamd_field.cuh */
+#define ECAMD_MAX_SLOTS_HOST 16 /* == ECAMD_MAX_SLOTS in ecamd_field.h */
 
 struct EcamdSmulArgs {
 	const uint8_t *scalars;  // n x slen, big-endian

@@ -1,11 +1,11 @@
-// libecc_amd/csrc/ecamd_jacg.cuh -- Jacobian group law over ecamd_u29g.cuh, any short-Weierstrass
-// curve y^2 = x^3 + a x + b (a = -3 shortcut and generic a), same structure as ecamd_p256.cuh.
+// libecc_amd/csrc/ecamd_jacg.h -- Jacobian group law over ecamd_u29g.h, any short-Weierstrass
+// curve y^2 = x^3 + a x + b (a = -3 shortcut and generic a), same structure as ecamd_p256.h.
 //   doubling  a = -3: 4M + 4S     a = 0: 3M + 4S     generic a: 4M + 6S (M = 3 X^2 + a Z^4)
 //   addition 12M + 4S (add-1998-cmo-2)
 // Thanks to the headroom limb no value fold is needed; carry() is inserted where the
-// static_asserts of ecamd_u29g.cuh demand it.
+// static_asserts of ecamd_u29g.h demand it.
 #pragma once
-#include "ecamd_u29g.cuh"
+#include "ecamd_u29g.h"
 
 namespace jacg {
 using namespace g29;

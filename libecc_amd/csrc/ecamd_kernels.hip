@@ -16,7 +16,7 @@
 //   complete RCB addition/doubling; one Fermat inversion to affine.
 // Per item: 4 on-curve mults, 14 table additions, 8*slen doublings, 2*slen additions,
 // ~1.5*|p| mults for the inversion.
-#include "ecamd_point.cuh"
+#include "ecamd_point.h"
 #include "ecamd_internal.h"
 
 #define ECAMD_DEF_CONST(NW) __constant__ CurveSlots<NW> g_curves_##NW;

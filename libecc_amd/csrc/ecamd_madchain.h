@@ -1,5 +1,5 @@
-// libecc_amd/csrc/ecamd_madchain.cuh -- chains of v_mad_u64_u32 as single inline-asm statements, shared by
-// the secp256r1 field (ecamd_u29.cuh) and the generic radix-2^29 field (ecamd_u29g.cuh).
+// libecc_amd/csrc/ecamd_madchain.h -- chains of v_mad_u64_u32 as single inline-asm statements, shared by
+// the secp256r1 field (ecamd_u29.h) and the generic radix-2^29 field (ecamd_u29g.h).
 //
 // hipcc pads every inline-asm statement that defines registers with an s_nop; with one statement per
 // product that is one s_nop per v_mad_u64_u32, which a kernel running one wave per SIMD (the large

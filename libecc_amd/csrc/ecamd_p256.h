@@ -1,4 +1,4 @@
-// libecc_amd/csrc/ecamd_p256.cuh -- secp256r1 group law on radix-2^29 lazy-reduced elements.
+// libecc_amd/csrc/ecamd_p256.h -- secp256r1 group law on radix-2^29 lazy-reduced elements.
 //
 // Jacobian coordinates (x = X/Z^2, y = Y/Z^3), a = -3:
 //   doubling  4M + 4S   (dbl-2001-b with Z3 = 2YZ and 8 gamma^2 = 2 (2 gamma)^2)
@@ -11,9 +11,9 @@
 // observable result is the reference's for EVERY input.
 //
 // Every intermediate is a bound-tracked u29::F<LB, TB, VB>; the carry()/fold() calls below are
-// exactly the ones the static_asserts of ecamd_u29.cuh demand.
+// exactly the ones the static_asserts of ecamd_u29.h demand.
 #pragma once
-#include "ecamd_u29.cuh"
+#include "ecamd_u29.h"
 
 namespace p256 {
 using namespace u29;

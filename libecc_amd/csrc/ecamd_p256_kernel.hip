@@ -2,8 +2,8 @@
 //
 // One scalar multiplication per lane (replaces prj_pt_import_from_aff_buf -> prj_pt_mul ->
 // prj_pt_unique -> prj_pt_export_to_aff_buf, curves/prj_pt.c:511,1759,241,600 of the reference):
-//   * field: radix-2^29 lazy Montgomery arithmetic (ecamd_u29.cuh), v_mad_u64_u32 only;
-//   * group: Jacobian a = -3 doubling (4M + 4S) and addition (12M + 4S) (ecamd_p256.cuh);
+//   * field: radix-2^29 lazy Montgomery arithmetic (ecamd_u29.h), v_mad_u64_u32 only;
+//   * group: Jacobian a = -3 doubling (4M + 4S) and addition (12M + 4S) (ecamd_p256.h);
 //   * scalar: signed fixed window w = 4 over k' = k + 0x88...8 (digit = nibble - 8 in [-8, 7]),
 //     left to right, 4 doublings + 1 MIXED addition (8M + 3S) per window, AFFINE table [1..8]P;
 //   * four kernels per batch, all inversions shared by Montgomery's trick over 8 items per lane:
@@ -24,7 +24,7 @@
 // such a lane is detected exactly (Z3 == 0 with both inputs finite), marked ECAMD_REDO and
 // recomputed by the complete-formula kernel k_smul<8> in the same call (ecamd_host.cpp).
 #include <hip/hip_runtime.h>
-#include "ecamd_p256.cuh"
+#include "ecamd_p256.h"
 #include "ecamd_internal.h"
 
 using namespace p256;

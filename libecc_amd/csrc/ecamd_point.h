@@ -1,15 +1,15 @@
-// libecc_amd/csrc/ecamd_point.cuh -- short-Weierstrass group law on gfx950, one point per lane.
+// libecc_amd/csrc/ecamd_point.h -- short-Weierstrass group law on gfx950, one point per lane.
 //
 // Replaces (paths relative to /root/reference/src):
 //   __prj_pt_add_monty_cf  curves/prj_pt.c:971-1071  RCB Alg. 1 complete addition (generic a)
 //   __prj_pt_dbl_monty_cf  curves/prj_pt.c:892-950   RCB Alg. 3 complete doubling (generic a)
 //   prj_pt_is_on_curve     curves/prj_pt.c:144-190
 // Homogeneous projective (X:Y:Z), infinity = (0:1:0), all coordinates in the Montgomery
-// domain of ecamd_field.cuh.  The formulas are the Renes-Costello-Batina complete ones the
+// domain of ecamd_field.h.  The formulas are the Renes-Costello-Batina complete ones the
 // reference uses, so every input pair -- P+P, P+(-P), P+inf, inf+inf -- is handled by the same
 // straight-line code and no lane ever diverges inside the scalar-multiplication loop.
 #pragma once
-#include "ecamd_field.cuh"
+#include "ecamd_field.h"
 
 template <int NW> struct Pt {
 	Fe<NW> X, Y, Z;

@@ -1,4 +1,4 @@
-// libecc_amd/csrc/ecamd_u29.cuh -- unsaturated radix-2^29 prime-field arithmetic with lazy
+// libecc_amd/csrc/ecamd_u29.h -- unsaturated radix-2^29 prime-field arithmetic with lazy
 // reduction and compile-time bound tracking (the fast path of the scalar multiplication).
 //
 // Why not 32/64-bit saturated limbs (the reference's layout, nn/nn.h:42-45)?  Measured on
@@ -31,7 +31,7 @@
 #pragma once
 #include <stdint.h>
 #include <utility>
-#include "ecamd_madchain.cuh"
+#include "ecamd_madchain.h"
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -146,7 +146,7 @@ template <u64 VBO> struct MulOut {
 
 // raw kernels on plain arrays (bounds are checked by the typed wrappers below).  Columns are compile-time
 // indexed so that each one's products and reduction terms go out as asm statements of up to twelve MADs
-// (ecamd_madchain.cuh: one padding s_nop per statement instead of one per MAD).
+// (ecamd_madchain.h: one padding s_nop per statement instead of one per MAD).
 template <bool SQR, int K_> struct Col9 {
 	static constexpr int LO = (K_ < 9) ? 0 : (K_ - 8);
 	static constexpr int HI = (K_ < 9) ? K_ : 8;

@@ -1,5 +1,5 @@
-// libecc_amd/csrc/ecamd_u29g.cuh -- radix-2^29 lazy Montgomery arithmetic for ANY odd prime,
-// with compile-time bound tracking (generalisation of ecamd_u29.cuh, which stays the
+// libecc_amd/csrc/ecamd_u29g.h -- radix-2^29 lazy Montgomery arithmetic for ANY odd prime,
+// with compile-time bound tracking (generalisation of ecamd_u29.h, which stays the
 // hand-specialised secp256r1 path).
 //
 // Same idea: limbs of 29 bits in u32, 64-bit column accumulators, one v_mad_u64_u32 per
@@ -15,7 +15,7 @@
 #pragma once
 #include <stdint.h>
 #include <utility>
-#include "ecamd_madchain.cuh"
+#include "ecamd_madchain.h"
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -201,7 +201,7 @@ template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
 #define G29_PIN(acc) (void)0
 #endif
 
-// ---- multiply-accumulate chains (ecamd_madchain.cuh): a column's products go out in asm statements of up
+// ---- multiply-accumulate chains (ecamd_madchain.h): a column's products go out in asm statements of up
 // to four MADs; from G29_DUAL_FROM_NL limbs on (one or two waves per SIMD) on two alternating accumulators ----
 #ifndef G29_DUAL_FROM_NL
 #define G29_DUAL_FROM_NL 12

@@ -145,7 +145,7 @@ static double g_wall_khz;  // rate of s_memrealtime
 // one multiplication PER LANE.  Both compute the 17 column sums of a 9 x 9-limb (29-bit) schoolbook product -- the part of a
 // multiplication that is pure MADs in the per-lane layout; the carry pass and the reduction that follow would add the same kind of
 // cross-lane steps again on the spread side.
-//   per lane:    81 v_mad_u64_u32 per multiplication, no data movement (what ecamd_u29.cuh does);
+//   per lane:    81 v_mad_u64_u32 per multiplication, no data movement (what ecamd_u29.h does);
 //   lane spread: a DPP row of 16 lanes holds one multiplication; lane r (r < 9) forms its row a_r * b_j (9 MADs), then column c
 //                is gathered by lane c with eight row_shr / row_shl steps of 64-bit values (two v_mov_dpp + a 64-bit add each),
 //                for the low and for the high half: 4 multiplications per wave instruction stream instead of 64.

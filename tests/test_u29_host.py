@@ -1,5 +1,5 @@
-"""CPU tests of the radix-2^29 lazy-reduction field / Jacobian code (libecc_amd/csrc/ecamd_u29.cuh,
-ecamd_p256.cuh): the product headers are compiled for the host (tests/u29_host_shim.cpp, g++) and
+"""CPU tests of the radix-2^29 lazy-reduction field / Jacobian code (libecc_amd/csrc/ecamd_u29.h,
+ecamd_p256.h): the product headers are compiled for the host (tests/u29_host_shim.cpp, g++) and
 driven against Python integers, including operands sitting at the extreme of their declared bound
 classes (the compile-time bound tracking must make those overflow-free)."""
 import ctypes as C

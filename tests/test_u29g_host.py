@@ -1,4 +1,4 @@
-"""CPU tests of the generic radix-2^29 field / Jacobian code (ecamd_u29g.cuh, ecamd_jacg.cuh) for
+"""CPU tests of the generic radix-2^29 field / Jacobian code (ecamd_u29g.h, ecamd_jacg.h) for
 every field size libecc's curves use: host build of the product headers (tests/u29g_host_shim.cpp)
 against Python integers, with operands spread over their whole bound class."""
 import ctypes as C

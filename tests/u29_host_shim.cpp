@@ -3,7 +3,7 @@
 // (including its compile-time bound checks) against Python integers without a GPU.
 #include <cstring>
 #define U29_INLINE_MUL 1
-#include "../libecc_amd/csrc/ecamd_p256.cuh"
+#include "../libecc_amd/csrc/ecamd_p256.h"
 
 using namespace p256;
 

@@ -1,8 +1,8 @@
 // tests/u29g_host_shim.cpp -- TEST INFRASTRUCTURE: host build of the generic radix-2^29 headers
-// (ecamd_u29g.cuh, ecamd_jacg.cuh) for tests/test_u29g_host.py.  One set of entry points per
+// (ecamd_u29g.h, ecamd_jacg.h) for tests/test_u29g_host.py.  One set of entry points per
 // field size; the curve constants (CurveG image) are supplied by the test as a flat u32 array.
 #include <cstring>
-#include "../libecc_amd/csrc/ecamd_jacg.cuh"
+#include "../libecc_amd/csrc/ecamd_jacg.h"
 
 using namespace jacg;
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Python mirror of the CurveG<NL> constant image of libecc_amd/csrc/ecamd_u29g.cuh (what
+"""Python mirror of the CurveG<NL> constant image of libecc_amd/csrc/ecamd_u29g.h (what
 ecamd_host.cpp uploads per curve).  Used by tests/test_u29g_host.py to drive the host build of the
 generic radix-2^29 code; tests/test_gpu_parity.py cross-checks the C++ builder through the GPU."""
 W = 29

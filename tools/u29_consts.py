@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Derive (and print as C initialisers) the radix-2^29 constants of libecc_amd/csrc/ecamd_u29*.cuh
+"""Derive (and print as C initialisers) the radix-2^29 constants of libecc_amd/csrc/ecamd_u29*.h
 from the P-256 domain parameters.  tests/test_u29_host.py re-derives them and compares with what the
 header holds, so nothing here needs to be trusted."""
 W, NL = 29, 9
