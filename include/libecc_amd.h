@@ -292,9 +292,10 @@ int ec_structured_key_pair_import_batch(ecamd_ctx *ctx, const ecamd_curve *curve
 /* Device-pointer forms of the verification / key-agreement entry points, for callers whose batches
  * already live in HBM (and for sharding a batch over GPUs, one context per device): same semantics and
  * layouts as the host-pointer forms above, every buffer a device pointer, kernels enqueued on
- * hip_stream (a hipStream_t; NULL = the context's stream).  ec_ecdsa_verify_batch_dev returns with the
- * results complete (it synchronises the stream to re-check exceptional items); the others only
- * enqueue -- synchronise the stream (or ecamd_ctx_synchronize for the context's stream) before reading. */
+ * hip_stream (a hipStream_t; NULL = the context's stream).  They only enqueue (ec_ecdsa_verify_batch_dev included: the
+ * items its interleaved secp256r1 loop could not finish are re-verified by kernels on the same stream) -- synchronise the
+ * stream (or ecamd_ctx_synchronize for the context's stream) before reading.  The first call of a size may allocate
+ * scratch (hipMalloc / hipFree, which synchronise the device); later calls of that size or smaller do not. */
 int ec_ecdsa_verify_batch_dev(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const void *d_pubkeys_aff,
 			      const void *d_sigs, const void *d_digests, uint32_t digest_len, void *d_result,
 			      void *hip_stream);

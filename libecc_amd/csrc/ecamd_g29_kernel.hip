@@ -384,7 +384,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_smul
 }
 
 // ------------------------------------------------------------------------------------------
-// Affine-table pipeline (every flavour except the nine-limb plain-residue ones): the pipeline of ecamd_p256_kernel.hip
+// Affine-table pipeline (every flavour except secp256k1's, see HAVE_MADD in ecamd_jacg.h): the pipeline of ecamd_p256_kernel.hip
 //   k_table_g    import + on-curve check, Jacobian multiples 2P..8P into the item's staging slots, recoded scalar
 //   k_affine_g   2P..8P -> affine with ONE inversion per AFFG_K items x 7 entries (Montgomery's trick; the prefix products
 //                rest in the affine slots they are about to be replaced by)
@@ -562,8 +562,10 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_table_g(Ecam
 	A.status[i] = ECAMD_STATUS_TAB;
 }
 
+// items per inversion: 8 for large batches (the inversion costs each of the 7 x 8 entries a few multiplications), fewer
+// for small ones so that the kernel still fills the chip (the launcher decides)
 #define AFFG_K 8
-template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_affine_g(EcamdSmulArgs A, int gslot, u32 nthreads)
+template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_affine_g(EcamdSmulArgs A, int gslot, u32 nthreads, int items)
 {
 	typedef Lay<PB> L;
 	typedef typename Cls<PB>::FM FM;
@@ -576,7 +578,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_affine_g(Eca
 	const CurveG<NL> &K = TabGP<PB>::get(gslot);
 	FM c = weaken<FM>(constant<FC>(K.one));
 #pragma unroll 1
-	for (int j = 0; j < AFFG_K; j++) {
+	for (int j = 0; j < items; j++) {
 		const u32 i = t + (u32)j * nthreads;
 		if (i >= A.n || A.status[i] != ECAMD_STATUS_TAB) {
 			continue;
@@ -592,7 +594,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_affine_g(Eca
 	}
 	FM tinv = inv<PB>(c, K);
 #pragma unroll 1
-	for (int j = AFFG_K - 1; j >= 0; j--) {
+	for (int j = items - 1; j >= 0; j--) {
 		const u32 i = t + (u32)j * nthreads;
 		if (i >= A.n || A.status[i] != ECAMD_STATUS_TAB) {
 			continue;
@@ -758,7 +760,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_g(Ecamd
 		kw[NW] = (u32)c;  // top digit: 0 or 1
 	}
 	// accumulator: the tight class and the mixed addition where the flavour has them (see k_loop_g), else Jac / add_jac
-	typedef typename std::conditional<PLAIN9, Jac<PB>, JacT<PB>>::type JA;
+	typedef typename std::conditional<HAVE_MADD, JacT<PB>, Jac<PB>>::type JA;
 	typedef decltype(JA::X) FX;
 	const FX onez = weaken<FX>(constant<FC>(K.one));
 	JA acc;
@@ -794,7 +796,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_g(Ecamd
 		const FX txa = weaken<FX>(tx);
 		FX ty;
 		JA S;
-		if constexpr (PLAIN9) {
+		if constexpr (!HAVE_MADD) {
 			ty = selg(dig < 0, neg<PB>(tyc, K), weaken<FA>(tyc));
 			S = add_jac(acc, txa, ty, onez, hz, K);
 		} else {
@@ -809,7 +811,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_g(Ecamd
 		acc.Z = selg(keep, acc.Z, selg(use_t, onez, S.Z));
 		inf = inf & keep;
 	}
-	if constexpr (!PLAIN9) {
+	if constexpr (HAVE_MADD) {
 		bad = !inf && is_zero_mulout(mulc(acc.Z, constant<FC>(K.one), K), K);
 	}
 	if (bad) {
@@ -2020,7 +2022,7 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_TAG)(int gslot, const EcamdSmulArgs &a
 	const dim3 fgrid((nthreads + 63) / 64);
 	// event slots as in ecamd_launch_smul_p256: [0] start, [3] after the loop kernel, [4] after finalisation
 	const bool pipeline_events =
-#if defined(G29_P25519) || defined(G29_K256) || defined(G29_JACTAB)
+#if defined(G29_K256) || defined(G29_JACTAB)
 		false;
 #else
 		!(a.lut && a.lut_kind == 1);
@@ -2035,8 +2037,8 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_TAG)(int gslot, const EcamdSmulArgs &a
 	if (a.lut && a.lut_kind == 1) {
 		hipLaunchKernelGGL((k_comb_g<G29_PB, G29_FLAV>), grid, block, 0, s, a, gslot);
 	} else {
-#if defined(G29_P25519) || defined(G29_K256) || defined(G29_JACTAB)
-		// nine-limb plain-residue flavours: Jacobian table, one kernel
+#if defined(G29_K256) || defined(G29_JACTAB)
+		// secp256k1's flavour (and the A/B build): Jacobian table, one kernel
 		hipLaunchKernelGGL((k_smul_g<G29_PB, G29_FLAV>), grid, block, 0, s, a, gslot);
 #else
 		// affine-table pipeline; a.stg: n x LayA::AITEMW words
@@ -2044,8 +2046,9 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_TAG)(int gslot, const EcamdSmulArgs &a
 		if (ev) {
 			(void)hipEventRecord(ev[1], s);
 		}
-		const uint32_t athreads = (a.n + AFFG_K - 1) / AFFG_K;
-		hipLaunchKernelGGL((k_affine_g<G29_PB, G29_FLAV>), dim3((athreads + 63) / 64), block, 0, s, a, gslot, athreads);
+		const int aitems = a.n >= (1u << 19) ? AFFG_K : (a.n >= (1u << 17) ? 4 : 2);
+		const uint32_t athreads = (a.n + (uint32_t)aitems - 1) / (uint32_t)aitems;
+		hipLaunchKernelGGL((k_affine_g<G29_PB, G29_FLAV>), dim3((athreads + 63) / 64), block, 0, s, a, gslot, athreads, aitems);
 		if (ev) {
 			(void)hipEventRecord(ev[2], s);
 		}

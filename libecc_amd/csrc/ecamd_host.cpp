@@ -680,7 +680,7 @@ static void release_modulus(int device, int nw, int slot)
 
 static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_scalars, uint32_t slen,
 			   const uint8_t *d_points, uint8_t *d_out, uint8_t *d_status, hipStream_t s,
-			   uint32_t sstride = 0xffffffffu);
+			   uint32_t sstride = 0xffffffffu, bool redo_only = false);
 
 // 29-bit digits of a (nl of them, the last one takes whatever is left)
 static void big_digits29(uint32_t *dst, int nl, const Big &a)
@@ -1143,8 +1143,9 @@ static void maybe_build_comb(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n)
 // sstride = slen normally; 0 broadcasts one scalar to every item (subgroup / cofactor passes)
 static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_scalars,
 			   uint32_t slen, const uint8_t *d_points, uint8_t *d_out, uint8_t *d_status,
-			   hipStream_t s, uint32_t sstride)
+			   hipStream_t s, uint32_t sstride, bool redo_only)
 {
+	// redo_only: d_status is given; only the items marked ECAMD_STATUS_REDO in it are computed (complete-formula kernel)
 	if (sstride == 0xffffffffu) {
 		sstride = slen;
 	}
@@ -1159,7 +1160,7 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 	const bool fast256 = cv->is_p256 && slen <= 68;
 	const bool fastg = !fast256 && cv->gslot >= 0 && slen <= ecamd_g29_max_slen(cv->pbits);
 	const bool comb_ok = !secret && (cv->is_p256 ? slen <= 32 : slen <= ecamd_g29_comb_max_slen(cv->pbits));
-	const bool fast = fast256 || fastg;
+	const bool fast = !redo_only && (fast256 || fastg);
 	if (fast && !d_points && comb_ok) {
 		maybe_build_comb(ctx, const_cast<ecamd_curve *>(cv), n);
 	}
@@ -1196,7 +1197,7 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 		A.clen = (uint32_t)cv->clen;
 		A.stride = stride;
 		A.slot = cv->slot;
-		A.only_redo = 0;
+		A.only_redo = redo_only ? 1 : 0;
 		A.lut = nullptr;
 		A.lut_kind = 0;
 		A.stg = nullptr;
@@ -1506,14 +1507,17 @@ extern "C" int ec_fp_op_batch(ecamd_ctx *ctx, const ecamd_curve *cv, int op, uin
 // All pointers are device pointers; intermediates live in stage[3..11].
 // d_pub == NULL: every public key is the point at infinity (libecc imports (0 : 1 : 0) as a key, and its verification
 // then computes W' = uG + v*infinity = uG, sig/ecdsa_common.c:788-800): [u2]Y is not computed and W' = [u1]G.
+// d_only (may be d_res itself): a status array; only the items marked ECAMD_STATUS_REDO in it are verified (by the complete-formula
+// kernel) and get a result -- the redo pass of the interleaved secp256r1 loop, entirely on the device.  Only enqueues.
 static int ecdsa_two_smul_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_pub,
-			      const uint8_t *d_sig, const uint8_t *d_dig, uint32_t hlen, uint8_t *d_res, hipStream_t s)
+			      const uint8_t *d_sig, const uint8_t *d_dig, uint32_t hlen, uint8_t *d_res, hipStream_t s,
+			      const uint8_t *d_only = nullptr)
 {
 	if (n > ctx->max_chunk) {  // bound the scratch: pieces of max_chunk items, in order on the stream
 		for (uint32_t off = 0; off < n; off += ctx->max_chunk) {
 			const uint32_t m = (n - off) < ctx->max_chunk ? (n - off) : ctx->max_chunk;
 			if (ecdsa_two_smul_dev(ctx, cv, m, d_pub ? d_pub + (size_t)off * 2 * cv->clen : nullptr, d_sig + (size_t)off * 2 * cv->qlen,
-					       d_dig + (size_t)off * hlen, hlen, d_res + off, s)) {
+					       d_dig + (size_t)off * hlen, hlen, d_res + off, s, d_only ? d_only + off : nullptr)) {
 				return -1;
 			}
 		}
@@ -1539,41 +1543,38 @@ static int ecdsa_two_smul_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n,
 	P.hlen = hlen;
 	P.qbits = (uint32_t)cv->qbits;
 	P.qslot = cv->qslot;
+	P.only = d_only;
 	HIPCHK(ecamd_launch_ecdsa_prep(cv->qnw, P, s));
+	const bool redo = d_only != nullptr;
+	if (redo) {
+		// the marks select the lanes of the complete-formula kernel (A.only_redo); the other items keep what they have
+		HIPCHK(hipMemcpyAsync(S[7], d_only, n, hipMemcpyDeviceToDevice, s));
+		HIPCHK(hipMemcpyAsync(S[8], d_only, n, hipMemcpyDeviceToDevice, s));
+	}
 	// uG and vY: two independent prj_pt_mul, as in the reference (sig/ecdsa_common.c:788,793)
-	if (smul_dev_locked(ctx, cv, n, S[3], (uint32_t)cv->qlen, nullptr, S[5], S[7], s)) {
+	if (smul_dev_locked(ctx, cv, n, S[3], (uint32_t)cv->qlen, nullptr, S[5], S[7], s, 0xffffffffu, redo)) {
 		return -1;
 	}
 	if (!d_pub) {
 		HIPCHK(hipMemsetAsync(S[6], 0, n * plen, s));
 		HIPCHK(hipMemsetAsync(S[8], 2, n, s));   // [u2]Y = infinity
-	} else if (smul_dev_locked(ctx, cv, n, S[4], (uint32_t)cv->qlen, d_pub, S[6], S[8], s)) {
+	} else if (smul_dev_locked(ctx, cv, n, S[4], (uint32_t)cv->qlen, d_pub, S[6], S[8], s, 0xffffffffu, redo)) {
 		return -1;
 	}
 	if (d_pub && big_cmp(cv->order, cv->q) != 0) {
 		// cofactor != 1: ec_pub_key_import_from_aff_buf also requires [q]Y == infinity
-		// (sig/ec_key.c:199-205).  One more pass with the broadcast scalar q; a key outside the
-		// subgroup is turned into an import error (status 1) for the final stage.
-		std::vector<uint8_t> qb(ql);
-		big_to_be(qb.data(), (int)ql, cv->q);
-		uint8_t *qs = S[11] + n * plen;
-		HIPCHK(hipMemcpyAsync(qs, qb.data(), ql, hipMemcpyHostToDevice, s));
-		HIPCHK(hipStreamSynchronize(s));
-		if (smul_dev_locked(ctx, cv, n, qs, (uint32_t)ql, d_pub, S[11], S[10], s, 0)) {
+		// (sig/ec_key.c:199-205).  One more pass with the broadcast scalar q (it sits behind the generator in HBM); a key
+		// outside the subgroup is turned into an import error (status 1) for the final stage, on the device.
+		const uint8_t *qs = cv->d_gen + plen;
+		if (redo) {
+			HIPCHK(hipMemcpyAsync(S[10], d_only, n, hipMemcpyDeviceToDevice, s));
+		}
+		if (smul_dev_locked(ctx, cv, n, qs, (uint32_t)ql, d_pub, S[11], S[10], s, 0, redo)) {
 			return -1;
 		}
 		// S[10] holds 2 (infinity) for keys in the subgroup; anything else rejects: fold into stB
-		std::vector<uint8_t> sub(n), stb(n);
-		HIPCHK(hipMemcpyAsync(sub.data(), S[10], n, hipMemcpyDeviceToHost, s));
-		HIPCHK(hipMemcpyAsync(stb.data(), S[8], n, hipMemcpyDeviceToHost, s));
-		HIPCHK(hipStreamSynchronize(s));
-		for (uint32_t i = 0; i < n; i++) {
-			if (sub[i] != 2) {
-				stb[i] = 1;
-			}
-		}
-		HIPCHK(hipMemcpyAsync(S[8], stb.data(), n, hipMemcpyHostToDevice, s));
-		HIPCHK(hipStreamSynchronize(s));
+		// (redo pass: items that were not marked keep their old result byte there, and the final stage skips them)
+		HIPCHK(ecamd_launch_status_require(S[8], S[10], 2, n, s));
 	}
 	EcamdEcdsaFinArgs Fn;
 	Fn.A = S[5];
@@ -1600,11 +1601,12 @@ static int ecdsa_two_smul_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n,
 		Fn.q[w] = (size_t)w < cv->q.size() ? cv->q[(size_t)w] : 0;
 	}
 	Fn.slot = cv->slot;
+	Fn.only = d_only;
 	HIPCHK(ecamd_launch_ecdsa_fin(cv->nw, Fn, s));
 	return 0;
 }
 
-// device pointers in and out; returns with the results complete (the stream is synchronised)
+// device pointers in and out; only enqueues on s
 static int ecdsa_verify_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_pub,
 				   const uint8_t *d_sig, const uint8_t *d_dig, uint32_t hlen, uint8_t *d_res, hipStream_t s,
 				   const std::function<int()> *between = nullptr)
@@ -1616,7 +1618,6 @@ static int ecdsa_verify_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 		if (between && (*between)()) {
 			return -1;
 		}
-		HIPCHK(hipStreamSynchronize(s));
 		return 0;
 	}
 	// secp256r1: interleaved [u1]G + [u2]Q loop (ecamd_launch_verify_p256), in chunks
@@ -1651,6 +1652,7 @@ static int ecdsa_verify_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 		P.hlen = hlen;
 		P.qbits = (uint32_t)cv->qbits;
 		P.qslot = cv->qslot;
+		P.only = nullptr;
 		HIPCHK(ecamd_launch_ecdsa_prep(cv->qnw, P, s));
 		EcamdSmulArgs K;
 		memset(&K, 0, sizeof(K));
@@ -1666,40 +1668,14 @@ static int ecdsa_verify_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 		HIPCHK(ecamd_launch_verify_p256(K, S[3], S[4], d_sig + (size_t)off * 64, S[5],
 						cv->d_comb ? cv->d_comb : cv->d_gtab, cv->d_comb ? 1 : 0, cv->qdig, d_res + off, s));
 	}
-	// exceptional pairs inside the interleaved loop (never for honest signatures) come back as
-	// ECAMD_STATUS_REDO: re-verify those items the reference's way
-	if (between && (*between)()) {
+	// exceptional pairs inside the interleaved loop (never for honest signatures) come back as ECAMD_STATUS_REDO: those
+	// items are verified again the reference's way -- two complete-formula multiplications -- by kernels whose other
+	// lanes exit at once (with nothing marked: five near-empty launches)
+	if (ecdsa_two_smul_dev(ctx, cv, n, d_pub, d_sig, d_dig, hlen, d_res, s, d_res)) {
 		return -1;
 	}
-	std::vector<uint8_t> hres(n);
-	HIPCHK(hipMemcpyAsync(hres.data(), d_res, n, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
-	std::vector<uint32_t> redo;
-	for (uint32_t i = 0; i < n; i++) {
-		if (hres[i] == ECAMD_STATUS_REDO) {
-			redo.push_back(i);
-		}
-	}
-	if (!redo.empty()) {
-		const uint32_t r = (uint32_t)redo.size();
-		const size_t gneed[4] = {(size_t)r * 64, (size_t)r * 64, (size_t)r * hlen, r};
-		for (int i = 0; i < 4; i++) {
-			if (ensure(&ctx->stage[13 + i], &ctx->stage_bytes[13 + i], gneed[i])) {
-				return -1;
-			}
-		}
-		for (uint32_t j = 0; j < r; j++) {
-			HIPCHK(hipMemcpyAsync(S[13] + (size_t)j * 64, d_pub + (size_t)redo[j] * 64, 64, hipMemcpyDeviceToDevice, s));
-			HIPCHK(hipMemcpyAsync(S[14] + (size_t)j * 64, d_sig + (size_t)redo[j] * 64, 64, hipMemcpyDeviceToDevice, s));
-			HIPCHK(hipMemcpyAsync(S[15] + (size_t)j * hlen, d_dig + (size_t)redo[j] * hlen, hlen, hipMemcpyDeviceToDevice, s));
-		}
-		if (ecdsa_two_smul_dev(ctx, cv, r, S[13], S[14], S[15], hlen, S[16], s)) {
-			return -1;
-		}
-		for (uint32_t j = 0; j < r; j++) {
-			HIPCHK(hipMemcpyAsync(d_res + redo[j], S[16] + j, 1, hipMemcpyDeviceToDevice, s));
-		}
-		HIPCHK(hipStreamSynchronize(s));
+	if (between && (*between)()) {
+		return -1;
 	}
 	return 0;
 }

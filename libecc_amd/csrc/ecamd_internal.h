@@ -51,6 +51,7 @@ struct EcamdEcdsaPrepArgs {
 	uint8_t *flags;          // n: 0 ok, 1 reject (r or s not in [1, q-1])
 	uint32_t n, qlen, hlen, qbits;
 	int qslot;               // constant slot holding the Montgomery context of the generator order q
+	const uint8_t *only;     // NULL, or n status bytes: handle only the items marked ECAMD_STATUS_REDO (a lane none of whose items is marked exits at once)
 };
 struct EcamdEcdsaFinArgs {
 	const uint8_t *A, *stA;  // [u1]G affine + status
@@ -60,6 +61,7 @@ struct EcamdEcdsaFinArgs {
 	uint32_t n, clen, qlen, jmax;  // jmax = floor((p-1)/q): candidates x = r + j q
 	uint32_t q[17];          // generator order, little-endian words, zero padded to NW
 	int slot;
+	const uint8_t *only;     // NULL, or n status bytes (may be `result` itself): only the items marked ECAMD_STATUS_REDO
 };
 struct EcamdEcdsaSignArgs {
 	const uint8_t *privs, *nonces, *digests;  // n x qlen, n x qlen, n x hlen
@@ -315,6 +317,7 @@ struct EcamdBlindArgs {
 };
 hipError_t ecamd_launch_blind_scalar(const EcamdBlindArgs &a, hipStream_t s);
 // status[i] = 1 and out[i] zeroed where bad[i] != 0
+hipError_t ecamd_launch_status_require(uint8_t *status, const uint8_t *sub, uint8_t want, uint32_t n, hipStream_t s);
 hipError_t ecamd_launch_status_or(uint8_t *status, const uint8_t *bad, uint8_t *out, uint32_t out_stride, uint32_t n, hipStream_t s);
 hipError_t ecamd_launch_prj_import(int nw, const EcamdPrjInArgs &a, hipStream_t s);
 hipError_t ecamd_launch_prj_export(const EcamdPrjOutArgs &a, hipStream_t s);

@@ -33,8 +33,11 @@ template <int PB> struct Jac {
 // Tight class for the accumulator of the mixed-addition loop (madd_jac below subtracts X1 and Y1 themselves, so their
 // declared bound becomes the bias, and everything after it, of that addition): doublings and mixed additions map it into
 // itself for every field size (checked by the static_asserts of weaken / sub_auto / mul).
+// (p = 2^255 - 19 on nine limbs: products want v_a v_b <= 2^14, met with the accumulator below 20p; secp256k1's flavour,
+// v_a v_b <= 2^12, has no room for it -- H = U2 - X1 needs the 64p bias -- and keeps the Jacobian-table kernel)
+constexpr bool HAVE_MADD = !K256;
 template <int PB> struct ClsT {
-	static constexpr u64 VT = PLAIN9 ? Cls<PB>::VA : (128ull << Cfg<PB>::BIAS_OFF);
+	static constexpr u64 VT = P25519 ? 20 : (PLAIN9 ? Cls<PB>::VA : (128ull << Cfg<PB>::BIAS_OFF));
 	typedef E<PB, MASK + 8, Cfg<PB>::top_from_vb(VT), VT> FT;
 };
 template <int PB> struct JacT {

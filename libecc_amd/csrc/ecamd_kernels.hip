@@ -312,6 +312,16 @@ template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_prep(EcamdEcdsaP
 	if (first >= A.n) {
 		return;
 	}
+	if (A.only != nullptr) {
+		// redo pass: nothing to do unless one of the lane's items is marked
+		bool any = false;
+		for (int k = 0; k < ECDSA_PREP_K; k++) {
+			any = any | (first + k < A.n && A.only[first + k] == ECAMD_STATUS_REDO);
+		}
+		if (!any) {
+			return;
+		}
+	}
 	const int qs = A.qslot;  // modulus of this slot is q
 	const int qlen = (int)A.qlen, hlen = (int)A.hlen;
 	const Fe<NW> one = fe_const<NW>(ConstTab<NW>::get(qs).one);
@@ -427,6 +437,9 @@ template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_fin(EcamdEcdsaFi
 	const u32 i = blockIdx.x * 64 + threadIdx.x;
 	if (i >= A.n) {
 		return;
+	}
+	if (A.only != nullptr && A.only[i] != ECAMD_STATUS_REDO) {
+		return;   // redo pass: the item already has its result
 	}
 	const int slot = A.slot;
 	const int clen = (int)A.clen, qlen = (int)A.qlen;
@@ -1762,6 +1775,23 @@ __global__ __launch_bounds__(64) void k_status_or(u8 *status, const u8 *bad, u8 
 			out[(size_t)i * stride + k] = 0;
 		}
 	}
+}
+
+// status[i] = 1 wherever sub[i] != want (a public key whose [q]Y is not the point at infinity is an import error)
+__global__ __launch_bounds__(256) void k_status_require(u8 *status, const u8 *sub, u8 want, u32 n)
+{
+	const u32 i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n && sub[i] != want) {
+		status[i] = 1;
+	}
+}
+hipError_t ecamd_launch_status_require(uint8_t *status, const uint8_t *sub, uint8_t want, uint32_t n, hipStream_t s)
+{
+	if (n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_status_require, dim3((n + 255) / 256), dim3(256), 0, s, status, sub, want, n);
+	return hipGetLastError();
 }
 
 hipError_t ecamd_launch_status_or(uint8_t *status, const uint8_t *bad, uint8_t *out, uint32_t out_stride, uint32_t n, hipStream_t s)

@@ -731,6 +731,7 @@ def test_device_pointer_entry_points(gpu_ctx):
             dp, ds, dd, dr = t(pubs), t(sigs), t(dg), empty(n)
             torch.cuda.synchronize()
             cv.ecdsa_verify_dev(n, dp.data_ptr(), ds.data_ptr(), dd.data_ptr(), hl, dr.data_ptr(), stream.cuda_stream)
+            stream.synchronize()   # every *_dev form only enqueues
             assert bytes(dr.cpu().numpy()) == exp
             # scalar multiplication on the caller's stream
             sc = rand_bytes(rng, n * o.qlen)
@@ -1484,6 +1485,7 @@ def test_device_cores_chunked_by_max_chunk(gpu_ctx):
                 dr = torch.full((n,), 0xAA, dtype=torch.uint8, device=dev)
                 torch.cuda.synchronize()
                 b.ecdsa_verify_dev(n, dp.data_ptr(), ds.data_ptr(), dd.data_ptr(), hl, dr.data_ptr(), None)
+                ctx2.synchronize()
                 assert bytes(dr.cpu().numpy()) == exp and 0 in exp and 1 in exp
             finally:
                 a.free()

@@ -186,8 +186,8 @@ def test_jacobian(lib, curve, flavour=0):
             acc = aff_add(acc, acc, a, p)
         assert aff(cur) == acc
         in_class(cur)
-    # mixed addition and doubling on the tight accumulator class of the affine-table kernels (not for the nine-limb
-    # plain-residue flavours, which keep the Jacobian table)
+    # mixed addition and doubling on the tight accumulator class of the affine-table kernels (not for secp256k1's flavour,
+    # which keeps the Jacobian table)
     it3 = (C.c_uint32 * 3)()
     getattr(lib, f"g_infot_{f.pb}")(it3)
     if it3[0]:

@@ -54,7 +54,7 @@ template <int PB> struct Shim {
 		memcpy(out + 2 * NL, R.Z.l, 4 * NL);
 		return hz ? 1 : 0;
 	}
-#if !defined(G29_P25519) && !defined(G29_K256)
+#if !defined(G29_K256)
 	// mixed addition / doubling on the tight accumulator class JacT (the window loop of the affine-table kernels)
 	static int madd_(const uint32_t *k, const uint32_t *p, const uint32_t *q, uint32_t *out)
 	{
@@ -91,8 +91,8 @@ template <int PB> struct Shim {
 		out[2] = (uint32_t)ClsT<PB>::FT::TB;
 	}
 #else
-	// the nine-limb plain-residue flavours keep the Jacobian-table kernel (their products leave no room for the bias of a
-	// subtraction from the accumulator itself)
+	// secp256k1's flavour keeps the Jacobian-table kernel (its products leave no room for the bias of a subtraction from
+	// the accumulator itself)
 	static int madd_(const uint32_t *, const uint32_t *, const uint32_t *, uint32_t *) { return -1; }
 	static void dblt_(const uint32_t *, const uint32_t *, uint32_t *) {}
 	static void infot_(uint32_t *out) { out[0] = 0; }
