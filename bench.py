@@ -43,7 +43,7 @@ def popcount(x):
     return bin(x).count("1")
 
 
-def work_model(curve_params, nw, slen):
+def work_model(curve_params, nw, slen, batch=1 << 20):
     """Field multiplications and 32x32 MADs (v_mad_u64_u32) executed per item, derived from the
     kernels' own parameters.  secp256r1 takes the hand-specialised radix-2^29 Jacobian path
     (ecamd_p256_kernel.hip: multiplication 81 product + 36 reduction MADs, squaring 45 + 36), every
@@ -92,13 +92,28 @@ def work_model(curve_params, nw, slen):
         am3 = curve_params["a"] == p - 3 or iso_to_am3(p, curve_params["a"])
         dbl = (3, 4) if curve_params["a"] == 0 else ((4, 4) if am3 else (4, 6))
         add = (12, 4)
-        nm = 2 + 2 + 4 * dbl[0] + 3 * add[0] + 7 + nwin * (4 * dbl[0] + add[0]) + 1   # import, table (+7 Y normalisations), loop, Z test
-        ns = 2 + 4 * dbl[1] + 3 * add[1] + nwin * (4 * dbl[1] + add[1])
         inv_s, inv_m = pbits, popcount(p - 2)
+        if p == 2**256 - 2**32 - 977:
+            # secp256k1's flavour keeps the one-kernel Jacobian-table path k_smul_g (ecamd_jacg.h: HAVE_MADD)
+            nm = 2 + 2 + 4 * dbl[0] + 3 * add[0] + 7 + nwin * (4 * dbl[0] + add[0]) + 1   # import, table (+7 Y normalisations), loop, Z test
+            ns = 2 + 4 * dbl[1] + 3 * add[1] + nwin * (4 * dbl[1] + add[1])
+            nm += 1 + inv_m / fin_k + 2 + 3 + 2
+            ns += inv_s / fin_k + 1
+            loop_mads = (nm - (1 + inv_m / fin_k + 2 + 3 + 2)) * M + (ns - (inv_s / fin_k + 1)) * S
+            return nm + ns, nm * M + ns * S, f"k_smul_g<{pbits}>", loop_mads
+        # affine-table pipeline k_table_g / k_affine_g / k_loop_g / k_finalize_g (round 2)
+        madd = (8, 3)
+        aff_k = 8 if batch >= (1 << 19) else (4 if batch >= (1 << 17) else 2)
+        nm = 2 + 2 + 4 * dbl[0] + 3 * add[0] + 2                    # import, on-curve, 2P..8P, exact test of the last Z's
+        ns = 2 + 4 * dbl[1] + 3 * add[1]
+        nm += 7 * 6 + inv_m / aff_k                                  # per entry: prefix 1M, back-substitution 2M, Z^-3 1M, x 1M, y 1M
+        ns += 7 * 1 + inv_s / aff_k                                  # + Z^-2 1S; one Fermat inversion per aff_k items
+        loop_m, loop_s = nwin * (4 * dbl[0] + madd[0]) + 1, nwin * (4 * dbl[1] + madd[1])   # + the exact test of the final Z
+        nm += loop_m
+        ns += loop_s
         nm += 1 + inv_m / fin_k + 2 + 3 + 2
         ns += inv_s / fin_k + 1
-        loop_mads = (nm - (1 + inv_m / fin_k + 2 + 3 + 2)) * M + (ns - (inv_s / fin_k + 1)) * S
-        return nm + ns, nm * M + ns * S, f"k_smul_g<{pbits}>", loop_mads
+        return nm + ns, nm * M + ns * S, f"k_loop_g<{pbits}>", loop_m * M + loop_s * S
     mm_add, mm_dbl = 17, 16                              # RCB Alg. 1 / Alg. 3, generic a
     mm = 2 + 3                                           # to Montgomery (x, y) + on-curve check
     mm += 14 * mm_add                                    # table [2..15]P
@@ -429,7 +444,7 @@ def main():
     if rank == 0:
         total_items = B * world * args.steps
         value = total_items / elapsed
-        mm, mads, kname, kmads = work_model(cp, cv.words, slen)
+        mm, mads, kname, kmads = work_model(cp, cv.words, slen, B)
         step_ms = float(np.mean(kern_ms))             # HIP-event time of one whole step on the launch stream
         if ktimes:
             kt = np.mean(np.array(ktimes), axis=0)     # per-kernel averages over the timed steps
