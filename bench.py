@@ -93,8 +93,8 @@ def work_model(curve_params, nw, slen, batch=1 << 20):
         dbl = (3, 4) if curve_params["a"] == 0 else ((4, 4) if am3 else (4, 6))
         add = (12, 4)
         inv_s, inv_m = pbits, popcount(p - 2)
-        if p == 2**256 - 2**32 - 977:
-            # secp256k1's flavour keeps the one-kernel Jacobian-table path k_smul_g (ecamd_jacg.h: HAVE_MADD)
+        if p == 2**256 - 2**32 - 977 or p == 2**255 - 19:
+            # the two nine-limb flavours keep the one-kernel Jacobian-table path k_smul_g (ecamd_g29_kernel.hip, launcher)
             nm = 2 + 2 + 4 * dbl[0] + 3 * add[0] + 7 + nwin * (4 * dbl[0] + add[0]) + 1   # import, table (+7 Y normalisations), loop, Z test
             ns = 2 + 4 * dbl[1] + 3 * add[1] + nwin * (4 * dbl[1] + add[1])
             nm += 1 + inv_m / fin_k + 2 + 3 + 2
@@ -151,12 +151,12 @@ def measured_mad_peak():
 
 
 def pmc_traffic(kernel, batch_log2):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_r1d.json:
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_r2j.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected separately; gfx950 correction 2 x FETCH_SIZE).
     Only valid for the batch size it was collected at; null otherwise.  It is window-table scratch
-    traffic (64 look-ups x 80 B per item), not re-reads of the 160 algorithmic bytes per item."""
+    traffic (64 look-ups x 64 B per item, one 128-byte line each), not re-reads of the 160 algorithmic bytes per item."""
     try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "pmc_r1d.json")))
+        j = json.load(open(os.path.join(ROOT, "profiles", "pmc_r2j.json")))
         k = j["kernels"][kernel]
         if batch_log2 != 20:
             return None

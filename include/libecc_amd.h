@@ -358,6 +358,11 @@ int ecamd_multi_xdh_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n,
 			  uint8_t *out, uint8_t *status);
 int ecamd_multi_eddsa_verify_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *pubkeys,
 				   const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, uint8_t *result);
+/* ec_verify_batch's whole-batch bit, sharded (see ec_eddsa_verify_all_batch: Ed25519 shards of at least 2^18 items run the
+ * multi-scalar multiplication on their device); first_rejected (may be NULL): lowest rejected index of the whole batch, n if none */
+int ecamd_multi_eddsa_verify_all_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *pubkeys,
+				       const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, int *all_valid,
+				       uint32_t *first_rejected);
 /* The one collective, for callers that keep device-resident outputs on every GPU: an RCCL all-gather (over xGMI) of
  * equal-size shards.  d_send[r]: bytes_per_rank bytes on rank r's device; d_recv[r]: nranks * bytes_per_rank bytes
  * there.  librccl is loaded on first use; needs distinct devices.  Synchronous. */

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "ecamd_multi_curve_handle", "ecamd_multi_curve_coord_len", "ecamd_multi_curve_order_len",
     "ecamd_multi_prj_pt_mul_batch", "ecamd_multi_prj_pt_mul_batch_fmt", "ecamd_multi_prj_pt_unique_batch",
     "ecamd_multi_ecdsa_verify_batch", "ecamd_multi_ecdsa_verify_batch_fmt", "ecamd_multi_ecdsa_sign_batch", "ecamd_multi_ecccdh_derive_batch",
-    "ecamd_multi_xdh_batch", "ecamd_multi_eddsa_verify_batch", "ecamd_multi_allgather",
+    "ecamd_multi_xdh_batch", "ecamd_multi_eddsa_verify_batch", "ecamd_multi_eddsa_verify_all_batch", "ecamd_multi_allgather",
 ]
 
 
@@ -120,6 +120,7 @@ def load_library():
         L.ecamd_multi_ecccdh_derive_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
         L.ecamd_multi_xdh_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p]
         L.ecamd_multi_eddsa_verify_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u8p]
+        L.ecamd_multi_eddsa_verify_all_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
         L.ecamd_multi_allgather.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.c_size_t]
         _LIB = L
     return _LIB
@@ -502,3 +503,12 @@ class MultiCurve:
         _chk(self.L, self.L.ecamd_multi_eddsa_verify_batch(self.m.h, self.h, n, pubkeys, sigs, hram, hram_len, res),
              "ecamd_multi_eddsa_verify_batch")
         return res.raw[:n]
+
+    def eddsa_verify_all(self, pubkeys, sigs, hram, hram_len=None):
+        klen = 57 if self.clen == 56 else self.clen
+        hram_len = hram_len or (114 if self.clen == 56 else 64)
+        n = len(pubkeys) // klen
+        ok, first = C.c_int(0), C.c_uint32(0)
+        _chk(self.L, self.L.ecamd_multi_eddsa_verify_all_batch(self.m.h, self.h, n, pubkeys, sigs, hram, hram_len,
+                                                                C.byref(ok), C.byref(first)), "ecamd_multi_eddsa_verify_all_batch")
+        return bool(ok.value), first.value

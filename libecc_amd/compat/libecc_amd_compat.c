@@ -799,6 +799,10 @@ static void eddsa_pack(u32 lo, u32 hi, void *arg)
 	}
 }
 
+/* set by eddsa_verify_batch_gpu: the caller only wants ec_verify_batch's one bit, so a group may be decided by the
+ * device's multi-scalar multiplication (the reference's own random linear combination, ec_eddsa_verify_all_batch) */
+static __thread int t_all_only = 0;
+
 static int eddsa_group(ed_job *E, u32 cnt, int *results)
 {
 	ver_job *J = &E->v;
@@ -825,6 +829,27 @@ static int eddsa_group(ed_job *E, u32 cnt, int *results)
 		goto done;
 	}
 	parallel_for(cnt, eddsa_pack, E);
+	if (t_all_only) {
+		int all = 0, pre_bad = 0;
+		for (j = 0; j < cnt; j++) {
+			pre_bad |= J->pre[j];
+		}
+		if (!pre_bad) {
+			if (ecamd_multi_eddsa_verify_all_batch(g_multi, e->mc, cnt, J->pk, J->sg, J->dg, J->hlen, &all, NULL)) {
+				fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+				goto done;
+			}
+			if (all) {
+				note_items(cnt);
+				for (j = 0; j < cnt; j++) {
+					results[J->idx[j]] = 0;
+				}
+				ret = 0;
+				goto done;
+			}
+		}
+		/* rejected (or an item failed before the device): the item-by-item results below say which */
+	}
 	if (ecamd_multi_eddsa_verify_batch(g_multi, e->mc, cnt, J->pk, J->sg, J->dg, J->hlen, res)) {
 		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
 		goto done;
@@ -1017,7 +1042,13 @@ int eddsa_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **pub
 			return -1;   /* "all our public keys have the same parameters" */
 		}
 	}
-	return all_accepted(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len);
+	{
+		int r;
+		t_all_only = 1;
+		r = all_accepted(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len);
+		t_all_only = 0;
+		return r;
+	}
 }
 
 /* ------------------------------------------------------------------------------------------------

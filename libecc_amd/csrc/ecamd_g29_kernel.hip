@@ -384,7 +384,8 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_smul
 }
 
 // ------------------------------------------------------------------------------------------
-// Affine-table pipeline (every flavour except secp256k1's, see HAVE_MADD in ecamd_jacg.h): the pipeline of ecamd_p256_kernel.hip
+// Affine-table pipeline (every flavour except the two nine-limb ones, see the launcher and HAVE_MADD in ecamd_jacg.h): the
+// pipeline of ecamd_p256_kernel.hip
 //   k_table_g    import + on-curve check, Jacobian multiples 2P..8P into the item's staging slots, recoded scalar
 //   k_affine_g   2P..8P -> affine with ONE inversion per AFFG_K items x 7 entries (Montgomery's trick; the prefix products
 //                rest in the affine slots they are about to be replaced by)
@@ -2022,7 +2023,7 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_TAG)(int gslot, const EcamdSmulArgs &a
 	const dim3 fgrid((nthreads + 63) / 64);
 	// event slots as in ecamd_launch_smul_p256: [0] start, [3] after the loop kernel, [4] after finalisation
 	const bool pipeline_events =
-#if defined(G29_K256) || defined(G29_JACTAB)
+#if defined(G29_K256) || defined(G29_P25519) || defined(G29_JACTAB)
 		false;
 #else
 		!(a.lut && a.lut_kind == 1);
@@ -2037,8 +2038,10 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_TAG)(int gslot, const EcamdSmulArgs &a
 	if (a.lut && a.lut_kind == 1) {
 		hipLaunchKernelGGL((k_comb_g<G29_PB, G29_FLAV>), grid, block, 0, s, a, gslot);
 	} else {
-#if defined(G29_K256) || defined(G29_JACTAB)
-		// secp256k1's flavour (and the A/B build): Jacobian table, one kernel
+#if defined(G29_K256) || defined(G29_P25519) || defined(G29_JACTAB)
+		// secp256k1's flavour (no room for the mixed addition), the 2^255 - 19 flavour (measured: the two extra passes cost what
+		// the cheaper loop saves, 62.7 against 63.1 M/s at 2^20 and -6 % at 2^16; its comb kernel does use the mixed addition)
+		// and the A/B build: Jacobian table, one kernel
 		hipLaunchKernelGGL((k_smul_g<G29_PB, G29_FLAV>), grid, block, 0, s, a, gslot);
 #else
 		// affine-table pipeline; a.stg: n x LayA::AITEMW words

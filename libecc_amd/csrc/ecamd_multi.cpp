@@ -308,6 +308,47 @@ extern "C" int ecamd_multi_eddsa_verify_batch(ecamd_multi *m, const ecamd_mcurve
 	});
 }
 
+// ec_verify_batch's one bit for EdDSA, sharded: every device decides its shard (Ed25519 shards of at least 2^18 items with the
+// multi-scalar multiplication, ec_eddsa_verify_all_batch); the batch is valid when every shard is
+extern "C" int ecamd_multi_eddsa_verify_all_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys,
+						  const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, int *all_valid,
+						  uint32_t *first_rejected)
+{
+	if (!all_valid || n == 0) {
+		return mfail("ecamd_multi_eddsa_verify_all_batch: bad argument (the reference rejects num = 0 too)");
+	}
+	*all_valid = 0;
+	if (first_rejected) {
+		*first_rejected = n;
+	}
+	const size_t cl = (size_t)ecamd_multi_curve_coord_len(c), kl = (cl == 56) ? 57 : cl;
+	const int N = m ? (int)m->ctx.size() : 0;
+	std::vector<int> ok((size_t)(N > 0 ? N : 1), 1);
+	std::vector<uint32_t> first((size_t)(N > 0 ? N : 1), 0xffffffffu);
+	if (run_sharded(m, c, n, "ecamd_multi_eddsa_verify_all_batch", [&](int r, uint32_t lo, uint32_t hi) {
+		    uint32_t f = hi - lo;
+		    const int rc = ec_eddsa_verify_all_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(pubkeys, kl), OFF(sigs, 2 * kl),
+							     OFF(hram, hram_len), hram_len, &ok[(size_t)r], &f);
+		    first[(size_t)r] = (rc == 0 && !ok[(size_t)r]) ? lo + f : 0xffffffffu;
+		    return rc;
+	    })) {
+		return -1;
+	}
+	int all = 1;
+	uint32_t fr = n;
+	for (int r = 0; r < N; r++) {
+		all = all && ok[(size_t)r];
+		if (first[(size_t)r] < fr) {
+			fr = first[(size_t)r];
+		}
+	}
+	*all_valid = all;
+	if (first_rejected) {
+		*first_rejected = all ? n : fr;
+	}
+	return 0;
+}
+
 extern "C" int ecamd_multi_prj_pt_unique_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *points, int in_fmt,
 					       uint8_t *out, int out_fmt, uint8_t *status)
 {

@@ -183,6 +183,13 @@ def test_multi_device_layer_shards_like_one_device(gpu_ctx, devices):
             hram = b"".join(hashlib.sha512(sigs[64 * i:64 * i + 32] + pubs[32 * i:32 * i + 32] + msgs[i]).digest() for i in range(96))
             exp = cv.eddsa_verify(pubs, sigs, hram)
             assert mc.eddsa_verify(pubs, sigs, hram) == exp and exp[0] == 1 and exp[1] == 0
+            # the whole-batch bit, sharded: first rejected index of the whole batch; a valid subset is accepted
+            assert mc.eddsa_verify_all(pubs, sigs, hram) == (False, 0)
+            good = [i for i in range(96) if exp[i] == 0]
+            sub = lambda b, w, idx: b"".join(b[w * i:w * (i + 1)] for i in idx)
+            assert mc.eddsa_verify_all(sub(pubs, 32, good), sub(sigs, 64, good), sub(hram, 64, good)) == (True, len(good))
+            late = good[:60] + [5] + good[60:]
+            assert mc.eddsa_verify_all(sub(pubs, 32, late), sub(sigs, 64, late), sub(hram, 64, late)) == (False, 60)
         finally:
             mc.free()
             cv.free()
