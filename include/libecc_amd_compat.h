@@ -69,9 +69,11 @@ int ecdsa_verify_batch(const u8 **s, const u8 *s_len, const ec_pub_key **pub_key
 /*
  * EdDSA (EDDSA25519, EDDSA25519CTX, EDDSA25519PH, EDDSA448, EDDSA448PH) batch verification, same prototype; replaces
  * eddsa_verify_batch (sig/eddsa.c:2904).  Same argument checks as the reference (one ec_params for all keys, key type =
- * sig_type, hash_type = the variant's hash, signature lengths, scratch-pad length when a scratch pad is given); the
- * answer is the exact conjunction of the per-signature cofactored verifications, where the reference's random linear
- * combination may accept a bad batch with probability ~2^-128.
+ * sig_type, hash_type = the variant's hash, signature lengths, scratch-pad length when a scratch pad is given).
+ * Ed25519 groups of at least 2^18 signatures per device are decided by the reference's own random linear combination,
+ * evaluated as one multi-scalar multiplication on the GPU (ec_eddsa_verify_all_batch in libecc_amd.h; like the reference
+ * it may accept a bad batch with probability ~2^-128); smaller groups and Ed448 by the exact conjunction of the
+ * per-signature cofactored verifications.
  */
 int eddsa_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
 			   ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len,

@@ -2747,7 +2747,7 @@ static uint32_t eddsa_msm_pick_k(const ecamd_ctx *ctx, uint32_t n)
 		return ctx->msm_k;
 	}
 	// one wave per SIMD needs 65536 lanes; two or more hide the table look-ups better
-	uint32_t k = n >> 17;
+	uint32_t k = n >> 16;   // measured: 2^18 -> 4, 2^20 -> 8 (profiles/r2g_eddsa_msm.json)
 	if (k < 1) {
 		k = 1;
 	}

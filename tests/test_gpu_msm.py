@@ -176,3 +176,45 @@ def test_msm_large_batch(gpu_ctx):
     finally:
         gpu_ctx.set_eddsa_msm(1, 0, 0)
         cv.free()
+
+
+def test_device_pointer_form(gpu_ctx):
+    """ec_eddsa_verify_all_batch_dev: device pointers, a caller's stream, only enqueues; verdict byte 0 / 1; pieces of
+    max_chunk items share the byte"""
+    import torch
+    import libecc_amd
+    rng = np.random.default_rng(6)
+    n = 700
+    pubs, sigs, hram = make_items(rng, n)
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.Stream(device=dev)
+
+    def t(b):
+        return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    ctx2 = libecc_amd.Context(0)
+    try:
+        ctx2.set_max_chunk(256)
+        cv = ctx2.curve("WEI25519")
+        dp, ds, dh = t(pubs), t(sigs), t(hram)
+        verdict = torch.full((1,), 7, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        cv.eddsa_verify_all_dev(n, dp.data_ptr(), ds.data_ptr(), dh.data_ptr(), verdict.data_ptr(), stream.cuda_stream)
+        stream.synchronize()
+        assert int(verdict.item()) == 0
+        for bad in (0, 255, 256, n - 1):
+            h2 = bytearray(hram)
+            h2[64 * bad + 1] ^= 8
+            dh2 = t(bytes(h2))
+            torch.cuda.synchronize()
+            cv.eddsa_verify_all_dev(n, dp.data_ptr(), ds.data_ptr(), dh2.data_ptr(), verdict.data_ptr(), stream.cuda_stream)
+            stream.synchronize()
+            assert int(verdict.item()) == 1, bad
+        with pytest.raises(libecc_amd.EcamdError):
+            c448 = ctx2.curve("WEI448")
+            try:
+                c448.eddsa_verify_all_dev(n, dp.data_ptr(), ds.data_ptr(), dh.data_ptr(), verdict.data_ptr(), None)
+            finally:
+                c448.free()
+        cv.free()
+    finally:
+        ctx2.close()
