@@ -60,7 +60,7 @@ const char *ecamd_last_error(void);
  * scratch: 16 * 3 * 4*ceil(|p|/32) bytes per item).  Default 2^20. */
 int ecamd_ctx_set_max_chunk(ecamd_ctx *ctx, uint32_t max_items);
 /* Ed25519 whole-batch verification (ec_eddsa_verify_all_batch) through the multi-scalar multiplication: mode 0 never, 1 for
- * batches of at least min_items (default; min_items = 0 keeps the current threshold, initially 2^18 or $ECAMD_MSM_MIN),
+ * batches of at least min_items (default; min_items = 0 keeps the current threshold, initially 2^17 or $ECAMD_MSM_MIN),
  * 2 always.  items_per_lane: signatures that share one lane's doublings, 0 = chosen from the batch size (1 .. 8). */
 int ecamd_ctx_set_eddsa_msm(ecamd_ctx *ctx, int mode, uint32_t min_items, uint32_t items_per_lane);
 /* Secret scalars.  By default the kernels index their window / comb tables with the scalar's digits (fastest; fine for public
@@ -204,7 +204,7 @@ int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, 
  * _eddsa_verify_batch_no_memory :2278) for the EdDSA variants: *all_valid = 1 iff libecc's batch verification accepts.
  * libecc rejects num = 0, as this does (-1).  first_rejected (may be NULL) receives the lowest rejected index, n if none --
  * the reference gives no such hint and callers re-verify one by one.  Same inputs as ec_eddsa_verify_batch.
- *   Ed25519 batches of at least 2^18 items (ecamd_ctx_set_eddsa_msm): the reference's own equation
+ *   Ed25519 batches of at least 2^17 items (ecamd_ctx_set_eddsa_msm): the reference's own equation
  *     [8]([-sum z_i S_i]B + sum [z_i h_i]A_i + sum [z_i]R_i) = 0, z_i 128 random bits (ChaCha20 on the device, keyed by 32
  *     bytes of getrandom per call), after the reference's per-item rejections (decoding, S >= q, [8]A_i = 0) -- evaluated as
  *     ONE multi-scalar multiplication on the Edwards curve (Straus, the 256 doublings shared by up to 8 signatures per lane).
@@ -358,7 +358,7 @@ int ecamd_multi_xdh_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n,
 			  uint8_t *out, uint8_t *status);
 int ecamd_multi_eddsa_verify_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *pubkeys,
 				   const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, uint8_t *result);
-/* ec_verify_batch's whole-batch bit, sharded (see ec_eddsa_verify_all_batch: Ed25519 shards of at least 2^18 items run the
+/* ec_verify_batch's whole-batch bit, sharded (see ec_eddsa_verify_all_batch: Ed25519 shards of at least 2^17 items run the
  * multi-scalar multiplication on their device); first_rejected (may be NULL): lowest rejected index of the whole batch, n if none */
 int ecamd_multi_eddsa_verify_all_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *pubkeys,
 				       const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, int *all_valid,

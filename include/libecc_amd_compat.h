@@ -70,7 +70,7 @@ int ecdsa_verify_batch(const u8 **s, const u8 *s_len, const ec_pub_key **pub_key
  * EdDSA (EDDSA25519, EDDSA25519CTX, EDDSA25519PH, EDDSA448, EDDSA448PH) batch verification, same prototype; replaces
  * eddsa_verify_batch (sig/eddsa.c:2904).  Same argument checks as the reference (one ec_params for all keys, key type =
  * sig_type, hash_type = the variant's hash, signature lengths, scratch-pad length when a scratch pad is given).
- * Ed25519 groups of at least 2^18 signatures per device are decided by the reference's own random linear combination,
+ * Ed25519 groups of at least 2^17 signatures per device are decided by the reference's own random linear combination,
  * evaluated as one multi-scalar multiplication on the GPU (ec_eddsa_verify_all_batch in libecc_amd.h; like the reference
  * it may accept a bad batch with probability ~2^-128); smaller groups and Ed448 by the exact conjunction of the
  * per-signature cofactored verifications.

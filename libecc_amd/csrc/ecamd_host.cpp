@@ -347,7 +347,7 @@ extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
 	c->timing = false;
 	c->secret_scalars = false;
 	c->eddsa_msm = 1;
-	c->msm_min = 1u << 18;
+	c->msm_min = 1u << 17;   // measured break-even: 1.16x at 2^17, 0.92x at 2^16 (profiles/r2l_eddsa_msm.json)
 	c->msm_k = 0;
 	{
 		const char *e = getenv("ECAMD_MSM_MIN");
@@ -2747,7 +2747,7 @@ static uint32_t eddsa_msm_pick_k(const ecamd_ctx *ctx, uint32_t n)
 		return ctx->msm_k;
 	}
 	// one wave per SIMD needs 65536 lanes; two or more hide the table look-ups better
-	uint32_t k = n >> 16;   // measured: 2^18 -> 4, 2^20 -> 8 (profiles/r2g_eddsa_msm.json)
+	uint32_t k = n >> 16;   // measured: 2^17 -> 2, 2^18 -> 4, 2^19 and up -> 8 (profiles/r2l_eddsa_msm.json)
 	if (k < 1) {
 		k = 1;
 	}

@@ -308,7 +308,7 @@ extern "C" int ecamd_multi_eddsa_verify_batch(ecamd_multi *m, const ecamd_mcurve
 	});
 }
 
-// ec_verify_batch's one bit for EdDSA, sharded: every device decides its shard (Ed25519 shards of at least 2^18 items with the
+// ec_verify_batch's one bit for EdDSA, sharded: every device decides its shard (Ed25519 shards of at least 2^17 items with the
 // multi-scalar multiplication, ec_eddsa_verify_all_batch); the batch is valid when every shard is
 extern "C" int ecamd_multi_eddsa_verify_all_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys,
 						  const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, int *all_valid,
