@@ -2051,6 +2051,205 @@ hipError_t ecamd_launch_xdh_prep_c25519(const EcamdXdhPrepArgs &a, int gslot, hi
 }
 #endif  // G29_P25519
 
+#ifdef G29_P448
+// ------------------------------------------------------------------------------------------
+// Ed448 point decoding on the Goldilocks field of this unit (p = 2^448 - 2^224 - 1, plain residues): the computation of
+// k_ed448_decode<14> in ecamd_kernels.hip (which stays the reference implementation and serves when this unit has no
+// slot), operation for operation -- EDDSA448 branch of eddsa_decode_point (sig/eddsa.c:430-560), the 4-isogeny to the
+// Edwards model of curve448, the map to the Weierstrass model WEI448.
+// ------------------------------------------------------------------------------------------
+namespace c448 {
+constexpr int PB = 448;
+typedef Cls<PB>::FA FA;
+typedef Cls<PB>::FM FM;
+typedef Cls<PB>::FC FC;
+typedef CurveG<16> CK;
+#define M_(a, b) weaken<FM>(mulc(a, b, K))
+#define S_(a) weaken<FM>(sqrc(a, K))
+#define SUB_(a, b) carry(sub_auto<1>(a, b, K))   /* b: a multiplication result or a constant */
+#define ADD_(a, b) carry(add(a, b))
+
+static __device__ __forceinline__ FM sqr_n(FM a, int n, const CK &K)
+{
+	for (int k = 0; k < n; k++) {
+		a = S_(a);
+	}
+	return a;
+}
+static __device__ __forceinline__ FC digits16(const u32 *d)
+{
+	FC r;
+#pragma unroll
+	for (int w = 0; w < 16; w++) {
+		r.l[w] = d[w];
+	}
+	return r;
+}
+static __device__ __forceinline__ FC small_const(u32 v)
+{
+	FC r;
+#pragma unroll
+	for (int w = 0; w < 16; w++) {
+		r.l[w] = (w == 0) ? v : 0u;
+	}
+	return r;
+}
+// exact zero test of a lazily reduced value
+template <class A> static __device__ __forceinline__ bool is_zero(const A &a, const CK &K)
+{
+	return is_zero_mulout(mulc(a, constant<FC>(K.one), K), K);
+}
+// w^((p - 3) / 4), (p - 3) / 4 = 2^223 (2^223 - 1) + 2^222 - 1: 446 S + 14 M (the chain of fe_pow_p448_e34)
+static __device__ FM pow_e34(const FM &w, const CK &K)
+{
+	const int steps[12] = {1, 0, 3, 6, 0, 13, 0, 27, 0, 55, 0, 111};
+	FM f = w;
+#pragma unroll 1
+	for (int s = 0; s < 12; s++) {
+		const int k = steps[s];
+		const FM g = (k == 0) ? w : f;
+		f = M_(sqr_n(f, k == 0 ? 1 : k, K), g);
+	}
+	const FM f223 = M_(S_(f), w);
+	return M_(sqr_n(f223, 223, K), f);
+}
+static __device__ FM inv448(const FM &w, const CK &K)   // 0 -> 0, like Fermat's
+{
+	return M_(sqr_n(pow_e34(w, K), 2, K), w);
+}
+template <class A> static __device__ __forceinline__ void store_canon_be(u8 *dst, const A &a, bool ok, const CK &K)
+{
+	u32 d[16], w[14];
+	canonical_digits(d, mulc(a, constant<FC>(K.one), K), K);
+	to_words<16, 14>(w, d);
+#pragma unroll
+	for (int i = 0; i < 14; i++) {
+		w[i] = ok ? w[i] : 0u;
+	}
+	store_be<14>(dst, 56, w);
+}
+}  // namespace c448
+
+__global__ __launch_bounds__(64) void k_ed448_decode_g(EcamdEd448DecodeArgs A, int gslot)
+{
+	using namespace c448;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const CK &K = TabGP<448>::get(gslot);
+	const FC onec = constant<FC>(K.one);
+	const FC twoc = small_const(2u);
+	const FC zeroc = small_const(0u);
+	const FA onea = weaken<FA>(onec);
+	FA x[2], d1[2], d2[2];
+	FM ym[2], xx[2], yy[2];
+	bool ok[2], neutral[2] = {false, false};
+#pragma unroll 1
+	for (int k = 0; k < 2; k++) {
+		const u8 *src = (k == 0) ? A.encA + (size_t)i * A.strideA : A.encR + (size_t)i * A.strideR;
+		u32 yw[14];
+#pragma unroll
+		for (int w = 0; w < 14; w++) {
+			yw[w] = (u32)src[4 * w] | ((u32)src[4 * w + 1] << 8) | ((u32)src[4 * w + 2] << 16) | ((u32)src[4 * w + 3] << 24);
+		}
+		const u32 last = src[56];
+		const u32 x0 = last >> 7;
+		const auto yd = from_words<PB, 14>(yw);
+		bool below;
+		{
+			u32 b = 0;
+#pragma unroll
+			for (int j = 0; j < 16; j++) {
+				b = (yd.l[j] - K.p[j] - b) >> 31;
+			}
+			below = b != 0;
+		}
+		bool good = ((last & 0x7fu) == 0) & below;                      // the 57th byte only carries the sign
+		ym[k] = M_(yd, onec);
+		yy[k] = S_(ym[k]);
+		const auto u = SUB_(onec, yy[k]);                                // 1 - y^2
+		const auto v = SUB_(onec, M_(digits16(A.g_d448), yy[k]));        // a - d y^2, a = 1
+		good = good & !is_zero(v, K);                                    // fp_inv(0)
+		const FM v2 = S_(v), u2 = S_(u);
+		const FM u3v = M_(M_(u2, u), v);
+		const FM u5v3 = M_(M_(u3v, u2), v2);
+		const FM r = M_(u3v, pow_e34(u5v3, K));
+		good = good & is_zero(SUB_(u, M_(v, S_(r))), K);                 // u / v has no root: error
+		u32 rd[16];
+		canonical_digits(rd, r, K);
+		u32 nz = 0;
+#pragma unroll
+		for (int w = 0; w < 16; w++) {
+			nz |= rd[w];
+		}
+		x[k] = selg((rd[0] & 1u) != x0, weaken<FA>(SUB_(zeroc, r)), weaken<FA>(r));
+		good = good & !((nz == 0) & (x0 == 1u));
+		xx[k] = S_(r);
+		const auto e1 = SUB_(SUB_(twoc, xx[k]), yy[k]);                  // 2 - x^2 - y^2
+		const auto e2 = SUB_(yy[k], xx[k]);                              // y^2 - x^2
+		good = good & !is_zero(e1, K) & !is_zero(e2, K);                 // fp_inv(0)
+		ok[k] = good;
+		d1[k] = selg(good, weaken<FA>(e1), onea);
+		d2[k] = selg(good, weaken<FA>(e2), onea);
+	}
+	// isogeny: 1 / (d1 d2) for both points from one inversion
+	FA X[2], omy[2];
+	FM Y[2];
+	{
+		const FM pa = M_(d1[0], d2[0]), pr = M_(d1[1], d2[1]);
+		const FM inv = inv448(M_(pa, pr), K);
+		const FM ia = M_(inv, pr), ir = M_(inv, pa);                     // 1 / (d1 d2) of A, of R
+#pragma unroll 1
+		for (int k = 0; k < 2; k++) {
+			const FM di = (k == 0) ? ia : ir;
+			const FM Xk = M_(M_(digits16(A.g_alpha), M_(x[k], ym[k])), M_(di, d2[k]));
+			const FM Yk = M_(ADD_(xx[k], yy[k]), M_(di, d1[k]));
+			const FM X2 = S_(Xk), Y2 = S_(Yk);
+			const FM rhs = M_(ADD_(onec, M_(digits16(A.g_diso), M_(X2, Y2))), onec);
+			const bool on = is_zero(SUB_(ADD_(X2, Y2), rhs), K);         // on the Edwards model of curve448
+			const auto om = SUB_(onec, Yk);
+			const bool xz = is_zero_mulout(Xk, K), oz = is_zero(om, K);
+			// (0, 1) -- the image of both (0, 1) and (0, -1) of Ed448 -- is the neutral element: the point at infinity of the
+			// Weierstrass model (fine for R; a key is then rejected as small-order).  X = 0 with Y = -1 dies in fp_inv(0).
+			neutral[k] = ok[k] & on & xz & oz;
+			ok[k] = ok[k] & on & !xz & !oz;
+			X[k] = selg(ok[k], weaken<FA>(Xk), onea);
+			omy[k] = selg(ok[k], weaken<FA>(om), onea);
+			Y[k] = Yk;
+		}
+	}
+	{
+		const FM pa = M_(omy[0], X[0]), pr = M_(omy[1], X[1]);
+		const FM inv = inv448(M_(pa, pr), K);
+		const FM ia = M_(inv, pr), ir = M_(inv, pa);                     // 1 / ((1 - Y) X) of A, of R
+#pragma unroll 1
+		for (int k = 0; k < 2; k++) {
+			const FM mi = (k == 0) ? ia : ir;
+			const FM u = M_(ADD_(onec, Y[k]), M_(mi, X[k]));
+			const FM v = M_(M_(digits16(A.g_alpha), u), M_(mi, omy[k]));
+			u8 *pd = (k == 0 ? A.pointsA : A.pointsR) + (size_t)i * 112;
+			store_canon_be(pd, SUB_(digits16(A.g_A3), u), ok[k], K);     // (A, B) = (-156326, -1): X = A/3 - u
+			store_canon_be(pd + 56, SUB_(zeroc, v), ok[k], K);           // Y = -v
+			(k == 0 ? A.flagsA : A.flagsR)[i] = ok[k] ? 0 : ((k == 1 && neutral[1]) ? 2 : 1);   // 2: R is the point at infinity
+		}
+	}
+}
+#undef M_
+#undef S_
+#undef SUB_
+#undef ADD_
+
+hipError_t ecamd_launch_ed448_decode_g(const EcamdEd448DecodeArgs &a, int gslot, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_ed448_decode_g, dim3((a.n + 63) / 64), dim3(64), 0, s, a, gslot);
+	return hipGetLastError();
+}
+#endif  // G29_P448
+
 hipError_t G29_CAT(ecamd_g29_upload_, G29_TAG)(int slot, const void *img, size_t bytes)
 {
 	typedef CurveG<Lay<G29_PB>::NL> CK;

@@ -2570,6 +2570,10 @@ static void ed448_setup(ecamd_curve *cv)
 	big_store(D.diso, nw, big_mulmod(diso, R, p));
 	big_store(D.alpha, nw, big_mulmod(alpha, R, p));
 	big_store(D.A3, nw, big_mulmod(A3, R, p));
+	big_digits29(D.g_d448, 16, d448);
+	big_digits29(D.g_diso, 16, diso);
+	big_digits29(D.g_alpha, 16, alpha);
+	big_digits29(D.g_A3, 16, A3);
 	cv->ed448_state = 1;
 }
 
@@ -2608,7 +2612,11 @@ static int eddsa448_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t 
 	D.pointsR = S[4];
 	D.flagsA = S[5];
 	D.flagsR = S[6];
-	HIPCHK(ecamd_launch_ed448_decode(D, s));
+	if (cv->gflavour == 5 && cv->gslot >= 0 && getenv("ECAMD_NO_G448_DECODE") == nullptr) {
+		HIPCHK(ecamd_launch_ed448_decode_g(D, cv->gslot, s));   // the same decoding on the Goldilocks radix-2^29 field
+	} else {
+		HIPCHK(ecamd_launch_ed448_decode(D, s));
+	}
 	EcamdEdScalArgs C;
 	memset(&C, 0, sizeof(C));
 	C.sigs = d_sig;

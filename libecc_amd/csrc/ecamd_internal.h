@@ -218,8 +218,11 @@ struct EcamdEd448DecodeArgs {
 	uint8_t *flagsA, *flagsR;
 	uint32_t n;
 	uint32_t d448[17], diso[17], alpha[17], A3[17];   // Montgomery form (radix 2^448)
+	uint32_t g_d448[16], g_diso[16], g_alpha[16], g_A3[16];   // the same as plain radix-2^29 digits (Goldilocks unit)
 	int slot;
 };
+// the same kernel on the radix-2^29 field of the Goldilocks unit (gslot: its constant slot)
+hipError_t ecamd_launch_ed448_decode_g(const EcamdEd448DecodeArgs &a, int gslot, hipStream_t s);
 // Ed25519 signing, the device-side steps around the caller's two hashes (sig/eddsa.c:1554-1870)
 struct EcamdEdSignArgs {
 	const uint8_t *r_hash;   // n x 64 little-endian: H(dom2 || prefix || PH(M))
