@@ -92,7 +92,10 @@ def work_model(curve_params, nw, slen, batch=1 << 20):
         am3 = curve_params["a"] == p - 3 or iso_to_am3(p, curve_params["a"])
         dbl = (3, 4) if curve_params["a"] == 0 else ((4, 4) if am3 else (4, 6))
         add = (12, 4)
-        inv_s, inv_m = pbits, popcount(p - 2)
+        # jacg::inv: 2-bit windows over p - 2 with the table x, x^2, x^3
+        e, top = p - 2, (pbits - 1) | 1
+        inv_s = top + 1 + 1
+        inv_m = 1 + sum(1 for i in range(top, 0, -2) if (e >> (i - 1)) & 3)
         if p == 2**256 - 2**32 - 977 or p == 2**255 - 19:
             # the two nine-limb flavours keep the one-kernel Jacobian-table path k_smul_g (ecamd_g29_kernel.hip, launcher)
             nm = 2 + 2 + 4 * dbl[0] + 3 * add[0] + 7 + nwin * (4 * dbl[0] + add[0]) + 1   # import, table (+7 Y normalisations), loop, Z test
