@@ -2235,10 +2235,94 @@ __global__ __launch_bounds__(64) void k_ed448_decode_g(EcamdEd448DecodeArgs A, i
 		}
 	}
 }
+// X448 front end (k_xdh_prep<14> of ecamd_kernels.hip on this field): clamped scalar, u < p, v = w^((p + 1) / 4) with
+// w = u (u (u + A) + 1) -- (p + 1) / 4 = 2^222 (2^224 - 1): the chain of pow_e34 two steps further, then 222 squarings --
+// v^2 = w or the point is on the twist, the map to WEI448, [4]Q != infinity by two doublings.
+__global__ __launch_bounds__(64) void k_xdh_prep_c448(EcamdXdhPrepArgs A, int gslot)
+{
+	using namespace c448;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const CK &K = TabGP<448>::get(gslot);
+	const FC onec = constant<FC>(K.one);
+	{
+		// scalar: reversed to big-endian and clamped (decode_scalar)
+		const u8 *ks = A.k + (size_t)i * 56;
+		u8 *kd = A.scalars + (size_t)i * 56;
+		for (int b = 0; b < 56; b++) {
+			u8 v = ks[b];
+			if (b == 0) v &= 252;
+			if (b == 55) v |= 128;
+			kd[55 - b] = v;
+		}
+	}
+	const u8 *src = A.u + (size_t)i * 56;
+	u32 uw[14];
+#pragma unroll
+	for (int w = 0; w < 14; w++) {
+		uw[w] = (u32)src[4 * w] | ((u32)src[4 * w + 1] << 8) | ((u32)src[4 * w + 2] << 16) | ((u32)src[4 * w + 3] << 24);
+	}
+	const auto ud = from_words<PB, 14>(uw);
+	bool ok;
+	{
+		u32 b = 0;
+#pragma unroll
+		for (int j = 0; j < 16; j++) {
+			b = (ud.l[j] - K.p[j] - b) >> 31;
+		}
+		ok = b != 0;   // u >= p is rejected
+	}
+	const FM um = M_(ud, onec);
+	const FM w = M_(um, ADD_(M_(um, ADD_(um, digits16(A.g_A))), onec));   // u (u (u + A) + 1)
+	FM c;
+	{
+		const int steps[12] = {1, 0, 3, 6, 0, 13, 0, 27, 0, 55, 0, 111};
+		FM f = w;
+#pragma unroll 1
+		for (int s = 0; s < 12; s++) {
+			const int k = steps[s];
+			const FM g = (k == 0) ? w : f;
+			f = M_(sqr_n(f, k == 0 ? 1 : k, K), g);                 // ... f(222)
+		}
+		f = M_(S_(f), w);                                              // f(223)
+		f = M_(S_(f), w);                                              // f(224) = w^(2^224 - 1)
+		c = sqr_n(f, 222, K);
+	}
+	ok = ok & is_zero(SUB_(S_(c), w), K);                                  // no root: u is on the twist
+	const auto xm = ADD_(um, digits16(A.g_A3));
+	{
+		// [h]Q must not be infinity (x25519_448.c:259-260): cof_dbl doublings; a doubling reaches infinity exactly when Y = 0,
+		// which shows as Z = 0 one step later (or at once for y = 0)
+		// (through the unit's import factors: the constants may be those of the isomorphic a = -3 curve)
+		Jac<PB> P;
+		P.X = weaken<FA>(M_(xm, constant<FC>(K.ix)));
+		P.Y = weaken<FA>(M_(c, constant<FC>(K.iy)));
+		P.Z = weaken<FA>(onec);
+		for (u32 r = 0; r < A.cof_dbl; r++) {
+			P = dbl(P, K);
+		}
+		ok = ok & !is_zero(P.Z, K);
+	}
+	u8 *pd = A.points + (size_t)i * 112;
+	store_canon_be(pd, xm, ok, K);
+	store_canon_be(pd + 56, c, ok, K);
+	A.flags[i] = ok ? 0 : 1;
+}
 #undef M_
 #undef S_
 #undef SUB_
 #undef ADD_
+
+hipError_t ecamd_launch_xdh_prep_c448(const EcamdXdhPrepArgs &a, int gslot, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_xdh_prep_c448, dim3((a.n + 63) / 64), dim3(64), 0, s, a, gslot);
+	return hipGetLastError();
+}
 
 hipError_t ecamd_launch_ed448_decode_g(const EcamdEd448DecodeArgs &a, int gslot, hipStream_t s)
 {

@@ -2105,6 +2105,9 @@ static void xdh_setup(ecamd_curve *cv)
 		big_digits29(P.g_A, 9, A);
 		big_digits29(P.g_A3, 9, A3);
 		big_digits29(P.g_sm1, 9, big_sqrt_m1(p));
+	} else if (cv->pbits == 448) {
+		big_digits29(P.g_A, 16, A);
+		big_digits29(P.g_A3, 16, A3);
 	}
 	P.slot = cv->slot;
 	big_store(cv->xdh_A3, 17, A3);
@@ -2177,6 +2180,8 @@ static int xdh_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uin
 			HIPCHK(ecamd_launch_x25519_ladder(L, cv->gslot, s));
 			return 0;
 		}
+	} else if (cv->gflavour == 5 && cv->gslot >= 0 && P.mode == 1 && getenv("ECAMD_NO_G448_DECODE") == nullptr) {
+		HIPCHK(ecamd_launch_xdh_prep_c448(P, cv->gslot, s));   // X448: the same front end on the Goldilocks radix-2^29 field
 	} else {
 		HIPCHK(ecamd_launch_xdh_prep(nw, P, s));
 	}

@@ -99,7 +99,7 @@ struct EcamdXdhPrepArgs {
 	uint32_t cof_dbl;        // log2(cofactor)
 	uint32_t e[17];          // the exponent, little-endian words
 	uint32_t A[17], A3[17], sm1[17];  // A, A/3, sqrt(-1) in Montgomery form (radix 2^(32 NW))
-	uint32_t g_A[9], g_A3[9], g_sm1[9];  // the same as plain radix-2^29 digits (2^255 - 19 unit, X25519 only)
+	uint32_t g_A[16], g_A3[16], g_sm1[16];  // the same as plain radix-2^29 digits (9 for the 2^255 - 19 unit, 16 for the Goldilocks unit)
 	int slot;
 };
 struct EcamdXdhFinArgs {
@@ -248,6 +248,7 @@ hipError_t ecamd_launch_ed_decode(int nw, const EcamdEdDecodeArgs &a, hipStream_
 // the same two front-end kernels on the radix-2^29 field of the 2^255 - 19 unit (gslot: its constant slot)
 hipError_t ecamd_launch_ed_decode_c25519(const EcamdEdDecodeArgs &a, int gslot, hipStream_t s);
 hipError_t ecamd_launch_xdh_prep_c25519(const EcamdXdhPrepArgs &a, int gslot, hipStream_t s);
+hipError_t ecamd_launch_xdh_prep_c448(const EcamdXdhPrepArgs &a, int gslot, hipStream_t s);   // X448 on the Goldilocks unit
 // X25519 x-only Montgomery ladder + shared inversion (after k_xdh_prep_c25519 validated and clamped)
 struct EcamdXdhLadderArgs {
 	const uint8_t *u;        // n x 32 little-endian u coordinates (as given by the caller)
