@@ -2310,6 +2310,192 @@ __global__ __launch_bounds__(64) void k_xdh_prep_c448(EcamdXdhPrepArgs A, int gs
 	store_canon_be(pd + 56, c, ok, K);
 	A.flags[i] = ok ? 0 : 1;
 }
+// ------------------------------------------------------------------------------------------
+// X448: the x-only Montgomery ladder on v^2 = u^3 + 156326 u^2 + u itself (RFC 7748 section 5), for inputs k_xdh_prep_c448
+// accepted -- the 448-bit twin of k_x25519_ladder / k_x25519_fin above the #ifdef (same argument for why it is observably
+// the reference's result: [k]Q's u coordinate is all x448() exposes, ecdh/x25519_448.c:268-276).  448 steps of 5M + 4S +
+// one multiplication by a24 = 39081; the divisions are shared by 8 items per lane.
+// ------------------------------------------------------------------------------------------
+#define X448_REC_WORDS 32   /* X2, Z2: 16 limbs each */
+#ifndef X448_OCC
+#define X448_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))   /* 256 VGPRs and a few spills; without it: one wave per SIMD, no spills (A/B) */
+#endif
+__global__ __launch_bounds__(64) X448_OCC void k_x448_ladder(EcamdXdhLadderArgs A, int gslot)
+{
+	using namespace c448;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n || A.flags[i]) {
+		return;
+	}
+	const CK &K = TabGP<448>::get(gslot);
+	const FC onec = constant<FC>(K.one);
+	const u8 *src = A.u + (size_t)i * 56;
+	u32 uw[14], kw[14];
+#pragma unroll
+	for (int w = 0; w < 14; w++) {
+		uw[w] = (u32)src[4 * w] | ((u32)src[4 * w + 1] << 8) | ((u32)src[4 * w + 2] << 16) | ((u32)src[4 * w + 3] << 24);
+	}
+	load_be<14>(A.scalars + (size_t)i * 56, 56, kw);           // clamped by the prep kernel
+	const auto ud = from_words<PB, 14>(uw);
+	const FM x1 = M_(ud, onec);
+	FM x2 = weaken<FM>(onec), z2, x3 = x1, z3 = weaken<FM>(onec);
+#pragma unroll
+	for (int w = 0; w < 16; w++) {
+		z2.l[w] = 0;
+	}
+	const FC a24 = small_const(39081u);
+	u32 swap = 0;
+#pragma unroll 1
+	for (int t = 447; t >= 0; t--) {
+		u32 word = 0;
+#pragma unroll
+		for (int w = 0; w < 14; w++) {
+			word = (w == (t >> 5)) ? kw[w] : word;
+		}
+		const u32 kt = (word >> (t & 31)) & 1u;
+		swap ^= kt;
+		{
+			const FM tx = selg(swap != 0, x3, x2), tz = selg(swap != 0, z3, z2);
+			x3 = selg(swap != 0, x2, x3);
+			z3 = selg(swap != 0, z2, z3);
+			x2 = tx;
+			z2 = tz;
+		}
+		swap = kt;
+		const auto a = ADD_(x2, z2);
+		const auto b = SUB_(x2, z2);
+		const FM aa = S_(a);
+		const FM bb = S_(b);
+		const auto e = SUB_(aa, bb);
+		const auto c = ADD_(x3, z3);
+		const auto d = SUB_(x3, z3);
+		const FM da = M_(d, a);
+		const FM cb = M_(c, b);
+		x3 = S_(ADD_(da, cb));
+		z3 = M_(x1, S_(SUB_(da, cb)));
+		x2 = M_(aa, bb);
+		z2 = M_(e, ADD_(aa, M_(a24, e)));
+	}
+	{
+		const FM tx = selg(swap != 0, x3, x2), tz = selg(swap != 0, z3, z2);
+		x2 = tx;
+		z2 = tz;
+	}
+	u32 buf[X448_REC_WORDS];
+#pragma unroll
+	for (int w = 0; w < 16; w++) {
+		buf[w] = x2.l[w];
+		buf[16 + w] = z2.l[w];
+	}
+	uint4 *dst = (uint4 *)(A.rec + (size_t)i * X448_REC_WORDS);
+#pragma unroll
+	for (int q = 0; q < X448_REC_WORDS / 4; q++) {
+		dst[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
+	}
+}
+
+#define X448_FIN_K 8
+__global__ __launch_bounds__(64) void k_x448_fin(EcamdXdhLadderArgs A, int gslot, u32 nthreads)
+{
+	using namespace c448;
+	const u32 t = blockIdx.x * 64 + threadIdx.x;
+	if (t >= nthreads) {
+		return;
+	}
+	const CK &K = TabGP<448>::get(gslot);
+	const FM onem = weaken<FM>(constant<FC>(K.one));
+	// product of the Z2 of this lane's items (rejected items and Z2 = 0 take part with 1).  The partial products are not kept
+	// (8 x 16 registers): the way back recomputes the one it needs, 28 multiplications per lane against 8 x 460 for inversions
+	u32 live = 0;
+	FM acc = onem;
+#pragma unroll 1
+	for (int j = 0; j < X448_FIN_K; j++) {
+		const u32 i = t + (u32)j * nthreads;
+		if (i >= A.n || A.flags[i]) {
+			continue;
+		}
+		FM z;
+		const u32 *rec = A.rec + (size_t)i * X448_REC_WORDS;
+#pragma unroll
+		for (int w = 0; w < 16; w++) {
+			z.l[w] = rec[16 + w];
+		}
+		if (!is_zero_mulout(z, K)) {
+			live |= 1u << j;
+			acc = M_(acc, z);
+		}
+	}
+	FM inv = inv448(acc, K);   // 1 / (product of the live Z2)
+#pragma unroll 1
+	for (int j = X448_FIN_K - 1; j >= 0; j--) {
+		const u32 i = t + (u32)j * nthreads;
+		if (i >= A.n) {
+			continue;
+		}
+		u8 *out = A.out + (size_t)i * 56;
+		bool ok = ((live >> j) & 1u) != 0;
+		u32 w14[14];
+#pragma unroll
+		for (int w = 0; w < 14; w++) {
+			w14[w] = 0;
+		}
+		if (ok) {
+			const u32 *rec = A.rec + (size_t)i * X448_REC_WORDS;
+			FM x, z;
+#pragma unroll
+			for (int w = 0; w < 16; w++) {
+				x.l[w] = rec[w];
+				z.l[w] = rec[16 + w];
+			}
+			// 1 / z_j = inv * (product of the live z before j): recomputed by walking the earlier items again
+			FM before = onem;
+#pragma unroll 1
+			for (int jj = 0; jj < j; jj++) {
+				if ((live >> jj) & 1u) {
+					const u32 *r2 = A.rec + (size_t)(t + (u32)jj * nthreads) * X448_REC_WORDS;
+					FM zz;
+#pragma unroll
+					for (int w = 0; w < 16; w++) {
+						zz.l[w] = r2[16 + w];
+					}
+					before = M_(before, zz);
+				}
+			}
+			const FM zi = M_(inv, before);
+			inv = M_(inv, z);
+			u32 d[16];
+			canonical_digits(d, mul(x, zi, K), K);
+			to_words<16, 14>(w14, d);
+			u32 nz = 0;
+#pragma unroll
+			for (int w = 0; w < 14; w++) {
+				nz |= w14[w];
+			}
+			ok = nz != 0;   // an all-zero output is rejected (x25519_448.c:275-276)
+		}
+#pragma unroll 1
+		for (int w = 0; w < 14; w++) {
+			const u32 v = ok ? w14[w] : 0u;
+			out[4 * w] = (u8)v;
+			out[4 * w + 1] = (u8)(v >> 8);
+			out[4 * w + 2] = (u8)(v >> 16);
+			out[4 * w + 3] = (u8)(v >> 24);
+		}
+		A.status[i] = ok ? 0 : 1;
+	}
+}
+
+hipError_t ecamd_launch_x448_ladder(const EcamdXdhLadderArgs &a, int gslot, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_x448_ladder, dim3((a.n + 63) / 64), dim3(64), 0, s, a, gslot);
+	const uint32_t nthreads = (a.n + X448_FIN_K - 1) / X448_FIN_K;
+	hipLaunchKernelGGL(k_x448_fin, dim3((nthreads + 63) / 64), dim3(64), 0, s, a, gslot, nthreads);
+	return hipGetLastError();
+}
+
 #undef M_
 #undef S_
 #undef SUB_

@@ -2182,6 +2182,22 @@ static int xdh_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uin
 		}
 	} else if (cv->gflavour == 5 && cv->gslot >= 0 && P.mode == 1 && getenv("ECAMD_NO_G448_DECODE") == nullptr) {
 		HIPCHK(ecamd_launch_xdh_prep_c448(P, cv->gslot, s));   // X448: the same front end on the Goldilocks radix-2^29 field
+		if (getenv("ECAMD_NO_X448_LADDER") == nullptr) {
+			// and the x-only Montgomery ladder with a shared inversion, as for X25519
+			if (ensure(&ctx->stage[5], &ctx->stage_bytes[5], (size_t)n * ECAMD_X448_REC_WORDS * 4)) {
+				return -1;
+			}
+			EcamdXdhLadderArgs L;
+			L.u = d_u;
+			L.scalars = S[2];
+			L.flags = S[4];
+			L.rec = (uint32_t *)S[5];
+			L.out = d_out;
+			L.status = d_status;
+			L.n = n;
+			HIPCHK(ecamd_launch_x448_ladder(L, cv->gslot, s));
+			return 0;
+		}
 	} else {
 		HIPCHK(ecamd_launch_xdh_prep(nw, P, s));
 	}

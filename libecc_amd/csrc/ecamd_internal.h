@@ -249,6 +249,9 @@ hipError_t ecamd_launch_ed_decode(int nw, const EcamdEdDecodeArgs &a, hipStream_
 hipError_t ecamd_launch_ed_decode_c25519(const EcamdEdDecodeArgs &a, int gslot, hipStream_t s);
 hipError_t ecamd_launch_xdh_prep_c25519(const EcamdXdhPrepArgs &a, int gslot, hipStream_t s);
 hipError_t ecamd_launch_xdh_prep_c448(const EcamdXdhPrepArgs &a, int gslot, hipStream_t s);   // X448 on the Goldilocks unit
+#define ECAMD_X448_REC_WORDS 32
+struct EcamdXdhLadderArgs;
+hipError_t ecamd_launch_x448_ladder(const EcamdXdhLadderArgs &a, int gslot, hipStream_t s);  // rec: n x ECAMD_X448_REC_WORDS
 // X25519 x-only Montgomery ladder + shared inversion (after k_xdh_prep_c25519 validated and clamped)
 struct EcamdXdhLadderArgs {
 	const uint8_t *u;        // n x 32 little-endian u coordinates (as given by the caller)
