@@ -59,13 +59,22 @@ def build(force=False, verbose=False):
     for src, obj, extra in _jobs():
         spath, opath = os.path.join(CSRC, src), os.path.join(LIBDIR, obj)
         objs.append(opath)
-        if force or _stale(opath, [spath] + deps + (hdeps if src.endswith(".cpp") else [])):
-            todo.append([HIPCC] + FLAGS + extra + ["-x", "hip", "-c", spath, "-o", opath])
+        cmd = [HIPCC] + FLAGS + extra + ["-x", "hip", "-c", spath, "-o", opath]
+        # an object is also stale when it was built with other flags (its command line is kept beside it)
+        try:
+            same_cmd = open(opath + ".cmd").read() == " ".join(cmd)
+        except OSError:
+            same_cmd = False
+        if force or not same_cmd or _stale(opath, [spath] + deps + (hdeps if src.endswith(".cpp") else [])):
+            todo.append(cmd)
 
     def run(cmd):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        if "-c" in cmd:
+            with open(cmd[-1] + ".cmd", "w") as f:
+                f.write(" ".join(cmd))
 
     with ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1))) as ex:
         list(ex.map(run, todo))
