@@ -24,15 +24,16 @@
  * concurrency -- any number of contexts may share a device (the __constant__ curve slots are managed per
  * device, not per context).  Streams: a context owns ONE set of scratch buffers, so its calls execute one
  * after the other on the device even when they are enqueued on different streams (each call makes its stream
- * wait for the previous call's last kernel); use two contexts for two concurrent streams.  Memory: scratch grows with the largest batch seen (about 2.8 KB per item of a chunk of
- * <= 2^20 items); a curve handle that has served a fixed-base batch of >= 4096 items keeps a table of
+ * wait for the previous call's last kernel); use two contexts for two concurrent streams.  Memory: scratch grows with the largest batch seen (up to about 4 KB per item of a chunk of
+ * <= 2^20 items, by curve size and entry point); a curve handle that has served a fixed-base batch of >= 4096 items keeps a table of
  * multiples of the generator in HBM (42 MB for 256-bit curves, 183 MB for 521 bits).
  *
  * Environment (read when a context / curve handle is created; for measurements and fallbacks):
  *   ECAMD_HOST_CHUNK=<items>      chunk size of the host-pointer entry points (default 2^18)
  *   ECAMD_COMB_MIN_BATCH=<items>  smallest fixed-base batch that builds / uses the generator table (default 4096)
+ *   ECAMD_MSM_MIN=<items>, ECAMD_MSM_K=<items per lane>   initial values of ecamd_ctx_set_eddsa_msm (default 2^17, chosen from the batch size)
  *   ECAMD_NO_COMB, ECAMD_NO_FAST_PATH, ECAMD_NO_P25519, ECAMD_NO_K256, ECAMD_NO_P448, ECAMD_NO_MPINV1, ECAMD_NO_ISO, ECAMD_NO_X25519_LADDER,
- *   ECAMD_NO_EDWARDS_SMUL         route around one fast path each (results are identical)
+ *   ECAMD_NO_EDWARDS_SMUL, ECAMD_NO_G448_DECODE, ECAMD_NO_X448_LADDER   route around one fast path each (results are identical)
  */
 #ifndef LIBECC_AMD_H
 #define LIBECC_AMD_H

@@ -1192,6 +1192,12 @@ def test_libecc_typed_boundary_vs_scalar_api():
     assert r.stdout.count(": ok") >= 19 and "FAILED" not in r.stdout and "MISMATCH" not in r.stdout
     sent = int(r.stdout.split("items sent to the GPU:")[1].split()[0])
     assert sent >= 640 * 20, sent          # the batch forms did run on the GPU (there is no CPU fallback to hide behind)
+    # the same program with the Ed25519 multi-scalar multiplication forced for every batch size: ec_verify_batch's EdDSA
+    # branch then decides valid batches by the combination and falls back to the item-by-item pass for the others
+    env = dict(os.environ, ECAMD_MSM_MIN="1")
+    r = subprocess.run([exe, "200"], capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert "compat_check: all ok" in r.stdout and "FAILED" not in r.stdout and "MISMATCH" not in r.stdout
 
 
 def test_libecc_self_tests_against_libsign_amd():
