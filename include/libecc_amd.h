@@ -24,8 +24,8 @@
  * concurrency -- any number of contexts may share a device (the __constant__ curve slots are managed per
  * device, not per context).  Streams: a context owns ONE set of scratch buffers, so its calls execute one
  * after the other on the device even when they are enqueued on different streams (each call makes its stream
- * wait for the previous call's last kernel); use two contexts for two concurrent streams.  Memory: scratch grows with the largest batch seen (up to about 4 KB per item of a chunk of
- * <= 2^20 items, by curve size and entry point); a curve handle that has served a fixed-base batch of >= 4096 items keeps a table of
+ * wait for the previous call's last kernel); use two contexts for two concurrent streams.  Memory: scratch grows with the largest batch seen (about 3 KB per item of a chunk of
+ * <= 2^20 items for 256-bit curves, 7 KB for 521 bits); a curve handle that has served a fixed-base batch of >= 4096 items keeps a table of
  * multiples of the generator in HBM (42 MB for 256-bit curves, 183 MB for 521 bits).
  *
  * Environment (read when a context / curve handle is created; for measurements and fallbacks):
