@@ -304,7 +304,9 @@ template <int NW> static __device__ __forceinline__ Fe<NW> digest_to_e(const u8 
 // One lane prepares ECDSA_PREP_K consecutive items and shares one Fermat inversion among them
 // (Montgomery's trick: prefix products, one x^(q-2), back-substitution): 3 multiplications + 1/K of an
 // inversion per item instead of a whole one.  Items whose s is out of range take part with 1.
+#ifndef ECDSA_PREP_K
 #define ECDSA_PREP_K 8
+#endif
 template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_prep(EcamdEcdsaPrepArgs A)
 {
 	const u32 t = blockIdx.x * 64 + threadIdx.x;
