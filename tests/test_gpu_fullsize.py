@@ -99,6 +99,12 @@ def test_ed25519_full_size_vs_reference_binary(gpu_ctx):
         Sb = cv.eddsa_sign_S(r_hash, hram, a)
         sigs = np.concatenate([np.frombuffer(R, dtype=np.uint8).reshape(n, 32), np.frombuffer(Sb, dtype=np.uint8).reshape(n, 32)], axis=1)
         assert cv.eddsa_verify(A, sigs.tobytes(), hram) == bytes(n)
+        # ec_verify_batch's one bit for the whole batch: at this size the library decides it with the multi-scalar
+        # multiplication of the reference's batch equation (tests/test_gpu_msm.py pins that kernel on small batches)
+        assert cv.eddsa_verify_all(A, sigs.tobytes(), hram) == (True, n)
+        spoiled = bytearray(hram)
+        spoiled[64 * (n - 7) + 9] ^= 2
+        assert cv.eddsa_verify_all(A, sigs.tobytes(), bytes(spoiled)) == (False, n - 7)
         i = np.arange(n)
         bad = (i % 10) == 3
         kind = (i // 10) % 3
