@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include "libecc_amd_compat.h"
 #include "external_deps/rand.h"   /* get_random: supplied by the application, as for libecc's own libsign */
 
@@ -319,9 +320,73 @@ static void check_inf_key(const char *curve, hash_alg_type hash_type, u32 n)
 	printf("ec_verify_batch key at infinity %-12s %u items, %u accepted by ec_verify: %s\n", curve, n, nacc, failures == before ? "ok" : "FAILED");
 }
 
+/* ---- "compat_check bench <log2 n>": end-to-end rate of ec_verify_batch as a libecc application sees it -- libecc structures
+ * in, one int out, the marshalling and the message hashing on the host threads included.  `base` distinct (key, message,
+ * signature) triples made with libecc's ec_sign, repeated to n pointers (the batch arrays are arrays of pointers). ---- */
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static void bench_verify(const char *curve, ec_alg_type sig_type, hash_alg_type hash_type, const char *label, u32 n)
+{
+	enum { base = 512, ML = 48 };
+	ec_params params;
+	static ec_key_pair kps[base];
+	static u8 sigbuf[base][2 * 72], msgbuf[base][ML];
+	const ec_pub_key **pubs = calloc(n, sizeof(*pubs));
+	const u8 **sigs = calloc(n, sizeof(*sigs)), **msgs = calloc(n, sizeof(*msgs)), **adatas = calloc(n, sizeof(*adatas));
+	u8 *siglens = calloc(n, 1), siglen = 0;
+	u32 *msglens = calloc(n, sizeof(u32)), i;
+	u16 *adlens = calloc(n, sizeof(u16));
+	double t0, best = 1e30;
+	int r = 0, rep;
+	if (load_params(curve, &params) || ec_get_sig_len(&params, sig_type, hash_type, &siglen) || siglen > sizeof(sigbuf[0])) {
+		printf("bench %s: setup failed\n", label);
+		return;
+	}
+	for (i = 0; i < base; i++) {
+		if (ec_key_pair_gen(&kps[i], &params, sig_type) || get_random(msgbuf[i], ML) ||
+		    ec_sign(sigbuf[i], siglen, &kps[i], msgbuf[i], ML, sig_type, hash_type, NULL, 0)) {
+			printf("bench %s: signing failed\n", label);
+			return;
+		}
+	}
+	for (i = 0; i < n; i++) {
+		pubs[i] = &kps[i % base].pub_key;
+		sigs[i] = sigbuf[i % base];
+		msgs[i] = msgbuf[i % base];
+		siglens[i] = siglen;
+		msglens[i] = ML;
+	}
+	for (rep = 0; rep < 4; rep++) {   /* the first call also creates the curve handle and its tables */
+		t0 = now_s();
+		r |= ec_verify_batch(sigs, siglens, pubs, msgs, msglens, n, sig_type, hash_type, adatas, adlens, NULL, NULL);
+		if (rep && now_s() - t0 < best) {
+			best = now_s() - t0;
+		}
+	}
+	printf("bench ec_verify_batch %-24s n = %u: %s, %.1f ms, %.2f M verifications/s end to end (libecc structures in, host hashing and marshalling included)\n",
+	       label, n, r ? "REJECTED" : "accepted", best * 1e3, (double)n / best / 1e6);
+	free(pubs); free(sigs); free(msgs); free(adatas); free(siglens); free(msglens); free(adlens);
+}
+
 int main(int argc, char **argv)
 {
 	const u32 n = (argc > 1) ? (u32)atoi(argv[1]) : 256;
+	if (argc > 2 && !strcmp(argv[1], "bench")) {
+		const u32 bn = 1u << (u32)atoi(argv[2]);
+		if (ecamd_compat_init(NULL, 0, 0)) {
+			printf("no GPU path\n");
+			return 3;
+		}
+		bench_verify("SECP256R1", ECDSA, SHA256, "ECDSA/SECP256R1/SHA256", bn);
+		bench_verify("SECP384R1", ECDSA, SHA384, "ECDSA/SECP384R1/SHA384", bn);
+		bench_verify("WEI25519", EDDSA25519, SHA512, "EDDSA25519", bn);
+		ecamd_compat_shutdown();
+		return 0;
+	}
 	if (ecamd_compat_init(NULL, 0, 0)) {
 		printf("no GPU path\n");
 		return 3;
