@@ -216,6 +216,13 @@ int ec_eddsa_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t
 			      const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, int *all_valid,
 			      uint32_t *first_rejected);
 
+/* eddsa_export_pub_key in batch (sig/eddsa.c:795-860): n projective Weierstrass points X || Y || Z (what ec_pub_key.y holds,
+ * prj_pt_export_to_buf) of the WEI25519 / WEI448 handle -> prj_pt_shortw_to_aff_pt_edwards -> eddsa_encode_point: n x 32 / 57
+ * octets, the public-key encoding the verifier hashes.  status ECAMD_ERR for a point that is not on the curve; the point at
+ * infinity encodes the neutral element (0, 1) as in the reference. */
+int ec_eddsa_encode_point_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *points_prj,
+				uint8_t *enc, uint8_t *status);
+
 /* The multi-scalar multiplication alone, device pointers (WEI25519 handle; any n > 0): d_verdict[0] = 0 when libecc's batch
  * equation holds and no item is rejected beforehand, 1 otherwise.  Only enqueues on the stream. */
 int ec_eddsa_verify_all_batch_dev(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const void *d_pubkeys,
@@ -359,6 +366,8 @@ int ecamd_multi_xdh_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n,
 			  uint8_t *out, uint8_t *status);
 int ecamd_multi_eddsa_verify_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *pubkeys,
 				   const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, uint8_t *result);
+int ecamd_multi_eddsa_encode_point_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *points_prj,
+					 uint8_t *enc, uint8_t *status);
 /* ec_verify_batch's whole-batch bit, sharded (see ec_eddsa_verify_all_batch: Ed25519 shards of at least 2^17 items run the
  * multi-scalar multiplication on their device); first_rejected (may be NULL): lowest rejected index of the whole batch, n if none */
 int ecamd_multi_eddsa_verify_all_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *pubkeys,

@@ -9,7 +9,7 @@ FP_MUL_MONTY, FP_ADD, FP_SUB, FP_MUL, FP_INV = 0, 1, 2, 3, 4
 # every symbol include/libecc_amd.h declares (tests check the .so exports exactly these)
 EXPORTED_SYMBOLS = [
     "ecamd_device_count", "ecamd_ctx_create", "ecamd_ctx_destroy", "ecamd_last_error",
-    "ecamd_ctx_set_max_chunk", "ecamd_ctx_set_secret_scalars", "ecamd_ctx_set_eddsa_msm", "ec_eddsa_verify_all_batch_dev", "ecamd_debug_eddsa_msm", "ecamd_ctx_enable_kernel_timing", "ecamd_ctx_kernel_times", "ecamd_curve_by_name", "ecamd_curve_from_params", "ecamd_curve_free",
+    "ecamd_ctx_set_max_chunk", "ecamd_ctx_set_secret_scalars", "ecamd_ctx_set_eddsa_msm", "ec_eddsa_verify_all_batch_dev", "ecamd_debug_eddsa_msm", "ec_eddsa_encode_point_batch", "ecamd_multi_eddsa_encode_point_batch", "ecamd_ctx_enable_kernel_timing", "ecamd_ctx_kernel_times", "ecamd_curve_by_name", "ecamd_curve_from_params", "ecamd_curve_free",
     "ecamd_curve_coord_len", "ecamd_curve_order_len", "ecamd_curve_words", "ec_prj_pt_mul_batch", "ec_prj_pt_mul_blind_batch",
     "ec_prj_pt_mul_batch_dev", "ecamd_ctx_synchronize", "ec_prj_pt_add_batch", "ec_prj_pt_dbl_batch",
     "ec_fp_op_batch", "ec_ecdsa_verify_batch", "ec_ecdsa_verify_batch_fmt", "ec_ecdsa_sign_batch", "ec_ecccdh_derive_batch", "ec_xdh_batch",
@@ -78,6 +78,8 @@ def load_library():
         L.ecamd_debug_eddsa_msm.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p, C.POINTER(C.c_int), vp, vp]
         L.ecamd_ctx_set_eddsa_msm.argtypes = [vp, C.c_int, u32, u32]
         L.ec_eddsa_verify_all_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp]
+        L.ec_eddsa_encode_point_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p]
+        L.ecamd_multi_eddsa_encode_point_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p]
         L.ec_prj_pt_mul_batch_fmt.argtypes = [vp, vp, u32, u8p, u32, u8p, C.c_int, u8p, C.c_int, u8p]
         L.ec_prj_pt_unique_batch.argtypes = [vp, vp, u32, u8p, C.c_int, u8p, C.c_int, u8p]
         L.ec_structured_pub_key_import_batch.argtypes = [vp, vp, u32, u8p, u32, C.c_int, u8p, u8p]
@@ -310,6 +312,14 @@ class Curve:
         out = C.create_string_buffer(max(1, kl * n))
         _chk(self.L, self.L.ec_eddsa_sign_S_batch(self.ctx.h, self.h, n, r_hash, hram, a_scalars, out), "ec_eddsa_sign_S_batch")
         return out.raw[:kl * n]
+
+    def eddsa_encode_points(self, points_prj):
+        """eddsa_export_pub_key in batch: projective Weierstrass X || Y || Z -> the 32 / 57-byte EdDSA encodings, status"""
+        kl = 57 if self.clen == 56 else 32
+        n = len(points_prj) // (3 * self.clen)
+        out, st = C.create_string_buffer(max(1, kl * n)), C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_eddsa_encode_point_batch(self.ctx.h, self.h, n, points_prj, out, st), "ec_eddsa_encode_point_batch")
+        return out.raw[:kl * n], st.raw[:n]
 
     def eddsa_verify_all(self, pubkeys, sigs, hram, hram_len=None):
         """ec_verify_batch's whole-batch predicate: (all_valid, index of the first rejected item or n)"""

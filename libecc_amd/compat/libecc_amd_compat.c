@@ -630,6 +630,7 @@ typedef struct {
 	const u32 *idx;          /* the items of this group */
 	const ec_params *params;
 	u8 *pk, *sg, *dg, *pre;  /* packed: keys (projective X||Y||Z or EdDSA encoding), signatures, digests / hram, per-item pre-check */
+	u8 *kprj;                /* EdDSA: the key points X||Y||Z, input of the device-side encoding */
 	u32 clen, qlen, hlen, klen, siglen;
 } ver_job;
 
@@ -702,8 +703,9 @@ done:
 	free(J->sg);
 	free(J->dg);
 	free(J->pre);
+	free(J->kprj);
 	free(res);
-	J->pk = J->sg = J->dg = J->pre = NULL;
+	J->pk = J->sg = J->dg = J->pre = J->kprj = NULL;
 	return ret;
 }
 
@@ -752,6 +754,22 @@ typedef struct {
 	u32 ph_len;   /* bytes of PH(M) that enter the main hash */
 } ed_job;
 
+/* first pass of an EdDSA group: the projective key points as octets for ec_eddsa_encode_point_batch */
+static void eddsa_export_keys(u32 lo, u32 hi, void *arg)
+{
+	ed_job *E = (ed_job *)arg;
+	ver_job *J = &E->v;
+	u32 j;
+	for (j = lo; j < hi; j++) {
+		const ec_pub_key *pk = J->pub_keys[J->idx[j]];
+		u8 *dst = J->kprj + (size_t)j * 3 * J->clen;
+		if (pub_key_check_initialized_and_type(pk, J->sig_type) || pk->params != J->params ||
+		    prj_pt_export_to_buf(&pk->y, dst, (u32)(3 * J->clen))) {
+			memset(dst, 0xff, (size_t)3 * J->clen);   /* coordinates >= p: an import error on the device */
+		}
+	}
+}
+
 static void eddsa_pack(u32 lo, u32 hi, void *arg)
 {
 	ed_job *E = (ed_job *)arg;
@@ -773,8 +791,9 @@ static void eddsa_pack(u32 lo, u32 hi, void *arg)
 #if defined(WITH_SIG_EDDSA25519)
 		bad = bad || (J->sig_type == EDDSA25519CTX && !ad);
 #endif
-		/* the encoding of the key as the reference hashes it: its own export (Weierstrass -> Edwards -> octets) */
-		bad = bad || eddsa_export_pub_key(pk, kenc, (u16)J->klen);
+		/* the encoding of the key as the reference hashes it -- eddsa_export_pub_key: Weierstrass -> Edwards -> octets -- was
+		 * computed on the device for the whole group (eddsa_group; libecc's own export costs about 1.5 ms of CPU per key) */
+		bad = bad || J->pre[j];
 		bad = bad || J->hm->hfunc_init(&hc);
 		if (!bad && E->dom) {
 			bad = dom_prefix(J->hm, &hc, E->is448, E->ph, ad, adl);
@@ -824,8 +843,15 @@ static int eddsa_group(ed_job *E, u32 cnt, int *results)
 	J->sg = (u8 *)malloc((size_t)cnt * J->siglen);
 	J->dg = (u8 *)malloc((size_t)cnt * J->hlen);
 	J->pre = (u8 *)malloc(cnt);
+	J->kprj = (u8 *)malloc((size_t)cnt * 3 * J->clen);
 	res = (u8 *)malloc(cnt);
-	if (!J->pk || !J->sg || !J->dg || !J->pre || !res) {
+	if (!J->pk || !J->sg || !J->dg || !J->pre || !J->kprj || !res) {
+		goto done;
+	}
+	/* the keys as the reference hashes them: exported as points here, encoded on the device (pre[j] != 0: no encoding) */
+	parallel_for(cnt, eddsa_export_keys, E);
+	if (ecamd_multi_eddsa_encode_point_batch(g_multi, e->mc, cnt, J->kprj, J->pk, J->pre)) {
+		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
 		goto done;
 	}
 	parallel_for(cnt, eddsa_pack, E);

@@ -3130,6 +3130,53 @@ extern "C" int ec_eddsa_sign_R_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint
 	});
 }
 
+// eddsa_export_pub_key in batch (sig/eddsa.c:795-860): the projective Weierstrass point an ec_pub_key holds ->
+// prj_pt_shortw_to_aff_pt_edwards -> eddsa_encode_point, i.e. the octets the verifier hashes as "A".  (libecc spends about
+// 1.5 ms of CPU per call on it -- it rebuilds the curve maps every time --, which is what made ec_verify_batch through
+// libsign_amd.so host-bound by three orders of magnitude before this entry point existed.)
+extern "C" int ec_eddsa_encode_point_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *points_prj,
+					   uint8_t *enc, uint8_t *status)
+{
+	if (!ctx) {
+		return fail("ec_eddsa_encode_point_batch: bad argument");
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	EcamdEdSignArgs T;
+	if (eddsa_sign_setup("ec_eddsa_encode_point_batch", ctx, cv, n, points_prj, enc, status, &T)) {
+		return -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t cl = (size_t)cv->clen, kl = T.is448 ? 57 : 32;
+	const std::vector<HostArr> arrs = {{points_prj, nullptr, 3 * cl}, {nullptr, enc, kl}, {nullptr, status, 1}};
+	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+					       hipStream_t s, const std::function<int()> &) {
+		// stage: 3 affine points, 4 import status (0 / 1 error / 2 infinity: the encode kernel's convention)
+		if (ensure(&ctx->stage[3], &ctx->stage_bytes[3], (size_t)m * 2 * cl) || ensure(&ctx->stage[4], &ctx->stage_bytes[4], m)) {
+			return -1;
+		}
+		EcamdPrjInArgs I;
+		I.in = ip[0];
+		I.aff = ctx->stage[3];
+		I.pre = ctx->stage[4];
+		I.n = m;
+		I.clen = (uint32_t)cl;
+		I.for_mul = 0;
+		I.slot = cv->slot;
+		HIPCHK(ecamd_launch_prj_import(cv->nw, I, s));
+		EcamdEdSignArgs A = T;
+		A.n = m;
+		A.Rw = ctx->stage[3];
+		A.stR = ctx->stage[4];
+		A.out = op[1];
+		A.status = op[2];
+		HIPCHK(ecamd_launch_ed_sign_enc(A, s));
+		return 0;
+	});
+}
+
 extern "C" int ec_eddsa_sign_S_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *r_hash,
 				     const uint8_t *hram, const uint8_t *a_scalars, uint8_t *S_out)
 {

@@ -308,6 +308,15 @@ extern "C" int ecamd_multi_eddsa_verify_batch(ecamd_multi *m, const ecamd_mcurve
 	});
 }
 
+extern "C" int ecamd_multi_eddsa_encode_point_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *points_prj,
+						    uint8_t *enc, uint8_t *status)
+{
+	const size_t cl = (size_t)ecamd_multi_curve_coord_len(c), kl = (cl == 56) ? 57 : cl;
+	return run_sharded(m, c, n, "ecamd_multi_eddsa_encode_point_batch", [&](int r, uint32_t lo, uint32_t hi) {
+		return ec_eddsa_encode_point_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(points_prj, 3 * cl), OFF(enc, kl), OFF(status, 1));
+	});
+}
+
 // ec_verify_batch's one bit for EdDSA, sharded: every device decides its shard (Ed25519 shards of at least 2^17 items with the
 // multi-scalar multiplication, ec_eddsa_verify_all_batch); the batch is valid when every shard is
 extern "C" int ecamd_multi_eddsa_verify_all_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys,

@@ -197,3 +197,33 @@ def test_eddsa448_sign_steps(gpu_ctx):
         assert R2 == b"".join(exp)
     finally:
         cv.free()
+
+
+@pytest.mark.gpu
+def test_eddsa_encode_point_batch(gpu_ctx):
+    """ec_eddsa_encode_point_batch = eddsa_export_pub_key in batch: projective Weierstrass points of WEI25519 -> the RFC 8032
+    encodings (python integers: [a]B encoded), scaled representatives included; the point at infinity encodes the neutral
+    element, a point off the curve is an error"""
+    import oracles as O
+    rng = np.random.default_rng(31)
+    n = 70
+    p = O.ED_P
+    cv = gpu_ctx.curve("WEI25519")
+    try:
+        scal = [int.from_bytes(rng.integers(0, 256, size=32, dtype=np.uint8).tobytes(), "little") % O.ED_Q or 1 for _ in range(n)]
+        aff, st = cv.scalar_mult(b"".join(a.to_bytes(32, "big") for a in scal))
+        assert set(st) == {0}
+        prj = bytearray()
+        for i in range(n):
+            x, y = int.from_bytes(aff[64 * i:64 * i + 32], "big"), int.from_bytes(aff[64 * i + 32:64 * i + 64], "big")
+            z = int.from_bytes(rng.integers(0, 256, size=40, dtype=np.uint8).tobytes(), "big") % p or 1 if i % 2 else 1
+            prj += (x * z % p).to_bytes(32, "big") + (y * z % p).to_bytes(32, "big") + z.to_bytes(32, "big")
+        prj += bytes(32) + (1).to_bytes(32, "big") + bytes(32)                         # (0 : 1 : 0)
+        prj += (5).to_bytes(32, "big") + (7).to_bytes(32, "big") + (1).to_bytes(32, "big")   # not on the curve
+        enc, st = cv.eddsa_encode_points(bytes(prj))
+        for i in range(n):
+            assert enc[32 * i:32 * i + 32] == O.ed_encode(O.ed_mul(scal[i], O.ED_B)), i
+        assert list(st) == [0] * (n + 1) + [1]
+        assert enc[32 * n:32 * n + 32] == (1).to_bytes(32, "little")
+    finally:
+        cv.free()
