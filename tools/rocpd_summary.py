@@ -3,6 +3,7 @@
 
 usage: tools/rocpd_summary.py kernels <results.db>      per-kernel count / total / average duration
        tools/rocpd_summary.py pmc <results.db>          per-kernel, per-counter sums per dispatch
+       tools/rocpd_summary.py dispatches <results.db> <name part>   every dispatch of the matching kernels, in launch order
 """
 import sqlite3
 import sys
@@ -37,5 +38,20 @@ def pmc(db):
         print(f"| {k[:70]} | {c} | {len(v)} | {sum(v)/len(v):.6g} | {max(v):.6g} |")
 
 
+def dispatches(db, part):
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, start, end - start, grid_x from kernels where name like ? order by start", (f"%{part}%",)).fetchall()
+    print("| # | kernel | grid | ms |")
+    print("|---|---|---|---|")
+    for i, r in enumerate(rows):
+        print(f"| {i} | {r[0][:60]} | {r[3]} | {r[2]/1e6:.4f} |")
+    full = [r[2] / 1e6 for r in rows if r[3] == max(x[3] for x in rows)]
+    if full:
+        print(f"\nfull-size dispatches: {len(full)}, mean {sum(full)/len(full):.4f} ms, last ten mean {sum(full[-10:])/len(full[-10:]):.4f} ms")
+
+
 if __name__ == "__main__":
-    {"kernels": kernels, "pmc": pmc}[sys.argv[1]](sys.argv[2])
+    if sys.argv[1] == "dispatches":
+        dispatches(sys.argv[2], sys.argv[3])
+    else:
+        {"kernels": kernels, "pmc": pmc}[sys.argv[1]](sys.argv[2])
