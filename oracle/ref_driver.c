@@ -813,3 +813,28 @@ int refdrv_structured_sig_batch(uint32_t n, const uint8_t *in, uint32_t in_len, 
 	}
 	return 0;
 }
+
+/* ---- eddsa_export_pub_key (sig/eddsa.c:795-860) on keys given as projective Weierstrass points X || Y || Z: the octets a
+ * verifier hashes as "A".  ret[i] = 0 / -1 (the import or the export failed). ---- */
+int refdrv_eddsa_export_pub_key_batch(int is448, uint32_t n, const uint8_t *points_prj, uint8_t *enc, int *ret)
+{
+	ec_params params;
+	uint32_t i;
+	const size_t klen = is448 ? 57 : 32;
+	const ec_alg_type alg = is448 ? EDDSA448 : EDDSA25519;
+	size_t clen;
+	if (load_params(is448 ? "WEI448" : "WEI25519", &params)) {
+		return -1;
+	}
+	clen = (size_t)BYTECEIL(params.ec_fp.p_bitlen);
+	for (i = 0; i < n; i++) {
+		ec_pub_key pk;
+		memset(enc + (size_t)i * klen, 0, klen);
+		ret[i] = ec_pub_key_import_from_buf(&pk, &params, points_prj + (size_t)i * 3 * clen, (u8)(3 * clen), alg);
+		if (!ret[i]) {
+			ret[i] = eddsa_export_pub_key(&pk, enc + (size_t)i * klen, (u16)klen);
+		}
+		ret[i] = ret[i] ? -1 : 0;
+	}
+	return 0;
+}

@@ -315,6 +315,17 @@ def ref_eddsa_verify_all(pubs, sigs, msgs, msg_len, ed448=False, scratch=False):
     return bool(ok.value)
 
 
+def ref_eddsa_export_pub_key(points_prj, ed448=False):
+    """libecc's eddsa_export_pub_key on keys given as projective Weierstrass points: (encodings, per-item 0 / -1)"""
+    L = C.CDLL(REF_SO)
+    cl, kl = (56, 57) if ed448 else (32, 32)
+    n = len(points_prj) // (3 * cl)
+    enc = C.create_string_buffer(max(1, kl * n))
+    ret = (C.c_int * max(1, n))()
+    assert L.refdrv_eddsa_export_pub_key_batch(int(ed448), n, points_prj, enc, ret) == 0
+    return enc.raw[:kl * n], [ret[i] for i in range(n)]
+
+
 def digest(hash_name, msg):
     return hashlib.new(HASHLIB[hash_name], msg).digest()
 
