@@ -95,3 +95,23 @@ def test_compat_fails_loudly_without_gpu():
     exe = os.path.join(ROOT, "libecc_amd", "lib", "compat_check")
     r = subprocess.run([exe, "16"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 3 and "no HIP device" in (r.stdout + r.stderr)
+
+
+def test_integration_md_glue_example_compiles(tmp_path):
+    """the C example of INTEGRATION.md section 2 (an application calling the C ABI beside libecc) compiles against
+    libecc's headers and include/libecc_amd.h as printed"""
+    import re
+    import subprocess
+    ref = "/root/reference/src"
+    if not os.path.isdir(ref):
+        pytest.skip("the libecc headers are not here")
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```c\n(.*?)```", md, flags=re.S)
+    glue = [b for b in blocks if "ecamd_glue_init" in b]
+    assert len(glue) == 1
+    src = tmp_path / "ecc_amd_glue.c"
+    src.write_text(glue[0])
+    r = subprocess.run(["gcc", "-std=gnu99", "-Wall", "-Werror", "-DWITH_STDLIB", "-include", "stdlib.h", "-include", "string.h",
+                        "-I", ref, "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "glue.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
