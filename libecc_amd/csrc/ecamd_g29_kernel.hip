@@ -1599,6 +1599,53 @@ static __device__ __forceinline__ void ed_window_add(Ext &acc, const u32 *tb, u3
 #undef S_
 }  // namespace c25519
 
+// Decoding for the Edwards [h]A path: A and R are decoded as in k_ed_decode_c25519 but stay on the Edwards curve.  The key's
+// [cofactor]A = infinity test runs there too (three complete doublings; the map is a group isomorphism), and R's map to the
+// Weierstrass model -- the only reason k_ed_decode_c25519 needs a field inversion per item -- moves to k_ed_hA_fin, where it
+// shares one inversion with the [h]A of eight items.
+__global__ __launch_bounds__(64) void k_ed_decode_ed_c25519(EcamdEdDecodeArgs A, int gslot)
+{
+	using namespace c25519;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+#pragma unroll 1
+	for (int k = 0; k < 2; k++) {
+		const DecXY P = decode_xy(A, k == 0 ? A.encA + (size_t)i * A.strideA : A.encR + (size_t)i * A.strideR, K);
+		bool good = P.ok;
+		Ext P1 = ed_neutral(K);
+		if (P.ok) {
+			P1 = ed_from_affine(P.x, P.ym, K);
+		}
+		if (k == 0 && good) {
+			Ext Q = P1;
+			for (u32 r = 0; r < A.cof_dbl; r++) {
+				Q = ed_dbl<false>(Q, K);
+			}
+			good = !is_zero_mulout(Q.X, K);   // [cofactor]A is the neutral element: rejected (sig/eddsa.c:2463-2472)
+		}
+		u32 buf[20];
+#pragma unroll
+		for (int w = 0; w < 9; w++) {
+			buf[w] = P1.X.l[w];
+			buf[9 + w] = P1.Y.l[w];
+		}
+		buf[18] = buf[19] = 0;
+		uint4 *dst = (uint4 *)((k == 0 ? A.edA : A.edR) + (size_t)i * 20);
+#pragma unroll
+		for (int q = 0; q < 5; q++) {
+			dst[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
+		}
+		if (k == 0) {
+			A.flagsA[i] = good ? 0 : 1;
+		} else {
+			A.flagsR[i] = good ? 0 : (P.neutral ? 2 : 1);   // 2: R is the point at infinity of the Weierstrass model
+		}
+	}
+}
+
 // [h]A per lane: table [1..8]A, signed window w = 4; the extended result goes to rec
 // phase 0: the table, phase 1: the window loop -- two launches, so that the table construction's register needs (256 VGPRs)
 // do not bound the loop's occupancy (113 VGPRs, four waves per SIMD): Ed25519 verification 51.9 -> 57.4 M/s
@@ -1703,6 +1750,23 @@ template <int phase> __global__ __launch_bounds__(64) void k_ed_smul_c25519(Ecam
 //   u = (Z + Y) X w, v = alpha (Z + Y) Z w.   X = 0: the neutral element (Y = Z: infinity, status 2) or the
 //   point of order two (Y = -Z: (A/3, 0)).
 #define EDF_K 8
+// (x, y) of a decoded R (k_ed_decode_ed_c25519's record)
+static __device__ __forceinline__ void edr_load(const u32 *rec, c25519::FM &x, c25519::FM &y)
+{
+	u32 buf[20];
+	const uint4 *src = (const uint4 *)rec;
+#pragma unroll
+	for (int q = 0; q < 5; q++) {
+		const uint4 v = src[q];
+		buf[4 * q] = v.x; buf[4 * q + 1] = v.y; buf[4 * q + 2] = v.z; buf[4 * q + 3] = v.w;
+	}
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		x.l[w] = buf[w];
+		y.l[w] = buf[9 + w];
+	}
+}
+
 __global__ __launch_bounds__(64) void k_ed_hA_fin(EcamdEdSmulArgs A, int gslot, u32 nthreads)
 {
 	using namespace c25519;
@@ -1713,13 +1777,16 @@ __global__ __launch_bounds__(64) void k_ed_hA_fin(EcamdEdSmulArgs A, int gslot, 
 	const CK &K = TabGP<255>::get(gslot);
 	const FC onec = constant<FC>(K.one);
 	const FM onem = weaken<FM>(onec);
-	FM pre[EDF_K];
+	// element 2j: [h]A of item j, element 2j + 1: its R (when this kernel maps it); pre[e] = the product of the live
+	// denominators before element e
+	FM pre[2 * EDF_K];
 	u32 live = 0;
 	FM acc = onem;
 #pragma unroll 1
 	for (int j = 0; j < EDF_K; j++) {
 		const u32 i = t + (u32)j * nthreads;
-		pre[j] = acc;
+		pre[2 * j] = acc;
+		pre[2 * j + 1] = acc;
 		if (i >= A.n || A.flags[i]) {
 			continue;
 		}
@@ -1739,8 +1806,18 @@ __global__ __launch_bounds__(64) void k_ed_hA_fin(EcamdEdSmulArgs A, int gslot, 
 		}
 		const FM den = weaken<FM>(mulc(carry(sub_auto<1>(Z, Y, K)), X, K));
 		if (!is_zero_mulout(den, K)) {
-			live |= 1u << j;
+			live |= 1u << (2 * j);
 			acc = weaken<FM>(mul(acc, den, K));
+		}
+		pre[2 * j + 1] = acc;
+		if (A.edR != nullptr && A.flagsR[i] == 0) {
+			FM xr, yr;
+			edr_load(A.edR + (size_t)i * 20, xr, yr);
+			const FM denr = weaken<FM>(mulc(carry(sub_auto<1>(onec, yr, K)), xr, K));   // (1 - y) x, non-zero for a decoded R
+			if (!is_zero_mulout(denr, K)) {
+				live |= 1u << (2 * j + 1);
+				acc = weaken<FM>(mul(acc, denr, K));
+			}
 		}
 	}
 	FM a11;
@@ -1759,6 +1836,28 @@ __global__ __launch_bounds__(64) void k_ed_hA_fin(EcamdEdSmulArgs A, int gslot, 
 			A.status[i] = 1;
 			continue;
 		}
+		if (A.edR != nullptr && A.flagsR[i] == 0) {
+			// R: u = (1 + y) / (1 - y), v = alpha u / x; with w = ((1 - y) x)^-1: u = (1 + y) x w, v = alpha (1 + y) w
+			u8 *outr = A.outR + (size_t)i * 64;
+			if ((live >> (2 * j + 1)) & 1u) {
+				FM xr, yr;
+				edr_load(A.edR + (size_t)i * 20, xr, yr);
+				const FM denr = weaken<FM>(mulc(carry(sub_auto<1>(onec, yr, K)), xr, K));
+				const FM wr = weaken<FM>(mul(inv, pre[2 * j + 1], K));
+				inv = weaken<FM>(mul(inv, denr, K));
+				const FM opy = weaken<FM>(mulc(carry(add(onec, yr)), wr, K));          // (1 + y) w
+				const FM um = weaken<FM>(mul(opy, xr, K));
+				const FM vm = weaken<FM>(mul(digits9(A.g_alpha), opy, K));
+				store_canon_be(outr, carry(add(um, digits9(A.g_A3))), true, K);
+				store_canon_be(outr + 32, vm, true, K);
+			} else {
+				// cannot happen for an R the decoder accepted (x != 0, hence y != 1): reject it
+				for (int b = 0; b < 64; b++) {
+					outr[b] = 0;
+				}
+				A.flagsR[i] = 1;
+			}
+		}
 		u32 buf[EDR_REC_WORDS];
 		const uint4 *src = (const uint4 *)(A.rec + (size_t)i * EDR_REC_WORDS);
 #pragma unroll
@@ -1773,9 +1872,9 @@ __global__ __launch_bounds__(64) void k_ed_hA_fin(EcamdEdSmulArgs A, int gslot, 
 			Y.l[w] = buf[9 + w];
 			Z.l[w] = buf[18 + w];
 		}
-		if ((live >> j) & 1u) {
+		if ((live >> (2 * j)) & 1u) {
 			const FM den = weaken<FM>(mulc(carry(sub_auto<1>(Z, Y, K)), X, K));
-			const FM w_ = weaken<FM>(mul(inv, pre[j], K));
+			const FM w_ = weaken<FM>(mul(inv, pre[2 * j], K));
 			inv = weaken<FM>(mul(inv, den, K));
 			const FM zpy = weaken<FM>(mulc(carry(add(Z, Y)), w_, K));          // (Z + Y) w
 			const FM um = weaken<FM>(mul(zpy, X, K));
@@ -2033,6 +2132,14 @@ hipError_t ecamd_launch_ed_smul_c25519(const EcamdEdSmulArgs &a, int gslot, hipS
 	return hipGetLastError();
 }
 
+hipError_t ecamd_launch_ed_decode_ed_c25519(const EcamdEdDecodeArgs &a, int gslot, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_ed_decode_ed_c25519, dim3((a.n + 63) / 64), dim3(64), 0, s, a, gslot);
+	return hipGetLastError();
+}
 hipError_t ecamd_launch_ed_decode_c25519(const EcamdEdDecodeArgs &a, int gslot, hipStream_t s)
 {
 	if (a.n == 0) {

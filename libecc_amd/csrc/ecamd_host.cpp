@@ -2437,7 +2437,16 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 		}
 		D.edA = (uint32_t *)S[10];
 	}
-	if (unit25519) {
+	// Edwards path: R's map to the Weierstrass model rides on the shared inversion of k_ed_hA_fin instead of costing the
+	// decode kernel an inversion per item (stage 19: R on the Edwards curve)
+	const bool late_map = edwards_hA && getenv("ECAMD_NO_ED_LATE_MAP") == nullptr;
+	if (late_map) {
+		if (ensure(&ctx->stage[19], &ctx->stage_bytes[19], (size_t)n * 20 * 4)) {
+			return -1;
+		}
+		D.edR = (uint32_t *)ctx->stage[19];
+		HIPCHK(ecamd_launch_ed_decode_ed_c25519(D, cv->gslot, s));
+	} else if (unit25519) {
 		HIPCHK(ecamd_launch_ed_decode_c25519(D, cv->gslot, s));  // the same decoding on the radix-2^29 field
 	} else {
 		HIPCHK(ecamd_launch_ed_decode(nw, D, s));
@@ -2470,6 +2479,11 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 		memcpy(E.g_2d, cv->ed_2d, sizeof(E.g_2d));
 		memcpy(E.g_alpha, cv->ed_tmpl.g_alpha, sizeof(E.g_alpha));
 		memcpy(E.g_A3, cv->ed_tmpl.g_A3, sizeof(E.g_A3));
+		if (late_map) {
+			E.edR = (const uint32_t *)ctx->stage[19];
+			E.flagsR = S[6];
+			E.outR = S[4];
+		}
 		HIPCHK(ecamd_launch_ed_smul_c25519(E, cv->gslot, s));
 	}
 	if ((!edwards_hA && smul_dev_locked(ctx, cv, n, S[9], (uint32_t)len, S[3], S[12], S[13], s)) ||

@@ -126,8 +126,12 @@ struct EcamdEdDecodeArgs {
 	uint32_t a[17], d[17], sm1[17], alpha[17], A3[17];  // Edwards a, d; sqrt(-1); alpha_edwards; A/3 (Montgomery form)
 	uint32_t g_d[9], g_sm1[9], g_alpha[9], g_A3[9];     // the same as plain radix-2^29 digits (2^255 - 19 unit)
 	uint32_t *edA;              // 2^255 - 19 unit only, may be NULL: n x 20 words, A on the Edwards curve (x, y digits)
+	uint32_t *edR;              // k_ed_decode_ed_c25519: n x 20 words, R on the Edwards curve (its map to the Weierstrass model
+	                            // waits for the shared inversion of k_ed_hA_fin)
 	int slot;
 };
+// decoding for the Edwards [h]A path: A and R stay on the Edwards curve (edA, edR), flags as above, no inversion here
+hipError_t ecamd_launch_ed_decode_ed_c25519(const EcamdEdDecodeArgs &a, int gslot, hipStream_t s);
 // [h]A on the Edwards curve (extended coordinates) and its map to the Weierstrass model (2^255 - 19 unit)
 struct EcamdEdSmulArgs {
 	const uint32_t *edA;     // n x 20 words (k_ed_decode_c25519)
@@ -138,6 +142,10 @@ struct EcamdEdSmulArgs {
 	uint8_t *out, *status;   // n x 64 affine Weierstrass big-endian, n (0 ok / 1 rejected key / 2 infinity)
 	uint32_t n;
 	uint32_t g_2d[9], g_alpha[9], g_A3[9];
+	// k_ed_hA_fin also maps R (decoded by k_ed_decode_ed_c25519) to the Weierstrass model with the same shared inversion:
+	const uint32_t *edR;     // n x 20 words, or NULL (R was mapped by the decode kernel)
+	uint8_t *flagsR;         // n: 0 / 1 / 2 as the decode kernels write them
+	uint8_t *outR;           // n x 64 affine Weierstrass big-endian
 };
 #define ECAMD_EDT_ITEM_WORDS 320
 #define ECAMD_EDR_REC_WORDS 28
