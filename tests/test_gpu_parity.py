@@ -1314,7 +1314,8 @@ def test_host_pipeline_multi_chunk(gpu_ctx):
 
 
 @pytest.mark.parametrize("env", ["ECAMD_NO_COMB", "ECAMD_NO_P25519", "ECAMD_NO_X25519_LADDER", "ECAMD_NO_EDWARDS_SMUL",
-                                 "ECAMD_NO_FAST_PATH", "ECAMD_NO_ISO", "ECAMD_NO_K256", "ECAMD_NO_P448"])
+                                 "ECAMD_NO_FAST_PATH", "ECAMD_NO_ISO", "ECAMD_NO_K256", "ECAMD_NO_P448",
+                                 "ECAMD_NO_ED_LATE_MAP", "ECAMD_NO_G448_DECODE", "ECAMD_NO_X448_LADDER"])
 def test_fallback_paths_stay_correct(env):
     """every fast path has a switch that routes around it (A/B measurements, fallbacks): the slower routes
     must give the same bytes -- fixed-base without the comb, WEI25519 on the dense field, X25519 and Ed25519
@@ -1353,6 +1354,12 @@ def test_fallback_paths_stay_correct(env):
                 assert pub == o.scalar_mult(sc)
                 sc2 = rand_bytes(rng, 56 * 40)
                 assert cv.scalar_mult(sc2, pub[0]) == o.scalar_mult(sc2, pub[0])
+                # X448 and Ed448 verification: front ends / ladder on the Goldilocks unit unless ECAMD_NO_G448_DECODE / _X448_LADDER
+                ek, eu = xdh_edge_inputs(56, rng)
+                assert cv.xdh(ek, eu) == o.xdh(ek, eu)
+                from test_oracle import ed448_cases
+                p4, s4, m4, h4 = ed448_cases(rng, 4)
+                assert cv.eddsa_verify(p4, s4, h4) == o.eddsa_verify(p4, s4, h4)
             finally:
                 cv.free()
             cv = ctx.curve("SECP256K1")             # pseudo-Mersenne field unless ECAMD_NO_K256
