@@ -1,4 +1,3 @@
-#define _GNU_SOURCE   /* sched_getaffinity, CPU_COUNT */
 /*
  * libecc_amd/compat/libecc_amd_compat.c -- the boundary in libecc's own types (include/libecc_amd_compat.h).
  *
@@ -10,7 +9,6 @@
  * File:line references are relative to /root/reference/src.
  */
 #include <pthread.h>
-#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -48,38 +46,6 @@ static void note_items(u32 n)
 
 unsigned long long ecamd_compat_gpu_items(void) { return g_items; }
 
-/* CPUs this process may actually use: the online count, cut by its affinity mask and by the container's CPU quota (cgroup v2
- * cpu.max "<quota> <period>" or "max") -- a box that shows 256 CPUs to a process allowed 16 would otherwise start 255 threads
- * per marshalling pass */
-static int usable_cpus(void)
-{
-	long n = sysconf(_SC_NPROCESSORS_ONLN);
-	cpu_set_t set;
-	FILE *f;
-	if (n < 1) {
-		n = 1;
-	}
-	if (sched_getaffinity(0, sizeof(set), &set) == 0) {
-		const int c = CPU_COUNT(&set);
-		if (c > 0 && c < n) {
-			n = c;
-		}
-	}
-	f = fopen("/sys/fs/cgroup/cpu.max", "r");
-	if (f) {
-		char q[32];
-		long period = 0;
-		if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
-			const long quota = atol(q) / period;
-			if (quota >= 1 && quota < n) {
-				n = quota;
-			}
-		}
-		fclose(f);
-	}
-	return (int)n;
-}
-
 static int compat_init_locked(const int *devices, int ndev, int host_threads)
 {
 	int devs[64], nd = 0;
@@ -105,7 +71,7 @@ static int compat_init_locked(const int *devices, int ndev, int host_threads)
 	}
 	if (host_threads <= 0) {
 		const char *e = getenv("ECAMD_COMPAT_THREADS");
-		host_threads = e ? atoi(e) : usable_cpus();
+		host_threads = e ? atoi(e) : (int)sysconf(_SC_NPROCESSORS_ONLN);
 	}
 	g_threads = host_threads < 1 ? 1 : (host_threads > 256 ? 256 : host_threads);
 	return 0;
