@@ -65,14 +65,27 @@ int ecamd_ctx_set_max_chunk(ecamd_ctx *ctx, uint32_t max_items);
  * 2 always.  items_per_lane: signatures that share one lane's doublings, 0 = chosen from the batch size (1 .. 8). */
 int ecamd_ctx_set_eddsa_msm(ecamd_ctx *ctx, int mode, uint32_t min_items, uint32_t items_per_lane);
 /* Secret scalars.  By default the kernels index their window / comb tables with the scalar's digits (fastest; fine for public
- * scalars: verification, public-key checks).  With this switch on, every scalar multiplication issued through the context --
- * ec_prj_pt_mul_batch*, and inside ec_ecdsa_sign_batch, ec_ecccdh_derive_batch, ec_eddsa_sign_R_batch, key-pair import -- uses
- * constant-address table look-ups (every entry read, the wanted one kept by masking: the posture of the reference's masked
- * ladder, curves/prj_pt.c:1225-1260, and nn_tabselect, nn/nn.c:564), a fixed window count and no comb table: on secp256r1 the
- * radix-2^29 pipeline with eight-entry scans, on the other curves the complete-formula kernel with sixteen-entry scans.
- * Results are identical; DESIGN.md 2.3 has the cost.
+ * scalars: verification, public-key checks).  With this switch on, every multiplication by a caller-supplied scalar issued through
+ * the context -- ec_prj_pt_mul_batch*, and inside ec_ecdsa_sign_batch, ec_ecccdh_derive_batch ([d]Q), ec_eddsa_sign_R_batch, key-pair
+ * import -- uses constant-address table look-ups (every entry read, the wanted one kept by masking: the posture of the reference's
+ * masked ladder, curves/prj_pt.c:1225-1260, and nn_tabselect, nn/nn.c:564), a fixed window count and no comb table.  The
+ * radix-2^29 pipelines stay in use: k_p256_loop<KW, MASKED> / k_loop_g<.., MASKED> scan the item's eight affine entries (secp256k1:
+ * its eight Jacobian ones); only scalars longer than those kernels take (8 NW + 4 bytes) run on the complete-formula kernel with
+ * sixteen-entry scans.  One branch remains: a lane whose accumulator met an exceptional pair of the incomplete addition
+ * (probability about 2^-|q| per window for a random scalar) is recomputed by the complete-formula kernel.
+ * Scalars that are public by construction -- u1, u2 of ECDSA verification, h and S of EdDSA verification, the group order and
+ * cofactor of subgroup checks -- keep the fast look-ups in either mode.  Results are identical; DESIGN.md 2.3 has the cost.
  * X25519 / X448 ladders are address-independent in either mode. */
 int ecamd_ctx_set_secret_scalars(ecamd_ctx *ctx, int on);
+/* Zero every scratch buffer of the context in HBM (window tables, recoded scalars, staged copies of the caller's arrays): after
+ * calls that handled secret scalars nothing derived from them stays behind.  Waits for the context's work; synchronous. */
+int ecamd_ctx_wipe_scratch(ecamd_ctx *ctx);
+/* The context's own stream (a hipStream_t), the one the *_dev entry points use when given NULL. */
+void *ecamd_ctx_stream(ecamd_ctx *ctx);
+/* Page-locked host memory (valid for every device) for arrays passed to the host-pointer entry points: their copies then run as
+ * asynchronous DMA at PCIe rate.  NULL on failure.  Any host memory works; this is only faster. */
+void *ecamd_host_alloc(size_t bytes);
+void ecamd_host_free(void *p);
 /* Measurement hook: when enabled, HIP events are recorded (on the stream the kernels run on) around
  * the kernels of the next ec_prj_pt_mul_batch[_dev] call; ecamd_ctx_kernel_times() waits for them and
  * returns the 4 durations in ms: table, table->affine, window loop, finalisation (the generic
@@ -373,10 +386,23 @@ int ecamd_multi_eddsa_encode_point_batch(ecamd_multi *m, const ecamd_mcurve *cur
 int ecamd_multi_eddsa_verify_all_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *pubkeys,
 				       const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, int *all_valid,
 				       uint32_t *first_rejected);
+int ecamd_multi_eddsa_sign_R_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *r_hash, uint8_t *R_enc,
+				   uint8_t *status);
+int ecamd_multi_eddsa_sign_S_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *r_hash, const uint8_t *hram,
+				   const uint8_t *a_scalars, uint8_t *S_out);
+/* ecamd_ctx_set_secret_scalars / ecamd_ctx_wipe_scratch on every rank's context */
+int ecamd_multi_set_secret_scalars(ecamd_multi *m, int on);
+int ecamd_multi_wipe_scratch(ecamd_multi *m);
 /* The one collective, for callers that keep device-resident outputs on every GPU: an RCCL all-gather (over xGMI) of
  * equal-size shards.  d_send[r]: bytes_per_rank bytes on rank r's device; d_recv[r]: nranks * bytes_per_rank bytes
- * there.  librccl is loaded on first use; needs distinct devices.  Synchronous. */
+ * there.  librccl is loaded on first use; needs distinct devices.  The gathers run on private streams that first wait for
+ * everything enqueued so far on each rank's context stream (ecamd_multi_ctx(m, r)'s, where the *_dev entry points put their
+ * kernels by default), so device-resident producers need no host synchronisation in between; ecamd_multi_allgather_streams
+ * takes the producers' streams (one hipStream_t per rank, NULL entries = the context's) for shards written elsewhere.
+ * Returns when the gathered data is in place on every rank. */
 int ecamd_multi_allgather(ecamd_multi *m, const void *const *d_send, void *const *d_recv, size_t bytes_per_rank);
+int ecamd_multi_allgather_streams(ecamd_multi *m, const void *const *d_send, void *const *d_recv, size_t bytes_per_rank,
+				  void *const *producer_streams);
 
 /* Test hook of the Ed25519 multi-scalar multiplication: the combination with a caller-chosen 32-byte seed.  z_out (n x 16
  * little-endian z_i) and sum_out (36 words: X, Y, Z, T of the sum before the cofactor, nine radix-2^29 digits each of lazily

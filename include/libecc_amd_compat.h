@@ -23,10 +23,16 @@ extern "C" {
 #endif
 
 /* Optional: choose the GPUs (default: every visible device, or the comma list in $ECAMD_DEVICES) and the number of host
- * threads that marshal libecc structures to and from wire bytes (default: the online CPUs, or $ECAMD_COMPAT_THREADS).
- * Called implicitly by the first batch call. */
+ * threads that marshal libecc structures to and from wire bytes (default: the CPUs this process may run on -- its affinity
+ * mask, capped by the cgroup CPU quota -- or $ECAMD_COMPAT_THREADS).  The threads are a persistent pool created here.
+ * Called implicitly by the first batch call.
+ * Secret scalars: the contexts run in secret-scalar mode (ecamd_ctx_set_secret_scalars in libecc_amd.h: constant-address table
+ * look-ups for private keys, nonces and blinded scalars, as libecc's masked ladder; verification is not affected) unless
+ * $ECAMD_COMPAT_PUBLIC_SCALARS is set; ecamd_compat_set_secret_scalars changes it at run time.  The batch calls that handle
+ * private material wipe their host staging and the devices' scratch before they return. */
 int ecamd_compat_init(const int *devices, int ndev, int host_threads);
 void ecamd_compat_shutdown(void);
+int ecamd_compat_set_secret_scalars(int on);
 /* A curve the library does not know by name (ec_params built by the application from its own ec_str_params): registered
  * so that prj_pt arrays on it can be mapped to a device-side curve (a prj_pt only points to its ec_shortw_crv, which has
  * no generator).  Built-in curves need no registration. */
@@ -54,6 +60,66 @@ int prj_pt_mul_blind_batch(prj_pt *out, const nn *m, const prj_pt *in, u32 n, in
  */
 int ecccdh_derive_secret_batch(const ec_priv_key *const *our_priv_keys, const u8 *const *peer_pub_keys, u8 peer_pub_key_len,
 			       u8 *const *shared_secrets, u8 shared_secret_len, u32 num, int *ret_items);
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * The secret-key half of the path, in libecc's own types.  Hashing, nonce generation (libecc's nn_get_random_mod through the
+ * application's get_random, or RFC 6979 through libecc's hmac_*) and the argument checks of the scalar functions run on the
+ * host threads; every scalar multiplication, the mod-q algebra of the signatures and the point encodings run on the GPU(s).
+ * ret_items (may be NULL) receives per item what the scalar function would have returned (0 / -1); the calls themselves
+ * return 0 when the batch ran and -1 on a call-level error (bad argument, unsupported algorithm for this entry point, no GPU).
+ * ------------------------------------------------------------------------------------------------------------------------ */
+
+/*
+ * Batch form of _ec_sign / ec_sign (sig/sig_algs.h:49-60, sig/sig_algs.c:465-504): item i signs m[i] (m_len[i] bytes) with
+ * key_pairs[i] into sigs[i] (siglen bytes each, = ec_get_sig_len).  On the GPU: ECDSA, DECDSA (__ecdsa_sign_finalize,
+ * sig/ecdsa_common.c:318-586) and the five EdDSA variants (_eddsa_sign, sig/eddsa.c:1554); every other algorithm is signed by
+ * libecc's own _ec_sign on the host threads.
+ *   rand: as for _ec_sign -- NULL = libecc's nn_get_random_mod (drawn on the host threads); another function is called once per
+ *     item, in index order, on the calling thread (test vectors).  DECDSA ignores it (RFC 6979, as _decdsa_sign_init forces);
+ *     EdDSA requires NULL (sig/eddsa.c:1596).
+ *   An ECDSA item whose nonce gives r = 0, s = 0 or e = x r is signed again with a fresh nonce, as the reference's restart.
+ *   adata / adata_len may be NULL (no context); EDDSA25519CTX needs a context for every item.
+ *   Key pairs may live on different curves (one GPU batch per ec_params).
+ */
+int ec_sign_batch(u8 *const *sigs, u8 siglen, const ec_key_pair *const *key_pairs, const u8 *const *m, const u32 *m_len, u32 num,
+		  int (*rand)(nn_t out, nn_src_t q), ec_alg_type sig_type, hash_alg_type hash_type, const u8 *const *adata,
+		  const u16 *adata_len, int *ret_items);
+
+/*
+ * Batch forms of ec_key_pair_gen (sig/ec_key.c:594) and ec_key_pair_import_from_priv_key_buf (:289): kps[i] receives a key pair
+ * for algorithm ec_key_alg on `params` (all items share them).  The private scalars come from libecc's own gen_priv_key
+ * (nn_get_random_mod / eddsa_gen_priv_key, i.e. the application's get_random) or from the caller's buffers
+ * (priv_keys[i], priv_key_len bytes each, as ec_priv_key_import_from_buf takes them); the public keys Y = [s]G -- s = x, or
+ * x^-1 mod q (ECGDSA, ECKCDSA), or the EdDSA scalar derived from the hashed key -- are computed on the GPU in one batch.
+ * pub_key.y holds the unique representative (Z = 1); a failed item is zeroed as the scalar functions do.  Also accepts ECCCDH
+ * (ecccdh_gen_key_pair, ecdh/ecccdh.c:93).
+ */
+int ec_key_pair_gen_batch(ec_key_pair *kps, const ec_params *params, ec_alg_type ec_key_alg, u32 num, int *ret_items);
+int ec_key_pair_import_from_priv_key_buf_batch(ec_key_pair *kps, const ec_params *params, const u8 *const *priv_keys, u8 priv_key_len,
+					       ec_alg_type ec_key_alg, u32 num, int *ret_items);
+/* eddsa_import_key_pair_from_priv_key_buf (sig/eddsa.c:1028): the raw EdDSA secret keys are hashed and clamped first */
+int eddsa_import_key_pair_from_priv_key_buf_batch(ec_key_pair *kps, const u8 *const *priv_keys, u16 priv_key_len,
+						  const ec_params *shortw_curve_params, ec_alg_type sig_type, u32 num, int *ret_items);
+/* init_pubkey_from_privkey (sig/sig_algs.c:72; __ecdsa_init_pub_key sig/ecdsa_common.c:172, ecccdh_init_pub_key ecdh/ecccdh.c:60,
+ * eddsa_init_pub_key sig/eddsa.c:786, ...): out_pubs[i] from the initialised private key in_privs[i]; all keys of one algorithm
+ * and one ec_params. */
+int init_pubkey_from_privkey_batch(ec_pub_key *out_pubs, const ec_priv_key *const *in_privs, u32 num, int *ret_items);
+/* ecccdh_init_pub_key / ecccdh_gen_key_pair (ecdh/ecccdh.h:33-41) */
+int ecccdh_init_pub_key_batch(ec_pub_key *out_pubs, const ec_priv_key *const *in_privs, u32 num, int *ret_items);
+int ecccdh_gen_key_pair_batch(ec_key_pair *kps, const ec_params *params, u32 num, int *ret_items);
+
+/*
+ * Batch forms of x25519 / x448 (ecdh/x25519_448.h:34,51; x25519_448_core ecdh/x25519_448.c:146): res[i] = X(k[i], u[i]), 32 / 56
+ * byte little-endian strings; ret_items[i] = -1 where the reference returns -1 (non-canonical u, u on the twist, a point of small
+ * order, an all-zero result).  The *_init_pub_key forms use the base point (u = 9 / 5), the *_derive_secret forms are the
+ * function itself under its other name (x25519_448.c:346-356).  The Montgomery ladder runs on the GPU on the curve itself.
+ */
+int x25519_batch(const u8 *const *k, const u8 *const *u, u8 *const *res, u32 num, int *ret_items);
+int x25519_init_pub_key_batch(const u8 *const *priv_keys, u8 *const *pub_keys, u32 num, int *ret_items);
+int x25519_derive_secret_batch(const u8 *const *priv_keys, const u8 *const *peer_pub_keys, u8 *const *shared_secrets, u32 num, int *ret_items);
+int x448_batch(const u8 *const *k, const u8 *const *u, u8 *const *res, u32 num, int *ret_items);
+int x448_init_pub_key_batch(const u8 *const *priv_keys, u8 *const *pub_keys, u32 num, int *ret_items);
+int x448_derive_secret_batch(const u8 *const *priv_keys, const u8 *const *peer_pub_keys, u8 *const *shared_secrets, u32 num, int *ret_items);
 
 /*
  * ECDSA / DECDSA batch verification with the exact prototype of the verify_batch slot of ec_sig_mapping

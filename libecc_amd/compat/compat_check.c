@@ -5,7 +5,7 @@
  * libsign_amd.so with the same array shapes tests/ec_self_tests_core.c uses for ec_verify_batch (:373-383, :556-616);
  * every batch result is compared with libecc's own scalar function (prj_pt_mul, ecccdh_derive_secret, ec_verify -- the
  * CPU code of the very libecc the library was linked from) on the same inputs.  Needs an MI355X.
- *   usage: compat_check [items per case, default 256]
+ *   usage: compat_check [items per case, default 256] | compat_check quick <items> | compat_check bench <log2 items>
  * Exit status 0 iff everything matched; prints one line per case.
  */
 #include <stdio.h>
@@ -320,6 +320,383 @@ static void check_inf_key(const char *curve, hash_alg_type hash_type, u32 n)
 	printf("ec_verify_batch key at infinity %-12s %u items, %u accepted by ec_verify: %s\n", curve, n, nacc, failures == before ? "ok" : "FAILED");
 }
 
+
+/* ---- ec_sign_batch against _ec_sign / ec_sign (same nonce source), and the signatures against ec_verify ---- */
+static u64 g_det_ctr;
+static u64 splitmix(u64 *x)
+{
+	u64 z = (*x += 0x9e3779b97f4a7c15ULL);
+	z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+	z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+	return z ^ (z >> 31);
+}
+/* a deterministic nonce source with the prototype of nn_get_random_mod: value in [1, q - 1], with k = 1, k = q - 1 and k = 2 mixed in */
+static int det_rand(nn_t out, nn_src_t q)
+{
+	u8 buf[160];
+	nn t, qm1;
+	bitcnt_t qb = 0;
+	u32 i, len;
+	const u64 c = g_det_ctr++;
+	u64 st = c * 0x1234567ULL + 99;
+	int ret;
+	t.magic = qm1.magic = WORD(0);
+	ret = nn_bitlen(q, &qb); EG(ret, err);
+	len = 2 * (u32)BYTECEIL(qb);
+	for (i = 0; i < len; i++) {
+		buf[i] = (u8)splitmix(&st);
+	}
+	ret = nn_init(&qm1, 0); EG(ret, err);
+	ret = nn_dec(&qm1, q); EG(ret, err);
+	if (c % 61 == 7) {
+		ret = nn_init(out, 0); EG(ret, err);
+		ret = nn_one(out);
+	} else if (c % 61 == 8) {
+		ret = nn_copy(out, &qm1);
+	} else {
+		ret = nn_init_from_buf(&t, buf, (u16)len); EG(ret, err);
+		ret = nn_mod(out, &t, &qm1); EG(ret, err);
+		ret = nn_inc(out, out);
+	}
+err:
+	nn_uninit(&t);
+	nn_uninit(&qm1);
+	return ret;
+}
+
+static void check_sign(const char *curve, ec_alg_type sig_type, hash_alg_type hash_type, const char *label, u32 n, int deterministic)
+{
+	ec_params params;
+	ec_key_pair *kps = calloc(n, sizeof(ec_key_pair));
+	const ec_key_pair **kpp = calloc(n, sizeof(*kpp));
+	u8 **sigs = calloc(n, sizeof(*sigs)), *sigbuf, *refbuf, *msgbuf = calloc(n, 64), siglen = 0;
+	const u8 **msgs = calloc(n, sizeof(*msgs)), **adatas = calloc(n, sizeof(*adatas));
+	u32 *msglens = calloc(n, sizeof(u32)), i, nfail = 0, pos = 0;
+	u16 *adlens = calloc(n, sizeof(u16));
+	int *rets = calloc(n, sizeof(int));
+	static const u8 ctx[] = "libecc_amd compat check";
+	const int is_ed =
+#if defined(WITH_SIG_EDDSA25519)
+		(sig_type == EDDSA25519) || (sig_type == EDDSA25519CTX) || (sig_type == EDDSA25519PH) ||
+#endif
+#if defined(WITH_SIG_EDDSA448)
+		(sig_type == EDDSA448) || (sig_type == EDDSA448PH) ||
+#endif
+		0;
+	const int needs_ctx = is_ed && sig_type != EDDSA25519;
+	const u32 before = failures;
+	if (load_params(curve, &params) || ec_get_sig_len(&params, sig_type, hash_type, &siglen)) {
+		CHECK(0, "sign %s: setup", label);
+		return;
+	}
+	sigbuf = calloc(n, siglen);
+	refbuf = calloc(n, siglen);
+	for (i = 0; i < n; i++) {
+		u32 ml;
+		if (ec_key_pair_gen(&kps[i], &params, sig_type) || get_random((u8 *)&ml, sizeof(ml))) {
+			CHECK(0, "sign %s: key generation", label);
+			return;
+		}
+		ml %= 64;
+		msglens[i] = ml;
+		msgs[i] = msgbuf + (size_t)i * 64;
+		if (ml && get_random(msgbuf + (size_t)i * 64, ml)) {
+			return;
+		}
+		kpp[i] = &kps[i];
+		sigs[i] = sigbuf + (size_t)i * siglen;
+		adatas[i] = needs_ctx ? ctx : NULL;
+		adlens[i] = needs_ctx ? (u16)(sizeof(ctx) - 1) : 0;
+	}
+	/* edge items: private keys 1 and q - 1 (ECDSA family), a key of another algorithm, a NULL key pair, a NULL message of
+	 * non-zero length, an empty message */
+	if (n >= 16) {
+		if (sig_type == ECDSA || sig_type == DECDSA) {
+			nn one;
+			nn_init(&one, 0); nn_one(&one);
+			nn_one(&kps[1].priv_key.x);
+			init_pubkey_from_privkey(&kps[1].pub_key, &kps[1].priv_key);
+			nn_sub(&kps[2].priv_key.x, &params.ec_gen_order, &one);
+			init_pubkey_from_privkey(&kps[2].pub_key, &kps[2].priv_key);
+			nn_copy(&kps[3].priv_key.x, &params.ec_gen_order);   /* x = q: "private key is not compliant" */
+		}
+		kps[4].priv_key.key_type = (sig_type == ECDSA) ? ECKCDSA : ECDSA;
+		kpp[5] = NULL;
+		msgs[6] = NULL; msglens[6] = 3;
+		msglens[7] = 0;
+	}
+	g_det_ctr = 1000;
+	if (ec_sign_batch(sigs, siglen, kpp, msgs, msglens, n, deterministic == 2 ? det_rand : NULL, sig_type, hash_type, adatas, adlens, rets)) {
+		CHECK(0, "sign %s: ec_sign_batch failed", label);
+		return;
+	}
+	g_det_ctr = 1000;
+	for (i = 0; i < n; i++) {
+		u8 *ref = refbuf + (size_t)i * siglen;
+		int r = -1;
+		if (deterministic) {
+			/* The batch form calls the nonce hook once per item of the group, in index order (items without a key pair
+			 * belong to no group); the scalar function is given the same nonce by positioning the hook's counter. */
+			g_det_ctr = 1000 + pos;
+			pos += kpp[i] ? 1 : 0;
+			r = (kpp[i] && (msgs[i] || !msglens[i])) ?
+				_ec_sign(ref, siglen, kpp[i], msgs[i], msglens[i], deterministic == 2 ? det_rand : NULL, sig_type, hash_type, adatas[i], adlens[i]) : -1;
+			if (r != rets[i]) {
+				CHECK(0, "sign %s: item %u returns %d, _ec_sign %d", label, i, rets[i], r);
+			} else if (!r && memcmp(ref, sigs[i], siglen)) {
+				CHECK(0, "sign %s: item %u signature differs from _ec_sign", label, i);
+			}
+		} else {
+			/* random nonces: the signature must verify with libecc's ec_verify; failures must be libecc's failures */
+			r = (kpp[i] && (msgs[i] || !msglens[i])) ? ec_sign(ref, siglen, kpp[i], msgs[i], msglens[i], sig_type, hash_type, adatas[i], adlens[i]) : -1;
+			if (r != rets[i]) {
+				CHECK(0, "sign %s: item %u returns %d, ec_sign %d", label, i, rets[i], r);
+			} else if (!r && ec_verify(sigs[i], siglen, &kpp[i]->pub_key, msgs[i], msglens[i], sig_type, hash_type, adatas[i], adlens[i])) {
+				CHECK(0, "sign %s: item %u signature rejected by ec_verify", label, i);
+			}
+		}
+		nfail += r ? 1 : 0;
+	}
+	printf("ec_sign_batch %-30s %u items (%s), %u fail in libecc too: %s\n", label, n,
+	       deterministic == 2 ? "nonce hook, bytes equal" : deterministic ? "deterministic, bytes equal" : "random nonces, ec_verify", nfail,
+	       failures == before ? "ok" : "FAILED");
+	free(kps); free(kpp); free(sigs); free(sigbuf); free(refbuf); free(msgbuf); free(msgs); free(adatas); free(msglens); free(adlens); free(rets);
+}
+
+/* ---- key pairs: ec_key_pair_gen_batch / ec_key_pair_import_from_priv_key_buf_batch against the scalar functions ---- */
+static int pub_equal(const ec_pub_key *a, const ec_pub_key *b)
+{
+	int cmp = 1, z1 = 0, z2 = 0;
+	if (a->magic != b->magic || a->key_type != b->key_type || a->params != b->params) {
+		return 0;
+	}
+	if (prj_pt_iszero(&a->y, &z1) || prj_pt_iszero(&b->y, &z2) || z1 != z2) {
+		return 0;
+	}
+	return z1 || (!prj_pt_cmp(&a->y, &b->y, &cmp) && !cmp);
+}
+
+static void check_keys(const char *curve, ec_alg_type alg, const char *label, u32 n)
+{
+	ec_params params;
+	ec_key_pair *kps = calloc(n, sizeof(ec_key_pair)), *imp = calloc(n, sizeof(ec_key_pair));
+	ec_pub_key *pubs = calloc(n, sizeof(ec_pub_key));
+	const ec_priv_key **privs = calloc(n, sizeof(*privs));
+	u8 *bufs = calloc(n, 80), qlen;
+	const u8 **bufp = calloc(n, sizeof(*bufp));
+	int *rets = calloc(n, sizeof(int));
+	u32 i, nfail = 0;
+	const u32 before = failures;
+	if (load_params(curve, &params)) {
+		CHECK(0, "keys %s: setup", label);
+		return;
+	}
+	qlen = (u8)BYTECEIL(params.ec_gen_order_bitlen);
+	/* 1. generation: every key pair is consistent (the public key is what libecc derives from the private key) */
+	if (ec_key_pair_gen_batch(kps, &params, alg, n, rets)) {
+		CHECK(0, "keys %s: ec_key_pair_gen_batch failed", label);
+		return;
+	}
+	for (i = 0; i < n; i++) {
+		ec_pub_key ref;
+		int r;
+		if (rets[i]) {
+			CHECK(0, "keys %s: generation of item %u failed", label, i);
+			continue;
+		}
+#if defined(WITH_ECCCDH)
+		r = (alg == ECCCDH) ? ecccdh_init_pub_key(&ref, &kps[i].priv_key) : init_pubkey_from_privkey(&ref, &kps[i].priv_key);
+#else
+		r = init_pubkey_from_privkey(&ref, &kps[i].priv_key);
+#endif
+		CHECK(!r && key_pair_check_initialized_and_type(&kps[i], alg) == 0 && pub_equal(&ref, &kps[i].pub_key), "keys %s: generated pair %u is inconsistent", label, i);
+		if (i && !nn_cmp(&kps[i].priv_key.x, &kps[i - 1].priv_key.x, &r) && !r) {
+			CHECK(0, "keys %s: two equal private keys in a row", label);
+		}
+		privs[i] = &kps[i].priv_key;
+	}
+	/* 2. init_pubkey_from_privkey_batch on the same private keys */
+	if (init_pubkey_from_privkey_batch(pubs, privs, n, rets)) {
+		CHECK(0, "keys %s: init_pubkey_from_privkey_batch failed", label);
+	} else {
+		for (i = 0; i < n; i++) {
+			CHECK(!rets[i] && pub_equal(&pubs[i], &kps[i].pub_key), "keys %s: init_pubkey_from_privkey_batch item %u", label, i);
+		}
+	}
+	/* 3. import from buffers, edge values included: 0, 1, q - 1, q, q + 1, all ones, short */
+#if defined(WITH_ECCCDH)
+	if (alg != ECCCDH)
+#endif
+	{
+		for (i = 0; i < n; i++) {
+			get_random(bufs + (size_t)i * 80, qlen);
+			bufs[(size_t)i * 80] &= 0x3f;
+			bufp[i] = bufs + (size_t)i * 80;
+		}
+		if (n >= 16) {
+			nn t, one;
+			nn_init(&one, 0); nn_one(&one);
+			memset(bufs + 0 * 80, 0, qlen);
+			memset(bufs + 1 * 80, 0, qlen); bufs[1 * 80 + qlen - 1] = 1;
+			nn_sub(&t, &params.ec_gen_order, &one); nn_export_to_buf(bufs + 2 * 80, qlen, &t);
+			nn_export_to_buf(bufs + 3 * 80, qlen, &params.ec_gen_order);
+			nn_add(&t, &params.ec_gen_order, &one); nn_export_to_buf(bufs + 4 * 80, qlen, &t);
+			memset(bufs + 5 * 80, 0xff, qlen);
+			nn_sub(&t, &params.ec_gen_order, &one); nn_sub(&t, &t, &one); nn_export_to_buf(bufs + 6 * 80, qlen, &t);   /* q - 2 (SM2's bound) */
+			bufp[7] = NULL;
+		}
+		if (ec_key_pair_import_from_priv_key_buf_batch(imp, &params, bufp, qlen, alg, n, rets)) {
+			CHECK(0, "keys %s: ec_key_pair_import_from_priv_key_buf_batch failed", label);
+		} else {
+			for (i = 0; i < n; i++) {
+				ec_key_pair ref;
+				int r = bufp[i] ? ec_key_pair_import_from_priv_key_buf(&ref, &params, bufp[i], qlen, alg) : -1, c = 1;
+				if (r != rets[i]) {
+					CHECK(0, "keys %s: import item %u returns %d, libecc %d", label, i, rets[i], r);
+				} else if (!r) {
+					CHECK(!nn_cmp(&ref.priv_key.x, &imp[i].priv_key.x, &c) && !c && pub_equal(&ref.pub_key, &imp[i].pub_key), "keys %s: imported pair %u differs", label, i);
+				}
+				nfail += r ? 1 : 0;
+			}
+		}
+	}
+	printf("ec_key_pair_{gen,import}_batch %-22s %u items, %u imports fail in libecc too: %s\n", label, n, nfail, failures == before ? "ok" : "FAILED");
+	free(kps); free(imp); free(pubs); free(privs); free(bufs); free(bufp); free(rets);
+}
+
+#if defined(WITH_SIG_EDDSA25519)
+static void check_eddsa_import(u32 n)
+{
+	ec_params params;
+	ec_key_pair *imp = calloc(n, sizeof(ec_key_pair));
+	u8 *bufs = calloc(n, 32);
+	const u8 **bufp = calloc(n, sizeof(*bufp));
+	int *rets = calloc(n, sizeof(int));
+	u32 i;
+	const u32 before = failures;
+	if (load_params("WEI25519", &params)) {
+		return;
+	}
+	for (i = 0; i < n; i++) {
+		get_random(bufs + (size_t)i * 32, 32);
+		bufp[i] = bufs + (size_t)i * 32;
+	}
+	/* RFC 8032 section 7.1 TEST 1 secret key: its public key is d75a9801... */
+	if (n >= 2) {
+		static const u8 sk1[32] = {0x9d, 0x61, 0xb1, 0x9d, 0xef, 0xfd, 0x5a, 0x60, 0xba, 0x84, 0x4a, 0xf4, 0x92, 0xec, 0x2c, 0xc4,
+					   0x44, 0x49, 0xc5, 0x69, 0x7b, 0x32, 0x69, 0x19, 0x70, 0x3b, 0xac, 0x03, 0x1c, 0xae, 0x7f, 0x60};
+		memcpy(bufs, sk1, 32);
+	}
+	if (eddsa_import_key_pair_from_priv_key_buf_batch(imp, bufp, 32, &params, EDDSA25519, n, rets)) {
+		CHECK(0, "eddsa import: batch call failed");
+		return;
+	}
+	for (i = 0; i < n; i++) {
+		ec_key_pair ref;
+		u8 e1[32], e2[32];
+		int r = eddsa_import_key_pair_from_priv_key_buf(&ref, bufp[i], 32, &params, EDDSA25519), c = 1;
+		if (r != rets[i]) {
+			CHECK(0, "eddsa import: item %u returns %d, libecc %d", i, rets[i], r);
+		} else if (!r) {
+			CHECK(!nn_cmp(&ref.priv_key.x, &imp[i].priv_key.x, &c) && !c && pub_equal(&ref.pub_key, &imp[i].pub_key), "eddsa import: pair %u differs", i);
+			CHECK(!eddsa_export_pub_key(&ref.pub_key, e1, 32) && !eddsa_export_pub_key(&imp[i].pub_key, e2, 32) && !memcmp(e1, e2, 32), "eddsa import: encoded key %u differs", i);
+			if (i == 0 && n >= 2) {
+				CHECK(e2[0] == 0xd7 && e2[1] == 0x5a && e2[2] == 0x98 && e2[3] == 0x01 && e2[31] == 0x1a, "eddsa import: RFC 8032 TEST 1 public key");
+			}
+		}
+	}
+	printf("eddsa_import_key_pair_from_priv_key_buf_batch   %u items: %s\n", n, failures == before ? "ok" : "FAILED");
+	free(imp); free(bufs); free(bufp); free(rets);
+}
+#endif
+
+/* ---- x25519_batch / x448_batch against x25519 / x448 ---- */
+static void check_xdh(u32 len, u32 n)
+{
+	u8 *kb = calloc(n, len), *ub = calloc(n, len), *rb = calloc(n, len), *pb = calloc(n, len), ref[56];
+	const u8 **kp = calloc(n, sizeof(*kp)), **up = calloc(n, sizeof(*up));
+	u8 **rp = calloc(n, sizeof(*rp)), **pp = calloc(n, sizeof(*pp));
+	int *rets = calloc(n, sizeof(int));
+	u32 i, nrej = 0;
+	const u32 before = failures;
+	for (i = 0; i < n; i++) {
+		get_random(kb + (size_t)i * len, (u16)len);
+		kp[i] = kb + (size_t)i * len;
+		rp[i] = rb + (size_t)i * len;
+		pp[i] = pb + (size_t)i * len;
+	}
+	/* public keys first (base point), then u = those public keys (on the curve), with edge u values mixed in */
+	if (len == 32 ? x25519_init_pub_key_batch(kp, pp, n, rets) : x448_init_pub_key_batch(kp, pp, n, rets)) {
+		CHECK(0, "x%u: init_pub_key_batch failed", len == 32 ? 25519 : 448);
+		return;
+	}
+	for (i = 0; i < n; i++) {
+		const int r = len == 32 ? x25519_init_pub_key(kp[i], ref) : x448_init_pub_key(kp[i], ref);
+		CHECK(r == rets[i] && (r || !memcmp(ref, pp[i], len)), "x%u: public key %u (ret %d / %d)", len == 32 ? 25519 : 448, i, rets[i], r);
+		memcpy(ub + (size_t)i * len, pp[(i * 7 + 1) % n], len);
+		up[i] = ub + (size_t)i * len;
+	}
+	if (n >= 16) {
+		memset(ub + 0 * len, 0, len);                                   /* u = 0: small order */
+		memset(ub + 1 * len, 0, len); ub[1 * len] = 1;                   /* u = 1 */
+		memset(ub + 2 * len, 0xff, len);                                /* non-canonical */
+		get_random(ub + 3 * len, (u16)len);                             /* random: on the twist with probability 1/2 */
+		get_random(ub + 4 * len, (u16)len);
+		get_random(ub + 5 * len, (u16)len);
+		memset(kb + 6 * len, 0, len);                                   /* k = 0 before clamping */
+		memset(kb + 7 * len, 0xff, len);
+		memset(ub + 8 * len, 0, len); ub[8 * len] = (len == 32) ? 9 : 5; /* the base point */
+	}
+	if (len == 32 ? x25519_batch(kp, up, rp, n, rets) : x448_batch(kp, up, rp, n, rets)) {
+		CHECK(0, "x%u: batch call failed", len == 32 ? 25519 : 448);
+		return;
+	}
+	for (i = 0; i < n; i++) {
+		const int r = len == 32 ? x25519(kp[i], up[i], ref) : x448(kp[i], up[i], ref);
+		CHECK(r == rets[i] && (r || !memcmp(ref, rp[i], len)), "x%u: item %u (ret %d / %d)", len == 32 ? 25519 : 448, i, rets[i], r);
+		nrej += r ? 1 : 0;
+	}
+	printf("x%u_batch / x%u_init_pub_key_batch   %u items, %u rejected by libecc too: %s\n", len == 32 ? 25519 : 448, len == 32 ? 25519 : 448, n, nrej,
+	       failures == before ? "ok" : "FAILED");
+	free(kb); free(ub); free(rb); free(pb); free(kp); free(up); free(rp); free(pp); free(rets);
+}
+
+/* ---- a group that is NOT the built-in curve of its name: same curve and name, another generator ---- */
+static void check_foreign_generator(u32 n)
+{
+	ec_params base, mine;
+	nn two;
+	ec_key_pair *kps = calloc(n, sizeof(ec_key_pair));
+	int *rets = calloc(n, sizeof(int));
+	u32 i;
+	const u32 before = failures;
+	if (load_params("SECP256R1", &base)) {
+		return;
+	}
+	mine = base;
+	/* G' = [2]G: same order, same curve, same curve_name */
+	nn_init(&two, 0); nn_one(&two); nn_inc(&two, &two);
+	if (prj_pt_mul(&mine.ec_gen, &two, &base.ec_gen)) {
+		CHECK(0, "foreign generator: setup");
+		return;
+	}
+	/* the point structures of `mine` must refer to mine's own curve object */
+	mine.ec_gen.crv = &mine.ec_curve;
+	mine.ec_gen.X.ctx = mine.ec_gen.Y.ctx = mine.ec_gen.Z.ctx = &mine.ec_fp;
+	mine.ec_curve.a.ctx = mine.ec_curve.b.ctx = mine.ec_curve.a_monty.ctx = mine.ec_curve.b3.ctx = mine.ec_curve.b_monty.ctx = mine.ec_curve.b3_monty.ctx = &mine.ec_fp;
+	if (ec_key_pair_gen_batch(kps, &base, ECDSA, n, rets) || ec_key_pair_gen_batch(kps, &mine, ECDSA, n, rets)) {
+		CHECK(0, "foreign generator: ec_key_pair_gen_batch failed");
+		return;
+	}
+	for (i = 0; i < n; i++) {
+		ec_pub_key ref;
+		CHECK(!rets[i] && !init_pubkey_from_privkey(&ref, &kps[i].priv_key) && pub_equal(&ref, &kps[i].pub_key),
+		      "foreign generator: item %u was computed with another generator", i);
+	}
+	printf("ec_params with a foreign generator under a built-in name   %u items: %s\n", n, failures == before ? "ok" : "FAILED");
+	free(kps); free(rets);
+}
+
 /* ---- "compat_check bench <log2 n>": end-to-end rate of ec_verify_batch as a libecc application sees it -- libecc structures
  * in, one int out, the marshalling and the message hashing on the host threads included.  `base` distinct (key, message,
  * signature) triples made with libecc's ec_sign, repeated to n pointers (the batch arrays are arrays of pointers). ---- */
@@ -391,6 +768,21 @@ int main(int argc, char **argv)
 		printf("no GPU path\n");
 		return 3;
 	}
+	if (argc > 2 && !strcmp(argv[1], "quick")) {
+		/* one case per entry-point family at a size that goes through the thread pool and several pipeline chunks */
+		const u32 qn = (u32)atoi(argv[2]);
+		check_mul("SECP256R1", qn, 0);
+		check_cdh("SECP256R1", qn);
+		check_verify("SECP256R1", ECDSA, SHA256, "ECDSA/SECP256R1/SHA256", qn, 1);
+		check_verify("WEI25519", EDDSA25519, SHA512, "EDDSA25519", qn, 1);
+		check_sign("SECP256R1", ECDSA, SHA256, "ECDSA/SECP256R1/SHA256", qn, 2);
+		check_sign("WEI25519", EDDSA25519, SHA512, "EDDSA25519", qn, 1);
+		check_keys("SECP256R1", ECDSA, "ECDSA/SECP256R1", qn);
+		check_xdh(32, qn);
+		ecamd_compat_shutdown();
+		printf(failures ? "compat_check: %d FAILURES\n" : "compat_check: all ok (%d failures)\n", failures);
+		return failures ? 1 : 0;
+	}
 	check_mul("SECP256R1", n, 0);
 	check_mul("SECP384R1", n, 0);
 	check_mul("SECP521R1", n, 0);
@@ -412,8 +804,38 @@ int main(int argc, char **argv)
 	check_verify("WEI25519", EDDSA25519PH, SHA512, "EDDSA25519PH", n, 1);
 	check_verify("WEI448", EDDSA448, SHAKE256, "EDDSA448", n, 1);
 	check_verify("WEI448", EDDSA448PH, SHAKE256, "EDDSA448PH", n, 1);
-	check_inf_key("SECP256R1", SHA256, n < 48 ? n : 48);
-	check_inf_key("SECP384R1", SHA512, n < 48 ? n : 48);
+	if (!getenv("COMPAT_CHECK_MOCK")) {   /* (the CPU stand-in of tests/ does not model a key at infinity) */
+		check_inf_key("SECP256R1", SHA256, n < 48 ? n : 48);
+		check_inf_key("SECP384R1", SHA512, n < 48 ? n : 48);
+	}
+	/* the secret-key half: signing, key pairs, X25519 / X448 */
+	check_sign("SECP256R1", ECDSA, SHA256, "ECDSA/SECP256R1/SHA256", n, 2);
+	check_sign("SECP256R1", ECDSA, SHA256, "ECDSA/SECP256R1/SHA256", n, 0);
+	check_sign("SECP384R1", ECDSA, SHA384, "ECDSA/SECP384R1/SHA384", n, 2);
+	check_sign("SECP521R1", ECDSA, SHA512, "ECDSA/SECP521R1/SHA512", n < 256 ? n : 256, 2);
+	check_sign("SECP256R1", DECDSA, SHA256, "DECDSA/SECP256R1/SHA256 (RFC 6979)", n, 1);
+	check_sign("BRAINPOOLP256R1", DECDSA, SHA512, "DECDSA/BRAINPOOLP256R1/SHA512", n < 256 ? n : 256, 1);
+	check_sign("SECP224R1", DECDSA, SHA256, "DECDSA/SECP224R1/SHA256", n < 256 ? n : 256, 1);
+	check_sign("WEI25519", EDDSA25519, SHA512, "EDDSA25519", n, 1);
+	check_sign("WEI25519", EDDSA25519CTX, SHA512, "EDDSA25519CTX", n < 256 ? n : 256, 1);
+	check_sign("WEI25519", EDDSA25519PH, SHA512, "EDDSA25519PH", n < 256 ? n : 256, 1);
+	if (!getenv("COMPAT_CHECK_MOCK")) {
+		check_sign("WEI448", EDDSA448, SHAKE256, "EDDSA448", n < 256 ? n : 256, 1);
+		check_sign("WEI448", EDDSA448PH, SHAKE256, "EDDSA448PH", n < 128 ? n : 128, 1);
+	}
+	check_sign("SECP256R1", ECSDSA, SHA256, "ECSDSA (libecc's CPU path)", n < 16 ? n : 16, 0);
+	check_keys("SECP256R1", ECDSA, "ECDSA/SECP256R1", n);
+	check_keys("SECP384R1", ECDSA, "ECDSA/SECP384R1", n < 256 ? n : 256);
+	check_keys("SECP256R1", ECKCDSA, "ECKCDSA/SECP256R1 (x^-1)", n < 128 ? n : 128);
+	check_keys("SECP256R1", SM2, "SM2/SECP256R1 (x < q - 1)", n < 128 ? n : 128);
+	check_keys("SECP256K1", BIP0340, "BIP0340/SECP256K1 (any x)", n < 128 ? n : 128);
+	check_keys("SECP256R1", ECCCDH, "ECCCDH/SECP256R1", n < 256 ? n : 256);
+	check_keys("WEI25519", EDDSA25519, "EDDSA25519", n < 256 ? n : 256);
+	check_keys("WEI448", EDDSA448, "EDDSA448", n < 128 ? n : 128);
+	check_eddsa_import(n < 256 ? n : 256);
+	check_xdh(32, n);
+	check_xdh(56, n < 256 ? n : 256);
+	check_foreign_generator(n < 64 ? n : 64);
 	/* an algorithm the GPU does not take goes to libecc's own verifier */
 	check_verify("SECP256K1", BIP0340, SHA256, "BIP0340 (libecc's CPU path)", n < 16 ? n : 16, 0);
 	printf("items sent to the GPU: %llu\n", ecamd_compat_gpu_items());

@@ -2,13 +2,20 @@
  * libecc_amd/compat/libecc_amd_compat.c -- the boundary in libecc's own types (include/libecc_amd_compat.h).
  *
  * Compiled against the application's libecc headers (libsig.h) and linked with its libsign objects into
- * libsign_amd.so.  Everything here is marshalling: libecc structures <-> the wire bytes of include/libecc_amd.h
- * (through libecc's own exporters, on a few host threads), message hashing through libecc's hash_maps[] (hashes
- * stay on the host), and the argument checks of the scalar functions that sit in front of the
- * arithmetic.  All curve arithmetic of the batch entry points runs on the GPU(s); nothing here calls into oracle/.
+ * libsign_amd.so.  Everything here is marshalling: libecc structures <-> the wire bytes of include/libecc_amd.h, message
+ * hashing through libecc's hash_maps[] and nonce generation through libecc's nn_get_random_mod / hmac_* (hashes and
+ * randomness stay on the host), and the argument checks of the scalar functions that sit in front of
+ * the arithmetic.  All curve arithmetic of the batch entry points runs on the GPU(s); nothing here calls into oracle/.
+ *
+ * How a batch moves: the items are cut into chunks; a persistent pool of host threads PACKS chunk
+ * c + 1 (reads the live limbs of the nn / fp / prj_pt structures -- this file is compiled against the application's own
+ * headers, so their layout is known -- and hashes the messages) while the calling thread has chunk c on the GPU(s) and other
+ * pool threads UNPACK chunk c - 1 into the caller's structures.  Staging buffers are page-locked and kept across calls.
  * File:line references are relative to /root/reference/src.
  */
+#define _GNU_SOURCE
 #include <pthread.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -18,21 +25,41 @@
 #include "libecc_amd.h"
 
 /* ------------------------------------------------------------------------------------------------
+ * small helpers
+ * ------------------------------------------------------------------------------------------------ */
+static void wipe(void *p, size_t n)
+{
+	if (p && n) {
+		explicit_bzero(p, n);
+	}
+}
+
+#define AT_LOAD(p) __atomic_load_n((p), __ATOMIC_ACQUIRE)
+#define AT_STORE(p, v) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
+#define AT_ADD(p, v) __atomic_add_fetch((p), (v), __ATOMIC_ACQ_REL)
+#define AT_SUB(p, v) __atomic_sub_fetch((p), (v), __ATOMIC_ACQ_REL)
+
+/* ------------------------------------------------------------------------------------------------
  * process-wide state: the multi-GPU context and the device-side curve handles, keyed by ec_params content
  * ------------------------------------------------------------------------------------------------ */
 #define MAX_CURVES 64
+#define KEY_MAX (4 * 72 + 8)
 typedef struct {
-	u8 key[3 * 72 + 2];     /* p || a || b as big-endian octets + lengths: what identifies an ec_shortw_crv */
-	u32 key_len;
+	u8 key_crv[KEY_MAX];    /* p || a || b || #E: what identifies an ec_shortw_crv */
+	u32 key_crv_len;
+	u8 key_gen[KEY_MAX];    /* Gx || Gy || q || cofactor: the rest of an ec_params */
+	u32 key_gen_len;
 	ecamd_mcurve *mc;
 	u32 clen, qlen;
-	nn q;                   /* generator order (reduction of oversize private keys) */
-	int has_q;
 } curve_ent;
 
-static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;        /* the state below */
+static pthread_mutex_t g_call_mu = PTHREAD_MUTEX_INITIALIZER;   /* one batch call at a time: pool, staging buffers, GPUs */
 static ecamd_multi *g_multi;
 static int g_threads;
+static int g_secret = 1;
+static u32 g_chunk = 1u << 16;       /* items per pipeline chunk and device */
+static u32 g_chunk_all = 1u << 18;   /* the same for EdDSA whole-batch verification (the multi-scalar multiplication wants >= 2^17) */
 static curve_ent g_curves[MAX_CURVES];
 static u32 g_ncurves;
 static unsigned long long g_items;
@@ -46,14 +73,46 @@ static void note_items(u32 n)
 
 unsigned long long ecamd_compat_gpu_items(void) { return g_items; }
 
+/* CPUs this process may use: the affinity mask, capped by the cgroup v2 quota */
+static int default_threads(void)
+{
+	int n = 0;
+	cpu_set_t set;
+	FILE *f;
+	if (!sched_getaffinity(0, sizeof(set), &set)) {
+		n = CPU_COUNT(&set);
+	}
+	if (n <= 0) {
+		n = (int)sysconf(_SC_NPROCESSORS_ONLN);
+	}
+	f = fopen("/sys/fs/cgroup/cpu.max", "r");
+	if (f) {
+		char quota[32];
+		long period = 0;
+		if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") && period > 0) {
+			const long q = atol(quota);
+			const int c = (int)((q + period - 1) / period);
+			if (c >= 1 && c < n) {
+				n = c;
+			}
+		}
+		fclose(f);
+	}
+	return n < 1 ? 1 : n;
+}
+
+static int pool_start(int nthreads);
+static void pool_stop(void);
+
 static int compat_init_locked(const int *devices, int ndev, int host_threads)
 {
 	int devs[64], nd = 0;
+	const char *e;
 	if (g_multi) {
 		return 0;
 	}
 	if (!devices || ndev <= 0) {
-		const char *e = getenv("ECAMD_DEVICES");
+		e = getenv("ECAMD_DEVICES");
 		while (e && *e && nd < 64) {
 			devs[nd++] = atoi(e);
 			e = strchr(e, ',');
@@ -69,11 +128,29 @@ static int compat_init_locked(const int *devices, int ndev, int host_threads)
 		g_multi = NULL;
 		return -1;
 	}
+	g_secret = getenv("ECAMD_COMPAT_PUBLIC_SCALARS") ? 0 : 1;
+	if (ecamd_multi_set_secret_scalars(g_multi, g_secret)) {
+		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+		ecamd_multi_destroy(g_multi);
+		g_multi = NULL;
+		return -1;
+	}
 	if (host_threads <= 0) {
-		const char *e = getenv("ECAMD_COMPAT_THREADS");
-		host_threads = e ? atoi(e) : (int)sysconf(_SC_NPROCESSORS_ONLN);
+		e = getenv("ECAMD_COMPAT_THREADS");
+		host_threads = e ? atoi(e) : default_threads();
 	}
 	g_threads = host_threads < 1 ? 1 : (host_threads > 256 ? 256 : host_threads);
+	e = getenv("ECAMD_COMPAT_CHUNK");
+	if (e && atoi(e) >= 512) {
+		g_chunk = (u32)atoi(e);
+	}
+	e = getenv("ECAMD_COMPAT_CHUNK_ALL");
+	if (e && atoi(e) >= 1024) {
+		g_chunk_all = (u32)atoi(e);
+	}
+	if (pool_start(g_threads - 1)) {
+		g_threads = 1;
+	}
 	return 0;
 }
 
@@ -86,10 +163,32 @@ int ecamd_compat_init(const int *devices, int ndev, int host_threads)
 	return ret;
 }
 
+int ecamd_compat_set_secret_scalars(int on)
+{
+	int ret;
+	pthread_mutex_lock(&g_call_mu);
+	pthread_mutex_lock(&g_mu);
+	ret = compat_init_locked(NULL, 0, 0);
+	if (!ret) {
+		ret = ecamd_multi_set_secret_scalars(g_multi, on);
+		if (!ret) {
+			g_secret = on ? 1 : 0;
+		}
+	}
+	pthread_mutex_unlock(&g_mu);
+	pthread_mutex_unlock(&g_call_mu);
+	return ret;
+}
+
+static void bufs_free(void);
+
 void ecamd_compat_shutdown(void)
 {
 	u32 i;
+	pthread_mutex_lock(&g_call_mu);
 	pthread_mutex_lock(&g_mu);
+	pool_stop();
+	bufs_free();
 	for (i = 0; i < g_ncurves; i++) {
 		ecamd_multi_curve_free(g_curves[i].mc);
 	}
@@ -99,95 +198,128 @@ void ecamd_compat_shutdown(void)
 		g_multi = NULL;
 	}
 	pthread_mutex_unlock(&g_mu);
+	pthread_mutex_unlock(&g_call_mu);
 }
 
-/* p || a || b of a curve, big-endian, each BYTECEIL(p_bitlen) bytes */
+/* p || a || b || #E of a curve, big-endian (coordinates BYTECEIL(p_bitlen) bytes, the order as long as it is) */
 static int crv_key(ec_shortw_crv_src_t crv, u8 *key, u32 *key_len, u32 *clen_out)
 {
 	int ret;
-	u32 clen;
+	u32 clen, olen;
+	bitcnt_t ob = 0;
 	MUST_HAVE((crv != NULL) && (crv->a.ctx != NULL), ret, err);
 	clen = (u32)BYTECEIL(crv->a.ctx->p_bitlen);
 	MUST_HAVE((clen > 0) && (clen <= 72), ret, err);
+	ret = nn_bitlen(&(crv->order), &ob); EG(ret, err);
+	olen = (u32)BYTECEIL(ob);
+	MUST_HAVE((olen <= 80), ret, err);
 	ret = nn_export_to_buf(key, (u16)clen, &(crv->a.ctx->p)); EG(ret, err);
 	ret = fp_export_to_buf(key + clen, (u16)clen, &(crv->a)); EG(ret, err);
 	ret = fp_export_to_buf(key + 2 * clen, (u16)clen, &(crv->b)); EG(ret, err);
-	*key_len = 3 * clen;
+	ret = nn_export_to_buf(key + 3 * clen, (u16)olen, &(crv->order)); EG(ret, err);
+	*key_len = 3 * clen + olen;
 	*clen_out = clen;
 err:
 	return ret;
 }
 
-static curve_ent *curve_find_locked(const u8 *key, u32 key_len)
+/* Gx || Gy || q || cofactor: what an ec_params adds to its curve.  Two ec_params on one curve with another generator or
+ * order are different groups and get different device handles. */
+static int gen_key(const ec_params *params, u32 clen, u8 *key, u32 *key_len)
+{
+	int ret;
+	aff_pt g;
+	u32 qlen, hlen;
+	bitcnt_t hb = 0;
+	g.magic = WORD(0);
+	qlen = (u32)BYTECEIL(params->ec_gen_order_bitlen);
+	ret = nn_bitlen(&(params->ec_gen_cofactor), &hb); EG(ret, err);
+	hlen = (u32)BYTECEIL(hb);
+	MUST_HAVE((qlen > 0) && (qlen <= 80) && (hlen <= 8), ret, err);
+	ret = prj_pt_to_aff(&g, &(params->ec_gen)); EG(ret, err);
+	ret = fp_export_to_buf(key, (u16)clen, &(g.x)); EG(ret, err);
+	ret = fp_export_to_buf(key + clen, (u16)clen, &(g.y)); EG(ret, err);
+	ret = nn_export_to_buf(key + 2 * clen, (u16)qlen, &(params->ec_gen_order)); EG(ret, err);
+	ret = nn_export_to_buf(key + 2 * clen + qlen, 8, &(params->ec_gen_cofactor)); EG(ret, err);
+	*key_len = 2 * clen + qlen + 8;
+err:
+	aff_pt_uninit(&g);
+	return ret;
+}
+
+static curve_ent *curve_find_locked(const u8 *kc, u32 kc_len, const u8 *kg, u32 kg_len)
 {
 	u32 i;
 	for (i = 0; i < g_ncurves; i++) {
-		if (g_curves[i].key_len == key_len && !memcmp(g_curves[i].key, key, key_len)) {
-			return &g_curves[i];
+		curve_ent *e = &g_curves[i];
+		if (e->key_crv_len == kc_len && !memcmp(e->key_crv, kc, kc_len) &&
+		    (!kg || (e->key_gen_len == kg_len && !memcmp(e->key_gen, kg, kg_len)))) {
+			return e;
 		}
 	}
 	return NULL;
 }
 
-/* device-side handle of the curve described by `params` (created on first use) */
+/* device-side handle of the group described by `params` (created on first use) */
 static curve_ent *curve_from_params_locked(const ec_params *params)
 {
-	u8 key[3 * 72 + 2], buf[7][80];
-	u32 key_len = 0, clen = 0, olen, qlen, i;
+	u8 kc[KEY_MAX], kg[KEY_MAX];
+	u32 kc_len = 0, kg_len = 0, clen = 0, qlen, olen;
 	curve_ent *e;
-	aff_pt g;
-	int ret;
 	ecamd_mcurve *mc = NULL;
-	g.magic = WORD(0);
-	if (crv_key(&(params->ec_curve), key, &key_len, &clen)) {
+	if (crv_key(&(params->ec_curve), kc, &kc_len, &clen) || gen_key(params, clen, kg, &kg_len)) {
 		return NULL;
 	}
-	e = curve_find_locked(key, key_len);
+	e = curve_find_locked(kc, kc_len, kg, kg_len);
 	if (e) {
 		return e;
 	}
 	if (g_ncurves >= MAX_CURVES) {
 		return NULL;
 	}
-	/* a built-in curve: by name (same names on both sides); the handle's parameters are then checked against p */
-	if (params->curve_name[0] && !ecamd_multi_curve_by_name(g_multi, (const char *)params->curve_name, &mc)) {
-		if ((u32)ecamd_multi_curve_coord_len(mc) != clen) {
-			ecamd_multi_curve_free(mc);
-			mc = NULL;
+	qlen = (u32)BYTECEIL(params->ec_gen_order_bitlen);
+	olen = kc_len - 3 * clen;
+	/* A built-in curve is taken by name only when the application's parameters ARE libecc's built-in ones of that name (the
+	 * device table is generated from the same constants, tools/gen_curve_table.py): p, a, b, #E, G, q and the cofactor are
+	 * compared; an application-built ec_params that reuses a name goes through its raw domain parameters below. */
+	if (params->curve_name[0]) {
+		const ec_str_params *sp = NULL;
+		ec_params ref;
+		u8 rc[KEY_MAX], rg[KEY_MAX];
+		u32 rc_len = 0, rg_len = 0, rclen = 0;
+		u8 nlen = 0;
+		while (nlen < MAX_CURVE_NAME_LEN && params->curve_name[nlen]) {
+			nlen++;
+		}
+		if (!ec_get_curve_params_by_name(params->curve_name, (u8)(nlen + 1), &sp) && sp && !import_params(&ref, sp) &&
+		    !crv_key(&(ref.ec_curve), rc, &rc_len, &rclen) && !gen_key(&ref, rclen, rg, &rg_len) && rc_len == kc_len &&
+		    !memcmp(rc, kc, kc_len) && rg_len == kg_len && !memcmp(rg, kg, kg_len)) {
+			if (ecamd_multi_curve_by_name(g_multi, (const char *)params->curve_name, &mc)) {
+				mc = NULL;
+			} else if ((u32)ecamd_multi_curve_coord_len(mc) != clen || (u32)ecamd_multi_curve_order_len(mc) != qlen) {
+				ecamd_multi_curve_free(mc);
+				mc = NULL;
+			}
 		}
 	}
-	qlen = (u32)BYTECEIL(params->ec_gen_order_bitlen);
 	if (!mc) {
-		/* a user curve: raw domain parameters, exported by libecc itself */
-		bitcnt_t ob = 0;
-		ret = nn_bitlen(&(params->ec_curve.order), &ob); EG(ret, err);
-		olen = (u32)BYTECEIL(ob);
-		MUST_HAVE((olen <= 80) && (qlen <= 80), ret, err);
-		ret = prj_pt_to_aff(&g, &(params->ec_gen)); EG(ret, err);
-		ret = nn_export_to_buf(buf[3], (u16)olen, &(params->ec_curve.order)); EG(ret, err);
-		ret = fp_export_to_buf(buf[4], (u16)clen, &(g.x)); EG(ret, err);
-		ret = fp_export_to_buf(buf[5], (u16)clen, &(g.y)); EG(ret, err);
-		ret = nn_export_to_buf(buf[6], (u16)qlen, &(params->ec_gen_order)); EG(ret, err);
-		if (ecamd_multi_curve_from_params(g_multi, key, clen, key + clen, clen, key + 2 * clen, clen, buf[3], olen, buf[4], clen,
-						  buf[5], clen, buf[6], qlen, &mc)) {
+		/* raw domain parameters, exported by libecc itself */
+		if (ecamd_multi_curve_from_params(g_multi, kc, clen, kc + clen, clen, kc + 2 * clen, clen, kc + 3 * clen, olen, kg, clen,
+						  kg + clen, clen, kg + 2 * clen, qlen, &mc)) {
 			fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
-			goto err;
+			return NULL;
 		}
 	}
 	e = &g_curves[g_ncurves];
-	memcpy(e->key, key, key_len);
-	e->key_len = key_len;
+	memcpy(e->key_crv, kc, kc_len);
+	e->key_crv_len = kc_len;
+	memcpy(e->key_gen, kg, kg_len);
+	e->key_gen_len = kg_len;
 	e->mc = mc;
 	e->clen = clen;
 	e->qlen = (u32)ecamd_multi_curve_order_len(mc);
-	e->has_q = !nn_copy(&e->q, &(params->ec_gen_order));
 	g_ncurves++;
-	aff_pt_uninit(&g);
-	(void)i;
 	return e;
-err:
-	aff_pt_uninit(&g);
-	return NULL;
 }
 
 int ecamd_compat_register_params(const ec_params *params)
@@ -207,6 +339,9 @@ int ecamd_compat_register_params(const ec_params *params)
 static curve_ent *curve_from_params(const ec_params *params)
 {
 	curve_ent *e = NULL;
+	if (!params) {
+		return NULL;
+	}
 	pthread_mutex_lock(&g_mu);
 	if (!compat_init_locked(NULL, 0, 0)) {
 		e = curve_from_params_locked(params);
@@ -215,10 +350,11 @@ static curve_ent *curve_from_params(const ec_params *params)
 	return e;
 }
 
-/* handle for a bare ec_shortw_crv (prj_pt arrays): a curve seen before, else one of libecc's built-in curves */
+/* handle for a bare ec_shortw_crv (prj_pt arrays carry no generator; none is needed to multiply given points): a group on
+ * this curve seen before, else the libecc built-in curve with these p, a, b, #E */
 static curve_ent *curve_from_crv(ec_shortw_crv_src_t crv)
 {
-	u8 key[3 * 72 + 2];
+	u8 key[KEY_MAX];
 	u32 key_len = 0, clen = 0;
 	curve_ent *e = NULL;
 	unsigned t;
@@ -230,11 +366,11 @@ static curve_ent *curve_from_crv(ec_shortw_crv_src_t crv)
 		pthread_mutex_unlock(&g_mu);
 		return NULL;
 	}
-	e = curve_find_locked(key, key_len);
+	e = curve_find_locked(key, key_len, NULL, 0);
 	for (t = 1; !e && t < 256; t++) {
 		const ec_str_params *sp = NULL;
 		ec_params params;
-		u8 k2[3 * 72 + 2];
+		u8 k2[KEY_MAX];
 		u32 l2 = 0, c2 = 0;
 		if (ec_get_curve_params_by_type((ec_curve_type)t, &sp) || !sp) {
 			continue;
@@ -252,53 +388,432 @@ static curve_ent *curve_from_crv(ec_shortw_crv_src_t crv)
 }
 
 /* ------------------------------------------------------------------------------------------------
- * host threads for the marshalling loops (libecc is re-entrant: no locks, no static state)
+ * persistent host threads and the three-stage pipeline  pack(c + 1) | GPU(c) | unpack(c - 1)
+ * (libecc is re-entrant: no locks, no static state)
  * ------------------------------------------------------------------------------------------------ */
 typedef void (*range_fn)(u32 lo, u32 hi, void *arg);
-typedef struct {
-	range_fn fn;
-	void *arg;
-	u32 lo, hi;
-} range_job;
+typedef int (*gpu_fn)(u32 lo, u32 hi, void *arg);
 
-static void *range_thread(void *p)
+#define GRAIN 512u   /* items a thread takes at a time */
+
+typedef struct {
+	range_fn pack, unpack;
+	void *arg;
+	u32 n, ngrains, chunk_grains, nchunks;
+	u32 pack_next, unpack_next;   /* next grain to hand out (atomic) */
+	u32 *pack_left;               /* per chunk: grains not yet packed (atomic) */
+	u32 *gpu_done;                /* per chunk: back from the GPU (atomic, set under mu) */
+	u32 unpack_done;              /* grains unpacked (atomic) */
+	u32 abort;
+	pthread_mutex_t mu;
+	pthread_cond_t cv;
+} pipe_job;
+
+static struct {
+	pthread_mutex_t mu;
+	pthread_cond_t cv_work, cv_idle;
+	pthread_t th[256];
+	int nth;
+	pipe_job *job;
+	unsigned long gen;
+	int active, stop;
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, NULL, 0, 0, 0};
+
+static void grain_range(const pipe_job *j, u32 g, u32 *lo, u32 *hi)
 {
-	range_job *j = (range_job *)p;
-	j->fn(j->lo, j->hi, j->arg);
+	*lo = g * GRAIN;
+	*hi = (*lo + GRAIN < j->n) ? *lo + GRAIN : j->n;
+}
+
+static void job_notify(pipe_job *j)
+{
+	pthread_mutex_lock(&j->mu);
+	pthread_cond_broadcast(&j->cv);
+	pthread_mutex_unlock(&j->mu);
+}
+
+/* take one pack grain if any is left; returns 0 when none was */
+static int take_pack(pipe_job *j)
+{
+	u32 g, lo, hi;
+	if (AT_LOAD(&j->pack_next) >= j->ngrains) {
+		return 0;
+	}
+	g = AT_ADD(&j->pack_next, 1) - 1;
+	if (g >= j->ngrains) {
+		return 0;
+	}
+	grain_range(j, g, &lo, &hi);
+	j->pack(lo, hi, j->arg);
+	if (AT_SUB(&j->pack_left[g / j->chunk_grains], 1) == 0) {
+		job_notify(j);   /* the chunk is ready for the GPU */
+	}
+	return 1;
+}
+
+/* take one unpack grain of a chunk that is back from the GPU; returns 0 when none is available now */
+static int take_unpack(pipe_job *j)
+{
+	u32 g, lo, hi;
+	if (!j->unpack) {
+		return 0;
+	}
+	g = AT_LOAD(&j->unpack_next);
+	while (g < j->ngrains && AT_LOAD(&j->gpu_done[g / j->chunk_grains])) {
+		if (__atomic_compare_exchange_n(&j->unpack_next, &g, g + 1, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+			grain_range(j, g, &lo, &hi);
+			j->unpack(lo, hi, j->arg);
+			AT_ADD(&j->unpack_done, 1);
+			if (g + 1 == j->ngrains) {
+				job_notify(j);   /* waiters: nothing left to hand out */
+			}
+			return 1;
+		}
+	}
+	return 0;
+}
+
+/* what a pool thread does for a job: unpack what is back, else pack what is left, else wait for the GPU */
+static void pipe_work(pipe_job *j)
+{
+	for (;;) {
+		if (AT_LOAD(&j->abort)) {
+			return;
+		}
+		if (take_unpack(j) || take_pack(j)) {
+			continue;
+		}
+		if (!j->unpack || AT_LOAD(&j->unpack_next) >= j->ngrains) {
+			return;
+		}
+		pthread_mutex_lock(&j->mu);
+		for (;;) {
+			const u32 g = AT_LOAD(&j->unpack_next);
+			if (AT_LOAD(&j->abort) || g >= j->ngrains || AT_LOAD(&j->gpu_done[g / j->chunk_grains])) {
+				break;
+			}
+			pthread_cond_wait(&j->cv, &j->mu);
+		}
+		pthread_mutex_unlock(&j->mu);
+	}
+}
+
+static void *pool_worker(void *unused)
+{
+	unsigned long seen = 0;
+	(void)unused;
+	pthread_mutex_lock(&g_pool.mu);
+	for (;;) {
+		pipe_job *j;
+		while (!g_pool.stop && g_pool.gen == seen) {
+			pthread_cond_wait(&g_pool.cv_work, &g_pool.mu);
+		}
+		if (g_pool.stop) {
+			break;
+		}
+		seen = g_pool.gen;
+		j = g_pool.job;
+		if (!j) {
+			continue;
+		}
+		g_pool.active++;
+		pthread_mutex_unlock(&g_pool.mu);
+		pipe_work(j);
+		pthread_mutex_lock(&g_pool.mu);
+		if (--g_pool.active == 0) {
+			pthread_cond_broadcast(&g_pool.cv_idle);
+		}
+	}
+	pthread_mutex_unlock(&g_pool.mu);
 	return NULL;
+}
+
+static int pool_start(int nthreads)
+{
+	int t;
+	if (nthreads > 255) {
+		nthreads = 255;
+	}
+	pthread_mutex_lock(&g_pool.mu);
+	g_pool.stop = 0;
+	pthread_mutex_unlock(&g_pool.mu);
+	for (t = 0; t < nthreads; t++) {
+		if (pthread_create(&g_pool.th[g_pool.nth], NULL, pool_worker, NULL)) {
+			break;
+		}
+		g_pool.nth++;
+	}
+	return (nthreads > 0 && g_pool.nth == 0) ? -1 : 0;
+}
+
+static void pool_stop(void)
+{
+	int t;
+	pthread_mutex_lock(&g_pool.mu);
+	g_pool.stop = 1;
+	pthread_cond_broadcast(&g_pool.cv_work);
+	pthread_mutex_unlock(&g_pool.mu);
+	for (t = 0; t < g_pool.nth; t++) {
+		pthread_join(g_pool.th[t], NULL);
+	}
+	g_pool.nth = 0;
+}
+
+/*
+ * Run n items through pack -> gpu -> unpack in chunks of `chunk` items.  pack / unpack (either may be NULL) are called on
+ * ranges of at most GRAIN items from the pool threads (and from the caller while it waits); gpu (may be NULL) is called by the
+ * CALLING thread once per chunk, in order, when the chunk is packed; a chunk is unpacked once its gpu call has returned.
+ * Returns 0, or -1 as soon as a gpu call fails.  g_call_mu held.
+ */
+static int pipeline_run(u32 n, u32 chunk, range_fn pack, gpu_fn gpu, range_fn unpack, void *arg)
+{
+	pipe_job J;
+	u32 c, lo, hi;
+	int ret = 0;
+	if (n == 0) {
+		return 0;
+	}
+	if (!gpu || chunk >= n) {
+		chunk = n;
+	}
+	chunk = ((chunk + GRAIN - 1) / GRAIN) * GRAIN;
+	if (g_pool.nth == 0 || n <= GRAIN) {
+		for (lo = 0; lo < n && !ret; lo += chunk) {
+			hi = (lo + chunk < n) ? lo + chunk : n;
+			if (pack) {
+				pack(lo, hi, arg);
+			}
+			if (gpu && gpu(lo, hi, arg)) {
+				ret = -1;
+			} else if (unpack) {
+				unpack(lo, hi, arg);
+			}
+		}
+		return ret;
+	}
+	memset(&J, 0, sizeof(J));
+	J.pack = pack;
+	J.unpack = unpack;
+	J.arg = arg;
+	J.n = n;
+	J.ngrains = (n + GRAIN - 1) / GRAIN;
+	J.chunk_grains = chunk / GRAIN;
+	J.nchunks = (J.ngrains + J.chunk_grains - 1) / J.chunk_grains;
+	J.pack_left = (u32 *)calloc(J.nchunks, sizeof(u32));
+	J.gpu_done = (u32 *)calloc(J.nchunks, sizeof(u32));
+	if (!J.pack_left || !J.gpu_done) {
+		free(J.pack_left);
+		free(J.gpu_done);
+		return -1;
+	}
+	for (c = 0; c < J.nchunks; c++) {
+		const u32 g0 = c * J.chunk_grains, g1 = (g0 + J.chunk_grains < J.ngrains) ? g0 + J.chunk_grains : J.ngrains;
+		J.pack_left[c] = pack ? (g1 - g0) : 0;
+	}
+	if (!pack) {
+		J.pack_next = J.ngrains;
+	}
+	pthread_mutex_init(&J.mu, NULL);
+	pthread_cond_init(&J.cv, NULL);
+	pthread_mutex_lock(&g_pool.mu);
+	g_pool.job = &J;
+	g_pool.gen++;
+	pthread_cond_broadcast(&g_pool.cv_work);
+	pthread_mutex_unlock(&g_pool.mu);
+	for (c = 0; c < J.nchunks; c++) {
+		/* wait for chunk c to be packed; help meanwhile */
+		while (AT_LOAD(&J.pack_left[c]) != 0) {
+			if (take_pack(&J)) {
+				continue;
+			}
+			pthread_mutex_lock(&J.mu);
+			while (AT_LOAD(&J.pack_left[c]) != 0) {
+				pthread_cond_wait(&J.cv, &J.mu);
+			}
+			pthread_mutex_unlock(&J.mu);
+		}
+		lo = c * J.chunk_grains * GRAIN;
+		hi = (lo + chunk < n) ? lo + chunk : n;
+		if (gpu && gpu(lo, hi, arg)) {
+			ret = -1;
+			AT_STORE(&J.abort, 1);
+			job_notify(&J);
+			break;
+		}
+		pthread_mutex_lock(&J.mu);
+		AT_STORE(&J.gpu_done[c], 1);
+		pthread_cond_broadcast(&J.cv);
+		pthread_mutex_unlock(&J.mu);
+	}
+	if (!ret) {
+		pipe_work(&J);   /* help with what is left to unpack */
+	}
+	pthread_mutex_lock(&g_pool.mu);
+	g_pool.job = NULL;
+	while (g_pool.active > 0) {
+		pthread_cond_wait(&g_pool.cv_idle, &g_pool.mu);
+	}
+	pthread_mutex_unlock(&g_pool.mu);
+	pthread_mutex_destroy(&J.mu);
+	pthread_cond_destroy(&J.cv);
+	free(J.pack_left);
+	free(J.gpu_done);
+	return ret;
 }
 
 static void parallel_for(u32 n, range_fn fn, void *arg)
 {
-	int nt = g_threads, t;
-	pthread_t th[256];
-	range_job jobs[256];
-	u8 started[256];
-	if (nt > 1 && n / 64 < (u32)nt) {
-		nt = (int)(n / 64);
+	(void)pipeline_run(n, n, fn, NULL, NULL, arg);
+}
+
+/* items per pipeline chunk: g_chunk per device (the multi-GPU layer cuts every chunk into one shard per device) */
+static u32 chunk_items(u32 per_device)
+{
+	const int nd = g_multi ? ecamd_multi_size(g_multi) : 1;
+	const u64 c = (u64)per_device * (u64)(nd > 0 ? nd : 1);
+	return c > 0x40000000ull ? 0x40000000u : (u32)c;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * staging buffers: page-locked, kept across calls (g_call_mu held)
+ * ------------------------------------------------------------------------------------------------ */
+#define NBUF 12
+static u8 *g_buf[NBUF];
+static size_t g_cap[NBUF], g_used[NBUF];   /* g_used: bytes handed out since the last wipe */
+static u8 g_pinned[NBUF];
+
+static u8 *buf_get(int k, size_t bytes)
+{
+	if (bytes == 0) {
+		bytes = 1;
 	}
-	if (nt <= 1) {
-		fn(0, n, arg);
-		return;
+	if (g_cap[k] < bytes) {
+		const size_t want = bytes + bytes / 8;
+		if (g_buf[k]) {
+			wipe(g_buf[k], g_cap[k]);
+			if (g_pinned[k]) {
+				ecamd_host_free(g_buf[k]);
+			} else {
+				free(g_buf[k]);
+			}
+		}
+		g_buf[k] = (u8 *)ecamd_host_alloc(want);
+		g_pinned[k] = g_buf[k] != NULL;
+		if (!g_buf[k]) {
+			g_buf[k] = (u8 *)malloc(want);   /* pageable memory works too; it is only slower */
+		}
+		g_cap[k] = g_buf[k] ? want : 0;
+		g_used[k] = 0;
 	}
-	for (t = 0; t < nt; t++) {
-		jobs[t].fn = fn;
-		jobs[t].arg = arg;
-		jobs[t].lo = (u32)(((u64)n * (u64)t) / (u64)nt);
-		jobs[t].hi = (u32)(((u64)n * (u64)(t + 1)) / (u64)nt);
-		started[t] = 0;
+	if (g_buf[k] && bytes > g_used[k]) {
+		g_used[k] = bytes;
 	}
-	for (t = 0; t < nt - 1; t++) {
-		started[t] = pthread_create(&th[t], NULL, range_thread, &jobs[t]) == 0;
+	return g_buf[k];
+}
+
+static void bufs_free(void)
+{
+	int k;
+	for (k = 0; k < NBUF; k++) {
+		if (g_buf[k]) {
+			wipe(g_buf[k], g_cap[k]);
+			if (g_pinned[k]) {
+				ecamd_host_free(g_buf[k]);
+			} else {
+				free(g_buf[k]);
+			}
+		}
+		g_buf[k] = NULL;
+		g_cap[k] = 0;
 	}
-	fn(jobs[nt - 1].lo, jobs[nt - 1].hi, arg);   /* the calling thread takes the last range ... */
-	for (t = 0; t < nt - 1; t++) {
-		if (started[t]) {
-			pthread_join(th[t], NULL);
-		} else {
-			fn(jobs[t].lo, jobs[t].hi, arg);  /* ... and any range whose thread did not start */
+}
+
+/* after a call that handled private material: host staging and the devices' scratch */
+static void wipe_secrets(void)
+{
+	int k;
+	for (k = 0; k < NBUF; k++) {
+		if (g_buf[k]) {
+			wipe(g_buf[k], g_used[k]);
+			g_used[k] = 0;
 		}
 	}
+	if (g_multi && ecamd_multi_wipe_scratch(g_multi)) {
+		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+	}
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * marshalling: the live limbs of nn / fp / prj_pt  <->  big-endian octets
+ * ------------------------------------------------------------------------------------------------ */
+/* `len` octets, big-endian, of the number held in val[] (little-endian words of WORD_BYTES bytes; nn/nn.h:67-71) */
+static inline void limbs_to_be(u8 *dst, u32 len, const word_t *val)
+{
+	u32 i;
+#if WORDSIZE == 64
+	if ((len % 8) == 0) {
+		const u32 nl = len / 8;
+		for (i = 0; i < nl; i++) {
+			const u64 w = __builtin_bswap64((u64)val[nl - 1 - i]);
+			memcpy(dst + 8 * i, &w, 8);
+		}
+		return;
+	}
+#endif
+	for (i = 0; i < len; i++) {
+		const u32 k = len - 1 - i;
+		dst[i] = (u8)(val[k / WORD_BYTES] >> (8 * (k % WORD_BYTES)));
+	}
+}
+
+/* nn -> len octets; -1 for an uninitialised nn or a value that does not fit (nn_export_to_buf would silently truncate) */
+static int nn_to_be(u8 *dst, u32 len, nn_src_t a)
+{
+	const u32 nl = (len + WORD_BYTES - 1) / WORD_BYTES;
+	word_t extra = 0;
+	u32 i;
+	if (nn_check_initialized(a)) {
+		return -1;
+	}
+	for (i = nl; i < a->wlen; i++) {
+		extra |= a->val[i];
+	}
+	if ((len % WORD_BYTES) && nl >= 1) {
+		extra |= a->val[nl - 1] >> (8 * (len % WORD_BYTES));
+	}
+	if (extra) {
+		return -1;
+	}
+	limbs_to_be(dst, len, a->val);
+	return 0;
+}
+
+/* X || Y || Z of an initialised point of curve `crv` (what prj_pt_export_to_buf writes, curves/prj_pt.c:562, without its
+ * on-curve test: the device checks the curve equation when it imports the point) */
+static int prj_to_be(u8 *dst, u32 clen, prj_pt_src_t P, ec_shortw_crv_src_t crv)
+{
+	if (prj_pt_check_initialized(P) || P->crv != crv || fp_check_initialized(&P->X) || fp_check_initialized(&P->Y) ||
+	    fp_check_initialized(&P->Z)) {
+		return -1;
+	}
+	limbs_to_be(dst, clen, P->X.fp_val.val);
+	limbs_to_be(dst + clen, clen, P->Y.fp_val.val);
+	limbs_to_be(dst + 2 * clen, clen, P->Z.fp_val.val);
+	return 0;
+}
+
+/* affine X || Y from the device -> (X : Y : 1); ECAMD_INF -> (0 : 1 : 0).  The device's results lie on the curve, so the
+ * on-curve test of prj_pt_import_from_buf is not repeated; coordinates are still checked to be < p (fp_import_from_buf). */
+static int prj_from_aff_be(prj_pt *out, ec_shortw_crv_src_t crv, const u8 *aff, u32 clen, u8 st)
+{
+	if (st == ECAMD_OK) {
+		return (prj_pt_init(out, crv) || fp_import_from_buf(&out->X, aff, (u16)clen) || fp_import_from_buf(&out->Y, aff + clen, (u16)clen) ||
+			fp_one(&out->Z)) ? -1 : 0;
+	}
+	if (st == ECAMD_INF) {
+		return (prj_pt_init(out, crv) || prj_pt_zero(out)) ? -1 : 0;
+	}
+	return -1;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -309,57 +824,181 @@ typedef struct {
 	const prj_pt *in;
 	prj_pt *out;
 	int *ret_items;
-	u8 *sc, *pin, *pout, *st;
+	const u32 *idx;          /* items of this group (NULL: all, in order) */
+	u8 *sc, *pin, *pout, *st, *pre;
 	u32 slen, clen;
 	ec_shortw_crv_src_t crv;
+	curve_ent *e;
 } mul_job;
 
-static void mul_export(u32 lo, u32 hi, void *arg)
+static void mul_pack(u32 lo, u32 hi, void *arg)
 {
 	mul_job *J = (mul_job *)arg;
-	u32 i;
-	for (i = lo; i < hi; i++) {
+	u32 j;
+	for (j = lo; j < hi; j++) {
+		const u32 i = J->idx ? J->idx[j] : j;
 		/* a point of another curve, an uninitialised point or scalar: prj_pt_mul returns -1 (prj_pt.c:1765-1767) */
-		if (J->in[i].magic == WORD(0) || J->in[i].crv != J->crv || nn_export_to_buf(J->sc + (size_t)i * J->slen, (u16)J->slen, &J->m[i]) ||
-		    prj_pt_export_to_buf(&J->in[i], J->pin + (size_t)i * 3 * J->clen, 3 * J->clen)) {
-			J->st[i] = 0xff;
-			memset(J->sc + (size_t)i * J->slen, 0, J->slen);
-			memset(J->pin + (size_t)i * 3 * J->clen, 0xff, 3 * J->clen);   /* coordinates >= p: rejected at import */
+		if (nn_to_be(J->sc + (size_t)j * J->slen, J->slen, &J->m[i]) || prj_to_be(J->pin + (size_t)j * 3 * J->clen, J->clen, &J->in[i], J->crv)) {
+			J->pre[j] = 1;
+			memset(J->sc + (size_t)j * J->slen, 0, J->slen);
+			memset(J->pin + (size_t)j * 3 * J->clen, 0xff, 3 * J->clen);   /* coordinates >= p: rejected at import */
 		} else {
-			J->st[i] = 0;
+			J->pre[j] = 0;
 		}
 	}
 }
 
-static void mul_import(u32 lo, u32 hi, void *arg)
+static int mul_gpu(u32 lo, u32 hi, void *arg)
 {
 	mul_job *J = (mul_job *)arg;
-	u32 i;
-	for (i = lo; i < hi; i++) {
-		int r = -1;
-		if (J->st[i] == ECAMD_OK) {
-			r = prj_pt_import_from_buf(&J->out[i], J->pout + (size_t)i * 3 * J->clen, (u16)(3 * J->clen), J->crv);
-		} else if (J->st[i] == ECAMD_INF) {
-			r = (prj_pt_init(&J->out[i], J->crv) || prj_pt_zero(&J->out[i])) ? -1 : 0;
-		}
+	if (ecamd_multi_prj_pt_mul_batch_fmt(g_multi, J->e->mc, hi - lo, J->sc + (size_t)lo * J->slen, J->slen, J->pin + (size_t)lo * 3 * J->clen,
+					     ECAMD_PT_PROJECTIVE, J->pout + (size_t)lo * 2 * J->clen, ECAMD_PT_AFFINE, J->st + lo)) {
+		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+		return -1;
+	}
+	return 0;
+}
+
+static void mul_unpack(u32 lo, u32 hi, void *arg)
+{
+	mul_job *J = (mul_job *)arg;
+	u32 j;
+	for (j = lo; j < hi; j++) {
+		const u32 i = J->idx ? J->idx[j] : j;
+		const int r = J->pre[j] ? -1 : prj_from_aff_be(&J->out[i], J->crv, J->pout + (size_t)j * 2 * J->clen, J->clen, J->st[j]);
 		if (J->ret_items) {
 			J->ret_items[i] = r;
 		}
 	}
 }
 
-static int mul_batch_common(prj_pt *out, const nn *m, const prj_pt *in, u32 n, int *ret_items);
+/* one GPU batch over the items idx[0..cnt) (idx == NULL: all n items) whose scalars fit slen octets */
+static int mul_group(mul_job *J, u32 cnt)
+{
+	J->sc = buf_get(0, (size_t)cnt * J->slen);
+	J->pin = buf_get(1, (size_t)cnt * 3 * J->clen);
+	J->pout = buf_get(2, (size_t)cnt * 2 * J->clen);
+	J->st = buf_get(3, cnt);
+	J->pre = buf_get(4, cnt);
+	if (!J->sc || !J->pin || !J->pout || !J->st || !J->pre) {
+		return -1;
+	}
+	if (pipeline_run(cnt, chunk_items(g_chunk), mul_pack, mul_gpu, mul_unpack, J)) {
+		return -1;
+	}
+	note_items(cnt);
+	return 0;
+}
+
+typedef struct {
+	const nn *m;
+	u32 *bits;
+} bits_job;
+
+static void mul_bits(u32 lo, u32 hi, void *arg)
+{
+	bits_job *B = (bits_job *)arg;
+	u32 i;
+	for (i = lo; i < hi; i++) {
+		bitcnt_t b = 0;
+		B->bits[i] = nn_bitlen(&B->m[i], &b) ? 0 : (u32)b;
+	}
+}
+
+static int mul_batch_common(prj_pt *out, const nn *m, const prj_pt *in, u32 n, int *ret_items, int secret)
+{
+	mul_job J;
+	bits_job B;
+	curve_ent *e;
+	u32 i, nlong = 0, maxbits = 0, *idx = NULL;
+	int ret = -1;
+	memset(&J, 0, sizeof(J));
+	if (!out || !m || !in) {
+		return -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	if (prj_pt_check_initialized(&in[0])) {
+		return -1;
+	}
+	e = curve_from_crv(in[0].crv);
+	if (!e) {
+		return -1;
+	}
+	pthread_mutex_lock(&g_call_mu);
+	B.m = m;
+	B.bits = (u32 *)malloc((size_t)n * sizeof(u32));
+	if (!B.bits) {
+		goto done;
+	}
+	parallel_for(n, mul_bits, &B);
+	/* Scalars of up to the order's length run on the fast window kernels; a few longer ones (m >= 2^(8 qlen), e.g. blinded
+	 * scalars mixed into a batch) must not drag the whole batch onto the long-scalar kernel: they go in a second batch. */
+	for (i = 0; i < n; i++) {
+		if (B.bits[i] > 8 * e->qlen) {
+			nlong++;
+			if (B.bits[i] > maxbits) {
+				maxbits = B.bits[i];
+			}
+		}
+	}
+	J.m = m;
+	J.in = in;
+	J.out = out;
+	J.ret_items = ret_items;
+	J.crv = in[0].crv;
+	J.clen = e->clen;
+	J.e = e;
+	if (nlong == 0 || nlong == n) {
+		J.slen = nlong ? (u32)BYTECEIL(maxbits) : e->qlen;
+		ret = mul_group(&J, n);
+	} else {
+		u32 ns = 0, nl = 0;
+		idx = (u32 *)malloc((size_t)n * sizeof(u32));
+		if (!idx) {
+			goto done;
+		}
+		for (i = 0; i < n; i++) {   /* short ones first, long ones behind them */
+			if (B.bits[i] <= 8 * e->qlen) {
+				idx[ns++] = i;
+			}
+		}
+		for (i = 0; i < n; i++) {
+			if (B.bits[i] > 8 * e->qlen) {
+				idx[ns + nl++] = i;
+			}
+		}
+		J.idx = idx;
+		J.slen = e->qlen;
+		ret = mul_group(&J, ns);
+		if (!ret) {
+			J.idx = idx + ns;
+			J.slen = (u32)BYTECEIL(maxbits);
+			ret = mul_group(&J, nl);
+		}
+	}
+done:
+	if (secret) {
+		wipe_secrets();
+	}
+	pthread_mutex_unlock(&g_call_mu);
+	free(B.bits);
+	free(idx);
+	return ret;
+}
 
 int prj_pt_mul_batch(prj_pt *out, const nn *m, const prj_pt *in, u32 n, int *ret_items)
 {
-	return mul_batch_common(out, m, in, n, ret_items);
+	/* prj_pt_mul is the reference's protected multiplication (masked ladder): its scalars are treated as secret */
+	return mul_batch_common(out, m, in, n, ret_items, 1);
 }
 
 typedef struct {
 	const nn *m;
 	nn *mb;
 	nn_src_t order;
-	int failed;
+	u32 failed;
 } blind_job;
 
 static void blind_scalars(u32 lo, u32 hi, void *arg)
@@ -372,7 +1011,7 @@ static void blind_scalars(u32 lo, u32 hi, void *arg)
 		nn b;
 		b.magic = WORD(0);
 		if (nn_get_random_mod(&b, B->order) || nn_mul(&b, &b, B->order) || nn_add(&B->mb[i], &B->m[i], &b)) {
-			B->failed = 1;
+			AT_STORE(&B->failed, 1);
 		}
 		nn_uninit(&b);
 	}
@@ -402,79 +1041,352 @@ int prj_pt_mul_blind_batch(prj_pt *out, const nn *m, const prj_pt *in, u32 n, in
 		free(B.mb);
 		return -1;
 	}
+	pthread_mutex_lock(&g_call_mu);
 	parallel_for(n, blind_scalars, &B);
-	ret = B.failed ? -1 : mul_batch_common(out, B.mb, in, n, ret_items);
-	memset(B.mb, 0, (size_t)n * sizeof(nn));
+	pthread_mutex_unlock(&g_call_mu);
+	ret = AT_LOAD(&B.failed) ? -1 : mul_batch_common(out, B.mb, in, n, ret_items, 1);
+	wipe(B.mb, (size_t)n * sizeof(nn));
 	free(B.mb);
 	return ret;
 }
 
-static int mul_batch_common(prj_pt *out, const nn *m, const prj_pt *in, u32 n, int *ret_items)
+/* ------------------------------------------------------------------------------------------------
+ * public keys from private keys: init_pubkey_from_privkey and everything built on it
+ * (key-pair generation / import, ecccdh_init_pub_key)
+ * ------------------------------------------------------------------------------------------------ */
+enum { RULE_NONE = 0, RULE_X_LT_Q, RULE_X_ANY, RULE_X_LT_QM1, RULE_XINV, RULE_EDDSA25519, RULE_EDDSA448 };
+
+/* the scalar s of Y = [s]G for each algorithm, and the check of the private key in front of it */
+static int pub_rule(ec_alg_type t)
 {
-	mul_job J;
-	curve_ent *e;
-	u32 i, maxbits = 0;
-	int ret = -1;
-	u8 *pre = NULL;
-	memset(&J, 0, sizeof(J));
-	if (!out || !m || !in) {
+	switch (t) {
+#if defined(WITH_SIG_ECDSA)
+	case ECDSA: return RULE_X_LT_Q;            /* __ecdsa_init_pub_key, sig/ecdsa_common.c:172-201 */
+#endif
+#if defined(WITH_SIG_DECDSA)
+	case DECDSA: return RULE_X_LT_Q;
+#endif
+#if defined(WITH_SIG_ECKCDSA)
+	case ECKCDSA: return RULE_XINV;            /* Y = [x^-1]G, sig/eckcdsa.c:36-72 */
+#endif
+#if defined(WITH_SIG_ECSDSA)
+	case ECSDSA: return RULE_X_ANY;            /* __ecsdsa_init_pub_key: no range check, sig/ecsdsa_common.c:30-58 */
+#endif
+#if defined(WITH_SIG_ECOSDSA)
+	case ECOSDSA: return RULE_X_ANY;
+#endif
+#if defined(WITH_SIG_ECFSDSA)
+	case ECFSDSA: return RULE_X_LT_Q;          /* sig/ecfsdsa.c:30-58 */
+#endif
+#if defined(WITH_SIG_ECGDSA)
+	case ECGDSA: return RULE_XINV;             /* sig/ecgdsa.c:30-66 */
+#endif
+#if defined(WITH_SIG_ECRDSA)
+	case ECRDSA: return RULE_X_LT_Q;           /* sig/ecrdsa.c:70-98 */
+#endif
+#if defined(WITH_SIG_SM2)
+	case SM2: return RULE_X_LT_QM1;            /* x < q - 1, sig/sm2.c:60-92 */
+#endif
+#if defined(WITH_SIG_EDDSA25519)
+	case EDDSA25519: case EDDSA25519CTX: case EDDSA25519PH: return RULE_EDDSA25519;   /* eddsa_init_pub_key, sig/eddsa.c:786 */
+#endif
+#if defined(WITH_SIG_EDDSA448)
+	case EDDSA448: case EDDSA448PH: return RULE_EDDSA448;
+#endif
+#if defined(WITH_SIG_BIGN)
+	case BIGN: return RULE_X_LT_Q;             /* __bign_init_pub_key, sig/bign_common.c:345-375 */
+#endif
+#if defined(WITH_SIG_DBIGN)
+	case DBIGN: return RULE_X_LT_Q;
+#endif
+#if defined(WITH_SIG_BIP0340)
+	case BIP0340: return RULE_X_ANY;           /* sig/bip0340.c:102-125 */
+#endif
+#if defined(WITH_ECCCDH)
+	case ECCCDH: return RULE_X_LT_Q;           /* ecccdh_init_pub_key, ecdh/ecccdh.c:60-90 */
+#endif
+	default: return RULE_NONE;
+	}
+}
+
+/* the multiplier of the generator for one private key, big-endian in dst[slen]; -1 where the scalar function fails before its
+ * multiplication */
+static int pub_scalar(const ec_priv_key *pk, ec_alg_type alg, int rule, const ec_params *params, u8 *dst, u32 slen)
+{
+	nn_src_t q = &(params->ec_gen_order);
+	nn t;
+	int ret = -1, cmp = 0;
+	t.magic = WORD(0);
+	if (priv_key_check_initialized_and_type(pk, alg) || pk->params != params) {
 		return -1;
 	}
-	if (n == 0) {
+	switch (rule) {
+	case RULE_X_LT_Q:
+		ret = (nn_cmp(&pk->x, q, &cmp) || cmp >= 0) ? -1 : nn_to_be(dst, slen, &pk->x);
+		break;
+	case RULE_X_LT_QM1:
+		ret = (nn_init(&t, 0) || nn_dec(&t, q) || nn_cmp(&pk->x, &t, &cmp) || cmp >= 0) ? -1 : nn_to_be(dst, slen, &pk->x);
+		break;
+	case RULE_X_ANY:
+		/* any x: [x]G = [x mod q]G (G has order q); what is sent keeps to the order's length */
+		ret = (nn_mod(&t, &pk->x, q)) ? -1 : nn_to_be(dst, slen, &t);
+		break;
+	case RULE_XINV:
+		ret = (nn_cmp(&pk->x, q, &cmp) || cmp >= 0 || nn_modinv_fermat(&t, &pk->x, q)) ? -1 : nn_to_be(dst, slen, &t);
+		break;
+	case RULE_EDDSA25519:
+	case RULE_EDDSA448: {
+		/* eddsa_init_pub_key (sig/eddsa.c:786-858): x holds the hashed secret key (digest_size octets); the multiplier is
+		 * the little-endian integer in its first half (eddsa_compute_s :291), shifted right by 2 for Ed448 (:840-850) */
+		const u32 hsize = (rule == RULE_EDDSA448) ? 114 : 64;
+		u8 dig[114];
+		u32 k;
+		if (params->curve_type != ((rule == RULE_EDDSA448) ? WEI448 : WEI25519) || slen != hsize / 2) {
+			return -1;   /* eddsa_key_type_check_curve, sig/eddsa.c:156-186 */
+		}
+		if (nn_to_be(dig, hsize, &pk->x)) {
+			return -1;
+		}
+		for (k = 0; k < slen; k++) {
+			dst[k] = dig[slen - 1 - k];
+		}
+		if (rule == RULE_EDDSA448) {
+			u32 carry = 0;
+			for (k = 0; k < slen; k++) {
+				const u32 v = dst[k];
+				dst[k] = (u8)((v >> 2) | (carry << 6));
+				carry = v & 3u;
+			}
+		}
+		wipe(dig, sizeof(dig));
+		ret = 0;
+		break;
+	}
+	default:
+		break;
+	}
+	nn_uninit(&t);
+	return ret;
+}
+
+typedef struct {
+	const ec_params *params;
+	ec_alg_type alg;
+	int rule;
+	curve_ent *e;
+	u32 slen, clen;
+	/* per item: where the private key is and where the public key goes */
+	ec_key_pair *kps;                    /* key pairs (generation / import), or NULL */
+	const ec_priv_key *const *privs;     /* or: private keys ... */
+	ec_pub_key *pubs;                    /* ... and public keys out */
+	int mode;                            /* 0 keys exist, 1 generate, 2 import raw buffers, 3 import + EdDSA derivation */
+	const u8 *const *bufs;
+	u16 buf_len;
+	int *ret_items;
+	u8 *sc, *out, *st, *pre;
+} key_job;
+
+static void key_pack(u32 lo, u32 hi, void *arg)
+{
+	key_job *J = (key_job *)arg;
+	u32 i;
+	for (i = lo; i < hi; i++) {
+		const ec_priv_key *pk = J->kps ? &J->kps[i].priv_key : J->privs[i];
+		int bad = 0;
+		if (J->mode == 1) {
+			/* ec_key_pair_gen (sig/ec_key.c:594-621) / ecccdh_gen_key_pair (ecdh/ecccdh.c:93-118) up to the public key */
+			ec_priv_key *w = &J->kps[i].priv_key;
+			bad = nn_get_random_mod(&w->x, &(J->params->ec_gen_order));
+			w->key_type = J->alg;
+			w->params = J->params;
+			w->magic = PRIV_KEY_MAGIC;
+#if defined(WITH_ECCCDH)
+			if (!bad && J->alg != ECCCDH) {
+				bad = gen_priv_key(w);
+			}
+#else
+			bad = bad || gen_priv_key(w);
+#endif
+		} else if (J->mode == 2) {
+			/* ec_key_pair_import_from_priv_key_buf -> ec_priv_key_import_from_buf (sig/ec_key.c:289, :56) */
+			bad = !J->bufs[i] || ec_priv_key_import_from_buf(&J->kps[i].priv_key, J->params, J->bufs[i], (u8)J->buf_len, J->alg);
+		} else if (J->mode == 3) {
+			/* eddsa_import_key_pair_from_priv_key_buf -> eddsa_import_priv_key (sig/eddsa.c:1028, :737) */
+			bad = !J->bufs[i] || eddsa_import_priv_key(&J->kps[i].priv_key, J->bufs[i], J->buf_len, J->params, J->alg);
+		}
+		bad = bad || !pk || pub_scalar(pk, J->alg, J->rule, J->params, J->sc + (size_t)i * J->slen, J->slen);
+		J->pre[i] = bad ? 1 : 0;
+		if (bad) {
+			memset(J->sc + (size_t)i * J->slen, 0, J->slen);
+		}
+	}
+}
+
+static int key_gpu(u32 lo, u32 hi, void *arg)
+{
+	key_job *J = (key_job *)arg;
+	/* Y = [s]G: the generator (points == NULL); secret-scalar mode keeps the look-ups address-independent */
+	if (ecamd_multi_prj_pt_mul_batch(g_multi, J->e->mc, hi - lo, J->sc + (size_t)lo * J->slen, J->slen, NULL, J->out + (size_t)lo * 2 * J->clen,
+					 J->st + lo)) {
+		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+		return -1;
+	}
+	return 0;
+}
+
+static void key_unpack(u32 lo, u32 hi, void *arg)
+{
+	key_job *J = (key_job *)arg;
+	u32 i;
+	for (i = lo; i < hi; i++) {
+		ec_pub_key *pub = J->kps ? &J->kps[i].pub_key : &J->pubs[i];
+		int r = -1;
+		memset(pub, 0, sizeof(ec_pub_key));
+		if (!J->pre[i] && !prj_from_aff_be(&pub->y, &(J->params->ec_curve), J->out + (size_t)i * 2 * J->clen, J->clen, J->st[i])) {
+			pub->key_type = J->alg;
+			pub->params = J->params;
+			pub->magic = PUB_KEY_MAGIC;
+			r = 0;
+		}
+		if (r && J->kps) {
+			memset(&J->kps[i], 0, sizeof(ec_key_pair));   /* as the scalar functions' error paths */
+		}
+		if (J->ret_items) {
+			J->ret_items[i] = r;
+		}
+	}
+}
+
+static int key_batch(key_job *J, u32 num)
+{
+	int ret = -1;
+	if (num == 0) {
 		return 0;
 	}
-	if (prj_pt_check_initialized(&in[0])) {
+	if (!J->params) {
 		return -1;
 	}
-	e = curve_from_crv(in[0].crv);
-	if (!e) {
+	J->rule = pub_rule(J->alg);
+	if (J->rule == RULE_NONE) {
 		return -1;
 	}
-	for (i = 0; i < n; i++) {
-		bitcnt_t b = 0;
-		if (!nn_bitlen(&m[i], &b) && (u32)b > maxbits) {
-			maxbits = (u32)b;
-		}
+	J->e = curve_from_params(J->params);
+	if (!J->e) {
+		return -1;
 	}
-	J.m = m;
-	J.in = in;
-	J.out = out;
-	J.ret_items = ret_items;
-	J.crv = in[0].crv;
-	J.clen = e->clen;
-	J.slen = (u32)BYTECEIL(maxbits);
-	if (J.slen < e->qlen) {
-		J.slen = e->qlen;   /* the fast kernels take scalars of up to the order's length; longer ones the generic kernel */
+	J->clen = J->e->clen;
+	J->slen = (J->rule == RULE_EDDSA25519) ? 32 : (J->rule == RULE_EDDSA448) ? 57 : J->e->qlen;
+	pthread_mutex_lock(&g_call_mu);
+	J->sc = buf_get(0, (size_t)num * J->slen);
+	J->out = buf_get(1, (size_t)num * 2 * J->clen);
+	J->st = buf_get(2, num);
+	J->pre = buf_get(3, num);
+	if (J->sc && J->out && J->st && J->pre && !pipeline_run(num, chunk_items(g_chunk), key_pack, key_gpu, key_unpack, J)) {
+		note_items(num);
+		ret = 0;
 	}
-	J.sc = (u8 *)malloc((size_t)n * J.slen);
-	J.pin = (u8 *)malloc((size_t)n * 3 * J.clen);
-	J.pout = (u8 *)malloc((size_t)n * 3 * J.clen);
-	J.st = (u8 *)malloc(n);
-	pre = (u8 *)malloc(n);
-	if (!J.sc || !J.pin || !J.pout || !J.st || !pre) {
-		goto done;
-	}
-	parallel_for(n, mul_export, &J);
-	memcpy(pre, J.st, n);
-	if (ecamd_multi_prj_pt_mul_batch_fmt(g_multi, e->mc, n, J.sc, J.slen, J.pin, ECAMD_PT_PROJECTIVE, J.pout, ECAMD_PT_PROJECTIVE, J.st)) {
-		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
-		goto done;
-	}
-	for (i = 0; i < n; i++) {
-		if (pre[i]) {
-			J.st[i] = ECAMD_ERR;
-		}
-	}
-	note_items(n);
-	parallel_for(n, mul_import, &J);
-	ret = 0;
-done:
-	free(J.sc);
-	free(J.pin);
-	free(J.pout);
-	free(J.st);
-	free(pre);
+	wipe_secrets();
+	pthread_mutex_unlock(&g_call_mu);
 	return ret;
+}
+
+int ec_key_pair_gen_batch(ec_key_pair *kps, const ec_params *params, ec_alg_type ec_key_alg, u32 num, int *ret_items)
+{
+	key_job J;
+	memset(&J, 0, sizeof(J));
+	if (!kps || !params) {
+		return -1;
+	}
+	J.params = params;
+	J.alg = ec_key_alg;
+	J.kps = kps;
+	J.mode = 1;
+	J.ret_items = ret_items;
+	return key_batch(&J, num);
+}
+
+int ec_key_pair_import_from_priv_key_buf_batch(ec_key_pair *kps, const ec_params *params, const u8 *const *priv_keys, u8 priv_key_len,
+					       ec_alg_type ec_key_alg, u32 num, int *ret_items)
+{
+	key_job J;
+	memset(&J, 0, sizeof(J));
+	if (!kps || !params || !priv_keys) {
+		return -1;
+	}
+	J.params = params;
+	J.alg = ec_key_alg;
+	J.kps = kps;
+	J.mode = 2;
+	J.bufs = priv_keys;
+	J.buf_len = priv_key_len;
+	J.ret_items = ret_items;
+	return key_batch(&J, num);
+}
+
+int eddsa_import_key_pair_from_priv_key_buf_batch(ec_key_pair *kps, const u8 *const *priv_keys, u16 priv_key_len,
+						  const ec_params *shortw_curve_params, ec_alg_type sig_type, u32 num, int *ret_items)
+{
+	key_job J;
+	memset(&J, 0, sizeof(J));
+	if (!kps || !shortw_curve_params || !priv_keys) {
+		return -1;
+	}
+	J.params = shortw_curve_params;
+	J.alg = sig_type;
+	J.kps = kps;
+	J.mode = 3;
+	J.bufs = priv_keys;
+	J.buf_len = priv_key_len;
+	J.ret_items = ret_items;
+	if (pub_rule(sig_type) != RULE_EDDSA25519 && pub_rule(sig_type) != RULE_EDDSA448) {
+		return -1;
+	}
+	return key_batch(&J, num);
+}
+
+int init_pubkey_from_privkey_batch(ec_pub_key *out_pubs, const ec_priv_key *const *in_privs, u32 num, int *ret_items)
+{
+	key_job J;
+	memset(&J, 0, sizeof(J));
+	if (!out_pubs || !in_privs) {
+		return -1;
+	}
+	if (num == 0) {
+		return 0;
+	}
+	if (priv_key_check_initialized(in_privs[0])) {
+		return -1;
+	}
+	J.params = in_privs[0]->params;
+	J.alg = in_privs[0]->key_type;
+	J.privs = in_privs;
+	J.pubs = out_pubs;
+	J.mode = 0;
+	J.ret_items = ret_items;
+	return key_batch(&J, num);
+}
+
+int ecccdh_init_pub_key_batch(ec_pub_key *out_pubs, const ec_priv_key *const *in_privs, u32 num, int *ret_items)
+{
+#if defined(WITH_ECCCDH)
+	if (num && (!in_privs || priv_key_check_initialized_and_type(in_privs[0], ECCCDH))) {
+		return -1;
+	}
+	return init_pubkey_from_privkey_batch(out_pubs, in_privs, num, ret_items);
+#else
+	(void)out_pubs; (void)in_privs; (void)num; (void)ret_items;
+	return -1;
+#endif
+}
+
+int ecccdh_gen_key_pair_batch(ec_key_pair *kps, const ec_params *params, u32 num, int *ret_items)
+{
+#if defined(WITH_ECCCDH)
+	return ec_key_pair_gen_batch(kps, params, ECCCDH, num, ret_items);
+#else
+	(void)kps; (void)params; (void)num; (void)ret_items;
+	return -1;
+#endif
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -485,13 +1397,14 @@ typedef struct {
 	const u8 *const *peers;
 	u8 *const *secrets;
 	const ec_params *params;
+	curve_ent *e;
 	u8 *pv, *pk, *sec, *st, *pre;
 	u32 qlen, clen;
 	nn_src_t q;
 	int *ret_items;
 } cdh_job;
 
-static void cdh_export(u32 lo, u32 hi, void *arg)
+static void cdh_pack(u32 lo, u32 hi, void *arg)
 {
 	cdh_job *J = (cdh_job *)arg;
 	u32 i;
@@ -500,17 +1413,14 @@ static void cdh_export(u32 lo, u32 hi, void *arg)
 		int bad = 1;
 		/* sanity checks of ecccdh_derive_secret (ecdh/ecccdh.c:176-178) */
 		if (J->secrets[i] && J->peers[i] && !priv_key_check_initialized_and_type(k, ECCCDH) && k->params == J->params) {
-			bitcnt_t b = 0;
-			bad = nn_bitlen(&k->x, &b);
-			if (!bad && (u32)b > 8 * J->qlen) {
+			bad = nn_to_be(J->pv + (size_t)i * J->qlen, J->qlen, &k->x);
+			if (bad && !nn_check_initialized(&k->x)) {
 				/* a private scalar longer than the group order: [x]Q = [x mod q]Q for every Q that passes the
 				 * checks in front of the multiplication (Q lies in the subgroup of order q) */
 				nn t;
 				t.magic = WORD(0);
-				bad = nn_mod(&t, &k->x, J->q) || nn_export_to_buf(J->pv + (size_t)i * J->qlen, (u16)J->qlen, &t);
+				bad = nn_mod(&t, &k->x, J->q) || nn_to_be(J->pv + (size_t)i * J->qlen, J->qlen, &t);
 				nn_uninit(&t);
-			} else if (!bad) {
-				bad = nn_export_to_buf(J->pv + (size_t)i * J->qlen, (u16)J->qlen, &k->x);
 			}
 		}
 		J->pre[i] = bad ? 1 : 0;
@@ -523,7 +1433,18 @@ static void cdh_export(u32 lo, u32 hi, void *arg)
 	}
 }
 
-static void cdh_import(u32 lo, u32 hi, void *arg)
+static int cdh_gpu(u32 lo, u32 hi, void *arg)
+{
+	cdh_job *J = (cdh_job *)arg;
+	if (ecamd_multi_ecccdh_derive_batch(g_multi, J->e->mc, hi - lo, J->pv + (size_t)lo * J->qlen, J->pk + (size_t)lo * 2 * J->clen,
+					    J->sec + (size_t)lo * J->clen, J->st + lo)) {
+		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+		return -1;
+	}
+	return 0;
+}
+
+static void cdh_unpack(u32 lo, u32 hi, void *arg)
 {
 	cdh_job *J = (cdh_job *)arg;
 	u32 i;
@@ -542,7 +1463,6 @@ int ecccdh_derive_secret_batch(const ec_priv_key *const *our_priv_keys, const u8
 			       u8 *const *shared_secrets, u8 shared_secret_len, u32 num, int *ret_items)
 {
 	cdh_job J;
-	curve_ent *e;
 	u8 want_pk = 0, want_ss = 0;
 	u32 i;
 	int ret = -1;
@@ -568,47 +1488,166 @@ int ecccdh_derive_secret_batch(const ec_priv_key *const *our_priv_keys, const u8
 		}
 		return 0;
 	}
-	e = curve_from_params(J.params);
-	if (!e) {
+	J.e = curve_from_params(J.params);
+	if (!J.e) {
 		return -1;
 	}
 	J.privs = our_priv_keys;
 	J.peers = peer_pub_keys;
 	J.secrets = shared_secrets;
 	J.ret_items = ret_items;
-	J.qlen = e->qlen;
-	J.clen = e->clen;
+	J.qlen = J.e->qlen;
+	J.clen = J.e->clen;
 	J.q = &(J.params->ec_gen_order);
-	J.pv = (u8 *)malloc((size_t)num * J.qlen);
-	J.pk = (u8 *)malloc((size_t)num * 2 * J.clen);
-	J.sec = (u8 *)malloc((size_t)num * J.clen);
-	J.st = (u8 *)malloc(num);
-	J.pre = (u8 *)malloc(num);
-	if (!J.pv || !J.pk || !J.sec || !J.st || !J.pre) {
-		goto done;
+	pthread_mutex_lock(&g_call_mu);
+	J.pv = buf_get(0, (size_t)num * J.qlen);
+	J.pk = buf_get(1, (size_t)num * 2 * J.clen);
+	J.sec = buf_get(2, (size_t)num * J.clen);
+	J.st = buf_get(3, num);
+	J.pre = buf_get(4, num);
+	if (J.pv && J.pk && J.sec && J.st && J.pre && !pipeline_run(num, chunk_items(g_chunk), cdh_pack, cdh_gpu, cdh_unpack, &J)) {
+		note_items(num);
+		ret = 0;
 	}
-	parallel_for(num, cdh_export, &J);
-	if (ecamd_multi_ecccdh_derive_batch(g_multi, e->mc, num, J.pv, J.pk, J.sec, J.st)) {
-		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
-		goto done;
-	}
-	note_items(num);
-	parallel_for(num, cdh_import, &J);
-	ret = 0;
-done:
-	if (J.pv) {
-		memset(J.pv, 0, (size_t)num * J.qlen);   /* private scalars */
-	}
-	free(J.pv);
-	free(J.pk);
-	free(J.sec);
-	free(J.st);
-	free(J.pre);
+	wipe_secrets();   /* private scalars and shared secrets */
+	pthread_mutex_unlock(&g_call_mu);
 	return ret;
 }
 
 /* ------------------------------------------------------------------------------------------------
- * signature verification
+ * X25519 / X448
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+	const u8 *const *k, *const *u;
+	u8 *const *res;
+	u32 len;
+	curve_ent *e;
+	u8 *kb, *ub, *rb, *st, *pre;
+	int *ret_items;
+} xdh_job;
+
+static void xdh_pack(u32 lo, u32 hi, void *arg)
+{
+	xdh_job *J = (xdh_job *)arg;
+	u32 i;
+	for (i = lo; i < hi; i++) {
+		/* MUST_HAVE((k != NULL) && (u != NULL) && (res != NULL)), ecdh/x25519_448.c:163 */
+		const int bad = !J->k[i] || !J->res[i] || (J->u && !J->u[i]);
+		J->pre[i] = bad ? 1 : 0;
+		if (bad) {
+			memset(J->kb + (size_t)i * J->len, 0, J->len);
+			memset(J->ub + (size_t)i * J->len, 0xff, J->len);   /* non-canonical u: rejected */
+			continue;
+		}
+		memcpy(J->kb + (size_t)i * J->len, J->k[i], J->len);
+		if (J->u) {
+			memcpy(J->ub + (size_t)i * J->len, J->u[i], J->len);
+		} else {
+			/* x25519_448_init_pub_key: the base point u = 9 / 5 (ecdh/x25519_448.c:333-349) */
+			memset(J->ub + (size_t)i * J->len, 0, J->len);
+			J->ub[(size_t)i * J->len] = (J->len == 32) ? 0x09 : 0x05;
+		}
+	}
+}
+
+static int xdh_gpu(u32 lo, u32 hi, void *arg)
+{
+	xdh_job *J = (xdh_job *)arg;
+	if (ecamd_multi_xdh_batch(g_multi, J->e->mc, hi - lo, J->kb + (size_t)lo * J->len, J->ub + (size_t)lo * J->len, J->rb + (size_t)lo * J->len,
+				  J->st + lo)) {
+		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+		return -1;
+	}
+	return 0;
+}
+
+static void xdh_unpack(u32 lo, u32 hi, void *arg)
+{
+	xdh_job *J = (xdh_job *)arg;
+	u32 i;
+	for (i = lo; i < hi; i++) {
+		const int ok = !J->pre[i] && J->st[i] == ECAMD_OK;
+		if (ok) {
+			memcpy(J->res[i], J->rb + (size_t)i * J->len, J->len);
+		}
+		if (J->ret_items) {
+			J->ret_items[i] = ok ? 0 : -1;
+		}
+	}
+}
+
+static int xdh_batch(const char *curve, u32 len, const u8 *const *k, const u8 *const *u, u8 *const *res, u32 num, int *ret_items)
+{
+	xdh_job J;
+	const ec_str_params *sp = NULL;
+	ec_params params;
+	int ret = -1;
+	memset(&J, 0, sizeof(J));
+	if (!k || !res) {
+		return -1;
+	}
+	if (num == 0) {
+		return 0;
+	}
+	/* the Weierstrass model the reference itself computes on (x25519_448_core imports WEI25519 / WEI448, :180-190) */
+	if (ec_get_curve_params_by_name((const u8 *)curve, (u8)(strlen(curve) + 1), &sp) || !sp || import_params(&params, sp)) {
+		return -1;
+	}
+	J.e = curve_from_params(&params);
+	if (!J.e || J.e->clen != len) {
+		return -1;
+	}
+	J.k = k;
+	J.u = u;
+	J.res = res;
+	J.len = len;
+	J.ret_items = ret_items;
+	pthread_mutex_lock(&g_call_mu);
+	J.kb = buf_get(0, (size_t)num * len);
+	J.ub = buf_get(1, (size_t)num * len);
+	J.rb = buf_get(2, (size_t)num * len);
+	J.st = buf_get(3, num);
+	J.pre = buf_get(4, num);
+	if (J.kb && J.ub && J.rb && J.st && J.pre && !pipeline_run(num, chunk_items(g_chunk), xdh_pack, xdh_gpu, xdh_unpack, &J)) {
+		note_items(num);
+		ret = 0;
+	}
+	wipe_secrets();
+	pthread_mutex_unlock(&g_call_mu);
+	return ret;
+}
+
+#if defined(WITH_X25519)
+int x25519_batch(const u8 *const *k, const u8 *const *u, u8 *const *res, u32 num, int *ret_items)
+{
+	return u ? xdh_batch("WEI25519", 32, k, u, res, num, ret_items) : -1;
+}
+int x25519_init_pub_key_batch(const u8 *const *priv_keys, u8 *const *pub_keys, u32 num, int *ret_items)
+{
+	return xdh_batch("WEI25519", 32, priv_keys, NULL, pub_keys, num, ret_items);
+}
+int x25519_derive_secret_batch(const u8 *const *priv_keys, const u8 *const *peer_pub_keys, u8 *const *shared_secrets, u32 num, int *ret_items)
+{
+	return x25519_batch(priv_keys, peer_pub_keys, shared_secrets, num, ret_items);
+}
+#endif
+#if defined(WITH_X448)
+int x448_batch(const u8 *const *k, const u8 *const *u, u8 *const *res, u32 num, int *ret_items)
+{
+	return u ? xdh_batch("WEI448", 56, k, u, res, num, ret_items) : -1;
+}
+int x448_init_pub_key_batch(const u8 *const *priv_keys, u8 *const *pub_keys, u32 num, int *ret_items)
+{
+	return xdh_batch("WEI448", 56, priv_keys, NULL, pub_keys, num, ret_items);
+}
+int x448_derive_secret_batch(const u8 *const *priv_keys, const u8 *const *peer_pub_keys, u8 *const *shared_secrets, u32 num, int *ret_items)
+{
+	return x448_batch(priv_keys, peer_pub_keys, shared_secrets, num, ret_items);
+}
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * hashing helpers shared by signing and verification
  * ------------------------------------------------------------------------------------------------ */
 static const hash_mapping *find_hash(hash_alg_type hash_type)
 {
@@ -619,97 +1658,31 @@ static const hash_mapping *find_hash(hash_alg_type hash_type)
 	return hm;
 }
 
-typedef struct {
-	const u8 **s, **m, **adata;
-	const u8 *s_len;
-	const u32 *m_len;
-	const u16 *adata_len;
-	const ec_pub_key **pub_keys;
-	ec_alg_type sig_type;
-	const hash_mapping *hm;
-	const u32 *idx;          /* the items of this group */
-	const ec_params *params;
-	u8 *pk, *sg, *dg, *pre;  /* packed: keys (projective X||Y||Z or EdDSA encoding), signatures, digests / hram, per-item pre-check */
-	u8 *kprj;                /* EdDSA: the key points X||Y||Z, input of the device-side encoding */
-	u32 clen, qlen, hlen, klen, siglen;
-} ver_job;
-
-/* ---- ECDSA / DECDSA ---- */
-static void ecdsa_pack(u32 lo, u32 hi, void *arg)
+static int is_ecdsa(ec_alg_type t)
 {
-	ver_job *J = (ver_job *)arg;
-	u32 j;
-	for (j = lo; j < hi; j++) {
-		const u32 i = J->idx[j];
-		const ec_pub_key *pk = J->pub_keys[i];
-		hash_context hc;
-		u8 dig[MAX_DIGEST_SIZE];
-		int bad;
-		/* ec_verify_init / __ecdsa_verify_init (sig/sig_algs.c:516, sig/ecdsa_common.c:623-649): key initialised and of
-		 * this algorithm, signature present and of the expected length; then H(m) */
-		bad = pub_key_check_initialized_and_type(pk, J->sig_type) || pk->params != J->params || !J->s[i] ||
-		      J->s_len[i] != J->siglen || (!J->m[i] && J->m_len[i]);
-		bad = bad || prj_pt_export_to_buf(&pk->y, J->pk + (size_t)j * 3 * J->clen, 3 * J->clen);
-		bad = bad || J->hm->hfunc_init(&hc) || J->hm->hfunc_update(&hc, J->m[i], J->m_len[i]) || J->hm->hfunc_finalize(&hc, dig);
-		J->pre[j] = bad ? 1 : 0;
-		if (bad) {
-			memset(J->pk + (size_t)j * 3 * J->clen, 0xff, 3 * J->clen);
-			memset(J->sg + (size_t)j * J->siglen, 0, J->siglen);
-			memset(J->dg + (size_t)j * J->hlen, 0, J->hlen);
-		} else {
-			memcpy(J->sg + (size_t)j * J->siglen, J->s[i], J->siglen);
-			memcpy(J->dg + (size_t)j * J->hlen, dig, J->hlen);
-		}
+#if defined(WITH_SIG_ECDSA)
+	if (t == ECDSA) {
+		return 1;
 	}
+#endif
+#if defined(WITH_SIG_DECDSA)
+	if (t == DECDSA) {
+		return 1;
+	}
+#endif
+	return 0;
 }
 
-/* results[i] for the items idx[0..cnt) that share `params` */
-static int ecdsa_group(ver_job *J, u32 cnt, int *results)
+static int is_decdsa(ec_alg_type t)
 {
-	curve_ent *e = curve_from_params(J->params);
-	u8 *res = NULL;
-	u32 j;
-	int ret = -1;
-	if (!e) {
-		return -1;
-	}
-	J->clen = e->clen;
-	J->qlen = e->qlen;
-	J->siglen = 2 * (u32)BYTECEIL(J->params->ec_gen_order_bitlen);   /* ECDSA_SIGLEN */
-	if (J->siglen != 2 * e->qlen) {
-		return -1;
-	}
-	J->hlen = J->hm->digest_size;
-	J->pk = (u8 *)malloc((size_t)cnt * 3 * J->clen);
-	J->sg = (u8 *)malloc((size_t)cnt * J->siglen);
-	J->dg = (u8 *)malloc((size_t)cnt * J->hlen);
-	J->pre = (u8 *)malloc(cnt);
-	res = (u8 *)malloc(cnt);
-	if (!J->pk || !J->sg || !J->dg || !J->pre || !res) {
-		goto done;
-	}
-	parallel_for(cnt, ecdsa_pack, J);
-	if (ecamd_multi_ecdsa_verify_batch_fmt(g_multi, e->mc, cnt, J->pk, ECAMD_PT_PROJECTIVE, J->sg, J->dg, J->hlen, res)) {
-		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
-		goto done;
-	}
-	note_items(cnt);
-	for (j = 0; j < cnt; j++) {
-		results[J->idx[j]] = (J->pre[j] || res[j]) ? -1 : 0;
-	}
-	ret = 0;
-done:
-	free(J->pk);
-	free(J->sg);
-	free(J->dg);
-	free(J->pre);
-	free(J->kprj);
-	free(res);
-	J->pk = J->sg = J->dg = J->pre = J->kprj = NULL;
-	return ret;
+#if defined(WITH_SIG_DECDSA)
+	return t == DECDSA;
+#else
+	(void)t;
+	return 0;
+#endif
 }
 
-/* ---- EdDSA ---- */
 static int eddsa_variant(ec_alg_type t, hash_alg_type *h, ec_curve_type *c, int *ph, int *dom, int *is448)
 {
 	switch (t) {
@@ -748,23 +1721,631 @@ static int dom_prefix(const hash_mapping *hm, hash_context *hc, int is448, int p
 	return y ? hm->hfunc_update(hc, y, ylen) : 0;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * signing: ec_sign_batch
+ * ------------------------------------------------------------------------------------------------ */
 typedef struct {
-	ver_job v;
+	u8 *const *sigs;
+	const ec_key_pair *const *kps;
+	const u8 *const *m;
+	const u32 *m_len;
+	const u8 *const *adata;
+	const u16 *adata_len;
+	int (*rand)(nn_t out, nn_src_t q);
+	ec_alg_type sig_type;
+	hash_alg_type hash_type;
+	const hash_mapping *hm;
+	const u32 *idx;
+	const ec_params *params;
+	curve_ent *e;
+	int *ret_items;
+	u8 siglen;
+	u32 clen, qlen, hlen, klen;
+	/* ECDSA: private keys, nonces, digests in; signatures, status out.  EdDSA: see eddsa_sign_group */
+	u8 *b0, *b1, *b2, *b3, *b4, *b5, *b6, *b7, *pre;
+	int nonces_given;    /* the nonces were drawn beforehand (caller's rand hook) */
 	int ph, dom, is448;
-	u32 ph_len;   /* bytes of PH(M) that enter the main hash */
-} ed_job;
+	u32 ph_len;
+} sign_job;
 
+/* RFC 6979 nonce, as __ecdsa_rfc6979_nonce (sig/ecdsa_common.c:48-168) computes it, through libecc's own hmac_*:
+ * k_be[qlen] from the private key x_be[qlen] and the message digest */
+static int rfc6979_nonce(u8 *k_be, u32 qlen, nn_src_t q, bitcnt_t q_bit_len, const u8 *x_be, const u8 *hash, u8 hsize, hash_alg_type hash_type)
+{
+	u8 V[MAX_DIGEST_SIZE], K[MAX_DIGEST_SIZE], T[80 + 2 * MAX_DIGEST_SIZE], h1[80], tmp, hmac_size;
+	hmac_context hc;
+	nn k;
+	int ret = -1, cmp = 0, tries;
+	bitcnt_t t_bit_len;
+	k.magic = WORD(0);
+	if (qlen > 80 || hsize > MAX_DIGEST_SIZE || hsize == 0) {
+		return -1;
+	}
+	memset(V, 0x01, hsize);
+	memset(K, 0x00, hsize);
+	/* bits2octets(h1): the digest's leftmost qbits bits, reduced mod q (:90-96) */
+	ret = nn_init_from_buf(&k, hash, hsize); EG(ret, err);
+	if ((8 * (u32)hsize) > (u32)q_bit_len) {
+		ret = nn_rshift(&k, &k, (bitcnt_t)((8 * hsize) - q_bit_len)); EG(ret, err);
+	}
+	ret = nn_mod(&k, &k, q); EG(ret, err);
+	ret = nn_export_to_buf(h1, (u16)qlen, &k); EG(ret, err);
+	for (tmp = 0; tmp < 2; tmp++) {
+		/* steps d / f: K = HMAC_K(V || 0x00 / 0x01 || int2octets(x) || bits2octets(h1)); steps e / g: V = HMAC_K(V) */
+		ret = hmac_init(&hc, K, hsize, hash_type); EG(ret, err);
+		ret = hmac_update(&hc, V, hsize); EG(ret, err);
+		ret = hmac_update(&hc, &tmp, 1); EG(ret, err);
+		ret = hmac_update(&hc, x_be, qlen); EG(ret, err);
+		ret = hmac_update(&hc, h1, qlen); EG(ret, err);
+		hmac_size = sizeof(K);
+		ret = hmac_finalize(&hc, K, &hmac_size); EG(ret, err);
+		hmac_size = sizeof(V);
+		ret = hmac(K, hsize, hash_type, V, hsize, V, &hmac_size); EG(ret, err);
+	}
+	/* step h */
+	for (tries = 0; tries < 1000; tries++) {
+		t_bit_len = 0;
+		while (t_bit_len < q_bit_len) {
+			hmac_size = sizeof(V);
+			ret = hmac(K, hsize, hash_type, V, hsize, V, &hmac_size); EG(ret, err);
+			memcpy(&T[BYTECEIL(t_bit_len)], V, hmac_size);
+			t_bit_len = (bitcnt_t)(t_bit_len + (8 * hmac_size));
+		}
+		ret = nn_init_from_buf(&k, T, (u16)qlen); EG(ret, err);
+		if ((8 * qlen) > (u32)q_bit_len) {
+			ret = nn_rshift(&k, &k, (bitcnt_t)((8 * qlen) - q_bit_len)); EG(ret, err);
+		}
+		ret = nn_cmp(&k, q, &cmp); EG(ret, err);
+		if (cmp < 0) {
+			ret = nn_export_to_buf(k_be, (u16)qlen, &k);
+			goto err;
+		}
+		/* K = HMAC_K(V || 0x00), V = HMAC_K(V) */
+		tmp = 0x00;
+		ret = hmac_init(&hc, K, hsize, hash_type); EG(ret, err);
+		ret = hmac_update(&hc, V, hsize); EG(ret, err);
+		ret = hmac_update(&hc, &tmp, 1); EG(ret, err);
+		hmac_size = sizeof(K);
+		ret = hmac_finalize(&hc, K, &hmac_size); EG(ret, err);
+		hmac_size = sizeof(V);
+		ret = hmac(K, hsize, hash_type, V, hsize, V, &hmac_size); EG(ret, err);
+	}
+	ret = -1;
+err:
+	nn_uninit(&k);
+	wipe(V, sizeof(V));
+	wipe(K, sizeof(K));
+	wipe(T, sizeof(T));
+	return ret;
+}
+
+/* ---- ECDSA / DECDSA: b0 private keys, b1 nonces, b2 digests, b3 signatures, b4 status ---- */
+static void ecdsa_sign_pack(u32 lo, u32 hi, void *arg)
+{
+	sign_job *J = (sign_job *)arg;
+	u32 j;
+	for (j = lo; j < hi; j++) {
+		const u32 i = J->idx[j];
+		const ec_key_pair *kp = J->kps[i];
+		u8 *xb = J->b0 + (size_t)j * J->qlen, *kb = J->b1 + (size_t)j * J->qlen, *dg = J->b2 + (size_t)j * J->hlen;
+		hash_context hc;
+		int bad, cmp = 0;
+		/* _ec_sign_init / __ecdsa_sign_init / __ecdsa_sign_finalize up to the multiplication (sig/sig_algs.c:293-376,
+		 * sig/ecdsa_common.c:262-283, :318-400): key pair of this algorithm, x < q, signature length, h = H(m) */
+		bad = key_pair_check_initialized_and_type(kp, J->sig_type) || kp->priv_key.params != J->params || !J->sigs[i] ||
+		      (!J->m[i] && J->m_len[i]);
+		bad = bad || nn_cmp(&kp->priv_key.x, &(J->params->ec_gen_order), &cmp) || cmp >= 0 || nn_to_be(xb, J->qlen, &kp->priv_key.x);
+		bad = bad || J->hm->hfunc_init(&hc) || J->hm->hfunc_update(&hc, J->m[i], J->m_len[i]) || J->hm->hfunc_finalize(&hc, dg);
+		if (!bad && is_decdsa(J->sig_type)) {
+			bad = rfc6979_nonce(kb, J->qlen, &(J->params->ec_gen_order), J->params->ec_gen_order_bitlen, xb, dg, (u8)J->hlen, J->hash_type);
+		} else if (!bad && !J->nonces_given) {
+			nn k;
+			k.magic = WORD(0);
+			bad = nn_get_random_mod(&k, &(J->params->ec_gen_order)) || nn_to_be(kb, J->qlen, &k);
+			nn_uninit(&k);
+		} else if (!bad) {
+			bad = J->pre[j];   /* the caller's rand hook failed for this item */
+		}
+		J->pre[j] = bad ? 1 : 0;
+		if (bad) {
+			memset(xb, 0, J->qlen);
+			memset(kb, 0, J->qlen);
+			memset(dg, 0, J->hlen);
+		}
+	}
+}
+
+static int ecdsa_sign_gpu(u32 lo, u32 hi, void *arg)
+{
+	sign_job *J = (sign_job *)arg;
+	if (ecamd_multi_ecdsa_sign_batch(g_multi, J->e->mc, hi - lo, J->b0 + (size_t)lo * J->qlen, J->b1 + (size_t)lo * J->qlen,
+					 J->b2 + (size_t)lo * J->hlen, J->hlen, J->b3 + (size_t)lo * 2 * J->qlen, J->b4 + lo)) {
+		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+		return -1;
+	}
+	return 0;
+}
+
+static void ecdsa_sign_unpack(u32 lo, u32 hi, void *arg)
+{
+	sign_job *J = (sign_job *)arg;
+	u32 j;
+	for (j = lo; j < hi; j++) {
+		const u32 i = J->idx[j];
+		if (!J->pre[j] && J->b4[j] == 0) {
+			memcpy(J->sigs[i], J->b3 + (size_t)j * 2 * J->qlen, 2 * J->qlen);
+			J->ret_items[i] = 0;
+		} else {
+			J->ret_items[i] = J->pre[j] ? -1 : -2;   /* -2: the device asks for another nonce (resolved by the caller) */
+		}
+	}
+}
+
+static int ecdsa_sign_group(sign_job *J, u32 cnt)
+{
+	u32 j, round;
+	int ret = -1;
+	J->clen = J->e->clen;
+	J->qlen = J->e->qlen;
+	J->hlen = J->hm->digest_size;
+	if ((u32)J->siglen != 2 * (u32)BYTECEIL(J->params->ec_gen_order_bitlen) || 2 * J->qlen != (u32)J->siglen) {
+		/* MUST_HAVE((siglen == ECDSA_SIGLEN(q_bit_len))), sig/ecdsa_common.c:380: every item fails */
+		for (j = 0; j < cnt; j++) {
+			J->ret_items[J->idx[j]] = -1;
+		}
+		return 0;
+	}
+	J->b0 = buf_get(0, (size_t)cnt * J->qlen);
+	J->b1 = buf_get(1, (size_t)cnt * J->qlen);
+	J->b2 = buf_get(2, (size_t)cnt * J->hlen);
+	J->b3 = buf_get(3, (size_t)cnt * 2 * J->qlen);
+	J->b4 = buf_get(4, cnt);
+	J->pre = buf_get(5, cnt);
+	if (!J->b0 || !J->b1 || !J->b2 || !J->b3 || !J->b4 || !J->pre) {
+		return -1;
+	}
+	for (round = 0; round < 8; round++) {
+		u32 again = 0;
+		memset(J->pre, 0, cnt);
+		J->nonces_given = 0;
+		if (J->rand && J->rand != nn_get_random_mod && !is_decdsa(J->sig_type)) {
+			/* the caller's nonce source: one call per item, in index order, on this thread (it may be stateful) */
+			nn k;
+			k.magic = WORD(0);
+			for (j = 0; j < cnt; j++) {
+				int cmp = 0, z = 1;
+				if (J->rand(&k, &(J->params->ec_gen_order)) || nn_iszero(&k, &z) || z ||
+				    nn_cmp(&k, &(J->params->ec_gen_order), &cmp) || cmp >= 0 || nn_to_be(J->b1 + (size_t)j * J->qlen, J->qlen, &k)) {
+					J->pre[j] = 1;   /* "expected to initialize a nn 'out' with a value taken uniformly at random in [1, q-1]" */
+				}
+			}
+			nn_uninit(&k);
+			J->nonces_given = 1;
+		}
+		if (pipeline_run(cnt, chunk_items(g_chunk), ecdsa_sign_pack, ecdsa_sign_gpu, ecdsa_sign_unpack, J)) {
+			goto done;
+		}
+		note_items(cnt);
+		/* restart of steps 4-10 for the items whose nonce gave r = 0, e = x r or s = 0 (sig/ecdsa_common.c:497-557):
+		 * compact them to the front and sign them again with fresh nonces.  A deterministic nonce cannot change:
+		 * the reference would loop for ever on such a (key, message); the batch form reports -1. */
+		for (j = 0; j < cnt; j++) {
+			if (J->ret_items[J->idx[j]] == -2) {
+				if (is_decdsa(J->sig_type)) {
+					J->ret_items[J->idx[j]] = -1;
+				} else {
+					((u32 *)J->idx)[again++] = J->idx[j];
+				}
+			}
+		}
+		if (!again) {
+			break;
+		}
+		cnt = again;
+	}
+	for (j = 0; j < cnt; j++) {
+		if (J->ret_items[J->idx[j]] == -2) {
+			J->ret_items[J->idx[j]] = -1;
+		}
+	}
+	ret = 0;
+done:
+	return ret;
+}
+
+/* ---- EdDSA: b0 key points X||Y||Z -> b1 encoded keys A; b2 r_hash; b3 secret scalars a; b4 R; b5 hram; b6 S; b7 status of R ---- */
+static void eddsa_sign_keys(u32 lo, u32 hi, void *arg)
+{
+	sign_job *J = (sign_job *)arg;
+	u32 j;
+	for (j = lo; j < hi; j++) {
+		const ec_key_pair *kp = J->kps[J->idx[j]];
+		u8 *dst = J->b0 + (size_t)j * 3 * J->clen;
+		/* eddsa_key_pair_sanity_check (sig/eddsa.c:213-227): both halves initialised, of one EdDSA type, on the variant's curve */
+		if (key_pair_check_initialized_and_type(kp, J->sig_type) || kp->priv_key.params != J->params || kp->pub_key.params != J->params ||
+		    prj_to_be(dst, J->clen, &kp->pub_key.y, &(J->params->ec_curve))) {
+			memset(dst, 0xff, (size_t)3 * J->clen);   /* coordinates >= p: an import error on the device */
+		}
+	}
+}
+
+static int eddsa_msg_hash(sign_job *J, u32 i, u8 *ph_out)
+{
+	/* eddsa_compute_pre_hash (sig/eddsa.c:1049-1080): PH(M) with the variant's hash */
+	hash_context hp;
+	return J->hm->hfunc_init(&hp) || J->hm->hfunc_update(&hp, J->m[i], J->m_len[i]) || J->hm->hfunc_finalize(&hp, ph_out);
+}
+
+static void eddsa_sign_pack(u32 lo, u32 hi, void *arg)
+{
+	sign_job *J = (sign_job *)arg;
+	u32 j, k;
+	for (j = lo; j < hi; j++) {
+		const u32 i = J->idx[j];
+		const ec_key_pair *kp = J->kps[i];
+		const u8 *ad = J->adata ? J->adata[i] : NULL;
+		const u16 adl = J->adata_len ? J->adata_len[i] : 0;
+		u8 dig[MAX_DIGEST_SIZE], ph[MAX_DIGEST_SIZE];
+		u8 *rh = J->b2 + (size_t)j * J->hlen, *as = J->b3 + (size_t)j * J->klen;
+		hash_context hc;
+		bitcnt_t blen = 0;
+		int bad;
+		/* _eddsa_sign up to the multiplication (sig/eddsa.c:1596-1731) */
+		bad = J->pre[j] || !J->sigs[i] || (!J->m[i] && J->m_len[i]) || nn_bitlen(&kp->priv_key.x, &blen) || (u32)blen > 8 * J->hlen;
+#if defined(WITH_SIG_EDDSA25519)
+		bad = bad || (J->sig_type == EDDSA25519CTX && !ad);
+#endif
+		bad = bad || nn_to_be(dig, J->hlen, &kp->priv_key.x);   /* eddsa_get_digest_from_priv_key :306 */
+		bad = bad || (J->ph && eddsa_msg_hash(J, i, ph));
+		bad = bad || J->hm->hfunc_init(&hc);
+		if (!bad && J->dom) {
+			bad = dom_prefix(J->hm, &hc, J->is448, J->ph, ad, adl);
+		}
+		bad = bad || J->hm->hfunc_update(&hc, dig + J->klen, J->klen);   /* the prefix: second half of the hashed key */
+		if (!bad && J->ph) {
+			bad = J->hm->hfunc_update(&hc, ph, J->ph_len);
+		} else if (!bad) {
+			bad = J->hm->hfunc_update(&hc, J->m[i], J->m_len[i]);
+		}
+		bad = bad || J->hm->hfunc_finalize(&hc, rh);
+		J->pre[j] = bad ? 1 : 0;
+		if (bad) {
+			memset(rh, 0, J->hlen);
+			memset(as, 0, J->klen);
+		} else {
+			/* the secret scalar: first half of the hashed key, little-endian as the device takes it (eddsa_compute_s :291) */
+			for (k = 0; k < J->klen; k++) {
+				as[k] = dig[k];
+			}
+		}
+		wipe(dig, sizeof(dig));
+	}
+}
+
+static int eddsa_sign_gpu_R(u32 lo, u32 hi, void *arg)
+{
+	sign_job *J = (sign_job *)arg;
+	if (ecamd_multi_eddsa_sign_R_batch(g_multi, J->e->mc, hi - lo, J->b2 + (size_t)lo * J->hlen, J->b4 + (size_t)lo * J->klen, J->b7 + lo)) {
+		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+		return -1;
+	}
+	return 0;
+}
+
+static void eddsa_sign_hram(u32 lo, u32 hi, void *arg)
+{
+	sign_job *J = (sign_job *)arg;
+	u32 j;
+	for (j = lo; j < hi; j++) {
+		const u32 i = J->idx[j];
+		const u8 *ad = J->adata ? J->adata[i] : NULL;
+		const u16 adl = J->adata_len ? J->adata_len[i] : 0;
+		u8 ph[MAX_DIGEST_SIZE];
+		u8 *hr = J->b5 + (size_t)j * J->hlen;
+		hash_context hc;
+		int bad = J->pre[j] || J->b7[j] != 0;
+		/* H(dom || R || A || PH(M)) (sig/eddsa.c:1778-1836) */
+		bad = bad || (J->ph && eddsa_msg_hash(J, i, ph));
+		bad = bad || J->hm->hfunc_init(&hc);
+		if (!bad && J->dom) {
+			bad = dom_prefix(J->hm, &hc, J->is448, J->ph, ad, adl);
+		}
+		bad = bad || J->hm->hfunc_update(&hc, J->b4 + (size_t)j * J->klen, J->klen) || J->hm->hfunc_update(&hc, J->b1 + (size_t)j * J->klen, J->klen);
+		if (!bad && J->ph) {
+			bad = J->hm->hfunc_update(&hc, ph, J->ph_len);
+		} else if (!bad) {
+			bad = J->hm->hfunc_update(&hc, J->m[i], J->m_len[i]);
+		}
+		bad = bad || J->hm->hfunc_finalize(&hc, hr);
+		J->pre[j] = bad ? 1 : 0;
+		if (bad) {
+			memset(hr, 0, J->hlen);
+		}
+	}
+}
+
+static void eddsa_sign_out(u32 lo, u32 hi, void *arg)
+{
+	sign_job *J = (sign_job *)arg;
+	u32 j;
+	for (j = lo; j < hi; j++) {
+		const u32 i = J->idx[j];
+		if (!J->pre[j]) {
+			memcpy(J->sigs[i], J->b4 + (size_t)j * J->klen, J->klen);
+			memcpy(J->sigs[i] + J->klen, J->b6 + (size_t)j * J->klen, J->klen);
+		}
+		J->ret_items[i] = J->pre[j] ? -1 : 0;
+	}
+}
+
+static int eddsa_sign_group(sign_job *J, u32 cnt)
+{
+	u32 j;
+	J->clen = J->e->clen;
+	J->hlen = J->hm->digest_size;      /* 64 (SHA-512) / 114 (SHAKE256 as libecc configures it) */
+	J->klen = J->hlen / 2;             /* EDDSA_R_LEN = EDDSA_S_LEN: 32 / 57 */
+	J->ph_len = J->is448 ? 64 : J->hlen;   /* EDDSA448PH: SHAKE256 with 64 bytes (sig/eddsa.c:1650-1657) */
+	if (J->klen != (J->is448 ? 57u : 32u) || J->clen != (J->is448 ? 56u : 32u)) {
+		return -1;
+	}
+	if ((u32)J->siglen != J->hlen) {   /* MUST_HAVE((siglen == EDDSA_SIGLEN(hsize))), sig/eddsa.c:1638 */
+		for (j = 0; j < cnt; j++) {
+			J->ret_items[J->idx[j]] = -1;
+		}
+		return 0;
+	}
+	J->b0 = buf_get(0, (size_t)cnt * 3 * J->clen);
+	J->b1 = buf_get(1, (size_t)cnt * J->klen);
+	J->b2 = buf_get(2, (size_t)cnt * J->hlen);
+	J->b3 = buf_get(3, (size_t)cnt * J->klen);
+	J->b4 = buf_get(4, (size_t)cnt * J->klen);
+	J->b5 = buf_get(5, (size_t)cnt * J->hlen);
+	J->b6 = buf_get(6, (size_t)cnt * J->klen);
+	J->b7 = buf_get(7, cnt);
+	J->pre = buf_get(8, cnt);
+	if (!J->b0 || !J->b1 || !J->b2 || !J->b3 || !J->b4 || !J->b5 || !J->b6 || !J->b7 || !J->pre) {
+		return -1;
+	}
+	/* 1. the public keys as the hash takes them: exported as points here, encoded on the device (pre[j] != 0: no encoding) */
+	parallel_for(cnt, eddsa_sign_keys, J);
+	if (ecamd_multi_eddsa_encode_point_batch(g_multi, J->e->mc, cnt, J->b0, J->b1, J->pre)) {
+		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+		return -1;
+	}
+	/* 2. r = H(dom || prefix || PH(M)) on the host | R = [r]G encoded on the device | H(dom || R || A || PH(M)) on the host */
+	if (pipeline_run(cnt, chunk_items(g_chunk), eddsa_sign_pack, eddsa_sign_gpu_R, eddsa_sign_hram, J)) {
+		return -1;
+	}
+	/* 3. S = (r + h a) mod q */
+	if (ecamd_multi_eddsa_sign_S_batch(g_multi, J->e->mc, cnt, J->b2, J->b5, J->b3, J->b6)) {
+		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+		return -1;
+	}
+	parallel_for(cnt, eddsa_sign_out, J);
+	note_items(cnt);
+	return 0;
+}
+
+/* every other algorithm: libecc's own _ec_sign, item by item on the host threads */
+static void cpu_sign_items(u32 lo, u32 hi, void *arg)
+{
+	sign_job *J = (sign_job *)arg;
+	u32 j;
+	for (j = lo; j < hi; j++) {
+		const u32 i = J->idx[j];
+		J->ret_items[i] = (J->kps[i] && J->sigs[i] && (J->m[i] || !J->m_len[i])) ?
+			_ec_sign(J->sigs[i], J->siglen, J->kps[i], J->m[i], J->m_len[i], J->rand, J->sig_type, J->hash_type,
+				 J->adata ? J->adata[i] : NULL, J->adata_len ? J->adata_len[i] : 0) : -1;
+		if (J->ret_items[i]) {
+			J->ret_items[i] = -1;
+		}
+	}
+}
+
+int ec_sign_batch(u8 *const *sigs, u8 siglen, const ec_key_pair *const *key_pairs, const u8 *const *m, const u32 *m_len, u32 num,
+		  int (*rand)(nn_t out, nn_src_t q), ec_alg_type sig_type, hash_alg_type hash_type, const u8 *const *adata,
+		  const u16 *adata_len, int *ret_items)
+{
+	const hash_mapping *hm;
+	const ec_sig_mapping *sm = NULL;
+	hash_alg_type eh = UNKNOWN_HASH_ALG;
+	ec_curve_type ec = UNKNOWN_CURVE;
+	int ph = 0, dom = 0, is448 = 0, ed, ret = -1, *rets = ret_items;
+	u32 *idx = NULL, i, done = 0;
+	u8 *seen = NULL;
+	if (!sigs || !key_pairs || !m || !m_len) {
+		return -1;
+	}
+	if (num == 0) {
+		return 0;
+	}
+	if (get_sig_by_type(sig_type, &sm) || !sm) {
+		return -1;   /* _ec_sign: unknown algorithm (sig/sig_algs.c:476) */
+	}
+	ed = !eddsa_variant(sig_type, &eh, &ec, &ph, &dom, &is448);
+	if (!rets) {
+		rets = (int *)malloc((size_t)num * sizeof(int));
+		if (!rets) {
+			return -1;
+		}
+	}
+	for (i = 0; i < num; i++) {
+		rets[i] = -1;
+	}
+	hm = find_hash(hash_type);
+	idx = (u32 *)malloc((size_t)num * sizeof(u32));
+	seen = (u8 *)calloc(num, 1);
+	if (!idx || !seen) {
+		goto out;
+	}
+	if (!hm || (ed && (hash_type != eh || rand != NULL))) {
+		ret = 0;   /* every ec_sign fails: unknown hash (_ec_sign_init), or EdDSA with another hash / a nonce source (sig/eddsa.c:1596,1612) */
+		goto out;
+	}
+	if (ecamd_compat_init(NULL, 0, 0)) {
+		goto out;
+	}
+	pthread_mutex_lock(&g_call_mu);
+	/* groups of items that share their ec_params (one GPU batch each; normally there is one group) */
+	ret = 0;
+	while (done < num && !ret) {
+		const ec_params *params = NULL;
+		sign_job J;
+		u32 cnt = 0;
+		for (i = 0; i < num; i++) {
+			const ec_key_pair *kp = key_pairs[i];
+			if (seen[i]) {
+				continue;
+			}
+			if (!kp || kp->priv_key.magic != PRIV_KEY_MAGIC || !kp->priv_key.params) {
+				seen[i] = 1;   /* stays -1 */
+				done++;
+				continue;
+			}
+			if (!params) {
+				params = kp->priv_key.params;
+			}
+			if (kp->priv_key.params == params) {
+				idx[cnt++] = i;
+				seen[i] = 1;
+				done++;
+			}
+		}
+		if (!cnt) {
+			break;
+		}
+		memset(&J, 0, sizeof(J));
+		J.sigs = sigs; J.kps = key_pairs; J.m = m; J.m_len = m_len; J.adata = adata; J.adata_len = adata_len; J.rand = rand;
+		J.sig_type = sig_type; J.hash_type = hash_type; J.hm = hm; J.idx = idx; J.params = params; J.ret_items = rets; J.siglen = siglen;
+		J.ph = ph; J.dom = dom; J.is448 = is448;
+		if (ed || is_ecdsa(sig_type)) {
+			if (ed && params->curve_type != ec) {
+				continue;   /* eddsa_key_type_check_curve fails: -1 for the group */
+			}
+			J.e = curve_from_params(params);
+			if (!J.e) {
+				ret = -1;
+				break;
+			}
+			ret = ed ? eddsa_sign_group(&J, cnt) : ecdsa_sign_group(&J, cnt);
+		} else {
+			parallel_for(cnt, cpu_sign_items, &J);
+		}
+	}
+	wipe_secrets();
+	pthread_mutex_unlock(&g_call_mu);
+out:
+	if (rets != ret_items) {
+		free(rets);
+	}
+	free(idx);
+	free(seen);
+	return ret;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * signature verification
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+	const u8 **s, **m, **adata;
+	const u8 *s_len;
+	const u32 *m_len;
+	const u16 *adata_len;
+	const ec_pub_key **pub_keys;
+	ec_alg_type sig_type;
+	const hash_mapping *hm;
+	const u32 *idx;          /* the items of this group */
+	const ec_params *params;
+	curve_ent *e;
+	u8 *pk, *sg, *dg, *pre, *res;  /* packed: keys (projective X||Y||Z or EdDSA encoding), signatures, digests / hram, pre-check, result */
+	u8 *kprj;                /* EdDSA: the key points X||Y||Z, input of the device-side encoding */
+	u32 clen, qlen, hlen, klen, siglen;
+	int ph, dom, is448;
+	u32 ph_len;              /* bytes of PH(M) that enter the main hash */
+	int all_only, all_ok;    /* EdDSA: only the conjunction is wanted; its value so far */
+} ver_job;
+
+/* ---- ECDSA / DECDSA ---- */
+static void ecdsa_pack(u32 lo, u32 hi, void *arg)
+{
+	ver_job *J = (ver_job *)arg;
+	u32 j;
+	for (j = lo; j < hi; j++) {
+		const u32 i = J->idx[j];
+		const ec_pub_key *pk = J->pub_keys[i];
+		hash_context hc;
+		int bad;
+		/* ec_verify_init / __ecdsa_verify_init (sig/sig_algs.c:516, sig/ecdsa_common.c:623-649): key initialised and of
+		 * this algorithm, signature present and of the expected length; then H(m).  The key leaves as the live limbs of
+		 * pk->y (what ec_pub_key_export_to_buf writes); the device checks the curve equation at import, as the reference's
+		 * multiplication does (curves/prj_pt.c:1765). */
+		bad = pub_key_check_initialized_and_type(pk, J->sig_type) || pk->params != J->params || !J->s[i] ||
+		      J->s_len[i] != J->siglen || (!J->m[i] && J->m_len[i]);
+		bad = bad || prj_to_be(J->pk + (size_t)j * 3 * J->clen, J->clen, &pk->y, &(J->params->ec_curve));
+		bad = bad || J->hm->hfunc_init(&hc) || J->hm->hfunc_update(&hc, J->m[i], J->m_len[i]) ||
+		      J->hm->hfunc_finalize(&hc, J->dg + (size_t)j * J->hlen);
+		J->pre[j] = bad ? 1 : 0;
+		if (bad) {
+			memset(J->pk + (size_t)j * 3 * J->clen, 0xff, 3 * J->clen);
+			memset(J->sg + (size_t)j * J->siglen, 0, J->siglen);
+			memset(J->dg + (size_t)j * J->hlen, 0, J->hlen);
+		} else {
+			memcpy(J->sg + (size_t)j * J->siglen, J->s[i], J->siglen);
+		}
+	}
+}
+
+static int ecdsa_ver_gpu(u32 lo, u32 hi, void *arg)
+{
+	ver_job *J = (ver_job *)arg;
+	if (ecamd_multi_ecdsa_verify_batch_fmt(g_multi, J->e->mc, hi - lo, J->pk + (size_t)lo * 3 * J->clen, ECAMD_PT_PROJECTIVE,
+					       J->sg + (size_t)lo * J->siglen, J->dg + (size_t)lo * J->hlen, J->hlen, J->res + lo)) {
+		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+		return -1;
+	}
+	return 0;
+}
+
+/* results[i] for the items idx[0..cnt) that share `params` */
+static int ecdsa_group(ver_job *J, u32 cnt, int *results)
+{
+	u32 j;
+	J->clen = J->e->clen;
+	J->qlen = J->e->qlen;
+	J->siglen = 2 * (u32)BYTECEIL(J->params->ec_gen_order_bitlen);   /* ECDSA_SIGLEN */
+	if (J->siglen != 2 * J->e->qlen) {
+		return -1;
+	}
+	J->hlen = J->hm->digest_size;
+	J->pk = buf_get(0, (size_t)cnt * 3 * J->clen);
+	J->sg = buf_get(1, (size_t)cnt * J->siglen);
+	J->dg = buf_get(2, (size_t)cnt * J->hlen);
+	J->pre = buf_get(3, cnt);
+	J->res = buf_get(4, cnt);
+	if (!J->pk || !J->sg || !J->dg || !J->pre || !J->res) {
+		return -1;
+	}
+	if (pipeline_run(cnt, chunk_items(g_chunk), ecdsa_pack, ecdsa_ver_gpu, NULL, J)) {
+		return -1;
+	}
+	note_items(cnt);
+	for (j = 0; j < cnt; j++) {
+		results[J->idx[j]] = (J->pre[j] || J->res[j]) ? -1 : 0;
+	}
+	return 0;
+}
+
+/* ---- EdDSA ---- */
 /* first pass of an EdDSA group: the projective key points as octets for ec_eddsa_encode_point_batch */
 static void eddsa_export_keys(u32 lo, u32 hi, void *arg)
 {
-	ed_job *E = (ed_job *)arg;
-	ver_job *J = &E->v;
+	ver_job *J = (ver_job *)arg;
 	u32 j;
 	for (j = lo; j < hi; j++) {
 		const ec_pub_key *pk = J->pub_keys[J->idx[j]];
 		u8 *dst = J->kprj + (size_t)j * 3 * J->clen;
 		if (pub_key_check_initialized_and_type(pk, J->sig_type) || pk->params != J->params ||
-		    prj_pt_export_to_buf(&pk->y, dst, (u32)(3 * J->clen))) {
+		    prj_to_be(dst, J->clen, &pk->y, &(J->params->ec_curve))) {
 			memset(dst, 0xff, (size_t)3 * J->clen);   /* coordinates >= p: an import error on the device */
 		}
 	}
@@ -772,8 +2353,7 @@ static void eddsa_export_keys(u32 lo, u32 hi, void *arg)
 
 static void eddsa_pack(u32 lo, u32 hi, void *arg)
 {
-	ed_job *E = (ed_job *)arg;
-	ver_job *J = &E->v;
+	ver_job *J = (ver_job *)arg;
 	u32 j;
 	for (j = lo; j < hi; j++) {
 		const u32 i = J->idx[j];
@@ -795,17 +2375,17 @@ static void eddsa_pack(u32 lo, u32 hi, void *arg)
 		 * computed on the device for the whole group (eddsa_group; libecc's own export costs about 1.5 ms of CPU per key) */
 		bad = bad || J->pre[j];
 		bad = bad || J->hm->hfunc_init(&hc);
-		if (!bad && E->dom) {
-			bad = dom_prefix(J->hm, &hc, E->is448, E->ph, ad, adl);
+		if (!bad && J->dom) {
+			bad = dom_prefix(J->hm, &hc, J->is448, J->ph, ad, adl);
 		}
 		bad = bad || J->hm->hfunc_update(&hc, J->s[i], J->klen) || J->hm->hfunc_update(&hc, kenc, J->klen);
-		if (!bad && E->ph) {
+		if (!bad && J->ph) {
 			bad = J->hm->hfunc_init(&hp) || J->hm->hfunc_update(&hp, J->m[i], J->m_len[i]) || J->hm->hfunc_finalize(&hp, dig) ||
-			      J->hm->hfunc_update(&hc, dig, E->ph_len);
+			      J->hm->hfunc_update(&hc, dig, J->ph_len);
 		} else if (!bad) {
 			bad = J->hm->hfunc_update(&hc, J->m[i], J->m_len[i]);
 		}
-		bad = bad || J->hm->hfunc_finalize(&hc, dig);
+		bad = bad || J->hm->hfunc_finalize(&hc, J->dg + (size_t)j * J->hlen);
 		J->pre[j] = bad ? 1 : 0;
 		if (bad) {
 			memset(kenc, 0xff, J->klen);   /* y >= p: rejected by the decoder */
@@ -813,105 +2393,96 @@ static void eddsa_pack(u32 lo, u32 hi, void *arg)
 			memset(J->dg + (size_t)j * J->hlen, 0, J->hlen);
 		} else {
 			memcpy(J->sg + (size_t)j * J->siglen, J->s[i], J->siglen);
-			memcpy(J->dg + (size_t)j * J->hlen, dig, J->hlen);
 		}
 	}
 }
 
-/* set by eddsa_verify_batch_gpu: the caller only wants ec_verify_batch's one bit, so a group may be decided by the
- * device's multi-scalar multiplication (the reference's own random linear combination, ec_eddsa_verify_all_batch) */
-static __thread int t_all_only = 0;
-
-static int eddsa_group(ed_job *E, u32 cnt, int *results)
+static int eddsa_ver_gpu(u32 lo, u32 hi, void *arg)
 {
-	ver_job *J = &E->v;
-	curve_ent *e = curve_from_params(J->params);
-	u8 *res = NULL;
-	u32 j;
-	int ret = -1;
-	if (!e) {
+	ver_job *J = (ver_job *)arg;
+	if (ecamd_multi_eddsa_verify_batch(g_multi, J->e->mc, hi - lo, J->pk + (size_t)lo * J->klen, J->sg + (size_t)lo * J->siglen,
+					   J->dg + (size_t)lo * J->hlen, J->hlen, J->res + lo)) {
+		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
 		return -1;
 	}
-	J->clen = e->clen;
-	J->hlen = J->hm->digest_size;      /* 64 (SHA-512) / 114 (SHAKE256 as libecc configures it) */
-	J->klen = J->hlen / 2;             /* EDDSA_R_LEN: 32 / 57 */
-	J->siglen = J->hlen;               /* EDDSA_SIGLEN */
-	if (J->klen != (E->is448 ? 57u : 32u) || J->clen != (E->is448 ? 56u : 32u)) {
-		return -1;
-	}
-	J->pk = (u8 *)malloc((size_t)cnt * J->klen);
-	J->sg = (u8 *)malloc((size_t)cnt * J->siglen);
-	J->dg = (u8 *)malloc((size_t)cnt * J->hlen);
-	J->pre = (u8 *)malloc(cnt);
-	J->kprj = (u8 *)malloc((size_t)cnt * 3 * J->clen);
-	res = (u8 *)malloc(cnt);
-	if (!J->pk || !J->sg || !J->dg || !J->pre || !J->kprj || !res) {
-		goto done;
-	}
-	/* the keys as the reference hashes them: exported as points here, encoded on the device (pre[j] != 0: no encoding) */
-	parallel_for(cnt, eddsa_export_keys, E);
-	if (ecamd_multi_eddsa_encode_point_batch(g_multi, e->mc, cnt, J->kprj, J->pk, J->pre)) {
-		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
-		goto done;
-	}
-	parallel_for(cnt, eddsa_pack, E);
-	if (t_all_only) {
-		int all = 0, pre_bad = 0;
-		for (j = 0; j < cnt; j++) {
-			pre_bad |= J->pre[j];
-		}
-		if (!pre_bad) {
-			if (ecamd_multi_eddsa_verify_all_batch(g_multi, e->mc, cnt, J->pk, J->sg, J->dg, J->hlen, &all, NULL)) {
-				fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
-				goto done;
-			}
-			if (all) {
-				note_items(cnt);
-				for (j = 0; j < cnt; j++) {
-					results[J->idx[j]] = 0;
-				}
-				ret = 0;
-				goto done;
-			}
-		}
-		/* rejected (or an item failed before the device): the item-by-item results below say which */
-	}
-	if (ecamd_multi_eddsa_verify_batch(g_multi, e->mc, cnt, J->pk, J->sg, J->dg, J->hlen, res)) {
-		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
-		goto done;
-	}
-	note_items(cnt);
-	for (j = 0; j < cnt; j++) {
-		results[J->idx[j]] = (J->pre[j] || res[j]) ? -1 : 0;
-	}
-	ret = 0;
-done:
-	free(J->pk);
-	free(J->sg);
-	free(J->dg);
-	free(J->pre);
-	free(res);
-	J->pk = J->sg = J->dg = J->pre = NULL;
-	return ret;
-}
-
-static int is_ecdsa(ec_alg_type t)
-{
-#if defined(WITH_SIG_ECDSA)
-	if (t == ECDSA) {
-		return 1;
-	}
-#endif
-#if defined(WITH_SIG_DECDSA)
-	if (t == DECDSA) {
-		return 1;
-	}
-#endif
 	return 0;
 }
 
-int ec_verify_batch_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
-			    ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len, int *results)
+/* the caller only wants ec_verify_batch's one bit: a chunk is decided by the device's multi-scalar multiplication (the
+ * reference's own random linear combination, ec_eddsa_verify_all_batch) after the host-side checks of its items */
+static int eddsa_ver_gpu_all(u32 lo, u32 hi, void *arg)
+{
+	ver_job *J = (ver_job *)arg;
+	int all = 0;
+	u32 j;
+	if (!J->all_ok) {
+		return 0;   /* already rejected: the remaining chunks cannot change the answer */
+	}
+	for (j = lo; j < hi; j++) {
+		if (J->pre[j]) {
+			J->all_ok = 0;
+			return 0;
+		}
+	}
+	if (ecamd_multi_eddsa_verify_all_batch(g_multi, J->e->mc, hi - lo, J->pk + (size_t)lo * J->klen, J->sg + (size_t)lo * J->siglen,
+					       J->dg + (size_t)lo * J->hlen, J->hlen, &all, NULL)) {
+		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+		return -1;
+	}
+	if (!all) {
+		J->all_ok = 0;
+	}
+	return 0;
+}
+
+static int eddsa_group(ver_job *J, u32 cnt, int *results)
+{
+	u32 j;
+	J->clen = J->e->clen;
+	J->hlen = J->hm->digest_size;      /* 64 (SHA-512) / 114 (SHAKE256 as libecc configures it) */
+	J->klen = J->hlen / 2;             /* EDDSA_R_LEN: 32 / 57 */
+	J->siglen = J->hlen;               /* EDDSA_SIGLEN */
+	if (J->klen != (J->is448 ? 57u : 32u) || J->clen != (J->is448 ? 56u : 32u)) {
+		return -1;
+	}
+	J->pk = buf_get(0, (size_t)cnt * J->klen);
+	J->sg = buf_get(1, (size_t)cnt * J->siglen);
+	J->dg = buf_get(2, (size_t)cnt * J->hlen);
+	J->pre = buf_get(3, cnt);
+	J->res = buf_get(4, cnt);
+	J->kprj = buf_get(5, (size_t)cnt * 3 * J->clen);
+	if (!J->pk || !J->sg || !J->dg || !J->pre || !J->res || !J->kprj) {
+		return -1;
+	}
+	/* the keys as the reference hashes them: exported as points here, encoded on the device (pre[j] != 0: no encoding) */
+	parallel_for(cnt, eddsa_export_keys, J);
+	if (ecamd_multi_eddsa_encode_point_batch(g_multi, J->e->mc, cnt, J->kprj, J->pk, J->pre)) {
+		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+		return -1;
+	}
+	if (J->all_only) {
+		J->all_ok = 1;
+		if (pipeline_run(cnt, chunk_items(g_chunk_all), eddsa_pack, eddsa_ver_gpu_all, NULL, J)) {
+			return -1;
+		}
+		note_items(cnt);
+		for (j = 0; j < cnt; j++) {
+			results[J->idx[j]] = J->all_ok ? 0 : -1;   /* only their conjunction is looked at */
+		}
+		return 0;
+	}
+	if (pipeline_run(cnt, chunk_items(g_chunk), eddsa_pack, eddsa_ver_gpu, NULL, J)) {
+		return -1;
+	}
+	note_items(cnt);
+	for (j = 0; j < cnt; j++) {
+		results[J->idx[j]] = (J->pre[j] || J->res[j]) ? -1 : 0;
+	}
+	return 0;
+}
+
+static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
+			  ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len, int *results, int all_only)
 {
 	const hash_mapping *hm;
 	hash_alg_type eh = UNKNOWN_HASH_ALG;
@@ -936,6 +2507,9 @@ int ec_verify_batch_results(const u8 **s, const u8 *s_len, const ec_pub_key **pu
 	if (!hm || (ed && hash_type != eh)) {
 		return 0;   /* every ec_verify fails in ec_verify_init / _eddsa_verify_init */
 	}
+	if (ecamd_compat_init(NULL, 0, 0)) {
+		return -1;
+	}
 	idx = (u32 *)malloc((size_t)num * sizeof(u32));
 	seen = (u8 *)calloc(num, 1);
 	if (!idx || !seen) {
@@ -944,7 +2518,9 @@ int ec_verify_batch_results(const u8 **s, const u8 *s_len, const ec_pub_key **pu
 	/* groups of items that share their ec_params (one GPU batch each; normally there is one group) */
 	while (done < num) {
 		const ec_params *params = NULL;
+		ver_job J;
 		u32 cnt = 0;
+		int r;
 		for (i = 0; i < num; i++) {
 			const ec_pub_key *pk = pub_keys[i];
 			if (seen[i]) {
@@ -967,27 +2543,24 @@ int ec_verify_batch_results(const u8 **s, const u8 *s_len, const ec_pub_key **pu
 		if (!cnt) {
 			break;
 		}
-		if (ed) {
-			ed_job E;
-			memset(&E, 0, sizeof(E));
-			if (params->curve_type != ec) {
-				continue;   /* eddsa_key_type_check_curve fails: -1 for the group */
-			}
-			E.v.s = s; E.v.s_len = s_len; E.v.m = m; E.v.m_len = m_len; E.v.adata = adata; E.v.adata_len = adata_len;
-			E.v.pub_keys = pub_keys; E.v.sig_type = sig_type; E.v.hm = hm; E.v.idx = idx; E.v.params = params;
-			E.ph = ph; E.dom = dom; E.is448 = is448;
-			E.ph_len = is448 ? 64 : hm->digest_size;   /* EDDSA448PH: SHAKE256 with 64 bytes (sig/eddsa.c:2343-2346) */
-			if (eddsa_group(&E, cnt, results)) {
-				goto out;
-			}
-		} else {
-			ver_job J;
-			memset(&J, 0, sizeof(J));
-			J.s = s; J.s_len = s_len; J.m = m; J.m_len = m_len; J.adata = adata; J.adata_len = adata_len;
-			J.pub_keys = pub_keys; J.sig_type = sig_type; J.hm = hm; J.idx = idx; J.params = params;
-			if (ecdsa_group(&J, cnt, results)) {
-				goto out;
-			}
+		if (ed && params->curve_type != ec) {
+			continue;   /* eddsa_key_type_check_curve fails: -1 for the group */
+		}
+		memset(&J, 0, sizeof(J));
+		J.s = s; J.s_len = s_len; J.m = m; J.m_len = m_len; J.adata = adata; J.adata_len = adata_len;
+		J.pub_keys = pub_keys; J.sig_type = sig_type; J.hm = hm; J.idx = idx; J.params = params;
+		J.ph = ph; J.dom = dom; J.is448 = is448;
+		J.ph_len = is448 ? 64 : hm->digest_size;   /* EDDSA448PH: SHAKE256 with 64 bytes (sig/eddsa.c:2343-2346) */
+		J.all_only = all_only && ed;
+		J.e = curve_from_params(params);
+		if (!J.e) {
+			goto out;
+		}
+		pthread_mutex_lock(&g_call_mu);
+		r = ed ? eddsa_group(&J, cnt, results) : ecdsa_group(&J, cnt, results);
+		pthread_mutex_unlock(&g_call_mu);
+		if (r) {
+			goto out;
 		}
 	}
 	ret = 0;
@@ -997,8 +2570,14 @@ out:
 	return ret;
 }
 
+int ec_verify_batch_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
+			    ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len, int *results)
+{
+	return verify_results(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, results, 0);
+}
+
 static int all_accepted(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
-			ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len)
+			ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len, int all_only)
 {
 	int *res, ret = -1;
 	u32 i;
@@ -1009,7 +2588,7 @@ static int all_accepted(const u8 **s, const u8 *s_len, const ec_pub_key **pub_ke
 	if (!res) {
 		return -1;
 	}
-	if (!ec_verify_batch_results(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, res)) {
+	if (!verify_results(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, res, all_only)) {
 		ret = 0;
 		for (i = 0; i < num; i++) {
 			if (res[i]) {
@@ -1030,7 +2609,7 @@ int ecdsa_verify_batch(const u8 **s, const u8 *s_len, const ec_pub_key **pub_key
 	if (!is_ecdsa(sig_type)) {
 		return -1;
 	}
-	return all_accepted(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len);
+	return all_accepted(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, 0);
 }
 
 int eddsa_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
@@ -1068,13 +2647,7 @@ int eddsa_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **pub
 			return -1;   /* "all our public keys have the same parameters" */
 		}
 	}
-	{
-		int r;
-		t_all_only = 1;
-		r = all_accepted(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len);
-		t_all_only = 0;
-		return r;
-	}
+	return all_accepted(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, 1);
 }
 
 /* ------------------------------------------------------------------------------------------------

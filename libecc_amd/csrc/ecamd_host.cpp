@@ -493,6 +493,67 @@ extern "C" int ecamd_ctx_kernel_times(ecamd_ctx *c, double *ms, int n)
 	return 0;
 }
 
+extern "C" void *ecamd_ctx_stream(ecamd_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+// Page-locked host memory for the arrays handed to the host-pointer entry points: the copies to and from the device then run
+// as asynchronous DMA at PCIe rate instead of going through the runtime's pageable staging.  Portable: valid for every device.
+extern "C" void *ecamd_host_alloc(size_t bytes)
+{
+	void *p = nullptr;
+	if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+		(void)hipGetLastError();
+		fail("ecamd_host_alloc: hipHostMalloc failed");
+		return nullptr;
+	}
+	return p;
+}
+
+extern "C" void ecamd_host_free(void *p)
+{
+	if (p) {
+		(void)hipHostFree(p);
+	}
+}
+
+// Zero every scratch buffer of the context (window tables, recoded scalars, staged inputs and outputs): after calls that
+// worked on secret scalars nothing derived from them stays in HBM.  Enqueued behind the context's last call; synchronous.
+extern "C" int ecamd_ctx_wipe_scratch(ecamd_ctx *c)
+{
+	if (!c) {
+		return fail("ecamd_ctx_wipe_scratch: NULL context");
+	}
+	std::lock_guard<std::mutex> lk(c->mu);
+	HIPCHK(hipSetDevice(c->device));
+	hipStream_t s = c->stream;
+	if (c->inflight && c->last_stream != s) {
+		HIPCHK(hipStreamWaitEvent(s, c->busy, 0));
+	}
+	HIPCHK(hipStreamSynchronize(c->copy_stream));
+	if (c->tbl) {
+		HIPCHK(hipMemsetAsync(c->tbl, 0, c->tbl_bytes, s));
+	}
+	if (c->tbl_fast) {
+		HIPCHK(hipMemsetAsync(c->tbl_fast, 0, c->tbl_fast_bytes, s));
+	}
+	if (c->msm) {
+		HIPCHK(hipMemsetAsync(c->msm, 0, c->msm_bytes, s));
+	}
+	for (int i = 0; i < ECAMD_NSTAGE; i++) {
+		if (c->stage[i]) {
+			HIPCHK(hipMemsetAsync(c->stage[i], 0, c->stage_bytes[i], s));
+		}
+	}
+	for (int b = 0; b < 2; b++) {
+		for (int k = 0; k < 6; k++) {
+			if (c->hbuf[b][k]) {
+				HIPCHK(hipMemsetAsync(c->hbuf[b][k], 0, c->hbuf_bytes[b][k], s));
+			}
+		}
+	}
+	HIPCHK(hipStreamSynchronize(s));
+	return 0;
+}
+
 extern "C" int ecamd_ctx_synchronize(ecamd_ctx *c)
 {
 	if (!c) {
@@ -522,6 +583,16 @@ struct StreamScope {
 			c->inflight = true;
 		}
 	}
+};
+
+// Scalars that are public by construction (u1, u2 of a verification, h and S of EdDSA, the group order and cofactor of a
+// subgroup check) keep the digit-indexed look-ups and the comb table even when the context is in secret-scalar mode
+// (ecamd_ctx_set_secret_scalars is about private keys, nonces and blinded scalars).  ctx->mu held.
+struct PublicScalars {
+	ecamd_ctx *c;
+	bool saved;
+	explicit PublicScalars(ecamd_ctx *ctx) : c(ctx), saved(ctx->secret_scalars) { c->secret_scalars = false; }
+	~PublicScalars() { c->secret_scalars = saved; }
 };
 
 static int ensure(uint8_t **buf, size_t *have, size_t need)
@@ -1524,6 +1595,7 @@ static int ecdsa_two_smul_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n,
 		return 0;
 	}
 	const size_t plen = (size_t)2 * cv->clen, ql = (size_t)cv->qlen;
+	PublicScalars pub_scope(ctx);   // u1, u2 and the group order are public
 	// stage: 3 u1, 4 u2, 5 A, 6 B, 7 stA, 8 stB, 9 flags, 10 subgroup status, 11 q scalar / tmp
 	const size_t need[12] = {0, 0, 0, n * ql, n * ql, n * plen, n * plen, n, n, n, n, n * plen + 256};
 	for (int i = 3; i < 12; i++) {
@@ -1953,6 +2025,7 @@ static int ecccdh_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, 
 		// cofactor h != 1 (ecdh/ecccdh.c:187-217): the peer key must lie in the subgroup ([q]Q = infinity,
 		// sig/ec_key.c:199-205), then Q' = [h]Q must not be infinity, then [d]Q'
 		const uint8_t *d_q = cv->d_gen + plen, *d_h = d_q + ql;
+		PublicScalars pub_scope(ctx);   // the order and the cofactor are public; the private key below is not
 		if (smul_dev_locked(ctx, cv, n, d_q, (uint32_t)ql, d_peers, S[7], S[8], s, 0) ||
 		    smul_dev_locked(ctx, cv, n, d_h, 1, d_peers, S[5], S[6], s, 0)) {
 			return -1;
@@ -2486,9 +2559,12 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 		}
 		HIPCHK(ecamd_launch_ed_smul_c25519(E, cv->gslot, s));
 	}
-	if ((!edwards_hA && smul_dev_locked(ctx, cv, n, S[9], (uint32_t)len, S[3], S[12], S[13], s)) ||
-	    smul_dev_locked(ctx, cv, n, S[8], (uint32_t)len, nullptr, S[14], S[15], s)) {
-		return -1;
+	{
+		PublicScalars pub_scope(ctx);   // h and S of a signature are public
+		if ((!edwards_hA && smul_dev_locked(ctx, cv, n, S[9], (uint32_t)len, S[3], S[12], S[13], s)) ||
+		    smul_dev_locked(ctx, cv, n, S[8], (uint32_t)len, nullptr, S[14], S[15], s)) {
+			return -1;
+		}
 	}
 	EcamdEdFinArgs F;
 	memset(&F, 0, sizeof(F));
@@ -2666,9 +2742,12 @@ static int eddsa448_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t 
 	C.c4_mod4 = cv->ed448_c4[55] & 3u;
 	HIPCHK(ecamd_launch_ed448_scal(C, s));
 	// the reference's [4h mod q]([4^-1 mod q]A) as one multiplication of A (k_ed448_scal), and [S]G
-	if (smul_dev_locked(ctx, cv, n, S[9], (uint32_t)len, S[3], S[12], S[13], s) ||
-	    smul_dev_locked(ctx, cv, n, S[8], (uint32_t)len, nullptr, S[14], S[15], s)) {
-		return -1;
+	{
+		PublicScalars pub_scope(ctx);   // h and S of a signature are public
+		if (smul_dev_locked(ctx, cv, n, S[9], (uint32_t)len, S[3], S[12], S[13], s) ||
+		    smul_dev_locked(ctx, cv, n, S[8], (uint32_t)len, nullptr, S[14], S[15], s)) {
+			return -1;
+		}
 	}
 	EcamdEdFinArgs F;
 	memset(&F, 0, sizeof(F));

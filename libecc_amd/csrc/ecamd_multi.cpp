@@ -9,6 +9,7 @@
 // A device may be listed several times (one context and one shard each): the shards then share that GPU.
 // That is how the 1-GPU development box exercises this file (tests/test_gpu_parity.py::test_multi_*).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and enumerators only (ncclComm_t, ncclUint8, ncclResult_t): librccl itself is dlopen'ed on first use
 #include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -29,8 +30,9 @@ struct ecamd_multi {
 	std::mutex mu;              // one multi-call at a time (the per-device contexts serialise anyway)
 	// RCCL, loaded on the first all-gather
 	void *rccl = nullptr;
-	std::vector<void *> comms;  // ncclComm_t per rank
+	std::vector<ncclComm_t> comms;  // one communicator per rank
 	std::vector<hipStream_t> cstreams;
+	std::vector<hipEvent_t> cready;  // recorded on a rank's compute stream, waited for by its gather stream
 };
 
 struct ecamd_mcurve {
@@ -91,7 +93,32 @@ extern "C" int ecamd_multi_create(ecamd_multi **out, const int *devices, int nde
 	return 0;
 }
 
-typedef int (*nccl_destroy_fn)(void *);
+typedef ncclResult_t (*nccl_destroy_fn)(ncclComm_t);
+
+// communicators, gather streams and events of the all-gather, and the library handle (also the clean-up of a partial set-up)
+static void rccl_teardown(ecamd_multi *m, void *h)
+{
+	nccl_destroy_fn destroy = h ? (nccl_destroy_fn)dlsym(h, "ncclCommDestroy") : nullptr;
+	for (size_t r = 0; r < m->devices.size(); r++) {
+		(void)hipSetDevice(m->devices[r]);
+		if (destroy && r < m->comms.size() && m->comms[r]) {
+			(void)destroy(m->comms[r]);
+		}
+		if (r < m->cstreams.size() && m->cstreams[r]) {
+			(void)hipStreamDestroy(m->cstreams[r]);
+		}
+		if (r < m->cready.size() && m->cready[r]) {
+			(void)hipEventDestroy(m->cready[r]);
+		}
+	}
+	m->comms.clear();
+	m->cstreams.clear();
+	m->cready.clear();
+	if (h) {
+		dlclose(h);
+	}
+	m->rccl = nullptr;
+}
 
 extern "C" void ecamd_multi_destroy(ecamd_multi *m)
 {
@@ -99,16 +126,7 @@ extern "C" void ecamd_multi_destroy(ecamd_multi *m)
 		return;
 	}
 	if (m->rccl) {
-		nccl_destroy_fn destroy = (nccl_destroy_fn)dlsym(m->rccl, "ncclCommDestroy");
-		for (size_t r = 0; r < m->comms.size(); r++) {
-			(void)hipSetDevice(m->devices[r]);
-			if (destroy && m->comms[r]) {
-				(void)destroy(m->comms[r]);
-			}
-			if (r < m->cstreams.size() && m->cstreams[r]) {
-				(void)hipStreamDestroy(m->cstreams[r]);
-			}
-		}
+		rccl_teardown(m, m->rccl);
 	}
 	for (ecamd_ctx *c : m->ctx) {
 		ecamd_ctx_destroy(c);
@@ -368,18 +386,72 @@ extern "C" int ecamd_multi_prj_pt_unique_batch(ecamd_multi *m, const ecamd_mcurv
 	});
 }
 
+// ---- settings applied to every rank's context ----
+extern "C" int ecamd_multi_set_secret_scalars(ecamd_multi *m, int on)
+{
+	if (!m) {
+		return mfail("ecamd_multi_set_secret_scalars: NULL argument");
+	}
+	std::lock_guard<std::mutex> lk(m->mu);
+	for (ecamd_ctx *c : m->ctx) {
+		if (ecamd_ctx_set_secret_scalars(c, on)) {
+			return -1;
+		}
+	}
+	return 0;
+}
+
+extern "C" int ecamd_multi_wipe_scratch(ecamd_multi *m)
+{
+	if (!m) {
+		return mfail("ecamd_multi_wipe_scratch: NULL argument");
+	}
+	std::lock_guard<std::mutex> lk(m->mu);
+	for (ecamd_ctx *c : m->ctx) {
+		if (ecamd_ctx_wipe_scratch(c)) {
+			return -1;
+		}
+	}
+	return 0;
+}
+
+extern "C" int ecamd_multi_eddsa_sign_R_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *r_hash, uint8_t *R_enc,
+					      uint8_t *status)
+{
+	// Ed25519: 64-byte hashes, 32-byte encodings; Ed448: 114 / 57 (coordinate length 56)
+	const size_t cl = (size_t)ecamd_multi_curve_coord_len(c), kl = (cl == 56) ? 57 : cl;
+	return run_sharded(m, c, n, "ecamd_multi_eddsa_sign_R_batch", [&](int r, uint32_t lo, uint32_t hi) {
+		return ec_eddsa_sign_R_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(r_hash, 2 * kl), OFF(R_enc, kl), OFF(status, 1));
+	});
+}
+
+extern "C" int ecamd_multi_eddsa_sign_S_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *r_hash, const uint8_t *hram,
+					      const uint8_t *a_scalars, uint8_t *S_out)
+{
+	const size_t cl = (size_t)ecamd_multi_curve_coord_len(c), kl = (cl == 56) ? 57 : cl;
+	return run_sharded(m, c, n, "ecamd_multi_eddsa_sign_S_batch", [&](int r, uint32_t lo, uint32_t hi) {
+		return ec_eddsa_sign_S_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(r_hash, 2 * kl), OFF(hram, 2 * kl), OFF(a_scalars, kl),
+					     OFF(S_out, kl));
+	});
+}
+
 // ------------------------------------------------------------------------------------------
 // the one collective: RCCL all-gather of equal-size device-resident shards (north_star: "RCCL gather over xGMI
 // for the output points").  d_send[r]: bytes_per_rank bytes on device r; d_recv[r]: nranks * bytes_per_rank bytes
 // on device r.  librccl is loaded on first use (dlopen), one communicator per rank of this process
 // (ncclCommInitAll), the gathers of all ranks issued inside one group call.
 // ------------------------------------------------------------------------------------------
-typedef int (*nccl_init_all_fn)(void **, int, const int *);
-typedef int (*nccl_group_fn)(void);
-typedef int (*nccl_allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
-typedef const char *(*nccl_err_fn)(int);
+typedef ncclResult_t (*nccl_init_all_fn)(ncclComm_t *, int, const int *);
+typedef ncclResult_t (*nccl_group_fn)(void);
+typedef ncclResult_t (*nccl_allgather_fn)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+typedef const char *(*nccl_err_fn)(ncclResult_t);
 
-extern "C" int ecamd_multi_allgather(ecamd_multi *m, const void *const *d_send, void *const *d_recv, size_t bytes_per_rank)
+// The gathers run on private streams (one per rank) so that they overlap whatever the contexts enqueue next; each gather
+// stream first waits for an event recorded on its rank's compute stream, so shards produced by the *_dev entry points on
+// ecamd_multi_ctx(m, r)'s stream need no host synchronisation in between (producers on other streams: pass them in
+// `producer_streams`, one hipStream_t per rank, or synchronise them first).
+extern "C" int ecamd_multi_allgather_streams(ecamd_multi *m, const void *const *d_send, void *const *d_recv, size_t bytes_per_rank,
+					     void *const *producer_streams)
 {
 	if (!m || !d_send || !d_recv) {
 		return mfail("ecamd_multi_allgather: NULL argument");
@@ -387,7 +459,9 @@ extern "C" int ecamd_multi_allgather(ecamd_multi *m, const void *const *d_send, 
 	std::lock_guard<std::mutex> lk(m->mu);
 	const int N = (int)m->ctx.size();
 	if (N == 1) {
-		if (hipSetDevice(m->devices[0]) != hipSuccess ||
+		// the producer is drained first: the copy below runs on the null stream, the contexts' streams are non-blocking ones
+		hipStream_t prod = (producer_streams && producer_streams[0]) ? (hipStream_t)producer_streams[0] : (hipStream_t)ecamd_ctx_stream(m->ctx[0]);
+		if (hipSetDevice(m->devices[0]) != hipSuccess || hipStreamSynchronize(prod) != hipSuccess ||
 		    hipMemcpy(d_recv[0], d_send[0], bytes_per_rank, hipMemcpyDeviceToDevice) != hipSuccess) {
 			return mfail("ecamd_multi_allgather: device copy failed");
 		}
@@ -414,19 +488,22 @@ extern "C" int ecamd_multi_allgather(ecamd_multi *m, const void *const *d_send, 
 			return mfail("ecamd_multi_allgather: librccl has no ncclCommInitAll");
 		}
 		m->comms.assign((size_t)N, nullptr);
-		const int e = init_all(m->comms.data(), N, m->devices.data());
-		if (e != 0) {
+		const ncclResult_t e = init_all(m->comms.data(), N, m->devices.data());
+		if (e != ncclSuccess) {
 			nccl_err_fn es = (nccl_err_fn)dlsym(h, "ncclGetErrorString");
 			const std::string msg = std::string("ecamd_multi_allgather: ncclCommInitAll: ") + (es ? es(e) : "error");
-			dlclose(h);
 			m->comms.clear();
+			dlclose(h);
 			return mfail(msg);
 		}
 		m->cstreams.assign((size_t)N, nullptr);
+		m->cready.assign((size_t)N, nullptr);
 		for (int r = 0; r < N; r++) {
 			if (hipSetDevice(m->devices[(size_t)r]) != hipSuccess ||
-			    hipStreamCreateWithFlags(&m->cstreams[(size_t)r], hipStreamNonBlocking) != hipSuccess) {
-				return mfail("ecamd_multi_allgather: stream creation failed");
+			    hipStreamCreateWithFlags(&m->cstreams[(size_t)r], hipStreamNonBlocking) != hipSuccess ||
+			    hipEventCreateWithFlags(&m->cready[(size_t)r], hipEventDisableTiming) != hipSuccess) {
+				rccl_teardown(m, h);  // communicators, the streams and events made so far, the library handle: a retry starts afresh
+				return mfail("ecamd_multi_allgather: stream / event creation failed");
 			}
 		}
 		m->rccl = h;
@@ -437,16 +514,23 @@ extern "C" int ecamd_multi_allgather(ecamd_multi *m, const void *const *d_send, 
 	if (!gstart || !gend || !ag) {
 		return mfail("ecamd_multi_allgather: librccl misses ncclGroupStart / ncclGroupEnd / ncclAllGather");
 	}
-	int e = gstart();
-	for (int r = 0; r < N && e == 0; r++) {
-		// ncclUint8 = 1 in rccl.h's ncclDataType_t (ncclInt8 = ncclChar = 0)
-		e = ag(d_send[r], d_recv[r], bytes_per_rank, 1, m->comms[(size_t)r], m->cstreams[(size_t)r]);
+	// every gather stream waits for what its rank's producer stream holds at this point
+	for (int r = 0; r < N; r++) {
+		hipStream_t prod = (producer_streams && producer_streams[r]) ? (hipStream_t)producer_streams[r] : (hipStream_t)ecamd_ctx_stream(m->ctx[(size_t)r]);
+		if (hipSetDevice(m->devices[(size_t)r]) != hipSuccess || hipEventRecord(m->cready[(size_t)r], prod) != hipSuccess ||
+		    hipStreamWaitEvent(m->cstreams[(size_t)r], m->cready[(size_t)r], 0) != hipSuccess) {
+			return mfail("ecamd_multi_allgather: cannot order the gather behind the producer stream");
+		}
 	}
-	const int e2 = gend();
-	if (e == 0) {
+	ncclResult_t e = gstart();
+	for (int r = 0; r < N && e == ncclSuccess; r++) {
+		e = ag(d_send[r], d_recv[r], bytes_per_rank, ncclUint8, m->comms[(size_t)r], m->cstreams[(size_t)r]);
+	}
+	const ncclResult_t e2 = gend();
+	if (e == ncclSuccess) {
 		e = e2;
 	}
-	if (e != 0) {
+	if (e != ncclSuccess) {
 		return mfail(std::string("ecamd_multi_allgather: ") + (es ? es(e) : "RCCL error"));
 	}
 	for (int r = 0; r < N; r++) {
@@ -455,4 +539,9 @@ extern "C" int ecamd_multi_allgather(ecamd_multi *m, const void *const *d_send, 
 		}
 	}
 	return 0;
+}
+
+extern "C" int ecamd_multi_allgather(ecamd_multi *m, const void *const *d_send, void *const *d_recv, size_t bytes_per_rank)
+{
+	return ecamd_multi_allgather_streams(m, d_send, d_recv, bytes_per_rank, nullptr);
 }

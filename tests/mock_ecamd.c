@@ -1,0 +1,272 @@
+/*
+ * tests/mock_ecamd.c -- TEST INFRASTRUCTURE ONLY.  A CPU stand-in for the part of include/libecc_amd.h that
+ * libecc_amd/compat/libecc_amd_compat.c calls (the ecamd_multi_* entry points), built on the oracle
+ * (oracle/ecc_oracle.c) and on libecc itself.  It exists so that the HOST logic of the libecc-typed boundary -- the
+ * marshalling of nn / prj_pt / ec_key_pair, the thread pool and the pack | GPU | unpack pipeline, the grouping and the
+ * error paths -- can be run by `pytest -m "not gpu"` in a container without a GPU (tests/test_compat_host.py links
+ * compat_check.c + libecc_amd_compat.c + this file).  It is never linked into libsign_amd.so or libecc_amd.so; the product
+ * has no CPU path.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "libsig.h"
+#include "libecc_amd.h"
+#include "../oracle/ecc_oracle.h"
+
+struct ecamd_multi {
+	int nranks;
+	int secret;
+};
+struct ecamd_mcurve {
+	orc_curve c;
+	ec_params params;
+	int have_params;
+};
+
+static const char *g_err = "";
+const char *ecamd_last_error(void) { return g_err; }
+static int mfail(const char *m) { g_err = m; return -1; }
+
+static unsigned long g_calls, g_max_items;
+unsigned long mock_ecamd_calls(void) { return g_calls; }
+unsigned long mock_ecamd_max_items(void) { return g_max_items; }
+static void note(uint32_t n) { __atomic_add_fetch(&g_calls, 1, __ATOMIC_RELAXED); if (n > g_max_items) { g_max_items = n; } }
+
+int ecamd_multi_create(ecamd_multi **m, const int *devices, int ndev)
+{
+	(void)devices;
+	if (getenv("MOCK_ECAMD_NO_DEVICE")) {
+		return mfail("ecamd_multi_create: no HIP device available (mock)");
+	}
+	*m = calloc(1, sizeof(**m));
+	(*m)->nranks = ndev > 0 ? ndev : 1;
+	return 0;
+}
+void ecamd_multi_destroy(ecamd_multi *m) { free(m); }
+int ecamd_multi_size(const ecamd_multi *m) { return m ? m->nranks : 0; }
+int ecamd_multi_set_secret_scalars(ecamd_multi *m, int on) { m->secret = on; return 0; }
+int ecamd_multi_wipe_scratch(ecamd_multi *m) { (void)m; return 0; }
+void *ecamd_host_alloc(size_t bytes) { return malloc(bytes); }
+void ecamd_host_free(void *p) { free(p); }
+
+static int curve_from_ec_params(const ec_params *params, ecamd_mcurve **out)
+{
+	u8 b[7][80];
+	aff_pt g;
+	bitcnt_t ob = 0;
+	u32 clen = (u32)BYTECEIL(params->ec_fp.p_bitlen), qlen = (u32)BYTECEIL(params->ec_gen_order_bitlen), olen;
+	ecamd_mcurve *c = calloc(1, sizeof(*c));
+	if (nn_bitlen(&params->ec_curve.order, &ob)) return -1;
+	olen = (u32)BYTECEIL(ob);
+	if (prj_pt_to_aff(&g, &params->ec_gen) || nn_export_to_buf(b[0], (u16)clen, &params->ec_fp.p) || fp_export_to_buf(b[1], (u16)clen, &params->ec_curve.a) ||
+	    fp_export_to_buf(b[2], (u16)clen, &params->ec_curve.b) || nn_export_to_buf(b[3], (u16)olen, &params->ec_curve.order) ||
+	    fp_export_to_buf(b[4], (u16)clen, &g.x) || fp_export_to_buf(b[5], (u16)clen, &g.y) || nn_export_to_buf(b[6], (u16)qlen, &params->ec_gen_order) ||
+	    orc_curve_init(&c->c, b[0], (int)clen, b[1], (int)clen, b[2], (int)clen, b[3], (int)olen, b[4], (int)clen, b[5], (int)clen, b[6], (int)qlen)) {
+		free(c);
+		return mfail("mock: curve setup failed");
+	}
+	*out = c;
+	return 0;
+}
+
+int ecamd_multi_curve_by_name(ecamd_multi *m, const char *name, ecamd_mcurve **curve)
+{
+	const ec_str_params *sp = NULL;
+	ec_params params;
+	(void)m;
+	if (ec_get_curve_params_by_name((const u8 *)name, (u8)(strlen(name) + 1), &sp) || !sp || import_params(&params, sp)) {
+		return mfail("mock: unknown curve");
+	}
+	if (curve_from_ec_params(&params, curve)) {
+		return -1;
+	}
+	/* libecc structures point into themselves: import again, in place */
+	(*curve)->have_params = !import_params(&(*curve)->params, sp);
+	return 0;
+}
+
+int ecamd_multi_curve_from_params(ecamd_multi *m, const uint8_t *p, uint32_t p_len, const uint8_t *a, uint32_t a_len,
+				  const uint8_t *b, uint32_t b_len, const uint8_t *curve_order, uint32_t curve_order_len,
+				  const uint8_t *gx, uint32_t gx_len, const uint8_t *gy, uint32_t gy_len,
+				  const uint8_t *gen_order, uint32_t gen_order_len, ecamd_mcurve **curve)
+{
+	ecamd_mcurve *c = calloc(1, sizeof(*c));
+	(void)m;
+	if (orc_curve_init(&c->c, p, (int)p_len, a, (int)a_len, b, (int)b_len, curve_order, (int)curve_order_len, gx, (int)gx_len, gy, (int)gy_len,
+			   gen_order, (int)gen_order_len)) {
+		free(c);
+		return mfail("mock: curve setup failed");
+	}
+	*curve = c;
+	return 0;
+}
+void ecamd_multi_curve_free(ecamd_mcurve *curve) { free(curve); }
+int ecamd_multi_curve_coord_len(const ecamd_mcurve *c) { return c ? c->c.clen : -1; }
+int ecamd_multi_curve_order_len(const ecamd_mcurve *c) { return c ? c->c.qlen : -1; }
+
+int ecamd_multi_prj_pt_mul_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *scalars, uint32_t slen,
+				 const uint8_t *points_aff, uint8_t *out_aff, uint8_t *status)
+{
+	(void)m;
+	note(n);
+	return orc_scalar_mult_batch(&c->c, n, scalars, slen, points_aff, out_aff, status);
+}
+
+int ecamd_multi_prj_pt_mul_batch_fmt(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *scalars, uint32_t slen,
+				     const uint8_t *points, int in_fmt, uint8_t *out, int out_fmt, uint8_t *status)
+{
+	const size_t cl = (size_t)c->c.clen;
+	uint8_t *tmp;
+	uint32_t i;
+	(void)m;
+	note(n);
+	if (in_fmt != ECAMD_PT_PROJECTIVE) {
+		return mfail("mock: projective inputs only");
+	}
+	tmp = malloc((size_t)n * 3 * cl);
+	if (orc_prj_batch(&c->c, n, scalars, slen, points, tmp, status)) {
+		free(tmp);
+		return mfail("mock: orc_prj_batch");
+	}
+	for (i = 0; i < n; i++) {
+		if (out_fmt == ECAMD_PT_PROJECTIVE) {
+			memcpy(out + i * 3 * cl, tmp + i * 3 * cl, 3 * cl);
+		} else {
+			memcpy(out + i * 2 * cl, tmp + i * 3 * cl, 2 * cl);
+		}
+	}
+	free(tmp);
+	return 0;
+}
+
+int ecamd_multi_ecdsa_verify_batch_fmt(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys, int pub_fmt,
+				       const uint8_t *sigs, const uint8_t *digests, uint32_t digest_len, uint8_t *result)
+{
+	const size_t cl = (size_t)c->c.clen;
+	uint8_t *prj = malloc((size_t)n * 3 * cl + 1), *aff = malloc((size_t)n * 2 * cl + 1), *st = malloc(n + 1);
+	uint32_t i;
+	int r;
+	(void)m;
+	note(n);
+	if (pub_fmt != ECAMD_PT_PROJECTIVE) {
+		return mfail("mock: projective keys only");
+	}
+	r = orc_prj_batch(&c->c, n, NULL, 0, pubkeys, prj, st);
+	for (i = 0; i < n; i++) {
+		memcpy(aff + i * 2 * cl, prj + i * 3 * cl, 2 * cl);
+	}
+	r = r || orc_ecdsa_verify_batch(&c->c, n, aff, sigs, digests, digest_len, result);
+	for (i = 0; i < n && !r; i++) {
+		if (st[i]) {
+			result[i] = 1;   /* a key at infinity (status 2) is not modelled here: tests/ on the GPU cover it */
+		}
+	}
+	free(prj); free(aff); free(st);
+	return r ? mfail("mock: ecdsa verify") : 0;
+}
+
+int ecamd_multi_ecdsa_sign_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *privs, const uint8_t *nonces,
+				 const uint8_t *digests, uint32_t digest_len, uint8_t *sigs, uint8_t *status)
+{
+	(void)m;
+	note(n);
+	return orc_ecdsa_sign_batch(&c->c, n, privs, nonces, digests, digest_len, sigs, status);
+}
+
+int ecamd_multi_ecccdh_derive_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *privs, const uint8_t *peers_aff,
+				    uint8_t *secrets, uint8_t *status)
+{
+	(void)m;
+	note(n);
+	return orc_ecccdh_batch(&c->c, n, privs, peers_aff, secrets, status);
+}
+
+int ecamd_multi_xdh_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *k, const uint8_t *u, uint8_t *out, uint8_t *status)
+{
+	(void)m;
+	note(n);
+	return orc_xdh_batch(&c->c, (uint32_t)c->c.clen, n, k, u, out, status);
+}
+
+int ecamd_multi_eddsa_verify_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs,
+				   const uint8_t *hram, uint32_t hram_len, uint8_t *result)
+{
+	(void)m;
+	note(n);
+	return c->c.clen == 56 ? orc_eddsa448_verify_batch(&c->c, n, pubkeys, sigs, hram, hram_len, result)
+			       : orc_eddsa25519_verify_batch(&c->c, n, pubkeys, sigs, hram, hram_len, result);
+}
+
+int ecamd_multi_eddsa_verify_all_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs,
+				       const uint8_t *hram, uint32_t hram_len, int *all_valid, uint32_t *first_rejected)
+{
+	uint8_t *res = malloc(n + 1);
+	uint32_t i;
+	int r = ecamd_multi_eddsa_verify_batch(m, c, n, pubkeys, sigs, hram, hram_len, res);
+	*all_valid = 1;
+	if (first_rejected) {
+		*first_rejected = n;
+	}
+	for (i = 0; i < n && !r; i++) {
+		if (res[i]) {
+			*all_valid = 0;
+			if (first_rejected && *first_rejected == n) {
+				*first_rejected = i;
+			}
+		}
+	}
+	free(res);
+	return r;
+}
+
+/* eddsa_export_pub_key (sig/eddsa.c:970) on each point, through libecc itself */
+int ecamd_multi_eddsa_encode_point_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *points_prj, uint8_t *enc,
+					 uint8_t *status)
+{
+	const u32 cl = (u32)c->c.clen, kl = (cl == 56) ? 57 : 32;
+	uint32_t i;
+	(void)m;
+	note(n);
+	if (!c->have_params) {
+		return mfail("mock: encode needs a named curve");
+	}
+	for (i = 0; i < n; i++) {
+		ec_pub_key pk;
+		memset(&pk, 0, sizeof(pk));
+		status[i] = 1;
+		memset(enc + (size_t)i * kl, 0, kl);
+		if (prj_pt_import_from_buf(&pk.y, points_prj + (size_t)i * 3 * cl, (u16)(3 * cl), &c->params.ec_curve)) {
+			continue;
+		}
+		pk.key_type = (cl == 56) ? EDDSA448 : EDDSA25519;
+		pk.params = &c->params;
+		pk.magic = PUB_KEY_MAGIC;
+		if (!eddsa_export_pub_key(&pk, enc + (size_t)i * kl, (u16)kl)) {
+			status[i] = 0;
+		}
+	}
+	return 0;
+}
+
+int ecamd_multi_eddsa_sign_R_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *r_hash, uint8_t *R_enc, uint8_t *status)
+{
+	(void)m;
+	note(n);
+	if (c->c.clen != 32) {
+		return mfail("mock: Ed448 signing is not modelled");
+	}
+	return orc_eddsa25519_sign_R_batch(&c->c, n, r_hash, R_enc, status);
+}
+
+int ecamd_multi_eddsa_sign_S_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *r_hash, const uint8_t *hram,
+				   const uint8_t *a_scalars, uint8_t *S_out)
+{
+	(void)m;
+	note(n);
+	if (c->c.clen != 32) {
+		return mfail("mock: Ed448 signing is not modelled");
+	}
+	return orc_eddsa25519_sign_S_batch(&c->c, n, r_hash, hram, a_scalars, S_out);
+}
