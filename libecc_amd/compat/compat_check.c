@@ -749,6 +749,72 @@ static void bench_verify(const char *curve, ec_alg_type sig_type, hash_alg_type 
 	free(pubs); free(sigs); free(msgs); free(adatas); free(siglens); free(msglens); free(adlens);
 }
 
+
+/* end-to-end rates of the secret-key entry points: ec_sign_batch, ec_key_pair_gen_batch, x25519_batch (libecc structures /
+ * pointer arrays in and out; hashing, nonce generation and marshalling on the host threads included) */
+static void bench_secret_half(u32 n)
+{
+	enum { base = 512, ML = 48 };
+	ec_params params;
+	static ec_key_pair kps[base];
+	static u8 msgbuf[base][ML];
+	const ec_key_pair **kpp = calloc(n, sizeof(*kpp));
+	const u8 **msgs = calloc(n, sizeof(*msgs));
+	u8 **sigs = calloc(n, sizeof(*sigs)), *sigbuf = calloc(n, 64), *kb = calloc(n, 32), *rb = calloc(n, 32);
+	const u8 **kp = calloc(n, sizeof(*kp));
+	u8 **rp = calloc(n, sizeof(*rp));
+	u32 *msglens = calloc(n, sizeof(u32)), i;
+	int *rets = calloc(n, sizeof(int)), rep, r = 0;
+	ec_key_pair *gen = calloc(n, sizeof(ec_key_pair));
+	double t0, best;
+	if (load_params("SECP256R1", &params) || !gen) {
+		printf("bench: setup failed\n");
+		return;
+	}
+	for (i = 0; i < base; i++) {
+		if (ec_key_pair_gen(&kps[i], &params, ECDSA) || get_random(msgbuf[i], ML)) {
+			return;
+		}
+	}
+	for (i = 0; i < n; i++) {
+		kpp[i] = &kps[i % base];
+		msgs[i] = msgbuf[i % base];
+		msglens[i] = ML;
+		sigs[i] = sigbuf + (size_t)i * 64;
+		kp[i] = kb + (size_t)i * 32;
+		rp[i] = rb + (size_t)i * 32;
+	}
+	get_random(kb, 32);
+	for (i = 32; i < n * 32u; i++) {
+		kb[i] = (u8)(kb[i - 32] * 5 + i);
+	}
+	for (best = 1e30, rep = 0; rep < 3; rep++) {
+		t0 = now_s();
+		r |= ec_sign_batch(sigs, 64, kpp, msgs, msglens, n, NULL, ECDSA, SHA256, NULL, NULL, rets);
+		if (rep && now_s() - t0 < best) { best = now_s() - t0; }
+	}
+	printf("bench ec_sign_batch ECDSA/SECP256R1/SHA256 n = %u: rc %d, %.1f ms, %.2f M signatures/s (nn_get_random_mod nonces, hashing, marshalling included)\n", n, r, best * 1e3, n / best / 1e6);
+	for (best = 1e30, rep = 0; rep < 3; rep++) {
+		t0 = now_s();
+		r |= ec_sign_batch(sigs, 64, kpp, msgs, msglens, n, NULL, DECDSA, SHA256, NULL, NULL, rets);
+		if (rep && now_s() - t0 < best) { best = now_s() - t0; }
+	}
+	printf("bench ec_sign_batch DECDSA (key type mismatch: every item fails in libecc's checks) n = %u: %.1f ms\n", n, best * 1e3);
+	for (best = 1e30, rep = 0; rep < 3; rep++) {
+		t0 = now_s();
+		r |= ec_key_pair_gen_batch(gen, &params, ECDSA, n, rets);
+		if (rep && now_s() - t0 < best) { best = now_s() - t0; }
+	}
+	printf("bench ec_key_pair_gen_batch ECDSA/SECP256R1 n = %u: rc %d, %.1f ms, %.2f M key pairs/s\n", n, r, best * 1e3, n / best / 1e6);
+	for (best = 1e30, rep = 0; rep < 3; rep++) {
+		t0 = now_s();
+		r |= x25519_init_pub_key_batch(kp, rp, n, rets);
+		if (rep && now_s() - t0 < best) { best = now_s() - t0; }
+	}
+	printf("bench x25519_init_pub_key_batch n = %u: rc %d, %.1f ms, %.2f M/s\n", n, r, best * 1e3, n / best / 1e6);
+	free(kpp); free(msgs); free(sigs); free(sigbuf); free(kb); free(rb); free(kp); free(rp); free(msglens); free(rets); free(gen);
+}
+
 int main(int argc, char **argv)
 {
 	const u32 n = (argc > 1) ? (u32)atoi(argv[1]) : 256;
@@ -761,6 +827,7 @@ int main(int argc, char **argv)
 		bench_verify("SECP256R1", ECDSA, SHA256, "ECDSA/SECP256R1/SHA256", bn);
 		bench_verify("SECP384R1", ECDSA, SHA384, "ECDSA/SECP384R1/SHA384", bn);
 		bench_verify("WEI25519", EDDSA25519, SHA512, "EDDSA25519", bn);
+		bench_secret_half(bn);
 		ecamd_compat_shutdown();
 		return 0;
 	}
