@@ -69,8 +69,12 @@ def work_model(curve_params, nw, slen, batch=1 << 20):
         nm += 1 + 13 / fin_k + 2 + 3 + 2
         ns += 255 / fin_k + 1
         loop_mads = nwin * ((4 * dbl[0] + madd[0]) * M + (4 * dbl[1] + madd[1]) * S)
+        # 36 of a multiplication's 117 (a squaring's 81) MADs are the reduction products m_k x (p + 1)'s four digits: an SGPR
+        # multiplier (ecamd_u29.h), which issues faster than the VGPR x VGPR form (ubench: v_mad_u64_u32_sgpr)
+        work_model.loop_sgpr_share = 36.0 * (4 * dbl[0] + madd[0] + 4 * dbl[1] + madd[1]) * nwin / loop_mads
         return nm + ns, nm * M + ns * S, "k_p256_loop", loop_mads
     fin_k = 8
+    work_model.loop_sgpr_share = 0.0
     if slen <= 4 * ((pbits + 31) // 32):
         # generic radix-2^29 Jacobian kernels k_smul_g<|p|> + k_finalize_g<|p|> (ecamd_g29_kernel.hip):
         # NL = ceil((|p| + 16) / 29) limbs, multiplication NL^2 products + NL^2 reduction MADs,
@@ -116,6 +120,11 @@ def work_model(curve_params, nw, slen, batch=1 << 20):
         ns += loop_s
         nm += 1 + inv_m / fin_k + 2 + 3 + 2
         ns += inv_s / fin_k + 1
+        # the reduction MADs multiply by digits of p held in __constant__ memory (scalar registers)
+        red = {True: nl}.get(p == 2**521 - 1, nl * nl)
+        if p == 2**448 - 2**224 - 1:
+            red = 34
+        work_model.loop_sgpr_share = (loop_m + loop_s) * red / (loop_m * M + loop_s * S)
         return nm + ns, nm * M + ns * S, f"k_loop_g<{pbits}>", loop_m * M + loop_s * S
     mm_add, mm_dbl = 17, 16                              # RCB Alg. 1 / Alg. 3, generic a
     mm = 2 + 3                                           # to Montgomery (x, y) + on-curve check
@@ -153,19 +162,94 @@ def measured_mad_peak():
         return None, None
 
 
-def pmc_traffic(kernel, batch_log2):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_r2j.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected separately; gfx950 correction 2 x FETCH_SIZE).
-    Only valid for the batch size it was collected at; null otherwise.  It is window-table scratch
-    traffic (64 look-ups x 64 B per item, one 128-byte line each), not re-reads of the 160 algorithmic bytes per item."""
+def mix_peak(ub, sgpr_share):
+    """The MAD issue ceiling for a kernel whose MADs are `sgpr_share` SGPR-multiplier and the rest VGPR-multiplier: the two
+    measured streams weighted by their share of the instruction count (issue time adds up)."""
+    pv = ub["v_mad_u64_u32"]["lane_ops_per_s"]
+    ps = ub.get("v_mad_u64_u32_sgpr", {}).get("lane_ops_per_s")
+    if not ps or sgpr_share <= 0.0:
+        return pv
+    return 1.0 / ((1.0 - sgpr_share) / pv + sgpr_share / ps)
+
+
+def secondary_lines(ub):
+    """BASELINE.json configs[2]-[4] as compact records behind the headline line: secp384r1 and
+    secp521r1 scalar multiplication, secp256r1 ECDSA verification, Ed25519 verification, X25519 -- each a fresh process at
+    2^20 items with its own reference-binary gate, `ms_per_step` and the dominant kernel's fraction of the MAD stream."""
+    env = dict(os.environ)
+    pv = ub["v_mad_u64_u32"]["lane_ops_per_s"] if ub else 0.0
+    ps = (ub.get("v_mad_u64_u32_sgpr", {}).get("lane_ops_per_s", 0.0)) if ub else 0.0
+    jobs = [("configs[2] secp384r1", [sys.executable, os.path.abspath(__file__), "--curve", "SECP384R1"]),
+            ("configs[2] secp521r1", [sys.executable, os.path.abspath(__file__), "--curve", "SECP521R1"])]
+    jobs = [(n, c + ["--no-cpu-baseline", "--no-secondary", "--no-traffic", "--parity-items", "4096", "--steps", "5", "--warmup", "2"]) for n, c in jobs]
+    tool = os.path.join(ROOT, "tools", "bench_protocols.py")
+    for name, w in (("configs[3] ECDSA verify secp256r1", "ecdsa_verify"), ("configs[4] Ed25519 verify", "ed25519_verify"),
+                    ("configs[4] X25519", "x25519")):
+        jobs.append((name, [sys.executable, tool, "--workload", w, "--no-cpu-baseline", "--steps", "5", "--warmup", "2",
+                            "--mad-peak", repr(pv), "--mad-peak-sgpr", repr(ps)]))
+    out = []
+    for name, cmd in jobs:
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
+            line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            roof = line.get("roofline") or {}
+            out.append({"config": name, "metric": line["metric"], "value": line["value"], "unit": line["unit"], "steps": line["steps"],
+                        "ms_per_step": line["ms_per_step"], "parity_gate": line["config"].get("parity_gate"),
+                        "kernel": roof.get("kernel"), "kernel_ms": roof.get("kernel_ms"), "kernel_mads_per_item": roof.get("kernel_mads_per_item"),
+                        "frac": roof.get("frac"), "peak": roof.get("peak"), "pipeline_frac": roof.get("pipeline_frac"),
+                        "wall_s": time.time() - t0})
+        except Exception as e:
+            out.append({"config": name, "error": f"{type(e).__name__}: {e}"[:300], "wall_s": time.time() - t0})
+    return out
+
+
+def pmc_traffic(kernel, batch_log2, curve):
+    """HBM bytes per launch of the pipeline's kernels, MEASURED IN THIS RUN: two child runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, nothing else traced, as MI355X_MICROARCH.md's HBM
+    section prescribes; gfx950 correction 2 x FETCH_SIZE, both counters in KiB).  The children run the same batch on seeded
+    inputs without the parity gate.  Returns (bytes per launch of `kernel`, {kernel: bytes per launch}, note); nulls with a
+    note when rocprofv3 is missing or a pass fails -- never an estimate.  What it counts is window-table scratch (the
+    loop's 64 look-ups x 64 B per item and the staging of the table kernels), not re-reads of the 160 algorithmic bytes."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, None, "rocprofv3 not found"
+    per = {}
+    tmp = tempfile.mkdtemp(prefix="ecamd_pmc_", dir="/tmp")
     try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "pmc_r2j.json")))
-        k = j["kernels"][kernel]
-        if batch_log2 != 20:
-            return None
-        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
-    except Exception:
-        return None
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "-d", d, "--", sys.executable, os.path.abspath(__file__), "--traffic-child", "--curve", curve,
+                   "--batch-log2", str(batch_log2), "--steps", "2", "--warmup", "1"]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            dbs = sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True), key=os.path.getsize)
+            if r.returncode != 0 or not dbs:
+                return None, None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or '')[-200:]}"
+            con = sqlite3.connect(dbs[-1])
+            cols = [x[1] for x in con.execute("pragma table_info(counters_collection)")]
+            ni, ci, vi, di = cols.index("kernel_name"), cols.index("counter_name"), cols.index("value"), cols.index("dispatch_id")
+            agg = {}
+            for row in con.execute("select * from counters_collection"):
+                if row[ci] == counter:
+                    agg.setdefault(row[ni], {}).setdefault(row[di], 0.0)
+                    agg[row[ni]][row[di]] += row[vi]
+            con.close()
+            for k, dd in agg.items():
+                v = [dd[i] for i in sorted(dd)]
+                per.setdefault(k, {})[counter] = max(v)     # the full-size launches (smaller ones: redo lanes, set-up)
+    except Exception as e:
+        return None, None, f"PMC pass failed: {type(e).__name__}: {e}"[:300]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    by_kernel = {k: (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 for k, v in per.items()
+                 if k.startswith(("k_", "void k_"))}
+    dom = [v for k, v in by_kernel.items() if kernel.split("<")[0] in k and "verify" not in k]
+    note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this run's batch, separate passes; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch"
+    return (max(dom) if dom else None), by_kernel, note
 
 
 def cpu_baseline(curve, scalars, points, slen):
@@ -285,6 +369,33 @@ def parity_gate(curve, cv, scalars_h, pts_h, out_h, slen, plen, B, nrand):
             f"byte-identical to {who}, {time.time() - t0:.1f} s")
 
 
+def traffic_child(args):
+    """the workload of the timed region alone (no gate, no timing), for the rocprofv3 --pmc passes of pmc_traffic()"""
+    from oracles import CURVES
+    cp = CURVES[args.curve]
+    B = 1 << args.batch_log2
+    slen, clen = (cp["q"].bit_length() + 7) // 8, (cp["p"].bit_length() + 7) // 8
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    ctx = libecc_amd.Context(0)
+    cv = ctx.curve(args.curve)
+    rng = np.random.default_rng(SEED)
+    raw = rng.integers(0, 256, size=(2, B * slen), dtype=np.uint8)
+    raw[:, ::slen] &= 0x7f                       # any scalar value is fine for the traffic; keep them below 2^(8 slen - 1)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    d_s, d_t = torch.from_numpy(raw[0]).to(dev), torch.from_numpy(raw[1]).to(dev)
+    d_p = torch.empty(B * 2 * clen, dtype=torch.uint8, device=dev)
+    d_o = torch.empty(B * 2 * clen, dtype=torch.uint8, device=dev)
+    d_st = torch.empty(B, dtype=torch.uint8, device=dev)
+    cv.scalar_mult_dev(B, d_t.data_ptr(), slen, None, d_p.data_ptr(), d_st.data_ptr(), stream.cuda_stream)
+    for _ in range(args.warmup + args.steps):
+        cv.scalar_mult_dev(B, d_s.data_ptr(), slen, d_p.data_ptr(), d_o.data_ptr(), d_st.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    cv.free()
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -295,8 +406,13 @@ def main():
     ap.add_argument("--ubench-json", default=None, help="also write the raw micro-benchmark output (instruction rates, sustained clock) here")
     ap.add_argument("--parity-items", type=int, default=1 << 16, help="random items of the batch checked against the CPU reference before timing")
     ap.add_argument("--curve", default=CURVE, help="ad-hoc runs on another built-in curve (the driver uses the default)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that measure the HBM bytes per launch")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the records of BASELINE configs[2]-[4] that follow the headline measurement at N = 1")
     args = ap.parse_args()
 
+    if args.traffic_child:
+        return traffic_child(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -402,7 +518,6 @@ def main():
     assert set(st_h) == {0}, "unexpected status in the synthetic batch"
     gate = parity_gate(curve, cv, scalars_h, pts_h, out_h, slen, plen, B, args.parity_items if rank == 0 else 256)
     setup_s = time.time() - t_setup
-    setup_s = time.time() - t_setup
 
     # ---- warmup, then exactly K timed steps ----
     for _ in range(args.warmup):
@@ -457,7 +572,9 @@ def main():
             kt, launch_ms, kmads = None, step_ms, mads
         mad_rate = B * kmads / (launch_ms * 1e-3)      # executed lane-MADs per second of the dominant kernel
         # the MAD issue peak is a per-GPU number: measured on rank 0's GPU after the timed region
-        peak, ub = measured_mad_peak()
+        peak_v, ub = measured_mad_peak()
+        sg = getattr(work_model, "loop_sgpr_share", 0.0) if kt is not None else 0.0
+        peak = mix_peak(ub, sg) if ub else None
         nominal_quarter = 256 * 4 * 16 * 2.4e9 / 4.0   # SURVEY.md 8d planning figure (quarter rate)
         alg_bytes = float(slen + 2 * plen)             # scalar + affine point in + affine point out (160 B for P-256)
         hbm_rate = B * alg_bytes / (step_ms * 1e-3)
@@ -477,13 +594,16 @@ def main():
                 "bound": "valu-int-mad (v_mad_u64_u32 issue; not hbm, not mfma -- SURVEY.md 8d)",
                 "achieved": mad_rate / 1e9, "peak": (peak or nominal_quarter) / 1e9, "unit": "GMAD/s (one GPU)",
                 "frac": mad_rate / (peak or nominal_quarter),
-                "peak_source": "measured live by libecc_amd/lib/ubench" if peak else "nominal quarter-rate estimate",
+                "peak_source": ("measured live by libecc_amd/lib/ubench: the v_mad_u64_u32 streams with a VGPR and with an SGPR multiplier, "
+                                "weighted by the kernel's operand mix") if peak else "nominal quarter-rate estimate",
+                "sgpr_multiplier_share": sg, "peak_vgpr_stream": (peak_v or 0) / 1e9,
+                "frac_of_vgpr_stream": mad_rate / peak_v if peak_v else None,
                 "kernel": kname, "kernel_ms": launch_ms, "kernel_mads_per_item": kmads,
                 "pipeline_ms": ({k_: float(v) for k_, v in zip(knames, kt)} if kt is not None else None),
                 "step_ms": step_ms, "pipeline_frac": (B * mads / (step_ms * 1e-3)) / (peak or nominal_quarter),
                 "field_mults_per_item": mm, "mads_per_item": mads,
                 "ref_equivalent_mads_per_item": ref_equiv_mads(),
-                "traffic": pmc_traffic(kname, args.batch_log2),
+                "traffic": None,
                 "hbm": {"achieved": hbm_rate / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": hbm_rate / 8e12, "algorithmic_bytes_per_item": alg_bytes},
             },
@@ -511,9 +631,23 @@ def main():
             line["cpu_baseline"] = cpu_baseline(curve, scalars_h, pts_h, slen)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line))
     cv.free()
     ctx.close()
+    if rank == 0:
+        # after the headline region, with this process's device memory released:
+        # (i) the HBM bytes per launch from PMC counters, measured on this very batch by two profiled child runs
+        if world == 1 and not args.no_traffic:
+            t0 = time.time()
+            tr, by_kernel, note = pmc_traffic(kname, args.batch_log2, curve)
+            line["roofline"]["traffic"] = tr
+            line["roofline"]["traffic_by_kernel"] = by_kernel
+            line["roofline"]["traffic_note"] = f"{note}; {time.time() - t0:.0f} s"
+            if tr:
+                line["roofline"]["traffic_over_algorithmic"] = tr / (B * alg_bytes)
+        # (ii) the other BASELINE configs, one fresh process each
+        if world == 1 and not args.no_secondary and curve == CURVE:
+            line["secondary"] = secondary_lines(ub)
+        print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
 

@@ -92,6 +92,10 @@ void ecamd_host_free(void *p);
  * radix-2^29 path reports 0, 0, loop, finalisation). */
 int ecamd_ctx_enable_kernel_timing(ecamd_ctx *ctx, int on);
 int ecamd_ctx_kernel_times(ecamd_ctx *ctx, double *ms, int n);
+/* The same hook for the protocol entry points: duration (ms) of the dominant kernel of the last call made with timing enabled --
+ * the interleaved window loop of secp256r1 ECDSA verification, the X25519 / X448 ladder, the Edwards window loop of Ed25519
+ * verification.  (ECDSA verification on other curves is two scalar multiplications: ecamd_ctx_kernel_times covers them.) */
+int ecamd_ctx_dominant_kernel_ms(ecamd_ctx *ctx, double *ms);
 
 /* ---- curves: ec_get_curve_params_by_name (curves/curves.h:21) + import_params
  *      (curves/ec_params.h:89).  Same 44 names as libecc's ec_maps[] ("SECP256R1", ...). ---- */

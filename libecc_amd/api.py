@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "ecamd_multi_ecdsa_verify_batch", "ecamd_multi_ecdsa_verify_batch_fmt", "ecamd_multi_ecdsa_sign_batch", "ecamd_multi_ecccdh_derive_batch",
     "ecamd_multi_xdh_batch", "ecamd_multi_eddsa_verify_batch", "ecamd_multi_eddsa_verify_all_batch", "ecamd_multi_allgather",
     "ecamd_multi_allgather_streams", "ecamd_multi_eddsa_sign_R_batch", "ecamd_multi_eddsa_sign_S_batch",
-    "ecamd_multi_set_secret_scalars", "ecamd_multi_wipe_scratch", "ecamd_ctx_wipe_scratch", "ecamd_ctx_stream", "ecamd_host_alloc", "ecamd_host_free",
+    "ecamd_multi_set_secret_scalars", "ecamd_multi_wipe_scratch", "ecamd_ctx_wipe_scratch", "ecamd_ctx_stream", "ecamd_host_alloc", "ecamd_host_free", "ecamd_ctx_dominant_kernel_ms",
 ]
 
 
@@ -166,6 +166,12 @@ class Context:
         ms = (C.c_double * 4)()
         _chk(self.L, self.L.ecamd_ctx_kernel_times(self.h, ms, 4), "ecamd_ctx_kernel_times")
         return list(ms)
+
+    def dominant_kernel_ms(self):
+        """ms of the dominant kernel of the last protocol call (verify loop / ladder / Edwards window loop), timing enabled"""
+        ms = C.c_double(0.0)
+        _chk(self.L, self.L.ecamd_ctx_dominant_kernel_ms(self.h, C.byref(ms)), "ecamd_ctx_dominant_kernel_ms")
+        return ms.value
 
     def synchronize(self):
         _chk(self.L, self.L.ecamd_ctx_synchronize(self.h), "ecamd_ctx_synchronize")

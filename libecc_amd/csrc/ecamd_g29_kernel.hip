@@ -1368,12 +1368,18 @@ __global__ __launch_bounds__(64) void k_x25519_fin(EcamdXdhLadderArgs A, int gsl
 	}
 }
 
-hipError_t ecamd_launch_x25519_ladder(const EcamdXdhLadderArgs &a, int gslot, hipStream_t s)
+hipError_t ecamd_launch_x25519_ladder(const EcamdXdhLadderArgs &a, int gslot, hipStream_t s, hipEvent_t *dom)
 {
 	if (a.n == 0) {
 		return hipSuccess;
 	}
+	if (dom) {
+		(void)hipEventRecord(dom[0], s);
+	}
 	hipLaunchKernelGGL(k_x25519_ladder, dim3((a.n + 63) / 64), dim3(64), 0, s, a, gslot);
+	if (dom) {
+		(void)hipEventRecord(dom[1], s);
+	}
 	const uint32_t nthreads = (a.n + XDH_FIN_K - 1) / XDH_FIN_K;
 	hipLaunchKernelGGL(k_x25519_fin, dim3((nthreads + 63) / 64), dim3(64), 0, s, a, gslot, nthreads);
 	return hipGetLastError();
@@ -2120,13 +2126,19 @@ hipError_t ecamd_launch_edmsm_reduce(const EcamdEdMsmArgs &a, uint32_t *tmp, con
 	return hipGetLastError();
 }
 
-hipError_t ecamd_launch_ed_smul_c25519(const EcamdEdSmulArgs &a, int gslot, hipStream_t s)
+hipError_t ecamd_launch_ed_smul_c25519(const EcamdEdSmulArgs &a, int gslot, hipStream_t s, hipEvent_t *dom)
 {
 	if (a.n == 0) {
 		return hipSuccess;
 	}
 	hipLaunchKernelGGL(k_ed_smul_c25519<0>, dim3((a.n + 63) / 64), dim3(64), 0, s, a, gslot);
+	if (dom) {
+		(void)hipEventRecord(dom[0], s);
+	}
 	hipLaunchKernelGGL(k_ed_smul_c25519<1>, dim3((a.n + 63) / 64), dim3(64), 0, s, a, gslot);
+	if (dom) {
+		(void)hipEventRecord(dom[1], s);
+	}
 	const uint32_t nthreads = (a.n + EDF_K - 1) / EDF_K;
 	hipLaunchKernelGGL(k_ed_hA_fin, dim3((nthreads + 63) / 64), dim3(64), 0, s, a, gslot, nthreads);
 	return hipGetLastError();
@@ -2592,12 +2604,18 @@ __global__ __launch_bounds__(64) void k_x448_fin(EcamdXdhLadderArgs A, int gslot
 	}
 }
 
-hipError_t ecamd_launch_x448_ladder(const EcamdXdhLadderArgs &a, int gslot, hipStream_t s)
+hipError_t ecamd_launch_x448_ladder(const EcamdXdhLadderArgs &a, int gslot, hipStream_t s, hipEvent_t *dom)
 {
 	if (a.n == 0) {
 		return hipSuccess;
 	}
+	if (dom) {
+		(void)hipEventRecord(dom[0], s);
+	}
 	hipLaunchKernelGGL(k_x448_ladder, dim3((a.n + 63) / 64), dim3(64), 0, s, a, gslot);
+	if (dom) {
+		(void)hipEventRecord(dom[1], s);
+	}
 	const uint32_t nthreads = (a.n + X448_FIN_K - 1) / X448_FIN_K;
 	hipLaunchKernelGGL(k_x448_fin, dim3((nthreads + 63) / 64), dim3(64), 0, s, a, gslot, nthreads);
 	return hipGetLastError();

@@ -238,7 +238,9 @@ struct ecamd_ctx {
 	size_t msm_bytes;
 	bool timing;               // record HIP events around the kernels of the scalar-mult pipeline
 	hipEvent_t ev[ECAMD_NTIMED + 1];
-	bool ev_valid;  // radix-2^29 constant slots, indexed by |p| in bits
+	bool ev_valid;
+	hipEvent_t ev_dom[2];      // around the dominant kernel of the last protocol call (verify loop, ladder, Edwards window loop)
+	bool ev_dom_valid;
 	std::mutex mu;
 };
 
@@ -362,11 +364,16 @@ extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
 	c->msm = nullptr;
 	c->msm_bytes = 0;
 	c->ev_valid = false;
+	c->ev_dom_valid = false;
 	for (int i = 0; i <= ECAMD_NTIMED; i++) {
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) {
 			delete c;
 			return fail("ecamd_ctx_create: hipEventCreate failed");
 		}
+	}
+	if (hipEventCreate(&c->ev_dom[0]) != hipSuccess || hipEventCreate(&c->ev_dom[1]) != hipSuccess) {
+		delete c;
+		return fail("ecamd_ctx_create: hipEventCreate failed");
 	}
 	memset(c->hbuf, 0, sizeof(c->hbuf));
 	memset(c->hbuf_bytes, 0, sizeof(c->hbuf_bytes));
@@ -415,6 +422,8 @@ extern "C" void ecamd_ctx_destroy(ecamd_ctx *c)
 	for (int i = 0; i <= ECAMD_NTIMED; i++) {
 		(void)hipEventDestroy(c->ev[i]);
 	}
+	(void)hipEventDestroy(c->ev_dom[0]);
+	(void)hipEventDestroy(c->ev_dom[1]);
 	(void)hipStreamDestroy(c->stream);
 	(void)hipStreamDestroy(c->copy_stream);
 	(void)hipEventDestroy(c->in_ready[0]);
@@ -471,6 +480,7 @@ extern "C" int ecamd_ctx_enable_kernel_timing(ecamd_ctx *c, int on)
 	std::lock_guard<std::mutex> lk(c->mu);
 	c->timing = on != 0;
 	c->ev_valid = false;
+	c->ev_dom_valid = false;
 	return 0;
 }
 
@@ -490,6 +500,26 @@ extern "C" int ecamd_ctx_kernel_times(ecamd_ctx *c, double *ms, int n)
 		HIPCHK(hipEventElapsedTime(&f, c->ev[i], c->ev[i + 1]));
 		ms[i] = (double)f;
 	}
+	return 0;
+}
+
+// duration of the dominant kernel of the last protocol call made with timing enabled: k_p256_verify_loop (ECDSA verification
+// on secp256r1), k_x25519_ladder / k_x448_ladder (X25519 / X448), k_ed_smul_c25519<1> (the [h]A window loop of Ed25519
+// verification); the first chunk of the call
+extern "C" int ecamd_ctx_dominant_kernel_ms(ecamd_ctx *c, double *ms)
+{
+	if (!c || !ms) {
+		return fail("ecamd_ctx_dominant_kernel_ms: bad argument");
+	}
+	std::lock_guard<std::mutex> lk(c->mu);
+	if (!c->timing || !c->ev_dom_valid) {
+		return fail("ecamd_ctx_dominant_kernel_ms: timing not enabled or no protocol call with a timed kernel ran since");
+	}
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipEventSynchronize(c->ev_dom[1]));
+	float f = 0.0f;
+	HIPCHK(hipEventElapsedTime(&f, c->ev_dom[0], c->ev_dom[1]));
+	*ms = (double)f;
 	return 0;
 }
 
@@ -1737,8 +1767,10 @@ static int ecdsa_verify_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 		K.n = m;
 		K.clen = 32;
 		K.slot = cv->slot;
+		hipEvent_t *dom = (ctx->timing && off == 0) ? ctx->ev_dom : nullptr;
 		HIPCHK(ecamd_launch_verify_p256(K, S[3], S[4], d_sig + (size_t)off * 64, S[5],
-						cv->d_comb ? cv->d_comb : cv->d_gtab, cv->d_comb ? 1 : 0, cv->qdig, d_res + off, s));
+						cv->d_comb ? cv->d_comb : cv->d_gtab, cv->d_comb ? 1 : 0, cv->qdig, d_res + off, s, dom));
+		ctx->ev_dom_valid = ctx->ev_dom_valid || (dom != nullptr);
 	}
 	// exceptional pairs inside the interleaved loop (never for honest signatures) come back as ECAMD_STATUS_REDO: those
 	// items are verified again the reference's way -- two complete-formula multiplications -- by kernels whose other
@@ -2250,7 +2282,8 @@ static int xdh_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uin
 			L.out = d_out;
 			L.status = d_status;
 			L.n = n;
-			HIPCHK(ecamd_launch_x25519_ladder(L, cv->gslot, s));
+			HIPCHK(ecamd_launch_x25519_ladder(L, cv->gslot, s, ctx->timing ? ctx->ev_dom : nullptr));
+			ctx->ev_dom_valid = ctx->ev_dom_valid || ctx->timing;
 			return 0;
 		}
 	} else if (cv->gflavour == 5 && cv->gslot >= 0 && P.mode == 1 && getenv("ECAMD_NO_G448_DECODE") == nullptr) {
@@ -2268,7 +2301,8 @@ static int xdh_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uin
 			L.out = d_out;
 			L.status = d_status;
 			L.n = n;
-			HIPCHK(ecamd_launch_x448_ladder(L, cv->gslot, s));
+			HIPCHK(ecamd_launch_x448_ladder(L, cv->gslot, s, ctx->timing ? ctx->ev_dom : nullptr));
+			ctx->ev_dom_valid = ctx->ev_dom_valid || ctx->timing;
 			return 0;
 		}
 	} else {
@@ -2557,7 +2591,8 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 			E.flagsR = S[6];
 			E.outR = S[4];
 		}
-		HIPCHK(ecamd_launch_ed_smul_c25519(E, cv->gslot, s));
+		HIPCHK(ecamd_launch_ed_smul_c25519(E, cv->gslot, s, ctx->timing ? ctx->ev_dom : nullptr));
+		ctx->ev_dom_valid = ctx->ev_dom_valid || ctx->timing;
 	}
 	{
 		PublicScalars pub_scope(ctx);   // h and S of a signature are public

@@ -86,7 +86,7 @@ hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s, hipEven
 // qdigits = group order in radix 2^29; result 0 accept / 1 reject / ECAMD_STATUS_REDO
 hipError_t ecamd_launch_verify_p256(const EcamdSmulArgs &pubkeys, const uint8_t *u1, const uint8_t *u2, const uint8_t *sigs,
 				    const uint8_t *flags, const uint32_t *gtbl, int gtbl_is_comb, const uint32_t *qdigits,
-				    uint8_t *result, hipStream_t s);
+				    uint8_t *result, hipStream_t s, hipEvent_t *dom = nullptr);
 // affine big-endian points -> comb table entries (Montgomery radix-2^29 digits, 20 words each)
 hipError_t ecamd_launch_comb_build_p256(const uint8_t *points, uint32_t n, uint32_t *table, hipStream_t s);
 // ---- X25519 / X448 (ecdh/x25519_448.c:146-302 of the reference) around the scalar multiplication ----
@@ -149,7 +149,7 @@ struct EcamdEdSmulArgs {
 };
 #define ECAMD_EDT_ITEM_WORDS 320
 #define ECAMD_EDR_REC_WORDS 28
-hipError_t ecamd_launch_ed_smul_c25519(const EcamdEdSmulArgs &a, int gslot, hipStream_t s);
+hipError_t ecamd_launch_ed_smul_c25519(const EcamdEdSmulArgs &a, int gslot, hipStream_t s, hipEvent_t *dom = nullptr);   // dom: two events around the window loop
 // ---- Ed25519 whole-batch verification as ONE multi-scalar multiplication on the Edwards curve (2^255 - 19 unit) ----
 // T = [q - sum z_i S_i]B + sum_i ([z_i h_i mod q]A_i + [z_i]R_i), accepted when [8]T is the neutral element
 // (_eddsa_verify_batch_no_memory, sig/eddsa.c:2278-2545).  Straus evaluation: lane l owns the items j * L + l (j < K) and
@@ -259,7 +259,7 @@ hipError_t ecamd_launch_xdh_prep_c25519(const EcamdXdhPrepArgs &a, int gslot, hi
 hipError_t ecamd_launch_xdh_prep_c448(const EcamdXdhPrepArgs &a, int gslot, hipStream_t s);   // X448 on the Goldilocks unit
 #define ECAMD_X448_REC_WORDS 32
 struct EcamdXdhLadderArgs;
-hipError_t ecamd_launch_x448_ladder(const EcamdXdhLadderArgs &a, int gslot, hipStream_t s);  // rec: n x ECAMD_X448_REC_WORDS
+hipError_t ecamd_launch_x448_ladder(const EcamdXdhLadderArgs &a, int gslot, hipStream_t s, hipEvent_t *dom = nullptr);  // rec: n x ECAMD_X448_REC_WORDS
 // X25519 x-only Montgomery ladder + shared inversion (after k_xdh_prep_c25519 validated and clamped)
 struct EcamdXdhLadderArgs {
 	const uint8_t *u;        // n x 32 little-endian u coordinates (as given by the caller)
@@ -270,7 +270,7 @@ struct EcamdXdhLadderArgs {
 	uint32_t n;
 };
 #define ECAMD_XDH_REC_WORDS 20
-hipError_t ecamd_launch_x25519_ladder(const EcamdXdhLadderArgs &a, int gslot, hipStream_t s);
+hipError_t ecamd_launch_x25519_ladder(const EcamdXdhLadderArgs &a, int gslot, hipStream_t s, hipEvent_t *dom = nullptr);   // dom: two events around the ladder kernel
 hipError_t ecamd_launch_ed_scal(int nw, const EcamdEdScalArgs &a, hipStream_t s);
 hipError_t ecamd_launch_ed_fin(int nw, const EcamdEdFinArgs &a, hipStream_t s);
 

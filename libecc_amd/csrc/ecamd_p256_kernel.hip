@@ -871,7 +871,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 
 hipError_t ecamd_launch_verify_p256(const EcamdSmulArgs &pubkeys, const uint8_t *u1, const uint8_t *u2, const uint8_t *sigs,
 				    const uint8_t *flags, const uint32_t *gtbl, int gtbl_is_comb, const uint32_t *qdigits,
-				    uint8_t *result, hipStream_t s)
+				    uint8_t *result, hipStream_t s, hipEvent_t *dom)
 {
 	if (pubkeys.n == 0) {
 		return hipSuccess;
@@ -893,10 +893,16 @@ hipError_t ecamd_launch_verify_p256(const EcamdSmulArgs &pubkeys, const uint8_t 
 	for (int w = 0; w < 9; w++) {
 		V.qd[w] = qdigits[w];
 	}
+	if (dom) {
+		(void)hipEventRecord(dom[0], s);
+	}
 	if (gtbl_is_comb) {
 		hipLaunchKernelGGL(k_p256_verify_loop<true>, grid, block, 0, s, V);
 	} else {
 		hipLaunchKernelGGL(k_p256_verify_loop<false>, grid, block, 0, s, V);
+	}
+	if (dom) {
+		(void)hipEventRecord(dom[1], s);
 	}
 	return hipGetLastError();
 }

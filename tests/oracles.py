@@ -177,6 +177,41 @@ def have_ref():
     return os.path.exists(REF_SO)
 
 
+def host_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def in_slices(fn, n, threads=None):
+    """Run fn(lo, hi) over contiguous slices of range(n) on `threads` Python threads and return the results in order.
+    The checkers are ctypes calls into re-entrant C (the oracle, the unmodified reference): they release the GIL, so
+    large reference samples (2^16 items) finish in seconds on the GPU box's host cores."""
+    from concurrent.futures import ThreadPoolExecutor
+    threads = max(1, min(threads or host_threads(), n or 1))
+    cuts = [(n * t // threads, n * (t + 1) // threads) for t in range(threads)]
+    cuts = [c for c in cuts if c[1] > c[0]]
+    if len(cuts) <= 1:
+        return [fn(0, n)]
+    with ThreadPoolExecutor(max_workers=len(cuts)) as ex:
+        return list(ex.map(lambda c: fn(*c), cuts))
+
+
+def join_slices(parts):
+    """concatenate per-slice results: bytes, or tuples of bytes"""
+    if isinstance(parts[0], tuple):
+        return tuple(b"".join(p[k] for p in parts) for k in range(len(parts[0])))
+    return b"".join(parts)
+
+
 class RefLib:
     """The unmodified reference, through oracle/ref_driver.c."""
 

@@ -1,7 +1,7 @@
 """BASELINE.json configs[3] and [4] at their full size (2^20 items in one call) -- ECDSA verification on secp256r1,
-Ed25519 verification and X25519 -- with (i) size-independent properties over every item and (ii) 2^12 items of each
-result compared with the UNMODIFIED reference binary (oracle/_ref: ec_verify, ec_sign, x25519 of libecc itself), not
-with the restatement.  configs[1] / [2] at full size are tests/test_gpu_parity.py::test_full_batch_properties."""
+Ed25519 verification and X25519 -- with (i) size-independent properties over every item and (ii) 2^16 items of each
+result (SURVEY.md section 8d's sample size; $ECAMD_TEST_REF_ITEMS) compared with the UNMODIFIED reference binary
+(oracle/_ref: ec_verify, ec_sign, x25519 of libecc itself, run on all host threads), not with the restatement.  configs[1] / [2] at full size are tests/test_gpu_parity.py::test_full_batch_properties."""
 import hashlib
 import os
 
@@ -15,7 +15,7 @@ from test_gpu_parity import rand_bytes
 pytestmark = pytest.mark.gpu
 
 LOG2N = int(os.environ.get("ECAMD_TEST_FULL_LOG2", "20"))
-NREF = int(os.environ.get("ECAMD_TEST_REF_ITEMS", str(1 << 12)))
+NREF = int(os.environ.get("ECAMD_TEST_REF_ITEMS", str(1 << 16)))
 
 
 def cut(b, w, idx):
@@ -62,10 +62,12 @@ def test_ecdsa_secp256r1_full_size_vs_reference_binary(gpu_ctx):
         assert res == bytes(bad.astype(np.uint8))
         # against the reference binary
         idx = [int(x) for x in np.sort(rng.choice(n, size=min(n, NREF), replace=False))]
-        exp = r.ecdsa_verify(h, cut(P.tobytes(), 64, idx), cut(S.tobytes(), 64, idx), cut(M.tobytes(), ml, idx), ml)
+        sp, ss, sm = cut(P.tobytes(), 64, idx), cut(S.tobytes(), 64, idx), cut(M.tobytes(), ml, idx)
+        exp = O.join_slices(O.in_slices(lambda lo, hi: r.ecdsa_verify(h, sp[64 * lo:64 * hi], ss[64 * lo:64 * hi], sm[ml * lo:ml * hi], ml), len(idx)))
         assert exp == bytes(res[j] for j in idx) and 0 < sum(exp) < len(idx)
         idx2 = idx[:len(idx) // 2]
-        rs, rp, rst = r.ecdsa_sign(h, cut(d, 32, idx2), cut(ks, 32, idx2), cut(msgs, ml, idx2), ml)
+        sd, sk, sm2 = cut(d, 32, idx2), cut(ks, 32, idx2), cut(msgs, ml, idx2)
+        rs, rp, rst = O.join_slices(O.in_slices(lambda lo, hi: r.ecdsa_sign(h, sd[32 * lo:32 * hi], sk[32 * lo:32 * hi], sm2[ml * lo:ml * hi], ml), len(idx2)))
         assert set(rst) == {0} and rs == cut(sigs, 64, idx2) and rp == cut(pubs, 64, idx2)
     finally:
         cv.free()
@@ -121,10 +123,12 @@ def test_ed25519_full_size_vs_reference_binary(gpu_ctx):
         res = cv.eddsa_verify(A, S.tobytes(), H.tobytes())
         assert res == bytes(bad.astype(np.uint8))
         idx = [int(x) for x in np.sort(rng.choice(n, size=min(n, NREF), replace=False))]
-        exp = O.ref_ed25519_verify(cut(A, 32, idx), cut(S.tobytes(), 64, idx), cut(M.tobytes(), ml, idx), ml)
+        sa, ss, sm = cut(A, 32, idx), cut(S.tobytes(), 64, idx), cut(M.tobytes(), ml, idx)
+        exp = O.join_slices(O.in_slices(lambda lo, hi: O.ref_ed25519_verify(sa[32 * lo:32 * hi], ss[64 * lo:64 * hi], sm[ml * lo:ml * hi], ml), len(idx)))
         assert exp == bytes(res[j] for j in idx) and 0 < sum(exp) < len(idx)
         idx2 = idx[:len(idx) // 4]
-        rp, rs, rst = O.ref_ed25519_sign(cut(seeds, 32, idx2), cut(msgs, ml, idx2), ml)
+        se, sm2 = cut(seeds, 32, idx2), cut(msgs, ml, idx2)
+        rp, rs, rst = O.join_slices(O.in_slices(lambda lo, hi: O.ref_ed25519_sign(se[32 * lo:32 * hi], sm2[ml * lo:ml * hi], ml), len(idx2)))
         assert set(rst) == {0} and rp == cut(A, 32, idx2) and rs == cut(sigs.tobytes(), 64, idx2)
     finally:
         cv.free()
@@ -153,7 +157,10 @@ def test_x25519_full_size_vs_reference_binary(gpu_ctx):
         out, st = cv.xdh(ka, u.tobytes())
         assert 0.3 * n < st.count(1) < 0.7 * n
         idx = [int(x) for x in np.sort(rng.choice(n, size=min(n, NREF), replace=False))]
-        assert O.ref_xdh(32, cut(ka, 32, idx), cut(u.tobytes(), 32, idx)) == (cut(out, 32, idx), bytes(st[j] for j in idx))
-        assert O.ref_xdh(32, cut(ka, 32, idx), cut(pb, 32, idx)) == (cut(s1, 32, idx), bytes(len(idx)))
+        sk, su, sp = cut(ka, 32, idx), cut(u.tobytes(), 32, idx), cut(pb, 32, idx)
+        assert O.join_slices(O.in_slices(lambda lo, hi: O.ref_xdh(32, sk[32 * lo:32 * hi], su[32 * lo:32 * hi]), len(idx))) == \
+            (cut(out, 32, idx), bytes(st[j] for j in idx))
+        assert O.join_slices(O.in_slices(lambda lo, hi: O.ref_xdh(32, sk[32 * lo:32 * hi], sp[32 * lo:32 * hi]), len(idx))) == \
+            (cut(s1, 32, idx), bytes(len(idx)))
     finally:
         cv.free()

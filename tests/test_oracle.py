@@ -6,7 +6,8 @@ import os
 import numpy as np
 import pytest
 
-from oracles import (CURVES, GOLDEN, Oracle, RefLib, digest, have_ref, py_smul_bytes, ref_xdh, rfc6979_nonce)
+from oracles import (CURVES, GOLDEN, Oracle, RefLib, digest, have_ref, host_threads, in_slices, join_slices, py_smul_bytes, ref_xdh,
+                     rfc6979_nonce)
 import oracles as O
 
 KAT_CDH = json.load(open(os.path.join(GOLDEN, "ecccdh_kats.json")))
@@ -102,6 +103,15 @@ def test_oracle_vs_reference_binary(curve):
     m = len(pts) // (2 * n)
     sc2 = rb(rng, o.qlen * m)
     assert o.scalar_mult(sc2, pts) == r.scalar_mult(sc2, pts)
+    # 2^12 random (scalar, point) pairs (the restatement is what smoke() and bench.py's fallback trust):
+    # points [t]G from the reference, then variable-base multiplications on both, on all host threads
+    big = int(os.environ.get("ECAMD_TEST_ORACLE_PIN_ITEMS", "4096"))
+    ts, ks = rb(rng, o.qlen * big), rb(rng, o.qlen * big)
+    bp, bst = r.scalar_mult(ts, None, None, nthreads=host_threads())
+    assert set(bst) <= {0, 2}
+    bp = b"".join(bp[2 * n * i:2 * n * (i + 1)] if bst[i] == 0 else g for i in range(big))   # (an off-curve point where [t]G = infinity)
+    got = join_slices(in_slices(lambda lo, hi: o.scalar_mult(ks[o.qlen * lo:o.qlen * hi], bp[2 * n * lo:2 * n * hi]), big))
+    assert got == r.scalar_mult(ks, bp, None, nthreads=host_threads())
     # long scalars (m >= q^2 branch) and short ones
     for slen in (1, 2 * o.qlen + 8):
         s3 = rb(rng, slen * 3)

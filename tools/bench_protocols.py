@@ -8,8 +8,10 @@ bytes per step); not the driver's headline bench.
     python tools/bench_protocols.py --workload ecdsa_verify|ecdsa_sign|ecccdh|ed25519_verify|ed448_verify|x25519 [--gpus N --steps K --warmup W]
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,6 +35,9 @@ def main():
     ap.add_argument("--batch-log2", type=int, default=20)
     ap.add_argument("--curve", default="SECP256R1", help="ecdsa_verify / ecdsa_sign / ecccdh: any 256-bit prime-order curve libecc names")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ref-items", type=int, default=4096, help="random items of the batch checked against the unmodified reference binary (all host threads)")
+    ap.add_argument("--mad-peak", type=float, default=0.0, help="lane-MADs/s of the v_mad_u64_u32 streams measured by ubench (VGPR multiplier); 0: measure now")
+    ap.add_argument("--mad-peak-sgpr", type=float, default=0.0, help="the same with an SGPR multiplier")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -65,6 +70,7 @@ def main():
         return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
 
     t_setup = time.time()
+    ref_subset = work = None
     if a.workload == "ecdsa_verify":
         curve = a.curve
         assert O.CURVES[curve]["p"].bit_length() == 256 and O.CURVES[curve]["q"].bit_length() == 256
@@ -74,7 +80,10 @@ def main():
 
         def scal(rows):
             return b"".join(((int.from_bytes(rows[i].tobytes(), "big") % (q - 1)) + 1).to_bytes(32, "big") for i in range(B))
-        privs, nonces, dg = scal(raw[0]), scal(raw[1]), rb(32 * B)
+        ML = 32
+        msgs = rb(ML * B)
+        privs, nonces = scal(raw[0]), scal(raw[1])
+        dg = b"".join(hashlib.sha256(msgs[ML * i:ML * (i + 1)]).digest() for i in range(B))
         pubs, st = cv.scalar_mult(privs)
         assert set(st) == {0}
         sigs, st = cv.ecdsa_sign(privs, nonces, dg, 32)
@@ -97,6 +106,15 @@ def main():
             o = O.Oracle(curve)
             return o.ecdsa_verify(b"".join(pubs[64 * i:64 * i + 64] for i in idx), b"".join(sigs[64 * i:64 * i + 64] for i in idx),
                                   b"".join(dg[32 * i:32 * i + 32] for i in idx), 32)
+
+        def ref_subset(idx):
+            r = O.RefLib(curve)
+            sp, ss, sm = (b"".join(x[w * i:w * i + w] for i in idx) for x, w in ((pubs, 64), (sigs, 64), (msgs, ML)))
+            return O.join_slices(O.in_slices(lambda lo, hi: r.ecdsa_verify("SHA256", sp[64 * lo:64 * hi], ss[64 * lo:64 * hi], sm[ML * lo:ML * hi], ML), len(idx)))
+        # dominant kernel k_p256_verify_loop<COMB>: the top digit's mixed addition, 64 windows of 4 doublings + 1 mixed addition on Q's
+        # table, 17 mixed additions from the comb table of G, the projective x mod q == r test (1 S + 6 M); M = 117, S = 81 MADs
+        work = {"kernel": "k_p256_verify_loop<true>", "mads_per_item": 64 * (24 * 117 + 19 * 81) + 18 * (8 * 117 + 3 * 81) + 81 + 6 * 117,
+                "sgpr_mads_per_item": 36 * (64 * 43 + 18 * 11 + 7)} if curve == "SECP256R1" else None
         metric, unit, cfg = "ECDSA verifications/sec (%s, SHA-256 digests, batch=2^%d)" % (curve.lower(), a.batch_log2), "verifications/s", 3
     elif a.workload in ("ecdsa_sign", "ecccdh"):
         # secp256r1: signing with caller-supplied nonces (the tail of ec_sign) / ECC-CDH shared secrets
@@ -142,16 +160,18 @@ def main():
     elif a.workload == "ed25519_verify":
         cv = ctx.curve("WEI25519")
         m = 512
-        items = [O.ed25519_sign(rb(32), rb(32)) for _ in range(m)]
+        emsgs = [rb(32) for _ in range(m)]
+        items = [O.ed25519_sign(rb(32), emsgs[j]) for j in range(m)]
         reps = B // m
         pubs = b"".join(i[0] for i in items) * reps
-        sigs = b"".join(i[1] for i in items) * reps
-        hram = bytearray(b"".join(i[2] for i in items) * reps)
+        sigs = bytearray(b"".join(i[1] for i in items) * reps)
+        hram = b"".join(i[2] for i in items) * reps
+        msgs = b"".join(emsgs) * reps
         bad = np.zeros(B, dtype=np.uint8)
-        for i in range(0, B, 10):
-            hram[64 * i + (i % 64)] ^= 1 << (i % 8)
+        for i in range(0, B, 10):          # every 10th signature corrupted in S (the hash binds R, A and M, not S)
+            sigs[64 * i + 32 + (i % 31)] ^= 1 << (i % 8)
             bad[i] = 1
-        hram = bytes(hram)
+        sigs = bytes(sigs)
         ins = [t(pubs), t(sigs), t(hram)]
         d_res = torch.empty(B, dtype=torch.uint8, device=dev)
 
@@ -163,6 +183,13 @@ def main():
             o = O.Oracle("WEI25519")
             return o.eddsa_verify(b"".join(pubs[32 * i:32 * i + 32] for i in idx), b"".join(sigs[64 * i:64 * i + 64] for i in idx),
                                   b"".join(hram[64 * i:64 * i + 64] for i in idx))
+
+        def ref_subset(idx):
+            sp, ss, sm = (b"".join(x[w * i:w * i + w] for i in idx) for x, w in ((pubs, 32), (sigs, 64), (msgs, 32)))
+            return O.join_slices(O.in_slices(lambda lo, hi: O.ref_ed25519_verify(sp[32 * lo:32 * hi], ss[64 * lo:64 * hi], sm[32 * lo:32 * hi], 32), len(idx)))
+        # dominant kernel k_ed_smul_c25519<1>: 64 windows of 3 doublings (3M + 4S), 1 doubling (4M + 4S) and 1 addition (8M) in
+        # extended coordinates; 2^255 - 19 flavour: M = 81 + 9 + 2 = 92, S = 45 + 9 + 2 = 56 MADs, 11 of them with a constant multiplier
+        work = {"kernel": "k_ed_smul_c25519<1>", "mads_per_item": 64 * (21 * 92 + 16 * 56), "sgpr_mads_per_item": 64 * 37 * 11}
         metric, unit, cfg = "Ed25519 verifications/sec (batch=2^%d, %d distinct signatures tiled)" % (a.batch_log2, m), "verifications/s", 4
     elif a.workload == "ed448_verify":
         cv = ctx.curve("WEI448")
@@ -206,6 +233,12 @@ def main():
             o = O.Oracle("WEI25519")
             return o.xdh(b"".join(k2[32 * i:32 * i + 32] for i in idx), b"".join(pub[32 * i:32 * i + 32] for i in idx))
         out_w = 32
+
+        def ref_subset(idx):
+            sk, su = (b"".join(x[32 * i:32 * i + 32] for i in idx) for x in (k2, pub))
+            return O.join_slices(O.in_slices(lambda lo, hi: O.ref_xdh(32, sk[32 * lo:32 * hi], su[32 * lo:32 * hi]), len(idx)))
+        # dominant kernel k_x25519_ladder: 255 steps of 6 multiplications (one of them by a24, run as a full product) and 4 squarings
+        work = {"kernel": "k_x25519_ladder", "mads_per_item": 255 * (6 * 92 + 4 * 56) + 92, "sgpr_mads_per_item": 255 * 10 * 11}
         metric, unit, cfg = "X25519 shared secrets/sec (batch=2^%d)" % a.batch_log2, "shared-secrets/s", 4
     gathered = torch.empty(world * B, dtype=torch.uint8, device=dev) if world > 1 else None
 
@@ -230,6 +263,18 @@ def main():
         got = bytes(res[i] for i in idx)
     if got != exp:
         raise SystemExit("PARITY FAILURE: GPU output differs from the CPU oracle")
+    gate = "all accept/reject bits as constructed; 128 random items identical to the CPU oracle"
+    if ref_subset is not None and O.have_ref() and rank == 0 and a.ref_items > 0:
+        tg = time.time()
+        ridx = [int(i) for i in np.sort(np.random.default_rng(2).choice(B, size=min(B, a.ref_items), replace=False))]
+        rexp = ref_subset(ridx)
+        if payload:
+            rgot = (b"".join(out[out_w * i:out_w * i + out_w] for i in ridx), bytes(res[i] for i in ridx))
+        else:
+            rgot = bytes(res[i] for i in ridx)
+        if rgot != rexp:
+            raise SystemExit("PARITY FAILURE: GPU output differs from the unmodified reference binary")
+        gate += f"; {len(ridx)} random items identical to the unmodified reference (oracle/_ref) on {O.host_threads()} threads, {time.time() - tg:.1f} s"
     setup_s = time.time() - t_setup
 
     for _ in range(a.warmup):
@@ -250,6 +295,31 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    # roofline of the dominant kernel: one more step with the library's own HIP events around it (on the launch stream)
+    roof = None
+    if rank == 0 and work is not None:
+        try:
+            ctx.enable_kernel_timing(True)
+            kms = []
+            for _ in range(3):
+                full_step()
+                torch.cuda.synchronize()
+                kms.append(ctx.dominant_kernel_ms())
+            ctx.enable_kernel_timing(False)
+            kernel_ms = float(np.mean(kms))
+            pv, ps = a.mad_peak, a.mad_peak_sgpr
+            if not pv:
+                ub = json.loads(subprocess.run([os.path.join(ROOT, "libecc_amd", "lib", "ubench"), "2000"], capture_output=True, text=True, timeout=120).stdout)
+                pv, ps = ub["v_mad_u64_u32"]["lane_ops_per_s"], ub.get("v_mad_u64_u32_sgpr", {}).get("lane_ops_per_s", 0.0)
+            fs = work["sgpr_mads_per_item"] / work["mads_per_item"] if ps else 0.0
+            peak = 1.0 / ((1.0 - fs) / pv + (fs / ps if ps else 0.0))     # operand-mix weighted stream (VGPR / SGPR multiplier)
+            rate = B * work["mads_per_item"] / (kernel_ms * 1e-3)
+            roof = {"bound": "valu-int-mad (v_mad_u64_u32 issue)", "kernel": work["kernel"], "kernel_ms": kernel_ms,
+                    "kernel_mads_per_item": work["mads_per_item"], "sgpr_multiplier_share": fs, "achieved": rate / 1e9, "peak": peak / 1e9,
+                    "unit": "GMAD/s (one GPU)", "frac": rate / peak, "peak_vgpr_stream": pv / 1e9, "peak_sgpr_stream": ps / 1e9,
+                    "kernel_share_of_step": kernel_ms / (1e3 * elapsed / a.steps)}
+        except Exception as e:   # the timing hook only covers the fast paths
+            roof = {"error": str(e)}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and O.have_ref():
         # the unmodified reference on this host, one thread, on a bounded sample of the same inputs
@@ -258,7 +328,7 @@ def main():
         if a.workload == "ecdsa_verify":
             # ec_verify hashes the message itself: time it on messages of the digest's length (SHA-256 of 32 bytes
             # is noise next to the two scalar multiplications); accept bits are not compared here
-            O.RefLib(curve).ecdsa_verify("SHA256", pubs[:64 * m], sigs[:64 * m], dg[:32 * m], 32)
+            O.RefLib(curve).ecdsa_verify("SHA256", pubs[:64 * m], sigs[:64 * m], msgs[:32 * m], 32)
             what = "ec_pub_key_import_from_aff_buf + ec_verify (ECDSA, SHA-256 over 32-byte messages)"
         elif a.workload == "ecdsa_sign":
             O.RefLib(curve).ecdsa_sign("SHA256", privs[:32 * m], other[:32 * m], dg[:32 * m], 32)
@@ -267,8 +337,8 @@ def main():
             O.RefLib(curve).ecccdh(privs[:32 * m], peers[:64 * m])
             what = "ecccdh_derive_secret"
         elif a.workload == "ed25519_verify":
-            O.ref_ed25519_verify(pubs[:32 * m], sigs[:64 * m], hram[:64 * m], 64)
-            what = "eddsa_import_pub_key + ec_verify (EDDSA25519, SHA-512 over 64-byte messages)"
+            O.ref_ed25519_verify(pubs[:32 * m], sigs[:64 * m], msgs[:32 * m], 32)
+            what = "eddsa_import_pub_key + ec_verify (EDDSA25519, 32-byte messages)"
         elif a.workload == "ed448_verify":
             m = 256
             O.ref_ed448_verify(pubs[:57 * m], sigs[:114 * m], hram[:114 * m], 114)
@@ -289,8 +359,8 @@ def main():
                     else "synthetic (seeded), inputs resident in HBM; valid keys",
             "config": {"workload": f"{a.workload} (BASELINE.json configs[{cfg}]), batch 2^{a.batch_log2} per GPU",
                        "sharding": "contiguous per-rank shards" + (", RCCL all_gather of result bytes per step" if world > 1 else ""),
-                       "parity_gate": "all accept/reject bits as constructed; 128 random items identical to the CPU oracle"},
-            "cpu_baseline": cpu, "setup_s": setup_s}))
+                       "parity_gate": gate},
+            "roofline": roof, "cpu_baseline": cpu, "setup_s": setup_s}))
     cv.free()
     ctx.close()
     if world > 1:
