@@ -64,6 +64,10 @@ int ecamd_ctx_set_max_chunk(ecamd_ctx *ctx, uint32_t max_items);
  * batches of at least min_items (default; min_items = 0 keeps the current threshold, initially 2^17 or $ECAMD_MSM_MIN),
  * 2 always.  items_per_lane: signatures that share one lane's doublings, 0 = chosen from the batch size (1 .. 8). */
 int ecamd_ctx_set_eddsa_msm(ecamd_ctx *ctx, int mode, uint32_t min_items, uint32_t items_per_lane);
+/* Key of the random z_i of the NEXT whole-batch verification on this context (used once, then wiped): 32 bytes from the caller's
+ * own randomness source instead of getrandom -- libsign_amd.so passes bytes of the application's get_random, the import libecc's
+ * own batch verifier draws its z_i from (sig/eddsa.c:2388), so a seeded test harness makes the combination reproducible. */
+int ecamd_ctx_set_msm_seed(ecamd_ctx *ctx, const uint8_t seed[32]);
 /* Secret scalars.  By default the kernels index their window / comb tables with the scalar's digits (fastest; fine for public
  * scalars: verification, public-key checks).  With this switch on, every multiplication by a caller-supplied scalar issued through
  * the context -- ec_prj_pt_mul_batch*, and inside ec_ecdsa_sign_batch, ec_ecccdh_derive_batch ([d]Q), ec_eddsa_sign_R_batch, key-pair
@@ -396,6 +400,7 @@ int ecamd_multi_eddsa_sign_S_batch(ecamd_multi *m, const ecamd_mcurve *curve, ui
 				   const uint8_t *a_scalars, uint8_t *S_out);
 /* ecamd_ctx_set_secret_scalars / ecamd_ctx_wipe_scratch on every rank's context */
 int ecamd_multi_set_secret_scalars(ecamd_multi *m, int on);
+int ecamd_multi_set_msm_seed(ecamd_multi *m, const uint8_t seed[32]);   /* rank r: seed with r xored into its first bytes */
 int ecamd_multi_wipe_scratch(ecamd_multi *m);
 /* The one collective, for callers that keep device-resident outputs on every GPU: an RCCL all-gather (over xGMI) of
  * equal-size shards.  d_send[r]: bytes_per_rank bytes on rank r's device; d_recv[r]: nranks * bytes_per_rank bytes

@@ -12,8 +12,48 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <sys/random.h>
 #include "libecc_amd_compat.h"
 #include "external_deps/rand.h"   /* get_random: supplied by the application, as for libecc's own libsign */
+
+/* The application's randomness source (libsign leaves get_random undefined: external_deps/rand.c is libecc's example of
+ * it and opens /dev/urandom on every call -- two opens per nonce, which caps a 16-thread host at about 1 M nonces/s).
+ * This application reads the kernel's generator through getrandom(2) in blocks of 4 KiB per thread. */
+int get_random(unsigned char *buf, u16 len)
+{
+	static __thread unsigned char pool[4096];
+	static __thread unsigned int pos = sizeof(pool);
+	u16 done = 0;
+	while (done < len) {
+		unsigned int take;
+		if (pos == sizeof(pool)) {
+			size_t got = 0;
+			while (got < sizeof(pool)) {
+				const ssize_t r = getrandom(pool + got, sizeof(pool) - got, 0);
+				if (r <= 0) {
+					return -1;
+				}
+				got += (size_t)r;
+			}
+			pos = 0;
+		}
+		take = (unsigned int)(len - done);
+		if (take > sizeof(pool) - pos) {
+			take = (unsigned int)(sizeof(pool) - pos);
+		}
+		memcpy(buf + done, pool + pos, take);
+		memset(pool + pos, 0, take);
+		pos += take;
+		done = (u16)(done + take);
+	}
+	return 0;
+}
+
+/* the other symbol libsign imports: the non-cryptographic generator of libecc's self tests (here simply the same source) */
+int get_unsafe_random(unsigned char *buf, u16 len)
+{
+	return get_random(buf, len);
+}
 
 static int failures;
 #define CHECK(cond, ...) do { if (!(cond)) { failures++; printf("  MISMATCH " __VA_ARGS__); printf("\n"); } } while (0)

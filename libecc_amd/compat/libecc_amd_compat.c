@@ -23,6 +23,7 @@
 
 #include "libecc_amd_compat.h"
 #include "libecc_amd.h"
+#include "external_deps/rand.h"   /* get_random: the application's randomness source (stays undefined in libsign_amd.so) */
 
 /* ------------------------------------------------------------------------------------------------
  * small helpers
@@ -2423,6 +2424,16 @@ static int eddsa_ver_gpu_all(u32 lo, u32 hi, void *arg)
 			J->all_ok = 0;
 			return 0;
 		}
+	}
+	{
+		/* the z_i of the combination are keyed by the application's own randomness source, the import libecc draws them from
+		 * (sig/eddsa.c:2388; SURVEY.md 8b: get_random stays the application's) */
+		u8 seed[32];
+		if (get_random(seed, sizeof(seed)) || ecamd_multi_set_msm_seed(g_multi, seed)) {
+			wipe(seed, sizeof(seed));
+			return -1;
+		}
+		wipe(seed, sizeof(seed));
 	}
 	if (ecamd_multi_eddsa_verify_all_batch(g_multi, J->e->mc, hi - lo, J->pk + (size_t)lo * J->klen, J->sg + (size_t)lo * J->siglen,
 					       J->dg + (size_t)lo * J->hlen, J->hlen, &all, NULL)) {

@@ -614,7 +614,20 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_affine_g(Eca
 	}
 }
 
-template <int PB, int FLAV, bool MASKED> __global__ __launch_bounds__(64) G29_OCC void k_loop_g(EcamdSmulArgs A, int gslot)
+// layout of the generator's 16-bit comb table (k_comb_build_g / k_comb_g below; k_loop_g<.., DUAL> reads it too)
+template <int PB> struct CombLay {
+	static constexpr int NL = Cfg<PB>::NL;
+	static constexpr int NW = (PB + 31) / 32;
+	static constexpr int CENTW = ((2 * NL + 3) / 4) * 4;
+	static constexpr int NWIN = 2 * NW;
+};
+#define COMB_PER_WIN 32768
+
+// DUAL (ECDSA verification, lut_kind 2): after the window loop of [u2]Q the accumulator takes [u1]G from the generator's 16-bit
+// comb table -- 2 NW + 1 more mixed additions instead of a second scalar multiplication and a complete addition (the reference
+// computes uG and vY separately and adds them, sig/ecdsa_common.c:786-810; only x mod q of the sum is observable).  An exceptional
+// pair anywhere leaves Z = 0 and the item goes back as ECAMD_STATUS_REDO: the host verifies it again the reference's way.
+template <int PB, int FLAV, bool MASKED, bool DUAL = false> __global__ __launch_bounds__(64) G29_OCC void k_loop_g(EcamdSmulArgs A, int gslot)
 {
 	typedef Lay<PB> L;
 	typedef typename Cls<PB>::FA FA;
@@ -671,6 +684,58 @@ template <int PB, int FLAV, bool MASKED> __global__ __launch_bounds__(64) G29_OC
 		acc.Z = selg(keep, acc.Z, selg(use_t, weaken<FT>(onec), S.Z));
 		inf = inf & keep;
 	}
+	if constexpr (DUAL) {
+		// + [u1]G: k = sum_j s_j 2^(16 j) + D_top 2^(32 NW) over the comb table (see k_comb_g)
+		constexpr int NW = L::NW, KW = L::KW, CENTW = CombLay<PB>::CENTW, NWIN = CombLay<PB>::NWIN;
+		u32 kw[KW];
+		load_be<KW>(A.scalars2 + (size_t)i * A.s2len, (int)A.s2len, kw);
+		{
+			uint64_t c = 0;
+#pragma unroll
+			for (int w = 0; w < NW; w++) {
+				c += (uint64_t)kw[w] + 0x80008000u;
+				kw[w] = (u32)c;
+				c >>= 32;
+			}
+			kw[NW] = (u32)c;  // top digit: 0 or 1
+		}
+		const FT onet = weaken<FT>(onec);
+#pragma unroll 1
+		for (int j = 0; j <= NWIN; j++) {
+			u32 word = 0;
+#pragma unroll
+			for (int w = 0; w < KW; w++) {
+				word = (w == (j >> 1)) ? kw[w] : word;
+			}
+			const int dig = (j < NWIN) ? (int)((word >> (16 * (j & 1))) & 0xffffu) - 0x8000 : (int)word;
+			const u32 mag = (u32)(dig < 0 ? -dig : dig);
+			const uint4 *src = (const uint4 *)(A.lut + ((size_t)j * COMB_PER_WIN + (mag ? mag - 1 : 0)) * CENTW);
+			u32 buf[CENTW];
+#pragma unroll
+			for (int q = 0; q < CENTW / 4; q++) {
+				const uint4 v = src[q];
+				buf[4 * q] = v.x;
+				buf[4 * q + 1] = v.y;
+				buf[4 * q + 2] = v.z;
+				buf[4 * q + 3] = v.w;
+			}
+			FM tx, tyc;
+#pragma unroll
+			for (int w = 0; w < NL; w++) {
+				tx.l[w] = buf[w];
+				tyc.l[w] = buf[NL + w];
+			}
+			const FT txa = weaken<FT>(tx);
+			const FT ty = selg(dig < 0, neg_t<PB>(tyc, K), weaken<FT>(tyc));
+			const JacT<PB> S = madd_jac(acc, weaken<FA>(txa), weaken<FA>(ty), K);
+			const bool use_t = inf & (mag != 0);
+			const bool keep = (mag == 0);
+			acc.X = selg(keep, acc.X, selg(use_t, txa, S.X));
+			acc.Y = selg(keep, acc.Y, selg(use_t, ty, S.Y));
+			acc.Z = selg(keep, acc.Z, selg(use_t, onet, S.Z));
+			inf = inf & keep;
+		}
+	}
 	// an exceptional pair of the mixed addition, or a doubling that reached infinity, leaves Z = 0 for good: one exact test
 	if (!inf && is_zero_mulout(mulc(acc.Z, onec, K), K)) {
 		A.status[i] = ECAMD_STATUS_REDO;
@@ -699,13 +764,6 @@ template <int PB, int FLAV, bool MASKED> __global__ __launch_bounds__(64) G29_OC
 //   plus [2^(32 NW)]G; entries are affine (x, y) in the field representation of this unit, CENTW words each.
 //   [k]G = 2 NW + 1 additions and no doubling.  Partial sums are smaller in magnitude than the next term, so
 //   an exceptional pair can only be the last addition of a scalar >= q: flagged, recomputed by k_smul<NW>.
-template <int PB> struct CombLay {
-	static constexpr int NL = Cfg<PB>::NL;
-	static constexpr int NW = (PB + 31) / 32;
-	static constexpr int CENTW = ((2 * NL + 3) / 4) * 4;
-	static constexpr int NWIN = 2 * NW;
-};
-#define COMB_PER_WIN 32768
 
 template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_build_g(const u8 *pts, u32 n, u32 clen, u32 *table, int gslot)
 {
@@ -2677,6 +2735,9 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_TAG)(int gslot, const EcamdSmulArgs &a
 		hipLaunchKernelGGL((k_comb_g<G29_PB, G29_FLAV>), grid, block, 0, s, a, gslot);
 	} else {
 #if defined(G29_K256) || defined(G29_P25519) || defined(G29_JACTAB)
+		if (a.lut_kind == 2) {
+			return hipErrorInvalidValue;   // the fused double-scalar loop needs the affine-table pipeline
+		}
 		// secp256k1's flavour (no room for the mixed addition), the 2^255 - 19 flavour (measured: the two extra passes cost what
 		// the cheaper loop saves, 62.7 against 63.1 M/s at 2^20 and -6 % at 2^16; its comb kernel does use the mixed addition)
 		// and the A/B build: Jacobian table, one kernel
@@ -2693,7 +2754,9 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_TAG)(int gslot, const EcamdSmulArgs &a
 		if (ev) {
 			(void)hipEventRecord(ev[2], s);
 		}
-		if (a.masked) {
+		if (a.lut && a.lut_kind == 2) {
+			hipLaunchKernelGGL((k_loop_g<G29_PB, G29_FLAV, false, true>), grid, block, 0, s, a, gslot);
+		} else if (a.masked) {
 			hipLaunchKernelGGL((k_loop_g<G29_PB, G29_FLAV, true>), grid, block, 0, s, a, gslot);
 		} else {
 			hipLaunchKernelGGL((k_loop_g<G29_PB, G29_FLAV, false>), grid, block, 0, s, a, gslot);

@@ -236,6 +236,8 @@ struct ecamd_ctx {
 	uint32_t msm_min, msm_k;   // msm_k: items per lane of the Straus evaluation (0: chosen from the batch size)
 	uint8_t *msm;              // scratch of the multi-scalar multiplication
 	size_t msm_bytes;
+	uint8_t msm_seed_bytes[32]; // ecamd_ctx_set_msm_seed: key of the next whole-batch combination's z_i (used once)
+	bool msm_seed_valid;
 	bool timing;               // record HIP events around the kernels of the scalar-mult pipeline
 	hipEvent_t ev[ECAMD_NTIMED + 1];
 	bool ev_valid;
@@ -363,6 +365,7 @@ extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
 	}
 	c->msm = nullptr;
 	c->msm_bytes = 0;
+	c->msm_seed_valid = false;
 	c->ev_valid = false;
 	c->ev_dom_valid = false;
 	for (int i = 0; i <= ECAMD_NTIMED; i++) {
@@ -459,6 +462,20 @@ extern "C" int ecamd_ctx_set_eddsa_msm(ecamd_ctx *c, int mode, uint32_t min_item
 		c->msm_min = min_items;
 	}
 	c->msm_k = items_per_lane;
+	return 0;
+}
+
+// The z_i of the next ec_eddsa_verify_all_batch[_dev] call on this context are ChaCha20(seed, item index) instead of being keyed
+// by getrandom: an application that owns the randomness source of its libecc (get_random) keys the batch equation with it.
+// Used once; the bytes are wiped when consumed.
+extern "C" int ecamd_ctx_set_msm_seed(ecamd_ctx *c, const uint8_t seed[32])
+{
+	if (!c || !seed) {
+		return fail("ecamd_ctx_set_msm_seed: bad argument");
+	}
+	std::lock_guard<std::mutex> lk(c->mu);
+	memcpy(c->msm_seed_bytes, seed, 32);
+	c->msm_seed_valid = true;
 	return 0;
 }
 
@@ -781,7 +798,7 @@ static void release_modulus(int device, int nw, int slot)
 
 static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_scalars, uint32_t slen,
 			   const uint8_t *d_points, uint8_t *d_out, uint8_t *d_status, hipStream_t s,
-			   uint32_t sstride = 0xffffffffu, bool redo_only = false);
+			   uint32_t sstride = 0xffffffffu, bool redo_only = false, const uint8_t *d_scalars2 = nullptr);
 
 // 29-bit digits of a (nl of them, the last one takes whatever is left)
 static void big_digits29(uint32_t *dst, int nl, const Big &a)
@@ -1244,8 +1261,10 @@ static void maybe_build_comb(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n)
 // sstride = slen normally; 0 broadcasts one scalar to every item (subgroup / cofactor passes)
 static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_scalars,
 			   uint32_t slen, const uint8_t *d_points, uint8_t *d_out, uint8_t *d_status,
-			   hipStream_t s, uint32_t sstride, bool redo_only)
+			   hipStream_t s, uint32_t sstride, bool redo_only, const uint8_t *d_scalars2)
 {
+	// d_scalars2 (generic radix-2^29 units with a comb table, see fused_verify_ok): out = [scalars]P + [scalars2]G by the fused
+	// window loop; items that met an exceptional pair keep ECAMD_STATUS_REDO in d_status for the caller (no complete-formula pass here)
 	// redo_only: d_status is given; only the items marked ECAMD_STATUS_REDO in it are computed (complete-formula kernel)
 	if (sstride == 0xffffffffu) {
 		sstride = slen;
@@ -1303,6 +1322,25 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 		A.lut_kind = 0;
 		A.stg = nullptr;
 		A.masked = secret ? 1 : 0;   // (copied into Fa below: the secp256r1 loop honours it too)
+		A.scalars2 = nullptr;
+		A.s2len = 0;
+		if (d_scalars2) {
+			if (!fastg || !d_points || !cv->d_comb) {
+				return fail("internal: fused double-scalar loop requested without its preconditions");
+			}
+			EcamdSmulArgs Fa = A;
+			Fa.tbl = ctx->tbl_fast;
+			Fa.stg = ctx->tbl_fast + (size_t)stride * (size_t)ecamd_g29_table_words(cv->pbits, cv->gflavour);
+			Fa.lut = cv->d_comb;
+			Fa.lut_kind = 2u;
+			Fa.scalars2 = d_scalars2 + (size_t)off * slen;
+			Fa.s2len = slen;
+			Fa.masked = 0;
+			hipEvent_t *ev = (ctx->timing && off == 0) ? ctx->ev : nullptr;
+			HIPCHK(ecamd_launch_smul_g29(cv->pbits, cv->gslot, Fa, s, ev, cv->gflavour));
+			ctx->ev_valid = ctx->ev_valid || (ev != nullptr);
+			continue;
+		}
 		if (fast) {
 			// Jacobian fast path; lanes that met an exceptional pair come back as ECAMD_STATUS_REDO and
 			// are recomputed by the complete-formula kernel (all other lanes exit at once)
@@ -1709,12 +1747,102 @@ static int ecdsa_two_smul_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n,
 }
 
 // device pointers in and out; only enqueues on s
+// The fused double-scalar loop of the generic radix-2^29 units (k_loop_g<.., DUAL>): curves on the affine-table pipeline (every
+// flavour but the two nine-limb ones), prime-order groups (no subgroup check of the key to run beside it), u1 within the comb
+// table's reach, and a comb table of the generator (built on the first batch of at least comb_min_batch items).
+static bool fused_verify_ok(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n)
+{
+	if (cv->is_p256 || cv->gslot < 0 || getenv("ECAMD_NO_FUSED_VERIFY") != nullptr) {
+		return false;
+	}
+	if (!(cv->gflavour == 0 || cv->gflavour == 1 || cv->gflavour == 3 || cv->gflavour == 5)) {
+		return false;
+	}
+	if (big_cmp(cv->order, cv->q) != 0 || (uint32_t)cv->qlen > ecamd_g29_comb_max_slen(cv->pbits)) {
+		return false;
+	}
+	{
+		PublicScalars pub_scope(ctx);
+		maybe_build_comb(ctx, const_cast<ecamd_curve *>(cv), n);
+	}
+	return cv->d_comb != nullptr;
+}
+
+// W' = [u1]G + [u2]Q by ONE window loop over Q's affine table plus 2 NW + 1 comb additions for G, for every field size (the
+// reference: two prj_pt_mul and a prj_pt_add, sig/ecdsa_common.c:786-796); the affine W' then meets the same final stage as the
+// two-multiplication path (x mod q == r over the candidates r + j q < p).  Items whose loop met an exceptional pair come back
+// marked and are verified again by ecdsa_two_smul_dev (complete formulas), entirely on the device.
+static int ecdsa_fused_g_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig,
+			     const uint8_t *d_dig, uint32_t hlen, uint8_t *d_res, hipStream_t s)
+{
+	const size_t plen = (size_t)2 * cv->clen, ql = (size_t)cv->qlen;
+	const uint32_t chunk = n < ctx->max_chunk ? n : ctx->max_chunk;
+	PublicScalars pub_scope(ctx);
+	// stage: 3 u1, 4 u2, 5 W' affine, 7 its status, 8 "the other point is infinity", 9 flags
+	const size_t need[10] = {0, 0, 0, chunk * ql, chunk * ql, chunk * plen, 0, chunk, chunk, chunk};
+	for (int i = 3; i < 10; i++) {
+		if (need[i] && ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
+			return -1;
+		}
+	}
+	uint8_t **S = ctx->stage;
+	uint32_t jmax = 0;
+	{
+		Big t = cv->q;
+		while (big_cmp(t, cv->p) < 0 && jmax < 64) {
+			t = big_add(t, cv->q);
+			jmax++;
+		}
+	}
+	for (uint32_t off = 0; off < n; off += chunk) {
+		const uint32_t m = (n - off) < chunk ? (n - off) : chunk;
+		EcamdEcdsaPrepArgs P;
+		P.sigs = d_sig + (size_t)off * 2 * ql;
+		P.digests = d_dig + (size_t)off * hlen;
+		P.u1 = S[3];
+		P.u2 = S[4];
+		P.flags = S[9];
+		P.n = m;
+		P.qlen = (uint32_t)cv->qlen;
+		P.hlen = hlen;
+		P.qbits = (uint32_t)cv->qbits;
+		P.qslot = cv->qslot;
+		P.only = nullptr;
+		HIPCHK(ecamd_launch_ecdsa_prep(cv->qnw, P, s));
+		if (smul_dev_locked(ctx, cv, m, S[4], (uint32_t)ql, d_pub + (size_t)off * plen, S[5], S[7], s, 0xffffffffu, false, S[3])) {
+			return -1;
+		}
+		HIPCHK(hipMemsetAsync(S[8], 2, m, s));
+		EcamdEcdsaFinArgs Fn;
+		Fn.A = S[5];
+		Fn.stA = S[7];
+		Fn.B = S[5];            // never read: its status says infinity
+		Fn.stB = S[8];
+		Fn.sigs = d_sig + (size_t)off * 2 * ql;
+		Fn.flags = S[9];
+		Fn.result = d_res + off;
+		Fn.n = m;
+		Fn.clen = (uint32_t)cv->clen;
+		Fn.qlen = (uint32_t)cv->qlen;
+		Fn.jmax = jmax;
+		for (int w = 0; w < 17; w++) {
+			Fn.q[w] = (size_t)w < cv->q.size() ? cv->q[(size_t)w] : 0;
+		}
+		Fn.slot = cv->slot;
+		Fn.only = nullptr;
+		HIPCHK(ecamd_launch_ecdsa_fin(cv->nw, Fn, s));
+	}
+	// the redo pass: only the marked items (with nothing marked: near-empty launches)
+	return ecdsa_two_smul_dev(ctx, cv, n, d_pub, d_sig, d_dig, hlen, d_res, s, d_res);
+}
+
 static int ecdsa_verify_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_pub,
 				   const uint8_t *d_sig, const uint8_t *d_dig, uint32_t hlen, uint8_t *d_res, hipStream_t s,
 				   const std::function<int()> *between = nullptr)
 {
 	if (!cv->is_p256 || !cv->d_gtab) {
-		if (ecdsa_two_smul_dev(ctx, cv, n, d_pub, d_sig, d_dig, hlen, d_res, s)) {
+		if (fused_verify_ok(ctx, cv, n) ? ecdsa_fused_g_dev(ctx, cv, n, d_pub, d_sig, d_dig, hlen, d_res, s)
+						: ecdsa_two_smul_dev(ctx, cv, n, d_pub, d_sig, d_dig, hlen, d_res, s)) {
 			return -1;
 		}
 		if (between && (*between)()) {
@@ -1723,6 +1851,7 @@ static int ecdsa_verify_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 		return 0;
 	}
 	// secp256r1: interleaved [u1]G + [u2]Q loop (ecamd_launch_verify_p256), in chunks
+	PublicScalars pub_scope(ctx);   // everything a verification multiplies by is public
 	maybe_build_comb(ctx, const_cast<ecamd_curve *>(cv), n);
 	const uint32_t chunk = n < ctx->max_chunk ? n : ctx->max_chunk;
 	{
@@ -1860,10 +1989,32 @@ extern "C" int ec_ecdsa_verify_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *cv, 
 		return 0;
 	}
 	const size_t alen = (size_t)2 * cv->clen, sl = (size_t)2 * cv->qlen;
-	std::vector<uint8_t> aff((size_t)n * alen), st(n);
-	if (ec_prj_pt_unique_batch(ctx, cv, n, pubkeys, ECAMD_PT_PROJECTIVE, aff.data(), ECAMD_PT_AFFINE, st.data()) ||
-	    ec_ecdsa_verify_batch(ctx, cv, n, aff.data(), sigs, digests, hlen, result)) {
-		return -1;
+	std::vector<uint8_t> st(n);
+	{
+		// keys, signatures and digests go to the device once, chunk by chunk behind the double-buffered staging; the keys are
+		// imported and normalised there (k_prj_import) and the verification core consumes the affine form in HBM
+		std::lock_guard<std::mutex> lk(ctx->mu);
+		HIPCHK(hipSetDevice(ctx->device));
+		const std::vector<HostArr> arrs = {{pubkeys, nullptr, 3 * (size_t)cv->clen}, {sigs, nullptr, sl}, {digests, nullptr, hlen},
+						   {nullptr, result, 1}, {nullptr, st.data(), 1}};
+		if (host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+						     hipStream_t s, const std::function<int()> &between) {
+			    if (ensure(&ctx->stage[12], &ctx->stage_bytes[12], (size_t)m * alen)) {
+				    return -1;
+			    }
+			    EcamdPrjInArgs I;
+			    I.in = ip[0];
+			    I.aff = ctx->stage[12];
+			    I.pre = op[4];
+			    I.n = m;
+			    I.clen = (uint32_t)cv->clen;
+			    I.for_mul = 0;
+			    I.slot = cv->slot;
+			    HIPCHK(ecamd_launch_prj_import(cv->nw, I, s));
+			    return ecdsa_verify_dev_locked(ctx, cv, m, ctx->stage[12], ip[1], ip[2], hlen, op[3], s, &between);
+		    })) {
+			return -1;
+		}
 	}
 	std::vector<uint32_t> inf;
 	for (uint32_t i = 0; i < n; i++) {
@@ -2989,8 +3140,15 @@ static int eddsa_msm_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, con
 	return 0;
 }
 
-static int msm_seed(uint8_t seed[32])
+// key of the z_i of the batch equation: the caller's 32 bytes when ecamd_ctx_set_msm_seed left some (used once), else getrandom
+static int msm_seed(ecamd_ctx *ctx, uint8_t seed[32])
 {
+	if (ctx->msm_seed_valid) {
+		memcpy(seed, ctx->msm_seed_bytes, 32);
+		memset(ctx->msm_seed_bytes, 0, 32);
+		ctx->msm_seed_valid = false;
+		return 0;
+	}
 	size_t got = 0;
 	while (got < 32) {
 		const ssize_t r = getrandom(seed + got, 32 - got, 0);
@@ -3009,7 +3167,7 @@ static int eddsa_msm_host_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, co
 	uint8_t seed[32];
 	if (fixed_seed) {
 		memcpy(seed, fixed_seed, 32);
-	} else if (msm_seed(seed)) {
+	} else if (msm_seed(ctx, seed)) {
 		return -1;
 	}
 	hipStream_t s = ctx->stream;
@@ -3070,7 +3228,7 @@ extern "C" int ec_eddsa_verify_all_batch_dev(ecamd_ctx *ctx, const ecamd_curve *
 		return fail("ec_eddsa_verify_all_batch_dev: needs n > 0 and Ed25519 (the WEI25519 handle on the 2^255 - 19 unit)");
 	}
 	uint8_t seed[32];
-	if (msm_seed(seed)) {
+	if (msm_seed(ctx, seed)) {
 		return -1;
 	}
 	HIPCHK(hipSetDevice(ctx->device));

@@ -23,8 +23,12 @@ struct EcamdSmulArgs {
 	int slot;
 	int only_redo;           // generic kernel: process only items whose status is ECAMD_STATUS_REDO
 	const uint32_t *lut;     // secp256r1 fixed base: shared affine table of G (NULL: per-item tables)
-	uint32_t lut_kind;       // 0: window table [1..8]G (8 x 40 words), 1: 16-bit comb table of the generator
+	uint32_t lut_kind;       // 0: window table [1..8]G (8 x 40 words), 1: 16-bit comb table of the generator,
+	                         // 2 (generic radix-2^29 units): per-item window tables of `points` AND the comb table of the generator
+	                         //   for a second scalar: [scalars]P + [scalars2]G in one window loop (ECDSA verification)
 	int masked;              // generic kernel: secret scalars -- constant-address (full-scan, masked) table look-ups
+	const uint8_t *scalars2; // lut_kind 2: n x s2len big-endian multipliers of the generator
+	uint32_t s2len;
 };
 #define ECAMD_COMB_ENTRIES (16u * 32768u + 1u)
 

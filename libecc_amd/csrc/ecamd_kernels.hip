@@ -451,6 +451,11 @@ template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_fin(EcamdEcdsaFi
 		A.result[i] = 1;
 		return;
 	}
+	if (sa == ECAMD_STATUS_REDO || sb == ECAMD_STATUS_REDO) {
+		// the fused double-scalar loop met an exceptional pair: the host's redo pass verifies the item the reference's way
+		A.result[i] = ECAMD_STATUS_REDO;
+		return;
+	}
 	const Fe<NW> one = fe_const<NW>(ConstTab<NW>::get(slot).one);
 	Pt<NW> P, Q, W;
 	{
@@ -1469,9 +1474,21 @@ template <int NW> __global__ __launch_bounds__(64) void k_prj_import(EcamdPrjInA
 	}
 	Fe<NW> ax = fe_zero<NW>(), ay = fe_zero<NW>();
 	if (st == 0) {
-		const Fe<NW> zi = fe_inv<NW>(Zm, slot);
-		ax = fe_from_mont<NW>(fe_mul<NW>(Xm, zi, slot), slot);
-		ay = fe_from_mont<NW>(fe_mul<NW>(Ym, zi, slot), slot);
+		// Z = 1 (a key imported from affine bytes, or normalised before): nothing to divide by -- the lanes of a wave whose
+		// keys all have Z = 1 skip the Fermat inversion altogether
+		bool z_one = Z.v[0] == 1u;
+#pragma unroll
+		for (int w = 1; w < NW; w++) {
+			z_one = z_one & (Z.v[w] == 0u);
+		}
+		if (z_one) {
+			ax = X;
+			ay = Y;
+		} else {
+			const Fe<NW> zi = fe_inv<NW>(Zm, slot);
+			ax = fe_from_mont<NW>(fe_mul<NW>(Xm, zi, slot), slot);
+			ay = fe_from_mont<NW>(fe_mul<NW>(Ym, zi, slot), slot);
+		}
 	}
 	fe_store_be<NW>(dst, clen, ax);
 	fe_store_be<NW>(dst + clen, clen, ay);

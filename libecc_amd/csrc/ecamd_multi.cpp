@@ -401,6 +401,27 @@ extern "C" int ecamd_multi_set_secret_scalars(ecamd_multi *m, int on)
 	return 0;
 }
 
+// one 32-byte seed for the next whole-batch EdDSA verification: rank r keys its shard's combination with seed ^ r (first byte)
+extern "C" int ecamd_multi_set_msm_seed(ecamd_multi *m, const uint8_t seed[32])
+{
+	if (!m || !seed) {
+		return mfail("ecamd_multi_set_msm_seed: NULL argument");
+	}
+	std::lock_guard<std::mutex> lk(m->mu);
+	for (size_t r = 0; r < m->ctx.size(); r++) {
+		uint8_t sr[32];
+		memcpy(sr, seed, 32);
+		sr[0] ^= (uint8_t)r;
+		sr[1] ^= (uint8_t)(r >> 8);
+		const int rc = ecamd_ctx_set_msm_seed(m->ctx[r], sr);
+		memset(sr, 0, sizeof(sr));
+		if (rc) {
+			return -1;
+		}
+	}
+	return 0;
+}
+
 extern "C" int ecamd_multi_wipe_scratch(ecamd_multi *m)
 {
 	if (!m) {

@@ -48,6 +48,7 @@ void ecamd_multi_destroy(ecamd_multi *m) { free(m); }
 int ecamd_multi_size(const ecamd_multi *m) { return m ? m->nranks : 0; }
 int ecamd_multi_set_secret_scalars(ecamd_multi *m, int on) { m->secret = on; return 0; }
 int ecamd_multi_wipe_scratch(ecamd_multi *m) { (void)m; return 0; }
+int ecamd_multi_set_msm_seed(ecamd_multi *m, const uint8_t seed[32]) { (void)m; (void)seed; return 0; }
 void *ecamd_host_alloc(size_t bytes) { return malloc(bytes); }
 void ecamd_host_free(void *p) { free(p); }
 

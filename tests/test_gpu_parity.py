@@ -1525,3 +1525,74 @@ def test_edge_fixtures_gpu(gpu_ctx):
     from test_oracle import check_edge_fixtures
     check_edge_fixtures(gpu_ctx.curve)
 
+
+
+@pytest.mark.parametrize("curve", ["SECP384R1", "SECP521R1", "BRAINPOOLP256R1", "SECP224R1", "BRAINPOOLP512R1"])
+def test_ecdsa_fused_verify_generic_curves(gpu_ctx, curve):
+    """ECDSA verification on the generic radix-2^29 units: batches of >= 4096 items take the fused double-scalar loop
+    (k_loop_g<.., DUAL>: [u2]Q by the window loop + [u1]G from the comb table, sig/ecdsa_common.c:786-796 replaced by one
+    loop).  4096 signatures made on the GPU, 10 % corrupted, plus the exceptional families -- key G / -G with u1 == u2 small, so
+    that the first comb addition meets the doubling / the inverse case -- against the oracle, and the whole batch against the
+    two-multiplication path ($ECAMD_NO_FUSED_VERIFY) and the construction."""
+    c = CURVES[curve]
+    q, p = c["q"], c["p"]
+    cl, ql = clen(curve), qlen(curve)
+    rng = np.random.default_rng(77)
+    o = Oracle(curve)
+    cv = gpu_ctx.curve(curve)
+    try:
+        n = 4096
+        scal = lambda: b"".join(((int.from_bytes(rand_bytes(rng, ql + 8), "big") % (q - 1)) + 1).to_bytes(ql, "big") for _ in range(n))
+        d, ks = scal(), scal()
+        hl = 32
+        dg = rand_bytes(rng, hl * n)
+        pubs, st = cv.scalar_mult(d)
+        assert set(st) == {0}
+        sigs, st = cv.ecdsa_sign(d, ks, dg, hl)
+        assert set(st) == {0}
+        S = np.frombuffer(sigs, dtype=np.uint8).copy().reshape(n, 2 * ql)
+        D = np.frombuffer(dg, dtype=np.uint8).copy().reshape(n, hl)
+        P = np.frombuffer(pubs, dtype=np.uint8).copy().reshape(n, 2 * cl)
+        i = np.arange(n)
+        bad = (i % 10) == 4
+        kind = (i // 10) % 4
+        S[bad & (kind == 0), ql - 1] ^= 0x02            # r
+        S[bad & (kind == 1), 2 * ql - 2] ^= 0x10        # s
+        D[bad & (kind == 2), 7] ^= 0x01                 # digest
+        P[bad & (kind == 3), 2 * cl - 1] ^= 0x01        # key: off the curve
+        # exceptional families (see test_ecdsa_verify_exceptional_pairs): u1 == u2 == k / 2 with the key G or -G
+        G = c["gx"].to_bytes(cl, "big") + c["gy"].to_bytes(cl, "big")
+        negG = c["gx"].to_bytes(cl, "big") + (p - c["gy"]).to_bytes(cl, "big")
+        xp, xs, xd = b"", b"", b""
+        hl_x = ql
+
+        def dig_of(e):   # a digest of ql bytes whose leftmost qbits bits are e (bits2int of sig/ecdsa_common.c:404-412)
+            return (e << (8 * ql - q.bit_length())).to_bytes(ql, "big")
+        for k in (10, 0x2468, 2 * 0x7fff, 2 * 0x8000, 2 * 0x12345, 5, q - 3, (q + 1) // 2):
+            kG, st = o.scalar_mult(k.to_bytes(ql, "big"))
+            r = int.from_bytes(kG[:cl], "big") % q
+            s_ = pow(k, q - 2, q) * (2 * r) % q
+            for key, e in ((G, r), (negG, 3 * r % q), (negG, r)):
+                xp += key
+                xs += r.to_bytes(ql, "big") + s_.to_bytes(ql, "big")
+                xd += dig_of(e)
+        nx = len(xs) // (2 * ql)
+        exp_x = o.ecdsa_verify(xp, xs, xd, hl_x)
+        assert exp_x == bytes([0, 0, 1] * (nx // 3))
+        # the digests of the two groups have different lengths: two calls, each of >= 4096 items (the exceptional ones tiled)
+        got = cv.ecdsa_verify(P.tobytes(), S.tobytes(), D.tobytes(), hl)
+        assert got == bytes(bad.astype(np.uint8))
+        reps = 4096 // nx + 1
+        got_x = cv.ecdsa_verify(xp * reps, xs * reps, xd * reps, hl_x)
+        assert got_x == exp_x * reps
+        idx = [int(x) for x in rng.choice(n, size=96, replace=False)]
+        cut = lambda b, w: b"".join(b[w * j:w * j + w] for j in idx)
+        assert o.ecdsa_verify(cut(P.tobytes(), 2 * cl), cut(S.tobytes(), 2 * ql), cut(D.tobytes(), hl), hl) == bytes(got[j] for j in idx)
+        os.environ["ECAMD_NO_FUSED_VERIFY"] = "1"
+        try:
+            assert cv.ecdsa_verify(P.tobytes(), S.tobytes(), D.tobytes(), hl) == got
+            assert cv.ecdsa_verify(xp * reps, xs * reps, xd * reps, hl_x) == got_x
+        finally:
+            del os.environ["ECAMD_NO_FUSED_VERIFY"]
+    finally:
+        cv.free()
