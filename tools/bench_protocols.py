@@ -73,49 +73,51 @@ def main():
     ref_subset = work = None
     if a.workload == "ecdsa_verify":
         curve = a.curve
-        assert O.CURVES[curve]["p"].bit_length() == 256 and O.CURVES[curve]["q"].bit_length() == 256
         cv = ctx.curve(curve)
         q = O.CURVES[curve]["q"]
-        raw = rng.integers(0, 256, size=(2, B, 40), dtype=np.uint8)
+        ql, cl = O.qlen(curve), O.clen(curve)
+        hname, hl = ("SHA256", 32) if ql <= 32 else (("SHA384", 48) if ql <= 48 else ("SHA512", 64))
+        raw = rng.integers(0, 256, size=(2, B, ql + 8), dtype=np.uint8)
 
         def scal(rows):
-            return b"".join(((int.from_bytes(rows[i].tobytes(), "big") % (q - 1)) + 1).to_bytes(32, "big") for i in range(B))
+            return b"".join(((int.from_bytes(rows[i].tobytes(), "big") % (q - 1)) + 1).to_bytes(ql, "big") for i in range(B))
         ML = 32
         msgs = rb(ML * B)
         privs, nonces = scal(raw[0]), scal(raw[1])
-        dg = b"".join(hashlib.sha256(msgs[ML * i:ML * (i + 1)]).digest() for i in range(B))
+        hf = getattr(hashlib, hname.lower())
+        dg = b"".join(hf(msgs[ML * i:ML * (i + 1)]).digest() for i in range(B))
         pubs, st = cv.scalar_mult(privs)
         assert set(st) == {0}
-        sigs, st = cv.ecdsa_sign(privs, nonces, dg, 32)
+        sigs, st = cv.ecdsa_sign(privs, nonces, dg, hl)
         assert set(st) == {0}
         sigs = bytearray(sigs)
         bad = np.zeros(B, dtype=np.uint8)
         for i in range(0, B, 10):          # every 10th signature corrupted
-            sigs[64 * i + 32 + (i % 32)] ^= 1 << (i % 8)
+            sigs[2 * ql * i + ql + (i % ql)] ^= 1 << (i % 8)
             bad[i] = 1
         sigs = bytes(sigs)
         ins = [t(pubs), t(sigs), t(dg)]
         d_res = torch.empty(B, dtype=torch.uint8, device=dev)
 
         def step():
-            cv.ecdsa_verify_dev(B, ins[0].data_ptr(), ins[1].data_ptr(), ins[2].data_ptr(), 32, d_res.data_ptr(),
+            cv.ecdsa_verify_dev(B, ins[0].data_ptr(), ins[1].data_ptr(), ins[2].data_ptr(), hl, d_res.data_ptr(),
                                 stream.cuda_stream)
         expected = bad.tobytes()
 
         def oracle_subset(idx):
             o = O.Oracle(curve)
-            return o.ecdsa_verify(b"".join(pubs[64 * i:64 * i + 64] for i in idx), b"".join(sigs[64 * i:64 * i + 64] for i in idx),
-                                  b"".join(dg[32 * i:32 * i + 32] for i in idx), 32)
+            return o.ecdsa_verify(b"".join(pubs[2 * cl * i:2 * cl * (i + 1)] for i in idx), b"".join(sigs[2 * ql * i:2 * ql * (i + 1)] for i in idx),
+                                  b"".join(dg[hl * i:hl * (i + 1)] for i in idx), hl)
 
         def ref_subset(idx):
             r = O.RefLib(curve)
-            sp, ss, sm = (b"".join(x[w * i:w * i + w] for i in idx) for x, w in ((pubs, 64), (sigs, 64), (msgs, ML)))
-            return O.join_slices(O.in_slices(lambda lo, hi: r.ecdsa_verify("SHA256", sp[64 * lo:64 * hi], ss[64 * lo:64 * hi], sm[ML * lo:ML * hi], ML), len(idx)))
+            sp, ss, sm = (b"".join(x[w * i:w * i + w] for i in idx) for x, w in ((pubs, 2 * cl), (sigs, 2 * ql), (msgs, ML)))
+            return O.join_slices(O.in_slices(lambda lo, hi: r.ecdsa_verify(hname, sp[2 * cl * lo:2 * cl * hi], ss[2 * ql * lo:2 * ql * hi], sm[ML * lo:ML * hi], ML), len(idx)))
         # dominant kernel k_p256_verify_loop<COMB>: the top digit's mixed addition, 64 windows of 4 doublings + 1 mixed addition on Q's
         # table, 17 mixed additions from the comb table of G, the projective x mod q == r test (1 S + 6 M); M = 117, S = 81 MADs
         work = {"kernel": "k_p256_verify_loop<true>", "mads_per_item": 64 * (24 * 117 + 19 * 81) + 18 * (8 * 117 + 3 * 81) + 81 + 6 * 117,
                 "sgpr_mads_per_item": 36 * (64 * 43 + 18 * 11 + 7)} if curve == "SECP256R1" else None
-        metric, unit, cfg = "ECDSA verifications/sec (%s, SHA-256 digests, batch=2^%d)" % (curve.lower(), a.batch_log2), "verifications/s", 3
+        metric, unit, cfg = "ECDSA verifications/sec (%s, %s digests, batch=2^%d)" % (curve.lower(), hname, a.batch_log2), "verifications/s", 3
     elif a.workload in ("ecdsa_sign", "ecccdh"):
         # secp256r1: signing with caller-supplied nonces (the tail of ec_sign) / ECC-CDH shared secrets
         curve = a.curve
@@ -328,7 +330,7 @@ def main():
         if a.workload == "ecdsa_verify":
             # ec_verify hashes the message itself: time it on messages of the digest's length (SHA-256 of 32 bytes
             # is noise next to the two scalar multiplications); accept bits are not compared here
-            O.RefLib(curve).ecdsa_verify("SHA256", pubs[:64 * m], sigs[:64 * m], msgs[:32 * m], 32)
+            O.RefLib(curve).ecdsa_verify(hname, pubs[:2 * cl * m], sigs[:2 * ql * m], msgs[:32 * m], 32)
             what = "ec_pub_key_import_from_aff_buf + ec_verify (ECDSA, SHA-256 over 32-byte messages)"
         elif a.workload == "ecdsa_sign":
             O.RefLib(curve).ecdsa_sign("SHA256", privs[:32 * m], other[:32 * m], dg[:32 * m], 32)
