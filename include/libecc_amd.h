@@ -372,6 +372,8 @@ int ecamd_multi_prj_pt_mul_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint
 int ecamd_multi_prj_pt_mul_batch_fmt(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *scalars,
 				     uint32_t scalar_len, const uint8_t *points, int in_fmt, uint8_t *out, int out_fmt,
 				     uint8_t *status);
+int ecamd_multi_prj_pt_add_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *p1_aff, const uint8_t *p2_aff,
+				uint8_t *out_aff, uint8_t *status);
 int ecamd_multi_prj_pt_unique_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *points, int in_fmt,
 				    uint8_t *out, int out_fmt, uint8_t *status);
 int ecamd_multi_ecdsa_verify_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *pubkeys_aff,

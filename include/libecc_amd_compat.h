@@ -146,7 +146,17 @@ int eddsa_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **pub
 			   verify_batch_scratch_pad *scratch_pad_area, u32 *scratch_pad_area_len);
 
 /*
- * The per-item form of both: results[i] = what ec_verify(s[i], s_len[i], pub_keys[i], m[i], m_len[i], sig_type, hash_type,
+ * BIP0340 (Schnorr, any curve, as sig/bip0340.c) batch verification, same prototype; replaces bip0340_verify_batch
+ * (sig/bip0340.c:1196) behind ec_verify_batch.  Every signature is verified on the GPU(s) -- the key's unique representative
+ * with an even y, [s]G + [q - e]Y, the parity and x = r tests -- and the answer is the exact conjunction (the reference's random
+ * linear combination has the same answer up to its 2^-128 error); tagged hashes on the host threads.
+ */
+int bip0340_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
+			     ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len,
+			     verify_batch_scratch_pad *scratch_pad_area, u32 *scratch_pad_area_len);
+
+/*
+ * The per-item form of all three: results[i] = what ec_verify(s[i], s_len[i], pub_keys[i], m[i], m_len[i], sig_type, hash_type,
  * adata[i], adata_len[i]) returns (0 / -1).  Returns 0 when the batch ran, -1 on a call-level error (unsupported
  * algorithm, no GPU).
  */
@@ -157,8 +167,8 @@ int ec_verify_batch_results(const u8 **s, const u8 *s_len, const ec_pub_key **pu
  * libsign_amd.so also REPLACES these two libecc symbols (libecc's own definitions are kept under the names
  * libecc_cpu_ec_verify_batch / libecc_cpu_is_verify_batch_mode_supported):
  *   ec_verify_batch (sig/sig_algs.h:90-93): ECDSA, DECDSA -> ecdsa_verify_batch; the EdDSA variants ->
- *     eddsa_verify_batch_gpu; every other algorithm -> libecc's own ec_verify_batch (BIP0340, ECFSDSA on the CPU,
- *     unsupported_verify_batch for the rest);
+ *     eddsa_verify_batch_gpu; BIP0340 -> bip0340_verify_batch_gpu; every other algorithm -> libecc's own ec_verify_batch
+ *     (ECFSDSA on the CPU, unsupported_verify_batch for the rest);
  *   is_verify_batch_mode_supported (sig/sig_algs_internal.h:267): additionally reports ECDSA and DECDSA as supported.
  */
 int libecc_cpu_ec_verify_batch(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,

@@ -943,8 +943,10 @@ int main(int argc, char **argv)
 	check_xdh(32, n);
 	check_xdh(56, n < 256 ? n : 256);
 	check_foreign_generator(n < 64 ? n : 64);
+	check_verify("SECP256K1", BIP0340, SHA256, "BIP0340/SECP256K1/SHA256", n, 1);
+	check_verify("SECP256R1", BIP0340, SHA512, "BIP0340/SECP256R1/SHA512", n < 128 ? n : 128, 1);
 	/* an algorithm the GPU does not take goes to libecc's own verifier */
-	check_verify("SECP256K1", BIP0340, SHA256, "BIP0340 (libecc's CPU path)", n < 16 ? n : 16, 0);
+	check_verify("SECP256R1", ECFSDSA, SHA256, "ECFSDSA (libecc's CPU path)", n < 16 ? n : 16, 0);
 	printf("items sent to the GPU: %llu\n", ecamd_compat_gpu_items());
 	if (!ecamd_compat_gpu_items()) {
 		failures++;

@@ -59,7 +59,7 @@ static pthread_mutex_t g_call_mu = PTHREAD_MUTEX_INITIALIZER;   /* one batch cal
 static ecamd_multi *g_multi;
 static int g_threads;
 static int g_secret = 1;
-static u32 g_chunk = 1u << 16;       /* items per pipeline chunk and device */
+static u32 g_chunk = 0;              /* items per pipeline chunk and device; 0: chosen from the batch size (chunk_items) */
 static u32 g_chunk_all = 1u << 18;   /* the same for EdDSA whole-batch verification (the multi-scalar multiplication wants >= 2^17) */
 static curve_ent g_curves[MAX_CURVES];
 static u32 g_ncurves;
@@ -667,11 +667,26 @@ static void parallel_for(u32 n, range_fn fn, void *arg)
 	(void)pipeline_run(n, n, fn, NULL, NULL, arg);
 }
 
-/* items per pipeline chunk: g_chunk per device (the multi-GPU layer cuts every chunk into one shard per device) */
-static u32 chunk_items(u32 per_device)
+/* Items per pipeline chunk.  Every chunk costs the device side a fixed few hundred microseconds (launches, staging, one
+ * synchronisation), so chunks should be large; the overlap of packing with the GPU needs several of them.  Measured on 2^20
+ * ECDSA verifications (profiles/r3b_compat_end_to_end.md): 12.8 / 22.4 / 27.9 / 28.8 M/s at 2^15 / 2^16 / 2^17 / 2^18 items per
+ * chunk.  Default: a quarter of the batch per device, between 2^15 and 2^18 ($ECAMD_COMPAT_CHUNK fixes it); the multi-GPU
+ * layer cuts every chunk into one shard per device. */
+static u32 chunk_items_for(u32 per_device, u32 n)
 {
 	const int nd = g_multi ? ecamd_multi_size(g_multi) : 1;
-	const u64 c = (u64)per_device * (u64)(nd > 0 ? nd : 1);
+	u64 c;
+	if (per_device == 0) {
+		const u32 per_dev_n = n / (u32)(nd > 0 ? nd : 1);
+		per_device = per_dev_n / 4;
+		if (per_device < (1u << 15)) {
+			per_device = 1u << 15;
+		}
+		if (per_device > (1u << 18)) {
+			per_device = 1u << 18;
+		}
+	}
+	c = (u64)per_device * (u64)(nd > 0 ? nd : 1);
 	return c > 0x40000000ull ? 0x40000000u : (u32)c;
 }
 
@@ -884,7 +899,7 @@ static int mul_group(mul_job *J, u32 cnt)
 	if (!J->sc || !J->pin || !J->pout || !J->st || !J->pre) {
 		return -1;
 	}
-	if (pipeline_run(cnt, chunk_items(g_chunk), mul_pack, mul_gpu, mul_unpack, J)) {
+	if (pipeline_run(cnt, chunk_items_for(g_chunk, cnt), mul_pack, mul_gpu, mul_unpack, J)) {
 		return -1;
 	}
 	note_items(cnt);
@@ -1282,7 +1297,7 @@ static int key_batch(key_job *J, u32 num)
 	J->out = buf_get(1, (size_t)num * 2 * J->clen);
 	J->st = buf_get(2, num);
 	J->pre = buf_get(3, num);
-	if (J->sc && J->out && J->st && J->pre && !pipeline_run(num, chunk_items(g_chunk), key_pack, key_gpu, key_unpack, J)) {
+	if (J->sc && J->out && J->st && J->pre && !pipeline_run(num, chunk_items_for(g_chunk, num), key_pack, key_gpu, key_unpack, J)) {
 		note_items(num);
 		ret = 0;
 	}
@@ -1506,7 +1521,7 @@ int ecccdh_derive_secret_batch(const ec_priv_key *const *our_priv_keys, const u8
 	J.sec = buf_get(2, (size_t)num * J.clen);
 	J.st = buf_get(3, num);
 	J.pre = buf_get(4, num);
-	if (J.pv && J.pk && J.sec && J.st && J.pre && !pipeline_run(num, chunk_items(g_chunk), cdh_pack, cdh_gpu, cdh_unpack, &J)) {
+	if (J.pv && J.pk && J.sec && J.st && J.pre && !pipeline_run(num, chunk_items_for(g_chunk, num), cdh_pack, cdh_gpu, cdh_unpack, &J)) {
 		note_items(num);
 		ret = 0;
 	}
@@ -1609,7 +1624,7 @@ static int xdh_batch(const char *curve, u32 len, const u8 *const *k, const u8 *c
 	J.rb = buf_get(2, (size_t)num * len);
 	J.st = buf_get(3, num);
 	J.pre = buf_get(4, num);
-	if (J.kb && J.ub && J.rb && J.st && J.pre && !pipeline_run(num, chunk_items(g_chunk), xdh_pack, xdh_gpu, xdh_unpack, &J)) {
+	if (J.kb && J.ub && J.rb && J.st && J.pre && !pipeline_run(num, chunk_items_for(g_chunk, num), xdh_pack, xdh_gpu, xdh_unpack, &J)) {
 		note_items(num);
 		ret = 0;
 	}
@@ -1923,7 +1938,7 @@ static int ecdsa_sign_group(sign_job *J, u32 cnt)
 			nn_uninit(&k);
 			J->nonces_given = 1;
 		}
-		if (pipeline_run(cnt, chunk_items(g_chunk), ecdsa_sign_pack, ecdsa_sign_gpu, ecdsa_sign_unpack, J)) {
+		if (pipeline_run(cnt, chunk_items_for(g_chunk, cnt), ecdsa_sign_pack, ecdsa_sign_gpu, ecdsa_sign_unpack, J)) {
 			goto done;
 		}
 		note_items(cnt);
@@ -2114,7 +2129,7 @@ static int eddsa_sign_group(sign_job *J, u32 cnt)
 		return -1;
 	}
 	/* 2. r = H(dom || prefix || PH(M)) on the host | R = [r]G encoded on the device | H(dom || R || A || PH(M)) on the host */
-	if (pipeline_run(cnt, chunk_items(g_chunk), eddsa_sign_pack, eddsa_sign_gpu_R, eddsa_sign_hram, J)) {
+	if (pipeline_run(cnt, chunk_items_for(g_chunk, cnt), eddsa_sign_pack, eddsa_sign_gpu_R, eddsa_sign_hram, J)) {
 		return -1;
 	}
 	/* 3. S = (r + h a) mod q */
@@ -2326,7 +2341,7 @@ static int ecdsa_group(ver_job *J, u32 cnt, int *results)
 	if (!J->pk || !J->sg || !J->dg || !J->pre || !J->res) {
 		return -1;
 	}
-	if (pipeline_run(cnt, chunk_items(g_chunk), ecdsa_pack, ecdsa_ver_gpu, NULL, J)) {
+	if (pipeline_run(cnt, chunk_items_for(g_chunk, cnt), ecdsa_pack, ecdsa_ver_gpu, NULL, J)) {
 		return -1;
 	}
 	note_items(cnt);
@@ -2473,7 +2488,7 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
 	}
 	if (J->all_only) {
 		J->all_ok = 1;
-		if (pipeline_run(cnt, chunk_items(g_chunk_all), eddsa_pack, eddsa_ver_gpu_all, NULL, J)) {
+		if (pipeline_run(cnt, chunk_items_for(g_chunk_all, cnt), eddsa_pack, eddsa_ver_gpu_all, NULL, J)) {
 			return -1;
 		}
 		note_items(cnt);
@@ -2482,7 +2497,7 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
 		}
 		return 0;
 	}
-	if (pipeline_run(cnt, chunk_items(g_chunk), eddsa_pack, eddsa_ver_gpu, NULL, J)) {
+	if (pipeline_run(cnt, chunk_items_for(g_chunk, cnt), eddsa_pack, eddsa_ver_gpu, NULL, J)) {
 		return -1;
 	}
 	note_items(cnt);
@@ -2490,6 +2505,191 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
 		results[J->idx[j]] = (J->pre[j] || J->res[j]) ? -1 : 0;
 	}
 	return 0;
+}
+
+
+/* ---- BIP0340 (Schnorr signatures as libecc implements them on any curve, sig/bip0340.c:383-560) ----
+ * per item: Y = the key's unique representative with an even y (lift_x), r < p, s < q, e = H_tag(r || Y.x || m) mod q, then
+ * R = [s]G + [q - e]Y must be finite, have an even y and x = r.  The normalisation of the keys, both scalar multiplications and
+ * the addition run on the GPU(s) as whole-batch calls; the hashes and the byte checks on the host threads between them.
+ * Buffers: 0 keys X||Y||Z, 1 keys affine -> Y, 2 their status, 3 s, 4 q - e, 5 [s]G, 6 its status, 7 [q - e]Y, 8 its status,
+ * 9 the sum, 10 its status, 11 pre-check. */
+typedef struct {
+	ver_job v;
+	u8 *kaff, *kst, *sc_s, *sc_e, *pA, *stA, *pB, *stB, *sum, *stS;
+	u8 p_be[80], q_be[80], tagd[MAX_DIGEST_SIZE];
+} bip_job;
+
+static int be_lt(const u8 *a, const u8 *b, u32 len)   /* a < b, big-endian */
+{
+	u32 i;
+	for (i = 0; i < len; i++) {
+		if (a[i] != b[i]) {
+			return a[i] < b[i];
+		}
+	}
+	return 0;
+}
+
+static void bip_export_keys(u32 lo, u32 hi, void *arg)
+{
+	bip_job *B = (bip_job *)arg;
+	ver_job *J = &B->v;
+	u32 j;
+	for (j = lo; j < hi; j++) {
+		const ec_pub_key *pk = J->pub_keys[J->idx[j]];
+		u8 *dst = J->kprj + (size_t)j * 3 * J->clen;
+		J->pre[j] = (pub_key_check_initialized_and_type(pk, J->sig_type) || pk->params != J->params ||
+			     prj_to_be(dst, J->clen, &pk->y, &(J->params->ec_curve))) ? 1 : 0;
+		if (J->pre[j]) {
+			memset(dst, 0xff, (size_t)3 * J->clen);
+		}
+	}
+}
+
+static void bip_pack(u32 lo, u32 hi, void *arg)
+{
+	bip_job *B = (bip_job *)arg;
+	ver_job *J = &B->v;
+	const u32 cl = J->clen, ql = J->qlen;
+	u32 j, k;
+	for (j = lo; j < hi; j++) {
+		const u32 i = J->idx[j];
+		const u8 *sig = J->s[i];
+		u8 *Y = B->kaff + (size_t)j * 2 * cl, dig[MAX_DIGEST_SIZE];
+		hash_context hc;
+		nn e;
+		int bad;
+		e.magic = WORD(0);
+		/* _bip0340_verify_init (sig/bip0340.c:383-462): signature length, the key's unique representative (a key at infinity
+		 * fails in prj_pt_unique), r < p (fp_import_from_buf), s < q */
+		bad = J->pre[j] || B->kst[j] != ECAMD_OK || !sig || J->s_len[i] != J->siglen || (!J->m[i] && J->m_len[i]);
+		bad = bad || !be_lt(sig, B->p_be, cl) || !be_lt(sig + cl, B->q_be, ql);
+		/* e = H(H(tag) || H(tag) || r || Y.x || m) mod q (:45-69, :437-441, :470-494), then q - e (:531) */
+		bad = bad || J->hm->hfunc_init(&hc) || J->hm->hfunc_update(&hc, B->tagd, J->hm->digest_size) ||
+		      J->hm->hfunc_update(&hc, B->tagd, J->hm->digest_size) || J->hm->hfunc_update(&hc, sig, cl) || J->hm->hfunc_update(&hc, Y, cl) ||
+		      J->hm->hfunc_update(&hc, J->m[i], J->m_len[i]) || J->hm->hfunc_finalize(&hc, dig);
+		bad = bad || nn_init_from_buf(&e, dig, J->hm->digest_size) || nn_mod(&e, &e, &(J->params->ec_gen_order)) ||
+		      nn_mod_neg(&e, &e, &(J->params->ec_gen_order)) || nn_to_be(B->sc_e + (size_t)j * ql, ql, &e);
+		nn_uninit(&e);
+		J->pre[j] = bad ? 1 : 0;
+		if (bad) {
+			memset(B->sc_s + (size_t)j * ql, 0, ql);
+			memset(B->sc_e + (size_t)j * ql, 0, ql);
+			memset(Y, 0xff, (size_t)2 * cl);
+			continue;
+		}
+		memcpy(B->sc_s + (size_t)j * ql, sig + cl, ql);
+		/* lift_x: the representative with an even y (:532-535): y <- p - y when y is odd */
+		if (Y[2 * cl - 1] & 1) {
+			int borrow = 0;
+			for (k = cl; k-- > 0;) {
+				const int d = (int)B->p_be[k] - (int)Y[cl + k] - borrow;
+				Y[cl + k] = (u8)(d & 0xff);
+				borrow = d < 0;
+			}
+		}
+	}
+}
+
+static void bip_final(u32 lo, u32 hi, void *arg)
+{
+	bip_job *B = (bip_job *)arg;
+	ver_job *J = &B->v;
+	const u32 cl = J->clen;
+	u32 j;
+	for (j = lo; j < hi; j++) {
+		const u8 *W = NULL;
+		int ok = 0;
+		if (!J->pre[j] && B->stA[j] != ECAMD_ERR && B->stB[j] != ECAMD_ERR) {
+			/* prj_pt_add of the two products, then prj_pt_unique / prj_pt_iszero (:536-541): an operand at infinity leaves the
+			 * other one; the sum itself at infinity is rejected */
+			if (B->stA[j] == ECAMD_INF && B->stB[j] == ECAMD_INF) {
+				W = NULL;
+			} else if (B->stA[j] == ECAMD_INF) {
+				W = B->pB + (size_t)j * 2 * cl;
+			} else if (B->stB[j] == ECAMD_INF) {
+				W = B->pA + (size_t)j * 2 * cl;
+			} else if (B->stS[j] == ECAMD_OK) {
+				W = B->sum + (size_t)j * 2 * cl;
+			}
+			/* y even and x = r (:542-547) */
+			ok = W && !(W[2 * cl - 1] & 1) && !memcmp(W, J->s[J->idx[j]], cl);
+		}
+		J->res[j] = ok ? 0 : 1;
+	}
+}
+
+static int bip0340_group(ver_job *J0, u32 cnt, int *results)
+{
+	bip_job B;
+	ver_job *J = &B.v;
+	hash_context hc;
+	u32 j;
+	int ret = -1, was_secret = g_secret;
+	memset(&B, 0, sizeof(B));
+	B.v = *J0;
+	J->clen = J->e->clen;
+	J->qlen = J->e->qlen;
+	J->siglen = J->clen + J->qlen;   /* BIP0340_SIGLEN */
+	if (J->clen > 80 || J->qlen > 80 || nn_to_be(B.p_be, J->clen, &(J->params->ec_fp.p)) || nn_to_be(B.q_be, J->qlen, &(J->params->ec_gen_order)) ||
+	    J->hm->hfunc_init(&hc) || J->hm->hfunc_update(&hc, (const u8 *)"BIP0340/challenge", 17) || J->hm->hfunc_finalize(&hc, B.tagd)) {
+		return -1;
+	}
+	J->kprj = buf_get(0, (size_t)cnt * 3 * J->clen);
+	B.kaff = buf_get(1, (size_t)cnt * 2 * J->clen);
+	B.kst = buf_get(2, cnt);
+	B.sc_s = buf_get(3, (size_t)cnt * J->qlen);
+	B.sc_e = buf_get(4, (size_t)cnt * J->qlen);
+	B.pA = buf_get(5, (size_t)cnt * 2 * J->clen);
+	B.stA = buf_get(6, cnt);
+	B.pB = buf_get(7, (size_t)cnt * 2 * J->clen);
+	B.stB = buf_get(8, cnt);
+	B.sum = buf_get(9, (size_t)cnt * 2 * J->clen);
+	B.stS = buf_get(10, cnt);
+	J->pre = buf_get(11, cnt);
+	J->res = B.stS;   /* the verdicts overwrite the sum's status, read just before */
+	if (!J->kprj || !B.kaff || !B.kst || !B.sc_s || !B.sc_e || !B.pA || !B.stA || !B.pB || !B.stB || !B.sum || !B.stS || !J->pre) {
+		return -1;
+	}
+	/* everything a verification multiplies by is public: digit-indexed look-ups and the generator's comb table */
+	if (was_secret && ecamd_multi_set_secret_scalars(g_multi, 0)) {
+		return -1;
+	}
+	parallel_for(cnt, bip_export_keys, &B);
+	if (ecamd_multi_prj_pt_unique_batch(g_multi, J->e->mc, cnt, J->kprj, ECAMD_PT_PROJECTIVE, B.kaff, ECAMD_PT_AFFINE, B.kst)) {
+		goto gpu_err;
+	}
+	parallel_for(cnt, bip_pack, &B);
+	if (ecamd_multi_prj_pt_mul_batch(g_multi, J->e->mc, cnt, B.sc_s, J->qlen, NULL, B.pA, B.stA) ||
+	    ecamd_multi_prj_pt_mul_batch(g_multi, J->e->mc, cnt, B.sc_e, J->qlen, B.kaff, B.pB, B.stB) ||
+	    ecamd_multi_prj_pt_add_batch(g_multi, J->e->mc, cnt, B.pA, B.pB, B.sum, B.stS)) {
+		goto gpu_err;
+	}
+	parallel_for(cnt, bip_final, &B);
+	note_items(cnt);
+	for (j = 0; j < cnt; j++) {
+		results[J->idx[j]] = J->res[j] ? -1 : 0;
+	}
+	ret = 0;
+	goto done;
+gpu_err:
+	fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+done:
+	if (was_secret && ecamd_multi_set_secret_scalars(g_multi, 1)) {
+		ret = -1;
+	}
+	return ret;
+}
+
+static int is_bip0340(ec_alg_type t)
+{
+#if defined(WITH_SIG_BIP0340)
+	return t == BIP0340;
+#else
+	(void)t;
+	return 0;
+#endif
 }
 
 static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
@@ -2505,7 +2705,7 @@ static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_
 		return -1;
 	}
 	ed = !eddsa_variant(sig_type, &eh, &ec, &ph, &dom, &is448);
-	if (!ed && !is_ecdsa(sig_type)) {
+	if (!ed && !is_ecdsa(sig_type) && !is_bip0340(sig_type)) {
 		return -1;
 	}
 	for (i = 0; i < num; i++) {
@@ -2568,7 +2768,7 @@ static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_
 			goto out;
 		}
 		pthread_mutex_lock(&g_call_mu);
-		r = ed ? eddsa_group(&J, cnt, results) : ecdsa_group(&J, cnt, results);
+		r = ed ? eddsa_group(&J, cnt, results) : (is_bip0340(sig_type) ? bip0340_group(&J, cnt, results) : ecdsa_group(&J, cnt, results));
 		pthread_mutex_unlock(&g_call_mu);
 		if (r) {
 			goto out;
@@ -2661,6 +2861,41 @@ int eddsa_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **pub
 	return all_accepted(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, 1);
 }
 
+int bip0340_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
+			     ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len,
+			     verify_batch_scratch_pad *scratch_pad_area, u32 *scratch_pad_area_len)
+{
+	u32 i;
+	if (!is_bip0340(sig_type)) {
+		return -1;
+	}
+	/* argument checks of bip0340_verify_batch / _bip0340_verify_batch[_no_memory] (sig/bip0340.c:1196-1219, :905-920, :651-660):
+	 * arrays present, at least one item, one set of parameters, the scratch pad long enough when one is given */
+	if (!s || !pub_keys || !m) {
+		return -1;
+	}
+	if (scratch_pad_area) {
+		if (!scratch_pad_area_len) {
+			return -1;
+		}
+		if (num > 1) {
+			const u64 expected = ((2 * (u64)num) + 1) * sizeof(verify_batch_scratch_pad);
+			if (expected >= 0xffffffffULL || *scratch_pad_area_len < expected) {
+				return -1;
+			}
+		}
+	}
+	if (num == 0 || !pub_keys[0]) {
+		return -1;
+	}
+	for (i = 0; i < num; i++) {
+		if (!pub_keys[i] || pub_keys[i]->params != pub_keys[0]->params) {
+			return -1;
+		}
+	}
+	return all_accepted(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, 0);
+}
+
 /* ------------------------------------------------------------------------------------------------
  * the two replaced libecc symbols
  * ------------------------------------------------------------------------------------------------ */
@@ -2678,6 +2913,10 @@ int ec_verify_batch(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, 
 	if (!eddsa_variant(sig_type, &eh, &ec, &ph, &dom, &is448)) {
 		return eddsa_verify_batch_gpu(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, scratch_pad_area,
 					      scratch_pad_area_len);
+	}
+	if (is_bip0340(sig_type)) {
+		return bip0340_verify_batch_gpu(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, scratch_pad_area,
+						scratch_pad_area_len);
 	}
 	return libecc_cpu_ec_verify_batch(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, scratch_pad_area,
 					  scratch_pad_area_len);

@@ -614,7 +614,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_affine_g(Eca
 	}
 }
 
-// layout of the generator's 16-bit comb table (k_comb_build_g / k_comb_g below; k_loop_g<.., DUAL> reads it too)
+// layout of the generator's 16-bit comb table (k_comb_build_g / k_comb_g / k_comb_add_g below)
 template <int PB> struct CombLay {
 	static constexpr int NL = Cfg<PB>::NL;
 	static constexpr int NW = (PB + 31) / 32;
@@ -623,11 +623,7 @@ template <int PB> struct CombLay {
 };
 #define COMB_PER_WIN 32768
 
-// DUAL (ECDSA verification, lut_kind 2): after the window loop of [u2]Q the accumulator takes [u1]G from the generator's 16-bit
-// comb table -- 2 NW + 1 more mixed additions instead of a second scalar multiplication and a complete addition (the reference
-// computes uG and vY separately and adds them, sig/ecdsa_common.c:786-810; only x mod q of the sum is observable).  An exceptional
-// pair anywhere leaves Z = 0 and the item goes back as ECAMD_STATUS_REDO: the host verifies it again the reference's way.
-template <int PB, int FLAV, bool MASKED, bool DUAL = false> __global__ __launch_bounds__(64) G29_OCC void k_loop_g(EcamdSmulArgs A, int gslot)
+template <int PB, int FLAV, bool MASKED> __global__ __launch_bounds__(64) G29_OCC void k_loop_g(EcamdSmulArgs A, int gslot)
 {
 	typedef Lay<PB> L;
 	typedef typename Cls<PB>::FA FA;
@@ -684,59 +680,118 @@ template <int PB, int FLAV, bool MASKED, bool DUAL = false> __global__ __launch_
 		acc.Z = selg(keep, acc.Z, selg(use_t, weaken<FT>(onec), S.Z));
 		inf = inf & keep;
 	}
-	if constexpr (DUAL) {
-		// + [u1]G: k = sum_j s_j 2^(16 j) + D_top 2^(32 NW) over the comb table (see k_comb_g)
-		constexpr int NW = L::NW, KW = L::KW, CENTW = CombLay<PB>::CENTW, NWIN = CombLay<PB>::NWIN;
-		u32 kw[KW];
-		load_be<KW>(A.scalars2 + (size_t)i * A.s2len, (int)A.s2len, kw);
-		{
-			uint64_t c = 0;
-#pragma unroll
-			for (int w = 0; w < NW; w++) {
-				c += (uint64_t)kw[w] + 0x80008000u;
-				kw[w] = (u32)c;
-				c >>= 32;
-			}
-			kw[NW] = (u32)c;  // top digit: 0 or 1
+	// an exceptional pair of the mixed addition, or a doubling that reached infinity, leaves Z = 0 for good: one exact test
+	if (!inf && is_zero_mulout(mulc(acc.Z, onec, K), K)) {
+		A.status[i] = ECAMD_STATUS_REDO;
+		return;
+	}
+	if (inf) {
+		const int clen = (int)A.clen;
+		u8 *out = A.out + (size_t)i * 2 * clen;
+		A.status[i] = 2;
+		for (int b = 0; b < 2 * clen; b++) {
+			out[b] = 0;
 		}
-		const FT onet = weaken<FT>(onec);
-#pragma unroll 1
-		for (int j = 0; j <= NWIN; j++) {
-			u32 word = 0;
+		return;
+	}
+	Jac<PB> R;
+	R.X = weaken<FA>(acc.X);
+	R.Y = weaken<FA>(acc.Y);
+	R.Z = weaken<FA>(acc.Z);
+	jac_store<PB>(tb, R);
+	A.status[i] = ECAMD_STATUS_JAC;
+}
+
+// ECDSA verification (lut_kind 2): W' = [u2]Q + [u1]G.  k_loop_g leaves [u2]Q in the item's staging slot (Jacobian, status
+// ECAMD_STATUS_JAC; status 2 when it is the point at infinity); this kernel adds [u1]G from the generator's 16-bit comb table --
+// 2 NW + 1 mixed additions instead of a second scalar multiplication and a complete addition (the reference computes uG and vY
+// separately and adds them, sig/ecdsa_common.c:786-810; only x mod q of the sum is observable).  An exceptional pair leaves
+// Z = 0 and the item goes back as ECAMD_STATUS_REDO: the host verifies it again the reference's way.  A kernel of its own: inside
+// the window loop the comb's registers cost the loop a wave per SIMD at 384 bits and both at 448 / 521 bits (231 / 323 / 258
+// VGPRs against 167 / 216 / 248; profiles/r3b_fused_verify.md).
+template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_add_g(EcamdSmulArgs A, int gslot)
+{
+	typedef Lay<PB> L;
+	typedef typename Cls<PB>::FA FA;
+	typedef typename Cls<PB>::FM FM;
+	typedef typename Cls<PB>::FC FC;
+	typedef typename ClsT<PB>::FT FT;
+	constexpr int NL = L::NL, NW = L::NW, KW = L::KW, CENTW = CombLay<PB>::CENTW, NWIN = CombLay<PB>::NWIN;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const u32 st = A.status[i];
+	if (st != ECAMD_STATUS_JAC && st != 2u) {
+		return;   // key rejected at import, or an exceptional pair already met
+	}
+	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	const FC onec = constant<FC>(K.one);
+	const FT onet = weaken<FT>(onec);
+	u32 *tb = A.tbl + (size_t)i * L::ITEMW;
+	JacT<PB> acc;
+	bool inf = (st == 2u);
+	acc.X = onet;
+	acc.Y = onet;
+	acc.Z = onet;
+	if (!inf) {
+		// the loop's result: stored from the tight class (k_loop_g widens the type, not the digits), so it re-enters it as it is
+		const Jac<PB> R = jac_load<PB>(tb);
 #pragma unroll
-			for (int w = 0; w < KW; w++) {
-				word = (w == (j >> 1)) ? kw[w] : word;
-			}
-			const int dig = (j < NWIN) ? (int)((word >> (16 * (j & 1))) & 0xffffu) - 0x8000 : (int)word;
-			const u32 mag = (u32)(dig < 0 ? -dig : dig);
-			const uint4 *src = (const uint4 *)(A.lut + ((size_t)j * COMB_PER_WIN + (mag ? mag - 1 : 0)) * CENTW);
-			u32 buf[CENTW];
-#pragma unroll
-			for (int q = 0; q < CENTW / 4; q++) {
-				const uint4 v = src[q];
-				buf[4 * q] = v.x;
-				buf[4 * q + 1] = v.y;
-				buf[4 * q + 2] = v.z;
-				buf[4 * q + 3] = v.w;
-			}
-			FM tx, tyc;
-#pragma unroll
-			for (int w = 0; w < NL; w++) {
-				tx.l[w] = buf[w];
-				tyc.l[w] = buf[NL + w];
-			}
-			const FT txa = weaken<FT>(tx);
-			const FT ty = selg(dig < 0, neg_t<PB>(tyc, K), weaken<FT>(tyc));
-			const JacT<PB> S = madd_jac(acc, weaken<FA>(txa), weaken<FA>(ty), K);
-			const bool use_t = inf & (mag != 0);
-			const bool keep = (mag == 0);
-			acc.X = selg(keep, acc.X, selg(use_t, txa, S.X));
-			acc.Y = selg(keep, acc.Y, selg(use_t, ty, S.Y));
-			acc.Z = selg(keep, acc.Z, selg(use_t, onet, S.Z));
-			inf = inf & keep;
+		for (int w = 0; w < NL; w++) {
+			acc.X.l[w] = R.X.l[w];
+			acc.Y.l[w] = R.Y.l[w];
+			acc.Z.l[w] = R.Z.l[w];
 		}
 	}
-	// an exceptional pair of the mixed addition, or a doubling that reached infinity, leaves Z = 0 for good: one exact test
+	// k = sum_j s_j 2^(16 j) + D_top 2^(32 NW) over the comb table (see k_comb_g)
+	u32 kw[KW];
+	load_be<KW>(A.scalars2 + (size_t)i * A.s2len, (int)A.s2len, kw);
+	{
+		uint64_t c = 0;
+#pragma unroll
+		for (int w = 0; w < NW; w++) {
+			c += (uint64_t)kw[w] + 0x80008000u;
+			kw[w] = (u32)c;
+			c >>= 32;
+		}
+		kw[NW] = (u32)c;  // top digit: 0 or 1
+	}
+#pragma unroll 1
+	for (int j = 0; j <= NWIN; j++) {
+		u32 word = 0;
+#pragma unroll
+		for (int w = 0; w < KW; w++) {
+			word = (w == (j >> 1)) ? kw[w] : word;
+		}
+		const int dig = (j < NWIN) ? (int)((word >> (16 * (j & 1))) & 0xffffu) - 0x8000 : (int)word;
+		const u32 mag = (u32)(dig < 0 ? -dig : dig);
+		const uint4 *src = (const uint4 *)(A.lut + ((size_t)j * COMB_PER_WIN + (mag ? mag - 1 : 0)) * CENTW);
+		u32 buf[CENTW];
+#pragma unroll
+		for (int q = 0; q < CENTW / 4; q++) {
+			const uint4 v = src[q];
+			buf[4 * q] = v.x;
+			buf[4 * q + 1] = v.y;
+			buf[4 * q + 2] = v.z;
+			buf[4 * q + 3] = v.w;
+		}
+		FM tx, tyc;
+#pragma unroll
+		for (int w = 0; w < NL; w++) {
+			tx.l[w] = buf[w];
+			tyc.l[w] = buf[NL + w];
+		}
+		const FT txa = weaken<FT>(tx);
+		const FT ty = selg(dig < 0, neg_t<PB>(tyc, K), weaken<FT>(tyc));
+		const JacT<PB> S = madd_jac(acc, weaken<FA>(txa), weaken<FA>(ty), K);
+		const bool use_t = inf & (mag != 0);
+		const bool keep = (mag == 0);
+		acc.X = selg(keep, acc.X, selg(use_t, txa, S.X));
+		acc.Y = selg(keep, acc.Y, selg(use_t, ty, S.Y));
+		acc.Z = selg(keep, acc.Z, selg(use_t, onet, S.Z));
+		inf = inf & keep;
+	}
 	if (!inf && is_zero_mulout(mulc(acc.Z, onec, K), K)) {
 		A.status[i] = ECAMD_STATUS_REDO;
 		return;
@@ -2755,7 +2810,9 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_TAG)(int gslot, const EcamdSmulArgs &a
 			(void)hipEventRecord(ev[2], s);
 		}
 		if (a.lut && a.lut_kind == 2) {
-			hipLaunchKernelGGL((k_loop_g<G29_PB, G29_FLAV, false, true>), grid, block, 0, s, a, gslot);
+			// [u2]Q by the window loop, then + [u1]G from the comb table
+			hipLaunchKernelGGL((k_loop_g<G29_PB, G29_FLAV, false>), grid, block, 0, s, a, gslot);
+			hipLaunchKernelGGL((k_comb_add_g<G29_PB, G29_FLAV>), grid, block, 0, s, a, gslot);
 		} else if (a.masked) {
 			hipLaunchKernelGGL((k_loop_g<G29_PB, G29_FLAV, true>), grid, block, 0, s, a, gslot);
 		} else {

@@ -1747,7 +1747,7 @@ static int ecdsa_two_smul_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n,
 }
 
 // device pointers in and out; only enqueues on s
-// The fused double-scalar loop of the generic radix-2^29 units (k_loop_g<.., DUAL>): curves on the affine-table pipeline (every
+// The fused double-scalar loop of the generic radix-2^29 units (k_loop_g then k_comb_add_g): curves on the affine-table pipeline (every
 // flavour but the two nine-limb ones), prime-order groups (no subgroup check of the key to run beside it), u1 within the comb
 // table's reach, and a comb table of the generator (built on the first batch of at least comb_min_batch items).
 static bool fused_verify_ok(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n)

@@ -376,6 +376,16 @@ extern "C" int ecamd_multi_eddsa_verify_all_batch(ecamd_multi *m, const ecamd_mc
 	return 0;
 }
 
+extern "C" int ecamd_multi_prj_pt_add_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *p1_aff, const uint8_t *p2_aff,
+					    uint8_t *out_aff, uint8_t *status)
+{
+	const size_t plen = 2 * (size_t)ecamd_multi_curve_coord_len(c);
+	return run_sharded(m, c, n, "ecamd_multi_prj_pt_add_batch", [&](int r, uint32_t lo, uint32_t hi) {
+		return ec_prj_pt_add_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(p1_aff, plen), OFF(p2_aff, plen), OFF(out_aff, plen),
+					   OFF(status, 1));
+	});
+}
+
 extern "C" int ecamd_multi_prj_pt_unique_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *points, int in_fmt,
 					       uint8_t *out, int out_fmt, uint8_t *status)
 {

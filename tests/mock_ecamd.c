@@ -142,6 +142,20 @@ int ecamd_multi_prj_pt_mul_batch_fmt(ecamd_multi *m, const ecamd_mcurve *c, uint
 	return 0;
 }
 
+int ecamd_multi_prj_pt_unique_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *points, int in_fmt, uint8_t *out, int out_fmt,
+				    uint8_t *status)
+{
+	return ecamd_multi_prj_pt_mul_batch_fmt(m, c, n, NULL, 0, points, in_fmt, out, out_fmt, status);
+}
+
+int ecamd_multi_prj_pt_add_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *p1_aff, const uint8_t *p2_aff, uint8_t *out_aff,
+				 uint8_t *status)
+{
+	(void)m;
+	note(n);
+	return orc_pt_add_batch(&c->c, n, p1_aff, p2_aff, out_aff, status, 0);
+}
+
 int ecamd_multi_ecdsa_verify_batch_fmt(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys, int pub_fmt,
 				       const uint8_t *sigs, const uint8_t *digests, uint32_t digest_len, uint8_t *result)
 {

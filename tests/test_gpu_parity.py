@@ -1530,8 +1530,8 @@ def test_edge_fixtures_gpu(gpu_ctx):
 @pytest.mark.parametrize("curve", ["SECP384R1", "SECP521R1", "BRAINPOOLP256R1", "SECP224R1", "BRAINPOOLP512R1"])
 def test_ecdsa_fused_verify_generic_curves(gpu_ctx, curve):
     """ECDSA verification on the generic radix-2^29 units: batches of >= 4096 items take the fused double-scalar loop
-    (k_loop_g<.., DUAL>: [u2]Q by the window loop + [u1]G from the comb table, sig/ecdsa_common.c:786-796 replaced by one
-    loop).  4096 signatures made on the GPU, 10 % corrupted, plus the exceptional families -- key G / -G with u1 == u2 small, so
+    (k_loop_g for [u2]Q, then k_comb_add_g adds [u1]G from the comb table: sig/ecdsa_common.c:786-796 without the second
+    scalar multiplication).  4096 signatures made on the GPU, 10 % corrupted, plus the exceptional families -- key G / -G with u1 == u2 small, so
     that the first comb addition meets the doubling / the inverse case -- against the oracle, and the whole batch against the
     two-multiplication path ($ECAMD_NO_FUSED_VERIFY) and the construction."""
     c = CURVES[curve]
