@@ -150,6 +150,9 @@ int eddsa_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **pub
  * (sig/bip0340.c:1196) behind ec_verify_batch.  Every signature is verified on the GPU(s) -- the key's unique representative
  * with an even y, [s]G + [q - e]Y, the parity and x = r tests -- and the answer is the exact conjunction (the reference's random
  * linear combination has the same answer up to its 2^-128 error); tagged hashes on the host threads.
+ * The same entry point serves ECFSDSA (sig/ecfsdsa.c:470-640 per item, ecfsdsa_verify_batch at sig/ecfsdsa.c:1042): signature
+ * (r = Wx || Wy, s), e = H(r || m) mod q, accept when [s]G + [q - e]Y is the finite point whose affine coordinates are the bytes
+ * of r (both compared on the host after one batched unique-representative pass).
  */
 int bip0340_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
 			     ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len,
@@ -167,8 +170,9 @@ int ec_verify_batch_results(const u8 **s, const u8 *s_len, const ec_pub_key **pu
  * libsign_amd.so also REPLACES these two libecc symbols (libecc's own definitions are kept under the names
  * libecc_cpu_ec_verify_batch / libecc_cpu_is_verify_batch_mode_supported):
  *   ec_verify_batch (sig/sig_algs.h:90-93): ECDSA, DECDSA -> ecdsa_verify_batch; the EdDSA variants ->
- *     eddsa_verify_batch_gpu; BIP0340 -> bip0340_verify_batch_gpu; every other algorithm -> libecc's own ec_verify_batch
- *     (ECFSDSA on the CPU, unsupported_verify_batch for the rest);
+ *     eddsa_verify_batch_gpu; BIP0340 and ECFSDSA -> bip0340_verify_batch_gpu; every other algorithm -> libecc's own
+ *     ec_verify_batch (unsupported_verify_batch for all of them: with these four families every algorithm libecc lists in
+ *     is_verify_batch_mode_supported is served by the GPU);
  *   is_verify_batch_mode_supported (sig/sig_algs_internal.h:267): additionally reports ECDSA and DECDSA as supported.
  */
 int libecc_cpu_ec_verify_batch(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,

@@ -247,6 +247,16 @@ static void check_verify(const char *curve, ec_alg_type sig_type, hash_alg_type 
 		}
 	}
 	r = is_verify_batch_mode_supported(sig_type, &check);
+	if (on_gpu < 0) {
+		/* an algorithm without any batch form (libecc: unsupported_verify_batch): the replaced symbols must keep saying so */
+		CHECK(!r && !check, "%s: is_verify_batch_mode_supported says yes", label);
+		r = ec_verify_batch(sigs, siglens, pubs, msgs, msglens, n, sig_type, hash_type, adatas, adlens, NULL, NULL);
+		CHECK(r == -1, "%s: ec_verify_batch accepted a batch of an algorithm without a batch form", label);
+		r = ec_verify_batch_results(sigs, siglens, pubs, msgs, msglens, n, sig_type, hash_type, adatas, adlens, res);
+		CHECK(r == -1, "%s: ec_verify_batch_results took an algorithm it does not implement", label);
+		printf("ec_verify_batch %-28s %u items: %s\n", label, n, failures == before ? "ok" : "FAILED");
+		return;
+	}
 	CHECK(!r && check, "%s: is_verify_batch_mode_supported says no", label);
 	/* 1. the three calls of ec_self_tests_core.c: no scratch pad, length query, with scratch pad */
 	r = ec_verify_batch(sigs, siglens, pubs, msgs, msglens, n, sig_type, hash_type, adatas, adlens, NULL, NULL);
@@ -945,8 +955,10 @@ int main(int argc, char **argv)
 	check_foreign_generator(n < 64 ? n : 64);
 	check_verify("SECP256K1", BIP0340, SHA256, "BIP0340/SECP256K1/SHA256", n, 1);
 	check_verify("SECP256R1", BIP0340, SHA512, "BIP0340/SECP256R1/SHA512", n < 128 ? n : 128, 1);
-	/* an algorithm the GPU does not take goes to libecc's own verifier */
-	check_verify("SECP256R1", ECFSDSA, SHA256, "ECFSDSA (libecc's CPU path)", n < 16 ? n : 16, 0);
+	check_verify("SECP256R1", ECFSDSA, SHA256, "ECFSDSA/SECP256R1/SHA256", n, 1);
+	check_verify("BRAINPOOLP384R1", ECFSDSA, SHA384, "ECFSDSA/BRAINPOOLP384R1/SHA384", n < 128 ? n : 128, 1);
+	/* an algorithm the GPU does not take goes to libecc's own verifier (no batch form there: -1) */
+	check_verify("SECP256R1", ECKCDSA, SHA256, "ECKCDSA (no batch form)", n < 16 ? n : 16, -1);
 	printf("items sent to the GPU: %llu\n", ecamd_compat_gpu_items());
 	if (!ecamd_compat_gpu_items()) {
 		failures++;

@@ -693,7 +693,7 @@ static u32 chunk_items_for(u32 per_device, u32 n)
 /* ------------------------------------------------------------------------------------------------
  * staging buffers: page-locked, kept across calls (g_call_mu held)
  * ------------------------------------------------------------------------------------------------ */
-#define NBUF 12
+#define NBUF 16
 static u8 *g_buf[NBUF];
 static size_t g_cap[NBUF], g_used[NBUF];   /* g_used: bytes handed out since the last wipe */
 static u8 g_pinned[NBUF];
@@ -2508,7 +2508,7 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
 }
 
 
-/* ---- BIP0340 (Schnorr signatures as libecc implements them on any curve, sig/bip0340.c:383-560) ----
+/* ---- BIP0340 (Schnorr signatures as libecc implements them on any curve, sig/bip0340.c:383-560) and ECFSDSA (sig/ecfsdsa.c:404-580) ----
  * per item: Y = the key's unique representative with an even y (lift_x), r < p, s < q, e = H_tag(r || Y.x || m) mod q, then
  * R = [s]G + [q - e]Y must be finite, have an even y and x = r.  The normalisation of the keys, both scalar multiplications and
  * the addition run on the GPU(s) as whole-batch calls; the hashes and the byte checks on the host threads between them.
@@ -2516,7 +2516,9 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
  * 9 the sum, 10 its status, 11 pre-check. */
 typedef struct {
 	ver_job v;
+	int fs;                  /* 0: BIP0340, 1: ECFSDSA */
 	u8 *kaff, *kst, *sc_s, *sc_e, *pA, *stA, *pB, *stB, *sum, *stS;
+	u8 *wpt, *wst, *kinf;    /* ECFSDSA: the signatures' points W (validated on the device), their status; keys at infinity */
 	u8 p_be[80], q_be[80], tagd[MAX_DIGEST_SIZE];
 } bip_job;
 
@@ -2551,7 +2553,7 @@ static void bip_pack(u32 lo, u32 hi, void *arg)
 {
 	bip_job *B = (bip_job *)arg;
 	ver_job *J = &B->v;
-	const u32 cl = J->clen, ql = J->qlen;
+	const u32 cl = J->clen, ql = J->qlen, rl = B->fs ? 2 * cl : cl;
 	u32 j, k;
 	for (j = lo; j < hi; j++) {
 		const u32 i = J->idx[j];
@@ -2561,14 +2563,27 @@ static void bip_pack(u32 lo, u32 hi, void *arg)
 		nn e;
 		int bad;
 		e.magic = WORD(0);
-		/* _bip0340_verify_init (sig/bip0340.c:383-462): signature length, the key's unique representative (a key at infinity
-		 * fails in prj_pt_unique), r < p (fp_import_from_buf), s < q */
-		bad = J->pre[j] || B->kst[j] != ECAMD_OK || !sig || J->s_len[i] != J->siglen || (!J->m[i] && J->m_len[i]);
-		bad = bad || !be_lt(sig, B->p_be, cl) || !be_lt(sig + cl, B->q_be, ql);
-		/* e = H(H(tag) || H(tag) || r || Y.x || m) mod q (:45-69, :437-441, :470-494), then q - e (:531) */
-		bad = bad || J->hm->hfunc_init(&hc) || J->hm->hfunc_update(&hc, B->tagd, J->hm->digest_size) ||
-		      J->hm->hfunc_update(&hc, B->tagd, J->hm->digest_size) || J->hm->hfunc_update(&hc, sig, cl) || J->hm->hfunc_update(&hc, Y, cl) ||
-		      J->hm->hfunc_update(&hc, J->m[i], J->m_len[i]) || J->hm->hfunc_finalize(&hc, dig);
+		bad = J->pre[j] || !sig || J->s_len[i] != J->siglen || (!J->m[i] && J->m_len[i]);
+		if (!B->fs) {
+			/* _bip0340_verify_init (sig/bip0340.c:383-462): the key's unique representative (a key at infinity fails in
+			 * prj_pt_unique), r < p (fp_import_from_buf), s < q; e = H(H(tag) || H(tag) || r || Y.x || m) mod q (:45-69,
+			 * :437-441, :470-494) */
+			bad = bad || B->kst[j] != ECAMD_OK || !be_lt(sig, B->p_be, cl) || !be_lt(sig + cl, B->q_be, ql);
+			bad = bad || J->hm->hfunc_init(&hc) || J->hm->hfunc_update(&hc, B->tagd, J->hm->digest_size) ||
+			      J->hm->hfunc_update(&hc, B->tagd, J->hm->digest_size) || J->hm->hfunc_update(&hc, sig, cl) || J->hm->hfunc_update(&hc, Y, cl);
+		} else {
+			/* _ecfsdsa_verify_init (sig/ecfsdsa.c:404-470): r = W.x || W.y, both < p and on the curve (checked on the device:
+			 * wst), s in [1, q - 1]; e = H(r || m) mod q.  The key is used as it is: at infinity it contributes nothing. */
+			int snz = 0;
+			for (k = 0; k < ql && sig; k++) {
+				snz |= sig[2 * cl + k];
+			}
+			B->kinf[j] = (B->kst[j] == ECAMD_INF) ? 1 : 0;
+			bad = bad || B->kst[j] == ECAMD_ERR || B->wst[j] != ECAMD_OK || !snz || !be_lt(sig + 2 * cl, B->q_be, ql);
+			bad = bad || J->hm->hfunc_init(&hc) || J->hm->hfunc_update(&hc, sig, 2 * cl);
+		}
+		bad = bad || J->hm->hfunc_update(&hc, J->m[i], J->m_len[i]) || J->hm->hfunc_finalize(&hc, dig);
+		/* ... then q - e (bip0340.c:531, ecfsdsa.c:561) */
 		bad = bad || nn_init_from_buf(&e, dig, J->hm->digest_size) || nn_mod(&e, &e, &(J->params->ec_gen_order)) ||
 		      nn_mod_neg(&e, &e, &(J->params->ec_gen_order)) || nn_to_be(B->sc_e + (size_t)j * ql, ql, &e);
 		nn_uninit(&e);
@@ -2579,9 +2594,12 @@ static void bip_pack(u32 lo, u32 hi, void *arg)
 			memset(Y, 0xff, (size_t)2 * cl);
 			continue;
 		}
-		memcpy(B->sc_s + (size_t)j * ql, sig + cl, ql);
-		/* lift_x: the representative with an even y (:532-535): y <- p - y when y is odd */
-		if (Y[2 * cl - 1] & 1) {
+		memcpy(B->sc_s + (size_t)j * ql, sig + rl, ql);
+		if (B->fs && B->kinf[j]) {
+			memcpy(Y, B->wpt + (size_t)j * 2 * cl, (size_t)2 * cl);   /* any valid point: the product is not used */
+		}
+		/* BIP0340 lift_x: the representative with an even y (:532-535): y <- p - y when y is odd */
+		if (!B->fs && (Y[2 * cl - 1] & 1)) {
 			int borrow = 0;
 			for (k = cl; k-- > 0;) {
 				const int d = (int)B->p_be[k] - (int)Y[cl + k] - borrow;
@@ -2602,25 +2620,45 @@ static void bip_final(u32 lo, u32 hi, void *arg)
 		const u8 *W = NULL;
 		int ok = 0;
 		if (!J->pre[j] && B->stA[j] != ECAMD_ERR && B->stB[j] != ECAMD_ERR) {
-			/* prj_pt_add of the two products, then prj_pt_unique / prj_pt_iszero (:536-541): an operand at infinity leaves the
-			 * other one; the sum itself at infinity is rejected */
-			if (B->stA[j] == ECAMD_INF && B->stB[j] == ECAMD_INF) {
+			const u8 b_inf = (B->stB[j] == ECAMD_INF) || (B->fs && B->kinf[j]);
+			/* prj_pt_add of the two products, then prj_pt_unique / prj_pt_iszero (bip0340.c:536-541, ecfsdsa.c:563-567): an operand
+			 * at infinity leaves the other one; the sum itself at infinity is rejected */
+			if (B->stA[j] == ECAMD_INF && b_inf) {
 				W = NULL;
 			} else if (B->stA[j] == ECAMD_INF) {
 				W = B->pB + (size_t)j * 2 * cl;
-			} else if (B->stB[j] == ECAMD_INF) {
+			} else if (b_inf) {
 				W = B->pA + (size_t)j * 2 * cl;
 			} else if (B->stS[j] == ECAMD_OK) {
 				W = B->sum + (size_t)j * 2 * cl;
 			}
-			/* y even and x = r (:542-547) */
-			ok = W && !(W[2 * cl - 1] & 1) && !memcmp(W, J->s[J->idx[j]], cl);
+			if (B->fs) {
+				ok = W && !memcmp(W, J->s[J->idx[j]], (size_t)2 * cl);                    /* W' = W, both coordinates (ecfsdsa.c:569-576) */
+			} else {
+				ok = W && !(W[2 * cl - 1] & 1) && !memcmp(W, J->s[J->idx[j]], cl);        /* y even and x = r (bip0340.c:542-547) */
+			}
 		}
 		J->res[j] = ok ? 0 : 1;
 	}
 }
 
-static int bip0340_group(ver_job *J0, u32 cnt, int *results)
+static void fs_export_w(u32 lo, u32 hi, void *arg)
+{
+	bip_job *B = (bip_job *)arg;
+	ver_job *J = &B->v;
+	u32 j;
+	for (j = lo; j < hi; j++) {
+		const u32 i = J->idx[j];
+		u8 *dst = B->wpt + (size_t)j * 2 * J->clen;
+		if (J->s[i] && J->s_len[i] == J->siglen) {
+			memcpy(dst, J->s[i], (size_t)2 * J->clen);
+		} else {
+			memset(dst, 0xff, (size_t)2 * J->clen);
+		}
+	}
+}
+
+static int schnorr_group(ver_job *J0, u32 cnt, int *results, int fs)
 {
 	bip_job B;
 	ver_job *J = &B.v;
@@ -2629,9 +2667,10 @@ static int bip0340_group(ver_job *J0, u32 cnt, int *results)
 	int ret = -1, was_secret = g_secret;
 	memset(&B, 0, sizeof(B));
 	B.v = *J0;
+	B.fs = fs;
 	J->clen = J->e->clen;
 	J->qlen = J->e->qlen;
-	J->siglen = J->clen + J->qlen;   /* BIP0340_SIGLEN */
+	J->siglen = (fs ? 2 * J->clen : J->clen) + J->qlen;   /* ECFSDSA_SIGLEN / BIP0340_SIGLEN */
 	if (J->clen > 80 || J->qlen > 80 || nn_to_be(B.p_be, J->clen, &(J->params->ec_fp.p)) || nn_to_be(B.q_be, J->qlen, &(J->params->ec_gen_order)) ||
 	    J->hm->hfunc_init(&hc) || J->hm->hfunc_update(&hc, (const u8 *)"BIP0340/challenge", 17) || J->hm->hfunc_finalize(&hc, B.tagd)) {
 		return -1;
@@ -2648,8 +2687,12 @@ static int bip0340_group(ver_job *J0, u32 cnt, int *results)
 	B.sum = buf_get(9, (size_t)cnt * 2 * J->clen);
 	B.stS = buf_get(10, cnt);
 	J->pre = buf_get(11, cnt);
+	B.wpt = buf_get(12, fs ? (size_t)cnt * 2 * J->clen : 1);
+	B.wst = buf_get(13, cnt);
+	B.kinf = buf_get(14, cnt);
 	J->res = B.stS;   /* the verdicts overwrite the sum's status, read just before */
-	if (!J->kprj || !B.kaff || !B.kst || !B.sc_s || !B.sc_e || !B.pA || !B.stA || !B.pB || !B.stB || !B.sum || !B.stS || !J->pre) {
+	if (!J->kprj || !B.kaff || !B.kst || !B.sc_s || !B.sc_e || !B.pA || !B.stA || !B.pB || !B.stB || !B.sum || !B.stS || !J->pre || !B.wpt ||
+	    !B.wst || !B.kinf) {
 		return -1;
 	}
 	/* everything a verification multiplies by is public: digit-indexed look-ups and the generator's comb table */
@@ -2659,6 +2702,13 @@ static int bip0340_group(ver_job *J0, u32 cnt, int *results)
 	parallel_for(cnt, bip_export_keys, &B);
 	if (ecamd_multi_prj_pt_unique_batch(g_multi, J->e->mc, cnt, J->kprj, ECAMD_PT_PROJECTIVE, B.kaff, ECAMD_PT_AFFINE, B.kst)) {
 		goto gpu_err;
+	}
+	if (fs) {
+		/* the points the signatures carry: coordinates < p and on the curve (is_on_shortw_curve, sig/ecfsdsa.c:452-455) */
+		parallel_for(cnt, fs_export_w, &B);
+		if (ecamd_multi_prj_pt_unique_batch(g_multi, J->e->mc, cnt, B.wpt, ECAMD_PT_AFFINE, B.sum, ECAMD_PT_AFFINE, B.wst)) {
+			goto gpu_err;
+		}
 	}
 	parallel_for(cnt, bip_pack, &B);
 	if (ecamd_multi_prj_pt_mul_batch(g_multi, J->e->mc, cnt, B.sc_s, J->qlen, NULL, B.pA, B.stA) ||
@@ -2692,6 +2742,16 @@ static int is_bip0340(ec_alg_type t)
 #endif
 }
 
+static int is_ecfsdsa(ec_alg_type t)
+{
+#if defined(WITH_SIG_ECFSDSA)
+	return t == ECFSDSA;
+#else
+	(void)t;
+	return 0;
+#endif
+}
+
 static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
 			  ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len, int *results, int all_only)
 {
@@ -2705,7 +2765,7 @@ static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_
 		return -1;
 	}
 	ed = !eddsa_variant(sig_type, &eh, &ec, &ph, &dom, &is448);
-	if (!ed && !is_ecdsa(sig_type) && !is_bip0340(sig_type)) {
+	if (!ed && !is_ecdsa(sig_type) && !is_bip0340(sig_type) && !is_ecfsdsa(sig_type)) {
 		return -1;
 	}
 	for (i = 0; i < num; i++) {
@@ -2768,7 +2828,7 @@ static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_
 			goto out;
 		}
 		pthread_mutex_lock(&g_call_mu);
-		r = ed ? eddsa_group(&J, cnt, results) : (is_bip0340(sig_type) ? bip0340_group(&J, cnt, results) : ecdsa_group(&J, cnt, results));
+		r = ed ? eddsa_group(&J, cnt, results) : ((is_bip0340(sig_type) || is_ecfsdsa(sig_type)) ? schnorr_group(&J, cnt, results, is_ecfsdsa(sig_type)) : ecdsa_group(&J, cnt, results));
 		pthread_mutex_unlock(&g_call_mu);
 		if (r) {
 			goto out;
@@ -2866,7 +2926,7 @@ int bip0340_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **p
 			     verify_batch_scratch_pad *scratch_pad_area, u32 *scratch_pad_area_len)
 {
 	u32 i;
-	if (!is_bip0340(sig_type)) {
+	if (!is_bip0340(sig_type) && !is_ecfsdsa(sig_type)) {
 		return -1;
 	}
 	/* argument checks of bip0340_verify_batch / _bip0340_verify_batch[_no_memory] (sig/bip0340.c:1196-1219, :905-920, :651-660):
@@ -2914,7 +2974,7 @@ int ec_verify_batch(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, 
 		return eddsa_verify_batch_gpu(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, scratch_pad_area,
 					      scratch_pad_area_len);
 	}
-	if (is_bip0340(sig_type)) {
+	if (is_bip0340(sig_type) || is_ecfsdsa(sig_type)) {
 		return bip0340_verify_batch_gpu(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, scratch_pad_area,
 						scratch_pad_area_len);
 	}

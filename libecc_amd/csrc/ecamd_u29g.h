@@ -192,8 +192,12 @@ template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
 	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(acc), "=s"(dead_) : "v"(a), "v"(b)); } while (0)
 #define G29_MUL_VS(acc, a, b) \
 	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(acc), "=s"(dead_) : "v"(a), "s"(b)); } while (0)
+// two dependent MADs in ONE asm statement (hipcc pads every asm statement with an s_nop: one for the pair)
+#define G29_MAD2_VS(acc, a1, b1, a2, b2) \
+	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0" : "+v"(acc), "=&s"(dead_) : "v"(a1), "s"(b1), "v"(a2), "s"(b2)); } while (0)
 #define G29_PIN(acc) asm("" : "+v"(acc))
 #else
+#define G29_MAD2_VS(acc, a1, b1, a2, b2) acc += (u64)(a1) * (b1) + (u64)(a2) * (b2)
 #define G29_MUL_VV(acc, a, b) acc = (u64)(a) * (b)
 #define G29_MUL_VS(acc, a, b) acc = (u64)(a) * (b)
 #define G29_MAD_VV(acc, a, b) acc += (u64)(a) * (b)
@@ -341,9 +345,10 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 		// fed in at limb 0.
 		static_assert(NL == 9, "2^255 - 19 flavour: 9 limbs");
 		t[2 * NL - 1] = (u32)acc;  // < va vb 2^17 <= 2^31 (Cfg::prod_ok)
-		u32 f = 1216u;
+		u32 f = 1216u, one1 = 1u;
 #if defined(__HIPCC__)
-		asm volatile("" : "+s"(f));  // keep the folds MADs
+		asm volatile("" : "+s"(f), "+s"(one1));  // keep the folds MADs (one1: "acc += t[j]" as ONE MAD, 4.85 cycles, instead of
+		                                          // v_add_co_u32 + v_addc_co_u32, 9.4 -- profiles/r3a_effective_clock.md)
 #endif
 		// limb 8 without the carry from below: its bits from 23 up are multiples of 2^255 = 19
 		u64 top = t[NL - 1];
@@ -351,8 +356,7 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 		acc = (u64)((u32)(top >> 23)) * 19u;  // quotient < 64 + 19 va vb, times 19 < 2^23
 #pragma unroll
 		for (int j = 0; j < NL - 1; j++) {
-			acc += t[j];
-			G29_MAD_VS(acc, t[j + NL], f);
+			G29_MAD2_VS(acc, t[j], one1, t[j + NL], f);
 			r[j] = (u32)acc & MASK;
 			acc >>= W;
 			G29_PIN(acc);
@@ -368,15 +372,14 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 		//   second, MAD-free carry pass.
 		static_assert(NL == 16, "Goldilocks flavour: 16 limbs");
 		t[2 * NL - 1] = (u32)acc;  // < va vb / 8 (Cfg::prod_ok: < 2^27)
-		u32 c16 = 1u << 16, c24 = 1u << 24, c8 = 1u << 8, c17 = 1u << 17;
+		u32 c16 = 1u << 16, c24 = 1u << 24, c8 = 1u << 8, c17 = 1u << 17, one1 = 1u;
 #if defined(__HIPCC__)
-		asm volatile("" : "+s"(c16), "+s"(c24), "+s"(c8), "+s"(c17));  // keep the folds MADs
+		asm volatile("" : "+s"(c16), "+s"(c24), "+s"(c8), "+s"(c17), "+s"(one1));  // keep the folds MADs ("+= t[i]" as one MAD too)
 #endif
 		acc = 0;
 #pragma unroll
 		for (int i = 0; i < 8; i++) {
-			acc += t[i];
-			G29_MAD_VS(acc, t[16 + i], c16);
+			G29_MAD2_VS(acc, t[i], one1, t[16 + i], c16);
 			G29_MAD_VS(acc, t[24 + i], c24);
 			r[i] = (u32)acc & MASK;
 			acc >>= W;
@@ -384,15 +387,13 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 		}
 #pragma unroll
 		for (int i = 0; i < 7; i++) {
-			acc += t[i + 8];
-			G29_MAD_VS(acc, t[16 + i], c8);
+			G29_MAD2_VS(acc, t[i + 8], one1, t[16 + i], c8);
 			G29_MAD_VS(acc, t[24 + i], c17);
 			r[i + 8] = (u32)acc & MASK;
 			acc >>= W;
 			G29_PIN(acc);
 		}
-		acc += t[15];
-		G29_MAD_VS(acc, t[23], c8);
+		G29_MAD2_VS(acc, t[15], one1, t[23], c8);
 		G29_MAD_VS(acc, t[31], c17);               // < 2^29 + 2^37 + 2^44 + 2^25
 		const u32 q = (u32)(acc >> 13);           // < 2^32
 		const u32 top = (u32)acc & ((1u << 13) - 1);
@@ -422,9 +423,9 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 		//   2^256 = 8 2^29 + 977:                       the bits of limb 8 from 24 up (q) go to limbs 1 (x 8) and 0 (x 977)
 		static_assert(NL == 9, "secp256k1 flavour: 9 limbs");
 		t[2 * NL - 1] = (u32)acc;  // < va vb 2^19 <= 2^31 (Cfg::prod_ok)
-		u32 f = 31264u, g = 256u, f17 = 8003584u, g17 = 65536u, fq = 977u;
+		u32 f = 31264u, g = 256u, f17 = 8003584u, g17 = 65536u, fq = 977u, one1 = 1u, eight = 8u;
 #if defined(__HIPCC__)
-		asm volatile("" : "+s"(f), "+s"(g), "+s"(f17), "+s"(g17), "+s"(fq));  // keep the folds MADs
+		asm volatile("" : "+s"(f), "+s"(g), "+s"(f17), "+s"(g17), "+s"(fq), "+s"(one1), "+s"(eight));  // keep the folds MADs ("+= t[j]" as one MAD too)
 #endif
 		// limb 8 without the carry from below: < 2^29 + 2^37 + 2^46
 		u64 top = t[NL - 1];
@@ -432,13 +433,12 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 		G29_MAD_VS(top, t[2 * NL - 1], f);
 		const u32 q = (u32)(top >> 24);  // < 2^23
 		G29_MUL_VS(acc, q, fq);
-		acc += t[0];
-		G29_MAD_VS(acc, t[NL], f);
+		G29_MAD2_VS(acc, t[0], one1, t[NL], f);
 		G29_MAD_VS(acc, t[2 * NL - 1], f17);
 		r[0] = (u32)acc & MASK;
 		acc >>= W;
 		G29_PIN(acc);
-		acc += t[1] + ((u64)q << 3);
+		G29_MAD2_VS(acc, t[1], one1, q, eight);
 		G29_MAD_VS(acc, t[NL + 1], f);
 		G29_MAD_VS(acc, t[NL], g);
 		G29_MAD_VS(acc, t[2 * NL - 1], g17);
@@ -447,8 +447,7 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 		G29_PIN(acc);
 #pragma unroll
 		for (int j = 2; j < NL - 1; j++) {
-			acc += t[j];
-			G29_MAD_VS(acc, t[j + NL], f);
+			G29_MAD2_VS(acc, t[j], one1, t[j + NL], f);
 			G29_MAD_VS(acc, t[j + NL - 1], g);
 			r[j] = (u32)acc & MASK;
 			acc >>= W;

@@ -123,14 +123,23 @@ int ecamd_multi_prj_pt_mul_batch_fmt(ecamd_multi *m, const ecamd_mcurve *c, uint
 	uint32_t i;
 	(void)m;
 	note(n);
+	uint8_t *prj = NULL;
 	if (in_fmt != ECAMD_PT_PROJECTIVE) {
-		return mfail("mock: projective inputs only");
+		/* affine X || Y: the same point with Z = 1 */
+		prj = calloc((size_t)n + 1, 3 * cl);
+		for (i = 0; i < n; i++) {
+			memcpy(prj + i * 3 * cl, points + i * 2 * cl, 2 * cl);
+			prj[i * 3 * cl + 3 * cl - 1] = 1;
+		}
+		points = prj;
 	}
-	tmp = malloc((size_t)n * 3 * cl);
+	tmp = malloc((size_t)n * 3 * cl + 1);
 	if (orc_prj_batch(&c->c, n, scalars, slen, points, tmp, status)) {
 		free(tmp);
+		free(prj);
 		return mfail("mock: orc_prj_batch");
 	}
+	free(prj);
 	for (i = 0; i < n; i++) {
 		if (out_fmt == ECAMD_PT_PROJECTIVE) {
 			memcpy(out + i * 3 * cl, tmp + i * 3 * cl, 3 * cl);

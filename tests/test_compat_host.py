@@ -40,7 +40,7 @@ def test_every_typed_entry_point_matches_libecc_scalar_functions():
     assert "all ok" in r.stdout
     for row in ("prj_pt_mul_batch", "prj_pt_mul_blind_batch", "ecccdh_derive_secret_batch", "ec_verify_batch ECDSA", "ec_verify_batch EDDSA448",
                 "ec_sign_batch ECDSA", "ec_sign_batch DECDSA", "ec_sign_batch EDDSA25519", "ec_key_pair_{gen,import}_batch", "x25519_batch",
-                "x448_batch", "foreign generator", "ec_verify_batch BIP0340/SECP256K1"):
+                "x448_batch", "foreign generator", "ec_verify_batch BIP0340/SECP256K1", "ec_verify_batch ECFSDSA/SECP256R1", "ECKCDSA (no batch form)"):
         assert row in r.stdout, row
 
 

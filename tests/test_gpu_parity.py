@@ -1180,7 +1180,7 @@ def test_libecc_typed_boundary_vs_scalar_api():
     """include/libecc_amd_compat.h through libsign_amd.so, driven by a libecc application (libecc_amd/compat/compat_check.c):
     prj_pt_mul_batch(prj_pt[], nn[], prj_pt[]), ecccdh_derive_secret_batch and ec_verify_batch -- called with const u8 **,
     const ec_pub_key ** arrays exactly as tests/ec_self_tests_core.c:373-383, 556-616 call it -- for ECDSA, DECDSA, the
-    five EdDSA variants and BIP0340; ec_sign_batch (same nonce hook as _ec_sign, RFC 6979, EdDSA: signature bytes equal),
+    five EdDSA variants, BIP0340 and ECFSDSA; ec_sign_batch (same nonce hook as _ec_sign, RFC 6979, EdDSA: signature bytes equal),
     ec_key_pair_gen_batch / import / init_pubkey_from_privkey_batch for seven algorithms' key rules, x25519_batch / x448_batch --
     every result compared with libecc's own scalar function (the CPU code of the libecc the library was linked from) on
     the same structures, 640 items per case with the edge families"""
@@ -1193,7 +1193,7 @@ def test_libecc_typed_boundary_vs_scalar_api():
     assert "compat_check: all ok" in r.stdout
     assert r.stdout.count(": ok") >= 48 and "FAILED" not in r.stdout and "MISMATCH" not in r.stdout
     for row in ("ec_sign_batch ECDSA", "ec_sign_batch DECDSA", "ec_sign_batch EDDSA25519", "ec_sign_batch EDDSA448", "ec_key_pair_{gen,import}_batch",
-                "x25519_batch", "x448_batch", "ec_verify_batch BIP0340", "foreign generator"):
+                "x25519_batch", "x448_batch", "ec_verify_batch BIP0340", "ec_verify_batch ECFSDSA", "foreign generator"):
         assert row in r.stdout, row
     sent = int(r.stdout.split("items sent to the GPU:")[1].split()[0])
     assert sent >= 640 * 20, sent          # the batch forms did run on the GPU (there is no CPU fallback to hide behind)
