@@ -88,8 +88,8 @@ def work_model(curve_params, nw, slen, batch=1 << 20):
         if p == 2**255 - 19:                         # 2^255 - 19 flavour: 9 limbs, 9 + 1 fold MADs + 1 (x 19)
             nl = 9
             M, S = nl * nl + nl + 2, nl * (nl + 1) // 2 + nl + 2
-        if p == 2**448 - 2**224 - 1:                 # Goldilocks flavour: 16 limbs, 34 fold MADs (+ a MAD-free carry pass)
-            M, S = nl * nl + 34, nl * (nl + 1) // 2 + 34
+        if p == 2**448 - 2**224 - 1:                 # Goldilocks flavour: 16 limbs of 28 bits, phi^2 = phi + 1 folded inside the columns:
+            M, S = nl * nl, 2 * 36 + 64              # 256 MADs; squaring a0^2 + a1^2 (36 each) and a1 (2 a0 + a1) (64), ecamd_u29g.h:mul_p448
         if p == 2**256 - 2**32 - 977:                # secp256k1 flavour: 9 limbs, 2 + 3 + 3 + 6 * 2 = 20 fold MADs
             nl = 9
             M, S = nl * nl + 20, nl * (nl + 1) // 2 + 20
@@ -123,7 +123,7 @@ def work_model(curve_params, nw, slen, batch=1 << 20):
         # the reduction MADs multiply by digits of p held in __constant__ memory (scalar registers)
         red = {True: nl}.get(p == 2**521 - 1, nl * nl)
         if p == 2**448 - 2**224 - 1:
-            red = 34
+            red = 0                                   # no constant multipliers at all
         work_model.loop_sgpr_share = (loop_m + loop_s) * red / (loop_m * M + loop_s * S)
         return nm + ns, nm * M + ns * S, f"k_loop_g<{pbits}>", loop_m * M + loop_s * S
     mm_add, mm_dbl = 17, 16                              # RCB Alg. 1 / Alg. 3, generic a

@@ -800,13 +800,14 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 			   const uint8_t *d_points, uint8_t *d_out, uint8_t *d_status, hipStream_t s,
 			   uint32_t sstride = 0xffffffffu, bool redo_only = false, const uint8_t *d_scalars2 = nullptr);
 
-// 29-bit digits of a (nl of them, the last one takes whatever is left)
-static void big_digits29(uint32_t *dst, int nl, const Big &a)
+// w-bit digits of a (nl of them, the last one takes whatever is left): 29 bits on every radix-2^29 unit but the Goldilocks one
+// (flavour 5), which runs on 28-bit limbs so that 2^224 falls on a limb boundary (ecamd_u29g.h)
+static void big_digits29(uint32_t *dst, int nl, const Big &a, int w = 29)
 {
 	const int bits = big_bitlen(a);
 	for (int i = 0; i < nl; i++) {
 		uint64_t d = 0;
-		const int lo = 29 * i, hi = (i == nl - 1) ? (bits > lo + 29 ? bits : lo + 29) : lo + 29;
+		const int lo = w * i, hi = (i == nl - 1) ? (bits > lo + w ? bits : lo + w) : lo + w;
 		for (int b = lo; b < hi && b < bits; b++) {
 			if ((a[(size_t)b / 32] >> (b % 32)) & 1u) {
 				d |= 1ull << (b - lo);
@@ -827,11 +828,14 @@ static int upload_g29(ecamd_curve *cv)
 	const int pbits = cv->pbits, nl = ecamd_g29_nl(pbits, cv->gflavour);
 	const Big &p = cv->p;
 	// flavours 2 (p = 2^255 - 19), 4 (secp256k1's prime) and 5 (p = 2^448 - 2^224 - 1) keep plain residues: R = 1
-	const Big R = (cv->gflavour == 2 || cv->gflavour == 4 || cv->gflavour == 5) ? Big(1, 1) : big_mod(big_pow2(29 * nl), p);
+	const int w = (cv->gflavour == 5) ? 28 : 29;   // limb width of the unit (g29::W of its translation unit)
+	const Big R = (cv->gflavour == 2 || cv->gflavour == 4 || cv->gflavour == 5) ? Big(1, 1) : big_mod(big_pow2(w * nl), p);
 	Big two(1, 2), three(1, 3);
-	static const int step[16] = {2, 4, 6, 8, 10, 12, 14, 16, 2, 4, 6, 8, 10, 12, 14, 16};
+	static const int step29[16] = {2, 4, 6, 8, 10, 12, 14, 16, 2, 4, 6, 8, 10, 12, 14, 16};
+	static const int step28[16] = {1, 2, 3, 4, 5, 6, 7, 8, 1, 2, 3, 4, 5, 6, 7, 8};    // g29::bias_step of the Goldilocks flavour
+	const int *step = (cv->gflavour == 5) ? step28 : step29;
 	static const int sv[16] = {1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2};
-	const int topsh = pbits - 29 * (nl - 1);
+	const int topsh = pbits - w * (nl - 1);
 	const int off = (1 - topsh) > 0 ? (1 - topsh) : 0;
 	// Isomorphism onto a curve with a = -3 (cheaper doubling): (x, y) -> (u^2 x, u^3 y) with u^4 a = -3, when such a u
 	// exists.  Tried for p = 3 mod 4, where square roots are one exponentiation and exactly one of +-s is a square
@@ -868,24 +872,28 @@ static int upload_g29(ecamd_curve *cv)
 	const Big u2 = big_mulmod(u, u, p), u3 = big_mulmod(u2, u, p);
 	const Big RR = big_mulmod(R, R, p);
 	std::vector<uint32_t> img((size_t)(10 + 16) * nl + 4, 0);
-	big_digits29(&img[0 * nl], nl, p);
-	big_digits29(&img[1 * nl], nl, RR);
-	big_digits29(&img[2 * nl], nl, R);
-	big_digits29(&img[3 * nl], nl, big_mulmod(a_img, R, p));
-	big_digits29(&img[4 * nl], nl, big_mulmod(b_img, R, p));
-	big_digits29(&img[5 * nl], nl, big_sub(p, two));
-	big_digits29(&img[22 * nl], nl, big_mulmod(u2, RR, p));                             // ix
-	big_digits29(&img[23 * nl], nl, big_mulmod(u3, RR, p));                             // iy
-	big_digits29(&img[24 * nl], nl, big_powmod(u2, big_sub(p, two), p));                // ex = u^-2
-	big_digits29(&img[25 * nl], nl, big_powmod(u3, big_sub(p, two), p));                // ey = u^-3
+	big_digits29(&img[0 * nl], nl, p, w);
+	big_digits29(&img[1 * nl], nl, RR, w);
+	big_digits29(&img[2 * nl], nl, R, w);
+	big_digits29(&img[3 * nl], nl, big_mulmod(a_img, R, p), w);
+	big_digits29(&img[4 * nl], nl, big_mulmod(b_img, R, p), w);
+	big_digits29(&img[5 * nl], nl, big_sub(p, two), w);
+	big_digits29(&img[22 * nl], nl, big_mulmod(u2, RR, p), w);                             // ix
+	big_digits29(&img[23 * nl], nl, big_mulmod(u3, RR, p), w);                             // iy
+	big_digits29(&img[24 * nl], nl, big_powmod(u2, big_sub(p, two), p), w);                // ex = u^-2
+	big_digits29(&img[25 * nl], nl, big_powmod(u3, big_sub(p, two), p), w);                // ey = u^-3
 	for (int t = 0; t < 16; t++) {
 		uint32_t *l = &img[(size_t)(6 + t) * nl];
-		if (big_bitlen(p) + step[t] + off > 29 * (nl - 1) + 32) {
+		if (big_bitlen(p) + step[t] + off > w * (nl - 1) + 32) {
 			continue;  // this multiple does not fit the limbs (only without a headroom limb); never selected
 		}
-		big_digits29(l, nl, big_shl(p, step[t] + off));
-		const uint32_t M = 1u << (29 + sv[t]), BW = 1u << sv[t];
+		big_digits29(l, nl, big_shl(p, step[t] + off), w);
+		const uint32_t M = 1u << (w + sv[t]), BW = 1u << sv[t];
 		if (l[nl - 1] < BW) {
+			if (w == 28) {
+				memset(l, 0, sizeof(uint32_t) * (size_t)nl);
+				continue;  // 2p on the Goldilocks unit cannot lend the borrow; never selected (BiasB's static_asserts)
+			}
 			return fail("internal: bias table underflow");
 		}
 		l[0] += M;
@@ -898,7 +906,7 @@ static int upload_g29(ecamd_curve *cv)
 	for (int i = 0; i < 5; i++) {
 		x *= 2u - p0 * x;
 	}
-	img[(size_t)26 * nl + 0] = (0u - x) & 0x1fffffffu;
+	img[(size_t)26 * nl + 0] = (0u - x) & ((1u << w) - 1u);
 	img[(size_t)26 * nl + 1] = (uint32_t)pbits;
 	img[(size_t)26 * nl + 2] = (big_cmp(big_add(a_img, three), p) == 0) ? 1u : 0u;
 	img[(size_t)26 * nl + 3] = (big_bitlen(a_img) == 0) ? 1u : 0u;
@@ -2362,8 +2370,8 @@ static void xdh_setup(ecamd_curve *cv)
 		big_digits29(P.g_A3, 9, A3);
 		big_digits29(P.g_sm1, 9, big_sqrt_m1(p));
 	} else if (cv->pbits == 448) {
-		big_digits29(P.g_A, 16, A);
-		big_digits29(P.g_A3, 16, A3);
+		big_digits29(P.g_A, 16, A, 28);      // the Goldilocks unit's 28-bit limbs
+		big_digits29(P.g_A3, 16, A3, 28);
 	}
 	P.slot = cv->slot;
 	big_store(cv->xdh_A3, 17, A3);
@@ -2867,10 +2875,10 @@ static void ed448_setup(ecamd_curve *cv)
 	big_store(D.diso, nw, big_mulmod(diso, R, p));
 	big_store(D.alpha, nw, big_mulmod(alpha, R, p));
 	big_store(D.A3, nw, big_mulmod(A3, R, p));
-	big_digits29(D.g_d448, 16, d448);
-	big_digits29(D.g_diso, 16, diso);
-	big_digits29(D.g_alpha, 16, alpha);
-	big_digits29(D.g_A3, 16, A3);
+	big_digits29(D.g_d448, 16, d448, 28);     // the Goldilocks unit's 28-bit limbs
+	big_digits29(D.g_diso, 16, diso, 28);
+	big_digits29(D.g_alpha, 16, alpha, 28);
+	big_digits29(D.g_A3, 16, A3, 28);
 	cv->ed448_state = 1;
 }
 

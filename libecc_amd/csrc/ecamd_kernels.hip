@@ -307,17 +307,26 @@ template <int NW> static __device__ __forceinline__ Fe<NW> digest_to_e(const u8 
 #ifndef ECDSA_PREP_K
 #define ECDSA_PREP_K 8
 #endif
+// k_ecdsa_prep shares its inversion among sixteen items from twelve words on: measured against 8 and 4 at 2^20 signatures
+// (profiles/r3d_variants.md), ECDSA verification secp384r1 14.37 -> 14.55 M/s, secp521r1 10.03 -> 10.33, secp256r1 65.4 -> 65.0
+// (kept at eight there: one lane per sixteen items leaves too few waves at 256 bits)
+#ifdef ECDSA_PREP_K_ALL
+constexpr int ecdsa_prep_items(int) { return ECDSA_PREP_K_ALL; }
+#else
+constexpr int ecdsa_prep_items(int nw) { return nw >= 12 ? 16 : ECDSA_PREP_K; }
+#endif
 template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_prep(EcamdEcdsaPrepArgs A)
 {
+	constexpr int KP = ecdsa_prep_items(NW);
 	const u32 t = blockIdx.x * 64 + threadIdx.x;
-	const u32 first = t * ECDSA_PREP_K;
+	const u32 first = t * KP;
 	if (first >= A.n) {
 		return;
 	}
 	if (A.only != nullptr) {
 		// redo pass: nothing to do unless one of the lane's items is marked
 		bool any = false;
-		for (int k = 0; k < ECDSA_PREP_K; k++) {
+		for (int k = 0; k < KP; k++) {
 			any = any | (first + k < A.n && A.only[first + k] == ECAMD_STATUS_REDO);
 		}
 		if (!any) {
@@ -327,11 +336,11 @@ template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_prep(EcamdEcdsaP
 	const int qs = A.qslot;  // modulus of this slot is q
 	const int qlen = (int)A.qlen, hlen = (int)A.hlen;
 	const Fe<NW> one = fe_const<NW>(ConstTab<NW>::get(qs).one);
-	Fe<NW> pre[ECDSA_PREP_K];  // pre[k] = s_0 ... s_k (Montgomery form)
+	Fe<NW> pre[KP];  // pre[k] = s_0 ... s_k (Montgomery form)
 	u32 okmask = 0;
 	Fe<NW> acc = one;
 #pragma unroll
-	for (int k = 0; k < ECDSA_PREP_K; k++) {
+	for (int k = 0; k < KP; k++) {
 		const u32 i = first + k;
 		if (i < A.n) {
 			const u8 *sig = A.sigs + (size_t)i * 2 * qlen;
@@ -345,7 +354,7 @@ template <int NW> __global__ __launch_bounds__(64) void k_ecdsa_prep(EcamdEcdsaP
 	// (s_0 ... s_last)^-1 = x^(q-2) (q prime): the unique inverse, equal to nn_modinv's (nn/nn_modinv.c:220)
 	Fe<NW> inv = fe_inv<NW>(acc, qs);
 #pragma unroll
-	for (int k = ECDSA_PREP_K - 1; k >= 0; k--) {
+	for (int k = KP - 1; k >= 0; k--) {
 		const u32 i = first + k;
 		if (i >= A.n) {
 			continue;
@@ -1637,7 +1646,8 @@ hipError_t ecamd_launch_ecdsa_prep(int nw, const EcamdEcdsaPrepArgs &a, hipStrea
 	if (a.n == 0) {
 		return hipSuccess;
 	}
-	const uint32_t lanes = (a.n + ECDSA_PREP_K - 1) / ECDSA_PREP_K;
+	const uint32_t kp = (uint32_t)ecdsa_prep_items(nw);
+	const uint32_t lanes = (a.n + kp - 1) / kp;
 	const dim3 grid((lanes + 63) / 64), block(64);
 	switch (nw) {
 #define X(N) case N: hipLaunchKernelGGL(k_ecdsa_prep<N>, grid, block, 0, s, a); break;

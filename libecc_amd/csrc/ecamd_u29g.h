@@ -40,9 +40,6 @@ namespace g29 {
 typedef uint32_t u32;
 typedef uint64_t u64;
 
-constexpr int W = 29;
-constexpr u32 MASK = (1u << W) - 1;
-
 // Reduction flavour of a translation unit: dense Montgomery (any prime), or one of the special cases
 //   -DG29_MERSENNE521  p = 2^521 - 1 (secp521r1), still Montgomery form;
 //   -DG29_P25519       p = 2^255 - 19 (WEI25519 / Ed25519 / X25519): NO Montgomery form (R = 1) and no
@@ -65,13 +62,19 @@ constexpr bool K256 = true;
 #else
 constexpr bool K256 = false;
 #endif
-//   -DG29_P448         p = 2^448 - 2^224 - 1 (WEI448 / Ed448 / X448): plain residues on the usual 16 limbs (16 bits of
-//                      headroom stay); the product is folded with 2^464 = 2^8 2^(29*8) + 2^16 and 2^448 = 2^21 2^(29*7) + 1.
+//   -DG29_P448         p = 2^448 - 2^224 - 1 (WEI448 / Ed448 / X448): plain residues on 16 limbs of TWENTY-EIGHT bits, so that
+//                      2^224 = phi sits on the boundary of limbs 7 | 8 and phi^2 = phi + 1 folds the product inside its
+//                      columns: with a = a0 + a1 phi, b = b0 + b1 phi the product is (a0 b0 + a1 b1) + (a0 b1 + a1 (b0 + b1)) phi,
+//                      256 MADs in 16 column pairs and no second pass (the radix-2^29 form of round 2 needed 304 MADs in
+//                      47 columns: 0.63 of the MAD stream).  No headroom limb: carry() folds the bits from 2^448 up as well,
+//                      every carried value is below 2p, and the bias multiples of a subtraction are 4p and 8p.
 #if defined(G29_P448)
 constexpr bool P448 = true;
 #else
 constexpr bool P448 = false;
 #endif
+constexpr int W = P448 ? 28 : 29;   // limb width of this translation unit
+constexpr u32 MASK = (1u << W) - 1;
 constexpr bool PLAIN9 = P25519 || K256;  // R = 1 on nine limbs, no headroom limb
 constexpr bool PLAIN = PLAIN9 || P448;   // R = 1
 //   -DG29_MPINV1       p = -1 mod 2^29 (secp384r1): the Montgomery quotient digit of a column is its low digit and
@@ -84,7 +87,7 @@ constexpr bool MPINV1 = false;
 #endif
 
 constexpr int nl_for(int pbits) { return (pbits + 16 + W - 1) / W; }
-constexpr int nl_for_flavour(int pbits, int flavour) { return (flavour == 2 || flavour == 4) ? 9 : nl_for(pbits); }
+constexpr int nl_for_flavour(int pbits, int flavour) { return (flavour == 2 || flavour == 4) ? 9 : (flavour == 5 ? 16 : nl_for(pbits)); }
 constexpr u64 cmin(u64 a, u64 b) { return a < b ? a : b; }
 constexpr u64 cmax(u64 a, u64 b) { return a > b ? a : b; }
 // x * 2^e for any sign of e, rounded up
@@ -97,10 +100,10 @@ template <int PB> struct Cfg {
 	static_assert(!P25519 || PB == 255, "the 2^255 - 19 flavour is only for 255-bit fields");
 	static_assert(!K256 || PB == 256, "the secp256k1 flavour is only for 256-bit fields");
 	static_assert(!P448 || PB == 448, "the Goldilocks flavour is only for 448-bit fields");
-	static constexpr int NL = PLAIN9 ? 9 : nl_for(PB);
+	static constexpr int NL = PLAIN9 ? 9 : (P448 ? 16 : nl_for(PB));
 	static constexpr int HEAD = W * NL - PB;           // R / p >= 2^HEAD, HEAD >= 16 (Montgomery flavours)
 	static constexpr int TOPSH = PB - W * (NL - 1);    // p < 2^(29 (NL-1) + TOPSH); may be <= 0
-	static_assert((HEAD >= 16 || PLAIN9) && NL <= 19, "field size not supported");
+	static_assert((HEAD >= 16 || PLAIN9 || P448) && NL <= 19, "field size not supported");
 	// top limb of a non-negative-limb value < vb * p
 	static constexpr u64 top_from_vb(u64 vb) { return shl_ceil(vb, TOPSH) + 1; }
 	// bias multiples are 2^(BIAS_STEP + BIAS_OFF) p: with a (nearly) empty top limb the smallest
@@ -109,14 +112,18 @@ template <int PB> struct Cfg {
 	// va * vb < 2^(2 HEAD - 2) without overflowing u64
 	// (2^255 - 19 flavour: va * vb <= 2^14 keeps the last product limb and the fold quotient in 32 bits)
 	// (secp256k1 flavour: the last product limb is < va vb 2^19, so va * vb <= 2^12)
-	static constexpr int PROD_E = P25519 ? 14 : (K256 ? 12 : ((2 * HEAD - 2) > 62 ? 62 : (2 * HEAD - 2)));
+	// (Goldilocks flavour: the product is folded inside its columns, whatever the operands' values: only limb bounds matter)
+	static constexpr int PROD_E = P25519 ? 14 : (K256 ? 12 : (P448 ? 62 : ((2 * HEAD - 2) > 62 ? 62 : (2 * HEAD - 2))));
 	static constexpr bool prod_ok(u64 va, u64 vb) { return va == 0 || vb <= ((1ull << PROD_E) - (PLAIN9 ? 0 : 1)) / va; }
 };
 
 // the (LOGC, S) combinations the formulas use for "a - b + C p": bias tables for exactly these
 // are precomputed per curve by the host
 constexpr int NBIAS = 16;
-constexpr int BIAS_STEP[NBIAS] = {2, 4, 6, 8, 10, 12, 14, 16, 2, 4, 6, 8, 10, 12, 14, 16};
+// (Goldilocks flavour, no headroom limb: steps of one -- 2p, 4p, 8p are the multiples whose top limb fits 32 bits)
+constexpr int bias_step(int i) { return P448 ? (i % 8) + 1 : 2 * (i % 8) + 2; }
+constexpr int BIAS_STEP[NBIAS] = {bias_step(0), bias_step(1), bias_step(2),  bias_step(3),  bias_step(4),  bias_step(5),  bias_step(6),  bias_step(7),
+				  bias_step(8), bias_step(9), bias_step(10), bias_step(11), bias_step(12), bias_step(13), bias_step(14), bias_step(15)};
 constexpr int BIAS_S[NBIAS] = {1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2};
 // table index of the multiple 2^logc p for a field with bias offset 'off' (logc = step + off)
 constexpr int bias_index(int logc, int s, int off)
@@ -172,14 +179,22 @@ template <class T, class S> G29_FN T weaken(const S &s)
 
 // ---- multiplication ----
 template <int PB> constexpr u64 mul_vb(u64 va, u64 vb) { return PLAIN ? 2 : shl_ceil(va * vb, -Cfg<PB>::HEAD) + 1; }
+constexpr u64 P448_MULX = 1ull << 10;
 template <int PB, u64 VBO> struct MulOut {
 	// 2^255 - 19 flavour: exact low digits, top limb < 2^23 + 2^12 (see mul_raw), value < 2p
 	// secp256k1 flavour: exact low digits, top limb < 2^24 + 2^17, value < 2p
-	typedef E<PB, MASK, P25519 ? ((1ull << 23) + (1ull << 12)) : (K256 ? ((1ull << 24) + (1ull << 17)) : Cfg<PB>::top_from_vb(VBO)), VBO> type;
+	// Goldilocks flavour: limbs 1 and 9 carry the (lazily added) high parts of the two wrap-around carries, see mul_p448
+	typedef E<PB, P448 ? (MASK + P448_MULX) : MASK,
+		  P25519 ? ((1ull << 23) + (1ull << 12)) : (K256 ? ((1ull << 24) + (1ull << 17)) : (P448 ? (u64)MASK : Cfg<PB>::top_from_vb(VBO))), VBO> type;
 };
 template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
 {
 	// NL*la*lb + NL*2^58 + 2^36 < 2^64
+	if (P448) {
+		// Goldilocks flavour: the fullest column (limb 8) sums 38 la lb -- 16 products, those against b0 + b1 counted twice, plus
+		// the shared column S_0 -- and a carry below 2^37
+		return la == 0 || lb <= ((0xFFFFFFFFFFFFFFFFull - (1ull << 40)) / 38) / la;
+	}
 	return la == 0 || lb <= ((0xFFFFFFFFFFFFFFFFull - (u64)NL * (1ull << 58) - (1ull << 36)) / NL) / la;
 }
 
@@ -192,9 +207,16 @@ template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
 	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(acc), "=s"(dead_) : "v"(a), "v"(b)); } while (0)
 #define G29_MUL_VS(acc, a, b) \
 	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(acc), "=s"(dead_) : "v"(a), "s"(b)); } while (0)
-// two dependent MADs in ONE asm statement (hipcc pads every asm statement with an s_nop: one for the pair)
+// "acc += a1; acc += a2 * b2" of a fold (every use has b1 = 1).  The 64-bit addition is ONE instruction on gfx950
+// (v_lshl_add_u64); -DG29_FOLD_MAD makes it a MAD by one instead, paired with the next MAD in one asm statement -- measured
+// 1 % SLOWER on all three plain-residue units (profiles/r3d_variants.md), so the addition stays
+#ifndef G29_FOLD_MAD
+#define G29_MAD2_VS(acc, a1, b1, a2, b2) \
+	do { acc += (a1); G29_MAD_VS(acc, a2, b2); } while (0)
+#else
 #define G29_MAD2_VS(acc, a1, b1, a2, b2) \
 	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0" : "+v"(acc), "=&s"(dead_) : "v"(a1), "s"(b1), "v"(a2), "s"(b2)); } while (0)
+#endif
 #define G29_PIN(acc) asm("" : "+v"(acc))
 #else
 #define G29_MAD2_VS(acc, a1, b1, a2, b2) acc += (u64)(a1) * (b1) + (u64)(a2) * (b2)
@@ -312,6 +334,146 @@ template <int NL, bool SQR, int K_> G29_FN void mul_column(u64 &acc, u32 *m, u32
 	// (no pin needed: the next column starts with an asm statement that takes acc as an operand)
 }
 
+// ---- Goldilocks flavour (p = 2^448 - 2^224 - 1, sixteen 28-bit limbs, phi = 2^224 = 2^(28*8), phi^2 = phi + 1) ----
+// a = a0 + a1 phi, b = b0 + b1 phi:  a b = lo + hi phi with lo = a0 b0 + a1 b1 and hi = a0 b1 + a1 (b0 + b1), two sums of 8 x 8
+// products with columns 0..14; columns 8..14 of lo are multiples of phi, those of hi multiples of phi^2 = phi + 1:
+//     limb j     = lo_j + hi_(j+8)
+//     limb j + 8 = hi_j + lo_(j+8) + hi_(j+8)                    (j = 0..7; column 15 is empty)
+// Per pair j one chain computes S = hi_(j+8) from zero, two more (on the carries of the low and of the high half) the rest, and
+// S is added to both: 32 MADs and two 64-bit additions per pair, 256 MADs in all.  The three chains of a pair go out as two
+// dual-accumulator asm statements (two independent accumulators keep a lone wave issuing, ecamd_madchain.h).
+// Squaring: lo = a0^2 + a1^2 (off-diagonal products once, against the doubled operand), hi = a1 (2 a0 + a1): 136 MADs.
+// The carry out of limb 7 belongs to limb 8, the carry out of limb 15 (multiples of 2^448 = phi + 1) to limbs 0 and 8: both are
+// below 2^37 and are added lazily (low 28 bits to the limb, the rest to the next one), then limbs 0 and 8 give their bit 28 up to
+// limbs 1 and 9: the result has limbs 1 and 9 below 2^28 + 2^10, all others below 2^28, and a value below 2^448 + 2^263 < 2p.
+//
+// two product lists X (accumulator ax) and Y (accumulator ay, starting from zero when ZY) of any lengths, interleaved as long as
+// both last
+template <int NX, int NY, bool ZY> G29_FN void p448_dual(u64 &ax, u64 &ay, const u32 *xx, const u32 *yx, const u32 *xy, const u32 *yy)
+{
+	constexpr int NM = NX < NY ? NX : NY;
+	if constexpr (NM > 0) {
+		u32 x[2 * NM], y[2 * NM];
+#pragma unroll
+		for (int n = 0; n < NM; n++) {
+			x[2 * n] = xx[n];
+			y[2 * n] = yx[n];
+			x[2 * n + 1] = xy[n];
+			y[2 * n + 1] = yy[n];
+		}
+		mad_chain<2 * NM, true, false, ZY>(ax, ay, x, y);
+	} else if constexpr (ZY) {
+		ay = 0;
+	}
+	u64 unused;
+	if constexpr (NX > NM) {
+		mad_chain<NX - NM, false, false>(ax, unused, xx + NM, yx + NM);
+	}
+	if constexpr (NY > NM) {
+		mad_chain<NY - NM, false, false>(ay, unused, xy + NM, yy + NM);
+	}
+}
+
+// column pair J: clo / chi hold the carries of the two halves on entry and on exit; bx = b0 + b1 (SQR: 2 a0 + a1), a2 = 2 a (SQR)
+template <bool SQR, int J> G29_FN void p448_pair(u64 &clo, u64 &chi, u32 *r, const u32 *a, const u32 *b, const u32 *bx, const u32 *a2)
+{
+	// product counts: hiA = lo_(J+8), S = hi_(J+8), hiB = hi_J, lo = lo_J
+	constexpr int NHA = SQR ? 2 * (((J + 8) / 2) - J) : 2 * (7 - J);     // SQR: i = J+1 .. (J+8)/2, both halves
+	constexpr int NS = SQR ? (7 - J) : 2 * (7 - J);
+	constexpr int NHB = SQR ? (J + 1) : 2 * (J + 1);
+	constexpr int NLO = SQR ? 2 * (J / 2 + 1) : 2 * (J + 1);
+	u32 xha[NHA + 1], yha[NHA + 1], xs[NS + 1], ys[NS + 1], xhb[NHB], yhb[NHB], xlo[NLO], ylo[NLO];
+	if constexpr (!SQR) {
+#pragma unroll
+		for (int i = J + 1; i < 8; i++) {
+			const int k = J + 8 - i, n = 2 * (i - J - 1);
+			xha[n] = a[i];      yha[n] = b[k];              // a0 b0
+			xha[n + 1] = a[8 + i]; yha[n + 1] = b[8 + k];   // a1 b1
+			xs[n] = a[i];       ys[n] = b[8 + k];           // a0 b1
+			xs[n + 1] = a[8 + i];  ys[n + 1] = bx[k];       // a1 (b0 + b1)
+		}
+#pragma unroll
+		for (int i = 0; i <= J; i++) {
+			const int k = J - i;
+			xhb[2 * i] = a[i];         yhb[2 * i] = b[8 + k];
+			xhb[2 * i + 1] = a[8 + i]; yhb[2 * i + 1] = bx[k];
+			xlo[2 * i] = a[i];         ylo[2 * i] = b[k];
+			xlo[2 * i + 1] = a[8 + i]; ylo[2 * i + 1] = b[8 + k];
+		}
+	} else {
+#pragma unroll
+		for (int i = J + 1; 2 * i <= J + 8; i++) {
+			const int k = J + 8 - i, n = 2 * (i - J - 1);
+			xha[n] = a[i];         yha[n] = (i < k) ? a2[k] : a[i];
+			xha[n + 1] = a[8 + i]; yha[n + 1] = (i < k) ? a2[8 + k] : a[8 + i];
+		}
+#pragma unroll
+		for (int i = J + 1; i < 8; i++) {
+			xs[i - J - 1] = a[8 + i];
+			ys[i - J - 1] = bx[J + 8 - i];
+		}
+#pragma unroll
+		for (int i = 0; i <= J; i++) {
+			xhb[i] = a[8 + i];
+			yhb[i] = bx[J - i];
+		}
+#pragma unroll
+		for (int i = 0; 2 * i <= J; i++) {
+			const int k = J - i;
+			xlo[2 * i] = a[i];         ylo[2 * i] = (i < k) ? a2[k] : a[i];
+			xlo[2 * i + 1] = a[8 + i]; ylo[2 * i + 1] = (i < k) ? a2[8 + k] : a[8 + i];
+		}
+	}
+	if constexpr (NS > 0) {
+		u64 s;
+		p448_dual<NHA, NS, true>(chi, s, xha, yha, xs, ys);
+		p448_dual<NHB, NLO, false>(chi, clo, xhb, yhb, xlo, ylo);
+		clo += s;
+		chi += s;
+	} else {
+		p448_dual<NHB, NLO, false>(chi, clo, xhb, yhb, xlo, ylo);
+	}
+	r[J] = (u32)clo & MASK;
+	clo >>= W;
+	r[8 + J] = (u32)chi & MASK;
+	chi >>= W;
+}
+
+template <bool SQR, int... Js> G29_FN void p448_pairs(u64 &clo, u64 &chi, u32 *r, const u32 *a, const u32 *b, const u32 *bx, const u32 *a2,
+						      std::integer_sequence<int, Js...>)
+{
+	(p448_pair<SQR, Js>(clo, chi, r, a, b, bx, a2), ...);
+}
+
+template <bool SQR> G29_FN void mul_p448(u32 *r, const u32 *a, const u32 *b)
+{
+	u32 bx[8], a2[16];
+	if constexpr (SQR) {
+#pragma unroll
+		for (int i = 0; i < 16; i++) {
+			a2[i] = a[i] << 1;
+		}
+#pragma unroll
+		for (int i = 0; i < 8; i++) {
+			bx[i] = a2[i] + a[8 + i];
+		}
+	} else {
+#pragma unroll
+		for (int i = 0; i < 8; i++) {
+			bx[i] = b[i] + b[8 + i];
+		}
+	}
+	u64 clo = 0, chi = 0;
+	p448_pairs<SQR>(clo, chi, r, a, b, bx, a2, std::make_integer_sequence<int, 8>());
+	// clo: the carry out of limb 7, chi: out of limb 15 (both < 2^37)
+	const u32 l7 = (u32)clo & MASK, h7 = (u32)(clo >> W), l15 = (u32)chi & MASK, h15 = (u32)(chi >> W);
+	const u32 r0 = r[0] + l15, r8 = r[8] + l7 + l15;
+	r[0] = r0 & MASK;
+	r[1] += h15 + (r0 >> W);
+	r[8] = r8 & MASK;
+	r[9] += h7 + h15 + (r8 >> W);
+}
+
 template <int NL, bool SQR, int... Ks>
 G29_FN void mul_columns(u64 &acc, u32 *m, u32 *r, u32 *t, const u32 *a, const u32 *b, const u32 *a2, const u32 *p, u32 mpinv,
 			u32 q17v, std::integer_sequence<int, Ks...>)
@@ -324,6 +486,11 @@ G29_FN void mul_columns(u64 &acc, u32 *m, u32 *r, u32 *t, const u32 *a, const u3
 template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 *b, const u32 *p, u32 mpinv)
 {
 	static_assert(!MERSENNE521 || NL == 19, "the Mersenne flavour is only for secp521r1");
+	if constexpr (P448) {
+		static_assert(NL == 16, "Goldilocks flavour: 16 limbs");
+		mul_p448<SQR>(r, a, b);
+		return;
+	}
 	u32 m[NL], a2[NL], t[2 * NL];
 	if (SQR) {
 #pragma unroll
@@ -347,8 +514,7 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 		t[2 * NL - 1] = (u32)acc;  // < va vb 2^17 <= 2^31 (Cfg::prod_ok)
 		u32 f = 1216u, one1 = 1u;
 #if defined(__HIPCC__)
-		asm volatile("" : "+s"(f), "+s"(one1));  // keep the folds MADs (one1: "acc += t[j]" as ONE MAD, 4.85 cycles, instead of
-		                                          // v_add_co_u32 + v_addc_co_u32, 9.4 -- profiles/r3a_effective_clock.md)
+		asm volatile("" : "+s"(f), "+s"(one1));  // keep the folds MADs (one1 only matters under -DG29_FOLD_MAD, see G29_MAD2_VS)
 #endif
 		// limb 8 without the carry from below: its bits from 23 up are multiples of 2^255 = 19
 		u64 top = t[NL - 1];
@@ -362,60 +528,6 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 			G29_PIN(acc);
 		}
 		r[NL - 1] = ((u32)top & ((1u << 23) - 1)) + (u32)acc;  // carry in < 2^12
-	} else if constexpr (P448) {
-		// r = a b mod p, p = 2^448 - 2^224 - 1, value < 2p.  32 product limbs t; modulo p
-		//   2^464 = 2^8 2^(29*8) + 2^16:  t[16 + j] goes to limb j (x 2^16) and limb j + 8 (x 2^8); for j >= 8 the second
-		//   target is limb 16 + i (i = j - 8) again, i.e. limb i (x 2^24 in all) and limb i + 8 (x 2^16 more):
-		//     limb i     (0..7):  t[i]     + 2^16 t[16 + i] + 2^24 t[24 + i]
-		//     limb i + 8 (8..15): t[i + 8] + 2^8  t[16 + i] + 2^17 t[24 + i]
-		//   then the bits of limb 15 from 2^13 up (q, multiples of 2^448 = 2^21 2^(29*7) + 1) go to limbs 7 and 0 in a
-		//   second, MAD-free carry pass.
-		static_assert(NL == 16, "Goldilocks flavour: 16 limbs");
-		t[2 * NL - 1] = (u32)acc;  // < va vb / 8 (Cfg::prod_ok: < 2^27)
-		u32 c16 = 1u << 16, c24 = 1u << 24, c8 = 1u << 8, c17 = 1u << 17, one1 = 1u;
-#if defined(__HIPCC__)
-		asm volatile("" : "+s"(c16), "+s"(c24), "+s"(c8), "+s"(c17), "+s"(one1));  // keep the folds MADs ("+= t[i]" as one MAD too)
-#endif
-		acc = 0;
-#pragma unroll
-		for (int i = 0; i < 8; i++) {
-			G29_MAD2_VS(acc, t[i], one1, t[16 + i], c16);
-			G29_MAD_VS(acc, t[24 + i], c24);
-			r[i] = (u32)acc & MASK;
-			acc >>= W;
-			G29_PIN(acc);
-		}
-#pragma unroll
-		for (int i = 0; i < 7; i++) {
-			G29_MAD2_VS(acc, t[i + 8], one1, t[16 + i], c8);
-			G29_MAD_VS(acc, t[24 + i], c17);
-			r[i + 8] = (u32)acc & MASK;
-			acc >>= W;
-			G29_PIN(acc);
-		}
-		G29_MAD2_VS(acc, t[15], one1, t[23], c8);
-		G29_MAD_VS(acc, t[31], c17);               // < 2^29 + 2^37 + 2^44 + 2^25
-		const u32 q = (u32)(acc >> 13);           // < 2^32
-		const u32 top = (u32)acc & ((1u << 13) - 1);
-		u64 c = (u64)r[0] + q;
-		r[0] = (u32)c & MASK;
-		u32 cy = (u32)(c >> W);
-#pragma unroll
-		for (int i = 1; i < 7; i++) {
-			const u32 x = r[i] + cy;
-			r[i] = x & MASK;
-			cy = x >> W;
-		}
-		c = (u64)r[7] + cy + ((u64)q << 21);
-		r[7] = (u32)c & MASK;
-		cy = (u32)(c >> W);                        // < 2^25
-#pragma unroll
-		for (int i = 8; i < NL - 1; i++) {
-			const u32 x = r[i] + cy;
-			r[i] = x & MASK;
-			cy = x >> W;
-		}
-		r[NL - 1] = top + cy;                      // <= 2^13
 	} else if constexpr (K256) {
 		// r = a b mod p, p = 2^256 - c, c = 2^32 + 977, value < 2p.  18 product limbs t; modulo p
 		//   2^261 = 32 c = 2^8 2^29 + 31264:          t[j + 9] goes to limb j (x 31264) and limb j + 1 (x 256), j = 0..7
@@ -425,7 +537,7 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 		t[2 * NL - 1] = (u32)acc;  // < va vb 2^19 <= 2^31 (Cfg::prod_ok)
 		u32 f = 31264u, g = 256u, f17 = 8003584u, g17 = 65536u, fq = 977u, one1 = 1u, eight = 8u;
 #if defined(__HIPCC__)
-		asm volatile("" : "+s"(f), "+s"(g), "+s"(f17), "+s"(g17), "+s"(fq), "+s"(one1), "+s"(eight));  // keep the folds MADs ("+= t[j]" as one MAD too)
+		asm volatile("" : "+s"(f), "+s"(g), "+s"(f17), "+s"(g17), "+s"(fq), "+s"(one1), "+s"(eight));  // keep the folds MADs
 #endif
 		// limb 8 without the carry from below: < 2^29 + 2^37 + 2^46
 		u64 top = t[NL - 1];
@@ -610,27 +722,45 @@ template <int PB, int S> constexpr int pick_logc(u64 lb_b, u64 tb_b)
 template <int S, class A, class B, int NLc> G29_FN auto sub_auto(const A &a, const B &b, const CurveG<NLc> &K)
 {
 	constexpr int logc = pick_logc<A::C::PBITS, S>(B::LB, B::TB);
-	static_assert(logc >= 0, "sub_auto: no tabulated bias dominates b (carry it first?)");
-	return sub<logc, S>(a, b, K);
+	if constexpr (logc < 0 && S == 1 && P448) {
+		// Goldilocks flavour: a product's limbs 1 and 9 are a little over 28 bits, so its double is a little over 2^29
+		return sub_auto<2>(a, b, K);
+	} else {
+		static_assert(logc >= 0, "sub_auto: no tabulated bias dominates b (carry it first?)");
+		return sub<logc, S>(a, b, K);
+	}
 }
 
-template <class A> G29_FN E<A::C::PBITS, MASK + (A::LB >> W), A::TB + (A::LB >> W), A::VB> carry(const A &a)
+// One step of limb carries.  The integer value is kept, except in the Goldilocks flavour (no headroom limb): there the top
+// limb gives its bits from 28 up -- multiples of 2^448 = 2^224 + 1 (mod p) -- to limbs 0 and 8, so that the result is the same
+// residue with every limb near 28 bits and a value below 2p.
+template <class A> struct CarryT {
+	static constexpr u64 LBO = MASK + (A::LB >> W) + (P448 ? (A::TB >> W) : 0);
+	static constexpr u64 TBO = P448 ? (MASK + (A::LB >> W)) : (A::TB + (A::LB >> W));
+	static_assert(!P448 || LBO - MASK < (1ull << 20), "carry: limbs too loose for the value bound 2p");
+	typedef E<A::C::PBITS, LBO, TBO, P448 ? 2 : A::VB> type;
+};
+template <class A> G29_FN typename CarryT<A>::type carry(const A &a)
 {
 	constexpr int NL = A::C::NL;
-	E<A::C::PBITS, MASK + (A::LB >> W), A::TB + (A::LB >> W), A::VB> r;
+	typename CarryT<A>::type r;
 	r.l[0] = a.l[0] & MASK;
 #pragma unroll
 	for (int i = 1; i < NL - 1; i++) {
 		r.l[i] = (a.l[i] & MASK) + (a.l[i - 1] >> W);
 	}
-	r.l[NL - 1] = a.l[NL - 1] + (a.l[NL - 2] >> W);
+	if constexpr (P448) {
+		const u32 t = a.l[NL - 1] >> W;
+		r.l[NL - 1] = (a.l[NL - 1] & MASK) + (a.l[NL - 2] >> W);
+		r.l[0] += t;
+		r.l[NL / 2] += t;
+	} else {
+		r.l[NL - 1] = a.l[NL - 1] + (a.l[NL - 2] >> W);
+	}
 	return r;
 }
 
 // ---- multiplication with the carries the operand bounds require (decided at compile time) ----
-template <class A> struct CarryT {
-	typedef E<A::C::PBITS, MASK + (A::LB >> W), A::TB + (A::LB >> W), A::VB> type;
-};
 template <class A, class B, int NLc> G29_FN auto mulc(const A &a, const B &b, const CurveG<NLc> &K)
 {
 	constexpr int NL = A::C::NL;
@@ -663,10 +793,27 @@ template <class A, int NLc> G29_FN auto sqrc(const A &a, const CurveG<NLc> &K)
 template <class A, int NLc> G29_FN void canonical_digits(u32 *d, const A &a, const CurveG<NLc> &K)
 {
 	constexpr int NL = A::C::NL;
-	static_assert(A::LB == MASK && A::VB <= 3, "canonical_digits needs a multiplication result < 3p");
+	static_assert((A::LB == MASK || (P448 && A::LB <= MASK + P448_MULX)) && A::VB <= 3, "canonical_digits needs a multiplication result < 3p");
 #pragma unroll
 	for (int i = 0; i < NL; i++) {
 		d[i] = a.l[i];
+	}
+	if constexpr (P448) {
+		// limbs 1 and 9 are lazy and the value may reach 2^448 and a little more: exact carries with the bits from 2^448 up folded
+		// to limbs 0 and 8, twice (after the first round limbs 0 and 8 exceed 28 bits by at most the folded amount; the second
+		// round can only fold when everything below is nearly zero), then the value is below 2^448 < 2p
+#pragma unroll
+		for (int round = 0; round < 2; round++) {
+			u32 c = 0;
+#pragma unroll
+			for (int i = 0; i < NL; i++) {
+				const u32 x = d[i] + c;
+				d[i] = x & MASK;
+				c = x >> W;
+			}
+			d[0] += c;
+			d[NL / 2] += c;
+		}
 	}
 #pragma unroll
 	for (int rep = 0; rep + 1 < (int)A::VB; rep++) {
@@ -707,7 +854,7 @@ template <int PB, int NW> G29_FN E<PB, MASK, MASK, 1> from_words(const u32 *w)
 	for (int i = 0; i < NL; i++) {
 		const int bit = W * i, wi = bit >> 5, sh = bit & 31;
 		u32 x = (wi < NW) ? (w[wi] >> sh) : 0u;
-		if (sh > 3 && wi + 1 < NW) {
+		if (sh > 32 - W && wi + 1 < NW) {
 			x |= w[wi + 1] << (32 - sh);
 		}
 		r.l[i] = x & MASK;

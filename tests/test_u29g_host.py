@@ -50,8 +50,8 @@ def lib_p25519():
     return C.CDLL(so)
 
 
-def val(l):
-    return sum(int(v) << (W * i) for i, v in enumerate(l))
+def val(l, w=W):
+    return sum(int(v) << (w * i) for i, v in enumerate(l))
 
 
 def arr(l):
@@ -65,31 +65,43 @@ class Field:
         self.p, self.a, self.b = c["p"], c["a"], c["b"]
         self.pb = self.p.bit_length()
         img, self.nl = G.image(self.p, self.a, self.b, flavour)
+        self.W = G.width(flavour)          # 28 on the Goldilocks unit, 29 everywhere else
+        self.MASK = (1 << self.W) - 1
         self.k = arr(img)
         self.lib = lib
         info = (C.c_uint32 * 8)()
         getattr(lib, f"g_info_{self.pb}")(info)
         assert info[0] == self.nl and info[5] == 4 * len(img), (list(info), len(img))
         self.head, self.va, self.fa_lb, self.fa_tb = info[1], info[4], info[6], info[7]
-        self.R = 1 if flavour in (2, 4, 5) else 1 << (W * self.nl)
+        self.R = 1 if flavour in (2, 4, 5) else 1 << (self.W * self.nl)
         self.Rinv = pow(self.R, self.p - 2, self.p)
 
     def fn(self, name):
         return getattr(self.lib, f"g_{name}_{self.pb}")
 
+    def val(self, l):
+        return val(l, self.W)
+
+    def digits(self, v):
+        return G.digits(v, self.nl, self.W)
+
+    def vmax(self, vb, tb):
+        """largest multiple of p a class (value bound vb, top limb bound tb) can hold"""
+        return min(vb, ((tb - 1) << (self.W * (self.nl - 1))) // self.p)
+
     def loose(self, rng, v, lb, tb):
-        l = G.digits(v, self.nl)
+        l = self.digits(v)
         for i in range(self.nl - 1):
-            room = (lb - l[i]) >> W
+            room = (lb - l[i]) >> self.W
             k = min(room, l[i + 1], int(rng.integers(0, 8)))
-            l[i] += k << W
+            l[i] += k << self.W
             l[i + 1] -= k
-        assert val(l) == v and max(l[:-1]) <= lb and l[-1] <= tb, (l, lb, tb)
+        assert self.val(l) == v and max(l[:-1]) <= lb and l[-1] <= tb, (l, lb, tb)
         return l
 
     def fa(self, rng, residue, mult=None):
         """an FA-class representation of `residue` mod p: value residue + mult*p, loose limbs"""
-        vmax = min(self.va, ((self.fa_tb - 1) << (W * (self.nl - 1))) // self.p)
+        vmax = self.vmax(self.va, self.fa_tb)
         mult = int(rng.integers(0, max(1, vmax - 1))) if mult is None else mult
         return self.loose(rng, residue % self.p + mult * self.p, self.fa_lb, self.fa_tb)
 
@@ -109,24 +121,43 @@ def test_field_ops(lib, curve, flavour=0):
         y = int.from_bytes(rng.bytes(80), "big") % p
         lx, ly = f.fa(rng, x), f.fa(rng, y)
         if it == 0:  # extreme: largest value the class allows, every low limb at its bound
-            vmax = min(f.va, ((f.fa_tb - 1) << (W * (f.nl - 1))) // p) - 1
+            vmax = max(0, f.vmax(f.va, f.fa_tb) - 1)
             lx = f.fa(rng, x, vmax)
             ly = f.fa(rng, y, vmax)
+        if it == 1 and flavour == 5:   # every limb at the class bound (the value is then what it is: only the residue matters)
+            lx = [f.fa_lb] * (f.nl - 1) + [f.fa_tb]
+            ly = [f.fa_lb] * (f.nl - 1) + [f.fa_tb]
+            x, y = f.val(lx) % p, f.val(ly) % p
         out = (C.c_uint32 * f.nl)()
         f.fn("mul")(f.k, arr(lx), arr(ly), out, 0)
-        assert val(out) % p == val(lx) * val(ly) * f.Rinv % p
-        assert val(out) < 2 * p + (val(lx) * val(ly) >> (W * f.nl)) and max(list(out)[:-1]) <= MASK
+        assert f.val(out) % p == f.val(lx) * f.val(ly) * f.Rinv % p
+        # exact low digits -- on the Goldilocks unit limbs 1 and 9 keep the high parts of the two wrap-around carries (< 2^10)
+        slack = [(1 << 10) if (flavour == 5 and i in (1, 9)) else 0 for i in range(f.nl)]
+        assert f.val(out) < 2 * p + (f.val(lx) * f.val(ly) >> (f.W * f.nl) if flavour != 5 else 0)
+        assert all(v <= f.MASK + sl for v, sl in zip(list(out)[:-1], slack))
         f.fn("mul")(f.k, arr(lx), arr(lx), out, 1)
-        assert val(out) % p == val(lx) ** 2 * f.Rinv % p
+        assert f.val(out) % p == f.val(lx) ** 2 * f.Rinv % p
+        assert all(v <= f.MASK + sl for v, sl in zip(list(out)[:-1], slack)) and (flavour != 5 or f.val(out) < 2 * p)
     # canonical digits, negation, inversion
     for v in (0, 1, p - 1, p, p + 1, 2 * p - 1, int.from_bytes(rng.bytes(80), "big") % (2 * p)):
-        d, _ = f.call("canon", G.digits(v, f.nl))
-        assert val(d) == v % p and max(d[:-1]) <= MASK
-        n, _ = f.call("neg", G.digits(v, f.nl))
-        assert (val(n) + v) % p == 0 and max(n[:-1]) <= f.fa_lb and n[-1] <= f.fa_tb
+        d, _ = f.call("canon", f.digits(v))
+        assert f.val(d) == v % p and max(d[:-1]) <= f.MASK
+        n, _ = f.call("neg", f.digits(v))
+        assert (f.val(n) + v) % p == 0 and max(n[:-1]) <= f.fa_lb and n[-1] <= f.fa_tb
+    if flavour == 5:
+        # lazy representatives of a multiplication result: limbs 1 and 9 over 28 bits, values around 2^448
+        for v in (2**448 - 1, 2**448, 2**448 + 2**224, 2 * p - 1, p + 2**224 + 1):
+            l = f.digits(v)
+            for i in (1, 9):
+                k = min(l[i + 1], 3)
+                l[i] += k << f.W
+                l[i + 1] -= k
+            if max(l) <= f.MASK + (1 << 10):
+                d, _ = f.call("canon", l)
+                assert f.val(d) == v % p and max(d) <= f.MASK, hex(v)
     x = int.from_bytes(rng.bytes(80), "big") % p or 1
-    iv, _ = f.call("inv", G.digits(x * f.R % p, f.nl))
-    assert val(iv) % p == pow(x, p - 2, p) * f.R % p
+    iv, _ = f.call("inv", f.digits(x * f.R % p))
+    assert f.val(iv) % p == pow(x, p - 2, p) * f.R % p
 
 
 def aff_add(P, Q, a, p):
@@ -159,7 +190,7 @@ def test_jacobian(lib, curve, flavour=0):
 
     def aff(l):
         nl = f.nl
-        X, Y, Z = (val(l[0:nl]) * f.Rinv % p, val(l[nl:2 * nl]) * f.Rinv % p, val(l[2 * nl:3 * nl]) * f.Rinv % p)
+        X, Y, Z = (f.val(l[0:nl]) * f.Rinv % p, f.val(l[nl:2 * nl]) * f.Rinv % p, f.val(l[2 * nl:3 * nl]) * f.Rinv % p)
         if Z == 0:
             return None
         zi = pow(Z, p - 2, p)
@@ -169,7 +200,7 @@ def test_jacobian(lib, curve, flavour=0):
         nl = f.nl
         for k in range(3):
             part = l[k * nl:(k + 1) * nl]
-            assert max(part[:-1]) <= f.fa_lb and part[-1] <= f.fa_tb and val(part) < f.va * p
+            assert max(part[:-1]) <= f.fa_lb and part[-1] <= f.fa_tb and f.val(part) < f.va * p
 
     P = G0
     Q = aff_add(G0, G0, a, p)
@@ -194,7 +225,7 @@ def test_jacobian(lib, curve, flavour=0):
         vt, ft_lb, ft_tb = it3[0], it3[1], it3[2]
 
         def ft(residue):
-            vmax = min(vt, ((ft_tb - 1) << (W * (f.nl - 1))) // p)
+            vmax = f.vmax(vt, ft_tb)
             mult = int(rng.integers(0, max(1, vmax - 1)))
             return f.loose(rng, residue % p + mult * p, ft_lb, ft_tb)
 
@@ -205,7 +236,7 @@ def test_jacobian(lib, curve, flavour=0):
         def in_class_t(l):
             for k in range(3):
                 part = l[k * f.nl:(k + 1) * f.nl]
-                assert max(part[:-1]) <= ft_lb and part[-1] <= ft_tb and val(part) < vt * p
+                assert max(part[:-1]) <= ft_lb and part[-1] <= ft_tb and f.val(part) < vt * p
 
         def affine_fa(P):
             return f.fa(rng, P[0] * f.R % p) + f.fa(rng, P[1] * f.R % p)

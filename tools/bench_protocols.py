@@ -5,7 +5,7 @@ X25519).  Same launch contract and JSON line as bench.py (one process per GPU un
 torch.distributed.run, weak scaling, contiguous shards, one RCCL all-gather of the per-rank result
 bytes per step); not the driver's headline bench.
 
-    python tools/bench_protocols.py --workload ecdsa_verify|ecdsa_sign|ecccdh|ed25519_verify|ed448_verify|x25519 [--gpus N --steps K --warmup W]
+    python tools/bench_protocols.py --workload ecdsa_verify|ecdsa_sign|ecccdh|ed25519_verify|ed448_verify|x25519|x448 [--gpus N --steps K --warmup W]
 """
 import argparse
 import hashlib
@@ -28,7 +28,7 @@ SEED = 0x5EC9256
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", required=True, choices=["ecdsa_verify", "ecdsa_sign", "ecccdh", "ed25519_verify", "ed448_verify", "x25519"])
+    ap.add_argument("--workload", required=True, choices=["ecdsa_verify", "ecdsa_sign", "ecccdh", "ed25519_verify", "ed448_verify", "x25519", "x448"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
@@ -219,12 +219,14 @@ def main():
                                   b"".join(hram[114 * i:114 * i + 114] for i in idx))
         metric, unit, cfg = "Ed448 verifications/sec (batch=2^%d, %d distinct signatures tiled)" % (a.batch_log2, m), "verifications/s", "4], Ed448 counterpart [not in BASELINE"
     else:
-        cv = ctx.curve("WEI25519")
-        k1, k2 = rb(32 * B), rb(32 * B)
-        pub, st = cv.xdh(k1, (9).to_bytes(32, "little") * B)   # peers' public keys: u on the curve
+        x448 = a.workload == "x448"
+        xw, xcurve = (56, "WEI448") if x448 else (32, "WEI25519")
+        cv = ctx.curve(xcurve)
+        k1, k2 = rb(xw * B), rb(xw * B)
+        pub, st = cv.xdh(k1, (5 if x448 else 9).to_bytes(xw, "little") * B)   # peers' public keys: u on the curve
         assert set(st) == {0}
         ins = [t(k2), t(pub)]
-        d_out = torch.empty(32 * B, dtype=torch.uint8, device=dev)
+        d_out = torch.empty(xw * B, dtype=torch.uint8, device=dev)
         d_res = torch.empty(B, dtype=torch.uint8, device=dev)
 
         def step():
@@ -232,16 +234,22 @@ def main():
         expected = bytes(B)
 
         def oracle_subset(idx):
-            o = O.Oracle("WEI25519")
-            return o.xdh(b"".join(k2[32 * i:32 * i + 32] for i in idx), b"".join(pub[32 * i:32 * i + 32] for i in idx))
-        out_w = 32
+            o = O.Oracle(xcurve)
+            return o.xdh(b"".join(k2[xw * i:xw * i + xw] for i in idx), b"".join(pub[xw * i:xw * i + xw] for i in idx))
+        out_w = xw
 
         def ref_subset(idx):
-            sk, su = (b"".join(x[32 * i:32 * i + 32] for i in idx) for x in (k2, pub))
-            return O.join_slices(O.in_slices(lambda lo, hi: O.ref_xdh(32, sk[32 * lo:32 * hi], su[32 * lo:32 * hi]), len(idx)))
-        # dominant kernel k_x25519_ladder: 255 steps of 6 multiplications (one of them by a24, run as a full product) and 4 squarings
-        work = {"kernel": "k_x25519_ladder", "mads_per_item": 255 * (6 * 92 + 4 * 56) + 92, "sgpr_mads_per_item": 255 * 10 * 11}
-        metric, unit, cfg = "X25519 shared secrets/sec (batch=2^%d)" % a.batch_log2, "shared-secrets/s", 4
+            sk, su = (b"".join(x[xw * i:xw * i + xw] for i in idx) for x in (k2, pub))
+            return O.join_slices(O.in_slices(lambda lo, hi: O.ref_xdh(xw, sk[xw * lo:xw * hi], su[xw * lo:xw * hi]), len(idx)))
+        if x448:
+            # dominant kernel k_x448_ladder: 448 steps of 6 multiplications (one by a24, a full product) and 4 squarings on the
+            # Goldilocks unit (16 limbs of 28 bits: M = 256, S = 136 MADs, no constant multipliers)
+            work = {"kernel": "k_x448_ladder", "mads_per_item": 448 * (6 * 256 + 4 * 136) + 256, "sgpr_mads_per_item": 0}
+            metric, unit, cfg = "X448 shared secrets/sec (batch=2^%d)" % a.batch_log2, "shared-secrets/s", "5], X448 counterpart [not in BASELINE"
+        else:
+            # dominant kernel k_x25519_ladder: 255 steps of 6 multiplications (one of them by a24, run as a full product) and 4 squarings
+            work = {"kernel": "k_x25519_ladder", "mads_per_item": 255 * (6 * 92 + 4 * 56) + 92, "sgpr_mads_per_item": 255 * 10 * 11}
+            metric, unit, cfg = "X25519 shared secrets/sec (batch=2^%d)" % a.batch_log2, "shared-secrets/s", 4
     gathered = torch.empty(world * B, dtype=torch.uint8, device=dev) if world > 1 else None
 
     def full_step():
@@ -257,7 +265,7 @@ def main():
         raise SystemExit("PARITY FAILURE: accept/reject bits differ from the construction of the batch")
     idx = [int(i) for i in np.random.default_rng(1).choice(B, size=128, replace=False)]
     exp = oracle_subset(idx)
-    payload = a.workload in ("x25519", "ecdsa_sign", "ecccdh")
+    payload = a.workload in ("x25519", "x448", "ecdsa_sign", "ecccdh")
     if payload:
         out = d_out.cpu().numpy().tobytes()
         got = (b"".join(out[out_w * i:out_w * i + out_w] for i in idx), bytes(res[i] for i in idx))
@@ -326,6 +334,8 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline and O.have_ref():
         # the unmodified reference on this host, one thread, on a bounded sample of the same inputs
         m = 1536 if a.workload != "x25519" else 3072
+        if a.workload == "x448":
+            m = 512
         t0 = time.time()
         if a.workload == "ecdsa_verify":
             # ec_verify hashes the message itself: time it on messages of the digest's length (SHA-256 of 32 bytes
@@ -346,8 +356,8 @@ def main():
             O.ref_ed448_verify(pubs[:57 * m], sigs[:114 * m], hram[:114 * m], 114)
             what = "eddsa_import_pub_key + ec_verify (EDDSA448, SHAKE256 over 114-byte messages)"
         else:
-            O.ref_xdh(32, k2[:32 * m], pub[:32 * m])
-            what = "x25519()"
+            O.ref_xdh(xw, k2[:xw * m], pub[:xw * m])
+            what = "x448()" if x448 else "x25519()"
         el = time.time() - t0
         cpu = {"value": m / el, "unit": unit, "cores": 1, "kind": "reference",
                "sample": f"first {m} items of the same batch through {what} of the unmodified reference (oracle/_ref), "

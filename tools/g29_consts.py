@@ -12,41 +12,55 @@ def nl_for(pbits):
     return (pbits + 16 + W - 1) // W
 
 
-def digits(x, nl):
-    d = [(x >> (W * i)) & MASK for i in range(nl - 1)]
-    d.append(x >> (W * (nl - 1)))
+def width(flavour):
+    """limb width of a flavour: the Goldilocks unit (5) runs on 28-bit limbs (2^224 on a limb boundary), all others on 29"""
+    return 28 if flavour == 5 else W
+
+
+def bias_steps(flavour):
+    return ([1, 2, 3, 4, 5, 6, 7, 8] if flavour == 5 else [2, 4, 6, 8, 10, 12, 14, 16]) * 2
+
+
+def digits(x, nl, w=W):
+    d = [(x >> (w * i)) & ((1 << w) - 1) for i in range(nl - 1)]
+    d.append(x >> (w * (nl - 1)))
     return d
 
 
 def image(p, a, b, flavour=0):
     """flavour 0: dense Montgomery (also what the secp521r1 flavour uses); 2: p = 2^255 - 19, nine limbs
-    and plain residues (R = 1); 4: p = 2^256 - 2^32 - 977 (secp256k1), the same shape; 5: p = 2^448 - 2^224 - 1, plain residues on the usual 16 limbs"""
+    and plain residues (R = 1); 4: p = 2^256 - 2^32 - 977 (secp256k1), the same shape; 5: p = 2^448 - 2^224 - 1, plain residues on 16 limbs
+    of 28 bits"""
     pbits = p.bit_length()
     plain = flavour in (2, 4, 5)
-    nl = 9 if flavour in (2, 4) else nl_for(pbits)
-    R = 1 if plain else 1 << (W * nl)
-    topsh = pbits - W * (nl - 1)
+    w = width(flavour)
+    nl = 9 if flavour in (2, 4) else (16 if flavour == 5 else nl_for(pbits))
+    R = 1 if plain else 1 << (w * nl)
+    topsh = pbits - w * (nl - 1)
     off = max(0, 1 - topsh)
     out = []
-    out += digits(p, nl)
-    out += digits(R * R % p, nl)
-    out += digits(R % p, nl)
-    out += digits(a * R % p, nl)
-    out += digits(b * R % p, nl)
-    out += digits(p - 2, nl)
-    for step, s in zip(BIAS_STEP, BIAS_S):
+    out += digits(p, nl, w)
+    out += digits(R * R % p, nl, w)
+    out += digits(R % p, nl, w)
+    out += digits(a * R % p, nl, w)
+    out += digits(b * R % p, nl, w)
+    out += digits(p - 2, nl, w)
+    for step, s in zip(bias_steps(flavour), BIAS_S):
         c = p << (step + off)
-        if c.bit_length() > W * (nl - 1) + 32:
+        if c.bit_length() > w * (nl - 1) + 32:
             out += [0] * nl   # does not fit the limbs (only without a headroom limb); never selected
             continue
-        d = digits(c, nl)
-        M, BW = 1 << (W + s), 1 << s
+        d = digits(c, nl, w)
+        M, BW = 1 << (w + s), 1 << s
         l = [d[0] + M] + [d[j] + M - BW for j in range(1, nl - 1)] + [d[nl - 1] - BW]
-        assert l[-1] >= 0 and sum(v << (W * j) for j, v in enumerate(l)) == c
+        if l[-1] < 0:
+            out += [0] * nl   # the top digit cannot lend the borrow (2p on the Goldilocks unit with S = 2); never selected
+            continue
+        assert sum(v << (w * j) for j, v in enumerate(l)) == c
         assert all(v < 2**32 for v in l)
         out += l
     # coordinate import / export factors (no isomorphism here: R^2, R^2, 1, 1)
-    out += digits(R * R % p, nl) * 2 + digits(1, nl) * 2
-    mpinv = (-pow(p, -1, 1 << W)) % (1 << W)
+    out += digits(R * R % p, nl, w) * 2 + digits(1, nl, w) * 2
+    mpinv = (-pow(p, -1, 1 << w)) % (1 << w)
     out += [mpinv, pbits, 1 if a == p - 3 else 0, 1 if a == 0 else 0]
     return out, nl
