@@ -582,7 +582,7 @@ def main():
             "metric": f"scalar-mults/sec ({curve.lower()}, batch=2^{args.batch_log2}, variable base, affine out, bit-exact vs CPU)",
             "value": value, "unit": "scalar-mults/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32 (29-bit limbs, v_mad_u64_u32 integer MAD, u64 accumulators)",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32 (%d-bit limbs, v_mad_u64_u32 integer MAD, u64 accumulators)" % (28 if cp["p"] == 2**448 - 2**224 - 1 else 29),
             "data": "synthetic (seeded): scalars uniform in [1,q-1], base points P_i=[t_i]G",
             "config": {"workload": f"{curve} prj_pt_mul+prj_pt_unique, batch 2^{args.batch_log2} per GPU "
                                    "(BASELINE.json configs[1])",

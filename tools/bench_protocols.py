@@ -366,7 +366,7 @@ def main():
         print(json.dumps({
             "metric": metric, "value": B * world * a.steps / elapsed, "unit": unit, "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32 (29-bit limbs, v_mad_u64_u32 integer MAD, u64 accumulators)",
+            "vs_baseline": None, "dtype": "u32 (%d-bit limbs, v_mad_u64_u32 integer MAD, u64 accumulators)" % (28 if a.workload in ("x448", "ed448_verify") else 29),
             "data": "synthetic (seeded), inputs resident in HBM; 10 % of the signatures corrupted" if not payload
                     else "synthetic (seeded), inputs resident in HBM; valid keys",
             "config": {"workload": f"{a.workload} (BASELINE.json configs[{cfg}]), batch 2^{a.batch_log2} per GPU",
