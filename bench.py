@@ -81,8 +81,9 @@ def work_model(curve_params, nw, slen, batch=1 << 20):
         # squaring NL (NL + 1) / 2 products + NL^2 reduction MADs
         nl = (pbits + 16 + 28) // 29
         M, S = 2 * nl * nl, nl * (nl + 1) // 2 + nl * nl
-        if p == 2**521 - 1:                          # secp521r1 flavour: one reduction MAD per digit
-            M, S = nl * nl + nl, nl * (nl + 1) // 2 + nl
+        if p == 2**521 - 1:                          # secp521r1 flavour: plain residues on 18 limbs, 2^522 = 2 folded inside the columns
+            nl = 18
+            M, S = nl * nl, nl * (nl + 1) // 2
         if pbits == 384 and p % (1 << 29) == (1 << 29) - 1:   # p = -1 mod 2^29 flavour: no m p_0 product per quotient digit
             M, S = M - nl, S - nl
         if p == 2**255 - 19:                         # 2^255 - 19 flavour: 9 limbs, 9 + 1 fold MADs + 1 (x 19)
@@ -121,7 +122,7 @@ def work_model(curve_params, nw, slen, batch=1 << 20):
         nm += 1 + inv_m / fin_k + 2 + 3 + 2
         ns += inv_s / fin_k + 1
         # the reduction MADs multiply by digits of p held in __constant__ memory (scalar registers)
-        red = {True: nl}.get(p == 2**521 - 1, nl * nl)
+        red = {True: 0}.get(p == 2**521 - 1, nl * nl)      # (no constant multipliers in the plain Mersenne flavour)
         if p == 2**448 - 2**224 - 1:
             red = 0                                   # no constant multipliers at all
         work_model.loop_sgpr_share = (loop_m + loop_s) * red / (loop_m * M + loop_s * S)

@@ -1022,8 +1022,8 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_finalize_g(E
 // ---- one field size: constants + launch / upload entry points with the size in their name ----
 #define G29_CAT2(a, b) a##b
 #define G29_CAT(a, b) G29_CAT2(a, b)
-#if defined(G29_MERSENNE521)
-#define G29_TAG G29_CAT(G29_PB, m)   /* 521m: the secp521r1 flavour lives beside the dense 521 one */
+#if defined(G29_MERSENNE521) || defined(G29_M521P)
+#define G29_TAG G29_CAT(G29_PB, m)   /* 521m: the secp521r1 flavour (plain residues on 18 limbs) lives beside the dense 521 one */
 #define G29_FLAV 1
 #elif defined(G29_P25519)
 #define G29_TAG G29_CAT(G29_PB, c)   /* 255c: p = 2^255 - 19 beside the dense 255-bit unit */

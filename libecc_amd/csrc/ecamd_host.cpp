@@ -829,11 +829,13 @@ static int upload_g29(ecamd_curve *cv)
 	const Big &p = cv->p;
 	// flavours 2 (p = 2^255 - 19), 4 (secp256k1's prime) and 5 (p = 2^448 - 2^224 - 1) keep plain residues: R = 1
 	const int w = (cv->gflavour == 5) ? 28 : 29;   // limb width of the unit (g29::W of its translation unit)
-	const Big R = (cv->gflavour == 2 || cv->gflavour == 4 || cv->gflavour == 5) ? Big(1, 1) : big_mod(big_pow2(w * nl), p);
+	// flavours 1 (p = 2^521 - 1 on 18 limbs), 2, 4 and 5 keep plain residues: R = 1
+	const bool plain = cv->gflavour == 1 || cv->gflavour == 2 || cv->gflavour == 4 || cv->gflavour == 5;
+	const Big R = plain ? Big(1, 1) : big_mod(big_pow2(w * nl), p);
 	Big two(1, 2), three(1, 3);
 	static const int step29[16] = {2, 4, 6, 8, 10, 12, 14, 16, 2, 4, 6, 8, 10, 12, 14, 16};
-	static const int step28[16] = {1, 2, 3, 4, 5, 6, 7, 8, 1, 2, 3, 4, 5, 6, 7, 8};    // g29::bias_step of the Goldilocks flavour
-	const int *step = (cv->gflavour == 5) ? step28 : step29;
+	static const int step28[16] = {1, 2, 3, 4, 5, 6, 7, 8, 1, 2, 3, 4, 5, 6, 7, 8};    // g29::bias_step of the no-headroom flavours
+	const int *step = (cv->gflavour == 5 || cv->gflavour == 1) ? step28 : step29;
 	static const int sv[16] = {1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2};
 	const int topsh = pbits - w * (nl - 1);
 	const int off = (1 - topsh) > 0 ? (1 - topsh) : 0;
@@ -890,9 +892,9 @@ static int upload_g29(ecamd_curve *cv)
 		big_digits29(l, nl, big_shl(p, step[t] + off), w);
 		const uint32_t M = 1u << (w + sv[t]), BW = 1u << sv[t];
 		if (l[nl - 1] < BW) {
-			if (w == 28) {
+			if (cv->gflavour == 5 || cv->gflavour == 1) {
 				memset(l, 0, sizeof(uint32_t) * (size_t)nl);
-				continue;  // 2p on the Goldilocks unit cannot lend the borrow; never selected (BiasB's static_asserts)
+				continue;  // a multiple too small to lend the borrow; never selected (BiasB's static_asserts)
 			}
 			return fail("internal: bias table underflow");
 		}

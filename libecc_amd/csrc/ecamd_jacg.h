@@ -13,18 +13,18 @@ using namespace g29;
 template <int PB> struct Cls {
 	typedef Cfg<PB> C;
 	// generous cover for the largest bias the formulas below ever need ...
-	static constexpr int LC = P448 ? 0 : pick_logc<PB, 2>(3ull * MASK, C::top_from_vb(8)) + 4;
-	static_assert(LC >= (P448 ? 0 : 4), "no bias table large enough for this field size");
+	static constexpr int LC = NOHEAD ? 0 : pick_logc<PB, 2>(3ull * MASK, C::top_from_vb(8)) + 4;
+	static_assert(LC >= (NOHEAD ? 0 : 4), "no bias table large enough for this field size");
 	// ... bounds every loop-carried coordinate: carried limbs, value < 4 * 2^LC p
 	// (2^255 - 19 flavour: no headroom limb, the top limb holds values below 512 p, and products want
 	// va * vb <= 2^14; the formulas stay well inside 48 p)
-	// (Goldilocks flavour: no headroom at all -- carry() folds the top limb, so every carried coordinate and every multiplication
-	// result is below 2p with limbs a little over 28 bits; bias multiples are 4p and 8p)
-	static constexpr u64 VA = P448 ? 2 : (PLAIN9 ? 48 : (4ull << LC));
-	static constexpr u64 SLACK = P448 ? (1ull << 11) : 8;   // what a carried limb (Goldilocks: or a product's limb) may exceed the mask by
-	typedef E<PB, MASK + SLACK, P448 ? (MASK + SLACK) : C::top_from_vb(VA), VA> FA;
+	// (no-headroom flavours, Goldilocks and plain Mersenne: carry() folds the top limb, so every carried coordinate and every
+	// multiplication result is below 2p with limbs a little over their width; bias multiples are 4p and 8p)
+	static constexpr u64 VA = NOHEAD ? 2 : (PLAIN9 ? 48 : (4ull << LC));
+	static constexpr u64 SLACK = NOHEAD ? (1ull << 11) : 8;   // what a carried limb (no headroom: or a product's limb) may exceed the mask by
+	typedef E<PB, MASK + SLACK, NOHEAD ? (TOPMASK28 + SLACK) : C::top_from_vb(VA), VA> FA;
 	typedef typename MulOut<PB, 2>::type FM;  // multiplication result (value < 2p, exact low digits)
-	typedef E<PB, MASK, MASK, 1> FC;          // canonical constant
+	typedef E<PB, MASK, CANON_TB, 1> FC;      // canonical constant
 };
 
 template <int PB> struct Jac {
@@ -40,8 +40,8 @@ template <int PB> struct Jac {
 // v_a v_b <= 2^12, has no room for it -- H = U2 - X1 needs the 64p bias -- and keeps the Jacobian-table kernel)
 constexpr bool HAVE_MADD = !K256;
 template <int PB> struct ClsT {
-	static constexpr u64 VT = P25519 ? 20 : ((PLAIN9 || P448) ? Cls<PB>::VA : (128ull << Cfg<PB>::BIAS_OFF));
-	typedef E<PB, MASK + Cls<PB>::SLACK, P448 ? (MASK + Cls<PB>::SLACK) : Cfg<PB>::top_from_vb(VT), VT> FT;
+	static constexpr u64 VT = P25519 ? 20 : (PLAIN ? Cls<PB>::VA : (128ull << Cfg<PB>::BIAS_OFF));
+	typedef E<PB, MASK + Cls<PB>::SLACK, NOHEAD ? (TOPMASK28 + Cls<PB>::SLACK) : Cfg<PB>::top_from_vb(VT), VT> FT;
 };
 template <int PB> struct JacT {
 	typename ClsT<PB>::FT X, Y, Z;

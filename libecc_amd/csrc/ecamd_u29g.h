@@ -73,10 +73,20 @@ constexpr bool P448 = true;
 #else
 constexpr bool P448 = false;
 #endif
+//   -DG29_M521P        p = 2^521 - 1 (secp521r1) on plain residues: EIGHTEEN limbs of 29 bits (2^522 = 2 mod p), so a product
+//                      column is sum_(i+j=k) a_i b_j + sum_(i+j=k+18) a_i (2 b_j): 324 MADs in 18 columns, one pass, no Montgomery
+//                      form (the -DG29_MERSENNE521 flavour it replaces: 19 limbs, 361 + 19 MADs in 37 columns).  One bit of
+//                      headroom: handled like the Goldilocks flavour (carry() folds the bits from 2^521 up into limb 0).
+#if defined(G29_M521P)
+constexpr bool M521P = true;
+#else
+constexpr bool M521P = false;
+#endif
 constexpr int W = P448 ? 28 : 29;   // limb width of this translation unit
 constexpr u32 MASK = (1u << W) - 1;
 constexpr bool PLAIN9 = P25519 || K256;  // R = 1 on nine limbs, no headroom limb
-constexpr bool PLAIN = PLAIN9 || P448;   // R = 1
+constexpr bool NOHEAD = P448 || M521P;   // R = 1, top limb of 28 bits, no headroom: carried values are below 2p, biases are 4p / 8p
+constexpr bool PLAIN = PLAIN9 || NOHEAD; // R = 1
 //   -DG29_MPINV1       p = -1 mod 2^29 (secp384r1): the Montgomery quotient digit of a column is its low digit and
 //                      "+ m p_0" = "- m + m 2^29" clears it -- no multiplication in the quotient step.  (It has to be a
 //                      compile-time flavour: a wave-uniform branch inside the multiplier cost 25-45 %.)
@@ -87,7 +97,7 @@ constexpr bool MPINV1 = false;
 #endif
 
 constexpr int nl_for(int pbits) { return (pbits + 16 + W - 1) / W; }
-constexpr int nl_for_flavour(int pbits, int flavour) { return (flavour == 2 || flavour == 4) ? 9 : (flavour == 5 ? 16 : nl_for(pbits)); }
+constexpr int nl_for_flavour(int pbits, int flavour) { return (flavour == 2 || flavour == 4) ? 9 : (flavour == 5 ? 16 : (flavour == 1 ? 18 : nl_for(pbits))); }
 constexpr u64 cmin(u64 a, u64 b) { return a < b ? a : b; }
 constexpr u64 cmax(u64 a, u64 b) { return a > b ? a : b; }
 // x * 2^e for any sign of e, rounded up
@@ -100,10 +110,12 @@ template <int PB> struct Cfg {
 	static_assert(!P25519 || PB == 255, "the 2^255 - 19 flavour is only for 255-bit fields");
 	static_assert(!K256 || PB == 256, "the secp256k1 flavour is only for 256-bit fields");
 	static_assert(!P448 || PB == 448, "the Goldilocks flavour is only for 448-bit fields");
-	static constexpr int NL = PLAIN9 ? 9 : (P448 ? 16 : nl_for(PB));
+	static_assert(!M521P || PB == 521, "the plain Mersenne flavour is only for 521-bit fields");
+	static constexpr int NL = PLAIN9 ? 9 : (P448 ? 16 : (M521P ? 18 : nl_for(PB)));
 	static constexpr int HEAD = W * NL - PB;           // R / p >= 2^HEAD, HEAD >= 16 (Montgomery flavours)
 	static constexpr int TOPSH = PB - W * (NL - 1);    // p < 2^(29 (NL-1) + TOPSH); may be <= 0
-	static_assert((HEAD >= 16 || PLAIN9 || P448) && NL <= 19, "field size not supported");
+	static_assert((HEAD >= 16 || PLAIN9 || NOHEAD) && NL <= 19, "field size not supported");
+	static_assert(!NOHEAD || TOPSH == 28, "no-headroom flavours: the top limb holds 28 bits of p");
 	// top limb of a non-negative-limb value < vb * p
 	static constexpr u64 top_from_vb(u64 vb) { return shl_ceil(vb, TOPSH) + 1; }
 	// bias multiples are 2^(BIAS_STEP + BIAS_OFF) p: with a (nearly) empty top limb the smallest
@@ -113,15 +125,15 @@ template <int PB> struct Cfg {
 	// (2^255 - 19 flavour: va * vb <= 2^14 keeps the last product limb and the fold quotient in 32 bits)
 	// (secp256k1 flavour: the last product limb is < va vb 2^19, so va * vb <= 2^12)
 	// (Goldilocks flavour: the product is folded inside its columns, whatever the operands' values: only limb bounds matter)
-	static constexpr int PROD_E = P25519 ? 14 : (K256 ? 12 : (P448 ? 62 : ((2 * HEAD - 2) > 62 ? 62 : (2 * HEAD - 2))));
+	static constexpr int PROD_E = P25519 ? 14 : (K256 ? 12 : (NOHEAD ? 62 : ((2 * HEAD - 2) > 62 ? 62 : (2 * HEAD - 2))));
 	static constexpr bool prod_ok(u64 va, u64 vb) { return va == 0 || vb <= ((1ull << PROD_E) - (PLAIN9 ? 0 : 1)) / va; }
 };
 
 // the (LOGC, S) combinations the formulas use for "a - b + C p": bias tables for exactly these
 // are precomputed per curve by the host
 constexpr int NBIAS = 16;
-// (Goldilocks flavour, no headroom limb: steps of one -- 2p, 4p, 8p are the multiples whose top limb fits 32 bits)
-constexpr int bias_step(int i) { return P448 ? (i % 8) + 1 : 2 * (i % 8) + 2; }
+// (no-headroom flavours: steps of one -- 2p, 4p, 8p are the multiples whose top limb fits 32 bits)
+constexpr int bias_step(int i) { return NOHEAD ? (i % 8) + 1 : 2 * (i % 8) + 2; }
 constexpr int BIAS_STEP[NBIAS] = {bias_step(0), bias_step(1), bias_step(2),  bias_step(3),  bias_step(4),  bias_step(5),  bias_step(6),  bias_step(7),
 				  bias_step(8), bias_step(9), bias_step(10), bias_step(11), bias_step(12), bias_step(13), bias_step(14), bias_step(15)};
 constexpr int BIAS_S[NBIAS] = {1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2};
@@ -179,13 +191,15 @@ template <class T, class S> G29_FN T weaken(const S &s)
 
 // ---- multiplication ----
 template <int PB> constexpr u64 mul_vb(u64 va, u64 vb) { return PLAIN ? 2 : shl_ceil(va * vb, -Cfg<PB>::HEAD) + 1; }
-constexpr u64 P448_MULX = 1ull << 10;
+constexpr u64 P448_MULX = 1ull << 10;     // what the lazy limbs of a no-headroom product (1 and 9 / 1) may exceed the mask by
+constexpr u32 TOPMASK28 = (1u << 28) - 1;  // top limb of the no-headroom flavours
+constexpr u64 CANON_TB = NOHEAD ? TOPMASK28 : MASK;   // top limb of a canonical value (< p)
 template <int PB, u64 VBO> struct MulOut {
 	// 2^255 - 19 flavour: exact low digits, top limb < 2^23 + 2^12 (see mul_raw), value < 2p
 	// secp256k1 flavour: exact low digits, top limb < 2^24 + 2^17, value < 2p
 	// Goldilocks flavour: limbs 1 and 9 carry the (lazily added) high parts of the two wrap-around carries, see mul_p448
-	typedef E<PB, P448 ? (MASK + P448_MULX) : MASK,
-		  P25519 ? ((1ull << 23) + (1ull << 12)) : (K256 ? ((1ull << 24) + (1ull << 17)) : (P448 ? (u64)MASK : Cfg<PB>::top_from_vb(VBO))), VBO> type;
+	typedef E<PB, NOHEAD ? (MASK + P448_MULX) : MASK,
+		  P25519 ? ((1ull << 23) + (1ull << 12)) : (K256 ? ((1ull << 24) + (1ull << 17)) : (NOHEAD ? (u64)TOPMASK28 : Cfg<PB>::top_from_vb(VBO))), VBO> type;
 };
 template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
 {
@@ -194,6 +208,10 @@ template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
 		// Goldilocks flavour: the fullest column (limb 8) sums 38 la lb -- 16 products, those against b0 + b1 counted twice, plus
 		// the shared column S_0 -- and a carry below 2^37
 		return la == 0 || lb <= ((0xFFFFFFFFFFFFFFFFull - (1ull << 40)) / 38) / la;
+	}
+	if (M521P) {
+		// plain Mersenne flavour: a column sums (k + 1) la lb + (17 - k) la (2 lb) <= 35 la lb and a carry below 2^37
+		return la == 0 || lb <= ((0xFFFFFFFFFFFFFFFFull - (1ull << 40)) / 36) / la;
 	}
 	return la == 0 || lb <= ((0xFFFFFFFFFFFFFFFFull - (u64)NL * (1ull << 58) - (1ull << 36)) / NL) / la;
 }
@@ -349,7 +367,7 @@ template <int NL, bool SQR, int K_> G29_FN void mul_column(u64 &acc, u32 *m, u32
 //
 // two product lists X (accumulator ax) and Y (accumulator ay, starting from zero when ZY) of any lengths, interleaved as long as
 // both last
-template <int NX, int NY, bool ZY> G29_FN void p448_dual(u64 &ax, u64 &ay, const u32 *xx, const u32 *yx, const u32 *xy, const u32 *yy)
+template <int NX, int NY, bool ZY> G29_FN void dual_chains(u64 &ax, u64 &ay, const u32 *xx, const u32 *yx, const u32 *xy, const u32 *yy)
 {
 	constexpr int NM = NX < NY ? NX : NY;
 	if constexpr (NM > 0) {
@@ -426,12 +444,12 @@ template <bool SQR, int J> G29_FN void p448_pair(u64 &clo, u64 &chi, u32 *r, con
 	}
 	if constexpr (NS > 0) {
 		u64 s;
-		p448_dual<NHA, NS, true>(chi, s, xha, yha, xs, ys);
-		p448_dual<NHB, NLO, false>(chi, clo, xhb, yhb, xlo, ylo);
+		dual_chains<NHA, NS, true>(chi, s, xha, yha, xs, ys);
+		dual_chains<NHB, NLO, false>(chi, clo, xhb, yhb, xlo, ylo);
 		clo += s;
 		chi += s;
 	} else {
-		p448_dual<NHB, NLO, false>(chi, clo, xhb, yhb, xlo, ylo);
+		dual_chains<NHB, NLO, false>(chi, clo, xhb, yhb, xlo, ylo);
 	}
 	r[J] = (u32)clo & MASK;
 	clo >>= W;
@@ -474,6 +492,87 @@ template <bool SQR> G29_FN void mul_p448(u32 *r, const u32 *a, const u32 *b)
 	r[9] += h7 + h15 + (r8 >> W);
 }
 
+// ---- plain Mersenne flavour (p = 2^521 - 1, eighteen 29-bit limbs: 2^522 = 2^(29*18) = 2 mod p) ----
+// column k = sum_(i+j=k) a_i b_j + 2 sum_(i+j=k+18) a_i b_j, eighteen products on two accumulators -- the direct and the wrapped
+// ones, the latter doubled when the two are joined -- and one carry chain (squaring: the off-diagonal products once against the
+// doubled operand, the wrapped ones against the doubled operand on both sides).  The carry out of limb 17 (< 2^36, weight 2^522 = 2) and bit 28 of limb 17 (2^521 = 1) go to limbs 0 and 1 lazily:
+// limb 1 below 2^29 + 2^10, limb 17 below 2^28, all others below 2^29, value below 2^521 + 2^40 < 2p.
+template <bool SQR, int K_> G29_FN void m521p_column(u64 &acc, u32 *r, const u32 *a, const u32 *b, const u32 *a2)
+{
+	constexpr int NWRAP = SQR ? ((K_ + 18) / 2 - K_) : (17 - K_);     // SQR: i = K+1 .. (K+18)/2
+	constexpr int NDIR = SQR ? (K_ / 2 + 1) : (K_ + 1);
+	if constexpr (!SQR) {
+		// the wrapped products go to the second accumulator as they are and are doubled in the addition that joins the two
+		// (one v_lshl_add_u64), so no doubled copy of b has to stay in registers
+		u32 xd[NDIR], yd[NDIR], xw[NWRAP + 1], yw[NWRAP + 1];
+#pragma unroll
+		for (int i = 0; i <= K_; i++) {
+			xd[i] = a[i];
+			yd[i] = b[K_ - i];
+		}
+#pragma unroll
+		for (int i = K_ + 1; i < 18; i++) {
+			xw[i - K_ - 1] = a[i];
+			yw[i - K_ - 1] = b[K_ + 18 - i];
+		}
+		if constexpr (NWRAP > 0) {
+			u64 wrap;
+			dual_chains<NDIR, NWRAP, true>(acc, wrap, xd, yd, xw, yw);
+			acc += wrap << 1;
+		} else {
+			u64 acc2;
+			mad_chain<NDIR, true, false, true>(acc, acc2, xd, yd);
+			acc += acc2;
+		}
+	} else {
+		constexpr int N = NDIR + NWRAP;
+		u32 x[N], y[N];
+#pragma unroll
+		for (int i = 0; 2 * i <= K_; i++) {
+			x[i] = a[i];
+			y[i] = (i < K_ - i) ? a2[K_ - i] : a[i];
+		}
+#pragma unroll
+		for (int i = K_ + 1; 2 * i <= K_ + 18; i++) {
+			const int j = K_ + 18 - i;
+			x[NDIR + i - K_ - 1] = a2[i];
+			y[NDIR + i - K_ - 1] = (i < j) ? a2[j] : a[i];
+		}
+		if constexpr (N >= 2) {
+			u64 acc2;
+			mad_chain<N, true, false, true>(acc, acc2, x, y);
+			acc += acc2;
+		} else {
+			u64 unused;
+			mad_chain<N, false, false>(acc, unused, x, y);
+		}
+	}
+	r[K_] = (u32)acc & MASK;
+	acc >>= W;
+}
+template <bool SQR, int... Ks> G29_FN void m521p_columns(u64 &acc, u32 *r, const u32 *a, const u32 *b, const u32 *a2, std::integer_sequence<int, Ks...>)
+{
+	(m521p_column<SQR, Ks>(acc, r, a, b, a2), ...);
+}
+template <bool SQR> G29_FN void mul_m521p(u32 *r, const u32 *a, const u32 *b)
+{
+	u32 a2[18];   // squaring: 2 a
+	if constexpr (SQR) {
+#pragma unroll
+		for (int i = 0; i < 18; i++) {
+			a2[i] = a[i] << 1;
+		}
+	}
+	u64 acc = 0;
+	m521p_columns<SQR>(acc, r, a, b, a2, std::make_integer_sequence<int, 18>());
+	// acc: the carry out of limb 17 (weight 2^522 = 2); bit 28 of limb 17 is 2^521 = 1
+	const u64 w = (acc << 1) + (r[17] >> 28);
+	r[17] &= TOPMASK28;
+	const u32 r0 = r[0] + ((u32)w & MASK);
+	r[0] = r0 & MASK;
+	r[1] += (u32)(w >> W) + (r0 >> W);
+}
+
 template <int NL, bool SQR, int... Ks>
 G29_FN void mul_columns(u64 &acc, u32 *m, u32 *r, u32 *t, const u32 *a, const u32 *b, const u32 *a2, const u32 *p, u32 mpinv,
 			u32 q17v, std::integer_sequence<int, Ks...>)
@@ -489,6 +588,11 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 	if constexpr (P448) {
 		static_assert(NL == 16, "Goldilocks flavour: 16 limbs");
 		mul_p448<SQR>(r, a, b);
+		return;
+	}
+	if constexpr (M521P) {
+		static_assert(NL == 18, "plain Mersenne flavour: 18 limbs");
+		mul_m521p<SQR>(r, a, b);
 		return;
 	}
 	u32 m[NL], a2[NL], t[2 * NL];
@@ -722,8 +826,8 @@ template <int PB, int S> constexpr int pick_logc(u64 lb_b, u64 tb_b)
 template <int S, class A, class B, int NLc> G29_FN auto sub_auto(const A &a, const B &b, const CurveG<NLc> &K)
 {
 	constexpr int logc = pick_logc<A::C::PBITS, S>(B::LB, B::TB);
-	if constexpr (logc < 0 && S == 1 && P448) {
-		// Goldilocks flavour: a product's limbs 1 and 9 are a little over 28 bits, so its double is a little over 2^29
+	if constexpr (logc < 0 && S == 1 && NOHEAD) {
+		// no-headroom flavours: a product's lazy limbs are a little over the limb width, so its double is a little over 2^(W+1)
 		return sub_auto<2>(a, b, K);
 	} else {
 		static_assert(logc >= 0, "sub_auto: no tabulated bias dominates b (carry it first?)");
@@ -731,14 +835,14 @@ template <int S, class A, class B, int NLc> G29_FN auto sub_auto(const A &a, con
 	}
 }
 
-// One step of limb carries.  The integer value is kept, except in the Goldilocks flavour (no headroom limb): there the top
-// limb gives its bits from 28 up -- multiples of 2^448 = 2^224 + 1 (mod p) -- to limbs 0 and 8, so that the result is the same
-// residue with every limb near 28 bits and a value below 2p.
+// One step of limb carries.  The integer value is kept, except in the no-headroom flavours (Goldilocks, plain Mersenne): there
+// the top limb gives its bits from 28 up -- multiples of 2^448 = 2^224 + 1 resp. 2^521 = 1 (mod p) -- to limbs 0 (and 8), so that
+// the result is the same residue with every limb near its width and a value below 2p.
 template <class A> struct CarryT {
-	static constexpr u64 LBO = MASK + (A::LB >> W) + (P448 ? (A::TB >> W) : 0);
-	static constexpr u64 TBO = P448 ? (MASK + (A::LB >> W)) : (A::TB + (A::LB >> W));
-	static_assert(!P448 || LBO - MASK < (1ull << 20), "carry: limbs too loose for the value bound 2p");
-	typedef E<A::C::PBITS, LBO, TBO, P448 ? 2 : A::VB> type;
+	static constexpr u64 LBO = MASK + (A::LB >> W) + (NOHEAD ? (A::TB >> 28) : 0);
+	static constexpr u64 TBO = NOHEAD ? (TOPMASK28 + (A::LB >> W)) : (A::TB + (A::LB >> W));
+	static_assert(!NOHEAD || LBO - MASK < (1ull << 20), "carry: limbs too loose for the value bound 2p");
+	typedef E<A::C::PBITS, LBO, TBO, NOHEAD ? 2 : A::VB> type;
 };
 template <class A> G29_FN typename CarryT<A>::type carry(const A &a)
 {
@@ -749,11 +853,14 @@ template <class A> G29_FN typename CarryT<A>::type carry(const A &a)
 	for (int i = 1; i < NL - 1; i++) {
 		r.l[i] = (a.l[i] & MASK) + (a.l[i - 1] >> W);
 	}
-	if constexpr (P448) {
-		const u32 t = a.l[NL - 1] >> W;
-		r.l[NL - 1] = (a.l[NL - 1] & MASK) + (a.l[NL - 2] >> W);
+	if constexpr (NOHEAD) {
+		// the top limb's bits from 28 up are multiples of 2^448 = 2^224 + 1 (Goldilocks) / of 2^521 = 1 (Mersenne)
+		const u32 t = a.l[NL - 1] >> 28;
+		r.l[NL - 1] = (a.l[NL - 1] & TOPMASK28) + (a.l[NL - 2] >> W);
 		r.l[0] += t;
-		r.l[NL / 2] += t;
+		if constexpr (P448) {
+			r.l[NL / 2] += t;
+		}
 	} else {
 		r.l[NL - 1] = a.l[NL - 1] + (a.l[NL - 2] >> W);
 	}
@@ -793,26 +900,28 @@ template <class A, int NLc> G29_FN auto sqrc(const A &a, const CurveG<NLc> &K)
 template <class A, int NLc> G29_FN void canonical_digits(u32 *d, const A &a, const CurveG<NLc> &K)
 {
 	constexpr int NL = A::C::NL;
-	static_assert((A::LB == MASK || (P448 && A::LB <= MASK + P448_MULX)) && A::VB <= 3, "canonical_digits needs a multiplication result < 3p");
+	static_assert((A::LB == MASK || (NOHEAD && A::LB <= MASK + P448_MULX)) && A::VB <= 3, "canonical_digits needs a multiplication result < 3p");
 #pragma unroll
 	for (int i = 0; i < NL; i++) {
 		d[i] = a.l[i];
 	}
-	if constexpr (P448) {
-		// limbs 1 and 9 are lazy and the value may reach 2^448 and a little more: exact carries with the bits from 2^448 up folded
-		// to limbs 0 and 8, twice (after the first round limbs 0 and 8 exceed 28 bits by at most the folded amount; the second
-		// round can only fold when everything below is nearly zero), then the value is below 2^448 < 2p
+	if constexpr (NOHEAD) {
+		// some limbs are lazy and the value may reach 2^|p| and a little more: exact carries with the bits from 2^|p| up folded
+		// to limb 0 (Goldilocks: and 8), twice (after the first round those limbs exceed their width by at most the folded amount;
+		// the second round can only fold when everything below is nearly zero), then the value is below 2^|p| < 2p
 #pragma unroll
 		for (int round = 0; round < 2; round++) {
 			u32 c = 0;
 #pragma unroll
 			for (int i = 0; i < NL; i++) {
 				const u32 x = d[i] + c;
-				d[i] = x & MASK;
-				c = x >> W;
+				d[i] = x & (i < NL - 1 ? MASK : TOPMASK28);
+				c = x >> (i < NL - 1 ? W : 28);
 			}
 			d[0] += c;
-			d[NL / 2] += c;
+			if constexpr (P448) {
+				d[NL / 2] += c;
+			}
 		}
 	}
 #pragma unroll
@@ -846,10 +955,10 @@ template <class A, int NLc> G29_FN bool is_zero_mulout(const A &a, const CurveG<
 }
 
 // ---- saturated 32-bit words <-> 29-bit limbs (NW words; value < p) ----
-template <int PB, int NW> G29_FN E<PB, MASK, MASK, 1> from_words(const u32 *w)
+template <int PB, int NW> G29_FN E<PB, MASK, CANON_TB, 1> from_words(const u32 *w)
 {
 	constexpr int NL = Cfg<PB>::NL;
-	E<PB, MASK, MASK, 1> r;
+	E<PB, MASK, CANON_TB, 1> r;
 #pragma unroll
 	for (int i = 0; i < NL; i++) {
 		const int bit = W * i, wi = bit >> 5, sh = bit & 31;

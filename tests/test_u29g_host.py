@@ -32,10 +32,10 @@ def lib():
 
 @pytest.fixture(scope="module")
 def lib_m521():
-    """the secp521r1 flavour (single-digit reduction) of the same headers"""
+    """the secp521r1 flavour (plain residues on 18 limbs, 2^522 = 2 folded inside the product columns) of the same headers"""
     os.makedirs(BUILD, exist_ok=True)
-    so = os.path.join(BUILD, "u29g_host_m521.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DG29_MERSENNE521", "-DSHIM_ONLY_521", "-o", so,
+    so = os.path.join(BUILD, "u29g_host_m521p.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DG29_M521P", "-DSHIM_ONLY_521", "-o", so,
                            os.path.join(ROOT, "tests", "u29g_host_shim.cpp")])
     return C.CDLL(so)
 
@@ -73,7 +73,7 @@ class Field:
         getattr(lib, f"g_info_{self.pb}")(info)
         assert info[0] == self.nl and info[5] == 4 * len(img), (list(info), len(img))
         self.head, self.va, self.fa_lb, self.fa_tb = info[1], info[4], info[6], info[7]
-        self.R = 1 if flavour in (2, 4, 5) else 1 << (self.W * self.nl)
+        self.R = 1 if flavour in (1, 2, 4, 5) else 1 << (self.W * self.nl)
         self.Rinv = pow(self.R, self.p - 2, self.p)
 
     def fn(self, name):
@@ -124,7 +124,7 @@ def test_field_ops(lib, curve, flavour=0):
             vmax = max(0, f.vmax(f.va, f.fa_tb) - 1)
             lx = f.fa(rng, x, vmax)
             ly = f.fa(rng, y, vmax)
-        if it == 1 and flavour == 5:   # every limb at the class bound (the value is then what it is: only the residue matters)
+        if it == 1 and flavour in (1, 5):   # every limb at the class bound (the value is then what it is: only the residue matters)
             lx = [f.fa_lb] * (f.nl - 1) + [f.fa_tb]
             ly = [f.fa_lb] * (f.nl - 1) + [f.fa_tb]
             x, y = f.val(lx) % p, f.val(ly) % p
@@ -132,29 +132,37 @@ def test_field_ops(lib, curve, flavour=0):
         f.fn("mul")(f.k, arr(lx), arr(ly), out, 0)
         assert f.val(out) % p == f.val(lx) * f.val(ly) * f.Rinv % p
         # exact low digits -- on the Goldilocks unit limbs 1 and 9 keep the high parts of the two wrap-around carries (< 2^10)
-        slack = [(1 << 10) if (flavour == 5 and i in (1, 9)) else 0 for i in range(f.nl)]
-        assert f.val(out) < 2 * p + (f.val(lx) * f.val(ly) >> (f.W * f.nl) if flavour != 5 else 0)
+        slack = [(1 << 10) if ((flavour == 5 and i in (1, 9)) or (flavour == 1 and i == 1)) else 0 for i in range(f.nl)]
+        assert f.val(out) < 2 * p + (f.val(lx) * f.val(ly) >> (f.W * f.nl) if flavour not in (1, 5) else 0)
         assert all(v <= f.MASK + sl for v, sl in zip(list(out)[:-1], slack))
         f.fn("mul")(f.k, arr(lx), arr(lx), out, 1)
         assert f.val(out) % p == f.val(lx) ** 2 * f.Rinv % p
-        assert all(v <= f.MASK + sl for v, sl in zip(list(out)[:-1], slack)) and (flavour != 5 or f.val(out) < 2 * p)
+        assert all(v <= f.MASK + sl for v, sl in zip(list(out)[:-1], slack)) and (flavour not in (1, 5) or f.val(out) < 2 * p)
     # canonical digits, negation, inversion
     for v in (0, 1, p - 1, p, p + 1, 2 * p - 1, int.from_bytes(rng.bytes(80), "big") % (2 * p)):
         d, _ = f.call("canon", f.digits(v))
         assert f.val(d) == v % p and max(d[:-1]) <= f.MASK
         n, _ = f.call("neg", f.digits(v))
         assert (f.val(n) + v) % p == 0 and max(n[:-1]) <= f.fa_lb and n[-1] <= f.fa_tb
-    if flavour == 5:
-        # lazy representatives of a multiplication result: limbs 1 and 9 over 28 bits, values around 2^448
-        for v in (2**448 - 1, 2**448, 2**448 + 2**224, 2 * p - 1, p + 2**224 + 1):
+    if flavour in (1, 5):
+        # lazy representatives of a multiplication result: limbs 1 (and 9) over their width, values around 2^|p|
+        top = 1 << f.pb
+        for v in (top - 1, top, top + 2**224, 2 * p - 1, p + 2**224 + 1, top + 5):
             l = f.digits(v)
-            for i in (1, 9):
+            for i in ((1, 9) if flavour == 5 else (1,)):
                 k = min(l[i + 1], 3)
                 l[i] += k << f.W
                 l[i + 1] -= k
-            if max(l) <= f.MASK + (1 << 10):
+            if max(l[:-1]) <= f.MASK + (1 << 10) and l[-1] < (1 << 28):
                 d, _ = f.call("canon", l)
                 assert f.val(d) == v % p and max(d) <= f.MASK, hex(v)
+        # the largest member of the class: every limb at its mask, the lazy ones at mask + 2^10 (value above 2^|p|)
+        for extra in ((1 << 10), 1, 0):
+            l = [f.MASK] * (f.nl - 1) + [(1 << 28) - 1]
+            for i in ((1, 9) if flavour == 5 else (1,)):
+                l[i] += extra
+            d, _ = f.call("canon", l)
+            assert f.val(d) == f.val(l) % p and max(d) <= f.MASK
     x = int.from_bytes(rng.bytes(80), "big") % p or 1
     iv, _ = f.call("inv", f.digits(x * f.R % p))
     assert f.val(iv) % p == pow(x, p - 2, p) * f.R % p
@@ -273,8 +281,8 @@ def test_jacobian(lib, curve, flavour=0):
 
 
 def test_secp521r1_mersenne_flavour(lib_m521):
-    test_field_ops(lib_m521, "SECP521R1")
-    test_jacobian(lib_m521, "SECP521R1")
+    test_field_ops(lib_m521, "SECP521R1", 1)
+    test_jacobian(lib_m521, "SECP521R1", 1)
 
 
 def test_p25519_flavour(lib_p25519):

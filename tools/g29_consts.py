@@ -18,7 +18,8 @@ def width(flavour):
 
 
 def bias_steps(flavour):
-    return ([1, 2, 3, 4, 5, 6, 7, 8] if flavour == 5 else [2, 4, 6, 8, 10, 12, 14, 16]) * 2
+    """the no-headroom flavours (1: secp521r1 on plain residues, 5: Goldilocks) use 2p, 4p, 8p ...; the others 4p, 16p, 64p ..."""
+    return ([1, 2, 3, 4, 5, 6, 7, 8] if flavour in (1, 5) else [2, 4, 6, 8, 10, 12, 14, 16]) * 2
 
 
 def digits(x, nl, w=W):
@@ -28,13 +29,13 @@ def digits(x, nl, w=W):
 
 
 def image(p, a, b, flavour=0):
-    """flavour 0: dense Montgomery (also what the secp521r1 flavour uses); 2: p = 2^255 - 19, nine limbs
+    """flavour 0: dense Montgomery; 1: p = 2^521 - 1 on plain residues, 18 limbs (2^522 = 2); 2: p = 2^255 - 19, nine limbs
     and plain residues (R = 1); 4: p = 2^256 - 2^32 - 977 (secp256k1), the same shape; 5: p = 2^448 - 2^224 - 1, plain residues on 16 limbs
     of 28 bits"""
     pbits = p.bit_length()
-    plain = flavour in (2, 4, 5)
+    plain = flavour in (1, 2, 4, 5)
     w = width(flavour)
-    nl = 9 if flavour in (2, 4) else (16 if flavour == 5 else nl_for(pbits))
+    nl = 9 if flavour in (2, 4) else (16 if flavour == 5 else (18 if flavour == 1 else nl_for(pbits)))
     R = 1 if plain else 1 << (w * nl)
     topsh = pbits - w * (nl - 1)
     off = max(0, 1 - topsh)
