@@ -84,8 +84,8 @@ def work_model(curve_params, nw, slen, batch=1 << 20):
         if p == 2**521 - 1:                          # secp521r1 flavour: plain residues on 18 limbs, 2^522 = 2 folded inside the columns
             nl = 18
             M, S = nl * nl, nl * (nl + 1) // 2
-        if pbits == 384 and p % (1 << 29) == (1 << 29) - 1:   # p = -1 mod 2^29 flavour: no m p_0 product per quotient digit
-            M, S = M - nl, S - nl
+        if p == 2**384 - 2**128 - 2**96 + 2**32 - 1:  # secp384r1 flavour: m_k (p + 1) as four signed MADs per quotient digit
+            M, S = nl * nl + 4 * nl, nl * (nl + 1) // 2 + 4 * nl
         if p == 2**255 - 19:                         # 2^255 - 19 flavour: 9 limbs, 9 + 1 fold MADs + 1 (x 19)
             nl = 9
             M, S = nl * nl + nl + 2, nl * (nl + 1) // 2 + nl + 2
@@ -123,6 +123,8 @@ def work_model(curve_params, nw, slen, batch=1 << 20):
         ns += inv_s / fin_k + 1
         # the reduction MADs multiply by digits of p held in __constant__ memory (scalar registers)
         red = {True: 0}.get(p == 2**521 - 1, nl * nl)      # (no constant multipliers in the plain Mersenne flavour)
+        if p == 2**384 - 2**128 - 2**96 + 2**32 - 1:
+            red = 4 * nl
         if p == 2**448 - 2**224 - 1:
             red = 0                                   # no constant multipliers at all
         work_model.loop_sgpr_share = (loop_m + loop_s) * red / (loop_m * M + loop_s * S)

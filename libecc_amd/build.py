@@ -46,7 +46,8 @@ def _jobs():
     jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_255c.o", ["-DG29_PB=255", "-DG29_P25519", "-DG29_WAVES=3"]))
     jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_256k.o", ["-DG29_PB=256", "-DG29_K256", "-DG29_WAVES=3"]))
     jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_448g.o", ["-DG29_PB=448", "-DG29_P448"]))
-    jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_384n.o", ["-DG29_PB=384", "-DG29_MPINV1"]))
+    # secp384r1: Montgomery reduction on the four signed digits of p + 1 (ecamd_u29g.h:p384s_reduction)
+    jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_384n.o", ["-DG29_PB=384", "-DG29_P384S"]))
     jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_dispatch.o", ["-DG29_DISPATCH"]))
     return jobs
 

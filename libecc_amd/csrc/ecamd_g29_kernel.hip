@@ -1022,7 +1022,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_finalize_g(E
 // ---- one field size: constants + launch / upload entry points with the size in their name ----
 #define G29_CAT2(a, b) a##b
 #define G29_CAT(a, b) G29_CAT2(a, b)
-#if defined(G29_MERSENNE521) || defined(G29_M521P)
+#if defined(G29_M521P)
 #define G29_TAG G29_CAT(G29_PB, m)   /* 521m: the secp521r1 flavour (plain residues on 18 limbs) lives beside the dense 521 one */
 #define G29_FLAV 1
 #elif defined(G29_P25519)
@@ -1034,8 +1034,8 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_finalize_g(E
 #elif defined(G29_K256)
 #define G29_TAG G29_CAT(G29_PB, k)   /* 256k: p = 2^256 - 2^32 - 977 (secp256k1) beside the dense 256-bit unit */
 #define G29_FLAV 4
-#elif defined(G29_MPINV1)
-#define G29_TAG G29_CAT(G29_PB, n)   /* 384n: primes that are -1 mod 2^29 (secp384r1) beside the dense 384-bit unit */
+#elif defined(G29_P384S)
+#define G29_TAG G29_CAT(G29_PB, n)   /* 384n: secp384r1's prime (signed sparse reduction) beside the dense 384-bit unit */
 #define G29_FLAV 3
 #else
 #define G29_FLAV 0

@@ -1035,8 +1035,9 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	    big_cmp(cv->p, big_sub(big_sub(big_pow2(448), big_pow2(224)), Big(1, 1))) == 0) {
 		cv->gflavour = 5;  // p = 2^448 - 2^224 - 1 (WEI448): plain residues, Goldilocks folds
 	}
-	if (cv->pbits == 384 && (cv->p[0] & 0x1fffffffu) == 0x1fffffffu && getenv("ECAMD_NO_MPINV1") == nullptr) {
-		cv->gflavour = 3;  // p = -1 mod 2^29 (secp384r1): quotient digits without a multiplication
+	if (cv->pbits == 384 && getenv("ECAMD_NO_MPINV1") == nullptr &&
+	    big_cmp(big_add(cv->p, big_add(big_pow2(128), big_pow2(96))), big_add(big_pow2(384), big_sub(big_pow2(32), Big(1, 1)))) == 0) {
+		cv->gflavour = 3;  // secp384r1's prime: Montgomery reduction on the four signed digits of p + 1 (ecamd_u29g.h, -DG29_P384S)
 	}
 	if (!cv->is_p256 && ecamd_g29_supported(cv->pbits) && cv->pbits + 8 < ECAMD_G29_KEYS && getenv("ECAMD_NO_FAST_PATH") == nullptr) {
 		int rc;

@@ -292,18 +292,34 @@ def test_p25519_flavour(lib_p25519):
 
 @pytest.fixture(scope="module")
 def lib_n384():
-    """the p = -1 mod 2^29 flavour (quotient digits without a multiplication) of the 384-bit unit"""
+    """secp384r1's flavour of the 384-bit unit: Montgomery reduction on the four signed digits of p + 1, signed column sums"""
     os.makedirs(BUILD, exist_ok=True)
     so = os.path.join(BUILD, "u29g_host_n384.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DG29_MPINV1", "-DSHIM_ONLY_384", "-o", so,
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DG29_P384S", "-DSHIM_ONLY_384", "-o", so,
                            os.path.join(ROOT, "tests", "u29g_host_shim.cpp")])
     return C.CDLL(so)
 
 
 def test_secp384r1_mpinv1_flavour(lib_n384):
-    assert CURVES["SECP384R1"]["p"] % (1 << 29) == (1 << 29) - 1
+    assert CURVES["SECP384R1"]["p"] == 2**384 - 2**128 - 2**96 + 2**32 - 1
     test_field_ops(lib_n384, "SECP384R1")
     test_jacobian(lib_n384, "SECP384R1")
+    # small products: the negative reduction terms (- 2^9 m_(k-3) - 2^12 m_(k-4)) outweigh a column's products, so column sums go
+    # negative and the carries must be arithmetic
+    rng = np.random.default_rng(384)
+    f = Field(lib_n384, "SECP384R1")
+    p = f.p
+    out = (C.c_uint32 * f.nl)()
+    for it in range(200):
+        x = int.from_bytes(rng.bytes(48), "big") % p
+        y = (0, 1, 2, 1 << 29, (1 << 29) - 1, 1 << 58, p - 1, int(rng.integers(0, 1 << 20)))[it % 8]
+        lx, ly = f.digits(x), f.digits(y)
+        if it % 3 == 0:
+            lx, ly = ly, lx
+        f.fn("mul")(f.k, arr(lx), arr(ly), out, 0)
+        assert f.val(out) % p == x * y * f.Rinv % p and f.val(out) < 2 * p and max(list(out)[:-1]) <= f.MASK
+        f.fn("mul")(f.k, arr(f.digits(y)), arr(f.digits(y)), out, 1)
+        assert f.val(out) % p == y * y * f.Rinv % p and f.val(out) < 2 * p and max(list(out)[:-1]) <= f.MASK
 
 
 @pytest.fixture(scope="module")
