@@ -86,9 +86,9 @@ def work_model(curve_params, nw, slen, batch=1 << 20):
             M, S = nl * nl, nl * (nl + 1) // 2
         if p == 2**384 - 2**128 - 2**96 + 2**32 - 1:  # secp384r1 flavour: m_k (p + 1) as four signed MADs per quotient digit
             M, S = nl * nl + 4 * nl, nl * (nl + 1) // 2 + 4 * nl
-        if p == 2**255 - 19:                         # 2^255 - 19 flavour: 9 limbs, 9 + 1 fold MADs + 1 (x 19)
+        if p == 2**255 - 19:                         # 2^255 - 19 flavour: 9 limbs, 9 fold MADs riding in the low columns
             nl = 9
-            M, S = nl * nl + nl + 2, nl * (nl + 1) // 2 + nl + 2
+            M, S = nl * nl + nl, nl * (nl + 1) // 2 + nl
         if p == 2**448 - 2**224 - 1:                 # Goldilocks flavour: 16 limbs of 28 bits, phi^2 = phi + 1 folded inside the columns:
             M, S = nl * nl, 2 * 36 + 64              # 256 MADs; squaring a0^2 + a1^2 (36 each) and a1 (2 a0 + a1) (64), ecamd_u29g.h:mul_p448
         if p == 2**256 - 2**32 - 977:                # secp256k1 flavour: 9 limbs, 2 + 3 + 3 + 6 * 2 = 20 fold MADs

@@ -188,6 +188,7 @@ template <class T, class S> G29_FN T weaken(const S &s)
 
 // ---- multiplication ----
 template <int PB> constexpr u64 mul_vb(u64 va, u64 vb) { return PLAIN ? 2 : shl_ceil(va * vb, -Cfg<PB>::HEAD) + 1; }
+constexpr u64 P25519_MULX = 1ull << 17;   // what limb 1 of a 2^255 - 19 product may exceed the mask by
 constexpr u64 P448_MULX = 1ull << 10;     // what the lazy limbs of a no-headroom product (1 and 9 / 1) may exceed the mask by
 constexpr u32 TOPMASK28 = (1u << 28) - 1;  // top limb of the no-headroom flavours
 constexpr u64 CANON_TB = NOHEAD ? TOPMASK28 : MASK;   // top limb of a canonical value (< p)
@@ -195,7 +196,9 @@ template <int PB, u64 VBO> struct MulOut {
 	// 2^255 - 19 flavour: exact low digits, top limb < 2^23 + 2^12 (see mul_raw), value < 2p
 	// secp256k1 flavour: exact low digits, top limb < 2^24 + 2^17, value < 2p
 	// Goldilocks flavour: limbs 1 and 9 carry the (lazily added) high parts of the two wrap-around carries, see mul_p448
-	typedef E<PB, NOHEAD ? (MASK + P448_MULX) : MASK,
+	// 2^255 - 19 flavour: limb 1 takes the high part of the folded overflow lazily (see mul_p25519); the top limb is below 2^23 (the
+	// bound stays the round-2 one, which also covers a canonical constant's 2^23 + 1)
+	typedef E<PB, NOHEAD ? (MASK + P448_MULX) : (P25519 ? (MASK + P25519_MULX) : MASK),
 		  P25519 ? ((1ull << 23) + (1ull << 12)) : (K256 ? ((1ull << 24) + (1ull << 17)) : (NOHEAD ? (u64)TOPMASK28 : Cfg<PB>::top_from_vb(VBO))), VBO> type;
 };
 template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
@@ -608,6 +611,59 @@ template <bool SQR> G29_FN void mul_m521p(u32 *r, const u32 *a, const u32 *b)
 	r[1] += (u32)(w >> W) + (r0 >> W);
 }
 
+// ---- 2^255 - 19 flavour (nine 29-bit limbs, plain residues; 2^261 = 64 * 2^255 = 1216 mod p) ----
+// The high columns 9..16 of the product are summed FIRST, on a carry chain of their own: digits h[0..7] and the last carry h[8]
+// (< va vb 2^17 <= 2^31, Cfg::prod_ok).  The low columns then take 1216 h[k] as one more MAD of column k, so the fold costs no pass
+// of its own: 81 + 9 MADs and 17 column ends (round 2: 92 MADs, 26 column ends).  Column 8 -- with the carry of column 7 -- holds
+// everything from 2^232 up: its bits from 23 up are multiples of 2^255 = 19 and go to limbs 0 and 1 lazily (19 q < 2^46: limb 1 below
+// 2^29 + 2^17), the result is below 2^255 + 2^47 < 2p with a top limb below 2^23.
+template <bool SQR, int K_> G29_FN void p25519_column(u64 &acc, u32 *out, const u32 *a, const u32 *b, const u32 *a2, const u32 *h, u32 f)
+{
+	u64 acc2;
+	Column<9, SQR, K_>::products(acc, acc2, a, b, a2);
+	if constexpr (K_ < 9) {
+		G29_MAD_VS(acc, h[K_], f);
+	}
+	if constexpr (K_ != 8) {
+		out[K_ < 9 ? K_ : K_ - 9] = (u32)acc & MASK;
+		acc >>= W;
+	}
+}
+template <bool SQR, int... Ks> G29_FN void p25519_columns(u64 &acc, u32 *out, const u32 *a, const u32 *b, const u32 *a2, const u32 *h, u32 f,
+							  std::integer_sequence<int, Ks...>)
+{
+	(p25519_column<SQR, Ks>(acc, out, a, b, a2, h, f), ...);
+}
+template <bool SQR, int... Ks> G29_FN void p25519_hi_columns(u64 &acc, u32 *out, const u32 *a, const u32 *b, const u32 *a2, std::integer_sequence<int, Ks...>)
+{
+	(p25519_column<SQR, 9 + Ks>(acc, out, a, b, a2, nullptr, 0u), ...);
+}
+template <bool SQR> G29_FN void mul_p25519(u32 *r, const u32 *a, const u32 *b)
+{
+	u32 a2[9], h[9];
+	if (SQR) {
+#pragma unroll
+		for (int i = 0; i < 9; i++) {
+			a2[i] = a[i] << 1;
+		}
+	}
+	u32 f = 1216u;
+#if defined(__HIPCC__)
+	asm volatile("" : "+s"(f));  // keep the folds MADs
+#endif
+	u64 acc = 0;
+	p25519_hi_columns<SQR>(acc, h, a, b, a2, std::make_integer_sequence<int, 8>());      // columns 9..16
+	h[8] = (u32)acc;
+	acc = 0;
+	p25519_columns<SQR>(acc, r, a, b, a2, h, f, std::make_integer_sequence<int, 9>());    // columns 0..8 (8: products and fold only)
+	const u64 q = acc >> 23;                      // < 2^41
+	r[8] = (u32)acc & ((1u << 23) - 1);
+	const u64 w = (q << 4) + (q << 1) + q;        // 19 q < 2^46
+	const u32 r0 = r[0] + ((u32)w & MASK);
+	r[0] = r0 & MASK;
+	r[1] += (u32)(w >> W) + (r0 >> W);
+}
+
 template <int NL, bool SQR, int... Ks>
 G29_FN void mul_columns(u64 &acc, u32 *m, u32 *r, u32 *t, const u32 *a, const u32 *b, const u32 *a2, const u32 *p, u32 mpinv,
 			const int32_t *c384, std::integer_sequence<int, Ks...>)
@@ -629,6 +685,11 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 		mul_m521p<SQR>(r, a, b);
 		return;
 	}
+	if constexpr (P25519) {
+		static_assert(NL == 9, "2^255 - 19 flavour: 9 limbs");
+		mul_p25519<SQR>(r, a, b);
+		return;
+	}
 	u32 m[NL], a2[NL], t[2 * NL];
 	if (SQR) {
 #pragma unroll
@@ -644,29 +705,7 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 	}
 #endif
 	mul_columns<NL, SQR>(acc, m, r, t, a, b, a2, p, mpinv, c384, std::make_integer_sequence<int, 2 * NL - 1>());
-	if constexpr (P25519) {
-		// r = a b mod p, p = 2^255 - 19, value < 2p: the 81 product MADs gave 18 limbs t (17 columns + the
-		// last carry); now t[j] + 1216 t[j + 9] (2^261 = 64 * 2^255 = 1216) with 19 * (bits from 2^255 up)
-		// fed in at limb 0.
-		static_assert(NL == 9, "2^255 - 19 flavour: 9 limbs");
-		t[2 * NL - 1] = (u32)acc;  // < va vb 2^17 <= 2^31 (Cfg::prod_ok)
-		u32 f = 1216u, one1 = 1u;
-#if defined(__HIPCC__)
-		asm volatile("" : "+s"(f), "+s"(one1));  // keep the folds MADs (one1 only matters under -DG29_FOLD_MAD, see G29_MAD2_VS)
-#endif
-		// limb 8 without the carry from below: its bits from 23 up are multiples of 2^255 = 19
-		u64 top = t[NL - 1];
-		G29_MAD_VS(top, t[2 * NL - 1], f);
-		acc = (u64)((u32)(top >> 23)) * 19u;  // quotient < 64 + 19 va vb, times 19 < 2^23
-#pragma unroll
-		for (int j = 0; j < NL - 1; j++) {
-			G29_MAD2_VS(acc, t[j], one1, t[j + NL], f);
-			r[j] = (u32)acc & MASK;
-			acc >>= W;
-			G29_PIN(acc);
-		}
-		r[NL - 1] = ((u32)top & ((1u << 23) - 1)) + (u32)acc;  // carry in < 2^12
-	} else if constexpr (K256) {
+	if constexpr (K256) {
 		// r = a b mod p, p = 2^256 - c, c = 2^32 + 977, value < 2p.  18 product limbs t; modulo p
 		//   2^261 = 32 c = 2^8 2^29 + 31264:          t[j + 9] goes to limb j (x 31264) and limb j + 1 (x 256), j = 0..7
 		//   2^493 = 2^16 2^29 + 977 2^13 + 31264 2^232: t[17] goes to limbs 1 (x 2^16), 0 (x 8003584) and 8 (x 31264)
@@ -860,8 +899,8 @@ template <int PB, int S> constexpr int pick_logc(u64 lb_b, u64 tb_b)
 template <int S, class A, class B, int NLc> G29_FN auto sub_auto(const A &a, const B &b, const CurveG<NLc> &K)
 {
 	constexpr int logc = pick_logc<A::C::PBITS, S>(B::LB, B::TB);
-	if constexpr (logc < 0 && S == 1 && NOHEAD) {
-		// no-headroom flavours: a product's lazy limbs are a little over the limb width, so its double is a little over 2^(W+1)
+	if constexpr (logc < 0 && S == 1 && (NOHEAD || P25519)) {
+		// flavours whose products have lazy limbs a little over the limb width: the double of one is a little over 2^(W+1)
 		return sub_auto<2>(a, b, K);
 	} else {
 		static_assert(logc >= 0, "sub_auto: no tabulated bias dominates b (carry it first?)");
@@ -934,10 +973,26 @@ template <class A, int NLc> G29_FN auto sqrc(const A &a, const CurveG<NLc> &K)
 template <class A, int NLc> G29_FN void canonical_digits(u32 *d, const A &a, const CurveG<NLc> &K)
 {
 	constexpr int NL = A::C::NL;
-	static_assert((A::LB == MASK || (NOHEAD && A::LB <= MASK + P448_MULX)) && A::VB <= 3, "canonical_digits needs a multiplication result < 3p");
+	static_assert((A::LB == MASK || (NOHEAD && A::LB <= MASK + P448_MULX) || (P25519 && A::LB <= MASK + P25519_MULX)) && A::VB <= 3,
+		      "canonical_digits needs a multiplication result < 3p");
 #pragma unroll
 	for (int i = 0; i < NL; i++) {
 		d[i] = a.l[i];
+	}
+	if constexpr (P25519) {
+		// limb 1 is lazy and the value may reach 2^255 and a little more: exact carries with the bits from 2^255 up folded (x 19)
+		// to limb 0, twice, then the value is below 2^255 < 2p
+#pragma unroll
+		for (int round = 0; round < 2; round++) {
+			u32 c = 0;
+#pragma unroll
+			for (int i = 0; i < NL; i++) {
+				const u32 x = d[i] + c;
+				d[i] = x & (i < NL - 1 ? MASK : ((1u << 23) - 1));
+				c = x >> (i < NL - 1 ? W : 23);
+			}
+			d[0] += 19u * c;
+		}
 	}
 	if constexpr (NOHEAD) {
 		// some limbs are lazy and the value may reach 2^|p| and a little more: exact carries with the bits from 2^|p| up folded

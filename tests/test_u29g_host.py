@@ -124,7 +124,7 @@ def test_field_ops(lib, curve, flavour=0):
             vmax = max(0, f.vmax(f.va, f.fa_tb) - 1)
             lx = f.fa(rng, x, vmax)
             ly = f.fa(rng, y, vmax)
-        if it == 1 and flavour in (1, 5):   # every limb at the class bound (the value is then what it is: only the residue matters)
+        if it == 1 and flavour in (1, 2, 5):   # every limb at the class bound (the value is then what it is: only the residue matters)
             lx = [f.fa_lb] * (f.nl - 1) + [f.fa_tb]
             ly = [f.fa_lb] * (f.nl - 1) + [f.fa_tb]
             x, y = f.val(lx) % p, f.val(ly) % p
@@ -132,7 +132,8 @@ def test_field_ops(lib, curve, flavour=0):
         f.fn("mul")(f.k, arr(lx), arr(ly), out, 0)
         assert f.val(out) % p == f.val(lx) * f.val(ly) * f.Rinv % p
         # exact low digits -- on the Goldilocks unit limbs 1 and 9 keep the high parts of the two wrap-around carries (< 2^10)
-        slack = [(1 << 10) if ((flavour == 5 and i in (1, 9)) or (flavour == 1 and i == 1)) else 0 for i in range(f.nl)]
+        slack = [(1 << 10) if ((flavour == 5 and i in (1, 9)) or (flavour == 1 and i == 1)) else ((1 << 17) if (flavour == 2 and i == 1) else 0)
+                 for i in range(f.nl)]
         assert f.val(out) < 2 * p + (f.val(lx) * f.val(ly) >> (f.W * f.nl) if flavour not in (1, 5) else 0)
         assert all(v <= f.MASK + sl for v, sl in zip(list(out)[:-1], slack))
         f.fn("mul")(f.k, arr(lx), arr(lx), out, 1)
@@ -144,21 +145,23 @@ def test_field_ops(lib, curve, flavour=0):
         assert f.val(d) == v % p and max(d[:-1]) <= f.MASK
         n, _ = f.call("neg", f.digits(v))
         assert (f.val(n) + v) % p == 0 and max(n[:-1]) <= f.fa_lb and n[-1] <= f.fa_tb
-    if flavour in (1, 5):
+    if flavour in (1, 2, 5):
         # lazy representatives of a multiplication result: limbs 1 (and 9) over their width, values around 2^|p|
         top = 1 << f.pb
-        for v in (top - 1, top, top + 2**224, 2 * p - 1, p + 2**224 + 1, top + 5):
+        lazy = (1 << 17) if flavour == 2 else (1 << 10)      # P25519_MULX / P448_MULX
+        topbits = f.pb - f.W * (f.nl - 1)                     # 23 for 2^255 - 19, 28 for the no-headroom flavours
+        for v in (top - 1, top, top + 2**224, 2 * p - 1, p + 2**224 + 1, top + 5, top + 18, top + 19, top + 20):
             l = f.digits(v)
             for i in ((1, 9) if flavour == 5 else (1,)):
                 k = min(l[i + 1], 3)
                 l[i] += k << f.W
                 l[i + 1] -= k
-            if max(l[:-1]) <= f.MASK + (1 << 10) and l[-1] < (1 << 28):
+            if max(l[:-1]) <= f.MASK + lazy and l[-1] < (1 << topbits):
                 d, _ = f.call("canon", l)
                 assert f.val(d) == v % p and max(d) <= f.MASK, hex(v)
-        # the largest member of the class: every limb at its mask, the lazy ones at mask + 2^10 (value above 2^|p|)
-        for extra in ((1 << 10), 1, 0):
-            l = [f.MASK] * (f.nl - 1) + [(1 << 28) - 1]
+        # the largest member of the class: every limb at its mask, the lazy ones at mask + the slack (value above 2^|p|)
+        for extra in (lazy, 1, 0):
+            l = [f.MASK] * (f.nl - 1) + [(1 << topbits) - 1]
             for i in ((1, 9) if flavour == 5 else (1,)):
                 l[i] += extra
             d, _ = f.call("canon", l)
