@@ -1316,7 +1316,10 @@ __global__ __launch_bounds__(64) void k_xdh_prep_c25519(EcamdXdhPrepArgs A, int 
 #define XDH_REC_WORDS 20   /* X2 (9 limbs), Z2 (9 limbs), padding */
 #define XDH_FIN_K 8
 
-__global__ __launch_bounds__(64) void k_x25519_ladder(EcamdXdhLadderArgs A, int gslot)
+#ifndef X25519_OCC
+#define X25519_OCC   /* A/B hook: -DX25519_OCC='__attribute__((amdgpu_waves_per_eu(5,5)))' (tools/build_variant.py) */
+#endif
+__global__ __launch_bounds__(64) X25519_OCC void k_x25519_ladder(EcamdXdhLadderArgs A, int gslot)
 {
 	using namespace c25519;
 	const u32 i = blockIdx.x * 64 + threadIdx.x;
@@ -1768,7 +1771,10 @@ __global__ __launch_bounds__(64) void k_ed_decode_ed_c25519(EcamdEdDecodeArgs A,
 // [h]A per lane: table [1..8]A, signed window w = 4; the extended result goes to rec
 // phase 0: the table, phase 1: the window loop -- two launches, so that the table construction's register needs (256 VGPRs)
 // do not bound the loop's occupancy (113 VGPRs, four waves per SIMD): Ed25519 verification 51.9 -> 57.4 M/s
-template <int phase> __global__ __launch_bounds__(64) void k_ed_smul_c25519(EcamdEdSmulArgs A, int gslot)
+#ifndef ED_SMUL_WAVES
+#define ED_SMUL_WAVES 1   /* A/B hook: minimum waves per SIMD of the window loop (phase 1), -DED_SMUL_WAVES=4 (tools/build_variant.py) */
+#endif
+template <int phase> __global__ __launch_bounds__(64, phase == 1 ? ED_SMUL_WAVES : 1) void k_ed_smul_c25519(EcamdEdSmulArgs A, int gslot)
 {
 	using namespace c25519;
 	const u32 i = blockIdx.x * 64 + threadIdx.x;
