@@ -91,9 +91,9 @@ def work_model(curve_params, nw, slen, batch=1 << 20):
             M, S = nl * nl + nl, nl * (nl + 1) // 2 + nl
         if p == 2**448 - 2**224 - 1:                 # Goldilocks flavour: 16 limbs of 28 bits, phi^2 = phi + 1 folded inside the columns:
             M, S = nl * nl, 2 * 36 + 64              # 256 MADs; squaring a0^2 + a1^2 (36 each) and a1 (2 a0 + a1) (64), ecamd_u29g.h:mul_p448
-        if p == 2**256 - 2**32 - 977:                # secp256k1 flavour: 9 limbs, 2 + 3 + 3 + 6 * 2 = 20 fold MADs
+        if p == 2**256 - 2**32 - 977:                # secp256k1 flavour: 9 limbs, 9 + 8 + 2 = 19 fold MADs riding in the low columns
             nl = 9
-            M, S = nl * nl + 20, nl * (nl + 1) // 2 + 20
+            M, S = nl * nl + 19, nl * (nl + 1) // 2 + 19
         am3 = curve_params["a"] == p - 3 or iso_to_am3(p, curve_params["a"])
         dbl = (3, 4) if curve_params["a"] == 0 else ((4, 4) if am3 else (4, 6))
         add = (12, 4)

@@ -22,7 +22,7 @@ template <int PB> struct Cls {
 	// multiplication result is below 2p with limbs a little over their width; bias multiples are 4p and 8p)
 	static constexpr u64 VA = NOHEAD ? 2 : (PLAIN9 ? 48 : (4ull << LC));
 	// what a carried limb (no headroom, 2^255 - 19: or a product's lazy limb) may exceed the mask by
-	static constexpr u64 SLACK = NOHEAD ? (1ull << 11) : (P25519 ? (1ull << 18) : 8);
+	static constexpr u64 SLACK = NOHEAD ? (1ull << 11) : (P25519 ? (1ull << 18) : (K256 ? (1ull << 16) : 8));
 	typedef E<PB, MASK + SLACK, NOHEAD ? (TOPMASK28 + SLACK) : C::top_from_vb(VA), VA> FA;
 	typedef typename MulOut<PB, 2>::type FM;  // multiplication result (value < 2p, exact low digits)
 	typedef E<PB, MASK, CANON_TB, 1> FC;      // canonical constant

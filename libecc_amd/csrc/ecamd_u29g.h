@@ -188,6 +188,7 @@ template <class T, class S> G29_FN T weaken(const S &s)
 
 // ---- multiplication ----
 template <int PB> constexpr u64 mul_vb(u64 va, u64 vb) { return PLAIN ? 2 : shl_ceil(va * vb, -Cfg<PB>::HEAD) + 1; }
+constexpr u64 K256_MULX = 1ull << 15;     // what limb 2 of a secp256k1 product may exceed the mask by
 constexpr u64 P25519_MULX = 1ull << 17;   // what limb 1 of a 2^255 - 19 product may exceed the mask by
 constexpr u64 P448_MULX = 1ull << 10;     // what the lazy limbs of a no-headroom product (1 and 9 / 1) may exceed the mask by
 constexpr u32 TOPMASK28 = (1u << 28) - 1;  // top limb of the no-headroom flavours
@@ -198,7 +199,8 @@ template <int PB, u64 VBO> struct MulOut {
 	// Goldilocks flavour: limbs 1 and 9 carry the (lazily added) high parts of the two wrap-around carries, see mul_p448
 	// 2^255 - 19 flavour: limb 1 takes the high part of the folded overflow lazily (see mul_p25519); the top limb is below 2^23 (the
 	// bound stays the round-2 one, which also covers a canonical constant's 2^23 + 1)
-	typedef E<PB, NOHEAD ? (MASK + P448_MULX) : (P25519 ? (MASK + P25519_MULX) : MASK),
+	// secp256k1 flavour: limb 2 takes the last carries of the folded overflow lazily (see mul_k256); top-limb bound as in round 2
+	typedef E<PB, NOHEAD ? (MASK + P448_MULX) : (P25519 ? (MASK + P25519_MULX) : (K256 ? (MASK + K256_MULX) : MASK)),
 		  P25519 ? ((1ull << 23) + (1ull << 12)) : (K256 ? ((1ull << 24) + (1ull << 17)) : (NOHEAD ? (u64)TOPMASK28 : Cfg<PB>::top_from_vb(VBO))), VBO> type;
 };
 template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
@@ -350,18 +352,14 @@ template <int NL, int K_> G29_FN void p384s_reduction(u64 &acc, const u32 *m, co
 	}
 }
 
-template <int NL, bool SQR, int K_> G29_FN void mul_column(u64 &acc, u32 *m, u32 *r, u32 *t, const u32 *a, const u32 *b,
+template <int NL, bool SQR, int K_> G29_FN void mul_column(u64 &acc, u32 *m, u32 *r, const u32 *a, const u32 *b,
 							   const u32 *a2, const u32 *p, u32 mpinv, const int32_t *c384)
 {
+	static_assert(!PLAIN || NL < 0, "the plain-residue flavours have multipliers of their own");
 	typedef Column<NL, SQR, K_> C;
 	u64 acc2;  // written by the first chain that uses it (Z2), never read otherwise
 	C::products(acc, acc2, a, b, a2);
-	if constexpr (PLAIN) {
-		if constexpr (C::USES2_PROD) {
-			acc += acc2;
-		}
-		t[K_] = (u32)acc & MASK;
-	} else if constexpr (P384S) {
+	if constexpr (P384S) {
 		if constexpr (C::USES2_PROD) {
 			acc += acc2;
 		}
@@ -664,11 +662,79 @@ template <bool SQR> G29_FN void mul_p25519(u32 *r, const u32 *a, const u32 *b)
 	r[1] += (u32)(w >> W) + (r0 >> W);
 }
 
+// ---- secp256k1 flavour (p = 2^256 - 2^32 - 977, nine 29-bit limbs, plain residues) ----
+// The same order as above: high columns first (digits h[0..7], last carry h[8] < va vb 2^19 <= 2^31), then the low columns with the
+// fold riding in them.  2^261 = 32 (2^32 + 977) = 2^8 2^29 + 31264: h[k] goes to column k (x 31264) and column k + 1 (x 256); for
+// h[8] the second target is 2^261 again: columns 0 (x 256 x 31264 = 8003584) and 1 (x 2^16).  Column 8 -- with the carry of
+// column 7 -- holds everything from 2^232 up; its bits from 24 up (q < 2^40) are multiples of 2^256 = 8 2^29 + 977 and go to limbs 0
+// (977 q), 1 (8 q) and, as carries, 2: limb 2 below 2^29 + 2^15, the top limb below 2^24, value below 2p.
+// 81 + 19 MADs and 17 column ends (rounds 1-2: 101 MADs, 26 column ends).
+template <bool SQR, int K_> G29_FN void k256_column(u64 &acc, u32 *out, const u32 *a, const u32 *b, const u32 *a2, const u32 *h, const u32 *c)
+{
+	u64 acc2;
+	Column<9, SQR, K_>::products(acc, acc2, a, b, a2);
+	if constexpr (K_ < 9) {
+		G29_MAD_VS(acc, h[K_], c[0]);               // x 31264
+		if constexpr (K_ >= 1) {
+			G29_MAD_VS(acc, h[K_ - 1], c[1]);   // x 256
+		}
+		if constexpr (K_ == 0) {
+			G29_MAD_VS(acc, h[8], c[2]);        // x 8003584
+		}
+		if constexpr (K_ == 1) {
+			G29_MAD_VS(acc, h[8], c[3]);        // x 65536
+		}
+	}
+	if constexpr (K_ != 8) {
+		out[K_ < 9 ? K_ : K_ - 9] = (u32)acc & MASK;
+		acc >>= W;
+	}
+}
+template <bool SQR, int... Ks> G29_FN void k256_columns(u64 &acc, u32 *out, const u32 *a, const u32 *b, const u32 *a2, const u32 *h, const u32 *c,
+							std::integer_sequence<int, Ks...>)
+{
+	(k256_column<SQR, Ks>(acc, out, a, b, a2, h, c), ...);
+}
+template <bool SQR, int... Ks> G29_FN void k256_hi_columns(u64 &acc, u32 *out, const u32 *a, const u32 *b, const u32 *a2, std::integer_sequence<int, Ks...>)
+{
+	(k256_column<SQR, 9 + Ks>(acc, out, a, b, a2, nullptr, nullptr), ...);
+}
+template <bool SQR> G29_FN void mul_k256(u32 *r, const u32 *a, const u32 *b)
+{
+	u32 a2[9], h[9];
+	if (SQR) {
+#pragma unroll
+		for (int i = 0; i < 9; i++) {
+			a2[i] = a[i] << 1;
+		}
+	}
+	u32 c[5] = {31264u, 256u, 8003584u, 65536u, 977u};
+#if defined(__HIPCC__)
+	asm volatile("" : "+s"(c[0]), "+s"(c[1]), "+s"(c[2]), "+s"(c[3]), "+s"(c[4]));  // keep the folds MADs
+#endif
+	u64 acc = 0;
+	k256_hi_columns<SQR>(acc, h, a, b, a2, std::make_integer_sequence<int, 8>());         // columns 9..16
+	h[8] = (u32)acc;
+	acc = 0;
+	k256_columns<SQR>(acc, r, a, b, a2, h, c, std::make_integer_sequence<int, 9>());      // columns 0..8 (8: products and folds only)
+	const u64 q = acc >> 24;                      // < 2^40
+	r[8] = (u32)acc & ((1u << 24) - 1);
+	u64 w0;                                       // 977 q < 2^50
+	G29_MUL_VS(w0, (u32)q, c[4]);
+	w0 += (u64)((u32)(q >> 32) * 977u) << 32;
+	const u64 w1 = q << 3;                        // 8 q < 2^43
+	const u32 r0 = r[0] + ((u32)w0 & MASK);
+	r[0] = r0 & MASK;
+	const u32 r1 = r[1] + (u32)(w0 >> W) + (r0 >> W) + ((u32)w1 & MASK);   // < 2^29 + 2^21 + 1 + 2^29
+	r[1] = r1 & MASK;
+	r[2] += (u32)(w1 >> W) + (r1 >> W);           // + < 2^14 + 2
+}
+
 template <int NL, bool SQR, int... Ks>
-G29_FN void mul_columns(u64 &acc, u32 *m, u32 *r, u32 *t, const u32 *a, const u32 *b, const u32 *a2, const u32 *p, u32 mpinv,
+G29_FN void mul_columns(u64 &acc, u32 *m, u32 *r, const u32 *a, const u32 *b, const u32 *a2, const u32 *p, u32 mpinv,
 			const int32_t *c384, std::integer_sequence<int, Ks...>)
 {
-	(mul_column<NL, SQR, Ks>(acc, m, r, t, a, b, a2, p, mpinv, c384), ...);
+	(mul_column<NL, SQR, Ks>(acc, m, r, a, b, a2, p, mpinv, c384), ...);
 }
 
 // r = a b / R mod p (lazy): product scanning with the reduction interleaved.  SQR: a == b, the
@@ -678,72 +744,32 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 	if constexpr (P448) {
 		static_assert(NL == 16, "Goldilocks flavour: 16 limbs");
 		mul_p448<SQR>(r, a, b);
-		return;
-	}
-	if constexpr (M521P) {
+	} else if constexpr (M521P) {
 		static_assert(NL == 18, "plain Mersenne flavour: 18 limbs");
 		mul_m521p<SQR>(r, a, b);
-		return;
-	}
-	if constexpr (P25519) {
+	} else if constexpr (P25519) {
 		static_assert(NL == 9, "2^255 - 19 flavour: 9 limbs");
 		mul_p25519<SQR>(r, a, b);
-		return;
-	}
-	u32 m[NL], a2[NL], t[2 * NL];
-	if (SQR) {
-#pragma unroll
-		for (int i = 0; i < NL; i++) {
-			a2[i] = a[i] << 1;
-		}
-	}
-	u64 acc = 0;
-	int32_t c384[4] = {8, -512, -4096, 128};  // secp384r1 flavour: the signed digits of p + 1, kept opaque so that they stay MAD operands
-#if defined(__HIPCC__)
-	if (P384S) {
-		asm volatile("" : "+s"(c384[0]), "+s"(c384[1]), "+s"(c384[2]), "+s"(c384[3]));
-	}
-#endif
-	mul_columns<NL, SQR>(acc, m, r, t, a, b, a2, p, mpinv, c384, std::make_integer_sequence<int, 2 * NL - 1>());
-	if constexpr (K256) {
-		// r = a b mod p, p = 2^256 - c, c = 2^32 + 977, value < 2p.  18 product limbs t; modulo p
-		//   2^261 = 32 c = 2^8 2^29 + 31264:          t[j + 9] goes to limb j (x 31264) and limb j + 1 (x 256), j = 0..7
-		//   2^493 = 2^16 2^29 + 977 2^13 + 31264 2^232: t[17] goes to limbs 1 (x 2^16), 0 (x 8003584) and 8 (x 31264)
-		//   2^256 = 8 2^29 + 977:                       the bits of limb 8 from 24 up (q) go to limbs 1 (x 8) and 0 (x 977)
+	} else if constexpr (K256) {
 		static_assert(NL == 9, "secp256k1 flavour: 9 limbs");
-		t[2 * NL - 1] = (u32)acc;  // < va vb 2^19 <= 2^31 (Cfg::prod_ok)
-		u32 f = 31264u, g = 256u, f17 = 8003584u, g17 = 65536u, fq = 977u, one1 = 1u, eight = 8u;
-#if defined(__HIPCC__)
-		asm volatile("" : "+s"(f), "+s"(g), "+s"(f17), "+s"(g17), "+s"(fq), "+s"(one1), "+s"(eight));  // keep the folds MADs
-#endif
-		// limb 8 without the carry from below: < 2^29 + 2^37 + 2^46
-		u64 top = t[NL - 1];
-		G29_MAD_VS(top, t[2 * NL - 2], g);
-		G29_MAD_VS(top, t[2 * NL - 1], f);
-		const u32 q = (u32)(top >> 24);  // < 2^23
-		G29_MUL_VS(acc, q, fq);
-		G29_MAD2_VS(acc, t[0], one1, t[NL], f);
-		G29_MAD_VS(acc, t[2 * NL - 1], f17);
-		r[0] = (u32)acc & MASK;
-		acc >>= W;
-		G29_PIN(acc);
-		G29_MAD2_VS(acc, t[1], one1, q, eight);
-		G29_MAD_VS(acc, t[NL + 1], f);
-		G29_MAD_VS(acc, t[NL], g);
-		G29_MAD_VS(acc, t[2 * NL - 1], g17);
-		r[1] = (u32)acc & MASK;
-		acc >>= W;
-		G29_PIN(acc);
-#pragma unroll
-		for (int j = 2; j < NL - 1; j++) {
-			G29_MAD2_VS(acc, t[j], one1, t[j + NL], f);
-			G29_MAD_VS(acc, t[j + NL - 1], g);
-			r[j] = (u32)acc & MASK;
-			acc >>= W;
-			G29_PIN(acc);
-		}
-		r[NL - 1] = ((u32)top & ((1u << 24) - 1)) + (u32)acc;  // carry in < 2^17
+		mul_k256<SQR>(r, a, b);
 	} else {
+		// Montgomery flavours: product scanning with the reduction interleaved, one pass over 2 NL - 1 columns
+		u32 m[NL], a2[NL];
+		if (SQR) {
+#pragma unroll
+			for (int i = 0; i < NL; i++) {
+				a2[i] = a[i] << 1;
+			}
+		}
+		u64 acc = 0;
+		int32_t c384[4] = {8, -512, -4096, 128};  // secp384r1 flavour: the signed digits of p + 1, kept opaque so that they stay MAD operands
+#if defined(__HIPCC__)
+		if (P384S) {
+			asm volatile("" : "+s"(c384[0]), "+s"(c384[1]), "+s"(c384[2]), "+s"(c384[3]));
+		}
+#endif
+		mul_columns<NL, SQR>(acc, m, r, a, b, a2, p, mpinv, c384, std::make_integer_sequence<int, 2 * NL - 1>());
 		r[NL - 1] = (u32)acc;
 	}
 }
@@ -899,7 +925,7 @@ template <int PB, int S> constexpr int pick_logc(u64 lb_b, u64 tb_b)
 template <int S, class A, class B, int NLc> G29_FN auto sub_auto(const A &a, const B &b, const CurveG<NLc> &K)
 {
 	constexpr int logc = pick_logc<A::C::PBITS, S>(B::LB, B::TB);
-	if constexpr (logc < 0 && S == 1 && (NOHEAD || P25519)) {
+	if constexpr (logc < 0 && S == 1 && (NOHEAD || PLAIN9)) {
 		// flavours whose products have lazy limbs a little over the limb width: the double of one is a little over 2^(W+1)
 		return sub_auto<2>(a, b, K);
 	} else {
@@ -973,7 +999,8 @@ template <class A, int NLc> G29_FN auto sqrc(const A &a, const CurveG<NLc> &K)
 template <class A, int NLc> G29_FN void canonical_digits(u32 *d, const A &a, const CurveG<NLc> &K)
 {
 	constexpr int NL = A::C::NL;
-	static_assert((A::LB == MASK || (NOHEAD && A::LB <= MASK + P448_MULX) || (P25519 && A::LB <= MASK + P25519_MULX)) && A::VB <= 3,
+	static_assert((A::LB == MASK || (NOHEAD && A::LB <= MASK + P448_MULX) || (P25519 && A::LB <= MASK + P25519_MULX) ||
+		       (K256 && A::LB <= MASK + K256_MULX)) && A::VB <= 3,
 		      "canonical_digits needs a multiplication result < 3p");
 #pragma unroll
 	for (int i = 0; i < NL; i++) {
@@ -992,6 +1019,22 @@ template <class A, int NLc> G29_FN void canonical_digits(u32 *d, const A &a, con
 				c = x >> (i < NL - 1 ? W : 23);
 			}
 			d[0] += 19u * c;
+		}
+	}
+	if constexpr (K256) {
+		// limb 2 is lazy and the value may reach 2^256 and a little more: exact carries with the bits from 2^256 up folded
+		// (x 977 to limb 0, x 8 to limb 1), twice, then the value is below 2^256 < 2p
+#pragma unroll
+		for (int round = 0; round < 2; round++) {
+			u32 c = 0;
+#pragma unroll
+			for (int i = 0; i < NL; i++) {
+				const u32 x = d[i] + c;
+				d[i] = x & (i < NL - 1 ? MASK : ((1u << 24) - 1));
+				c = x >> (i < NL - 1 ? W : 24);
+			}
+			d[0] += 977u * c;
+			d[1] += 8u * c;
 		}
 	}
 	if constexpr (NOHEAD) {

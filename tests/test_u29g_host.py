@@ -124,7 +124,7 @@ def test_field_ops(lib, curve, flavour=0):
             vmax = max(0, f.vmax(f.va, f.fa_tb) - 1)
             lx = f.fa(rng, x, vmax)
             ly = f.fa(rng, y, vmax)
-        if it == 1 and flavour in (1, 2, 5):   # every limb at the class bound (the value is then what it is: only the residue matters)
+        if it == 1 and flavour in (1, 2, 4, 5):   # every limb at the class bound (the value is then what it is: only the residue matters)
             lx = [f.fa_lb] * (f.nl - 1) + [f.fa_tb]
             ly = [f.fa_lb] * (f.nl - 1) + [f.fa_tb]
             x, y = f.val(lx) % p, f.val(ly) % p
@@ -132,8 +132,8 @@ def test_field_ops(lib, curve, flavour=0):
         f.fn("mul")(f.k, arr(lx), arr(ly), out, 0)
         assert f.val(out) % p == f.val(lx) * f.val(ly) * f.Rinv % p
         # exact low digits -- on the Goldilocks unit limbs 1 and 9 keep the high parts of the two wrap-around carries (< 2^10)
-        slack = [(1 << 10) if ((flavour == 5 and i in (1, 9)) or (flavour == 1 and i == 1)) else ((1 << 17) if (flavour == 2 and i == 1) else 0)
-                 for i in range(f.nl)]
+        slack = [(1 << 10) if ((flavour == 5 and i in (1, 9)) or (flavour == 1 and i == 1)) else
+                 ((1 << 17) if (flavour == 2 and i == 1) else ((1 << 15) if (flavour == 4 and i == 2) else 0)) for i in range(f.nl)]
         assert f.val(out) < 2 * p + (f.val(lx) * f.val(ly) >> (f.W * f.nl) if flavour not in (1, 5) else 0)
         assert all(v <= f.MASK + sl for v, sl in zip(list(out)[:-1], slack))
         f.fn("mul")(f.k, arr(lx), arr(lx), out, 1)
@@ -145,14 +145,17 @@ def test_field_ops(lib, curve, flavour=0):
         assert f.val(d) == v % p and max(d[:-1]) <= f.MASK
         n, _ = f.call("neg", f.digits(v))
         assert (f.val(n) + v) % p == 0 and max(n[:-1]) <= f.fa_lb and n[-1] <= f.fa_tb
-    if flavour in (1, 2, 5):
-        # lazy representatives of a multiplication result: limbs 1 (and 9) over their width, values around 2^|p|
+    if flavour in (1, 2, 4, 5):
+        # lazy representatives of a multiplication result: limbs 1 (and 9; secp256k1: 2) over their width, values around 2^|p|
         top = 1 << f.pb
-        lazy = (1 << 17) if flavour == 2 else (1 << 10)      # P25519_MULX / P448_MULX
-        topbits = f.pb - f.W * (f.nl - 1)                     # 23 for 2^255 - 19, 28 for the no-headroom flavours
-        for v in (top - 1, top, top + 2**224, 2 * p - 1, p + 2**224 + 1, top + 5, top + 18, top + 19, top + 20):
+        lazy = {2: 1 << 17, 4: 1 << 15}.get(flavour, 1 << 10)     # P25519_MULX / K256_MULX / P448_MULX
+        topbits = f.pb - f.W * (f.nl - 1)                     # 23 for 2^255 - 19, 24 for secp256k1, 28 for the no-headroom flavours
+        lazy_limbs = {5: (1, 9), 4: (2,)}.get(flavour, (1,))
+        for v in (top - 1, top, top + 2**224, 2 * p - 1, p + 2**224 + 1, top + 5, top + 18, top + 19, top + 20, top + 2**32 + 976,
+                  top + 2**32 + 977, top + 2**32 + 978):
+            v = min(v, 2 * p - 1)
             l = f.digits(v)
-            for i in ((1, 9) if flavour == 5 else (1,)):
+            for i in lazy_limbs:
                 k = min(l[i + 1], 3)
                 l[i] += k << f.W
                 l[i + 1] -= k
@@ -162,7 +165,7 @@ def test_field_ops(lib, curve, flavour=0):
         # the largest member of the class: every limb at its mask, the lazy ones at mask + the slack (value above 2^|p|)
         for extra in (lazy, 1, 0):
             l = [f.MASK] * (f.nl - 1) + [(1 << topbits) - 1]
-            for i in ((1, 9) if flavour == 5 else (1,)):
+            for i in lazy_limbs:
                 l[i] += extra
             d, _ = f.call("canon", l)
             assert f.val(d) == f.val(l) % p and max(d) <= f.MASK
