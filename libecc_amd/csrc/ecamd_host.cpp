@@ -227,6 +227,11 @@ struct ecamd_ctx {
 	// host-pointer entry points: chunks of host_chunk items, the copy of chunk c+1 overlaps the kernels of chunk c
 	hipStream_t copy_stream;
 	hipEvent_t in_ready[2];
+	// ECDSA verification: k_ecdsa_prep (s^-1, u1, u2 mod q: a few waves per SIMD, compute only) runs on this stream beside the
+	// bandwidth-bound table / affine kernels of the same chunk; the window loop waits for side_done ($ECAMD_NO_SIDE_STREAM: off)
+	hipStream_t side_stream;
+	hipEvent_t side_fork, side_done;
+	bool side_ok;
 	uint32_t host_chunk;
 	uint8_t *hbuf[2][6];       // double-buffered device staging of the caller's arrays (inputs and outputs)
 	size_t hbuf_bytes[2][6];
@@ -397,6 +402,13 @@ extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
 		delete c;
 		return fail("ecamd_ctx_create: hipStreamCreate failed");
 	}
+	if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->side_done, hipEventDisableTiming) != hipSuccess) {
+		delete c;
+		return fail("ecamd_ctx_create: side stream creation failed");
+	}
+	c->side_ok = getenv("ECAMD_NO_SIDE_STREAM") == nullptr;
 	*out = c;
 	return 0;
 }
@@ -429,6 +441,10 @@ extern "C" void ecamd_ctx_destroy(ecamd_ctx *c)
 	(void)hipEventDestroy(c->ev_dom[1]);
 	(void)hipStreamDestroy(c->stream);
 	(void)hipStreamDestroy(c->copy_stream);
+	(void)hipStreamSynchronize(c->side_stream);
+	(void)hipStreamDestroy(c->side_stream);
+	(void)hipEventDestroy(c->side_fork);
+	(void)hipEventDestroy(c->side_done);
 	(void)hipEventDestroy(c->in_ready[0]);
 	(void)hipEventDestroy(c->in_ready[1]);
 	(void)hipEventDestroy(c->busy);
@@ -798,7 +814,8 @@ static void release_modulus(int device, int nw, int slot)
 
 static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_scalars, uint32_t slen,
 			   const uint8_t *d_points, uint8_t *d_out, uint8_t *d_status, hipStream_t s,
-			   uint32_t sstride = 0xffffffffu, bool redo_only = false, const uint8_t *d_scalars2 = nullptr);
+			   uint32_t sstride = 0xffffffffu, bool redo_only = false, const uint8_t *d_scalars2 = nullptr,
+			   hipEvent_t scalars_ready = nullptr);
 
 // w-bit digits of a (nl of them, the last one takes whatever is left): 29 bits on every radix-2^29 unit but the Goldilocks one
 // (flavour 5), which runs on 28-bit limbs so that 2^224 falls on a limb boundary (ecamd_u29g.h)
@@ -1272,7 +1289,7 @@ static void maybe_build_comb(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n)
 // sstride = slen normally; 0 broadcasts one scalar to every item (subgroup / cofactor passes)
 static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_scalars,
 			   uint32_t slen, const uint8_t *d_points, uint8_t *d_out, uint8_t *d_status,
-			   hipStream_t s, uint32_t sstride, bool redo_only, const uint8_t *d_scalars2)
+			   hipStream_t s, uint32_t sstride, bool redo_only, const uint8_t *d_scalars2, hipEvent_t scalars_ready)
 {
 	// d_scalars2 (generic radix-2^29 units with a comb table, see fused_verify_ok): out = [scalars]P + [scalars2]G by the fused
 	// window loop; items that met an exceptional pair keep ECAMD_STATUS_REDO in d_status for the caller (no complete-formula pass here)
@@ -1335,6 +1352,10 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 		A.masked = secret ? 1 : 0;   // (copied into Fa below: the secp256r1 loop honours it too)
 		A.scalars2 = nullptr;
 		A.s2len = 0;
+		A.scalars_ready = nullptr;
+		if (scalars_ready && !d_scalars2) {
+			return fail("internal: only the fused double-scalar loop takes its scalars from another stream");
+		}
 		if (d_scalars2) {
 			if (!fastg || !d_points || !cv->d_comb) {
 				return fail("internal: fused double-scalar loop requested without its preconditions");
@@ -1347,6 +1368,7 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 			Fa.scalars2 = d_scalars2 + (size_t)off * slen;
 			Fa.s2len = slen;
 			Fa.masked = 0;
+			Fa.scalars_ready = (void *)scalars_ready;
 			hipEvent_t *ev = (ctx->timing && off == 0) ? ctx->ev : nullptr;
 			HIPCHK(ecamd_launch_smul_g29(cv->pbits, cv->gslot, Fa, s, ev, cv->gflavour));
 			ctx->ev_valid = ctx->ev_valid || (ev != nullptr);
@@ -1757,6 +1779,28 @@ static int ecdsa_two_smul_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n,
 	return 0;
 }
 
+// k_ecdsa_prep of a chunk on the side stream: it starts when everything enqueued on s so far is done (the stage buffers it
+// writes are read by the previous chunk's loop) and the caller makes the consumer of u1 / u2 wait for side_done.
+// Returns the event to wait for, or nullptr when the kernel was enqueued on s itself.
+static hipEvent_t ecdsa_prep_beside(ecamd_ctx *ctx, int qnw, const EcamdEcdsaPrepArgs &P, hipStream_t s, hipError_t *err)
+{
+	if (!ctx->side_ok) {
+		*err = ecamd_launch_ecdsa_prep(qnw, P, s);
+		return nullptr;
+	}
+	*err = hipEventRecord(ctx->side_fork, s);
+	if (*err == hipSuccess) {
+		*err = hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0);
+	}
+	if (*err == hipSuccess) {
+		*err = ecamd_launch_ecdsa_prep(qnw, P, ctx->side_stream);
+	}
+	if (*err == hipSuccess) {
+		*err = hipEventRecord(ctx->side_done, ctx->side_stream);
+	}
+	return ctx->side_done;
+}
+
 // device pointers in and out; only enqueues on s
 // The fused double-scalar loop of the generic radix-2^29 units (k_loop_g then k_comb_add_g): curves on the affine-table pipeline (every
 // flavour but the two nine-limb ones), prime-order groups (no subgroup check of the key to run beside it), u1 within the comb
@@ -1819,8 +1863,10 @@ static int ecdsa_fused_g_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, 
 		P.qbits = (uint32_t)cv->qbits;
 		P.qslot = cv->qslot;
 		P.only = nullptr;
-		HIPCHK(ecamd_launch_ecdsa_prep(cv->qnw, P, s));
-		if (smul_dev_locked(ctx, cv, m, S[4], (uint32_t)ql, d_pub + (size_t)off * plen, S[5], S[7], s, 0xffffffffu, false, S[3])) {
+		hipError_t perr = hipSuccess;
+		const hipEvent_t prep_done = ecdsa_prep_beside(ctx, cv->qnw, P, s, &perr);   // beside the table and affine kernels
+		HIPCHK(perr);
+		if (smul_dev_locked(ctx, cv, m, S[4], (uint32_t)ql, d_pub + (size_t)off * plen, S[5], S[7], s, 0xffffffffu, false, S[3], prep_done)) {
 			return -1;
 		}
 		HIPCHK(hipMemsetAsync(S[8], 2, m, s));
@@ -1895,7 +1941,9 @@ static int ecdsa_verify_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 		P.qbits = (uint32_t)cv->qbits;
 		P.qslot = cv->qslot;
 		P.only = nullptr;
-		HIPCHK(ecamd_launch_ecdsa_prep(cv->qnw, P, s));
+		hipError_t perr = hipSuccess;
+		const hipEvent_t prep_done = ecdsa_prep_beside(ctx, cv->qnw, P, s, &perr);
+		HIPCHK(perr);
 		EcamdSmulArgs K;
 		memset(&K, 0, sizeof(K));
 		K.points = d_pub + (size_t)off * 64;
@@ -1909,7 +1957,7 @@ static int ecdsa_verify_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 		K.slot = cv->slot;
 		hipEvent_t *dom = (ctx->timing && off == 0) ? ctx->ev_dom : nullptr;
 		HIPCHK(ecamd_launch_verify_p256(K, S[3], S[4], d_sig + (size_t)off * 64, S[5],
-						cv->d_comb ? cv->d_comb : cv->d_gtab, cv->d_comb ? 1 : 0, cv->qdig, d_res + off, s, dom));
+						cv->d_comb ? cv->d_comb : cv->d_gtab, cv->d_comb ? 1 : 0, cv->qdig, d_res + off, s, dom, prep_done));
 		ctx->ev_dom_valid = ctx->ev_dom_valid || (dom != nullptr);
 	}
 	// exceptional pairs inside the interleaved loop (never for honest signatures) come back as ECAMD_STATUS_REDO: those

@@ -29,6 +29,8 @@ struct EcamdSmulArgs {
 	int masked;              // generic kernel: secret scalars -- constant-address (full-scan, masked) table look-ups
 	const uint8_t *scalars2; // lut_kind 2: n x s2len big-endian multipliers of the generator
 	uint32_t s2len;
+	void *scalars_ready;     // host side only (a hipEvent_t or NULL): the kernels that read the scalars wait for it -- the table and
+	                         // affine kernels before them do not (lut_kind 2: the scalars come from k_ecdsa_prep on another stream)
 };
 #define ECAMD_COMB_ENTRIES (16u * 32768u + 1u)
 
@@ -90,7 +92,7 @@ hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s, hipEven
 // qdigits = group order in radix 2^29; result 0 accept / 1 reject / ECAMD_STATUS_REDO
 hipError_t ecamd_launch_verify_p256(const EcamdSmulArgs &pubkeys, const uint8_t *u1, const uint8_t *u2, const uint8_t *sigs,
 				    const uint8_t *flags, const uint32_t *gtbl, int gtbl_is_comb, const uint32_t *qdigits,
-				    uint8_t *result, hipStream_t s, hipEvent_t *dom = nullptr);
+				    uint8_t *result, hipStream_t s, hipEvent_t *dom = nullptr, hipEvent_t scalars_ready = nullptr);
 // affine big-endian points -> comb table entries (Montgomery radix-2^29 digits, 20 words each)
 hipError_t ecamd_launch_comb_build_p256(const uint8_t *points, uint32_t n, uint32_t *table, hipStream_t s);
 // ---- X25519 / X448 (ecdh/x25519_448.c:146-302 of the reference) around the scalar multiplication ----

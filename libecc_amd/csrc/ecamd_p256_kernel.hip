@@ -871,10 +871,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P256_WAVES, 
 
 hipError_t ecamd_launch_verify_p256(const EcamdSmulArgs &pubkeys, const uint8_t *u1, const uint8_t *u2, const uint8_t *sigs,
 				    const uint8_t *flags, const uint32_t *gtbl, int gtbl_is_comb, const uint32_t *qdigits,
-				    uint8_t *result, hipStream_t s, hipEvent_t *dom)
+				    uint8_t *result, hipStream_t s, hipEvent_t *dom, hipEvent_t scalars_ready)
 {
 	if (pubkeys.n == 0) {
-		return hipSuccess;
+		return scalars_ready ? hipStreamWaitEvent(s, scalars_ready, 0) : hipSuccess;
 	}
 	const dim3 grid((pubkeys.n + 63) / 64), block(64);
 	const uint32_t athreads = (((pubkeys.n + AFF_K - 1) / AFF_K) + 63u) & ~63u;
@@ -892,6 +892,13 @@ hipError_t ecamd_launch_verify_p256(const EcamdSmulArgs &pubkeys, const uint8_t 
 	V.n = pubkeys.n;
 	for (int w = 0; w < 9; w++) {
 		V.qd[w] = qdigits[w];
+	}
+	if (scalars_ready) {
+		// u1, u2 and the flags come from k_ecdsa_prep on the context's side stream (it ran beside the two kernels above)
+		const hipError_t e = hipStreamWaitEvent(s, scalars_ready, 0);
+		if (e != hipSuccess) {
+			return e;
+		}
 	}
 	if (dom) {
 		(void)hipEventRecord(dom[0], s);
