@@ -2816,12 +2816,6 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_TAG)(int gslot, const EcamdSmulArgs &a
 			(void)hipEventRecord(ev[2], s);
 		}
 		if (a.lut && a.lut_kind == 2) {
-			if (a.scalars_ready) {
-				const hipError_t e = hipStreamWaitEvent(s, (hipEvent_t)a.scalars_ready, 0);
-				if (e != hipSuccess) {
-					return e;
-				}
-			}
 			// [u2]Q by the window loop, then + [u1]G from the comb table
 			hipLaunchKernelGGL((k_loop_g<G29_PB, G29_FLAV, false>), grid, block, 0, s, a, gslot);
 			hipLaunchKernelGGL((k_comb_add_g<G29_PB, G29_FLAV>), grid, block, 0, s, a, gslot);

@@ -29,8 +29,6 @@ struct EcamdSmulArgs {
 	int masked;              // generic kernel: secret scalars -- constant-address (full-scan, masked) table look-ups
 	const uint8_t *scalars2; // lut_kind 2: n x s2len big-endian multipliers of the generator
 	uint32_t s2len;
-	void *scalars_ready;     // host side only (a hipEvent_t or NULL): the kernels that read the scalars wait for it -- the table and
-	                         // affine kernels before them do not (lut_kind 2: the scalars come from k_ecdsa_prep on another stream)
 };
 #define ECAMD_COMB_ENTRIES (16u * 32768u + 1u)
 
