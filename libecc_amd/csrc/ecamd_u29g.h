@@ -222,33 +222,16 @@ template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
 	return la == 0 || lb <= ((0xFFFFFFFFFFFFFFFFull - (u64)NL * (1ull << 58) - (1ull << 36)) / NL) / la;
 }
 
+// single MADs with a wave-uniform multiplier (fold constants; hipcc pads every asm statement with an s_nop, so the product columns
+// use the chains of ecamd_madchain.h instead)
 #if defined(__HIPCC__) && defined(U29_ASM_MAD)
-#define G29_MAD_VV(acc, a, b) \
-	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(dead_) : "v"(a), "v"(b)); } while (0)
 #define G29_MAD_VS(acc, a, b) \
 	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(dead_) : "v"(a), "s"(b)); } while (0)
-#define G29_MUL_VV(acc, a, b) \
-	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(acc), "=s"(dead_) : "v"(a), "v"(b)); } while (0)
 #define G29_MUL_VS(acc, a, b) \
 	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(acc), "=s"(dead_) : "v"(a), "s"(b)); } while (0)
-// "acc += a1; acc += a2 * b2" of a fold (every use has b1 = 1).  The 64-bit addition is ONE instruction on gfx950
-// (v_lshl_add_u64); -DG29_FOLD_MAD makes it a MAD by one instead, paired with the next MAD in one asm statement -- measured
-// 1 % SLOWER on all three plain-residue units (profiles/r3d_variants.md), so the addition stays
-#ifndef G29_FOLD_MAD
-#define G29_MAD2_VS(acc, a1, b1, a2, b2) \
-	do { acc += (a1); G29_MAD_VS(acc, a2, b2); } while (0)
 #else
-#define G29_MAD2_VS(acc, a1, b1, a2, b2) \
-	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0" : "+v"(acc), "=&s"(dead_) : "v"(a1), "s"(b1), "v"(a2), "s"(b2)); } while (0)
-#endif
-#define G29_PIN(acc) asm("" : "+v"(acc))
-#else
-#define G29_MAD2_VS(acc, a1, b1, a2, b2) acc += (u64)(a1) * (b1) + (u64)(a2) * (b2)
-#define G29_MUL_VV(acc, a, b) acc = (u64)(a) * (b)
 #define G29_MUL_VS(acc, a, b) acc = (u64)(a) * (b)
-#define G29_MAD_VV(acc, a, b) acc += (u64)(a) * (b)
 #define G29_MAD_VS(acc, a, b) acc += (u64)(a) * (b)
-#define G29_PIN(acc) (void)0
 #endif
 
 // ---- multiply-accumulate chains (ecamd_madchain.h): a column's products go out in asm statements of up
