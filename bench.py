@@ -165,11 +165,14 @@ def measured_mad_peak():
         return None, None
 
 
-def mix_peak(ub, sgpr_share):
+def mix_peak(ub, sgpr_share, signed=False):
     """The MAD issue ceiling for a kernel whose MADs are `sgpr_share` SGPR-multiplier and the rest VGPR-multiplier: the two
-    measured streams weighted by their share of the instruction count (issue time adds up)."""
+    measured streams weighted by their share of the instruction count (issue time adds up).
+    signed: the SGPR-multiplier MADs are v_mad_i64_i32 (secp384r1's reduction) -- its own measured stream when ubench has it."""
     pv = ub["v_mad_u64_u32"]["lane_ops_per_s"]
     ps = ub.get("v_mad_u64_u32_sgpr", {}).get("lane_ops_per_s")
+    if signed:
+        ps = ub.get("v_mad_i64_i32_sgpr", {}).get("lane_ops_per_s") or ps
     if not ps or sgpr_share <= 0.0:
         return pv
     return 1.0 / ((1.0 - sgpr_share) / pv + sgpr_share / ps)
@@ -577,7 +580,7 @@ def main():
         # the MAD issue peak is a per-GPU number: measured on rank 0's GPU after the timed region
         peak_v, ub = measured_mad_peak()
         sg = getattr(work_model, "loop_sgpr_share", 0.0) if kt is not None else 0.0
-        peak = mix_peak(ub, sg) if ub else None
+        peak = mix_peak(ub, sg, signed=(cp["p"] == 2**384 - 2**128 - 2**96 + 2**32 - 1)) if ub else None
         nominal_quarter = 256 * 4 * 16 * 2.4e9 / 4.0   # SURVEY.md 8d planning figure (quarter rate)
         alg_bytes = float(slen + 2 * plen)             # scalar + affine point in + affine point out (160 B for P-256)
         hbm_rate = B * alg_bytes / (step_ms * 1e-3)

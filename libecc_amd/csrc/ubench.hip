@@ -94,6 +94,8 @@ template <int KIND> __global__ __launch_bounds__(256) void k_rate(u32 *out, u32 
 					asm volatile("v_sub_u32 %0, %1, %0" : "+v"(w[i]) : "v"(a));
 				} else if (KIND == 21) {  // v_mad_u64_u32 with an SGPR multiplier (reduction constants)
 					asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(w[i]), "s"((u32)mask) : "vcc");
+				} else if (KIND == 24) {  // v_mad_i64_i32 with an SGPR multiplier (the signed reduction MADs of secp384r1's flavour)
+					asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(w[i]), "s"((u32)mask) : "vcc");
 				} else if (KIND == 22) {  // v_mul_u32_u24 (24-bit multiply, VOP2)
 					asm volatile("v_mul_u32_u24 %0, %1, %0" : "+v"(w[i]) : "v"(a));
 				} else if (KIND == 23) {  // v_and_or_b32 (VOP3)
@@ -299,12 +301,12 @@ int main(int argc, char **argv)
 		}
 		g_wall_khz = (double)khz;
 	}
-	const int NK = 24;
+	const int NK = 25;
 	const char *names[NK] = {"v_mad_u64_u32", "v_add_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_lshl_add_u64",
 				 "v_mad_u32_u24", "v_addc_co_u32_vccchain", "v_cndmask_b32_vcc", "v_mad_u64_u32_b", "v_alignbit_b32",
 				 "v_cndmask_b32_sgpr", "v_add_co_u32", "v_addc_co_u32_sgprpairs", "v_xor_b32", "v_add3_u32",
 				 "mix_5mad_2vop2_1vop3", "v_lshrrev_b64", "pair_alignbit_lshr", "v_and_b32_const", "v_lshrrev_b32", "v_sub_u32",
-				 "v_mad_u64_u32_sgpr", "v_mul_u32_u24", "v_and_or_b32"};
+				 "v_mad_u64_u32_sgpr", "v_mul_u32_u24", "v_and_or_b32", "v_mad_i64_i32_sgpr"};
 	double r[NK], f[NK];
 	r[0] = run_rate<0>(d_out, blocks, iters, &f[0]);
 	r[1] = run_rate<1>(d_out, blocks, iters, &f[1]);
@@ -330,6 +332,7 @@ int main(int argc, char **argv)
 	r[21] = run_rate<21>(d_out, blocks, iters, &f[21]);
 	r[22] = run_rate<22>(d_out, blocks, iters, &f[22]);
 	r[23] = run_rate<23>(d_out, blocks, iters, &f[23]);
+	r[24] = run_rate<24>(d_out, blocks, iters, &f[24]);
 	// dependent chain, one wave per SIMD
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0);
