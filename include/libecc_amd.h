@@ -33,7 +33,9 @@
  *   ECAMD_COMB_MIN_BATCH=<items>  smallest fixed-base batch that builds / uses the generator table (default 4096)
  *   ECAMD_MSM_MIN=<items>, ECAMD_MSM_K=<items per lane>   initial values of ecamd_ctx_set_eddsa_msm (default 2^17, chosen from the batch size)
  *   ECAMD_NO_COMB, ECAMD_NO_FAST_PATH, ECAMD_NO_P25519, ECAMD_NO_K256, ECAMD_NO_P448, ECAMD_NO_MPINV1, ECAMD_NO_ISO, ECAMD_NO_X25519_LADDER,
- *   ECAMD_NO_EDWARDS_SMUL, ECAMD_NO_ED_LATE_MAP, ECAMD_NO_G448_DECODE, ECAMD_NO_X448_LADDER   route around one fast path each (results are identical)
+ *   ECAMD_NO_EDWARDS_SMUL, ECAMD_NO_ED_LATE_MAP, ECAMD_NO_G448_DECODE, ECAMD_NO_X448_LADDER   route around one fast path each (results are identical;
+ *                                 ECAMD_NO_MPINV1: secp384r1 on the dense 384-bit unit instead of its signed sparse reduction)
+ *   ECAMD_NO_SIDE_STREAM          secp256r1 ECDSA verification: k_ecdsa_prep on the caller's stream instead of the context's second stream
  */
 #ifndef LIBECC_AMD_H
 #define LIBECC_AMD_H
