@@ -43,6 +43,30 @@ def popcount(x):
     return bin(x).count("1")
 
 
+def field_mads(p):
+    """(limbs, MADs per multiplication, MADs per squaring, of which with a wave-uniform multiplier) of the generic radix-2^29 field
+    code for the prime p (ecamd_u29g.h; tests/test_u29g_host.py counts the MADs the host build of that header really executes)."""
+    pbits = p.bit_length()
+    # dense Montgomery: NL = ceil((|p| + 16) / 29) limbs, NL^2 products + NL^2 reduction MADs (the digits of p sit in SGPRs);
+    # squaring NL (NL + 1) / 2 products + NL^2 reduction MADs
+    nl = (pbits + 16 + 28) // 29
+    M, S, red = 2 * nl * nl, nl * (nl + 1) // 2 + nl * nl, nl * nl
+    if p == 2**521 - 1:                              # secp521r1: plain residues on 18 limbs, 2^522 = 2 folded inside the columns
+        nl = 18
+        M, S, red = nl * nl, nl * (nl + 1) // 2, 0
+    if p == 2**384 - 2**128 - 2**96 + 2**32 - 1:     # secp384r1: m_k (p + 1) as four signed MADs per quotient digit
+        M, S, red = nl * nl + 4 * nl, nl * (nl + 1) // 2 + 4 * nl, 4 * nl
+    if p == 2**255 - 19:                             # 2^255 - 19: 9 limbs, 9 fold MADs riding in the low columns
+        nl = 9
+        M, S, red = nl * nl + nl, nl * (nl + 1) // 2 + nl, nl
+    if p == 2**448 - 2**224 - 1:                     # Goldilocks: 16 limbs of 28 bits, phi^2 = phi + 1 folded inside the columns;
+        M, S, red = nl * nl, 2 * 36 + 64, 0          # squaring a0^2 + a1^2 (36 each) and a1 (2 a0 + a1) (64), ecamd_u29g.h:mul_p448
+    if p == 2**256 - 2**32 - 977:                    # secp256k1: 9 limbs, 9 + 8 + 2 = 19 fold MADs riding in the low columns + 977 q
+        nl = 9
+        M, S, red = nl * nl + 20, nl * (nl + 1) // 2 + 20, 20
+    return nl, M, S, red
+
+
 def work_model(curve_params, nw, slen, batch=1 << 20):
     """Field multiplications and 32x32 MADs (v_mad_u64_u32) executed per item, derived from the
     kernels' own parameters.  secp256r1 takes the hand-specialised radix-2^29 Jacobian path
@@ -79,21 +103,7 @@ def work_model(curve_params, nw, slen, batch=1 << 20):
         # generic radix-2^29 Jacobian kernels k_smul_g<|p|> + k_finalize_g<|p|> (ecamd_g29_kernel.hip):
         # NL = ceil((|p| + 16) / 29) limbs, multiplication NL^2 products + NL^2 reduction MADs,
         # squaring NL (NL + 1) / 2 products + NL^2 reduction MADs
-        nl = (pbits + 16 + 28) // 29
-        M, S = 2 * nl * nl, nl * (nl + 1) // 2 + nl * nl
-        if p == 2**521 - 1:                          # secp521r1 flavour: plain residues on 18 limbs, 2^522 = 2 folded inside the columns
-            nl = 18
-            M, S = nl * nl, nl * (nl + 1) // 2
-        if p == 2**384 - 2**128 - 2**96 + 2**32 - 1:  # secp384r1 flavour: m_k (p + 1) as four signed MADs per quotient digit
-            M, S = nl * nl + 4 * nl, nl * (nl + 1) // 2 + 4 * nl
-        if p == 2**255 - 19:                         # 2^255 - 19 flavour: 9 limbs, 9 fold MADs riding in the low columns
-            nl = 9
-            M, S = nl * nl + nl, nl * (nl + 1) // 2 + nl
-        if p == 2**448 - 2**224 - 1:                 # Goldilocks flavour: 16 limbs of 28 bits, phi^2 = phi + 1 folded inside the columns:
-            M, S = nl * nl, 2 * 36 + 64              # 256 MADs; squaring a0^2 + a1^2 (36 each) and a1 (2 a0 + a1) (64), ecamd_u29g.h:mul_p448
-        if p == 2**256 - 2**32 - 977:                # secp256k1 flavour: 9 limbs, 9 + 8 + 2 = 19 fold MADs riding in the low columns
-            nl = 9
-            M, S = nl * nl + 19, nl * (nl + 1) // 2 + 19
+        nl, M, S, red = field_mads(p)
         am3 = curve_params["a"] == p - 3 or iso_to_am3(p, curve_params["a"])
         dbl = (3, 4) if curve_params["a"] == 0 else ((4, 4) if am3 else (4, 6))
         add = (12, 4)
@@ -122,11 +132,6 @@ def work_model(curve_params, nw, slen, batch=1 << 20):
         nm += 1 + inv_m / fin_k + 2 + 3 + 2
         ns += inv_s / fin_k + 1
         # the reduction MADs multiply by digits of p held in __constant__ memory (scalar registers)
-        red = {True: 0}.get(p == 2**521 - 1, nl * nl)      # (no constant multipliers in the plain Mersenne flavour)
-        if p == 2**384 - 2**128 - 2**96 + 2**32 - 1:
-            red = 4 * nl
-        if p == 2**448 - 2**224 - 1:
-            red = 0                                   # no constant multipliers at all
         work_model.loop_sgpr_share = (loop_m + loop_s) * red / (loop_m * M + loop_s * S)
         return nm + ns, nm * M + ns * S, f"k_loop_g<{pbits}>", loop_m * M + loop_s * S
     mm_add, mm_dbl = 17, 16                              # RCB Alg. 1 / Alg. 3, generic a

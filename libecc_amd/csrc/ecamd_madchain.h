@@ -326,9 +326,18 @@ ECAMD_CHAIN_FN void ecamd_mad_chain(uint64_t &acc, uint64_t &acc2, const uint32_
 	}
 }
 #else
+// host build (tests): -DECAMD_COUNT_MADS makes every MAD the field code would issue increment a counter, so that the work models of
+// bench.py can be checked against the code (tests/test_u29g_host.py::test_mad_counts_match_the_work_model)
+#ifdef ECAMD_COUNT_MADS
+extern "C" uint64_t ecamd_mad_count;
+#define ECAMD_COUNT_MAD(n) (ecamd_mad_count += (uint64_t)(n))
+#else
+#define ECAMD_COUNT_MAD(n) ((void)0)
+#endif
 template <int N, bool DUAL, bool YS, bool Z2 = false>
 ECAMD_CHAIN_FN void ecamd_mad_chain(uint64_t &acc, uint64_t &acc2, const uint32_t *x, const uint32_t *y)
 {
+	ECAMD_COUNT_MAD(N);
 	if (Z2 && DUAL && N > 1) {
 		acc2 = 0;
 	}

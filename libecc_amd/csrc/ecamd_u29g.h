@@ -230,8 +230,8 @@ template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
 #define G29_MUL_VS(acc, a, b) \
 	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(acc), "=s"(dead_) : "v"(a), "s"(b)); } while (0)
 #else
-#define G29_MUL_VS(acc, a, b) acc = (u64)(a) * (b)
-#define G29_MAD_VS(acc, a, b) acc += (u64)(a) * (b)
+#define G29_MUL_VS(acc, a, b) do { ECAMD_COUNT_MAD(1); acc = (u64)(a) * (b); } while (0)
+#define G29_MAD_VS(acc, a, b) do { ECAMD_COUNT_MAD(1); acc += (u64)(a) * (b); } while (0)
 #endif
 
 // ---- multiply-accumulate chains (ecamd_madchain.h): a column's products go out in asm statements of up
@@ -307,6 +307,7 @@ template <int N> G29_FN void smad_chain(u64 &acc, const u32 *x, const int32_t *y
 		    : "+v"(acc), "=&s"(dead_) : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]));
 	}
 #else
+	ECAMD_COUNT_MAD(N);
 	for (int n = 0; n < N; n++) {
 		acc += (u64)((int64_t)(int32_t)x[n] * (int64_t)y[n]);
 	}

@@ -358,3 +358,48 @@ def test_p448_flavour(lib_p448):
     assert CURVES["WEI448"]["p"] == 2**448 - 2**224 - 1
     test_field_ops(lib_p448, "WEI448", 5)
     test_jacobian(lib_p448, "WEI448", 5)
+
+
+def test_mad_counts_match_the_work_model():
+    """bench.py prices a kernel by the MADs its field operations issue (`field_mads`: per multiplication, per squaring).  The host
+    build of the same headers counts the MADs it really executes (-DECAMD_COUNT_MADS: every chain and every single MAD bumps a
+    counter): the two must agree for every flavour, or the roofline fractions of the bench lines are wrong."""
+    import importlib.util
+    import types
+    for name in ("torch", "libecc_amd"):          # bench.py imports them at module level; the model itself is pure Python
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+    spec = importlib.util.spec_from_file_location("bench_for_model", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    os.makedirs(BUILD, exist_ok=True)
+    rng = np.random.default_rng(7)
+    cases = [("SECP192R1", 0, []), ("SECP224R1", 0, []), ("BRAINPOOLP256R1", 0, []), ("BRAINPOOLP320R1", 0, []), ("BRAINPOOLP384R1", 0, []),
+             ("BRAINPOOLP512R1", 0, []), ("SECP384R1", 0, ["-DG29_P384S", "-DSHIM_ONLY_384"]), ("SECP521R1", 1, ["-DG29_M521P", "-DSHIM_ONLY_521"]),
+             ("WEI25519", 2, ["-DG29_P25519", "-DSHIM_ONLY_255"]), ("SECP256K1", 4, ["-DG29_K256", "-DSHIM_ONLY_256"]),
+             ("WEI448", 5, ["-DG29_P448", "-DSHIM_ONLY_448"])]
+    libs = {}
+    for curve, flavour, flags in cases:
+        key = tuple(flags)
+        if key not in libs:
+            so = os.path.join(BUILD, "u29g_count_%s.so" % ("_".join(f[2:] for f in flags) or "dense"))
+            subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DECAMD_COUNT_MADS"] + flags +
+                                  ["-o", so, os.path.join(ROOT, "tests", "u29g_host_shim.cpp")])
+            libs[key] = C.CDLL(so)
+        lib = libs[key]
+        lib.g_madcount_get.restype = C.c_uint64
+        f = Field(lib, curve, flavour)
+        nl, M, S, _ = bench.field_mads(f.p)
+        assert nl == f.nl, (curve, nl, f.nl)
+        x, y = (int.from_bytes(rng.bytes(80), "big") % f.p for _ in range(2))
+        out = (C.c_uint32 * f.nl)()
+        lib.g_madcount_reset()
+        f.fn("mul")(f.k, arr(f.digits(x)), arr(f.digits(y)), out, 0)
+        got_m = lib.g_madcount_get()
+        lib.g_madcount_reset()
+        f.fn("mul")(f.k, arr(f.digits(x)), arr(f.digits(x)), out, 1)
+        got_s = lib.g_madcount_get()
+        assert (got_m, got_s) == (M, S), (curve, "counted", got_m, got_s, "model", M, S)

@@ -2,7 +2,15 @@
 // (ecamd_u29g.h, ecamd_jacg.h) for tests/test_u29g_host.py.  One set of entry points per
 // field size; the curve constants (CurveG image) are supplied by the test as a flat u32 array.
 #include <cstring>
+#include <cstdint>
+#ifdef ECAMD_COUNT_MADS
+extern "C" { uint64_t ecamd_mad_count = 0; }
+#endif
 #include "../libecc_amd/csrc/ecamd_jacg.h"
+#ifdef ECAMD_COUNT_MADS
+extern "C" void g_madcount_reset(void) { ecamd_mad_count = 0; }
+extern "C" uint64_t g_madcount_get(void) { return ecamd_mad_count; }
+#endif
 
 using namespace jacg;
 
