@@ -652,7 +652,7 @@ template <bool SQR> G29_FN void mul_p25519(u32 *r, const u32 *a, const u32 *b)
 // h[8] the second target is 2^261 again: columns 0 (x 256 x 31264 = 8003584) and 1 (x 2^16).  Column 8 -- with the carry of
 // column 7 -- holds everything from 2^232 up; its bits from 24 up (q < 2^40) are multiples of 2^256 = 8 2^29 + 977 and go to limbs 0
 // (977 q), 1 (8 q) and, as carries, 2: limb 2 below 2^29 + 2^15, the top limb below 2^24, value below 2p.
-// 81 + 19 MADs and 17 column ends (rounds 1-2: 101 MADs, 26 column ends).
+// 81 + 20 MADs (19 folds and 977 q) and 17 column ends (rounds 1-2: the same 101 MADs, but 26 column ends and a second pass).
 template <bool SQR, int K_> G29_FN void k256_column(u64 &acc, u32 *out, const u32 *a, const u32 *b, const u32 *a2, const u32 *h, const u32 *c)
 {
 	u64 acc2;
