@@ -56,6 +56,8 @@ def field_mads(p):
         M, S, red = nl * nl, nl * (nl + 1) // 2, 0
     if p == 2**384 - 2**128 - 2**96 + 2**32 - 1:     # secp384r1: m_k (p + 1) as four signed MADs per quotient digit
         M, S, red = nl * nl + 4 * nl, nl * (nl + 1) // 2 + 4 * nl, 4 * nl
+    if p == 2**224 - 2**96 + 1 or p == 2**192 - 2**64 - 1:   # secp224r1 / secp192r1: two signed MADs per quotient digit
+        M, S, red = nl * nl + 2 * nl, nl * (nl + 1) // 2 + 2 * nl, 2 * nl
     if p == 2**255 - 19:                             # 2^255 - 19: 9 limbs, 9 fold MADs riding in the low columns
         nl = 9
         M, S, red = nl * nl + nl, nl * (nl + 1) // 2 + nl, nl

@@ -48,6 +48,8 @@ def _jobs():
     jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_448g.o", ["-DG29_PB=448", "-DG29_P448"]))
     # secp384r1: Montgomery reduction on the four signed digits of p + 1 (ecamd_u29g.h:p384s_reduction)
     jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_384n.o", ["-DG29_PB=384", "-DG29_P384S"]))
+    jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_224s.o", ["-DG29_PB=224", "-DG29_P224S"]))
+    jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_192s.o", ["-DG29_PB=192", "-DG29_P192S"]))
     jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_dispatch.o", ["-DG29_DISPATCH"]))
     return jobs
 

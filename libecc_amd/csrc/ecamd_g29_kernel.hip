@@ -1037,6 +1037,12 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_finalize_g(E
 #elif defined(G29_P384S)
 #define G29_TAG G29_CAT(G29_PB, n)   /* 384n: secp384r1's prime (signed sparse reduction) beside the dense 384-bit unit */
 #define G29_FLAV 3
+#elif defined(G29_P224S)
+#define G29_TAG G29_CAT(G29_PB, s)   /* 224s: secp224r1's prime (signed sparse reduction) beside the dense 224-bit unit */
+#define G29_FLAV 6
+#elif defined(G29_P192S)
+#define G29_TAG G29_CAT(G29_PB, s)   /* 192s: secp192r1's prime (signed sparse reduction) beside the dense 192-bit unit */
+#define G29_FLAV 7
 #else
 #define G29_FLAV 0
 #define G29_TAG G29_PB
@@ -2857,6 +2863,8 @@ G29_FOR_PB(X)
 X(521m)
 X(255c)
 X(384n)
+X(224s)
+X(192s)
 X(256k)
 X(448g)
 #undef X
@@ -2889,7 +2897,8 @@ size_t ecamd_g29_image_bytes(int pbits, int flavour)
 	return (size_t)((10 + g29::NBIAS) * g29::nl_for_flavour(pbits, flavour) + 4) * 4;
 }
 
-// 'flavour' 1 selects the secp521r1 (p = 2^521 - 1) instantiation, 2 the p = 2^255 - 19 one, 3 secp384r1's, 4 secp256k1's, 5 WEI448's
+// 'flavour' 1 selects the secp521r1 (p = 2^521 - 1) instantiation, 2 the p = 2^255 - 19 one, 3 secp384r1's, 4 secp256k1's, 5 WEI448's,
+// 6 secp224r1's, 7 secp192r1's
 hipError_t ecamd_g29_upload(int pbits, int slot, const void *img, size_t bytes, int flavour)
 {
 	if (pbits == 521 && flavour == 1) {
@@ -2900,6 +2909,12 @@ hipError_t ecamd_g29_upload(int pbits, int slot, const void *img, size_t bytes, 
 	}
 	if (pbits == 384 && flavour == 3) {
 		return ecamd_g29_upload_384n(slot, img, bytes);
+	}
+	if (pbits == 224 && flavour == 6) {
+		return ecamd_g29_upload_224s(slot, img, bytes);
+	}
+	if (pbits == 192 && flavour == 7) {
+		return ecamd_g29_upload_192s(slot, img, bytes);
 	}
 	if (pbits == 256 && flavour == 4) {
 		return ecamd_g29_upload_256k(slot, img, bytes);
@@ -2928,6 +2943,12 @@ hipError_t ecamd_launch_smul_g29(int pbits, int gslot, const EcamdSmulArgs &a, h
 	}
 	if (pbits == 384 && flavour == 3) {
 		return ecamd_g29_launch_384n(gslot, a, s, ev);
+	}
+	if (pbits == 224 && flavour == 6) {
+		return ecamd_g29_launch_224s(gslot, a, s, ev);
+	}
+	if (pbits == 192 && flavour == 7) {
+		return ecamd_g29_launch_192s(gslot, a, s, ev);
 	}
 	if (pbits == 256 && flavour == 4) {
 		return ecamd_g29_launch_256k(gslot, a, s, ev);
@@ -2962,6 +2983,12 @@ hipError_t ecamd_g29_comb_build(int pbits, int gslot, const uint8_t *pts, uint32
 	}
 	if (pbits == 384 && flavour == 3) {
 		return ecamd_g29_comb_build_384n(gslot, pts, n, clen, table, s);
+	}
+	if (pbits == 224 && flavour == 6) {
+		return ecamd_g29_comb_build_224s(gslot, pts, n, clen, table, s);
+	}
+	if (pbits == 192 && flavour == 7) {
+		return ecamd_g29_comb_build_192s(gslot, pts, n, clen, table, s);
 	}
 	if (pbits == 256 && flavour == 4) {
 		return ecamd_g29_comb_build_256k(gslot, pts, n, clen, table, s);

@@ -285,7 +285,8 @@ struct ecamd_curve {
 	EcamdYfromXArgs sqrt_tmpl;
 	bool is_p256;    // exactly secp256r1: hand-specialised radix-2^29 Jacobian kernel
 	int gslot;       // constant slot of the generic radix-2^29 Jacobian kernel (-1: none)
-	int gflavour;    // 0 dense reduction, 1 secp521r1 (p = 2^521 - 1), 2 p = 2^255 - 19, 3 p = -1 mod 2^29 at 384 bits, 4 secp256k1's prime, 5 p = 2^448 - 2^224 - 1
+	int gflavour;    // 0 dense reduction, 1 secp521r1 (p = 2^521 - 1), 2 p = 2^255 - 19, 3 secp384r1's prime, 4 secp256k1's prime, 5 p = 2^448 - 2^224 - 1,
+	                 // 6 secp224r1's prime, 7 secp192r1's prime (3, 6, 7: signed sparse Montgomery reduction)
 	uint32_t *d_gtab; // secp256r1: affine window table [1..8]G, radix-2^29 Montgomery digits, 8 x 40 words
 	uint32_t *d_comb; // fast paths: 16-bit comb table of G, built on the first large fixed-base batch (NULL before / disabled)
 	bool comb_off;    // construction failed or is in progress: do not try (again)
@@ -1052,6 +1053,15 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	    big_cmp(cv->p, big_sub(big_sub(big_pow2(448), big_pow2(224)), Big(1, 1))) == 0) {
 		cv->gflavour = 5;  // p = 2^448 - 2^224 - 1 (WEI448): plain residues, Goldilocks folds
 	}
+	if (getenv("ECAMD_NO_MPINV1") == nullptr) {
+		// the other two NIST primes with a two-term p -+ 1: secp224r1 (2^224 - 2^96 + 1) and secp192r1 (2^192 - 2^64 - 1)
+		if (cv->pbits == 224 && big_cmp(big_add(cv->p, big_pow2(96)), big_add(big_pow2(224), Big(1, 1))) == 0) {
+			cv->gflavour = 6;
+		}
+		if (cv->pbits == 192 && big_cmp(big_add(cv->p, big_add(big_pow2(64), Big(1, 1))), big_pow2(192)) == 0) {
+			cv->gflavour = 7;
+		}
+	}
 	if (cv->pbits == 384 && getenv("ECAMD_NO_MPINV1") == nullptr &&
 	    big_cmp(big_add(cv->p, big_add(big_pow2(128), big_pow2(96))), big_add(big_pow2(384), big_sub(big_pow2(32), Big(1, 1)))) == 0) {
 		cv->gflavour = 3;  // secp384r1's prime: Montgomery reduction on the four signed digits of p + 1 (ecamd_u29g.h, -DG29_P384S)
@@ -1805,7 +1815,7 @@ static bool fused_verify_ok(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n)
 	if (cv->is_p256 || cv->gslot < 0 || getenv("ECAMD_NO_FUSED_VERIFY") != nullptr) {
 		return false;
 	}
-	if (!(cv->gflavour == 0 || cv->gflavour == 1 || cv->gflavour == 3 || cv->gflavour == 5)) {
+	if (!(cv->gflavour == 0 || cv->gflavour == 1 || cv->gflavour == 3 || cv->gflavour == 5 || cv->gflavour == 6 || cv->gflavour == 7)) {
 		return false;
 	}
 	if (big_cmp(cv->order, cv->q) != 0 || (uint32_t)cv->qlen > ecamd_g29_comb_max_slen(cv->pbits)) {

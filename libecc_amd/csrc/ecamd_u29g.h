@@ -92,6 +92,27 @@ constexpr bool P384S = true;
 #else
 constexpr bool P384S = false;
 #endif
+//   -DG29_P192S        p = 2^192 - 2^64 - 1 (secp192r1): the same reduction, p + 1 = -2^6 2^(29*2) + 2^18 2^(29*6): TWO signed MADs per
+//                      quotient digit (80 MADs per multiplication instead of 128, 52 per squaring instead of 100)
+//   -DG29_P224S        p = 2^224 - 2^96 + 1 (secp224r1): p = +1 mod 2^29, so the quotient digit is the NEGATED low digit of the
+//                      column, "+ m_k" clears it (and carries), and m_k (p - 1) = m_k (-2^9 2^(29*3) + 2^21 2^(29*7)) is two signed
+//                      MADs (99 / 63 MADs instead of 162 / 126)
+#if defined(G29_P192S)
+constexpr bool P192S = true;
+#else
+constexpr bool P192S = false;
+#endif
+#if defined(G29_P224S)
+constexpr bool P224S = true;
+#else
+constexpr bool P224S = false;
+#endif
+constexpr bool SPARSE = P384S || P192S || P224S;   // Montgomery form, signed sparse reduction, signed column sums
+// the signed digits (column offset, factor) of p + 1 (p - 1 for secp224r1) in radix 2^29, padded to four
+constexpr int SPARSE_N = P384S ? 4 : 2;
+constexpr int SPARSE_OFF[4] = {P384S ? 1 : (P192S ? 2 : 3), P384S ? 3 : (P192S ? 6 : 7), 4, 13};
+constexpr int32_t SPARSE_C[4] = {P384S ? 8 : (P192S ? -64 : -512), P384S ? -512 : (P192S ? (1 << 18) : (1 << 21)), -4096, 128};
+constexpr bool SPARSE_PLUS1 = P224S;               // p = +1 mod 2^29: m_k = -column mod 2^29 and "+ m_k" clears the digit
 
 constexpr int nl_for(int pbits) { return (pbits + 16 + W - 1) / W; }
 constexpr int nl_for_flavour(int pbits, int flavour) { return (flavour == 2 || flavour == 4) ? 9 : (flavour == 5 ? 16 : (flavour == 1 ? 18 : nl_for(pbits))); }
@@ -211,9 +232,9 @@ template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
 		// the shared column S_0 -- and a carry below 2^37
 		return la == 0 || lb <= ((0xFFFFFFFFFFFFFFFFull - (1ull << 40)) / 38) / la;
 	}
-	if (P384S) {
-		// secp384r1 flavour: signed column sums -- NL la lb + NL 2^43 (reduction) + 2^35 (carry) < 2^63
-		return la == 0 || lb <= (((1ull << 63) - (1ull << 48)) / NL) / la;
+	if (SPARSE) {
+		// signed sparse flavours: signed column sums -- NL la lb + NL 2^52 (reduction) + 2^35 (carry) < 2^63
+		return la == 0 || lb <= (((1ull << 63) - (1ull << 57)) / NL) / la;
 	}
 	if (M521P) {
 		// plain Mersenne flavour: a column sums (k + 1) la lb + (17 - k) la (2 lb) <= 35 la lb and a carry below 2^37
@@ -313,19 +334,20 @@ template <int N> G29_FN void smad_chain(u64 &acc, const u32 *x, const int32_t *y
 	}
 #endif
 }
-template <int NL, int K_> G29_FN void p384s_reduction(u64 &acc, const u32 *m, const int32_t *c)
+template <int NL, int K_> G29_FN void sparse_reduction(u64 &acc, const u32 *m, const int32_t *c)
 {
-	static_assert(NL == 14, "secp384r1 flavour: 14 limbs");
-	constexpr int OFF[4] = {1, 3, 4, 13};
-	constexpr int N = ((K_ - 1 >= 0 && K_ - 1 < NL) ? 1 : 0) + ((K_ - 3 >= 0 && K_ - 3 < NL) ? 1 : 0) + ((K_ - 4 >= 0 && K_ - 4 < NL) ? 1 : 0) +
-			  ((K_ - 13 >= 0 && K_ - 13 < NL) ? 1 : 0);
+	static_assert(!P384S || NL == 14, "secp384r1 flavour: 14 limbs");
+	static_assert(!P192S || NL == 8, "secp192r1 flavour: 8 limbs");
+	static_assert(!P224S || NL == 9, "secp224r1 flavour: 9 limbs");
+	constexpr auto has = [](int t) { return t < SPARSE_N && K_ - SPARSE_OFF[t] >= 0 && K_ - SPARSE_OFF[t] < NL; };
+	constexpr int N = (has(0) ? 1 : 0) + (has(1) ? 1 : 0) + (has(2) ? 1 : 0) + (has(3) ? 1 : 0);
 	if constexpr (N > 0) {
 		u32 x[N];
 		int32_t y[N];
 		int n = 0;
 #pragma unroll
-		for (int t = 0; t < 4; t++) {
-			const int i = K_ - OFF[t];
+		for (int t = 0; t < SPARSE_N; t++) {
+			const int i = K_ - SPARSE_OFF[t];
 			if (i >= 0 && i < NL) {
 				x[n] = m[i];
 				y[n] = c[t];
@@ -343,13 +365,17 @@ template <int NL, bool SQR, int K_> G29_FN void mul_column(u64 &acc, u32 *m, u32
 	typedef Column<NL, SQR, K_> C;
 	u64 acc2;  // written by the first chain that uses it (Z2), never read otherwise
 	C::products(acc, acc2, a, b, a2);
-	if constexpr (P384S) {
+	if constexpr (SPARSE) {
 		if constexpr (C::USES2_PROD) {
 			acc += acc2;
 		}
-		p384s_reduction<NL, K_>(acc, m, c384);
-		// "- m_k" clears the low digit of a column below NL; the column sum is signed
-		if constexpr (K_ < NL) {
+		sparse_reduction<NL, K_>(acc, m, c384);
+		// the quotient digit of a column below NL and the "-+ m_k" that clears its low digit; the column sum is signed
+		if constexpr (K_ < NL && SPARSE_PLUS1) {
+			const u32 mk = (0u - (u32)acc) & MASK;
+			m[K_] = mk;
+			acc += mk;
+		} else if constexpr (K_ < NL) {
 			m[K_] = (u32)acc & MASK;
 		} else {
 			r[K_ - NL] = (u32)acc & MASK;
@@ -747,9 +773,10 @@ template <int NL, bool SQR> G29_FN void mul_raw(u32 *r, const u32 *a, const u32 
 			}
 		}
 		u64 acc = 0;
-		int32_t c384[4] = {8, -512, -4096, 128};  // secp384r1 flavour: the signed digits of p + 1, kept opaque so that they stay MAD operands
+		// signed sparse flavours: the signed digits of p + 1 (p - 1), kept opaque so that they stay MAD operands
+		int32_t c384[4] = {SPARSE_C[0], SPARSE_C[1], SPARSE_C[2], SPARSE_C[3]};
 #if defined(__HIPCC__)
-		if (P384S) {
+		if (SPARSE) {
 			asm volatile("" : "+s"(c384[0]), "+s"(c384[1]), "+s"(c384[2]), "+s"(c384[3]));
 		}
 #endif

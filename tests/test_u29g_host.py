@@ -306,14 +306,13 @@ def lib_n384():
     return C.CDLL(so)
 
 
-def test_secp384r1_mpinv1_flavour(lib_n384):
-    assert CURVES["SECP384R1"]["p"] == 2**384 - 2**128 - 2**96 + 2**32 - 1
-    test_field_ops(lib_n384, "SECP384R1")
-    test_jacobian(lib_n384, "SECP384R1")
-    # small products: the negative reduction terms (- 2^9 m_(k-3) - 2^12 m_(k-4)) outweigh a column's products, so column sums go
-    # negative and the carries must be arithmetic
+def _sparse_flavour_checks(lib, curve):
+    test_field_ops(lib, curve)
+    test_jacobian(lib, curve)
+    # small products: the negative reduction terms outweigh a column's products, so column sums go negative and the carries must
+    # be arithmetic
     rng = np.random.default_rng(384)
-    f = Field(lib_n384, "SECP384R1")
+    f = Field(lib, curve)
     p = f.p
     out = (C.c_uint32 * f.nl)()
     for it in range(200):
@@ -326,6 +325,31 @@ def test_secp384r1_mpinv1_flavour(lib_n384):
         assert f.val(out) % p == x * y * f.Rinv % p and f.val(out) < 2 * p and max(list(out)[:-1]) <= f.MASK
         f.fn("mul")(f.k, arr(f.digits(y)), arr(f.digits(y)), out, 1)
         assert f.val(out) % p == y * y * f.Rinv % p and f.val(out) < 2 * p and max(list(out)[:-1]) <= f.MASK
+
+
+def test_secp384r1_mpinv1_flavour(lib_n384):
+    assert CURVES["SECP384R1"]["p"] == 2**384 - 2**128 - 2**96 + 2**32 - 1
+    _sparse_flavour_checks(lib_n384, "SECP384R1")
+
+
+def _sparse_lib(pb, flag):
+    os.makedirs(BUILD, exist_ok=True)
+    so = os.path.join(BUILD, f"u29g_host_s{pb}.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", flag, f"-DSHIM_ONLY_{pb}", "-o", so,
+                           os.path.join(ROOT, "tests", "u29g_host_shim.cpp")])
+    return C.CDLL(so)
+
+
+def test_secp224r1_sparse_flavour():
+    """p = 2^224 - 2^96 + 1 = +1 mod 2^29: negated quotient digits, "+ m_k" clears the column, m_k (p - 1) as two signed MADs"""
+    assert CURVES["SECP224R1"]["p"] == 2**224 - 2**96 + 1
+    _sparse_flavour_checks(_sparse_lib(224, "-DG29_P224S"), "SECP224R1")
+
+
+def test_secp192r1_sparse_flavour():
+    """p = 2^192 - 2^64 - 1 = -1 mod 2^29: m_k (p + 1) as two signed MADs"""
+    assert CURVES["SECP192R1"]["p"] == 2**192 - 2**64 - 1
+    _sparse_flavour_checks(_sparse_lib(192, "-DG29_P192S"), "SECP192R1")
 
 
 @pytest.fixture(scope="module")
@@ -377,7 +401,8 @@ def test_mad_counts_match_the_work_model():
     spec.loader.exec_module(bench)
     os.makedirs(BUILD, exist_ok=True)
     rng = np.random.default_rng(7)
-    cases = [("SECP192R1", 0, []), ("SECP224R1", 0, []), ("BRAINPOOLP256R1", 0, []), ("BRAINPOOLP320R1", 0, []), ("BRAINPOOLP384R1", 0, []),
+    cases = [("SECP192R1", 0, ["-DG29_P192S", "-DSHIM_ONLY_192"]), ("SECP224R1", 0, ["-DG29_P224S", "-DSHIM_ONLY_224"]), ("BRAINPOOLP192R1", 0, []),
+             ("BRAINPOOLP224R1", 0, []), ("BRAINPOOLP256R1", 0, []), ("BRAINPOOLP320R1", 0, []), ("BRAINPOOLP384R1", 0, []),
              ("BRAINPOOLP512R1", 0, []), ("SECP384R1", 0, ["-DG29_P384S", "-DSHIM_ONLY_384"]), ("SECP521R1", 1, ["-DG29_M521P", "-DSHIM_ONLY_521"]),
              ("WEI25519", 2, ["-DG29_P25519", "-DSHIM_ONLY_255"]), ("SECP256K1", 4, ["-DG29_K256", "-DSHIM_ONLY_256"]),
              ("WEI448", 5, ["-DG29_P448", "-DSHIM_ONLY_448"])]

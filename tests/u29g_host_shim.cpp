@@ -162,6 +162,10 @@ SHIM(384)
 SHIM(256)
 #elif defined(SHIM_ONLY_448)
 SHIM(448)
+#elif defined(SHIM_ONLY_224)
+SHIM(224)
+#elif defined(SHIM_ONLY_192)
+SHIM(192)
 #elif !defined(SHIM_ONLY_521)
 SHIM(192)
 SHIM(224)
@@ -173,6 +177,7 @@ SHIM(448)
 SHIM(511)
 SHIM(512)
 #endif
-#if !defined(SHIM_ONLY_255) && !defined(SHIM_ONLY_384) && !defined(SHIM_ONLY_256) && !defined(SHIM_ONLY_448)
+#if !defined(SHIM_ONLY_255) && !defined(SHIM_ONLY_384) && !defined(SHIM_ONLY_256) && !defined(SHIM_ONLY_448) && !defined(SHIM_ONLY_224) && \
+	!defined(SHIM_ONLY_192)
 SHIM(521)
 #endif
