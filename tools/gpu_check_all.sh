@@ -12,12 +12,12 @@ cd $R
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 timeout 300 python bench.py --ubench-json $O/ubench.json > $O/bench.json 2> $O/bench.err
 # 2. the other field sizes (batch 2^20)
-B="python $R/bench.py --no-cpu-baseline --parity-items 4096 --steps 5 --warmup 2"
-for c in SECP384R1 SECP521R1 WEI448 BRAINPOOLP256R1 BRAINPOOLP512R1 SECP256K1 WEI25519; do
+B="python $R/bench.py --no-cpu-baseline --no-traffic --no-secondary --parity-items 4096 --steps 5 --warmup 2"
+for c in SECP384R1 SECP521R1 WEI448 BRAINPOOLP256R1 BRAINPOOLP512R1 SECP256K1 WEI25519 SECP224R1 SECP192R1; do
   timeout 200 $B --curve $c > $O/bench_$c.json 2> $O/bench_$c.err
 done
 # 3. protocol workloads, the whole-batch EdDSA predicate, secret mode / blinding, the libecc-typed boundary end to end
-for w in ecdsa_verify ed25519_verify x25519 ed448_verify ecdsa_sign ecccdh; do
+for w in ecdsa_verify ed25519_verify x25519 ed448_verify x448 ecdsa_sign ecccdh; do
   timeout 200 python tools/bench_protocols.py --workload $w --no-cpu-baseline > $O/proto_$w.json 2> $O/proto_$w.err
 done
 MSM_LOG2=16,17,18,20 MSM_K=0 timeout 200 python tools/bench_msm.py > $O/bench_msm.json 2> $O/bench_msm.err
