@@ -35,6 +35,7 @@
  *   ECAMD_NO_COMB, ECAMD_NO_FAST_PATH, ECAMD_NO_P25519, ECAMD_NO_K256, ECAMD_NO_P448, ECAMD_NO_MPINV1, ECAMD_NO_ISO, ECAMD_NO_X25519_LADDER,
  *   ECAMD_NO_EDWARDS_SMUL, ECAMD_NO_ED_LATE_MAP, ECAMD_NO_G448_DECODE, ECAMD_NO_X448_LADDER   route around one fast path each (results are identical;
  *                                 ECAMD_NO_MPINV1: secp384r1 on the dense 384-bit unit instead of its signed sparse reduction)
+ *   ECAMD_NO_ED_FIN_G             EdDSA verification: the final additions / doublings on the saturated-word kernel instead of the unit's own field
  *   ECAMD_NO_SIDE_STREAM          secp256r1 ECDSA verification: k_ecdsa_prep on the caller's stream instead of the context's second stream
  */
 #ifndef LIBECC_AMD_H

@@ -11,6 +11,9 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "ecamd_jacg.h"
+#if defined(G29_P25519) || defined(G29_P448)
+#include "ecamd_rcbg.h"
+#endif
 #include "ecamd_internal.h"
 
 using namespace jacg;
@@ -2770,6 +2773,93 @@ hipError_t ecamd_launch_ed448_decode_g(const EcamdEd448DecodeArgs &a, int gslot,
 }
 #endif  // G29_P448
 
+#if defined(G29_P25519) || defined(G29_P448)
+// ------------------------------------------------------------------------------------------
+// The tail of an EdDSA verification (k_ed_fin<NW> of ecamd_kernels.hip, statement for statement) on this unit's field:
+// [S]B - R - [h]A by two complete additions -- an exceptional pair (result Y = Z = 0) rejects, as prj_pt_add's -1 does
+// (curves/prj_pt.c:1058-1060) --, the cofactor doublings of _prj_pt_unprotected_mult (curves/prj_pt.c:1862-1905), accepted when the
+// result is the point at infinity.  Ed448 also checks [4]A != infinity of the decoded key here (A.Akey).
+// ------------------------------------------------------------------------------------------
+static __device__ __forceinline__ rcbg::PtG<G29_PB> edfin_load(const u8 *src, u32 st, int clen, bool negate,
+								 const CurveG<Lay<G29_PB>::NL> &K)
+{
+	using namespace rcbg;
+	typedef Cls<G29_PB>::FA FA;
+	typedef Cls<G29_PB>::FC FC;
+	constexpr int NW = Lay<G29_PB>::NW;
+	if (st == 2) {
+		return infinity<G29_PB>(K);
+	}
+	u32 xw[NW], yw[NW];
+	load_be<NW>(src, clen, xw);
+	load_be<NW>(src + clen, clen, yw);
+	const auto xd = from_words<G29_PB, NW>(xw), yd = from_words<G29_PB, NW>(yw);
+	PtG<G29_PB> P;
+	P.X = weaken<FA>(mul(xd, constant<FC>(K.ix), K));
+	const auto ym = mul(yd, constant<FC>(K.iy), K);
+	if (negate) {
+		P.Y = neg<G29_PB>(weaken<Cls<G29_PB>::FM>(ym), K);
+	} else {
+		P.Y = weaken<FA>(ym);
+	}
+	P.Z = weaken<FA>(constant<FC>(K.one));
+	return P;
+}
+
+// (PB only makes the kernel symbols of the two units distinct)
+template <int PB> __global__ __launch_bounds__(64) void k_ed_fin_g(EcamdEdFinArgs A, int gslot)
+{
+	static_assert(PB == G29_PB, "one instantiation per unit");
+	using namespace rcbg;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const CurveG<Lay<G29_PB>::NL> &K = TabGP<G29_PB>::get(gslot);
+	const int clen = (int)A.clen;
+	const u32 sSG = A.stSG[i], shA = A.sthA[i];
+	const u32 fR = A.flagsR[i];   // 2: R decoded to the neutral element, i.e. the point at infinity
+	if (A.flagsA[i] || fR == 1 || A.flagsS[i] || sSG == 1 || shA == 1) {
+		A.result[i] = 1;
+		return;
+	}
+	if (A.Akey != nullptr) {
+		if (A.stA != nullptr && A.stA[i] != 0) {
+			A.result[i] = 1;
+			return;
+		}
+		PtG<G29_PB> K4 = edfin_load(A.Akey + (size_t)i * 2 * clen, 0, clen, false, K);
+		for (u32 k = 0; k < A.cof_dbl; k++) {
+			K4 = dbl_rcb<G29_PB>(K4, K);
+		}
+		if (coord_is_zero<G29_PB>(K4.Z, K)) {
+			A.result[i] = 1;
+			return;
+		}
+	}
+	PtG<G29_PB> W = edfin_load(A.SG + (size_t)i * 2 * clen, sSG, clen, false, K);
+	const PtG<G29_PB> Rn = edfin_load(A.R + (size_t)i * 2 * clen, fR, clen, true, K);
+	const PtG<G29_PB> Hn = edfin_load(A.hA + (size_t)i * 2 * clen, shA, clen, true, K);
+	W = add_rcb<G29_PB>(W, Rn, K);
+	bool bad = coord_is_zero<G29_PB>(W.Z, K) & coord_is_zero<G29_PB>(W.Y, K);
+	W = add_rcb<G29_PB>(W, Hn, K);
+	bad = bad | (coord_is_zero<G29_PB>(W.Z, K) & coord_is_zero<G29_PB>(W.Y, K));
+	for (u32 k = 0; k < A.cof_dbl; k++) {
+		W = dbl_rcb<G29_PB>(W, K);
+	}
+	A.result[i] = (!bad && coord_is_zero<G29_PB>(W.Z, K)) ? 0 : 1;
+}
+
+hipError_t G29_CAT(ecamd_g29_ed_fin_, G29_TAG)(int gslot, const EcamdEdFinArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_ed_fin_g<G29_PB>, dim3((a.n + 63) / 64), dim3(64), 0, s, a, gslot);
+	return hipGetLastError();
+}
+#endif
+
 hipError_t G29_CAT(ecamd_g29_upload_, G29_TAG)(int slot, const void *img, size_t bytes)
 {
 	typedef CurveG<Lay<G29_PB>::NL> CK;
@@ -2868,6 +2958,20 @@ X(192s)
 X(256k)
 X(448g)
 #undef X
+hipError_t ecamd_g29_ed_fin_255c(int gslot, const EcamdEdFinArgs &a, hipStream_t s);
+hipError_t ecamd_g29_ed_fin_448g(int gslot, const EcamdEdFinArgs &a, hipStream_t s);
+
+// the tail of an EdDSA verification on the 2^255 - 19 (flavour 2) or the Goldilocks (flavour 5) unit
+hipError_t ecamd_launch_ed_fin_g29(int flavour, int gslot, const EcamdEdFinArgs &a, hipStream_t s)
+{
+	if (flavour == 2) {
+		return ecamd_g29_ed_fin_255c(gslot, a, s);
+	}
+	if (flavour == 5) {
+		return ecamd_g29_ed_fin_448g(gslot, a, s);
+	}
+	return hipErrorInvalidValue;
+}
 
 int ecamd_g29_supported(int pbits)
 {

@@ -2831,7 +2831,11 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 	F.clen = (uint32_t)len;
 	F.cof_dbl = cof_dbl;
 	F.slot = cv->slot;
-	HIPCHK(ecamd_launch_ed_fin(nw, F, s));
+	if (cv->gflavour == 2 && cv->gslot >= 0 && getenv("ECAMD_NO_ED_FIN_G") == nullptr) {
+		HIPCHK(ecamd_launch_ed_fin_g29(2, cv->gslot, F, s));   // the same tail on the 2^255 - 19 unit (k_ed_fin_g)
+	} else {
+		HIPCHK(ecamd_launch_ed_fin(nw, F, s));
+	}
 	return 0;
 }
 
@@ -3016,7 +3020,11 @@ static int eddsa448_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t 
 	F.Akey = S[3];      // [4]A = infinity <=> the stored key [4^-1 mod q]A has small order
 	F.stA = nullptr;
 	F.slot = cv->slot;
-	HIPCHK(ecamd_launch_ed_fin(cv->nw, F, s));
+	if (cv->gflavour == 5 && cv->gslot >= 0 && getenv("ECAMD_NO_ED_FIN_G") == nullptr) {
+		HIPCHK(ecamd_launch_ed_fin_g29(5, cv->gslot, F, s));   // the same tail on the Goldilocks unit (k_ed_fin_g)
+	} else {
+		HIPCHK(ecamd_launch_ed_fin(cv->nw, F, s));
+	}
 	return 0;
 }
 

@@ -277,6 +277,8 @@ struct EcamdXdhLadderArgs {
 hipError_t ecamd_launch_x25519_ladder(const EcamdXdhLadderArgs &a, int gslot, hipStream_t s, hipEvent_t *dom = nullptr);   // dom: two events around the ladder kernel
 hipError_t ecamd_launch_ed_scal(int nw, const EcamdEdScalArgs &a, hipStream_t s);
 hipError_t ecamd_launch_ed_fin(int nw, const EcamdEdFinArgs &a, hipStream_t s);
+// the same on the radix-2^29 / 2^28 field of the 2^255 - 19 (flavour 2) / Goldilocks (flavour 5) unit (k_ed_fin_g, ecamd_rcbg.h)
+hipError_t ecamd_launch_ed_fin_g29(int flavour, int gslot, const EcamdEdFinArgs &a, hipStream_t s);
 
 // ---- projective wire format X || Y || Z (curves/prj_pt.c:462, 562) ----
 struct EcamdPrjInArgs {

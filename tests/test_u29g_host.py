@@ -428,3 +428,104 @@ def test_mad_counts_match_the_work_model():
         f.fn("mul")(f.k, arr(f.digits(x)), arr(f.digits(x)), out, 1)
         got_s = lib.g_madcount_get()
         assert (got_m, got_s) == (M, S), (curve, "counted", got_m, got_s, "model", M, S)
+
+
+def _rcb_add_py(P, Q, a, b, p):
+    """RCB Algorithm 1 (generic a) over Python integers: the polynomials of ecamd_point.h:pt_add"""
+    X1, Y1, Z1 = P
+    X2, Y2, Z2 = Q
+    b3 = 3 * b
+    t0, t1, t2 = X1 * X2 % p, Y1 * Y2 % p, Z1 * Z2 % p
+    t3 = ((X1 + Y1) * (X2 + Y2) - t0 - t1) % p
+    t4 = ((X1 + Z1) * (X2 + Z2) - t0 - t2) % p
+    t5 = ((Y1 + Z1) * (Y2 + Z2) - t1 - t2) % p
+    z3 = (b3 * t2 + a * t4) % p
+    x3, z3 = (t1 - z3) % p, (t1 + z3) % p
+    y3 = x3 * z3 % p
+    t1 = (3 * t0 + a * t2) % p
+    t4 = (b3 * t4 + a * (t0 - a * t2)) % p
+    return ((t3 * x3 - t5 * t4) % p, (y3 + t1 * t4) % p, (t5 * z3 + t3 * t1) % p)
+
+
+def _rcb_dbl_py(P, a, b, p):
+    """RCB Algorithm 3 (generic a): the polynomials of ecamd_point.h:pt_dbl"""
+    X, Y, Z = P
+    b3 = 3 * b
+    t0, t1, t2 = X * X % p, Y * Y % p, Z * Z % p
+    t3, z3 = 2 * X * Y % p, 2 * X * Z % p
+    y3 = (a * z3 + b3 * t2) % p
+    x3, y3 = (t1 - y3) % p, (t1 + y3) % p
+    y3 = x3 * y3 % p
+    x3 = t3 * x3 % p
+    t3 = (a * (t0 - a * t2) + b3 * z3) % p
+    t0 = (3 * t0 + a * t2) % p
+    t2 = 2 * Y * Z % p
+    return ((x3 - t2 * t3) % p, (y3 + t0 * t3) % p, 4 * t2 * t1 % p)
+
+
+@pytest.mark.parametrize("curve,flavour,fixture", [("WEI25519", 2, "lib_p25519"), ("WEI448", 5, "lib_p448")])
+def test_complete_formulas_on_the_radix29_types(curve, flavour, fixture, request):
+    """ecamd_rcbg.h (the tail of the EdDSA verifications on the 2^255 - 19 and Goldilocks units): the same FIELD ELEMENTS as the
+    Renes-Costello-Batina polynomials over Python integers -- not just the same projective point -- for random pairs, P + P,
+    P + (-P), infinity on either side, and the exceptional pairs of these even-order curves (P and P + T with T of order two:
+    the result is (0 : 0 : 0), which the callers reject as libecc's prj_pt_add does)."""
+    lib = request.getfixturevalue(fixture)
+    rng = np.random.default_rng(99)
+    f = Field(lib, curve, flavour)
+    c = CURVES[curve]
+    p, a, b = f.p, f.a, f.b
+    G0 = (c["gx"], c["gy"])
+
+    def proj(P):
+        if P is None:
+            return (0, 1, 0)
+        z = int.from_bytes(rng.bytes(80), "big") % p or 1
+        return (P[0] * z % p, P[1] * z % p, z)
+
+    def limbs(P):
+        return f.fa(rng, P[0]) + f.fa(rng, P[1]) + f.fa(rng, P[2])
+
+    def got(out):
+        nl = f.nl
+        return tuple(f.val(out[k * nl:(k + 1) * nl]) % p for k in range(3))
+
+    def in_class(out):
+        nl = f.nl
+        for k in range(3):
+            part = out[k * nl:(k + 1) * nl]
+            assert max(part[:-1]) <= f.fa_lb and part[-1] <= f.fa_tb and f.val(part) < f.va * p
+
+    # the point of order two: (x0, 0) with x0 a root of x^3 + a x + b (x0 = A / 3 on these two curves' Montgomery twins)
+    A = {"WEI25519": 486662, "WEI448": 156326}[curve]
+    x0 = next(x for x in (A * pow(3, p - 2, p) % p, (-A) * pow(3, p - 2, p) % p) if (x * x * x + a * x + b) % p == 0)
+    T2 = (x0, 0)
+    pts = [G0]
+    for _ in range(6):
+        pts.append(aff_add(pts[-1], G0, a, p))
+    cases = []
+    for i in range(1, 6):
+        cases.append((pts[i], pts[i - 1]))                 # generic pairs
+    cases += [(pts[2], pts[2]), (pts[3], (pts[3][0], p - pts[3][1])), (None, pts[1]), (pts[1], None), (None, None),
+              (T2, T2), (pts[1], T2)]
+    Q = aff_add(pts[4], T2, a, p)
+    cases += [(pts[4], Q), (Q, pts[4])]                    # exceptional: the difference has order two
+    fn = f.fn("rcb")
+    for P, Q in cases:
+        PP, QQ = proj(P), proj(Q)
+        out = (C.c_uint32 * (3 * f.nl))()
+        flags = fn(f.k, arr(limbs(PP)), arr(limbs(QQ)), out, 0)
+        exp = _rcb_add_py(PP, QQ, a, b, p)
+        assert got(list(out)) == exp, (curve, P, Q)
+        assert flags == (1 if exp[1] == 0 else 0) | (2 if exp[2] == 0 else 0)
+        in_class(list(out))
+        if P is not None and Q is not None and P != Q and (P[0] != Q[0]) and aff_add(P, (Q[0], p - Q[1]), a, p) != T2:
+            R = aff_add(P, Q, a, p)
+            zi = pow(exp[2], p - 2, p)
+            assert (exp[0] * zi % p, exp[1] * zi % p) == R
+        out2 = (C.c_uint32 * (3 * f.nl))()
+        fn(f.k, arr(limbs(PP)), arr(limbs(PP)), out2, 1)
+        assert got(list(out2)) == _rcb_dbl_py(PP, a, b, p)
+        in_class(list(out2))
+    # the exceptional pairs do give (0 : 0 : 0)
+    e = _rcb_add_py(proj(pts[4]), proj(aff_add(pts[4], T2, a, p)), a, b, p)
+    assert e == (0, 0, 0)

@@ -7,6 +7,10 @@
 extern "C" { uint64_t ecamd_mad_count = 0; }
 #endif
 #include "../libecc_amd/csrc/ecamd_jacg.h"
+#if defined(G29_P25519) || defined(G29_P448)
+#include "../libecc_amd/csrc/ecamd_rcbg.h"   /* the two units whose EdDSA tail uses it */
+#define SHIM_RCB 1
+#endif
 #ifdef ECAMD_COUNT_MADS
 extern "C" void g_madcount_reset(void) { ecamd_mad_count = 0; }
 extern "C" uint64_t g_madcount_get(void) { return ecamd_mad_count; }
@@ -128,6 +132,27 @@ template <int PB> struct Shim {
 		memcpy(x.l, a, 4 * NL);
 		canonical_digits(digits, x, K);
 	}
+#ifdef SHIM_RCB
+	// complete (RCB) addition / doubling of ecamd_rcbg.h: p, q, out = X || Y || Z (FA class); dbl: q ignored.  Returns Y == Z == 0
+	static int rcb_(const uint32_t *k, const uint32_t *p, const uint32_t *q, uint32_t *out, int dbl)
+	{
+		const CK &K = *(const CK *)k;
+		rcbg::PtG<PB> P, Q;
+		memcpy(P.X.l, p, 4 * NL);
+		memcpy(P.Y.l, p + NL, 4 * NL);
+		memcpy(P.Z.l, p + 2 * NL, 4 * NL);
+		memcpy(Q.X.l, q, 4 * NL);
+		memcpy(Q.Y.l, q + NL, 4 * NL);
+		memcpy(Q.Z.l, q + 2 * NL, 4 * NL);
+		const rcbg::PtG<PB> R = dbl ? rcbg::dbl_rcb<PB>(P, K) : rcbg::add_rcb<PB>(P, Q, K);
+		memcpy(out, R.X.l, 4 * NL);
+		memcpy(out + NL, R.Y.l, 4 * NL);
+		memcpy(out + 2 * NL, R.Z.l, 4 * NL);
+		return (rcbg::coord_is_zero<PB>(R.Y, K) ? 1 : 0) | (rcbg::coord_is_zero<PB>(R.Z, K) ? 2 : 0);
+	}
+#else
+	static int rcb_(const uint32_t *, const uint32_t *, const uint32_t *, uint32_t *, int) { return -1; }
+#endif
 	static void info_(uint32_t *out)
 	{
 		out[0] = NL;
@@ -153,6 +178,7 @@ template <int PB> struct Shim {
 	void g_inv_##PB(const uint32_t *k, const uint32_t *a, uint32_t *o) { Shim<PB>::inv_(k, a, o); } \
 	void g_canon_##PB(const uint32_t *k, const uint32_t *a, uint32_t *o) { Shim<PB>::canon_(k, a, o); } \
 	void g_info_##PB(uint32_t *o) { Shim<PB>::info_(o); } \
+	int g_rcb_##PB(const uint32_t *k, const uint32_t *p, const uint32_t *q, uint32_t *o, int dbl) { return Shim<PB>::rcb_(k, p, q, o, dbl); } \
 	}
 #if defined(SHIM_ONLY_255)
 SHIM(255)
