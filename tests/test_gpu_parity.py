@@ -1320,7 +1320,7 @@ def test_host_pipeline_multi_chunk(gpu_ctx):
 
 @pytest.mark.parametrize("env", ["ECAMD_NO_COMB", "ECAMD_NO_P25519", "ECAMD_NO_X25519_LADDER", "ECAMD_NO_EDWARDS_SMUL",
                                  "ECAMD_NO_FAST_PATH", "ECAMD_NO_ISO", "ECAMD_NO_K256", "ECAMD_NO_P448",
-                                 "ECAMD_NO_ED_LATE_MAP", "ECAMD_NO_G448_DECODE", "ECAMD_NO_X448_LADDER"])
+                                 "ECAMD_NO_ED_LATE_MAP", "ECAMD_NO_G448_DECODE", "ECAMD_NO_X448_LADDER", "ECAMD_NO_ED_FIN_G"])
 def test_fallback_paths_stay_correct(env):
     """every fast path has a switch that routes around it (A/B measurements, fallbacks): the slower routes
     must give the same bytes -- fixed-base without the comb, WEI25519 on the dense field, X25519 and Ed25519
