@@ -58,9 +58,9 @@ def field_mads(p):
         M, S, red = nl * nl + 4 * nl, nl * (nl + 1) // 2 + 4 * nl, 4 * nl
     if p == 2**224 - 2**96 + 1 or p == 2**192 - 2**64 - 1:   # secp224r1 / secp192r1: two signed MADs per quotient digit
         M, S, red = nl * nl + 2 * nl, nl * (nl + 1) // 2 + 2 * nl, 2 * nl
-    if p == 2**255 - 19:                             # 2^255 - 19: 9 limbs, 9 fold MADs riding in the low columns
-        nl = 9
-        M, S, red = nl * nl + nl, nl * (nl + 1) // 2 + nl, nl
+    if p == 2**255 - 19:                             # 2^255 - 19: 9 limbs; the eight high columns fold as their two register halves,
+        nl = 9                                       # 2 x 8 MADs with wave-uniform multipliers riding in the low columns (round 4)
+        M, S, red = nl * nl + 16, nl * (nl + 1) // 2 + 16, 16
     if p == 2**448 - 2**224 - 1:                     # Goldilocks: 16 limbs of 28 bits, phi^2 = phi + 1 folded inside the columns;
         M, S, red = nl * nl, 2 * 36 + 64, 0          # squaring a0^2 + a1^2 (36 each) and a1 (2 a0 + a1) (64), ecamd_u29g.h:mul_p448
     if p == 2**256 - 2**32 - 977:                    # secp256k1: 9 limbs, 9 + 8 + 2 = 19 fold MADs riding in the low columns + 977 q

@@ -1346,11 +1346,6 @@ __global__ __launch_bounds__(64) X25519_OCC void k_x25519_ladder(EcamdXdhLadderA
 	for (int w = 0; w < 9; w++) {
 		z2.l[w] = 0;
 	}
-	FC a24;
-#pragma unroll
-	for (int w = 0; w < 9; w++) {
-		a24.l[w] = (w == 0) ? 121665u : 0u;
-	}
 	u32 swap = 0;
 #pragma unroll 1
 	for (int t = 254; t >= 0; t--) {
@@ -1381,7 +1376,7 @@ __global__ __launch_bounds__(64) X25519_OCC void k_x25519_ladder(EcamdXdhLadderA
 		x3 = weaken<FM>(sqrc(carry(add(da, cb)), K));
 		z3 = weaken<FM>(mulc(x1, sqrc(carry(sub_auto<1>(da, cb, K)), K), K));
 		x2 = weaken<FM>(mul(aa, bb, K));
-		z2 = weaken<FM>(mulc(e, carry(add(aa, mulc(a24, e, K))), K));
+		z2 = weaken<FM>(mulc(e, carry(add(aa, mul_word<121665u>(e))), K));   // a24 e: nine MADs (round 3: a full product, 90)
 	}
 	{
 		const FM tx = selg(swap != 0, x3, x2), tz = selg(swap != 0, z3, z2);
@@ -1560,8 +1555,8 @@ template <bool WITH_T> static __device__ __forceinline__ Ext ed_dbl(const Ext &P
 	return R;
 }
 
-// P + (+-Q) for the precomputed entry Q (negated when neg)
-static __device__ __forceinline__ Ext ed_add(const Ext &P, const Pre &Q, bool neg, const CK &K)
+// P + (+-Q) for the precomputed entry Q (negated when neg); WITH_T = false when a doubling follows (it does not read T): 7 M
+template <bool WITH_T = true> static __device__ __forceinline__ Ext ed_add(const Ext &P, const Pre &Q, bool neg, const CK &K)
 {
 	const FM qa = selg(neg, Q.ypx, Q.ymx), qb = selg(neg, Q.ymx, Q.ypx);
 	const FM a = M_(carry(sub_auto<1>(P.Y, P.X, K)), qa);
@@ -1580,7 +1575,11 @@ static __device__ __forceinline__ Ext ed_add(const Ext &P, const Pre &Q, bool ne
 	Ext R;
 	R.X = M_(e, f);
 	R.Y = M_(g, hh);
-	R.T = M_(e, hh);
+	if (WITH_T) {
+		R.T = M_(e, hh);
+	} else {
+		R.T = P.T;
+	}
 	R.Z = M_(f, g);
 	return R;
 }
@@ -1726,6 +1725,70 @@ static __device__ __forceinline__ void ed_window_add(Ext &acc, const u32 *tb, u3
 	acc.Z = selg(keep, acc.Z, S.Z);
 	acc.T = selg(keep, acc.T, S.T);
 }
+// ---- round 4: the whole tail of an Ed25519 verification on the Edwards curve (k_ed_tail_c25519) ----
+// affine precomputed entry (the comb table of B, a decoded R): y - x, y + x, 2d x y
+struct PreA {
+	FM ymx, ypx, t2d;
+};
+// P + (+-Q) for an affine precomputed Q (Z2 = 1, so D = 2 Z1 costs no multiplication): 7 M, 6 M without T
+template <bool WITH_T> static __device__ __forceinline__ Ext ed_madd(const Ext &P, const PreA &Q, bool neg, const CK &K)
+{
+	const FM qa = selg(neg, Q.ypx, Q.ymx), qb = selg(neg, Q.ymx, Q.ypx);
+	const FM a = M_(carry(sub_auto<1>(P.Y, P.X, K)), qa);
+	const FM b = M_(carry(add(P.Y, P.X)), qb);
+	const FM c = M_(P.T, Q.t2d);
+	const auto d = carry(mul_small<2>(P.Z));
+	const auto e = carry(sub_auto<1>(b, a, K));
+	const auto hh = carry(add(b, a));
+	const auto dmc = carry(sub_auto<1>(d, c, K));
+	const auto dpc = carry(add(d, c));
+	typedef decltype(dmc) TS;
+	typedef decltype(dpc) TA;
+	typedef E<PB, cmax(TS::LB, TA::LB), cmax(TS::TB, TA::TB), cmax(TS::VB, TA::VB)> TU;
+	const TU f = selg(neg, weaken<TU>(dpc), weaken<TU>(dmc));
+	const TU g = selg(neg, weaken<TU>(dmc), weaken<TU>(dpc));
+	Ext R;
+	R.X = M_(e, f);
+	R.Y = M_(g, hh);
+	if (WITH_T) {
+		R.T = M_(e, hh);
+	} else {
+		R.T = P.T;
+	}
+	R.Z = M_(f, g);
+	return R;
+}
+// (x, y) affine -> precomputed entry
+template <class AX, class AY> static __device__ __forceinline__ PreA ed_prea(const AX &x, const AY &y, const FC &d2, const CK &K)
+{
+	const FC onec = constant<FC>(K.one);
+	PreA Q;
+	Q.ymx = M_(carry(sub_auto<1>(y, x, K)), onec);
+	Q.ypx = M_(carry(add(y, x)), onec);
+	Q.t2d = M_(M_(x, y), d2);
+	return Q;
+}
+#define EDC_ENT_WORDS 32          /* one comb entry: ymx, ypx, t2d (canonical digits) + padding: 128 bytes, one cache line */
+#define EDC_PER_WIN 32768
+#define EDC_NWIN 16
+static __device__ __forceinline__ PreA prea_load(const u32 *ent)
+{
+	u32 buf[28];
+	const uint4 *src = (const uint4 *)ent;
+#pragma unroll
+	for (int q = 0; q < 7; q++) {
+		const uint4 v = src[q];
+		buf[4 * q] = v.x; buf[4 * q + 1] = v.y; buf[4 * q + 2] = v.z; buf[4 * q + 3] = v.w;
+	}
+	PreA Q;
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		Q.ymx.l[w] = buf[w];
+		Q.ypx.l[w] = buf[9 + w];
+		Q.t2d.l[w] = buf[18 + w];
+	}
+	return Q;
+}
 #undef M_
 #undef S_
 }  // namespace c25519
@@ -1857,12 +1920,11 @@ template <int phase> __global__ __launch_bounds__(64, phase == 1 ? ED_SMUL_WAVES
 			kw[w] = (kw[w] << 4) | (kw[w - 1] >> 28);
 		}
 		kw[0] <<= 4;
-		const Ext S = ed_add(acc, Q, dig < 0, K);
+		const Ext S = ed_add<false>(acc, Q, dig < 0, K);   // four doublings follow, or the end: T is not read again
 		const bool keep = (mag == 0);
 		acc.X = selg(keep, acc.X, S.X);
 		acc.Y = selg(keep, acc.Y, S.Y);
 		acc.Z = selg(keep, acc.Z, S.Z);
-		acc.T = selg(keep, acc.T, S.T);
 	}
 	u32 buf[EDR_REC_WORDS];
 #pragma unroll
@@ -2254,6 +2316,168 @@ hipError_t ecamd_launch_edmsm_reduce(const EcamdEdMsmArgs &a, uint32_t *tmp, con
 	return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 4: the Edwards comb table of the base point and the tail of an Ed25519 verification on the Edwards curve.
+//
+// k_edcomb_build_c25519: the affine Weierstrass points [m 2^(16 j)]G the engine computed for the comb table of the generator
+// (maybe_build_comb's batch) -> the same multiples of B on edwards25519, as precomputed entries (y - x, y + x, 2d x y):
+// x = alpha u / v, y = (u - 1) / (u + 1) with u = X - A/3, v = Y (the inverse of the map in k_ed_hA_fin); one inversion per entry,
+// a one-time cost per curve handle.  Multiples of B have odd prime order: v (u + 1) != 0.
+//
+// k_ed_tail_c25519: [S]B by seventeen mixed additions from that table, then the reference's tail (sig/eddsa.c:2225-2243)
+//     W1 = [S]G - R,   W2 = W1 - [h]A,   [8]W2 == infinity
+// on the Edwards curve: the map to the Weierstrass model is a group isomorphism defined on every point, so the sums are the same
+// points and [8]W2 is the point at infinity exactly when it is the neutral element (0 : Z : Z) here.  What the map does not carry
+// over is prj_pt_add's failure (curves/prj_pt.c:1058-1060, the complete formulas of RCB15 Alg. 1 on a curve of even order):
+// the call returns -1, and the reference rejects the signature, exactly when the DIFFERENCE of the two summands is the point of
+// order two (tests/test_ed_tail_model.py checks that characterisation against the formulas of the oracle on every torsion coset).
+// Restated on this curve, with T2 = (0, -1) = -T2:
+//     [S]G - (-R) = T2   <=>  [S]B = (x_R, -y_R)                      (E1)
+//     W1 - (-[h]A) = T2  <=>  W1 = (x_hA, -y_hA)                      (E2)
+// -- two projective comparisons; a rejection by either overrides the equation, as the -1 does in the reference.  R decoded to the
+// neutral element (flagsR = 2: the reference's point at infinity) enters as (0, 1).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_edcomb_build_c25519(const u8 *pts, u32 n, u32 *table, EcamdEdTailConsts Cst, int gslot)
+{
+	using namespace c25519;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= n) {
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const FC onec = constant<FC>(K.one);
+	u32 xw[8], yw[8];
+	load_be<8>(pts + (size_t)i * 64, 32, xw);
+	load_be<8>(pts + (size_t)i * 64 + 32, 32, yw);
+	const FM X = weaken<FM>(mul(from_words<PB, 8>(xw), constant<FC>(K.ix), K));
+	const FM v = weaken<FM>(mul(from_words<PB, 8>(yw), constant<FC>(K.iy), K));
+	const auto u = carry(sub_auto<1>(X, digits9(Cst.g_A3), K));
+	const auto up1 = carry(add(u, onec));
+	const auto um1 = carry(sub_auto<1>(u, onec, K));
+	const FM den = weaken<FM>(mulc(v, up1, K));
+	FM a11;
+	const FM inv = weaken<FM>(mul(sqr_n(pow_2_250m1(den, &a11, K), 5, K), a11, K));   // den^(p - 2)
+	const FM x = weaken<FM>(mul(mul(mulc(mulc(digits9(Cst.g_alpha), u, K), up1, K), inv, K), onec, K));
+	const FM y = weaken<FM>(mul(mulc(mulc(um1, v, K), inv, K), onec, K));
+	const PreA Q = ed_prea(x, y, digits9(Cst.g_2d), K);
+	u32 buf[EDC_ENT_WORDS];
+	canonical_digits(buf, Q.ymx, K);
+	canonical_digits(buf + 9, Q.ypx, K);
+	canonical_digits(buf + 18, Q.t2d, K);
+#pragma unroll
+	for (int w = 27; w < EDC_ENT_WORDS; w++) {
+		buf[w] = 0;
+	}
+	uint4 *dst = (uint4 *)(table + (size_t)i * EDC_ENT_WORDS);
+#pragma unroll
+	for (int q = 0; q < EDC_ENT_WORDS / 4; q++) {
+		dst[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
+	}
+}
+
+__global__ __launch_bounds__(64) void k_ed_tail_c25519(EcamdEdTailArgs A, int gslot)
+{
+	using namespace c25519;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const u32 fR = A.flagsR[i];   // 2: R decoded to the neutral element (the reference's point at infinity)
+	if (A.flagsA[i] || fR == 1 || A.flagsS[i]) {
+		A.result[i] = 1;
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const FC d2 = digits9(A.C.g_2d);
+	// ---- [S]B: K = S + 0x8000..8000, signed 16-bit digits, one mixed addition per window ----
+	u32 kw[9];
+	load_be<8>(A.S_be + (size_t)i * 32, 32, kw);
+	{
+		uint64_t c = 0;
+#pragma unroll
+		for (int w = 0; w < 8; w++) {
+			c += (uint64_t)kw[w] + 0x80008000u;
+			kw[w] = (u32)c;
+			c >>= 32;
+		}
+		kw[8] = (u32)c;   // top digit: 0 or 1
+	}
+	Ext SG = ed_neutral(K);
+#pragma unroll 1
+	for (int j = 0; j <= EDC_NWIN; j++) {
+		u32 word = 0;
+#pragma unroll
+		for (int w = 0; w < 9; w++) {
+			word = (w == (j >> 1)) ? kw[w] : word;
+		}
+		const int dig = (j < EDC_NWIN) ? (int)((word >> (16 * (j & 1))) & 0xffffu) - 0x8000 : (int)word;
+		const u32 mag = (u32)(dig < 0 ? -dig : dig);
+		const PreA Q = prea_load(A.comb + ((size_t)j * EDC_PER_WIN + (mag ? mag - 1 : 0)) * EDC_ENT_WORDS);
+		const Ext S = ed_madd<true>(SG, Q, dig < 0, K);
+		const bool keep = (mag == 0);
+		SG.X = selg(keep, SG.X, S.X);
+		SG.Y = selg(keep, SG.Y, S.Y);
+		SG.Z = selg(keep, SG.Z, S.Z);
+		SG.T = selg(keep, SG.T, S.T);
+	}
+	// ---- R (affine; (0, 1) when it decoded to the neutral element) ----
+	FM xr, yr;
+	edr_load(A.edR + (size_t)i * 20, xr, yr);
+	// E1: [S]B == (x_R, -y_R)
+	bool bad = eq(SG.X, mul(xr, SG.Z, K), K) & eq_neg(SG.Y, mul(yr, SG.Z, K), K);
+	// W1 = [S]B - R
+	const PreA QR = ed_prea(xr, yr, d2, K);
+	const Ext W1 = ed_madd<true>(SG, QR, true, K);
+	// ---- [h]A (X : Y : Z) from the window loop ----
+	FM hX, hY, hZ;
+	{
+		u32 buf[EDR_REC_WORDS];
+		const uint4 *src = (const uint4 *)(A.rec + (size_t)i * EDR_REC_WORDS);
+#pragma unroll
+		for (int q = 0; q < EDR_REC_WORDS / 4; q++) {
+			const uint4 v = src[q];
+			buf[4 * q] = v.x; buf[4 * q + 1] = v.y; buf[4 * q + 2] = v.z; buf[4 * q + 3] = v.w;
+		}
+#pragma unroll
+		for (int w = 0; w < 9; w++) {
+			hX.l[w] = buf[w];
+			hY.l[w] = buf[9 + w];
+			hZ.l[w] = buf[18 + w];
+		}
+	}
+	// E2: W1 == (x_hA, -y_hA), projectively
+	bad = bad | (eq(mul(W1.X, hZ, K), mul(hX, W1.Z, K), K) & eq_neg(mul(W1.Y, hZ, K), mul(hY, W1.Z, K), K));
+	// W2 = W1 - [h]A: (X : Y : Z) -> the extended point (X Z : Y Z : Z^2 : X Y), its precomputed form, one addition
+	Ext H;
+	H.X = weaken<FM>(mul(hX, hZ, K));
+	H.Y = weaken<FM>(mul(hY, hZ, K));
+	H.Z = weaken<FM>(sqr(hZ, K));
+	H.T = weaken<FM>(mul(hX, hY, K));
+	Ext W2 = ed_add<false>(W1, ed_pre(H, d2, K), true, K);
+	for (u32 k = 0; k < A.cof_dbl; k++) {
+		W2 = ed_dbl<false>(W2, K);
+	}
+	const bool neutral = is_zero_mulout(W2.X, K) & eq(W2.Y, W2.Z, K);
+	A.result[i] = (!bad && neutral) ? 0 : 1;
+}
+
+hipError_t ecamd_launch_edcomb_build_c25519(const uint8_t *pts, uint32_t n, uint32_t *table, const EcamdEdTailConsts &c, int gslot, hipStream_t s)
+{
+	if (n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_edcomb_build_c25519, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, table, c, gslot);
+	return hipGetLastError();
+}
+hipError_t ecamd_launch_ed_tail_c25519(const EcamdEdTailArgs &a, int gslot, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_ed_tail_c25519, dim3((a.n + 63) / 64), dim3(64), 0, s, a, gslot);
+	return hipGetLastError();
+}
+
 hipError_t ecamd_launch_ed_smul_c25519(const EcamdEdSmulArgs &a, int gslot, hipStream_t s, hipEvent_t *dom)
 {
 	if (a.n == 0) {
@@ -2267,8 +2491,10 @@ hipError_t ecamd_launch_ed_smul_c25519(const EcamdEdSmulArgs &a, int gslot, hipS
 	if (dom) {
 		(void)hipEventRecord(dom[1], s);
 	}
-	const uint32_t nthreads = (a.n + EDF_K - 1) / EDF_K;
-	hipLaunchKernelGGL(k_ed_hA_fin, dim3((nthreads + 63) / 64), dim3(64), 0, s, a, gslot, nthreads);
+	if (a.out != nullptr) {   // (NULL: the caller continues on the Edwards curve, k_ed_tail_c25519)
+		const uint32_t nthreads = (a.n + EDF_K - 1) / EDF_K;
+		hipLaunchKernelGGL(k_ed_hA_fin, dim3((nthreads + 63) / 64), dim3(64), 0, s, a, gslot, nthreads);
+	}
 	return hipGetLastError();
 }
 

@@ -290,6 +290,9 @@ struct ecamd_curve {
 	uint32_t *d_gtab; // secp256r1: affine window table [1..8]G, radix-2^29 Montgomery digits, 8 x 40 words
 	uint32_t *d_comb; // fast paths: 16-bit comb table of G, built on the first large fixed-base batch (NULL before / disabled)
 	bool comb_off;    // construction failed or is in progress: do not try (again)
+	uint32_t *d_edcomb; // WEI25519 on the 2^255 - 19 unit: 16-bit comb table of the Ed25519 base point ON THE EDWARDS CURVE
+	                    // (k_ed_tail_c25519), built on the first verification batch of comb_min_batch items; NULL before / disabled
+	bool edcomb_off;
 	uint32_t qdig[9]; // secp256r1: digits of the group order
 };
 
@@ -959,6 +962,10 @@ static void curve_free_device(ecamd_curve *cv)
 		(void)hipFree(cv->d_comb);
 		cv->d_comb = nullptr;
 	}
+	if (cv->d_edcomb) {
+		(void)hipFree(cv->d_edcomb);
+		cv->d_edcomb = nullptr;
+	}
 	if (cv->d_gtab) {
 		(void)hipFree(cv->d_gtab);
 		cv->d_gtab = nullptr;
@@ -998,6 +1005,8 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	cv->slot = cv->qslot = cv->gslot = -1;
 	cv->d_gen = nullptr;
 	cv->d_comb = nullptr;
+	cv->d_edcomb = nullptr;
+	cv->edcomb_off = false;
 	cv->d_gtab = nullptr;
 	if (!(cv->p[0] & 1) || big_bitlen(cv->p) < 160) {
 		return curve_abort(cv, "curve: p must be odd and at least 160 bits");
@@ -1099,6 +1108,8 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	cv->d_gtab = nullptr;
 	cv->d_comb = nullptr;
 	cv->comb_off = false;
+	cv->d_edcomb = nullptr;
+	cv->edcomb_off = false;
 	cv->sqrt_state = 0;
 	cv->ed_state = 0;
 	cv->ed448_state = 0;
@@ -2709,6 +2720,65 @@ static void ed_setup(ecamd_curve *cv)
 	cv->ed_state = 1;
 }
 
+// Round 4: the 16-bit comb table of the Ed25519 base point on the Edwards curve, T[j][m-1] = [m 2^(16 j)]B (m = 1..32768, j < 16)
+// and [2^256]B, as precomputed entries (y - x, y + x, 2d x y), 128 bytes each (67 MB of the 288 GB).  The multiples come from this
+// engine's own scalar multiplication on the Weierstrass model -- the batch maybe_build_comb uses -- and k_edcomb_build_c25519 maps
+// them to the Edwards curve.  With it k_ed_tail_c25519 finishes a verification without leaving the Edwards curve.  ctx->mu held.
+static void maybe_build_edcomb(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n)
+{
+	if (cv->d_edcomb || cv->edcomb_off || ctx->comb_min_batch == 0 || n < ctx->comb_min_batch || cv->gflavour != 2 || cv->gslot < 0) {
+		return;
+	}
+	cv->edcomb_off = true;   // stays set if anything fails
+	if (hipDeviceSynchronize() != hipSuccess) {   // the build borrows the context's scratch (see maybe_build_comb)
+		return;
+	}
+	const uint32_t slen = 32, nwin = 16, ne = ECAMD_EDC_ENTRIES;
+	std::vector<uint8_t> hs((size_t)ne * slen, 0);
+	for (uint32_t j = 0; j < nwin; j++) {
+		for (uint32_t m = 1; m <= 32768; m++) {
+			uint8_t *e = &hs[((size_t)j * 32768 + (m - 1)) * slen];
+			e[slen - 1 - 2 * j] = (uint8_t)(m & 0xff);
+			e[slen - 2 - 2 * j] = (uint8_t)(m >> 8);
+		}
+	}
+	big_to_be(&hs[(size_t)nwin * 32768 * slen], (int)slen, big_mod(big_pow2(256), cv->q));
+	uint8_t *dsc = nullptr, *dpt = nullptr, *dst = nullptr;
+	uint32_t *table = nullptr;
+	std::vector<uint8_t> st(ne);
+	hipStream_t s = ctx->stream;
+	bool ok = hipMalloc((void **)&dsc, hs.size()) == hipSuccess && hipMalloc((void **)&dpt, (size_t)ne * 64) == hipSuccess &&
+		  hipMalloc((void **)&dst, ne) == hipSuccess && hipMalloc((void **)&table, (size_t)ne * ECAMD_EDC_ENT_WORDS * 4) == hipSuccess &&
+		  hipMemcpy(dsc, hs.data(), hs.size(), hipMemcpyHostToDevice) == hipSuccess;
+	{
+		const uint32_t user_chunk = ctx->max_chunk;
+		ctx->max_chunk = user_chunk < (1u << 20) ? (1u << 20) : user_chunk;
+		ok = ok && smul_dev_locked(ctx, cv, ne, dsc, slen, nullptr, dpt, dst, s) == 0;
+		ctx->max_chunk = user_chunk;
+	}
+	if (ok) {
+		EcamdEdTailConsts C;
+		memcpy(C.g_2d, cv->ed_2d, sizeof(C.g_2d));
+		memcpy(C.g_alpha, cv->ed_tmpl.g_alpha, sizeof(C.g_alpha));
+		memcpy(C.g_A3, cv->ed_tmpl.g_A3, sizeof(C.g_A3));
+		ok = ecamd_launch_edcomb_build_c25519(dpt, ne, table, C, cv->gslot, s) == hipSuccess &&
+		     hipMemcpyAsync(st.data(), dst, ne, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+	}
+	for (uint32_t i = 0; ok && i < ne; i++) {
+		ok = (st[i] == 0);
+	}
+	(void)hipFree(dsc);
+	(void)hipFree(dpt);
+	(void)hipFree(dst);
+	if (!ok) {
+		(void)hipFree(table);
+		(void)hipGetLastError();
+		return;   // the Weierstrass tail keeps serving
+	}
+	cv->d_edcomb = table;
+	cv->edcomb_off = false;
+}
+
 // device pointers in and out; only enqueues on s
 static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig,
 				   const uint8_t *d_hram, uint32_t hram_len, uint8_t *d_res, hipStream_t s)
@@ -2762,6 +2832,12 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 	// Edwards path: R's map to the Weierstrass model rides on the shared inversion of k_ed_hA_fin instead of costing the
 	// decode kernel an inversion per item (stage 19: R on the Edwards curve)
 	const bool late_map = edwards_hA && getenv("ECAMD_NO_ED_LATE_MAP") == nullptr;
+	// round 4: the whole tail on the Edwards curve ([S]B from the Edwards comb table; no map, no inversion, no Weierstrass pass)
+	bool ed_tail = false;
+	if (late_map && getenv("ECAMD_NO_ED_TAIL") == nullptr) {
+		maybe_build_edcomb(ctx, cv, n);
+		ed_tail = cv->d_edcomb != nullptr;
+	}
 	if (late_map) {
 		if (ensure(&ctx->stage[19], &ctx->stage_bytes[19], (size_t)n * 20 * 4)) {
 			return -1;
@@ -2806,8 +2882,28 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 			E.flagsR = S[6];
 			E.outR = S[4];
 		}
+		if (ed_tail) {
+			E.out = nullptr;   // no k_ed_hA_fin: [h]A stays in E.rec
+		}
 		HIPCHK(ecamd_launch_ed_smul_c25519(E, cv->gslot, s, ctx->timing ? ctx->ev_dom : nullptr));
 		ctx->ev_dom_valid = ctx->ev_dom_valid || ctx->timing;
+	}
+	if (ed_tail) {
+		EcamdEdTailArgs T;
+		memset(&T, 0, sizeof(T));
+		T.rec = (const uint32_t *)S[11];
+		T.edR = (const uint32_t *)ctx->stage[19];
+		T.flagsA = S[5];
+		T.flagsR = S[6];
+		T.flagsS = S[7];
+		T.S_be = S[8];
+		T.comb = cv->d_edcomb;
+		T.result = d_res;
+		T.n = n;
+		T.cof_dbl = cof_dbl;
+		memcpy(T.C.g_2d, cv->ed_2d, sizeof(T.C.g_2d));
+		HIPCHK(ecamd_launch_ed_tail_c25519(T, cv->gslot, s));
+		return 0;
 	}
 	{
 		PublicScalars pub_scope(ctx);   // h and S of a signature are public

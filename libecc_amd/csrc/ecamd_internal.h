@@ -153,6 +153,25 @@ struct EcamdEdSmulArgs {
 };
 #define ECAMD_EDT_ITEM_WORDS 320
 #define ECAMD_EDR_REC_WORDS 28
+// Round 4: the tail of an Ed25519 verification on the Edwards curve (k_ed_tail_c25519): [S]B from an Edwards comb table of the
+// base point, W1 = [S]B - R, W2 = W1 - [h]A, [8]W2 == neutral, with prj_pt_add's two failures restated as comparisons.
+struct EcamdEdTailConsts {
+	uint32_t g_2d[9], g_alpha[9], g_A3[9];   // plain radix-2^29 digits
+};
+#define ECAMD_EDC_ENT_WORDS 32
+#define ECAMD_EDC_ENTRIES (16u * 32768u + 1u)
+struct EcamdEdTailArgs {
+	const uint32_t *rec;     // n x ECAMD_EDR_REC_WORDS: [h]A (X, Y, Z) from k_ed_smul_c25519<1>
+	const uint32_t *edR;     // n x 20 words: R on the Edwards curve (k_ed_decode_ed_c25519)
+	const uint8_t *flagsA, *flagsR, *flagsS;
+	const uint8_t *S_be;     // n x 32 big-endian
+	const uint32_t *comb;    // ECAMD_EDC_ENTRIES x ECAMD_EDC_ENT_WORDS: [m 2^(16 j)]B as (y - x, y + x, 2d x y)
+	uint8_t *result;         // n: 0 accept / 1 reject
+	uint32_t n, cof_dbl;
+	EcamdEdTailConsts C;
+};
+hipError_t ecamd_launch_edcomb_build_c25519(const uint8_t *pts, uint32_t n, uint32_t *table, const EcamdEdTailConsts &c, int gslot, hipStream_t s);
+hipError_t ecamd_launch_ed_tail_c25519(const EcamdEdTailArgs &a, int gslot, hipStream_t s);
 hipError_t ecamd_launch_ed_smul_c25519(const EcamdEdSmulArgs &a, int gslot, hipStream_t s, hipEvent_t *dom = nullptr);   // dom: two events around the window loop
 // ---- Ed25519 whole-batch verification as ONE multi-scalar multiplication on the Edwards curve (2^255 - 19 unit) ----
 // T = [q - sum z_i S_i]B + sum_i ([z_i h_i mod q]A_i + [z_i]R_i), accepted when [8]T is the neutral element

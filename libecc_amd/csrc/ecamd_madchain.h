@@ -325,6 +325,45 @@ ECAMD_CHAIN_FN void ecamd_mad_chain(uint64_t &acc, uint64_t &acc2, const uint32_
 		}
 	}
 }
+// a chain of N <= 8 VGPR x VGPR products that STARTS an accumulator (first addend 0): no v_mov to clear the register pair
+template <int N> ECAMD_CHAIN_FN void ecamd_mad_chain_z(uint64_t &acc, const uint32_t *x, const uint32_t *y)
+{
+	uint64_t dead_;
+	static_assert(N >= 1 && N <= 8, "zero-start chains of one to eight products");
+	if constexpr (N == 1) {
+		asm("v_mad_u64_u32 %0, %1, %2, %3, 0"
+		    : "=&v"(acc), "=&s"(dead_)
+		    : "v"(x[0]), "v"(y[0]));
+	} 	else if constexpr (N == 2) {
+		asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+		    : "=&v"(acc), "=&s"(dead_)
+		    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]));
+	} 	else if constexpr (N == 3) {
+		asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+		    : "=&v"(acc), "=&s"(dead_)
+		    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]));
+	} 	else if constexpr (N == 4) {
+		asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+		    : "=&v"(acc), "=&s"(dead_)
+		    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]));
+	} 	else if constexpr (N == 5) {
+		asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+		    : "=&v"(acc), "=&s"(dead_)
+		    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]));
+	} 	else if constexpr (N == 6) {
+		asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
+		    : "=&v"(acc), "=&s"(dead_)
+		    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]));
+	} 	else if constexpr (N == 7) {
+		asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
+		    : "=&v"(acc), "=&s"(dead_)
+		    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]));
+	} 	else if constexpr (N == 8) {
+		asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
+		    : "=&v"(acc), "=&s"(dead_)
+		    : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]));
+	}
+}
 #else
 // host build (tests): -DECAMD_COUNT_MADS makes every MAD the field code would issue increment a counter, so that the work models of
 // bench.py can be checked against the code (tests/test_u29g_host.py::test_mad_counts_match_the_work_model)
@@ -347,6 +386,14 @@ ECAMD_CHAIN_FN void ecamd_mad_chain(uint64_t &acc, uint64_t &acc2, const uint32_
 		} else {
 			acc += (uint64_t)x[i] * y[i];
 		}
+	}
+}
+template <int N> ECAMD_CHAIN_FN void ecamd_mad_chain_z(uint64_t &acc, const uint32_t *x, const uint32_t *y)
+{
+	ECAMD_COUNT_MAD(N);
+	acc = 0;
+	for (int i = 0; i < N; i++) {
+		acc += (uint64_t)x[i] * y[i];
 	}
 }
 #endif

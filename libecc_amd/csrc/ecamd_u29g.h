@@ -250,7 +250,12 @@ template <int NL> constexpr bool mul_fits(u64 la, u64 lb)
 	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(dead_) : "v"(a), "s"(b)); } while (0)
 #define G29_MUL_VS(acc, a, b) \
 	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(acc), "=s"(dead_) : "v"(a), "s"(b)); } while (0)
+// two MADs with wave-uniform multipliers in one statement (one padding s_nop instead of two)
+#define G29_MAD2_VS(acc, a, b, c, d) \
+	do { u64 dead_; asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0" \
+			    : "+v"(acc), "=&s"(dead_) : "v"(a), "s"(b), "v"(c), "s"(d)); } while (0)
 #else
+#define G29_MAD2_VS(acc, a, b, c, d) do { ECAMD_COUNT_MAD(2); acc += (u64)(a) * (b) + (u64)(c) * (d); } while (0)
 #define G29_MUL_VS(acc, a, b) do { ECAMD_COUNT_MAD(1); acc = (u64)(a) * (b); } while (0)
 #define G29_MAD_VS(acc, a, b) do { ECAMD_COUNT_MAD(1); acc += (u64)(a) * (b); } while (0)
 #endif
@@ -620,11 +625,16 @@ template <bool SQR> G29_FN void mul_m521p(u32 *r, const u32 *a, const u32 *b)
 }
 
 // ---- 2^255 - 19 flavour (nine 29-bit limbs, plain residues; 2^261 = 64 * 2^255 = 1216 mod p) ----
-// The high columns 9..16 of the product are summed FIRST, on a carry chain of their own: digits h[0..7] and the last carry h[8]
-// (< va vb 2^17 <= 2^31, Cfg::prod_ok).  The low columns then take 1216 h[k] as one more MAD of column k, so the fold costs no pass
-// of its own: 81 + 9 MADs and 17 column ends (round 2: 92 MADs, 26 column ends).  Column 8 -- with the carry of column 7 -- holds
-// everything from 2^232 up: its bits from 23 up are multiples of 2^255 = 19 and go to limbs 0 and 1 lazily (19 q < 2^46: limb 1 below
-// 2^29 + 2^17), the result is below 2^255 + 2^47 < 2p with a top limb below 2^23.
+// Round 4 ("split fold", the default): the high columns 9..16 are summed into EIGHT INDEPENDENT 64-bit accumulators H_k -- no carry
+// chain, no column ends -- and fold as the two register halves they already are: H_k 2^(29 (9 + k)) = 1216 H_k 2^(29 k) and
+// H_k = lo32 + 2^32 hi32 = lo32 + 8 hi32 2^29, so column k takes 1216 lo32(H_k) and column k + 1 takes 9728 hi32(H_k): two MADs
+// with wave-uniform multipliers per high column instead of a MAD, a v_and_b32 and a v_lshrrev_b64 on a serial chain.
+// 81 + 16 MADs and 9 column ends (round 3: 81 + 9 MADs and 17 column ends, kept below as -DG29_P25519_CHAINFOLD; the high columns
+// first on a carry chain of their own: digits h[0..7] and the last carry h[8] < va vb 2^17 <= 2^31, Cfg::prod_ok, then 1216 h[k] as
+// one more MAD of column k).  Column 8 -- with the carry of column 7 -- holds everything from 2^232 up: its bits from 23 up are
+// multiples of 2^255 = 19 and go to limbs 0 and 1 lazily (19 q < 2^46: limb 1 below 2^29 + 2^17), the result is below
+// 2^255 + 2^47 < 2p with a top limb below 2^23.
+#if defined(G29_P25519_CHAINFOLD)
 template <bool SQR, int K_> G29_FN void p25519_column(u64 &acc, u32 *out, const u32 *a, const u32 *b, const u32 *a2, const u32 *h, u32 f)
 {
 	u64 acc2;
@@ -646,9 +656,48 @@ template <bool SQR, int... Ks> G29_FN void p25519_hi_columns(u64 &acc, u32 *out,
 {
 	(p25519_column<SQR, 9 + Ks>(acc, out, a, b, a2, nullptr, 0u), ...);
 }
+#else
+template <bool SQR, int K_> G29_FN void p25519_hi_column(u64 *H, const u32 *a, const u32 *b, const u32 *a2)
+{
+	typedef Column<9, SQR, 9 + K_> C;
+	u32 x[C::NPROD], y[C::NPROD];
+#pragma unroll
+	for (int n = 0; n < C::NPROD; n++) {
+		const int i = C::LO + n, j = 9 + K_ - i;
+		x[n] = a[i];
+		y[n] = !SQR ? b[j] : (i < j ? a2[j] : a[i]);
+	}
+	ecamd_mad_chain_z<C::NPROD>(H[K_], x, y);   // the chain starts its accumulator: no register pair to clear
+}
+template <bool SQR, int... Ks> G29_FN void p25519_hi_columns(u64 *H, const u32 *a, const u32 *b, const u32 *a2, std::integer_sequence<int, Ks...>)
+{
+	(p25519_hi_column<SQR, Ks>(H, a, b, a2), ...);
+}
+template <bool SQR, int K_> G29_FN void p25519_lo_column(u64 &acc, u32 *out, const u32 *a, const u32 *b, const u32 *a2, const u64 *H, u32 f, u32 f8)
+{
+	u64 acc2;
+	Column<9, SQR, K_>::products(acc, acc2, a, b, a2);
+	if constexpr (K_ >= 1 && K_ < 8) {
+		G29_MAD2_VS(acc, (u32)H[K_], f, (u32)(H[K_ - 1] >> 32), f8);
+	} else if constexpr (K_ < 8) {
+		G29_MAD_VS(acc, (u32)H[K_], f);
+	} else {
+		G29_MAD_VS(acc, (u32)(H[K_ - 1] >> 32), f8);
+	}
+	if constexpr (K_ != 8) {
+		out[K_] = (u32)acc & MASK;
+		acc >>= W;
+	}
+}
+template <bool SQR, int... Ks> G29_FN void p25519_lo_columns(u64 &acc, u32 *out, const u32 *a, const u32 *b, const u32 *a2, const u64 *H, u32 f, u32 f8,
+							     std::integer_sequence<int, Ks...>)
+{
+	(p25519_lo_column<SQR, Ks>(acc, out, a, b, a2, H, f, f8), ...);
+}
+#endif
 template <bool SQR> G29_FN void mul_p25519(u32 *r, const u32 *a, const u32 *b)
 {
-	u32 a2[9], h[9];
+	u32 a2[9];
 	if (SQR) {
 #pragma unroll
 		for (int i = 0; i < 9; i++) {
@@ -656,6 +705,8 @@ template <bool SQR> G29_FN void mul_p25519(u32 *r, const u32 *a, const u32 *b)
 		}
 	}
 	u32 f = 1216u;
+#if defined(G29_P25519_CHAINFOLD)
+	u32 h[9];
 #if defined(__HIPCC__)
 	asm volatile("" : "+s"(f));  // keep the folds MADs
 #endif
@@ -664,9 +715,44 @@ template <bool SQR> G29_FN void mul_p25519(u32 *r, const u32 *a, const u32 *b)
 	h[8] = (u32)acc;
 	acc = 0;
 	p25519_columns<SQR>(acc, r, a, b, a2, h, f, std::make_integer_sequence<int, 9>());    // columns 0..8 (8: products and fold only)
+#else
+	u32 f8 = 9728u;
+#if defined(__HIPCC__)
+	asm volatile("" : "+s"(f), "+s"(f8));  // keep the folds MADs
+#endif
+	u64 H[8];
+	p25519_hi_columns<SQR>(H, a, b, a2, std::make_integer_sequence<int, 8>());             // columns 9..16, no chain between them
+	u64 acc = 0;
+	p25519_lo_columns<SQR>(acc, r, a, b, a2, H, f, f8, std::make_integer_sequence<int, 9>());   // columns 0..8 (8: no column end)
+#endif
 	const u64 q = acc >> 23;                      // < 2^41
 	r[8] = (u32)acc & ((1u << 23) - 1);
 	const u64 w = (q << 4) + (q << 1) + q;        // 19 q < 2^46
+	const u32 r0 = r[0] + ((u32)w & MASK);
+	r[0] = r0 & MASK;
+	r[1] += (u32)(w >> W) + (r0 >> W);
+}
+
+// a * c for a small wave-uniform constant c < 2^20 on the 2^255 - 19 flavour (X25519's a24 = 121665): NINE MADs on one carry chain
+// instead of a 9 x 9 product against a constant whose eight upper limbs are zero.  Any limb bounds that fit 32 bits; the bits of
+// the last column from 2^255 up fold (x 19) into limbs 0 and 1 exactly as in mul_p25519, so the result is in the same class.
+template <bool DUMMY = true> G29_FN void mul_word_p25519(u32 *r, const u32 *a, u32 c)
+{
+#if defined(__HIPCC__)
+	asm volatile("" : "+s"(c));
+#endif
+	u64 acc = 0;
+#pragma unroll
+	for (int i = 0; i < 9; i++) {
+		G29_MAD_VS(acc, a[i], c);
+		if (i < 8) {
+			r[i] = (u32)acc & MASK;
+			acc >>= W;
+		}
+	}
+	const u64 q = acc >> 23;                      // < 2^(32 + 20 - 23 + 1)
+	r[8] = (u32)acc & ((1u << 23) - 1);
+	const u64 w = (q << 4) + (q << 1) + q;
 	const u32 r0 = r[0] + ((u32)w & MASK);
 	r[0] = r0 & MASK;
 	r[1] += (u32)(w >> W) + (r0 >> W);
@@ -1003,6 +1089,17 @@ template <class A, int NLc> G29_FN auto sqrc(const A &a, const CurveG<NLc> &K)
 	} else {
 		return sqr(carry(a), K);
 	}
+}
+
+// a * CST for a small constant (X25519's a24): nine MADs, result in the class of a multiplication result (mul_word_p25519)
+template <u32 CST, class A> G29_FN typename MulOut<A::C::PBITS, 2>::type mul_word(const A &a)
+{
+	static_assert(P25519 && A::C::NL == 9, "mul_word: only the 2^255 - 19 flavour has it");
+	static_assert(CST < (1u << 20) && A::LB < (1ull << 32) && A::TB < (1ull << 32), "mul_word: operand out of range");
+	static_assert(A::VB <= (1ull << 14), "mul_word: value out of range");
+	typename MulOut<A::C::PBITS, 2>::type r;
+	mul_word_p25519(r.l, a.l, CST);
+	return r;
 }
 
 // ---- exact zero test and canonical form of a multiplication result ----

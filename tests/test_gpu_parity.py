@@ -1252,6 +1252,38 @@ def test_eddsa25519_zero_challenge(gpu_ctx):
         cv.free()
 
 
+def test_eddsa25519_exceptional_pairs(gpu_ctx):
+    """signatures whose cofactored equation holds while one of the reference's two prj_pt_add calls meets its exceptional pair
+    (reachable through the API: the caller supplies the hash), with accepted neighbours -- on the Edwards tail of round 4
+    (k_ed_tail_c25519: batches of at least ECAMD_COMB_MIN_BATCH items), on the Weierstrass tail it replaces
+    (ECAMD_NO_ED_TAIL) and on a batch too small for the comb table; the zero-challenge and edge families through the new tail too"""
+    from test_ed_tail_model import ed_exceptional_cases
+    from test_oracle import ed25519_cases
+    rng = np.random.default_rng(43)
+    pubs, sigs, hram, kinds = ed_exceptional_cases(rng, n_each=8)
+    p2, s2, _, h2 = ed25519_cases(rng, nvalid=8)
+    pubs, sigs, hram = pubs + p2, sigs + s2, hram + h2
+    n = len(pubs) // 32
+    assert n >= 64
+    exp = Oracle("WEI25519").eddsa_verify(pubs, sigs, hram)
+    for k, e in zip(kinds, exp):
+        assert e == (1 if k in ("E1", "E2", "E1-wrongS") else 0), k
+    cv = gpu_ctx.curve("WEI25519")
+    try:
+        assert cv.eddsa_verify(pubs, sigs, hram) == exp                      # Edwards tail
+        assert cv.eddsa_verify(pubs[:32 * 20], sigs[:64 * 20], hram[:64 * 20]) == exp[:20]   # below the comb threshold
+        os.environ["ECAMD_NO_ED_TAIL"] = "1"
+        try:
+            assert cv.eddsa_verify(pubs, sigs, hram) == exp                  # Weierstrass tail
+        finally:
+            del os.environ["ECAMD_NO_ED_TAIL"]
+        # a larger tiled batch (several waves, ragged end)
+        reps = 4099 // n + 1
+        assert cv.eddsa_verify((pubs * reps)[:32 * 4099], (sigs * reps)[:64 * 4099], (hram * reps)[:64 * 4099]) == (exp * reps)[:4099]
+    finally:
+        cv.free()
+
+
 def test_host_pipeline_multi_chunk(gpu_ctx):
     """host-pointer entry points split a batch into chunks and overlap the copy of the next chunk with the
     kernels of the current one: a context with a tiny chunk (ECAMD_HOST_CHUNK) must give the same bytes as the

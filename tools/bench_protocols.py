@@ -189,10 +189,10 @@ def main():
         def ref_subset(idx):
             sp, ss, sm = (b"".join(x[w * i:w * i + w] for i in idx) for x, w in ((pubs, 32), (sigs, 64), (msgs, 32)))
             return O.join_slices(O.in_slices(lambda lo, hi: O.ref_ed25519_verify(sp[32 * lo:32 * hi], ss[64 * lo:64 * hi], sm[32 * lo:32 * hi], 32), len(idx)))
-        # dominant kernel k_ed_smul_c25519<1>: 64 windows of 3 doublings (3M + 4S), 1 doubling (4M + 4S) and 1 addition (8M) in
-        # extended coordinates; 2^255 - 19 flavour (high columns first, the fold rides in the low columns): M = 81 + 9 = 90, S = 45 + 9 = 54
-        # MADs, 9 of them with a constant multiplier
-        work = {"kernel": "k_ed_smul_c25519<1>", "mads_per_item": 64 * (21 * 90 + 16 * 54), "sgpr_mads_per_item": 64 * 37 * 9}
+        # dominant kernel k_ed_smul_c25519<1>: 64 windows of 3 doublings (3M + 4S), 1 doubling (4M + 4S) and 1 addition without its T
+        # (7M; round 3: 8M) in extended coordinates; 2^255 - 19 flavour (round 4: the high columns fold as their register halves):
+        # M = 81 + 16 = 97, S = 45 + 16 = 61 MADs, 16 of them with a constant multiplier
+        work = {"kernel": "k_ed_smul_c25519<1>", "mads_per_item": 64 * (20 * 97 + 16 * 61), "sgpr_mads_per_item": 64 * 36 * 16}
         metric, unit, cfg = "Ed25519 verifications/sec (batch=2^%d, %d distinct signatures tiled)" % (a.batch_log2, m), "verifications/s", 4
     elif a.workload == "ed448_verify":
         cv = ctx.curve("WEI448")
@@ -248,8 +248,9 @@ def main():
             work = {"kernel": "k_x448_ladder", "mads_per_item": 448 * (6 * 256 + 4 * 136) + 256, "sgpr_mads_per_item": 0}
             metric, unit, cfg = "X448 shared secrets/sec (batch=2^%d)" % a.batch_log2, "shared-secrets/s", "5], X448 counterpart [not in BASELINE"
         else:
-            # dominant kernel k_x25519_ladder: 255 steps of 6 multiplications (one of them by a24, run as a full product) and 4 squarings
-            work = {"kernel": "k_x25519_ladder", "mads_per_item": 255 * (6 * 90 + 4 * 54) + 90, "sgpr_mads_per_item": 255 * 10 * 9}
+            # dominant kernel k_x25519_ladder: 255 steps of 5 multiplications, 4 squarings and a24 e as nine MADs (round 3: a full
+            # product); M = 81 + 16 = 97, S = 45 + 16 = 61 MADs (ecamd_u29g.h:mul_p25519)
+            work = {"kernel": "k_x25519_ladder", "mads_per_item": 255 * (5 * 97 + 4 * 61 + 9) + 97, "sgpr_mads_per_item": 255 * (9 * 16 + 9)}
             metric, unit, cfg = "X25519 shared secrets/sec (batch=2^%d)" % a.batch_log2, "shared-secrets/s", 4
     gathered = torch.empty(world * B, dtype=torch.uint8, device=dev) if world > 1 else None
 
