@@ -56,6 +56,50 @@ typedef struct {
 
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;        /* the state below */
 static pthread_mutex_t g_call_mu = PTHREAD_MUTEX_INITIALIZER;   /* one batch call at a time: pool, staging buffers, GPUs */
+static pthread_mutex_t g_rand_mu = PTHREAD_MUTEX_INITIALIZER;   /* the application's get_random: one caller at a time (see compat_random_mod) */
+static u32 g_rand_concurrent;                                   /* ecamd_compat_set_concurrent_random */
+
+/* nn_get_random_mod (nn/nn_rand.c:92-150: q' = q - 1, a random value of twice q's length, out = that mod q' + 1) with the ONE call
+ * that reaches the application -- get_random -- made by one thread at a time.  libecc's scalar API never calls get_random from two
+ * threads at once unless the application does, and a stateful source (a user-space DRBG, a seeded test harness) need not be
+ * reentrant; the batch forms pack their items on a thread pool, so by default the draw is serialised here (a
+ * torn or repeated ECDSA nonce gives the private key away).  ecamd_compat_set_concurrent_random(1) removes the lock for
+ * applications whose get_random is thread-safe (e.g. one getrandom(2) / /dev/urandom read per call). */
+static int compat_random_mod(nn_t out, nn_src_t q)
+{
+	nn tmp_rand, qprime;
+	bitcnt_t q_bit_len, q_len;
+	int ret, isone;
+	qprime.magic = tmp_rand.magic = WORD(0);
+	ret = nn_check_initialized(q); EG(ret, err);
+	ret = nn_bitlen(q, &q_bit_len); EG(ret, err);
+	q_len = (bitcnt_t)BYTECEIL(q_bit_len);
+	MUST_HAVE((q_len) && (q_len <= (NN_MAX_BYTE_LEN / 2)), ret, err);
+	MUST_HAVE((!nn_isone(q, &isone)) && (!isone), ret, err);
+	ret = nn_copy(&qprime, q); EG(ret, err);
+	ret = nn_dec(&qprime, &qprime); EG(ret, err);
+	ret = nn_init(&tmp_rand, (u16)(2 * q_len)); EG(ret, err);
+	if (AT_LOAD(&g_rand_concurrent)) {
+		ret = get_random((u8 *)tmp_rand.val, (u16)(2 * q_len));
+	} else {
+		pthread_mutex_lock(&g_rand_mu);
+		ret = get_random((u8 *)tmp_rand.val, (u16)(2 * q_len));
+		pthread_mutex_unlock(&g_rand_mu);
+	}
+	EG(ret, err);
+	ret = nn_init(out, (u16)q_len); EG(ret, err);
+	ret = nn_mod_notrim(out, &tmp_rand, &qprime); EG(ret, err);
+	ret = nn_inc(out, out);
+err:
+	nn_uninit(&qprime);
+	nn_uninit(&tmp_rand);
+	return ret;
+}
+
+void ecamd_compat_set_concurrent_random(int on)
+{
+	AT_STORE(&g_rand_concurrent, on ? 1u : 0u);
+}
 static ecamd_multi *g_multi;
 static int g_threads;
 static int g_secret = 1;
@@ -1026,7 +1070,7 @@ static void blind_scalars(u32 lo, u32 hi, void *arg)
 		 * b random in [1, #E), scalar = m + b * #E */
 		nn b;
 		b.magic = WORD(0);
-		if (nn_get_random_mod(&b, B->order) || nn_mul(&b, &b, B->order) || nn_add(&B->mb[i], &B->m[i], &b)) {
+		if (compat_random_mod(&b, B->order) || nn_mul(&b, &b, B->order) || nn_add(&B->mb[i], &B->m[i], &b)) {
 			AT_STORE(&B->failed, 1);
 		}
 		nn_uninit(&b);
@@ -1212,7 +1256,7 @@ static void key_pack(u32 lo, u32 hi, void *arg)
 		if (J->mode == 1) {
 			/* ec_key_pair_gen (sig/ec_key.c:594-621) / ecccdh_gen_key_pair (ecdh/ecccdh.c:93-118) up to the public key */
 			ec_priv_key *w = &J->kps[i].priv_key;
-			bad = nn_get_random_mod(&w->x, &(J->params->ec_gen_order));
+			bad = compat_random_mod(&w->x, &(J->params->ec_gen_order));
 			w->key_type = J->alg;
 			w->params = J->params;
 			w->magic = PRIV_KEY_MAGIC;
@@ -1857,7 +1901,7 @@ static void ecdsa_sign_pack(u32 lo, u32 hi, void *arg)
 		} else if (!bad && !J->nonces_given) {
 			nn k;
 			k.magic = WORD(0);
-			bad = nn_get_random_mod(&k, &(J->params->ec_gen_order)) || nn_to_be(kb, J->qlen, &k);
+			bad = compat_random_mod(&k, &(J->params->ec_gen_order)) || nn_to_be(kb, J->qlen, &k);
 			nn_uninit(&k);
 		} else if (!bad) {
 			bad = J->pre[j];   /* the caller's rand hook failed for this item */
@@ -2035,6 +2079,8 @@ static void eddsa_sign_pack(u32 lo, u32 hi, void *arg)
 			}
 		}
 		wipe(dig, sizeof(dig));
+		wipe(&hc, sizeof(hc));   /* the hash context absorbed the secret prefix (the reference clears h_ctx, sig/eddsa.c:1883) */
+		wipe(ph, sizeof(ph));
 	}
 }
 
@@ -2444,11 +2490,21 @@ static int eddsa_ver_gpu_all(u32 lo, u32 hi, void *arg)
 		/* the z_i of the combination are keyed by the application's own randomness source, the import libecc draws them from
 		 * (sig/eddsa.c:2388; SURVEY.md 8b: get_random stays the application's) */
 		u8 seed[32];
-		if (get_random(seed, sizeof(seed)) || ecamd_multi_set_msm_seed(g_multi, seed)) {
+		int r = 0;
+		if (!J->is448) {   /* only the Ed25519 combination consumes a seed; the engine discards an unused one when the call returns */
+			if (AT_LOAD(&g_rand_concurrent)) {
+				r = get_random(seed, sizeof(seed));
+			} else {
+				pthread_mutex_lock(&g_rand_mu);
+				r = get_random(seed, sizeof(seed));
+				pthread_mutex_unlock(&g_rand_mu);
+			}
+			r = r || ecamd_multi_set_msm_seed(g_multi, seed);
 			wipe(seed, sizeof(seed));
-			return -1;
+			if (r) {
+				return -1;
+			}
 		}
-		wipe(seed, sizeof(seed));
 	}
 	if (ecamd_multi_eddsa_verify_all_batch(g_multi, J->e->mc, hi - lo, J->pk + (size_t)lo * J->klen, J->sg + (size_t)lo * J->siglen,
 					       J->dg + (size_t)lo * J->hlen, J->hlen, &all, NULL)) {

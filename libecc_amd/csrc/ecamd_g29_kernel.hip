@@ -2816,7 +2816,6 @@ __global__ __launch_bounds__(64) X448_OCC void k_x448_ladder(EcamdXdhLadderArgs 
 	for (int w = 0; w < 16; w++) {
 		z2.l[w] = 0;
 	}
-	const FC a24 = small_const(39081u);
 	u32 swap = 0;
 #pragma unroll 1
 	for (int t = 447; t >= 0; t--) {
@@ -2847,7 +2846,7 @@ __global__ __launch_bounds__(64) X448_OCC void k_x448_ladder(EcamdXdhLadderArgs 
 		x3 = S_(ADD_(da, cb));
 		z3 = M_(x1, S_(SUB_(da, cb)));
 		x2 = M_(aa, bb);
-		z2 = M_(e, ADD_(aa, M_(a24, e)));
+		z2 = M_(e, ADD_(aa, mul_word<39081u>(e)));   // a24 e: sixteen MADs (round 3: a full product, 256)
 	}
 	{
 		const FM tx = selg(swap != 0, x3, x2), tz = selg(swap != 0, z3, z2);

@@ -669,6 +669,10 @@ static int ensure(uint8_t **buf, size_t *have, size_t need)
 		return 0;
 	}
 	if (*buf) {
+		// a scratch buffer that has to grow may hold values derived from secret scalars (window tables, recoded or staged
+		// scalars of an earlier group of the same call): it goes back to the allocator zeroed
+		HIPCHK(hipMemset(*buf, 0, *have));
+		HIPCHK(hipDeviceSynchronize());
 		HIPCHK(hipFree(*buf));
 		*buf = nullptr;
 		*have = 0;
@@ -3380,7 +3384,19 @@ static int eddsa_msm_host_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, co
 	return 0;
 }
 
+static void msm_seed_discard(ecamd_ctx *ctx);
+static int eddsa_verify_all_batch_dev_impl(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const void *d_pubkeys,
+					     const void *d_sigs, const void *d_hram, uint32_t hram_len, void *d_verdict,
+					     void *hip_stream);
 extern "C" int ec_eddsa_verify_all_batch_dev(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const void *d_pubkeys,
+					     const void *d_sigs, const void *d_hram, uint32_t hram_len, void *d_verdict,
+					     void *hip_stream)
+{
+	const int r = eddsa_verify_all_batch_dev_impl(ctx, cv_in, n, d_pubkeys, d_sigs, d_hram, hram_len, d_verdict, hip_stream);
+	msm_seed_discard(ctx);
+	return r;
+}
+static int eddsa_verify_all_batch_dev_impl(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const void *d_pubkeys,
 					     const void *d_sigs, const void *d_hram, uint32_t hram_len, void *d_verdict,
 					     void *hip_stream)
 {
@@ -3440,9 +3456,32 @@ extern "C" int ecamd_debug_eddsa_msm(ecamd_ctx *ctx, const ecamd_curve *cv_in, u
 // batch when one random linear combination of the cofactored equations vanishes, which holds when every signature verifies
 // and fails otherwise except with probability ~2^-128 over its random z_i.  Here every item is verified (the batch is the
 // parallel dimension already), so the bit is the exact conjunction and the first rejected index comes for free.
+// the seed of ecamd_ctx_set_msm_seed keys ONE whole-batch call: whichever path that call took (Ed448, a batch below msm_min,
+// mode 0, an error), it is gone afterwards
+static void msm_seed_discard(ecamd_ctx *ctx)
+{
+	if (ctx) {
+		std::lock_guard<std::mutex> lk(ctx->mu);
+		if (ctx->msm_seed_valid) {
+			memset(ctx->msm_seed_bytes, 0, sizeof(ctx->msm_seed_bytes));
+			ctx->msm_seed_valid = false;
+		}
+	}
+}
+static int eddsa_verify_all_batch_impl(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys,
+				       const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, int *all_valid,
+				       uint32_t *first_rejected);
 extern "C" int ec_eddsa_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys,
 					 const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, int *all_valid,
 					 uint32_t *first_rejected)
+{
+	const int r = eddsa_verify_all_batch_impl(ctx, cv, n, pubkeys, sigs, hram, hram_len, all_valid, first_rejected);
+	msm_seed_discard(ctx);
+	return r;
+}
+static int eddsa_verify_all_batch_impl(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys,
+				       const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, int *all_valid,
+				       uint32_t *first_rejected)
 {
 	if (!all_valid || n == 0) {
 		return fail("ec_eddsa_verify_all_batch: bad argument (the reference rejects num = 0 too)");

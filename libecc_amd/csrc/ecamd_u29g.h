@@ -758,6 +758,28 @@ template <bool DUMMY = true> G29_FN void mul_word_p25519(u32 *r, const u32 *a, u
 	r[1] += (u32)(w >> W) + (r0 >> W);
 }
 
+// the same for the Goldilocks flavour (X448's a24 = 39081): sixteen MADs on one chain through both halves; the carry out of limb 15
+// (multiples of 2^448 = phi + 1, below 2^24 here) goes to limbs 0 and 8 as in mul_p448
+template <bool DUMMY = true> G29_FN void mul_word_p448(u32 *r, const u32 *a, u32 c)
+{
+#if defined(__HIPCC__)
+	asm volatile("" : "+s"(c));
+#endif
+	u64 acc = 0;
+#pragma unroll
+	for (int i = 0; i < 16; i++) {
+		G29_MAD_VS(acc, a[i], c);
+		r[i] = (u32)acc & MASK;
+		acc >>= W;
+	}
+	const u32 chi = (u32)acc;                     // < 2^(32 + 20 - 28)
+	const u32 r0 = r[0] + chi, r8 = r[8] + chi;
+	r[0] = r0 & MASK;
+	r[1] += r0 >> W;
+	r[8] = r8 & MASK;
+	r[9] += r8 >> W;
+}
+
 // ---- secp256k1 flavour (p = 2^256 - 2^32 - 977, nine 29-bit limbs, plain residues) ----
 // The same order as above: high columns first (digits h[0..7], last carry h[8] < va vb 2^19 <= 2^31), then the low columns with the
 // fold riding in them.  2^261 = 32 (2^32 + 977) = 2^8 2^29 + 31264: h[k] goes to column k (x 31264) and column k + 1 (x 256); for
@@ -1094,11 +1116,16 @@ template <class A, int NLc> G29_FN auto sqrc(const A &a, const CurveG<NLc> &K)
 // a * CST for a small constant (X25519's a24): nine MADs, result in the class of a multiplication result (mul_word_p25519)
 template <u32 CST, class A> G29_FN typename MulOut<A::C::PBITS, 2>::type mul_word(const A &a)
 {
-	static_assert(P25519 && A::C::NL == 9, "mul_word: only the 2^255 - 19 flavour has it");
+	static_assert((P25519 && A::C::NL == 9) || (P448 && A::C::NL == 16), "mul_word: only the 2^255 - 19 and Goldilocks flavours have it");
 	static_assert(CST < (1u << 20) && A::LB < (1ull << 32) && A::TB < (1ull << 32), "mul_word: operand out of range");
 	static_assert(A::VB <= (1ull << 14), "mul_word: value out of range");
 	typename MulOut<A::C::PBITS, 2>::type r;
-	mul_word_p25519(r.l, a.l, CST);
+	if constexpr (P448) {
+		static_assert(A::TB < (1ull << 29), "mul_word: the top limb's bits from 28 up are not folded here");
+		mul_word_p448(r.l, a.l, CST);
+	} else {
+		mul_word_p25519(r.l, a.l, CST);
+	}
 	return r;
 }
 

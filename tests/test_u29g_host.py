@@ -291,9 +291,34 @@ def test_secp521r1_mersenne_flavour(lib_m521):
     test_jacobian(lib_m521, "SECP521R1", 1)
 
 
+def _check_mul_word(lib, curve, flavour, cst, lazy, lazy_limbs):
+    """mul_word (round 4: a24 e of the x-only ladders as NL MADs): residue, limb class of a multiplication result, value < 2p,
+    on random operands and on operands with every limb at the top of its range"""
+    rng = np.random.default_rng(44)
+    f = Field(lib, curve, flavour)
+    fn = getattr(lib, "g_mulword_%d" % f.pb)
+    topmax = (1 << 29) - 1 if flavour == 5 else (1 << 32) - 1
+    for it in range(40):
+        if it == 0:
+            l = [(1 << 32) - 1] * (f.nl - 1) + [topmax]
+        elif it == 1:
+            l = [0] * f.nl
+        else:
+            l = [int(rng.integers(0, 1 << 32)) for _ in range(f.nl - 1)] + [int(rng.integers(0, topmax + 1))]
+            if it % 3 == 0:
+                l = f.digits(int.from_bytes(rng.bytes(80), "big") % f.p)
+        out = (C.c_uint32 * f.nl)()
+        fn(arr(l), out)
+        assert f.val(out) % f.p == f.val(l) * cst % f.p
+        assert f.val(out) < 2 * f.p
+        assert all(v <= f.MASK + (lazy if i in lazy_limbs else 0) for i, v in enumerate(list(out)[:-1]))
+        assert out[f.nl - 1] < (1 << (f.pb - f.W * (f.nl - 1)))
+
+
 def test_p25519_flavour(lib_p25519):
     test_field_ops(lib_p25519, "WEI25519", 2)
     test_jacobian(lib_p25519, "WEI25519", 2)
+    _check_mul_word(lib_p25519, "WEI25519", 2, 121665, 1 << 17, (1,))
 
 
 @pytest.fixture(scope="module")
@@ -382,6 +407,7 @@ def test_p448_flavour(lib_p448):
     assert CURVES["WEI448"]["p"] == 2**448 - 2**224 - 1
     test_field_ops(lib_p448, "WEI448", 5)
     test_jacobian(lib_p448, "WEI448", 5)
+    _check_mul_word(lib_p448, "WEI448", 5, 39081, 1 << 10, (1, 9))
 
 
 def test_mad_counts_match_the_work_model():

@@ -36,6 +36,20 @@ template <int PB> struct Shim {
 			memcpy(out, r.l, 4 * NL);
 		}
 	}
+	// a * 121665 (2^255 - 19 flavour) / a * 39081 (Goldilocks flavour): the a24 of the x-only ladders as one word (mul_word)
+	static void mulword_(const uint32_t *a, uint32_t *out)
+	{
+#if defined(G29_P25519) || defined(G29_P448)
+		// the loosest operand class the ladders hand over: a carried difference
+		E<PB, (1ull << 32) - 1, g29::P448 ? ((1ull << 29) - 1) : ((1ull << 32) - 1), 16> x;
+		memcpy(x.l, a, 4 * NL);
+		auto r = mul_word<g29::P448 ? 39081u : 121665u>(x);
+		memcpy(out, r.l, 4 * NL);
+#else
+		(void)a;
+		(void)out;
+#endif
+	}
 	static void dbl_(const uint32_t *k, const uint32_t *p, uint32_t *out)
 	{
 		const CK &K = *(const CK *)k;
@@ -170,6 +184,7 @@ template <int PB> struct Shim {
 	extern "C" { \
 	void g_mul_##PB(const uint32_t *k, const uint32_t *a, const uint32_t *b, uint32_t *o, int sq) { Shim<PB>::mul_(k, a, b, o, sq); } \
 	void g_dbl_##PB(const uint32_t *k, const uint32_t *p, uint32_t *o) { Shim<PB>::dbl_(k, p, o); } \
+	void g_mulword_##PB(const uint32_t *a, uint32_t *o) { Shim<PB>::mulword_(a, o); } \
 	int g_add_##PB(const uint32_t *k, const uint32_t *p, const uint32_t *q, uint32_t *o) { return Shim<PB>::add_(k, p, q, o); } \
 	int g_madd_##PB(const uint32_t *k, const uint32_t *p, const uint32_t *q, uint32_t *o) { return Shim<PB>::madd_(k, p, q, o); } \
 	void g_dblt_##PB(const uint32_t *k, const uint32_t *p, uint32_t *o) { Shim<PB>::dblt_(k, p, o); } \

@@ -243,9 +243,9 @@ def main():
             sk, su = (b"".join(x[xw * i:xw * i + xw] for i in idx) for x in (k2, pub))
             return O.join_slices(O.in_slices(lambda lo, hi: O.ref_xdh(xw, sk[xw * lo:xw * hi], su[xw * lo:xw * hi]), len(idx)))
         if x448:
-            # dominant kernel k_x448_ladder: 448 steps of 6 multiplications (one by a24, a full product) and 4 squarings on the
-            # Goldilocks unit (16 limbs of 28 bits: M = 256, S = 136 MADs, no constant multipliers)
-            work = {"kernel": "k_x448_ladder", "mads_per_item": 448 * (6 * 256 + 4 * 136) + 256, "sgpr_mads_per_item": 0}
+            # dominant kernel k_x448_ladder: 448 steps of 5 multiplications, 4 squarings and a24 e as sixteen MADs (round 3: a full
+            # product) on the Goldilocks unit (16 limbs of 28 bits: M = 256, S = 136 MADs)
+            work = {"kernel": "k_x448_ladder", "mads_per_item": 448 * (5 * 256 + 4 * 136 + 16) + 256, "sgpr_mads_per_item": 448 * 16}
             metric, unit, cfg = "X448 shared secrets/sec (batch=2^%d)" % a.batch_log2, "shared-secrets/s", "5], X448 counterpart [not in BASELINE"
         else:
             # dominant kernel k_x25519_ladder: 255 steps of 5 multiplications, 4 squarings and a24 e as nine MADs (round 3: a full
