@@ -33,6 +33,14 @@ extern "C" {
 int ecamd_compat_init(const int *devices, int ndev, int host_threads);
 void ecamd_compat_shutdown(void);
 int ecamd_compat_set_secret_scalars(int on);
+/* The application's get_random (an import of this library, as of libecc) is called by ONE thread at a time: the batch forms pack
+ * their items on the pool threads, and the random scalars they draw -- ECDSA nonces when rand == NULL, generated private keys,
+ * the blinding factors of prj_pt_mul_blind_batch, the seed of a whole-batch EdDSA combination -- go through a process-wide
+ * lock around the get_random call itself (the reduction mod q stays parallel).  libecc never required get_random to be
+ * reentrant, and a stateful source that is not could hand out torn or repeated nonces.  An application whose get_random IS
+ * thread-safe (one getrandom(2) / /dev/urandom read per call, a locked DRBG) may lift the lock: on = 1, or
+ * $ECAMD_COMPAT_CONCURRENT_RANDOM=1 before the first batch call. */
+void ecamd_compat_set_concurrent_random(int on);
 /* A curve the library does not know by name (ec_params built by the application from its own ec_str_params): registered
  * so that prj_pt arrays on it can be mapped to a device-side curve (a prj_pt only points to its ec_shortw_crv, which has
  * no generator).  Built-in curves need no registration. */
@@ -74,9 +82,14 @@ int ecccdh_derive_secret_batch(const ec_priv_key *const *our_priv_keys, const u8
  * key_pairs[i] into sigs[i] (siglen bytes each, = ec_get_sig_len).  On the GPU: ECDSA, DECDSA (__ecdsa_sign_finalize,
  * sig/ecdsa_common.c:318-586) and the five EdDSA variants (_eddsa_sign, sig/eddsa.c:1554); every other algorithm is signed by
  * libecc's own _ec_sign on the host threads.
- *   rand: as for _ec_sign -- NULL = libecc's nn_get_random_mod (drawn on the host threads); another function is called once per
- *     item, in index order, on the calling thread (test vectors).  DECDSA ignores it (RFC 6979, as _decdsa_sign_init forces);
- *     EdDSA requires NULL (sig/eddsa.c:1596).
+ *   rand: as for _ec_sign -- NULL = libecc's nn_get_random_mod (its steps restated around a serialised get_random, see
+ *     ecamd_compat_set_concurrent_random); another function is called once per item on the calling thread (test vectors).
+ *     Two deviations from a loop of ec_sign calls, both only visible to a caller-supplied hook: (i) the hook must return a value
+ *     in [1, q-1] as its contract says ("a value taken uniformly at random in [1, q-1]") -- an item whose hook returns 0 or a
+ *     value >= q fails with -1 here, where __ecdsa_sign_finalize would go on with whatever came back; (ii) for a batch whose key
+ *     pairs live on several curves the hook is called group by group (one group per ec_params, items in index order inside a
+ *     group), not in global index order; with one curve the order is the index order.  DECDSA ignores rand (RFC 6979, as
+ *     _decdsa_sign_init forces); EdDSA requires NULL (sig/eddsa.c:1596).
  *   An ECDSA item whose nonce gives r = 0, s = 0 or e = x r is signed again with a fresh nonce, as the reference's restart.
  *   adata / adata_len may be NULL (no context); EDDSA25519CTX needs a context for every item.
  *   Key pairs may live on different curves (one GPU batch per ec_params).

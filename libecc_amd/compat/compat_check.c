@@ -19,11 +19,20 @@
 /* The application's randomness source (libsign leaves get_random undefined: external_deps/rand.c is libecc's example of
  * it and opens /dev/urandom on every call -- two opens per nonce, which caps a 16-thread host at about 1 M nonces/s).
  * This application reads the kernel's generator through getrandom(2) in blocks of 4 KiB per thread. */
+static volatile int g_rand_inside;       /* a caller is inside get_random */
+static volatile int g_rand_overlaps;     /* entries that found another caller inside */
+static int g_rand_expect_serial = 1;     /* the default contract: the library calls get_random from one thread at a time */
 int get_random(unsigned char *buf, u16 len)
 {
 	static __thread unsigned char pool[4096];
 	static __thread unsigned int pos = sizeof(pool);
 	u16 done = 0;
+	/* libecc_amd_compat.h: unless the application lifts it (ecamd_compat_set_concurrent_random), the batch forms serialise
+	 * their calls into this function; count the entries that overlap another one (checked at the end of the run) */
+	if (__atomic_exchange_n(&g_rand_inside, 1, __ATOMIC_ACQ_REL)) {
+		__atomic_add_fetch(&g_rand_overlaps, 1, __ATOMIC_RELAXED);
+	}
+#define RAND_LEAVE() __atomic_store_n(&g_rand_inside, 0, __ATOMIC_RELEASE)
 	while (done < len) {
 		unsigned int take;
 		if (pos == sizeof(pool)) {
@@ -31,6 +40,7 @@ int get_random(unsigned char *buf, u16 len)
 			while (got < sizeof(pool)) {
 				const ssize_t r = getrandom(pool + got, sizeof(pool) - got, 0);
 				if (r <= 0) {
+					RAND_LEAVE();
 					return -1;
 				}
 				got += (size_t)r;
@@ -46,6 +56,7 @@ int get_random(unsigned char *buf, u16 len)
 		pos += take;
 		done = (u16)(done + take);
 	}
+	RAND_LEAVE();
 	return 0;
 }
 
@@ -874,6 +885,8 @@ int main(int argc, char **argv)
 			printf("no GPU path\n");
 			return 3;
 		}
+		ecamd_compat_set_concurrent_random(1);   /* this application's get_random is thread-safe (per-thread pools) */
+		g_rand_expect_serial = 0;
 		bench_verify("SECP256R1", ECDSA, SHA256, "ECDSA/SECP256R1/SHA256", bn);
 		bench_verify("SECP384R1", ECDSA, SHA384, "ECDSA/SECP384R1/SHA384", bn);
 		bench_verify("WEI25519", EDDSA25519, SHA512, "EDDSA25519", bn);
@@ -897,6 +910,7 @@ int main(int argc, char **argv)
 		check_keys("SECP256R1", ECDSA, "ECDSA/SECP256R1", qn);
 		check_xdh(32, qn);
 		ecamd_compat_shutdown();
+		CHECK(!g_rand_expect_serial || g_rand_overlaps == 0, "get_random entered concurrently %d times", g_rand_overlaps);
 		printf(failures ? "compat_check: %d FAILURES\n" : "compat_check: all ok (%d failures)\n", failures);
 		return failures ? 1 : 0;
 	}
@@ -964,6 +978,7 @@ int main(int argc, char **argv)
 		failures++;
 	}
 	ecamd_compat_shutdown();
+	CHECK(!g_rand_expect_serial || g_rand_overlaps == 0, "get_random entered concurrently %d times", g_rand_overlaps);
 	printf(failures ? "compat_check: %d FAILURES\n" : "compat_check: all ok (%d failures)\n", failures);
 	return failures ? 1 : 0;
 }

@@ -173,6 +173,9 @@ static int compat_init_locked(const int *devices, int ndev, int host_threads)
 		g_multi = NULL;
 		return -1;
 	}
+	if (getenv("ECAMD_COMPAT_CONCURRENT_RANDOM")) {
+		AT_STORE(&g_rand_concurrent, 1u);
+	}
 	g_secret = getenv("ECAMD_COMPAT_PUBLIC_SCALARS") ? 0 : 1;
 	if (ecamd_multi_set_secret_scalars(g_multi, g_secret)) {
 		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
