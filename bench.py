@@ -81,7 +81,7 @@ def work_model(curve_params, nw, slen, batch=1 << 20):
     if p == 2**256 - 2**224 + 2**192 + 2**96 - 1 and slen <= 32:
         M, S = 117, 81
         dbl, madd = (4, 4), (8, 3)                       # (mults, squarings); mixed addition: affine table
-        fin_k = aff_k = 8                                # items per lane sharing one inversion
+        fin_k = aff_k = 8 if batch >= (1 << 19) else (4 if batch >= (1 << 17) else 2)   # items per lane sharing one inversion (p256_items_per_inversion)
         # k_p256_table: to Montgomery 2M, on-curve 2M+2S, 4 dbl + 3 madd
         nm = 2 + 2 + 4 * dbl[0] + 3 * madd[0]
         ns = 2 + 4 * dbl[1] + 3 * madd[1]
@@ -186,32 +186,38 @@ def mix_peak(ub, sgpr_share, signed=False):
 
 
 def secondary_lines(ub):
-    """BASELINE.json configs[2]-[4] as compact records behind the headline line: secp384r1 and
-    secp521r1 scalar multiplication, secp256r1 ECDSA verification, Ed25519 verification, X25519 -- each a fresh process at
-    2^20 items with its own reference-binary gate, `ms_per_step` and the dominant kernel's fraction of the MAD stream."""
+    """BASELINE.json configs[2]-[4] as records behind the headline line, each with the keys of the headline (VERDICT round 3,
+    item 2): secp384r1 and secp521r1 scalar multiplication, secp256r1 ECDSA verification, Ed25519 verification, X25519 -- a fresh
+    process per workload at 2^20 items, 10 timed steps, a 2^16-item gate against the unmodified reference binary on every host
+    thread (whose own wall time is the workload's `cpu_baseline`: ec_verify / x25519() / prj_pt_mul of the reference on the same
+    inputs), the dominant kernel's and the whole step's fraction of the mix-weighted MAD stream, and the PMC HBM bytes per launch."""
     env = dict(os.environ)
     pv = ub["v_mad_u64_u32"]["lane_ops_per_s"] if ub else 0.0
     ps = (ub.get("v_mad_u64_u32_sgpr", {}).get("lane_ops_per_s", 0.0)) if ub else 0.0
+    common = ["--steps", "10", "--warmup", "2"]
     jobs = [("configs[2] secp384r1", [sys.executable, os.path.abspath(__file__), "--curve", "SECP384R1"]),
             ("configs[2] secp521r1", [sys.executable, os.path.abspath(__file__), "--curve", "SECP521R1"])]
-    jobs = [(n, c + ["--no-cpu-baseline", "--no-secondary", "--no-traffic", "--parity-items", "4096", "--steps", "5", "--warmup", "2"]) for n, c in jobs]
+    jobs = [(n, c + ["--no-secondary", "--parity-items", "65536"] + common) for n, c in jobs]
     tool = os.path.join(ROOT, "tools", "bench_protocols.py")
     for name, w in (("configs[3] ECDSA verify secp256r1", "ecdsa_verify"), ("configs[4] Ed25519 verify", "ed25519_verify"),
                     ("configs[4] X25519", "x25519")):
-        jobs.append((name, [sys.executable, tool, "--workload", w, "--no-cpu-baseline", "--steps", "5", "--warmup", "2",
-                            "--mad-peak", repr(pv), "--mad-peak-sgpr", repr(ps)]))
+        jobs.append((name, [sys.executable, tool, "--workload", w, "--ref-items", "65536", "--traffic", "--mad-peak", repr(pv),
+                            "--mad-peak-sgpr", repr(ps)] + common))
     out = []
     for name, cmd in jobs:
         t0 = time.time()
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
             line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
             roof = line.get("roofline") or {}
             out.append({"config": name, "metric": line["metric"], "value": line["value"], "unit": line["unit"], "steps": line["steps"],
                         "ms_per_step": line["ms_per_step"], "parity_gate": line["config"].get("parity_gate"),
                         "kernel": roof.get("kernel"), "kernel_ms": roof.get("kernel_ms"), "kernel_mads_per_item": roof.get("kernel_mads_per_item"),
                         "frac": roof.get("frac"), "peak": roof.get("peak"), "pipeline_frac": roof.get("pipeline_frac"),
-                        "wall_s": time.time() - t0})
+                        "mads_per_item": roof.get("mads_per_item"), "step_ms": roof.get("step_ms"),
+                        "traffic": roof.get("traffic"), "traffic_by_kernel": roof.get("traffic_by_kernel"),
+                        "traffic_over_algorithmic": roof.get("traffic_over_algorithmic"),
+                        "cpu_baseline": line.get("cpu_baseline"), "wall_s": time.time() - t0})
         except Exception as e:
             out.append({"config": name, "error": f"{type(e).__name__}: {e}"[:300], "wall_s": time.time() - t0})
     return out
@@ -219,54 +225,26 @@ def secondary_lines(ub):
 
 def pmc_traffic(kernel, batch_log2, curve):
     """HBM bytes per launch of the pipeline's kernels, MEASURED IN THIS RUN: two child runs of this script under
-    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, nothing else traced, as MI355X_MICROARCH.md's HBM
-    section prescribes; gfx950 correction 2 x FETCH_SIZE, both counters in KiB).  The children run the same batch on seeded
-    inputs without the parity gate.  Returns (bytes per launch of `kernel`, {kernel: bytes per launch}, note); nulls with a
-    note when rocprofv3 is missing or a pass fails -- never an estimate.  What it counts is window-table scratch (the
-    loop's 64 look-ups x 64 B per item and the staging of the table kernels), not re-reads of the 160 algorithmic bytes."""
-    import glob
-    import shutil
-    import sqlite3
-    import tempfile
-    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(exe):
-        return None, None, "rocprofv3 not found"
-    per = {}
-    tmp = tempfile.mkdtemp(prefix="ecamd_pmc_", dir="/tmp")
-    try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "-d", d, "--", sys.executable, os.path.abspath(__file__), "--traffic-child", "--curve", curve,
-                   "--batch-log2", str(batch_log2), "--steps", "2", "--warmup", "1"]
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
-            dbs = sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True), key=os.path.getsize)
-            if r.returncode != 0 or not dbs:
-                return None, None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or '')[-200:]}"
-            con = sqlite3.connect(dbs[-1])
-            cols = [x[1] for x in con.execute("pragma table_info(counters_collection)")]
-            ni, ci, vi, di = cols.index("kernel_name"), cols.index("counter_name"), cols.index("value"), cols.index("dispatch_id")
-            agg = {}
-            for row in con.execute("select * from counters_collection"):
-                if row[ci] == counter:
-                    agg.setdefault(row[ni], {}).setdefault(row[di], 0.0)
-                    agg[row[ni]][row[di]] += row[vi]
-            con.close()
-            for k, dd in agg.items():
-                v = [dd[i] for i in sorted(dd)]
-                per.setdefault(k, {})[counter] = max(v)     # the full-size launches (smaller ones: redo lanes, set-up)
-    except Exception as e:
-        return None, None, f"PMC pass failed: {type(e).__name__}: {e}"[:300]
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
-    by_kernel = {k: (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 for k, v in per.items()
-                 if k.startswith(("k_", "void k_"))}
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (tools/pmc.py: separate passes, nothing else traced, as
+    MI355X_MICROARCH.md's HBM section prescribes; gfx950 correction 2 x FETCH_SIZE, both counters in KiB).  The children run the
+    same batch on seeded inputs without the parity gate.  Returns (bytes per launch of `kernel`, {kernel: bytes per launch}, note);
+    nulls with a note when rocprofv3 is missing or a pass fails -- never an estimate.  What it counts is window-table scratch
+    (the loop's 64 look-ups x 64 B per item and the staging of the table kernels), not re-reads of the 160 algorithmic bytes."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc
+    child = [sys.executable, os.path.abspath(__file__), "--traffic-child", "--curve", curve, "--batch-log2", str(batch_log2),
+             "--steps", "2", "--warmup", "1"]
+    by_kernel, note = pmc.hbm_bytes_per_launch(child, timeout=240)
+    if by_kernel is None:
+        return None, None, note
     dom = [v for k, v in by_kernel.items() if kernel.split("<")[0] in k and "verify" not in k]
-    note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this run's batch, separate passes; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch"
     return (max(dom) if dom else None), by_kernel, note
 
 
-def cpu_baseline(curve, scalars, points, slen):
-    """Reference CPU path on this box's host cores, bounded to ~10-20 s of wall time."""
+def cpu_baseline(curve, scalars, points, slen, gate_timing=None):
+    """Reference CPU path on this box's host cores, bounded to ~10-20 s of wall time.  gate_timing: the parity gate already ran
+    the unmodified reference over a random subset of the same batch on every host thread and timed it -- when that sample is
+    at least 3 s of work it IS the baseline (no second run), and only the one-thread probe is added."""
     from oracles import Oracle, RefLib, have_ref
     cores = host_cores()
     nmax = len(scalars) // slen
@@ -276,6 +254,13 @@ def cpu_baseline(curve, scalars, points, slen):
         t0 = time.time()
         r.scalar_mult(scalars[:probe * slen], points[:probe * 2 * r.clen], slen)
         rate1 = probe / (time.time() - t0)
+        if gate_timing and gate_timing["seconds"] >= 3.0:
+            g = gate_timing
+            return {"value": g["items"] / g["seconds"], "unit": "scalar-mults/s", "cores": g["cores"], "kind": "reference",
+                    "one_core_value": rate1,
+                    "sample": f"the parity gate's own run: {g['items']} random items of the same batch, prj_pt_mul+prj_pt_unique of the "
+                              f"unmodified reference (oracle/_ref, default flags) on {g['cores']} pthreads, {g['seconds']:.1f} s wall; "
+                              f"1-thread probe on 64 items {rate1:.0f}/s"}
         # multi-thread probe (4 items per thread) to size the real sample: hosts rarely scale linearly
         n0 = min(nmax, 4 * cores)
         _, _, el0, _ = r.scalar_mult(scalars[:n0 * slen], points[:n0 * 2 * r.clen], slen, nthreads=cores, timing=True)
@@ -360,10 +345,12 @@ def parity_gate(curve, cv, scalars_h, pts_h, out_h, slen, plen, B, nrand):
     e_sc, e_pt = edge_slice(CURVES[curve], slen, clen, pts_h, 4096 if B >= 4096 else B)
     e_got = cv.scalar_mult(e_sc, e_pt, slen)
     t0 = time.time()
+    ref_timing = None
     if use_ref:
         r = RefLib(curve)
         cores = host_cores()
-        exp, est = r.scalar_mult(sub_s, sub_p, slen, nthreads=cores)[:2]
+        exp, est, el_ref, _ = r.scalar_mult(sub_s, sub_p, slen, nthreads=cores, timing=True)
+        ref_timing = {"items": nrand, "seconds": el_ref, "cores": cores}   # the gate's own CPU run doubles as the cpu_baseline sample
         e_exp = tuple(r.scalar_mult(e_sc, e_pt, slen, nthreads=cores)[:2])
         who = f"the unmodified reference (oracle/_ref) on {cores} threads"
     else:
@@ -379,7 +366,7 @@ def parity_gate(curve, cv, scalars_h, pts_h, out_h, slen, plen, B, nrand):
         raise SystemExit(f"PARITY FAILURE: edge slice differs from the CPU reference at items {bad[:8]}")
     st = e_exp[1]
     return (f"{nrand} random items of the timed batch + {len(st)} edge items ({st.count(1)} rejected, {st.count(2)} at infinity) "
-            f"byte-identical to {who}, {time.time() - t0:.1f} s")
+            f"byte-identical to {who}, {time.time() - t0:.1f} s"), ref_timing
 
 
 def traffic_child(args):
@@ -422,6 +409,9 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that measure the HBM bytes per launch")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-secondary", action="store_true", help="skip the records of BASELINE configs[2]-[4] that follow the headline measurement at N = 1")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, the driver's contract): every rank owns 2^batch-log2 items; strong: 2^batch-log2 items in total, "
+                         "split into contiguous shards of 2^batch-log2 / N per rank (BASELINE.json's metric read literally: batch = 2^20 at 1/2/4/8 GPUs)")
     args = ap.parse_args()
 
     if args.traffic_child:
@@ -469,6 +459,10 @@ def main():
     cp = CURVES[curve]
     q = cp["q"]
     B = 1 << args.batch_log2
+    if args.scaling == "strong":
+        if B % world:
+            raise SystemExit(f"bench.py: --scaling strong needs 2^{args.batch_log2} items to divide by {world} ranks")
+        B //= world                      # contiguous shard of this rank; the job's batch stays 2^batch_log2
     slen, clen = (q.bit_length() + 7) // 8, (cp["p"].bit_length() + 7) // 8
     plen = 2 * clen
 
@@ -529,7 +523,7 @@ def main():
     pts_h = d_points.cpu().numpy().tobytes()
     st_h = d_status.cpu().numpy().tobytes()
     assert set(st_h) == {0}, "unexpected status in the synthetic batch"
-    gate = parity_gate(curve, cv, scalars_h, pts_h, out_h, slen, plen, B, args.parity_items if rank == 0 else 256)
+    gate, gate_timing = parity_gate(curve, cv, scalars_h, pts_h, out_h, slen, plen, B, args.parity_items if rank == 0 else 256)
     setup_s = time.time() - t_setup
 
     # ---- warmup, then exactly K timed steps ----
@@ -595,10 +589,10 @@ def main():
             "metric": f"scalar-mults/sec ({curve.lower()}, batch=2^{args.batch_log2}, variable base, affine out, bit-exact vs CPU)",
             "value": value, "unit": "scalar-mults/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32 (%d-bit limbs, v_mad_u64_u32 integer MAD, u64 accumulators)" % (28 if cp["p"] == 2**448 - 2**224 - 1 else 29),
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "u32 (%d-bit limbs, v_mad_u64_u32 integer MAD, u64 accumulators)" % (28 if cp["p"] == 2**448 - 2**224 - 1 else 29),
             "data": "synthetic (seeded): scalars uniform in [1,q-1], base points P_i=[t_i]G",
-            "config": {"workload": f"{curve} prj_pt_mul+prj_pt_unique, batch 2^{args.batch_log2} per GPU "
-                                   "(BASELINE.json configs[1])",
+            "config": {"workload": f"{curve} prj_pt_mul+prj_pt_unique, batch 2^{args.batch_log2} " +
+                                   ("per GPU" if args.scaling == "weak" else f"in total ({B} per GPU)") + " (BASELINE.json configs[1])",
                        "batch_per_gpu": B, "scalar_len": slen, "window": "signed fixed w=4",
                        "sharding": "contiguous per-rank shards" + (", one RCCL all_gather of the output shards per step, overlapped with the next step's kernels" if world > 1 else ""),
                        "parity_gate": gate,
@@ -641,7 +635,7 @@ def main():
                 except OSError:
                     pass
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(curve, scalars_h, pts_h, slen)
+            line["cpu_baseline"] = cpu_baseline(curve, scalars_h, pts_h, slen, gate_timing)
         else:
             line["cpu_baseline"] = None
     cv.free()

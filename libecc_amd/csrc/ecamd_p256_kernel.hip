@@ -41,8 +41,17 @@ typedef uint8_t u8;
 #define FIN_K 8                  /* items per lane in k_p256_finalize */
 #endif
 #ifndef AFF_K
-#define AFF_K 8                  /* items per lane in k_p256_affine (x 7 table entries each); 2/4/8 measured equal */
+#define AFF_K 8                  /* items per lane in k_p256_affine (x 7 table entries each); 2/4/8 measured equal AT 2^20 items */
 #endif
+// Items that share one Fermat inversion in the affine and finalisation kernels, chosen from the batch size (round 4): a lane's
+// inversion is a serial chain of 255 squarings, so the kernel wants every SIMD busy more than it wants the 1/8 share -- the strong-
+// scaling shards of a 2^20-item job (2^17 ... 2^19 items per GPU) and small batches keep the chip filled with 4 and 2 items per lane
+// (the generic units do the same, ecamd_g29_kernel.hip).  kmax: the compile-time A/B value (8).
+static inline int p256_items_per_inversion(uint32_t n, int kmax)
+{
+	const int k = n >= (1u << 19) ? 8 : (n >= (1u << 17) ? 4 : 2);
+	return k < kmax ? k : kmax;
+}
 
 // 32 big-endian bytes -> 8 little-endian words
 static __device__ __forceinline__ void load_be256(const u8 *src, u32 *w)
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(64) void k_p256_table(EcamdSmulArgs A)
 //    up:   cb_k = c (prefix BEFORE entry k) parked in the entry, c *= Z_k
 //    down: 1/Z_k = t * cb_k, t *= Z_k        with t = 1 / (product of all Z)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_p256_affine(EcamdSmulArgs A, u32 nthreads)
+__global__ __launch_bounds__(64) void k_p256_affine(EcamdSmulArgs A, u32 nthreads, int items)
 {
 	// nthreads is a multiple of 64: the AFF_K items of a lane keep its lane index, so a wave's accesses to one staging
 	// slot are 64 consecutive 16-byte words
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(64) void k_p256_affine(EcamdSmulArgs A, u32 nthread
 	}
 	Fmul c = weaken<Fmul>(constant<Fcanon>(K::ONE));
 #pragma unroll 1
-	for (int j = 0; j < AFF_K; j++) {
+	for (int j = 0; j < items; j++) {
 		const u32 i = t + (u32)j * nthreads;
 		if (i >= A.n) {
 			break;
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(64) void k_p256_affine(EcamdSmulArgs A, u32 nthread
 	}
 	Fmul tinv = inv(c);
 #pragma unroll 1
-	for (int j = AFF_K - 1; j >= 0; j--) {
+	for (int j = items - 1; j >= 0; j--) {
 		const u32 i = t + (u32)j * nthreads;
 		if (i >= A.n || A.status[i] != ECAMD_STATUS_TAB) {
 			continue;
@@ -669,7 +678,7 @@ __global__ __launch_bounds__(64) void k_p256_comb(EcamdSmulArgs A)
 // ------------------------------------------------------------------------------------------
 // D. finalisation: Jacobian -> affine for FIN_K items per lane with ONE field inversion
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_p256_finalize(EcamdSmulArgs A, u32 nthreads)
+__global__ __launch_bounds__(64) void k_p256_finalize(EcamdSmulArgs A, u32 nthreads, int items)
 {
 	// nthreads is a multiple of 64 (coalesced staging accesses, as in k_p256_affine)
 	const u32 t = blockIdx.x * 64 + threadIdx.x;
@@ -678,7 +687,7 @@ __global__ __launch_bounds__(64) void k_p256_finalize(EcamdSmulArgs A, u32 nthre
 	}
 	Fmul c = weaken<Fmul>(constant<Fcanon>(K::ONE));
 #pragma unroll 1
-	for (int j = 0; j < FIN_K; j++) {
+	for (int j = 0; j < items; j++) {
 		const u32 i = t + (u32)j * nthreads;
 		if (i >= A.n) {
 			break;
@@ -695,7 +704,7 @@ __global__ __launch_bounds__(64) void k_p256_finalize(EcamdSmulArgs A, u32 nthre
 		plain1.l[w] = (w == 0) ? 1u : 0u;
 	}
 #pragma unroll 1
-	for (int j = FIN_K - 1; j >= 0; j--) {
+	for (int j = items - 1; j >= 0; j--) {
 		const u32 i = t + (u32)j * nthreads;
 		if (i >= A.n || A.status[i] != ECAMD_STATUS_JAC) {
 			continue;
@@ -877,9 +886,10 @@ hipError_t ecamd_launch_verify_p256(const EcamdSmulArgs &pubkeys, const uint8_t 
 		return scalars_ready ? hipStreamWaitEvent(s, scalars_ready, 0) : hipSuccess;
 	}
 	const dim3 grid((pubkeys.n + 63) / 64), block(64);
-	const uint32_t athreads = (((pubkeys.n + AFF_K - 1) / AFF_K) + 63u) & ~63u;
+	const uint32_t ak = (uint32_t)p256_items_per_inversion(pubkeys.n, AFF_K);
+	const uint32_t athreads = (((pubkeys.n + ak - 1) / ak) + 63u) & ~63u;
 	hipLaunchKernelGGL(k_p256_table, grid, block, 0, s, pubkeys);
-	hipLaunchKernelGGL(k_p256_affine, dim3((athreads + 63) / 64), block, 0, s, pubkeys, athreads);
+	hipLaunchKernelGGL(k_p256_affine, dim3((athreads + 63) / 64), block, 0, s, pubkeys, athreads, (int)ak);
 	P256VerifyArgs V;
 	V.u1 = u1;
 	V.u2 = u2;
@@ -920,7 +930,8 @@ hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s, hipEven
 		return hipSuccess;
 	}
 	const dim3 grid((a.n + 63) / 64), block(64);
-	const uint32_t nthreads = (((a.n + FIN_K - 1) / FIN_K) + 63u) & ~63u;
+	const uint32_t fk = (uint32_t)p256_items_per_inversion(a.n, FIN_K);
+	const uint32_t nthreads = (((a.n + fk - 1) / fk) + 63u) & ~63u;
 	const dim3 fgrid((nthreads + 63) / 64);
 #define P256_MARK(i) do { if (ev) (void)hipEventRecord(ev[i], s); } while (0)
 	P256_MARK(0);
@@ -931,8 +942,9 @@ hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s, hipEven
 	} else {
 		hipLaunchKernelGGL(k_p256_table, grid, block, 0, s, a);
 		P256_MARK(1);
-		const uint32_t athreads = (((a.n + AFF_K - 1) / AFF_K) + 63u) & ~63u;
-		hipLaunchKernelGGL(k_p256_affine, dim3((athreads + 63) / 64), block, 0, s, a, athreads);
+		const uint32_t ak = (uint32_t)p256_items_per_inversion(a.n, AFF_K);
+		const uint32_t athreads = (((a.n + ak - 1) / ak) + 63u) & ~63u;
+		hipLaunchKernelGGL(k_p256_affine, dim3((athreads + 63) / 64), block, 0, s, a, athreads, (int)ak);
 	}
 	P256_MARK(2);
 	if (a.lut && a.lut_kind == 1) {
@@ -951,7 +963,7 @@ hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s, hipEven
 		}
 	}
 	P256_MARK(3);
-	hipLaunchKernelGGL(k_p256_finalize, fgrid, block, 0, s, a, nthreads);
+	hipLaunchKernelGGL(k_p256_finalize, fgrid, block, 0, s, a, nthreads, (int)fk);
 	P256_MARK(4);
 	return hipGetLastError();
 }

@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--curve", default="SECP256R1", help="ecdsa_verify / ecdsa_sign / ecccdh: any 256-bit prime-order curve libecc names")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ref-items", type=int, default=4096, help="random items of the batch checked against the unmodified reference binary (all host threads)")
+    ap.add_argument("--traffic", action="store_true", help="after the timed region: HBM bytes per launch from two rocprofv3 --pmc child runs (tools/pmc.py)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--mad-peak", type=float, default=0.0, help="lane-MADs/s of the v_mad_u64_u32 streams measured by ubench (VGPR multiplier); 0: measure now")
     ap.add_argument("--mad-peak-sgpr", type=float, default=0.0, help="the same with an SGPR multiplier")
     a = ap.parse_args()
@@ -70,7 +72,7 @@ def main():
         return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
 
     t_setup = time.time()
-    ref_subset = work = None
+    ref_subset = work = gate_ref = None
     if a.workload == "ecdsa_verify":
         curve = a.curve
         cv = ctx.curve(curve)
@@ -117,6 +119,11 @@ def main():
         # table, 17 mixed additions from the comb table of G, the projective x mod q == r test (1 S + 6 M); M = 117, S = 81 MADs
         work = {"kernel": "k_p256_verify_loop<true>", "mads_per_item": 64 * (24 * 117 + 19 * 81) + 18 * (8 * 117 + 3 * 81) + 81 + 6 * 117,
                 "sgpr_mads_per_item": 36 * (64 * 43 + 18 * 11 + 7)} if curve == "SECP256R1" else None
+        if work:
+            # the whole step: k_p256_table (44 M + 27 S) and k_p256_affine (42 M + 7 S + one Fermat inversion, 255 S + 13 M, per 8 items)
+            # in front of the loop; k_ecdsa_prep / k_ecdsa_fin (mod-q words on the saturated unit) not counted
+            work["step_mads_per_item"] = work["mads_per_item"] + (44 + 42 + 13 / 8) * 117 + (27 + 7 + 255 / 8) * 81
+            work["alg_bytes_per_item"] = 2 * cl + 2 * ql + hl + 1
         metric, unit, cfg = "ECDSA verifications/sec (%s, %s digests, batch=2^%d)" % (curve.lower(), hname, a.batch_log2), "verifications/s", 3
     elif a.workload in ("ecdsa_sign", "ecccdh"):
         # secp256r1: signing with caller-supplied nonces (the tail of ec_sign) / ECC-CDH shared secrets
@@ -161,14 +168,43 @@ def main():
             metric, unit, cfg = "ECC-CDH shared secrets/sec (%s, batch=2^%d)" % (curve.lower(), a.batch_log2), "shared-secrets/s", 3
     elif a.workload == "ed25519_verify":
         cv = ctx.curve("WEI25519")
-        m = 512
-        emsgs = [rb(32) for _ in range(m)]
-        items = [O.ed25519_sign(rb(32), emsgs[j]) for j in range(m)]
-        reps = B // m
-        pubs = b"".join(i[0] for i in items) * reps
-        sigs = bytearray(b"".join(i[1] for i in items) * reps)
-        hram = b"".join(i[2] for i in items) * reps
-        msgs = b"".join(emsgs) * reps
+        if a.traffic_child:
+            # the PMC passes only need the shape of the work: 512 signatures of the Python signer, tiled
+            m = 512
+            emsgs = [rb(32) for _ in range(m)]
+            items = [O.ed25519_sign(rb(32), emsgs[j]) for j in range(m)]
+            reps = B // m
+            pubs = b"".join(i[0] for i in items) * reps
+            sigs = bytearray(b"".join(i[1] for i in items) * reps)
+            hram = b"".join(i[2] for i in items) * reps
+            msgs = b"".join(emsgs) * reps
+            distinct = "%d distinct signatures tiled" % m
+        else:
+            # B DISTINCT (key, message, signature) triples: RFC 8032 5.1.5 / 5.1.6 with the hashes on the host and the
+            # three scalar-multiplication / mod-q steps on the GPU through the library's own signing entry points
+            # (ec_eddsa_sign_R_batch also serves for A = [a]B: it encodes [x mod q]B for any 64-byte x)
+            seeds, msgs = rb(32 * B), rb(32 * B)
+            hk = [hashlib.sha512(seeds[32 * i:32 * i + 32]).digest() for i in range(B)]
+            a_np = np.frombuffer(b"".join(h[:32] for h in hk), dtype=np.uint8).reshape(B, 32).copy()
+            a_np[:, 0] &= 248
+            a_np[:, 31] &= 127
+            a_np[:, 31] |= 64
+            a_le = a_np.tobytes()
+            wide = np.zeros((B, 64), dtype=np.uint8)
+            wide[:, :32] = a_np
+            pubs, st = cv.eddsa_sign_R(wide.tobytes())
+            assert set(st) == {0}
+            r_hash = b"".join(hashlib.sha512(hk[i][32:] + msgs[32 * i:32 * i + 32]).digest() for i in range(B))
+            Renc, st = cv.eddsa_sign_R(r_hash)
+            assert set(st) == {0}
+            hram = b"".join(hashlib.sha512(Renc[32 * i:32 * i + 32] + pubs[32 * i:32 * i + 32] + msgs[32 * i:32 * i + 32]).digest() for i in range(B))
+            S = cv.eddsa_sign_S(r_hash, hram, a_le)
+            sg = np.empty((B, 64), dtype=np.uint8)
+            sg[:, :32] = np.frombuffer(Renc, dtype=np.uint8).reshape(B, 32)
+            sg[:, 32:] = np.frombuffer(S, dtype=np.uint8).reshape(B, 32)
+            sigs = bytearray(sg.tobytes())
+            del hk, wide, sg
+            distinct = "all keys, messages and signatures distinct, signed on the GPU by ec_eddsa_sign_R/S_batch"
         bad = np.zeros(B, dtype=np.uint8)
         for i in range(0, B, 10):          # every 10th signature corrupted in S (the hash binds R, A and M, not S)
             sigs[64 * i + 32 + (i % 31)] ^= 1 << (i % 8)
@@ -193,7 +229,12 @@ def main():
         # (7M; round 3: 8M) in extended coordinates; 2^255 - 19 flavour (round 4: the high columns fold as their register halves):
         # M = 81 + 16 = 97, S = 45 + 16 = 61 MADs, 16 of them with a constant multiplier
         work = {"kernel": "k_ed_smul_c25519<1>", "mads_per_item": 64 * (20 * 97 + 16 * 61), "sgpr_mads_per_item": 64 * 36 * 16}
-        metric, unit, cfg = "Ed25519 verifications/sec (batch=2^%d, %d distinct signatures tiled)" % (a.batch_log2, m), "verifications/s", 4
+        # the whole step (pipeline_frac): k_ed_decode_ed_c25519 (two square roots: 2 x (255 S + 25 M), the key's cofactor doublings),
+        # k_ed_smul_c25519<0> (window table: 73 M + 16 S), the loop, k_ed_tail_c25519 (17 mixed additions from the Edwards comb of B,
+        # the two comparisons, two additions, three doublings: 165 M + 13 S); k_ed_scal (mod-q words, not this unit's MADs) not counted
+        work["step_mads_per_item"] = (59 + 73 + 1 + 64 * 20 + 165) * 97 + (522 + 16 + 64 * 16 + 13) * 61
+        work["alg_bytes_per_item"] = 32 + 64 + 64 + 1
+        metric, unit, cfg = "Ed25519 verifications/sec (batch=2^%d, %s)" % (a.batch_log2, distinct), "verifications/s", 4
     elif a.workload == "ed448_verify":
         cv = ctx.curve("WEI448")
         m = 128
@@ -251,6 +292,10 @@ def main():
             # dominant kernel k_x25519_ladder: 255 steps of 5 multiplications, 4 squarings and a24 e as nine MADs (round 3: a full
             # product); M = 81 + 16 = 97, S = 45 + 16 = 61 MADs (ecamd_u29g.h:mul_p25519)
             work = {"kernel": "k_x25519_ladder", "mads_per_item": 255 * (5 * 97 + 4 * 61 + 9) + 97, "sgpr_mads_per_item": 255 * (9 * 16 + 9)}
+            # the whole step: k_xdh_prep_c25519 (the on-curve square root and the small-order doublings: 267 S + 35 M), the ladder,
+            # k_x25519_fin (one inversion per 8 items: 32 S + 6 M per item)
+            work["step_mads_per_item"] = work["mads_per_item"] + (35 + 6) * 97 + (267 + 32) * 61
+            work["alg_bytes_per_item"] = 32 + 32 + 32 + 1
             metric, unit, cfg = "X25519 shared secrets/sec (batch=2^%d)" % a.batch_log2, "shared-secrets/s", 4
     gathered = torch.empty(world * B, dtype=torch.uint8, device=dev) if world > 1 else None
 
@@ -259,6 +304,13 @@ def main():
         if world > 1:
             dist.all_gather_into_tensor(gathered, d_res)
 
+    if a.traffic_child:
+        for _ in range(a.warmup + a.steps):
+            full_step()
+        torch.cuda.synchronize()
+        cv.free()
+        ctx.close()
+        return
     # ---- parity gate: the whole result against what the construction implies, 128 items against the oracle ----
     full_step()
     torch.cuda.synchronize()
@@ -279,7 +331,9 @@ def main():
     if ref_subset is not None and O.have_ref() and rank == 0 and a.ref_items > 0:
         tg = time.time()
         ridx = [int(i) for i in np.sort(np.random.default_rng(2).choice(B, size=min(B, a.ref_items), replace=False))]
+        tr0 = time.time()
         rexp = ref_subset(ridx)
+        gate_ref = {"items": len(ridx), "seconds": time.time() - tr0, "cores": O.host_threads()}
         if payload:
             rgot = (b"".join(out[out_w * i:out_w * i + out_w] for i in ridx), bytes(res[i] for i in ridx))
         else:
@@ -330,10 +384,42 @@ def main():
                     "kernel_mads_per_item": work["mads_per_item"], "sgpr_multiplier_share": fs, "achieved": rate / 1e9, "peak": peak / 1e9,
                     "unit": "GMAD/s (one GPU)", "frac": rate / peak, "peak_vgpr_stream": pv / 1e9, "peak_sgpr_stream": ps / 1e9,
                     "kernel_share_of_step": kernel_ms / (1e3 * elapsed / a.steps)}
+            if work.get("step_mads_per_item"):
+                step_ms = 1e3 * elapsed / a.steps
+                roof["step_ms"] = step_ms
+                roof["mads_per_item"] = work["step_mads_per_item"]
+                roof["pipeline_frac"] = (B * work["step_mads_per_item"] / (step_ms * 1e-3)) / peak
+                hb = B * work["alg_bytes_per_item"] / (step_ms * 1e-3)
+                roof["hbm"] = {"achieved": hb / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": hb / 8e12,
+                               "algorithmic_bytes_per_item": work["alg_bytes_per_item"]}
         except Exception as e:   # the timing hook only covers the fast paths
             roof = {"error": str(e)}
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and O.have_ref():
+    # HBM bytes per launch from PMC counters: two profiled child runs of this workload (tools/pmc.py), after the timed region
+    if rank == 0 and world == 1 and a.traffic and isinstance(roof, dict) and "kernel" in roof:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc
+        tt = time.time()
+        child = [sys.executable, os.path.abspath(__file__), "--workload", a.workload, "--curve", a.curve, "--batch-log2", str(a.batch_log2),
+                 "--traffic-child", "--steps", "2", "--warmup", "1"]
+        by_kernel, note = pmc.hbm_bytes_per_launch(child, timeout=300)
+        roof["traffic_by_kernel"] = by_kernel
+        dom = [v for k, v in (by_kernel or {}).items() if roof["kernel"].split("<")[0] in k]
+        roof["traffic"] = max(dom) if dom else None
+        roof["traffic_note"] = f"{note}; {time.time() - tt:.0f} s"
+        if by_kernel and work.get("alg_bytes_per_item"):
+            roof["step_traffic"] = sum(by_kernel.values())
+            roof["traffic_over_algorithmic"] = roof["step_traffic"] / (B * work["alg_bytes_per_item"])
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and gate_ref and gate_ref["seconds"] >= 3.0:
+        # the parity gate already ran the unmodified reference over a random subset of this batch on every host thread: that run
+        # IS the CPU baseline of the workload (ec_verify / x25519() of the reference beside configs 3-5)
+        what = {"ecdsa_verify": "ec_pub_key_import_from_aff_buf + ec_verify (ECDSA)", "ecdsa_sign": "ec_sign (ECDSA, nonce supplied)",
+                "ecccdh": "ecccdh_derive_secret", "ed25519_verify": "eddsa_import_pub_key + ec_verify (EDDSA25519)",
+                "ed448_verify": "eddsa_import_pub_key + ec_verify (EDDSA448)", "x25519": "x25519()", "x448": "x448()"}[a.workload]
+        cpu = {"value": gate_ref["items"] / gate_ref["seconds"], "unit": unit, "cores": gate_ref["cores"], "kind": "reference",
+               "sample": f"the parity gate's own run: {gate_ref['items']} random items of the same batch through {what} of the unmodified "
+                         f"reference (oracle/_ref) on {gate_ref['cores']} threads, {gate_ref['seconds']:.1f} s wall"}
+    elif rank == 0 and world == 1 and not a.no_cpu_baseline and O.have_ref():
         # the unmodified reference on this host, one thread, on a bounded sample of the same inputs
         m = 1536 if a.workload != "x25519" else 3072
         if a.workload == "x448":

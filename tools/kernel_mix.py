@@ -43,6 +43,12 @@ def main():
     obj, pat = sys.argv[1], sys.argv[2]
     whole = "--whole" in sys.argv
     top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 14
+    report(obj, pat, whole, top, verbose=True)
+
+
+def report(obj, pat, whole=False, top=14, verbose=False):
+    """{'instructions', 'valu', 'mads', 'weighted_cycles', 'mad_cycle_share', 'mad_count_share_of_valu'} of the kernel's hottest
+    loop (or whole body); prints the table when verbose"""
     text = disasm(obj)
     # split into functions
     funcs = re.split(r"\n(?=[0-9a-f]{16} <)", text)
@@ -53,7 +59,7 @@ def main():
             body = f
             break
     if body is None:
-        sys.exit(f"no kernel matching {pat!r}")
+        raise SystemExit(f"no kernel matching {pat!r}")
     lines = []
     for ln in body.split("\n")[1:]:
         m = re.match(r"\s+(\S+)\s+(.*?)//\s*([0-9A-F]+):\s*(.*)$", ln)
@@ -89,12 +95,16 @@ def main():
     n = sum(cnt.values())
     mad = sum(v for k, v in cyc.items() if k.startswith("v_mad_u64_u32") or k.startswith("v_mad_i64_i32"))
     nmad = sum(v for k, v in cnt.items() if k.startswith("v_mad_u64_u32") or k.startswith("v_mad_i64_i32"))
-    print(f"kernel {pat}: {'whole body' if whole else f'loop 0x{lo:x}..0x{hi:x}'}: {n} instructions, {nmad} MADs, "
-          f"{total:.0f} weighted VALU cycles, MAD share {mad / total:.3f}")
-    for op, c in cyc.most_common(top):
-        print(f"  {op:28s} {cnt[op]:6d}  {c:8.0f}  {c / total:6.3f}")
-    rest = [(op, cnt[op]) for op in cnt if cyc[op] == 0]
-    print("  non-VALU:", ", ".join(f"{op} {k}" for op, k in sorted(rest, key=lambda x: -x[1])[:10]))
+    nvalu = sum(v for k, v in cnt.items() if k.startswith("v_"))
+    if verbose:
+        print(f"kernel {pat}: {'whole body' if whole else f'loop 0x{lo:x}..0x{hi:x}'}: {n} instructions ({nvalu} VALU), {nmad} MADs, "
+              f"{total:.0f} weighted VALU cycles, MAD share {mad / total:.3f} of the cycles, {nmad / max(1, nvalu):.3f} of the VALU instructions")
+        for op, c in cyc.most_common(top):
+            print(f"  {op:28s} {cnt[op]:6d}  {c:8.0f}  {c / total:6.3f}")
+        rest = [(op, cnt[op]) for op in cnt if cyc[op] == 0]
+        print("  non-VALU:", ", ".join(f"{op} {k}" for op, k in sorted(rest, key=lambda x: -x[1])[:10]))
+    return {"instructions": n, "valu": nvalu, "mads": nmad, "weighted_cycles": total, "mad_cycle_share": mad / total,
+            "mad_count_share_of_valu": nmad / max(1, nvalu)}
 
 
 if __name__ == "__main__":
