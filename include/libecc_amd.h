@@ -289,6 +289,29 @@ int ec_prj_pt_mul_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n
 int ec_prj_pt_unique_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *points, int in_fmt,
 			   uint8_t *out, int out_fmt, uint8_t *status);
 
+/* The group law, the on-curve test and the public-scalar multiplication in either wire format (round 4; SURVEY.md 8a rows a17, a18,
+ * a21, a22 as callable batch operations).
+ *   ec_prj_pt_op_batch_fmt: op ECAMD_PT_OP_ADD = prj_pt_add (curves/prj_pt.c:1204, the complete formulas of :971-1071; an
+ *     "exceptional pair" -- the difference of the two points has order two, only possible on a curve of even order -- is the
+ *     reference's -1, :1058-1060: ECAMD_ERR), ECAMD_PT_OP_DBL = prj_pt_dbl (:1132), ECAMD_PT_OP_ON_CURVE = prj_pt_is_on_curve (:144;
+ *     status 0 on the curve / 1 not, out may be NULL).  Inputs as prj_pt_import_from_[aff_]buf takes them: every coordinate < p and
+ *     the projective curve equation -- the reference's prj_pt_add / prj_pt_dbl do not test their operands, here a point off the
+ *     curve is ECAMD_ERR; Z = 0 on the curve is the point at infinity, (0 : 0 : 0) included.  Output: the unique representative
+ *     (prj_pt_unique: X / Z || Y / Z [|| 1]) or ECAMD_INF with zero bytes.
+ *   ec_prj_pt_unprotected_mult_batch: _prj_pt_unprotected_mult (curves/prj_pt.c:1835-1880) statement for statement -- on-curve test,
+ *     zero scalar -> infinity, out = in, then per bit below the top one a doubling and, when the bit is set, an addition whose
+ *     exceptional pair is the call's -1 -- so that the batch form returns what the scalar function returns for EVERY public scalar
+ *     and point (the window kernels return the same group element but never fail that way).  scalar_stride = scalar_len: one
+ *     big-endian scalar per item; scalar_stride = 0: one scalar for every item, which is check_prj_pt_order (:1909) for PUBLIC_PT:
+ *     "in_isorder is a multiple of the point's order" <=> status ECAMD_INF. */
+#define ECAMD_PT_OP_ADD 0
+#define ECAMD_PT_OP_DBL 1
+#define ECAMD_PT_OP_ON_CURVE 2
+int ec_prj_pt_op_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *curve, int op, uint32_t n, const uint8_t *p1, const uint8_t *p2, int in_fmt,
+			   uint8_t *out, int out_fmt, uint8_t *status);
+int ec_prj_pt_unprotected_mult_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *scalars, uint32_t scalar_len,
+				     uint32_t scalar_stride, const uint8_t *points, int in_fmt, uint8_t *out, int out_fmt, uint8_t *status);
+
 /* Structured public keys, batch form of ec_structured_pub_key_import_from_buf (sig/ec_key.c:312): each key is
  * 3 header bytes -- EC_PUBKEY (0), the ec_alg_type the key is for (ECDSA = 1, ...), libecc's ec_curve_type -- followed by
  * the projective X || Y || Z of ec_pub_key_export_to_buf.  Checks the header, imports (prj_pt_import_from_buf), checks the
@@ -377,6 +400,11 @@ int ecamd_multi_prj_pt_mul_batch_fmt(ecamd_multi *m, const ecamd_mcurve *curve, 
 				     uint8_t *status);
 int ecamd_multi_prj_pt_add_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *p1_aff, const uint8_t *p2_aff,
 				uint8_t *out_aff, uint8_t *status);
+int ecamd_multi_prj_pt_op_batch_fmt(ecamd_multi *m, const ecamd_mcurve *curve, int op, uint32_t n, const uint8_t *p1, const uint8_t *p2,
+				    int in_fmt, uint8_t *out, int out_fmt, uint8_t *status);
+int ecamd_multi_prj_pt_unprotected_mult_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *scalars,
+					      uint32_t scalar_len, uint32_t scalar_stride, const uint8_t *points, int in_fmt, uint8_t *out,
+					      int out_fmt, uint8_t *status);
 int ecamd_multi_prj_pt_unique_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *points, int in_fmt,
 				    uint8_t *out, int out_fmt, uint8_t *status);
 int ecamd_multi_ecdsa_verify_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *pubkeys_aff,

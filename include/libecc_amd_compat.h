@@ -62,6 +62,33 @@ int prj_pt_mul_batch(prj_pt *out, const nn *m, const prj_pt *in, u32 n, int *ret
 int prj_pt_mul_blind_batch(prj_pt *out, const nn *m, const prj_pt *in, u32 n, int *ret_items);
 
 /*
+ * Round 4: the rest of curves/prj_pt.h's arithmetic in batch form (SURVEY.md 8b's export list), each item what the scalar function
+ * computes, ret_items (may be NULL) what it would have returned.  All points of one call lie on ONE curve (in[0]'s / in1[0]'s);
+ * results are the unique representative (Z = 1) or (0 : 1 : 0).  One difference from the scalar functions, which do not look at
+ * their operands: a point that does not satisfy the curve equation is an error here (ret_items -1).
+ *   prj_pt_add_batch       prj_pt_add (:48, curves/prj_pt.c:1204): out[i] = in1[i] + in2[i]; -1 also on the addition's exceptional pair
+ *                          (the difference of the two points has order two -- only on curves of even order; :1058-1060)
+ *   prj_pt_dbl_batch       prj_pt_dbl (:50, :1132)
+ *   prj_pt_unique_batch    prj_pt_unique (:44, :241): -1 for the point at infinity, as the scalar function
+ *   prj_pt_is_on_curve_batch  prj_pt_is_on_curve (:42, :144): on_curve[i] = 1 / 0
+ *   _prj_pt_unprotected_mult_batch  _prj_pt_unprotected_mult (:84, :1835-1905): the reference's double-and-add for PUBLIC scalars, bit
+ *                          by bit on the device, so that its -1 on an exceptional pair of one of its additions is reproduced too
+ *   check_prj_pt_order_batch  check_prj_pt_order (:86, :1909): check[i] = 1 when [in_isorder] in[i] is the point at infinity;
+ *                          PUBLIC_PT points through the double-and-add above, sensitive ones through prj_pt_mul_blind_batch
+ */
+int prj_pt_add_batch(prj_pt *out, const prj_pt *in1, const prj_pt *in2, u32 n, int *ret_items);
+int prj_pt_dbl_batch(prj_pt *out, const prj_pt *in, u32 n, int *ret_items);
+int prj_pt_unique_batch(prj_pt *out, const prj_pt *in, u32 n, int *ret_items);
+int prj_pt_is_on_curve_batch(const prj_pt *in, u32 n, int *on_curve, int *ret_items);
+int _prj_pt_unprotected_mult_batch(prj_pt *out, const nn *scalars, const prj_pt *in, u32 n, int *ret_items);
+int check_prj_pt_order_batch(const prj_pt *in, nn_src_t in_isorder, prj_pt_sensitivity s, u32 n, int *check, int *ret_items);
+/* Batch form of ec_pub_key_import_from_aff_buf (sig/ec_key.h, sig/ec_key.c:181): pub_keys[i] from the affine X || Y octets
+ * pub_key_bufs[i] (pub_key_buf_len each): range and curve equation on the device, and -- when the curve's cofactor is not 1 -- the
+ * reference's subgroup test [q]Y = infinity by its own double-and-add (check_prj_pt_order, PUBLIC_PT). */
+int ec_pub_key_import_from_aff_buf_batch(ec_pub_key *pub_keys, const ec_params *params, const u8 *const *pub_key_bufs, u8 pub_key_buf_len,
+					 ec_alg_type ec_key_alg, u32 num, int *ret_items);
+
+/*
  * Batch form of ecccdh_derive_secret (ecdh/ecccdh.h:57, ecdh/ecccdh.c:167): item i derives
  * shared_secrets[i] (shared_secret_len bytes, = ecccdh_shared_secret_size) from our_priv_keys[i] and the serialised
  * peer key peer_pub_keys[i] (peer_pub_key_len bytes each, = ecccdh_serialized_pub_key_size).  All keys on one curve.

@@ -14,6 +14,7 @@ EXPORTED_SYMBOLS = [
     "ec_prj_pt_mul_batch_dev", "ecamd_ctx_synchronize", "ec_prj_pt_add_batch", "ec_prj_pt_dbl_batch",
     "ec_fp_op_batch", "ec_ecdsa_verify_batch", "ec_ecdsa_verify_batch_fmt", "ec_ecdsa_sign_batch", "ec_ecccdh_derive_batch", "ec_xdh_batch",
     "ec_prj_pt_mul_batch_fmt", "ec_prj_pt_unique_batch", "ec_structured_pub_key_import_batch",
+    "ec_prj_pt_op_batch_fmt", "ec_prj_pt_unprotected_mult_batch", "ecamd_multi_prj_pt_op_batch_fmt", "ecamd_multi_prj_pt_unprotected_mult_batch",
     "ec_aff_pt_y_from_x_batch", "ec_point_decompress_batch", "ec_structured_sig_import_batch", "ec_structured_key_pair_import_batch",
     "ec_eddsa_verify_batch", "ec_eddsa_verify_all_batch", "ec_ecdsa_verify_batch_dev", "ec_eddsa_verify_batch_dev", "ec_xdh_batch_dev",
     "ec_ecdsa_sign_batch_dev", "ec_ecccdh_derive_batch_dev", "ec_eddsa_sign_R_batch", "ec_eddsa_sign_S_batch",
@@ -393,6 +394,24 @@ class Curve:
         _chk(self.L, self.L.ec_prj_pt_unique_batch(self.ctx.h, self.h, n, points, in_fmt, out, out_fmt, st),
              "ec_prj_pt_unique_batch")
         return out.raw[:w * n], st.raw[:n]
+
+    def pt_op_fmt(self, op, p1, p2, in_fmt, out_fmt):
+        """prj_pt_add (op 0) / prj_pt_dbl (1) / prj_pt_is_on_curve (2) in either wire format: (out, status)"""
+        iw, ow = (3 if in_fmt else 2) * self.clen, (3 if out_fmt else 2) * self.clen
+        n = len(p1) // iw
+        out, st = C.create_string_buffer(max(1, ow * n)), C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_prj_pt_op_batch_fmt(self.ctx.h, self.h, op, n, p1, p2, in_fmt, None if op == 2 else out, out_fmt, st),
+             "ec_prj_pt_op_batch_fmt")
+        return (b"" if op == 2 else out.raw[:ow * n]), st.raw[:n]
+
+    def unprotected_mult(self, scalars, slen, points, in_fmt, out_fmt, broadcast=False):
+        """_prj_pt_unprotected_mult per item (broadcast: one scalar of slen bytes for every point, check_prj_pt_order's use)"""
+        iw, ow = (3 if in_fmt else 2) * self.clen, (3 if out_fmt else 2) * self.clen
+        n = len(points) // iw
+        out, st = C.create_string_buffer(max(1, ow * n)), C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_prj_pt_unprotected_mult_batch(self.ctx.h, self.h, n, scalars, slen, 0 if broadcast else slen, points, in_fmt,
+                                                             out, out_fmt, st), "ec_prj_pt_unprotected_mult_batch")
+        return out.raw[:ow * n], st.raw[:n]
 
     def y_from_x(self, xs):
         """aff_pt_y_from_x: (y1, y2, status), y1 the root the reference's fp_sqrt returns first"""

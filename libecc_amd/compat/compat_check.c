@@ -154,6 +154,201 @@ static void check_mul(const char *curve, u32 n, int blind)
 	free(in); free(out); free(m); free(rets);
 }
 
+/* ---- round 4: prj_pt_add / dbl / unique / is_on_curve, _prj_pt_unprotected_mult, check_prj_pt_order and
+ *      ec_pub_key_import_from_aff_buf in batch form against the scalar functions ---- */
+static int same_point(prj_pt_src_t a, prj_pt_src_t b)
+{
+	int z1 = 0, z2 = 0, cmp = 1;
+	if (prj_pt_iszero(a, &z1) || prj_pt_iszero(b, &z2) || z1 != z2) {
+		return 0;
+	}
+	return z1 ? 1 : (!prj_pt_cmp(a, b, &cmp) && !cmp);
+}
+
+static void check_group_law(const char *curve, u32 n)
+{
+	ec_params params;
+	prj_pt *a = calloc(n, sizeof(prj_pt)), *b = calloc(n, sizeof(prj_pt)), *out = calloc(n, sizeof(prj_pt));
+	nn *m = calloc(n, sizeof(nn));
+	int *rets = calloc(n, sizeof(int)), *flags = calloc(n, sizeof(int));
+	ec_pub_key *pubs = calloc(n, sizeof(ec_pub_key));
+	u8 *bufs = calloc(n, 2 * 72);
+	const u8 **bp = calloc(n, sizeof(u8 *));
+	u32 i, clen, nerr = 0, ninf = 0;
+	const u32 before = failures;
+	int isone = 0;
+	if (load_params(curve, &params) || !a || !b || !out || !m || !rets || !flags || !pubs || !bufs || !bp) {
+		CHECK(0, "%s: setup", curve);
+		return;
+	}
+	clen = (u32)BYTECEIL(params.ec_fp.p_bitlen);
+	nn_isone(&params.ec_gen_cofactor, &isone);
+	for (i = 0; i < n; i++) {
+		nn t;
+		if (nn_get_random_mod(&t, &params.ec_gen_order) || prj_pt_mul(&a[i], &t, &params.ec_gen) ||
+		    nn_get_random_mod(&t, &params.ec_gen_order) || prj_pt_mul(&b[i], &t, &params.ec_gen) ||
+		    nn_get_random_mod(&m[i], &params.ec_gen_order)) {
+			CHECK(0, "%s: input generation", curve);
+			return;
+		}
+		if (i % 5 == 4) {
+			u8 w[2];
+			get_random(w, 2);
+			nn_init(&m[i], 0);
+			m[i].val[0] = (word_t)(w[0] | (w[1] << 8));   /* short public scalars (cofactors and the like) */
+			m[i].wlen = 1;
+		}
+	}
+	if (n >= 16) {
+		prj_pt_copy(&b[0], &a[0]);                              /* P + P through the addition */
+		prj_pt_neg(&b[1], &a[1]);                               /* P + (-P) = infinity */
+		prj_pt_zero(&b[2]);                                     /* P + infinity */
+		prj_pt_zero(&a[3]);                                     /* infinity + Q */
+		prj_pt_zero(&a[4]); prj_pt_zero(&b[4]);                 /* infinity + infinity */
+		fp_inc(&a[5].Y, &a[5].Y);                               /* off the curve: an error in the batch forms */
+		nn_zero(&m[6]);                                         /* [0]P */
+		nn_copy(&m[7], &params.ec_gen_order);                   /* [q]P = infinity */
+		nn_one(&m[8]);
+		if (!isone) {
+			/* a cofactor curve: the point of order two (x, 0) exists -- on libecc's 25519 / 448 models x = A/3 -- as does a
+			 * point of order 2q; the addition's exceptional pair and the double-and-add's -1 live there */
+			int found = 0, tries;
+			for (tries = 0; tries < 200 && !found; tries++) {
+				/* a curve point outside the subgroup: x = a small value, y from the curve equation; [q] of it has an order
+				 * that divides the cofactor, and doubling that until the next doubling is infinity leaves the point of order two */
+				aff_pt ap;
+				prj_pt T, Q2, D;
+				fp xs, y1, yb;
+				int z = 0, zz = 0, guard = 0;
+				if (fp_init(&xs, &params.ec_fp) || fp_init(&y1, &params.ec_fp) || fp_init(&yb, &params.ec_fp) ||
+				    fp_set_word_value(&xs, (word_t)(2 + tries))) {
+					break;
+				}
+				if (aff_pt_y_from_x(&y1, &yb, &xs, &params.ec_curve) || aff_pt_init_from_coords(&ap, &params.ec_curve, &xs, &y1) ||
+				    ec_shortw_aff_to_prj(&T, &ap) || prj_pt_mul(&Q2, &params.ec_gen_order, &T) || prj_pt_iszero(&Q2, &z) || z) {
+					continue;
+				}
+				while (guard++ < 8 && !prj_pt_dbl(&D, &Q2) && !prj_pt_iszero(&D, &zz) && !zz) {
+					prj_pt_copy(&Q2, &D);
+				}
+				if (zz) {
+					/* Q2 has order two: a[9] + (a[9] + Q2) is an exceptional pair; a[10] = Q2 itself; a[11] has order 2q */
+					if (!prj_pt_add(&b[9], &a[9], &Q2) && !prj_pt_copy(&a[10], &Q2) && !nn_copy(&m[10], &params.ec_gen_order) &&
+					    !prj_pt_add(&a[11], &a[11], &Q2) && !nn_copy(&m[11], &params.ec_gen_order)) {
+						found = 1;
+					}
+				}
+			}
+			CHECK(found, "%s: no point of order two found for the exceptional-pair items", curve);
+		}
+	}
+	/* prj_pt_add_batch / prj_pt_dbl_batch / prj_pt_unique_batch / prj_pt_is_on_curve_batch */
+	if (prj_pt_add_batch(out, a, b, n, rets)) {
+		CHECK(0, "%s: prj_pt_add_batch failed", curve);
+		return;
+	}
+	for (i = 0; i < n; i++) {
+		prj_pt ref;
+		int on1 = 0, on2 = 0;
+		int r = prj_pt_add(&ref, &a[i], &b[i]);
+		prj_pt_is_on_curve(&a[i], &on1); prj_pt_is_on_curve(&b[i], &on2);
+		if (!on1 || !on2) {
+			CHECK(rets[i] == -1, "%s: add item %u off the curve must be an error", curve, i);
+			nerr++;
+			continue;
+		}
+		CHECK(r == rets[i], "%s: add item %u returns %d, prj_pt_add %d", curve, i, rets[i], r);
+		if (r) { nerr++; continue; }
+		CHECK(same_point(&ref, &out[i]), "%s: add item %u differs from prj_pt_add", curve, i);
+	}
+	if (prj_pt_dbl_batch(out, a, n, rets)) {
+		CHECK(0, "%s: prj_pt_dbl_batch failed", curve);
+		return;
+	}
+	for (i = 0; i < n; i++) {
+		prj_pt ref;
+		int on1 = 0, z = 0;
+		prj_pt_is_on_curve(&a[i], &on1);
+		if (!on1) { CHECK(rets[i] == -1, "%s: dbl item %u off the curve must be an error", curve, i); continue; }
+		CHECK(!prj_pt_dbl(&ref, &a[i]) && rets[i] == 0 && same_point(&ref, &out[i]), "%s: dbl item %u differs from prj_pt_dbl", curve, i);
+		if (!prj_pt_iszero(&out[i], &z) && z) ninf++;
+	}
+	if (prj_pt_unique_batch(out, a, n, rets) || prj_pt_is_on_curve_batch(a, n, flags, NULL)) {
+		CHECK(0, "%s: prj_pt_unique_batch / prj_pt_is_on_curve_batch failed", curve);
+		return;
+	}
+	for (i = 0; i < n; i++) {
+		prj_pt ref;
+		int on1 = 0, cmp = 1, isone_z = 0;
+		fp one_fp;
+		int r;
+		prj_pt_is_on_curve(&a[i], &on1);
+		CHECK(flags[i] == on1, "%s: on-curve flag of item %u is %d, prj_pt_is_on_curve %d", curve, i, flags[i], on1);
+		if (!on1) { CHECK(rets[i] == -1, "%s: unique item %u off the curve must be an error", curve, i); continue; }
+		r = prj_pt_unique(&ref, &a[i]);
+		CHECK(r == rets[i], "%s: unique item %u returns %d, prj_pt_unique %d", curve, i, rets[i], r);
+		if (r) continue;
+		CHECK(!prj_pt_cmp(&ref, &out[i], &cmp) && !cmp && !fp_init(&one_fp, &params.ec_fp) && !fp_one(&one_fp) && !fp_cmp(&out[i].Z, &one_fp, &isone_z) && !isone_z, "%s: unique item %u differs", curve, i);
+	}
+	/* _prj_pt_unprotected_mult_batch and check_prj_pt_order_batch (PUBLIC_PT and sensitive) */
+	if (_prj_pt_unprotected_mult_batch(out, m, a, n, rets)) {
+		CHECK(0, "%s: _prj_pt_unprotected_mult_batch failed", curve);
+		return;
+	}
+	for (i = 0; i < n; i++) {
+		prj_pt ref;
+		const int r = _prj_pt_unprotected_mult(&ref, &m[i], &a[i]);
+		CHECK(r == rets[i], "%s: unprotected mult item %u returns %d, the scalar function %d", curve, i, rets[i], r);
+		if (r) continue;
+		CHECK(same_point(&ref, &out[i]), "%s: unprotected mult item %u differs", curve, i);
+	}
+	{
+		int s;
+		for (s = 0; s < 2; s++) {
+			const prj_pt_sensitivity sens = s ? PRIVATE_PT : PUBLIC_PT;
+			const u32 cnt = s ? (n < 64 ? n : 64) : n;
+			if (check_prj_pt_order_batch(a, &params.ec_gen_order, sens, cnt, flags, rets)) {
+				CHECK(0, "%s: check_prj_pt_order_batch failed", curve);
+				return;
+			}
+			for (i = 0; i < cnt; i++) {
+				int chk = 0;
+				const int r = check_prj_pt_order(&a[i], &params.ec_gen_order, sens, &chk);
+				CHECK(r == rets[i] && (r || chk == flags[i]), "%s: order check (%s) item %u: %d/%d, the scalar function %d/%d", curve,
+				      s ? "sensitive" : "public", i, rets[i], flags[i], r, chk);
+			}
+		}
+	}
+	/* ec_pub_key_import_from_aff_buf_batch: the affine octets of the points above (and what does not decode) */
+	for (i = 0; i < n; i++) {
+		int z = 0, on = 0;
+		bp[i] = bufs + (size_t)i * 2 * 72;
+		memset(bufs + (size_t)i * 2 * 72, 0xff, 2 * clen);
+		prj_pt_is_on_curve(&a[i], &on);
+		if (on && !prj_pt_iszero(&a[i], &z) && !z) {
+			prj_pt u;
+			if (!prj_pt_unique(&u, &a[i])) {
+				prj_pt_export_to_aff_buf(&u, bufs + (size_t)i * 2 * 72, 2 * clen);
+			}
+		}
+	}
+	if (ec_pub_key_import_from_aff_buf_batch(pubs, &params, bp, (u8)(2 * clen), ECDSA, n, rets)) {
+		CHECK(0, "%s: ec_pub_key_import_from_aff_buf_batch failed", curve);
+		return;
+	}
+	for (i = 0; i < n; i++) {
+		ec_pub_key ref;
+		const int r = ec_pub_key_import_from_aff_buf(&ref, &params, bp[i], (u8)(2 * clen), ECDSA);
+		CHECK(r == rets[i], "%s: key import item %u returns %d, the scalar function %d", curve, i, rets[i], r);
+		if (r) continue;
+		CHECK(same_point(&ref.y, &pubs[i].y) && pubs[i].key_type == ECDSA && pubs[i].params == &params && pubs[i].magic == ref.magic,
+		      "%s: key import item %u differs", curve, i);
+	}
+	printf("group law / public-scalar batch forms %-16s %u items, %u addition errors, %u doublings at infinity: %s\n", curve, n, nerr, ninf,
+	       failures == before ? "ok" : "FAILED");
+	free(a); free(b); free(out); free(m); free(rets); free(flags); free(pubs); free(bufs); free((void *)bp);
+}
+
 /* ---- ecccdh_derive_secret_batch against ecccdh_derive_secret ---- */
 static void check_cdh(const char *curve, u32 n)
 {
@@ -902,6 +1097,7 @@ int main(int argc, char **argv)
 		/* one case per entry-point family at a size that goes through the thread pool and several pipeline chunks */
 		const u32 qn = (u32)atoi(argv[2]);
 		check_mul("SECP256R1", qn, 0);
+		check_group_law("WEI25519", qn < 96 ? qn : 96);
 		check_cdh("SECP256R1", qn);
 		check_verify("SECP256R1", ECDSA, SHA256, "ECDSA/SECP256R1/SHA256", qn, 1);
 		check_verify("WEI25519", EDDSA25519, SHA512, "EDDSA25519", qn, 1);
@@ -920,6 +1116,9 @@ int main(int argc, char **argv)
 	check_mul("BRAINPOOLP256R1", n, 0);
 	check_mul("WEI25519", n, 0);
 	check_mul("SECP256R1", n, 1);
+	check_group_law("SECP256R1", n);
+	check_group_law("WEI25519", n < 256 ? n : 256);
+	check_group_law("SECP384R1", n < 128 ? n : 128);
 	check_mul("SECP384R1", n < 128 ? n : 128, 1);
 	check_mul("WEI25519", n < 128 ? n : 128, 1);
 	check_cdh("SECP256R1", n);

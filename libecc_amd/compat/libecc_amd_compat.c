@@ -1114,6 +1114,351 @@ int prj_pt_mul_blind_batch(prj_pt *out, const nn *m, const prj_pt *in, u32 n, in
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Round 4: the group law, the normalisation, the on-curve test and the public-scalar multiplication in libecc's own types
+ * (prj_pt_add / prj_pt_dbl / prj_pt_unique / prj_pt_is_on_curve, curves/prj_pt.h:42-86; _prj_pt_unprotected_mult and
+ * check_prj_pt_order, curves/prj_pt.c:1835-1945) and ec_pub_key_import_from_aff_buf (sig/ec_key.c:181).
+ * One job shape serves all of them: inputs as projective X || Y || Z (or the caller's affine buffers), results as affine
+ * X || Y + status from the device (ec_prj_pt_op_batch_fmt / ec_prj_pt_unprotected_mult_batch of libecc_amd.h).
+ * ------------------------------------------------------------------------------------------------ */
+enum { PTOP_ADD = 0, PTOP_DBL, PTOP_ON_CURVE, PTOP_UNIQUE, PTOP_UMULT, PTOP_ORDER, PTOP_PUBIMPORT };
+typedef struct {
+	int op;
+	const prj_pt *in1, *in2;
+	const nn *m;                 /* PTOP_UMULT: per-item scalars */
+	const u8 *const *bufs;       /* PTOP_PUBIMPORT: affine buffers */
+	u32 buf_len;
+	prj_pt *out;
+	ec_pub_key *pubs;
+	const ec_params *params;
+	ec_alg_type alg;
+	int *ret_items, *flags;      /* flags: on_curve (PTOP_ON_CURVE) / check (PTOP_ORDER) */
+	int need_order;              /* PTOP_PUBIMPORT on a cofactor curve: the subgroup test of ec_pub_key_import_from_aff_buf */
+	u8 *b1, *b2, *sc, *pout, *st, *pre;
+	u8 bsc[NN_MAX_BYTE_LEN];     /* the one scalar of PTOP_ORDER / PTOP_PUBIMPORT */
+	u32 slen, clen, iw;
+	int in_fmt;
+	ec_shortw_crv_src_t crv;
+	curve_ent *e;
+} ptop_job;
+
+static void ptop_pack(u32 lo, u32 hi, void *arg)
+{
+	ptop_job *J = (ptop_job *)arg;
+	u32 i;
+	for (i = lo; i < hi; i++) {
+		int bad;
+		if (J->op == PTOP_PUBIMPORT) {
+			/* prj_pt_import_from_aff_buf wants exactly 2 * BYTECEIL(|p|) octets (curves/prj_pt.c:520-526) */
+			bad = !J->bufs[i] || J->buf_len != 2 * J->clen;
+			if (!bad) {
+				memcpy(J->b1 + (size_t)i * J->iw, J->bufs[i], J->iw);
+			}
+		} else {
+			bad = prj_to_be(J->b1 + (size_t)i * J->iw, J->clen, &J->in1[i], J->crv);
+			if (!bad && J->op == PTOP_ADD) {
+				/* MUST_HAVE((in1->crv == in2->crv)), curves/prj_pt.c:1210 */
+				bad = prj_to_be(J->b2 + (size_t)i * J->iw, J->clen, &J->in2[i], J->crv);
+			}
+			if (!bad && J->op == PTOP_UMULT) {
+				bad = nn_to_be(J->sc + (size_t)i * J->slen, J->slen, &J->m[i]);
+			}
+		}
+		J->pre[i] = bad ? 1 : 0;
+		if (bad) {
+			memset(J->b1 + (size_t)i * J->iw, 0xff, J->iw);   /* coordinates >= p: rejected at import */
+			if (J->op == PTOP_ADD) {
+				memset(J->b2 + (size_t)i * J->iw, 0xff, J->iw);
+			}
+			if (J->op == PTOP_UMULT) {
+				memset(J->sc + (size_t)i * J->slen, 0, J->slen);
+			}
+		}
+	}
+}
+
+static int ptop_gpu(u32 lo, u32 hi, void *arg)
+{
+	ptop_job *J = (ptop_job *)arg;
+	const u32 m = hi - lo;
+	u8 *pout = J->pout + (size_t)lo * 2 * J->clen;
+	int r;
+	switch (J->op) {
+	case PTOP_ADD:
+	case PTOP_DBL:
+	case PTOP_ON_CURVE:
+		r = ecamd_multi_prj_pt_op_batch_fmt(g_multi, J->e->mc, J->op == PTOP_ADD ? ECAMD_PT_OP_ADD : (J->op == PTOP_DBL ? ECAMD_PT_OP_DBL : ECAMD_PT_OP_ON_CURVE),
+						    m, J->b1 + (size_t)lo * J->iw, J->op == PTOP_ADD ? J->b2 + (size_t)lo * J->iw : NULL, J->in_fmt, pout,
+						    ECAMD_PT_AFFINE, J->st + lo);
+		break;
+	case PTOP_UNIQUE:
+		r = ecamd_multi_prj_pt_unique_batch(g_multi, J->e->mc, m, J->b1 + (size_t)lo * J->iw, J->in_fmt, pout, ECAMD_PT_AFFINE, J->st + lo);
+		break;
+	case PTOP_UMULT:
+		r = ecamd_multi_prj_pt_unprotected_mult_batch(g_multi, J->e->mc, m, J->sc + (size_t)lo * J->slen, J->slen, J->slen, J->b1 + (size_t)lo * J->iw,
+							      J->in_fmt, pout, ECAMD_PT_AFFINE, J->st + lo);
+		break;
+	case PTOP_PUBIMPORT:
+		if (!J->need_order) {
+			r = ecamd_multi_prj_pt_op_batch_fmt(g_multi, J->e->mc, ECAMD_PT_OP_ON_CURVE, m, J->b1 + (size_t)lo * J->iw, NULL, J->in_fmt, pout,
+							    ECAMD_PT_AFFINE, J->st + lo);
+			break;
+		}
+		/* [q]Y must be the point at infinity */
+		/* fall through */
+	default:
+		r = ecamd_multi_prj_pt_unprotected_mult_batch(g_multi, J->e->mc, m, J->bsc, J->slen, 0, J->b1 + (size_t)lo * J->iw, J->in_fmt, pout,
+							      ECAMD_PT_AFFINE, J->st + lo);
+		break;
+	}
+	if (r) {
+		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+		return -1;
+	}
+	return 0;
+}
+
+static void ptop_unpack(u32 lo, u32 hi, void *arg)
+{
+	ptop_job *J = (ptop_job *)arg;
+	u32 i;
+	for (i = lo; i < hi; i++) {
+		const u8 st = J->st[i];
+		int r = -1;
+		if (J->pre[i]) {
+			r = -1;
+		} else if (J->op == PTOP_ON_CURVE) {
+			J->flags[i] = (st == ECAMD_OK) ? 1 : 0;   /* the call itself succeeds for an initialised point */
+			r = 0;
+		} else if (J->op == PTOP_ORDER) {
+			if (st != ECAMD_ERR) {
+				J->flags[i] = (st == ECAMD_INF) ? 1 : 0;
+				r = 0;
+			}
+		} else if (J->op == PTOP_PUBIMPORT) {
+			ec_pub_key *pub = &J->pubs[i];
+			const int ok = J->need_order ? (st == ECAMD_INF) : (st == ECAMD_OK);
+			memset(pub, 0, sizeof(ec_pub_key));
+			if (ok && !prj_from_aff_be(&pub->y, &(J->params->ec_curve), J->b1 + (size_t)i * J->iw, J->clen, ECAMD_OK)) {
+				pub->key_type = J->alg;
+				pub->params = J->params;
+				pub->magic = PUB_KEY_MAGIC;
+				r = 0;
+			}
+		} else if (J->op == PTOP_UNIQUE) {
+			/* prj_pt_unique / prj_pt_to_aff refuse the point at infinity (curves/prj_pt.c:218-241) */
+			r = (st == ECAMD_OK) ? prj_from_aff_be(&J->out[i], J->crv, J->pout + (size_t)i * 2 * J->clen, J->clen, st) : -1;
+		} else {
+			r = prj_from_aff_be(&J->out[i], J->crv, J->pout + (size_t)i * 2 * J->clen, J->clen, st);
+		}
+		if (J->ret_items) {
+			J->ret_items[i] = r;
+		}
+	}
+}
+
+static int ptop_run(ptop_job *J, u32 n)
+{
+	int ret = -1;
+	if (n == 0) {
+		return 0;
+	}
+	if (ecamd_compat_init(NULL, 0, 0)) {
+		return -1;
+	}
+	J->clen = J->e->clen;
+	J->in_fmt = (J->op == PTOP_PUBIMPORT) ? ECAMD_PT_AFFINE : ECAMD_PT_PROJECTIVE;
+	J->iw = (J->in_fmt ? 3u : 2u) * J->clen;
+	pthread_mutex_lock(&g_call_mu);
+	J->b1 = buf_get(0, (size_t)n * J->iw);
+	J->b2 = (J->op == PTOP_ADD) ? buf_get(1, (size_t)n * J->iw) : J->b1;
+	J->sc = (J->op == PTOP_UMULT) ? buf_get(2, (size_t)n * J->slen) : J->b1;
+	J->pout = buf_get(3, (size_t)n * 2 * J->clen);
+	J->st = buf_get(4, n);
+	J->pre = buf_get(5, n);
+	if (J->b1 && J->b2 && J->sc && J->pout && J->st && J->pre &&
+	    !pipeline_run(n, chunk_items_for(g_chunk, n), ptop_pack, ptop_gpu, ptop_unpack, J)) {
+		note_items(n);
+		ret = 0;
+	}
+	pthread_mutex_unlock(&g_call_mu);
+	return ret;
+}
+
+static int ptop_points(ptop_job *J, int op, prj_pt *out, const prj_pt *in1, const prj_pt *in2, u32 n, int *ret_items)
+{
+	memset(J, 0, sizeof(*J));
+	if (!in1 || (op == PTOP_ADD && !in2) || ((op == PTOP_ADD || op == PTOP_DBL || op == PTOP_UNIQUE || op == PTOP_UMULT) && !out)) {
+		return -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	if (prj_pt_check_initialized(&in1[0])) {
+		return -1;
+	}
+	J->op = op;
+	J->in1 = in1;
+	J->in2 = in2;
+	J->out = out;
+	J->ret_items = ret_items;
+	J->crv = in1[0].crv;
+	J->e = curve_from_crv(J->crv);
+	return J->e ? 1 : -1;
+}
+
+int prj_pt_add_batch(prj_pt *out, const prj_pt *in1, const prj_pt *in2, u32 n, int *ret_items)
+{
+	ptop_job J;
+	const int r = ptop_points(&J, PTOP_ADD, out, in1, in2, n, ret_items);
+	return r <= 0 ? r : ptop_run(&J, n);
+}
+
+int prj_pt_dbl_batch(prj_pt *out, const prj_pt *in, u32 n, int *ret_items)
+{
+	ptop_job J;
+	const int r = ptop_points(&J, PTOP_DBL, out, in, NULL, n, ret_items);
+	return r <= 0 ? r : ptop_run(&J, n);
+}
+
+int prj_pt_unique_batch(prj_pt *out, const prj_pt *in, u32 n, int *ret_items)
+{
+	ptop_job J;
+	const int r = ptop_points(&J, PTOP_UNIQUE, out, in, NULL, n, ret_items);
+	return r <= 0 ? r : ptop_run(&J, n);
+}
+
+int prj_pt_is_on_curve_batch(const prj_pt *in, u32 n, int *on_curve, int *ret_items)
+{
+	ptop_job J;
+	int r;
+	if (!on_curve) {
+		return -1;
+	}
+	r = ptop_points(&J, PTOP_ON_CURVE, NULL, in, NULL, n, ret_items);
+	J.flags = on_curve;
+	return r <= 0 ? r : ptop_run(&J, n);
+}
+
+int _prj_pt_unprotected_mult_batch(prj_pt *out, const nn *scalars, const prj_pt *in, u32 n, int *ret_items)
+{
+	ptop_job J;
+	bits_job B;
+	u32 i, maxbits = 0;
+	int r;
+	if (!scalars) {
+		return -1;
+	}
+	r = ptop_points(&J, PTOP_UMULT, out, in, NULL, n, ret_items);
+	if (r <= 0) {
+		return r;
+	}
+	if (ecamd_compat_init(NULL, 0, 0)) {
+		return -1;
+	}
+	/* one octet length for the batch: the longest scalar's */
+	B.m = scalars;
+	B.bits = (u32 *)malloc((size_t)n * sizeof(u32));
+	if (!B.bits) {
+		return -1;
+	}
+	pthread_mutex_lock(&g_call_mu);
+	parallel_for(n, mul_bits, &B);
+	pthread_mutex_unlock(&g_call_mu);
+	for (i = 0; i < n; i++) {
+		maxbits = B.bits[i] > maxbits ? B.bits[i] : maxbits;
+	}
+	free(B.bits);
+	J.m = scalars;
+	J.slen = maxbits ? (maxbits + 7) / 8 : 1;
+	return ptop_run(&J, n);
+}
+
+int check_prj_pt_order_batch(const prj_pt *in, nn_src_t in_isorder, prj_pt_sensitivity s, u32 n, int *check, int *ret_items)
+{
+	ptop_job J;
+	bitcnt_t bl = 0;
+	int r;
+	u32 i;
+	if (!check || !in_isorder || nn_check_initialized(in_isorder) || nn_bitlen(in_isorder, &bl)) {
+		return -1;
+	}
+	if (s != PUBLIC_PT) {
+		/* a sensitive point: the reference multiplies with prj_pt_mul_blind (curves/prj_pt.c:1930-1935), and so does the batch */
+		prj_pt *res;
+		nn *m;
+		int ret = -1;
+		if (!in) {
+			return -1;
+		}
+		if (n == 0) {
+			return 0;
+		}
+		res = (prj_pt *)calloc(n, sizeof(prj_pt));
+		m = (nn *)calloc(n, sizeof(nn));
+		if (res && m) {
+			for (i = 0; i < n; i++) {
+				if (nn_copy(&m[i], in_isorder)) {
+					break;
+				}
+			}
+			if (i == n && !prj_pt_mul_blind_batch(res, m, in, n, ret_items)) {
+				for (i = 0; i < n; i++) {
+					int z = 0;
+					check[i] = (!prj_pt_iszero(&res[i], &z) && z) ? 1 : 0;
+				}
+				ret = 0;
+			}
+		}
+		free(res);
+		free(m);
+		return ret;
+	}
+	r = ptop_points(&J, PTOP_ORDER, NULL, in, NULL, n, ret_items);
+	if (r <= 0) {
+		return r;
+	}
+	J.flags = check;
+	J.slen = bl ? (u32)BYTECEIL(bl) : 1;
+	if (nn_to_be(J.bsc, J.slen, in_isorder)) {
+		return -1;
+	}
+	return ptop_run(&J, n);
+}
+
+int ec_pub_key_import_from_aff_buf_batch(ec_pub_key *pub_keys, const ec_params *params, const u8 *const *pub_key_bufs, u8 pub_key_buf_len,
+					 ec_alg_type ec_key_alg, u32 num, int *ret_items)
+{
+	ptop_job J;
+	int isone = 0;
+	bitcnt_t bl = 0;
+	memset(&J, 0, sizeof(J));
+	if (!pub_keys || !params || !pub_key_bufs) {
+		return -1;
+	}
+	if (num == 0) {
+		return 0;
+	}
+	J.op = PTOP_PUBIMPORT;
+	J.bufs = pub_key_bufs;
+	J.buf_len = pub_key_buf_len;
+	J.pubs = pub_keys;
+	J.params = params;
+	J.alg = ec_key_alg;
+	J.ret_items = ret_items;
+	J.crv = &(params->ec_curve);
+	J.e = curve_from_params(params);
+	if (!J.e || nn_isone(&(params->ec_gen_cofactor), &isone) || nn_bitlen(&(params->ec_gen_order), &bl)) {
+		return -1;
+	}
+	J.need_order = !isone;
+	J.slen = bl ? (u32)BYTECEIL(bl) : 1;
+	if (nn_to_be(J.bsc, J.slen, &(params->ec_gen_order))) {
+		return -1;
+	}
+	return ptop_run(&J, num);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * public keys from private keys: init_pubkey_from_privkey and everything built on it
  * (key-pair generation / import, ecccdh_init_pub_key)
  * ------------------------------------------------------------------------------------------------ */
@@ -1259,17 +1604,26 @@ static void key_pack(u32 lo, u32 hi, void *arg)
 		if (J->mode == 1) {
 			/* ec_key_pair_gen (sig/ec_key.c:594-621) / ecccdh_gen_key_pair (ecdh/ecccdh.c:93-118) up to the public key */
 			ec_priv_key *w = &J->kps[i].priv_key;
-			bad = compat_random_mod(&w->x, &(J->params->ec_gen_order));
+			bad = nn_init(&w->x, 0);
 			w->key_type = J->alg;
 			w->params = J->params;
 			w->magic = PRIV_KEY_MAGIC;
 #if defined(WITH_ECCCDH)
-			if (!bad && J->alg != ECCCDH) {
-				bad = gen_priv_key(w);
-			}
-#else
-			bad = bad || gen_priv_key(w);
+			if (!bad && J->alg == ECCCDH) {
+				bad = compat_random_mod(&w->x, &(J->params->ec_gen_order));   /* ecccdh_gen_key_pair: x in ]0, q[ */
+			} else
 #endif
+			if (!bad) {
+				/* libecc's own gen_priv_key draws through get_random inside (nn_get_random_mod, eddsa_gen_priv_key): one
+				 * caller at a time unless the application lifted that (compat_random_mod) */
+				if (AT_LOAD(&g_rand_concurrent)) {
+					bad = gen_priv_key(w);
+				} else {
+					pthread_mutex_lock(&g_rand_mu);
+					bad = gen_priv_key(w);
+					pthread_mutex_unlock(&g_rand_mu);
+				}
+			}
 		} else if (J->mode == 2) {
 			/* ec_key_pair_import_from_priv_key_buf -> ec_priv_key_import_from_buf (sig/ec_key.c:289, :56) */
 			bad = !J->bufs[i] || ec_priv_key_import_from_buf(&J->kps[i].priv_key, J->params, J->bufs[i], (u8)J->buf_len, J->alg);

@@ -1655,6 +1655,103 @@ extern "C" int ec_prj_pt_dbl_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 4: prj_pt_add / prj_pt_dbl / prj_pt_is_on_curve in either wire format (k_ptf), and _prj_pt_unprotected_mult /
+// check_prj_pt_order statement for statement (k_unprot) -- SURVEY.md 8a rows a17, a18, a21, a22 as callable batch operations
+// ------------------------------------------------------------------------------------------
+extern "C" int ec_prj_pt_op_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *cv, int op, uint32_t n, const uint8_t *p1, const uint8_t *p2,
+				      int in_fmt, uint8_t *out, int out_fmt, uint8_t *status)
+{
+	if (!ctx || !cv || cv->ctx != ctx || op < 0 || op > 2 || (in_fmt != 0 && in_fmt != 1) || (out_fmt != 0 && out_fmt != 1) ||
+	    (n && (!p1 || (op == 0 && !p2) || (op != 2 && !out) || !status))) {
+		return fail("ec_prj_pt_op_batch_fmt: bad argument");
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t iw = (size_t)(in_fmt ? 3 : 2) * cv->clen, ow = (size_t)(out_fmt ? 3 : 2) * cv->clen;
+	hipStream_t s = ctx->stream;
+	StreamScope scope(ctx, s);
+	for (uint32_t off = 0; off < n; off += ctx->max_chunk) {
+		const uint32_t m = (n - off) < ctx->max_chunk ? (n - off) : ctx->max_chunk;
+		if (ensure(&ctx->stage[0], &ctx->stage_bytes[0], (size_t)m * iw) || ensure(&ctx->stage[1], &ctx->stage_bytes[1], (size_t)m * iw) ||
+		    ensure(&ctx->stage[2], &ctx->stage_bytes[2], (size_t)m * ow) || ensure(&ctx->stage[3], &ctx->stage_bytes[3], (size_t)m)) {
+			return -1;
+		}
+		HIPCHK(hipMemcpyAsync(ctx->stage[0], p1 + (size_t)off * iw, (size_t)m * iw, hipMemcpyHostToDevice, s));
+		if (op == 0) {
+			HIPCHK(hipMemcpyAsync(ctx->stage[1], p2 + (size_t)off * iw, (size_t)m * iw, hipMemcpyHostToDevice, s));
+		}
+		EcamdPtfArgs A;
+		memset(&A, 0, sizeof(A));
+		A.p1 = ctx->stage[0];
+		A.p2 = ctx->stage[1];
+		A.out = ctx->stage[2];
+		A.status = ctx->stage[3];
+		A.n = m;
+		A.clen = (uint32_t)cv->clen;
+		A.op = op;
+		A.in_fmt = in_fmt;
+		A.out_fmt = out_fmt;
+		A.slot = cv->slot;
+		HIPCHK(ecamd_launch_ptf(cv->nw, A, s));
+		if (op != 2) {
+			HIPCHK(hipMemcpyAsync(out + (size_t)off * ow, ctx->stage[2], (size_t)m * ow, hipMemcpyDeviceToHost, s));
+		}
+		HIPCHK(hipMemcpyAsync(status + off, ctx->stage[3], (size_t)m, hipMemcpyDeviceToHost, s));
+		HIPCHK(hipStreamSynchronize(s));
+	}
+	return 0;
+}
+
+extern "C" int ec_prj_pt_unprotected_mult_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *scalars,
+						uint32_t scalar_len, uint32_t scalar_stride, const uint8_t *points, int in_fmt, uint8_t *out,
+						int out_fmt, uint8_t *status)
+{
+	if (!ctx || !cv || cv->ctx != ctx || (in_fmt != 0 && in_fmt != 1) || (out_fmt != 0 && out_fmt != 1) || scalar_len == 0 ||
+	    scalar_len > 4096 || (scalar_stride != 0 && scalar_stride != scalar_len) || (n && (!scalars || !points || !out || !status))) {
+		return fail("ec_prj_pt_unprotected_mult_batch: bad argument (scalar_stride is scalar_len, or 0 for one scalar for every item)");
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t iw = (size_t)(in_fmt ? 3 : 2) * cv->clen, ow = (size_t)(out_fmt ? 3 : 2) * cv->clen;
+	hipStream_t s = ctx->stream;
+	StreamScope scope(ctx, s);
+	for (uint32_t off = 0; off < n; off += ctx->max_chunk) {
+		const uint32_t m = (n - off) < ctx->max_chunk ? (n - off) : ctx->max_chunk;
+		const size_t sbytes = scalar_stride ? (size_t)m * scalar_len : (size_t)scalar_len;
+		if (ensure(&ctx->stage[0], &ctx->stage_bytes[0], (size_t)m * iw) || ensure(&ctx->stage[1], &ctx->stage_bytes[1], sbytes) ||
+		    ensure(&ctx->stage[2], &ctx->stage_bytes[2], (size_t)m * ow) || ensure(&ctx->stage[3], &ctx->stage_bytes[3], (size_t)m)) {
+			return -1;
+		}
+		HIPCHK(hipMemcpyAsync(ctx->stage[0], points + (size_t)off * iw, (size_t)m * iw, hipMemcpyHostToDevice, s));
+		HIPCHK(hipMemcpyAsync(ctx->stage[1], scalars + (size_t)off * scalar_stride, sbytes, hipMemcpyHostToDevice, s));
+		EcamdUnprotArgs A;
+		memset(&A, 0, sizeof(A));
+		A.points = ctx->stage[0];
+		A.scalars = ctx->stage[1];
+		A.out = ctx->stage[2];
+		A.status = ctx->stage[3];
+		A.n = m;
+		A.clen = (uint32_t)cv->clen;
+		A.slen = scalar_len;
+		A.sstride = scalar_stride;
+		A.in_fmt = in_fmt;
+		A.out_fmt = out_fmt;
+		A.slot = cv->slot;
+		HIPCHK(ecamd_launch_unprot(cv->nw, A, s));
+		HIPCHK(hipMemcpyAsync(out + (size_t)off * ow, ctx->stage[2], (size_t)m * ow, hipMemcpyDeviceToHost, s));
+		HIPCHK(hipMemcpyAsync(status + off, ctx->stage[3], (size_t)m, hipMemcpyDeviceToHost, s));
+		HIPCHK(hipStreamSynchronize(s));
+	}
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // batched field ops on libecc's 64-bit limb layout
 // ------------------------------------------------------------------------------------------
 extern "C" int ec_fp_op_batch(ecamd_ctx *ctx, const ecamd_curve *cv, int op, uint32_t n, const uint64_t *a,

@@ -47,6 +47,24 @@ struct EcamdPtArgs {
 	int dbl, slot;
 };
 
+// group law / on-curve test in either wire format (k_ptf), and _prj_pt_unprotected_mult statement for statement (k_unprot)
+struct EcamdPtfArgs {
+	const uint8_t *p1, *p2;  // n x (in_fmt ? 3 : 2) * clen
+	uint8_t *out, *status;   // n x (out_fmt ? 3 : 2) * clen (untouched by op 2), n
+	uint32_t n, clen;
+	int op;                  // 0 prj_pt_add, 1 prj_pt_dbl, 2 prj_pt_is_on_curve (status 0 on the curve / 1 not)
+	int in_fmt, out_fmt, slot;
+};
+struct EcamdUnprotArgs {
+	const uint8_t *points;   // n x (in_fmt ? 3 : 2) * clen
+	const uint8_t *scalars;  // big-endian, slen octets each; sstride = 0: one scalar for every item
+	uint8_t *out, *status;
+	uint32_t n, clen, slen, sstride;
+	int in_fmt, out_fmt, slot;
+};
+hipError_t ecamd_launch_ptf(int nw, const EcamdPtfArgs &a, hipStream_t s);
+hipError_t ecamd_launch_unprot(int nw, const EcamdUnprotArgs &a, hipStream_t s);
+
 // ---- ECDSA verify (sig/ecdsa_common.c:619-840 of the reference), three stages around two scalar mults ----
 struct EcamdEcdsaPrepArgs {
 	const uint8_t *sigs;     // n x 2*qlen, r || s big-endian

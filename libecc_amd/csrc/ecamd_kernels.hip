@@ -1874,6 +1874,161 @@ hipError_t ecamd_launch_fp(int nw, const EcamdFpArgs &a, hipStream_t s)
 	return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 4: the group law and the public-scalar multiplication in either wire format.
+//
+// k_ptf<NW>: prj_pt_add (curves/prj_pt.c:1204) / prj_pt_dbl (:1132) / prj_pt_is_on_curve (:144) on affine X || Y or projective
+// X || Y || Z inputs (Z = 0: the point at infinity; (0 : 0 : 0) satisfies the curve equation as in the reference), the complete
+// formulas of ecamd_point.h (RCB Alg. 1 / 3, the reference's), an "exceptional pair" of the addition (Y3 = Z3 = 0, :1058-1060)
+// reported as an error.  The reference's prj_pt_add / prj_pt_dbl do not test their inputs; here a point that is not on the curve
+// is an error (status 1).  Output: the unique representative (X / Z, Y / Z [, 1]) or status 2 (infinity, zero bytes).
+//
+// k_unprot<NW>: _prj_pt_unprotected_mult (curves/prj_pt.c:1835-1880) STATEMENT FOR STATEMENT -- on-curve test of the input, zero
+// scalar -> infinity, out = in, then per bit below the top one: out = 2 out, and out = out + in when the bit is set, with the
+// addition's exceptional pair as the reference's -1 (on a curve of even order (2m - 1) in can be the point of order two), the
+// on-curve test of the result -- because the batch form must return what the scalar function returns for EVERY public scalar and
+// point, which the window kernels (same group element, no such failure) do not promise.  Scalars: per item, or one for all
+// (sstride = 0: check_prj_pt_order).  Lanes run both branches of "if bit" and select: control flow stays uniform.
+// ------------------------------------------------------------------------------------------
+template <int NW> static __device__ __forceinline__ bool ptf_load(Pt<NW> &P, const u8 *src, int clen, int fmt, int slot)
+{
+	const CurveK<NW> &K = ConstTab<NW>::get(slot);
+	const Fe<NW> X = fe_load_be<NW>(src, clen), Y = fe_load_be<NW>(src + clen, clen);
+	bool ok = fe_lt_p<NW>(X, slot) & fe_lt_p<NW>(Y, slot);
+	P.X = fe_to_mont<NW>(X, slot);
+	P.Y = fe_to_mont<NW>(Y, slot);
+	if (fmt == 0) {
+		P.Z = fe_const<NW>(K.one);
+	} else {
+		const Fe<NW> Z = fe_load_be<NW>(src + 2 * clen, clen);
+		ok = ok & fe_lt_p<NW>(Z, slot);
+		P.Z = fe_to_mont<NW>(Z, slot);
+	}
+	// Y^2 Z = X^3 + a X Z^2 + b Z^3 (prj_pt_is_on_curve)
+	const Fe<NW> z2 = fe_mul<NW>(P.Z, P.Z, slot);
+	const Fe<NW> x2 = fe_mul<NW>(P.X, P.X, slot);
+	Fe<NW> rhs = fe_add<NW>(x2, fe_mul<NW>(fe_const<NW>(K.a), z2, slot), slot);
+	rhs = fe_mul<NW>(rhs, P.X, slot);
+	rhs = fe_add<NW>(rhs, fe_mul<NW>(fe_mul<NW>(fe_const<NW>(K.b), z2, slot), P.Z, slot), slot);
+	const Fe<NW> lhs = fe_mul<NW>(fe_mul<NW>(P.Y, P.Y, slot), P.Z, slot);
+	return ok & fe_eq<NW>(lhs, rhs);
+}
+// the unique representative of R (or zero bytes) and its status
+template <int NW> static __device__ __forceinline__ void ptf_store(u8 *out, u8 *status, const Pt<NW> &R, bool err, int clen, int fmt, int slot)
+{
+	const int ow = (fmt ? 3 : 2) * clen;
+	if (err || fe_is_zero<NW>(R.Z)) {
+		for (int b = 0; b < ow; b++) {
+			out[b] = 0;
+		}
+		*status = err ? 1 : 2;
+		return;
+	}
+	const Fe<NW> zi = fe_inv<NW>(R.Z, slot);
+	fe_store_be<NW>(out, clen, fe_from_mont<NW>(fe_mul<NW>(R.X, zi, slot), slot));
+	fe_store_be<NW>(out + clen, clen, fe_from_mont<NW>(fe_mul<NW>(R.Y, zi, slot), slot));
+	if (fmt) {
+		for (int b = 0; b < clen; b++) {
+			out[2 * clen + b] = (u8)(b == clen - 1 ? 1 : 0);
+		}
+	}
+	*status = 0;
+}
+
+template <int NW> __global__ __launch_bounds__(64) void k_ptf(EcamdPtfArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int slot = A.slot, clen = (int)A.clen;
+	const int iw = (A.in_fmt ? 3 : 2) * clen, ow = (A.out_fmt ? 3 : 2) * clen;
+	Pt<NW> P, Q;
+	bool ok = ptf_load<NW>(P, A.p1 + (size_t)i * iw, clen, A.in_fmt, slot);
+	if (A.op == 2) {
+		A.status[i] = ok ? 0 : 1;
+		return;
+	}
+	if (A.op == 0) {
+		ok = ok & ptf_load<NW>(Q, A.p2 + (size_t)i * iw, clen, A.in_fmt, slot);
+	}
+	Pt<NW> R = P;
+	bool err = !ok;
+	if (ok) {
+		R = A.op == 1 ? pt_dbl<NW>(P, slot) : pt_add<NW>(P, Q, slot);
+		err = (A.op == 0) && fe_is_zero<NW>(R.Z) && fe_is_zero<NW>(R.Y);   // the addition's exceptional pair
+	}
+	ptf_store<NW>(A.out + (size_t)i * ow, A.status + i, R, err, clen, A.out_fmt, slot);
+}
+
+template <int NW> __global__ __launch_bounds__(64) void k_unprot(EcamdUnprotArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int slot = A.slot, clen = (int)A.clen, slen = (int)A.slen;
+	const int iw = (A.in_fmt ? 3 : 2) * clen, ow = (A.out_fmt ? 3 : 2) * clen;
+	Pt<NW> P;
+	bool err = !ptf_load<NW>(P, A.points + (size_t)i * iw, clen, A.in_fmt, slot);
+	const u8 *sc = A.scalars + (size_t)i * A.sstride;
+	// bit length of the scalar (big-endian octets)
+	int bits = 0;
+	for (int b = 0; b < slen; b++) {
+		const u32 v = sc[b];
+		if (bits == 0 && v != 0) {
+			bits = 8 * (slen - b) - (__clz(v) - 24);
+		}
+	}
+	Pt<NW> R = P;
+	if (!err && bits == 0) {
+		// "Multiplication by zero is the point at infinity"
+		R.Z = fe_zero<NW>();
+	}
+	for (int t = bits - 2; t >= 0 && !err; t--) {
+		const u32 bit = (sc[slen - 1 - (t >> 3)] >> (t & 7)) & 1u;
+		R = pt_dbl<NW>(R, slot);
+		const Pt<NW> S = pt_add<NW>(R, P, slot);
+		if (bit) {
+			err = fe_is_zero<NW>(S.Z) && fe_is_zero<NW>(S.Y);
+			R = S;
+		}
+	}
+	// (the reference's on-curve test of the result cannot fail for an input on the curve: the formulas are polynomial identities
+	// there, and (0 : 0 : 0) -- only reachable through the exceptional pair, an error above -- satisfies the equation anyway)
+	ptf_store<NW>(A.out + (size_t)i * ow, A.status + i, R, err, clen, A.out_fmt, slot);
+}
+
+hipError_t ecamd_launch_ptf(int nw, const EcamdPtfArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	const dim3 grid((a.n + 63) / 64), block(64);
+	switch (nw) {
+#define X(N) case N: hipLaunchKernelGGL(k_ptf<N>, grid, block, 0, s, a); break;
+		ECAMD_FOR_NW(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_unprot(int nw, const EcamdUnprotArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	const dim3 grid((a.n + 63) / 64), block(64);
+	switch (nw) {
+#define X(N) case N: hipLaunchKernelGGL(k_unprot<N>, grid, block, 0, s, a); break;
+		ECAMD_FOR_NW(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
 hipError_t ecamd_launch_pt(int nw, const EcamdPtArgs &a, hipStream_t s)
 {
 	if (a.n == 0) {

@@ -1441,6 +1441,101 @@ int orc_prj_batch(const orc_curve *c, uint32_t n, const uint8_t *scalars, uint32
 }
 
 /* ------------------------------------------------------------------------------------
+ * The group law and the public-scalar multiplication in either wire format (round 4; the batch forms ec_prj_pt_op_batch_fmt and
+ * ec_prj_pt_unprotected_mult_batch of include/libecc_amd.h).  in_fmt / out_fmt: 0 affine X || Y, 1 projective X || Y || Z.
+ *   import: fp_init_from_buf on every coordinate (each < p) and the projective curve equation (prj_pt_import_from_[aff_]buf,
+ *     curves/prj_pt.c:462-552); Z = 0 is accepted when it satisfies the equation, (0 : 0 : 0) included.
+ *   op 0 prj_pt_add (:1204; -1 on the exceptional pair :1058-1060), op 1 prj_pt_dbl (:1132), op 2 prj_pt_is_on_curve (:144) of an
+ *     already range-checked triple (status 0 on the curve / 1 not, no output).
+ *   output: prj_pt_iszero -> status 2 (zero bytes), else prj_pt_unique + export.
+ * ---------------------------------------------------------------------------------- */
+static int pt_import_fmt(pt *P, const u8 *src, int fmt, const orc_curve *c)
+{
+	const orc_fp_ctx *f = &c->fp;
+	const int clen = c->clen;
+	if (fp_from_be(P->X, src, clen, f) || fp_from_be(P->Y, src + clen, clen, f)) return -1;
+	if (fmt) {
+		if (fp_from_be(P->Z, src + 2 * clen, clen, f)) return -1;
+	} else {
+		nn_zero(P->Z, f->n);
+		P->Z[0] = 1;
+	}
+	return pt_is_on_curve(P, c) ? 0 : -1;
+}
+static void pt_export_fmt(u8 *dst, uint8_t *status, pt *Q, int fmt, const orc_curve *c)
+{
+	const orc_fp_ctx *f = &c->fp;
+	const int clen = c->clen;
+	memset(dst, 0, (size_t)(fmt ? 3 : 2) * clen);
+	if (nn_iszero(Q->Z, f->n)) { *status = 2; return; }
+	if (pt_unique(Q, c)) { *status = 1; return; }
+	nn_to_be(dst, clen, Q->X, f->n);
+	nn_to_be(dst + clen, clen, Q->Y, f->n);
+	if (fmt) nn_to_be(dst + 2 * clen, clen, Q->Z, f->n);
+	*status = 0;
+}
+int orc_pt_op_batch_fmt(const orc_curve *c, int op, uint32_t n, const uint8_t *p1, const uint8_t *p2, int in_fmt,
+			uint8_t *out, int out_fmt, uint8_t *status)
+{
+	const int iw = (in_fmt ? 3 : 2) * c->clen, ow = (out_fmt ? 3 : 2) * c->clen;
+	uint32_t i;
+	for (i = 0; i < n; i++) {
+		pt A, B, C;
+		int ret;
+		status[i] = 1;
+		if (op == 2) {
+			status[i] = pt_import_fmt(&A, p1 + (size_t)i * iw, in_fmt, c) ? 1 : 0;
+			continue;
+		}
+		memset(out + (size_t)i * ow, 0, (size_t)ow);
+		if (pt_import_fmt(&A, p1 + (size_t)i * iw, in_fmt, c)) continue;
+		if (op == 1) {
+			ret = pt_dbl(&C, &A, c);
+		} else {
+			if (pt_import_fmt(&B, p2 + (size_t)i * iw, in_fmt, c)) continue;
+			ret = pt_add(&C, &A, &B, c);
+		}
+		if (ret) continue;
+		pt_export_fmt(out + (size_t)i * ow, status + i, &C, out_fmt, c);
+	}
+	return 0;
+}
+
+/* _prj_pt_unprotected_mult (curves/prj_pt.c:1835-1880): on-curve test of the input; a zero scalar gives the point at infinity;
+ * out = in, then for every bit below the top one: out = 2 out, and out = out + in when the bit is set -- the addition's -1 on an
+ * exceptional pair is the call's -1 --; on-curve test of the result.  sstride = 0: one scalar for every item
+ * (check_prj_pt_order, :1909: "is the order a multiple of in_isorder" = the result is the point at infinity, status 2). */
+int orc_unprotected_mult_batch(const orc_curve *c, uint32_t n, const uint8_t *scalars, uint32_t slen, uint32_t sstride,
+			       const uint8_t *points, int in_fmt, uint8_t *out, int out_fmt, uint8_t *status)
+{
+	const int iw = (in_fmt ? 3 : 2) * c->clen, ow = (out_fmt ? 3 : 2) * c->clen;
+	uint32_t i;
+	for (i = 0; i < n; i++) {
+		const u8 *sc = scalars + (size_t)i * sstride;
+		pt P, R;
+		int bits = 0, t, b, bad = 0;
+		status[i] = 1;
+		memset(out + (size_t)i * ow, 0, (size_t)ow);
+		if (pt_import_fmt(&P, points + (size_t)i * iw, in_fmt, c)) continue;
+		for (b = 0; b < (int)slen && !bits; b++) {
+			int k;
+			for (k = 7; k >= 0; k--) {
+				if ((sc[b] >> k) & 1) { bits = 8 * ((int)slen - 1 - b) + k + 1; break; }
+			}
+		}
+		if (!bits) { status[i] = 2; continue; }
+		R = P;
+		for (t = bits - 2; t >= 0 && !bad; t--) {
+			pt_dbl(&R, &R, c);
+			if ((sc[slen - 1 - (uint32_t)(t >> 3)] >> (t & 7)) & 1) bad = pt_add(&R, &R, &P, c);
+		}
+		if (bad || !pt_is_on_curve(&R, c)) continue;
+		pt_export_fmt(out + (size_t)i * ow, status + i, &R, out_fmt, c);
+	}
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------
  * Ed448 verification on the Weierstrass model WEI448 (sig/eddsa.c), hash supplied by the caller.
  *   eddsa_decode_point, EDDSA448 branch (:424-556): y little-endian (57 bytes, bit 455 = sign of x), y >= p
  *     rejected, x from y on Ed448 itself (a = 1, d = -39081: x^2 = (1 - y^2) / (1 - d y^2), root with the sign's

@@ -60,5 +60,9 @@ int orc_prj_batch(const orc_curve *c, uint32_t n, const uint8_t *scalars, uint32
 		  uint8_t *out, uint8_t *status);
 int orc_eddsa448_verify_batch(const orc_curve *c, uint32_t n, const uint8_t *pubs, const uint8_t *sigs,
 			      const uint8_t *hram, uint32_t hlen, uint8_t *result);
+int orc_pt_op_batch_fmt(const orc_curve *c, int op, uint32_t n, const uint8_t *p1, const uint8_t *p2, int in_fmt,
+			uint8_t *out, int out_fmt, uint8_t *status);
+int orc_unprotected_mult_batch(const orc_curve *c, uint32_t n, const uint8_t *scalars, uint32_t slen, uint32_t sstride,
+			       const uint8_t *points, int in_fmt, uint8_t *out, int out_fmt, uint8_t *status);
 int orc_y_from_x_batch(const orc_curve *c, uint32_t n, const uint8_t *xs, uint8_t *y1, uint8_t *y2, uint8_t *status);
 #endif

@@ -254,6 +254,99 @@ int refdrv_pt_add_batch(const char *curve, uint32_t n, const uint8_t *p1, const 
 	return 0;
 }
 
+/* ---- the group law, the on-curve test and _prj_pt_unprotected_mult of the unmodified reference in either wire format
+ *      (in_fmt / out_fmt: 0 affine X || Y, 1 projective X || Y || Z); status 0 ok / 1 the call chain returned -1 / 2 infinity ---- */
+static int ref_import_fmt(prj_pt *P, const uint8_t *src, int fmt, uint32_t clen, ec_shortw_crv_src_t crv)
+{
+	return fmt ? prj_pt_import_from_buf(P, src, (u16)(3 * clen), crv) : prj_pt_import_from_aff_buf(P, src, (u16)(2 * clen), crv);
+}
+static void ref_export_fmt(uint8_t *dst, uint8_t *status, prj_pt *Q, int fmt, uint32_t clen)
+{
+	int iszero = 0, ret;
+	*status = 1;
+	if (prj_pt_iszero(Q, &iszero)) {
+		return;
+	}
+	if (iszero) {
+		*status = 2;
+		return;
+	}
+	if (prj_pt_unique(Q, Q)) {
+		return;
+	}
+	ret = fmt ? prj_pt_export_to_buf(Q, dst, 3 * clen) : prj_pt_export_to_aff_buf(Q, dst, 2 * clen);
+	*status = ret ? 1 : 0;
+}
+int refdrv_pt_op_batch_fmt(const char *curve, int op, uint32_t n, const uint8_t *p1, const uint8_t *p2, int in_fmt, uint8_t *out,
+			   int out_fmt, uint8_t *status)
+{
+	ec_params params;
+	uint32_t i, clen, iw, ow;
+	if (load_params(curve, &params)) {
+		return -1;
+	}
+	clen = (uint32_t)BYTECEIL(params.ec_fp.p_bitlen);
+	iw = (in_fmt ? 3u : 2u) * clen;
+	ow = (out_fmt ? 3u : 2u) * clen;
+	for (i = 0; i < n; i++) {
+		prj_pt A, B, C;
+		int ret, on = 0;
+		A.magic = B.magic = C.magic = WORD(0);
+		status[i] = 1;
+		if (op == 2) {
+			/* prj_pt_is_on_curve of a triple whose coordinates are in range (the import tests the equation itself) */
+			status[i] = ref_import_fmt(&A, p1 + (size_t)i * iw, in_fmt, clen, &params.ec_curve) ? 1 : 0;
+			if (!status[i] && (prj_pt_is_on_curve(&A, &on) || !on)) {
+				status[i] = 1;
+			}
+			continue;
+		}
+		memset(out + (size_t)i * ow, 0, ow);
+		if (ref_import_fmt(&A, p1 + (size_t)i * iw, in_fmt, clen, &params.ec_curve)) {
+			continue;
+		}
+		if (op == 1) {
+			ret = prj_pt_dbl(&C, &A);
+		} else {
+			if (ref_import_fmt(&B, p2 + (size_t)i * iw, in_fmt, clen, &params.ec_curve)) {
+				continue;
+			}
+			ret = prj_pt_add(&C, &A, &B);
+		}
+		if (ret) {
+			continue;
+		}
+		ref_export_fmt(out + (size_t)i * ow, status + i, &C, out_fmt, clen);
+	}
+	return 0;
+}
+int refdrv_unprotected_mult_batch(const char *curve, uint32_t n, const uint8_t *scalars, uint32_t slen, uint32_t sstride,
+				  const uint8_t *points, int in_fmt, uint8_t *out, int out_fmt, uint8_t *status)
+{
+	ec_params params;
+	uint32_t i, clen, iw, ow;
+	if (load_params(curve, &params)) {
+		return -1;
+	}
+	clen = (uint32_t)BYTECEIL(params.ec_fp.p_bitlen);
+	iw = (in_fmt ? 3u : 2u) * clen;
+	ow = (out_fmt ? 3u : 2u) * clen;
+	for (i = 0; i < n; i++) {
+		prj_pt P, Q;
+		nn m;
+		P.magic = Q.magic = WORD(0);
+		m.magic = WORD(0);
+		status[i] = 1;
+		memset(out + (size_t)i * ow, 0, ow);
+		if (ref_import_fmt(&P, points + (size_t)i * iw, in_fmt, clen, &params.ec_curve) ||
+		    nn_init_from_buf(&m, scalars + (size_t)i * sstride, (u16)slen) || _prj_pt_unprotected_mult(&Q, &m, &P)) {
+			continue;
+		}
+		ref_export_fmt(out + (size_t)i * ow, status + i, &Q, out_fmt, clen);
+	}
+	return 0;
+}
+
 /* ---- field level: nn_mul_redc1 / plain fp ops on little-endian u64 limbs ---- */
 /* op: 0 = fp_mul_monty (nn_mul_redc1), 1 = fp_add, 2 = fp_sub, 3 = fp_mul (plain), 4 = fp_inv (b ignored) */
 int refdrv_fp_op_batch(const char *curve, int op, uint32_t n, uint32_t nlimbs, const uint64_t *a,

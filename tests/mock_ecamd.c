@@ -157,6 +157,22 @@ int ecamd_multi_prj_pt_unique_batch(ecamd_multi *m, const ecamd_mcurve *c, uint3
 	return ecamd_multi_prj_pt_mul_batch_fmt(m, c, n, NULL, 0, points, in_fmt, out, out_fmt, status);
 }
 
+int ecamd_multi_prj_pt_op_batch_fmt(ecamd_multi *m, const ecamd_mcurve *c, int op, uint32_t n, const uint8_t *p1, const uint8_t *p2, int in_fmt,
+				    uint8_t *out, int out_fmt, uint8_t *status)
+{
+	(void)m;
+	note(n);
+	return orc_pt_op_batch_fmt(&c->c, op, n, p1, p2, in_fmt, out, out_fmt, status);
+}
+
+int ecamd_multi_prj_pt_unprotected_mult_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *scalars, uint32_t scalar_len,
+					      uint32_t scalar_stride, const uint8_t *points, int in_fmt, uint8_t *out, int out_fmt, uint8_t *status)
+{
+	(void)m;
+	note(n);
+	return orc_unprotected_mult_batch(&c->c, n, scalars, scalar_len, scalar_stride, points, in_fmt, out, out_fmt, status);
+}
+
 int ecamd_multi_prj_pt_add_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *p1_aff, const uint8_t *p2_aff, uint8_t *out_aff,
 				 uint8_t *status)
 {

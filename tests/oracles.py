@@ -87,6 +87,22 @@ class Oracle:
         assert self.L.orc_pt_add_batch(self.ctx, n, p1, p2, out, st, 1 if p2 is None else 0) == 0
         return out.raw, st.raw
 
+    def pt_op_fmt(self, op, p1, p2, in_fmt, out_fmt):
+        """op 0 add / 1 dbl / 2 on-curve test; formats 0 affine X || Y, 1 projective X || Y || Z; returns (out, status)"""
+        iw, ow = (3 if in_fmt else 2) * self.clen, (3 if out_fmt else 2) * self.clen
+        n = len(p1) // iw
+        out, st = C.create_string_buffer(max(1, ow * n)), C.create_string_buffer(max(1, n))
+        assert self.L.orc_pt_op_batch_fmt(self.ctx, op, n, p1, p2, in_fmt, out, out_fmt, st) == 0
+        return (b"" if op == 2 else out.raw[:ow * n]), st.raw[:n]
+
+    def unprotected_mult(self, scalars, slen, points, in_fmt, out_fmt, broadcast=False):
+        """_prj_pt_unprotected_mult per item; broadcast: one scalar (slen bytes) for every point"""
+        iw, ow = (3 if in_fmt else 2) * self.clen, (3 if out_fmt else 2) * self.clen
+        n = len(points) // iw
+        out, st = C.create_string_buffer(max(1, ow * n)), C.create_string_buffer(max(1, n))
+        assert self.L.orc_unprotected_mult_batch(self.ctx, n, scalars, slen, 0 if broadcast else slen, points, in_fmt, out, out_fmt, st) == 0
+        return out.raw[:ow * n], st.raw[:n]
+
     def fp_op(self, op, a, b):
         """a, b: lists of ints < p; returns list of ints."""
         n = len(a)
@@ -242,6 +258,20 @@ class RefLib:
         st = C.create_string_buffer(n)
         assert self.L.refdrv_pt_add_batch(self.name, n, p1, p2, out, st, 1 if p2 is None else 0) == 0
         return out.raw, st.raw
+
+    def pt_op_fmt(self, op, p1, p2, in_fmt, out_fmt):
+        iw, ow = (3 if in_fmt else 2) * self.clen, (3 if out_fmt else 2) * self.clen
+        n = len(p1) // iw
+        out, st = C.create_string_buffer(max(1, ow * n)), C.create_string_buffer(max(1, n))
+        assert self.L.refdrv_pt_op_batch_fmt(self.name, op, n, p1, p2, in_fmt, out, out_fmt, st) == 0
+        return (b"" if op == 2 else out.raw[:ow * n]), st.raw[:n]
+
+    def unprotected_mult(self, scalars, slen, points, in_fmt, out_fmt, broadcast=False):
+        iw, ow = (3 if in_fmt else 2) * self.clen, (3 if out_fmt else 2) * self.clen
+        n = len(points) // iw
+        out, st = C.create_string_buffer(max(1, ow * n)), C.create_string_buffer(max(1, n))
+        assert self.L.refdrv_unprotected_mult_batch(self.name, n, scalars, slen, 0 if broadcast else slen, points, in_fmt, out, out_fmt, st) == 0
+        return out.raw[:ow * n], st.raw[:n]
 
     def fp_op(self, op, a, b):
         n = len(a)

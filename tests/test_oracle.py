@@ -844,3 +844,112 @@ def test_y_from_x_restatement_vs_reference(curve):
     p = CURVES[curve]["p"]
     xs = b"".join((int.from_bytes(rb(rng, o.clen + 8), "big") % p).to_bytes(o.clen, "big") for _ in range(200))
     assert o.y_from_x(xs) == O.ref_y_from_x(curve, xs)
+
+
+def group_law_cases(curve, rng, n=24):
+    """Projective triples X || Y || Z for the group-law / public-scalar tests: points [t]G rescaled by random Z, the point at
+    infinity as (0 : 1 : 0) and (0 : y : 0), the degenerate (0 : 0 : 0), off-curve and out-of-range triples, and -- on the
+    cofactor curve WEI25519 -- points of order 2, 4, 8 and mixed order (the addition's exceptional pairs live there).
+    Returns (p1, p2, scalars, slen): p2[i] is chosen to hit P + P, P - P, P + infinity and exceptional pairs among random pairs."""
+    from oracles import clen, qlen, py_add
+    c = CURVES[curve]
+    p, a, cl, ql = c["p"], c["a"], clen(curve), qlen(curve)
+    o = Oracle(curve)
+    sc = b"".join(int(rng.integers(1, 2**62)).to_bytes(ql, "big") for _ in range(n))
+    aff, st = o.scalar_mult(sc)
+    assert set(st) == {0}
+    pts = [(int.from_bytes(aff[2 * cl * i:2 * cl * i + cl], "big"), int.from_bytes(aff[2 * cl * i + cl:2 * cl * (i + 1)], "big")) for i in range(n)]
+    tors = []
+    if curve == "WEI25519":
+        A3 = 486662 * pow(3, p - 2, p) % p
+        T2 = (A3, 0)                                             # order 2
+        # a point of order 8 on the Weierstrass model: the image of the Edwards torsion point, via a point of full order 8q
+        import oracles as O
+        t8e = O.ed_decode(O.ED_TORSION8)
+        zi = pow(t8e[2], p - 2, p)
+        xe, ye = t8e[0] * zi % p, t8e[1] * zi % p
+        alpha = pow(-(486662 + 2) % p, (p + 3) // 8, p)
+        if alpha * alpha % p != -(486662 + 2) % p:
+            alpha = alpha * O.ED_I % p
+        u = (1 + ye) * pow(1 - ye, p - 2, p) % p
+        T8 = ((u + A3) % p, alpha * u * pow(xe, p - 2, p) % p)
+        T4 = py_add(T8, T8, a, p)
+        assert py_add(T4, T4, a, p) == T2 and py_add(T2, T2, a, p) is None
+        tors = [T2, T4, T8, py_add(pts[0], T2, a, p), py_add(pts[1], T8, a, p), py_add(pts[2], T4, a, p)]
+    def prj(P, z=None):
+        if P is None:
+            return (0).to_bytes(cl, "big") + (1).to_bytes(cl, "big") + bytes(cl)
+        z = z if z is not None else (int.from_bytes(rng.bytes(cl + 8), "big") % (p - 1) + 1)
+        return (P[0] * z % p).to_bytes(cl, "big") + (P[1] * z % p).to_bytes(cl, "big") + z.to_bytes(cl, "big")
+    allp = pts + tors
+    p1, p2 = [], []
+    for i, P in enumerate(allp):
+        Q = allp[(i * 7 + 3) % len(allp)]
+        kind = i % 6
+        if kind == 0:
+            Q = P                                                # P + P through the addition
+        elif kind == 1:
+            Q = (P[0], (p - P[1]) % p)                           # P + (-P)
+        elif kind == 2:
+            Q = None                                             # P + infinity
+        elif kind == 3 and tors:
+            Q = py_add(P, tors[0], a, p)                         # Q - P = T2: the exceptional pair
+        p1.append(prj(P))
+        p2.append(prj(Q))
+    # special triples
+    inf2 = bytes(cl) + (7).to_bytes(cl, "big") + bytes(cl)       # (0 : 7 : 0)
+    zero3 = bytes(3 * cl)                                        # (0 : 0 : 0)
+    off = prj((pts[0][0], (pts[0][1] + 1) % p))                  # not on the curve
+    big = p.to_bytes(cl, "big") + prj(pts[1])[cl:]               # X = p: out of range
+    xz0 = (5).to_bytes(cl, "big") + (1).to_bytes(cl, "big") + bytes(cl)   # (5 : 1 : 0): Z = 0 but off the curve
+    for spec in (prj(None), inf2, zero3, off, big, xz0):
+        p1 += [spec, prj(pts[3])]
+        p2 += [prj(pts[4]), spec]
+    q = c["q"]
+    ks = [0, 1, 2, 3, 4, 8, q - 1, q, q + 1, 2 * q, 8 * q, c["order"], (1 << (8 * ql)) - 1, 6, 5 * q]
+    slen = ql + 1
+    scal = b"".join((ks[i % len(ks)] if i % 3 else int.from_bytes(rng.bytes(ql), "big")).to_bytes(slen, "big") for i in range(len(p1)))
+    return b"".join(p1), b"".join(p2), scal, slen
+
+
+@pytest.mark.parametrize("curve", ["SECP256R1", "WEI25519", "SECP384R1", "BRAINPOOLP256R1", "SECP521R1"])
+def test_group_law_and_unprotected_mult_vs_reference(curve):
+    """the restatements behind ec_prj_pt_op_batch_fmt / ec_prj_pt_unprotected_mult_batch (round 4) against the unmodified
+    reference: prj_pt_add / prj_pt_dbl / prj_pt_is_on_curve and _prj_pt_unprotected_mult in both wire formats, with the
+    exceptional pairs of the cofactor curve, infinity in its several spellings, (0 : 0 : 0), off-curve and out-of-range input"""
+    from oracles import clen
+    if not have_ref():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(51)
+    o, r = Oracle(curve), RefLib(curve)
+    p1, p2, scal, slen = group_law_cases(curve, rng)
+    cl = clen(curve)
+    n = len(p1) // (3 * cl)
+    for op in (0, 1, 2):
+        for out_fmt in (0, 1):
+            assert o.pt_op_fmt(op, p1, p2, 1, out_fmt) == r.pt_op_fmt(op, p1, p2, 1, out_fmt), (curve, op, out_fmt)
+    st = o.pt_op_fmt(0, p1, p2, 1, 0)[1]
+    assert 0 in st and 1 in st and 2 in st
+    if curve == "WEI25519":
+        # the exceptional pairs are there: a valid pair of points whose sum the reference refuses
+        on = o.pt_op_fmt(2, p1, None, 1, 0)[1]
+        on2 = o.pt_op_fmt(2, p2, None, 1, 0)[1]
+        assert any(st[i] == 1 and on[i] == 0 and on2[i] == 0 for i in range(n))
+    # affine inputs: the affine forms of the finite on-curve items
+    aff1, s1 = o.pt_op_fmt(1, p1, None, 1, 0)
+    keep = [i for i in range(n) if s1[i] == 0]
+    a1 = b"".join(aff1[2 * cl * i:2 * cl * (i + 1)] for i in keep)
+    a2 = b"".join(aff1[2 * cl * i:2 * cl * (i + 1)] for i in reversed(keep))
+    for op in (0, 1, 2):
+        assert o.pt_op_fmt(op, a1, a2, 0, 1) == r.pt_op_fmt(op, a1, a2, 0, 1)
+    # _prj_pt_unprotected_mult: per-item scalars, then one scalar for all (check_prj_pt_order's use)
+    got, exp = o.unprotected_mult(scal, slen, p1, 1, 1), r.unprotected_mult(scal, slen, p1, 1, 1)
+    assert got == exp
+    assert 0 in got[1] and 2 in got[1] and 1 in got[1]
+    qb = CURVES[curve]["q"].to_bytes(slen, "big")
+    assert o.unprotected_mult(qb, slen, p1, 1, 0, broadcast=True) == r.unprotected_mult(qb * n, slen, p1, 1, 0)
+    if curve == "WEI25519":
+        # the window kernels' group element is NOT always what the literal double-and-add returns: some item must fail here
+        # while the point itself is fine (the reason k_unprot exists)
+        on = o.pt_op_fmt(2, p1, None, 1, 0)[1]
+        assert any(got[1][i] == 1 and on[i] == 0 for i in range(n))
