@@ -2461,6 +2461,264 @@ __global__ __launch_bounds__(64) void k_ed_tail_c25519(EcamdEdTailArgs A, int gs
 	A.result[i] = (!bad && neutral) ? 0 : 1;
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 4, second step: the verification equation with HALF-LENGTH scalars (k_ed_lat in ecamd_kernels.hip finds them):
+//     8 ([s']B - [u]R - [v]A) = neutral,  s' = u S mod q,  v = u h mod q,  |u| < 2^126, 0 <= v < 2^127.
+// k_ed_smul2_c25519<0>      the window tables [1..8]A and [1..8]R of an item (two ed_table passes)
+// k_ed_smul2_c25519<1, NWIN> L = -[v]A - [u]R by ONE signed-window loop over both tables: per window four doublings and two
+//                           additions; NWIN = 33 windows cover 128-bit scalars (K = k + 0x8..8 over 33 nibbles: the top digit is 0 or 1,
+//                           no carry to treat apart), NWIN = 65 the full-length fall-back of an item k_ed_lat could not shorten
+//                           (u = 1, v = h).  A launch handles the items whose mode it is told (meta bit 1), the others return at once.
+// k_ed_tail2_c25519         [S]B for the first exceptional pair (E1 as in k_ed_tail_c25519), then W = [s']B + L from a second comb
+//                           pass, the second exceptional pair restated for this form -- among accepted signatures W1 + [h]A = T2 is
+//                           only possible for h = 0 mod q (2 [h]A would be torsion, and a key of small order was rejected), which is
+//                           v = 0, u = 1, W = W1: the test is W = T2 there -- and [8]W = neutral.
+// ------------------------------------------------------------------------------------------
+template <int NWIN> static __device__ __forceinline__ void ed_recode(u32 *kw, const u32 *k, int nk)
+{
+	// K = k + 0x88..8 over NWIN nibbles, left-aligned so that the top nibble sits in bits 31..28 of kw[KWORDS - 1]
+	constexpr int KWORDS = (NWIN + 7) / 8;
+	constexpr int TOPN = NWIN - 8 * (KWORDS - 1);          // nibbles in the top word
+	uint64_t c = 0;
+#pragma unroll
+	for (int w = 0; w < KWORDS; w++) {
+		const u32 add = (w < KWORDS - 1 || TOPN == 8) ? 0x88888888u : (0x88888888u >> (4 * (8 - TOPN)));
+		c += (uint64_t)(w < nk ? k[w] : 0u) + add;
+		kw[w] = (u32)c;
+		c >>= 32;
+	}
+	if (TOPN != 8) {
+		// shift left by 4 (8 - TOPN) bits over the whole array
+		constexpr int SH = 4 * (8 - TOPN);
+#pragma unroll
+		for (int w = KWORDS - 1; w > 0; w--) {
+			kw[w] = (kw[w] << SH) | (kw[w - 1] >> (32 - SH));
+		}
+		kw[0] <<= SH;
+	}
+}
+template <int KWORDS> static __device__ __forceinline__ int ed_next_digit(u32 *kw)
+{
+	const int dig = (int)(kw[KWORDS - 1] >> 28) - 8;
+#pragma unroll
+	for (int w = KWORDS - 1; w > 0; w--) {
+		kw[w] = (kw[w] << 4) | (kw[w - 1] >> 28);
+	}
+	kw[0] <<= 4;
+	return dig;
+}
+
+template <int phase, int NWIN> __global__ __launch_bounds__(64) void k_ed_smul2_c25519(EcamdEdSmul2Args A, int gslot)
+{
+	using namespace c25519;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n || A.flagsA[i] || A.flagsR[i] == 1 || A.flagsS[i]) {
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const FC onec = constant<FC>(K.one);
+	const FM onem = weaken<FM>(onec);
+	const FC d2 = digits9(A.g_2d);
+	u32 *tbA = A.tbl + (size_t)i * 2 * EDT_ITEM_WORDS, *tbR = tbA + EDT_ITEM_WORDS;
+	if (phase == 0) {
+#pragma unroll 1
+		for (int k = 0; k < 2; k++) {
+			Ext P1;
+			edr_load((k == 0 ? A.edA : A.edR) + (size_t)i * 20, P1.X, P1.Y);
+			P1.Z = onem;
+			P1.T = weaken<FM>(mul(P1.X, P1.Y, K));
+			ed_table(k == 0 ? tbA : tbR, P1, d2, K);
+		}
+		return;
+	}
+	const u32 meta = A.meta[i];
+	if (((meta >> 1) & 1u) != (NWIN > 33 ? 1u : 0u)) {
+		return;   // the other launch's item
+	}
+	constexpr int KWORDS = (NWIN + 7) / 8;
+	u32 kv[KWORDS], ku[KWORDS];
+	{
+		const u32 *uv = A.uv + (size_t)i * 12;
+		u32 v[8], u[4];
+#pragma unroll
+		for (int w = 0; w < 8; w++) {
+			v[w] = uv[w];
+		}
+#pragma unroll
+		for (int w = 0; w < 4; w++) {
+			u[w] = uv[8 + w];
+		}
+		ed_recode<NWIN>(kv, v, 8);
+		ed_recode<NWIN>(ku, u, 4);
+	}
+	const bool uneg = (meta & 1u) != 0;
+	Ext acc = ed_neutral(K);
+#pragma unroll 1
+	for (int t = 0; t < NWIN; t++) {
+#pragma unroll 1
+		for (int d = 0; d < 3; d++) {
+			acc = ed_dbl<false>(acc, K);
+		}
+		acc = ed_dbl<true>(acc, K);
+		{
+			// - [d]A: subtract the entry for a positive digit
+			const int dig = ed_next_digit<KWORDS>(kv);
+			const u32 mag = (u32)(dig < 0 ? -dig : dig);
+			const Pre Q = pre_load(tbA, mag ? mag - 1 : 0);
+			const Ext S = ed_add<true>(acc, Q, dig > 0, K);
+			const bool keep = (mag == 0);
+			acc.X = selg(keep, acc.X, S.X);
+			acc.Y = selg(keep, acc.Y, S.Y);
+			acc.Z = selg(keep, acc.Z, S.Z);
+			acc.T = selg(keep, acc.T, S.T);
+		}
+		{
+			// - [u]R: u > 0 subtracts the entry for a positive digit, u < 0 adds it
+			const int dig = ed_next_digit<KWORDS>(ku);
+			const u32 mag = (u32)(dig < 0 ? -dig : dig);
+			const Pre Q = pre_load(tbR, mag ? mag - 1 : 0);
+			const Ext S = ed_add<false>(acc, Q, uneg ? (dig < 0) : (dig > 0), K);
+			const bool keep = (mag == 0);
+			acc.X = selg(keep, acc.X, S.X);
+			acc.Y = selg(keep, acc.Y, S.Y);
+			acc.Z = selg(keep, acc.Z, S.Z);
+		}
+	}
+	u32 buf[EDR_REC_WORDS];
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		buf[w] = acc.X.l[w];
+		buf[9 + w] = acc.Y.l[w];
+		buf[18 + w] = acc.Z.l[w];
+	}
+	buf[27] = 0;
+	uint4 *dst = (uint4 *)(A.rec + (size_t)i * EDR_REC_WORDS);
+#pragma unroll
+	for (int q = 0; q < EDR_REC_WORDS / 4; q++) {
+		dst[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
+	}
+}
+
+// [k]B for the big-endian 32-byte scalar at sc: seventeen mixed additions from the Edwards comb table
+static __device__ __forceinline__ c25519::Ext ed_comb_B(const u8 *sc, const u32 *comb, const c25519::CK &K)
+{
+	using namespace c25519;
+	u32 kw[9];
+	load_be<8>(sc, 32, kw);
+	{
+		uint64_t c = 0;
+#pragma unroll
+		for (int w = 0; w < 8; w++) {
+			c += (uint64_t)kw[w] + 0x80008000u;
+			kw[w] = (u32)c;
+			c >>= 32;
+		}
+		kw[8] = (u32)c;   // top digit: 0 or 1
+	}
+	Ext SG = ed_neutral(K);
+#pragma unroll 1
+	for (int j = 0; j <= EDC_NWIN; j++) {
+		u32 word = 0;
+#pragma unroll
+		for (int w = 0; w < 9; w++) {
+			word = (w == (j >> 1)) ? kw[w] : word;
+		}
+		const int dig = (j < EDC_NWIN) ? (int)((word >> (16 * (j & 1))) & 0xffffu) - 0x8000 : (int)word;
+		const u32 mag = (u32)(dig < 0 ? -dig : dig);
+		const PreA Q = prea_load(comb + ((size_t)j * EDC_PER_WIN + (mag ? mag - 1 : 0)) * EDC_ENT_WORDS);
+		const Ext S = ed_madd<true>(SG, Q, dig < 0, K);
+		const bool keep = (mag == 0);
+		SG.X = selg(keep, SG.X, S.X);
+		SG.Y = selg(keep, SG.Y, S.Y);
+		SG.Z = selg(keep, SG.Z, S.Z);
+		SG.T = selg(keep, SG.T, S.T);
+	}
+	return SG;
+}
+
+__global__ __launch_bounds__(64) void k_ed_tail2_c25519(EcamdEdTailArgs A, int gslot)
+{
+	using namespace c25519;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const u32 fR = A.flagsR[i];
+	if (A.flagsA[i] || fR == 1 || A.flagsS[i]) {
+		A.result[i] = 1;
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const FC d2 = digits9(A.C.g_2d);
+	// E1: [S]B == (x_R, -y_R)
+	FM xr, yr;
+	edr_load(A.edR + (size_t)i * 20, xr, yr);
+	bool bad;
+	{
+		const Ext SG = ed_comb_B(A.S_be + (size_t)i * 32, A.comb, K);
+		bad = eq(SG.X, mul(xr, SG.Z, K), K) & eq_neg(SG.Y, mul(yr, SG.Z, K), K);
+	}
+	// W = [s']B + L,  L = -[v]A - [u]R from the window loop
+	Ext W = ed_comb_B(A.sp_be + (size_t)i * 32, A.comb, K);
+	{
+		FM hX, hY, hZ;
+		u32 buf[EDR_REC_WORDS];
+		const uint4 *src = (const uint4 *)(A.rec + (size_t)i * EDR_REC_WORDS);
+#pragma unroll
+		for (int q = 0; q < EDR_REC_WORDS / 4; q++) {
+			const uint4 v = src[q];
+			buf[4 * q] = v.x; buf[4 * q + 1] = v.y; buf[4 * q + 2] = v.z; buf[4 * q + 3] = v.w;
+		}
+#pragma unroll
+		for (int w = 0; w < 9; w++) {
+			hX.l[w] = buf[w];
+			hY.l[w] = buf[9 + w];
+			hZ.l[w] = buf[18 + w];
+		}
+		Ext H;
+		H.X = weaken<FM>(mul(hX, hZ, K));
+		H.Y = weaken<FM>(mul(hY, hZ, K));
+		H.Z = weaken<FM>(sqr(hZ, K));
+		H.T = weaken<FM>(mul(hX, hY, K));
+		W = ed_add<false>(W, ed_pre(H, d2, K), false, K);
+	}
+	// E2 (only possible for h = 0 mod q, i.e. v = 0, u = 1, W = W1): W1 == T2 = (0, -1)
+	if (A.meta[i] & 4u) {
+		bad = bad | (is_zero_mulout(W.X, K) & eq_neg(W.Y, W.Z, K));
+	}
+	for (u32 k = 0; k < A.cof_dbl; k++) {
+		W = ed_dbl<false>(W, K);
+	}
+	const bool neutral = is_zero_mulout(W.X, K) & eq(W.Y, W.Z, K);
+	A.result[i] = (!bad && neutral) ? 0 : 1;
+}
+
+hipError_t ecamd_launch_ed_smul2_c25519(const EcamdEdSmul2Args &a, int gslot, hipStream_t s, hipEvent_t *dom)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	const dim3 grid((a.n + 63) / 64), block(64);
+	hipLaunchKernelGGL((k_ed_smul2_c25519<0, 33>), grid, block, 0, s, a, gslot);
+	if (dom) {
+		(void)hipEventRecord(dom[0], s);
+	}
+	hipLaunchKernelGGL((k_ed_smul2_c25519<1, 33>), grid, block, 0, s, a, gslot);
+	if (dom) {
+		(void)hipEventRecord(dom[1], s);
+	}
+	hipLaunchKernelGGL((k_ed_smul2_c25519<1, 65>), grid, block, 0, s, a, gslot);   // the items k_ed_lat left at full length (normally none)
+	return hipGetLastError();
+}
+hipError_t ecamd_launch_ed_tail2_c25519(const EcamdEdTailArgs &a, int gslot, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_ed_tail2_c25519, dim3((a.n + 63) / 64), dim3(64), 0, s, a, gslot);
+	return hipGetLastError();
+}
+
 hipError_t ecamd_launch_edcomb_build_c25519(const uint8_t *pts, uint32_t n, uint32_t *table, const EcamdEdTailConsts &c, int gslot, hipStream_t s)
 {
 	if (n == 0) {

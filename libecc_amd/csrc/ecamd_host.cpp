@@ -2939,6 +2939,11 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 		maybe_build_edcomb(ctx, cv, n);
 		ed_tail = cv->d_edcomb != nullptr;
 	}
+	// round 4, second step: half-length scalars (k_ed_lat) and one window loop over the tables of A and R (k_ed_smul2_c25519)
+	const bool lattice = ed_tail && len == 32 && getenv("ECAMD_NO_ED_LATTICE") == nullptr;
+	if (lattice && ensure(&ctx->stage[18], &ctx->stage_bytes[18], (size_t)n * 2 * ECAMD_EDT_ITEM_WORDS * 4)) {
+		return -1;
+	}
 	if (late_map) {
 		if (ensure(&ctx->stage[19], &ctx->stage_bytes[19], (size_t)n * 20 * 4)) {
 			return -1;
@@ -2949,6 +2954,54 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 		HIPCHK(ecamd_launch_ed_decode_c25519(D, cv->gslot, s));  // the same decoding on the radix-2^29 field
 	} else {
 		HIPCHK(ecamd_launch_ed_decode(nw, D, s));
+	}
+	if (lattice) {
+		// stage 3 (n x 64, free on this path): v and |u|, 12 words per item; 9: s' = u S mod q; 13: meta
+		EcamdEdLatArgs L;
+		memset(&L, 0, sizeof(L));
+		L.sigs = d_sig;
+		L.hram = d_hram;
+		L.S_be = S[8];
+		L.sp_be = S[9];
+		L.uv = (uint32_t *)S[3];
+		L.meta = S[13];
+		L.flags = S[7];
+		L.n = n;
+		L.hlen = hram_len;
+		L.qslot = cv->qslot;
+		HIPCHK(ecamd_launch_ed_lat(L, s));
+		EcamdEdSmul2Args E;
+		memset(&E, 0, sizeof(E));
+		E.edA = (const uint32_t *)S[10];
+		E.edR = (const uint32_t *)ctx->stage[19];
+		E.flagsA = S[5];
+		E.flagsR = S[6];
+		E.flagsS = S[7];
+		E.uv = (const uint32_t *)S[3];
+		E.meta = S[13];
+		E.tbl = (uint32_t *)ctx->stage[18];
+		E.rec = (uint32_t *)S[11];
+		E.n = n;
+		memcpy(E.g_2d, cv->ed_2d, sizeof(E.g_2d));
+		HIPCHK(ecamd_launch_ed_smul2_c25519(E, cv->gslot, s, ctx->timing ? ctx->ev_dom : nullptr));
+		ctx->ev_dom_valid = ctx->ev_dom_valid || ctx->timing;
+		EcamdEdTailArgs T;
+		memset(&T, 0, sizeof(T));
+		T.rec = (const uint32_t *)S[11];
+		T.edR = (const uint32_t *)ctx->stage[19];
+		T.flagsA = S[5];
+		T.flagsR = S[6];
+		T.flagsS = S[7];
+		T.S_be = S[8];
+		T.sp_be = S[9];
+		T.meta = S[13];
+		T.comb = cv->d_edcomb;
+		T.result = d_res;
+		T.n = n;
+		T.cof_dbl = cof_dbl;
+		memcpy(T.C.g_2d, cv->ed_2d, sizeof(T.C.g_2d));
+		HIPCHK(ecamd_launch_ed_tail2_c25519(T, cv->gslot, s));
+		return 0;
 	}
 	EcamdEdScalArgs C;
 	memset(&C, 0, sizeof(C));

@@ -178,11 +178,24 @@ struct EcamdEdTailConsts {
 };
 #define ECAMD_EDC_ENT_WORDS 32
 #define ECAMD_EDC_ENTRIES (16u * 32768u + 1u)
+// the half-length form (k_ed_lat -> k_ed_smul2_c25519 -> k_ed_tail2_c25519)
+struct EcamdEdSmul2Args {
+	const uint32_t *edA, *edR;   // n x 20 words (k_ed_decode_ed_c25519)
+	const uint8_t *flagsA, *flagsR, *flagsS;
+	const uint32_t *uv;          // n x 12 words: v (8), |u| (4)
+	const uint8_t *meta;         // n: bit 0 u < 0, bit 1 full-length scalars
+	uint32_t *tbl;               // scratch: n x 2 x ECAMD_EDT_ITEM_WORDS
+	uint32_t *rec;               // n x ECAMD_EDR_REC_WORDS: L = -[v]A - [u]R (X, Y, Z)
+	uint32_t n;
+	uint32_t g_2d[9];
+};
 struct EcamdEdTailArgs {
-	const uint32_t *rec;     // n x ECAMD_EDR_REC_WORDS: [h]A (X, Y, Z) from k_ed_smul_c25519<1>
+	const uint32_t *rec;     // n x ECAMD_EDR_REC_WORDS: [h]A (X, Y, Z) from k_ed_smul_c25519<1>; tail2: L from k_ed_smul2_c25519<1>
 	const uint32_t *edR;     // n x 20 words: R on the Edwards curve (k_ed_decode_ed_c25519)
 	const uint8_t *flagsA, *flagsR, *flagsS;
 	const uint8_t *S_be;     // n x 32 big-endian
+	const uint8_t *sp_be;    // tail2: n x 32 big-endian s' = u S mod q
+	const uint8_t *meta;     // tail2: k_ed_lat's meta bytes
 	const uint32_t *comb;    // ECAMD_EDC_ENTRIES x ECAMD_EDC_ENT_WORDS: [m 2^(16 j)]B as (y - x, y + x, 2d x y)
 	uint8_t *result;         // n: 0 accept / 1 reject
 	uint32_t n, cof_dbl;
@@ -190,6 +203,8 @@ struct EcamdEdTailArgs {
 };
 hipError_t ecamd_launch_edcomb_build_c25519(const uint8_t *pts, uint32_t n, uint32_t *table, const EcamdEdTailConsts &c, int gslot, hipStream_t s);
 hipError_t ecamd_launch_ed_tail_c25519(const EcamdEdTailArgs &a, int gslot, hipStream_t s);
+hipError_t ecamd_launch_ed_smul2_c25519(const EcamdEdSmul2Args &a, int gslot, hipStream_t s, hipEvent_t *dom = nullptr);   // dom: events around the 33-window loop
+hipError_t ecamd_launch_ed_tail2_c25519(const EcamdEdTailArgs &a, int gslot, hipStream_t s);
 hipError_t ecamd_launch_ed_smul_c25519(const EcamdEdSmulArgs &a, int gslot, hipStream_t s, hipEvent_t *dom = nullptr);   // dom: two events around the window loop
 // ---- Ed25519 whole-batch verification as ONE multi-scalar multiplication on the Edwards curve (2^255 - 19 unit) ----
 // T = [q - sum z_i S_i]B + sum_i ([z_i h_i mod q]A_i + [z_i]R_i), accepted when [8]T is the neutral element
@@ -248,6 +263,18 @@ struct EcamdEdScalArgs {
 	int qslot;
 	uint32_t c4_mod4;        // Ed448: (4^-1 mod q) mod 4, see k_ed448_scal
 };
+// Round 4: k_ed_scal's work plus the half-length scalars (u, v) of the verification equation (k_ed_lat, ecamd_kernels.hip)
+struct EcamdEdLatArgs {
+	const uint8_t *sigs;     // n x 64: R || S
+	const uint8_t *hram;     // n x hlen little-endian
+	uint8_t *S_be, *sp_be;   // out: n x 32 big-endian S and s' = u S mod q
+	uint32_t *uv;            // out: n x 12 words: v (8, little-endian words), |u| (4)
+	uint8_t *meta;           // out: n: bit 0 u < 0, bit 1 full-length scalars (u = 1, v = h), bit 2 v = 0
+	uint8_t *flags;          // out: n, 1 when S >= q
+	uint32_t n, hlen;
+	int qslot;
+};
+hipError_t ecamd_launch_ed_lat(const EcamdEdLatArgs &a, hipStream_t s);
 struct EcamdEdFinArgs {
 	const uint8_t *SG, *stSG;   // [S]G
 	const uint8_t *hA, *sthA;   // [h]A

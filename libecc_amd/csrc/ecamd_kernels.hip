@@ -798,6 +798,100 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed_scal(EcamdEdScalArg
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 4: half-length scalars for the Ed25519 verification equation (k_ed_lat<8>).
+//
+// The equation 8 ([S]B - R - [h]A) = infinity holds exactly when 8 ([u S]B - [u]R - [u h]A) = infinity for any u that is not a
+// multiple of q (8 (...) lies in the subgroup of prime order q, where u is invertible), and [u h]A may be taken with u h reduced
+// mod q (8 A has order dividing q).  With (u, v) a short vector of the lattice {(x, y) : y = x h mod q} -- |u| < 2^126,
+// 0 <= v < 2^127, found by the Euclidean algorithm on (q, h) stopped at the first remainder below 2^127 (the extended-gcd
+// cofactor of that remainder is bounded by q over the previous one) -- the two variable-base multiplications have 128-bit scalars
+// and share their doublings: half the doublings of [h]A (T. Pornin, "Optimized lattice basis reduction in dimension 2, and fast
+// Schnorr and EdDSA signature verification", 2020; the reduction here is the plain truncated Euclid, per lane).
+// Per item the kernel does what k_ed_scal does (S < q, h = hram mod q) and then
+//     r0 = q, r1 = h, t0 = 0, t1 = 1;  while r1 >= 2^127: k = a lower bound of r0 / r1 from the leading 63 bits (at least 1, at most
+//     2^32 - 1), r0 -= k r1, |t0| += k |t1|, and the pairs swap when r0 < r1 (t0 and t1 always have opposite signs, so only the sign of
+//     t1 is kept);  v = r1, u = t1.
+// Nothing downstream trusts that loop: u != 0, |u| < 2^128, v < 2^128 and |u| h = +-v (mod q) are CHECKED with the Montgomery
+// arithmetic mod q of this unit, and an item that fails (it cannot, short of a bug) keeps u = 1, v = h and takes the full-length
+// window loop (meta bit 1).  Outputs: S and s' = u S mod q (big-endian, for the two comb passes of the tail), v and |u| as words,
+// meta: bit 0 u < 0, bit 1 long mode, bit 2 v = 0 (h = 0 mod q: [h]A is the neutral element, see k_ed_tail2_c25519).
+// ------------------------------------------------------------------------------------------
+#include "ecamd_lattice.h"
+
+template <int NW> __global__ __launch_bounds__(64) void k_ed_lat(EcamdEdLatArgs A)
+{
+	static_assert(NW == 8, "Ed25519 only");
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int qs = A.qslot;
+	const int hlen = (int)A.hlen;
+	const CurveK<NW> &Q = ConstTab<NW>::get(qs);
+	const Fe<NW> S = fe_load_le<NW>(A.sigs + (size_t)i * 64 + 32, 32);
+	const bool ok = fe_lt_p<NW>(S, qs);
+	const u8 *hp = A.hram + (size_t)i * hlen;
+	const int lo_len = hlen < 4 * NW ? hlen : 4 * NW;
+	const Fe<NW> lo = fe_load_le<NW>(hp, lo_len);
+	const Fe<NW> hi = fe_load_le<NW>(hp + lo_len, hlen - lo_len);
+	const Fe<NW> r2 = fe_const<NW>(Q.r2);
+	Fe<NW> onep = fe_zero<NW>();
+	onep.v[0] = 1u;
+	const Fe<NW> h = fe_add<NW>(fe_mul<NW>(hi, r2, qs), fe_mul<NW>(fe_mul<NW>(lo, r2, qs), onep, qs), qs);   // as k_ed_scal
+	const Fe<NW> Sok = ok ? S : fe_zero<NW>();
+	u32 qw[8], v[8], u[4];
+#pragma unroll
+	for (int w = 0; w < 8; w++) {
+		qw[w] = Q.p[w];
+	}
+	bool neg = false;
+	bool good = lat_reduce(qw, h.v, v, u, &neg);
+	Fe<NW> uf = fe_zero<NW>(), vf;
+#pragma unroll
+	for (int w = 0; w < 4; w++) {
+		uf.v[w] = u[w];
+	}
+#pragma unroll
+	for (int w = 0; w < 8; w++) {
+		vf.v[w] = v[w];
+	}
+	// the relation the tail relies on: |u| h = v (u > 0) or q - v (u < 0), mod q
+	const Fe<NW> uR = fe_mul<NW>(uf, r2, qs);
+	const Fe<NW> uh = fe_mul<NW>(uR, h, qs);
+	const Fe<NW> want = neg ? fe_sub<NW>(fe_zero<NW>(), vf, qs) : vf;
+	good = good & fe_eq<NW>(uh, want) & ((v[4] | v[5] | v[6] | v[7]) == 0u);
+	Fe<NW> sp = fe_mul<NW>(uR, Sok, qs);            // |u| S mod q
+	if (neg) {
+		sp = fe_sub<NW>(fe_zero<NW>(), sp, qs);
+	}
+	if (!good) {
+		// full-length scalars: u = 1, v = h
+		neg = false;
+		sp = Sok;
+#pragma unroll
+		for (int w = 0; w < 8; w++) {
+			v[w] = h.v[w];
+		}
+		u[0] = 1u;
+		u[1] = u[2] = u[3] = 0u;
+	}
+	fe_store_be<NW>(A.S_be + (size_t)i * 32, 32, Sok);
+	fe_store_be<NW>(A.sp_be + (size_t)i * 32, 32, sp);
+	u32 *dst = A.uv + (size_t)i * 12;
+#pragma unroll
+	for (int w = 0; w < 8; w++) {
+		dst[w] = v[w];
+	}
+#pragma unroll
+	for (int w = 0; w < 4; w++) {
+		dst[8 + w] = u[w];
+	}
+	const bool vzero = (v[0] | v[1] | v[2] | v[3] | v[4] | v[5] | v[6] | v[7]) == 0u;
+	A.meta[i] = (u8)((neg ? 1u : 0u) | (good ? 0u : 2u) | (vzero ? 4u : 0u));
+	A.flags[i] = ok ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------
 // Scalars of the Ed25519 batch equation (ecamd_g29_kernel.hip, k_edmsm_*): z_i = 128 bits of ChaCha20(seed; counter = item)
 // (the reference draws hsize / 4 = 16 random bytes per signature, sig/eddsa.c:2388), c_i = z_i h_i mod q, z_i S_i mod q.
 // ------------------------------------------------------------------------------------------
@@ -2065,6 +2159,15 @@ hipError_t ecamd_launch_ed_scal(int nw, const EcamdEdScalArgs &a, hipStream_t s)
 		return hipErrorInvalidValue;
 	}
 	hipLaunchKernelGGL(k_ed_scal<8>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_ed_lat(const EcamdEdLatArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_ed_lat<8>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
 	return hipGetLastError();
 }
 

@@ -1257,6 +1257,7 @@ def test_eddsa25519_exceptional_pairs(gpu_ctx):
     (reachable through the API: the caller supplies the hash), with accepted neighbours -- on the Edwards tail of round 4
     (k_ed_tail_c25519: batches of at least ECAMD_COMB_MIN_BATCH items), on the Weierstrass tail it replaces
     (ECAMD_NO_ED_TAIL) and on a batch too small for the comb table; the zero-challenge and edge families through the new tail too"""
+    import oracles as O
     from test_ed_tail_model import ed_exceptional_cases
     from test_oracle import ed25519_cases
     rng = np.random.default_rng(43)
@@ -1268,15 +1269,34 @@ def test_eddsa25519_exceptional_pairs(gpu_ctx):
     exp = Oracle("WEI25519").eddsa_verify(pubs, sigs, hram)
     for k, e in zip(kinds, exp):
         assert e == (1 if k in ("E1", "E2", "E1-wrongS") else 0), k
+    # hashes with a huge partial quotient in the Euclidean algorithm on (q, h): k_ed_lat cannot shorten them within its
+    # iteration budget and the item takes the full-length window loop (meta bit 1) -- valid signatures under such h (the
+    # caller supplies the hash) and their corrupted neighbours
+    q = O.ED_Q
+    for j, h in enumerate([2**127, 2**127 + 1, 2**128, 2**130 + 5, 2**200, 2**220 - 1, int("8" * 64, 16) % q, q // 2**20, q - 2**127, 2**127 - 1, 5, q - 1]):
+        a = int.from_bytes(rand_bytes(rng, 40), "little") % q or 1
+        r = int.from_bytes(rand_bytes(rng, 40), "little") % q
+        A, R = O.ed_mul(a, O.ED_B), (O.ed_mul(r, O.ED_B) if r else (0, 1, 1, 0))
+        if j % 3 == 1:
+            A = O.ed_add(A, O.ed_decode(O.ED_TORSION8))
+        S = (r + h * a) % q
+        for bad in (0, 1):
+            pubs += O.ed_encode(A)
+            sigs += O.ed_encode(R) + ((S + bad) % q).to_bytes(32, "little")
+            hram += (h + q * (j % 2)).to_bytes(64, "little")
+    exp = Oracle("WEI25519").eddsa_verify(pubs, sigs, hram)
+    assert exp[n:] == bytes([0, 1] * 12)
+    n = len(pubs) // 32
     cv = gpu_ctx.curve("WEI25519")
     try:
-        assert cv.eddsa_verify(pubs, sigs, hram) == exp                      # Edwards tail
+        assert cv.eddsa_verify(pubs, sigs, hram) == exp                      # half-length scalars, Edwards tail
         assert cv.eddsa_verify(pubs[:32 * 20], sigs[:64 * 20], hram[:64 * 20]) == exp[:20]   # below the comb threshold
-        os.environ["ECAMD_NO_ED_TAIL"] = "1"
-        try:
-            assert cv.eddsa_verify(pubs, sigs, hram) == exp                  # Weierstrass tail
-        finally:
-            del os.environ["ECAMD_NO_ED_TAIL"]
+        for off in ("ECAMD_NO_ED_LATTICE", "ECAMD_NO_ED_TAIL"):
+            os.environ[off] = "1"
+            try:
+                assert cv.eddsa_verify(pubs, sigs, hram) == exp              # full-length loop + Edwards tail; Weierstrass tail
+            finally:
+                del os.environ[off]
         # a larger tiled batch (several waves, ragged end)
         reps = 4099 // n + 1
         assert cv.eddsa_verify((pubs * reps)[:32 * 4099], (sigs * reps)[:64 * 4099], (hram * reps)[:64 * 4099]) == (exp * reps)[:4099]
