@@ -264,7 +264,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_smul
 	typedef typename Cls<PB>::FA FA;
 	typedef typename Cls<PB>::FM FM;
 	typedef typename Cls<PB>::FC FC;
-	constexpr int NL = L::NL, NW = L::NW;
+	constexpr int NL = L::NL;
 	const u32 i = blockIdx.x * 64 + threadIdx.x;
 	if (i >= A.n) {
 		return;
@@ -2555,10 +2555,16 @@ template <int phase, int NWIN> __global__ __launch_bounds__(64) void k_ed_smul2_
 	Ext acc = ed_neutral(K);
 #pragma unroll 1
 	for (int t = 0; t < NWIN; t++) {
+#if defined(ED_SMUL2_UNROLL)   /* A/B hook (tools/build_variant.py): the three T-less doublings spelled out (57 KB of loop body instead of 42) */
+		acc = ed_dbl<false>(acc, K);
+		acc = ed_dbl<false>(acc, K);
+		acc = ed_dbl<false>(acc, K);
+#else
 #pragma unroll 1
 		for (int d = 0; d < 3; d++) {
 			acc = ed_dbl<false>(acc, K);
 		}
+#endif
 		acc = ed_dbl<true>(acc, K);
 		{
 			// - [d]A: subtract the entry for a positive digit

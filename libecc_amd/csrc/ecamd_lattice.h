@@ -76,9 +76,11 @@ LAT_FN bool lat_reduce(const lat_u32 *q, const lat_u32 *h, lat_u32 *v, lat_u32 *
 			const int len = 32 * top + 32 - LAT_CLZ(lat_word_at(r0, top));
 			const int sh = len - 63;
 			const lat_u64 x0 = lat_extract64(r0, sh), x1 = lat_extract64(r1, sh);
-			lat_u64 k = x0 / (x1 + 1);          // <= floor(r0 / r1)
-			k = (k == 0) ? 1 : k;           // r0 >= r1: one subtraction is always possible
-			const lat_u32 k32 = (k > 0xffffffffull) ? 0xffffffffu : (lat_u32)k;
+			// a lower bound of floor(r0 / r1) in single precision: conversions and division err by less than 2^-21 relative,
+			// the factor 1 - 2^-20 keeps the estimate below x0 / (x1 + 1) <= r0 / r1 (a 64-bit integer division would cost more
+			// than the rest of the iteration; an estimate one too small only costs one more iteration with quotient 1)
+			const float kf = ((float)x0 / (float)(x1 + 1)) * 0.99999904632568359375f;
+			const lat_u32 k32 = (kf >= 4294967040.0f) ? 0xffffffffu : ((kf < 1.0f) ? 1u : (lat_u32)kf);   // r0 >= r1: at least one
 			// r0 -= k r1 (no underflow), |t0| += k |t1|
 			lat_u64 carry = 0;
 			lat_u32 borrow = 0;

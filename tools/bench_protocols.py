@@ -225,14 +225,20 @@ def main():
         def ref_subset(idx):
             sp, ss, sm = (b"".join(x[w * i:w * i + w] for i in idx) for x, w in ((pubs, 32), (sigs, 64), (msgs, 32)))
             return O.join_slices(O.in_slices(lambda lo, hi: O.ref_ed25519_verify(sp[32 * lo:32 * hi], ss[64 * lo:64 * hi], sm[32 * lo:32 * hi], 32), len(idx)))
-        # dominant kernel k_ed_smul_c25519<1>: 64 windows of 3 doublings (3M + 4S), 1 doubling (4M + 4S) and 1 addition without its T
-        # (7M; round 3: 8M) in extended coordinates; 2^255 - 19 flavour (round 4: the high columns fold as their register halves):
-        # M = 81 + 16 = 97, S = 45 + 16 = 61 MADs, 16 of them with a constant multiplier
-        work = {"kernel": "k_ed_smul_c25519<1>", "mads_per_item": 64 * (20 * 97 + 16 * 61), "sgpr_mads_per_item": 64 * 36 * 16}
-        # the whole step (pipeline_frac): k_ed_decode_ed_c25519 (two square roots: 2 x (255 S + 25 M), the key's cofactor doublings),
-        # k_ed_smul_c25519<0> (window table: 73 M + 16 S), the loop, k_ed_tail_c25519 (17 mixed additions from the Edwards comb of B,
-        # the two comparisons, two additions, three doublings: 165 M + 13 S); k_ed_scal (mod-q words, not this unit's MADs) not counted
-        work["step_mads_per_item"] = (59 + 73 + 1 + 64 * 20 + 165) * 97 + (522 + 16 + 64 * 16 + 13) * 61
+        if os.environ.get("ECAMD_NO_ED_LATTICE") or os.environ.get("ECAMD_NO_ED_TAIL"):
+            # the full-length form (round 4, first step): k_ed_smul_c25519<1>, 64 windows of 3 doublings (3M + 4S), 1 doubling (4M + 4S) and
+            # 1 addition without its T (7M); M = 81 + 16 = 97, S = 45 + 16 = 61 MADs, 16 of them with a constant multiplier
+            work = {"kernel": "k_ed_smul_c25519<1>", "mads_per_item": 64 * (20 * 97 + 16 * 61), "sgpr_mads_per_item": 64 * 36 * 16}
+            work["step_mads_per_item"] = (59 + 73 + 1 + 64 * 20 + 165) * 97 + (522 + 16 + 64 * 16 + 13) * 61
+        else:
+            # half-length scalars (k_ed_lat): dominant kernel k_ed_smul2_c25519<1, 33>, 33 windows of 3 doublings (3M + 4S), 1 doubling with T
+            # (4M + 4S), 1 addition with T (8M) and 1 without (7M) over the tables of A and R
+            work = {"kernel": "k_ed_smul2_c25519<1, 33>", "mads_per_item": 33 * (28 * 97 + 16 * 61), "sgpr_mads_per_item": 33 * 44 * 16}
+            # the whole step: k_ed_decode_ed_c25519 (two square roots: 2 x (255 S + 25 M), the key's cofactor doublings: 59 M + 522 S),
+            # k_ed_lat (word arithmetic mod q and the Euclidean loop: no MADs of this unit), the two window tables (2 x (73 M + 16 S)),
+            # the loop, k_ed_tail2_c25519 (two comb passes of 17 mixed additions, the comparisons, one addition, three doublings:
+            # 268 M + 13 S)
+            work["step_mads_per_item"] = (59 + 146 + 2 + 33 * 28 + 268) * 97 + (522 + 32 + 33 * 16 + 13) * 61
         work["alg_bytes_per_item"] = 32 + 64 + 64 + 1
         metric, unit, cfg = "Ed25519 verifications/sec (batch=2^%d, %s)" % (a.batch_log2, distinct), "verifications/s", 4
     elif a.workload == "ed448_verify":
