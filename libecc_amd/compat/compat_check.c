@@ -1093,6 +1093,15 @@ int main(int argc, char **argv)
 		printf("no GPU path\n");
 		return 3;
 	}
+	if (argc > 1 && !strcmp(argv[1], "cfg1")) {
+		/* BASELINE.json configs[0] / SURVEY.md 8d-1, the plumbing case: 1024 secp256r1 scalar multiplications (scalars uniform in
+		 * [1, q - 1], bases [t]G and G) through the library API -- every item of prj_pt_mul_batch against a loop of libecc's own
+		 * prj_pt_mul on the same structures */
+		check_mul("SECP256R1", 1024, 0);
+		ecamd_compat_shutdown();
+		printf(failures ? "compat_check cfg1: %d FAILURES\n" : "compat_check cfg1: all ok (%d failures)\n", failures);
+		return failures ? 1 : 0;
+	}
 	if (argc > 2 && !strcmp(argv[1], "quick")) {
 		/* one case per entry-point family at a size that goes through the thread pool and several pipeline chunks */
 		const u32 qn = (u32)atoi(argv[2]);

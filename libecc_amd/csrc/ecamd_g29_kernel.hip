@@ -1523,8 +1523,17 @@ namespace c25519 {
 struct Ext {
 	FM X, Y, Z, T;
 };
+// a precomputed point (Y - X, Y + X, 2d T, 2 Z).  Round 4: the three sums are stored as they come out of one carry pass -- class FT, the
+// loosest of the three -- instead of being multiplied by one into the class of a product (3 of the 4 multiplications of an entry, a
+// third of a window table's cost); the additions take an FT operand as they are (the bounds are checked at compile time as everywhere).
+typedef decltype(carry(sub_auto<1>(FM(), FM(), *(const CK *)nullptr))) PreS;
+typedef decltype(carry(add(FM(), FM()))) PreA_;
+typedef decltype(carry(mul_small<2>(FM()))) PreZ;
+typedef E<PB, cmax(cmax(PreS::LB, PreA_::LB), PreZ::LB), cmax(cmax(PreS::TB, PreA_::TB), PreZ::TB), cmax(cmax(PreS::VB, PreA_::VB), PreZ::VB)> FT;
 struct Pre {
-	FM ymx, ypx, t2d, z2;
+	FT ymx, ypx;
+	FM t2d;
+	FT z2;
 };
 #define M_(a, b) weaken<FM>(mulc(a, b, K))
 #define S_(a) weaken<FM>(sqrc(a, K))
@@ -1558,7 +1567,7 @@ template <bool WITH_T> static __device__ __forceinline__ Ext ed_dbl(const Ext &P
 // P + (+-Q) for the precomputed entry Q (negated when neg); WITH_T = false when a doubling follows (it does not read T): 7 M
 template <bool WITH_T = true> static __device__ __forceinline__ Ext ed_add(const Ext &P, const Pre &Q, bool neg, const CK &K)
 {
-	const FM qa = selg(neg, Q.ypx, Q.ymx), qb = selg(neg, Q.ymx, Q.ypx);
+	const FT qa = selg(neg, Q.ypx, Q.ymx), qb = selg(neg, Q.ymx, Q.ypx);
 	const FM a = M_(carry(sub_auto<1>(P.Y, P.X, K)), qa);
 	const FM b = M_(carry(add(P.Y, P.X)), qb);
 	const FM c = M_(P.T, Q.t2d);
@@ -1586,12 +1595,11 @@ template <bool WITH_T = true> static __device__ __forceinline__ Ext ed_add(const
 
 static __device__ __forceinline__ Pre ed_pre(const Ext &P, const FC &d2, const CK &K)
 {
-	const FC onec = constant<FC>(K.one);
 	Pre Q;
-	Q.ymx = M_(carry(sub_auto<1>(P.Y, P.X, K)), onec);
-	Q.ypx = M_(carry(add(P.Y, P.X)), onec);
+	Q.ymx = weaken<FT>(carry(sub_auto<1>(P.Y, P.X, K)));
+	Q.ypx = weaken<FT>(carry(add(P.Y, P.X)));
 	Q.t2d = M_(P.T, d2);
-	Q.z2 = M_(carry(mul_small<2>(P.Z)), onec);
+	Q.z2 = weaken<FT>(carry(mul_small<2>(P.Z)));
 	return Q;
 }
 

@@ -148,9 +148,14 @@ def test_der_reader():
 
 def test_runner_on_selfmade_file_cpu():
     """the runner over the self-made file in the Wycheproof schema (reference verdicts), on the restatement oracle"""
-    t = run_all(CpuBackend(), selfmade("ecdsa_"), selfmade("eddsa_") + selfmade("ed448_"), selfmade("x25519") + selfmade("x448"), [])
+    t = run_all(CpuBackend(), selfmade("ecdsa_"), selfmade("eddsa_") + selfmade("ed448_"), selfmade("x25519") + selfmade("x448"), selfmade("ecdh_"))
     assert not t.errors, t.errors[:5]
-    assert t.performed > 500 and t.skipped == 0
+    assert t.performed > 700 and t.skipped == 0
+    # the ECDH families (round 4): compressed peers, invalid-curve points, coordinates out of range, wrong encodings, edge private keys
+    ecdh = W.Tally()
+    be = CpuBackend()
+    W.run_ecdh_ecpoint(selfmade("ecdh_"), be.derive, be.decompress, ecdh)
+    assert not ecdh.errors and ecdh.performed > 200
 
 
 def test_official_wycheproof_vectors_cpu():
@@ -165,9 +170,9 @@ def test_official_wycheproof_vectors_cpu():
 def test_runner_on_selfmade_file_gpu(gpu_ctx):
     be = GpuBackend(gpu_ctx)
     try:
-        t = run_all(be, selfmade("ecdsa_"), selfmade("eddsa_") + selfmade("ed448_"), selfmade("x25519") + selfmade("x448"), [])
+        t = run_all(be, selfmade("ecdsa_"), selfmade("eddsa_") + selfmade("ed448_"), selfmade("x25519") + selfmade("x448"), selfmade("ecdh_"))
         assert not t.errors, t.errors[:5]
-        assert t.performed > 500
+        assert t.performed > 700
     finally:
         be.close()
 

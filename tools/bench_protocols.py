@@ -229,16 +229,17 @@ def main():
             # the full-length form (round 4, first step): k_ed_smul_c25519<1>, 64 windows of 3 doublings (3M + 4S), 1 doubling (4M + 4S) and
             # 1 addition without its T (7M); M = 81 + 16 = 97, S = 45 + 16 = 61 MADs, 16 of them with a constant multiplier
             work = {"kernel": "k_ed_smul_c25519<1>", "mads_per_item": 64 * (20 * 97 + 16 * 61), "sgpr_mads_per_item": 64 * 36 * 16}
-            work["step_mads_per_item"] = (59 + 73 + 1 + 64 * 20 + 165) * 97 + (522 + 16 + 64 * 16 + 13) * 61
+            # whole step: decode 59 M + 522 S, window table 49 M + 16 S, the loop, k_ed_tail_c25519 162 M + 13 S
+            work["step_mads_per_item"] = (59 + 49 + 64 * 20 + 162) * 97 + (522 + 16 + 64 * 16 + 13) * 61
         else:
             # half-length scalars (k_ed_lat): dominant kernel k_ed_smul2_c25519<1, 33>, 33 windows of 3 doublings (3M + 4S), 1 doubling with T
             # (4M + 4S), 1 addition with T (8M) and 1 without (7M) over the tables of A and R
             work = {"kernel": "k_ed_smul2_c25519<1, 33>", "mads_per_item": 33 * (28 * 97 + 16 * 61), "sgpr_mads_per_item": 33 * 44 * 16}
             # the whole step: k_ed_decode_ed_c25519 (two square roots: 2 x (255 S + 25 M), the key's cofactor doublings: 59 M + 522 S),
-            # k_ed_lat (word arithmetic mod q and the Euclidean loop: no MADs of this unit), the two window tables (2 x (73 M + 16 S)),
-            # the loop, k_ed_tail2_c25519 (two comb passes of 17 mixed additions, the comparisons, one addition, three doublings:
-            # 268 M + 13 S)
-            work["step_mads_per_item"] = (59 + 146 + 2 + 33 * 28 + 268) * 97 + (522 + 32 + 33 * 16 + 13) * 61
+            # k_ed_lat (word arithmetic mod q and the Euclidean loop: no MADs of this unit), the two window tables (2 x (49 M + 16 S): four
+            # doublings with T, three additions, eight entries of one multiplication each), the loop, k_ed_tail2_c25519 (two comb passes
+            # of 17 mixed additions, the comparisons, one addition, three doublings: 264 M + 13 S)
+            work["step_mads_per_item"] = (59 + 98 + 33 * 28 + 264) * 97 + (522 + 32 + 33 * 16 + 13) * 61
         work["alg_bytes_per_item"] = 32 + 64 + 64 + 1
         metric, unit, cfg = "Ed25519 verifications/sec (batch=2^%d, %s)" % (a.batch_log2, distinct), "verifications/s", 4
     elif a.workload == "ed448_verify":
