@@ -3357,6 +3357,151 @@ hipError_t G29_CAT(ecamd_g29_ed_fin_, G29_TAG)(int gslot, const EcamdEdFinArgs &
 }
 #endif
 
+#if G29_FLAV == 0
+// ------------------------------------------------------------------------------------------
+// Round 4: the mod-q algebra in front of an ECDSA verification (k_ecdsa_prep<NW> of ecamd_kernels.hip: range checks of r and s,
+// s^-1 by one Fermat inversion shared by the items of a lane, u1 = e / s, u2 = r / s; sig/ecdsa_common.c:760-791) on the dense
+// radix-2^29 unit of the ORDER's size, with q in a constant slot of its own: the same field code as the curve arithmetic, the
+// modulus being q instead of p (upload_g29_mod in ecamd_host.cpp builds its constants; ix = R^2 takes a value into the
+// Montgomery domain, ex = 1 out of it).  The prefix products of Montgomery's trick rest in `scratch` (NL words per item),
+// so a lane can take sixteen items whatever the field size.  Lane t owns the items t, t + lanes, t + 2 lanes, ...
+// ------------------------------------------------------------------------------------------
+template <int PB> __global__ __launch_bounds__(64) void k_ecdsa_prep_g(EcamdEcdsaPrepArgs A, u32 *scratch, int qgslot, u32 lanes, int kp)
+{
+	static_assert(PB == G29_PB, "one instantiation per unit");
+	typedef Lay<PB> L;
+	typedef typename Cls<PB>::FM FM;
+	typedef typename Cls<PB>::FC FC;
+	constexpr int NL = L::NL, NW = L::NW;
+	const u32 t = blockIdx.x * 64 + threadIdx.x;
+	if (t >= lanes) {
+		return;
+	}
+	if (A.only != nullptr) {
+		bool any = false;
+		for (int j = 0; j < kp; j++) {
+			const u32 i = t + (u32)j * lanes;
+			any = any | (i < A.n && A.only[i] == ECAMD_STATUS_REDO);
+		}
+		if (!any) {
+			return;
+		}
+	}
+	const CurveG<NL> &K = TabGP<PB>::get(qgslot);
+	const int qlen = (int)A.qlen, hlen = (int)A.hlen;
+	const FM onem = weaken<FM>(constant<FC>(K.one));
+	u32 qw[NW];
+	to_words<NL, NW>(qw, K.p);
+	// value (NW words) in [1, q - 1]?
+	auto in_range = [&](const u32 *w) {
+		u32 nz = 0, borrow = 0;
+#pragma unroll
+		for (int k = 0; k < NW; k++) {
+			nz |= w[k];
+			const uint64_t d = (uint64_t)w[k] - qw[k] - borrow;
+			borrow = (u32)(d >> 63);
+		}
+		return (nz != 0u) & (borrow != 0u);
+	};
+	FM acc = onem;
+#pragma unroll 1
+	for (int j = 0; j < kp; j++) {
+		const u32 i = t + (u32)j * lanes;
+		if (i >= A.n) {
+			break;
+		}
+		const u8 *sig = A.sigs + (size_t)i * 2 * qlen;
+		u32 rw[NW], sw[NW];
+		load_be<NW>(sig, qlen, rw);
+		load_be<NW>(sig + qlen, qlen, sw);
+		const bool ok = in_range(rw) & in_range(sw);
+		if (ok) {
+			const FM sm = weaken<FM>(mul(from_words<PB, NW>(sw), constant<FC>(K.ix), K));
+			acc = weaken<FM>(mul(acc, sm, K));
+		}
+		u32 *dst = scratch + (size_t)i * NL;
+#pragma unroll
+		for (int k = 0; k < NL; k++) {
+			dst[k] = acc.l[k];
+		}
+	}
+	FM inv = jacg::inv<PB>(acc, K);   // (s_0 ... s_last)^-1 = x^(q - 2): the unique inverse, nn_modinv's (nn/nn_modinv.c:220)
+#pragma unroll 1
+	for (int j = kp - 1; j >= 0; j--) {
+		const u32 i = t + (u32)j * lanes;
+		if (i >= A.n) {
+			continue;
+		}
+		const u8 *sig = A.sigs + (size_t)i * 2 * qlen;
+		u32 rw[NW], sw[NW];
+		load_be<NW>(sig, qlen, rw);
+		load_be<NW>(sig + qlen, qlen, sw);
+		const bool ok = in_range(rw) & in_range(sw);
+		u32 u1w[NW], u2w[NW];
+#pragma unroll
+		for (int k = 0; k < NW; k++) {
+			u1w[k] = u2w[k] = 0;
+		}
+		if (ok) {
+			FM pre = onem;
+			if (j > 0) {
+				const u32 *src = scratch + (size_t)(i - lanes) * NL;
+#pragma unroll
+				for (int k = 0; k < NL; k++) {
+					pre.l[k] = src[k];
+				}
+			}
+			const FM sm = weaken<FM>(mul(from_words<PB, NW>(sw), constant<FC>(K.ix), K));
+			const FM sinv = weaken<FM>(mul(inv, pre, K));     // Montgomery form of 1 / s
+			inv = weaken<FM>(mul(inv, sm, K));
+			// e = the leftmost |q| bits of the digest, mod q (sig/ecdsa_common.c:760-778): one conditional subtraction
+			const int elen = hlen < qlen ? hlen : qlen;
+			u32 ew[NW];
+			load_be<NW>(A.digests + (size_t)i * hlen, elen, ew);
+			const int rshift = (8 * hlen > (int)A.qbits) ? (8 * elen - (int)A.qbits) : 0;   // 0 .. 7
+			if (rshift > 0) {
+#pragma unroll
+				for (int k = 0; k < NW; k++) {
+					const u32 hi = (k + 1 < NW) ? ew[k + 1] : 0u;
+					ew[k] = (ew[k] >> rshift) | (hi << (32 - rshift));
+				}
+			}
+			{
+				u32 tw[NW], borrow = 0;
+#pragma unroll
+				for (int k = 0; k < NW; k++) {
+					const uint64_t d = (uint64_t)ew[k] - qw[k] - borrow;
+					tw[k] = (u32)d;
+					borrow = (u32)(d >> 63);
+				}
+#pragma unroll
+				for (int k = 0; k < NW; k++) {
+					ew[k] = borrow ? ew[k] : tw[k];
+				}
+			}
+			u32 dg[NL];
+			canonical_digits(dg, mul(from_words<PB, NW>(ew), sinv, K), K);     // plain x Montgomery = plain e / s
+			to_words<NL, NW>(u1w, dg);
+			canonical_digits(dg, mul(from_words<PB, NW>(rw), sinv, K), K);
+			to_words<NL, NW>(u2w, dg);
+		}
+		store_be<NW>(A.u1 + (size_t)i * qlen, qlen, u1w);
+		store_be<NW>(A.u2 + (size_t)i * qlen, qlen, u2w);
+		A.flags[i] = ok ? 0 : 1;
+	}
+}
+
+hipError_t G29_CAT(ecamd_g29_ecdsa_prep_, G29_TAG)(int qgslot, const EcamdEcdsaPrepArgs &a, uint32_t *scratch, int kp, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	const uint32_t lanes = (a.n + (uint32_t)kp - 1) / (uint32_t)kp;
+	hipLaunchKernelGGL(k_ecdsa_prep_g<G29_PB>, dim3((lanes + 63) / 64), dim3(64), 0, s, a, scratch, qgslot, lanes, kp);
+	return hipGetLastError();
+}
+#endif
+
 hipError_t G29_CAT(ecamd_g29_upload_, G29_TAG)(int slot, const void *img, size_t bytes)
 {
 	typedef CurveG<Lay<G29_PB>::NL> CK;
@@ -3573,6 +3718,20 @@ uint32_t ecamd_g29_comb_entry_words(int pbits, int flavour)
 {
 	return (uint32_t)(((2 * g29::nl_for_flavour(pbits, flavour) + 3) / 4) * 4);
 }
+#define X(PB) hipError_t ecamd_g29_ecdsa_prep_##PB(int qgslot, const EcamdEcdsaPrepArgs &a, uint32_t *scratch, int kp, hipStream_t s);
+G29_FOR_PB(X)
+#undef X
+// k_ecdsa_prep_g on the dense unit of qbits bits (the order q in constant slot qgslot of that unit); scratch: n x ecamd_g29_nl(qbits, 0) words
+hipError_t ecamd_g29_ecdsa_prep(int qbits, int qgslot, const EcamdEcdsaPrepArgs &a, uint32_t *scratch, int kp, hipStream_t s)
+{
+	switch (qbits) {
+#define X(PB) case PB: return ecamd_g29_ecdsa_prep_##PB(qgslot, a, scratch, kp, s);
+		G29_FOR_PB(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+}
+
 hipError_t ecamd_g29_comb_build(int pbits, int gslot, const uint8_t *pts, uint32_t n, uint32_t clen, uint32_t *table,
 				hipStream_t s, int flavour)
 {

@@ -217,6 +217,8 @@ struct ecamd_ctx {
 	size_t tbl_bytes;
 	uint32_t *tbl_fast; // fast paths: per-item window tables (secp256r1: 512 B affine table + 1120 B staging per item)
 	size_t tbl_fast_bytes;
+	uint8_t *prep_scratch;     // k_ecdsa_prep_g: prefix products, n x NL words
+	size_t prep_scratch_bytes;
 	uint8_t *stage[ECAMD_NSTAGE];
 	size_t stage_bytes[ECAMD_NSTAGE];
 	// the scratch above is shared by every call: a call enqueued on another stream than the previous one first waits
@@ -285,6 +287,7 @@ struct ecamd_curve {
 	EcamdYfromXArgs sqrt_tmpl;
 	bool is_p256;    // exactly secp256r1: hand-specialised radix-2^29 Jacobian kernel
 	int gslot;       // constant slot of the generic radix-2^29 Jacobian kernel (-1: none)
+	int gqslot;      // constant slot of the dense radix-2^29 unit of the ORDER's size holding q as its modulus (k_ecdsa_prep_g; -1: none)
 	int gflavour;    // 0 dense reduction, 1 secp521r1 (p = 2^521 - 1), 2 p = 2^255 - 19, 3 secp384r1's prime, 4 secp256k1's prime, 5 p = 2^448 - 2^224 - 1,
 	                 // 6 secp224r1's prime, 7 secp192r1's prime (3, 6, 7: signed sparse Montgomery reduction)
 	uint32_t *d_gtab; // secp256r1: affine window table [1..8]G, radix-2^29 Montgomery digits, 8 x 40 words
@@ -352,6 +355,8 @@ extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
 		c->stage[i] = nullptr;
 		c->stage_bytes[i] = 0;
 	}
+	c->prep_scratch = nullptr;
+	c->prep_scratch_bytes = 0;
 	c->last_stream = nullptr;
 	c->inflight = false;
 	if (hipEventCreateWithFlags(&c->busy, hipEventDisableTiming) != hipSuccess) {
@@ -438,6 +443,9 @@ extern "C" void ecamd_ctx_destroy(ecamd_ctx *c)
 		if (c->stage[i]) {
 			(void)hipFree(c->stage[i]);
 		}
+	}
+	if (c->prep_scratch) {
+		(void)hipFree(c->prep_scratch);
 	}
 	for (int i = 0; i <= ECAMD_NTIMED; i++) {
 		(void)hipEventDestroy(c->ev[i]);
@@ -610,6 +618,9 @@ extern "C" int ecamd_ctx_wipe_scratch(ecamd_ctx *c)
 		if (c->stage[i]) {
 			HIPCHK(hipMemsetAsync(c->stage[i], 0, c->stage_bytes[i], s));
 		}
+	}
+	if (c->prep_scratch) {
+		HIPCHK(hipMemsetAsync(c->prep_scratch, 0, c->prep_scratch_bytes, s));
 	}
 	for (int b = 0; b < 2; b++) {
 		for (int k = 0; k < 6; k++) {
@@ -824,6 +835,8 @@ static void release_modulus(int device, int nw, int slot)
 static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_scalars, uint32_t slen,
 			   const uint8_t *d_points, uint8_t *d_out, uint8_t *d_status, hipStream_t s,
 			   uint32_t sstride = 0xffffffffu, bool redo_only = false, const uint8_t *d_scalars2 = nullptr);
+static int prep_scratch_ok(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n);
+static hipError_t launch_ecdsa_prep(ecamd_ctx *ctx, const ecamd_curve *cv, const EcamdEcdsaPrepArgs &P, hipStream_t s);
 
 // w-bit digits of a (nl of them, the last one takes whatever is left): 29 bits on every radix-2^29 unit but the Goldilocks one
 // (flavour 5), which runs on 28-bit limbs so that 2^224 falls on a limb boundary (ecamd_u29g.h)
@@ -848,19 +861,20 @@ static Big big_shl(const Big &a, int e)
 
 // CurveG<NL> image of ecamd_u29g.h: p r2 one a b pm2 (NL digits each), 16 bias tables, ix iy ex ey, mpinv pbits
 // a_is_m3 pad -- mirrored by tools/g29_consts.py, which the CPU tests use against Python integers
-static int upload_g29(ecamd_curve *cv)
+// (p, a, b, pbits, flavour): the curve's own field (upload_g29), or the group order q with a = b = 0 on the dense unit of its
+// size (upload_g29_order: the mod-q algebra of ECDSA verification runs on the same field code, k_ecdsa_prep_g)
+static int upload_g29_mod(ecamd_curve *cv, const Big &p, const Big &a_in, const Big &b_in, int pbits, int gflavour, int *slot_out)
 {
-	const int pbits = cv->pbits, nl = ecamd_g29_nl(pbits, cv->gflavour);
-	const Big &p = cv->p;
+	const int nl = ecamd_g29_nl(pbits, gflavour);
 	// flavours 2 (p = 2^255 - 19), 4 (secp256k1's prime) and 5 (p = 2^448 - 2^224 - 1) keep plain residues: R = 1
-	const int w = (cv->gflavour == 5) ? 28 : 29;   // limb width of the unit (g29::W of its translation unit)
+	const int w = (gflavour == 5) ? 28 : 29;   // limb width of the unit (g29::W of its translation unit)
 	// flavours 1 (p = 2^521 - 1 on 18 limbs), 2, 4 and 5 keep plain residues: R = 1
-	const bool plain = cv->gflavour == 1 || cv->gflavour == 2 || cv->gflavour == 4 || cv->gflavour == 5;
+	const bool plain = gflavour == 1 || gflavour == 2 || gflavour == 4 || gflavour == 5;
 	const Big R = plain ? Big(1, 1) : big_mod(big_pow2(w * nl), p);
 	Big two(1, 2), three(1, 3);
 	static const int step29[16] = {2, 4, 6, 8, 10, 12, 14, 16, 2, 4, 6, 8, 10, 12, 14, 16};
 	static const int step28[16] = {1, 2, 3, 4, 5, 6, 7, 8, 1, 2, 3, 4, 5, 6, 7, 8};    // g29::bias_step of the no-headroom flavours
-	const int *step = (cv->gflavour == 5 || cv->gflavour == 1) ? step28 : step29;
+	const int *step = (gflavour == 5 || gflavour == 1) ? step28 : step29;
 	static const int sv[16] = {1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2};
 	const int topsh = pbits - w * (nl - 1);
 	const int off = (1 - topsh) > 0 ? (1 - topsh) : 0;
@@ -868,8 +882,8 @@ static int upload_g29(ecamd_curve *cv)
 	// exists.  Tried for p = 3 mod 4, where square roots are one exponentiation and exactly one of +-s is a square
 	// (the brainpool r1 curves -- their t1 twins are these images --, two GOST 512-bit sets); ECAMD_NO_ISO disables it.
 	Big u(1, 1);
-	Big a_img = cv->a, b_img = cv->b;
-	if ((cv->gflavour == 0 || cv->gflavour == 3 || cv->gflavour == 5) && (p[0] & 3u) == 3u && big_bitlen(cv->a) > 0 && big_cmp(big_add(cv->a, three), p) != 0 &&
+	Big a_img = a_in, b_img = b_in;
+	if ((gflavour == 0 || gflavour == 3 || gflavour == 5) && (p[0] & 3u) == 3u && big_bitlen(a_in) > 0 && big_cmp(big_add(a_in, three), p) != 0 &&
 	    getenv("ECAMD_NO_ISO") == nullptr) {
 		Big e = big_add(p, Big(1, 1));  // (p + 1) / 4
 		Big q4(e.size(), 0);
@@ -877,7 +891,7 @@ static int upload_g29(ecamd_curve *cv)
 			q4[i] = (e[i] >> 2) | ((i + 1 < e.size()) ? (e[i + 1] << 30) : 0u);
 		}
 		big_trim(q4);
-		const Big t = big_mulmod(big_sub(p, three), big_powmod(cv->a, big_sub(p, two), p), p);  // -3 / a
+		const Big t = big_mulmod(big_sub(p, three), big_powmod(a_in, big_sub(p, two), p), p);  // -3 / a
 		Big s1 = big_powmod(t, q4, p);
 		if (big_cmp(big_mulmod(s1, s1, p), t) == 0) {
 			Big r = big_powmod(s1, q4, p);
@@ -888,8 +902,8 @@ static int upload_g29(ecamd_curve *cv)
 			if (big_cmp(big_mulmod(r, r, p), s1) == 0) {
 				u = r;
 				const Big u2 = big_mulmod(u, u, p), u4 = big_mulmod(u2, u2, p);
-				a_img = big_mulmod(cv->a, u4, p);
-				b_img = big_mulmod(cv->b, big_mulmod(u4, u2, p), p);
+				a_img = big_mulmod(a_in, u4, p);
+				b_img = big_mulmod(b_in, big_mulmod(u4, u2, p), p);
 				if (big_cmp(big_add(a_img, three), p) != 0) {
 					return fail("internal: isomorphism onto a = -3 failed");
 				}
@@ -917,7 +931,7 @@ static int upload_g29(ecamd_curve *cv)
 		big_digits29(l, nl, big_shl(p, step[t] + off), w);
 		const uint32_t M = 1u << (w + sv[t]), BW = 1u << sv[t];
 		if (l[nl - 1] < BW) {
-			if (cv->gflavour == 5 || cv->gflavour == 1) {
+			if (gflavour == 5 || gflavour == 1) {
 				memset(l, 0, sizeof(uint32_t) * (size_t)nl);
 				continue;  // a multiple too small to lend the borrow; never selected (BiasB's static_asserts)
 			}
@@ -937,23 +951,45 @@ static int upload_g29(ecamd_curve *cv)
 	img[(size_t)26 * nl + 1] = (uint32_t)pbits;
 	img[(size_t)26 * nl + 2] = (big_cmp(big_add(a_img, three), p) == 0) ? 1u : 0u;
 	img[(size_t)26 * nl + 3] = (big_bitlen(a_img) == 0) ? 1u : 0u;
-	if (img.size() * 4 != ecamd_g29_image_bytes(pbits, cv->gflavour)) {
+	if (img.size() * 4 != ecamd_g29_image_bytes(pbits, gflavour)) {
 		return fail("internal: CurveG image size mismatch");
 	}
 	SlotRegistry *reg = slot_registry(cv->ctx->device);
-	const int key = pbits + cv->gflavour;
+	const int key = pbits + gflavour;
 	if (!reg || key >= ECAMD_G29_KEYS) {
 		return fail("internal: no slot registry for this device / field size");
 	}
-	const int flavour = cv->gflavour;
+	const int flavour = gflavour;
 	const int slot = slot_acquire(reg->g[key], ecamd_g29_slots() < 8 ? ecamd_g29_slots() : 8, img,
 				      [&](int sl) { return ecamd_g29_upload(pbits, sl, img.data(), img.size() * 4, flavour); });
 	if (slot == -2) {
 		return fail("curve: upload of the radix-2^29 curve constants failed");
 	}
-	cv->gslot = slot < 0 ? -1 : slot;  // no free slot: the saturated-word kernels serve this handle
+	*slot_out = slot < 0 ? -1 : slot;  // no free slot: the saturated-word kernels serve this handle
 	return 0;
 }
+
+static int upload_g29(ecamd_curve *cv)
+{
+	return upload_g29_mod(cv, cv->p, cv->a, cv->b, cv->pbits, cv->gflavour, &cv->gslot);
+}
+
+// the group order as the modulus of the dense unit of its size (only sizes that unit exists for; failure is not an error:
+// the saturated-word k_ecdsa_prep keeps serving)
+static void upload_g29_order(ecamd_curve *cv)
+{
+	cv->gqslot = -1;
+	const int qbits = big_bitlen(cv->q);
+	if (!ecamd_g29_supported(qbits) || qbits == 255 || qbits == 448 || qbits >= ECAMD_G29_KEYS || getenv("ECAMD_NO_PREP_G29") != nullptr ||
+	    getenv("ECAMD_NO_FAST_PATH") != nullptr) {
+		return;
+	}
+	int slot = -1;
+	if (upload_g29_mod(cv, cv->q, Big(), Big(), qbits, 0, &slot) == 0) {
+		cv->gqslot = slot;
+	}
+}
+
 
 // device allocations of a curve handle (also used on the failure paths of its construction)
 static void curve_free_device(ecamd_curve *cv)
@@ -988,10 +1024,17 @@ static void curve_release_slots(ecamd_curve *cv)
 	release_modulus(dev, cv->qnw, cv->qslot);
 	SlotRegistry *reg = slot_registry(dev);
 	const int key = cv->pbits + cv->gflavour;
+	{
+		const int qkey = big_bitlen(cv->q);
+		if (reg && cv->gqslot >= 0 && cv->gqslot < 8 && qkey < ECAMD_G29_KEYS && reg->g[qkey][cv->gqslot].ref > 0) {
+			reg->g[qkey][cv->gqslot].ref--;
+		}
+		cv->gqslot = -1;
+	}
 	if (reg && cv->gslot >= 0 && cv->gslot < 8 && key < ECAMD_G29_KEYS && reg->g[key][cv->gslot].ref > 0) {
 		reg->g[key][cv->gslot].ref--;
 	}
-	cv->slot = cv->qslot = cv->gslot = -1;
+	cv->slot = cv->qslot = cv->gslot = cv->gqslot = -1;
 }
 
 // failure exit of curve construction: releases the handle; msg == NULL keeps the error already recorded
@@ -1006,7 +1049,7 @@ static int curve_abort(ecamd_curve *cv, const char *msg)
 static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 {
 	cv->ctx = nullptr;
-	cv->slot = cv->qslot = cv->gslot = -1;
+	cv->slot = cv->qslot = cv->gslot = cv->gqslot = -1;
 	cv->d_gen = nullptr;
 	cv->d_comb = nullptr;
 	cv->d_edcomb = nullptr;
@@ -1088,6 +1131,10 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 		if (rc) {
 			return curve_abort(cv, nullptr);
 		}
+	}
+	{
+		std::lock_guard<std::mutex> sl(g_slot_mu);
+		upload_g29_order(cv);
 	}
 	// generator X || Y, then the two broadcast scalars of the subgroup / cofactor passes: q (qlen bytes) and h (1 byte)
 	std::vector<uint8_t> g((size_t)2 * cv->clen + cv->qlen + 1, 0);
@@ -1834,7 +1881,10 @@ static int ecdsa_two_smul_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n,
 	P.qbits = (uint32_t)cv->qbits;
 	P.qslot = cv->qslot;
 	P.only = d_only;
-	HIPCHK(ecamd_launch_ecdsa_prep(cv->qnw, P, s));
+	if (prep_scratch_ok(ctx, cv, n)) {
+		return -1;
+	}
+	HIPCHK(launch_ecdsa_prep(ctx, cv, P, s));
 	const bool redo = d_only != nullptr;
 	if (redo) {
 		// the marks select the lanes of the complete-formula kernel (A.only_redo); the other items keep what they have
@@ -1896,13 +1946,38 @@ static int ecdsa_two_smul_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n,
 	return 0;
 }
 
+// The mod-q algebra in front of a verification: on the dense radix-2^29 unit of the order's size when the handle has q in a slot
+// there (round 4: k_ecdsa_prep_g, sixteen items per inversion from 320 bits on, eight below), else on the saturated words.
+// The caller has sized ctx->prep_scratch (prep_scratch_ok).
+static bool prep_g29(const ecamd_curve *cv)
+{
+	return cv->gqslot >= 0 && getenv("ECAMD_NO_PREP_G29") == nullptr;
+}
+static int prep_scratch_ok(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n)
+{
+	if (!prep_g29(cv)) {
+		return 0;
+	}
+	return ensure(&ctx->prep_scratch, &ctx->prep_scratch_bytes, (size_t)n * (size_t)ecamd_g29_nl(big_bitlen(cv->q), 0) * 4);
+}
+static hipError_t launch_ecdsa_prep(ecamd_ctx *ctx, const ecamd_curve *cv, const EcamdEcdsaPrepArgs &P, hipStream_t s)
+{
+	if (prep_g29(cv) && ctx->prep_scratch) {
+		const int qbits = big_bitlen(cv->q);
+		static const int kp_env = getenv("ECAMD_PREP_KP") ? atoi(getenv("ECAMD_PREP_KP")) : 0;   // A/B hook
+		const int kp = (kp_env >= 1 && kp_env <= 64) ? kp_env : (qbits > 320 ? 16 : 8);
+		return ecamd_g29_ecdsa_prep(qbits, cv->gqslot, P, (uint32_t *)ctx->prep_scratch, kp, s);
+	}
+	return ecamd_launch_ecdsa_prep(cv->qnw, P, s);
+}
+
 // k_ecdsa_prep of a chunk on the side stream: it starts when everything enqueued on s so far is done (the stage buffers it
 // writes are read by the previous chunk's loop) and the caller makes the consumer of u1 / u2 wait for side_done.
 // Returns the event to wait for, or nullptr when the kernel was enqueued on s itself.
-static hipEvent_t ecdsa_prep_beside(ecamd_ctx *ctx, int qnw, const EcamdEcdsaPrepArgs &P, hipStream_t s, hipError_t *err)
+static hipEvent_t ecdsa_prep_beside(ecamd_ctx *ctx, const ecamd_curve *cv, const EcamdEcdsaPrepArgs &P, hipStream_t s, hipError_t *err)
 {
 	if (!ctx->side_ok) {
-		*err = ecamd_launch_ecdsa_prep(qnw, P, s);
+		*err = launch_ecdsa_prep(ctx, cv, P, s);
 		return nullptr;
 	}
 	*err = hipEventRecord(ctx->side_fork, s);
@@ -1910,7 +1985,7 @@ static hipEvent_t ecdsa_prep_beside(ecamd_ctx *ctx, int qnw, const EcamdEcdsaPre
 		*err = hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0);
 	}
 	if (*err == hipSuccess) {
-		*err = ecamd_launch_ecdsa_prep(qnw, P, ctx->side_stream);
+		*err = launch_ecdsa_prep(ctx, cv, P, ctx->side_stream);
 	}
 	if (*err == hipSuccess) {
 		*err = hipEventRecord(ctx->side_done, ctx->side_stream);
@@ -1982,7 +2057,10 @@ static int ecdsa_fused_g_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, 
 		P.only = nullptr;
 		// (on s itself: k_table_g already reads the scalars -- it stores their recoding beside the window table -- so there is
 		// nothing for this kernel to run beside; the secp256r1 path below does overlap it)
-		HIPCHK(ecamd_launch_ecdsa_prep(cv->qnw, P, s));
+		if (prep_scratch_ok(ctx, cv, m)) {
+			return -1;
+		}
+		HIPCHK(launch_ecdsa_prep(ctx, cv, P, s));
 		if (smul_dev_locked(ctx, cv, m, S[4], (uint32_t)ql, d_pub + (size_t)off * plen, S[5], S[7], s, 0xffffffffu, false, S[3])) {
 			return -1;
 		}
@@ -2059,7 +2137,10 @@ static int ecdsa_verify_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 		P.qslot = cv->qslot;
 		P.only = nullptr;
 		hipError_t perr = hipSuccess;
-		const hipEvent_t prep_done = ecdsa_prep_beside(ctx, cv->qnw, P, s, &perr);
+		if (prep_scratch_ok(ctx, cv, m)) {
+			return -1;
+		}
+		const hipEvent_t prep_done = ecdsa_prep_beside(ctx, cv, P, s, &perr);
 		HIPCHK(perr);
 		EcamdSmulArgs K;
 		memset(&K, 0, sizeof(K));

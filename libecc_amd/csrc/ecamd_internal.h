@@ -423,6 +423,9 @@ uint32_t ecamd_g29_comb_entries(int pbits);
 uint32_t ecamd_g29_comb_entry_words(int pbits, int flavour);
 hipError_t ecamd_g29_comb_build(int pbits, int gslot, const uint8_t *pts, uint32_t n, uint32_t clen, uint32_t *table,
 				hipStream_t s, int flavour);
+struct EcamdEcdsaPrepArgs;
+// the mod-q algebra of an ECDSA verification on the dense radix-2^29 unit of the order's size (k_ecdsa_prep_g)
+hipError_t ecamd_g29_ecdsa_prep(int qbits, int qgslot, const EcamdEcdsaPrepArgs &a, uint32_t *scratch, int kp, hipStream_t s);
 hipError_t ecamd_launch_fp(int nw, const EcamdFpArgs &a, hipStream_t s);
 hipError_t ecamd_launch_pt(int nw, const EcamdPtArgs &a, hipStream_t s);
 size_t ecamd_curvek_bytes(int nw);
