@@ -188,6 +188,17 @@ int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, 
  * at infinity is a key for libecc (its import accepts (0 : 1 : 0)); verification against it is W' = uG, reproduced here. */
 int ec_ecdsa_verify_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *pubkeys, int pub_fmt,
 			      const uint8_t *sigs, const uint8_t *digests, uint32_t digest_len, uint8_t *result);
+/* Verification from MESSAGES instead of digests (round 4): the hash is computed on the device.  Item i's message sits in a slot of
+ * msg_stride bytes (one stride per call, a multiple of 4, at most 4096): a little-endian u32 length, then the bytes
+ * (4 + length <= msg_stride).  hash_type: libecc's hash_alg_type numbers (hash/hash_algs.h) 1 = SHA224, 2 = SHA256, 3 = SHA384,
+ * 4 = SHA512 -- the digests are FIPS 180-4's, the bytes libecc's hfunc_* produce.  Everything else is ec_ecdsa_verify_batch_fmt /
+ * ec_eddsa_verify_batch; for EdDSA the slot holds what the verifier hashes, dom2 || R || A || PH(M) (Ed25519: SHA-512).
+ * Why: end to end, a libecc application spends more host time hashing short messages (0.3 - 0.5 us each in portable C) than on
+ * everything else it does per signature; a million short messages are less than 0.1 ms of one kernel. */
+int ec_ecdsa_verify_msg_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *pubkeys, int pub_fmt,
+				  const uint8_t *sigs, int hash_type, const uint8_t *msg_slots, uint32_t msg_stride, uint8_t *result);
+int ec_eddsa_verify_msg_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs,
+			      const uint8_t *hash_slots, uint32_t stride, uint8_t *result);
 /* ECDSA signing with caller-supplied nonces: per item the tail of ec_sign / __ecdsa_sign_finalize
  * (sig/ecdsa_common.c:318-586) -- kG = prj_pt_mul(k, G), r = kG.x mod q, s = k^-1 (x r + e) mod q --
  * with h = H(m) and the nonce k supplied by the caller (random, or RFC 6979 computed on the host;
@@ -411,6 +422,10 @@ int ecamd_multi_ecdsa_verify_batch(ecamd_multi *m, const ecamd_mcurve *curve, ui
 				   const uint8_t *sigs, const uint8_t *digests, uint32_t digest_len, uint8_t *result);
 int ecamd_multi_ecdsa_verify_batch_fmt(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *pubkeys, int pub_fmt,
 				       const uint8_t *sigs, const uint8_t *digests, uint32_t digest_len, uint8_t *result);
+int ecamd_multi_ecdsa_verify_msg_batch_fmt(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *pubkeys, int pub_fmt,
+					   const uint8_t *sigs, int hash_type, const uint8_t *msg_slots, uint32_t msg_stride, uint8_t *result);
+int ecamd_multi_eddsa_verify_msg_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs,
+				       const uint8_t *hash_slots, uint32_t stride, uint8_t *result);
 int ecamd_multi_ecdsa_sign_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *privs,
 				 const uint8_t *nonces, const uint8_t *digests, uint32_t digest_len, uint8_t *sigs,
 				 uint8_t *status);

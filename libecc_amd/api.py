@@ -14,6 +14,7 @@ EXPORTED_SYMBOLS = [
     "ec_prj_pt_mul_batch_dev", "ecamd_ctx_synchronize", "ec_prj_pt_add_batch", "ec_prj_pt_dbl_batch",
     "ec_fp_op_batch", "ec_ecdsa_verify_batch", "ec_ecdsa_verify_batch_fmt", "ec_ecdsa_sign_batch", "ec_ecccdh_derive_batch", "ec_xdh_batch",
     "ec_prj_pt_mul_batch_fmt", "ec_prj_pt_unique_batch", "ec_structured_pub_key_import_batch",
+    "ec_ecdsa_verify_msg_batch_fmt", "ec_eddsa_verify_msg_batch", "ecamd_multi_ecdsa_verify_msg_batch_fmt", "ecamd_multi_eddsa_verify_msg_batch",
     "ec_prj_pt_op_batch_fmt", "ec_prj_pt_unprotected_mult_batch", "ecamd_multi_prj_pt_op_batch_fmt", "ecamd_multi_prj_pt_unprotected_mult_batch",
     "ec_aff_pt_y_from_x_batch", "ec_point_decompress_batch", "ec_structured_sig_import_batch", "ec_structured_key_pair_import_batch",
     "ec_eddsa_verify_batch", "ec_eddsa_verify_all_batch", "ec_ecdsa_verify_batch_dev", "ec_eddsa_verify_batch_dev", "ec_xdh_batch_dev",
@@ -261,6 +262,33 @@ class Curve:
         res = C.create_string_buffer(max(1, n))
         _chk(self.L, self.L.ec_ecdsa_verify_batch(self.ctx.h, self.h, n, pubs, sigs, digests, hlen, res),
              "ec_ecdsa_verify_batch")
+        return res.raw[:n]
+
+    @staticmethod
+    def msg_slots(msgs, stride=None):
+        """fixed-stride slots (u32 little-endian length + bytes) of a list of messages, as the *_msg_* entry points take them"""
+        stride = stride or ((4 + max([len(m) for m in msgs] + [0]) + 3) // 4) * 4
+        buf = bytearray(stride * len(msgs))
+        for i, m in enumerate(msgs):
+            buf[stride * i:stride * i + 4] = len(m).to_bytes(4, "little")
+            buf[stride * i + 4:stride * i + 4 + len(m)] = m
+        return bytes(buf), stride
+
+    def ecdsa_verify_msgs(self, pubs, pub_fmt, sigs, hash_type, msgs):
+        """ECDSA verification with H(m) computed on the device (hash_type 1..4 = SHA-224/256/384/512); msgs: list of bytes"""
+        n = len(msgs)
+        slots, stride = self.msg_slots(msgs)
+        res = C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_ecdsa_verify_msg_batch_fmt(self.ctx.h, self.h, n, pubs, pub_fmt, sigs, hash_type, slots, stride, res),
+             "ec_ecdsa_verify_msg_batch_fmt")
+        return res.raw[:n]
+
+    def eddsa_verify_msgs(self, pubkeys, sigs, hash_inputs):
+        """Ed25519 verification with hram = SHA-512(dom2 || R || A || PH(M)) computed on the device; hash_inputs: list of bytes"""
+        n = len(hash_inputs)
+        slots, stride = self.msg_slots(hash_inputs)
+        res = C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_eddsa_verify_msg_batch(self.ctx.h, self.h, n, pubkeys, sigs, slots, stride, res), "ec_eddsa_verify_msg_batch")
         return res.raw[:n]
 
     def ecdsa_verify_fmt(self, pubs, pub_fmt, sigs, digests, hlen):

@@ -29,10 +29,10 @@ int get_random(unsigned char *buf, u16 len)
 	u16 done = 0;
 	/* libecc_amd_compat.h: unless the application lifts it (ecamd_compat_set_concurrent_random), the batch forms serialise
 	 * their calls into this function; count the entries that overlap another one (checked at the end of the run) */
-	if (__atomic_exchange_n(&g_rand_inside, 1, __ATOMIC_ACQ_REL)) {
-		__atomic_add_fetch(&g_rand_overlaps, 1, __ATOMIC_RELAXED);
+	if (g_rand_expect_serial && __atomic_exchange_n(&g_rand_inside, 1, __ATOMIC_ACQ_REL)) {
+		__atomic_add_fetch(&g_rand_overlaps, 1, __ATOMIC_RELAXED);   /* (not in bench mode: the shared flag would be the bottleneck there) */
 	}
-#define RAND_LEAVE() __atomic_store_n(&g_rand_inside, 0, __ATOMIC_RELEASE)
+#define RAND_LEAVE() do { if (g_rand_expect_serial) __atomic_store_n(&g_rand_inside, 0, __ATOMIC_RELEASE); } while (0)
 	while (done < len) {
 		unsigned int take;
 		if (pos == sizeof(pool)) {
@@ -1074,6 +1074,21 @@ static void bench_secret_half(u32 n)
 int main(int argc, char **argv)
 {
 	const u32 n = (argc > 1) ? (u32)atoi(argv[1]) : 256;
+	if (argc > 2 && !strcmp(argv[1], "benchv")) {
+		/* only the ECDSA secp256r1 (or, with a third argument "384", secp384r1) verification of `bench` (for profiling runs) */
+		const u32 bn = 1u << (u32)atoi(argv[2]);
+		if (ecamd_compat_init(NULL, 0, 0)) {
+			printf("no GPU path\n");
+			return 3;
+		}
+		if (argc > 3 && !strcmp(argv[3], "384")) {
+			bench_verify("SECP384R1", ECDSA, SHA384, "ECDSA/SECP384R1/SHA384", bn);
+		} else {
+			bench_verify("SECP256R1", ECDSA, SHA256, "ECDSA/SECP256R1/SHA256", bn);
+		}
+		ecamd_compat_shutdown();
+		return 0;
+	}
 	if (argc > 2 && !strcmp(argv[1], "bench")) {
 		const u32 bn = 1u << (u32)atoi(argv[2]);
 		if (ecamd_compat_init(NULL, 0, 0)) {

@@ -15,6 +15,7 @@
  */
 #define _GNU_SOURCE
 #include <pthread.h>
+#include <time.h>
 #include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -613,11 +614,26 @@ static void pool_stop(void)
  * CALLING thread once per chunk, in order, when the chunk is packed; a chunk is unpacked once its gpu call has returned.
  * Returns 0, or -1 as soon as a gpu call fails.  g_call_mu held.
  */
+/* $ECAMD_COMPAT_TIMING: one line per pipeline run on stderr -- where the calling thread's time went (waiting for the pool to pack a
+ * chunk | inside the GPU entry point, copies included | the rest: helping to pack / unpack, draining) */
+static double now_ms(void)
+{
+	struct timespec t;
+	clock_gettime(CLOCK_MONOTONIC, &t);
+	return 1e3 * (double)t.tv_sec + 1e-6 * (double)t.tv_nsec;
+}
+
 static int pipeline_run(u32 n, u32 chunk, range_fn pack, gpu_fn gpu, range_fn unpack, void *arg)
 {
 	pipe_job J;
 	u32 c, lo, hi;
 	int ret = 0;
+	static int timing = -1;
+	double t_start = 0, t_wait = 0, t_gpu = 0, t0;
+	if (timing < 0) {
+		timing = getenv("ECAMD_COMPAT_TIMING") ? 1 : 0;
+	}
+	t_start = timing ? now_ms() : 0;
 	if (n == 0) {
 		return 0;
 	}
@@ -670,6 +686,7 @@ static int pipeline_run(u32 n, u32 chunk, range_fn pack, gpu_fn gpu, range_fn un
 	pthread_mutex_unlock(&g_pool.mu);
 	for (c = 0; c < J.nchunks; c++) {
 		/* wait for chunk c to be packed; help meanwhile */
+		t0 = timing ? now_ms() : 0;
 		while (AT_LOAD(&J.pack_left[c]) != 0) {
 			if (take_pack(&J)) {
 				continue;
@@ -682,11 +699,18 @@ static int pipeline_run(u32 n, u32 chunk, range_fn pack, gpu_fn gpu, range_fn un
 		}
 		lo = c * J.chunk_grains * GRAIN;
 		hi = (lo + chunk < n) ? lo + chunk : n;
+		if (timing) {
+			t_wait += now_ms() - t0;
+			t0 = now_ms();
+		}
 		if (gpu && gpu(lo, hi, arg)) {
 			ret = -1;
 			AT_STORE(&J.abort, 1);
 			job_notify(&J);
 			break;
+		}
+		if (timing) {
+			t_gpu += now_ms() - t0;
 		}
 		pthread_mutex_lock(&J.mu);
 		AT_STORE(&J.gpu_done[c], 1);
@@ -706,6 +730,11 @@ static int pipeline_run(u32 n, u32 chunk, range_fn pack, gpu_fn gpu, range_fn un
 	pthread_cond_destroy(&J.cv);
 	free(J.pack_left);
 	free(J.gpu_done);
+	if (timing) {
+		const double tot = now_ms() - t_start;
+		fprintf(stderr, "libecc_amd compat timing: %u items, %u chunks of %u, %d threads: total %.2f ms = pack wait %.2f + gpu entry point %.2f + rest %.2f\n",
+			n, J.nchunks, chunk, g_pool.nth + 1, tot, t_wait, t_gpu, tot - t_wait - t_gpu);
+	}
 	return ret;
 }
 
@@ -719,6 +748,23 @@ static void parallel_for(u32 n, range_fn fn, void *arg)
  * ECDSA verifications (profiles/r3b_compat_end_to_end.md): 12.8 / 22.4 / 27.9 / 28.8 M/s at 2^15 / 2^16 / 2^17 / 2^18 items per
  * chunk.  Default: a quarter of the batch per device, between 2^15 and 2^18 ($ECAMD_COMPAT_CHUNK fixes it); the multi-GPU
  * layer cuts every chunk into one shard per device. */
+/* Verification (round 4, measured: profiles/r4i_typed_boundary.md): packing a signature is half a millisecond per 2^18 items on the
+ * pool, so overlapping it with the GPU gains at most that, while quarter-batch GPU calls cost more -- the kernels of a 2^18-item launch run
+ * at 0.8 - 0.9 of their 2^20 rate and the calls follow each other with their copies in between.  One chunk per device up to 2^20 items
+ * (the C ABI's own double-buffered staging overlaps copies and kernels inside the call); $ECAMD_COMPAT_CHUNK still fixes it. */
+static u32 chunk_items_verify(u32 n)
+{
+	const int nd = g_multi ? ecamd_multi_size(g_multi) : 1;
+	u64 c;
+	if (g_chunk) {
+		c = (u64)g_chunk * (u64)(nd > 0 ? nd : 1);
+	} else {
+		c = (u64)(1u << 20) * (u64)(nd > 0 ? nd : 1);
+	}
+	(void)n;
+	return c > 0x40000000ull ? 0x40000000u : (u32)c;
+}
+
 static u32 chunk_items_for(u32 per_device, u32 n)
 {
 	const int nd = g_multi ? ecamd_multi_size(g_multi) : 1;
@@ -2682,7 +2728,54 @@ typedef struct {
 	int ph, dom, is448;
 	u32 ph_len;              /* bytes of PH(M) that enter the main hash */
 	int all_only, all_ok;    /* EdDSA: only the conjunction is wanted; its value so far */
+	int aff_keys;            /* ECDSA, round 4: every key of the group has Z = 1 -- they travel as affine X || Y and the device skips its
+	                          * projective import (k_prj_import: a quarter of the kernel time of a secp256r1 verification otherwise) */
+	u32 kw;                  /* ... octets of a packed key: 2 * clen or 3 * clen */
+	int dev_hash;            /* round 4: SHA-2 of short messages on the device -- 0 host hashing, else the hash_alg_type number */
+	u32 slot;                /* ... stride of a message slot in dg (u32 length + bytes), a multiple of 4 */
 } ver_job;
+
+/* Hashing on the device (ec_ecdsa_verify_msg_batch_fmt / ec_eddsa_verify_msg_batch of libecc_amd.h): for SHA-224 / 256 / 384 / 512
+ * and a group whose longest hash input fits a 256-byte slot, the pack step copies the message instead of hashing it -- libecc's
+ * portable hfunc_* cost 0.3 - 0.5 us per short message and thread, more than everything else the layer does per signature.
+ * $ECAMD_COMPAT_HOST_HASH keeps the hashing on the host (through the application's hash_maps[], as before). */
+#define DEV_HASH_MAX_SLOT 256u
+static int dev_hash_type(const hash_mapping *hm)
+{
+	if (getenv("ECAMD_COMPAT_HOST_HASH")) {
+		return 0;
+	}
+	switch (hm->type) {
+	case SHA224: return 1;
+	case SHA256: return 2;
+	case SHA384: return 3;
+	case SHA512: return 4;
+	default: return 0;
+	}
+}
+/* stride of the slots for the items idx[0..cnt) with `extra` bytes in front of every message, or 0 when one does not fit */
+static u32 dev_hash_slot(const ver_job *J, u32 cnt, u32 extra)
+{
+	u32 j, mx = 0;
+	for (j = 0; j < cnt; j++) {
+		const u32 l = J->m_len[J->idx[j]];
+		mx = l > mx ? l : mx;
+		if (mx > DEV_HASH_MAX_SLOT) {
+			return 0;
+		}
+	}
+	mx = (4 + extra + mx + 3u) & ~3u;
+	return mx <= DEV_HASH_MAX_SLOT ? mx : 0;
+}
+static void slot_put(u8 *slot, u32 stride, const u8 *a, u32 alen, const u8 *b, u32 blen, const u8 *m, u32 mlen)
+{
+	const u32 len = alen + blen + mlen;
+	slot[0] = (u8)len; slot[1] = (u8)(len >> 8); slot[2] = (u8)(len >> 16); slot[3] = (u8)(len >> 24);
+	if (alen) memcpy(slot + 4, a, alen);
+	if (blen) memcpy(slot + 4 + alen, b, blen);
+	if (mlen) memcpy(slot + 4 + alen + blen, m, mlen);
+	memset(slot + 4 + len, 0, stride - 4 - len);
+}
 
 /* ---- ECDSA / DECDSA ---- */
 static void ecdsa_pack(u32 lo, u32 hi, void *arg)
@@ -2700,14 +2793,27 @@ static void ecdsa_pack(u32 lo, u32 hi, void *arg)
 		 * multiplication does (curves/prj_pt.c:1765). */
 		bad = pub_key_check_initialized_and_type(pk, J->sig_type) || pk->params != J->params || !J->s[i] ||
 		      J->s_len[i] != J->siglen || (!J->m[i] && J->m_len[i]);
-		bad = bad || prj_to_be(J->pk + (size_t)j * 3 * J->clen, J->clen, &pk->y, &(J->params->ec_curve));
-		bad = bad || J->hm->hfunc_init(&hc) || J->hm->hfunc_update(&hc, J->m[i], J->m_len[i]) ||
-		      J->hm->hfunc_finalize(&hc, J->dg + (size_t)j * J->hlen);
+		if (!bad && J->aff_keys) {
+			/* (Z = 1 was established for the whole group by ecdsa_keys_affine) */
+			u8 tmp[3 * 72];
+			bad = prj_to_be(tmp, J->clen, &pk->y, &(J->params->ec_curve));
+			memcpy(J->pk + (size_t)j * J->kw, tmp, J->kw);
+		} else {
+			bad = bad || prj_to_be(J->pk + (size_t)j * J->kw, J->clen, &pk->y, &(J->params->ec_curve));
+		}
+		if (J->dev_hash) {
+			if (!bad) {
+				slot_put(J->dg + (size_t)j * J->slot, J->slot, NULL, 0, NULL, 0, J->m[i], J->m_len[i]);
+			}
+		} else {
+			bad = bad || J->hm->hfunc_init(&hc) || J->hm->hfunc_update(&hc, J->m[i], J->m_len[i]) ||
+			      J->hm->hfunc_finalize(&hc, J->dg + (size_t)j * J->hlen);
+		}
 		J->pre[j] = bad ? 1 : 0;
 		if (bad) {
-			memset(J->pk + (size_t)j * 3 * J->clen, 0xff, 3 * J->clen);
+			memset(J->pk + (size_t)j * J->kw, 0xff, J->kw);
 			memset(J->sg + (size_t)j * J->siglen, 0, J->siglen);
-			memset(J->dg + (size_t)j * J->hlen, 0, J->hlen);
+			memset(J->dg + (size_t)j * (J->dev_hash ? J->slot : J->hlen), 0, J->dev_hash ? J->slot : J->hlen);
 		} else {
 			memcpy(J->sg + (size_t)j * J->siglen, J->s[i], J->siglen);
 		}
@@ -2717,18 +2823,48 @@ static void ecdsa_pack(u32 lo, u32 hi, void *arg)
 static int ecdsa_ver_gpu(u32 lo, u32 hi, void *arg)
 {
 	ver_job *J = (ver_job *)arg;
-	if (ecamd_multi_ecdsa_verify_batch_fmt(g_multi, J->e->mc, hi - lo, J->pk + (size_t)lo * 3 * J->clen, ECAMD_PT_PROJECTIVE,
-					       J->sg + (size_t)lo * J->siglen, J->dg + (size_t)lo * J->hlen, J->hlen, J->res + lo)) {
+	const int fmt = J->aff_keys ? ECAMD_PT_AFFINE : ECAMD_PT_PROJECTIVE;
+	const int r = J->dev_hash
+			      ? ecamd_multi_ecdsa_verify_msg_batch_fmt(g_multi, J->e->mc, hi - lo, J->pk + (size_t)lo * J->kw, fmt,
+								       J->sg + (size_t)lo * J->siglen, J->dev_hash, J->dg + (size_t)lo * J->slot, J->slot,
+								       J->res + lo)
+			      : ecamd_multi_ecdsa_verify_batch_fmt(g_multi, J->e->mc, hi - lo, J->pk + (size_t)lo * J->kw, fmt,
+								   J->sg + (size_t)lo * J->siglen, J->dg + (size_t)lo * J->hlen, J->hlen, J->res + lo);
+	if (r) {
 		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
 		return -1;
 	}
 	return 0;
 }
 
+/* does every usable key of the group have Z = 1 (the form every import and every batch result leaves)?  Keys that fail the
+ * checks of the pack step do not count: they are rejected there whatever their format. */
+typedef struct {
+	const ver_job *J;
+	u32 not_affine;
+} affk_job;
+static void ecdsa_keys_affine(u32 lo, u32 hi, void *arg)
+{
+	affk_job *A = (affk_job *)arg;
+	u32 j;
+	for (j = lo; j < hi && !AT_LOAD(&A->not_affine); j++) {
+		const ec_pub_key *pk = A->J->pub_keys[A->J->idx[j]];
+		int one = 0;
+		if (pub_key_check_initialized_and_type(pk, A->J->sig_type) || pk->params != A->J->params || prj_pt_check_initialized(&pk->y) ||
+		    fp_check_initialized(&pk->y.Z)) {
+			continue;
+		}
+		if (nn_isone(&pk->y.Z.fp_val, &one) || !one) {
+			AT_STORE(&A->not_affine, 1);
+		}
+	}
+}
+
 /* results[i] for the items idx[0..cnt) that share `params` */
 static int ecdsa_group(ver_job *J, u32 cnt, int *results)
 {
 	u32 j;
+	affk_job AK;
 	J->clen = J->e->clen;
 	J->qlen = J->e->qlen;
 	J->siglen = 2 * (u32)BYTECEIL(J->params->ec_gen_order_bitlen);   /* ECDSA_SIGLEN */
@@ -2736,15 +2872,27 @@ static int ecdsa_group(ver_job *J, u32 cnt, int *results)
 		return -1;
 	}
 	J->hlen = J->hm->digest_size;
-	J->pk = buf_get(0, (size_t)cnt * 3 * J->clen);
+	J->dev_hash = dev_hash_type(J->hm);
+	J->slot = J->dev_hash ? dev_hash_slot(J, cnt, 0) : 0;
+	if (!J->slot) {
+		J->dev_hash = 0;
+	}
+	AK.J = J;
+	AK.not_affine = getenv("ECAMD_COMPAT_PRJ_KEYS") ? 1 : 0;
+	if (!AK.not_affine) {
+		parallel_for(cnt, ecdsa_keys_affine, &AK);
+	}
+	J->aff_keys = AT_LOAD(&AK.not_affine) ? 0 : 1;
+	J->kw = (J->aff_keys ? 2u : 3u) * J->clen;
+	J->pk = buf_get(0, (size_t)cnt * J->kw);
 	J->sg = buf_get(1, (size_t)cnt * J->siglen);
-	J->dg = buf_get(2, (size_t)cnt * J->hlen);
+	J->dg = buf_get(2, (size_t)cnt * (J->dev_hash ? J->slot : J->hlen));
 	J->pre = buf_get(3, cnt);
 	J->res = buf_get(4, cnt);
 	if (!J->pk || !J->sg || !J->dg || !J->pre || !J->res) {
 		return -1;
 	}
-	if (pipeline_run(cnt, chunk_items_for(g_chunk, cnt), ecdsa_pack, ecdsa_ver_gpu, NULL, J)) {
+	if (pipeline_run(cnt, chunk_items_verify(cnt), ecdsa_pack, ecdsa_ver_gpu, NULL, J)) {
 		return -1;
 	}
 	note_items(cnt);
@@ -2793,6 +2941,19 @@ static void eddsa_pack(u32 lo, u32 hi, void *arg)
 		/* the encoding of the key as the reference hashes it -- eddsa_export_pub_key: Weierstrass -> Edwards -> octets -- was
 		 * computed on the device for the whole group (eddsa_group; libecc's own export costs about 1.5 ms of CPU per key) */
 		bad = bad || J->pre[j];
+		if (J->dev_hash) {
+			/* hram = SHA-512(R || A || M) on the device: the slot holds the hash input */
+			if (!bad) {
+				slot_put(J->dg + (size_t)j * J->slot, J->slot, J->s[i], J->klen, kenc, J->klen, J->m[i], J->m_len[i]);
+				memcpy(J->sg + (size_t)j * J->siglen, J->s[i], J->siglen);
+			} else {
+				memset(kenc, 0xff, J->klen);
+				memset(J->sg + (size_t)j * J->siglen, 0xff, J->siglen);
+				memset(J->dg + (size_t)j * J->slot, 0, J->slot);
+			}
+			J->pre[j] = bad ? 1 : 0;
+			continue;
+		}
 		bad = bad || J->hm->hfunc_init(&hc);
 		if (!bad && J->dom) {
 			bad = dom_prefix(J->hm, &hc, J->is448, J->ph, ad, adl);
@@ -2819,8 +2980,11 @@ static void eddsa_pack(u32 lo, u32 hi, void *arg)
 static int eddsa_ver_gpu(u32 lo, u32 hi, void *arg)
 {
 	ver_job *J = (ver_job *)arg;
-	if (ecamd_multi_eddsa_verify_batch(g_multi, J->e->mc, hi - lo, J->pk + (size_t)lo * J->klen, J->sg + (size_t)lo * J->siglen,
-					   J->dg + (size_t)lo * J->hlen, J->hlen, J->res + lo)) {
+	const int r = J->dev_hash ? ecamd_multi_eddsa_verify_msg_batch(g_multi, J->e->mc, hi - lo, J->pk + (size_t)lo * J->klen,
+								       J->sg + (size_t)lo * J->siglen, J->dg + (size_t)lo * J->slot, J->slot, J->res + lo)
+				  : ecamd_multi_eddsa_verify_batch(g_multi, J->e->mc, hi - lo, J->pk + (size_t)lo * J->klen, J->sg + (size_t)lo * J->siglen,
+								   J->dg + (size_t)lo * J->hlen, J->hlen, J->res + lo);
+	if (r) {
 		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
 		return -1;
 	}
@@ -2884,9 +3048,18 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
 	if (J->klen != (J->is448 ? 57u : 32u) || J->clen != (J->is448 ? 56u : 32u)) {
 		return -1;
 	}
+	/* hashing on the device: the plain Ed25519 variant (no dom2 prefix, no pre-hash), item-by-item results */
+	J->dev_hash = 0;
+	J->slot = 0;
+#if defined(WITH_SIG_EDDSA25519)
+	if (J->sig_type == EDDSA25519 && !J->all_only && !J->dom && !J->ph && dev_hash_type(J->hm) == 4) {
+		J->slot = dev_hash_slot(J, cnt, 2 * J->klen);
+		J->dev_hash = J->slot ? 4 : 0;
+	}
+#endif
 	J->pk = buf_get(0, (size_t)cnt * J->klen);
 	J->sg = buf_get(1, (size_t)cnt * J->siglen);
-	J->dg = buf_get(2, (size_t)cnt * J->hlen);
+	J->dg = buf_get(2, (size_t)cnt * (J->dev_hash ? J->slot : J->hlen));
 	J->pre = buf_get(3, cnt);
 	J->res = buf_get(4, cnt);
 	J->kprj = buf_get(5, (size_t)cnt * 3 * J->clen);
@@ -2910,7 +3083,7 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
 		}
 		return 0;
 	}
-	if (pipeline_run(cnt, chunk_items_for(g_chunk, cnt), eddsa_pack, eddsa_ver_gpu, NULL, J)) {
+	if (pipeline_run(cnt, chunk_items_verify(cnt), eddsa_pack, eddsa_ver_gpu, NULL, J)) {
 		return -1;
 	}
 	note_items(cnt);

@@ -3502,6 +3502,136 @@ hipError_t G29_CAT(ecamd_g29_ecdsa_prep_, G29_TAG)(int qgslot, const EcamdEcdsaP
 }
 #endif
 
+// ------------------------------------------------------------------------------------------
+// Round 4: prj_pt_import_from_buf + prj_pt_unique for n projective X || Y || Z triples on this unit's field (what k_prj_import<NW> of
+// ecamd_kernels.hip does on saturated words with one Fermat inversion per item): range check of every coordinate, the projective
+// curve equation Y^2 Z = X^3 + a X Z^2 + b Z^3 (on the unit's image curve when the handle computes on an isomorphic one: the factors
+// u^2, u^3 ride on ix, iy and cancel in the equation), Z = 0 -> infinity, and the affine form by ONE inversion per `items` triples
+// (Montgomery's trick; the prefix product of a triple rests in its own output slot until the way back).  The libecc-typed layer hands
+// over keys and points as live projective limbs: at 2^20 keys the saturated kernel was a quarter of a secp256r1 verification's
+// kernel time (profiles/r4i_typed_boundary.md).  Lane t owns the triples t, t + nthreads, ...
+// ------------------------------------------------------------------------------------------
+template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_prj_import_g(EcamdPrjInArgs A, int gslot, u32 nthreads, int items)
+{
+	typedef Lay<PB> L;
+	typedef typename Cls<PB>::FM FM;
+	typedef typename Cls<PB>::FC FC;
+	constexpr int NL = L::NL, NW = L::NW;
+	const u32 t = blockIdx.x * 64 + threadIdx.x;
+	if (t >= nthreads) {
+		return;
+	}
+	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	const FC onec = constant<FC>(K.one);
+	const int clen = (int)A.clen;
+	// one triple: Montgomery / image-curve forms of X, Y, Z and its status (0 finite / 1 error / 2 infinity)
+	auto load = [&](u32 i, FM &xm, FM &ym, FM &zm) -> u32 {
+		const u8 *src = A.in + (size_t)i * 3 * clen;
+		u32 xw[NW], yw[NW], zw[NW];
+		load_be<NW>(src, clen, xw);
+		load_be<NW>(src + clen, clen, yw);
+		load_be<NW>(src + 2 * clen, clen, zw);
+		const auto xd = from_words<PB, NW>(xw), yd = from_words<PB, NW>(yw), zd = from_words<PB, NW>(zw);
+		u32 bx = 0, by = 0, bz = 0, xnz = 0, ynz = 0, znz = 0;
+#pragma unroll
+		for (int j = 0; j < NL; j++) {
+			bx = (xd.l[j] - K.p[j] - bx) >> 31;
+			by = (yd.l[j] - K.p[j] - by) >> 31;
+			bz = (zd.l[j] - K.p[j] - bz) >> 31;
+			xnz |= xd.l[j];
+			ynz |= yd.l[j];
+			znz |= zd.l[j];
+		}
+		bool ok = (bx != 0) & (by != 0) & (bz != 0);
+		xm = weaken<FM>(mul(xd, constant<FC>(K.ix), K));
+		ym = weaken<FM>(mul(yd, constant<FC>(K.iy), K));
+		zm = weaken<FM>(mul(zd, constant<FC>(K.r2), K));
+		{
+			// Y^2 Z == (X^2 + a Z^2) X + b Z^3
+			const FM z2 = weaken<FM>(sqr(zm, K));
+			const auto t1 = mulc(carry(add(sqr(xm, K), mul(constant<FC>(K.a), z2, K))), xm, K);
+			const auto rhs = add(t1, mul(mul(constant<FC>(K.b), z2, K), zm, K));
+			const auto dif = carry(sub_auto<1>(rhs, mul(sqr(ym, K), zm, K), K));
+			ok = ok & is_zero_mulout(mulc(dif, onec, K), K);
+		}
+		if (!ok) {
+			return 1u;
+		}
+		if (znz == 0) {
+			// (0 : 0 : 0) satisfies the equation too: prj_pt_unique reports it as infinity, a multiplication fails on it
+			return (A.for_mul && xnz == 0 && ynz == 0) ? 1u : 2u;
+		}
+		return 0u;
+	};
+	FM c = weaken<FM>(onec);
+#pragma unroll 1
+	for (int j = 0; j < items; j++) {
+		const u32 i = t + (u32)j * nthreads;
+		if (i >= A.n) {
+			break;
+		}
+		FM xm, ym, zm;
+		const u32 st = load(i, xm, ym, zm);
+		A.pre[i] = (u8)st;
+		u8 *dst = A.aff + (size_t)i * 2 * clen;
+		// the prefix product BEFORE this triple parks in its output slot (NL words fit 2 clen bytes for every size libecc has)
+#pragma unroll
+		for (int w = 0; w < NL; w++) {
+			const u32 v = c.l[w];
+			dst[4 * w] = (u8)v;
+			dst[4 * w + 1] = (u8)(v >> 8);
+			dst[4 * w + 2] = (u8)(v >> 16);
+			dst[4 * w + 3] = (u8)(v >> 24);
+		}
+		if (st == 0) {
+			c = weaken<FM>(mul(c, zm, K));
+		}
+	}
+	FM tinv = inv<PB>(c, K);
+	const FC ex = constant<FC>(K.ex), ey = constant<FC>(K.ey);
+#pragma unroll 1
+	for (int j = items - 1; j >= 0; j--) {
+		const u32 i = t + (u32)j * nthreads;
+		if (i >= A.n) {
+			continue;
+		}
+		u8 *dst = A.aff + (size_t)i * 2 * clen;
+		if (A.pre[i] != 0) {
+			for (int b = 0; b < 2 * clen; b++) {
+				dst[b] = 0;
+			}
+			continue;
+		}
+		FM xm, ym, zm, cp;
+		(void)load(i, xm, ym, zm);
+#pragma unroll
+		for (int w = 0; w < NL; w++) {
+			cp.l[w] = (u32)dst[4 * w] | ((u32)dst[4 * w + 1] << 8) | ((u32)dst[4 * w + 2] << 16) | ((u32)dst[4 * w + 3] << 24);
+		}
+		const FM zi = weaken<FM>(mul(tinv, cp, K));
+		tinv = weaken<FM>(mul(tinv, zm, K));
+		u32 dg[NL], ow[NW];
+		canonical_digits(dg, mul(mul(xm, zi, K), ex, K), K);
+		to_words<NL, NW>(ow, dg);
+		store_be<NW>(dst, clen, ow);
+		canonical_digits(dg, mul(mul(ym, zi, K), ey, K), K);
+		to_words<NL, NW>(ow, dg);
+		store_be<NW>(dst + clen, clen, ow);
+	}
+}
+
+hipError_t G29_CAT(ecamd_g29_prj_import_, G29_TAG)(int gslot, const EcamdPrjInArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	static_assert(4 * Lay<G29_PB>::NL <= 2 * ((G29_PB + 7) / 8), "the prefix product must fit the output slot");
+	const int items = a.n >= (1u << 19) ? 8 : (a.n >= (1u << 17) ? 4 : 2);
+	const uint32_t nthreads = (a.n + (uint32_t)items - 1) / (uint32_t)items;
+	hipLaunchKernelGGL((k_prj_import_g<G29_PB, G29_FLAV>), dim3((nthreads + 63) / 64), dim3(64), 0, s, a, gslot, nthreads, items);
+	return hipGetLastError();
+}
+
 hipError_t G29_CAT(ecamd_g29_upload_, G29_TAG)(int slot, const void *img, size_t bytes)
 {
 	typedef CurveG<Lay<G29_PB>::NL> CK;
@@ -3726,6 +3856,48 @@ hipError_t ecamd_g29_ecdsa_prep(int qbits, int qgslot, const EcamdEcdsaPrepArgs 
 {
 	switch (qbits) {
 #define X(PB) case PB: return ecamd_g29_ecdsa_prep_##PB(qgslot, a, scratch, kp, s);
+		G29_FOR_PB(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+}
+
+#define X(PB) hipError_t ecamd_g29_prj_import_##PB(int gslot, const EcamdPrjInArgs &a, hipStream_t s);
+G29_FOR_PB(X)
+X(521m)
+X(255c)
+X(384n)
+X(224s)
+X(192s)
+X(256k)
+X(448g)
+#undef X
+// k_prj_import_g on the unit (pbits, flavour)
+hipError_t ecamd_g29_prj_import(int pbits, int gslot, const EcamdPrjInArgs &a, hipStream_t s, int flavour)
+{
+	if (pbits == 521 && flavour == 1) {
+		return ecamd_g29_prj_import_521m(gslot, a, s);
+	}
+	if (pbits == 255 && flavour == 2) {
+		return ecamd_g29_prj_import_255c(gslot, a, s);
+	}
+	if (pbits == 384 && flavour == 3) {
+		return ecamd_g29_prj_import_384n(gslot, a, s);
+	}
+	if (pbits == 224 && flavour == 6) {
+		return ecamd_g29_prj_import_224s(gslot, a, s);
+	}
+	if (pbits == 192 && flavour == 7) {
+		return ecamd_g29_prj_import_192s(gslot, a, s);
+	}
+	if (pbits == 256 && flavour == 4) {
+		return ecamd_g29_prj_import_256k(gslot, a, s);
+	}
+	if (pbits == 448 && flavour == 5) {
+		return ecamd_g29_prj_import_448g(gslot, a, s);
+	}
+	switch (pbits) {
+#define X(PB) case PB: return ecamd_g29_prj_import_##PB(gslot, a, s);
 		G29_FOR_PB(X)
 #undef X
 	default: return hipErrorInvalidValue;

@@ -287,6 +287,8 @@ struct ecamd_curve {
 	EcamdYfromXArgs sqrt_tmpl;
 	bool is_p256;    // exactly secp256r1: hand-specialised radix-2^29 Jacobian kernel
 	int gslot;       // constant slot of the generic radix-2^29 Jacobian kernel (-1: none)
+	int gpslot;      // secp256r1 handles only (their scalar multiplication has its own kernels): slot of the dense 256-bit radix-2^29 unit holding
+			 // the curve, for k_prj_import_g (-1: none, k_prj_import<8> serves)
 	int gqslot;      // constant slot of the dense radix-2^29 unit of the ORDER's size holding q as its modulus (k_ecdsa_prep_g; -1: none)
 	int gflavour;    // 0 dense reduction, 1 secp521r1 (p = 2^521 - 1), 2 p = 2^255 - 19, 3 secp384r1's prime, 4 secp256k1's prime, 5 p = 2^448 - 2^224 - 1,
 	                 // 6 secp224r1's prime, 7 secp192r1's prime (3, 6, 7: signed sparse Montgomery reduction)
@@ -397,9 +399,11 @@ extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
 	memset(c->hbuf_bytes, 0, sizeof(c->hbuf_bytes));
 	{
 		const char *e = getenv("ECAMD_HOST_CHUNK");
-		c->host_chunk = e ? (uint32_t)strtoul(e, nullptr, 10) : (1u << 18);
+		// (round 4: 2^19 -- a 2^18-item launch runs the window kernels at 0.92 of their 2^20 rate, a 2^19-item one at 0.97,
+		// and two pieces of a 2^20 batch still overlap the second's copy with the first's kernels; profiles/r4_batch_sweep.md)
+		c->host_chunk = e ? (uint32_t)strtoul(e, nullptr, 10) : (1u << 19);
 		if (c->host_chunk == 0) {
-			c->host_chunk = 1u << 18;
+			c->host_chunk = 1u << 19;
 		}
 	}
 	if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -974,6 +978,20 @@ static int upload_g29(ecamd_curve *cv)
 	return upload_g29_mod(cv, cv->p, cv->a, cv->b, cv->pbits, cv->gflavour, &cv->gslot);
 }
 
+// prj_pt_import_from_buf + prj_pt_unique of a batch: the handle's radix-2^29 unit when it has one (one inversion per eight triples),
+// else one Fermat inversion per triple on saturated words.  ECAMD_NO_PRJ_IMPORT_G29 keeps the latter (A/B hook).
+static hipError_t launch_prj_import(const ecamd_curve *cv, const EcamdPrjInArgs &I, hipStream_t s)
+{
+	static const bool off = getenv("ECAMD_NO_PRJ_IMPORT_G29") != nullptr;
+	if (!off && cv->gslot >= 0) {
+		return ecamd_g29_prj_import(cv->pbits, cv->gslot, I, s, cv->gflavour);
+	}
+	if (!off && cv->is_p256 && cv->gpslot >= 0) {
+		return ecamd_g29_prj_import(256, cv->gpslot, I, s, 0);
+	}
+	return ecamd_launch_prj_import(cv->nw, I, s);
+}
+
 // the group order as the modulus of the dense unit of its size (only sizes that unit exists for; failure is not an error:
 // the saturated-word k_ecdsa_prep keeps serving)
 static void upload_g29_order(ecamd_curve *cv)
@@ -1034,7 +1052,10 @@ static void curve_release_slots(ecamd_curve *cv)
 	if (reg && cv->gslot >= 0 && cv->gslot < 8 && key < ECAMD_G29_KEYS && reg->g[key][cv->gslot].ref > 0) {
 		reg->g[key][cv->gslot].ref--;
 	}
-	cv->slot = cv->qslot = cv->gslot = cv->gqslot = -1;
+	if (reg && cv->gpslot >= 0 && cv->gpslot < 8 && reg->g[256][cv->gpslot].ref > 0) {
+		reg->g[256][cv->gpslot].ref--;
+	}
+	cv->slot = cv->qslot = cv->gslot = cv->gqslot = cv->gpslot = -1;
 }
 
 // failure exit of curve construction: releases the handle; msg == NULL keeps the error already recorded
@@ -1049,7 +1070,7 @@ static int curve_abort(ecamd_curve *cv, const char *msg)
 static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 {
 	cv->ctx = nullptr;
-	cv->slot = cv->qslot = cv->gslot = cv->gqslot = -1;
+	cv->slot = cv->qslot = cv->gslot = cv->gqslot = cv->gpslot = -1;
 	cv->d_gen = nullptr;
 	cv->d_comb = nullptr;
 	cv->d_edcomb = nullptr;
@@ -1135,6 +1156,12 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	{
 		std::lock_guard<std::mutex> sl(g_slot_mu);
 		upload_g29_order(cv);
+		if (cv->is_p256 && getenv("ECAMD_NO_FAST_PATH") == nullptr) {
+			int slot = -1;
+			if (upload_g29_mod(cv, cv->p, cv->a, cv->b, 256, 0, &slot) == 0) {
+				cv->gpslot = slot;   // failure is not an error: the saturated-word import keeps serving
+			}
+		}
 	}
 	// generator X || Y, then the two broadcast scalars of the subgroup / cofactor passes: q (qlen bytes) and h (1 byte)
 	std::vector<uint8_t> g((size_t)2 * cv->clen + cv->qlen + 1, 0);
@@ -2207,10 +2234,23 @@ extern "C" int ec_ecdsa_verify_batch_dev(ecamd_ctx *ctx, const ecamd_curve *cv, 
 				       (const uint8_t *)d_digests, hlen, (uint8_t *)d_result, s);
 }
 
-extern "C" int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys,
-				     const uint8_t *sigs, const uint8_t *digests, uint32_t hlen, uint8_t *result)
+// Messages instead of digests (round 4): `data` then holds one fixed-stride SLOT per item -- a little-endian u32 length and the
+// message bytes (ecamd_hash.hip) -- and the digests H(m) are computed on the device (hash_type: libecc's hash_alg_type numbers,
+// SHA224 = 1 ... SHA512 = 4) into stage 17 before the verification core runs; dig_out (host, n x digest length, may be NULL)
+// receives them for the callers that need a digest on the host again.
+static int ecdsa_hash_stage(ecamd_ctx *ctx, int hash_type, uint32_t m, const uint8_t *d_slots, uint32_t stride, uint32_t dlen, hipStream_t s)
 {
-	if (ecdsa_verify_args_ok("ec_ecdsa_verify_batch", ctx, cv, n, pubkeys, sigs, digests, result, hlen)) {
+	if (ensure(&ctx->stage[17], &ctx->stage_bytes[17], (size_t)m * dlen)) {
+		return -1;
+	}
+	HIPCHK(ecamd_launch_sha2_slots(hash_type, d_slots, stride, m, ctx->stage[17], dlen, s));
+	return 0;
+}
+
+static int ecdsa_verify_host_aff(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs,
+				 const uint8_t *data, uint32_t data_stride, int hash_type, uint32_t hlen, uint8_t *result, const char *fn)
+{
+	if (ecdsa_verify_args_ok(fn, ctx, cv, n, pubkeys, sigs, data, result, hlen)) {
 		return -1;
 	}
 	if (n == 0) {
@@ -2219,27 +2259,40 @@ extern "C" int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint
 	std::lock_guard<std::mutex> lk(ctx->mu);
 	HIPCHK(hipSetDevice(ctx->device));
 	const size_t plen = (size_t)2 * cv->clen, slen2 = (size_t)2 * cv->qlen;
-	const std::vector<HostArr> arrs = {{pubkeys, nullptr, plen}, {sigs, nullptr, slen2}, {digests, nullptr, hlen}, {nullptr, result, 1}};
+	const std::vector<HostArr> arrs = {{pubkeys, nullptr, plen}, {sigs, nullptr, slen2}, {data, nullptr, data_stride}, {nullptr, result, 1}};
 	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &between) {
-		return ecdsa_verify_dev_locked(ctx, cv, m, ip[0], ip[1], ip[2], hlen, op[3], s, &between);
+		const uint8_t *d_dig = ip[2];
+		if (hash_type) {
+			if (ecdsa_hash_stage(ctx, hash_type, m, ip[2], data_stride, hlen, s)) {
+				return -1;
+			}
+			d_dig = ctx->stage[17];
+		}
+		return ecdsa_verify_dev_locked(ctx, cv, m, ip[0], ip[1], d_dig, hlen, op[3], s, &between);
 	});
+}
+
+extern "C" int ec_ecdsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys,
+				     const uint8_t *sigs, const uint8_t *digests, uint32_t hlen, uint8_t *result)
+{
+	return ecdsa_verify_host_aff(ctx, cv, n, pubkeys, sigs, digests, hlen, 0, hlen, result, "ec_ecdsa_verify_batch");
 }
 
 // ECDSA verification with the public keys in either point wire format.  ECAMD_PT_PROJECTIVE is what an ec_pub_key holds
 // (ec_pub_key_export_to_buf: X || Y || Z of pub_key->y): imported as prj_pt_import_from_buf does, normalised on the device,
 // and a key that is the point at infinity -- which libecc imports and verifies against, W' = uG -- is handled as the
 // reference does.
-extern "C" int ec_ecdsa_verify_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys, int pub_fmt,
-					 const uint8_t *sigs, const uint8_t *digests, uint32_t hlen, uint8_t *result)
+static int ecdsa_verify_host_fmt(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys, int pub_fmt, const uint8_t *sigs,
+				 const uint8_t *data, uint32_t data_stride, int hash_type, uint32_t hlen, uint8_t *result, const char *fn)
 {
 	if (pub_fmt == ECAMD_PT_AFFINE) {
-		return ec_ecdsa_verify_batch(ctx, cv, n, pubkeys, sigs, digests, hlen, result);
+		return ecdsa_verify_host_aff(ctx, cv, n, pubkeys, sigs, data, data_stride, hash_type, hlen, result, fn);
 	}
 	if (pub_fmt != ECAMD_PT_PROJECTIVE) {
 		return fail("ec_ecdsa_verify_batch_fmt: point format must be ECAMD_PT_AFFINE or ECAMD_PT_PROJECTIVE");
 	}
-	if (ecdsa_verify_args_ok("ec_ecdsa_verify_batch_fmt", ctx, cv, n, pubkeys, sigs, digests, result, hlen)) {
+	if (ecdsa_verify_args_ok(fn, ctx, cv, n, pubkeys, sigs, data, result, hlen)) {
 		return -1;
 	}
 	if (n == 0) {
@@ -2252,12 +2305,19 @@ extern "C" int ec_ecdsa_verify_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *cv, 
 		// imported and normalised there (k_prj_import) and the verification core consumes the affine form in HBM
 		std::lock_guard<std::mutex> lk(ctx->mu);
 		HIPCHK(hipSetDevice(ctx->device));
-		const std::vector<HostArr> arrs = {{pubkeys, nullptr, 3 * (size_t)cv->clen}, {sigs, nullptr, sl}, {digests, nullptr, hlen},
-						   {nullptr, result, 1}, {nullptr, st.data(), 1}};
+		std::vector<HostArr> arrs = {{pubkeys, nullptr, 3 * (size_t)cv->clen}, {sigs, nullptr, sl}, {data, nullptr, data_stride},
+					     {nullptr, result, 1}, {nullptr, st.data(), 1}};
 		if (host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 						     hipStream_t s, const std::function<int()> &between) {
 			    if (ensure(&ctx->stage[12], &ctx->stage_bytes[12], (size_t)m * alen)) {
 				    return -1;
+			    }
+			    const uint8_t *d_dig = ip[2];
+			    if (hash_type) {
+				    if (ecdsa_hash_stage(ctx, hash_type, m, ip[2], data_stride, hlen, s)) {
+					    return -1;
+				    }
+				    d_dig = ctx->stage[17];
 			    }
 			    EcamdPrjInArgs I;
 			    I.in = ip[0];
@@ -2267,8 +2327,8 @@ extern "C" int ec_ecdsa_verify_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *cv, 
 			    I.clen = (uint32_t)cv->clen;
 			    I.for_mul = 0;
 			    I.slot = cv->slot;
-			    HIPCHK(ecamd_launch_prj_import(cv->nw, I, s));
-			    return ecdsa_verify_dev_locked(ctx, cv, m, ctx->stage[12], ip[1], ip[2], hlen, op[3], s, &between);
+			    HIPCHK(launch_prj_import(cv, I, s));
+			    return ecdsa_verify_dev_locked(ctx, cv, m, ctx->stage[12], ip[1], d_dig, hlen, op[3], s, &between);
 		    })) {
 			return -1;
 		}
@@ -2292,16 +2352,18 @@ extern "C" int ec_ecdsa_verify_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *cv, 
 	if (inf.empty()) {
 		return 0;
 	}
-	// keys at infinity: W' = [u1]G
+	// keys at infinity: W' = [u1]G.  Their signatures and digests (or message slots, hashed on the device again: the digests of
+	// the batch never travel back) are gathered on the host -- a handful of items at most.
 	const uint32_t r = (uint32_t)inf.size();
-	std::vector<uint8_t> hs((size_t)r * sl), hd((size_t)r * hlen), hr(r);
+	const size_t dl = hash_type ? (size_t)data_stride : (size_t)hlen;
+	std::vector<uint8_t> hs((size_t)r * sl), hd((size_t)r * dl), hr(r);
 	for (uint32_t j = 0; j < r; j++) {
 		memcpy(&hs[(size_t)j * sl], sigs + (size_t)inf[j] * sl, sl);
-		memcpy(&hd[(size_t)j * hlen], digests + (size_t)inf[j] * hlen, hlen);
+		memcpy(&hd[(size_t)j * dl], data + (size_t)inf[j] * dl, dl);
 	}
 	std::lock_guard<std::mutex> lk(ctx->mu);
 	HIPCHK(hipSetDevice(ctx->device));
-	const size_t gneed[3] = {(size_t)r * sl, (size_t)r * hlen, r};
+	const size_t gneed[3] = {(size_t)r * sl, (size_t)r * dl, r};
 	for (int i = 0; i < 3; i++) {
 		if (ensure(&ctx->stage[14 + i], &ctx->stage_bytes[14 + i], gneed[i])) {
 			return -1;
@@ -2312,7 +2374,14 @@ extern "C" int ec_ecdsa_verify_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *cv, 
 	uint8_t **S = ctx->stage;
 	HIPCHK(hipMemcpyAsync(S[14], hs.data(), hs.size(), hipMemcpyHostToDevice, s));
 	HIPCHK(hipMemcpyAsync(S[15], hd.data(), hd.size(), hipMemcpyHostToDevice, s));
-	if (ecdsa_two_smul_dev(ctx, cv, r, nullptr, S[14], S[15], hlen, S[16], s)) {
+	const uint8_t *d_dig = S[15];
+	if (hash_type) {
+		if (ecdsa_hash_stage(ctx, hash_type, r, S[15], data_stride, hlen, s)) {
+			return -1;
+		}
+		d_dig = S[17];
+	}
+	if (ecdsa_two_smul_dev(ctx, cv, r, nullptr, S[14], d_dig, hlen, S[16], s)) {
 		return -1;
 	}
 	HIPCHK(hipMemcpyAsync(hr.data(), S[16], r, hipMemcpyDeviceToHost, s));
@@ -2321,6 +2390,26 @@ extern "C" int ec_ecdsa_verify_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *cv, 
 		result[inf[j]] = hr[j];
 	}
 	return 0;
+}
+
+extern "C" int ec_ecdsa_verify_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys, int pub_fmt,
+					 const uint8_t *sigs, const uint8_t *digests, uint32_t hlen, uint8_t *result)
+{
+	return ecdsa_verify_host_fmt(ctx, cv, n, pubkeys, pub_fmt, sigs, digests, hlen, 0, hlen, result, "ec_ecdsa_verify_batch_fmt");
+}
+
+// ECDSA verification from MESSAGES: item i's message sits in a slot of msg_stride bytes (a multiple of 4, at most 4096): a
+// little-endian u32 length, then the bytes (4 + length <= msg_stride); H(m) is SHA-224 / 256 / 384 / 512 (hash_type 1 .. 4,
+// libecc's hash_alg_type numbers) computed on the device, the rest is ec_ecdsa_verify_batch_fmt.
+extern "C" int ec_ecdsa_verify_msg_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys, int pub_fmt,
+					     const uint8_t *sigs, int hash_type, const uint8_t *msg_slots, uint32_t msg_stride, uint8_t *result)
+{
+	const int dl = ecamd_sha2_digest_len(hash_type);
+	if (dl == 0 || msg_stride < 4 || (msg_stride & 3u) || msg_stride > 4096) {
+		return fail("ec_ecdsa_verify_msg_batch_fmt: hash_type must be 1 .. 4 (SHA-224 / 256 / 384 / 512), msg_stride a multiple of 4 in 4 .. 4096");
+	}
+	return ecdsa_verify_host_fmt(ctx, cv, n, pubkeys, pub_fmt, sigs, msg_slots, msg_stride, hash_type, (uint32_t)dl, result,
+				     "ec_ecdsa_verify_msg_batch_fmt");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3440,6 +3529,36 @@ extern "C" int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, u
 	});
 }
 
+// Ed25519 verification with the hash INPUTS instead of the hashes: slot i (stride bytes: u32 length, then the bytes) holds
+// dom2 || R || A || PH(M) as the verifier would feed them to SHA-512 (sig/eddsa.c:1995-2045, :2180-2200); hram is computed on the device.
+extern "C" int ec_eddsa_verify_msg_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs,
+					 const uint8_t *hash_slots, uint32_t stride, uint8_t *result)
+{
+	if (!ctx || stride < 4 || (stride & 3u) || stride > 4096) {
+		return fail("ec_eddsa_verify_msg_batch: bad argument (stride: a multiple of 4 in 4 .. 4096)");
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (eddsa_args_ok("ec_eddsa_verify_msg_batch", ctx, cv_in, n, pubkeys, sigs, hash_slots, result, 64)) {
+		return -1;
+	}
+	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
+	if (cv->pbits != 255) {
+		return fail("ec_eddsa_verify_msg_batch: Ed25519 (the WEI25519 handle) only: Ed448 hashes with SHAKE256");
+	}
+	if (n == 0) {
+		return 0;
+	}
+	HIPCHK(hipSetDevice(ctx->device));
+	const std::vector<HostArr> arrs = {{pubkeys, nullptr, 32u}, {sigs, nullptr, 64u}, {hash_slots, nullptr, stride}, {nullptr, result, 1}};
+	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+					       hipStream_t s, const std::function<int()> &) {
+		if (ecdsa_hash_stage(ctx, 4, m, ip[2], stride, 64, s)) {
+			return -1;
+		}
+		return eddsa_verify_dev_locked(ctx, cv, m, ip[0], ip[1], ctx->stage[17], 64, op[3], s);
+	});
+}
+
 // ------------------------------------------------------------------------------------------
 // Ed25519 whole-batch verification as one multi-scalar multiplication (the equation of _eddsa_verify_batch_no_memory,
 // sig/eddsa.c:2278-2545, on the Edwards curve; kernels k_edmsm_* of ecamd_g29_kernel.hip / ecamd_kernels.hip).
@@ -3889,7 +4008,7 @@ extern "C" int ec_eddsa_encode_point_batch(ecamd_ctx *ctx, const ecamd_curve *cv
 		I.clen = (uint32_t)cl;
 		I.for_mul = 0;
 		I.slot = cv->slot;
-		HIPCHK(ecamd_launch_prj_import(cv->nw, I, s));
+		HIPCHK(launch_prj_import(cv, I, s));
 		EcamdEdSignArgs A = T;
 		A.n = m;
 		A.Rw = ctx->stage[3];
@@ -3982,7 +4101,7 @@ static int pt_fmt_batch(const char *fn, ecamd_ctx *ctx, const ecamd_curve *cv, u
 		I.clen = (uint32_t)clen;
 		I.for_mul = mul ? 1 : 0;
 		I.slot = cv->slot;
-		HIPCHK(ecamd_launch_prj_import(cv->nw, I, s));
+		HIPCHK(launch_prj_import(cv, I, s));
 		d_aff = S[2];
 		d_pre = S[3];
 	}

@@ -423,6 +423,12 @@ uint32_t ecamd_g29_comb_entries(int pbits);
 uint32_t ecamd_g29_comb_entry_words(int pbits, int flavour);
 hipError_t ecamd_g29_comb_build(int pbits, int gslot, const uint8_t *pts, uint32_t n, uint32_t clen, uint32_t *table,
 				hipStream_t s, int flavour);
+// SHA-224 / 256 / 384 / 512 of n messages in fixed-stride slots (ecamd_hash.hip); hash_type: libecc's hash_alg_type numbers 1 .. 4
+int ecamd_sha2_digest_len(int hash_type);
+hipError_t ecamd_launch_sha2_slots(int hash_type, const uint8_t *slots, uint32_t stride, uint32_t n, uint8_t *out, uint32_t out_stride, hipStream_t s);
+struct EcamdPrjInArgs;
+// prj_pt_import_from_buf + prj_pt_unique on a radix-2^29 unit, one inversion per eight triples (k_prj_import_g)
+hipError_t ecamd_g29_prj_import(int pbits, int gslot, const EcamdPrjInArgs &a, hipStream_t s, int flavour);
 struct EcamdEcdsaPrepArgs;
 // the mod-q algebra of an ECDSA verification on the dense radix-2^29 unit of the order's size (k_ecdsa_prep_g)
 hipError_t ecamd_g29_ecdsa_prep(int qbits, int qgslot, const EcamdEcdsaPrepArgs &a, uint32_t *scratch, int kp, hipStream_t s);

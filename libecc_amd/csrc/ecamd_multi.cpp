@@ -285,6 +285,25 @@ extern "C" int ecamd_multi_ecdsa_verify_batch_fmt(ecamd_multi *m, const ecamd_mc
 	});
 }
 
+extern "C" int ecamd_multi_ecdsa_verify_msg_batch_fmt(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys, int pub_fmt,
+						      const uint8_t *sigs, int hash_type, const uint8_t *msg_slots, uint32_t msg_stride, uint8_t *result)
+{
+	const size_t plen = (pub_fmt ? 3 : 2) * (size_t)ecamd_multi_curve_coord_len(c), sl = 2 * (size_t)ecamd_multi_curve_order_len(c);
+	return run_sharded(m, c, n, "ecamd_multi_ecdsa_verify_msg_batch_fmt", [&](int r, uint32_t lo, uint32_t hi) {
+		return ec_ecdsa_verify_msg_batch_fmt(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(pubkeys, plen), pub_fmt, OFF(sigs, sl), hash_type,
+						     OFF(msg_slots, (size_t)msg_stride), msg_stride, OFF(result, 1));
+	});
+}
+
+extern "C" int ecamd_multi_eddsa_verify_msg_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs,
+						  const uint8_t *hash_slots, uint32_t stride, uint8_t *result)
+{
+	return run_sharded(m, c, n, "ecamd_multi_eddsa_verify_msg_batch", [&](int r, uint32_t lo, uint32_t hi) {
+		return ec_eddsa_verify_msg_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(pubkeys, 32), OFF(sigs, 64), OFF(hash_slots, (size_t)stride),
+						 stride, OFF(result, 1));
+	});
+}
+
 extern "C" int ecamd_multi_ecdsa_sign_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *privs,
 					    const uint8_t *nonces, const uint8_t *digests, uint32_t digest_len, uint8_t *sigs,
 					    uint8_t *status)

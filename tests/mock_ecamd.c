@@ -190,8 +190,11 @@ int ecamd_multi_ecdsa_verify_batch_fmt(ecamd_multi *m, const ecamd_mcurve *c, ui
 	int r;
 	(void)m;
 	note(n);
-	if (pub_fmt != ECAMD_PT_PROJECTIVE) {
-		return mfail("mock: projective keys only");
+	if (pub_fmt == ECAMD_PT_AFFINE) {
+		/* affine keys (the typed layer sends them when every key of a group has Z = 1): straight to the oracle */
+		r = orc_ecdsa_verify_batch(&c->c, n, pubkeys, sigs, digests, digest_len, result);
+		free(prj); free(aff); free(st);
+		return r ? mfail("mock: ecdsa verify") : 0;
 	}
 	r = orc_prj_batch(&c->c, n, NULL, 0, pubkeys, prj, st);
 	for (i = 0; i < n; i++) {
@@ -205,6 +208,50 @@ int ecamd_multi_ecdsa_verify_batch_fmt(ecamd_multi *m, const ecamd_mcurve *c, ui
 	}
 	free(prj); free(aff); free(st);
 	return r ? mfail("mock: ecdsa verify") : 0;
+}
+
+/* the message-taking forms: the stand-in hashes the slots with libecc's own hash functions (what the device computes with
+ * ecamd_hash.hip, tested against hashlib in tests/test_hash_host.py) and goes on with the digest-taking forms */
+static int mock_hash_slots(int hash_type, uint32_t n, const uint8_t *slots, uint32_t stride, uint8_t *dg, uint32_t *dl)
+{
+	static const hash_alg_type types[5] = {UNKNOWN_HASH_ALG, SHA224, SHA256, SHA384, SHA512};
+	const hash_mapping *hm;
+	uint32_t i;
+	if (hash_type < 1 || hash_type > 4 || get_hash_by_type(types[hash_type], &hm) || !hm) {
+		return -1;
+	}
+	*dl = hm->digest_size;
+	for (i = 0; i < n; i++) {
+		const uint8_t *sl = slots + (size_t)i * stride;
+		const uint32_t len = (uint32_t)sl[0] | ((uint32_t)sl[1] << 8) | ((uint32_t)sl[2] << 16) | ((uint32_t)sl[3] << 24);
+		hash_context hc;
+		if (len > stride - 4 || hm->hfunc_init(&hc) || hm->hfunc_update(&hc, sl + 4, len) || hm->hfunc_finalize(&hc, dg + (size_t)i * *dl)) {
+			return -1;
+		}
+	}
+	return 0;
+}
+
+int ecamd_multi_ecdsa_verify_msg_batch_fmt(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys, int pub_fmt,
+					   const uint8_t *sigs, int hash_type, const uint8_t *msg_slots, uint32_t msg_stride, uint8_t *result)
+{
+	uint8_t *dg = malloc((size_t)n * 64 + 1);
+	uint32_t dl = 0;
+	int r = (!dg || mock_hash_slots(hash_type, n, msg_slots, msg_stride, dg, &dl)) ? mfail("mock: hashing failed")
+		    : ecamd_multi_ecdsa_verify_batch_fmt(m, c, n, pubkeys, pub_fmt, sigs, dg, dl, result);
+	free(dg);
+	return r;
+}
+
+int ecamd_multi_eddsa_verify_msg_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs,
+				       const uint8_t *hash_slots, uint32_t stride, uint8_t *result)
+{
+	uint8_t *dg = malloc((size_t)n * 64 + 1);
+	uint32_t dl = 0;
+	int r = (!dg || mock_hash_slots(4, n, hash_slots, stride, dg, &dl)) ? mfail("mock: hashing failed")
+		    : ecamd_multi_eddsa_verify_batch(m, c, n, pubkeys, sigs, dg, 64, result);
+	free(dg);
+	return r;
 }
 
 int ecamd_multi_ecdsa_sign_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *privs, const uint8_t *nonces,

@@ -1,0 +1,77 @@
+"""GPU tests of the verification entry points that take MESSAGES and hash on the device (ec_ecdsa_verify_msg_batch_fmt,
+ec_eddsa_verify_msg_batch; libecc_amd/csrc/ecamd_hash.hip): the same accept / reject bytes as the digest-taking entry points fed with
+hashlib's digests, on messages of every length class (empty, one block, the padding boundaries, two blocks), valid and corrupted."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracles as O
+from oracles import Oracle, clen, qlen
+from test_gpu_parity import rand_bytes
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("SECP256R1", 2, hashlib.sha256), ("SECP384R1", 3, hashlib.sha384), ("SECP521R1", 4, hashlib.sha512), ("SECP224R1", 1, hashlib.sha224),
+         ("SECP256R1", 4, hashlib.sha512), ("BRAINPOOLP256R1", 2, hashlib.sha256)]
+
+
+@pytest.mark.parametrize("curve,hash_type,hf", CASES)
+def test_ecdsa_verify_from_messages(gpu_ctx, curve, hash_type, hf):
+    rng = np.random.default_rng(90 + hash_type)
+    cv = gpu_ctx.curve(curve)
+    o = Oracle(curve)
+    cl, ql = clen(curve), qlen(curve)
+    q = O.CURVES[curve]["q"]
+    try:
+        lens = [0, 1, 31, 32, 55, 56, 63, 64, 65, 111, 112, 119, 120, 127, 128, 129, 200] * 4
+        n = len(lens)
+        msgs = [rand_bytes(rng, k) for k in lens]
+        dg = b"".join(hf(m).digest() for m in msgs)
+        hl = hf().digest_size
+        privs = b"".join(((int.from_bytes(rand_bytes(rng, ql + 8), "big") % (q - 1)) + 1).to_bytes(ql, "big") for _ in range(n))
+        nonces = b"".join(((int.from_bytes(rand_bytes(rng, ql + 8), "big") % (q - 1)) + 1).to_bytes(ql, "big") for _ in range(n))
+        pubs, st = cv.scalar_mult(privs)
+        assert set(st) == {0}
+        sigs, st = cv.ecdsa_sign(privs, nonces, dg, hl)
+        assert set(st) == {0}
+        sigs = bytearray(sigs)
+        for i in range(0, n, 5):
+            sigs[2 * ql * i + ql + 3] ^= 1
+        sigs = bytes(sigs)
+        exp = cv.ecdsa_verify(pubs, sigs, dg, hl)
+        assert exp == o.ecdsa_verify(pubs, sigs, dg, hl) and 0 in exp and 1 in exp
+        assert cv.ecdsa_verify_msgs(pubs, 0, sigs, hash_type, msgs) == exp
+        # projective keys (what an ec_pub_key holds), and a flipped message byte
+        prj = b"".join(pubs[2 * cl * i:2 * cl * (i + 1)] + (1).to_bytes(cl, "big") for i in range(n))
+        assert cv.ecdsa_verify_msgs(prj, 1, sigs, hash_type, msgs) == exp
+        bad = [bytes([m[0] ^ 1]) + m[1:] if m else b"x" for m in msgs]
+        assert cv.ecdsa_verify_msgs(pubs, 0, sigs, hash_type, bad) == bytes([1]) * n
+        # a larger tiled batch with a wider stride
+        reps = 40
+        slots, stride = cv.msg_slots(msgs * reps, 256)
+        import ctypes as C
+        res = C.create_string_buffer(n * reps)
+        assert cv.L.ec_ecdsa_verify_msg_batch_fmt(cv.ctx.h, cv.h, n * reps, pubs * reps, 0, sigs * reps, hash_type, slots, stride, res) == 0
+        assert res.raw == exp * reps
+        assert cv.ecdsa_verify_msgs(b"", 0, b"", hash_type, []) == b""
+    finally:
+        cv.free()
+
+
+def test_eddsa_verify_from_hash_inputs(gpu_ctx):
+    from test_oracle import ed25519_cases, ED_MSG_LEN
+    rng = np.random.default_rng(95)
+    cv = gpu_ctx.curve("WEI25519")
+    try:
+        pubs, sigs, msgs, hram = ed25519_cases(rng, nvalid=30)
+        n = len(pubs) // 32
+        exp = cv.eddsa_verify(pubs, sigs, hram)
+        assert 0 in exp and 1 in exp
+        inputs = [sigs[64 * i:64 * i + 32] + pubs[32 * i:32 * i + 32] + msgs[ED_MSG_LEN * i:ED_MSG_LEN * (i + 1)] for i in range(n)]
+        assert hashlib.sha512(inputs[0]).digest() == hram[:64]
+        assert cv.eddsa_verify_msgs(pubs, sigs, inputs) == exp
+        reps = 4200 // n + 1
+        assert cv.eddsa_verify_msgs(pubs * reps, sigs * reps, inputs * reps) == exp * reps
+    finally:
+        cv.free()
