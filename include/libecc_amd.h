@@ -29,7 +29,8 @@
  * multiples of the generator in HBM (42 MB for 256-bit curves, 183 MB for 521 bits).
  *
  * Environment (read when a context / curve handle is created; for measurements and fallbacks):
- *   ECAMD_HOST_CHUNK=<items>      chunk size of the host-pointer entry points (default 2^18)
+ *   ECAMD_HOST_CHUNK=<items>      chunk size of the host-pointer entry points (default 2^19)
+ *   ECAMD_HOST_RAMP_MIN=<items>   a call of several chunks starts with a short one, max(chunk / 8, this) items (default 2^16); ECAMD_NO_HOST_RAMP: equal chunks
  *   ECAMD_COMB_MIN_BATCH=<items>  smallest fixed-base batch that builds / uses the generator table (default 4096)
  *   ECAMD_MSM_MIN=<items>, ECAMD_MSM_K=<items per lane>   initial values of ecamd_ctx_set_eddsa_msm (default 2^17, chosen from the batch size)
  *   ECAMD_NO_COMB, ECAMD_NO_FAST_PATH, ECAMD_NO_P25519, ECAMD_NO_K256, ECAMD_NO_P448, ECAMD_NO_MPINV1, ECAMD_NO_ISO, ECAMD_NO_X25519_LADDER,
@@ -93,6 +94,15 @@ void *ecamd_ctx_stream(ecamd_ctx *ctx);
  * asynchronous DMA at PCIe rate.  NULL on failure.  Any host memory works; this is only faster. */
 void *ecamd_host_alloc(size_t bytes);
 void ecamd_host_free(void *p);
+/* Producer hook of the host-pointer entry points.  Those stage the caller's arrays through the device in chunks of host_chunk items
+ * (ECAMD_HOST_CHUNK), chunk c+1's copies overlapping chunk c's kernels; a caller that is still FILLING its input arrays while the call
+ * runs registers fn, which the call invokes -- on the calling thread, with the context's lock held -- before it reads items
+ * [first, first + count) of the call's input arrays, and which returns once that range is complete.  libsign_amd.so uses it so that
+ * its host threads marshal libecc structures into the tail of a batch while the GPU already works on its head (it is the whole of the
+ * overlap between the typed layer's packing and the device: one call per batch, no quarter-batch launches).  NULL clears it; the
+ * hook stays until cleared and applies to every host-pointer call on the context.  fn must not call into the context. */
+typedef void (*ecamd_host_ready_fn)(void *arg, uint32_t first, uint32_t count);
+int ecamd_ctx_set_host_ready_hook(ecamd_ctx *ctx, ecamd_host_ready_fn fn, void *arg);
 /* Measurement hook: when enabled, HIP events are recorded (on the stream the kernels run on) around
  * the kernels of the next ec_prj_pt_mul_batch[_dev] call; ecamd_ctx_kernel_times() waits for them and
  * returns the 4 durations in ms: table, table->affine, window loop, finalisation (the generic
@@ -448,6 +458,9 @@ int ecamd_multi_eddsa_sign_S_batch(ecamd_multi *m, const ecamd_mcurve *curve, ui
 				   const uint8_t *a_scalars, uint8_t *S_out);
 /* ecamd_ctx_set_secret_scalars / ecamd_ctx_wipe_scratch on every rank's context */
 int ecamd_multi_set_secret_scalars(ecamd_multi *m, int on);
+/* ecamd_ctx_set_host_ready_hook for every rank: fn sees item numbers of the WHOLE call's arrays (a rank's shard offset is added) and may be
+ * entered from several ranks' threads at once */
+int ecamd_multi_set_host_ready_hook(ecamd_multi *m, ecamd_host_ready_fn fn, void *arg);
 int ecamd_multi_set_msm_seed(ecamd_multi *m, const uint8_t seed[32]);   /* rank r: seed with r xored into its first bytes */
 int ecamd_multi_wipe_scratch(ecamd_multi *m);
 /* The one collective, for callers that keep device-resident outputs on every GPU: an RCCL all-gather (over xGMI) of

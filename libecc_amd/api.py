@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "ecamd_multi_ecdsa_verify_batch", "ecamd_multi_ecdsa_verify_batch_fmt", "ecamd_multi_ecdsa_sign_batch", "ecamd_multi_ecccdh_derive_batch",
     "ecamd_multi_xdh_batch", "ecamd_multi_eddsa_verify_batch", "ecamd_multi_eddsa_verify_all_batch", "ecamd_multi_allgather",
     "ecamd_multi_allgather_streams", "ecamd_multi_eddsa_sign_R_batch", "ecamd_multi_eddsa_sign_S_batch",
-    "ecamd_multi_set_secret_scalars", "ecamd_multi_wipe_scratch", "ecamd_ctx_wipe_scratch", "ecamd_ctx_stream", "ecamd_host_alloc", "ecamd_host_free", "ecamd_ctx_dominant_kernel_ms", "ecamd_ctx_set_msm_seed", "ecamd_multi_set_msm_seed", "ecamd_multi_prj_pt_add_batch",
+    "ecamd_multi_set_secret_scalars", "ecamd_multi_wipe_scratch", "ecamd_ctx_wipe_scratch", "ecamd_ctx_stream", "ecamd_host_alloc", "ecamd_host_free", "ecamd_ctx_dominant_kernel_ms", "ecamd_ctx_set_msm_seed", "ecamd_multi_set_msm_seed", "ecamd_ctx_set_host_ready_hook", "ecamd_multi_set_host_ready_hook", "ecamd_multi_prj_pt_add_batch",
 ]
 
 
@@ -159,6 +159,15 @@ class Context:
     def set_eddsa_msm(self, mode=1, min_items=0, items_per_lane=0):
         """Ed25519 whole-batch verification through the multi-scalar multiplication: 0 never, 1 large batches, 2 always"""
         _chk(self.L, self.L.ecamd_ctx_set_eddsa_msm(self.h, mode, min_items, items_per_lane), "ecamd_ctx_set_eddsa_msm")
+
+    def set_host_ready_hook(self, fn):
+        """ecamd_ctx_set_host_ready_hook: fn(first, count) is called before the host-pointer entry points read that range of their
+        input arrays (None clears it)"""
+        HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32)
+        self._hook = HOOK((lambda arg, first, count: fn(first, count))) if fn else C.cast(None, HOOK)   # kept alive with the context
+        self.L.ecamd_ctx_set_host_ready_hook.argtypes = [C.c_void_p, HOOK, C.c_void_p]
+        self.L.ecamd_ctx_set_host_ready_hook.restype = C.c_int
+        _chk(self.L, self.L.ecamd_ctx_set_host_ready_hook(self.h, self._hook, None), "ecamd_ctx_set_host_ready_hook")
 
     def enable_kernel_timing(self, on=True):
         _chk(self.L, self.L.ecamd_ctx_enable_kernel_timing(self.h, 1 if on else 0), "ecamd_ctx_enable_kernel_timing")

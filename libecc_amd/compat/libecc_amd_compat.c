@@ -56,6 +56,7 @@ typedef struct {
 } curve_ent;
 
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;        /* the state below */
+static void words_free_all(void);
 static pthread_mutex_t g_call_mu = PTHREAD_MUTEX_INITIALIZER;   /* one batch call at a time: pool, staging buffers, GPUs */
 static pthread_mutex_t g_rand_mu = PTHREAD_MUTEX_INITIALIZER;   /* the application's get_random: one caller at a time (see compat_random_mod) */
 static u32 g_rand_concurrent;                                   /* ecamd_compat_set_concurrent_random */
@@ -238,6 +239,7 @@ void ecamd_compat_shutdown(void)
 	pthread_mutex_lock(&g_mu);
 	pool_stop();
 	bufs_free();
+	words_free_all();
 	for (i = 0; i < g_ncurves; i++) {
 		ecamd_multi_curve_free(g_curves[i].mc);
 	}
@@ -623,7 +625,42 @@ static double now_ms(void)
 	return 1e3 * (double)t.tv_sec + 1e-6 * (double)t.tv_nsec;
 }
 
+/* the producer hook of a streamed run (ecamd_multi_set_host_ready_hook): the GPU call is about to read items [first, first + count) of
+ * the packed arrays -- wait until the pool has packed them, helping meanwhile.  May be entered from several rank threads. */
+static void stream_ready(void *arg, u32 first, u32 count)
+{
+	pipe_job *J = (pipe_job *)arg;
+	const u32 per = J->chunk_grains * GRAIN;
+	u32 c, c1;
+	if (count == 0 || first >= J->n) {
+		return;
+	}
+	c1 = (first + count - 1 < J->n ? first + count - 1 : J->n - 1) / per;
+	for (c = first / per; c <= c1 && c < J->nchunks; c++) {
+		while (AT_LOAD(&J->pack_left[c]) != 0) {
+			if (take_pack(J)) {
+				continue;
+			}
+			pthread_mutex_lock(&J->mu);
+			while (AT_LOAD(&J->pack_left[c]) != 0) {
+				pthread_cond_wait(&J->cv, &J->mu);
+			}
+			pthread_mutex_unlock(&J->mu);
+		}
+	}
+}
+
+/* streamed != 0: ONE gpu call over all n items, started at once; the C ABI asks (stream_ready) for every range of the packed arrays
+ * before it copies it to the device, so the pool packs the tail of the batch while the device works on its head, and `chunk` is only
+ * the granularity of that handshake.  (Round 4: a 2^20-item verification spent 4 ms packing before the first copy started, and
+ * quarter-batch GPU calls to hide that cost more than they hid -- profiles/r4i_typed_boundary.md.) */
+static int pipeline_run_ex(u32 n, u32 chunk, range_fn pack, gpu_fn gpu, range_fn unpack, void *arg, int streamed);
 static int pipeline_run(u32 n, u32 chunk, range_fn pack, gpu_fn gpu, range_fn unpack, void *arg)
+{
+	return pipeline_run_ex(n, chunk, pack, gpu, unpack, arg, 0);
+}
+
+static int pipeline_run_ex(u32 n, u32 chunk, range_fn pack, gpu_fn gpu, range_fn unpack, void *arg, int streamed)
 {
 	pipe_job J;
 	u32 c, lo, hi;
@@ -684,7 +721,31 @@ static int pipeline_run(u32 n, u32 chunk, range_fn pack, gpu_fn gpu, range_fn un
 	g_pool.gen++;
 	pthread_cond_broadcast(&g_pool.cv_work);
 	pthread_mutex_unlock(&g_pool.mu);
-	for (c = 0; c < J.nchunks; c++) {
+	if (streamed && gpu && pack && J.nchunks > 1) {
+		t0 = timing ? now_ms() : 0;
+		if (ecamd_multi_set_host_ready_hook(g_multi, stream_ready, &J)) {
+			ret = -1;
+		} else {
+			ret = gpu(0, n, arg) ? -1 : 0;
+			(void)ecamd_multi_set_host_ready_hook(g_multi, NULL, NULL);
+		}
+		if (ret) {
+			AT_STORE(&J.abort, 1);
+			job_notify(&J);
+		} else {
+			stream_ready(&J, 0, n);   /* (a call that returned without reading everything: nothing may stay unpacked) */
+			pthread_mutex_lock(&J.mu);
+			for (c = 0; c < J.nchunks; c++) {
+				AT_STORE(&J.gpu_done[c], 1);
+			}
+			pthread_cond_broadcast(&J.cv);
+			pthread_mutex_unlock(&J.mu);
+		}
+		if (timing) {
+			t_gpu += now_ms() - t0;
+		}
+	}
+	for (c = 0; c < J.nchunks && !(streamed && gpu && pack && J.nchunks > 1); c++) {
 		/* wait for chunk c to be packed; help meanwhile */
 		t0 = timing ? now_ms() : 0;
 		while (AT_LOAD(&J.pack_left[c]) != 0) {
@@ -717,9 +778,11 @@ static int pipeline_run(u32 n, u32 chunk, range_fn pack, gpu_fn gpu, range_fn un
 		pthread_cond_broadcast(&J.cv);
 		pthread_mutex_unlock(&J.mu);
 	}
+	t0 = timing ? now_ms() : 0;
 	if (!ret) {
 		pipe_work(&J);   /* help with what is left to unpack */
 	}
+	t0 = timing ? now_ms() : 0;
 	pthread_mutex_lock(&g_pool.mu);
 	g_pool.job = NULL;
 	while (g_pool.active > 0) {
@@ -748,10 +811,19 @@ static void parallel_for(u32 n, range_fn fn, void *arg)
  * ECDSA verifications (profiles/r3b_compat_end_to_end.md): 12.8 / 22.4 / 27.9 / 28.8 M/s at 2^15 / 2^16 / 2^17 / 2^18 items per
  * chunk.  Default: a quarter of the batch per device, between 2^15 and 2^18 ($ECAMD_COMPAT_CHUNK fixes it); the multi-GPU
  * layer cuts every chunk into one shard per device. */
-/* Verification (round 4, measured: profiles/r4i_typed_boundary.md): packing a signature is half a millisecond per 2^18 items on the
- * pool, so overlapping it with the GPU gains at most that, while quarter-batch GPU calls cost more -- the kernels of a 2^18-item launch run
- * at 0.8 - 0.9 of their 2^20 rate and the calls follow each other with their copies in between.  One chunk per device up to 2^20 items
- * (the C ABI's own double-buffered staging overlaps copies and kernels inside the call); $ECAMD_COMPAT_CHUNK still fixes it. */
+/* Verification (round 4, measured: profiles/r4i_typed_boundary.md): quarter-batch GPU calls cost more than the packing they hide -- the
+ * kernels of a 2^18-item launch run at 0.8 - 0.9 of their 2^20 rate and every call is copy-in, kernels, copy-out in sequence -- so a
+ * verification is ONE call per batch (up to 2^20 items per device) and the packing overlaps it through the C ABI's producer hook
+ * (pipeline_run_ex, streamed).  $ECAMD_COMPAT_CHUNK brings the chunked calls back, $ECAMD_COMPAT_NO_STREAM one call after all packing. */
+#define READY_ITEMS (1u << 16)   /* granularity of the producer handshake */
+static int verify_streamed(void)
+{
+	static int on = -1;
+	if (on < 0) {
+		on = (g_chunk || getenv("ECAMD_COMPAT_NO_STREAM")) ? 0 : 1;
+	}
+	return on;
+}
 static u32 chunk_items_verify(u32 n)
 {
 	const int nd = g_multi ? ecamd_multi_size(g_multi) : 1;
@@ -763,6 +835,18 @@ static u32 chunk_items_verify(u32 n)
 	}
 	(void)n;
 	return c > 0x40000000ull ? 0x40000000u : (u32)c;
+}
+/* pack | GPU | unpack of a verification group of cnt items */
+static int verify_pipeline(u32 cnt, range_fn pack, gpu_fn gpu, range_fn unpack, void *arg)
+{
+	const u32 per_call = chunk_items_verify(cnt);
+	if (!verify_streamed()) {
+		return pipeline_run(cnt, per_call, pack, gpu, unpack, arg);
+	}
+	if (cnt <= per_call) {
+		return pipeline_run_ex(cnt, READY_ITEMS, pack, gpu, unpack, arg, 1);
+	}
+	return pipeline_run(cnt, per_call, pack, gpu, unpack, arg);   /* (more than 2^20 items per device: chunked calls of that size) */
 }
 
 static u32 chunk_items_for(u32 per_device, u32 n)
@@ -2733,6 +2817,11 @@ typedef struct {
 	u32 kw;                  /* ... octets of a packed key: 2 * clen or 3 * clen */
 	int dev_hash;            /* round 4: SHA-2 of short messages on the device -- 0 host hashing, else the hash_alg_type number */
 	u32 slot;                /* ... stride of a message slot in dg (u32 length + bytes), a multiple of 4 */
+	int *results;            /* the caller's per-item results (written by the unpack step of a chunk, on the pool) */
+	int pre_scanned;         /* verify_results' one pass over the keys already found: */
+	u32 pre_max_mlen;        /* ... the longest message of the group */
+	u32 pre_not_affine;      /* ... whether some usable key has Z != 1 */
+	u32 fail_tracked, any_fail;   /* ver_unpack notes whether any item was rejected (ec_verify_batch wants that one bit) */
 } ver_job;
 
 /* Hashing on the device (ec_ecdsa_verify_msg_batch_fmt / ec_eddsa_verify_msg_batch of libecc_amd.h): for SHA-224 / 256 / 384 / 512
@@ -2753,16 +2842,38 @@ static int dev_hash_type(const hash_mapping *hm)
 	default: return 0;
 	}
 }
-/* stride of the slots for the items idx[0..cnt) with `extra` bytes in front of every message, or 0 when one does not fit */
+/* stride of the slots for the items idx[0..cnt) with `extra` bytes in front of every message, or 0 when one does not fit
+ * (the longest message: a reduction over the pool -- a serial pass over 2^20 lengths is a millisecond of the caller's time) */
+typedef struct {
+	const ver_job *J;
+	u32 mx;
+} mlen_job;
+static void mlen_max(u32 lo, u32 hi, void *arg)
+{
+	mlen_job *M = (mlen_job *)arg;
+	u32 j, mx = 0, cur;
+	for (j = lo; j < hi; j++) {
+		const u32 l = M->J->m_len[M->J->idx[j]];
+		mx = l > mx ? l : mx;
+	}
+	cur = AT_LOAD(&M->mx);
+	while (mx > cur && !__atomic_compare_exchange_n(&M->mx, &cur, mx, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+	}
+}
 static u32 dev_hash_slot(const ver_job *J, u32 cnt, u32 extra)
 {
-	u32 j, mx = 0;
-	for (j = 0; j < cnt; j++) {
-		const u32 l = J->m_len[J->idx[j]];
-		mx = l > mx ? l : mx;
-		if (mx > DEV_HASH_MAX_SLOT) {
-			return 0;
-		}
+	mlen_job M;
+	u32 mx;
+	M.J = J;
+	M.mx = 0;
+	if (J->pre_scanned) {
+		M.mx = J->pre_max_mlen;
+	} else {
+		parallel_for(cnt, mlen_max, &M);
+	}
+	mx = M.mx;
+	if (mx > DEV_HASH_MAX_SLOT) {
+		return 0;
 	}
 	mx = (4 + extra + mx + 3u) & ~3u;
 	return mx <= DEV_HASH_MAX_SLOT ? mx : 0;
@@ -2820,6 +2931,21 @@ static void ecdsa_pack(u32 lo, u32 hi, void *arg)
 	}
 }
 
+static void ver_unpack(u32 lo, u32 hi, void *arg)
+{
+	ver_job *J = (ver_job *)arg;
+	u32 j;
+	u32 bad = 0;
+	for (j = lo; j < hi; j++) {
+		const int r = (J->pre[j] || J->res[j]) ? -1 : 0;
+		J->results[J->idx[j]] = r;
+		bad |= (u32)(r != 0);
+	}
+	if (bad) {
+		AT_STORE(&J->any_fail, 1);
+	}
+}
+
 static int ecdsa_ver_gpu(u32 lo, u32 hi, void *arg)
 {
 	ver_job *J = (ver_job *)arg;
@@ -2863,7 +2989,6 @@ static void ecdsa_keys_affine(u32 lo, u32 hi, void *arg)
 /* results[i] for the items idx[0..cnt) that share `params` */
 static int ecdsa_group(ver_job *J, u32 cnt, int *results)
 {
-	u32 j;
 	affk_job AK;
 	J->clen = J->e->clen;
 	J->qlen = J->e->qlen;
@@ -2879,7 +3004,9 @@ static int ecdsa_group(ver_job *J, u32 cnt, int *results)
 	}
 	AK.J = J;
 	AK.not_affine = getenv("ECAMD_COMPAT_PRJ_KEYS") ? 1 : 0;
-	if (!AK.not_affine) {
+	if (!AK.not_affine && J->pre_scanned) {
+		AK.not_affine = J->pre_not_affine;
+	} else if (!AK.not_affine) {
 		parallel_for(cnt, ecdsa_keys_affine, &AK);
 	}
 	J->aff_keys = AT_LOAD(&AK.not_affine) ? 0 : 1;
@@ -2892,13 +3019,12 @@ static int ecdsa_group(ver_job *J, u32 cnt, int *results)
 	if (!J->pk || !J->sg || !J->dg || !J->pre || !J->res) {
 		return -1;
 	}
-	if (pipeline_run(cnt, chunk_items_verify(cnt), ecdsa_pack, ecdsa_ver_gpu, NULL, J)) {
+	J->results = results;
+	J->fail_tracked = 1;
+	if (verify_pipeline(cnt, ecdsa_pack, ecdsa_ver_gpu, ver_unpack, J)) {
 		return -1;
 	}
 	note_items(cnt);
-	for (j = 0; j < cnt; j++) {
-		results[J->idx[j]] = (J->pre[j] || J->res[j]) ? -1 : 0;
-	}
 	return 0;
 }
 
@@ -3083,13 +3209,12 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
 		}
 		return 0;
 	}
-	if (pipeline_run(cnt, chunk_items_verify(cnt), eddsa_pack, eddsa_ver_gpu, NULL, J)) {
+	J->results = results;
+	J->fail_tracked = 1;
+	if (verify_pipeline(cnt, eddsa_pack, eddsa_ver_gpu, ver_unpack, J)) {
 		return -1;
 	}
 	note_items(cnt);
-	for (j = 0; j < cnt; j++) {
-		results[J->idx[j]] = (J->pre[j] || J->res[j]) ? -1 : 0;
-	}
 	return 0;
 }
 
@@ -3338,13 +3463,125 @@ static int is_ecfsdsa(ec_alg_type t)
 #endif
 }
 
+/* Index / result arrays of a verification call (4 bytes per item each): kept across calls.  A fresh 4 MB malloc is an mmap whose
+ * pages fault in one by one under the first loop that touches them -- half a millisecond per array and call on the GPU host, the
+ * price of a whole 2^20-item pack under a sandboxed kernel.  Up to four blocks rest here between calls; concurrent callers that find
+ * none simply allocate. */
+static pthread_mutex_t g_words_mu = PTHREAD_MUTEX_INITIALIZER;
+static void *g_words[4];
+static size_t g_words_cap[4];
+static void *words_take(size_t bytes)
+{
+	void *p = NULL;
+	int k;
+	pthread_mutex_lock(&g_words_mu);
+	for (k = 0; k < 4 && !p; k++) {
+		if (g_words[k] && g_words_cap[k] >= bytes) {
+			p = g_words[k];
+			g_words[k] = NULL;
+		}
+	}
+	pthread_mutex_unlock(&g_words_mu);
+	if (!p) {
+		size_t cap = 1u << 16;
+		while (cap < bytes) {
+			cap <<= 1;
+		}
+		p = malloc(cap + sizeof(size_t) * 2);
+		if (!p) {
+			return NULL;
+		}
+		*(size_t *)p = cap;
+		return (u8 *)p + sizeof(size_t) * 2;
+	}
+	return p;
+}
+static void words_give(void *q)
+{
+	int k;
+	if (!q) {
+		return;
+	}
+	pthread_mutex_lock(&g_words_mu);
+	for (k = 0; k < 4; k++) {
+		if (!g_words[k]) {
+			g_words[k] = q;
+			g_words_cap[k] = *(size_t *)((u8 *)q - sizeof(size_t) * 2);
+			q = NULL;
+			break;
+		}
+	}
+	pthread_mutex_unlock(&g_words_mu);
+	if (q) {
+		free((u8 *)q - sizeof(size_t) * 2);
+	}
+}
+static void words_free_all(void)
+{
+	int k;
+	pthread_mutex_lock(&g_words_mu);
+	for (k = 0; k < 4; k++) {
+		if (g_words[k]) {
+			free((u8 *)g_words[k] - sizeof(size_t) * 2);
+			g_words[k] = NULL;
+		}
+	}
+	pthread_mutex_unlock(&g_words_mu);
+}
+
+/* the common shape of a batch -- every key present, initialised and of ONE set of parameters -- established on the pool, together
+ * with the initial -1 of every result and the identity index map (a serial pass over 2^20 key pointers costs the caller more
+ * than a millisecond); any other batch goes through the serial grouping below */
+typedef struct {
+	const ec_pub_key **pub_keys;
+	const ec_params *params;
+	const u32 *m_len;
+	ec_alg_type sig_type;
+	u32 *idx;
+	int *results;
+	u32 mixed, max_mlen, not_affine;   /* (not_affine: ecdsa_keys_affine's answer, from the same pass) */
+} scan_job;
+static void scan_keys(u32 lo, u32 hi, void *arg)
+{
+	scan_job *S = (scan_job *)arg;
+	u32 i, mixed = 0, mx = 0, naff = 0, cur;
+	for (i = lo; i < hi; i++) {
+		const ec_pub_key *pk = S->pub_keys[i];
+		int one = 0;
+		S->results[i] = -1;
+		S->idx[i] = i;
+		mx = S->m_len[i] > mx ? S->m_len[i] : mx;
+		if (!pk || pk->magic != PUB_KEY_MAGIC || pk->params != S->params) {
+			mixed = 1;
+			continue;
+		}
+		if (naff || pub_key_check_initialized_and_type(pk, S->sig_type) || prj_pt_check_initialized(&pk->y) || fp_check_initialized(&pk->y.Z)) {
+			continue;
+		}
+		if (nn_isone(&pk->y.Z.fp_val, &one) || !one) {
+			naff = 1;
+		}
+	}
+	if (mixed) {
+		AT_STORE(&S->mixed, 1);
+	}
+	if (naff) {
+		AT_STORE(&S->not_affine, 1);
+	}
+	cur = AT_LOAD(&S->max_mlen);
+	while (mx > cur && !__atomic_compare_exchange_n(&S->max_mlen, &cur, mx, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+	}
+}
+
 static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
-			  ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len, int *results, int all_only)
+			  ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len, int *results, int all_only,
+			  int *fail_known, int *fail)
 {
 	const hash_mapping *hm;
 	hash_alg_type eh = UNKNOWN_HASH_ALG;
 	ec_curve_type ec = UNKNOWN_CURVE;
-	int ph = 0, dom = 0, is448 = 0, ed, ret = -1;
+	int ph = 0, dom = 0, is448 = 0, ed, ret = -1, one_group = 0;
+	scan_job S;
 	u32 *idx = NULL, i, done = 0;
 	u8 *seen = NULL;
 	if (!s || !s_len || !pub_keys || !m || !m_len || !results) {
@@ -3354,23 +3591,39 @@ static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_
 	if (!ed && !is_ecdsa(sig_type) && !is_bip0340(sig_type) && !is_ecfsdsa(sig_type)) {
 		return -1;
 	}
-	for (i = 0; i < num; i++) {
-		results[i] = -1;
-	}
 	if (num == 0) {
 		return 0;
 	}
 	hm = find_hash(hash_type);
-	if (!hm || (ed && hash_type != eh)) {
-		return 0;   /* every ec_verify fails in ec_verify_init / _eddsa_verify_init */
+	if (!hm || (ed && hash_type != eh) || ecamd_compat_init(NULL, 0, 0)) {
+		for (i = 0; i < num; i++) {
+			results[i] = -1;
+		}
+		return (!hm || (ed && hash_type != eh)) ? 0 : -1;   /* (every ec_verify fails in ec_verify_init / _eddsa_verify_init) */
 	}
-	if (ecamd_compat_init(NULL, 0, 0)) {
-		return -1;
-	}
-	idx = (u32 *)malloc((size_t)num * sizeof(u32));
-	seen = (u8 *)calloc(num, 1);
-	if (!idx || !seen) {
+	idx = (u32 *)words_take((size_t)num * sizeof(u32));
+	if (!idx) {
 		goto out;
+	}
+	{
+		S.m_len = m_len;
+		S.sig_type = sig_type;
+		S.max_mlen = S.not_affine = 0;
+		S.pub_keys = pub_keys;
+		S.params = (pub_keys[0] && pub_keys[0]->magic == PUB_KEY_MAGIC) ? pub_keys[0]->params : NULL;
+		S.idx = idx;
+		S.results = results;
+		S.mixed = S.params ? 0 : 1;
+		pthread_mutex_lock(&g_call_mu);
+		parallel_for(num, scan_keys, &S);
+		pthread_mutex_unlock(&g_call_mu);
+		one_group = !AT_LOAD(&S.mixed);
+	}
+	if (!one_group) {
+		seen = (u8 *)calloc(num, 1);
+		if (!seen) {
+			goto out;
+		}
 	}
 	/* groups of items that share their ec_params (one GPU batch each; normally there is one group) */
 	while (done < num) {
@@ -3378,7 +3631,11 @@ static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_
 		ver_job J;
 		u32 cnt = 0;
 		int r;
-		for (i = 0; i < num; i++) {
+		if (one_group) {
+			params = pub_keys[0]->params;
+			cnt = done = num;
+		}
+		for (i = 0; i < num && !one_group; i++) {
 			const ec_pub_key *pk = pub_keys[i];
 			if (seen[i]) {
 				continue;
@@ -3413,16 +3670,25 @@ static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_
 		if (!J.e) {
 			goto out;
 		}
+		if (one_group) {
+			J.pre_scanned = 1;
+			J.pre_max_mlen = S.max_mlen;
+			J.pre_not_affine = S.not_affine;
+		}
 		pthread_mutex_lock(&g_call_mu);
 		r = ed ? eddsa_group(&J, cnt, results) : ((is_bip0340(sig_type) || is_ecfsdsa(sig_type)) ? schnorr_group(&J, cnt, results, is_ecfsdsa(sig_type)) : ecdsa_group(&J, cnt, results));
 		pthread_mutex_unlock(&g_call_mu);
 		if (r) {
 			goto out;
 		}
+		if (one_group && J.fail_tracked && fail_known) {
+			*fail_known = 1;
+			*fail = AT_LOAD(&J.any_fail) ? 1 : 0;
+		}
 	}
 	ret = 0;
 out:
-	free(idx);
+	words_give(idx);
 	free(seen);
 	return ret;
 }
@@ -3430,30 +3696,57 @@ out:
 int ec_verify_batch_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
 			    ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len, int *results)
 {
-	return verify_results(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, results, 0);
+	return verify_results(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, results, 0, NULL, NULL);
+}
+
+typedef struct {
+	const int *res;
+	u32 fail;
+} anyfail_job;
+static void any_failure(u32 lo, u32 hi, void *arg)
+{
+	anyfail_job *A = (anyfail_job *)arg;
+	u32 i, f = 0;
+	for (i = lo; i < hi; i++) {
+		f |= (u32)(A->res[i] != 0);
+	}
+	if (f) {
+		AT_STORE(&A->fail, 1);
+	}
 }
 
 static int all_accepted(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
 			ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len, int all_only)
 {
-	int *res, ret = -1;
-	u32 i;
+	int *res, ret = -1, known = 0, fail = 0;
+	double t0 = 0;
 	if (num == 0) {
 		return -1;   /* "We need at least one element in our batch data bags" (sig/eddsa.c:2312) */
 	}
-	res = (int *)malloc((size_t)num * sizeof(int));
+	res = (int *)words_take((size_t)num * sizeof(int));
 	if (!res) {
 		return -1;
 	}
-	if (!verify_results(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, res, all_only)) {
-		ret = 0;
-		for (i = 0; i < num; i++) {
-			if (res[i]) {
-				ret = -1;
-			}
+	if (getenv("ECAMD_COMPAT_TIMING")) {
+		t0 = now_ms();
+	}
+	if (!verify_results(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, res, all_only, &known, &fail)) {
+		if (known) {
+			ret = fail ? -1 : 0;
+		} else {
+			anyfail_job A;
+			A.res = res;
+			A.fail = 0;
+			pthread_mutex_lock(&g_call_mu);
+			parallel_for(num, any_failure, &A);
+			pthread_mutex_unlock(&g_call_mu);
+			ret = AT_LOAD(&A.fail) ? -1 : 0;
 		}
 	}
-	free(res);
+	words_give(res);
+	if (t0 != 0) {
+		fprintf(stderr, "libecc_amd compat timing: verify call of %u items: %.2f ms in all\n", num, now_ms() - t0);
+	}
 	return ret;
 }
 

@@ -236,6 +236,10 @@ struct ecamd_ctx {
 	hipEvent_t side_fork, side_done;
 	bool side_ok;
 	uint32_t host_chunk;
+	uint32_t host_first_min;   // smallest first chunk of a multi-chunk call (ECAMD_HOST_RAMP_MIN, default 2^16; host_pipeline)
+	// producer hook of the host-pointer entry points (ecamd_ctx_set_host_ready_hook): called before a range of the caller's input arrays is read
+	ecamd_host_ready_fn ready_fn = nullptr;
+	void *ready_arg = nullptr;
 	uint8_t *hbuf[2][6];       // double-buffered device staging of the caller's arrays (inputs and outputs)
 	size_t hbuf_bytes[2][6];
 	uint32_t comb_min_batch;   // fixed-base batches of at least this many items build / use the generator's comb table (0: never)
@@ -404,6 +408,11 @@ extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
 		c->host_chunk = e ? (uint32_t)strtoul(e, nullptr, 10) : (1u << 19);
 		if (c->host_chunk == 0) {
 			c->host_chunk = 1u << 19;
+		}
+		e = getenv("ECAMD_HOST_RAMP_MIN");
+		c->host_first_min = e ? (uint32_t)strtoul(e, nullptr, 10) : (1u << 16);
+		if (c->host_first_min == 0) {
+			c->host_first_min = 1u << 16;
 		}
 	}
 	if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1516,7 +1525,16 @@ static int host_pipeline(ecamd_ctx *ctx, uint32_t n, const std::vector<HostArr> 
 	if (na > 6) {
 		return fail("internal: too many host arrays");
 	}
-	const int nbuf = (n > chunk) ? 2 : 1;
+	// Nothing overlaps the copy of the FIRST chunk (and, with a producer hook, its packing): a batch of several chunks starts with a
+	// short one -- an eighth of a chunk, at least 2^16 items ($ECAMD_HOST_RAMP_MIN) -- so that the kernels start a millisecond earlier at 2^20 items
+	// (profiles/r4i_typed_boundary.md); $ECAMD_NO_HOST_RAMP: equal chunks.
+	static const bool no_ramp = getenv("ECAMD_NO_HOST_RAMP") != nullptr;
+	uint32_t first = chunk;
+	if (n > chunk && !no_ramp) {
+		first = chunk / 8 < ctx->host_first_min ? ctx->host_first_min : chunk / 8;
+		first = first < chunk ? first : chunk;
+	}
+	const int nbuf = (n > first) ? 2 : 1;
 	for (int b = 0; b < nbuf; b++) {
 		for (size_t k = 0; k < na; k++) {
 			if (ensure(&ctx->hbuf[b][k], &ctx->hbuf_bytes[b][k], (size_t)chunk * arrs[k].stride)) {
@@ -1527,6 +1545,9 @@ static int host_pipeline(ecamd_ctx *ctx, uint32_t n, const std::vector<HostArr> 
 	hipStream_t cs = ctx->copy_stream, s = ctx->stream;
 	StreamScope scope(ctx, s);
 	auto copy_in = [&](uint32_t off, uint32_t m, int b) -> int {
+		if (ctx->ready_fn) {
+			ctx->ready_fn(ctx->ready_arg, off, m);   // the producer of the arrays completes [off, off + m) first
+		}
 		for (size_t k = 0; k < na; k++) {
 			if (arrs[k].in) {
 				HIPCHK(hipMemcpyAsync(ctx->hbuf[b][k], arrs[k].in + (size_t)off * arrs[k].stride, (size_t)m * arrs[k].stride,
@@ -1536,12 +1557,12 @@ static int host_pipeline(ecamd_ctx *ctx, uint32_t n, const std::vector<HostArr> 
 		HIPCHK(hipEventRecord(ctx->in_ready[b], cs));
 		return 0;
 	};
-	if (copy_in(0, chunk, 0)) {
+	if (copy_in(0, first, 0)) {
 		return -1;
 	}
 	int b = 0;
-	for (uint32_t off = 0; off < n; off += chunk, b ^= (nbuf - 1)) {
-		const uint32_t m = (n - off) < chunk ? (n - off) : chunk;
+	uint32_t m = first;
+	for (uint32_t off = 0; off < n; off += m, m = (n - off) < chunk ? (n - off) : chunk, b ^= (nbuf - 1)) {
 		std::vector<const uint8_t *> ip(na, nullptr);
 		std::vector<uint8_t *> op(na, nullptr);
 		for (size_t k = 0; k < na; k++) {
@@ -1552,7 +1573,7 @@ static int host_pipeline(ecamd_ctx *ctx, uint32_t n, const std::vector<HostArr> 
 		// `between`: called once this chunk's kernels are enqueued and before anything waits for them -- by the
 		// core itself if it has to synchronise (ECDSA re-checks exceptional items), otherwise right after it
 		bool next_issued = false;
-		const uint32_t noff = off + chunk;
+		const uint32_t noff = off + m;
 		const std::function<int()> between = [&]() -> int {
 			if (next_issued || noff >= n) {
 				return 0;
@@ -1575,6 +1596,17 @@ static int host_pipeline(ecamd_ctx *ctx, uint32_t n, const std::vector<HostArr> 
 		}
 		HIPCHK(hipStreamSynchronize(s));
 	}
+	return 0;
+}
+
+extern "C" int ecamd_ctx_set_host_ready_hook(ecamd_ctx *ctx, ecamd_host_ready_fn fn, void *arg)
+{
+	if (!ctx) {
+		return fail("ecamd_ctx_set_host_ready_hook: NULL context");
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	ctx->ready_fn = fn;
+	ctx->ready_arg = fn ? arg : nullptr;
 	return 0;
 }
 

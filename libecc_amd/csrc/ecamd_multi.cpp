@@ -28,6 +28,14 @@ struct ecamd_multi {
 	std::vector<int> devices;
 	std::vector<ecamd_ctx *> ctx;
 	std::mutex mu;              // one multi-call at a time (the per-device contexts serialise anyway)
+	// producer hook (ecamd_multi_set_host_ready_hook): per rank a trampoline that adds the shard's first item
+	ecamd_host_ready_fn ready_fn = nullptr;
+	void *ready_arg = nullptr;
+	struct ReadyTramp {
+		ecamd_multi *m;
+		uint32_t base;
+	};
+	std::vector<ReadyTramp> tramp;
 	// RCCL, loaded on the first all-gather
 	void *rccl = nullptr;
 	std::vector<ncclComm_t> comms;  // one communicator per rank
@@ -215,6 +223,9 @@ static int run_sharded(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const 
 	auto body = [&](int r) {
 		const uint32_t lo = shard_lo(n, r, N), hi = shard_lo(n, r + 1, N);
 		if (hi > lo) {
+			if (m->ready_fn) {
+				m->tramp[(size_t)r].base = lo;
+			}
 			rc[(size_t)r] = shard(r, lo, hi);
 			if (rc[(size_t)r]) {
 				err[(size_t)r] = ecamd_last_error();  // thread-local of the worker
@@ -452,6 +463,33 @@ extern "C" int ecamd_multi_set_secret_scalars(ecamd_multi *m, int on)
 }
 
 // one 32-byte seed for the next whole-batch EdDSA verification: rank r keys its shard's combination with seed ^ r (first byte)
+static void ready_trampoline(void *arg, uint32_t first, uint32_t count)
+{
+	const ecamd_multi::ReadyTramp *t = (const ecamd_multi::ReadyTramp *)arg;
+	if (t->m->ready_fn) {
+		t->m->ready_fn(t->m->ready_arg, t->base + first, count);
+	}
+}
+
+extern "C" int ecamd_multi_set_host_ready_hook(ecamd_multi *m, ecamd_host_ready_fn fn, void *arg)
+{
+	if (!m) {
+		return mfail("ecamd_multi_set_host_ready_hook: NULL argument");
+	}
+	std::lock_guard<std::mutex> lk(m->mu);
+	m->ready_fn = fn;
+	m->ready_arg = fn ? arg : nullptr;
+	m->tramp.resize(m->ctx.size());
+	for (size_t r = 0; r < m->ctx.size(); r++) {
+		m->tramp[r].m = m;
+		m->tramp[r].base = 0;
+		if (ecamd_ctx_set_host_ready_hook(m->ctx[r], fn ? ready_trampoline : nullptr, &m->tramp[r])) {
+			return mfail(std::string("ecamd_multi_set_host_ready_hook: ") + ecamd_last_error());
+		}
+	}
+	return 0;
+}
+
 extern "C" int ecamd_multi_set_msm_seed(ecamd_multi *m, const uint8_t seed[32])
 {
 	if (!m || !seed) {

@@ -49,6 +49,11 @@ int ecamd_multi_size(const ecamd_multi *m) { return m ? m->nranks : 0; }
 int ecamd_multi_set_secret_scalars(ecamd_multi *m, int on) { m->secret = on; return 0; }
 int ecamd_multi_wipe_scratch(ecamd_multi *m) { (void)m; return 0; }
 int ecamd_multi_set_msm_seed(ecamd_multi *m, const uint8_t seed[32]) { (void)m; (void)seed; return 0; }
+/* the producer hook: the mock's batch calls read their arrays in one go, so they ask for the whole range first */
+static ecamd_host_ready_fn g_ready_fn;
+static void *g_ready_arg;
+int ecamd_multi_set_host_ready_hook(ecamd_multi *m, ecamd_host_ready_fn fn, void *arg) { (void)m; g_ready_fn = fn; g_ready_arg = arg; return 0; }
+static void mock_ready(uint32_t n) { if (g_ready_fn) { uint32_t o; for (o = 0; o < n; o += 1000) { g_ready_fn(g_ready_arg, o, (n - o) < 1000 ? (n - o) : 1000); } } }
 void *ecamd_host_alloc(size_t bytes) { return malloc(bytes); }
 void ecamd_host_free(void *p) { free(p); }
 
@@ -184,6 +189,7 @@ int ecamd_multi_prj_pt_add_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t
 int ecamd_multi_ecdsa_verify_batch_fmt(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys, int pub_fmt,
 				       const uint8_t *sigs, const uint8_t *digests, uint32_t digest_len, uint8_t *result)
 {
+	mock_ready(n);
 	const size_t cl = (size_t)c->c.clen;
 	uint8_t *prj = malloc((size_t)n * 3 * cl + 1), *aff = malloc((size_t)n * 2 * cl + 1), *st = malloc(n + 1);
 	uint32_t i;
@@ -235,6 +241,11 @@ static int mock_hash_slots(int hash_type, uint32_t n, const uint8_t *slots, uint
 int ecamd_multi_ecdsa_verify_msg_batch_fmt(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys, int pub_fmt,
 					   const uint8_t *sigs, int hash_type, const uint8_t *msg_slots, uint32_t msg_stride, uint8_t *result)
 {
+	mock_ready(n);
+	if (getenv("MOCK_ACCEPT_ALL")) {   /* timing harness of the typed layer's host side: no verification at all */
+		memset(result, 0, n);
+		return 0;
+	}
 	uint8_t *dg = malloc((size_t)n * 64 + 1);
 	uint32_t dl = 0;
 	int r = (!dg || mock_hash_slots(hash_type, n, msg_slots, msg_stride, dg, &dl)) ? mfail("mock: hashing failed")
@@ -246,6 +257,7 @@ int ecamd_multi_ecdsa_verify_msg_batch_fmt(ecamd_multi *m, const ecamd_mcurve *c
 int ecamd_multi_eddsa_verify_msg_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs,
 				       const uint8_t *hash_slots, uint32_t stride, uint8_t *result)
 {
+	mock_ready(n);
 	uint8_t *dg = malloc((size_t)n * 64 + 1);
 	uint32_t dl = 0;
 	int r = (!dg || mock_hash_slots(4, n, hash_slots, stride, dg, &dl)) ? mfail("mock: hashing failed")
@@ -280,6 +292,7 @@ int ecamd_multi_xdh_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, con
 int ecamd_multi_eddsa_verify_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs,
 				   const uint8_t *hram, uint32_t hram_len, uint8_t *result)
 {
+	mock_ready(n);
 	(void)m;
 	note(n);
 	return c->c.clen == 56 ? orc_eddsa448_verify_batch(&c->c, n, pubkeys, sigs, hram, hram_len, result)

@@ -1312,17 +1312,29 @@ def test_host_pipeline_multi_chunk(gpu_ctx):
     import libecc_amd
     from test_oracle import ed25519_cases
     rng = np.random.default_rng(38)
-    old = os.environ.get("ECAMD_HOST_CHUNK")
+    old = {k: os.environ.get(k) for k in ("ECAMD_HOST_CHUNK", "ECAMD_HOST_RAMP_MIN")}
     os.environ["ECAMD_HOST_CHUNK"] = "700"
+    os.environ["ECAMD_HOST_RAMP_MIN"] = "100"    # the short first chunk of a multi-chunk call: 100, then 700, 700, 700, 23 items
     try:
         ctx2 = libecc_amd.Context(0)
     finally:
-        if old is None:
-            del os.environ["ECAMD_HOST_CHUNK"]
-        else:
-            os.environ["ECAMD_HOST_CHUNK"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     try:
         n = 3 * 700 + 123
+        # the producer hook: asked for every range of the input arrays before it is read, in order, exactly once
+        asked = []
+        ctx2.set_host_ready_hook(lambda first, count: asked.append((first, count)))
+        hk = ctx2.curve("SECP256R1")
+        try:
+            hk.scalar_mult(rand_bytes(rng, 32 * n))
+        finally:
+            hk.free()
+            ctx2.set_host_ready_hook(None)
+        assert asked == [(0, 100), (100, 700), (800, 700), (1500, 700), (2200, 23)], asked
         a, b = gpu_ctx.curve("SECP256R1"), ctx2.curve("SECP256R1")
         try:
             sc = rand_bytes(rng, 32 * n)
