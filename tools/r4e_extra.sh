@@ -1,17 +1,28 @@
-cd /tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/${PASS:-r4p}
+# A/B of the prefetching affine / finalisation kernels against the variants built without it
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/${PASS:-r4r}
 mkdir -p $O
-B=$GRAFT_REPO_ROOT/libecc_amd/lib/compat_check
-export ECAMD_COMPAT_TIMING=1
-run() { name=$1; shift; ( env "$@" timeout 200 $B benchv 20 $CURVE ) > $O/benchv_${CURVE}_$name.txt 2>&1; echo "== $CURVE $name"; grep -E "M verif" $O/benchv_${CURVE}_$name.txt | cut -c40-130; grep -E "timing" $O/benchv_${CURVE}_$name.txt | grep -v "1 chunks" | tail -2 | cut -c1-200; }
-for CURVE in 256 384; do
-run ramp_h19 A=1
-run ramp_h18 ECAMD_HOST_CHUNK=262144
-run noramp_h19 ECAMD_NO_HOST_RAMP=1
-run noramp_h18 ECAMD_NO_HOST_RAMP=1 ECAMD_HOST_CHUNK=262144
-run ramp32k_h19 ECAMD_HOST_RAMP_MIN=32768
-run nostream ECAMD_COMPAT_NO_STREAM=1
-done
-unset ECAMD_COMPAT_TIMING
-( timeout 300 $B 256 ) > $O/compat_check_256.txt 2>&1; tail -2 $O/compat_check_256.txt
-( timeout 300 $B bench 20 ) > $O/compat_bench_20.txt 2>&1; grep -E "bench " $O/compat_bench_20.txt | cut -c1-150
+V=libecc_amd/lib/variants
+one() { name=$1; shift; ( "$@" ) > $O/$name.json 2> $O/$name.err; python - $O/$name.json <<'PY'
+import json, sys
+try:
+    j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = j.get("roofline") or {}
+    print(sys.argv[1].split("/")[-1], "value %.3f M/s" % (j["value"] / 1e6), "ms %.3f" % j["ms_per_step"], "kernel_ms", r.get("kernel_ms"), "frac", r.get("frac"), "pipeline", r.get("pipeline_frac"))
+except Exception as e:
+    print(sys.argv[1], "unreadable", e)
+PY
+}
+B="python bench.py --no-secondary --no-traffic --no-cpu-baseline --steps 10 --warmup 3 --parity-items 256"
+one p256_pf $B
+one p256_nopf env ECAMD_LIB_PATH=$PWD/$V/libecc_amd_nopf256.so $B
+one p256_pf2 $B
+one p256_nopf2 env ECAMD_LIB_PATH=$PWD/$V/libecc_amd_nopf256.so $B
+one p384_pf $B --curve SECP384R1
+one p384_nopf env ECAMD_LIB_PATH=$PWD/$V/libecc_amd_nopf384.so $B --curve SECP384R1
+one p521_pf $B --curve SECP521R1
+one p521_nopf env ECAMD_LIB_PATH=$PWD/$V/libecc_amd_nopf521.so $B --curve SECP521R1
+P="python tools/bench_protocols.py --no-cpu-baseline --steps 8 --warmup 2"
+one ecdsa256_pf $P --workload ecdsa_verify
+one ecdsa256_nopf env ECAMD_LIB_PATH=$PWD/$V/libecc_amd_nopf256.so $P --workload ecdsa_verify
+one ecdsa384_pf $P --workload ecdsa_verify --curve SECP384R1
+one ecdsa384_nopf env ECAMD_LIB_PATH=$PWD/$V/libecc_amd_nopf384.so $P --workload ecdsa_verify --curve SECP384R1
