@@ -209,6 +209,14 @@ int ec_ecdsa_verify_msg_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *curve, uint
 				  const uint8_t *sigs, int hash_type, const uint8_t *msg_slots, uint32_t msg_stride, uint8_t *result);
 int ec_eddsa_verify_msg_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs,
 			      const uint8_t *hash_slots, uint32_t stride, uint8_t *result);
+/* The same from the PROJECTIVE key an ec_pub_key holds (n x 3*32 bytes X || Y || Z on WEI25519, the layout of ec_pub_key_export_to_buf's
+ * payload): the key is imported and normalised as prj_pt_import_from_buf / prj_pt_unique do, encoded as eddsa_export_pub_key does
+ * (sig/eddsa.c:795), and the 32 octets are written into the item's hash input at message offset a_offset (bytes 4 + a_offset .. of its
+ * slot, which the caller leaves blank and counts in the slot's length; the caller's array is not modified) before hashing -- what
+ * ec_eddsa_encode_point_batch, a copy back, and ec_eddsa_verify_msg_batch would do in three steps.  An item whose key does not import
+ * is rejected (result 1); a key at infinity encodes as (0, 1) and is rejected by the small-order test like in the reference. */
+int ec_eddsa_verify_msg_prj_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
+				  const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, uint8_t *result);
 /* ECDSA signing with caller-supplied nonces: per item the tail of ec_sign / __ecdsa_sign_finalize
  * (sig/ecdsa_common.c:318-586) -- kG = prj_pt_mul(k, G), r = kG.x mod q, s = k^-1 (x r + e) mod q --
  * with h = H(m) and the nonce k supplied by the caller (random, or RFC 6979 computed on the host;
@@ -436,6 +444,8 @@ int ecamd_multi_ecdsa_verify_msg_batch_fmt(ecamd_multi *m, const ecamd_mcurve *c
 					   const uint8_t *sigs, int hash_type, const uint8_t *msg_slots, uint32_t msg_stride, uint8_t *result);
 int ecamd_multi_eddsa_verify_msg_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs,
 				       const uint8_t *hash_slots, uint32_t stride, uint8_t *result);
+int ecamd_multi_eddsa_verify_msg_prj_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
+					   const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, uint8_t *result);
 int ecamd_multi_ecdsa_sign_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *privs,
 				 const uint8_t *nonces, const uint8_t *digests, uint32_t digest_len, uint8_t *sigs,
 				 uint8_t *status);

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "ecamd_multi_ecdsa_verify_batch", "ecamd_multi_ecdsa_verify_batch_fmt", "ecamd_multi_ecdsa_sign_batch", "ecamd_multi_ecccdh_derive_batch",
     "ecamd_multi_xdh_batch", "ecamd_multi_eddsa_verify_batch", "ecamd_multi_eddsa_verify_all_batch", "ecamd_multi_allgather",
     "ecamd_multi_allgather_streams", "ecamd_multi_eddsa_sign_R_batch", "ecamd_multi_eddsa_sign_S_batch",
-    "ecamd_multi_set_secret_scalars", "ecamd_multi_wipe_scratch", "ecamd_ctx_wipe_scratch", "ecamd_ctx_stream", "ecamd_host_alloc", "ecamd_host_free", "ecamd_ctx_dominant_kernel_ms", "ecamd_ctx_set_msm_seed", "ecamd_multi_set_msm_seed", "ecamd_ctx_set_host_ready_hook", "ecamd_multi_set_host_ready_hook", "ecamd_multi_prj_pt_add_batch",
+    "ecamd_multi_set_secret_scalars", "ecamd_multi_wipe_scratch", "ecamd_ctx_wipe_scratch", "ecamd_ctx_stream", "ecamd_host_alloc", "ecamd_host_free", "ecamd_ctx_dominant_kernel_ms", "ecamd_ctx_set_msm_seed", "ecamd_multi_set_msm_seed", "ec_eddsa_verify_msg_prj_batch", "ecamd_multi_eddsa_verify_msg_prj_batch", "ecamd_ctx_set_host_ready_hook", "ecamd_multi_set_host_ready_hook", "ecamd_multi_prj_pt_add_batch",
 ]
 
 
@@ -298,6 +298,16 @@ class Curve:
         slots, stride = self.msg_slots(hash_inputs)
         res = C.create_string_buffer(max(1, n))
         _chk(self.L, self.L.ec_eddsa_verify_msg_batch(self.ctx.h, self.h, n, pubkeys, sigs, slots, stride, res), "ec_eddsa_verify_msg_batch")
+        return res.raw[:n]
+
+    def eddsa_verify_msgs_prj(self, keys_prj, sigs, hash_inputs, a_offset):
+        """the same from projective keys (X || Y || Z on WEI25519): the device writes each key's encoding into bytes
+        a_offset .. a_offset + 32 of its hash input (left blank by the caller) before hashing"""
+        n = len(hash_inputs)
+        slots, stride = self.msg_slots(hash_inputs)
+        res = C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_eddsa_verify_msg_prj_batch(self.ctx.h, self.h, n, keys_prj, sigs, slots, stride, a_offset, res),
+             "ec_eddsa_verify_msg_prj_batch")
         return res.raw[:n]
 
     def ecdsa_verify_fmt(self, pubs, pub_fmt, sigs, digests, hlen):

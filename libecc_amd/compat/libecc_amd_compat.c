@@ -3103,6 +3103,46 @@ static void eddsa_pack(u32 lo, u32 hi, void *arg)
 	}
 }
 
+/* EDDSA25519 with the hashing on the device, round 4: ONE pass.  The key leaves as the projective point the ec_pub_key holds; the device
+ * imports it, encodes it the way eddsa_export_pub_key does and writes the 32 octets into the hash input R || A || M itself
+ * (ec_eddsa_verify_msg_prj_batch), so the separate encoding call of the whole group -- and with it the only reason the packing could
+ * not start before a GPU round trip -- is gone.  $ECAMD_COMPAT_ED_TWO_PASS keeps the two calls. */
+static void eddsa_pack_prj(u32 lo, u32 hi, void *arg)
+{
+	static const u8 blank[32] = {0};
+	ver_job *J = (ver_job *)arg;
+	u32 j;
+	for (j = lo; j < hi; j++) {
+		const u32 i = J->idx[j];
+		const ec_pub_key *pk = J->pub_keys[i];
+		u8 *kdst = J->kprj + (size_t)j * 3 * J->clen;
+		/* _eddsa_verify_init (sig/eddsa.c:1880-1960), as in eddsa_pack */
+		int bad = pub_key_check_initialized_and_type(pk, J->sig_type) || pk->params != J->params || !J->s[i] ||
+			  J->s_len[i] != J->siglen || (!J->m[i] && J->m_len[i]);
+		bad = bad || prj_to_be(kdst, J->clen, &pk->y, &(J->params->ec_curve));
+		if (!bad) {
+			slot_put(J->dg + (size_t)j * J->slot, J->slot, J->s[i], J->klen, blank, J->klen, J->m[i], J->m_len[i]);
+			memcpy(J->sg + (size_t)j * J->siglen, J->s[i], J->siglen);
+		} else {
+			memset(kdst, 0xff, (size_t)3 * J->clen);   /* coordinates >= p: an import error on the device */
+			memset(J->sg + (size_t)j * J->siglen, 0xff, J->siglen);
+			memset(J->dg + (size_t)j * J->slot, 0, J->slot);
+		}
+		J->pre[j] = bad ? 1 : 0;
+	}
+}
+
+static int eddsa_ver_gpu_prj(u32 lo, u32 hi, void *arg)
+{
+	ver_job *J = (ver_job *)arg;
+	if (ecamd_multi_eddsa_verify_msg_prj_batch(g_multi, J->e->mc, hi - lo, J->kprj + (size_t)lo * 3 * J->clen, J->sg + (size_t)lo * J->siglen,
+						   J->dg + (size_t)lo * J->slot, J->slot, J->klen, J->res + lo)) {
+		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+		return -1;
+	}
+	return 0;
+}
+
 static int eddsa_ver_gpu(u32 lo, u32 hi, void *arg)
 {
 	ver_job *J = (ver_job *)arg;
@@ -3167,6 +3207,7 @@ static int eddsa_ver_gpu_all(u32 lo, u32 hi, void *arg)
 static int eddsa_group(ver_job *J, u32 cnt, int *results)
 {
 	u32 j;
+	int one_pass = 0;
 	J->clen = J->e->clen;
 	J->hlen = J->hm->digest_size;      /* 64 (SHA-512) / 114 (SHAKE256 as libecc configures it) */
 	J->klen = J->hlen / 2;             /* EDDSA_R_LEN: 32 / 57 */
@@ -3178,9 +3219,15 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
 	J->dev_hash = 0;
 	J->slot = 0;
 #if defined(WITH_SIG_EDDSA25519)
-	if (J->sig_type == EDDSA25519 && !J->all_only && !J->dom && !J->ph && dev_hash_type(J->hm) == 4) {
+	if (J->sig_type == EDDSA25519 && !J->dom && !J->ph && dev_hash_type(J->hm) == 4) {
+		/* (also when only the conjunction is wanted: since the half-length scalars of round 4 the item-by-item verification of 2^20
+		 * signatures takes the 12 ms the multi-scalar combination takes, needs no z_i, and does not wait for the host to hash) */
 		J->slot = dev_hash_slot(J, cnt, 2 * J->klen);
-		J->dev_hash = J->slot ? 4 : 0;
+		one_pass = J->slot && !getenv("ECAMD_COMPAT_ED_TWO_PASS");
+		J->dev_hash = (J->slot && (one_pass || !J->all_only)) ? 4 : 0;
+		if (!J->dev_hash) {
+			J->slot = 0;
+		}
 	}
 #endif
 	J->pk = buf_get(0, (size_t)cnt * J->klen);
@@ -3191,6 +3238,15 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
 	J->kprj = buf_get(5, (size_t)cnt * 3 * J->clen);
 	if (!J->pk || !J->sg || !J->dg || !J->pre || !J->res || !J->kprj) {
 		return -1;
+	}
+	if (one_pass) {
+		J->results = results;
+		J->fail_tracked = 1;
+		if (verify_pipeline(cnt, eddsa_pack_prj, eddsa_ver_gpu_prj, ver_unpack, J)) {
+			return -1;
+		}
+		note_items(cnt);
+		return 0;
 	}
 	/* the keys as the reference hashes them: exported as points here, encoded on the device (pre[j] != 0: no encoding) */
 	parallel_for(cnt, eddsa_export_keys, J);

@@ -208,3 +208,40 @@ hipError_t ecamd_launch_sha2_slots(int hash_type, const uint8_t *slots, uint32_t
 	}
 	return hipGetLastError();
 }
+
+// ---- two byte movers of ec_eddsa_verify_msg_prj_batch: the key's encoding into its place in the hash input, and "an item whose key did not
+//      import is rejected" ----
+__global__ __launch_bounds__(256) void k_slot_patch(u8 *slots, u32 stride, u32 off, const u8 *src, u32 len, const u8 *skip, u32 n)
+{
+	const u32 i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n || (skip && skip[i])) {
+		return;
+	}
+	u8 *d = slots + (size_t)i * stride + 4 + off;
+	const u8 *v = src + (size_t)i * len;
+	for (u32 b = 0; b < len; b++) {
+		d[b] = v[b];
+	}
+}
+__global__ __launch_bounds__(256) void k_reject_where(u8 *result, const u8 *status, u32 n)
+{
+	const u32 i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n && status[i]) {
+		result[i] = 1;
+	}
+}
+hipError_t ecamd_launch_slot_patch(uint8_t *slots, uint32_t stride, uint32_t off, const uint8_t *src, uint32_t len, const uint8_t *skip, uint32_t n,
+				   hipStream_t s)
+{
+	if (n) {
+		hipLaunchKernelGGL(k_slot_patch, dim3((n + 255) / 256), dim3(256), 0, s, slots, stride, off, src, len, skip, n);
+	}
+	return hipGetLastError();
+}
+hipError_t ecamd_launch_reject_where(uint8_t *result, const uint8_t *status, uint32_t n, hipStream_t s)
+{
+	if (n) {
+		hipLaunchKernelGGL(k_reject_where, dim3((n + 255) / 256), dim3(256), 0, s, result, status, n);
+	}
+	return hipGetLastError();
+}

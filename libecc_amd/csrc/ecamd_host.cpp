@@ -207,7 +207,7 @@ static const CurveRow g_curve_rows[] = {
 // ------------------------------------------------------------------------------------------
 // objects behind the opaque handles
 // ------------------------------------------------------------------------------------------
-#define ECAMD_NSTAGE 20
+#define ECAMD_NSTAGE 24
 struct ecamd_ctx {
 	int device;
 	hipStream_t stream;
@@ -3588,6 +3588,69 @@ extern "C" int ec_eddsa_verify_msg_batch(ecamd_ctx *ctx, const ecamd_curve *cv_i
 			return -1;
 		}
 		return eddsa_verify_dev_locked(ctx, cv, m, ip[0], ip[1], ctx->stage[17], 64, op[3], s);
+	});
+}
+
+static int eddsa_sign_setup(const char *fn, ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const void *a, const void *b,
+			    const void *c, EcamdEdSignArgs *T);
+// The same from the PROJECTIVE key an ec_pub_key holds (X || Y || Z on WEI25519): what a verifier that starts from libecc structures
+// needs -- the reference hashes the key's Ed25519 ENCODING (eddsa_export_pub_key, sig/eddsa.c:795: Weierstrass -> Edwards -> octets), which
+// ec_eddsa_encode_point_batch computes; here that encoding goes straight into the item's hash input on the device (bytes a_offset ..
+// a_offset + 32 of the slot's message, which the caller leaves blank; the caller's array itself is not written), so one call replaces encode / copy back / build the inputs /
+// verify.  A key that does not import (coordinates >= p, not on the curve) or is the point at infinity rejects its item.
+extern "C" int ec_eddsa_verify_msg_prj_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
+					     const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, uint8_t *result)
+{
+	if (!ctx || stride < 4 || (stride & 3u) || stride > 4096 || (uint64_t)a_offset + 36 > stride) {
+		return fail("ec_eddsa_verify_msg_prj_batch: bad argument (stride: a multiple of 4 in 4 .. 4096; 4 + a_offset + 32 <= stride)");
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	EcamdEdSignArgs T;
+	if (eddsa_sign_setup("ec_eddsa_verify_msg_prj_batch", ctx, cv_in, n, keys_prj, sigs, hash_slots, &T) ||
+	    eddsa_args_ok("ec_eddsa_verify_msg_prj_batch", ctx, cv_in, n, keys_prj, sigs, hash_slots, result, 64)) {
+		return -1;
+	}
+	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
+	if (cv->pbits != 255) {
+		return fail("ec_eddsa_verify_msg_prj_batch: Ed25519 (the WEI25519 handle) only: Ed448 hashes with SHAKE256");
+	}
+	if (n == 0) {
+		return 0;
+	}
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t cl = (size_t)cv->clen;
+	const std::vector<HostArr> arrs = {{keys_prj, nullptr, 3 * cl}, {sigs, nullptr, 64u}, {hash_slots, nullptr, stride}, {nullptr, result, 1}};
+	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+					       hipStream_t s, const std::function<int()> &) {
+		// stage: 20 affine keys, 21 import status, 22 encodings, 23 their status (the verification core owns 3 .. 19)
+		if (ensure(&ctx->stage[20], &ctx->stage_bytes[20], (size_t)m * 2 * cl) || ensure(&ctx->stage[21], &ctx->stage_bytes[21], m) ||
+		    ensure(&ctx->stage[22], &ctx->stage_bytes[22], (size_t)m * 32) || ensure(&ctx->stage[23], &ctx->stage_bytes[23], m)) {
+			return -1;
+		}
+		EcamdPrjInArgs I;
+		I.in = ip[0];
+		I.aff = ctx->stage[20];
+		I.pre = ctx->stage[21];
+		I.n = m;
+		I.clen = (uint32_t)cl;
+		I.for_mul = 0;
+		I.slot = cv->slot;
+		HIPCHK(launch_prj_import(cv, I, s));
+		EcamdEdSignArgs A = T;
+		A.n = m;
+		A.Rw = ctx->stage[20];
+		A.stR = ctx->stage[21];
+		A.out = ctx->stage[22];
+		A.status = ctx->stage[23];
+		HIPCHK(ecamd_launch_ed_sign_enc(A, s));
+		uint8_t *slots = const_cast<uint8_t *>(ip[2]);   // the staged copy of the caller's slots
+		HIPCHK(ecamd_launch_slot_patch(slots, stride, a_offset, ctx->stage[22], 32, ctx->stage[23], m, s));
+		if (ecdsa_hash_stage(ctx, 4, m, slots, stride, 64, s) ||
+		    eddsa_verify_dev_locked(ctx, cv, m, ctx->stage[22], ip[1], ctx->stage[17], 64, op[3], s)) {
+			return -1;
+		}
+		HIPCHK(ecamd_launch_reject_where(op[3], ctx->stage[23], m, s));
+		return 0;
 	});
 }
 

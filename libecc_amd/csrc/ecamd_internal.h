@@ -425,6 +425,10 @@ hipError_t ecamd_g29_comb_build(int pbits, int gslot, const uint8_t *pts, uint32
 				hipStream_t s, int flavour);
 // SHA-224 / 256 / 384 / 512 of n messages in fixed-stride slots (ecamd_hash.hip); hash_type: libecc's hash_alg_type numbers 1 .. 4
 int ecamd_sha2_digest_len(int hash_type);
+// the key's encoding written into the item's hash input (bytes 4 + off .. of its slot; items with skip[i] != 0 left alone); result[i] = 1 where status[i] != 0
+hipError_t ecamd_launch_slot_patch(uint8_t *slots, uint32_t stride, uint32_t off, const uint8_t *src, uint32_t len, const uint8_t *skip, uint32_t n,
+				   hipStream_t s);
+hipError_t ecamd_launch_reject_where(uint8_t *result, const uint8_t *status, uint32_t n, hipStream_t s);
 hipError_t ecamd_launch_sha2_slots(int hash_type, const uint8_t *slots, uint32_t stride, uint32_t n, uint8_t *out, uint32_t out_stride, hipStream_t s);
 struct EcamdPrjInArgs;
 // prj_pt_import_from_buf + prj_pt_unique on a radix-2^29 unit, one inversion per eight triples (k_prj_import_g)

@@ -315,6 +315,16 @@ extern "C" int ecamd_multi_eddsa_verify_msg_batch(ecamd_multi *m, const ecamd_mc
 	});
 }
 
+extern "C" int ecamd_multi_eddsa_verify_msg_prj_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
+						      const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, uint8_t *result)
+{
+	const size_t kl = 3 * (size_t)ecamd_multi_curve_coord_len(c);
+	return run_sharded(m, c, n, "ecamd_multi_eddsa_verify_msg_prj_batch", [&](int r, uint32_t lo, uint32_t hi) {
+		return ec_eddsa_verify_msg_prj_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(keys_prj, kl), OFF(sigs, 64), OFF(hash_slots, (size_t)stride),
+						     stride, a_offset, OFF(result, 1));
+	});
+}
+
 extern "C" int ecamd_multi_ecdsa_sign_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *privs,
 					    const uint8_t *nonces, const uint8_t *digests, uint32_t digest_len, uint8_t *sigs,
 					    uint8_t *status)

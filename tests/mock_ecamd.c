@@ -289,6 +289,36 @@ int ecamd_multi_xdh_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, con
 	return orc_xdh_batch(&c->c, (uint32_t)c->c.clen, n, k, u, out, status);
 }
 
+int ecamd_multi_eddsa_encode_point_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *points_prj, uint8_t *enc, uint8_t *status);
+int ecamd_multi_eddsa_verify_msg_prj_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
+					   const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, uint8_t *result)
+{
+	/* encode, write the encodings into a copy of the slots, hash, verify; an item whose key has no encoding is rejected */
+	uint8_t *enc = malloc((size_t)n * 32 + 1), *st = malloc(n + 1), *sl = malloc((size_t)n * stride + 1);
+	uint32_t i;
+	int r;
+	mock_ready(n);
+	if (!enc || !st || !sl) {
+		free(enc); free(st); free(sl);
+		return mfail("mock: out of memory");
+	}
+	memcpy(sl, hash_slots, (size_t)n * stride);
+	r = ecamd_multi_eddsa_encode_point_batch(m, c, n, keys_prj, enc, st);
+	for (i = 0; i < n && !r; i++) {
+		if (!st[i]) {
+			memcpy(sl + (size_t)i * stride + 4 + a_offset, enc + (size_t)i * 32, 32);
+		}
+	}
+	r = r || ecamd_multi_eddsa_verify_msg_batch(m, c, n, enc, sigs, sl, stride, result);
+	for (i = 0; i < n && !r; i++) {
+		if (st[i]) {
+			result[i] = 1;
+		}
+	}
+	free(enc); free(st); free(sl);
+	return r;
+}
+
 int ecamd_multi_eddsa_verify_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs,
 				   const uint8_t *hram, uint32_t hram_len, uint8_t *result)
 {

@@ -75,3 +75,66 @@ def test_eddsa_verify_from_hash_inputs(gpu_ctx):
         assert cv.eddsa_verify_msgs(pubs * reps, sigs * reps, inputs * reps) == exp * reps
     finally:
         cv.free()
+
+
+def test_eddsa_verify_from_projective_keys_and_messages(gpu_ctx):
+    """ec_eddsa_verify_msg_prj_batch: the projective Weierstrass key an ec_pub_key holds goes in, the device imports it, encodes it
+    (eddsa_export_pub_key) and writes the 32 octets into the blank of the hash input R || A || M before hashing.  Expected verdicts:
+    ec_eddsa_verify_batch on the encodings ec_eddsa_encode_point_batch gives for the same keys and hashlib's hashes -- both pinned
+    against the reference elsewhere -- with signatures made here from Python integers; keys that do not import, keys at infinity,
+    corrupted signatures and messages, ragged message lengths, a multi-chunk batch."""
+    rng = np.random.default_rng(97)
+    cv = gpu_ctx.curve("WEI25519")
+    c = O.CURVES["WEI25519"]
+    p, q = c["p"], c["q"]
+    try:
+        n = 96
+        lens = [0, 1, 31, 47, 48, 63, 64, 65, 111, 150] * 10
+        msgs = [rand_bytes(rng, lens[i]) for i in range(n)]
+        a = [(int.from_bytes(rand_bytes(rng, 40), "big") % (q - 1)) + 1 for _ in range(n)]
+        r = [(int.from_bytes(rand_bytes(rng, 40), "big") % (q - 1)) + 1 for _ in range(n)]
+        Aw, st = cv.scalar_mult(b"".join(x.to_bytes(32, "big") for x in a))
+        Rw, st2 = cv.scalar_mult(b"".join(x.to_bytes(32, "big") for x in r))
+        assert set(st) == {0} and set(st2) == {0}
+
+        def prj(aff, i, lam):
+            x, y = int.from_bytes(aff[64 * i:64 * i + 32], "big"), int.from_bytes(aff[64 * i + 32:64 * i + 64], "big")
+            return b"".join((v % p).to_bytes(32, "big") for v in (x * lam, y * lam, lam))
+        lams = [1 if i % 3 == 0 else int.from_bytes(rand_bytes(rng, 40), "big") % (p - 1) + 1 for i in range(n)]
+        keys = b"".join(prj(Aw, i, lams[i]) for i in range(n))
+        Aenc, est = cv.eddsa_encode_points(keys)
+        Renc, est2 = cv.eddsa_encode_points(b"".join(prj(Rw, i, 1) for i in range(n)))
+        assert set(est) == {0} and set(est2) == {0}
+        sigs, hram, inputs = bytearray(), b"", []
+        for i in range(n):
+            Ri, Ai = Renc[32 * i:32 * i + 32], Aenc[32 * i:32 * i + 32]
+            hd = hashlib.sha512(Ri + Ai + msgs[i]).digest()
+            S = (r[i] + (int.from_bytes(hd, "little") % q) * a[i]) % q
+            sigs += Ri + S.to_bytes(32, "little")
+            hram += hd
+            inputs.append(Ri + bytes(32) + msgs[i])          # the blank the device fills
+        for i in range(0, n, 7):
+            sigs[64 * i + 40] ^= 4                           # corrupted S
+        for i in range(3, n, 11):
+            sigs[64 * i + 5] ^= 1                            # corrupted R (the hash input keeps the original: also a rejection)
+        sigs = bytes(sigs)
+        exp = cv.eddsa_verify(Aenc, sigs, hram)
+        assert 0 in exp and 1 in exp
+        assert cv.eddsa_verify_msgs_prj(keys, sigs, inputs, 32) == exp
+        # keys that do not import / are at infinity / are not on the curve reject their item and nothing else
+        kb = bytearray(keys)
+        kb[96 * 1:96 * 1 + 32] = p.to_bytes(32, "big")                        # X = p
+        kb[96 * 2 + 64:96 * 3] = bytes(32)                                   # Z = 0 (with X, Y left): not on the curve
+        kb[96 * 4:96 * 5] = bytes(32) + (1).to_bytes(32, "big") + bytes(32)  # (0 : 1 : 0): the point at infinity
+        kb[96 * 5 + 31] ^= 1                                                 # off the curve
+        got = cv.eddsa_verify_msgs_prj(bytes(kb), sigs, inputs, 32)
+        for i in range(n):
+            assert got[i] == (1 if i in (1, 2, 4, 5) else exp[i]), i
+        # a flipped message byte
+        bad = [x[:64] + (bytes([x[64] ^ 1]) + x[65:] if len(x) > 64 else b"y") for x in inputs]
+        assert cv.eddsa_verify_msgs_prj(keys, sigs, bad, 32) == bytes([1]) * n
+        # several chunks of the host pipeline (short first chunk included)
+        reps = 4200 // n + 1
+        assert cv.eddsa_verify_msgs_prj(keys * reps, sigs * reps, inputs * reps, 32) == exp * reps
+    finally:
+        cv.free()
