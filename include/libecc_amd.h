@@ -226,6 +226,22 @@ int ec_eddsa_verify_msg_prj_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint
 int ec_ecdsa_sign_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *privs,
 			const uint8_t *nonces, const uint8_t *digests, uint32_t digest_len, uint8_t *sigs,
 			uint8_t *status);
+/* nn_get_random_mod (nn/nn_rand.c:92-150) given its random bytes.  The reference draws 2 * qlen bytes with get_random straight into the
+ * limb array of an nn (they read as a little-endian integer on the little-endian hosts libecc and this library run on), reduces modulo
+ * q - 1 and adds one.  raw: n x 2*qlen bytes from the caller's own randomness source; out: n x qlen big-endian, each in [1, q - 1].  The
+ * reduction is libecc's constant-time division on the host otherwise -- about a microsecond of a host thread per value. */
+int ec_nn_random_mod_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *raw, uint8_t *out);
+/* ec_ecdsa_sign_batch from MESSAGES and RAW nonce material: per item k = the nn_get_random_mod value of its 2*qlen random bytes (what
+ * __ecdsa_sign_finalize draws through ctx->rand = nn_get_random_mod, sig/ecdsa_common.c:424-470), h = SHA-224 / 256 / 384 / 512 of its
+ * message slot (hash_type 1 .. 4; slots as for ec_ecdsa_verify_msg_batch_fmt), or hash_type 0: the slots are the digests themselves,
+ * msg_stride bytes each.  Signature bytes equal those of ec_ecdsa_sign_batch fed with the reduced nonces and the digests. */
+int ec_ecdsa_sign_msg_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *privs, const uint8_t *nonce_raw,
+			    int hash_type, const uint8_t *msg_slots, uint32_t msg_stride, uint8_t *sigs, uint8_t *status);
+/* ec_key_pair_gen's generic rule (sig/ec_key.c:594-610): x = nn_get_random_mod(q) from the item's 2*qlen random bytes, Y = [x]G.
+ * priv_out: n x qlen big-endian; pub_out: n x 2*clen affine X || Y; status as ec_prj_pt_mul_batch.  (Secret scalars: see
+ * ecamd_ctx_set_secret_scalars; the private keys cross the bus on their way back, as supplied ones do on their way in.) */
+int ec_key_pair_gen_raw_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *raw, uint8_t *priv_out,
+			      uint8_t *pub_out_aff, uint8_t *status);
 /* ECC-CDH, batch form of ecccdh_derive_secret (ecdh/ecccdh.c:167): privs n x qlen, peers n x 2*clen
  * affine, secrets n x clen (x coordinate of d*Q), status[i] = 0 ok / 1 the reference returns -1.
  * Cofactor curves: subgroup check of the peer key and the [h]Q step as in the reference. */
@@ -449,6 +465,10 @@ int ecamd_multi_eddsa_verify_msg_prj_batch(ecamd_multi *m, const ecamd_mcurve *c
 int ecamd_multi_ecdsa_sign_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *privs,
 				 const uint8_t *nonces, const uint8_t *digests, uint32_t digest_len, uint8_t *sigs,
 				 uint8_t *status);
+int ecamd_multi_ecdsa_sign_msg_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *privs, const uint8_t *nonce_raw,
+				     int hash_type, const uint8_t *msg_slots, uint32_t msg_stride, uint8_t *sigs, uint8_t *status);
+int ecamd_multi_key_pair_gen_raw_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *raw, uint8_t *priv_out,
+				       uint8_t *pub_out_aff, uint8_t *status);
 int ecamd_multi_ecccdh_derive_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *privs,
 				    const uint8_t *peers_aff, uint8_t *secrets, uint8_t *status);
 int ecamd_multi_xdh_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *k, const uint8_t *u,

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "ecamd_multi_ecdsa_verify_batch", "ecamd_multi_ecdsa_verify_batch_fmt", "ecamd_multi_ecdsa_sign_batch", "ecamd_multi_ecccdh_derive_batch",
     "ecamd_multi_xdh_batch", "ecamd_multi_eddsa_verify_batch", "ecamd_multi_eddsa_verify_all_batch", "ecamd_multi_allgather",
     "ecamd_multi_allgather_streams", "ecamd_multi_eddsa_sign_R_batch", "ecamd_multi_eddsa_sign_S_batch",
-    "ecamd_multi_set_secret_scalars", "ecamd_multi_wipe_scratch", "ecamd_ctx_wipe_scratch", "ecamd_ctx_stream", "ecamd_host_alloc", "ecamd_host_free", "ecamd_ctx_dominant_kernel_ms", "ecamd_ctx_set_msm_seed", "ecamd_multi_set_msm_seed", "ec_eddsa_verify_msg_prj_batch", "ecamd_multi_eddsa_verify_msg_prj_batch", "ecamd_ctx_set_host_ready_hook", "ecamd_multi_set_host_ready_hook", "ecamd_multi_prj_pt_add_batch",
+    "ecamd_multi_set_secret_scalars", "ecamd_multi_wipe_scratch", "ecamd_ctx_wipe_scratch", "ecamd_ctx_stream", "ecamd_host_alloc", "ecamd_host_free", "ecamd_ctx_dominant_kernel_ms", "ecamd_ctx_set_msm_seed", "ecamd_multi_set_msm_seed", "ec_nn_random_mod_batch", "ec_ecdsa_sign_msg_batch", "ec_key_pair_gen_raw_batch", "ecamd_multi_ecdsa_sign_msg_batch", "ecamd_multi_key_pair_gen_raw_batch", "ec_eddsa_verify_msg_prj_batch", "ecamd_multi_eddsa_verify_msg_prj_batch", "ecamd_ctx_set_host_ready_hook", "ecamd_multi_set_host_ready_hook", "ecamd_multi_prj_pt_add_batch",
 ]
 
 
@@ -324,6 +324,33 @@ class Curve:
         _chk(self.L, self.L.ec_ecdsa_sign_batch(self.ctx.h, self.h, n, privs, nonces, digests, hlen, sigs, st),
              "ec_ecdsa_sign_batch")
         return sigs.raw[:2 * self.qlen * n], st.raw[:n]
+
+    def random_mod(self, raw):
+        """nn_get_random_mod given its 2 * qlen random bytes per item: LE(raw) mod (q - 1) + 1, big-endian"""
+        n = len(raw) // (2 * self.qlen)
+        out = C.create_string_buffer(max(1, self.qlen * n))
+        _chk(self.L, self.L.ec_nn_random_mod_batch(self.ctx.h, self.h, n, raw, out), "ec_nn_random_mod_batch")
+        return out.raw[:self.qlen * n]
+
+    def ecdsa_sign_msgs(self, privs, nonce_raw, hash_type, msgs, stride=None):
+        """ECDSA signatures with the nonces reduced (nn_get_random_mod) and the messages hashed on the device; hash_type 0: msgs
+        are digests of equal length"""
+        n = len(privs) // self.qlen
+        if hash_type:
+            slots, stride = self.msg_slots(msgs, stride)
+        else:
+            slots, stride = b"".join(msgs), (len(msgs[0]) if msgs else 32)
+        sigs, st = C.create_string_buffer(max(1, 2 * self.qlen * n)), C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_ecdsa_sign_msg_batch(self.ctx.h, self.h, n, privs, nonce_raw, hash_type, slots, stride, sigs, st),
+             "ec_ecdsa_sign_msg_batch")
+        return sigs.raw[:2 * self.qlen * n], st.raw[:n]
+
+    def key_pair_gen_raw(self, raw):
+        """x = nn_get_random_mod value of the item's 2 * qlen random bytes, Y = [x]G: (privs, pubs affine, status)"""
+        n = len(raw) // (2 * self.qlen)
+        pr, pb, st = C.create_string_buffer(max(1, self.qlen * n)), C.create_string_buffer(max(1, 2 * self.clen * n)), C.create_string_buffer(max(1, n))
+        _chk(self.L, self.L.ec_key_pair_gen_raw_batch(self.ctx.h, self.h, n, raw, pr, pb, st), "ec_key_pair_gen_raw_batch")
+        return pr.raw[:self.qlen * n], pb.raw[:2 * self.clen * n], st.raw[:n]
 
     def ecccdh(self, privs, peers):
         n = len(privs) // self.qlen

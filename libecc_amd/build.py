@@ -13,7 +13,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libecc_amd.so")
 SOURCES = ["ecamd_kernels.hip", "ecamd_p256_kernel.hip", "ecamd_hash.hip", "ecamd_host.cpp", "ecamd_multi.cpp"]
 DEPS = ["ecamd_madchain.h", "ecamd_field.h", "ecamd_point.h", "ecamd_u29.h", "ecamd_p256.h", "ecamd_u29g.h", "ecamd_jacg.h",
-        "ecamd_internal.h", "ecamd_lattice.h",
+        "ecamd_internal.h", "ecamd_lattice.h", "ecamd_randmod.h",
         "ecamd_curve_table.inc"]
 # the public header only matters to the host-side translation units (the kernels see ecamd_internal.h)
 HOST_DEPS = [os.path.join("..", "..", "include", "libecc_amd.h")]

@@ -98,6 +98,31 @@ err:
 	return ret;
 }
 
+/* the application's get_random for `len` bytes, under the same contract */
+static int compat_get_random(u8 *buf, u16 len)
+{
+	int ret;
+	if (AT_LOAD(&g_rand_concurrent)) {
+		return get_random(buf, len);
+	}
+	pthread_mutex_lock(&g_rand_mu);
+	ret = get_random(buf, len);
+	pthread_mutex_unlock(&g_rand_mu);
+	return ret;
+}
+/* Round 4: where the value wanted is exactly nn_get_random_mod's (ECDSA nonces, the private scalar of ec_key_pair_gen's generic rule),
+ * only the get_random call stays on the host -- the same single call of 2 * qlen bytes per value the reference makes -- and the
+ * reduction modulo q - 1 runs on the device (ec_ecdsa_sign_msg_batch, ec_key_pair_gen_raw_batch): libecc's constant-time division was
+ * the largest cost of a signature or a key pair on the host side.  $ECAMD_COMPAT_HOST_RANDMOD keeps it on the host. */
+static int raw_random_on_device(void)
+{
+	static int on = -1;
+	if (on < 0) {
+		on = getenv("ECAMD_COMPAT_HOST_RANDMOD") ? 0 : 1;
+	}
+	return on;
+}
+
 void ecamd_compat_set_concurrent_random(int on)
 {
 	AT_STORE(&g_rand_concurrent, on ? 1u : 0u);
@@ -922,14 +947,41 @@ static void bufs_free(void)
 }
 
 /* after a call that handled private material: host staging and the devices' scratch */
-static void wipe_secrets(void)
+/* (on the pool: after a 2^20-item signing call the staging holds some 200 MB, which one thread takes ten milliseconds to clear) */
+#define WIPE_BLOCK 4096u
+typedef struct {
+	u32 first[NBUF + 1];   /* first block of buffer k in the concatenation of all used staging */
+} wipe_job;
+static void wipe_blocks(u32 lo, u32 hi, void *arg)
 {
+	const wipe_job *W = (const wipe_job *)arg;
 	int k;
 	for (k = 0; k < NBUF; k++) {
-		if (g_buf[k]) {
-			wipe(g_buf[k], g_used[k]);
-			g_used[k] = 0;
+		const u32 b0 = lo > W->first[k] ? lo : W->first[k], b1 = hi < W->first[k + 1] ? hi : W->first[k + 1];
+		if (b0 < b1) {
+			const size_t off = (size_t)(b0 - W->first[k]) * WIPE_BLOCK;
+			size_t len = (size_t)(b1 - b0) * WIPE_BLOCK;
+			if (off + len > g_used[k]) {
+				len = g_used[k] - off;
+			}
+			wipe(g_buf[k] + off, len);
 		}
+	}
+}
+static void wipe_secrets(void)
+{
+	wipe_job W;
+	int k;
+	W.first[0] = 0;
+	for (k = 0; k < NBUF; k++) {
+		const size_t used = g_buf[k] ? g_used[k] : 0;
+		W.first[k + 1] = W.first[k] + (u32)((used + WIPE_BLOCK - 1) / WIPE_BLOCK);
+	}
+	if (W.first[NBUF]) {
+		parallel_for(W.first[NBUF], wipe_blocks, &W);
+	}
+	for (k = 0; k < NBUF; k++) {
+		g_used[k] = 0;
 	}
 	if (g_multi && ecamd_multi_wipe_scratch(g_multi)) {
 		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
@@ -1722,6 +1774,8 @@ typedef struct {
 	u16 buf_len;
 	int *ret_items;
 	u8 *sc, *out, *st, *pre;
+	int raw_mode;                        /* generation by the generic rule: raw random bytes out, x and Y back (ec_key_pair_gen_raw_batch) */
+	u8 *raw;
 } key_job;
 
 static void key_pack(u32 lo, u32 hi, void *arg)
@@ -1731,6 +1785,20 @@ static void key_pack(u32 lo, u32 hi, void *arg)
 	for (i = lo; i < hi; i++) {
 		const ec_priv_key *pk = J->kps ? &J->kps[i].priv_key : J->privs[i];
 		int bad = 0;
+		if (J->mode == 1 && J->raw_mode) {
+			/* generic_gen_priv_key / ecccdh_gen_key_pair: x = nn_get_random_mod(q) -- its get_random call here, its reduction on the device */
+			ec_priv_key *w = &J->kps[i].priv_key;
+			bad = nn_init(&w->x, 0);
+			w->key_type = J->alg;
+			w->params = J->params;
+			w->magic = PRIV_KEY_MAGIC;
+			bad = bad || compat_get_random(J->raw + (size_t)i * 2 * J->slen, (u16)(2 * J->slen));
+			J->pre[i] = bad ? 1 : 0;
+			if (bad) {
+				memset(J->raw + (size_t)i * 2 * J->slen, 0, (size_t)2 * J->slen);
+			}
+			continue;
+		}
 		if (J->mode == 1) {
 			/* ec_key_pair_gen (sig/ec_key.c:594-621) / ecccdh_gen_key_pair (ecdh/ecccdh.c:93-118) up to the public key */
 			ec_priv_key *w = &J->kps[i].priv_key;
@@ -1772,6 +1840,14 @@ static void key_pack(u32 lo, u32 hi, void *arg)
 static int key_gpu(u32 lo, u32 hi, void *arg)
 {
 	key_job *J = (key_job *)arg;
+	if (J->raw_mode) {
+		if (ecamd_multi_key_pair_gen_raw_batch(g_multi, J->e->mc, hi - lo, J->raw + (size_t)lo * 2 * J->slen, J->sc + (size_t)lo * J->slen,
+						       J->out + (size_t)lo * 2 * J->clen, J->st + lo)) {
+			fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+			return -1;
+		}
+		return 0;
+	}
 	/* Y = [s]G: the generator (points == NULL); secret-scalar mode keeps the look-ups address-independent */
 	if (ecamd_multi_prj_pt_mul_batch(g_multi, J->e->mc, hi - lo, J->sc + (size_t)lo * J->slen, J->slen, NULL, J->out + (size_t)lo * 2 * J->clen,
 					 J->st + lo)) {
@@ -1789,6 +1865,9 @@ static void key_unpack(u32 lo, u32 hi, void *arg)
 		ec_pub_key *pub = J->kps ? &J->kps[i].pub_key : &J->pubs[i];
 		int r = -1;
 		memset(pub, 0, sizeof(ec_pub_key));
+		if (J->raw_mode && !J->pre[i] && nn_init_from_buf(&J->kps[i].priv_key.x, J->sc + (size_t)i * J->slen, (u16)J->slen)) {
+			J->pre[i] = 1;   /* (the private scalar the device reduced comes back as qlen big-endian octets) */
+		}
 		if (!J->pre[i] && !prj_from_aff_be(&pub->y, &(J->params->ec_curve), J->out + (size_t)i * 2 * J->clen, J->clen, J->st[i])) {
 			pub->key_type = J->alg;
 			pub->params = J->params;
@@ -1828,6 +1907,11 @@ static int key_batch(key_job *J, u32 num)
 	J->out = buf_get(1, (size_t)num * 2 * J->clen);
 	J->st = buf_get(2, num);
 	J->pre = buf_get(3, num);
+	J->raw_mode = J->mode == 1 && J->rule == RULE_X_LT_Q && J->kps && raw_random_on_device();
+	J->raw = J->raw_mode ? buf_get(4, (size_t)num * 2 * J->slen) : NULL;
+	if (J->raw_mode && !J->raw) {
+		J->sc = NULL;
+	}
 	if (J->sc && J->out && J->st && J->pre && !pipeline_run(num, chunk_items_for(g_chunk, num), key_pack, key_gpu, key_unpack, J)) {
 		note_items(num);
 		ret = 0;
@@ -2268,6 +2352,72 @@ static int dom_prefix(const hash_mapping *hm, hash_context *hc, int is448, int p
 	return y ? hm->hfunc_update(hc, y, ylen) : 0;
 }
 
+/* Hashing on the device (ec_ecdsa_verify_msg_batch_fmt / ec_eddsa_verify_msg_batch of libecc_amd.h): for SHA-224 / 256 / 384 / 512
+ * and a group whose longest hash input fits a 256-byte slot, the pack step copies the message instead of hashing it -- libecc's
+ * portable hfunc_* cost 0.3 - 0.5 us per short message and thread, more than everything else the layer does per signature.
+ * $ECAMD_COMPAT_HOST_HASH keeps the hashing on the host (through the application's hash_maps[], as before). */
+#define DEV_HASH_MAX_SLOT 256u
+static int dev_hash_type(const hash_mapping *hm)
+{
+	if (getenv("ECAMD_COMPAT_HOST_HASH")) {
+		return 0;
+	}
+	switch (hm->type) {
+	case SHA224: return 1;
+	case SHA256: return 2;
+	case SHA384: return 3;
+	case SHA512: return 4;
+	default: return 0;
+	}
+}
+/* stride of the slots for the items idx[0..cnt) with `extra` bytes in front of every message, or 0 when one does not fit
+ * (the longest message: a reduction over the pool -- a serial pass over 2^20 lengths is a millisecond of the caller's time) */
+typedef struct {
+	const u32 *m_len, *idx;
+	u32 mx;
+} mlen_job;
+static void mlen_max(u32 lo, u32 hi, void *arg)
+{
+	mlen_job *M = (mlen_job *)arg;
+	u32 j, mx = 0, cur;
+	for (j = lo; j < hi; j++) {
+		const u32 l = M->m_len[M->idx[j]];
+		mx = l > mx ? l : mx;
+	}
+	cur = AT_LOAD(&M->mx);
+	while (mx > cur && !__atomic_compare_exchange_n(&M->mx, &cur, mx, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+	}
+}
+/* known_max >= 0: the longest message was found by an earlier pass */
+static u32 dev_hash_slot_for(const u32 *m_len, const u32 *idx, u32 cnt, u32 extra, long known_max)
+{
+	mlen_job M;
+	u32 mx;
+	M.m_len = m_len;
+	M.idx = idx;
+	M.mx = 0;
+	if (known_max >= 0) {
+		M.mx = (u32)known_max;
+	} else {
+		parallel_for(cnt, mlen_max, &M);
+	}
+	mx = M.mx;
+	if (mx > DEV_HASH_MAX_SLOT) {
+		return 0;
+	}
+	mx = (4 + extra + mx + 3u) & ~3u;
+	return mx <= DEV_HASH_MAX_SLOT ? mx : 0;
+}
+static void slot_put(u8 *slot, u32 stride, const u8 *a, u32 alen, const u8 *b, u32 blen, const u8 *m, u32 mlen)
+{
+	const u32 len = alen + blen + mlen;
+	slot[0] = (u8)len; slot[1] = (u8)(len >> 8); slot[2] = (u8)(len >> 16); slot[3] = (u8)(len >> 24);
+	if (alen) memcpy(slot + 4, a, alen);
+	if (blen) memcpy(slot + 4 + alen, b, blen);
+	if (mlen) memcpy(slot + 4 + alen + blen, m, mlen);
+	memset(slot + 4 + len, 0, stride - 4 - len);
+}
+
 /* ------------------------------------------------------------------------------------------------
  * signing: ec_sign_batch
  * ------------------------------------------------------------------------------------------------ */
@@ -2291,6 +2441,9 @@ typedef struct {
 	/* ECDSA: private keys, nonces, digests in; signatures, status out.  EdDSA: see eddsa_sign_group */
 	u8 *b0, *b1, *b2, *b3, *b4, *b5, *b6, *b7, *pre;
 	int nonces_given;    /* the nonces were drawn beforehand (caller's rand hook) */
+	int raw_nonces;      /* ECDSA with libecc's own nonce source: b1 holds 2 * qlen raw random bytes per item, reduced on the device */
+	int dev_hash;        /* ... and H(m) of short messages comes from the device: b2 holds message slots of `slot` bytes */
+	u32 slot;
 	int ph, dom, is448;
 	u32 ph_len;
 } sign_job;
@@ -2374,7 +2527,8 @@ static void ecdsa_sign_pack(u32 lo, u32 hi, void *arg)
 	for (j = lo; j < hi; j++) {
 		const u32 i = J->idx[j];
 		const ec_key_pair *kp = J->kps[i];
-		u8 *xb = J->b0 + (size_t)j * J->qlen, *kb = J->b1 + (size_t)j * J->qlen, *dg = J->b2 + (size_t)j * J->hlen;
+		const u32 kstride = J->raw_nonces ? 2 * J->qlen : J->qlen, dstride = J->dev_hash ? J->slot : J->hlen;
+		u8 *xb = J->b0 + (size_t)j * J->qlen, *kb = J->b1 + (size_t)j * kstride, *dg = J->b2 + (size_t)j * dstride;
 		hash_context hc;
 		int bad, cmp = 0;
 		/* _ec_sign_init / __ecdsa_sign_init / __ecdsa_sign_finalize up to the multiplication (sig/sig_algs.c:293-376,
@@ -2382,8 +2536,16 @@ static void ecdsa_sign_pack(u32 lo, u32 hi, void *arg)
 		bad = key_pair_check_initialized_and_type(kp, J->sig_type) || kp->priv_key.params != J->params || !J->sigs[i] ||
 		      (!J->m[i] && J->m_len[i]);
 		bad = bad || nn_cmp(&kp->priv_key.x, &(J->params->ec_gen_order), &cmp) || cmp >= 0 || nn_to_be(xb, J->qlen, &kp->priv_key.x);
-		bad = bad || J->hm->hfunc_init(&hc) || J->hm->hfunc_update(&hc, J->m[i], J->m_len[i]) || J->hm->hfunc_finalize(&hc, dg);
-		if (!bad && is_decdsa(J->sig_type)) {
+		if (J->dev_hash) {
+			if (!bad) {
+				slot_put(dg, J->slot, NULL, 0, NULL, 0, J->m[i], J->m_len[i]);
+			}
+		} else {
+			bad = bad || J->hm->hfunc_init(&hc) || J->hm->hfunc_update(&hc, J->m[i], J->m_len[i]) || J->hm->hfunc_finalize(&hc, dg);
+		}
+		if (!bad && J->raw_nonces) {
+			bad = compat_get_random(kb, (u16)(2 * J->qlen));   /* nn_get_random_mod's one call; the reduction runs on the device */
+		} else if (!bad && is_decdsa(J->sig_type)) {
 			bad = rfc6979_nonce(kb, J->qlen, &(J->params->ec_gen_order), J->params->ec_gen_order_bitlen, xb, dg, (u8)J->hlen, J->hash_type);
 		} else if (!bad && !J->nonces_given) {
 			nn k;
@@ -2396,8 +2558,8 @@ static void ecdsa_sign_pack(u32 lo, u32 hi, void *arg)
 		J->pre[j] = bad ? 1 : 0;
 		if (bad) {
 			memset(xb, 0, J->qlen);
-			memset(kb, 0, J->qlen);
-			memset(dg, 0, J->hlen);
+			memset(kb, 0, kstride);
+			memset(dg, 0, dstride);
 		}
 	}
 }
@@ -2405,6 +2567,15 @@ static void ecdsa_sign_pack(u32 lo, u32 hi, void *arg)
 static int ecdsa_sign_gpu(u32 lo, u32 hi, void *arg)
 {
 	sign_job *J = (sign_job *)arg;
+	if (J->raw_nonces) {
+		if (ecamd_multi_ecdsa_sign_msg_batch(g_multi, J->e->mc, hi - lo, J->b0 + (size_t)lo * J->qlen, J->b1 + (size_t)lo * 2 * J->qlen,
+						     J->dev_hash, J->b2 + (size_t)lo * (J->dev_hash ? J->slot : J->hlen), J->dev_hash ? J->slot : J->hlen,
+						     J->b3 + (size_t)lo * 2 * J->qlen, J->b4 + lo)) {
+			fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+			return -1;
+		}
+		return 0;
+	}
 	if (ecamd_multi_ecdsa_sign_batch(g_multi, J->e->mc, hi - lo, J->b0 + (size_t)lo * J->qlen, J->b1 + (size_t)lo * J->qlen,
 					 J->b2 + (size_t)lo * J->hlen, J->hlen, J->b3 + (size_t)lo * 2 * J->qlen, J->b4 + lo)) {
 		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
@@ -2442,9 +2613,17 @@ static int ecdsa_sign_group(sign_job *J, u32 cnt)
 		}
 		return 0;
 	}
+	/* libecc's own nonce source (rand == NULL or nn_get_random_mod), not the deterministic variant: raw bytes out, reduction on the device */
+	J->raw_nonces = (!J->rand || J->rand == nn_get_random_mod) && !is_decdsa(J->sig_type) && raw_random_on_device();
+	J->dev_hash = 0;
+	J->slot = 0;
+	if (J->raw_nonces && dev_hash_type(J->hm)) {
+		J->slot = dev_hash_slot_for(J->m_len, J->idx, cnt, 0, -1);
+		J->dev_hash = J->slot ? dev_hash_type(J->hm) : 0;
+	}
 	J->b0 = buf_get(0, (size_t)cnt * J->qlen);
-	J->b1 = buf_get(1, (size_t)cnt * J->qlen);
-	J->b2 = buf_get(2, (size_t)cnt * J->hlen);
+	J->b1 = buf_get(1, (size_t)cnt * (J->raw_nonces ? 2 : 1) * J->qlen);
+	J->b2 = buf_get(2, (size_t)cnt * (J->dev_hash ? J->slot : J->hlen));
 	J->b3 = buf_get(3, (size_t)cnt * 2 * J->qlen);
 	J->b4 = buf_get(4, cnt);
 	J->pre = buf_get(5, cnt);
@@ -2691,6 +2870,32 @@ static void cpu_sign_items(u32 lo, u32 hi, void *arg)
 	}
 }
 
+/* the common shape of a signing batch -- every key pair present, initialised and of ONE set of parameters -- found on the pool, with
+ * the initial -1 of every item and the identity index map (cf. scan_keys of the verification side) */
+typedef struct {
+	const ec_key_pair *const *kps;
+	const ec_params *params;
+	u32 *idx;
+	int *rets;
+	u32 mixed;
+} sign_scan_job;
+static void sign_scan(u32 lo, u32 hi, void *arg)
+{
+	sign_scan_job *S = (sign_scan_job *)arg;
+	u32 i, mixed = 0;
+	for (i = lo; i < hi; i++) {
+		const ec_key_pair *kp = S->kps[i];
+		S->rets[i] = -1;
+		S->idx[i] = i;
+		if (!kp || kp->priv_key.magic != PRIV_KEY_MAGIC || kp->priv_key.params != S->params) {
+			mixed = 1;
+		}
+	}
+	if (mixed) {
+		AT_STORE(&S->mixed, 1);
+	}
+}
+
 int ec_sign_batch(u8 *const *sigs, u8 siglen, const ec_key_pair *const *key_pairs, const u8 *const *m, const u32 *m_len, u32 num,
 		  int (*rand)(nn_t out, nn_src_t q), ec_alg_type sig_type, hash_alg_type hash_type, const u8 *const *adata,
 		  const u16 *adata_len, int *ret_items)
@@ -2699,7 +2904,7 @@ int ec_sign_batch(u8 *const *sigs, u8 siglen, const ec_key_pair *const *key_pair
 	const ec_sig_mapping *sm = NULL;
 	hash_alg_type eh = UNKNOWN_HASH_ALG;
 	ec_curve_type ec = UNKNOWN_CURVE;
-	int ph = 0, dom = 0, is448 = 0, ed, ret = -1, *rets = ret_items;
+	int ph = 0, dom = 0, is448 = 0, ed, ret = -1, *rets = ret_items, one_group = 0;
 	u32 *idx = NULL, i, done = 0;
 	u8 *seen = NULL;
 	if (!sigs || !key_pairs || !m || !m_len) {
@@ -2718,30 +2923,45 @@ int ec_sign_batch(u8 *const *sigs, u8 siglen, const ec_key_pair *const *key_pair
 			return -1;
 		}
 	}
-	for (i = 0; i < num; i++) {
-		rets[i] = -1;
-	}
 	hm = find_hash(hash_type);
 	idx = (u32 *)malloc((size_t)num * sizeof(u32));
-	seen = (u8 *)calloc(num, 1);
-	if (!idx || !seen) {
-		goto out;
-	}
-	if (!hm || (ed && (hash_type != eh || rand != NULL))) {
-		ret = 0;   /* every ec_sign fails: unknown hash (_ec_sign_init), or EdDSA with another hash / a nonce source (sig/eddsa.c:1596,1612) */
-		goto out;
-	}
-	if (ecamd_compat_init(NULL, 0, 0)) {
+	if (!idx || !hm || (ed && (hash_type != eh || rand != NULL)) || ecamd_compat_init(NULL, 0, 0)) {
+		for (i = 0; i < num; i++) {
+			rets[i] = -1;
+		}
+		/* every ec_sign fails: unknown hash (_ec_sign_init), or EdDSA with another hash / a nonce source (sig/eddsa.c:1596,1612) */
+		ret = (idx && (!hm || (ed && (hash_type != eh || rand != NULL)))) ? 0 : -1;
 		goto out;
 	}
 	pthread_mutex_lock(&g_call_mu);
+	{
+		sign_scan_job S;
+		S.kps = key_pairs;
+		S.params = (key_pairs[0] && key_pairs[0]->priv_key.magic == PRIV_KEY_MAGIC) ? key_pairs[0]->priv_key.params : NULL;
+		S.idx = idx;
+		S.rets = rets;
+		S.mixed = S.params ? 0 : 1;
+		parallel_for(num, sign_scan, &S);
+		one_group = !AT_LOAD(&S.mixed);
+	}
+	if (!one_group) {
+		seen = (u8 *)calloc(num, 1);
+		if (!seen) {
+			pthread_mutex_unlock(&g_call_mu);
+			goto out;
+		}
+	}
 	/* groups of items that share their ec_params (one GPU batch each; normally there is one group) */
 	ret = 0;
 	while (done < num && !ret) {
 		const ec_params *params = NULL;
 		sign_job J;
 		u32 cnt = 0;
-		for (i = 0; i < num; i++) {
+		if (one_group) {
+			params = key_pairs[0]->priv_key.params;
+			cnt = done = num;
+		}
+		for (i = 0; i < num && !one_group; i++) {
 			const ec_key_pair *kp = key_pairs[i];
 			if (seen[i]) {
 				continue;
@@ -2824,68 +3044,9 @@ typedef struct {
 	u32 fail_tracked, any_fail;   /* ver_unpack notes whether any item was rejected (ec_verify_batch wants that one bit) */
 } ver_job;
 
-/* Hashing on the device (ec_ecdsa_verify_msg_batch_fmt / ec_eddsa_verify_msg_batch of libecc_amd.h): for SHA-224 / 256 / 384 / 512
- * and a group whose longest hash input fits a 256-byte slot, the pack step copies the message instead of hashing it -- libecc's
- * portable hfunc_* cost 0.3 - 0.5 us per short message and thread, more than everything else the layer does per signature.
- * $ECAMD_COMPAT_HOST_HASH keeps the hashing on the host (through the application's hash_maps[], as before). */
-#define DEV_HASH_MAX_SLOT 256u
-static int dev_hash_type(const hash_mapping *hm)
-{
-	if (getenv("ECAMD_COMPAT_HOST_HASH")) {
-		return 0;
-	}
-	switch (hm->type) {
-	case SHA224: return 1;
-	case SHA256: return 2;
-	case SHA384: return 3;
-	case SHA512: return 4;
-	default: return 0;
-	}
-}
-/* stride of the slots for the items idx[0..cnt) with `extra` bytes in front of every message, or 0 when one does not fit
- * (the longest message: a reduction over the pool -- a serial pass over 2^20 lengths is a millisecond of the caller's time) */
-typedef struct {
-	const ver_job *J;
-	u32 mx;
-} mlen_job;
-static void mlen_max(u32 lo, u32 hi, void *arg)
-{
-	mlen_job *M = (mlen_job *)arg;
-	u32 j, mx = 0, cur;
-	for (j = lo; j < hi; j++) {
-		const u32 l = M->J->m_len[M->J->idx[j]];
-		mx = l > mx ? l : mx;
-	}
-	cur = AT_LOAD(&M->mx);
-	while (mx > cur && !__atomic_compare_exchange_n(&M->mx, &cur, mx, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
-	}
-}
 static u32 dev_hash_slot(const ver_job *J, u32 cnt, u32 extra)
 {
-	mlen_job M;
-	u32 mx;
-	M.J = J;
-	M.mx = 0;
-	if (J->pre_scanned) {
-		M.mx = J->pre_max_mlen;
-	} else {
-		parallel_for(cnt, mlen_max, &M);
-	}
-	mx = M.mx;
-	if (mx > DEV_HASH_MAX_SLOT) {
-		return 0;
-	}
-	mx = (4 + extra + mx + 3u) & ~3u;
-	return mx <= DEV_HASH_MAX_SLOT ? mx : 0;
-}
-static void slot_put(u8 *slot, u32 stride, const u8 *a, u32 alen, const u8 *b, u32 blen, const u8 *m, u32 mlen)
-{
-	const u32 len = alen + blen + mlen;
-	slot[0] = (u8)len; slot[1] = (u8)(len >> 8); slot[2] = (u8)(len >> 16); slot[3] = (u8)(len >> 24);
-	if (alen) memcpy(slot + 4, a, alen);
-	if (blen) memcpy(slot + 4 + alen, b, blen);
-	if (mlen) memcpy(slot + 4 + alen + blen, m, mlen);
-	memset(slot + 4 + len, 0, stride - 4 - len);
+	return dev_hash_slot_for(J->m_len, J->idx, cnt, extra, J->pre_scanned ? (long)J->pre_max_mlen : -1);
 }
 
 /* ---- ECDSA / DECDSA ---- */

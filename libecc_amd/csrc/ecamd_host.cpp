@@ -2552,6 +2552,121 @@ extern "C" int ec_ecdsa_sign_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 4: the secret-key half without libecc's division on the host.  nn_get_random_mod (nn/nn_rand.c:92-150) is get_random for
+// 2 * qlen bytes, then a constant-time reduction modulo q - 1 that costs a host thread about a microsecond: more than everything else
+// a signature or a key pair needs from the host.  The random bytes stay the application's; the reduction moves to the
+// device (k_rand_mod, ecamd_randmod.h), and so does H(m) (k_sha2_slots).
+// ------------------------------------------------------------------------------------------
+static int rand_mod_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_raw, uint8_t *d_out, hipStream_t s)
+{
+	(void)ctx;
+	EcamdRandModArgs R;
+	R.raw = d_raw;
+	R.out = d_out;
+	R.n = n;
+	R.qlen = (uint32_t)cv->qlen;
+	R.rawlen = 2 * (uint32_t)cv->qlen;
+	for (int w = 0; w < 18; w++) {
+		R.q[w] = (size_t)w < cv->q.size() ? cv->q[(size_t)w] : 0;
+	}
+	HIPCHK(ecamd_launch_rand_mod(cv->qnw, R, s));
+	return 0;
+}
+static int rand_mod_args_ok(const char *fn, ecamd_ctx *ctx, const ecamd_curve *cv)
+{
+	if (!ctx || !cv || cv->ctx != ctx) {
+		return fail(std::string(fn) + ": bad argument");
+	}
+	if (!(cv->q[0] & 1) || big_bitlen(cv->q) < 2 || !cv->qnw || !ecamd_nw_supported(cv->qnw) || cv->q.size() > 18) {
+		return fail(std::string(fn) + ": generator order not supported (odd, at most 544 bits)");
+	}
+	return 0;
+}
+
+extern "C" int ec_nn_random_mod_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *raw, uint8_t *out)
+{
+	if (rand_mod_args_ok("ec_nn_random_mod_batch", ctx, cv) || (n && (!raw || !out))) {
+		return n && (!raw || !out) ? fail("ec_nn_random_mod_batch: bad argument") : -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t ql = (size_t)cv->qlen;
+	const std::vector<HostArr> arrs = {{raw, nullptr, 2 * ql}, {nullptr, out, ql}};
+	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+					       hipStream_t s, const std::function<int()> &) {
+		return rand_mod_dev_locked(ctx, cv, m, ip[0], op[1], s);
+	});
+}
+
+// ECDSA signatures from messages and RAW nonce material: k = nn_get_random_mod's value for the 2 * qlen random bytes of the item,
+// h = SHA-2(m) of its message slot (hash_type 1 .. 4; 0: the slots ARE the digests, msg_stride bytes each), then ec_ecdsa_sign_batch.
+extern "C" int ec_ecdsa_sign_msg_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *privs, const uint8_t *nonce_raw,
+				       int hash_type, const uint8_t *msg_slots, uint32_t msg_stride, uint8_t *sigs, uint8_t *status)
+{
+	const uint32_t hlen = hash_type ? (uint32_t)ecamd_sha2_digest_len(hash_type) : msg_stride;
+	if (hash_type && (hlen == 0 || msg_stride < 4 || (msg_stride & 3u) || msg_stride > 4096)) {
+		return fail("ec_ecdsa_sign_msg_batch: hash_type must be 0 (digests) or 1 .. 4 (SHA-224 / 256 / 384 / 512) with a slot stride that is a multiple of 4 in 4 .. 4096");
+	}
+	if (rand_mod_args_ok("ec_ecdsa_sign_msg_batch", ctx, cv) ||
+	    ecdsa_sign_args_ok("ec_ecdsa_sign_msg_batch", ctx, cv, n, privs, nonce_raw, msg_slots, sigs, status, hlen)) {
+		return -1;
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t ql = (size_t)cv->qlen;
+	const std::vector<HostArr> arrs = {{privs, nullptr, ql}, {nonce_raw, nullptr, 2 * ql}, {msg_slots, nullptr, msg_stride},
+					   {nullptr, sigs, 2 * ql}, {nullptr, status, 1}};
+	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+					       hipStream_t s, const std::function<int()> &) {
+		// stage 20: the nonces (secret: ensure() wipes what it frees, ecamd_ctx_wipe_scratch the rest); 17: the digests
+		if (ensure(&ctx->stage[20], &ctx->stage_bytes[20], (size_t)m * ql) || rand_mod_dev_locked(ctx, cv, m, ip[1], ctx->stage[20], s)) {
+			return -1;
+		}
+		const uint8_t *d_dig = ip[2];
+		if (hash_type) {
+			if (ecdsa_hash_stage(ctx, hash_type, m, ip[2], msg_stride, hlen, s)) {
+				return -1;
+			}
+			d_dig = ctx->stage[17];
+		}
+		return ecdsa_sign_dev_locked(ctx, cv, m, ip[0], ctx->stage[20], d_dig, hlen, op[3], op[4], s);
+	});
+}
+
+// Key pairs from RAW random material: x = nn_get_random_mod's value for the item's 2 * qlen random bytes (ec_key_pair_gen ->
+// generic_gen_priv_key, sig/ec_key.c:602), Y = [x]G.  priv_out: n x qlen big-endian; pub_out: n x 2 clen affine X || Y.
+extern "C" int ec_key_pair_gen_raw_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *raw, uint8_t *priv_out,
+					 uint8_t *pub_out, uint8_t *status)
+{
+	if (rand_mod_args_ok("ec_key_pair_gen_raw_batch", ctx, cv)) {
+		return -1;
+	}
+	if (n && (!raw || !priv_out || !pub_out || !status)) {
+		return fail("ec_key_pair_gen_raw_batch: bad argument");
+	}
+	if (n == 0) {
+		return 0;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	const size_t ql = (size_t)cv->qlen, plen = (size_t)2 * cv->clen;
+	const std::vector<HostArr> arrs = {{raw, nullptr, 2 * ql}, {nullptr, priv_out, ql}, {nullptr, pub_out, plen}, {nullptr, status, 1}};
+	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+					       hipStream_t s, const std::function<int()> &) {
+		if (rand_mod_dev_locked(ctx, cv, m, ip[0], op[1], s)) {
+			return -1;
+		}
+		return smul_dev_locked(ctx, cv, m, op[1], (uint32_t)ql, nullptr, op[2], op[3], s);
+	});
+}
+
+// ------------------------------------------------------------------------------------------
 // batched ECC-CDH (ecccdh_derive_secret, ecdh/ecccdh.c:167-233)
 // ------------------------------------------------------------------------------------------
 // Device core: stage 3 [d]Q', 4 its status, 5 [h]Q, 6 status of [h]Q, 7 [q]Q (discarded), 8 its status.

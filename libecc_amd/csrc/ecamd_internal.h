@@ -401,6 +401,14 @@ struct EcamdBlindArgs {
 	uint32_t order[18];      // #E (the CURVE order, cofactor included), little-endian words
 };
 hipError_t ecamd_launch_blind_scalar(const EcamdBlindArgs &a, hipStream_t s);
+// nn_get_random_mod given its random bytes (ecamd_randmod.h): out = LE(raw) mod (q - 1) + 1
+struct EcamdRandModArgs {
+	const uint8_t *raw;      // n x rawlen (2 * qlen) bytes, read as a little-endian integer
+	uint8_t *out;            // n x qlen big-endian
+	uint32_t n, rawlen, qlen;
+	uint32_t q[18];          // the generator's order, little-endian words
+};
+hipError_t ecamd_launch_rand_mod(int qnw, const EcamdRandModArgs &a, hipStream_t s);
 // status[i] = 1 and out[i] zeroed where bad[i] != 0
 hipError_t ecamd_launch_status_require(uint8_t *status, const uint8_t *sub, uint8_t want, uint32_t n, hipStream_t s);
 hipError_t ecamd_launch_status_or(uint8_t *status, const uint8_t *bad, uint8_t *out, uint32_t out_stride, uint32_t n, hipStream_t s);

@@ -816,6 +816,7 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed_scal(EcamdEdScalArg
 // window loop (meta bit 1).  Outputs: S and s' = u S mod q (big-endian, for the two comb passes of the tail), v and |u| as words,
 // meta: bit 0 u < 0, bit 1 long mode, bit 2 v = 0 (h = 0 mod q: [h]A is the neutral element, see k_ed_tail2_c25519).
 // ------------------------------------------------------------------------------------------
+#include "ecamd_randmod.h"
 #include "ecamd_lattice.h"
 
 template <int NW> __global__ __launch_bounds__(64) void k_ed_lat(EcamdEdLatArgs A)
@@ -1935,6 +1936,47 @@ hipError_t ecamd_launch_blind_scalar(const EcamdBlindArgs &a, hipStream_t s)
 		return hipErrorInvalidValue;
 	}
 	hipLaunchKernelGGL(k_blind_scalar, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+	return hipGetLastError();
+}
+
+// nn_get_random_mod given its random bytes (ecamd_randmod.h): out = LE(raw) mod (q - 1) + 1, qlen big-endian bytes per item
+template <int NW> __global__ __launch_bounds__(64) void k_rand_mod(EcamdRandModArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	u32 q[NW], w[NW];
+#pragma unroll
+	for (int k = 0; k < NW; k++) {
+		q[k] = A.q[k];
+	}
+	randmod_words<NW>(w, A.raw + (size_t)i * A.rawlen, (int)A.rawlen, q);
+	u8 *dst = A.out + (size_t)i * A.qlen;
+#pragma unroll
+	for (int k = 0; k < NW; k++) {
+#pragma unroll
+		for (int b = 0; b < 4; b++) {
+			const u32 pos = 4 * (u32)k + (u32)b;
+			if (pos < A.qlen) {
+				dst[A.qlen - 1 - pos] = (u8)(w[k] >> (8 * b));
+			}
+		}
+	}
+}
+
+hipError_t ecamd_launch_rand_mod(int qnw, const EcamdRandModArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	const dim3 grid((a.n + 63) / 64), block(64);
+	switch (qnw) {
+#define X(N) case N: hipLaunchKernelGGL(k_rand_mod<N>, grid, block, 0, s, a); break;
+		ECAMD_FOR_NW(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
 	return hipGetLastError();
 }
 

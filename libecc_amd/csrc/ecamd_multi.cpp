@@ -336,6 +336,26 @@ extern "C" int ecamd_multi_ecdsa_sign_batch(ecamd_multi *m, const ecamd_mcurve *
 	});
 }
 
+extern "C" int ecamd_multi_ecdsa_sign_msg_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *privs, const uint8_t *nonce_raw,
+						int hash_type, const uint8_t *msg_slots, uint32_t msg_stride, uint8_t *sigs, uint8_t *status)
+{
+	const size_t ql = (size_t)ecamd_multi_curve_order_len(c);
+	return run_sharded(m, c, n, "ecamd_multi_ecdsa_sign_msg_batch", [&](int r, uint32_t lo, uint32_t hi) {
+		return ec_ecdsa_sign_msg_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(privs, ql), OFF(nonce_raw, 2 * ql), hash_type,
+					       OFF(msg_slots, (size_t)msg_stride), msg_stride, OFF(sigs, 2 * ql), OFF(status, 1));
+	});
+}
+
+extern "C" int ecamd_multi_key_pair_gen_raw_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *raw, uint8_t *priv_out,
+						  uint8_t *pub_out, uint8_t *status)
+{
+	const size_t ql = (size_t)ecamd_multi_curve_order_len(c), cl = (size_t)ecamd_multi_curve_coord_len(c);
+	return run_sharded(m, c, n, "ecamd_multi_key_pair_gen_raw_batch", [&](int r, uint32_t lo, uint32_t hi) {
+		return ec_key_pair_gen_raw_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(raw, 2 * ql), OFF(priv_out, ql), OFF(pub_out, 2 * cl),
+						 OFF(status, 1));
+	});
+}
+
 extern "C" int ecamd_multi_ecccdh_derive_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *privs,
 					       const uint8_t *peers_aff, uint8_t *secrets, uint8_t *status)
 {

@@ -975,6 +975,36 @@ int orc_ecdsa_sign_batch(const orc_curve *c, uint32_t n, const uint8_t *privs,
 	return 0;
 }
 
+/*
+ * nn_get_random_mod (nn/nn_rand.c:92-150) with the bytes get_random would have delivered supplied by the caller: the reference lets
+ * get_random write 2 * qlen bytes straight into the limb array of an nn (:127-128) -- a little-endian integer on a little-endian
+ * host --, reduces it modulo q' = q - 1 (nn_mod_notrim, :134) and adds one (:137).  raw: n x 2 qlen; out: n x qlen big-endian.
+ */
+int orc_random_mod_batch(const orc_curve *c, uint32_t n, const uint8_t *raw, uint8_t *out)
+{
+	uint32_t i;
+	const int rl = 2 * c->qlen, rw = (rl + 7) / 8;
+	u64 qp[ORC_MAXW], one[ORC_MAXW];
+	if (rw > ORC_MAXW) {
+		return -1;
+	}
+	nn_zero(one, c->q_n);
+	one[0] = 1;
+	nn_sub(qp, c->q, one, c->q_n);
+	for (i = 0; i < n; i++) {
+		u64 t[ORC_MAXW], r[ORC_MAXW], k[ORC_MAXW];
+		int b;
+		nn_zero(t, rw);
+		for (b = 0; b < rl; b++) {
+			t[b / 8] |= (u64)raw[(size_t)i * rl + b] << (8 * (b % 8));
+		}
+		nn_mod(r, t, rw, qp, c->q_n);
+		nn_add(k, r, one, c->q_n);
+		nn_to_be(out + (size_t)i * c->qlen, c->qlen, k, c->q_n);
+	}
+	return 0;
+}
+
 /* ecccdh_derive_secret (ecdh/ecccdh.c:167-233): import peer (on-curve + subgroup check),
  * cofactor multiplication if h != 1, reject infinity, d*Q, reject infinity, x coordinate. */
 int orc_ecccdh_batch(const orc_curve *c, uint32_t n, const uint8_t *privs, const uint8_t *peers_aff,

@@ -47,6 +47,8 @@ int orc_ecdsa_verify_batch(const orc_curve *c, uint32_t n, const uint8_t *pubs_a
 int orc_ecdsa_sign_batch(const orc_curve *c, uint32_t n, const uint8_t *privs,
 			 const uint8_t *nonces, const uint8_t *digests, uint32_t hsize,
 			 uint8_t *sigs, uint8_t *status);
+/* nn_get_random_mod given its 2 * qlen random bytes per item (little-endian integer mod (q - 1), plus one) */
+int orc_random_mod_batch(const orc_curve *c, uint32_t n, const uint8_t *raw, uint8_t *out);
 int orc_ecccdh_batch(const orc_curve *c, uint32_t n, const uint8_t *privs, const uint8_t *peers_aff,
 		     uint8_t *secrets, uint8_t *status);
 int orc_xdh_batch(const orc_curve *c, uint32_t len, uint32_t n, const uint8_t *k, const uint8_t *u,

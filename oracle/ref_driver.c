@@ -33,9 +33,21 @@ static uint64_t splitmix64(void)
 	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
 	return z ^ (z >> 31);
 }
+/* replay mode (refdrv_random_mod_batch): the next get_random calls deliver these bytes instead of the generator's */
+static __thread const unsigned char *tl_replay;
+static __thread unsigned int tl_replay_left;
 int get_random(unsigned char *buf, u16 len)
 {
 	u16 i;
+	if (tl_replay) {
+		if (len > tl_replay_left) {
+			return -1;
+		}
+		memcpy(buf, tl_replay, len);
+		tl_replay += len;
+		tl_replay_left -= len;
+		return 0;
+	}
 	for (i = 0; i < len; i++) {
 		buf[i] = (unsigned char)(splitmix64() >> 24);
 	}
@@ -930,4 +942,29 @@ int refdrv_eddsa_export_pub_key_batch(int is448, uint32_t n, const uint8_t *poin
 		ret[i] = ret[i] ? -1 : 0;
 	}
 	return 0;
+}
+
+/* The reference's own nn_get_random_mod (nn/nn_rand.c:92) with get_random replaying the caller's bytes: raw n x 2*qlen, out n x qlen
+ * big-endian; q = the generator order of the named curve.  Returns -1 if the function asked for another number of bytes. */
+int refdrv_random_mod_batch(const char *curve, uint32_t n, const uint8_t *raw, uint8_t *out)
+{
+	ec_params params;
+	uint32_t i;
+	u16 ql;
+	int ret = 0;
+	if (load_params(curve, &params)) {
+		return -1;
+	}
+	ql = (u16)BYTECEIL(params.ec_gen_order_bitlen);
+	for (i = 0; i < n && !ret; i++) {
+		nn k;
+		k.magic = WORD(0);
+		tl_replay = raw + (size_t)i * 2 * ql;
+		tl_replay_left = 2u * ql;
+		ret = nn_get_random_mod(&k, &(params.ec_gen_order)) || tl_replay_left != 0 || nn_export_to_buf(out + (size_t)i * ql, ql, &k);
+		nn_uninit(&k);
+	}
+	tl_replay = NULL;
+	tl_replay_left = 0;
+	return ret ? -1 : 0;
 }

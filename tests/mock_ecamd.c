@@ -274,6 +274,29 @@ int ecamd_multi_ecdsa_sign_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t
 	return orc_ecdsa_sign_batch(&c->c, n, privs, nonces, digests, digest_len, sigs, status);
 }
 
+int ecamd_multi_ecdsa_sign_msg_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *privs, const uint8_t *nonce_raw,
+				     int hash_type, const uint8_t *msg_slots, uint32_t msg_stride, uint8_t *sigs, uint8_t *status)
+{
+	const size_t ql = (size_t)c->c.qlen;
+	uint8_t *k = malloc((size_t)n * ql + 1), *dg = malloc((size_t)n * 64 + 1);
+	uint32_t dl = msg_stride;
+	int r = (!k || !dg) ? mfail("mock: out of memory") : orc_random_mod_batch(&c->c, n, nonce_raw, k);
+	if (!r && hash_type) {
+		r = mock_hash_slots(hash_type, n, msg_slots, msg_stride, dg, &dl) ? mfail("mock: hashing failed") : 0;
+	}
+	r = r || ecamd_multi_ecdsa_sign_batch(m, c, n, privs, k, hash_type ? dg : msg_slots, dl, sigs, status);
+	free(k); free(dg);
+	return r;
+}
+
+int ecamd_multi_key_pair_gen_raw_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *raw, uint8_t *priv_out,
+				       uint8_t *pub_out_aff, uint8_t *status)
+{
+	(void)m;
+	note(n);
+	return orc_random_mod_batch(&c->c, n, raw, priv_out) || orc_scalar_mult_batch(&c->c, n, priv_out, (uint32_t)c->c.qlen, NULL, pub_out_aff, status);
+}
+
 int ecamd_multi_ecccdh_derive_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *privs, const uint8_t *peers_aff,
 				    uint8_t *secrets, uint8_t *status)
 {

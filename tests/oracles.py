@@ -103,6 +103,13 @@ class Oracle:
         assert self.L.orc_unprotected_mult_batch(self.ctx, n, scalars, slen, 0 if broadcast else slen, points, in_fmt, out, out_fmt, st) == 0
         return out.raw[:ow * n], st.raw[:n]
 
+    def random_mod(self, raw):
+        """nn_get_random_mod given its 2 * qlen random bytes per item"""
+        n = len(raw) // (2 * self.qlen)
+        out = C.create_string_buffer(max(1, self.qlen * n))
+        assert self.L.orc_random_mod_batch(self.ctx, n, raw, out) == 0
+        return out.raw[:self.qlen * n]
+
     def fp_op(self, op, a, b):
         """a, b: lists of ints < p; returns list of ints."""
         n = len(a)
@@ -272,6 +279,13 @@ class RefLib:
         out, st = C.create_string_buffer(max(1, ow * n)), C.create_string_buffer(max(1, n))
         assert self.L.refdrv_unprotected_mult_batch(self.name, n, scalars, slen, 0 if broadcast else slen, points, in_fmt, out, out_fmt, st) == 0
         return out.raw[:ow * n], st.raw[:n]
+
+    def random_mod(self, raw):
+        """the reference's nn_get_random_mod with get_random replaying `raw` (2 * qlen bytes per item)"""
+        n = len(raw) // (2 * self.qlen)
+        out = C.create_string_buffer(max(1, self.qlen * n))
+        assert self.L.refdrv_random_mod_batch(self.name, n, raw, out) == 0
+        return out.raw[:self.qlen * n]
 
     def fp_op(self, op, a, b):
         n = len(a)

@@ -953,3 +953,17 @@ def test_group_law_and_unprotected_mult_vs_reference(curve):
         # while the point itself is fine (the reason k_unprot exists)
         on = o.pt_op_fmt(2, p1, None, 1, 0)[1]
         assert any(got[1][i] == 1 and on[i] == 0 for i in range(n))
+
+
+@pytest.mark.parametrize("curve", ["SECP256R1", "SECP384R1", "SECP521R1", "SECP224R1", "BRAINPOOLP256R1", "WEI25519"])
+def test_random_mod_vs_reference(curve):
+    """nn_get_random_mod given its random bytes (round 4: ec_nn_random_mod_batch, ec_ecdsa_sign_msg_batch, ec_key_pair_gen_raw_batch):
+    the unmodified reference, with its get_random replaying the bytes, against the restatement and against the plain formula
+    LE(raw) mod (q - 1) + 1 that the host test of the device code (tests/test_randmod_host.py) uses"""
+    from test_randmod_host import randmod_cases
+    q = CURVES[curve]["q"]
+    ql, vals = randmod_cases(q, np.random.default_rng(7), nrand=300)
+    raw = b"".join(v.to_bytes(2 * ql, "little") for v in vals)
+    exp = b"".join((v % (q - 1) + 1).to_bytes(ql, "big") for v in vals)
+    assert RefLib(curve).random_mod(raw) == exp
+    assert Oracle(curve).random_mod(raw) == exp
