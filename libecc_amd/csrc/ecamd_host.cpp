@@ -296,6 +296,7 @@ struct ecamd_curve {
 	int gqslot;      // constant slot of the dense radix-2^29 unit of the ORDER's size holding q as its modulus (k_ecdsa_prep_g; -1: none)
 	int gflavour;    // 0 dense reduction, 1 secp521r1 (p = 2^521 - 1), 2 p = 2^255 - 19, 3 secp384r1's prime, 4 secp256k1's prime, 5 p = 2^448 - 2^224 - 1,
 	                 // 6 secp224r1's prime, 7 secp192r1's prime (3, 6, 7: signed sparse Montgomery reduction)
+	uint32_t *d_comb4;  // secp256r1: the 4-bit comb of the generator for SECRET scalars, 65 x 8 entries of 40 words (k_p256_comb4m); NULL: none
 	uint32_t *d_gtab; // secp256r1: affine window table [1..8]G, radix-2^29 Montgomery digits, 8 x 40 words
 	uint32_t *d_comb; // fast paths: 16-bit comb table of G, built on the first large fixed-base batch (NULL before / disabled)
 	bool comb_off;    // construction failed or is in progress: do not try (again)
@@ -1037,6 +1038,10 @@ static void curve_free_device(ecamd_curve *cv)
 		(void)hipFree(cv->d_gtab);
 		cv->d_gtab = nullptr;
 	}
+	if (cv->d_comb4) {
+		(void)hipFree(cv->d_comb4);
+		cv->d_comb4 = nullptr;
+	}
 }
 
 // constant slots of a handle back to the device's registry (g_slot_mu NOT held by the caller)
@@ -1085,6 +1090,7 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	cv->d_edcomb = nullptr;
 	cv->edcomb_off = false;
 	cv->d_gtab = nullptr;
+	cv->d_comb4 = nullptr;
 	if (!(cv->p[0] & 1) || big_bitlen(cv->p) < 160) {
 		return curve_abort(cv, "curve: p must be odd and at least 160 bits");
 	}
@@ -1193,6 +1199,7 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 		return curve_abort(cv, "curve: generator upload failed");
 	}
 	cv->d_gtab = nullptr;
+	cv->d_comb4 = nullptr;
 	cv->d_comb = nullptr;
 	cv->comb_off = false;
 	cv->d_edcomb = nullptr;
@@ -1241,6 +1248,43 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 			return curve_abort(cv, "curve: generator table construction failed");
 		}
 		big_digits29(cv->qdig, 9, cv->q);
+		// the masked 4-bit comb of the generator for secret scalars (k_p256_comb4m): [m 16^j]G, m = 1..8, j = 0..63, and [2^256]G, again
+		// through our own kernels (public scalars: constants of the curve).  Not fatal when it fails: the masked window loop serves.
+		if (getenv("ECAMD_NO_SECRET_COMB") == nullptr) {
+			const uint32_t ne = 64 * 8 + 1;
+			std::vector<uint8_t> hs((size_t)ne * 32, 0), hp((size_t)ne * 64), hst(ne, 1);
+			for (uint32_t j = 0; j < 64; j++) {
+				for (uint32_t m = 1; m <= 8; m++) {
+					hs[((size_t)j * 8 + (m - 1)) * 32 + 31 - j / 2] = (uint8_t)(m << (4 * (j & 1)));
+				}
+			}
+			big_to_be(&hs[(size_t)64 * 8 * 32], 32, big_mod(big_pow2(256), cv->q));
+			uint8_t *dd = nullptr;
+			bool ok = hipMalloc((void **)&dd, hs.size() + hp.size() + hst.size()) == hipSuccess &&
+				  hipMemcpy(dd, hs.data(), hs.size(), hipMemcpyHostToDevice) == hipSuccess;
+			if (ok) {
+				PublicScalars pub_scope(ctx);
+				ok = smul_dev_locked(ctx, cv, ne, dd, 32, nullptr, dd + hs.size(), dd + hs.size() + hp.size(), ctx->stream) == 0 &&
+				     hipStreamSynchronize(ctx->stream) == hipSuccess &&
+				     hipMemcpy(hp.data(), dd + hs.size(), hp.size(), hipMemcpyDeviceToHost) == hipSuccess &&
+				     hipMemcpy(hst.data(), dd + hs.size() + hp.size(), hst.size(), hipMemcpyDeviceToHost) == hipSuccess;
+			}
+			if (dd) {
+				(void)hipFree(dd);
+			}
+			std::vector<uint32_t> tab4((size_t)65 * 8 * 40, 0);
+			for (uint32_t e = 0; ok && e < ne; e++) {
+				ok = hst[e] == 0;
+				big_digits29(&tab4[(size_t)e * 40], 9, big_mulmod(big_from_be(&hp[(size_t)e * 64], 32), R261, cv->p));
+				big_digits29(&tab4[(size_t)e * 40 + 9], 9, big_mulmod(big_from_be(&hp[(size_t)e * 64 + 32], 32), R261, cv->p));
+			}
+			if (ok && hipMalloc((void **)&cv->d_comb4, tab4.size() * 4) == hipSuccess &&
+			    hipMemcpy(cv->d_comb4, tab4.data(), tab4.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+				(void)hipFree(cv->d_comb4);
+				cv->d_comb4 = nullptr;
+			}
+			(void)hipGetLastError();
+		}
 	}
 	*out = cv;
 	return 0;
@@ -1488,6 +1532,10 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 				const bool use_comb = cv->d_comb && comb_ok;
 				Fa.lut = use_comb ? cv->d_comb : (fast256 ? cv->d_gtab : nullptr);
 				Fa.lut_kind = use_comb ? 1u : 0u;
+				if (secret && fast256 && cv->d_comb4 && slen <= 32) {
+					Fa.lut = cv->d_comb4;   // secret scalars: the scanned 4-bit comb (65 additions) instead of the scanned window loop
+					Fa.lut_kind = 3u;
+				}
 			}
 			hipEvent_t *ev = (ctx->timing && off == 0) ? ctx->ev : nullptr;  // first chunk of the call
 			if (fast256) {

@@ -676,6 +676,98 @@ __global__ __launch_bounds__(64) void k_p256_comb(EcamdSmulArgs A)
 }
 
 // ------------------------------------------------------------------------------------------
+// C''. fixed base with SECRET scalars (ecamd_ctx_set_secret_scalars): a 4-bit comb whose look-ups are scans.
+//   k = sum_j d_j 16^j + c 2^256 with d_j = D_j - 8 in [-8, 7], D = nibbles of K = k + 0x88..8, c its carry; table T[j][m-1] = [m 16^j]G,
+//   m = 1..8, j = 0..63, and T[64][0] = [2^256]G: 65 x 8 entries of the shared-table format (83 KB per curve handle, L2-resident).
+//   Window j's eight entries are read by EVERY lane, in order, whatever its digit -- the addresses depend on j alone and are the same
+//   across the wave -- and the wanted one is kept by masking (lut_load_masked): the posture of the masked window loop, at 65 mixed
+//   additions and no doubling instead of 256 doublings and 64 additions.  Round 4: a nonce multiplication [k]G was 15 of the 21 ms a
+//   2^20-signature ec_sign_batch spent on the device (profiles/r4u_secret_half.md).
+//   Exceptional pairs as for the 16-bit comb: only the last additions of a scalar >= q can meet one; flagged, recomputed by the
+//   complete-formula kernel.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_p256_comb4m(EcamdSmulArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	u32 kw[8];
+	const int slen = (int)A.slen;
+	const u8 *sc = A.scalars + (size_t)i * A.sstride;
+	if (slen == 32) {
+		load_be256(sc, kw);
+	} else {
+#pragma unroll
+		for (int w = 0; w < 8; w++) {
+			u32 x = 0;
+#pragma unroll
+			for (int b = 0; b < 4; b++) {
+				const int pos = 4 * w + b;
+				if (pos < slen) {
+					x |= (u32)sc[slen - 1 - pos] << (8 * b);
+				}
+			}
+			kw[w] = x;
+		}
+	}
+	u32 top;
+	{
+		uint64_t c = 0;
+#pragma unroll
+		for (int w = 0; w < 8; w++) {
+			c += (uint64_t)kw[w] + 0x88888888u;
+			kw[w] = (u32)c;
+			c >>= 32;
+		}
+		top = (u32)c;
+	}
+	Jac acc;
+	{
+		Fcanon px, py;
+		lut_load(A.lut, 0, px, py);   // any finite point: replaced by the first non-zero digit
+		acc.X = weaken<FX>(px);
+		acc.Y = weaken<FY>(py);
+		acc.Z = weaken<FZ>(constant<Fcanon>(K::ONE));
+	}
+	bool inf = true, bad = false;
+	const FZ onez = weaken<FZ>(constant<Fcanon>(K::ONE));
+#pragma unroll 1
+	for (int j = 0; j <= 64; j++) {
+		u32 word = 0;
+#pragma unroll
+		for (int w = 0; w < 8; w++) {
+			word = (w == (j >> 3)) ? kw[w] : word;
+		}
+		const int dig = (j < 64) ? (int)((word >> (4 * (j & 7))) & 15u) - 8 : (int)top;
+		const u32 mag = (u32)(dig < 0 ? -dig : dig);
+		Fcanon tx, tyc;
+		lut_load_masked(A.lut + (size_t)j * TBL_ENTRIES * TBL_WORDS_PER_ENTRY, mag ? mag - 1 : 0, tx, tyc);
+		const FYaff ty = sel(dig < 0, neg_aff(tyc), weaken<FYaff>(tyc));
+		bool hz;
+		const Jac S = madd(acc, tx, ty, hz);
+		const bool use_t = inf & (mag != 0);
+		const bool keep = (mag == 0);
+		bad = bad | (!inf & !keep & hz);
+		acc.X = sel(keep, acc.X, sel(use_t, weaken<FX>(tx), S.X));
+		acc.Y = sel(keep, acc.Y, sel(use_t, weaken<FY>(carry(ty)), S.Y));
+		acc.Z = sel(keep, acc.Z, sel(use_t, onez, S.Z));
+		inf = inf & keep;
+	}
+	if (bad) {
+		A.status[i] = ECAMD_STATUS_REDO;
+		return;
+	}
+	if (inf) {
+		A.status[i] = 2;
+		zero_out(A.out + (size_t)i * 64);
+		return;
+	}
+	jac_store(A.stg, i, 0, acc);
+	A.status[i] = ECAMD_STATUS_JAC;
+}
+
+// ------------------------------------------------------------------------------------------
 // D. finalisation: Jacobian -> affine for FIN_K items per lane with ONE field inversion
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_p256_finalize(EcamdSmulArgs A, u32 nthreads, int items)
@@ -949,6 +1041,8 @@ hipError_t ecamd_launch_smul_p256(const EcamdSmulArgs &a, hipStream_t s, hipEven
 	P256_MARK(2);
 	if (a.lut && a.lut_kind == 1) {
 		hipLaunchKernelGGL(k_p256_comb, grid, block, 0, s, a);
+	} else if (a.lut && a.lut_kind == 3) {
+		hipLaunchKernelGGL(k_p256_comb4m, grid, block, 0, s, a);
 	} else {
 		if (a.masked) {
 			if (a.slen <= 32) {

@@ -89,3 +89,32 @@ def test_key_pairs_from_raw_random_bytes(gpu_ctx, curve):
     finally:
         gpu_ctx.set_secret_scalars(False)
         cv.free()
+
+
+def test_secret_fixed_base_comb_p256(gpu_ctx):
+    """secp256r1, secret-scalar mode, fixed base: the scanned 4-bit comb (k_p256_comb4m) gives the bytes of the public-mode comb and
+    of the oracle on edge scalars (0, 1, small, q - 1, q, q + 1, 2^256 - 1, single nibbles, all-8 / all-7 / all-f nibbles), short
+    scalars and random ones; ECAMD_NO_SECRET_COMB's path (the scanned window loop) is what test_gpu_multi covers"""
+    rng = np.random.default_rng(77)
+    q = O.CURVES["SECP256R1"]["q"]
+    cv = gpu_ctx.curve("SECP256R1")
+    try:
+        vals = [0, 1, 2, 7, 8, 9, 15, 16, 17, q - 2, q - 1, q, q + 1, 2**256 - 1, 2**255, 2**255 - 1, int("8" * 64, 16), int("7" * 64, 16),
+                int("f" * 64, 16), int("78" * 32, 16), int("87" * 32, 16)]
+        vals += [m << (4 * j) for j in (0, 1, 31, 62, 63) for m in (1, 7, 8, 9, 15)]
+        vals += [int.from_bytes(rand_bytes(rng, 32), "big") for _ in range(3000)]
+        sc = b"".join(v.to_bytes(32, "big") for v in vals)
+        pub = cv.scalar_mult(sc)
+        gpu_ctx.set_secret_scalars(True)
+        try:
+            sec = cv.scalar_mult(sc)
+            short = cv.scalar_mult(b"".join((v % 2**72).to_bytes(9, "big") for v in vals), slen=9)
+        finally:
+            gpu_ctx.set_secret_scalars(False)
+        assert sec == pub
+        assert short == cv.scalar_mult(b"".join((v % 2**72).to_bytes(9, "big") for v in vals), slen=9)
+        o = Oracle("SECP256R1")
+        assert o.scalar_mult(sc[:32 * 60]) == (sec[0][:64 * 60], sec[1][:60])
+        assert 2 in sec[1]          # k = 0 and k = q: the point at infinity
+    finally:
+        cv.free()
