@@ -849,13 +849,18 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_build_g
 	}
 }
 
-template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_g(EcamdSmulArgs A, int gslot)
+// SCAN4 (round 4, secret scalars: ecamd_ctx_set_secret_scalars): the same kernel over a 4-bit comb -- T[j][m-1] = [m 16^j]G, m = 1..8,
+// j = 0 .. 8 NW - 1, and T[8 NW][0] = [2^(32 NW)]G; k = sum_j d_j 16^j + c 2^(32 NW), d_j = D_j - 8, D = nibbles of k + 0x88..8 --
+// whose look-ups are SCANS: every lane reads the eight entries of window j, in order, whatever its digit (the addresses depend on j
+// alone), and keeps the wanted one by masking.  8 NW + 1 mixed additions and no doubling instead of the masked window loop's 32 NW
+// doublings and 8 NW additions (cf. k_p256_comb4m).
+template <int PB, int FLAV, bool SCAN4 = false> __global__ __launch_bounds__(64) void k_comb_g(EcamdSmulArgs A, int gslot)
 {
 	typedef Lay<PB> L;
 	typedef typename Cls<PB>::FA FA;
 	typedef typename Cls<PB>::FM FM;
 	typedef typename Cls<PB>::FC FC;
-	constexpr int NL = L::NL, NW = L::NW, KW = L::KW, CENTW = CombLay<PB>::CENTW, NWIN = CombLay<PB>::NWIN;
+	constexpr int NL = L::NL, NW = L::NW, KW = L::KW, CENTW = CombLay<PB>::CENTW, NWIN = SCAN4 ? 8 * NW : CombLay<PB>::NWIN;
 	const u32 i = blockIdx.x * 64 + threadIdx.x;
 	if (i >= A.n) {
 		return;
@@ -870,7 +875,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_g(Ecamd
 		uint64_t c = 0;
 #pragma unroll
 		for (int w = 0; w < NW; w++) {
-			c += (uint64_t)kw[w] + 0x80008000u;
+			c += (uint64_t)kw[w] + (SCAN4 ? 0x88888888u : 0x80008000u);
 			kw[w] = (u32)c;
 			c >>= 32;
 		}
@@ -890,19 +895,40 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_g(Ecamd
 		u32 word = 0;
 #pragma unroll
 		for (int w = 0; w < KW; w++) {
-			word = (w == (j >> 1)) ? kw[w] : word;
+			word = (w == (SCAN4 ? (j >> 3) : (j >> 1))) ? kw[w] : word;
 		}
-		const int dig = (j < NWIN) ? (int)((word >> (16 * (j & 1))) & 0xffffu) - 0x8000 : (int)word;
+		const int dig = (j < NWIN) ? (SCAN4 ? (int)((word >> (4 * (j & 7))) & 15u) - 8 : (int)((word >> (16 * (j & 1))) & 0xffffu) - 0x8000) : (int)word;
 		const u32 mag = (u32)(dig < 0 ? -dig : dig);
-		const uint4 *src = (const uint4 *)(A.lut + ((size_t)j * COMB_PER_WIN + (mag ? mag - 1 : 0)) * CENTW);
 		u32 buf[CENTW];
+		if constexpr (SCAN4) {
+			const u32 idx = mag ? mag - 1 : 0;
 #pragma unroll
-		for (int q = 0; q < CENTW / 4; q++) {
-			const uint4 v = src[q];
-			buf[4 * q] = v.x;
-			buf[4 * q + 1] = v.y;
-			buf[4 * q + 2] = v.z;
-			buf[4 * q + 3] = v.w;
+			for (int w = 0; w < CENTW; w++) {
+				buf[w] = 0;
+			}
+#pragma unroll 1
+			for (u32 e = 0; e < 8; e++) {
+				const uint4 *src = (const uint4 *)(A.lut + ((size_t)j * 8 + e) * CENTW);
+				const u32 m = 0u - (u32)(e == idx);
+#pragma unroll
+				for (int q = 0; q < CENTW / 4; q++) {
+					const uint4 v = src[q];
+					buf[4 * q] |= v.x & m;
+					buf[4 * q + 1] |= v.y & m;
+					buf[4 * q + 2] |= v.z & m;
+					buf[4 * q + 3] |= v.w & m;
+				}
+			}
+		} else {
+			const uint4 *src = (const uint4 *)(A.lut + ((size_t)j * COMB_PER_WIN + (mag ? mag - 1 : 0)) * CENTW);
+#pragma unroll
+			for (int q = 0; q < CENTW / 4; q++) {
+				const uint4 v = src[q];
+				buf[4 * q] = v.x;
+				buf[4 * q + 1] = v.y;
+				buf[4 * q + 2] = v.z;
+				buf[4 * q + 3] = v.w;
+			}
 		}
 		FM tx, tyc;
 #pragma unroll
@@ -3651,7 +3677,7 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_TAG)(int gslot, const EcamdSmulArgs &a
 #if defined(G29_K256) || defined(G29_P25519) || defined(G29_JACTAB)
 		false;
 #else
-		!(a.lut && a.lut_kind == 1);
+		!(a.lut && (a.lut_kind == 1 || a.lut_kind == 3));
 #endif
 	if (ev) {
 		(void)hipEventRecord(ev[0], s);
@@ -3662,6 +3688,8 @@ hipError_t G29_CAT(ecamd_g29_launch_, G29_TAG)(int gslot, const EcamdSmulArgs &a
 	}
 	if (a.lut && a.lut_kind == 1) {
 		hipLaunchKernelGGL((k_comb_g<G29_PB, G29_FLAV>), grid, block, 0, s, a, gslot);
+	} else if (a.lut && a.lut_kind == 3) {
+		hipLaunchKernelGGL((k_comb_g<G29_PB, G29_FLAV, true>), grid, block, 0, s, a, gslot);   // secret scalars: the scanned 4-bit comb
 	} else {
 #if defined(G29_K256) || defined(G29_P25519) || defined(G29_JACTAB)
 		if (a.lut_kind == 2) {

@@ -296,7 +296,9 @@ struct ecamd_curve {
 	int gqslot;      // constant slot of the dense radix-2^29 unit of the ORDER's size holding q as its modulus (k_ecdsa_prep_g; -1: none)
 	int gflavour;    // 0 dense reduction, 1 secp521r1 (p = 2^521 - 1), 2 p = 2^255 - 19, 3 secp384r1's prime, 4 secp256k1's prime, 5 p = 2^448 - 2^224 - 1,
 	                 // 6 secp224r1's prime, 7 secp192r1's prime (3, 6, 7: signed sparse Montgomery reduction)
-	uint32_t *d_comb4;  // secp256r1: the 4-bit comb of the generator for SECRET scalars, 65 x 8 entries of 40 words (k_p256_comb4m); NULL: none
+	uint32_t *d_comb4;  // the 4-bit comb of the generator for SECRET scalars: secp256r1 65 x 8 entries of 40 words (k_p256_comb4m, built with the
+			    // handle), radix-2^29 units (8 NW + 1) x 8 comb entries (k_comb_g<.., SCAN4>, built on first use); NULL: none
+	bool comb4_off;     // ... its construction was tried
 	uint32_t *d_gtab; // secp256r1: affine window table [1..8]G, radix-2^29 Montgomery digits, 8 x 40 words
 	uint32_t *d_comb; // fast paths: 16-bit comb table of G, built on the first large fixed-base batch (NULL before / disabled)
 	bool comb_off;    // construction failed or is in progress: do not try (again)
@@ -1091,6 +1093,7 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	cv->edcomb_off = false;
 	cv->d_gtab = nullptr;
 	cv->d_comb4 = nullptr;
+	cv->comb4_off = false;
 	if (!(cv->p[0] & 1) || big_bitlen(cv->p) < 160) {
 		return curve_abort(cv, "curve: p must be odd and at least 160 bits");
 	}
@@ -1200,6 +1203,7 @@ static int curve_finish(ecamd_ctx *ctx, ecamd_curve *cv, ecamd_curve **out)
 	}
 	cv->d_gtab = nullptr;
 	cv->d_comb4 = nullptr;
+	cv->comb4_off = false;
 	cv->d_comb = nullptr;
 	cv->comb_off = false;
 	cv->d_edcomb = nullptr;
@@ -1438,6 +1442,60 @@ static void maybe_build_comb(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n)
 	cv->comb_off = false;
 }
 
+// The generator's 4-bit comb for SECRET scalars on a radix-2^29 unit (k_comb_g<.., SCAN4>): [m 16^j]G, m = 1..8, j = 0 .. 8 NW - 1, and
+// [2^(32 NW)]G, (8 NW + 1) x 8 entries of the unit's comb-entry format, built on the first secret fixed-base call of the handle through
+// the library's own (public-scalar) multiplication.  Failure is not an error: the masked window loop keeps serving.
+static void maybe_build_comb4(ecamd_ctx *ctx, ecamd_curve *cv)
+{
+	static const bool off = getenv("ECAMD_NO_SECRET_COMB") != nullptr;
+	if (off || cv->d_comb4 || cv->comb4_off || cv->is_p256 || cv->gslot < 0) {
+		return;
+	}
+	cv->comb4_off = true;   // one attempt
+	if (hipDeviceSynchronize() != hipSuccess) {
+		return;
+	}
+	const uint32_t nwords = (uint32_t)((cv->pbits + 31) / 32);
+	const uint32_t slen = 4 * nwords, nwin = 8 * nwords, ne = nwin * 8u + 1u;
+	const uint32_t ew = ecamd_g29_comb_entry_words(cv->pbits, cv->gflavour);
+	if (slen > ecamd_g29_comb_max_slen(cv->pbits)) {
+		return;
+	}
+	std::vector<uint8_t> hs((size_t)ne * slen, 0), st(ne, 1);
+	for (uint32_t j = 0; j < nwin; j++) {
+		for (uint32_t m = 1; m <= 8; m++) {
+			hs[((size_t)j * 8 + (m - 1)) * slen + slen - 1 - j / 2] = (uint8_t)(m << (4 * (j & 1)));
+		}
+	}
+	big_to_be(&hs[(size_t)nwin * 8 * slen], (int)slen, big_mod(big_pow2(8 * (int)slen), cv->q));
+	const size_t plen = (size_t)2 * cv->clen;
+	uint8_t *dsc = nullptr, *dpt = nullptr, *dst = nullptr;
+	uint32_t *table = nullptr;
+	hipStream_t s = ctx->stream;
+	bool ok = hipMalloc((void **)&dsc, hs.size()) == hipSuccess && hipMalloc((void **)&dpt, (size_t)ne * plen) == hipSuccess &&
+		  hipMalloc((void **)&dst, ne) == hipSuccess && hipMalloc((void **)&table, (size_t)(nwin + 1) * 8 * ew * 4) == hipSuccess &&
+		  hipMemset(table, 0, (size_t)(nwin + 1) * 8 * ew * 4) == hipSuccess &&
+		  hipMemcpy(dsc, hs.data(), hs.size(), hipMemcpyHostToDevice) == hipSuccess;
+	if (ok) {
+		PublicScalars pub_scope(ctx);   // constants of the curve
+		ok = smul_dev_locked(ctx, cv, ne, dsc, slen, nullptr, dpt, dst, s) == 0 &&
+		     ecamd_g29_comb_build(cv->pbits, cv->gslot, dpt, ne, (uint32_t)cv->clen, table, s, cv->gflavour) == hipSuccess &&
+		     hipMemcpyAsync(st.data(), dst, ne, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+	}
+	for (uint32_t i = 0; ok && i < ne; i++) {
+		ok = (st[i] == 0);
+	}
+	(void)hipFree(dsc);
+	(void)hipFree(dpt);
+	(void)hipFree(dst);
+	if (!ok) {
+		(void)hipFree(table);
+		(void)hipGetLastError();
+		return;
+	}
+	cv->d_comb4 = table;
+}
+
 // sstride = slen normally; 0 broadcasts one scalar to every item (subgroup / cofactor passes)
 static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_scalars,
 			   uint32_t slen, const uint8_t *d_points, uint8_t *d_out, uint8_t *d_status,
@@ -1463,6 +1521,9 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 	const bool fast = !redo_only && (fast256 || fastg);
 	if (fast && !d_points && comb_ok) {
 		maybe_build_comb(ctx, const_cast<ecamd_curve *>(cv), n);
+	}
+	if (fast && fastg && !d_points && secret && n >= 64) {
+		maybe_build_comb4(ctx, const_cast<ecamd_curve *>(cv));
 	}
 	{
 		uint8_t *t = (uint8_t *)ctx->tbl;
@@ -1532,8 +1593,8 @@ static int smul_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, co
 				const bool use_comb = cv->d_comb && comb_ok;
 				Fa.lut = use_comb ? cv->d_comb : (fast256 ? cv->d_gtab : nullptr);
 				Fa.lut_kind = use_comb ? 1u : 0u;
-				if (secret && fast256 && cv->d_comb4 && slen <= 32) {
-					Fa.lut = cv->d_comb4;   // secret scalars: the scanned 4-bit comb (65 additions) instead of the scanned window loop
+				if (secret && cv->d_comb4 && (fast256 ? slen <= 32 : slen <= 4 * (uint32_t)((cv->pbits + 31) / 32))) {
+					Fa.lut = cv->d_comb4;   // secret scalars: the scanned 4-bit comb (8 NW + 1 additions) instead of the scanned window loop
 					Fa.lut_kind = 3u;
 				}
 			}

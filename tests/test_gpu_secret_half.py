@@ -118,3 +118,32 @@ def test_secret_fixed_base_comb_p256(gpu_ctx):
         assert 2 in sec[1]          # k = 0 and k = q: the point at infinity
     finally:
         cv.free()
+
+
+@pytest.mark.parametrize("curve", ["SECP384R1", "SECP521R1", "BRAINPOOLP256R1", "SECP256K1", "WEI25519", "SECP224R1", "WEI448", "BRAINPOOLP512R1"])
+def test_secret_fixed_base_comb_generic_units(gpu_ctx, curve):
+    """the radix-2^29 units, secret-scalar mode, fixed base: the scanned 4-bit comb (k_comb_g<.., SCAN4>, built on the first such call
+    of the handle) against the public-mode results and the oracle, on edge scalars and random ones of full and of short length"""
+    rng = np.random.default_rng(78)
+    c = O.CURVES[curve]
+    q, ql = c["q"], qlen(curve)
+    nb = 8 * ql
+    cv = gpu_ctx.curve(curve)
+    try:
+        vals = [0, 1, 2, 7, 8, 9, 15, 16, q - 2, q - 1, q % 2**nb, (q + 1) % 2**nb, 2**nb - 1, 2**(nb - 1), int("8" * (2 * ql), 16), int("7" * (2 * ql), 16),
+                int("f" * (2 * ql), 16)]
+        vals += [(m << (4 * j)) % 2**nb for j in (0, 1, ql, 2 * ql - 2, 2 * ql - 1) for m in (1, 7, 8, 9, 15)]
+        vals += [int.from_bytes(rand_bytes(rng, ql), "big") for _ in range(1200)]
+        sc = b"".join(v.to_bytes(ql, "big") for v in vals)
+        short = b"".join((v % 2**56).to_bytes(7, "big") for v in vals)
+        pub, pub_short = cv.scalar_mult(sc), cv.scalar_mult(short, slen=7)
+        gpu_ctx.set_secret_scalars(True)
+        try:
+            sec, sec_short = cv.scalar_mult(sc), cv.scalar_mult(short, slen=7)
+        finally:
+            gpu_ctx.set_secret_scalars(False)
+        assert sec == pub and sec_short == pub_short
+        o = Oracle(curve)
+        assert o.scalar_mult(sc[:ql * 24]) == (sec[0][:2 * clen(curve) * 24], sec[1][:24])
+    finally:
+        cv.free()

@@ -21,7 +21,7 @@ print("headline", round(j["value"] / 1e6, 2), "M/s", round(j["ms_per_step"], 3),
 for s in j.get("secondary", []):
     if isinstance(s, dict):
         rr = s.get("roofline") or {}
-        print(" ", (s.get("config") or {}).get("workload"), round(s["value"] / 1e6, 2), "M/s", "frac", rr.get("frac"), "pipeline", rr.get("pipeline_frac"))
+        print(" ", s.get("config"), round(s["value"] / 1e6, 2), "M/s", "frac", s.get("frac", rr.get("frac")), "pipeline", s.get("pipeline_frac", rr.get("pipeline_frac")))
 PY
 cd /tmp
 timeout 200 rocprofv3 --kernel-trace --stats -d $O/prof -- python $R/bench.py --no-secondary --no-traffic --no-cpu-baseline --parity-items 256 --steps 10 --warmup 3 > $O/prof_bench.json 2> $O/prof_bench.err
