@@ -76,8 +76,8 @@ int ecamd_ctx_set_msm_seed(ecamd_ctx *ctx, const uint8_t seed[32]);
  * scalars: verification, public-key checks).  With this switch on, every multiplication by a caller-supplied scalar issued through
  * the context -- ec_prj_pt_mul_batch*, and inside ec_ecdsa_sign_batch, ec_ecccdh_derive_batch ([d]Q), ec_eddsa_sign_R_batch, key-pair
  * import -- uses constant-address table look-ups (every entry read, the wanted one kept by masking: the posture of the reference's
- * masked ladder, curves/prj_pt.c:1225-1260, and nn_tabselect, nn/nn.c:564), a fixed window count and no digit-indexed comb table (secp256r1's fixed-base
- * multiplications use a 4-bit comb whose windows are scanned whole, k_p256_comb4m; ECAMD_NO_SECRET_COMB: the scanned window loop).  The
+ * masked ladder, curves/prj_pt.c:1225-1260, and nn_tabselect, nn/nn.c:564), a fixed window count and no digit-indexed comb table (fixed-base
+ * multiplications use a 4-bit comb whose windows are scanned whole: k_p256_comb4m, k_comb_g<.., SCAN4>; ECAMD_NO_SECRET_COMB: the scanned window loop).  The
  * radix-2^29 pipelines stay in use: k_p256_loop<KW, MASKED> / k_loop_g<.., MASKED> scan the item's eight affine entries (secp256k1:
  * its eight Jacobian ones); only scalars longer than those kernels take (8 NW + 4 bytes) run on the complete-formula kernel with
  * sixteen-entry scans.  One branch remains: a lane whose accumulator met an exceptional pair of the incomplete addition
