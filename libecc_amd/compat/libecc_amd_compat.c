@@ -839,13 +839,23 @@ static void parallel_for(u32 n, range_fn fn, void *arg)
 /* Verification (round 4, measured: profiles/r4i_typed_boundary.md): quarter-batch GPU calls cost more than the packing they hide -- the
  * kernels of a 2^18-item launch run at 0.8 - 0.9 of their 2^20 rate and every call is copy-in, kernels, copy-out in sequence -- so a
  * verification is ONE call per batch (up to 2^20 items per device) and the packing overlaps it through the C ABI's producer hook
- * (pipeline_run_ex, streamed).  $ECAMD_COMPAT_CHUNK brings the chunked calls back, $ECAMD_COMPAT_NO_STREAM one call after all packing. */
-#define READY_ITEMS (1u << 16)   /* granularity of the producer handshake */
+ * (pipeline_run_ex, streamed).  $ECAMD_COMPAT_NO_STREAM: one call after all packing, or chunked calls of $ECAMD_COMPAT_CHUNK items. */
+#define READY_ITEMS (1u << 16)   /* granularity of the producer handshake ($ECAMD_COMPAT_READY_ITEMS: for tests of small batches) */
+static u32 ready_items(void)
+{
+	static u32 v;
+	if (!v) {
+		const char *e = getenv("ECAMD_COMPAT_READY_ITEMS");
+		const unsigned long x = e ? strtoul(e, NULL, 10) : 0;
+		v = (x >= GRAIN && x <= (1u << 24)) ? (u32)x : READY_ITEMS;
+	}
+	return v;
+}
 static int verify_streamed(void)
 {
 	static int on = -1;
 	if (on < 0) {
-		on = (g_chunk || getenv("ECAMD_COMPAT_NO_STREAM")) ? 0 : 1;
+		on = getenv("ECAMD_COMPAT_NO_STREAM") ? 0 : 1;
 	}
 	return on;
 }
@@ -869,7 +879,7 @@ static int verify_pipeline(u32 cnt, range_fn pack, gpu_fn gpu, range_fn unpack, 
 		return pipeline_run(cnt, per_call, pack, gpu, unpack, arg);
 	}
 	if (cnt <= per_call) {
-		return pipeline_run_ex(cnt, READY_ITEMS, pack, gpu, unpack, arg, 1);
+		return pipeline_run_ex(cnt, ready_items(), pack, gpu, unpack, arg, 1);
 	}
 	return pipeline_run(cnt, per_call, pack, gpu, unpack, arg);   /* (more than 2^20 items per device: chunked calls of that size) */
 }

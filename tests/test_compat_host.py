@@ -45,9 +45,22 @@ def test_every_typed_entry_point_matches_libecc_scalar_functions():
 
 
 def test_thread_pool_and_pipeline_chunks():
-    """one case per family at a size that takes the pool threads and three pipeline chunks (pack c+1 | GPU c | unpack c-1)"""
+    """one case per family at a size that takes the pool threads and three pipeline chunks (pack c+1 | GPU c | unpack c-1); the
+    verification calls are streamed (round 4): ONE device call, started at once, that asks the pool through the producer hook for
+    each of three ranges of the arrays being packed (the stand-in asks 1000 items at a time); nonces and private scalars leave as raw
+    random bytes and are reduced behind the C ABI"""
     _build()
-    r = _run(["quick", "1100"], ECAMD_COMPAT_CHUNK="512", ECAMD_COMPAT_THREADS="6")
+    r = _run(["quick", "1100"], ECAMD_COMPAT_CHUNK="512", ECAMD_COMPAT_READY_ITEMS="512", ECAMD_COMPAT_THREADS="6")
+    assert r.returncode == 0, r.stdout[-4000:]
+    assert "all ok" in r.stdout
+
+
+def test_host_side_fallbacks_of_round_4():
+    """the same program with every round-4 path switched back to its host-side predecessor: libecc's hashes, chunked verification
+    calls, the two-pass EdDSA verification, nn_get_random_mod on the pool threads, projective keys although Z = 1"""
+    _build()
+    r = _run(["quick", "300"], ECAMD_COMPAT_HOST_HASH="1", ECAMD_COMPAT_NO_STREAM="1", ECAMD_COMPAT_ED_TWO_PASS="1", ECAMD_COMPAT_HOST_RANDMOD="1",
+             ECAMD_COMPAT_PRJ_KEYS="1", ECAMD_COMPAT_THREADS="3", ECAMD_COMPAT_CHUNK="128")
     assert r.returncode == 0, r.stdout[-4000:]
     assert "all ok" in r.stdout
 
