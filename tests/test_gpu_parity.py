@@ -1206,14 +1206,14 @@ def test_libecc_typed_boundary_vs_scalar_api():
     # three ranks on device 0 with tiny chunks: the verification calls are streamed (the pool packs while the C ABI asks for each
     # range through the producer hook, which the multi-device layer offsets per shard), several chunks per shard, short first chunk
     env = dict(os.environ, ECAMD_DEVICES="0,0,0", ECAMD_COMPAT_READY_ITEMS="512", ECAMD_HOST_CHUNK="96", ECAMD_HOST_RAMP_MIN="16")
-    r = subprocess.run([exe, "1300"], capture_output=True, text=True, timeout=1500, env=env)
+    r = subprocess.run([exe, "quick", "600"], capture_output=True, text=True, timeout=1500, env=env)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     assert "compat_check: all ok" in r.stdout and "FAILED" not in r.stdout and "MISMATCH" not in r.stdout
     # the paths round 4 left as fall-backs: host hashing, chunked calls, two-pass EdDSA, nn_get_random_mod on the host, the scanned
     # window loop for secret fixed-base multiplications, the saturated-word projective import
     env = dict(os.environ, ECAMD_COMPAT_HOST_HASH="1", ECAMD_COMPAT_NO_STREAM="1", ECAMD_COMPAT_ED_TWO_PASS="1", ECAMD_COMPAT_HOST_RANDMOD="1",
                ECAMD_NO_SECRET_COMB="1", ECAMD_NO_PRJ_IMPORT_G29="1", ECAMD_COMPAT_PRJ_KEYS="1")
-    r = subprocess.run([exe, "200"], capture_output=True, text=True, timeout=1500, env=env)
+    r = subprocess.run([exe, "quick", "150"], capture_output=True, text=True, timeout=1500, env=env)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     assert "compat_check: all ok" in r.stdout and "FAILED" not in r.stdout and "MISMATCH" not in r.stdout
 
