@@ -3048,6 +3048,8 @@ typedef struct {
 	int dev_hash;            /* round 4: SHA-2 of short messages on the device -- 0 host hashing, else the hash_alg_type number */
 	u32 slot;                /* ... stride of a message slot in dg (u32 length + bytes), a multiple of 4 */
 	int *results;            /* the caller's per-item results (written by the unpack step of a chunk, on the pool) */
+	u32 a_off;               /* one-pass EdDSA: where the key's encoding goes in the hash input (after dom2 and R) */
+	u32 dom_len;             /* ... octets of the dom2 prefix in front of R (0: plain Ed25519) */
 	int pre_scanned;         /* verify_results' one pass over the keys already found: */
 	u32 pre_max_mlen;        /* ... the longest message of the group */
 	u32 pre_not_affine;      /* ... whether some usable key has Z != 1 */
@@ -3291,10 +3293,25 @@ static void eddsa_pack_prj(u32 lo, u32 hi, void *arg)
 		int bad = pub_key_check_initialized_and_type(pk, J->sig_type) || pk->params != J->params || !J->s[i] ||
 			  J->s_len[i] != J->siglen || (!J->m[i] && J->m_len[i]);
 		bad = bad || prj_to_be(kdst, J->clen, &pk->y, &(J->params->ec_curve));
-		if (!bad) {
+		if (!bad && J->dom_len) {
+			/* EDDSA25519CTX: dom2(0, context) in front of R (sig/eddsa.c:56-84); the group's contexts have one length (eddsa_group) */
+			const u8 *ad = J->adata ? J->adata[i] : NULL;
+			u8 head[32 + 2 + 255 + 32];
+			bad = !ad || (u32)(J->adata_len ? J->adata_len[i] : 0) + 34u != J->dom_len;
+			if (!bad) {
+				memcpy(head, "SigEd25519 no Ed25519 collisions", 32);
+				head[32] = 0;
+				head[33] = (u8)(J->dom_len - 34u);
+				memcpy(head + 34, ad, J->dom_len - 34u);
+				memcpy(head + J->dom_len, J->s[i], J->klen);
+				slot_put(J->dg + (size_t)j * J->slot, J->slot, head, J->dom_len + J->klen, blank, J->klen, J->m[i], J->m_len[i]);
+				memcpy(J->sg + (size_t)j * J->siglen, J->s[i], J->siglen);
+			}
+		} else if (!bad) {
 			slot_put(J->dg + (size_t)j * J->slot, J->slot, J->s[i], J->klen, blank, J->klen, J->m[i], J->m_len[i]);
 			memcpy(J->sg + (size_t)j * J->siglen, J->s[i], J->siglen);
-		} else {
+		}
+		if (bad) {
 			memset(kdst, 0xff, (size_t)3 * J->clen);   /* coordinates >= p: an import error on the device */
 			memset(J->sg + (size_t)j * J->siglen, 0xff, J->siglen);
 			memset(J->dg + (size_t)j * J->slot, 0, J->slot);
@@ -3307,7 +3324,7 @@ static int eddsa_ver_gpu_prj(u32 lo, u32 hi, void *arg)
 {
 	ver_job *J = (ver_job *)arg;
 	if (ecamd_multi_eddsa_verify_msg_prj_batch(g_multi, J->e->mc, hi - lo, J->kprj + (size_t)lo * 3 * J->clen, J->sg + (size_t)lo * J->siglen,
-						   J->dg + (size_t)lo * J->slot, J->slot, J->klen, J->res + lo)) {
+						   J->dg + (size_t)lo * J->slot, J->slot, J->a_off, J->res + lo)) {
 		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
 		return -1;
 	}
@@ -3375,10 +3392,30 @@ static int eddsa_ver_gpu_all(u32 lo, u32 hi, void *arg)
 	return 0;
 }
 
+/* do the items of an EDDSA25519CTX group carry contexts of one length?  (items without one fail in the pack step whatever the answer) */
+typedef struct {
+	const ver_job *J;
+	u32 first, mixed;
+} adl_job;
+static void adl_scan(u32 lo, u32 hi, void *arg)
+{
+	adl_job *A = (adl_job *)arg;
+	u32 j, mixed = 0;
+	for (j = lo; j < hi; j++) {
+		const u32 i = A->J->idx[j];
+		if (A->J->adata && A->J->adata[i] && (A->J->adata_len ? A->J->adata_len[i] : 0) != A->first) {
+			mixed = 1;
+		}
+	}
+	if (mixed) {
+		AT_STORE(&A->mixed, 1);
+	}
+}
+
 static int eddsa_group(ver_job *J, u32 cnt, int *results)
 {
 	u32 j;
-	int one_pass = 0;
+	int one_pass = 0, ctx_uniform = 0;
 	J->clen = J->e->clen;
 	J->hlen = J->hm->digest_size;      /* 64 (SHA-512) / 114 (SHAKE256 as libecc configures it) */
 	J->klen = J->hlen / 2;             /* EDDSA_R_LEN: 32 / 57 */
@@ -3390,10 +3427,24 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
 	J->dev_hash = 0;
 	J->slot = 0;
 #if defined(WITH_SIG_EDDSA25519)
-	if (J->sig_type == EDDSA25519 && !J->dom && !J->ph && dev_hash_type(J->hm) == 4) {
+	J->dom_len = 0;
+	if (J->sig_type == EDDSA25519CTX && J->dom && !J->ph && cnt) {
+		/* the contexts of a batch normally have one length: then dom2 || R || A sits at one offset in every hash input */
+		adl_job A;
+		A.J = J;
+		A.first = J->adata_len ? J->adata_len[J->idx[0]] : 0;
+		A.mixed = A.first > 255 ? 1 : 0;
+		if (!A.mixed) {
+			parallel_for(cnt, adl_scan, &A);
+		}
+		ctx_uniform = !AT_LOAD(&A.mixed);
+		J->dom_len = ctx_uniform ? 34u + A.first : 0;
+	}
+	if (((J->sig_type == EDDSA25519 && !J->dom) || ctx_uniform) && !J->ph && dev_hash_type(J->hm) == 4) {
 		/* (also when only the conjunction is wanted: since the half-length scalars of round 4 the item-by-item verification of 2^20
 		 * signatures takes the 12 ms the multi-scalar combination takes, needs no z_i, and does not wait for the host to hash) */
-		J->slot = dev_hash_slot(J, cnt, 2 * J->klen);
+		J->slot = dev_hash_slot(J, cnt, J->dom_len + 2 * J->klen);
+		J->a_off = J->dom_len + J->klen;
 		one_pass = J->slot && !getenv("ECAMD_COMPAT_ED_TWO_PASS");
 		J->dev_hash = (J->slot && (one_pass || !J->all_only)) ? 4 : 0;
 		if (!J->dev_hash) {
@@ -3409,6 +3460,9 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
 	J->kprj = buf_get(5, (size_t)cnt * 3 * J->clen);
 	if (!J->pk || !J->sg || !J->dg || !J->pre || !J->res || !J->kprj) {
 		return -1;
+	}
+	if (getenv("ECAMD_COMPAT_TIMING")) {
+		fprintf(stderr, "libecc_amd compat timing: EdDSA group of %u items: %s, dom2 prefix %u octets\n", cnt, one_pass ? "one device call" : "two passes", J->dom_len);
 	}
 	if (one_pass) {
 		J->results = results;

@@ -2694,8 +2694,11 @@ static int rand_mod_args_ok(const char *fn, ecamd_ctx *ctx, const ecamd_curve *c
 
 extern "C" int ec_nn_random_mod_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *raw, uint8_t *out)
 {
-	if (rand_mod_args_ok("ec_nn_random_mod_batch", ctx, cv) || (n && (!raw || !out))) {
-		return n && (!raw || !out) ? fail("ec_nn_random_mod_batch: bad argument") : -1;
+	if (rand_mod_args_ok("ec_nn_random_mod_batch", ctx, cv)) {
+		return -1;
+	}
+	if (n && (!raw || !out)) {
+		return fail("ec_nn_random_mod_batch: bad argument");
 	}
 	if (n == 0) {
 		return 0;
