@@ -50,7 +50,7 @@ def test_thread_pool_and_pipeline_chunks():
     each of three ranges of the arrays being packed (the stand-in asks 1000 items at a time); nonces and private scalars leave as raw
     random bytes and are reduced behind the C ABI"""
     _build()
-    r = _run(["quick", "1100"], ECAMD_COMPAT_CHUNK="512", ECAMD_COMPAT_READY_ITEMS="512", ECAMD_COMPAT_THREADS="6")
+    r = _run(["quick", "1040"], ECAMD_COMPAT_CHUNK="512", ECAMD_COMPAT_READY_ITEMS="512", ECAMD_COMPAT_THREADS="6")
     assert r.returncode == 0, r.stdout[-4000:]
     assert "all ok" in r.stdout
 
