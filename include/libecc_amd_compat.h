@@ -39,7 +39,20 @@ int ecamd_compat_set_secret_scalars(int on);
  * lock around the get_random call itself (the reduction mod q stays parallel).  libecc never required get_random to be
  * reentrant, and a stateful source that is not could hand out torn or repeated nonces.  An application whose get_random IS
  * thread-safe (one getrandom(2) / /dev/urandom read per call, a locked DRBG) may lift the lock: on = 1, or
- * $ECAMD_COMPAT_CONCURRENT_RANDOM=1 before the first batch call. */
+ * $ECAMD_COMPAT_CONCURRENT_RANDOM=1 before the first batch call.
+ * What is drawn is what libecc draws: nn_get_random_mod's ONE get_random call of 2 * qlen bytes per ECDSA nonce / generic private
+ * scalar; since round 4 only that call runs on the host -- the reduction modulo q - 1 of those bytes, like the SHA-2 of short messages,
+ * runs on the device ($ECAMD_COMPAT_HOST_RANDMOD, $ECAMD_COMPAT_HOST_HASH: on the host through libecc's own functions, as before).
+ *
+ * Environment of the layer (read at the first batch call; for measurements and fall-backs -- results are identical):
+ *   ECAMD_DEVICES=0,1,..  ECAMD_COMPAT_THREADS=<n>  ECAMD_COMPAT_CHUNK=<items per pipeline chunk and device>  ECAMD_COMPAT_PUBLIC_SCALARS
+ *   ECAMD_COMPAT_CONCURRENT_RANDOM  ECAMD_COMPAT_HOST_HASH  ECAMD_COMPAT_HOST_RANDMOD
+ *   ECAMD_COMPAT_NO_STREAM        verification: pack everything, then call the device (default: one call per batch that asks the pool
+ *                                 for each range of the arrays through ecamd_multi_set_host_ready_hook while they are being packed)
+ *   ECAMD_COMPAT_READY_ITEMS=<n>  granularity of that handshake (default 2^16)
+ *   ECAMD_COMPAT_ED_TWO_PASS      EDDSA25519 / EDDSA25519CTX verification: encode the keys in a call of its own and hash on the host
+ *   ECAMD_COMPAT_PRJ_KEYS         ECDSA verification: send keys as X || Y || Z even when every Z is 1
+ *   ECAMD_COMPAT_TIMING           one line per pipeline run on stderr: where the calling thread's time went */
 void ecamd_compat_set_concurrent_random(int on);
 /* A curve the library does not know by name (ec_params built by the application from its own ec_str_params): registered
  * so that prj_pt arrays on it can be mapped to a device-side curve (a prj_pt only points to its ec_shortw_crv, which has
