@@ -218,6 +218,12 @@ int ec_eddsa_verify_msg_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t
  * is rejected (result 1); a key at infinity encodes as (0, 1) and is rejected by the small-order test like in the reference. */
 int ec_eddsa_verify_msg_prj_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
 				  const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, uint8_t *result);
+/* The pre-hashed variant (EDDSA25519PH, sig/eddsa.c:1049-1080, :1995-2045): the hash input is dom2(1, context) || R || A || PH(M) with
+ * PH(M) = SHA-512(M).  The caller leaves 96 blank octets at message offset a_offset (A, then PH(M)) and hands the messages over in
+ * slots of their own (msg_slots, msg_stride: u32 length + bytes); both hashes run on the device. */
+int ec_eddsa_verify_ph_prj_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
+				 const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, const uint8_t *msg_slots, uint32_t msg_stride,
+				 uint8_t *result);
 /* ECDSA signing with caller-supplied nonces: per item the tail of ec_sign / __ecdsa_sign_finalize
  * (sig/ecdsa_common.c:318-586) -- kG = prj_pt_mul(k, G), r = kG.x mod q, s = k^-1 (x r + e) mod q --
  * with h = H(m) and the nonce k supplied by the caller (random, or RFC 6979 computed on the host;
@@ -463,6 +469,9 @@ int ecamd_multi_eddsa_verify_msg_batch(ecamd_multi *m, const ecamd_mcurve *curve
 				       const uint8_t *hash_slots, uint32_t stride, uint8_t *result);
 int ecamd_multi_eddsa_verify_msg_prj_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
 					   const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, uint8_t *result);
+int ecamd_multi_eddsa_verify_ph_prj_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
+					  const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, const uint8_t *msg_slots, uint32_t msg_stride,
+					  uint8_t *result);
 int ecamd_multi_ecdsa_sign_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *privs,
 				 const uint8_t *nonces, const uint8_t *digests, uint32_t digest_len, uint8_t *sigs,
 				 uint8_t *status);

@@ -3048,6 +3048,8 @@ typedef struct {
 	int dev_hash;            /* round 4: SHA-2 of short messages on the device -- 0 host hashing, else the hash_alg_type number */
 	u32 slot;                /* ... stride of a message slot in dg (u32 length + bytes), a multiple of 4 */
 	int *results;            /* the caller's per-item results (written by the unpack step of a chunk, on the pool) */
+	u8 *ms;                  /* one-pass EDDSA25519PH: the messages in slots of their own (hashed on the device into the hash input) */
+	u32 mslot;
 	u32 a_off;               /* one-pass EdDSA: where the key's encoding goes in the hash input (after dom2 and R) */
 	u32 dom_len;             /* ... octets of the dom2 prefix in front of R (0: plain Ed25519) */
 	int pre_scanned;         /* verify_results' one pass over the keys already found: */
@@ -3294,17 +3296,27 @@ static void eddsa_pack_prj(u32 lo, u32 hi, void *arg)
 			  J->s_len[i] != J->siglen || (!J->m[i] && J->m_len[i]);
 		bad = bad || prj_to_be(kdst, J->clen, &pk->y, &(J->params->ec_curve));
 		if (!bad && J->dom_len) {
-			/* EDDSA25519CTX: dom2(0, context) in front of R (sig/eddsa.c:56-84); the group's contexts have one length (eddsa_group) */
+			/* EDDSA25519CTX / PH: dom2(phflag, context) in front of R (sig/eddsa.c:56-84); the group's contexts have one length
+			 * (eddsa_group); CTX wants a context, PH takes one or none */
 			const u8 *ad = J->adata ? J->adata[i] : NULL;
+			const u32 adl = J->dom_len - 34u;
 			u8 head[32 + 2 + 255 + 32];
-			bad = !ad || (u32)(J->adata_len ? J->adata_len[i] : 0) + 34u != J->dom_len;
+			bad = (u32)(J->adata_len ? J->adata_len[i] : 0) != adl || (J->ph ? (adl && !ad) : !ad);
 			if (!bad) {
 				memcpy(head, "SigEd25519 no Ed25519 collisions", 32);
-				head[32] = 0;
-				head[33] = (u8)(J->dom_len - 34u);
-				memcpy(head + 34, ad, J->dom_len - 34u);
+				head[32] = (u8)(J->ph ? 1 : 0);
+				head[33] = (u8)adl;
+				if (adl) {
+					memcpy(head + 34, ad, adl);
+				}
 				memcpy(head + J->dom_len, J->s[i], J->klen);
-				slot_put(J->dg + (size_t)j * J->slot, J->slot, head, J->dom_len + J->klen, blank, J->klen, J->m[i], J->m_len[i]);
+				if (J->ph) {
+					static const u8 blank96[96] = {0};
+					slot_put(J->dg + (size_t)j * J->slot, J->slot, head, J->dom_len + J->klen, blank96, 96, NULL, 0);
+					slot_put(J->ms + (size_t)j * J->mslot, J->mslot, NULL, 0, NULL, 0, J->m[i], J->m_len[i]);
+				} else {
+					slot_put(J->dg + (size_t)j * J->slot, J->slot, head, J->dom_len + J->klen, blank, J->klen, J->m[i], J->m_len[i]);
+				}
 				memcpy(J->sg + (size_t)j * J->siglen, J->s[i], J->siglen);
 			}
 		} else if (!bad) {
@@ -3315,6 +3327,9 @@ static void eddsa_pack_prj(u32 lo, u32 hi, void *arg)
 			memset(kdst, 0xff, (size_t)3 * J->clen);   /* coordinates >= p: an import error on the device */
 			memset(J->sg + (size_t)j * J->siglen, 0xff, J->siglen);
 			memset(J->dg + (size_t)j * J->slot, 0, J->slot);
+			if (J->ph) {
+				memset(J->ms + (size_t)j * J->mslot, 0, J->mslot);
+			}
 		}
 		J->pre[j] = bad ? 1 : 0;
 	}
@@ -3323,6 +3338,14 @@ static void eddsa_pack_prj(u32 lo, u32 hi, void *arg)
 static int eddsa_ver_gpu_prj(u32 lo, u32 hi, void *arg)
 {
 	ver_job *J = (ver_job *)arg;
+	if (J->ph) {
+		if (ecamd_multi_eddsa_verify_ph_prj_batch(g_multi, J->e->mc, hi - lo, J->kprj + (size_t)lo * 3 * J->clen, J->sg + (size_t)lo * J->siglen,
+							  J->dg + (size_t)lo * J->slot, J->slot, J->a_off, J->ms + (size_t)lo * J->mslot, J->mslot, J->res + lo)) {
+			fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+			return -1;
+		}
+		return 0;
+	}
 	if (ecamd_multi_eddsa_verify_msg_prj_batch(g_multi, J->e->mc, hi - lo, J->kprj + (size_t)lo * 3 * J->clen, J->sg + (size_t)lo * J->siglen,
 						   J->dg + (size_t)lo * J->slot, J->slot, J->a_off, J->res + lo)) {
 		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
@@ -3403,8 +3426,10 @@ static void adl_scan(u32 lo, u32 hi, void *arg)
 	u32 j, mixed = 0;
 	for (j = lo; j < hi; j++) {
 		const u32 i = A->J->idx[j];
-		if (A->J->adata && A->J->adata[i] && (A->J->adata_len ? A->J->adata_len[i] : 0) != A->first) {
-			mixed = 1;
+		const u32 adl = A->J->adata_len ? A->J->adata_len[i] : 0;
+		const u8 *ad = A->J->adata ? A->J->adata[i] : NULL;
+		if (A->J->ph ? (adl != A->first || (adl && !ad)) : (ad && adl != A->first)) {
+			mixed = 1;   /* (pre-hashed variant: the context is optional, its length octet is hashed either way) */
 		}
 	}
 	if (mixed) {
@@ -3428,7 +3453,7 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
 	J->slot = 0;
 #if defined(WITH_SIG_EDDSA25519)
 	J->dom_len = 0;
-	if (J->sig_type == EDDSA25519CTX && J->dom && !J->ph && cnt) {
+	if ((J->sig_type == EDDSA25519CTX || J->sig_type == EDDSA25519PH) && J->dom && cnt) {
 		/* the contexts of a batch normally have one length: then dom2 || R || A sits at one offset in every hash input */
 		adl_job A;
 		A.J = J;
@@ -3440,13 +3465,23 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
 		ctx_uniform = !AT_LOAD(&A.mixed);
 		J->dom_len = ctx_uniform ? 34u + A.first : 0;
 	}
-	if (((J->sig_type == EDDSA25519 && !J->dom) || ctx_uniform) && !J->ph && dev_hash_type(J->hm) == 4) {
+	if (((J->sig_type == EDDSA25519 && !J->dom && !J->ph) || ctx_uniform) && dev_hash_type(J->hm) == 4) {
 		/* (also when only the conjunction is wanted: since the half-length scalars of round 4 the item-by-item verification of 2^20
 		 * signatures takes the 12 ms the multi-scalar combination takes, needs no z_i, and does not wait for the host to hash) */
-		J->slot = dev_hash_slot(J, cnt, J->dom_len + 2 * J->klen);
+		if (J->ph) {
+			/* pre-hashed: the hash input is dom2 || R || A || PH(M) -- a fixed length --, the messages travel in slots of their own */
+			J->mslot = dev_hash_slot(J, cnt, 0);
+			J->slot = J->mslot ? ((4u + J->dom_len + 2 * J->klen + 64u + 3u) & ~3u) : 0;
+			if (J->slot > DEV_HASH_MAX_SLOT) {
+				J->slot = 0;
+			}
+		} else {
+			J->slot = dev_hash_slot(J, cnt, J->dom_len + 2 * J->klen);
+		}
 		J->a_off = J->dom_len + J->klen;
 		one_pass = J->slot && !getenv("ECAMD_COMPAT_ED_TWO_PASS");
-		J->dev_hash = (J->slot && (one_pass || !J->all_only)) ? 4 : 0;
+		/* (the two-pass path builds its hash inputs for the plain variant only: CTX / PH hash on the host there) */
+		J->dev_hash = (J->slot && (one_pass || (!J->all_only && !J->dom_len && !J->ph))) ? 4 : 0;
 		if (!J->dev_hash) {
 			J->slot = 0;
 		}
@@ -3458,7 +3493,8 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
 	J->pre = buf_get(3, cnt);
 	J->res = buf_get(4, cnt);
 	J->kprj = buf_get(5, (size_t)cnt * 3 * J->clen);
-	if (!J->pk || !J->sg || !J->dg || !J->pre || !J->res || !J->kprj) {
+	J->ms = (one_pass && J->ph) ? buf_get(6, (size_t)cnt * J->mslot) : NULL;
+	if (!J->pk || !J->sg || !J->dg || !J->pre || !J->res || !J->kprj || (one_pass && J->ph && !J->ms)) {
 		return -1;
 	}
 	if (getenv("ECAMD_COMPAT_TIMING")) {

@@ -3825,34 +3825,50 @@ static int eddsa_sign_setup(const char *fn, ecamd_ctx *ctx, const ecamd_curve *c
 // ec_eddsa_encode_point_batch computes; here that encoding goes straight into the item's hash input on the device (bytes a_offset ..
 // a_offset + 32 of the slot's message, which the caller leaves blank; the caller's array itself is not written), so one call replaces encode / copy back / build the inputs /
 // verify.  A key that does not import (coordinates >= p, not on the curve) or is the point at infinity rejects its item.
-extern "C" int ec_eddsa_verify_msg_prj_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
-					     const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, uint8_t *result)
+static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
+				     const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, const uint8_t *msg_slots, uint32_t msg_stride,
+				     uint8_t *result)
 {
-	if (!ctx || stride < 4 || (stride & 3u) || stride > 4096 || (uint64_t)a_offset + 36 > stride) {
-		return fail("ec_eddsa_verify_msg_prj_batch: bad argument (stride: a multiple of 4 in 4 .. 4096; 4 + a_offset + 32 <= stride)");
+	const std::string f(fn);
+	const uint32_t blank = msg_slots ? 96u : 32u;   // A, or A || PH(M)
+	if (!ctx || stride < 4 || (stride & 3u) || stride > 4096 || (uint64_t)a_offset + 4 + blank > stride) {
+		return fail(f + ": bad argument (stride: a multiple of 4 in 4 .. 4096; the blank for A [and PH(M)] must lie inside the slot)");
+	}
+	if (msg_slots && (msg_stride < 4 || (msg_stride & 3u) || msg_stride > 4096)) {
+		return fail(f + ": bad argument (msg_stride: a multiple of 4 in 4 .. 4096)");
 	}
 	std::lock_guard<std::mutex> lk(ctx->mu);
 	EcamdEdSignArgs T;
-	if (eddsa_sign_setup("ec_eddsa_verify_msg_prj_batch", ctx, cv_in, n, keys_prj, sigs, hash_slots, &T) ||
-	    eddsa_args_ok("ec_eddsa_verify_msg_prj_batch", ctx, cv_in, n, keys_prj, sigs, hash_slots, result, 64)) {
+	if (eddsa_sign_setup(fn, ctx, cv_in, n, keys_prj, sigs, hash_slots, &T) || eddsa_args_ok(fn, ctx, cv_in, n, keys_prj, sigs, hash_slots, result, 64)) {
 		return -1;
 	}
 	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
 	if (cv->pbits != 255) {
-		return fail("ec_eddsa_verify_msg_prj_batch: Ed25519 (the WEI25519 handle) only: Ed448 hashes with SHAKE256");
+		return fail(f + ": Ed25519 (the WEI25519 handle) only: Ed448 hashes with SHAKE256");
 	}
 	if (n == 0) {
 		return 0;
 	}
 	HIPCHK(hipSetDevice(ctx->device));
 	const size_t cl = (size_t)cv->clen;
-	const std::vector<HostArr> arrs = {{keys_prj, nullptr, 3 * cl}, {sigs, nullptr, 64u}, {hash_slots, nullptr, stride}, {nullptr, result, 1}};
+	std::vector<HostArr> arrs = {{keys_prj, nullptr, 3 * cl}, {sigs, nullptr, 64u}, {hash_slots, nullptr, stride}, {nullptr, result, 1}};
+	if (msg_slots) {
+		arrs.push_back({msg_slots, nullptr, msg_stride});
+	}
 	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
 		// stage: 20 affine keys, 21 import status, 22 encodings, 23 their status (the verification core owns 3 .. 19)
 		if (ensure(&ctx->stage[20], &ctx->stage_bytes[20], (size_t)m * 2 * cl) || ensure(&ctx->stage[21], &ctx->stage_bytes[21], m) ||
 		    ensure(&ctx->stage[22], &ctx->stage_bytes[22], (size_t)m * 32) || ensure(&ctx->stage[23], &ctx->stage_bytes[23], m)) {
 			return -1;
+		}
+		uint8_t *slots = const_cast<uint8_t *>(ip[2]);   // the staged copy of the caller's slots
+		if (msg_slots) {
+			// PH(M) = SHA-512(M) of every message, written behind the blank for A (EDDSA25519PH: sig/eddsa.c:1049-1080)
+			if (ecdsa_hash_stage(ctx, 4, m, ip[4], msg_stride, 64, s)) {
+				return -1;
+			}
+			HIPCHK(ecamd_launch_slot_patch(slots, stride, a_offset + 32, ctx->stage[17], 64, nullptr, m, s));
 		}
 		EcamdPrjInArgs I;
 		I.in = ip[0];
@@ -3870,7 +3886,6 @@ extern "C" int ec_eddsa_verify_msg_prj_batch(ecamd_ctx *ctx, const ecamd_curve *
 		A.out = ctx->stage[22];
 		A.status = ctx->stage[23];
 		HIPCHK(ecamd_launch_ed_sign_enc(A, s));
-		uint8_t *slots = const_cast<uint8_t *>(ip[2]);   // the staged copy of the caller's slots
 		HIPCHK(ecamd_launch_slot_patch(slots, stride, a_offset, ctx->stage[22], 32, ctx->stage[23], m, s));
 		if (ecdsa_hash_stage(ctx, 4, m, slots, stride, 64, s) ||
 		    eddsa_verify_dev_locked(ctx, cv, m, ctx->stage[22], ip[1], ctx->stage[17], 64, op[3], s)) {
@@ -3879,6 +3894,26 @@ extern "C" int ec_eddsa_verify_msg_prj_batch(ecamd_ctx *ctx, const ecamd_curve *
 		HIPCHK(ecamd_launch_reject_where(op[3], ctx->stage[23], m, s));
 		return 0;
 	});
+}
+
+extern "C" int ec_eddsa_verify_msg_prj_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
+					     const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, uint8_t *result)
+{
+	return eddsa_verify_msg_prj_impl("ec_eddsa_verify_msg_prj_batch", ctx, cv, n, keys_prj, sigs, hash_slots, stride, a_offset, nullptr, 0, result);
+}
+
+// The pre-hashed variant (EDDSA25519PH): the hash input is dom2(1, ctx) || R || A || PH(M) with PH(M) = SHA-512(M); the caller leaves 96
+// blank octets at a_offset (A, then PH(M)) and hands the messages over in slots of their own, hashed on the device as well.
+extern "C" int ec_eddsa_verify_ph_prj_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
+					    const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, const uint8_t *msg_slots, uint32_t msg_stride,
+					    uint8_t *result)
+{
+	if (n && !msg_slots) {
+		return fail("ec_eddsa_verify_ph_prj_batch: bad argument");
+	}
+	static const uint8_t none = 0;
+	return eddsa_verify_msg_prj_impl("ec_eddsa_verify_ph_prj_batch", ctx, cv, n, keys_prj, sigs, hash_slots, stride, a_offset, msg_slots ? msg_slots : &none,
+					 msg_stride, result);
 }
 
 // ------------------------------------------------------------------------------------------

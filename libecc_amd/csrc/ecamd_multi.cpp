@@ -336,6 +336,17 @@ extern "C" int ecamd_multi_ecdsa_sign_batch(ecamd_multi *m, const ecamd_mcurve *
 	});
 }
 
+extern "C" int ecamd_multi_eddsa_verify_ph_prj_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
+						     const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, const uint8_t *msg_slots,
+						     uint32_t msg_stride, uint8_t *result)
+{
+	const size_t kl = 3 * (size_t)ecamd_multi_curve_coord_len(c);
+	return run_sharded(m, c, n, "ecamd_multi_eddsa_verify_ph_prj_batch", [&](int r, uint32_t lo, uint32_t hi) {
+		return ec_eddsa_verify_ph_prj_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(keys_prj, kl), OFF(sigs, 64), OFF(hash_slots, (size_t)stride),
+						    stride, a_offset, OFF(msg_slots, (size_t)msg_stride), msg_stride, OFF(result, 1));
+	});
+}
+
 extern "C" int ecamd_multi_ecdsa_sign_msg_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *privs, const uint8_t *nonce_raw,
 						int hash_type, const uint8_t *msg_slots, uint32_t msg_stride, uint8_t *sigs, uint8_t *status)
 {

@@ -342,6 +342,28 @@ int ecamd_multi_eddsa_verify_msg_prj_batch(ecamd_multi *m, const ecamd_mcurve *c
 	return r;
 }
 
+int ecamd_multi_eddsa_verify_ph_prj_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
+					  const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, const uint8_t *msg_slots, uint32_t msg_stride,
+					  uint8_t *result)
+{
+	/* PH(M) = SHA-512 of every message into the second blank of a copy of the slots, then the plain form */
+	uint8_t *sl = malloc((size_t)n * stride + 1), *dg = malloc((size_t)n * 64 + 1);
+	uint32_t i, dl = 0;
+	int r;
+	mock_ready(n);
+	if (!sl || !dg || mock_hash_slots(4, n, msg_slots, msg_stride, dg, &dl) || dl != 64) {
+		free(sl); free(dg);
+		return mfail("mock: pre-hashing failed");
+	}
+	memcpy(sl, hash_slots, (size_t)n * stride);
+	for (i = 0; i < n; i++) {
+		memcpy(sl + (size_t)i * stride + 4 + a_offset + 32, dg + (size_t)i * 64, 64);
+	}
+	r = ecamd_multi_eddsa_verify_msg_prj_batch(m, c, n, keys_prj, sigs, sl, stride, a_offset, result);
+	free(sl); free(dg);
+	return r;
+}
+
 int ecamd_multi_eddsa_verify_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs,
 				   const uint8_t *hram, uint32_t hram_len, uint8_t *result)
 {

@@ -136,5 +136,31 @@ def test_eddsa_verify_from_projective_keys_and_messages(gpu_ctx):
         # several chunks of the host pipeline (short first chunk included)
         reps = 4200 // n + 1
         assert cv.eddsa_verify_msgs_prj(keys * reps, sigs * reps, inputs * reps, 32) == exp * reps
+        # the context and pre-hashed variants: dom2(phflag, ctx) in front of R; for Ed25519ph the device also computes PH(M) = SHA-512(M)
+        # into the second blank (ec_eddsa_verify_ph_prj_batch)
+        ctxb = b"the context of this batch"
+        for ph in (0, 1):
+            dom = b"SigEd25519 no Ed25519 collisions" + bytes([ph, len(ctxb)]) + ctxb
+            sg2, hr2, in2 = bytearray(), b"", []
+            for i in range(n):
+                Ri, Ai = Renc[32 * i:32 * i + 32], Aenc[32 * i:32 * i + 32]
+                body = hashlib.sha512(msgs[i]).digest() if ph else msgs[i]
+                hd = hashlib.sha512(dom + Ri + Ai + body).digest()
+                S = (r[i] + (int.from_bytes(hd, "little") % q) * a[i]) % q
+                sg2 += Ri + S.to_bytes(32, "little")
+                hr2 += hd
+                in2.append(dom + Ri + bytes(96 if ph else 32) + (b"" if ph else msgs[i]))
+            for i in range(0, n, 6):
+                sg2[64 * i + 33] ^= 8
+            sg2 = bytes(sg2)
+            exp2 = cv.eddsa_verify(Aenc, sg2, hr2)
+            assert 0 in exp2 and 1 in exp2
+            off = len(dom) + 32
+            if ph:
+                assert cv.eddsa_verify_ph_prj(keys, sg2, in2, off, msgs) == exp2
+                assert cv.eddsa_verify_ph_prj(keys * reps, sg2 * reps, in2 * reps, off, msgs * reps) == exp2 * reps
+                assert cv.eddsa_verify_ph_prj(keys, sg2, in2, off, [m + b"!" for m in msgs]) == bytes([1]) * n
+            else:
+                assert cv.eddsa_verify_msgs_prj(keys, sg2, in2, off) == exp2
     finally:
         cv.free()
