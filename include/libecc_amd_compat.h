@@ -79,14 +79,14 @@ int prj_pt_mul_blind_batch(prj_pt *out, const nn *m, const prj_pt *in, u32 n, in
  * computes, ret_items (may be NULL) what it would have returned.  All points of one call lie on ONE curve (in[0]'s / in1[0]'s);
  * results are the unique representative (Z = 1) or (0 : 1 : 0).  One difference from the scalar functions, which do not look at
  * their operands: a point that does not satisfy the curve equation is an error here (ret_items -1).
- *   prj_pt_add_batch       prj_pt_add (:48, curves/prj_pt.c:1204): out[i] = in1[i] + in2[i]; -1 also on the addition's exceptional pair
+ *   prj_pt_add_batch       prj_pt_add (curves/prj_pt.h:59, curves/prj_pt.c:1204): out[i] = in1[i] + in2[i]; -1 also on the addition's exceptional pair
  *                          (the difference of the two points has order two -- only on curves of even order; :1058-1060)
- *   prj_pt_dbl_batch       prj_pt_dbl (:50, :1132)
- *   prj_pt_unique_batch    prj_pt_unique (:44, :241): -1 for the point at infinity, as the scalar function
- *   prj_pt_is_on_curve_batch  prj_pt_is_on_curve (:42, :144): on_curve[i] = 1 / 0
- *   _prj_pt_unprotected_mult_batch  _prj_pt_unprotected_mult (:84, :1835-1905): the reference's double-and-add for PUBLIC scalars, bit
+ *   prj_pt_dbl_batch       prj_pt_dbl (prj_pt.h:60, prj_pt.c:1132)
+ *   prj_pt_unique_batch    prj_pt_unique (prj_pt.h:54, prj_pt.c:241): -1 for the point at infinity, as the scalar function
+ *   prj_pt_is_on_curve_batch  prj_pt_is_on_curve (prj_pt.h:51, prj_pt.c:144): on_curve[i] = 1 / 0
+ *   _prj_pt_unprotected_mult_batch  _prj_pt_unprotected_mult (prj_pt.h:64, prj_pt.c:1835-1905): the reference's double-and-add for PUBLIC scalars, bit
  *                          by bit on the device, so that its -1 on an exceptional pair of one of its additions is reproduced too
- *   check_prj_pt_order_batch  check_prj_pt_order (:86, :1909): check[i] = 1 when [in_isorder] in[i] is the point at infinity;
+ *   check_prj_pt_order_batch  check_prj_pt_order (prj_pt.h:65, prj_pt.c:1909): check[i] = 1 when [in_isorder] in[i] is the point at infinity;
  *                          PUBLIC_PT points through the double-and-add above, sensitive ones through prj_pt_mul_blind_batch
  */
 int prj_pt_add_batch(prj_pt *out, const prj_pt *in1, const prj_pt *in2, u32 n, int *ret_items);
