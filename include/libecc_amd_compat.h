@@ -43,6 +43,10 @@ int ecamd_compat_set_secret_scalars(int on);
  * What is drawn is what libecc draws: nn_get_random_mod's ONE get_random call of 2 * qlen bytes per ECDSA nonce / generic private
  * scalar; since round 4 only that call runs on the host -- the reduction modulo q - 1 of those bytes, like the SHA-2 of short messages,
  * runs on the device ($ECAMD_COMPAT_HOST_RANDMOD, $ECAMD_COMPAT_HOST_HASH: on the host through libecc's own functions, as before).
+ * What the batch forms do NOT reproduce is the reference's total consumption of the random stream: libecc's CPU scalar multiplication
+ * and modular exponentiation draw their side-channel masks from the same get_random (216 + 3 x 8 octets per fp_inv, 64 - 72 per
+ * prj_pt_mul on secp256r1), and ec_key_pair_gen draws its private scalar twice (sig/ec_key.c:602, then gen_priv_key), so a seeded
+ * get_random does not yield the key pairs or nonces a loop over the scalar API would -- only values of the same distribution.
  *
  * Environment of the layer (read at the first batch call; for measurements and fall-backs -- results are identical):
  *   ECAMD_DEVICES=0,1,..  ECAMD_COMPAT_THREADS=<n>  ECAMD_COMPAT_CHUNK=<items per pipeline chunk and device>  ECAMD_COMPAT_PUBLIC_SCALARS
