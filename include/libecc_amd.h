@@ -210,7 +210,9 @@ int ec_ecdsa_verify_msg_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *curve, uint
 				  const uint8_t *sigs, int hash_type, const uint8_t *msg_slots, uint32_t msg_stride, uint8_t *result);
 int ec_eddsa_verify_msg_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs,
 			      const uint8_t *hash_slots, uint32_t stride, uint8_t *result);
-/* The same from the PROJECTIVE key an ec_pub_key holds (n x 3*32 bytes X || Y || Z on WEI25519, the layout of ec_pub_key_export_to_buf's
+/* (The two entry points below also take the WEI448 handle: Ed448, 57-octet encodings, 114-octet signatures, SHAKE256 with 114 octets of
+ * output -- 64 for the pre-hash --, keys n x 3*56 bytes.)
+ * The same from the PROJECTIVE key an ec_pub_key holds (n x 3*32 bytes X || Y || Z on WEI25519, the layout of ec_pub_key_export_to_buf's
  * payload): the key is imported and normalised as prj_pt_import_from_buf / prj_pt_unique do, encoded as eddsa_export_pub_key does
  * (sig/eddsa.c:795), and the 32 octets are written into the item's hash input at message offset a_offset (bytes 4 + a_offset .. of its
  * slot, which the caller leaves blank and counts in the slot's length; the caller's array is not modified) before hashing -- what

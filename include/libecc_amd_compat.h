@@ -54,7 +54,7 @@ int ecamd_compat_set_secret_scalars(int on);
  *   ECAMD_COMPAT_NO_STREAM        verification: pack everything, then call the device (default: one call per batch that asks the pool
  *                                 for each range of the arrays through ecamd_multi_set_host_ready_hook while they are being packed)
  *   ECAMD_COMPAT_READY_ITEMS=<n>  granularity of that handshake (default 2^16)
- *   ECAMD_COMPAT_ED_TWO_PASS      EDDSA25519 / CTX / PH verification: encode the keys in a call of its own and hash on the host
+ *   ECAMD_COMPAT_ED_TWO_PASS      EdDSA verification (all five variants): encode the keys in a call of its own and hash on the host
  *   ECAMD_COMPAT_PRJ_KEYS         ECDSA verification: send keys as X || Y || Z even when every Z is 1
  *   ECAMD_COMPAT_TIMING           one line per pipeline run on stderr: where the calling thread's time went */
 void ecamd_compat_set_concurrent_random(int on);

@@ -3284,7 +3284,7 @@ static void eddsa_pack(u32 lo, u32 hi, void *arg)
  * not start before a GPU round trip -- is gone.  $ECAMD_COMPAT_ED_TWO_PASS keeps the two calls. */
 static void eddsa_pack_prj(u32 lo, u32 hi, void *arg)
 {
-	static const u8 blank[32] = {0};
+	static const u8 blank[57 + 64] = {0};   /* the blank for A (32 / 57 octets), or for A || PH(M) */
 	ver_job *J = (ver_job *)arg;
 	u32 j;
 	for (j = lo; j < hi; j++) {
@@ -3296,23 +3296,22 @@ static void eddsa_pack_prj(u32 lo, u32 hi, void *arg)
 			  J->s_len[i] != J->siglen || (!J->m[i] && J->m_len[i]);
 		bad = bad || prj_to_be(kdst, J->clen, &pk->y, &(J->params->ec_curve));
 		if (!bad && J->dom_len) {
-			/* EDDSA25519CTX / PH: dom2(phflag, context) in front of R (sig/eddsa.c:56-84); the group's contexts have one length
-			 * (eddsa_group); CTX wants a context, PH takes one or none */
+			/* EDDSA25519CTX / PH, EDDSA448 / PH: dom2 / dom4(phflag, context) in front of R (sig/eddsa.c:56-84); the group's contexts have
+			 * one length (eddsa_group); EDDSA25519CTX wants a context, the others take one or none */
 			const u8 *ad = J->adata ? J->adata[i] : NULL;
-			const u32 adl = J->dom_len - 34u;
-			u8 head[32 + 2 + 255 + 32];
-			bad = (u32)(J->adata_len ? J->adata_len[i] : 0) != adl || (J->ph ? (adl && !ad) : !ad);
+			const u32 pl = J->is448 ? 8u : 32u, adl = J->dom_len - pl - 2u;
+			u8 head[32 + 2 + 255 + 57];
+			bad = (u32)(J->adata_len ? J->adata_len[i] : 0) != adl || ((J->ph || J->is448) ? (adl && !ad) : !ad);
 			if (!bad) {
-				memcpy(head, "SigEd25519 no Ed25519 collisions", 32);
-				head[32] = (u8)(J->ph ? 1 : 0);
-				head[33] = (u8)adl;
+				memcpy(head, J->is448 ? "SigEd448" : "SigEd25519 no Ed25519 collisions", pl);
+				head[pl] = (u8)(J->ph ? 1 : 0);
+				head[pl + 1] = (u8)adl;
 				if (adl) {
-					memcpy(head + 34, ad, adl);
+					memcpy(head + pl + 2, ad, adl);
 				}
 				memcpy(head + J->dom_len, J->s[i], J->klen);
 				if (J->ph) {
-					static const u8 blank96[96] = {0};
-					slot_put(J->dg + (size_t)j * J->slot, J->slot, head, J->dom_len + J->klen, blank96, 96, NULL, 0);
+					slot_put(J->dg + (size_t)j * J->slot, J->slot, head, J->dom_len + J->klen, blank, J->klen + 64u, NULL, 0);
 					slot_put(J->ms + (size_t)j * J->mslot, J->mslot, NULL, 0, NULL, 0, J->m[i], J->m_len[i]);
 				} else {
 					slot_put(J->dg + (size_t)j * J->slot, J->slot, head, J->dom_len + J->klen, blank, J->klen, J->m[i], J->m_len[i]);
@@ -3428,8 +3427,8 @@ static void adl_scan(u32 lo, u32 hi, void *arg)
 		const u32 i = A->J->idx[j];
 		const u32 adl = A->J->adata_len ? A->J->adata_len[i] : 0;
 		const u8 *ad = A->J->adata ? A->J->adata[i] : NULL;
-		if (A->J->ph ? (adl != A->first || (adl && !ad)) : (ad && adl != A->first)) {
-			mixed = 1;   /* (pre-hashed variant: the context is optional, its length octet is hashed either way) */
+		if ((A->J->ph || A->J->is448) ? (adl != A->first || (adl && !ad)) : (ad && adl != A->first)) {
+			mixed = 1;   /* (pre-hashed variants and Ed448: the context is optional, its length octet is hashed either way) */
 		}
 	}
 	if (mixed) {
@@ -3440,7 +3439,7 @@ static void adl_scan(u32 lo, u32 hi, void *arg)
 static int eddsa_group(ver_job *J, u32 cnt, int *results)
 {
 	u32 j;
-	int one_pass = 0, ctx_uniform = 0;
+	int one_pass = 0, ctx_uniform = 0, ed_hash_on_device = 0;
 	J->clen = J->e->clen;
 	J->hlen = J->hm->digest_size;      /* 64 (SHA-512) / 114 (SHAKE256 as libecc configures it) */
 	J->klen = J->hlen / 2;             /* EDDSA_R_LEN: 32 / 57 */
@@ -3453,7 +3452,7 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
 	J->slot = 0;
 #if defined(WITH_SIG_EDDSA25519)
 	J->dom_len = 0;
-	if ((J->sig_type == EDDSA25519CTX || J->sig_type == EDDSA25519PH) && J->dom && cnt) {
+	if (J->dom && cnt) {   /* EDDSA25519CTX / PH, EDDSA448 / PH */
 		/* the contexts of a batch normally have one length: then dom2 || R || A sits at one offset in every hash input */
 		adl_job A;
 		A.J = J;
@@ -3463,9 +3462,11 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
 			parallel_for(cnt, adl_scan, &A);
 		}
 		ctx_uniform = !AT_LOAD(&A.mixed);
-		J->dom_len = ctx_uniform ? 34u + A.first : 0;
+		J->dom_len = ctx_uniform ? (J->is448 ? 10u : 34u) + A.first : 0;
 	}
-	if (((J->sig_type == EDDSA25519 && !J->dom && !J->ph) || ctx_uniform) && dev_hash_type(J->hm) == 4) {
+	/* the variant's own hash on the device: SHA-512 (k_sha2_slots) for Ed25519, SHAKE256 (k_shake256_slots) for Ed448 */
+	ed_hash_on_device = !getenv("ECAMD_COMPAT_HOST_HASH") && (J->is448 ? J->hm->type == SHAKE256 : J->hm->type == SHA512);
+	if (((!J->dom && !J->ph) || ctx_uniform) && ed_hash_on_device) {
 		/* (also when only the conjunction is wanted: since the half-length scalars of round 4 the item-by-item verification of 2^20
 		 * signatures takes the 12 ms the multi-scalar combination takes, needs no z_i, and does not wait for the host to hash) */
 		if (J->ph) {

@@ -209,6 +209,118 @@ hipError_t ecamd_launch_sha2_slots(int hash_type, const uint8_t *slots, uint32_t
 	return hipGetLastError();
 }
 
+// ---- SHAKE256 (FIPS 202) of the same slots, for the Ed448 forms of the message-taking verification (round 4): Keccak-f[1600] on 25
+//      64-bit lanes per thread, rate 136 octets, domain separation 0x1F, the first outlen <= 136 octets of the output (libecc's hash
+//      type SHAKE256 is that function with 114 octets; EDDSA448PH's pre-hash takes its first 64, sig/eddsa.c:1650-1657) ----
+__constant__ u64 c_keccak_rc[24] = {
+	0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull, 0x0000000080000001ull,
+	0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000aull,
+	0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull,
+	0x000000000000800aull, 0x800000008000000aull, 0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+
+static __device__ __forceinline__ u64 rol64(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
+
+static __device__ __forceinline__ void keccak_f1600(u64 *st)
+{
+	constexpr int rotc[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+	constexpr int piln[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+#pragma unroll 1
+	for (int round = 0; round < 24; round++) {
+		u64 c[5];
+#pragma unroll
+		for (int x = 0; x < 5; x++) {
+			c[x] = st[x] ^ st[x + 5] ^ st[x + 10] ^ st[x + 15] ^ st[x + 20];
+		}
+#pragma unroll
+		for (int x = 0; x < 5; x++) {
+			const u64 d = c[(x + 4) % 5] ^ rol64(c[(x + 1) % 5], 1);
+#pragma unroll
+			for (int y = 0; y < 25; y += 5) {
+				st[y + x] ^= d;
+			}
+		}
+		u64 cur = st[1];
+#pragma unroll
+		for (int t = 0; t < 24; t++) {
+			const u64 tmp = st[piln[t]];
+			st[piln[t]] = rol64(cur, rotc[t]);
+			cur = tmp;
+		}
+#pragma unroll
+		for (int y = 0; y < 25; y += 5) {
+			u64 row[5];
+#pragma unroll
+			for (int x = 0; x < 5; x++) {
+				row[x] = st[y + x];
+			}
+#pragma unroll
+			for (int x = 0; x < 5; x++) {
+				st[y + x] = row[x] ^ (~row[(x + 1) % 5] & row[(x + 2) % 5]);
+			}
+		}
+		st[0] ^= c_keccak_rc[round];
+	}
+}
+
+__global__ __launch_bounds__(64) void k_shake256_slots(const u8 *slots, u32 stride, u32 n, u8 *out, u32 out_stride, u32 outlen)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= n) {
+		return;
+	}
+	const u8 *slot = slots + (size_t)i * stride;
+	u32 len = *(const u32 *)slot;
+	if (len > stride - 4) {
+		len = stride - 4;   // (a malformed length cannot read outside the slot)
+	}
+	const u8 *msg = slot + 4;
+	constexpr u32 RATE = 136;
+	const u32 nblocks = len / RATE + 1, total = nblocks * RATE;
+	u64 st[25];
+#pragma unroll
+	for (int k = 0; k < 25; k++) {
+		st[k] = 0;
+	}
+#pragma unroll 1
+	for (u32 b = 0; b < nblocks; b++) {
+#pragma unroll
+		for (u32 w = 0; w < RATE / 8; w++) {
+			u64 v = 0;
+#pragma unroll
+			for (u32 k = 0; k < 8; k++) {
+				const u32 pos = b * RATE + 8 * w + k;
+				u32 byte = pos < len ? (u32)msg[pos] : (pos == len ? 0x1fu : 0u);
+				byte ^= (pos == total - 1) ? 0x80u : 0u;
+				v |= (u64)byte << (8 * k);
+			}
+			st[w] ^= v;
+		}
+		keccak_f1600(st);
+	}
+	u8 *dst = out + (size_t)i * out_stride;
+#pragma unroll
+	for (u32 w = 0; w < RATE / 8; w++) {
+#pragma unroll
+		for (u32 k = 0; k < 8; k++) {
+			if (8 * w + k < outlen) {
+				dst[8 * w + k] = (u8)(st[w] >> (8 * k));
+			}
+		}
+	}
+}
+
+hipError_t ecamd_launch_shake256_slots(const uint8_t *slots, uint32_t stride, uint32_t n, uint8_t *out, uint32_t out_stride, uint32_t outlen, hipStream_t s)
+{
+	if (n == 0) {
+		return hipSuccess;
+	}
+	if (stride < 4 || (stride & 3u) || outlen == 0 || outlen > 136 || out_stride < outlen) {
+		return hipErrorInvalidValue;
+	}
+	hipLaunchKernelGGL(k_shake256_slots, dim3((n + 63) / 64), dim3(64), 0, s, slots, stride, n, out, out_stride, outlen);
+	return hipGetLastError();
+}
+
 // ---- two byte movers of ec_eddsa_verify_msg_prj_batch: the key's encoding into its place in the hash input, and "an item whose key did not
 //      import is rejected" ----
 __global__ __launch_bounds__(256) void k_slot_patch(u8 *slots, u32 stride, u32 off, const u8 *src, u32 len, const u8 *skip, u32 n)

@@ -2384,7 +2384,11 @@ static int ecdsa_hash_stage(ecamd_ctx *ctx, int hash_type, uint32_t m, const uin
 	if (ensure(&ctx->stage[17], &ctx->stage_bytes[17], (size_t)m * dlen)) {
 		return -1;
 	}
-	HIPCHK(ecamd_launch_sha2_slots(hash_type, d_slots, stride, m, ctx->stage[17], dlen, s));
+	if (hash_type == 5) {
+		HIPCHK(ecamd_launch_shake256_slots(d_slots, stride, m, ctx->stage[17], dlen, dlen, s));   // SHAKE256, dlen octets of output
+	} else {
+		HIPCHK(ecamd_launch_sha2_slots(hash_type, d_slots, stride, m, ctx->stage[17], dlen, s));
+	}
 	return 0;
 }
 
@@ -3830,8 +3834,15 @@ static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd
 				     uint8_t *result)
 {
 	const std::string f(fn);
-	const uint32_t blank = msg_slots ? 96u : 32u;   // A, or A || PH(M)
-	if (!ctx || stride < 4 || (stride & 3u) || stride > 4096 || (uint64_t)a_offset + 4 + blank > stride) {
+	if (!ctx || !cv_in) {
+		return fail(f + ": bad argument");
+	}
+	// Ed25519 (WEI25519 handle): 32-octet keys, SHA-512; Ed448 (WEI448 handle): 57-octet keys, SHAKE256 with 114 octets (pre-hash: 64)
+	const bool e448 = cv_in->pbits == 448;
+	const uint32_t kl = e448 ? 57u : 32u, sl = 2 * kl, hl = sl;
+	const int hash_type = e448 ? 5 : 4;
+	const uint32_t blank = msg_slots ? kl + 64u : kl;   // A, or A || PH(M)
+	if (stride < 4 || (stride & 3u) || stride > 4096 || (uint64_t)a_offset + 4 + blank > stride) {
 		return fail(f + ": bad argument (stride: a multiple of 4 in 4 .. 4096; the blank for A [and PH(M)] must lie inside the slot)");
 	}
 	if (msg_slots && (msg_stride < 4 || (msg_stride & 3u) || msg_stride > 4096)) {
@@ -3839,19 +3850,16 @@ static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd
 	}
 	std::lock_guard<std::mutex> lk(ctx->mu);
 	EcamdEdSignArgs T;
-	if (eddsa_sign_setup(fn, ctx, cv_in, n, keys_prj, sigs, hash_slots, &T) || eddsa_args_ok(fn, ctx, cv_in, n, keys_prj, sigs, hash_slots, result, 64)) {
+	if (eddsa_sign_setup(fn, ctx, cv_in, n, keys_prj, sigs, hash_slots, &T) || eddsa_args_ok(fn, ctx, cv_in, n, keys_prj, sigs, hash_slots, result, hl)) {
 		return -1;
 	}
 	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
-	if (cv->pbits != 255) {
-		return fail(f + ": Ed25519 (the WEI25519 handle) only: Ed448 hashes with SHAKE256");
-	}
 	if (n == 0) {
 		return 0;
 	}
 	HIPCHK(hipSetDevice(ctx->device));
 	const size_t cl = (size_t)cv->clen;
-	std::vector<HostArr> arrs = {{keys_prj, nullptr, 3 * cl}, {sigs, nullptr, 64u}, {hash_slots, nullptr, stride}, {nullptr, result, 1}};
+	std::vector<HostArr> arrs = {{keys_prj, nullptr, 3 * cl}, {sigs, nullptr, sl}, {hash_slots, nullptr, stride}, {nullptr, result, 1}};
 	if (msg_slots) {
 		arrs.push_back({msg_slots, nullptr, msg_stride});
 	}
@@ -3859,16 +3867,17 @@ static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd
 					       hipStream_t s, const std::function<int()> &) {
 		// stage: 20 affine keys, 21 import status, 22 encodings, 23 their status (the verification core owns 3 .. 19)
 		if (ensure(&ctx->stage[20], &ctx->stage_bytes[20], (size_t)m * 2 * cl) || ensure(&ctx->stage[21], &ctx->stage_bytes[21], m) ||
-		    ensure(&ctx->stage[22], &ctx->stage_bytes[22], (size_t)m * 32) || ensure(&ctx->stage[23], &ctx->stage_bytes[23], m)) {
+		    ensure(&ctx->stage[22], &ctx->stage_bytes[22], (size_t)m * kl) || ensure(&ctx->stage[23], &ctx->stage_bytes[23], m)) {
 			return -1;
 		}
 		uint8_t *slots = const_cast<uint8_t *>(ip[2]);   // the staged copy of the caller's slots
 		if (msg_slots) {
-			// PH(M) = SHA-512(M) of every message, written behind the blank for A (EDDSA25519PH: sig/eddsa.c:1049-1080)
-			if (ecdsa_hash_stage(ctx, 4, m, ip[4], msg_stride, 64, s)) {
+			// PH(M): SHA-512(M), or the first 64 octets of SHAKE256(M), of every message, written behind the blank for A
+			// (eddsa_compute_pre_hash, sig/eddsa.c:1049-1080, :1650-1657)
+			if (ecdsa_hash_stage(ctx, hash_type, m, ip[4], msg_stride, 64, s)) {
 				return -1;
 			}
-			HIPCHK(ecamd_launch_slot_patch(slots, stride, a_offset + 32, ctx->stage[17], 64, nullptr, m, s));
+			HIPCHK(ecamd_launch_slot_patch(slots, stride, a_offset + kl, ctx->stage[17], 64, nullptr, m, s));
 		}
 		EcamdPrjInArgs I;
 		I.in = ip[0];
@@ -3886,9 +3895,10 @@ static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd
 		A.out = ctx->stage[22];
 		A.status = ctx->stage[23];
 		HIPCHK(ecamd_launch_ed_sign_enc(A, s));
-		HIPCHK(ecamd_launch_slot_patch(slots, stride, a_offset, ctx->stage[22], 32, ctx->stage[23], m, s));
-		if (ecdsa_hash_stage(ctx, 4, m, slots, stride, 64, s) ||
-		    eddsa_verify_dev_locked(ctx, cv, m, ctx->stage[22], ip[1], ctx->stage[17], 64, op[3], s)) {
+		HIPCHK(ecamd_launch_slot_patch(slots, stride, a_offset, ctx->stage[22], kl, ctx->stage[23], m, s));
+		if (ecdsa_hash_stage(ctx, hash_type, m, slots, stride, hl, s) ||
+		    (e448 ? eddsa448_verify_dev_locked(ctx, cv, m, ctx->stage[22], ip[1], ctx->stage[17], op[3], s)
+			  : eddsa_verify_dev_locked(ctx, cv, m, ctx->stage[22], ip[1], ctx->stage[17], 64, op[3], s))) {
 			return -1;
 		}
 		HIPCHK(ecamd_launch_reject_where(op[3], ctx->stage[23], m, s));

@@ -437,6 +437,8 @@ int ecamd_sha2_digest_len(int hash_type);
 hipError_t ecamd_launch_slot_patch(uint8_t *slots, uint32_t stride, uint32_t off, const uint8_t *src, uint32_t len, const uint8_t *skip, uint32_t n,
 				   hipStream_t s);
 hipError_t ecamd_launch_reject_where(uint8_t *result, const uint8_t *status, uint32_t n, hipStream_t s);
+// SHAKE256 of the same slots: the first outlen (<= 136) octets of the output per message
+hipError_t ecamd_launch_shake256_slots(const uint8_t *slots, uint32_t stride, uint32_t n, uint8_t *out, uint32_t out_stride, uint32_t outlen, hipStream_t s);
 hipError_t ecamd_launch_sha2_slots(int hash_type, const uint8_t *slots, uint32_t stride, uint32_t n, uint8_t *out, uint32_t out_stride, hipStream_t s);
 struct EcamdPrjInArgs;
 // prj_pt_import_from_buf + prj_pt_unique on a radix-2^29 unit, one inversion per eight triples (k_prj_import_g)

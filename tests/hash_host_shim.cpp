@@ -7,3 +7,7 @@ extern "C" int sha2_slots_host(int hash_type, const uint8_t *slots, uint32_t str
 {
 	return (int)ecamd_launch_sha2_slots(hash_type, slots, stride, n, out, out_stride, nullptr);
 }
+extern "C" int shake256_slots_host(const uint8_t *slots, uint32_t stride, uint32_t n, uint8_t *out, uint32_t out_stride, uint32_t outlen)
+{
+	return (int)ecamd_launch_shake256_slots(slots, stride, n, out, out_stride, outlen, nullptr);
+}

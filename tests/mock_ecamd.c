@@ -218,22 +218,27 @@ int ecamd_multi_ecdsa_verify_batch_fmt(ecamd_multi *m, const ecamd_mcurve *c, ui
 
 /* the message-taking forms: the stand-in hashes the slots with libecc's own hash functions (what the device computes with
  * ecamd_hash.hip, tested against hashlib in tests/test_hash_host.py) and goes on with the digest-taking forms */
+/* hash_type 1 .. 4: SHA-224 .. SHA-512; 5: SHAKE256 as libecc configures it (114 octets); *dl on entry: octets to keep per digest
+ * (0: all of them) -- the pre-hash of Ed448ph keeps 64 */
 static int mock_hash_slots(int hash_type, uint32_t n, const uint8_t *slots, uint32_t stride, uint8_t *dg, uint32_t *dl)
 {
-	static const hash_alg_type types[5] = {UNKNOWN_HASH_ALG, SHA224, SHA256, SHA384, SHA512};
+	static const hash_alg_type types[6] = {UNKNOWN_HASH_ALG, SHA224, SHA256, SHA384, SHA512, SHAKE256};
 	const hash_mapping *hm;
+	const uint32_t keep = *dl;
 	uint32_t i;
-	if (hash_type < 1 || hash_type > 4 || get_hash_by_type(types[hash_type], &hm) || !hm) {
+	if (hash_type < 1 || hash_type > 5 || get_hash_by_type(types[hash_type], &hm) || !hm || keep > hm->digest_size) {
 		return -1;
 	}
-	*dl = hm->digest_size;
+	*dl = keep ? keep : hm->digest_size;
 	for (i = 0; i < n; i++) {
 		const uint8_t *sl = slots + (size_t)i * stride;
 		const uint32_t len = (uint32_t)sl[0] | ((uint32_t)sl[1] << 8) | ((uint32_t)sl[2] << 16) | ((uint32_t)sl[3] << 24);
+		uint8_t full[MAX_DIGEST_SIZE];
 		hash_context hc;
-		if (len > stride - 4 || hm->hfunc_init(&hc) || hm->hfunc_update(&hc, sl + 4, len) || hm->hfunc_finalize(&hc, dg + (size_t)i * *dl)) {
+		if (len > stride - 4 || hm->hfunc_init(&hc) || hm->hfunc_update(&hc, sl + 4, len) || hm->hfunc_finalize(&hc, full)) {
 			return -1;
 		}
+		memcpy(dg + (size_t)i * *dl, full, *dl);
 	}
 	return 0;
 }
@@ -282,6 +287,7 @@ int ecamd_multi_ecdsa_sign_msg_batch(ecamd_multi *m, const ecamd_mcurve *c, uint
 	uint32_t dl = msg_stride;
 	int r = (!k || !dg) ? mfail("mock: out of memory") : orc_random_mod_batch(&c->c, n, nonce_raw, k);
 	if (!r && hash_type) {
+		dl = 0;
 		r = mock_hash_slots(hash_type, n, msg_slots, msg_stride, dg, &dl) ? mfail("mock: hashing failed") : 0;
 	}
 	r = r || ecamd_multi_ecdsa_sign_batch(m, c, n, privs, k, hash_type ? dg : msg_slots, dl, sigs, status);
@@ -317,28 +323,31 @@ int ecamd_multi_eddsa_verify_msg_prj_batch(ecamd_multi *m, const ecamd_mcurve *c
 					   const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, uint8_t *result)
 {
 	/* encode, write the encodings into a copy of the slots, hash, verify; an item whose key has no encoding is rejected */
-	uint8_t *enc = malloc((size_t)n * 32 + 1), *st = malloc(n + 1), *sl = malloc((size_t)n * stride + 1);
-	uint32_t i;
+	const int e448 = c->c.clen == 56;
+	const uint32_t kl = e448 ? 57 : 32;
+	uint8_t *enc = malloc((size_t)n * kl + 1), *st = malloc(n + 1), *sl = malloc((size_t)n * stride + 1), *dg = malloc((size_t)n * 114 + 1);
+	uint32_t i, dl = 0;
 	int r;
 	mock_ready(n);
-	if (!enc || !st || !sl) {
-		free(enc); free(st); free(sl);
+	if (!enc || !st || !sl || !dg) {
+		free(enc); free(st); free(sl); free(dg);
 		return mfail("mock: out of memory");
 	}
 	memcpy(sl, hash_slots, (size_t)n * stride);
 	r = ecamd_multi_eddsa_encode_point_batch(m, c, n, keys_prj, enc, st);
 	for (i = 0; i < n && !r; i++) {
 		if (!st[i]) {
-			memcpy(sl + (size_t)i * stride + 4 + a_offset, enc + (size_t)i * 32, 32);
+			memcpy(sl + (size_t)i * stride + 4 + a_offset, enc + (size_t)i * kl, kl);
 		}
 	}
-	r = r || ecamd_multi_eddsa_verify_msg_batch(m, c, n, enc, sigs, sl, stride, result);
+	r = r || (mock_hash_slots(e448 ? 5 : 4, n, sl, stride, dg, &dl) ? mfail("mock: hashing failed") : 0);
+	r = r || ecamd_multi_eddsa_verify_batch(m, c, n, enc, sigs, dg, dl, result);
 	for (i = 0; i < n && !r; i++) {
 		if (st[i]) {
 			result[i] = 1;
 		}
 	}
-	free(enc); free(st); free(sl);
+	free(enc); free(st); free(sl); free(dg);
 	return r;
 }
 
@@ -347,17 +356,18 @@ int ecamd_multi_eddsa_verify_ph_prj_batch(ecamd_multi *m, const ecamd_mcurve *c,
 					  uint8_t *result)
 {
 	/* PH(M) = SHA-512 of every message into the second blank of a copy of the slots, then the plain form */
+	const int e448 = c->c.clen == 56;
 	uint8_t *sl = malloc((size_t)n * stride + 1), *dg = malloc((size_t)n * 64 + 1);
-	uint32_t i, dl = 0;
+	uint32_t i, dl = 64;
 	int r;
 	mock_ready(n);
-	if (!sl || !dg || mock_hash_slots(4, n, msg_slots, msg_stride, dg, &dl) || dl != 64) {
+	if (!sl || !dg || mock_hash_slots(e448 ? 5 : 4, n, msg_slots, msg_stride, dg, &dl) || dl != 64) {
 		free(sl); free(dg);
 		return mfail("mock: pre-hashing failed");
 	}
 	memcpy(sl, hash_slots, (size_t)n * stride);
 	for (i = 0; i < n; i++) {
-		memcpy(sl + (size_t)i * stride + 4 + a_offset + 32, dg + (size_t)i * 64, 64);
+		memcpy(sl + (size_t)i * stride + 4 + a_offset + (e448 ? 57 : 32), dg + (size_t)i * 64, 64);
 	}
 	r = ecamd_multi_eddsa_verify_msg_prj_batch(m, c, n, keys_prj, sigs, sl, stride, a_offset, result);
 	free(sl); free(dg);

@@ -46,3 +46,16 @@ def test_sha2_slots_match_hashlib(lib, hash_type):
         assert lib.sha2_slots_host(hash_type, slots_of(ms, st), st, len(ms), out, dl) == 0
         for i, m in enumerate(ms):
             assert out.raw[dl * i:dl * (i + 1)] == ALGS[hash_type](m).digest(), (hash_type, len(m))
+
+
+def test_shake256_slots_match_hashlib(lib):
+    """SHAKE256 (the Ed448 hash: 114 octets; the Ed448ph pre-hash: 64) of every length around the 136-octet rate boundaries"""
+    rng = np.random.default_rng(85)
+    stride = 300
+    msgs = [bytes(rng.integers(0, 256, size=n, dtype=np.uint8)) for n in range(0, stride - 3)]
+    msgs += [b"", b"abc", b"\x1f" * 135, b"\x80" * 136, b"\xff" * 137, b"a" * 271, b"a" * 272, b"a" * 273]
+    for outlen in (114, 64, 136, 1):
+        out = C.create_string_buffer(outlen * len(msgs))
+        assert lib.shake256_slots_host(slots_of(msgs, stride), stride, len(msgs), out, outlen, outlen) == 0
+        for i, m in enumerate(msgs):
+            assert out.raw[outlen * i:outlen * (i + 1)] == hashlib.shake_256(m).digest(outlen), (outlen, len(m))
