@@ -1125,10 +1125,10 @@ int main(int argc, char **argv)
 		check_cdh("SECP256R1", qn);
 		check_verify("SECP256R1", ECDSA, SHA256, "ECDSA/SECP256R1/SHA256", qn, 1);
 		check_verify("WEI25519", EDDSA25519, SHA512, "EDDSA25519", qn, 1);
-		check_verify("WEI25519", EDDSA25519CTX, SHA512, "EDDSA25519CTX", qn < 256 ? qn : 256, 1);
-		check_verify("WEI25519", EDDSA25519PH, SHA512, "EDDSA25519PH", qn < 256 ? qn : 256, 1);
-		check_verify("WEI448", EDDSA448, SHAKE256, "EDDSA448", qn < 96 ? qn : 96, 1);
-		check_verify("WEI448", EDDSA448PH, SHAKE256, "EDDSA448PH", qn < 96 ? qn : 96, 1);
+		check_verify("WEI25519", EDDSA25519CTX, SHA512, "EDDSA25519CTX", qn < 128 ? qn : 128, 1);
+		check_verify("WEI25519", EDDSA25519PH, SHA512, "EDDSA25519PH", qn < 128 ? qn : 128, 1);
+		check_verify("WEI448", EDDSA448, SHAKE256, "EDDSA448", qn < 48 ? qn : 48, 1);
+		check_verify("WEI448", EDDSA448PH, SHAKE256, "EDDSA448PH", qn < 48 ? qn : 48, 1);
 		check_sign("SECP256R1", ECDSA, SHA256, "ECDSA/SECP256R1/SHA256", qn, 2);
 		check_sign("WEI25519", EDDSA25519, SHA512, "EDDSA25519", qn, 1);
 		check_keys("SECP256R1", ECDSA, "ECDSA/SECP256R1", qn);
