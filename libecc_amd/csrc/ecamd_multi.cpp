@@ -255,6 +255,14 @@ static int run_sharded(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const 
 
 #define OFF(p, stride) ((p) ? (p) + (size_t)lo * (stride) : nullptr)
 
+// octets of an EdDSA point encoding on the curve behind `c` (sig/eddsa.c:93-120, EDDSA_R_LEN): 32 on WEI25519, 57 on WEI448 (coordinate
+// length 56 plus the sign octet); a signature is two of them.  Every EdDSA array below is sharded by these, never by a literal.
+static inline size_t eddsa_enc_len(const ecamd_mcurve *c)
+{
+	const size_t cl = (size_t)ecamd_multi_curve_coord_len(c);
+	return (cl == 56) ? 57 : cl;
+}
+
 extern "C" int ecamd_multi_prj_pt_mul_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *scalars,
 					    uint32_t scalar_len, const uint8_t *points_aff, uint8_t *out_aff, uint8_t *status)
 {
@@ -309,8 +317,10 @@ extern "C" int ecamd_multi_ecdsa_verify_msg_batch_fmt(ecamd_multi *m, const ecam
 extern "C" int ecamd_multi_eddsa_verify_msg_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs,
 						  const uint8_t *hash_slots, uint32_t stride, uint8_t *result)
 {
+	// Ed25519: 32-byte keys, 64-byte signatures; Ed448: 57 / 114 (coordinate length 56)
+	const size_t kl = eddsa_enc_len(c);
 	return run_sharded(m, c, n, "ecamd_multi_eddsa_verify_msg_batch", [&](int r, uint32_t lo, uint32_t hi) {
-		return ec_eddsa_verify_msg_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(pubkeys, 32), OFF(sigs, 64), OFF(hash_slots, (size_t)stride),
+		return ec_eddsa_verify_msg_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(pubkeys, kl), OFF(sigs, 2 * kl), OFF(hash_slots, (size_t)stride),
 						 stride, OFF(result, 1));
 	});
 }
@@ -318,9 +328,9 @@ extern "C" int ecamd_multi_eddsa_verify_msg_batch(ecamd_multi *m, const ecamd_mc
 extern "C" int ecamd_multi_eddsa_verify_msg_prj_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
 						      const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, uint8_t *result)
 {
-	const size_t kl = 3 * (size_t)ecamd_multi_curve_coord_len(c);
+	const size_t kl = 3 * (size_t)ecamd_multi_curve_coord_len(c), sl = 2 * eddsa_enc_len(c);  // signatures: 64 octets (Ed25519), 114 (Ed448)
 	return run_sharded(m, c, n, "ecamd_multi_eddsa_verify_msg_prj_batch", [&](int r, uint32_t lo, uint32_t hi) {
-		return ec_eddsa_verify_msg_prj_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(keys_prj, kl), OFF(sigs, 64), OFF(hash_slots, (size_t)stride),
+		return ec_eddsa_verify_msg_prj_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(keys_prj, kl), OFF(sigs, sl), OFF(hash_slots, (size_t)stride),
 						     stride, a_offset, OFF(result, 1));
 	});
 }
@@ -340,9 +350,9 @@ extern "C" int ecamd_multi_eddsa_verify_ph_prj_batch(ecamd_multi *m, const ecamd
 						     const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, const uint8_t *msg_slots,
 						     uint32_t msg_stride, uint8_t *result)
 {
-	const size_t kl = 3 * (size_t)ecamd_multi_curve_coord_len(c);
+	const size_t kl = 3 * (size_t)ecamd_multi_curve_coord_len(c), sl = 2 * eddsa_enc_len(c);
 	return run_sharded(m, c, n, "ecamd_multi_eddsa_verify_ph_prj_batch", [&](int r, uint32_t lo, uint32_t hi) {
-		return ec_eddsa_verify_ph_prj_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(keys_prj, kl), OFF(sigs, 64), OFF(hash_slots, (size_t)stride),
+		return ec_eddsa_verify_ph_prj_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(keys_prj, kl), OFF(sigs, sl), OFF(hash_slots, (size_t)stride),
 						    stride, a_offset, OFF(msg_slots, (size_t)msg_stride), msg_stride, OFF(result, 1));
 	});
 }
@@ -390,7 +400,7 @@ extern "C" int ecamd_multi_eddsa_verify_batch(ecamd_multi *m, const ecamd_mcurve
 					      const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, uint8_t *result)
 {
 	// Ed25519: 32-byte keys, 64-byte signatures; Ed448: 57 / 114 (coordinate length 56)
-	const size_t cl = (size_t)ecamd_multi_curve_coord_len(c), kl = (cl == 56) ? 57 : cl;
+	const size_t kl = eddsa_enc_len(c);
 	return run_sharded(m, c, n, "ecamd_multi_eddsa_verify_batch", [&](int r, uint32_t lo, uint32_t hi) {
 		return ec_eddsa_verify_batch(m->ctx[(size_t)r], c->cv[(size_t)r], hi - lo, OFF(pubkeys, kl), OFF(sigs, 2 * kl), OFF(hram, hram_len),
 					     hram_len, OFF(result, 1));

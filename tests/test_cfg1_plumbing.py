@@ -28,5 +28,7 @@ def test_cfg1_plumbing_gpu():
     if not os.path.exists(exe):
         pytest.skip("libecc_amd/lib/compat_check not built (needs the reference tree at build time)")
     r = subprocess.run([exe, "cfg1"], capture_output=True, text=True, timeout=600)
+    if r.returncode == 3 and "no GPU path" in r.stdout:
+        pytest.skip("no HIP device on this box (a plain `pytest` run on the authoring container)")
     assert r.returncode == 0 and "cfg1: all ok" in r.stdout, r.stdout[-2000:]
     assert "1024 items" in r.stdout

@@ -1176,46 +1176,50 @@ def test_eddsa25519_sign_steps(gpu_ctx):
 LIBDIR = os.path.join(os.path.dirname(GOLDEN), "..", "libecc_amd", "lib")
 
 
-def test_libecc_typed_boundary_vs_scalar_api():
+COMPAT_RUNS = {
+    # every row, 640 items per case with the edge families
+    "full_640": (["640"], {}),
+    # the Ed25519 multi-scalar multiplication forced for every batch size: ec_verify_batch's EdDSA branch then decides valid batches by
+    # the combination and falls back to the item-by-item pass for the others
+    "msm_forced": (["200"], {"ECAMD_MSM_MIN": "1"}),
+    # three ranks on device 0 with tiny chunks: the verification calls are streamed (the pool packs while the C ABI asks for each
+    # range through the producer hook, which the multi-device layer offsets per shard), several chunks per shard, short first chunk
+    "three_ranks_streamed": (["quick", "600"], {"ECAMD_DEVICES": "0,0,0", "ECAMD_COMPAT_READY_ITEMS": "512", "ECAMD_HOST_CHUNK": "96",
+                                                "ECAMD_HOST_RAMP_MIN": "16"}),
+    # eight ranks on device 0, uneven shards (the driver's 8-GPU shape without the hardware)
+    "eight_ranks": (["quick", "203"], {"ECAMD_DEVICES": "0,0,0,0,0,0,0,0"}),
+    # the paths round 4 left as fall-backs: host hashing, chunked calls, two-pass EdDSA, nn_get_random_mod on the host, the scanned
+    # window loop for secret fixed-base multiplications, the saturated-word projective import
+    "fallback_paths": (["quick", "150"], {"ECAMD_COMPAT_HOST_HASH": "1", "ECAMD_COMPAT_NO_STREAM": "1", "ECAMD_COMPAT_ED_TWO_PASS": "1",
+                                          "ECAMD_COMPAT_HOST_RANDMOD": "1", "ECAMD_NO_SECRET_COMB": "1", "ECAMD_NO_PRJ_IMPORT_G29": "1",
+                                          "ECAMD_COMPAT_PRJ_KEYS": "1"}),
+}
+
+
+@pytest.mark.parametrize("run", sorted(COMPAT_RUNS))
+def test_libecc_typed_boundary_vs_scalar_api(run):
     """include/libecc_amd_compat.h through libsign_amd.so, driven by a libecc application (libecc_amd/compat/compat_check.c):
     prj_pt_mul_batch(prj_pt[], nn[], prj_pt[]), ecccdh_derive_secret_batch and ec_verify_batch -- called with const u8 **,
     const ec_pub_key ** arrays exactly as tests/ec_self_tests_core.c:373-383, 556-616 call it -- for ECDSA, DECDSA, the
     five EdDSA variants, BIP0340 and ECFSDSA; ec_sign_batch (same nonce hook as _ec_sign, RFC 6979, EdDSA: signature bytes equal),
     ec_key_pair_gen_batch / import / init_pubkey_from_privkey_batch for seven algorithms' key rules, x25519_batch / x448_batch --
     every result compared with libecc's own scalar function (the CPU code of the libecc the library was linked from) on
-    the same structures, 640 items per case with the edge families"""
+    the same structures.  One pytest case per compat_check run (COMPAT_RUNS), so that one bad row hides nothing else."""
     import subprocess
     exe = os.path.join(LIBDIR, "compat_check")
     if not os.path.exists(exe):
         pytest.skip("libecc_amd/lib/compat_check not built (needs the libecc sources at build time)")
-    r = subprocess.run([exe, "640"], capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
-    assert "compat_check: all ok" in r.stdout
-    assert r.stdout.count(": ok") >= 48 and "FAILED" not in r.stdout and "MISMATCH" not in r.stdout
-    for row in ("ec_sign_batch ECDSA", "ec_sign_batch DECDSA", "ec_sign_batch EDDSA25519", "ec_sign_batch EDDSA448", "ec_key_pair_{gen,import}_batch",
-                "x25519_batch", "x448_batch", "ec_verify_batch BIP0340", "ec_verify_batch ECFSDSA", "foreign generator"):
-        assert row in r.stdout, row
-    sent = int(r.stdout.split("items sent to the GPU:")[1].split()[0])
-    assert sent >= 640 * 20, sent          # the batch forms did run on the GPU (there is no CPU fallback to hide behind)
-    # the same program with the Ed25519 multi-scalar multiplication forced for every batch size: ec_verify_batch's EdDSA
-    # branch then decides valid batches by the combination and falls back to the item-by-item pass for the others
-    env = dict(os.environ, ECAMD_MSM_MIN="1")
-    r = subprocess.run([exe, "200"], capture_output=True, text=True, timeout=1500, env=env)
+    args, extra = COMPAT_RUNS[run]
+    r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=1500, env=dict(os.environ, **extra))
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     assert "compat_check: all ok" in r.stdout and "FAILED" not in r.stdout and "MISMATCH" not in r.stdout
-    # three ranks on device 0 with tiny chunks: the verification calls are streamed (the pool packs while the C ABI asks for each
-    # range through the producer hook, which the multi-device layer offsets per shard), several chunks per shard, short first chunk
-    env = dict(os.environ, ECAMD_DEVICES="0,0,0", ECAMD_COMPAT_READY_ITEMS="512", ECAMD_HOST_CHUNK="96", ECAMD_HOST_RAMP_MIN="16")
-    r = subprocess.run([exe, "quick", "600"], capture_output=True, text=True, timeout=1500, env=env)
-    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
-    assert "compat_check: all ok" in r.stdout and "FAILED" not in r.stdout and "MISMATCH" not in r.stdout
-    # the paths round 4 left as fall-backs: host hashing, chunked calls, two-pass EdDSA, nn_get_random_mod on the host, the scanned
-    # window loop for secret fixed-base multiplications, the saturated-word projective import
-    env = dict(os.environ, ECAMD_COMPAT_HOST_HASH="1", ECAMD_COMPAT_NO_STREAM="1", ECAMD_COMPAT_ED_TWO_PASS="1", ECAMD_COMPAT_HOST_RANDMOD="1",
-               ECAMD_NO_SECRET_COMB="1", ECAMD_NO_PRJ_IMPORT_G29="1", ECAMD_COMPAT_PRJ_KEYS="1")
-    r = subprocess.run([exe, "quick", "150"], capture_output=True, text=True, timeout=1500, env=env)
-    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
-    assert "compat_check: all ok" in r.stdout and "FAILED" not in r.stdout and "MISMATCH" not in r.stdout
+    if run == "full_640":
+        assert r.stdout.count(": ok") >= 48
+        for row in ("ec_sign_batch ECDSA", "ec_sign_batch DECDSA", "ec_sign_batch EDDSA25519", "ec_sign_batch EDDSA448", "ec_key_pair_{gen,import}_batch",
+                    "x25519_batch", "x448_batch", "ec_verify_batch BIP0340", "ec_verify_batch ECFSDSA", "foreign generator"):
+            assert row in r.stdout, row
+        sent = int(r.stdout.split("items sent to the GPU:")[1].split()[0])
+        assert sent >= 640 * 20, sent          # the batch forms did run on the GPU (there is no CPU fallback to hide behind)
 
 
 def test_libecc_self_tests_against_libsign_amd():
