@@ -386,3 +386,131 @@ def test_secret_scalar_mode_gives_identical_results():
     finally:
         ctx_s.close()
         ctx_d.close()
+
+
+def _both(L, name, ctx, cv, m, mc, args, op=None):
+    """call ec_<name> on one context and ecamd_multi_<name> on the multi-context with the same inputs; args: bytes = input array,
+    ("out", size) = output array, anything else = a ctypes scalar.  Returns the two lists of output bytes."""
+    import ctypes as C
+    outs = []
+    for h1, h2, fn in ((ctx.h, cv.h, getattr(L, "ec_" + name)), (m.h, mc.h, getattr(L, "ecamd_multi_" + name))):
+        call, bufs = [h1, h2] + ([C.c_int(op)] if op is not None else []), []
+        for a in args:
+            if isinstance(a, tuple):
+                b = C.create_string_buffer(bytes([0xA5]) * max(1, a[1]), max(1, a[1]))
+                bufs.append((b, a[1]))
+                call.append(b)
+            else:
+                call.append(a)
+        rc = fn(*call)
+        assert rc == 0, (name, L.ecamd_last_error())
+        outs.append([b.raw[:k] for b, k in bufs])
+    return outs
+
+
+@pytest.mark.parametrize("curve", ["SECP256R1", "SECP521R1", "WEI25519", "WEI448"])
+def test_every_multi_entry_point_with_eight_ranks(gpu_ctx, curve):
+    """The driver's 8-GPU shape without the hardware: EVERY batch entry point of ecamd_multi.cpp with eight ranks on device 0 (uneven
+    shards; and fewer items than ranks) gives the bytes of the one-context call -- one curve per length class (32 / 66 octets, and
+    the 57 / 114-octet EdDSA encodings of Ed448 whose signature offsets round 4 got wrong).  Inputs are made valid with the library
+    itself (key pairs, signatures), so that accepted items exist and a shard reading at a wrong offset shows as a rejection."""
+    import ctypes as C
+    import hashlib
+    rng = np.random.default_rng(86)
+    L = libecc_amd.load_library()
+    m = libecc_amd.Multi([0] * 8)
+    cv, mc = gpu_ctx.curve(curve), m.curve(curve)
+    cl, ql = cv.clen, cv.qlen
+    q = CURVES[curve]["q"]
+    u32, ci = C.c_uint32, C.c_int
+    try:
+        for n in (203, 5):
+            def same(name, args, op=None, expect_ok=None):
+                a, b = _both(L, name, gpu_ctx, cv, m, mc, [u32(n)] + args if op is None else [u32(n)] + args, op)
+                assert a == b, (name, n)
+                if expect_ok is not None:       # the status / result array: accepted items exist (a wrong offset would reject them)
+                    assert a[expect_ok].count(0) >= (3 * n) // 4, (name, n, a[expect_ok])
+                return a
+            sc = b"".join(((int.from_bytes(rand_bytes(rng, ql + 8), "big") % (q - 1)) + 1).to_bytes(ql, "big") for _ in range(n))
+            pts = same("prj_pt_mul_batch", [sc, u32(ql), None, ("out", 2 * cl * n), ("out", n)], expect_ok=1)[0]
+            sc2 = rand_bytes(rng, (ql + 5) * n)
+            same("prj_pt_mul_batch", [sc2, u32(ql + 5), pts, ("out", 2 * cl * n), ("out", n)], expect_ok=1)
+            prj = same("prj_pt_mul_batch_fmt", [sc2, u32(ql), pts, ci(0), ("out", 3 * cl * n), ci(1), ("out", n)], expect_ok=1)[0]
+            same("prj_pt_mul_batch_fmt", [sc, u32(ql), prj, ci(1), ("out", 2 * cl * n), ci(0), ("out", n)], expect_ok=1)
+            same("prj_pt_unique_batch", [prj, ci(1), ("out", 2 * cl * n), ci(0), ("out", n)], expect_ok=1)
+            same("prj_pt_unique_batch", [pts, ci(0), ("out", 3 * cl * n), ci(1), ("out", n)], expect_ok=1)
+            same("prj_pt_add_batch", [pts, pts[2 * cl:] + pts[:2 * cl], ("out", 2 * cl * n), ("out", n)], expect_ok=1)
+            same("prj_pt_op_batch_fmt", [prj, prj[3 * cl:] + prj[:3 * cl], ci(1), ("out", 3 * cl * n), ci(1), ("out", n)], op=0, expect_ok=1)
+            same("prj_pt_op_batch_fmt", [pts, None, ci(0), ("out", 2 * cl * n), ci(0), ("out", n)], op=1, expect_ok=1)
+            same("prj_pt_unprotected_mult_batch", [sc2, u32(ql), u32(ql + 5), prj, ci(1), ("out", 2 * cl * n), ci(0), ("out", n)], expect_ok=1)
+            raw = rand_bytes(rng, 2 * ql * n)
+            privs, pubs, _ = same("key_pair_gen_raw_batch", [raw, ("out", ql * n), ("out", 2 * cl * n), ("out", n)], expect_ok=2)
+            same("ecccdh_derive_batch", [privs, pts, ("out", cl * n), ("out", n)], expect_ok=1)
+            if curve.startswith("SECP"):
+                dl = 32
+                dg = rand_bytes(rng, dl * n)
+                nonces = b"".join(((int.from_bytes(rand_bytes(rng, ql + 8), "big") % (q - 1)) + 1).to_bytes(ql, "big") for _ in range(n))
+                sigs = same("ecdsa_sign_batch", [privs, nonces, dg, u32(dl), ("out", 2 * ql * n), ("out", n)], expect_ok=1)[0]
+                same("ecdsa_verify_batch", [pubs, sigs, dg, u32(dl), ("out", n)], expect_ok=0)
+                pubs_prj = cv.unique(pubs, 0, 1)[0]
+                same("ecdsa_verify_batch_fmt", [pubs_prj, ci(1), sigs, dg, u32(dl), ("out", n)], expect_ok=0)
+                msgs = [rand_bytes(rng, 1 + (7 * i) % 60) for i in range(n)]
+                slots, stride = cv.msg_slots(msgs)
+                sg2 = same("ecdsa_sign_msg_batch", [privs, rand_bytes(rng, 2 * ql * n), ci(2), slots, u32(stride), ("out", 2 * ql * n), ("out", n)], expect_ok=1)[0]
+                same("ecdsa_verify_msg_batch_fmt", [pubs_prj, ci(1), sg2, ci(2), slots, u32(stride), ("out", n)], expect_ok=0)
+                bad = bytearray(sg2)
+                bad[-1] ^= 1                                      # the last item of the last rank's shard
+                got = same("ecdsa_verify_msg_batch_fmt", [pubs, ci(0), bytes(bad), ci(2), slots, u32(stride), ("out", n)])[0]
+                assert got == bytes(n - 1) + b"\x01"
+                continue
+            # ---- EdDSA on the WEI25519 / WEI448 handles: valid signatures made with the signing entry points themselves ----
+            ed448 = cl == 56
+            kl, hl = (57, 114) if ed448 else (32, 64)
+            H = (lambda x: hashlib.shake_256(b"SigEd448\x00\x00" + x).digest(114)) if ed448 else (lambda x: hashlib.sha512(x).digest())
+            kle = lambda x: x.to_bytes(kl, "little")
+            a = [(int.from_bytes(rand_bytes(rng, 64), "big") % (q - 1)) + 1 for _ in range(n)]
+            inv4 = pow(4, -1, q) if ed448 else 1                  # eddsa_derive_priv_key: the Ed448 key lives on the 4-isogenous curve
+            Aw = cv.scalar_mult(b"".join(((x * inv4) % q).to_bytes(ql, "big") for x in a))[0]
+            keys_prj = cv.unique(Aw, 0, 1)[0]
+            Aenc = same("eddsa_encode_point_batch", [keys_prj, ("out", kl * n), ("out", n)], expect_ok=1)[0]
+            r_hash = rand_bytes(rng, hl * n)
+            Renc = same("eddsa_sign_R_batch", [r_hash, ("out", kl * n), ("out", n)], expect_ok=1)[0]
+            msgs = [rand_bytes(rng, 1 + (5 * i) % 70) for i in range(n)]
+            inputs = [Renc[kl * i:kl * (i + 1)] + Aenc[kl * i:kl * (i + 1)] + msgs[i] for i in range(n)]
+            hram = b"".join(H(x) for x in inputs)
+            S = same("eddsa_sign_S_batch", [r_hash, hram, b"".join(kle(x) for x in a), ("out", kl * n)])[0]
+            sigs = b"".join(Renc[kl * i:kl * (i + 1)] + S[kl * i:kl * (i + 1)] for i in range(n))
+            same("eddsa_verify_batch", [Aenc, sigs, hram, u32(hl), ("out", n)], expect_ok=0)
+            dom = b"SigEd448\x00\x00" if ed448 else b""
+            slots, stride = cv.msg_slots([dom + x for x in inputs])
+            same("eddsa_verify_msg_batch", [Aenc, sigs, slots, u32(stride), ("out", n)], expect_ok=0)
+            blank = [dom + x[:kl] + bytes(kl) + x[2 * kl:] for x in inputs]
+            slots_b, stride_b = cv.msg_slots(blank)
+            same("eddsa_verify_msg_prj_batch", [keys_prj, sigs, slots_b, u32(stride_b), u32(len(dom) + kl), ("out", n)], expect_ok=0)
+            bad = bytearray(sigs)
+            bad[-3] ^= 1                                          # S of the last item of the last shard
+            got = same("eddsa_verify_msg_prj_batch", [keys_prj, bytes(bad), slots_b, u32(stride_b), u32(len(dom) + kl), ("out", n)])[0]
+            assert got == bytes(n - 1) + b"\x01"
+            # the pre-hashed variant: dom(1, "") || R || blank A || blank PH(M), the messages in slots of their own
+            domph = b"SigEd448\x01\x00" if ed448 else b"SigEd25519 no Ed25519 collisions\x01\x00"
+            PH = (lambda x: hashlib.shake_256(x).digest(64)) if ed448 else (lambda x: hashlib.sha512(x).digest())
+            Hph = (lambda x: hashlib.shake_256(x).digest(114)) if ed448 else (lambda x: hashlib.sha512(x).digest())
+            hram_ph = b"".join(Hph(domph + Renc[kl * i:kl * (i + 1)] + Aenc[kl * i:kl * (i + 1)] + PH(msgs[i])) for i in range(n))
+            S_ph = cv.eddsa_sign_S(r_hash, hram_ph, b"".join(kle(x) for x in a))
+            sigs_ph = b"".join(Renc[kl * i:kl * (i + 1)] + S_ph[kl * i:kl * (i + 1)] for i in range(n))
+            slots_p, stride_p = cv.msg_slots([domph + Renc[kl * i:kl * (i + 1)] + bytes(kl + 64) for i in range(n)])
+            mslots, mstride = cv.msg_slots(msgs)
+            same("eddsa_verify_ph_prj_batch", [keys_prj, sigs_ph, slots_p, u32(stride_p), u32(len(domph) + kl), mslots, u32(mstride), ("out", n)], expect_ok=0)
+            k = rand_bytes(rng, cl * n)
+            u = bytearray(rand_bytes(rng, cl * n))
+            if not ed448:
+                for i in range(n):
+                    u[32 * i + 31] &= 0x7f
+            same("xdh_batch", [k, bytes(u), ("out", cl * n), ("out", n)], expect_ok=1)
+            # the whole-batch bit: valid, then one bad item in the last shard
+            assert mc.eddsa_verify_all(Aenc, sigs, hram) == cv.eddsa_verify_all(Aenc, sigs, hram) == (True, n)
+            assert mc.eddsa_verify_all(Aenc, bytes(bad), hram) == cv.eddsa_verify_all(Aenc, bytes(bad), hram) == (False, n - 1)
+    finally:
+        mc.free()
+        cv.free()
+        m.close()

@@ -160,7 +160,7 @@ def test_runner_on_selfmade_file_cpu():
 
 def test_official_wycheproof_vectors_cpu():
     if not W.find_vectors():
-        pytest.skip("UNPINNED: no Wycheproof test-vector files here (set WYCHEPROOF_VECTORS or fill tests/wycheproof/)")
+        pytest.skip("UNPINNED: no Wycheproof test-vector files here (set WYCHEPROOF_DIR / WYCHEPROOF_VECTORS to a Wycheproof checkout or its testvectors/, or fill tests/wycheproof/)")
     t = run_all(CpuBackend(), *official_files())
     assert not t.errors, (len(t.errors), t.errors[:10])
     assert t.performed > 0
@@ -180,7 +180,7 @@ def test_runner_on_selfmade_file_gpu(gpu_ctx):
 @pytest.mark.gpu
 def test_official_wycheproof_vectors_gpu(gpu_ctx):
     if not W.find_vectors():
-        pytest.skip("UNPINNED: no Wycheproof test-vector files here (set WYCHEPROOF_VECTORS or fill tests/wycheproof/)")
+        pytest.skip("UNPINNED: no Wycheproof test-vector files here (set WYCHEPROOF_DIR / WYCHEPROOF_VECTORS to a Wycheproof checkout or its testvectors/, or fill tests/wycheproof/)")
     be = GpuBackend(gpu_ctx)
     try:
         t = run_all(be, *official_files())

@@ -3,7 +3,7 @@ XDH :278-, ECDH :542-726) over the record types of libecc_wycheproof.h:27-151, f
 (testvectors/*.json of the Wycheproof project) when they are present.
 
 The reference snapshot does not ship the generated vector header (libecc_wycheproof_tests.h) nor the JSON, and this build
-environment has no network: `find_vectors()` looks in $WYCHEPROOF_VECTORS, tests/wycheproof/ and
+environment has no network: `find_vectors()` looks in $WYCHEPROOF_VECTORS / $WYCHEPROOF_DIR (the directory itself, its testvectors/ and testvectors_v1/), tests/wycheproof/ and
 /root/reference/src/wycheproof_tests/ -- when nothing is found the tests that use this module SKIP with the word UNPINNED
 instead of passing.  tests/golden/wycheproof_style_selfmade.json is a file in the same schema built from this repository's own
 crafted families WITH THE UNMODIFIED REFERENCE'S VERDICTS (tests/golden/make_wycheproof_style.py); it exercises the runner, it is
@@ -37,9 +37,17 @@ HASH_NAMES = {"SHA-224": "SHA224", "SHA-256": "SHA256", "SHA-384": "SHA384", "SH
 
 def find_vectors():
     """directories that hold Wycheproof JSON test-vector files"""
-    cands = [os.environ.get("WYCHEPROOF_VECTORS"), os.path.join(HERE, "wycheproof"),
-             "/root/reference/src/wycheproof_tests", "/root/reference/src/wycheproof_tests/testvectors"]
-    return [d for d in cands if d and glob.glob(os.path.join(d, "*_test.json"))]
+    cands = [os.path.join(HERE, "wycheproof"), "/root/reference/src/wycheproof_tests", "/root/reference/src/wycheproof_tests/testvectors"]
+    for var in ("WYCHEPROOF_VECTORS", "WYCHEPROOF_DIR"):   # a checkout of the Wycheproof project, or its testvectors/ directory itself
+        root = os.environ.get(var)
+        if root:
+            cands = [root, os.path.join(root, "testvectors"), os.path.join(root, "testvectors_v1")] + cands
+    seen, out = set(), []
+    for d in cands:
+        if d and d not in seen and glob.glob(os.path.join(d, "*_test.json")):
+            seen.add(d)
+            out.append(d)
+    return out
 
 
 def load(pattern, dirs=None):
