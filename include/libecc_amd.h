@@ -294,6 +294,26 @@ int ec_eddsa_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t
 			      const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, int *all_valid,
 			      uint32_t *first_rejected);
 
+/* Whole-batch predicate of ec_verify_batch for the Schnorr-type algorithms libecc verifies in batches on a short-Weierstrass curve --
+ * BIP0340 (bip0340_verify_batch sig/bip0340.c:1196, _bip0340_verify_batch_no_memory :640-1010) and ECFSDSA (ecfsdsa_verify_batch
+ * sig/ecfsdsa.c:1042-) -- as ONE multi-scalar multiplication.  The item form of both is  [s_i]G + [q - e_i]Y_i = R_i  (bip0340.c:531-547,
+ * ecfsdsa.c:561-576); the reference's batch form draws scalars a_i and accepts when
+ *     [-sum a_i s_i]G + sum [a_i]R_i + sum [a_i e_i]Y_i   is the point at infinity (bip0340.c:925-1010).
+ * Here: z_i = 128 bits of ChaCha20 (keyed by 32 bytes of getrandom per call, or ecamd_ctx_set_msm_seed), and
+ *     T = [sum z_i s_i]G + sum ([z_i ne_i mod q]Y_i - [z_i]R_i),     *all_valid = 1 iff T is the point at infinity
+ * evaluated on the radix-2^29 unit of the curve by a Straus loop whose doublings are shared by up to 8 signatures per lane (the R_i
+ * only enter the low 33 windows).  s, ne: n x qlen big-endian, ne_i = q - e_i mod q as the item form multiplies it; keys_aff: n x 2*clen,
+ * the keys Y_i as the item form uses them (BIP0340: after lift_x); r: r_fmt 0 = n x 2*clen affine points R_i (ECFSDSA: the signature's
+ * W), r_fmt 1 = n x clen x coordinates, R_i = the point with that x and an EVEN y (BIP0340: lift_x of r_i, computed on the device;
+ * fields with p = 3 mod 4).
+ * *all_valid = 0 means "not decided here": some item fails the equation, or a point does not import / r_i is no abscissa / s_i >= q /
+ * an addition met equal or opposite operands, or the handle has no such unit (ec_schnorr_verify_all_available) -- the caller then
+ * verifies item by item, so the batch form never accepts or rejects anything the item form would not (a batch with a bad
+ * signature passes with probability ~2^-128, as the reference's does).  libecc rejects num = 0, as this does (-1). */
+int ec_schnorr_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *s, const uint8_t *ne,
+				const uint8_t *keys_aff, const uint8_t *r, int r_fmt, int *all_valid);
+int ec_schnorr_verify_all_available(const ecamd_curve *curve, int r_fmt);   /* 1: the multi-scalar form serves this handle */
+
 /* eddsa_export_pub_key in batch (sig/eddsa.c:795-860): n projective Weierstrass points X || Y || Z (what ec_pub_key.y holds,
  * prj_pt_export_to_buf) of the WEI25519 / WEI448 handle -> prj_pt_shortw_to_aff_pt_edwards -> eddsa_encode_point: n x 32 / 57
  * octets, the public-key encoding the verifier hashes.  status ECAMD_ERR for a point that is not on the curve; the point at
@@ -494,6 +514,9 @@ int ecamd_multi_eddsa_encode_point_batch(ecamd_multi *m, const ecamd_mcurve *cur
 int ecamd_multi_eddsa_verify_all_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *pubkeys,
 				       const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, int *all_valid,
 				       uint32_t *first_rejected);
+/* ec_schnorr_verify_all_batch, sharded: every device decides its shard with a combination of its own; valid iff every shard is */
+int ecamd_multi_schnorr_verify_all_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *s, const uint8_t *ne,
+					 const uint8_t *keys_aff, const uint8_t *r, int r_fmt, int *all_valid);
 int ecamd_multi_eddsa_sign_R_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *r_hash, uint8_t *R_enc,
 				   uint8_t *status);
 int ecamd_multi_eddsa_sign_S_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *r_hash, const uint8_t *hram,
@@ -521,6 +544,12 @@ int ecamd_multi_allgather_streams(ecamd_multi *m, const void *const *d_send, voi
  * reduced residues mod 2^255 - 19) may be NULL.  n <= the context's max_chunk. */
 int ecamd_debug_eddsa_msm(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs,
 			  const uint8_t *hram, const uint8_t seed[32], int *accept, uint8_t *z_out, uint32_t *sum_out);
+
+/* The same for the Schnorr-type multi-scalar multiplication (ec_schnorr_verify_all_batch).  sum_out: the lanes' sum before the generator's
+ * term, ecamd_debug_schnorr_msm_words() words (X, Y, Z digits of the unit's representation, then an "is infinity" word). */
+int ecamd_debug_schnorr_msm(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *s, const uint8_t *ne, const uint8_t *keys_aff,
+			    const uint8_t *r, int r_fmt, const uint8_t seed[32], int *accept, uint8_t *z_out, uint32_t *sum_out);
+uint32_t ecamd_debug_schnorr_msm_words(const ecamd_curve *curve);
 
 #ifdef __cplusplus
 }

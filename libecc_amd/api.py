@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = [
     "ecamd_multi_xdh_batch", "ecamd_multi_eddsa_verify_batch", "ecamd_multi_eddsa_verify_all_batch", "ecamd_multi_allgather",
     "ecamd_multi_allgather_streams", "ecamd_multi_eddsa_sign_R_batch", "ecamd_multi_eddsa_sign_S_batch",
     "ecamd_multi_set_secret_scalars", "ecamd_multi_wipe_scratch", "ecamd_ctx_wipe_scratch", "ecamd_ctx_stream", "ecamd_host_alloc", "ecamd_host_free", "ecamd_ctx_dominant_kernel_ms", "ecamd_ctx_set_msm_seed", "ecamd_multi_set_msm_seed", "ec_eddsa_verify_ph_prj_batch", "ecamd_multi_eddsa_verify_ph_prj_batch", "ec_nn_random_mod_batch", "ec_ecdsa_sign_msg_batch", "ec_key_pair_gen_raw_batch", "ecamd_multi_ecdsa_sign_msg_batch", "ecamd_multi_key_pair_gen_raw_batch", "ec_eddsa_verify_msg_prj_batch", "ecamd_multi_eddsa_verify_msg_prj_batch", "ecamd_ctx_set_host_ready_hook", "ecamd_multi_set_host_ready_hook", "ecamd_multi_prj_pt_add_batch",
+    "ec_schnorr_verify_all_batch", "ec_schnorr_verify_all_available", "ecamd_multi_schnorr_verify_all_batch", "ecamd_debug_schnorr_msm", "ecamd_debug_schnorr_msm_words",
 ]
 
 
@@ -81,6 +82,12 @@ def load_library():
         L.ec_eddsa_verify_all_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
         L.ecamd_debug_eddsa_msm.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p, C.POINTER(C.c_int), vp, vp]
         L.ecamd_ctx_set_eddsa_msm.argtypes = [vp, C.c_int, u32, u32]
+        L.ec_schnorr_verify_all_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p, C.c_int, C.POINTER(C.c_int)]
+        L.ecamd_multi_schnorr_verify_all_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p, C.c_int, C.POINTER(C.c_int)]
+        L.ec_schnorr_verify_all_available.argtypes = [vp, C.c_int]
+        L.ecamd_debug_schnorr_msm.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p, C.c_int, u8p, C.POINTER(C.c_int), vp, vp]
+        L.ecamd_debug_schnorr_msm_words.argtypes = [vp]
+        L.ecamd_debug_schnorr_msm_words.restype = C.c_uint32
         L.ec_eddsa_verify_all_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, u32, vp, vp]
         L.ec_eddsa_encode_point_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p]
         L.ecamd_multi_eddsa_encode_point_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p]
@@ -437,6 +444,28 @@ class Curve:
         coords = [sum(int(w[9 * c + i]) << (29 * i) for i in range(9)) % p for c in range(4)]
         return bool(acc.value), z.raw, coords
 
+    def schnorr_verify_all(self, s, ne, keys_aff, r, r_fmt=0):
+        """ec_schnorr_verify_all_batch: True iff sum z_i ([s_i]G + [ne_i]Y_i - R_i) vanishes (the BIP0340 / ECFSDSA batch equation as one
+        multi-scalar multiplication); False = not decided here.  r_fmt 1: r holds x coordinates, R_i has the even y."""
+        n = len(s) // self.qlen
+        ok = C.c_int(0)
+        _chk(self.L, self.L.ec_schnorr_verify_all_batch(self.ctx.h, self.h, n, s, ne, keys_aff, r, r_fmt, C.byref(ok)), "ec_schnorr_verify_all_batch")
+        return bool(ok.value)
+
+    def schnorr_msm_available(self, r_fmt=0):
+        return bool(self.L.ec_schnorr_verify_all_available(self.h, r_fmt))
+
+    def debug_schnorr_msm(self, s, ne, keys_aff, r, r_fmt, seed):
+        """test hook: (accept, z_i as n x 16 bytes little-endian, the "sum is infinity" word of the lanes' sum)"""
+        n = len(s) // self.qlen
+        acc = C.c_int(0)
+        z = C.create_string_buffer(16 * n)
+        nw = self.L.ecamd_debug_schnorr_msm_words(self.h)
+        w = (C.c_uint32 * max(1, nw))()
+        _chk(self.L, self.L.ecamd_debug_schnorr_msm(self.ctx.h, self.h, n, s, ne, keys_aff, r, r_fmt, seed, C.byref(acc),
+                                                     C.cast(z, C.c_void_p), C.cast(w, C.c_void_p)), "ecamd_debug_schnorr_msm")
+        return bool(acc.value), z.raw, int(w[nw - 4]) if nw else None
+
     # -- device-pointer forms (torch tensors' data_ptr()); see include/libecc_amd.h for which ones synchronise --
     def eddsa_verify_all_dev(self, n, d_pubs, d_sigs, d_hram, d_verdict, stream=None):
         _chk(self.L, self.L.ec_eddsa_verify_all_batch_dev(self.ctx.h, self.h, n, d_pubs, d_sigs, d_hram, 64, d_verdict, stream),
@@ -625,6 +654,13 @@ class MultiCurve:
         _chk(self.L, self.L.ecamd_multi_eddsa_verify_batch(self.m.h, self.h, n, pubkeys, sigs, hram, hram_len, res),
              "ecamd_multi_eddsa_verify_batch")
         return res.raw[:n]
+
+    def schnorr_verify_all(self, s, ne, keys_aff, r, r_fmt=0):
+        n = len(s) // self.qlen
+        ok = C.c_int(0)
+        _chk(self.L, self.L.ecamd_multi_schnorr_verify_all_batch(self.m.h, self.h, n, s, ne, keys_aff, r, r_fmt, C.byref(ok)),
+             "ecamd_multi_schnorr_verify_all_batch")
+        return bool(ok.value)
 
     def eddsa_verify_all(self, pubkeys, sigs, hram, hram_len=None):
         klen = 57 if self.clen == 56 else self.clen

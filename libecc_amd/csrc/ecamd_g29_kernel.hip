@@ -387,6 +387,327 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_smul
 }
 
 // ------------------------------------------------------------------------------------------
+// Schnorr-type whole-batch verification as one multi-scalar multiplication (EcamdMsmArgs in ecamd_internal.h; the equation of
+// _bip0340_verify_batch_no_memory, sig/bip0340.c:905-1010, and of _ecfsdsa_verify_batch_no_memory, sig/ecfsdsa.c:1042-):
+//   k_msm_table_g   the 2n points: import + on-curve check, Jacobian table [1..8]P, recoded scalar behind it (k_smul_g's first half)
+//   k_msm_loop_g    lane l: the Straus loop over its K keys (full-length scalars) and K signature points (128-bit scalars, negated)
+//   k_msm_sum_g     tree sum of the lanes' Jacobian sums, fan-in MSM_FAN
+//   k_msm_final_g   T = sum + [c]G is the point at infinity  <=>  sum = -[c]G (or both are infinite): exact comparison
+// A Jacobian table (12M + 4S additions) rather than the affine one: one code path for every flavour (secp256k1's has no mixed
+// addition), and no inversion pass over 16 entries per signature.
+// ------------------------------------------------------------------------------------------
+#define MSM_FAN 16
+template <int PB> struct MsmLay {
+	static constexpr int RECW = Lay<PB>::ENTW + 4;   // X, Y, Z (class FA) as a table entry, then the "is infinity" word
+};
+
+// BIP0340's lift_x on the unit's curve (aff_pt_y_from_x + "the even solution", sig/bip0340.c:947-953; curves/aff_pt.c:102): x < p,
+// y = (x^3 + a x + b)^((p + 1) / 4) for p = 3 mod 4 (the host guarantees it), y^2 checked, and the root whose ORIGINAL-curve
+// representative (through the export factor ey) is even.  Exponent bits are wave-uniform; 2-bit windows as in inv<PB>.
+template <int PB> static __device__ __forceinline__ bool msm_lift_x(const u8 *src, int clen, typename Cls<PB>::FM &xo, typename Cls<PB>::FM &yo,
+								     const CurveG<Cfg<PB>::NL> &K)
+{
+	typedef Lay<PB> L;
+	typedef typename Cls<PB>::FM FM;
+	typedef typename Cls<PB>::FC FC;
+	constexpr int NL = L::NL, NW = L::NW;
+	u32 xw[NW];
+	load_be<NW>(src, clen, xw);
+	const auto xd = from_words<PB, NW>(xw);
+	u32 bx = 0;
+#pragma unroll
+	for (int j = 0; j < NL; j++) {
+		bx = (xd.l[j] - K.p[j] - bx) >> 31;
+	}
+	bool ok = (bx != 0);   // x < p (fp_import_from_buf)
+	const FC onec = constant<FC>(K.one);
+	const auto xm = mul(xd, constant<FC>(K.ix), K);
+	const auto rhs0 = add(mulc(carry(add(sqr(xm, K), constant<FC>(K.a))), xm, K), constant<FC>(K.b));
+	const FM rhs = weaken<FM>(mulc(carry(rhs0), onec, K));
+	// e = (p + 1) / 4, digits in radix 2^29
+	u32 e[NL];
+	{
+		u32 c = 1;
+#pragma unroll
+		for (int j = 0; j < NL; j++) {
+			const u32 t = K.p[j] + c;
+			e[j] = t & MASK;
+			c = t >> W;
+		}
+#pragma unroll
+		for (int j = 0; j < NL; j++) {
+			e[j] = (e[j] >> 2) | ((j + 1 < NL ? (e[j + 1] & 3u) : 0u) << (W - 2));
+		}
+	}
+	const FM x2 = weaken<FM>(sqr(rhs, K));
+	const FM x3 = weaken<FM>(mul(x2, rhs, K));
+	FM r = weaken<FM>(onec);
+	const int top = ((int)K.pbits - 1) | 1;
+	for (int i = top; i >= 1; i -= 2) {
+		r = weaken<FM>(sqr(r, K));
+		r = weaken<FM>(sqr(r, K));
+		const u32 hi = (e[i / W] >> (i % W)) & 1u, lo = (e[(i - 1) / W] >> ((i - 1) % W)) & 1u;
+		const u32 c = 2u * hi + lo;
+		if (c == 1u) {
+			r = weaken<FM>(mul(r, rhs, K));
+		} else if (c == 2u) {
+			r = weaken<FM>(mul(r, x2, K));
+		} else if (c == 3u) {
+			r = weaken<FM>(mul(r, x3, K));
+		}
+	}
+	{
+		const auto dif = carry(sub_auto<1>(rhs, sqr(r, K), K));
+		ok = ok & is_zero_mulout(mulc(dif, onec, K), K);   // not a square: aff_pt_y_from_x fails
+	}
+	u32 d[NL];
+	canonical_digits(d, mul(r, constant<FC>(K.ey), K), K);
+	const bool odd = (d[0] & 1u) != 0u;
+	const FM rn = weaken<FM>(mulc(neg<PB>(r, K), onec, K));
+	xo = weaken<FM>(xm);
+	yo = selg(odd, rn, r);
+	return ok;
+}
+
+template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_msm_table_g(EcamdMsmArgs A, int gslot)
+{
+	typedef Lay<PB> L;
+	typedef typename Cls<PB>::FA FA;
+	typedef typename Cls<PB>::FM FM;
+	typedef typename Cls<PB>::FC FC;
+	constexpr int NL = L::NL;
+	const u32 idx = blockIdx.x * 64 + threadIdx.x;
+	if (idx >= 2 * A.n) {
+		return;
+	}
+	const bool isR = idx >= A.n;
+	const u32 i = isR ? idx - A.n : idx;
+	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	EcamdSmulArgs S;
+	S.points = isR ? A.ptsR : A.ptsY;
+	S.pstride = 2u * A.clen;
+	S.clen = A.clen;
+	const FC onec = constant<FC>(K.one);
+	FM xm, ym;
+	bool bad;
+	if (isR && A.r_fmt == 1u) {
+		bad = !msm_lift_x<PB>(A.ptsR + (size_t)i * A.clen, (int)A.clen, xm, ym, K);
+	} else {
+		bad = !import_point<PB>(S, i, xm, ym, K);
+	}
+	u32 *tb = A.tbl + (size_t)idx * L::ITEMW;
+	Jac<PB> P1;
+	P1.X = weaken<FA>(xm);
+	P1.Y = weaken<FA>(ym);
+	P1.Z = weaken<FA>(onec);
+	bool hz;
+	TabEnt<PB> T1;
+	T1.X = P1.X;
+	T1.Y = weaken<FM>(ym);
+	T1.Z = P1.Z;
+	const FA y1 = weaken<FA>(T1.Y);
+	tab_store<PB>(tb, 0, T1);
+	{
+		Jac<PB> Pa = dbl(P1, K);
+		tab_store<PB>(tb, 1, to_tab(Pa, K));
+		Jac<PB> Pb = add_jac(Pa, T1.X, y1, T1.Z, hz, K);
+		bad |= hz;
+		tab_store<PB>(tb, 2, to_tab(Pb, K));
+		Pa = dbl(Pa, K);
+		tab_store<PB>(tb, 3, to_tab(Pa, K));
+		Pb = add_jac(Pa, T1.X, y1, T1.Z, hz, K);
+		bad |= hz;
+		tab_store<PB>(tb, 4, to_tab(Pb, K));
+		{
+			const TabEnt<PB> t3 = tab_load<PB>(tb, 2);
+			Jac<PB> P3;
+			P3.X = t3.X;
+			P3.Y = weaken<FA>(t3.Y);
+			P3.Z = t3.Z;
+			Pb = dbl(P3, K);
+		}
+		tab_store<PB>(tb, 5, to_tab(Pb, K));
+		Pb = add_jac(Pb, T1.X, y1, T1.Z, hz, K);
+		bad |= hz;
+		tab_store<PB>(tb, 6, to_tab(Pb, K));
+		Pa = dbl(Pa, K);
+		tab_store<PB>(tb, 7, to_tab(Pa, K));
+		// a doubling reaches infinity silently (points of even order): exact test of the last Z's
+		bad = bad | is_zero_mulout(mulc(mulc(Pa.Z, Pb.Z, K), onec, K), K);
+	}
+	u32 *kr = tb + 8 * L::ENTW;
+	const int slen = (int)(isR ? A.zlen : A.wlen);
+	const u8 *sc = isR ? A.scZ + (size_t)i * A.zlen : A.scW + (size_t)i * A.wlen;
+	kr[L::KRECW - 1] = recode_scalar(sc, slen, kr);
+	if (bad) {
+		atomicOr(A.flagword, 1u);   // the point does not import, or a multiple below 9P is infinity: not decided here
+	}
+}
+
+// one term of the Straus sum: acc += (+-) [dig]P from the item's table
+template <int PB>
+static __device__ __forceinline__ void msm_step(Jac<PB> &acc, bool &inf, bool &bad, const u32 *tb, int dig, bool negate, const CurveG<Cfg<PB>::NL> &K)
+{
+	typedef typename Cls<PB>::FA FA;
+	const u32 mag = (u32)(dig < 0 ? -dig : dig);
+	const TabEnt<PB> T = tab_load<PB>(tb, mag ? mag - 1 : 0);
+	const FA ty = selg((dig < 0) != negate, neg<PB>(T.Y, K), weaken<FA>(T.Y));
+	bool hz;
+	const Jac<PB> S = add_jac(acc, T.X, ty, T.Z, hz, K);
+	const bool use_t = inf & (mag != 0);
+	const bool keep = (mag == 0);
+	bad = bad | (!inf & !keep & hz);
+	acc.X = selg(keep, acc.X, selg(use_t, T.X, S.X));
+	acc.Y = selg(keep, acc.Y, selg(use_t, ty, S.Y));
+	acc.Z = selg(keep, acc.Z, selg(use_t, T.Z, S.Z));
+	inf = inf & keep;
+}
+
+template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_msm_loop_g(EcamdMsmArgs A, int gslot)
+{
+	typedef Lay<PB> L;
+	typedef typename Cls<PB>::FC FC;
+	constexpr int NL = L::NL;
+	const u32 lane = blockIdx.x * 64 + threadIdx.x;
+	if (lane >= A.L) {
+		return;
+	}
+	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	const FC onec = constant<FC>(K.one);
+	const int wwin = 2 * (int)A.wlen, zwin = 2 * (int)A.zlen;
+	// (a placeholder until the first non-zero digit replaces it: the lane's first key)
+	Jac<PB> acc;
+	{
+		const TabEnt<PB> T = tab_load<PB>(A.tbl + (size_t)lane * L::ITEMW, 0);
+		acc.X = T.X;
+		acc.Y = weaken<typename Cls<PB>::FA>(T.Y);
+		acc.Z = T.Z;
+	}
+	bool inf = true, bad = false;
+#pragma unroll 1
+	for (int pos = wwin; pos >= 0; pos--) {
+		if (pos != wwin) {
+#pragma unroll 1
+			for (int d = 0; d < 4; d++) {
+				acc = dbl(acc, K);
+			}
+		}
+		// the keys: digit `pos` of z_i (q - e_i); position wwin holds the carry of the recoding (0 / 1)
+#pragma unroll 1
+		for (u32 j = 0; j < A.K; j++) {
+			const u32 item = j * A.L + lane;
+			const bool live = item < A.n;
+			const u32 *tb = A.tbl + (size_t)(live ? item : 0u) * L::ITEMW;
+			const u32 *kr = tb + 8 * L::ENTW;
+			int dig = (pos == wwin) ? (int)kr[L::KRECW - 1] : (int)((kr[pos >> 3] >> (4 * (pos & 7))) & 15u) - 8;
+			dig = live ? dig : 0;
+			msm_step<PB>(acc, inf, bad, tb, dig, false, K);
+		}
+		// the signatures' points, negated: digit `pos` of z_i, 2 zlen + 1 digits
+		if (pos <= zwin) {
+#pragma unroll 1
+			for (u32 j = 0; j < A.K; j++) {
+				const u32 item = j * A.L + lane;
+				const bool live = item < A.n;
+				const u32 *tb = A.tbl + (size_t)(A.n + (live ? item : 0u)) * L::ITEMW;
+				const u32 *kr = tb + 8 * L::ENTW;
+				int dig = (pos == zwin) ? (int)kr[L::KRECW - 1] : (int)((kr[pos >> 3] >> (4 * (pos & 7))) & 15u) - 8;
+				dig = live ? dig : 0;
+				msm_step<PB>(acc, inf, bad, tb, dig, true, K);
+			}
+		}
+	}
+	// a doubling that reached infinity silently (cofactor curves) leaves Z = 0: not a sum this path vouches for
+	if (!inf) {
+		bad = bad | is_zero_mulout(mulc(acc.Z, onec, K), K);
+	}
+	u32 *rec = A.rec + (size_t)lane * MsmLay<PB>::RECW;
+	jac_store<PB>(rec, acc);
+	rec[L::ENTW] = inf ? 1u : 0u;
+	if (bad) {
+		atomicOr(A.flagword, 2u);
+	}
+}
+
+template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_msm_sum_g(const u32 *in, u32 count, u32 *out, u32 *flagword, int gslot)
+{
+	typedef Lay<PB> L;
+	constexpr int NL = L::NL, RECW = MsmLay<PB>::RECW;
+	const u32 t = blockIdx.x * 64 + threadIdx.x;
+	const u32 first = t * MSM_FAN;
+	if (first >= count) {
+		return;
+	}
+	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	Jac<PB> acc = jac_load<PB>(in + (size_t)first * RECW);
+	bool inf = in[(size_t)first * RECW + L::ENTW] != 0u, bad = false;
+#pragma unroll 1
+	for (u32 k = 1; k < MSM_FAN; k++) {
+		const u32 r = first + k;
+		const bool live = r < count;
+		const u32 *rec = in + (size_t)(live ? r : first) * RECW;
+		const Jac<PB> P = jac_load<PB>(rec);
+		const bool pinf = !live || rec[L::ENTW] != 0u;
+		bool hz;
+		const Jac<PB> S = add_jac(acc, P.X, P.Y, P.Z, hz, K);
+		bad = bad | (!inf & !pinf & hz);   // equal or opposite partial sums: not decided here
+		acc.X = selg(pinf, acc.X, selg(inf, P.X, S.X));
+		acc.Y = selg(pinf, acc.Y, selg(inf, P.Y, S.Y));
+		acc.Z = selg(pinf, acc.Z, selg(inf, P.Z, S.Z));
+		inf = inf & pinf;
+	}
+	u32 *rec = out + (size_t)t * RECW;
+	jac_store<PB>(rec, acc);
+	rec[L::ENTW] = inf ? 1u : 0u;
+	if (bad) {
+		atomicOr(flagword, 4u);
+	}
+}
+
+// sum + [c]G = infinity  <=>  both infinite, or X = x Z^2 and Y = -y Z^3 with (x, y) = [c]G affine (as the comb path exported it)
+template <int PB, int FLAV>
+__global__ __launch_bounds__(64) void k_msm_final_g(const u32 *in, const u8 *gen, const u8 *gen_status, u32 clen, const u32 *flagword, u8 *verdict,
+						     u32 *sum_out, int gslot)
+{
+	typedef Lay<PB> L;
+	typedef typename Cls<PB>::FM FM;
+	typedef typename Cls<PB>::FC FC;
+	constexpr int NL = L::NL, RECW = MsmLay<PB>::RECW;
+	if (blockIdx.x != 0 || threadIdx.x != 0) {
+		return;
+	}
+	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	const FC onec = constant<FC>(K.one);
+	if (sum_out) {
+		for (int w = 0; w < RECW; w++) {
+			sum_out[w] = in[w];
+		}
+	}
+	const Jac<PB> S = jac_load<PB>(in);
+	const bool sinf = in[L::ENTW] != 0u;
+	const u32 gst = gen_status[0];
+	bool ok = false;
+	if (gst == 2u) {
+		ok = sinf;
+	} else if (gst == 0u && !sinf) {
+		EcamdSmulArgs G;
+		G.points = gen;
+		G.pstride = 2u * clen;
+		G.clen = clen;
+		FM xg, yg;
+		ok = import_point<PB>(G, 0, xg, yg, K);
+		const auto zz = sqrc(S.Z, K);
+		const auto zzz = mulc(zz, S.Z, K);
+		// (the sum's coordinates through a multiplication by one first: values below 2p whatever the accumulator class allows)
+		const auto dx = carry(sub_auto<1>(mulc(xg, zz, K), mulc(S.X, onec, K), K));
+		const auto dy = carry(add(mulc(yg, zzz, K), mulc(S.Y, onec, K)));
+		ok = ok & is_zero_mulout(mulc(dx, onec, K), K) & is_zero_mulout(mulc(dy, onec, K), K);
+		ok = ok & !is_zero_mulout(mulc(S.Z, onec, K), K);
+	}
+	verdict[0] = (ok && flagword[0] == 0u) ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------
 // Affine-table pipeline (every flavour except the two nine-limb ones, see the launcher and HAVE_MADD in ecamd_jacg.h): the
 // pipeline of ecamd_p256_kernel.hip
 //   k_table_g    import + on-curve check, Jacobian multiples 2P..8P into the item's staging slots, recoded scalar
@@ -3646,6 +3967,36 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_prj_import_g
 	}
 }
 
+hipError_t G29_CAT(ecamd_g29_msm_, G29_TAG)(int gslot, int phase, const EcamdMsmArgs &a, uint32_t *tmp, const uint8_t *gen, const uint8_t *gen_status,
+					    uint8_t *verdict, uint32_t *sum_out, hipStream_t s)
+{
+	constexpr uint32_t RECW = (uint32_t)MsmLay<G29_PB>::RECW;
+	if (a.n == 0) {
+		return hipErrorInvalidValue;
+	}
+	if (phase == 0) {
+		hipLaunchKernelGGL((k_msm_table_g<G29_PB, G29_FLAV>), dim3((2 * a.n + 63) / 64), dim3(64), 0, s, a, gslot);
+	} else if (phase == 1) {
+		hipLaunchKernelGGL((k_msm_loop_g<G29_PB, G29_FLAV>), dim3((a.L + 63) / 64), dim3(64), 0, s, a, gslot);
+	} else {
+		// tree sum, ping-pong between a.rec and tmp
+		uint32_t count = a.L;
+		uint32_t *src = a.rec, *dst = tmp;
+		while (count > 1) {
+			const uint32_t outc = (count + MSM_FAN - 1) / MSM_FAN;
+			hipLaunchKernelGGL((k_msm_sum_g<G29_PB, G29_FLAV>), dim3((outc + 63) / 64), dim3(64), 0, s, (const uint32_t *)src, count, dst, a.flagword, gslot);
+			uint32_t *t = src;
+			src = dst;
+			dst = t;
+			count = outc;
+		}
+		(void)RECW;
+		hipLaunchKernelGGL((k_msm_final_g<G29_PB, G29_FLAV>), dim3(1), dim3(64), 0, s, (const uint32_t *)src, gen, gen_status, a.clen, (const uint32_t *)a.flagword,
+				   verdict, sum_out, gslot);
+	}
+	return hipGetLastError();
+}
+
 hipError_t G29_CAT(ecamd_g29_prj_import_, G29_TAG)(int gslot, const EcamdPrjInArgs &a, hipStream_t s)
 {
 	if (a.n == 0) {
@@ -3888,6 +4239,53 @@ hipError_t ecamd_g29_ecdsa_prep(int qbits, int qgslot, const EcamdEcdsaPrepArgs 
 #undef X
 	default: return hipErrorInvalidValue;
 	}
+}
+
+#define X(PB) hipError_t ecamd_g29_msm_##PB(int gslot, int phase, const EcamdMsmArgs &a, uint32_t *tmp, const uint8_t *gen, const uint8_t *gen_status, \
+					   uint8_t *verdict, uint32_t *sum_out, hipStream_t s);
+G29_FOR_PB(X)
+X(521m)
+X(255c)
+X(384n)
+X(224s)
+X(192s)
+X(256k)
+X(448g)
+#undef X
+uint32_t ecamd_g29_msm_rec_words(int pbits, int flavour) { return (uint32_t)(((3 * g29::nl_for_flavour(pbits, flavour) + 3) / 4) * 4) + 4u; }   // MsmLay<PB>::RECW
+// the Schnorr-type multi-scalar multiplication on the unit (pbits, flavour)
+hipError_t ecamd_launch_msm_g29(int pbits, int gslot, int flavour, int phase, const EcamdMsmArgs &a, uint32_t *tmp, const uint8_t *gen,
+				const uint8_t *gen_status, uint8_t *verdict, uint32_t *sum_out, hipStream_t s)
+{
+#define Y(TAG) return ecamd_g29_msm_##TAG(gslot, phase, a, tmp, gen, gen_status, verdict, sum_out, s)
+	if (pbits == 521 && flavour == 1) {
+		Y(521m);
+	}
+	if (pbits == 255 && flavour == 2) {
+		Y(255c);
+	}
+	if (pbits == 384 && flavour == 3) {
+		Y(384n);
+	}
+	if (pbits == 224 && flavour == 6) {
+		Y(224s);
+	}
+	if (pbits == 192 && flavour == 7) {
+		Y(192s);
+	}
+	if (pbits == 256 && flavour == 4) {
+		Y(256k);
+	}
+	if (pbits == 448 && flavour == 5) {
+		Y(448g);
+	}
+	switch (pbits) {
+#define X(PB) case PB: Y(PB);
+		G29_FOR_PB(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+#undef Y
 }
 
 #define X(PB) hipError_t ecamd_g29_prj_import_##PB(int gslot, const EcamdPrjInArgs &a, hipStream_t s);

@@ -4101,6 +4101,258 @@ static int eddsa_msm_host_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, co
 	return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Schnorr-type whole-batch verification on a short-Weierstrass curve as one multi-scalar multiplication (EcamdMsmArgs in
+// ecamd_internal.h; BIP0340's and ECFSDSA's batch equation, sig/bip0340.c:905-1196, sig/ecfsdsa.c:1042-): per piece of at most
+// max_chunk items   k_msm_scal (z_i, z_i (q - e_i), z_i s_i mod q)  ->  k_msm_vsum (c = sum z_i s_i)  ->  [c]G by the handle's
+// fixed-base path  ->  k_msm_table_g (2n window tables)  ->  k_msm_loop_g (Straus, K items per lane)  ->  k_msm_sum_g / final.
+// ------------------------------------------------------------------------------------------
+static bool schnorr_msm_unit(const ecamd_curve *cv, int *pbits, int *flavour, int *slot)
+{
+	if (cv->gslot >= 0) {
+		*pbits = cv->pbits;
+		*flavour = cv->gflavour;
+		*slot = cv->gslot;
+		return true;
+	}
+	if (cv->is_p256 && cv->gpslot >= 0) {   // secp256r1: the dense 256-bit unit that serves its projective import
+		*pbits = 256;
+		*flavour = 0;
+		*slot = cv->gpslot;
+		return true;
+	}
+	return false;
+}
+
+static uint32_t schnorr_msm_pick_k(uint32_t n)
+{
+	if (const char *e = getenv("ECAMD_SCHNORR_MSM_K")) {
+		const uint32_t k = (uint32_t)strtoul(e, nullptr, 10);
+		if (k >= 1 && k <= 64) {
+			return k;
+		}
+	}
+	// two waves per SIMD need 131072 lanes; below that the shared doublings are worth more than the occupancy
+	uint32_t k = n >> 17;
+	if (k < 2) {
+		k = 2;
+	}
+	return k > 8 ? 8 : k;
+}
+
+static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_s, const uint8_t *d_ne, const uint8_t *d_keys,
+				  const uint8_t *d_r, int r_fmt, const uint8_t seed[32], uint32_t piece, uint8_t *d_verdict, uint8_t *d_z_dump,
+				  uint32_t *d_sum_dump, hipStream_t s)
+{
+	int pbits = 0, flav = 0, gslot = -1;
+	if (!schnorr_msm_unit(cv, &pbits, &flav, &gslot) || cv->qslot < 0) {
+		return fail("internal: Schnorr multi-scalar multiplication without a radix-2^29 unit");
+	}
+	const uint32_t K = schnorr_msm_pick_k(n);
+	const uint32_t L = (n + K - 1) / K;
+	const size_t itemw = ecamd_g29_table_words(pbits, flav), recw = ecamd_g29_msm_rec_words(pbits, flav);
+	const size_t cl = (size_t)cv->clen, ql = (size_t)cv->qlen, qnw = (size_t)cv->qnw;
+	size_t off = 0;
+	auto carve = [&](size_t bytes) {
+		const size_t o = off;
+		off += msm_align(bytes);
+		return o;
+	};
+	const size_t o_tbl = carve((size_t)2 * n * itemw * 4);
+	const size_t o_rec = carve((size_t)L * recw * 4), o_tmp = carve(((size_t)L / 16 + 2) * recw * 4);
+	const size_t o_w = carve((size_t)n * ql), o_z = carve((size_t)n * 16), o_v = carve((size_t)n * qnw * 4);
+	const size_t o_v1 = carve(((size_t)n / 64 + 2) * qnw * 4), o_v2 = carve(((size_t)n / 4096 + 2) * qnw * 4);
+	const size_t o_c = carve(ql), o_gen = carve(2 * cl), o_gst = carve(4), o_word = carve(4);
+	if (ensure(&ctx->msm, &ctx->msm_bytes, off)) {
+		return -1;
+	}
+	uint8_t *M = ctx->msm;
+	HIPCHK(hipMemsetAsync(M + o_word, 0, 4, s));
+	EcamdMsmScalArgs C;
+	memset(&C, 0, sizeof(C));
+	C.s = d_s;
+	C.ne = d_ne;
+	C.scW = M + o_w;
+	C.scZ = M + o_z;
+	C.v = (uint32_t *)(M + o_v);
+	C.flagword = (uint32_t *)(M + o_word);
+	C.z_dump = d_z_dump;
+	memcpy(C.seed, seed, 32);
+	C.nonce[0] = piece;
+	C.nonce[1] = 0x5343484eu;   // "SCHN": another stream than the Ed25519 combination's under the same seed
+	C.n = n;
+	C.qlen = (uint32_t)ql;
+	C.qslot = cv->qslot;
+	HIPCHK(ecamd_launch_msm_scal(cv->qnw, C, s));
+	{
+		// c = sum v_i mod q: levels of fan-in 64, the last one writes the big-endian bytes
+		EcamdMsmVsumArgs V;
+		memset(&V, 0, sizeof(V));
+		V.qlen = (uint32_t)ql;
+		V.qslot = cv->qslot;
+		const uint32_t *src = (const uint32_t *)(M + o_v);
+		uint32_t *bufs[2] = {(uint32_t *)(M + o_v1), (uint32_t *)(M + o_v2)};
+		uint32_t count = n;
+		int b = 0;
+		do {
+			const uint32_t outc = (count + 63) / 64;
+			V.in = src;
+			V.out = bufs[b];
+			V.count = count;
+			V.c_be = outc == 1 ? M + o_c : nullptr;
+			HIPCHK(ecamd_launch_msm_vsum(cv->qnw, V, s));
+			src = bufs[b];
+			b ^= 1;
+			count = outc;
+		} while (count > 1);
+	}
+	// [c]G from the handle's own fixed-base path, one item, device pointers (the comb table is built for a batch of this size: without
+	// it the single item would walk the whole window loop alone, a millisecond of latency)
+	maybe_build_comb(ctx, const_cast<ecamd_curve *>(cv), n);
+	if (smul_dev_locked(ctx, cv, 1, M + o_c, (uint32_t)ql, nullptr, M + o_gen, M + o_gst, s, 0xffffffffu, false, nullptr)) {
+		return -1;
+	}
+	EcamdMsmArgs A;
+	memset(&A, 0, sizeof(A));
+	A.ptsY = d_keys;
+	A.ptsR = d_r;
+	A.scW = M + o_w;
+	A.scZ = M + o_z;
+	A.tbl = (uint32_t *)(M + o_tbl);
+	A.rec = (uint32_t *)(M + o_rec);
+	A.flagword = (uint32_t *)(M + o_word);
+	A.n = n;
+	A.K = K;
+	A.L = L;
+	A.clen = (uint32_t)cl;
+	A.wlen = (uint32_t)ql;
+	A.zlen = 16;
+	A.r_fmt = (uint32_t)r_fmt;
+	for (int phase = 0; phase < 3; phase++) {
+		HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, phase, A, (uint32_t *)(M + o_tmp), M + o_gen, M + o_gst, d_verdict, d_sum_dump, s));
+	}
+	return 0;
+}
+
+static int schnorr_args_ok(const char *fn, ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const void *a, const void *b, const void *c,
+			   const void *d, int r_fmt, const void *out)
+{
+	if (!ctx || !cv || cv->ctx != ctx || !out || n == 0 || !a || !b || !c || !d || (r_fmt != 0 && r_fmt != 1)) {
+		return fail(std::string(fn) + ": bad argument (the reference rejects num = 0 too)");
+	}
+	return 0;
+}
+
+// 1: the multi-scalar form can serve this handle (a radix-2^29 unit; q usable as a modulus of at least 160 bits; for r_fmt 1, p = 3 mod 4)
+static bool schnorr_msm_available(const ecamd_curve *cv, int r_fmt)
+{
+	int pb, fl, sl;
+	if (!schnorr_msm_unit(cv, &pb, &fl, &sl) || cv->qslot < 0 || cv->qbits < 160 || (uint32_t)cv->qlen < 16u) {
+		return false;
+	}
+	if (r_fmt == 1 && (cv->p[0] & 3u) != 3u) {
+		return false;
+	}
+	return true;
+}
+
+static int schnorr_msm_host_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *sv, const uint8_t *ne, const uint8_t *keys,
+				   const uint8_t *r, int r_fmt, const uint8_t *fixed_seed, int *accept, uint8_t *z_out, uint32_t *sum_out)
+{
+	uint8_t seed[32];
+	if (fixed_seed) {
+		memcpy(seed, fixed_seed, 32);
+	} else if (msm_seed(ctx, seed)) {
+		return -1;
+	}
+	hipStream_t s = ctx->stream;
+	StreamScope scope(ctx, s);
+	PublicScalars pub_scope(ctx);   // everything a verification multiplies by is public
+	const size_t cl = (size_t)cv->clen, ql = (size_t)cv->qlen, rl = r_fmt ? cl : 2 * cl;
+	const uint32_t chunk = n < ctx->max_chunk ? n : ctx->max_chunk;
+	const uint32_t pieces = (n + chunk - 1) / chunk;
+	int pb, fl, sl;
+	(void)schnorr_msm_unit(cv, &pb, &fl, &sl);
+	const size_t recw = ecamd_g29_msm_rec_words(pb, fl);
+	if (ensure(&ctx->stage[0], &ctx->stage_bytes[0], (size_t)chunk * ql) || ensure(&ctx->stage[1], &ctx->stage_bytes[1], (size_t)chunk * ql) ||
+	    ensure(&ctx->stage[2], &ctx->stage_bytes[2], (size_t)chunk * 2 * cl) || ensure(&ctx->stage[4], &ctx->stage_bytes[4], (size_t)chunk * rl) ||
+	    ensure(&ctx->stage[3], &ctx->stage_bytes[3], (size_t)pieces + (z_out ? (size_t)chunk * 16 : 0) + 512 + recw * 4)) {
+		return -1;
+	}
+	uint8_t *d_verdicts = ctx->stage[3];
+	HIPCHK(hipMemsetAsync(d_verdicts, 1, pieces, s));
+	uint32_t *d_sum = (uint32_t *)(ctx->stage[3] + ((pieces + 255) & ~(size_t)255));
+	uint8_t *d_z = z_out ? (uint8_t *)(d_sum + recw) : nullptr;
+	for (uint32_t off = 0, pc = 0; off < n; off += chunk, pc++) {
+		const uint32_t m = (n - off) < chunk ? (n - off) : chunk;
+		HIPCHK(hipMemcpyAsync(ctx->stage[0], sv + (size_t)off * ql, (size_t)m * ql, hipMemcpyHostToDevice, s));
+		HIPCHK(hipMemcpyAsync(ctx->stage[1], ne + (size_t)off * ql, (size_t)m * ql, hipMemcpyHostToDevice, s));
+		HIPCHK(hipMemcpyAsync(ctx->stage[2], keys + (size_t)off * 2 * cl, (size_t)m * 2 * cl, hipMemcpyHostToDevice, s));
+		HIPCHK(hipMemcpyAsync(ctx->stage[4], r + (size_t)off * rl, (size_t)m * rl, hipMemcpyHostToDevice, s));
+		if (schnorr_msm_dev_locked(ctx, cv, m, ctx->stage[0], ctx->stage[1], ctx->stage[2], ctx->stage[4], r_fmt, seed, pc, d_verdicts + pc, d_z,
+					   sum_out ? d_sum : nullptr, s)) {
+			(void)hipStreamSynchronize(s);
+			return -1;
+		}
+		if (z_out) {
+			HIPCHK(hipMemcpyAsync(z_out + (size_t)off * 16, d_z, (size_t)m * 16, hipMemcpyDeviceToHost, s));
+		}
+	}
+	std::vector<uint8_t> v(pieces, 1);
+	HIPCHK(hipMemcpyAsync(v.data(), d_verdicts, pieces, hipMemcpyDeviceToHost, s));
+	if (sum_out) {
+		HIPCHK(hipMemcpyAsync(sum_out, d_sum, recw * 4, hipMemcpyDeviceToHost, s));
+	}
+	HIPCHK(hipStreamSynchronize(s));
+	memset(seed, 0, sizeof(seed));
+	*accept = 1;
+	for (uint32_t pc = 0; pc < pieces; pc++) {
+		if (v[pc] != 0) {
+			*accept = 0;
+		}
+	}
+	return 0;
+}
+
+extern "C" int ec_schnorr_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *s, const uint8_t *ne,
+					   const uint8_t *keys_aff, const uint8_t *r, int r_fmt, int *all_valid)
+{
+	if (schnorr_args_ok("ec_schnorr_verify_all_batch", ctx, cv, n, s, ne, keys_aff, r, r_fmt, all_valid)) {
+		return -1;
+	}
+	*all_valid = 0;
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	if (!schnorr_msm_available(cv, r_fmt)) {
+		return 0;   // not decided here: the caller verifies item by item
+	}
+	return schnorr_msm_host_locked(ctx, cv, n, s, ne, keys_aff, r, r_fmt, nullptr, all_valid, nullptr, nullptr);
+}
+
+extern "C" uint32_t ecamd_debug_schnorr_msm_words(const ecamd_curve *cv)
+{
+	int pb, fl, sl;
+	return (cv && schnorr_msm_unit(cv, &pb, &fl, &sl)) ? ecamd_g29_msm_rec_words(pb, fl) : 0u;
+}
+
+extern "C" int ec_schnorr_verify_all_available(const ecamd_curve *cv, int r_fmt) { return (cv && schnorr_msm_available(cv, r_fmt)) ? 1 : 0; }
+
+// test hook: the combination with a caller-chosen seed; z_out (n x 16 little-endian) and sum_out (the lanes' Jacobian sum: X, Y, Z digits
+// of the unit and an "is infinity" word, ecamd_debug_schnorr_msm_words() words) may be NULL
+extern "C" int ecamd_debug_schnorr_msm(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *s, const uint8_t *ne, const uint8_t *keys_aff,
+				       const uint8_t *r, int r_fmt, const uint8_t seed[32], int *accept, uint8_t *z_out, uint32_t *sum_out)
+{
+	if (schnorr_args_ok("ecamd_debug_schnorr_msm", ctx, cv, n, s, ne, keys_aff, r, r_fmt, accept) || !seed) {
+		return -1;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	HIPCHK(hipSetDevice(ctx->device));
+	if (n > ctx->max_chunk || !schnorr_msm_available(cv, r_fmt)) {
+		return fail("ecamd_debug_schnorr_msm: needs a radix-2^29 unit for the curve and 0 < n <= max_chunk");
+	}
+	return schnorr_msm_host_locked(ctx, cv, n, s, ne, keys_aff, r, r_fmt, seed, accept, z_out, sum_out);
+}
+
 static void msm_seed_discard(ecamd_ctx *ctx);
 static int eddsa_verify_all_batch_dev_impl(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const void *d_pubkeys,
 					     const void *d_sigs, const void *d_hram, uint32_t hram_len, void *d_verdict,

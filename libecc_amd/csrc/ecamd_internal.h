@@ -253,6 +253,54 @@ struct EcamdEdMsmLaneArgs {
 	int qslot;
 };
 hipError_t ecamd_launch_edmsm_scal(const EcamdEdMsmScalArgs &a, hipStream_t s);
+// ------------------------------------------------------------------------------------------
+// Schnorr-type whole-batch verification on a short-Weierstrass curve as ONE multi-scalar multiplication (BIP0340's and ECFSDSA's
+// batch equation, sig/bip0340.c:905-1196, sig/ecfsdsa.c:1042-): with random z_i
+//     T = [sum z_i s_i]G + sum_i ([z_i (q - e_i) mod q]Y_i - [z_i]R_i),        accepted when T is the point at infinity.
+// Straus evaluation on the radix-2^29 unit of the curve (k_msm_*_g in ecamd_g29_kernel.hip): the 2n points get signed 4-bit
+// window tables [1..8]P (Jacobian entries); lane l owns the items j * L + l (j < K) and shares the doublings between their 2K
+// points -- the z_i are 128 bits, so the R_i only take part in the low 33 windows; the lanes' sums are added by a tree; the
+// generator's term comes from the comb table of the handle.  Every exceptional event (a point that does not import, a table
+// multiple at infinity, an addition of equal or opposite points, s >= q) sets a bit of *flagword and the verdict is "not
+// decided here" = 1: the caller then verifies item by item, so the batch form never decides anything the item form would not.
+// ------------------------------------------------------------------------------------------
+struct EcamdMsmArgs {
+	const uint8_t *ptsY, *ptsR;  // n x 2*clen affine X || Y big-endian: the keys, the signatures' points (r_fmt 1: n x clen, x only)
+	const uint8_t *scW, *scZ;    // n x wlen / n x zlen big-endian: z_i (q - e_i) mod q, z_i
+	uint32_t *tbl;               // 2n x ecamd_g29_table_words: tables and recoded scalars (Y items first, then R items)
+	uint32_t *rec;               // L x ecamd_g29_msm_rec_words: the lanes' sums (Jacobian X, Y, Z and an "is infinity" word)
+	uint32_t *flagword;
+	uint32_t n, K, L, clen, wlen, zlen;
+	uint32_t r_fmt;              // 1: R_i is the point with the given x and an EVEN y (BIP0340's lift_x, sig/bip0340.c:532-535 / :947-953);
+	                             //    p = 3 mod 4 only (the host checks): y = (x^3 + a x + b)^((p + 1) / 4)
+};
+// scalars of the combination (mod q, saturated unit of the order's size): z_i = 128 bits of ChaCha20(seed; counter = item)
+struct EcamdMsmScalArgs {
+	const uint8_t *s, *ne;       // n x qlen big-endian: s_i, q - e_i (both must be < q)
+	uint8_t *scW, *scZ;          // n x qlen, n x 16 big-endian (outputs)
+	uint32_t *v;                 // n x NW words: z_i s_i mod q
+	uint32_t *flagword;          // bit 2: some s_i or q - e_i is not below q
+	uint8_t *z_dump;             // may be NULL: n x 16 little-endian z_i (tests)
+	uint32_t seed[8], nonce[3];
+	uint32_t n, qlen;
+	int qslot;
+};
+struct EcamdMsmVsumArgs {
+	const uint32_t *in;          // count x NW words, values < q
+	uint32_t *out;               // ceil(count / 64) x NW words
+	uint8_t *c_be;               // last level only: the sum, qlen bytes big-endian
+	uint32_t count, qlen;
+	int qslot;
+};
+hipError_t ecamd_launch_msm_scal(int nw, const EcamdMsmScalArgs &a, hipStream_t s);
+hipError_t ecamd_launch_msm_vsum(int nw, const EcamdMsmVsumArgs &a, hipStream_t s);
+uint32_t ecamd_g29_msm_rec_words(int pbits, int flavour);
+// phase 0: tables of the 2n points; 1: the Straus loop; 2: the tree sum and the verdict (tmp: ceil(L / 16) records;
+// gen: [sum z_i s_i]G affine, 2*clen bytes big-endian, gen_status its status byte; verdict[0] = 0 accept / 1 not decided here;
+// sum_out may be NULL: the sum of the lanes, ecamd_g29_msm_rec_words words)
+hipError_t ecamd_launch_msm_g29(int pbits, int gslot, int flavour, int phase, const EcamdMsmArgs &a, uint32_t *tmp, const uint8_t *gen,
+				const uint8_t *gen_status, uint8_t *verdict, uint32_t *sum_out, hipStream_t s);
+
 hipError_t ecamd_launch_edmsm_lane(const EcamdEdMsmLaneArgs &a, hipStream_t s);
 struct EcamdEdScalArgs {
 	const uint8_t *sigs;     // n x 2*len: R || S

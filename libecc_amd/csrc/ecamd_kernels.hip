@@ -1023,6 +1023,85 @@ template <int NW> __global__ __launch_bounds__(64) void k_edmsm_lane(EcamdEdMsmL
 	}
 }
 
+// ------------------------------------------------------------------------------------------
+// Scalars of the Schnorr-type batch equation (EcamdMsmScalArgs; the multi-scalar multiplication itself is k_msm_*_g of
+// ecamd_g29_kernel.hip): z_i = 128 bits of ChaCha20(seed; counter = item) -- the reference keys ChaCha20 with a hash of the batch
+// (sig/bip0340.c:688-760) or draws the z_i with get_random (sig/ecfsdsa.c); any unpredictable z_i decide the same batches --,
+// w_i = z_i (q - e_i) mod q and z_i as big-endian strings for the table kernel, v_i = z_i s_i mod q for the generator's term.
+// ------------------------------------------------------------------------------------------
+template <int NW> __global__ __launch_bounds__(64) void k_msm_scal(EcamdMsmScalArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const int qs = A.qslot;
+	const CurveK<NW> &Q = ConstTab<NW>::get(qs);
+	const int ql = (int)A.qlen;
+	const Fe<NW> sv = fe_load_be<NW>(A.s + (size_t)i * ql, ql);
+	const Fe<NW> ne = fe_load_be<NW>(A.ne + (size_t)i * ql, ql);
+	if (!(fe_lt_p<NW>(sv, qs) & fe_lt_p<NW>(ne, qs))) {
+		atomicOr(A.flagword, 8u);
+	}
+	u32 z4[4];
+	chacha20_block4(A.seed, i, A.nonce, z4);
+	if ((z4[0] | z4[1] | z4[2] | z4[3]) == 0u) {
+		z4[0] = 1u;
+	}
+	static_assert(NW >= 5, "the 128-bit z_i must be residues: orders of at least 160 bits");
+	Fe<NW> z = fe_zero<NW>();
+#pragma unroll
+	for (int w = 0; w < 4; w++) {
+		z.v[w] = z4[w];
+	}
+	const Fe<NW> zR = fe_mul<NW>(z, fe_const<NW>(Q.r2), qs);   // z in Montgomery form
+	const Fe<NW> w = fe_mul<NW>(zR, ne, qs);                    // z (q - e) mod q, plain
+	const Fe<NW> v = fe_mul<NW>(zR, sv, qs);                    // z s mod q, plain
+	fe_store_be<NW>(A.scW + (size_t)i * ql, ql, w);
+	u8 *zb = A.scZ + (size_t)i * 16;
+#pragma unroll
+	for (int b = 0; b < 16; b++) {
+		zb[15 - b] = (u8)(z4[b >> 2] >> (8 * (b & 3)));
+	}
+#pragma unroll
+	for (int k = 0; k < NW; k++) {
+		A.v[(size_t)i * NW + k] = v.v[k];
+	}
+	if (A.z_dump != nullptr) {
+#pragma unroll
+		for (int b = 0; b < 16; b++) {
+			A.z_dump[(size_t)i * 16 + b] = zb[15 - b];
+		}
+	}
+}
+
+// one level of the sum of the v_i mod q (fan-in 64); the last level also writes the sum as qlen big-endian bytes
+template <int NW> __global__ __launch_bounds__(64) void k_msm_vsum(EcamdMsmVsumArgs A)
+{
+	const u32 t = blockIdx.x * 64 + threadIdx.x;
+	const u32 first = t * 64u;
+	if (first >= A.count) {
+		return;
+	}
+	const int qs = A.qslot;
+	Fe<NW> sum = fe_zero<NW>();
+	for (u32 k = first; k < first + 64u && k < A.count; k++) {
+		Fe<NW> x;
+#pragma unroll
+		for (int w = 0; w < NW; w++) {
+			x.v[w] = A.in[(size_t)k * NW + w];
+		}
+		sum = fe_add<NW>(sum, x, qs);
+	}
+#pragma unroll
+	for (int w = 0; w < NW; w++) {
+		A.out[(size_t)t * NW + w] = sum.v[w];
+	}
+	if (A.c_be != nullptr && t == 0) {
+		fe_store_be<NW>(A.c_be, (int)A.qlen, sum);
+	}
+}
+
 template <int NW> static __device__ __forceinline__ Pt<NW> ed_load_neg(const u8 *src, u32 st, int clen, bool neg, int slot)
 {
 	Pt<NW> P;
@@ -1973,6 +2052,37 @@ hipError_t ecamd_launch_rand_mod(int qnw, const EcamdRandModArgs &a, hipStream_t
 	const dim3 grid((a.n + 63) / 64), block(64);
 	switch (qnw) {
 #define X(N) case N: hipLaunchKernelGGL(k_rand_mod<N>, grid, block, 0, s, a); break;
+		ECAMD_FOR_NW(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_msm_scal(int nw, const EcamdMsmScalArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	const dim3 grid((a.n + 63) / 64), block(64);
+	switch (nw) {
+#define X(N) case N: hipLaunchKernelGGL(k_msm_scal<N>, grid, block, 0, s, a); break;
+		ECAMD_FOR_NW(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_msm_vsum(int nw, const EcamdMsmVsumArgs &a, hipStream_t s)
+{
+	if (a.count == 0) {
+		return hipSuccess;
+	}
+	const uint32_t threads = (a.count + 63) / 64;
+	const dim3 grid((threads + 63) / 64), block(64);
+	switch (nw) {
+#define X(N) case N: hipLaunchKernelGGL(k_msm_vsum<N>, grid, block, 0, s, a); break;
 		ECAMD_FOR_NW(X)
 #undef X
 	default: return hipErrorInvalidValue;

@@ -457,6 +457,32 @@ extern "C" int ecamd_multi_eddsa_verify_all_batch(ecamd_multi *m, const ecamd_mc
 	return 0;
 }
 
+// ec_verify_batch's one bit for the Schnorr-type algorithms, sharded: every device decides its shard with a combination of its own
+// (rank r keys it with seed ^ r, ecamd_multi_set_msm_seed); the batch is valid when every shard is
+extern "C" int ecamd_multi_schnorr_verify_all_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *s, const uint8_t *ne,
+						    const uint8_t *keys_aff, const uint8_t *r, int r_fmt, int *all_valid)
+{
+	if (!all_valid || n == 0) {
+		return mfail("ecamd_multi_schnorr_verify_all_batch: bad argument (the reference rejects num = 0 too)");
+	}
+	*all_valid = 0;
+	const size_t cl = (size_t)ecamd_multi_curve_coord_len(c), ql = (size_t)ecamd_multi_curve_order_len(c), rl = r_fmt ? cl : 2 * cl;
+	const int N = m ? (int)m->ctx.size() : 0;
+	std::vector<int> ok((size_t)(N > 0 ? N : 1), 1);
+	if (run_sharded(m, c, n, "ecamd_multi_schnorr_verify_all_batch", [&](int rk, uint32_t lo, uint32_t hi) {
+		    return ec_schnorr_verify_all_batch(m->ctx[(size_t)rk], c->cv[(size_t)rk], hi - lo, OFF(s, ql), OFF(ne, ql), OFF(keys_aff, 2 * cl), OFF(r, rl), r_fmt,
+						       &ok[(size_t)rk]);
+	    })) {
+		return -1;
+	}
+	int all = 1;
+	for (int rk = 0; rk < N; rk++) {
+		all = all && ok[(size_t)rk];
+	}
+	*all_valid = all;
+	return 0;
+}
+
 extern "C" int ecamd_multi_prj_pt_add_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *p1_aff, const uint8_t *p2_aff,
 					    uint8_t *out_aff, uint8_t *status)
 {

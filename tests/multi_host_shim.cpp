@@ -159,6 +159,12 @@ int ec_eddsa_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *, uint32_t n, c
 	*first_rejected = bad ? (g_bad_item < n ? g_bad_item : n - 1) : n;
 	return rec(__func__, ctx, n, {pubkeys, sigs, hram}, {hram_len});
 }
+int ec_schnorr_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *, uint32_t n, const uint8_t *s, const uint8_t *ne, const uint8_t *keys_aff,
+				const uint8_t *r, int r_fmt, int *all_valid)
+{
+	*all_valid = ((g_bad_mask >> ctx->rank) & 1u) ? 0 : 1;
+	return rec(__func__, ctx, n, {s, ne, keys_aff, r}, {r_fmt});
+}
 int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs, const uint8_t *hram,
 			  uint32_t hram_len, uint8_t *result)
 {

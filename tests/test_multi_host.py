@@ -182,6 +182,34 @@ def test_verify_all_combines_shard_verdicts(lib, curve, nranks):
     lib.ecamd_multi_destroy(m)
 
 
+@pytest.mark.parametrize("curve", ["SECP256R1", "SECP224K1", "SECP521R1"])
+@pytest.mark.parametrize("nranks", [1, 2, 3, 8])
+def test_schnorr_verify_all_shards_and_combines(lib, curve, nranks):
+    """ecamd_multi_schnorr_verify_all_batch: s, q - e by the order's length, keys by 2 clen, r by 2 clen (points) or clen (abscissae);
+    valid only when every shard is"""
+    cl, ql = CURVES[curve]
+    m, mc = make_multi(lib, nranks, curve)
+    n = 1001
+    bounds = shard_bounds(n, nranks)
+    for r_fmt in (0, 1):
+        for mask in (0, 1, 1 << (nranks - 1)):
+            lib.mh_set_bad(mask, 0)
+            sv, ne, ky, rr = Arr(ql), Arr(ql), Arr(2 * cl), Arr(cl if r_fmt else 2 * cl)
+            ok = C.c_int(-7)
+            before = lib.mh_count()
+            assert lib.ecamd_multi_schnorr_verify_all_batch(m, mc, u32(n), sv.arg, ne.arg, ky.arg, rr.arg, C.c_int(r_fmt), C.byref(ok)) == 0
+            recs = records(lib)[before:]
+            assert sorted(r[1] for r in recs) == list(range(nranks))
+            for rfn, rank, rn, ptrs, ints in recs:
+                lo, hi = bounds[rank]
+                assert rfn == "ec_schnorr_verify_all_batch" and rn == hi - lo and ints == [r_fmt]
+                assert ptrs == [a.base + lo * a.item for a in (sv, ne, ky, rr)]
+            assert ok.value == (0 if mask else 1)
+    ok = C.c_int(1)
+    assert lib.ecamd_multi_schnorr_verify_all_batch(m, mc, u32(0), None, None, None, None, C.c_int(0), C.byref(ok)) == -1
+    lib.mh_set_bad(0, 0)
+
+
 def test_error_of_one_rank_fails_the_call_and_names_the_rank(lib):
     m, mc = make_multi(lib, 3, "SECP256R1")
     lib.mh_set_fail_rank(1)
