@@ -1133,6 +1133,10 @@ int main(int argc, char **argv)
 		check_sign("WEI25519", EDDSA25519, SHA512, "EDDSA25519", qn, 1);
 		check_keys("SECP256R1", ECDSA, "ECDSA/SECP256R1", qn);
 		check_xdh(32, qn);
+		check_verify("SECP256K1", BIP0340, SHA256, "BIP0340/SECP256K1/SHA256", qn, 1);
+		check_verify("SECP256R1", ECFSDSA, SHA256, "ECFSDSA/SECP256R1/SHA256", qn < 128 ? qn : 128, 1);
+		check_verify("BRAINPOOLP384R1", ECFSDSA, SHA384, "ECFSDSA/BRAINPOOLP384R1/SHA384", qn < 64 ? qn : 64, 1);
+		printf("schnorr multi-scalar calls: %lu\n", ecamd_compat_schnorr_msm_calls());
 		ecamd_compat_shutdown();
 		CHECK(!g_rand_expect_serial || g_rand_overlaps == 0, "get_random entered concurrently %d times", g_rand_overlaps);
 		printf(failures ? "compat_check: %d FAILURES\n" : "compat_check: all ok (%d failures)\n", failures);
@@ -1201,6 +1205,7 @@ int main(int argc, char **argv)
 	/* an algorithm the GPU does not take goes to libecc's own verifier (no batch form there: -1) */
 	check_verify("SECP256R1", ECKCDSA, SHA256, "ECKCDSA (no batch form)", n < 16 ? n : 16, -1);
 	printf("items sent to the GPU: %llu\n", ecamd_compat_gpu_items());
+	printf("schnorr multi-scalar calls: %lu\n", ecamd_compat_schnorr_msm_calls());
 	if (!ecamd_compat_gpu_items()) {
 		failures++;
 	}

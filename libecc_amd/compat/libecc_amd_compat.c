@@ -3548,6 +3548,7 @@ typedef struct {
 	int fs;                  /* 0: BIP0340, 1: ECFSDSA */
 	u8 *kaff, *kst, *sc_s, *sc_e, *pA, *stA, *pB, *stB, *sum, *stS;
 	u8 *wpt, *wst, *kinf;    /* ECFSDSA: the signatures' points W (validated on the device), their status; keys at infinity */
+	u8 *rx;                  /* BIP0340: the signatures' r, n x clen (the abscissae of the multi-scalar form) */
 	u8 p_be[80], q_be[80], tagd[MAX_DIGEST_SIZE];
 } bip_job;
 
@@ -3621,9 +3622,15 @@ static void bip_pack(u32 lo, u32 hi, void *arg)
 			memset(B->sc_s + (size_t)j * ql, 0, ql);
 			memset(B->sc_e + (size_t)j * ql, 0, ql);
 			memset(Y, 0xff, (size_t)2 * cl);
+			if (!B->fs) {
+				memset(B->rx + (size_t)j * cl, 0xff, cl);
+			}
 			continue;
 		}
 		memcpy(B->sc_s + (size_t)j * ql, sig + rl, ql);
+		if (!B->fs) {
+			memcpy(B->rx + (size_t)j * cl, sig, cl);
+		}
 		if (B->fs && B->kinf[j]) {
 			memcpy(Y, B->wpt + (size_t)j * 2 * cl, (size_t)2 * cl);   /* any valid point: the product is not used */
 		}
@@ -3687,6 +3694,24 @@ static void fs_export_w(u32 lo, u32 hi, void *arg)
 	}
 }
 
+/* the multi-scalar form pays from about 2^17 items per device on (profiles/r5b_schnorr_msm.md); $ECAMD_COMPAT_SCHNORR_MSM_MIN moves the
+ * threshold (items per device; 0 = never) */
+static unsigned long g_schnorr_msm_calls;
+unsigned long ecamd_compat_schnorr_msm_calls(void) { return AT_LOAD(&g_schnorr_msm_calls); }
+static int schnorr_msm_wanted(u32 cnt)
+{
+	unsigned long min_items = 1ul << 17;
+	const char *e = getenv("ECAMD_COMPAT_SCHNORR_MSM_MIN");
+	const int ranks = ecamd_multi_size(g_multi);
+	if (e) {
+		min_items = strtoul(e, NULL, 10);
+		if (min_items == 0) {
+			return 0;
+		}
+	}
+	return ranks > 0 && (unsigned long)cnt / (unsigned long)ranks >= min_items;
+}
+
 static int schnorr_group(ver_job *J0, u32 cnt, int *results, int fs)
 {
 	bip_job B;
@@ -3719,9 +3744,10 @@ static int schnorr_group(ver_job *J0, u32 cnt, int *results, int fs)
 	B.wpt = buf_get(12, fs ? (size_t)cnt * 2 * J->clen : 1);
 	B.wst = buf_get(13, cnt);
 	B.kinf = buf_get(14, cnt);
+	B.rx = buf_get(15, fs ? 1 : (size_t)cnt * J->clen);
 	J->res = B.stS;   /* the verdicts overwrite the sum's status, read just before */
 	if (!J->kprj || !B.kaff || !B.kst || !B.sc_s || !B.sc_e || !B.pA || !B.stA || !B.pB || !B.stB || !B.sum || !B.stS || !J->pre || !B.wpt ||
-	    !B.wst || !B.kinf) {
+	    !B.wst || !B.kinf || !B.rx) {
 		return -1;
 	}
 	/* everything a verification multiplies by is public: digit-indexed look-ups and the generator's comb table */
@@ -3740,6 +3766,49 @@ static int schnorr_group(ver_job *J0, u32 cnt, int *results, int fs)
 		}
 	}
 	parallel_for(cnt, bip_pack, &B);
+	/* The whole batch as ONE multi-scalar multiplication first (sig/bip0340.c:905-1010, sig/ecfsdsa.c:1042-: the reference's own batch
+	 * equation; include/libecc_amd.h: ec_schnorr_verify_all_batch) when every item passed its pre-checks and the shards are large enough
+	 * for it to pay (profiles/r5b_schnorr_msm.md): it vouches for a VALID batch; anything else -- a bad signature, an abscissa without
+	 * a point, an exceptional addition -- comes back "not decided" and the item-by-item pass below gives the verdict, as the reference's
+	 * own fall-back does.  ECFSDSA keys the combination through the application's get_random, the import the reference draws its a_i
+	 * from (nn_get_random_mod, sig/ecfsdsa.c:960); BIP0340's reference takes no randomness (a ChaCha20 stream keyed by a hash of the
+	 * batch, sig/bip0340.c:758-860): there the engine keys its z_i with getrandom. */
+	if (schnorr_msm_wanted(cnt)) {
+		int all = 0, clean = 1;
+		for (j = 0; j < cnt && clean; j++) {
+			clean = !J->pre[j] && !(fs && B.kinf[j]);
+		}
+		if (clean && fs) {
+			u8 seed[32];
+			int r;
+			if (AT_LOAD(&g_rand_concurrent)) {
+				r = get_random(seed, sizeof(seed));
+			} else {
+				pthread_mutex_lock(&g_rand_mu);
+				r = get_random(seed, sizeof(seed));
+				pthread_mutex_unlock(&g_rand_mu);
+			}
+			r = r || ecamd_multi_set_msm_seed(g_multi, seed);
+			wipe(seed, sizeof(seed));
+			if (r) {
+				goto gpu_err;
+			}
+		}
+		if (clean) {
+			if (ecamd_multi_schnorr_verify_all_batch(g_multi, J->e->mc, cnt, B.sc_s, B.sc_e, B.kaff, fs ? B.wpt : B.rx, fs ? 0 : 1, &all)) {
+				goto gpu_err;
+			}
+			AT_ADD(&g_schnorr_msm_calls, 1);
+			if (all) {
+				note_items(cnt);
+				for (j = 0; j < cnt; j++) {
+					results[J->idx[j]] = 0;
+				}
+				ret = 0;
+				goto done;
+			}
+		}
+	}
 	if (ecamd_multi_prj_pt_mul_batch(g_multi, J->e->mc, cnt, B.sc_s, J->qlen, NULL, B.pA, B.stA) ||
 	    ecamd_multi_prj_pt_mul_batch(g_multi, J->e->mc, cnt, B.sc_e, J->qlen, B.kaff, B.pB, B.stB) ||
 	    ecamd_multi_prj_pt_add_batch(g_multi, J->e->mc, cnt, B.pA, B.pB, B.sum, B.stS)) {

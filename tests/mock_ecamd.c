@@ -406,6 +406,46 @@ int ecamd_multi_eddsa_verify_all_batch(ecamd_multi *m, const ecamd_mcurve *c, ui
 	return r;
 }
 
+/* the Schnorr-type whole-batch predicate as the exact conjunction of the item form ([s]G + [ne]Y = R; r_fmt 1: same x and an even y) */
+int ecamd_multi_schnorr_verify_all_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *s, const uint8_t *ne, const uint8_t *keys_aff,
+					 const uint8_t *r, int r_fmt, int *all_valid)
+{
+	const u32 cl = (u32)c->c.clen, ql = (u32)c->c.qlen;
+	uint8_t *A = malloc((size_t)n * 2 * cl + 1), *B = malloc((size_t)n * 2 * cl + 1), *W = malloc((size_t)n * 2 * cl + 1);
+	uint8_t *sa = malloc(n + 1), *sb = malloc(n + 1), *sw = malloc(n + 1);
+	uint32_t i;
+	int rc;
+	(void)m;
+	note(n);
+	*all_valid = 0;
+	if (!A || !B || !W || !sa || !sb || !sw) {
+		free(A); free(B); free(W); free(sa); free(sb); free(sw);
+		return mfail("mock: out of memory");
+	}
+	rc = orc_scalar_mult_batch(&c->c, n, s, ql, NULL, A, sa) || orc_scalar_mult_batch(&c->c, n, ne, ql, keys_aff, B, sb) ||
+	     orc_pt_add_batch(&c->c, n, A, B, W, sw, 0);
+	if (!rc) {
+		int all = 1;
+		for (i = 0; i < n && all; i++) {
+			const uint8_t *w = W + (size_t)i * 2 * cl;
+			if (sa[i] == 1 || sb[i] == 1) {
+				all = 0;
+			} else if (sa[i] == 2 || sb[i] == 2) {
+				w = sa[i] == 2 ? B + (size_t)i * 2 * cl : A + (size_t)i * 2 * cl;
+				all = !(sa[i] == 2 && sb[i] == 2);
+			} else {
+				all = sw[i] == 0;
+			}
+			if (all) {
+				all = r_fmt ? (!memcmp(w, r + (size_t)i * cl, cl) && !(w[2 * cl - 1] & 1)) : !memcmp(w, r + (size_t)i * 2 * cl, (size_t)2 * cl);
+			}
+		}
+		*all_valid = all;
+	}
+	free(A); free(B); free(W); free(sa); free(sb); free(sw);
+	return rc;
+}
+
 /* eddsa_export_pub_key (sig/eddsa.c:970) on each point, through libecc itself */
 int ecamd_multi_eddsa_encode_point_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *points_prj, uint8_t *enc,
 					 uint8_t *status)

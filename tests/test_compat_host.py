@@ -65,6 +65,19 @@ def test_host_side_fallbacks_of_round_4():
     assert "all ok" in r.stdout
 
 
+def test_schnorr_batches_try_the_multi_scalar_form_first():
+    """BIP0340 / ECFSDSA behind ec_verify_batch with the threshold of the multi-scalar form lowered to one item: every batch whose items
+    pass their pre-checks asks ecamd_multi_schnorr_verify_all_batch first (the stand-in answers with the exact conjunction of the item
+    form); accepted batches end there, spoiled ones go on to the item-by-item pass and ec_verify_batch_results still matches ec_verify"""
+    _build()
+    r = _run(["quick", "60"], ECAMD_COMPAT_SCHNORR_MSM_MIN="1", ECAMD_COMPAT_THREADS="2")
+    assert r.returncode == 0, r.stdout[-4000:]
+    assert "all ok" in r.stdout and "ec_verify_batch BIP0340/SECP256K1" in r.stdout and "ec_verify_batch ECFSDSA/SECP256R1" in r.stdout
+    assert int(r.stdout.split("schnorr multi-scalar calls:")[1].split()[0]) >= 6, r.stdout[-600:]
+    r = _run(["quick", "60"], ECAMD_COMPAT_SCHNORR_MSM_MIN="0", ECAMD_COMPAT_THREADS="2")
+    assert r.returncode == 0 and int(r.stdout.split("schnorr multi-scalar calls:")[1].split()[0]) == 0
+
+
 def test_no_device_is_an_error_not_a_fallback():
     _build()
     r = _run(["8"], MOCK_ECAMD_NO_DEVICE="1")

@@ -442,7 +442,7 @@ def test_every_multi_entry_point_with_eight_ranks(gpu_ctx, curve):
             same("prj_pt_add_batch", [pts, pts[2 * cl:] + pts[:2 * cl], ("out", 2 * cl * n), ("out", n)], expect_ok=1)
             same("prj_pt_op_batch_fmt", [prj, prj[3 * cl:] + prj[:3 * cl], ci(1), ("out", 3 * cl * n), ci(1), ("out", n)], op=0, expect_ok=1)
             same("prj_pt_op_batch_fmt", [pts, None, ci(0), ("out", 2 * cl * n), ci(0), ("out", n)], op=1, expect_ok=1)
-            same("prj_pt_unprotected_mult_batch", [sc2, u32(ql), u32(ql + 5), prj, ci(1), ("out", 2 * cl * n), ci(0), ("out", n)], expect_ok=1)
+            same("prj_pt_unprotected_mult_batch", [sc, u32(ql), u32(ql), prj, ci(1), ("out", 2 * cl * n), ci(0), ("out", n)], expect_ok=1)
             raw = rand_bytes(rng, 2 * ql * n)
             privs, pubs, _ = same("key_pair_gen_raw_batch", [raw, ("out", ql * n), ("out", 2 * cl * n), ("out", n)], expect_ok=2)
             same("ecccdh_derive_batch", [privs, pts, ("out", cl * n), ("out", n)], expect_ok=1)

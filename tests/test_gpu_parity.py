@@ -1188,6 +1188,9 @@ COMPAT_RUNS = {
                                                 "ECAMD_HOST_RAMP_MIN": "16"}),
     # eight ranks on device 0, uneven shards (the driver's 8-GPU shape without the hardware)
     "eight_ranks": (["quick", "203"], {"ECAMD_DEVICES": "0,0,0,0,0,0,0,0"}),
+    # BIP0340 / ECFSDSA batches through the multi-scalar multiplication whatever their size (valid batches are decided by it, spoiled
+    # ones fall through to the item-by-item pass); three ranks
+    "schnorr_msm_forced": (["quick", "300"], {"ECAMD_COMPAT_SCHNORR_MSM_MIN": "1", "ECAMD_DEVICES": "0,0,0"}),
     # the paths round 4 left as fall-backs: host hashing, chunked calls, two-pass EdDSA, nn_get_random_mod on the host, the scanned
     # window loop for secret fixed-base multiplications, the saturated-word projective import
     "fallback_paths": (["quick", "150"], {"ECAMD_COMPAT_HOST_HASH": "1", "ECAMD_COMPAT_NO_STREAM": "1", "ECAMD_COMPAT_ED_TWO_PASS": "1",
@@ -1213,6 +1216,8 @@ def test_libecc_typed_boundary_vs_scalar_api(run):
     r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=1500, env=dict(os.environ, **extra))
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     assert "compat_check: all ok" in r.stdout and "FAILED" not in r.stdout and "MISMATCH" not in r.stdout
+    if run == "schnorr_msm_forced":
+        assert int(r.stdout.split("schnorr multi-scalar calls:")[1].split()[0]) >= 6, r.stdout[-600:]
     if run == "full_640":
         assert r.stdout.count(": ok") >= 48
         for row in ("ec_sign_batch ECDSA", "ec_sign_batch DECDSA", "ec_sign_batch EDDSA25519", "ec_sign_batch EDDSA448", "ec_key_pair_{gen,import}_batch",
