@@ -67,7 +67,9 @@ template <int NW> static __device__ __forceinline__ void store_be(u8 *dst, int l
 	}
 }
 
-template <int PB> static __device__ __forceinline__ void tab_store(u32 *base, int e, const TabEnt<PB> &T)
+// QS: words between consecutive 16-byte quads of an entry -- 4 for an item-major record (base = the item's record), 256 for the
+// wave-blocked staging of the affine-table pipeline (stg_ent below: quad q of entry e of the 64 items of a wave sits in one 1 KB run)
+template <int PB, int QS = 4> static __device__ __forceinline__ void tab_store(u32 *base, int e, const TabEnt<PB> &T)
 {
 	constexpr int NL = Lay<PB>::NL, ENTW = Lay<PB>::ENTW;
 	u32 buf[ENTW];
@@ -81,20 +83,20 @@ template <int PB> static __device__ __forceinline__ void tab_store(u32 *base, in
 	for (int i = 3 * NL; i < ENTW; i++) {
 		buf[i] = 0;
 	}
-	uint4 *d = (uint4 *)(base + (size_t)e * ENTW);
+	u32 *d = base + (size_t)e * (ENTW / 4) * QS;
 #pragma unroll
 	for (int i = 0; i < ENTW / 4; i++) {
-		d[i] = make_uint4(buf[4 * i], buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3]);
+		*(uint4 *)(d + (size_t)i * QS) = make_uint4(buf[4 * i], buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3]);
 	}
 }
-template <int PB> static __device__ __forceinline__ TabEnt<PB> tab_load(const u32 *base, u32 e)
+template <int PB, int QS = 4> static __device__ __forceinline__ TabEnt<PB> tab_load(const u32 *base, u32 e)
 {
 	constexpr int NL = Lay<PB>::NL, ENTW = Lay<PB>::ENTW;
 	u32 buf[ENTW];
-	const uint4 *s = (const uint4 *)(base + (size_t)e * ENTW);
+	const u32 *s = base + (size_t)e * (ENTW / 4) * QS;
 #pragma unroll
 	for (int i = 0; i < ENTW / 4; i++) {
-		const uint4 v = s[i];
+		const uint4 v = *(const uint4 *)(s + (size_t)i * QS);
 		buf[4 * i] = v.x;
 		buf[4 * i + 1] = v.y;
 		buf[4 * i + 2] = v.z;
@@ -142,7 +144,7 @@ template <int PB> static __device__ __forceinline__ TabEnt<PB> tab_load_masked(c
 	return T;
 }
 // Jacobian result record (all three coordinates in class FA) in the first table slot
-template <int PB> static __device__ __forceinline__ void jac_store(u32 *base, const Jac<PB> &P)
+template <int PB, int QS = 4> static __device__ __forceinline__ void jac_store(u32 *base, const Jac<PB> &P)
 {
 	TabEnt<PB> T;
 	T.X = P.X;
@@ -151,11 +153,11 @@ template <int PB> static __device__ __forceinline__ void jac_store(u32 *base, co
 	for (int i = 0; i < Lay<PB>::NL; i++) {
 		T.Y.l[i] = P.Y.l[i];
 	}
-	tab_store<PB>(base, 0, T);
+	tab_store<PB, QS>(base, 0, T);
 }
-template <int PB> static __device__ __forceinline__ Jac<PB> jac_load(const u32 *base)
+template <int PB, int QS = 4> static __device__ __forceinline__ Jac<PB> jac_load(const u32 *base)
 {
-	const TabEnt<PB> T = tab_load<PB>(base, 0);
+	const TabEnt<PB> T = tab_load<PB, QS>(base, 0);
 	Jac<PB> P;
 	P.X = T.X;
 	P.Z = T.Z;
@@ -174,6 +176,51 @@ template <class T> static __device__ __forceinline__ T selg(bool c, const T &a, 
 		r.l[i] = c ? a.l[i] : b.l[i];
 	}
 	return r;
+}
+
+// Staging of the affine-table pipeline (k_table_g / k_affine_g / k_loop_g / k_comb*_g / k_finalize_g): the Jacobian multiples, the loop's
+// result and the prefix products of the shared inversions.  In those kernels every lane walks the entries in the same order, so the
+// records of the 64 items of a wave are interleaved quad by quad (STG_QS = 256 words between the quads of an entry): each 16-byte
+// access of a wave is one contiguous kilobyte instead of 64 lines ITEMW words apart (round 5; the secp256r1 kernels have had this
+// since round 2).  The recoded scalars follow the entries of the block, item-major.  The Jacobian-table kernel of the two nine-limb
+// flavours (k_smul_g: per-lane digit-indexed look-ups) and the multi-scalar kernels keep item-major records (STG_QS = 4).
+#if defined(G29_K256) || defined(G29_P25519) || defined(G29_JACTAB) || defined(G29_STG_ITEM_MAJOR)
+#define STG_QS 4
+#else
+#define STG_QS 256
+#endif
+template <int PB> static __device__ __forceinline__ u32 *stg_ent(u32 *tbl, u32 i)
+{
+	if (STG_QS == 4) {
+		return tbl + (size_t)i * Lay<PB>::ITEMW;
+	}
+	return tbl + (size_t)(i >> 6) * 64 * Lay<PB>::ITEMW + (size_t)(i & 63u) * 4;
+}
+template <int PB> static __device__ __forceinline__ u32 *stg_kr(u32 *tbl, u32 i)
+{
+	if (STG_QS == 4) {
+		return tbl + (size_t)i * Lay<PB>::ITEMW + 8 * Lay<PB>::ENTW;
+	}
+	return tbl + (size_t)(i >> 6) * 64 * Lay<PB>::ITEMW + (size_t)64 * 8 * Lay<PB>::ENTW + (size_t)(i & 63u) * Lay<PB>::KRECW;
+}
+// one field element in the X third of staging entry e (the prefix products of k_finalize_g)
+template <int PB> static __device__ __forceinline__ void stg_fe_store(u32 *ent, int e, const typename Cls<PB>::FM &v)
+{
+	constexpr int NL = Lay<PB>::NL, ENTW = Lay<PB>::ENTW;
+#pragma unroll
+	for (int w = 0; w < NL; w++) {
+		ent[((size_t)e * (ENTW / 4) + (size_t)(w >> 2)) * STG_QS + (w & 3)] = v.l[w];
+	}
+}
+template <int PB> static __device__ __forceinline__ typename Cls<PB>::FM stg_fe_load(const u32 *ent, int e)
+{
+	constexpr int NL = Lay<PB>::NL, ENTW = Lay<PB>::ENTW;
+	typename Cls<PB>::FM v;
+#pragma unroll
+	for (int w = 0; w < NL; w++) {
+		v.l[w] = ent[((size_t)e * (ENTW / 4) + (size_t)(w >> 2)) * STG_QS + (w & 3)];
+	}
+	return v;
 }
 
 // import of item i (curves/prj_pt.c:511-552): coordinates < p, y != 0, on the curve; (xm, ym) in the field representation
@@ -810,11 +857,11 @@ template <int PB> static __device__ __forceinline__ void jac_store_at(u32 *base,
 	for (int i = 0; i < Lay<PB>::NL; i++) {
 		T.Y.l[i] = P.Y.l[i];
 	}
-	tab_store<PB>(base, e, T);
+	tab_store<PB, STG_QS>(base, e, T);
 }
 template <int PB> static __device__ __forceinline__ Jac<PB> jac_load_at(const u32 *base, int e)
 {
-	const TabEnt<PB> T = tab_load<PB>(base, (u32)e);
+	const TabEnt<PB> T = tab_load<PB, STG_QS>(base, (u32)e);
 	Jac<PB> P;
 	P.X = T.X;
 	P.Z = T.Z;
@@ -849,7 +896,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_table_g(Ecam
 		}
 		return;
 	}
-	u32 *tb = A.tbl + (size_t)i * L::ITEMW;
+	u32 *tb = stg_ent<PB>(A.tbl, i);
 	aff_store<PB>(A.stg + (size_t)i * LayA<PB>::AITEMW, 0, xm, ym);
 	Jac<PB> P1;
 	P1.X = weaken<FA>(xm);
@@ -882,7 +929,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_table_g(Ecam
 		A.status[i] = ECAMD_STATUS_REDO;   // a multiple below 9P is infinity: the complete-formula kernel takes the item
 		return;
 	}
-	u32 *kr = tb + 8 * L::ENTW;
+	u32 *kr = stg_kr<PB>(A.tbl, i);
 	kr[L::KRECW - 1] = recode_scalar(A.scalars + (size_t)i * A.sstride, (int)A.slen, kr);   // (the scalar fills at most KRECW - 1 words)
 	A.status[i] = ECAMD_STATUS_TAB;
 }
@@ -908,7 +955,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_affine_g(Eca
 		if (i >= A.n || A.status[i] != ECAMD_STATUS_TAB) {
 			continue;
 		}
-		const u32 *tb = A.tbl + (size_t)i * L::ITEMW;
+		const u32 *tb = stg_ent<PB>(A.tbl, i);
 		u32 *af = A.stg + (size_t)i * LayA<PB>::AITEMW;
 #pragma unroll 1
 		for (int e = 1; e < 8; e++) {
@@ -924,7 +971,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_affine_g(Eca
 		if (i >= A.n || A.status[i] != ECAMD_STATUS_TAB) {
 			continue;
 		}
-		const u32 *tb = A.tbl + (size_t)i * L::ITEMW;
+		const u32 *tb = stg_ent<PB>(A.tbl, i);
 		u32 *af = A.stg + (size_t)i * LayA<PB>::AITEMW;
 #pragma unroll 1
 		for (int e = 7; e >= 1; e--) {
@@ -961,9 +1008,9 @@ template <int PB, int FLAV, bool MASKED> __global__ __launch_bounds__(64) G29_OC
 	}
 	const CurveG<NL> &K = TabGP<PB>::get(gslot);
 	const FC onec = constant<FC>(K.one);
-	u32 *tb = A.tbl + (size_t)i * L::ITEMW;
+	u32 *tb = stg_ent<PB>(A.tbl, i);
 	const u32 *af = A.stg + (size_t)i * LayA<PB>::AITEMW;
-	const u32 *kr = tb + 8 * L::ENTW;
+	const u32 *kr = stg_kr<PB>(A.tbl, i);
 	const int slen = (int)A.slen;
 	const int nwin = 2 * slen;
 	const u32 carry_bit = kr[L::KRECW - 1];   // the leading digit 0 / 1 (k_table_g)
@@ -1022,7 +1069,7 @@ template <int PB, int FLAV, bool MASKED> __global__ __launch_bounds__(64) G29_OC
 	R.X = weaken<FA>(acc.X);
 	R.Y = weaken<FA>(acc.Y);
 	R.Z = weaken<FA>(acc.Z);
-	jac_store<PB>(tb, R);
+	jac_store<PB, STG_QS>(tb, R);
 	A.status[i] = ECAMD_STATUS_JAC;
 }
 
@@ -1052,7 +1099,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_add_g(E
 	const CurveG<NL> &K = TabGP<PB>::get(gslot);
 	const FC onec = constant<FC>(K.one);
 	const FT onet = weaken<FT>(onec);
-	u32 *tb = A.tbl + (size_t)i * L::ITEMW;
+	u32 *tb = stg_ent<PB>(A.tbl, i);
 	JacT<PB> acc;
 	bool inf = (st == 2u);
 	acc.X = onet;
@@ -1060,7 +1107,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_add_g(E
 	acc.Z = onet;
 	if (!inf) {
 		// the loop's result: stored from the tight class (k_loop_g widens the type, not the digits), so it re-enters it as it is
-		const Jac<PB> R = jac_load<PB>(tb);
+		const Jac<PB> R = jac_load<PB, STG_QS>(tb);
 #pragma unroll
 		for (int w = 0; w < NL; w++) {
 			acc.X.l[w] = R.X.l[w];
@@ -1133,7 +1180,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_comb_add_g(E
 	R.X = weaken<FA>(acc.X);
 	R.Y = weaken<FA>(acc.Y);
 	R.Z = weaken<FA>(acc.Z);
-	jac_store<PB>(tb, R);
+	jac_store<PB, STG_QS>(tb, R);
 	A.status[i] = ECAMD_STATUS_JAC;
 }
 
@@ -1289,12 +1336,12 @@ template <int PB, int FLAV, bool SCAN4 = false> __global__ __launch_bounds__(64)
 		}
 		return;
 	}
-	u32 *tb = A.tbl + (size_t)i * L::ITEMW;
+	u32 *tb = stg_ent<PB>(A.tbl, i);
 	Jac<PB> R;
 	R.X = weaken<FA>(acc.X);
 	R.Y = weaken<FA>(acc.Y);
 	R.Z = weaken<FA>(acc.Z);
-	jac_store<PB>(tb, R);
+	jac_store<PB, STG_QS>(tb, R);
 	A.status[i] = ECAMD_STATUS_JAC;
 }
 
@@ -1304,7 +1351,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_finalize_g(E
 	typedef Lay<PB> L;
 	typedef typename Cls<PB>::FM FM;
 	typedef typename Cls<PB>::FC FC;
-	constexpr int NL = L::NL, NW = L::NW, ENTW = L::ENTW;
+	constexpr int NL = L::NL, NW = L::NW;
 	const u32 t = blockIdx.x * 64 + threadIdx.x;
 	if (t >= nthreads) {
 		return;
@@ -1319,16 +1366,12 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_finalize_g(E
 		if (i >= A.n) {
 			break;
 		}
-		u32 *tb = A.tbl + (size_t)i * Lay<PB>::ITEMW;
+		u32 *tb = stg_ent<PB>(A.tbl, i);
 		if (A.status[i] == ECAMD_STATUS_JAC) {
-			const Jac<PB> P = jac_load<PB>(tb);
+			const Jac<PB> P = jac_load<PB, STG_QS>(tb);
 			c = weaken<FM>(mulc(c, P.Z, K));
 		}
-		u32 *d = tb + ENTW;  // park the prefix product in the second table slot
-#pragma unroll
-		for (int w = 0; w < NL; w++) {
-			d[w] = c.l[w];
-		}
+		stg_fe_store<PB>(tb, 1, c);  // park the prefix product in the second table slot
 	}
 	FM tinv = inv<PB>(c, K);
 	const FC ex = constant<FC>(K.ex), ey = constant<FC>(K.ey);  // out of the Montgomery domain (and back from the isomorphic curve)
@@ -1338,17 +1381,12 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_finalize_g(E
 		if (i >= A.n || A.status[i] != ECAMD_STATUS_JAC) {
 			continue;
 		}
-		u32 *tb = A.tbl + (size_t)i * Lay<PB>::ITEMW;
-		const Jac<PB> P = jac_load<PB>(tb);
+		u32 *tb = stg_ent<PB>(A.tbl, i);
+		const Jac<PB> P = jac_load<PB, STG_QS>(tb);
 		FM zi = tinv;
 		if (j > 0) {
 			const u32 ip = t + (u32)(j - 1) * nthreads;
-			const u32 *s = A.tbl + (size_t)ip * Lay<PB>::ITEMW + ENTW;
-			FM cp;
-#pragma unroll
-			for (int w = 0; w < NL; w++) {
-				cp.l[w] = s[w];
-			}
+			const FM cp = stg_fe_load<PB>(stg_ent<PB>(A.tbl, ip), 1);
 			zi = weaken<FM>(mul(tinv, cp, K));
 		}
 		tinv = weaken<FM>(mulc(tinv, P.Z, K));

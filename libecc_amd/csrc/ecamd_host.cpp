@@ -3377,6 +3377,30 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 	if (lattice && ensure(&ctx->stage[18], &ctx->stage_bytes[18], (size_t)n * 2 * ECAMD_EDT_ITEM_WORDS * 4)) {
 		return -1;
 	}
+	// k_ed_lat (S < q, h mod q, the truncated Euclid: integer work with data-dependent trip counts, 0.43 VALU busy) beside the decode
+	// kernel (two square-root chains, MAD bound) on the side stream: both read only the caller's arrays.  $ECAMD_NO_ED_LAT_BESIDE: in line.
+	bool lat_beside = false;
+	if (lattice) {
+		EcamdEdLatArgs L;
+		memset(&L, 0, sizeof(L));
+		L.sigs = d_sig;
+		L.hram = d_hram;
+		L.S_be = S[8];
+		L.sp_be = S[9];
+		L.uv = (uint32_t *)S[3];
+		L.meta = S[13];
+		L.flags = S[7];
+		L.n = n;
+		L.hlen = hram_len;
+		L.qslot = cv->qslot;
+		if (ctx->side_ok && getenv("ECAMD_NO_ED_LAT_BESIDE") == nullptr) {
+			HIPCHK(hipEventRecord(ctx->side_fork, s));
+			HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+			HIPCHK(ecamd_launch_ed_lat(L, ctx->side_stream));
+			HIPCHK(hipEventRecord(ctx->side_done, ctx->side_stream));
+			lat_beside = true;
+		}
+	}
 	if (late_map) {
 		if (ensure(&ctx->stage[19], &ctx->stage_bytes[19], (size_t)n * 20 * 4)) {
 			return -1;
@@ -3402,7 +3426,11 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 		L.n = n;
 		L.hlen = hram_len;
 		L.qslot = cv->qslot;
-		HIPCHK(ecamd_launch_ed_lat(L, s));
+		if (lat_beside) {
+			HIPCHK(hipStreamWaitEvent(s, ctx->side_done, 0));
+		} else {
+			HIPCHK(ecamd_launch_ed_lat(L, s));
+		}
 		EcamdEdSmul2Args E;
 		memset(&E, 0, sizeof(E));
 		E.edA = (const uint32_t *)S[10];

@@ -506,7 +506,8 @@ def test_every_multi_entry_point_with_eight_ranks(gpu_ctx, curve):
             if not ed448:
                 for i in range(n):
                     u[32 * i + 31] &= 0x7f
-            same("xdh_batch", [k, bytes(u), ("out", cl * n), ("out", n)], expect_ok=1)
+            xs = same("xdh_batch", [k, bytes(u), ("out", cl * n), ("out", n)])[1]
+            assert xs.count(0) >= n // 4         # (a random u is on the curve -- not its twist -- half of the time: libecc rejects the others)
             # the whole-batch bit: valid, then one bad item in the last shard
             assert mc.eddsa_verify_all(Aenc, sigs, hram) == cv.eddsa_verify_all(Aenc, sigs, hram) == (True, n)
             assert mc.eddsa_verify_all(Aenc, bytes(bad), hram) == cv.eddsa_verify_all(Aenc, bytes(bad), hram) == (False, n - 1)
