@@ -127,8 +127,12 @@ int ecccdh_derive_secret_batch(const ec_priv_key *const *our_priv_keys, const u8
 /*
  * Batch form of _ec_sign / ec_sign (sig/sig_algs.h:49-60, sig/sig_algs.c:465-504): item i signs m[i] (m_len[i] bytes) with
  * key_pairs[i] into sigs[i] (siglen bytes each, = ec_get_sig_len).  On the GPU: ECDSA, DECDSA (__ecdsa_sign_finalize,
- * sig/ecdsa_common.c:318-586) and the five EdDSA variants (_eddsa_sign, sig/eddsa.c:1554); every other algorithm is signed by
- * libecc's own _ec_sign on the host threads.
+ * sig/ecdsa_common.c:318-586) and the five EdDSA variants (_eddsa_sign, sig/eddsa.c:1554).  ON THE CPU: every other algorithm of
+ * sig/sig_algs_internal.h's table -- ECKCDSA, ECSDSA, ECOSDSA, ECFSDSA, ECGDSA, ECRDSA, SM2, BIGN, DBIGN, BIP0340 -- is signed item by
+ * item by libecc's own _ec_sign on the pool threads (cpu_sign_items): the call parallelises them over the host cores and nothing
+ * more; they are not part of the accelerated path (the hot path is ECDSA / EdDSA / ECDH).  The host side of
+ * the GPU algorithms also uses the application's libecc for what is per call or rare: nn_mod of an over-long private scalar,
+ * nn_modinv_fermat for ECKCDSA-type key rules, the HMAC of RFC 6979, the blinding product m + b #E of prj_pt_mul_blind_batch.
  *   rand: as for _ec_sign -- NULL = libecc's nn_get_random_mod (its steps restated around a serialised get_random, see
  *     ecamd_compat_set_concurrent_random); another function is called once per item on the calling thread (test vectors).
  *     Two deviations from a loop of ec_sign calls, both only visible to a caller-supplied hook: (i) the hook must return a value

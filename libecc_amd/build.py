@@ -38,10 +38,12 @@ def _jobs():
     jobs = [(src, os.path.splitext(src)[0] + ".o", []) for src in SOURCES]
     # the 19-limb dense units need two registers too many for two waves per SIMD; pinned there the window loop fits without a
     # spill: brainpoolP512r1 6.0 -> 7.1 M/s (profiles/r2s_waves_per_simd.md; three waves on the 384 / 521-bit units: no gain / worse)
-    jobs += [("ecamd_g29_kernel.hip", f"ecamd_g29_{pb}.o", [f"-DG29_PB={pb}"] + (["-DG29_WAVES=2"] if pb in (511, 512) else []))
+    # (round 5: the 521-bit units too -- left alone the window loop takes 258 / 269 registers, ONE wave per SIMD; pinned at two it compiles to
+    # 212 / 224 without a spill)
+    jobs += [("ecamd_g29_kernel.hip", f"ecamd_g29_{pb}.o", [f"-DG29_PB={pb}"] + (["-DG29_WAVES=2"] if pb in (511, 512, 521) else []))
              for pb in G29_SIZES]
     # secp521r1: plain residues on 18 limbs, 2^522 = 2 folded inside the product columns (ecamd_u29g.h:mul_m521p)
-    jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_521m.o", ["-DG29_PB=521", "-DG29_M521P"]))
+    jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_521m.o", ["-DG29_PB=521", "-DG29_M521P", "-DG29_WAVES=2"]))
     # the two nine-limb plain-residue units run best at three waves per SIMD (profiles/r2e_variants.md: 62.7 -> 63.5 and 68.0 -> 69.6 M/s)
     jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_255c.o", ["-DG29_PB=255", "-DG29_P25519", "-DG29_WAVES=3"]))
     jobs.append(("ecamd_g29_kernel.hip", "ecamd_g29_256k.o", ["-DG29_PB=256", "-DG29_K256", "-DG29_WAVES=3"]))

@@ -5,7 +5,7 @@
  * libsign_amd.so with the same array shapes tests/ec_self_tests_core.c uses for ec_verify_batch (:373-383, :556-616);
  * every batch result is compared with libecc's own scalar function (prj_pt_mul, ecccdh_derive_secret, ec_verify -- the
  * CPU code of the very libecc the library was linked from) on the same inputs.  Needs an MI355X.
- *   usage: compat_check [items per case, default 256] | compat_check quick <items> | compat_check bench <log2 items>
+ *   usage: compat_check [items per case, default 256] | compat_check quick <items> | compat_check bench <log2 items> | compat_check bench_schnorr <log2 items>
  * Exit status 0 iff everything matched; prints one line per case.
  */
 #include <stdio.h>
@@ -1006,6 +1006,60 @@ static void bench_verify(const char *curve, ec_alg_type sig_type, hash_alg_type 
 }
 
 
+/* ec_verify_batch of a Schnorr-type algorithm on n DISTINCT signatures (keys from ec_key_pair_gen_batch, signatures from ec_sign_batch --
+ * libecc's own _ec_sign on the pool threads for these algorithms): with the multi-scalar form (default threshold) and without it
+ * ($ECAMD_COMPAT_SCHNORR_MSM_MIN=0 in the environment of a second run) */
+static void bench_schnorr(const char *curve, ec_alg_type sig_type, hash_alg_type hash_type, const char *label, u32 n)
+{
+	enum { ML = 32 };
+	ec_params params;
+	ec_key_pair *kps = calloc(n, sizeof(ec_key_pair));
+	const ec_key_pair **kpp = calloc(n, sizeof(*kpp));
+	const ec_pub_key **pubs = calloc(n, sizeof(*pubs));
+	u8 **sigw = calloc(n, sizeof(*sigw));
+	const u8 **sigs = calloc(n, sizeof(*sigs)), **msgs = calloc(n, sizeof(*msgs)), **adatas = calloc(n, sizeof(*adatas));
+	u8 *siglens = calloc(n, 1), *sigbuf, *msgbuf = calloc(n, ML), siglen = 0;
+	u32 *msglens = calloc(n, sizeof(u32)), i;
+	u16 *adlens = calloc(n, sizeof(u16));
+	int *rets = calloc(n, sizeof(int)), r = 0, rep;
+	double t0, best = 1e30;
+	const unsigned long calls0 = ecamd_compat_schnorr_msm_calls();
+	if (!kps || load_params(curve, &params) || ec_get_sig_len(&params, sig_type, hash_type, &siglen)) {
+		printf("bench %s: setup failed\n", label);
+		return;
+	}
+	sigbuf = calloc(n, siglen);
+	if (ec_key_pair_gen_batch(kps, &params, sig_type, n, rets) || get_random(msgbuf, ML)) {
+		printf("bench %s: key generation failed\n", label);
+		return;
+	}
+	for (i = 0; i < n; i++) {
+		memcpy(msgbuf + (size_t)i * ML, msgbuf, ML);
+		memcpy(msgbuf + (size_t)i * ML, &i, sizeof(i));
+		kpp[i] = &kps[i];
+		pubs[i] = &kps[i].pub_key;
+		sigw[i] = sigbuf + (size_t)i * siglen;
+		sigs[i] = sigw[i];
+		msgs[i] = msgbuf + (size_t)i * ML;
+		siglens[i] = siglen;
+		msglens[i] = ML;
+		r |= rets[i];
+	}
+	t0 = now_s();
+	r |= ec_sign_batch(sigw, siglen, kpp, msgs, msglens, n, NULL, sig_type, hash_type, NULL, NULL, rets);
+	printf("bench %s: %u key pairs, %u signatures by libecc's _ec_sign on the pool in %.1f s%s\n", label, n, n, now_s() - t0, r ? " (FAILED)" : "");
+	for (rep = 0; rep < 4; rep++) {
+		t0 = now_s();
+		r |= ec_verify_batch(sigs, siglens, pubs, msgs, msglens, n, sig_type, hash_type, adatas, adlens, NULL, NULL);
+		if (rep && now_s() - t0 < best) {
+			best = now_s() - t0;
+		}
+	}
+	printf("bench ec_verify_batch %-24s n = %u: %s, %.1f ms, %.2f M verifications/s end to end, %lu multi-scalar calls\n", label, n, r ? "REJECTED" : "accepted",
+	       best * 1e3, (double)n / best / 1e6, ecamd_compat_schnorr_msm_calls() - calls0);
+	free(kps); free(kpp); free(pubs); free(sigw); free(sigs); free(msgs); free(adatas); free(siglens); free(sigbuf); free(msgbuf); free(msglens); free(adlens); free(rets);
+}
+
 /* end-to-end rates of the secret-key entry points: ec_sign_batch, ec_key_pair_gen_batch, x25519_batch (libecc structures /
  * pointer arrays in and out; hashing, nonce generation and marshalling on the host threads included) */
 static void bench_secret_half(u32 n)
@@ -1086,6 +1140,19 @@ int main(int argc, char **argv)
 		} else {
 			bench_verify("SECP256R1", ECDSA, SHA256, "ECDSA/SECP256R1/SHA256", bn);
 		}
+		ecamd_compat_shutdown();
+		return 0;
+	}
+	if (argc > 2 && !strcmp(argv[1], "bench_schnorr")) {
+		const u32 bn = 1u << (u32)atoi(argv[2]);
+		if (ecamd_compat_init(NULL, 0, 0)) {
+			printf("no GPU path\n");
+			return 3;
+		}
+		ecamd_compat_set_concurrent_random(1);
+		g_rand_expect_serial = 0;
+		bench_schnorr("SECP256K1", BIP0340, SHA256, "BIP0340/SECP256K1/SHA256", bn);
+		bench_schnorr("SECP256R1", ECFSDSA, SHA256, "ECFSDSA/SECP256R1/SHA256", bn);
 		ecamd_compat_shutdown();
 		return 0;
 	}

@@ -182,7 +182,7 @@ template <class T> static __device__ __forceinline__ T selg(bool c, const T &a, 
 // result and the prefix products of the shared inversions.  In those kernels every lane walks the entries in the same order, so the
 // records of the 64 items of a wave are interleaved quad by quad (STG_QS = 256 words between the quads of an entry): each 16-byte
 // access of a wave is one contiguous kilobyte instead of 64 lines ITEMW words apart (round 5; the secp256r1 kernels have had this
-// since round 2).  The recoded scalars follow the entries of the block, item-major.  The Jacobian-table kernel of the two nine-limb
+// since round 2).  The recoded scalars follow the entries in the same addressing.  The Jacobian-table kernel of the two nine-limb
 // flavours (k_smul_g: per-lane digit-indexed look-ups) and the multi-scalar kernels keep item-major records (STG_QS = 4).
 #if defined(G29_K256) || defined(G29_P25519) || defined(G29_JACTAB) || defined(G29_STG_ITEM_MAJOR)
 #define STG_QS 4
@@ -196,13 +196,14 @@ template <int PB> static __device__ __forceinline__ u32 *stg_ent(u32 *tbl, u32 i
 	}
 	return tbl + (size_t)(i >> 6) * 64 * Lay<PB>::ITEMW + (size_t)(i & 63u) * 4;
 }
-template <int PB> static __device__ __forceinline__ u32 *stg_kr(u32 *tbl, u32 i)
+// the recoded scalar follows the eight entries in the same quad addressing (a constant offset from the item's entry pointer:
+// the window loop keeps ONE pointer live -- a second one cost k_loop_g<521> its second wave per SIMD); word w: stg_krw(kr, w)
+template <int PB> static __device__ __forceinline__ u32 *stg_kr(u32 *ent)
 {
-	if (STG_QS == 4) {
-		return tbl + (size_t)i * Lay<PB>::ITEMW + 8 * Lay<PB>::ENTW;
-	}
-	return tbl + (size_t)(i >> 6) * 64 * Lay<PB>::ITEMW + (size_t)64 * 8 * Lay<PB>::ENTW + (size_t)(i & 63u) * Lay<PB>::KRECW;
+	return ent + (size_t)8 * (Lay<PB>::ENTW / 4) * STG_QS;
 }
+static __device__ __forceinline__ u32 &stg_krw(u32 *kr, int w) { return kr[(size_t)(w >> 2) * STG_QS + (w & 3)]; }
+static __device__ __forceinline__ u32 stg_krw(const u32 *kr, int w) { return kr[(size_t)(w >> 2) * STG_QS + (w & 3)]; }
 // one field element in the X third of staging entry e (the prefix products of k_finalize_g)
 template <int PB> static __device__ __forceinline__ void stg_fe_store(u32 *ent, int e, const typename Cls<PB>::FM &v)
 {
@@ -271,7 +272,8 @@ template <int PB> static __device__ __forceinline__ bool import_point(const Ecam
 
 // k' = k + 0x88..8 over the 2*slen nibbles of item i's big-endian scalar, little-endian words into kr (any length the host
 // lets through: slen <= 4 KRECW - 4); returns the carry out of the top nibble (the leading digit 0 / 1)
-static __device__ __forceinline__ u32 recode_scalar(const u8 *sc, int slen, u32 *kr)
+// (QS: word w of the recoded scalar sits at kr[(w >> 2) * QS + (w & 3)] -- 4: a plain array; STG_QS: the wave-blocked staging)
+template <int QS = 4> static __device__ __forceinline__ u32 recode_scalar(const u8 *sc, int slen, u32 *kr)
 {
 	const int nwords = (slen + 3) >> 2;
 	uint64_t c = 0;
@@ -290,7 +292,7 @@ static __device__ __forceinline__ u32 recode_scalar(const u8 *sc, int slen, u32 
 		const u32 add8 = (nb >= 4) ? 0x88888888u : (nb == 3 ? 0x00888888u : (nb == 2 ? 0x00008888u : 0x00000088u));
 		c += (uint64_t)x + add8;
 		last = (u32)c;
-		kr[w] = last;
+		kr[(size_t)(w >> 2) * QS + (w & 3)] = last;
 		c >>= 32;
 	}
 	// the carry out of the top nibble sits just above the scalar's bytes
@@ -929,8 +931,9 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_table_g(Ecam
 		A.status[i] = ECAMD_STATUS_REDO;   // a multiple below 9P is infinity: the complete-formula kernel takes the item
 		return;
 	}
-	u32 *kr = stg_kr<PB>(A.tbl, i);
-	kr[L::KRECW - 1] = recode_scalar(A.scalars + (size_t)i * A.sstride, (int)A.slen, kr);   // (the scalar fills at most KRECW - 1 words)
+	u32 *kr = stg_kr<PB>(tb);
+	const u32 top = recode_scalar<STG_QS>(A.scalars + (size_t)i * A.sstride, (int)A.slen, kr);   // (the scalar fills at most KRECW - 1 words)
+	stg_krw(kr, L::KRECW - 1) = top;
 	A.status[i] = ECAMD_STATUS_TAB;
 }
 
@@ -1010,10 +1013,10 @@ template <int PB, int FLAV, bool MASKED> __global__ __launch_bounds__(64) G29_OC
 	const FC onec = constant<FC>(K.one);
 	u32 *tb = stg_ent<PB>(A.tbl, i);
 	const u32 *af = A.stg + (size_t)i * LayA<PB>::AITEMW;
-	const u32 *kr = stg_kr<PB>(A.tbl, i);
+	const u32 *kr = stg_kr<PB>(tb);
 	const int slen = (int)A.slen;
 	const int nwin = 2 * slen;
-	const u32 carry_bit = kr[L::KRECW - 1];   // the leading digit 0 / 1 (k_table_g)
+	const u32 carry_bit = stg_krw(kr, L::KRECW - 1);   // the leading digit 0 / 1 (k_table_g)
 	JacT<PB> acc;
 	FM x1, y1;
 	aff_load<PB, false>(af, 0, x1, y1);
@@ -1021,14 +1024,14 @@ template <int PB, int FLAV, bool MASKED> __global__ __launch_bounds__(64) G29_OC
 	acc.Y = weaken<FT>(y1);
 	acc.Z = weaken<FT>(onec);
 	bool inf = (carry_bit == 0);
-	u32 wcur = nwin ? kr[(nwin - 1) >> 3] : 0u, wnext = 0u;
+	u32 wcur = nwin ? stg_krw(kr, (nwin - 1) >> 3) : 0u, wnext = 0u;
 #pragma unroll 1
 	for (int t = 0; t < nwin; t++) {
 		const int pos = nwin - 1 - t;
 		const int dig = (int)((wcur >> (4 * (pos & 7))) & 15u) - 8;
 		const u32 mag = (u32)(dig < 0 ? -dig : dig);
 		if ((pos & 7) == 0 && pos != 0) {
-			wnext = kr[(pos >> 3) - 1];
+			wnext = stg_krw(kr, (pos >> 3) - 1);
 		}
 		FM tx, tyc;
 #ifdef G29_PRELOAD
@@ -2029,24 +2032,56 @@ static __device__ __forceinline__ Pre pre_load(const u32 *base, u32 e)
 }
 // window table [1..8]P of the signed w = 4 recoding
 // (order chosen so that at most two multiples are alive at a time beside the entry of P)
-static __device__ __forceinline__ void ed_table(u32 *tb, const Ext &P1, const FC &d2, const CK &K)
+template <class Store> static __device__ __forceinline__ void ed_table_with(const Store &st, const Ext &P1, const FC &d2, const CK &K)
 {
 	const Pre Q1 = ed_pre(P1, d2, K);
-	pre_store(tb, 0, Q1);
+	st(0, Q1);
 	const Ext P2 = ed_dbl<true>(P1, K);
-	pre_store(tb, 1, ed_pre(P2, d2, K));
+	st(1, ed_pre(P2, d2, K));
 	Ext Pa = ed_add(P2, Q1, false, K);            // 3P
-	pre_store(tb, 2, ed_pre(Pa, d2, K));
+	st(2, ed_pre(Pa, d2, K));
 	Pa = ed_dbl<true>(Pa, K);                     // 6P
-	pre_store(tb, 5, ed_pre(Pa, d2, K));
+	st(5, ed_pre(Pa, d2, K));
 	Pa = ed_add(Pa, Q1, false, K);                // 7P
-	pre_store(tb, 6, ed_pre(Pa, d2, K));
+	st(6, ed_pre(Pa, d2, K));
 	Ext Pb = ed_dbl<true>(P2, K);                 // 4P
-	pre_store(tb, 3, ed_pre(Pb, d2, K));
+	st(3, ed_pre(Pb, d2, K));
 	Pa = ed_add(Pb, Q1, false, K);                // 5P
-	pre_store(tb, 4, ed_pre(Pa, d2, K));
+	st(4, ed_pre(Pa, d2, K));
 	Pb = ed_dbl<true>(Pb, K);                     // 8P
-	pre_store(tb, 7, ed_pre(Pb, d2, K));
+	st(7, ed_pre(Pb, d2, K));
+}
+static __device__ __forceinline__ void ed_table(u32 *tb, const Ext &P1, const FC &d2, const CK &K)
+{
+	ed_table_with([&](int e, const Pre &Q) { pre_store(tb, e, Q); }, P1, d2, K);
+}
+// The same entry of all 64 items of a wave through LDS: a lane's own store is nine 16-byte pieces 2560 bytes apart from its
+// neighbours' (every store instruction of the wave touches 64 cache lines); transposed, consecutive lanes write consecutive quads
+// of one item's entry (144-byte runs).  sh: 64 x 37 words + 64 flags.  Called by every lane of the block (one wave).
+#define EDT_LDS_STRIDE 37
+static __device__ __forceinline__ void pre_store_wave(u32 *sh, u32 *wave_base, u32 item_words, int e, const Pre &Q, bool live)
+{
+	const u32 lane = threadIdx.x;
+	u32 *row = sh + lane * EDT_LDS_STRIDE;
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		row[w] = Q.ymx.l[w];
+		row[9 + w] = Q.ypx.l[w];
+		row[18 + w] = Q.t2d.l[w];
+		row[27 + w] = Q.z2.l[w];
+	}
+	sh[64 * EDT_LDS_STRIDE + lane] = live ? 1u : 0u;
+	__syncthreads();
+#pragma unroll
+	for (int it = 0; it < 9; it++) {
+		const u32 g = (u32)it * 64u + lane;
+		const u32 item = g / 9u, q = g - 9u * item;
+		if (sh[64 * EDT_LDS_STRIDE + item]) {
+			const u32 *src = sh + item * EDT_LDS_STRIDE + 4 * q;
+			*(uint4 *)(wave_base + (size_t)item * item_words + (size_t)e * EDT_ENT_WORDS + 4 * q) = make_uint4(src[0], src[1], src[2], src[3]);
+		}
+	}
+	__syncthreads();
 }
 static __device__ __forceinline__ Ext ed_neutral(const CK &K)
 {
@@ -2905,22 +2940,44 @@ template <int phase, int NWIN> __global__ __launch_bounds__(64) void k_ed_smul2_
 {
 	using namespace c25519;
 	const u32 i = blockIdx.x * 64 + threadIdx.x;
-	if (i >= A.n || A.flagsA[i] || A.flagsR[i] == 1 || A.flagsS[i]) {
+	const bool live = i < A.n && !(A.flagsA[i] || A.flagsR[i] == 1 || A.flagsS[i]);
+#if defined(ED_TABLE_DIRECT_STORE)   /* A/B hook (tools/build_variant.py): every lane stores its own entries */
+	if (!live) {
 		return;
 	}
+#else
+	if (phase != 0 && !live) {
+		return;
+	}
+#endif
 	const CK &K = TabGP<255>::get(gslot);
 	const FC onec = constant<FC>(K.one);
 	const FM onem = weaken<FM>(onec);
 	const FC d2 = digits9(A.g_2d);
 	u32 *tbA = A.tbl + (size_t)i * 2 * EDT_ITEM_WORDS, *tbR = tbA + EDT_ITEM_WORDS;
 	if (phase == 0) {
+#if !defined(ED_TABLE_DIRECT_STORE)
+		// the tables leave through LDS, an entry of the whole wave at a time (pre_store_wave): every lane stays to the end
+		__shared__ u32 sh[64 * EDT_LDS_STRIDE + 64];
+		u32 *wave_base = A.tbl + (size_t)(blockIdx.x * 64u) * 2 * EDT_ITEM_WORDS;
+		const u32 ic = i < A.n ? i : 0u;
+#endif
 #pragma unroll 1
 		for (int k = 0; k < 2; k++) {
 			Ext P1;
+#if defined(ED_TABLE_DIRECT_STORE)
 			edr_load((k == 0 ? A.edA : A.edR) + (size_t)i * 20, P1.X, P1.Y);
+#else
+			edr_load((k == 0 ? A.edA : A.edR) + (size_t)ic * 20, P1.X, P1.Y);
+#endif
 			P1.Z = onem;
 			P1.T = weaken<FM>(mul(P1.X, P1.Y, K));
+#if defined(ED_TABLE_DIRECT_STORE)
 			ed_table(k == 0 ? tbA : tbR, P1, d2, K);
+#else
+			u32 *wb = wave_base + (k == 0 ? 0 : EDT_ITEM_WORDS);
+			ed_table_with([&](int e, const Pre &Q) { pre_store_wave(sh, wb, 2 * EDT_ITEM_WORDS, e, Q, live); }, P1, d2, K);
+#endif
 		}
 		return;
 	}

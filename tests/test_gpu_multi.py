@@ -483,7 +483,8 @@ def test_every_multi_entry_point_with_eight_ranks(gpu_ctx, curve):
             same("eddsa_verify_batch", [Aenc, sigs, hram, u32(hl), ("out", n)], expect_ok=0)
             dom = b"SigEd448\x00\x00" if ed448 else b""
             slots, stride = cv.msg_slots([dom + x for x in inputs])
-            same("eddsa_verify_msg_batch", [Aenc, sigs, slots, u32(stride), ("out", n)], expect_ok=0)
+            if not ed448:   # (the encoded-key form hashes with SHA-512 only; Ed448 has the two projective-key forms below)
+                same("eddsa_verify_msg_batch", [Aenc, sigs, slots, u32(stride), ("out", n)], expect_ok=0)
             blank = [dom + x[:kl] + bytes(kl) + x[2 * kl:] for x in inputs]
             slots_b, stride_b = cv.msg_slots(blank)
             same("eddsa_verify_msg_prj_batch", [keys_prj, sigs, slots_b, u32(stride_b), u32(len(dom) + kl), ("out", n)], expect_ok=0)
