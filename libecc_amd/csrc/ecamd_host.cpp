@@ -4160,10 +4160,11 @@ static uint32_t schnorr_msm_pick_k(uint32_t n)
 			return k;
 		}
 	}
-	// two waves per SIMD need 131072 lanes; below that the shared doublings are worth more than the occupancy
-	uint32_t k = n >> 17;
-	if (k < 2) {
-		k = 2;
+	// measured on secp256k1 (profiles/r5h_schnorr_msm.md): the Straus loop wants about 2^18 lanes (four waves per SIMD: its additions are
+	// dependent chains) before sharing doublings pays -- 2^20 items: K = 4 (19.3 ms) beats 8 (23.1) and 2 (20.6); 2^18 items: K = 1
+	uint32_t k = n >> 18;
+	if (k < 1) {
+		k = 1;
 	}
 	return k > 8 ? 8 : k;
 }
