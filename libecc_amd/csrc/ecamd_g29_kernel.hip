@@ -2036,6 +2036,18 @@ template <class Store> static __device__ __forceinline__ void ed_table_with(cons
 {
 	const Pre Q1 = ed_pre(P1, d2, K);
 	st(0, Q1);
+#if !defined(ED_TABLE_UNROLLED)
+	// [e]P = [e - 1]P + P, seven times ONE addition body (the unified formulas are complete, so the first step may be P + P): 56 M instead of
+	// the 16 M + 16 S + 24 M of the doubling / addition mix below, but 11 KB of code run seven times instead of 80 KB run once -- the
+	// spelled-out form ran at a quarter of the MAD rate (A/B: -DED_TABLE_UNROLLED, tools/build_variant.py)
+	Ext Pe = P1;
+#pragma unroll 1
+	for (int e = 1; e < 8; e++) {
+		Pe = ed_add(Pe, Q1, false, K);
+		st(e, ed_pre(Pe, d2, K));
+	}
+	return;
+#endif
 	const Ext P2 = ed_dbl<true>(P1, K);
 	st(1, ed_pre(P2, d2, K));
 	Ext Pa = ed_add(P2, Q1, false, K);            // 3P
@@ -2936,7 +2948,12 @@ template <int KWORDS> static __device__ __forceinline__ int ed_next_digit(u32 *k
 	return dig;
 }
 
-template <int phase, int NWIN> __global__ __launch_bounds__(64) void k_ed_smul2_c25519(EcamdEdSmul2Args A, int gslot)
+// The window tables of A and R (phase 0 of the half-length-scalar path) as a kernel of its own, so that its register budget is its own:
+// ED_TABLE_WAVES = minimum waves per SIMD (2: the rolled table loop keeps its 200 registers; 3: 168 and a few spills -- A/B)
+#ifndef ED_TABLE_WAVES
+#define ED_TABLE_WAVES 2
+#endif
+__global__ __launch_bounds__(64, ED_TABLE_WAVES) void k_ed_table2_c25519(EcamdEdSmul2Args A, int gslot)
 {
 	using namespace c25519;
 	const u32 i = blockIdx.x * 64 + threadIdx.x;
@@ -2945,42 +2962,48 @@ template <int phase, int NWIN> __global__ __launch_bounds__(64) void k_ed_smul2_
 	if (!live) {
 		return;
 	}
-#else
-	if (phase != 0 && !live) {
-		return;
-	}
 #endif
 	const CK &K = TabGP<255>::get(gslot);
 	const FC onec = constant<FC>(K.one);
 	const FM onem = weaken<FM>(onec);
 	const FC d2 = digits9(A.g_2d);
+#if defined(ED_TABLE_DIRECT_STORE)
 	u32 *tbA = A.tbl + (size_t)i * 2 * EDT_ITEM_WORDS, *tbR = tbA + EDT_ITEM_WORDS;
-	if (phase == 0) {
-#if !defined(ED_TABLE_DIRECT_STORE)
-		// the tables leave through LDS, an entry of the whole wave at a time (pre_store_wave): every lane stays to the end
-		__shared__ u32 sh[64 * EDT_LDS_STRIDE + 64];
-		u32 *wave_base = A.tbl + (size_t)(blockIdx.x * 64u) * 2 * EDT_ITEM_WORDS;
-		const u32 ic = i < A.n ? i : 0u;
+#else
+	// the tables leave through LDS, an entry of the whole wave at a time (pre_store_wave): every lane stays to the end
+	__shared__ u32 sh[64 * EDT_LDS_STRIDE + 64];
+	u32 *wave_base = A.tbl + (size_t)(blockIdx.x * 64u) * 2 * EDT_ITEM_WORDS;
+	const u32 ic = i < A.n ? i : 0u;
 #endif
 #pragma unroll 1
-		for (int k = 0; k < 2; k++) {
-			Ext P1;
+	for (int k = 0; k < 2; k++) {
+		Ext P1;
 #if defined(ED_TABLE_DIRECT_STORE)
-			edr_load((k == 0 ? A.edA : A.edR) + (size_t)i * 20, P1.X, P1.Y);
+		edr_load((k == 0 ? A.edA : A.edR) + (size_t)i * 20, P1.X, P1.Y);
 #else
-			edr_load((k == 0 ? A.edA : A.edR) + (size_t)ic * 20, P1.X, P1.Y);
+		edr_load((k == 0 ? A.edA : A.edR) + (size_t)ic * 20, P1.X, P1.Y);
 #endif
-			P1.Z = onem;
-			P1.T = weaken<FM>(mul(P1.X, P1.Y, K));
+		P1.Z = onem;
+		P1.T = weaken<FM>(mul(P1.X, P1.Y, K));
 #if defined(ED_TABLE_DIRECT_STORE)
-			ed_table(k == 0 ? tbA : tbR, P1, d2, K);
+		ed_table(k == 0 ? tbA : tbR, P1, d2, K);
 #else
-			u32 *wb = wave_base + (k == 0 ? 0 : EDT_ITEM_WORDS);
-			ed_table_with([&](int e, const Pre &Q) { pre_store_wave(sh, wb, 2 * EDT_ITEM_WORDS, e, Q, live); }, P1, d2, K);
+		u32 *wb = wave_base + (k == 0 ? 0 : EDT_ITEM_WORDS);
+		ed_table_with([&](int e, const Pre &Q) { pre_store_wave(sh, wb, 2 * EDT_ITEM_WORDS, e, Q, live); }, P1, d2, K);
 #endif
-		}
+	}
+}
+
+template <int phase, int NWIN> __global__ __launch_bounds__(64) void k_ed_smul2_c25519(EcamdEdSmul2Args A, int gslot)
+{
+	static_assert(phase == 1, "phase 0 is k_ed_table2_c25519");
+	using namespace c25519;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n || A.flagsA[i] || A.flagsR[i] == 1 || A.flagsS[i]) {
 		return;
 	}
+	const CK &K = TabGP<255>::get(gslot);
+	u32 *tbA = A.tbl + (size_t)i * 2 * EDT_ITEM_WORDS, *tbR = tbA + EDT_ITEM_WORDS;
 	const u32 meta = A.meta[i];
 	if (((meta >> 1) & 1u) != (NWIN > 33 ? 1u : 0u)) {
 		return;   // the other launch's item
@@ -3139,6 +3162,11 @@ __global__ __launch_bounds__(64) void k_ed_tail2_c25519(EcamdEdTailArgs A, int g
 		W = ed_add<false>(W, ed_pre(H, d2, K), false, K);
 	}
 	// E2 (only possible for h = 0 mod q, i.e. v = 0, u = 1, W = W1): W1 == T2 = (0, -1)
+	// INVARIANT this shortcut rests on: for h != 0 mod q the pair W1 + [h]A = T2 would need [8]([S]B - R) = [8h]A with
+	// [h]A of order two up to the torsion of an accepted equation, i.e. [8]A = infinity -- and k_ed_decode_ed_c25519 (flagsA, the
+	// reference's small-order test of the key, sig/eddsa.c:2190-2200) has already rejected such keys before this kernel sees the item.
+	// An entry point that feeds this tail MUST keep that test in front of it; tests/test_gpu_parity.py::test_eddsa25519_exceptional_pairs
+	// runs small-order and mixed-torsion keys with the lattice path on and forced off against the unmodified reference.
 	if (A.meta[i] & 4u) {
 		bad = bad | (is_zero_mulout(W.X, K) & eq_neg(W.Y, W.Z, K));
 	}
@@ -3155,7 +3183,7 @@ hipError_t ecamd_launch_ed_smul2_c25519(const EcamdEdSmul2Args &a, int gslot, hi
 		return hipSuccess;
 	}
 	const dim3 grid((a.n + 63) / 64), block(64);
-	hipLaunchKernelGGL((k_ed_smul2_c25519<0, 33>), grid, block, 0, s, a, gslot);
+	hipLaunchKernelGGL(k_ed_table2_c25519, grid, block, 0, s, a, gslot);
 	if (dom) {
 		(void)hipEventRecord(dom[0], s);
 	}

@@ -45,13 +45,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--curve", default="SECP256R1")
     ap.add_argument("--batch-log2", default="20")
+    ap.add_argument("--workload", default=None, help="a tools/bench_protocols.py workload instead of the scalar multiplication (ed25519_verify, x25519, ecdsa_verify ...)")
     a = ap.parse_args()
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--traffic-child", "--curve", a.curve, "--batch-log2", a.batch_log2, "--steps", "2", "--warmup", "1"]
+    if a.workload:
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_protocols.py"), "--workload", a.workload, "--no-cpu-baseline", "--steps", "2", "--warmup", "1"]
+        a.curve = a.workload
     ms = kernel_ms(cmd) or {}
     hbm, note = pmc.hbm_bytes_per_launch(cmd)
     sq, _ = pmc.valu_counters(cmd, counters=("SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES",))
     gr, _ = pmc.valu_counters(cmd, counters=("GRBM_GUI_ACTIVE",))
-    print(f"# Round 4: what bounds each kernel of one {a.curve} scalar-multiplication batch of 2^{a.batch_log2} items\n")
+    print(f"# What bounds each kernel of one {a.curve} batch of 2^{a.batch_log2} items\n")
     print("`tools/kernel_bound.py` on one MI355X: durations from `rocprofv3 --kernel-trace` (longest dispatch = the full-size launch), HBM bytes = "
           "(2 x FETCH_SIZE + WRITE_SIZE) KiB of the largest dispatch, VALU busy = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); "
           "each counter in its own pass.\n")
