@@ -450,72 +450,15 @@ template <int PB> struct MsmLay {
 	static constexpr int RECW = Lay<PB>::ENTW + 4;   // X, Y, Z (class FA) as a table entry, then the "is infinity" word
 };
 
-// BIP0340's lift_x on the unit's curve (aff_pt_y_from_x + "the even solution", sig/bip0340.c:947-953; curves/aff_pt.c:102): x < p,
-// y = (x^3 + a x + b)^((p + 1) / 4) for p = 3 mod 4 (the host guarantees it), y^2 checked, and the root whose ORIGINAL-curve
-// representative (through the export factor ey) is even.  Exponent bits are wave-uniform; 2-bit windows as in inv<PB>.
+// BIP0340's lift_x of item i's r (jacg::lift_x_even; host-tested in tests/test_u29g_host.py::test_lift_x_even)
 template <int PB> static __device__ __forceinline__ bool msm_lift_x(const u8 *src, int clen, typename Cls<PB>::FM &xo, typename Cls<PB>::FM &yo,
 								     const CurveG<Cfg<PB>::NL> &K)
 {
-	typedef Lay<PB> L;
-	typedef typename Cls<PB>::FM FM;
-	typedef typename Cls<PB>::FC FC;
-	constexpr int NL = L::NL, NW = L::NW;
+	constexpr int NW = Lay<PB>::NW;
 	u32 xw[NW];
 	load_be<NW>(src, clen, xw);
 	const auto xd = from_words<PB, NW>(xw);
-	u32 bx = 0;
-#pragma unroll
-	for (int j = 0; j < NL; j++) {
-		bx = (xd.l[j] - K.p[j] - bx) >> 31;
-	}
-	bool ok = (bx != 0);   // x < p (fp_import_from_buf)
-	const FC onec = constant<FC>(K.one);
-	const auto xm = mul(xd, constant<FC>(K.ix), K);
-	const auto rhs0 = add(mulc(carry(add(sqr(xm, K), constant<FC>(K.a))), xm, K), constant<FC>(K.b));
-	const FM rhs = weaken<FM>(mulc(carry(rhs0), onec, K));
-	// e = (p + 1) / 4, digits in radix 2^29
-	u32 e[NL];
-	{
-		u32 c = 1;
-#pragma unroll
-		for (int j = 0; j < NL; j++) {
-			const u32 t = K.p[j] + c;
-			e[j] = t & MASK;
-			c = t >> W;
-		}
-#pragma unroll
-		for (int j = 0; j < NL; j++) {
-			e[j] = (e[j] >> 2) | ((j + 1 < NL ? (e[j + 1] & 3u) : 0u) << (W - 2));
-		}
-	}
-	const FM x2 = weaken<FM>(sqr(rhs, K));
-	const FM x3 = weaken<FM>(mul(x2, rhs, K));
-	FM r = weaken<FM>(onec);
-	const int top = ((int)K.pbits - 1) | 1;
-	for (int i = top; i >= 1; i -= 2) {
-		r = weaken<FM>(sqr(r, K));
-		r = weaken<FM>(sqr(r, K));
-		const u32 hi = (e[i / W] >> (i % W)) & 1u, lo = (e[(i - 1) / W] >> ((i - 1) % W)) & 1u;
-		const u32 c = 2u * hi + lo;
-		if (c == 1u) {
-			r = weaken<FM>(mul(r, rhs, K));
-		} else if (c == 2u) {
-			r = weaken<FM>(mul(r, x2, K));
-		} else if (c == 3u) {
-			r = weaken<FM>(mul(r, x3, K));
-		}
-	}
-	{
-		const auto dif = carry(sub_auto<1>(rhs, sqr(r, K), K));
-		ok = ok & is_zero_mulout(mulc(dif, onec, K), K);   // not a square: aff_pt_y_from_x fails
-	}
-	u32 d[NL];
-	canonical_digits(d, mul(r, constant<FC>(K.ey), K), K);
-	const bool odd = (d[0] & 1u) != 0u;
-	const FM rn = weaken<FM>(mulc(neg<PB>(r, K), onec, K));
-	xo = weaken<FM>(xm);
-	yo = selg(odd, rn, r);
-	return ok;
+	return lift_x_even<PB>(xd, K, xo, yo);
 }
 
 template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_msm_table_g(EcamdMsmArgs A, int gslot)

@@ -204,5 +204,71 @@ template <int PB> G29_FN typename Cls<PB>::FM inv(const typename Cls<PB>::FM &x,
 	return r;
 }
 
+// BIP0340's lift_x on the unit's curve (aff_pt_y_from_x + "the even solution", sig/bip0340.c:947-953; curves/aff_pt.c:102), for fields with
+// p = 3 mod 4 (the callers guarantee it): x < p, y = (x^3 + a x + b)^((p + 1) / 4), y^2 checked (not a square: aff_pt_y_from_x fails), and the
+// root whose ORIGINAL-curve representative -- through the export factor ey, so also when the unit computes on an isomorphic curve -- is
+// even.  xd: the canonical digits of x.  Exponent bits are wave-uniform; 2-bit windows as in inv<PB>.  (xo, yo): as import_point delivers them.
+template <int PB, class XD> G29_FN bool lift_x_even(const XD &xd, JG_K, typename Cls<PB>::FM &xo, typename Cls<PB>::FM &yo)
+{
+	typedef typename Cls<PB>::FM FM;
+	typedef typename Cls<PB>::FC FC;
+	constexpr int NL = Cfg<PB>::NL;
+	u32 bx = 0;
+#pragma unroll
+	for (int j = 0; j < NL; j++) {
+		bx = (xd.l[j] - K.p[j] - bx) >> 31;
+	}
+	bool ok = (bx != 0);   // x < p (fp_import_from_buf)
+	const FC onec = constant<FC>(K.one);
+	const auto xm = mul(xd, constant<FC>(K.ix), K);
+	const auto rhs0 = add(mulc(carry(add(sqr(xm, K), constant<FC>(K.a))), xm, K), constant<FC>(K.b));
+	const FM rhs = weaken<FM>(mulc(carry(rhs0), onec, K));
+	u32 e[NL];   // (p + 1) / 4
+	{
+		u32 c = 1;
+#pragma unroll
+		for (int j = 0; j < NL; j++) {
+			const u32 t = K.p[j] + c;
+			e[j] = t & MASK;
+			c = t >> W;
+		}
+#pragma unroll
+		for (int j = 0; j < NL; j++) {
+			e[j] = (e[j] >> 2) | ((j + 1 < NL ? (e[j + 1] & 3u) : 0u) << (W - 2));
+		}
+	}
+	const FM x2 = weaken<FM>(sqr(rhs, K));
+	const FM x3 = weaken<FM>(mul(x2, rhs, K));
+	FM r = weaken<FM>(onec);
+	const int top = ((int)K.pbits - 1) | 1;
+	for (int i = top; i >= 1; i -= 2) {
+		r = weaken<FM>(sqr(r, K));
+		r = weaken<FM>(sqr(r, K));
+		const u32 hi = (e[i / W] >> (i % W)) & 1u, lo = (e[(i - 1) / W] >> ((i - 1) % W)) & 1u;
+		const u32 c = 2u * hi + lo;
+		if (c == 1u) {
+			r = weaken<FM>(mul(r, rhs, K));
+		} else if (c == 2u) {
+			r = weaken<FM>(mul(r, x2, K));
+		} else if (c == 3u) {
+			r = weaken<FM>(mul(r, x3, K));
+		}
+	}
+	{
+		const auto dif = carry(sub_auto<1>(rhs, sqr(r, K), K));
+		ok = ok & is_zero_mulout(mulc(dif, onec, K), K);
+	}
+	u32 d[NL];
+	canonical_digits(d, mul(r, constant<FC>(K.ey), K), K);
+	const bool odd = (d[0] & 1u) != 0u;
+	const FM rn = weaken<FM>(mulc(neg<PB>(r, K), onec, K));
+	xo = weaken<FM>(xm);
+#pragma unroll
+	for (int j = 0; j < NL; j++) {
+		yo.l[j] = odd ? rn.l[j] : r.l[j];
+	}
+	return ok;
+}
+
 #undef JG_K
 }  // namespace jacg

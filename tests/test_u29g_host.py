@@ -60,11 +60,11 @@ def arr(l):
 
 
 class Field:
-    def __init__(self, lib, curve, flavour=0):
+    def __init__(self, lib, curve, flavour=0, iso_u=None):
         c = CURVES[curve]
         self.p, self.a, self.b = c["p"], c["a"], c["b"]
         self.pb = self.p.bit_length()
-        img, self.nl = G.image(self.p, self.a, self.b, flavour)
+        img, self.nl = G.image(self.p, self.a, self.b, flavour, iso_u)
         self.W = G.width(flavour)          # 28 on the Goldilocks unit, 29 everywhere else
         self.MASK = (1 << self.W) - 1
         self.k = arr(img)
@@ -555,3 +555,60 @@ def test_complete_formulas_on_the_radix29_types(curve, flavour, fixture, request
     # the exceptional pairs do give (0 : 0 : 0)
     e = _rcb_add_py(proj(pts[4]), proj(aff_add(pts[4], T2, a, p)), a, b, p)
     assert e == (0, 0, 0)
+
+
+def _iso_u(p, a):
+    """u with a u^4 = -3 mod p (p = 3 mod 4), or None: the isomorphism ecamd_host.cpp:upload_g29 looks for (the brainpool r1 curves have one)"""
+    t = (p - 3) * pow(a, -1, p) % p                  # u^4
+    for s2 in (1, -1):
+        r = pow(t, (p + 1) // 4, p)                   # a square root of t, if any
+        if r * r % p != t:
+            return None
+        r = r * s2 % p
+        u = pow(r, (p + 1) // 4, p)
+        if u * u % p == r:
+            return u
+    return None
+
+
+@pytest.mark.parametrize("curve,flavour,fixture,iso", [
+    ("SECP192R1", 0, "lib", False), ("SECP256R1", 0, "lib", False), ("SECP256K1", 0, "lib", False), ("SECP256K1", 4, "lib_k256", False),
+    ("BRAINPOOLP256R1", 0, "lib", False), ("BRAINPOOLP256R1", 0, "lib", True), ("BRAINPOOLP320R1", 0, "lib", True), ("SECP384R1", 0, "lib", False),
+    ("SECP384R1", 3, "lib_n384", False), ("WEI448", 5, "lib_p448", False), ("BRAINPOOLP512R1", 0, "lib", True), ("SECP521R1", 0, "lib", False),
+    ("SECP521R1", 1, "lib_m521", False)])
+def test_lift_x_even(curve, flavour, fixture, iso, request):
+    """jacg::lift_x_even -- BIP0340's lift_x as the Schnorr multi-scalar multiplication runs it on the device (k_msm_table_g, r_fmt 1): for
+    p = 3 mod 4, x < p, y = (x^3 + a x + b)^((p + 1) / 4) with the square test, and the root that is EVEN ON THE ORIGINAL CURVE also when the
+    unit computes on the isomorphic a = -3 image (the parity goes through the export factor ey); every flavour's own multiplication."""
+    lib = request.getfixturevalue(fixture)
+    c = CURVES[curve]
+    p, a, b = c["p"], c["a"], c["b"]
+    assert p % 4 == 3
+    u = _iso_u(p, a) if iso else None
+    assert (u is not None) == iso
+    f = Field(lib, curve, flavour, u)
+    rng = np.random.default_rng(31 + flavour)
+    nw = (f.pb + 31) // 32
+    fn = getattr(lib, f"g_liftx_{f.pb}")
+    xs = [c["gx"], 0, 1, 2, p - 1, p - 2] + [int.from_bytes(rng.bytes(80), "big") % p for _ in range(60)]
+    n_ok = 0
+    for x in xs + [p, p + 1, (1 << (32 * nw)) - 1]:
+        if x >= 1 << (32 * nw):
+            continue
+        xw = arr([(x >> (32 * k)) & 0xffffffff for k in range(nw)])
+        out = (C.c_uint32 * (2 * f.nl))()
+        ok = fn(f.k, xw, out)
+        rhs = (x * x * x + a * x + b) % p
+        y = pow(rhs, (p + 1) // 4, p)
+        want = x < p and y * y % p == rhs
+        assert bool(ok) == want, (curve, flavour, hex(x))
+        if not want:
+            continue
+        n_ok += 1
+        y = y if y % 2 == 0 else p - y
+        xo, yo = f.val(out[:f.nl]), f.val(out[f.nl:])
+        assert xo < 2 * p and yo < 2 * p and max(out[:f.nl - 1]) <= f.MASK + (1 << 18)     # a multiplication result of the unit
+        uu = u if u is not None else 1
+        assert xo * f.Rinv % p == x * uu * uu % p, (curve, flavour, hex(x))               # the unit's (Montgomery / plain) form of u^2 x
+        assert yo * f.Rinv % p == y * uu**3 % p, (curve, flavour, hex(x))                 # ... of u^3 y_even
+    assert 20 <= n_ok <= len(xs)

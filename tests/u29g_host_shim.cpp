@@ -167,6 +167,18 @@ template <int PB> struct Shim {
 #else
 	static int rcb_(const uint32_t *, const uint32_t *, const uint32_t *, uint32_t *, int) { return -1; }
 #endif
+	// lift_x_even: xw = the abscissa as NW saturated little-endian words; out = xo || yo (multiplication-result class); returns ok
+	static int liftx_(const uint32_t *k, const uint32_t *xw, uint32_t *out)
+	{
+		const CK &K = *(const CK *)k;
+		constexpr int NW = (PB + 31) / 32;
+		const auto xd = from_words<PB, NW>(xw);
+		typename Cls<PB>::FM xo, yo;
+		const bool ok = lift_x_even<PB>(xd, K, xo, yo);
+		memcpy(out, xo.l, 4 * NL);
+		memcpy(out + NL, yo.l, 4 * NL);
+		return ok ? 1 : 0;
+	}
 	static void info_(uint32_t *out)
 	{
 		out[0] = NL;
@@ -193,6 +205,7 @@ template <int PB> struct Shim {
 	void g_inv_##PB(const uint32_t *k, const uint32_t *a, uint32_t *o) { Shim<PB>::inv_(k, a, o); } \
 	void g_canon_##PB(const uint32_t *k, const uint32_t *a, uint32_t *o) { Shim<PB>::canon_(k, a, o); } \
 	void g_info_##PB(uint32_t *o) { Shim<PB>::info_(o); } \
+	int g_liftx_##PB(const uint32_t *k, const uint32_t *xw, uint32_t *o) { return Shim<PB>::liftx_(k, xw, o); } \
 	int g_rcb_##PB(const uint32_t *k, const uint32_t *p, const uint32_t *q, uint32_t *o, int dbl) { return Shim<PB>::rcb_(k, p, q, o, dbl); } \
 	}
 #if defined(SHIM_ONLY_255)

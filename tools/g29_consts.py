@@ -28,7 +28,7 @@ def digits(x, nl, w=W):
     return d
 
 
-def image(p, a, b, flavour=0):
+def image(p, a, b, flavour=0, iso_u=None):
     """flavour 0: dense Montgomery; 1: p = 2^521 - 1 on plain residues, 18 limbs (2^522 = 2); 2: p = 2^255 - 19, nine limbs
     and plain residues (R = 1); 4: p = 2^256 - 2^32 - 977 (secp256k1), the same shape; 5: p = 2^448 - 2^224 - 1, plain residues on 16 limbs
     of 28 bits"""
@@ -43,6 +43,9 @@ def image(p, a, b, flavour=0):
     out += digits(p, nl, w)
     out += digits(R * R % p, nl, w)
     out += digits(R % p, nl, w)
+    if iso_u is not None:
+        # the unit computes on the isomorphic curve (x, y) -> (u^2 x, u^3 y): a u^4, b u^6 (ecamd_host.cpp:upload_g29 does this when a u^4 = -3)
+        a, b = a * pow(iso_u, 4, p) % p, b * pow(iso_u, 6, p) % p
     out += digits(a * R % p, nl, w)
     out += digits(b * R % p, nl, w)
     out += digits(p - 2, nl, w)
@@ -61,7 +64,11 @@ def image(p, a, b, flavour=0):
         assert all(v < 2**32 for v in l)
         out += l
     # coordinate import / export factors (no isomorphism here: R^2, R^2, 1, 1)
-    out += digits(R * R % p, nl, w) * 2 + digits(1, nl, w) * 2
+    if iso_u is None:
+        out += digits(R * R % p, nl, w) * 2 + digits(1, nl, w) * 2
+    else:
+        ui = pow(iso_u, -1, p)
+        out += digits(iso_u**2 * R * R % p, nl, w) + digits(iso_u**3 * R * R % p, nl, w) + digits(ui**2 % p, nl, w) + digits(ui**3 % p, nl, w)
     mpinv = (-pow(p, -1, 1 << w)) % (1 << w)
     out += [mpinv, pbits, 1 if a == p - 3 else 0, 1 if a == 0 else 0]
     return out, nl
