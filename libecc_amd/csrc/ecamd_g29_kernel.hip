@@ -555,7 +555,16 @@ static __device__ __forceinline__ void msm_step(Jac<PB> &acc, bool &inf, bool &b
 	inf = inf & keep;
 }
 
-template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_msm_loop_g(EcamdMsmArgs A, int gslot)
+// occupancy of the Straus loop: the unit's window-loop choice (G29_OCC) unless -DMSM_WAVES=n pins it at n waves per SIMD (0: the compiler's
+// own choice); A/B in profiles/r5l_schnorr_msm_prefetch.md
+#if !defined(MSM_WAVES)
+#define MSM_OCC G29_OCC
+#elif MSM_WAVES == 0
+#define MSM_OCC
+#else
+#define MSM_OCC __attribute__((amdgpu_waves_per_eu(MSM_WAVES, MSM_WAVES)))
+#endif
+template <int PB, int FLAV> __global__ __launch_bounds__(64) MSM_OCC void k_msm_loop_g(EcamdMsmArgs A, int gslot)
 {
 	typedef Lay<PB> L;
 	typedef typename Cls<PB>::FC FC;
@@ -576,38 +585,68 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_msm_
 		acc.Z = T.Z;
 	}
 	bool inf = true, bad = false;
+	// One flat sequence of terms: window pos = wwin .. 0 (position wwin / zwin holds the carry digit 0 / 1 of a recoding), inside a window the
+	// K keys (digit `pos` of z_i (q - e_i)) and, from window zwin down, the K signature points (digit `pos` of z_i, negated).  The next term's
+	// digit is fetched before the current addition starts.  Touching the next term's table entry as well (-DMSM_PREFETCH) was measured and
+	// does not pay (secp256k1, 2^20 items: 19.8 against 19.0 ms, profiles/r5l_schnorr_msm_prefetch.md): the loop waits on its dependent
+	// multiplication chains, not on its look-ups.
+	auto locate = [&](int pos, u32 o, const u32 *&tb, int &dig) {
+		const bool isR = o >= A.K;
+		const u32 j = isR ? o - A.K : o;
+		const u32 item = j * A.L + lane;
+		const bool live = item < A.n;
+		tb = A.tbl + (size_t)((isR ? A.n : 0u) + (live ? item : 0u)) * L::ITEMW;
+		const u32 *kr = tb + 8 * L::ENTW;
+		const int top = isR ? zwin : wwin;
+		const int d = (pos == top) ? (int)kr[L::KRECW - 1] : (int)((kr[pos >> 3] >> (4 * (pos & 7))) & 15u) - 8;
+		dig = live ? d : 0;
+	};
+	int pos = wwin;
+	u32 o = 0;
+	const u32 *ctb;
+	int cdig;
+	locate(pos, o, ctb, cdig);
 #pragma unroll 1
-	for (int pos = wwin; pos >= 0; pos--) {
-		if (pos != wwin) {
+	for (;;) {
+		const u32 nops = (pos <= zwin) ? 2u * A.K : A.K;
+		int npos = pos;
+		u32 no = o + 1;
+		if (no == nops) {
+			npos = pos - 1;
+			no = 0;
+		}
+		const bool has_next = npos >= 0;
+		const u32 *ntb = ctb;
+		int ndig = 0;
+#ifdef MSM_PREFETCH
+		u32 t0 = 0, t1 = 0;
+#endif
+		if (has_next) {
+			locate(npos, no, ntb, ndig);
+#ifdef MSM_PREFETCH
+			const u32 nmag = (u32)(ndig < 0 ? -ndig : ndig);
+			const u32 *ent = ntb + (size_t)(nmag ? nmag - 1 : 0) * L::ENTW;
+			t0 = ent[0];
+			t1 = ent[3 * NL - 1];
+#endif
+		}
+		msm_step<PB>(acc, inf, bad, ctb, cdig, o >= A.K, K);
+#ifdef MSM_PREFETCH
+		asm volatile("" ::"v"(t0), "v"(t1));   // (keeps the two touches alive until here; their values are not used)
+#endif
+		if (!has_next) {
+			break;
+		}
+		if (npos != pos) {
 #pragma unroll 1
 			for (int d = 0; d < 4; d++) {
 				acc = dbl(acc, K);
 			}
 		}
-		// the keys: digit `pos` of z_i (q - e_i); position wwin holds the carry of the recoding (0 / 1)
-#pragma unroll 1
-		for (u32 j = 0; j < A.K; j++) {
-			const u32 item = j * A.L + lane;
-			const bool live = item < A.n;
-			const u32 *tb = A.tbl + (size_t)(live ? item : 0u) * L::ITEMW;
-			const u32 *kr = tb + 8 * L::ENTW;
-			int dig = (pos == wwin) ? (int)kr[L::KRECW - 1] : (int)((kr[pos >> 3] >> (4 * (pos & 7))) & 15u) - 8;
-			dig = live ? dig : 0;
-			msm_step<PB>(acc, inf, bad, tb, dig, false, K);
-		}
-		// the signatures' points, negated: digit `pos` of z_i, 2 zlen + 1 digits
-		if (pos <= zwin) {
-#pragma unroll 1
-			for (u32 j = 0; j < A.K; j++) {
-				const u32 item = j * A.L + lane;
-				const bool live = item < A.n;
-				const u32 *tb = A.tbl + (size_t)(A.n + (live ? item : 0u)) * L::ITEMW;
-				const u32 *kr = tb + 8 * L::ENTW;
-				int dig = (pos == zwin) ? (int)kr[L::KRECW - 1] : (int)((kr[pos >> 3] >> (4 * (pos & 7))) & 15u) - 8;
-				dig = live ? dig : 0;
-				msm_step<PB>(acc, inf, bad, tb, dig, true, K);
-			}
-		}
+		pos = npos;
+		o = no;
+		ctb = ntb;
+		cdig = ndig;
 	}
 	// a doubling that reached infinity silently (cofactor curves) leaves Z = 0: not a sum this path vouches for
 	if (!inf) {
