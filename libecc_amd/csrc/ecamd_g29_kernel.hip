@@ -500,32 +500,27 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_msm_table_g(
 	const FA y1 = weaken<FA>(T1.Y);
 	tab_store<PB>(tb, 0, T1);
 	{
-		Jac<PB> Pa = dbl(P1, K);
-		tab_store<PB>(tb, 1, to_tab(Pa, K));
-		Jac<PB> Pb = add_jac(Pa, T1.X, y1, T1.Z, hz, K);
-		bad |= hz;
-		tab_store<PB>(tb, 2, to_tab(Pb, K));
-		Pa = dbl(Pa, K);
-		tab_store<PB>(tb, 3, to_tab(Pa, K));
-		Pb = add_jac(Pa, T1.X, y1, T1.Z, hz, K);
-		bad |= hz;
-		tab_store<PB>(tb, 4, to_tab(Pb, K));
-		{
-			const TabEnt<PB> t3 = tab_load<PB>(tb, 2);
-			Jac<PB> P3;
-			P3.X = t3.X;
-			P3.Y = weaken<FA>(t3.Y);
-			P3.Z = t3.Z;
-			Pb = dbl(P3, K);
+		// the rolled order of k_table_g: [2j + 1]P = [2j]P + P, [2j + 2]P = 2 [j + 1]P, the multiples re-read from the table as they were stored
+		auto entry = [&](u32 e) {
+			const TabEnt<PB> t = tab_load<PB>(tb, e);
+			Jac<PB> P;
+			P.X = t.X;
+			P.Y = weaken<FA>(t.Y);
+			P.Z = t.Z;
+			return P;
+		};
+		Jac<PB> Pb = dbl(P1, K), Pc = Pb;
+		tab_store<PB>(tb, 1, to_tab(Pb, K));
+#pragma unroll 1
+		for (int j = 1; j <= 3; j++) {
+			Pb = add_jac(entry((u32)(2 * j - 1)), T1.X, y1, T1.Z, hz, K);
+			bad |= hz;
+			tab_store<PB>(tb, 2 * j, to_tab(Pb, K));
+			Pc = dbl(entry((u32)j), K);
+			tab_store<PB>(tb, 2 * j + 1, to_tab(Pc, K));
 		}
-		tab_store<PB>(tb, 5, to_tab(Pb, K));
-		Pb = add_jac(Pb, T1.X, y1, T1.Z, hz, K);
-		bad |= hz;
-		tab_store<PB>(tb, 6, to_tab(Pb, K));
-		Pa = dbl(Pa, K);
-		tab_store<PB>(tb, 7, to_tab(Pa, K));
-		// a doubling reaches infinity silently (points of even order): exact test of the last Z's
-		bad = bad | is_zero_mulout(mulc(mulc(Pa.Z, Pb.Z, K), onec, K), K);
+		// a doubling reaches infinity silently (points of even order): exact test of the last Z's (8P and 7P)
+		bad = bad | is_zero_mulout(mulc(mulc(Pc.Z, Pb.Z, K), onec, K), K);
 	}
 	u32 *kr = tb + 8 * L::ENTW;
 	const int slen = (int)(isR ? A.zlen : A.wlen);
@@ -887,6 +882,25 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_table_g(Ecam
 	P1.Y = weaken<FA>(ym);
 	P1.Z = weaken<FA>(onec);
 	bool hz, bad = false;
+#if !defined(G29_TABLE_UNROLLED)
+	{
+		// staging slot e - 1 holds [e]P, e = 2..8.  A rolled loop: [2j + 1]P = [2j]P + P and [2j + 2]P = 2 [j + 1]P for j = 1..3 -- the same
+		// four doublings and three additions as the spelled-out order (-DG29_TABLE_UNROLLED), re-reading two multiples from the staging they
+		// were just written to, in 40 % of the code (the spelled-out kernel is 300 KB of straight-line code at 384 bits)
+		Jac<PB> Pb = dbl(P1, K), Pc = Pb;
+		jac_store_at<PB>(tb, 1, Pb);
+#pragma unroll 1
+		for (int j = 1; j <= 3; j++) {
+			Pb = add_jac(jac_load_at<PB>(tb, 2 * j - 1), P1.X, P1.Y, P1.Z, hz, K);
+			bad |= hz;
+			jac_store_at<PB>(tb, 2 * j, Pb);
+			Pc = dbl(jac_load_at<PB>(tb, j), K);
+			jac_store_at<PB>(tb, 2 * j + 1, Pc);
+		}
+		// a doubling reaches infinity silently (points of even order): exact test of the last Z's (8P and 7P)
+		bad = bad | is_zero_mulout(mulc(mulc(Pc.Z, Pb.Z, K), onec, K), K);
+	}
+#else
 	{
 		// staging slot e - 1 holds [e]P, e = 2..8
 		Jac<PB> Pa = dbl(P1, K);                                   // 2P
@@ -909,6 +923,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_table_g(Ecam
 		// a doubling reaches infinity silently (points of even order): exact test of the last Z's
 		bad = bad | is_zero_mulout(mulc(mulc(Pa.Z, Pb.Z, K), onec, K), K);
 	}
+#endif
 	if (bad) {
 		A.status[i] = ECAMD_STATUS_REDO;   // a multiple below 9P is infinity: the complete-formula kernel takes the item
 		return;
