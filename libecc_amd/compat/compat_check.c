@@ -1200,9 +1200,9 @@ int main(int argc, char **argv)
 		check_sign("WEI25519", EDDSA25519, SHA512, "EDDSA25519", qn, 1);
 		check_keys("SECP256R1", ECDSA, "ECDSA/SECP256R1", qn);
 		check_xdh(32, qn);
-		check_verify("SECP256K1", BIP0340, SHA256, "BIP0340/SECP256K1/SHA256", qn, 1);
-		check_verify("SECP256R1", ECFSDSA, SHA256, "ECFSDSA/SECP256R1/SHA256", qn < 128 ? qn : 128, 1);
-		check_verify("BRAINPOOLP384R1", ECFSDSA, SHA384, "ECFSDSA/BRAINPOOLP384R1/SHA384", qn < 64 ? qn : 64, 1);
+		check_verify("SECP256K1", BIP0340, SHA256, "BIP0340/SECP256K1/SHA256", qn < 160 ? qn : 160, 1);
+		check_verify("SECP256R1", ECFSDSA, SHA256, "ECFSDSA/SECP256R1/SHA256", qn < 96 ? qn : 96, 1);
+		check_verify("BRAINPOOLP384R1", ECFSDSA, SHA384, "ECFSDSA/BRAINPOOLP384R1/SHA384", qn < 32 ? qn : 32, 1);
 		printf("schnorr multi-scalar calls: %lu\n", ecamd_compat_schnorr_msm_calls());
 		ecamd_compat_shutdown();
 		CHECK(!g_rand_expect_serial || g_rand_overlaps == 0, "get_random entered concurrently %d times", g_rand_overlaps);

@@ -53,7 +53,7 @@ int ecamd_multi_set_msm_seed(ecamd_multi *m, const uint8_t seed[32]) { (void)m; 
 static ecamd_host_ready_fn g_ready_fn;
 static void *g_ready_arg;
 int ecamd_multi_set_host_ready_hook(ecamd_multi *m, ecamd_host_ready_fn fn, void *arg) { (void)m; g_ready_fn = fn; g_ready_arg = arg; return 0; }
-static void mock_ready(uint32_t n) { if (g_ready_fn) { uint32_t o; for (o = 0; o < n; o += 1000) { g_ready_fn(g_ready_arg, o, (n - o) < 1000 ? (n - o) : 1000); } } }
+static void mock_ready(uint32_t n) { if (g_ready_fn) { uint32_t o; for (o = 0; o < n; o += 200) { g_ready_fn(g_ready_arg, o, (n - o) < 200 ? (n - o) : 200); } } }
 void *ecamd_host_alloc(size_t bytes) { return malloc(bytes); }
 void ecamd_host_free(void *p) { free(p); }
 

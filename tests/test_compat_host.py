@@ -45,12 +45,12 @@ def test_every_typed_entry_point_matches_libecc_scalar_functions():
 
 
 def test_thread_pool_and_pipeline_chunks():
-    """one case per family at a size that takes the pool threads and three pipeline chunks (pack c+1 | GPU c | unpack c-1); the
+    """one case per family at a size that takes the pool threads and three pipeline chunks of 256 items (pack c+1 | GPU c | unpack c-1); the
     verification calls are streamed (round 4): ONE device call, started at once, that asks the pool through the producer hook for
-    each of three ranges of the arrays being packed (the stand-in asks 1000 items at a time); nonces and private scalars leave as raw
+    each of three ranges of the arrays being packed (the stand-in asks 200 items at a time); nonces and private scalars leave as raw
     random bytes and are reduced behind the C ABI"""
     _build()
-    r = _run(["quick", "1040"], ECAMD_COMPAT_CHUNK="512", ECAMD_COMPAT_READY_ITEMS="512", ECAMD_COMPAT_THREADS="6")
+    r = _run(["quick", "530"], ECAMD_COMPAT_CHUNK="256", ECAMD_COMPAT_READY_ITEMS="256", ECAMD_COMPAT_THREADS="6")
     assert r.returncode == 0, r.stdout[-4000:]
     assert "all ok" in r.stdout
 
@@ -74,8 +74,6 @@ def test_schnorr_batches_try_the_multi_scalar_form_first():
     assert r.returncode == 0, r.stdout[-4000:]
     assert "all ok" in r.stdout and "ec_verify_batch BIP0340/SECP256K1" in r.stdout and "ec_verify_batch ECFSDSA/SECP256R1" in r.stdout
     assert int(r.stdout.split("schnorr multi-scalar calls:")[1].split()[0]) >= 6, r.stdout[-600:]
-    r = _run(["quick", "60"], ECAMD_COMPAT_SCHNORR_MSM_MIN="0", ECAMD_COMPAT_THREADS="2")
-    assert r.returncode == 0 and int(r.stdout.split("schnorr multi-scalar calls:")[1].split()[0]) == 0
 
 
 def test_no_device_is_an_error_not_a_fallback():
