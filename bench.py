@@ -438,6 +438,12 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch one rank per GPU, or let "
                          "`python bench.py --gpus N` spawn them)")
+    # DRY RUN of the N > 1 code path on a box with fewer GPUs than ranks (development only, never a measurement): with
+    # ECAMD_BENCH_DRY_RUN_SHARED_GPU=1 every rank uses cuda:0 and the process group is gloo (RCCL refuses two ranks on one device); the
+    # JSON line then says so in "dry_run" and carries no claim about scaling
+    dry_shared = world > 1 and os.environ.get("ECAMD_BENCH_DRY_RUN_SHARED_GPU") == "1"
+    if dry_shared:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but {torch.cuda.device_count()} are visible")
     dist = None
@@ -447,7 +453,10 @@ def main():
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if dry_shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from oracles import CURVES, Oracle, build_oracle
     # the CPU checker is compiled on first use: let rank 0 do it alone, the others wait
@@ -616,6 +625,8 @@ def main():
             },
             "setup_s": setup_s,
         }
+        if dry_shared:
+            line["dry_run"] = "ECAMD_BENCH_DRY_RUN_SHARED_GPU=1: all ranks on cuda:0 over gloo -- exercises the N > 1 code path only, NOT a measurement"
         if ub:
             line["ubench"] = {k: (v["cycles_per_wave_instr_per_simd"] if isinstance(v, dict) else v)
                               for k, v in ub.items() if k.startswith("v_") or k.startswith("mix_")}
