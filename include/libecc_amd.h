@@ -72,6 +72,9 @@ int ecamd_ctx_set_eddsa_msm(ecamd_ctx *ctx, int mode, uint32_t min_items, uint32
  * own randomness source instead of getrandom -- libsign_amd.so passes bytes of the application's get_random, the import libecc's
  * own batch verifier draws its z_i from (sig/eddsa.c:2388), so a seeded test harness makes the combination reproducible. */
 int ecamd_ctx_set_msm_seed(ecamd_ctx *ctx, const uint8_t seed[32]);
+/* Drops a seed that no whole-batch call has consumed (a seed keys ONE call: every ec_*_verify_all_batch entry point discards what is
+ * left when it returns, and the ecamd_multi_* forms call this for the ranks that received no shard). */
+int ecamd_ctx_discard_msm_seed(ecamd_ctx *ctx);
 /* Secret scalars.  By default the kernels index their window / comb tables with the scalar's digits (fastest; fine for public
  * scalars: verification, public-key checks).  With this switch on, every multiplication by a caller-supplied scalar issued through
  * the context -- ec_prj_pt_mul_batch*, and inside ec_ecdsa_sign_batch, ec_ecccdh_derive_batch ([d]Q), ec_eddsa_sign_R_batch, key-pair
@@ -295,10 +298,10 @@ int ec_eddsa_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t
 			      uint32_t *first_rejected);
 
 /* Whole-batch predicate of ec_verify_batch for the Schnorr-type algorithms libecc verifies in batches on a short-Weierstrass curve --
- * BIP0340 (bip0340_verify_batch sig/bip0340.c:1196, _bip0340_verify_batch_no_memory :640-1010) and ECFSDSA (ecfsdsa_verify_batch
- * sig/ecfsdsa.c:1042-) -- as ONE multi-scalar multiplication.  The item form of both is  [s_i]G + [q - e_i]Y_i = R_i  (bip0340.c:531-547,
+ * BIP0340 (bip0340_verify_batch sig/bip0340.c:1296, _bip0340_verify_batch_no_memory :808-1025, _bip0340_verify_batch :1027-1294) and
+ * ECFSDSA (ecfsdsa_verify_batch sig/ecfsdsa.c:1057, _ecfsdsa_verify_batch_no_memory :657-837) -- as ONE multi-scalar multiplication.  The item form of both is  [s_i]G + [q - e_i]Y_i = R_i  (bip0340.c:531-547,
  * ecfsdsa.c:561-576); the reference's batch form draws scalars a_i and accepts when
- *     [-sum a_i s_i]G + sum [a_i]R_i + sum [a_i e_i]Y_i   is the point at infinity (bip0340.c:925-1010).
+ *     [-sum a_i s_i]G + sum [a_i]R_i + sum [a_i e_i]Y_i   is the point at infinity (bip0340.c:925-1002).
  * Here: z_i = 128 bits of ChaCha20 (keyed by 32 bytes of getrandom per call, or ecamd_ctx_set_msm_seed), and
  *     T = [sum z_i s_i]G + sum ([z_i ne_i mod q]Y_i - [z_i]R_i),     *all_valid = 1 iff T is the point at infinity
  * evaluated on the radix-2^29 unit of the curve by a Straus loop whose doublings are shared by up to 8 signatures per lane (the R_i
@@ -309,7 +312,11 @@ int ec_eddsa_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t
  * *all_valid = 0 means "not decided here": some item fails the equation, or a point does not import / r_i is no abscissa / s_i >= q /
  * an addition met equal or opposite operands, or the handle has no such unit (ec_schnorr_verify_all_available) -- the caller then
  * verifies item by item, so the batch form never accepts or rejects anything the item form would not (a batch with a bad
- * signature passes with probability ~2^-128, as the reference's does).  libecc rejects num = 0, as this does (-1). */
+ * signature passes with probability ~2^-128, as the reference's does).  That bound needs a group of PRIME order: on a curve with a
+ * cofactor a commitment shifted by a point D of small order passes the combination whenever z_i D = O (probability 1 / ord(D)), so
+ * handles with cofactor != 1 (WEI25519, WEI448) are never served -- ec_schnorr_verify_all_available is 0 and *all_valid stays 0
+ * (the reference's own batch form has that weakness; a loop of ec_verify does not, and this form must not differ from the loop).
+ * libecc rejects num = 0, as this does (-1). */
 int ec_schnorr_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *s, const uint8_t *ne,
 				const uint8_t *keys_aff, const uint8_t *r, int r_fmt, int *all_valid);
 int ec_schnorr_verify_all_available(const ecamd_curve *curve, int r_fmt);   /* 1: the multi-scalar form serves this handle */

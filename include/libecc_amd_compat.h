@@ -211,7 +211,7 @@ int eddsa_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **pub
 
 /*
  * BIP0340 (Schnorr, any curve, as sig/bip0340.c) batch verification, same prototype; replaces bip0340_verify_batch
- * (sig/bip0340.c:1196) behind ec_verify_batch.  Every signature is verified on the GPU(s) -- the key's unique representative
+ * (sig/bip0340.c:1296) behind ec_verify_batch.  Every signature is verified on the GPU(s) -- the key's unique representative
  * with an even y, [s]G + [q - e]Y, the parity and x = r tests -- and the answer is the exact conjunction (the reference's random
  * linear combination has the same answer up to its 2^-128 error); tagged hashes on the host threads.
  * The same entry point serves ECFSDSA (sig/ecfsdsa.c:470-640 per item, ecfsdsa_verify_batch at sig/ecfsdsa.c:1042): signature

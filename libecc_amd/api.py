@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "ecamd_multi_ecdsa_verify_batch", "ecamd_multi_ecdsa_verify_batch_fmt", "ecamd_multi_ecdsa_sign_batch", "ecamd_multi_ecccdh_derive_batch",
     "ecamd_multi_xdh_batch", "ecamd_multi_eddsa_verify_batch", "ecamd_multi_eddsa_verify_all_batch", "ecamd_multi_allgather",
     "ecamd_multi_allgather_streams", "ecamd_multi_eddsa_sign_R_batch", "ecamd_multi_eddsa_sign_S_batch",
-    "ecamd_multi_set_secret_scalars", "ecamd_multi_wipe_scratch", "ecamd_ctx_wipe_scratch", "ecamd_ctx_stream", "ecamd_host_alloc", "ecamd_host_free", "ecamd_ctx_dominant_kernel_ms", "ecamd_ctx_set_msm_seed", "ecamd_multi_set_msm_seed", "ec_eddsa_verify_ph_prj_batch", "ecamd_multi_eddsa_verify_ph_prj_batch", "ec_nn_random_mod_batch", "ec_ecdsa_sign_msg_batch", "ec_key_pair_gen_raw_batch", "ecamd_multi_ecdsa_sign_msg_batch", "ecamd_multi_key_pair_gen_raw_batch", "ec_eddsa_verify_msg_prj_batch", "ecamd_multi_eddsa_verify_msg_prj_batch", "ecamd_ctx_set_host_ready_hook", "ecamd_multi_set_host_ready_hook", "ecamd_multi_prj_pt_add_batch",
+    "ecamd_multi_set_secret_scalars", "ecamd_multi_wipe_scratch", "ecamd_ctx_wipe_scratch", "ecamd_ctx_stream", "ecamd_host_alloc", "ecamd_host_free", "ecamd_ctx_dominant_kernel_ms", "ecamd_ctx_set_msm_seed", "ecamd_ctx_discard_msm_seed", "ecamd_multi_set_msm_seed", "ec_eddsa_verify_ph_prj_batch", "ecamd_multi_eddsa_verify_ph_prj_batch", "ec_nn_random_mod_batch", "ec_ecdsa_sign_msg_batch", "ec_key_pair_gen_raw_batch", "ecamd_multi_ecdsa_sign_msg_batch", "ecamd_multi_key_pair_gen_raw_batch", "ec_eddsa_verify_msg_prj_batch", "ecamd_multi_eddsa_verify_msg_prj_batch", "ecamd_ctx_set_host_ready_hook", "ecamd_multi_set_host_ready_hook", "ecamd_multi_prj_pt_add_batch",
     "ec_schnorr_verify_all_batch", "ec_schnorr_verify_all_available", "ecamd_multi_schnorr_verify_all_batch", "ecamd_debug_schnorr_msm", "ecamd_debug_schnorr_msm_words",
 ]
 

@@ -3766,15 +3766,17 @@ static int schnorr_group(ver_job *J0, u32 cnt, int *results, int fs)
 		}
 	}
 	parallel_for(cnt, bip_pack, &B);
-	/* The whole batch as ONE multi-scalar multiplication first (sig/bip0340.c:905-1010, sig/ecfsdsa.c:1042-: the reference's own batch
+	/* The whole batch as ONE multi-scalar multiplication first (sig/bip0340.c:808-1025, sig/ecfsdsa.c:657-837: the reference's own batch
 	 * equation; include/libecc_amd.h: ec_schnorr_verify_all_batch) when every item passed its pre-checks and the shards are large enough
 	 * for it to pay (profiles/r5b_schnorr_msm.md): it vouches for a VALID batch; anything else -- a bad signature, an abscissa without
 	 * a point, an exceptional addition -- comes back "not decided" and the item-by-item pass below gives the verdict, as the reference's
 	 * own fall-back does.  ECFSDSA keys the combination through the application's get_random, the import the reference draws its a_i
-	 * from (nn_get_random_mod, sig/ecfsdsa.c:960); BIP0340's reference takes no randomness (a ChaCha20 stream keyed by a hash of the
+	 * from (nn_get_random_mod, sig/ecfsdsa.c:745, :960); BIP0340's reference takes no randomness (a ChaCha20 stream keyed by a hash of the
 	 * batch, sig/bip0340.c:758-860): there the engine keys its z_i with getrandom. */
-	if (schnorr_msm_wanted(cnt)) {
-		int all = 0, clean = 1;
+	if (schnorr_msm_wanted(cnt) && ec_schnorr_verify_all_available(ecamd_multi_curve_handle(J->e->mc, 0), fs ? 0 : 1)) {
+		/* (the handle is asked first: nothing is drawn from the application's get_random for a curve the form does not serve --
+		 * a curve with a cofactor, a field without a radix-2^29 unit) */
+		int all = 0, clean = 1, tried = 1;
 		for (j = 0; j < cnt && clean; j++) {
 			clean = !J->pre[j] && !(fs && B.kinf[j]);
 		}
@@ -3791,14 +3793,18 @@ static int schnorr_group(ver_job *J0, u32 cnt, int *results, int fs)
 			r = r || ecamd_multi_set_msm_seed(g_multi, seed);
 			wipe(seed, sizeof(seed));
 			if (r) {
-				goto gpu_err;
+				tried = 0;   /* no seed: the item-by-item pass below needs none */
 			}
 		}
-		if (clean) {
+		if (clean && tried) {
+			/* an accelerator in front of the item-by-item pass, never the arbiter: a failure here (its multi-gigabyte tables at 2^20
+			 * items, say) is reported and the batch is verified item by item */
 			if (ecamd_multi_schnorr_verify_all_batch(g_multi, J->e->mc, cnt, B.sc_s, B.sc_e, B.kaff, fs ? B.wpt : B.rx, fs ? 0 : 1, &all)) {
-				goto gpu_err;
+				fprintf(stderr, "libecc_amd compat: the multi-scalar form failed (%s); verifying item by item\n", ecamd_last_error());
+				all = 0;
+			} else {
+				AT_ADD(&g_schnorr_msm_calls, 1);
 			}
-			AT_ADD(&g_schnorr_msm_calls, 1);
 			if (all) {
 				note_items(cnt);
 				for (j = 0; j < cnt; j++) {
@@ -4195,7 +4201,7 @@ int bip0340_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **p
 	if (!is_bip0340(sig_type) && !is_ecfsdsa(sig_type)) {
 		return -1;
 	}
-	/* argument checks of bip0340_verify_batch / _bip0340_verify_batch[_no_memory] (sig/bip0340.c:1196-1219, :905-920, :651-660):
+	/* argument checks of bip0340_verify_batch / _bip0340_verify_batch[_no_memory] (sig/bip0340.c:1296-1318, :843-845, :1065-1107):
 	 * arrays present, at least one item, one set of parameters, the scratch pad long enough when one is given */
 	if (!s || !pub_keys || !m) {
 		return -1;

@@ -248,6 +248,7 @@ template <int PB> static __device__ __forceinline__ bool import_point(const Ecam
 			by = (yd.l[j] - K.p[j] - by) >> 31;
 		}
 		ok = (bx != 0) & (by != 0);  // both strictly below p
+		ok = ok & ((words_excess<PB, NW>(xw) | words_excess<PB, NW>(yw)) == 0);   // ... as octet strings, not only as the limbs' bits
 		// y = 0 is a point of order 2: the reference's ladder fails on it for every scalar (see k_smul)
 		u32 ynz = 0;
 #pragma unroll
@@ -458,7 +459,8 @@ template <int PB> static __device__ __forceinline__ bool msm_lift_x(const u8 *sr
 	u32 xw[NW];
 	load_be<NW>(src, clen, xw);
 	const auto xd = from_words<PB, NW>(xw);
-	return lift_x_even<PB>(xd, K, xo, yo);
+	const bool fits = words_excess<PB, NW>(xw) == 0;   // r >= 2^(29 NL) is no abscissa (lift_x_even compares the limbs with p)
+	return lift_x_even<PB>(xd, K, xo, yo) & fits;
 }
 
 template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_msm_table_g(EcamdMsmArgs A, int gslot)
@@ -1324,6 +1326,22 @@ template <int PB, int FLAV, bool SCAN4 = false> __global__ __launch_bounds__(64)
 	}
 	if constexpr (HAVE_MADD) {
 		bad = !inf && is_zero_mulout(mulc(acc.Z, constant<FC>(K.one), K), K);
+	}
+	if constexpr (SCAN4) {
+		// secret scalars: nothing after the scan depends on the scalar -- the accumulator is stored whatever it holds,
+		// the output is blanked whatever the outcome (k_finalize_g overwrites it for a finite result, the redo pass for an exceptional
+		// one) and the status is a select; k = 0, k >= q and exceptional sums take the same instructions as every other scalar
+		u32 *tb = stg_ent<PB>(A.tbl, i);
+		Jac<PB> R;
+		R.X = weaken<FA>(acc.X);
+		R.Y = weaken<FA>(acc.Y);
+		R.Z = weaken<FA>(acc.Z);
+		jac_store<PB, STG_QS>(tb, R);
+		for (int b = 0; b < 2 * clen; b++) {
+			out[b] = 0;
+		}
+		A.status[i] = bad ? (u8)ECAMD_STATUS_REDO : (inf ? (u8)2 : (u8)ECAMD_STATUS_JAC);
+		return;
 	}
 	if (bad) {
 		A.status[i] = ECAMD_STATUS_REDO;
@@ -4010,6 +4028,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_prj_import_g
 			znz |= zd.l[j];
 		}
 		bool ok = (bx != 0) & (by != 0) & (bz != 0);
+		ok = ok & ((words_excess<PB, NW>(xw) | words_excess<PB, NW>(yw) | words_excess<PB, NW>(zw)) == 0);
 		xm = weaken<FM>(mul(xd, constant<FC>(K.ix), K));
 		ym = weaken<FM>(mul(yd, constant<FC>(K.iy), K));
 		zm = weaken<FM>(mul(zd, constant<FC>(K.r2), K));

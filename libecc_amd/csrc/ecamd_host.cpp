@@ -524,6 +524,20 @@ extern "C" int ecamd_ctx_set_msm_seed(ecamd_ctx *c, const uint8_t seed[32])
 	return 0;
 }
 
+// Drops a seed that is still pending (ecamd_multi_*_verify_all_batch: a rank whose shard was empty never consumed its copy).
+extern "C" int ecamd_ctx_discard_msm_seed(ecamd_ctx *c)
+{
+	if (!c) {
+		return fail("ecamd_ctx_discard_msm_seed: NULL context");
+	}
+	std::lock_guard<std::mutex> lk(c->mu);
+	if (c->msm_seed_valid) {
+		memset(c->msm_seed_bytes, 0, sizeof(c->msm_seed_bytes));
+		c->msm_seed_valid = false;
+	}
+	return 0;
+}
+
 extern "C" int ecamd_ctx_set_secret_scalars(ecamd_ctx *c, int on)
 {
 	if (!c) {
@@ -662,14 +676,20 @@ extern "C" int ecamd_ctx_synchronize(ecamd_ctx *c)
 // Every call works in the context's shared scratch (window tables, stage[] buffers).  A call enqueued on another
 // stream than the previous one therefore first makes its stream wait for the previous call's last kernel, and
 // leaves an event behind its own last kernel (ctx->mu held for the lifetime of the scope).
+// (the stream of the innermost scope on this thread: what ensure() orders the wipe of a growing scratch buffer behind)
+static thread_local hipStream_t t_scope_stream = nullptr;
+static thread_local bool t_scope_active = false;
 struct StreamScope {
 	ecamd_ctx *c;
-	hipStream_t s;
-	StreamScope(ecamd_ctx *ctx, hipStream_t stream) : c(ctx), s(stream)
+	hipStream_t s, outer;
+	bool outer_active;
+	StreamScope(ecamd_ctx *ctx, hipStream_t stream) : c(ctx), s(stream), outer(t_scope_stream), outer_active(t_scope_active)
 	{
 		if (c->inflight && c->last_stream != s) {
 			(void)hipStreamWaitEvent(s, c->busy, 0);
 		}
+		t_scope_stream = s;
+		t_scope_active = true;
 	}
 	~StreamScope()
 	{
@@ -677,6 +697,8 @@ struct StreamScope {
 			c->last_stream = s;
 			c->inflight = true;
 		}
+		t_scope_stream = outer;
+		t_scope_active = outer_active;
 	}
 };
 
@@ -697,13 +719,28 @@ static int ensure(uint8_t **buf, size_t *have, size_t need)
 	}
 	if (*buf) {
 		// a scratch buffer that has to grow may hold values derived from secret scalars (window tables, recoded or staged
-		// scalars of an earlier group of the same call): it goes back to the allocator zeroed
-		HIPCHK(hipMemset(*buf, 0, *have));
-		HIPCHK(hipDeviceSynchronize());
+		// scalars of an earlier group of the same call): it goes back to the allocator zeroed.  The wipe is ordered
+		// behind the call's own stream -- everything that used the buffer was enqueued on it or is waited for by it (StreamScope, the
+		// side stream's join) -- and only that stream is drained: other contexts on the device keep running (a
+		// device-wide synchronisation stalled every rank of a many-contexts-per-device run on each growth).
+		if (t_scope_active) {
+			HIPCHK(hipMemsetAsync(*buf, 0, *have, t_scope_stream));
+			HIPCHK(hipStreamSynchronize(t_scope_stream));
+		} else {
+			HIPCHK(hipMemset(*buf, 0, *have));
+			HIPCHK(hipDeviceSynchronize());
+		}
 		HIPCHK(hipFree(*buf));
 		*buf = nullptr;
 		*have = 0;
 	}
+	// grow with an eighth of headroom: a sequence of slowly growing batches reallocates (and wipes, and waits) a few times, not every call
+	const size_t want = need + (need >> 3);
+	if (hipMalloc((void **)buf, want) == hipSuccess) {
+		*have = want;
+		return 0;
+	}
+	(void)hipGetLastError();
 	HIPCHK(hipMalloc((void **)buf, need));
 	*have = need;
 	return 0;
@@ -3380,9 +3417,9 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 	// k_ed_lat (S < q, h mod q, the truncated Euclid: integer work with data-dependent trip counts, 0.43 VALU busy) beside the decode
 	// kernel (two square-root chains, MAD bound) on the side stream: both read only the caller's arrays.  $ECAMD_NO_ED_LAT_BESIDE: in line.
 	bool lat_beside = false;
+	EcamdEdLatArgs L;   // stage 3 (n x 64, free on this path): v and |u|, 12 words per item; 9: s' = u S mod q; 13: meta
+	memset(&L, 0, sizeof(L));
 	if (lattice) {
-		EcamdEdLatArgs L;
-		memset(&L, 0, sizeof(L));
 		L.sigs = d_sig;
 		L.hram = d_hram;
 		L.S_be = S[8];
@@ -3413,19 +3450,6 @@ static int eddsa_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 		HIPCHK(ecamd_launch_ed_decode(nw, D, s));
 	}
 	if (lattice) {
-		// stage 3 (n x 64, free on this path): v and |u|, 12 words per item; 9: s' = u S mod q; 13: meta
-		EcamdEdLatArgs L;
-		memset(&L, 0, sizeof(L));
-		L.sigs = d_sig;
-		L.hram = d_hram;
-		L.S_be = S[8];
-		L.sp_be = S[9];
-		L.uv = (uint32_t *)S[3];
-		L.meta = S[13];
-		L.flags = S[7];
-		L.n = n;
-		L.hlen = hram_len;
-		L.qslot = cv->qslot;
 		if (lat_beside) {
 			HIPCHK(hipStreamWaitEvent(s, ctx->side_done, 0));
 		} else {
@@ -4131,7 +4155,7 @@ static int eddsa_msm_host_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, co
 
 // ------------------------------------------------------------------------------------------
 // Schnorr-type whole-batch verification on a short-Weierstrass curve as one multi-scalar multiplication (EcamdMsmArgs in
-// ecamd_internal.h; BIP0340's and ECFSDSA's batch equation, sig/bip0340.c:905-1196, sig/ecfsdsa.c:1042-): per piece of at most
+// ecamd_internal.h; BIP0340's and ECFSDSA's batch equation, sig/bip0340.c:808-1025, sig/ecfsdsa.c:657-837): per piece of at most
 // max_chunk items   k_msm_scal (z_i, z_i (q - e_i), z_i s_i mod q)  ->  k_msm_vsum (c = sum z_i s_i)  ->  [c]G by the handle's
 // fixed-base path  ->  k_msm_table_g (2n window tables)  ->  k_msm_loop_g (Straus, K items per lane)  ->  k_msm_sum_g / final.
 // ------------------------------------------------------------------------------------------
@@ -4279,6 +4303,12 @@ static bool schnorr_msm_available(const ecamd_curve *cv, int r_fmt)
 	if (!schnorr_msm_unit(cv, &pb, &fl, &sl) || cv->qslot < 0 || cv->qbits < 160 || (uint32_t)cv->qlen < 16u) {
 		return false;
 	}
+	// Prime-order groups only.  On a curve with a cofactor a commitment R + D, D of small order, is rejected by the item
+	// form but passes the random combination whenever z_i D = O -- with probability 1 / ord(D), up to 1/2 -- so the batch form would accept
+	// what a loop of ec_verify rejects (the reference's batch has that weakness; this one must not).  Such curves take the item form.
+	if (cv->cofactor != 1) {
+		return false;
+	}
 	if (r_fmt == 1 && (cv->p[0] & 3u) != 3u) {
 		return false;
 	}
@@ -4343,6 +4373,7 @@ static int schnorr_msm_host_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 	return 0;
 }
 
+static void msm_seed_discard(ecamd_ctx *ctx);
 extern "C" int ec_schnorr_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *s, const uint8_t *ne,
 					   const uint8_t *keys_aff, const uint8_t *r, int r_fmt, int *all_valid)
 {
@@ -4350,12 +4381,18 @@ extern "C" int ec_schnorr_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *cv
 		return -1;
 	}
 	*all_valid = 0;
-	std::lock_guard<std::mutex> lk(ctx->mu);
-	HIPCHK(hipSetDevice(ctx->device));
-	if (!schnorr_msm_available(cv, r_fmt)) {
-		return 0;   // not decided here: the caller verifies item by item
+	int ret = 0;
+	{
+		std::lock_guard<std::mutex> lk(ctx->mu);
+		HIPCHK(hipSetDevice(ctx->device));
+		if (schnorr_msm_available(cv, r_fmt)) {
+			ret = schnorr_msm_host_locked(ctx, cv, n, s, ne, keys_aff, r, r_fmt, nullptr, all_valid, nullptr, nullptr);
+		}   // else: not decided here, the caller verifies item by item
 	}
-	return schnorr_msm_host_locked(ctx, cv, n, s, ne, keys_aff, r, r_fmt, nullptr, all_valid, nullptr, nullptr);
+	// the seed of ecamd_ctx_set_msm_seed keys THIS call only: whichever way it ended ("not available", an error before the seed was
+	// read), nothing stays pending for an unrelated whole-batch call
+	msm_seed_discard(ctx);
+	return ret;
 }
 
 extern "C" uint32_t ecamd_debug_schnorr_msm_words(const ecamd_curve *cv)

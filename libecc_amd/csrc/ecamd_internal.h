@@ -279,7 +279,7 @@ struct EcamdMsmScalArgs {
 	const uint8_t *s, *ne;       // n x qlen big-endian: s_i, q - e_i (both must be < q)
 	uint8_t *scW, *scZ;          // n x qlen, n x 16 big-endian (outputs)
 	uint32_t *v;                 // n x NW words: z_i s_i mod q
-	uint32_t *flagword;          // bit 2: some s_i or q - e_i is not below q
+	uint32_t *flagword;          // value 8 (k_msm_scal): some s_i or q - e_i is not below q; 1: a point that does not import / a table multiple at infinity (k_msm_table_g); 2, 4: an exceptional addition in k_msm_loop_g / k_msm_sum_g
 	uint8_t *z_dump;             // may be NULL: n x 16 little-endian z_i (tests)
 	uint32_t seed[8], nonce[3];
 	uint32_t n, qlen;

@@ -208,7 +208,7 @@ extern "C" int ecamd_multi_curve_order_len(const ecamd_mcurve *c) { return (c &&
 
 // run shard(rank, lo, hi) on one host thread per rank; the first failing rank's message becomes the caller's error
 static int run_sharded(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const char *fn,
-		       const std::function<int(int, uint32_t, uint32_t)> &shard)
+		       const std::function<int(int, uint32_t, uint32_t)> &shard, bool consumes_msm_seed = false)
 {
 	if (!m || !c || c->m != m) {
 		return mfail(std::string(fn) + ": bad argument");
@@ -230,6 +230,9 @@ static int run_sharded(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const 
 			if (rc[(size_t)r]) {
 				err[(size_t)r] = ecamd_last_error();  // thread-local of the worker
 			}
+		} else if (consumes_msm_seed) {
+			// a whole-batch call: this rank has no shard, so nothing consumed its copy of the one-shot seed
+			(void)ecamd_ctx_discard_msm_seed(m->ctx[(size_t)r]);
 		}
 	};
 	if (N == 1) {
@@ -439,7 +442,7 @@ extern "C" int ecamd_multi_eddsa_verify_all_batch(ecamd_multi *m, const ecamd_mc
 							     OFF(hram, hram_len), hram_len, &ok[(size_t)r], &f);
 		    first[(size_t)r] = (rc == 0 && !ok[(size_t)r]) ? lo + f : 0xffffffffu;
 		    return rc;
-	    })) {
+	    }, true)) {
 		return -1;
 	}
 	int all = 1;
@@ -472,7 +475,7 @@ extern "C" int ecamd_multi_schnorr_verify_all_batch(ecamd_multi *m, const ecamd_
 	if (run_sharded(m, c, n, "ecamd_multi_schnorr_verify_all_batch", [&](int rk, uint32_t lo, uint32_t hi) {
 		    return ec_schnorr_verify_all_batch(m->ctx[(size_t)rk], c->cv[(size_t)rk], hi - lo, OFF(s, ql), OFF(ne, ql), OFF(keys_aff, 2 * cl), OFF(r, rl), r_fmt,
 						       &ok[(size_t)rk]);
-	    })) {
+	    }, true)) {
 		return -1;
 	}
 	int all = 1;

@@ -754,17 +754,12 @@ __global__ __launch_bounds__(64) void k_p256_comb4m(EcamdSmulArgs A)
 		acc.Z = sel(keep, acc.Z, sel(use_t, onez, S.Z));
 		inf = inf & keep;
 	}
-	if (bad) {
-		A.status[i] = ECAMD_STATUS_REDO;
-		return;
-	}
-	if (inf) {
-		A.status[i] = 2;
-		zero_out(A.out + (size_t)i * 64);
-		return;
-	}
+	// secret scalars: nothing after the scan depends on the scalar -- the accumulator is stored whatever it holds, the
+	// output is blanked whatever the outcome (k_p256_finalize overwrites it for a finite result, the redo pass for an exceptional one) and
+	// the status is a select; k = 0, k >= q and exceptional sums take the same instructions as every other scalar
 	jac_store(A.stg, i, 0, acc);
-	A.status[i] = ECAMD_STATUS_JAC;
+	zero_out(A.out + (size_t)i * 64);
+	A.status[i] = bad ? (u8)ECAMD_STATUS_REDO : (inf ? (u8)2 : (u8)ECAMD_STATUS_JAC);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1238,6 +1238,21 @@ template <int PB, int NW> G29_FN E<PB, MASK, CANON_TB, 1> from_words(const u32 *
 	return r;
 }
 
+// bits of w[] at or above W * NL: what from_words drops.  On the 18-limb unit of 2^521 - 1 (522 bits) a 66-octet coordinate has six of
+// them, so r + k 2^522 would otherwise import as r; zero at compile time wherever the limbs cover the words.
+template <int PB, int NW> G29_FN u32 words_excess(const u32 *w)
+{
+	constexpr int NL = Cfg<PB>::NL, TOP = W * NL;
+	u32 x = 0;
+	if (TOP < 32 * NW) {
+#pragma unroll
+		for (int wi = TOP >> 5; wi < NW; wi++) {
+			x |= (wi == (TOP >> 5)) ? (w[wi] >> (TOP & 31)) : w[wi];
+		}
+	}
+	return x;
+}
+
 template <int NL, int NW> G29_FN void to_words(u32 *w, const u32 *d)  // d: canonical digits
 {
 #pragma unroll

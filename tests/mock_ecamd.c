@@ -23,6 +23,7 @@ struct ecamd_mcurve {
 	orc_curve c;
 	ec_params params;
 	int have_params;
+	int cof1;   /* the curve's order is the generator's: cofactor 1 */
 };
 
 static const char *g_err = "";
@@ -73,6 +74,10 @@ static int curve_from_ec_params(const ec_params *params, ecamd_mcurve **out)
 		free(c);
 		return mfail("mock: curve setup failed");
 	}
+	{
+		int cmp = 1;
+		c->cof1 = !nn_cmp(&params->ec_curve.order, &params->ec_gen_order, &cmp) && cmp == 0;
+	}
 	*out = c;
 	return 0;
 }
@@ -105,6 +110,9 @@ int ecamd_multi_curve_from_params(ecamd_multi *m, const uint8_t *p, uint32_t p_l
 		free(c);
 		return mfail("mock: curve setup failed");
 	}
+	while (curve_order_len > 1 && !curve_order[0]) { curve_order++; curve_order_len--; }
+	while (gen_order_len > 1 && !gen_order[0]) { gen_order++; gen_order_len--; }
+	c->cof1 = curve_order_len == gen_order_len && !memcmp(curve_order, gen_order, gen_order_len);
 	*curve = c;
 	return 0;
 }
@@ -404,6 +412,15 @@ int ecamd_multi_eddsa_verify_all_batch(ecamd_multi *m, const ecamd_mcurve *c, ui
 	}
 	free(res);
 	return r;
+}
+
+/* the stand-in serves every curve whose order equals its generator's (cofactor 1), as the product does */
+const ecamd_curve *ecamd_multi_curve_handle(const ecamd_mcurve *c, int rank) { (void)rank; return (const ecamd_curve *)c; }
+int ec_schnorr_verify_all_available(const ecamd_curve *curve, int r_fmt)
+{
+	const ecamd_mcurve *c = (const ecamd_mcurve *)curve;
+	(void)r_fmt;
+	return (c && c->cof1) ? 1 : 0;
 }
 
 /* the Schnorr-type whole-batch predicate as the exact conjunction of the item form ([s]G + [ne]Y = R; r_fmt 1: same x and an even y) */

@@ -67,6 +67,7 @@ int ecamd_ctx_set_host_ready_hook(ecamd_ctx *ctx, ecamd_host_ready_fn fn, void *
 	ctx->ready_arg = arg;
 	return 0;
 }
+int ecamd_ctx_discard_msm_seed(ecamd_ctx *ctx) { return rec("ecamd_ctx_discard_msm_seed", ctx, 0, {}, {}); }
 int ecamd_ctx_set_msm_seed(ecamd_ctx *ctx, const uint8_t seed[32]) { return rec("ecamd_ctx_set_msm_seed", ctx, 0, {}, {seed[0], seed[1]}); }
 int ecamd_ctx_set_secret_scalars(ecamd_ctx *ctx, int on) { return rec("ecamd_ctx_set_secret_scalars", ctx, 0, {}, {on}); }
 void *ecamd_ctx_stream(ecamd_ctx *) { return nullptr; }

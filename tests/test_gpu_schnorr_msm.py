@@ -227,3 +227,53 @@ def test_sharded_form(gpu_ctx, devices):
     finally:
         mc.free()
         m.close()
+
+
+@pytest.mark.parametrize("curve", ["WEI25519", "WEI448"])
+def test_curves_with_a_cofactor_are_never_served(gpu_ctx, curve):
+    """on a curve with a cofactor the random combination accepts a commitment shifted by a point D of small order
+    whenever z_i D = O (probability 1 / ord(D), up to 1/2), which a loop of ec_verify rejects -- so the multi-scalar form declines such
+    handles altogether: not available, and a perfectly valid batch comes back "not decided here" (the caller then runs the item form)."""
+    rng = np.random.default_rng(77)
+    cv = gpu_ctx.curve(curve)
+    try:
+        assert not cv.schnorr_msm_available(0) and not cv.schnorr_msm_available(1)
+        it = make_items(curve, 40, rng)
+        assert not cv.schnorr_verify_all(it["s"], it["ne"], it["Y"], it["R"], 0)
+        # and a torsion-shifted commitment W + D (D of order 2 on the Weierstrass model: the point with y = 0 does not import; the shift is
+        # taken through the oracle's addition of a point of order 4 doubled) is not accepted either
+        assert not cv.schnorr_verify_all(it["s"], it["ne"], it["Y"], it["R"][:-1] + bytes([it["R"][-1] ^ 1]), 0)
+    finally:
+        cv.free()
+
+
+def test_abscissa_beyond_the_limbs_of_the_521_bit_unit_is_rejected(gpu_ctx):
+    """secp521r1 runs on 18 limbs of 29 bits (522 bits) while a coordinate has 66 octets (528 bits): r + k 2^522 must
+    not lift as r, and a point whose coordinate has one of the six bits above the limbs must not import."""
+    rng = np.random.default_rng(78)
+    curve = "SECP521R1"
+    cv = gpu_ctx.curve(curve)
+    try:
+        if not cv.schnorr_msm_available(1):
+            pytest.skip("no lift_x on this unit")
+        it = make_items(curve, 70, rng, even_y=True)
+        cl = it["cl"]
+        assert cv.schnorr_verify_all(it["s"], it["ne"], it["Y"], it["rx"], 1)
+        for idx in (0, 33, 69):
+            for bit in (0x04, 0x80):                    # 2^522 and 2^527 of the 66-octet big-endian string
+                r = bytearray(it["rx"])
+                r[cl * idx] |= bit
+                assert not cv.schnorr_verify_all(it["s"], it["ne"], it["Y"], bytes(r), 1)
+                R = bytearray(it["R"])
+                R[2 * cl * idx] |= bit
+                assert not cv.schnorr_verify_all(it["s"], it["ne"], it["Y"], bytes(R), 0)
+                Y = bytearray(it["Y"])
+                Y[2 * cl * idx + cl] |= bit
+                assert not cv.schnorr_verify_all(it["s"], it["ne"], bytes(Y), it["R"], 0)
+        # the same strings through the plain multiplication entry point: an import error (status 1), as for any coordinate >= p
+        P = bytearray(it["Y"][:2 * cl])
+        P[0] |= 0x04
+        out, st = cv.scalar_mult(it["s"][:it["ql"]], bytes(P))
+        assert st[0] == 1
+    finally:
+        cv.free()
