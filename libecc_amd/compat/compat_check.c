@@ -956,6 +956,83 @@ static void check_foreign_generator(u32 n)
 /* ---- "compat_check bench <log2 n>": end-to-end rate of ec_verify_batch as a libecc application sees it -- libecc structures
  * in, one int out, the marshalling and the message hashing on the host threads included.  `base` distinct (key, message,
  * signature) triples made with libecc's ec_sign, repeated to n pointers (the batch arrays are arrays of pointers). ---- */
+/* ---- a commitment shifted by a point of small order on a curve with a cofactor.  ECFSDSA on WEI25519: W' = W + D,
+ * D = [q]P != O of order 2, 4 or 8.  ec_verify rejects the item (W' != [s]G - [e]Y); a random linear combination of the batch
+ * accepts it whenever z_i D = O -- probability 1 / ord(D) -- so ec_verify_batch would differ from a loop of ec_verify if the
+ * multi-scalar form served this curve.  One shifted item per round, `rounds` rounds with fresh randomness each. ---- */
+static void check_torsion_shift(u32 rounds)
+{
+	enum { N = 24 };
+	ec_params params;
+	ec_key_pair kps[N];
+	const ec_pub_key *pubs[N];
+	const u8 *sigs[N], *msgs[N];
+	u8 sigbuf[N][3 * 32 + 8], msgbuf[N][16], siglens[N], siglen = 0, saved[64];
+	u32 msglens[N], i, r;
+	int res[N];
+	prj_pt P, D, W;
+	aff_pt A;
+	fp x, y1, y2;
+	int iszero = 1, tries = 0;
+	const u32 before = failures;
+	if (load_params("WEI25519", &params) || ec_get_sig_len(&params, ECFSDSA, SHA512, &siglen) || siglen != 96) {
+		CHECK(0, "torsion shift: setup");
+		return;
+	}
+	/* D: the cofactor-clearing complement of a random curve point */
+	while (iszero && tries++ < 64) {
+		u8 xb[32];
+		if (get_random(xb, sizeof(xb))) {
+			return;
+		}
+		xb[0] &= 0x3f;
+		if (fp_init(&x, &(params.ec_fp)) || fp_init(&y1, &(params.ec_fp)) || fp_init(&y2, &(params.ec_fp)) || fp_import_from_buf(&x, xb, 32)) {
+			continue;
+		}
+		if (aff_pt_y_from_x(&y1, &y2, &x, &(params.ec_curve))) {
+			continue;   /* x is no abscissa */
+		}
+		if (aff_pt_init_from_coords(&A, &(params.ec_curve), &x, &y1) || ec_shortw_aff_to_prj(&P, &A) ||
+		    _prj_pt_unprotected_mult(&D, &(params.ec_gen_order), &P) || prj_pt_iszero(&D, &iszero)) {
+			CHECK(0, "torsion shift: building D");
+			return;
+		}
+	}
+	CHECK(!iszero, "torsion shift: no point of small order found");
+	for (i = 0; i < N; i++) {
+		msglens[i] = 16;
+		msgs[i] = msgbuf[i];
+		pubs[i] = &kps[i].pub_key;
+		sigs[i] = sigbuf[i];
+		siglens[i] = siglen;
+		if (ec_key_pair_gen(&kps[i], &params, ECFSDSA) || get_random(msgbuf[i], 16) ||
+		    ec_sign(sigbuf[i], siglen, &kps[i], msgs[i], 16, ECFSDSA, SHA512, NULL, 0)) {
+			CHECK(0, "torsion shift: signing");
+			return;
+		}
+	}
+	CHECK(ec_verify_batch(sigs, siglens, pubs, msgs, msglens, N, ECFSDSA, SHA512, NULL, NULL, NULL, NULL) == 0, "torsion shift: valid batch rejected");
+	for (r = 0; r < rounds; r++) {
+		const u32 k = r % N;
+		int rb;
+		memcpy(saved, sigbuf[k], 64);
+		if (aff_pt_import_from_buf(&A, sigbuf[k], 64, &(params.ec_curve)) || ec_shortw_aff_to_prj(&W, &A) || prj_pt_add(&W, &W, &D) ||
+		    prj_pt_to_aff(&A, &W) || aff_pt_export_to_buf(&A, sigbuf[k], 64)) {
+			CHECK(0, "torsion shift: W + D");
+			return;
+		}
+		CHECK(ec_verify(sigs[k], siglen, pubs[k], msgs[k], 16, ECFSDSA, SHA512, NULL, 0) != 0, "torsion shift: ec_verify accepts W + D?");
+		rb = ec_verify_batch(sigs, siglens, pubs, msgs, msglens, N, ECFSDSA, SHA512, NULL, NULL, NULL, NULL);
+		CHECK(rb == -1, "torsion shift: round %u: ec_verify_batch accepted a batch whose item %u a loop of ec_verify rejects", r, k);
+		CHECK(ec_verify_batch_results(sigs, siglens, pubs, msgs, msglens, N, ECFSDSA, SHA512, NULL, NULL, res) == 0, "torsion shift: results call");
+		for (i = 0; i < N; i++) {
+			CHECK(res[i] == (i == k ? -1 : 0), "torsion shift: round %u item %u: %d", r, i, res[i]);
+		}
+		memcpy(sigbuf[k], saved, 64);
+	}
+	printf("ec_verify_batch ECFSDSA/WEI25519, W + D with D of small order, %u rounds: %s\n", rounds, failures == before ? "ok" : "FAILED");
+}
+
 static double now_s(void)
 {
 	struct timespec ts;
@@ -1203,6 +1280,7 @@ int main(int argc, char **argv)
 		check_verify("SECP256K1", BIP0340, SHA256, "BIP0340/SECP256K1/SHA256", qn < 160 ? qn : 160, 1);
 		check_verify("SECP256R1", ECFSDSA, SHA256, "ECFSDSA/SECP256R1/SHA256", qn < 96 ? qn : 96, 1);
 		check_verify("BRAINPOOLP384R1", ECFSDSA, SHA384, "ECFSDSA/BRAINPOOLP384R1/SHA384", qn < 32 ? qn : 32, 1);
+		check_torsion_shift(8);
 		printf("schnorr multi-scalar calls: %lu\n", ecamd_compat_schnorr_msm_calls());
 		ecamd_compat_shutdown();
 		CHECK(!g_rand_expect_serial || g_rand_overlaps == 0, "get_random entered concurrently %d times", g_rand_overlaps);
@@ -1269,6 +1347,7 @@ int main(int argc, char **argv)
 	check_verify("SECP256R1", BIP0340, SHA512, "BIP0340/SECP256R1/SHA512", n < 128 ? n : 128, 1);
 	check_verify("SECP256R1", ECFSDSA, SHA256, "ECFSDSA/SECP256R1/SHA256", n, 1);
 	check_verify("BRAINPOOLP384R1", ECFSDSA, SHA384, "ECFSDSA/BRAINPOOLP384R1/SHA384", n < 128 ? n : 128, 1);
+	check_torsion_shift(8);
 	/* an algorithm the GPU does not take goes to libecc's own verifier (no batch form there: -1) */
 	check_verify("SECP256R1", ECKCDSA, SHA256, "ECKCDSA (no batch form)", n < 16 ? n : 16, -1);
 	printf("items sent to the GPU: %llu\n", ecamd_compat_gpu_items());
