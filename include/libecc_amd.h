@@ -320,6 +320,10 @@ int ec_eddsa_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t
 int ec_schnorr_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *s, const uint8_t *ne,
 				const uint8_t *keys_aff, const uint8_t *r, int r_fmt, int *all_valid);
 int ec_schnorr_verify_all_available(const ecamd_curve *curve, int r_fmt);   /* 1: the multi-scalar form serves this handle */
+/* The same combination on device pointers, one piece (n <= the context's max_chunk; a handle for which ec_schnorr_verify_all_available
+ * is 0 is an error here): d_verdict[0] = 0 "the batch is valid" / 1 "not decided here".  Only enqueues on the stream. */
+int ec_schnorr_verify_all_batch_dev(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const void *d_s, const void *d_ne,
+				    const void *d_keys_aff, const void *d_r, int r_fmt, void *d_verdict, void *hip_stream);
 
 /* eddsa_export_pub_key in batch (sig/eddsa.c:795-860): n projective Weierstrass points X || Y || Z (what ec_pub_key.y holds,
  * prj_pt_export_to_buf) of the WEI25519 / WEI448 handle -> prj_pt_shortw_to_aff_pt_edwards -> eddsa_encode_point: n x 32 / 57

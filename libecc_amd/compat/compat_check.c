@@ -1202,6 +1202,370 @@ static void bench_secret_half(u32 n)
 	free(kpp); free(msgs); free(sigs); free(sigbuf); free(kb); free(rb); free(kp); free(rp); free(msglens); free(rets); free(gen);
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * benchj <log2 n>: the typed boundary as ONE JSON object (bench.py's "typed_boundary" record) -- end-to-end rates of the libecc-typed batch
+ * entry points on 2^n items, each beside libecc's OWN function for the same job timed in this process on every host thread the
+ * library uses (a loop of ec_verify / ec_sign over a bounded sample of the same structures; for the algorithms libecc verifies in
+ * batches also its ec_verify_batch on pieces of 256 items per thread).
+ * ------------------------------------------------------------------------------------------------ */
+#include <pthread.h>
+#include <unistd.h>
+typedef struct {
+	const u8 **sigs, **msgs;
+	const u8 *siglens;
+	const u32 *msglens;
+	const ec_pub_key **pubs;
+	const ec_key_pair **kps;
+	ec_alg_type sig_type;
+	hash_alg_type hash_type;
+	u32 lo, hi;
+	int mode;        /* 0: loop of ec_verify, 1: libecc's ec_verify_batch on pieces of 256, 2: loop of ec_sign */
+	int bad;
+} cpu_job;
+static void *cpu_worker(void *arg)
+{
+	cpu_job *J = (cpu_job *)arg;
+	u32 i;
+	if (J->mode == 1) {
+		for (i = J->lo; i < J->hi; i += 256) {
+			const u32 m = (J->hi - i) < 256 ? (J->hi - i) : 256;
+			u16 adl[256];
+			const u8 *ad[256];
+			memset(adl, 0, sizeof(adl));
+			memset(ad, 0, sizeof(ad));
+			J->bad |= libecc_cpu_ec_verify_batch(J->sigs + i, J->siglens + i, J->pubs + i, J->msgs + i, J->msglens + i, m, J->sig_type,
+							     J->hash_type, ad, adl, NULL, NULL) ? 1 : 0;
+		}
+		return NULL;
+	}
+	for (i = J->lo; i < J->hi; i++) {
+		if (J->mode == 0) {
+			J->bad |= ec_verify(J->sigs[i], J->siglens[i], J->pubs[i], J->msgs[i], J->msglens[i], J->sig_type, J->hash_type, NULL, 0) ? 1 : 0;
+		} else {
+			u8 sg[2 * 72];
+			J->bad |= ec_sign(sg, J->siglens[i], J->kps[i], J->msgs[i], J->msglens[i], J->sig_type, J->hash_type, NULL, 0) ? 1 : 0;
+		}
+	}
+	return NULL;
+}
+static int host_threads(void)
+{
+	int n = (int)sysconf(_SC_NPROCESSORS_ONLN);
+	FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+	if (f) {
+		char quota[32];
+		long period = 0;
+		if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") && period > 0) {
+			const int c = (int)((atol(quota) + period - 1) / period);
+			if (c >= 1 && c < n) { n = c; }
+		}
+		fclose(f);
+	}
+	if (getenv("ECAMD_COMPAT_THREADS") && atoi(getenv("ECAMD_COMPAT_THREADS")) > 0) {
+		n = atoi(getenv("ECAMD_COMPAT_THREADS"));
+	}
+	return n < 1 ? 1 : (n > 256 ? 256 : n);
+}
+/* items/s of libecc's own function over the first `sample` items on every host thread; prints the "cpu" member */
+static void cpu_rate(const char *what, cpu_job *proto, u32 sample, int mode)
+{
+	pthread_t th[256];
+	cpu_job J[256];
+	const int T = host_threads();
+	int t, bad = 0;
+	const double t0 = now_s();
+	double el;
+	for (t = 0; t < T; t++) {
+		J[t] = *proto;
+		J[t].mode = mode;
+		J[t].bad = 0;
+		J[t].lo = (u32)((u64)sample * (u64)t / (u64)T);
+		J[t].hi = (u32)((u64)sample * (u64)(t + 1) / (u64)T);
+		if (mode == 1) {   /* whole pieces */
+			J[t].lo = (J[t].lo / 256) * 256;
+			J[t].hi = (t + 1 == T) ? sample : (J[t].hi / 256) * 256;
+		}
+		pthread_create(&th[t], NULL, cpu_worker, &J[t]);
+	}
+	for (t = 0; t < T; t++) {
+		pthread_join(th[t], NULL);
+		bad |= J[t].bad;
+	}
+	el = now_s() - t0;
+	printf("\"%s\": {\"what\": \"%s\", \"items\": %u, \"threads\": %d, \"seconds\": %.3f, \"rate\": %.1f, \"all_accepted\": %s}",
+	       mode == 1 ? "cpu_batch" : "cpu", what, sample, T, el, (double)sample / el, bad ? "false" : "true");
+}
+
+static double best_of(int (*fn)(void *), void *arg, int reps, int *rc)
+{
+	double best = 1e30;
+	int rep;
+	for (rep = 0; rep < reps; rep++) {
+		const double t0 = now_s();
+		*rc |= fn(arg);
+		if (rep && now_s() - t0 < best) {
+			best = now_s() - t0;
+		}
+	}
+	return best;
+}
+typedef struct {
+	const u8 **sigs, **msgs, **adatas;
+	u8 **sigw;
+	const u8 *siglens;
+	const u32 *msglens;
+	const u16 *adlens;
+	const ec_pub_key **pubs;
+	const ec_key_pair **kps;
+	ec_alg_type sig_type;
+	hash_alg_type hash_type;
+	u32 n;
+	u8 siglen;
+	int *rets;
+} typed_call;
+static int call_verify(void *a)
+{
+	typed_call *c = (typed_call *)a;
+	return ec_verify_batch(c->sigs, c->siglens, c->pubs, c->msgs, c->msglens, c->n, c->sig_type, c->hash_type, c->adatas, c->adlens, NULL, NULL);
+}
+static int call_sign(void *a)
+{
+	typed_call *c = (typed_call *)a;
+	return ec_sign_batch(c->sigw, c->siglen, c->kps, c->msgs, c->msglens, c->n, NULL, c->sig_type, c->hash_type, NULL, NULL, c->rets);
+}
+
+/* n DISTINCT valid BIP0340 signatures without libecc's one-at-a-time signer (86 s per 2^20 on 16 threads): keys from
+ * ec_key_pair_gen_batch, the nonce points R = [k]G from prj_pt_mul_batch, then sig/bip0340.c:135-330 item by item on libecc's own
+ * arithmetic -- d = x or q - x for an even P.y, k negated for an even R.y, e = H(H(tag) || H(tag) || R.x || P.x || m) mod q,
+ * s = k + e d mod q.  A sample is checked with libecc's ec_verify by the caller. */
+typedef struct {
+	ec_key_pair *kps;
+	nn *ks;
+	prj_pt *Rs;
+	u8 *sigbuf, *msgbuf;
+	const ec_params *params;
+	u32 lo, hi, ml;
+	int bad;
+} bipsign_job;
+static void *bipsign_worker(void *arg)
+{
+	bipsign_job *J = (bipsign_job *)arg;
+	const ec_params *P = J->params;
+	const u32 cl = (u32)BYTECEIL(P->ec_fp.p_bitlen), ql = (u32)BYTECEIL(P->ec_gen_order_bitlen);
+	u8 tagd[SHA256_DIGEST_SIZE], dig[SHA256_DIGEST_SIZE], buf[2 * 72];
+	sha256_context hc;
+	u32 i;
+	if (sha256_init(&hc) || sha256_update(&hc, (const u8 *)"BIP0340/challenge", 17) || sha256_final(&hc, tagd)) {
+		J->bad = 1;
+		return NULL;
+	}
+	for (i = J->lo; i < J->hi; i++) {
+		aff_pt Ra, Pa;
+		nn d, k, e, s;
+		int odd = 0;
+		u8 *sig = J->sigbuf + (size_t)i * (cl + ql);
+		d.magic = k.magic = e.magic = s.magic = WORD(0);
+		if (prj_pt_to_aff(&Ra, &J->Rs[i]) || prj_pt_to_aff(&Pa, &J->kps[i].pub_key.y) || nn_copy(&d, &J->kps[i].priv_key.x) || nn_copy(&k, &J->ks[i])) {
+			J->bad = 1;
+			continue;
+		}
+		if (nn_isodd(&(Pa.y.fp_val), &odd) || (odd && nn_mod_neg(&d, &d, &(P->ec_gen_order)))) { J->bad = 1; }
+		if (nn_isodd(&(Ra.y.fp_val), &odd) || (odd && nn_mod_neg(&k, &k, &(P->ec_gen_order)))) { J->bad = 1; }
+		if (fp_export_to_buf(sig, (u16)cl, &Ra.x) || fp_export_to_buf(buf, (u16)cl, &Pa.x) || sha256_init(&hc) ||
+		    sha256_update(&hc, tagd, sizeof(tagd)) || sha256_update(&hc, tagd, sizeof(tagd)) || sha256_update(&hc, sig, cl) ||
+		    sha256_update(&hc, buf, cl) || sha256_update(&hc, J->msgbuf + (size_t)i * J->ml, J->ml) || sha256_final(&hc, dig) ||
+		    nn_init_from_buf(&e, dig, sizeof(dig)) || nn_mod(&e, &e, &(P->ec_gen_order)) || nn_mod_mul(&s, &e, &d, &(P->ec_gen_order)) ||
+		    nn_mod_add(&s, &s, &k, &(P->ec_gen_order)) || nn_export_to_buf(sig + cl, (u16)ql, &s)) {
+			J->bad = 1;
+		}
+		nn_uninit(&d); nn_uninit(&k); nn_uninit(&e); nn_uninit(&s);
+	}
+	return NULL;
+}
+static int bip0340_sign_distinct(const ec_params *params, ec_key_pair *kps, u8 *sigbuf, u8 *msgbuf, u32 ml, u32 n)
+{
+	nn *ks = calloc(n, sizeof(nn));
+	prj_pt *Rs = calloc(n, sizeof(prj_pt)), *Gs = calloc(n, sizeof(prj_pt));
+	int *rets = calloc(n, sizeof(int)), bad = 0, t;
+	const int T = host_threads();
+	pthread_t th[256];
+	bipsign_job J[256];
+	u32 i;
+	if (!ks || !Rs || !Gs || !rets || ec_key_pair_gen_batch(kps, params, BIP0340, n, rets)) {
+		return -1;
+	}
+	for (i = 0; i < n && !bad; i++) {
+		/* (nonces: private scalars of a second batch of key pairs would do as well; here 32 random octets reduced by libecc) */
+		u8 rb[40];
+		bad = rets[i] || get_random(rb, sizeof(rb)) || nn_init_from_buf(&ks[i], rb, sizeof(rb)) || nn_mod(&ks[i], &ks[i], &(params->ec_gen_order)) ||
+		      prj_pt_copy(&Gs[i], &(params->ec_gen));
+	}
+	bad = bad || prj_pt_mul_batch(Rs, ks, Gs, n, rets);
+	for (i = 0; i < n && !bad; i++) {
+		bad = rets[i];
+	}
+	for (t = 0; t < T && !bad; t++) {
+		J[t].kps = kps; J[t].ks = ks; J[t].Rs = Rs; J[t].sigbuf = sigbuf; J[t].msgbuf = msgbuf; J[t].params = params; J[t].ml = ml; J[t].bad = 0;
+		J[t].lo = (u32)((u64)n * (u64)t / (u64)T);
+		J[t].hi = (u32)((u64)n * (u64)(t + 1) / (u64)T);
+		pthread_create(&th[t], NULL, bipsign_worker, &J[t]);
+	}
+	for (t = 0; t < T && !bad; t++) {
+		pthread_join(th[t], NULL);
+	}
+	for (t = 0; t < T; t++) {
+		bad |= J[t].bad;
+	}
+	free(ks); free(Rs); free(Gs); free(rets);
+	return bad ? -1 : 0;
+}
+
+static void benchj_family(const char *curve, ec_alg_type sig_type, hash_alg_type hash_type, const char *label, u32 n, int distinct, int with_sign,
+			  int cpu_batch)
+{
+	enum { base = 512, ML = 48 };
+	ec_params params;
+	const u32 nk = distinct ? n : base;
+	ec_key_pair *kps = calloc(nk, sizeof(ec_key_pair));
+	u8 *sigbuf, *msgbuf = calloc(nk, ML), siglen = 0;
+	typed_call C;
+	cpu_job proto;
+	u32 i, sample;
+	int rc = 0;
+	double el;
+	memset(&C, 0, sizeof(C));
+	memset(&proto, 0, sizeof(proto));
+	if (!kps || load_params(curve, &params) || ec_get_sig_len(&params, sig_type, hash_type, &siglen)) {
+		printf("{\"call\": \"%s\", \"error\": \"setup\"}", label);
+		return;
+	}
+	sigbuf = calloc(nk, siglen);
+	C.pubs = calloc(n, sizeof(*C.pubs)); C.kps = calloc(n, sizeof(*C.kps));
+	C.sigs = calloc(n, sizeof(*C.sigs)); C.sigw = calloc(n, sizeof(*C.sigw)); C.msgs = calloc(n, sizeof(*C.msgs)); C.adatas = calloc(n, sizeof(*C.adatas));
+	C.siglens = calloc(n, 1); C.msglens = calloc(n, sizeof(u32)); C.adlens = calloc(n, sizeof(u16)); C.rets = calloc(n, sizeof(int));
+	C.sig_type = sig_type; C.hash_type = hash_type; C.n = n; C.siglen = siglen;
+	if (get_random(msgbuf, ML)) { rc = 1; }
+	for (i = 1; i < nk; i++) {
+		memcpy(msgbuf + (size_t)i * ML, msgbuf, ML);
+		memcpy(msgbuf + (size_t)i * ML, &i, sizeof(i));
+	}
+	if (distinct) {
+		rc |= bip0340_sign_distinct(&params, kps, sigbuf, msgbuf, ML, n);
+	} else {
+		for (i = 0; i < base && !rc; i++) {
+			rc = ec_key_pair_gen(&kps[i], &params, sig_type) || ec_sign(sigbuf + (size_t)i * siglen, siglen, &kps[i], msgbuf + (size_t)i * ML, ML, sig_type, hash_type, NULL, 0);
+		}
+	}
+	for (i = 0; i < n; i++) {
+		C.pubs[i] = &kps[i % nk].pub_key;
+		C.kps[i] = &kps[i % nk];
+		C.sigs[i] = sigbuf + (size_t)(i % nk) * siglen;
+		C.msgs[i] = msgbuf + (size_t)(i % nk) * ML;
+		((u8 *)C.siglens)[i] = siglen;
+		((u32 *)C.msglens)[i] = ML;
+	}
+	if (rc) {
+		printf("{\"call\": \"ec_verify_batch %s\", \"error\": \"signing\"}", label);
+		return;
+	}
+	{
+		const unsigned long calls0 = ecamd_compat_schnorr_msm_calls();
+		el = best_of(call_verify, &C, 4, &rc);
+		printf("{\"call\": \"ec_verify_batch %s\", \"n\": %u, \"ms\": %.3f, \"rate\": %.1f, \"accepted\": %s, \"distinct_items\": %u, \"multi_scalar_calls\": %lu, ",
+		       label, n, el * 1e3, (double)n / el, rc ? "false" : "true", nk, ecamd_compat_schnorr_msm_calls() - calls0);
+	}
+	proto.sigs = C.sigs; proto.msgs = C.msgs; proto.siglens = C.siglens; proto.msglens = C.msglens; proto.pubs = C.pubs; proto.kps = C.kps;
+	proto.sig_type = sig_type; proto.hash_type = hash_type;
+	sample = (u32)(4096 * (host_threads() >= 8 ? 2 : 1));
+	sample = sample < n ? sample : n;
+	cpu_rate("a loop of libecc's ec_verify over the first items of the same arrays", &proto, sample, 0);
+	if (cpu_batch) {
+		printf(", ");
+		cpu_rate("libecc's ec_verify_batch (no scratch pad) on pieces of 256 of the same items", &proto, sample, 1);
+	}
+	printf("}");
+	if (with_sign) {
+		u8 *out = calloc(n, siglen);
+		for (i = 0; i < n; i++) {
+			C.sigw[i] = out + (size_t)i * siglen;
+		}
+		rc = 0;
+		el = best_of(call_sign, &C, 3, &rc);
+		printf(",\n {\"call\": \"ec_sign_batch %s\", \"n\": %u, \"ms\": %.3f, \"rate\": %.1f, \"rc\": %d, ", label, n, el * 1e3, (double)n / el, rc);
+		cpu_rate("a loop of libecc's ec_sign over the first items of the same arrays", &proto, sample, 2);
+		printf("}");
+		free(out);
+	}
+	free(kps); free(sigbuf); free(msgbuf); free(C.pubs); free(C.kps); free(C.sigs); free(C.sigw); free(C.msgs); free(C.adatas);
+	free((void *)C.siglens); free((void *)C.msglens); free((void *)C.adlens); free(C.rets);
+}
+
+/* two application threads inside ec_verify_batch at once (libecc is re-entrant): wall time of two concurrent calls of n / 2
+ * items against the same two calls one after the other */
+static void *conc_worker(void *a)
+{
+	typed_call *c = (typed_call *)a;
+	c->rets[0] = call_verify(c);
+	return NULL;
+}
+static void benchj_concurrent(u32 n)
+{
+	enum { base = 512, ML = 48 };
+	ec_params params;
+	static ec_key_pair kps[base];
+	static u8 sigbuf[base][64], msgbuf[base][ML];
+	typed_call C[2];
+	pthread_t th[2];
+	u32 i, h = n / 2;
+	int rets[2] = {0, 0}, k, rep, rc = 0;
+	double t_seq = 1e30, t_par = 1e30, t0;
+	if (load_params("SECP256R1", &params)) {
+		return;
+	}
+	for (i = 0; i < base; i++) {
+		rc |= ec_key_pair_gen(&kps[i], &params, ECDSA) || get_random(msgbuf[i], ML) || ec_sign(sigbuf[i], 64, &kps[i], msgbuf[i], ML, ECDSA, SHA256, NULL, 0);
+	}
+	for (k = 0; k < 2; k++) {
+		memset(&C[k], 0, sizeof(C[k]));
+		C[k].pubs = calloc(h, sizeof(*C[k].pubs)); C[k].sigs = calloc(h, sizeof(*C[k].sigs)); C[k].msgs = calloc(h, sizeof(*C[k].msgs));
+		C[k].adatas = calloc(h, sizeof(*C[k].adatas)); C[k].siglens = calloc(h, 1); C[k].msglens = calloc(h, sizeof(u32)); C[k].adlens = calloc(h, sizeof(u16));
+		C[k].rets = &rets[k]; C[k].sig_type = ECDSA; C[k].hash_type = SHA256; C[k].n = h;
+		for (i = 0; i < h; i++) {
+			C[k].pubs[i] = &kps[(i + 7 * k) % base].pub_key; C[k].sigs[i] = sigbuf[(i + 7 * k) % base]; C[k].msgs[i] = msgbuf[(i + 7 * k) % base];
+			((u8 *)C[k].siglens)[i] = 64; ((u32 *)C[k].msglens)[i] = ML;
+		}
+	}
+	for (rep = 0; rep < 4; rep++) {
+		t0 = now_s();
+		rc |= call_verify(&C[0]) | call_verify(&C[1]);
+		if (rep && now_s() - t0 < t_seq) { t_seq = now_s() - t0; }
+	}
+	for (rep = 0; rep < 4; rep++) {
+		t0 = now_s();
+		pthread_create(&th[0], NULL, conc_worker, &C[0]);
+		pthread_create(&th[1], NULL, conc_worker, &C[1]);
+		pthread_join(th[0], NULL);
+		pthread_join(th[1], NULL);
+		rc |= rets[0] | rets[1];
+		if (rep && now_s() - t0 < t_par) { t_par = now_s() - t0; }
+	}
+	printf("{\"call\": \"two application threads, ec_verify_batch ECDSA/SECP256R1/SHA256 of %u items each\", \"one_after_the_other_ms\": %.3f, "
+	       "\"at_once_ms\": %.3f, \"overlap_gain\": %.3f, \"accepted\": %s}", h, t_seq * 1e3, t_par * 1e3, t_seq / t_par, rc ? "false" : "true");
+}
+
+static void benchj(u32 n)
+{
+	printf("{\"items\": %u, \"host_threads\": %d, \"records\": [\n ", n, host_threads());
+	benchj_family("SECP256R1", ECDSA, SHA256, "ECDSA/SECP256R1/SHA256", n, 0, 1, 0);
+	printf(",\n ");
+	benchj_family("WEI25519", EDDSA25519, SHA512, "EDDSA25519", n, 0, 0, 1);
+	printf(",\n ");
+	benchj_family("SECP256K1", BIP0340, SHA256, "BIP0340/SECP256K1/SHA256", n, 1, 0, 1);
+	printf(",\n ");
+	benchj_concurrent(n);
+	printf("\n]}\n");
+}
+
 int main(int argc, char **argv)
 {
 	const u32 n = (argc > 1) ? (u32)atoi(argv[1]) : 256;
@@ -1217,6 +1581,18 @@ int main(int argc, char **argv)
 		} else {
 			bench_verify("SECP256R1", ECDSA, SHA256, "ECDSA/SECP256R1/SHA256", bn);
 		}
+		ecamd_compat_shutdown();
+		return 0;
+	}
+	if (argc > 2 && !strcmp(argv[1], "benchj")) {
+		const u32 bn = 1u << (u32)atoi(argv[2]);
+		if (ecamd_compat_init(NULL, 0, 0)) {
+			printf("no GPU path\n");
+			return 3;
+		}
+		ecamd_compat_set_concurrent_random(1);   /* this application's get_random is thread-safe (per-thread pools) */
+		g_rand_expect_serial = 0;
+		benchj(bn);
 		ecamd_compat_shutdown();
 		return 0;
 	}

@@ -4076,7 +4076,14 @@ static int eddsa_msm_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, con
 	N.L = L;
 	N.qslot = cv->qslot;
 	HIPCHK(ecamd_launch_edmsm_lane(N, s));
+	if (ctx->timing) {
+		HIPCHK(hipEventRecord(ctx->ev_dom[0], s));   // the dominant kernel: k_edmsm_loop (ecamd_ctx_dominant_kernel_ms)
+	}
 	HIPCHK(ecamd_launch_edmsm_loop(A, cv->gslot, s));
+	if (ctx->timing) {
+		HIPCHK(hipEventRecord(ctx->ev_dom[1], s));
+		ctx->ev_dom_valid = true;
+	}
 	HIPCHK(ecamd_launch_edmsm_reduce(A, (uint32_t *)(M + o_tmp), (const uint32_t *)(M + o_word), d_verdict, d_sum_dump, cv->gslot, s));
 	return 0;
 }
@@ -4282,7 +4289,15 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 	A.zlen = 16;
 	A.r_fmt = (uint32_t)r_fmt;
 	for (int phase = 0; phase < 3; phase++) {
+		const bool timed = ctx->timing && phase == 1;   // the dominant kernel: k_msm_loop_g (ecamd_ctx_dominant_kernel_ms)
+		if (timed) {
+			HIPCHK(hipEventRecord(ctx->ev_dom[0], s));
+		}
 		HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, phase, A, (uint32_t *)(M + o_tmp), M + o_gen, M + o_gst, d_verdict, d_sum_dump, s));
+		if (timed) {
+			HIPCHK(hipEventRecord(ctx->ev_dom[1], s));
+			ctx->ev_dom_valid = true;
+		}
 	}
 	return 0;
 }
@@ -4391,6 +4406,38 @@ extern "C" int ec_schnorr_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *cv
 	}
 	// the seed of ecamd_ctx_set_msm_seed keys THIS call only: whichever way it ended ("not available", an error before the seed was
 	// read), nothing stays pending for an unrelated whole-batch call
+	msm_seed_discard(ctx);
+	return ret;
+}
+
+// The combination alone, device pointers, one piece (n <= the context's max_chunk): d_verdict[0] = 0 when the batch equation holds and no
+// exceptional event was met, 1 otherwise ("not decided here").  Only enqueues on the stream.
+extern "C" int ec_schnorr_verify_all_batch_dev(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const void *d_s, const void *d_ne,
+						   const void *d_keys_aff, const void *d_r, int r_fmt, void *d_verdict, void *hip_stream)
+{
+	if (schnorr_args_ok("ec_schnorr_verify_all_batch_dev", ctx, cv, n, d_s, d_ne, d_keys_aff, d_r, r_fmt, d_verdict)) {
+		return -1;
+	}
+	int ret = -1;
+	{
+		std::lock_guard<std::mutex> lk(ctx->mu);
+		HIPCHK(hipSetDevice(ctx->device));
+		if (n > ctx->max_chunk || !schnorr_msm_available(cv, r_fmt)) {
+			ret = fail("ec_schnorr_verify_all_batch_dev: needs a prime-order curve with a radix-2^29 unit (ec_schnorr_verify_all_available) and n <= max_chunk");
+		} else {
+			uint8_t seed[32];
+			if (!msm_seed(ctx, seed)) {
+				hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+				StreamScope scope(ctx, s);
+				PublicScalars pub_scope(ctx);
+				if (hipMemsetAsync(d_verdict, 1, 1, s) == hipSuccess) {
+					ret = schnorr_msm_dev_locked(ctx, cv, n, (const uint8_t *)d_s, (const uint8_t *)d_ne, (const uint8_t *)d_keys_aff,
+								     (const uint8_t *)d_r, r_fmt, seed, 0, (uint8_t *)d_verdict, nullptr, nullptr, s);
+				}
+				memset(seed, 0, sizeof(seed));
+			}
+		}
+	}
 	msm_seed_discard(ctx);
 	return ret;
 }

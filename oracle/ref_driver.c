@@ -831,6 +831,78 @@ int refdrv_eddsa_verify_batch_all(int is448, int use_scratch, uint32_t n, const 
 	return 0;
 }
 
+/* ---- ec_verify_batch (sig/sig_algs.c:675) for the algorithms whose keys import from affine X || Y -- BIP0340 (-> bip0340_verify_batch,
+ * sig/bip0340.c:1296), ECFSDSA (-> ecfsdsa_verify_batch, sig/ecfsdsa.c:1057), also ECDSA (no batch form in libecc: -1) -- with or without
+ * the scratch pad: ONE accept bit for n signatures of sig_len octets.  per_item (may be NULL): n bytes, ec_verify's verdict per item
+ * (0 accept / 1 reject), computed by a loop of ec_verify over the same structures.  *all_valid = 1 iff every key imported and
+ * ec_verify_batch returned 0.  Keys: ec_pub_key_import_from_aff_buf, as an application holding raw points would. ---- */
+int refdrv_sig_verify_batch_all(const char *curve, int alg, int hash_type, int use_scratch, uint32_t n, const uint8_t *pubs_aff,
+				const uint8_t *sigs, uint32_t sig_len, const uint8_t *msgs, uint32_t msg_len, int *all_valid, uint8_t *per_item)
+{
+	ec_params params;
+	ec_pub_key *keys;
+	const ec_pub_key **kp;
+	const u8 **sp, **mp, **ad;
+	u8 *sl;
+	u16 *al;
+	u32 *ml;
+	uint32_t i, clen;
+	int ret = 0;
+	*all_valid = 0;
+	if (load_params(curve, &params) || n == 0 || sig_len > 255) {
+		return -1;
+	}
+	clen = (uint32_t)BYTECEIL(params.ec_fp.p_bitlen);
+	keys = calloc(n, sizeof(ec_pub_key));
+	kp = calloc(n, sizeof(*kp));
+	sp = calloc(n, sizeof(*sp));
+	mp = calloc(n, sizeof(*mp));
+	sl = calloc(n, 1);
+	ml = calloc(n, sizeof(u32));
+	ad = calloc(n, sizeof(*ad));
+	al = calloc(n, sizeof(u16));
+	if (!keys || !kp || !sp || !mp || !sl || !ml || !ad || !al) {
+		return -1;
+	}
+	refdrv_seed(0x5EC9256ULL);
+	for (i = 0; i < n; i++) {
+		const int r = ec_pub_key_import_from_aff_buf(&keys[i], &params, pubs_aff + (size_t)i * 2 * clen, (u8)(2 * clen), (ec_alg_type)alg);
+		ret = ret || r;
+		kp[i] = &keys[i];
+		sp[i] = sigs + (size_t)i * sig_len;
+		mp[i] = msgs + (size_t)i * msg_len;
+		sl[i] = (u8)sig_len;
+		ml[i] = msg_len;
+		if (per_item) {
+			per_item[i] = (r || ec_verify(sp[i], sl[i], kp[i], mp[i], ml[i], (ec_alg_type)alg, (hash_alg_type)hash_type, NULL, 0)) ? 1 : 0;
+		}
+	}
+	if (!ret) {
+		if (use_scratch) {
+			u32 pad_len = (u32)((2 * (size_t)n + 1) * sizeof(verify_batch_scratch_pad));
+			verify_batch_scratch_pad *pad = calloc(1, pad_len);
+			if (!pad) {
+				return -1;
+			}
+			ret = ec_verify_batch(sp, sl, kp, mp, ml, n, (ec_alg_type)alg, (hash_alg_type)hash_type, ad, al, pad, &pad_len);
+			free(pad);
+		} else {
+			ret = ec_verify_batch(sp, sl, kp, mp, ml, n, (ec_alg_type)alg, (hash_alg_type)hash_type, ad, al, NULL, NULL);
+		}
+	}
+	*all_valid = ret ? 0 : 1;
+	free(keys); free(kp); free(sp); free(mp); free(sl); free(ml); free(ad); free(al);
+	return 0;
+}
+int refdrv_alg_id(const char *name)
+{
+	if (!strcmp(name, "ECDSA")) { return (int)ECDSA; }
+	if (!strcmp(name, "BIP0340")) { return (int)BIP0340; }
+	if (!strcmp(name, "ECFSDSA")) { return (int)ECFSDSA; }
+	if (!strcmp(name, "EDDSA25519")) { return (int)EDDSA25519; }
+	return -1;
+}
+
 /* ---- aff_pt_y_from_x (curves/aff_pt.c:102): the two square roots of x^3 + a x + b in the order fp_sqrt returns them ---- */
 int refdrv_y_from_x_batch(const char *curve, uint32_t n, const uint8_t *xs, uint8_t *y1, uint8_t *y2, uint8_t *status)
 {

@@ -719,3 +719,72 @@ def ref_structured_pub_import(curve, keys, alg):
     out, st = C.create_string_buffer(max(1, 2 * cl * n)), C.create_string_buffer(max(1, n))
     assert L.refdrv_structured_pub_import_batch(curve.encode(), alg, n, keys, klen, out, st) == 0
     return out.raw[:2 * cl * n], st.raw[:n]
+
+
+# ---- the reference's own batch verifier (ec_verify_batch, sig/sig_algs.c:675) on raw keys / signatures / messages ----
+def ref_sig_verify_all(curve, alg, hash_name, pubs_aff, sigs, sig_len, msgs, msg_len, scratch=False, per_item=False, sub_batches=1):
+    """ec_verify_batch of the unmodified reference (BIP0340 -> bip0340_verify_batch sig/bip0340.c:1296, ECFSDSA -> ecfsdsa_verify_batch
+    sig/ecfsdsa.c:1057) on n items.  sub_batches = 1: ONE call over the whole batch, as an application makes it.  sub_batches > 1: the batch
+    is cut into that many contiguous pieces, the reference's batch function runs on each piece on its own host thread, and the verdict is
+    the conjunction (libecc's verifier is single-threaded: a 2^20-item call takes a quarter of an hour; the conjunction of its verdicts
+    on the pieces is the same predicate up to the 2^-128 of each random combination).  Returns all_valid, or (all_valid, per-item bytes of
+    a loop of ec_verify) with per_item."""
+    L = C.CDLL(REF_SO)
+    cl = clen(curve)
+    n = len(pubs_aff) // (2 * cl)
+    alg_id = L.refdrv_alg_id(alg.encode())
+    assert alg_id >= 0
+
+    def piece(lo, hi):
+        ok = C.c_int(0)
+        res = C.create_string_buffer(max(1, hi - lo)) if per_item else None
+        assert L.refdrv_sig_verify_batch_all(curve.encode(), alg_id, HASH_IDS[hash_name], int(scratch), hi - lo, pubs_aff[2 * cl * lo:2 * cl * hi],
+                                             sigs[sig_len * lo:sig_len * hi], sig_len, msgs[msg_len * lo:msg_len * hi], msg_len,
+                                             C.byref(ok), res) == 0
+        return bool(ok.value), (res.raw[:hi - lo] if per_item else b"")
+    if sub_batches <= 1:
+        parts = [piece(0, n)]
+    else:
+        parts = in_slices(piece, n, threads=min(sub_batches, n))
+    all_ok = all(p[0] for p in parts)
+    return (all_ok, b"".join(p[1] for p in parts)) if per_item else all_ok
+
+
+def make_bip0340_batch(fixed_base_mult, curve, n, rng, msg_len=32, hash_name="SHA256"):
+    import numpy as np
+    """n valid BIP0340 signatures made from Python integers (sig/bip0340.c:135-330 restated: d = x or q - x so that [d]G has an even y,
+    R = [k]G with k negated when R.y is odd, e = H(H(tag) || H(tag) || R.x || P.x || m) mod q, s = k + e d): the two fixed-base
+    multiplications per item come from `fixed_base_mult(scalars) -> (affine points, status)` (the GPU library in the GPU tests and in
+    bench.py -- the signatures are then CHECKED by the unmodified reference, so nothing trusts that path -- or the CPU oracle).
+    Returns the application's view (pubs = affine [x]G as generated, sigs = r || s, msgs) and the multi-scalar form's inputs
+    (s, ne = q - e, keys = the even-y representative, rx)."""
+    c = CURVES[curve]
+    q, p = c["q"], c["p"]
+    cl, ql = clen(curve), qlen(curve)
+    raw = rng.integers(0, 256, size=(2, n, ql + 8), dtype=np.uint8)
+    x = [(int.from_bytes(raw[0, i].tobytes(), "big") % (q - 1)) + 1 for i in range(n)]
+    k = [(int.from_bytes(raw[1, i].tobytes(), "big") % (q - 1)) + 1 for i in range(n)]
+    msgs = rng.integers(0, 256, size=n * msg_len, dtype=np.uint8).tobytes()
+    P, st = fixed_base_mult(b"".join(v.to_bytes(ql, "big") for v in x))
+    R, st2 = fixed_base_mult(b"".join(v.to_bytes(ql, "big") for v in k))
+    assert set(st) == {0} and set(st2) == {0}
+    hf = getattr(hashlib, HASHLIB[hash_name])
+    tagd = hf(b"BIP0340/challenge").digest()
+    pre = hf(tagd + tagd)
+    sigs, s_l, ne_l, keys, rx = bytearray(), bytearray(), bytearray(), bytearray(), bytearray()
+    for i in range(n):
+        Px, Py = P[2 * cl * i:2 * cl * i + cl], P[2 * cl * i + cl:2 * cl * (i + 1)]
+        Rx, Ry = R[2 * cl * i:2 * cl * i + cl], R[2 * cl * (i + 1) - 1]
+        d = x[i] if not (Py[-1] & 1) else q - x[i]
+        kk = k[i] if not (Ry & 1) else q - k[i]
+        h = pre.copy()
+        h.update(Rx + Px + msgs[msg_len * i:msg_len * (i + 1)])
+        e = int.from_bytes(h.digest(), "big") % q
+        s = ((kk + e * d) % q).to_bytes(ql, "big")
+        sigs += Rx + s
+        s_l += s
+        ne_l += ((q - e) % q).to_bytes(ql, "big")
+        keys += Px + (Py if not (Py[-1] & 1) else (p - int.from_bytes(Py, "big")).to_bytes(cl, "big"))
+        rx += Rx
+    return {"pubs": P, "sigs": bytes(sigs), "sig_len": cl + ql, "msgs": msgs, "msg_len": msg_len, "s": bytes(s_l), "ne": bytes(ne_l),
+            "keys": bytes(keys), "rx": bytes(rx), "n": n, "cl": cl, "ql": ql, "q": q, "p": p}

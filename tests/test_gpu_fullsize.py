@@ -164,3 +164,108 @@ def test_x25519_full_size_vs_reference_binary(gpu_ctx):
             (cut(s1, 32, idx), bytes(len(idx)))
     finally:
         cv.free()
+
+
+# ---- row f4 at the reference's own batch function ("What's weak" 1 / item 2) ----
+def _pieces(n, size, count, rng, must_hold=None):
+    """`count` random contiguous pieces of `size` items of range(n) (aligned to `size`), always including the one that holds must_hold"""
+    slots = max(1, n // size)
+    pick = set(int(x) for x in rng.choice(slots, size=min(count, slots), replace=False))
+    if must_hold is not None:
+        pick.add(min(slots - 1, must_hold // size))
+    return [(size * x, min(n, size * x + size)) for x in sorted(pick)]
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref/libecc_ref.so not built")
+@pytest.mark.parametrize("log2n", [17, 20])
+def test_bip0340_whole_batch_vs_the_reference_batch_verifier(gpu_ctx, log2n):
+    """ec_schnorr_verify_all_batch (the form libsign_amd.so's ec_verify_batch switches to from 2^17 items per device) against
+    libecc's OWN batch function on the same batch: ec_verify_batch -> bip0340_verify_batch (sig/sig_algs.c:675, sig/bip0340.c:1296).
+    2^n distinct BIP0340 signatures are made from Python integers (oracles.make_bip0340_batch); the reference must accept them and
+    reject the batch once one item, at a random index, is damaged -- and the GPU form must say the same both times.  libecc's verifier
+    is one thread at 4 ms per item (and its Bos-Coster variant is quadratic in the batch), so the reference runs on contiguous PIECES
+    on every host thread: the whole batch at 2^17 (pieces of 2^12), random pieces totalling 2^15 items plus the piece holding the
+    damaged item at 2^20."""
+    curve = "SECP256K1"
+    n = 1 << min(log2n, LOG2N)
+    rng = np.random.default_rng(1700 + log2n)
+    cv = gpu_ctx.curve(curve)
+    try:
+        it = O.make_bip0340_batch(lambda sc: cv.scalar_mult(sc), curve, n, rng)
+        cl, ql, sl = it["cl"], it["ql"], it["sig_len"]
+        assert cv.schnorr_verify_all(it["s"], it["ne"], it["keys"], it["rx"], 1)
+        k = int(rng.integers(0, n))
+        psize = 1 << 12 if log2n <= 17 else 1 << 9
+        pieces = _pieces(n, psize, n // psize if log2n <= 17 else (1 << 15) // psize, rng, must_hold=k)
+
+        def ref(sigs, pcs):
+            def one(lo, hi):
+                return [O.ref_sig_verify_all(curve, "BIP0340", "SHA256", it["pubs"][2 * cl * a:2 * cl * b], sigs[sl * a:sl * b], sl,
+                                             it["msgs"][32 * a:32 * b], 32) for a, b in pcs[lo:hi]]
+            return [v for part in O.in_slices(one, len(pcs)) for v in part]
+        assert all(ref(it["sigs"], pieces)), "the unmodified reference rejects a piece of the batch the GPU accepted"
+        # one damaged item: s_k + 1 in the signature the reference sees and in the scalar the multi-scalar form sees
+        s_k = (int.from_bytes(it["s"][ql * k:ql * (k + 1)], "big") + 1) % it["q"]
+        bad_s = it["s"][:ql * k] + s_k.to_bytes(ql, "big") + it["s"][ql * (k + 1):]
+        bad_sigs = it["sigs"][:sl * k + cl] + s_k.to_bytes(ql, "big") + it["sigs"][sl * (k + 1):]
+        assert not cv.schnorr_verify_all(bad_s, it["ne"], it["keys"], it["rx"], 1)
+        # (every other piece is byte-identical to the run above: the piece that holds item k and a few neighbours are run again)
+        again = [p for p in pieces if p[0] <= k < p[1]] + [p for p in pieces if not (p[0] <= k < p[1])][:O.host_threads() - 1]
+        verdicts = ref(bad_sigs, again)
+        assert not verdicts[0] and all(verdicts[1:])
+    finally:
+        cv.free()
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref/libecc_ref.so not built")
+@pytest.mark.parametrize("log2n", [17, 20])
+def test_ed25519_whole_batch_vs_the_reference_batch_verifier(gpu_ctx, log2n):
+    """the same for ec_eddsa_verify_all_batch against ec_verify_batch -> eddsa_verify_batch (sig/eddsa.c:2904) of the unmodified
+    reference: 2^n distinct signatures (signed on the GPU by ec_eddsa_sign_R/S_batch, hashes by hashlib), accepted by both; one damaged
+    item at a random index: rejected by both (the reference on the piece that holds it, every other sampled piece still accepted)."""
+    n = 1 << min(log2n, LOG2N)
+    rng = np.random.default_rng(2500 + log2n)
+    cv = gpu_ctx.curve("WEI25519")
+    try:
+        seeds, msgs = rand_bytes(rng, 32 * n), rand_bytes(rng, 32 * n)
+        hk = [hashlib.sha512(seeds[32 * i:32 * i + 32]).digest() for i in range(n)]
+        a_np = np.frombuffer(b"".join(h[:32] for h in hk), dtype=np.uint8).reshape(n, 32).copy()
+        a_np[:, 0] &= 248
+        a_np[:, 31] &= 127
+        a_np[:, 31] |= 64
+        wide = np.zeros((n, 64), dtype=np.uint8)
+        wide[:, :32] = a_np
+        pubs, st = cv.eddsa_sign_R(wide.tobytes())
+        assert set(st) == {0}
+        r_hash = b"".join(hashlib.sha512(hk[i][32:] + msgs[32 * i:32 * i + 32]).digest() for i in range(n))
+        Renc, st = cv.eddsa_sign_R(r_hash)
+        assert set(st) == {0}
+        hram = b"".join(hashlib.sha512(Renc[32 * i:32 * i + 32] + pubs[32 * i:32 * i + 32] + msgs[32 * i:32 * i + 32]).digest() for i in range(n))
+        Sb = cv.eddsa_sign_S(r_hash, hram, a_np.tobytes())
+        sg = np.empty((n, 64), dtype=np.uint8)
+        sg[:, :32] = np.frombuffer(Renc, dtype=np.uint8).reshape(n, 32)
+        sg[:, 32:] = np.frombuffer(Sb, dtype=np.uint8).reshape(n, 32)
+        sigs = sg.tobytes()
+        gpu_ctx.set_eddsa_msm(2, 0, 0)                  # the multi-scalar form whatever the size
+        ok, first = cv.eddsa_verify_all(pubs, sigs, hram)
+        assert ok and first == n
+        k = int(rng.integers(0, n))
+        psize = 1 << 12 if log2n <= 17 else 1 << 9
+        pieces = _pieces(n, psize, n // psize if log2n <= 17 else (1 << 15) // psize, rng, must_hold=k)
+
+        def ref(sg_bytes, pcs):
+            def one(lo, hi):
+                return [O.ref_eddsa_verify_all(pubs[32 * a:32 * b], sg_bytes[64 * a:64 * b], msgs[32 * a:32 * b], 32) for a, b in pcs[lo:hi]]
+            return [v for part in O.in_slices(one, len(pcs)) for v in part]
+        assert all(ref(sigs, pieces))
+        bad = bytearray(sigs)
+        bad[64 * k + 33] ^= 0x04                      # S_k damaged (the hash binds R, A and M, not S)
+        bad = bytes(bad)
+        ok, first = cv.eddsa_verify_all(pubs, bad, hram)
+        assert not ok and first == k
+        again = [p for p in pieces if p[0] <= k < p[1]] + [p for p in pieces if not (p[0] <= k < p[1])][:O.host_threads() - 1]
+        verdicts = ref(bad, again)
+        assert not verdicts[0] and all(verdicts[1:])
+    finally:
+        gpu_ctx.set_eddsa_msm(1, 0, 0)
+        cv.free()

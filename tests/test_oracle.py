@@ -967,3 +967,32 @@ def test_random_mod_vs_reference(curve):
     exp = b"".join((v % (q - 1) + 1).to_bytes(ql, "big") for v in vals)
     assert RefLib(curve).random_mod(raw) == exp
     assert Oracle(curve).random_mod(raw) == exp
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref/libecc_ref.so not built")
+def test_bip0340_signatures_from_python_integers_vs_reference():
+    """oracles.make_bip0340_batch (what the row-f4 GPU tests and bench records build their batches with) restates sig/bip0340.c:135-330 on
+    Python integers: the unmodified reference accepts every signature it makes (ec_verify item by item, ec_verify_batch with and
+    without the scratch pad, whole and in pieces) and rejects a damaged one exactly where it is."""
+    import numpy as np
+    from oracles import make_bip0340_batch, ref_sig_verify_all
+    for curve in ("SECP256K1", "SECP256R1"):
+        o = Oracle(curve)
+        it = make_bip0340_batch(lambda sc: o.scalar_mult(sc), curve, 48, np.random.default_rng(5))
+        a = (curve, "BIP0340", "SHA256", it["pubs"])
+        ok, per = ref_sig_verify_all(*a, it["sigs"], it["sig_len"], it["msgs"], 32, per_item=True)
+        assert ok and per == bytes(48)
+        assert ref_sig_verify_all(*a, it["sigs"], it["sig_len"], it["msgs"], 32, scratch=True)
+        assert ref_sig_verify_all(*a, it["sigs"], it["sig_len"], it["msgs"], 32, sub_batches=3)
+        bad = bytearray(it["sigs"])
+        bad[it["sig_len"] * 17 + it["cl"] + 5] ^= 0x20
+        ok, per = ref_sig_verify_all(*a, bytes(bad), it["sig_len"], it["msgs"], 32, per_item=True)
+        assert not ok and per == bytes(17) + b"\x01" + bytes(30)
+        # the multi-scalar form's inputs describe the same items: [s]G + [q - e]Y = R with Y, R the even-y representatives
+        cl, ql = it["cl"], it["ql"]
+        A, sa = o.scalar_mult(it["s"])
+        B, sb = o.scalar_mult(it["ne"], it["keys"])
+        W, sw = o.pt_add(A, B)
+        assert set(sa) | set(sb) | set(sw) == {0}
+        for i in range(48):
+            assert W[2 * cl * i:2 * cl * i + cl] == it["rx"][cl * i:cl * (i + 1)] and not (W[2 * cl * (i + 1) - 1] & 1)

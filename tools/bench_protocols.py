@@ -5,7 +5,7 @@ X25519).  Same launch contract and JSON line as bench.py (one process per GPU un
 torch.distributed.run, weak scaling, contiguous shards, one RCCL all-gather of the per-rank result
 bytes per step); not the driver's headline bench.
 
-    python tools/bench_protocols.py --workload ecdsa_verify|ecdsa_sign|ecccdh|ed25519_verify|ed448_verify|x25519|x448 [--gpus N --steps K --warmup W]
+    python tools/bench_protocols.py --workload ecdsa_verify|ecdsa_sign|ecccdh|ed25519_verify|ed448_verify|x25519|x448|bip0340_msm|ed25519_msm [--gpus N --steps K --warmup W]
 """
 import argparse
 import hashlib
@@ -28,7 +28,7 @@ SEED = 0x5EC9256
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", required=True, choices=["ecdsa_verify", "ecdsa_sign", "ecccdh", "ed25519_verify", "ed448_verify", "x25519", "x448"])
+    ap.add_argument("--workload", required=True, choices=["ecdsa_verify", "ecdsa_sign", "ecccdh", "ed25519_verify", "ed448_verify", "x25519", "x448", "bip0340_msm", "ed25519_msm"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
@@ -242,6 +242,134 @@ def main():
             work["step_mads_per_item"] = (59 + 98 + 33 * 28 + 264) * 97 + (522 + 32 + 33 * 16 + 13) * 61
         work["alg_bytes_per_item"] = 32 + 64 + 64 + 1
         metric, unit, cfg = "Ed25519 verifications/sec (batch=2^%d, %s)" % (a.batch_log2, distinct), "verifications/s", 4
+    elif a.workload in ("bip0340_msm", "ed25519_msm"):
+        # the reference's whole-batch verification (ec_verify_batch -> bip0340_verify_batch sig/bip0340.c:1296,
+        # eddsa_verify_batch sig/eddsa.c:2904) as ONE multi-scalar multiplication.  A step is one verdict over B VALID signatures resident in
+        # HBM (a batch with a bad item comes back "not decided" in the same time and the caller then runs the item form: that path is
+        # the ed25519_verify / item-form workload).  Gates: the verdict for the valid batch, the verdict with one item damaged at a random
+        # index, and the unmodified reference's own batch function on random contiguous pieces of the same batch (see oracles.py:
+        # its Bos-Coster / no-memory verifiers take minutes per 2^17 items on one thread, so the batch is sampled in pieces).
+        msm_bad = None
+        d_res = torch.full((1,), 7, dtype=torch.uint8, device=dev)
+        expected = bytes(1)
+        if a.workload == "bip0340_msm":
+            curve = "SECP256K1" if a.curve == "SECP256R1" else a.curve
+            cv = ctx.curve(curve)
+            assert cv.schnorr_msm_available(1)
+            if a.traffic_child:
+                # the PMC passes only need the shape of the work: valid points and scalars below q; the equation need not hold
+                cl, ql = cv.clen, cv.qlen
+                raw = rng.integers(0, 256, size=(4, B * ql), dtype=np.uint8)
+                raw[:, ::ql] &= 0x7f
+                Pk, _ = cv.scalar_mult(raw[0].tobytes())
+                Rk, _ = cv.scalar_mult(raw[1].tobytes())
+                it = {"s": raw[2].tobytes(), "ne": raw[3].tobytes(), "keys": Pk, "cl": cl, "ql": ql,
+                      "rx": np.frombuffer(Rk, dtype=np.uint8).reshape(B, 2 * cl)[:, :cl].tobytes()}
+            else:
+                it = O.make_bip0340_batch(lambda sc: cv.scalar_mult(sc), curve, B, rng)
+            cl, ql = it["cl"], it["ql"]
+            ins = [t(it["s"]), t(it["ne"]), t(it["keys"]), t(it["rx"])]
+            bad_i = int(rng.integers(0, B))
+            bad_s = bytearray(it["s"][ql * bad_i:ql * (bad_i + 1)])
+            bad_s[ql - 1] ^= 1
+
+            def step():
+                cv.schnorr_verify_all_dev(B, ins[0].data_ptr(), ins[1].data_ptr(), ins[2].data_ptr(), ins[3].data_ptr(), 1, d_res.data_ptr(),
+                                          stream.cuda_stream)
+
+            def msm_bad():
+                good = ins[0][ql * bad_i:ql * (bad_i + 1)].clone()
+                ins[0][ql * bad_i:ql * (bad_i + 1)] = t(bytes(bad_s))
+                step()
+                torch.cuda.synchronize()
+                v = int(d_res.item())
+                ins[0][ql * bad_i:ql * (bad_i + 1)] = good
+                return v, bad_i
+
+            def ref_pieces(pieces):
+                def one(lo, hi):
+                    return all(O.ref_sig_verify_all(curve, "BIP0340", "SHA256", it["pubs"][2 * cl * l:2 * cl * h], it["sigs"][(cl + ql) * l:(cl + ql) * h],
+                                                    cl + ql, it["msgs"][32 * l:32 * h], 32) for l, h in pieces[lo:hi])
+                return all(O.in_slices(one, len(pieces)))
+            K = max(1, min(8, B >> 18))
+            nl, M, S, red = 9, 101, 65, 20       # secp256k1's flavour (ecamd_u29g.h: 81 + 20 / 45 + 20 MADs)
+            if curve != "SECP256K1":
+                import bench as _b
+                nl, M, S, red = _b.field_mads(O.CURVES[curve]["p"])
+            dbl = (3, 4) if O.CURVES[curve]["a"] == 0 else (4, 4)
+            # k_msm_loop_g: per lane 64 windows x 4 doublings shared by K items; per item 64 additions of key multiples and 33 of R's
+            # (z_i has 128 bits), Jacobian + Jacobian 12M + 4S each
+            loop = (256 / K) * (dbl[0] * M + dbl[1] * S) + 97 * (12 * M + 4 * S)
+            # k_msm_table_g per item: lift_x of r (a square root: ~ |p| squarings + 12 M) and the import of Y, then 2 x (4 doublings + 3 additions)
+            pb = O.CURVES[curve]["p"].bit_length()
+            table = (pb * S + 12 * M) + 2 * (4 * (dbl[0] * M + dbl[1] * S) + 3 * (12 * M + 4 * S)) + 8 * M
+            work = {"kernel": "k_msm_loop_g", "mads_per_item": loop, "sgpr_mads_per_item": loop * red / M,
+                    "step_mads_per_item": loop + table, "alg_bytes_per_item": ql + ql + 2 * cl + cl}
+            metric, unit, cfg = "BIP0340 signatures/sec in whole-batch verification (%s, one multi-scalar multiplication per 2^%d-item batch, K = %d items per lane)" % (curve.lower(), a.batch_log2, K), "verifications/s", "f4"
+            ref_what = "ec_verify_batch (BIP0340: bip0340_verify_batch, no scratch pad)"
+        else:
+            cv = ctx.curve("WEI25519")
+            if a.traffic_child:
+                # the PMC passes only need the shape of the work: encodings that decode, S below q; the equation need not hold
+                pubs, _ = cv.eddsa_sign_R(rb(64 * B))
+                Renc, _ = cv.eddsa_sign_R(rb(64 * B))
+                sg = np.empty((B, 64), dtype=np.uint8)
+                sg[:, :32] = np.frombuffer(Renc, dtype=np.uint8).reshape(B, 32)
+                sg[:, 32:] = rng.integers(0, 256, size=(B, 32), dtype=np.uint8)
+                sg[:, 63] &= 0x0f
+                sigs, hram, msgs = sg.tobytes(), rb(64 * B), b""
+            else:
+                seeds, msgs = rb(32 * B), rb(32 * B)
+                hk = [hashlib.sha512(seeds[32 * i:32 * i + 32]).digest() for i in range(B)]
+                a_np = np.frombuffer(b"".join(h[:32] for h in hk), dtype=np.uint8).reshape(B, 32).copy()
+                a_np[:, 0] &= 248
+                a_np[:, 31] &= 127
+                a_np[:, 31] |= 64
+                wide = np.zeros((B, 64), dtype=np.uint8)
+                wide[:, :32] = a_np
+                pubs, st = cv.eddsa_sign_R(wide.tobytes())
+                assert set(st) == {0}
+                r_hash = b"".join(hashlib.sha512(hk[i][32:] + msgs[32 * i:32 * i + 32]).digest() for i in range(B))
+                Renc, st = cv.eddsa_sign_R(r_hash)
+                assert set(st) == {0}
+                hram = b"".join(hashlib.sha512(Renc[32 * i:32 * i + 32] + pubs[32 * i:32 * i + 32] + msgs[32 * i:32 * i + 32]).digest() for i in range(B))
+                Sb = cv.eddsa_sign_S(r_hash, hram, a_np.tobytes())
+                sg = np.empty((B, 64), dtype=np.uint8)
+                sg[:, :32] = np.frombuffer(Renc, dtype=np.uint8).reshape(B, 32)
+                sg[:, 32:] = np.frombuffer(Sb, dtype=np.uint8).reshape(B, 32)
+                sigs = sg.tobytes()
+                del hk, wide, sg
+            ins = [t(pubs), t(sigs), t(hram)]
+            bad_i = int(rng.integers(0, B))
+            ctx.set_eddsa_msm(2, 0, 0)      # the multi-scalar form whatever the size
+
+            def step():
+                cv.eddsa_verify_all_dev(B, ins[0].data_ptr(), ins[1].data_ptr(), ins[2].data_ptr(), d_res.data_ptr(), stream.cuda_stream)
+
+            def msm_bad():
+                pos = 64 * bad_i + 40
+                ins[1][pos] ^= 1
+                step()
+                torch.cuda.synchronize()
+                v = int(d_res.item())
+                ins[1][pos] ^= 1
+                return v, bad_i
+
+            def ref_pieces(pieces):
+                def one(lo, hi):
+                    return all(O.ref_eddsa_verify_all(pubs[32 * l:32 * h], sigs[64 * l:64 * h], msgs[32 * l:32 * h], 32) for l, h in pieces[lo:hi])
+                return all(O.in_slices(one, len(pieces)))
+            K = max(1, min(8, B >> 16))
+            M, S = 97, 61
+            # k_edmsm_loop: per lane 64 windows of 3 doublings (3M + 4S), 1 doubling with T (4M + 4S) and one addition from B's table (8M),
+            # shared by K items; per item 64 additions from A's table and 33 from R's, 8M each
+            loop = (64 / K) * (13 * M + 16 * S + 8 * M) + 97 * 8 * M
+            # k_edmsm_prep: two decodings (a square root each: 255 S + 25 M), [8]A (3 doublings), two window tables (49 M + 16 S each)
+            prep = 2 * (255 * S + 25 * M) + 3 * (4 * M + 4 * S) + 2 * (49 * M + 16 * S)
+            work = {"kernel": "k_edmsm_loop", "mads_per_item": loop, "sgpr_mads_per_item": loop * 16 / 97, "step_mads_per_item": loop + prep,
+                    "alg_bytes_per_item": 32 + 64 + 64}
+            metric, unit, cfg = "Ed25519 signatures/sec in whole-batch verification (one multi-scalar multiplication per 2^%d-item batch, K = %d items per lane)" % (a.batch_log2, K), "verifications/s", "f4"
+            ref_what = "ec_verify_batch (EDDSA25519: eddsa_verify_batch, no scratch pad)"
     elif a.workload == "ed448_verify":
         cv = ctx.curve("WEI448")
         m = 128
@@ -304,7 +432,7 @@ def main():
             work["step_mads_per_item"] = work["mads_per_item"] + (35 + 6) * 97 + (267 + 32) * 61
             work["alg_bytes_per_item"] = 32 + 32 + 32 + 1
             metric, unit, cfg = "X25519 shared secrets/sec (batch=2^%d)" % a.batch_log2, "shared-secrets/s", 4
-    gathered = torch.empty(world * B, dtype=torch.uint8, device=dev) if world > 1 else None
+    gathered = torch.empty(world * d_res.numel(), dtype=torch.uint8, device=dev) if world > 1 else None
 
     def full_step():
         step()
@@ -324,17 +452,41 @@ def main():
     res = d_res.cpu().numpy().tobytes()
     if res != expected:
         raise SystemExit("PARITY FAILURE: accept/reject bits differ from the construction of the batch")
-    idx = [int(i) for i in np.random.default_rng(1).choice(B, size=128, replace=False)]
-    exp = oracle_subset(idx)
+    msm = a.workload in ("bip0340_msm", "ed25519_msm")
+    if msm:
+        v, where = msm_bad()
+        if v != 1:
+            raise SystemExit("PARITY FAILURE: the whole-batch form accepted a batch with a damaged item")
+        full_step()
+        torch.cuda.synchronize()
+        if int(d_res.item()) != 0:
+            raise SystemExit("PARITY FAILURE: the whole-batch form rejected the restored batch")
+        gate = f"valid batch of 2^{a.batch_log2} accepted; rejected with item {where} damaged; accepted again once restored"
+        if O.have_ref() and rank == 0 and a.ref_items > 0:
+            # the unmodified reference's batch function on random contiguous pieces of 256 items of the same batch, one piece list per host thread
+            nt = O.host_threads()
+            npieces = max(nt, min(a.ref_items, B) // 256)
+            starts = sorted(int(x) for x in np.random.default_rng(2).choice(max(1, B // 256), size=min(npieces, max(1, B // 256)), replace=False))
+            pieces = [(256 * x, min(B, 256 * x + 256)) for x in starts]
+            tr0 = time.time()
+            if not ref_pieces(pieces):
+                raise SystemExit("PARITY FAILURE: the unmodified reference's batch verifier rejects a piece of the batch the GPU accepted")
+            el = time.time() - tr0
+            items = sum(h - l for l, h in pieces)
+            gate_ref = {"items": items, "seconds": el, "cores": nt, "what": ref_what}
+            gate += f"; {len(pieces)} random pieces of 256 items ({items} items) accepted by the unmodified reference's {ref_what} on {nt} threads, {el:.1f} s"
+    idx = [int(i) for i in np.random.default_rng(1).choice(B, size=128, replace=False)] if not msm else []
+    exp = oracle_subset(idx) if not msm else None
     payload = a.workload in ("x25519", "x448", "ecdsa_sign", "ecccdh")
     if payload:
         out = d_out.cpu().numpy().tobytes()
         got = (b"".join(out[out_w * i:out_w * i + out_w] for i in idx), bytes(res[i] for i in idx))
-    else:
+    elif not msm:
         got = bytes(res[i] for i in idx)
-    if got != exp:
+    if not msm and got != exp:
         raise SystemExit("PARITY FAILURE: GPU output differs from the CPU oracle")
-    gate = "all accept/reject bits as constructed; 128 random items identical to the CPU oracle"
+    if not msm:
+        gate = "all accept/reject bits as constructed; 128 random items identical to the CPU oracle"
     if ref_subset is not None and O.have_ref() and rank == 0 and a.ref_items > 0:
         tg = time.time()
         ridx = [int(i) for i in np.sort(np.random.default_rng(2).choice(B, size=min(B, a.ref_items), replace=False))]
@@ -417,16 +569,17 @@ def main():
         if by_kernel and work.get("alg_bytes_per_item"):
             roof["step_traffic"] = sum(by_kernel.values())
             roof["traffic_over_algorithmic"] = roof["step_traffic"] / (B * work["alg_bytes_per_item"])
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and gate_ref and gate_ref["seconds"] >= 3.0:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and gate_ref and (gate_ref["seconds"] >= 3.0 or msm):
         # the parity gate already ran the unmodified reference over a random subset of this batch on every host thread: that run
         # IS the CPU baseline of the workload (ec_verify / x25519() of the reference beside configs 3-5)
         what = {"ecdsa_verify": "ec_pub_key_import_from_aff_buf + ec_verify (ECDSA)", "ecdsa_sign": "ec_sign (ECDSA, nonce supplied)",
                 "ecccdh": "ecccdh_derive_secret", "ed25519_verify": "eddsa_import_pub_key + ec_verify (EDDSA25519)",
-                "ed448_verify": "eddsa_import_pub_key + ec_verify (EDDSA448)", "x25519": "x25519()", "x448": "x448()"}[a.workload]
+                "ed448_verify": "eddsa_import_pub_key + ec_verify (EDDSA448)", "x25519": "x25519()", "x448": "x448()",
+                "bip0340_msm": gate_ref.get("what"), "ed25519_msm": gate_ref.get("what")}[a.workload]
         cpu = {"value": gate_ref["items"] / gate_ref["seconds"], "unit": unit, "cores": gate_ref["cores"], "kind": "reference",
                "sample": f"the parity gate's own run: {gate_ref['items']} random items of the same batch through {what} of the unmodified "
                          f"reference (oracle/_ref) on {gate_ref['cores']} threads, {gate_ref['seconds']:.1f} s wall"}
-    elif rank == 0 and world == 1 and not a.no_cpu_baseline and O.have_ref():
+    elif rank == 0 and world == 1 and not a.no_cpu_baseline and O.have_ref() and not msm:
         # the unmodified reference on this host, one thread, on a bounded sample of the same inputs
         m = 1536 if a.workload != "x25519" else 3072
         if a.workload == "x448":
@@ -462,9 +615,11 @@ def main():
             "metric": metric, "value": B * world * a.steps / elapsed, "unit": unit, "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 (%d-bit limbs, v_mad_u64_u32 integer MAD, u64 accumulators)" % (28 if a.workload in ("x448", "ed448_verify") else 29),
-            "data": "synthetic (seeded), inputs resident in HBM; 10 % of the signatures corrupted" if not payload
+            "data": ("synthetic (seeded), inputs resident in HBM; every signature valid (the form vouches for valid batches)" if msm else
+                     "synthetic (seeded), inputs resident in HBM; 10 % of the signatures corrupted") if not payload
                     else "synthetic (seeded), inputs resident in HBM; valid keys",
-            "config": {"workload": f"{a.workload} (BASELINE.json configs[{cfg}]), batch 2^{a.batch_log2} per GPU",
+            "config": {"workload": (f"{a.workload} (SURVEY.md section 8 row f4), batch 2^{a.batch_log2} per GPU" if msm else
+                                    f"{a.workload} (BASELINE.json configs[{cfg}]), batch 2^{a.batch_log2} per GPU"),
                        "sharding": "contiguous per-rank shards" + (", RCCL all_gather of result bytes per step" if world > 1 else ""),
                        "parity_gate": gate},
             "roofline": roof, "cpu_baseline": cpu, "setup_s": setup_s}))
