@@ -14,6 +14,8 @@
 #include <time.h>
 #include <sys/random.h>
 #include "libecc_amd_compat.h"
+#include <pthread.h>
+#include <unistd.h>
 #include "external_deps/rand.h"   /* get_random: supplied by the application, as for libecc's own libsign */
 
 /* The application's randomness source (libsign leaves get_random undefined: external_deps/rand.c is libecc's example of
@@ -1033,6 +1035,82 @@ static void check_torsion_shift(u32 rounds)
 	printf("ec_verify_batch ECFSDSA/WEI25519, W + D with D of small order, %u rounds: %s\n", rounds, failures == before ? "ok" : "FAILED");
 }
 
+/* ---- round 6: several application threads inside ec_verify_batch at once (libecc is re-entrant; the batch layer gives every
+ * call its own staging and lets the pool pack one call while another has the GPU).  Three threads -- ECDSA/SECP256R1, EDDSA25519 and
+ * ECDSA/SECP384R1, each with its own spoiled items -- verify at the same time, several rounds; every item's result must be ec_verify's. ---- */
+typedef struct {
+	const char *curve, *label;
+	ec_alg_type sig_type;
+	hash_alg_type hash_type;
+	u32 n, rounds;
+	int bad;
+} conc_arg;
+static void *conc_verify_thread(void *a)
+{
+	conc_arg *C = (conc_arg *)a;
+	enum { ML = 24 };
+	ec_params params;
+	const u32 n = C->n;
+	ec_key_pair *kps = calloc(n, sizeof(ec_key_pair));
+	const ec_pub_key **pubs = calloc(n, sizeof(*pubs));
+	const u8 **sigs = calloc(n, sizeof(*sigs)), **msgs = calloc(n, sizeof(*msgs)), **adatas = calloc(n, sizeof(*adatas));
+	u8 *siglens = calloc(n, 1), *sigbuf, *msgbuf = calloc(n, ML), siglen = 0;
+	u32 *msglens = calloc(n, sizeof(u32)), i, r;
+	u16 *adlens = calloc(n, sizeof(u16));
+	int *res = calloc(n, sizeof(int)), *want = calloc(n, sizeof(int));
+	C->bad = 1;
+	if (!kps || load_params(C->curve, &params) || ec_get_sig_len(&params, C->sig_type, C->hash_type, &siglen)) {
+		return NULL;
+	}
+	sigbuf = calloc(n, siglen);
+	for (i = 0; i < n; i++) {
+		if (ec_key_pair_gen(&kps[i], &params, C->sig_type) || get_random(msgbuf + (size_t)i * ML, ML) ||
+		    ec_sign(sigbuf + (size_t)i * siglen, siglen, &kps[i], msgbuf + (size_t)i * ML, ML, C->sig_type, C->hash_type, NULL, 0)) {
+			return NULL;
+		}
+		pubs[i] = &kps[i].pub_key; sigs[i] = sigbuf + (size_t)i * siglen; msgs[i] = msgbuf + (size_t)i * ML; siglens[i] = siglen; msglens[i] = ML;
+	}
+	for (i = 3; i < n; i += 11) {
+		sigbuf[(size_t)i * siglen + (i % siglen)] ^= 0x08;
+	}
+	for (i = 0; i < n; i++) {
+		want[i] = ec_verify(sigs[i], siglens[i], pubs[i], msgs[i], msglens[i], C->sig_type, C->hash_type, NULL, 0);
+	}
+	C->bad = 0;
+	for (r = 0; r < C->rounds; r++) {
+		memset(res, 0x55, n * sizeof(int));
+		if (ec_verify_batch_results(sigs, siglens, pubs, msgs, msglens, n, C->sig_type, C->hash_type, adatas, adlens, res)) {
+			C->bad = 1;
+		}
+		for (i = 0; i < n; i++) {
+			C->bad |= (res[i] != want[i]);
+		}
+		C->bad |= (ec_verify_batch(sigs, siglens, pubs, msgs, msglens, n, C->sig_type, C->hash_type, adatas, adlens, NULL, NULL) != -1);
+	}
+	free(kps); free(pubs); free(sigs); free(msgs); free(adatas); free(siglens); free(sigbuf); free(msgbuf); free(msglens); free(adlens); free(res); free(want);
+	return NULL;
+}
+static void check_concurrent_verify(u32 n)
+{
+	conc_arg C[3] = {{"SECP256R1", "ECDSA/SECP256R1/SHA256", ECDSA, SHA256, n, 4, 0},
+			 {"WEI25519", "EDDSA25519", EDDSA25519, SHA512, n, 4, 0},
+			 {"SECP384R1", "ECDSA/SECP384R1/SHA384", ECDSA, SHA384, n > 96 ? n / 2 : n, 4, 0}};
+	pthread_t th[3];
+	const u32 before = failures;
+	const int was_serial = g_rand_expect_serial;
+	int t;
+	g_rand_expect_serial = 0;   /* (three application threads draw their own keys at once: that is the application's business) */
+	for (t = 0; t < 3; t++) {
+		pthread_create(&th[t], NULL, conc_verify_thread, &C[t]);
+	}
+	for (t = 0; t < 3; t++) {
+		pthread_join(th[t], NULL);
+		CHECK(!C[t].bad, "concurrent callers: %s: a result differs from ec_verify", C[t].label);
+	}
+	g_rand_expect_serial = was_serial;
+	printf("ec_verify_batch from three application threads at once, %u items each: %s\n", n, failures == before ? "ok" : "FAILED");
+}
+
 static double now_s(void)
 {
 	struct timespec ts;
@@ -1208,8 +1286,6 @@ static void bench_secret_half(u32 n)
  * library uses (a loop of ec_verify / ec_sign over a bounded sample of the same structures; for the algorithms libecc verifies in
  * batches also its ec_verify_batch on pieces of 256 items per thread).
  * ------------------------------------------------------------------------------------------------ */
-#include <pthread.h>
-#include <unistd.h>
 typedef struct {
 	const u8 **sigs, **msgs;
 	const u8 *siglens;
@@ -1657,6 +1733,7 @@ int main(int argc, char **argv)
 		check_verify("SECP256R1", ECFSDSA, SHA256, "ECFSDSA/SECP256R1/SHA256", qn < 96 ? qn : 96, 1);
 		check_verify("BRAINPOOLP384R1", ECFSDSA, SHA384, "ECFSDSA/BRAINPOOLP384R1/SHA384", qn < 32 ? qn : 32, 1);
 		check_torsion_shift(8);
+		check_concurrent_verify(qn);
 		printf("schnorr multi-scalar calls: %lu\n", ecamd_compat_schnorr_msm_calls());
 		ecamd_compat_shutdown();
 		CHECK(!g_rand_expect_serial || g_rand_overlaps == 0, "get_random entered concurrently %d times", g_rand_overlaps);
@@ -1724,6 +1801,7 @@ int main(int argc, char **argv)
 	check_verify("SECP256R1", ECFSDSA, SHA256, "ECFSDSA/SECP256R1/SHA256", n, 1);
 	check_verify("BRAINPOOLP384R1", ECFSDSA, SHA384, "ECFSDSA/BRAINPOOLP384R1/SHA384", n < 128 ? n : 128, 1);
 	check_torsion_shift(8);
+	check_concurrent_verify(n);
 	/* an algorithm the GPU does not take goes to libecc's own verifier (no batch form there: -1) */
 	check_verify("SECP256R1", ECKCDSA, SHA256, "ECKCDSA (no batch form)", n < 16 ? n : 16, -1);
 	printf("items sent to the GPU: %llu\n", ecamd_compat_gpu_items());

@@ -57,7 +57,8 @@ typedef struct {
 
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;        /* the state below */
 static void words_free_all(void);
-static pthread_mutex_t g_call_mu = PTHREAD_MUTEX_INITIALIZER;   /* one batch call at a time: pool, staging buffers, GPUs */
+static void call_enter(int shared);   /* the gate of every batch call: shared (verification, NARENA at a time) or exclusive */
+static void call_leave(void);
 static pthread_mutex_t g_rand_mu = PTHREAD_MUTEX_INITIALIZER;   /* the application's get_random: one caller at a time (see compat_random_mod) */
 static u32 g_rand_concurrent;                                   /* ecamd_compat_set_concurrent_random */
 
@@ -241,7 +242,7 @@ int ecamd_compat_init(const int *devices, int ndev, int host_threads)
 int ecamd_compat_set_secret_scalars(int on)
 {
 	int ret;
-	pthread_mutex_lock(&g_call_mu);
+	call_enter(0);
 	pthread_mutex_lock(&g_mu);
 	ret = compat_init_locked(NULL, 0, 0);
 	if (!ret) {
@@ -251,7 +252,7 @@ int ecamd_compat_set_secret_scalars(int on)
 		}
 	}
 	pthread_mutex_unlock(&g_mu);
-	pthread_mutex_unlock(&g_call_mu);
+	call_leave();
 	return ret;
 }
 
@@ -260,7 +261,7 @@ static void bufs_free(void);
 void ecamd_compat_shutdown(void)
 {
 	u32 i;
-	pthread_mutex_lock(&g_call_mu);
+	call_enter(0);
 	pthread_mutex_lock(&g_mu);
 	pool_stop();
 	bufs_free();
@@ -274,7 +275,7 @@ void ecamd_compat_shutdown(void)
 		g_multi = NULL;
 	}
 	pthread_mutex_unlock(&g_mu);
-	pthread_mutex_unlock(&g_call_mu);
+	call_leave();
 }
 
 /* p || a || b || #E of a curve, big-endian (coordinates BYTECEIL(p_bitlen) bytes, the order as long as it is) */
@@ -481,19 +482,25 @@ typedef struct {
 	u32 *gpu_done;                /* per chunk: back from the GPU (atomic, set under mu) */
 	u32 unpack_done;              /* grains unpacked (atomic) */
 	u32 abort;
-	pthread_mutex_t mu;
+	int active;                   /* pool threads inside this job (g_pool.mu) */
+	pthread_mutex_t mu;           /* the OWNER's waits: a chunk is packed / everything is unpacked */
 	pthread_cond_t cv;
 } pipe_job;
 
+/* Round 6: the pool serves SEVERAL jobs at a time (two application threads inside ec_verify_batch: one call's packing runs on the pool
+ * while the other call has the GPU), so a pool thread never blocks inside a job: it takes what grain of work any registered job has,
+ * and sleeps on the pool's own condition when none has any; whoever creates work (a job registered, a chunk back from the GPU) kicks
+ * the pool. */
+#define POOL_JOBS 4
 static struct {
 	pthread_mutex_t mu;
 	pthread_cond_t cv_work, cv_idle;
 	pthread_t th[256];
 	int nth;
-	pipe_job *job;
+	pipe_job *jobs[POOL_JOBS];
 	unsigned long gen;
-	int active, stop;
-} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, NULL, 0, 0, 0};
+	int stop;
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, {NULL}, 0, 0};
 
 static void grain_range(const pipe_job *j, u32 g, u32 *lo, u32 *hi)
 {
@@ -508,11 +515,19 @@ static void job_notify(pipe_job *j)
 	pthread_mutex_unlock(&j->mu);
 }
 
+static void pool_kick(void)
+{
+	pthread_mutex_lock(&g_pool.mu);
+	g_pool.gen++;
+	pthread_cond_broadcast(&g_pool.cv_work);
+	pthread_mutex_unlock(&g_pool.mu);
+}
+
 /* take one pack grain if any is left; returns 0 when none was */
 static int take_pack(pipe_job *j)
 {
 	u32 g, lo, hi;
-	if (AT_LOAD(&j->pack_next) >= j->ngrains) {
+	if (AT_LOAD(&j->abort) || AT_LOAD(&j->pack_next) >= j->ngrains) {
 		return 0;
 	}
 	g = AT_ADD(&j->pack_next, 1) - 1;
@@ -531,7 +546,7 @@ static int take_pack(pipe_job *j)
 static int take_unpack(pipe_job *j)
 {
 	u32 g, lo, hi;
-	if (!j->unpack) {
+	if (!j->unpack || AT_LOAD(&j->abort)) {
 		return 0;
 	}
 	g = AT_LOAD(&j->unpack_next);
@@ -539,39 +554,13 @@ static int take_unpack(pipe_job *j)
 		if (__atomic_compare_exchange_n(&j->unpack_next, &g, g + 1, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
 			grain_range(j, g, &lo, &hi);
 			j->unpack(lo, hi, j->arg);
-			AT_ADD(&j->unpack_done, 1);
-			if (g + 1 == j->ngrains) {
-				job_notify(j);   /* waiters: nothing left to hand out */
+			if (AT_ADD(&j->unpack_done, 1) >= j->ngrains) {
+				job_notify(j);   /* the owner: everything is unpacked */
 			}
 			return 1;
 		}
 	}
 	return 0;
-}
-
-/* what a pool thread does for a job: unpack what is back, else pack what is left, else wait for the GPU */
-static void pipe_work(pipe_job *j)
-{
-	for (;;) {
-		if (AT_LOAD(&j->abort)) {
-			return;
-		}
-		if (take_unpack(j) || take_pack(j)) {
-			continue;
-		}
-		if (!j->unpack || AT_LOAD(&j->unpack_next) >= j->ngrains) {
-			return;
-		}
-		pthread_mutex_lock(&j->mu);
-		for (;;) {
-			const u32 g = AT_LOAD(&j->unpack_next);
-			if (AT_LOAD(&j->abort) || g >= j->ngrains || AT_LOAD(&j->gpu_done[g / j->chunk_grains])) {
-				break;
-			}
-			pthread_cond_wait(&j->cv, &j->mu);
-		}
-		pthread_mutex_unlock(&j->mu);
-	}
 }
 
 static void *pool_worker(void *unused)
@@ -580,7 +569,7 @@ static void *pool_worker(void *unused)
 	(void)unused;
 	pthread_mutex_lock(&g_pool.mu);
 	for (;;) {
-		pipe_job *j;
+		int k, did;
 		while (!g_pool.stop && g_pool.gen == seen) {
 			pthread_cond_wait(&g_pool.cv_work, &g_pool.mu);
 		}
@@ -588,17 +577,24 @@ static void *pool_worker(void *unused)
 			break;
 		}
 		seen = g_pool.gen;
-		j = g_pool.job;
-		if (!j) {
-			continue;
-		}
-		g_pool.active++;
-		pthread_mutex_unlock(&g_pool.mu);
-		pipe_work(j);
-		pthread_mutex_lock(&g_pool.mu);
-		if (--g_pool.active == 0) {
-			pthread_cond_broadcast(&g_pool.cv_idle);
-		}
+		do {
+			did = 0;
+			for (k = 0; k < POOL_JOBS; k++) {
+				pipe_job *j = g_pool.jobs[k];
+				if (!j) {
+					continue;
+				}
+				j->active++;
+				pthread_mutex_unlock(&g_pool.mu);
+				while (take_unpack(j) || take_pack(j)) {
+					did = 1;
+				}
+				pthread_mutex_lock(&g_pool.mu);
+				if (--j->active == 0) {
+					pthread_cond_broadcast(&g_pool.cv_idle);
+				}
+			}
+		} while (did && !g_pool.stop);
 	}
 	pthread_mutex_unlock(&g_pool.mu);
 	return NULL;
@@ -635,11 +631,47 @@ static void pool_stop(void)
 	g_pool.nth = 0;
 }
 
+/* a job joins / leaves the pool's list; leaving waits until no pool thread is inside it any more */
+static void pool_register(pipe_job *j)
+{
+	int k, placed = 0;
+	pthread_mutex_lock(&g_pool.mu);
+	while (!placed) {
+		for (k = 0; k < POOL_JOBS && !placed; k++) {
+			if (!g_pool.jobs[k]) {
+				g_pool.jobs[k] = j;
+				placed = 1;
+			}
+		}
+		if (!placed) {
+			pthread_cond_wait(&g_pool.cv_idle, &g_pool.mu);   /* (more concurrent jobs than slots: wait for one to leave) */
+		}
+	}
+	g_pool.gen++;
+	pthread_cond_broadcast(&g_pool.cv_work);
+	pthread_mutex_unlock(&g_pool.mu);
+}
+static void pool_unregister(pipe_job *j)
+{
+	int k;
+	pthread_mutex_lock(&g_pool.mu);
+	for (k = 0; k < POOL_JOBS; k++) {
+		if (g_pool.jobs[k] == j) {
+			g_pool.jobs[k] = NULL;
+		}
+	}
+	while (j->active > 0) {
+		pthread_cond_wait(&g_pool.cv_idle, &g_pool.mu);
+	}
+	pthread_cond_broadcast(&g_pool.cv_idle);   /* a slot is free */
+	pthread_mutex_unlock(&g_pool.mu);
+}
+
 /*
  * Run n items through pack -> gpu -> unpack in chunks of `chunk` items.  pack / unpack (either may be NULL) are called on
  * ranges of at most GRAIN items from the pool threads (and from the caller while it waits); gpu (may be NULL) is called by the
  * CALLING thread once per chunk, in order, when the chunk is packed; a chunk is unpacked once its gpu call has returned.
- * Returns 0, or -1 as soon as a gpu call fails.  g_call_mu held.
+ * Returns 0, or -1 as soon as a gpu call fails.  The caller is inside call_enter() .. call_leave().
  */
 /* $ECAMD_COMPAT_TIMING: one line per pipeline run on stderr -- where the calling thread's time went (waiting for the pool to pack a
  * chunk | inside the GPU entry point, copies included | the rest: helping to pack / unpack, draining) */
@@ -648,6 +680,26 @@ static double now_ms(void)
 	struct timespec t;
 	clock_gettime(CLOCK_MONOTONIC, &t);
 	return 1e3 * (double)t.tv_sec + 1e-6 * (double)t.tv_nsec;
+}
+
+/* Every entry into the C ABI from a pipeline holds this lock: the producer hook is state of the multi-GPU context, so "install the
+ * hook, make the call, remove the hook" must not interleave with another application thread's call (which would be handed a hook whose
+ * job is gone); the devices run one call at a time anyway (ecamd_multi's own lock). */
+static pthread_mutex_t g_gpu_mu = PTHREAD_MUTEX_INITIALIZER;
+
+/* the owner waits until chunk c is packed, helping meanwhile */
+static void wait_packed(pipe_job *J, u32 c)
+{
+	while (AT_LOAD(&J->pack_left[c]) != 0) {
+		if (take_pack(J)) {
+			continue;
+		}
+		pthread_mutex_lock(&J->mu);
+		while (AT_LOAD(&J->pack_left[c]) != 0) {
+			pthread_cond_wait(&J->cv, &J->mu);
+		}
+		pthread_mutex_unlock(&J->mu);
+	}
 }
 
 /* the producer hook of a streamed run (ecamd_multi_set_host_ready_hook): the GPU call is about to read items [first, first + count) of
@@ -662,16 +714,7 @@ static void stream_ready(void *arg, u32 first, u32 count)
 	}
 	c1 = (first + count - 1 < J->n ? first + count - 1 : J->n - 1) / per;
 	for (c = first / per; c <= c1 && c < J->nchunks; c++) {
-		while (AT_LOAD(&J->pack_left[c]) != 0) {
-			if (take_pack(J)) {
-				continue;
-			}
-			pthread_mutex_lock(&J->mu);
-			while (AT_LOAD(&J->pack_left[c]) != 0) {
-				pthread_cond_wait(&J->cv, &J->mu);
-			}
-			pthread_mutex_unlock(&J->mu);
-		}
+		wait_packed(J, c);
 	}
 }
 
@@ -709,9 +752,12 @@ static int pipeline_run_ex(u32 n, u32 chunk, range_fn pack, gpu_fn gpu, range_fn
 			if (pack) {
 				pack(lo, hi, arg);
 			}
-			if (gpu && gpu(lo, hi, arg)) {
-				ret = -1;
-			} else if (unpack) {
+			if (gpu) {
+				pthread_mutex_lock(&g_gpu_mu);
+				ret = gpu(lo, hi, arg) ? -1 : 0;
+				pthread_mutex_unlock(&g_gpu_mu);
+			}
+			if (!ret && unpack) {
 				unpack(lo, hi, arg);
 			}
 		}
@@ -741,19 +787,21 @@ static int pipeline_run_ex(u32 n, u32 chunk, range_fn pack, gpu_fn gpu, range_fn
 	}
 	pthread_mutex_init(&J.mu, NULL);
 	pthread_cond_init(&J.cv, NULL);
-	pthread_mutex_lock(&g_pool.mu);
-	g_pool.job = &J;
-	g_pool.gen++;
-	pthread_cond_broadcast(&g_pool.cv_work);
-	pthread_mutex_unlock(&g_pool.mu);
+	pool_register(&J);
 	if (streamed && gpu && pack && J.nchunks > 1) {
 		t0 = timing ? now_ms() : 0;
+		pthread_mutex_lock(&g_gpu_mu);   /* (another application thread may have the GPU: this call's packing goes on meanwhile, on the pool) */
+		if (timing) {
+			t_wait += now_ms() - t0;
+			t0 = now_ms();
+		}
 		if (ecamd_multi_set_host_ready_hook(g_multi, stream_ready, &J)) {
 			ret = -1;
 		} else {
 			ret = gpu(0, n, arg) ? -1 : 0;
 			(void)ecamd_multi_set_host_ready_hook(g_multi, NULL, NULL);
 		}
+		pthread_mutex_unlock(&g_gpu_mu);
 		if (ret) {
 			AT_STORE(&J.abort, 1);
 			job_notify(&J);
@@ -763,8 +811,8 @@ static int pipeline_run_ex(u32 n, u32 chunk, range_fn pack, gpu_fn gpu, range_fn
 			for (c = 0; c < J.nchunks; c++) {
 				AT_STORE(&J.gpu_done[c], 1);
 			}
-			pthread_cond_broadcast(&J.cv);
 			pthread_mutex_unlock(&J.mu);
+			pool_kick();
 		}
 		if (timing) {
 			t_gpu += now_ms() - t0;
@@ -773,47 +821,57 @@ static int pipeline_run_ex(u32 n, u32 chunk, range_fn pack, gpu_fn gpu, range_fn
 	for (c = 0; c < J.nchunks && !(streamed && gpu && pack && J.nchunks > 1); c++) {
 		/* wait for chunk c to be packed; help meanwhile */
 		t0 = timing ? now_ms() : 0;
-		while (AT_LOAD(&J.pack_left[c]) != 0) {
-			if (take_pack(&J)) {
-				continue;
-			}
-			pthread_mutex_lock(&J.mu);
-			while (AT_LOAD(&J.pack_left[c]) != 0) {
-				pthread_cond_wait(&J.cv, &J.mu);
-			}
-			pthread_mutex_unlock(&J.mu);
-		}
+		wait_packed(&J, c);
 		lo = c * J.chunk_grains * GRAIN;
 		hi = (lo + chunk < n) ? lo + chunk : n;
 		if (timing) {
 			t_wait += now_ms() - t0;
 			t0 = now_ms();
 		}
-		if (gpu && gpu(lo, hi, arg)) {
-			ret = -1;
-			AT_STORE(&J.abort, 1);
-			job_notify(&J);
-			break;
+		if (gpu) {
+			int r;
+			pthread_mutex_lock(&g_gpu_mu);
+			r = gpu(lo, hi, arg);
+			pthread_mutex_unlock(&g_gpu_mu);
+			if (r) {
+				ret = -1;
+				AT_STORE(&J.abort, 1);
+				job_notify(&J);
+				break;
+			}
 		}
 		if (timing) {
 			t_gpu += now_ms() - t0;
 		}
-		pthread_mutex_lock(&J.mu);
 		AT_STORE(&J.gpu_done[c], 1);
-		pthread_cond_broadcast(&J.cv);
-		pthread_mutex_unlock(&J.mu);
+		if (unpack) {
+			pool_kick();
+		}
 	}
-	t0 = timing ? now_ms() : 0;
-	if (!ret) {
-		pipe_work(&J);   /* help with what is left to unpack */
+	if (!ret && unpack) {
+		/* help with what is left to unpack, then wait for the grains other threads still hold */
+		for (;;) {
+			if (take_unpack(&J)) {
+				continue;
+			}
+			if (AT_LOAD(&J.unpack_done) >= J.ngrains) {
+				break;
+			}
+			pthread_mutex_lock(&J.mu);
+			if (AT_LOAD(&J.unpack_done) < J.ngrains && AT_LOAD(&J.unpack_next) >= J.ngrains) {
+				struct timespec ts;
+				clock_gettime(CLOCK_REALTIME, &ts);
+				ts.tv_nsec += 200000;
+				if (ts.tv_nsec >= 1000000000L) {
+					ts.tv_sec++;
+					ts.tv_nsec -= 1000000000L;
+				}
+				(void)pthread_cond_timedwait(&J.cv, &J.mu, &ts);
+			}
+			pthread_mutex_unlock(&J.mu);
+		}
 	}
-	t0 = timing ? now_ms() : 0;
-	pthread_mutex_lock(&g_pool.mu);
-	g_pool.job = NULL;
-	while (g_pool.active > 0) {
-		pthread_cond_wait(&g_pool.cv_idle, &g_pool.mu);
-	}
-	pthread_mutex_unlock(&g_pool.mu);
+	pool_unregister(&J);   /* (also on failure: pool threads inside a pack / unpack grain finish it first) */
 	pthread_mutex_destroy(&J.mu);
 	pthread_cond_destroy(&J.cv);
 	free(J.pack_left);
@@ -903,56 +961,125 @@ static u32 chunk_items_for(u32 per_device, u32 n)
 }
 
 /* ------------------------------------------------------------------------------------------------
- * staging buffers: page-locked, kept across calls (g_call_mu held)
+ * staging buffers: page-locked, kept across calls, one set per concurrent call
  * ------------------------------------------------------------------------------------------------ */
 #define NBUF 16
-static u8 *g_buf[NBUF];
-static size_t g_cap[NBUF], g_used[NBUF];   /* g_used: bytes handed out since the last wipe */
-static u8 g_pinned[NBUF];
+/* Round 6: staging is per CALL, not per process.  A batch call works in an arena -- its sixteen page-locked buffers, kept across
+ * calls -- that it holds from call_enter() to call_leave(); there are NARENA of them, so that many application threads can be inside
+ * the verification entry points at once (the next one waits).  Everything else -- the secret-key half, the multi-step Schnorr path,
+ * set-up and shutdown -- enters EXCLUSIVELY, as under the process-wide lock of rounds 2-5: those paths switch the devices between
+ * secret- and public-scalar mode, wipe scratch, or make several dependent GPU calls in a row. */
+#define NARENA 2
+typedef struct {
+	u8 *buf[NBUF];
+	size_t cap[NBUF], used[NBUF];   /* used: bytes handed out since the last wipe */
+	u8 pinned[NBUF];
+	int busy;
+} arena;
+static arena g_arena[NARENA];
+static __thread arena *t_arena;     /* the arena of the batch call this thread is inside */
+static __thread int t_shared;
+static pthread_mutex_t g_gate_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_gate_cv = PTHREAD_COND_INITIALIZER;
+static int g_shared_in, g_excl_in, g_excl_waiting;
+
+static void call_enter(int shared)
+{
+	int k;
+	pthread_mutex_lock(&g_gate_mu);
+	if (shared) {
+		while (g_excl_in || g_excl_waiting || g_shared_in >= NARENA) {
+			pthread_cond_wait(&g_gate_cv, &g_gate_mu);
+		}
+		for (k = 0; k < NARENA; k++) {
+			if (!g_arena[k].busy) {
+				break;
+			}
+		}
+		g_arena[k].busy = 1;
+		t_arena = &g_arena[k];
+		g_shared_in++;
+	} else {
+		g_excl_waiting++;
+		while (g_excl_in || g_shared_in) {
+			pthread_cond_wait(&g_gate_cv, &g_gate_mu);
+		}
+		g_excl_waiting--;
+		g_excl_in = 1;
+		g_arena[0].busy = 1;
+		t_arena = &g_arena[0];
+	}
+	t_shared = shared;
+	pthread_mutex_unlock(&g_gate_mu);
+}
+
+static void call_leave(void)
+{
+	pthread_mutex_lock(&g_gate_mu);
+	if (t_arena) {
+		t_arena->busy = 0;
+	}
+	if (t_shared) {
+		g_shared_in--;
+	} else {
+		g_excl_in = 0;
+	}
+	t_arena = NULL;
+	pthread_cond_broadcast(&g_gate_cv);
+	pthread_mutex_unlock(&g_gate_mu);
+}
 
 static u8 *buf_get(int k, size_t bytes)
 {
+	arena *A = t_arena;
+	if (!A) {
+		return NULL;   /* (a batch path outside call_enter / call_leave: a bug, reported as an allocation failure) */
+	}
 	if (bytes == 0) {
 		bytes = 1;
 	}
-	if (g_cap[k] < bytes) {
+	if (A->cap[k] < bytes) {
 		const size_t want = bytes + bytes / 8;
-		if (g_buf[k]) {
-			wipe(g_buf[k], g_cap[k]);
-			if (g_pinned[k]) {
-				ecamd_host_free(g_buf[k]);
+		if (A->buf[k]) {
+			wipe(A->buf[k], A->cap[k]);
+			if (A->pinned[k]) {
+				ecamd_host_free(A->buf[k]);
 			} else {
-				free(g_buf[k]);
+				free(A->buf[k]);
 			}
 		}
-		g_buf[k] = (u8 *)ecamd_host_alloc(want);
-		g_pinned[k] = g_buf[k] != NULL;
-		if (!g_buf[k]) {
-			g_buf[k] = (u8 *)malloc(want);   /* pageable memory works too; it is only slower */
+		A->buf[k] = (u8 *)ecamd_host_alloc(want);
+		A->pinned[k] = A->buf[k] != NULL;
+		if (!A->buf[k]) {
+			A->buf[k] = (u8 *)malloc(want);   /* pageable memory works too; it is only slower */
 		}
-		g_cap[k] = g_buf[k] ? want : 0;
-		g_used[k] = 0;
+		A->cap[k] = A->buf[k] ? want : 0;
+		A->used[k] = 0;
 	}
-	if (g_buf[k] && bytes > g_used[k]) {
-		g_used[k] = bytes;
+	if (A->buf[k] && bytes > A->used[k]) {
+		A->used[k] = bytes;
 	}
-	return g_buf[k];
+	return A->buf[k];
 }
 
 static void bufs_free(void)
 {
-	int k;
-	for (k = 0; k < NBUF; k++) {
-		if (g_buf[k]) {
-			wipe(g_buf[k], g_cap[k]);
-			if (g_pinned[k]) {
-				ecamd_host_free(g_buf[k]);
-			} else {
-				free(g_buf[k]);
+	int a, k;
+	for (a = 0; a < NARENA; a++) {
+		arena *A = &g_arena[a];
+		for (k = 0; k < NBUF; k++) {
+			if (A->buf[k]) {
+				wipe(A->buf[k], A->cap[k]);
+				if (A->pinned[k]) {
+					ecamd_host_free(A->buf[k]);
+				} else {
+					free(A->buf[k]);
+				}
 			}
+			A->buf[k] = NULL;
+			A->cap[k] = 0;
+			A->used[k] = 0;
 		}
-		g_buf[k] = NULL;
-		g_cap[k] = 0;
 	}
 }
 
@@ -960,6 +1087,7 @@ static void bufs_free(void)
 /* (on the pool: after a 2^20-item signing call the staging holds some 200 MB, which one thread takes ten milliseconds to clear) */
 #define WIPE_BLOCK 4096u
 typedef struct {
+	arena *A;
 	u32 first[NBUF + 1];   /* first block of buffer k in the concatenation of all used staging */
 } wipe_job;
 static void wipe_blocks(u32 lo, u32 hi, void *arg)
@@ -971,10 +1099,10 @@ static void wipe_blocks(u32 lo, u32 hi, void *arg)
 		if (b0 < b1) {
 			const size_t off = (size_t)(b0 - W->first[k]) * WIPE_BLOCK;
 			size_t len = (size_t)(b1 - b0) * WIPE_BLOCK;
-			if (off + len > g_used[k]) {
-				len = g_used[k] - off;
+			if (off + len > W->A->used[k]) {
+				len = W->A->used[k] - off;
 			}
-			wipe(g_buf[k] + off, len);
+			wipe(W->A->buf[k] + off, len);
 		}
 	}
 }
@@ -982,16 +1110,20 @@ static void wipe_secrets(void)
 {
 	wipe_job W;
 	int k;
+	W.A = t_arena;
+	if (!W.A) {
+		return;
+	}
 	W.first[0] = 0;
 	for (k = 0; k < NBUF; k++) {
-		const size_t used = g_buf[k] ? g_used[k] : 0;
+		const size_t used = W.A->buf[k] ? W.A->used[k] : 0;
 		W.first[k + 1] = W.first[k] + (u32)((used + WIPE_BLOCK - 1) / WIPE_BLOCK);
 	}
 	if (W.first[NBUF]) {
 		parallel_for(W.first[NBUF], wipe_blocks, &W);
 	}
 	for (k = 0; k < NBUF; k++) {
-		g_used[k] = 0;
+		W.A->used[k] = 0;
 	}
 	if (g_multi && ecamd_multi_wipe_scratch(g_multi)) {
 		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
@@ -1181,7 +1313,7 @@ static int mul_batch_common(prj_pt *out, const nn *m, const prj_pt *in, u32 n, i
 	if (!e) {
 		return -1;
 	}
-	pthread_mutex_lock(&g_call_mu);
+	call_enter(0);
 	B.m = m;
 	B.bits = (u32 *)malloc((size_t)n * sizeof(u32));
 	if (!B.bits) {
@@ -1237,7 +1369,7 @@ done:
 	if (secret) {
 		wipe_secrets();
 	}
-	pthread_mutex_unlock(&g_call_mu);
+	call_leave();
 	free(B.bits);
 	free(idx);
 	return ret;
@@ -1296,9 +1428,9 @@ int prj_pt_mul_blind_batch(prj_pt *out, const nn *m, const prj_pt *in, u32 n, in
 		free(B.mb);
 		return -1;
 	}
-	pthread_mutex_lock(&g_call_mu);
+	call_enter(0);
 	parallel_for(n, blind_scalars, &B);
-	pthread_mutex_unlock(&g_call_mu);
+	call_leave();
 	ret = AT_LOAD(&B.failed) ? -1 : mul_batch_common(out, B.mb, in, n, ret_items, 1);
 	wipe(B.mb, (size_t)n * sizeof(nn));
 	free(B.mb);
@@ -1460,7 +1592,7 @@ static int ptop_run(ptop_job *J, u32 n)
 	J->clen = J->e->clen;
 	J->in_fmt = (J->op == PTOP_PUBIMPORT) ? ECAMD_PT_AFFINE : ECAMD_PT_PROJECTIVE;
 	J->iw = (J->in_fmt ? 3u : 2u) * J->clen;
-	pthread_mutex_lock(&g_call_mu);
+	call_enter(0);
 	J->b1 = buf_get(0, (size_t)n * J->iw);
 	J->b2 = (J->op == PTOP_ADD) ? buf_get(1, (size_t)n * J->iw) : J->b1;
 	J->sc = (J->op == PTOP_UMULT) ? buf_get(2, (size_t)n * J->slen) : J->b1;
@@ -1472,7 +1604,7 @@ static int ptop_run(ptop_job *J, u32 n)
 		note_items(n);
 		ret = 0;
 	}
-	pthread_mutex_unlock(&g_call_mu);
+	call_leave();
 	return ret;
 }
 
@@ -1553,9 +1685,9 @@ int _prj_pt_unprotected_mult_batch(prj_pt *out, const nn *scalars, const prj_pt 
 	if (!B.bits) {
 		return -1;
 	}
-	pthread_mutex_lock(&g_call_mu);
+	call_enter(0);
 	parallel_for(n, mul_bits, &B);
-	pthread_mutex_unlock(&g_call_mu);
+	call_leave();
 	for (i = 0; i < n; i++) {
 		maxbits = B.bits[i] > maxbits ? B.bits[i] : maxbits;
 	}
@@ -1912,7 +2044,7 @@ static int key_batch(key_job *J, u32 num)
 	}
 	J->clen = J->e->clen;
 	J->slen = (J->rule == RULE_EDDSA25519) ? 32 : (J->rule == RULE_EDDSA448) ? 57 : J->e->qlen;
-	pthread_mutex_lock(&g_call_mu);
+	call_enter(0);
 	J->sc = buf_get(0, (size_t)num * J->slen);
 	J->out = buf_get(1, (size_t)num * 2 * J->clen);
 	J->st = buf_get(2, num);
@@ -1927,7 +2059,7 @@ static int key_batch(key_job *J, u32 num)
 		ret = 0;
 	}
 	wipe_secrets();
-	pthread_mutex_unlock(&g_call_mu);
+	call_leave();
 	return ret;
 }
 
@@ -2140,7 +2272,7 @@ int ecccdh_derive_secret_batch(const ec_priv_key *const *our_priv_keys, const u8
 	J.qlen = J.e->qlen;
 	J.clen = J.e->clen;
 	J.q = &(J.params->ec_gen_order);
-	pthread_mutex_lock(&g_call_mu);
+	call_enter(0);
 	J.pv = buf_get(0, (size_t)num * J.qlen);
 	J.pk = buf_get(1, (size_t)num * 2 * J.clen);
 	J.sec = buf_get(2, (size_t)num * J.clen);
@@ -2151,7 +2283,7 @@ int ecccdh_derive_secret_batch(const ec_priv_key *const *our_priv_keys, const u8
 		ret = 0;
 	}
 	wipe_secrets();   /* private scalars and shared secrets */
-	pthread_mutex_unlock(&g_call_mu);
+	call_leave();
 	return ret;
 }
 
@@ -2243,7 +2375,7 @@ static int xdh_batch(const char *curve, u32 len, const u8 *const *k, const u8 *c
 	J.res = res;
 	J.len = len;
 	J.ret_items = ret_items;
-	pthread_mutex_lock(&g_call_mu);
+	call_enter(0);
 	J.kb = buf_get(0, (size_t)num * len);
 	J.ub = buf_get(1, (size_t)num * len);
 	J.rb = buf_get(2, (size_t)num * len);
@@ -2254,7 +2386,7 @@ static int xdh_batch(const char *curve, u32 len, const u8 *const *k, const u8 *c
 		ret = 0;
 	}
 	wipe_secrets();
-	pthread_mutex_unlock(&g_call_mu);
+	call_leave();
 	return ret;
 }
 
@@ -2943,7 +3075,7 @@ int ec_sign_batch(u8 *const *sigs, u8 siglen, const ec_key_pair *const *key_pair
 		ret = (idx && (!hm || (ed && (hash_type != eh || rand != NULL)))) ? 0 : -1;
 		goto out;
 	}
-	pthread_mutex_lock(&g_call_mu);
+	call_enter(0);
 	{
 		sign_scan_job S;
 		S.kps = key_pairs;
@@ -2957,7 +3089,7 @@ int ec_sign_batch(u8 *const *sigs, u8 siglen, const ec_key_pair *const *key_pair
 	if (!one_group) {
 		seen = (u8 *)calloc(num, 1);
 		if (!seen) {
-			pthread_mutex_unlock(&g_call_mu);
+			call_leave();
 			goto out;
 		}
 	}
@@ -3012,7 +3144,7 @@ int ec_sign_batch(u8 *const *sigs, u8 siglen, const ec_key_pair *const *key_pair
 		}
 	}
 	wipe_secrets();
-	pthread_mutex_unlock(&g_call_mu);
+	call_leave();
 out:
 	if (rets != ret_items) {
 		free(rets);
@@ -3512,9 +3644,15 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
 	}
 	/* the keys as the reference hashes them: exported as points here, encoded on the device (pre[j] != 0: no encoding) */
 	parallel_for(cnt, eddsa_export_keys, J);
-	if (ecamd_multi_eddsa_encode_point_batch(g_multi, J->e->mc, cnt, J->kprj, J->pk, J->pre)) {
-		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
-		return -1;
+	{
+		int r;
+		pthread_mutex_lock(&g_gpu_mu);   /* (a C-ABI call outside a pipeline: see g_gpu_mu) */
+		r = ecamd_multi_eddsa_encode_point_batch(g_multi, J->e->mc, cnt, J->kprj, J->pk, J->pre);
+		pthread_mutex_unlock(&g_gpu_mu);
+		if (r) {
+			fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+			return -1;
+		}
 	}
 	if (J->all_only) {
 		J->all_ok = 1;
@@ -4007,9 +4145,9 @@ static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_
 		S.idx = idx;
 		S.results = results;
 		S.mixed = S.params ? 0 : 1;
-		pthread_mutex_lock(&g_call_mu);
+		call_enter(1);
 		parallel_for(num, scan_keys, &S);
-		pthread_mutex_unlock(&g_call_mu);
+		call_leave();
 		one_group = !AT_LOAD(&S.mixed);
 	}
 	if (!one_group) {
@@ -4068,9 +4206,12 @@ static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_
 			J.pre_max_mlen = S.max_mlen;
 			J.pre_not_affine = S.not_affine;
 		}
-		pthread_mutex_lock(&g_call_mu);
+		/* ECDSA and EdDSA verification: a pipeline around ONE kind of C-ABI call on public data -- up to NARENA application threads at a
+		 * time, each in its own staging, the GPU calls one after the other (g_gpu_mu); the Schnorr-type path makes dependent calls and
+		 * switches the devices' scalar mode: exclusive */
+		call_enter((is_bip0340(sig_type) || is_ecfsdsa(sig_type)) ? 0 : 1);
 		r = ed ? eddsa_group(&J, cnt, results) : ((is_bip0340(sig_type) || is_ecfsdsa(sig_type)) ? schnorr_group(&J, cnt, results, is_ecfsdsa(sig_type)) : ecdsa_group(&J, cnt, results));
-		pthread_mutex_unlock(&g_call_mu);
+		call_leave();
 		if (r) {
 			goto out;
 		}
@@ -4130,9 +4271,9 @@ static int all_accepted(const u8 **s, const u8 *s_len, const ec_pub_key **pub_ke
 			anyfail_job A;
 			A.res = res;
 			A.fail = 0;
-			pthread_mutex_lock(&g_call_mu);
+			call_enter(1);
 			parallel_for(num, any_failure, &A);
-			pthread_mutex_unlock(&g_call_mu);
+			call_leave();
 			ret = AT_LOAD(&A.fail) ? -1 : 0;
 		}
 	}

@@ -1664,26 +1664,65 @@ struct HostArr {
 };
 
 template <class Core>
-static int host_pipeline(ecamd_ctx *ctx, uint32_t n, const std::vector<HostArr> &arrs, Core core)
+static int host_pipeline(ecamd_ctx *ctx, int pbits, uint32_t n, const std::vector<HostArr> &arrs, Core core)
 {
 	const uint32_t chunk = n < ctx->host_chunk ? n : ctx->host_chunk;
 	const size_t na = arrs.size();
 	if (na > 6) {
 		return fail("internal: too many host arrays");
 	}
-	// Nothing overlaps the copy of the FIRST chunk (and, with a producer hook, its packing): a batch of several chunks starts with a
-	// short one -- an eighth of a chunk, at least 2^16 items ($ECAMD_HOST_RAMP_MIN) -- so that the kernels start a millisecond earlier at 2^20 items
-	// (profiles/r4i_typed_boundary.md); $ECAMD_NO_HOST_RAMP: equal chunks.
+	// The chunk schedule.  Nothing overlaps the copy of the FIRST chunk (and, with a producer hook, its packing), and the copy of chunk
+	// c + 1 hides behind the kernels of chunk c only when it is not much larger than c: so a batch of several chunks starts short -- 2^16
+	// items ($ECAMD_HOST_RAMP_MIN) -- and DOUBLES up to the chunk size (round 6: with an eighth of a chunk followed at once by a full
+	// chunk the device sat idle for 1.7 ms of a 2^20-item verification, waiting for 111 MB to arrive behind 1.4 ms of kernels;
+	// profiles/r6c_typed_boundary.md), and a remainder of up to a chunk and a quarter goes as ONE launch (2^20 items: 2^16, 2^17, 2^18,
+	// 589 824 = three full rounds of the window kernels' 3 072 resident waves).  $ECAMD_HOST_SCHEDULE=a,b,c: explicit leading chunk
+	// sizes (tests, measurements); $ECAMD_NO_HOST_RAMP: equal chunks.
 	static const bool no_ramp = getenv("ECAMD_NO_HOST_RAMP") != nullptr;
-	uint32_t first = chunk;
-	if (n > chunk && !no_ramp) {
-		first = chunk / 8 < ctx->host_first_min ? ctx->host_first_min : chunk / 8;
-		first = first < chunk ? first : chunk;
+	std::vector<uint32_t> sched;
+	{
+		uint32_t left = n;
+		if (const char *e = getenv("ECAMD_HOST_SCHEDULE")) {
+			while (*e && left) {
+				uint32_t v = (uint32_t)strtoul(e, nullptr, 10);
+				v = v < 1 ? 1 : (v > left ? left : v);
+				sched.push_back(v);
+				left -= v;
+				e = strchr(e, ',');
+				if (!e) {
+					break;
+				}
+				e++;
+			}
+		} else if (n > chunk && !no_ramp && pbits <= 256) {
+			for (uint32_t m = ctx->host_first_min < chunk ? ctx->host_first_min : chunk; m < chunk && left > m + m; m += m) {
+				sched.push_back(m);
+				left -= m;
+			}
+		} else if (n > chunk && !no_ramp) {
+			// fields above 256 bits: the kernels of a 2^16-item chunk outlast the copy of a full one (secp384r1: 4 ms against 2.7), and
+			// their window loops lose more to short launches than the doubling wins (measured: 60.6 against 63.6 ms per 2^20
+			// verifications) -- one short chunk, then full ones
+			const uint32_t m = chunk / 8 < ctx->host_first_min ? ctx->host_first_min : chunk / 8;
+			if (m < chunk) {
+				sched.push_back(m);
+				left -= m;
+			}
+		}
+		while (left) {
+			const uint32_t m = (left <= chunk + chunk / 4) ? left : chunk;
+			sched.push_back(m);
+			left -= m;
+		}
 	}
-	const int nbuf = (n > first) ? 2 : 1;
+	uint32_t largest = 0;
+	for (uint32_t m : sched) {
+		largest = m > largest ? m : largest;
+	}
+	const int nbuf = sched.size() > 1 ? 2 : 1;
 	for (int b = 0; b < nbuf; b++) {
 		for (size_t k = 0; k < na; k++) {
-			if (ensure(&ctx->hbuf[b][k], &ctx->hbuf_bytes[b][k], (size_t)chunk * arrs[k].stride)) {
+			if (ensure(&ctx->hbuf[b][k], &ctx->hbuf_bytes[b][k], (size_t)largest * arrs[k].stride)) {
 				return -1;
 			}
 		}
@@ -1703,12 +1742,13 @@ static int host_pipeline(ecamd_ctx *ctx, uint32_t n, const std::vector<HostArr> 
 		HIPCHK(hipEventRecord(ctx->in_ready[b], cs));
 		return 0;
 	};
-	if (copy_in(0, first, 0)) {
+	if (copy_in(0, sched[0], 0)) {
 		return -1;
 	}
 	int b = 0;
-	uint32_t m = first;
-	for (uint32_t off = 0; off < n; off += m, m = (n - off) < chunk ? (n - off) : chunk, b ^= (nbuf - 1)) {
+	uint32_t off = 0;
+	for (size_t ci = 0; ci < sched.size(); off += sched[ci], ci++, b ^= (nbuf - 1)) {
+		const uint32_t m = sched[ci];
 		std::vector<const uint8_t *> ip(na, nullptr);
 		std::vector<uint8_t *> op(na, nullptr);
 		for (size_t k = 0; k < na; k++) {
@@ -1721,12 +1761,12 @@ static int host_pipeline(ecamd_ctx *ctx, uint32_t n, const std::vector<HostArr> 
 		bool next_issued = false;
 		const uint32_t noff = off + m;
 		const std::function<int()> between = [&]() -> int {
-			if (next_issued || noff >= n) {
+			if (next_issued || ci + 1 >= sched.size()) {
 				return 0;
 			}
 			next_issued = true;
 			// the other staging set is free: its chunk was drained at the end of the previous iteration
-			return copy_in(noff, (n - noff) < chunk ? (n - noff) : chunk, b ^ 1);
+			return copy_in(noff, sched[ci + 1], b ^ 1);
 		};
 		if (core(m, ip, op, s, between) || between()) {
 			// leave nothing in flight on the staging buffers of a failed call
@@ -1793,7 +1833,7 @@ extern "C" int ec_prj_pt_mul_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 	HIPCHK(hipSetDevice(ctx->device));
 	const size_t plen = (size_t)2 * cv->clen;
 	const std::vector<HostArr> arrs = {{scalars, nullptr, slen}, {points, nullptr, plen}, {nullptr, out, plen}, {nullptr, status, 1}};
-	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+	return host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
 		return smul_dev_locked(ctx, cv, m, ip[0], slen, ip[1], op[2], op[3], s);
 	});
@@ -1823,7 +1863,7 @@ extern "C" int ec_prj_pt_mul_blind_batch(ecamd_ctx *ctx, const ecamd_curve *cv, 
 	const size_t plen = (size_t)2 * cv->clen;
 	// stage: 12 blinded scalars, 13 "bad blind" flags (beside the host pipeline's own buffers)
 	const std::vector<HostArr> arrs = {{scalars, nullptr, slen}, {blinds, nullptr, blen}, {points, nullptr, plen}, {nullptr, out, plen}, {nullptr, status, 1}};
-	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op, hipStream_t s,
+	return host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op, hipStream_t s,
 					       const std::function<int()> &) {
 		if (ensure(&ctx->stage[12], &ctx->stage_bytes[12], (size_t)m * outlen) || ensure(&ctx->stage[13], &ctx->stage_bytes[13], m)) {
 			return -1;
@@ -2442,7 +2482,7 @@ static int ecdsa_verify_host_aff(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t
 	HIPCHK(hipSetDevice(ctx->device));
 	const size_t plen = (size_t)2 * cv->clen, slen2 = (size_t)2 * cv->qlen;
 	const std::vector<HostArr> arrs = {{pubkeys, nullptr, plen}, {sigs, nullptr, slen2}, {data, nullptr, data_stride}, {nullptr, result, 1}};
-	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+	return host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &between) {
 		const uint8_t *d_dig = ip[2];
 		if (hash_type) {
@@ -2489,7 +2529,7 @@ static int ecdsa_verify_host_fmt(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t
 		HIPCHK(hipSetDevice(ctx->device));
 		std::vector<HostArr> arrs = {{pubkeys, nullptr, 3 * (size_t)cv->clen}, {sigs, nullptr, sl}, {data, nullptr, data_stride},
 					     {nullptr, result, 1}, {nullptr, st.data(), 1}};
-		if (host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+		if (host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 						     hipStream_t s, const std::function<int()> &between) {
 			    if (ensure(&ctx->stage[12], &ctx->stage_bytes[12], (size_t)m * alen)) {
 				    return -1;
@@ -2695,7 +2735,7 @@ extern "C" int ec_ecdsa_sign_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 	const size_t ql = (size_t)cv->qlen;
 	const std::vector<HostArr> arrs = {{privs, nullptr, ql}, {nonces, nullptr, ql}, {digests, nullptr, hlen},
 					   {nullptr, sigs, 2 * ql}, {nullptr, status, 1}};
-	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+	return host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
 		return ecdsa_sign_dev_locked(ctx, cv, m, ip[0], ip[1], ip[2], hlen, op[3], op[4], s);
 	});
@@ -2748,7 +2788,7 @@ extern "C" int ec_nn_random_mod_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uin
 	HIPCHK(hipSetDevice(ctx->device));
 	const size_t ql = (size_t)cv->qlen;
 	const std::vector<HostArr> arrs = {{raw, nullptr, 2 * ql}, {nullptr, out, ql}};
-	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+	return host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
 		return rand_mod_dev_locked(ctx, cv, m, ip[0], op[1], s);
 	});
@@ -2775,7 +2815,7 @@ extern "C" int ec_ecdsa_sign_msg_batch(ecamd_ctx *ctx, const ecamd_curve *cv, ui
 	const size_t ql = (size_t)cv->qlen;
 	const std::vector<HostArr> arrs = {{privs, nullptr, ql}, {nonce_raw, nullptr, 2 * ql}, {msg_slots, nullptr, msg_stride},
 					   {nullptr, sigs, 2 * ql}, {nullptr, status, 1}};
-	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+	return host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
 		// stage 20: the nonces (secret: ensure() wipes what it frees, ecamd_ctx_wipe_scratch the rest); 17: the digests
 		if (ensure(&ctx->stage[20], &ctx->stage_bytes[20], (size_t)m * ql) || rand_mod_dev_locked(ctx, cv, m, ip[1], ctx->stage[20], s)) {
@@ -2810,7 +2850,7 @@ extern "C" int ec_key_pair_gen_raw_batch(ecamd_ctx *ctx, const ecamd_curve *cv, 
 	HIPCHK(hipSetDevice(ctx->device));
 	const size_t ql = (size_t)cv->qlen, plen = (size_t)2 * cv->clen;
 	const std::vector<HostArr> arrs = {{raw, nullptr, 2 * ql}, {nullptr, priv_out, ql}, {nullptr, pub_out, plen}, {nullptr, status, 1}};
-	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+	return host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
 		if (rand_mod_dev_locked(ctx, cv, m, ip[0], op[1], s)) {
 			return -1;
@@ -2920,7 +2960,7 @@ extern "C" int ec_ecccdh_derive_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uin
 	const size_t plen = (size_t)2 * cv->clen, ql = (size_t)cv->qlen;
 	const std::vector<HostArr> arrs = {{privs, nullptr, ql}, {peers, nullptr, plen}, {nullptr, secrets, (size_t)cv->clen},
 					   {nullptr, status, 1}};
-	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+	return host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
 		return ecccdh_dev_locked(ctx, cv, m, ip[0], ip[1], op[2], op[3], s);
 	});
@@ -3177,7 +3217,7 @@ extern "C" int ec_xdh_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n
 	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
 	const size_t len = (size_t)cv->clen;
 	const std::vector<HostArr> arrs = {{k, nullptr, len}, {u, nullptr, len}, {nullptr, out, len}, {nullptr, status, 1}};
-	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+	return host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
 		return xdh_dev_locked(ctx, cv, m, ip[0], ip[1], op[2], op[3], s);
 	});
@@ -3837,7 +3877,7 @@ extern "C" int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *cv_in, u
 	const bool e448 = cv->pbits == 448;
 	const std::vector<HostArr> arrs = {{pubkeys, nullptr, e448 ? 57u : 32u}, {sigs, nullptr, e448 ? 114u : 64u},
 					   {hram, nullptr, hram_len}, {nullptr, result, 1}};
-	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+	return host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
 		return e448 ? eddsa448_verify_dev_locked(ctx, cv, m, ip[0], ip[1], ip[2], op[3], s)
 			    : eddsa_verify_dev_locked(ctx, cv, m, ip[0], ip[1], ip[2], hram_len, op[3], s);
@@ -3865,7 +3905,7 @@ extern "C" int ec_eddsa_verify_msg_batch(ecamd_ctx *ctx, const ecamd_curve *cv_i
 	}
 	HIPCHK(hipSetDevice(ctx->device));
 	const std::vector<HostArr> arrs = {{pubkeys, nullptr, 32u}, {sigs, nullptr, 64u}, {hash_slots, nullptr, stride}, {nullptr, result, 1}};
-	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+	return host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
 		if (ecdsa_hash_stage(ctx, 4, m, ip[2], stride, 64, s)) {
 			return -1;
@@ -3915,7 +3955,7 @@ static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd
 	if (msg_slots) {
 		arrs.push_back({msg_slots, nullptr, msg_stride});
 	}
-	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+	return host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
 		// stage: 20 affine keys, 21 import status, 22 encodings, 23 their status (the verification core owns 3 .. 19)
 		if (ensure(&ctx->stage[20], &ctx->stage_bytes[20], (size_t)m * 2 * cl) || ensure(&ctx->stage[21], &ctx->stage_bytes[21], m) ||
@@ -4699,7 +4739,7 @@ extern "C" int ec_eddsa_sign_R_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint
 	}
 	HIPCHK(hipSetDevice(ctx->device));
 	const std::vector<HostArr> arrs = {{r_hash, nullptr, (size_t)(T.is448 ? 114 : 64)}, {nullptr, R_enc, (size_t)(T.is448 ? 57 : 32)}, {nullptr, status, 1}};
-	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+	return host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
 		return eddsa_sign_R_dev_locked(ctx, cv, T, m, ip[0], op[1], op[2], s);
 	});
@@ -4726,7 +4766,7 @@ extern "C" int ec_eddsa_encode_point_batch(ecamd_ctx *ctx, const ecamd_curve *cv
 	HIPCHK(hipSetDevice(ctx->device));
 	const size_t cl = (size_t)cv->clen, kl = T.is448 ? 57 : 32;
 	const std::vector<HostArr> arrs = {{points_prj, nullptr, 3 * cl}, {nullptr, enc, kl}, {nullptr, status, 1}};
-	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+	return host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
 		// stage: 3 affine points, 4 import status (0 / 1 error / 2 infinity: the encode kernel's convention)
 		if (ensure(&ctx->stage[3], &ctx->stage_bytes[3], (size_t)m * 2 * cl) || ensure(&ctx->stage[4], &ctx->stage_bytes[4], m)) {
@@ -4769,7 +4809,7 @@ extern "C" int ec_eddsa_sign_S_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint
 	HIPCHK(hipSetDevice(ctx->device));
 	const size_t hl = T.is448 ? 114 : 64, kl = T.is448 ? 57 : 32;
 	const std::vector<HostArr> arrs = {{r_hash, nullptr, hl}, {hram, nullptr, hl}, {a_scalars, nullptr, kl}, {nullptr, S_out, kl}};
-	return host_pipeline(ctx, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+	return host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
 		EcamdEdSignArgs A = T;
 		A.n = m;
