@@ -320,6 +320,19 @@ int ec_eddsa_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t
 int ec_schnorr_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *s, const uint8_t *ne,
 				const uint8_t *keys_aff, const uint8_t *r, int r_fmt, int *all_valid);
 int ec_schnorr_verify_all_available(const ecamd_curve *curve, int r_fmt);   /* 1: the multi-scalar form serves this handle */
+/* The same verdict FROM keys, signatures and hash inputs (round 6) -- what an ec_verify_batch of BIP0340 / ECFSDSA signatures needs so that
+ * only marshalling stays on the host.  keys: n points in key_fmt (ECAMD_PT_AFFINE X || Y or ECAMD_PT_PROJECTIVE X || Y || Z, what an
+ * ec_pub_key holds; imported and normalised on the device); sigs: n x (rlen + qlen), the commitment then s, rlen = clen for r_fmt 1
+ * (BIP0340: r, an abscissa) and 2 * clen for r_fmt 0 (ECFSDSA: the point W); hash_slots: per item a little-endian u32 length and the
+ * scheme's hash input (stride a multiple of 4, at most 4096): for BIP0340  H(tag) || H(tag) || r || <blank of clen octets> || m  with
+ * x_offset the blank's offset in the input -- the device writes the x of the key's unique representative there (sig/bip0340.c:437-494)
+ * -- and for ECFSDSA  W.x || W.y || m  with x_offset = 0xffffffff (sig/ecfsdsa.c:520-540); hash_type 1 .. 4 (SHA-224 .. SHA-512).  The
+ * device computes e = H(input) mod q and q - e, takes the key's even-y representative for r_fmt 1 (lift_x, bip0340.c:532-535), and
+ * evaluates ec_schnorr_verify_all_batch's combination over the whole batch once the last chunk has arrived.  *all_valid = 0: not
+ * decided here -- also when a key does not import or is the point at infinity. */
+int ec_schnorr_verify_msg_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *keys, int key_fmt,
+				    const uint8_t *sigs, int r_fmt, int hash_type, const uint8_t *hash_slots, uint32_t stride,
+				    uint32_t x_offset, int *all_valid);
 /* The same combination on device pointers, one piece (n <= the context's max_chunk; a handle for which ec_schnorr_verify_all_available
  * is 0 is an error here): d_verdict[0] = 0 "the batch is valid" / 1 "not decided here".  Only enqueues on the stream. */
 int ec_schnorr_verify_all_batch_dev(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const void *d_s, const void *d_ne,
@@ -528,6 +541,9 @@ int ecamd_multi_eddsa_verify_all_batch(ecamd_multi *m, const ecamd_mcurve *curve
 /* ec_schnorr_verify_all_batch, sharded: every device decides its shard with a combination of its own; valid iff every shard is */
 int ecamd_multi_schnorr_verify_all_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *s, const uint8_t *ne,
 					 const uint8_t *keys_aff, const uint8_t *r, int r_fmt, int *all_valid);
+int ecamd_multi_schnorr_verify_msg_all_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *keys, int key_fmt,
+					     const uint8_t *sigs, int r_fmt, int hash_type, const uint8_t *hash_slots, uint32_t stride,
+					     uint32_t x_offset, int *all_valid);
 int ecamd_multi_eddsa_sign_R_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *r_hash, uint8_t *R_enc,
 				   uint8_t *status);
 int ecamd_multi_eddsa_sign_S_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *r_hash, const uint8_t *hram,

@@ -3832,6 +3832,81 @@ static void fs_export_w(u32 lo, u32 hi, void *arg)
 	}
 }
 
+/* Round 6: the whole Schnorr-type batch as ONE streamed device call (include/libecc_amd.h: ec_schnorr_verify_msg_all_batch).  The pool packs
+ * what ec_verify_init would look at -- the key's live limbs (X || Y || Z, or X || Y when every key has Z = 1), the signature, and the
+ * scheme's hash input with a blank where the key's x goes (BIP0340: H(tag) || H(tag) || r || <blank> || m, sig/bip0340.c:437-494; ECFSDSA:
+ * W || m, sig/ecfsdsa.c:520-540) -- while the device imports, hashes, reduces and evaluates the batch equation: no libecc hash, no nn_mod, no
+ * separate normalisation call on the way.  Any item that fails a host-side check (key type, lengths, r >= p, s = 0 or >= q) makes the
+ * attempt void (`dirty`): the caller then takes the item-by-item path, as for a batch the device does not vouch for. */
+typedef struct {
+	ver_job *J;
+	int fs;
+	u8 *keys, *sigs, *slots;
+	u32 kw, stride, xoff, pre_len;
+	u8 pre[2 * MAX_DIGEST_SIZE];
+	u8 p_be[80], q_be[80];
+	u32 dirty;
+	int all;
+} schfast_job;
+static void schfast_pack(u32 lo, u32 hi, void *arg)
+{
+	schfast_job *F = (schfast_job *)arg;
+	ver_job *J = F->J;
+	const u32 cl = J->clen, ql = J->qlen, rl = F->fs ? 2 * cl : cl;
+	u32 j, k;
+	for (j = lo; j < hi; j++) {
+		const u32 i = J->idx[j];
+		const ec_pub_key *pk = J->pub_keys[i];
+		const u8 *sig = J->s[i];
+		u8 *slot = F->slots + (size_t)j * F->stride, tmp[3 * 80];
+		int bad = pub_key_check_initialized_and_type(pk, J->sig_type) || pk->params != J->params || !sig || J->s_len[i] != J->siglen ||
+			  (!J->m[i] && J->m_len[i]) || prj_to_be(tmp, cl, &pk->y, &(J->params->ec_curve));
+		if (!bad) {
+			int snz = 0;
+			for (k = 0; k < ql; k++) {
+				snz |= sig[rl + k];
+			}
+			bad = !be_lt(sig + rl, F->q_be, ql) || (F->fs ? !snz : !be_lt(sig, F->p_be, cl));
+		}
+		if (bad) {
+			AT_STORE(&F->dirty, 1);
+			memset(F->keys + (size_t)j * F->kw, 0xff, F->kw);
+			memset(F->sigs + (size_t)j * J->siglen, 0, J->siglen);
+			memset(slot, 0, F->stride);
+			continue;
+		}
+		memcpy(F->keys + (size_t)j * F->kw, tmp, F->kw);
+		memcpy(F->sigs + (size_t)j * J->siglen, sig, J->siglen);
+		if (F->fs) {
+			slot_put(slot, F->stride, sig, 2 * cl, NULL, 0, J->m[i], J->m_len[i]);
+		} else {
+			/* H(tag) || H(tag) || r || blank || m: the blank (clen zero octets here) is filled with the key's x on the device */
+			const u32 len = F->pre_len + 2 * cl + J->m_len[i];
+			slot[0] = (u8)len; slot[1] = (u8)(len >> 8); slot[2] = (u8)(len >> 16); slot[3] = (u8)(len >> 24);
+			memcpy(slot + 4, F->pre, F->pre_len);
+			memcpy(slot + 4 + F->pre_len, sig, cl);
+			memset(slot + 4 + F->pre_len + cl, 0, cl);
+			if (J->m_len[i]) {
+				memcpy(slot + 4 + F->pre_len + 2 * cl, J->m[i], J->m_len[i]);
+			}
+			memset(slot + 4 + len, 0, F->stride - 4 - len);
+		}
+	}
+}
+static int schfast_gpu(u32 lo, u32 hi, void *arg)
+{
+	schfast_job *F = (schfast_job *)arg;
+	ver_job *J = F->J;
+	int all = 0;
+	if (ecamd_multi_schnorr_verify_msg_all_batch(g_multi, J->e->mc, hi - lo, F->keys + (size_t)lo * F->kw, F->kw == 2 * J->clen ? ECAMD_PT_AFFINE : ECAMD_PT_PROJECTIVE,
+						      F->sigs + (size_t)lo * J->siglen, F->fs ? 0 : 1, J->dev_hash, F->slots + (size_t)lo * F->stride, F->stride,
+						      F->xoff, &all)) {
+		return -1;
+	}
+	F->all = F->all && all;
+	return 0;
+}
+
 /* the multi-scalar form pays from about 2^17 items per device on (profiles/r5b_schnorr_msm.md); $ECAMD_COMPAT_SCHNORR_MSM_MIN moves the
  * threshold (items per device; 0 = never) */
 static unsigned long g_schnorr_msm_calls;
@@ -3856,7 +3931,7 @@ static int schnorr_group(ver_job *J0, u32 cnt, int *results, int fs)
 	ver_job *J = &B.v;
 	hash_context hc;
 	u32 j;
-	int ret = -1, was_secret = g_secret;
+	int ret = -1, was_secret = g_secret, msm_declined = 0;
 	memset(&B, 0, sizeof(B));
 	B.v = *J0;
 	B.fs = fs;
@@ -3866,6 +3941,64 @@ static int schnorr_group(ver_job *J0, u32 cnt, int *results, int fs)
 	if (J->clen > 80 || J->qlen > 80 || nn_to_be(B.p_be, J->clen, &(J->params->ec_fp.p)) || nn_to_be(B.q_be, J->qlen, &(J->params->ec_gen_order)) ||
 	    J->hm->hfunc_init(&hc) || J->hm->hfunc_update(&hc, (const u8 *)"BIP0340/challenge", 17) || J->hm->hfunc_finalize(&hc, B.tagd)) {
 		return -1;
+	}
+	/* round 6: one streamed device call from keys, signatures and hash inputs first (schfast_job above) */
+	if (schnorr_msm_wanted(cnt) && ec_schnorr_verify_all_available(ecamd_multi_curve_handle(J->e->mc, 0), fs ? 0 : 1) && !getenv("ECAMD_COMPAT_SCHNORR_HOST_PATH")) {
+		schfast_job F;
+		memset(&F, 0, sizeof(F));
+		F.J = J;
+		F.fs = fs;
+		F.all = 1;
+		J->dev_hash = dev_hash_type(J->hm);
+		F.pre_len = fs ? 0 : 2u * J->hm->digest_size;
+		F.stride = J->dev_hash ? dev_hash_slot(J, cnt, fs ? 2 * J->clen : F.pre_len + 2 * J->clen) : 0;
+		F.xoff = fs ? 0xffffffffu : F.pre_len + J->clen;
+		F.kw = (J->pre_scanned && !J->pre_not_affine && !getenv("ECAMD_COMPAT_PRJ_KEYS")) ? 2 * J->clen : 3 * J->clen;
+		memcpy(F.p_be, B.p_be, sizeof(F.p_be));
+		memcpy(F.q_be, B.q_be, sizeof(F.q_be));
+		if (!fs) {
+			memcpy(F.pre, B.tagd, J->hm->digest_size);
+			memcpy(F.pre + J->hm->digest_size, B.tagd, J->hm->digest_size);
+		}
+		if (F.stride) {
+			int tried = 1;
+			F.keys = buf_get(0, (size_t)cnt * F.kw);
+			F.sigs = buf_get(1, (size_t)cnt * J->siglen);
+			F.slots = buf_get(2, (size_t)cnt * F.stride);
+			if (!F.keys || !F.sigs || !F.slots) {
+				return -1;
+			}
+			if (fs) {
+				/* (ECFSDSA keys the combination through the application's get_random, as below) */
+				u8 seed[32];
+				int r;
+				if (AT_LOAD(&g_rand_concurrent)) {
+					r = get_random(seed, sizeof(seed));
+				} else {
+					pthread_mutex_lock(&g_rand_mu);
+					r = get_random(seed, sizeof(seed));
+					pthread_mutex_unlock(&g_rand_mu);
+				}
+				r = r || ecamd_multi_set_msm_seed(g_multi, seed);
+				wipe(seed, sizeof(seed));
+				tried = !r;
+			}
+			if (tried) {
+				if (verify_pipeline(cnt, schfast_pack, schfast_gpu, NULL, &F)) {
+					fprintf(stderr, "libecc_amd compat: the one-call Schnorr form failed (%s); verifying step by step\n", ecamd_last_error());
+				} else {
+					AT_ADD(&g_schnorr_msm_calls, 1);
+					if (F.all && !AT_LOAD(&F.dirty)) {
+						note_items(cnt);
+						for (j = 0; j < cnt; j++) {
+							results[J->idx[j]] = 0;
+						}
+						return 0;
+					}
+					msm_declined = 1;   /* the combination was evaluated and does not vouch: straight to the item-by-item pass below */
+				}
+			}
+		}
 	}
 	J->kprj = buf_get(0, (size_t)cnt * 3 * J->clen);
 	B.kaff = buf_get(1, (size_t)cnt * 2 * J->clen);
@@ -3911,7 +4044,7 @@ static int schnorr_group(ver_job *J0, u32 cnt, int *results, int fs)
 	 * own fall-back does.  ECFSDSA keys the combination through the application's get_random, the import the reference draws its a_i
 	 * from (nn_get_random_mod, sig/ecfsdsa.c:745, :960); BIP0340's reference takes no randomness (a ChaCha20 stream keyed by a hash of the
 	 * batch, sig/bip0340.c:758-860): there the engine keys its z_i with getrandom. */
-	if (schnorr_msm_wanted(cnt) && ec_schnorr_verify_all_available(ecamd_multi_curve_handle(J->e->mc, 0), fs ? 0 : 1)) {
+	if (!msm_declined && schnorr_msm_wanted(cnt) && ec_schnorr_verify_all_available(ecamd_multi_curve_handle(J->e->mc, 0), fs ? 0 : 1)) {
 		/* (the handle is asked first: nothing is drawn from the application's get_random for a curve the form does not serve --
 		 * a curve with a cofactor, a field without a radix-2^29 unit) */
 		int all = 0, clean = 1, tried = 1;

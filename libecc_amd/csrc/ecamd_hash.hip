@@ -350,6 +350,55 @@ hipError_t ecamd_launch_slot_patch(uint8_t *slots, uint32_t stride, uint32_t off
 	}
 	return hipGetLastError();
 }
+// ---- the byte mover in front of the Schnorr-type multi-scalar form (EcamdSchnorrPrepArgs) ----
+__global__ __launch_bounds__(256) void k_schnorr_prep(EcamdSchnorrPrepArgs A)
+{
+	const u32 i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const u32 cl = A.clen, ql = A.qlen, rl = A.rlen;
+	const u8 *key = A.keys_aff + (size_t)i * 2 * cl, *sig = A.sigs + (size_t)i * (rl + ql);
+	u8 *ko = A.keys_out + (size_t)i * 2 * cl;
+	if (A.kst && A.kst[i] != 0) {
+		atomicOr(A.flag, 1u);   // the reference fails on such a key (prj_pt_unique of a point at infinity, an import error): not decided here
+	}
+	if (A.x_off != 0xffffffffu) {
+		u8 *d = A.slots + (size_t)i * A.stride + 4 + A.x_off;
+		for (u32 b = 0; b < cl; b++) {
+			d[b] = key[b];
+		}
+	}
+	for (u32 b = 0; b < cl; b++) {
+		ko[b] = key[b];
+	}
+	if (A.even_y && (key[2 * cl - 1] & 1)) {
+		int borrow = 0;
+		for (u32 b = cl; b-- > 0;) {
+			const int d = (int)A.p_be[b] - (int)key[cl + b] - borrow;
+			ko[cl + b] = (u8)(d & 0xff);
+			borrow = d < 0;
+		}
+	} else {
+		for (u32 b = 0; b < cl; b++) {
+			ko[cl + b] = key[cl + b];
+		}
+	}
+	u8 *ro = A.r_out + (size_t)i * rl, *so = A.s_out + (size_t)i * ql;
+	for (u32 b = 0; b < rl; b++) {
+		ro[b] = sig[b];
+	}
+	for (u32 b = 0; b < ql; b++) {
+		so[b] = sig[rl + b];
+	}
+}
+hipError_t ecamd_launch_schnorr_prep(const EcamdSchnorrPrepArgs &a, hipStream_t s)
+{
+	if (a.n) {
+		hipLaunchKernelGGL(k_schnorr_prep, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+	}
+	return hipGetLastError();
+}
 hipError_t ecamd_launch_reject_where(uint8_t *result, const uint8_t *status, uint32_t n, hipStream_t s)
 {
 	if (n) {

@@ -207,7 +207,7 @@ static const CurveRow g_curve_rows[] = {
 // ------------------------------------------------------------------------------------------
 // objects behind the opaque handles
 // ------------------------------------------------------------------------------------------
-#define ECAMD_NSTAGE 24
+#define ECAMD_NSTAGE 30   /* 24 .. 28: the batch-wide arrays of ec_schnorr_verify_msg_all_batch */
 struct ecamd_ctx {
 	int device;
 	hipStream_t stream;
@@ -4477,6 +4477,143 @@ extern "C" int ec_schnorr_verify_all_batch_dev(ecamd_ctx *ctx, const ecamd_curve
 				memset(seed, 0, sizeof(seed));
 			}
 		}
+	}
+	msm_seed_discard(ctx);
+	return ret;
+}
+
+// BIP0340 / ECFSDSA whole-batch verification FROM keys, signatures and hash inputs (round 6): what libsign_amd.so's ec_verify_batch needs
+// so that nothing but marshalling stays on the host.  Per chunk of the double-buffered staging: the keys are imported and normalised on
+// the device (k_prj_import_g; affine keys go as they are), k_schnorr_prep writes the key's x into the blank of the item's hash input
+// (BIP0340: e = H(H(tag) || H(tag) || r || Y.x || m), sig/bip0340.c:437-494 -- the caller supplies everything but Y.x) and files the key as
+// the equation uses it (the even-y representative), s and the commitment in batch-wide arrays; the hash inputs are hashed
+// (k_sha2_slots) and k_schnorr_ne leaves q - e.  When the last chunk is in, the batch is ONE multi-scalar multiplication per max_chunk
+// items (schnorr_msm_dev_locked): the copies of the 200 MB a 2^20-item batch brings hide behind the front-end kernels, and the
+// Straus loop runs at its full-batch rate.  *all_valid = 0: not decided here (see ec_schnorr_verify_all_batch).
+extern "C" int ec_schnorr_verify_msg_all_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *keys, int key_fmt,
+						   const uint8_t *sigs, int r_fmt, int hash_type, const uint8_t *hash_slots, uint32_t stride,
+						   uint32_t x_offset, int *all_valid)
+{
+	if (schnorr_args_ok("ec_schnorr_verify_msg_all_batch", ctx, cv, n, keys, sigs, hash_slots, hash_slots, r_fmt, all_valid)) {
+		return -1;
+	}
+	*all_valid = 0;
+	const int hl = ecamd_sha2_digest_len(hash_type);
+	const size_t cl = (size_t)cv->clen, ql = (size_t)cv->qlen, rl = r_fmt ? cl : 2 * cl, sl = rl + ql;
+	if ((key_fmt != ECAMD_PT_AFFINE && key_fmt != ECAMD_PT_PROJECTIVE) || hl == 0 || stride < 4 || (stride & 3u) || stride > 4096 ||
+	    (x_offset != 0xffffffffu && (uint64_t)x_offset + 4 + cl > stride) || cl > 72) {
+		return fail("ec_schnorr_verify_msg_all_batch: bad argument (key_fmt ECAMD_PT_AFFINE / _PROJECTIVE; hash_type 1 .. 4 (SHA-224 / 256 / 384 / 512); stride a "
+			    "multiple of 4 in 4 .. 4096; the blank for the key's x, if any, inside the slot)");
+	}
+	int ret = 0;
+	{
+		std::lock_guard<std::mutex> lk(ctx->mu);
+		HIPCHK(hipSetDevice(ctx->device));
+		if (schnorr_msm_available(cv, r_fmt)) {
+			ret = -1;
+			uint8_t seed[32];
+			const size_t kw = (key_fmt == ECAMD_PT_PROJECTIVE ? 3 : 2) * cl;
+			// batch-wide arrays: 24 s, 25 q - e, 26 keys, 27 commitments, 28 the front end's flag word and the verdicts
+			const uint32_t pieces = (n + ctx->max_chunk - 1) / ctx->max_chunk;
+			if (!msm_seed(ctx, seed) && !ensure(&ctx->stage[24], &ctx->stage_bytes[24], (size_t)n * ql) &&
+			    !ensure(&ctx->stage[25], &ctx->stage_bytes[25], (size_t)n * ql) && !ensure(&ctx->stage[26], &ctx->stage_bytes[26], (size_t)n * 2 * cl) &&
+			    !ensure(&ctx->stage[27], &ctx->stage_bytes[27], (size_t)n * rl) && !ensure(&ctx->stage[28], &ctx->stage_bytes[28], 256 + (size_t)pieces)) {
+				uint8_t **S = ctx->stage;
+				uint32_t *d_flag = (uint32_t *)S[28];
+				uint8_t *d_verdicts = S[28] + 256;
+				uint32_t done = 0;
+				PublicScalars pub_scope(ctx);   // everything a verification multiplies by is public
+				EcamdSchnorrPrepArgs P;
+				memset(&P, 0, sizeof(P));
+				big_to_be(P.p_be, (int)cl, cv->p);
+				EcamdSchnorrNeArgs N;
+				memset(&N, 0, sizeof(N));
+				for (int w = 0; w < 18; w++) {
+					N.q[w] = (size_t)w < cv->q.size() ? cv->q[(size_t)w] : 0;
+				}
+				bool first = true;
+				const std::vector<HostArr> arrs = {{keys, nullptr, kw}, {sigs, nullptr, sl}, {hash_slots, nullptr, stride}};
+				int rc = host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &,
+										     hipStream_t s, const std::function<int()> &) {
+					if (first) {
+						HIPCHK(hipMemsetAsync(d_flag, 0, 4, s));
+						HIPCHK(hipMemsetAsync(d_verdicts, 1, pieces, s));
+						first = false;
+					}
+					const uint8_t *d_aff = ip[0], *d_kst = nullptr;
+					if (key_fmt == ECAMD_PT_PROJECTIVE) {
+						if (ensure(&ctx->stage[20], &ctx->stage_bytes[20], (size_t)m * 2 * cl) || ensure(&ctx->stage[21], &ctx->stage_bytes[21], m)) {
+							return -1;
+						}
+						EcamdPrjInArgs I;
+						I.in = ip[0];
+						I.aff = S[20];
+						I.pre = S[21];
+						I.n = m;
+						I.clen = (uint32_t)cl;
+						I.for_mul = 0;
+						I.slot = cv->slot;
+						HIPCHK(launch_prj_import(cv, I, s));
+						d_aff = S[20];
+						d_kst = S[21];
+					}
+					P.keys_aff = d_aff;
+					P.kst = d_kst;
+					P.sigs = ip[1];
+					P.slots = const_cast<uint8_t *>(ip[2]);   // the staged copy of the caller's slots
+					P.keys_out = S[26] + (size_t)done * 2 * cl;
+					P.s_out = S[24] + (size_t)done * ql;
+					P.r_out = S[27] + (size_t)done * rl;
+					P.flag = d_flag;
+					P.n = m;
+					P.clen = (uint32_t)cl;
+					P.qlen = (uint32_t)ql;
+					P.rlen = (uint32_t)rl;
+					P.stride = stride;
+					P.x_off = x_offset;
+					P.even_y = r_fmt ? 1u : 0u;
+					HIPCHK(ecamd_launch_schnorr_prep(P, s));
+					if (ecdsa_hash_stage(ctx, hash_type, m, ip[2], stride, (uint32_t)hl, s)) {
+						return -1;
+					}
+					N.dig = S[17];
+					N.ne = S[25] + (size_t)done * ql;
+					N.n = m;
+					N.hlen = (uint32_t)hl;
+					N.qlen = (uint32_t)ql;
+					HIPCHK(ecamd_launch_schnorr_ne(cv->qnw, N, s));
+					done += m;
+					return 0;
+				});
+				if (!rc) {
+					hipStream_t s = ctx->stream;
+					StreamScope scope(ctx, s);
+					uint32_t pc = 0;
+					for (uint32_t off = 0; off < n && !rc; off += ctx->max_chunk, pc++) {
+						const uint32_t m = (n - off) < ctx->max_chunk ? (n - off) : ctx->max_chunk;
+						rc = schnorr_msm_dev_locked(ctx, cv, m, S[24] + (size_t)off * ql, S[25] + (size_t)off * ql, S[26] + (size_t)off * 2 * cl,
+									    S[27] + (size_t)off * rl, r_fmt, seed, pc, d_verdicts + pc, nullptr, nullptr, s);
+					}
+					std::vector<uint8_t> v(pieces, 1);
+					uint32_t flag = 1;
+					if (!rc && hipMemcpyAsync(v.data(), d_verdicts, pieces, hipMemcpyDeviceToHost, s) == hipSuccess &&
+					    hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
+						int ok = flag == 0;
+						for (uint32_t k = 0; k < pieces; k++) {
+							ok = ok && v[k] == 0;
+						}
+						*all_valid = ok;
+						ret = 0;
+					} else {
+						(void)hipStreamSynchronize(s);
+						if (!rc) {
+							ret = fail("ec_schnorr_verify_msg_all_batch: reading the verdict back failed");
+						}
+					}
+				}
+			}
+			memset(seed, 0, sizeof(seed));
+		}   // else: not decided here
 	}
 	msm_seed_discard(ctx);
 	return ret;

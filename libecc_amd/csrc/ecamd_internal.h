@@ -457,6 +457,31 @@ struct EcamdRandModArgs {
 	uint32_t q[18];          // the generator's order, little-endian words
 };
 hipError_t ecamd_launch_rand_mod(int qnw, const EcamdRandModArgs &a, hipStream_t s);
+// Front end of ec_schnorr_verify_msg_all_batch (BIP0340 / ECFSDSA from keys, signatures and hash inputs; round 6), per chunk of m items:
+//   k_schnorr_prep  the imported key's x into the blank of the item's hash input (BIP0340), the key as the equation uses it (BIP0340: the
+//                   representative with an even y), s and the commitment (r, or W) into the batch-wide arrays; a key that did not import
+//                   or is the point at infinity sets *flag
+//   k_schnorr_ne    ne = q - (digest mod q) mod q, big-endian (sig/bip0340.c:470-494, :531; sig/ecfsdsa.c:520-561)
+struct EcamdSchnorrPrepArgs {
+	const uint8_t *keys_aff;   // m x 2 clen: the keys, affine
+	const uint8_t *kst;        // m import statuses (0 ok), or NULL (keys given affine: the multi-scalar kernels validate them)
+	const uint8_t *sigs;       // m x (rlen + qlen)
+	uint8_t *slots;            // m x stride: u32 length, then the hash input
+	uint8_t *keys_out, *s_out, *r_out;   // m x 2 clen, m x qlen, m x rlen
+	uint32_t *flag;
+	uint32_t n, clen, qlen, rlen, stride;
+	uint32_t x_off;            // offset of the blank for Y.x inside the hash input, 0xffffffff: none
+	uint32_t even_y;           // 1: BIP0340's lift_x of the key (y <- p - y when y is odd)
+	uint8_t p_be[72];
+};
+hipError_t ecamd_launch_schnorr_prep(const EcamdSchnorrPrepArgs &a, hipStream_t s);
+struct EcamdSchnorrNeArgs {
+	const uint8_t *dig;        // n x hlen big-endian digests
+	uint8_t *ne;               // n x qlen big-endian
+	uint32_t n, hlen, qlen;
+	uint32_t q[18];
+};
+hipError_t ecamd_launch_schnorr_ne(int qnw, const EcamdSchnorrNeArgs &a, hipStream_t s);
 // status[i] = 1 and out[i] zeroed where bad[i] != 0
 hipError_t ecamd_launch_status_require(uint8_t *status, const uint8_t *sub, uint8_t want, uint32_t n, hipStream_t s);
 hipError_t ecamd_launch_status_or(uint8_t *status, const uint8_t *bad, uint8_t *out, uint32_t out_stride, uint32_t n, hipStream_t s);

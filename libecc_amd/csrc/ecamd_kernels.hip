@@ -2059,6 +2059,83 @@ hipError_t ecamd_launch_rand_mod(int qnw, const EcamdRandModArgs &a, hipStream_t
 	return hipGetLastError();
 }
 
+// ne = q - (digest mod q) mod q (EcamdSchnorrNeArgs): the digest is a big-endian integer of hlen octets (nn_init_from_buf), reduced by a
+// restoring binary division as in ecamd_randmod.h -- 8 hlen steps of one shift and one conditional subtraction over NW words
+template <int NW> __global__ __launch_bounds__(64) void k_schnorr_ne(EcamdSchnorrNeArgs A)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	u32 q[NW], r[NW];
+#pragma unroll
+	for (int k = 0; k < NW; k++) {
+		q[k] = A.q[k];
+		r[k] = 0;
+	}
+	const u8 *dg = A.dig + (size_t)i * A.hlen;
+#pragma unroll 1
+	for (u32 byte = 0; byte < A.hlen; byte++) {
+		const u32 v = dg[byte];
+#pragma unroll 1
+		for (int bit = 7; bit >= 0; bit--) {
+			const u32 top = r[NW - 1] >> 31;
+#pragma unroll
+			for (int w = NW - 1; w > 0; w--) {
+				r[w] = (r[w] << 1) | (r[w - 1] >> 31);
+			}
+			r[0] = (r[0] << 1) | ((v >> bit) & 1u);
+			u32 d[NW], borrow = 0;
+#pragma unroll
+			for (int w = 0; w < NW; w++) {
+				const uint64_t x = (uint64_t)r[w] - q[w] - borrow;
+				d[w] = (u32)x;
+				borrow = (u32)(x >> 63);
+			}
+			const bool ge = (top != 0) | (borrow == 0);
+#pragma unroll
+			for (int w = 0; w < NW; w++) {
+				r[w] = ge ? d[w] : r[w];
+			}
+		}
+	}
+	// q - e, and 0 when e = 0
+	u32 ne[NW], borrow = 0, nz = 0;
+#pragma unroll
+	for (int w = 0; w < NW; w++) {
+		const uint64_t x = (uint64_t)q[w] - r[w] - borrow;
+		ne[w] = (u32)x;
+		borrow = (u32)(x >> 63);
+		nz |= r[w];
+	}
+	u8 *dst = A.ne + (size_t)i * A.qlen;
+#pragma unroll
+	for (int k = 0; k < NW; k++) {
+#pragma unroll
+		for (int b = 0; b < 4; b++) {
+			const u32 pos = 4 * (u32)k + (u32)b;
+			if (pos < A.qlen) {
+				dst[A.qlen - 1 - pos] = nz ? (u8)(ne[k] >> (8 * b)) : (u8)0;
+			}
+		}
+	}
+}
+
+hipError_t ecamd_launch_schnorr_ne(int qnw, const EcamdSchnorrNeArgs &a, hipStream_t s)
+{
+	if (a.n == 0) {
+		return hipSuccess;
+	}
+	const dim3 grid((a.n + 63) / 64), block(64);
+	switch (qnw) {
+#define X(N) case N: hipLaunchKernelGGL(k_schnorr_ne<N>, grid, block, 0, s, a); break;
+		ECAMD_FOR_NW(X)
+#undef X
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
 hipError_t ecamd_launch_msm_scal(int nw, const EcamdMsmScalArgs &a, hipStream_t s)
 {
 	if (a.n == 0) {

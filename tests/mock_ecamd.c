@@ -463,6 +463,70 @@ int ecamd_multi_schnorr_verify_all_batch(ecamd_multi *m, const ecamd_mcurve *c, 
 	return rc;
 }
 
+/* the one-call form from keys, signatures and hash inputs (round 6): normalise the keys, write their x into the blanks, hash with libecc's
+ * hash functions, e mod q and q - e with libecc's nn, the even-y representative for r_fmt 1, then the conjunction above */
+int ecamd_multi_schnorr_verify_msg_all_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *keys, int key_fmt, const uint8_t *sigs,
+					     int r_fmt, int hash_type, const uint8_t *hash_slots, uint32_t stride, uint32_t x_offset, int *all_valid)
+{
+	const u32 cl = (u32)c->c.clen, ql = (u32)c->c.qlen, rl = r_fmt ? cl : 2 * cl;
+	uint8_t *aff = malloc((size_t)n * 2 * cl + 1), *st = malloc(n + 1), *sl = malloc((size_t)n * stride + 1), *dg = malloc((size_t)n * 64 + 1);
+	uint8_t *sv = malloc((size_t)n * ql + 1), *ne = malloc((size_t)n * ql + 1), *rr = malloc((size_t)n * rl + 1);
+	uint8_t pb[80], qb[80];
+	uint32_t i, k, dl = 0;
+	nn q, e;
+	int rc = -1, bad = 0;
+	*all_valid = 0;
+	mock_ready(n);
+	q.magic = e.magic = WORD(0);
+	if (!aff || !st || !sl || !dg || !sv || !ne || !rr) {
+		goto out;
+	}
+	if (ecamd_multi_prj_pt_unique_batch(m, c, n, keys, key_fmt, aff, ECAMD_PT_AFFINE, st)) {
+		goto out;
+	}
+	memcpy(sl, hash_slots, (size_t)n * stride);
+	for (k = 0; k < cl; k++) {   /* p and q big-endian from the oracle's little-endian 64-bit limbs */
+		pb[cl - 1 - k] = (uint8_t)(c->c.fp.p[k / 8] >> (8 * (k % 8)));
+	}
+	for (k = 0; k < ql; k++) {
+		qb[ql - 1 - k] = (uint8_t)(c->c.q[k / 8] >> (8 * (k % 8)));
+	}
+	if (nn_init_from_buf(&q, qb, (u16)ql)) {
+		goto out;
+	}
+	for (i = 0; i < n; i++) {
+		uint8_t *Y = aff + (size_t)i * 2 * cl;
+		bad |= st[i] != 0;
+		if (x_offset != 0xffffffffu) {
+			memcpy(sl + (size_t)i * stride + 4 + x_offset, Y, cl);
+		}
+		if (r_fmt && (Y[2 * cl - 1] & 1)) {
+			int borrow = 0;
+			for (k = cl; k-- > 0;) {
+				const int d = (int)pb[k] - (int)Y[cl + k] - borrow;
+				Y[cl + k] = (uint8_t)(d & 0xff);
+				borrow = d < 0;
+			}
+		}
+		memcpy(rr + (size_t)i * rl, sigs + (size_t)i * (rl + ql), rl);
+		memcpy(sv + (size_t)i * ql, sigs + (size_t)i * (rl + ql) + rl, ql);
+	}
+	if (mock_hash_slots(hash_type, n, sl, stride, dg, &dl)) {
+		mfail("mock: hashing failed");
+		goto out;
+	}
+	for (i = 0; i < n; i++) {
+		if (nn_init_from_buf(&e, dg + (size_t)i * dl, (u16)dl) || nn_mod(&e, &e, &q) || nn_mod_neg(&e, &e, &q) || nn_export_to_buf(ne + (size_t)i * ql, (u16)ql, &e)) {
+			goto out;
+		}
+	}
+	rc = bad ? 0 : ecamd_multi_schnorr_verify_all_batch(m, c, n, sv, ne, aff, rr, r_fmt, all_valid);
+out:
+	nn_uninit(&q); nn_uninit(&e);
+	free(aff); free(st); free(sl); free(dg); free(sv); free(ne); free(rr);
+	return rc;
+}
+
 /* eddsa_export_pub_key (sig/eddsa.c:970) on each point, through libecc itself */
 int ecamd_multi_eddsa_encode_point_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *points_prj, uint8_t *enc,
 					 uint8_t *status)

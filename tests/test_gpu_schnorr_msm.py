@@ -274,3 +274,97 @@ def test_abscissa_beyond_the_limbs_of_the_521_bit_unit_is_rejected(gpu_ctx):
         assert st[0] == 1
     finally:
         cv.free()
+
+
+def _slots(parts, stride):
+    """hash-input slots: little-endian u32 length, the bytes, zero padding to `stride`"""
+    out = bytearray(stride * len(parts))
+    for i, b in enumerate(parts):
+        out[stride * i:stride * i + 4] = len(b).to_bytes(4, "little")
+        out[stride * i + 4:stride * i + 4 + len(b)] = b
+    return bytes(out)
+
+
+def _projective(aff, cl, p, rng):
+    """X || Y || Z with a random Z of the affine points X || Y"""
+    out = bytearray()
+    for i in range(len(aff) // (2 * cl)):
+        x, y = int.from_bytes(aff[2 * cl * i:2 * cl * i + cl], "big"), int.from_bytes(aff[2 * cl * i + cl:2 * cl * (i + 1)], "big")
+        z = (int.from_bytes(rand_bytes(rng, cl + 8), "big") % (p - 1)) + 1
+        out += (x * z % p).to_bytes(cl, "big") + (y * z % p).to_bytes(cl, "big") + z.to_bytes(cl, "big")
+    return bytes(out)
+
+
+@pytest.mark.parametrize("curve,hash_name", [("SECP256K1", "SHA256"), ("SECP256R1", "SHA512"), ("SECP384R1", "SHA384"), ("SECP224R1", "SHA256")])
+def test_from_keys_signatures_and_messages(gpu_ctx, curve, hash_name):
+    """ec_schnorr_verify_msg_all_batch (round 6): the same verdicts from what an application holds -- keys as generated (any y parity; affine,
+    or projective with a random Z), signatures r || s / W || s, and the schemes' hash inputs with a blank where the key's x goes; the device
+    hashes (SHA-256 / 384 / 512 against hashlib through the items' construction), reduces e mod q -- also when the digest is longer or
+    shorter than q --, lifts the key to its even-y representative and runs the multi-scalar form.  Chunked staging (a host chunk of 64
+    items) so that the batch-wide arrays are filled piece by piece."""
+    import hashlib
+    from oracles import HASHLIB, HASH_IDS, make_bip0340_batch
+    rng = np.random.default_rng(4242 + len(curve))
+    cv = gpu_ctx.curve(curve)
+    old_sched = os.environ.get("ECAMD_HOST_SCHEDULE")
+    os.environ["ECAMD_HOST_SCHEDULE"] = "64,100"          # three staging chunks: 64, 100, 169 items
+    try:
+        p, q = CURVES[curve]["p"], CURVES[curve]["q"]
+        n = 333
+        hid = HASH_IDS[hash_name]
+        hl = hashlib.new(HASHLIB[hash_name]).digest_size
+        if p % 4 == 3:
+            # BIP0340
+            it = make_bip0340_batch(lambda sc: cv.scalar_mult(sc), curve, n, rng, msg_len=19, hash_name=hash_name)
+            cl, ql = it["cl"], it["ql"]
+            tagd = hashlib.new(HASHLIB[hash_name], b"BIP0340/challenge").digest()
+            parts = [tagd + tagd + it["rx"][cl * i:cl * (i + 1)] + bytes(cl) + it["msgs"][19 * i:19 * (i + 1)] for i in range(n)]
+            stride = (4 + 2 * hl + 2 * cl + 19 + 3) & ~3
+            slots = _slots(parts, stride)
+            xo = 2 * hl + cl
+            for keys, fmt in ((it["pubs"], 0), (_projective(it["pubs"], cl, p, rng), 1)):
+                assert cv.schnorr_verify_msg_all(keys, fmt, it["sigs"], 1, hid, slots, stride, xo)
+                for k in (0, n // 2, n - 1):
+                    bad = bytearray(it["sigs"])
+                    bad[(cl + ql) * k + cl + ql - 1] ^= 1                      # s_k
+                    assert not cv.schnorr_verify_msg_all(keys, fmt, bytes(bad), 1, hid, slots, stride, xo)
+                    bs = bytearray(slots)
+                    bs[stride * k + 4 + 2 * hl + 2 * cl] ^= 0x10                 # the message: another e_k
+                    assert not cv.schnorr_verify_msg_all(keys, fmt, it["sigs"], 1, hid, bytes(bs), stride, xo)
+                # another item's key
+                kw = (3 if fmt else 2) * cl
+                swapped = keys[kw:2 * kw] + keys[:kw] + keys[2 * kw:]
+                assert not cv.schnorr_verify_msg_all(swapped, fmt, it["sigs"], 1, hid, slots, stride, xo)
+            # a key at infinity / off the curve: not decided
+            prj = bytearray(_projective(it["pubs"], cl, p, rng))
+            prj[3 * cl * 5:3 * cl * 6] = bytes(cl) + (1).to_bytes(cl, "big") + bytes(cl)
+            assert not cv.schnorr_verify_msg_all(bytes(prj), 1, it["sigs"], 1, hid, slots, stride, xo)
+        # ECFSDSA on every curve: e = H(W.x || W.y || m) mod q, s = k + e x, the equation [s]G + [q - e]Y = W
+        o = Oracle(curve)
+        cl, ql = o.clen, o.qlen
+        rnd = lambda: (int.from_bytes(rand_bytes(rng, ql + 8), "big") % (q - 1)) + 1
+        x, k = [rnd() for _ in range(n)], [rnd() for _ in range(n)]
+        Y, st = cv.scalar_mult(b"".join(v.to_bytes(ql, "big") for v in x))
+        W, st2 = cv.scalar_mult(b"".join(v.to_bytes(ql, "big") for v in k))
+        assert set(st) == {0} and set(st2) == {0}
+        msgs = rand_bytes(rng, 23 * n)
+        sigs, parts = bytearray(), []
+        for i in range(n):
+            hin = W[2 * cl * i:2 * cl * (i + 1)] + msgs[23 * i:23 * (i + 1)]
+            e = int.from_bytes(hashlib.new(HASHLIB[hash_name], hin).digest(), "big") % q
+            # sig/ecfsdsa.c:300-330: s = k + e x (libecc's sign convention: the verifier checks [s]G - [e]Y = W)
+            sigs += W[2 * cl * i:2 * cl * (i + 1)] + ((k[i] + e * x[i]) % q).to_bytes(ql, "big")
+            parts.append(hin)
+        stride = (4 + 2 * cl + 23 + 3) & ~3
+        slots = _slots(parts, stride)
+        for keys, fmt in ((Y, 0), (_projective(Y, cl, p, rng), 1)):
+            assert cv.schnorr_verify_msg_all(keys, fmt, bytes(sigs), 0, hid, slots, stride, 0xffffffff)
+            bad = bytearray(sigs)
+            bad[(2 * cl + ql) * 7 + 2 * cl + 3] ^= 0x20
+            assert not cv.schnorr_verify_msg_all(keys, fmt, bytes(bad), 0, hid, slots, stride, 0xffffffff)
+    finally:
+        if old_sched is None:
+            os.environ.pop("ECAMD_HOST_SCHEDULE", None)
+        else:
+            os.environ["ECAMD_HOST_SCHEDULE"] = old_sched
+        cv.free()

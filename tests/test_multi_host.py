@@ -210,6 +210,37 @@ def test_schnorr_verify_all_shards_and_combines(lib, curve, nranks):
     lib.mh_set_bad(0, 0)
 
 
+@pytest.mark.parametrize("curve", ["SECP256R1", "SECP224K1", "SECP521R1"])
+@pytest.mark.parametrize("nranks", [1, 2, 3, 8])
+def test_schnorr_verify_msg_all_shards_and_combines(lib, curve, nranks):
+    """ecamd_multi_schnorr_verify_msg_all_batch (round 6): keys by 2 or 3 clen (affine / projective), signatures by rlen + qlen (rlen = clen for
+    abscissae, 2 clen for points), hash-input slots by their stride; valid only when every shard is"""
+    cl, ql = CURVES[curve]
+    m, mc = make_multi(lib, nranks, curve)
+    n = 777
+    bounds = shard_bounds(n, nranks)
+    for key_fmt in (0, 1):
+        for r_fmt in (0, 1):
+            for mask in (0, 1 << (nranks - 1)):
+                lib.mh_set_bad(mask, 0)
+                stride = 132
+                ky, sg, sl = Arr((3 if key_fmt else 2) * cl), Arr((cl if r_fmt else 2 * cl) + ql), Arr(stride)
+                ok = C.c_int(-7)
+                before = lib.mh_count()
+                assert lib.ecamd_multi_schnorr_verify_msg_all_batch(m, mc, u32(n), ky.arg, C.c_int(key_fmt), sg.arg, C.c_int(r_fmt), C.c_int(2), sl.arg,
+                                                                    u32(stride), u32(2 * 32 + cl), C.byref(ok)) == 0
+                recs = [r for r in records(lib)[before:] if r[0] != "ecamd_ctx_discard_msm_seed"]
+                assert sorted(r[1] for r in recs) == list(range(nranks))
+                for rfn, rank, rn, ptrs, ints in recs:
+                    lo, hi = bounds[rank]
+                    assert rfn == "ec_schnorr_verify_msg_all_batch" and rn == hi - lo and ints == [key_fmt, r_fmt, 2, stride, 2 * 32 + cl]
+                    assert ptrs == [a.base + lo * a.item for a in (ky, sg, sl)]
+                assert ok.value == (0 if mask else 1)
+    ok = C.c_int(1)
+    assert lib.ecamd_multi_schnorr_verify_msg_all_batch(m, mc, u32(0), None, C.c_int(0), None, C.c_int(0), C.c_int(2), None, u32(4), u32(0), C.byref(ok)) == -1
+    lib.mh_set_bad(0, 0)
+
+
 def test_error_of_one_rank_fails_the_call_and_names_the_rank(lib):
     m, mc = make_multi(lib, 3, "SECP256R1")
     lib.mh_set_fail_rank(1)
