@@ -736,6 +736,301 @@ __global__ __launch_bounds__(64) void k_msm_final_g(const u32 *in, const u8 *gen
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 6: the same combination by BUCKETS (Pippenger) -- per item 24 complete additions instead of the Straus loop's 97 additions and
+// 64 shared doublings.  T - [c]G = sum_i [w_i]Y_i - [z_i]R_i with w_i of 8 wlen bits and z_i of 128: cut into windows of c bits,
+//     sum_win 2^(c win) sum_b b B[win][b],     B[win][b] = the sum of the points whose digit in window `win` is b.
+//   k_bkt_points_g   the 2n points imported once (on-curve check, or BIP0340's lift_x), R negated: affine (x, y) in the unit's
+//                    representation
+//   (k_bkt_hist / k_bkt_scan / k_bkt_scatter, ecamd_kernels.hip: a counting sort of the (window, digit, point) triples -- point
+//                    indices in bucket order)
+//   k_bkt_accum_g    one lane per bucket: its points added up
+//   k_bkt_reduce_g   sum_b b B[b] by levels of 16: a lane folds 16 consecutive entries X[0..16) into T = sum X[r] and
+//                    U = sum r X[r] (running sums, 30 additions), so that  V(X) = sum_j U_j + 16 V(T);  the sums of the U's of
+//                    earlier levels ride along as carry arrays (blockIdx.y > 0: plain sums of 16)
+//   k_bkt_window_g   per window V = C_0 + 16 (C_1 + 16 (... + 16 U_last)), scaled by 2^(c win); k_bkt_total_g adds the windows up
+//   k_msm_final_g    as for the Straus form
+// Every addition here is COMPLETE (bkt_add): equal points are doubled and opposite ones cancel, exactly -- batches whose keys repeat
+// (one signer, many messages) fill buckets with multiples of one point, and "P + P" is then the common case, not an exceptional one.
+// ------------------------------------------------------------------------------------------
+template <int PB> struct BktLay {
+	static constexpr int NL = Cfg<PB>::NL;
+	static constexpr int PENTW = ((2 * NL + 3) / 4) * 4;   // affine point record
+	static constexpr int RECW = MsmLay<PB>::RECW;          // Jacobian record + "is infinity" word
+};
+
+template <int PB> static __device__ __forceinline__ void bkt_add(Jac<PB> &acc, bool &inf, const typename Cls<PB>::FA &X2, const typename Cls<PB>::FA &Y2,
+								  const typename Cls<PB>::FA &Z2, bool inf2, const CurveG<Cfg<PB>::NL> &K)
+{
+	typedef typename Cls<PB>::FC FC;
+	bool hz;
+	Jac<PB> S = add_jac(acc, X2, Y2, Z2, hz, K);
+	bool cancel = false;
+	if (!inf && !inf2 && hz) {
+		// the same x: the same point (the sum is its double) or opposite points (the sum is infinity); decided exactly on Y2 Z1^3 - Y1 Z2^3
+		const FC onec = constant<FC>(K.one);
+		const auto z1z1 = sqrc(acc.Z, K);
+		const auto z2z2 = sqrc(Z2, K);
+		const auto s1 = mulc(mulc(acc.Y, Z2, K), z2z2, K);
+		const auto s2 = mulc(mulc(Y2, acc.Z, K), z1z1, K);
+		const auto d = carry(sub_auto<1>(s2, s1, K));
+		if (is_zero_mulout(mulc(d, onec, K), K)) {
+			S = dbl(acc, K);
+		} else {
+			cancel = true;
+		}
+	}
+	acc.X = selg(inf2, acc.X, selg(inf, X2, S.X));
+	acc.Y = selg(inf2, acc.Y, selg(inf, Y2, S.Y));
+	acc.Z = selg(inf2, acc.Z, selg(inf, Z2, S.Z));
+	inf = (inf & inf2) | cancel;
+}
+
+// the same with an affine second operand (the bucket accumulation)
+template <int PB> static __device__ __forceinline__ void bkt_add_aff(Jac<PB> &acc, bool &inf, const typename Cls<PB>::FA &X2, const typename Cls<PB>::FA &Y2,
+								      const typename Cls<PB>::FA &onez, const CurveG<Cfg<PB>::NL> &K)
+{
+	typedef typename Cls<PB>::FC FC;
+	bool hz;
+	Jac<PB> S = add_aff(acc, X2, Y2, hz, K);
+	bool cancel = false;
+	if (!inf && hz) {
+		const FC onec = constant<FC>(K.one);
+		const auto z1z1 = sqrc(acc.Z, K);
+		const auto s2 = mulc(mulc(Y2, acc.Z, K), z1z1, K);
+		const auto d = carry(sub_auto<1>(s2, mulc(acc.Y, onec, K), K));
+		if (is_zero_mulout(mulc(d, onec, K), K)) {
+			S = dbl(acc, K);
+		} else {
+			cancel = true;
+		}
+	}
+	acc.X = selg(inf, X2, S.X);
+	acc.Y = selg(inf, Y2, S.Y);
+	acc.Z = selg(inf, onez, S.Z);
+	inf = cancel;
+}
+
+template <int PB> static __device__ __forceinline__ void bkt_rec_store(u32 *rec, const Jac<PB> &P, bool inf)
+{
+	jac_store<PB>(rec, P);
+	rec[Lay<PB>::ENTW] = inf ? 1u : 0u;
+}
+template <int PB> static __device__ __forceinline__ Jac<PB> bkt_rec_load(const u32 *rec, bool &inf)
+{
+	inf = rec[Lay<PB>::ENTW] != 0u;
+	return jac_load<PB>(rec);
+}
+// a valid placeholder for an accumulator that holds nothing yet
+template <int PB> static __device__ __forceinline__ Jac<PB> bkt_blank(const CurveG<Cfg<PB>::NL> &K)
+{
+	typedef typename Cls<PB>::FA FA;
+	typedef typename Cls<PB>::FC FC;
+	Jac<PB> P;
+	P.X = weaken<FA>(constant<FC>(K.one));
+	P.Y = P.X;
+	P.Z = P.X;
+	return P;
+}
+
+template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_bkt_points_g(EcamdMsmArgs A, int gslot)
+{
+	typedef Lay<PB> L;
+	typedef typename Cls<PB>::FA FA;
+	typedef typename Cls<PB>::FM FM;
+	constexpr int NL = L::NL, PENTW = BktLay<PB>::PENTW;
+	const u32 idx = blockIdx.x * 64 + threadIdx.x;
+	if (idx >= 2 * A.n) {
+		return;
+	}
+	const bool isR = idx >= A.n;
+	const u32 i = isR ? idx - A.n : idx;
+	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	EcamdSmulArgs S;
+	S.points = isR ? A.ptsR : A.ptsY;
+	S.pstride = 2u * A.clen;
+	S.clen = A.clen;
+	FM xm, ym;
+	bool bad;
+	if (isR && A.r_fmt == 1u) {
+		bad = !msm_lift_x<PB>(A.ptsR + (size_t)i * A.clen, (int)A.clen, xm, ym, K);
+	} else {
+		bad = !import_point<PB>(S, i, xm, ym, K);
+	}
+	const FA x = weaken<FA>(xm);
+	const FA y = selg(isR, neg<PB>(ym, K), weaken<FA>(ym));   // the equation subtracts [z_i]R_i
+	u32 buf[PENTW];
+#pragma unroll
+	for (int w = 0; w < NL; w++) {
+		buf[w] = x.l[w];
+		buf[NL + w] = y.l[w];
+	}
+#pragma unroll
+	for (int w = 2 * NL; w < PENTW; w++) {
+		buf[w] = 0;
+	}
+	uint4 *d = (uint4 *)(A.pts + (size_t)idx * PENTW);
+#pragma unroll
+	for (int q = 0; q < PENTW / 4; q++) {
+		d[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
+	}
+	if (bad) {
+		atomicOr(A.flagword, 1u);   // the point does not import / the abscissa has no point: not decided here
+	}
+}
+
+template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_bkt_accum_g(EcamdMsmArgs A, int gslot)
+{
+	typedef Lay<PB> L;
+	typedef typename Cls<PB>::FA FA;
+	typedef typename Cls<PB>::FC FC;
+	constexpr int NL = L::NL, PENTW = BktLay<PB>::PENTW, RECW = BktLay<PB>::RECW;
+	const u32 t = blockIdx.x * 64 + threadIdx.x;
+	const u32 NB = 1u << A.c;
+	if (t >= A.nwin * NB) {
+		return;
+	}
+	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	const u32 win = t >> A.c, b = t & (NB - 1u);
+	const u32 cnt = b ? A.bcount[t] : 0u, start = A.bstart[t];
+	const u32 *ord = A.order + (size_t)win * 2u * A.n + start;
+	const FA onez = weaken<FA>(constant<FC>(K.one));
+	Jac<PB> acc = bkt_blank<PB>(K);
+	bool inf = true;
+#pragma unroll 1
+	for (u32 k = 0; k < cnt; k++) {
+		const u32 idx = ord[k];
+		const uint4 *src = (const uint4 *)(A.pts + (size_t)idx * PENTW);
+		u32 buf[PENTW];
+#pragma unroll
+		for (int q = 0; q < PENTW / 4; q++) {
+			const uint4 v = src[q];
+			buf[4 * q] = v.x;
+			buf[4 * q + 1] = v.y;
+			buf[4 * q + 2] = v.z;
+			buf[4 * q + 3] = v.w;
+		}
+		FA x, y;
+#pragma unroll
+		for (int w = 0; w < NL; w++) {
+			x.l[w] = buf[w];
+			y.l[w] = buf[NL + w];
+		}
+		bkt_add_aff<PB>(acc, inf, x, y, onez, K);
+	}
+	bkt_rec_store<PB>(A.bsum + (size_t)t * RECW, acc, inf);
+}
+
+// one level of the bucket reduction (see the header above).  in: nwin x Lin records; FOLD = 16 consecutive entries per lane.
+// blockIdx.y = 0: T and U of the level's input; blockIdx.y = k > 0: the sums of 16 of carry array k - 1.
+#define BKT_FOLD 16
+#define BKT_MAXCARRY 6
+struct BktLevel {
+	const u32 *inT;
+	const u32 *inC[BKT_MAXCARRY];
+	u32 *outT, *outU;
+	u32 *outC[BKT_MAXCARRY];
+	u32 Lin, Lout, nwin, ncarry;
+};
+template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_bkt_reduce_g(BktLevel V, int gslot)
+{
+	typedef Lay<PB> L;
+	constexpr int NL = L::NL, RECW = BktLay<PB>::RECW;
+	const u32 t = blockIdx.x * 64 + threadIdx.x;
+	if (t >= V.nwin * V.Lout) {
+		return;
+	}
+	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	const u32 win = t / V.Lout, j = t - win * V.Lout;
+	const u32 first = j * BKT_FOLD, len = (V.Lin - first) < BKT_FOLD ? (V.Lin - first) : BKT_FOLD;
+	const u32 role = blockIdx.y;
+	const u32 *in = (role == 0 ? V.inT : V.inC[role - 1]) + ((size_t)win * V.Lin + first) * RECW;
+	Jac<PB> run = bkt_blank<PB>(K), acc = run;
+	bool rinf = true, ainf = true;
+	if (role == 0) {
+#pragma unroll 1
+		for (u32 r = len; r-- > 1;) {
+			bool pinf;
+			const Jac<PB> P = bkt_rec_load<PB>(in + (size_t)r * RECW, pinf);
+			bkt_add<PB>(run, rinf, P.X, P.Y, P.Z, pinf, K);
+			bkt_add<PB>(acc, ainf, run.X, run.Y, run.Z, rinf, K);
+		}
+		{
+			bool pinf;
+			const Jac<PB> P = bkt_rec_load<PB>(in, pinf);
+			bkt_add<PB>(run, rinf, P.X, P.Y, P.Z, pinf, K);
+		}
+		bkt_rec_store<PB>(V.outT + (size_t)t * RECW, run, rinf);
+		bkt_rec_store<PB>(V.outU + (size_t)t * RECW, acc, ainf);
+	} else {
+#pragma unroll 1
+		for (u32 r = 0; r < len; r++) {
+			bool pinf;
+			const Jac<PB> P = bkt_rec_load<PB>(in + (size_t)r * RECW, pinf);
+			bkt_add<PB>(run, rinf, P.X, P.Y, P.Z, pinf, K);
+		}
+		bkt_rec_store<PB>(V.outC[role - 1] + (size_t)t * RECW, run, rinf);
+	}
+}
+
+// per window: V = C_0 + 16 (C_1 + 16 (... + 16 U_last)) from the one record per window every array has come down to, then 2^(c win) V
+struct BktWindows {
+	const u32 *U;                   // nwin records: the last level's U
+	const u32 *C[BKT_MAXCARRY];     // nwin records each: the totals of the earlier levels' U, first level first
+	u32 *out;                       // nwin records
+	u32 nwin, ncarry, c;
+};
+template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_bkt_window_g(BktWindows V, int gslot)
+{
+	typedef Lay<PB> L;
+	constexpr int NL = L::NL, RECW = BktLay<PB>::RECW;
+	const u32 win = blockIdx.x * 64 + threadIdx.x;
+	if (win >= V.nwin) {
+		return;
+	}
+	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	bool inf;
+	Jac<PB> acc = bkt_rec_load<PB>(V.U + (size_t)win * RECW, inf);
+#pragma unroll 1
+	for (u32 k = V.ncarry; k-- > 0;) {
+#pragma unroll 1
+		for (int d = 0; d < 4; d++) {      // x 16 (a doubling of a placeholder is harmless: `inf` keeps it out of the sums)
+			acc = dbl(acc, K);
+		}
+		bool cinf;
+		const Jac<PB> P = bkt_rec_load<PB>(V.C[k] + (size_t)win * RECW, cinf);
+		bkt_add<PB>(acc, inf, P.X, P.Y, P.Z, cinf, K);
+	}
+#pragma unroll 1
+	for (u32 d = 0; d < V.c * win; d++) {
+		acc = dbl(acc, K);
+	}
+	bkt_rec_store<PB>(V.out + (size_t)win * RECW, acc, inf);
+}
+template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_bkt_total_g(const u32 *in, u32 nwin, u32 *out, u32 *flagword, int gslot)
+{
+	typedef Lay<PB> L;
+	typedef typename Cls<PB>::FC FC;
+	constexpr int NL = L::NL, RECW = BktLay<PB>::RECW;
+	if (blockIdx.x != 0 || threadIdx.x != 0) {
+		return;
+	}
+	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	bool inf;
+	Jac<PB> acc = bkt_rec_load<PB>(in, inf);
+#pragma unroll 1
+	for (u32 w = 1; w < nwin; w++) {
+		bool pinf;
+		const Jac<PB> P = bkt_rec_load<PB>(in + (size_t)w * RECW, pinf);
+		bkt_add<PB>(acc, inf, P.X, P.Y, P.Z, pinf, K);
+	}
+	// a Z that became zero without the bookkeeping noticing (it cannot on a curve of prime order): not a sum this path vouches for
+	if (!inf && is_zero_mulout(mulc(acc.Z, constant<FC>(K.one), K), K)) {
+		atomicOr(flagword, 2u);
+	}
+	bkt_rec_store<PB>(out, acc, inf);
+}
+
+// ------------------------------------------------------------------------------------------
 // Affine-table pipeline (every flavour except the two nine-limb ones, see the launcher and HAVE_MADD in ecamd_jacg.h): the
 // pipeline of ecamd_p256_kernel.hip
 //   k_table_g    import + on-curve check, Jacobian multiples 2P..8P into the item's staging slots, recoded scalar
@@ -4117,6 +4412,60 @@ hipError_t G29_CAT(ecamd_g29_msm_, G29_TAG)(int gslot, int phase, const EcamdMsm
 		hipLaunchKernelGGL((k_msm_table_g<G29_PB, G29_FLAV>), dim3((2 * a.n + 63) / 64), dim3(64), 0, s, a, gslot);
 	} else if (phase == 1) {
 		hipLaunchKernelGGL((k_msm_loop_g<G29_PB, G29_FLAV>), dim3((a.L + 63) / 64), dim3(64), 0, s, a, gslot);
+	} else if (phase == 10) {
+		hipLaunchKernelGGL((k_bkt_points_g<G29_PB, G29_FLAV>), dim3((2 * a.n + 63) / 64), dim3(64), 0, s, a, gslot);
+	} else if (phase == 11) {
+		const uint32_t lanes = a.nwin << a.c;
+		hipLaunchKernelGGL((k_bkt_accum_g<G29_PB, G29_FLAV>), dim3((lanes + 63) / 64), dim3(64), 0, s, a, gslot);
+	} else if (phase == 12) {
+		// the reduction: levels of BKT_FOLD over the bucket sums, ping-pong between the two halves of a.red; then the windows, their total,
+		// and the comparison with -[c]G
+		BktLevel V = {};
+		V.nwin = a.nwin;
+		V.inT = a.bsum;
+		V.Lin = 1u << a.c;
+		uint32_t *half[2] = {a.red, a.red + (size_t)a.red_words / 2};
+		int hsel = 0;
+		while (V.Lin > 1) {
+			V.Lout = (V.Lin + BKT_FOLD - 1) / BKT_FOLD;
+			uint32_t *o = half[hsel];
+			const size_t arr = (size_t)a.nwin * V.Lout * RECW;
+			if ((2 + (size_t)V.ncarry) * arr > (size_t)a.red_words / 2 || V.ncarry + 1 > BKT_MAXCARRY) {
+				return hipErrorInvalidValue;
+			}
+			V.outT = o;
+			V.outU = o + arr;
+			for (uint32_t k = 0; k < V.ncarry; k++) {
+				V.outC[k] = o + (2 + (size_t)k) * arr;
+			}
+			const uint32_t lanes = a.nwin * V.Lout;
+			hipLaunchKernelGGL((k_bkt_reduce_g<G29_PB, G29_FLAV>), dim3((lanes + 63) / 64, 1 + V.ncarry), dim3(64), 0, s, V, gslot);
+			// the next level folds this level's T; this level's U joins the carry arrays
+			V.inT = V.outT;
+			for (uint32_t k = 0; k < V.ncarry; k++) {
+				V.inC[k] = V.outC[k];
+			}
+			V.inC[V.ncarry] = V.outU;
+			V.ncarry++;
+			V.Lin = V.Lout;
+			hsel ^= 1;
+		}
+		// now every array holds one record per window: inC[0 .. ncarry - 2] the totals of the earlier levels' U, inC[ncarry - 1] the last U
+		BktWindows W = {};
+		W.nwin = a.nwin;
+		W.c = a.c;
+		W.U = V.inC[V.ncarry - 1];
+		W.ncarry = V.ncarry - 1;
+		for (uint32_t k = 0; k + 1 < V.ncarry; k++) {
+			W.C[k] = V.inC[k];
+		}
+		uint32_t *o = half[hsel];
+		W.out = o;
+		hipLaunchKernelGGL((k_bkt_window_g<G29_PB, G29_FLAV>), dim3((a.nwin + 63) / 64), dim3(64), 0, s, W, gslot);
+		uint32_t *tot = o + (size_t)a.nwin * RECW;
+		hipLaunchKernelGGL((k_bkt_total_g<G29_PB, G29_FLAV>), dim3(1), dim3(64), 0, s, (const uint32_t *)o, a.nwin, tot, a.flagword, gslot);
+		hipLaunchKernelGGL((k_msm_final_g<G29_PB, G29_FLAV>), dim3(1), dim3(64), 0, s, (const uint32_t *)tot, gen, gen_status, a.clen, (const uint32_t *)a.flagword,
+				   verdict, sum_out, gslot);
 	} else {
 		// tree sum, ping-pong between a.rec and tmp
 		uint32_t count = a.L;
@@ -4391,6 +4740,7 @@ X(192s)
 X(256k)
 X(448g)
 #undef X
+uint32_t ecamd_g29_bkt_point_words(int pbits, int flavour) { return (uint32_t)(((2 * g29::nl_for_flavour(pbits, flavour) + 3) / 4) * 4); }   // BktLay<PB>::PENTW
 uint32_t ecamd_g29_msm_rec_words(int pbits, int flavour) { return (uint32_t)(((3 * g29::nl_for_flavour(pbits, flavour) + 3) / 4) * 4) + 4u; }   // MsmLay<PB>::RECW
 // the Schnorr-type multi-scalar multiplication on the unit (pbits, flavour)
 hipError_t ecamd_launch_msm_g29(int pbits, int gslot, int flavour, int phase, const EcamdMsmArgs &a, uint32_t *tmp, const uint8_t *gen,

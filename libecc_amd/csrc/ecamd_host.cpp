@@ -4240,6 +4240,29 @@ static uint32_t schnorr_msm_pick_k(uint32_t n)
 	return k > 8 ? 8 : k;
 }
 
+// Straus (round 5) or buckets (round 6) for a piece of n items.  Buckets: windows of 16 bits -- z_i has 128 = 8 x 16 of them, and the
+// orders of the usual curves a multiple of 16 -- from 2^17 items on (below, the fixed costs of the sort and of the reduction over 2^16
+// buckets per window outweigh the additions they save: profiles/r6h_schnorr_bucket.md), and only when the order's TOP window still has
+// at least 12 bits: a top window of t bits files n points into 2^t buckets, each added up by one lane (secp521r1: 9 bits, secp224k1:
+// 1 bit -- those keep the Straus loop).  $ECAMD_SCHNORR_MSM_ALGO=straus|bucket overrides the size rule (tests, measurements).
+static bool schnorr_msm_use_buckets(const ecamd_curve *cv, uint32_t n)
+{
+	const uint32_t top_bits = (uint32_t)cv->qbits - 16u * (((uint32_t)cv->qbits - 1u) / 16u);
+	if (top_bits < 12u) {
+		return false;
+	}
+	if (const char *e = getenv("ECAMD_SCHNORR_MSM_ALGO")) {
+		if (!strcmp(e, "straus")) {
+			return false;
+		}
+		if (!strcmp(e, "bucket")) {
+			return true;
+		}
+	}
+	return n >= (1u << 17);
+}
+static uint32_t schnorr_bkt_window(uint32_t) { return 16u; }
+
 static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_s, const uint8_t *d_ne, const uint8_t *d_keys,
 				  const uint8_t *d_r, int r_fmt, const uint8_t seed[32], uint32_t piece, uint8_t *d_verdict, uint8_t *d_z_dump,
 				  uint32_t *d_sum_dump, hipStream_t s)
@@ -4248,18 +4271,25 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 	if (!schnorr_msm_unit(cv, &pbits, &flav, &gslot) || cv->qslot < 0) {
 		return fail("internal: Schnorr multi-scalar multiplication without a radix-2^29 unit");
 	}
+	const bool buckets = schnorr_msm_use_buckets(cv, n);
 	const uint32_t K = schnorr_msm_pick_k(n);
 	const uint32_t L = (n + K - 1) / K;
 	const size_t itemw = ecamd_g29_table_words(pbits, flav), recw = ecamd_g29_msm_rec_words(pbits, flav);
 	const size_t cl = (size_t)cv->clen, ql = (size_t)cv->qlen, qnw = (size_t)cv->qnw;
+	// bucket evaluation: window bits, windows of the full-length scalars / of the 128-bit z_i, counters, reduction scratch
+	const uint32_t bc = schnorr_bkt_window(n), bnwin = (uint32_t)((8 * ql + bc - 1) / bc), bnwinZ = (128u + bc - 1) / bc;
+	const size_t bcounters = (size_t)bnwin << bc, bpw = ecamd_g29_bkt_point_words(pbits, flav);
+	const size_t bred_words = 2 * (2 * (size_t)bnwin * ((((size_t)1 << bc) + 15) / 16) * recw + ((size_t)bnwin + 2) * recw);
 	size_t off = 0;
 	auto carve = [&](size_t bytes) {
 		const size_t o = off;
 		off += msm_align(bytes);
 		return o;
 	};
-	const size_t o_tbl = carve((size_t)2 * n * itemw * 4);
-	const size_t o_rec = carve((size_t)L * recw * 4), o_tmp = carve(((size_t)L / 16 + 2) * recw * 4);
+	const size_t o_tbl = carve(buckets ? (size_t)2 * n * bpw * 4 : (size_t)2 * n * itemw * 4);
+	const size_t o_rec = carve(buckets ? bcounters * recw * 4 : (size_t)L * recw * 4);
+	const size_t o_tmp = carve(buckets ? bred_words * 4 : ((size_t)L / 16 + 2) * recw * 4);
+	const size_t o_cnt = carve(buckets ? 3 * bcounters * 4 : 0), o_ord = carve(buckets ? (size_t)bnwin * 2 * n * 4 : 0);
 	const size_t o_w = carve((size_t)n * ql), o_z = carve((size_t)n * 16), o_v = carve((size_t)n * qnw * 4);
 	const size_t o_v1 = carve(((size_t)n / 64 + 2) * qnw * 4), o_v2 = carve(((size_t)n / 4096 + 2) * qnw * 4);
 	const size_t o_c = carve(ql), o_gen = carve(2 * cl), o_gst = carve(4), o_word = carve(4);
@@ -4268,6 +4298,25 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 	}
 	uint8_t *M = ctx->msm;
 	HIPCHK(hipMemsetAsync(M + o_word, 0, 4, s));
+	bool points_beside = false;
+	if (buckets && ctx->side_ok && getenv("ECAMD_NO_BKT_BESIDE") == nullptr) {
+		// the import of the 2n points (on-curve checks, BIP0340's square roots: VALU work that reads only the caller's arrays) runs on the side
+		// stream beside the scalar kernels and the counting sort (atomics and scattered stores); the bucket additions wait for both
+		EcamdMsmArgs P;
+		memset(&P, 0, sizeof(P));
+		P.ptsY = d_keys;
+		P.ptsR = d_r;
+		P.flagword = (uint32_t *)(M + o_word);
+		P.pts = (uint32_t *)(M + o_tbl);
+		P.n = n;
+		P.clen = (uint32_t)cl;
+		P.r_fmt = (uint32_t)r_fmt;
+		HIPCHK(hipEventRecord(ctx->side_fork, s));
+		HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+		HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 10, P, nullptr, nullptr, nullptr, nullptr, nullptr, ctx->side_stream));
+		HIPCHK(hipEventRecord(ctx->side_done, ctx->side_stream));
+		points_beside = true;
+	}
 	EcamdMsmScalArgs C;
 	memset(&C, 0, sizeof(C));
 	C.s = d_s;
@@ -4328,6 +4377,48 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 	A.wlen = (uint32_t)ql;
 	A.zlen = 16;
 	A.r_fmt = (uint32_t)r_fmt;
+	if (buckets) {
+		A.pts = (uint32_t *)(M + o_tbl);
+		A.bsum = (uint32_t *)(M + o_rec);
+		A.red = (uint32_t *)(M + o_tmp);
+		A.red_words = bred_words;
+		A.c = bc;
+		A.nwin = bnwin;
+		uint32_t *cnt = (uint32_t *)(M + o_cnt);
+		A.bcount = cnt;
+		A.bstart = cnt + bcounters;
+		A.order = (const uint32_t *)(M + o_ord);
+		EcamdBktSortArgs B;
+		memset(&B, 0, sizeof(B));
+		B.scW = M + o_w;
+		B.scZ = M + o_z;
+		B.hist = cnt;
+		B.start = cnt + bcounters;
+		B.cursor = cnt + 2 * bcounters;
+		B.order = (uint32_t *)(M + o_ord);
+		B.n = n;
+		B.wlen = (uint32_t)ql;
+		B.zlen = 16;
+		B.c = bc;
+		B.nwin = bnwin;
+		B.nwinZ = bnwinZ < bnwin ? bnwinZ : bnwin;
+		HIPCHK(ecamd_launch_bkt_sort(B, s));
+		if (points_beside) {
+			HIPCHK(hipStreamWaitEvent(s, ctx->side_done, 0));
+		}
+		for (int phase = points_beside ? 11 : 10; phase <= 12; phase++) {
+			const bool timed = ctx->timing && phase == 11;   // the dominant kernel: k_bkt_accum_g
+			if (timed) {
+				HIPCHK(hipEventRecord(ctx->ev_dom[0], s));
+			}
+			HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, phase, A, nullptr, M + o_gen, M + o_gst, d_verdict, d_sum_dump, s));
+			if (timed) {
+				HIPCHK(hipEventRecord(ctx->ev_dom[1], s));
+				ctx->ev_dom_valid = true;
+			}
+		}
+		return 0;
+	}
 	for (int phase = 0; phase < 3; phase++) {
 		const bool timed = ctx->timing && phase == 1;   // the dominant kernel: k_msm_loop_g (ecamd_ctx_dominant_kernel_ms)
 		if (timed) {

@@ -273,7 +273,24 @@ struct EcamdMsmArgs {
 	uint32_t n, K, L, clen, wlen, zlen;
 	uint32_t r_fmt;              // 1: R_i is the point with the given x and an EVEN y (BIP0340's lift_x, sig/bip0340.c:532-535 / :947-953);
 	                             //    p = 3 mod 4 only (the host checks): y = (x^3 + a x + b)^((p + 1) / 4)
+	// the bucket evaluation (round 6; phases 10 - 12 of ecamd_launch_msm_g29, k_bkt_* in ecamd_g29_kernel.hip and ecamd_kernels.hip)
+	uint32_t *pts;               // 2n affine point records (ecamd_g29_bkt_point_words words each; R_i negated)
+	const uint32_t *bstart, *bcount;   // nwin << c: where every bucket's list starts in its window's `order`, and how long it is
+	const uint32_t *order;       // nwin x 2n point indices, every window's in bucket order
+	uint32_t *bsum;              // nwin << c records: the buckets' sums
+	uint32_t *red;               // scratch of the reduction, red_words words
+	uint64_t red_words;
+	uint32_t c, nwin;            // window bits (11 .. 16), windows of the full-length scalars
 };
+uint32_t ecamd_g29_bkt_point_words(int pbits, int flavour);
+// the counting sort of the (window, digit, point) triples (ecamd_kernels.hip); point index i < n: Y_i with scalar scW[i], n + i: R_i with scZ[i]
+struct EcamdBktSortArgs {
+	const uint8_t *scW, *scZ;    // n x wlen, n x zlen big-endian
+	uint32_t *hist, *start, *cursor;   // nwin << c counters each (hist and cursor zeroed by the launcher)
+	uint32_t *order;             // nwin x 2n
+	uint32_t n, wlen, zlen, c, nwin, nwinZ;
+};
+hipError_t ecamd_launch_bkt_sort(const EcamdBktSortArgs &a, hipStream_t s);
 // scalars of the combination (mod q, saturated unit of the order's size): z_i = 128 bits of ChaCha20(seed; counter = item)
 struct EcamdMsmScalArgs {
 	const uint8_t *s, *ne;       // n x qlen big-endian: s_i, q - e_i (both must be < q)

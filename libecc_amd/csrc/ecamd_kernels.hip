@@ -2136,6 +2136,102 @@ hipError_t ecamd_launch_schnorr_ne(int qnw, const EcamdSchnorrNeArgs &a, hipStre
 	return hipGetLastError();
 }
 
+// ---- the counting sort in front of the bucket evaluation of the Schnorr-type combination (EcamdBktSortArgs; round 6).  Pairs are
+//      enumerated window-major: window win has the n keys (digit of scW) and, below nwinZ, the n signature points (digit of scZ).
+//      Digit 0 contributes nothing and is not filed. ----
+static __device__ __forceinline__ u32 bkt_digit(const u8 *sc, u32 len, u32 win, u32 c)
+{
+	// bits [win c, win c + c) of the big-endian integer sc[0 .. len)
+	const u32 bit = win * c, byte = bit >> 3, sh = bit & 7u;
+	u32 v = 0;
+#pragma unroll
+	for (u32 k = 0; k < 3; k++) {
+		const u32 pos = byte + k;
+		if (pos < len) {
+			v |= (u32)sc[len - 1u - pos] << (8u * k);
+		}
+	}
+	return (v >> sh) & ((1u << c) - 1u);
+}
+static __device__ __forceinline__ u32 bkt_pair_digit(const EcamdBktSortArgs &A, u32 win, u32 j, u32 &pt)
+{
+	const bool isR = j >= A.n;
+	pt = j;
+	return isR ? bkt_digit(A.scZ + (size_t)(j - A.n) * A.zlen, A.zlen, win, A.c) : bkt_digit(A.scW + (size_t)j * A.wlen, A.wlen, win, A.c);
+}
+__global__ __launch_bounds__(256) void k_bkt_hist(EcamdBktSortArgs A)
+{
+	const u32 win = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+	const u32 cnt = (win < A.nwinZ) ? 2u * A.n : A.n;
+	if (j >= cnt) {
+		return;
+	}
+	u32 pt;
+	const u32 d = bkt_pair_digit(A, win, j, pt);
+	if (d) {
+		atomicAdd(&A.hist[((size_t)win << A.c) + d], 1u);
+	}
+}
+// exclusive scan of the 2^c counters of one window by one block of 256 threads
+__global__ __launch_bounds__(256) void k_bkt_scan(EcamdBktSortArgs A)
+{
+	__shared__ u32 part[256];
+	const u32 win = blockIdx.x, t = threadIdx.x, per = (1u << A.c) / 256u;
+	const u32 *h = A.hist + ((size_t)win << A.c) + (size_t)t * per;
+	u32 sum = 0;
+	for (u32 k = 0; k < per; k++) {
+		sum += h[k];
+	}
+	part[t] = sum;
+	__syncthreads();
+	for (u32 d = 1; d < 256; d <<= 1) {
+		const u32 v = (t >= d) ? part[t - d] : 0u;
+		__syncthreads();
+		part[t] += v;
+		__syncthreads();
+	}
+	u32 run = part[t] - sum;
+	u32 *o = A.start + ((size_t)win << A.c) + (size_t)t * per;
+	for (u32 k = 0; k < per; k++) {
+		o[k] = run;
+		run += h[k];
+	}
+}
+__global__ __launch_bounds__(256) void k_bkt_scatter(EcamdBktSortArgs A)
+{
+	const u32 win = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+	const u32 cnt = (win < A.nwinZ) ? 2u * A.n : A.n;
+	if (j >= cnt) {
+		return;
+	}
+	u32 pt;
+	const u32 d = bkt_pair_digit(A, win, j, pt);
+	if (d) {
+		const size_t b = ((size_t)win << A.c) + d;
+		const u32 pos = A.start[b] + atomicAdd(&A.cursor[b], 1u);
+		A.order[(size_t)win * 2u * A.n + pos] = pt;
+	}
+}
+hipError_t ecamd_launch_bkt_sort(const EcamdBktSortArgs &a, hipStream_t s)
+{
+	if (a.n == 0 || a.c < 8 || a.c > 16 || a.nwin == 0) {
+		return hipErrorInvalidValue;
+	}
+	const size_t counters = (size_t)a.nwin << a.c;
+	hipError_t e = hipMemsetAsync(a.hist, 0, counters * 4, s);
+	if (e == hipSuccess) {
+		e = hipMemsetAsync(a.cursor, 0, counters * 4, s);
+	}
+	if (e != hipSuccess) {
+		return e;
+	}
+	const dim3 gp((2 * a.n + 255) / 256, a.nwin);
+	hipLaunchKernelGGL(k_bkt_hist, gp, dim3(256), 0, s, a);
+	hipLaunchKernelGGL(k_bkt_scan, dim3(a.nwin), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(k_bkt_scatter, gp, dim3(256), 0, s, a);
+	return hipGetLastError();
+}
+
 hipError_t ecamd_launch_msm_scal(int nw, const EcamdMsmScalArgs &a, hipStream_t s)
 {
 	if (a.n == 0) {

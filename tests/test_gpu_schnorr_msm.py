@@ -53,6 +53,19 @@ def patched(buf, width, i, new):
     return buf[:width * i] + new + buf[width * (i + 1):]
 
 
+@pytest.fixture(autouse=True, params=["straus", "bucket"])
+def msm_algo(request):
+    """every test of this module runs on both evaluations of the combination: the Straus loop (round 5) and the bucket form (round 6);
+    ECAMD_SCHNORR_MSM_ALGO is read by the library at every call"""
+    old = os.environ.get("ECAMD_SCHNORR_MSM_ALGO")
+    os.environ["ECAMD_SCHNORR_MSM_ALGO"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("ECAMD_SCHNORR_MSM_ALGO", None)
+    else:
+        os.environ["ECAMD_SCHNORR_MSM_ALGO"] = old
+
+
 @pytest.fixture
 def msm_k():
     """ECAMD_SCHNORR_MSM_K for the duration of a test (read by the library at every call)"""
@@ -367,4 +380,44 @@ def test_from_keys_signatures_and_messages(gpu_ctx, curve, hash_name):
             os.environ.pop("ECAMD_HOST_SCHEDULE", None)
         else:
             os.environ["ECAMD_HOST_SCHEDULE"] = old_sched
+        cv.free()
+
+
+@pytest.mark.parametrize("curve", ["SECP256K1", "SECP256R1", "SECP384R1"])
+def test_repeated_and_opposite_keys(gpu_ctx, curve):
+    """One signer, many messages -- and the signer whose key is the opposite point: every bucket of the round-6 evaluation then holds
+    multiples of ONE point, "P + P" and "P + (-P)" are ordinary events (2 048 items, 16-bit windows: hundreds of equal and of opposite
+    pairs meet in a bucket), and the additions must double / cancel exactly instead of giving up.  The verdicts are those of distinct keys:
+    accepted when valid, not accepted with one damaged item -- on both evaluations."""
+    rng = np.random.default_rng(6006)
+    o = Oracle(curve)
+    c = CURVES[curve]
+    q, p = c["q"], c["p"]
+    cl, ql = o.clen, o.qlen
+    n = 2048
+    x0 = (int.from_bytes(rand_bytes(rng, ql + 8), "big") % (q - 1)) + 1
+    xs = [x0 if i % 2 == 0 else q - x0 for i in range(n)]
+    Y0, st = o.scalar_mult(x0.to_bytes(ql, "big"))
+    assert set(st) == {0}
+    Ym = Y0[:cl] + (p - int.from_bytes(Y0[cl:], "big")).to_bytes(cl, "big")
+    ks = [(int.from_bytes(rand_bytes(rng, ql + 8), "big") % (q - 1)) + 1 for _ in range(n)]
+    es = [(int.from_bytes(rand_bytes(rng, ql + 8), "big") % (q - 1)) + 1 for _ in range(n)]
+    R, st = o.scalar_mult(b"".join(k.to_bytes(ql, "big") for k in ks))
+    assert set(st) == {0}
+    s = b"".join(((ks[i] + es[i] * xs[i]) % q).to_bytes(ql, "big") for i in range(n))
+    ne = b"".join(((q - e) % q).to_bytes(ql, "big") for e in es)
+    Y = b"".join(Y0 if i % 2 == 0 else Ym for i in range(n))
+    cv = gpu_ctx.curve(curve)
+    try:
+        assert cv.schnorr_verify_all(s, ne, Y, R, 0)
+        for k in (0, 1, n - 1):
+            sk = (int.from_bytes(s[ql * k:ql * (k + 1)], "big") + 1) % q
+            assert not cv.schnorr_verify_all(patched(s, ql, k, sk.to_bytes(ql, "big")), ne, Y, R, 0)
+        # the same commitment twice, and its opposite: items 0 and 1 share R_0 (k_1 := k_0), item 2 carries -R_0 (k_2 := q - k_0)
+        ks[1], ks[2] = ks[0], q - ks[0]
+        R0 = R[:2 * cl]
+        R = R0 + R0 + R0[:cl] + (p - int.from_bytes(R0[cl:], "big")).to_bytes(cl, "big") + R[6 * cl:]
+        s = b"".join(((ks[i] + es[i] * xs[i]) % q).to_bytes(ql, "big") for i in range(n))
+        assert cv.schnorr_verify_all(s, ne, Y, R, 0)
+    finally:
         cv.free()

@@ -305,7 +305,22 @@ def main():
             table = (pb * S + 12 * M) + 2 * (4 * (dbl[0] * M + dbl[1] * S) + 3 * (12 * M + 4 * S)) + 8 * M
             work = {"kernel": "k_msm_loop_g", "mads_per_item": loop, "sgpr_mads_per_item": loop * red / M,
                     "step_mads_per_item": loop + table, "alg_bytes_per_item": ql + ql + 2 * cl + cl}
-            metric, unit, cfg = "BIP0340 signatures/sec in whole-batch verification (%s, one multi-scalar multiplication per 2^%d-item batch, K = %d items per lane)" % (curve.lower(), a.batch_log2, K), "verifications/s", "f4"
+            how = "Straus, K = %d items per lane" % K
+            qb = O.CURVES[curve]["q"].bit_length()
+            algo = os.environ.get("ECAMD_SCHNORR_MSM_ALGO") or ("bucket" if B >= (1 << 17) else "straus")
+            if algo == "bucket" and qb - 16 * ((qb - 1) // 16) >= 12:
+                # round 6, the bucket evaluation (ecamd_host.cpp:schnorr_msm_use_buckets): per item 8 ql / 16 windows of the key's scalar and 8 of
+                # z_i, one complete addition with an affine operand each (add_aff: 10M + 3S) in k_bkt_accum_g, the dominant kernel; the step
+                # adds the import of the two points (the key: on-curve check; r: a square root), and the bucket reduction -- 2^16 buckets
+                # per window, 2 Jacobian additions (12M + 4S) each, whatever the batch size
+                pairs = (8 * ql + 15) // 16 + 8
+                acc = pairs * (10 * M + 3 * S)
+                front = (pb * S + 14 * M) + 5 * M + 2 * S
+                reduce_ = ((8 * ql + 15) // 16) * 65536 * 2 * (12 * M + 4 * S) / B
+                work = {"kernel": "k_bkt_accum_g", "mads_per_item": acc, "sgpr_mads_per_item": acc * red / M,
+                        "step_mads_per_item": acc + front + reduce_, "alg_bytes_per_item": ql + ql + 2 * cl + cl}
+                how = "buckets, 16-bit windows, %d additions per item" % pairs
+            metric, unit, cfg = "BIP0340 signatures/sec in whole-batch verification (%s, one multi-scalar multiplication per 2^%d-item batch: %s)" % (curve.lower(), a.batch_log2, how), "verifications/s", "f4"
             ref_what = "ec_verify_batch (BIP0340: bip0340_verify_batch, no scratch pad)"
         else:
             cv = ctx.curve("WEI25519")
