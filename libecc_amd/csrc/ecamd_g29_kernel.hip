@@ -884,23 +884,22 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_bkt_
 	typedef typename Cls<PB>::FA FA;
 	typedef typename Cls<PB>::FC FC;
 	constexpr int NL = L::NL, PENTW = BktLay<PB>::PENTW, RECW = BktLay<PB>::RECW;
-	const u32 t = blockIdx.x * 64 + threadIdx.x;
+	const u32 lane = blockIdx.x * 64 + threadIdx.x;
 	const u32 NB = 1u << A.c;
-	if (t >= A.nwin * NB) {
+	if (lane >= A.nwin * NB) {
 		return;
 	}
 	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	const u32 t = A.perm ? A.perm[lane] : lane;
 	const u32 win = t >> A.c, b = t & (NB - 1u);
 	const u32 cnt = b ? A.bcount[t] : 0u, start = A.bstart[t];
 	const u32 *ord = A.order + (size_t)win * 2u * A.n + start;
 	const FA onez = weaken<FA>(constant<FC>(K.one));
 	Jac<PB> acc = bkt_blank<PB>(K);
 	bool inf = true;
-#pragma unroll 1
-	for (u32 k = 0; k < cnt; k++) {
-		const u32 idx = ord[k];
+	// the next point's record is on its way while the current addition runs (its index was read an iteration earlier still)
+	auto fetch = [&](u32 idx, u32 *buf) {
 		const uint4 *src = (const uint4 *)(A.pts + (size_t)idx * PENTW);
-		u32 buf[PENTW];
 #pragma unroll
 		for (int q = 0; q < PENTW / 4; q++) {
 			const uint4 v = src[q];
@@ -909,11 +908,24 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_bkt_
 			buf[4 * q + 2] = v.z;
 			buf[4 * q + 3] = v.w;
 		}
+	};
+	u32 nbuf[PENTW];
+	u32 nidx = 0;
+	if (cnt) {
+		fetch(ord[0], nbuf);
+		nidx = cnt > 1 ? ord[1] : 0u;
+	}
+#pragma unroll 1
+	for (u32 k = 0; k < cnt; k++) {
 		FA x, y;
 #pragma unroll
 		for (int w = 0; w < NL; w++) {
-			x.l[w] = buf[w];
-			y.l[w] = buf[NL + w];
+			x.l[w] = nbuf[w];
+			y.l[w] = nbuf[NL + w];
+		}
+		if (k + 1 < cnt) {
+			fetch(nidx, nbuf);
+			nidx = k + 2 < cnt ? ord[k + 2] : 0u;
 		}
 		bkt_add_aff<PB>(acc, inf, x, y, onez, K);
 	}

@@ -4289,7 +4289,7 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 	const size_t o_tbl = carve(buckets ? (size_t)2 * n * bpw * 4 : (size_t)2 * n * itemw * 4);
 	const size_t o_rec = carve(buckets ? bcounters * recw * 4 : (size_t)L * recw * 4);
 	const size_t o_tmp = carve(buckets ? bred_words * 4 : ((size_t)L / 16 + 2) * recw * 4);
-	const size_t o_cnt = carve(buckets ? 3 * bcounters * 4 : 0), o_ord = carve(buckets ? (size_t)bnwin * 2 * n * 4 : 0);
+	const size_t o_cnt = carve(buckets ? 4 * bcounters * 4 : 0), o_ord = carve(buckets ? (size_t)bnwin * 2 * n * 4 : 0);
 	const size_t o_w = carve((size_t)n * ql), o_z = carve((size_t)n * 16), o_v = carve((size_t)n * qnw * 4);
 	const size_t o_v1 = carve(((size_t)n / 64 + 2) * qnw * 4), o_v2 = carve(((size_t)n / 4096 + 2) * qnw * 4);
 	const size_t o_c = carve(ql), o_gen = carve(2 * cl), o_gst = carve(4), o_word = carve(4);
@@ -4314,8 +4314,7 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 		HIPCHK(hipEventRecord(ctx->side_fork, s));
 		HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
 		HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 10, P, nullptr, nullptr, nullptr, nullptr, nullptr, ctx->side_stream));
-		HIPCHK(hipEventRecord(ctx->side_done, ctx->side_stream));
-		points_beside = true;
+		points_beside = true;   // (side_done is recorded further down, behind [c]G)
 	}
 	EcamdMsmScalArgs C;
 	memset(&C, 0, sizeof(C));
@@ -4333,6 +4332,14 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 	C.qlen = (uint32_t)ql;
 	C.qslot = cv->qslot;
 	HIPCHK(ecamd_launch_msm_scal(cv->qnw, C, s));
+	// c = sum z_i s_i and [c]G: four tiny reduction launches and a one-item fixed-base multiplication, a latency-bound chain of 0.7 ms that
+	// only the final comparison needs -- on the side stream behind the points when there is one, beside the counting sort
+	hipStream_t vs = s;
+	if (points_beside) {
+		HIPCHK(hipEventRecord(ctx->side_fork, s));
+		HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+		vs = ctx->side_stream;
+	}
 	{
 		// c = sum v_i mod q: levels of fan-in 64, the last one writes the big-endian bytes
 		EcamdMsmVsumArgs V;
@@ -4349,7 +4356,7 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 			V.out = bufs[b];
 			V.count = count;
 			V.c_be = outc == 1 ? M + o_c : nullptr;
-			HIPCHK(ecamd_launch_msm_vsum(cv->qnw, V, s));
+			HIPCHK(ecamd_launch_msm_vsum(cv->qnw, V, vs));
 			src = bufs[b];
 			b ^= 1;
 			count = outc;
@@ -4358,8 +4365,11 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 	// [c]G from the handle's own fixed-base path, one item, device pointers (the comb table is built for a batch of this size: without
 	// it the single item would walk the whole window loop alone, a millisecond of latency)
 	maybe_build_comb(ctx, const_cast<ecamd_curve *>(cv), n);
-	if (smul_dev_locked(ctx, cv, 1, M + o_c, (uint32_t)ql, nullptr, M + o_gen, M + o_gst, s, 0xffffffffu, false, nullptr)) {
+	if (smul_dev_locked(ctx, cv, 1, M + o_c, (uint32_t)ql, nullptr, M + o_gen, M + o_gst, vs, 0xffffffffu, false, nullptr)) {
 		return -1;
+	}
+	if (points_beside) {
+		HIPCHK(hipEventRecord(ctx->side_done, ctx->side_stream));
 	}
 	EcamdMsmArgs A;
 	memset(&A, 0, sizeof(A));
@@ -4395,6 +4405,8 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 		B.hist = cnt;
 		B.start = cnt + bcounters;
 		B.cursor = cnt + 2 * bcounters;
+		B.perm = getenv("ECAMD_NO_BKT_RANK") ? nullptr : cnt + 3 * bcounters;
+		A.perm = B.perm;
 		B.order = (uint32_t *)(M + o_ord);
 		B.n = n;
 		B.wlen = (uint32_t)ql;

@@ -277,6 +277,7 @@ struct EcamdMsmArgs {
 	uint32_t *pts;               // 2n affine point records (ecamd_g29_bkt_point_words words each; R_i negated)
 	const uint32_t *bstart, *bcount;   // nwin << c: where every bucket's list starts in its window's `order`, and how long it is
 	const uint32_t *order;       // nwin x 2n point indices, every window's in bucket order
+	const uint32_t *perm;        // nwin << c: lane t of k_bkt_accum_g serves bucket perm[t] (NULL: bucket t)
 	uint32_t *bsum;              // nwin << c records: the buckets' sums
 	uint32_t *red;               // scratch of the reduction, red_words words
 	uint64_t red_words;
@@ -288,6 +289,7 @@ struct EcamdBktSortArgs {
 	const uint8_t *scW, *scZ;    // n x wlen, n x zlen big-endian
 	uint32_t *hist, *start, *cursor;   // nwin << c counters each (hist and cursor zeroed by the launcher)
 	uint32_t *order;             // nwin x 2n
+	uint32_t *perm;              // nwin << c: the buckets, every 4096 of them ranked by size (k_bkt_rank); may be NULL
 	uint32_t n, wlen, zlen, c, nwin, nwinZ;
 };
 hipError_t ecamd_launch_bkt_sort(const EcamdBktSortArgs &a, hipStream_t s);
