@@ -838,10 +838,11 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_bkt_points_g
 	typedef typename Cls<PB>::FA FA;
 	typedef typename Cls<PB>::FM FM;
 	constexpr int NL = L::NL, PENTW = BktLay<PB>::PENTW;
-	const u32 idx = blockIdx.x * 64 + threadIdx.x;
-	if (idx >= 2 * A.n) {
+	const u32 rel = blockIdx.x * 64 + threadIdx.x;
+	if (rel >= (A.pt_count ? A.pt_count : 2 * A.n)) {
 		return;
 	}
+	const u32 idx = A.pt_first + rel;
 	const bool isR = idx >= A.n;
 	const u32 i = isR ? idx - A.n : idx;
 	const CurveG<NL> &K = TabGP<PB>::get(gslot);
@@ -884,16 +885,23 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_bkt_
 	typedef typename Cls<PB>::FA FA;
 	typedef typename Cls<PB>::FC FC;
 	constexpr int NL = L::NL, PENTW = BktLay<PB>::PENTW, RECW = BktLay<PB>::RECW;
-	const u32 lane = blockIdx.x * 64 + threadIdx.x;
+	const u32 rel = blockIdx.x * 64 + threadIdx.x;
 	const u32 NB = 1u << A.c;
-	if (lane >= A.nwin * NB) {
+	if (rel >= (A.win_count ? A.win_count : A.nwin) * NB) {
 		return;
 	}
+	const u32 lane = A.win_first * NB + rel;
 	const CurveG<NL> &K = TabGP<PB>::get(gslot);
 	const u32 t = A.perm ? A.perm[lane] : lane;
 	const u32 win = t >> A.c, b = t & (NB - 1u);
-	const u32 cnt = b ? A.bcount[t] : 0u, start = A.bstart[t];
-	const u32 *ord = A.order + (size_t)win * 2u * A.n + start;
+	u32 cnt = b ? A.bcount[t] : 0u;
+	const u32 *ord;
+	if (A.cap) {
+		cnt = cnt < A.cap ? cnt : A.cap;
+		ord = A.order + (size_t)t * A.cap;
+	} else {
+		ord = A.order + (size_t)win * 2u * A.n + A.bstart[t];
+	}
 	const FA onez = weaken<FA>(constant<FC>(K.one));
 	Jac<PB> acc = bkt_blank<PB>(K);
 	bool inf = true;
@@ -4425,10 +4433,15 @@ hipError_t G29_CAT(ecamd_g29_msm_, G29_TAG)(int gslot, int phase, const EcamdMsm
 	} else if (phase == 1) {
 		hipLaunchKernelGGL((k_msm_loop_g<G29_PB, G29_FLAV>), dim3((a.L + 63) / 64), dim3(64), 0, s, a, gslot);
 	} else if (phase == 10) {
-		hipLaunchKernelGGL((k_bkt_points_g<G29_PB, G29_FLAV>), dim3((2 * a.n + 63) / 64), dim3(64), 0, s, a, gslot);
+		const uint32_t cnt = a.pt_count ? a.pt_count : 2 * a.n;
+		hipLaunchKernelGGL((k_bkt_points_g<G29_PB, G29_FLAV>), dim3((cnt + 63) / 64), dim3(64), 0, s, a, gslot);
 	} else if (phase == 11) {
-		const uint32_t lanes = a.nwin << a.c;
+		const uint32_t lanes = (a.win_count ? a.win_count : a.nwin) << a.c;
 		hipLaunchKernelGGL((k_bkt_accum_g<G29_PB, G29_FLAV>), dim3((lanes + 63) / 64), dim3(64), 0, s, a, gslot);
+	} else if (phase == 13) {
+		// the comparison with -[c]G alone (the total of phase 12 rests behind the window records of the reduction's last half)
+		hipLaunchKernelGGL((k_msm_final_g<G29_PB, G29_FLAV>), dim3(1), dim3(64), 0, s, (const uint32_t *)tmp, gen, gen_status, a.clen, (const uint32_t *)a.flagword,
+				   verdict, sum_out, gslot);
 	} else if (phase == 12) {
 		// the reduction: levels of BKT_FOLD over the bucket sums, ping-pong between the two halves of a.red; then the windows, their total,
 		// and the comparison with -[c]G
@@ -4476,8 +4489,8 @@ hipError_t G29_CAT(ecamd_g29_msm_, G29_TAG)(int gslot, int phase, const EcamdMsm
 		hipLaunchKernelGGL((k_bkt_window_g<G29_PB, G29_FLAV>), dim3((a.nwin + 63) / 64), dim3(64), 0, s, W, gslot);
 		uint32_t *tot = o + (size_t)a.nwin * RECW;
 		hipLaunchKernelGGL((k_bkt_total_g<G29_PB, G29_FLAV>), dim3(1), dim3(64), 0, s, (const uint32_t *)o, a.nwin, tot, a.flagword, gslot);
-		hipLaunchKernelGGL((k_msm_final_g<G29_PB, G29_FLAV>), dim3(1), dim3(64), 0, s, (const uint32_t *)tot, gen, gen_status, a.clen, (const uint32_t *)a.flagword,
-				   verdict, sum_out, gslot);
+		// (phase 13 compares it with -[c]G; the caller finds it at a.red + a.red_words - RECW: copied there)
+		hipLaunchKernelGGL((k_bkt_total_g<G29_PB, G29_FLAV>), dim3(1), dim3(64), 0, s, (const uint32_t *)tot, 1u, a.red + (size_t)a.red_words - RECW, a.flagword, gslot);
 	} else {
 		// tree sum, ping-pong between a.rec and tmp
 		uint32_t count = a.L;

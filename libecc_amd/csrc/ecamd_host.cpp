@@ -233,7 +233,7 @@ struct ecamd_ctx {
 	// beside the bandwidth-bound k_p256_table / k_p256_affine of the same chunk; the interleaved window loop -- the first reader
 	// of u1, u2 and the flags -- waits for side_done ($ECAMD_NO_SIDE_STREAM: off).  66.0 -> 67.0 M verifications/s.
 	hipStream_t side_stream;
-	hipEvent_t side_fork, side_done;
+	hipEvent_t side_fork, side_done, side_mid, side_aux;   // (side_mid / side_aux: the bucket evaluation's second and third joins)
 	bool side_ok;
 	uint32_t host_chunk;
 	uint32_t host_first_min;   // smallest first chunk of a multi-chunk call (ECAMD_HOST_RAMP_MIN, default 2^16; host_pipeline)
@@ -430,7 +430,9 @@ extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
 	}
 	if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
 	    hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&c->side_done, hipEventDisableTiming) != hipSuccess) {
+	    hipEventCreateWithFlags(&c->side_done, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->side_mid, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->side_aux, hipEventDisableTiming) != hipSuccess) {
 		delete c;
 		return fail("ecamd_ctx_create: side stream creation failed");
 	}
@@ -474,6 +476,8 @@ extern "C" void ecamd_ctx_destroy(ecamd_ctx *c)
 	(void)hipStreamDestroy(c->side_stream);
 	(void)hipEventDestroy(c->side_fork);
 	(void)hipEventDestroy(c->side_done);
+	(void)hipEventDestroy(c->side_mid);
+	(void)hipEventDestroy(c->side_aux);
 	(void)hipEventDestroy(c->in_ready[0]);
 	(void)hipEventDestroy(c->in_ready[1]);
 	(void)hipEventDestroy(c->busy);
@@ -4289,7 +4293,10 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 	const size_t o_tbl = carve(buckets ? (size_t)2 * n * bpw * 4 : (size_t)2 * n * itemw * 4);
 	const size_t o_rec = carve(buckets ? bcounters * recw * 4 : (size_t)L * recw * 4);
 	const size_t o_tmp = carve(buckets ? bred_words * 4 : ((size_t)L / 16 + 2) * recw * 4);
-	const size_t o_cnt = carve(buckets ? 4 * bcounters * 4 : 0), o_ord = carve(buckets ? (size_t)bnwin * 2 * n * 4 : 0);
+	// fixed-capacity filing unless $ECAMD_BKT_EXACT_SORT: 32 + 2 lambda slots per bucket, lambda = 2n / 2^16 the mean of the fullest windows
+	const uint32_t bcap = getenv("ECAMD_BKT_EXACT_SORT") ? 0u : 32u + 2u * (uint32_t)(((size_t)2 * n + 65535) >> 16);
+	const size_t o_cnt = carve(buckets ? 4 * bcounters * 4 : 0);
+	const size_t o_ord = carve(buckets ? (bcap ? bcounters * bcap * 4 : (size_t)bnwin * 2 * n * 4) : 0);
 	const size_t o_w = carve((size_t)n * ql), o_z = carve((size_t)n * 16), o_v = carve((size_t)n * qnw * 4);
 	const size_t o_v1 = carve(((size_t)n / 64 + 2) * qnw * 4), o_v2 = carve(((size_t)n / 4096 + 2) * qnw * 4);
 	const size_t o_c = carve(ql), o_gen = carve(2 * cl), o_gst = carve(4), o_word = carve(4);
@@ -4313,8 +4320,16 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 		P.r_fmt = (uint32_t)r_fmt;
 		HIPCHK(hipEventRecord(ctx->side_fork, s));
 		HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+		// the keys first (an on-curve check each): the windows above z_i's 128 bits hold keys only and can be added up while the
+		// commitments are still being lifted (a square root each)
+		P.pt_first = 0;
+		P.pt_count = n;
 		HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 10, P, nullptr, nullptr, nullptr, nullptr, nullptr, ctx->side_stream));
-		points_beside = true;   // (side_done is recorded further down, behind [c]G)
+		HIPCHK(hipEventRecord(ctx->side_mid, ctx->side_stream));
+		P.pt_first = n;
+		HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 10, P, nullptr, nullptr, nullptr, nullptr, nullptr, ctx->side_stream));
+		HIPCHK(hipEventRecord(ctx->side_done, ctx->side_stream));
+		points_beside = true;
 	}
 	EcamdMsmScalArgs C;
 	memset(&C, 0, sizeof(C));
@@ -4369,7 +4384,7 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 		return -1;
 	}
 	if (points_beside) {
-		HIPCHK(hipEventRecord(ctx->side_done, ctx->side_stream));
+		HIPCHK(hipEventRecord(ctx->side_aux, ctx->side_stream));
 	}
 	EcamdMsmArgs A;
 	memset(&A, 0, sizeof(A));
@@ -4407,6 +4422,8 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 		B.cursor = cnt + 2 * bcounters;
 		B.perm = getenv("ECAMD_NO_BKT_RANK") ? nullptr : cnt + 3 * bcounters;
 		A.perm = B.perm;
+		B.cap = A.cap = bcap;
+		B.flag = (uint32_t *)(M + o_word);
 		B.order = (uint32_t *)(M + o_ord);
 		B.n = n;
 		B.wlen = (uint32_t)ql;
@@ -4415,20 +4432,39 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 		B.nwin = bnwin;
 		B.nwinZ = bnwinZ < bnwin ? bnwinZ : bnwin;
 		HIPCHK(ecamd_launch_bkt_sort(B, s));
-		if (points_beside) {
+		uint32_t *d_total = (uint32_t *)(M + o_tmp) + bred_words - recw;
+		if (!points_beside) {
+			HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 10, A, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+		}
+		if (ctx->timing) {   // the dominant kernel: k_bkt_accum_g, both launches (ecamd_ctx_dominant_kernel_ms)
+			HIPCHK(hipEventRecord(ctx->ev_dom[0], s));
+		}
+		if (points_beside && B.nwinZ < bnwin) {
+			// the windows that hold keys only, as soon as the keys are in; then the rest once the commitments are
+			HIPCHK(hipStreamWaitEvent(s, ctx->side_mid, 0));
+			A.win_first = B.nwinZ;
+			A.win_count = bnwin - B.nwinZ;
+			HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 11, A, nullptr, nullptr, nullptr, nullptr, nullptr, s));
 			HIPCHK(hipStreamWaitEvent(s, ctx->side_done, 0));
-		}
-		for (int phase = points_beside ? 11 : 10; phase <= 12; phase++) {
-			const bool timed = ctx->timing && phase == 11;   // the dominant kernel: k_bkt_accum_g
-			if (timed) {
-				HIPCHK(hipEventRecord(ctx->ev_dom[0], s));
+			A.win_first = 0;
+			A.win_count = B.nwinZ;
+			HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 11, A, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+			A.win_count = 0;
+		} else {
+			if (points_beside) {
+				HIPCHK(hipStreamWaitEvent(s, ctx->side_done, 0));
 			}
-			HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, phase, A, nullptr, M + o_gen, M + o_gst, d_verdict, d_sum_dump, s));
-			if (timed) {
-				HIPCHK(hipEventRecord(ctx->ev_dom[1], s));
-				ctx->ev_dom_valid = true;
-			}
+			HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 11, A, nullptr, nullptr, nullptr, nullptr, nullptr, s));
 		}
+		if (ctx->timing) {
+			HIPCHK(hipEventRecord(ctx->ev_dom[1], s));
+			ctx->ev_dom_valid = true;
+		}
+		HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 12, A, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+		if (points_beside) {
+			HIPCHK(hipStreamWaitEvent(s, ctx->side_aux, 0));   // [c]G
+		}
+		HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 13, A, d_total, M + o_gen, M + o_gst, d_verdict, d_sum_dump, s));
 		return 0;
 	}
 	for (int phase = 0; phase < 3; phase++) {

@@ -282,6 +282,9 @@ struct EcamdMsmArgs {
 	uint32_t *red;               // scratch of the reduction, red_words words
 	uint64_t red_words;
 	uint32_t c, nwin;            // window bits (11 .. 16), windows of the full-length scalars
+	uint32_t cap;                // != 0: bucket t's list is order[t cap .. t cap + min(bcount[t], cap))
+	uint32_t pt_first, pt_count; // phase 10: the point indices [pt_first, pt_first + pt_count) of the 2n (count 0: all of them)
+	uint32_t win_first, win_count;   // phase 11: the windows [win_first, win_first + win_count) (count 0: all of them)
 };
 uint32_t ecamd_g29_bkt_point_words(int pbits, int flavour);
 // the counting sort of the (window, digit, point) triples (ecamd_kernels.hip); point index i < n: Y_i with scalar scW[i], n + i: R_i with scZ[i]
@@ -290,6 +293,8 @@ struct EcamdBktSortArgs {
 	uint32_t *hist, *start, *cursor;   // nwin << c counters each (hist and cursor zeroed by the launcher)
 	uint32_t *order;             // nwin x 2n
 	uint32_t *perm;              // nwin << c: the buckets, every 4096 of them ranked by size (k_bkt_rank); may be NULL
+	uint32_t *flag;              // |= 16 when a bucket overflows its `cap` slots
+	uint32_t cap;                // != 0: fixed-capacity filing -- order is (nwin << c) x cap, hist counts, no scan (k_bkt_file)
 	uint32_t n, wlen, zlen, c, nwin, nwinZ;
 };
 hipError_t ecamd_launch_bkt_sort(const EcamdBktSortArgs &a, hipStream_t s);

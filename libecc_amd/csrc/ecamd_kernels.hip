@@ -2212,6 +2212,30 @@ __global__ __launch_bounds__(256) void k_bkt_scatter(EcamdBktSortArgs A)
 		A.order[(size_t)win * 2u * A.n + pos] = pt;
 	}
 }
+// Fixed-capacity filing (the default): the digits of z_i (q - e_i) and of z_i are uniform whatever the batch holds -- z_i is 128 bits of a
+// keyed stream --, so bucket sizes are Poisson with mean lambda = pairs / 2^c, and a bucket of `cap` = 32 + 2 lambda slots overflows with
+// a probability below 10^-18 per batch: point indices go straight to slot[bucket][cursor++], without the histogram and the scan of a
+// counting sort (a millisecond per 2^20 items).  An overflow is reported (*flag |= 16: "not decided here"), never dropped silently.
+__global__ __launch_bounds__(256) void k_bkt_file(EcamdBktSortArgs A)
+{
+	const u32 win = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+	const u32 cnt = (win < A.nwinZ) ? 2u * A.n : A.n;
+	if (j >= cnt) {
+		return;
+	}
+	u32 pt;
+	const u32 d = bkt_pair_digit(A, win, j, pt);
+	if (d) {
+		const size_t b = ((size_t)win << A.c) + d;
+		const u32 pos = atomicAdd(&A.hist[b], 1u);
+		if (pos < A.cap) {
+			A.order[b * A.cap + pos] = pt;
+		} else {
+			atomicOr(A.flag, 16u);
+		}
+	}
+}
+
 // Buckets of one size side by side: a lane of k_bkt_accum_g walks its bucket's list, so a wave takes as long as its LONGEST bucket
 // (sizes are Poisson: 46 against a mean of 32 over 64 lanes).  Every block ranks 4096 consecutive buckets by size (a counting sort in
 // LDS: sizes capped at 255) and writes the permutation; lane t of the accumulation then serves bucket perm[t], and the 64 lanes of a
@@ -2256,16 +2280,20 @@ hipError_t ecamd_launch_bkt_sort(const EcamdBktSortArgs &a, hipStream_t s)
 	}
 	const size_t counters = (size_t)a.nwin << a.c;
 	hipError_t e = hipMemsetAsync(a.hist, 0, counters * 4, s);
-	if (e == hipSuccess) {
+	if (e == hipSuccess && !a.cap) {
 		e = hipMemsetAsync(a.cursor, 0, counters * 4, s);
 	}
 	if (e != hipSuccess) {
 		return e;
 	}
 	const dim3 gp((2 * a.n + 255) / 256, a.nwin);
-	hipLaunchKernelGGL(k_bkt_hist, gp, dim3(256), 0, s, a);
-	hipLaunchKernelGGL(k_bkt_scan, dim3(a.nwin), dim3(256), 0, s, a);
-	hipLaunchKernelGGL(k_bkt_scatter, gp, dim3(256), 0, s, a);
+	if (a.cap) {
+		hipLaunchKernelGGL(k_bkt_file, gp, dim3(256), 0, s, a);
+	} else {
+		hipLaunchKernelGGL(k_bkt_hist, gp, dim3(256), 0, s, a);
+		hipLaunchKernelGGL(k_bkt_scan, dim3(a.nwin), dim3(256), 0, s, a);
+		hipLaunchKernelGGL(k_bkt_scatter, gp, dim3(256), 0, s, a);
+	}
 	if (a.perm) {
 		hipLaunchKernelGGL(k_bkt_rank, dim3((unsigned)((counters + 4095) / 4096)), dim3(256), 0, s, (const u32 *)a.hist, a.perm, (u32)counters);
 	}
