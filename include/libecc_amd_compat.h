@@ -29,7 +29,12 @@ extern "C" {
  * Secret scalars: the contexts run in secret-scalar mode (ecamd_ctx_set_secret_scalars in libecc_amd.h: constant-address table
  * look-ups for private keys, nonces and blinded scalars, as libecc's masked ladder; verification is not affected) unless
  * $ECAMD_COMPAT_PUBLIC_SCALARS is set; ecamd_compat_set_secret_scalars changes it at run time.  The batch calls that handle
- * private material wipe their host staging and the devices' scratch before they return. */
+ * private material wipe their host staging and the devices' scratch before they return.
+ * Threads (round 6): like libecc, the batch entry points may be entered from several application threads.  ECDSA / DECDSA and EdDSA
+ * verification (ec_verify_batch, ec_verify_batch_results and their per-algorithm forms) run up to two calls at a time -- each in its own
+ * page-locked staging, the pool packing and unpacking for both, their GPU calls one after the other; a third caller waits.  Every other
+ * entry point -- the secret-key half, the key and point forms, BIP0340 / ECFSDSA -- runs one call at a time (and not beside a
+ * verification): those switch the devices between secret- and public-scalar mode, wipe scratch, or make dependent GPU calls. */
 int ecamd_compat_init(const int *devices, int ndev, int host_threads);
 void ecamd_compat_shutdown(void);
 int ecamd_compat_set_secret_scalars(int on);
@@ -214,7 +219,12 @@ int eddsa_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **pub
  * (sig/bip0340.c:1296) behind ec_verify_batch.  Every signature is verified on the GPU(s) -- the key's unique representative
  * with an even y, [s]G + [q - e]Y, the parity and x = r tests -- and the answer is the exact conjunction (the reference's random
  * linear combination has the same answer up to its 2^-128 error); tagged hashes on the host threads.
- * The same entry point serves ECFSDSA (sig/ecfsdsa.c:470-640 per item, ecfsdsa_verify_batch at sig/ecfsdsa.c:1042): signature
+ * Round 6: batches of at least 2^17 items per device ($ECAMD_COMPAT_SCHNORR_MSM_MIN) on a prime-order curve whose hash the device has
+ * (SHA-224 .. SHA-512, hash inputs up to 252 octets) are first offered to the device as ONE streamed call -- keys, signatures and the
+ * tagged-hash inputs travel as ec_verify_init finds them, the device imports the keys, hashes, reduces, lifts and evaluates the
+ * reference's batch equation (include/libecc_amd.h: ec_schnorr_verify_msg_all_batch); it vouches for VALID batches only, so anything
+ * else -- a bad signature, a key at infinity, an item that fails a length or range check -- is decided by the item-by-item path above.
+ * The same entry point serves ECFSDSA (sig/ecfsdsa.c:470-640 per item, ecfsdsa_verify_batch at sig/ecfsdsa.c:1057): signature
  * (r = Wx || Wy, s), e = H(r || m) mod q, accept when [s]G + [q - e]Y is the finite point whose affine coordinates are the bytes
  * of r (both compared on the host after one batched unique-representative pass).
  */
