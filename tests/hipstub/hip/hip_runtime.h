@@ -26,3 +26,4 @@ extern thread_local dim3 blockIdx, threadIdx;
 			}                                                          \
 		}                                                                  \
 	} while (0)
+static inline uint32_t atomicOr(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o | v; return o; }   // lanes run one after the other here

@@ -1336,7 +1336,7 @@ def test_host_pipeline_multi_chunk(gpu_ctx):
     rng = np.random.default_rng(38)
     old = {k: os.environ.get(k) for k in ("ECAMD_HOST_CHUNK", "ECAMD_HOST_RAMP_MIN")}
     os.environ["ECAMD_HOST_CHUNK"] = "700"
-    os.environ["ECAMD_HOST_RAMP_MIN"] = "100"    # the short first chunk of a multi-chunk call: 100, then 700, 700, 700, 23 items
+    os.environ["ECAMD_HOST_RAMP_MIN"] = "100"    # the doubling start of a multi-chunk call (round 6): 100, 200, 400, then 700, and the last 823 as one
     try:
         ctx2 = libecc_amd.Context(0)
     finally:
@@ -1356,7 +1356,7 @@ def test_host_pipeline_multi_chunk(gpu_ctx):
         finally:
             hk.free()
             ctx2.set_host_ready_hook(None)
-        assert asked == [(0, 100), (100, 700), (800, 700), (1500, 700), (2200, 23)], asked
+        assert asked == [(0, 100), (100, 200), (300, 400), (700, 700), (1400, 823)], asked
         a, b = gpu_ctx.curve("SECP256R1"), ctx2.curve("SECP256R1")
         try:
             sc = rand_bytes(rng, 32 * n)

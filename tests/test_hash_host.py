@@ -59,3 +59,38 @@ def test_shake256_slots_match_hashlib(lib):
         assert lib.shake256_slots_host(slots_of(msgs, stride), stride, len(msgs), out, outlen, outlen) == 0
         for i, m in enumerate(msgs):
             assert out.raw[outlen * i:outlen * (i + 1)] == hashlib.shake_256(m).digest(outlen), (outlen, len(m))
+
+
+@pytest.mark.parametrize("cl,ql,rl_is_x", [(32, 32, True), (32, 32, False), (48, 48, False), (28, 29, True)])
+def test_schnorr_prep_moves_the_bytes(lib, cl, ql, rl_is_x):
+    """k_schnorr_prep (round 6), lane by lane on the CPU: the key's x into the blank of the hash input, the key's even-y representative
+    (y <- p - y when y is odd, BIP0340's lift_x), s and the commitment split off the signature, the flag for a key that did not import"""
+    rng = np.random.default_rng(90 + cl)
+    n, rl = 37, (cl if rl_is_x else 2 * cl)
+    p = (1 << (8 * cl)) - 189 if cl != 28 else (1 << 224) - 6803
+    p |= 1
+    keys = bytearray()
+    for i in range(n):
+        x = int.from_bytes(rng.integers(0, 256, size=cl, dtype=np.uint8).tobytes(), "big") % p
+        y = int.from_bytes(rng.integers(0, 256, size=cl, dtype=np.uint8).tobytes(), "big") % p
+        keys += x.to_bytes(cl, "big") + y.to_bytes(cl, "big")
+    sigs = rng.integers(0, 256, size=n * (rl + ql), dtype=np.uint8).tobytes()
+    stride, xo = 160, 70
+    slots0 = rng.integers(0, 256, size=n * stride, dtype=np.uint8).tobytes()
+    for even_y, use_xoff, kst in ((1, True, None), (0, False, bytes(n)), (1, True, bytes([0] * 5 + [2] + [0] * (n - 6)))):
+        slots = C.create_string_buffer(slots0, n * stride)
+        ko, so, ro = C.create_string_buffer(2 * cl * n), C.create_string_buffer(ql * n), C.create_string_buffer(rl * n)
+        flag = C.c_uint32(0)
+        assert lib.schnorr_prep_host(bytes(keys), kst, sigs, slots, ko, so, ro, C.byref(flag), n, cl, ql, rl, stride,
+                                     xo if use_xoff else 0xffffffff, even_y, p.to_bytes(cl, "big")) == 0
+        assert flag.value == (1 if kst and any(kst) else 0)
+        for i in range(n):
+            kx, ky = keys[2 * cl * i:2 * cl * i + cl], keys[2 * cl * i + cl:2 * cl * (i + 1)]
+            want_y = (p - int.from_bytes(ky, "big")).to_bytes(cl, "big") if (even_y and ky[-1] & 1) else bytes(ky)
+            assert ko.raw[2 * cl * i:2 * cl * (i + 1)] == bytes(kx) + want_y
+            assert ro.raw[rl * i:rl * (i + 1)] == sigs[(rl + ql) * i:(rl + ql) * i + rl]
+            assert so.raw[ql * i:ql * (i + 1)] == sigs[(rl + ql) * i + rl:(rl + ql) * (i + 1)]
+            want = bytearray(slots0[stride * i:stride * (i + 1)])
+            if use_xoff:
+                want[4 + xo:4 + xo + cl] = kx
+            assert slots.raw[stride * i:stride * (i + 1)] == bytes(want)
