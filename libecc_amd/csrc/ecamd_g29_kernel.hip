@@ -897,8 +897,9 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_bkt_
 	u32 cnt = b ? A.bcount[t] : 0u;
 	const u32 *ord;
 	if (A.cap) {
-		cnt = cnt < A.cap ? cnt : A.cap;
-		ord = A.order + (size_t)t * A.cap;
+		u32 capb;
+		ord = A.order + ecamd_bkt_slot(t, A.cap, A.cap_top, A.top_win, &capb);
+		cnt = cnt < capb ? cnt : capb;
 	} else {
 		ord = A.order + (size_t)win * 2u * A.n + A.bstart[t];
 	}
@@ -3083,6 +3084,228 @@ hipError_t ecamd_launch_edmsm_reduce(const EcamdEdMsmArgs &a, uint32_t *tmp, con
 		count = T;
 	}
 	hipLaunchKernelGGL(k_edmsm_final, dim3(1), dim3(64), 0, s, a, in, count, flagword, verdict, sum_out, gslot);
+	return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 6: the Ed25519 batch equation by buckets (EcamdEdBktArgs; the Schnorr-type form of the same idea: k_bkt_* above).  The unified
+// Edwards addition is complete, so there is nothing to flag and nothing to compare: equal points double, opposite ones give the
+// neutral element, which is an ordinary point.
+//   k_edbkt_points  per item: A_i and R_i decoded (the reference's rejections as in k_edmsm_prep), as affine precomputed entries
+//                   (y - x, y + x, 2d x y); the first LB lanes also write the LB copies of B
+//   k_edbkt_accum   one lane per bucket: 7M per point (ed_madd)
+//   k_edbkt_reduce  levels of 16 by running sums, the U-sums carried along (see k_bkt_reduce_g)
+//   k_edbkt_window  per window C_0 + 16 (C_1 + ...), times 2^(16 win); k_edmsm_final adds the sixteen windows, clears the cofactor, decides
+// ------------------------------------------------------------------------------------------
+static __device__ __forceinline__ void edb_store(u32 *dst, const c25519::PreA &Q)
+{
+	u32 buf[ECAMD_EDB_PT_WORDS];
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		buf[w] = Q.ymx.l[w];
+		buf[9 + w] = Q.ypx.l[w];
+		buf[18 + w] = Q.t2d.l[w];
+	}
+	buf[27] = 0;
+	uint4 *d = (uint4 *)dst;
+#pragma unroll
+	for (int q = 0; q < ECAMD_EDB_PT_WORDS / 4; q++) {
+		d[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
+	}
+}
+__global__ __launch_bounds__(64) void k_edbkt_points(EcamdEdMsmArgs A, EcamdEdBktArgs B, int gslot)
+{
+	using namespace c25519;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= A.n) {
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const FC d2 = digits9(A.g_2d);
+	if (i < B.LB) {
+		const FM ym = weaken<FM>(mul(digits9(A.g_By), constant<FC>(K.one), K));
+		edb_store(B.pts + (size_t)(A.n + i) * ECAMD_EDB_PT_WORDS, ed_prea(digits9(A.g_Bx), ym, d2, K));
+	}
+	EcamdEdDecodeArgs D;   // decode_xy reads the two constants only
+#pragma unroll
+	for (int w = 0; w < 9; w++) {
+		D.g_d[w] = A.g_d[w];
+		D.g_sm1[w] = A.g_sm1[w];
+	}
+	u8 flag = 0;
+#pragma unroll 1
+	for (int k = 0; k < 2; k++) {
+		const DecXY P = decode_xy(D, k == 0 ? A.encA + (size_t)i * A.strideA : A.encR + (size_t)i * A.strideR, K);
+		// R = (0, 1) is accepted by the reference (it becomes the point at infinity of the Weierstrass model)
+		bool good = P.ok | (k == 1 && P.neutral);
+		Ext P1 = ed_neutral(K);
+		if (P.ok) {
+			P1 = ed_from_affine(P.x, P.ym, K);
+		}
+		if (k == 0 && good) {
+			// the reference rejects a key with [cofactor]A = infinity (sig/eddsa.c:2463-2472)
+			Ext Q = P1;
+			for (u32 r = 0; r < A.cof_dbl; r++) {
+				Q = ed_dbl<false>(Q, K);
+			}
+			good = !is_zero_mulout(Q.X, K);
+			if (!good) {
+				P1 = ed_neutral(K);
+			}
+		}
+		// P1 is affine (Z = 1): its precomputed entry straight from X and Y
+		const u32 idx = k == 0 ? i : A.n + B.LB + i;
+		edb_store(B.pts + (size_t)idx * ECAMD_EDB_PT_WORDS, ed_prea(P1.X, P1.Y, d2, K));
+		flag |= good ? 0 : 1;
+	}
+	A.flags[i] = flag;
+}
+
+__global__ __launch_bounds__(64) void k_edbkt_accum(EcamdEdBktArgs B, int gslot)
+{
+	using namespace c25519;
+	const u32 lane = blockIdx.x * 64 + threadIdx.x;
+	if (lane >= (16u << 16)) {
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const u32 t = B.perm[lane];
+	u32 cnt = (t & 0xffffu) ? B.count[t] : 0u, capb;
+	const u32 *ord = B.order + ecamd_bkt_slot(t, B.cap, B.cap_top, 15u, &capb);
+	cnt = cnt < capb ? cnt : capb;
+	Ext acc = ed_neutral(K);
+	PreA nxt;
+	u32 nidx = 0;
+	if (cnt) {
+		nxt = prea_load(B.pts + (size_t)ord[0] * ECAMD_EDB_PT_WORDS);
+		nidx = cnt > 1 ? ord[1] : 0u;
+	}
+#pragma unroll 1
+	for (u32 k = 0; k < cnt; k++) {
+		const PreA cur = nxt;
+		if (k + 1 < cnt) {
+			nxt = prea_load(B.pts + (size_t)nidx * ECAMD_EDB_PT_WORDS);   // on its way while the current addition runs
+			nidx = k + 2 < cnt ? ord[k + 2] : 0u;
+		}
+		acc = ed_madd<true>(acc, cur, false, K);
+	}
+	ext_store(B.bsum + (size_t)t * ECAMD_EDM_REC_WORDS, acc);
+}
+
+struct EdBktLevel {
+	const u32 *inT;
+	const u32 *inC[BKT_MAXCARRY];
+	u32 *outT, *outU;
+	u32 *outC[BKT_MAXCARRY];
+	u32 Lin, Lout, ncarry;
+};
+__global__ __launch_bounds__(64) void k_edbkt_reduce(EcamdEdMsmArgs A, EdBktLevel V, int gslot)
+{
+	using namespace c25519;
+	const u32 t = blockIdx.x * 64 + threadIdx.x;
+	if (t >= 16u * V.Lout) {
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const FC d2 = digits9(A.g_2d);
+	const u32 win = t / V.Lout, j = t - win * V.Lout;
+	const u32 first = j * BKT_FOLD, len = (V.Lin - first) < BKT_FOLD ? (V.Lin - first) : BKT_FOLD;
+	const u32 role = blockIdx.y;
+	const u32 *in = (role == 0 ? V.inT : V.inC[role - 1]) + ((size_t)win * V.Lin + first) * ECAMD_EDM_REC_WORDS;
+	Ext run = ed_neutral(K), acc = run;
+	if (role == 0) {
+#pragma unroll 1
+		for (u32 r = len; r-- > 1;) {
+			run = ed_add(run, ed_pre(ext_load(in + (size_t)r * ECAMD_EDM_REC_WORDS), d2, K), false, K);
+			acc = ed_add(acc, ed_pre(run, d2, K), false, K);
+		}
+		run = ed_add(run, ed_pre(ext_load(in), d2, K), false, K);
+		ext_store(V.outT + (size_t)t * ECAMD_EDM_REC_WORDS, run);
+		ext_store(V.outU + (size_t)t * ECAMD_EDM_REC_WORDS, acc);
+	} else {
+#pragma unroll 1
+		for (u32 r = 0; r < len; r++) {
+			run = ed_add(run, ed_pre(ext_load(in + (size_t)r * ECAMD_EDM_REC_WORDS), d2, K), false, K);
+		}
+		ext_store(V.outC[role - 1] + (size_t)t * ECAMD_EDM_REC_WORDS, run);
+	}
+}
+struct EdBktWindows {
+	const u32 *U;
+	const u32 *C[BKT_MAXCARRY];
+	u32 *out;
+	u32 ncarry;
+};
+__global__ __launch_bounds__(64) void k_edbkt_window(EcamdEdMsmArgs A, EdBktWindows V, int gslot)
+{
+	using namespace c25519;
+	const u32 win = blockIdx.x * 64 + threadIdx.x;
+	if (win >= 16u) {
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const FC d2 = digits9(A.g_2d);
+	Ext acc = ext_load(V.U + (size_t)win * ECAMD_EDM_REC_WORDS);
+#pragma unroll 1
+	for (u32 k = V.ncarry; k-- > 0;) {
+#pragma unroll 1
+		for (int d = 0; d < 4; d++) {
+			acc = ed_dbl<true>(acc, K);
+		}
+		acc = ed_add(acc, ed_pre(ext_load(V.C[k] + (size_t)win * ECAMD_EDM_REC_WORDS), d2, K), false, K);
+	}
+#pragma unroll 1
+	for (u32 d = 0; d < 16u * win; d++) {
+		acc = ed_dbl<true>(acc, K);
+	}
+	ext_store(V.out + (size_t)win * ECAMD_EDM_REC_WORDS, acc);
+}
+hipError_t ecamd_launch_edbkt(const EcamdEdMsmArgs &a, const EcamdEdBktArgs &b, int phase, const uint32_t *flagword, uint8_t *verdict, uint32_t *sum_out,
+			      int gslot, hipStream_t s)
+{
+	constexpr size_t RECW = ECAMD_EDM_REC_WORDS;
+	if (phase == 0) {
+		hipLaunchKernelGGL(k_edbkt_points, dim3((a.n + 63) / 64), dim3(64), 0, s, a, b, gslot);
+	} else if (phase == 1) {
+		hipLaunchKernelGGL(k_edbkt_accum, dim3((16u << 16) / 64), dim3(64), 0, s, b, gslot);
+	} else {
+		EdBktLevel V = {};
+		V.inT = b.bsum;
+		V.Lin = 1u << 16;
+		uint32_t *half[2] = {b.red, b.red + (size_t)b.red_words / 2};
+		int hsel = 0;
+		while (V.Lin > 1) {
+			V.Lout = (V.Lin + BKT_FOLD - 1) / BKT_FOLD;
+			uint32_t *o = half[hsel];
+			const size_t arr = (size_t)16 * V.Lout * RECW;
+			if ((2 + (size_t)V.ncarry) * arr > (size_t)b.red_words / 2 || V.ncarry + 1 > BKT_MAXCARRY) {
+				return hipErrorInvalidValue;
+			}
+			V.outT = o;
+			V.outU = o + arr;
+			for (uint32_t k = 0; k < V.ncarry; k++) {
+				V.outC[k] = o + (2 + (size_t)k) * arr;
+			}
+			hipLaunchKernelGGL(k_edbkt_reduce, dim3((16 * V.Lout + 63) / 64, 1 + V.ncarry), dim3(64), 0, s, a, V, gslot);
+			V.inT = V.outT;
+			for (uint32_t k = 0; k < V.ncarry; k++) {
+				V.inC[k] = V.outC[k];
+			}
+			V.inC[V.ncarry] = V.outU;
+			V.ncarry++;
+			V.Lin = V.Lout;
+			hsel ^= 1;
+		}
+		EdBktWindows W = {};
+		W.U = V.inC[V.ncarry - 1];
+		W.ncarry = V.ncarry - 1;
+		for (uint32_t k = 0; k + 1 < V.ncarry; k++) {
+			W.C[k] = V.inC[k];
+		}
+		W.out = half[hsel];
+		hipLaunchKernelGGL(k_edbkt_window, dim3(1), dim3(64), 0, s, a, W, gslot);
+		hipLaunchKernelGGL(k_edmsm_final, dim3(1), dim3(64), 0, s, a, (const uint32_t *)W.out, 16u, flagword, verdict, sum_out, gslot);
+	}
 	return hipGetLastError();
 }
 

@@ -4047,10 +4047,135 @@ static uint32_t eddsa_msm_pick_k(const ecamd_ctx *ctx, uint32_t n)
 	return k > 8 ? 8 : k;
 }
 
+// Round 6: the Ed25519 combination by buckets (k_edbkt_*; the Schnorr-type form: schnorr_msm_dev_locked) from 2^18 items on --
+// $ECAMD_ED_MSM_ALGO=straus|bucket overrides the size rule.  The base point's term [q - sum z_i S_i]B enters as one copy of B per 64
+// items with that group's share of the scalar: no global sum, no separate multiplication.
+static int eddsa_bkt_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig, const uint8_t *d_hram,
+				const uint8_t seed[32], uint32_t piece, uint8_t *d_verdict, uint8_t *d_z_dump, uint32_t *d_sum_dump, hipStream_t s)
+{
+	const uint32_t LB = (n + 63) / 64;
+	const size_t counters = (size_t)16 << 16, recw = ECAMD_EDM_REC_WORDS;
+	const uint32_t cap = 32u + 2u * (uint32_t)(((size_t)2 * n + LB + 65535) >> 16);
+	// window 15: z_i h_i mod q < q = 2^252 + ..., so its digits take 4 097 values only and the n + LB scalars of that window crowd into as many buckets
+	const uint32_t cap_top = 32u + 2u * (uint32_t)(((size_t)n + LB + 4096) / 4097);
+	const size_t red_words = 2 * (2 * (size_t)16 * 4096 * recw + 18 * recw);
+	size_t off = 0;
+	auto carve = [&](size_t bytes) {
+		const size_t o = off;
+		off += msm_align(bytes);
+		return o;
+	};
+	const size_t o_pts = carve(((size_t)2 * n + LB) * ECAMD_EDB_PT_WORDS * 4);
+	const size_t o_cA = carve((size_t)n * 32), o_zR = carve((size_t)n * 20), o_zs = carve((size_t)n * 32);
+	const size_t o_rawC = carve((size_t)n * 32), o_rawZ = carve((size_t)n * 16), o_rawB = carve((size_t)LB * 32), o_sB = carve((size_t)LB * 32);
+	const size_t o_flags = carve(n), o_flagsS = carve(n);
+	const size_t o_cnt = carve(2 * counters * 4), o_ord = carve(((size_t)15 << 16) * cap * 4 + ((size_t)1 << 16) * cap_top * 4);
+	const size_t o_bsum = carve(counters * recw * 4), o_red = carve(red_words * 4);
+	const size_t o_word = carve(4);
+	if (ensure(&ctx->msm, &ctx->msm_bytes, off)) {
+		return -1;
+	}
+	uint8_t *M = ctx->msm;
+	HIPCHK(hipMemsetAsync(M + o_word, 0, 4, s));
+	EcamdEdMsmArgs A;
+	memset(&A, 0, sizeof(A));
+	A.encA = d_pub;
+	A.strideA = 32;
+	A.encR = d_sig;
+	A.strideR = 64;
+	A.flags = M + o_flags;
+	A.n = n;
+	A.cof_dbl = cv->ed_cof_dbl;
+	memcpy(A.g_d, cv->ed_tmpl.g_d, sizeof(A.g_d));
+	memcpy(A.g_sm1, cv->ed_tmpl.g_sm1, sizeof(A.g_sm1));
+	memcpy(A.g_2d, cv->ed_2d, sizeof(A.g_2d));
+	memcpy(A.g_Bx, cv->ed_Bx, sizeof(A.g_Bx));
+	memcpy(A.g_By, cv->ed_By, sizeof(A.g_By));
+	EcamdEdBktArgs B;
+	memset(&B, 0, sizeof(B));
+	B.rawC = (const uint32_t *)(M + o_rawC);
+	B.rawB = (const uint32_t *)(M + o_rawB);
+	B.rawZ = (const uint32_t *)(M + o_rawZ);
+	B.pts = (uint32_t *)(M + o_pts);
+	B.count = (uint32_t *)(M + o_cnt);
+	B.perm = B.count + counters;
+	B.order = (uint32_t *)(M + o_ord);
+	B.bsum = (uint32_t *)(M + o_bsum);
+	B.red = (uint32_t *)(M + o_red);
+	B.red_words = red_words;
+	B.flagword = (uint32_t *)(M + o_word);
+	B.n = n;
+	B.LB = LB;
+	B.cap = cap;
+	B.cap_top = cap_top;
+	// the decoding (two square roots per item: VALU work on the caller's arrays alone) on the side stream, beside the scalars and the filing
+	const bool beside = ctx->side_ok && getenv("ECAMD_NO_BKT_BESIDE") == nullptr;
+	hipStream_t ps = s;
+	if (beside) {
+		HIPCHK(hipEventRecord(ctx->side_fork, s));
+		HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+		ps = ctx->side_stream;
+	}
+	HIPCHK(ecamd_launch_edbkt(A, B, 0, nullptr, nullptr, nullptr, cv->gslot, ps));
+	if (beside) {
+		HIPCHK(hipEventRecord(ctx->side_done, ctx->side_stream));
+	}
+	EcamdEdMsmScalArgs C;
+	memset(&C, 0, sizeof(C));
+	C.sigs = d_sig;
+	C.hram = d_hram;
+	C.cA = (uint32_t *)(M + o_cA);
+	C.zR = (uint32_t *)(M + o_zR);
+	C.zs = (uint32_t *)(M + o_zs);
+	C.rawC = (uint32_t *)(M + o_rawC);
+	C.rawZ = (uint32_t *)(M + o_rawZ);
+	C.flagsS = M + o_flagsS;
+	C.z_dump = d_z_dump;
+	memcpy(C.seed, seed, 32);
+	C.nonce[0] = piece;
+	C.n = n;
+	C.qslot = cv->qslot;
+	HIPCHK(ecamd_launch_edmsm_scal(C, s));
+	if (beside) {
+		HIPCHK(hipStreamWaitEvent(s, ctx->side_done, 0));   // (the lane kernel reads the decoding's flags)
+	}
+	EcamdEdMsmLaneArgs N;
+	memset(&N, 0, sizeof(N));
+	N.zs = (const uint32_t *)(M + o_zs);
+	N.flags = M + o_flags;
+	N.flagsS = M + o_flagsS;
+	N.sB = (uint32_t *)(M + o_sB);
+	N.rawB = (uint32_t *)(M + o_rawB);
+	N.flagword = (uint32_t *)(M + o_word);
+	N.n = n;
+	N.K = 64;
+	N.L = LB;
+	N.qslot = cv->qslot;
+	HIPCHK(ecamd_launch_edmsm_lane(N, s));
+	HIPCHK(ecamd_launch_edbkt_file(B, s));
+	if (ctx->timing) {
+		HIPCHK(hipEventRecord(ctx->ev_dom[0], s));   // the dominant kernel: k_edbkt_accum (ecamd_ctx_dominant_kernel_ms)
+	}
+	HIPCHK(ecamd_launch_edbkt(A, B, 1, nullptr, nullptr, nullptr, cv->gslot, s));
+	if (ctx->timing) {
+		HIPCHK(hipEventRecord(ctx->ev_dom[1], s));
+		ctx->ev_dom_valid = true;
+	}
+	HIPCHK(ecamd_launch_edbkt(A, B, 2, (const uint32_t *)(M + o_word), d_verdict, d_sum_dump, cv->gslot, s));
+	return 0;
+}
+
 static int eddsa_msm_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig,
 				const uint8_t *d_hram, const uint8_t seed[32], uint32_t piece, uint8_t *d_verdict, uint8_t *d_z_dump,
 				uint32_t *d_sum_dump, hipStream_t s)
 {
+	{
+		const char *e = getenv("ECAMD_ED_MSM_ALGO");
+		const bool force_b = e && !strcmp(e, "bucket"), force_s = e && !strcmp(e, "straus");
+		if (force_b || (!force_s && n >= (1u << 18))) {   // measured: 2^17 items 2.18 ms by buckets, 2.06 by Straus; 2^18: 2.80 / 3.22; 2^20: 6.85 / 10.8
+			return eddsa_bkt_dev_locked(ctx, cv, n, d_pub, d_sig, d_hram, seed, piece, d_verdict, d_z_dump, d_sum_dump, s);
+		}
+	}
 	const uint32_t K = eddsa_msm_pick_k(ctx, n);
 	const uint32_t L = (n + K - 1) / K;
 	size_t off = 0;
@@ -4295,8 +4420,19 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 	const size_t o_tmp = carve(buckets ? bred_words * 4 : ((size_t)L / 16 + 2) * recw * 4);
 	// fixed-capacity filing unless $ECAMD_BKT_EXACT_SORT: 32 + 2 lambda slots per bucket, lambda = 2n / 2^16 the mean of the fullest windows
 	const uint32_t bcap = getenv("ECAMD_BKT_EXACT_SORT") ? 0u : 32u + 2u * (uint32_t)(((size_t)2 * n + 65535) >> 16);
+	// ... and the order's TOP window: z_i (q - e_i) < q, so its digits take (q >> 16 top_win) + 1 values only and the n keys crowd into that many
+	// buckets (brainpoolP256r1: 43 516 of 65 536; an order just above a power of 2^16: a few) -- a capacity of its own
+	const uint32_t btop = ((uint32_t)cv->qbits - 1u) / 16u;
+	uint32_t btopvals = 1;
+	{
+		const uint32_t bit = 16u * btop;   // the digit of q itself in that window, + 1
+		const size_t wi = bit / 32u;
+		const uint32_t word = wi < cv->q.size() ? cv->q[wi] : 0u;
+		btopvals = ((word >> (bit % 32u)) & 0xffffu) + 1u;
+	}
+	const uint32_t bcap_top = bcap ? 32u + 2u * (uint32_t)(((size_t)n + btopvals - 1) / btopvals) : 0u;
 	const size_t o_cnt = carve(buckets ? 4 * bcounters * 4 : 0);
-	const size_t o_ord = carve(buckets ? (bcap ? bcounters * bcap * 4 : (size_t)bnwin * 2 * n * 4) : 0);
+	const size_t o_ord = carve(buckets ? (bcap ? ((size_t)btop << 16) * bcap * 4 + ((size_t)(bnwin - btop) << 16) * bcap_top * 4 : (size_t)bnwin * 2 * n * 4) : 0);
 	const size_t o_w = carve((size_t)n * ql), o_z = carve((size_t)n * 16), o_v = carve((size_t)n * qnw * 4);
 	const size_t o_v1 = carve(((size_t)n / 64 + 2) * qnw * 4), o_v2 = carve(((size_t)n / 4096 + 2) * qnw * 4);
 	const size_t o_c = carve(ql), o_gen = carve(2 * cl), o_gst = carve(4), o_word = carve(4);
@@ -4423,6 +4559,8 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 		B.perm = getenv("ECAMD_NO_BKT_RANK") ? nullptr : cnt + 3 * bcounters;
 		A.perm = B.perm;
 		B.cap = A.cap = bcap;
+		B.cap_top = A.cap_top = bcap_top;
+		B.top_win = A.top_win = btop;
 		B.flag = (uint32_t *)(M + o_word);
 		B.order = (uint32_t *)(M + o_ord);
 		B.n = n;

@@ -240,6 +240,7 @@ struct EcamdEdMsmScalArgs {
 	uint32_t *zs;                // n x 8 words: z_i S_i mod q
 	uint8_t *flagsS;             // n: S >= q
 	uint8_t *z_dump;             // may be NULL: n x 16 little-endian z_i (tests)
+	uint32_t *rawC, *rawZ;       // may be NULL (bucket evaluation, round 6): n x 8 / n x 4 little-endian words, z_i h_i mod q and z_i as they are
 	uint32_t seed[8], nonce[3];
 	uint32_t n;
 	int qslot;
@@ -248,10 +249,41 @@ struct EcamdEdMsmLaneArgs {
 	const uint32_t *zs;
 	const uint8_t *flags, *flagsS;
 	uint32_t *sB;
+	uint32_t *rawB;              // may be NULL (bucket evaluation): L x 8 little-endian words, q - sum of the lane's z_i S_i as it is
 	uint32_t *flagword;          // |= 1 when any item of the lane is flagged
 	uint32_t n, K, L;
 	int qslot;
 };
+// The Ed25519 batch equation by buckets (round 6; k_edbkt_* in ecamd_g29_kernel.hip, k_edbkt_file in ecamd_kernels.hip): 16-bit windows over
+// z_i h_i (16 windows), the base point's LB scalars (16 windows: the term [q - sum z_i S_i]B as LB copies of B, one per 64 items) and z_i (8
+// windows).  Point index: A_i = i, the copies of B = n + l, R_i = n + LB + i.  The Edwards addition is complete: no exceptional cases.
+#define ECAMD_EDB_PT_WORDS 28   /* y - x, y + x, 2d x y: 3 x 9 limbs, padded */
+struct EcamdEdBktArgs {
+	const uint32_t *rawC, *rawB, *rawZ;
+	uint32_t *pts;               // (2n + LB) x ECAMD_EDB_PT_WORDS
+	uint32_t *count, *perm;      // 16 << 16 counters (the buckets' sizes) / the ranking of k_bkt_rank
+	uint32_t *order;             // (16 << 16) x cap point indices
+	uint32_t *bsum;              // 16 << 16 records of ECAMD_EDM_REC_WORDS
+	uint32_t *red;               // scratch of the reduction, red_words words
+	uint64_t red_words;
+	uint32_t *flagword;          // |= 16: a bucket overflowed its cap slots
+	uint32_t n, LB, cap, cap_top;   // cap_top: slots of the buckets of window 15 (z h mod q < 2^253: 4 097 digit values only)
+};
+// first slot of bucket b (= window << 16 | digit) and its capacity under the two-capacity layout
+static inline __host__ __device__ size_t ecamd_bkt_slot(uint32_t b, uint32_t cap, uint32_t cap_top, uint32_t top_win, uint32_t *cap_out)
+{
+	const uint32_t tb = top_win << 16;
+	if (b < tb) {
+		*cap_out = cap;
+		return (size_t)b * cap;
+	}
+	*cap_out = cap_top;
+	return (size_t)tb * cap + (size_t)(b - tb) * cap_top;
+}
+hipError_t ecamd_launch_edbkt_file(const EcamdEdBktArgs &b, hipStream_t s);
+// phase 0: the points; 1: the buckets' sums; 2: the reduction, the windows and the verdict (as ecamd_launch_edmsm_reduce)
+hipError_t ecamd_launch_edbkt(const EcamdEdMsmArgs &a, const EcamdEdBktArgs &b, int phase, const uint32_t *flagword, uint8_t *verdict, uint32_t *sum_out,
+			      int gslot, hipStream_t s);
 hipError_t ecamd_launch_edmsm_scal(const EcamdEdMsmScalArgs &a, hipStream_t s);
 // ------------------------------------------------------------------------------------------
 // Schnorr-type whole-batch verification on a short-Weierstrass curve as ONE multi-scalar multiplication (BIP0340's and ECFSDSA's
@@ -283,6 +315,8 @@ struct EcamdMsmArgs {
 	uint64_t red_words;
 	uint32_t c, nwin;            // window bits (11 .. 16), windows of the full-length scalars
 	uint32_t cap;                // != 0: bucket t's list is order[t cap .. t cap + min(bcount[t], cap))
+	uint32_t cap_top, top_win;   // ... except in window top_win, the order's top window, whose digits take (q >> 16 top_win) + 1 values only: its
+	                             //     buckets have cap_top slots, behind the (top_win << c) x cap slots of the windows below (ecamd_bkt_slot)
 	uint32_t pt_first, pt_count; // phase 10: the point indices [pt_first, pt_first + pt_count) of the 2n (count 0: all of them)
 	uint32_t win_first, win_count;   // phase 11: the windows [win_first, win_first + win_count) (count 0: all of them)
 };
@@ -294,7 +328,8 @@ struct EcamdBktSortArgs {
 	uint32_t *order;             // nwin x 2n
 	uint32_t *perm;              // nwin << c: the buckets, every 4096 of them ranked by size (k_bkt_rank); may be NULL
 	uint32_t *flag;              // |= 16 when a bucket overflows its `cap` slots
-	uint32_t cap;                // != 0: fixed-capacity filing -- order is (nwin << c) x cap, hist counts, no scan (k_bkt_file)
+	uint32_t cap;                // != 0: fixed-capacity filing -- hist counts, no scan (k_bkt_file); slots as ecamd_bkt_slot lays them out
+	uint32_t cap_top, top_win;
 	uint32_t n, wlen, zlen, c, nwin, nwinZ;
 };
 hipError_t ecamd_launch_bkt_sort(const EcamdBktSortArgs &a, hipStream_t s);

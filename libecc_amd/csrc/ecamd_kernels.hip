@@ -978,6 +978,16 @@ template <int NW> __global__ __launch_bounds__(64) void k_edmsm_scal(EcamdEdMsmS
 	for (int w = 0; w < 8; w++) {
 		A.zs[(size_t)i * 8 + w] = zs.v[w];
 	}
+	if (A.rawC != nullptr) {
+#pragma unroll
+		for (int w = 0; w < 8; w++) {
+			A.rawC[(size_t)i * 8 + w] = c.v[w];
+		}
+#pragma unroll
+		for (int w = 0; w < 4; w++) {
+			A.rawZ[(size_t)i * 4 + w] = z4[w];
+		}
+	}
 	A.flagsS[i] = ok ? 0 : 1;
 	if (A.z_dump != nullptr) {
 #pragma unroll
@@ -1011,6 +1021,12 @@ template <int NW> __global__ __launch_bounds__(64) void k_edmsm_lane(EcamdEdMsmL
 		bad |= (u32)A.flags[item] | (u32)A.flagsS[item];
 	}
 	const Fe<NW> neg = fe_sub<NW>(fe_zero<NW>(), sum, qs);
+	if (A.rawB != nullptr) {
+#pragma unroll
+		for (int w = 0; w < 8; w++) {
+			A.rawB[(size_t)lane * 8 + w] = neg.v[w];
+		}
+	}
 	uint64_t cy = 0;
 #pragma unroll
 	for (int w = 0; w < 8; w++) {
@@ -2226,10 +2242,12 @@ __global__ __launch_bounds__(256) void k_bkt_file(EcamdBktSortArgs A)
 	u32 pt;
 	const u32 d = bkt_pair_digit(A, win, j, pt);
 	if (d) {
-		const size_t b = ((size_t)win << A.c) + d;
+		const u32 b = (win << A.c) + d;
 		const u32 pos = atomicAdd(&A.hist[b], 1u);
-		if (pos < A.cap) {
-			A.order[b * A.cap + pos] = pt;
+		u32 capb;
+		const size_t base = ecamd_bkt_slot(b, A.cap, A.cap_top, A.top_win, &capb);
+		if (pos < capb) {
+			A.order[base + pos] = pt;
 		} else {
 			atomicOr(A.flag, 16u);
 		}
@@ -2561,6 +2579,49 @@ hipError_t ecamd_launch_ed_lat(const EcamdEdLatArgs &a, hipStream_t s)
 		return hipSuccess;
 	}
 	hipLaunchKernelGGL(k_ed_lat<8>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+	return hipGetLastError();
+}
+
+// the filing of the Ed25519 bucket evaluation (EcamdEdBktArgs): one thread per (window, point); see k_bkt_file
+__global__ __launch_bounds__(256) void k_edbkt_file(EcamdEdBktArgs B)
+{
+	const u32 win = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+	const u32 npts = 2u * B.n + B.LB;
+	if (j >= npts) {
+		return;
+	}
+	u32 d;
+	if (j < B.n) {
+		d = (B.rawC[(size_t)j * 8 + (win >> 1)] >> (16u * (win & 1u))) & 0xffffu;
+	} else if (j < B.n + B.LB) {
+		d = (B.rawB[(size_t)(j - B.n) * 8 + (win >> 1)] >> (16u * (win & 1u))) & 0xffffu;
+	} else {
+		if (win >= 8u) {
+			return;
+		}
+		d = (B.rawZ[(size_t)(j - B.n - B.LB) * 4 + (win >> 1)] >> (16u * (win & 1u))) & 0xffffu;
+	}
+	if (d) {
+		const u32 b = (win << 16) + d;
+		const u32 pos = atomicAdd(&B.count[b], 1u);
+		u32 capb;
+		const size_t base = ecamd_bkt_slot(b, B.cap, B.cap_top, 15u, &capb);
+		if (pos < capb) {
+			B.order[base + pos] = j;
+		} else {
+			atomicOr(B.flagword, 16u);
+		}
+	}
+}
+hipError_t ecamd_launch_edbkt_file(const EcamdEdBktArgs &b, hipStream_t s)
+{
+	const size_t counters = (size_t)16 << 16;
+	const hipError_t e = hipMemsetAsync(b.count, 0, counters * 4, s);
+	if (e != hipSuccess) {
+		return e;
+	}
+	hipLaunchKernelGGL(k_edbkt_file, dim3((2 * b.n + b.LB + 255) / 256, 16), dim3(256), 0, s, b);
+	hipLaunchKernelGGL(k_bkt_rank, dim3((unsigned)(counters / 4096)), dim3(256), 0, s, (const u32 *)b.count, b.perm, (u32)counters);
 	return hipGetLastError();
 }
 

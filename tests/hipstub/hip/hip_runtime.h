@@ -13,6 +13,7 @@ extern thread_local dim3 blockIdx, threadIdx;
 #define __constant__ static const
 #define __global__
 #define __device__
+#define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
 #define __builtin_amdgcn_alignbit(hi, lo, b) ((uint32_t)(((((uint64_t)(hi)) << 32) | (uint64_t)(lo)) >> ((b) & 31)))

@@ -249,6 +249,20 @@ def test_ed25519_whole_batch_vs_the_reference_batch_verifier(gpu_ctx, log2n):
         gpu_ctx.set_eddsa_msm(2, 0, 0)                  # the multi-scalar form whatever the size
         ok, first = cv.eddsa_verify_all(pubs, sigs, hram)
         assert ok and first == n
+
+        def combination_alone(sg_bytes):
+            """the verdict byte of the multi-scalar multiplication ITSELF (the host-pointer form above follows a rejected combination with the
+            item-by-item pass and would hide a combination that wrongly rejects): 0 = the batch equation holds"""
+            import torch
+            dev = torch.device("cuda:0")
+            t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+            dp, ds, dh = t(pubs), t(sg_bytes), t(hram)
+            verdict = torch.full((1,), 7, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            cv.eddsa_verify_all_dev(n, dp.data_ptr(), ds.data_ptr(), dh.data_ptr(), verdict.data_ptr(), None)
+            torch.cuda.synchronize()
+            return int(verdict.item())
+        assert combination_alone(sigs) == 0
         k = int(rng.integers(0, n))
         psize = 1 << 12 if log2n <= 17 else 1 << 9
         pieces = _pieces(n, psize, n // psize if log2n <= 17 else (1 << 15) // psize, rng, must_hold=k)
@@ -263,6 +277,7 @@ def test_ed25519_whole_batch_vs_the_reference_batch_verifier(gpu_ctx, log2n):
         bad = bytes(bad)
         ok, first = cv.eddsa_verify_all(pubs, bad, hram)
         assert not ok and first == k
+        assert combination_alone(bad) == 1
         again = [p for p in pieces if p[0] <= k < p[1]] + [p for p in pieces if not (p[0] <= k < p[1])][:O.host_threads() - 1]
         verdicts = ref(bad, again)
         assert not verdicts[0] and all(verdicts[1:])

@@ -15,6 +15,19 @@ from oracles import Oracle  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["straus", "bucket"])
+def ed_msm_algo(request):
+    """every test of this module runs on both evaluations of the combination: the Straus loop (round 2) and the bucket form (round 6);
+    ECAMD_ED_MSM_ALGO is read by the library at every call"""
+    old = os.environ.get("ECAMD_ED_MSM_ALGO")
+    os.environ["ECAMD_ED_MSM_ALGO"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("ECAMD_ED_MSM_ALGO", None)
+    else:
+        os.environ["ECAMD_ED_MSM_ALGO"] = old
+
+
 def chacha20_block(key, counter, nonce):
     """RFC 8439 section 2.3 (key 32 bytes, counter u32, nonce 3 x u32) -> 64 bytes"""
     def rotl(x, r):

@@ -383,7 +383,21 @@ def main():
             prep = 2 * (255 * S + 25 * M) + 3 * (4 * M + 4 * S) + 2 * (49 * M + 16 * S)
             work = {"kernel": "k_edmsm_loop", "mads_per_item": loop, "sgpr_mads_per_item": loop * 16 / 97, "step_mads_per_item": loop + prep,
                     "alg_bytes_per_item": 32 + 64 + 64}
-            metric, unit, cfg = "Ed25519 signatures/sec in whole-batch verification (one multi-scalar multiplication per 2^%d-item batch, K = %d items per lane)" % (a.batch_log2, K), "verifications/s", "f4"
+            how = "Straus, K = %d items per lane" % K
+            algo = os.environ.get("ECAMD_ED_MSM_ALGO") or ("bucket" if B >= (1 << 18) else "straus")
+            if algo == "bucket":
+                # round 6, the bucket evaluation (ecamd_host.cpp:eddsa_bkt_dev_locked): 16 windows of z h mod q, 8 of z, and a copy of B per 64
+                # items with 16 windows: one addition with an affine precomputed operand (ed_madd: 7M) per pair in k_edbkt_accum; the step adds
+                # the decoding (two square roots, the key's cofactor doublings, two precomputed entries of 3M), and the reduction -- 2^16
+                # buckets per window, 2 unified additions (8M + the operand's conversion 1M) each, whatever the batch size
+                pairs = 16 + 8 + 16 / 64
+                acc = pairs * 7 * M
+                front = 2 * (255 * S + 25 * M) + 3 * (4 * M + 4 * S) + 2 * 3 * M
+                reduce_ = 16 * 65536 * 2 * 9 * M / B
+                work = {"kernel": "k_edbkt_accum", "mads_per_item": acc, "sgpr_mads_per_item": acc * 16 / 97, "step_mads_per_item": acc + front + reduce_,
+                        "alg_bytes_per_item": 32 + 64 + 64}
+                how = "buckets, 16-bit windows, %.2f additions per item" % pairs
+            metric, unit, cfg = "Ed25519 signatures/sec in whole-batch verification (one multi-scalar multiplication per 2^%d-item batch: %s)" % (a.batch_log2, how), "verifications/s", "f4"
             ref_what = "ec_verify_batch (EDDSA25519: eddsa_verify_batch, no scratch pad)"
     elif a.workload == "ed448_verify":
         cv = ctx.curve("WEI448")
