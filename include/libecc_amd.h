@@ -223,6 +223,12 @@ int ec_eddsa_verify_msg_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t
  * is rejected (result 1); a key at infinity encodes as (0, 1) and is rejected by the small-order test like in the reference. */
 int ec_eddsa_verify_msg_prj_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
 				  const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, uint8_t *result);
+/* ec_verify_batch's ONE bit for plain Ed25519 / Ed25519ctx from the same inputs (round 6): the front end per staging chunk as above, then
+ * the reference's batch equation over the whole batch as one multi-scalar multiplication per max_chunk items (by buckets from 2^18 items
+ * on).  *all_valid = 0 means "not decided here" -- a bad signature, a key that does not import or has no encoding, or a handle
+ * without the form (WEI448): verify item by item (ec_eddsa_verify_msg_prj_batch). */
+int ec_eddsa_verify_msg_prj_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
+				      const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, int *all_valid);
 /* The pre-hashed variant (EDDSA25519PH, sig/eddsa.c:1049-1080, :1995-2045): the hash input is dom2(1, context) || R || A || PH(M) with
  * PH(M) = SHA-512(M).  The caller leaves 96 blank octets at message offset a_offset (A, then PH(M)) and hands the messages over in
  * slots of their own (msg_slots, msg_stride: u32 length + bytes); both hashes run on the device. */
@@ -515,6 +521,8 @@ int ecamd_multi_eddsa_verify_msg_batch(ecamd_multi *m, const ecamd_mcurve *curve
 				       const uint8_t *hash_slots, uint32_t stride, uint8_t *result);
 int ecamd_multi_eddsa_verify_msg_prj_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
 					   const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, uint8_t *result);
+int ecamd_multi_eddsa_verify_msg_prj_all_batch(ecamd_multi *m, const ecamd_mcurve *curve, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
+					       const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, int *all_valid);
 int ecamd_multi_eddsa_verify_ph_prj_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
 					  const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, const uint8_t *msg_slots, uint32_t msg_stride,
 					  uint8_t *result);

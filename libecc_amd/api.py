@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "ecamd_multi_xdh_batch", "ecamd_multi_eddsa_verify_batch", "ecamd_multi_eddsa_verify_all_batch", "ecamd_multi_allgather",
     "ecamd_multi_allgather_streams", "ecamd_multi_eddsa_sign_R_batch", "ecamd_multi_eddsa_sign_S_batch",
     "ecamd_multi_set_secret_scalars", "ecamd_multi_wipe_scratch", "ecamd_ctx_wipe_scratch", "ecamd_ctx_stream", "ecamd_host_alloc", "ecamd_host_free", "ecamd_ctx_dominant_kernel_ms", "ecamd_ctx_set_msm_seed", "ecamd_ctx_discard_msm_seed", "ecamd_multi_set_msm_seed", "ec_eddsa_verify_ph_prj_batch", "ecamd_multi_eddsa_verify_ph_prj_batch", "ec_nn_random_mod_batch", "ec_ecdsa_sign_msg_batch", "ec_key_pair_gen_raw_batch", "ecamd_multi_ecdsa_sign_msg_batch", "ecamd_multi_key_pair_gen_raw_batch", "ec_eddsa_verify_msg_prj_batch", "ecamd_multi_eddsa_verify_msg_prj_batch", "ecamd_ctx_set_host_ready_hook", "ecamd_multi_set_host_ready_hook", "ecamd_multi_prj_pt_add_batch",
-    "ec_schnorr_verify_all_batch", "ec_schnorr_verify_all_batch_dev", "ec_schnorr_verify_msg_all_batch", "ecamd_multi_schnorr_verify_msg_all_batch", "ec_schnorr_verify_all_available", "ecamd_multi_schnorr_verify_all_batch", "ecamd_debug_schnorr_msm", "ecamd_debug_schnorr_msm_words",
+    "ec_schnorr_verify_all_batch", "ec_schnorr_verify_all_batch_dev", "ec_schnorr_verify_msg_all_batch", "ec_eddsa_verify_msg_prj_all_batch", "ecamd_multi_eddsa_verify_msg_prj_all_batch", "ecamd_multi_schnorr_verify_msg_all_batch", "ec_schnorr_verify_all_available", "ecamd_multi_schnorr_verify_all_batch", "ecamd_debug_schnorr_msm", "ecamd_debug_schnorr_msm_words",
 ]
 
 
@@ -84,6 +84,8 @@ def load_library():
         L.ecamd_ctx_set_eddsa_msm.argtypes = [vp, C.c_int, u32, u32]
         L.ec_schnorr_verify_all_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p, C.c_int, C.POINTER(C.c_int)]
         L.ec_schnorr_verify_all_batch_dev.argtypes = [vp, vp, u32, vp, vp, vp, vp, C.c_int, vp, vp]
+        L.ec_eddsa_verify_msg_prj_all_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u32, C.POINTER(C.c_int)]
+        L.ecamd_multi_eddsa_verify_msg_prj_all_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u32, u32, C.POINTER(C.c_int)]
         L.ec_schnorr_verify_msg_all_batch.argtypes = [vp, vp, u32, u8p, C.c_int, u8p, C.c_int, C.c_int, u8p, u32, u32, C.POINTER(C.c_int)]
         L.ecamd_multi_schnorr_verify_msg_all_batch.argtypes = [vp, vp, u32, u8p, C.c_int, u8p, C.c_int, C.c_int, u8p, u32, u32, C.POINTER(C.c_int)]
         L.ecamd_multi_schnorr_verify_all_batch.argtypes = [vp, vp, u32, u8p, u8p, u8p, u8p, C.c_int, C.POINTER(C.c_int)]
@@ -457,6 +459,15 @@ class Curve:
 
     def schnorr_msm_available(self, r_fmt=0):
         return bool(self.L.ec_schnorr_verify_all_available(self.h, r_fmt))
+
+    def eddsa_verify_msg_prj_all(self, keys_prj, sigs, slots, stride, a_offset):
+        """ec_eddsa_verify_msg_prj_all_batch: ec_verify_batch's one bit for plain Ed25519 from projective keys, signatures and hash inputs;
+        True = the whole batch is valid, False = not decided here"""
+        n = len(slots) // stride
+        ok = C.c_int(0)
+        _chk(self.L, self.L.ec_eddsa_verify_msg_prj_all_batch(self.ctx.h, self.h, n, keys_prj, sigs, slots, stride, a_offset, C.byref(ok)),
+             "ec_eddsa_verify_msg_prj_all_batch")
+        return bool(ok.value)
 
     def schnorr_verify_msg_all(self, keys, key_fmt, sigs, r_fmt, hash_type, slots, stride, x_offset):
         """ec_schnorr_verify_msg_all_batch: the BIP0340 / ECFSDSA batch from keys, signatures and hash inputs (hashes, q - e and the

@@ -1735,6 +1735,7 @@ int main(int argc, char **argv)
 		check_torsion_shift(8);
 		check_concurrent_verify(qn);
 		printf("schnorr multi-scalar calls: %lu\n", ecamd_compat_schnorr_msm_calls());
+		printf("ed25519 whole-batch calls: %lu\n", ecamd_compat_ed_msm_calls());
 		ecamd_compat_shutdown();
 		CHECK(!g_rand_expect_serial || g_rand_overlaps == 0, "get_random entered concurrently %d times", g_rand_overlaps);
 		printf(failures ? "compat_check: %d FAILURES\n" : "compat_check: all ok (%d failures)\n", failures);

@@ -3485,6 +3485,67 @@ static int eddsa_ver_gpu_prj(u32 lo, u32 hi, void *arg)
 	return 0;
 }
 
+/* Round 6: only the batch bit is wanted and the batch is large -- the same packed arrays as ONE streamed call whose front end files
+ * every chunk and whose end is the reference's batch equation over the whole batch (ec_eddsa_verify_msg_prj_all_batch: by buckets).  The
+ * z_i are keyed through the application's get_random, as in eddsa_ver_gpu_all.  An item that fails a host-side check makes the attempt
+ * void (J->all_ok = 0): the caller then verifies item by item. */
+static unsigned long g_ed_msm_calls;
+unsigned long ecamd_compat_ed_msm_calls(void) { return AT_LOAD(&g_ed_msm_calls); }
+static int eddsa_ver_gpu_prj_all(u32 lo, u32 hi, void *arg)
+{
+	ver_job *J = (ver_job *)arg;
+	int all = 0;
+	u8 seed[32];
+	int r;
+	if (AT_LOAD(&g_rand_concurrent)) {
+		r = get_random(seed, sizeof(seed));
+	} else {
+		pthread_mutex_lock(&g_rand_mu);
+		r = get_random(seed, sizeof(seed));
+		pthread_mutex_unlock(&g_rand_mu);
+	}
+	r = r || ecamd_multi_set_msm_seed(g_multi, seed);
+	wipe(seed, sizeof(seed));
+	if (r) {
+		return -1;
+	}
+	if (ecamd_multi_eddsa_verify_msg_prj_all_batch(g_multi, J->e->mc, hi - lo, J->kprj + (size_t)lo * 3 * J->clen, J->sg + (size_t)lo * J->siglen,
+						       J->dg + (size_t)lo * J->slot, J->slot, J->a_off, &all)) {
+		fprintf(stderr, "libecc_amd compat: %s\n", ecamd_last_error());
+		return -1;
+	}
+	AT_ADD(&g_ed_msm_calls, 1);
+	if (!all) {
+		J->all_ok = 0;
+	}
+	return 0;
+}
+/* (the pre-checks of the items: any failure voids the whole-batch attempt) */
+static void eddsa_any_pre(u32 lo, u32 hi, void *arg)
+{
+	ver_job *J = (ver_job *)arg;
+	u32 j, bad = 0;
+	for (j = lo; j < hi; j++) {
+		bad |= J->pre[j];
+	}
+	if (bad) {
+		AT_STORE(&J->any_fail, 1);
+	}
+}
+static int ed_msm_wanted(u32 cnt)
+{
+	unsigned long min_items = 1ul << 18;
+	const char *e = getenv("ECAMD_COMPAT_ED_MSM_MIN");
+	const int ranks = ecamd_multi_size(g_multi);
+	if (e) {
+		min_items = strtoul(e, NULL, 10);
+		if (min_items == 0) {
+			return 0;
+		}
+	}
+	return ranks > 0 && (unsigned long)cnt / (unsigned long)ranks >= min_items;
+}
+
 static int eddsa_ver_gpu(u32 lo, u32 hi, void *arg)
 {
 	ver_job *J = (ver_job *)arg;
@@ -3632,6 +3693,25 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
 	}
 	if (getenv("ECAMD_COMPAT_TIMING")) {
 		fprintf(stderr, "libecc_amd compat timing: EdDSA group of %u items: %s, dom2 prefix %u octets\n", cnt, one_pass ? "one device call" : "two passes", J->dom_len);
+	}
+	if (one_pass && J->all_only && !J->ph && !J->is448 && ed_msm_wanted(cnt)) {
+		/* ec_verify_batch of a large Ed25519 batch: the batch equation first (round 6); it vouches for VALID batches only */
+		J->all_ok = 1;
+		J->any_fail = 0;
+		if (verify_pipeline(cnt, eddsa_pack_prj, eddsa_ver_gpu_prj_all, NULL, J)) {
+			fprintf(stderr, "libecc_amd compat: the whole-batch form failed (%s); verifying item by item\n", ecamd_last_error());
+		} else {
+			parallel_for(cnt, eddsa_any_pre, J);
+			if (J->all_ok && !AT_LOAD(&J->any_fail)) {
+				note_items(cnt);
+				for (j = 0; j < cnt; j++) {
+					results[J->idx[j]] = 0;
+				}
+				J->fail_tracked = 1;   /* (and nothing failed) */
+				return 0;
+			}
+		}
+		J->any_fail = 0;
 	}
 	if (one_pass) {
 		J->results = results;

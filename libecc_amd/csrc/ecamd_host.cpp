@@ -3925,9 +3925,19 @@ static int eddsa_sign_setup(const char *fn, ecamd_ctx *ctx, const ecamd_curve *c
 // ec_eddsa_encode_point_batch computes; here that encoding goes straight into the item's hash input on the device (bytes a_offset ..
 // a_offset + 32 of the slot's message, which the caller leaves blank; the caller's array itself is not written), so one call replaces encode / copy back / build the inputs /
 // verify.  A key that does not import (coordinates >= p, not on the curve) or is the point at infinity rejects its item.
+static bool eddsa_msm_available(const ecamd_curve *cv);
+static int msm_seed(ecamd_ctx *ctx, uint8_t seed[32]);
+static void msm_seed_discard(ecamd_ctx *ctx);
+static int eddsa_msm_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig,
+				const uint8_t *d_hram, const uint8_t seed[32], uint32_t piece, uint8_t *d_verdict, uint8_t *d_z_dump,
+				uint32_t *d_sum_dump, hipStream_t s);
+// all_valid != NULL (round 6, Ed25519 only): ONE accept bit instead of per-item results -- the front end of every chunk (import, encoding, hashes)
+// files the encoded keys, the signatures and the hashes in batch-wide arrays (stage 24 - 26; 27: per-item "the key has no encoding"), and when
+// the last chunk is in the batch equation is evaluated once per max_chunk items (eddsa_msm_dev_locked: by buckets from 2^18 items on).
+// *all_valid = 0: not decided here (ec_eddsa_verify_all_batch's contract without its item-by-item pass: the caller has one).
 static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
 				     const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, const uint8_t *msg_slots, uint32_t msg_stride,
-				     uint8_t *result)
+				     uint8_t *result, int *all_valid = nullptr)
 {
 	const std::string f(fn);
 	if (!ctx || !cv_in) {
@@ -3946,7 +3956,9 @@ static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd
 	}
 	std::lock_guard<std::mutex> lk(ctx->mu);
 	EcamdEdSignArgs T;
-	if (eddsa_sign_setup(fn, ctx, cv_in, n, keys_prj, sigs, hash_slots, &T) || eddsa_args_ok(fn, ctx, cv_in, n, keys_prj, sigs, hash_slots, result, hl)) {
+	uint8_t dummy = 0;
+	if (eddsa_sign_setup(fn, ctx, cv_in, n, keys_prj, sigs, hash_slots, &T) ||
+	    eddsa_args_ok(fn, ctx, cv_in, n, keys_prj, sigs, hash_slots, all_valid ? &dummy : result, hl)) {
 		return -1;
 	}
 	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
@@ -3955,11 +3967,23 @@ static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd
 	}
 	HIPCHK(hipSetDevice(ctx->device));
 	const size_t cl = (size_t)cv->clen;
-	std::vector<HostArr> arrs = {{keys_prj, nullptr, 3 * cl}, {sigs, nullptr, sl}, {hash_slots, nullptr, stride}, {nullptr, result, 1}};
+	uint8_t seed[32] = {0};
+	uint32_t done = 0;
+	if (all_valid) {
+		*all_valid = 0;
+		if (e448 || !eddsa_msm_available(cv)) {
+			return 0;   // not decided here
+		}
+		if (msm_seed(ctx, seed) || ensure(&ctx->stage[24], &ctx->stage_bytes[24], (size_t)n * 32) || ensure(&ctx->stage[25], &ctx->stage_bytes[25], (size_t)n * 64) ||
+		    ensure(&ctx->stage[26], &ctx->stage_bytes[26], (size_t)n * 64) || ensure(&ctx->stage[27], &ctx->stage_bytes[27], (size_t)n + 256)) {
+			return -1;
+		}
+	}
+	std::vector<HostArr> arrs = {{keys_prj, nullptr, 3 * cl}, {sigs, nullptr, sl}, {hash_slots, nullptr, stride}, {nullptr, all_valid ? nullptr : result, 1}};
 	if (msg_slots) {
 		arrs.push_back({msg_slots, nullptr, msg_stride});
 	}
-	return host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
+	const int prc = host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
 		// stage: 20 affine keys, 21 import status, 22 encodings, 23 their status (the verification core owns 3 .. 19)
 		if (ensure(&ctx->stage[20], &ctx->stage_bytes[20], (size_t)m * 2 * cl) || ensure(&ctx->stage[21], &ctx->stage_bytes[21], m) ||
@@ -3992,6 +4016,18 @@ static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd
 		A.status = ctx->stage[23];
 		HIPCHK(ecamd_launch_ed_sign_enc(A, s));
 		HIPCHK(ecamd_launch_slot_patch(slots, stride, a_offset, ctx->stage[22], kl, ctx->stage[23], m, s));
+		if (all_valid) {
+			// the whole-batch form: file this chunk's encoded keys, signatures, hashes and "no encoding" marks; the equation comes at the end
+			if (ecdsa_hash_stage(ctx, hash_type, m, slots, stride, hl, s)) {
+				return -1;
+			}
+			HIPCHK(hipMemcpyAsync(ctx->stage[24] + (size_t)done * 32, ctx->stage[22], (size_t)m * 32, hipMemcpyDeviceToDevice, s));
+			HIPCHK(hipMemcpyAsync(ctx->stage[25] + (size_t)done * 64, ip[1], (size_t)m * 64, hipMemcpyDeviceToDevice, s));
+			HIPCHK(hipMemcpyAsync(ctx->stage[26] + (size_t)done * 64, ctx->stage[17], (size_t)m * 64, hipMemcpyDeviceToDevice, s));
+			HIPCHK(hipMemcpyAsync(ctx->stage[27] + (size_t)done, ctx->stage[23], m, hipMemcpyDeviceToDevice, s));
+			done += m;
+			return 0;
+		}
 		if (ecdsa_hash_stage(ctx, hash_type, m, slots, stride, hl, s) ||
 		    (e448 ? eddsa448_verify_dev_locked(ctx, cv, m, ctx->stage[22], ip[1], ctx->stage[17], op[3], s)
 			  : eddsa_verify_dev_locked(ctx, cv, m, ctx->stage[22], ip[1], ctx->stage[17], 64, op[3], s))) {
@@ -4000,6 +4036,49 @@ static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd
 		HIPCHK(ecamd_launch_reject_where(op[3], ctx->stage[23], m, s));
 		return 0;
 	});
+	if (prc || !all_valid) {
+		return prc;
+	}
+	// the batch equation over the filed arrays, a piece of max_chunk items at a time; the verdict byte rests behind the marks
+	hipStream_t s = ctx->stream;
+	StreamScope scope(ctx, s);
+	uint8_t *d_verdict = ctx->stage[27] + n;
+	HIPCHK(hipMemsetAsync(d_verdict, 0, 1, s));
+	uint32_t pc = 0;
+	for (uint32_t off = 0; off < n; off += ctx->max_chunk, pc++) {
+		const uint32_t m = (n - off) < ctx->max_chunk ? (n - off) : ctx->max_chunk;
+		if (eddsa_msm_dev_locked(ctx, cv, m, ctx->stage[24] + (size_t)off * 32, ctx->stage[25] + (size_t)off * 64, ctx->stage[26] + (size_t)off * 64, seed, pc,
+					 d_verdict, nullptr, nullptr, s)) {
+			(void)hipStreamSynchronize(s);
+			return -1;
+		}
+	}
+	std::vector<uint8_t> marks((size_t)n + 1, 1);
+	HIPCHK(hipMemcpyAsync(marks.data(), ctx->stage[27], (size_t)n + 1, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	memset(seed, 0, sizeof(seed));
+	int ok = marks[n] == 0;
+	for (uint32_t i = 0; i < n && ok; i++) {
+		ok = marks[i] == 0;   // a key without an encoding (not on the curve, at infinity): the reference rejects the item
+	}
+	*all_valid = ok;
+	return 0;
+}
+
+// ec_verify_batch's one bit for plain Ed25519 FROM the projective keys, signatures and hash inputs of ec_eddsa_verify_msg_prj_batch (round 6):
+// the same front end per staging chunk, then the batch equation over the whole batch as one multi-scalar multiplication per max_chunk
+// items.  *all_valid = 0: not decided here -- a bad signature, a key that does not import or has no encoding, or a handle without the
+// form (Ed448): the caller verifies item by item.
+extern "C" int ec_eddsa_verify_msg_prj_all_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
+						 const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, int *all_valid)
+{
+	if (!all_valid || n == 0) {
+		return fail("ec_eddsa_verify_msg_prj_all_batch: bad argument (the reference rejects num = 0 too)");
+	}
+	const int r = eddsa_verify_msg_prj_impl("ec_eddsa_verify_msg_prj_all_batch", ctx, cv, n, keys_prj, sigs, hash_slots, stride, a_offset, nullptr, 0, nullptr,
+						all_valid);
+	msm_seed_discard(ctx);
+	return r;
 }
 
 extern "C" int ec_eddsa_verify_msg_prj_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,

@@ -486,6 +486,32 @@ extern "C" int ecamd_multi_schnorr_verify_all_batch(ecamd_multi *m, const ecamd_
 	return 0;
 }
 
+// ec_verify_batch's one bit for plain Ed25519 from projective keys, signatures and hash inputs (ec_eddsa_verify_msg_prj_all_batch): every
+// device runs the front end and decides its shard with a combination of its own
+extern "C" int ecamd_multi_eddsa_verify_msg_prj_all_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
+							  const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, int *all_valid)
+{
+	if (!all_valid || n == 0) {
+		return mfail("ecamd_multi_eddsa_verify_msg_prj_all_batch: bad argument (the reference rejects num = 0 too)");
+	}
+	*all_valid = 0;
+	const size_t cl = (size_t)ecamd_multi_curve_coord_len(c), kl = eddsa_enc_len(c);
+	const int N = m ? (int)m->ctx.size() : 0;
+	std::vector<int> ok((size_t)(N > 0 ? N : 1), 1);
+	if (run_sharded(m, c, n, "ecamd_multi_eddsa_verify_msg_prj_all_batch", [&](int rk, uint32_t lo, uint32_t hi) {
+		    return ec_eddsa_verify_msg_prj_all_batch(m->ctx[(size_t)rk], c->cv[(size_t)rk], hi - lo, OFF(keys_prj, 3 * cl), OFF(sigs, 2 * kl), OFF(hash_slots, stride),
+							     stride, a_offset, &ok[(size_t)rk]);
+	    }, true)) {
+		return -1;
+	}
+	int all = 1;
+	for (int rk = 0; rk < N; rk++) {
+		all = all && ok[(size_t)rk];
+	}
+	*all_valid = all;
+	return 0;
+}
+
 // the same from keys, signatures and hash inputs (ec_schnorr_verify_msg_all_batch): every device imports, hashes and decides its shard
 extern "C" int ecamd_multi_schnorr_verify_msg_all_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *keys, int key_fmt,
 							const uint8_t *sigs, int r_fmt, int hash_type, const uint8_t *hash_slots, uint32_t stride,

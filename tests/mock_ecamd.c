@@ -359,6 +359,30 @@ int ecamd_multi_eddsa_verify_msg_prj_batch(ecamd_multi *m, const ecamd_mcurve *c
 	return r;
 }
 
+/* the whole-batch bit from the same inputs (round 6): the exact conjunction of the item results */
+int ecamd_multi_eddsa_verify_msg_prj_all_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
+					       const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, int *all_valid)
+{
+	uint8_t *res = malloc(n + 1);
+	uint32_t i;
+	int r;
+	*all_valid = 0;
+	if (!res) {
+		return mfail("mock: out of memory");
+	}
+	r = ecamd_multi_eddsa_verify_msg_prj_batch(m, c, n, keys_prj, sigs, hash_slots, stride, a_offset, res);
+	if (!r) {
+		*all_valid = 1;
+		for (i = 0; i < n; i++) {
+			if (res[i]) {
+				*all_valid = 0;
+			}
+		}
+	}
+	free(res);
+	return r;
+}
+
 int ecamd_multi_eddsa_verify_ph_prj_batch(ecamd_multi *m, const ecamd_mcurve *c, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
 					  const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, const uint8_t *msg_slots, uint32_t msg_stride,
 					  uint8_t *result)

@@ -166,6 +166,12 @@ int ec_schnorr_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *, uint32_t n,
 	*all_valid = ((g_bad_mask >> ctx->rank) & 1u) ? 0 : 1;
 	return rec(__func__, ctx, n, {s, ne, keys_aff, r}, {r_fmt});
 }
+int ec_eddsa_verify_msg_prj_all_batch(ecamd_ctx *ctx, const ecamd_curve *, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs, const uint8_t *hash_slots,
+				      uint32_t stride, uint32_t a_offset, int *all_valid)
+{
+	*all_valid = ((g_bad_mask >> ctx->rank) & 1u) ? 0 : 1;
+	return rec(__func__, ctx, n, {keys_prj, sigs, hash_slots}, {stride, a_offset});
+}
 int ec_schnorr_verify_msg_all_batch(ecamd_ctx *ctx, const ecamd_curve *, uint32_t n, const uint8_t *keys, int key_fmt, const uint8_t *sigs, int r_fmt,
 				    int hash_type, const uint8_t *hash_slots, uint32_t stride, uint32_t x_offset, int *all_valid)
 {

@@ -70,10 +70,12 @@ def test_schnorr_batches_try_the_multi_scalar_form_first():
     pass their pre-checks asks ecamd_multi_schnorr_verify_all_batch first (the stand-in answers with the exact conjunction of the item
     form); accepted batches end there, spoiled ones go on to the item-by-item pass and ec_verify_batch_results still matches ec_verify"""
     _build()
-    r = _run(["quick", "60"], ECAMD_COMPAT_SCHNORR_MSM_MIN="1", ECAMD_COMPAT_THREADS="2")
+    r = _run(["quick", "60"], ECAMD_COMPAT_SCHNORR_MSM_MIN="1", ECAMD_COMPAT_ED_MSM_MIN="1", ECAMD_COMPAT_THREADS="2")
     assert r.returncode == 0, r.stdout[-4000:]
     assert "all ok" in r.stdout and "ec_verify_batch BIP0340/SECP256K1" in r.stdout and "ec_verify_batch ECFSDSA/SECP256R1" in r.stdout
     assert int(r.stdout.split("schnorr multi-scalar calls:")[1].split()[0]) >= 6, r.stdout[-600:]
+    # round 6: ec_verify_batch of Ed25519 / Ed25519ctx batches asks for the whole-batch bit first as well (valid batches end there)
+    assert int(r.stdout.split("ed25519 whole-batch calls:")[1].split()[0]) >= 4, r.stdout[-600:]
 
 
 def test_no_device_is_an_error_not_a_fallback():

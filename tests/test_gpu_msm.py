@@ -231,3 +231,63 @@ def test_device_pointer_form(gpu_ctx):
         cv.free()
     finally:
         ctx2.close()
+
+
+def test_whole_batch_bit_from_projective_keys_and_messages(gpu_ctx):
+    """ec_eddsa_verify_msg_prj_all_batch (round 6): ec_verify_batch's one bit from what libsign_amd.so holds -- the key as a projective
+    Weierstrass point (random Z), R || S, and the hash input R || <blank for A> || M; the device imports, encodes, hashes and evaluates the
+    batch equation.  Valid batch: True; one damaged signature, a damaged message, a key off the curve or at infinity: False (not decided).
+    Staged in three chunks.  Signatures from Python integers on the keys [a]G the library computes (as in test_gpu_hash.py)."""
+    rng = np.random.default_rng(77)
+    n = 600
+    c = O.CURVES["WEI25519"]
+    p, q = c["p"], c["q"]
+    rb = lambda k: rng.integers(0, 256, size=k, dtype=np.uint8).tobytes()
+    cv = gpu_ctx.curve("WEI25519")
+    old = os.environ.get("ECAMD_HOST_SCHEDULE")
+    os.environ["ECAMD_HOST_SCHEDULE"] = "100,200"
+    try:
+        a = [(int.from_bytes(rb(40), "big") % (q - 1)) + 1 for _ in range(n)]
+        r = [(int.from_bytes(rb(40), "big") % (q - 1)) + 1 for _ in range(n)]
+        msgs = [rb(20 + i % 9) for i in range(n)]
+        Aw, st = cv.scalar_mult(b"".join(x.to_bytes(32, "big") for x in a))
+        Rw, st2 = cv.scalar_mult(b"".join(x.to_bytes(32, "big") for x in r))
+        assert set(st) == {0} and set(st2) == {0}
+
+        def prj(aff, i, lam):
+            x, y = int.from_bytes(aff[64 * i:64 * i + 32], "big"), int.from_bytes(aff[64 * i + 32:64 * i + 64], "big")
+            return b"".join((v % p).to_bytes(32, "big") for v in (x * lam, y * lam, lam))
+        keys = b"".join(prj(Aw, i, 1 if i % 3 == 0 else int.from_bytes(rb(40), "big") % (p - 1) + 1) for i in range(n))
+        Aenc, est = cv.eddsa_encode_points(keys)
+        Renc, est2 = cv.eddsa_encode_points(b"".join(prj(Rw, i, 1) for i in range(n)))
+        assert set(est) == {0} and set(est2) == {0}
+        stride = (4 + 64 + 28 + 3) & ~3
+        sigs, slots = bytearray(), bytearray(stride * n)
+        for i in range(n):
+            Ri, Ai = Renc[32 * i:32 * i + 32], Aenc[32 * i:32 * i + 32]
+            hd = hashlib.sha512(Ri + Ai + msgs[i]).digest()
+            sigs += Ri + ((r[i] + (int.from_bytes(hd, "little") % q) * a[i]) % q).to_bytes(32, "little")
+            inp = Ri + bytes(32) + msgs[i]                      # the blank the device fills
+            slots[stride * i:stride * i + 4] = len(inp).to_bytes(4, "little")
+            slots[stride * i + 4:stride * i + 4 + len(inp)] = inp
+        sigs, slots = bytes(sigs), bytes(slots)
+        assert cv.eddsa_verify_msg_prj_all(keys, sigs, slots, stride, 32)
+        for k in (0, 299, n - 1):
+            bad = bytearray(sigs)
+            bad[64 * k + 40] ^= 2
+            assert not cv.eddsa_verify_msg_prj_all(keys, bytes(bad), slots, stride, 32)
+            bs = bytearray(slots)
+            bs[stride * k + 4 + 64 + 5] ^= 1
+            assert not cv.eddsa_verify_msg_prj_all(keys, sigs, bytes(bs), stride, 32)
+        bk = bytearray(keys)
+        bk[96 * 7 + 31] ^= 1                                    # off the curve
+        assert not cv.eddsa_verify_msg_prj_all(bytes(bk), sigs, slots, stride, 32)
+        bk = bytearray(keys)
+        bk[96 * 9:96 * 10] = bytes(32) + (1).to_bytes(32, "big") + bytes(32)   # the point at infinity
+        assert not cv.eddsa_verify_msg_prj_all(bytes(bk), sigs, slots, stride, 32)
+    finally:
+        if old is None:
+            os.environ.pop("ECAMD_HOST_SCHEDULE", None)
+        else:
+            os.environ["ECAMD_HOST_SCHEDULE"] = old
+        cv.free()

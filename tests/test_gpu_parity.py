@@ -1190,7 +1190,7 @@ COMPAT_RUNS = {
     "eight_ranks": (["quick", "203"], {"ECAMD_DEVICES": "0,0,0,0,0,0,0,0"}),
     # BIP0340 / ECFSDSA batches through the multi-scalar multiplication whatever their size (valid batches are decided by it, spoiled
     # ones fall through to the item-by-item pass); three ranks
-    "schnorr_msm_forced": (["quick", "300"], {"ECAMD_COMPAT_SCHNORR_MSM_MIN": "1", "ECAMD_DEVICES": "0,0,0"}),
+    "schnorr_msm_forced": (["quick", "300"], {"ECAMD_COMPAT_SCHNORR_MSM_MIN": "1", "ECAMD_COMPAT_ED_MSM_MIN": "1", "ECAMD_DEVICES": "0,0,0"}),
     # the paths round 4 left as fall-backs: host hashing, chunked calls, two-pass EdDSA, nn_get_random_mod on the host, the scanned
     # window loop for secret fixed-base multiplications, the saturated-word projective import
     "fallback_paths": (["quick", "150"], {"ECAMD_COMPAT_HOST_HASH": "1", "ECAMD_COMPAT_NO_STREAM": "1", "ECAMD_COMPAT_ED_TWO_PASS": "1",
@@ -1218,6 +1218,7 @@ def test_libecc_typed_boundary_vs_scalar_api(run):
     assert "compat_check: all ok" in r.stdout and "FAILED" not in r.stdout and "MISMATCH" not in r.stdout
     if run == "schnorr_msm_forced":
         assert int(r.stdout.split("schnorr multi-scalar calls:")[1].split()[0]) >= 6, r.stdout[-600:]
+        assert int(r.stdout.split("ed25519 whole-batch calls:")[1].split()[0]) >= 4, r.stdout[-600:]
     if run == "full_640":
         assert r.stdout.count(": ok") >= 48
         for row in ("ec_sign_batch ECDSA", "ec_sign_batch DECDSA", "ec_sign_batch EDDSA25519", "ec_sign_batch EDDSA448", "ec_key_pair_{gen,import}_batch",

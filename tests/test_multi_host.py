@@ -241,6 +241,32 @@ def test_schnorr_verify_msg_all_shards_and_combines(lib, curve, nranks):
     lib.mh_set_bad(0, 0)
 
 
+@pytest.mark.parametrize("nranks", [1, 2, 3, 8])
+def test_eddsa_verify_msg_prj_all_shards_and_combines(lib, nranks):
+    """ecamd_multi_eddsa_verify_msg_prj_all_batch (round 6): projective keys by 3 clen, signatures by two encoding lengths, hash-input slots by
+    their stride; valid only when every shard is"""
+    curve = "WEI25519"
+    cl, _ = CURVES[curve]
+    m, mc = make_multi(lib, nranks, curve)
+    n = 900
+    bounds = shard_bounds(n, nranks)
+    for mask in (0, 1, 1 << (nranks - 1)):
+        lib.mh_set_bad(mask, 0)
+        stride = 100
+        ky, sg, sl = Arr(3 * cl), Arr(64), Arr(stride)
+        ok = C.c_int(-7)
+        before = lib.mh_count()
+        assert lib.ecamd_multi_eddsa_verify_msg_prj_all_batch(m, mc, u32(n), ky.arg, sg.arg, sl.arg, u32(stride), u32(32), C.byref(ok)) == 0
+        recs = [r for r in records(lib)[before:] if r[0] != "ecamd_ctx_discard_msm_seed"]
+        assert sorted(r[1] for r in recs) == list(range(nranks))
+        for rfn, rank, rn, ptrs, ints in recs:
+            lo, hi = bounds[rank]
+            assert rfn == "ec_eddsa_verify_msg_prj_all_batch" and rn == hi - lo and ints == [stride, 32]
+            assert ptrs == [a.base + lo * a.item for a in (ky, sg, sl)]
+        assert ok.value == (0 if mask else 1)
+    lib.mh_set_bad(0, 0)
+
+
 def test_error_of_one_rank_fails_the_call_and_names_the_rank(lib):
     m, mc = make_multi(lib, 3, "SECP256R1")
     lib.mh_set_fail_rank(1)
