@@ -402,6 +402,12 @@ int ec_prj_pt_unique_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n,
  *     the projective curve equation -- the reference's prj_pt_add / prj_pt_dbl do not test their operands, here a point off the
  *     curve is ECAMD_ERR; Z = 0 on the curve is the point at infinity, (0 : 0 : 0) included.  Output: the unique representative
  *     (prj_pt_unique: X / Z || Y / Z [|| 1]) or ECAMD_INF with zero bytes.
+ *     (round 6) ECAMD_PT_OP_NEG = prj_pt_neg (:435): (X : -Y : Z), handed back as the unique representative like the sum.
+ *     ECAMD_PT_OP_CMP = prj_pt_cmp (:303) and ECAMD_PT_OP_EQ_OR_OPP = prj_pt_eq_or_opp (:412) of p1[i] and p2[i]: `out` is ONE BYTE
+ *     per item (out_fmt is ignored) -- CMP: 0 where the reference's *cmp is 0 (X1 Z2 = X2 Z1 and Y1 Z2 = Y2 Z1: the same point;
+ *     like the reference no special case for Z = 0, so (0 : 0 : 0) compares equal to everything), 1 where it is not (the reference
+ *     hands back the sign of a comparison of Montgomery residues in its word size; that sign is not reproduced); EQ_OR_OPP: the
+ *     reference's *eq_or_opp, 1 for P = +-Q, else 0.  status 0, or ECAMD_ERR for an operand off the curve (out byte 0).
  *   ec_prj_pt_unprotected_mult_batch: _prj_pt_unprotected_mult (curves/prj_pt.c:1835-1880) statement for statement -- on-curve test,
  *     zero scalar -> infinity, out = in, then per bit below the top one a doubling and, when the bit is set, an addition whose
  *     exceptional pair is the call's -1 -- so that the batch form returns what the scalar function returns for EVERY public scalar
@@ -411,6 +417,9 @@ int ec_prj_pt_unique_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n,
 #define ECAMD_PT_OP_ADD 0
 #define ECAMD_PT_OP_DBL 1
 #define ECAMD_PT_OP_ON_CURVE 2
+#define ECAMD_PT_OP_NEG 3
+#define ECAMD_PT_OP_CMP 4
+#define ECAMD_PT_OP_EQ_OR_OPP 5
 int ec_prj_pt_op_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *curve, int op, uint32_t n, const uint8_t *p1, const uint8_t *p2, int in_fmt,
 			   uint8_t *out, int out_fmt, uint8_t *status);
 int ec_prj_pt_unprotected_mult_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *scalars, uint32_t scalar_len,

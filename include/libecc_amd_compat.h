@@ -97,6 +97,10 @@ int prj_pt_mul_blind_batch(prj_pt *out, const nn *m, const prj_pt *in, u32 n, in
  *   prj_pt_add_batch       prj_pt_add (curves/prj_pt.h:59, curves/prj_pt.c:1204): out[i] = in1[i] + in2[i]; -1 also on the addition's exceptional pair
  *                          (the difference of the two points has order two -- only on curves of even order; :1058-1060)
  *   prj_pt_dbl_batch       prj_pt_dbl (prj_pt.h:60, prj_pt.c:1132)
+ *   prj_pt_neg_batch       prj_pt_neg (prj_pt.h:57, prj_pt.c:435): out[i] = -in[i] (as the unique representative, where the scalar function keeps Z)
+ *   prj_pt_cmp_batch       prj_pt_cmp (prj_pt.h:55, prj_pt.c:303): cmp[i] = 0 when in1[i] and in2[i] are the same projective point, 1 when not (the scalar
+ *                          function hands back -1 or 1 there, the sign of a comparison of Montgomery residues: callers test against 0)
+ *   prj_pt_eq_or_opp_batch prj_pt_eq_or_opp (prj_pt.h:56, prj_pt.c:412): eq_or_opp[i] = 1 when in1[i] = +-in2[i], else 0
  *   prj_pt_unique_batch    prj_pt_unique (prj_pt.h:54, prj_pt.c:241): -1 for the point at infinity, as the scalar function
  *   prj_pt_is_on_curve_batch  prj_pt_is_on_curve (prj_pt.h:51, prj_pt.c:144): on_curve[i] = 1 / 0
  *   _prj_pt_unprotected_mult_batch  _prj_pt_unprotected_mult (prj_pt.h:64, prj_pt.c:1835-1905): the reference's double-and-add for PUBLIC scalars, bit
@@ -106,6 +110,9 @@ int prj_pt_mul_blind_batch(prj_pt *out, const nn *m, const prj_pt *in, u32 n, in
  */
 int prj_pt_add_batch(prj_pt *out, const prj_pt *in1, const prj_pt *in2, u32 n, int *ret_items);
 int prj_pt_dbl_batch(prj_pt *out, const prj_pt *in, u32 n, int *ret_items);
+int prj_pt_neg_batch(prj_pt *out, const prj_pt *in, u32 n, int *ret_items);
+int prj_pt_cmp_batch(const prj_pt *in1, const prj_pt *in2, u32 n, int *cmp, int *ret_items);
+int prj_pt_eq_or_opp_batch(const prj_pt *in1, const prj_pt *in2, u32 n, int *eq_or_opp, int *ret_items);
 int prj_pt_unique_batch(prj_pt *out, const prj_pt *in, u32 n, int *ret_items);
 int prj_pt_is_on_curve_batch(const prj_pt *in, u32 n, int *on_curve, int *ret_items);
 int _prj_pt_unprotected_mult_batch(prj_pt *out, const nn *scalars, const prj_pt *in, u32 n, int *ret_items);

@@ -537,8 +537,9 @@ class Curve:
         return out.raw[:w * n], st.raw[:n]
 
     def pt_op_fmt(self, op, p1, p2, in_fmt, out_fmt):
-        """prj_pt_add (op 0) / prj_pt_dbl (1) / prj_pt_is_on_curve (2) in either wire format: (out, status)"""
-        iw, ow = (3 if in_fmt else 2) * self.clen, (3 if out_fmt else 2) * self.clen
+        """prj_pt_add (op 0) / prj_pt_dbl (1) / prj_pt_is_on_curve (2) / prj_pt_neg (3) in either wire format, prj_pt_cmp (4) /
+        prj_pt_eq_or_opp (5) with one predicate byte per item: (out, status)"""
+        iw, ow = (3 if in_fmt else 2) * self.clen, (1 if op >= 4 else (3 if out_fmt else 2) * self.clen)
         n = len(p1) // iw
         out, st = C.create_string_buffer(max(1, ow * n)), C.create_string_buffer(max(1, n))
         _chk(self.L, self.L.ec_prj_pt_op_batch_fmt(self.ctx.h, self.h, op, n, p1, p2, in_fmt, None if op == 2 else out, out_fmt, st),

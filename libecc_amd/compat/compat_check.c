@@ -275,6 +275,63 @@ static void check_group_law(const char *curve, u32 n)
 		CHECK(!prj_pt_dbl(&ref, &a[i]) && rets[i] == 0 && same_point(&ref, &out[i]), "%s: dbl item %u differs from prj_pt_dbl", curve, i);
 		if (!prj_pt_iszero(&out[i], &z) && z) ninf++;
 	}
+	/* prj_pt_neg_batch / prj_pt_cmp_batch / prj_pt_eq_or_opp_batch (round 6): against the scalar functions on the same pairs -- equal,
+	 * opposite, infinity on either side, different -- and on each point against itself, its opposite and its double */
+	if (prj_pt_neg_batch(out, a, n, rets)) {
+		CHECK(0, "%s: prj_pt_neg_batch failed", curve);
+		return;
+	}
+	for (i = 0; i < n; i++) {
+		prj_pt ref;
+		int on1 = 0;
+		prj_pt_is_on_curve(&a[i], &on1);
+		if (!on1) { CHECK(rets[i] == -1, "%s: neg item %u off the curve must be an error", curve, i); continue; }
+		CHECK(!prj_pt_neg(&ref, &a[i]) && rets[i] == 0 && same_point(&ref, &out[i]), "%s: neg item %u differs from prj_pt_neg", curve, i);
+	}
+	{
+		int pass, neq = 0, nopp = 0, ndiff = 0;
+		for (pass = 0; pass < 3; pass++) {
+			/* pass 0: the pairs of the addition test; pass 1: each point against its opposite as the device returned it (another Z);
+			 * pass 2: each point against the next one */
+			const prj_pt *second = pass == 0 ? b : (pass == 1 ? out : NULL);
+			prj_pt *rot = NULL;
+			if (pass == 2) {
+				rot = (prj_pt *)malloc((size_t)n * sizeof(prj_pt));
+				if (!rot) { CHECK(0, "%s: out of memory", curve); return; }
+				for (i = 0; i < n; i++) rot[i] = a[(i + 1) % n];
+				second = rot;
+			}
+			if (prj_pt_cmp_batch(a, second, n, flags, rets)) {
+				CHECK(0, "%s: prj_pt_cmp_batch failed", curve);
+				free(rot);
+				return;
+			}
+			for (i = 0; i < n; i++) {
+				int on1 = 0, on2 = 0, c = 7;
+				prj_pt_is_on_curve(&a[i], &on1); prj_pt_is_on_curve(&second[i], &on2);
+				if (!on1 || !on2) { CHECK(rets[i] == -1, "%s: cmp item %u off the curve must be an error", curve, i); continue; }
+				CHECK(!prj_pt_cmp(&a[i], &second[i], &c) && rets[i] == 0 && (flags[i] != 0) == (c != 0), "%s: cmp pass %d item %u: %d, prj_pt_cmp %d", curve,
+				      pass, i, flags[i], c);
+				if (!c) neq++; else ndiff++;
+			}
+			if (prj_pt_eq_or_opp_batch(a, second, n, flags, rets)) {
+				CHECK(0, "%s: prj_pt_eq_or_opp_batch failed", curve);
+				free(rot);
+				return;
+			}
+			for (i = 0; i < n; i++) {
+				int on1 = 0, on2 = 0, c = 7;
+				prj_pt_is_on_curve(&a[i], &on1); prj_pt_is_on_curve(&second[i], &on2);
+				if (!on1 || !on2) { CHECK(rets[i] == -1, "%s: eq_or_opp item %u off the curve must be an error", curve, i); continue; }
+				CHECK(!prj_pt_eq_or_opp(&a[i], &second[i], &c) && rets[i] == 0 && flags[i] == c, "%s: eq_or_opp pass %d item %u: %d, prj_pt_eq_or_opp %d",
+				      curve, pass, i, flags[i], c);
+				if (c) nopp++;
+			}
+			free(rot);
+		}
+		CHECK(n < 16 || (neq > 0 && ndiff > 0 && nopp > neq), "%s: the comparison items do not cover equal / opposite / different (%d %d %d)", curve, neq,
+		      ndiff, nopp);
+	}
 	if (prj_pt_unique_batch(out, a, n, rets) || prj_pt_is_on_curve_batch(a, n, flags, NULL)) {
 		CHECK(0, "%s: prj_pt_unique_batch / prj_pt_is_on_curve_batch failed", curve);
 		return;

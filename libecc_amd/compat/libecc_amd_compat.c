@@ -1439,12 +1439,14 @@ int prj_pt_mul_blind_batch(prj_pt *out, const nn *m, const prj_pt *in, u32 n, in
 
 /* ------------------------------------------------------------------------------------------------
  * Round 4: the group law, the normalisation, the on-curve test and the public-scalar multiplication in libecc's own types
- * (prj_pt_add / prj_pt_dbl / prj_pt_unique / prj_pt_is_on_curve, curves/prj_pt.h:42-86; _prj_pt_unprotected_mult and
+ * (prj_pt_add / prj_pt_dbl / prj_pt_unique / prj_pt_is_on_curve -- round 6: prj_pt_neg / prj_pt_cmp / prj_pt_eq_or_opp --, curves/prj_pt.h:42-86; _prj_pt_unprotected_mult and
  * check_prj_pt_order, curves/prj_pt.c:1835-1945) and ec_pub_key_import_from_aff_buf (sig/ec_key.c:181).
  * One job shape serves all of them: inputs as projective X || Y || Z (or the caller's affine buffers), results as affine
  * X || Y + status from the device (ec_prj_pt_op_batch_fmt / ec_prj_pt_unprotected_mult_batch of libecc_amd.h).
  * ------------------------------------------------------------------------------------------------ */
-enum { PTOP_ADD = 0, PTOP_DBL, PTOP_ON_CURVE, PTOP_UNIQUE, PTOP_UMULT, PTOP_ORDER, PTOP_PUBIMPORT };
+enum { PTOP_ADD = 0, PTOP_DBL, PTOP_ON_CURVE, PTOP_UNIQUE, PTOP_UMULT, PTOP_ORDER, PTOP_PUBIMPORT, PTOP_NEG, PTOP_CMP, PTOP_EQ_OR_OPP };
+/* the operations with a second point */
+#define PTOP_TWO(op) ((op) == PTOP_ADD || (op) == PTOP_CMP || (op) == PTOP_EQ_OR_OPP)
 typedef struct {
 	int op;
 	const prj_pt *in1, *in2;
@@ -1455,7 +1457,7 @@ typedef struct {
 	ec_pub_key *pubs;
 	const ec_params *params;
 	ec_alg_type alg;
-	int *ret_items, *flags;      /* flags: on_curve (PTOP_ON_CURVE) / check (PTOP_ORDER) */
+	int *ret_items, *flags;      /* flags: on_curve (PTOP_ON_CURVE) / check (PTOP_ORDER) / cmp (PTOP_CMP) / eq_or_opp (PTOP_EQ_OR_OPP) */
 	int need_order;              /* PTOP_PUBIMPORT on a cofactor curve: the subgroup test of ec_pub_key_import_from_aff_buf */
 	u8 *b1, *b2, *sc, *pout, *st, *pre;
 	u8 bsc[NN_MAX_BYTE_LEN];     /* the one scalar of PTOP_ORDER / PTOP_PUBIMPORT */
@@ -1479,8 +1481,8 @@ static void ptop_pack(u32 lo, u32 hi, void *arg)
 			}
 		} else {
 			bad = prj_to_be(J->b1 + (size_t)i * J->iw, J->clen, &J->in1[i], J->crv);
-			if (!bad && J->op == PTOP_ADD) {
-				/* MUST_HAVE((in1->crv == in2->crv)), curves/prj_pt.c:1210 */
+			if (!bad && PTOP_TWO(J->op)) {
+				/* MUST_HAVE((in1->crv == in2->crv)), curves/prj_pt.c:1210, :313, :418 */
 				bad = prj_to_be(J->b2 + (size_t)i * J->iw, J->clen, &J->in2[i], J->crv);
 			}
 			if (!bad && J->op == PTOP_UMULT) {
@@ -1490,7 +1492,7 @@ static void ptop_pack(u32 lo, u32 hi, void *arg)
 		J->pre[i] = bad ? 1 : 0;
 		if (bad) {
 			memset(J->b1 + (size_t)i * J->iw, 0xff, J->iw);   /* coordinates >= p: rejected at import */
-			if (J->op == PTOP_ADD) {
+			if (PTOP_TWO(J->op)) {
 				memset(J->b2 + (size_t)i * J->iw, 0xff, J->iw);
 			}
 			if (J->op == PTOP_UMULT) {
@@ -1513,6 +1515,16 @@ static int ptop_gpu(u32 lo, u32 hi, void *arg)
 		r = ecamd_multi_prj_pt_op_batch_fmt(g_multi, J->e->mc, J->op == PTOP_ADD ? ECAMD_PT_OP_ADD : (J->op == PTOP_DBL ? ECAMD_PT_OP_DBL : ECAMD_PT_OP_ON_CURVE),
 						    m, J->b1 + (size_t)lo * J->iw, J->op == PTOP_ADD ? J->b2 + (size_t)lo * J->iw : NULL, J->in_fmt, pout,
 						    ECAMD_PT_AFFINE, J->st + lo);
+		break;
+	case PTOP_NEG:
+		r = ecamd_multi_prj_pt_op_batch_fmt(g_multi, J->e->mc, ECAMD_PT_OP_NEG, m, J->b1 + (size_t)lo * J->iw, NULL, J->in_fmt, pout, ECAMD_PT_AFFINE,
+						    J->st + lo);
+		break;
+	case PTOP_CMP:
+	case PTOP_EQ_OR_OPP:
+		/* one predicate byte per item: J->pout is used with a stride of one */
+		r = ecamd_multi_prj_pt_op_batch_fmt(g_multi, J->e->mc, J->op == PTOP_CMP ? ECAMD_PT_OP_CMP : ECAMD_PT_OP_EQ_OR_OPP, m, J->b1 + (size_t)lo * J->iw,
+						    J->b2 + (size_t)lo * J->iw, J->in_fmt, J->pout + lo, ECAMD_PT_AFFINE, J->st + lo);
 		break;
 	case PTOP_UNIQUE:
 		r = ecamd_multi_prj_pt_unique_batch(g_multi, J->e->mc, m, J->b1 + (size_t)lo * J->iw, J->in_fmt, pout, ECAMD_PT_AFFINE, J->st + lo);
@@ -1553,6 +1565,11 @@ static void ptop_unpack(u32 lo, u32 hi, void *arg)
 		} else if (J->op == PTOP_ON_CURVE) {
 			J->flags[i] = (st == ECAMD_OK) ? 1 : 0;   /* the call itself succeeds for an initialised point */
 			r = 0;
+		} else if (J->op == PTOP_CMP || J->op == PTOP_EQ_OR_OPP) {
+			if (st == ECAMD_OK) {
+				J->flags[i] = J->pout[i];
+				r = 0;
+			}
 		} else if (J->op == PTOP_ORDER) {
 			if (st != ECAMD_ERR) {
 				J->flags[i] = (st == ECAMD_INF) ? 1 : 0;
@@ -1594,7 +1611,7 @@ static int ptop_run(ptop_job *J, u32 n)
 	J->iw = (J->in_fmt ? 3u : 2u) * J->clen;
 	call_enter(0);
 	J->b1 = buf_get(0, (size_t)n * J->iw);
-	J->b2 = (J->op == PTOP_ADD) ? buf_get(1, (size_t)n * J->iw) : J->b1;
+	J->b2 = PTOP_TWO(J->op) ? buf_get(1, (size_t)n * J->iw) : J->b1;
 	J->sc = (J->op == PTOP_UMULT) ? buf_get(2, (size_t)n * J->slen) : J->b1;
 	J->pout = buf_get(3, (size_t)n * 2 * J->clen);
 	J->st = buf_get(4, n);
@@ -1611,7 +1628,7 @@ static int ptop_run(ptop_job *J, u32 n)
 static int ptop_points(ptop_job *J, int op, prj_pt *out, const prj_pt *in1, const prj_pt *in2, u32 n, int *ret_items)
 {
 	memset(J, 0, sizeof(*J));
-	if (!in1 || (op == PTOP_ADD && !in2) || ((op == PTOP_ADD || op == PTOP_DBL || op == PTOP_UNIQUE || op == PTOP_UMULT) && !out)) {
+	if (!in1 || (PTOP_TWO(op) && !in2) || ((op == PTOP_ADD || op == PTOP_DBL || op == PTOP_UNIQUE || op == PTOP_UMULT || op == PTOP_NEG) && !out)) {
 		return -1;
 	}
 	if (n == 0) {
@@ -1641,6 +1658,37 @@ int prj_pt_dbl_batch(prj_pt *out, const prj_pt *in, u32 n, int *ret_items)
 {
 	ptop_job J;
 	const int r = ptop_points(&J, PTOP_DBL, out, in, NULL, n, ret_items);
+	return r <= 0 ? r : ptop_run(&J, n);
+}
+
+int prj_pt_neg_batch(prj_pt *out, const prj_pt *in, u32 n, int *ret_items)
+{
+	ptop_job J;
+	const int r = ptop_points(&J, PTOP_NEG, out, in, NULL, n, ret_items);
+	return r <= 0 ? r : ptop_run(&J, n);
+}
+
+int prj_pt_cmp_batch(const prj_pt *in1, const prj_pt *in2, u32 n, int *cmp, int *ret_items)
+{
+	ptop_job J;
+	int r;
+	if (!cmp) {
+		return -1;
+	}
+	r = ptop_points(&J, PTOP_CMP, NULL, in1, in2, n, ret_items);
+	J.flags = cmp;
+	return r <= 0 ? r : ptop_run(&J, n);
+}
+
+int prj_pt_eq_or_opp_batch(const prj_pt *in1, const prj_pt *in2, u32 n, int *eq_or_opp, int *ret_items)
+{
+	ptop_job J;
+	int r;
+	if (!eq_or_opp) {
+		return -1;
+	}
+	r = ptop_points(&J, PTOP_EQ_OR_OPP, NULL, in1, in2, n, ret_items);
+	J.flags = eq_or_opp;
 	return r <= 0 ? r : ptop_run(&J, n);
 }
 

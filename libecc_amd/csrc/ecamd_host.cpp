@@ -1957,8 +1957,9 @@ extern "C" int ec_prj_pt_dbl_batch(ecamd_ctx *ctx, const ecamd_curve *cv, uint32
 extern "C" int ec_prj_pt_op_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *cv, int op, uint32_t n, const uint8_t *p1, const uint8_t *p2,
 				      int in_fmt, uint8_t *out, int out_fmt, uint8_t *status)
 {
-	if (!ctx || !cv || cv->ctx != ctx || op < 0 || op > 2 || (in_fmt != 0 && in_fmt != 1) || (out_fmt != 0 && out_fmt != 1) ||
-	    (n && (!p1 || (op == 0 && !p2) || (op != 2 && !out) || !status))) {
+	const bool two = op == ECAMD_PT_OP_ADD || op == ECAMD_PT_OP_CMP || op == ECAMD_PT_OP_EQ_OR_OPP;
+	if (!ctx || !cv || cv->ctx != ctx || op < 0 || op > ECAMD_PT_OP_EQ_OR_OPP || (in_fmt != 0 && in_fmt != 1) ||
+	    (out_fmt != 0 && out_fmt != 1) || (n && (!p1 || (two && !p2) || (op != ECAMD_PT_OP_ON_CURVE && !out) || !status))) {
 		return fail("ec_prj_pt_op_batch_fmt: bad argument");
 	}
 	if (n == 0) {
@@ -1966,7 +1967,8 @@ extern "C" int ec_prj_pt_op_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *cv, int
 	}
 	std::lock_guard<std::mutex> lk(ctx->mu);
 	HIPCHK(hipSetDevice(ctx->device));
-	const size_t iw = (size_t)(in_fmt ? 3 : 2) * cv->clen, ow = (size_t)(out_fmt ? 3 : 2) * cv->clen;
+	// the two predicates hand back one byte per item, the other operations a point
+	const size_t iw = (size_t)(in_fmt ? 3 : 2) * cv->clen, ow = op >= ECAMD_PT_OP_CMP ? 1 : (size_t)(out_fmt ? 3 : 2) * cv->clen;
 	hipStream_t s = ctx->stream;
 	StreamScope scope(ctx, s);
 	for (uint32_t off = 0; off < n; off += ctx->max_chunk) {
@@ -1976,7 +1978,7 @@ extern "C" int ec_prj_pt_op_batch_fmt(ecamd_ctx *ctx, const ecamd_curve *cv, int
 			return -1;
 		}
 		HIPCHK(hipMemcpyAsync(ctx->stage[0], p1 + (size_t)off * iw, (size_t)m * iw, hipMemcpyHostToDevice, s));
-		if (op == 0) {
+		if (two) {
 			HIPCHK(hipMemcpyAsync(ctx->stage[1], p2 + (size_t)off * iw, (size_t)m * iw, hipMemcpyHostToDevice, s));
 		}
 		EcamdPtfArgs A;

@@ -2454,12 +2454,25 @@ template <int NW> __global__ __launch_bounds__(64) void k_ptf(EcamdPtfArgs A)
 		A.status[i] = ok ? 0 : 1;
 		return;
 	}
-	if (A.op == 0) {
+	if (A.op == 0 || A.op >= 4) {
 		ok = ok & ptf_load<NW>(Q, A.p2 + (size_t)i * iw, clen, A.in_fmt, slot);
+	}
+	if (A.op >= 4) {
+		// prj_pt_cmp (curves/prj_pt.c:303): X1 Z2 against X2 Z1 and Y1 Z2 against Y2 Z1, no special case for Z = 0 -- out byte 0
+		// where the reference's *cmp is 0, 1 where it is not (its sign is that of the Montgomery residues in the reference's
+		// word size and is not reproduced); prj_pt_eq_or_opp (:412): the X test and Y1 Z2 = +-Y2 Z1 -- out byte = *eq_or_opp
+		const bool xe = fe_eq<NW>(fe_mul<NW>(P.X, Q.Z, slot), fe_mul<NW>(Q.X, P.Z, slot));
+		const Fe<NW> y1 = fe_mul<NW>(P.Y, Q.Z, slot), y2 = fe_mul<NW>(Q.Y, P.Z, slot);
+		const bool ye = fe_eq<NW>(y1, y2), yo = fe_is_zero<NW>(fe_add<NW>(y1, y2, slot));
+		A.out[i] = !ok ? 0 : (A.op == 4 ? (u8)((xe & ye) ? 0 : 1) : (u8)((xe & (ye | yo)) ? 1 : 0));
+		A.status[i] = ok ? 0 : 1;
+		return;
 	}
 	Pt<NW> R = P;
 	bool err = !ok;
-	if (ok) {
+	if (ok && A.op == 3) {
+		R.Y = fe_sub<NW>(fe_zero<NW>(), P.Y, slot);   // prj_pt_neg (:435): (X : -Y : Z)
+	} else if (ok) {
 		R = A.op == 1 ? pt_dbl<NW>(P, slot) : pt_add<NW>(P, Q, slot);
 		err = (A.op == 0) && fe_is_zero<NW>(R.Z) && fe_is_zero<NW>(R.Y);   // the addition's exceptional pair
 	}

@@ -562,7 +562,8 @@ extern "C" int ecamd_multi_prj_pt_unique_batch(ecamd_multi *m, const ecamd_mcurv
 extern "C" int ecamd_multi_prj_pt_op_batch_fmt(ecamd_multi *m, const ecamd_mcurve *c, int op, uint32_t n, const uint8_t *p1, const uint8_t *p2,
 					       int in_fmt, uint8_t *out, int out_fmt, uint8_t *status)
 {
-	const size_t cl = (size_t)ecamd_multi_curve_coord_len(c), il = (in_fmt ? 3 : 2) * cl, ol = (out_fmt ? 3 : 2) * cl;
+	const size_t cl = (size_t)ecamd_multi_curve_coord_len(c), il = (in_fmt ? 3 : 2) * cl;
+	const size_t ol = op >= ECAMD_PT_OP_CMP ? 1 : (out_fmt ? 3 : 2) * cl;   // the predicates: one byte per item
 	return run_sharded(m, c, n, "ecamd_multi_prj_pt_op_batch_fmt", [&](int r, uint32_t lo, uint32_t hi) {
 		return ec_prj_pt_op_batch_fmt(m->ctx[(size_t)r], c->cv[(size_t)r], op, hi - lo, OFF(p1, il), p2 ? OFF(p2, il) : nullptr, in_fmt,
 					      out ? OFF(out, ol) : nullptr, out_fmt, OFF(status, 1));

@@ -1476,7 +1476,8 @@ int orc_prj_batch(const orc_curve *c, uint32_t n, const uint8_t *scalars, uint32
  *   import: fp_init_from_buf on every coordinate (each < p) and the projective curve equation (prj_pt_import_from_[aff_]buf,
  *     curves/prj_pt.c:462-552); Z = 0 is accepted when it satisfies the equation, (0 : 0 : 0) included.
  *   op 0 prj_pt_add (:1204; -1 on the exceptional pair :1058-1060), op 1 prj_pt_dbl (:1132), op 2 prj_pt_is_on_curve (:144) of an
- *     already range-checked triple (status 0 on the curve / 1 not, no output).
+ *     already range-checked triple (status 0 on the curve / 1 not, no output); op 3 prj_pt_neg (:435), op 4 prj_pt_cmp (:303) and
+ *     op 5 prj_pt_eq_or_opp (:412), the last two with one predicate byte per item as output (round 6).
  *   output: prj_pt_iszero -> status 2 (zero bytes), else prj_pt_unique + export.
  * ---------------------------------------------------------------------------------- */
 static int pt_import_fmt(pt *P, const u8 *src, int fmt, const orc_curve *c)
@@ -1507,7 +1508,8 @@ static void pt_export_fmt(u8 *dst, uint8_t *status, pt *Q, int fmt, const orc_cu
 int orc_pt_op_batch_fmt(const orc_curve *c, int op, uint32_t n, const uint8_t *p1, const uint8_t *p2, int in_fmt,
 			uint8_t *out, int out_fmt, uint8_t *status)
 {
-	const int iw = (in_fmt ? 3 : 2) * c->clen, ow = (out_fmt ? 3 : 2) * c->clen;
+	const int iw = (in_fmt ? 3 : 2) * c->clen, ow = op >= 4 ? 1 : (out_fmt ? 3 : 2) * c->clen;
+	const orc_fp_ctx *f = &c->fp;
 	uint32_t i;
 	for (i = 0; i < n; i++) {
 		pt A, B, C;
@@ -1519,7 +1521,29 @@ int orc_pt_op_batch_fmt(const orc_curve *c, int op, uint32_t n, const uint8_t *p
 		}
 		memset(out + (size_t)i * ow, 0, (size_t)ow);
 		if (pt_import_fmt(&A, p1 + (size_t)i * iw, in_fmt, c)) continue;
-		if (op == 1) {
+		if (op >= 4) {
+			/* op 4 prj_pt_cmp (curves/prj_pt.c:303-348): X1 Z2 against X2 Z1, Y1 Z2 against Y2 Z1, *cmp = x_cmp | y_cmp -- the
+			 * byte is 0 where that is 0, else 1.  op 5 prj_pt_eq_or_opp (:412-430): the X products equal (:354-376) and the
+			 * Y products equal or opposite (fp_eq_or_opp, :382-404) -- the byte is *eq_or_opp. */
+			u64 x1[ORC_MAXW], x2[ORC_MAXW], y1[ORC_MAXW], y2[ORC_MAXW], ys[ORC_MAXW];
+			int xe, ye, yo;
+			if (pt_import_fmt(&B, p2 + (size_t)i * iw, in_fmt, c)) continue;
+			fp_mul(x1, A.X, B.Z, f); fp_mul(x2, B.X, A.Z, f);
+			fp_mul(y1, A.Y, B.Z, f); fp_mul(y2, B.Y, A.Z, f);
+			fp_add(ys, y1, y2, f);
+			xe = nn_cmp(x1, x2, f->n) == 0; ye = nn_cmp(y1, y2, f->n) == 0; yo = nn_iszero(ys, f->n);
+			out[i] = (uint8_t)(op == 4 ? !(xe && ye) : (xe && (ye || yo)));
+			status[i] = 0;
+			continue;
+		}
+		if (op == 3) {
+			/* prj_pt_neg (:435-451): the copy with Y negated */
+			u64 z[ORC_MAXW];
+			nn_zero(z, ORC_MAXW);
+			C = A;
+			fp_sub(C.Y, z, A.Y, f);
+			ret = 0;
+		} else if (op == 1) {
 			ret = pt_dbl(&C, &A, c);
 		} else {
 			if (pt_import_fmt(&B, p2 + (size_t)i * iw, in_fmt, c)) continue;

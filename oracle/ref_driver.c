@@ -299,12 +299,28 @@ int refdrv_pt_op_batch_fmt(const char *curve, int op, uint32_t n, const uint8_t 
 	}
 	clen = (uint32_t)BYTECEIL(params.ec_fp.p_bitlen);
 	iw = (in_fmt ? 3u : 2u) * clen;
-	ow = (out_fmt ? 3u : 2u) * clen;
+	ow = op >= 4 ? 1u : (out_fmt ? 3u : 2u) * clen;
 	for (i = 0; i < n; i++) {
 		prj_pt A, B, C;
 		int ret, on = 0;
 		A.magic = B.magic = C.magic = WORD(0);
 		status[i] = 1;
+		if (op >= 4) {
+			/* prj_pt_cmp / prj_pt_eq_or_opp of the unmodified reference: one predicate byte per item */
+			int v = 0;
+			out[i] = 0;
+			if (ref_import_fmt(&A, p1 + (size_t)i * iw, in_fmt, clen, &params.ec_curve) ||
+			    ref_import_fmt(&B, p2 + (size_t)i * iw, in_fmt, clen, &params.ec_curve)) {
+				continue;
+			}
+			B.crv = A.crv;
+			if (op == 4 ? prj_pt_cmp(&A, &B, &v) : prj_pt_eq_or_opp(&A, &B, &v)) {
+				continue;
+			}
+			out[i] = (uint8_t)(v != 0);
+			status[i] = 0;
+			continue;
+		}
 		if (op == 2) {
 			/* prj_pt_is_on_curve of a triple whose coordinates are in range (the import tests the equation itself) */
 			status[i] = ref_import_fmt(&A, p1 + (size_t)i * iw, in_fmt, clen, &params.ec_curve) ? 1 : 0;
@@ -317,7 +333,9 @@ int refdrv_pt_op_batch_fmt(const char *curve, int op, uint32_t n, const uint8_t 
 		if (ref_import_fmt(&A, p1 + (size_t)i * iw, in_fmt, clen, &params.ec_curve)) {
 			continue;
 		}
-		if (op == 1) {
+		if (op == 3) {
+			ret = prj_pt_neg(&C, &A);
+		} else if (op == 1) {
 			ret = prj_pt_dbl(&C, &A);
 		} else {
 			if (ref_import_fmt(&B, p2 + (size_t)i * iw, in_fmt, clen, &params.ec_curve)) {

@@ -88,8 +88,8 @@ class Oracle:
         return out.raw, st.raw
 
     def pt_op_fmt(self, op, p1, p2, in_fmt, out_fmt):
-        """op 0 add / 1 dbl / 2 on-curve test; formats 0 affine X || Y, 1 projective X || Y || Z; returns (out, status)"""
-        iw, ow = (3 if in_fmt else 2) * self.clen, (3 if out_fmt else 2) * self.clen
+        """op 0 add / 1 dbl / 2 on-curve test / 3 neg / 4 cmp / 5 eq_or_opp (4, 5: one predicate byte per item); formats 0 affine X || Y, 1 projective X || Y || Z; returns (out, status)"""
+        iw, ow = (3 if in_fmt else 2) * self.clen, (1 if op >= 4 else (3 if out_fmt else 2) * self.clen)
         n = len(p1) // iw
         out, st = C.create_string_buffer(max(1, ow * n)), C.create_string_buffer(max(1, n))
         assert self.L.orc_pt_op_batch_fmt(self.ctx, op, n, p1, p2, in_fmt, out, out_fmt, st) == 0
@@ -267,7 +267,7 @@ class RefLib:
         return out.raw, st.raw
 
     def pt_op_fmt(self, op, p1, p2, in_fmt, out_fmt):
-        iw, ow = (3 if in_fmt else 2) * self.clen, (3 if out_fmt else 2) * self.clen
+        iw, ow = (3 if in_fmt else 2) * self.clen, (1 if op >= 4 else (3 if out_fmt else 2) * self.clen)
         n = len(p1) // iw
         out, st = C.create_string_buffer(max(1, ow * n)), C.create_string_buffer(max(1, n))
         assert self.L.refdrv_pt_op_batch_fmt(self.name, op, n, p1, p2, in_fmt, out, out_fmt, st) == 0

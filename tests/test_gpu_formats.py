@@ -232,7 +232,7 @@ def test_eddsa_encode_point_batch(gpu_ctx):
 @pytest.mark.gpu
 @pytest.mark.parametrize("curve", ["SECP256R1", "WEI25519", "SECP384R1", "BRAINPOOLP256R1", "SECP521R1"])
 def test_group_law_and_unprotected_mult(gpu_ctx, curve):
-    """ec_prj_pt_op_batch_fmt (prj_pt_add / prj_pt_dbl / prj_pt_is_on_curve) and ec_prj_pt_unprotected_mult_batch
+    """ec_prj_pt_op_batch_fmt (prj_pt_add / prj_pt_dbl / prj_pt_is_on_curve / prj_pt_neg / prj_pt_cmp / prj_pt_eq_or_opp) and ec_prj_pt_unprotected_mult_batch
     (_prj_pt_unprotected_mult statement for statement; one scalar for all = check_prj_pt_order) against the oracle -- itself pinned
     on the unmodified reference for exactly these cases, tests/test_oracle.py -- in both wire formats: exceptional pairs of the
     cofactor curve, infinity in its spellings, (0 : 0 : 0), off-curve and out-of-range triples, P + P and P - P through the addition"""
@@ -245,14 +245,17 @@ def test_group_law_and_unprotected_mult(gpu_ctx, curve):
     try:
         p1, p2, scal, slen = group_law_cases(curve, rng, n=40)
         n = len(p1) // (3 * cl)
-        for op in (0, 1, 2):
+        for op in (0, 1, 2, 3, 4, 5):       # add, dbl, on-curve, neg, cmp, eq_or_opp
             for out_fmt in (0, 1):
                 assert cv.pt_op_fmt(op, p1, p2, 1, out_fmt) == o.pt_op_fmt(op, p1, p2, 1, out_fmt), (op, out_fmt)
+        cmpb = cv.pt_op_fmt(4, p1, p2, 1, 0)[0]
+        eqb = cv.pt_op_fmt(5, p1, p2, 1, 0)[0]
+        assert 0 in cmpb and 1 in cmpb and 0 in eqb and 1 in eqb
         aff1, s1 = o.pt_op_fmt(1, p1, None, 1, 0)
         keep = [i for i in range(n) if s1[i] == 0]
         a1 = b"".join(aff1[2 * cl * i:2 * cl * (i + 1)] for i in keep)
         a2 = b"".join(aff1[2 * cl * i:2 * cl * (i + 1)] for i in reversed(keep))
-        for op in (0, 1, 2):
+        for op in (0, 1, 2, 3, 4, 5):
             assert cv.pt_op_fmt(op, a1, a2, 0, 1) == o.pt_op_fmt(op, a1, a2, 0, 1)
         # the old affine-only entry points are the same operation
         assert cv.pt_add(a1, a2) == o.pt_op_fmt(0, a1, a2, 0, 0)
@@ -267,6 +270,9 @@ def test_group_law_and_unprotected_mult(gpu_ctx, curve):
         P1, P2, SC = p1 * reps, p2 * reps, scal * reps
         exp = o.pt_op_fmt(0, p1, p2, 1, 1)
         assert cv.pt_op_fmt(0, P1, P2, 1, 1) == (exp[0] * reps, exp[1] * reps)
+        for op in (3, 4, 5):
+            exp = o.pt_op_fmt(op, p1, p2, 1, 1)
+            assert cv.pt_op_fmt(op, P1, P2, 1, 1) == (exp[0] * reps, exp[1] * reps)
         exp = o.unprotected_mult(scal, slen, p1, 1, 0)
         assert cv.unprotected_mult(SC, slen, P1, 1, 0) == (exp[0] * reps, exp[1] * reps)
         assert cv.pt_op_fmt(0, b"", b"", 1, 1) == (b"", b"")

@@ -69,7 +69,11 @@ def cases(cl, ql, eddsa):
             out.append(("ecamd_multi_prj_pt_mul_batch_fmt", [A(ql), u32(ql), A(il), C.c_int(fi), A(ol), C.c_int(fo), A(1)], "ec_prj_pt_mul_batch_fmt", None))
             out.append(("ecamd_multi_prj_pt_unique_batch", [A(il), C.c_int(fi), A(ol), C.c_int(fo), A(1)], "ec_prj_pt_unique_batch", None))
             out.append(("ecamd_multi_prj_pt_op_batch_fmt", [A(il), A(il), C.c_int(fi), A(ol), C.c_int(fo), A(1)], "ec_prj_pt_op_batch_fmt", 0))
-            out.append(("ecamd_multi_prj_pt_op_batch_fmt", [A(il), A(0), C.c_int(fi), A(0), C.c_int(fo), A(1)], "ec_prj_pt_op_batch_fmt", 3))
+            out.append(("ecamd_multi_prj_pt_op_batch_fmt", [A(il), A(0), C.c_int(fi), A(0), C.c_int(fo), A(1)], "ec_prj_pt_op_batch_fmt", 2))
+            out.append(("ecamd_multi_prj_pt_op_batch_fmt", [A(il), A(0), C.c_int(fi), A(ol), C.c_int(fo), A(1)], "ec_prj_pt_op_batch_fmt", 3))
+            # prj_pt_cmp / prj_pt_eq_or_opp: the output advances by ONE byte per item whatever out_fmt says
+            out.append(("ecamd_multi_prj_pt_op_batch_fmt", [A(il), A(il), C.c_int(fi), A(1), C.c_int(fo), A(1)], "ec_prj_pt_op_batch_fmt", 4))
+            out.append(("ecamd_multi_prj_pt_op_batch_fmt", [A(il), A(il), C.c_int(fi), A(1), C.c_int(fo), A(1)], "ec_prj_pt_op_batch_fmt", 5))
             out.append(("ecamd_multi_prj_pt_unprotected_mult_batch", [A(ql + 8), u32(ql + 3), u32(ql + 8), A(il), C.c_int(fi), A(ol), C.c_int(fo), A(1)],
                         "ec_prj_pt_unprotected_mult_batch", None))
             out.append(("ecamd_multi_ecdsa_verify_batch_fmt", [A(il), C.c_int(fi), A(2 * ql), A(20 + fo), u32(20 + fo), A(1)], "ec_ecdsa_verify_batch_fmt", None))

@@ -905,6 +905,9 @@ def group_law_cases(curve, rng, n=24):
     for spec in (prj(None), inf2, zero3, off, big, xz0):
         p1 += [spec, prj(pts[3])]
         p2 += [prj(pts[4]), spec]
+    # infinity against infinity in two spellings, and against the degenerate triple (prj_pt_cmp / prj_pt_eq_or_opp have no special case)
+    p1 += [prj(None), inf2, zero3]
+    p2 += [inf2, zero3, zero3]
     q = c["q"]
     ks = [0, 1, 2, 3, 4, 8, q - 1, q, q + 1, 2 * q, 8 * q, c["order"], (1 << (8 * ql)) - 1, 6, 5 * q]
     slen = ql + 1
@@ -915,7 +918,8 @@ def group_law_cases(curve, rng, n=24):
 @pytest.mark.parametrize("curve", ["SECP256R1", "WEI25519", "SECP384R1", "BRAINPOOLP256R1", "SECP521R1"])
 def test_group_law_and_unprotected_mult_vs_reference(curve):
     """the restatements behind ec_prj_pt_op_batch_fmt / ec_prj_pt_unprotected_mult_batch (round 4) against the unmodified
-    reference: prj_pt_add / prj_pt_dbl / prj_pt_is_on_curve and _prj_pt_unprotected_mult in both wire formats, with the
+    reference: prj_pt_add / prj_pt_dbl / prj_pt_is_on_curve / prj_pt_neg / prj_pt_cmp / prj_pt_eq_or_opp and
+    _prj_pt_unprotected_mult in both wire formats, with the
     exceptional pairs of the cofactor curve, infinity in its several spellings, (0 : 0 : 0), off-curve and out-of-range input"""
     from oracles import clen
     if not have_ref():
@@ -925,9 +929,15 @@ def test_group_law_and_unprotected_mult_vs_reference(curve):
     p1, p2, scal, slen = group_law_cases(curve, rng)
     cl = clen(curve)
     n = len(p1) // (3 * cl)
-    for op in (0, 1, 2):
+    for op in (0, 1, 2, 3, 4, 5):
         for out_fmt in (0, 1):
             assert o.pt_op_fmt(op, p1, p2, 1, out_fmt) == r.pt_op_fmt(op, p1, p2, 1, out_fmt), (curve, op, out_fmt)
+    # prj_pt_cmp / prj_pt_eq_or_opp (round 6): equal, opposite and different pairs are all there
+    cmpb, cst = o.pt_op_fmt(4, p1, p2, 1, 0)
+    eqb, est = o.pt_op_fmt(5, p1, p2, 1, 0)
+    assert cst == est and 0 in cst and 1 in cst
+    assert any(cmpb[i] == 0 and eqb[i] == 1 for i in range(n)) and any(cmpb[i] == 1 and eqb[i] == 1 for i in range(n))
+    assert any(cmpb[i] == 1 and eqb[i] == 0 and cst[i] == 0 for i in range(n))
     st = o.pt_op_fmt(0, p1, p2, 1, 0)[1]
     assert 0 in st and 1 in st and 2 in st
     if curve == "WEI25519":
@@ -940,7 +950,7 @@ def test_group_law_and_unprotected_mult_vs_reference(curve):
     keep = [i for i in range(n) if s1[i] == 0]
     a1 = b"".join(aff1[2 * cl * i:2 * cl * (i + 1)] for i in keep)
     a2 = b"".join(aff1[2 * cl * i:2 * cl * (i + 1)] for i in reversed(keep))
-    for op in (0, 1, 2):
+    for op in (0, 1, 2, 3, 4, 5):
         assert o.pt_op_fmt(op, a1, a2, 0, 1) == r.pt_op_fmt(op, a1, a2, 0, 1)
     # _prj_pt_unprotected_mult: per-item scalars, then one scalar for all (check_prj_pt_order's use)
     got, exp = o.unprotected_mult(scal, slen, p1, 1, 1), r.unprotected_mult(scal, slen, p1, 1, 1)
