@@ -491,7 +491,7 @@ class Curve:
 
     # -- device-pointer forms (torch tensors' data_ptr()); see include/libecc_amd.h for which ones synchronise --
     def eddsa_verify_all_dev(self, n, d_pubs, d_sigs, d_hram, d_verdict, stream=None):
-        _chk(self.L, self.L.ec_eddsa_verify_all_batch_dev(self.ctx.h, self.h, n, d_pubs, d_sigs, d_hram, 64, d_verdict, stream),
+        _chk(self.L, self.L.ec_eddsa_verify_all_batch_dev(self.ctx.h, self.h, n, d_pubs, d_sigs, d_hram, 114 if self.clen == 56 else 64, d_verdict, stream),
              "ec_eddsa_verify_all_batch_dev")
 
     def schnorr_verify_all_dev(self, n, d_s, d_ne, d_keys, d_r, r_fmt, d_verdict, stream=None):

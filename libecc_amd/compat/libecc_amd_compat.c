@@ -3742,8 +3742,9 @@ static int eddsa_group(ver_job *J, u32 cnt, int *results)
 	if (getenv("ECAMD_COMPAT_TIMING")) {
 		fprintf(stderr, "libecc_amd compat timing: EdDSA group of %u items: %s, dom2 prefix %u octets\n", cnt, one_pass ? "one device call" : "two passes", J->dom_len);
 	}
-	if (one_pass && J->all_only && !J->ph && !J->is448 && ed_msm_wanted(cnt)) {
-		/* ec_verify_batch of a large Ed25519 batch: the batch equation first (round 6); it vouches for VALID batches only */
+	if (one_pass && J->all_only && !J->ph && ed_msm_wanted(cnt)) {
+		/* ec_verify_batch of a large Ed25519 / Ed25519ctx / Ed448 batch: the batch equation first (round 6; Ed448: on the Weierstrass model with
+		 * the cofactored final test); it vouches for VALID batches only */
 		J->all_ok = 1;
 		J->any_fail = 0;
 		if (verify_pipeline(cnt, eddsa_pack_prj, eddsa_ver_gpu_prj_all, NULL, J)) {

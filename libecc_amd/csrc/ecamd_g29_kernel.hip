@@ -695,9 +695,15 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_msm_sum_g(co
 // sum + [c]G = infinity  <=>  both infinite, or X = x Z^2 and Y = -y Z^3 with (x, y) = [c]G affine (as the comb path exported it)
 template <int PB, int FLAV>
 __global__ __launch_bounds__(64) void k_msm_final_g(const u32 *in, const u8 *gen, const u8 *gen_status, u32 clen, const u32 *flagword, u8 *verdict,
-						     u32 *sum_out, int gslot)
+						     u32 *sum_out, int gslot, u32 cof_dbl);
+template <int PB> static __device__ __forceinline__ void bkt_add_aff(Jac<PB> &acc, bool &inf, const typename Cls<PB>::FA &X2, const typename Cls<PB>::FA &Y2,
+								      const typename Cls<PB>::FA &onez, const CurveG<Cfg<PB>::NL> &K);
+template <int PB, int FLAV>
+__global__ __launch_bounds__(64) void k_msm_final_g(const u32 *in, const u8 *gen, const u8 *gen_status, u32 clen, const u32 *flagword, u8 *verdict,
+						     u32 *sum_out, int gslot, u32 cof_dbl)
 {
 	typedef Lay<PB> L;
+	typedef typename Cls<PB>::FA FA;
 	typedef typename Cls<PB>::FM FM;
 	typedef typename Cls<PB>::FC FC;
 	constexpr int NL = L::NL, RECW = MsmLay<PB>::RECW;
@@ -715,7 +721,27 @@ __global__ __launch_bounds__(64) void k_msm_final_g(const u32 *in, const u8 *gen
 	const bool sinf = in[L::ENTW] != 0u;
 	const u32 gst = gen_status[0];
 	bool ok = false;
-	if (gst == 2u) {
+	if (cof_dbl != 0u) {
+		// EdDSA's cofactored equation: T = sum + [c]G by the complete addition, doubled cof_dbl times, must be the point at infinity
+		// (_eddsa_verify_batch, sig/eddsa.c:2580-2860: every point of its combination enters multiplied by the cofactor)
+		Jac<PB> T = S;
+		bool tinf = sinf;
+		ok = gst == 0u || gst == 2u;
+		if (gst == 0u) {
+			EcamdSmulArgs G;
+			G.points = gen;
+			G.pstride = 2u * clen;
+			G.clen = clen;
+			FM xg, yg;
+			ok = import_point<PB>(G, 0, xg, yg, K);
+			bkt_add_aff<PB>(T, tinf, weaken<FA>(xg), weaken<FA>(yg), weaken<FA>(onec), K);
+		}
+		for (u32 d = 0; d < cof_dbl && !tinf; d++) {
+			T = dbl(T, K);
+			tinf = is_zero_mulout(mulc(T.Z, onec, K), K);
+		}
+		ok = ok & tinf;
+	} else if (gst == 2u) {
 		ok = sinf;
 	} else if (gst == 0u && !sinf) {
 		EcamdSmulArgs G;
@@ -775,6 +801,7 @@ template <int PB> static __device__ __forceinline__ void bkt_add(Jac<PB> &acc, b
 		const auto d = carry(sub_auto<1>(s2, s1, K));
 		if (is_zero_mulout(mulc(d, onec, K), K)) {
 			S = dbl(acc, K);
+			cancel = is_zero_mulout(mulc(S.Z, onec, K), K);   // the double of a point of order two (curves of even order only)
 		} else {
 			cancel = true;
 		}
@@ -800,6 +827,7 @@ template <int PB> static __device__ __forceinline__ void bkt_add_aff(Jac<PB> &ac
 		const auto d = carry(sub_auto<1>(s2, mulc(acc.Y, onec, K), K));
 		if (is_zero_mulout(mulc(d, onec, K), K)) {
 			S = dbl(acc, K);
+			cancel = is_zero_mulout(mulc(S.Z, onec, K), K);   // the double of a point of order two (curves of even order only)
 		} else {
 			cancel = true;
 		}
@@ -1009,13 +1037,23 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_bkt_window_g
 		return;
 	}
 	const CurveG<NL> &K = TabGP<PB>::get(gslot);
+	const typename Cls<PB>::FC onec = constant<typename Cls<PB>::FC>(K.one);
 	bool inf;
 	Jac<PB> acc = bkt_rec_load<PB>(V.U + (size_t)win * RECW, inf);
+	// a doubling of a placeholder is harmless (`inf` keeps it out of the sums); a doubling that REACHES infinity -- a sum of order two, on a
+	// curve of even order only -- is noticed: one test per doubling in a kernel of nwin lanes
+	auto dbl_exact = [&]() {
+		acc = dbl(acc, K);
+		if (!inf && is_zero_mulout(mulc(acc.Z, onec, K), K)) {
+			inf = true;
+			acc = bkt_blank<PB>(K);
+		}
+	};
 #pragma unroll 1
 	for (u32 k = V.ncarry; k-- > 0;) {
 #pragma unroll 1
-		for (int d = 0; d < 4; d++) {      // x 16 (a doubling of a placeholder is harmless: `inf` keeps it out of the sums)
-			acc = dbl(acc, K);
+		for (int d = 0; d < 4; d++) {      // x 16
+			dbl_exact();
 		}
 		bool cinf;
 		const Jac<PB> P = bkt_rec_load<PB>(V.C[k] + (size_t)win * RECW, cinf);
@@ -1023,7 +1061,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_bkt_window_g
 	}
 #pragma unroll 1
 	for (u32 d = 0; d < V.c * win; d++) {
-		acc = dbl(acc, K);
+		dbl_exact();
 	}
 	bkt_rec_store<PB>(V.out + (size_t)win * RECW, acc, inf);
 }
@@ -4664,7 +4702,7 @@ hipError_t G29_CAT(ecamd_g29_msm_, G29_TAG)(int gslot, int phase, const EcamdMsm
 	} else if (phase == 13) {
 		// the comparison with -[c]G alone (the total of phase 12 rests behind the window records of the reduction's last half)
 		hipLaunchKernelGGL((k_msm_final_g<G29_PB, G29_FLAV>), dim3(1), dim3(64), 0, s, (const uint32_t *)tmp, gen, gen_status, a.clen, (const uint32_t *)a.flagword,
-				   verdict, sum_out, gslot);
+				   verdict, sum_out, gslot, a.cof_dbl);
 	} else if (phase == 12) {
 		// the reduction: levels of BKT_FOLD over the bucket sums, ping-pong between the two halves of a.red; then the windows, their total,
 		// and the comparison with -[c]G
@@ -4728,7 +4766,7 @@ hipError_t G29_CAT(ecamd_g29_msm_, G29_TAG)(int gslot, int phase, const EcamdMsm
 		}
 		(void)RECW;
 		hipLaunchKernelGGL((k_msm_final_g<G29_PB, G29_FLAV>), dim3(1), dim3(64), 0, s, (const uint32_t *)src, gen, gen_status, a.clen, (const uint32_t *)a.flagword,
-				   verdict, sum_out, gslot);
+				   verdict, sum_out, gslot, a.cof_dbl);
 	}
 	return hipGetLastError();
 }

@@ -3809,6 +3809,127 @@ static int eddsa448_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t 
 	return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 6: Ed448 whole-batch verification (SURVEY.md 8 row f4 for EDDSA448 / EDDSA448PH; _eddsa_verify_batch, sig/eddsa.c:2580-2860, serves both
+// EdDSA curves).  The reference's combination  sum [cof z_i]R_i + sum [z_i 4 h_i][cof]A'_i + [-sum z_i S_i][cof]G = infinity  on the Weierstrass
+// model is, on the prime-order components, the Schnorr-type equation  [sum z_i S_i]G + sum [z_i (q - h_i)]A_i - sum [z_i]R_i  of
+// schnorr_msm_dev_locked with its final test cofactored: the decoding of eddsa448_verify_dev_locked (A_i, R_i as affine points of WEI448), S_i
+// and (q - h_i) mod q from k_ed448_scal, the reference's per-item rejections as one gate word (k_ed_msm_gate), then the multi-scalar
+// multiplication on the Goldilocks unit -- by buckets from 2^17 items on, the Straus loop below -- ending in [4](sum + [c]G) = infinity.
+// Soundness as for the item form: [4] kills every torsion component, so scalars taken mod q and the decoded (not the stored [4^-1]A) key are
+// exact; a batch with an item that fails its cofactored equation passes with probability ~2^-128.  d_verdict[0] is SET to 1 for "not
+// decided here" and never cleared (the pieces of one call share it).  Only enqueues.
+// ------------------------------------------------------------------------------------------
+static int msm_seed(ecamd_ctx *ctx, uint8_t seed[32]);
+static bool schnorr_msm_unit(const ecamd_curve *cv, int *pbits, int *flavour, int *slot);
+static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_s, const uint8_t *d_ne, const uint8_t *d_keys,
+				  const uint8_t *d_r, int r_fmt, const uint8_t seed[32], uint32_t piece, uint8_t *d_verdict, uint8_t *d_z_dump,
+				  uint32_t *d_sum_dump, hipStream_t s, uint32_t cof_dbl = 0);
+static bool eddsa448_msm_available(const ecamd_curve *cv)
+{
+	int pb, fl, sl;
+	return cv->pbits == 448 && cv->ed448_state == 1 && cv->nw == 14 && cv->cofactor == 4 && cv->qslot >= 0 && cv->qbits >= 160 &&
+	       schnorr_msm_unit(cv, &pb, &fl, &sl);
+}
+
+static int eddsa448_msm_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig, const uint8_t *d_hram,
+				   const uint8_t seed[32], uint32_t piece, uint8_t *d_verdict, hipStream_t s)
+{
+	if (n == 0 || n > ctx->max_chunk) {
+		return fail("internal: eddsa448_msm_dev_locked serves one piece of at most max_chunk items");
+	}
+	const size_t len = 56, plen = 112;
+	// stage: 3 A (Weierstrass, affine), 4 R, 5 flagsA, 6 flagsR, 7 flagsS, 8 S, 9 k (unused here), 12 (q - h) mod q, 13 gate word + piece verdict
+	size_t need[ECAMD_NSTAGE] = {0};
+	need[3] = need[4] = n * plen;
+	need[5] = need[6] = need[7] = n;
+	need[8] = need[9] = need[12] = n * len;
+	need[13] = 256;
+	for (int i = 0; i < 16; i++) {
+		if (need[i] && ensure(&ctx->stage[i], &ctx->stage_bytes[i], need[i])) {
+			return -1;
+		}
+	}
+	uint8_t **S = ctx->stage;
+	EcamdEd448DecodeArgs D = cv->ed448_tmpl;
+	D.n = n;
+	D.encA = d_pub;
+	D.strideA = 57;
+	D.encR = d_sig;
+	D.strideR = 114;
+	D.pointsA = S[3];
+	D.pointsR = S[4];
+	D.flagsA = S[5];
+	D.flagsR = S[6];
+	if (cv->gflavour == 5 && cv->gslot >= 0 && getenv("ECAMD_NO_G448_DECODE") == nullptr) {
+		HIPCHK(ecamd_launch_ed448_decode_g(D, cv->gslot, s));
+	} else {
+		HIPCHK(ecamd_launch_ed448_decode(D, s));
+	}
+	EcamdEdScalArgs C;
+	memset(&C, 0, sizeof(C));
+	C.sigs = d_sig;
+	C.hram = d_hram;
+	C.S_be = S[8];
+	C.h_be = S[9];
+	C.ne_be = S[12];
+	C.flags = S[7];
+	C.n = n;
+	C.len = 57;
+	C.hlen = 114;
+	C.qslot = cv->qslot;
+	C.c4_mod4 = cv->ed448_c4[55] & 3u;
+	HIPCHK(ecamd_launch_ed448_scal(C, s));
+	uint32_t *d_gate = (uint32_t *)S[13];
+	uint8_t *d_piece = S[13] + 16;
+	HIPCHK(hipMemsetAsync(S[13], 0, 16, s));
+	HIPCHK(hipMemsetAsync(d_piece, 1, 1, s));
+	HIPCHK(ecamd_launch_ed_msm_gate(cv->nw, S[3], S[5], S[6], S[7], n, (uint32_t)len, 2, cv->slot, d_gate, s));
+	{
+		PublicScalars pub_scope(ctx);   // everything a verification multiplies by is public
+		if (schnorr_msm_dev_locked(ctx, cv, n, S[8], S[12], S[3], S[4], 0, seed, piece, d_piece, nullptr, nullptr, s, 2)) {
+			return -1;
+		}
+	}
+	HIPCHK(ecamd_launch_verdict_or(d_verdict, d_piece, d_gate, s));
+	return 0;
+}
+
+// host arrays -> one verdict: pieces of max_chunk items, each with its own combination.  *accept = 1 when every piece accepts.
+static int eddsa448_msm_host_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *pubkeys, const uint8_t *sigs, const uint8_t *hram,
+				    int *accept)
+{
+	uint8_t seed[32];
+	if (msm_seed(ctx, seed)) {
+		return -1;
+	}
+	hipStream_t s = ctx->stream;
+	StreamScope scope(ctx, s);
+	const uint32_t chunk = n < ctx->max_chunk ? n : ctx->max_chunk;
+	if (ensure(&ctx->stage[0], &ctx->stage_bytes[0], (size_t)chunk * 57) || ensure(&ctx->stage[1], &ctx->stage_bytes[1], (size_t)chunk * 114) ||
+	    ensure(&ctx->stage[2], &ctx->stage_bytes[2], (size_t)chunk * 114) || ensure(&ctx->stage[14], &ctx->stage_bytes[14], 256)) {
+		return -1;
+	}
+	uint8_t *d_verdict = ctx->stage[14];
+	HIPCHK(hipMemsetAsync(d_verdict, 0, 1, s));
+	for (uint32_t off = 0, pc = 0; off < n; off += chunk, pc++) {
+		const uint32_t m = (n - off) < chunk ? (n - off) : chunk;
+		HIPCHK(hipMemcpyAsync(ctx->stage[0], pubkeys + (size_t)off * 57, (size_t)m * 57, hipMemcpyHostToDevice, s));
+		HIPCHK(hipMemcpyAsync(ctx->stage[1], sigs + (size_t)off * 114, (size_t)m * 114, hipMemcpyHostToDevice, s));
+		HIPCHK(hipMemcpyAsync(ctx->stage[2], hram + (size_t)off * 114, (size_t)m * 114, hipMemcpyHostToDevice, s));
+		if (eddsa448_msm_dev_locked(ctx, cv, m, ctx->stage[0], ctx->stage[1], ctx->stage[2], seed, pc, d_verdict, s)) {
+			(void)hipStreamSynchronize(s);
+			return -1;
+		}
+	}
+	uint8_t v = 1;
+	HIPCHK(hipMemcpyAsync(&v, d_verdict, 1, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	memset(seed, 0, sizeof(seed));
+	*accept = v == 0;
+	return 0;
+}
+
 static int eddsa_args_ok(const char *fn, ecamd_ctx *ctx, const ecamd_curve *cv_in, uint32_t n, const void *a, const void *b,
 			 const void *c, const void *d, uint32_t hram_len)
 {
@@ -3928,6 +4049,9 @@ static int eddsa_sign_setup(const char *fn, ecamd_ctx *ctx, const ecamd_curve *c
 // a_offset + 32 of the slot's message, which the caller leaves blank; the caller's array itself is not written), so one call replaces encode / copy back / build the inputs /
 // verify.  A key that does not import (coordinates >= p, not on the curve) or is the point at infinity rejects its item.
 static bool eddsa_msm_available(const ecamd_curve *cv);
+static bool eddsa448_msm_available(const ecamd_curve *cv);
+static int eddsa448_msm_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig, const uint8_t *d_hram,
+				   const uint8_t seed[32], uint32_t piece, uint8_t *d_verdict, hipStream_t s);
 static int msm_seed(ecamd_ctx *ctx, uint8_t seed[32]);
 static void msm_seed_discard(ecamd_ctx *ctx);
 static int eddsa_msm_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig,
@@ -3973,11 +4097,11 @@ static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd
 	uint32_t done = 0;
 	if (all_valid) {
 		*all_valid = 0;
-		if (e448 || !eddsa_msm_available(cv)) {
+		if (e448 ? !eddsa448_msm_available(cv) : !eddsa_msm_available(cv)) {
 			return 0;   // not decided here
 		}
-		if (msm_seed(ctx, seed) || ensure(&ctx->stage[24], &ctx->stage_bytes[24], (size_t)n * 32) || ensure(&ctx->stage[25], &ctx->stage_bytes[25], (size_t)n * 64) ||
-		    ensure(&ctx->stage[26], &ctx->stage_bytes[26], (size_t)n * 64) || ensure(&ctx->stage[27], &ctx->stage_bytes[27], (size_t)n + 256)) {
+		if (msm_seed(ctx, seed) || ensure(&ctx->stage[24], &ctx->stage_bytes[24], (size_t)n * kl) || ensure(&ctx->stage[25], &ctx->stage_bytes[25], (size_t)n * sl) ||
+		    ensure(&ctx->stage[26], &ctx->stage_bytes[26], (size_t)n * hl) || ensure(&ctx->stage[27], &ctx->stage_bytes[27], (size_t)n + 256)) {
 			return -1;
 		}
 	}
@@ -4023,9 +4147,9 @@ static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd
 			if (ecdsa_hash_stage(ctx, hash_type, m, slots, stride, hl, s)) {
 				return -1;
 			}
-			HIPCHK(hipMemcpyAsync(ctx->stage[24] + (size_t)done * 32, ctx->stage[22], (size_t)m * 32, hipMemcpyDeviceToDevice, s));
-			HIPCHK(hipMemcpyAsync(ctx->stage[25] + (size_t)done * 64, ip[1], (size_t)m * 64, hipMemcpyDeviceToDevice, s));
-			HIPCHK(hipMemcpyAsync(ctx->stage[26] + (size_t)done * 64, ctx->stage[17], (size_t)m * 64, hipMemcpyDeviceToDevice, s));
+			HIPCHK(hipMemcpyAsync(ctx->stage[24] + (size_t)done * kl, ctx->stage[22], (size_t)m * kl, hipMemcpyDeviceToDevice, s));
+			HIPCHK(hipMemcpyAsync(ctx->stage[25] + (size_t)done * sl, ip[1], (size_t)m * sl, hipMemcpyDeviceToDevice, s));
+			HIPCHK(hipMemcpyAsync(ctx->stage[26] + (size_t)done * hl, ctx->stage[17], (size_t)m * hl, hipMemcpyDeviceToDevice, s));
 			HIPCHK(hipMemcpyAsync(ctx->stage[27] + (size_t)done, ctx->stage[23], m, hipMemcpyDeviceToDevice, s));
 			done += m;
 			return 0;
@@ -4049,8 +4173,10 @@ static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd
 	uint32_t pc = 0;
 	for (uint32_t off = 0; off < n; off += ctx->max_chunk, pc++) {
 		const uint32_t m = (n - off) < ctx->max_chunk ? (n - off) : ctx->max_chunk;
-		if (eddsa_msm_dev_locked(ctx, cv, m, ctx->stage[24] + (size_t)off * 32, ctx->stage[25] + (size_t)off * 64, ctx->stage[26] + (size_t)off * 64, seed, pc,
-					 d_verdict, nullptr, nullptr, s)) {
+		if (e448 ? eddsa448_msm_dev_locked(ctx, cv, m, ctx->stage[24] + (size_t)off * kl, ctx->stage[25] + (size_t)off * sl, ctx->stage[26] + (size_t)off * hl,
+						   seed, pc, d_verdict, s)
+			 : eddsa_msm_dev_locked(ctx, cv, m, ctx->stage[24] + (size_t)off * 32, ctx->stage[25] + (size_t)off * 64, ctx->stage[26] + (size_t)off * 64, seed, pc,
+						d_verdict, nullptr, nullptr, s)) {
 			(void)hipStreamSynchronize(s);
 			return -1;
 		}
@@ -4475,8 +4601,9 @@ static uint32_t schnorr_bkt_window(uint32_t) { return 16u; }
 
 static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_s, const uint8_t *d_ne, const uint8_t *d_keys,
 				  const uint8_t *d_r, int r_fmt, const uint8_t seed[32], uint32_t piece, uint8_t *d_verdict, uint8_t *d_z_dump,
-				  uint32_t *d_sum_dump, hipStream_t s)
+				  uint32_t *d_sum_dump, hipStream_t s, uint32_t cof_dbl)
 {
+	// cof_dbl > 0 (eddsa448_msm_dev_locked only): the final test is [2^cof_dbl](sum + [c]G) = infinity, EdDSA's cofactored equation
 	int pbits = 0, flav = 0, gslot = -1;
 	if (!schnorr_msm_unit(cv, &pbits, &flav, &gslot) || cv->qslot < 0) {
 		return fail("internal: Schnorr multi-scalar multiplication without a radix-2^29 unit");
@@ -4619,6 +4746,7 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 	A.wlen = (uint32_t)ql;
 	A.zlen = 16;
 	A.r_fmt = (uint32_t)r_fmt;
+	A.cof_dbl = cof_dbl;
 	if (buckets) {
 		A.pts = (uint32_t *)(M + o_tbl);
 		A.bsum = (uint32_t *)(M + o_rec);
@@ -5025,8 +5153,9 @@ static int eddsa_verify_all_batch_dev_impl(ecamd_ctx *ctx, const ecamd_curve *cv
 		return -1;
 	}
 	ecamd_curve *cv = const_cast<ecamd_curve *>(cv_in);
-	if (n == 0 || !eddsa_msm_available(cv)) {
-		return fail("ec_eddsa_verify_all_batch_dev: needs n > 0 and Ed25519 (the WEI25519 handle on the 2^255 - 19 unit)");
+	const bool e448 = cv->pbits == 448;
+	if (n == 0 || (e448 ? !eddsa448_msm_available(cv) : !eddsa_msm_available(cv))) {
+		return fail("ec_eddsa_verify_all_batch_dev: needs n > 0 and Ed25519 (the WEI25519 handle on the 2^255 - 19 unit) or Ed448 (WEI448 on the Goldilocks unit)");
 	}
 	uint8_t seed[32];
 	if (msm_seed(ctx, seed)) {
@@ -5039,6 +5168,13 @@ static int eddsa_verify_all_batch_dev_impl(ecamd_ctx *ctx, const ecamd_curve *cv
 	uint32_t pc = 0;
 	for (uint32_t off = 0; off < n; off += ctx->max_chunk, pc++) {
 		const uint32_t m = (n - off) < ctx->max_chunk ? (n - off) : ctx->max_chunk;
+		if (e448) {
+			if (eddsa448_msm_dev_locked(ctx, cv, m, (const uint8_t *)d_pubkeys + (size_t)off * 57, (const uint8_t *)d_sigs + (size_t)off * 114,
+						    (const uint8_t *)d_hram + (size_t)off * 114, seed, pc, (uint8_t *)d_verdict, s)) {
+				return -1;
+			}
+			continue;
+		}
 		if (eddsa_msm_dev_locked(ctx, cv, m, (const uint8_t *)d_pubkeys + (size_t)off * 32, (const uint8_t *)d_sigs + (size_t)off * 64,
 					 (const uint8_t *)d_hram + (size_t)off * 64, seed, pc, (uint8_t *)d_verdict, nullptr, nullptr, s)) {
 			return -1;
@@ -5121,6 +5257,27 @@ static int eddsa_verify_all_batch_impl(ecamd_ctx *ctx, const ecamd_curve *cv, ui
 				HIPCHK(hipSetDevice(ctx->device));
 				int accept = 0;
 				if (eddsa_msm_host_locked(ctx, cw, n, pubkeys, sigs, hram, nullptr, &accept, nullptr, nullptr)) {
+					return -1;
+				}
+				if (accept) {
+					*all_valid = 1;
+					return 0;
+				}
+			}
+		}
+	}
+	// Ed448 (round 6): the same, on the Weierstrass model with the cofactored final test (eddsa448_msm_dev_locked)
+	if (ctx && cv && cv->ctx == ctx && pubkeys && sigs && hram && hram_len == 114 && cv->pbits == 448) {
+		std::lock_guard<std::mutex> lk(ctx->mu);
+		ecamd_curve *cw = const_cast<ecamd_curve *>(cv);
+		if (ctx->eddsa_msm != 0 && (ctx->eddsa_msm == 2 || n >= ctx->msm_min)) {
+			if (cw->ed448_state == 0) {
+				ed448_setup(cw);
+			}
+			if (eddsa448_msm_available(cw)) {
+				HIPCHK(hipSetDevice(ctx->device));
+				int accept = 0;
+				if (eddsa448_msm_host_locked(ctx, cw, n, pubkeys, sigs, hram, &accept)) {
 					return -1;
 				}
 				if (accept) {

@@ -319,6 +319,8 @@ struct EcamdMsmArgs {
 	                             //     buckets have cap_top slots, behind the (top_win << c) x cap slots of the windows below (ecamd_bkt_slot)
 	uint32_t pt_first, pt_count; // phase 10: the point indices [pt_first, pt_first + pt_count) of the 2n (count 0: all of them)
 	uint32_t win_first, win_count;   // phase 11: the windows [win_first, win_first + win_count) (count 0: all of them)
+	uint32_t cof_dbl;            // the final test (k_msm_final_g): 0: sum + [c]G is the point at infinity; d > 0: [2^d](sum + [c]G) is -- EdDSA's
+	                             //     cofactored equation on a curve of order 2^d q (Ed448 on WEI448: d = 2)
 };
 uint32_t ecamd_g29_bkt_point_words(int pbits, int flavour);
 // the counting sort of the (window, digit, point) triples (ecamd_kernels.hip); point index i < n: Y_i with scalar scW[i], n + i: R_i with scZ[i]
@@ -365,6 +367,7 @@ struct EcamdEdScalArgs {
 	const uint8_t *sigs;     // n x 2*len: R || S
 	const uint8_t *hram;     // n x hlen: H(dom || R || A || M), little-endian integer
 	uint8_t *S_be, *h_be;    // out: n x len big-endian scalars S and h mod q
+	uint8_t *ne_be;          // out, may be NULL (k_ed448_scal only): n x len big-endian (q - h) mod q, the key's scalar of the batch equation
 	uint8_t *flags;          // out: n, 1 when S >= q
 	uint32_t n, len, hlen;
 	int qslot;
@@ -427,6 +430,12 @@ hipError_t ecamd_launch_ed_sign_enc(const EcamdEdSignArgs &a, hipStream_t s);
 hipError_t ecamd_launch_ed_sign_S(const EcamdEdSignArgs &a, hipStream_t s);
 hipError_t ecamd_launch_ed448_decode(const EcamdEd448DecodeArgs &a, hipStream_t s);
 hipError_t ecamd_launch_ed448_scal(const EcamdEdScalArgs &a, hipStream_t s);
+// Ed448 whole-batch verification (round 6), the reference's per-item rejections ahead of the batch equation: gate[0] |= 1 when some item has a
+// decoding flag set (A, R -- the neutral element included --, S >= q) or a key with [2^cof_dbl]A = infinity (keys: n x 2*clen affine big-endian)
+hipError_t ecamd_launch_ed_msm_gate(int nw, const uint8_t *keys_aff, const uint8_t *flagsA, const uint8_t *flagsR, const uint8_t *flagsS, uint32_t n,
+				    uint32_t clen, uint32_t cof_dbl, int slot, uint32_t *gate, hipStream_t s);
+// verdict[0] = 1 when piece[0] != 0 or gate[0] != 0 (never cleared: the pieces of one call share the byte)
+hipError_t ecamd_launch_verdict_or(uint8_t *verdict, const uint8_t *piece, const uint32_t *gate, hipStream_t s);
 hipError_t ecamd_launch_ed_decode(int nw, const EcamdEdDecodeArgs &a, hipStream_t s);
 // the same two front-end kernels on the radix-2^29 field of the 2^255 - 19 unit (gslot: its constant slot)
 hipError_t ecamd_launch_ed_decode_c25519(const EcamdEdDecodeArgs &a, int gslot, hipStream_t s);

@@ -1537,7 +1537,40 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed448_scal(EcamdEdScal
 	}
 	fe_store_be<NW>(A.S_be + (size_t)i * 56, 56, ok ? S : fe_zero<NW>());
 	fe_store_be<NW>(A.h_be + (size_t)i * 56, 56, k);
+	if (A.ne_be != nullptr) {
+		// the whole-batch form works on the prime-order components only (its test is cofactored): the key's scalar is -h mod q
+		fe_store_be<NW>(A.ne_be + (size_t)i * 56, 56, fe_sub<NW>(fe_zero<NW>(), h, qs));
+	}
 	A.flags[i] = ok ? 0 : 1;
+}
+
+// Ed448 whole-batch verification: what _eddsa_verify_batch (sig/eddsa.c:2580-2860) rejects item by item before its combination -- a key or a
+// commitment that does not decode (:2766), S >= q (:2783), [cofactor]A = infinity (:2801-2806) -- as one word for the batch.  A commitment
+// that decodes to the neutral element has no affine Weierstrass form: "not decided here" as well (the item form accepts it).
+template <int NW> __global__ __launch_bounds__(64) void k_ed_msm_gate(const u8 *keys, const u8 *fA, const u8 *fR, const u8 *fS, u32 n, u32 clen, u32 cof_dbl,
+								       int slot, u32 *gate)
+{
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= n) {
+		return;
+	}
+	bool bad = (fA[i] | fR[i] | fS[i]) != 0;
+	if (!bad) {
+		Pt<NW> K4 = ed_load_neg<NW>(keys + (size_t)i * 2 * clen, 0, (int)clen, false, slot);
+		for (u32 k = 0; k < cof_dbl; k++) {
+			K4 = pt_dbl<NW>(K4, slot);
+		}
+		bad = fe_is_zero<NW>(K4.Z);
+	}
+	if (bad) {
+		atomicOr(gate, 1u);
+	}
+}
+__global__ void k_verdict_or(u8 *verdict, const u8 *piece, const u32 *gate)
+{
+	if (blockIdx.x == 0 && threadIdx.x == 0 && ((piece && piece[0] != 0) || (gate && gate[0] != 0u))) {
+		verdict[0] = 1;
+	}
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2717,6 +2750,25 @@ hipError_t ecamd_launch_ed448_scal(const EcamdEdScalArgs &a, hipStream_t s)
 		return hipSuccess;
 	}
 	hipLaunchKernelGGL(k_ed448_scal<14>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_ed_msm_gate(int nw, const uint8_t *keys_aff, const uint8_t *flagsA, const uint8_t *flagsR, const uint8_t *flagsS, uint32_t n,
+				    uint32_t clen, uint32_t cof_dbl, int slot, uint32_t *gate, hipStream_t s)
+{
+	if (n == 0) {
+		return hipSuccess;
+	}
+	if (nw != 14) {
+		return hipErrorInvalidValue;   // Ed448 on the WEI448 handle (Ed25519 has its own combination: k_edmsm_*, k_edbkt_*)
+	}
+	hipLaunchKernelGGL(k_ed_msm_gate<14>, dim3((n + 63) / 64), dim3(64), 0, s, keys_aff, flagsA, flagsR, flagsS, n, clen, cof_dbl, slot, gate);
+	return hipGetLastError();
+}
+
+hipError_t ecamd_launch_verdict_or(uint8_t *verdict, const uint8_t *piece, const uint32_t *gate, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_verdict_or, dim3(1), dim3(64), 0, s, verdict, piece, gate);
 	return hipGetLastError();
 }
 
