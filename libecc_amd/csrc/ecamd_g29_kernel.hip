@@ -887,6 +887,20 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_bkt_points_g
 	}
 	const FA x = weaken<FA>(xm);
 	const FA y = selg(isR, neg<PB>(ym, K), weaken<FA>(ym));   // the equation subtracts [z_i]R_i
+	if (A.cof_dbl != 0u && !isR && !bad) {
+		// EdDSA on a curve of order 2^d q: a key with [2^d]A = infinity is the reference's per-item rejection (sig/eddsa.c:2801-2806) -- here
+		// "not decided" (the Straus form sees the same key as a table multiple at infinity)
+		typedef typename Cls<PB>::FC FC;
+		const FC onec = constant<FC>(K.one);
+		Jac<PB> T;
+		T.X = x;
+		T.Y = y;
+		T.Z = weaken<FA>(onec);
+		for (u32 d = 0; d < A.cof_dbl; d++) {
+			T = dbl(T, K);
+		}
+		bad = is_zero_mulout(mulc(T.Z, onec, K), K);
+	}
 	u32 buf[PENTW];
 #pragma unroll
 	for (int w = 0; w < NL; w++) {
@@ -1027,6 +1041,7 @@ struct BktWindows {
 	const u32 *C[BKT_MAXCARRY];     // nwin records each: the totals of the earlier levels' U, first level first
 	u32 *out;                       // nwin records
 	u32 nwin, ncarry, c;
+	u32 win_base;                   // record w of these arrays is window win_base + w of the combination (its weight: 2^(c (win_base + w)))
 };
 template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_bkt_window_g(BktWindows V, int gslot)
 {
@@ -1060,7 +1075,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_bkt_window_g
 		bkt_add<PB>(acc, inf, P.X, P.Y, P.Z, cinf, K);
 	}
 #pragma unroll 1
-	for (u32 d = 0; d < V.c * win; d++) {
+	for (u32 d = 0; d < V.c * (V.win_base + win); d++) {
 		dbl_exact();
 	}
 	bkt_rec_store<PB>(V.out + (size_t)win * RECW, acc, inf);
@@ -4703,53 +4718,71 @@ hipError_t G29_CAT(ecamd_g29_msm_, G29_TAG)(int gslot, int phase, const EcamdMsm
 		// the comparison with -[c]G alone (the total of phase 12 rests behind the window records of the reduction's last half)
 		hipLaunchKernelGGL((k_msm_final_g<G29_PB, G29_FLAV>), dim3(1), dim3(64), 0, s, (const uint32_t *)tmp, gen, gen_status, a.clen, (const uint32_t *)a.flagword,
 				   verdict, sum_out, gslot, a.cof_dbl);
-	} else if (phase == 12) {
-		// the reduction: levels of BKT_FOLD over the bucket sums, ping-pong between the two halves of a.red; then the windows, their total,
-		// and the comparison with -[c]G
-		BktLevel V = {};
-		V.nwin = a.nwin;
-		V.inT = a.bsum;
-		V.Lin = 1u << a.c;
-		uint32_t *half[2] = {a.red, a.red + (size_t)a.red_words / 2};
-		int hsel = 0;
-		while (V.Lin > 1) {
-			V.Lout = (V.Lin + BKT_FOLD - 1) / BKT_FOLD;
-			uint32_t *o = half[hsel];
-			const size_t arr = (size_t)a.nwin * V.Lout * RECW;
-			if ((2 + (size_t)V.ncarry) * arr > (size_t)a.red_words / 2 || V.ncarry + 1 > BKT_MAXCARRY) {
+	} else if (phase == 12 || phase == 14) {
+		// the reduction: levels of BKT_FOLD over the bucket sums of the windows [win_first, win_first + win_count) (count 0: all of them, and the
+		// total behind it), ping-pong between that range's share of the two halves of a.red; then the windows.  Phase 14: the windows' total
+		// alone -- a caller that reduces two window ranges on two streams (the key-only windows while the others are still accumulating:
+		// their doubling chains, 2^(c win), are the long ones) joins them there.  Layout of a.red: two halves of nwin x per_win words, the
+		// second one followed by one record per window, the total, and its copy (what phase 13 compares with -[c]G).
+		const uint32_t nb16 = ((1u << a.c) + BKT_FOLD - 1) / BKT_FOLD;
+		const size_t per_win = 2 * (size_t)nb16 * RECW, halfw = (size_t)a.red_words / 2;
+		if ((size_t)a.nwin * per_win + ((size_t)a.nwin + 2) * RECW > halfw) {
+			return hipErrorInvalidValue;
+		}
+		uint32_t *wout = a.red + (size_t)a.red_words - ((size_t)a.nwin + 2) * RECW;
+		if (phase == 12) {
+			const uint32_t wf = a.win_count ? a.win_first : 0u, wc = a.win_count ? a.win_count : a.nwin;
+			if (wf + wc > a.nwin) {
 				return hipErrorInvalidValue;
 			}
-			V.outT = o;
-			V.outU = o + arr;
-			for (uint32_t k = 0; k < V.ncarry; k++) {
-				V.outC[k] = o + (2 + (size_t)k) * arr;
+			BktLevel V = {};
+			V.nwin = wc;
+			V.inT = a.bsum + ((size_t)wf << a.c) * RECW;
+			V.Lin = 1u << a.c;
+			uint32_t *half[2] = {a.red + (size_t)wf * per_win, a.red + halfw + (size_t)wf * per_win};
+			int hsel = 0;
+			while (V.Lin > 1) {
+				V.Lout = (V.Lin + BKT_FOLD - 1) / BKT_FOLD;
+				uint32_t *o = half[hsel];
+				const size_t arr = (size_t)wc * V.Lout * RECW;
+				if ((2 + (size_t)V.ncarry) * arr > (size_t)wc * per_win || V.ncarry + 1 > BKT_MAXCARRY) {
+					return hipErrorInvalidValue;
+				}
+				V.outT = o;
+				V.outU = o + arr;
+				for (uint32_t k = 0; k < V.ncarry; k++) {
+					V.outC[k] = o + (2 + (size_t)k) * arr;
+				}
+				const uint32_t lanes = wc * V.Lout;
+				hipLaunchKernelGGL((k_bkt_reduce_g<G29_PB, G29_FLAV>), dim3((lanes + 63) / 64, 1 + V.ncarry), dim3(64), 0, s, V, gslot);
+				// the next level folds this level's T; this level's U joins the carry arrays
+				V.inT = V.outT;
+				for (uint32_t k = 0; k < V.ncarry; k++) {
+					V.inC[k] = V.outC[k];
+				}
+				V.inC[V.ncarry] = V.outU;
+				V.ncarry++;
+				V.Lin = V.Lout;
+				hsel ^= 1;
 			}
-			const uint32_t lanes = a.nwin * V.Lout;
-			hipLaunchKernelGGL((k_bkt_reduce_g<G29_PB, G29_FLAV>), dim3((lanes + 63) / 64, 1 + V.ncarry), dim3(64), 0, s, V, gslot);
-			// the next level folds this level's T; this level's U joins the carry arrays
-			V.inT = V.outT;
-			for (uint32_t k = 0; k < V.ncarry; k++) {
-				V.inC[k] = V.outC[k];
+			// now every array holds one record per window: inC[0 .. ncarry - 2] the totals of the earlier levels' U, inC[ncarry - 1] the last U
+			BktWindows W = {};
+			W.nwin = wc;
+			W.win_base = wf;
+			W.c = a.c;
+			W.U = V.inC[V.ncarry - 1];
+			W.ncarry = V.ncarry - 1;
+			for (uint32_t k = 0; k + 1 < V.ncarry; k++) {
+				W.C[k] = V.inC[k];
 			}
-			V.inC[V.ncarry] = V.outU;
-			V.ncarry++;
-			V.Lin = V.Lout;
-			hsel ^= 1;
+			W.out = wout + (size_t)wf * RECW;
+			hipLaunchKernelGGL((k_bkt_window_g<G29_PB, G29_FLAV>), dim3((wc + 63) / 64), dim3(64), 0, s, W, gslot);
+			if (a.win_count) {
+				return hipGetLastError();
+			}
 		}
-		// now every array holds one record per window: inC[0 .. ncarry - 2] the totals of the earlier levels' U, inC[ncarry - 1] the last U
-		BktWindows W = {};
-		W.nwin = a.nwin;
-		W.c = a.c;
-		W.U = V.inC[V.ncarry - 1];
-		W.ncarry = V.ncarry - 1;
-		for (uint32_t k = 0; k + 1 < V.ncarry; k++) {
-			W.C[k] = V.inC[k];
-		}
-		uint32_t *o = half[hsel];
-		W.out = o;
-		hipLaunchKernelGGL((k_bkt_window_g<G29_PB, G29_FLAV>), dim3((a.nwin + 63) / 64), dim3(64), 0, s, W, gslot);
-		uint32_t *tot = o + (size_t)a.nwin * RECW;
-		hipLaunchKernelGGL((k_bkt_total_g<G29_PB, G29_FLAV>), dim3(1), dim3(64), 0, s, (const uint32_t *)o, a.nwin, tot, a.flagword, gslot);
+		uint32_t *tot = wout + (size_t)a.nwin * RECW;
+		hipLaunchKernelGGL((k_bkt_total_g<G29_PB, G29_FLAV>), dim3(1), dim3(64), 0, s, (const uint32_t *)wout, a.nwin, tot, a.flagword, gslot);
 		// (phase 13 compares it with -[c]G; the caller finds it at a.red + a.red_words - RECW: copied there)
 		hipLaunchKernelGGL((k_bkt_total_g<G29_PB, G29_FLAV>), dim3(1), dim3(64), 0, s, (const uint32_t *)tot, 1u, a.red + (size_t)a.red_words - RECW, a.flagword, gslot);
 	} else {

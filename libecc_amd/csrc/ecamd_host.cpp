@@ -234,6 +234,7 @@ struct ecamd_ctx {
 	// of u1, u2 and the flags -- waits for side_done ($ECAMD_NO_SIDE_STREAM: off).  66.0 -> 67.0 M verifications/s.
 	hipStream_t side_stream;
 	hipEvent_t side_fork, side_done, side_mid, side_aux;   // (side_mid / side_aux: the bucket evaluation's second and third joins)
+	hipEvent_t side_hi, side_red;   // the bucket evaluation: the key-only windows are summed (on the caller's stream) / reduced (on the side stream)
 	bool side_ok;
 	uint32_t host_chunk;
 	uint32_t host_first_min;   // smallest first chunk of a multi-chunk call (ECAMD_HOST_RAMP_MIN, default 2^16; host_pipeline)
@@ -432,7 +433,9 @@ extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
 	    hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&c->side_done, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&c->side_mid, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&c->side_aux, hipEventDisableTiming) != hipSuccess) {
+	    hipEventCreateWithFlags(&c->side_aux, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->side_hi, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->side_red, hipEventDisableTiming) != hipSuccess) {
 		delete c;
 		return fail("ecamd_ctx_create: side stream creation failed");
 	}
@@ -478,6 +481,8 @@ extern "C" void ecamd_ctx_destroy(ecamd_ctx *c)
 	(void)hipEventDestroy(c->side_done);
 	(void)hipEventDestroy(c->side_mid);
 	(void)hipEventDestroy(c->side_aux);
+	(void)hipEventDestroy(c->side_hi);
+	(void)hipEventDestroy(c->side_red);
 	(void)hipEventDestroy(c->in_ready[0]);
 	(void)hipEventDestroy(c->in_ready[1]);
 	(void)hipEventDestroy(c->busy);
@@ -3884,7 +3889,8 @@ static int eddsa448_msm_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, 
 	uint8_t *d_piece = S[13] + 16;
 	HIPCHK(hipMemsetAsync(S[13], 0, 16, s));
 	HIPCHK(hipMemsetAsync(d_piece, 1, 1, s));
-	HIPCHK(ecamd_launch_ed_msm_gate(cv->nw, S[3], S[5], S[6], S[7], n, (uint32_t)len, 2, cv->slot, d_gate, s));
+	// (the keys of small order, [4]A = infinity: seen by the combination's own import of the keys on the fast unit -- cof_dbl of EcamdMsmArgs)
+	HIPCHK(ecamd_launch_ed_msm_gate(cv->nw, S[3], S[5], S[6], S[7], n, (uint32_t)len, 0, cv->slot, d_gate, s));
 	{
 		PublicScalars pub_scope(ctx);   // everything a verification multiplies by is public
 		if (schnorr_msm_dev_locked(ctx, cv, n, S[8], S[12], S[3], S[4], 0, seed, piece, d_piece, nullptr, nullptr, s, 2)) {
@@ -4662,6 +4668,7 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 		P.n = n;
 		P.clen = (uint32_t)cl;
 		P.r_fmt = (uint32_t)r_fmt;
+		P.cof_dbl = cof_dbl;
 		HIPCHK(hipEventRecord(ctx->side_fork, s));
 		HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
 		// the keys first (an on-curve check each): the windows above z_i's 128 bits hold keys only and can be added up while the
@@ -4786,16 +4793,38 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 		if (ctx->timing) {   // the dominant kernel: k_bkt_accum_g, both launches (ecamd_ctx_dominant_kernel_ms)
 			HIPCHK(hipEventRecord(ctx->ev_dom[0], s));
 		}
+		bool reduced = false;
 		if (points_beside && B.nwinZ < bnwin) {
 			// the windows that hold keys only, as soon as the keys are in; then the rest once the commitments are
 			HIPCHK(hipStreamWaitEvent(s, ctx->side_mid, 0));
 			A.win_first = B.nwinZ;
 			A.win_count = bnwin - B.nwinZ;
 			HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 11, A, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+			const bool red_beside = getenv("ECAMD_NO_BKT_RED_BESIDE") == nullptr;
+			if (red_beside) {
+				// ... and their reduction on the side stream (idle by now: the commitments and [c]G are short) while the other windows are
+				// still being summed: the doubling chain of window w is 16 w long -- one lane per window, latency-bound -- and these are the
+				// long ones; the windows below 2^128 then end in chains of at most 112 doublings
+				HIPCHK(hipEventRecord(ctx->side_hi, s));
+				HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->side_hi, 0));
+				HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 12, A, nullptr, nullptr, nullptr, nullptr, nullptr, ctx->side_stream));
+				HIPCHK(hipEventRecord(ctx->side_red, ctx->side_stream));
+			}
 			HIPCHK(hipStreamWaitEvent(s, ctx->side_done, 0));
 			A.win_first = 0;
 			A.win_count = B.nwinZ;
 			HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 11, A, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+			if (red_beside) {
+				if (ctx->timing) {
+					HIPCHK(hipEventRecord(ctx->ev_dom[1], s));
+					ctx->ev_dom_valid = true;
+				}
+				HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 12, A, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+				HIPCHK(hipStreamWaitEvent(s, ctx->side_red, 0));
+				A.win_count = 0;
+				HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 14, A, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+				reduced = true;
+			}
 			A.win_count = 0;
 		} else {
 			if (points_beside) {
@@ -4803,11 +4832,13 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 			}
 			HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 11, A, nullptr, nullptr, nullptr, nullptr, nullptr, s));
 		}
-		if (ctx->timing) {
-			HIPCHK(hipEventRecord(ctx->ev_dom[1], s));
-			ctx->ev_dom_valid = true;
+		if (!reduced) {
+			if (ctx->timing) {
+				HIPCHK(hipEventRecord(ctx->ev_dom[1], s));
+				ctx->ev_dom_valid = true;
+			}
+			HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 12, A, nullptr, nullptr, nullptr, nullptr, nullptr, s));
 		}
-		HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 12, A, nullptr, nullptr, nullptr, nullptr, nullptr, s));
 		if (points_beside) {
 			HIPCHK(hipStreamWaitEvent(s, ctx->side_aux, 0));   // [c]G
 		}

@@ -1555,7 +1555,7 @@ template <int NW> __global__ __launch_bounds__(64) void k_ed_msm_gate(const u8 *
 		return;
 	}
 	bool bad = (fA[i] | fR[i] | fS[i]) != 0;
-	if (!bad) {
+	if (!bad && cof_dbl != 0u) {   // (cof_dbl 0: the combination's own kernels look at the keys -- k_bkt_points_g, k_msm_table_g)
 		Pt<NW> K4 = ed_load_neg<NW>(keys + (size_t)i * 2 * clen, 0, (int)clen, false, slot);
 		for (u32 k = 0; k < cof_dbl; k++) {
 			K4 = pt_dbl<NW>(K4, slot);

@@ -28,7 +28,7 @@ SEED = 0x5EC9256
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", required=True, choices=["ecdsa_verify", "ecdsa_sign", "ecccdh", "ed25519_verify", "ed448_verify", "x25519", "x448", "bip0340_msm", "ed25519_msm"])
+    ap.add_argument("--workload", required=True, choices=["ecdsa_verify", "ecdsa_sign", "ecccdh", "ed25519_verify", "ed448_verify", "x25519", "x448", "bip0340_msm", "ed25519_msm", "ed448_msm"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
@@ -242,7 +242,7 @@ def main():
             work["step_mads_per_item"] = (59 + 98 + 33 * 28 + 264) * 97 + (522 + 32 + 33 * 16 + 13) * 61
         work["alg_bytes_per_item"] = 32 + 64 + 64 + 1
         metric, unit, cfg = "Ed25519 verifications/sec (batch=2^%d, %s)" % (a.batch_log2, distinct), "verifications/s", 4
-    elif a.workload in ("bip0340_msm", "ed25519_msm"):
+    elif a.workload in ("bip0340_msm", "ed25519_msm", "ed448_msm"):
         # the reference's whole-batch verification (ec_verify_batch -> bip0340_verify_batch sig/bip0340.c:1296,
         # eddsa_verify_batch sig/eddsa.c:2904) as ONE multi-scalar multiplication.  A step is one verdict over B VALID signatures resident in
         # HBM (a batch with a bad item comes back "not decided" in the same time and the caller then runs the item form: that path is
@@ -322,6 +322,79 @@ def main():
                 how = "buckets, 16-bit windows, %d additions per item" % pairs
             metric, unit, cfg = "BIP0340 signatures/sec in whole-batch verification (%s, one multi-scalar multiplication per 2^%d-item batch: %s)" % (curve.lower(), a.batch_log2, how), "verifications/s", "f4"
             ref_what = "ec_verify_batch (BIP0340: bip0340_verify_batch, no scratch pad)"
+        elif a.workload == "ed448_msm":
+            # round 6: EDDSA448's batch equation on the Weierstrass model WEI448 -- 2^batch_log2 DISTINCT signatures made here (keys, [r]B and S on
+            # the device, SHAKE256 by hashlib), the Schnorr-type combination on the Goldilocks unit with the cofactored final test
+            cv = ctx.curve("WEI448")
+            dom = O.ed_dom4(0, b"")
+            shake = lambda x: hashlib.shake_256(x).digest(114)
+            if a.traffic_child:
+                pubs, _ = cv.eddsa_sign_R(rb(114 * B))
+                Renc, _ = cv.eddsa_sign_R(rb(114 * B))
+                sg = np.zeros((B, 114), dtype=np.uint8)
+                sg[:, :57] = np.frombuffer(Renc, dtype=np.uint8).reshape(B, 57)
+                sg[:, 57:112] = rng.integers(0, 256, size=(B, 55), dtype=np.uint8)
+                sigs, hram, msgs = sg.tobytes(), rb(114 * B), b""
+            else:
+                seeds, msgs = rb(57 * B), rb(32 * B)
+                hk = [shake(seeds[57 * i:57 * i + 57]) for i in range(B)]
+                a_np = np.frombuffer(b"".join(h[:57] for h in hk), dtype=np.uint8).reshape(B, 57).copy()
+                a_np[:, 0] &= 252
+                a_np[:, 55] |= 128
+                a_np[:, 56] = 0
+                wide = np.zeros((B, 114), dtype=np.uint8)
+                wide[:, :57] = a_np
+                pubs, st = cv.eddsa_sign_R(wide.tobytes())
+                assert set(st) == {0}
+                r_hash = b"".join(shake(dom + hk[i][57:] + msgs[32 * i:32 * i + 32]) for i in range(B))
+                Renc, st = cv.eddsa_sign_R(r_hash)
+                assert set(st) == {0}
+                hram = b"".join(shake(dom + Renc[57 * i:57 * i + 57] + pubs[57 * i:57 * i + 57] + msgs[32 * i:32 * i + 32]) for i in range(B))
+                Sb = cv.eddsa_sign_S(r_hash, hram, a_np.tobytes())
+                sg = np.empty((B, 114), dtype=np.uint8)
+                sg[:, :57] = np.frombuffer(Renc, dtype=np.uint8).reshape(B, 57)
+                sg[:, 57:] = np.frombuffer(Sb, dtype=np.uint8).reshape(B, 57)
+                sigs = sg.tobytes()
+                del hk, wide, sg
+            ins = [t(pubs), t(sigs), t(hram)]
+            bad_i = int(rng.integers(0, B))
+            ctx.set_eddsa_msm(2, 0, 0)
+
+            def step():
+                cv.eddsa_verify_all_dev(B, ins[0].data_ptr(), ins[1].data_ptr(), ins[2].data_ptr(), d_res.data_ptr(), stream.cuda_stream)
+
+            def msm_bad():
+                pos = 114 * bad_i + 70
+                ins[1][pos] ^= 1
+                step()
+                torch.cuda.synchronize()
+                v = int(d_res.item())
+                ins[1][pos] ^= 1
+                return v, bad_i
+
+            def ref_pieces(pieces):
+                def one(lo, hi):
+                    return all(O.ref_eddsa_verify_all(pubs[57 * l:57 * h], sigs[114 * l:114 * h], msgs[32 * l:32 * h], 32, ed448=True) for l, h in pieces[lo:hi])
+                return all(O.in_slices(one, len(pieces)))
+            import bench as _b
+            nl, M, S, red = _b.field_mads(O.CURVES["WEI448"]["p"])
+            K = max(1, min(8, B >> 18))
+            loop = (448 / K) * (4 * M + 4 * S) + (112 + 33) * (12 * M + 4 * S)
+            # the front end: two decodings (a square root and two inversions-by-exponentiation each: ~ 3 x 448 S + 60 M), [4]A, S and h mod q
+            front = 2 * (3 * 448 * S + 60 * M) + 2 * (4 * M + 4 * S)
+            work = {"kernel": "k_msm_loop_g", "mads_per_item": loop, "sgpr_mads_per_item": loop * red / M, "step_mads_per_item": loop + front,
+                    "alg_bytes_per_item": 57 + 114 + 114}
+            how = "Straus, K = %d items per lane" % K
+            algo = os.environ.get("ECAMD_SCHNORR_MSM_ALGO") or ("bucket" if B >= (1 << 17) else "straus")
+            if algo == "bucket":
+                pairs = 28 + 8
+                acc = pairs * (10 * M + 3 * S)
+                reduce_ = 28 * 65536 * 2 * (12 * M + 4 * S) / B
+                work = {"kernel": "k_bkt_accum_g", "mads_per_item": acc, "sgpr_mads_per_item": acc * red / M, "step_mads_per_item": acc + front + reduce_,
+                        "alg_bytes_per_item": 57 + 114 + 114}
+                how = "buckets, 16-bit windows, %d additions per item" % pairs
+            metric, unit, cfg = "Ed448 signatures/sec in whole-batch verification (one multi-scalar multiplication per 2^%d-item batch: %s)" % (a.batch_log2, how), "verifications/s", "f4"
+            ref_what = "ec_verify_batch (EDDSA448: eddsa_verify_batch, no scratch pad)"
         else:
             cv = ctx.curve("WEI25519")
             if a.traffic_child:
@@ -481,7 +554,7 @@ def main():
     res = d_res.cpu().numpy().tobytes()
     if res != expected:
         raise SystemExit("PARITY FAILURE: accept/reject bits differ from the construction of the batch")
-    msm = a.workload in ("bip0340_msm", "ed25519_msm")
+    msm = a.workload in ("bip0340_msm", "ed25519_msm", "ed448_msm")
     if msm:
         v, where = msm_bad()
         if v != 1:
