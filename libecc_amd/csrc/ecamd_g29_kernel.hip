@@ -3951,7 +3951,10 @@ template <class A> static __device__ __forceinline__ void store_canon_be(u8 *dst
 }
 }  // namespace c448
 
-__global__ __launch_bounds__(64) void k_ed448_decode_g(EcamdEd448DecodeArgs A, int gslot)
+#ifndef ED448_DECODE_OCC
+#define ED448_DECODE_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))   /* left alone the single-inversion form takes 293 registers: one wave per SIMD */
+#endif
+__global__ __launch_bounds__(64) ED448_DECODE_OCC void k_ed448_decode_g(EcamdEd448DecodeArgs A, int gslot)
 {
 	using namespace c448;
 	const u32 i = blockIdx.x * 64 + threadIdx.x;
@@ -3963,8 +3966,13 @@ __global__ __launch_bounds__(64) void k_ed448_decode_g(EcamdEd448DecodeArgs A, i
 	const FC twoc = small_const(2u);
 	const FC zeroc = small_const(0u);
 	const FA onea = weaken<FA>(onec);
-	FA x[2], d1[2], d2[2];
-	FM ym[2], xx[2], yy[2];
+	// Round 6: ONE inversion per item instead of two.  With x' = Nx / d1, y' = Ny / d2 (Nx = alpha x y, Ny = x^2 + y^2, d1 = 2 - x^2 - y^2,
+	// d2 = y^2 - x^2) the map to the Weierstrass model needs u = (1 + y') / (1 - y') = (d2 + Ny) / (d2 - Ny) and v = alpha u / x' =
+	// alpha (d2 + Ny) d1 / ((d2 - Ny) Nx): both over W = (d2 - Ny) Nx, so the isogeny's own inversion is never needed -- its two
+	// denominators are only tested for zero (the reference's fp_inv(0) errors), the Edwards-model curve equation is tested with the
+	// denominators cleared, and x' = 0 / y' = 1 are Nx = 0 / d2 = Ny.  Same verdicts and the same canonical coordinates as
+	// k_ed448_decode<14> (ecamd_kernels.hip), which keeps the reference's order of operations.
+	FA Nx[2], D1[2], Pn[2], Wd[2];
 	bool ok[2], neutral[2] = {false, false};
 #pragma unroll 1
 	for (int k = 0; k < 2; k++) {
@@ -3987,10 +3995,10 @@ __global__ __launch_bounds__(64) void k_ed448_decode_g(EcamdEd448DecodeArgs A, i
 			below = b != 0;
 		}
 		bool good = ((last & 0x7fu) == 0) & below;                      // the 57th byte only carries the sign
-		ym[k] = M_(yd, onec);
-		yy[k] = S_(ym[k]);
-		const auto u = SUB_(onec, yy[k]);                                // 1 - y^2
-		const auto v = SUB_(onec, M_(digits16(A.g_d448), yy[k]));        // a - d y^2, a = 1
+		const FM ym = M_(yd, onec);
+		const FM yy = S_(ym);
+		const auto u = SUB_(onec, yy);                                   // 1 - y^2
+		const auto v = SUB_(onec, M_(digits16(A.g_d448), yy));           // a - d y^2, a = 1
 		good = good & !is_zero(v, K);                                    // fp_inv(0)
 		const FM v2 = S_(v), u2 = S_(u);
 		const FM u3v = M_(M_(u2, u), v);
@@ -4004,51 +4012,37 @@ __global__ __launch_bounds__(64) void k_ed448_decode_g(EcamdEd448DecodeArgs A, i
 		for (int w = 0; w < 16; w++) {
 			nz |= rd[w];
 		}
-		x[k] = selg((rd[0] & 1u) != x0, weaken<FA>(SUB_(zeroc, r)), weaken<FA>(r));
+		const FA x = selg((rd[0] & 1u) != x0, weaken<FA>(SUB_(zeroc, r)), weaken<FA>(r));
 		good = good & !((nz == 0) & (x0 == 1u));
-		xx[k] = S_(r);
-		const auto e1 = SUB_(SUB_(twoc, xx[k]), yy[k]);                  // 2 - x^2 - y^2
-		const auto e2 = SUB_(yy[k], xx[k]);                              // y^2 - x^2
-		good = good & !is_zero(e1, K) & !is_zero(e2, K);                 // fp_inv(0)
-		ok[k] = good;
-		d1[k] = selg(good, weaken<FA>(e1), onea);
-		d2[k] = selg(good, weaken<FA>(e2), onea);
-	}
-	// isogeny: 1 / (d1 d2) for both points from one inversion
-	FA X[2], omy[2];
-	FM Y[2];
-	{
-		const FM pa = M_(d1[0], d2[0]), pr = M_(d1[1], d2[1]);
-		const FM inv = inv448(M_(pa, pr), K);
-		const FM ia = M_(inv, pr), ir = M_(inv, pa);                     // 1 / (d1 d2) of A, of R
-#pragma unroll 1
-		for (int k = 0; k < 2; k++) {
-			const FM di = (k == 0) ? ia : ir;
-			const FM Xk = M_(M_(digits16(A.g_alpha), M_(x[k], ym[k])), M_(di, d2[k]));
-			const FM Yk = M_(ADD_(xx[k], yy[k]), M_(di, d1[k]));
-			const FM X2 = S_(Xk), Y2 = S_(Yk);
-			const FM rhs = M_(ADD_(onec, M_(digits16(A.g_diso), M_(X2, Y2))), onec);
-			const bool on = is_zero(SUB_(ADD_(X2, Y2), rhs), K);         // on the Edwards model of curve448
-			const auto om = SUB_(onec, Yk);
-			const bool xz = is_zero_mulout(Xk, K), oz = is_zero(om, K);
-			// (0, 1) -- the image of both (0, 1) and (0, -1) of Ed448 -- is the neutral element: the point at infinity of the
-			// Weierstrass model (fine for R; a key is then rejected as small-order).  X = 0 with Y = -1 dies in fp_inv(0).
-			neutral[k] = ok[k] & on & xz & oz;
-			ok[k] = ok[k] & on & !xz & !oz;
-			X[k] = selg(ok[k], weaken<FA>(Xk), onea);
-			omy[k] = selg(ok[k], weaken<FA>(om), onea);
-			Y[k] = Yk;
-		}
+		const FM xx = S_(r);
+		const auto e1 = SUB_(SUB_(twoc, xx), yy);                        // d1 = 2 - x^2 - y^2
+		const auto e2 = SUB_(yy, xx);                                    // d2 = y^2 - x^2
+		good = good & !is_zero(e1, K) & !is_zero(e2, K);                 // fp_inv(0) of the isogeny
+		const FM nx = M_(digits16(A.g_alpha), M_(x, ym));                // alpha x y
+		const FM ny = M_(ADD_(xx, yy), onec);                            // x^2 + y^2
+		// on the Edwards model of curve448, x'^2 + y'^2 = 1 + d' x'^2 y'^2, times d1^2 d2^2
+		const FM a2 = S_(M_(nx, e2)), b2 = S_(M_(ny, e1)), dd = S_(M_(e1, e2)), nn = S_(M_(nx, ny));
+		const FM rhs = M_(ADD_(dd, M_(digits16(A.g_diso), nn)), onec);
+		const bool on = is_zero(SUB_(ADD_(a2, b2), rhs), K);
+		const auto om = SUB_(e2, ny);                                    // (1 - y') d2
+		const bool xz = is_zero_mulout(nx, K), oz = is_zero(om, K);
+		// (0, 1) -- the image of both (0, 1) and (0, -1) of Ed448 -- is the neutral element: the point at infinity of the
+		// Weierstrass model (fine for R; a key is then rejected as small-order).  X = 0 with Y = -1 dies in fp_inv(0).
+		neutral[k] = good & on & xz & oz;
+		ok[k] = good & on & !xz & !oz;
+		Nx[k] = selg(ok[k], weaken<FA>(nx), onea);
+		D1[k] = selg(ok[k], weaken<FA>(e1), onea);
+		Pn[k] = weaken<FA>(ADD_(e2, ny));                                // (1 + y') d2
+		Wd[k] = selg(ok[k], weaken<FA>(M_(om, nx)), onea);               // W = (d2 - Ny) Nx
 	}
 	{
-		const FM pa = M_(omy[0], X[0]), pr = M_(omy[1], X[1]);
-		const FM inv = inv448(M_(pa, pr), K);
-		const FM ia = M_(inv, pr), ir = M_(inv, pa);                     // 1 / ((1 - Y) X) of A, of R
+		const FM inv = inv448(M_(Wd[0], Wd[1]), K);
+		const FM ia = M_(inv, Wd[1]), ir = M_(inv, Wd[0]);               // 1 / W of A, of R
 #pragma unroll 1
 		for (int k = 0; k < 2; k++) {
 			const FM mi = (k == 0) ? ia : ir;
-			const FM u = M_(ADD_(onec, Y[k]), M_(mi, X[k]));
-			const FM v = M_(M_(digits16(A.g_alpha), u), M_(mi, omy[k]));
+			const FM u = M_(M_(Pn[k], Nx[k]), mi);
+			const FM v = M_(M_(digits16(A.g_alpha), M_(Pn[k], D1[k])), mi);
 			u8 *pd = (k == 0 ? A.pointsA : A.pointsR) + (size_t)i * 112;
 			store_canon_be(pd, SUB_(digits16(A.g_A3), u), ok[k], K);     // (A, B) = (-156326, -1): X = A/3 - u
 			store_canon_be(pd + 56, SUB_(zeroc, v), ok[k], K);           // Y = -v
