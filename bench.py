@@ -210,6 +210,11 @@ def secondary_lines(ub):
                     ("f4 Ed25519 whole-batch verification (one multi-scalar multiplication)", "ed25519_msm")):
         jobs.append((name, [sys.executable, tool, "--workload", w, "--ref-items", "16384", "--traffic", "--mad-peak", repr(pv),
                             "--mad-peak-sgpr", repr(ps), "--steps", "10", "--warmup", "2"]))
+    # ... and the same row for EDDSA448 (round 6: the combination on the Weierstrass model WEI448 with the cofactored final test); no PMC passes
+    # (the default run stays within minutes)
+    jobs.append(("f4 Ed448 whole-batch verification (one multi-scalar multiplication)",
+                 [sys.executable, tool, "--workload", "ed448_msm", "--ref-items", "8192", "--mad-peak", repr(pv), "--mad-peak-sgpr", repr(ps),
+                  "--steps", "6", "--warmup", "2"]))
     out = []
     for name, cmd in jobs:
         t0 = time.time()

@@ -225,8 +225,9 @@ int ec_eddsa_verify_msg_prj_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint
 				  const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, uint8_t *result);
 /* ec_verify_batch's ONE bit for plain Ed25519 / Ed25519ctx from the same inputs (round 6): the front end per staging chunk as above, then
  * the reference's batch equation over the whole batch as one multi-scalar multiplication per max_chunk items (by buckets from 2^18 items
- * on).  *all_valid = 0 means "not decided here" -- a bad signature, a key that does not import or has no encoding, or a handle
- * without the form (WEI448): verify item by item (ec_eddsa_verify_msg_prj_batch). */
+ * on; Ed448 on the WEI448 handle: 57-octet encodings, SHAKE256, the combination of ec_eddsa_verify_all_batch's Ed448 form).  *all_valid = 0
+ * means "not decided here" -- a bad signature, a key that does not import or has no encoding, or a handle without the form: verify
+ * item by item (ec_eddsa_verify_msg_prj_batch). */
 int ec_eddsa_verify_msg_prj_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
 				      const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, int *all_valid);
 /* The pre-hashed variant (EDDSA25519PH, sig/eddsa.c:1049-1080, :1995-2045): the hash input is dom2(1, context) || R || A || PH(M) with
@@ -298,7 +299,15 @@ int ec_eddsa_verify_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, 
  *     ONE multi-scalar multiplication on the Edwards curve (Straus, the 256 doublings shared by up to 8 signatures per lane).
  *     Like libecc's, this test accepts a batch with a bad signature with probability ~2^-128.  A batch it rejects is then
  *     verified item by item, which yields first_rejected.
- *   otherwise (small batches, Ed448): every item is verified; the bit is the exact conjunction. */
+ *   Ed448 batches of at least 2^17 items (round 6): the same equation on the Weierstrass model WEI448 the reference computes on -- A_i, R_i
+ *     decoded as for ec_eddsa_verify_batch, the Schnorr-type combination [sum z_i S_i]G + sum [z_i (q - h_i)]A_i - sum [z_i]R_i on the
+ *     Goldilocks unit (buckets of 16-bit windows; the Straus loop below 2^17 items when ecamd_ctx_set_eddsa_msm says "always"), and the
+ *     final test cofactored, [4](...) = infinity, as every point of the reference's combination enters multiplied by the cofactor
+ *     (sig/eddsa.c:2580-2860).  [4] kills the torsion components, so the scalars may be taken mod q and the key may be the decoded A
+ *     (libecc stores [4^-1 mod q]A); a key with [4]A = infinity, an undecodable key or commitment, S >= q, and a commitment that
+ *     decodes to the neutral element (no affine Weierstrass form; the item form accepts it) make the combination "not decided" and
+ *     the items are verified one by one.  Measured: 26 ms per 2^20 signatures against 70 ms item by item (profiles/r6_ed448_msm.md).
+ *   otherwise (small batches): every item is verified; the bit is the exact conjunction. */
 int ec_eddsa_verify_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *pubkeys,
 			      const uint8_t *sigs, const uint8_t *hram, uint32_t hram_len, int *all_valid,
 			      uint32_t *first_rejected);
@@ -351,8 +360,9 @@ int ec_schnorr_verify_all_batch_dev(ecamd_ctx *ctx, const ecamd_curve *curve, ui
 int ec_eddsa_encode_point_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *points_prj,
 				uint8_t *enc, uint8_t *status);
 
-/* The multi-scalar multiplication alone, device pointers (WEI25519 handle; any n > 0): d_verdict[0] = 0 when libecc's batch
- * equation holds and no item is rejected beforehand, 1 otherwise.  Only enqueues on the stream. */
+/* The multi-scalar multiplication alone, device pointers (WEI25519 handle, hram_len 64; WEI448 handle, hram_len 114: round 6; any n > 0):
+ * d_verdict[0] = 0 when libecc's batch equation holds and no item is rejected beforehand, 1 otherwise ("not decided here").  Only
+ * enqueues on the stream. */
 int ec_eddsa_verify_all_batch_dev(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const void *d_pubkeys,
 				  const void *d_sigs, const void *d_hram, uint32_t hram_len, void *d_verdict, void *hip_stream);
 

@@ -217,8 +217,9 @@ int ecdsa_verify_batch(const u8 **s, const u8 *s_len, const ec_pub_key **pub_key
  * sig_type, hash_type = the variant's hash, signature lengths, scratch-pad length when a scratch pad is given).
  * Ed25519 groups of at least 2^17 signatures per device are decided by the reference's own random linear combination,
  * evaluated as one multi-scalar multiplication on the GPU (ec_eddsa_verify_all_batch in libecc_amd.h; like the reference
- * it may accept a bad batch with probability ~2^-128); smaller groups and Ed448 by the exact conjunction of the
- * per-signature cofactored verifications.
+ * it may accept a bad batch with probability ~2^-128) -- Ed448 groups too since round 6, on the Weierstrass model with the final test
+ * cofactored; smaller groups, the pre-hashed variants and any batch the combination does not vouch for by the exact conjunction of
+ * the per-signature cofactored verifications.
  */
 int eddsa_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
 			   ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len,

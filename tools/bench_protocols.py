@@ -677,7 +677,7 @@ def main():
         what = {"ecdsa_verify": "ec_pub_key_import_from_aff_buf + ec_verify (ECDSA)", "ecdsa_sign": "ec_sign (ECDSA, nonce supplied)",
                 "ecccdh": "ecccdh_derive_secret", "ed25519_verify": "eddsa_import_pub_key + ec_verify (EDDSA25519)",
                 "ed448_verify": "eddsa_import_pub_key + ec_verify (EDDSA448)", "x25519": "x25519()", "x448": "x448()",
-                "bip0340_msm": gate_ref.get("what"), "ed25519_msm": gate_ref.get("what")}[a.workload]
+                "bip0340_msm": gate_ref.get("what"), "ed25519_msm": gate_ref.get("what"), "ed448_msm": gate_ref.get("what")}[a.workload]
         cpu = {"value": gate_ref["items"] / gate_ref["seconds"], "unit": unit, "cores": gate_ref["cores"], "kind": "reference",
                "sample": f"the parity gate's own run: {gate_ref['items']} random items of the same batch through {what} of the unmodified "
                          f"reference (oracle/_ref) on {gate_ref['cores']} threads, {gate_ref['seconds']:.1f} s wall"}
@@ -716,7 +716,7 @@ def main():
         print(json.dumps({
             "metric": metric, "value": B * world * a.steps / elapsed, "unit": unit, "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32 (%d-bit limbs, v_mad_u64_u32 integer MAD, u64 accumulators)" % (28 if a.workload in ("x448", "ed448_verify") else 29),
+            "vs_baseline": None, "dtype": "u32 (%d-bit limbs, v_mad_u64_u32 integer MAD, u64 accumulators)" % (28 if a.workload in ("x448", "ed448_verify", "ed448_msm") else 29),
             "data": ("synthetic (seeded), inputs resident in HBM; every signature valid (the form vouches for valid batches)" if msm else
                      "synthetic (seeded), inputs resident in HBM; 10 % of the signatures corrupted") if not payload
                     else "synthetic (seeded), inputs resident in HBM; valid keys",
