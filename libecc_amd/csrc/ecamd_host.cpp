@@ -235,6 +235,9 @@ struct ecamd_ctx {
 	hipStream_t side_stream;
 	hipEvent_t side_fork, side_done, side_mid, side_aux;   // (side_mid / side_aux: the bucket evaluation's second and third joins)
 	hipEvent_t side_hi, side_red;   // the bucket evaluation: the key-only windows are summed (on the caller's stream) / reduced (on the side stream)
+	hipStream_t side2_stream;       // the bucket evaluation: the windows below 2^128 are filed here while the key-only windows are summed
+	hipEvent_t side2_fork, side2_done;
+	bool side2_ok;
 	bool side_ok;
 	uint32_t host_chunk;
 	uint32_t host_first_min;   // smallest first chunk of a multi-chunk call (ECAMD_HOST_RAMP_MIN, default 2^16; host_pipeline)
@@ -435,11 +438,15 @@ extern "C" int ecamd_ctx_create(ecamd_ctx **out, int device)
 	    hipEventCreateWithFlags(&c->side_mid, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&c->side_aux, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&c->side_hi, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&c->side_red, hipEventDisableTiming) != hipSuccess) {
+	    hipEventCreateWithFlags(&c->side_red, hipEventDisableTiming) != hipSuccess ||
+	    hipStreamCreateWithFlags(&c->side2_stream, hipStreamNonBlocking) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->side2_fork, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->side2_done, hipEventDisableTiming) != hipSuccess) {
 		delete c;
 		return fail("ecamd_ctx_create: side stream creation failed");
 	}
 	c->side_ok = getenv("ECAMD_NO_SIDE_STREAM") == nullptr;
+	c->side2_ok = c->side_ok;
 	*out = c;
 	return 0;
 }
@@ -483,6 +490,10 @@ extern "C" void ecamd_ctx_destroy(ecamd_ctx *c)
 	(void)hipEventDestroy(c->side_aux);
 	(void)hipEventDestroy(c->side_hi);
 	(void)hipEventDestroy(c->side_red);
+	(void)hipStreamSynchronize(c->side2_stream);
+	(void)hipStreamDestroy(c->side2_stream);
+	(void)hipEventDestroy(c->side2_fork);
+	(void)hipEventDestroy(c->side2_done);
 	(void)hipEventDestroy(c->in_ready[0]);
 	(void)hipEventDestroy(c->in_ready[1]);
 	(void)hipEventDestroy(c->busy);
@@ -4785,7 +4796,24 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 		B.c = bc;
 		B.nwin = bnwin;
 		B.nwinZ = bnwinZ < bnwin ? bnwinZ : bnwin;
-		HIPCHK(ecamd_launch_bkt_sort(B, s));
+		// $ECAMD_BKT_FILE_SPLIT (off by default): the key-only windows filed first, on the caller's stream, and summed while the windows below
+		// 2^128 are filed on a stream of their own.  Measured (profiles/r6_f4_kernels.md): secp256k1 2^20 items 6.91 -> 7.35 ms, Ed448 25.8 -> 25.7 --
+		// the filing's atomics and scattered stores slow the gathers of the accumulation they run beside by more than the wait they save
+		const bool file_split = points_beside && B.nwinZ < bnwin && bcap != 0u && ctx->side2_ok && getenv("ECAMD_BKT_FILE_SPLIT") != nullptr;
+		if (file_split) {
+			HIPCHK(hipMemsetAsync(B.hist, 0, bcounters * 4, s));
+			B.win_first = B.nwinZ;
+			B.win_count = bnwin - B.nwinZ;
+			HIPCHK(ecamd_launch_bkt_sort(B, s));
+			HIPCHK(hipEventRecord(ctx->side2_fork, s));
+			HIPCHK(hipStreamWaitEvent(ctx->side2_stream, ctx->side2_fork, 0));
+			B.win_first = 0;
+			B.win_count = B.nwinZ;
+			HIPCHK(ecamd_launch_bkt_sort(B, ctx->side2_stream));
+			HIPCHK(hipEventRecord(ctx->side2_done, ctx->side2_stream));
+		} else {
+			HIPCHK(ecamd_launch_bkt_sort(B, s));
+		}
 		uint32_t *d_total = (uint32_t *)(M + o_tmp) + bred_words - recw;
 		if (!points_beside) {
 			HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 10, A, nullptr, nullptr, nullptr, nullptr, nullptr, s));
@@ -4811,6 +4839,9 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 				HIPCHK(hipEventRecord(ctx->side_red, ctx->side_stream));
 			}
 			HIPCHK(hipStreamWaitEvent(s, ctx->side_done, 0));
+			if (file_split) {
+				HIPCHK(hipStreamWaitEvent(s, ctx->side2_done, 0));
+			}
 			A.win_first = 0;
 			A.win_count = B.nwinZ;
 			HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 11, A, nullptr, nullptr, nullptr, nullptr, nullptr, s));

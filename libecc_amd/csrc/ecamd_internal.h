@@ -333,6 +333,8 @@ struct EcamdBktSortArgs {
 	uint32_t cap;                // != 0: fixed-capacity filing -- hist counts, no scan (k_bkt_file); slots as ecamd_bkt_slot lays them out
 	uint32_t cap_top, top_win;
 	uint32_t n, wlen, zlen, c, nwin, nwinZ;
+	uint32_t win_first, win_count;   // fixed-capacity filing only: the windows [win_first, win_first + win_count) alone, counters NOT cleared (the caller
+	                                 // cleared them once; the key-only windows are filed first and summed while the others are filed); count 0: all
 };
 hipError_t ecamd_launch_bkt_sort(const EcamdBktSortArgs &a, hipStream_t s);
 // scalars of the combination (mod q, saturated unit of the order's size): z_i = 128 bits of ChaCha20(seed; counter = item)

@@ -2267,7 +2267,7 @@ __global__ __launch_bounds__(256) void k_bkt_scatter(EcamdBktSortArgs A)
 // counting sort (a millisecond per 2^20 items).  An overflow is reported (*flag |= 16: "not decided here"), never dropped silently.
 __global__ __launch_bounds__(256) void k_bkt_file(EcamdBktSortArgs A)
 {
-	const u32 win = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+	const u32 win = A.win_first + blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
 	const u32 cnt = (win < A.nwinZ) ? 2u * A.n : A.n;
 	if (j >= cnt) {
 		return;
@@ -2291,10 +2291,10 @@ __global__ __launch_bounds__(256) void k_bkt_file(EcamdBktSortArgs A)
 // (sizes are Poisson: 46 against a mean of 32 over 64 lanes).  Every block ranks 4096 consecutive buckets by size (a counting sort in
 // LDS: sizes capped at 255) and writes the permutation; lane t of the accumulation then serves bucket perm[t], and the 64 lanes of a
 // wave get buckets of (nearly) one size.
-__global__ __launch_bounds__(256) void k_bkt_rank(const u32 *count, u32 *perm, u32 total)
+__global__ __launch_bounds__(256) void k_bkt_rank(const u32 *count, u32 *perm, u32 total, u32 first_block)
 {
 	__shared__ u32 hist[256], base[256];
-	const u32 t = threadIdx.x, first = blockIdx.x * 4096u;
+	const u32 t = threadIdx.x, first = (first_block + blockIdx.x) * 4096u;
 	hist[t] = 0;
 	__syncthreads();
 	u32 key[16];
@@ -2330,6 +2330,19 @@ hipError_t ecamd_launch_bkt_sort(const EcamdBktSortArgs &a, hipStream_t s)
 		return hipErrorInvalidValue;
 	}
 	const size_t counters = (size_t)a.nwin << a.c;
+	if (a.win_count) {
+		// a range of windows of the fixed-capacity filing (whole groups of 4096 buckets: c >= 12); the caller cleared the counters
+		if (!a.cap || a.c < 12 || a.win_first + a.win_count > a.nwin) {
+			return hipErrorInvalidValue;
+		}
+		const uint32_t cnt = (a.win_first < a.nwinZ) ? 2 * a.n : a.n;   // (the windows above z_i's hold keys only)
+		hipLaunchKernelGGL(k_bkt_file, dim3((cnt + 255) / 256, a.win_count), dim3(256), 0, s, a);
+		if (a.perm) {
+			const uint32_t per_win = (1u << a.c) / 4096u;
+			hipLaunchKernelGGL(k_bkt_rank, dim3(a.win_count * per_win), dim3(256), 0, s, (const u32 *)a.hist, a.perm, (u32)counters, a.win_first * per_win);
+		}
+		return hipGetLastError();
+	}
 	hipError_t e = hipMemsetAsync(a.hist, 0, counters * 4, s);
 	if (e == hipSuccess && !a.cap) {
 		e = hipMemsetAsync(a.cursor, 0, counters * 4, s);
@@ -2346,7 +2359,7 @@ hipError_t ecamd_launch_bkt_sort(const EcamdBktSortArgs &a, hipStream_t s)
 		hipLaunchKernelGGL(k_bkt_scatter, gp, dim3(256), 0, s, a);
 	}
 	if (a.perm) {
-		hipLaunchKernelGGL(k_bkt_rank, dim3((unsigned)((counters + 4095) / 4096)), dim3(256), 0, s, (const u32 *)a.hist, a.perm, (u32)counters);
+		hipLaunchKernelGGL(k_bkt_rank, dim3((unsigned)((counters + 4095) / 4096)), dim3(256), 0, s, (const u32 *)a.hist, a.perm, (u32)counters, 0u);
 	}
 	return hipGetLastError();
 }
@@ -2667,7 +2680,7 @@ hipError_t ecamd_launch_edbkt_file(const EcamdEdBktArgs &b, hipStream_t s)
 		return e;
 	}
 	hipLaunchKernelGGL(k_edbkt_file, dim3((2 * b.n + b.LB + 255) / 256, 16), dim3(256), 0, s, b);
-	hipLaunchKernelGGL(k_bkt_rank, dim3((unsigned)(counters / 4096)), dim3(256), 0, s, (const u32 *)b.count, b.perm, (u32)counters);
+	hipLaunchKernelGGL(k_bkt_rank, dim3((unsigned)(counters / 4096)), dim3(256), 0, s, (const u32 *)b.count, b.perm, (u32)counters, 0u);
 	return hipGetLastError();
 }
 
