@@ -3421,6 +3421,64 @@ __global__ __launch_bounds__(64) void k_edcomb_build_c25519(const u8 *pts, u32 n
 	}
 }
 
+// Round 6: eddsa_encode_point of a Weierstrass point (eddsa_export_pub_key / the R of a signature, sig/eddsa.c:795-860: prj_pt_shortw_to_aff_pt_edwards
+// then y little-endian with the parity of x in bit 255) on this unit -- k_ed_sign_enc<8> of ecamd_kernels.hip (saturated words, which stays the
+// reference implementation and serves handles without this unit), operation for operation: x = alpha u / v, y = (u - 1) / (u + 1) with
+// u = X - A/3, v = Y over ONE inverse of v (u + 1); a zero denominator (a point of order two, or u = -1) is "no encoding" (status 1, zero octets).
+// The typed verification path spent 2.5 ms per 2^20 keys in the saturated-word kernel (profiles/r6_typed_boundary.md: 1.47 ms per 589 824).
+__global__ __launch_bounds__(64) void k_ed_enc_c25519(const u8 *Rw, const u8 *stR, u8 *enc, u8 *status, u32 n, EcamdEdTailConsts Cst, int gslot)
+{
+	using namespace c25519;
+	const u32 i = blockIdx.x * 64 + threadIdx.x;
+	if (i >= n) {
+		return;
+	}
+	u8 *out = enc + (size_t)i * 32;
+	const u32 st = stR[i];
+	if (st != 0) {
+		// r = 0 mod q: the neutral element (0, 1); a failed multiplication or import: an error
+		for (int b = 0; b < 32; b++) {
+			out[b] = (u8)((st == 2 && b == 0) ? 1 : 0);
+		}
+		status[i] = (st == 2) ? 0 : 1;
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const FC onec = constant<FC>(K.one);
+	u32 xw[8], yw[8];
+	load_be<8>(Rw + (size_t)i * 64, 32, xw);
+	load_be<8>(Rw + (size_t)i * 64 + 32, 32, yw);
+	const FM X = weaken<FM>(mul(from_words<PB, 8>(xw), constant<FC>(K.ix), K));
+	const FM v = weaken<FM>(mul(from_words<PB, 8>(yw), constant<FC>(K.iy), K));
+	const auto u = carry(sub_auto<1>(X, digits9(Cst.g_A3), K));
+	const auto up1 = carry(add(u, onec));
+	const auto um1 = carry(sub_auto<1>(u, onec, K));
+	const FM den = weaken<FM>(mulc(v, up1, K));
+	FM a11;
+	const FM inv = weaken<FM>(mul(sqr_n(pow_2_250m1(den, &a11, K), 5, K), a11, K));   // den^(p - 2); 0 for den = 0
+	const FM x = weaken<FM>(mul(mul(mulc(mulc(digits9(Cst.g_alpha), u, K), up1, K), inv, K), onec, K));
+	const FM y = weaken<FM>(mul(mulc(mulc(um1, v, K), inv, K), onec, K));
+	u32 dx[9], dy[9], w[8];
+	canonical_digits(dx, x, K);
+	canonical_digits(dy, y, K);
+	to_words<9, 8>(w, dy);
+	w[7] |= (dx[0] & 1u) << 31;                      // y < 2^255; bit 255 carries the parity of x
+#pragma unroll
+	for (int b = 0; b < 32; b++) {
+		out[b] = (u8)(w[b >> 2] >> (8 * (b & 3)));
+	}
+	status[i] = is_zero_mulout(mulc(den, onec, K), K) ? 1 : 0;
+}
+hipError_t ecamd_launch_ed_enc_c25519(const uint8_t *Rw, const uint8_t *stR, uint8_t *enc, uint8_t *status, uint32_t n, const EcamdEdTailConsts &c, int gslot,
+				      hipStream_t s)
+{
+	if (n == 0) {
+		return hipSuccess;
+	}
+	hipLaunchKernelGGL(k_ed_enc_c25519, dim3((n + 63) / 64), dim3(64), 0, s, Rw, stR, enc, status, n, c, gslot);
+	return hipGetLastError();
+}
+
 __global__ __launch_bounds__(64) void k_ed_tail_c25519(EcamdEdTailArgs A, int gslot)
 {
 	using namespace c25519;

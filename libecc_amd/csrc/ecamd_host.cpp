@@ -4065,6 +4065,19 @@ static int eddsa_sign_setup(const char *fn, ecamd_ctx *ctx, const ecamd_curve *c
 // ec_eddsa_encode_point_batch computes; here that encoding goes straight into the item's hash input on the device (bytes a_offset ..
 // a_offset + 32 of the slot's message, which the caller leaves blank; the caller's array itself is not written), so one call replaces encode / copy back / build the inputs /
 // verify.  A key that does not import (coordinates >= p, not on the curve) or is the point at infinity rejects its item.
+// the encode step of EcamdEdSignArgs (Rw, stR -> out, status): on the 2^255 - 19 unit when the handle has it (k_ed_enc_c25519; round 6), else the
+// saturated-word kernel ($ECAMD_NO_ED_ENC_G: always the latter)
+static hipError_t launch_ed_sign_enc(const ecamd_curve *cv, const EcamdEdSignArgs &A, hipStream_t s)
+{
+	if (!A.is448 && cv->pbits == 255 && cv->ed_state == 1 && cv->gflavour == 2 && cv->gslot >= 0 && getenv("ECAMD_NO_ED_ENC_G") == nullptr) {
+		EcamdEdTailConsts C;
+		memcpy(C.g_2d, cv->ed_2d, sizeof(C.g_2d));
+		memcpy(C.g_alpha, cv->ed_tmpl.g_alpha, sizeof(C.g_alpha));
+		memcpy(C.g_A3, cv->ed_tmpl.g_A3, sizeof(C.g_A3));
+		return ecamd_launch_ed_enc_c25519(A.Rw, A.stR, A.out, A.status, A.n, C, cv->gslot, s);
+	}
+	return ecamd_launch_ed_sign_enc(A, s);
+}
 static bool eddsa_msm_available(const ecamd_curve *cv);
 static bool eddsa448_msm_available(const ecamd_curve *cv);
 static int eddsa448_msm_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig, const uint8_t *d_hram,
@@ -4157,7 +4170,7 @@ static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd
 		A.stR = ctx->stage[21];
 		A.out = ctx->stage[22];
 		A.status = ctx->stage[23];
-		HIPCHK(ecamd_launch_ed_sign_enc(A, s));
+		HIPCHK(launch_ed_sign_enc(cv, A, s));
 		HIPCHK(ecamd_launch_slot_patch(slots, stride, a_offset, ctx->stage[22], kl, ctx->stage[23], m, s));
 		if (all_valid) {
 			// the whole-batch form: file this chunk's encoded keys, signatures, hashes and "no encoding" marks; the equation comes at the end
@@ -5433,7 +5446,7 @@ static int eddsa_sign_R_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, const 
 	A.stR = S[5];
 	A.out = d_Renc;
 	A.status = d_status;
-	HIPCHK(ecamd_launch_ed_sign_enc(A, s));
+	HIPCHK(launch_ed_sign_enc(cv, A, s));
 	return 0;
 }
 
@@ -5501,7 +5514,7 @@ extern "C" int ec_eddsa_encode_point_batch(ecamd_ctx *ctx, const ecamd_curve *cv
 		A.stR = ctx->stage[4];
 		A.out = op[1];
 		A.status = op[2];
-		HIPCHK(ecamd_launch_ed_sign_enc(A, s));
+		HIPCHK(launch_ed_sign_enc(cv, A, s));
 		return 0;
 	});
 }

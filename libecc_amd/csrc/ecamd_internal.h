@@ -202,6 +202,9 @@ struct EcamdEdTailArgs {
 	EcamdEdTailConsts C;
 };
 hipError_t ecamd_launch_edcomb_build_c25519(const uint8_t *pts, uint32_t n, uint32_t *table, const EcamdEdTailConsts &c, int gslot, hipStream_t s);
+// eddsa_encode_point of n affine Weierstrass points (the encode step of EcamdEdSignArgs: Rw, stR -> enc, status) on the 2^255 - 19 unit
+hipError_t ecamd_launch_ed_enc_c25519(const uint8_t *Rw, const uint8_t *stR, uint8_t *enc, uint8_t *status, uint32_t n, const EcamdEdTailConsts &c, int gslot,
+				      hipStream_t s);
 hipError_t ecamd_launch_ed_tail_c25519(const EcamdEdTailArgs &a, int gslot, hipStream_t s);
 hipError_t ecamd_launch_ed_smul2_c25519(const EcamdEdSmul2Args &a, int gslot, hipStream_t s, hipEvent_t *dom = nullptr);   // dom: events around the 33-window loop
 hipError_t ecamd_launch_ed_tail2_c25519(const EcamdEdTailArgs &a, int gslot, hipStream_t s);
