@@ -1711,6 +1711,15 @@ int main(int argc, char **argv)
 		}
 		if (argc > 3 && !strcmp(argv[3], "384")) {
 			bench_verify("SECP384R1", ECDSA, SHA384, "ECDSA/SECP384R1/SHA384", bn);
+		} else if (argc > 3 && !strcmp(argv[3], "ed25519")) {
+			/* benchj's EDDSA25519 record alone: ec_verify_batch of 2^n signatures, the batch bit (profiling runs) */
+			printf("{\"records\": [\n");
+			benchj_family("WEI25519", EDDSA25519, SHA512, "EDDSA25519", bn, 0, 0, 1);
+			printf("]}\n");
+		} else if (argc > 3 && !strcmp(argv[3], "bip0340")) {
+			printf("{\"records\": [\n");
+			benchj_family("SECP256K1", BIP0340, SHA256, "BIP0340/SECP256K1/SHA256", bn, 1, 0, 1);
+			printf("]}\n");
 		} else {
 			bench_verify("SECP256R1", ECDSA, SHA256, "ECDSA/SECP256R1/SHA256", bn);
 		}

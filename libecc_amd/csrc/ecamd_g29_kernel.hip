@@ -3169,10 +3169,11 @@ static __device__ __forceinline__ void edb_store(u32 *dst, const c25519::PreA &Q
 __global__ __launch_bounds__(64) void k_edbkt_points(EcamdEdMsmArgs A, EcamdEdBktArgs B, int gslot)
 {
 	using namespace c25519;
-	const u32 i = blockIdx.x * 64 + threadIdx.x;
-	if (i >= A.n) {
+	const u32 rel = blockIdx.x * 64 + threadIdx.x;
+	if (rel >= (A.count ? A.count : A.n)) {
 		return;
 	}
+	const u32 i = A.first + rel;
 	const CK &K = TabGP<255>::get(gslot);
 	const FC d2 = digits9(A.g_2d);
 	if (i < B.LB) {
@@ -3318,7 +3319,7 @@ hipError_t ecamd_launch_edbkt(const EcamdEdMsmArgs &a, const EcamdEdBktArgs &b, 
 {
 	constexpr size_t RECW = ECAMD_EDM_REC_WORDS;
 	if (phase == 0) {
-		hipLaunchKernelGGL(k_edbkt_points, dim3((a.n + 63) / 64), dim3(64), 0, s, a, b, gslot);
+		hipLaunchKernelGGL(k_edbkt_points, dim3(((a.count ? a.count : a.n) + 63) / 64), dim3(64), 0, s, a, b, gslot);
 	} else if (phase == 1) {
 		hipLaunchKernelGGL(k_edbkt_accum, dim3((16u << 16) / 64), dim3(64), 0, s, b, gslot);
 	} else {

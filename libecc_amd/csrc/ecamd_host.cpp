@@ -1684,9 +1684,11 @@ struct HostArr {
 };
 
 template <class Core>
-static int host_pipeline(ecamd_ctx *ctx, int pbits, uint32_t n, const std::vector<HostArr> &arrs, Core core)
+static int host_pipeline(ecamd_ctx *ctx, int pbits, uint32_t n, const std::vector<HostArr> &arrs, Core core, uint32_t even_chunk = 0)
 {
-	const uint32_t chunk = n < ctx->host_chunk ? n : ctx->host_chunk;
+	// even_chunk != 0 (the whole-batch forms that file a batch chunk by chunk: their per-chunk kernels are light, what matters is that the LAST
+	// chunk -- whose copy nothing hides -- is small): a short first chunk, then equal chunks of that size
+	const uint32_t chunk = even_chunk && even_chunk < ctx->host_chunk ? (n < even_chunk ? n : even_chunk) : (n < ctx->host_chunk ? n : ctx->host_chunk);
 	const size_t na = arrs.size();
 	if (na > 6) {
 		return fail("internal: too many host arrays");
@@ -1713,6 +1715,12 @@ static int host_pipeline(ecamd_ctx *ctx, int pbits, uint32_t n, const std::vecto
 					break;
 				}
 				e++;
+			}
+		} else if (even_chunk && n > chunk) {
+			const uint32_t m = ctx->host_first_min < chunk ? ctx->host_first_min : chunk;
+			if (m < chunk && left > m) {
+				sched.push_back(m);
+				left -= m;
 			}
 		} else if (n > chunk && !no_ramp && pbits <= 256) {
 			for (uint32_t m = ctx->host_first_min < chunk ? ctx->host_first_min : chunk; m < chunk && left > m + m; m += m) {
@@ -4078,6 +4086,19 @@ static hipError_t launch_ed_sign_enc(const ecamd_curve *cv, const EcamdEdSignArg
 	}
 	return ecamd_launch_ed_sign_enc(A, s);
 }
+struct EdBktRun {
+	EcamdEdMsmArgs A;
+	EcamdEdBktArgs B;
+	EcamdEdMsmScalArgs C;
+	EcamdEdMsmLaneArgs N;
+	uint32_t *flagword;
+	uint32_t n;
+};
+static bool eddsa_msm_use_buckets(uint32_t n);
+static int eddsa_bkt_stream_begin(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig, const uint8_t *d_hram,
+				  const uint8_t seed[32], EdBktRun &R, hipStream_t s);
+static int eddsa_bkt_stream_chunk(ecamd_curve *cv, EdBktRun &R, uint32_t first, uint32_t count, hipStream_t s);
+static int eddsa_bkt_stream_end(ecamd_ctx *ctx, ecamd_curve *cv, EdBktRun &R, uint8_t *d_verdict, hipStream_t s);
 static bool eddsa_msm_available(const ecamd_curve *cv);
 static bool eddsa448_msm_available(const ecamd_curve *cv);
 static int eddsa448_msm_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig, const uint8_t *d_hram,
@@ -4139,6 +4160,16 @@ static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd
 	if (msg_slots) {
 		arrs.push_back({msg_slots, nullptr, msg_stride});
 	}
+	// Ed25519, one piece, by buckets: the combination's per-item stages on every chunk as it lands (eddsa_bkt_stream_*; $ECAMD_NO_ED_STREAM: the
+	// whole combination after the last chunk, as for Ed448 and for batches of several pieces)
+	EdBktRun run;
+	const bool streamed = all_valid && !e448 && n <= ctx->max_chunk && eddsa_msm_use_buckets(n) && getenv("ECAMD_NO_ED_STREAM") == nullptr;
+	if (streamed) {
+		StreamScope scope(ctx, ctx->stream);
+		if (eddsa_bkt_stream_begin(ctx, cv, n, ctx->stage[24], ctx->stage[25], ctx->stage[26], seed, run, ctx->stream)) {
+			return -1;
+		}
+	}
 	const int prc = host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &op,
 					       hipStream_t s, const std::function<int()> &) {
 		// stage: 20 affine keys, 21 import status, 22 encodings, 23 their status (the verification core owns 3 .. 19)
@@ -4181,6 +4212,9 @@ static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd
 			HIPCHK(hipMemcpyAsync(ctx->stage[25] + (size_t)done * sl, ip[1], (size_t)m * sl, hipMemcpyDeviceToDevice, s));
 			HIPCHK(hipMemcpyAsync(ctx->stage[26] + (size_t)done * hl, ctx->stage[17], (size_t)m * hl, hipMemcpyDeviceToDevice, s));
 			HIPCHK(hipMemcpyAsync(ctx->stage[27] + (size_t)done, ctx->stage[23], m, hipMemcpyDeviceToDevice, s));
+			if (streamed && eddsa_bkt_stream_chunk(cv, run, done, m, s)) {
+				return -1;
+			}
 			done += m;
 			return 0;
 		}
@@ -4191,7 +4225,7 @@ static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd
 		}
 		HIPCHK(ecamd_launch_reject_where(op[3], ctx->stage[23], m, s));
 		return 0;
-	});
+	}, streamed ? (1u << 17) : 0u);
 	if (prc || !all_valid) {
 		return prc;
 	}
@@ -4201,7 +4235,11 @@ static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd
 	uint8_t *d_verdict = ctx->stage[27] + n;
 	HIPCHK(hipMemsetAsync(d_verdict, 0, 1, s));
 	uint32_t pc = 0;
-	for (uint32_t off = 0; off < n; off += ctx->max_chunk, pc++) {
+	if (streamed && eddsa_bkt_stream_end(ctx, cv, run, d_verdict, s)) {
+		(void)hipStreamSynchronize(s);
+		return -1;
+	}
+	for (uint32_t off = 0; off < n && !streamed; off += ctx->max_chunk, pc++) {
 		const uint32_t m = (n - off) < ctx->max_chunk ? (n - off) : ctx->max_chunk;
 		if (e448 ? eddsa448_msm_dev_locked(ctx, cv, m, ctx->stage[24] + (size_t)off * kl, ctx->stage[25] + (size_t)off * sl, ctx->stage[26] + (size_t)off * hl,
 						   seed, pc, d_verdict, s)
@@ -4287,8 +4325,9 @@ static uint32_t eddsa_msm_pick_k(const ecamd_ctx *ctx, uint32_t n)
 // Round 6: the Ed25519 combination by buckets (k_edbkt_*; the Schnorr-type form: schnorr_msm_dev_locked) from 2^18 items on --
 // $ECAMD_ED_MSM_ALGO=straus|bucket overrides the size rule.  The base point's term [q - sum z_i S_i]B enters as one copy of B per 64
 // items with that group's share of the scalar: no global sum, no separate multiplication.
-static int eddsa_bkt_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig, const uint8_t *d_hram,
-				const uint8_t seed[32], uint32_t piece, uint8_t *d_verdict, uint8_t *d_z_dump, uint32_t *d_sum_dump, hipStream_t s)
+// scratch and kernel arguments of one combination over n items (ctx->msm; the flag word cleared)
+static int eddsa_bkt_setup(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig, const uint8_t *d_hram,
+			   const uint8_t seed[32], uint32_t piece, uint8_t *d_z_dump, EdBktRun &R, hipStream_t s)
 {
 	const uint32_t LB = (n + 63) / 64;
 	const size_t counters = (size_t)16 << 16, recw = ECAMD_EDM_REC_WORDS;
@@ -4314,7 +4353,9 @@ static int eddsa_bkt_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, con
 	}
 	uint8_t *M = ctx->msm;
 	HIPCHK(hipMemsetAsync(M + o_word, 0, 4, s));
-	EcamdEdMsmArgs A;
+	R.n = n;
+	R.flagword = (uint32_t *)(M + o_word);
+	EcamdEdMsmArgs &A = R.A;
 	memset(&A, 0, sizeof(A));
 	A.encA = d_pub;
 	A.strideA = 32;
@@ -4328,7 +4369,7 @@ static int eddsa_bkt_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, con
 	memcpy(A.g_2d, cv->ed_2d, sizeof(A.g_2d));
 	memcpy(A.g_Bx, cv->ed_Bx, sizeof(A.g_Bx));
 	memcpy(A.g_By, cv->ed_By, sizeof(A.g_By));
-	EcamdEdBktArgs B;
+	EcamdEdBktArgs &B = R.B;
 	memset(&B, 0, sizeof(B));
 	B.rawC = (const uint32_t *)(M + o_rawC);
 	B.rawB = (const uint32_t *)(M + o_rawB);
@@ -4340,24 +4381,12 @@ static int eddsa_bkt_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, con
 	B.bsum = (uint32_t *)(M + o_bsum);
 	B.red = (uint32_t *)(M + o_red);
 	B.red_words = red_words;
-	B.flagword = (uint32_t *)(M + o_word);
+	B.flagword = R.flagword;
 	B.n = n;
 	B.LB = LB;
 	B.cap = cap;
 	B.cap_top = cap_top;
-	// the decoding (two square roots per item: VALU work on the caller's arrays alone) on the side stream, beside the scalars and the filing
-	const bool beside = ctx->side_ok && getenv("ECAMD_NO_BKT_BESIDE") == nullptr;
-	hipStream_t ps = s;
-	if (beside) {
-		HIPCHK(hipEventRecord(ctx->side_fork, s));
-		HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
-		ps = ctx->side_stream;
-	}
-	HIPCHK(ecamd_launch_edbkt(A, B, 0, nullptr, nullptr, nullptr, cv->gslot, ps));
-	if (beside) {
-		HIPCHK(hipEventRecord(ctx->side_done, ctx->side_stream));
-	}
-	EcamdEdMsmScalArgs C;
+	EcamdEdMsmScalArgs &C = R.C;
 	memset(&C, 0, sizeof(C));
 	C.sigs = d_sig;
 	C.hram = d_hram;
@@ -4372,46 +4401,113 @@ static int eddsa_bkt_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, con
 	C.nonce[0] = piece;
 	C.n = n;
 	C.qslot = cv->qslot;
-	HIPCHK(ecamd_launch_edmsm_scal(C, s));
-	if (beside) {
-		HIPCHK(hipStreamWaitEvent(s, ctx->side_done, 0));   // (the lane kernel reads the decoding's flags)
-	}
-	EcamdEdMsmLaneArgs N;
+	EcamdEdMsmLaneArgs &N = R.N;
 	memset(&N, 0, sizeof(N));
 	N.zs = (const uint32_t *)(M + o_zs);
 	N.flags = M + o_flags;
 	N.flagsS = M + o_flagsS;
 	N.sB = (uint32_t *)(M + o_sB);
 	N.rawB = (uint32_t *)(M + o_rawB);
-	N.flagword = (uint32_t *)(M + o_word);
+	N.flagword = R.flagword;
 	N.n = n;
 	N.K = 64;
 	N.L = LB;
 	N.qslot = cv->qslot;
-	HIPCHK(ecamd_launch_edmsm_lane(N, s));
-	HIPCHK(ecamd_launch_edbkt_file(B, s));
+	return 0;
+}
+// the buckets summed, reduced and compared (everything is filed)
+static int eddsa_bkt_tail(ecamd_ctx *ctx, ecamd_curve *cv, EdBktRun &R, uint8_t *d_verdict, uint32_t *d_sum_dump, hipStream_t s)
+{
 	if (ctx->timing) {
 		HIPCHK(hipEventRecord(ctx->ev_dom[0], s));   // the dominant kernel: k_edbkt_accum (ecamd_ctx_dominant_kernel_ms)
 	}
-	HIPCHK(ecamd_launch_edbkt(A, B, 1, nullptr, nullptr, nullptr, cv->gslot, s));
+	HIPCHK(ecamd_launch_edbkt(R.A, R.B, 1, nullptr, nullptr, nullptr, cv->gslot, s));
 	if (ctx->timing) {
 		HIPCHK(hipEventRecord(ctx->ev_dom[1], s));
 		ctx->ev_dom_valid = true;
 	}
-	HIPCHK(ecamd_launch_edbkt(A, B, 2, (const uint32_t *)(M + o_word), d_verdict, d_sum_dump, cv->gslot, s));
+	HIPCHK(ecamd_launch_edbkt(R.A, R.B, 2, R.flagword, d_verdict, d_sum_dump, cv->gslot, s));
 	return 0;
+}
+
+static int eddsa_bkt_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig, const uint8_t *d_hram,
+				const uint8_t seed[32], uint32_t piece, uint8_t *d_verdict, uint8_t *d_z_dump, uint32_t *d_sum_dump, hipStream_t s)
+{
+	EdBktRun R;
+	if (eddsa_bkt_setup(ctx, cv, n, d_pub, d_sig, d_hram, seed, piece, d_z_dump, R, s)) {
+		return -1;
+	}
+	// the decoding (two square roots per item: VALU work on the caller's arrays alone) on the side stream, beside the scalars and the filing
+	const bool beside = ctx->side_ok && getenv("ECAMD_NO_BKT_BESIDE") == nullptr;
+	hipStream_t ps = s;
+	if (beside) {
+		HIPCHK(hipEventRecord(ctx->side_fork, s));
+		HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+		ps = ctx->side_stream;
+	}
+	HIPCHK(ecamd_launch_edbkt(R.A, R.B, 0, nullptr, nullptr, nullptr, cv->gslot, ps));
+	if (beside) {
+		HIPCHK(hipEventRecord(ctx->side_done, ctx->side_stream));
+	}
+	HIPCHK(ecamd_launch_edmsm_scal(R.C, s));
+	if (beside) {
+		HIPCHK(hipStreamWaitEvent(s, ctx->side_done, 0));   // (the lane kernel reads the decoding's flags)
+	}
+	HIPCHK(ecamd_launch_edmsm_lane(R.N, s));
+	HIPCHK(ecamd_launch_edbkt_file(R.B, s));
+	return eddsa_bkt_tail(ctx, cv, R, d_verdict, d_sum_dump, s);
+}
+
+// The same combination FILED CHUNK BY CHUNK (round 6, ec_eddsa_verify_msg_prj_all_batch): a batch that arrives through the host pipeline is
+// copy-bound while it arrives -- 285 MB per 2^20 items at PCIe rate, the device nearly idle -- and the combination used to start when the last
+// chunk was in (7 ms).  Its per-item stages (the two decodings, the scalars, the filing: 4.4 of the 7 ms) now run on each chunk as it lands;
+// what is left for the end is the base point's copies, the ranking, the additions and the reduction.  z_i is keyed by the item's index in the
+// batch, so the verdict is that of eddsa_bkt_dev_locked with the same seed.
+static int eddsa_bkt_stream_begin(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig, const uint8_t *d_hram,
+				  const uint8_t seed[32], EdBktRun &R, hipStream_t s)
+{
+	if (eddsa_bkt_setup(ctx, cv, n, d_pub, d_sig, d_hram, seed, 0, nullptr, R, s)) {
+		return -1;
+	}
+	HIPCHK(hipMemsetAsync(R.B.count, 0, ((size_t)16 << 16) * 4, s));
+	return 0;
+}
+static int eddsa_bkt_stream_chunk(ecamd_curve *cv, EdBktRun &R, uint32_t first, uint32_t count, hipStream_t s)
+{
+	if (count == 0) {
+		return 0;
+	}
+	R.A.first = R.C.first = R.B.first = first;
+	R.A.count = R.C.count = R.B.count_items = count;
+	R.B.part = 1;
+	HIPCHK(ecamd_launch_edbkt(R.A, R.B, 0, nullptr, nullptr, nullptr, cv->gslot, s));
+	HIPCHK(ecamd_launch_edmsm_scal(R.C, s));
+	HIPCHK(ecamd_launch_edbkt_file(R.B, s));
+	return 0;
+}
+static int eddsa_bkt_stream_end(ecamd_ctx *ctx, ecamd_curve *cv, EdBktRun &R, uint8_t *d_verdict, hipStream_t s)
+{
+	R.A.first = R.A.count = R.C.first = R.C.count = 0;
+	HIPCHK(ecamd_launch_edmsm_lane(R.N, s));
+	R.B.part = 2;
+	HIPCHK(ecamd_launch_edbkt_file(R.B, s));
+	return eddsa_bkt_tail(ctx, cv, R, d_verdict, nullptr, s);
+}
+
+// buckets or the Straus loop for a piece of n items ($ECAMD_ED_MSM_ALGO=straus|bucket overrides the size rule)
+static bool eddsa_msm_use_buckets(uint32_t n)
+{
+	const char *e = getenv("ECAMD_ED_MSM_ALGO");
+	const bool force_b = e && !strcmp(e, "bucket"), force_s = e && !strcmp(e, "straus");
+	return force_b || (!force_s && n >= (1u << 18));   // measured: 2^17 items 2.18 ms by buckets, 2.06 by Straus; 2^18: 2.80 / 3.22; 2^20: 6.85 / 10.8
 }
 
 static int eddsa_msm_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const uint8_t *d_pub, const uint8_t *d_sig,
 				const uint8_t *d_hram, const uint8_t seed[32], uint32_t piece, uint8_t *d_verdict, uint8_t *d_z_dump,
 				uint32_t *d_sum_dump, hipStream_t s)
 {
-	{
-		const char *e = getenv("ECAMD_ED_MSM_ALGO");
-		const bool force_b = e && !strcmp(e, "bucket"), force_s = e && !strcmp(e, "straus");
-		if (force_b || (!force_s && n >= (1u << 18))) {   // measured: 2^17 items 2.18 ms by buckets, 2.06 by Straus; 2^18: 2.80 / 3.22; 2^20: 6.85 / 10.8
-			return eddsa_bkt_dev_locked(ctx, cv, n, d_pub, d_sig, d_hram, seed, piece, d_verdict, d_z_dump, d_sum_dump, s);
-		}
+	if (eddsa_msm_use_buckets(n)) {
+		return eddsa_bkt_dev_locked(ctx, cv, n, d_pub, d_sig, d_hram, seed, piece, d_verdict, d_z_dump, d_sum_dump, s);
 	}
 	const uint32_t K = eddsa_msm_pick_k(ctx, n);
 	const uint32_t L = (n + K - 1) / K;

@@ -226,6 +226,8 @@ struct EcamdEdMsmArgs {
 	uint32_t n, K, L;
 	uint32_t cof_dbl;
 	uint32_t g_d[9], g_sm1[9], g_2d[9], g_Bx[9], g_By[9];
+	uint32_t first, count;       // k_edbkt_points: the items [first, first + count) of the n (count 0: all) -- the streamed form files a batch
+	                             // chunk by chunk while the next chunk is still on its way (eddsa_bkt_chunk)
 };
 #define ECAMD_EDM_REC_WORDS 36
 hipError_t ecamd_launch_edmsm_btable(const EcamdEdMsmArgs &a, uint32_t *tblB, int gslot, hipStream_t s);
@@ -247,6 +249,7 @@ struct EcamdEdMsmScalArgs {
 	uint32_t seed[8], nonce[3];
 	uint32_t n;
 	int qslot;
+	uint32_t first, count;       // the items [first, first + count) of the n (count 0: all); z_i is keyed by the item's index in the batch either way
 };
 struct EcamdEdMsmLaneArgs {
 	const uint32_t *zs;
@@ -271,6 +274,8 @@ struct EcamdEdBktArgs {
 	uint64_t red_words;
 	uint32_t *flagword;          // |= 16: a bucket overflowed its cap slots
 	uint32_t n, LB, cap, cap_top;   // cap_top: slots of the buckets of window 15 (z h mod q < 2^253: 4 097 digit values only)
+	uint32_t part, first, count_items;   // ecamd_launch_edbkt_file: part 0 everything (counters cleared, ranking at the end); 1: the keys and commitments
+	                                // of the items [first, first + count_items) alone, counters as they are; 2: the LB copies of B, then the ranking
 };
 // first slot of bucket b (= window << 16 | digit) and its capacity under the two-capacity layout
 static inline __host__ __device__ size_t ecamd_bkt_slot(uint32_t b, uint32_t cap, uint32_t cap_top, uint32_t top_win, uint32_t *cap_out)

@@ -930,10 +930,11 @@ static __device__ void chacha20_block4(const u32 *key, u32 ctr, const u32 *nonce
 template <int NW> __global__ __launch_bounds__(64) void k_edmsm_scal(EcamdEdMsmScalArgs A)
 {
 	static_assert(NW == 8, "Ed25519 only");
-	const u32 i = blockIdx.x * 64 + threadIdx.x;
-	if (i >= A.n) {
+	const u32 rel = blockIdx.x * 64 + threadIdx.x;
+	if (rel >= (A.count ? A.count : A.n)) {
 		return;
 	}
+	const u32 i = A.first + rel;
 	const int qs = A.qslot;
 	const CurveK<NW> &Q = ConstTab<NW>::get(qs);
 	const Fe<NW> S = fe_load_le<NW>(A.sigs + (size_t)i * 64 + 32, 32);
@@ -2644,9 +2645,19 @@ hipError_t ecamd_launch_ed_lat(const EcamdEdLatArgs &a, hipStream_t s)
 // the filing of the Ed25519 bucket evaluation (EcamdEdBktArgs): one thread per (window, point); see k_bkt_file
 __global__ __launch_bounds__(256) void k_edbkt_file(EcamdEdBktArgs B)
 {
-	const u32 win = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
-	const u32 npts = 2u * B.n + B.LB;
-	if (j >= npts) {
+	const u32 win = blockIdx.y, rel = blockIdx.x * 256 + threadIdx.x;
+	u32 j = rel;
+	if (B.part == 1u) {          // the keys, then the commitments, of the items [first, first + count)
+		if (rel >= 2u * B.count_items) {
+			return;
+		}
+		j = rel < B.count_items ? B.first + rel : B.n + B.LB + B.first + (rel - B.count_items);
+	} else if (B.part == 2u) {   // the copies of B
+		if (rel >= B.LB) {
+			return;
+		}
+		j = B.n + rel;
+	} else if (rel >= 2u * B.n + B.LB) {
 		return;
 	}
 	u32 d;
@@ -2675,18 +2686,27 @@ __global__ __launch_bounds__(256) void k_edbkt_file(EcamdEdBktArgs B)
 hipError_t ecamd_launch_edbkt_file(const EcamdEdBktArgs &b, hipStream_t s)
 {
 	const size_t counters = (size_t)16 << 16;
-	const hipError_t e = hipMemsetAsync(b.count, 0, counters * 4, s);
-	if (e != hipSuccess) {
-		return e;
+	if (b.part == 1u) {   // a chunk of the streamed form: the caller cleared the counters when the batch began
+		if (b.count_items) {
+			hipLaunchKernelGGL(k_edbkt_file, dim3((2 * b.count_items + 255) / 256, 16), dim3(256), 0, s, b);
+		}
+		return hipGetLastError();
 	}
-	hipLaunchKernelGGL(k_edbkt_file, dim3((2 * b.n + b.LB + 255) / 256, 16), dim3(256), 0, s, b);
+	if (b.part == 0u) {
+		const hipError_t e = hipMemsetAsync(b.count, 0, counters * 4, s);
+		if (e != hipSuccess) {
+			return e;
+		}
+	}
+	const uint32_t threads = b.part == 2u ? b.LB : 2 * b.n + b.LB;
+	hipLaunchKernelGGL(k_edbkt_file, dim3((threads + 255) / 256, 16), dim3(256), 0, s, b);
 	hipLaunchKernelGGL(k_bkt_rank, dim3((unsigned)(counters / 4096)), dim3(256), 0, s, (const u32 *)b.count, b.perm, (u32)counters, 0u);
 	return hipGetLastError();
 }
 
 hipError_t ecamd_launch_edmsm_scal(const EcamdEdMsmScalArgs &a, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_edmsm_scal<8>, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+	hipLaunchKernelGGL(k_edmsm_scal<8>, dim3(((a.count ? a.count : a.n) + 63) / 64), dim3(64), 0, s, a);
 	return hipGetLastError();
 }
 hipError_t ecamd_launch_edmsm_lane(const EcamdEdMsmLaneArgs &a, hipStream_t s)
