@@ -533,6 +533,32 @@ static void check_verify(const char *curve, ec_alg_type sig_type, hash_alg_type 
 	r = ec_verify_batch(sigs, siglens, pubs, msgs, msglens, n, sig_type, hash_type, adatas, adlens, pad, &scratch_len);
 	CHECK(r == 0, "%s: valid batch rejected (scratch pad): %d", label, r);
 	free(pad);
+	/* 1b. one key under a second copy of the parameters, then a missing key: the schemes libecc has a batch form for answer -1 ("all our public
+	 * keys have the same parameters", sig/eddsa.c:2358, sig/bip0340.c:843-845) and so must the replaced symbol; our ECDSA form groups by parameters */
+	if (n >= 3) {
+		static ec_params params2;
+		ec_pub_key alt;
+		u8 kbuf[3 * 80];
+		const u8 klen = (u8)(3 * BYTECEIL(params.ec_fp.p_bitlen));
+		int lib_check = 0;
+		if (load_params(curve, &params2) || ec_pub_key_export_to_buf(&kps[1].pub_key, kbuf, klen) ||
+		    ec_pub_key_import_from_buf(&alt, &params2, kbuf, klen, sig_type)) {
+			CHECK(0, "%s: the key under a second copy of the parameters", label);
+			return;
+		}
+		pubs[1] = &alt;
+		r = ec_verify_batch(sigs, siglens, pubs, msgs, msglens, n, sig_type, hash_type, adatas, adlens, NULL, NULL);
+		if (!libecc_cpu_is_verify_batch_mode_supported(sig_type, &lib_check) && lib_check) {
+			const int ref = libecc_cpu_ec_verify_batch(sigs, siglens, pubs, msgs, msglens, n, sig_type, hash_type, adatas, adlens, NULL, NULL);
+			CHECK(r == ref && r == -1, "%s: a key under other parameters: %d, libecc's ec_verify_batch %d", label, r, ref);
+		} else {
+			CHECK(r == 0, "%s: a key under a copy of the parameters rejected: %d", label, r);
+		}
+		pubs[1] = NULL;
+		r = ec_verify_batch(sigs, siglens, pubs, msgs, msglens, n, sig_type, hash_type, adatas, adlens, NULL, NULL);
+		CHECK(r == -1, "%s: a batch with a missing key accepted", label);
+		pubs[1] = &kps[1].pub_key;
+	}
 	/* 2. spoil some items: a flipped signature bit, another message, another key's signature, a short signature */
 	for (i = 0; i < n; i += 7) {
 		switch ((i / 7) % 4) {

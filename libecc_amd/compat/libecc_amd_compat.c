@@ -4368,7 +4368,7 @@ static void scan_keys(u32 lo, u32 hi, void *arg)
 
 static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
 			  ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len, int *results, int all_only,
-			  int *fail_known, int *fail)
+			  int *fail_known, int *fail, int one_params)
 {
 	const hash_mapping *hm;
 	hash_alg_type eh = UNKNOWN_HASH_ALG;
@@ -4411,6 +4411,11 @@ static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_
 		parallel_for(num, scan_keys, &S);
 		call_leave();
 		one_group = !AT_LOAD(&S.mixed);
+	}
+	if (one_params && !one_group) {
+		/* eddsa_verify_batch / bip0340_verify_batch: "all our public keys have the same parameters" (sig/eddsa.c:2358, sig/bip0340.c:843-845) --
+		 * a missing key, another set of parameters: -1 for the batch; the scan above has just looked at every key on the pool */
+		goto out;
 	}
 	if (!one_group) {
 		seen = (u8 *)calloc(num, 1);
@@ -4492,7 +4497,7 @@ out:
 int ec_verify_batch_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
 			    ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len, int *results)
 {
-	return verify_results(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, results, 0, NULL, NULL);
+	return verify_results(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, results, 0, NULL, NULL, 0);
 }
 
 typedef struct {
@@ -4512,7 +4517,7 @@ static void any_failure(u32 lo, u32 hi, void *arg)
 }
 
 static int all_accepted(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
-			ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len, int all_only)
+			ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len, int all_only, int one_params)
 {
 	int *res, ret = -1, known = 0, fail = 0;
 	double t0 = 0;
@@ -4526,7 +4531,7 @@ static int all_accepted(const u8 **s, const u8 *s_len, const ec_pub_key **pub_ke
 	if (getenv("ECAMD_COMPAT_TIMING")) {
 		t0 = now_ms();
 	}
-	if (!verify_results(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, res, all_only, &known, &fail)) {
+	if (!verify_results(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, res, all_only, &known, &fail, one_params)) {
 		if (known) {
 			ret = fail ? -1 : 0;
 		} else {
@@ -4555,7 +4560,7 @@ int ecdsa_verify_batch(const u8 **s, const u8 *s_len, const ec_pub_key **pub_key
 	if (!is_ecdsa(sig_type)) {
 		return -1;
 	}
-	return all_accepted(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, 0);
+	return all_accepted(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, 0, 0);
 }
 
 int eddsa_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
@@ -4565,7 +4570,6 @@ int eddsa_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **pub
 	hash_alg_type eh = UNKNOWN_HASH_ALG;
 	ec_curve_type ec = UNKNOWN_CURVE;
 	int ph, dom, is448;
-	u32 i;
 	if (eddsa_variant(sig_type, &eh, &ec, &ph, &dom, &is448)) {
 		return -1;
 	}
@@ -4588,19 +4592,14 @@ int eddsa_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **pub
 	if (num == 0 || !pub_keys[0]) {
 		return -1;
 	}
-	for (i = 0; i < num; i++) {
-		if (!pub_keys[i] || pub_keys[i]->params != pub_keys[0]->params) {
-			return -1;   /* "all our public keys have the same parameters" */
-		}
-	}
-	return all_accepted(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, 1);
+	/* "all our public keys have the same parameters": verify_results' scan of the keys (one_params) */
+	return all_accepted(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, 1, 1);
 }
 
 int bip0340_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
 			     ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len,
 			     verify_batch_scratch_pad *scratch_pad_area, u32 *scratch_pad_area_len)
 {
-	u32 i;
 	if (!is_bip0340(sig_type) && !is_ecfsdsa(sig_type)) {
 		return -1;
 	}
@@ -4623,12 +4622,7 @@ int bip0340_verify_batch_gpu(const u8 **s, const u8 *s_len, const ec_pub_key **p
 	if (num == 0 || !pub_keys[0]) {
 		return -1;
 	}
-	for (i = 0; i < num; i++) {
-		if (!pub_keys[i] || pub_keys[i]->params != pub_keys[0]->params) {
-			return -1;
-		}
-	}
-	return all_accepted(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, 0);
+	return all_accepted(s, s_len, pub_keys, m, m_len, num, sig_type, hash_type, adata, adata_len, 0, 1);
 }
 
 /* ------------------------------------------------------------------------------------------------

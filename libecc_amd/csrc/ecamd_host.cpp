@@ -3845,10 +3845,16 @@ static int eddsa448_verify_dev_locked(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t 
 // decided here" and never cleared (the pieces of one call share it).  Only enqueues.
 // ------------------------------------------------------------------------------------------
 static int msm_seed(ecamd_ctx *ctx, uint8_t seed[32]);
+// the bucket evaluation FILED CHUNK BY CHUNK (ec_schnorr_verify_msg_all_batch): which part of schnorr_msm_dev_locked a call runs
+struct SchnorrStreamStep {
+	int mode;                // 1: scratch sized, flag word and counters cleared; 2: the items [first, first + count) imported, their scalars
+	                         // formed, filed; 3: c and [c]G, the ranking, the buckets summed, reduced and compared
+	uint32_t first, count;
+};
 static bool schnorr_msm_unit(const ecamd_curve *cv, int *pbits, int *flavour, int *slot);
 static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_s, const uint8_t *d_ne, const uint8_t *d_keys,
 				  const uint8_t *d_r, int r_fmt, const uint8_t seed[32], uint32_t piece, uint8_t *d_verdict, uint8_t *d_z_dump,
-				  uint32_t *d_sum_dump, hipStream_t s, uint32_t cof_dbl = 0);
+				  uint32_t *d_sum_dump, hipStream_t s, uint32_t cof_dbl = 0, const struct SchnorrStreamStep *step = nullptr);
 static bool eddsa448_msm_available(const ecamd_curve *cv)
 {
 	int pb, fl, sl;
@@ -4724,11 +4730,18 @@ static bool schnorr_msm_use_buckets(const ecamd_curve *cv, uint32_t n)
 	return n >= (1u << 17);
 }
 static uint32_t schnorr_bkt_window(uint32_t) { return 16u; }
+// the streamed form (SchnorrStreamStep) files into fixed-capacity buckets and ends on the side stream's joins
+static bool schnorr_msm_streams(const ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n)
+{
+	return n <= ctx->max_chunk && schnorr_msm_use_buckets(cv, n) && ctx->side_ok && getenv("ECAMD_NO_BKT_BESIDE") == nullptr &&
+	       getenv("ECAMD_BKT_EXACT_SORT") == nullptr && getenv("ECAMD_NO_SCHNORR_STREAM") == nullptr;
+}
 
 static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_t n, const uint8_t *d_s, const uint8_t *d_ne, const uint8_t *d_keys,
 				  const uint8_t *d_r, int r_fmt, const uint8_t seed[32], uint32_t piece, uint8_t *d_verdict, uint8_t *d_z_dump,
-				  uint32_t *d_sum_dump, hipStream_t s, uint32_t cof_dbl)
+				  uint32_t *d_sum_dump, hipStream_t s, uint32_t cof_dbl, const SchnorrStreamStep *step)
 {
+	const int mode = step ? step->mode : 0;
 	// cof_dbl > 0 (eddsa448_msm_dev_locked only): the final test is [2^cof_dbl](sum + [c]G) = infinity, EdDSA's cofactored equation
 	int pbits = 0, flav = 0, gslot = -1;
 	if (!schnorr_msm_unit(cv, &pbits, &flav, &gslot) || cv->qslot < 0) {
@@ -4774,9 +4787,33 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 		return -1;
 	}
 	uint8_t *M = ctx->msm;
-	HIPCHK(hipMemsetAsync(M + o_word, 0, 4, s));
-	bool points_beside = false;
-	if (buckets && ctx->side_ok && getenv("ECAMD_NO_BKT_BESIDE") == nullptr) {
+	if (mode <= 1) {
+		HIPCHK(hipMemsetAsync(M + o_word, 0, 4, s));
+	}
+	if (mode == 1) {
+		HIPCHK(hipMemsetAsync(M + o_cnt, 0, bcounters * 4, s));   // (the filing's counters)
+		return 0;
+	}
+	if (mode == 2) {
+		// one staging chunk of the streamed form, everything on the caller's stream: the keys' and the commitments' import, the scalars, the filing
+		EcamdMsmArgs P;
+		memset(&P, 0, sizeof(P));
+		P.ptsY = d_keys;
+		P.ptsR = d_r;
+		P.flagword = (uint32_t *)(M + o_word);
+		P.pts = (uint32_t *)(M + o_tbl);
+		P.n = n;
+		P.clen = (uint32_t)cl;
+		P.r_fmt = (uint32_t)r_fmt;
+		P.cof_dbl = cof_dbl;
+		P.pt_first = step->first;
+		P.pt_count = step->count;
+		HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 10, P, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+		P.pt_first = n + step->first;
+		HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 10, P, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+	}
+	bool points_beside = mode == 3;   // (the streamed form asked schnorr_msm_streams first: buckets, a side stream)
+	if (mode == 0 && buckets && ctx->side_ok && getenv("ECAMD_NO_BKT_BESIDE") == nullptr) {
 		// the import of the 2n points (on-curve checks, BIP0340's square roots: VALU work that reads only the caller's arrays) runs on the side
 		// stream beside the scalar kernels and the counting sort (atomics and scattered stores); the bucket additions wait for both
 		EcamdMsmArgs P;
@@ -4817,7 +4854,37 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 	C.n = n;
 	C.qlen = (uint32_t)ql;
 	C.qslot = cv->qslot;
-	HIPCHK(ecamd_launch_msm_scal(cv->qnw, C, s));
+	if (mode == 2) {
+		C.first = step->first;
+		C.count = step->count;
+	}
+	if (mode != 3) {
+		HIPCHK(ecamd_launch_msm_scal(cv->qnw, C, s));
+	}
+	if (mode == 2) {
+		uint32_t *cnt = (uint32_t *)(M + o_cnt);
+		EcamdBktSortArgs B;
+		memset(&B, 0, sizeof(B));
+		B.scW = M + o_w;
+		B.scZ = M + o_z;
+		B.hist = cnt;
+		B.cap = bcap;
+		B.cap_top = bcap_top;
+		B.top_win = btop;
+		B.flag = (uint32_t *)(M + o_word);
+		B.order = (uint32_t *)(M + o_ord);
+		B.n = n;
+		B.wlen = (uint32_t)ql;
+		B.zlen = 16;
+		B.c = bc;
+		B.nwin = bnwin;
+		B.nwinZ = bnwinZ < bnwin ? bnwinZ : bnwin;
+		B.part = 1;
+		B.item_first = step->first;
+		B.item_count = step->count;
+		HIPCHK(ecamd_launch_bkt_sort(B, s));
+		return 0;
+	}
 	// c = sum z_i s_i and [c]G: four tiny reduction launches and a one-item fixed-base multiplication, a latency-bound chain of 0.7 ms that
 	// only the final comparison needs -- on the side stream behind the points when there is one, beside the counting sort
 	hipStream_t vs = s;
@@ -4908,7 +4975,7 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 		// $ECAMD_BKT_FILE_SPLIT (off by default): the key-only windows filed first, on the caller's stream, and summed while the windows below
 		// 2^128 are filed on a stream of their own.  Measured (profiles/r6_f4_kernels.md): secp256k1 2^20 items 6.91 -> 7.35 ms, Ed448 25.8 -> 25.7 --
 		// the filing's atomics and scattered stores slow the gathers of the accumulation they run beside by more than the wait they save
-		const bool file_split = points_beside && B.nwinZ < bnwin && bcap != 0u && ctx->side2_ok && getenv("ECAMD_BKT_FILE_SPLIT") != nullptr;
+		const bool file_split = mode == 0 && points_beside && B.nwinZ < bnwin && bcap != 0u && ctx->side2_ok && getenv("ECAMD_BKT_FILE_SPLIT") != nullptr;
 		if (file_split) {
 			HIPCHK(hipMemsetAsync(B.hist, 0, bcounters * 4, s));
 			B.win_first = B.nwinZ;
@@ -4921,6 +4988,7 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 			HIPCHK(ecamd_launch_bkt_sort(B, ctx->side2_stream));
 			HIPCHK(hipEventRecord(ctx->side2_done, ctx->side2_stream));
 		} else {
+			B.part = mode == 3 ? 2u : 0u;   // (the streamed form has filed everything: the ranking alone)
 			HIPCHK(ecamd_launch_bkt_sort(B, s));
 		}
 		uint32_t *d_total = (uint32_t *)(M + o_tmp) + bred_words - recw;
@@ -4933,7 +5001,9 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 		bool reduced = false;
 		if (points_beside && B.nwinZ < bnwin) {
 			// the windows that hold keys only, as soon as the keys are in; then the rest once the commitments are
-			HIPCHK(hipStreamWaitEvent(s, ctx->side_mid, 0));
+			if (mode == 0) {
+				HIPCHK(hipStreamWaitEvent(s, ctx->side_mid, 0));
+			}
 			A.win_first = B.nwinZ;
 			A.win_count = bnwin - B.nwinZ;
 			HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 11, A, nullptr, nullptr, nullptr, nullptr, nullptr, s));
@@ -4947,7 +5017,9 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 				HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 12, A, nullptr, nullptr, nullptr, nullptr, nullptr, ctx->side_stream));
 				HIPCHK(hipEventRecord(ctx->side_red, ctx->side_stream));
 			}
-			HIPCHK(hipStreamWaitEvent(s, ctx->side_done, 0));
+			if (mode == 0) {
+				HIPCHK(hipStreamWaitEvent(s, ctx->side_done, 0));
+			}
 			if (file_split) {
 				HIPCHK(hipStreamWaitEvent(s, ctx->side2_done, 0));
 			}
@@ -4967,7 +5039,7 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 			}
 			A.win_count = 0;
 		} else {
-			if (points_beside) {
+			if (points_beside && mode == 0) {
 				HIPCHK(hipStreamWaitEvent(s, ctx->side_done, 0));
 			}
 			HIPCHK(ecamd_launch_msm_g29(pbits, gslot, flav, 11, A, nullptr, nullptr, nullptr, nullptr, nullptr, s));
@@ -5190,7 +5262,17 @@ extern "C" int ec_schnorr_verify_msg_all_batch(ecamd_ctx *ctx, const ecamd_curve
 				}
 				bool first = true;
 				const std::vector<HostArr> arrs = {{keys, nullptr, kw}, {sigs, nullptr, sl}, {hash_slots, nullptr, stride}};
-				int rc = host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &,
+				// One piece, by buckets: the combination's per-item stages (the 2n points' import, the scalars, the filing) on every chunk as it
+				// lands, in even chunks of 2^17 items -- what waits for the last chunk is the ranking, the additions and the reduction
+				// ($ECAMD_NO_SCHNORR_STREAM: the whole combination after the last chunk, as for batches of several pieces)
+				const bool streamed = schnorr_msm_streams(ctx, cv, n);
+				SchnorrStreamStep step = {1, 0, 0};
+				int begun = 0;
+				if (streamed) {
+					StreamScope scope(ctx, ctx->stream);
+					begun = schnorr_msm_dev_locked(ctx, cv, n, S[24], S[25], S[26], S[27], r_fmt, seed, 0, d_verdicts, nullptr, nullptr, ctx->stream, 0, &step);
+				}
+				int rc = begun ? -1 : host_pipeline(ctx, cv->pbits, n, arrs, [&](uint32_t m, const std::vector<const uint8_t *> &ip, const std::vector<uint8_t *> &,
 										     hipStream_t s, const std::function<int()> &) {
 					if (first) {
 						HIPCHK(hipMemsetAsync(d_flag, 0, 4, s));
@@ -5239,14 +5321,26 @@ extern "C" int ec_schnorr_verify_msg_all_batch(ecamd_ctx *ctx, const ecamd_curve
 					N.hlen = (uint32_t)hl;
 					N.qlen = (uint32_t)ql;
 					HIPCHK(ecamd_launch_schnorr_ne(cv->qnw, N, s));
+					if (streamed) {
+						step.mode = 2;
+						step.first = done;
+						step.count = m;
+						if (schnorr_msm_dev_locked(ctx, cv, n, S[24], S[25], S[26], S[27], r_fmt, seed, 0, d_verdicts, nullptr, nullptr, s, 0, &step)) {
+							return -1;
+						}
+					}
 					done += m;
 					return 0;
-				});
+				}, streamed ? (1u << 17) : 0u);
 				if (!rc) {
 					hipStream_t s = ctx->stream;
 					StreamScope scope(ctx, s);
 					uint32_t pc = 0;
-					for (uint32_t off = 0; off < n && !rc; off += ctx->max_chunk, pc++) {
+					if (streamed) {
+						step.mode = 3;
+						rc = schnorr_msm_dev_locked(ctx, cv, n, S[24], S[25], S[26], S[27], r_fmt, seed, 0, d_verdicts, nullptr, nullptr, s, 0, &step);
+					}
+					for (uint32_t off = 0; off < n && !rc && !streamed; off += ctx->max_chunk, pc++) {
 						const uint32_t m = (n - off) < ctx->max_chunk ? (n - off) : ctx->max_chunk;
 						rc = schnorr_msm_dev_locked(ctx, cv, m, S[24] + (size_t)off * ql, S[25] + (size_t)off * ql, S[26] + (size_t)off * 2 * cl,
 									    S[27] + (size_t)off * rl, r_fmt, seed, pc, d_verdicts + pc, nullptr, nullptr, s);

@@ -343,6 +343,9 @@ struct EcamdBktSortArgs {
 	uint32_t n, wlen, zlen, c, nwin, nwinZ;
 	uint32_t win_first, win_count;   // fixed-capacity filing only: the windows [win_first, win_first + win_count) alone, counters NOT cleared (the caller
 	                                 // cleared them once; the key-only windows are filed first and summed while the others are filed); count 0: all
+	uint32_t part, item_first, item_count;   // fixed-capacity filing, the streamed form (ec_schnorr_verify_msg_all_batch): part 1 files the keys and
+	                                 // commitments of the items [item_first, item_first + item_count) alone -- every window, counters as they are (the
+	                                 // caller cleared them when the batch began), no ranking; part 2: the ranking alone, once everything is filed
 };
 hipError_t ecamd_launch_bkt_sort(const EcamdBktSortArgs &a, hipStream_t s);
 // scalars of the combination (mod q, saturated unit of the order's size): z_i = 128 bits of ChaCha20(seed; counter = item)
@@ -355,6 +358,7 @@ struct EcamdMsmScalArgs {
 	uint32_t seed[8], nonce[3];
 	uint32_t n, qlen;
 	int qslot;
+	uint32_t first, count;       // the items [first, first + count) of the n (count 0: all); z_i is keyed by the item's index in the batch either way
 };
 struct EcamdMsmVsumArgs {
 	const uint32_t *in;          // count x NW words, values < q

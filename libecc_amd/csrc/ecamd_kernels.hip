@@ -1048,10 +1048,11 @@ template <int NW> __global__ __launch_bounds__(64) void k_edmsm_lane(EcamdEdMsmL
 // ------------------------------------------------------------------------------------------
 template <int NW> __global__ __launch_bounds__(64) void k_msm_scal(EcamdMsmScalArgs A)
 {
-	const u32 i = blockIdx.x * 64 + threadIdx.x;
-	if (i >= A.n) {
+	const u32 rel = blockIdx.x * 64 + threadIdx.x;
+	if (rel >= (A.count ? A.count : A.n)) {
 		return;
 	}
+	const u32 i = A.first + rel;
 	const int qs = A.qslot;
 	const CurveK<NW> &Q = ConstTab<NW>::get(qs);
 	const int ql = (int)A.qlen;
@@ -2268,9 +2269,14 @@ __global__ __launch_bounds__(256) void k_bkt_scatter(EcamdBktSortArgs A)
 // counting sort (a millisecond per 2^20 items).  An overflow is reported (*flag |= 16: "not decided here"), never dropped silently.
 __global__ __launch_bounds__(256) void k_bkt_file(EcamdBktSortArgs A)
 {
-	const u32 win = A.win_first + blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
-	const u32 cnt = (win < A.nwinZ) ? 2u * A.n : A.n;
-	if (j >= cnt) {
+	const u32 win = A.win_first + blockIdx.y;
+	u32 j = blockIdx.x * 256 + threadIdx.x;
+	if (A.part == 1u) {   // the keys, then the commitments, of the items [item_first, item_first + item_count)
+		if (j >= ((win < A.nwinZ) ? 2u * A.item_count : A.item_count)) {
+			return;
+		}
+		j = j < A.item_count ? A.item_first + j : A.n + A.item_first + (j - A.item_count);
+	} else if (j >= ((win < A.nwinZ) ? 2u * A.n : A.n)) {
 		return;
 	}
 	u32 pt;
@@ -2331,6 +2337,18 @@ hipError_t ecamd_launch_bkt_sort(const EcamdBktSortArgs &a, hipStream_t s)
 		return hipErrorInvalidValue;
 	}
 	const size_t counters = (size_t)a.nwin << a.c;
+	if (a.part) {
+		// the streamed form: a range of items into every window (1) / the ranking when everything is filed (2); the caller cleared the counters
+		if (!a.cap || a.part > 2u || (a.part == 1u && (a.item_count == 0 || (uint64_t)a.item_first + a.item_count > a.n))) {
+			return hipErrorInvalidValue;
+		}
+		if (a.part == 1u) {
+			hipLaunchKernelGGL(k_bkt_file, dim3((2 * a.item_count + 255) / 256, a.nwin), dim3(256), 0, s, a);
+		} else if (a.perm) {
+			hipLaunchKernelGGL(k_bkt_rank, dim3((unsigned)((counters + 4095) / 4096)), dim3(256), 0, s, (const u32 *)a.hist, a.perm, (u32)counters, 0u);
+		}
+		return hipGetLastError();
+	}
 	if (a.win_count) {
 		// a range of windows of the fixed-capacity filing (whole groups of 4096 buckets: c >= 12); the caller cleared the counters
 		if (!a.cap || a.c < 12 || a.win_first + a.win_count > a.nwin) {
@@ -2370,7 +2388,7 @@ hipError_t ecamd_launch_msm_scal(int nw, const EcamdMsmScalArgs &a, hipStream_t 
 	if (a.n == 0) {
 		return hipSuccess;
 	}
-	const dim3 grid((a.n + 63) / 64), block(64);
+	const dim3 grid(((a.count ? a.count : a.n) + 63) / 64), block(64);
 	switch (nw) {
 #define X(N) case N: hipLaunchKernelGGL(k_msm_scal<N>, grid, block, 0, s, a); break;
 		ECAMD_FOR_NW(X)

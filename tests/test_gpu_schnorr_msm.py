@@ -308,8 +308,26 @@ def _projective(aff, cl, p, rng):
     return bytes(out)
 
 
+@pytest.fixture(params=["streamed", "after_the_last_chunk"])
+def schnorr_stream(request, msm_algo):
+    """the bucket evaluation of ec_schnorr_verify_msg_all_batch files every staging chunk as it lands (the default) or runs whole after the
+    last chunk ($ECAMD_NO_SCHNORR_STREAM, read at every call); the Straus loop has one form only"""
+    if request.param != "streamed" and msm_algo != "bucket":
+        pytest.skip("the Straus evaluation always runs after the last chunk")
+    old = os.environ.get("ECAMD_NO_SCHNORR_STREAM")
+    if request.param == "streamed":
+        os.environ.pop("ECAMD_NO_SCHNORR_STREAM", None)
+    else:
+        os.environ["ECAMD_NO_SCHNORR_STREAM"] = "1"
+    yield request.param
+    if old is None:
+        os.environ.pop("ECAMD_NO_SCHNORR_STREAM", None)
+    else:
+        os.environ["ECAMD_NO_SCHNORR_STREAM"] = old
+
+
 @pytest.mark.parametrize("curve,hash_name", [("SECP256K1", "SHA256"), ("SECP256R1", "SHA512"), ("SECP384R1", "SHA384"), ("SECP224R1", "SHA256")])
-def test_from_keys_signatures_and_messages(gpu_ctx, curve, hash_name):
+def test_from_keys_signatures_and_messages(gpu_ctx, curve, hash_name, schnorr_stream):
     """ec_schnorr_verify_msg_all_batch (round 6): the same verdicts from what an application holds -- keys as generated (any y parity; affine,
     or projective with a random Z), signatures r || s / W || s, and the schemes' hash inputs with a blank where the key's x goes; the device
     hashes (SHA-256 / 384 / 512 against hashlib through the items' construction), reduces e mod q -- also when the digest is longer or
