@@ -3236,7 +3236,59 @@ typedef struct {
 	u32 pre_max_mlen;        /* ... the longest message of the group */
 	u32 pre_not_affine;      /* ... whether some usable key has Z != 1 */
 	u32 fail_tracked, any_fail;   /* ver_unpack notes whether any item was rejected (ec_verify_batch wants that one bit) */
+	u32 *broken;             /* verify_results skipped its pass over the keys (one set of parameters, keys as the sampled ones: taken for granted);
+	                          * a packing step that meets a key that says otherwise sets this and the call starts over with the pass */
+	int assumed_affine;      /* ... Z = 1 is a guess from a sample of the keys: the packing steps that drop Z look at it */
 } ver_job;
+
+/* a key the packing steps cannot use: missing, not a public key, under other parameters (-> *broken: in a batch of several sets of parameters
+ * that key belongs to another group; verify_results sorts that out), or not a key of this algorithm (an item failure in any grouping) */
+static int key_unusable(const ver_job *J, const ec_pub_key *pk)
+{
+	if (!pk || pk->magic != PUB_KEY_MAGIC || pk->params != J->params) {
+		if (J->broken) {
+			AT_STORE(J->broken, 1);
+		}
+		return 1;
+	}
+	return pub_key_check_initialized_and_type(pk, J->sig_type) ? 1 : 0;
+}
+/* The packing steps walk a million 0.7 KB key structures and look at a dozen cache lines of each (the magic words of the key, of its point, of
+ * the three coordinates and of their numbers sit at both ends of every structure): the lines of the key a few items ahead are asked for while
+ * this one is packed ($ECAMD_COMPAT_NO_PREFETCH: off). */
+#define KEY_PREFETCH_AHEAD 4u
+static int key_prefetch_on(void)
+{
+	static int on = -1;
+	if (on < 0) {
+		on = getenv("ECAMD_COMPAT_NO_PREFETCH") ? 0 : 1;
+	}
+	return on;
+}
+static inline void key_prefetch(const ver_job *J, u32 j, u32 hi)
+{
+	if (j + KEY_PREFETCH_AHEAD < hi && key_prefetch_on()) {
+		const char *b = (const char *)J->pub_keys[J->idx[j + KEY_PREFETCH_AHEAD]];
+		size_t o;
+		for (o = 0; b && o < sizeof(ec_pub_key); o += 64) {
+			__builtin_prefetch(b + o, 0, 0);
+		}
+	}
+}
+/* Z of X || Y || Z (clen big-endian octets each) is not 1 although the group was packed as affine on a guess */
+static void affine_guess_check(const ver_job *J, const u8 *xyz, u32 cl)
+{
+	u32 k, nz = 0;
+	if (!J->assumed_affine || !J->broken) {
+		return;
+	}
+	for (k = 0; k + 1 < cl; k++) {
+		nz |= xyz[2 * cl + k];
+	}
+	if (nz || xyz[3 * cl - 1] != 1) {
+		AT_STORE(J->broken, 1);
+	}
+}
 
 static u32 dev_hash_slot(const ver_job *J, u32 cnt, u32 extra)
 {
@@ -3253,16 +3305,20 @@ static void ecdsa_pack(u32 lo, u32 hi, void *arg)
 		const ec_pub_key *pk = J->pub_keys[i];
 		hash_context hc;
 		int bad;
+		key_prefetch(J, j, hi);
 		/* ec_verify_init / __ecdsa_verify_init (sig/sig_algs.c:516, sig/ecdsa_common.c:623-649): key initialised and of
 		 * this algorithm, signature present and of the expected length; then H(m).  The key leaves as the live limbs of
 		 * pk->y (what ec_pub_key_export_to_buf writes); the device checks the curve equation at import, as the reference's
 		 * multiplication does (curves/prj_pt.c:1765). */
-		bad = pub_key_check_initialized_and_type(pk, J->sig_type) || pk->params != J->params || !J->s[i] ||
+		bad = key_unusable(J, pk) || !J->s[i] ||
 		      J->s_len[i] != J->siglen || (!J->m[i] && J->m_len[i]);
 		if (!bad && J->aff_keys) {
 			/* (Z = 1 was established for the whole group by ecdsa_keys_affine) */
 			u8 tmp[3 * 72];
 			bad = prj_to_be(tmp, J->clen, &pk->y, &(J->params->ec_curve));
+			if (!bad) {
+				affine_guess_check(J, tmp, J->clen);
+			}
 			memcpy(J->pk + (size_t)j * J->kw, tmp, J->kw);
 		} else {
 			bad = bad || prj_to_be(J->pk + (size_t)j * J->kw, J->clen, &pk->y, &(J->params->ec_curve));
@@ -3331,7 +3387,7 @@ static void ecdsa_keys_affine(u32 lo, u32 hi, void *arg)
 	for (j = lo; j < hi && !AT_LOAD(&A->not_affine); j++) {
 		const ec_pub_key *pk = A->J->pub_keys[A->J->idx[j]];
 		int one = 0;
-		if (pub_key_check_initialized_and_type(pk, A->J->sig_type) || pk->params != A->J->params || prj_pt_check_initialized(&pk->y) ||
+		if (key_unusable(A->J, pk) || prj_pt_check_initialized(&pk->y) ||
 		    fp_check_initialized(&pk->y.Z)) {
 			continue;
 		}
@@ -3392,7 +3448,7 @@ static void eddsa_export_keys(u32 lo, u32 hi, void *arg)
 	for (j = lo; j < hi; j++) {
 		const ec_pub_key *pk = J->pub_keys[J->idx[j]];
 		u8 *dst = J->kprj + (size_t)j * 3 * J->clen;
-		if (pub_key_check_initialized_and_type(pk, J->sig_type) || pk->params != J->params ||
+		if (key_unusable(J, pk) ||
 		    prj_to_be(dst, J->clen, &pk->y, &(J->params->ec_curve))) {
 			memset(dst, 0xff, (size_t)3 * J->clen);   /* coordinates >= p: an import error on the device */
 		}
@@ -3414,7 +3470,7 @@ static void eddsa_pack(u32 lo, u32 hi, void *arg)
 		int bad;
 		/* _eddsa_verify_init (sig/eddsa.c:1880-1960): key of this variant, on the variant's curve, signature length;
 		 * EDDSA25519CTX wants a context (:1923) */
-		bad = pub_key_check_initialized_and_type(pk, J->sig_type) || pk->params != J->params || !J->s[i] ||
+		bad = key_unusable(J, pk) || !J->s[i] ||
 		      J->s_len[i] != J->siglen || (!J->m[i] && J->m_len[i]);
 #if defined(WITH_SIG_EDDSA25519)
 		bad = bad || (J->sig_type == EDDSA25519CTX && !ad);
@@ -3472,7 +3528,7 @@ static void eddsa_pack_prj(u32 lo, u32 hi, void *arg)
 		const ec_pub_key *pk = J->pub_keys[i];
 		u8 *kdst = J->kprj + (size_t)j * 3 * J->clen;
 		/* _eddsa_verify_init (sig/eddsa.c:1880-1960), as in eddsa_pack */
-		int bad = pub_key_check_initialized_and_type(pk, J->sig_type) || pk->params != J->params || !J->s[i] ||
+		int bad = (key_prefetch(J, j, hi), key_unusable(J, pk)) || !J->s[i] ||
 			  J->s_len[i] != J->siglen || (!J->m[i] && J->m_len[i]);
 		bad = bad || prj_to_be(kdst, J->clen, &pk->y, &(J->params->ec_curve));
 		if (!bad && J->dom_len) {
@@ -3838,7 +3894,7 @@ static void bip_export_keys(u32 lo, u32 hi, void *arg)
 	for (j = lo; j < hi; j++) {
 		const ec_pub_key *pk = J->pub_keys[J->idx[j]];
 		u8 *dst = J->kprj + (size_t)j * 3 * J->clen;
-		J->pre[j] = (pub_key_check_initialized_and_type(pk, J->sig_type) || pk->params != J->params ||
+		J->pre[j] = (key_unusable(J, pk) ||
 			     prj_to_be(dst, J->clen, &pk->y, &(J->params->ec_curve))) ? 1 : 0;
 		if (J->pre[j]) {
 			memset(dst, 0xff, (size_t)3 * J->clen);
@@ -3988,7 +4044,7 @@ static void schfast_pack(u32 lo, u32 hi, void *arg)
 		const ec_pub_key *pk = J->pub_keys[i];
 		const u8 *sig = J->s[i];
 		u8 *slot = F->slots + (size_t)j * F->stride, tmp[3 * 80];
-		int bad = pub_key_check_initialized_and_type(pk, J->sig_type) || pk->params != J->params || !sig || J->s_len[i] != J->siglen ||
+		int bad = (key_prefetch(J, j, hi), key_unusable(J, pk)) || !sig || J->s_len[i] != J->siglen ||
 			  (!J->m[i] && J->m_len[i]) || prj_to_be(tmp, cl, &pk->y, &(J->params->ec_curve));
 		if (!bad) {
 			int snz = 0;
@@ -4003,6 +4059,9 @@ static void schfast_pack(u32 lo, u32 hi, void *arg)
 			memset(F->sigs + (size_t)j * J->siglen, 0, J->siglen);
 			memset(slot, 0, F->stride);
 			continue;
+		}
+		if (F->kw == 2 * cl) {
+			affine_guess_check(J, tmp, cl);
 		}
 		memcpy(F->keys + (size_t)j * F->kw, tmp, F->kw);
 		memcpy(F->sigs + (size_t)j * J->siglen, sig, J->siglen);
@@ -4366,6 +4425,41 @@ static void scan_keys(u32 lo, u32 hi, void *arg)
 	}
 }
 
+/* The pass WITHOUT the keys (round 6): a batch's keys are 0.7 KB structures each -- reading a million of them for their parameters pointer and
+ * their Z is 3 ms of DRAM traffic that the packing steps repeat anyway.  So: results and indices initialised, the longest message found, one
+ * set of parameters taken for granted and "Z = 1 everywhere" guessed from 64 keys; a packing step that meets a key under other parameters, no
+ * key at all, or a Z != 1 under the affine guess sets the job's `broken` word and verify_results starts over with scan_keys. */
+static void scan_light(u32 lo, u32 hi, void *arg)
+{
+	scan_job *S = (scan_job *)arg;
+	u32 i, mx = 0, cur;
+	for (i = lo; i < hi; i++) {
+		S->results[i] = -1;
+		S->idx[i] = i;
+		mx = S->m_len[i] > mx ? S->m_len[i] : mx;
+	}
+	cur = AT_LOAD(&S->max_mlen);
+	while (mx > cur && !__atomic_compare_exchange_n(&S->max_mlen, &cur, mx, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+	}
+}
+static u32 sample_not_affine(const scan_job *S, u32 num)
+{
+	const u32 step = num > 64 ? num / 64 : 1;
+	u32 i;
+	for (i = 0; i < num; i += step) {
+		const ec_pub_key *pk = S->pub_keys[i];
+		int one = 0;
+		if (!pk || pk->magic != PUB_KEY_MAGIC || pk->params != S->params || pub_key_check_initialized_and_type(pk, S->sig_type) ||
+		    prj_pt_check_initialized(&pk->y) || fp_check_initialized(&pk->y.Z)) {
+			continue;
+		}
+		if (nn_isone(&pk->y.Z.fp_val, &one) || !one) {
+			return 1;
+		}
+	}
+	return 0;
+}
+
 static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_keys, const u8 **m, const u32 *m_len, u32 num,
 			  ec_alg_type sig_type, hash_alg_type hash_type, const u8 **adata, const u16 *adata_len, int *results, int all_only,
 			  int *fail_known, int *fail, int one_params)
@@ -4375,8 +4469,9 @@ static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_
 	ec_curve_type ec = UNKNOWN_CURVE;
 	int ph = 0, dom = 0, is448 = 0, ed, ret = -1, one_group = 0;
 	scan_job S;
-	u32 *idx = NULL, i, done = 0;
+	u32 *idx = NULL, i, done = 0, broken = 0;
 	u8 *seen = NULL;
+	int optimistic;
 	if (!s || !s_len || !pub_keys || !m || !m_len || !results) {
 		return -1;
 	}
@@ -4398,6 +4493,8 @@ static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_
 	if (!idx) {
 		goto out;
 	}
+	optimistic = getenv("ECAMD_COMPAT_FULL_SCAN") == NULL;
+again:
 	{
 		S.m_len = m_len;
 		S.sig_type = sig_type;
@@ -4407,8 +4504,16 @@ static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_
 		S.idx = idx;
 		S.results = results;
 		S.mixed = S.params ? 0 : 1;
+		optimistic = optimistic && S.params != NULL;
+		done = 0;
+		AT_STORE(&broken, 0);
 		call_enter(1);
-		parallel_for(num, scan_keys, &S);
+		if (optimistic) {
+			parallel_for(num, scan_light, &S);
+			S.not_affine = sample_not_affine(&S, num);
+		} else {
+			parallel_for(num, scan_keys, &S);
+		}
 		call_leave();
 		one_group = !AT_LOAD(&S.mixed);
 	}
@@ -4473,12 +4578,22 @@ static int verify_results(const u8 **s, const u8 *s_len, const ec_pub_key **pub_
 			J.pre_max_mlen = S.max_mlen;
 			J.pre_not_affine = S.not_affine;
 		}
+		if (optimistic) {
+			J.broken = &broken;
+			J.assumed_affine = !S.not_affine;
+		}
 		/* ECDSA and EdDSA verification: a pipeline around ONE kind of C-ABI call on public data -- up to NARENA application threads at a
 		 * time, each in its own staging, the GPU calls one after the other (g_gpu_mu); the Schnorr-type path makes dependent calls and
 		 * switches the devices' scalar mode: exclusive */
 		call_enter((is_bip0340(sig_type) || is_ecfsdsa(sig_type)) ? 0 : 1);
 		r = ed ? eddsa_group(&J, cnt, results) : ((is_bip0340(sig_type) || is_ecfsdsa(sig_type)) ? schnorr_group(&J, cnt, results, is_ecfsdsa(sig_type)) : ecdsa_group(&J, cnt, results));
 		call_leave();
+		if (optimistic && AT_LOAD(&broken)) {
+			/* a key under other parameters, a missing key, a Z != 1 under the affine guess: the whole call again, behind the pass over the keys
+			 * (whatever the attempt wrote into `results` is initialised again there) */
+			optimistic = 0;
+			goto again;
+		}
 		if (r) {
 			goto out;
 		}
