@@ -227,7 +227,8 @@ int ec_eddsa_verify_msg_prj_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint
  * the reference's batch equation over the whole batch as one multi-scalar multiplication per max_chunk items (by buckets from 2^18 items
  * on; Ed448 on the WEI448 handle: 57-octet encodings, SHAKE256, the combination of ec_eddsa_verify_all_batch's Ed448 form).  *all_valid = 0
  * means "not decided here" -- a bad signature, a key that does not import or has no encoding, or a handle without the form: verify
- * item by item (ec_eddsa_verify_msg_prj_batch). */
+ * item by item (ec_eddsa_verify_msg_prj_batch).  Ed25519, one piece, by buckets: the decodings, the scalars and the filing run on every
+ * staging chunk (2^17 items) as it lands, the bucket sums and their reduction after the last ($ECAMD_NO_ED_STREAM: everything after the last). */
 int ec_eddsa_verify_msg_prj_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *keys_prj, const uint8_t *sigs,
 				      const uint8_t *hash_slots, uint32_t stride, uint32_t a_offset, int *all_valid);
 /* The pre-hashed variant (EDDSA25519PH, sig/eddsa.c:1049-1080, :1995-2045): the hash input is dom2(1, context) || R || A || PH(M) with
@@ -344,7 +345,11 @@ int ec_schnorr_verify_all_available(const ecamd_curve *curve, int r_fmt);   /* 1
  * -- and for ECFSDSA  W.x || W.y || m  with x_offset = 0xffffffff (sig/ecfsdsa.c:520-540); hash_type 1 .. 4 (SHA-224 .. SHA-512).  The
  * device computes e = H(input) mod q and q - e, takes the key's even-y representative for r_fmt 1 (lift_x, bip0340.c:532-535), and
  * evaluates ec_schnorr_verify_all_batch's combination over the whole batch once the last chunk has arrived.  *all_valid = 0: not
- * decided here -- also when a key does not import or is the point at infinity. */
+ * decided here -- also when a key does not import or is the point at infinity.
+ * A batch of one piece (n <= max_chunk) evaluated by buckets is FILED CHUNK BY CHUNK: the points' import, the scalars z_i, z_i (q - e_i)
+ * and the filing of every staging chunk (2^17 items) run while the next chunk is on its way, and only the bucket sums and their reduction
+ * wait for the last one; z_i is keyed by the item's index in the batch, so the verdict does not depend on the chunking
+ * ($ECAMD_NO_SCHNORR_STREAM: the whole combination after the last chunk). */
 int ec_schnorr_verify_msg_all_batch(ecamd_ctx *ctx, const ecamd_curve *curve, uint32_t n, const uint8_t *keys, int key_fmt,
 				    const uint8_t *sigs, int r_fmt, int hash_type, const uint8_t *hash_slots, uint32_t stride,
 				    uint32_t x_offset, int *all_valid);

@@ -61,7 +61,10 @@ int ecamd_compat_set_secret_scalars(int on);
  *   ECAMD_COMPAT_READY_ITEMS=<n>  granularity of that handshake (default 2^16)
  *   ECAMD_COMPAT_ED_TWO_PASS      EdDSA verification (all five variants): encode the keys in a call of its own and hash on the host
  *   ECAMD_COMPAT_PRJ_KEYS         ECDSA verification: send keys as X || Y || Z even when every Z is 1
- *   ECAMD_COMPAT_TIMING           one line per pipeline run on stderr: where the calling thread's time went */
+ *   ECAMD_COMPAT_TIMING           one line per pipeline run on stderr: where the calling thread's time went
+ *   ECAMD_COMPAT_FULL_SCAN        verification: look at every key before packing (parameters, Z = 1) instead of taking one set of parameters
+ *                                 for granted and guessing Z = 1 from 64 keys (a packing step that finds otherwise restarts the call with the scan)
+ *   ECAMD_COMPAT_NO_PREFETCH      the packing steps do not prefetch the key structures a few items ahead */
 void ecamd_compat_set_concurrent_random(int on);
 /* A curve the library does not know by name (ec_params built by the application from its own ec_str_params): registered
  * so that prj_pt arrays on it can be mapped to a device-side curve (a prj_pt only points to its ec_shortw_crv, which has
