@@ -770,10 +770,13 @@ __global__ __launch_bounds__(64) void k_msm_final_g(const u32 *in, const u8 *gen
 //   (k_bkt_hist / k_bkt_scan / k_bkt_scatter, ecamd_kernels.hip: a counting sort of the (window, digit, point) triples -- point
 //                    indices in bucket order)
 //   k_bkt_accum_g    one lane per bucket: its points added up
-//   k_bkt_reduce_g   sum_b b B[b] by levels of 16: a lane folds 16 consecutive entries X[0..16) into T = sum X[r] and
-//                    U = sum r X[r] (running sums, 30 additions), so that  V(X) = sum_j U_j + 16 V(T);  the sums of the U's of
-//                    earlier levels ride along as carry arrays (blockIdx.y > 0: plain sums of 16)
-//   k_bkt_window_g   per window V = C_0 + 16 (C_1 + 16 (... + 16 U_last)), scaled by 2^(c win); k_bkt_total_g adds the windows up
+//   k_bkt_reduce_g   sum_b b B[b] by levels of f = ecamd_bkt_fold(): a lane folds f consecutive entries X[0..f) into T = sum X[r] and
+//                    U = sum r X[r] (running sums, 2 (f - 1) additions), so that  V(X) = sum_j U_j + f V(T);  the sums of the U's of
+//                    earlier levels ride along as carry arrays (blockIdx.y > 0: plain sums of f).  Every level is latency-bound --
+//                    its additions are one dependent chain per lane -- so what counts is the number of DEPENDENT additions over all
+//                    levels, 2 (f - 1) log_f(2^c): 120 for f = 16 (round 6's first version), 84 for f = 8 (the default: six launches,
+//                    the last of two entries), 48 for f = 4, 32 for f = 2 (sixteen launches: the launches outweigh the chains)
+//   k_bkt_window_g   per window V = C_0 + f (C_1 + f (... + f U_last)), scaled by 2^(c win); k_bkt_total_g adds the windows up
 //   k_msm_final_g    as for the Straus form
 // Every addition here is COMPLETE (bkt_add): equal points are doubled and opposite ones cancel, exactly -- batches whose keys repeat
 // (one signer, many messages) fill buckets with multiples of one point, and "P + P" is then the common case, not an exceptional one.
@@ -983,16 +986,16 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_bkt_
 	bkt_rec_store<PB>(A.bsum + (size_t)t * RECW, acc, inf);
 }
 
-// one level of the bucket reduction (see the header above).  in: nwin x Lin records; FOLD = 16 consecutive entries per lane.
+// one level of the bucket reduction (see the header above).  in: nwin x Lin records; V.fold consecutive entries per lane.
 // blockIdx.y = 0: T and U of the level's input; blockIdx.y = k > 0: the sums of 16 of carry array k - 1.
-#define BKT_FOLD 16
-#define BKT_MAXCARRY 6
+#define BKT_MAXCARRY 16
 struct BktLevel {
 	const u32 *inT;
 	const u32 *inC[BKT_MAXCARRY];
 	u32 *outT, *outU;
 	u32 *outC[BKT_MAXCARRY];
 	u32 Lin, Lout, nwin, ncarry;
+	u32 fold;                       // entries per lane (ecamd_bkt_fold(): a power of two)
 };
 template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_bkt_reduce_g(BktLevel V, int gslot)
 {
@@ -1004,7 +1007,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_bkt_reduce_g
 	}
 	const CurveG<NL> &K = TabGP<PB>::get(gslot);
 	const u32 win = t / V.Lout, j = t - win * V.Lout;
-	const u32 first = j * BKT_FOLD, len = (V.Lin - first) < BKT_FOLD ? (V.Lin - first) : BKT_FOLD;
+	const u32 first = j * V.fold, len = (V.Lin - first) < V.fold ? (V.Lin - first) : V.fold;
 	const u32 role = blockIdx.y;
 	const u32 *in = (role == 0 ? V.inT : V.inC[role - 1]) + ((size_t)win * V.Lin + first) * RECW;
 	Jac<PB> run = bkt_blank<PB>(K), acc = run;
@@ -1041,6 +1044,7 @@ struct BktWindows {
 	const u32 *C[BKT_MAXCARRY];     // nwin records each: the totals of the earlier levels' U, first level first
 	u32 *out;                       // nwin records
 	u32 nwin, ncarry, c;
+	u32 fold_log2;                  // V = C_0 + fold (C_1 + fold (...)): that many doublings between the levels
 	u32 win_base;                   // record w of these arrays is window win_base + w of the combination (its weight: 2^(c (win_base + w)))
 };
 template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_bkt_window_g(BktWindows V, int gslot)
@@ -1067,7 +1071,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_bkt_window_g
 #pragma unroll 1
 	for (u32 k = V.ncarry; k-- > 0;) {
 #pragma unroll 1
-		for (int d = 0; d < 4; d++) {      // x 16
+		for (u32 d = 0; d < V.fold_log2; d++) {      // x fold
 			dbl_exact();
 		}
 		bool cinf;
@@ -3252,6 +3256,7 @@ struct EdBktLevel {
 	u32 *outT, *outU;
 	u32 *outC[BKT_MAXCARRY];
 	u32 Lin, Lout, ncarry;
+	u32 fold;
 };
 __global__ __launch_bounds__(64) void k_edbkt_reduce(EcamdEdMsmArgs A, EdBktLevel V, int gslot)
 {
@@ -3263,7 +3268,7 @@ __global__ __launch_bounds__(64) void k_edbkt_reduce(EcamdEdMsmArgs A, EdBktLeve
 	const CK &K = TabGP<255>::get(gslot);
 	const FC d2 = digits9(A.g_2d);
 	const u32 win = t / V.Lout, j = t - win * V.Lout;
-	const u32 first = j * BKT_FOLD, len = (V.Lin - first) < BKT_FOLD ? (V.Lin - first) : BKT_FOLD;
+	const u32 first = j * V.fold, len = (V.Lin - first) < V.fold ? (V.Lin - first) : V.fold;
 	const u32 role = blockIdx.y;
 	const u32 *in = (role == 0 ? V.inT : V.inC[role - 1]) + ((size_t)win * V.Lin + first) * ECAMD_EDM_REC_WORDS;
 	Ext run = ed_neutral(K), acc = run;
@@ -3288,7 +3293,7 @@ struct EdBktWindows {
 	const u32 *U;
 	const u32 *C[BKT_MAXCARRY];
 	u32 *out;
-	u32 ncarry;
+	u32 ncarry, fold_log2;
 };
 __global__ __launch_bounds__(64) void k_edbkt_window(EcamdEdMsmArgs A, EdBktWindows V, int gslot)
 {
@@ -3303,7 +3308,7 @@ __global__ __launch_bounds__(64) void k_edbkt_window(EcamdEdMsmArgs A, EdBktWind
 #pragma unroll 1
 	for (u32 k = V.ncarry; k-- > 0;) {
 #pragma unroll 1
-		for (int d = 0; d < 4; d++) {
+		for (u32 d = 0; d < V.fold_log2; d++) {
 			acc = ed_dbl<true>(acc, K);
 		}
 		acc = ed_add(acc, ed_pre(ext_load(V.C[k] + (size_t)win * ECAMD_EDM_REC_WORDS), d2, K), false, K);
@@ -3324,12 +3329,14 @@ hipError_t ecamd_launch_edbkt(const EcamdEdMsmArgs &a, const EcamdEdBktArgs &b, 
 		hipLaunchKernelGGL(k_edbkt_accum, dim3((16u << 16) / 64), dim3(64), 0, s, b, gslot);
 	} else {
 		EdBktLevel V = {};
+		const uint32_t fold = ecamd_bkt_fold();
+		V.fold = fold;
 		V.inT = b.bsum;
 		V.Lin = 1u << 16;
 		uint32_t *half[2] = {b.red, b.red + (size_t)b.red_words / 2};
 		int hsel = 0;
 		while (V.Lin > 1) {
-			V.Lout = (V.Lin + BKT_FOLD - 1) / BKT_FOLD;
+			V.Lout = (V.Lin + fold - 1) / fold;
 			uint32_t *o = half[hsel];
 			const size_t arr = (size_t)16 * V.Lout * RECW;
 			if ((2 + (size_t)V.ncarry) * arr > (size_t)b.red_words / 2 || V.ncarry + 1 > BKT_MAXCARRY) {
@@ -3353,6 +3360,7 @@ hipError_t ecamd_launch_edbkt(const EcamdEdMsmArgs &a, const EcamdEdBktArgs &b, 
 		EdBktWindows W = {};
 		W.U = V.inC[V.ncarry - 1];
 		W.ncarry = V.ncarry - 1;
+		W.fold_log2 = (uint32_t)__builtin_ctz(fold);
 		for (uint32_t k = 0; k + 1 < V.ncarry; k++) {
 			W.C[k] = V.inC[k];
 		}
@@ -4772,12 +4780,13 @@ hipError_t G29_CAT(ecamd_g29_msm_, G29_TAG)(int gslot, int phase, const EcamdMsm
 		hipLaunchKernelGGL((k_msm_final_g<G29_PB, G29_FLAV>), dim3(1), dim3(64), 0, s, (const uint32_t *)tmp, gen, gen_status, a.clen, (const uint32_t *)a.flagword,
 				   verdict, sum_out, gslot, a.cof_dbl);
 	} else if (phase == 12 || phase == 14) {
-		// the reduction: levels of BKT_FOLD over the bucket sums of the windows [win_first, win_first + win_count) (count 0: all of them, and the
+		// the reduction: levels of ecamd_bkt_fold() entries over the bucket sums of the windows [win_first, win_first + win_count) (count 0: all of them, and the
 		// total behind it), ping-pong between that range's share of the two halves of a.red; then the windows.  Phase 14: the windows' total
 		// alone -- a caller that reduces two window ranges on two streams (the key-only windows while the others are still accumulating:
 		// their doubling chains, 2^(c win), are the long ones) joins them there.  Layout of a.red: two halves of nwin x per_win words, the
 		// second one followed by one record per window, the total, and its copy (what phase 13 compares with -[c]G).
-		const uint32_t nb16 = ((1u << a.c) + BKT_FOLD - 1) / BKT_FOLD;
+		const uint32_t fold = ecamd_bkt_fold(), fold_log2 = (uint32_t)__builtin_ctz(fold);
+		const uint32_t nb16 = ((1u << a.c) + fold - 1) / fold;
 		const size_t per_win = 2 * (size_t)nb16 * RECW, halfw = (size_t)a.red_words / 2;
 		if ((size_t)a.nwin * per_win + ((size_t)a.nwin + 2) * RECW > halfw) {
 			return hipErrorInvalidValue;
@@ -4790,12 +4799,13 @@ hipError_t G29_CAT(ecamd_g29_msm_, G29_TAG)(int gslot, int phase, const EcamdMsm
 			}
 			BktLevel V = {};
 			V.nwin = wc;
+			V.fold = fold;
 			V.inT = a.bsum + ((size_t)wf << a.c) * RECW;
 			V.Lin = 1u << a.c;
 			uint32_t *half[2] = {a.red + (size_t)wf * per_win, a.red + halfw + (size_t)wf * per_win};
 			int hsel = 0;
 			while (V.Lin > 1) {
-				V.Lout = (V.Lin + BKT_FOLD - 1) / BKT_FOLD;
+				V.Lout = (V.Lin + fold - 1) / fold;
 				uint32_t *o = half[hsel];
 				const size_t arr = (size_t)wc * V.Lout * RECW;
 				if ((2 + (size_t)V.ncarry) * arr > (size_t)wc * per_win || V.ncarry + 1 > BKT_MAXCARRY) {
@@ -4823,6 +4833,7 @@ hipError_t G29_CAT(ecamd_g29_msm_, G29_TAG)(int gslot, int phase, const EcamdMsm
 			W.nwin = wc;
 			W.win_base = wf;
 			W.c = a.c;
+			W.fold_log2 = fold_log2;
 			W.U = V.inC[V.ncarry - 1];
 			W.ncarry = V.ncarry - 1;
 			for (uint32_t k = 0; k + 1 < V.ncarry; k++) {

@@ -4340,7 +4340,7 @@ static int eddsa_bkt_setup(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const ui
 	const uint32_t cap = 32u + 2u * (uint32_t)(((size_t)2 * n + LB + 65535) >> 16);
 	// window 15: z_i h_i mod q < q = 2^252 + ..., so its digits take 4 097 values only and the n + LB scalars of that window crowd into as many buckets
 	const uint32_t cap_top = 32u + 2u * (uint32_t)(((size_t)n + LB + 4096) / 4097);
-	const size_t red_words = 2 * (2 * (size_t)16 * 4096 * recw + 18 * recw);
+	const size_t red_words = 2 * (2 * (size_t)16 * (65536 / ecamd_bkt_fold()) * recw + 18 * recw);   // (k_edbkt_reduce: two halves, T and U of the first level)
 	size_t off = 0;
 	auto carve = [&](size_t bytes) {
 		const size_t o = off;
@@ -4755,7 +4755,8 @@ static int schnorr_msm_dev_locked(ecamd_ctx *ctx, const ecamd_curve *cv, uint32_
 	// bucket evaluation: window bits, windows of the full-length scalars / of the 128-bit z_i, counters, reduction scratch
 	const uint32_t bc = schnorr_bkt_window(n), bnwin = (uint32_t)((8 * ql + bc - 1) / bc), bnwinZ = (128u + bc - 1) / bc;
 	const size_t bcounters = (size_t)bnwin << bc, bpw = ecamd_g29_bkt_point_words(pbits, flav);
-	const size_t bred_words = 2 * (2 * (size_t)bnwin * ((((size_t)1 << bc) + 15) / 16) * recw + ((size_t)bnwin + 2) * recw);
+	const size_t bfold = ecamd_bkt_fold();
+	const size_t bred_words = 2 * (2 * (size_t)bnwin * ((((size_t)1 << bc) + bfold - 1) / bfold) * recw + ((size_t)bnwin + 2) * recw);
 	size_t off = 0;
 	auto carve = [&](size_t bytes) {
 		const size_t o = off;

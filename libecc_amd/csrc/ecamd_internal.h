@@ -1,6 +1,7 @@
 // libecc_amd/csrc/ecamd_internal.h -- launch interface between the host side (ecamd_host.cpp)
 // and the kernels (ecamd_kernels.hip).  Not part of the public C ABI (include/libecc_amd.h).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -277,6 +278,16 @@ struct EcamdEdBktArgs {
 	uint32_t part, first, count_items;   // ecamd_launch_edbkt_file: part 0 everything (counters cleared, ranking at the end); 1: the keys and commitments
 	                                // of the items [first, first + count_items) alone, counters as they are; 2: the LB copies of B, then the ranking
 };
+// entries a lane of the bucket reduction folds per level (k_bkt_reduce_g / k_edbkt_reduce: 2 (fold - 1) dependent additions per level, log_fold(2^c)
+// levels): 8 by default -- measured per 2^20 items (tools/gpu_r6zb.sh): BIP0340 / secp256k1 6.84 (16) / 6.66 (8) / 6.71 (4) / 6.87 ms (2), Ed25519
+// 6.89 / 6.64 / 6.67 / 6.84, Ed448 25.9 / 25.8 / 26.8 / 28.4; $ECAMD_BKT_FOLD=2|4|8|16 (measurements, tests; read at every call, by the host's
+// scratch sizing and by the launchers alike)
+static inline uint32_t ecamd_bkt_fold()
+{
+	const char *e = getenv("ECAMD_BKT_FOLD");
+	const int v = e ? atoi(e) : 8;
+	return (v == 2 || v == 4 || v == 8 || v == 16) ? (uint32_t)v : 8u;
+}
 // first slot of bucket b (= window << 16 | digit) and its capacity under the two-capacity layout
 static inline __host__ __device__ size_t ecamd_bkt_slot(uint32_t b, uint32_t cap, uint32_t cap_top, uint32_t top_win, uint32_t *cap_out)
 {

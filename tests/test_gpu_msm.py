@@ -117,6 +117,31 @@ def test_combination_vs_python(gpu_ctx, n, k):
         cv.free()
 
 
+@pytest.mark.parametrize("fold", [2, 4, 16])
+def test_bucket_reduction_folds(gpu_ctx, fold, ed_msm_algo):
+    """$ECAMD_BKT_FOLD (entries per lane and level of the bucket reduction; 8 by default): the device's sum is the python combination for every fold"""
+    if ed_msm_algo != "bucket":
+        pytest.skip("the Straus evaluation has no bucket reduction")
+    old = os.environ.get("ECAMD_BKT_FOLD")
+    os.environ["ECAMD_BKT_FOLD"] = str(fold)
+    rng = np.random.default_rng(2000 + fold)
+    cv = gpu_ctx.curve("WEI25519")
+    try:
+        n = 70
+        for wrong in ((), (1, 33, 69)):
+            pubs, sigs, hram = make_items(rng, n, wrong)
+            seed = rng.integers(0, 256, size=32, dtype=np.uint8).tobytes()
+            acc, zs, T = cv.debug_eddsa_msm(pubs, sigs, hram, seed)
+            assert same_point(T, python_combination(pubs, sigs, hram, zs)), (fold, wrong)
+            assert acc == (len(wrong) == 0)
+    finally:
+        if old is None:
+            os.environ.pop("ECAMD_BKT_FOLD", None)
+        else:
+            os.environ["ECAMD_BKT_FOLD"] = old
+        cv.free()
+
+
 def test_msm_verdict_on_the_edge_families(gpu_ctx):
     """the accept bit over the case families of tests/test_oracle.py (torsion-shifted R and A, non-canonical and undecodable
     encodings, S >= q, small-order keys, R = neutral ...): every subset the per-item oracle accepts is accepted, a subset with

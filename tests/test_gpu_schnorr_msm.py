@@ -149,6 +149,45 @@ def test_valid_batches_accepted_and_one_bad_item_rejects(gpu_ctx, curve, msm_k):
         cv.free()
 
 
+@pytest.mark.parametrize("fold", [2, 4, 8, 16])
+def test_bucket_reduction_folds(gpu_ctx, fold, msm_algo):
+    """the bucket reduction folds $ECAMD_BKT_FOLD entries per lane and level (8 by default: V = C_0 + f (C_1 + f (...))): every fold gives the same
+    verdicts -- a valid batch, an item damaged at either end or in the middle, the cancelling pair of test_combination_is_the_sum_with_the_dumped_z"""
+    if msm_algo != "bucket":
+        pytest.skip("the Straus evaluation has no bucket reduction")
+    old = os.environ.get("ECAMD_BKT_FOLD")
+    os.environ["ECAMD_BKT_FOLD"] = str(fold)
+    rng = np.random.default_rng(77)
+    cv = gpu_ctx.curve("SECP256K1")
+    try:
+        n = 211
+        it = make_items("SECP256K1", n, rng, even_y=True)
+        ql, q = it["ql"], it["q"]
+        assert cv.schnorr_verify_all(it["s"], it["ne"], it["Y"], it["R"], 0)
+        assert cv.schnorr_verify_all(it["s"], it["ne"], it["Y"], it["rx"], 1)
+        for idx in (0, n // 2, n - 1):
+            s_i = int.from_bytes(it["s"][ql * idx:ql * (idx + 1)], "big")
+            assert not cv.schnorr_verify_all(patched(it["s"], ql, idx, ((s_i + 1) % q).to_bytes(ql, "big")), it["ne"], it["Y"], it["R"], 0)
+        seed = bytes(range(32))
+        acc, z, _ = cv.debug_schnorr_msm(it["s"], it["ne"], it["Y"], it["R"], 0, seed)
+        assert acc
+        zi = [int.from_bytes(z[16 * i:16 * (i + 1)], "little") for i in range(n)]
+        d = 0x7654321
+        s0 = (int.from_bytes(it["s"][:ql], "big") + d) % q
+        s1 = (int.from_bytes(it["s"][ql:2 * ql], "big") - d * zi[0] * pow(zi[1], -1, q)) % q
+        s_bad = s0.to_bytes(ql, "big") + s1.to_bytes(ql, "big") + it["s"][2 * ql:]
+        acc, zz, _ = cv.debug_schnorr_msm(s_bad, it["ne"], it["Y"], it["R"], 0, seed)
+        assert acc and zz == z
+        acc, _, _ = cv.debug_schnorr_msm(s_bad, it["ne"], it["Y"], it["R"], 0, bytes(range(1, 33)))
+        assert not acc
+    finally:
+        if old is None:
+            os.environ.pop("ECAMD_BKT_FOLD", None)
+        else:
+            os.environ["ECAMD_BKT_FOLD"] = old
+        cv.free()
+
+
 @pytest.mark.parametrize("curve", ["SECP256K1", "SECP384R1", "SECP256R1"])
 def test_combination_is_the_sum_with_the_dumped_z(gpu_ctx, curve):
     """two damaged items whose errors cancel under the z_i of one seed: s_0 += d, s_1 -= d z_0 / z_1 mod q leaves
