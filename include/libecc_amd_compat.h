@@ -75,6 +75,9 @@ unsigned long long ecamd_compat_gpu_items(void);
 /* calls of the Schnorr-type multi-scalar multiplication made on behalf of ec_verify_batch (BIP0340 / ECFSDSA batches of at least 2^17
  * items per device, $ECAMD_COMPAT_SCHNORR_MSM_MIN; a valid batch is accepted by it, any other goes on to the item-by-item pass) */
 unsigned long ecamd_compat_schnorr_msm_calls(void);
+/* verification calls that started over behind the full pass over the keys: a packing step met a key under other parameters, a missing key, or a
+ * Z != 1 after the 64-key sample had said "affine" (tests: the restart must happen, and only then) */
+unsigned long ecamd_compat_verify_restarts(void);
 /* ... and how many Ed25519 ec_verify_batch groups were first offered to the device as one whole-batch call (round 6: batches of at least
  * 2^18 items per device, $ECAMD_COMPAT_ED_MSM_MIN; 0 = never) */
 unsigned long ecamd_compat_ed_msm_calls(void);

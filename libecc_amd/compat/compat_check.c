@@ -559,6 +559,42 @@ static void check_verify(const char *curve, ec_alg_type sig_type, hash_alg_type 
 		CHECK(r == -1, "%s: a batch with a missing key accepted", label);
 		pubs[1] = &kps[1].pub_key;
 	}
+	/* 1c. keys as an application imports them (Z = 1) with ONE key as a multiplication left it (Z != 1), at an index the layer's 64-key sample
+	 * does not look at: the packing steps must notice and the call start over (libecc_amd_compat.c: affine_guess_check) */
+	if (n >= 130 && on_gpu > 0) {
+		ec_pub_key *aff = calloc(n, sizeof(ec_pub_key));
+		int one = 0;
+		for (i = 0; i < n; i++) {
+			if (i == 1) {
+				continue;
+			}
+			aff[i] = kps[i].pub_key;   /* (the copy shares the parameters; its point is normalised as ec_pub_key_import_from_aff_buf leaves one) */
+			if (prj_pt_unique(&aff[i].y, &aff[i].y)) {
+				CHECK(0, "%s: normalisation of key %u", label, i);
+				return;
+			}
+			pubs[i] = &aff[i];
+		}
+		const unsigned long restarts0 = ecamd_compat_verify_restarts();
+		int z1 = 0;
+		CHECK(!nn_isone(&(aff[0].y.Z.fp_val), &one) && one, "%s: an imported key without Z = 1", label);
+		r = ec_verify_batch(sigs, siglens, pubs, msgs, msglens, n, sig_type, hash_type, adatas, adlens, NULL, NULL);
+		CHECK(r == 0, "%s: valid batch of imported keys and one projective key rejected: %d", label, r);
+		/* ECDSA and the one-call Schnorr form send affine keys as X || Y: there the guess must have been caught (EdDSA always sends X || Y || Z) */
+		if (!nn_isone(&(kps[1].pub_key.y.Z.fp_val), &z1) && !z1 && !getenv("ECAMD_COMPAT_FULL_SCAN") && !getenv("ECAMD_COMPAT_PRJ_KEYS") &&
+		    (sig_type == ECDSA || sig_type == DECDSA)) {
+			CHECK(ecamd_compat_verify_restarts() > restarts0, "%s: a projective key among affine ones did not restart the call", label);
+		}
+		r = ec_verify_batch_results(sigs, siglens, pubs, msgs, msglens, n, sig_type, hash_type, adatas, adlens, res);
+		CHECK(r == 0, "%s: ec_verify_batch_results (imported keys) failed", label);
+		for (i = 0; i < n && !r; i++) {
+			CHECK(res[i] == 0, "%s: item %u of the imported-key batch: %d", label, i, res[i]);
+		}
+		for (i = 0; i < n; i++) {
+			pubs[i] = &kps[i].pub_key;
+		}
+		free(aff);
+	}
 	/* 2. spoil some items: a flipped signature bit, another message, another key's signature, a short signature */
 	for (i = 0; i < n; i += 7) {
 		switch ((i / 7) % 4) {

@@ -4429,6 +4429,8 @@ static void scan_keys(u32 lo, u32 hi, void *arg)
  * their Z is 3 ms of DRAM traffic that the packing steps repeat anyway.  So: results and indices initialised, the longest message found, one
  * set of parameters taken for granted and "Z = 1 everywhere" guessed from 64 keys; a packing step that meets a key under other parameters, no
  * key at all, or a Z != 1 under the affine guess sets the job's `broken` word and verify_results starts over with scan_keys. */
+static unsigned long g_verify_restarts;
+unsigned long ecamd_compat_verify_restarts(void) { return AT_LOAD(&g_verify_restarts); }
 static void scan_light(u32 lo, u32 hi, void *arg)
 {
 	scan_job *S = (scan_job *)arg;
@@ -4589,6 +4591,7 @@ again:
 		r = ed ? eddsa_group(&J, cnt, results) : ((is_bip0340(sig_type) || is_ecfsdsa(sig_type)) ? schnorr_group(&J, cnt, results, is_ecfsdsa(sig_type)) : ecdsa_group(&J, cnt, results));
 		call_leave();
 		if (optimistic && AT_LOAD(&broken)) {
+			AT_ADD(&g_verify_restarts, 1);
 			/* a key under other parameters, a missing key, a Z != 1 under the affine guess: the whole call again, behind the pass over the keys
 			 * (whatever the attempt wrote into `results` is initialised again there) */
 			optimistic = 0;
