@@ -781,9 +781,41 @@ __global__ __launch_bounds__(64) void k_msm_final_g(const u32 *in, const u8 *gen
 // Every addition here is COMPLETE (bkt_add): equal points are doubled and opposite ones cancel, exactly -- batches whose keys repeat
 // (one signer, many messages) fill buckets with multiples of one point, and "P + P" is then the common case, not an exceptional one.
 // ------------------------------------------------------------------------------------------
+// The order in which the accumulation's waves are dispatched.  k_bkt_rank sorts every 4096 consecutive buckets by size, longest first, so that
+// the 64 lanes of a wave hold buckets of one size: wave w of a group (w = 0 .. 63) holds the group's (w + 1)-th 64th of the size distribution.
+// Dispatched in lane order, block b lands on the SIMD b mod 1024 (1024 = 16 x 64), so a SIMD got the SAME quantile of every group -- the
+// longest buckets of all its waves or the shortest of all: 0.6 VALU busy, the kernel as long as the SIMDs with the top quantile
+// (profiles/r6_bucket_kernel_bound.md).  Block b now serves wave (b / G) of group (b mod G), G the number of groups: the longest waves of all
+// groups go first (longest-processing-time-first for the slots that free up), and a SIMD's waves come from every part of the distribution.
+// The order's TOP window is another distribution altogether -- its n keys crowd into (q >> 16 top) + 1 buckets, eight times the others' length
+// for Ed25519 -- so when the launch holds it (tw: its index among the launch's windows, else -1) its wpb blocks go first, the rest behind them.
+static __device__ __forceinline__ u32 bkt_block_order(u32 b, u32 nblocks, bool ranked, int tw, u32 wpb)
+{
+	if (!ranked || (nblocks & 63u) != 0u || nblocks < 64u) {
+		return b;
+	}
+	if (tw < 0 || (wpb & 63u) != 0u || wpb == 0u || nblocks < wpb || (u32)tw * wpb + wpb > nblocks) {
+		const u32 G = nblocks >> 6;
+		return (b % G) * 64u + b / G;
+	}
+	if (b < wpb) {
+		const u32 Gt = wpb >> 6;
+		return (u32)tw * wpb + (b % Gt) * 64u + b / Gt;
+	}
+	const u32 r = b - wpb, Gr = (nblocks - wpb) >> 6;
+	if (Gr == 0u) {
+		return b;
+	}
+	const u32 idx = (r % Gr) * 64u + r / Gr;          // among the blocks of the other windows
+	return idx < (u32)tw * wpb ? idx : idx + wpb;
+}
+
 template <int PB> struct BktLay {
 	static constexpr int NL = Cfg<PB>::NL;
-	static constexpr int PENTW = ((2 * NL + 3) / 4) * 4;   // affine point record
+	static constexpr int PENTW = ((2 * NL + 3) / 4) * 4;   // affine point record: the words that travel
+	// ... and the words between records: the next power of two, so that a record never straddles a 128-byte line (nine limbs: 80-byte records at an
+	// 80-byte stride crossed a line every other time -- 4.5 GB of HBM traffic per 2^20 items for 2 GB of records, profiles/r6_bucket_kernel_bound.md)
+	static constexpr int PSTRIDE = PENTW <= 16 ? 16 : (PENTW <= 32 ? 32 : (PENTW <= 64 ? 64 : 128));
 	static constexpr int RECW = MsmLay<PB>::RECW;          // Jacobian record + "is infinity" word
 };
 
@@ -868,7 +900,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_bkt_points_g
 	typedef Lay<PB> L;
 	typedef typename Cls<PB>::FA FA;
 	typedef typename Cls<PB>::FM FM;
-	constexpr int NL = L::NL, PENTW = BktLay<PB>::PENTW;
+	constexpr int NL = L::NL, PENTW = BktLay<PB>::PENTW, PSTRIDE = BktLay<PB>::PSTRIDE;
 	const u32 rel = blockIdx.x * 64 + threadIdx.x;
 	if (rel >= (A.pt_count ? A.pt_count : 2 * A.n)) {
 		return;
@@ -914,7 +946,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) void k_bkt_points_g
 	for (int w = 2 * NL; w < PENTW; w++) {
 		buf[w] = 0;
 	}
-	uint4 *d = (uint4 *)(A.pts + (size_t)idx * PENTW);
+	uint4 *d = (uint4 *)(A.pts + (size_t)idx * PSTRIDE);
 #pragma unroll
 	for (int q = 0; q < PENTW / 4; q++) {
 		d[q] = make_uint4(buf[4 * q], buf[4 * q + 1], buf[4 * q + 2], buf[4 * q + 3]);
@@ -929,9 +961,11 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_bkt_
 	typedef Lay<PB> L;
 	typedef typename Cls<PB>::FA FA;
 	typedef typename Cls<PB>::FC FC;
-	constexpr int NL = L::NL, PENTW = BktLay<PB>::PENTW, RECW = BktLay<PB>::RECW;
-	const u32 rel = blockIdx.x * 64 + threadIdx.x;
+	constexpr int NL = L::NL, PENTW = BktLay<PB>::PENTW, PSTRIDE = BktLay<PB>::PSTRIDE, RECW = BktLay<PB>::RECW;
 	const u32 NB = 1u << A.c;
+	const u32 wfirst = A.win_first, wcount = A.win_count ? A.win_count : A.nwin;
+	const int tw = (A.cap != 0u && A.top_win >= wfirst && A.top_win < wfirst + wcount) ? (int)(A.top_win - wfirst) : -1;
+	const u32 rel = bkt_block_order(blockIdx.x, gridDim.x, A.perm != nullptr && A.c >= 12u, tw, NB >> 6) * 64 + threadIdx.x;
 	if (rel >= (A.win_count ? A.win_count : A.nwin) * NB) {
 		return;
 	}
@@ -953,7 +987,7 @@ template <int PB, int FLAV> __global__ __launch_bounds__(64) G29_OCC void k_bkt_
 	bool inf = true;
 	// the next point's record is on its way while the current addition runs (its index was read an iteration earlier still)
 	auto fetch = [&](u32 idx, u32 *buf) {
-		const uint4 *src = (const uint4 *)(A.pts + (size_t)idx * PENTW);
+		const uint4 *src = (const uint4 *)(A.pts + (size_t)idx * PSTRIDE);
 #pragma unroll
 		for (int q = 0; q < PENTW / 4; q++) {
 			const uint4 v = src[q];
@@ -3182,7 +3216,7 @@ __global__ __launch_bounds__(64) void k_edbkt_points(EcamdEdMsmArgs A, EcamdEdBk
 	const FC d2 = digits9(A.g_2d);
 	if (i < B.LB) {
 		const FM ym = weaken<FM>(mul(digits9(A.g_By), constant<FC>(K.one), K));
-		edb_store(B.pts + (size_t)(A.n + i) * ECAMD_EDB_PT_WORDS, ed_prea(digits9(A.g_Bx), ym, d2, K));
+		edb_store(B.pts + (size_t)(A.n + i) * ECAMD_EDB_PT_STRIDE, ed_prea(digits9(A.g_Bx), ym, d2, K));
 	}
 	EcamdEdDecodeArgs D;   // decode_xy reads the two constants only
 #pragma unroll
@@ -3213,7 +3247,7 @@ __global__ __launch_bounds__(64) void k_edbkt_points(EcamdEdMsmArgs A, EcamdEdBk
 		}
 		// P1 is affine (Z = 1): its precomputed entry straight from X and Y
 		const u32 idx = k == 0 ? i : A.n + B.LB + i;
-		edb_store(B.pts + (size_t)idx * ECAMD_EDB_PT_WORDS, ed_prea(P1.X, P1.Y, d2, K));
+		edb_store(B.pts + (size_t)idx * ECAMD_EDB_PT_STRIDE, ed_prea(P1.X, P1.Y, d2, K));
 		flag |= good ? 0 : 1;
 	}
 	A.flags[i] = flag;
@@ -3222,7 +3256,7 @@ __global__ __launch_bounds__(64) void k_edbkt_points(EcamdEdMsmArgs A, EcamdEdBk
 __global__ __launch_bounds__(64) void k_edbkt_accum(EcamdEdBktArgs B, int gslot)
 {
 	using namespace c25519;
-	const u32 lane = blockIdx.x * 64 + threadIdx.x;
+	const u32 lane = bkt_block_order(blockIdx.x, gridDim.x, true, 15, 1024u) * 64 + threadIdx.x;
 	if (lane >= (16u << 16)) {
 		return;
 	}
@@ -3235,14 +3269,14 @@ __global__ __launch_bounds__(64) void k_edbkt_accum(EcamdEdBktArgs B, int gslot)
 	PreA nxt;
 	u32 nidx = 0;
 	if (cnt) {
-		nxt = prea_load(B.pts + (size_t)ord[0] * ECAMD_EDB_PT_WORDS);
+		nxt = prea_load(B.pts + (size_t)ord[0] * ECAMD_EDB_PT_STRIDE);
 		nidx = cnt > 1 ? ord[1] : 0u;
 	}
 #pragma unroll 1
 	for (u32 k = 0; k < cnt; k++) {
 		const PreA cur = nxt;
 		if (k + 1 < cnt) {
-			nxt = prea_load(B.pts + (size_t)nidx * ECAMD_EDB_PT_WORDS);   // on its way while the current addition runs
+			nxt = prea_load(B.pts + (size_t)nidx * ECAMD_EDB_PT_STRIDE);   // on its way while the current addition runs
 			nidx = k + 2 < cnt ? ord[k + 2] : 0u;
 		}
 		acc = ed_madd<true>(acc, cur, false, K);
@@ -5123,7 +5157,11 @@ X(192s)
 X(256k)
 X(448g)
 #undef X
-uint32_t ecamd_g29_bkt_point_words(int pbits, int flavour) { return (uint32_t)(((2 * g29::nl_for_flavour(pbits, flavour) + 3) / 4) * 4); }   // BktLay<PB>::PENTW
+uint32_t ecamd_g29_bkt_point_words(int pbits, int flavour)   // BktLay<PB>::PSTRIDE
+{
+	const uint32_t w = (uint32_t)(((2 * g29::nl_for_flavour(pbits, flavour) + 3) / 4) * 4);
+	return w <= 16 ? 16u : (w <= 32 ? 32u : (w <= 64 ? 64u : 128u));
+}
 uint32_t ecamd_g29_msm_rec_words(int pbits, int flavour) { return (uint32_t)(((3 * g29::nl_for_flavour(pbits, flavour) + 3) / 4) * 4) + 4u; }   // MsmLay<PB>::RECW
 // the Schnorr-type multi-scalar multiplication on the unit (pbits, flavour)
 hipError_t ecamd_launch_msm_g29(int pbits, int gslot, int flavour, int phase, const EcamdMsmArgs &a, uint32_t *tmp, const uint8_t *gen,

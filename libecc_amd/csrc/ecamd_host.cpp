@@ -4347,7 +4347,7 @@ static int eddsa_bkt_setup(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const ui
 		off += msm_align(bytes);
 		return o;
 	};
-	const size_t o_pts = carve(((size_t)2 * n + LB) * ECAMD_EDB_PT_WORDS * 4);
+	const size_t o_pts = carve(((size_t)2 * n + LB) * ECAMD_EDB_PT_STRIDE * 4);
 	const size_t o_cA = carve((size_t)n * 32), o_zR = carve((size_t)n * 20), o_zs = carve((size_t)n * 32);
 	const size_t o_rawC = carve((size_t)n * 32), o_rawZ = carve((size_t)n * 16), o_rawB = carve((size_t)LB * 32), o_sB = carve((size_t)LB * 32);
 	const size_t o_flags = carve(n), o_flagsS = carve(n);

@@ -265,9 +265,12 @@ struct EcamdEdMsmLaneArgs {
 // z_i h_i (16 windows), the base point's LB scalars (16 windows: the term [q - sum z_i S_i]B as LB copies of B, one per 64 items) and z_i (8
 // windows).  Point index: A_i = i, the copies of B = n + l, R_i = n + LB + i.  The Edwards addition is complete: no exceptional cases.
 #define ECAMD_EDB_PT_WORDS 28   /* y - x, y + x, 2d x y: 3 x 9 limbs, padded */
+#define ECAMD_EDB_PT_STRIDE 32  /* words between records: one 128-byte line each -- a gather of k_edbkt_accum touches ONE line (112-byte records
+                                 * at a 112-byte stride straddled two lines seven times out of eight: 8.1 GB of HBM traffic per 2^20 items for
+                                 * 3.8 GB of records, 3.9 TB/s at 0.41 VALU busy, profiles/r6_bucket_kernel_bound.md) */
 struct EcamdEdBktArgs {
 	const uint32_t *rawC, *rawB, *rawZ;
-	uint32_t *pts;               // (2n + LB) x ECAMD_EDB_PT_WORDS
+	uint32_t *pts;               // (2n + LB) x ECAMD_EDB_PT_STRIDE
 	uint32_t *count, *perm;      // 16 << 16 counters (the buckets' sizes) / the ranking of k_bkt_rank
 	uint32_t *order;             // (16 << 16) x cap point indices
 	uint32_t *bsum;              // 16 << 16 records of ECAMD_EDM_REC_WORDS
