@@ -3262,26 +3262,55 @@ __global__ __launch_bounds__(64) void k_edbkt_accum(EcamdEdBktArgs B, int gslot)
 	}
 	const CK &K = TabGP<255>::get(gslot);
 	const u32 t = B.perm[lane];
-	u32 cnt = (t & 0xffffu) ? B.count[t] : 0u, capb;
-	const u32 *ord = B.order + ecamd_bkt_slot(t, B.cap, B.cap_top, 15u, &capb);
+	// the top window: lane (15 << 16 | part * 8192 + d) takes the points part, part + 8, ... of bucket d (ecamd_internal.h: ECAMD_EDB_SPLIT)
+	u32 tb = t, k0 = 0, step = 1;
+	if ((t >> 16) == 15u) {
+		const u32 d = t & 0xffffu;
+		tb = (15u << 16) | (d & (ECAMD_EDB_SPLIT_DIGITS - 1u));
+		k0 = d / ECAMD_EDB_SPLIT_DIGITS;
+		step = ECAMD_EDB_SPLIT;
+	}
+	u32 cnt = (tb & 0xffffu) ? B.count[tb] : 0u, capb;
+	const u32 *ord = B.order + ecamd_bkt_slot(tb, B.cap, B.cap_top, 15u, &capb);
 	cnt = cnt < capb ? cnt : capb;
 	Ext acc = ed_neutral(K);
 	PreA nxt;
 	u32 nidx = 0;
-	if (cnt) {
-		nxt = prea_load(B.pts + (size_t)ord[0] * ECAMD_EDB_PT_STRIDE);
-		nidx = cnt > 1 ? ord[1] : 0u;
+	if (k0 < cnt) {
+		nxt = prea_load(B.pts + (size_t)ord[k0] * ECAMD_EDB_PT_STRIDE);
+		nidx = k0 + step < cnt ? ord[k0 + step] : 0u;
 	}
 #pragma unroll 1
-	for (u32 k = 0; k < cnt; k++) {
+	for (u32 k = k0; k < cnt; k += step) {
 		const PreA cur = nxt;
-		if (k + 1 < cnt) {
+		if (k + step < cnt) {
 			nxt = prea_load(B.pts + (size_t)nidx * ECAMD_EDB_PT_STRIDE);   // on its way while the current addition runs
-			nidx = k + 2 < cnt ? ord[k + 2] : 0u;
+			nidx = k + 2 * step < cnt ? ord[k + 2 * step] : 0u;
 		}
 		acc = ed_madd<true>(acc, cur, false, K);
 	}
 	ext_store(B.bsum + (size_t)t * ECAMD_EDM_REC_WORDS, acc);
+}
+// the top window's eight partial sums per bucket, added up; the seven borrowed records become neutral elements again (the reduction reads them)
+__global__ __launch_bounds__(64) void k_edbkt_combine(EcamdEdMsmArgs A, EcamdEdBktArgs B, int gslot)
+{
+	using namespace c25519;
+	const u32 dp = blockIdx.x * 64 + threadIdx.x;
+	if (dp >= ECAMD_EDB_SPLIT_DIGITS) {
+		return;
+	}
+	const CK &K = TabGP<255>::get(gslot);
+	const FC d2 = digits9(A.g_2d);
+	u32 *rec = B.bsum + ((size_t)(15u << 16) + dp) * ECAMD_EDM_REC_WORDS;
+	Ext acc = ext_load(rec);
+	const Ext zero = ed_neutral(K);
+#pragma unroll 1
+	for (u32 part = 1; part < ECAMD_EDB_SPLIT; part++) {
+		u32 *r2 = rec + (size_t)part * ECAMD_EDB_SPLIT_DIGITS * ECAMD_EDM_REC_WORDS;
+		acc = ed_add(acc, ed_pre(ext_load(r2), d2, K), false, K);
+		ext_store(r2, zero);
+	}
+	ext_store(rec, acc);
 }
 
 struct EdBktLevel {
@@ -3361,6 +3390,7 @@ hipError_t ecamd_launch_edbkt(const EcamdEdMsmArgs &a, const EcamdEdBktArgs &b, 
 		hipLaunchKernelGGL(k_edbkt_points, dim3(((a.count ? a.count : a.n) + 63) / 64), dim3(64), 0, s, a, b, gslot);
 	} else if (phase == 1) {
 		hipLaunchKernelGGL(k_edbkt_accum, dim3((16u << 16) / 64), dim3(64), 0, s, b, gslot);
+		hipLaunchKernelGGL(k_edbkt_combine, dim3(ECAMD_EDB_SPLIT_DIGITS / 64), dim3(64), 0, s, a, b, gslot);
 	} else {
 		EdBktLevel V = {};
 		const uint32_t fold = ecamd_bkt_fold();

@@ -281,6 +281,13 @@ struct EcamdEdBktArgs {
 	uint32_t part, first, count_items;   // ecamd_launch_edbkt_file: part 0 everything (counters cleared, ranking at the end); 1: the keys and commitments
 	                                // of the items [first, first + count_items) alone, counters as they are; 2: the LB copies of B, then the ranking
 };
+// Ed25519's top window (15): z h mod q < 2^252 + 2^125, so its digits take 4 097 values and all n keys crowd into as many buckets -- 256 points each
+// at 2^20 items, eight times the other windows' buckets, and ONE lane's chain of 256 dependent additions outlasted the whole balanced launch
+// (profiles/r6_bucket_kernel_bound.md).  The window's other 61 439 lanes were idle: lane (15 << 16 | s * 8192 + d), s = 0 .. 7, now sums the
+// points s, s + 8, s + 16, ... of bucket d, and k_edbkt_combine adds the eight partial sums up (and blanks the seven borrowed records).
+#define ECAMD_EDB_SPLIT 8u
+#define ECAMD_EDB_SPLIT_LOG2 3u
+#define ECAMD_EDB_SPLIT_DIGITS 8192u
 // entries a lane of the bucket reduction folds per level (k_bkt_reduce_g / k_edbkt_reduce: 2 (fold - 1) dependent additions per level, log_fold(2^c)
 // levels): 8 by default -- measured per 2^20 items (tools/gpu_r6zb.sh): BIP0340 / secp256k1 6.84 (16) / 6.66 (8) / 6.71 (4) / 6.87 ms (2), Ed25519
 // 6.89 / 6.64 / 6.67 / 6.84, Ed448 25.9 / 25.8 / 26.8 / 28.4; $ECAMD_BKT_FOLD=2|4|8|16 (measurements, tests; read at every call, by the host's

@@ -2298,7 +2298,9 @@ __global__ __launch_bounds__(256) void k_bkt_file(EcamdBktSortArgs A)
 // (sizes are Poisson: 46 against a mean of 32 over 64 lanes).  Every block ranks 4096 consecutive buckets by size (a counting sort in
 // LDS: sizes capped at 255) and writes the permutation; lane t of the accumulation then serves bucket perm[t], and the 64 lanes of a
 // wave get buckets of (nearly) one size.
-__global__ __launch_bounds__(256) void k_bkt_rank(const u32 *count, u32 *perm, u32 total, u32 first_block)
+// split_first (the Ed25519 form: 15 << 16; else 0xffffffff): the window whose buckets are shared by ECAMD_EDB_SPLIT lanes each -- a lane's size
+// there is its share of the bucket it helps with
+__global__ __launch_bounds__(256) void k_bkt_rank(const u32 *count, u32 *perm, u32 total, u32 first_block, u32 split_first)
 {
 	__shared__ u32 hist[256], base[256];
 	const u32 t = threadIdx.x, first = (first_block + blockIdx.x) * 4096u;
@@ -2308,7 +2310,12 @@ __global__ __launch_bounds__(256) void k_bkt_rank(const u32 *count, u32 *perm, u
 #pragma unroll
 	for (u32 k = 0; k < 16; k++) {
 		const u32 b = first + k * 256u + t;
-		const u32 cnt = (b < total) ? count[b] : 0u;
+		u32 cnt = (b < total) ? count[b] : 0u;
+		if (b < total && (b & 0xffff0000u) == split_first) {
+			const u32 d = b & 0xffffu, dp = d & (ECAMD_EDB_SPLIT_DIGITS - 1u), part = d / ECAMD_EDB_SPLIT_DIGITS;
+			const u32 full = dp ? count[split_first | dp] : 0u;
+			cnt = (full + (ECAMD_EDB_SPLIT - 1u) - part) >> ECAMD_EDB_SPLIT_LOG2;
+		}
 		key[k] = 255u - (cnt > 255u ? 255u : cnt);      // the longest first
 		atomicAdd(&hist[key[k]], 1u);
 	}
@@ -2345,7 +2352,7 @@ hipError_t ecamd_launch_bkt_sort(const EcamdBktSortArgs &a, hipStream_t s)
 		if (a.part == 1u) {
 			hipLaunchKernelGGL(k_bkt_file, dim3((2 * a.item_count + 255) / 256, a.nwin), dim3(256), 0, s, a);
 		} else if (a.perm) {
-			hipLaunchKernelGGL(k_bkt_rank, dim3((unsigned)((counters + 4095) / 4096)), dim3(256), 0, s, (const u32 *)a.hist, a.perm, (u32)counters, 0u);
+			hipLaunchKernelGGL(k_bkt_rank, dim3((unsigned)((counters + 4095) / 4096)), dim3(256), 0, s, (const u32 *)a.hist, a.perm, (u32)counters, 0u, 0xffffffffu);
 		}
 		return hipGetLastError();
 	}
@@ -2358,7 +2365,7 @@ hipError_t ecamd_launch_bkt_sort(const EcamdBktSortArgs &a, hipStream_t s)
 		hipLaunchKernelGGL(k_bkt_file, dim3((cnt + 255) / 256, a.win_count), dim3(256), 0, s, a);
 		if (a.perm) {
 			const uint32_t per_win = (1u << a.c) / 4096u;
-			hipLaunchKernelGGL(k_bkt_rank, dim3(a.win_count * per_win), dim3(256), 0, s, (const u32 *)a.hist, a.perm, (u32)counters, a.win_first * per_win);
+			hipLaunchKernelGGL(k_bkt_rank, dim3(a.win_count * per_win), dim3(256), 0, s, (const u32 *)a.hist, a.perm, (u32)counters, a.win_first * per_win, 0xffffffffu);
 		}
 		return hipGetLastError();
 	}
@@ -2378,7 +2385,7 @@ hipError_t ecamd_launch_bkt_sort(const EcamdBktSortArgs &a, hipStream_t s)
 		hipLaunchKernelGGL(k_bkt_scatter, gp, dim3(256), 0, s, a);
 	}
 	if (a.perm) {
-		hipLaunchKernelGGL(k_bkt_rank, dim3((unsigned)((counters + 4095) / 4096)), dim3(256), 0, s, (const u32 *)a.hist, a.perm, (u32)counters, 0u);
+		hipLaunchKernelGGL(k_bkt_rank, dim3((unsigned)((counters + 4095) / 4096)), dim3(256), 0, s, (const u32 *)a.hist, a.perm, (u32)counters, 0u, 0xffffffffu);
 	}
 	return hipGetLastError();
 }
@@ -2718,7 +2725,7 @@ hipError_t ecamd_launch_edbkt_file(const EcamdEdBktArgs &b, hipStream_t s)
 	}
 	const uint32_t threads = b.part == 2u ? b.LB : 2 * b.n + b.LB;
 	hipLaunchKernelGGL(k_edbkt_file, dim3((threads + 255) / 256, 16), dim3(256), 0, s, b);
-	hipLaunchKernelGGL(k_bkt_rank, dim3((unsigned)(counters / 4096)), dim3(256), 0, s, (const u32 *)b.count, b.perm, (u32)counters, 0u);
+	hipLaunchKernelGGL(k_bkt_rank, dim3((unsigned)(counters / 4096)), dim3(256), 0, s, (const u32 *)b.count, b.perm, (u32)counters, 0u, 15u << 16);
 	return hipGetLastError();
 }
 
