@@ -3253,13 +3253,16 @@ __global__ __launch_bounds__(64) void k_edbkt_points(EcamdEdMsmArgs A, EcamdEdBk
 	A.flags[i] = flag;
 }
 
-__global__ __launch_bounds__(64) void k_edbkt_accum(EcamdEdBktArgs B, int gslot)
+__global__ __launch_bounds__(64) void k_edbkt_accum(EcamdEdBktArgs B, int gslot, u32 win_first, u32 win_count)
 {
 	using namespace c25519;
-	const u32 lane = bkt_block_order(blockIdx.x, gridDim.x, true, 15, 1024u) * 64 + threadIdx.x;
-	if (lane >= (16u << 16)) {
+	// the windows [win_first, win_first + win_count); the top window (15) ahead of the others when the launch holds it
+	const int tw = (win_first + win_count == 16u) ? (int)(15u - win_first) : -1;
+	const u32 rel = bkt_block_order(blockIdx.x, gridDim.x, true, tw, 1024u) * 64 + threadIdx.x;
+	if (rel >= (win_count << 16)) {
 		return;
 	}
+	const u32 lane = (win_first << 16) + rel;
 	const CK &K = TabGP<255>::get(gslot);
 	const u32 t = B.perm[lane];
 	// the top window: lane (15 << 16 | part * 8192 + d) takes the points part, part + 8, ... of bucket d (ecamd_internal.h: ECAMD_EDB_SPLIT)
@@ -3320,12 +3323,13 @@ struct EdBktLevel {
 	u32 *outC[BKT_MAXCARRY];
 	u32 Lin, Lout, ncarry;
 	u32 fold;
+	u32 nwin;                       // windows in these arrays (a range of the sixteen)
 };
 __global__ __launch_bounds__(64) void k_edbkt_reduce(EcamdEdMsmArgs A, EdBktLevel V, int gslot)
 {
 	using namespace c25519;
 	const u32 t = blockIdx.x * 64 + threadIdx.x;
-	if (t >= 16u * V.Lout) {
+	if (t >= V.nwin * V.Lout) {
 		return;
 	}
 	const CK &K = TabGP<255>::get(gslot);
@@ -3357,12 +3361,13 @@ struct EdBktWindows {
 	const u32 *C[BKT_MAXCARRY];
 	u32 *out;
 	u32 ncarry, fold_log2;
+	u32 nwin, win_base;             // record w of these arrays is window win_base + w (its weight: 2^(16 (win_base + w)))
 };
 __global__ __launch_bounds__(64) void k_edbkt_window(EcamdEdMsmArgs A, EdBktWindows V, int gslot)
 {
 	using namespace c25519;
 	const u32 win = blockIdx.x * 64 + threadIdx.x;
-	if (win >= 16u) {
+	if (win >= V.nwin) {
 		return;
 	}
 	const CK &K = TabGP<255>::get(gslot);
@@ -3377,7 +3382,7 @@ __global__ __launch_bounds__(64) void k_edbkt_window(EcamdEdMsmArgs A, EdBktWind
 		acc = ed_add(acc, ed_pre(ext_load(V.C[k] + (size_t)win * ECAMD_EDM_REC_WORDS), d2, K), false, K);
 	}
 #pragma unroll 1
-	for (u32 d = 0; d < 16u * win; d++) {
+	for (u32 d = 0; d < 16u * (V.win_base + win); d++) {
 		acc = ed_dbl<true>(acc, K);
 	}
 	ext_store(V.out + (size_t)win * ECAMD_EDM_REC_WORDS, acc);
@@ -3388,49 +3393,82 @@ hipError_t ecamd_launch_edbkt(const EcamdEdMsmArgs &a, const EcamdEdBktArgs &b, 
 	constexpr size_t RECW = ECAMD_EDM_REC_WORDS;
 	if (phase == 0) {
 		hipLaunchKernelGGL(k_edbkt_points, dim3(((a.count ? a.count : a.n) + 63) / 64), dim3(64), 0, s, a, b, gslot);
-	} else if (phase == 1) {
-		hipLaunchKernelGGL(k_edbkt_accum, dim3((16u << 16) / 64), dim3(64), 0, s, b, gslot);
-		hipLaunchKernelGGL(k_edbkt_combine, dim3(ECAMD_EDB_SPLIT_DIGITS / 64), dim3(64), 0, s, a, b, gslot);
 	} else {
-		EdBktLevel V = {};
+		// phase 1: every window summed; 2: reduced, weighted and compared.  By window range, for a caller that reduces the key-only windows (8 .. 15:
+		// z_i has 128 bits) on a second stream while the others are still being summed -- their doubling chains, 16 w long, are the long ones --:
+		// 10 / 11 the sums of the windows 8 .. 15 / 0 .. 7, 12 / 13 their reduction and weighting, 14 the total and the verdict.  The sixteen weighted
+		// window sums rest in the spare tail of the reduction scratch.
 		const uint32_t fold = ecamd_bkt_fold();
-		V.fold = fold;
-		V.inT = b.bsum;
-		V.Lin = 1u << 16;
-		uint32_t *half[2] = {b.red, b.red + (size_t)b.red_words / 2};
-		int hsel = 0;
-		while (V.Lin > 1) {
-			V.Lout = (V.Lin + fold - 1) / fold;
-			uint32_t *o = half[hsel];
-			const size_t arr = (size_t)16 * V.Lout * RECW;
-			if ((2 + (size_t)V.ncarry) * arr > (size_t)b.red_words / 2 || V.ncarry + 1 > BKT_MAXCARRY) {
-				return hipErrorInvalidValue;
+		const size_t halfw = (size_t)b.red_words / 2, per_win = (halfw - 18 * RECW) / 16;
+		uint32_t *wout = b.red + (size_t)b.red_words - 18 * RECW;
+		auto accum = [&](uint32_t wf, uint32_t wc) {
+			hipLaunchKernelGGL(k_edbkt_accum, dim3((wc << 16) / 64), dim3(64), 0, s, b, gslot, wf, wc);
+			if (wf + wc == 16u) {
+				hipLaunchKernelGGL(k_edbkt_combine, dim3(ECAMD_EDB_SPLIT_DIGITS / 64), dim3(64), 0, s, a, b, gslot);
 			}
-			V.outT = o;
-			V.outU = o + arr;
-			for (uint32_t k = 0; k < V.ncarry; k++) {
-				V.outC[k] = o + (2 + (size_t)k) * arr;
+		};
+		auto reduce = [&](uint32_t wf, uint32_t wc) -> hipError_t {
+			EdBktLevel V = {};
+			V.fold = fold;
+			V.nwin = wc;
+			V.inT = b.bsum + ((size_t)wf << 16) * RECW;
+			V.Lin = 1u << 16;
+			uint32_t *half[2] = {b.red + (size_t)wf * per_win, b.red + halfw + (size_t)wf * per_win};
+			int hsel = 0;
+			while (V.Lin > 1) {
+				V.Lout = (V.Lin + fold - 1) / fold;
+				uint32_t *o = half[hsel];
+				const size_t arr = (size_t)wc * V.Lout * RECW;
+				if ((2 + (size_t)V.ncarry) * arr > (size_t)wc * per_win || V.ncarry + 1 > BKT_MAXCARRY) {
+					return hipErrorInvalidValue;
+				}
+				V.outT = o;
+				V.outU = o + arr;
+				for (uint32_t k = 0; k < V.ncarry; k++) {
+					V.outC[k] = o + (2 + (size_t)k) * arr;
+				}
+				hipLaunchKernelGGL(k_edbkt_reduce, dim3((wc * V.Lout + 63) / 64, 1 + V.ncarry), dim3(64), 0, s, a, V, gslot);
+				V.inT = V.outT;
+				for (uint32_t k = 0; k < V.ncarry; k++) {
+					V.inC[k] = V.outC[k];
+				}
+				V.inC[V.ncarry] = V.outU;
+				V.ncarry++;
+				V.Lin = V.Lout;
+				hsel ^= 1;
 			}
-			hipLaunchKernelGGL(k_edbkt_reduce, dim3((16 * V.Lout + 63) / 64, 1 + V.ncarry), dim3(64), 0, s, a, V, gslot);
-			V.inT = V.outT;
-			for (uint32_t k = 0; k < V.ncarry; k++) {
-				V.inC[k] = V.outC[k];
+			EdBktWindows W = {};
+			W.U = V.inC[V.ncarry - 1];
+			W.ncarry = V.ncarry - 1;
+			W.fold_log2 = (uint32_t)__builtin_ctz(fold);
+			W.nwin = wc;
+			W.win_base = wf;
+			for (uint32_t k = 0; k + 1 < V.ncarry; k++) {
+				W.C[k] = V.inC[k];
 			}
-			V.inC[V.ncarry] = V.outU;
-			V.ncarry++;
-			V.Lin = V.Lout;
-			hsel ^= 1;
+			W.out = wout + (size_t)wf * RECW;
+			hipLaunchKernelGGL(k_edbkt_window, dim3(1), dim3(64), 0, s, a, W, gslot);
+			return hipSuccess;
+		};
+		hipError_t e = hipSuccess;
+		switch (phase) {
+		case 1: accum(0, 16); break;
+		case 10: accum(8, 8); break;
+		case 11: accum(0, 8); break;
+		case 12: e = reduce(8, 8); break;
+		case 13: e = reduce(0, 8); break;
+		case 2: e = reduce(0, 16);   // and the total
+			// fall through
+		case 14:
+			if (e == hipSuccess) {
+				hipLaunchKernelGGL(k_edmsm_final, dim3(1), dim3(64), 0, s, a, (const uint32_t *)wout, 16u, flagword, verdict, sum_out, gslot);
+			}
+			break;
+		default: return hipErrorInvalidValue;
 		}
-		EdBktWindows W = {};
-		W.U = V.inC[V.ncarry - 1];
-		W.ncarry = V.ncarry - 1;
-		W.fold_log2 = (uint32_t)__builtin_ctz(fold);
-		for (uint32_t k = 0; k + 1 < V.ncarry; k++) {
-			W.C[k] = V.inC[k];
+		if (e != hipSuccess) {
+			return e;
 		}
-		W.out = half[hsel];
-		hipLaunchKernelGGL(k_edbkt_window, dim3(1), dim3(64), 0, s, a, W, gslot);
-		hipLaunchKernelGGL(k_edmsm_final, dim3(1), dim3(64), 0, s, a, (const uint32_t *)W.out, 16u, flagword, verdict, sum_out, gslot);
 	}
 	return hipGetLastError();
 }

@@ -4425,7 +4425,25 @@ static int eddsa_bkt_setup(ecamd_ctx *ctx, ecamd_curve *cv, uint32_t n, const ui
 static int eddsa_bkt_tail(ecamd_ctx *ctx, ecamd_curve *cv, EdBktRun &R, uint8_t *d_verdict, uint32_t *d_sum_dump, hipStream_t s)
 {
 	if (ctx->timing) {
-		HIPCHK(hipEventRecord(ctx->ev_dom[0], s));   // the dominant kernel: k_edbkt_accum (ecamd_ctx_dominant_kernel_ms)
+		HIPCHK(hipEventRecord(ctx->ev_dom[0], s));   // the dominant kernel: k_edbkt_accum, both launches (ecamd_ctx_dominant_kernel_ms)
+	}
+	if (ctx->side_ok && getenv("ECAMD_NO_EDBKT_SPLIT") == nullptr) {
+		// the key-only windows (8 .. 15: z_i has 128 bits) first; their reduction and their doubling chains -- 16 w doublings in one lane, the long
+		// ones -- on the side stream (idle by now) while the windows that hold the commitments too are summed (the Schnorr-type form does the same)
+		HIPCHK(ecamd_launch_edbkt(R.A, R.B, 10, nullptr, nullptr, nullptr, cv->gslot, s));
+		HIPCHK(hipEventRecord(ctx->side_hi, s));
+		HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->side_hi, 0));
+		HIPCHK(ecamd_launch_edbkt(R.A, R.B, 12, nullptr, nullptr, nullptr, cv->gslot, ctx->side_stream));
+		HIPCHK(hipEventRecord(ctx->side_red, ctx->side_stream));
+		HIPCHK(ecamd_launch_edbkt(R.A, R.B, 11, nullptr, nullptr, nullptr, cv->gslot, s));
+		if (ctx->timing) {
+			HIPCHK(hipEventRecord(ctx->ev_dom[1], s));
+			ctx->ev_dom_valid = true;
+		}
+		HIPCHK(ecamd_launch_edbkt(R.A, R.B, 13, nullptr, nullptr, nullptr, cv->gslot, s));
+		HIPCHK(hipStreamWaitEvent(s, ctx->side_red, 0));
+		HIPCHK(ecamd_launch_edbkt(R.A, R.B, 14, R.flagword, d_verdict, d_sum_dump, cv->gslot, s));
+		return 0;
 	}
 	HIPCHK(ecamd_launch_edbkt(R.A, R.B, 1, nullptr, nullptr, nullptr, cv->gslot, s));
 	if (ctx->timing) {
