@@ -4205,19 +4205,24 @@ static int eddsa_verify_msg_prj_impl(const char *fn, ecamd_ctx *ctx, const ecamd
 		A.n = m;
 		A.Rw = ctx->stage[20];
 		A.stR = ctx->stage[21];
-		A.out = ctx->stage[22];
-		A.status = ctx->stage[23];
+		// (the whole-batch form files the encodings and their "no encoding" marks in batch-wide arrays: Ed25519's 32-octet encodings are written
+		// there directly; Ed448's 57-octet ones keep their aligned staging and a copy)
+		const bool direct = all_valid && !e448;
+		A.out = direct ? ctx->stage[24] + (size_t)done * kl : ctx->stage[22];
+		A.status = direct ? ctx->stage[27] + (size_t)done : ctx->stage[23];
 		HIPCHK(launch_ed_sign_enc(cv, A, s));
-		HIPCHK(ecamd_launch_slot_patch(slots, stride, a_offset, ctx->stage[22], kl, ctx->stage[23], m, s));
+		HIPCHK(ecamd_launch_slot_patch(slots, stride, a_offset, A.out, kl, A.status, m, s));
 		if (all_valid) {
 			// the whole-batch form: file this chunk's encoded keys, signatures, hashes and "no encoding" marks; the equation comes at the end
 			if (ecdsa_hash_stage(ctx, hash_type, m, slots, stride, hl, s)) {
 				return -1;
 			}
-			HIPCHK(hipMemcpyAsync(ctx->stage[24] + (size_t)done * kl, ctx->stage[22], (size_t)m * kl, hipMemcpyDeviceToDevice, s));
+			if (!direct) {
+				HIPCHK(hipMemcpyAsync(ctx->stage[24] + (size_t)done * kl, ctx->stage[22], (size_t)m * kl, hipMemcpyDeviceToDevice, s));
+				HIPCHK(hipMemcpyAsync(ctx->stage[27] + (size_t)done, ctx->stage[23], m, hipMemcpyDeviceToDevice, s));
+			}
 			HIPCHK(hipMemcpyAsync(ctx->stage[25] + (size_t)done * sl, ip[1], (size_t)m * sl, hipMemcpyDeviceToDevice, s));
 			HIPCHK(hipMemcpyAsync(ctx->stage[26] + (size_t)done * hl, ctx->stage[17], (size_t)m * hl, hipMemcpyDeviceToDevice, s));
-			HIPCHK(hipMemcpyAsync(ctx->stage[27] + (size_t)done, ctx->stage[23], m, hipMemcpyDeviceToDevice, s));
 			if (streamed && eddsa_bkt_stream_chunk(cv, run, done, m, s)) {
 				return -1;
 			}
